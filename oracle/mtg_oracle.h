@@ -1,0 +1,77 @@
+/*
+ * mtg_oracle.h -- C ABI of the CPU ORACLE for the MindTheGap `fill` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / reported baseline.  The product (mindthegap_amd/) never links or calls it.
+ *
+ * The oracle is a CPU restatement of
+ *   - the in-tree reference code  (src/Filler.cpp, src/GraphAnalysis.cpp, src/IGraphOutput.cpp,
+ *     src/GraphOutputDot.cpp, src/Utils.{hpp,cpp}), cited function by function in mtg_oracle.cpp, and
+ *   - the ABSENT third-party dependency GATB/gatb-core (pinned by the reference's goldens at 1.4.2 /
+ *     1.4.1, test/full_test/gold_fill.output:3, test/contig_test/gold.log:3), restated from its
+ *     published algorithm.
+ * Parity is pinned by the reference's own golden files (tests/golden/), see tests/test_oracle_golden.py.
+ */
+#ifndef MTG_ORACLE_H
+#define MTG_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtgo_index mtgo_index;
+
+typedef struct mtgo_params {
+    int max_nodes;        /* -max-nodes  (default 100)   src/Filler.cpp:101 */
+    int max_depth;        /* -max-length (default 10000) src/Filler.cpp:100 */
+    int nb_mis_allowed;   /* hard-wired 2, src/Filler.cpp:56 */
+    int overlap;          /* -overlap (0 -> k), contig mode, src/Filler.cpp:299-307 */
+    int fwd_only;         /* -fwd-only */
+    int filter;           /* -filter */
+    int extend;           /* -extend */
+    int nb_cores;         /* worker threads (records dispatched 30 per task, src/Filler.cpp:824,844) */
+    int end_rule_nonbranching; /* 0 (default): find_end_of_branching succeeds as soon as frontline size==1;
+                                  1: additionally require the end node to be non-branching */
+} mtgo_params;
+
+void mtgo_default_params(mtgo_params* p);
+
+/* index construction.  paths_csv: comma separated FASTA/FASTQ(.gz).  abundance_min < 0 => auto. */
+mtgo_index* mtgo_index_from_files(const char* paths_csv, int k, int abundance_min, int abundance_max);
+/* canonical k-mers in this library's encoding (A=0,C=1,T=2,G=3, first nt most significant) */
+mtgo_index* mtgo_index_from_kmers(const uint64_t* canon_kmers, const uint32_t* counts, size_t n, int k);
+/* every k-mer of the given ASCII sequences gets abundance 1 + (splitmix64(canon) % mod) */
+mtgo_index* mtgo_index_from_sequences(const char* const* seqs, size_t nseq, int k, uint32_t abund_mod);
+void   mtgo_index_free(mtgo_index*);
+int    mtgo_index_k(const mtgo_index*);
+size_t mtgo_index_size(const mtgo_index*);
+int    mtgo_index_abundance_min(const mtgo_index*);
+int    mtgo_index_auto_cutoff(const mtgo_index*);        /* -1 if not computed */
+size_t mtgo_index_export(const mtgo_index*, uint64_t* kmers, uint32_t* counts, size_t cap); /* sorted by k-mer */
+void   mtgo_index_stats(const mtgo_index*, uint64_t* nb_solid, uint64_t* nb_branching);
+void   mtgo_contains_batch(const mtgo_index*, const uint64_t* kmers /*any orientation*/, size_t n, uint8_t* out);
+void   mtgo_abundance_batch(const mtgo_index*, const uint64_t* kmers, size_t n, uint32_t* out);
+
+/* Stage A only (gatb IterativeExtensions::construct_linear_seqs, call site src/Filler.cpp:884).
+ * Returns the contigs joined by '\n' in a malloc'd buffer (free with mtgo_free). */
+char* mtgo_stage_a(const mtgo_index*, const mtgo_params*, const char* source, const char* target_R,
+                   uint64_t* probes_out);
+
+/* Whole `fill` run, files written like the reference CLI (src/Filler.cpp:231-280).
+ * mode 0 = -bkpt, 1 = -contig.  sample_name goes to the VCF header only.
+ * stats[0]=records (sites or seeds) stats[1]=filled stats[2]=multiple stats[3]=membership probes
+ * stats[4]=abundance lookups stats[5]=nb_contigs stats[6]=nb_used_contigs.  Returns 0 on success. */
+int mtgo_fill_files(const mtgo_index*, const mtgo_params*, int mode, const char* input_path,
+                    const char* out_prefix, const char* sample_name, uint64_t* stats, double* seconds);
+
+void mtgo_free(void*);
+
+/* KAT helper: src/Utils.cpp:87-189 */
+float mtgo_needleman_wunsch(const char* a, const char* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

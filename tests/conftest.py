@@ -1,0 +1,25 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """ctypes handle on the CPU oracle (test infrastructure; built on demand with g++)."""
+    from tests import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
