@@ -1,0 +1,162 @@
+/*
+ * mtg_fill.h -- C ABI of libmtgfill.so: the MI355X-native drop-in for the hot path of `MindTheGap fill`.
+ *
+ * The reference has no plugin / FFI seam; its de-facto boundary for this path is
+ *   (i)  the tool entry      Filler::run(argc, argv) -> Filler::execute   (src/main.cpp:105-120, src/Filler.cpp:136)
+ *   (ii) the per-gap call    Filler::gapFillFromSource<span>               (src/Filler.hpp:188-189, src/Filler.cpp:854-1026)
+ *   (iii) the gatb Graph it queries: Graph::create / Graph::load / successors / predecessors / contains /
+ *        queryAbundance (call sites src/Filler.cpp:210,222,415-428,978)
+ * Every entry point below names the reference interface it replaces (paths relative to /root/reference).
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain C types only; every function returns an int status (MTG_OK = 0) unless noted; handles are
+ * created by the library and released by the matching *_free; result arenas are library-owned until freed; all
+ * functions require a HIP device (gfx950) and return MTG_ERR_NO_DEVICE without one -- there is no CPU fallback.
+ * k-mer encoding everywhere: 2 bits per nucleotide, A=0 C=1 T=2 G=3 ((ascii>>1)&3, as gatb), first nucleotide in
+ * the most significant bits of a uint64_t; k <= 31.
+ */
+#ifndef MTG_FILL_H
+#define MTG_FILL_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    MTG_OK = 0,
+    MTG_ERR_NO_DEVICE = 1,   /* no HIP device / HIP runtime failure (message via mtg_last_error) */
+    MTG_ERR_ARG = 2,         /* invalid argument (k out of range, null pointer, non-ACGT k-mer, ...) */
+    MTG_ERR_IO = 3,          /* cannot read / write a file */
+    MTG_ERR_NOMEM = 4,       /* device or host allocation failed */
+    MTG_ERR_OVERFLOW = 5,    /* a gap exceeded the largest scratch tier (pathological traversal) */
+    MTG_ERR_FORMAT = 6       /* unsupported index container (e.g. a GATB HDF5 graph) */
+};
+
+const char* mtg_last_error(void);           /* thread-local message of the last failing call */
+int mtg_device_count(void);                 /* number of visible HIP devices (0 if none); not a status */
+int mtg_set_device(int device);             /* device used by subsequent calls of this thread */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Index = gatb Graph (solid canonical k-mers + abundance), device resident.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct mtg_index mtg_index;
+
+typedef struct mtg_index_info {
+    int k;
+    int abundance_min;          /* threshold used ("abundance_min (used)", src/Filler.cpp:419-424) */
+    int abundance_auto;         /* auto-inferred cut-off or -1 (src/Filler.cpp:415) */
+    uint64_t nb_solid_kmers;    /* "kmers_nb_solid"  (src/Filler.cpp:427) */
+    uint64_t nb_branching;      /* "nb_branching"    (src/Filler.cpp:428) */
+    uint64_t device_bytes;      /* HBM held by the index */
+    uint64_t adj_buckets, abnd_buckets;
+} mtg_index_info;
+
+/* Graph::create(props) from read files (src/Filler.cpp:172-213): paths_csv = comma separated FASTA/FASTQ(.gz);
+ * abundance_min < 0 = "auto" (src/Filler.cpp:106); abundance_max <= 0 = unlimited. */
+int mtg_index_create_from_reads(const char* paths_csv, int k, int abundance_min, int abundance_max, mtg_index** out);
+/* Graph from an already counted solid set (host arrays; canonical k-mers, abundance >= 1). */
+int mtg_index_create_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out);
+/* Graph whose nodes are all k-mers of the given sequences (2-bit packed, 32 nt per uint64_t word, nt i at bits
+ * 2*(i%32); seq s occupies words [word_off[s], ...) and has len[s] nts; arrays in DEVICE memory).  Abundance of a
+ * k-mer = abund_lo + hash(k-mer) % abund_span (deterministic).  Used for the synthetic benchmark sets. */
+int mtg_index_create_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq,
+                                        uint64_t total_kmers_upper_bound, int k, uint32_t abund_lo, uint32_t abund_span, mtg_index** out);
+/* Graph::load / save (src/Filler.cpp:222): this library's own container; a GATB .h5 gives MTG_ERR_FORMAT. */
+int mtg_index_load(const char* path, mtg_index** out);
+int mtg_index_save(const mtg_index* idx, const char* path);
+int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info);
+void mtg_index_free(mtg_index* idx);
+
+/* Batched graph queries (host arrays in, host arrays out).  kmers[] in any orientation.
+ * contains   : Graph::contains            -> 1/0
+ * abundance  : Graph::queryAbundance      (src/Filler.cpp:978), 0 if absent, saturates at 255
+ * neighbors  : Graph::successors / predecessors: bit nt of succ[i] set iff kmer[1:]+nt is solid (order A,C,T,G) */
+int mtg_index_contains(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* out);
+int mtg_index_abundance(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* out);
+int mtg_index_neighbors(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* succ, uint8_t* pred);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gap filling = Filler::gapFillFromSource over a batch of gaps.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct mtg_params {
+    int max_nodes;              /* -max-nodes  (100),   src/Filler.cpp:101 */
+    int max_depth;              /* -max-length (10000), src/Filler.cpp:100 */
+    int nb_mis_allowed;         /* 2, src/Filler.cpp:56 */
+    int end_rule_nonbranching;  /* 0; see SURVEY.md A.5(i) */
+    int nb_host_threads;        /* host workers for the contig-graph stages (0 = all cores) */
+} mtg_params;
+void mtg_default_params(mtg_params* p);
+
+/* one call of gapFillFromSource (arguments as src/Filler.hpp:188-189) */
+typedef struct mtg_gap {
+    const char* source;               /* sourceSequence (first k nts seed the traversal) */
+    const char* target;               /* targetSequence: the early-stop pattern R */
+    int n_targets;                    /* targetDictionary, in the caller's iteration order */
+    const char* const* target_seqs;   /*   key: k-mer string */
+    const char* const* target_names;  /*   value.first */
+    const uint8_t* target_is_rc;      /*   value.second */
+    int is_anchor_repeated;
+    int reverse;
+} mtg_gap;
+
+typedef struct mtg_filled {           /* filled_insertion_t, src/Utils.hpp:46-104 */
+    const char* seq;                  /* NUL terminated, owned by the result arena */
+    int nb_errors_in_anchor;
+    int target_index;                 /* index into the gap's targetDictionary */
+    float avg_coverage, median_coverage;
+    int qual, solution_count, solution_rank;
+} mtg_filled;
+
+typedef struct mtg_gap_result {
+    int nb_nodes;                     /* infostring fields, src/IGraphOutput.cpp:82-83, src/Filler.cpp:905,1012-1016 */
+    int total_nt;
+    int nb_terminal;
+    int has_solution_counts;          /* whether the two fields below are appended to the infostring */
+    int nb_total_filled, nb_reported;
+    int n_filled;
+    const mtg_filled* filled;         /* appended to filledSequences */
+    const char* extension;            /* extensionSequence ("" when solutions exist) */
+} mtg_gap_result;
+
+typedef struct mtg_results mtg_results;
+int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out);
+const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
+void mtg_results_free(mtg_results* r);
+
+/* Stage A only (gatb IterativeExtensions::construct_linear_seqs, call site src/Filler.cpp:884): contigs of each gap
+ * as ASCII, for parity tests and the info file.  sources[i] / targets[i] are NUL terminated strings. */
+typedef struct mtg_contigs mtg_contigs;
+int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n,
+                      mtg_contigs** out);
+size_t mtg_contigs_count(const mtg_contigs* c, size_t gap);
+const char* mtg_contigs_get(const mtg_contigs* c, size_t gap, size_t i);
+void mtg_contigs_free(mtg_contigs* c);
+
+/* timings / counters of the last fill or stage-A batch on this thread */
+typedef struct mtg_batch_stats {
+    double kernel_ms;            /* HIP-event time of the traversal kernel launches (sum over tiers / attempts) */
+    double total_ms;             /* wall time of the whole call */
+    double h2d_ms, d2h_ms, host_ms;
+    uint64_t index_lines;        /* 64-byte index lines the kernels actually read */
+    uint64_t n_launches;
+    uint64_t n_retried_gaps;     /* gaps re-run in a larger scratch tier */
+    uint64_t contig_nt;          /* nucleotides of all contigs built */
+} mtg_batch_stats;
+int mtg_last_batch_stats(mtg_batch_stats* s);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Whole tool: `MindTheGap fill ...` = Filler::run(argc, argv) (src/main.cpp:105-120).  argv[0] is the first option.
+ * Returns the process exit code of the reference (0 / 1).
+ * ---------------------------------------------------------------------------------------------------------- */
+int mtg_fill_main(int argc, const char* const* argv);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Bench support: measured ceiling of dependent random 64-byte reads over a table of the given size.
+ * ---------------------------------------------------------------------------------------------------------- */
+int mtg_bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, double* ms, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

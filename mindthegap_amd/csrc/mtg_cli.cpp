@@ -1,0 +1,429 @@
+/*
+ * mtg_cli.cpp -- `MindTheGap fill` front end of libmtgfill.so: option parsing, the two drivers and the writers.
+ *
+ *   options / checks     Filler::Filler, Filler::execute          /root/reference/src/Filler.cpp:76-113,136-165,231-317
+ *   -bkpt driver         breakpointFunctor::operator()            src/Filler.cpp:623-699
+ *   -contig driver       fillAny (contig part) + contigFunctor    src/Filler.cpp:755-829, 492-572
+ *   writers              writeFilledBreakpoint / writeVcf / writeToGFA / writeExtensions / writeVcfHeader
+ *                        src/Filler.cpp:1029-1093, 1095-1214, 1216-1273, 1275-1291, 349-383
+ * Records are written in input order, which is the reference's order with -nb-cores 1.
+ */
+#include "mtg_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <sstream>
+#include <unordered_map>
+
+namespace mtgi {
+
+static const char* MTG_VERSION = "2.3.0";
+
+typedef std::pair<std::string, bool> bkpt_t;
+typedef std::unordered_map<std::string, bkpt_t> bkpt_dict_t; /* src/Utils.hpp:43-44; iteration order is part of the output */
+
+static std::string short_name(const std::string& c) { size_t p = c.find(' '); return p == std::string::npos ? c : c.substr(0, p); }
+static std::string revcomp_str(const std::string& s)
+{
+    std::string r;
+    for (auto it = s.rbegin(); it != s.rend(); ++it) {
+        switch (*it) {
+            case 'a': r += 't'; break; case 't': r += 'a'; break; case 'c': r += 'g'; break; case 'g': r += 'c'; break;
+            case 'A': r += 'T'; break; case 'T': r += 'A'; break; case 'C': r += 'G'; break; case 'G': r += 'C'; break;
+        }
+    }
+    return r;
+}
+
+static GapWork make_gap(const std::string& source, const bkpt_dict_t& dict, bool repeated, bool reverse)
+{
+    GapWork g;
+    g.source = source;
+    g.anchor_repeated = repeated;
+    g.reverse = reverse;
+    for (auto it = dict.begin(); it != dict.end(); ++it) {
+        Target t;
+        t.seq = it->first;
+        t.name = it->second.first;
+        t.is_rc = it->second.second;
+        g.targets.push_back(t);
+    }
+    return g;
+}
+
+static std::string info_string(const GapWork& g)
+{
+    char buf[128];
+    std::string s;
+    snprintf(buf, sizeof buf, "\t%i\t%i\t%d", g.nb_nodes, g.total_nt, g.nb_terminal);
+    s += buf;
+    if (g.nb_terminal > 0 && g.has_counts) { snprintf(buf, sizeof buf, "\t%d\t%d", g.nb_total_filled, (int)g.sols.size()); s += buf; }
+    return s;
+}
+
+struct Options {
+    std::string in, graph, bkpt, contig, out;
+    int k = 31, abundance_min = -1, abundance_max = 0, max_nodes = 100, max_depth = 10000, overlap = 0, nb_cores = 0;
+    bool fwd_only = false, filter = false, extend = false, has_out = false;
+};
+
+struct Files {
+    FILE *insert = nullptr, *info = nullptr, *vcf = nullptr, *gfa = nullptr, *ext = nullptr;
+    ~Files() { for (FILE* f : {insert, info, vcf, gfa, ext}) if (f) fclose(f); }
+};
+
+static std::string solu_str(const Solution& s)
+{
+    if (s.count <= 1) return "";
+    std::ostringstream o;
+    o << "solution " << s.rank << "/" << s.count;
+    return o.str();
+}
+
+/* writeFilledBreakpoint, src/Filler.cpp:1029-1093.  The bkpt-mode header passes its arguments in a different order
+ * than its format (:1052-1054); the visible x86-64 result is NAME_len_L_qual_Q_avg_cov_A_median_cov_M   SOLU. */
+static void write_filled(Files& F, bool bkpt_mode, const GapWork& g, const std::vector<Solution>& sols, const std::string& seedName, const std::string& info)
+{
+    for (auto& s : sols) {
+        const int llen = (int)s.seq.length();
+        const std::string solu = solu_str(s);
+        if (bkpt_mode) {
+            fprintf(F.insert, ">%s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n", seedName.c_str(), llen, s.qual, (double)s.avg, (double)s.median, solu.c_str());
+        } else {
+            std::string targetName = g.targets[s.target].name;
+            if (g.targets[s.target].is_rc) targetName.append("_Rc");
+            int cov = s.median + 0.5;
+            fprintf(F.insert, ">%s;%s;len_%d_qual_%d_median_cov_%d\t%s\n", seedName.c_str(), targetName.c_str(), llen, s.qual, cov, solu.c_str());
+        }
+        fprintf(F.insert, "%.*s\n", llen, s.seq.c_str());
+    }
+    fprintf(F.info, "%s\t%s\n", seedName.c_str(), info.c_str());
+}
+
+/* writeVcf, src/Filler.cpp:1095-1214 */
+static void write_vcf(Files& F, bool filter, const std::vector<Solution>& sols, const std::string& breakpointName, const std::string& sourceSequence)
+{
+    for (auto& s : sols) {
+        std::string insertion = s.seq;
+        int repeatSize = 0;
+        int i = (int)sourceSequence.size() - 1, j = (int)s.seq.size() - 1;
+        while (i > 0 && j >= 0) { /* longest common suffix with a circular insert index, :1107-1126 */
+            if (sourceSequence[i] != s.seq[j]) break;
+            repeatSize++; i--; j--;
+            if (j == -1) j = (int)s.seq.size() - 1;
+        }
+        insertion = sourceSequence.substr(sourceSequence.size() - (repeatSize + 1), repeatSize + 1) + insertion;
+        insertion = insertion.substr(0, insertion.size() - repeatSize);
+        const std::string ref = sourceSequence.substr(sourceSequence.size() - (repeatSize + 1), 1);
+        std::vector<std::string> tokens;
+        { std::istringstream iss(breakpointName); std::string tok; while (getline(iss, tok, '_')) tokens.push_back(tok); }
+        std::string bkpt = breakpointName, position = ".", chromosome = ".", GT = "./.", genotype = "";
+        if (tokens.size() == 7) {
+            bkpt = tokens[0]; position = std::to_string(atoi(tokens[3].c_str()) - repeatSize); chromosome = tokens[1]; genotype = tokens[6];
+            GT = genotype == "HOM" ? "1/1" : "0/1";
+        }
+        if (tokens.size() == 8) {
+            bkpt = tokens[0] + tokens[2]; position = std::to_string(atoi(tokens[4].c_str()) - repeatSize); chromosome = tokens[1]; genotype = tokens[7];
+            GT = genotype == "HOM" ? "1/1" : "0/1";
+        }
+        const int size = (int)(insertion.size() - ref.size()), nsol = s.count, npos = repeatSize + 1;
+        std::string filt = "PASS";
+        if ((genotype == "HET" && nsol > 1) || (genotype == "HOM" && nsol > 1)) {
+            if (filter) break;
+            filt = "LOW_QUAL";
+        }
+        fprintf(F.vcf, "%s\t%s\t%s\t%s\t%s\t.\t%s\tTYPE=INS;LEN=%i;QUAL=%i;NSOL=%i;NPOS=%i;AVK=%.2f;MDK=%.2f\tGT\t%s\n", chromosome.c_str(), position.c_str(), bkpt.c_str(),
+                ref.c_str(), insertion.c_str(), filt.c_str(), size, s.qual, nsol, npos, (double)s.avg, (double)s.median, GT.c_str());
+    }
+}
+
+/* writeToGFA, src/Filler.cpp:1216-1273 */
+static void write_gfa(Files& F, int trim, const GapWork& g, const std::vector<Solution>& sols, std::string seedName, bool isRc)
+{
+    const std::string seedNameNode = seedName;
+    std::string seedDirection = "+";
+    if (isRc) { seedName = seedName.substr(0, seedName.size() - 3); seedDirection = "-"; }
+    for (auto& s : sols) {
+        const std::string& tname = g.targets[s.target].name;
+        const bool trc = g.targets[s.target].is_rc;
+        const std::string targetNameNode = trc ? tname + "_Rc" : tname;
+        int cov = s.median + 0.5;
+        const std::string nodeName = seedNameNode + ";" + targetNameNode + ";len_" + std::to_string((int)s.seq.length()) + "_qual_" + std::to_string(s.qual) +
+                                     "_median_cov_" + std::to_string(cov) + " " + solu_str(s);
+        fprintf(F.gfa, "S\t%s\t%s\n", nodeName.c_str(), s.seq.c_str());
+        fprintf(F.gfa, "L\t%s\t%s\t%s\t+\t%iM\n", seedName.c_str(), seedDirection.c_str(), nodeName.c_str(), trim);
+        fprintf(F.gfa, "L\t%s\t+\t%s\t%s\t%iM\n", nodeName.c_str(), tname.c_str(), trc ? "-" : "+", trim);
+    }
+}
+
+static void write_extension(Files& F, const std::string& contigSeq, const std::string& seedName, const std::string& sourceSequence) /* :1275-1291 */
+{
+    const int llen = (int)contigSeq.length();
+    if (llen > 0) {
+        fprintf(F.ext, ">%s_len_%d source=%s\n", seedName.c_str(), llen, sourceSequence.c_str());
+        fprintf(F.ext, "%.*s\n", llen, contigSeq.c_str());
+    }
+}
+
+static void write_vcf_header(FILE* f, const std::string& sample, const std::string& prefix) /* src/Filler.cpp:349-383 */
+{
+    time_t now = time(NULL);
+    fprintf(f,
+            "##fileformat=VCFv4.1\n##filedate=%s##source=MindTheGap fill version %s\n##SAMPLE=file:%s\n##REF=file:%s\n"
+            "##INFO=<ID=TYPE,Number=1,Type=String,Description=\"INS\">\n##INFO=<ID=LEN,Number=1,Type=Integer,Description=\"variant size\">\n"
+            "##INFO=<=QUAL,Number=.,Type=Integer,Description=\"Quality of the insertion\">\n"
+            "##INFO=<=AVK,Number=.,Type=Float,Description=\"Average k-mer coverage along the insertion\">\n"
+            "##INFO=<=MDK,Number=.,Type=Float,Description=\"Median k-mer coverage along the insertion\">\n"
+            "##INFO=<=NSOL,Number=1,Type=String,Description=\"number of alternative insertion sequences for the breakpoint\">\n"
+            "##INFO=<ID=NPOS,Number=1,Type=Integer,Description=\"number of alternative positions for the insertion site (= size of repeat (fuzzy) +1)\">\n"
+            "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tG1\n",
+            ctime(&now), MTG_VERSION, sample.c_str(), prefix.c_str());
+}
+
+static void usage()
+{
+    fprintf(stdout,
+            "\nUsage:  MindTheGap fill (-in <reads.fq> | -graph <graph.mtgidx>) -bkpt <breakpoints.fa or -contig <contig.fa> [options]\n"
+            "   -in -graph -contig -bkpt -out -overlap -filter -extend | -kmer-size (31) -abundance-min (auto) -abundance-max |\n"
+            "   -max-nodes (100) -max-length (10000) -fwd-only | -nb-cores (0) -max-disk -max-memory -verbose\n");
+}
+
+struct Summary {
+    int nb_breakpoints = 0, nb_filled = 0, nb_multiple = 0, nb_contigs = 0, nb_used_contigs = 0;
+    void count(size_t nsol) { nb_breakpoints++; if (nsol > 0) { nb_filled++; if (nsol > 1) nb_multiple++; } }
+};
+
+static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O, Files& F, Summary& S)
+{
+    std::vector<std::pair<std::string, std::string>> recs;
+    if (!read_sequences(O.bkpt, recs)) { set_error("cannot read %s", O.bkpt.c_str()); return MTG_ERR_IO; }
+    const size_t nsites = recs.size() / 2; /* records 2i / 2i+1 = left / right k-mer, src/Filler.cpp:625-629 */
+    struct Site { std::string source, target, name, name_r; bool repeated; };
+    std::vector<Site> sites(nsites);
+    std::vector<GapWork> fwd;
+    std::vector<std::string> swf;
+    for (size_t i = 0; i < nsites; i++) {
+        Site& s = sites[i];
+        s.source = recs[2 * i].second;
+        s.target = recs[2 * i + 1].second;
+        s.name = short_name(recs[2 * i].first);
+        s.name_r = short_name(recs[2 * i + 1].first);
+        s.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
+        bkpt_dict_t dict;
+        dict.insert({s.target, std::make_pair(s.name_r, false)});
+        fwd.push_back(make_gap(s.source, dict, s.repeated, false));
+        swf.push_back(s.target);
+    }
+    int rc = fill_gaps(idx, &P, fwd, swf, nullptr);
+    if (rc) return rc;
+    /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
+    std::vector<size_t> rev_of;
+    std::vector<GapWork> rev;
+    std::vector<std::string> swf2;
+    if (!O.fwd_only)
+        for (size_t i = 0; i < nsites; i++)
+            if (fwd[i].sols.empty()) {
+                const Site& s = sites[i];
+                const std::string target2 = revcomp_str(s.source), source2 = revcomp_str(s.target);
+                bkpt_dict_t dict;
+                dict.insert({target2, std::make_pair(s.name, false)});
+                rev.push_back(make_gap(source2, dict, s.repeated, true));
+                swf2.push_back(target2);
+                rev_of.push_back(i);
+            }
+    if (!rev.empty()) { rc = fill_gaps(idx, &P, rev, swf2, nullptr); if (rc) return rc; }
+    std::vector<long> rev_idx(nsites, -1);
+    for (size_t j = 0; j < rev_of.size(); j++) rev_idx[rev_of[j]] = (long)j;
+    for (size_t i = 0; i < nsites; i++) {
+        const Site& s = sites[i];
+        std::string info = info_string(fwd[i]);
+        std::string name = s.name;
+        const std::vector<Solution>* sols = &fwd[i].sols;
+        const GapWork* gw = &fwd[i];
+        if (rev_idx[i] >= 0) {
+            const GapWork& r = rev[rev_idx[i]];
+            info += info_string(r);
+            name = s.name_r; /* src/Filler.cpp:674 */
+            sols = &r.sols;
+            gw = &r;
+        }
+        write_filled(F, true, *gw, *sols, name, info);
+        write_vcf(F, O.filter, *sols, name, s.source);
+        if (sols->empty() && O.extend) {
+            write_extension(F, fwd[i].extension, name, s.source);
+            write_extension(F, rev_idx[i] >= 0 ? rev[rev_idx[i]].extension : std::string(), name + "_reverse", revcomp_str(s.target));
+        }
+        S.count(sols->size());
+    }
+    return MTG_OK;
+}
+
+static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& O, Files& F, Summary& S, int trim)
+{
+    const int k = idx->info.k;
+    std::vector<std::pair<std::string, std::string>> recs;
+    if (!read_sequences(O.contig, recs)) { set_error("cannot read %s", O.contig.c_str()); return MTG_ERR_IO; }
+    bkpt_dict_t all_targets;
+    std::vector<std::pair<std::string, std::string>> seeds; /* name, k-mer */
+    {
+        std::ofstream seedFile(O.out + "_seed_dictionary.fasta");
+        for (auto& r : recs) {
+            const std::string& contig = r.second;
+            const std::string name = short_name(r.first);
+            S.nb_contigs++;
+            fprintf(F.gfa, "S\t%s\t%s\n", name.c_str(), contig.c_str());
+            if (contig.size() > (size_t)(2 * trim + k)) { /* src/Filler.cpp:776 */
+                const std::string rc = revcomp_str(contig);
+                const std::string seed_f = contig.substr(contig.size() - (trim + k), k), target_f = contig.substr(trim, k);
+                const std::string seed_rc = rc.substr(rc.size() - (trim + k), k), target_rc = rc.substr(trim, k);
+                all_targets.insert({{target_f, std::make_pair(name, false)}, {target_rc, std::make_pair(name, true)}});
+                seedFile << ">" + name + "\n" << seed_f << std::endl;
+                seedFile << ">" + name + "_Rc\n" << seed_rc << std::endl;
+                seeds.push_back({name, seed_f});
+                seeds.push_back({name + "_Rc", seed_rc});
+                S.nb_used_contigs++;
+            } else {
+                fprintf(stderr, "Warning contig not used (too short: <= 2 x overlap + kmerSize = %d nt): %s of size %zu nt\n", 2 * trim + k, name.c_str(), contig.size());
+            }
+        }
+    }
+    /* contigFunctor, src/Filler.cpp:492-572 */
+    std::vector<GapWork> gaps;
+    std::vector<std::string> swf;
+    for (auto& sd : seeds) {
+        std::string conc;
+        bkpt_dict_t dict;
+        for (auto its = all_targets.begin(); its != all_targets.end(); ++its) {
+            std::string tempName = its->second.first;
+            if (its->second.second) tempName += "_Rc";
+            if (tempName.compare(sd.first) != 0) { conc.append(its->first); dict.insert({its->first, its->second}); }
+        }
+        gaps.push_back(make_gap(sd.second, dict, false, false));
+        swf.push_back(conc);
+    }
+    int rc = fill_gaps(idx, &P, gaps, swf, nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < seeds.size(); i++) {
+        const std::string& seedName = seeds[i].first;
+        const bool isRc = seedName.length() >= 3 && seedName.compare(seedName.length() - 3, 3, "_Rc") == 0;
+        std::vector<Solution> kept;
+        for (auto& s : gaps[i].sols) { /* drop loops: target == seed reversed, :540-557 */
+            const Target& t = gaps[i].targets[s.target];
+            const std::string revTargetName = t.is_rc ? t.name : t.name + "_Rc";
+            if (revTargetName != seedName) kept.push_back(s);
+        }
+        write_filled(F, false, gaps[i], kept, seedName, info_string(gaps[i]));
+        write_gfa(F, trim, gaps[i], kept, seedName, isRc);
+        if (kept.empty() && O.extend) write_extension(F, gaps[i].extension, seedName, seeds[i].second);
+        S.count(kept.size());
+    }
+    return MTG_OK;
+}
+
+int fill_main(int argc, const char* const* argv)
+{
+    Options O;
+    for (int i = 0; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&](std::string& dst) -> bool { if (i + 1 >= argc) return false; dst = argv[++i]; return true; };
+        std::string v;
+        bool ok = true;
+        if (a == "-in") ok = val(O.in);
+        else if (a == "-graph") ok = val(O.graph);
+        else if (a == "-bkpt") ok = val(O.bkpt);
+        else if (a == "-contig") ok = val(O.contig);
+        else if (a == "-out") { ok = val(O.out); O.has_out = true; }
+        else if (a == "-kmer-size") { ok = val(v); O.k = atoi(v.c_str()); }
+        else if (a == "-abundance-min") { ok = val(v); O.abundance_min = v == "auto" ? -1 : atoi(v.c_str()); }
+        else if (a == "-abundance-max") { ok = val(v); O.abundance_max = atoi(v.c_str()); }
+        else if (a == "-max-nodes") { ok = val(v); O.max_nodes = atoi(v.c_str()); }
+        else if (a == "-max-length") { ok = val(v); O.max_depth = atoi(v.c_str()); }
+        else if (a == "-overlap") { ok = val(v); O.overlap = atoi(v.c_str()); }
+        else if (a == "-nb-cores") { ok = val(v); O.nb_cores = atoi(v.c_str()); }
+        else if (a == "-max-memory" || a == "-max-disk" || a == "-verbose") ok = val(v);
+        else if (a == "-fwd-only") O.fwd_only = true;
+        else if (a == "-filter") O.filter = true;
+        else if (a == "-extend") O.extend = true;
+        else if (a == "-help" || a == "-h") { usage(); return 1; }
+        else { fprintf(stderr, "EXCEPTION: unknown option '%s'\n", a.c_str()); usage(); return 1; }
+        if (!ok) { fprintf(stderr, "EXCEPTION: missing value for option '%s'\n", a.c_str()); return 1; }
+    }
+    /* src/Filler.cpp:140-150 */
+    if (O.graph.empty() == O.in.empty()) { fprintf(stderr, "EXCEPTION: options -graph and -in are incompatible, but at least one of these is mandatory\n"); return 1; }
+    if (O.bkpt.empty() == O.contig.empty()) { fprintf(stderr, "EXCEPTION: option -bkpt and -contig are incompatible, but at least one of these is mandatory\n"); return 1; }
+    if (!O.has_out) { /* src/Filler.cpp:154-165 */
+        time_t now = time(0);
+        struct tm tstruct = *localtime(&now);
+        char buf[80];
+        strftime(buf, sizeof(buf), "%Y-%m-%d.%I:%M", &tstruct);
+        O.out = std::string("MindTheGap_Expe-") + buf;
+    }
+    mtg_index* idx = nullptr;
+    int rc;
+    if (!O.in.empty()) {
+        rc = index_from_reads(O.in.c_str(), O.k, O.abundance_min, O.abundance_max, &idx);
+        if (!rc) (void)index_save(idx, (O.out + ".mtgidx").c_str()); /* the reference leaves <out>.h5 behind */
+    } else {
+        fprintf(stderr, "Loading the graph...");
+        rc = index_load(O.graph.c_str(), &idx);
+        if (!rc) fprintf(stderr, "done\n");
+    }
+    if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); return 1; }
+    const int k = idx->info.k;
+    const bool bkpt_mode = !O.bkpt.empty();
+    Files F;
+    const std::string insert_name = O.out + ".insertions.fasta", info_name = O.out + ".info.txt", vcf_name = O.out + ".insertions.vcf", gfa_name = O.out + ".gfa",
+                      ext_name = O.out + ".extensions.fasta";
+    auto open_w = [&](FILE*& f, const std::string& name) -> bool {
+        f = fopen(name.c_str(), "w");
+        if (!f) fprintf(stderr, "EXCEPTION: Cannot open file %s for writing\n", name.c_str());
+        return f != nullptr;
+    };
+    if (!open_w(F.insert, insert_name) || !open_w(F.info, info_name)) { mtg_index_free(idx); return 1; }
+    if (bkpt_mode) { if (!open_w(F.vcf, vcf_name)) { mtg_index_free(idx); return 1; } write_vcf_header(F.vcf, O.in.empty() ? O.graph : O.in, O.out); }
+    else if (!open_w(F.gfa, gfa_name)) { mtg_index_free(idx); return 1; }
+    if (O.extend && !open_w(F.ext, ext_name)) { mtg_index_free(idx); return 1; }
+    int trim = O.overlap; /* src/Filler.cpp:299-307 */
+    if (trim == 0) trim = k;
+    if (trim < k) { trim = k; fprintf(stderr, "Warning :  the contig overlap parameter should be greater or equal to kmer size, setting it to %d\n", k); }
+    mtg_params P;
+    mtg_default_params(&P);
+    P.max_nodes = O.max_nodes;
+    P.max_depth = O.max_depth;
+    P.nb_host_threads = O.nb_cores;
+    Summary S;
+    const time_t t_start = time(0);
+    rc = bkpt_mode ? run_bkpt(idx, P, O, F, S) : run_contig(idx, P, O, F, S, trim);
+    const double seconds = difftime(time(0), t_start);
+    if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); mtg_index_free(idx); return 1; }
+    /* resumeParameters / resumeResults, src/Filler.cpp:385-481 */
+    printf("MindTheGap fill\n    version                                  : %s\n    backend                                  : mindthegap_amd (HIP, gfx950)\n", MTG_VERSION);
+    printf("Parameters\n    Input data\n");
+    if (!O.in.empty()) printf("        Reads                                    : %s\n", O.in.c_str());
+    else printf("        Graph                                    : %s\n", O.graph.c_str());
+    printf("        %-40s : %s\n", bkpt_mode ? "Breakpoints" : "Contigs", bkpt_mode ? O.bkpt.c_str() : O.contig.c_str());
+    printf("    Graph\n        kmer-size                                : %i\n", k);
+    if (idx->info.abundance_auto >= 0) printf("        abundance_min (auto inferred)            : %d\n", idx->info.abundance_auto);
+    printf("        abundance_min (used)                     : %d\n        nb_solid_kmers                           : %llu\n        nb_branching_nodes                       : %llu\n",
+           idx->info.abundance_min, (unsigned long long)idx->info.nb_solid_kmers, (unsigned long long)idx->info.nb_branching);
+    printf("    Assembly options\n        max_depth                                : %i\n        max_nodes                                : %i\n", O.max_depth, O.max_nodes);
+    if (!bkpt_mode) printf("        contig trim size before gap-filling      : %i\n", trim);
+    printf("Results\n");
+    if (bkpt_mode) printf("    Breakpoints\n        nb_input_breakpoints                     : %i\n        nb_filled_breakpoints                    : %i\n", S.nb_breakpoints, S.nb_filled);
+    else printf("    Contigs\n        nb_input_contigs                         : %i\n        nb_used_contigs                          : %i\n        nb_input_seeds                           : %i\n        nb_filled_seeds                          : %i\n",
+                S.nb_contigs, S.nb_used_contigs, S.nb_breakpoints, S.nb_filled);
+    printf("            as_unique_sequence                       : %i\n            as_multiple_sequence                     : %i\n", S.nb_filled - S.nb_multiple, S.nb_multiple);
+    printf("    Time                                     : %.1f s\n    Output files\n        assembled sequence file                  : %s\n", seconds, insert_name.c_str());
+    if (bkpt_mode) printf("        insertion variant vcf file               : %s\n", vcf_name.c_str());
+    else printf("        assembly graph file                      : %s\n", gfa_name.c_str());
+    printf("        assembly statistics file                 : %s\n", info_name.c_str());
+    if (O.extend) printf("        extension sequence file                  : %s\n", ext_name.c_str());
+    mtg_index_free(idx);
+    return 0;
+}
+
+} // namespace mtgi
+
+extern "C" int mtg_fill_main(int argc, const char* const* argv) { return mtgi::fill_main(argc, argv); }

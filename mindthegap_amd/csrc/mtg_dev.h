@@ -1,0 +1,243 @@
+/*
+ * mtg_dev.h -- device-side k-mer model and the exact, neighbourhood-blocked index tables.
+ *
+ * Replaces, for the fill hot path, gatb-core's Graph neighbour / abundance queries
+ * (call sites /root/reference/src/Filler.cpp:866-867,884,978; SURVEY.md 8a rows a5,a6).
+ *
+ * Layout (all in HBM, 64-byte buckets = one memory line per query):
+ *   ADJ  table: key = canonical (k-1)-mer -> 8-bit edge mask (low nibble: nts b with key+b solid,
+ *               high nibble: nts a with a+key solid).  One bucket answers the whole
+ *               simplePathAvance neighbourhood of a node (its 4 successors AND the 4 predecessors
+ *               of those successors share this (k-1)-mer), i.e. 8 gatb membership probes.
+ *   ABND table: key = canonical k-mer -> 8-bit abundance (saturating at 255).
+ * A bucket holds 8 slots of 64 bits: [tag : tag_bits][disp : 3][value : 8].  The key is hashed by a
+ * bijection of its 2m-bit domain, the bucket is floor(H * nbuckets / 2^2m) and the tag the low
+ * tag_bits = 2m - floor(log2 nbuckets) bits of H, which makes (bucket, tag) lossless: the tables are
+ * exact (no false positives), unlike a Bloom filter + cFP cascade, for any query k-mer.
+ *
+ * The same source is compiled for gfx950 by hipcc and, TEST-ONLY, by g++ into the host emulation
+ * harness under tests/emu (kernel-logic tests and CPU sanitizers; never loaded by the product).
+ */
+#ifndef MTG_DEV_H
+#define MTG_DEV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MTG_DEV __device__ __forceinline__
+#define MTG_DEV_NOINLINE __device__ __noinline__
+#else
+#define MTG_EMU 1
+#define MTG_DEV inline
+#define MTG_DEV_NOINLINE inline
+#endif
+
+namespace mtg {
+
+/* A=0 C=1 T=2 G=3 ((ascii>>1)&3); complement = code ^ 2; first nt in the most significant bits. */
+MTG_DEV uint64_t kmask(int k) { return (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1); }
+
+MTG_DEV uint64_t revcomp(uint64_t x, int k)
+{
+    x ^= 0xAAAAAAAAAAAAAAAAULL;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * k);
+}
+
+MTG_DEV int popc4(uint32_t m) { return (int)((0xE994u >> ((m & 7u) << 1)) & 3u) + (int)((m >> 3) & 1u); }
+MTG_DEV int ctz4(uint32_t m) { return (m & 1u) ? 0 : (m & 2u) ? 1 : (m & 4u) ? 2 : 3; }
+/* complement the nucleotides of a 4-bit nt mask: bit i <-> bit i^2 */
+MTG_DEV uint32_t comp_mask(uint32_t m) { return ((m & 3u) << 2) | ((m >> 2) & 3u); }
+
+/* oriented k-mer: forward value and its reverse complement, rolled together */
+struct Kmer {
+    uint64_t f, r;
+};
+MTG_DEV Kmer make_kmer(uint64_t f, int k) { Kmer x; x.f = f; x.r = revcomp(f, k); return x; }
+MTG_DEV uint64_t canon(const Kmer& x) { return x.f < x.r ? x.f : x.r; }
+MTG_DEV Kmer kmer_next(const Kmer& x, uint32_t nt, int k, uint64_t mk)
+{
+    Kmer y;
+    y.f = ((x.f << 2) | (uint64_t)nt) & mk;
+    y.r = (x.r >> 2) | ((uint64_t)(nt ^ 2u) << (2 * (k - 1)));
+    return y;
+}
+MTG_DEV Kmer kmer_prev(const Kmer& x, uint32_t nt, int k, uint64_t mk)
+{
+    Kmer y;
+    y.f = (x.f >> 2) | ((uint64_t)nt << (2 * (k - 1)));
+    y.r = ((x.r << 2) | (uint64_t)(nt ^ 2u)) & mk;
+    return y;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+struct Table {
+    uint64_t* slots;   /* nbuckets * 8 words, 64-byte aligned */
+    uint64_t nbuckets;
+    uint32_t key_bits; /* 2m */
+    uint32_t tag_bits; /* key_bits - floor(log2(nbuckets)), <= 53 */
+};
+enum { MTG_MAX_DISP = 7, MTG_DISP_BITS = 3, MTG_SLOTS = 8 };
+
+/* bijection of the key_bits-wide domain */
+MTG_DEV uint64_t mix(uint64_t x, uint32_t key_bits)
+{
+    const uint64_t M = (1ULL << key_bits) - 1;
+    const uint32_t sh = key_bits >> 1; /* xorshift by >= 1 bit and multiplication by an odd constant are invertible mod 2^key_bits */
+    x ^= x >> sh;
+    x = (x * 0xBF58476D1CE4E5B9ULL) & M;
+    x ^= x >> sh;
+    x = (x * 0x94D049BB133111EBULL) & M;
+    x ^= x >> sh;
+    return x;
+}
+MTG_DEV uint64_t bucket_of(uint64_t H, uint64_t nb, uint32_t key_bits)
+{
+#ifdef MTG_EMU
+    return (uint64_t)(((unsigned __int128)H * nb) >> key_bits);
+#else
+    uint64_t hi = __umul64hi(H, nb), lo = H * nb;
+    return (hi << (64 - key_bits)) | (lo >> key_bits);
+#endif
+}
+
+struct alignas(16) U64x2 {
+    uint64_t x, y;
+};
+
+/* value of key, 0 if absent.  One 64-byte line in the common case. */
+MTG_DEV uint32_t table_get(const Table& t, uint64_t key, uint32_t& lines)
+{
+    const uint64_t H = mix(key, t.key_bits);
+    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
+        const U64x2* p = reinterpret_cast<const U64x2*>(t.slots + b * MTG_SLOTS);
+        const U64x2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        lines++;
+        const uint64_t want = (tag << MTG_DISP_BITS) | d;
+        uint32_t val = 0; /* empty slots (all zero) may alias tag 0 / disp 0 but contribute no bits */
+        val |= ((q0.x >> 8) == want) ? (uint32_t)(q0.x & 255) : 0u;
+        val |= ((q0.y >> 8) == want) ? (uint32_t)(q0.y & 255) : 0u;
+        val |= ((q1.x >> 8) == want) ? (uint32_t)(q1.x & 255) : 0u;
+        val |= ((q1.y >> 8) == want) ? (uint32_t)(q1.y & 255) : 0u;
+        val |= ((q2.x >> 8) == want) ? (uint32_t)(q2.x & 255) : 0u;
+        val |= ((q2.y >> 8) == want) ? (uint32_t)(q2.y & 255) : 0u;
+        val |= ((q3.x >> 8) == want) ? (uint32_t)(q3.x & 255) : 0u;
+        val |= ((q3.y >> 8) == want) ? (uint32_t)(q3.y & 255) : 0u;
+        if (val) return val;
+        /* slots fill in order, so a free last slot means the key cannot be further away */
+        if (q3.y == 0) return 0;
+        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
+    }
+    return 0;
+}
+
+MTG_DEV uint64_t atomic_cas64(uint64_t* p, uint64_t cmp, uint64_t val)
+{
+#ifdef MTG_EMU
+    return __sync_val_compare_and_swap(p, cmp, val);
+#else
+    return (uint64_t)atomicCAS(reinterpret_cast<unsigned long long*>(p), (unsigned long long)cmp, (unsigned long long)val);
+#endif
+}
+MTG_DEV void atomic_or64(uint64_t* p, uint64_t bits)
+{
+#ifdef MTG_EMU
+    __sync_fetch_and_or(p, bits);
+#else
+    atomicOr(reinterpret_cast<unsigned long long*>(p), (unsigned long long)bits);
+#endif
+}
+
+/* insert key with value bits, OR-ing into an existing entry.  Returns 0 (entry existed), 2 (entry created), or
+ * 1 when the key would be displaced by more than MTG_MAX_DISP buckets (the host then rebuilds with more buckets). */
+MTG_DEV int table_or(const Table& t, uint64_t key, uint32_t bits)
+{
+    const uint64_t H = mix(key, t.key_bits);
+    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
+        const uint64_t want = (tag << MTG_DISP_BITS) | d;
+        uint64_t* p = t.slots + b * MTG_SLOTS;
+        for (int i = 0; i < MTG_SLOTS; i++) {
+            uint64_t v = *(volatile uint64_t*)(p + i);
+            if (v == 0) {
+                v = atomic_cas64(p + i, 0, (want << 8) | bits);
+                if (v == 0) return 2;
+            }
+            if ((v >> 8) == want) {
+                if ((v & bits) != bits) atomic_or64(p + i, bits);
+                return 0;
+            }
+        }
+        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+struct Index {
+    Table adj;  /* canonical (k-1)-mer -> edge masks */
+    Table abnd; /* canonical k-mer     -> abundance  */
+    int k;
+};
+
+struct Adj {
+    uint32_t out; /* nts b such that x[1:]+b is solid  (successors of x)                     */
+    uint32_t in;  /* nts a such that a+x[1:] is solid  (predecessors of every successor of x) */
+};
+
+/* right neighbourhood of x: successors of x and in-neighbours of those successors (one line). */
+MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
+{
+    const uint64_t s = x.f & mk1, rs = x.r >> 2;
+    const uint32_t m = table_get(ix.adj, s <= rs ? s : rs, lines);
+    Adj a;
+    if (s <= rs) { a.out = m & 15u; a.in = m >> 4; }
+    else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
+    return a;
+}
+/* left neighbourhood of x: .in = predecessors of x, .out = successors of every predecessor. */
+MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
+{
+    const uint64_t p = x.f >> 2, rp = x.r & mk1;
+    const uint32_t m = table_get(ix.adj, p <= rp ? p : rp, lines);
+    Adj a;
+    if (p <= rp) { a.out = m & 15u; a.in = m >> 4; }
+    else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
+    return a;
+}
+MTG_DEV uint32_t abundance(const Index& ix, const Kmer& x, uint32_t& lines) { return table_get(ix.abnd, canon(x), lines); }
+
+/* index construction: one call per solid k-mer (canonical value c, abundance >= 1).
+ * Returns bit 0 = displacement overflow, bit 1 = the k-mer was new. */
+MTG_DEV int index_insert(const Index& ix, uint64_t c, uint32_t abund)
+{
+    const int k = ix.k;
+    const uint64_t mk1 = kmask(k - 1);
+    int fail = table_or(ix.abnd, c, abund > 255u ? 255u : (abund ? abund : 1u));
+    const int created = fail & 2;
+    Kmer o[2];
+    o[0].f = c; o[0].r = revcomp(c, k);
+    o[1].f = o[0].r; o[1].r = c;
+    for (int s = 0; s < 2; s++) {
+        const Kmer& x = o[s];
+        const uint32_t a = (uint32_t)(x.f >> (2 * (k - 1))) & 3u, b = (uint32_t)x.f & 3u;
+        const uint64_t suf = x.f & mk1, rsuf = x.r >> 2; /* a + suf is solid */
+        if (suf <= rsuf) fail |= table_or(ix.adj, suf, 1u << (4 + a)) & 1;
+        else fail |= table_or(ix.adj, rsuf, 1u << (a ^ 2u)) & 1;
+        const uint64_t pre = x.f >> 2, rpre = x.r & mk1; /* pre + b is solid */
+        if (pre <= rpre) fail |= table_or(ix.adj, pre, 1u << b) & 1;
+        else fail |= table_or(ix.adj, rpre, 1u << (4 + (b ^ 2u))) & 1;
+    }
+    return (fail & 1) | created;
+}
+
+} // namespace mtg
+#endif

@@ -1,0 +1,583 @@
+/*
+ * mtg_gpu.hip -- HIP kernels and device management of libmtgfill.so (gfx950 only).
+ *
+ *   k_insert_kmers / k_insert_packed : index construction (Graph::create, /root/reference/src/Filler.cpp:210)
+ *   k_query                          : batched contains / queryAbundance / successors / predecessors
+ *   k_stage_a                        : breadth-first contig construction of one gap per lane
+ *                                      (IterativeExtensions::construct_linear_seqs, src/Filler.cpp:884)
+ *   k_compact                        : gathers the contigs of a chunk into a dense arena for the copy back
+ *   k_chase                          : dependent random 64-byte reads (measured roofline ceiling)
+ */
+#include "mtg_internal.h"
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+using namespace mtg;
+
+namespace mtgi {
+
+static thread_local char g_err[512] = "";
+static thread_local mtg_batch_stats g_stats{};
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+void stats_store(const mtg_batch_stats& s) { g_stats = s; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);       \
+            return (e_ == hipErrorOutOfMemory) ? MTG_ERR_NOMEM : MTG_ERR_NO_DEVICE;                     \
+        }                                                                                               \
+    } while (0)
+
+static int ensure_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libmtgfill has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return MTG_ERR_NO_DEVICE;
+    }
+    return MTG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ kernels */
+__device__ __forceinline__ uint64_t d_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+/* counters[0] = overflow flag, counters[1] = new k-mers */
+__global__ void k_insert_kmers(Index ix, const uint64_t* __restrict__ kmers, const uint32_t* __restrict__ ab, size_t n, unsigned long long* counters)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned long long created = 0;
+    int fail = 0;
+    for (; i < n; i += stride) {
+        int r = index_insert(ix, kmers[i], ab[i]);
+        fail |= r & 1;
+        created += (r >> 1) & 1;
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (created) atomicAdd(&counters[1], created);
+}
+
+/* one workgroup per sequence; lanes stride over k-mer start positions */
+__global__ void k_insert_packed(Index ix, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len,
+                                size_t nseq, uint32_t abund_lo, uint32_t abund_span, unsigned long long* counters)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k);
+    unsigned long long created = 0;
+    int fail = 0;
+    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const uint64_t* w = words + word_off[s];
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        for (uint32_t p = threadIdx.x; p + k <= L; p += blockDim.x) {
+            /* nts p .. p+k-1, nt i at bits 2*(i%32) of word i/32 */
+            uint64_t f = 0;
+            for (int j = 0; j < k; j++) {
+                const uint32_t i = p + j;
+                f = (f << 2) | ((w[i >> 5] >> (2 * (i & 31))) & 3ull);
+            }
+            f &= mk;
+            const uint64_t r = revcomp(f, k);
+            const uint64_t c = f < r ? f : r;
+            const uint32_t a = abund_lo + (uint32_t)(d_splitmix64(c) % (abund_span ? abund_span : 1u));
+            int rr = index_insert(ix, c, a);
+            fail |= rr & 1;
+            created += (rr >> 1) & 1;
+        }
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (created) atomicAdd(&counters[1], created);
+}
+
+/* counters[2] += branching nodes among kmers[] (in-degree != 1 or out-degree != 1) */
+__global__ void k_count_branching(Index ix, const uint64_t* __restrict__ kmers, size_t n, unsigned long long* counters)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint64_t mk1 = kmask(ix.k - 1);
+    unsigned long long nb = 0;
+    uint32_t lines = 0;
+    for (; i < n; i += stride) {
+        Kmer x = make_kmer(kmers[i], ix.k);
+        const int outd = popc4(adj_right(ix, x, mk1, lines).out), ind = popc4(adj_left(ix, x, mk1, lines).in);
+        nb += !(outd == 1 && ind == 1);
+    }
+    if (nb) atomicAdd(&counters[2], nb);
+}
+
+__global__ void k_query(Index ix, const uint64_t* __restrict__ kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint64_t mk1 = kmask(ix.k - 1);
+    uint32_t lines = 0;
+    for (; i < n; i += stride) {
+        Kmer x = make_kmer(kmers[i] & kmask(ix.k), ix.k);
+        if (abund) abund[i] = abundance(ix, x, lines);
+        if (succ) succ[i] = (uint8_t)adj_right(ix, x, mk1, lines).out;
+        if (pred) pred[i] = (uint8_t)adj_left(ix, x, mk1, lines).in;
+    }
+}
+
+/* one gap per lane, one wave per workgroup (waves retire independently) */
+__global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* zero, uint8_t* raw, const uint64_t* __restrict__ src,
+                                                const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
+                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
+                                                GapOut* out, uint32_t n)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
+    GapScratch S = carve(cfg, zero, raw, slot);
+    SwfPattern R;
+    R.words = rwords + roff[g];
+    R.rlen = rlen[g];
+    R.r0 = r0[g];
+    GapOut o;
+    stage_a_gap(ix, cfg, S, src[g], R, o);
+    out[slot] = o;
+}
+
+/* dense copy of the contigs of a chunk: words, then (start,len) pairs per contig */
+__global__ void k_compact(FillCfg cfg, const uint8_t* raw, const GapOut* __restrict__ outs, const uint64_t* __restrict__ word_base,
+                          const uint64_t* __restrict__ contig_base, uint64_t* dense_words, uint32_t* dense_len, uint32_t* dense_start, uint32_t n)
+{
+    for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        const GapOut o = outs[slot];
+        if (o.status != GAP_OK) continue;
+        GapScratch S;
+        S.z = nullptr;
+        S.r = const_cast<uint8_t*>(raw) + (uint64_t)slot * cfg.raw_stride;
+        const uint64_t* w = s_words(cfg, S);
+        uint64_t* dw = dense_words + word_base[slot];
+        for (uint32_t i = threadIdx.x; i < o.n_words; i += blockDim.x) dw[i] = w[i];
+        const uint32_t* cs = s_cstart(cfg, S);
+        const uint32_t* cl = s_clen(cfg, S);
+        for (uint32_t i = threadIdx.x; i < o.n_contigs; i += blockDim.x) {
+            dense_len[contig_base[slot] + i] = cl[i];
+            dense_start[contig_base[slot] + i] = cs[i];
+        }
+    }
+}
+
+/* dependent chains of random 64-byte line reads: the access pattern of the simple-path walk */
+__global__ void __launch_bounds__(64) k_chase(const uint64_t* __restrict__ table, uint64_t nlines, uint64_t n_chains, uint32_t chain_len, uint64_t* sink)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chains) return;
+    uint64_t x = d_splitmix64(t + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < chain_len; i++) {
+        const uint64_t line = x % nlines;
+        const U64x2* p = reinterpret_cast<const U64x2*>(table + line * 8);
+        const U64x2 a = p[0], b = p[1], c = p[2], d = p[3];
+        const uint64_t v = a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y ^ d.x ^ d.y;
+        acc += v;
+        x = d_splitmix64(x ^ v);
+    }
+    if (acc == 0x123456789ull) sink[0] = acc;
+}
+
+__global__ void k_fill_random(uint64_t* p, uint64_t nwords, uint64_t seed)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < nwords; i += stride) p[i] = d_splitmix64(seed + i);
+}
+
+/* ------------------------------------------------------------------------------------------------ index */
+static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load)
+{
+    const int k = idx->dev.k;
+    table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load, 2 * (k - 1)), 2 * (k - 1));
+    table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k), 2 * k);
+    const size_t ba = idx->dev.adj.nbuckets * 64, bb = idx->dev.abnd.nbuckets * 64;
+    HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));
+    hipError_t e = hipMalloc((void**)&idx->dev.abnd.slots, bb);
+    if (e != hipSuccess) {
+        (void)hipFree(idx->dev.adj.slots);
+        idx->dev.adj.slots = nullptr;
+        set_error("hipMalloc of %zu bytes failed: %s", bb, hipGetErrorString(e));
+        return MTG_ERR_NOMEM;
+    }
+    HIP_TRY(hipMemsetAsync(idx->dev.adj.slots, 0, ba, 0));
+    HIP_TRY(hipMemsetAsync(idx->dev.abnd.slots, 0, bb, 0));
+    idx->info.device_bytes = ba + bb;
+    idx->info.adj_buckets = idx->dev.adj.nbuckets;
+    idx->info.abnd_buckets = idx->dev.abnd.nbuckets;
+    return MTG_OK;
+}
+static void free_tables(mtg_index* idx)
+{
+    if (idx->dev.adj.slots) (void)hipFree(idx->dev.adj.slots);
+    if (idx->dev.abnd.slots) (void)hipFree(idx->dev.abnd.slots);
+    idx->dev.adj.slots = idx->dev.abnd.slots = nullptr;
+}
+
+int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
+{
+    if (int rc = ensure_device()) return rc;
+    if (k < 11 || k > 31 || !out || (n && (!canon_kmers || !abundance))) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    mtg_index* idx = new mtg_index();
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    uint64_t* d_k = nullptr;
+    uint32_t* d_a = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_k, (n + 1) * 8));
+    HIP_TRY(hipMalloc((void**)&d_a, (n + 1) * 4));
+    HIP_TRY(hipMalloc((void**)&d_cnt, 4 * 8));
+    HIP_TRY(hipMemcpy(d_k, canon_kmers, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_a, abundance, n * 4, hipMemcpyHostToDevice));
+    double load = 0.5;
+    int rc = MTG_OK;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        rc = alloc_tables(idx, n, load);
+        if (rc) break;
+        HIP_TRY(hipMemset(d_cnt, 0, 32));
+        const int blocks = (int)std::min<size_t>((n + 255) / 256 + 1, 256 * 16);
+        hipLaunchKernelGGL(k_insert_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, d_a, n, d_cnt);
+        unsigned long long cnt[4];
+        HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+        if (!cnt[0]) {
+            hipLaunchKernelGGL(k_count_branching, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, n, d_cnt);
+            HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+            idx->info.nb_solid_kmers = cnt[1];
+            idx->info.nb_branching = cnt[2];
+            rc = MTG_OK;
+            break;
+        }
+        free_tables(idx);
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    (void)hipFree(d_k);
+    (void)hipFree(d_a);
+    (void)hipFree(d_cnt);
+    if (rc) { free_tables(idx); delete idx; return rc; }
+    idx->info.k = k;
+    idx->info.abundance_min = 0;
+    idx->info.abundance_auto = -1;
+    *out = idx;
+    return MTG_OK;
+}
+
+int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t total_kmers_ub, int k,
+                             uint32_t abund_lo, uint32_t abund_span, mtg_index** out)
+{
+    if (int rc = ensure_device()) return rc;
+    if (k < 11 || k > 31 || !out || !d_words || !d_word_off || !d_len) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    mtg_index* idx = new mtg_index();
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    unsigned long long* d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_cnt, 32));
+    double load = 0.5;
+    int rc = MTG_OK;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        rc = alloc_tables(idx, total_kmers_ub, load);
+        if (rc) break;
+        HIP_TRY(hipMemset(d_cnt, 0, 32));
+        const int blocks = (int)std::min<size_t>(nseq, 256 * 32);
+        hipLaunchKernelGGL(k_insert_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq, abund_lo, abund_span, d_cnt);
+        unsigned long long cnt[4];
+        HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+        if (!cnt[0]) {
+            idx->info.nb_solid_kmers = cnt[1];
+            idx->info.nb_branching = ~0ull; /* not computed on this path */
+            rc = MTG_OK;
+            break;
+        }
+        free_tables(idx);
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    (void)hipFree(d_cnt);
+    if (rc) { free_tables(idx); delete idx; return rc; }
+    idx->info.k = k;
+    idx->info.abundance_min = (int)abund_lo;
+    idx->info.abundance_auto = -1;
+    *out = idx;
+    return MTG_OK;
+}
+
+void index_release(mtg_index* idx)
+{
+    if (!idx) return;
+    index_forget_host_copy(idx);
+    free_tables(idx);
+    delete idx;
+}
+
+int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
+{
+    if (int rc = ensure_device()) return rc;
+    if (!idx || (n && !kmers)) { set_error("null argument"); return MTG_ERR_ARG; }
+    if (n == 0) return MTG_OK;
+    uint64_t* d_k = nullptr;
+    uint32_t* d_a = nullptr;
+    uint8_t *d_s = nullptr, *d_p = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_k, n * 8));
+    HIP_TRY(hipMemcpy(d_k, kmers, n * 8, hipMemcpyHostToDevice));
+    if (abund) HIP_TRY(hipMalloc((void**)&d_a, n * 4));
+    if (succ) HIP_TRY(hipMalloc((void**)&d_s, n));
+    if (pred) HIP_TRY(hipMalloc((void**)&d_p, n));
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_query, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, n, d_a, d_s, d_p);
+    HIP_TRY(hipGetLastError());
+    if (abund) HIP_TRY(hipMemcpy(abund, d_a, n * 4, hipMemcpyDeviceToHost));
+    if (succ) HIP_TRY(hipMemcpy(succ, d_s, n, hipMemcpyDeviceToHost));
+    if (pred) HIP_TRY(hipMemcpy(pred, d_p, n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_k);
+    if (d_a) (void)hipFree(d_a);
+    if (d_s) (void)hipFree(d_s);
+    if (d_p) (void)hipFree(d_p);
+    return MTG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ stage A */
+void StageAInput::add(const char* source, const char* target, int k)
+{
+    src.push_back(encode_kmer(source, k));
+    const size_t rl = strlen(target);
+    std::vector<uint64_t> w;
+    pack_seq(target, rl, w);
+    roff.push_back((uint32_t)rwords.size());
+    rwords.insert(rwords.end(), w.begin(), w.end());
+    rlen.push_back((uint32_t)rl);
+    r0.push_back(rl >= (size_t)k ? encode_kmer(target, k) : 0);
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T* as() { return (T*)p; }
+};
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} // namespace
+
+int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in, std::vector<GapContigs>& out, mtg_batch_stats* stats)
+{
+    if (int rc = ensure_device()) return rc;
+    const size_t n = in.src.size();
+    out.assign(n, GapContigs());
+    mtg_batch_stats st{};
+    const double t_begin = now_ms();
+    if (n == 0) { if (stats) *stats = st; return MTG_OK; }
+    const int k = idx->dev.k;
+
+    DevBuf d_src, d_rw, d_roff, d_rlen, d_r0;
+    double t0 = now_ms();
+    HIP_TRY(d_src.alloc(n * 8)); HIP_TRY(d_rw.alloc(in.rwords.size() * 8)); HIP_TRY(d_roff.alloc(n * 4)); HIP_TRY(d_rlen.alloc(n * 4)); HIP_TRY(d_r0.alloc(n * 8));
+    HIP_TRY(hipMemcpy(d_src.p, in.src.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_rw.p, in.rwords.data(), in.rwords.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_roff.p, in.roff.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_rlen.p, in.rlen.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_r0.p, in.r0.data(), n * 8, hipMemcpyHostToDevice));
+    st.h2d_ms += now_ms() - t0;
+
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+
+    std::vector<uint32_t> todo(n);
+    for (size_t i = 0; i < n; i++) todo[i] = (uint32_t)i;
+    int rc = MTG_OK;
+
+    for (int tier = 0; tier <= MTG_MAX_TIER && !todo.empty(); tier++) {
+        FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + sizeof(GapOut) + 64;
+        size_t chunk = (size_t)((double)free_b * 0.6 / (double)per_gap);
+        if (chunk > todo.size()) chunk = todo.size();
+        if (chunk > (1u << 20)) chunk = 1u << 20;
+        if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }
+        DevBuf d_zero, d_raw, d_out, d_ids;
+        HIP_TRY(d_zero.alloc(chunk * cfg.zero_stride));
+        HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride));
+        HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
+        HIP_TRY(d_ids.alloc(chunk * 4));
+        std::vector<uint32_t> retry;
+        std::vector<GapOut> h_out(chunk);
+        for (size_t base = 0; base < todo.size(); base += chunk) {
+            const uint32_t m = (uint32_t)std::min(chunk, todo.size() - base);
+            t0 = now_ms();
+            HIP_TRY(hipMemcpy(d_ids.p, todo.data() + base, (size_t)m * 4, hipMemcpyHostToDevice));
+            st.h2d_ms += now_ms() - t0;
+            HIP_TRY(hipMemsetAsync(d_zero.p, 0, (size_t)m * cfg.zero_stride, 0));
+            HIP_TRY(hipEventRecord(ev0, 0));
+            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_src.as<uint64_t>(),
+                               d_rw.as<uint64_t>(), d_roff.as<uint32_t>(), d_rlen.as<uint32_t>(), d_r0.as<uint64_t>(), d_ids.as<uint32_t>(),
+                               d_out.as<GapOut>(), m);
+            HIP_TRY(hipEventRecord(ev1, 0));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventSynchronize(ev1));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+            st.kernel_ms += ms;
+            st.n_launches++;
+            t0 = now_ms();
+            HIP_TRY(hipMemcpy(h_out.data(), d_out.p, (size_t)m * sizeof(GapOut), hipMemcpyDeviceToHost));
+            /* dense copy back */
+            std::vector<uint64_t> wbase(m), cbase(m);
+            uint64_t nw = 0, nc = 0;
+            for (uint32_t s = 0; s < m; s++) {
+                wbase[s] = nw; cbase[s] = nc;
+                st.index_lines += h_out[s].lines;
+                if (h_out[s].status == GAP_OK) { nw += h_out[s].n_words; nc += h_out[s].n_contigs; }
+                else retry.push_back(todo[base + s]);
+            }
+            DevBuf d_wb, d_cb, d_dw, d_dl, d_ds;
+            HIP_TRY(d_wb.alloc((size_t)m * 8)); HIP_TRY(d_cb.alloc((size_t)m * 8)); HIP_TRY(d_dw.alloc(nw * 8)); HIP_TRY(d_dl.alloc(nc * 4)); HIP_TRY(d_ds.alloc(nc * 4));
+            HIP_TRY(hipMemcpy(d_wb.p, wbase.data(), (size_t)m * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_cb.p, cbase.data(), (size_t)m * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_compact, dim3(std::min<uint32_t>(m, 256 * 16)), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_wb.as<uint64_t>(),
+                               d_cb.as<uint64_t>(), d_dw.as<uint64_t>(), d_dl.as<uint32_t>(), d_ds.as<uint32_t>(), m);
+            HIP_TRY(hipGetLastError());
+            std::vector<uint64_t> hw(nw);
+            std::vector<uint32_t> hl(nc), hs(nc);
+            HIP_TRY(hipMemcpy(hw.data(), d_dw.p, nw * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(hl.data(), d_dl.p, nc * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(hs.data(), d_ds.p, nc * 4, hipMemcpyDeviceToHost));
+            st.d2h_ms += now_ms() - t0;
+            for (uint32_t s = 0; s < m; s++) {
+                if (h_out[s].status != GAP_OK) continue;
+                GapContigs& gc = out[todo[base + s]];
+                gc.n_contigs = h_out[s].n_contigs;
+                gc.total_nt = h_out[s].total_nt;
+                gc.words.assign(hw.begin() + wbase[s], hw.begin() + wbase[s] + h_out[s].n_words);
+                gc.words.push_back(0);
+                gc.len.assign(hl.begin() + cbase[s], hl.begin() + cbase[s] + gc.n_contigs);
+                gc.word_start.assign(hs.begin() + cbase[s], hs.begin() + cbase[s] + gc.n_contigs);
+                st.contig_nt += gc.total_nt;
+            }
+        }
+        if (tier > 0) st.n_retried_gaps += todo.size();
+        todo.swap(retry);
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (rc == MTG_OK && !todo.empty()) {
+        set_error("%zu gap(s) exceeded the largest traversal scratch tier", todo.size());
+        rc = MTG_ERR_OVERFLOW;
+    }
+    st.total_ms = now_ms() - t_begin;
+    if (stats) *stats = st;
+    return rc;
+}
+
+int bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, double* ms_out, double* gbps)
+{
+    if (int rc = ensure_device()) return rc;
+    const uint64_t nlines = table_bytes / 64;
+    if (nlines == 0 || n_chains == 0 || chain_len == 0) { set_error("invalid argument"); return MTG_ERR_ARG; }
+    DevBuf tab, sink;
+    HIP_TRY(tab.alloc(nlines * 64));
+    HIP_TRY(sink.alloc(8));
+    hipLaunchKernelGGL(k_fill_random, dim3(256 * 16), dim3(256), 0, 0, tab.as<uint64_t>(), nlines * 8, 12345ull);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const uint32_t blocks = (uint32_t)((n_chains + 63) / 64);
+    hipLaunchKernelGGL(k_chase, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, std::min<uint32_t>(chain_len, 64), sink.as<uint64_t>());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_chase, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, chain_len, sink.as<uint64_t>());
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms_out) *ms_out = ms;
+    if (gbps) *gbps = (double)n_chains * chain_len * 64.0 / (ms * 1e-3) / 1e9;
+    return MTG_OK;
+}
+
+} // namespace mtgi
+
+/* ------------------------------------------------------------------------------------------------ C ABI (device side) */
+namespace mtgi {
+int index_from_kmers(const uint64_t*, const uint32_t*, size_t, int, mtg_index**);
+int index_from_packed_device(const uint64_t*, const uint64_t*, const uint32_t*, size_t, uint64_t, int, uint32_t, uint32_t, mtg_index**);
+void index_release(mtg_index*);
+int bench_random_lines(uint64_t, uint64_t, uint32_t, double*, double*);
+}
+
+extern "C" {
+
+const char* mtg_last_error(void) { return mtgi::g_err; }
+int mtg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int mtg_set_device(int device)
+{
+    if (hipSetDevice(device) != hipSuccess) { mtgi::set_error("hipSetDevice(%d) failed", device); return MTG_ERR_NO_DEVICE; }
+    return MTG_OK;
+}
+int mtg_index_create_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
+{
+    return mtgi::index_from_kmers(canon_kmers, abundance, n, k, out);
+}
+int mtg_index_create_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t ub, int k,
+                                        uint32_t abund_lo, uint32_t abund_span, mtg_index** out)
+{
+    return mtgi::index_from_packed_device(d_words, d_word_off, d_len, nseq, ub, k, abund_lo, abund_span, out);
+}
+void mtg_index_free(mtg_index* idx) { mtgi::index_release(idx); }
+int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info)
+{
+    if (!idx || !info) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    *info = idx->info;
+    return MTG_OK;
+}
+int mtg_index_contains(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* out)
+{
+    std::vector<uint32_t> ab(n);
+    int rc = mtgi::query_run(idx, kmers, n, ab.data(), nullptr, nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) out[i] = ab[i] != 0;
+    return MTG_OK;
+}
+int mtg_index_abundance(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* out) { return mtgi::query_run(idx, kmers, n, out, nullptr, nullptr); }
+int mtg_index_neighbors(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* succ, uint8_t* pred)
+{
+    return mtgi::query_run(idx, kmers, n, nullptr, succ, pred);
+}
+int mtg_last_batch_stats(mtg_batch_stats* s)
+{
+    if (!s) return MTG_ERR_ARG;
+    *s = mtgi::g_stats;
+    return MTG_OK;
+}
+int mtg_bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, double* ms, double* gbps)
+{
+    return mtgi::bench_random_lines(table_bytes, n_chains, chain_len, ms, gbps);
+}
+}

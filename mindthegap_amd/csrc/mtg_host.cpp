@@ -1,0 +1,666 @@
+/*
+ * mtg_host.cpp -- host orchestration of libmtgfill.so.
+ *
+ * The device builds the contigs of every gap (stage A, mtg_gpu.hip) and answers abundance queries; this file
+ * holds the rest of Filler::gapFillFromSource (/root/reference/src/Filler.cpp:854-1026) for a whole batch:
+ *   contig graph      IGraphOutput::construct_graph / print_edges   src/IGraphOutput.cpp:97-133,144-179
+ *   terminal nodes    Filler::find_nodes_containing_multiple_R      src/Filler.cpp:1294-1378
+ *   reverse DFS       GraphAnalysis::find_all_paths_rev             src/GraphAnalysis.cpp:205-326
+ *   path -> sequence  GraphAnalysis::paths_to_sequences             src/GraphAnalysis.cpp:331-460
+ *   dedupe            remove_almost_identical_solutions             src/Utils.cpp:208-238 (NW identity :87-189)
+ *   coverage / qual   src/Filler.cpp:959-1003, src/Utils.hpp:85-103, src/Utils.cpp:241-254
+ * plus the index construction from read files (Graph::create, src/Filler.cpp:172-213) and the index container.
+ * The temp-file round trips of the reference (contigs FASTA + dot graph per gap) are not reproduced.
+ */
+#include "mtg_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <thread>
+#include <unordered_map>
+#include <zlib.h>
+
+using namespace mtg;
+
+namespace mtgi {
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <typename F> static void parallel_for(size_t n, int nthreads, F f)
+{
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = (int)std::max<size_t>(n, 1);
+    if (nthreads == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                size_t b = next.fetch_add(16);
+                if (b >= n) break;
+                size_t e = std::min(n, b + 16);
+                for (size_t i = b; i < e; i++) f(i);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+/* ------------------------------------------------------------------------------------------------ sequence files */
+bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out)
+{
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) return false;
+    gzbuffer(f, 1 << 20);
+    std::string line, pending;
+    std::vector<char> buf(1 << 16);
+    auto getl = [&](std::string& l) -> bool {
+        l.clear();
+        bool got = false;
+        while (gzgets(f, buf.data(), (int)buf.size())) {
+            got = true;
+            size_t n = strlen(buf.data());
+            if (n && buf[n - 1] == '\n') {
+                l.append(buf.data(), n - 1);
+                if (!l.empty() && l.back() == '\r') l.pop_back();
+                return true;
+            }
+            l.append(buf.data(), n);
+        }
+        return got;
+    };
+    bool have = getl(line);
+    while (have) {
+        if (!line.empty() && line[0] == '>') {
+            out.emplace_back(line.substr(1), std::string());
+            while ((have = getl(line)) && (line.empty() || line[0] != '>')) out.back().second += line;
+        } else if (!line.empty() && line[0] == '@') {
+            out.emplace_back(line.substr(1), std::string());
+            if ((have = getl(line))) out.back().second = line;
+            have = getl(line);
+            have = getl(line);
+            have = getl(line);
+        } else {
+            have = getl(line);
+        }
+    }
+    gzclose(f);
+    return true;
+}
+
+/* ------------------------------------------------------------------------------------------------ index from reads */
+static inline bool nt_bad(unsigned char c) { return (c >> 3) & 1; } /* gatb: bit 3 of the ASCII code flags 'N' */
+
+/* gatb's automatic solidity cut-off, restated: smoothed histogram, first minimum, coverage peak,
+ * arg-min between; floor 3 (src/Filler.cpp:201).  One golden datapoint: 7 (test/full_test/gold_fill.output:11). */
+static int auto_cutoff(const std::vector<uint64_t>& h, int floor_thr)
+{
+    const size_t len = h.size();
+    if (len < 5) return floor_thr;
+    std::vector<double> sm(len, 0.0);
+    sm[1] = 0.6 * h[1] + 0.4 * h[2];
+    for (size_t i = 2; i + 1 < len; i++) sm[i] = 0.2 * h[i - 1] + 0.6 * h[i] + 0.2 * h[i + 1];
+    size_t valley = 2;
+    while (valley + 2 < len && !(sm[valley] < sm[valley + 1])) valley++;
+    size_t peak = valley;
+    for (size_t i = valley; i + 1 < len; i++) if (sm[i] > sm[peak]) peak = i;
+    size_t best = valley;
+    for (size_t i = valley; i <= peak; i++) if (sm[i] < sm[best]) best = i;
+    return std::max((int)best, floor_thr);
+}
+
+struct HostIndexData {
+    std::vector<uint64_t> kmers;
+    std::vector<uint32_t> counts;
+};
+static std::unordered_map<const mtg_index*, HostIndexData>& host_copies()
+{
+    static std::unordered_map<const mtg_index*, HostIndexData> m;
+    return m;
+}
+static std::mutex& host_copies_mtx() { static std::mutex m; return m; }
+
+int index_from_reads(const char* paths_csv, int k, int abundance_min, int abundance_max, mtg_index** out)
+{
+    if (!paths_csv || !out || k < 11 || k > 31) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    std::vector<uint64_t> all;
+    const uint64_t mk = kmask(k);
+    std::string csv(paths_csv);
+    size_t pos = 0;
+    while (pos <= csv.size()) {
+        size_t e = csv.find(',', pos);
+        if (e == std::string::npos) e = csv.size();
+        std::string path = csv.substr(pos, e - pos);
+        pos = e + 1;
+        if (path.empty()) continue;
+        std::vector<std::pair<std::string, std::string>> recs;
+        if (!read_sequences(path, recs)) { set_error("cannot read %s", path.c_str()); return MTG_ERR_IO; }
+        for (auto& r : recs) {
+            uint64_t f = 0;
+            int valid = 0;
+            for (unsigned char c : r.second) {
+                if (nt_bad(c)) { valid = 0; f = 0; continue; }
+                f = ((f << 2) | nt_code(c)) & mk;
+                if (++valid >= k) { uint64_t rc = revcomp(f, k); all.push_back(f < rc ? f : rc); }
+            }
+        }
+    }
+    std::sort(all.begin(), all.end());
+    std::vector<uint64_t> histo(10003, 0); /* STR_HISTOGRAM_MAX 10000, src/Filler.cpp:200 */
+    std::vector<uint64_t> uk;
+    std::vector<uint32_t> uc;
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i;
+        while (j < all.size() && all[j] == all[i]) j++;
+        uint32_t c = (uint32_t)(j - i);
+        histo[std::min<uint32_t>(c, 10001)]++;
+        uk.push_back(all[i]);
+        uc.push_back(c);
+        i = j;
+    }
+    int autoc = -1;
+    if (abundance_min < 0) { autoc = auto_cutoff(histo, 3); abundance_min = autoc; }
+    HostIndexData hd;
+    for (size_t i = 0; i < uk.size(); i++)
+        if ((int64_t)uc[i] >= abundance_min && (abundance_max <= 0 || (int64_t)uc[i] <= abundance_max)) { hd.kmers.push_back(uk[i]); hd.counts.push_back(uc[i]); }
+    int rc = index_from_kmers(hd.kmers.data(), hd.counts.data(), hd.kmers.size(), k, out);
+    if (rc) return rc;
+    (*out)->info.abundance_min = abundance_min;
+    (*out)->info.abundance_auto = autoc;
+    std::lock_guard<std::mutex> lk(host_copies_mtx());
+    host_copies()[*out] = std::move(hd);
+    return MTG_OK;
+}
+
+static const char IDX_MAGIC[8] = {'M', 'T', 'G', 'I', 'D', 'X', '1', 0};
+
+int index_save(const mtg_index* idx, const char* path)
+{
+    if (!idx || !path) { set_error("null argument"); return MTG_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(host_copies_mtx());
+    auto it = host_copies().find(idx);
+    if (it == host_copies().end()) { set_error("this index has no host copy of its k-mers and cannot be saved"); return MTG_ERR_ARG; }
+    FILE* f = fopen(path, "wb");
+    if (!f) { set_error("cannot write %s", path); return MTG_ERR_IO; }
+    int32_t hdr[4] = {idx->info.k, idx->info.abundance_min, idx->info.abundance_auto, 0};
+    uint64_t n = it->second.kmers.size();
+    bool ok = fwrite(IDX_MAGIC, 1, 8, f) == 8 && fwrite(hdr, 4, 4, f) == 4 && fwrite(&n, 8, 1, f) == 1 &&
+              fwrite(it->second.kmers.data(), 8, n, f) == n && fwrite(it->second.counts.data(), 4, n, f) == n;
+    fclose(f);
+    if (!ok) { set_error("short write on %s", path); return MTG_ERR_IO; }
+    return MTG_OK;
+}
+
+int index_load(const char* path, mtg_index** out)
+{
+    if (!path || !out) { set_error("null argument"); return MTG_ERR_ARG; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot read %s", path); return MTG_ERR_IO; }
+    char magic[8] = {0};
+    int32_t hdr[4];
+    uint64_t n = 0;
+    if (fread(magic, 1, 8, f) != 8) { fclose(f); set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
+    if (memcmp(magic, "\x89HDF\r\n\x1a\n", 8) == 0) {
+        fclose(f);
+        set_error("%s is an HDF5 file: GATB .h5 graphs are not readable by this library (SURVEY.md 8f-2); build the index with -in", path);
+        return MTG_ERR_FORMAT;
+    }
+    if (memcmp(magic, IDX_MAGIC, 8) != 0 || fread(hdr, 4, 4, f) != 4 || fread(&n, 8, 1, f) != 1) { fclose(f); set_error("%s: not a mtg index", path); return MTG_ERR_FORMAT; }
+    HostIndexData hd;
+    hd.kmers.resize(n);
+    hd.counts.resize(n);
+    bool ok = fread(hd.kmers.data(), 8, n, f) == n && fread(hd.counts.data(), 4, n, f) == n;
+    fclose(f);
+    if (!ok) { set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
+    int rc = index_from_kmers(hd.kmers.data(), hd.counts.data(), n, hdr[0], out);
+    if (rc) return rc;
+    (*out)->info.abundance_min = hdr[1];
+    (*out)->info.abundance_auto = hdr[2];
+    std::lock_guard<std::mutex> lk(host_copies_mtx());
+    host_copies()[*out] = std::move(hd);
+    return MTG_OK;
+}
+
+void index_forget_host_copy(const mtg_index* idx)
+{
+    std::lock_guard<std::mutex> lk(host_copies_mtx());
+    host_copies().erase(idx);
+}
+
+/* ------------------------------------------------------------------------------------------------ gap post-processing */
+struct TermInfo { /* info_node_t, src/Filler.hpp:44-71 */
+    int node, pos, errors, target;
+};
+
+static inline int identNT(char a, char b) { return ((a == b || a - b == 32 || a - b == -32) && a != 'N'); }
+
+static void prepare_target(Target& t, int k)
+{
+    t.usable = (int)t.seq.size() >= k;
+    t.code = 0;
+    t.badmask = 0;
+    if (!t.usable) return;
+    for (int i = 0; i < k; i++) {
+        unsigned char c = (unsigned char)t.seq[i];
+        t.code = (t.code << 2) | nt_code(c);
+        t.badmask <<= 2;
+        unsigned char u = c & 0xDF;
+        if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) t.badmask |= 1;
+    }
+}
+
+/* Filler::find_nodes_containing_multiple_R (src/Filler.cpp:1294-1378): at most one info per contig; best_match is
+ * not reset between positions (:1327); strict improvement (:1341); an exact match ends the contig (:1348-1351). */
+static void find_terminal_nodes(const GapContigs& gc, const std::vector<Target>& targets, int k, int nb_mis, std::vector<TermInfo>& out)
+{
+    const uint64_t mk = kmask(k);
+    const uint64_t lsb = 0x5555555555555555ULL & mk;
+    for (uint32_t c = 0; c < gc.n_contigs; c++) {
+        const uint64_t* w = gc.words.data() + gc.word_start[c];
+        const uint32_t L = gc.len[c];
+        if (L < (uint32_t)k) continue;
+        int best = 0, best_t = -1, position = 0;
+        bool stop = false;
+        uint64_t f = 0;
+        for (uint32_t i = 0; i < L && !stop; i++) {
+            f = ((f << 2) | ((w[i >> 5] >> (2 * (i & 31))) & 3ull)) & mk;
+            if (i + 1 < (uint32_t)k) continue;
+            const uint32_t j = i + 1 - k;
+            for (size_t t = 0; t < targets.size(); t++) {
+                const Target& T = targets[t];
+                if (!T.usable) continue; /* reading past a shorter anchor is undefined in the reference */
+                const uint64_t x = f ^ T.code;
+                const uint64_t mism = ((x | (x >> 1)) & lsb) | T.badmask;
+                const int nbmatch = k - __builtin_popcountll(mism);
+                if (nbmatch > best && nbmatch >= k - nb_mis) {
+                    best = nbmatch; best_t = (int)t; position = (int)j;
+                    if (nbmatch == k) { stop = true; break; }
+                }
+            }
+        }
+        if (best != 0) out.push_back(TermInfo{(int)c, position, k - best, best_t});
+    }
+}
+
+struct ContigGraph {
+    std::vector<std::vector<int>> in_edges; /* ascending, unique (std::set order of src/GraphAnalysis.cpp:110) */
+    ContigGraph(const GapContigs& gc, int k)
+    {
+        const uint32_t n = gc.n_contigs;
+        in_edges.resize(n);
+        const uint64_t mk1 = kmask(k - 1);
+        auto kmer_at = [&](uint32_t c, uint32_t start) {
+            const uint64_t* w = gc.words.data() + gc.word_start[c];
+            uint64_t f = 0;
+            for (int j = 0; j < k - 1; j++) { uint32_t i = start + j; f = (f << 2) | ((w[i >> 5] >> (2 * (i & 31))) & 3ull); }
+            return f & mk1;
+        };
+        std::unordered_map<uint64_t, std::vector<int>> by_prefix;
+        for (uint32_t j = 0; j < n; j++) by_prefix[kmer_at(j, 0)].push_back((int)j);
+        for (uint32_t i = 0; i < n; i++) {
+            auto it = by_prefix.find(kmer_at(i, gc.len[i] - (k - 1)));
+            if (it == by_prefix.end()) continue;
+            for (int j : it->second) {
+                if (j == (int)i && (int)gc.len[i] == k - 1) continue; /* src/IGraphOutput.cpp:160 */
+                in_edges[j].push_back((int)i);
+            }
+        }
+        for (auto& v : in_edges) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+    }
+};
+
+typedef std::vector<int> Path;
+typedef std::set<std::pair<Path, int>> PathSet; /* (path, target index); see order note in process_gap */
+
+struct RevDfs { /* GraphAnalysis::find_all_paths_rev, src/GraphAnalysis.cpp:244-326 */
+    const ContigGraph& g;
+    const std::vector<TermInfo>& terms;
+    int terminal_node, target;
+    int nb_calls = 0;
+    bool success = true;
+    static const size_t max_breadth = 20; /* src/GraphAnalysis.hpp:43 */
+    std::set<Path> run(int start_node, const Path& current)
+    {
+        std::set<Path> paths;
+        if (nb_calls++ > 10000000) { success = false; return paths; }
+        if (start_node != terminal_node)
+            for (auto& t : terms) if (t.node == start_node) return paths;
+        if (start_node == 0) { paths.insert(current); return paths; }
+        for (int next : g.in_edges[start_node]) {
+            if (std::find(current.begin(), current.end(), next) == current.end()) {
+                Path ext;
+                ext.reserve(current.size() + 1);
+                ext.push_back(next);
+                ext.insert(ext.end(), current.begin(), current.end());
+                std::set<Path> sub = run(next, ext);
+                paths.insert(sub.begin(), sub.end());
+                if (paths.size() >= max_breadth) success = false;
+            }
+            if (!success) return paths;
+        }
+        return paths;
+    }
+};
+
+/* identity of src/Utils.cpp:87-189 with two DP rows: the traceback's choice at (i,j) depends only on scores known
+ * when (i,j) is filled, so the match count along the traceback is carried forward (scores are exact multiples of 5) */
+static float nw_identity(const std::string& a, const std::string& b)
+{
+    const int na = (int)a.size(), nb = (int)b.size();
+    std::vector<int32_t> sp(nb + 1), sc(nb + 1), mp(nb + 1, 0), mc(nb + 1, 0);
+    for (int j = 0; j <= nb; j++) sp[j] = -5 * j;
+    for (int i = 1; i <= na; i++) {
+        sc[0] = -5 * i; mc[0] = 0;
+        const char ai = a[i - 1];
+        for (int j = 1; j <= nb; j++) {
+            const bool eq = ai == b[j - 1];
+            const int diag = sp[j - 1] + (eq ? 10 : -5), del = sp[j] - 5, ins = sc[j - 1] - 5;
+            const int best = std::max(std::max(diag, del), ins);
+            sc[j] = best;
+            mc[j] = best == diag ? mp[j - 1] + (eq ? 1 : 0) : (best == del ? mp[j] : mc[j - 1]);
+        }
+        sp.swap(sc); mp.swap(mc);
+    }
+    float identity = (float)mp[nb];
+    identity /= std::max(na, nb);
+    return identity;
+}
+
+/* everything after stage A for one gapFillFromSource call, except the coverage numbers */
+static void process_gap(const GapContigs& gc, GapWork& W, int k, int nb_mis_allowed)
+{
+    W.nb_nodes = (int)gc.n_contigs;
+    W.total_nt = (int)gc.total_nt;
+    const int nb_mis = W.anchor_repeated ? 0 : nb_mis_allowed; /* src/Filler.cpp:859-863 */
+    std::vector<TermInfo> terms;
+    find_terminal_nodes(gc, W.targets, k, nb_mis, terms);
+    W.nb_terminal = (int)terms.size();
+    if (terms.empty()) { /* get_first_contig, src/Filler.cpp:1381-1407 */
+        W.extension.clear();
+        if (gc.n_contigs > 0 && (int)gc.len[0] > k) W.extension = gc.contig(0).substr(k);
+        return;
+    }
+    ContigGraph graph(gc, k);
+    /* find_all_paths_rev wrapper, src/GraphAnalysis.cpp:205-237.  The reference keeps set<pair<path, bkpt_t>>; paths
+     * reaching different targets end in different nodes, so ordering by (path, target index) gives the same sequence. */
+    std::vector<std::pair<Path, int>> paths;
+    if (terms[0].node == 0) {
+        paths.push_back({Path{0}, terms[0].target});
+    } else {
+        PathSet all;
+        for (auto& t : terms) {
+            RevDfs dfs{graph, terms, t.node, t.target};
+            std::set<Path> ps = dfs.run(t.node, Path{t.node});
+            for (auto& p : ps) all.insert({p, t.target});
+        }
+        paths.assign(all.begin(), all.end());
+    }
+    /* group by target name: unordered_map<string, set<path>> iterated in libstdc++ order (src/Filler.cpp:924-936) */
+    std::unordered_map<std::string, std::set<Path>> paths_to_compare;
+    for (auto& pr : paths) {
+        std::string key = W.targets[pr.second].name;
+        if (W.targets[pr.second].is_rc) key += "_Rc";
+        paths_to_compare[key].insert(pr.first);
+    }
+    std::vector<std::string> node_seq(gc.n_contigs);
+    std::vector<char> have(gc.n_contigs, 0);
+    auto node = [&](int i) -> const std::string& { if (!have[i]) { node_seq[i] = gc.contig(i); have[i] = 1; } return node_seq[i]; };
+    const size_t K = (size_t)k;
+    for (auto it = paths_to_compare.begin(); it != paths_to_compare.end(); ++it) {
+        /* paths_to_sequences, src/GraphAnalysis.cpp:331-460 */
+        std::vector<Solution> tmp;
+        int errs = 0, tgt = -1;
+        for (const Path& p : it->second) {
+            std::string sequence;
+            for (size_t ip = 0; ip < p.size(); ip++) {
+                const std::string& ns = node(p[ip]);
+                if (ip + 1 == p.size()) {
+                    int pos_anchor = 0;
+                    for (auto& t : terms) if (t.node == p[ip]) { pos_anchor = t.pos; errs = t.errors; tgt = t.target; break; }
+                    if ((size_t)pos_anchor <= K - 1) {
+                        sequence = sequence.substr(0, sequence.length() - ((K - 1) - (size_t)pos_anchor)); /* size_t wrap-around as in :406 */
+                    } else {
+                        const size_t from = ip != 0 ? K - 1 : K;
+                        sequence.append(ns, from, (size_t)pos_anchor - from);
+                    }
+                    break;
+                }
+                sequence.append(ns, ip != 0 ? K - 1 : K, std::string::npos);
+            }
+            if (!sequence.empty()) { Solution s; s.seq = std::move(sequence); s.nb_errors = errs; s.target = tgt; tmp.push_back(std::move(s)); }
+        }
+        W.nb_total_filled += (int)tmp.size();
+        if (tmp.size() > 1) { /* remove_almost_identical_solutions(.., 90), src/Utils.cpp:208-238 */
+            std::vector<Solution> fin;
+            fin.push_back(tmp[0]);
+            for (auto& a : tmp) {
+                bool similar = false;
+                for (auto& b : fin) {
+                    if (a.seq == b.seq || nw_identity(a.seq, b.seq) * 100 >= 90) {
+                        if (a.nb_errors < b.nb_errors) { b.seq = a.seq; b.nb_errors = a.nb_errors; }
+                        similar = true;
+                        break;
+                    }
+                }
+                if (!similar) fin.push_back(a);
+            }
+            tmp.swap(fin);
+        }
+        int rank = 1;
+        for (auto& s : tmp) { s.count = (int)tmp.size(); s.rank = rank++; W.sols.push_back(std::move(s)); }
+    }
+    W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
+}
+
+static std::string revcomp_str(const std::string& s) /* revcomp_sequence, src/Utils.cpp:44-77: other characters are dropped */
+{
+    std::string r;
+    r.reserve(s.size());
+    for (auto it = s.rbegin(); it != s.rend(); ++it) {
+        switch (*it) {
+            case 'a': r += 't'; break; case 't': r += 'a'; break; case 'c': r += 'g'; break; case 'g': r += 'c'; break;
+            case 'A': r += 'T'; break; case 'T': r += 'A'; break; case 'C': r += 'G'; break; case 'G': r += 'C'; break;
+        }
+    }
+    return r;
+}
+
+static double median_of(std::vector<unsigned int>& v) /* src/Utils.cpp:241-254 */
+{
+    size_t n = v.size() / 2;
+    std::nth_element(v.begin(), v.begin() + n, v.end());
+    unsigned int vn = v[n];
+    if (v.size() % 2 == 1) return vn;
+    std::nth_element(v.begin(), v.begin() + n - 1, v.end());
+    return 0.5 * (vn + v[n - 1]);
+}
+
+static int compute_qual(const Solution& s, bool repeated) /* src/Utils.hpp:85-103 */
+{
+    int q = 50;
+    if (repeated) q = 25;
+    if (s.count > 1) q = 15;
+    if (s.nb_errors == 1) q = 10;
+    if (s.nb_errors == 2) q = 5;
+    return q;
+}
+
+/* runs a batch of gapFillFromSource calls */
+int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, mtg_batch_stats* stats_out)
+{
+    const int k = idx->dev.k;
+    const size_t n = gaps.size();
+    const double t_begin = now_ms();
+    StageAInput in;
+    for (size_t i = 0; i < n; i++) {
+        if ((int)gaps[i].source.size() < k) { set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
+        in.add(gaps[i].source.c_str(), swf_targets[i].c_str(), k);
+    }
+    std::vector<GapContigs> contigs;
+    mtg_batch_stats st{};
+    int rc = stage_a_run(idx, p, in, contigs, &st);
+    if (rc) return rc;
+    double t0 = now_ms();
+    for (auto& g : gaps) for (auto& t : g.targets) prepare_target(t, k);
+    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(contigs[i], gaps[i], k, p->nb_mis_allowed); });
+    /* coverage: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
+    std::vector<uint64_t> q;
+    const uint64_t mk = kmask(k);
+    for (auto& g : gaps)
+        for (auto& s : g.sols) {
+            s.ab_off = q.size();
+            uint64_t f = 0;
+            int valid = 0;
+            auto feed = [&](const std::string& str) {
+                for (unsigned char c : str) {
+                    if (nt_bad(c)) { valid = 0; f = 0; continue; }
+                    f = ((f << 2) | nt_code(c)) & mk;
+                    if (++valid >= k) q.push_back(f);
+                }
+            };
+            feed(g.source);
+            feed(s.seq);
+            s.ab_n = q.size() - s.ab_off;
+        }
+    st.host_ms += now_ms() - t0;
+    std::vector<uint32_t> ab(q.size());
+    if (!q.empty()) {
+        rc = query_run(idx, q.data(), q.size(), ab.data(), nullptr, nullptr);
+        if (rc) return rc;
+    }
+    t0 = now_ms();
+    parallel_for(n, p->nb_host_threads, [&](size_t i) {
+        GapWork& g = gaps[i];
+        for (auto& s : g.sols) {
+            std::vector<unsigned int> v(ab.begin() + s.ab_off, ab.begin() + s.ab_off + s.ab_n);
+            uint64_t sum = 0;
+            for (size_t j = 0; j < v.size(); j++) {
+                if (v[j] == 0) fprintf(stderr, "WARNING Unknown kmer : %s\n", [&] { std::string d; uint64_t c = q[s.ab_off + j]; uint64_t r = revcomp(c, k); c = c < r ? c : r; std::vector<uint64_t> w(2, 0); for (int t = 0; t < k; t++) w[t >> 5] |= ((c >> (2 * (k - 1 - t))) & 3ull) << (2 * (t & 31)); unpack_seq(w.data(), (uint32_t)k, d); return d; }().c_str());
+                sum += v[j];
+            }
+            s.avg = sum / (float)v.size();
+            s.median = v.empty() ? 0.f : (float)median_of(v);
+            s.qual = compute_qual(s, g.anchor_repeated);
+            if (g.reverse) s.seq = revcomp_str(s.seq);
+        }
+    });
+    st.host_ms += now_ms() - t0;
+    st.total_ms = now_ms() - t_begin;
+    if (stats_out) *stats_out = st;
+    stats_store(st);
+    return MTG_OK;
+}
+
+} // namespace mtgi
+
+/* ------------------------------------------------------------------------------------------------ C ABI (host side) */
+struct mtg_results {
+    std::vector<mtgi::GapWork> gaps;
+    std::vector<std::vector<mtg_filled>> filled;
+    std::vector<mtg_gap_result> res;
+};
+struct mtg_contigs {
+    std::vector<std::vector<std::string>> c;
+};
+
+
+extern "C" {
+
+void mtg_default_params(mtg_params* p)
+{
+    p->max_nodes = 100;
+    p->max_depth = 10000;
+    p->nb_mis_allowed = 2;
+    p->end_rule_nonbranching = 0;
+    p->nb_host_threads = 0;
+}
+
+int mtg_index_create_from_reads(const char* paths_csv, int k, int abundance_min, int abundance_max, mtg_index** out)
+{
+    return mtgi::index_from_reads(paths_csv, k, abundance_min, abundance_max, out);
+}
+int mtg_index_save(const mtg_index* idx, const char* path) { return mtgi::index_save(idx, path); }
+int mtg_index_load(const char* path, mtg_index** out) { return mtgi::index_load(path, out); }
+
+int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out)
+{
+    if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    mtg_results* R = new mtg_results();
+    R->gaps.resize(n);
+    std::vector<std::string> swf(n);
+    for (size_t i = 0; i < n; i++) {
+        const mtg_gap& g = gaps[i];
+        if (!g.source || !g.target || (g.n_targets && (!g.target_seqs || !g.target_names))) { delete R; mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
+        mtgi::GapWork& w = R->gaps[i];
+        w.source = g.source;
+        swf[i] = g.target;
+        w.anchor_repeated = g.is_anchor_repeated != 0;
+        w.reverse = g.reverse != 0;
+        for (int t = 0; t < g.n_targets; t++) {
+            mtgi::Target T;
+            T.seq = g.target_seqs[t];
+            T.name = g.target_names[t];
+            T.is_rc = g.target_is_rc ? g.target_is_rc[t] != 0 : false;
+            w.targets.push_back(std::move(T));
+        }
+    }
+    int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, nullptr);
+    if (rc) { delete R; return rc; }
+    R->filled.resize(n);
+    R->res.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        mtgi::GapWork& w = R->gaps[i];
+        for (auto& s : w.sols) {
+            mtg_filled f;
+            f.seq = s.seq.c_str();
+            f.nb_errors_in_anchor = s.nb_errors;
+            f.target_index = s.target;
+            f.avg_coverage = s.avg;
+            f.median_coverage = s.median;
+            f.qual = s.qual;
+            f.solution_count = s.count;
+            f.solution_rank = s.rank;
+            R->filled[i].push_back(f);
+        }
+        mtg_gap_result& r = R->res[i];
+        r.nb_nodes = w.nb_nodes; r.total_nt = w.total_nt; r.nb_terminal = w.nb_terminal;
+        r.has_solution_counts = w.has_counts; r.nb_total_filled = w.nb_total_filled; r.nb_reported = (int)w.sols.size();
+        r.n_filled = (int)R->filled[i].size();
+        r.filled = R->filled[i].data();
+        r.extension = w.extension.c_str();
+    }
+    *out = R;
+    return MTG_OK;
+}
+const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->res.size()) ? &r->res[i] : nullptr; }
+void mtg_results_free(mtg_results* r) { delete r; }
+
+int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n, mtg_contigs** out)
+{
+    if (!idx || !p || !out || (n && (!sources || !targets))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    mtgi::StageAInput in;
+    for (size_t i = 0; i < n; i++) {
+        if ((int)strlen(sources[i]) < idx->dev.k) { mtgi::set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
+        in.add(sources[i], targets[i], idx->dev.k);
+    }
+    std::vector<mtgi::GapContigs> gc;
+    mtg_batch_stats st{};
+    int rc = mtgi::stage_a_run(idx, p, in, gc, &st);
+    if (rc) return rc;
+    mtgi::stats_store(st);
+    mtg_contigs* C = new mtg_contigs();
+    C->c.resize(n);
+    for (size_t i = 0; i < n; i++)
+        for (uint32_t j = 0; j < gc[i].n_contigs; j++) C->c[i].push_back(gc[i].contig(j));
+    *out = C;
+    return MTG_OK;
+}
+size_t mtg_contigs_count(const mtg_contigs* c, size_t gap) { return (c && gap < c->c.size()) ? c->c[gap].size() : 0; }
+const char* mtg_contigs_get(const mtg_contigs* c, size_t gap, size_t i) { return (c && gap < c->c.size() && i < c->c[gap].size()) ? c->c[gap][i].c_str() : nullptr; }
+void mtg_contigs_free(mtg_contigs* c) { delete c; }
+}

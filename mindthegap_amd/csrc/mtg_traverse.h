@@ -1,0 +1,640 @@
+/*
+ * mtg_traverse.h -- stage A of Filler::gapFillFromSource on the device: the breadth-first contig
+ * construction that the reference delegates to gatb-core
+ *   IterativeExtensions<span>::construct_linear_seqs   (call site /root/reference/src/Filler.cpp:884,
+ *                                                        ctor args src/Filler.cpp:867)
+ *   MonumentTraversal (TRAVERSAL_CONTIG) + Frontline + BranchingTerminator (src/Filler.cpp:866)
+ * restated from SURVEY.md Appendix A.3-A.6.  One gap is processed by one lane; every lane owns a
+ * private scratch block in HBM (layout: struct GapScratch).  The hot loop (simple-path walking) costs
+ * one 64-byte ADJ line per nucleotide; the bubble / tip logic lives in noinline functions.
+ *
+ * Compiled for gfx950 by hipcc, and TEST-ONLY by g++ for tests/emu (see mtg_dev.h).
+ */
+#ifndef MTG_TRAVERSE_H
+#define MTG_TRAVERSE_H
+#include "mtg_dev.h"
+
+namespace mtg {
+
+enum GapStatus {
+    GAP_OK = 0,
+    GAP_OVF_CONTIG = 1,  /* contig arena full            */
+    GAP_OVF_MARKED = 2,  /* marked-node set full          */
+    GAP_OVF_SEEN = 3,    /* frontline visited set full    */
+    GAP_OVF_INVOLVED = 4,
+    GAP_OVF_QUEUE = 5,
+    GAP_OVF_DFS = 6
+};
+
+/* uniform launch configuration */
+struct FillCfg {
+    int k;
+    int max_nodes;       /* -max-nodes,  src/Filler.cpp:101 */
+    int max_depth;       /* -max-length, src/Filler.cpp:100 */
+    int mono_max_depth;  /* gatb MonumentTraversal max_depth   = 500 [MEM] */
+    int mono_max_breadth;/* gatb MonumentTraversal max_breadth = 20  [MEM] */
+    int end_rule_nonbranching;
+    /* scratch capacities (per gap) */
+    uint32_t cap_words;   /* contig arena, 32 nt per word */
+    uint32_t cap_contigs; /* max_nodes + 1 */
+    uint32_t qcap;        /* 4 * cap_contigs + 2 */
+    uint32_t mcap;        /* marked set slots, power of two */
+    uint32_t seen_cap;    /* frontline visited set slots, power of two */
+    uint32_t inv_cap;     /* involved list */
+    uint32_t iseen_cap;   /* nested frontline visited set, power of two */
+    uint64_t zero_stride; /* bytes per gap in the zero-initialised region */
+    uint64_t raw_stride;  /* bytes per gap in the raw region */
+    /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
+    uint32_t z_seen, z_iseen;
+    uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_dfsf, o_dfsc,
+        o_dfsmask, o_dfsnt, o_cons, o_conslen, o_nw;
+};
+
+enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
+
+/* per-gap scratch: two base pointers; the arrays sit at uniform offsets (FillCfg::o_*) */
+struct GapScratch {
+    uint8_t* z; /* zero-initialised before the launch: marked | seen | iseen (canonical k-mer + 1, open addressing) */
+    uint8_t* r; /* raw */
+};
+#define MTG_ARR(T, name, base, off) \
+    MTG_DEV T* name(const FillCfg& c, const GapScratch& S) { return reinterpret_cast<T*>(S.base + (off)); }
+MTG_ARR(uint64_t, s_marked, z, 0)
+MTG_ARR(uint64_t, s_seen, z, c.z_seen)
+MTG_ARR(uint64_t, s_iseen, z, c.z_iseen)
+MTG_ARR(uint64_t, s_words, r, 0)             /* contig arena */
+MTG_ARR(uint32_t, s_cstart, r, c.o_cstart)   /* first word of contig i */
+MTG_ARR(uint32_t, s_clen, r, c.o_clen)       /* length in nt */
+MTG_ARR(uint64_t, s_qf, r, c.o_qf)           /* BFS queue: oriented k-mer */
+MTG_ARR(uint64_t, s_qc, r, c.o_qc)           /*   canonical k-mer (doubles as already_extended_from) */
+MTG_ARR(int32_t, s_qd, r, c.o_qd)
+MTG_ARR(uint32_t, s_seenlog, r, c.o_seenlog) /* slots touched in seen[] */
+MTG_ARR(uint32_t, s_iseenlog, r, c.o_iseenlog)
+MTG_ARR(uint64_t, s_inv, r, c.o_inv)
+MTG_ARR(uint64_t, s_fl0, r, c.o_fl0)         /* frontline double buffer */
+MTG_ARR(uint64_t, s_fl1, r, c.o_fl1)
+MTG_ARR(uint64_t, s_ifl0, r, c.o_ifl0)       /* nested frontline */
+MTG_ARR(uint64_t, s_ifl1, r, c.o_ifl1)
+MTG_ARR(uint8_t, s_flnt0, r, c.o_flnt0)
+MTG_ARR(uint8_t, s_flnt1, r, c.o_flnt1)
+MTG_ARR(uint64_t, s_dfsf, r, c.o_dfsf)       /* consensus enumeration stack */
+MTG_ARR(uint64_t, s_dfsc, r, c.o_dfsc)
+MTG_ARR(uint8_t, s_dfsmask, r, c.o_dfsmask)
+MTG_ARR(uint8_t, s_dfsnt, r, c.o_dfsnt)
+MTG_ARR(uint8_t, s_cons, r, c.o_cons)        /* CONS_CAP x CONS_LEN nts */
+MTG_ARR(uint16_t, s_conslen, r, c.o_conslen)
+MTG_ARR(int32_t, s_nw, r, c.o_nw)            /* 4 rows x (CONS_LEN+1) */
+
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+/* host side: derive strides and offsets from the capacities */
+inline void finalize_cfg(FillCfg& c)
+{
+    c.z_seen = 8u * c.mcap;
+    c.z_iseen = c.z_seen + 8u * c.seen_cap;
+    c.zero_stride = align_up((uint64_t)c.z_iseen + 8ull * c.iseen_cap, 64);
+    uint64_t b = 8ull * c.cap_words;
+    c.o_cstart = (uint32_t)b; b += 4ull * c.cap_contigs;
+    c.o_clen = (uint32_t)b; b += 4ull * c.cap_contigs;
+    b = align_up(b, 8);
+    c.o_qf = (uint32_t)b; b += 8ull * c.qcap;
+    c.o_qc = (uint32_t)b; b += 8ull * c.qcap;
+    c.o_qd = (uint32_t)b; b += 4ull * c.qcap;
+    b = align_up(b, 8);
+    c.o_seenlog = (uint32_t)b; b += 4ull * c.seen_cap;
+    c.o_iseenlog = (uint32_t)b; b += 4ull * c.iseen_cap;
+    b = align_up(b, 8);
+    c.o_inv = (uint32_t)b; b += 8ull * c.inv_cap;
+    c.o_fl0 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_fl1 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_ifl0 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_ifl1 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_flnt0 = (uint32_t)b; b += FL_CAP;
+    c.o_flnt1 = (uint32_t)b; b += FL_CAP;
+    b = align_up(b, 8);
+    c.o_dfsf = (uint32_t)b; b += 8ull * DFS_CAP;
+    c.o_dfsc = (uint32_t)b; b += 8ull * DFS_CAP;
+    c.o_dfsmask = (uint32_t)b; b += DFS_CAP;
+    c.o_dfsnt = (uint32_t)b; b += DFS_CAP;
+    c.o_cons = (uint32_t)b; b += (uint64_t)CONS_CAP * CONS_LEN;
+    c.o_conslen = (uint32_t)b; b += 2ull * CONS_CAP;
+    b = align_up(b, 8);
+    c.o_nw = (uint32_t)b; b += 4ull * 4 * (CONS_LEN + 1);
+    c.raw_stride = align_up(b, 64);
+}
+
+MTG_DEV GapScratch carve(const FillCfg& c, uint8_t* zero_base, uint8_t* raw_base, uint64_t gap)
+{
+    GapScratch S;
+    S.z = zero_base + gap * c.zero_stride;
+    S.r = raw_base + gap * c.raw_stride;
+    return S;
+}
+
+/* ---- small open-addressing sets of canonical k-mers (stored +1, 0 = empty) ---------------- */
+MTG_DEV uint32_t set_hash(uint64_t c, uint32_t cap) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 32) & (cap - 1); }
+MTG_DEV bool set_has(const uint64_t* tab, uint32_t cap, uint64_t c)
+{
+    uint32_t h = set_hash(c, cap);
+    for (;;) {
+        uint64_t v = tab[h];
+        if (v == 0) return false;
+        if (v == c + 1) return true;
+        h = (h + 1) & (cap - 1);
+    }
+}
+/* returns the slot used (>=0), -1 if already present, -2 if full (never fills past cap-1) */
+MTG_DEV int set_add(uint64_t* tab, uint32_t cap, uint32_t& count, uint64_t c)
+{
+    uint32_t h = set_hash(c, cap);
+    for (;;) {
+        uint64_t v = tab[h];
+        if (v == c + 1) return -1;
+        if (v == 0) {
+            if (count + 1 >= cap) return -2;
+            tab[h] = c + 1;
+            count++;
+            return (int)h;
+        }
+        h = (h + 1) & (cap - 1);
+    }
+}
+
+/* ---- per-gap walker state ------------------------------------------------------------------ */
+struct Worker {
+    const Index& ix;
+    const FillCfg& cfg;
+    GapScratch S;
+    int k;
+    uint64_t mk, mk1;
+    uint32_t lines;      /* 64-byte index lines read */
+    uint32_t status;
+    uint32_t n_marked, n_seen, n_iseen, n_inv;
+    /* contig writer */
+    uint64_t acc;
+    uint32_t nacc, wpos;
+
+    MTG_DEV Worker(const Index& i, const FillCfg& c, const GapScratch& s)
+        : ix(i), cfg(c), S(s), k(i.k), mk(kmask(i.k)), mk1(kmask(i.k - 1)), lines(0), status(GAP_OK), n_marked(0), n_seen(0), n_iseen(0),
+          n_inv(0), acc(0), nacc(0), wpos(0)
+    {
+    }
+
+    MTG_DEV void push_nt(uint32_t nt)
+    {
+        acc |= (uint64_t)nt << (2 * nacc);
+        if (++nacc == 32) flush();
+    }
+    MTG_DEV void flush()
+    {
+        if (nacc == 0) return;
+        if (wpos >= cfg.cap_words) { status = GAP_OVF_CONTIG; }
+        else s_words(cfg, S)[wpos] = acc;
+        wpos++;
+        acc = 0;
+        nacc = 0;
+    }
+    MTG_DEV void mark_canon(uint64_t c)
+    {
+        if (set_add(s_marked(cfg, S), cfg.mcap, n_marked, c) == -2) status = GAP_OVF_MARKED;
+    }
+    MTG_DEV bool is_marked(uint64_t c) const { return set_has(s_marked(cfg, S), cfg.mcap, c); }
+    MTG_DEV bool is_branching(const Kmer& x)
+    {
+        Adj l = adj_left(ix, x, mk1, lines);
+        if (popc4(l.in) != 1) return true;
+        Adj r = adj_right(ix, x, mk1, lines);
+        return popc4(r.out) != 1;
+    }
+    MTG_DEV void mark(const Kmer& x) { if (is_branching(x)) mark_canon(canon(x)); }
+
+    /* frontline visited sets with undo logs */
+    MTG_DEV bool seen_add(uint64_t c)
+    {
+        int s = set_add(s_seen(cfg, S), cfg.seen_cap, n_seen, c);
+        if (s == -2) { status = GAP_OVF_SEEN; return false; }
+        if (s >= 0) s_seenlog(cfg, S)[n_seen - 1] = (uint32_t)s;
+        return s >= 0;
+    }
+    MTG_DEV void seen_clear() { for (uint32_t i = 0; i < n_seen; i++) s_seen(cfg, S)[s_seenlog(cfg, S)[i]] = 0; n_seen = 0; }
+    MTG_DEV bool iseen_add(uint64_t c)
+    {
+        int s = set_add(s_iseen(cfg, S), cfg.iseen_cap, n_iseen, c);
+        if (s == -2) { status = GAP_OVF_SEEN; return false; }
+        if (s >= 0) s_iseenlog(cfg, S)[n_iseen - 1] = (uint32_t)s;
+        return s >= 0;
+    }
+    MTG_DEV void iseen_clear() { for (uint32_t i = 0; i < n_iseen; i++) s_iseen(cfg, S)[s_iseenlog(cfg, S)[i]] = 0; n_iseen = 0; }
+    MTG_DEV void involve(uint64_t c)
+    {
+        if (n_inv >= cfg.inv_cap) { status = GAP_OVF_INVOLVED; return; }
+        s_inv(cfg, S)[n_inv++] = c;
+    }
+};
+
+/* [MEM] gatb FrontlineBranching::check: look for large in-branching at m.
+ * dir: 0 = frontline moves along successors.  Only used with dir 0 on this path. */
+MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
+{
+    const int k = W.k;
+    Kmer m = make_kmer(mf, k);
+    Adj l = adj_left(W.ix, m, W.mk1, W.lines);
+    for (uint32_t nt = 0; nt < 4; nt++) {
+        if (!(l.in & (1u << nt))) continue;
+        Kmer b = kmer_prev(m, nt, k, W.mk);
+        if (set_has(s_seen(W.cfg, W.S), W.cfg.seen_cap, canon(b))) continue;
+        /* plain frontline from b along predecessors, previous node = m */
+        W.iseen_add(canon(b));
+        W.iseen_add(canon(m));
+        int cur = 0, ncur = 1, depth = 0, remaining = 0;
+        s_ifl0(W.cfg, W.S)[0] = b.f;
+        for (;;) {
+            /* go_next_depth */
+            bool cont = true;
+            int nnext = 0;
+            uint64_t* cf = cur ? s_ifl1(W.cfg, W.S) : s_ifl0(W.cfg, W.S);
+            uint64_t* nf = cur ? s_ifl0(W.cfg, W.S) : s_ifl1(W.cfg, W.S);
+            for (int i = 0; i < ncur && cont; i++) {
+                Kmer x = make_kmer(cf[i], k);
+                Adj xl = adj_left(W.ix, x, W.mk1, W.lines);
+                for (uint32_t n2 = 0; n2 < 4; n2++) {
+                    if (!(xl.in & (1u << n2))) continue;
+                    Kmer y = kmer_prev(x, n2, k, W.mk);
+                    uint64_t cy = canon(y);
+                    if (set_has(s_iseen(W.cfg, W.S), W.cfg.iseen_cap, cy)) continue;
+                    if (W.is_marked(cy)) { cont = false; remaining = ncur - i - 1; break; }
+                    if (nnext < FL_CAP) nf[nnext] = y.f;
+                    nnext++;
+                    W.iseen_add(cy);
+                    W.involve(cy);
+                }
+            }
+            if (!cont) break;
+            cur ^= 1; ncur = nnext; remaining = ncur; depth++;
+            if (depth > 3 * k) break;
+            if (ncur > 10) break;
+            if (ncur == 0) break;
+            if (W.status) break;
+        }
+        W.iseen_clear();
+        if (remaining > 0) return false;
+        if (W.status) return false;
+    }
+    return true;
+}
+
+/* [MEM] MonumentTraversal::find_end_of_branching.  Returns depth (0 = failure). */
+MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_t prev_c, uint64_t& end_f)
+{
+    const int k = W.k;
+    W.seen_add(canon(start));
+    W.seen_add(prev_c);
+    int cur = 0, ncur = 1, depth = 0;
+    s_fl0(W.cfg, W.S)[0] = start.f;
+    s_flnt0(W.cfg, W.S)[0] = 255;
+    for (;;) {
+        uint64_t* cf = cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S);
+        uint8_t* cn = cur ? s_flnt1(W.cfg, W.S) : s_flnt0(W.cfg, W.S);
+        uint64_t* nf = cur ? s_fl0(W.cfg, W.S) : s_fl1(W.cfg, W.S);
+        uint8_t* nn = cur ? s_flnt0(W.cfg, W.S) : s_flnt1(W.cfg, W.S);
+        int nnext = 0;
+        for (int i = 0; i < ncur; i++) {
+            if (depth > 0 && !fl_check(W, cf[i])) return 0;
+            Kmer x = make_kmer(cf[i], k);
+            Adj a = adj_right(W.ix, x, W.mk1, W.lines);
+            for (uint32_t nt = 0; nt < 4; nt++) {
+                if (!(a.out & (1u << nt))) continue;
+                Kmer y = kmer_next(x, nt, k, W.mk);
+                uint64_t cy = canon(y);
+                if (set_has(s_seen(W.cfg, W.S), W.cfg.seen_cap, cy)) continue;
+                if (W.is_marked(cy)) return 0; /* bubble touches an assembled region */
+                if (nnext < FL_CAP) { nf[nnext] = y.f; nn[nnext] = (cn[i] == 255) ? (uint8_t)nt : cn[i]; }
+                nnext++;
+                W.seen_add(cy);
+                W.involve(cy);
+            }
+            if (W.status) return 0;
+        }
+        cur ^= 1; ncur = nnext; depth++;
+        if (depth > W.cfg.mono_max_depth) return 0;
+        if (ncur > W.cfg.mono_max_breadth) return 0;
+        if (ncur == 0) return 0;
+        if (ncur == 1) {
+            if (!W.cfg.end_rule_nonbranching) break;
+            Kmer e = make_kmer((cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S))[0], k);
+            if (!W.is_branching(e)) break;
+        }
+    }
+    end_f = (cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S))[0];
+    return depth;
+}
+
+/* [MEM] MonumentTraversal::all_consensuses_between, explicit stack.
+ * Consensuses come out in lexicographic (A,C,T,G) order, which is std::set<Path> order. */
+MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint64_t end_c, int traversal_depth, int& ncons)
+{
+    const int k = W.k;
+    uint64_t* dfs_f = s_dfsf(W.cfg, W.S);
+    uint64_t* dfs_c = s_dfsc(W.cfg, W.S);
+    uint8_t* dfs_mask = s_dfsmask(W.cfg, W.S);
+    uint8_t* dfs_nt = s_dfsnt(W.cfg, W.S);
+    uint8_t* cons = s_cons(W.cfg, W.S);
+    uint16_t* cons_len = s_conslen(W.cfg, W.S);
+    ncons = 0;
+    int d = 0; /* current frame */
+    dfs_f[0] = start.f;
+    dfs_c[0] = canon(start);
+    /* enter frame 0 */
+    bool entering = true;
+    for (;;) {
+        if (entering) {
+            entering = false;
+            int depth_left = traversal_depth - d;
+            if (depth_left < -1) return false;
+            if (dfs_c[d] == end_c) {
+                if (ncons >= CONS_CAP || d > CONS_LEN) { W.status = GAP_OVF_DFS; return false; }
+                for (int i = 0; i < d; i++) cons[(size_t)ncons * CONS_LEN + i] = dfs_nt[i];
+                cons_len[ncons] = (uint16_t)d;
+                ncons++;
+                dfs_mask[d] = 0; /* return */
+            } else {
+                Kmer x = make_kmer(dfs_f[d], k);
+                dfs_mask[d] = (uint8_t)adj_right(W.ix, x, W.mk1, W.lines).out;
+            }
+        }
+        uint32_t mask = dfs_mask[d];
+        if (mask == 0) {
+            /* return to the parent; the parent re-checks the breadth limit after each child */
+            if (d == 0) return true;
+            d--;
+            if (ncons > W.cfg.mono_max_breadth) return false;
+            continue;
+        }
+        uint32_t nt = (uint32_t)ctz4(mask);
+        dfs_mask[d] = (uint8_t)(mask & (mask - 1));
+        Kmer x = make_kmer(dfs_f[d], k);
+        Kmer y = kmer_next(x, nt, k, W.mk);
+        uint64_t cy = canon(y);
+        for (int i = 0; i <= d; i++) if (dfs_c[i] == cy) return false; /* loop inside the bubble */
+        if (d + 1 >= DFS_CAP) { W.status = GAP_OVF_DFS; return false; }
+        dfs_nt[d] = (uint8_t)nt;
+        d++;
+        dfs_f[d] = y.f;
+        dfs_c[d] = cy;
+        entering = true;
+    }
+}
+
+/* identity of src/Utils.cpp:87-189 (same routine in gatb's Traversal [MEM]) without the full matrix:
+ * the traceback's choice at (i,j) only depends on scores already known when (i,j) is filled, so the
+ * number of matches on the traceback path is carried forward.  Scores are multiples of 5 (exact). */
+MTG_DEV_NOINLINE int nw_matches(Worker& W, const uint8_t* a, int na, const uint8_t* b, int nb)
+{
+    int32_t* sp = s_nw(W.cfg, W.S);                      /* previous row scores */
+    int32_t* sc = sp + (CONS_LEN + 1);         /* current row scores  */
+    int32_t* mp = sc + (CONS_LEN + 1);         /* previous row match counts */
+    int32_t* mc = mp + (CONS_LEN + 1);
+    for (int j = 0; j <= nb; j++) { sp[j] = -5 * j; mp[j] = 0; }
+    for (int i = 1; i <= na; i++) {
+        sc[0] = -5 * i; mc[0] = 0;
+        for (int j = 1; j <= nb; j++) {
+            int sub = (a[i - 1] == b[j - 1]) ? 10 : -5;
+            int diag = sp[j - 1] + sub, del = sp[j] - 5, ins = sc[j - 1] - 5;
+            int best = diag > del ? diag : del;
+            best = best > ins ? best : ins;
+            sc[j] = best;
+            if (best == diag) mc[j] = mp[j - 1] + (a[i - 1] == b[j - 1] ? 1 : 0);
+            else if (best == del) mc[j] = mp[j];
+            else mc[j] = mc[j - 1];
+        }
+        int32_t* t = sp; sp = sc; sc = t;
+        t = mp; mp = mc; mc = t;
+    }
+    return mp[nb];
+}
+
+MTG_DEV bool identity_below_90(int matches, int na, int nb)
+{
+    int mx = na > nb ? na : nb;
+#ifdef MTG_EMU
+    float identity = (float)matches;
+    identity /= (float)mx;
+    return identity * 100 < 90;
+#else
+    float identity = __fdiv_rn((float)matches, (float)mx);
+    return __fmul_rn(identity, 100.0f) < 90.0f;
+#endif
+}
+
+/* [MEM] MonumentTraversal::validate_consensuses + most_abundant_consensus.
+ * Returns the index of the chosen consensus or -1. */
+MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncons)
+{
+    if (ncons <= 0) return -1;
+    const int k = W.k;
+    const uint8_t* cons = s_cons(W.cfg, W.S);
+    const uint16_t* cons_len = s_conslen(W.cfg, W.S);
+    int mean = 0;
+    for (int c = 0; c < ncons; c++) mean += cons_len[c];
+    mean /= ncons;
+    long long ss = 0;
+    for (int c = 0; c < ncons; c++) { long long dl = (long long)cons_len[c] - mean; ss += dl * dl; }
+    if (mean > W.cfg.mono_max_depth) return -1;
+    if (ncons == 1 && mean > k + 1) return -1;
+    /* stdev > mean/5  <=>  ss > (mean/5)^2 * n  (exact in integers) */
+    long long t = mean / 5;
+    if (ss > t * t * ncons) return -1;
+    for (int a = 0; a < ncons; a++)
+        for (int b = a + 1; b < ncons; b++) {
+            int na = cons_len[a], nb = cons_len[b];
+            int m = nw_matches(W, cons + (size_t)a * CONS_LEN, na, cons + (size_t)b * CONS_LEN, nb);
+            if (identity_below_90(m, na, nb)) return -1;
+        }
+    unsigned long best = 0;
+    int chosen = -1;
+    for (int c = 0; c < ncons; c++) {
+        int len = cons_len[c];
+        if (len == 0) continue;
+        unsigned long sum = 0;
+        Kmer x = start;
+        const uint8_t* p = cons + (size_t)c * CONS_LEN;
+        for (int i = 0; i < len; i++) {
+            sum += abundance(W.ix, x, W.lines);
+            x = kmer_next(x, p[i], k, W.mk);
+        }
+        sum /= (unsigned long)len;
+        if (sum > best) { best = sum; chosen = c; }
+    }
+    if (chosen < 0) return -1;
+    if ((int)cons_len[chosen] > W.cfg.mono_max_depth) return -1;
+    return chosen;
+}
+
+/* [MEM] MonumentTraversal::explore_branching.  On success the consensus sits in
+ * S.cons[chosen] and its length is returned; 0 on failure. */
+MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev_c, int& chosen)
+{
+    W.n_inv = 0;
+    uint64_t end_f = 0;
+    int d = find_end_of_branching(W, cur, prev_c, end_f);
+    W.seen_clear();
+#ifdef MTG_TRACE
+    fprintf(stderr, "EB cur=%llx d=%d end=%llx ninv=%u\n", (unsigned long long)cur.f, d, (unsigned long long)end_f, W.n_inv);
+#endif
+    if (!d || W.status) return 0;
+    Kmer e = make_kmer(end_f, W.k);
+    int ncons = 0;
+    if (!all_consensuses_between(W, cur, canon(e), d + 1, ncons)) return 0;
+    chosen = validate_consensuses(W, cur, ncons);
+#ifdef MTG_TRACE
+    fprintf(stderr, "   ncons=%d chosen=%d\n", ncons, chosen);
+#endif
+    if (chosen < 0) return 0;
+    /* mark all involved extensions (only the node bit of branching k-mers is ever read back) */
+    const uint64_t* inv = s_inv(W.cfg, W.S);
+    for (uint32_t i = 0; i < W.n_inv; i++) {
+        Kmer x;
+        x.f = inv[i];
+        x.r = revcomp(x.f, W.k);
+        if (W.is_branching(x)) W.mark_canon(inv[i]);
+    }
+    return s_conslen(W.cfg, W.S)[chosen];
+}
+
+/* result of one gap */
+struct GapOut {
+    uint32_t n_contigs;
+    uint32_t status;
+    uint32_t lines;
+    uint32_t total_nt;
+    uint32_t n_words; /* words of the contig arena in use */
+};
+
+/* the swf pattern R (gapFillFromSource's targetSequence, src/Filler.cpp:884): 2-bit packed, 32 nt per
+ * word, rlen nts.  bkpt mode: the target k-mer; contig mode: the concatenation of all targets
+ * (src/Filler.cpp:530,537).  r0 = its first k-mer (valid when rlen >= k). */
+struct SwfPattern {
+    const uint64_t* words;
+    uint32_t rlen;
+    uint64_t r0;
+};
+MTG_DEV uint32_t packed_nt(const uint64_t* w, uint32_t i) { return (uint32_t)(w[i >> 5] >> (2 * (i & 31))) & 3u; }
+
+/* does the contig contain R literally (strstr at IterativeExtensions [MEM]) */
+MTG_DEV_NOINLINE bool contig_contains(const uint64_t* wd, uint32_t clen, const SwfPattern& R)
+{
+    if (R.rlen == 0) return true;
+    if (R.rlen > clen) return false;
+    for (uint32_t p = 0; p + R.rlen <= clen; p++) {
+        bool ok = true;
+        for (uint32_t j = 0; j < R.rlen && ok; j++) ok = packed_nt(wd, p + j) == packed_nt(R.words, j);
+        if (ok) return true;
+    }
+    return false;
+}
+
+/* [MEM] IterativeExtensions::construct_linear_seqs + Traversal::traverse (A.5). */
+MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out)
+{
+    Worker W(ix, cfg, S);
+    const int k = W.k;
+    const uint64_t mk = W.mk, mk1 = W.mk1;
+    const long long MAXLEN = 10LL * 1000 * 1000;
+    const bool r_is_kmer = (R.rlen == (uint32_t)k);
+    uint64_t* q_f = s_qf(cfg, S);
+    uint64_t* q_c = s_qc(cfg, S);
+    int32_t* q_d = s_qd(cfg, S);
+
+    int head = 0, tail = 0;
+    q_f[0] = src_f;
+    q_c[0] = canon(make_kmer(src_f, k));
+    q_d[0] = 0;
+    tail = 1;
+    uint32_t nb = 0, total_nt = 0;
+
+    while (head < tail && W.status == GAP_OK) {
+        const uint64_t node_f = q_f[head];
+        const int node_depth = q_d[head];
+        head++;
+        /* ---- traverse(node) ---- */
+        const uint32_t c_first = W.wpos;
+        for (int i = k - 1; i >= 0; i--) W.push_nt((uint32_t)(node_f >> (2 * i)) & 3u);
+        Kmer cur = make_kmer(node_f, k);
+        const uint64_t start_c = canon(cur);
+        uint64_t prev_c = 0; /* gatb: default-constructed previousNode has k-mer value 0 */
+        long long len = 0;
+        bool looping = false;
+        bool found_R = (r_is_kmer && cur.f == R.r0);
+        Adj a = adj_right(ix, cur, mk1, W.lines);
+        for (;;) {
+            if (popc4(a.out) == 1 && popc4(a.in) <= 1) {
+                /* simple path: one line per nucleotide */
+                const uint32_t nt = (uint32_t)ctz4(a.out);
+                prev_c = canon(cur);
+                cur = kmer_next(cur, nt, k, mk);
+                W.push_nt(nt);
+                len++;
+                const Adj a2 = adj_right(ix, cur, mk1, W.lines);
+                if (!(popc4(a2.out) == 1 && popc4(a.in) == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
+                if (r_is_kmer && cur.f == R.r0) found_R = true;
+                a = a2;
+                if (canon(cur) == start_c) break; /* looping */
+                if (len > MAXLEN) break;
+                if (W.status) break;
+                continue;
+            }
+            int chosen = -1;
+            const int n = explore_branching(W, cur, prev_c, chosen);
+            if (n <= 0) break;
+            const uint8_t* p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;
+            for (int i = 0; i < n; i++) {
+                prev_c = canon(cur);
+                cur = kmer_next(cur, p[i], k, mk);
+                W.push_nt(p[i]);
+                len++;
+                W.mark(cur);
+                if (r_is_kmer && cur.f == R.r0) found_R = true;
+                if (canon(cur) == start_c) looping = true;
+            }
+            if (looping) break;
+            if (len > MAXLEN) break;
+            if (W.status) break;
+            a = adj_right(ix, cur, mk1, W.lines);
+        }
+        W.flush();
+        if (W.status) break;
+        const uint32_t clen = (uint32_t)(k + len);
+        s_cstart(cfg, S)[nb] = c_first;
+        s_clen(cfg, S)[nb] = clen;
+        nb++;
+        total_nt += clen;
+        /* ---- swf: stop when R occurs in the contig and depth > k ---- */
+        if (!r_is_kmer && node_depth > k) found_R = contig_contains(s_words(cfg, S) + c_first, clen, R);
+        if (found_R && node_depth > k) break;
+        if ((int)nb > cfg.max_nodes) break;
+        if (node_depth + (int)clen > cfg.max_depth) continue;
+        /* push the successors that were never extended from */
+        const Adj ea = adj_right(ix, cur, mk1, W.lines);
+        for (uint32_t nt = 0; nt < 4; nt++) {
+            if (!(ea.out & (1u << nt))) continue;
+            const Kmer s = kmer_next(cur, nt, k, mk);
+            const uint64_t cs = canon(s);
+            bool seen = false;
+            for (int i = 1; i < tail; i++) if (q_c[i] == cs) { seen = true; break; }
+            if (seen) continue;
+            if ((uint32_t)tail >= cfg.qcap) { W.status = GAP_OVF_QUEUE; break; }
+            q_f[tail] = s.f;
+            q_c[tail] = cs;
+            q_d[tail] = node_depth + (int)len + 1;
+            tail++;
+        }
+    }
+    out.n_contigs = nb;
+    out.status = W.status;
+    out.lines = W.lines;
+    out.total_nt = total_nt;
+    out.n_words = W.wpos;
+}
+
+} // namespace mtg
+#endif

@@ -457,6 +457,7 @@ struct Monument {
         unordered_set<kmer_t> involved;
         kmer_t end_node = 0;
         int d = find_end_of_branching(cur, prev_canon, end_node, involved);
+        if (getenv("MTGO_TRACE")) fprintf(stderr, "EB cur=%llx d=%d end=%llx ninv=%zu\n", (unsigned long long)cur, d, (unsigned long long)end_node, involved.size());
         if (!d) return false;
         set<vector<int>> cons;
         vector<kmer_t> used; used.push_back(g.can(cur));
@@ -465,7 +466,9 @@ struct Monument {
         all_consensuses_between(cur, g.can(end_node), d + 1, used, current, cons, success);
         if (!success) return false;
         consensus.clear();
-        if (!validate_consensuses(cur, cons, consensus)) return false;
+        bool okv = validate_consensuses(cur, cons, consensus);
+        if (getenv("MTGO_TRACE")) fprintf(stderr, "   ncons=%zu ok=%d len=%zu\n", cons.size(), (int)okv, consensus.size());
+        if (!okv) return false;
         /* mark every involved extension; node bit only matters for branching ones */
         for (kmer_t c : involved) if (g.is_branching(c)) term.marked.insert(c);
         return true;

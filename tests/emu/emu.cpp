@@ -1,0 +1,109 @@
+/*
+ * tests/emu/emu.cpp -- TEST-ONLY host emulation harness for the device code in
+ * mindthegap_amd/csrc/mtg_dev.h / mtg_traverse.h (compiled by g++; every "lane" runs sequentially).
+ * It lets the CPU test-suite (and CPU sanitizers) exercise the kernel logic against the oracle
+ * before any GPU time is spent.  It is never built into, loaded by or reachable from the product
+ * library, which requires a HIP device.
+ */
+#include "../../mindthegap_amd/csrc/mtg_hostutil.h"
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mtg;
+
+struct EmuIndex {
+    Index ix;
+    std::vector<uint64_t> adj_slots, abnd_slots;
+};
+
+extern "C" {
+
+void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, int k, double load)
+{
+    for (;;) {
+        EmuIndex* e = new EmuIndex();
+        e->ix.k = k;
+        table_shape(e->ix.adj, buckets_for(n + n / 8 + 16, load, 2 * (k - 1)), 2 * (k - 1));
+        table_shape(e->ix.abnd, buckets_for(n, load, 2 * k), 2 * k);
+        e->adj_slots.assign(e->ix.adj.nbuckets * 8, 0);
+        e->abnd_slots.assign(e->ix.abnd.nbuckets * 8, 0);
+        e->ix.adj.slots = e->adj_slots.data();
+        e->ix.abnd.slots = e->abnd_slots.data();
+        int fail = 0;
+        for (size_t i = 0; i < n; i++) fail |= index_insert(e->ix, kmers[i], counts[i]) & 1;
+        if (!fail) return e;
+        delete e;
+        load *= 0.7;
+    }
+}
+void emu_index_free(void* p) { delete (EmuIndex*)p; }
+
+void emu_query(void* p, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
+{
+    EmuIndex* e = (EmuIndex*)p;
+    int k = e->ix.k;
+    uint64_t mk1 = kmask(k - 1);
+    uint32_t lines = 0;
+    for (size_t i = 0; i < n; i++) {
+        Kmer x = make_kmer(kmers[i], k);
+        abund[i] = abundance(e->ix, x, lines);
+        succ[i] = (uint8_t)adj_right(e->ix, x, mk1, lines).out;
+        pred[i] = (uint8_t)adj_left(e->ix, x, mk1, lines).in;
+    }
+}
+
+/* stage A for one gap; contigs joined by '\n' (malloc'd).  tier < 0: escalate tiers on overflow. */
+char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const char* source, const char* R, int tier, uint32_t* status,
+                  uint32_t* lines, uint32_t* tier_used)
+{
+    EmuIndex* e = (EmuIndex*)p;
+    int k = e->ix.k;
+    int t0 = tier < 0 ? 0 : tier, t1 = tier < 0 ? MTG_MAX_TIER : tier;
+    std::string joined;
+    GapOut out{};
+    for (int t = t0; t <= t1; t++) {
+        FillCfg cfg = make_cfg(k, max_nodes, max_depth, end_rule, t);
+        std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0xCD);
+        GapScratch S = carve(cfg, zero.data(), raw.data(), 0);
+        std::vector<uint64_t> rw;
+        size_t rl = strlen(R);
+        pack_seq(R, rl, rw);
+        SwfPattern pat;
+        pat.words = rw.data();
+        pat.rlen = (uint32_t)rl;
+        pat.r0 = rl >= (size_t)k ? encode_kmer(R, k) : 0;
+        stage_a_gap(e->ix, cfg, S, encode_kmer(source, k), pat, out);
+        if (tier_used) *tier_used = (uint32_t)t;
+        if (out.status == GAP_OK) {
+            joined.clear();
+            for (uint32_t i = 0; i < out.n_contigs; i++) {
+                std::string s;
+                unpack_seq(s_words(cfg, S) + s_cstart(cfg, S)[i], s_clen(cfg, S)[i], s);
+                if (i) joined += "\n";
+                joined += s;
+            }
+            break;
+        }
+    }
+    if (status) *status = out.status;
+    if (lines) *lines = out.lines;
+    char* r = (char*)malloc(joined.size() + 1);
+    memcpy(r, joined.c_str(), joined.size() + 1);
+    return r;
+}
+void emu_free(void* p) { free(p); }
+}
+
+extern "C" void emu_debug_adj(void* p, uint64_t key)
+{
+    EmuIndex* e = (EmuIndex*)p;
+    const Table& t = e->ix.adj;
+    uint64_t H = mix(key, t.key_bits), b = bucket_of(H, t.nbuckets, t.key_bits), tag = H & ((1ULL << t.tag_bits) - 1);
+    printf("key %llx H %llx nb %llu bucket %llu tag %llx tag_bits %u key_bits %u\n", (unsigned long long)key, (unsigned long long)H,
+           (unsigned long long)t.nbuckets, (unsigned long long)b, (unsigned long long)tag, t.tag_bits, t.key_bits);
+    for (int d = 0; d < 3; d++) {
+        for (int i = 0; i < 8; i++) { uint64_t v = t.slots[((b + d) % t.nbuckets) * 8 + i]; printf("  [%d,%d] tag %llx disp %llu val %llx\n", d, i, (unsigned long long)(v >> 10), (unsigned long long)((v >> 8) & 3), (unsigned long long)(v & 255)); }
+    }
+}

@@ -1,0 +1,135 @@
+/*
+ * tests/emu/emu_backend.cpp -- TEST-ONLY stand-in for mtg_gpu.hip: the same device functions
+ * (mtg_dev.h / mtg_traverse.h) executed lane by lane on the host, behind the internal interface of
+ * mtg_internal.h.  Linked with the product's host translation units (mtg_host.cpp, mtg_cli.cpp) into
+ * tests/emu/libmtgfill_emu.so so that the CPU test-suite can run the whole `MindTheGap fill` logic
+ * (and sanitizers) without a GPU.  The product library never contains this file.
+ */
+#include "../../mindthegap_amd/csrc/mtg_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+using namespace mtg;
+
+namespace mtgi {
+static thread_local char g_err[512] = "";
+static thread_local mtg_batch_stats g_stats{};
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+void stats_store(const mtg_batch_stats& s) { g_stats = s; }
+
+int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k, mtg_index** out)
+{
+    if (k < 11 || k > 31) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    double load = 0.5;
+    for (;;) {
+        mtg_index* idx = new mtg_index();
+        idx->dev.k = k;
+        table_shape(idx->dev.adj, buckets_for(n + n / 8 + 1024, load, 2 * (k - 1)), 2 * (k - 1));
+        table_shape(idx->dev.abnd, buckets_for(n, load, 2 * k), 2 * k);
+        idx->dev.adj.slots = (uint64_t*)calloc(idx->dev.adj.nbuckets * 8, 8);
+        idx->dev.abnd.slots = (uint64_t*)calloc(idx->dev.abnd.nbuckets * 8, 8);
+        int fail = 0;
+        uint64_t created = 0;
+        for (size_t i = 0; i < n; i++) { int r = index_insert(idx->dev, kmers[i], ab[i]); fail |= r & 1; created += (r >> 1) & 1; }
+        if (!fail) {
+            uint64_t nbr = 0, mk1 = kmask(k - 1);
+            uint32_t lines = 0;
+            for (size_t i = 0; i < n; i++) {
+                Kmer x = make_kmer(kmers[i], k);
+                nbr += !(popc4(adj_right(idx->dev, x, mk1, lines).out) == 1 && popc4(adj_left(idx->dev, x, mk1, lines).in) == 1);
+            }
+            idx->info.k = k; idx->info.nb_solid_kmers = created; idx->info.nb_branching = nbr; idx->info.abundance_auto = -1;
+            *out = idx;
+            return MTG_OK;
+        }
+        free(idx->dev.adj.slots); free(idx->dev.abnd.slots); delete idx;
+        load *= 0.7;
+    }
+}
+void index_release(mtg_index* idx)
+{
+    if (!idx) return;
+    index_forget_host_copy(idx);
+    free(idx->dev.adj.slots); free(idx->dev.abnd.slots);
+    delete idx;
+}
+
+int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
+{
+    const int k = idx->dev.k;
+    const uint64_t mk1 = kmask(k - 1);
+    uint32_t lines = 0;
+    for (size_t i = 0; i < n; i++) {
+        Kmer x = make_kmer(kmers[i] & kmask(k), k);
+        if (abund) abund[i] = abundance(idx->dev, x, lines);
+        if (succ) succ[i] = (uint8_t)adj_right(idx->dev, x, mk1, lines).out;
+        if (pred) pred[i] = (uint8_t)adj_left(idx->dev, x, mk1, lines).in;
+    }
+    return MTG_OK;
+}
+
+void StageAInput::add(const char* source, const char* target, int k)
+{
+    src.push_back(encode_kmer(source, k));
+    const size_t rl = strlen(target);
+    std::vector<uint64_t> w;
+    pack_seq(target, rl, w);
+    roff.push_back((uint32_t)rwords.size());
+    rwords.insert(rwords.end(), w.begin(), w.end());
+    rlen.push_back((uint32_t)rl);
+    r0.push_back(rl >= (size_t)k ? encode_kmer(target, k) : 0);
+}
+
+int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in, std::vector<GapContigs>& out, mtg_batch_stats* stats)
+{
+    const size_t n = in.src.size();
+    out.assign(n, GapContigs());
+    mtg_batch_stats st{};
+    for (size_t g = 0; g < n; g++) {
+        GapOut o{};
+        for (int tier = 0; tier <= MTG_MAX_TIER; tier++) {
+            FillCfg cfg = make_cfg(idx->dev.k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
+            std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0xCD);
+            GapScratch S = carve(cfg, zero.data(), raw.data(), 0);
+            SwfPattern R;
+            R.words = in.rwords.data() + in.roff[g];
+            R.rlen = in.rlen[g];
+            R.r0 = in.r0[g];
+            stage_a_gap(idx->dev, cfg, S, in.src[g], R, o);
+            st.index_lines += o.lines;
+            if (o.status != GAP_OK) { st.n_retried_gaps++; continue; }
+            GapContigs& gc = out[g];
+            gc.n_contigs = o.n_contigs;
+            gc.total_nt = o.total_nt;
+            gc.words.assign(s_words(cfg, S), s_words(cfg, S) + o.n_words);
+            gc.words.push_back(0);
+            gc.len.assign(s_clen(cfg, S), s_clen(cfg, S) + o.n_contigs);
+            gc.word_start.assign(s_cstart(cfg, S), s_cstart(cfg, S) + o.n_contigs);
+            st.contig_nt += o.total_nt;
+            break;
+        }
+        if (o.status != GAP_OK) { set_error("gap %zu exceeded the largest traversal scratch tier", g); return MTG_ERR_OVERFLOW; }
+    }
+    if (stats) *stats = st;
+    return MTG_OK;
+}
+} // namespace mtgi
+
+extern "C" {
+const char* mtg_last_error(void) { return mtgi::g_err; }
+int mtg_device_count(void) { return 0; }
+int mtg_set_device(int) { return MTG_OK; }
+int mtg_index_create_from_kmers(const uint64_t* k, const uint32_t* a, size_t n, int kk, mtg_index** out) { return mtgi::index_from_kmers(k, a, n, kk, out); }
+void mtg_index_free(mtg_index* idx) { mtgi::index_release(idx); }
+int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info) { *info = idx->info; return MTG_OK; }
+int mtg_index_abundance(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* out) { return mtgi::query_run(idx, kmers, n, out, nullptr, nullptr); }
+int mtg_index_neighbors(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* s, uint8_t* p) { return mtgi::query_run(idx, kmers, n, nullptr, s, p); }
+int mtg_last_batch_stats(mtg_batch_stats* s) { *s = mtgi::g_stats; return MTG_OK; }
+}

@@ -1,0 +1,64 @@
+"""ctypes binding of the TEST-ONLY host emulation of the device code (tests/emu/emu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "emu", "emu.cpp")
+SO = os.path.join(ROOT, "tests", "emu", "libmtg_emu.so")
+HDRS = [os.path.join(ROOT, "mindthegap_amd", "csrc", h) for h in ("mtg_dev.h", "mtg_traverse.h", "mtg_hostutil.h")]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    deps = [SRC] + HDRS
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SO, SRC])
+    lib = C.CDLL(SO)
+    P = C.POINTER
+    lib.emu_index_create.restype = C.c_void_p
+    lib.emu_index_create.argtypes = [P(C.c_uint64), P(C.c_uint32), C.c_size_t, C.c_int, C.c_double]
+    lib.emu_index_free.argtypes = [C.c_void_p]
+    lib.emu_query.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint32), P(C.c_uint8), P(C.c_uint8)]
+    lib.emu_stage_a.restype = C.c_void_p
+    lib.emu_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
+    lib.emu_free.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class EmuIndex:
+    def __init__(self, kmers, counts, k, load_factor=0.6):
+        self.lib = load()
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        self.k = k
+        self.h = C.c_void_p(self.lib.emu_index_create(kmers.ctypes.data_as(C.POINTER(C.c_uint64)), counts.ctypes.data_as(C.POINTER(C.c_uint32)), len(kmers), k, load_factor))
+
+    def query(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        n = len(kmers)
+        ab = np.zeros(n, dtype=np.uint32)
+        su = np.zeros(n, dtype=np.uint8)
+        pr = np.zeros(n, dtype=np.uint8)
+        self.lib.emu_query(self.h, kmers.ctypes.data_as(C.POINTER(C.c_uint64)), n, ab.ctypes.data_as(C.POINTER(C.c_uint32)),
+                           su.ctypes.data_as(C.POINTER(C.c_uint8)), pr.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return ab, su, pr
+
+    def stage_a(self, source, target, max_nodes=100, max_depth=10000, end_rule=0, tier=-1):
+        st, ln, tu = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        ptr = self.lib.emu_stage_a(self.h, max_nodes, max_depth, end_rule, source.encode(), target.encode(), tier, C.byref(st), C.byref(ln), C.byref(tu))
+        s = C.string_at(ptr).decode()
+        self.lib.emu_free(ptr)
+        return (s.split("\n") if s else []), st.value, ln.value, tu.value
+
+    def close(self):
+        if self.h:
+            self.lib.emu_index_free(self.h)
+            self.h = None
