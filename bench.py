@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- breakpoints filled / second on the synthetic human-scale set (BASELINE.json configs[3]).
+
+One "step" = one pass of the fill hot path (Filler::gapFillFromSource for every site, reverse attempt for the unfilled ones)
+over one batch of sites, through the C ABI of libmtgfill.so.  The index is built once, before the timed region, and stays
+resident in HBM.  N > 1: one process per GPU (torchrun), the index is replicated (each rank builds the same deterministic
+donor genome), each rank fills its own sites (no data-path collective), the filled sequences are gathered on rank 0 over RCCL.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny"])
+    ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the workload's)")
+    ap.add_argument("--nseq", type=int, default=0)
+    ap.add_argument("--cpu-sites", type=int, default=3000, help="sites of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-index-seqs", type=int, default=12000, help="donor sequences in the CPU baseline's index")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the random-64B-line ceiling micro-benchmark")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    # name: (donor sequences, sites per GPU, description)
+    "human": (600000, 100000, "synthetic human-scale: 3 Gbp i.i.d. donor as 600000 x 5 kb sequences, 100000 insertion sites (50-1000 nt), k=31, max-nodes 100"),
+    "ecoli": (1000, 1000, "synthetic E.coli-scale: 5 Mbp donor as 1000 x 5 kb sequences, 1000 insertion sites, k=31"),
+    "tiny": (400, 256, "tiny smoke workload"),
+}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    import mindthegap_amd as mtg
+    from mindthegap_amd.synth import SynthSet
+
+    lib = mtg.load_library()
+    if not torch.cuda.is_available() or mtg.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    lib.mtg_set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    nseq0, sites0, desc = WORKLOADS[a.workload]
+    sites_per_gpu = a.sites or sites0
+    n_sites_total = sites_per_gpu * world
+    nseq = max(a.nseq or nseq0, n_sites_total)
+    k = 31
+
+    # ---------------------------------------------------------------- synthetic donor genome + index (not timed as "fill")
+    t0 = time.time()
+    S = SynthSet(nseq=nseq, n_sites=n_sites_total, seed=1, k=k)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    w = torch.from_numpy(S.words.view(np.int64)).to(dev)
+    wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev)
+    ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
+    idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, k, 3, 40)
+    torch.cuda.synchronize()
+    t_index = time.time() - t0
+    info = idx.info()
+    del w, wo, ln
+    torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------- this rank's sites
+    my_sites = range(rank * sites_per_gpu, (rank + 1) * sites_per_gpu)
+    gaps, expected = [], []
+    for i in my_sites:
+        l, r, ins = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+        expected.append(ins)
+    prepared = mtg.Index.prepare_gaps(gaps)
+    params = mtg.FillParams(max_nodes=100, max_depth=10000)
+    exp_digest = hashlib.sha256(("\n".join(expected) + "\n").encode()).hexdigest()
+
+    def rc(s):
+        return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+    def step():
+        """forward attempt for every site, reverse attempt (src/Filler.cpp:669-680) for the unfilled ones"""
+        h, nf, seqs = idx.fill_prepared(prepared, params)
+        st = mtg.last_batch_stats()
+        idx.free_results(h)
+        unfilled = np.nonzero(nf == 0)[0]
+        n_filled = int((nf > 0).sum())
+        if len(unfilled):
+            rg = [mtg.Gap(rc(gaps[j].target), rc(gaps[j].source), [(rc(gaps[j].source), "rev", False)], reverse=True) for j in unfilled]
+            h2, nf2, _ = idx.fill_prepared(mtg.Index.prepare_gaps(rg), params)
+            st2 = mtg.last_batch_stats()
+            idx.free_results(h2)
+            n_filled += int((nf2 > 0).sum())
+            for key in ("kernel_ms", "h2d_ms", "d2h_ms", "host_ms", "index_lines", "n_launches", "contig_nt"):
+                st[key] += st2[key]
+        if world > 1:  # results gathered on rank 0 over RCCL / xGMI (sizes, then padded payloads)
+            payload = torch.frombuffer(bytearray(seqs), dtype=torch.uint8).to(dev)
+            sz = torch.tensor([payload.numel()], device=dev, dtype=torch.int64)
+            sizes = [torch.zeros_like(sz) for _ in range(world)]
+            dist.all_gather(sizes, sz)
+            mx = int(max(int(s.item()) for s in sizes))
+            pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
+            pad[: payload.numel()] = payload
+            bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, bufs, dst=0)
+        return n_filled, seqs, st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = lines = contig_nt = launches = host_ms = d2h_ms = 0
+    n_filled, seqs = 0, b""
+    for _ in range(a.steps):
+        n_filled, seqs, st = step()
+        kernel_ms += st["kernel_ms"]; lines += st["index_lines"]; contig_nt += st["contig_nt"]; launches += st["n_launches"]
+        host_ms += st["host_ms"]; d2h_ms += st["d2h_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nf_t = torch.tensor([n_filled], device=dev, dtype=torch.int64)
+        dist.all_reduce(nf_t)
+        n_filled_all = int(nf_t.item())
+    else:
+        n_filled_all = n_filled
+    # size-independent parity property at full size: every site is filled with exactly its inserted sequence
+    identical = hashlib.sha256(seqs).hexdigest() == exp_digest
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = n_sites_total * a.steps / elapsed
+    # ---------------------------------------------------------------- CPU baseline (oracle = "port"), bounded sample, rank 0, N = 1 only
+    cpu = None
+    probes_per_nt = 8.0
+    if world == 1 and a.cpu_sites > 0:
+        from tests import oracle_lib
+        ns = min(a.cpu_sites, sites_per_gpu)
+        nidx = max(min(a.cpu_index_seqs, S.nseq), ns)
+        cores = os.cpu_count() or 1
+        seqs_ascii = [S.ascii(j) for j in range(nidx)]
+        oidx = oracle_lib.Index.from_sequences(seqs_ascii, k, 3, 40)
+        with tempfile.TemporaryDirectory() as d:
+            bk = os.path.join(d, "s.breakpoints")
+            S.write_breakpoints(bk, range(ns))
+            ost = oidx.fill_files("bkpt", bk, os.path.join(d, "cpu"), params=oracle_lib.default_params(nb_cores=cores))
+            cpu_fa = open(os.path.join(d, "cpu.insertions.fasta")).read()
+        cpu_seqs = "".join(l + "\n" for l in cpu_fa.splitlines() if not l.startswith(">"))
+        hip_seqs = "".join(e + "\n" for e in expected[:ns])
+        # algorithmic probes per contig nucleotide, counted by the oracle on the sample
+        sample_nt = sum(S.seq_len + int(S.ins_len[i]) - int(S.pos[i]) + k for i in range(ns))
+        probes_per_nt = ost["probes"] / max(sample_nt, 1)
+        cpu = {"value": ns / ost["seconds"], "unit": "breakpoints/s", "cores": cores, "kind": "port",
+               "sample": "%d of the %d sites, index over the first %d donor sequences (%d k-mers), CPU restatement of the reference Filler (gatb-core unavailable)"
+                         % (ns, sites_per_gpu, nidx, len(oidx)),
+               "seconds": ost["seconds"], "identical_to_hip": cpu_seqs == hip_seqs and identical}
+        oidx.close()
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel (k_stage_a)
+    alg_bytes_per_launch = 64.0 * probes_per_nt * contig_nt / max(launches, 1)
+    avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
+    achieved = alg_bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "kernel": "k_stage_a", "avg_kernel_ms": kernel_ms / max(launches, 1), "launches": int(launches),
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch, "probes_per_contig_nt": probes_per_nt,
+            "index_lines_per_launch": lines / max(launches, 1), "line_GBps": (lines * 64.0 / max(kernel_ms, 1e-9) / 1e6)}
+    if not a.no_ceiling:
+        tb = min(int(info["device_bytes"] // 2), 64 << 30)
+        ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), sites_per_gpu, 512)
+        roof["random_line_ceiling_GBps"] = gbps
+        roof["frac_of_random_line_ceiling"] = roof["line_GBps"] / gbps if gbps else None
+
+    out = {"metric": "breakpoints filled/sec", "value": value, "unit": "breakpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": desc, "sites_per_gpu": sites_per_gpu, "donor_sequences": S.nseq, "k": k, "max_nodes": 100, "max_length": 10000,
+                      "index": "exact k-mer set of the donor, abundance = 3 + hash %% 40 (no reads simulated)", "nb_solid_kmers": int(info["nb_solid_kmers"]),
+                      "index_bytes": int(info["device_bytes"]), "index_build_s": t_index, "genome_gen_s": t_gen},
+           "filled": n_filled_all, "filled_sequences_identical_to_truth": bool(identical),
+           "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps},
+           "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,10 @@ typedef struct mtg_results mtg_results;
 int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
 void mtg_results_free(mtg_results* r);
+/* bulk view of a result set (for gathers / checksums): n_filled[i] = number of sequences of gap i (may be NULL);
+ * *seq_bytes = size of the concatenation "seq\n" of all filled sequences in gap order, which mtg_results_copy_seqs writes to dst */
+int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled);
+int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap);
 
 /* Stage A only (gatb IterativeExtensions::construct_linear_seqs, call site src/Filler.cpp:884): contigs of each gap
  * as ASCII, for parity tests and the info file.  sources[i] / targets[i] are NUL terminated strings. */

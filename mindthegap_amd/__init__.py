@@ -1,0 +1,11 @@
+"""mindthegap_amd -- MI355X-native drop-in for the hot path of `MindTheGap fill`.
+
+The compute lives in libmtgfill.so (hand-written HIP for gfx950 behind the C ABI of include/mtg_fill.h);
+this package is the thin host mirror used by tests, bench.py and Python callers.  There is no CPU
+fallback: every call fails loudly when the library or a HIP device is missing."""
+from .lib import (Index, FillParams, Gap, MtgError, build_library, device_count, fill_main, last_batch_stats, library_path,
+                  load_library, random_line_ceiling)
+from .filler import Filler
+
+__all__ = ["Index", "FillParams", "Gap", "MtgError", "Filler", "build_library", "device_count", "fill_main", "last_batch_stats",
+           "library_path", "load_library", "random_line_ceiling"]

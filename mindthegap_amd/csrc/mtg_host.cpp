@@ -639,6 +639,32 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
 }
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->res.size()) ? &r->res[i] : nullptr; }
 void mtg_results_free(mtg_results* r) { delete r; }
+int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
+{
+    if (!r) return MTG_ERR_ARG;
+    uint64_t b = 0, nf = 0;
+    for (size_t i = 0; i < r->gaps.size(); i++) {
+        if (n_filled) n_filled[i] = (uint32_t)r->gaps[i].sols.size();
+        nf += !r->gaps[i].sols.empty();
+        for (auto& s : r->gaps[i].sols) b += s.seq.size() + 1;
+    }
+    if (seq_bytes) *seq_bytes = b;
+    if (n_gaps_filled) *n_gaps_filled = nf;
+    return MTG_OK;
+}
+int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
+{
+    if (!r || !dst) return MTG_ERR_ARG;
+    uint64_t o = 0;
+    for (auto& g : r->gaps)
+        for (auto& s : g.sols) {
+            if (o + s.seq.size() + 1 > cap) { mtgi::set_error("destination too small"); return MTG_ERR_ARG; }
+            memcpy(dst + o, s.seq.data(), s.seq.size());
+            o += s.seq.size();
+            dst[o++] = '\n';
+        }
+    return MTG_OK;
+}
 
 int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n, mtg_contigs** out)
 {

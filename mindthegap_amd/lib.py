@@ -1,0 +1,288 @@
+"""ctypes binding of libmtgfill.so (include/mtg_fill.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+SO = os.path.join(LIBDIR, "libmtgfill.so")
+
+ERRORS = {1: "MTG_ERR_NO_DEVICE", 2: "MTG_ERR_ARG", 3: "MTG_ERR_IO", 4: "MTG_ERR_NOMEM", 5: "MTG_ERR_OVERFLOW", 6: "MTG_ERR_FORMAT"}
+
+
+class MtgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERRORS.get(code, code), msg))
+        self.code = code
+
+
+def library_path():
+    return SO
+
+
+def build_library(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "mtg_fill.h")]
+    stale = force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs if os.path.isfile(s))
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return SO
+
+
+class Params(C.Structure):
+    _fields_ = [("max_nodes", C.c_int), ("max_depth", C.c_int), ("nb_mis_allowed", C.c_int), ("end_rule_nonbranching", C.c_int),
+                ("nb_host_threads", C.c_int)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("k", C.c_int), ("abundance_min", C.c_int), ("abundance_auto", C.c_int), ("nb_solid_kmers", C.c_uint64),
+                ("nb_branching", C.c_uint64), ("device_bytes", C.c_uint64), ("adj_buckets", C.c_uint64), ("abnd_buckets", C.c_uint64)]
+
+
+class CGap(C.Structure):
+    _fields_ = [("source", C.c_char_p), ("target", C.c_char_p), ("n_targets", C.c_int), ("target_seqs", C.POINTER(C.c_char_p)),
+                ("target_names", C.POINTER(C.c_char_p)), ("target_is_rc", C.POINTER(C.c_uint8)), ("is_anchor_repeated", C.c_int),
+                ("reverse", C.c_int)]
+
+
+class CFilled(C.Structure):
+    _fields_ = [("seq", C.c_char_p), ("nb_errors_in_anchor", C.c_int), ("target_index", C.c_int), ("avg_coverage", C.c_float),
+                ("median_coverage", C.c_float), ("qual", C.c_int), ("solution_count", C.c_int), ("solution_rank", C.c_int)]
+
+
+class CGapResult(C.Structure):
+    _fields_ = [("nb_nodes", C.c_int), ("total_nt", C.c_int), ("nb_terminal", C.c_int), ("has_solution_counts", C.c_int),
+                ("nb_total_filled", C.c_int), ("nb_reported", C.c_int), ("n_filled", C.c_int), ("filled", C.POINTER(CFilled)),
+                ("extension", C.c_char_p)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("host_ms", C.c_double),
+                ("index_lines", C.c_uint64), ("n_launches", C.c_uint64), ("n_retried_gaps", C.c_uint64), ("contig_nt", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmtgfill.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise MtgError(1, "libmtgfill.so is not built (%s); run __graft_entry__.build() or make -C mindthegap_amd/csrc" % SO)
+    _lib = _bind(C.CDLL(SO))
+    return _lib
+
+
+def _bind(lib):
+    P = C.POINTER
+    lib.mtg_last_error.restype = C.c_char_p
+    lib.mtg_index_create_from_reads.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.mtg_index_create_from_kmers.argtypes = [P(C.c_uint64), P(C.c_uint32), C.c_size_t, C.c_int, P(C.c_void_p)]
+    lib.mtg_index_create_from_packed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, P(C.c_void_p)]
+    lib.mtg_index_load.argtypes = [C.c_char_p, P(C.c_void_p)]
+    lib.mtg_index_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mtg_index_get_info.argtypes = [C.c_void_p, P(IndexInfo)]
+    lib.mtg_index_free.argtypes = [C.c_void_p]
+    lib.mtg_index_free.restype = None
+    lib.mtg_index_contains.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint8)]
+    lib.mtg_index_abundance.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint32)]
+    lib.mtg_index_neighbors.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint8), P(C.c_uint8)]
+    lib.mtg_default_params.argtypes = [P(Params)]
+    lib.mtg_default_params.restype = None
+    lib.mtg_fill_batch.argtypes = [C.c_void_p, P(Params), P(CGap), C.c_size_t, P(C.c_void_p)]
+    lib.mtg_results_get.argtypes = [C.c_void_p, C.c_size_t]
+    lib.mtg_results_get.restype = P(CGapResult)
+    lib.mtg_results_free.argtypes = [C.c_void_p]
+    lib.mtg_results_free.restype = None
+    lib.mtg_results_summary.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint64), P(C.c_uint64)]
+    lib.mtg_results_copy_seqs.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    lib.mtg_stage_a_batch.argtypes = [C.c_void_p, P(Params), P(C.c_char_p), P(C.c_char_p), C.c_size_t, P(C.c_void_p)]
+    lib.mtg_contigs_count.argtypes = [C.c_void_p, C.c_size_t]
+    lib.mtg_contigs_count.restype = C.c_size_t
+    lib.mtg_contigs_get.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    lib.mtg_contigs_get.restype = C.c_char_p
+    lib.mtg_contigs_free.argtypes = [C.c_void_p]
+    lib.mtg_contigs_free.restype = None
+    lib.mtg_last_batch_stats.argtypes = [P(BatchStats)]
+    lib.mtg_fill_main.argtypes = [C.c_int, P(C.c_char_p)]
+    lib.mtg_bench_random_lines.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, P(C.c_double), P(C.c_double)]
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MtgError(rc, load_library().mtg_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return load_library().mtg_device_count()
+
+
+class FillParams:
+    def __init__(self, max_nodes=100, max_depth=10000, nb_mis_allowed=2, end_rule_nonbranching=0, nb_host_threads=0):
+        self.c = Params(max_nodes, max_depth, nb_mis_allowed, end_rule_nonbranching, nb_host_threads)
+
+
+class Gap:
+    """One Filler::gapFillFromSource call (src/Filler.hpp:188-189)."""
+
+    def __init__(self, source, target, targets, is_anchor_repeated=False, reverse=False):
+        self.source, self.target = source, target
+        self.targets = list(targets)  # [(kmer, name, is_rc)] in dictionary iteration order
+        self.is_anchor_repeated, self.reverse = is_anchor_repeated, reverse
+
+
+class Index:
+    """Device-resident de Bruijn graph index (the gatb Graph of src/Filler.cpp:210,222)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.lib = load_library()
+
+    @classmethod
+    def from_reads(cls, paths, k=31, abundance_min=-1, abundance_max=0):
+        h = C.c_void_p()
+        _check(load_library().mtg_index_create_from_reads(",".join(paths).encode(), k, abundance_min, abundance_max, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_kmers(cls, kmers, abundance, k=31):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        abundance = np.ascontiguousarray(abundance, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(load_library().mtg_index_create_from_kmers(kmers.ctypes.data_as(C.POINTER(C.c_uint64)), abundance.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                          len(kmers), k, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_packed_device(cls, words_ptr, word_off_ptr, len_ptr, nseq, total_kmers_upper_bound, k=31, abund_lo=3, abund_span=40):
+        """Device pointers (e.g. torch tensor .data_ptr()) of 2-bit packed sequences."""
+        h = C.c_void_p()
+        _check(load_library().mtg_index_create_from_packed_device(words_ptr, word_off_ptr, len_ptr, nseq, total_kmers_upper_bound, k, abund_lo, abund_span, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        _check(load_library().mtg_index_load(path.encode(), C.byref(h)))
+        return cls(h)
+
+    def save(self, path):
+        _check(self.lib.mtg_index_save(self.h, path.encode()))
+
+    def info(self):
+        i = IndexInfo()
+        _check(self.lib.mtg_index_get_info(self.h, C.byref(i)))
+        return {f[0]: getattr(i, f[0]) for f in IndexInfo._fields_}
+
+    def contains(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(len(kmers), dtype=np.uint8)
+        _check(self.lib.mtg_index_contains(self.h, kmers.ctypes.data_as(C.POINTER(C.c_uint64)), len(kmers), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def abundance(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(len(kmers), dtype=np.uint32)
+        _check(self.lib.mtg_index_abundance(self.h, kmers.ctypes.data_as(C.POINTER(C.c_uint64)), len(kmers), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def neighbors(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        s = np.zeros(len(kmers), dtype=np.uint8)
+        p = np.zeros(len(kmers), dtype=np.uint8)
+        _check(self.lib.mtg_index_neighbors(self.h, kmers.ctypes.data_as(C.POINTER(C.c_uint64)), len(kmers), s.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            p.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return s, p
+
+    def stage_a(self, sources, targets, params=None):
+        """Contigs of every gap (gatb IterativeExtensions::construct_linear_seqs, src/Filler.cpp:884)."""
+        params = params or FillParams()
+        n = len(sources)
+        sa = (C.c_char_p * n)(*[s.encode() for s in sources])
+        ta = (C.c_char_p * n)(*[t.encode() for t in targets])
+        h = C.c_void_p()
+        _check(self.lib.mtg_stage_a_batch(self.h, C.byref(params.c), sa, ta, n, C.byref(h)))
+        out = []
+        for g in range(n):
+            out.append([self.lib.mtg_contigs_get(h, g, i).decode() for i in range(self.lib.mtg_contigs_count(h, g))])
+        self.lib.mtg_contigs_free(h)
+        return out
+
+    @staticmethod
+    def prepare_gaps(gaps):
+        """marshal a list of Gap once; the returned object can be passed to fill_prepared repeatedly"""
+        n = len(gaps)
+        arr = (CGap * n)()
+        keep = []
+        for i, g in enumerate(gaps):
+            m = len(g.targets)
+            seqs = (C.c_char_p * max(m, 1))(*[t[0].encode() for t in g.targets])
+            names = (C.c_char_p * max(m, 1))(*[t[1].encode() for t in g.targets])
+            rcs = (C.c_uint8 * max(m, 1))(*[1 if t[2] else 0 for t in g.targets])
+            keep.append((seqs, names, rcs))
+            arr[i] = CGap(g.source.encode(), g.target.encode(), m, seqs, names, rcs, int(g.is_anchor_repeated), int(g.reverse))
+        return (arr, n, keep)
+
+    def fill_prepared(self, prepared, params=None):
+        """one mtg_fill_batch call; returns (results handle, n_filled per gap, packed "seq\\n" bytes).  Free with free_results."""
+        params = params or FillParams()
+        arr, n, _ = prepared
+        h = C.c_void_p()
+        _check(self.lib.mtg_fill_batch(self.h, C.byref(params.c), arr, n, C.byref(h)))
+        nf = np.zeros(n, dtype=np.uint32)
+        nb, ng = C.c_uint64(), C.c_uint64()
+        _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nb), C.byref(ng)))
+        buf = C.create_string_buffer(max(int(nb.value), 1))
+        _check(self.lib.mtg_results_copy_seqs(h, buf, nb.value))
+        return h, nf, buf.raw[: nb.value]
+
+    def free_results(self, h):
+        self.lib.mtg_results_free(h)
+
+    def fill_batch(self, gaps, params=None):
+        """Filler::gapFillFromSource for every gap; returns one dict per gap."""
+        params = params or FillParams()
+        arr, n, _keep = self.prepare_gaps(gaps)
+        h = C.c_void_p()
+        _check(self.lib.mtg_fill_batch(self.h, C.byref(params.c), arr, n, C.byref(h)))
+        res = []
+        for i in range(n):
+            r = self.lib.mtg_results_get(h, i).contents
+            filled = []
+            for j in range(r.n_filled):
+                f = r.filled[j]
+                filled.append(dict(seq=f.seq.decode(), nb_errors_in_anchor=f.nb_errors_in_anchor, target_index=f.target_index, avg_coverage=f.avg_coverage,
+                                   median_coverage=f.median_coverage, qual=f.qual, solution_count=f.solution_count, solution_rank=f.solution_rank))
+            res.append(dict(nb_nodes=r.nb_nodes, total_nt=r.total_nt, nb_terminal=r.nb_terminal, has_solution_counts=bool(r.has_solution_counts),
+                            nb_total_filled=r.nb_total_filled, nb_reported=r.nb_reported, filled=filled, extension=r.extension.decode()))
+        self.lib.mtg_results_free(h)
+        return res
+
+    def close(self):
+        if self.h:
+            self.lib.mtg_index_free(self.h)
+            self.h = None
+
+
+def last_batch_stats():
+    s = BatchStats()
+    _check(load_library().mtg_last_batch_stats(C.byref(s)))
+    return {f[0]: getattr(s, f[0]) for f in BatchStats._fields_}
+
+
+def fill_main(argv):
+    """`MindTheGap fill <argv>` (Filler::run, src/main.cpp:105-120); returns the exit code."""
+    arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+    return load_library().mtg_fill_main(len(argv), arr)
+
+
+def random_line_ceiling(table_bytes, n_chains, chain_len):
+    ms, gbps = C.c_double(), C.c_double()
+    _check(load_library().mtg_bench_random_lines(table_bytes, n_chains, chain_len, C.byref(ms), C.byref(gbps)))
+    return ms.value, gbps.value

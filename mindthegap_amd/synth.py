@@ -1,0 +1,54 @@
+"""Synthetic benchmark sets of SURVEY.md 8(d) / BASELINE.md: an i.i.d. donor genome laid out as many short sequences
+(prevents unbounded unitig walks), one insertion per chosen sequence, breakpoints = the 31-mers flanking it.
+
+The index is built from the donor's k-mers directly (error-free, abundance = lo + hash % span, i.e. the
+"donor k-mers with synthetic abundance" variant the survey allows instead of simulating 30x reads)."""
+import numpy as np
+
+NT = np.frombuffer(b"ACTG", dtype=np.uint8)  # code -> letter (A=0 C=1 T=2 G=3)
+
+
+class SynthSet:
+    def __init__(self, nseq, n_sites, seq_len=5000, seed=1, ins_min=50, ins_max=1000, k=31):
+        assert n_sites <= nseq
+        rng = np.random.default_rng(seed)
+        self.k, self.nseq, self.n_sites, self.seq_len = k, nseq, n_sites, seq_len
+        self.ins_len = np.exp(rng.uniform(np.log(ins_min), np.log(ins_max), n_sites)).astype(np.int64)  # log-uniform
+        self.pos = rng.integers(1000, seq_len - 1000 + 1, n_sites)
+        self.lens = np.full(nseq, seq_len, dtype=np.uint32)
+        self.lens[:n_sites] += self.ins_len.astype(np.uint32)
+        self.words_per_seq = int((seq_len + ins_max + 31) // 32 + 1)
+        # random 2-bit nucleotides, 32 per word
+        self.words = rng.integers(0, 2**64, size=(nseq, self.words_per_seq), dtype=np.uint64)
+        self.word_off = (np.arange(nseq, dtype=np.uint64) * np.uint64(self.words_per_seq))
+
+    @property
+    def total_kmers_upper_bound(self):
+        return int(self.lens.astype(np.int64).sum() - (self.k - 1) * self.nseq)
+
+    def codes(self, j):
+        """2-bit codes of donor sequence j"""
+        w = self.words[j]
+        sh = (np.arange(32, dtype=np.uint64) * np.uint64(2))
+        c = ((w[:, None] >> sh[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)
+        return c[: int(self.lens[j])]
+
+    def ascii(self, j):
+        return NT[self.codes(j)].tobytes().decode()
+
+    def site(self, i):
+        """(left k-mer, right k-mer, expected inserted sequence) of site i (donor sequence i)."""
+        s = self.ascii(i)
+        p, L, k = int(self.pos[i]), int(self.ins_len[i]), self.k
+        return s[p - k:p], s[p + L:p + L + k], s[p:p + L]
+
+    def site_name(self, i):
+        # 7 '_' tokens so the VCF header parser path of src/Filler.cpp:1165-1172 is exercised
+        return "bkpt%d_s%d_pos_%d_fuzzy_0_HOM" % (i, i, int(self.pos[i]))
+
+    def write_breakpoints(self, path, sites=None):
+        sites = range(self.n_sites) if sites is None else sites
+        with open(path, "w") as f:
+            for i in sites:
+                l, r, _ = self.site(i)
+                f.write(">%s left_kmer\n%s\n>%s right_kmer\n%s\n" % (self.site_name(i), l, self.site_name(i), r))

@@ -239,7 +239,8 @@ struct GraphView {
     }
     inline int degree(kmer_t x, int dir) { return __builtin_popcount(nbr_mask(x, dir)); }
     inline bool is_branching(kmer_t x) { return !(degree(x, 0) == 1 && degree(x, 1) == 1); }
-    inline uint32_t abundance(kmer_t x) { abund_lookups++; return idx->get(canon(x, k)); }
+    /* 8-bit abundance saturating at 255 (gatb stores 8 bits and discretises above ~70: unpinned) */
+    inline uint32_t abundance(kmer_t x) { abund_lookups++; uint32_t a = idx->get(canon(x, k)); return a > 255 ? 255 : a; }
     inline kmer_t can(kmer_t x) const { return canon(x, k); }
 };
 
@@ -1101,7 +1102,7 @@ mtgo_index* mtgo_index_from_kmers(const uint64_t* canon_kmers, const uint32_t* c
     return idx;
 }
 
-mtgo_index* mtgo_index_from_sequences(const char* const* seqs, size_t nseq, int k, uint32_t abund_mod)
+mtgo_index* mtgo_index_from_sequences(const char* const* seqs, size_t nseq, int k, uint32_t abund_lo, uint32_t abund_span)
 {
     vector<kmer_t> all;
     for (size_t i = 0; i < nseq; i++) count_kmers_of_seq(string(seqs[i]), k, all);
@@ -1109,7 +1110,8 @@ mtgo_index* mtgo_index_from_sequences(const char* const* seqs, size_t nseq, int 
     all.erase(unique(all.begin(), all.end()), all.end());
     mtgo_index* idx = new mtgo_index();
     idx->k = k; idx->init(all.size());
-    for (kmer_t c : all) idx->put(c, 1 + (uint32_t)(splitmix64(c) % (abund_mod ? abund_mod : 1)));
+    for (kmer_t c : all) idx->put(c, abund_lo + (uint32_t)(splitmix64(c) % (abund_span ? abund_span : 1)));
+    idx->abundance_min = (int)abund_lo;
     return idx;
 }
 
@@ -1143,7 +1145,7 @@ void mtgo_contains_batch(const mtgo_index* idx, const uint64_t* kmers, size_t n,
 }
 void mtgo_abundance_batch(const mtgo_index* idx, const uint64_t* kmers, size_t n, uint32_t* out)
 {
-    for (size_t i = 0; i < n; i++) out[i] = idx->get(canon(kmers[i], idx->k));
+    for (size_t i = 0; i < n; i++) { uint32_t a = idx->get(canon(kmers[i], idx->k)); out[i] = a > 255 ? 255 : a; }
 }
 
 char* mtgo_stage_a(const mtgo_index* idx, const mtgo_params* P, const char* source, const char* target_R, uint64_t* probes_out)

@@ -42,8 +42,8 @@ void mtgo_default_params(mtgo_params* p);
 mtgo_index* mtgo_index_from_files(const char* paths_csv, int k, int abundance_min, int abundance_max);
 /* canonical k-mers in this library's encoding (A=0,C=1,T=2,G=3, first nt most significant) */
 mtgo_index* mtgo_index_from_kmers(const uint64_t* canon_kmers, const uint32_t* counts, size_t n, int k);
-/* every k-mer of the given ASCII sequences gets abundance 1 + (splitmix64(canon) % mod) */
-mtgo_index* mtgo_index_from_sequences(const char* const* seqs, size_t nseq, int k, uint32_t abund_mod);
+/* every k-mer of the given ASCII sequences gets abundance abund_lo + (splitmix64(canon) % abund_span) */
+mtgo_index* mtgo_index_from_sequences(const char* const* seqs, size_t nseq, int k, uint32_t abund_lo, uint32_t abund_span);
 void   mtgo_index_free(mtgo_index*);
 int    mtgo_index_k(const mtgo_index*);
 size_t mtgo_index_size(const mtgo_index*);

@@ -132,4 +132,17 @@ int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info) { *info = idx
 int mtg_index_abundance(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* out) { return mtgi::query_run(idx, kmers, n, out, nullptr, nullptr); }
 int mtg_index_neighbors(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* s, uint8_t* p) { return mtgi::query_run(idx, kmers, n, nullptr, s, p); }
 int mtg_last_batch_stats(mtg_batch_stats* s) { *s = mtgi::g_stats; return MTG_OK; }
+int mtg_index_contains(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* out)
+{
+    std::vector<uint32_t> ab(n);
+    mtgi::query_run(idx, kmers, n, ab.data(), nullptr, nullptr);
+    for (size_t i = 0; i < n; i++) out[i] = ab[i] != 0;
+    return MTG_OK;
+}
+int mtg_index_create_from_packed_device(const uint64_t*, const uint64_t*, const uint32_t*, size_t, uint64_t, int, uint32_t, uint32_t, mtg_index**)
+{
+    mtgi::set_error("emulation harness: no device");
+    return MTG_ERR_NO_DEVICE;
+}
+int mtg_bench_random_lines(uint64_t, uint64_t, uint32_t, double*, double*) { mtgi::set_error("emulation harness: no device"); return MTG_ERR_NO_DEVICE; }
 }

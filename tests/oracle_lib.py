@@ -38,7 +38,7 @@ def load():
     lib.mtgo_index_from_kmers.restype = C.c_void_p
     lib.mtgo_index_from_kmers.argtypes = [P(C.c_uint64), P(C.c_uint32), C.c_size_t, C.c_int]
     lib.mtgo_index_from_sequences.restype = C.c_void_p
-    lib.mtgo_index_from_sequences.argtypes = [P(C.c_char_p), C.c_size_t, C.c_int, C.c_uint32]
+    lib.mtgo_index_from_sequences.argtypes = [P(C.c_char_p), C.c_size_t, C.c_int, C.c_uint32, C.c_uint32]
     lib.mtgo_index_free.argtypes = [C.c_void_p]
     lib.mtgo_index_k.argtypes = [C.c_void_p]
     lib.mtgo_index_size.restype = C.c_size_t
@@ -80,9 +80,9 @@ class Index:
         return cls(load().mtgo_index_from_files(",".join(paths).encode(), k, abundance_min, abundance_max))
 
     @classmethod
-    def from_sequences(cls, seqs, k=31, abund_mod=40):
+    def from_sequences(cls, seqs, k=31, abund_lo=1, abund_span=40):
         arr = (C.c_char_p * len(seqs))(*[s.encode() for s in seqs])
-        return cls(load().mtgo_index_from_sequences(arr, len(seqs), k, abund_mod))
+        return cls(load().mtgo_index_from_sequences(arr, len(seqs), k, abund_lo, abund_span))
 
     @classmethod
     def from_kmers(cls, kmers, counts, k=31):

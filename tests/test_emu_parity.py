@@ -1,0 +1,170 @@
+"""CPU-side logic tests: the device code (mtg_dev.h / mtg_traverse.h) executed by the TEST-ONLY host emulation
+harness, plus the product's host code and CLI linked against it, checked against the oracle and the goldens.
+These do not replace the -m gpu parity tests; they validate kernel and host logic before GPU time is spent."""
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+
+from tests import emu_lib, oracle_lib
+
+
+def _read(p):
+    with open(p) as f:
+        return f.read()
+
+
+def _vcf_body(p):
+    return [l for l in _read(p).splitlines() if not l.startswith("##")]
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def _rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def _make_case(seed, k):
+    """random genome with repeats, SNP / indel variants (bubbles) and erroneous fragments (tips)"""
+    rng = random.Random(seed)
+    g = _rand_seq(rng, rng.randrange(800, 4000))
+    for _ in range(rng.randrange(0, 3)):
+        a = rng.randrange(0, len(g) - 200)
+        rl = rng.randrange(k - 5, 150)
+        b = rng.randrange(0, len(g))
+        g = g[:b] + g[a:a + rl] + g[b:]
+    seqs = [g]
+    for _ in range(rng.randrange(0, 4)):
+        s = list(g)
+        for _ in range(rng.randrange(0, 6)):
+            p = rng.randrange(len(s))
+            s[p] = rng.choice([c for c in "ACGT" if c != s[p]])
+        s = "".join(s)
+        for _ in range(rng.randrange(0, 3)):
+            p = rng.randrange(50, len(s) - 50)
+            s = s[:p] + _rand_seq(rng, rng.randrange(1, 40)) + s[p:] if rng.random() < 0.5 else s[:p] + s[p + rng.randrange(1, 40):]
+        seqs.append(s)
+    for _ in range(rng.randrange(0, 6)):
+        p = rng.randrange(0, len(g) - k - 20)
+        f = list(g[p:p + rng.randrange(k + 1, k + 45)])
+        q = rng.randrange(len(f))
+        f[q] = rng.choice([c for c in "ACGT" if c != f[q]])
+        seqs.append("".join(f))
+    return rng, g, seqs
+
+
+@pytest.mark.parametrize("k", [31, 21, 13])
+def test_stage_a_fuzz_against_oracle(k):
+    """bubbles, tips, repeats, loops, cut-offs (max_nodes / max_depth), both end rules, several table load factors"""
+    for seed in range(25):
+        rng, g, seqs = _make_case(seed, k)
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k, load_factor=rng.choice([0.3, 0.6, 0.9]))
+        q = np.concatenate([km, np.array([rng.getrandbits(2 * k) for _ in range(200)], dtype=np.uint64)])
+        ab, su, pr = emu.query(q)
+        assert (ab == idx.abundance(q)).all()
+        for _ in range(8):
+            p = rng.randrange(0, len(g) - k)
+            s = g[p:p + k] if rng.random() < 0.5 else _rc(g[p:p + k])
+            tp = rng.randrange(0, len(g) - k)
+            t = g[tp:tp + k] + (g[tp + k:tp + k + rng.randrange(1, 30)] if rng.random() < 0.2 else "")
+            mn, md, er = rng.choice([100, 100, 5, 20]), rng.choice([10000, 10000, 300, 1500]), rng.choice([0, 0, 1])
+            oc, _ = idx.stage_a(s, t, oracle_lib.default_params(max_nodes=mn, max_depth=md, end_rule_nonbranching=er))
+            ec, st, _, _ = emu.stage_a(s, t, mn, md, er)
+            assert st == 0 and ec == oc, (seed, k, s, t, mn, md, er)
+        idx.close()
+        emu.close()
+
+
+def test_scratch_tier_escalation():
+    """a gap that overflows the tier-0 contig arena is re-run in a larger tier with identical contigs"""
+    rng = random.Random(5)
+    g = _rand_seq(rng, 150000)
+    idx = oracle_lib.Index.from_sequences([g], 31, 1, 40)
+    km, ct = idx.export()
+    emu = emu_lib.EmuIndex(km, ct, 31)
+    oc, _ = idx.stage_a(g[:31], g[500:531])
+    ec, st, _, tier = emu.stage_a(g[:31], g[500:531])
+    assert st == 0 and tier >= 1 and ec == oc and len(oc[0]) == 150000
+    _, st0, _, _ = emu.stage_a(g[:31], g[500:531], tier=0)
+    assert st0 == 1  # GAP_OVF_CONTIG reported, never silently truncated
+
+
+@pytest.fixture(scope="module")
+def emu_product():
+    return emu_lib.product_on_emulator()
+
+
+def test_cli_on_emulator_reproduces_goldens(emu_product, golden_dir, tmp_path):
+    d = os.path.join(golden_dir, "data")
+    F = emu_product.Filler()
+    assert F.run(["-in", os.path.join(d, "reads_r1.fastq") + "," + os.path.join(d, "reads_r2.fastq"), "-bkpt", os.path.join(golden_dir, "full_test", "gold.breakpoints"),
+                  "-out", str(tmp_path / "full")]) == 0
+    assert _read(tmp_path / "full.insertions.fasta") == _read(os.path.join(golden_dir, "full_test", "gold.insertions.fasta"))
+    assert _vcf_body(tmp_path / "full.insertions.vcf") == _vcf_body(os.path.join(golden_dir, "full_test", "gold.insertions.vcf"))
+    assert F.run(["-in", os.path.join(d, "contig-reads.fasta.gz"), "-contig", os.path.join(d, "contigs.fasta"), "-abundance-min", "3", "-out", str(tmp_path / "ctg")]) == 0
+    g = os.path.join(golden_dir, "contig_test")
+    assert _read(tmp_path / "ctg.gfa") == _read(os.path.join(g, "gold.gfa"))
+    assert _read(tmp_path / "ctg.insertions.fasta") == _read(os.path.join(g, "gold.insertions.fasta"))
+    assert _read(tmp_path / "ctg_seed_dictionary.fasta") == _read(os.path.join(g, "gold_seed_dictionary.fasta"))
+    assert F.run(["-bkpt", "x"]) == 1 and F.run(["-in", "a"]) == 1 and F.run(["-in", "a", "-graph", "b", "-bkpt", "x"]) == 1
+
+
+def _write_idx(path, km, ct, k=31, amin=3):
+    with open(path, "wb") as f:
+        f.write(b"MTGIDX1\0" + struct.pack("<4i", k, amin, -1, 0) + struct.pack("<Q", len(km)) + km.tobytes() + ct.astype(np.uint32).tobytes())
+
+
+def test_cli_on_emulator_reverse_attempts_and_extensions(emu_product, tmp_path):
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=40, n_sites=30, seed=11)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    bk = str(tmp_path / "rev.breakpoints")
+    with open(bk, "w") as f:
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            if i % 3 == 0:
+                l = ("A" if l[0] != "A" else "C") + l[1:]
+            if i % 3 == 1:
+                l = l[:15] + ("A" if l[15] != "A" else "C") + l[16:]
+            if i % 7 == 3:
+                r = r[:10] + ("A" if r[10] != "A" else "C") + r[11:]
+            f.write(">%s left_kmer\n%s\n>%s right_kmer\n%s\n" % (S.site_name(i), l, S.site_name(i), r))
+    _write_idx(str(tmp_path / "rev.mtgidx"), km, ct)
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"), params=oracle_lib.default_params(extend=1))
+    assert emu_product.Filler().run(["-graph", str(tmp_path / "rev.mtgidx"), "-bkpt", bk, "-out", str(tmp_path / "hip"), "-extend"]) == 0
+    for ext in (".insertions.fasta", ".info.txt", ".extensions.fasta"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    assert _read(str(tmp_path / "hip.insertions.fasta")).count(">") >= 20
+    o.close()
+
+
+def test_cli_on_emulator_bubbly_contig_mode(emu_product, tmp_path):
+    """contig mode on a diploid-like graph (SNP bubbles + tips): multi-solution paths, NW dedupe, GFA order"""
+    rng = random.Random(99)
+    g = _rand_seq(rng, 6000)
+    h = list(g)
+    for p in range(300, 5800, 400):
+        h[p] = rng.choice([c for c in "ACGT" if c != h[p]])
+    h = "".join(h)
+    h = h[:2500] + _rand_seq(rng, 120) + h[2500:]
+    o = oracle_lib.Index.from_sequences([g, h, g[1000:1060] + "A"], 31, 3, 40)
+    km, ct = o.export()
+    contigs = str(tmp_path / "c.fa")
+    with open(contigs, "w") as f:
+        for i, (a, b) in enumerate([(0, 700), (1100, 1900), (2300, 2480), (3100, 3900), (4300, 5200)]):
+            f.write(">ctg%d\n%s\n" % (i + 1, g[a:b]))
+    _write_idx(str(tmp_path / "b.mtgidx"), km, ct)
+    o.fill_files("contig", contigs, str(tmp_path / "cpu"))
+    assert emu_product.Filler().run(["-graph", str(tmp_path / "b.mtgidx"), "-contig", contigs, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt", ".gfa", "_seed_dictionary.fasta"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert "solution" in _read(str(tmp_path / "hip.gfa")) or _read(str(tmp_path / "hip.gfa")).count("\nS\t") > 5
+    o.close()

@@ -1,0 +1,204 @@
+"""Parity tests proper: the HIP path (through the C ABI of include/mtg_fill.h) against the CPU oracle, the committed
+golden files and size-independent properties.  Bit-exact everywhere (integer / byte / text work)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _read(p):
+    with open(p) as f:
+        return f.read()
+
+
+def _vcf_body(p):
+    return [l for l in _read(p).splitlines() if not l.startswith("##")]
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def _fasta(path):
+    recs = []
+    for l in open(path):
+        l = l.rstrip("\n")
+        if l.startswith(">"):
+            recs.append([l[1:], ""])
+        elif recs:
+            recs[-1][1] += l
+    return recs
+
+
+@pytest.fixture(scope="module")
+def mtg():
+    import mindthegap_amd
+    mindthegap_amd.load_library()
+    assert mindthegap_amd.device_count() >= 1, "these tests need a HIP device"
+    return mindthegap_amd
+
+
+@pytest.fixture(scope="module")
+def full_idx(mtg, golden_dir):
+    from tests import oracle_lib
+    d = os.path.join(golden_dir, "data")
+    o = oracle_lib.Index.from_files([os.path.join(d, "reads_r1.fastq"), os.path.join(d, "reads_r2.fastq")], 31, 7)
+    km, ct = o.export()
+    return o, mtg.Index.from_kmers(km, ct, 31), km, ct
+
+
+@pytest.fixture(scope="module")
+def ctg_idx(mtg, golden_dir):
+    from tests import oracle_lib
+    o = oracle_lib.Index.from_files([os.path.join(golden_dir, "data", "contig-reads.fasta.gz")], 31, 3)
+    km, ct = o.export()
+    return o, mtg.Index.from_kmers(km, ct, 31), km, ct
+
+
+def test_index_queries_match_oracle(full_idx):
+    o, g, km, ct = full_idx
+    info = g.info()
+    assert (info["nb_solid_kmers"], info["nb_branching"]) == (7419, 36)  # test/full_test/gold_fill.output:13-14
+    rng = np.random.default_rng(3)
+    M = np.uint64((1 << 62) - 1)
+    succ = ((km[:, None] << np.uint64(2)) & M) | np.arange(4, dtype=np.uint64)[None, :]
+    pred = (km[:, None] >> np.uint64(2)) | (np.arange(4, dtype=np.uint64)[None, :] << np.uint64(60))
+    q = np.concatenate([km, succ.reshape(-1), pred.reshape(-1), rng.integers(0, 1 << 62, 5000, dtype=np.uint64)])
+    assert (g.contains(q) == o.contains(q)).all()
+    assert (g.abundance(q) == o.abundance(q)).all()
+    s, p = g.neighbors(km)
+    es = (o.contains(succ.reshape(-1)).reshape(-1, 4) * (1 << np.arange(4))).sum(1)
+    ep = (o.contains(pred.reshape(-1)).reshape(-1, 4) * (1 << np.arange(4))).sum(1)
+    assert (s == es).all() and (p == ep).all()
+
+
+def test_stage_a_matches_oracle_on_goldens(full_idx, ctg_idx, golden_dir):
+    o, g, _, _ = full_idx
+    recs = _fasta(os.path.join(golden_dir, "full_test", "gold.breakpoints"))
+    src, tgt = [], []
+    for i in range(0, len(recs), 2):
+        src += [recs[i][1], _rc(recs[i + 1][1])]
+        tgt += [recs[i + 1][1], _rc(recs[i][1])]
+    got = g.stage_a(src, tgt)
+    for s, t, c in zip(src, tgt, got):
+        assert c == o.stage_a(s, t)[0]
+    o2, g2, _, _ = ctg_idx
+    seeds = _fasta(os.path.join(golden_dir, "contig_test", "gold_seed_dictionary.fasta"))
+    src = [s for _, s in seeds]
+    tgt = ["ACGT" * 20] * len(src)
+    got = g2.stage_a(src, tgt)
+    assert max(len(c) for c in got) == 22  # multi-contig gaps with tips are exercised
+    for s, t, c in zip(src, tgt, got):
+        assert c == o2.stage_a(s, t)[0]
+
+
+def test_cli_bkpt_mode_equals_golden_and_oracle(mtg, full_idx, golden_dir, tmp_path):
+    d = os.path.join(golden_dir, "data")
+    bk = os.path.join(golden_dir, "full_test", "gold.breakpoints")
+    rc = mtg.Filler().run(["-in", os.path.join(d, "reads_r1.fastq") + "," + os.path.join(d, "reads_r2.fastq"), "-bkpt", bk, "-out", str(tmp_path / "hip")])
+    assert rc == 0
+    assert _read(tmp_path / "hip.insertions.fasta") == _read(os.path.join(golden_dir, "full_test", "gold.insertions.fasta"))
+    assert _vcf_body(tmp_path / "hip.insertions.vcf") == _vcf_body(os.path.join(golden_dir, "full_test", "gold.insertions.vcf"))
+    o = full_idx[0]
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert _read(tmp_path / "hip.info.txt") == _read(tmp_path / "cpu.info.txt")
+    # -graph round trip through the index container written by -in
+    rc = mtg.Filler().run(["-graph", str(tmp_path / "hip.mtgidx"), "-bkpt", bk, "-out", str(tmp_path / "hip2"), "-extend"])
+    assert rc == 0
+    assert _read(tmp_path / "hip2.insertions.fasta") == _read(tmp_path / "hip.insertions.fasta")
+
+
+def test_cli_contig_mode_equals_golden_and_oracle(mtg, ctg_idx, golden_dir, tmp_path):
+    d = os.path.join(golden_dir, "data")
+    g = os.path.join(golden_dir, "contig_test")
+    rc = mtg.Filler().run(["-in", os.path.join(d, "contig-reads.fasta.gz"), "-contig", os.path.join(d, "contigs.fasta"), "-abundance-min", "3", "-out", str(tmp_path / "hip")])
+    assert rc == 0
+    assert _read(tmp_path / "hip.gfa") == _read(os.path.join(g, "gold.gfa"))
+    assert _read(tmp_path / "hip.insertions.fasta") == _read(os.path.join(g, "gold.insertions.fasta"))
+    assert _read(tmp_path / "hip_seed_dictionary.fasta") == _read(os.path.join(g, "gold_seed_dictionary.fasta"))
+    ctg_idx[0].fill_files("contig", os.path.join(d, "contigs.fasta"), str(tmp_path / "cpu"))
+    assert _read(tmp_path / "hip.info.txt") == _read(tmp_path / "cpu.info.txt")
+
+
+def test_cli_errors(mtg, tmp_path):
+    assert mtg.Filler().run(["-bkpt", "x"]) == 1  # -graph xor -in, src/Filler.cpp:140-145
+    assert mtg.Filler().run(["-in", "a", "-graph", "b", "-bkpt", "x"]) == 1
+    assert mtg.Filler().run(["-in", "a"]) == 1  # -bkpt xor -contig, src/Filler.cpp:147-150
+    assert mtg.Filler().run(["-in", "/nonexistent.fq", "-bkpt", "x", "-out", str(tmp_path / "e")]) == 1
+
+
+def test_synthetic_sites_packed_device_index(mtg, tmp_path):
+    """config-2 shaped set at reduced size: device-built index from packed sequences, every site must be filled with exactly
+    its inserted sequence, and files must equal the oracle's byte for byte."""
+    import torch
+    from mindthegap_amd.synth import SynthSet
+    from tests import oracle_lib
+    S = SynthSet(nseq=300, n_sites=200, seed=7)
+    w = torch.from_numpy(S.words.view(np.int64)).cuda()
+    wo = torch.from_numpy(S.word_off.view(np.int64)).cuda()
+    ln = torch.from_numpy(S.lens.view(np.int32)).cuda()
+    g = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 40)
+    seqs = [S.ascii(j) for j in range(S.nseq)]
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    assert g.info()["nb_solid_kmers"] == len(o)
+    gaps = []
+    for i in range(S.n_sites):
+        l, r, _ = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+    res = g.fill_batch(gaps)
+    for i, r in enumerate(res):
+        assert len(r["filled"]) == 1 and r["filled"][0]["seq"] == S.site(i)[2] and r["filled"][0]["qual"] == 50
+    bk = str(tmp_path / "syn.breakpoints")
+    S.write_breakpoints(bk)
+    idxf = str(tmp_path / "syn.mtgidx")
+    km, ct = o.export()
+    g2 = mtg.Index.from_kmers(km, ct, 31)
+    # same graph through the k-mer list path and the CLI
+    import ctypes as C
+    g2.lib.mtg_index_save.argtypes  # noqa
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    # write an index container for the CLI
+    import struct
+    with open(idxf, "wb") as f:
+        f.write(b"MTGIDX1\0" + struct.pack("<4i", 31, 3, -1, 0) + struct.pack("<Q", len(km)) + km.tobytes() + np.minimum(ct, 255).astype(np.uint32).tobytes())
+    assert mtg.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext)
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    g.close(); g2.close(); o.close()
+
+
+def test_reverse_attempt_and_unfillable(mtg, tmp_path):
+    """sites whose forward source k-mer is absent from the graph are rescued by the reverse attempt (src/Filler.cpp:669-680);
+    sites with neither anchor produce no sequence; both must match the oracle byte for byte."""
+    from mindthegap_amd.synth import SynthSet
+    from tests import oracle_lib
+    S = SynthSet(nseq=40, n_sites=30, seed=11)
+    seqs = [S.ascii(j) for j in range(S.nseq)]
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    g = mtg.Index.from_kmers(km, ct, 31)
+    bk = str(tmp_path / "rev.breakpoints")
+    with open(bk, "w") as f:
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            if i % 3 == 0:  # break the left anchor's first base: forward start is not solid but may still extend
+                l = ("A" if l[0] != "A" else "C") + l[1:]
+            if i % 3 == 1:  # break the left anchor in the middle: forward fails, reverse succeeds
+                l = l[:15] + ("A" if l[15] != "A" else "C") + l[16:]
+            if i % 7 == 3:  # mismatch inside the right anchor (within nb_mis_allowed)
+                r = r[:10] + ("A" if r[10] != "A" else "C") + r[11:]
+            f.write(">%s left_kmer\n%s\n>%s right_kmer\n%s\n" % (S.site_name(i), l, S.site_name(i), r))
+    import struct
+    idxf = str(tmp_path / "rev.mtgidx")
+    with open(idxf, "wb") as fh:
+        fh.write(b"MTGIDX1\0" + struct.pack("<4i", 31, 3, -1, 0) + struct.pack("<Q", len(km)) + km.tobytes() + ct.astype(np.uint32).tobytes())
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"), params=oracle_lib.default_params(extend=1))
+    assert mtg.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "hip"), "-extend"]) == 0
+    for ext in (".insertions.fasta", ".info.txt", ".extensions.fasta"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    assert ">" in _read(str(tmp_path / "hip.insertions.fasta"))
+    g.close(); o.close()
