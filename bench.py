@@ -31,8 +31,8 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny"])
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the workload's)")
     ap.add_argument("--nseq", type=int, default=0)
-    ap.add_argument("--cpu-sites", type=int, default=3000, help="sites of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-index-seqs", type=int, default=12000, help="donor sequences in the CPU baseline's index")
+    ap.add_argument("--cpu-sites", type=int, default=60000, help="sites of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-index-seqs", type=int, default=60000, help="donor sequences in the CPU baseline's index")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the random-64B-line ceiling micro-benchmark")
     return ap.parse_args()
 
@@ -176,8 +176,9 @@ def main():
             S.write_breakpoints(bk, range(ns))
             ost = oidx.fill_files("bkpt", bk, os.path.join(d, "cpu"), params=oracle_lib.default_params(nb_cores=cores))
             cpu_fa = open(os.path.join(d, "cpu.insertions.fasta")).read()
-        cpu_seqs = "".join(l + "\n" for l in cpu_fa.splitlines() if not l.startswith(">"))
-        hip_seqs = "".join(e + "\n" for e in expected[:ns])
+        # the oracle's worker threads write records in completion order: compare as multisets
+        cpu_seqs = sorted(l for l in cpu_fa.splitlines() if not l.startswith(">"))
+        hip_seqs = sorted(expected[:ns])
         # algorithmic probes per contig nucleotide, counted by the oracle on the sample
         sample_nt = sum(S.seq_len + int(S.ins_len[i]) - int(S.pos[i]) + k for i in range(ns))
         probes_per_nt = ost["probes"] / max(sample_nt, 1)

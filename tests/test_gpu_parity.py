@@ -34,6 +34,8 @@ def _fasta(path):
 
 @pytest.fixture(scope="module")
 def mtg():
+    import torch
+    torch.cuda.init()  # torch bundles its own HIP runtime: initialise it before libmtgfill.so touches the device
     import mindthegap_amd
     mindthegap_amd.load_library()
     assert mindthegap_amd.device_count() >= 1, "these tests need a HIP device"
