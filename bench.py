@@ -31,8 +31,8 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny"])
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the workload's)")
     ap.add_argument("--nseq", type=int, default=0)
-    ap.add_argument("--cpu-sites", type=int, default=60000, help="sites of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-index-seqs", type=int, default=60000, help="donor sequences in the CPU baseline's index")
+    ap.add_argument("--cpu-sites", type=int, default=30000, help="sites of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-index-seqs", type=int, default=30000, help="donor sequences in the CPU baseline's index")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the random-64B-line ceiling micro-benchmark")
     return ap.parse_args()
 
@@ -101,9 +101,15 @@ def main():
 
     def step():
         """forward attempt for every site, reverse attempt (src/Filler.cpp:669-680) for the unfilled ones"""
+        tp0 = time.perf_counter()
         h, nf, seqs = idx.fill_prepared(prepared, params)
         st = mtg.last_batch_stats()
+        tp1 = time.perf_counter()
         idx.free_results(h)
+        if os.environ.get("MTG_BENCH_DEBUG"):
+            sys.stderr.write("step: fill_prepared %.1f ms (C total %.1f: marshal %.1f kernel %.1f post %.1f h2d %.1f d2h %.1f host %.1f result %.1f) free %.1f ms\n" % (
+                (tp1 - tp0) * 1e3, st["total_ms"], st["marshal_ms"], st["kernel_ms"], st["post_kernel_ms"], st["h2d_ms"], st["d2h_ms"], st["host_ms"], st["result_ms"],
+                (time.perf_counter() - tp1) * 1e3))
         unfilled = np.nonzero(nf == 0)[0]
         n_filled = int((nf > 0).sum())
         if len(unfilled):
@@ -112,7 +118,7 @@ def main():
             st2 = mtg.last_batch_stats()
             idx.free_results(h2)
             n_filled += int((nf2 > 0).sum())
-            for key in ("kernel_ms", "h2d_ms", "d2h_ms", "host_ms", "index_lines", "n_launches", "contig_nt"):
+            for key in ("kernel_ms", "post_kernel_ms", "h2d_ms", "d2h_ms", "host_ms", "index_lines", "n_launches", "contig_nt"):
                 st[key] += st2[key]
         if world > 1:  # results gathered on rank 0 over RCCL / xGMI (sizes, then padded payloads)
             payload = torch.frombuffer(bytearray(seqs), dtype=torch.uint8).to(dev)
@@ -135,12 +141,12 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = lines = contig_nt = launches = host_ms = d2h_ms = 0
+    kernel_ms = lines = contig_nt = launches = host_ms = d2h_ms = post_ms = 0
     n_filled, seqs = 0, b""
     for _ in range(a.steps):
         n_filled, seqs, st = step()
         kernel_ms += st["kernel_ms"]; lines += st["index_lines"]; contig_nt += st["contig_nt"]; launches += st["n_launches"]
-        host_ms += st["host_ms"]; d2h_ms += st["d2h_ms"]
+        host_ms += st["host_ms"]; d2h_ms += st["d2h_ms"]; post_ms += st["post_kernel_ms"]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -208,7 +214,7 @@ def main():
                       "index": "exact k-mer set of the donor, abundance = 3 + hash %% 40 (no reads simulated)", "nb_solid_kmers": int(info["nb_solid_kmers"]),
                       "index_bytes": int(info["device_bytes"]), "index_build_s": t_index, "genome_gen_s": t_gen},
            "filled": n_filled_all, "filled_sequences_identical_to_truth": bool(identical),
-           "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps},
+           "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "post_kernel": post_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps},
            "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:

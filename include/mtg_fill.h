@@ -139,9 +139,11 @@ void mtg_contigs_free(mtg_contigs* c);
 
 /* timings / counters of the last fill or stage-A batch on this thread */
 typedef struct mtg_batch_stats {
-    double kernel_ms;            /* HIP-event time of the traversal kernel launches (sum over tiers / attempts) */
+    double kernel_ms;            /* HIP-event time of the traversal kernel (k_stage_a) launches (sum over tiers / attempts) */
+    double post_kernel_ms;       /* HIP-event time of the terminal-search / coverage kernel (k_post) */
     double total_ms;             /* wall time of the whole call */
     double h2d_ms, d2h_ms, host_ms;
+    double marshal_ms, result_ms; /* mtg_fill_batch only: argument marshalling and result-arena construction */
     uint64_t index_lines;        /* 64-byte index lines the kernels actually read */
     uint64_t n_launches;
     uint64_t n_retried_gaps;     /* gaps re-run in a larger scratch tier */

@@ -5,7 +5,9 @@
  *   k_query                          : batched contains / queryAbundance / successors / predecessors
  *   k_stage_a                        : breadth-first contig construction of one gap per lane
  *                                      (IterativeExtensions::construct_linear_seqs, src/Filler.cpp:884)
- *   k_compact                        : gathers the contigs of a chunk into a dense arena for the copy back
+ *   k_post                           : terminal-node search per contig + coverage of the single-contig solution, one wave per gap
+ *                                      (find_nodes_containing_multiple_R, src/Filler.cpp:1294-1378; coverage :959-988)
+ *   k_compact                        : gathers what the host needs from a chunk into dense arrays for the copy back
  *   k_chase                          : dependent random 64-byte reads (measured roofline ceiling)
  */
 #include "mtg_internal.h"
@@ -156,24 +158,57 @@ __global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* 
     out[slot] = o;
 }
 
-/* dense copy of the contigs of a chunk: words, then (start,len) pairs per contig */
-__global__ void k_compact(FillCfg cfg, const uint8_t* raw, const GapOut* __restrict__ outs, const uint64_t* __restrict__ word_base,
-                          const uint64_t* __restrict__ contig_base, uint64_t* dense_words, uint32_t* dense_len, uint32_t* dense_start, uint32_t n)
+/* terminal search for every contig + coverage of the common single-contig solution: one wave per gap */
+__global__ void __launch_bounds__(64) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
+                                             const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
+                                             const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
+                                             PostOut* post, uint32_t n)
+{
+    __shared__ uint32_t hist[256];
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    for (uint32_t i = threadIdx.x; i < 256; i += 64) hist[i] = 0;
+    __syncthreads();
+    const GapOut o = outs[slot];
+    PostOut po;
+    po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = 0;
+    if (o.status == GAP_OK) {
+        const uint32_t g = ids ? ids[slot] : slot;
+        GapScratch S;
+        S.z = nullptr;
+        S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        PostTargets T;
+        T.le = tle + toff[g];
+        T.bad = tbad + toff[g];
+        T.n = tcnt[g];
+        T.nb_mis = nbmis[g];
+        T.fast_ok = fast_ok[g];
+        post_gap(ix, cfg, S, o, T, hist, po);
+    }
+    if (threadIdx.x == 0) post[slot] = po;
+}
+
+/* dense copy of what the host needs from a chunk: nw leading arena words per gap, and for nc contigs their
+ * (len, start) and terminal info */
+__global__ void k_compact(FillCfg cfg, const uint8_t* raw, const uint32_t* __restrict__ nw, const uint32_t* __restrict__ nc,
+                          const uint64_t* __restrict__ word_base, const uint64_t* __restrict__ contig_base, uint64_t* dense_words, uint32_t* dense_meta,
+                          uint64_t meta_stride, uint32_t n)
 {
     for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
-        const GapOut o = outs[slot];
-        if (o.status != GAP_OK) continue;
         GapScratch S;
         S.z = nullptr;
         S.r = const_cast<uint8_t*>(raw) + (uint64_t)slot * cfg.raw_stride;
         const uint64_t* w = s_words(cfg, S);
         uint64_t* dw = dense_words + word_base[slot];
-        for (uint32_t i = threadIdx.x; i < o.n_words; i += blockDim.x) dw[i] = w[i];
-        const uint32_t* cs = s_cstart(cfg, S);
-        const uint32_t* cl = s_clen(cfg, S);
-        for (uint32_t i = threadIdx.x; i < o.n_contigs; i += blockDim.x) {
-            dense_len[contig_base[slot] + i] = cl[i];
-            dense_start[contig_base[slot] + i] = cs[i];
+        const uint32_t nwords = nw[slot], ncont = nc[slot];
+        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) dw[i] = w[i];
+        const uint64_t cb = contig_base[slot];
+        for (uint32_t i = threadIdx.x; i < ncont; i += blockDim.x) {
+            dense_meta[cb + i] = s_clen(cfg, S)[i];
+            dense_meta[meta_stride + cb + i] = s_cstart(cfg, S)[i];
+            dense_meta[2 * meta_stride + cb + i] = s_tpos(cfg, S)[i];
+            dense_meta[3 * meta_stride + cb + i] = s_terr(cfg, S)[i];
+            dense_meta[4 * meta_stride + cb + i] = s_ttgt(cfg, S)[i];
         }
     }
 }
@@ -355,19 +390,7 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
     return MTG_OK;
 }
 
-/* ------------------------------------------------------------------------------------------------ stage A */
-void StageAInput::add(const char* source, const char* target, int k)
-{
-    src.push_back(encode_kmer(source, k));
-    const size_t rl = strlen(target);
-    std::vector<uint64_t> w;
-    pack_seq(target, rl, w);
-    roff.push_back((uint32_t)rwords.size());
-    rwords.insert(rwords.end(), w.begin(), w.end());
-    rlen.push_back((uint32_t)rl);
-    r0.push_back(rl >= (size_t)k ? encode_kmer(target, k) : 0);
-}
-
+/* ------------------------------------------------------------------------------------------------ fill batches */
 namespace {
 struct DevBuf {
     void* p = nullptr;
@@ -376,31 +399,34 @@ struct DevBuf {
     template <typename T> T* as() { return (T*)p; }
 };
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+template <typename T> hipError_t upload(DevBuf& b, const std::vector<T>& v)
+{
+    hipError_t e = b.alloc(v.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return v.empty() ? hipSuccess : hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
 } // namespace
 
-int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in, std::vector<GapContigs>& out, mtg_batch_stats* stats)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, std::vector<GapDev>& out, mtg_batch_stats* stats)
 {
     if (int rc = ensure_device()) return rc;
     const size_t n = in.src.size();
-    out.assign(n, GapContigs());
-    mtg_batch_stats st{};
-    const double t_begin = now_ms();
+    out.assign(n, GapDev());
+    mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     if (n == 0) { if (stats) *stats = st; return MTG_OK; }
     const int k = idx->dev.k;
 
-    DevBuf d_src, d_rw, d_roff, d_rlen, d_r0;
+    DevBuf d_src, d_rw, d_roff, d_rlen, d_r0, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok;
     double t0 = now_ms();
-    HIP_TRY(d_src.alloc(n * 8)); HIP_TRY(d_rw.alloc(in.rwords.size() * 8)); HIP_TRY(d_roff.alloc(n * 4)); HIP_TRY(d_rlen.alloc(n * 4)); HIP_TRY(d_r0.alloc(n * 8));
-    HIP_TRY(hipMemcpy(d_src.p, in.src.data(), n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_rw.p, in.rwords.data(), in.rwords.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_roff.p, in.roff.data(), n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_rlen.p, in.rlen.data(), n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_r0.p, in.r0.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(upload(d_src, in.src)); HIP_TRY(upload(d_rw, in.rwords)); HIP_TRY(upload(d_roff, in.roff)); HIP_TRY(upload(d_rlen, in.rlen));
+    HIP_TRY(upload(d_r0, in.r0)); HIP_TRY(upload(d_tle, in.tle)); HIP_TRY(upload(d_tbad, in.tbad)); HIP_TRY(upload(d_toff, in.toff));
+    HIP_TRY(upload(d_tcnt, in.tcnt)); HIP_TRY(upload(d_mis, in.nbmis)); HIP_TRY(upload(d_fok, in.fast_ok));
     st.h2d_ms += now_ms() - t0;
 
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0, ev1, ev2;
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventCreate(&ev2));
 
     std::vector<uint32_t> todo(n);
     for (size_t i = 0; i < n; i++) todo[i] = (uint32_t)i;
@@ -410,18 +436,22 @@ int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + sizeof(GapOut) + 64;
+        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + sizeof(GapOut) + sizeof(PostOut) + 64;
         size_t chunk = (size_t)((double)free_b * 0.6 / (double)per_gap);
         if (chunk > todo.size()) chunk = todo.size();
         if (chunk > (1u << 20)) chunk = 1u << 20;
         if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }
-        DevBuf d_zero, d_raw, d_out, d_ids;
+        DevBuf d_zero, d_raw, d_out, d_post, d_ids, d_nw, d_nc, d_wb, d_cb;
         HIP_TRY(d_zero.alloc(chunk * cfg.zero_stride));
-        HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride));
+        HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
-        HIP_TRY(d_ids.alloc(chunk * 4));
+        HIP_TRY(d_post.alloc(chunk * sizeof(PostOut)));
+        HIP_TRY(d_ids.alloc(chunk * 4)); HIP_TRY(d_nw.alloc(chunk * 4)); HIP_TRY(d_nc.alloc(chunk * 4)); HIP_TRY(d_wb.alloc(chunk * 8)); HIP_TRY(d_cb.alloc(chunk * 8));
         std::vector<uint32_t> retry;
         std::vector<GapOut> h_out(chunk);
+        std::vector<PostOut> h_post(chunk);
+        std::vector<uint32_t> nw(chunk), nc(chunk);
+        std::vector<uint64_t> wbase(chunk), cbase(chunk);
         for (size_t base = 0; base < todo.size(); base += chunk) {
             const uint32_t m = (uint32_t)std::min(chunk, todo.size() - base);
             t0 = now_ms();
@@ -433,58 +463,74 @@ int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in
                                d_rw.as<uint64_t>(), d_roff.as<uint32_t>(), d_rlen.as<uint32_t>(), d_r0.as<uint64_t>(), d_ids.as<uint32_t>(),
                                d_out.as<GapOut>(), m);
             HIP_TRY(hipEventRecord(ev1, 0));
+            hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_ids.as<uint32_t>(), d_tle.as<uint64_t>(),
+                               d_tbad.as<uint64_t>(), d_toff.as<uint32_t>(), d_tcnt.as<uint32_t>(), d_mis.as<uint8_t>(), d_fok.as<uint8_t>(), d_post.as<PostOut>(), m);
+            HIP_TRY(hipEventRecord(ev2, 0));
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventSynchronize(ev1));
-            float ms = 0;
+            HIP_TRY(hipEventSynchronize(ev2));
+            float ms = 0, ms2 = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+            HIP_TRY(hipEventElapsedTime(&ms2, ev1, ev2));
             st.kernel_ms += ms;
+            st.post_kernel_ms += ms2;
             st.n_launches++;
             t0 = now_ms();
             HIP_TRY(hipMemcpy(h_out.data(), d_out.p, (size_t)m * sizeof(GapOut), hipMemcpyDeviceToHost));
-            /* dense copy back */
-            std::vector<uint64_t> wbase(m), cbase(m);
-            uint64_t nw = 0, nc = 0;
+            HIP_TRY(hipMemcpy(h_post.data(), d_post.p, (size_t)m * sizeof(PostOut), hipMemcpyDeviceToHost));
+            uint64_t tw = 0, tc = 0;
             for (uint32_t s = 0; s < m; s++) {
-                wbase[s] = nw; cbase[s] = nc;
                 st.index_lines += h_out[s].lines;
-                if (h_out[s].status == GAP_OK) { nw += h_out[s].n_words; nc += h_out[s].n_contigs; }
-                else retry.push_back(todo[base + s]);
+                copy_plan(h_out[s], h_post[s], in.want_all_contigs, nw[s], nc[s]);
+                wbase[s] = tw; cbase[s] = tc;
+                tw += nw[s]; tc += nc[s];
+                if (h_out[s].status != GAP_OK) retry.push_back(todo[base + s]);
             }
-            DevBuf d_wb, d_cb, d_dw, d_dl, d_ds;
-            HIP_TRY(d_wb.alloc((size_t)m * 8)); HIP_TRY(d_cb.alloc((size_t)m * 8)); HIP_TRY(d_dw.alloc(nw * 8)); HIP_TRY(d_dl.alloc(nc * 4)); HIP_TRY(d_ds.alloc(nc * 4));
+            DevBuf d_dw, d_dm;
+            HIP_TRY(d_dw.alloc(tw * 8)); HIP_TRY(d_dm.alloc(tc * 5 * 4));
+            HIP_TRY(hipMemcpy(d_nw.p, nw.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_nc.p, nc.data(), (size_t)m * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_wb.p, wbase.data(), (size_t)m * 8, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_cb.p, cbase.data(), (size_t)m * 8, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_compact, dim3(std::min<uint32_t>(m, 256 * 16)), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_wb.as<uint64_t>(),
-                               d_cb.as<uint64_t>(), d_dw.as<uint64_t>(), d_dl.as<uint32_t>(), d_ds.as<uint32_t>(), m);
+            hipLaunchKernelGGL(k_compact, dim3(std::min<uint32_t>(m, 256 * 16)), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_nw.as<uint32_t>(), d_nc.as<uint32_t>(),
+                               d_wb.as<uint64_t>(), d_cb.as<uint64_t>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), tc, m);
             HIP_TRY(hipGetLastError());
-            std::vector<uint64_t> hw(nw);
-            std::vector<uint32_t> hl(nc), hs(nc);
-            HIP_TRY(hipMemcpy(hw.data(), d_dw.p, nw * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(hl.data(), d_dl.p, nc * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(hs.data(), d_ds.p, nc * 4, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> hw(tw);
+            std::vector<uint32_t> hm(tc * 5);
+            if (tw) HIP_TRY(hipMemcpy(hw.data(), d_dw.p, tw * 8, hipMemcpyDeviceToHost));
+            if (tc) HIP_TRY(hipMemcpy(hm.data(), d_dm.p, tc * 5 * 4, hipMemcpyDeviceToHost));
             st.d2h_ms += now_ms() - t0;
+            t0 = now_ms();
             for (uint32_t s = 0; s < m; s++) {
                 if (h_out[s].status != GAP_OK) continue;
-                GapContigs& gc = out[todo[base + s]];
-                gc.n_contigs = h_out[s].n_contigs;
-                gc.total_nt = h_out[s].total_nt;
-                gc.words.assign(hw.begin() + wbase[s], hw.begin() + wbase[s] + h_out[s].n_words);
-                gc.words.push_back(0);
-                gc.len.assign(hl.begin() + cbase[s], hl.begin() + cbase[s] + gc.n_contigs);
-                gc.word_start.assign(hs.begin() + cbase[s], hs.begin() + cbase[s] + gc.n_contigs);
-                st.contig_nt += gc.total_nt;
+                GapDev& gd = out[todo[base + s]];
+                gd.o = h_out[s];
+                gd.p = h_post[s];
+                gd.n_meta = nc[s];
+                gd.words.resize((size_t)nw[s] + 1);
+                if (nw[s]) memcpy(gd.words.data(), hw.data() + wbase[s], (size_t)nw[s] * 8);
+                gd.words[nw[s]] = 0;
+                if (nc[s]) {
+                    const uint32_t* b0 = hm.data() + cbase[s];
+                    gd.len.assign(b0, b0 + nc[s]);
+                    gd.word_start.assign(b0 + tc, b0 + tc + nc[s]);
+                    gd.tpos.assign(b0 + 2 * tc, b0 + 2 * tc + nc[s]);
+                    gd.terr.assign(b0 + 3 * tc, b0 + 3 * tc + nc[s]);
+                    gd.ttgt.assign(b0 + 4 * tc, b0 + 4 * tc + nc[s]);
+                }
+                st.contig_nt += gd.o.total_nt;
             }
+            st.host_ms += now_ms() - t0;
         }
         if (tier > 0) st.n_retried_gaps += todo.size();
         todo.swap(retry);
     }
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
+    (void)hipEventDestroy(ev2);
     if (rc == MTG_OK && !todo.empty()) {
         set_error("%zu gap(s) exceeded the largest traversal scratch tier", todo.size());
         rc = MTG_ERR_OVERFLOW;
     }
-    st.total_ms = now_ms() - t_begin;
     if (stats) *stats = st;
     return rc;
 }

@@ -237,61 +237,47 @@ struct TermInfo { /* info_node_t, src/Filler.hpp:44-71 */
     int node, pos, errors, target;
 };
 
-static inline int identNT(char a, char b) { return ((a == b || a - b == 32 || a - b == -32) && a != 'N'); }
-
-static void prepare_target(Target& t, int k)
+/* marshals one gapFillFromSource call.  targets == nullptr: contigs only (stage A parity entry) */
+void FillInput::add(const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis)
 {
-    t.usable = (int)t.seq.size() >= k;
-    t.code = 0;
-    t.badmask = 0;
-    if (!t.usable) return;
-    for (int i = 0; i < k; i++) {
-        unsigned char c = (unsigned char)t.seq[i];
-        t.code = (t.code << 2) | nt_code(c);
-        t.badmask <<= 2;
-        unsigned char u = c & 0xDF;
-        if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) t.badmask |= 1;
-    }
-}
-
-/* Filler::find_nodes_containing_multiple_R (src/Filler.cpp:1294-1378): at most one info per contig; best_match is
- * not reset between positions (:1327); strict improvement (:1341); an exact match ends the contig (:1348-1351). */
-static void find_terminal_nodes(const GapContigs& gc, const std::vector<Target>& targets, int k, int nb_mis, std::vector<TermInfo>& out)
-{
-    const uint64_t mk = kmask(k);
-    const uint64_t lsb = 0x5555555555555555ULL & mk;
-    for (uint32_t c = 0; c < gc.n_contigs; c++) {
-        const uint64_t* w = gc.words.data() + gc.word_start[c];
-        const uint32_t L = gc.len[c];
-        if (L < (uint32_t)k) continue;
-        int best = 0, best_t = -1, position = 0;
-        bool stop = false;
-        uint64_t f = 0;
-        for (uint32_t i = 0; i < L && !stop; i++) {
-            f = ((f << 2) | ((w[i >> 5] >> (2 * (i & 31))) & 3ull)) & mk;
-            if (i + 1 < (uint32_t)k) continue;
-            const uint32_t j = i + 1 - k;
-            for (size_t t = 0; t < targets.size(); t++) {
-                const Target& T = targets[t];
-                if (!T.usable) continue; /* reading past a shorter anchor is undefined in the reference */
-                const uint64_t x = f ^ T.code;
-                const uint64_t mism = ((x | (x >> 1)) & lsb) | T.badmask;
-                const int nbmatch = k - __builtin_popcountll(mism);
-                if (nbmatch > best && nbmatch >= k - nb_mis) {
-                    best = nbmatch; best_t = (int)t; position = (int)j;
-                    if (nbmatch == k) { stop = true; break; }
+    src.push_back(encode_kmer(source.c_str(), k));
+    const size_t rl = swf_target.size();
+    roff.push_back((uint32_t)rwords.size());
+    const size_t w0 = rwords.size();
+    rwords.resize(w0 + (rl + 31) / 32 + 1, 0);
+    for (size_t i = 0; i < rl; i++) rwords[w0 + (i >> 5)] |= (uint64_t)nt_code((unsigned char)swf_target[i]) << (2 * (i & 31));
+    rlen.push_back((uint32_t)rl);
+    r0.push_back(rl >= (size_t)k ? encode_kmer(swf_target.c_str(), k) : 0);
+    toff.push_back((uint32_t)tle.size());
+    uint32_t nt = 0;
+    if (targets)
+        for (const Target& t : *targets) {
+            /* identNT (src/Utils.cpp:81-84) is case-insensitive equality: compare 2-bit codes and force a mismatch where the anchor
+             * character is not a nucleotide; an anchor shorter than k can never be matched */
+            uint64_t le = 0, bad = 0;
+            if ((int)t.seq.size() < k) bad = ~0ull;
+            else
+                for (int i = 0; i < k; i++) {
+                    const unsigned char c = (unsigned char)t.seq[i], u = c & 0xDF;
+                    le |= (uint64_t)nt_code(c) << (2 * i);
+                    if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad |= 1ull << (2 * i);
                 }
-            }
+            tle.push_back(le);
+            tbad.push_back(bad & (0x5555555555555555ULL & kmask(k)));
+            nt++;
         }
-        if (best != 0) out.push_back(TermInfo{(int)c, position, k - best, best_t});
-    }
+    tcnt.push_back(nt);
+    nbmis.push_back((uint8_t)nb_mis);
+    bool ok = (int)source.size() == k;
+    for (unsigned char c : source) ok = ok && !nt_bad(c);
+    fast_ok.push_back(ok ? 1 : 0);
 }
 
 struct ContigGraph {
     std::vector<std::vector<int>> in_edges; /* ascending, unique (std::set order of src/GraphAnalysis.cpp:110) */
-    ContigGraph(const GapContigs& gc, int k)
+    ContigGraph(const GapDev& gc, int k)
     {
-        const uint32_t n = gc.n_contigs;
+        const uint32_t n = gc.o.n_contigs;
         in_edges.resize(n);
         const uint64_t mk1 = kmask(k - 1);
         auto kmer_at = [&](uint32_t c, uint32_t start) {
@@ -371,20 +357,40 @@ static float nw_identity(const std::string& a, const std::string& b)
     return identity;
 }
 
-/* everything after stage A for one gapFillFromSource call, except the coverage numbers */
-static void process_gap(const GapContigs& gc, GapWork& W, int k, int nb_mis_allowed)
+/* everything after the device kernels for one gapFillFromSource call, except the coverage numbers of the general path */
+static void process_gap(const GapDev& gc, GapWork& W, int k)
 {
-    W.nb_nodes = (int)gc.n_contigs;
-    W.total_nt = (int)gc.total_nt;
-    const int nb_mis = W.anchor_repeated ? 0 : nb_mis_allowed; /* src/Filler.cpp:859-863 */
-    std::vector<TermInfo> terms;
-    find_terminal_nodes(gc, W.targets, k, nb_mis, terms);
-    W.nb_terminal = (int)terms.size();
-    if (terms.empty()) { /* get_first_contig, src/Filler.cpp:1381-1407 */
+    W.nb_nodes = (int)gc.o.n_contigs;
+    W.total_nt = (int)gc.o.total_nt;
+    W.nb_terminal = (int)gc.p.nb_terminal;
+    if (gc.p.nb_terminal == 0) { /* get_first_contig, src/Filler.cpp:1381-1407 */
         W.extension.clear();
-        if (gc.n_contigs > 0 && (int)gc.len[0] > k) W.extension = gc.contig(0).substr(k);
+        if (gc.o.n_contigs > 0 && (int)gc.p.clen0 > k) W.extension = gc.contig0_slice((uint32_t)k, gc.p.clen0);
         return;
     }
+    if (gc.p.fast == 2) { W.has_counts = W.reverse; return; } /* target at the very start of contig 0: empty fill */
+    if (gc.p.fast == 1) {
+        /* terminal node 0: find_all_paths_rev returns the single path [0] (src/GraphAnalysis.cpp:222-226) and
+         * paths_to_sequences keeps contig0[k:pos] (:386-423); coverage was computed on the device */
+        Solution s;
+        s.seq = gc.contig0_slice((uint32_t)k, gc.p.pos);
+        s.nb_errors = (int)gc.p.errors;
+        s.target = (int)gc.p.target;
+        s.count = 1;
+        s.rank = 1;
+        const uint64_t sum = gc.p.ab_sum;
+        s.avg = sum / (float)gc.p.ab_n;
+        s.median = (float)((gc.p.ab_n % 2 == 1) ? (double)gc.p.med_hi : 0.5 * (gc.p.med_hi + gc.p.med_lo));
+        s.ab_n = 0; /* no host-side coverage query needed */
+        s.qual = -1;
+        W.sols.push_back(std::move(s));
+        W.nb_total_filled = 1;
+        W.has_counts = true;
+        return;
+    }
+    std::vector<TermInfo> terms;
+    for (uint32_t c = 0; c < gc.o.n_contigs; c++)
+        if (gc.tpos[c] != 0xFFFFFFFFu) terms.push_back(TermInfo{(int)c, (int)gc.tpos[c], (int)gc.terr[c], (int)gc.ttgt[c]});
     ContigGraph graph(gc, k);
     /* find_all_paths_rev wrapper, src/GraphAnalysis.cpp:205-237.  The reference keeps set<pair<path, bkpt_t>>; paths
      * reaching different targets end in different nodes, so ordering by (path, target index) gives the same sequence. */
@@ -407,8 +413,8 @@ static void process_gap(const GapContigs& gc, GapWork& W, int k, int nb_mis_allo
         if (W.targets[pr.second].is_rc) key += "_Rc";
         paths_to_compare[key].insert(pr.first);
     }
-    std::vector<std::string> node_seq(gc.n_contigs);
-    std::vector<char> have(gc.n_contigs, 0);
+    std::vector<std::string> node_seq(gc.o.n_contigs);
+    std::vector<char> have(gc.o.n_contigs, 0);
     auto node = [&](int i) -> const std::string& { if (!have[i]) { node_seq[i] = gc.contig(i); have[i] = 1; } return node_seq[i]; };
     const size_t K = (size_t)k;
     for (auto it = paths_to_compare.begin(); it != paths_to_compare.end(); ++it) {
@@ -452,7 +458,7 @@ static void process_gap(const GapContigs& gc, GapWork& W, int k, int nb_mis_allo
             tmp.swap(fin);
         }
         int rank = 1;
-        for (auto& s : tmp) { s.count = (int)tmp.size(); s.rank = rank++; W.sols.push_back(std::move(s)); }
+        for (auto& s : tmp) { s.count = (int)tmp.size(); s.rank = rank++; s.ab_n = 1; W.sols.push_back(std::move(s)); }
     }
     W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
 }
@@ -496,23 +502,25 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     const int k = idx->dev.k;
     const size_t n = gaps.size();
     const double t_begin = now_ms();
-    StageAInput in;
+    FillInput in;
+    in.k = k;
     for (size_t i = 0; i < n; i++) {
         if ((int)gaps[i].source.size() < k) { set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
-        in.add(gaps[i].source.c_str(), swf_targets[i].c_str(), k);
+        in.add(gaps[i].source, swf_targets[i], &gaps[i].targets, gaps[i].anchor_repeated ? 0 : p->nb_mis_allowed); /* src/Filler.cpp:859-863 */
     }
-    std::vector<GapContigs> contigs;
     mtg_batch_stats st{};
-    int rc = stage_a_run(idx, p, in, contigs, &st);
+    st.host_ms = now_ms() - t_begin;
+    std::vector<GapDev> dev;
+    int rc = device_run(idx, p, in, dev, &st);
     if (rc) return rc;
     double t0 = now_ms();
-    for (auto& g : gaps) for (auto& t : g.targets) prepare_target(t, k);
-    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(contigs[i], gaps[i], k, p->nb_mis_allowed); });
-    /* coverage: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
+    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k); });
+    /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);
     for (auto& g : gaps)
         for (auto& s : g.sols) {
+            if (s.ab_n == 0) continue; /* computed on the device */
             s.ab_off = q.size();
             uint64_t f = 0;
             int valid = 0;
@@ -526,6 +534,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
             feed(g.source);
             feed(s.seq);
             s.ab_n = q.size() - s.ab_off;
+            s.qual = -2;
         }
     st.host_ms += now_ms() - t0;
     std::vector<uint32_t> ab(q.size());
@@ -537,14 +546,22 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     parallel_for(n, p->nb_host_threads, [&](size_t i) {
         GapWork& g = gaps[i];
         for (auto& s : g.sols) {
-            std::vector<unsigned int> v(ab.begin() + s.ab_off, ab.begin() + s.ab_off + s.ab_n);
-            uint64_t sum = 0;
-            for (size_t j = 0; j < v.size(); j++) {
-                if (v[j] == 0) fprintf(stderr, "WARNING Unknown kmer : %s\n", [&] { std::string d; uint64_t c = q[s.ab_off + j]; uint64_t r = revcomp(c, k); c = c < r ? c : r; std::vector<uint64_t> w(2, 0); for (int t = 0; t < k; t++) w[t >> 5] |= ((c >> (2 * (k - 1 - t))) & 3ull) << (2 * (t & 31)); unpack_seq(w.data(), (uint32_t)k, d); return d; }().c_str());
-                sum += v[j];
+            if (s.qual == -2) {
+                std::vector<unsigned int> v(ab.begin() + s.ab_off, ab.begin() + s.ab_off + s.ab_n);
+                uint64_t sum = 0;
+                for (size_t j = 0; j < v.size(); j++) {
+                    if (v[j] == 0) {
+                        uint64_t c = q[s.ab_off + j], r = revcomp(c, k);
+                        c = c < r ? c : r;
+                        std::string d(k, 'A');
+                        for (int t = 0; t < k; t++) d[t] = "ACTG"[(c >> (2 * (k - 1 - t))) & 3];
+                        fprintf(stderr, "WARNING Unknown kmer : %s\n", d.c_str());
+                    }
+                    sum += v[j];
+                }
+                s.avg = sum / (float)v.size();
+                s.median = v.empty() ? 0.f : (float)median_of(v);
             }
-            s.avg = sum / (float)v.size();
-            s.median = v.empty() ? 0.f : (float)median_of(v);
             s.qual = compute_qual(s, g.anchor_repeated);
             if (g.reverse) s.seq = revcomp_str(s.seq);
         }
@@ -590,6 +607,7 @@ int mtg_index_load(const char* path, mtg_index** out) { return mtgi::index_load(
 int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out)
 {
     if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    const double t_m0 = mtgi::now_ms();
     mtg_results* R = new mtg_results();
     R->gaps.resize(n);
     std::vector<std::string> swf(n);
@@ -609,8 +627,11 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
             w.targets.push_back(std::move(T));
         }
     }
-    int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, nullptr);
+    const double t_m1 = mtgi::now_ms();
+    mtg_batch_stats st{};
+    int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, &st);
     if (rc) { delete R; return rc; }
+    const double t_m2 = mtgi::now_ms();
     R->filled.resize(n);
     R->res.resize(n);
     for (size_t i = 0; i < n; i++) {
@@ -634,6 +655,10 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
         r.filled = R->filled[i].data();
         r.extension = w.extension.c_str();
     }
+    st.marshal_ms = t_m1 - t_m0;
+    st.result_ms = mtgi::now_ms() - t_m2;
+    st.total_ms = mtgi::now_ms() - t_m0;
+    mtgi::stats_store(st);
     *out = R;
     return MTG_OK;
 }
@@ -669,20 +694,22 @@ int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
 int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n, mtg_contigs** out)
 {
     if (!idx || !p || !out || (n && (!sources || !targets))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
-    mtgi::StageAInput in;
+    mtgi::FillInput in;
+    in.k = idx->dev.k;
+    in.want_all_contigs = true;
     for (size_t i = 0; i < n; i++) {
         if ((int)strlen(sources[i]) < idx->dev.k) { mtgi::set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
-        in.add(sources[i], targets[i], idx->dev.k);
+        in.add(sources[i], targets[i], nullptr, 0);
     }
-    std::vector<mtgi::GapContigs> gc;
+    std::vector<mtgi::GapDev> gc;
     mtg_batch_stats st{};
-    int rc = mtgi::stage_a_run(idx, p, in, gc, &st);
+    int rc = mtgi::device_run(idx, p, in, gc, &st);
     if (rc) return rc;
     mtgi::stats_store(st);
     mtg_contigs* C = new mtg_contigs();
     C->c.resize(n);
     for (size_t i = 0; i < n; i++)
-        for (uint32_t j = 0; j < gc[i].n_contigs; j++) C->c[i].push_back(gc[i].contig(j));
+        for (uint32_t j = 0; j < gc[i].o.n_contigs; j++) C->c[i].push_back(gc[i].contig(j));
     *out = C;
     return MTG_OK;
 }

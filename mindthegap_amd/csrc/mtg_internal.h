@@ -7,6 +7,7 @@
 #define MTG_INTERNAL_H
 #include "../../include/mtg_fill.h"
 #include "mtg_hostutil.h"
+#include "mtg_post.h"
 #include <string>
 #include <vector>
 
@@ -20,37 +21,6 @@ namespace mtgi {
 
 void set_error(const char* fmt, ...);
 
-/* contigs of one gap as they come back from the device (2-bit packed) */
-struct GapContigs {
-    uint32_t n_contigs = 0;
-    uint32_t total_nt = 0;
-    std::vector<uint32_t> len;        /* nt per contig */
-    std::vector<uint32_t> word_start; /* into words */
-    std::vector<uint64_t> words;
-    std::string contig(size_t i) const
-    {
-        std::string s;
-        mtg::unpack_seq(words.data() + word_start[i], len[i], s);
-        return s;
-    }
-};
-
-struct StageAInput {
-    std::vector<uint64_t> src;     /* oriented source k-mer per gap */
-    std::vector<uint64_t> rwords;  /* packed swf patterns, concatenated */
-    std::vector<uint32_t> roff;    /* first word of gap i's pattern */
-    std::vector<uint32_t> rlen;    /* pattern length in nt */
-    std::vector<uint64_t> r0;      /* first k-mer of the pattern */
-    void add(const char* source, const char* target, int k);
-};
-
-/* runs stage A for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
-int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in, std::vector<GapContigs>& out, mtg_batch_stats* stats);
-
-int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
-
-void stats_store(const mtg_batch_stats& s);
-
 /* one gapFillFromSource call and its results (host side) */
 struct Target {
     std::string seq, name;
@@ -59,6 +29,65 @@ struct Target {
     uint64_t badmask = 0; /* positions (pair-lsb) that can never match (not ACGT/acgt) */
     bool usable = true;   /* at least k chars */
 };
+/* what comes back from the device for one gap */
+struct GapDev {
+    mtg::GapOut o{};
+    mtg::PostOut p{};
+    /* contig data: all contigs when n_meta == o.n_contigs, otherwise only the leading words of contig 0 */
+    uint32_t n_meta = 0;
+    std::vector<uint64_t> words;
+    std::vector<uint32_t> len, word_start, tpos, terr, ttgt;
+    std::string contig(size_t i) const
+    {
+        std::string s;
+        mtg::unpack_seq(words.data() + word_start[i], len[i], s);
+        return s;
+    }
+    /* contig0[from, to) from the leading words */
+    std::string contig0_slice(uint32_t from, uint32_t to) const
+    {
+        std::string s;
+        if (to <= from) return s;
+        static const char NT[4] = {'A', 'C', 'T', 'G'};
+        s.resize(to - from);
+        for (uint32_t i = from; i < to; i++) s[i - from] = NT[(words[i >> 5] >> (2 * (i & 31))) & 3];
+        return s;
+    }
+};
+
+/* what to copy back for a gap: nw leading words of its arena, metadata of nc contigs (0 or all) */
+inline void copy_plan(const mtg::GapOut& o, const mtg::PostOut& p, bool want_all, uint32_t& nw, uint32_t& nc)
+{
+    nw = nc = 0;
+    if (o.status != mtg::GAP_OK) return;
+    if (want_all || (p.fast == 0 && p.nb_terminal > 0)) { nw = o.n_words; nc = o.n_contigs; }
+    else if (p.fast == 1) nw = (p.pos + 31) / 32;
+    else if (p.fast == 2) nw = 0;
+    else nw = (p.clen0 + 31) / 32; /* no terminal node: contig 0 is the extension sequence */
+}
+
+/* a batch of gapFillFromSource calls, marshalled for the device */
+struct FillInput {
+    int k = 31;
+    bool want_all_contigs = false;
+    std::vector<uint64_t> src;     /* oriented source k-mer per gap */
+    std::vector<uint64_t> rwords;  /* packed swf patterns, concatenated */
+    std::vector<uint32_t> roff;    /* first word of gap i's pattern */
+    std::vector<uint32_t> rlen;    /* pattern length in nt */
+    std::vector<uint64_t> r0;      /* first k-mer of the pattern */
+    std::vector<uint64_t> tle, tbad; /* targets of all gaps: little-endian k-mer, never-match mask */
+    std::vector<uint32_t> toff, tcnt;
+    std::vector<uint8_t> nbmis, fast_ok;
+    void add(const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis);
+};
+
+/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, std::vector<GapDev>& out, mtg_batch_stats* stats);
+
+int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
+
+void stats_store(const mtg_batch_stats& s);
+
 struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
     std::string seq;
     int nb_errors = 0;

@@ -1,0 +1,164 @@
+/*
+ * mtg_post.h -- what follows the contig construction of a gap, on the device, one wave per gap:
+ *   - Filler::find_nodes_containing_multiple_R (/root/reference/src/Filler.cpp:1294-1378) for every contig
+ *   - the common case "contig 0 holds the target" (GraphAnalysis::find_all_paths_rev returns the single path [0],
+ *     src/GraphAnalysis.cpp:222-226; paths_to_sequences then gives contig0[k:pos], :386-423): the coverage pass of
+ *     src/Filler.cpp:959-988 (abundance of every k-mer of source+fill, sum and median) is done here too.
+ * Compiled for gfx950 (lanes = the 64 lanes of a wave) and, TEST-ONLY, for tests/emu (one lane).
+ */
+#ifndef MTG_POST_H
+#define MTG_POST_H
+#include "mtg_traverse.h"
+
+namespace mtg {
+
+struct PostOut {
+    uint32_t nb_terminal; /* contigs holding a target */
+    uint32_t fast;        /* 0: general path on the host; 1: solution = contig0[k:pos]; 2: target on contig 0 but empty fill */
+    uint32_t pos, errors, target; /* terminal info of contig 0 when fast != 0 */
+    uint32_t clen0;
+    uint32_t ab_sum, ab_n;        /* coverage pass (fast == 1) */
+    uint32_t med_hi, med_lo;      /* sorted[n/2], sorted[n/2-1] */
+};
+
+struct PostTargets {
+    const uint64_t* le;  /* target k-mers, little-endian packed (nt i at bits 2i), dictionary iteration order */
+    const uint64_t* bad; /* bit 2i set: position i can never match (not ACGT) or the whole anchor is unusable */
+    uint32_t n;
+    uint32_t nb_mis;
+    uint32_t fast_ok;    /* the source sequence is exactly k valid nucleotides */
+};
+
+#ifdef MTG_EMU
+#define MTG_LANE() 0u
+#define MTG_NLANES 1u
+MTG_DEV uint64_t wave_max64(uint64_t x) { return x; }
+MTG_DEV uint32_t wave_sum32(uint32_t x) { return x; }
+MTG_DEV void hist_add(uint32_t* h, uint32_t v) { h[v]++; }
+MTG_DEV void wave_sync() {}
+#else
+#define MTG_LANE() (threadIdx.x & 63u)
+#define MTG_NLANES 64u
+MTG_DEV uint64_t wave_max64(uint64_t x)
+{
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m, 64);
+        uint64_t y = ((uint64_t)hi << 32) | lo;
+        x = y > x ? y : x;
+    }
+    return x;
+}
+MTG_DEV uint32_t wave_sum32(uint32_t x)
+{
+    for (int m = 32; m >= 1; m >>= 1) x += (uint32_t)__shfl_xor((int)x, m, 64);
+    return x;
+}
+MTG_DEV void hist_add(uint32_t* h, uint32_t v) { atomicAdd(&h[v], 1u); }
+MTG_DEV void wave_sync() { __syncthreads(); }
+#endif
+
+/* k-mer starting at nt j of a packed sequence, little-endian (nt j+i at bits 2i) */
+MTG_DEV uint64_t le_kmer(const uint64_t* w, uint32_t j, uint64_t mk)
+{
+    const uint32_t s = 2u * (j & 31u);
+    const uint64_t lo = w[j >> 5] >> s;
+    const uint64_t hi = s ? (w[(j >> 5) + 1] << (64u - s)) : 0ull;
+    return (lo | hi) & mk;
+}
+
+/* hist: 256 zeroed counters shared by the lanes (LDS on the device) */
+MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, PostOut& out)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k);
+    const uint64_t lsb = 0x5555555555555555ULL & mk;
+    const uint32_t lane = MTG_LANE();
+    const uint64_t* words = s_words(cfg, S);
+    const uint32_t* cstart = s_cstart(cfg, S);
+    const uint32_t* clen = s_clen(cfg, S);
+    uint32_t* tpos = s_tpos(cfg, S);
+    uint32_t* terr = s_terr(cfg, S);
+    uint32_t* ttgt = s_ttgt(cfg, S);
+    const uint64_t ORD = (1ull << 40) - 1;
+    uint32_t nterm = 0;
+    uint32_t pos0 = 0, err0 = 0, tgt0 = 0;
+    bool has0 = false;
+    /* find_nodes_containing_multiple_R: the scan keeps the first (position-major, target-minor) occurrence of the best match count
+     * >= k - nb_mis and stops at the first exact match (src/Filler.cpp:1341-1351); an exact match is the largest possible count, so the
+     * result is the first occurrence of the maximum: an arg-max, evaluated here by all lanes at once. */
+    for (uint32_t c = 0; c < o.n_contigs; c++) {
+        const uint32_t L = clen[c];
+        const uint64_t* w = words + cstart[c];
+        uint64_t best = 0;
+        if (L >= (uint32_t)k && T.n) {
+            const uint32_t npos = L - (uint32_t)k + 1;
+            for (uint32_t j = lane; j < npos; j += MTG_NLANES) {
+                const uint64_t x = le_kmer(w, j, mk);
+                for (uint32_t t = 0; t < T.n; t++) {
+                    const uint64_t m = x ^ T.le[t];
+                    const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
+#ifdef MTG_EMU
+                    const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
+#else
+                    const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
+#endif
+                    if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
+                        const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t));
+                        best = key > best ? key : best;
+                    }
+                }
+            }
+        }
+        best = wave_max64(best);
+        if (best) {
+            const uint32_t nbm = (uint32_t)(best >> 40);
+            const uint64_t order = ORD - (best & ORD);
+            const uint32_t p = (uint32_t)(order / T.n), t = (uint32_t)(order % T.n);
+            if (lane == 0) { tpos[c] = p; terr[c] = (uint32_t)k - nbm; ttgt[c] = t; }
+            if (c == 0) { has0 = true; pos0 = p; err0 = (uint32_t)k - nbm; tgt0 = t; }
+            nterm++;
+        } else if (lane == 0) {
+            tpos[c] = 0xFFFFFFFFu;
+        }
+    }
+    out.nb_terminal = nterm;
+    out.clen0 = o.n_contigs ? clen[0] : 0;
+    out.fast = 0;
+    out.pos = pos0; out.errors = err0; out.target = tgt0;
+    out.ab_sum = out.ab_n = out.med_hi = out.med_lo = 0;
+    if (!(has0 && T.fast_ok)) return;
+    if (pos0 <= (uint32_t)k - 1) { out.fast = 2; return; } /* src/GraphAnalysis.cpp:404-407: nothing left of the first node */
+    /* coverage of source + fill = the k-mers of contig0[0:pos0] */
+    const uint64_t* w0 = words + cstart[0];
+    const uint32_t nk = pos0 - (uint32_t)k + 1;
+    uint32_t sum = 0, lines = 0;
+    for (uint32_t j = lane; j < nk; j += MTG_NLANES) {
+        Kmer x;
+        x.r = le_kmer(w0, j, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk); /* little-endian image = reversed order: complementing it gives revcomp */
+        x.f = revcomp(x.r, k);
+        const uint32_t a = abundance(ix, x, lines);
+        sum += a;
+        hist_add(hist, a);
+    }
+    sum = wave_sum32(sum);
+    wave_sync();
+    uint32_t hi = 0, lo = 0;
+    if (lane == 0) {
+        const uint32_t n2 = nk / 2; /* sorted[n2], sorted[n2-1] */
+        uint32_t cum = 0;
+        bool got_hi = false, got_lo = (n2 == 0);
+        for (uint32_t v = 0; v < 256 && !(got_hi && got_lo); v++) {
+            cum += hist[v];
+            if (!got_lo && cum > n2 - 1) { lo = v; got_lo = true; }
+            if (!got_hi && cum > n2) { hi = v; got_hi = true; }
+        }
+    }
+    out.fast = 1;
+    out.ab_sum = sum;
+    out.ab_n = nk;
+    out.med_hi = hi;
+    out.med_lo = lo;
+}
+
+} // namespace mtg
+#endif

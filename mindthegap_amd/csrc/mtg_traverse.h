@@ -47,7 +47,7 @@ struct FillCfg {
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_dfsf, o_dfsc,
-        o_dfsmask, o_dfsnt, o_cons, o_conslen, o_nw;
+        o_dfsmask, o_dfsnt, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt;
 };
 
 enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
@@ -84,6 +84,9 @@ MTG_ARR(uint8_t, s_dfsnt, r, c.o_dfsnt)
 MTG_ARR(uint8_t, s_cons, r, c.o_cons)        /* CONS_CAP x CONS_LEN nts */
 MTG_ARR(uint16_t, s_conslen, r, c.o_conslen)
 MTG_ARR(int32_t, s_nw, r, c.o_nw)            /* 4 rows x (CONS_LEN+1) */
+MTG_ARR(uint32_t, s_tpos, r, c.o_tpos)       /* per contig: position of the best target match (0xFFFFFFFF: none) */
+MTG_ARR(uint32_t, s_terr, r, c.o_terr)       /*             mismatches in the anchor */
+MTG_ARR(uint32_t, s_ttgt, r, c.o_ttgt)       /*             index of the target */
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
@@ -120,6 +123,9 @@ inline void finalize_cfg(FillCfg& c)
     c.o_conslen = (uint32_t)b; b += 2ull * CONS_CAP;
     b = align_up(b, 8);
     c.o_nw = (uint32_t)b; b += 4ull * 4 * (CONS_LEN + 1);
+    c.o_tpos = (uint32_t)b; b += 4ull * c.cap_contigs;
+    c.o_terr = (uint32_t)b; b += 4ull * c.cap_contigs;
+    c.o_ttgt = (uint32_t)b; b += 4ull * c.cap_contigs;
     c.raw_stride = align_up(b, 64);
 }
 

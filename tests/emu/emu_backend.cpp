@@ -75,28 +75,16 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
     return MTG_OK;
 }
 
-void StageAInput::add(const char* source, const char* target, int k)
-{
-    src.push_back(encode_kmer(source, k));
-    const size_t rl = strlen(target);
-    std::vector<uint64_t> w;
-    pack_seq(target, rl, w);
-    roff.push_back((uint32_t)rwords.size());
-    rwords.insert(rwords.end(), w.begin(), w.end());
-    rlen.push_back((uint32_t)rl);
-    r0.push_back(rl >= (size_t)k ? encode_kmer(target, k) : 0);
-}
-
-int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in, std::vector<GapContigs>& out, mtg_batch_stats* stats)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, std::vector<GapDev>& out, mtg_batch_stats* stats)
 {
     const size_t n = in.src.size();
-    out.assign(n, GapContigs());
-    mtg_batch_stats st{};
+    out.assign(n, GapDev());
+    mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     for (size_t g = 0; g < n; g++) {
         GapOut o{};
         for (int tier = 0; tier <= MTG_MAX_TIER; tier++) {
             FillCfg cfg = make_cfg(idx->dev.k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
-            std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0xCD);
+            std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64, 0xCD);
             GapScratch S = carve(cfg, zero.data(), raw.data(), 0);
             SwfPattern R;
             R.words = in.rwords.data() + in.roff[g];
@@ -105,13 +93,30 @@ int stage_a_run(const mtg_index* idx, const mtg_params* p, const StageAInput& in
             stage_a_gap(idx->dev, cfg, S, in.src[g], R, o);
             st.index_lines += o.lines;
             if (o.status != GAP_OK) { st.n_retried_gaps++; continue; }
-            GapContigs& gc = out[g];
-            gc.n_contigs = o.n_contigs;
-            gc.total_nt = o.total_nt;
-            gc.words.assign(s_words(cfg, S), s_words(cfg, S) + o.n_words);
-            gc.words.push_back(0);
-            gc.len.assign(s_clen(cfg, S), s_clen(cfg, S) + o.n_contigs);
-            gc.word_start.assign(s_cstart(cfg, S), s_cstart(cfg, S) + o.n_contigs);
+            PostTargets T;
+            T.le = in.tle.data() + in.toff[g];
+            T.bad = in.tbad.data() + in.toff[g];
+            T.n = in.tcnt[g];
+            T.nb_mis = in.nbmis[g];
+            T.fast_ok = in.fast_ok[g];
+            uint32_t hist[256] = {0};
+            PostOut po{};
+            post_gap(idx->dev, cfg, S, o, T, hist, po);
+            GapDev& gd = out[g];
+            gd.o = o;
+            gd.p = po;
+            uint32_t nw, nc;
+            copy_plan(o, po, in.want_all_contigs, nw, nc);
+            gd.words.assign(s_words(cfg, S), s_words(cfg, S) + nw);
+            gd.words.push_back(0);
+            gd.n_meta = nc;
+            if (nc) {
+                gd.len.assign(s_clen(cfg, S), s_clen(cfg, S) + nc);
+                gd.word_start.assign(s_cstart(cfg, S), s_cstart(cfg, S) + nc);
+                gd.tpos.assign(s_tpos(cfg, S), s_tpos(cfg, S) + nc);
+                gd.terr.assign(s_terr(cfg, S), s_terr(cfg, S) + nc);
+                gd.ttgt.assign(s_ttgt(cfg, S), s_ttgt(cfg, S) + nc);
+            }
             st.contig_nt += o.total_nt;
             break;
         }
