@@ -158,9 +158,9 @@ int mtg_last_batch_stats(mtg_batch_stats* s);
 int mtg_fill_main(int argc, const char* const* argv);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Bench support: measured ceiling of dependent random 64-byte reads over a table of the given size.
+ * Bench support: measured ceiling of dependent random reads of line_bytes (16/32/64/128) over a table of the given size.
  * ---------------------------------------------------------------------------------------------------------- */
-int mtg_bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, double* ms, double* gbps);
+int mtg_bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, uint32_t line_bytes, double* ms, double* gbps);
 
 #ifdef __cplusplus
 }

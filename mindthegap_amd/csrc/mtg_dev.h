@@ -10,7 +10,7 @@
  *               simplePathAvance neighbourhood of a node (its 4 successors AND the 4 predecessors
  *               of those successors share this (k-1)-mer), i.e. 8 gatb membership probes.
  *   ABND table: key = canonical k-mer -> 8-bit abundance (saturating at 255).
- * A bucket holds 8 slots of 64 bits: [tag : tag_bits][disp : 3][value : 8].  The key is hashed by a
+ * A bucket holds 8 slots of 64 bits: [tag : tag_bits][disp : 4][value : 8].  The key is hashed by a
  * bijection of its 2m-bit domain, the bucket is floor(H * nbuckets / 2^2m) and the tag the low
  * tag_bits = 2m - floor(log2 nbuckets) bits of H, which makes (bucket, tag) lossless: the tables are
  * exact (no false positives), unlike a Bloom filter + cFP cascade, for any query k-mer.
@@ -27,10 +27,12 @@
 #include <hip/hip_runtime.h>
 #define MTG_DEV __device__ __forceinline__
 #define MTG_DEV_NOINLINE __device__ __noinline__
+#define MTG_UNROLL _Pragma("unroll")
 #else
 #define MTG_EMU 1
 #define MTG_DEV inline
 #define MTG_DEV_NOINLINE inline
+#define MTG_UNROLL
 #endif
 
 namespace mtg {
@@ -77,12 +79,19 @@ MTG_DEV Kmer kmer_prev(const Kmer& x, uint32_t nt, int k, uint64_t mk)
 
 /* ------------------------------------------------------------------------------------------- */
 struct Table {
-    uint64_t* slots;   /* nbuckets * 8 words, 64-byte aligned */
+    uint64_t* slots;   /* nbuckets * SLOTS words */
     uint64_t nbuckets;
     uint32_t key_bits; /* 2m */
-    uint32_t tag_bits; /* key_bits - floor(log2(nbuckets)), <= 53 */
+    uint32_t tag_bits; /* key_bits - floor(log2(nbuckets)), <= 52 */
 };
-enum { MTG_MAX_DISP = 7, MTG_DISP_BITS = 3, MTG_SLOTS = 8 };
+/* slots per bucket: ADJ buckets are small because the walk pays per line touched, not per byte */
+#ifndef MTG_ADJ_SLOTS
+#define MTG_ADJ_SLOTS 2
+#endif
+#ifndef MTG_ABND_SLOTS
+#define MTG_ABND_SLOTS 4
+#endif
+enum { MTG_MAX_DISP = 15, MTG_DISP_BITS = 4 };
 
 /* bijection of the key_bits-wide domain */
 MTG_DEV uint64_t mix(uint64_t x, uint32_t key_bits)
@@ -110,29 +119,28 @@ struct alignas(16) U64x2 {
     uint64_t x, y;
 };
 
-/* value of key, 0 if absent.  One 64-byte line in the common case. */
-MTG_DEV uint32_t table_get(const Table& t, uint64_t key, uint32_t& lines)
+/* value of key, 0 if absent.  One bucket (SLOTS * 8 bytes) in the common case. */
+template <int SLOTS> MTG_DEV uint32_t table_get(const Table& t, uint64_t key, uint32_t& lines)
 {
     const uint64_t H = mix(key, t.key_bits);
     uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
     const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
     for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
-        const U64x2* p = reinterpret_cast<const U64x2*>(t.slots + b * MTG_SLOTS);
-        const U64x2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        const U64x2* p = reinterpret_cast<const U64x2*>(t.slots + b * SLOTS);
+        U64x2 q[SLOTS / 2];
+MTG_UNROLL
+        for (int i = 0; i < SLOTS / 2; i++) q[i] = p[i];
         lines++;
         const uint64_t want = (tag << MTG_DISP_BITS) | d;
         uint32_t val = 0; /* empty slots (all zero) may alias tag 0 / disp 0 but contribute no bits */
-        val |= ((q0.x >> 8) == want) ? (uint32_t)(q0.x & 255) : 0u;
-        val |= ((q0.y >> 8) == want) ? (uint32_t)(q0.y & 255) : 0u;
-        val |= ((q1.x >> 8) == want) ? (uint32_t)(q1.x & 255) : 0u;
-        val |= ((q1.y >> 8) == want) ? (uint32_t)(q1.y & 255) : 0u;
-        val |= ((q2.x >> 8) == want) ? (uint32_t)(q2.x & 255) : 0u;
-        val |= ((q2.y >> 8) == want) ? (uint32_t)(q2.y & 255) : 0u;
-        val |= ((q3.x >> 8) == want) ? (uint32_t)(q3.x & 255) : 0u;
-        val |= ((q3.y >> 8) == want) ? (uint32_t)(q3.y & 255) : 0u;
+MTG_UNROLL
+        for (int i = 0; i < SLOTS / 2; i++) {
+            val |= ((q[i].x >> 8) == want) ? (uint32_t)(q[i].x & 255) : 0u;
+            val |= ((q[i].y >> 8) == want) ? (uint32_t)(q[i].y & 255) : 0u;
+        }
         if (val) return val;
         /* slots fill in order, so a free last slot means the key cannot be further away */
-        if (q3.y == 0) return 0;
+        if (q[SLOTS / 2 - 1].y == 0) return 0;
         b = (b + 1 == t.nbuckets) ? 0 : b + 1;
     }
     return 0;
@@ -157,15 +165,15 @@ MTG_DEV void atomic_or64(uint64_t* p, uint64_t bits)
 
 /* insert key with value bits, OR-ing into an existing entry.  Returns 0 (entry existed), 2 (entry created), or
  * 1 when the key would be displaced by more than MTG_MAX_DISP buckets (the host then rebuilds with more buckets). */
-MTG_DEV int table_or(const Table& t, uint64_t key, uint32_t bits)
+template <int SLOTS> MTG_DEV int table_or(const Table& t, uint64_t key, uint32_t bits)
 {
     const uint64_t H = mix(key, t.key_bits);
     uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
     const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
     for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
         const uint64_t want = (tag << MTG_DISP_BITS) | d;
-        uint64_t* p = t.slots + b * MTG_SLOTS;
-        for (int i = 0; i < MTG_SLOTS; i++) {
+        uint64_t* p = t.slots + b * SLOTS;
+        for (int i = 0; i < SLOTS; i++) {
             uint64_t v = *(volatile uint64_t*)(p + i);
             if (v == 0) {
                 v = atomic_cas64(p + i, 0, (want << 8) | bits);
@@ -197,7 +205,7 @@ struct Adj {
 MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     const uint64_t s = x.f & mk1, rs = x.r >> 2;
-    const uint32_t m = table_get(ix.adj, s <= rs ? s : rs, lines);
+    const uint32_t m = table_get<MTG_ADJ_SLOTS>(ix.adj, s <= rs ? s : rs, lines);
     Adj a;
     if (s <= rs) { a.out = m & 15u; a.in = m >> 4; }
     else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
@@ -207,13 +215,13 @@ MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& li
 MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     const uint64_t p = x.f >> 2, rp = x.r & mk1;
-    const uint32_t m = table_get(ix.adj, p <= rp ? p : rp, lines);
+    const uint32_t m = table_get<MTG_ADJ_SLOTS>(ix.adj, p <= rp ? p : rp, lines);
     Adj a;
     if (p <= rp) { a.out = m & 15u; a.in = m >> 4; }
     else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
     return a;
 }
-MTG_DEV uint32_t abundance(const Index& ix, const Kmer& x, uint32_t& lines) { return table_get(ix.abnd, canon(x), lines); }
+MTG_DEV uint32_t abundance(const Index& ix, const Kmer& x, uint32_t& lines) { return table_get<MTG_ABND_SLOTS>(ix.abnd, canon(x), lines); }
 
 /* index construction: one call per solid k-mer (canonical value c, abundance >= 1).
  * Returns bit 0 = displacement overflow, bit 1 = the k-mer was new. */
@@ -221,7 +229,7 @@ MTG_DEV int index_insert(const Index& ix, uint64_t c, uint32_t abund)
 {
     const int k = ix.k;
     const uint64_t mk1 = kmask(k - 1);
-    int fail = table_or(ix.abnd, c, abund > 255u ? 255u : (abund ? abund : 1u));
+    int fail = table_or<MTG_ABND_SLOTS>(ix.abnd, c, abund > 255u ? 255u : (abund ? abund : 1u));
     const int created = fail & 2;
     Kmer o[2];
     o[0].f = c; o[0].r = revcomp(c, k);
@@ -230,11 +238,11 @@ MTG_DEV int index_insert(const Index& ix, uint64_t c, uint32_t abund)
         const Kmer& x = o[s];
         const uint32_t a = (uint32_t)(x.f >> (2 * (k - 1))) & 3u, b = (uint32_t)x.f & 3u;
         const uint64_t suf = x.f & mk1, rsuf = x.r >> 2; /* a + suf is solid */
-        if (suf <= rsuf) fail |= table_or(ix.adj, suf, 1u << (4 + a)) & 1;
-        else fail |= table_or(ix.adj, rsuf, 1u << (a ^ 2u)) & 1;
+        if (suf <= rsuf) fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, suf, 1u << (4 + a)) & 1;
+        else fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, rsuf, 1u << (a ^ 2u)) & 1;
         const uint64_t pre = x.f >> 2, rpre = x.r & mk1; /* pre + b is solid */
-        if (pre <= rpre) fail |= table_or(ix.adj, pre, 1u << b) & 1;
-        else fail |= table_or(ix.adj, rpre, 1u << (4 + (b ^ 2u))) & 1;
+        if (pre <= rpre) fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, pre, 1u << b) & 1;
+        else fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, rpre, 1u << (4 + (b ^ 2u))) & 1;
     }
     return (fail & 1) | created;
 }

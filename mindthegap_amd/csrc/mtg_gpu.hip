@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace mtg;
@@ -213,7 +214,8 @@ __global__ void k_compact(FillCfg cfg, const uint8_t* raw, const uint32_t* __res
     }
 }
 
-/* dependent chains of random 64-byte line reads: the access pattern of the simple-path walk */
+/* dependent chains of random line reads: the access pattern of the simple-path walk.  LINE = bytes read per step (16..128) */
+template <int LINE>
 __global__ void __launch_bounds__(64) k_chase(const uint64_t* __restrict__ table, uint64_t nlines, uint64_t n_chains, uint32_t chain_len, uint64_t* sink)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,9 +224,10 @@ __global__ void __launch_bounds__(64) k_chase(const uint64_t* __restrict__ table
     uint64_t acc = 0;
     for (uint32_t i = 0; i < chain_len; i++) {
         const uint64_t line = x % nlines;
-        const U64x2* p = reinterpret_cast<const U64x2*>(table + line * 8);
-        const U64x2 a = p[0], b = p[1], c = p[2], d = p[3];
-        const uint64_t v = a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y ^ d.x ^ d.y;
+        const U64x2* p = reinterpret_cast<const U64x2*>(table + line * (LINE / 8));
+        uint64_t v = 0;
+#pragma unroll
+        for (int j = 0; j < LINE / 16; j++) { const U64x2 q = p[j]; v ^= q.x ^ q.y; }
         acc += v;
         x = d_splitmix64(x ^ v);
     }
@@ -242,9 +245,9 @@ __global__ void k_fill_random(uint64_t* p, uint64_t nwords, uint64_t seed)
 static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load)
 {
     const int k = idx->dev.k;
-    table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load, 2 * (k - 1)), 2 * (k - 1));
-    table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k), 2 * k);
-    const size_t ba = idx->dev.adj.nbuckets * 64, bb = idx->dev.abnd.nbuckets * 64;
+    table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
+    table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+    const size_t ba = idx->dev.adj.nbuckets * 8 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
     HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));
     hipError_t e = hipMalloc((void**)&idx->dev.abnd.slots, bb);
     if (e != hipSuccess) {
@@ -282,7 +285,7 @@ int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, siz
     HIP_TRY(hipMalloc((void**)&d_cnt, 4 * 8));
     HIP_TRY(hipMemcpy(d_k, canon_kmers, n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_a, abundance, n * 4, hipMemcpyHostToDevice));
-    double load = 0.5;
+    double load = getenv("MTG_INDEX_LOAD") ? atof(getenv("MTG_INDEX_LOAD")) : 0.35;
     int rc = MTG_OK;
     for (int attempt = 0; attempt < 6; attempt++) {
         rc = alloc_tables(idx, n, load);
@@ -326,7 +329,7 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
     HIP_TRY(hipGetDevice(&idx->device));
     unsigned long long* d_cnt = nullptr;
     HIP_TRY(hipMalloc((void**)&d_cnt, 32));
-    double load = 0.5;
+    double load = getenv("MTG_INDEX_LOAD") ? atof(getenv("MTG_INDEX_LOAD")) : 0.35;
     int rc = MTG_OK;
     for (int attempt = 0; attempt < 6; attempt++) {
         rc = alloc_tables(idx, total_kmers_ub, load);
@@ -359,6 +362,7 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
 void index_release(mtg_index* idx)
 {
     if (!idx) return;
+    for (int i = 0; i < Workspace::NSLOTS; i++) if (idx->ws.ptr[i]) (void)hipFree(idx->ws.ptr[i]);
     index_forget_host_copy(idx);
     free_tables(idx);
     delete idx;
@@ -398,8 +402,30 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
     template <typename T> T* as() { return (T*)p; }
 };
+/* a view on a cached, grow-only workspace buffer of the index (no hipMalloc / hipFree on the steady-state path) */
+struct WsBuf {
+    void* p = nullptr;
+    mtgi::Workspace* ws = nullptr;
+    int slot = -1;
+    hipError_t alloc(size_t bytes)
+    {
+        bytes = bytes ? bytes : 8;
+        if (ws->cap[slot] < bytes) {
+            if (ws->ptr[slot]) (void)hipFree(ws->ptr[slot]);
+            ws->ptr[slot] = nullptr;
+            ws->cap[slot] = 0;
+            const size_t want = bytes + bytes / 8;
+            hipError_t e = hipMalloc(&ws->ptr[slot], want);
+            if (e != hipSuccess) { e = hipMalloc(&ws->ptr[slot], bytes); if (e != hipSuccess) return e; ws->cap[slot] = bytes; }
+            else ws->cap[slot] = want;
+        }
+        p = ws->ptr[slot];
+        return hipSuccess;
+    }
+    template <typename T> T* as() { return (T*)p; }
+};
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-template <typename T> hipError_t upload(DevBuf& b, const std::vector<T>& v)
+template <typename B, typename T> hipError_t upload(B& b, const std::vector<T>& v)
 {
     hipError_t e = b.alloc(v.size() * sizeof(T));
     if (e != hipSuccess) return e;
@@ -407,21 +433,33 @@ template <typename T> hipError_t upload(DevBuf& b, const std::vector<T>& v)
 }
 } // namespace
 
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, std::vector<GapDev>& out, mtg_batch_stats* stats)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats)
 {
+    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    double tk = now_ms();
+    auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
     if (int rc = ensure_device()) return rc;
     const size_t n = in.src.size();
+    std::vector<GapDev>& out = batch.gaps;
     out.assign(n, GapDev());
+    batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     if (n == 0) { if (stats) *stats = st; return MTG_OK; }
     const int k = idx->dev.k;
 
-    DevBuf d_src, d_rw, d_roff, d_rlen, d_r0, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok;
+    std::lock_guard<std::mutex> ws_lock(idx->ws.mtx); /* one batch at a time per index: the workspace is shared */
+    int ws_next = 0;
+    auto wsbuf = [&]() { WsBuf b; b.ws = &idx->ws; b.slot = ws_next++; return b; };
+    WsBuf d_src = wsbuf(), d_rw = wsbuf(), d_roff = wsbuf(), d_rlen = wsbuf(), d_r0 = wsbuf(), d_tle = wsbuf(), d_tbad = wsbuf(), d_toff = wsbuf(), d_tcnt = wsbuf(),
+          d_mis = wsbuf(), d_fok = wsbuf();
+    WsBuf d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_post = wsbuf(), d_ids = wsbuf(), d_nw = wsbuf(), d_nc = wsbuf(), d_wb = wsbuf(), d_cb = wsbuf(),
+          d_dw = wsbuf(), d_dm = wsbuf();
     double t0 = now_ms();
     HIP_TRY(upload(d_src, in.src)); HIP_TRY(upload(d_rw, in.rwords)); HIP_TRY(upload(d_roff, in.roff)); HIP_TRY(upload(d_rlen, in.rlen));
     HIP_TRY(upload(d_r0, in.r0)); HIP_TRY(upload(d_tle, in.tle)); HIP_TRY(upload(d_tbad, in.tbad)); HIP_TRY(upload(d_toff, in.toff));
     HIP_TRY(upload(d_tcnt, in.tcnt)); HIP_TRY(upload(d_mis, in.nbmis)); HIP_TRY(upload(d_fok, in.fast_ok));
     st.h2d_ms += now_ms() - t0;
+    tick("out.assign+upload");
 
     hipEvent_t ev0, ev1, ev2;
     HIP_TRY(hipEventCreate(&ev0));
@@ -437,16 +475,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, s
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + sizeof(GapOut) + sizeof(PostOut) + 64;
-        size_t chunk = (size_t)((double)free_b * 0.6 / (double)per_gap);
+        const size_t cached = idx->ws.cap[d_zero.slot] + idx->ws.cap[d_raw.slot]; /* already ours, reusable */
+        size_t chunk = (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
         if (chunk > todo.size()) chunk = todo.size();
         if (chunk > (1u << 20)) chunk = 1u << 20;
         if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }
-        DevBuf d_zero, d_raw, d_out, d_post, d_ids, d_nw, d_nc, d_wb, d_cb;
         HIP_TRY(d_zero.alloc(chunk * cfg.zero_stride));
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
         HIP_TRY(d_post.alloc(chunk * sizeof(PostOut)));
         HIP_TRY(d_ids.alloc(chunk * 4)); HIP_TRY(d_nw.alloc(chunk * 4)); HIP_TRY(d_nc.alloc(chunk * 4)); HIP_TRY(d_wb.alloc(chunk * 8)); HIP_TRY(d_cb.alloc(chunk * 8));
+        tick("workspace alloc");
         std::vector<uint32_t> retry;
         std::vector<GapOut> h_out(chunk);
         std::vector<PostOut> h_post(chunk);
@@ -467,7 +506,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, s
                                d_tbad.as<uint64_t>(), d_toff.as<uint32_t>(), d_tcnt.as<uint32_t>(), d_mis.as<uint8_t>(), d_fok.as<uint8_t>(), d_post.as<PostOut>(), m);
             HIP_TRY(hipEventRecord(ev2, 0));
             HIP_TRY(hipGetLastError());
+            tick("host prep+launch");
             HIP_TRY(hipEventSynchronize(ev2));
+            tick("kernels");
             float ms = 0, ms2 = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
             HIP_TRY(hipEventElapsedTime(&ms2, ev1, ev2));
@@ -485,7 +526,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, s
                 tw += nw[s]; tc += nc[s];
                 if (h_out[s].status != GAP_OK) retry.push_back(todo[base + s]);
             }
-            DevBuf d_dw, d_dm;
             HIP_TRY(d_dw.alloc(tw * 8)); HIP_TRY(d_dm.alloc(tc * 5 * 4));
             HIP_TRY(hipMemcpy(d_nw.p, nw.data(), (size_t)m * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_nc.p, nc.data(), (size_t)m * 4, hipMemcpyHostToDevice));
@@ -494,31 +534,36 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, s
             hipLaunchKernelGGL(k_compact, dim3(std::min<uint32_t>(m, 256 * 16)), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_nw.as<uint32_t>(), d_nc.as<uint32_t>(),
                                d_wb.as<uint64_t>(), d_cb.as<uint64_t>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), tc, m);
             HIP_TRY(hipGetLastError());
-            std::vector<uint64_t> hw(tw);
-            std::vector<uint32_t> hm(tc * 5);
+            batch.chunks.emplace_back(new HostChunk());
+            std::vector<uint64_t>& hw = batch.chunks.back()->words;
+            std::vector<uint32_t>& hm = batch.chunks.back()->meta;
+            hw.resize(tw);
+            hm.resize(tc * 5);
             if (tw) HIP_TRY(hipMemcpy(hw.data(), d_dw.p, tw * 8, hipMemcpyDeviceToHost));
             if (tc) HIP_TRY(hipMemcpy(hm.data(), d_dm.p, tc * 5 * 4, hipMemcpyDeviceToHost));
             st.d2h_ms += now_ms() - t0;
+            tick("plan+compact+d2h");
             t0 = now_ms();
-            for (uint32_t s = 0; s < m; s++) {
-                if (h_out[s].status != GAP_OK) continue;
+            std::atomic<uint64_t> nt_sum{0};
+            parallel_for(m, p->nb_host_threads, [&](size_t s) {
+                if (h_out[s].status != GAP_OK) return;
                 GapDev& gd = out[todo[base + s]];
                 gd.o = h_out[s];
                 gd.p = h_post[s];
                 gd.n_meta = nc[s];
-                gd.words.resize((size_t)nw[s] + 1);
-                if (nw[s]) memcpy(gd.words.data(), hw.data() + wbase[s], (size_t)nw[s] * 8);
-                gd.words[nw[s]] = 0;
+                gd.words = hw.data() + wbase[s];
                 if (nc[s]) {
                     const uint32_t* b0 = hm.data() + cbase[s];
-                    gd.len.assign(b0, b0 + nc[s]);
-                    gd.word_start.assign(b0 + tc, b0 + tc + nc[s]);
-                    gd.tpos.assign(b0 + 2 * tc, b0 + 2 * tc + nc[s]);
-                    gd.terr.assign(b0 + 3 * tc, b0 + 3 * tc + nc[s]);
-                    gd.ttgt.assign(b0 + 4 * tc, b0 + 4 * tc + nc[s]);
+                    gd.len = b0;
+                    gd.word_start = b0 + tc;
+                    gd.tpos = b0 + 2 * tc;
+                    gd.terr = b0 + 3 * tc;
+                    gd.ttgt = b0 + 4 * tc;
                 }
-                st.contig_nt += gd.o.total_nt;
-            }
+                nt_sum.fetch_add(gd.o.total_nt, std::memory_order_relaxed);
+            });
+            st.contig_nt += nt_sum.load();
+            tick("distribute");
             st.host_ms += now_ms() - t0;
         }
         if (tier > 0) st.n_retried_gaps += todo.size();
@@ -535,23 +580,32 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, s
     return rc;
 }
 
-int bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, double* ms_out, double* gbps)
+int bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, uint32_t line_bytes, double* ms_out, double* gbps)
 {
     if (int rc = ensure_device()) return rc;
-    const uint64_t nlines = table_bytes / 64;
+    if (line_bytes != 16 && line_bytes != 32 && line_bytes != 64 && line_bytes != 128) { set_error("line_bytes must be 16, 32, 64 or 128"); return MTG_ERR_ARG; }
+    const uint64_t nlines = table_bytes / line_bytes;
     if (nlines == 0 || n_chains == 0 || chain_len == 0) { set_error("invalid argument"); return MTG_ERR_ARG; }
     DevBuf tab, sink;
-    HIP_TRY(tab.alloc(nlines * 64));
+    HIP_TRY(tab.alloc(nlines * line_bytes));
     HIP_TRY(sink.alloc(8));
-    hipLaunchKernelGGL(k_fill_random, dim3(256 * 16), dim3(256), 0, 0, tab.as<uint64_t>(), nlines * 8, 12345ull);
+    hipLaunchKernelGGL(k_fill_random, dim3(256 * 16), dim3(256), 0, 0, tab.as<uint64_t>(), nlines * (line_bytes / 8), 12345ull);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     const uint32_t blocks = (uint32_t)((n_chains + 63) / 64);
-    hipLaunchKernelGGL(k_chase, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, std::min<uint32_t>(chain_len, 64), sink.as<uint64_t>());
+    auto launch = [&](uint32_t len) {
+        switch (line_bytes) {
+            case 16: hipLaunchKernelGGL(k_chase<16>, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, len, sink.as<uint64_t>()); break;
+            case 32: hipLaunchKernelGGL(k_chase<32>, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, len, sink.as<uint64_t>()); break;
+            case 64: hipLaunchKernelGGL(k_chase<64>, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, len, sink.as<uint64_t>()); break;
+            default: hipLaunchKernelGGL(k_chase<128>, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, len, sink.as<uint64_t>()); break;
+        }
+    };
+    launch(std::min<uint32_t>(chain_len, 64));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_chase, dim3(blocks), dim3(64), 0, 0, tab.as<uint64_t>(), nlines, n_chains, chain_len, sink.as<uint64_t>());
+    launch(chain_len);
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
@@ -559,7 +613,7 @@ int bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_l
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (ms_out) *ms_out = ms;
-    if (gbps) *gbps = (double)n_chains * chain_len * 64.0 / (ms * 1e-3) / 1e9;
+    if (gbps) *gbps = (double)n_chains * chain_len * (double)line_bytes / (ms * 1e-3) / 1e9;
     return MTG_OK;
 }
 
@@ -570,7 +624,7 @@ namespace mtgi {
 int index_from_kmers(const uint64_t*, const uint32_t*, size_t, int, mtg_index**);
 int index_from_packed_device(const uint64_t*, const uint64_t*, const uint32_t*, size_t, uint64_t, int, uint32_t, uint32_t, mtg_index**);
 void index_release(mtg_index*);
-int bench_random_lines(uint64_t, uint64_t, uint32_t, double*, double*);
+int bench_random_lines(uint64_t, uint64_t, uint32_t, uint32_t, double*, double*);
 }
 
 extern "C" {
@@ -622,8 +676,8 @@ int mtg_last_batch_stats(mtg_batch_stats* s)
     *s = mtgi::g_stats;
     return MTG_OK;
 }
-int mtg_bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, double* ms, double* gbps)
+int mtg_bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, uint32_t line_bytes, double* ms, double* gbps)
 {
-    return mtgi::bench_random_lines(table_bytes, n_chains, chain_len, ms, gbps);
+    return mtgi::bench_random_lines(table_bytes, n_chains, chain_len, line_bytes, ms, gbps);
 }
 }

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -30,26 +31,6 @@ using namespace mtg;
 namespace mtgi {
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-template <typename F> static void parallel_for(size_t n, int nthreads, F f)
-{
-    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
-    if (nthreads < 1) nthreads = 1;
-    if ((size_t)nthreads > n) nthreads = (int)std::max<size_t>(n, 1);
-    if (nthreads == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; t++)
-        th.emplace_back([&]() {
-            for (;;) {
-                size_t b = next.fetch_add(16);
-                if (b >= n) break;
-                size_t e = std::min(n, b + 16);
-                for (size_t i = b; i < e; i++) f(i);
-            }
-        });
-    for (auto& t : th) t.join();
-}
 
 /* ------------------------------------------------------------------------------------------------ sequence files */
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out)
@@ -237,20 +218,30 @@ struct TermInfo { /* info_node_t, src/Filler.hpp:44-71 */
     int node, pos, errors, target;
 };
 
-/* marshals one gapFillFromSource call.  targets == nullptr: contigs only (stage A parity entry) */
-void FillInput::add(const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis)
+/* marshalling of a batch of gapFillFromSource calls (targets == nullptr: contigs only, the stage A parity entry) */
+void FillInput::resize(size_t n)
 {
-    src.push_back(encode_kmer(source.c_str(), k));
-    const size_t rl = swf_target.size();
-    roff.push_back((uint32_t)rwords.size());
-    const size_t w0 = rwords.size();
-    rwords.resize(w0 + (rl + 31) / 32 + 1, 0);
+    src.assign(n, 0); roff.assign(n, 0); rlen.assign(n, 0); r0.assign(n, 0); toff.assign(n, 0); tcnt.assign(n, 0); nbmis.assign(n, 0); fast_ok.assign(n, 0);
+}
+void FillInput::layout()
+{
+    uint64_t rw = 0, nt = 0;
+    for (size_t i = 0; i < src.size(); i++) {
+        roff[i] = (uint32_t)rw; rw += (rlen[i] + 31) / 32 + 1;
+        toff[i] = (uint32_t)nt; nt += tcnt[i];
+    }
+    rwords.assign(rw, 0);
+    tle.assign(nt, 0);
+    tbad.assign(nt, 0);
+}
+void FillInput::set(size_t g, const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis)
+{
+    src[g] = encode_kmer(source.c_str(), k);
+    const size_t rl = swf_target.size(), w0 = roff[g];
     for (size_t i = 0; i < rl; i++) rwords[w0 + (i >> 5)] |= (uint64_t)nt_code((unsigned char)swf_target[i]) << (2 * (i & 31));
-    rlen.push_back((uint32_t)rl);
-    r0.push_back(rl >= (size_t)k ? encode_kmer(swf_target.c_str(), k) : 0);
-    toff.push_back((uint32_t)tle.size());
-    uint32_t nt = 0;
-    if (targets)
+    r0[g] = rl >= (size_t)k ? encode_kmer(swf_target.c_str(), k) : 0;
+    if (targets) {
+        size_t o = toff[g];
         for (const Target& t : *targets) {
             /* identNT (src/Utils.cpp:81-84) is case-insensitive equality: compare 2-bit codes and force a mismatch where the anchor
              * character is not a nucleotide; an anchor shorter than k can never be matched */
@@ -262,15 +253,15 @@ void FillInput::add(const std::string& source, const std::string& swf_target, co
                     le |= (uint64_t)nt_code(c) << (2 * i);
                     if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad |= 1ull << (2 * i);
                 }
-            tle.push_back(le);
-            tbad.push_back(bad & (0x5555555555555555ULL & kmask(k)));
-            nt++;
+            tle[o] = le;
+            tbad[o] = bad & (0x5555555555555555ULL & kmask(k));
+            o++;
         }
-    tcnt.push_back(nt);
-    nbmis.push_back((uint8_t)nb_mis);
+    }
+    nbmis[g] = (uint8_t)nb_mis;
     bool ok = (int)source.size() == k;
     for (unsigned char c : source) ok = ok && !nt_bad(c);
-    fast_ok.push_back(ok ? 1 : 0);
+    fast_ok[g] = ok ? 1 : 0;
 }
 
 struct ContigGraph {
@@ -281,7 +272,7 @@ struct ContigGraph {
         in_edges.resize(n);
         const uint64_t mk1 = kmask(k - 1);
         auto kmer_at = [&](uint32_t c, uint32_t start) {
-            const uint64_t* w = gc.words.data() + gc.word_start[c];
+            const uint64_t* w = gc.words + gc.word_start[c];
             uint64_t f = 0;
             for (int j = 0; j < k - 1; j++) { uint32_t i = start + j; f = (f << 2) | ((w[i >> 5] >> (2 * (i & 31))) & 3ull); }
             return f & mk1;
@@ -504,15 +495,24 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     const double t_begin = now_ms();
     FillInput in;
     in.k = k;
+    in.resize(n);
     for (size_t i = 0; i < n; i++) {
         if ((int)gaps[i].source.size() < k) { set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
-        in.add(gaps[i].source, swf_targets[i], &gaps[i].targets, gaps[i].anchor_repeated ? 0 : p->nb_mis_allowed); /* src/Filler.cpp:859-863 */
+        in.size(i, swf_targets[i].size(), gaps[i].targets.size());
     }
+    in.layout();
+    parallel_for(n, p->nb_host_threads, [&](size_t i) {
+        in.set(i, gaps[i].source, swf_targets[i], &gaps[i].targets, gaps[i].anchor_repeated ? 0 : p->nb_mis_allowed); /* src/Filler.cpp:859-863 */
+    });
     mtg_batch_stats st{};
     st.host_ms = now_ms() - t_begin;
-    std::vector<GapDev> dev;
-    int rc = device_run(idx, p, in, dev, &st);
+    DevBatch batch;
+    std::vector<GapDev>& dev = batch.gaps;
+    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    double tdev = now_ms();
+    int rc = device_run(idx, p, in, batch, &st);
     if (rc) return rc;
+    if (dbg) fprintf(stderr, "  [fill_gaps] pre %.2f device_run %.2f ms\n", tdev - t_begin, now_ms() - tdev);
     double t0 = now_ms();
     parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k); });
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
@@ -567,6 +567,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
         }
     });
     st.host_ms += now_ms() - t0;
+    if (dbg) fprintf(stderr, "  [fill_gaps] post-device %.2f ms\n", now_ms() - t0);
     st.total_ms = now_ms() - t_begin;
     if (stats_out) *stats_out = st;
     stats_store(st);
@@ -614,19 +615,22 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     for (size_t i = 0; i < n; i++) {
         const mtg_gap& g = gaps[i];
         if (!g.source || !g.target || (g.n_targets && (!g.target_seqs || !g.target_names))) { delete R; mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
+    }
+    mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
+        const mtg_gap& g = gaps[i];
         mtgi::GapWork& w = R->gaps[i];
         w.source = g.source;
         swf[i] = g.target;
         w.anchor_repeated = g.is_anchor_repeated != 0;
         w.reverse = g.reverse != 0;
+        w.targets.resize(g.n_targets);
         for (int t = 0; t < g.n_targets; t++) {
-            mtgi::Target T;
+            mtgi::Target& T = w.targets[t];
             T.seq = g.target_seqs[t];
             T.name = g.target_names[t];
             T.is_rc = g.target_is_rc ? g.target_is_rc[t] != 0 : false;
-            w.targets.push_back(std::move(T));
         }
-    }
+    });
     const double t_m1 = mtgi::now_ms();
     mtg_batch_stats st{};
     int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, &st);
@@ -634,7 +638,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     const double t_m2 = mtgi::now_ms();
     R->filled.resize(n);
     R->res.resize(n);
-    for (size_t i = 0; i < n; i++) {
+    mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
         mtgi::GapWork& w = R->gaps[i];
         for (auto& s : w.sols) {
             mtg_filled f;
@@ -654,7 +658,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
         r.n_filled = (int)R->filled[i].size();
         r.filled = R->filled[i].data();
         r.extension = w.extension.c_str();
-    }
+    });
     st.marshal_ms = t_m1 - t_m0;
     st.result_ms = mtgi::now_ms() - t_m2;
     st.total_ms = mtgi::now_ms() - t_m0;
@@ -663,7 +667,13 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     return MTG_OK;
 }
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->res.size()) ? &r->res[i] : nullptr; }
-void mtg_results_free(mtg_results* r) { delete r; }
+void mtg_results_free(mtg_results* r)
+{
+    if (!r) return;
+    /* release the per-gap strings from several threads */
+    mtgi::parallel_for(r->gaps.size(), 0, [&](size_t i) { mtgi::GapWork().swap_into(r->gaps[i]); std::vector<mtg_filled>().swap(r->filled[i]); }, 1024);
+    delete r;
+}
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
 {
     if (!r) return MTG_ERR_ARG;
@@ -680,30 +690,41 @@ int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_
 int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
 {
     if (!r || !dst) return MTG_ERR_ARG;
-    uint64_t o = 0;
-    for (auto& g : r->gaps)
-        for (auto& s : g.sols) {
-            if (o + s.seq.size() + 1 > cap) { mtgi::set_error("destination too small"); return MTG_ERR_ARG; }
+    const size_t n = r->gaps.size();
+    std::vector<uint64_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t b = 0;
+        for (auto& s : r->gaps[i].sols) b += s.seq.size() + 1;
+        off[i + 1] = off[i] + b;
+    }
+    if (off[n] > cap) { mtgi::set_error("destination too small"); return MTG_ERR_ARG; }
+    mtgi::parallel_for(n, 0, [&](size_t i) {
+        uint64_t o = off[i];
+        for (auto& s : r->gaps[i].sols) {
             memcpy(dst + o, s.seq.data(), s.seq.size());
             o += s.seq.size();
             dst[o++] = '\n';
         }
+    }, 512);
     return MTG_OK;
 }
-
 int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n, mtg_contigs** out)
 {
     if (!idx || !p || !out || (n && (!sources || !targets))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     mtgi::FillInput in;
     in.k = idx->dev.k;
     in.want_all_contigs = true;
+    in.resize(n);
     for (size_t i = 0; i < n; i++) {
         if ((int)strlen(sources[i]) < idx->dev.k) { mtgi::set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
-        in.add(sources[i], targets[i], nullptr, 0);
+        in.size(i, strlen(targets[i]), 0);
     }
-    std::vector<mtgi::GapDev> gc;
+    in.layout();
+    for (size_t i = 0; i < n; i++) in.set(i, sources[i], targets[i], nullptr, 0);
+    mtgi::DevBatch batch;
+    std::vector<mtgi::GapDev>& gc = batch.gaps;
     mtg_batch_stats st{};
-    int rc = mtgi::device_run(idx, p, in, gc, &st);
+    int rc = mtgi::device_run(idx, p, in, batch, &st);
     if (rc) return rc;
     mtgi::stats_store(st);
     mtg_contigs* C = new mtg_contigs();

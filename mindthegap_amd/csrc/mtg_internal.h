@@ -8,11 +8,29 @@
 #include "../../include/mtg_fill.h"
 #include "mtg_hostutil.h"
 #include "mtg_post.h"
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+namespace mtgi {
+/* grow-only device buffers reused by successive batches on one index */
+struct Workspace {
+    enum { NSLOTS = 32 };
+    void* ptr[NSLOTS] = {nullptr};
+    size_t cap[NSLOTS] = {0};
+    std::mutex mtx;
+};
+}
 
 struct mtg_index {
     mtg::Index dev{};          /* tables live in device memory */
+    mutable mtgi::Workspace ws;
     int device = 0;
     mtg_index_info info{};
 };
@@ -20,6 +38,90 @@ struct mtg_index {
 namespace mtgi {
 
 void set_error(const char* fmt, ...);
+
+/* persistent host worker pool for the per-gap loops (nthreads <= 0: all cores, capped at 64) */
+class Pool {
+public:
+    static Pool& get() { static Pool p; return p; }
+    /* runs job(worker) on `nworkers` threads (the caller is one of them) and waits */
+    void run(int nworkers, const std::function<void()>& job)
+    {
+        std::unique_lock<std::mutex> run_lock(run_mtx_); /* one parallel region at a time */
+        const int helpers = std::min<int>(nworkers - 1, (int)threads_.size());
+        if (helpers > 0) {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &job;
+            to_start_ = helpers;
+            active_ = helpers;
+            gen_++;
+        }
+        if (helpers > 0) cv_.notify_all();
+        job();
+        if (helpers > 0) {
+            std::unique_lock<std::mutex> lk(m_);
+            done_cv_.wait(lk, [&] { return active_ == 0; });
+            job_ = nullptr;
+        }
+    }
+    int size() const { return (int)threads_.size() + 1; }
+
+private:
+    Pool()
+    {
+        int n = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 64u);
+        for (int i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void()>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && to_start_ > 0); });
+                if (stop_) return;
+                seen = gen_;
+                to_start_--;
+                job = job_;
+            }
+            (*job)();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--active_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_, run_mtx_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void()>* job_ = nullptr;
+    int to_start_ = 0, active_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+template <typename F> inline void parallel_for(size_t n, int nthreads, F f, size_t grain = 64)
+{
+    if (nthreads <= 0) nthreads = Pool::get().size();
+    if ((size_t)nthreads * grain > n) nthreads = (int)std::max<size_t>(n / grain, 1);
+    if (nthreads <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::function<void()> work = [&]() {
+        for (;;) {
+            const size_t b = next.fetch_add(grain);
+            if (b >= n) break;
+            const size_t e = std::min(n, b + grain);
+            for (size_t i = b; i < e; i++) f(i);
+        }
+    };
+    Pool::get().run(nthreads, work);
+}
 
 /* one gapFillFromSource call and its results (host side) */
 struct Target {
@@ -29,18 +131,24 @@ struct Target {
     uint64_t badmask = 0; /* positions (pair-lsb) that can never match (not ACGT/acgt) */
     bool usable = true;   /* at least k chars */
 };
-/* what comes back from the device for one gap */
+/* host copies of what a chunk of gaps brought back; GapDev entries point into them */
+struct HostChunk {
+    std::vector<uint64_t> words;
+    std::vector<uint32_t> meta;
+};
+
+/* what comes back from the device for one gap (views into a HostChunk) */
 struct GapDev {
     mtg::GapOut o{};
     mtg::PostOut p{};
     /* contig data: all contigs when n_meta == o.n_contigs, otherwise only the leading words of contig 0 */
     uint32_t n_meta = 0;
-    std::vector<uint64_t> words;
-    std::vector<uint32_t> len, word_start, tpos, terr, ttgt;
+    const uint64_t* words = nullptr;
+    const uint32_t *len = nullptr, *word_start = nullptr, *tpos = nullptr, *terr = nullptr, *ttgt = nullptr;
     std::string contig(size_t i) const
     {
         std::string s;
-        mtg::unpack_seq(words.data() + word_start[i], len[i], s);
+        mtg::unpack_seq(words + word_start[i], len[i], s);
         return s;
     }
     /* contig0[from, to) from the leading words */
@@ -53,6 +161,10 @@ struct GapDev {
         for (uint32_t i = from; i < to; i++) s[i - from] = NT[(words[i >> 5] >> (2 * (i & 31))) & 3];
         return s;
     }
+};
+struct DevBatch {
+    std::vector<GapDev> gaps;
+    std::vector<std::unique_ptr<HostChunk>> chunks;
 };
 
 /* what to copy back for a gap: nw leading words of its arena, metadata of nc contigs (0 or all) */
@@ -78,11 +190,15 @@ struct FillInput {
     std::vector<uint64_t> tle, tbad; /* targets of all gaps: little-endian k-mer, never-match mask */
     std::vector<uint32_t> toff, tcnt;
     std::vector<uint8_t> nbmis, fast_ok;
-    void add(const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis);
+    /* two-pass marshalling: size(i, ...) for every gap in order, then layout(), then set(i, ...) from any thread */
+    void resize(size_t n);
+    void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }
+    void layout();
+    void set(size_t i, const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis);
 };
 
 /* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, std::vector<GapDev>& out, mtg_batch_stats* stats);
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats);
 
 int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
 
@@ -104,6 +220,7 @@ struct GapWork {
     bool has_counts = false;
     std::vector<Solution> sols;
     std::string extension;
+    void swap_into(GapWork& o) { std::swap(*this, o); } /* used to free o's storage on the calling thread */
 };
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
 int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, mtg_batch_stats* stats_out);

@@ -110,7 +110,7 @@ def _bind(lib):
     lib.mtg_contigs_free.restype = None
     lib.mtg_last_batch_stats.argtypes = [P(BatchStats)]
     lib.mtg_fill_main.argtypes = [C.c_int, P(C.c_char_p)]
-    lib.mtg_bench_random_lines.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, P(C.c_double), P(C.c_double)]
+    lib.mtg_bench_random_lines.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, P(C.c_double), P(C.c_double)]
     return lib
 
 
@@ -230,7 +230,7 @@ class Index:
         return (arr, n, keep)
 
     def fill_prepared(self, prepared, params=None):
-        """one mtg_fill_batch call; returns (results handle, n_filled per gap, packed "seq\\n" bytes).  Free with free_results."""
+        """one mtg_fill_batch call; returns (results handle, n_filled per gap, uint8 array of the packed "seq\\n" bytes).  Free with free_results."""
         params = params or FillParams()
         arr, n, _ = prepared
         h = C.c_void_p()
@@ -238,9 +238,9 @@ class Index:
         nf = np.zeros(n, dtype=np.uint32)
         nb, ng = C.c_uint64(), C.c_uint64()
         _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nb), C.byref(ng)))
-        buf = C.create_string_buffer(max(int(nb.value), 1))
-        _check(self.lib.mtg_results_copy_seqs(h, buf, nb.value))
-        return h, nf, buf.raw[: nb.value]
+        buf = np.empty(max(int(nb.value), 1), dtype=np.uint8)
+        _check(self.lib.mtg_results_copy_seqs(h, buf.ctypes.data_as(C.c_char_p), nb.value))
+        return h, nf, buf[: nb.value]
 
     def free_results(self, h):
         self.lib.mtg_results_free(h)
@@ -282,7 +282,7 @@ def fill_main(argv):
     return load_library().mtg_fill_main(len(argv), arr)
 
 
-def random_line_ceiling(table_bytes, n_chains, chain_len):
+def random_line_ceiling(table_bytes, n_chains, chain_len, line_bytes=64):
     ms, gbps = C.c_double(), C.c_double()
-    _check(load_library().mtg_bench_random_lines(table_bytes, n_chains, chain_len, C.byref(ms), C.byref(gbps)))
+    _check(load_library().mtg_bench_random_lines(table_bytes, n_chains, chain_len, line_bytes, C.byref(ms), C.byref(gbps)))
     return ms.value, gbps.value

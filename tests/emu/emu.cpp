@@ -25,10 +25,10 @@ void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, 
     for (;;) {
         EmuIndex* e = new EmuIndex();
         e->ix.k = k;
-        table_shape(e->ix.adj, buckets_for(n + n / 8 + 16, load, 2 * (k - 1)), 2 * (k - 1));
-        table_shape(e->ix.abnd, buckets_for(n, load, 2 * k), 2 * k);
-        e->adj_slots.assign(e->ix.adj.nbuckets * 8, 0);
-        e->abnd_slots.assign(e->ix.abnd.nbuckets * 8, 0);
+        table_shape(e->ix.adj, buckets_for(n + n / 8 + 16, load, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
+        table_shape(e->ix.abnd, buckets_for(n, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+        e->adj_slots.assign(e->ix.adj.nbuckets * MTG_ADJ_SLOTS, 0);
+        e->abnd_slots.assign(e->ix.abnd.nbuckets * MTG_ABND_SLOTS, 0);
         e->ix.adj.slots = e->adj_slots.data();
         e->ix.abnd.slots = e->abnd_slots.data();
         int fail = 0;
@@ -104,6 +104,6 @@ extern "C" void emu_debug_adj(void* p, uint64_t key)
     printf("key %llx H %llx nb %llu bucket %llu tag %llx tag_bits %u key_bits %u\n", (unsigned long long)key, (unsigned long long)H,
            (unsigned long long)t.nbuckets, (unsigned long long)b, (unsigned long long)tag, t.tag_bits, t.key_bits);
     for (int d = 0; d < 3; d++) {
-        for (int i = 0; i < 8; i++) { uint64_t v = t.slots[((b + d) % t.nbuckets) * 8 + i]; printf("  [%d,%d] tag %llx disp %llu val %llx\n", d, i, (unsigned long long)(v >> 10), (unsigned long long)((v >> 8) & 3), (unsigned long long)(v & 255)); }
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) { uint64_t v = t.slots[((b + d) % t.nbuckets) * MTG_ADJ_SLOTS + i]; printf("  [%d,%d] tag %llx disp %llu val %llx\n", d, i, (unsigned long long)(v >> 10), (unsigned long long)((v >> 8) & 3), (unsigned long long)(v & 255)); }
     }
 }

@@ -31,10 +31,10 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
     for (;;) {
         mtg_index* idx = new mtg_index();
         idx->dev.k = k;
-        table_shape(idx->dev.adj, buckets_for(n + n / 8 + 1024, load, 2 * (k - 1)), 2 * (k - 1));
-        table_shape(idx->dev.abnd, buckets_for(n, load, 2 * k), 2 * k);
-        idx->dev.adj.slots = (uint64_t*)calloc(idx->dev.adj.nbuckets * 8, 8);
-        idx->dev.abnd.slots = (uint64_t*)calloc(idx->dev.abnd.nbuckets * 8, 8);
+        table_shape(idx->dev.adj, buckets_for(n + n / 8 + 1024, load, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
+        table_shape(idx->dev.abnd, buckets_for(n, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+        idx->dev.adj.slots = (uint64_t*)calloc(idx->dev.adj.nbuckets * MTG_ADJ_SLOTS, 8);
+        idx->dev.abnd.slots = (uint64_t*)calloc(idx->dev.abnd.nbuckets * MTG_ABND_SLOTS, 8);
         int fail = 0;
         uint64_t created = 0;
         for (size_t i = 0; i < n; i++) { int r = index_insert(idx->dev, kmers[i], ab[i]); fail |= r & 1; created += (r >> 1) & 1; }
@@ -75,10 +75,12 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
     return MTG_OK;
 }
 
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, std::vector<GapDev>& out, mtg_batch_stats* stats)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats)
 {
     const size_t n = in.src.size();
+    std::vector<GapDev>& out = batch.gaps;
     out.assign(n, GapDev());
+    batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     for (size_t g = 0; g < n; g++) {
         GapOut o{};
@@ -107,15 +109,23 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, s
             gd.p = po;
             uint32_t nw, nc;
             copy_plan(o, po, in.want_all_contigs, nw, nc);
-            gd.words.assign(s_words(cfg, S), s_words(cfg, S) + nw);
-            gd.words.push_back(0);
+            batch.chunks.emplace_back(new HostChunk());
+            HostChunk& hc = *batch.chunks.back();
+            hc.words.assign(s_words(cfg, S), s_words(cfg, S) + nw);
+            hc.words.push_back(0);
+            gd.words = hc.words.data();
             gd.n_meta = nc;
             if (nc) {
-                gd.len.assign(s_clen(cfg, S), s_clen(cfg, S) + nc);
-                gd.word_start.assign(s_cstart(cfg, S), s_cstart(cfg, S) + nc);
-                gd.tpos.assign(s_tpos(cfg, S), s_tpos(cfg, S) + nc);
-                gd.terr.assign(s_terr(cfg, S), s_terr(cfg, S) + nc);
-                gd.ttgt.assign(s_ttgt(cfg, S), s_ttgt(cfg, S) + nc);
+                hc.meta.insert(hc.meta.end(), s_clen(cfg, S), s_clen(cfg, S) + nc);
+                hc.meta.insert(hc.meta.end(), s_cstart(cfg, S), s_cstart(cfg, S) + nc);
+                hc.meta.insert(hc.meta.end(), s_tpos(cfg, S), s_tpos(cfg, S) + nc);
+                hc.meta.insert(hc.meta.end(), s_terr(cfg, S), s_terr(cfg, S) + nc);
+                hc.meta.insert(hc.meta.end(), s_ttgt(cfg, S), s_ttgt(cfg, S) + nc);
+                gd.len = hc.meta.data();
+                gd.word_start = gd.len + nc;
+                gd.tpos = gd.len + 2 * nc;
+                gd.terr = gd.len + 3 * nc;
+                gd.ttgt = gd.len + 4 * nc;
             }
             st.contig_nt += o.total_nt;
             break;
@@ -149,5 +159,5 @@ int mtg_index_create_from_packed_device(const uint64_t*, const uint64_t*, const 
     mtgi::set_error("emulation harness: no device");
     return MTG_ERR_NO_DEVICE;
 }
-int mtg_bench_random_lines(uint64_t, uint64_t, uint32_t, double*, double*) { mtgi::set_error("emulation harness: no device"); return MTG_ERR_NO_DEVICE; }
+int mtg_bench_random_lines(uint64_t, uint64_t, uint32_t, uint32_t, double*, double*) { mtgi::set_error("emulation harness: no device"); return MTG_ERR_NO_DEVICE; }
 }
