@@ -53,6 +53,7 @@ def main():
     import torch
     import torch.distributed as dist
     import mindthegap_amd as mtg
+    from mindthegap_amd.shard import gather_bytes
     from mindthegap_amd.synth import SynthSet
 
     lib = mtg.load_library()
@@ -120,16 +121,8 @@ def main():
             n_filled += int((nf2 > 0).sum())
             for key in ("kernel_ms", "post_kernel_ms", "h2d_ms", "d2h_ms", "host_ms", "index_lines", "n_launches", "contig_nt"):
                 st[key] += st2[key]
-        if world > 1:  # results gathered on rank 0 over RCCL / xGMI (sizes, then padded payloads)
-            payload = torch.from_numpy(seqs).to(dev)
-            sz = torch.tensor([payload.numel()], device=dev, dtype=torch.int64)
-            sizes = [torch.zeros_like(sz) for _ in range(world)]
-            dist.all_gather(sizes, sz)
-            mx = int(max(int(s.item()) for s in sizes))
-            pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
-            pad[: payload.numel()] = payload
-            bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, bufs, dst=0)
+        if world > 1:  # results gathered on rank 0 over RCCL / xGMI (all_gather of sizes + padded gather)
+            gather_bytes(seqs, dst=0, device=dev)
         return n_filled, seqs, st
 
     def barrier():

@@ -1,0 +1,41 @@
+"""worker of tests/test_distributed_cpu.py: one rank of a world_size-N gloo job.  Fills its shard of a synthetic set on the
+TEST-ONLY emulation build (no GPU here) and gathers the filled sequences on rank 0."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out_path):
+    import torch.distributed as dist
+    from mindthegap_amd.shard import gather_bytes, shard_range
+    from mindthegap_amd.synth import SynthSet
+    from tests import emu_lib, oracle_lib
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mtg = emu_lib.product_on_emulator()
+    S = SynthSet(nseq=24, n_sites=20, seed=3)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    idx = mtg.Index.from_kmers(km, ct, 31)  # replicated index
+    lo, hi = shard_range(S.n_sites, rank, world)
+    gaps = []
+    for i in range(lo, hi):
+        l, r, _ = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+    h, nf, seqs = idx.fill_prepared(mtg.Index.prepare_gaps(gaps))
+    idx.free_results(h)
+    parts = gather_bytes(np.asarray(seqs), dst=0)
+    if rank == 0:
+        with open(out_path, "wb") as f:
+            for p in parts:
+                f.write(p.tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
