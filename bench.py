@@ -188,18 +188,27 @@ def main():
         oidx.close()
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (k_stage_a)
+    # achieved = ALGORITHMIC bytes (64 B per membership probe, probes counted by the oracle) / average kernel time.
+    # The ADJ layout answers a node's 8 probes with ONE bucket read, so the HBM traffic is ~1/8 of that figure.
+    line_bytes = int(info["adj_bucket_bytes"])
     alg_bytes_per_launch = 64.0 * probes_per_nt * contig_nt / max(launches, 1)
     avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
     achieved = alg_bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-    roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")
+    if a.workload == "human" and sites_per_gpu == 100000 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["mtgi::k_stage_a"]["hbm_read_bytes_avg"]
+        traffic_src = "profiles/r01_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same command; calibrated factor 1.000 on k_chase)"
+    roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "k_stage_a", "avg_kernel_ms": kernel_ms / max(launches, 1), "launches": int(launches),
             "algorithmic_bytes_per_launch": alg_bytes_per_launch, "probes_per_contig_nt": probes_per_nt,
-            "index_lines_per_launch": lines / max(launches, 1), "line_GBps": (lines * 64.0 / max(kernel_ms, 1e-9) / 1e6)}
+            "bucket_reads_per_launch": lines / max(launches, 1), "bucket_bytes": line_bytes,
+            "bucket_reads_per_s": lines / max(kernel_ms, 1e-9) * 1e3}
     if not a.no_ceiling:
         tb = min(int(info["device_bytes"] // 2), 64 << 30)
-        ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), sites_per_gpu, 512, 64)
-        roof["random_line_ceiling_GBps"] = gbps
-        roof["frac_of_random_line_ceiling"] = roof["line_GBps"] / gbps if gbps else None
+        ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), sites_per_gpu, 512, line_bytes)
+        roof["random_read_ceiling_reads_per_s"] = gbps * 1e9 / line_bytes
+        roof["frac_of_random_read_ceiling"] = roof["bucket_reads_per_s"] / roof["random_read_ceiling_reads_per_s"] if gbps else None
 
     out = {"metric": "breakpoints filled/sec", "value": value, "unit": "breakpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",

@@ -50,6 +50,7 @@ typedef struct mtg_index_info {
     uint64_t nb_branching;      /* "nb_branching"    (src/Filler.cpp:428) */
     uint64_t device_bytes;      /* HBM held by the index */
     uint64_t adj_buckets, abnd_buckets;
+    uint32_t adj_bucket_bytes, abnd_bucket_bytes; /* one bucket = one read of the walk / of an abundance query */
 } mtg_index_info;
 
 /* Graph::create(props) from read files (src/Filler.cpp:172-213): paths_csv = comma separated FASTA/FASTQ(.gz);

@@ -261,6 +261,8 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load)
     idx->info.device_bytes = ba + bb;
     idx->info.adj_buckets = idx->dev.adj.nbuckets;
     idx->info.abnd_buckets = idx->dev.abnd.nbuckets;
+    idx->info.adj_bucket_bytes = 8 * MTG_ADJ_SLOTS;
+    idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
     return MTG_OK;
 }
 static void free_tables(mtg_index* idx)

@@ -39,7 +39,7 @@ class Params(C.Structure):
 
 class IndexInfo(C.Structure):
     _fields_ = [("k", C.c_int), ("abundance_min", C.c_int), ("abundance_auto", C.c_int), ("nb_solid_kmers", C.c_uint64),
-                ("nb_branching", C.c_uint64), ("device_bytes", C.c_uint64), ("adj_buckets", C.c_uint64), ("abnd_buckets", C.c_uint64)]
+                ("nb_branching", C.c_uint64), ("device_bytes", C.c_uint64), ("adj_buckets", C.c_uint64), ("abnd_buckets", C.c_uint64), ("adj_bucket_bytes", C.c_uint32), ("abnd_bucket_bytes", C.c_uint32)]
 
 
 class CGap(C.Structure):

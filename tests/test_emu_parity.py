@@ -97,7 +97,10 @@ def test_scratch_tier_escalation():
 
 @pytest.fixture(scope="module")
 def emu_product():
-    return emu_lib.product_on_emulator()
+    from mindthegap_amd import lib as L
+    saved = L._lib
+    yield emu_lib.product_on_emulator()
+    L._lib = saved
 
 
 def test_cli_on_emulator_reproduces_goldens(emu_product, golden_dir, tmp_path):
