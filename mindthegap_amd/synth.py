@@ -52,3 +52,29 @@ class SynthSet:
             for i in sites:
                 l, r, _ = self.site(i)
                 f.write(">%s left_kmer\n%s\n>%s right_kmer\n%s\n" % (self.site_name(i), l, self.site_name(i), r))
+
+
+def simulate_reads(S, path, coverage=30, read_len=150, error_rate=0.0, seed=5):
+    """SURVEY 8(d) cfg-2 reads: uniform start, both strands, substitution errors at error_rate (variant E0 = 0, E1 = 0.001).
+    Writes a FASTA file; returns the number of reads."""
+    rng = np.random.default_rng(seed)
+    comp = np.array([2, 3, 0, 1], dtype=np.uint8)  # A<->T (0<->2), C<->G (1<->3)
+    n = 0
+    with open(path, "w") as f:
+        for j in range(S.nseq):
+            c = S.codes(j)
+            L = len(c)
+            nr = int(round(coverage * L / read_len))
+            starts = rng.integers(0, L - read_len + 1, nr)
+            strands = rng.integers(0, 2, nr)
+            for st, sd in zip(starts, strands):
+                r = c[st:st + read_len].copy()
+                if error_rate > 0:
+                    e = np.nonzero(rng.random(read_len) < error_rate)[0]
+                    if len(e):
+                        r[e] = (r[e] + rng.integers(1, 4, len(e)).astype(np.uint8)) & 3
+                if sd:
+                    r = comp[r[::-1]]
+                f.write(">r%d\n%s\n" % (n, NT[r].tobytes().decode()))
+                n += 1
+    return n

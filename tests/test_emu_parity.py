@@ -171,3 +171,27 @@ def test_cli_on_emulator_bubbly_contig_mode(emu_product, tmp_path):
         assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
     assert "solution" in _read(str(tmp_path / "hip.gfa")) or _read(str(tmp_path / "hip.gfa")).count("\nS\t") > 5
     o.close()
+
+
+@pytest.mark.parametrize("err", [0.0, 0.003])
+def test_cli_on_emulator_simulated_reads(emu_product, tmp_path, err):
+    """cfg-2 shaped set at reduced size, index built from simulated 30x reads (-in path, abundance-min 3): variant E0 (error-free)
+    and an error-laden variant whose surviving erroneous k-mers create tips and bubbles.  Both must equal the oracle byte for byte."""
+    from mindthegap_amd.synth import SynthSet, simulate_reads
+    S = SynthSet(nseq=12, n_sites=10, seed=21)
+    reads = str(tmp_path / "reads.fa")
+    simulate_reads(S, reads, coverage=30, error_rate=err, seed=5)
+    bk = str(tmp_path / "s.breakpoints")
+    S.write_breakpoints(bk)
+    o = oracle_lib.Index.from_files([reads], 31, 3)
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert emu_product.Filler().run(["-in", reads, "-bkpt", bk, "-abundance-min", "3", "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    filled = _read(str(tmp_path / "hip.insertions.fasta")).count(">")
+    assert filled >= 8
+    if err == 0.0:  # error-free reads: every fill is exactly the inserted sequence
+        seqs = [l for l in _read(str(tmp_path / "hip.insertions.fasta")).splitlines() if not l.startswith(">")]
+        assert seqs == [S.site(i)[2] for i in range(S.n_sites)]
+    o.close()

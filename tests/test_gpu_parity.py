@@ -204,3 +204,26 @@ def test_reverse_attempt_and_unfillable(mtg, tmp_path):
     assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
     assert ">" in _read(str(tmp_path / "hip.insertions.fasta"))
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("err", [0.0, 0.002])
+def test_simulated_reads_cfg2_shape(mtg, tmp_path, err):
+    """BASELINE config 2 at reduced size: 30x simulated reads (E0 error-free / E1-like with substitutions), index built by -in with
+    -abundance-min 3, CLI outputs byte-identical to the oracle."""
+    from mindthegap_amd.synth import SynthSet, simulate_reads
+    from tests import oracle_lib
+    S = SynthSet(nseq=60, n_sites=50, seed=21)
+    reads = str(tmp_path / "reads.fa")
+    simulate_reads(S, reads, coverage=30, error_rate=err, seed=5)
+    bk = str(tmp_path / "s.breakpoints")
+    S.write_breakpoints(bk)
+    o = oracle_lib.Index.from_files([reads], 31, 3)
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert mtg.Filler().run(["-in", reads, "-bkpt", bk, "-abundance-min", "3", "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    if err == 0.0:
+        seqs = [l for l in _read(str(tmp_path / "hip.insertions.fasta")).splitlines() if not l.startswith(">")]
+        assert seqs == [S.site(i)[2] for i in range(S.n_sites)]
+    o.close()
