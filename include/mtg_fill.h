@@ -51,6 +51,8 @@ typedef struct mtg_index_info {
     uint64_t device_bytes;      /* HBM held by the index */
     uint64_t adj_buckets, abnd_buckets;
     uint32_t adj_bucket_bytes, abnd_bucket_bytes; /* one bucket = one read of the walk / of an abundance query */
+    uint64_t bloom_blocks;      /* 64-byte blocks of the Bloom filter (0 = not built) */
+    uint32_t bloom_minimizer;   /* minimizer length selecting the block */
 } mtg_index_info;
 
 /* Graph::create(props) from read files (src/Filler.cpp:172-213): paths_csv = comma separated FASTA/FASTQ(.gz);
@@ -76,6 +78,21 @@ void mtg_index_free(mtg_index* idx);
 int mtg_index_contains(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* out);
 int mtg_index_abundance(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* out);
 int mtg_index_neighbors(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* succ, uint8_t* pred);
+
+/* Membership of every k-mer along sequences = Graph::contains per position (the access pattern of the reference's `find` scan,
+ * src/FindBreakpoints.hpp:851-853,1012-1046).  A rolling 2-bit k-mer per position, probed against the minimizer-blocked Bloom filter
+ * of the index (blocks staged in LDS, one coalesced 64-byte read per run of k-mers sharing a minimizer).
+ * mode 0: Bloom answer only (no false negatives); mode 1: exact (Bloom pre-filter, positives confirmed in the abundance table).
+ * out[s] receives len(seqs[s]) - k + 1 bytes (0/1); k-mers with a non-ACGT character give 0. */
+typedef struct mtg_scan_stats {
+    uint64_t n_kmers, bloom_positive, confirmed, blocks_staged;
+    double kernel_ms;
+} mtg_scan_stats;
+int mtg_index_scan_sequences(const mtg_index* idx, const char* const* seqs, size_t nseq, int mode, uint8_t* const* out, mtg_scan_stats* st);
+/* same on 2-bit packed sequences already in DEVICE memory (layout of mtg_index_create_from_packed_device);
+ * bit (p % 64) of d_out_bits[word_off[s] + p / 64] = membership of the k-mer starting at nt p of sequence s */
+int mtg_index_scan_packed_device(const mtg_index* idx, const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, int mode,
+                                 uint64_t* d_out_bits, mtg_scan_stats* st);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Gap filling = Filler::gapFillFromSource over a batch of gaps.

@@ -190,11 +190,79 @@ template <int SLOTS> MTG_DEV int table_or(const Table& t, uint64_t key, uint32_t
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* Blocked Bloom filter over the solid canonical k-mers, for membership scans along sequences (the `find`-style consumer,
+ * /root/reference/src/FindBreakpoints.hpp:851-853,1012-1046; gatb's BLOOM_NEIGHBOR idea, src/Filler.cpp:189).  A block is 512 bits =
+ * one 64-byte line; all NHASH bits of a k-mer fall in the block selected by the hash of the k-mer's MINIMIZER (smallest hashed
+ * canonical mm-mer), so that the ~ (k-mm+2)/2 consecutive k-mers of a sequence that share a minimizer share one block. */
+struct Bloom {
+    uint32_t* bits;    /* nblocks * 16 words */
+    uint64_t nblocks;
+    int mm;            /* minimizer length */
+};
+enum { MTG_BLOOM_NHASH = 4 };
+
 struct Index {
     Table adj;  /* canonical (k-1)-mer -> edge masks */
     Table abnd; /* canonical k-mer     -> abundance  */
+    Bloom bloom;
     int k;
 };
+
+MTG_DEV uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+/* block of the oriented k-mer x: orientation independent (canonical mm-mers) */
+MTG_DEV uint64_t bloom_block(const Bloom& bl, const Kmer& x, int k)
+{
+    const int mm = bl.mm;
+    const uint64_t mmask = kmask(mm);
+    uint64_t best = ~0ULL;
+    for (int i = 0; i + mm <= k; i++) {
+        const uint64_t a = (x.f >> (2 * i)) & mmask;               /* mm-mer ending i nts before the end of x          */
+        const uint64_t b = (x.r >> (2 * (k - mm - i))) & mmask;    /* its reverse complement, read from the rc strand */
+        const uint64_t h = mix64(a < b ? a : b);
+        best = h < best ? h : best;
+    }
+    best = mix64(best + 0x9E3779B97F4A7C15ULL); /* the minimum of several hashes is not uniform: scramble it again */
+#ifdef MTG_EMU
+    return (uint64_t)(((unsigned __int128)best * bl.nblocks) >> 64);
+#else
+    return __umul64hi(best, bl.nblocks);
+#endif
+}
+/* bit positions inside the block: 4 x 9 bits of a hash of the canonical k-mer */
+MTG_DEV uint64_t bloom_bits(uint64_t canon_kmer) { return mix64(canon_kmer ^ 0x9E3779B97F4A7C15ULL); }
+MTG_DEV bool bloom_test_block(const uint32_t* blk, uint64_t hb)
+{
+    bool ok = true;
+    MTG_UNROLL
+    for (int j = 0; j < MTG_BLOOM_NHASH; j++) {
+        const uint32_t bit = (uint32_t)(hb >> (9 * j)) & 511u;
+        ok = ok && ((blk[bit >> 5] >> (bit & 31u)) & 1u);
+    }
+    return ok;
+}
+MTG_DEV void bloom_insert(const Bloom& bl, const Kmer& x, int k)
+{
+    uint32_t* blk = bl.bits + bloom_block(bl, x, k) * 16;
+    const uint64_t hb = bloom_bits(canon(x));
+    for (int j = 0; j < MTG_BLOOM_NHASH; j++) {
+        const uint32_t bit = (uint32_t)(hb >> (9 * j)) & 511u;
+#ifdef MTG_EMU
+        __sync_fetch_and_or(&blk[bit >> 5], 1u << (bit & 31u));
+#else
+        atomicOr(&blk[bit >> 5], 1u << (bit & 31u));
+#endif
+    }
+}
+MTG_DEV bool bloom_test(const Bloom& bl, const Kmer& x, int k)
+{
+    return bloom_test_block(bl.bits + bloom_block(bl, x, k) * 16, bloom_bits(canon(x)));
+}
 
 struct Adj {
     uint32_t out; /* nts b such that x[1:]+b is solid  (successors of x)                     */
@@ -234,6 +302,7 @@ MTG_DEV int index_insert(const Index& ix, uint64_t c, uint32_t abund)
     Kmer o[2];
     o[0].f = c; o[0].r = revcomp(c, k);
     o[1].f = o[0].r; o[1].r = c;
+    if (ix.bloom.bits) bloom_insert(ix.bloom, o[0], k);
     for (int s = 0; s < 2; s++) {
         const Kmer& x = o[s];
         const uint32_t a = (uint32_t)(x.f >> (2 * (k - 1))) & 3u, b = (uint32_t)x.f & 3u;

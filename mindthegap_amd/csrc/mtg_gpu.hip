@@ -214,6 +214,79 @@ __global__ void k_compact(FillCfg cfg, const uint8_t* raw, const uint32_t* __res
     }
 }
 
+/* membership scan along packed sequences: rolling k-mer per position, minimizer-blocked Bloom with the blocks of a 256-position tile
+ * staged in LDS by coalesced 64-byte reads, optional exact confirmation in the ABND table.
+ * counters: [0] k-mers, [1] Bloom positives, [2] confirmed, [3] blocks staged */
+enum { SCAN_TILE = 256 };
+__global__ void __launch_bounds__(SCAN_TILE) k_scan(Index ix, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
+                                                    const uint32_t* __restrict__ len, size_t nseq, int mode, uint64_t* out_bits, unsigned long long* counters)
+{
+    __shared__ uint32_t s_blk[SCAN_TILE][16];
+    __shared__ uint64_t s_bid[SCAN_TILE];
+    __shared__ uint64_t s_slot_bid[SCAN_TILE];
+    __shared__ uint32_t s_wave_cnt[SCAN_TILE / 64];
+    const int k = ix.k;
+    const uint64_t mk = kmask(k);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned long long n_k = 0, n_pos = 0, n_conf = 0, n_staged = 0;
+    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        const uint64_t* w = words + word_off[s];
+        uint64_t* ob = out_bits + word_off[s];
+        const uint32_t npos = L - (uint32_t)k + 1;
+        for (uint32_t base = 0; base < npos; base += SCAN_TILE) {
+            const uint32_t p = base + tid;
+            const bool valid = p < npos;
+            Kmer x;
+            x.f = x.r = 0;
+            uint64_t b = ~0ull;
+            if (valid) {
+                x.r = le_kmer(w, p, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
+                x.f = revcomp(x.r, k);
+                b = bloom_block(ix.bloom, x, k);
+            }
+            s_bid[tid] = b;
+            __syncthreads();
+            const bool leader = valid && (tid == 0 || s_bid[tid - 1] != b);
+            const unsigned long long bal = __ballot(leader);
+            const uint32_t prefix = (uint32_t)__popcll(bal & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull)));
+            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t woff = 0, total = 0;
+            for (uint32_t i = 0; i < SCAN_TILE / 64; i++) { if (i < wave) woff += s_wave_cnt[i]; total += s_wave_cnt[i]; }
+            const uint32_t slot = woff + prefix - 1u; /* a follower at the start of a wave continues the last block of the previous wave */
+            if (leader) s_slot_bid[slot] = b;
+            __syncthreads();
+            for (uint32_t i = tid; i < total * 16u; i += SCAN_TILE) s_blk[i >> 4][i & 15u] = ix.bloom.bits[s_slot_bid[i >> 4] * 16u + (i & 15u)];
+            __syncthreads();
+            bool res = false;
+            if (valid) {
+                const uint64_t c = canon(x);
+                res = bloom_test_block(s_blk[slot], bloom_bits(c));
+                n_k++;
+                n_pos += res;
+                if (res && mode == 1) {
+                    uint32_t lines = 0;
+                    res = table_get<MTG_ABND_SLOTS>(ix.abnd, c, lines) != 0;
+                    n_conf += res;
+                }
+            }
+            const unsigned long long rb = __ballot(res);
+            if (lane == 0 && base + wave * 64u < npos) ob[(base >> 6) + wave] = rb;
+            if (tid == 0) n_staged += total;
+            __syncthreads();
+        }
+    }
+    /* per-workgroup totals */
+    __shared__ unsigned long long s_tot[4];
+    if (tid < 4) s_tot[tid] = 0;
+    __syncthreads();
+    atomicAdd(&s_tot[0], n_k); atomicAdd(&s_tot[1], n_pos); atomicAdd(&s_tot[2], n_conf); atomicAdd(&s_tot[3], n_staged);
+    __syncthreads();
+    if (tid < 4 && s_tot[tid]) atomicAdd(&counters[tid], s_tot[tid]);
+}
+
 /* dependent chains of random line reads: the access pattern of the simple-path walk.  LINE = bytes read per step (16..128) */
 template <int LINE>
 __global__ void __launch_bounds__(64) k_chase(const uint64_t* __restrict__ table, uint64_t nlines, uint64_t n_chains, uint32_t chain_len, uint64_t* sink)
@@ -256,9 +329,22 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load)
         set_error("hipMalloc of %zu bytes failed: %s", bb, hipGetErrorString(e));
         return MTG_ERR_NOMEM;
     }
+    const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
+    size_t bc = 0;
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.bloom.nblocks = 0;
+    if (bpk > 0) {
+        bloom_shape(idx->dev.bloom, nkeys, bpk, k);
+        bc = idx->dev.bloom.nblocks * 64;
+        hipError_t e2 = hipMalloc((void**)&idx->dev.bloom.bits, bc);
+        if (e2 != hipSuccess) { set_error("hipMalloc of %zu bytes failed: %s", bc, hipGetErrorString(e2)); return MTG_ERR_NOMEM; }
+        HIP_TRY(hipMemsetAsync(idx->dev.bloom.bits, 0, bc, 0));
+    }
     HIP_TRY(hipMemsetAsync(idx->dev.adj.slots, 0, ba, 0));
     HIP_TRY(hipMemsetAsync(idx->dev.abnd.slots, 0, bb, 0));
-    idx->info.device_bytes = ba + bb;
+    idx->info.device_bytes = ba + bb + bc;
+    idx->info.bloom_blocks = idx->dev.bloom.nblocks;
+    idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
     idx->info.adj_buckets = idx->dev.adj.nbuckets;
     idx->info.abnd_buckets = idx->dev.abnd.nbuckets;
     idx->info.adj_bucket_bytes = 8 * MTG_ADJ_SLOTS;
@@ -269,7 +355,9 @@ static void free_tables(mtg_index* idx)
 {
     if (idx->dev.adj.slots) (void)hipFree(idx->dev.adj.slots);
     if (idx->dev.abnd.slots) (void)hipFree(idx->dev.abnd.slots);
+    if (idx->dev.bloom.bits) (void)hipFree(idx->dev.bloom.bits);
     idx->dev.adj.slots = idx->dev.abnd.slots = nullptr;
+    idx->dev.bloom.bits = nullptr;
 }
 
 int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
@@ -582,6 +670,45 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     return rc;
 }
 
+int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits,
+             int device_ptrs, mtg_scan_stats* st)
+{
+    if (int rc = ensure_device()) return rc;
+    if (!idx || !idx->dev.bloom.bits) { set_error("the index has no Bloom filter (MTG_BLOOM_BITS=0)"); return MTG_ERR_ARG; }
+    if (nseq == 0) return MTG_OK;
+    DevBuf d_w, d_o, d_l, d_b, d_c;
+    const uint64_t *pw = words, *po = word_off;
+    const uint32_t* pl = len;
+    uint64_t* pb = out_bits;
+    if (!device_ptrs) {
+        HIP_TRY(d_w.alloc(nwords * 8)); HIP_TRY(d_o.alloc(nseq * 8)); HIP_TRY(d_l.alloc(nseq * 4)); HIP_TRY(d_b.alloc(nwords * 8));
+        HIP_TRY(hipMemcpy(d_w.p, words, nwords * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_o.p, word_off, nseq * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_l.p, len, nseq * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(d_b.p, 0, nwords * 8));
+        pw = d_w.as<uint64_t>(); po = d_o.as<uint64_t>(); pl = d_l.as<uint32_t>(); pb = d_b.as<uint64_t>();
+    }
+    HIP_TRY(d_c.alloc(32));
+    HIP_TRY(hipMemset(d_c.p, 0, 32));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)std::min<size_t>(nseq, 256 * 16)), dim3(SCAN_TILE), 0, 0, idx->dev, pw, po, pl, nseq, mode, pb, d_c.as<unsigned long long>());
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    unsigned long long c[4];
+    HIP_TRY(hipMemcpy(c, d_c.p, 32, hipMemcpyDeviceToHost));
+    if (!device_ptrs) HIP_TRY(hipMemcpy(out_bits, pb, nwords * 8, hipMemcpyDeviceToHost));
+    if (st) { st->n_kmers = c[0]; st->bloom_positive = c[1]; st->confirmed = c[2]; st->blocks_staged = c[3]; st->kernel_ms = ms; }
+    return MTG_OK;
+}
+
 int bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, uint32_t line_bytes, double* ms_out, double* gbps)
 {
     if (int rc = ensure_device()) return rc;
@@ -671,6 +798,12 @@ int mtg_index_abundance(const mtg_index* idx, const uint64_t* kmers, size_t n, u
 int mtg_index_neighbors(const mtg_index* idx, const uint64_t* kmers, size_t n, uint8_t* succ, uint8_t* pred)
 {
     return mtgi::query_run(idx, kmers, n, nullptr, succ, pred);
+}
+int mtg_index_scan_packed_device(const mtg_index* idx, const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, int mode,
+                                 uint64_t* d_out_bits, mtg_scan_stats* st)
+{
+    if (!d_words || !d_word_off || !d_len || !d_out_bits) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    return mtgi::scan_run(idx, d_words, 0, d_word_off, d_len, nseq, mode, d_out_bits, 1, st);
 }
 int mtg_last_batch_stats(mtg_batch_stats* s)
 {

@@ -708,6 +708,32 @@ int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
     }, 512);
     return MTG_OK;
 }
+int mtg_index_scan_sequences(const mtg_index* idx, const char* const* seqs, size_t nseq, int mode, uint8_t* const* out, mtg_scan_stats* st)
+{
+    if (!idx || (nseq && (!seqs || !out))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    const int k = idx->dev.k;
+    std::vector<uint64_t> off(nseq);
+    std::vector<uint32_t> len(nseq);
+    uint64_t nw = 0;
+    for (size_t s = 0; s < nseq; s++) { len[s] = (uint32_t)strlen(seqs[s]); off[s] = nw; nw += (len[s] + 31) / 32 + 2; }
+    std::vector<uint64_t> words(nw + 2, 0), bits(nw + 2, 0);
+    for (size_t s = 0; s < nseq; s++)
+        for (uint32_t i = 0; i < len[s]; i++) words[off[s] + (i >> 5)] |= (uint64_t)nt_code((unsigned char)seqs[s][i]) << (2 * (i & 31));
+    int rc = mtgi::scan_run(idx, words.data(), words.size(), off.data(), len.data(), nseq, mode, bits.data(), 0, st);
+    if (rc) return rc;
+    for (size_t s = 0; s < nseq; s++) {
+        if ((int)len[s] < k) continue;
+        const uint32_t npos = len[s] - k + 1;
+        int bad_until = -1; /* last position whose k-mer still contains an invalid character */
+        for (uint32_t i = 0; i < (uint32_t)k - 1 && i < len[s]; i++) if (mtgi::nt_bad((unsigned char)seqs[s][i])) bad_until = (int)i;
+        for (uint32_t p = 0; p < npos; p++) {
+            if (mtgi::nt_bad((unsigned char)seqs[s][p + k - 1])) bad_until = (int)(p + k - 1);
+            out[s][p] = (bad_until >= (int)p) ? 0 : (uint8_t)((bits[off[s] + (p >> 6)] >> (p & 63)) & 1);
+        }
+    }
+    return MTG_OK;
+}
+
 int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n, mtg_contigs** out)
 {
     if (!idx || !p || !out || (n && (!sources || !targets))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }

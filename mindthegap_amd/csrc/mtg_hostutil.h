@@ -31,6 +31,14 @@ inline void table_shape(Table& t, uint64_t nbuckets, uint32_t key_bits)
     t.tag_bits = key_bits > lg ? key_bits - lg : 0;
 }
 
+/* Bloom shape for n k-mers */
+inline void bloom_shape(Bloom& b, uint64_t nkeys, double bits_per_kmer, int k)
+{
+    b.nblocks = (uint64_t)((double)nkeys * bits_per_kmer / 512.0) + 16;
+    b.mm = k >= 25 ? 17 : (k - 8 > 5 ? k - 8 : 5);
+    b.bits = nullptr;
+}
+
 /* scratch tiers: tier 0 fits the common case, each further tier multiplies the growable capacities by 8 */
 inline FillCfg make_cfg(int k, int max_nodes, int max_depth, int end_rule_nonbranching, int tier)
 {

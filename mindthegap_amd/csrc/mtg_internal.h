@@ -200,6 +200,10 @@ struct FillInput {
 /* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats);
 
+/* membership scan over packed sequences: host arrays in (words/off/len), bit output as in mtg_index_scan_packed_device; device = 1: the pointers are device pointers */
+int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int device_ptrs,
+             mtg_scan_stats* st);
+
 int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
 
 void stats_store(const mtg_batch_stats& s);

@@ -39,7 +39,7 @@ class Params(C.Structure):
 
 class IndexInfo(C.Structure):
     _fields_ = [("k", C.c_int), ("abundance_min", C.c_int), ("abundance_auto", C.c_int), ("nb_solid_kmers", C.c_uint64),
-                ("nb_branching", C.c_uint64), ("device_bytes", C.c_uint64), ("adj_buckets", C.c_uint64), ("abnd_buckets", C.c_uint64), ("adj_bucket_bytes", C.c_uint32), ("abnd_bucket_bytes", C.c_uint32)]
+                ("nb_branching", C.c_uint64), ("device_bytes", C.c_uint64), ("adj_buckets", C.c_uint64), ("abnd_buckets", C.c_uint64), ("adj_bucket_bytes", C.c_uint32), ("abnd_bucket_bytes", C.c_uint32), ("bloom_blocks", C.c_uint64), ("bloom_minimizer", C.c_uint32)]
 
 
 class CGap(C.Structure):
@@ -57,6 +57,10 @@ class CGapResult(C.Structure):
     _fields_ = [("nb_nodes", C.c_int), ("total_nt", C.c_int), ("nb_terminal", C.c_int), ("has_solution_counts", C.c_int),
                 ("nb_total_filled", C.c_int), ("nb_reported", C.c_int), ("n_filled", C.c_int), ("filled", C.POINTER(CFilled)),
                 ("extension", C.c_char_p)]
+
+
+class ScanStats(C.Structure):
+    _fields_ = [("n_kmers", C.c_uint64), ("bloom_positive", C.c_uint64), ("confirmed", C.c_uint64), ("blocks_staged", C.c_uint64), ("kernel_ms", C.c_double)]
 
 
 class BatchStats(C.Structure):
@@ -92,6 +96,8 @@ def _bind(lib):
     lib.mtg_index_contains.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint8)]
     lib.mtg_index_abundance.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint32)]
     lib.mtg_index_neighbors.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint8), P(C.c_uint8)]
+    lib.mtg_index_scan_sequences.argtypes = [C.c_void_p, P(C.c_char_p), C.c_size_t, C.c_int, P(P(C.c_uint8)), P(ScanStats)]
+    lib.mtg_index_scan_packed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, P(ScanStats)]
     lib.mtg_default_params.argtypes = [P(Params)]
     lib.mtg_default_params.restype = None
     lib.mtg_fill_batch.argtypes = [C.c_void_p, P(Params), P(CGap), C.c_size_t, P(C.c_void_p)]
@@ -199,6 +205,22 @@ class Index:
         _check(self.lib.mtg_index_neighbors(self.h, kmers.ctypes.data_as(C.POINTER(C.c_uint64)), len(kmers), s.ctypes.data_as(C.POINTER(C.c_uint8)),
                                             p.ctypes.data_as(C.POINTER(C.c_uint8))))
         return s, p
+
+    def scan_sequences(self, seqs, exact=True):
+        """membership (0/1) of the k-mer starting at every position of every sequence; returns (list of uint8 arrays, stats dict)"""
+        k = self.info()["k"]
+        n = len(seqs)
+        arr = (C.c_char_p * n)(*[s.encode() for s in seqs])
+        outs = [np.zeros(max(len(s) - k + 1, 0), dtype=np.uint8) for s in seqs]
+        ptrs = (C.POINTER(C.c_uint8) * n)(*[o.ctypes.data_as(C.POINTER(C.c_uint8)) for o in outs])
+        st = ScanStats()
+        _check(self.lib.mtg_index_scan_sequences(self.h, arr, n, 1 if exact else 0, ptrs, C.byref(st)))
+        return outs, {f[0]: getattr(st, f[0]) for f in ScanStats._fields_}
+
+    def scan_packed_device(self, words_ptr, word_off_ptr, len_ptr, nseq, out_bits_ptr, exact=True):
+        st = ScanStats()
+        _check(self.lib.mtg_index_scan_packed_device(self.h, words_ptr, word_off_ptr, len_ptr, nseq, 1 if exact else 0, out_bits_ptr, C.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in ScanStats._fields_}
 
     def stage_a(self, sources, targets, params=None):
         """Contigs of every gap (gatb IterativeExtensions::construct_linear_seqs, src/Filler.cpp:884)."""

@@ -31,6 +31,8 @@ void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, 
         e->abnd_slots.assign(e->ix.abnd.nbuckets * MTG_ABND_SLOTS, 0);
         e->ix.adj.slots = e->adj_slots.data();
         e->ix.abnd.slots = e->abnd_slots.data();
+        e->ix.bloom.bits = nullptr;
+        e->ix.bloom.nblocks = 0;
         int fail = 0;
         for (size_t i = 0; i < n; i++) fail |= index_insert(e->ix, kmers[i], counts[i]) & 1;
         if (!fail) return e;

@@ -35,6 +35,8 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
         table_shape(idx->dev.abnd, buckets_for(n, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
         idx->dev.adj.slots = (uint64_t*)calloc(idx->dev.adj.nbuckets * MTG_ADJ_SLOTS, 8);
         idx->dev.abnd.slots = (uint64_t*)calloc(idx->dev.abnd.nbuckets * MTG_ABND_SLOTS, 8);
+        bloom_shape(idx->dev.bloom, n, 12.0, k);
+        idx->dev.bloom.bits = (uint32_t*)calloc(idx->dev.bloom.nblocks * 16, 4);
         int fail = 0;
         uint64_t created = 0;
         for (size_t i = 0; i < n; i++) { int r = index_insert(idx->dev, kmers[i], ab[i]); fail |= r & 1; created += (r >> 1) & 1; }
@@ -46,10 +48,11 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
                 nbr += !(popc4(adj_right(idx->dev, x, mk1, lines).out) == 1 && popc4(adj_left(idx->dev, x, mk1, lines).in) == 1);
             }
             idx->info.k = k; idx->info.nb_solid_kmers = created; idx->info.nb_branching = nbr; idx->info.abundance_auto = -1;
+            idx->info.bloom_blocks = idx->dev.bloom.nblocks; idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
             *out = idx;
             return MTG_OK;
         }
-        free(idx->dev.adj.slots); free(idx->dev.abnd.slots); delete idx;
+        free(idx->dev.adj.slots); free(idx->dev.abnd.slots); free(idx->dev.bloom.bits); delete idx;
         load *= 0.7;
     }
 }
@@ -57,7 +60,7 @@ void index_release(mtg_index* idx)
 {
     if (!idx) return;
     index_forget_host_copy(idx);
-    free(idx->dev.adj.slots); free(idx->dev.abnd.slots);
+    free(idx->dev.adj.slots); free(idx->dev.abnd.slots); free(idx->dev.bloom.bits);
     delete idx;
 }
 
@@ -72,6 +75,29 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
         if (succ) succ[i] = (uint8_t)adj_right(idx->dev, x, mk1, lines).out;
         if (pred) pred[i] = (uint8_t)adj_left(idx->dev, x, mk1, lines).in;
     }
+    return MTG_OK;
+}
+
+int scan_run(const mtg_index* idx, const uint64_t* words, size_t, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int,
+             mtg_scan_stats* st)
+{
+    const int k = idx->dev.k;
+    const uint64_t mk = kmask(k);
+    mtg_scan_stats t{};
+    for (size_t s = 0; s < nseq; s++) {
+        if (len[s] < (uint32_t)k) continue;
+        for (uint32_t p = 0; p + k <= len[s]; p++) {
+            Kmer x;
+            x.r = le_kmer(words + word_off[s], p, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
+            x.f = revcomp(x.r, k);
+            bool res = bloom_test(idx->dev.bloom, x, k);
+            t.n_kmers++;
+            t.bloom_positive += res;
+            if (res && mode == 1) { uint32_t lines = 0; res = abundance(idx->dev, x, lines) != 0; t.confirmed += res; }
+            if (res) out_bits[word_off[s] + (p >> 6)] |= 1ull << (p & 63);
+        }
+    }
+    if (st) *st = t;
     return MTG_OK;
 }
 
@@ -155,6 +181,11 @@ int mtg_index_contains(const mtg_index* idx, const uint64_t* kmers, size_t n, ui
     return MTG_OK;
 }
 int mtg_index_create_from_packed_device(const uint64_t*, const uint64_t*, const uint32_t*, size_t, uint64_t, int, uint32_t, uint32_t, mtg_index**)
+{
+    mtgi::set_error("emulation harness: no device");
+    return MTG_ERR_NO_DEVICE;
+}
+int mtg_index_scan_packed_device(const mtg_index*, const uint64_t*, const uint64_t*, const uint32_t*, size_t, int, uint64_t*, mtg_scan_stats*)
 {
     mtgi::set_error("emulation harness: no device");
     return MTG_ERR_NO_DEVICE;

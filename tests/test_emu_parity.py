@@ -195,3 +195,53 @@ def test_cli_on_emulator_simulated_reads(emu_product, tmp_path, err):
         seqs = [l for l in _read(str(tmp_path / "hip.insertions.fasta")).splitlines() if not l.startswith(">")]
         assert seqs == [S.site(i)[2] for i in range(S.n_sites)]
     o.close()
+
+
+def _scan_case(mtg_mod):
+    """shared by the emulator (CPU) and the GPU test: sequence scans against the oracle's exact membership"""
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=30, n_sites=10, seed=17)
+    seqs = [S.ascii(j) for j in range(S.nseq)]
+    o = oracle_lib.Index.from_sequences(seqs[:20], 31, 3, 40)  # sequences 20..29 are absent from the graph
+    km, ct = o.export()
+    g = mtg_mod.Index.from_kmers(km, ct, 31)
+    rng = random.Random(4)
+    q = list(seqs[15:25])
+    mutated = list(q[0])
+    for p in range(100, len(mutated), 97):
+        mutated[p] = "ACGT"[("ACGT".index(mutated[p]) + 1) % 4]
+    q.append("".join(mutated))
+    q.append(q[1][:700] + "N" + q[1][701:1500] + "nn" + q[1][1502:2000])
+    q.append(q[2][:40])
+    q.append("ACGT")
+    exact, st = g.scan_sequences(q, exact=True)
+    maybe, st0 = g.scan_sequences(q, exact=False)
+    M = (1 << 62) - 1
+    for s, e, m in zip(q, exact, maybe):
+        n = max(len(s) - 30, 0)
+        assert len(e) == n
+        if n == 0:
+            continue
+        codes = np.array([(ord(c) >> 1) & 3 for c in s], dtype=np.uint64)
+        bad = np.array([(ord(c) >> 3) & 1 for c in s], dtype=np.int64)
+        kmers = np.zeros(n, dtype=np.uint64)
+        f = 0
+        for i, c in enumerate(codes.tolist()):
+            f = ((f << 2) | c) & M
+            if i >= 30:
+                kmers[i - 30] = f
+        truth = o.contains(kmers)
+        cb = np.concatenate([[0], np.cumsum(bad)])
+        truth = np.where((cb[31:31 + n] - cb[:n]) > 0, 0, truth).astype(np.uint8)
+        assert (e == truth).all()              # exact mode == Graph::contains per position
+        assert (m >= e).all()                  # the Bloom answer has no false negatives
+    assert st["confirmed"] <= st["bloom_positive"] <= st["n_kmers"]
+    neg = st0["n_kmers"] - st["confirmed"]
+    assert (st0["bloom_positive"] - st["confirmed"]) <= 0.05 * neg + 5  # false-positive rate of the pre-filter
+    assert st["blocks_staged"] * 3 < st["n_kmers"]  # minimizer coherence: far fewer blocks than k-mers
+    g.close()
+    o.close()
+
+
+def test_sequence_scan_on_emulator(emu_product):
+    _scan_case(emu_product)

@@ -227,3 +227,9 @@ def test_simulated_reads_cfg2_shape(mtg, tmp_path, err):
         seqs = [l for l in _read(str(tmp_path / "hip.insertions.fasta")).splitlines() if not l.startswith(">")]
         assert seqs == [S.site(i)[2] for i in range(S.n_sites)]
     o.close()
+
+
+def test_sequence_scan_bloom_kernel(mtg):
+    """k_scan (rolling k-mer + LDS-staged minimizer-blocked Bloom + exact confirmation) against the oracle's Graph::contains"""
+    from tests.test_emu_parity import _scan_case
+    _scan_case(mtg)
