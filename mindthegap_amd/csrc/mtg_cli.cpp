@@ -106,7 +106,7 @@ static void write_filled(Files& F, bool bkpt_mode, const GapWork& g, const std::
 static void write_vcf(Files& F, bool filter, const std::vector<Solution>& sols, const std::string& breakpointName, const std::string& sourceSequence)
 {
     for (auto& s : sols) {
-        std::string insertion = s.seq;
+        std::string insertion = s.seq.str();
         int repeatSize = 0;
         int i = (int)sourceSequence.size() - 1, j = (int)s.seq.size() - 1;
         while (i > 0 && j >= 0) { /* longest common suffix with a circular insert index, :1107-1126 */
@@ -216,7 +216,8 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
         fwd.push_back(make_gap(s.source, dict, s.repeated, false));
         swf.push_back(s.target);
     }
-    int rc = fill_gaps(idx, &P, fwd, swf, nullptr);
+    FillArena arena_fwd, arena_rev;
+    int rc = fill_gaps(idx, &P, fwd, swf, arena_fwd, nullptr);
     if (rc) return rc;
     /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
     std::vector<size_t> rev_of;
@@ -233,7 +234,7 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
                 swf2.push_back(target2);
                 rev_of.push_back(i);
             }
-    if (!rev.empty()) { rc = fill_gaps(idx, &P, rev, swf2, nullptr); if (rc) return rc; }
+    if (!rev.empty()) { rc = fill_gaps(idx, &P, rev, swf2, arena_rev, nullptr); if (rc) return rc; }
     std::vector<long> rev_idx(nsites, -1);
     for (size_t j = 0; j < rev_of.size(); j++) rev_idx[rev_of[j]] = (long)j;
     for (size_t i = 0; i < nsites; i++) {
@@ -303,7 +304,8 @@ static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& 
         gaps.push_back(make_gap(sd.second, dict, false, false));
         swf.push_back(conc);
     }
-    int rc = fill_gaps(idx, &P, gaps, swf, nullptr);
+    FillArena arena;
+    int rc = fill_gaps(idx, &P, gaps, swf, arena, nullptr);
     if (rc) return rc;
     for (size_t i = 0; i < seeds.size(); i++) {
         const std::string& seedName = seeds[i].first;

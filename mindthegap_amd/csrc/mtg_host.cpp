@@ -349,7 +349,7 @@ static float nw_identity(const std::string& a, const std::string& b)
 }
 
 /* everything after the device kernels for one gapFillFromSource call, except the coverage numbers of the general path */
-static void process_gap(const GapDev& gc, GapWork& W, int k)
+static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
 {
     W.nb_nodes = (int)gc.o.n_contigs;
     W.total_nt = (int)gc.o.total_nt;
@@ -364,7 +364,13 @@ static void process_gap(const GapDev& gc, GapWork& W, int k)
         /* terminal node 0: find_all_paths_rev returns the single path [0] (src/GraphAnalysis.cpp:222-226) and
          * paths_to_sequences keeps contig0[k:pos] (:386-423); coverage was computed on the device */
         Solution s;
-        s.seq = gc.contig0_slice((uint32_t)k, gc.p.pos);
+        /* written straight into the batch arena (reverse-complemented when the attempt is a reverse one, src/Filler.cpp:998-1001) */
+        const uint32_t L = gc.p.pos - (uint32_t)k;
+        static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
+        if (!W.reverse) for (uint32_t i = 0; i < L; i++) { const uint32_t j = (uint32_t)k + i; arena_slot[i] = NT[(gc.words[j >> 5] >> (2 * (j & 31))) & 3]; }
+        else for (uint32_t i = 0; i < L; i++) { const uint32_t j = (uint32_t)k + i; arena_slot[L - 1 - i] = NTC[(gc.words[j >> 5] >> (2 * (j & 31))) & 3]; }
+        arena_slot[L] = 0;
+        s.seq.view(arena_slot, L);
         s.nb_errors = (int)gc.p.errors;
         s.target = (int)gc.p.target;
         s.count = 1;
@@ -438,7 +444,7 @@ static void process_gap(const GapDev& gc, GapWork& W, int k)
             for (auto& a : tmp) {
                 bool similar = false;
                 for (auto& b : fin) {
-                    if (a.seq == b.seq || nw_identity(a.seq, b.seq) * 100 >= 90) {
+                    if (a.seq == b.seq || nw_identity(a.seq.str(), b.seq.str()) * 100 >= 90) {
                         if (a.nb_errors < b.nb_errors) { b.seq = a.seq; b.nb_errors = a.nb_errors; }
                         similar = true;
                         break;
@@ -488,7 +494,8 @@ static int compute_qual(const Solution& s, bool repeated) /* src/Utils.hpp:85-10
 }
 
 /* runs a batch of gapFillFromSource calls */
-int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, mtg_batch_stats* stats_out)
+int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, FillArena& arena,
+              mtg_batch_stats* stats_out)
 {
     const int k = idx->dev.k;
     const size_t n = gaps.size();
@@ -514,7 +521,10 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     if (rc) return rc;
     if (dbg) fprintf(stderr, "  [fill_gaps] pre %.2f device_run %.2f ms\n", tdev - t_begin, now_ms() - tdev);
     double t0 = now_ms();
-    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k); });
+    std::vector<uint64_t> aoff(n + 1, 0);
+    for (size_t i = 0; i < n; i++) aoff[i + 1] = aoff[i] + (dev[i].p.fast == 1 ? (uint64_t)(dev[i].p.pos - (uint32_t)k) + 1 : 0);
+    arena.chars.resize(aoff[n] + 1);
+    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k, arena.chars.data() + aoff[i]); });
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);
@@ -524,15 +534,16 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
             s.ab_off = q.size();
             uint64_t f = 0;
             int valid = 0;
-            auto feed = [&](const std::string& str) {
-                for (unsigned char c : str) {
+            auto feed = [&](const char* str, size_t len) {
+                for (size_t ci = 0; ci < len; ci++) {
+                    const unsigned char c = (unsigned char)str[ci];
                     if (nt_bad(c)) { valid = 0; f = 0; continue; }
                     f = ((f << 2) | nt_code(c)) & mk;
                     if (++valid >= k) q.push_back(f);
                 }
             };
-            feed(g.source);
-            feed(s.seq);
+            feed(g.source.data(), g.source.size());
+            feed(s.seq.data(), s.seq.size());
             s.ab_n = q.size() - s.ab_off;
             s.qual = -2;
         }
@@ -563,7 +574,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
                 s.median = v.empty() ? 0.f : (float)median_of(v);
             }
             s.qual = compute_qual(s, g.anchor_repeated);
-            if (g.reverse) s.seq = revcomp_str(s.seq);
+            if (g.reverse && !s.seq.is_view()) s.seq = revcomp_str(s.seq.str()); /* views were written reverse-complemented */
         }
     });
     st.host_ms += now_ms() - t0;
@@ -578,6 +589,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
 
 /* ------------------------------------------------------------------------------------------------ C ABI (host side) */
 struct mtg_results {
+    mtgi::FillArena arena;
     std::vector<mtgi::GapWork> gaps;
     std::vector<std::vector<mtg_filled>> filled;
     std::vector<mtg_gap_result> res;
@@ -633,7 +645,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     });
     const double t_m1 = mtgi::now_ms();
     mtg_batch_stats st{};
-    int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, &st);
+    int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, R->arena, &st);
     if (rc) { delete R; return rc; }
     const double t_m2 = mtgi::now_ms();
     R->filled.resize(n);

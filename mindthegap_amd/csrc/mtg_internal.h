@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -208,8 +209,29 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
 
 void stats_store(const mtg_batch_stats& s);
 
+/* a filled sequence: either an owned string (general path) or a NUL-terminated view into the batch arena (common path) */
+struct SeqBuf {
+    std::string own;
+    const char* p = nullptr;
+    uint32_t n = 0;
+    bool is_view() const { return p != nullptr; }
+    size_t size() const { return p ? n : own.size(); }
+    size_t length() const { return size(); }
+    const char* data() const { return p ? p : own.data(); }
+    const char* c_str() const { return p ? p : own.c_str(); }
+    char operator[](size_t i) const { return data()[i]; }
+    std::string str() const { return std::string(data(), size()); }
+    SeqBuf& operator=(std::string s) { own = std::move(s); p = nullptr; n = 0; return *this; }
+    void view(const char* q, uint32_t len) { p = q; n = len; }
+    bool operator==(const SeqBuf& o) const { return size() == o.size() && memcmp(data(), o.data(), size()) == 0; }
+};
+/* storage of the common-path sequences of one batch; must outlive the GapWork results that point into it */
+struct FillArena {
+    std::vector<char> chars;
+};
+
 struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
-    std::string seq;
+    SeqBuf seq;
     int nb_errors = 0;
     int target = -1;
     float avg = 0, median = 0;
@@ -227,7 +249,8 @@ struct GapWork {
     void swap_into(GapWork& o) { std::swap(*this, o); } /* used to free o's storage on the calling thread */
 };
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
-int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, mtg_batch_stats* stats_out);
+int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, FillArena& arena,
+              mtg_batch_stats* stats_out);
 int index_from_kmers(const uint64_t*, const uint32_t*, size_t, int, mtg_index**);
 int index_from_reads(const char*, int, int, int, mtg_index**);
 int index_save(const mtg_index*, const char*);

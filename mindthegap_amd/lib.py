@@ -251,7 +251,7 @@ class Index:
             arr[i] = CGap(g.source.encode(), g.target.encode(), m, seqs, names, rcs, int(g.is_anchor_repeated), int(g.reverse))
         return (arr, n, keep)
 
-    def fill_prepared(self, prepared, params=None):
+    def fill_prepared(self, prepared, params=None, want_seqs=True):
         """one mtg_fill_batch call; returns (results handle, n_filled per gap, uint8 array of the packed "seq\\n" bytes).  Free with free_results."""
         params = params or FillParams()
         arr, n, _ = prepared
@@ -260,6 +260,8 @@ class Index:
         nf = np.zeros(n, dtype=np.uint32)
         nb, ng = C.c_uint64(), C.c_uint64()
         _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nb), C.byref(ng)))
+        if not want_seqs:
+            return h, nf, None
         buf = np.empty(max(int(nb.value), 1), dtype=np.uint8)
         _check(self.lib.mtg_results_copy_seqs(h, buf.ctypes.data_as(C.c_char_p), nb.value))
         return h, nf, buf[: nb.value]
