@@ -101,8 +101,6 @@ MTG_DEV uint64_t mix(uint64_t x, uint32_t key_bits)
     x ^= x >> sh;
     x = (x * 0xBF58476D1CE4E5B9ULL) & M;
     x ^= x >> sh;
-    x = (x * 0x94D049BB133111EBULL) & M;
-    x ^= x >> sh;
     return x;
 }
 MTG_DEV uint64_t bucket_of(uint64_t H, uint64_t nb, uint32_t key_bits)
@@ -270,15 +268,16 @@ struct Adj {
 };
 
 /* right neighbourhood of x: successors of x and in-neighbours of those successors (one line). */
-MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
+MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     const uint64_t s = x.f & mk1, rs = x.r >> 2;
-    const uint32_t m = table_get<MTG_ADJ_SLOTS>(ix.adj, s <= rs ? s : rs, lines);
+    const uint32_t m = table_get<MTG_ADJ_SLOTS>(adj, s <= rs ? s : rs, lines);
     Adj a;
     if (s <= rs) { a.out = m & 15u; a.in = m >> 4; }
     else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
     return a;
 }
+MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines) { return adj_right_t(ix.adj, x, mk1, lines); }
 /* left neighbourhood of x: .in = predecessors of x, .out = successors of every predecessor. */
 MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {

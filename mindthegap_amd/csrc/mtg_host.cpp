@@ -689,14 +689,20 @@ void mtg_results_free(mtg_results* r)
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
 {
     if (!r) return MTG_ERR_ARG;
-    uint64_t b = 0, nf = 0;
-    for (size_t i = 0; i < r->gaps.size(); i++) {
-        if (n_filled) n_filled[i] = (uint32_t)r->gaps[i].sols.size();
-        nf += !r->gaps[i].sols.empty();
-        for (auto& s : r->gaps[i].sols) b += s.seq.size() + 1;
-    }
-    if (seq_bytes) *seq_bytes = b;
-    if (n_gaps_filled) *n_gaps_filled = nf;
+    std::atomic<uint64_t> b{0}, nf{0};
+    const size_t n = r->gaps.size();
+    const size_t CH = 2048;
+    mtgi::parallel_for((n + CH - 1) / CH, 0, [&](size_t c) {
+        uint64_t lb = 0, lf = 0;
+        for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) {
+            if (n_filled) n_filled[i] = (uint32_t)r->gaps[i].sols.size();
+            lf += !r->gaps[i].sols.empty();
+            for (auto& s : r->gaps[i].sols) lb += s.seq.size() + 1;
+        }
+        b += lb; nf += lf;
+    }, 1);
+    if (seq_bytes) *seq_bytes = b.load();
+    if (n_gaps_filled) *n_gaps_filled = nf.load();
     return MTG_OK;
 }
 int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)

@@ -545,7 +545,8 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     Worker W(ix, cfg, S);
     const int k = W.k;
     const uint64_t mk = W.mk, mk1 = W.mk1;
-    const long long MAXLEN = 10LL * 1000 * 1000;
+    const uint32_t MAXLEN = 10u * 1000 * 1000;
+    const Table adj = ix.adj; /* local copy: the hot loop must not reload the table shape through the Worker */
     const bool r_is_kmer = (R.rlen == (uint32_t)k);
     uint64_t* q_f = s_qf(cfg, S);
     uint64_t* q_c = s_qc(cfg, S);
@@ -568,10 +569,10 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         Kmer cur = make_kmer(node_f, k);
         const uint64_t start_c = canon(cur);
         uint64_t prev_c = 0; /* gatb: default-constructed previousNode has k-mer value 0 */
-        long long len = 0;
+        uint32_t len = 0;
         bool looping = false;
         bool found_R = (r_is_kmer && cur.f == R.r0);
-        Adj a = adj_right(ix, cur, mk1, W.lines);
+        Adj a = adj_right_t(adj, cur, mk1, W.lines);
         for (;;) {
             if (popc4(a.out) == 1 && popc4(a.in) <= 1) {
                 /* simple path: one line per nucleotide */
@@ -580,7 +581,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
                 cur = kmer_next(cur, nt, k, mk);
                 W.push_nt(nt);
                 len++;
-                const Adj a2 = adj_right(ix, cur, mk1, W.lines);
+                const Adj a2 = adj_right_t(adj, cur, mk1, W.lines);
                 if (!(popc4(a2.out) == 1 && popc4(a.in) == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
                 if (r_is_kmer && cur.f == R.r0) found_R = true;
                 a = a2;

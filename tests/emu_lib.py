@@ -68,14 +68,22 @@ class EmuIndex:
 FULL_SO = os.path.join(ROOT, "tests", "emu", "libmtgfill_emu.so")
 
 
-def product_on_emulator():
-    """Returns the mindthegap_amd package with its ctypes handle pointed at the TEST-ONLY emulation build, so the CPU suite can
-    drive the real host code / CLI.  The product itself has no such switch."""
+def build_full():
+    """(re)build tests/emu/libmtgfill_emu.so when a source is newer"""
     csrc = os.path.join(ROOT, "mindthegap_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "emu", "emu_backend.cpp"), os.path.join(csrc, "mtg_host.cpp"), os.path.join(csrc, "mtg_cli.cpp")]
     deps = srcs + HDRS + [os.path.join(csrc, "mtg_internal.h"), os.path.join(ROOT, "include", "mtg_fill.h")]
     if not os.path.exists(FULL_SO) or any(os.path.getmtime(d) > os.path.getmtime(FULL_SO) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-o", FULL_SO] + srcs + ["-lz"])
+        tmp = FULL_SO + ".%d.tmp" % os.getpid()
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-o", tmp] + srcs + ["-lz"])
+        os.replace(tmp, FULL_SO)
+    return FULL_SO
+
+
+def product_on_emulator():
+    """Returns the mindthegap_amd package with its ctypes handle pointed at the TEST-ONLY emulation build, so the CPU suite can
+    drive the real host code / CLI.  The product itself has no such switch."""
+    build_full()
     import mindthegap_amd
     from mindthegap_amd import lib as L
     L._lib = L._bind(C.CDLL(FULL_SO))

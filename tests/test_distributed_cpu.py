@@ -19,6 +19,9 @@ def test_shard_range_partitions():
 
 
 def test_world_size_2_gloo_matches_truth(tmp_path):
+    from tests import emu_lib, oracle_lib
+    emu_lib.build_full()  # build once here: the two ranks must not race on the compiler
+    oracle_lib.build()
     out = str(tmp_path / "gathered.bin")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
