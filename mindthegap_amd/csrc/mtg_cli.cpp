@@ -37,6 +37,7 @@ static std::string revcomp_str(const std::string& s)
     return r;
 }
 
+/* the GapWork holds views: source and dict must outlive it */
 static GapWork make_gap(const std::string& source, const bkpt_dict_t& dict, bool repeated, bool reverse)
 {
     GapWork g;
@@ -92,7 +93,7 @@ static void write_filled(Files& F, bool bkpt_mode, const GapWork& g, const std::
         if (bkpt_mode) {
             fprintf(F.insert, ">%s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n", seedName.c_str(), llen, s.qual, (double)s.avg, (double)s.median, solu.c_str());
         } else {
-            std::string targetName = g.targets[s.target].name;
+            std::string targetName(g.targets[s.target].name);
             if (g.targets[s.target].is_rc) targetName.append("_Rc");
             int cov = s.median + 0.5;
             fprintf(F.insert, ">%s;%s;len_%d_qual_%d_median_cov_%d\t%s\n", seedName.c_str(), targetName.c_str(), llen, s.qual, cov, solu.c_str());
@@ -146,7 +147,7 @@ static void write_gfa(Files& F, int trim, const GapWork& g, const std::vector<So
     std::string seedDirection = "+";
     if (isRc) { seedName = seedName.substr(0, seedName.size() - 3); seedDirection = "-"; }
     for (auto& s : sols) {
-        const std::string& tname = g.targets[s.target].name;
+        const std::string tname(g.targets[s.target].name);
         const bool trc = g.targets[s.target].is_rc;
         const std::string targetNameNode = trc ? tname + "_Rc" : tname;
         int cov = s.median + 0.5;
@@ -203,7 +204,9 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
     struct Site { std::string source, target, name, name_r; bool repeated; };
     std::vector<Site> sites(nsites);
     std::vector<GapWork> fwd;
-    std::vector<std::string> swf;
+    std::vector<std::string_view> swf;
+    std::vector<bkpt_dict_t> dicts(nsites), dicts_rev(nsites); /* kept alive: the gaps hold views on their strings */
+    std::vector<std::string> src_rev(nsites), tgt_rev(nsites);
     for (size_t i = 0; i < nsites; i++) {
         Site& s = sites[i];
         s.source = recs[2 * i].second;
@@ -211,7 +214,7 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
         s.name = short_name(recs[2 * i].first);
         s.name_r = short_name(recs[2 * i + 1].first);
         s.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
-        bkpt_dict_t dict;
+        bkpt_dict_t& dict = dicts[i];
         dict.insert({s.target, std::make_pair(s.name_r, false)});
         fwd.push_back(make_gap(s.source, dict, s.repeated, false));
         swf.push_back(s.target);
@@ -222,16 +225,17 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
     /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
     std::vector<size_t> rev_of;
     std::vector<GapWork> rev;
-    std::vector<std::string> swf2;
+    std::vector<std::string_view> swf2;
     if (!O.fwd_only)
         for (size_t i = 0; i < nsites; i++)
             if (fwd[i].sols.empty()) {
                 const Site& s = sites[i];
-                const std::string target2 = revcomp_str(s.source), source2 = revcomp_str(s.target);
-                bkpt_dict_t dict;
-                dict.insert({target2, std::make_pair(s.name, false)});
-                rev.push_back(make_gap(source2, dict, s.repeated, true));
-                swf2.push_back(target2);
+                tgt_rev[i] = revcomp_str(s.source);
+                src_rev[i] = revcomp_str(s.target);
+                bkpt_dict_t& dict = dicts_rev[i];
+                dict.insert({tgt_rev[i], std::make_pair(s.name, false)});
+                rev.push_back(make_gap(src_rev[i], dict, s.repeated, true));
+                swf2.push_back(tgt_rev[i]);
                 rev_of.push_back(i);
             }
     if (!rev.empty()) { rc = fill_gaps(idx, &P, rev, swf2, arena_rev, nullptr); if (rc) return rc; }
@@ -292,10 +296,13 @@ static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& 
     }
     /* contigFunctor, src/Filler.cpp:492-572 */
     std::vector<GapWork> gaps;
-    std::vector<std::string> swf;
-    for (auto& sd : seeds) {
-        std::string conc;
-        bkpt_dict_t dict;
+    std::vector<std::string_view> swf;
+    std::vector<bkpt_dict_t> dicts(seeds.size()); /* kept alive: the gaps hold views on their strings */
+    std::vector<std::string> concs(seeds.size());
+    for (size_t si = 0; si < seeds.size(); si++) {
+        auto& sd = seeds[si];
+        std::string& conc = concs[si];
+        bkpt_dict_t& dict = dicts[si];
         for (auto its = all_targets.begin(); its != all_targets.end(); ++its) {
             std::string tempName = its->second.first;
             if (its->second.second) tempName += "_Rc";
@@ -313,7 +320,7 @@ static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& 
         std::vector<Solution> kept;
         for (auto& s : gaps[i].sols) { /* drop loops: target == seed reversed, :540-557 */
             const Target& t = gaps[i].targets[s.target];
-            const std::string revTargetName = t.is_rc ? t.name : t.name + "_Rc";
+            const std::string revTargetName = t.is_rc ? std::string(t.name) : std::string(t.name) + "_Rc";
             if (revTargetName != seedName) kept.push_back(s);
         }
         write_filled(F, false, gaps[i], kept, seedName, info_string(gaps[i]));

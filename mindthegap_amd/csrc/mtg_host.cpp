@@ -234,12 +234,12 @@ void FillInput::layout()
     tle.assign(nt, 0);
     tbad.assign(nt, 0);
 }
-void FillInput::set(size_t g, const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis)
+void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const std::vector<Target>* targets, int nb_mis)
 {
-    src[g] = encode_kmer(source.c_str(), k);
+    src[g] = encode_kmer(source.data(), k);
     const size_t rl = swf_target.size(), w0 = roff[g];
     for (size_t i = 0; i < rl; i++) rwords[w0 + (i >> 5)] |= (uint64_t)nt_code((unsigned char)swf_target[i]) << (2 * (i & 31));
-    r0[g] = rl >= (size_t)k ? encode_kmer(swf_target.c_str(), k) : 0;
+    r0[g] = rl >= (size_t)k ? encode_kmer(swf_target.data(), k) : 0;
     if (targets) {
         size_t o = toff[g];
         for (const Target& t : *targets) {
@@ -406,7 +406,7 @@ static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
     /* group by target name: unordered_map<string, set<path>> iterated in libstdc++ order (src/Filler.cpp:924-936) */
     std::unordered_map<std::string, std::set<Path>> paths_to_compare;
     for (auto& pr : paths) {
-        std::string key = W.targets[pr.second].name;
+        std::string key(W.targets[pr.second].name);
         if (W.targets[pr.second].is_rc) key += "_Rc";
         paths_to_compare[key].insert(pr.first);
     }
@@ -494,7 +494,7 @@ static int compute_qual(const Solution& s, bool repeated) /* src/Utils.hpp:85-10
 }
 
 /* runs a batch of gapFillFromSource calls */
-int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, FillArena& arena,
+int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,
               mtg_batch_stats* stats_out)
 {
     const int k = idx->dev.k;
@@ -623,7 +623,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     const double t_m0 = mtgi::now_ms();
     mtg_results* R = new mtg_results();
     R->gaps.resize(n);
-    std::vector<std::string> swf(n);
+    std::vector<std::string_view> swf(n);
     for (size_t i = 0; i < n; i++) {
         const mtg_gap& g = gaps[i];
         if (!g.source || !g.target || (g.n_targets && (!g.target_seqs || !g.target_names))) { delete R; mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
@@ -671,6 +671,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
         r.filled = R->filled[i].data();
         r.extension = w.extension.c_str();
     });
+    /* the views on the caller's strings end here */
     st.marshal_ms = t_m1 - t_m0;
     st.result_ms = mtgi::now_ms() - t_m2;
     st.total_ms = mtgi::now_ms() - t_m0;
@@ -764,7 +765,7 @@ int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* con
         in.size(i, strlen(targets[i]), 0);
     }
     in.layout();
-    for (size_t i = 0; i < n; i++) in.set(i, sources[i], targets[i], nullptr, 0);
+    for (size_t i = 0; i < n; i++) in.set(i, std::string_view(sources[i]), std::string_view(targets[i]), nullptr, 0);
     mtgi::DevBatch batch;
     std::vector<mtgi::GapDev>& gc = batch.gaps;
     mtg_batch_stats st{};

@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <vector>
 
@@ -125,8 +126,9 @@ template <typename F> inline void parallel_for(size_t n, int nthreads, F f, size
 }
 
 /* one gapFillFromSource call and its results (host side) */
+/* strings of a batch are VIEWS on the caller's storage, which must stay alive until the results have been consumed */
 struct Target {
-    std::string seq, name;
+    std::string_view seq, name;
     bool is_rc = false;
     uint64_t code = 0;    /* 2-bit code of the first k chars */
     uint64_t badmask = 0; /* positions (pair-lsb) that can never match (not ACGT/acgt) */
@@ -195,7 +197,7 @@ struct FillInput {
     void resize(size_t n);
     void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }
     void layout();
-    void set(size_t i, const std::string& source, const std::string& swf_target, const std::vector<Target>* targets, int nb_mis);
+    void set(size_t i, std::string_view source, std::string_view swf_target, const std::vector<Target>* targets, int nb_mis);
 };
 
 /* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
@@ -240,7 +242,7 @@ struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
 };
 struct GapWork {
     std::vector<Target> targets; /* targetDictionary in iteration order */
-    std::string source;
+    std::string_view source;
     bool anchor_repeated = false, reverse = false;
     int nb_nodes = 0, total_nt = 0, nb_terminal = 0, nb_total_filled = 0;
     bool has_counts = false;
@@ -249,7 +251,7 @@ struct GapWork {
     void swap_into(GapWork& o) { std::swap(*this, o); } /* used to free o's storage on the calling thread */
 };
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
-int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string>& swf_targets, FillArena& arena,
+int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,
               mtg_batch_stats* stats_out);
 int index_from_kmers(const uint64_t*, const uint32_t*, size_t, int, mtg_index**);
 int index_from_reads(const char*, int, int, int, mtg_index**);
