@@ -188,6 +188,81 @@ template <int SLOTS> MTG_DEV int table_or(const Table& t, uint64_t key, uint32_t
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* ---- ADJ entries: 2 words.  w0 = [tag | disp:4 | edge mask:8] as above; w1 = two 32-bit LOOKAHEADS (low half: walking to the
+ * right of the canonical (k-1)-mer, high half: walking to the right of its reverse complement).  A lookahead [count:4 | nt0:2 | nt1:2 ...]
+ * lists up to 14 further nucleotides of the unique simple path that starts with this node's single out-edge: every node on it has
+ * exactly one in- and one out-edge, so the walker may take those steps without touching memory (partial unitig compaction, filled by
+ * build_lookahead once all k-mers are inserted).  A bucket holds MTG_ADJ_SLOTS entries. */
+enum { MTG_LA_MAX = 14 };
+
+MTG_DEV uint32_t adj_get(const Table& t, uint64_t key, uint32_t& lines, uint64_t& aux)
+{
+    const uint64_t H = mix(key, t.key_bits);
+    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    aux = 0;
+    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
+        const U64x2* p = reinterpret_cast<const U64x2*>(t.slots + b * (2 * MTG_ADJ_SLOTS));
+        U64x2 q[MTG_ADJ_SLOTS];
+MTG_UNROLL
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) q[i] = p[i];
+        lines++;
+        const uint64_t want = (tag << MTG_DISP_BITS) | d;
+        uint32_t val = 0;
+MTG_UNROLL
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) {
+            const bool hit = (q[i].x >> 8) == want && q[i].x != 0;
+            val |= hit ? (uint32_t)(q[i].x & 255) : 0u;
+            aux |= hit ? q[i].y : 0ull;
+        }
+        if (val) return val;
+        if (q[MTG_ADJ_SLOTS - 1].x == 0) return 0;
+        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
+    }
+    return 0;
+}
+/* pointer to the entry of key (its w0), or nullptr */
+MTG_DEV uint64_t* adj_find(const Table& t, uint64_t key)
+{
+    const uint64_t H = mix(key, t.key_bits);
+    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
+        const uint64_t want = (tag << MTG_DISP_BITS) | d;
+        uint64_t* p = t.slots + b * (2 * MTG_ADJ_SLOTS);
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) {
+            const uint64_t v = p[2 * i];
+            if (v == 0) return nullptr;
+            if ((v >> 8) == want) return p + 2 * i;
+        }
+        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
+    }
+    return nullptr;
+}
+MTG_DEV int adj_or(const Table& t, uint64_t key, uint32_t bits)
+{
+    const uint64_t H = mix(key, t.key_bits);
+    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
+        const uint64_t want = (tag << MTG_DISP_BITS) | d;
+        uint64_t* p = t.slots + b * (2 * MTG_ADJ_SLOTS);
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) {
+            uint64_t v = *(volatile uint64_t*)(p + 2 * i);
+            if (v == 0) {
+                v = atomic_cas64(p + 2 * i, 0, (want << 8) | bits);
+                if (v == 0) return 2;
+            }
+            if ((v >> 8) == want) {
+                if ((v & bits) != bits) atomic_or64(p + 2 * i, bits);
+                return 0;
+            }
+        }
+        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
+    }
+    return 1;
+}
+
 /* Blocked Bloom filter over the solid canonical k-mers, for membership scans along sequences (the `find`-style consumer,
  * /root/reference/src/FindBreakpoints.hpp:851-853,1012-1046; gatb's BLOOM_NEIGHBOR idea, src/Filler.cpp:189).  A block is 512 bits =
  * one 64-byte line; all NHASH bits of a k-mer fall in the block selected by the hash of the k-mer's MINIMIZER (smallest hashed
@@ -265,16 +340,18 @@ MTG_DEV bool bloom_test(const Bloom& bl, const Kmer& x, int k)
 struct Adj {
     uint32_t out; /* nts b such that x[1:]+b is solid  (successors of x)                     */
     uint32_t in;  /* nts a such that a+x[1:] is solid  (predecessors of every successor of x) */
+    uint32_t la;  /* lookahead past the single successor, valid when out and in are single bits (adj_right only) */
 };
 
-/* right neighbourhood of x: successors of x and in-neighbours of those successors (one line). */
+/* right neighbourhood of x: successors of x and in-neighbours of those successors (one bucket read). */
 MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     const uint64_t s = x.f & mk1, rs = x.r >> 2;
-    const uint32_t m = table_get<MTG_ADJ_SLOTS>(adj, s <= rs ? s : rs, lines);
+    uint64_t aux;
+    const uint32_t m = adj_get(adj, s <= rs ? s : rs, lines, aux);
     Adj a;
-    if (s <= rs) { a.out = m & 15u; a.in = m >> 4; }
-    else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
+    if (s <= rs) { a.out = m & 15u; a.in = m >> 4; a.la = (uint32_t)aux; }
+    else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); a.la = (uint32_t)(aux >> 32); }
     return a;
 }
 MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines) { return adj_right_t(ix.adj, x, mk1, lines); }
@@ -282,8 +359,10 @@ MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& li
 MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     const uint64_t p = x.f >> 2, rp = x.r & mk1;
-    const uint32_t m = table_get<MTG_ADJ_SLOTS>(ix.adj, p <= rp ? p : rp, lines);
+    uint64_t aux;
+    const uint32_t m = adj_get(ix.adj, p <= rp ? p : rp, lines, aux);
     Adj a;
+    a.la = 0;
     if (p <= rp) { a.out = m & 15u; a.in = m >> 4; }
     else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
     return a;
@@ -306,13 +385,46 @@ MTG_DEV int index_insert(const Index& ix, uint64_t c, uint32_t abund)
         const Kmer& x = o[s];
         const uint32_t a = (uint32_t)(x.f >> (2 * (k - 1))) & 3u, b = (uint32_t)x.f & 3u;
         const uint64_t suf = x.f & mk1, rsuf = x.r >> 2; /* a + suf is solid */
-        if (suf <= rsuf) fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, suf, 1u << (4 + a)) & 1;
-        else fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, rsuf, 1u << (a ^ 2u)) & 1;
+        if (suf <= rsuf) fail |= adj_or(ix.adj, suf, 1u << (4 + a)) & 1;
+        else fail |= adj_or(ix.adj, rsuf, 1u << (a ^ 2u)) & 1;
         const uint64_t pre = x.f >> 2, rpre = x.r & mk1; /* pre + b is solid */
-        if (pre <= rpre) fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, pre, 1u << b) & 1;
-        else fail |= table_or<MTG_ADJ_SLOTS>(ix.adj, rpre, 1u << (4 + (b ^ 2u))) & 1;
+        if (pre <= rpre) fail |= adj_or(ix.adj, pre, 1u << b) & 1;
+        else fail |= adj_or(ix.adj, rpre, 1u << (4 + (b ^ 2u))) & 1;
     }
     return (fail & 1) | created;
+}
+
+/* Lookahead of the node "suffix (k-1)-mer of the solid k-mer x" in x's orientation; call for both orientations of every solid
+ * k-mer AFTER all insertions.  Idempotent (every caller computes the same value and ORs it in). */
+MTG_DEV void build_lookahead(const Index& ix, const Kmer& x)
+{
+    const int k = ix.k;
+    const uint64_t mk1 = kmask(k - 1);
+    uint64_t s = x.f & mk1, rs = x.r >> 2; /* the node and its reverse complement */
+    uint32_t lines = 0;
+    uint64_t aux;
+    const bool fwd0 = s <= rs;
+    const uint64_t key0 = fwd0 ? s : rs;
+    uint32_t m = adj_get(ix.adj, key0, lines, aux);
+    uint32_t out = fwd0 ? (m & 15u) : comp_mask(m >> 4), in = fwd0 ? (m >> 4) : comp_mask(m & 15u);
+    if (!(popc4(out) == 1 && popc4(in) == 1)) return;
+    uint32_t la = 0, n = 0;
+    while (n < MTG_LA_MAX) {
+        const uint32_t nt = (uint32_t)ctz4(out);
+        s = ((s << 2) | nt) & mk1;
+        rs = (rs >> 2) | ((uint64_t)(nt ^ 2u) << (2 * (k - 2)));
+        const bool fw = s <= rs;
+        m = adj_get(ix.adj, fw ? s : rs, lines, aux);
+        out = fw ? (m & 15u) : comp_mask(m >> 4);
+        in = fw ? (m >> 4) : comp_mask(m & 15u);
+        if (!(popc4(out) == 1 && popc4(in) == 1)) break;
+        la |= (uint32_t)ctz4(out) << (4 + 2 * n);
+        n++;
+    }
+    if (n == 0) return;
+    la |= n;
+    uint64_t* e = adj_find(ix.adj, key0);
+    if (e) atomic_or64(e + 1, fwd0 ? (uint64_t)la : ((uint64_t)la << 32));
 }
 
 } // namespace mtg

@@ -110,6 +110,39 @@ __global__ void k_insert_packed(Index ix, const uint64_t* __restrict__ words, co
     if (created) atomicAdd(&counters[1], created);
 }
 
+/* second build pass: lookaheads of the ADJ entries (after every k-mer has been inserted) */
+__global__ void k_lookahead_kmers(Index ix, const uint64_t* __restrict__ kmers, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Kmer x = make_kmer(kmers[i], ix.k);
+        build_lookahead(ix, x);
+        Kmer y;
+        y.f = x.r; y.r = x.f;
+        build_lookahead(ix, y);
+    }
+}
+__global__ void k_lookahead_packed(Index ix, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len, size_t nseq)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k);
+    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const uint64_t* w = words + word_off[s];
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        for (uint32_t p = threadIdx.x; p + k <= L; p += blockDim.x) {
+            Kmer x;
+            x.r = le_kmer(w, p, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
+            x.f = revcomp(x.r, k);
+            build_lookahead(ix, x);
+            Kmer y;
+            y.f = x.r; y.r = x.f;
+            build_lookahead(ix, y);
+        }
+    }
+}
+
 /* counters[2] += branching nodes among kmers[] (in-degree != 1 or out-degree != 1) */
 __global__ void k_count_branching(Index ix, const uint64_t* __restrict__ kmers, size_t n, unsigned long long* counters)
 {
@@ -315,12 +348,15 @@ __global__ void k_fill_random(uint64_t* p, uint64_t nwords, uint64_t seed)
 }
 
 /* ------------------------------------------------------------------------------------------------ index */
-static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load)
+static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
 {
     const int k = idx->dev.k;
-    table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
+    /* ADJ entries are 16 bytes and looked up on a dependent chain: keep buckets sparse; ABND is only read by independent queries */
+    const double load_adj = (getenv("MTG_ADJ_LOAD") ? atof(getenv("MTG_ADJ_LOAD")) : 0.45) * load_scale;
+    const double load = (getenv("MTG_ABND_LOAD") ? atof(getenv("MTG_ABND_LOAD")) : 0.5) * load_scale;
+    table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
     table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
-    const size_t ba = idx->dev.adj.nbuckets * 8 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
+    const size_t ba = idx->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
     HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));
     hipError_t e = hipMalloc((void**)&idx->dev.abnd.slots, bb);
     if (e != hipSuccess) {
@@ -347,7 +383,7 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load)
     idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
     idx->info.adj_buckets = idx->dev.adj.nbuckets;
     idx->info.abnd_buckets = idx->dev.abnd.nbuckets;
-    idx->info.adj_bucket_bytes = 8 * MTG_ADJ_SLOTS;
+    idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
     idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
     return MTG_OK;
 }
@@ -375,7 +411,7 @@ int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, siz
     HIP_TRY(hipMalloc((void**)&d_cnt, 4 * 8));
     HIP_TRY(hipMemcpy(d_k, canon_kmers, n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_a, abundance, n * 4, hipMemcpyHostToDevice));
-    double load = getenv("MTG_INDEX_LOAD") ? atof(getenv("MTG_INDEX_LOAD")) : 0.35;
+    double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
     int rc = MTG_OK;
     for (int attempt = 0; attempt < 6; attempt++) {
         rc = alloc_tables(idx, n, load);
@@ -386,6 +422,7 @@ int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, siz
         unsigned long long cnt[4];
         HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
         if (!cnt[0]) {
+            hipLaunchKernelGGL(k_lookahead_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, n);
             hipLaunchKernelGGL(k_count_branching, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, n, d_cnt);
             HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
             idx->info.nb_solid_kmers = cnt[1];
@@ -419,7 +456,7 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
     HIP_TRY(hipGetDevice(&idx->device));
     unsigned long long* d_cnt = nullptr;
     HIP_TRY(hipMalloc((void**)&d_cnt, 32));
-    double load = getenv("MTG_INDEX_LOAD") ? atof(getenv("MTG_INDEX_LOAD")) : 0.35;
+    double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
     int rc = MTG_OK;
     for (int attempt = 0; attempt < 6; attempt++) {
         rc = alloc_tables(idx, total_kmers_ub, load);
@@ -430,6 +467,8 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
         unsigned long long cnt[4];
         HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
         if (!cnt[0]) {
+            hipLaunchKernelGGL(k_lookahead_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq);
+            HIP_TRY(hipDeviceSynchronize());
             idx->info.nb_solid_kmers = cnt[1];
             idx->info.nb_branching = ~0ull; /* not computed on this path */
             rc = MTG_OK;

@@ -575,15 +575,31 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         Adj a = adj_right_t(adj, cur, mk1, W.lines);
         for (;;) {
             if (popc4(a.out) == 1 && popc4(a.in) <= 1) {
-                /* simple path: one line per nucleotide */
-                const uint32_t nt = (uint32_t)ctz4(a.out);
-                prev_c = canon(cur);
-                cur = kmer_next(cur, nt, k, mk);
-                W.push_nt(nt);
-                len++;
+                /* simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has exactly
+                 * one in- and one out-edge (lookahead): those nodes are non-branching (nothing to mark) and need no read. */
+                uint32_t nt = (uint32_t)ctz4(a.out);
+                uint32_t indeg = (uint32_t)popc4(a.in);          /* in-degree of the node we step onto */
+                uint32_t la = (indeg == 1) ? a.la : 0u;
+                uint32_t known = la & 15u;                       /* nodes ahead known to be simple */
+                la >>= 4;
+                bool stop = false;
+                for (;;) {
+                    prev_c = canon(cur);
+                    cur = kmer_next(cur, nt, k, mk);
+                    W.push_nt(nt);
+                    len++;
+                    if (r_is_kmer && cur.f == R.r0) found_R = true;
+                    if (known == 0) break;                       /* this node's neighbourhood has to be read */
+                    /* known simple node: terminator.mark() is a no-op on it */
+                    if (canon(cur) == start_c || len > MAXLEN || W.status) { stop = true; break; }
+                    nt = la & 3u;
+                    la >>= 2;
+                    known--;
+                    indeg = 1;
+                }
+                if (stop) break;
                 const Adj a2 = adj_right_t(adj, cur, mk1, W.lines);
-                if (!(popc4(a2.out) == 1 && popc4(a.in) == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
-                if (r_is_kmer && cur.f == R.r0) found_R = true;
+                if (!(popc4(a2.out) == 1 && indeg == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
                 a = a2;
                 if (canon(cur) == start_c) break; /* looping */
                 if (len > MAXLEN) break;

@@ -27,7 +27,7 @@ void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, 
         e->ix.k = k;
         table_shape(e->ix.adj, buckets_for(n + n / 8 + 16, load, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
         table_shape(e->ix.abnd, buckets_for(n, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
-        e->adj_slots.assign(e->ix.adj.nbuckets * MTG_ADJ_SLOTS, 0);
+        e->adj_slots.assign(e->ix.adj.nbuckets * MTG_ADJ_SLOTS * 2, 0);
         e->abnd_slots.assign(e->ix.abnd.nbuckets * MTG_ABND_SLOTS, 0);
         e->ix.adj.slots = e->adj_slots.data();
         e->ix.abnd.slots = e->abnd_slots.data();
@@ -35,7 +35,10 @@ void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, 
         e->ix.bloom.nblocks = 0;
         int fail = 0;
         for (size_t i = 0; i < n; i++) fail |= index_insert(e->ix, kmers[i], counts[i]) & 1;
-        if (!fail) return e;
+        if (!fail) {
+            for (size_t i = 0; i < n; i++) { Kmer x = make_kmer(kmers[i], k); build_lookahead(e->ix, x); Kmer y; y.f = x.r; y.r = x.f; build_lookahead(e->ix, y); }
+            return e;
+        }
         delete e;
         load *= 0.7;
     }

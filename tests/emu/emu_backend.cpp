@@ -33,7 +33,7 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
         idx->dev.k = k;
         table_shape(idx->dev.adj, buckets_for(n + n / 8 + 1024, load, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
         table_shape(idx->dev.abnd, buckets_for(n, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
-        idx->dev.adj.slots = (uint64_t*)calloc(idx->dev.adj.nbuckets * MTG_ADJ_SLOTS, 8);
+        idx->dev.adj.slots = (uint64_t*)calloc(idx->dev.adj.nbuckets * MTG_ADJ_SLOTS * 2, 8);
         idx->dev.abnd.slots = (uint64_t*)calloc(idx->dev.abnd.nbuckets * MTG_ABND_SLOTS, 8);
         bloom_shape(idx->dev.bloom, n, 12.0, k);
         idx->dev.bloom.bits = (uint32_t*)calloc(idx->dev.bloom.nblocks * 16, 4);
@@ -41,6 +41,7 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
         uint64_t created = 0;
         for (size_t i = 0; i < n; i++) { int r = index_insert(idx->dev, kmers[i], ab[i]); fail |= r & 1; created += (r >> 1) & 1; }
         if (!fail) {
+            for (size_t i = 0; i < n; i++) { Kmer x = make_kmer(kmers[i], k); build_lookahead(idx->dev, x); Kmer y; y.f = x.r; y.r = x.f; build_lookahead(idx->dev, y); }
             uint64_t nbr = 0, mk1 = kmask(k - 1);
             uint32_t lines = 0;
             for (size_t i = 0; i < n; i++) {
