@@ -208,7 +208,7 @@ def main():
             "bucket_reads_per_launch": lines / max(launches, 1), "bucket_bytes": line_bytes,
             "bucket_reads_per_s": lines / max(kernel_ms, 1e-9) * 1e3}
     if not a.no_ceiling:
-        tb = min(int(info["device_bytes"] // 2), 64 << 30)
+        tb = min(int(info["device_bytes"] // 2), 16 << 30)  # the ceiling is flat beyond ~16 GB (profiles/r01_random_line_ceiling.txt)
         ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), sites_per_gpu, 512, line_bytes)
         roof["random_read_ceiling_reads_per_s"] = gbps * 1e9 / line_bytes
         roof["frac_of_random_read_ceiling"] = roof["bucket_reads_per_s"] / roof["random_read_ceiling_reads_per_s"] if gbps else None

@@ -10,7 +10,7 @@
  *               simplePathAvance neighbourhood of a node (its 4 successors AND the 4 predecessors
  *               of those successors share this (k-1)-mer), i.e. 8 gatb membership probes.
  *   ABND table: key = canonical k-mer -> 8-bit abundance (saturating at 255).
- * A bucket holds 8 slots of 64 bits: [tag : tag_bits][disp : 4][value : 8].  The key is hashed by a
+ * A bucket holds 8 slots of 64 bits: [tag : tag_bits][disp : 6][value : 8].  The key is hashed by a
  * bijection of its 2m-bit domain, the bucket is floor(H * nbuckets / 2^2m) and the tag the low
  * tag_bits = 2m - floor(log2 nbuckets) bits of H, which makes (bucket, tag) lossless: the tables are
  * exact (no false positives), unlike a Bloom filter + cFP cascade, for any query k-mer.
@@ -82,7 +82,7 @@ struct Table {
     uint64_t* slots;   /* nbuckets * SLOTS words */
     uint64_t nbuckets;
     uint32_t key_bits; /* 2m */
-    uint32_t tag_bits; /* key_bits - floor(log2(nbuckets)), <= 52 */
+    uint32_t tag_bits; /* key_bits - floor(log2(nbuckets)), <= 50 */
 };
 /* slots per bucket: ADJ buckets are small because the walk pays per line touched, not per byte */
 #ifndef MTG_ADJ_SLOTS
@@ -91,7 +91,7 @@ struct Table {
 #ifndef MTG_ABND_SLOTS
 #define MTG_ABND_SLOTS 4
 #endif
-enum { MTG_MAX_DISP = 15, MTG_DISP_BITS = 4 };
+enum { MTG_MAX_DISP = 63, MTG_DISP_BITS = 6 };
 
 /* bijection of the key_bits-wide domain */
 MTG_DEV uint64_t mix(uint64_t x, uint32_t key_bits)
@@ -188,7 +188,7 @@ template <int SLOTS> MTG_DEV int table_or(const Table& t, uint64_t key, uint32_t
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* ---- ADJ entries: 2 words.  w0 = [tag | disp:4 | edge mask:8] as above; w1 = two 32-bit LOOKAHEADS (low half: walking to the
+/* ---- ADJ entries: 2 words.  w0 = [tag | disp:6 | edge mask:8] as above; w1 = two 32-bit LOOKAHEADS (low half: walking to the
  * right of the canonical (k-1)-mer, high half: walking to the right of its reverse complement).  A lookahead [count:4 | nt0:2 | nt1:2 ...]
  * lists up to 14 further nucleotides of the unique simple path that starts with this node's single out-edge: every node on it has
  * exactly one in- and one out-edge, so the walker may take those steps without touching memory (partial unitig compaction, filled by

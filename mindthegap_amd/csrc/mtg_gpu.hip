@@ -352,8 +352,8 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
 {
     const int k = idx->dev.k;
     /* ADJ entries are 16 bytes and looked up on a dependent chain: keep buckets sparse; ABND is only read by independent queries */
-    const double load_adj = (getenv("MTG_ADJ_LOAD") ? atof(getenv("MTG_ADJ_LOAD")) : 0.45) * load_scale;
-    const double load = (getenv("MTG_ABND_LOAD") ? atof(getenv("MTG_ABND_LOAD")) : 0.5) * load_scale;
+    const double load_adj = (getenv("MTG_ADJ_LOAD") ? atof(getenv("MTG_ADJ_LOAD")) : 0.5) * load_scale;
+    const double load = (getenv("MTG_ABND_LOAD") ? atof(getenv("MTG_ABND_LOAD")) : 0.6) * load_scale;
     table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
     table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
     const size_t ba = idx->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;

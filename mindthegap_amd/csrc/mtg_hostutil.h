@@ -16,7 +16,7 @@ inline uint32_t floor_log2_u64(uint64_t x) { uint32_t l = 0; while (x >>= 1) l++
 inline uint64_t buckets_for(uint64_t nkeys, double load, uint32_t key_bits, int slots)
 {
     uint64_t nb = (uint64_t)((double)nkeys / ((double)slots * load)) + 1;
-    uint64_t min_nb = key_bits > 52 ? (1ULL << (key_bits - 52)) : 1;
+    uint64_t min_nb = key_bits > 50 ? (1ULL << (key_bits - 50)) : 1;
     if (nb < min_nb) nb = min_nb;
     if (nb < 64) nb = 64;
     /* (bucket, tag) must stay lossless: nbuckets <= 2^key_bits */
