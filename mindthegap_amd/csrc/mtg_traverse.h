@@ -176,30 +176,13 @@ struct Worker {
     uint32_t lines;      /* 64-byte index lines read */
     uint32_t status;
     uint32_t n_marked, n_seen, n_iseen, n_inv;
-    /* contig writer */
-    uint64_t acc;
-    uint32_t nacc, wpos;
 
     MTG_DEV Worker(const Index& i, const FillCfg& c, const GapScratch& s)
         : ix(i), cfg(c), S(s), k(i.k), mk(kmask(i.k)), mk1(kmask(i.k - 1)), lines(0), status(GAP_OK), n_marked(0), n_seen(0), n_iseen(0),
-          n_inv(0), acc(0), nacc(0), wpos(0)
+          n_inv(0)
     {
     }
 
-    MTG_DEV void push_nt(uint32_t nt)
-    {
-        acc |= (uint64_t)nt << (2 * nacc);
-        if (++nacc == 32) flush();
-    }
-    MTG_DEV void flush()
-    {
-        if (nacc == 0) return;
-        if (wpos >= cfg.cap_words) { status = GAP_OVF_CONTIG; }
-        else s_words(cfg, S)[wpos] = acc;
-        wpos++;
-        acc = 0;
-        nacc = 0;
-    }
     MTG_DEV void mark_canon(uint64_t c)
     {
         if (set_add(s_marked(cfg, S), cfg.mcap, n_marked, c) == -2) status = GAP_OVF_MARKED;
@@ -552,6 +535,25 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     uint64_t* q_c = s_qc(cfg, S);
     int32_t* q_d = s_qd(cfg, S);
 
+    /* contig writer and hot counters live in registers: the Worker's address escapes to the noinline bubble code, so its fields are
+     * memory-resident and must stay out of the per-nucleotide path */
+    uint64_t* const words = s_words(cfg, S);
+    uint64_t acc = 0;
+    uint32_t nacc = 0, wpos = 0, lines = 0;
+    bool ovf = false;
+    auto push_nt = [&](uint32_t nt) {
+        acc |= (uint64_t)nt << (2 * nacc);
+        if (++nacc == 32) {
+            if (wpos >= cfg.cap_words) ovf = true; else words[wpos] = acc;
+            wpos++; acc = 0; nacc = 0;
+        }
+    };
+    auto flush = [&]() {
+        if (nacc == 0) return;
+        if (wpos >= cfg.cap_words) ovf = true; else words[wpos] = acc;
+        wpos++; acc = 0; nacc = 0;
+    };
+
     int head = 0, tail = 0;
     q_f[0] = src_f;
     q_c[0] = canon(make_kmer(src_f, k));
@@ -564,15 +566,15 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         const int node_depth = q_d[head];
         head++;
         /* ---- traverse(node) ---- */
-        const uint32_t c_first = W.wpos;
-        for (int i = k - 1; i >= 0; i--) W.push_nt((uint32_t)(node_f >> (2 * i)) & 3u);
+        const uint32_t c_first = wpos;
+        for (int i = k - 1; i >= 0; i--) push_nt((uint32_t)(node_f >> (2 * i)) & 3u);
         Kmer cur = make_kmer(node_f, k);
         const uint64_t start_c = canon(cur);
         uint64_t prev_c = 0; /* gatb: default-constructed previousNode has k-mer value 0 */
         uint32_t len = 0;
         bool looping = false;
         bool found_R = (r_is_kmer && cur.f == R.r0);
-        Adj a = adj_right_t(adj, cur, mk1, W.lines);
+        Adj a = adj_right_t(adj, cur, mk1, lines);
         for (;;) {
             if (popc4(a.out) == 1 && popc4(a.in) <= 1) {
                 /* simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has exactly
@@ -586,24 +588,24 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
                 for (;;) {
                     prev_c = canon(cur);
                     cur = kmer_next(cur, nt, k, mk);
-                    W.push_nt(nt);
+                    push_nt(nt);
                     len++;
                     if (r_is_kmer && cur.f == R.r0) found_R = true;
                     if (known == 0) break;                       /* this node's neighbourhood has to be read */
                     /* known simple node: terminator.mark() is a no-op on it */
-                    if (canon(cur) == start_c || len > MAXLEN || W.status) { stop = true; break; }
+                    if (canon(cur) == start_c || len > MAXLEN || ovf) { stop = true; break; }
                     nt = la & 3u;
                     la >>= 2;
                     known--;
                     indeg = 1;
                 }
                 if (stop) break;
-                const Adj a2 = adj_right_t(adj, cur, mk1, W.lines);
+                const Adj a2 = adj_right_t(adj, cur, mk1, lines);
                 if (!(popc4(a2.out) == 1 && indeg == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
                 a = a2;
                 if (canon(cur) == start_c) break; /* looping */
                 if (len > MAXLEN) break;
-                if (W.status) break;
+                if (ovf || W.status) break;
                 continue;
             }
             int chosen = -1;
@@ -613,7 +615,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             for (int i = 0; i < n; i++) {
                 prev_c = canon(cur);
                 cur = kmer_next(cur, p[i], k, mk);
-                W.push_nt(p[i]);
+                push_nt(p[i]);
                 len++;
                 W.mark(cur);
                 if (r_is_kmer && cur.f == R.r0) found_R = true;
@@ -621,10 +623,11 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             }
             if (looping) break;
             if (len > MAXLEN) break;
-            if (W.status) break;
-            a = adj_right(ix, cur, mk1, W.lines);
+            if (ovf || W.status) break;
+            a = adj_right_t(adj, cur, mk1, lines);
         }
-        W.flush();
+        flush();
+        if (ovf) W.status = GAP_OVF_CONTIG;
         if (W.status) break;
         const uint32_t clen = (uint32_t)(k + len);
         s_cstart(cfg, S)[nb] = c_first;
@@ -637,7 +640,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         if ((int)nb > cfg.max_nodes) break;
         if (node_depth + (int)clen > cfg.max_depth) continue;
         /* push the successors that were never extended from */
-        const Adj ea = adj_right(ix, cur, mk1, W.lines);
+        const Adj ea = adj_right_t(adj, cur, mk1, lines);
         for (uint32_t nt = 0; nt < 4; nt++) {
             if (!(ea.out & (1u << nt))) continue;
             const Kmer s = kmer_next(cur, nt, k, mk);
@@ -654,9 +657,9 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     }
     out.n_contigs = nb;
     out.status = W.status;
-    out.lines = W.lines;
+    out.lines = W.lines + lines;
     out.total_nt = total_nt;
-    out.n_words = W.wpos;
+    out.n_words = wpos;
 }
 
 } // namespace mtg
