@@ -427,5 +427,50 @@ MTG_DEV void build_lookahead(const Index& ix, const Kmer& x)
     if (e) atomic_or64(e + 1, fwd0 ? (uint64_t)la : ((uint64_t)la << 32));
 }
 
+/* ---- k-mer counting (Graph::create's DSK step, /root/reference/src/Filler.cpp:172-213): exact open-addressing count table ---- */
+struct CountTable {
+    uint64_t* keys;   /* ~0 = empty */
+    uint32_t* counts;
+    uint64_t mask;    /* capacity - 1 (power of two) */
+};
+/* gatb: bit 3 of the ASCII code flags a non-nucleotide ('N', and the '\n' separators of the concatenated reads) */
+MTG_DEV bool ascii_invalid(unsigned char c) { return (c >> 3) & 1; }
+/* canonical k-mer starting at text[i], or ~0 when the window holds an invalid character */
+MTG_DEV uint64_t kmer_from_ascii(const char* text, uint64_t i, int k)
+{
+    uint64_t f = 0;
+    bool bad = false;
+    for (int j = 0; j < k; j++) {
+        const unsigned char c = (unsigned char)text[i + j];
+        bad = bad || ascii_invalid(c);
+        f = (f << 2) | ((c >> 1) & 3u);
+    }
+    if (bad) return ~0ULL;
+    const uint64_t r = revcomp(f, k);
+    return f < r ? f : r;
+}
+/* returns false when the table is too full (probe limit reached) */
+MTG_DEV bool count_insert(const CountTable& t, uint64_t c)
+{
+    uint64_t h = mix64(c) & t.mask;
+    for (int probe = 0; probe < 8192; probe++) {
+        uint64_t cur = *(volatile uint64_t*)(t.keys + h);
+        if (cur == ~0ULL) {
+            cur = atomic_cas64(t.keys + h, ~0ULL, c);
+            if (cur == ~0ULL) cur = c;
+        }
+        if (cur == c) {
+#ifdef MTG_EMU
+            __sync_fetch_and_add(t.counts + h, 1u);
+#else
+            atomicAdd(t.counts + h, 1u);
+#endif
+            return true;
+        }
+        h = (h + 1) & t.mask;
+    }
+    return false;
+}
+
 } // namespace mtg
 #endif

@@ -110,6 +110,49 @@ __global__ void k_insert_packed(Index ix, const uint64_t* __restrict__ words, co
     if (created) atomicAdd(&counters[1], created);
 }
 
+/* k-mer counting: one text position per lane (adjacent lanes read adjacent bytes); flags[0] = table too full */
+__global__ void k_count(CountTable t, const char* __restrict__ text, uint64_t n, int k, unsigned long long* flags)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool full = false;
+    for (; i + k <= n; i += stride) {
+        const uint64_t c = kmer_from_ascii(text, i, k);
+        if (c != ~0ULL && !count_insert(t, c)) full = true;
+    }
+    if (full) atomicOr(&flags[0], 1ull);
+}
+/* abundance histogram of the distinct k-mers (per-workgroup LDS histogram for the low, hot bins) and number of candidates */
+__global__ void k_count_stats(CountTable t, uint32_t keep_min, unsigned long long* histo, uint32_t nbins, unsigned long long* n_keep)
+{
+    __shared__ unsigned int lh[256];
+    for (uint32_t j = threadIdx.x; j < 256; j += blockDim.x) lh[j] = 0;
+    __syncthreads();
+    unsigned long long keep = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (t.keys[i] == ~0ULL) continue;
+        const uint32_t c = t.counts[i];
+        const uint32_t b = c < nbins ? c : nbins - 1;
+        if (b < 256) atomicAdd(&lh[b], 1u); else atomicAdd(&histo[b], 1ull);
+        keep += c >= keep_min;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < 256 && j < nbins; j += blockDim.x) if (lh[j]) atomicAdd(&histo[j], (unsigned long long)lh[j]);
+    if (keep) atomicAdd(n_keep, keep);
+}
+__global__ void k_count_emit(CountTable t, uint32_t keep_min, uint64_t* out_k, uint32_t* out_c, unsigned long long* cursor)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = t.keys[i];
+        if (key == ~0ULL) continue;
+        const uint32_t c = t.counts[i];
+        if (c < keep_min) continue;
+        const unsigned long long o = atomicAdd(cursor, 1ull);
+        out_k[o] = key;
+        out_c[o] = c;
+    }
+}
+
 /* second build pass: lookaheads of the ADJ entries (after every k-mer has been inserted) */
 __global__ void k_lookahead_kmers(Index ix, const uint64_t* __restrict__ kmers, size_t n)
 {
@@ -746,6 +789,64 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const u
     if (!device_ptrs) HIP_TRY(hipMemcpy(out_bits, pb, nwords * 8, hipMemcpyDeviceToHost));
     if (st) { st->n_kmers = c[0]; st->bloom_positive = c[1]; st->confirmed = c[2]; st->blocks_staged = c[3]; st->kernel_ms = ms; }
     return MTG_OK;
+}
+
+/* Graph::create's counting step on the device.  The text is processed in P passes (k-mers are assigned to a pass by a hash) when one
+ * count table for all of them would not fit; within a pass the text is uploaded in chunks overlapping by k-1 characters. */
+int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<uint64_t>& histo, std::vector<uint64_t>& kmers, std::vector<uint32_t>& counts)
+{
+    if (int rc = ensure_device()) return rc;
+    kmers.clear();
+    counts.clear();
+    if (n < (size_t)k) return MTG_OK;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t chunk = std::min<size_t>(n, (size_t)1 << 28);
+    /* distinct k-mers <= instances; start from instances / 4 slots (30x data has ~25 instances per distinct k-mer) and grow on overflow */
+    uint64_t cap = 1ull << 16;
+    while (cap < n / 4) cap <<= 1;
+    const uint32_t nbins = (uint32_t)histo.size();
+    for (int attempt = 0; attempt < 8; attempt++, cap <<= 1) {
+        if (cap * 12 + chunk + (64 << 20) > free_b) { set_error("not enough device memory to count %zu k-mer instances in one pass", n); return MTG_ERR_NOMEM; }
+        DevBuf d_keys, d_cnts, d_text, d_flags, d_histo;
+        HIP_TRY(d_keys.alloc(cap * 8)); HIP_TRY(d_cnts.alloc(cap * 4)); HIP_TRY(d_text.alloc(chunk + 64)); HIP_TRY(d_flags.alloc(64)); HIP_TRY(d_histo.alloc((size_t)nbins * 8));
+        HIP_TRY(hipMemset(d_keys.p, 0xFF, cap * 8));
+        HIP_TRY(hipMemset(d_cnts.p, 0, cap * 4));
+        HIP_TRY(hipMemset(d_flags.p, 0, 64));
+        HIP_TRY(hipMemset(d_histo.p, 0, (size_t)nbins * 8));
+        CountTable t;
+        t.keys = d_keys.as<uint64_t>();
+        t.counts = d_cnts.as<uint32_t>();
+        t.mask = cap - 1;
+        for (size_t off = 0; off < n;) {
+            const size_t len = std::min(chunk, n - off);
+            HIP_TRY(hipMemcpy(d_text.p, text + off, len, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_count, dim3(256 * 32), dim3(256), 0, 0, t, d_text.as<char>(), (uint64_t)len, k, d_flags.as<unsigned long long>());
+            HIP_TRY(hipDeviceSynchronize());
+            if (off + len >= n) break;
+            off += len - (size_t)(k - 1); /* the next chunk re-reads the last k-1 characters so that no window is lost */
+        }
+        unsigned long long flags[8];
+        HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
+        if (flags[0]) continue; /* table too full: double it */
+        hipLaunchKernelGGL(k_count_stats, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_histo.as<unsigned long long>(), nbins, d_flags.as<unsigned long long>() + 1);
+        HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(histo.data(), d_histo.p, (size_t)nbins * 8, hipMemcpyDeviceToHost));
+        const size_t nk = (size_t)flags[1];
+        DevBuf d_ok, d_oc;
+        HIP_TRY(d_ok.alloc(nk * 8)); HIP_TRY(d_oc.alloc(nk * 4));
+        hipLaunchKernelGGL(k_count_emit, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_ok.as<uint64_t>(), d_oc.as<uint32_t>(), d_flags.as<unsigned long long>() + 2);
+        HIP_TRY(hipGetLastError());
+        kmers.resize(nk);
+        counts.resize(nk);
+        if (nk) {
+            HIP_TRY(hipMemcpy(kmers.data(), d_ok.p, nk * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(counts.data(), d_oc.p, nk * 4, hipMemcpyDeviceToHost));
+        }
+        return MTG_OK;
+    }
+    set_error("k-mer count table kept overflowing");
+    return MTG_ERR_OVERFLOW;
 }
 
 int bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, uint32_t line_bytes, double* ms_out, double* gbps)

@@ -109,8 +109,8 @@ static std::mutex& host_copies_mtx() { static std::mutex m; return m; }
 int index_from_reads(const char* paths_csv, int k, int abundance_min, int abundance_max, mtg_index** out)
 {
     if (!paths_csv || !out || k < 11 || k > 31) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    std::vector<uint64_t> all;
-    const uint64_t mk = kmask(k);
+    /* the reads, concatenated with '\n' separators (an invalid character by gatb's rule, so no k-mer spans two reads) */
+    std::string text;
     std::string csv(paths_csv);
     size_t pos = 0;
     while (pos <= csv.size()) {
@@ -121,35 +121,28 @@ int index_from_reads(const char* paths_csv, int k, int abundance_min, int abunda
         if (path.empty()) continue;
         std::vector<std::pair<std::string, std::string>> recs;
         if (!read_sequences(path, recs)) { set_error("cannot read %s", path.c_str()); return MTG_ERR_IO; }
-        for (auto& r : recs) {
-            uint64_t f = 0;
-            int valid = 0;
-            for (unsigned char c : r.second) {
-                if (nt_bad(c)) { valid = 0; f = 0; continue; }
-                f = ((f << 2) | nt_code(c)) & mk;
-                if (++valid >= k) { uint64_t rc = revcomp(f, k); all.push_back(f < rc ? f : rc); }
-            }
-        }
+        size_t add = 0;
+        for (auto& r : recs) add += r.second.size() + 1;
+        text.reserve(text.size() + add);
+        for (auto& r : recs) { text += r.second; text += '\n'; }
     }
-    std::sort(all.begin(), all.end());
+    /* counting on the device (k_count); sum solidity over all files (STR_SOLIDITY_KIND "sum", src/Filler.cpp:177) */
     std::vector<uint64_t> histo(10003, 0); /* STR_HISTOGRAM_MAX 10000, src/Filler.cpp:200 */
-    std::vector<uint64_t> uk;
-    std::vector<uint32_t> uc;
-    for (size_t i = 0; i < all.size();) {
-        size_t j = i;
-        while (j < all.size() && all[j] == all[i]) j++;
-        uint32_t c = (uint32_t)(j - i);
-        histo[std::min<uint32_t>(c, 10001)]++;
-        uk.push_back(all[i]);
-        uc.push_back(c);
-        i = j;
-    }
+    HostIndexData cand;
+    const uint32_t keep_min = abundance_min < 0 ? 3u : (uint32_t)std::max(abundance_min, 1); /* auto never goes below 3 (src/Filler.cpp:201) */
+    int rc = count_run(text.data(), text.size(), k, keep_min, histo, cand.kmers, cand.counts);
+    if (rc) return rc;
+    std::string().swap(text);
     int autoc = -1;
     if (abundance_min < 0) { autoc = auto_cutoff(histo, 3); abundance_min = autoc; }
+    /* deterministic container: sort the candidates by k-mer */
+    std::vector<size_t> order(cand.kmers.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cand.kmers[a] < cand.kmers[b]; });
     HostIndexData hd;
-    for (size_t i = 0; i < uk.size(); i++)
-        if ((int64_t)uc[i] >= abundance_min && (abundance_max <= 0 || (int64_t)uc[i] <= abundance_max)) { hd.kmers.push_back(uk[i]); hd.counts.push_back(uc[i]); }
-    int rc = index_from_kmers(hd.kmers.data(), hd.counts.data(), hd.kmers.size(), k, out);
+    for (size_t i : order)
+        if ((int64_t)cand.counts[i] >= abundance_min && (abundance_max <= 0 || (int64_t)cand.counts[i] <= abundance_max)) { hd.kmers.push_back(cand.kmers[i]); hd.counts.push_back(cand.counts[i]); }
+    rc = index_from_kmers(hd.kmers.data(), hd.counts.data(), hd.kmers.size(), k, out);
     if (rc) return rc;
     (*out)->info.abundance_min = abundance_min;
     (*out)->info.abundance_auto = autoc;

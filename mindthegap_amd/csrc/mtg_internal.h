@@ -207,6 +207,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int device_ptrs,
              mtg_scan_stats* st);
 
+/* counts the canonical k-mers of `text` (sequences separated by '\n'): histo[c] = number of distinct k-mers seen c times (c capped at
+ * histo.size()-1), kmers/counts = the distinct k-mers seen at least keep_min times (unordered) */
+int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<uint64_t>& histo, std::vector<uint64_t>& kmers, std::vector<uint32_t>& counts);
+
 int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
 
 void stats_store(const mtg_batch_stats& s);

@@ -79,6 +79,32 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
     return MTG_OK;
 }
 
+int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<uint64_t>& histo, std::vector<uint64_t>& kmers, std::vector<uint32_t>& counts)
+{
+    kmers.clear();
+    counts.clear();
+    if (n < (size_t)k) return MTG_OK;
+    uint64_t cap = 1ull << 10;
+    while (cap < n / 4) cap <<= 1;
+    for (;; cap <<= 1) {
+        std::vector<uint64_t> keys(cap, ~0ULL);
+        std::vector<uint32_t> cnts(cap, 0);
+        CountTable t{keys.data(), cnts.data(), cap - 1};
+        bool full = false;
+        for (size_t i = 0; i + k <= n && !full; i++) {
+            const uint64_t c = kmer_from_ascii(text, i, k);
+            if (c != ~0ULL && !count_insert(t, c)) full = true;
+        }
+        if (full) continue;
+        for (uint64_t i = 0; i < cap; i++) {
+            if (keys[i] == ~0ULL) continue;
+            histo[std::min<size_t>(cnts[i], histo.size() - 1)]++;
+            if (cnts[i] >= keep_min) { kmers.push_back(keys[i]); counts.push_back(cnts[i]); }
+        }
+        return MTG_OK;
+    }
+}
+
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int,
              mtg_scan_stats* st)
 {
