@@ -245,3 +245,34 @@ def _scan_case(mtg_mod):
 
 def test_sequence_scan_on_emulator(emu_product):
     _scan_case(emu_product)
+
+
+def _contig_gap_case(mtg_mod, tmp_path, nseq):
+    """contig mode at scale: every donor sequence is cut into two contigs around a hole; each seed sees the targets of all other
+    contigs (2 * (#contigs) - 1 anchors), the fill must bridge the hole.  Files must equal the oracle's byte for byte."""
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=nseq, n_sites=nseq, seed=31)
+    seqs = [S.ascii(j) for j in range(S.nseq)]
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    contigs = str(tmp_path / "contigs.fa")
+    with open(contigs, "w") as f:
+        for j, s in enumerate(seqs):
+            p, L = int(S.pos[j]), int(S.ins_len[j])
+            f.write(">c%dL\n%s\n>c%dR\n%s\n" % (j, s[:p], j, s[p + L:]))
+    idxf = str(tmp_path / "c.mtgidx")
+    _write_idx(idxf, km, ct)
+    o.fill_files("contig", contigs, str(tmp_path / "cpu"), params=oracle_lib.default_params(nb_cores=4))
+    assert mtg_mod.Filler().run(["-graph", idxf, "-contig", contigs, "-out", str(tmp_path / "hip")]) == 0
+    assert _read(str(tmp_path / "hip_seed_dictionary.fasta")) == _read(str(tmp_path / "cpu_seed_dictionary.fasta"))
+    # the oracle ran on 4 threads: its records come in completion order, compare as multisets of lines / records
+    assert sorted(_read(str(tmp_path / "hip.info.txt")).splitlines()) == sorted(_read(str(tmp_path / "cpu.info.txt")).splitlines())
+    assert sorted(_read(str(tmp_path / "hip.gfa")).splitlines()) == sorted(_read(str(tmp_path / "cpu.gfa")).splitlines())
+    assert sorted(_read(str(tmp_path / "hip.insertions.fasta")).splitlines()) == sorted(_read(str(tmp_path / "cpu.insertions.fasta")).splitlines())
+    nfill = sum(1 for l in _read(str(tmp_path / "hip.gfa")).splitlines() if l.startswith("S") and ";" in l)
+    assert nfill >= 2 * nseq  # both directions of every hole
+    o.close()
+
+
+def test_contig_mode_many_targets_on_emulator(emu_product, tmp_path):
+    _contig_gap_case(emu_product, tmp_path, 8)

@@ -233,3 +233,9 @@ def test_sequence_scan_bloom_kernel(mtg):
     """k_scan (rolling k-mer + LDS-staged minimizer-blocked Bloom + exact confirmation) against the oracle's Graph::contains"""
     from tests.test_emu_parity import _scan_case
     _scan_case(mtg)
+
+
+def test_contig_mode_many_targets(mtg, tmp_path):
+    """400 contigs / 800 seeds / ~800 anchors per seed: exercises the multi-target terminal search of k_post"""
+    from tests.test_emu_parity import _contig_gap_case
+    _contig_gap_case(mtg, tmp_path, 200)
