@@ -233,6 +233,11 @@ void FillInput::set(size_t g, std::string_view source, std::string_view swf_targ
     const size_t rl = swf_target.size(), w0 = roff[g];
     for (size_t i = 0; i < rl; i++) rwords[w0 + (i >> 5)] |= (uint64_t)nt_code((unsigned char)swf_target[i]) << (2 * (i & 31));
     r0[g] = rl >= (size_t)k ? encode_kmer(swf_target.data(), k) : 0;
+    /* the early stop is a literal strstr in upper-case contigs (IterativeExtensions [MEM]): a pattern with any other character never matches */
+    for (size_t i = 0; i < rl; i++) {
+        const char c = swf_target[i];
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { rlen[g] = 0xFFFFFFFFu; r0[g] = 0; break; }
+    }
     if (targets) {
         size_t o = toff[g];
         for (const Target& t : *targets) {

@@ -276,3 +276,63 @@ def _contig_gap_case(mtg_mod, tmp_path, nseq):
 
 def test_contig_mode_many_targets_on_emulator(emu_product, tmp_path):
     _contig_gap_case(emu_product, tmp_path, 8)
+
+
+def _edge_case_files(tmp_path):
+    """bkpt-mode inputs with the odd cases of src/Filler.cpp:623-699: REPEATED anchors (no mismatch allowed, qual 25), long / lowercase
+    source records, 'N' inside an anchor, anchors with 1-2 mismatches, unfillable sites; on a diploid-like graph with SNP bubbles."""
+    rng = random.Random(77)
+    g = _rand_seq(rng, 9000)
+    h = list(g)
+    for p in range(500, 8500, 700):
+        h[p] = rng.choice([c for c in "ACGT" if c != h[p]])
+    h = "".join(h)
+    ins = _rand_seq(rng, 260)
+    donor = g[:4000] + ins + g[4000:]
+    o = oracle_lib.Index.from_sequences([donor, h[:3000], h[5000:], g[2000:2040] + "T" + "ACGT" * 3], 31, 3, 40)
+    km, ct = o.export()
+    _write_idx(str(tmp_path / "e.mtgidx"), km, ct)
+    L, R = donor[4000 - 31:4000], donor[4260:4260 + 31]
+
+    def mut(s, i):
+        return s[:i] + ("A" if s[i] != "A" else "C") + s[i + 1:]
+    sites = [
+        ("bkpt1_chr1_pos_10_fuzzy_0_HOM", L, R, ""),
+        ("bkpt2_chr1_pos_20_fuzzy_0_HET", L, mut(R, 5), ""),                      # 1 mismatch in the anchor -> qual 10
+        ("bkpt3_chr1_pos_30_fuzzy_0_HOM", L, mut(mut(R, 5), 20), ""),              # 2 mismatches -> qual 5
+        ("bkpt4_chr1_pos_40_fuzzy_0_HOM", L, mut(mut(mut(R, 5), 20), 25), ""),     # 3 mismatches -> not found, reverse attempt
+        ("bkpt5_chr1_pos_50_fuzzy_0_HOM", L, mut(R, 5), " REPEATED"),              # repeated: no mismatch allowed
+        ("bkpt6_chr1_pos_60_fuzzy_0_HOM", L, R, " REPEATED"),                      # repeated exact -> qual 25
+        ("bkpt7_chr1_pos_70_fuzzy_0_HOM", L.lower(), R, ""),                       # lowercase source
+        ("bkpt8_chr1_pos_80_fuzzy_0_HOM", L + "ACGTACGTAC", R, ""),                # source record longer than k
+        ("bkpt9_chr1_pos_90_fuzzy_0_HOM", L, R[:12] + "N" + R[13:], ""),           # N in the anchor: one forced mismatch
+        ("bkpt10_chr1_pos_100_fuzzy_0_HOM", _rand_seq(rng, 31), _rand_seq(rng, 31), ""),  # nothing to find
+        ("bkpt11_weird_name", donor[1000 - 31:1000], donor[1200:1231], ""),        # 200-nt stretch of the donor itself, odd header
+        ("bkpt12_chr1_pos_120_fuzzy_0_HOM", g[2000 - 31 + 9:2000 + 9], g[6000:6031], ""),  # long walk through SNP bubbles
+        ("bkpt13_chr1_pos_130_fuzzy_0_HOM", g[2000 - 31 + 9:2000 + 9], g[6000:6031].lower(), ""),  # lowercase anchor: matched case-insensitively, never by strstr
+        ("bkpt14_chr1_pos_140_fuzzy_0_HOM", g[2000 - 31 + 9:2000 + 9], g[6000:6040], ""),  # anchor record longer than k
+    ]
+    bk = str(tmp_path / "edge.breakpoints")
+    with open(bk, "w") as f:
+        for name, l, r, tag in sites:
+            f.write(">%s%s left_kmer\n%s\n>%s%s right_kmer\n%s\n" % (name, tag, l, name, tag, r))
+    return o, str(tmp_path / "e.mtgidx"), bk
+
+
+def _edge_case_run(mtg_mod, tmp_path):
+    o, idxf, bk = _edge_case_files(tmp_path)
+    for tag, extra, okw in (("a", [], {}), ("b", ["-fwd-only", "-filter", "-extend"], dict(fwd_only=1, filter=1, extend=1)),
+                            ("c", ["-max-nodes", "3", "-max-length", "400"], dict(max_nodes=3, max_depth=400))):
+        o.fill_files("bkpt", bk, str(tmp_path / ("cpu" + tag)), params=oracle_lib.default_params(**okw))
+        assert mtg_mod.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / ("hip" + tag))] + extra) == 0
+        exts = [".insertions.fasta", ".info.txt"] + ([".extensions.fasta"] if "-extend" in extra else [])
+        for ext in exts:
+            assert _read(str(tmp_path / ("hip" + tag)) + ext) == _read(str(tmp_path / ("cpu" + tag)) + ext), (tag, ext)
+        assert _vcf_body(str(tmp_path / ("hip%s.insertions.vcf" % tag))) == _vcf_body(str(tmp_path / ("cpu%s.insertions.vcf" % tag))), tag
+    fa = _read(str(tmp_path / "hipa.insertions.fasta"))
+    assert "_qual_50_" in fa and "_qual_10_" in fa and "_qual_5_" in fa and "_qual_25_" in fa
+    o.close()
+
+
+def test_cli_edge_cases_on_emulator(emu_product, tmp_path):
+    _edge_case_run(emu_product, tmp_path)

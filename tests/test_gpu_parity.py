@@ -239,3 +239,9 @@ def test_contig_mode_many_targets(mtg, tmp_path):
     """400 contigs / 800 seeds / ~800 anchors per seed: exercises the multi-target terminal search of k_post"""
     from tests.test_emu_parity import _contig_gap_case
     _contig_gap_case(mtg, tmp_path, 200)
+
+
+def test_cli_edge_cases(mtg, tmp_path):
+    """REPEATED anchors, mismatching / N / lowercase / long anchors, unfillable sites, -fwd-only -filter -extend, -max-nodes / -max-length"""
+    from tests.test_emu_parity import _edge_case_run
+    _edge_case_run(mtg, tmp_path)
