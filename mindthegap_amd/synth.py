@@ -9,10 +9,15 @@ NT = np.frombuffer(b"ACTG", dtype=np.uint8)  # code -> letter (A=0 C=1 T=2 G=3)
 
 
 class SynthSet:
-    def __init__(self, nseq, n_sites, seq_len=5000, seed=1, ins_min=50, ins_max=1000, k=31):
-        assert n_sites <= nseq
+    """het_snps > 0: diploid variant -- sequences nseq/2 .. nseq-1 are second haplotypes of sequences 0 .. nseq/2-1 that differ by het_snps
+    substitutions (>= 150 nt away from the insertion anchors and the ends), so every walk crosses SNP bubbles (multi-path bubbles
+    are GATB-parity-unpinned logic; used as a secondary, divergence-heavy workload, never for the headline number)."""
+
+    def __init__(self, nseq, n_sites, seq_len=5000, seed=1, ins_min=50, ins_max=1000, k=31, het_snps=0):
+        nloci = nseq // 2 if het_snps else nseq
+        assert n_sites <= nloci
         rng = np.random.default_rng(seed)
-        self.k, self.nseq, self.n_sites, self.seq_len = k, nseq, n_sites, seq_len
+        self.k, self.nseq, self.n_sites, self.seq_len, self.het_snps = k, nseq, n_sites, seq_len, het_snps
         self.ins_len = np.exp(rng.uniform(np.log(ins_min), np.log(ins_max), n_sites)).astype(np.int64)  # log-uniform
         self.pos = rng.integers(1000, seq_len - 1000 + 1, n_sites)
         self.lens = np.full(nseq, seq_len, dtype=np.uint32)
@@ -21,6 +26,26 @@ class SynthSet:
         # random 2-bit nucleotides, 32 per word
         self.words = rng.integers(0, 2**64, size=(nseq, self.words_per_seq), dtype=np.uint64)
         self.word_off = (np.arange(nseq, dtype=np.uint64) * np.uint64(self.words_per_seq))
+        if het_snps:
+            self.lens[nloci:2 * nloci] = self.lens[:nloci]
+            self.words[nloci:2 * nloci] = self.words[:nloci]
+            lens = self.lens[:nloci].astype(np.int64)
+            pos = np.full(nloci, seq_len // 2, dtype=np.int64)
+            pos[:n_sites] = self.pos
+            ins = np.zeros(nloci, dtype=np.int64)
+            ins[:n_sites] = self.ins_len
+            for s_i in range(het_snps):
+                # SNP s_i of every locus: uniform in a window left or right of the insertion, away from anchors and ends
+                left = (np.arange(nloci) + s_i) % 2 == 0
+                lo = np.where(left, 150, pos + ins + 150)
+                hi = np.where(left, pos - 150, lens - 150)
+                p = (lo + (rng.random(nloci) * np.maximum(hi - lo, 1)).astype(np.int64)).astype(np.int64)
+                delta = rng.integers(1, 4, nloci).astype(np.uint64)  # add 1..3 to the 2-bit code
+                w, b = p // 32, (2 * (p % 32)).astype(np.uint64)
+                rows = np.arange(nloci) + nloci
+                old = (self.words[rows, w] >> b) & np.uint64(3)
+                new = (old + delta) & np.uint64(3)
+                self.words[rows, w] = (self.words[rows, w] & ~(np.uint64(3) << b)) | (new << b)
 
     @property
     def total_kmers_upper_bound(self):

@@ -336,3 +336,26 @@ def _edge_case_run(mtg_mod, tmp_path):
 
 def test_cli_edge_cases_on_emulator(emu_product, tmp_path):
     _edge_case_run(emu_product, tmp_path)
+
+
+def _diploid_case(mtg_mod, tmp_path, nloci):
+    """diploid donor: every walk crosses heterozygous-SNP bubbles (consensus enumeration, NW identity, most-abundant choice)"""
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=2 * nloci, n_sites=nloci, seed=13, het_snps=4)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    idxf = str(tmp_path / "d.mtgidx")
+    _write_idx(idxf, km, ct)
+    bk = str(tmp_path / "d.breakpoints")
+    S.write_breakpoints(bk)
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert mtg_mod.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    assert _read(str(tmp_path / "hip.insertions.fasta")).count(">") >= nloci
+    o.close()
+
+
+def test_cli_on_emulator_diploid(emu_product, tmp_path):
+    _diploid_case(emu_product, tmp_path, 10)

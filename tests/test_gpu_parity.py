@@ -245,3 +245,8 @@ def test_cli_edge_cases(mtg, tmp_path):
     """REPEATED anchors, mismatching / N / lowercase / long anchors, unfillable sites, -fwd-only -filter -extend, -max-nodes / -max-length"""
     from tests.test_emu_parity import _edge_case_run
     _edge_case_run(mtg, tmp_path)
+
+
+def test_diploid_bubbles(mtg, tmp_path):
+    from tests.test_emu_parity import _diploid_case
+    _diploid_case(mtg, tmp_path, 200)
