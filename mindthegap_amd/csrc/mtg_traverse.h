@@ -561,80 +561,98 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     tail = 1;
     uint32_t nb = 0, total_nt = 0;
 
-    while (head < tail && W.status == GAP_OK) {
-        const uint64_t node_f = q_f[head];
-        const int node_depth = q_d[head];
-        head++;
-        /* ---- traverse(node) ---- */
-        const uint32_t c_first = wpos;
-        for (int i = k - 1; i >= 0; i--) push_nt((uint32_t)(node_f >> (2 * i)) & 3u);
-        Kmer cur = make_kmer(node_f, k);
-        const uint64_t start_c = canon(cur);
-        uint64_t prev_c = 0; /* gatb: default-constructed previousNode has k-mer value 0 */
-        uint32_t len = 0;
-        bool looping = false;
-        bool found_R = (r_is_kmer && cur.f == R.r0);
-        Adj a = adj_right_t(adj, cur, mk1, lines);
-        for (;;) {
-            if (popc4(a.out) == 1 && popc4(a.in) <= 1) {
-                /* simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has exactly
-                 * one in- and one out-edge (lookahead): those nodes are non-branching (nothing to mark) and need no read. */
-                uint32_t nt = (uint32_t)ctz4(a.out);
-                uint32_t indeg = (uint32_t)popc4(a.in);          /* in-degree of the node we step onto */
-                uint32_t la = (indeg == 1) ? a.la : 0u;
-                uint32_t known = la & 15u;                       /* nodes ahead known to be simple */
-                la >>= 4;
-                bool stop = false;
-                for (;;) {
-                    prev_c = canon(cur);
-                    cur = kmer_next(cur, nt, k, mk);
-                    push_nt(nt);
-                    len++;
-                    if (r_is_kmer && cur.f == R.r0) found_R = true;
-                    if (known == 0) break;                       /* this node's neighbourhood has to be read */
-                    /* known simple node: terminator.mark() is a no-op on it */
-                    if (canon(cur) == start_c || len > MAXLEN || ovf) { stop = true; break; }
-                    nt = la & 3u;
-                    la >>= 2;
-                    known--;
-                    indeg = 1;
-                }
-                if (stop) break;
-                const Adj a2 = adj_right_t(adj, cur, mk1, lines);
-                if (!(popc4(a2.out) == 1 && indeg == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
-                a = a2;
-                if (canon(cur) == start_c) break; /* looping */
-                if (len > MAXLEN) break;
-                if (ovf || W.status) break;
-                continue;
+    /* One flat loop per lane instead of nested BFS / traverse loops: every iteration a lane (W) walks its simple path up to the next
+     * event, (B) resolves a branching node, (E) closes a contig and pops the next start node.  Lanes of a wave therefore reach the
+     * expensive bubble code of phase B together and run it concurrently, instead of stalling each other one bubble at a time. */
+    bool in_contig = false;
+    Kmer cur;
+    cur.f = cur.r = 0;
+    uint64_t start_c = 0, prev_c = 0;
+    uint32_t len = 0, c_first = 0;
+    int node_depth = 0;
+    bool found_R = false;
+    Adj a;
+    a.out = a.in = a.la = 0;
+    for (;;) {
+        if (!in_contig) {
+            if (!(head < tail) || W.status != GAP_OK) break;
+            const uint64_t node_f = q_f[head];
+            node_depth = q_d[head];
+            head++;
+            /* ---- traverse(node) ---- */
+            c_first = wpos;
+            for (int i = k - 1; i >= 0; i--) push_nt((uint32_t)(node_f >> (2 * i)) & 3u);
+            cur = make_kmer(node_f, k);
+            start_c = canon(cur);
+            prev_c = 0; /* gatb: default-constructed previousNode has k-mer value 0 */
+            len = 0;
+            found_R = (r_is_kmer && cur.f == R.r0);
+            a = adj_right_t(adj, cur, mk1, lines);
+            in_contig = true;
+        }
+        bool end_contig = false;
+        /* ---- phase W: simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has
+         * exactly one in- and one out-edge (lookahead): those nodes are non-branching (nothing to mark) and need no read. */
+        while (popc4(a.out) == 1 && popc4(a.in) <= 1) {
+            uint32_t nt = (uint32_t)ctz4(a.out);
+            uint32_t indeg = (uint32_t)popc4(a.in); /* in-degree of the node we step onto */
+            uint32_t la = (indeg == 1) ? a.la : 0u;
+            uint32_t known = la & 15u;              /* nodes ahead known to be simple */
+            la >>= 4;
+            for (;;) {
+                prev_c = canon(cur);
+                cur = kmer_next(cur, nt, k, mk);
+                push_nt(nt);
+                len++;
+                if (r_is_kmer && cur.f == R.r0) found_R = true;
+                if (known == 0) break;              /* this node's neighbourhood has to be read */
+                /* known simple node: terminator.mark() is a no-op on it */
+                if (canon(cur) == start_c || len > MAXLEN || ovf) { end_contig = true; break; }
+                nt = la & 3u;
+                la >>= 2;
+                known--;
+                indeg = 1;
             }
+            if (end_contig) break;
+            const Adj a2 = adj_right_t(adj, cur, mk1, lines);
+            if (!(popc4(a2.out) == 1 && indeg == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
+            a = a2;
+            if (canon(cur) == start_c || len > MAXLEN || ovf || W.status) { end_contig = true; break; } /* looping / limits */
+        }
+        /* ---- phase B: branching node ---- */
+        if (!end_contig) {
             int chosen = -1;
             const int n = explore_branching(W, cur, prev_c, chosen);
-            if (n <= 0) break;
-            const uint8_t* p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;
-            for (int i = 0; i < n; i++) {
-                prev_c = canon(cur);
-                cur = kmer_next(cur, p[i], k, mk);
-                push_nt(p[i]);
-                len++;
-                W.mark(cur);
-                if (r_is_kmer && cur.f == R.r0) found_R = true;
-                if (canon(cur) == start_c) looping = true;
+            if (n <= 0) {
+                end_contig = true;
+            } else {
+                const uint8_t* p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;
+                bool looping = false;
+                for (int i = 0; i < n; i++) {
+                    prev_c = canon(cur);
+                    cur = kmer_next(cur, p[i], k, mk);
+                    push_nt(p[i]);
+                    len++;
+                    W.mark(cur);
+                    if (r_is_kmer && cur.f == R.r0) found_R = true;
+                    if (canon(cur) == start_c) looping = true;
+                }
+                if (looping || len > MAXLEN || ovf || W.status) end_contig = true;
+                else a = adj_right_t(adj, cur, mk1, lines);
             }
-            if (looping) break;
-            if (len > MAXLEN) break;
-            if (ovf || W.status) break;
-            a = adj_right_t(adj, cur, mk1, lines);
         }
+        if (!end_contig) continue;
+        /* ---- phase E: the contig is complete ---- */
+        in_contig = false;
         flush();
         if (ovf) W.status = GAP_OVF_CONTIG;
         if (W.status) break;
-        const uint32_t clen = (uint32_t)(k + len);
+        const uint32_t clen = (uint32_t)k + len;
         s_cstart(cfg, S)[nb] = c_first;
         s_clen(cfg, S)[nb] = clen;
         nb++;
         total_nt += clen;
-        /* ---- swf: stop when R occurs in the contig and depth > k ---- */
+        /* swf: stop when R occurs in the contig and depth > k */
         if (!r_is_kmer && node_depth > k) found_R = contig_contains(s_words(cfg, S) + c_first, clen, R);
         if (found_R && node_depth > k) break;
         if ((int)nb > cfg.max_nodes) break;
