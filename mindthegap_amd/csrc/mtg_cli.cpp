@@ -37,20 +37,24 @@ static std::string revcomp_str(const std::string& s)
     return r;
 }
 
-/* the GapWork holds views: source and dict must outlive it */
-static GapWork make_gap(const std::string& source, const bkpt_dict_t& dict, bool repeated, bool reverse)
+/* the GapWork holds views: source, dict and the target store must outlive it */
+static GapWork make_gap(const std::string& source, const bkpt_dict_t& dict, bool repeated, bool reverse, std::vector<Target>& store)
 {
     GapWork g;
     g.source = source;
     g.anchor_repeated = repeated;
     g.reverse = reverse;
+    store.clear();
+    store.reserve(dict.size());
     for (auto it = dict.begin(); it != dict.end(); ++it) {
         Target t;
         t.seq = it->first;
         t.name = it->second.first;
         t.is_rc = it->second.second;
-        g.targets.push_back(t);
+        store.push_back(t);
     }
+    g.targets.p = store.data();
+    g.targets.n = (uint32_t)store.size();
     return g;
 }
 
@@ -207,6 +211,7 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
     std::vector<std::string_view> swf;
     std::vector<bkpt_dict_t> dicts(nsites), dicts_rev(nsites); /* kept alive: the gaps hold views on their strings */
     std::vector<std::string> src_rev(nsites), tgt_rev(nsites);
+    std::vector<std::vector<Target>> tstore(nsites), tstore_rev(nsites);
     for (size_t i = 0; i < nsites; i++) {
         Site& s = sites[i];
         s.source = recs[2 * i].second;
@@ -216,7 +221,7 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
         s.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
         bkpt_dict_t& dict = dicts[i];
         dict.insert({s.target, std::make_pair(s.name_r, false)});
-        fwd.push_back(make_gap(s.source, dict, s.repeated, false));
+        fwd.push_back(make_gap(s.source, dict, s.repeated, false, tstore[i]));
         swf.push_back(s.target);
     }
     FillArena arena_fwd, arena_rev;
@@ -234,7 +239,7 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
                 src_rev[i] = revcomp_str(s.target);
                 bkpt_dict_t& dict = dicts_rev[i];
                 dict.insert({tgt_rev[i], std::make_pair(s.name, false)});
-                rev.push_back(make_gap(src_rev[i], dict, s.repeated, true));
+                rev.push_back(make_gap(src_rev[i], dict, s.repeated, true, tstore_rev[i]));
                 swf2.push_back(tgt_rev[i]);
                 rev_of.push_back(i);
             }
@@ -299,6 +304,7 @@ static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& 
     std::vector<std::string_view> swf;
     std::vector<bkpt_dict_t> dicts(seeds.size()); /* kept alive: the gaps hold views on their strings */
     std::vector<std::string> concs(seeds.size());
+    std::vector<std::vector<Target>> tstore(seeds.size());
     for (size_t si = 0; si < seeds.size(); si++) {
         auto& sd = seeds[si];
         std::string& conc = concs[si];
@@ -308,7 +314,7 @@ static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& 
             if (its->second.second) tempName += "_Rc";
             if (tempName.compare(sd.first) != 0) { conc.append(its->first); dict.insert({its->first, its->second}); }
         }
-        gaps.push_back(make_gap(sd.second, dict, false, false));
+        gaps.push_back(make_gap(sd.second, dict, false, false, tstore[si]));
         swf.push_back(conc);
     }
     FillArena arena;

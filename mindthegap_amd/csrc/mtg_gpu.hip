@@ -612,8 +612,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
     if (int rc = ensure_device()) return rc;
     const size_t n = in.src.size();
-    std::vector<GapDev>& out = batch.gaps;
-    out.assign(n, GapDev());
+    batch.chunk_of.assign(n, 0);
+    batch.slot_of.assign(n, 0);
     batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     if (n == 0) { if (stats) *stats = st; return MTG_OK; }
@@ -659,12 +659,16 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         HIP_TRY(d_ids.alloc(chunk * 4)); HIP_TRY(d_nw.alloc(chunk * 4)); HIP_TRY(d_nc.alloc(chunk * 4)); HIP_TRY(d_wb.alloc(chunk * 8)); HIP_TRY(d_cb.alloc(chunk * 8));
         tick("workspace alloc");
         std::vector<uint32_t> retry;
-        std::vector<GapOut> h_out(chunk);
-        std::vector<PostOut> h_post(chunk);
-        std::vector<uint32_t> nw(chunk), nc(chunk);
-        std::vector<uint64_t> wbase(chunk), cbase(chunk);
         for (size_t base = 0; base < todo.size(); base += chunk) {
             const uint32_t m = (uint32_t)std::min(chunk, todo.size() - base);
+            batch.chunks.emplace_back(new HostChunk());
+            HostChunk& hc = *batch.chunks.back();
+            const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
+            hc.out.resize(m); hc.post.resize(m); hc.nw.resize(m); hc.nc.resize(m); hc.wbase.resize(m); hc.cbase.resize(m);
+            std::vector<GapOut>& h_out = hc.out;
+            std::vector<PostOut>& h_post = hc.post;
+            std::vector<uint32_t>&nw = hc.nw, &nc = hc.nc;
+            std::vector<uint64_t>&wbase = hc.wbase, &cbase = hc.cbase;
             t0 = now_ms();
             HIP_TRY(hipMemcpy(d_ids.p, todo.data() + base, (size_t)m * 4, hipMemcpyHostToDevice));
             st.h2d_ms += now_ms() - t0;
@@ -706,35 +710,24 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             hipLaunchKernelGGL(k_compact, dim3(std::min<uint32_t>(m, 256 * 16)), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_nw.as<uint32_t>(), d_nc.as<uint32_t>(),
                                d_wb.as<uint64_t>(), d_cb.as<uint64_t>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), tc, m);
             HIP_TRY(hipGetLastError());
-            batch.chunks.emplace_back(new HostChunk());
-            std::vector<uint64_t>& hw = batch.chunks.back()->words;
-            std::vector<uint32_t>& hm = batch.chunks.back()->meta;
-            hw.resize(tw);
+            std::vector<uint64_t>& hw = hc.words;
+            std::vector<uint32_t>& hm = hc.meta;
+            hw.resize(tw + 1);
             hm.resize(tc * 5);
+            hc.tc = tc;
             if (tw) HIP_TRY(hipMemcpy(hw.data(), d_dw.p, tw * 8, hipMemcpyDeviceToHost));
             if (tc) HIP_TRY(hipMemcpy(hm.data(), d_dm.p, tc * 5 * 4, hipMemcpyDeviceToHost));
             st.d2h_ms += now_ms() - t0;
             tick("plan+compact+d2h");
             t0 = now_ms();
-            std::atomic<uint64_t> nt_sum{0};
-            parallel_for(m, p->nb_host_threads, [&](size_t s) {
-                if (h_out[s].status != GAP_OK) return;
-                GapDev& gd = out[todo[base + s]];
-                gd.o = h_out[s];
-                gd.p = h_post[s];
-                gd.n_meta = nc[s];
-                gd.words = hw.data() + wbase[s];
-                if (nc[s]) {
-                    const uint32_t* b0 = hm.data() + cbase[s];
-                    gd.len = b0;
-                    gd.word_start = b0 + tc;
-                    gd.tpos = b0 + 2 * tc;
-                    gd.terr = b0 + 3 * tc;
-                    gd.ttgt = b0 + 4 * tc;
-                }
-                nt_sum.fetch_add(gd.o.total_nt, std::memory_order_relaxed);
-            });
-            st.contig_nt += nt_sum.load();
+            uint64_t nt_sum = 0;
+            for (uint32_t s2 = 0; s2 < m; s2++) {
+                if (h_out[s2].status != GAP_OK) continue;
+                batch.chunk_of[todo[base + s2]] = chunk_id;
+                batch.slot_of[todo[base + s2]] = s2;
+                nt_sum += h_out[s2].total_nt;
+            }
+            st.contig_nt += nt_sum;
             tick("distribute");
             st.host_ms += now_ms() - t0;
         }

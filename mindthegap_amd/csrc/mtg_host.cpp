@@ -227,7 +227,7 @@ void FillInput::layout()
     tle.assign(nt, 0);
     tbad.assign(nt, 0);
 }
-void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const std::vector<Target>* targets, int nb_mis)
+void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis)
 {
     src[g] = encode_kmer(source.data(), k);
     const size_t rl = swf_target.size(), w0 = roff[g];
@@ -501,10 +501,12 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     FillInput in;
     in.k = k;
     in.resize(n);
-    for (size_t i = 0; i < n; i++) {
-        if ((int)gaps[i].source.size() < k) { set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
+    std::atomic<long> bad_gap{-1};
+    parallel_for(n, p->nb_host_threads, [&](size_t i) {
+        if ((int)gaps[i].source.size() < k) bad_gap = (long)i;
         in.size(i, swf_targets[i].size(), gaps[i].targets.size());
-    }
+    }, 1024);
+    if (bad_gap >= 0) { set_error("gap %ld: source sequence shorter than k", bad_gap.load()); return MTG_ERR_ARG; }
     in.layout();
     parallel_for(n, p->nb_host_threads, [&](size_t i) {
         in.set(i, gaps[i].source, swf_targets[i], &gaps[i].targets, gaps[i].anchor_repeated ? 0 : p->nb_mis_allowed); /* src/Filler.cpp:859-863 */
@@ -512,7 +514,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     mtg_batch_stats st{};
     st.host_ms = now_ms() - t_begin;
     DevBatch batch;
-    std::vector<GapDev>& dev = batch.gaps;
+    DevBatch& dev = batch;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
     double tdev = now_ms();
     int rc = device_run(idx, p, in, batch, &st);
@@ -520,7 +522,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     if (dbg) fprintf(stderr, "  [fill_gaps] pre %.2f device_run %.2f ms\n", tdev - t_begin, now_ms() - tdev);
     double t0 = now_ms();
     std::vector<uint64_t> aoff(n + 1, 0);
-    for (size_t i = 0; i < n; i++) aoff[i + 1] = aoff[i] + (dev[i].p.fast == 1 ? (uint64_t)(dev[i].p.pos - (uint32_t)k) + 1 : 0);
+    for (size_t i = 0; i < n; i++) { const PostOut& po = dev.chunks[dev.chunk_of[i]]->post[dev.slot_of[i]]; aoff[i + 1] = aoff[i] + (po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0); }
     arena.chars.resize(aoff[n] + 1);
     parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k, arena.chars.data() + aoff[i]); });
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
@@ -588,8 +590,10 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
 /* ------------------------------------------------------------------------------------------------ C ABI (host side) */
 struct mtg_results {
     mtgi::FillArena arena;
+    std::vector<mtgi::Target> targets; /* flat storage of every gap's dictionary */
+    std::vector<mtg_filled> filled_flat;
+    std::vector<uint64_t> filled_off;
     std::vector<mtgi::GapWork> gaps;
-    std::vector<std::vector<mtg_filled>> filled;
     std::vector<mtg_gap_result> res;
 };
 struct mtg_contigs {
@@ -626,6 +630,9 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
         const mtg_gap& g = gaps[i];
         if (!g.source || !g.target || (g.n_targets && (!g.target_seqs || !g.target_names))) { delete R; mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
     }
+    std::vector<uint64_t> toff(n + 1, 0);
+    for (size_t i = 0; i < n; i++) toff[i + 1] = toff[i] + (uint64_t)std::max(gaps[i].n_targets, 0);
+    R->targets.resize(toff[n]);
     mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
         const mtg_gap& g = gaps[i];
         mtgi::GapWork& w = R->gaps[i];
@@ -633,25 +640,31 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
         swf[i] = g.target;
         w.anchor_repeated = g.is_anchor_repeated != 0;
         w.reverse = g.reverse != 0;
-        w.targets.resize(g.n_targets);
+        mtgi::Target* T0 = R->targets.data() + toff[i];
         for (int t = 0; t < g.n_targets; t++) {
-            mtgi::Target& T = w.targets[t];
+            mtgi::Target& T = T0[t];
             T.seq = g.target_seqs[t];
             T.name = g.target_names[t];
             T.is_rc = g.target_is_rc ? g.target_is_rc[t] != 0 : false;
         }
-    });
+        w.targets.p = T0;
+        w.targets.n = (uint32_t)std::max(g.n_targets, 0);
+    }, 256);
     const double t_m1 = mtgi::now_ms();
     mtg_batch_stats st{};
     int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, R->arena, &st);
     if (rc) { delete R; return rc; }
     const double t_m2 = mtgi::now_ms();
-    R->filled.resize(n);
     R->res.resize(n);
+    R->filled_off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) R->filled_off[i + 1] = R->filled_off[i] + R->gaps[i].sols.size();
+    R->filled_flat.resize(R->filled_off[n]);
     mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
         mtgi::GapWork& w = R->gaps[i];
+        mtg_filled* F0 = R->filled_flat.data() + R->filled_off[i];
+        size_t j = 0;
         for (auto& s : w.sols) {
-            mtg_filled f;
+            mtg_filled& f = F0[j++];
             f.seq = s.seq.c_str();
             f.nb_errors_in_anchor = s.nb_errors;
             f.target_index = s.target;
@@ -660,15 +673,14 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
             f.qual = s.qual;
             f.solution_count = s.count;
             f.solution_rank = s.rank;
-            R->filled[i].push_back(f);
         }
         mtg_gap_result& r = R->res[i];
         r.nb_nodes = w.nb_nodes; r.total_nt = w.total_nt; r.nb_terminal = w.nb_terminal;
         r.has_solution_counts = w.has_counts; r.nb_total_filled = w.nb_total_filled; r.nb_reported = (int)w.sols.size();
-        r.n_filled = (int)R->filled[i].size();
-        r.filled = R->filled[i].data();
+        r.n_filled = (int)w.sols.size();
+        r.filled = F0;
         r.extension = w.extension.c_str();
-    });
+    }, 256);
     /* the views on the caller's strings end here */
     st.marshal_ms = t_m1 - t_m0;
     st.result_ms = mtgi::now_ms() - t_m2;
@@ -682,7 +694,7 @@ void mtg_results_free(mtg_results* r)
 {
     if (!r) return;
     /* release the per-gap strings from several threads */
-    mtgi::parallel_for(r->gaps.size(), 0, [&](size_t i) { mtgi::GapWork().swap_into(r->gaps[i]); std::vector<mtg_filled>().swap(r->filled[i]); }, 1024);
+    mtgi::parallel_for(r->gaps.size(), 0, [&](size_t i) { mtgi::GapWork().swap_into(r->gaps[i]); }, 1024);
     delete r;
 }
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
@@ -765,7 +777,7 @@ int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* con
     in.layout();
     for (size_t i = 0; i < n; i++) in.set(i, std::string_view(sources[i]), std::string_view(targets[i]), nullptr, 0);
     mtgi::DevBatch batch;
-    std::vector<mtgi::GapDev>& gc = batch.gaps;
+    mtgi::DevBatch& gc = batch;
     mtg_batch_stats st{};
     int rc = mtgi::device_run(idx, p, in, batch, &st);
     if (rc) return rc;
@@ -773,7 +785,7 @@ int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* con
     mtg_contigs* C = new mtg_contigs();
     C->c.resize(n);
     for (size_t i = 0; i < n; i++)
-        for (uint32_t j = 0; j < gc[i].o.n_contigs; j++) C->c[i].push_back(gc[i].contig(j));
+        { const mtgi::GapDev gd = gc[i]; for (uint32_t j = 0; j < gd.o.n_contigs; j++) C->c[i].push_back(gd.contig(j)); }
     *out = C;
     return MTG_OK;
 }

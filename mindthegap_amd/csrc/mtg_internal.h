@@ -134,10 +134,24 @@ struct Target {
     uint64_t badmask = 0; /* positions (pair-lsb) that can never match (not ACGT/acgt) */
     bool usable = true;   /* at least k chars */
 };
-/* host copies of what a chunk of gaps brought back; GapDev entries point into them */
+struct TargetSpan {
+    const Target* p = nullptr;
+    uint32_t n = 0;
+    size_t size() const { return n; }
+    const Target& operator[](size_t i) const { return p[i]; }
+    const Target* begin() const { return p; }
+    const Target* end() const { return p + n; }
+};
+
+/* host copies of what a chunk of gaps brought back */
 struct HostChunk {
+    std::vector<mtg::GapOut> out;    /* per slot */
+    std::vector<mtg::PostOut> post;
+    std::vector<uint32_t> nw, nc;    /* words / contig-metadata entries copied back per slot */
+    std::vector<uint64_t> wbase, cbase;
     std::vector<uint64_t> words;
-    std::vector<uint32_t> meta;
+    std::vector<uint32_t> meta;      /* 5 arrays of tc entries: len, word_start, tpos, terr, ttgt */
+    uint64_t tc = 0;
 };
 
 /* what comes back from the device for one gap (views into a HostChunk) */
@@ -166,8 +180,25 @@ struct GapDev {
     }
 };
 struct DevBatch {
-    std::vector<GapDev> gaps;
+    std::vector<uint32_t> chunk_of, slot_of; /* where gap i's results sit */
     std::vector<std::unique_ptr<HostChunk>> chunks;
+    size_t size() const { return chunk_of.size(); }
+    /* view of gap i (cheap: a few pointer computations) */
+    GapDev operator[](size_t i) const
+    {
+        const HostChunk& c = *chunks[chunk_of[i]];
+        const uint32_t s = slot_of[i];
+        GapDev g;
+        g.o = c.out[s];
+        g.p = c.post[s];
+        g.n_meta = c.nc[s];
+        g.words = c.words.data() + c.wbase[s];
+        if (g.n_meta) {
+            const uint32_t* b0 = c.meta.data() + c.cbase[s];
+            g.len = b0; g.word_start = b0 + c.tc; g.tpos = b0 + 2 * c.tc; g.terr = b0 + 3 * c.tc; g.ttgt = b0 + 4 * c.tc;
+        }
+        return g;
+    }
 };
 
 /* what to copy back for a gap: nw leading words of its arena, metadata of nc contigs (0 or all) */
@@ -197,7 +228,7 @@ struct FillInput {
     void resize(size_t n);
     void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }
     void layout();
-    void set(size_t i, std::string_view source, std::string_view swf_target, const std::vector<Target>* targets, int nb_mis);
+    void set(size_t i, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis);
 };
 
 /* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
@@ -245,7 +276,7 @@ struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
     size_t ab_off = 0, ab_n = 0; /* slice of the batched abundance query */
 };
 struct GapWork {
-    std::vector<Target> targets; /* targetDictionary in iteration order */
+    TargetSpan targets; /* targetDictionary in iteration order (storage owned by the caller of fill_gaps) */
     std::string_view source;
     bool anchor_repeated = false, reverse = false;
     int nb_nodes = 0, total_nt = 0, nb_terminal = 0, nb_total_filled = 0;

@@ -436,7 +436,17 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
     for (int a = 0; a < ncons; a++)
         for (int b = a + 1; b < ncons; b++) {
             int na = cons_len[a], nb = cons_len[b];
-            int m = nw_matches(W, cons + (size_t)a * CONS_LEN, na, cons + (size_t)b * CONS_LEN, nb);
+            /* equal lengths and at most one substitution (the SNP bubble): the diagonal alignment scores 10n - 15h and any alignment with
+             * a gap pair at most 10n - 20, so the diagonal is the unique optimum and the traceback counts n - h matches; no DP needed */
+            int m = -1;
+            if (na == nb) {
+                int h = 0;
+                const uint8_t* pa = cons + (size_t)a * CONS_LEN;
+                const uint8_t* pb = cons + (size_t)b * CONS_LEN;
+                for (int i = 0; i < na && h < 2; i++) h += pa[i] != pb[i];
+                if (h < 2) m = na - h;
+            }
+            if (m < 0) m = nw_matches(W, cons + (size_t)a * CONS_LEN, na, cons + (size_t)b * CONS_LEN, nb);
             if (identity_below_90(m, na, nb)) return -1;
         }
     unsigned long best = 0;

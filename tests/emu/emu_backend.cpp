@@ -131,8 +131,8 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t, const uint64_t
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats)
 {
     const size_t n = in.src.size();
-    std::vector<GapDev>& out = batch.gaps;
-    out.assign(n, GapDev());
+    batch.chunk_of.assign(n, 0);
+    batch.slot_of.assign(n, 0);
     batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     for (size_t g = 0; g < n; g++) {
@@ -157,29 +157,23 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             uint32_t hist[256] = {0};
             PostOut po{};
             post_gap(idx->dev, cfg, S, o, T, hist, po);
-            GapDev& gd = out[g];
-            gd.o = o;
-            gd.p = po;
             uint32_t nw, nc;
             copy_plan(o, po, in.want_all_contigs, nw, nc);
             batch.chunks.emplace_back(new HostChunk());
             HostChunk& hc = *batch.chunks.back();
+            hc.out.assign(1, o); hc.post.assign(1, po); hc.nw.assign(1, nw); hc.nc.assign(1, nc); hc.wbase.assign(1, 0); hc.cbase.assign(1, 0);
             hc.words.assign(s_words(cfg, S), s_words(cfg, S) + nw);
             hc.words.push_back(0);
-            gd.words = hc.words.data();
-            gd.n_meta = nc;
+            hc.tc = nc;
             if (nc) {
                 hc.meta.insert(hc.meta.end(), s_clen(cfg, S), s_clen(cfg, S) + nc);
                 hc.meta.insert(hc.meta.end(), s_cstart(cfg, S), s_cstart(cfg, S) + nc);
                 hc.meta.insert(hc.meta.end(), s_tpos(cfg, S), s_tpos(cfg, S) + nc);
                 hc.meta.insert(hc.meta.end(), s_terr(cfg, S), s_terr(cfg, S) + nc);
                 hc.meta.insert(hc.meta.end(), s_ttgt(cfg, S), s_ttgt(cfg, S) + nc);
-                gd.len = hc.meta.data();
-                gd.word_start = gd.len + nc;
-                gd.tpos = gd.len + 2 * nc;
-                gd.terr = gd.len + 3 * nc;
-                gd.ttgt = gd.len + 4 * nc;
             }
+            batch.chunk_of[g] = (uint32_t)batch.chunks.size() - 1;
+            batch.slot_of[g] = 0;
             st.contig_nt += o.total_nt;
             break;
         }
