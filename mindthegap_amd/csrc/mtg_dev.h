@@ -26,7 +26,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MTG_DEV __device__ __forceinline__
+#ifndef MTG_NOINLINE_BUBBLES
+#define MTG_DEV_NOINLINE __device__ __forceinline__
+#else
 #define MTG_DEV_NOINLINE __device__ __noinline__
+#endif
 #define MTG_UNROLL _Pragma("unroll")
 #else
 #define MTG_EMU 1

@@ -333,8 +333,48 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
     int d = 0; /* current frame */
     dfs_f[0] = start.f;
     dfs_c[0] = canon(start);
+    /* k-mers of the current path: kept in the nested-frontline hash set (idle here) so that the loop test is one probe instead of a scan
+     * of the whole path; a popped k-mer leaves a tombstone (canonical k-mers are < 2^62, so ~0 - 1 is free) */
+    uint64_t* pset = s_iseen(W.cfg, W.S);
+    const uint32_t pcap = W.cfg.iseen_cap;
+    const uint64_t TOMB = ~0ULL - 1;
+    uint32_t plog_n = 0;
+    uint32_t* plog = s_iseenlog(W.cfg, W.S);
+    auto path_has = [&](uint64_t c) -> bool {
+        uint32_t h = set_hash(c, pcap);
+        for (;;) {
+            const uint64_t v = pset[h];
+            if (v == 0) return false;
+            if (v == c + 1) return true;
+            h = (h + 1) & (pcap - 1);
+        }
+    };
+    auto path_add = [&](uint64_t c) -> bool {
+        uint32_t h = set_hash(c, pcap);
+        for (;;) {
+            const uint64_t v = pset[h];
+            if (v == 0 || v == TOMB) {
+                if (v == 0) { if (plog_n + 2 >= pcap) return false; plog[plog_n++] = h; }
+                pset[h] = c + 1;
+                return true;
+            }
+            h = (h + 1) & (pcap - 1);
+        }
+    };
+    auto path_del = [&](uint64_t c) {
+        uint32_t h = set_hash(c, pcap);
+        for (;;) {
+            const uint64_t v = pset[h];
+            if (v == 0) return;
+            if (v == c + 1) { pset[h] = TOMB; return; }
+            h = (h + 1) & (pcap - 1);
+        }
+    };
+    auto path_clear = [&]() { for (uint32_t i = 0; i < plog_n; i++) pset[plog[i]] = 0; plog_n = 0; };
+    path_add(dfs_c[0]);
     /* enter frame 0 */
     bool entering = true;
+    auto run = [&]() -> bool {
     for (;;) {
         if (entering) {
             entering = false;
@@ -355,6 +395,7 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
         if (mask == 0) {
             /* return to the parent; the parent re-checks the breadth limit after each child */
             if (d == 0) return true;
+            path_del(dfs_c[d]);
             d--;
             if (ncons > W.cfg.mono_max_breadth) return false;
             continue;
@@ -364,14 +405,18 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
         Kmer x = make_kmer(dfs_f[d], k);
         Kmer y = kmer_next(x, nt, k, W.mk);
         uint64_t cy = canon(y);
-        for (int i = 0; i <= d; i++) if (dfs_c[i] == cy) return false; /* loop inside the bubble */
-        if (d + 1 >= DFS_CAP) { W.status = GAP_OVF_DFS; return false; }
+        if (path_has(cy)) return false; /* loop inside the bubble */
+        if (d + 1 >= DFS_CAP || !path_add(cy)) { W.status = GAP_OVF_DFS; return false; }
         dfs_nt[d] = (uint8_t)nt;
         d++;
         dfs_f[d] = y.f;
         dfs_c[d] = cy;
         entering = true;
     }
+    };
+    const bool ok = run();
+    path_clear();
+    return ok;
 }
 
 /* identity of src/Utils.cpp:87-189 (same routine in gatb's Traversal [MEM]) without the full matrix:
@@ -491,12 +536,14 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
     if (chosen < 0) return 0;
     /* mark all involved extensions (only the node bit of branching k-mers is ever read back) */
     const uint64_t* inv = s_inv(W.cfg, W.S);
+#ifndef MTG_EXP_NO_MARKINV
     for (uint32_t i = 0; i < W.n_inv; i++) {
         Kmer x;
         x.f = inv[i];
         x.r = revcomp(x.f, W.k);
         if (W.is_branching(x)) W.mark_canon(inv[i]);
     }
+#endif
     return s_conslen(W.cfg, W.S)[chosen];
 }
 
