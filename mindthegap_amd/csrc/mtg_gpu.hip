@@ -217,7 +217,7 @@ __global__ void k_query(Index ix, const uint64_t* __restrict__ kmers, size_t n, 
 }
 
 /* one gap per lane, one wave per workgroup (waves retire independently) */
-__global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* zero, uint8_t* raw, const uint64_t* __restrict__ src,
+__global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                 GapOut* out, uint32_t n)
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* 
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
-    GapScratch S = carve(cfg, zero, raw, slot);
+    GapScratch S = carve(cfg, zero, raw, ilv, slot);
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];
@@ -253,6 +253,8 @@ __global__ void __launch_bounds__(64) k_post(Index ix, FillCfg cfg, uint8_t* raw
         const uint32_t g = ids ? ids[slot] : slot;
         GapScratch S;
         S.z = nullptr;
+        S.v = nullptr;
+        S.lane = 0;
         S.r = raw + (uint64_t)slot * cfg.raw_stride;
         PostTargets T;
         T.le = tle + toff[g];
@@ -274,6 +276,8 @@ __global__ void k_compact(FillCfg cfg, const uint8_t* raw, const uint32_t* __res
     for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
         GapScratch S;
         S.z = nullptr;
+        S.v = nullptr;
+        S.lane = 0;
         S.r = const_cast<uint8_t*>(raw) + (uint64_t)slot * cfg.raw_stride;
         const uint64_t* w = s_words(cfg, S);
         uint64_t* dw = dense_words + word_base[slot];
@@ -624,6 +628,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     auto wsbuf = [&]() { WsBuf b; b.ws = &idx->ws; b.slot = ws_next++; return b; };
     WsBuf d_src = wsbuf(), d_rw = wsbuf(), d_roff = wsbuf(), d_rlen = wsbuf(), d_r0 = wsbuf(), d_tle = wsbuf(), d_tbad = wsbuf(), d_toff = wsbuf(), d_tcnt = wsbuf(),
           d_mis = wsbuf(), d_fok = wsbuf();
+    WsBuf d_ilv = wsbuf();
     WsBuf d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_post = wsbuf(), d_ids = wsbuf(), d_nw = wsbuf(), d_nc = wsbuf(), d_wb = wsbuf(), d_cb = wsbuf(),
           d_dw = wsbuf(), d_dm = wsbuf();
     double t0 = now_ms();
@@ -646,14 +651,15 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + sizeof(GapOut) + sizeof(PostOut) + 64;
-        const size_t cached = idx->ws.cap[d_zero.slot] + idx->ws.cap[d_raw.slot]; /* already ours, reusable */
+        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(PostOut) + 64;
+        const size_t cached = idx->ws.cap[d_zero.slot] + idx->ws.cap[d_raw.slot] + idx->ws.cap[d_ilv.slot]; /* already ours, reusable */
         size_t chunk = (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
         if (chunk > todo.size()) chunk = todo.size();
         if (chunk > (1u << 20)) chunk = 1u << 20;
         if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }
         HIP_TRY(d_zero.alloc(chunk * cfg.zero_stride));
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
+        HIP_TRY(d_ilv.alloc(((chunk + 63) / 64) * cfg.ilv_stride));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
         HIP_TRY(d_post.alloc(chunk * sizeof(PostOut)));
         HIP_TRY(d_ids.alloc(chunk * 4)); HIP_TRY(d_nw.alloc(chunk * 4)); HIP_TRY(d_nc.alloc(chunk * 4)); HIP_TRY(d_wb.alloc(chunk * 8)); HIP_TRY(d_cb.alloc(chunk * 8));
@@ -674,7 +680,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             st.h2d_ms += now_ms() - t0;
             HIP_TRY(hipMemsetAsync(d_zero.p, 0, (size_t)m * cfg.zero_stride, 0));
             HIP_TRY(hipEventRecord(ev0, 0));
-            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_src.as<uint64_t>(),
+            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src.as<uint64_t>(),
                                d_rw.as<uint64_t>(), d_roff.as<uint32_t>(), d_rlen.as<uint32_t>(), d_r0.as<uint64_t>(), d_ids.as<uint32_t>(),
                                d_out.as<GapOut>(), m);
             HIP_TRY(hipEventRecord(ev1, 0));

@@ -44,6 +44,7 @@ struct FillCfg {
     uint32_t iseen_cap;   /* nested frontline visited set, power of two */
     uint64_t zero_stride; /* bytes per gap in the zero-initialised region */
     uint64_t raw_stride;  /* bytes per gap in the raw region */
+    uint64_t ilv_stride;  /* bytes per WAVE (64 gaps) in the lane-interleaved region */
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_dfsf, o_dfsc,
@@ -55,8 +56,19 @@ enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
 /* per-gap scratch: two base pointers; the arrays sit at uniform offsets (FillCfg::o_*) */
 struct GapScratch {
     uint8_t* z; /* zero-initialised before the launch: marked | seen | iseen (canonical k-mer + 1, open addressing) */
-    uint8_t* r; /* raw */
+    uint8_t* r; /* raw, contiguous per gap: contigs, queue, terminal info (read by k_post / k_compact / the host) */
+    uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
+                   that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
+    uint32_t lane;
 };
+/* strided view of one lane's array in the interleaved region */
+template <typename T> struct SP {
+    T* p;
+    MTG_DEV T& operator[](size_t i) const { return p[i * 64]; }
+    MTG_DEV SP operator+(size_t off) const { SP r; r.p = p + off * 64; return r; }
+};
+#define MTG_ILV(T, name, off) \
+    MTG_DEV SP<T> name(const FillCfg& c, const GapScratch& S) { SP<T> r; r.p = reinterpret_cast<T*>(S.v + (uint64_t)(off) * 64) + S.lane; return r; }
 #define MTG_ARR(T, name, base, off) \
     MTG_DEV T* name(const FillCfg& c, const GapScratch& S) { return reinterpret_cast<T*>(S.base + (off)); }
 MTG_ARR(uint64_t, s_marked, z, 0)
@@ -68,22 +80,22 @@ MTG_ARR(uint32_t, s_clen, r, c.o_clen)       /* length in nt */
 MTG_ARR(uint64_t, s_qf, r, c.o_qf)           /* BFS queue: oriented k-mer */
 MTG_ARR(uint64_t, s_qc, r, c.o_qc)           /*   canonical k-mer (doubles as already_extended_from) */
 MTG_ARR(int32_t, s_qd, r, c.o_qd)
-MTG_ARR(uint32_t, s_seenlog, r, c.o_seenlog) /* slots touched in seen[] */
-MTG_ARR(uint32_t, s_iseenlog, r, c.o_iseenlog)
-MTG_ARR(uint64_t, s_inv, r, c.o_inv)
-MTG_ARR(uint64_t, s_fl0, r, c.o_fl0)         /* frontline double buffer */
-MTG_ARR(uint64_t, s_fl1, r, c.o_fl1)
-MTG_ARR(uint64_t, s_ifl0, r, c.o_ifl0)       /* nested frontline */
-MTG_ARR(uint64_t, s_ifl1, r, c.o_ifl1)
-MTG_ARR(uint8_t, s_flnt0, r, c.o_flnt0)
-MTG_ARR(uint8_t, s_flnt1, r, c.o_flnt1)
-MTG_ARR(uint64_t, s_dfsf, r, c.o_dfsf)       /* consensus enumeration stack */
-MTG_ARR(uint64_t, s_dfsc, r, c.o_dfsc)
-MTG_ARR(uint8_t, s_dfsmask, r, c.o_dfsmask)
-MTG_ARR(uint8_t, s_dfsnt, r, c.o_dfsnt)
-MTG_ARR(uint8_t, s_cons, r, c.o_cons)        /* CONS_CAP x CONS_LEN nts */
-MTG_ARR(uint16_t, s_conslen, r, c.o_conslen)
-MTG_ARR(int32_t, s_nw, r, c.o_nw)            /* 4 rows x (CONS_LEN+1) */
+MTG_ILV(uint32_t, s_seenlog, c.o_seenlog) /* slots touched in seen[] */
+MTG_ILV(uint32_t, s_iseenlog, c.o_iseenlog)
+MTG_ILV(uint64_t, s_inv, c.o_inv)
+MTG_ILV(uint64_t, s_fl0, c.o_fl0)         /* frontline double buffer */
+MTG_ILV(uint64_t, s_fl1, c.o_fl1)
+MTG_ILV(uint64_t, s_ifl0, c.o_ifl0)       /* nested frontline */
+MTG_ILV(uint64_t, s_ifl1, c.o_ifl1)
+MTG_ILV(uint8_t, s_flnt0, c.o_flnt0)
+MTG_ILV(uint8_t, s_flnt1, c.o_flnt1)
+MTG_ILV(uint64_t, s_dfsf, c.o_dfsf)       /* consensus enumeration stack */
+MTG_ILV(uint64_t, s_dfsc, c.o_dfsc)
+MTG_ILV(uint8_t, s_dfsmask, c.o_dfsmask)
+MTG_ILV(uint8_t, s_dfsnt, c.o_dfsnt)
+MTG_ILV(uint8_t, s_cons, c.o_cons)        /* CONS_CAP x CONS_LEN nts */
+MTG_ILV(uint16_t, s_conslen, c.o_conslen)
+MTG_ILV(int32_t, s_nw, c.o_nw)            /* 4 rows x (CONS_LEN+1) */
 MTG_ARR(uint32_t, s_tpos, r, c.o_tpos)       /* per contig: position of the best target match (0xFFFFFFFF: none) */
 MTG_ARR(uint32_t, s_terr, r, c.o_terr)       /*             mismatches in the anchor */
 MTG_ARR(uint32_t, s_ttgt, r, c.o_ttgt)       /*             index of the target */
@@ -96,44 +108,46 @@ inline void finalize_cfg(FillCfg& c)
     c.z_seen = 8u * c.mcap;
     c.z_iseen = c.z_seen + 8u * c.seen_cap;
     c.zero_stride = align_up((uint64_t)c.z_iseen + 8ull * c.iseen_cap, 64);
+    /* contiguous per gap */
     uint64_t b = 8ull * c.cap_words;
     c.o_cstart = (uint32_t)b; b += 4ull * c.cap_contigs;
     c.o_clen = (uint32_t)b; b += 4ull * c.cap_contigs;
+    c.o_tpos = (uint32_t)b; b += 4ull * c.cap_contigs;
+    c.o_terr = (uint32_t)b; b += 4ull * c.cap_contigs;
+    c.o_ttgt = (uint32_t)b; b += 4ull * c.cap_contigs;
     b = align_up(b, 8);
     c.o_qf = (uint32_t)b; b += 8ull * c.qcap;
     c.o_qc = (uint32_t)b; b += 8ull * c.qcap;
     c.o_qd = (uint32_t)b; b += 4ull * c.qcap;
-    b = align_up(b, 8);
-    c.o_seenlog = (uint32_t)b; b += 4ull * c.seen_cap;
-    c.o_iseenlog = (uint32_t)b; b += 4ull * c.iseen_cap;
-    b = align_up(b, 8);
+    c.raw_stride = align_up(b + 8, 64);
+    /* interleaved per wave: byte offsets within one lane's share (every array starts 8-byte aligned) */
+    b = 0;
+    c.o_seenlog = (uint32_t)b; b += align_up(4ull * c.seen_cap, 8);
+    c.o_iseenlog = (uint32_t)b; b += align_up(4ull * c.iseen_cap, 8);
     c.o_inv = (uint32_t)b; b += 8ull * c.inv_cap;
     c.o_fl0 = (uint32_t)b; b += 8ull * FL_CAP;
     c.o_fl1 = (uint32_t)b; b += 8ull * FL_CAP;
     c.o_ifl0 = (uint32_t)b; b += 8ull * FL_CAP;
     c.o_ifl1 = (uint32_t)b; b += 8ull * FL_CAP;
-    c.o_flnt0 = (uint32_t)b; b += FL_CAP;
-    c.o_flnt1 = (uint32_t)b; b += FL_CAP;
-    b = align_up(b, 8);
+    c.o_flnt0 = (uint32_t)b; b += align_up(FL_CAP, 8);
+    c.o_flnt1 = (uint32_t)b; b += align_up(FL_CAP, 8);
     c.o_dfsf = (uint32_t)b; b += 8ull * DFS_CAP;
     c.o_dfsc = (uint32_t)b; b += 8ull * DFS_CAP;
     c.o_dfsmask = (uint32_t)b; b += DFS_CAP;
     c.o_dfsnt = (uint32_t)b; b += DFS_CAP;
-    c.o_cons = (uint32_t)b; b += (uint64_t)CONS_CAP * CONS_LEN;
-    c.o_conslen = (uint32_t)b; b += 2ull * CONS_CAP;
-    b = align_up(b, 8);
+    c.o_cons = (uint32_t)b; b += align_up((uint64_t)CONS_CAP * CONS_LEN, 8);
+    c.o_conslen = (uint32_t)b; b += align_up(2ull * CONS_CAP, 8);
     c.o_nw = (uint32_t)b; b += 4ull * 4 * (CONS_LEN + 1);
-    c.o_tpos = (uint32_t)b; b += 4ull * c.cap_contigs;
-    c.o_terr = (uint32_t)b; b += 4ull * c.cap_contigs;
-    c.o_ttgt = (uint32_t)b; b += 4ull * c.cap_contigs;
-    c.raw_stride = align_up(b, 64);
+    c.ilv_stride = align_up(b, 8) * 64;
 }
 
-MTG_DEV GapScratch carve(const FillCfg& c, uint8_t* zero_base, uint8_t* raw_base, uint64_t gap)
+MTG_DEV GapScratch carve(const FillCfg& c, uint8_t* zero_base, uint8_t* raw_base, uint8_t* ilv_base, uint64_t gap)
 {
     GapScratch S;
     S.z = zero_base + gap * c.zero_stride;
     S.r = raw_base + gap * c.raw_stride;
+    S.v = ilv_base + (gap >> 6) * c.ilv_stride;
+    S.lane = (uint32_t)(gap & 63);
     return S;
 }
 
@@ -241,8 +255,8 @@ MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
             /* go_next_depth */
             bool cont = true;
             int nnext = 0;
-            uint64_t* cf = cur ? s_ifl1(W.cfg, W.S) : s_ifl0(W.cfg, W.S);
-            uint64_t* nf = cur ? s_ifl0(W.cfg, W.S) : s_ifl1(W.cfg, W.S);
+            const SP<uint64_t> cf = cur ? s_ifl1(W.cfg, W.S) : s_ifl0(W.cfg, W.S);
+            const SP<uint64_t> nf = cur ? s_ifl0(W.cfg, W.S) : s_ifl1(W.cfg, W.S);
             for (int i = 0; i < ncur && cont; i++) {
                 Kmer x = make_kmer(cf[i], k);
                 Adj xl = adj_left(W.ix, x, W.mk1, W.lines);
@@ -282,10 +296,10 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
     s_fl0(W.cfg, W.S)[0] = start.f;
     s_flnt0(W.cfg, W.S)[0] = 255;
     for (;;) {
-        uint64_t* cf = cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S);
-        uint8_t* cn = cur ? s_flnt1(W.cfg, W.S) : s_flnt0(W.cfg, W.S);
-        uint64_t* nf = cur ? s_fl0(W.cfg, W.S) : s_fl1(W.cfg, W.S);
-        uint8_t* nn = cur ? s_flnt0(W.cfg, W.S) : s_flnt1(W.cfg, W.S);
+        const SP<uint64_t> cf = cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S);
+        const SP<uint8_t> cn = cur ? s_flnt1(W.cfg, W.S) : s_flnt0(W.cfg, W.S);
+        const SP<uint64_t> nf = cur ? s_fl0(W.cfg, W.S) : s_fl1(W.cfg, W.S);
+        const SP<uint8_t> nn = cur ? s_flnt0(W.cfg, W.S) : s_flnt1(W.cfg, W.S);
         int nnext = 0;
         for (int i = 0; i < ncur; i++) {
             if (depth > 0 && !fl_check(W, cf[i])) return 0;
@@ -323,12 +337,12 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
 MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint64_t end_c, int traversal_depth, int& ncons)
 {
     const int k = W.k;
-    uint64_t* dfs_f = s_dfsf(W.cfg, W.S);
-    uint64_t* dfs_c = s_dfsc(W.cfg, W.S);
-    uint8_t* dfs_mask = s_dfsmask(W.cfg, W.S);
-    uint8_t* dfs_nt = s_dfsnt(W.cfg, W.S);
-    uint8_t* cons = s_cons(W.cfg, W.S);
-    uint16_t* cons_len = s_conslen(W.cfg, W.S);
+    const SP<uint64_t> dfs_f = s_dfsf(W.cfg, W.S);
+    const SP<uint64_t> dfs_c = s_dfsc(W.cfg, W.S);
+    const SP<uint8_t> dfs_mask = s_dfsmask(W.cfg, W.S);
+    const SP<uint8_t> dfs_nt = s_dfsnt(W.cfg, W.S);
+    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+    const SP<uint16_t> cons_len = s_conslen(W.cfg, W.S);
     ncons = 0;
     int d = 0; /* current frame */
     dfs_f[0] = start.f;
@@ -339,7 +353,7 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
     const uint32_t pcap = W.cfg.iseen_cap;
     const uint64_t TOMB = ~0ULL - 1;
     uint32_t plog_n = 0;
-    uint32_t* plog = s_iseenlog(W.cfg, W.S);
+    const SP<uint32_t> plog = s_iseenlog(W.cfg, W.S);
     auto path_has = [&](uint64_t c) -> bool {
         uint32_t h = set_hash(c, pcap);
         for (;;) {
@@ -422,12 +436,12 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
 /* identity of src/Utils.cpp:87-189 (same routine in gatb's Traversal [MEM]) without the full matrix:
  * the traceback's choice at (i,j) only depends on scores already known when (i,j) is filled, so the
  * number of matches on the traceback path is carried forward.  Scores are multiples of 5 (exact). */
-MTG_DEV_NOINLINE int nw_matches(Worker& W, const uint8_t* a, int na, const uint8_t* b, int nb)
+MTG_DEV_NOINLINE int nw_matches(Worker& W, SP<uint8_t> a, int na, SP<uint8_t> b, int nb)
 {
-    int32_t* sp = s_nw(W.cfg, W.S);                      /* previous row scores */
-    int32_t* sc = sp + (CONS_LEN + 1);         /* current row scores  */
-    int32_t* mp = sc + (CONS_LEN + 1);         /* previous row match counts */
-    int32_t* mc = mp + (CONS_LEN + 1);
+    SP<int32_t> sp = s_nw(W.cfg, W.S);        /* previous row scores */
+    SP<int32_t> sc = sp + (CONS_LEN + 1);      /* current row scores  */
+    SP<int32_t> mp = sc + (CONS_LEN + 1);      /* previous row match counts */
+    SP<int32_t> mc = mp + (CONS_LEN + 1);
     for (int j = 0; j <= nb; j++) { sp[j] = -5 * j; mp[j] = 0; }
     for (int i = 1; i <= na; i++) {
         sc[0] = -5 * i; mc[0] = 0;
@@ -441,7 +455,7 @@ MTG_DEV_NOINLINE int nw_matches(Worker& W, const uint8_t* a, int na, const uint8
             else if (best == del) mc[j] = mp[j];
             else mc[j] = mc[j - 1];
         }
-        int32_t* t = sp; sp = sc; sc = t;
+        SP<int32_t> t = sp; sp = sc; sc = t;
         t = mp; mp = mc; mc = t;
     }
     return mp[nb];
@@ -466,8 +480,8 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
 {
     if (ncons <= 0) return -1;
     const int k = W.k;
-    const uint8_t* cons = s_cons(W.cfg, W.S);
-    const uint16_t* cons_len = s_conslen(W.cfg, W.S);
+    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+    const SP<uint16_t> cons_len = s_conslen(W.cfg, W.S);
     int mean = 0;
     for (int c = 0; c < ncons; c++) mean += cons_len[c];
     mean /= ncons;
@@ -486,8 +500,8 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
             int m = -1;
             if (na == nb) {
                 int h = 0;
-                const uint8_t* pa = cons + (size_t)a * CONS_LEN;
-                const uint8_t* pb = cons + (size_t)b * CONS_LEN;
+                const SP<uint8_t> pa = cons + (size_t)a * CONS_LEN;
+                const SP<uint8_t> pb = cons + (size_t)b * CONS_LEN;
                 for (int i = 0; i < na && h < 2; i++) h += pa[i] != pb[i];
                 if (h < 2) m = na - h;
             }
@@ -501,7 +515,7 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
         if (len == 0) continue;
         unsigned long sum = 0;
         Kmer x = start;
-        const uint8_t* p = cons + (size_t)c * CONS_LEN;
+        const SP<uint8_t> p = cons + (size_t)c * CONS_LEN;
         for (int i = 0; i < len; i++) {
             sum += abundance(W.ix, x, W.lines);
             x = kmer_next(x, p[i], k, W.mk);
@@ -535,7 +549,7 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
 #endif
     if (chosen < 0) return 0;
     /* mark all involved extensions (only the node bit of branching k-mers is ever read back) */
-    const uint64_t* inv = s_inv(W.cfg, W.S);
+    const SP<uint64_t> inv = s_inv(W.cfg, W.S);
 #ifndef MTG_EXP_NO_MARKINV
     for (uint32_t i = 0; i < W.n_inv; i++) {
         Kmer x;
@@ -683,7 +697,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             if (n <= 0) {
                 end_contig = true;
             } else {
-                const uint8_t* p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;
+                const SP<uint8_t> p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;
                 bool looping = false;
                 for (int i = 0; i < n; i++) {
                     prev_c = canon(cur);
