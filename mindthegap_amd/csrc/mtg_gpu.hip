@@ -743,6 +743,16 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     (void)hipEventDestroy(ev2);
+#ifdef MTG_STAMPS
+    {
+        unsigned long long hs[16];
+        if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(mtg::g_stamps), sizeof hs) == hipSuccess && hs[8])
+            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f\n", hs[8], (double)hs[0] / hs[8],
+                    (double)hs[1] / hs[8], (double)hs[2] / hs[8], (double)hs[3] / hs[8], (double)hs[4] / hs[8], (double)hs[5] / hs[8]);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
+    }
+#endif
     if (rc == MTG_OK && !todo.empty()) {
         set_error("%zu gap(s) exceeded the largest traversal scratch tier", todo.size());
         rc = MTG_ERR_OVERFLOW;

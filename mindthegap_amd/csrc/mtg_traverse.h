@@ -180,6 +180,16 @@ MTG_DEV int set_add(uint64_t* tab, uint32_t cap, uint32_t& count, uint64_t c)
     }
 }
 
+/* diagnostic build (-DMTG_STAMPS): shader-clock time per phase, summed over lanes into a global array (never in the product build) */
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+__device__ unsigned long long g_stamps[16];
+#define MTG_T0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
+#define MTG_T1(v, slot) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[slot] += t_ - v; } while (0)
+#else
+#define MTG_T0(v)
+#define MTG_T1(v, slot)
+#endif
+
 /* ---- per-gap walker state ------------------------------------------------------------------ */
 struct Worker {
     const Index& ix;
@@ -190,6 +200,10 @@ struct Worker {
     uint32_t lines;      /* 64-byte index lines read */
     uint32_t status;
     uint32_t n_marked, n_seen, n_iseen, n_inv;
+    uint64_t msig0 = 0, msig1 = 0, msig2 = 0, msig3 = 0;
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     MTG_DEV Worker(const Index& i, const FillCfg& c, const GapScratch& s)
         : ix(i), cfg(c), S(s), k(i.k), mk(kmask(i.k)), mk1(kmask(i.k - 1)), lines(0), status(GAP_OK), n_marked(0), n_seen(0), n_iseen(0),
@@ -197,11 +211,30 @@ struct Worker {
     {
     }
 
+    /* 256-bit register signature of the marked set: most membership tests are answered without touching memory */
+    MTG_DEV static uint32_t sig_bit(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 56); }
     MTG_DEV void mark_canon(uint64_t c)
     {
         if (set_add(s_marked(cfg, S), cfg.mcap, n_marked, c) == -2) status = GAP_OVF_MARKED;
+        const uint32_t b = sig_bit(c);
+        const uint64_t m = 1ull << (b & 63);
+        if ((b >> 6) == 0) msig0 |= m; else if ((b >> 6) == 1) msig1 |= m; else if ((b >> 6) == 2) msig2 |= m; else msig3 |= m;
     }
-    MTG_DEV bool is_marked(uint64_t c) const { return set_has(s_marked(cfg, S), cfg.mcap, c); }
+    MTG_DEV bool is_marked(uint64_t c) const
+    {
+        const uint32_t b = sig_bit(c);
+        const uint64_t w = (b >> 6) == 0 ? msig0 : (b >> 6) == 1 ? msig1 : (b >> 6) == 2 ? msig2 : msig3;
+        if (!((w >> (b & 63)) & 1)) return false;
+        return set_has(s_marked(cfg, S), cfg.mcap, c);
+    }
+    /* adds c to the frontline visited set; true when it was not there yet (one probe sequence for test + insert) */
+    MTG_DEV bool seen_test_add(uint64_t c)
+    {
+        int s = set_add(s_seen(cfg, S), cfg.seen_cap, n_seen, c);
+        if (s == -2) { status = GAP_OVF_SEEN; return false; }
+        if (s >= 0) s_seenlog(cfg, S)[n_seen - 1] = (uint32_t)s;
+        return s >= 0;
+    }
     MTG_DEV bool is_branching(const Kmer& x)
     {
         Adj l = adj_left(ix, x, mk1, lines);
@@ -242,6 +275,8 @@ MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
     const int k = W.k;
     Kmer m = make_kmer(mf, k);
     Adj l = adj_left(W.ix, m, W.mk1, W.lines);
+    /* gatb's "just a speedup": with in-degree 1 the only predecessor is the frontline node m was reached from, which is in the visited set */
+    if (popc4(l.in) == 1) return true;
     for (uint32_t nt = 0; nt < 4; nt++) {
         if (!(l.in & (1u << nt))) continue;
         Kmer b = kmer_prev(m, nt, k, W.mk);
@@ -309,11 +344,10 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
                 if (!(a.out & (1u << nt))) continue;
                 Kmer y = kmer_next(x, nt, k, W.mk);
                 uint64_t cy = canon(y);
-                if (set_has(s_seen(W.cfg, W.S), W.cfg.seen_cap, cy)) continue;
+                if (!W.seen_test_add(cy)) continue;  /* already explored (on failure below the whole set is discarded anyway) */
                 if (W.is_marked(cy)) return 0; /* bubble touches an assembled region */
                 if (nnext < FL_CAP) { nf[nnext] = y.f; nn[nnext] = (cn[i] == 255) ? (uint8_t)nt : cn[i]; }
                 nnext++;
-                W.seen_add(cy);
                 W.involve(cy);
             }
             if (W.status) return 0;
@@ -354,23 +388,21 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
     const uint64_t TOMB = ~0ULL - 1;
     uint32_t plog_n = 0;
     const SP<uint32_t> plog = s_iseenlog(W.cfg, W.S);
-    auto path_has = [&](uint64_t c) -> bool {
+    /* 0: added, 1: already on the path, 2: table full.  A tombstone met on the way is reused only after the probe sequence has
+     * proven the key absent. */
+    auto path_add = [&](uint64_t c) -> int {
         uint32_t h = set_hash(c, pcap);
+        int64_t tomb = -1;
         for (;;) {
             const uint64_t v = pset[h];
-            if (v == 0) return false;
-            if (v == c + 1) return true;
-            h = (h + 1) & (pcap - 1);
-        }
-    };
-    auto path_add = [&](uint64_t c) -> bool {
-        uint32_t h = set_hash(c, pcap);
-        for (;;) {
-            const uint64_t v = pset[h];
-            if (v == 0 || v == TOMB) {
-                if (v == 0) { if (plog_n + 2 >= pcap) return false; plog[plog_n++] = h; }
+            if (v == c + 1) return 1;
+            if (v == TOMB && tomb < 0) tomb = (int64_t)h;
+            if (v == 0) {
+                if (tomb >= 0) { pset[(uint32_t)tomb] = c + 1; return 0; }
+                if (plog_n + 2 >= pcap) return 2;
+                plog[plog_n++] = h;
                 pset[h] = c + 1;
-                return true;
+                return 0;
             }
             h = (h + 1) & (pcap - 1);
         }
@@ -419,8 +451,10 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
         Kmer x = make_kmer(dfs_f[d], k);
         Kmer y = kmer_next(x, nt, k, W.mk);
         uint64_t cy = canon(y);
-        if (path_has(cy)) return false; /* loop inside the bubble */
-        if (d + 1 >= DFS_CAP || !path_add(cy)) { W.status = GAP_OVF_DFS; return false; }
+        if (d + 1 >= DFS_CAP) { W.status = GAP_OVF_DFS; return false; }
+        const int pa = path_add(cy);
+        if (pa == 1) return false; /* loop inside the bubble */
+        if (pa == 2) { W.status = GAP_OVF_DFS; return false; }
         dfs_nt[d] = (uint8_t)nt;
         d++;
         dfs_f[d] = y.f;
@@ -438,27 +472,32 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
  * number of matches on the traceback path is carried forward.  Scores are multiples of 5 (exact). */
 MTG_DEV_NOINLINE int nw_matches(Worker& W, SP<uint8_t> a, int na, SP<uint8_t> b, int nb)
 {
-    SP<int32_t> sp = s_nw(W.cfg, W.S);        /* previous row scores */
-    SP<int32_t> sc = sp + (CONS_LEN + 1);      /* current row scores  */
-    SP<int32_t> mp = sc + (CONS_LEN + 1);      /* previous row match counts */
-    SP<int32_t> mc = mp + (CONS_LEN + 1);
-    for (int j = 0; j <= nb; j++) { sp[j] = -5 * j; mp[j] = 0; }
+    /* one packed word per cell: (score + 16384) << 10 | matches (|score| <= 10 * 512, matches <= 512); the left and diagonal
+     * neighbours travel in registers, so a cell costs one load (upper neighbour), one load of b and one store */
+    SP<int32_t> prev = s_nw(W.cfg, W.S);
+    SP<int32_t> curr = prev + (CONS_LEN + 1);
+    const int OFF = 16384;
+    for (int j = 0; j <= nb; j++) prev[j] = (-5 * j + OFF) << 10;
     for (int i = 1; i <= na; i++) {
-        sc[0] = -5 * i; mc[0] = 0;
+        const uint32_t ai = a[i - 1];
+        int diag = prev[0];
+        int left = (-5 * i + OFF) << 10;
+        curr[0] = left;
         for (int j = 1; j <= nb; j++) {
-            int sub = (a[i - 1] == b[j - 1]) ? 10 : -5;
-            int diag = sp[j - 1] + sub, del = sp[j] - 5, ins = sc[j - 1] - 5;
-            int best = diag > del ? diag : del;
-            best = best > ins ? best : ins;
-            sc[j] = best;
-            if (best == diag) mc[j] = mp[j - 1] + (a[i - 1] == b[j - 1] ? 1 : 0);
-            else if (best == del) mc[j] = mp[j];
-            else mc[j] = mc[j - 1];
+            const int up = prev[j];
+            const bool eq = ai == b[j - 1];
+            const int sd = (diag >> 10) + (eq ? 10 : -5), su = (up >> 10) - 5, sl = (left >> 10) - 5;
+            int best = sd > su ? sd : su;
+            best = best > sl ? best : sl;
+            const int m = (best == sd) ? (diag & 1023) + (eq ? 1 : 0) : (best == su) ? (up & 1023) : (left & 1023);
+            const int cell = (best << 10) | m;
+            curr[j] = cell;
+            diag = up;
+            left = cell;
         }
-        SP<int32_t> t = sp; sp = sc; sc = t;
-        t = mp; mp = mc; mc = t;
+        SP<int32_t> t = prev; prev = curr; curr = t;
     }
-    return mp[nb];
+    return prev[nb] & 1023;
 }
 
 MTG_DEV bool identity_below_90(int matches, int na, int nb)
@@ -534,22 +573,33 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
 {
     W.n_inv = 0;
     uint64_t end_f = 0;
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    unsigned long long* stamp_acc = W.stamp_acc;
+#endif
+    MTG_T0(t_fe);
     int d = find_end_of_branching(W, cur, prev_c, end_f);
     W.seen_clear();
+    MTG_T1(t_fe, 2);
 #ifdef MTG_TRACE
     fprintf(stderr, "EB cur=%llx d=%d end=%llx ninv=%u\n", (unsigned long long)cur.f, d, (unsigned long long)end_f, W.n_inv);
 #endif
     if (!d || W.status) return 0;
     Kmer e = make_kmer(end_f, W.k);
     int ncons = 0;
-    if (!all_consensuses_between(W, cur, canon(e), d + 1, ncons)) return 0;
+    MTG_T0(t_dfs);
+    const bool okc = all_consensuses_between(W, cur, canon(e), d + 1, ncons);
+    MTG_T1(t_dfs, 3);
+    if (!okc) return 0;
+    MTG_T0(t_val);
     chosen = validate_consensuses(W, cur, ncons);
+    MTG_T1(t_val, 4);
 #ifdef MTG_TRACE
     fprintf(stderr, "   ncons=%d chosen=%d\n", ncons, chosen);
 #endif
     if (chosen < 0) return 0;
     /* mark all involved extensions (only the node bit of branching k-mers is ever read back) */
     const SP<uint64_t> inv = s_inv(W.cfg, W.S);
+    MTG_T0(t_mi);
 #ifndef MTG_EXP_NO_MARKINV
     for (uint32_t i = 0; i < W.n_inv; i++) {
         Kmer x;
@@ -558,6 +608,7 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
         if (W.is_branching(x)) W.mark_canon(inv[i]);
     }
 #endif
+    MTG_T1(t_mi, 5);
     return s_conslen(W.cfg, W.S)[chosen];
 }
 
@@ -661,7 +712,11 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             a = adj_right_t(adj, cur, mk1, lines);
             in_contig = true;
         }
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+        unsigned long long* stamp_acc = W.stamp_acc;
+#endif
         bool end_contig = false;
+        MTG_T0(t_w);
         /* ---- phase W: simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has
          * exactly one in- and one out-edge (lookahead): those nodes are non-branching (nothing to mark) and need no read. */
         while (popc4(a.out) == 1 && popc4(a.in) <= 1) {
@@ -690,6 +745,8 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             a = a2;
             if (canon(cur) == start_c || len > MAXLEN || ovf || W.status) { end_contig = true; break; } /* looping / limits */
         }
+        MTG_T1(t_w, 0);
+        MTG_T0(t_b);
         /* ---- phase B: branching node ---- */
         if (!end_contig) {
             int chosen = -1;
@@ -712,6 +769,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
                 else a = adj_right_t(adj, cur, mk1, lines);
             }
         }
+        MTG_T1(t_b, 1);
         if (!end_contig) continue;
         /* ---- phase E: the contig is complete ---- */
         in_contig = false;
@@ -744,6 +802,10 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             tail++;
         }
     }
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i], W.stamp_acc[i]);
+    atomicAdd(&g_stamps[8], 1ull);
+#endif
     out.n_contigs = nb;
     out.status = W.status;
     out.lines = W.lines + lines;
