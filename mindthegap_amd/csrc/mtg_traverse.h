@@ -473,17 +473,34 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
 MTG_DEV_NOINLINE int nw_matches(Worker& W, SP<uint8_t> a, int na, SP<uint8_t> b, int nb)
 {
     /* one packed word per cell: (score + 16384) << 10 | matches (|score| <= 10 * 512, matches <= 512); the left and diagonal
-     * neighbours travel in registers, so a cell costs one load (upper neighbour), one load of b and one store */
+     * neighbours travel in registers, so a cell costs one load (upper neighbour), one load of b and one store.
+     *
+     * Exact band: the alignment "diagonal, then the length difference as end gaps" scores s0, and any alignment with g gaps scores at
+     * most 5 (na + nb) - 10 g (every aligned pair a match), so an optimal alignment has g <= G = (5 (na + nb) - s0) / 10.  A path through
+     * cell (i, j) needs at least |i - j| + |(i - j) - (na - nb)| gaps: cells beyond that bound lie on no optimal path and are skipped
+     * (treated as minus infinity).  Cells on optimal paths keep their exact values and the traceback's equality tests can only succeed
+     * towards such cells, so the match count is the one of the full matrix (src/Utils.cpp:87-189). */
     SP<int32_t> prev = s_nw(W.cfg, W.S);
     SP<int32_t> curr = prev + (CONS_LEN + 1);
     const int OFF = 16384;
-    for (int j = 0; j <= nb; j++) prev[j] = (-5 * j + OFF) << 10;
+    const int NEG = (OFF - 12000) << 10; /* below every reachable score */
+    const int mn = na < nb ? na : nb, delta = na - nb;
+    int s0 = -5 * (delta < 0 ? -delta : delta);
+    for (int i = 0; i < mn; i++) s0 += (a[i] == b[i]) ? 10 : -5;
+    const int G = (5 * (na + nb) - s0) / 10;
+    /* feasible offsets o = i - j: |o| + |o - delta| <= G  <=>  omin <= o <= omax (G >= |delta| always holds) */
+    const int omax = (G + delta) / 2, omin = -((G - delta) / 2);
+    for (int j = 0; j <= nb; j++) prev[j] = (-j >= omin) ? ((-5 * j + OFF) << 10) : NEG; /* row 0: o = -j */
     for (int i = 1; i <= na; i++) {
         const uint32_t ai = a[i - 1];
-        int diag = prev[0];
-        int left = (-5 * i + OFF) << 10;
-        curr[0] = left;
-        for (int j = 1; j <= nb; j++) {
+        int jlo = i - omax, jhi = i - omin;
+        if (jlo < 1) jlo = 1;
+        if (jhi > nb) jhi = nb;
+        int diag = prev[jlo - 1];
+        int left;
+        if (jlo == 1) { left = (i <= omax) ? ((-5 * i + OFF) << 10) : NEG; curr[0] = left; } /* column 0: o = i */
+        else { left = NEG; curr[jlo - 1] = NEG; }
+        for (int j = jlo; j <= jhi; j++) {
             const int up = prev[j];
             const bool eq = ai == b[j - 1];
             const int sd = (diag >> 10) + (eq ? 10 : -5), su = (up >> 10) - 5, sl = (left >> 10) - 5;
@@ -495,6 +512,7 @@ MTG_DEV_NOINLINE int nw_matches(Worker& W, SP<uint8_t> a, int na, SP<uint8_t> b,
             diag = up;
             left = cell;
         }
+        if (jhi < nb) curr[jhi + 1] = NEG; /* the next row reads one cell past this row's band */
         SP<int32_t> t = prev; prev = curr; curr = t;
     }
     return prev[nb] & 1023;

@@ -112,3 +112,19 @@ extern "C" void emu_debug_adj(void* p, uint64_t key)
         for (int i = 0; i < MTG_ADJ_SLOTS; i++) { uint64_t v = t.slots[((b + d) % t.nbuckets) * MTG_ADJ_SLOTS + i]; printf("  [%d,%d] tag %llx disp %llu val %llx\n", d, i, (unsigned long long)(v >> 10), (unsigned long long)((v >> 8) & 3), (unsigned long long)(v & 255)); }
     }
 }
+
+/* unit access to the device NW routine (banded, exact) for tests */
+extern "C" int emu_nw_matches(const char* a, const char* b)
+{
+    FillCfg cfg = make_cfg(31, 100, 10000, 0, 0);
+    std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0), ilv(cfg.ilv_stride, 0);
+    GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
+    Index ix{};
+    ix.k = 31;
+    Worker W(ix, cfg, S);
+    const int na = (int)strlen(a), nb = (int)strlen(b);
+    SP<uint8_t> pa = s_cons(cfg, S), pb = s_cons(cfg, S) + CONS_LEN;
+    for (int i = 0; i < na; i++) pa[i] = (uint8_t)((a[i] >> 1) & 3);
+    for (int i = 0; i < nb; i++) pb[i] = (uint8_t)((b[i] >> 1) & 3);
+    return nw_matches(W, pa, na, pb, nb);
+}

@@ -29,6 +29,7 @@ def load():
     lib.emu_stage_a.restype = C.c_void_p
     lib.emu_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
     lib.emu_free.argtypes = [C.c_void_p]
+    lib.emu_nw_matches.argtypes = [C.c_char_p, C.c_char_p]
     _lib = lib
     return lib
 

@@ -359,3 +359,32 @@ def _diploid_case(mtg_mod, tmp_path, nloci):
 
 def test_cli_on_emulator_diploid(emu_product, tmp_path):
     _diploid_case(emu_product, tmp_path, 10)
+
+
+def test_banded_nw_equals_full_matrix(oracle):
+    """the device NW (exact band, packed cells) against src/Utils.cpp:87-189 as restated by the oracle"""
+    lib = emu_lib.load()
+    rng = random.Random(123)
+    for it in range(600):
+        n = rng.randrange(1, 160)
+        a = _rand_seq(rng, n)
+        kind = it % 6
+        if kind == 0:
+            b = _rand_seq(rng, rng.randrange(1, 160))
+        else:
+            b = list(a)
+            for _ in range(rng.randrange(0, 1 + kind * 2)):
+                if not b:
+                    break
+                p = rng.randrange(len(b))
+                r = rng.random()
+                if r < 0.5:
+                    b[p] = rng.choice("ACGT")
+                elif r < 0.75:
+                    del b[p:p + rng.randrange(1, 6)]
+                else:
+                    b[p:p] = list(_rand_seq(rng, rng.randrange(1, 6)))
+            b = "".join(b) or "A"
+        ident = oracle.mtgo_needleman_wunsch(a.encode(), b.encode())
+        expect = round(ident * max(len(a), len(b)))
+        assert lib.emu_nw_matches(a.encode(), b.encode()) == expect, (a, b)
