@@ -60,11 +60,20 @@ def main():
     lib = mtg.load_library()
     if not torch.cuda.is_available() or mtg.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # test hooks (single-GPU dry run of the N > 1 path): MTG_BENCH_ONE_DEVICE=1 puts every rank on device 0, MTG_BENCH_BACKEND=gloo
+    # replaces RCCL by gloo with host tensors.  The driver's runs use neither.
+    if os.environ.get("MTG_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("MTG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     lib.mtg_set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     nseq0, sites0, desc = WORKLOADS[a.workload]
     sites_per_gpu = a.sites or sites0
@@ -126,7 +135,7 @@ def main():
             for key in ("kernel_ms", "post_kernel_ms", "h2d_ms", "d2h_ms", "host_ms", "index_lines", "n_launches", "contig_nt"):
                 st[key] += st2[key]
         if world > 1:  # results gathered on rank 0 over RCCL / xGMI (all_gather of sizes + padded gather)
-            gather_bytes(seqs, dst=0, device=dev)
+            gather_bytes(seqs, dst=0, device=cdev)
         return n_filled, seqs, st
 
     def barrier():
@@ -148,10 +157,10 @@ def main():
     elapsed = time.perf_counter() - t0
     n_filled, seqs, _ = step(want_seqs=True)  # untimed pass whose sequences are verified below
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nf_t = torch.tensor([n_filled], device=dev, dtype=torch.int64)
+        nf_t = torch.tensor([n_filled], device=cdev, dtype=torch.int64)
         dist.all_reduce(nf_t)
         n_filled_all = int(nf_t.item())
     else:

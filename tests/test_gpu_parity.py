@@ -250,3 +250,26 @@ def test_cli_edge_cases(mtg, tmp_path):
 def test_diploid_bubbles(mtg, tmp_path):
     from tests.test_emu_parity import _diploid_case
     _diploid_case(mtg, tmp_path, 200)
+
+
+def test_scratch_tier_retry_inside_a_batch(mtg):
+    """one gap of the batch walks a 150 kb unitig and overflows the tier-0 contig arena: it is re-run in a larger tier on the device while
+    its neighbours keep their tier-0 results; contigs identical to the oracle's"""
+    import random
+    from tests import oracle_lib
+    rng = random.Random(5)
+    long_seq = "".join(rng.choice("ACGT") for _ in range(150000))
+    shorts = ["".join(rng.choice("ACGT") for _ in range(3000)) for _ in range(70)]
+    o = oracle_lib.Index.from_sequences([long_seq] + shorts, 31, 3, 40)
+    km, ct = o.export()
+    g = mtg.Index.from_kmers(km, ct, 31)
+    src = [s[:31] for s in shorts[:35]] + [long_seq[:31]] + [s[:31] for s in shorts[35:]]
+    tgt = [s[500:531] for s in shorts[:35]] + [long_seq[500:531]] + [s[500:531] for s in shorts[35:]]
+    got = g.stage_a(src, tgt)
+    assert mtg.last_batch_stats()["n_retried_gaps"] >= 1
+    for s, t, c in zip(src, tgt, got):
+        assert c == o.stage_a(s, t)[0]
+    assert len(got[35]) == 1 and len(got[35][0]) == 150000
+    res = g.fill_batch([mtg.Gap(s, t, [(t, "x", False)]) for s, t in zip(src, tgt)])
+    assert all(len(r["filled"]) == 1 and len(r["filled"][0]["seq"]) == 469 for r in res)
+    g.close(); o.close()
