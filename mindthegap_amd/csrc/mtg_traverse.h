@@ -618,14 +618,12 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
     /* mark all involved extensions (only the node bit of branching k-mers is ever read back) */
     const SP<uint64_t> inv = s_inv(W.cfg, W.S);
     MTG_T0(t_mi);
-#ifndef MTG_EXP_NO_MARKINV
     for (uint32_t i = 0; i < W.n_inv; i++) {
         Kmer x;
         x.f = inv[i];
         x.r = revcomp(x.f, W.k);
         if (W.is_branching(x)) W.mark_canon(inv[i]);
     }
-#endif
     MTG_T1(t_mi, 5);
     return s_conslen(W.cfg, W.S)[chosen];
 }

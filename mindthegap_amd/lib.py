@@ -2,6 +2,8 @@
 import ctypes as C
 import os
 import subprocess
+import sys
+import time
 
 import numpy as np
 
@@ -254,18 +256,16 @@ class Index:
     def fill_prepared(self, prepared, params=None, want_seqs=True):
         """one mtg_fill_batch call; returns (results handle, n_filled per gap, uint8 array of the packed "seq\\n" bytes).  Free with free_results."""
         params = params or FillParams()
-        import time as _t
         arr, n, _ = prepared
         h = C.c_void_p()
-        t0 = _t.perf_counter()
+        t0 = time.perf_counter()
         _check(self.lib.mtg_fill_batch(self.h, C.byref(params.c), arr, n, C.byref(h)))
-        t1 = _t.perf_counter()
+        t1 = time.perf_counter()
         nf = np.empty(n, dtype=np.uint32)
         nb, ng = C.c_uint64(), C.c_uint64()
         _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nb), C.byref(ng)))
         if os.environ.get("MTG_BENCH_DEBUG"):
-            import sys as _s
-            _s.stderr.write("  [py] mtg_fill_batch %.1f ms, summary %.1f ms\n" % ((t1 - t0) * 1e3, (_t.perf_counter() - t1) * 1e3))
+            sys.stderr.write("  [py] mtg_fill_batch %.1f ms, summary %.1f ms\n" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
         if not want_seqs:
             return h, nf, None
         buf = np.empty(max(int(nb.value), 1), dtype=np.uint8)
