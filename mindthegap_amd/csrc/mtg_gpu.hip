@@ -111,14 +111,16 @@ __global__ void k_insert_packed(Index ix, const uint64_t* __restrict__ words, co
 }
 
 /* k-mer counting: one text position per lane (adjacent lanes read adjacent bytes); flags[0] = table too full */
-__global__ void k_count(CountTable t, const char* __restrict__ text, uint64_t n, int k, unsigned long long* flags)
+__global__ void k_count(CountTable t, const char* __restrict__ text, uint64_t n, int k, uint32_t npass, uint32_t pass, unsigned long long* flags)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool full = false;
     for (; i + k <= n; i += stride) {
         const uint64_t c = kmer_from_ascii(text, i, k);
-        if (c != ~0ULL && !count_insert(t, c)) full = true;
+        if (c == ~0ULL) continue;
+        if (npass > 1 && (uint32_t)((mix64(c ^ 0x5851F42D4C957F2DULL) >> 40) % npass) != pass) continue; /* this k-mer belongs to another pass */
+        if (!count_insert(t, c)) full = true;
     }
     if (full) atomicOr(&flags[0], 1ull);
 }
@@ -811,47 +813,62 @@ int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t chunk = std::min<size_t>(n, (size_t)1 << 28);
-    /* distinct k-mers <= instances; start from instances / 4 slots (30x data has ~25 instances per distinct k-mer) and grow on overflow */
-    uint64_t cap = 1ull << 16;
-    while (cap < n / 4) cap <<= 1;
     const uint32_t nbins = (uint32_t)histo.size();
-    for (int attempt = 0; attempt < 8; attempt++, cap <<= 1) {
-        if (cap * 12 + chunk + (64 << 20) > free_b) { set_error("not enough device memory to count %zu k-mer instances in one pass", n); return MTG_ERR_NOMEM; }
+    const size_t budget = (size_t)((double)free_b * 0.6);
+    /* distinct k-mers <= instances; start from instances / 4 slots in total (30x data has ~25 instances per distinct k-mer) and grow on
+     * overflow; the slots are split over P passes when one table would not fit (a k-mer belongs to the pass its hash selects) */
+    uint64_t total_slots = 1ull << 16;
+    while (total_slots < n / 4) total_slots <<= 1;
+    uint32_t forced = getenv("MTG_COUNT_PASSES") ? (uint32_t)atoi(getenv("MTG_COUNT_PASSES")) : 0;
+    for (int attempt = 0; attempt < 8; attempt++, total_slots <<= 1) {
+        uint32_t npass = 1;
+        while (total_slots / npass * 12 + chunk + (64u << 20) > budget && npass < 1024) npass <<= 1;
+        if (forced > npass) npass = forced;
+        uint64_t cap = 1ull << 10;
+        while (cap < total_slots / npass) cap <<= 1;
+        if (cap * 12 + chunk + (64u << 20) > free_b) { set_error("not enough device memory to count %zu k-mer instances", n); return MTG_ERR_NOMEM; }
         DevBuf d_keys, d_cnts, d_text, d_flags, d_histo;
         HIP_TRY(d_keys.alloc(cap * 8)); HIP_TRY(d_cnts.alloc(cap * 4)); HIP_TRY(d_text.alloc(chunk + 64)); HIP_TRY(d_flags.alloc(64)); HIP_TRY(d_histo.alloc((size_t)nbins * 8));
-        HIP_TRY(hipMemset(d_keys.p, 0xFF, cap * 8));
-        HIP_TRY(hipMemset(d_cnts.p, 0, cap * 4));
-        HIP_TRY(hipMemset(d_flags.p, 0, 64));
         HIP_TRY(hipMemset(d_histo.p, 0, (size_t)nbins * 8));
         CountTable t;
         t.keys = d_keys.as<uint64_t>();
         t.counts = d_cnts.as<uint32_t>();
         t.mask = cap - 1;
-        for (size_t off = 0; off < n;) {
-            const size_t len = std::min(chunk, n - off);
-            HIP_TRY(hipMemcpy(d_text.p, text + off, len, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_count, dim3(256 * 32), dim3(256), 0, 0, t, d_text.as<char>(), (uint64_t)len, k, d_flags.as<unsigned long long>());
-            HIP_TRY(hipDeviceSynchronize());
-            if (off + len >= n) break;
-            off += len - (size_t)(k - 1); /* the next chunk re-reads the last k-1 characters so that no window is lost */
+        kmers.clear();
+        counts.clear();
+        bool overflow = false;
+        for (uint32_t pass = 0; pass < npass && !overflow; pass++) {
+            HIP_TRY(hipMemset(d_keys.p, 0xFF, cap * 8));
+            HIP_TRY(hipMemset(d_cnts.p, 0, cap * 4));
+            HIP_TRY(hipMemset(d_flags.p, 0, 64));
+            for (size_t off = 0; off < n;) {
+                const size_t len = std::min(chunk, n - off);
+                HIP_TRY(hipMemcpy(d_text.p, text + off, len, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_count, dim3(256 * 32), dim3(256), 0, 0, t, d_text.as<char>(), (uint64_t)len, k, npass, pass, d_flags.as<unsigned long long>());
+                HIP_TRY(hipDeviceSynchronize());
+                if (off + len >= n) break;
+                off += len - (size_t)(k - 1); /* the next chunk re-reads the last k-1 characters so that no window is lost */
+            }
+            unsigned long long flags[8];
+            HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
+            if (flags[0]) { overflow = true; break; } /* table too full: double the slots and start over */
+            hipLaunchKernelGGL(k_count_stats, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_histo.as<unsigned long long>(), nbins, d_flags.as<unsigned long long>() + 1);
+            HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
+            const size_t nk = (size_t)flags[1];
+            DevBuf d_ok, d_oc;
+            HIP_TRY(d_ok.alloc(nk * 8)); HIP_TRY(d_oc.alloc(nk * 4));
+            hipLaunchKernelGGL(k_count_emit, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_ok.as<uint64_t>(), d_oc.as<uint32_t>(), d_flags.as<unsigned long long>() + 2);
+            HIP_TRY(hipGetLastError());
+            const size_t base = kmers.size();
+            kmers.resize(base + nk);
+            counts.resize(base + nk);
+            if (nk) {
+                HIP_TRY(hipMemcpy(kmers.data() + base, d_ok.p, nk * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(counts.data() + base, d_oc.p, nk * 4, hipMemcpyDeviceToHost));
+            }
         }
-        unsigned long long flags[8];
-        HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
-        if (flags[0]) continue; /* table too full: double it */
-        hipLaunchKernelGGL(k_count_stats, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_histo.as<unsigned long long>(), nbins, d_flags.as<unsigned long long>() + 1);
-        HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
+        if (overflow) continue;
         HIP_TRY(hipMemcpy(histo.data(), d_histo.p, (size_t)nbins * 8, hipMemcpyDeviceToHost));
-        const size_t nk = (size_t)flags[1];
-        DevBuf d_ok, d_oc;
-        HIP_TRY(d_ok.alloc(nk * 8)); HIP_TRY(d_oc.alloc(nk * 4));
-        hipLaunchKernelGGL(k_count_emit, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_ok.as<uint64_t>(), d_oc.as<uint32_t>(), d_flags.as<unsigned long long>() + 2);
-        HIP_TRY(hipGetLastError());
-        kmers.resize(nk);
-        counts.resize(nk);
-        if (nk) {
-            HIP_TRY(hipMemcpy(kmers.data(), d_ok.p, nk * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(counts.data(), d_oc.p, nk * 4, hipMemcpyDeviceToHost));
-        }
         return MTG_OK;
     }
     set_error("k-mer count table kept overflowing");

@@ -207,7 +207,7 @@ def test_reverse_attempt_and_unfillable(mtg, tmp_path):
 
 
 @pytest.mark.parametrize("err", [0.0, 0.002])
-def test_simulated_reads_cfg2_shape(mtg, tmp_path, err):
+def test_simulated_reads_cfg2_shape(mtg, tmp_path, err, monkeypatch):
     """BASELINE config 2 at reduced size: 30x simulated reads (E0 error-free / E1-like with substitutions), index built by -in with
     -abundance-min 3, CLI outputs byte-identical to the oracle."""
     from mindthegap_amd.synth import SynthSet, simulate_reads
@@ -219,6 +219,8 @@ def test_simulated_reads_cfg2_shape(mtg, tmp_path, err):
     S.write_breakpoints(bk)
     o = oracle_lib.Index.from_files([reads], 31, 3)
     o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    if err > 0:
+        monkeypatch.setenv("MTG_COUNT_PASSES", "4")  # exercise the multi-pass k-mer counting on the erroneous set
     assert mtg.Filler().run(["-in", reads, "-bkpt", bk, "-abundance-min", "3", "-out", str(tmp_path / "hip")]) == 0
     for ext in (".insertions.fasta", ".info.txt"):
         assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
