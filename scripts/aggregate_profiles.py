@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output directories (gpurun_out/...) into the summaries kept under profiles/.
+
+  aggregate_profiles.py stats  <dir with *_kernel_stats.csv>                 <out.csv>
+  aggregate_profiles.py pmc    <FETCH_SIZE dir> [<WRITE_SIZE dir>]           <out.json>
+
+`stats` copies the per-kernel summary of `rocprofv3 --kernel-trace --stats` (this library's kernels are in namespace mtgi::).
+`pmc` averages FETCH_SIZE / WRITE_SIZE (KB, summed over the XCDs by rocprofv3) per kernel over the launches of one bench
+run; every pass was collected on its own, without any trace domain, as the pool requires.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    if not hits:
+        sys.exit(f"no {pat} under {d}")
+    return hits[0]
+
+
+def short(name):
+    return name.split("(")[0].split("<")[0].strip()
+
+
+def stats(d, out):
+    open(out, "w").write(open(find(d, "*_kernel_stats.csv")).read())
+
+
+def pmc(dirs, out):
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in dirs:
+        for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))):
+            k = short(r["Kernel_Name"])
+            if k.startswith("mtgi::"):
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, cs in acc.items():
+        e = {}
+        for c, v in cs.items():
+            e[f"{c}_KB_avg"] = sum(v) / len(v)
+            e[f"{c}_bytes_avg"] = 1024.0 * sum(v) / len(v)
+            e[f"launches_{c}"] = len(v)
+        if "FETCH_SIZE_bytes_avg" in e:
+            e["hbm_read_bytes_avg"] = e["FETCH_SIZE_bytes_avg"]
+        if "WRITE_SIZE_bytes_avg" in e:
+            e["hbm_write_bytes_avg"] = e["WRITE_SIZE_bytes_avg"]
+        res[k] = e
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 4:
+        sys.exit(__doc__)
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2:-1], sys.argv[-1])
