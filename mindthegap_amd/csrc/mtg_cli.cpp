@@ -89,7 +89,7 @@ static std::string solu_str(const Solution& s)
 
 /* writeFilledBreakpoint, src/Filler.cpp:1029-1093.  The bkpt-mode header passes its arguments in a different order
  * than its format (:1052-1054); the visible x86-64 result is NAME_len_L_qual_Q_avg_cov_A_median_cov_M   SOLU. */
-static void write_filled(Files& F, bool bkpt_mode, const GapWork& g, const std::vector<Solution>& sols, const std::string& seedName, const std::string& info)
+static void write_filled(Files& F, bool bkpt_mode, const GapWork& g, SolSpan sols, const std::string& seedName, const std::string& info)
 {
     for (auto& s : sols) {
         const int llen = (int)s.seq.length();
@@ -108,7 +108,7 @@ static void write_filled(Files& F, bool bkpt_mode, const GapWork& g, const std::
 }
 
 /* writeVcf, src/Filler.cpp:1095-1214 */
-static void write_vcf(Files& F, bool filter, const std::vector<Solution>& sols, const std::string& breakpointName, const std::string& sourceSequence)
+static void write_vcf(Files& F, bool filter, SolSpan sols, const std::string& breakpointName, const std::string& sourceSequence)
 {
     for (auto& s : sols) {
         std::string insertion = s.seq.str();
@@ -145,7 +145,7 @@ static void write_vcf(Files& F, bool filter, const std::vector<Solution>& sols, 
 }
 
 /* writeToGFA, src/Filler.cpp:1216-1273 */
-static void write_gfa(Files& F, int trim, const GapWork& g, const std::vector<Solution>& sols, std::string seedName, bool isRc)
+static void write_gfa(Files& F, int trim, const GapWork& g, SolSpan sols, std::string seedName, bool isRc)
 {
     const std::string seedNameNode = seedName;
     std::string seedDirection = "+";
@@ -250,7 +250,7 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
         const Site& s = sites[i];
         std::string info = info_string(fwd[i]);
         std::string name = s.name;
-        const std::vector<Solution>* sols = &fwd[i].sols;
+        const SolVec* sols = &fwd[i].sols;
         const GapWork* gw = &fwd[i];
         if (rev_idx[i] >= 0) {
             const GapWork& r = rev[rev_idx[i]];

@@ -5,9 +5,9 @@
  *   k_query                          : batched contains / queryAbundance / successors / predecessors
  *   k_stage_a                        : breadth-first contig construction of one gap per lane
  *                                      (IterativeExtensions::construct_linear_seqs, src/Filler.cpp:884)
- *   k_post                           : terminal-node search per contig + coverage of the single-contig solution, one wave per gap
+ *   k_post                           : terminal-node search per contig + coverage of the single-contig solution, one wave per gap;
+ *                                      then the dense copy of what the host needs of the gap
  *                                      (find_nodes_containing_multiple_R, src/Filler.cpp:1294-1378; coverage :959-988)
- *   k_compact                        : gathers what the host needs from a chunk into dense arrays for the copy back
  *   k_chase                          : dependent random 64-byte reads (measured roofline ceiling)
  */
 #include "mtg_internal.h"
@@ -237,13 +237,17 @@ __global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* 
     out[slot] = o;
 }
 
-/* terminal search for every contig + coverage of the common single-contig solution: one wave per gap */
+/* terminal-node search + coverage of the single-contig solution, one wave per gap; then the wave reserves room in the chunk's dense
+ * arrays (two atomic counters) and copies there what the host needs of this gap: nw leading arena words and, for nc contigs, their
+ * (length, first word) and terminal info.  counters: [0] words, [1] contig metadata entries */
 __global__ void __launch_bounds__(64) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
-                                             PostOut* post, uint32_t n)
+                                             uint32_t want_all, unsigned long long* counters, SlotRec* recs, uint64_t* dense_words, uint32_t* dense_meta,
+                                             uint32_t n)
 {
     __shared__ uint32_t hist[256];
+    __shared__ uint64_t s_base[2];
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
     for (uint32_t i = threadIdx.x; i < 256; i += 64) hist[i] = 0;
@@ -251,13 +255,13 @@ __global__ void __launch_bounds__(64) k_post(Index ix, FillCfg cfg, uint8_t* raw
     const GapOut o = outs[slot];
     PostOut po;
     po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = 0;
+    GapScratch S;
+    S.z = nullptr;
+    S.v = nullptr;
+    S.lane = 0;
+    S.r = raw + (uint64_t)slot * cfg.raw_stride;
     if (o.status == GAP_OK) {
         const uint32_t g = ids ? ids[slot] : slot;
-        GapScratch S;
-        S.z = nullptr;
-        S.v = nullptr;
-        S.lane = 0;
-        S.r = raw + (uint64_t)slot * cfg.raw_stride;
         PostTargets T;
         T.le = tle + toff[g];
         T.bad = tbad + toff[g];
@@ -266,33 +270,29 @@ __global__ void __launch_bounds__(64) k_post(Index ix, FillCfg cfg, uint8_t* raw
         T.fast_ok = fast_ok[g];
         post_gap(ix, cfg, S, o, T, hist, po);
     }
-    if (threadIdx.x == 0) post[slot] = po;
-}
-
-/* dense copy of what the host needs from a chunk: nw leading arena words per gap, and for nc contigs their
- * (len, start) and terminal info */
-__global__ void k_compact(FillCfg cfg, const uint8_t* raw, const uint32_t* __restrict__ nw, const uint32_t* __restrict__ nc,
-                          const uint64_t* __restrict__ word_base, const uint64_t* __restrict__ contig_base, uint64_t* dense_words, uint32_t* dense_meta,
-                          uint64_t meta_stride, uint32_t n)
-{
-    for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
-        GapScratch S;
-        S.z = nullptr;
-        S.v = nullptr;
-        S.lane = 0;
-        S.r = const_cast<uint8_t*>(raw) + (uint64_t)slot * cfg.raw_stride;
-        const uint64_t* w = s_words(cfg, S);
-        uint64_t* dw = dense_words + word_base[slot];
-        const uint32_t nwords = nw[slot], ncont = nc[slot];
-        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) dw[i] = w[i];
-        const uint64_t cb = contig_base[slot];
-        for (uint32_t i = threadIdx.x; i < ncont; i += blockDim.x) {
-            dense_meta[cb + i] = s_clen(cfg, S)[i];
-            dense_meta[meta_stride + cb + i] = s_cstart(cfg, S)[i];
-            dense_meta[2 * meta_stride + cb + i] = s_tpos(cfg, S)[i];
-            dense_meta[3 * meta_stride + cb + i] = s_terr(cfg, S)[i];
-            dense_meta[4 * meta_stride + cb + i] = s_ttgt(cfg, S)[i];
-        }
+    uint32_t nw, nc;
+    copy_plan(o, po, want_all != 0, nw, nc); /* po is uniform over the wave */
+    if (threadIdx.x == 0) {
+        s_base[0] = nw ? atomicAdd(&counters[0], (unsigned long long)nw) : 0ull;
+        s_base[1] = nc ? atomicAdd(&counters[1], (unsigned long long)nc) : 0ull;
+    }
+    __syncthreads();
+    const uint64_t wbase = s_base[0], cbase = s_base[1];
+    const uint64_t* w = s_words(cfg, S);
+    uint64_t* dw = dense_words + wbase;
+    for (uint32_t i = threadIdx.x; i < nw; i += 64) dw[i] = w[i];
+    uint32_t* dm = dense_meta + 5 * cbase;
+    for (uint32_t i = threadIdx.x; i < nc; i += 64) {
+        dm[i] = s_clen(cfg, S)[i];
+        dm[nc + i] = s_cstart(cfg, S)[i];
+        dm[2 * nc + i] = s_tpos(cfg, S)[i];
+        dm[3 * nc + i] = s_terr(cfg, S)[i];
+        dm[4 * nc + i] = s_ttgt(cfg, S)[i];
+    }
+    if (threadIdx.x == 0) {
+        SlotRec r;
+        r.o = o; r.p = po; r.nw = nw; r.nc = nc; r.pad_ = 0; r.wbase = wbase; r.cbase = cbase;
+        recs[slot] = r;
     }
 }
 
@@ -541,6 +541,7 @@ void index_release(mtg_index* idx)
 {
     if (!idx) return;
     for (int i = 0; i < Workspace::NSLOTS; i++) if (idx->ws.ptr[i]) (void)hipFree(idx->ws.ptr[i]);
+    for (int i = 0; i < Workspace::NHOST; i++) if (idx->ws.hptr[i]) (void)hipHostFree(idx->ws.hptr[i]);
     index_forget_host_copy(idx);
     free_tables(idx);
     delete idx;
@@ -611,6 +612,22 @@ template <typename B, typename T> hipError_t upload(B& b, const std::vector<T>& 
 }
 } // namespace
 
+void* staging_host(const mtg_index* idx, int slot, size_t bytes)
+{
+    Workspace& ws = idx->ws;
+    if (slot < 0 || slot >= Workspace::NHOST) return nullptr;
+    if (ws.hcap[slot] < bytes) {
+        if (ws.hptr[slot]) (void)hipHostFree(ws.hptr[slot]);
+        ws.hptr[slot] = nullptr;
+        ws.hcap[slot] = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&ws.hptr[slot], want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ws.hptr[slot] = nullptr; return nullptr; }
+        ws.hcap[slot] = want;
+    }
+    return ws.hptr[slot];
+}
+
+/* The caller holds idx->ws.mtx (the workspace and the staging blocks belong to one batch at a time). */
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats)
 {
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -618,80 +635,101 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
     if (int rc = ensure_device()) return rc;
     const size_t n = in.src.size();
-    batch.chunk_of.assign(n, 0);
-    batch.slot_of.assign(n, 0);
+    batch.n = n;
+    batch.chunk_of.clear();
+    batch.slot_of.clear();
     batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     if (n == 0) { if (stats) *stats = st; return MTG_OK; }
     const int k = idx->dev.k;
 
-    std::lock_guard<std::mutex> ws_lock(idx->ws.mtx); /* one batch at a time per index: the workspace is shared */
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &idx->ws; b.slot = ws_next++; return b; };
-    WsBuf d_src = wsbuf(), d_rw = wsbuf(), d_roff = wsbuf(), d_rlen = wsbuf(), d_r0 = wsbuf(), d_tle = wsbuf(), d_tbad = wsbuf(), d_toff = wsbuf(), d_tcnt = wsbuf(),
-          d_mis = wsbuf(), d_fok = wsbuf();
-    WsBuf d_ilv = wsbuf();
-    WsBuf d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_post = wsbuf(), d_ids = wsbuf(), d_nw = wsbuf(), d_nc = wsbuf(), d_wb = wsbuf(), d_cb = wsbuf(),
-          d_dw = wsbuf(), d_dm = wsbuf();
+    WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
+          d_dm = wsbuf(), d_cnt = wsbuf();
+    /* the marshalled input: two blocks, two copies */
     double t0 = now_ms();
-    HIP_TRY(upload(d_src, in.src)); HIP_TRY(upload(d_rw, in.rwords)); HIP_TRY(upload(d_roff, in.roff)); HIP_TRY(upload(d_rlen, in.rlen));
-    HIP_TRY(upload(d_r0, in.r0)); HIP_TRY(upload(d_tle, in.tle)); HIP_TRY(upload(d_tbad, in.tbad)); HIP_TRY(upload(d_toff, in.toff));
-    HIP_TRY(upload(d_tcnt, in.tcnt)); HIP_TRY(upload(d_mis, in.nbmis)); HIP_TRY(upload(d_fok, in.fast_ok));
+    HIP_TRY(d_ina.alloc(in.bytes_a));
+    HIP_TRY(d_inb.alloc(in.bytes_b));
+    HIP_TRY(d_cnt.alloc(64));
+    HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, 0));
+    const uint8_t* da = d_ina.as<uint8_t>();
+    const uint64_t* d_src = (const uint64_t*)(da + FillInput::off_a(n, 0));
+    const uint64_t* d_r0 = (const uint64_t*)(da + FillInput::off_a(n, 1));
+    const uint32_t* d_roff = (const uint32_t*)(da + FillInput::off_a(n, 2));
+    const uint32_t* d_rlen = (const uint32_t*)(da + FillInput::off_a(n, 3));
+    const uint32_t* d_toff = (const uint32_t*)(da + FillInput::off_a(n, 4));
+    const uint32_t* d_tcnt = (const uint32_t*)(da + FillInput::off_a(n, 5));
+    const uint8_t* d_mis = da + FillInput::off_a(n, 6);
+    const uint8_t* d_fok = da + FillInput::off_a(n, 7);
+    const uint64_t* d_rw = d_inb.as<uint64_t>();
+    const uint64_t* d_tle = d_rw + in.rwords.size();
+    const uint64_t* d_tbad = d_tle + in.tle.size();
     st.h2d_ms += now_ms() - t0;
-    tick("out.assign+upload");
+    tick("upload (async)");
 
     hipEvent_t ev0, ev1, ev2;
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
     HIP_TRY(hipEventCreate(&ev2));
 
-    std::vector<uint32_t> todo(n);
-    for (size_t i = 0; i < n; i++) todo[i] = (uint32_t)i;
+    std::vector<uint32_t> todo; /* empty at tier 0: every gap, in order */
+    size_t n_todo = n;
     int rc = MTG_OK;
 
-    for (int tier = 0; tier <= MTG_MAX_TIER && !todo.empty(); tier++) {
+    for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(PostOut) + 64;
-        const size_t cached = idx->ws.cap[d_zero.slot] + idx->ws.cap[d_raw.slot] + idx->ws.cap[d_ilv.slot]; /* already ours, reusable */
+        /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
+        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + (uint64_t)cfg.cap_words * 8 +
+                                 (uint64_t)cfg.cap_contigs * 20;
+        const size_t cached = idx->ws.cap[d_zero.slot] + idx->ws.cap[d_raw.slot] + idx->ws.cap[d_ilv.slot] + idx->ws.cap[d_dw.slot] + idx->ws.cap[d_dm.slot]; /* already ours */
         size_t chunk = (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
-        if (chunk > todo.size()) chunk = todo.size();
+        if (chunk > n_todo) chunk = n_todo;
         if (chunk > (1u << 20)) chunk = 1u << 20;
         if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }
         HIP_TRY(d_zero.alloc(chunk * cfg.zero_stride));
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
         HIP_TRY(d_ilv.alloc(((chunk + 63) / 64) * cfg.ilv_stride));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
-        HIP_TRY(d_post.alloc(chunk * sizeof(PostOut)));
-        HIP_TRY(d_ids.alloc(chunk * 4)); HIP_TRY(d_nw.alloc(chunk * 4)); HIP_TRY(d_nc.alloc(chunk * 4)); HIP_TRY(d_wb.alloc(chunk * 8)); HIP_TRY(d_cb.alloc(chunk * 8));
+        HIP_TRY(d_rec.alloc(chunk * sizeof(SlotRec)));
+        HIP_TRY(d_ids.alloc(chunk * 4));
+        HIP_TRY(d_dw.alloc(chunk * (uint64_t)cfg.cap_words * 8 + 64));
+        HIP_TRY(d_dm.alloc(chunk * (uint64_t)cfg.cap_contigs * 20 + 64));
         tick("workspace alloc");
         std::vector<uint32_t> retry;
-        for (size_t base = 0; base < todo.size(); base += chunk) {
-            const uint32_t m = (uint32_t)std::min(chunk, todo.size() - base);
+        for (size_t base = 0; base < n_todo; base += chunk) {
+            const uint32_t m = (uint32_t)std::min(chunk, n_todo - base);
             batch.chunks.emplace_back(new HostChunk());
             HostChunk& hc = *batch.chunks.back();
             const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
-            hc.out.resize(m); hc.post.resize(m); hc.nw.resize(m); hc.nc.resize(m); hc.wbase.resize(m); hc.cbase.resize(m);
-            std::vector<GapOut>& h_out = hc.out;
-            std::vector<PostOut>& h_post = hc.post;
-            std::vector<uint32_t>&nw = hc.nw, &nc = hc.nc;
-            std::vector<uint64_t>&wbase = hc.wbase, &cbase = hc.cbase;
-            t0 = now_ms();
-            HIP_TRY(hipMemcpy(d_ids.p, todo.data() + base, (size_t)m * 4, hipMemcpyHostToDevice));
-            st.h2d_ms += now_ms() - t0;
+            const bool identity = todo.empty() && base == 0 && m == n; /* the whole batch in one chunk: slot = gap */
+            const uint32_t* ids = nullptr;
+            std::vector<uint32_t> seq_ids;
+            if (!identity) {
+                t0 = now_ms();
+                const uint32_t* src_ids = nullptr;
+                if (todo.empty()) { seq_ids.resize(m); for (uint32_t s = 0; s < m; s++) seq_ids[s] = (uint32_t)(base + s); src_ids = seq_ids.data(); }
+                else src_ids = todo.data() + base;
+                HIP_TRY(hipMemcpy(d_ids.p, src_ids, (size_t)m * 4, hipMemcpyHostToDevice));
+                ids = d_ids.as<uint32_t>();
+                st.h2d_ms += now_ms() - t0;
+            }
             HIP_TRY(hipMemsetAsync(d_zero.p, 0, (size_t)m * cfg.zero_stride, 0));
+            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 64, 0));
             HIP_TRY(hipEventRecord(ev0, 0));
-            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src.as<uint64_t>(),
-                               d_rw.as<uint64_t>(), d_roff.as<uint32_t>(), d_rlen.as<uint32_t>(), d_r0.as<uint64_t>(), d_ids.as<uint32_t>(),
-                               d_out.as<GapOut>(), m);
+            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                               d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
             HIP_TRY(hipEventRecord(ev1, 0));
-            hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_ids.as<uint32_t>(), d_tle.as<uint64_t>(),
-                               d_tbad.as<uint64_t>(), d_toff.as<uint32_t>(), d_tcnt.as<uint32_t>(), d_mis.as<uint8_t>(), d_fok.as<uint8_t>(), d_post.as<PostOut>(), m);
+            hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
+                               in.want_all_contigs ? 1u : 0u, d_cnt.as<unsigned long long>(), d_rec.as<SlotRec>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), m);
             HIP_TRY(hipEventRecord(ev2, 0));
             HIP_TRY(hipGetLastError());
             tick("host prep+launch");
-            HIP_TRY(hipEventSynchronize(ev2));
+            unsigned long long totals[2] = {0, 0};
+            HIP_TRY(hipMemcpy(totals, d_cnt.p, 16, hipMemcpyDeviceToHost)); /* waits for the kernels */
             tick("kernels");
             float ms = 0, ms2 = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
@@ -700,47 +738,45 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             st.post_kernel_ms += ms2;
             st.n_launches++;
             t0 = now_ms();
-            HIP_TRY(hipMemcpy(h_out.data(), d_out.p, (size_t)m * sizeof(GapOut), hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(h_post.data(), d_post.p, (size_t)m * sizeof(PostOut), hipMemcpyDeviceToHost));
-            uint64_t tw = 0, tc = 0;
-            for (uint32_t s = 0; s < m; s++) {
-                st.index_lines += h_out[s].lines;
-                copy_plan(h_out[s], h_post[s], in.want_all_contigs, nw[s], nc[s]);
-                wbase[s] = tw; cbase[s] = tc;
-                tw += nw[s]; tc += nc[s];
-                if (h_out[s].status != GAP_OK) retry.push_back(todo[base + s]);
-            }
-            HIP_TRY(d_dw.alloc(tw * 8)); HIP_TRY(d_dm.alloc(tc * 5 * 4));
-            HIP_TRY(hipMemcpy(d_nw.p, nw.data(), (size_t)m * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_nc.p, nc.data(), (size_t)m * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_wb.p, wbase.data(), (size_t)m * 8, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_cb.p, cbase.data(), (size_t)m * 8, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_compact, dim3(std::min<uint32_t>(m, 256 * 16)), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_nw.as<uint32_t>(), d_nc.as<uint32_t>(),
-                               d_wb.as<uint64_t>(), d_cb.as<uint64_t>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), tc, m);
-            HIP_TRY(hipGetLastError());
-            std::vector<uint64_t>& hw = hc.words;
-            std::vector<uint32_t>& hm = hc.meta;
-            hw.resize(tw + 1);
-            hm.resize(tc * 5);
-            hc.tc = tc;
-            if (tw) HIP_TRY(hipMemcpy(hw.data(), d_dw.p, tw * 8, hipMemcpyDeviceToHost));
-            if (tc) HIP_TRY(hipMemcpy(hm.data(), d_dm.p, tc * 5 * 4, hipMemcpyDeviceToHost));
+            const uint64_t tw = totals[0], tc = totals[1];
+            SlotRec* h_rec = nullptr;
+            uint64_t* h_w = nullptr;
+            uint32_t* h_m = nullptr;
+            void* block = (int)chunk_id + 2 < Workspace::NHOST ? staging_host(idx, (int)chunk_id + 2, HostChunk::bytes_for(m, tw, tc)) : nullptr;
+            hc.carve(block, m, tw, tc, h_rec, h_w, h_m);
+            HIP_TRY(hipMemcpyAsync(h_rec, d_rec.p, (size_t)m * sizeof(SlotRec), hipMemcpyDeviceToHost, 0));
+            if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.p, tw * 8, hipMemcpyDeviceToHost, 0));
+            if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.p, tc * 20, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipStreamSynchronize(0));
+            h_w[tw] = 0;
             st.d2h_ms += now_ms() - t0;
-            tick("plan+compact+d2h");
+            tick("d2h");
             t0 = now_ms();
-            uint64_t nt_sum = 0;
+            uint64_t nt_sum = 0, lines = 0;
+            bool any_retry = false;
             for (uint32_t s2 = 0; s2 < m; s2++) {
-                if (h_out[s2].status != GAP_OK) continue;
-                batch.chunk_of[todo[base + s2]] = chunk_id;
-                batch.slot_of[todo[base + s2]] = s2;
-                nt_sum += h_out[s2].total_nt;
+                lines += h_rec[s2].o.lines;
+                if (h_rec[s2].o.status != GAP_OK) { any_retry = true; continue; }
+                nt_sum += h_rec[s2].o.total_nt;
             }
+            st.index_lines += lines;
             st.contig_nt += nt_sum;
+            if (!identity || any_retry) {
+                /* results are scattered over chunks from here on: keep an explicit map */
+                if (batch.chunk_of.empty()) { batch.chunk_of.assign(n, 0); batch.slot_of.resize(n); for (size_t i = 0; i < n; i++) batch.slot_of[i] = (uint32_t)i; }
+                for (uint32_t s2 = 0; s2 < m; s2++) {
+                    const uint32_t g = todo.empty() ? (uint32_t)(base + s2) : todo[base + s2];
+                    if (h_rec[s2].o.status != GAP_OK) { retry.push_back(g); continue; }
+                    batch.chunk_of[g] = chunk_id;
+                    batch.slot_of[g] = s2;
+                }
+            }
             tick("distribute");
             st.host_ms += now_ms() - t0;
         }
-        if (tier > 0) st.n_retried_gaps += todo.size();
+        if (tier > 0) st.n_retried_gaps += n_todo;
         todo.swap(retry);
+        n_todo = todo.size();
     }
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
@@ -755,8 +791,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
     }
 #endif
-    if (rc == MTG_OK && !todo.empty()) {
-        set_error("%zu gap(s) exceeded the largest traversal scratch tier", todo.size());
+    if (rc == MTG_OK && n_todo) {
+        set_error("%zu gap(s) exceeded the largest traversal scratch tier", n_todo);
         rc = MTG_ERR_OVERFLOW;
     }
     if (stats) *stats = st;

@@ -214,7 +214,14 @@ struct TermInfo { /* info_node_t, src/Filler.hpp:44-71 */
 /* marshalling of a batch of gapFillFromSource calls (targets == nullptr: contigs only, the stage A parity entry) */
 void FillInput::resize(size_t n)
 {
-    src.assign(n, 0); roff.assign(n, 0); rlen.assign(n, 0); r0.assign(n, 0); toff.assign(n, 0); tcnt.assign(n, 0); nbmis.assign(n, 0); fast_ok.assign(n, 0);
+    bytes_a = 34 * n8(n) + 64;
+    block_a = idx ? staging_host(idx, 0, bytes_a) : nullptr;
+    if (!block_a) { own_a.resize(bytes_a / 8 + 1); block_a = own_a.data(); }
+    uint8_t* b = (uint8_t*)block_a;
+    src.p = (uint64_t*)(b + off_a(n, 0)); r0.p = (uint64_t*)(b + off_a(n, 1));
+    roff.p = (uint32_t*)(b + off_a(n, 2)); rlen.p = (uint32_t*)(b + off_a(n, 3)); toff.p = (uint32_t*)(b + off_a(n, 4)); tcnt.p = (uint32_t*)(b + off_a(n, 5));
+    nbmis.p = b + off_a(n, 6); fast_ok.p = b + off_a(n, 7);
+    src.n = r0.n = roff.n = rlen.n = toff.n = tcnt.n = nbmis.n = fast_ok.n = n;
 }
 void FillInput::layout()
 {
@@ -223,14 +230,18 @@ void FillInput::layout()
         roff[i] = (uint32_t)rw; rw += (rlen[i] + 31) / 32 + 1;
         toff[i] = (uint32_t)nt; nt += tcnt[i];
     }
-    rwords.assign(rw, 0);
-    tle.assign(nt, 0);
-    tbad.assign(nt, 0);
+    bytes_b = 8 * (rw + 2 * nt) + 64;
+    block_b = idx ? staging_host(idx, 1, bytes_b) : nullptr;
+    if (!block_b) { own_b.resize(bytes_b / 8 + 1); block_b = own_b.data(); }
+    rwords.p = (uint64_t*)block_b; rwords.n = rw;
+    tle.p = rwords.p + rw; tle.n = nt;
+    tbad.p = tle.p + nt; tbad.n = nt;
 }
 void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis)
 {
     src[g] = encode_kmer(source.data(), k);
     const size_t rl = swf_target.size(), w0 = roff[g];
+    for (size_t w = 0; w < (rl + 31) / 32 + 1; w++) rwords[w0 + w] = 0; /* the block is recycled, not zeroed */
     for (size_t i = 0; i < rl; i++) rwords[w0 + (i >> 5)] |= (uint64_t)nt_code((unsigned char)swf_target[i]) << (2 * (i & 31));
     r0[g] = rl >= (size_t)k ? encode_kmer(swf_target.data(), k) : 0;
     /* the early stop is a literal strstr in upper-case contigs (IterativeExtensions [MEM]): a pattern with any other character never matches */
@@ -346,6 +357,39 @@ static float nw_identity(const std::string& a, const std::string& b)
     return identity;
 }
 
+/* ASCII of the packed nucleotides [from, from + L) of `words` (2 bits each, nucleotide i at bits 2(i mod 32) of word i / 32), four per
+ * table lookup; reversed and complemented when rc is set.  Reads at most one word past the last one used (the chunk storage is padded). */
+struct DecodeLut {
+    uint32_t fwd[256], rc[256];
+    DecodeLut()
+    {
+        static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
+        for (int b = 0; b < 256; b++) {
+            char f[4], r[4];
+            for (int j = 0; j < 4; j++) { f[j] = NT[(b >> (2 * j)) & 3]; r[3 - j] = NTC[(b >> (2 * j)) & 3]; }
+            memcpy(&fwd[b], f, 4);
+            memcpy(&rc[b], r, 4);
+        }
+    }
+};
+static void decode_slice(const uint64_t* words, uint32_t from, uint32_t L, bool rc, char* dst)
+{
+    static const DecodeLut lut;
+    static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
+    uint32_t i = 0;
+    for (; i + 4 <= L; i += 4) {
+        const uint32_t j = from + i, sh = 2 * (j & 31);
+        uint64_t w = words[j >> 5] >> sh;
+        if (sh > 56) w |= words[(j >> 5) + 1] << (64 - sh);
+        if (!rc) memcpy(dst + i, &lut.fwd[w & 0xFF], 4);
+        else memcpy(dst + (L - 4 - i), &lut.rc[w & 0xFF], 4);
+    }
+    for (; i < L; i++) {
+        const uint32_t j = from + i, c = (uint32_t)(words[j >> 5] >> (2 * (j & 31))) & 3;
+        if (!rc) dst[i] = NT[c]; else dst[L - 1 - i] = NTC[c];
+    }
+}
+
 /* everything after the device kernels for one gapFillFromSource call, except the coverage numbers of the general path */
 static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
 {
@@ -361,12 +405,10 @@ static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
     if (gc.p.fast == 1) {
         /* terminal node 0: find_all_paths_rev returns the single path [0] (src/GraphAnalysis.cpp:222-226) and
          * paths_to_sequences keeps contig0[k:pos] (:386-423); coverage was computed on the device */
-        Solution s;
+        Solution& s = W.sols.emplace_first();
         /* written straight into the batch arena (reverse-complemented when the attempt is a reverse one, src/Filler.cpp:998-1001) */
         const uint32_t L = gc.p.pos - (uint32_t)k;
-        static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
-        if (!W.reverse) for (uint32_t i = 0; i < L; i++) { const uint32_t j = (uint32_t)k + i; arena_slot[i] = NT[(gc.words[j >> 5] >> (2 * (j & 31))) & 3]; }
-        else for (uint32_t i = 0; i < L; i++) { const uint32_t j = (uint32_t)k + i; arena_slot[L - 1 - i] = NTC[(gc.words[j >> 5] >> (2 * (j & 31))) & 3]; }
+        decode_slice(gc.words, (uint32_t)k, L, W.reverse, arena_slot);
         arena_slot[L] = 0;
         s.seq.view(arena_slot, L);
         s.nb_errors = (int)gc.p.errors;
@@ -378,7 +420,6 @@ static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
         s.median = (float)((gc.p.ab_n % 2 == 1) ? (double)gc.p.med_hi : 0.5 * (gc.p.med_hi + gc.p.med_lo));
         s.ab_n = 0; /* no host-side coverage query needed */
         s.qual = -1;
-        W.sols.push_back(std::move(s));
         W.nb_total_filled = 1;
         W.has_counts = true;
         return;
@@ -498,8 +539,11 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     const int k = idx->dev.k;
     const size_t n = gaps.size();
     const double t_begin = now_ms();
+    /* the staging blocks of the index hold this batch from here until its results have been taken out of them */
+    std::lock_guard<std::mutex> batch_lock(idx->ws.mtx);
     FillInput in;
     in.k = k;
+    in.idx = idx;
     in.resize(n);
     std::atomic<long> bad_gap{-1};
     parallel_for(n, p->nb_host_threads, [&](size_t i) {
@@ -522,9 +566,9 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     if (dbg) fprintf(stderr, "  [fill_gaps] pre %.2f device_run %.2f ms\n", tdev - t_begin, now_ms() - tdev);
     double t0 = now_ms();
     std::vector<uint64_t> aoff(n + 1, 0);
-    for (size_t i = 0; i < n; i++) { const PostOut& po = dev.chunks[dev.chunk_of[i]]->post[dev.slot_of[i]]; aoff[i + 1] = aoff[i] + (po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0); }
-    arena.chars.resize(aoff[n] + 1);
-    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k, arena.chars.data() + aoff[i]); });
+    for (size_t i = 0; i < n; i++) { const PostOut& po = dev.rec(i).p; aoff[i + 1] = aoff[i] + (po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0); }
+    char* const arena_base = arena.ensure(aoff[n] + 1);
+    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k, arena_base + aoff[i]); });
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);
@@ -595,10 +639,35 @@ struct mtg_results {
     std::vector<uint64_t> filled_off;
     std::vector<mtgi::GapWork> gaps;
     std::vector<mtg_gap_result> res;
+    std::vector<std::string_view> swf; /* scratch of mtg_fill_batch */
+    std::vector<uint64_t> toff;
 };
 struct mtg_contigs {
     std::vector<std::vector<std::string>> c;
 };
+
+/* Result objects are recycled: a freed one keeps its storage (a few hundred bytes per gap plus the sequence arena) for the next batch,
+ * which then pays neither page faults nor allocator traffic.  At most two are kept. */
+namespace {
+std::mutex g_results_mtx;
+std::vector<mtg_results*> g_results_cache;
+mtg_results* results_acquire()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_results_mtx);
+        if (!g_results_cache.empty()) { mtg_results* r = g_results_cache.back(); g_results_cache.pop_back(); return r; }
+    }
+    return new mtg_results();
+}
+void results_release(mtg_results* r)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_results_mtx);
+        if (g_results_cache.size() < 2) { g_results_cache.push_back(r); return; }
+    }
+    delete r;
+}
+} // namespace
 
 
 extern "C" {
@@ -623,19 +692,23 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
 {
     if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     const double t_m0 = mtgi::now_ms();
-    mtg_results* R = new mtg_results();
-    R->gaps.resize(n);
-    std::vector<std::string_view> swf(n);
     for (size_t i = 0; i < n; i++) {
         const mtg_gap& g = gaps[i];
-        if (!g.source || !g.target || (g.n_targets && (!g.target_seqs || !g.target_names))) { delete R; mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
+        if (!g.source || !g.target || (g.n_targets && (!g.target_seqs || !g.target_names))) { mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
     }
-    std::vector<uint64_t> toff(n + 1, 0);
+    mtg_results* R = results_acquire();
+    R->gaps.resize(n);
+    std::vector<std::string_view>& swf = R->swf;
+    swf.resize(n);
+    std::vector<uint64_t>& toff = R->toff;
+    toff.resize(n + 1);
+    toff[0] = 0;
     for (size_t i = 0; i < n; i++) toff[i + 1] = toff[i] + (uint64_t)std::max(gaps[i].n_targets, 0);
     R->targets.resize(toff[n]);
     mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
         const mtg_gap& g = gaps[i];
         mtgi::GapWork& w = R->gaps[i];
+        w.reset(); /* a recycled object still holds the previous batch */
         w.source = g.source;
         swf[i] = g.target;
         w.anchor_repeated = g.is_anchor_repeated != 0;
@@ -653,10 +726,11 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     const double t_m1 = mtgi::now_ms();
     mtg_batch_stats st{};
     int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, R->arena, &st);
-    if (rc) { delete R; return rc; }
+    if (rc) { results_release(R); return rc; }
     const double t_m2 = mtgi::now_ms();
     R->res.resize(n);
-    R->filled_off.assign(n + 1, 0);
+    R->filled_off.resize(n + 1);
+    R->filled_off[0] = 0;
     for (size_t i = 0; i < n; i++) R->filled_off[i + 1] = R->filled_off[i] + R->gaps[i].sols.size();
     R->filled_flat.resize(R->filled_off[n]);
     mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
@@ -692,10 +766,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->res.size()) ? &r->res[i] : nullptr; }
 void mtg_results_free(mtg_results* r)
 {
-    if (!r) return;
-    /* release the per-gap strings from several threads */
-    mtgi::parallel_for(r->gaps.size(), 0, [&](size_t i) { mtgi::GapWork().swap_into(r->gaps[i]); }, 1024);
-    delete r;
+    if (r) results_release(r); /* its storage serves the next batch */
 }
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
 {
@@ -766,8 +837,10 @@ int mtg_index_scan_sequences(const mtg_index* idx, const char* const* seqs, size
 int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n, mtg_contigs** out)
 {
     if (!idx || !p || !out || (n && (!sources || !targets))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    std::lock_guard<std::mutex> batch_lock(idx->ws.mtx);
     mtgi::FillInput in;
     in.k = idx->dev.k;
+    in.idx = idx;
     in.want_all_contigs = true;
     in.resize(n);
     for (size_t i = 0; i < n; i++) {

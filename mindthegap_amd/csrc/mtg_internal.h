@@ -23,10 +23,13 @@
 namespace mtgi {
 /* grow-only device buffers reused by successive batches on one index */
 struct Workspace {
-    enum { NSLOTS = 32 };
+    enum { NSLOTS = 32, NHOST = 8 };
     void* ptr[NSLOTS] = {nullptr};
     size_t cap[NSLOTS] = {0};
-    std::mutex mtx;
+    /* page-locked host staging blocks: 0/1 = the marshalled input of a batch, 2.. = what the first chunks of a batch brought back */
+    void* hptr[NHOST] = {nullptr};
+    size_t hcap[NHOST] = {0};
+    std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
 }
 
@@ -143,15 +146,29 @@ struct TargetSpan {
     const Target* end() const { return p + n; }
 };
 
-/* host copies of what a chunk of gaps brought back */
+/* grow-only staging block `slot` of the index (page-locked on the device build); nullptr when it cannot be had */
+void* staging_host(const mtg_index* idx, int slot, size_t bytes);
+
+/* what a chunk of gaps brought back: one record per slot, the dense words and the dense contig metadata.  The three arrays sit in a
+ * staging block of the index (first chunks of a batch) or in `own`. */
 struct HostChunk {
-    std::vector<mtg::GapOut> out;    /* per slot */
-    std::vector<mtg::PostOut> post;
-    std::vector<uint32_t> nw, nc;    /* words / contig-metadata entries copied back per slot */
-    std::vector<uint64_t> wbase, cbase;
-    std::vector<uint64_t> words;
-    std::vector<uint32_t> meta;      /* 5 arrays of tc entries: len, word_start, tpos, terr, ttgt */
-    uint64_t tc = 0;
+    const mtg::SlotRec* recs = nullptr;
+    const uint64_t* words = nullptr;
+    const uint32_t* meta = nullptr;
+    uint32_t m = 0;
+    std::vector<uint64_t> own;
+    /* carves recs / words / meta for m slots, tw words, tc metadata entries out of `block` (or out of `own` when block is null) */
+    void carve(void* block, uint32_t m_, uint64_t tw, uint64_t tc, mtg::SlotRec*& r, uint64_t*& w, uint32_t*& mt)
+    {
+        if (!block) { own.resize(bytes_for(m_, tw, tc) / 8); block = own.data(); }
+        uint8_t* b = (uint8_t*)block;
+        r = (mtg::SlotRec*)b;
+        w = (uint64_t*)(b + rec_bytes(m_));
+        mt = (uint32_t*)(b + rec_bytes(m_) + (tw + 1) * 8);
+        recs = r; words = w; meta = mt; m = m_;
+    }
+    static size_t rec_bytes(uint32_t m_) { return ((size_t)m_ * sizeof(mtg::SlotRec) + 63) & ~(size_t)63; }
+    static size_t bytes_for(uint32_t m_, uint64_t tw, uint64_t tc) { return (rec_bytes(m_) + (tw + 1) * 8 + tc * 20 + 64 + 7) & ~(size_t)7; }
 };
 
 /* what comes back from the device for one gap (views into a HostChunk) */
@@ -180,55 +197,64 @@ struct GapDev {
     }
 };
 struct DevBatch {
-    std::vector<uint32_t> chunk_of, slot_of; /* where gap i's results sit */
+    std::vector<uint32_t> chunk_of, slot_of; /* where gap i's results sit; both empty: chunk 0, slot i */
     std::vector<std::unique_ptr<HostChunk>> chunks;
-    size_t size() const { return chunk_of.size(); }
+    size_t n = 0;
+    size_t size() const { return n; }
+    const mtg::SlotRec& rec(size_t i) const { return chunk_of.empty() ? chunks[0]->recs[i] : chunks[chunk_of[i]]->recs[slot_of[i]]; }
     /* view of gap i (cheap: a few pointer computations) */
     GapDev operator[](size_t i) const
     {
-        const HostChunk& c = *chunks[chunk_of[i]];
-        const uint32_t s = slot_of[i];
+        const HostChunk& c = chunk_of.empty() ? *chunks[0] : *chunks[chunk_of[i]];
+        const mtg::SlotRec& r = c.recs[chunk_of.empty() ? i : slot_of[i]];
         GapDev g;
-        g.o = c.out[s];
-        g.p = c.post[s];
-        g.n_meta = c.nc[s];
-        g.words = c.words.data() + c.wbase[s];
+        g.o = r.o;
+        g.p = r.p;
+        g.n_meta = r.nc;
+        g.words = c.words + r.wbase;
         if (g.n_meta) {
-            const uint32_t* b0 = c.meta.data() + c.cbase[s];
-            g.len = b0; g.word_start = b0 + c.tc; g.tpos = b0 + 2 * c.tc; g.terr = b0 + 3 * c.tc; g.ttgt = b0 + 4 * c.tc;
+            const uint32_t* b0 = c.meta + 5 * r.cbase;
+            g.len = b0; g.word_start = b0 + r.nc; g.tpos = b0 + 2 * (size_t)r.nc; g.terr = b0 + 3 * (size_t)r.nc; g.ttgt = b0 + 4 * (size_t)r.nc;
         }
         return g;
     }
 };
 
-/* what to copy back for a gap: nw leading words of its arena, metadata of nc contigs (0 or all) */
-inline void copy_plan(const mtg::GapOut& o, const mtg::PostOut& p, bool want_all, uint32_t& nw, uint32_t& nc)
-{
-    nw = nc = 0;
-    if (o.status != mtg::GAP_OK) return;
-    if (want_all || (p.fast == 0 && p.nb_terminal > 0)) { nw = o.n_words; nc = o.n_contigs; }
-    else if (p.fast == 1) nw = (p.pos + 31) / 32;
-    else if (p.fast == 2) nw = 0;
-    else nw = (p.clen0 + 31) / 32; /* no terminal node: contig 0 is the extension sequence */
-}
-
-/* a batch of gapFillFromSource calls, marshalled for the device */
+/* a batch of gapFillFromSource calls, marshalled for the device: two contiguous blocks (per-gap arrays; variable-length arrays) that
+ * go up in one copy each.  With an index they sit in its page-locked staging blocks, otherwise in `own_*`. */
+template <typename T> struct Arr {
+    T* p = nullptr;
+    size_t n = 0;
+    T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) const { return p[i]; }
+};
 struct FillInput {
     int k = 31;
     bool want_all_contigs = false;
-    std::vector<uint64_t> src;     /* oriented source k-mer per gap */
-    std::vector<uint64_t> rwords;  /* packed swf patterns, concatenated */
-    std::vector<uint32_t> roff;    /* first word of gap i's pattern */
-    std::vector<uint32_t> rlen;    /* pattern length in nt */
-    std::vector<uint64_t> r0;      /* first k-mer of the pattern */
-    std::vector<uint64_t> tle, tbad; /* targets of all gaps: little-endian k-mer, never-match mask */
-    std::vector<uint32_t> toff, tcnt;
-    std::vector<uint8_t> nbmis, fast_ok;
+    const mtg_index* idx = nullptr; /* whose staging blocks to use */
+    /* block A */
+    Arr<uint64_t> src;     /* oriented source k-mer per gap */
+    Arr<uint64_t> r0;      /* first k-mer of the pattern */
+    Arr<uint32_t> roff;    /* first word of gap i's pattern */
+    Arr<uint32_t> rlen;    /* pattern length in nt */
+    Arr<uint32_t> toff, tcnt;
+    Arr<uint8_t> nbmis, fast_ok;
+    /* block B */
+    Arr<uint64_t> rwords;  /* packed swf patterns, concatenated */
+    Arr<uint64_t> tle, tbad; /* targets of all gaps: little-endian k-mer, never-match mask */
+    void *block_a = nullptr, *block_b = nullptr;
+    size_t bytes_a = 0, bytes_b = 0;
+    std::vector<uint64_t> own_a, own_b;
     /* two-pass marshalling: size(i, ...) for every gap in order, then layout(), then set(i, ...) from any thread */
     void resize(size_t n);
     void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }
     void layout();
     void set(size_t i, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis);
+    /* byte offsets of the arrays inside their block (the device copy has the same layout) */
+    static size_t off_a(size_t n, int which) { static const size_t mul[8] = {0, 8, 16, 20, 24, 28, 32, 33}; return mul[which] * n8(n); }
+    static size_t n8(size_t n) { return (n + 7) & ~(size_t)7; }
 };
 
 /* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
@@ -262,9 +288,16 @@ struct SeqBuf {
     void view(const char* q, uint32_t len) { p = q; n = len; }
     bool operator==(const SeqBuf& o) const { return size() == o.size() && memcmp(data(), o.data(), size()) == 0; }
 };
-/* storage of the common-path sequences of one batch; must outlive the GapWork results that point into it */
+/* storage of the common-path sequences of one batch; must outlive the GapWork results that point into it.  Raw and uninitialised: every
+ * byte handed out is written by exactly one gap, and a recycled arena costs no page faults and no memset */
 struct FillArena {
-    std::vector<char> chars;
+    std::unique_ptr<char[]> buf;
+    size_t cap = 0;
+    char* ensure(size_t n)
+    {
+        if (cap < n) { buf.reset(); cap = n + n / 8 + 64; buf.reset(new char[cap]); }
+        return buf.get();
+    }
 };
 
 struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
@@ -275,15 +308,63 @@ struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
     int qual = 0, count = 0, rank = 0;
     size_t ab_off = 0, ab_n = 0; /* slice of the batched abundance query */
 };
+/* the solutions of one gap: nearly always zero or one, kept inline so that the common path never touches the heap */
+class SolVec {
+public:
+    SolVec() {}
+    SolVec(SolVec&& o) noexcept { take(o); }
+    SolVec& operator=(SolVec&& o) noexcept { if (this != &o) { clear(); more_.clear(); take(o); } return *this; }
+    SolVec(const SolVec&) = delete;
+    SolVec& operator=(const SolVec&) = delete;
+    size_t size() const { return more_.empty() ? (size_t)has_first_ : more_.size(); }
+    bool empty() const { return size() == 0; }
+    const Solution* begin() const { return more_.empty() ? &first_ : more_.data(); }
+    const Solution* end() const { return begin() + size(); }
+    Solution* begin() { return more_.empty() ? &first_ : more_.data(); }
+    Solution* end() { return begin() + size(); }
+    const Solution& operator[](size_t i) const { return begin()[i]; }
+    void clear() { if (has_first_) { first_ = Solution(); has_first_ = false; } more_.clear(); }
+    void push_back(Solution&& s)
+    {
+        if (!has_first_ && more_.empty()) { first_ = std::move(s); has_first_ = true; return; }
+        if (more_.empty()) { more_.reserve(4); more_.push_back(std::move(first_)); }
+        more_.push_back(std::move(s));
+    }
+    /* the inline slot, for writers that fill it in place */
+    Solution& emplace_first() { clear(); has_first_ = true; return first_; }
+
+private:
+    void take(SolVec& o) { first_ = std::move(o.first_); has_first_ = o.has_first_; more_ = std::move(o.more_); o.has_first_ = false; }
+    Solution first_;
+    bool has_first_ = false;
+    std::vector<Solution> more_; /* all solutions once there are two or more */
+};
+/* read-only view on a run of solutions (SolVec or std::vector) */
+struct SolSpan {
+    const Solution* p = nullptr;
+    size_t n = 0;
+    SolSpan(const SolVec& v) : p(v.begin()), n(v.size()) {}
+    SolSpan(const std::vector<Solution>& v) : p(v.data()), n(v.size()) {}
+    const Solution* begin() const { return p; }
+    const Solution* end() const { return p + n; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
 struct GapWork {
     TargetSpan targets; /* targetDictionary in iteration order (storage owned by the caller of fill_gaps) */
     std::string_view source;
     bool anchor_repeated = false, reverse = false;
     int nb_nodes = 0, total_nt = 0, nb_terminal = 0, nb_total_filled = 0;
     bool has_counts = false;
-    std::vector<Solution> sols;
+    SolVec sols;
     std::string extension;
-    void swap_into(GapWork& o) { std::swap(*this, o); } /* used to free o's storage on the calling thread */
+    /* back to the state of a fresh object, keeping the capacity of what it owns */
+    void reset()
+    {
+        targets = TargetSpan(); source = std::string_view(); anchor_repeated = reverse = has_counts = false;
+        nb_nodes = total_nt = nb_terminal = nb_total_filled = 0;
+        sols.clear(); extension.clear();
+    }
 };
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
 int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,

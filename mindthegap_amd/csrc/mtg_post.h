@@ -21,6 +21,28 @@ struct PostOut {
     uint32_t med_hi, med_lo;      /* sorted[n/2], sorted[n/2-1] */
 };
 
+/* what to copy back for a gap: nw leading words of its arena, metadata of nc contigs (0 or all) */
+MTG_DEV void copy_plan(const GapOut& o, const PostOut& p, bool want_all, uint32_t& nw, uint32_t& nc)
+{
+    nw = nc = 0;
+    if (o.status != GAP_OK) return;
+    if (want_all || (p.fast == 0 && p.nb_terminal > 0)) { nw = o.n_words; nc = o.n_contigs; }
+    else if (p.fast == 1) nw = (p.pos + 31) / 32;
+    else if (p.fast == 2) nw = 0;
+    else nw = (p.clen0 + 31) / 32; /* no terminal node: contig 0 is the extension sequence */
+}
+
+/* everything the host learns about one gap of a chunk, written by k_post: the counters of both kernels and where the gap's words /
+ * contig metadata sit in the chunk's dense arrays.  Metadata of a gap: 5 runs of nc entries at meta[5 * cbase] (length, first word,
+ * terminal position, errors, target index). */
+struct SlotRec {
+    GapOut o;
+    PostOut p;
+    uint32_t nw, nc;
+    uint32_t pad_;
+    uint64_t wbase, cbase;
+};
+
 struct PostTargets {
     const uint64_t* le;  /* target k-mers, little-endian packed (nt i at bits 2i), dictionary iteration order */
     const uint64_t* bad; /* bit 2i set: position i can never match (not ACGT) or the whole anchor is unusable */

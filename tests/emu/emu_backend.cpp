@@ -128,9 +128,13 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t, const uint64_t
     return MTG_OK;
 }
 
+/* the emulator keeps the marshalled input in the FillInput's own storage */
+void* staging_host(const mtg_index*, int, size_t) { return nullptr; }
+
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats)
 {
     const size_t n = in.src.size();
+    batch.n = n;
     batch.chunk_of.assign(n, 0);
     batch.slot_of.assign(n, 0);
     batch.chunks.clear();
@@ -161,16 +165,19 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             copy_plan(o, po, in.want_all_contigs, nw, nc);
             batch.chunks.emplace_back(new HostChunk());
             HostChunk& hc = *batch.chunks.back();
-            hc.out.assign(1, o); hc.post.assign(1, po); hc.nw.assign(1, nw); hc.nc.assign(1, nc); hc.wbase.assign(1, 0); hc.cbase.assign(1, 0);
-            hc.words.assign(s_words(cfg, S), s_words(cfg, S) + nw);
-            hc.words.push_back(0);
-            hc.tc = nc;
-            if (nc) {
-                hc.meta.insert(hc.meta.end(), s_clen(cfg, S), s_clen(cfg, S) + nc);
-                hc.meta.insert(hc.meta.end(), s_cstart(cfg, S), s_cstart(cfg, S) + nc);
-                hc.meta.insert(hc.meta.end(), s_tpos(cfg, S), s_tpos(cfg, S) + nc);
-                hc.meta.insert(hc.meta.end(), s_terr(cfg, S), s_terr(cfg, S) + nc);
-                hc.meta.insert(hc.meta.end(), s_ttgt(cfg, S), s_ttgt(cfg, S) + nc);
+            SlotRec* rec = nullptr;
+            uint64_t* hw = nullptr;
+            uint32_t* hm = nullptr;
+            hc.carve(nullptr, 1, nw, nc, rec, hw, hm);
+            rec->o = o; rec->p = po; rec->nw = nw; rec->nc = nc; rec->pad_ = 0; rec->wbase = 0; rec->cbase = 0;
+            for (uint32_t i = 0; i < nw; i++) hw[i] = s_words(cfg, S)[i];
+            hw[nw] = 0;
+            for (uint32_t i = 0; i < nc; i++) {
+                hm[i] = s_clen(cfg, S)[i];
+                hm[nc + i] = s_cstart(cfg, S)[i];
+                hm[2 * nc + i] = s_tpos(cfg, S)[i];
+                hm[3 * nc + i] = s_terr(cfg, S)[i];
+                hm[4 * nc + i] = s_ttgt(cfg, S)[i];
             }
             batch.chunk_of[g] = (uint32_t)batch.chunks.size() - 1;
             batch.slot_of[g] = 0;
