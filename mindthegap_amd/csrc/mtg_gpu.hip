@@ -586,10 +586,13 @@ struct WsBuf {
     void* p = nullptr;
     mtgi::Workspace* ws = nullptr;
     int slot = -1;
+    bool fresh = false; /* the last alloc() had to get new memory (contents undefined) */
     hipError_t alloc(size_t bytes)
     {
         bytes = bytes ? bytes : 8;
+        fresh = false;
         if (ws->cap[slot] < bytes) {
+            fresh = true;
             if (ws->ptr[slot]) (void)hipFree(ws->ptr[slot]);
             ws->ptr[slot] = nullptr;
             ws->cap[slot] = 0;
@@ -691,6 +694,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         if (chunk > (1u << 20)) chunk = 1u << 20;
         if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }
         HIP_TRY(d_zero.alloc(chunk * cfg.zero_stride));
+        /* zeroed once: every gap restores what it touched (stage_a_gap), so the region stays clean from launch to launch */
+        if (d_zero.fresh) HIP_TRY(hipMemsetAsync(d_zero.p, 0, idx->ws.cap[d_zero.slot], 0));
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
         HIP_TRY(d_ilv.alloc(((chunk + 63) / 64) * cfg.ilv_stride));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
@@ -717,7 +722,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 ids = d_ids.as<uint32_t>();
                 st.h2d_ms += now_ms() - t0;
             }
-            HIP_TRY(hipMemsetAsync(d_zero.p, 0, (size_t)m * cfg.zero_stride, 0));
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 64, 0));
             HIP_TRY(hipEventRecord(ev0, 0));
             hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,

@@ -357,6 +357,16 @@ static float nw_identity(const std::string& a, const std::string& b)
     return identity;
 }
 
+static int compute_qual(const Solution& s, bool repeated) /* src/Utils.hpp:85-103 */
+{
+    int q = 50;
+    if (repeated) q = 25;
+    if (s.count > 1) q = 15;
+    if (s.nb_errors == 1) q = 10;
+    if (s.nb_errors == 2) q = 5;
+    return q;
+}
+
 /* ASCII of the packed nucleotides [from, from + L) of `words` (2 bits each, nucleotide i at bits 2(i mod 32) of word i / 32), four per
  * table lookup; reversed and complemented when rc is set.  Reads at most one word past the last one used (the chunk storage is padded). */
 struct DecodeLut {
@@ -391,7 +401,7 @@ static void decode_slice(const uint64_t* words, uint32_t from, uint32_t L, bool 
 }
 
 /* everything after the device kernels for one gapFillFromSource call, except the coverage numbers of the general path */
-static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
+static bool process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
 {
     W.nb_nodes = (int)gc.o.n_contigs;
     W.total_nt = (int)gc.o.total_nt;
@@ -399,9 +409,9 @@ static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
     if (gc.p.nb_terminal == 0) { /* get_first_contig, src/Filler.cpp:1381-1407 */
         W.extension.clear();
         if (gc.o.n_contigs > 0 && (int)gc.p.clen0 > k) W.extension = gc.contig0_slice((uint32_t)k, gc.p.clen0);
-        return;
+        return false;
     }
-    if (gc.p.fast == 2) { W.has_counts = W.reverse; return; } /* target at the very start of contig 0: empty fill */
+    if (gc.p.fast == 2) { W.has_counts = W.reverse; return false; } /* target at the very start of contig 0: empty fill */
     if (gc.p.fast == 1) {
         /* terminal node 0: find_all_paths_rev returns the single path [0] (src/GraphAnalysis.cpp:222-226) and
          * paths_to_sequences keeps contig0[k:pos] (:386-423); coverage was computed on the device */
@@ -419,10 +429,10 @@ static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
         s.avg = sum / (float)gc.p.ab_n;
         s.median = (float)((gc.p.ab_n % 2 == 1) ? (double)gc.p.med_hi : 0.5 * (gc.p.med_hi + gc.p.med_lo));
         s.ab_n = 0; /* no host-side coverage query needed */
-        s.qual = -1;
+        s.qual = compute_qual(s, W.anchor_repeated);
         W.nb_total_filled = 1;
         W.has_counts = true;
-        return;
+        return false;
     }
     std::vector<TermInfo> terms;
     for (uint32_t c = 0; c < gc.o.n_contigs; c++)
@@ -497,6 +507,7 @@ static void process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
         for (auto& s : tmp) { s.count = (int)tmp.size(); s.rank = rank++; s.ab_n = 1; W.sols.push_back(std::move(s)); }
     }
     W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
+    return !W.sols.empty();
 }
 
 static std::string revcomp_str(const std::string& s) /* revcomp_sequence, src/Utils.cpp:44-77: other characters are dropped */
@@ -522,15 +533,6 @@ static double median_of(std::vector<unsigned int>& v) /* src/Utils.cpp:241-254 *
     return 0.5 * (vn + v[n - 1]);
 }
 
-static int compute_qual(const Solution& s, bool repeated) /* src/Utils.hpp:85-103 */
-{
-    int q = 50;
-    if (repeated) q = 25;
-    if (s.count > 1) q = 15;
-    if (s.nb_errors == 1) q = 10;
-    if (s.nb_errors == 2) q = 5;
-    return q;
-}
 
 /* runs a batch of gapFillFromSource calls */
 int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,
@@ -565,16 +567,19 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
     if (rc) return rc;
     if (dbg) fprintf(stderr, "  [fill_gaps] pre %.2f device_run %.2f ms\n", tdev - t_begin, now_ms() - tdev);
     double t0 = now_ms();
-    std::vector<uint64_t> aoff(n + 1, 0);
-    for (size_t i = 0; i < n; i++) { const PostOut& po = dev.rec(i).p; aoff[i + 1] = aoff[i] + (po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0); }
+    std::vector<uint64_t> aoff(n + 1);
+    parallel_prefix(n, p->nb_host_threads, aoff.data(), [&](size_t i) { const PostOut& po = dev.rec(i).p; return po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0; });
     char* const arena_base = arena.ensure(aoff[n] + 1);
-    parallel_for(n, p->nb_host_threads, [&](size_t i) { process_gap(dev[i], gaps[i], k, arena_base + aoff[i]); });
+    std::vector<uint8_t> general(n, 0); /* gaps whose solutions came out of the host's path enumeration: coverage still to do */
+    parallel_for(n, p->nb_host_threads, [&](size_t i) { general[i] = process_gap(dev[i], gaps[i], k, arena_base + aoff[i]) ? 1 : 0; });
+    std::vector<size_t> gen_idx;
+    for (size_t i = 0; i < n; i++) if (general[i]) gen_idx.push_back(i);
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);
-    for (auto& g : gaps)
+    for (size_t gi : gen_idx) {
+        GapWork& g = gaps[gi];
         for (auto& s : g.sols) {
-            if (s.ab_n == 0) continue; /* computed on the device */
             s.ab_off = q.size();
             uint64_t f = 0;
             int valid = 0;
@@ -589,8 +594,8 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
             feed(g.source.data(), g.source.size());
             feed(s.seq.data(), s.seq.size());
             s.ab_n = q.size() - s.ab_off;
-            s.qual = -2;
         }
+    }
     st.host_ms += now_ms() - t0;
     std::vector<uint32_t> ab(q.size());
     if (!q.empty()) {
@@ -598,29 +603,27 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
         if (rc) return rc;
     }
     t0 = now_ms();
-    parallel_for(n, p->nb_host_threads, [&](size_t i) {
-        GapWork& g = gaps[i];
+    parallel_for(gen_idx.size(), p->nb_host_threads, [&](size_t ii) {
+        GapWork& g = gaps[gen_idx[ii]];
         for (auto& s : g.sols) {
-            if (s.qual == -2) {
-                std::vector<unsigned int> v(ab.begin() + s.ab_off, ab.begin() + s.ab_off + s.ab_n);
-                uint64_t sum = 0;
-                for (size_t j = 0; j < v.size(); j++) {
-                    if (v[j] == 0) {
-                        uint64_t c = q[s.ab_off + j], r = revcomp(c, k);
-                        c = c < r ? c : r;
-                        std::string d(k, 'A');
-                        for (int t = 0; t < k; t++) d[t] = "ACTG"[(c >> (2 * (k - 1 - t))) & 3];
-                        fprintf(stderr, "WARNING Unknown kmer : %s\n", d.c_str());
-                    }
-                    sum += v[j];
+            std::vector<unsigned int> v(ab.begin() + s.ab_off, ab.begin() + s.ab_off + s.ab_n);
+            uint64_t sum = 0;
+            for (size_t j = 0; j < v.size(); j++) {
+                if (v[j] == 0) {
+                    uint64_t c = q[s.ab_off + j], r = revcomp(c, k);
+                    c = c < r ? c : r;
+                    std::string d(k, 'A');
+                    for (int t = 0; t < k; t++) d[t] = "ACTG"[(c >> (2 * (k - 1 - t))) & 3];
+                    fprintf(stderr, "WARNING Unknown kmer : %s\n", d.c_str());
                 }
-                s.avg = sum / (float)v.size();
-                s.median = v.empty() ? 0.f : (float)median_of(v);
+                sum += v[j];
             }
+            s.avg = sum / (float)v.size();
+            s.median = v.empty() ? 0.f : (float)median_of(v);
             s.qual = compute_qual(s, g.anchor_repeated);
             if (g.reverse && !s.seq.is_view()) s.seq = revcomp_str(s.seq.str()); /* views were written reverse-complemented */
         }
-    });
+    }, 1);
     st.host_ms += now_ms() - t0;
     if (dbg) fprintf(stderr, "  [fill_gaps] post-device %.2f ms\n", now_ms() - t0);
     st.total_ms = now_ms() - t_begin;
@@ -692,18 +695,19 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
 {
     if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     const double t_m0 = mtgi::now_ms();
-    for (size_t i = 0; i < n; i++) {
-        const mtg_gap& g = gaps[i];
-        if (!g.source || !g.target || (g.n_targets && (!g.target_seqs || !g.target_names))) { mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
-    }
     mtg_results* R = results_acquire();
     R->gaps.resize(n);
     std::vector<std::string_view>& swf = R->swf;
     swf.resize(n);
     std::vector<uint64_t>& toff = R->toff;
     toff.resize(n + 1);
-    toff[0] = 0;
-    for (size_t i = 0; i < n; i++) toff[i + 1] = toff[i] + (uint64_t)std::max(gaps[i].n_targets, 0);
+    std::atomic<long> bad{-1};
+    mtgi::parallel_prefix(n, p->nb_host_threads, toff.data(), [&](size_t i) {
+        const mtg_gap& g = gaps[i];
+        if (!g.source || !g.target || (g.n_targets > 0 && (!g.target_seqs || !g.target_names))) bad = (long)i;
+        return (uint64_t)std::max(g.n_targets, 0);
+    });
+    if (bad >= 0) { results_release(R); mtgi::set_error("gap %ld: null field", bad.load()); return MTG_ERR_ARG; }
     R->targets.resize(toff[n]);
     mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
         const mtg_gap& g = gaps[i];
@@ -730,8 +734,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     const double t_m2 = mtgi::now_ms();
     R->res.resize(n);
     R->filled_off.resize(n + 1);
-    R->filled_off[0] = 0;
-    for (size_t i = 0; i < n; i++) R->filled_off[i + 1] = R->filled_off[i] + R->gaps[i].sols.size();
+    mtgi::parallel_prefix(n, p->nb_host_threads, R->filled_off.data(), [&](size_t i) { return (uint64_t)R->gaps[i].sols.size(); });
     R->filled_flat.resize(R->filled_off[n]);
     mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
         mtgi::GapWork& w = R->gaps[i];

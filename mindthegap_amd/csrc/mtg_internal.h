@@ -128,6 +128,25 @@ template <typename F> inline void parallel_for(size_t n, int nthreads, F f, size
     Pool::get().run(nthreads, work);
 }
 
+/* out[0] = 0, out[i + 1] = out[i] + get(i), blocked over the pool; returns the total */
+template <typename G> inline uint64_t parallel_prefix(size_t n, int nthreads, uint64_t* out, G get)
+{
+    const size_t B = 4096, nb = (n + B - 1) / B;
+    std::vector<uint64_t> bs(nb + 1, 0);
+    out[0] = 0;
+    parallel_for(nb, nthreads, [&](size_t b) {
+        uint64_t sum = 0;
+        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) { const uint64_t v = get(i); out[i + 1] = v; sum += v; }
+        bs[b + 1] = sum;
+    }, 1);
+    for (size_t b = 0; b < nb; b++) bs[b + 1] += bs[b];
+    parallel_for(nb, nthreads, [&](size_t b) {
+        uint64_t run = bs[b];
+        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) { run += out[i + 1]; out[i + 1] = run; }
+    }, 1);
+    return bs[nb];
+}
+
 /* one gapFillFromSource call and its results (host side) */
 /* strings of a batch are VIEWS on the caller's storage, which must stay alive until the results have been consumed */
 struct Target {

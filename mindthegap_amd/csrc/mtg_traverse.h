@@ -47,7 +47,7 @@ struct FillCfg {
     uint64_t ilv_stride;  /* bytes per WAVE (64 gaps) in the lane-interleaved region */
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
-    uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_dfsf, o_dfsc,
+    uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_dfsf, o_dfsc,
         o_dfsmask, o_dfsnt, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt;
 };
 
@@ -55,7 +55,7 @@ enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
 
 /* per-gap scratch: two base pointers; the arrays sit at uniform offsets (FillCfg::o_*) */
 struct GapScratch {
-    uint8_t* z; /* zero-initialised before the launch: marked | seen | iseen (canonical k-mer + 1, open addressing) */
+    uint8_t* z; /* all zero before the launch and restored to zero by the gap itself: marked | seen | iseen (canonical k-mer + 1, open addressing) */
     uint8_t* r; /* raw, contiguous per gap: contigs, queue, terminal info (read by k_post / k_compact / the host) */
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
@@ -80,6 +80,7 @@ MTG_ARR(uint32_t, s_clen, r, c.o_clen)       /* length in nt */
 MTG_ARR(uint64_t, s_qf, r, c.o_qf)           /* BFS queue: oriented k-mer */
 MTG_ARR(uint64_t, s_qc, r, c.o_qc)           /*   canonical k-mer (doubles as already_extended_from) */
 MTG_ARR(int32_t, s_qd, r, c.o_qd)
+MTG_ILV(uint32_t, s_marklog, c.o_marklog) /* slots used in marked[] */
 MTG_ILV(uint32_t, s_seenlog, c.o_seenlog) /* slots touched in seen[] */
 MTG_ILV(uint32_t, s_iseenlog, c.o_iseenlog)
 MTG_ILV(uint64_t, s_inv, c.o_inv)
@@ -122,6 +123,7 @@ inline void finalize_cfg(FillCfg& c)
     c.raw_stride = align_up(b + 8, 64);
     /* interleaved per wave: byte offsets within one lane's share (every array starts 8-byte aligned) */
     b = 0;
+    c.o_marklog = (uint32_t)b; b += align_up(4ull * c.mcap, 8);
     c.o_seenlog = (uint32_t)b; b += align_up(4ull * c.seen_cap, 8);
     c.o_iseenlog = (uint32_t)b; b += align_up(4ull * c.iseen_cap, 8);
     c.o_inv = (uint32_t)b; b += 8ull * c.inv_cap;
@@ -215,11 +217,15 @@ struct Worker {
     MTG_DEV static uint32_t sig_bit(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 56); }
     MTG_DEV void mark_canon(uint64_t c)
     {
-        if (set_add(s_marked(cfg, S), cfg.mcap, n_marked, c) == -2) status = GAP_OVF_MARKED;
+        const int slot = set_add(s_marked(cfg, S), cfg.mcap, n_marked, c);
+        if (slot == -2) status = GAP_OVF_MARKED;
+        if (slot >= 0) s_marklog(cfg, S)[n_marked - 1] = (uint32_t)slot;
         const uint32_t b = sig_bit(c);
         const uint64_t m = 1ull << (b & 63);
         if ((b >> 6) == 0) msig0 |= m; else if ((b >> 6) == 1) msig1 |= m; else if ((b >> 6) == 2) msig2 |= m; else msig3 |= m;
     }
+    /* the three sets live in memory that is zero before a launch and must be zero again after it (nobody clears it in between) */
+    MTG_DEV void marked_clear() { for (uint32_t i = 0; i < n_marked; i++) s_marked(cfg, S)[s_marklog(cfg, S)[i]] = 0; n_marked = 0; }
     MTG_DEV bool is_marked(uint64_t c) const
     {
         const uint32_t b = sig_bit(c);
@@ -822,6 +828,10 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i], W.stamp_acc[i]);
     atomicAdd(&g_stamps[8], 1ull);
 #endif
+    /* leave the zero-initialised region as it was found, whatever the exit path */
+    W.seen_clear();
+    W.iseen_clear();
+    W.marked_clear();
     out.n_contigs = nb;
     out.status = W.status;
     out.lines = W.lines + lines;

@@ -80,6 +80,9 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
         pat.rlen = (uint32_t)rl;
         pat.r0 = rl >= (size_t)k ? encode_kmer(R, k) : 0;
         stage_a_gap(e->ix, cfg, S, encode_kmer(source, k), pat, out);
+        /* the device relies on every gap handing the zero region back clean: make a violation visible as a status no test expects */
+        for (uint8_t z : zero) if (z) { out.status = 0xDEAD; break; }
+        if (out.status == 0xDEAD) break;
         if (tier_used) *tier_used = (uint32_t)t;
         if (out.status == GAP_OK) {
             joined.clear();

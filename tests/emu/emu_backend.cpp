@@ -150,6 +150,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             R.rlen = in.rlen[g];
             R.r0 = in.r0[g];
             stage_a_gap(idx->dev, cfg, S, in.src[g], R, o);
+            /* the device never clears the zero region between launches: every exit path has to hand it back clean */
+            for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, o.status); return MTG_ERR_OVERFLOW; }
             st.index_lines += o.lines;
             if (o.status != GAP_OK) { st.n_retried_gaps++; continue; }
             PostTargets T;
