@@ -73,6 +73,23 @@ MTG_DEV Kmer kmer_next(const Kmer& x, uint32_t nt, int k, uint64_t mk)
     y.r = (x.r >> 2) | ((uint64_t)(nt ^ 2u) << (2 * (k - 1)));
     return y;
 }
+/* the 16 two-bit fields of x in reverse order */
+MTG_DEV uint32_t rev_fields32(uint32_t x)
+{
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+/* x followed by cnt nucleotides at once (0 <= cnt <= 15, cnt <= k): `seq` holds them first-at-the-bottom (nt i at bits 2i), zero above */
+MTG_DEV Kmer kmer_advance(const Kmer& x, uint32_t seq, uint32_t cnt, int k, uint64_t mk)
+{
+    Kmer y;
+    const uint32_t fwd = cnt ? rev_fields32(seq) >> (32 - 2 * cnt) : 0u; /* first nucleotide most significant */
+    const uint32_t cmp = seq ^ (0xAAAAAAAAu & ((1u << (2 * cnt)) - 1u));
+    y.f = ((x.f << (2 * cnt)) | (uint64_t)fwd) & mk;
+    y.r = (x.r >> (2 * cnt)) | ((uint64_t)cmp << (2 * ((uint32_t)k - cnt)));
+    return y;
+}
 MTG_DEV Kmer kmer_prev(const Kmer& x, uint32_t nt, int k, uint64_t mk)
 {
     Kmer y;

@@ -717,6 +717,14 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     bool found_R = false;
     Adj a;
     a.out = a.in = a.la = 0;
+    /* bulk steps of phase W: low halves of the k-mers to watch for, and the deferred "previous node" */
+    const bool bulk_ok = k >= 16; /* a step never covers more than MTG_LA_MAX + 1 <= k nucleotides, and 32 bits are a suffix of the k-mer */
+    const uint32_t r0_lo = (uint32_t)R.r0;
+    uint32_t start_lo = 0, start_rc_lo = 0;
+    bool watch_r = false, lazy_prev = false;
+    Kmer pv;
+    pv.f = pv.r = 0;
+    uint32_t pv_seq = 0, pv_cnt = 0;
     for (;;) {
         if (!in_contig) {
             if (!(head < tail) || W.status != GAP_OK) break;
@@ -731,6 +739,9 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             prev_c = 0; /* gatb: default-constructed previousNode has k-mer value 0 */
             len = 0;
             found_R = (r_is_kmer && cur.f == R.r0);
+            start_lo = (uint32_t)cur.f;
+            start_rc_lo = (uint32_t)cur.r;
+            watch_r = r_is_kmer && node_depth > k; /* found_R only matters there (see phase E) */
             a = adj_right_t(adj, cur, mk1, lines);
             in_contig = true;
         }
@@ -747,26 +758,62 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             uint32_t la = (indeg == 1) ? a.la : 0u;
             uint32_t known = la & 15u;              /* nodes ahead known to be simple */
             la >>= 4;
-            for (;;) {
-                prev_c = canon(cur);
-                cur = kmer_next(cur, nt, k, mk);
-                push_nt(nt);
-                len++;
-                if (r_is_kmer && cur.f == R.r0) found_R = true;
-                if (known == 0) break;              /* this node's neighbourhood has to be read */
-                /* known simple node: terminator.mark() is a no-op on it */
-                if (canon(cur) == start_c || len > MAXLEN || ovf) { end_contig = true; break; }
-                nt = la & 3u;
-                la >>= 2;
-                known--;
-                indeg = 1;
+            /* The step covers j = known + 1 nucleotides.  Per nucleotide the reference only (a) compares the node with the start node
+             * (looping contig) and (b), below the first BFS level, with the first k-mer of R.  Both are evaluated for all j nodes on the
+             * low 32 bits of the forward k-mers; unless one of them may hit, or a limit is near, the step is then taken in one go. */
+            const uint32_t j = known + 1;
+            const uint32_t seq = nt | (la << 2);
+            bool bulk = bulk_ok && len + j <= MAXLEN;
+            if (bulk) {
+                uint32_t x = (uint32_t)cur.f, s = seq, hit = 0;
+                MTG_UNROLL
+                for (uint32_t i = 1; i <= MTG_LA_MAX + 1; i++) {
+                    x = (x << 2) | (s & 3u);
+                    s >>= 2;
+                    const bool at_start = (x == start_lo) | (x == start_rc_lo);
+                    const bool at_r = (x == r0_lo);
+                    hit |= ((at_start & (i < j)) | (at_r & (i <= j) & watch_r)) ? 1u : 0u;
+                }
+                bulk = hit == 0;
             }
-            if (end_contig) break;
+            if (bulk) {
+                lazy_prev = true;
+                pv = cur; pv_seq = seq; pv_cnt = known;
+                cur = kmer_advance(cur, seq, j, k, mk);
+                acc |= (uint64_t)seq << (2 * nacc);
+                nacc += j;
+                if (nacc >= 32) {
+                    if (wpos >= cfg.cap_words) ovf = true; else words[wpos] = acc;
+                    wpos++;
+                    nacc -= 32;
+                    acc = (uint64_t)(seq >> (2 * (j - nacc))); /* the nacc nucleotides that did not fit */
+                }
+                len += j;
+                if (known) indeg = 1;
+            } else {
+                lazy_prev = false;
+                for (;;) {
+                    prev_c = canon(cur);
+                    cur = kmer_next(cur, nt, k, mk);
+                    push_nt(nt);
+                    len++;
+                    if (r_is_kmer && cur.f == R.r0) found_R = true;
+                    if (known == 0) break;              /* this node's neighbourhood has to be read */
+                    /* known simple node: terminator.mark() is a no-op on it */
+                    if (canon(cur) == start_c || len > MAXLEN || ovf) { end_contig = true; break; }
+                    nt = la & 3u;
+                    la >>= 2;
+                    known--;
+                    indeg = 1;
+                }
+                if (end_contig) break;
+            }
             const Adj a2 = adj_right_t(adj, cur, mk1, lines);
             if (!(popc4(a2.out) == 1 && indeg == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
             a = a2;
             if (canon(cur) == start_c || len > MAXLEN || ovf || W.status) { end_contig = true; break; } /* looping / limits */
         }
+        if (lazy_prev) { prev_c = canon(kmer_advance(pv, pv_seq & ((1u << (2 * pv_cnt)) - 1u), pv_cnt, k, mk)); lazy_prev = false; }
         MTG_T1(t_w, 0);
         MTG_T0(t_b);
         /* ---- phase B: branching node ---- */

@@ -57,6 +57,34 @@ def _make_case(seed, k):
     return rng, g, seqs
 
 
+@pytest.mark.parametrize("k", [31, 21, 16, 13])
+def test_looping_contigs_and_target_inside_lookahead_runs(k):
+    """circular simple paths: the walk comes back to its start node in the middle of a multi-nucleotide step; and, below the first BFS
+    level, the first k-mer of the target is met in the middle of one (both are what the bulk step of phase W has to notice)"""
+    rng = random.Random(1234 + k)
+    for case in range(12):
+        L = rng.randrange(k + 5, 400)
+        c = _rand_seq(rng, L)
+        seqs = [c + c[:k - 1]]  # every cyclic k-mer, nothing else: one simple cycle
+        if case % 3 == 2:       # a branch off the cycle, so that contigs start below the first BFS level too
+            p = rng.randrange(0, L - k)
+            seqs.append(c[p:p + k - 1] + _rand_seq(rng, 1) + _rand_seq(rng, 200) + c[:k] + c[k:k + 60])
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k, load_factor=0.5)
+        cc = c + c
+        for _ in range(10):
+            p = rng.randrange(0, L)
+            s = cc[p:p + k] if rng.random() < 0.7 else _rc(cc[p:p + k])
+            tp = rng.randrange(0, L)
+            t = cc[tp:tp + k]
+            for er in (0, 1):
+                oc, _ = idx.stage_a(s, t, oracle_lib.default_params(end_rule_nonbranching=er))
+                ec, st, _, _ = emu.stage_a(s, t, 100, 10000, er)
+                assert st == 0 and ec == oc, (case, k, s, t, er)
+        idx.close()
+
+
 @pytest.mark.parametrize("k", [31, 21, 13])
 def test_stage_a_fuzz_against_oracle(k):
     """bubbles, tips, repeats, loops, cut-offs (max_nodes / max_depth), both end rules, several table load factors"""
