@@ -631,8 +631,9 @@ void* staging_host(const mtg_index* idx, int slot, size_t bytes)
 }
 
 /* The caller holds idx->ws.mtx (the workspace and the staging blocks belong to one batch at a time). */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* overlap)
 {
+    bool overlap_done = false;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
     double tk = now_ms();
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
@@ -643,7 +644,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     batch.slot_of.clear();
     batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
-    if (n == 0) { if (stats) *stats = st; return MTG_OK; }
+    if (n == 0) { if (overlap) (*overlap)(); if (stats) *stats = st; return MTG_OK; }
     const int k = idx->dev.k;
 
     int ws_next = 0;
@@ -732,6 +733,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             HIP_TRY(hipEventRecord(ev2, 0));
             HIP_TRY(hipGetLastError());
             tick("host prep+launch");
+            if (overlap && !overlap_done) { overlap_done = true; (*overlap)(); tick("overlapped host work"); } /* the device is busy: the caller's turn */
             unsigned long long totals[2] = {0, 0};
             HIP_TRY(hipMemcpy(totals, d_cnt.p, 16, hipMemcpyDeviceToHost)); /* waits for the kernels */
             tick("kernels");
@@ -756,15 +758,22 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             st.d2h_ms += now_ms() - t0;
             tick("d2h");
             t0 = now_ms();
-            uint64_t nt_sum = 0, lines = 0;
-            bool any_retry = false;
-            for (uint32_t s2 = 0; s2 < m; s2++) {
-                lines += h_rec[s2].o.lines;
-                if (h_rec[s2].o.status != GAP_OK) { any_retry = true; continue; }
-                nt_sum += h_rec[s2].o.total_nt;
-            }
-            st.index_lines += lines;
-            st.contig_nt += nt_sum;
+            std::atomic<uint64_t> nt_sum{0}, lines{0};
+            std::atomic<bool> any_retry_a{false};
+            parallel_for(((size_t)m + 4095) / 4096, p->nb_host_threads, [&](size_t b) {
+                uint64_t l = 0, t = 0;
+                bool r = false;
+                for (uint32_t s2 = (uint32_t)(b * 4096); s2 < std::min<uint64_t>(m, (b + 1) * 4096); s2++) {
+                    l += h_rec[s2].o.lines;
+                    if (h_rec[s2].o.status != GAP_OK) { r = true; continue; }
+                    t += h_rec[s2].o.total_nt;
+                }
+                lines += l; nt_sum += t;
+                if (r) any_retry_a = true;
+            }, 1);
+            const bool any_retry = any_retry_a.load();
+            st.index_lines += lines.load();
+            st.contig_nt += nt_sum.load();
             if (!identity || any_retry) {
                 /* results are scattered over chunks from here on: keep an explicit map */
                 if (batch.chunk_of.empty()) { batch.chunk_of.assign(n, 0); batch.slot_of.resize(n); for (size_t i = 0; i < n; i++) batch.slot_of[i] = (uint32_t)i; }
@@ -795,6 +804,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
     }
 #endif
+    if (overlap && !overlap_done) (*overlap)();
     if (rc == MTG_OK && n_todo) {
         set_error("%zu gap(s) exceeded the largest traversal scratch tier", n_todo);
         rc = MTG_ERR_OVERFLOW;

@@ -223,13 +223,8 @@ void FillInput::resize(size_t n)
     nbmis.p = b + off_a(n, 6); fast_ok.p = b + off_a(n, 7);
     src.n = r0.n = roff.n = rlen.n = toff.n = tcnt.n = nbmis.n = fast_ok.n = n;
 }
-void FillInput::layout()
+void FillInput::alloc_b(uint64_t rw, uint64_t nt)
 {
-    uint64_t rw = 0, nt = 0;
-    for (size_t i = 0; i < src.size(); i++) {
-        roff[i] = (uint32_t)rw; rw += (rlen[i] + 31) / 32 + 1;
-        toff[i] = (uint32_t)nt; nt += tcnt[i];
-    }
     bytes_b = 8 * (rw + 2 * nt) + 64;
     block_b = idx ? staging_host(idx, 1, bytes_b) : nullptr;
     if (!block_b) { own_b.resize(bytes_b / 8 + 1); block_b = own_b.data(); }
@@ -237,7 +232,16 @@ void FillInput::layout()
     tle.p = rwords.p + rw; tle.n = nt;
     tbad.p = tle.p + nt; tbad.n = nt;
 }
-void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis)
+void FillInput::layout()
+{
+    uint64_t rw = 0, nt = 0;
+    for (size_t i = 0; i < src.size(); i++) {
+        roff[i] = (uint32_t)rw; rw += (rlen[i] + 31) / 32 + 1;
+        toff[i] = (uint32_t)nt; nt += tcnt[i];
+    }
+    alloc_b(rw, nt);
+}
+void FillInput::set_common(size_t g, std::string_view source, std::string_view swf_target, int nb_mis)
 {
     src[g] = encode_kmer(source.data(), k);
     const size_t rl = swf_target.size(), w0 = roff[g];
@@ -249,28 +253,38 @@ void FillInput::set(size_t g, std::string_view source, std::string_view swf_targ
         const char c = swf_target[i];
         if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { rlen[g] = 0xFFFFFFFFu; r0[g] = 0; break; }
     }
-    if (targets) {
-        size_t o = toff[g];
-        for (const Target& t : *targets) {
-            /* identNT (src/Utils.cpp:81-84) is case-insensitive equality: compare 2-bit codes and force a mismatch where the anchor
-             * character is not a nucleotide; an anchor shorter than k can never be matched */
-            uint64_t le = 0, bad = 0;
-            if ((int)t.seq.size() < k) bad = ~0ull;
-            else
-                for (int i = 0; i < k; i++) {
-                    const unsigned char c = (unsigned char)t.seq[i], u = c & 0xDF;
-                    le |= (uint64_t)nt_code(c) << (2 * i);
-                    if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad |= 1ull << (2 * i);
-                }
-            tle[o] = le;
-            tbad[o] = bad & (0x5555555555555555ULL & kmask(k));
-            o++;
-        }
-    }
     nbmis[g] = (uint8_t)nb_mis;
     bool ok = (int)source.size() == k;
     for (unsigned char c : source) ok = ok && !nt_bad(c);
     fast_ok[g] = ok ? 1 : 0;
+}
+void FillInput::set_target(size_t o, std::string_view seq)
+{
+    /* identNT (src/Utils.cpp:81-84) is case-insensitive equality: compare 2-bit codes and force a mismatch where the anchor
+     * character is not a nucleotide; an anchor shorter than k can never be matched */
+    uint64_t le = 0, bad = 0;
+    if ((int)seq.size() < k) bad = ~0ull;
+    else
+        for (int i = 0; i < k; i++) {
+            const unsigned char c = (unsigned char)seq[i], u = c & 0xDF;
+            le |= (uint64_t)nt_code(c) << (2 * i);
+            if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad |= 1ull << (2 * i);
+        }
+    tle[o] = le;
+    tbad[o] = bad & (0x5555555555555555ULL & kmask(k));
+}
+void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis)
+{
+    set_common(g, source, swf_target, nb_mis);
+    if (targets) {
+        size_t o = toff[g];
+        for (const Target& t : *targets) set_target(o++, t.seq);
+    }
+}
+void FillInput::set_raw(size_t g, std::string_view source, std::string_view swf_target, size_t n_targets, const char* const* target_seqs, int nb_mis)
+{
+    set_common(g, source, swf_target, nb_mis);
+    for (size_t t = 0; t < n_targets; t++) set_target(toff[g] + t, std::string_view(target_seqs[t]));
 }
 
 struct ContigGraph {
@@ -534,44 +548,93 @@ static double median_of(std::vector<unsigned int>& v) /* src/Utils.cpp:241-254 *
 }
 
 
-/* runs a batch of gapFillFromSource calls */
+/* a batch whose GapWork records already exist (the CLI drivers) */
+struct VecSource : BatchSource {
+    std::vector<GapWork>& g;
+    const std::vector<std::string_view>& swf;
+    VecSource(std::vector<GapWork>& g_, const std::vector<std::string_view>& s_) : g(g_), swf(s_) {}
+    size_t count() const override { return g.size(); }
+    bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const override
+    {
+        src_len = g[i].source.size(); swf_len = swf[i].size(); n_targets = g[i].targets.size();
+        return true;
+    }
+    void input(size_t i, FillInput& in, int nb_mis_allowed) const override
+    {
+        in.set(i, g[i].source, swf[i], &g[i].targets, g[i].anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
+    }
+    void marshal(const FillInput&, int) override {}
+    std::vector<GapWork>& gaps() override { return g; }
+};
 int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,
               mtg_batch_stats* stats_out)
 {
+    VecSource src(gaps, swf_targets);
+    return fill_gaps(idx, p, src, arena, stats_out, nullptr);
+}
+
+/* runs a batch of gapFillFromSource calls */
+int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillArena& arena, mtg_batch_stats* stats_out, std::vector<uint64_t>* sol_blocks)
+{
     const int k = idx->dev.k;
-    const size_t n = gaps.size();
+    const size_t n = src.count();
+    const int nth = p->nb_host_threads;
     const double t_begin = now_ms();
+    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    double tk = t_begin;
+    auto tick = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "  [fill_gaps] %-22s %.2f ms\n", what, t - tk); tk = t; } };
     /* the staging blocks of the index hold this batch from here until its results have been taken out of them */
     std::lock_guard<std::mutex> batch_lock(idx->ws.mtx);
     FillInput in;
     in.k = k;
     in.idx = idx;
-    in.resize(n);
-    std::atomic<long> bad_gap{-1};
-    parallel_for(n, p->nb_host_threads, [&](size_t i) {
-        if ((int)gaps[i].source.size() < k) bad_gap = (long)i;
-        in.size(i, swf_targets[i].size(), gaps[i].targets.size());
-    }, 1024);
-    if (bad_gap >= 0) { set_error("gap %ld: source sequence shorter than k", bad_gap.load()); return MTG_ERR_ARG; }
-    in.layout();
-    parallel_for(n, p->nb_host_threads, [&](size_t i) {
-        in.set(i, gaps[i].source, swf_targets[i], &gaps[i].targets, gaps[i].anchor_repeated ? 0 : p->nb_mis_allowed); /* src/Filler.cpp:859-863 */
+    std::atomic<long> bad_gap{-1}, short_gap{-1};
+    in.plan(n, nth, [&](size_t i, size_t& swf_len, size_t& n_targets) {
+        size_t src_len = 0;
+        if (!src.sizes(i, src_len, swf_len, n_targets)) { bad_gap = (long)i; swf_len = n_targets = 0; }
+        else if ((int)src_len < k) short_gap = (long)i;
     });
+    if (bad_gap >= 0) { set_error("gap %ld: null field", bad_gap.load()); return MTG_ERR_ARG; }
+    if (short_gap >= 0) { set_error("gap %ld: source sequence shorter than k", short_gap.load()); return MTG_ERR_ARG; }
+    tick("input sizes + layout");
+    in.fill(nth, [&](size_t i) { src.input(i, in, p->nb_mis_allowed); });
+    tick("input set");
     mtg_batch_stats st{};
     st.host_ms = now_ms() - t_begin;
     DevBatch batch;
     DevBatch& dev = batch;
-    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
-    double tdev = now_ms();
-    int rc = device_run(idx, p, in, batch, &st);
+    double t_marshal = 0;
+    const std::function<void()> overlap = [&]() { const double t = now_ms(); src.marshal(in, nth); t_marshal = now_ms() - t; };
+    int rc = device_run(idx, p, in, batch, &st, &overlap);
     if (rc) return rc;
-    if (dbg) fprintf(stderr, "  [fill_gaps] pre %.2f device_run %.2f ms\n", tdev - t_begin, now_ms() - tdev);
+    if (dbg) fprintf(stderr, "  [fill_gaps] marshal (overlapped)   %.2f ms\n", t_marshal);
+    std::vector<GapWork>& gaps = src.gaps();
+    tk = now_ms();
     double t0 = now_ms();
-    std::vector<uint64_t> aoff(n + 1);
-    parallel_prefix(n, p->nb_host_threads, aoff.data(), [&](size_t i) { const PostOut& po = dev.rec(i).p; return po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0; });
-    char* const arena_base = arena.ensure(aoff[n] + 1);
+    /* arena bytes of every block of gaps, then the gaps of a block one after the other */
+    const size_t B = RESULT_BLOCK, nb = (n + B - 1) / B;
+    std::vector<uint64_t> blk_arena(nb + 1, 0), blk_sols(nb, 0);
+    parallel_for(nb, nth, [&](size_t b) {
+        uint64_t sum = 0;
+        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) { const PostOut& po = dev.rec(i).p; sum += po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0; }
+        blk_arena[b + 1] = sum;
+    }, 1);
+    for (size_t b = 0; b < nb; b++) blk_arena[b + 1] += blk_arena[b];
+    tick("arena offsets");
+    char* const arena_base = arena.ensure(blk_arena[nb] + 1);
     std::vector<uint8_t> general(n, 0); /* gaps whose solutions came out of the host's path enumeration: coverage still to do */
-    parallel_for(n, p->nb_host_threads, [&](size_t i) { general[i] = process_gap(dev[i], gaps[i], k, arena_base + aoff[i]) ? 1 : 0; });
+    parallel_for(nb, nth, [&](size_t b) {
+        uint64_t off = blk_arena[b], nsol = 0;
+        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) {
+            const GapDev gd = dev[i];
+            general[i] = process_gap(gd, gaps[i], k, arena_base + off) ? 1 : 0;
+            off += gd.p.fast == 1 ? (uint64_t)(gd.p.pos - (uint32_t)k) + 1 : 0;
+            nsol += gaps[i].sols.size();
+        }
+        blk_sols[b] = nsol;
+    }, 1);
+    if (sol_blocks) sol_blocks->swap(blk_sols);
+    tick("process gaps");
     std::vector<size_t> gen_idx;
     for (size_t i = 0; i < n; i++) if (general[i]) gen_idx.push_back(i);
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
@@ -625,7 +688,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& g
         }
     }, 1);
     st.host_ms += now_ms() - t0;
-    if (dbg) fprintf(stderr, "  [fill_gaps] post-device %.2f ms\n", now_ms() - t0);
+    tick("general path");
     st.total_ms = now_ms() - t_begin;
     if (stats_out) *stats_out = st;
     stats_store(st);
@@ -639,11 +702,8 @@ struct mtg_results {
     mtgi::FillArena arena;
     std::vector<mtgi::Target> targets; /* flat storage of every gap's dictionary */
     std::vector<mtg_filled> filled_flat;
-    std::vector<uint64_t> filled_off;
     std::vector<mtgi::GapWork> gaps;
     std::vector<mtg_gap_result> res;
-    std::vector<std::string_view> swf; /* scratch of mtg_fill_batch */
-    std::vector<uint64_t> toff;
 };
 struct mtg_contigs {
     std::vector<std::vector<std::string>> c;
@@ -691,75 +751,100 @@ int mtg_index_create_from_reads(const char* paths_csv, int k, int abundance_min,
 int mtg_index_save(const mtg_index* idx, const char* path) { return mtgi::index_save(idx, path); }
 int mtg_index_load(const char* path, mtg_index** out) { return mtgi::index_load(path, out); }
 
+/* a batch handed over through the C ABI: the GapWork records are written while the device is busy */
+namespace {
+struct AbiSource : mtgi::BatchSource {
+    const mtg_gap* g;
+    size_t n;
+    mtg_results* R;
+    AbiSource(const mtg_gap* g_, size_t n_, mtg_results* R_) : g(g_), n(n_), R(R_) {}
+    size_t count() const override { return n; }
+    bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const override
+    {
+        const mtg_gap& a = g[i];
+        if (!a.source || !a.target || (a.n_targets > 0 && (!a.target_seqs || !a.target_names))) return false;
+        for (int t = 0; t < a.n_targets; t++) if (!a.target_seqs[t] || !a.target_names[t]) return false;
+        src_len = strlen(a.source); swf_len = strlen(a.target); n_targets = (size_t)std::max(a.n_targets, 0);
+        return true;
+    }
+    void input(size_t i, mtgi::FillInput& in, int nb_mis_allowed) const override
+    {
+        const mtg_gap& a = g[i];
+        in.set_raw(i, std::string_view(a.source), std::string_view(a.target, in.rlen[i]), (size_t)std::max(a.n_targets, 0), a.target_seqs,
+                   a.is_anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
+    }
+    void marshal(const mtgi::FillInput& in, int nthreads) override
+    {
+        R->gaps.resize(n);
+        R->targets.resize(in.tle.size());
+        mtgi::parallel_for(n, nthreads, [&](size_t i) {
+            const mtg_gap& a = g[i];
+            mtgi::GapWork& w = R->gaps[i];
+            w.reset(); /* a recycled object still holds the previous batch */
+            w.source = a.source;
+            w.anchor_repeated = a.is_anchor_repeated != 0;
+            w.reverse = a.reverse != 0;
+            mtgi::Target* T0 = R->targets.data() + in.toff[i];
+            for (int t = 0; t < a.n_targets; t++) {
+                mtgi::Target& T = T0[t];
+                T.seq = a.target_seqs[t];
+                T.name = a.target_names[t];
+                T.is_rc = a.target_is_rc ? a.target_is_rc[t] != 0 : false;
+            }
+            w.targets.p = T0;
+            w.targets.n = (uint32_t)std::max(a.n_targets, 0);
+        }, 256);
+    }
+    std::vector<mtgi::GapWork>& gaps() override { return R->gaps; }
+};
+} // namespace
+
 int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out)
 {
     if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     const double t_m0 = mtgi::now_ms();
+    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    double tk = t_m0;
+    auto tick = [&](const char* what) { if (dbg) { const double t = mtgi::now_ms(); fprintf(stderr, "  [fill_batch] %-21s %.2f ms\n", what, t - tk); tk = t; } };
     mtg_results* R = results_acquire();
-    R->gaps.resize(n);
-    std::vector<std::string_view>& swf = R->swf;
-    swf.resize(n);
-    std::vector<uint64_t>& toff = R->toff;
-    toff.resize(n + 1);
-    std::atomic<long> bad{-1};
-    mtgi::parallel_prefix(n, p->nb_host_threads, toff.data(), [&](size_t i) {
-        const mtg_gap& g = gaps[i];
-        if (!g.source || !g.target || (g.n_targets > 0 && (!g.target_seqs || !g.target_names))) bad = (long)i;
-        return (uint64_t)std::max(g.n_targets, 0);
-    });
-    if (bad >= 0) { results_release(R); mtgi::set_error("gap %ld: null field", bad.load()); return MTG_ERR_ARG; }
-    R->targets.resize(toff[n]);
-    mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
-        const mtg_gap& g = gaps[i];
-        mtgi::GapWork& w = R->gaps[i];
-        w.reset(); /* a recycled object still holds the previous batch */
-        w.source = g.source;
-        swf[i] = g.target;
-        w.anchor_repeated = g.is_anchor_repeated != 0;
-        w.reverse = g.reverse != 0;
-        mtgi::Target* T0 = R->targets.data() + toff[i];
-        for (int t = 0; t < g.n_targets; t++) {
-            mtgi::Target& T = T0[t];
-            T.seq = g.target_seqs[t];
-            T.name = g.target_names[t];
-            T.is_rc = g.target_is_rc ? g.target_is_rc[t] != 0 : false;
-        }
-        w.targets.p = T0;
-        w.targets.n = (uint32_t)std::max(g.n_targets, 0);
-    }, 256);
-    const double t_m1 = mtgi::now_ms();
+    AbiSource src(gaps, n, R);
     mtg_batch_stats st{};
-    int rc = mtgi::fill_gaps(idx, p, R->gaps, swf, R->arena, &st);
+    std::vector<uint64_t> sol_blocks;
+    int rc = mtgi::fill_gaps(idx, p, src, R->arena, &st, &sol_blocks);
     if (rc) { results_release(R); return rc; }
     const double t_m2 = mtgi::now_ms();
+    tk = t_m2;
+    const size_t B = mtgi::RESULT_BLOCK, nb = (n + B - 1) / B;
+    std::vector<uint64_t> blk_off(nb + 1, 0);
+    for (size_t b = 0; b < nb; b++) blk_off[b + 1] = blk_off[b] + sol_blocks[b];
     R->res.resize(n);
-    R->filled_off.resize(n + 1);
-    mtgi::parallel_prefix(n, p->nb_host_threads, R->filled_off.data(), [&](size_t i) { return (uint64_t)R->gaps[i].sols.size(); });
-    R->filled_flat.resize(R->filled_off[n]);
-    mtgi::parallel_for(n, p->nb_host_threads, [&](size_t i) {
-        mtgi::GapWork& w = R->gaps[i];
-        mtg_filled* F0 = R->filled_flat.data() + R->filled_off[i];
-        size_t j = 0;
-        for (auto& s : w.sols) {
-            mtg_filled& f = F0[j++];
-            f.seq = s.seq.c_str();
-            f.nb_errors_in_anchor = s.nb_errors;
-            f.target_index = s.target;
-            f.avg_coverage = s.avg;
-            f.median_coverage = s.median;
-            f.qual = s.qual;
-            f.solution_count = s.count;
-            f.solution_rank = s.rank;
+    R->filled_flat.resize(blk_off[nb]);
+    mtgi::parallel_for(nb, p->nb_host_threads, [&](size_t b) {
+        mtg_filled* F0 = R->filled_flat.data() + blk_off[b];
+        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) {
+            mtgi::GapWork& w = R->gaps[i];
+            mtg_gap_result& r = R->res[i];
+            r.filled = F0;
+            for (auto& s : w.sols) {
+                mtg_filled& f = *F0++;
+                f.seq = s.seq.c_str();
+                f.nb_errors_in_anchor = s.nb_errors;
+                f.target_index = s.target;
+                f.avg_coverage = s.avg;
+                f.median_coverage = s.median;
+                f.qual = s.qual;
+                f.solution_count = s.count;
+                f.solution_rank = s.rank;
+            }
+            r.nb_nodes = w.nb_nodes; r.total_nt = w.total_nt; r.nb_terminal = w.nb_terminal;
+            r.has_solution_counts = w.has_counts; r.nb_total_filled = w.nb_total_filled; r.nb_reported = (int)w.sols.size();
+            r.n_filled = (int)w.sols.size();
+            r.extension = w.extension.c_str();
         }
-        mtg_gap_result& r = R->res[i];
-        r.nb_nodes = w.nb_nodes; r.total_nt = w.total_nt; r.nb_terminal = w.nb_terminal;
-        r.has_solution_counts = w.has_counts; r.nb_total_filled = w.nb_total_filled; r.nb_reported = (int)w.sols.size();
-        r.n_filled = (int)w.sols.size();
-        r.filled = F0;
-        r.extension = w.extension.c_str();
-    }, 256);
+    }, 1);
     /* the views on the caller's strings end here */
-    st.marshal_ms = t_m1 - t_m0;
+    tick("result records");
+    st.marshal_ms = 0;
     st.result_ms = mtgi::now_ms() - t_m2;
     st.total_ms = mtgi::now_ms() - t_m0;
     mtgi::stats_store(st);

@@ -44,33 +44,49 @@ namespace mtgi {
 
 void set_error(const char* fmt, ...);
 
-/* persistent host worker pool for the per-gap loops (nthreads <= 0: all cores, capped at 64) */
+/* persistent host worker pool for the per-gap loops (nthreads <= 0: all cores, capped at 64).  A batch runs a dozen short parallel
+ * regions back to back, so idle workers first spin for a few tens of microseconds on the generation counter before they go to sleep,
+ * and the caller never waits for a helper that has not started by the time the work has run out. */
 class Pool {
 public:
     static Pool& get() { static Pool p; return p; }
-    /* runs job(worker) on `nworkers` threads (the caller is one of them) and waits */
+    /* runs job() on up to `nworkers` threads (the caller is one of them) and waits; job must return once the shared work is exhausted */
     void run(int nworkers, const std::function<void()>& job)
     {
         std::unique_lock<std::mutex> run_lock(run_mtx_); /* one parallel region at a time */
         const int helpers = std::min<int>(nworkers - 1, (int)threads_.size());
         if (helpers > 0) {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &job;
-            to_start_ = helpers;
-            active_ = helpers;
-            gen_++;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                job_ = &job;
+                active_.store(helpers, std::memory_order_relaxed);
+                to_start_.store(helpers, std::memory_order_relaxed);
+                gen_.fetch_add(1, std::memory_order_release);
+            }
+            cv_.notify_all();
         }
-        if (helpers > 0) cv_.notify_all();
         job();
         if (helpers > 0) {
-            std::unique_lock<std::mutex> lk(m_);
-            done_cv_.wait(lk, [&] { return active_ == 0; });
+            const int unclaimed = to_start_.exchange(0, std::memory_order_acq_rel); /* nothing left for late helpers */
+            if (unclaimed > 0) active_.fetch_sub(unclaimed, std::memory_order_acq_rel);
+            for (int spin = 0; spin < SPIN && active_.load(std::memory_order_acquire) != 0; spin++) cpu_relax();
+            if (active_.load(std::memory_order_acquire) != 0) {
+                std::unique_lock<std::mutex> lk(m_);
+                done_cv_.wait(lk, [&] { return active_.load(std::memory_order_acquire) == 0; });
+            }
             job_ = nullptr;
         }
     }
     int size() const { return (int)threads_.size() + 1; }
 
 private:
+    enum { SPIN = 4000 };
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
     Pool()
     {
         int n = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 64u);
@@ -78,27 +94,39 @@ private:
     }
     ~Pool()
     {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        { std::lock_guard<std::mutex> lk(m_); stop_.store(true); }
         cv_.notify_all();
         for (auto& t : threads_) t.join();
+    }
+    bool claim()
+    {
+        int v = to_start_.load(std::memory_order_acquire);
+        while (v > 0 && !to_start_.compare_exchange_weak(v, v - 1, std::memory_order_acq_rel)) {}
+        return v > 0;
     }
     void loop()
     {
         uint64_t seen = 0;
         for (;;) {
-            const std::function<void()>* job = nullptr;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && to_start_ > 0); });
-                if (stop_) return;
-                seen = gen_;
-                to_start_--;
-                job = job_;
+            bool mine = false;
+            for (int spin = 0; spin < SPIN && !mine; spin++) {
+                if (stop_.load(std::memory_order_relaxed)) return;
+                const uint64_t g = gen_.load(std::memory_order_acquire);
+                if (g != seen) { seen = g; mine = claim(); }
+                else cpu_relax();
             }
-            (*job)();
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (--active_ == 0) done_cv_.notify_all();
+            if (!mine) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_.load() || gen_.load(std::memory_order_acquire) != seen; });
+                if (stop_.load()) return;
+                seen = gen_.load(std::memory_order_acquire);
+                mine = claim();
+            }
+            if (!mine) continue;
+            (*job_)();
+            if (active_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(m_); /* the caller may be about to sleep on done_cv_ */
+                done_cv_.notify_all();
             }
         }
     }
@@ -106,9 +134,9 @@ private:
     std::mutex m_, run_mtx_;
     std::condition_variable cv_, done_cv_;
     const std::function<void()>* job_ = nullptr;
-    int to_start_ = 0, active_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    std::atomic<int> to_start_{0}, active_{0};
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<bool> stop_{false};
 };
 
 template <typename F> inline void parallel_for(size_t n, int nthreads, F f, size_t grain = 64)
@@ -271,13 +299,58 @@ struct FillInput {
     void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }
     void layout();
     void set(size_t i, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis);
+    /* the same with the target sequences as C strings (the C ABI's mtg_gap) */
+    void set_raw(size_t i, std::string_view source, std::string_view swf_target, size_t n_targets, const char* const* target_seqs, int nb_mis);
+    void set_common(size_t i, std::string_view source, std::string_view swf_target, int nb_mis);
+    void set_target(size_t slot, std::string_view seq);
+    /* The two passes over blocks of gaps, each one parallel region.  plan: sz(i, swf_len, n_targets) for every gap, then the offsets of
+     * every block; fill: offsets of every gap of a block in turn, then st(i) (which calls set / set_raw). */
+    enum { BLOCK = 2048 };
+    std::vector<uint64_t> blk_rw, blk_nt;
+    void alloc_b(uint64_t rw, uint64_t nt);
+    template <typename SizeFn> void plan(size_t n, int nthreads, SizeFn sz)
+    {
+        resize(n);
+        const size_t nb = (n + BLOCK - 1) / BLOCK;
+        blk_rw.assign(nb + 1, 0);
+        blk_nt.assign(nb + 1, 0);
+        parallel_for(nb, nthreads, [&](size_t b) {
+            uint64_t rw = 0, nt = 0;
+            for (size_t i = b * BLOCK; i < std::min(n, (b + 1) * (size_t)BLOCK); i++) {
+                size_t sl = 0, tn = 0;
+                sz(i, sl, tn);
+                size(i, sl, tn);
+                rw += (sl + 31) / 32 + 1;
+                nt += tn;
+            }
+            blk_rw[b + 1] = rw;
+            blk_nt[b + 1] = nt;
+        }, 1);
+        for (size_t b = 0; b < nb; b++) { blk_rw[b + 1] += blk_rw[b]; blk_nt[b + 1] += blk_nt[b]; }
+        alloc_b(blk_rw[nb], blk_nt[nb]);
+    }
+    template <typename SetFn> void fill(int nthreads, SetFn st)
+    {
+        const size_t n = src.size(), nb = (n + BLOCK - 1) / BLOCK;
+        parallel_for(nb, nthreads, [&](size_t b) {
+            uint64_t rw = blk_rw[b], nt = blk_nt[b];
+            for (size_t i = b * BLOCK; i < std::min(n, (b + 1) * (size_t)BLOCK); i++) {
+                roff[i] = (uint32_t)rw;
+                toff[i] = (uint32_t)nt;
+                rw += (rlen[i] + 31) / 32 + 1; /* before st(i): set() may flag the pattern by overwriting rlen */
+                nt += tcnt[i];
+                st(i);
+            }
+        }, 1);
+    }
     /* byte offsets of the arrays inside their block (the device copy has the same layout) */
     static size_t off_a(size_t n, int which) { static const size_t mul[8] = {0, 8, 16, 20, 24, 28, 32, 33}; return mul[which] * n8(n); }
     static size_t n8(size_t n) { return (n + 7) & ~(size_t)7; }
 };
 
-/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats);
+/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status.  `overlap`, when given, is called
+ * once on the calling thread while the device works on the first chunk. */
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats, const std::function<void()>* overlap = nullptr);
 
 /* membership scan over packed sequences: host arrays in (words/off/len), bit output as in mtg_index_scan_packed_device; device = 1: the pointers are device pointers */
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int device_ptrs,
@@ -385,6 +458,21 @@ struct GapWork {
         sols.clear(); extension.clear();
     }
 };
+/* where a batch of gapFillFromSource calls comes from */
+struct BatchSource {
+    virtual ~BatchSource() {}
+    virtual size_t count() const = 0;
+    /* pass 1, any thread: lengths of gap i's source and swf pattern, number of targets; false: the gap is malformed */
+    virtual bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const = 0;
+    /* pass 2, any thread: in.set(i, ...) / in.set_raw(i, ...) */
+    virtual void input(size_t i, FillInput& in, int nb_mis_allowed) const = 0;
+    /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
+    virtual void marshal(const FillInput& in, int nthreads) = 0;
+    virtual std::vector<GapWork>& gaps() = 0;
+};
+enum { RESULT_BLOCK = 2048 };
+/* sol_blocks (optional): number of solutions in each block of RESULT_BLOCK gaps */
+int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillArena& arena, mtg_batch_stats* stats_out, std::vector<uint64_t>* sol_blocks = nullptr);
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
 int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,
               mtg_batch_stats* stats_out);

@@ -131,8 +131,9 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t, const uint64_t
 /* the emulator keeps the marshalled input in the FillInput's own storage */
 void* staging_host(const mtg_index*, int, size_t) { return nullptr; }
 
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* overlap)
 {
+    if (overlap) (*overlap)();
     const size_t n = in.src.size();
     batch.n = n;
     batch.chunk_of.assign(n, 0);
