@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* 
 /* terminal-node search + coverage of the single-contig solution, one wave per gap; then the wave reserves room in the chunk's dense
  * arrays (two atomic counters) and copies there what the host needs of this gap: nw leading arena words and, for nc contigs, their
  * (length, first word) and terminal info.  counters: [0] words, [1] contig metadata entries */
-__global__ void __launch_bounds__(64) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
                                              uint32_t want_all, unsigned long long* counters, SlotRec* recs, uint64_t* dense_words, uint32_t* dense_meta,
@@ -649,12 +649,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
 
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &idx->ws; b.slot = ws_next++; return b; };
-    WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
+    WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
           d_dm = wsbuf(), d_cnt = wsbuf();
     /* the marshalled input: two blocks, two copies */
     double t0 = now_ms();
     HIP_TRY(d_ina.alloc(in.bytes_a));
     HIP_TRY(d_inb.alloc(in.bytes_b));
+    HIP_TRY(d_inc.alloc(in.bytes_c));
     HIP_TRY(d_cnt.alloc(64));
     HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, 0));
@@ -668,8 +669,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     const uint8_t* d_mis = da + FillInput::off_a(n, 6);
     const uint8_t* d_fok = da + FillInput::off_a(n, 7);
     const uint64_t* d_rw = d_inb.as<uint64_t>();
-    const uint64_t* d_tle = d_rw + in.rwords.size();
+    const uint64_t* d_tle = d_inc.as<uint64_t>(); /* sent after the overlapped host work, which is what fills it */
     const uint64_t* d_tbad = d_tle + in.tle.size();
+    bool targets_sent = false;
     st.h2d_ms += now_ms() - t0;
     tick("upload (async)");
 
@@ -728,12 +730,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
                                d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
             HIP_TRY(hipEventRecord(ev1, 0));
+            HIP_TRY(hipGetLastError());
+            tick("host prep+launch");
+            if (overlap && !overlap_done) { overlap_done = true; (*overlap)(); tick("overlapped host work"); } /* the device is busy: the caller's turn */
+            if (!targets_sent) { targets_sent = true; HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, 0)); }
             hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_cnt.as<unsigned long long>(), d_rec.as<SlotRec>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), m);
             HIP_TRY(hipEventRecord(ev2, 0));
             HIP_TRY(hipGetLastError());
-            tick("host prep+launch");
-            if (overlap && !overlap_done) { overlap_done = true; (*overlap)(); tick("overlapped host work"); } /* the device is busy: the caller's turn */
             unsigned long long totals[2] = {0, 0};
             HIP_TRY(hipMemcpy(totals, d_cnt.p, 16, hipMemcpyDeviceToHost)); /* waits for the kernels */
             tick("kernels");
@@ -748,7 +752,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             SlotRec* h_rec = nullptr;
             uint64_t* h_w = nullptr;
             uint32_t* h_m = nullptr;
-            void* block = (int)chunk_id + 2 < Workspace::NHOST ? staging_host(idx, (int)chunk_id + 2, HostChunk::bytes_for(m, tw, tc)) : nullptr;
+            void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST ? staging_host(idx, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(m, tw, tc)) : nullptr;
             hc.carve(block, m, tw, tc, h_rec, h_w, h_m);
             HIP_TRY(hipMemcpyAsync(h_rec, d_rec.p, (size_t)m * sizeof(SlotRec), hipMemcpyDeviceToHost, 0));
             if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.p, tw * 8, hipMemcpyDeviceToHost, 0));

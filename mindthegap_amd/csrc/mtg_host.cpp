@@ -225,11 +225,14 @@ void FillInput::resize(size_t n)
 }
 void FillInput::alloc_b(uint64_t rw, uint64_t nt)
 {
-    bytes_b = 8 * (rw + 2 * nt) + 64;
+    bytes_b = 8 * rw + 64;
     block_b = idx ? staging_host(idx, 1, bytes_b) : nullptr;
     if (!block_b) { own_b.resize(bytes_b / 8 + 1); block_b = own_b.data(); }
     rwords.p = (uint64_t*)block_b; rwords.n = rw;
-    tle.p = rwords.p + rw; tle.n = nt;
+    bytes_c = 16 * nt + 64;
+    block_c = idx ? staging_host(idx, 2, bytes_c) : nullptr;
+    if (!block_c) { own_c.resize(bytes_c / 8 + 1); block_c = own_c.data(); }
+    tle.p = (uint64_t*)block_c; tle.n = nt;
     tbad.p = tle.p + nt; tbad.n = nt;
 }
 void FillInput::layout()
@@ -280,11 +283,6 @@ void FillInput::set(size_t g, std::string_view source, std::string_view swf_targ
         size_t o = toff[g];
         for (const Target& t : *targets) set_target(o++, t.seq);
     }
-}
-void FillInput::set_raw(size_t g, std::string_view source, std::string_view swf_target, size_t n_targets, const char* const* target_seqs, int nb_mis)
-{
-    set_common(g, source, swf_target, nb_mis);
-    for (size_t t = 0; t < n_targets; t++) set_target(toff[g] + t, std::string_view(target_seqs[t]));
 }
 
 struct ContigGraph {
@@ -561,7 +559,12 @@ struct VecSource : BatchSource {
     }
     void input(size_t i, FillInput& in, int nb_mis_allowed) const override
     {
-        in.set(i, g[i].source, swf[i], &g[i].targets, g[i].anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
+        in.set_common(i, g[i].source, swf[i], g[i].anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
+    }
+    void targets(size_t i, FillInput& in) const override
+    {
+        size_t o = in.toff[i];
+        for (const Target& t : g[i].targets) in.set_target(o++, t.seq);
     }
     void marshal(const FillInput&, int) override {}
     std::vector<GapWork>& gaps() override { return g; }
@@ -604,7 +607,12 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     DevBatch batch;
     DevBatch& dev = batch;
     double t_marshal = 0;
-    const std::function<void()> overlap = [&]() { const double t = now_ms(); src.marshal(in, nth); t_marshal = now_ms() - t; };
+    const std::function<void()> overlap = [&]() {
+        const double t = now_ms();
+        parallel_for(n, nth, [&](size_t i) { src.targets(i, in); }, 512);
+        src.marshal(in, nth);
+        t_marshal = now_ms() - t;
+    };
     int rc = device_run(idx, p, in, batch, &st, &overlap);
     if (rc) return rc;
     if (dbg) fprintf(stderr, "  [fill_gaps] marshal (overlapped)   %.2f ms\n", t_marshal);
@@ -770,8 +778,12 @@ struct AbiSource : mtgi::BatchSource {
     void input(size_t i, mtgi::FillInput& in, int nb_mis_allowed) const override
     {
         const mtg_gap& a = g[i];
-        in.set_raw(i, std::string_view(a.source), std::string_view(a.target, in.rlen[i]), (size_t)std::max(a.n_targets, 0), a.target_seqs,
-                   a.is_anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
+        in.set_common(i, std::string_view(a.source), std::string_view(a.target, in.rlen[i]), a.is_anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
+    }
+    void targets(size_t i, mtgi::FillInput& in) const override
+    {
+        const mtg_gap& a = g[i];
+        for (int t = 0; t < a.n_targets; t++) in.set_target(in.toff[i] + (size_t)t, std::string_view(a.target_seqs[t]));
     }
     void marshal(const mtgi::FillInput& in, int nthreads) override
     {

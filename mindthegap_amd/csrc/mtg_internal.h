@@ -26,7 +26,7 @@ struct Workspace {
     enum { NSLOTS = 32, NHOST = 8 };
     void* ptr[NSLOTS] = {nullptr};
     size_t cap[NSLOTS] = {0};
-    /* page-locked host staging blocks: 0/1 = the marshalled input of a batch, 2.. = what the first chunks of a batch brought back */
+    /* page-locked host staging blocks: 0..2 = the marshalled input of a batch, 3.. = what the first chunks of a batch brought back */
     void* hptr[NHOST] = {nullptr};
     size_t hcap[NHOST] = {0};
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
@@ -290,21 +290,20 @@ struct FillInput {
     Arr<uint8_t> nbmis, fast_ok;
     /* block B */
     Arr<uint64_t> rwords;  /* packed swf patterns, concatenated */
+    /* block C: only the post-processing kernel reads it, so it may be filled and sent while the traversal kernel runs */
     Arr<uint64_t> tle, tbad; /* targets of all gaps: little-endian k-mer, never-match mask */
-    void *block_a = nullptr, *block_b = nullptr;
-    size_t bytes_a = 0, bytes_b = 0;
-    std::vector<uint64_t> own_a, own_b;
+    void *block_a = nullptr, *block_b = nullptr, *block_c = nullptr;
+    size_t bytes_a = 0, bytes_b = 0, bytes_c = 0;
+    std::vector<uint64_t> own_a, own_b, own_c;
     /* two-pass marshalling: size(i, ...) for every gap in order, then layout(), then set(i, ...) from any thread */
     void resize(size_t n);
     void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }
     void layout();
     void set(size_t i, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis);
-    /* the same with the target sequences as C strings (the C ABI's mtg_gap) */
-    void set_raw(size_t i, std::string_view source, std::string_view swf_target, size_t n_targets, const char* const* target_seqs, int nb_mis);
     void set_common(size_t i, std::string_view source, std::string_view swf_target, int nb_mis);
     void set_target(size_t slot, std::string_view seq);
     /* The two passes over blocks of gaps, each one parallel region.  plan: sz(i, swf_len, n_targets) for every gap, then the offsets of
-     * every block; fill: offsets of every gap of a block in turn, then st(i) (which calls set / set_raw). */
+     * every block; fill: offsets of every gap of a block in turn, then st(i) (which calls set_common). */
     enum { BLOCK = 2048 };
     std::vector<uint64_t> blk_rw, blk_nt;
     void alloc_b(uint64_t rw, uint64_t nt);
@@ -351,6 +350,7 @@ struct FillInput {
 /* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status.  `overlap`, when given, is called
  * once on the calling thread while the device works on the first chunk. */
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats, const std::function<void()>* overlap = nullptr);
+enum { STAGING_CHUNK0 = 3 }; /* first staging block used for results */
 
 /* membership scan over packed sequences: host arrays in (words/off/len), bit output as in mtg_index_scan_packed_device; device = 1: the pointers are device pointers */
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int device_ptrs,
@@ -464,8 +464,10 @@ struct BatchSource {
     virtual size_t count() const = 0;
     /* pass 1, any thread: lengths of gap i's source and swf pattern, number of targets; false: the gap is malformed */
     virtual bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const = 0;
-    /* pass 2, any thread: in.set(i, ...) / in.set_raw(i, ...) */
+    /* pass 2, any thread: in.set_common(i, ...) */
     virtual void input(size_t i, FillInput& in, int nb_mis_allowed) const = 0;
+    /* while the traversal kernel runs, any thread: in.set_target(in.toff[i] + t, ...) for every target of gap i */
+    virtual void targets(size_t i, FillInput& in) const = 0;
     /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
     virtual void marshal(const FillInput& in, int nthreads) = 0;
     virtual std::vector<GapWork>& gaps() = 0;
