@@ -304,7 +304,7 @@ struct FillInput {
     void set_target(size_t slot, std::string_view seq);
     /* The two passes over blocks of gaps, each one parallel region.  plan: sz(i, swf_len, n_targets) for every gap, then the offsets of
      * every block; fill: offsets of every gap of a block in turn, then st(i) (which calls set_common). */
-    enum { BLOCK = 2048 };
+    enum { BLOCK = 512 };
     std::vector<uint64_t> blk_rw, blk_nt;
     void alloc_b(uint64_t rw, uint64_t nt);
     template <typename SizeFn> void plan(size_t n, int nthreads, SizeFn sz)
@@ -472,7 +472,7 @@ struct BatchSource {
     virtual void marshal(const FillInput& in, int nthreads) = 0;
     virtual std::vector<GapWork>& gaps() = 0;
 };
-enum { RESULT_BLOCK = 2048 };
+enum { RESULT_BLOCK = 512 };
 /* sol_blocks (optional): number of solutions in each block of RESULT_BLOCK gaps */
 int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillArena& arena, mtg_batch_stats* stats_out, std::vector<uint64_t>* sol_blocks = nullptr);
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
