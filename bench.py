@@ -105,7 +105,9 @@ def main():
         gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
         expected.append(ins)
     prepared = mtg.Index.prepare_gaps(gaps)
-    params = mtg.FillParams(max_nodes=100, max_depth=10000)
+    # N ranks share the host: each gets its share of the cores for the per-gap host passes (0 = the library's default, up to 64 threads)
+    host_threads = 0 if world == 1 else max(4, min(64, (os.cpu_count() or 64) // world))
+    params = mtg.FillParams(max_nodes=100, max_depth=10000, nb_host_threads=host_threads)
     exp_digest = hashlib.sha256(("\n".join(expected) + "\n").encode()).hexdigest()
 
     def rc(s):

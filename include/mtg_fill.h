@@ -140,6 +140,8 @@ typedef struct mtg_gap_result {
 typedef struct mtg_results mtg_results;
 int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
+/* Every pointer obtained from r dies here.  The library keeps the storage of up to two freed result sets (a few hundred bytes per
+ * gap plus the sequences) and hands it to the next batches, which then pay no allocation, page fault or memset. */
 void mtg_results_free(mtg_results* r);
 /* bulk view of a result set (for gathers / checksums): n_filled[i] = number of sequences of gap i (may be NULL);
  * *seq_bytes = size of the concatenation "seq\n" of all filled sequences in gap order, which mtg_results_copy_seqs writes to dst */

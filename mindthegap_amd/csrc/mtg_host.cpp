@@ -712,6 +712,7 @@ struct mtg_results {
     std::vector<mtg_filled> filled_flat;
     std::vector<mtgi::GapWork> gaps;
     std::vector<mtg_gap_result> res;
+    int nthreads = 0; /* host threads of the batch that filled it */
 };
 struct mtg_contigs {
     std::vector<std::vector<std::string>> c;
@@ -819,6 +820,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     double tk = t_m0;
     auto tick = [&](const char* what) { if (dbg) { const double t = mtgi::now_ms(); fprintf(stderr, "  [fill_batch] %-21s %.2f ms\n", what, t - tk); tk = t; } };
     mtg_results* R = results_acquire();
+    R->nthreads = p->nb_host_threads;
     AbiSource src(gaps, n, R);
     mtg_batch_stats st{};
     std::vector<uint64_t> sol_blocks;
@@ -874,7 +876,7 @@ int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_
     std::atomic<uint64_t> b{0}, nf{0};
     const size_t n = r->gaps.size();
     const size_t CH = 2048;
-    mtgi::parallel_for((n + CH - 1) / CH, 0, [&](size_t c) {
+    mtgi::parallel_for((n + CH - 1) / CH, r->nthreads, [&](size_t c) {
         uint64_t lb = 0, lf = 0;
         for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) {
             if (n_filled) n_filled[i] = (uint32_t)r->gaps[i].sols.size();
@@ -898,7 +900,7 @@ int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
         off[i + 1] = off[i] + b;
     }
     if (off[n] > cap) { mtgi::set_error("destination too small"); return MTG_ERR_ARG; }
-    mtgi::parallel_for(n, 0, [&](size_t i) {
+    mtgi::parallel_for(n, r->nthreads, [&](size_t i) {
         uint64_t o = off[i];
         for (auto& s : r->gaps[i].sols) {
             memcpy(dst + o, s.seq.data(), s.seq.size());
