@@ -172,6 +172,14 @@ typedef struct mtg_batch_stats {
 int mtg_last_batch_stats(mtg_batch_stats* s);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * needleman_wunsch (src/Utils.cpp:87-189: match +10, mismatch -5, gap -5, traceback preference diagonal / up / left) for n pairs of
+ * NUL-terminated sequences, on the device: matches[i] = matching positions along the traceback of (a[i] = rows, b[i] = columns); the
+ * reference's identity is matches / max(strlen(a), strlen(b)).  Used by the fill path to de-duplicate multi-path solutions
+ * (remove_almost_identical_solutions, src/Utils.cpp:208-238).
+ * ---------------------------------------------------------------------------------------------------------- */
+int mtg_nw_matches(const char* const* a, const char* const* b, size_t n, uint32_t* matches);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Whole tool: `MindTheGap fill ...` = Filler::run(argc, argv) (src/main.cpp:105-120).  argv[0] is the first option.
  * Returns the process exit code of the reference (0 / 1).
  * ---------------------------------------------------------------------------------------------------------- */

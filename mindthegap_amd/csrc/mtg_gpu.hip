@@ -8,6 +8,8 @@
  *   k_post                           : terminal-node search per contig + coverage of the single-contig solution, one wave per gap;
  *                                      then the dense copy of what the host needs of the gap
  *                                      (find_nodes_containing_multiple_R, src/Filler.cpp:1294-1378; coverage :959-988)
+ *   k_nw                             : Needleman-Wunsch match counts for the de-duplication of multi-path solutions, one wave per pair
+ *                                      (remove_almost_identical_solutions, src/Utils.cpp:87-189,208-238)
  *   k_chase                          : dependent random 64-byte reads (measured roofline ceiling)
  */
 #include "mtg_internal.h"
@@ -294,6 +296,71 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_
         r.o = o; r.p = po; r.nw = nw; r.nc = nc; r.pad_ = 0; r.wbase = wbase; r.cbase = cbase;
         recs[slot] = r;
     }
+}
+
+/* Needleman-Wunsch match count of src/Utils.cpp:87-189, one wave per sequence pair (a = rows, b = columns), exact for any length.
+ * The matrix is swept in strips of 64 columns; inside a strip lane l owns column j0+l+1 and works on row t-l at step t, so that the
+ * cell to its left (lane l-1, previous step) and the diagonal one (lane l-1, two steps ago) arrive by a one-lane shift and the cell
+ * above is its own previous value.  The column left of a strip is kept in `bnd` (score, matches per row), read 64 rows at a time and
+ * overwritten by lane 63 as the strip advances (row i is read at step i and rewritten at step i+63).  Scores are the reference's
+ * floats times one (all multiples of 5: exact in int); ties are broken diagonal, up, left like the traceback of :150-180. */
+__global__ void __launch_bounds__(64) k_nw(const uint8_t* __restrict__ text, const uint64_t* __restrict__ off_a, const uint32_t* __restrict__ len_a,
+                                           const uint64_t* __restrict__ off_b, const uint32_t* __restrict__ len_b, int2* bnd_base,
+                                           const uint64_t* __restrict__ bnd_off, uint32_t* out, uint32_t npairs)
+{
+    const uint32_t pair = blockIdx.x, lane = threadIdx.x;
+    if (pair >= npairs) return;
+    const uint8_t* a = text + off_a[pair];
+    const uint8_t* b = text + off_b[pair];
+    const uint32_t na = len_a[pair], nb = len_b[pair];
+    int2* bnd = bnd_base + bnd_off[pair];
+    if (na == 0 || nb == 0) { if (lane == 0) out[pair] = 0; return; }
+    for (uint32_t i = lane; i <= na; i += 64) bnd[i] = make_int2(-5 * (int)i, 0); /* column 0 */
+    __syncthreads();
+    int result = 0;
+    for (uint32_t j0 = 0; j0 < nb; j0 += 64) {
+        const uint32_t j = j0 + lane + 1; /* 1-based column of this lane */
+        const bool col_ok = j <= nb;
+        const uint32_t bj = col_ok ? b[j - 1] : 256u;
+        int s_up = -5 * (int)j, m_up = 0;  /* cell above: row 0 to start with */
+        int s_cur = 0, m_cur = 0;          /* this lane's latest cell, handed to the right-hand neighbour at the next step */
+        int s_diag = 0, m_diag = 0;
+        uint32_t a_cur = 0;                /* the row character travels with the wavefront */
+        int2 bchunk = make_int2(0, 0);
+        uint32_t achunk = 0;
+        const uint32_t nsteps = na + 63;
+        for (uint32_t t = 1; t <= nsteps; t++) {
+            if (((t - 1) & 63u) == 0) { /* next 64 rows of the left boundary column and of a */
+                const uint32_t r = t + lane;
+                bchunk = r <= na ? bnd[r] : make_int2(0, 0);
+                achunk = r <= na ? a[r - 1] : 257u;
+            }
+            int s_left = __shfl_up(s_cur, 1, 64), m_left = __shfl_up(m_cur, 1, 64);
+            uint32_t a_in = (uint32_t)__shfl_up((int)a_cur, 1, 64);
+            const int src = (int)((t - 1) & 63u);
+            const int bs = __shfl(bchunk.x, src, 64), bm = __shfl(bchunk.y, src, 64);
+            const uint32_t ba = (uint32_t)__shfl((int)achunk, src, 64);
+            if (lane == 0) { s_left = bs; m_left = bm; a_in = ba; }
+            a_cur = a_in;
+            const int i = (int)t - (int)lane; /* row of this lane */
+            if (i == 1) { s_diag = -5 * ((int)j - 1); m_diag = 0; } /* row 0 */
+            if (col_ok && i >= 1 && i <= (int)na) {
+                const bool eq = a_cur == bj;
+                const int diag = s_diag + (eq ? 10 : -5), del = s_up - 5, ins = s_left - 5;
+                const int best = max(max(diag, del), ins);
+                const int m = best == diag ? m_diag + (eq ? 1 : 0) : (best == del ? m_up : m_left);
+                s_cur = best; m_cur = m;
+                s_up = best; m_up = m;
+                if (lane == 63) bnd[i] = make_int2(best, m);
+                if (i == (int)na && j == nb) result = m;
+            }
+            s_diag = s_left; m_diag = m_left;
+        }
+        __syncthreads(); /* lane 63's column is the next strip's boundary */
+    }
+    /* the final cell was computed by lane (nb - 1) % 64 */
+    result = __shfl(result, (int)((nb - 1) & 63u), 64);
+    if (lane == 0) out[pair] = (uint32_t)result;
 }
 
 /* membership scan along packed sequences: rolling k-mer per position, minimizer-blocked Bloom with the blocks of a 256-position tile
@@ -815,6 +882,30 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     }
     if (stats) *stats = st;
     return rc;
+}
+
+int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches)
+{
+    (void)idx;
+    if (int rc = ensure_device()) return rc;
+    const size_t np = pairs.size();
+    matches.assign(np, 0);
+    if (np == 0) return MTG_OK;
+    std::vector<uint64_t> oa(np), ob(np), bo(np);
+    std::vector<uint32_t> la(np), lb(np);
+    uint64_t nt = 0, nbnd = 0;
+    for (size_t i = 0; i < np; i++) { oa[i] = nt; nt += pairs[i].na; ob[i] = nt; nt += pairs[i].nb; la[i] = pairs[i].na; lb[i] = pairs[i].nb; bo[i] = nbnd; nbnd += (uint64_t)pairs[i].na + 1; }
+    std::vector<uint8_t> text(nt + 1);
+    for (size_t i = 0; i < np; i++) { memcpy(text.data() + oa[i], pairs[i].a, pairs[i].na); memcpy(text.data() + ob[i], pairs[i].b, pairs[i].nb); }
+    DevBuf d_text, d_oa, d_ob, d_la, d_lb, d_bo, d_bnd, d_out;
+    HIP_TRY(upload(d_text, text)); HIP_TRY(upload(d_oa, oa)); HIP_TRY(upload(d_ob, ob)); HIP_TRY(upload(d_la, la)); HIP_TRY(upload(d_lb, lb)); HIP_TRY(upload(d_bo, bo));
+    HIP_TRY(d_bnd.alloc(nbnd * sizeof(int2)));
+    HIP_TRY(d_out.alloc(np * 4));
+    hipLaunchKernelGGL(k_nw, dim3((unsigned)np), dim3(64), 0, 0, d_text.as<uint8_t>(), d_oa.as<uint64_t>(), d_la.as<uint32_t>(), d_ob.as<uint64_t>(), d_lb.as<uint32_t>(),
+                       d_bnd.as<int2>(), d_bo.as<uint64_t>(), d_out.as<uint32_t>(), (uint32_t)np);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(matches.data(), d_out.p, np * 4, hipMemcpyDeviceToHost));
+    return MTG_OK;
 }
 
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits,

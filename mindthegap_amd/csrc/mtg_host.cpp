@@ -345,30 +345,6 @@ struct RevDfs { /* GraphAnalysis::find_all_paths_rev, src/GraphAnalysis.cpp:244-
     }
 };
 
-/* identity of src/Utils.cpp:87-189 with two DP rows: the traceback's choice at (i,j) depends only on scores known
- * when (i,j) is filled, so the match count along the traceback is carried forward (scores are exact multiples of 5) */
-static float nw_identity(const std::string& a, const std::string& b)
-{
-    const int na = (int)a.size(), nb = (int)b.size();
-    std::vector<int32_t> sp(nb + 1), sc(nb + 1), mp(nb + 1, 0), mc(nb + 1, 0);
-    for (int j = 0; j <= nb; j++) sp[j] = -5 * j;
-    for (int i = 1; i <= na; i++) {
-        sc[0] = -5 * i; mc[0] = 0;
-        const char ai = a[i - 1];
-        for (int j = 1; j <= nb; j++) {
-            const bool eq = ai == b[j - 1];
-            const int diag = sp[j - 1] + (eq ? 10 : -5), del = sp[j] - 5, ins = sc[j - 1] - 5;
-            const int best = std::max(std::max(diag, del), ins);
-            sc[j] = best;
-            mc[j] = best == diag ? mp[j - 1] + (eq ? 1 : 0) : (best == del ? mp[j] : mc[j - 1]);
-        }
-        sp.swap(sc); mp.swap(mc);
-    }
-    float identity = (float)mp[nb];
-    identity /= std::max(na, nb);
-    return identity;
-}
-
 static int compute_qual(const Solution& s, bool repeated) /* src/Utils.hpp:85-103 */
 {
     int q = 50;
@@ -412,8 +388,16 @@ static void decode_slice(const uint64_t* words, uint32_t from, uint32_t L, bool 
     }
 }
 
-/* everything after the device kernels for one gapFillFromSource call, except the coverage numbers of the general path */
-static bool process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
+/* a gap whose solutions come out of the contig graph: candidate sequences per target (in the order the reference visits them), waiting
+ * for the alignments of remove_almost_identical_solutions, which run on the device for the whole batch */
+struct GenWork {
+    std::vector<std::vector<Solution>> groups;
+    std::vector<std::vector<int64_t>> pair; /* per group, n x n: index into the batch's NW pairs for (row j, column i < j); -2: equal strings */
+};
+
+/* everything after the device kernels for one gapFillFromSource call, except the de-duplication and the coverage numbers of the general
+ * path (returns the candidates of such a gap, nullptr otherwise) */
+static GenWork* process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
 {
     W.nb_nodes = (int)gc.o.n_contigs;
     W.total_nt = (int)gc.o.total_nt;
@@ -421,9 +405,9 @@ static bool process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
     if (gc.p.nb_terminal == 0) { /* get_first_contig, src/Filler.cpp:1381-1407 */
         W.extension.clear();
         if (gc.o.n_contigs > 0 && (int)gc.p.clen0 > k) W.extension = gc.contig0_slice((uint32_t)k, gc.p.clen0);
-        return false;
+        return nullptr;
     }
-    if (gc.p.fast == 2) { W.has_counts = W.reverse; return false; } /* target at the very start of contig 0: empty fill */
+    if (gc.p.fast == 2) { W.has_counts = W.reverse; return nullptr; } /* target at the very start of contig 0: empty fill */
     if (gc.p.fast == 1) {
         /* terminal node 0: find_all_paths_rev returns the single path [0] (src/GraphAnalysis.cpp:222-226) and
          * paths_to_sequences keeps contig0[k:pos] (:386-423); coverage was computed on the device */
@@ -444,8 +428,9 @@ static bool process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
         s.qual = compute_qual(s, W.anchor_repeated);
         W.nb_total_filled = 1;
         W.has_counts = true;
-        return false;
+        return nullptr;
     }
+    GenWork* gw = nullptr;
     std::vector<TermInfo> terms;
     for (uint32_t c = 0; c < gc.o.n_contigs; c++)
         if (gc.tpos[c] != 0xFFFFFFFFu) terms.push_back(TermInfo{(int)c, (int)gc.tpos[c], (int)gc.terr[c], (int)gc.ttgt[c]});
@@ -499,27 +484,53 @@ static bool process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
             if (!sequence.empty()) { Solution s; s.seq = std::move(sequence); s.nb_errors = errs; s.target = tgt; tmp.push_back(std::move(s)); }
         }
         W.nb_total_filled += (int)tmp.size();
-        if (tmp.size() > 1) { /* remove_almost_identical_solutions(.., 90), src/Utils.cpp:208-238 */
+        if (!tmp.empty()) { if (!gw) gw = new GenWork(); gw->groups.push_back(std::move(tmp)); }
+    }
+    W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
+    return gw;
+}
+
+/* remove_almost_identical_solutions(.., 90), src/Utils.cpp:208-238, for every group of a gap, with the match counts of the batch's
+ * alignments; then the solutions in their final order */
+static void finish_general(GapWork& W, GenWork& gw, const std::vector<uint32_t>& matches)
+{
+    for (size_t g = 0; g < gw.groups.size(); g++) {
+        std::vector<Solution>& tmp = gw.groups[g];
+        const size_t n = tmp.size();
+        if (n > 1) {
             std::vector<Solution> fin;
+            std::vector<size_t> fin_src; /* whose sequence a kept solution currently holds */
             fin.push_back(tmp[0]);
-            for (auto& a : tmp) {
+            fin_src.push_back(0);
+            for (size_t j = 0; j < n; j++) {
+                const Solution& a = tmp[j];
                 bool similar = false;
-                for (auto& b : fin) {
-                    if (a.seq == b.seq || nw_identity(a.seq.str(), b.seq.str()) * 100 >= 90) {
-                        if (a.nb_errors < b.nb_errors) { b.seq = a.seq; b.nb_errors = a.nb_errors; }
+                for (size_t f = 0; f < fin.size(); f++) {
+                    Solution& b = fin[f];
+                    const size_t i = fin_src[f];
+                    bool same = (i == j);
+                    if (!same) {
+                        const int64_t pi = gw.pair[g][j * n + i];
+                        if (pi == -2) same = true;
+                        else {
+                            float identity = (float)matches[(size_t)pi];
+                            identity /= std::max((int)a.seq.size(), (int)b.seq.size());
+                            same = identity * 100 >= 90;
+                        }
+                    }
+                    if (same) {
+                        if (a.nb_errors < b.nb_errors) { b.seq = a.seq; b.nb_errors = a.nb_errors; fin_src[f] = j; }
                         similar = true;
                         break;
                     }
                 }
-                if (!similar) fin.push_back(a);
+                if (!similar) { fin.push_back(a); fin_src.push_back(j); }
             }
             tmp.swap(fin);
         }
         int rank = 1;
         for (auto& s : tmp) { s.count = (int)tmp.size(); s.rank = rank++; s.ab_n = 1; W.sols.push_back(std::move(s)); }
     }
-    W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
-    return !W.sols.empty();
 }
 
 static std::string revcomp_str(const std::string& s) /* revcomp_sequence, src/Utils.cpp:44-77: other characters are dropped */
@@ -630,21 +641,47 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     for (size_t b = 0; b < nb; b++) blk_arena[b + 1] += blk_arena[b];
     tick("arena offsets");
     char* const arena_base = arena.ensure(blk_arena[nb] + 1);
-    std::vector<uint8_t> general(n, 0); /* gaps whose solutions came out of the host's path enumeration: coverage still to do */
+    std::vector<GenWork*> genw(n, nullptr); /* gaps whose solutions come out of the host's path enumeration */
+    struct GenGuard { std::vector<GenWork*>& v; ~GenGuard() { for (GenWork* g : v) delete g; } } gen_guard{genw};
     parallel_for(nb, nth, [&](size_t b) {
         uint64_t off = blk_arena[b], nsol = 0;
         for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) {
             const GapDev gd = dev[i];
-            general[i] = process_gap(gd, gaps[i], k, arena_base + off) ? 1 : 0;
+            genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
             off += gd.p.fast == 1 ? (uint64_t)(gd.p.pos - (uint32_t)k) + 1 : 0;
             nsol += gaps[i].sols.size();
         }
         blk_sols[b] = nsol;
     }, 1);
-    if (sol_blocks) sol_blocks->swap(blk_sols);
     tick("process gaps");
     std::vector<size_t> gen_idx;
-    for (size_t i = 0; i < n; i++) if (general[i]) gen_idx.push_back(i);
+    for (size_t i = 0; i < n; i++) if (genw[i]) gen_idx.push_back(i);
+    if (!gen_idx.empty()) {
+        /* every alignment remove_almost_identical_solutions can ask for: a later candidate (rows) against an earlier one (columns) */
+        std::vector<NwPair> pairs;
+        for (size_t gi : gen_idx) {
+            GenWork& gw = *genw[gi];
+            gw.pair.resize(gw.groups.size());
+            for (size_t g = 0; g < gw.groups.size(); g++) {
+                const std::vector<Solution>& tmp = gw.groups[g];
+                const size_t m = tmp.size();
+                if (m < 2) continue;
+                gw.pair[g].assign(m * m, -1);
+                for (size_t j = 1; j < m; j++)
+                    for (size_t i = 0; i < j; i++) {
+                        if (tmp[j].seq == tmp[i].seq) { gw.pair[g][j * m + i] = -2; continue; }
+                        gw.pair[g][j * m + i] = (int64_t)pairs.size();
+                        pairs.push_back(NwPair{tmp[j].seq.data(), (uint32_t)tmp[j].seq.size(), tmp[i].seq.data(), (uint32_t)tmp[i].seq.size()});
+                    }
+            }
+        }
+        std::vector<uint32_t> matches;
+        if (!pairs.empty()) { rc = nw_run(idx, pairs, matches); if (rc) return rc; }
+        parallel_for(gen_idx.size(), nth, [&](size_t ii) { finish_general(gaps[gen_idx[ii]], *genw[gen_idx[ii]], matches); }, 1);
+        for (size_t gi : gen_idx) blk_sols[gi / B] += gaps[gi].sols.size(); /* they had none when their block was counted */
+        tick("alignments");
+    }
+    if (sol_blocks) sol_blocks->swap(blk_sols);
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);
@@ -933,6 +970,21 @@ int mtg_index_scan_sequences(const mtg_index* idx, const char* const* seqs, size
             out[s][p] = (bad_until >= (int)p) ? 0 : (uint8_t)((bits[off[s] + (p >> 6)] >> (p & 63)) & 1);
         }
     }
+    return MTG_OK;
+}
+
+int mtg_nw_matches(const char* const* a, const char* const* b, size_t n, uint32_t* matches)
+{
+    if (n && (!a || !b || !matches)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    std::vector<mtgi::NwPair> pairs(n);
+    for (size_t i = 0; i < n; i++) {
+        if (!a[i] || !b[i]) { mtgi::set_error("pair %zu: null sequence", i); return MTG_ERR_ARG; }
+        pairs[i] = mtgi::NwPair{a[i], (uint32_t)strlen(a[i]), b[i], (uint32_t)strlen(b[i])};
+    }
+    std::vector<uint32_t> m;
+    int rc = mtgi::nw_run(nullptr, pairs, m);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) matches[i] = m[i];
     return MTG_OK;
 }
 

@@ -360,6 +360,16 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const u
  * histo.size()-1), kmers/counts = the distinct k-mers seen at least keep_min times (unordered) */
 int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<uint64_t>& histo, std::vector<uint64_t>& kmers, std::vector<uint32_t>& counts);
 
+/* Needleman-Wunsch of src/Utils.cpp:87-189 (match +10, mismatch -5, gap -5; traceback preference diagonal, up, left) for a batch of
+ * sequence pairs: matches[p] = number of matching positions along the traceback of pair p (a = rows, b = columns) */
+struct NwPair {
+    const char* a;
+    uint32_t na;
+    const char* b;
+    uint32_t nb;
+};
+int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches);
+
 int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
 
 void stats_store(const mtg_batch_stats& s);

@@ -118,6 +118,7 @@ def _bind(lib):
     lib.mtg_contigs_free.restype = None
     lib.mtg_last_batch_stats.argtypes = [P(BatchStats)]
     lib.mtg_fill_main.argtypes = [C.c_int, P(C.c_char_p)]
+    lib.mtg_nw_matches.argtypes = [P(C.c_char_p), P(C.c_char_p), C.c_size_t, P(C.c_uint32)]
     lib.mtg_bench_random_lines.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, P(C.c_double), P(C.c_double)]
     return lib
 
@@ -310,6 +311,16 @@ def fill_main(argv):
     """`MindTheGap fill <argv>` (Filler::run, src/main.cpp:105-120); returns the exit code."""
     arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
     return load_library().mtg_fill_main(len(argv), arr)
+
+
+def nw_matches(pairs):
+    """needleman_wunsch match counts (src/Utils.cpp:87-189) of [(a, b), ...] on the device; identity = matches / max(len(a), len(b))"""
+    n = len(pairs)
+    A = (C.c_char_p * n)(*[p[0].encode() for p in pairs])
+    B = (C.c_char_p * n)(*[p[1].encode() for p in pairs])
+    out = np.zeros(n, dtype=np.uint32)
+    _check(load_library().mtg_nw_matches(A, B, n, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return out
 
 
 def random_line_ceiling(table_bytes, n_chains, chain_len, line_bytes=64):

@@ -128,6 +128,31 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t, const uint64_t
     return MTG_OK;
 }
 
+/* stand-in for k_nw: the two-row integer DP with the traceback's match count carried forward (scores are exact multiples of 5) */
+int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches)
+{
+    matches.assign(pairs.size(), 0);
+    for (size_t p = 0; p < pairs.size(); p++) {
+        const int na = (int)pairs[p].na, nb = (int)pairs[p].nb;
+        const char *a = pairs[p].a, *b = pairs[p].b;
+        std::vector<int32_t> sp(nb + 1), sc(nb + 1), mp(nb + 1, 0), mc(nb + 1, 0);
+        for (int j = 0; j <= nb; j++) sp[j] = -5 * j;
+        for (int i = 1; i <= na; i++) {
+            sc[0] = -5 * i; mc[0] = 0;
+            for (int j = 1; j <= nb; j++) {
+                const bool eq = a[i - 1] == b[j - 1];
+                const int diag = sp[j - 1] + (eq ? 10 : -5), del = sp[j] - 5, ins = sc[j - 1] - 5;
+                const int best = std::max(std::max(diag, del), ins);
+                sc[j] = best;
+                mc[j] = best == diag ? mp[j - 1] + (eq ? 1 : 0) : (best == del ? mp[j] : mc[j - 1]);
+            }
+            sp.swap(sc); mp.swap(mc);
+        }
+        matches[p] = (uint32_t)mp[nb];
+    }
+    return MTG_OK;
+}
+
 /* the emulator keeps the marshalled input in the FillInput's own storage */
 void* staging_host(const mtg_index*, int, size_t) { return nullptr; }
 

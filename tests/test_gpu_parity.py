@@ -275,3 +275,40 @@ def test_scratch_tier_retry_inside_a_batch(mtg):
     res = g.fill_batch([mtg.Gap(s, t, [(t, "x", False)]) for s, t in zip(src, tgt)])
     assert all(len(r["filled"]) == 1 and len(r["filled"][0]["seq"]) == 469 for r in res)
     g.close(); o.close()
+
+
+def test_needleman_wunsch_kernel_matches_oracle(mtg):
+    """k_nw against the oracle's restatement of src/Utils.cpp:87-189: lengths around the 64-column strips, low-complexity sequences (ties in
+    the traceback), unrelated pairs, indels, a 6 kb pair"""
+    import random
+    from tests import oracle_lib
+    olib = oracle_lib.load()
+    rng = random.Random(5)
+    pairs = []
+    for _ in range(300):
+        na = rng.choice([1, 2, 3, 31, 63, 64, 65, 127, 128, 129, 200, 500, rng.randrange(1, 700)])
+        alpha = rng.choice(["ACGT", "AC", "A", "ACGT", "AAAC"])
+        a = "".join(rng.choice(alpha) for _ in range(na))
+        kind = rng.randrange(4)
+        if kind == 0:
+            b = "".join(rng.choice(alpha) for _ in range(rng.randrange(1, 700)))
+        else:
+            b = list(a)
+            for _ in range(rng.randrange(0, 1 + len(b) // 8)):
+                p = rng.randrange(len(b) + 1)
+                op = rng.randrange(3)
+                if op == 0 and p < len(b):
+                    b[p] = rng.choice("ACGT")
+                elif op == 1:
+                    b[p:p] = [rng.choice("ACGT") for _ in range(rng.randrange(1, 20))]
+                elif p < len(b):
+                    del b[p:p + rng.randrange(1, 20)]
+            b = "".join(b) or "A"
+        pairs.append((a, b))
+    big = "".join(rng.choice("ACGT") for _ in range(6000))
+    big2 = big[:1000] + big[1100:3000] + "ACGTACGT" * 20 + big[3000:]
+    pairs += [(big, big2), (big2, big), (big, big)]
+    got = mtg.nw_matches(pairs)
+    for (a, b), m in zip(pairs, got):
+        want = olib.mtgo_needleman_wunsch(a.encode(), b.encode())
+        assert np.float32(np.float32(m) / np.float32(max(len(a), len(b)))) == np.float32(want), (len(a), len(b), int(m), want)
