@@ -385,6 +385,53 @@ def _diploid_case(mtg_mod, tmp_path, nloci):
     o.close()
 
 
+def _allelic_inserts_case(mtg_mod, tmp_path, nloci):
+    """two alleles per insertion site that the bubble code cannot merge (a 30-nt indel, 15 % substitutions, unrelated inserts): the BFS
+    returns several contigs, the contig graph several paths per target, and remove_almost_identical_solutions aligns sequences of several
+    hundred nucleotides (the device's k_nw in the product, its stand-in on the emulator)"""
+    rng = random.Random(77)
+    seqs, sites = [], []
+    for i in range(nloci):
+        L, R = _rand_seq(rng, 400), _rand_seq(rng, 400)
+        a = _rand_seq(rng, rng.randrange(150, 900))
+        kind = i % 4
+        if kind == 0:    # long indel inside the insert
+            p = rng.randrange(40, len(a) - 80)
+            b = a[:p] + a[p + 30:]
+        elif kind == 1:  # diverged copy
+            b = "".join(c if rng.random() > 0.15 else rng.choice([x for x in "ACGT" if x != c]) for c in a)
+        elif kind == 2:  # unrelated insert of another length
+            b = _rand_seq(rng, rng.randrange(150, 900))
+        else:            # indel + a few substitutions far apart
+            p = rng.randrange(40, len(a) - 80)
+            b = list(a[:p] + _rand_seq(rng, 35) + a[p:])
+            for q in range(10, len(b) - 10, 97):
+                b[q] = rng.choice([x for x in "ACGT" if x != b[q]])
+            b = "".join(b)
+        seqs += [L + a + R, L + b + R]
+        sites.append((L[-31:], R[:31]))
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    idxf = str(tmp_path / "al.mtgidx")
+    _write_idx(idxf, km, ct)
+    bk = str(tmp_path / "al.breakpoints")
+    with open(bk, "w") as f:
+        for i, (l, r) in enumerate(sites):
+            f.write(">bkpt%d_s%d_pos_400_fuzzy_0_HOM left_kmer\n%s\n>bkpt%d_s%d_pos_400_fuzzy_0_HOM right_kmer\n%s\n" % (i, i, l, i, i, r))
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert mtg_mod.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    fa = _read(str(tmp_path / "hip.insertions.fasta"))
+    assert "solution 2/2" in fa and fa.count(">") > nloci  # both alleles reported somewhere, one allele kept elsewhere
+    o.close()
+
+
+def test_cli_on_emulator_allelic_inserts(emu_product, tmp_path):
+    _allelic_inserts_case(emu_product, tmp_path, 16)
+
+
 def test_cli_on_emulator_diploid(emu_product, tmp_path):
     _diploid_case(emu_product, tmp_path, 10)
 

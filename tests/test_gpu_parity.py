@@ -254,6 +254,12 @@ def test_diploid_bubbles(mtg, tmp_path):
     _diploid_case(mtg, tmp_path, 200)
 
 
+def test_allelic_inserts_general_path(mtg, tmp_path):
+    """multi-contig gaps: contig graph, reverse DFS, path sequences and k_nw-based de-duplication against the oracle"""
+    from tests.test_emu_parity import _allelic_inserts_case
+    _allelic_inserts_case(mtg, tmp_path, 120)
+
+
 def test_scratch_tier_retry_inside_a_batch(mtg):
     """one gap of the batch walks a 150 kb unitig and overflows the tier-0 contig arena: it is re-run in a larger tier on the device while
     its neighbours keep their tier-0 results; contigs identical to the oracle's"""
