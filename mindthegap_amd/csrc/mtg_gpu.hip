@@ -8,6 +8,8 @@
  *   k_post                           : terminal-node search per contig + coverage of the single-contig solution, one wave per gap;
  *                                      then the dense copy of what the host needs of the gap
  *                                      (find_nodes_containing_multiple_R, src/Filler.cpp:1294-1378; coverage :959-988)
+ *   k_paths                          : contig graph + reverse path enumeration of multi-contig gaps, one wave per gap
+ *                                      (find_all_paths_rev, src/GraphAnalysis.cpp:205-326)
  *   k_nw                             : Needleman-Wunsch match counts for the de-duplication of multi-path solutions, one wave per pair
  *                                      (remove_almost_identical_solutions, src/Utils.cpp:87-189,208-238)
  *   k_chase                          : dependent random 64-byte reads (measured roofline ceiling)
@@ -296,6 +298,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_
         r.o = o; r.p = po; r.nw = nw; r.nc = nc; r.pad_ = 0; r.wbase = wbase; r.cbase = cbase;
         recs[slot] = r;
     }
+}
+
+/* contig-graph walk of the multi-contig gaps of a chunk (mtg_paths.h), one wave per gap */
+__global__ void __launch_bounds__(64) k_paths(FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ slots, int k, uint32_t* out, uint32_t n)
+{
+    __shared__ PathsWork W;
+    if (blockIdx.x >= n) return;
+    const uint32_t slot = slots[blockIdx.x];
+    GapScratch S;
+    S.z = nullptr;
+    S.v = nullptr;
+    S.lane = 0;
+    S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    paths_gap(cfg, S, outs[slot], k, W, out + (uint64_t)blockIdx.x * PATHS_WORDS);
 }
 
 /* Needleman-Wunsch match count of src/Utils.cpp:87-189, one wave per sequence pair (a = rows, b = columns), exact for any length.
@@ -853,6 +869,25 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                     if (h_rec[s2].o.status != GAP_OK) { retry.push_back(g); continue; }
                     batch.chunk_of[g] = chunk_id;
                     batch.slot_of[g] = s2;
+                }
+            }
+            /* multi-contig gaps: their contig-graph paths, while the chunk's scratch is still in place */
+            static const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the enumeration to the host */
+            if (!host_paths) {
+                std::vector<uint32_t> gslots;
+                for (uint32_t s2 = 0; s2 < m; s2++)
+                    if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s2);
+                if (!gslots.empty()) {
+                    DevBuf d_gs, d_po;
+                    HIP_TRY(upload(d_gs, gslots));
+                    HIP_TRY(d_po.alloc(gslots.size() * (size_t)PATHS_WORDS * 4));
+                    hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
+                                       d_po.as<uint32_t>(), (uint32_t)gslots.size());
+                    HIP_TRY(hipGetLastError());
+                    hc.paths.resize(gslots.size() * (size_t)PATHS_WORDS);
+                    HIP_TRY(hipMemcpy(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost));
+                    hc.path_of.assign(m, -1);
+                    for (size_t g2 = 0; g2 < gslots.size(); g2++) hc.path_of[gslots[g2]] = (int32_t)g2;
                 }
             }
             tick("distribute");

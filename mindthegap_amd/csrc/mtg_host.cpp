@@ -438,7 +438,18 @@ static GenWork* process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slo
     /* find_all_paths_rev wrapper, src/GraphAnalysis.cpp:205-237.  The reference keeps set<pair<path, bkpt_t>>; paths
      * reaching different targets end in different nodes, so ordering by (path, target index) gives the same sequence. */
     std::vector<std::pair<Path, int>> paths;
-    if (terms[0].node == 0) {
+    if (gc.paths && gc.paths[0] == 0) {
+        /* enumerated on the device (k_paths); the reference keeps them in a set<pair<path, bkpt_t>>: same order after sorting */
+        const uint32_t* q = gc.paths + 2;
+        for (uint32_t i = 0; i < gc.paths[1]; i++) {
+            const int target = (int)q[0];
+            const uint32_t len = q[1];
+            paths.push_back({Path(q + 2, q + 2 + len), target});
+            q += 2 + len;
+        }
+        std::sort(paths.begin(), paths.end());
+        paths.erase(std::unique(paths.begin(), paths.end()), paths.end());
+    } else if (terms[0].node == 0) {
         paths.push_back({Path{0}, terms[0].target});
     } else {
         PathSet all;

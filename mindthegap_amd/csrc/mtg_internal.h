@@ -7,7 +7,7 @@
 #define MTG_INTERNAL_H
 #include "../../include/mtg_fill.h"
 #include "mtg_hostutil.h"
-#include "mtg_post.h"
+#include "mtg_paths.h"
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -204,6 +204,9 @@ struct HostChunk {
     const uint32_t* meta = nullptr;
     uint32_t m = 0;
     std::vector<uint64_t> own;
+    /* contig-graph paths of the multi-contig gaps of the chunk (k_paths): PATHS_WORDS words per such gap, path_of[slot] = its rank or -1 */
+    std::vector<uint32_t> paths;
+    std::vector<int32_t> path_of;
     /* carves recs / words / meta for m slots, tw words, tc metadata entries out of `block` (or out of `own` when block is null) */
     void carve(void* block, uint32_t m_, uint64_t tw, uint64_t tc, mtg::SlotRec*& r, uint64_t*& w, uint32_t*& mt)
     {
@@ -226,6 +229,7 @@ struct GapDev {
     uint32_t n_meta = 0;
     const uint64_t* words = nullptr;
     const uint32_t *len = nullptr, *word_start = nullptr, *tpos = nullptr, *terr = nullptr, *ttgt = nullptr;
+    const uint32_t* paths = nullptr; /* k_paths record of the gap (mtg_paths.h), if the device enumerated its paths */
     std::string contig(size_t i) const
     {
         std::string s;
@@ -253,8 +257,10 @@ struct DevBatch {
     GapDev operator[](size_t i) const
     {
         const HostChunk& c = chunk_of.empty() ? *chunks[0] : *chunks[chunk_of[i]];
-        const mtg::SlotRec& r = c.recs[chunk_of.empty() ? i : slot_of[i]];
+        const size_t slot = chunk_of.empty() ? i : slot_of[i];
+        const mtg::SlotRec& r = c.recs[slot];
         GapDev g;
+        if (!c.path_of.empty() && c.path_of[slot] >= 0) g.paths = c.paths.data() + (size_t)c.path_of[slot] * mtg::PATHS_WORDS;
         g.o = r.o;
         g.p = r.p;
         g.n_meta = r.nc;

@@ -207,6 +207,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 hm[3 * nc + i] = s_terr(cfg, S)[i];
                 hm[4 * nc + i] = s_ttgt(cfg, S)[i];
             }
+            if (!getenv("MTG_HOST_PATHS") && po.fast == 0 && po.nb_terminal > 0) { /* stand-in for k_paths */
+                PathsWork pw;
+                hc.paths.assign(PATHS_WORDS, 0);
+                paths_gap(cfg, S, o, idx->dev.k, pw, hc.paths.data());
+                hc.path_of.assign(1, 0);
+            }
             batch.chunk_of[g] = (uint32_t)batch.chunks.size() - 1;
             batch.slot_of[g] = 0;
             st.contig_nt += o.total_nt;
