@@ -222,8 +222,14 @@ __global__ void k_query(Index ix, const uint64_t* __restrict__ kmers, size_t n, 
     }
 }
 
+/* Index and configuration of the traversal kernel live in constant memory: its code takes them by reference all over (Worker, the
+ * bubble routines), and a by-value kernel argument whose address is taken is copied to private memory, which turned every field
+ * access into a per-lane scratch load; a reference to a __constant__ object stays a scalar load. */
+__constant__ Index c_ix;
+__constant__ FillCfg c_cfg;
+
 /* one gap per lane, one wave per workgroup (waves retire independently) */
-__global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
+__global__ void __launch_bounds__(64) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                 GapOut* out, uint32_t n)
@@ -231,13 +237,13 @@ __global__ void __launch_bounds__(64) k_stage_a(Index ix, FillCfg cfg, uint8_t* 
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
-    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    GapScratch S = carve(c_cfg, zero, raw, ilv, slot);
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];
     R.r0 = r0[g];
     GapOut o;
-    stage_a_gap(ix, cfg, S, src[g], R, o);
+    stage_a_gap(c_ix, c_cfg, S, src[g], R, o);
     out[slot] = o;
 }
 
@@ -810,7 +816,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             }
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 64, 0));
             HIP_TRY(hipEventRecord(ev0, 0));
-            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, idx->dev, cfg, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, 0));
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, 0));
+            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
                                d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
             HIP_TRY(hipEventRecord(ev1, 0));
             HIP_TRY(hipGetLastError());
