@@ -54,7 +54,7 @@ def main():
     import torch
     import torch.distributed as dist
     import mindthegap_amd as mtg
-    from mindthegap_amd.shard import gather_bytes
+    from mindthegap_amd.shard import PipelinedGather, gather_bytes
     from mindthegap_amd.synth import SynthSet
 
     lib = mtg.load_library()
@@ -113,12 +113,18 @@ def main():
     def rc(s):
         return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
 
-    def step(want_seqs=False):
+    pg = None  # N > 1: pipelined gather of every step's sequences on rank 0 (created after the first, untimed, step)
+
+    def step(want_seqs=False, final=False):
         """forward attempt for every site, reverse attempt (src/Filler.cpp:669-680) for the unfilled ones.  The results stay in the
-        library's result arena (mtg_results_get); they are only serialised when they have to travel (N > 1) or be checked."""
-        want_seqs = want_seqs or world > 1
+        library's result arena (mtg_results_get).  N > 1: every step's sequences are serialised into a page-locked buffer and gathered
+        on rank 0 over RCCL / xGMI while the next step runs; the final, untimed pass uses the blocking gather and is verified."""
         tp0 = time.perf_counter()
-        h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=want_seqs)
+        if pg is not None and not final:
+            h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=True, out=pg.buffer())
+            pg.submit(len(seqs))
+        else:
+            h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=want_seqs or final)
         st = mtg.last_batch_stats()
         tp1 = time.perf_counter()
         idx.free_results(h)
@@ -136,7 +142,7 @@ def main():
             n_filled += int((nf2 > 0).sum())
             for key in ("kernel_ms", "post_kernel_ms", "h2d_ms", "d2h_ms", "host_ms", "index_lines", "n_launches", "contig_nt"):
                 st[key] += st2[key]
-        if world > 1:  # results gathered on rank 0 over RCCL / xGMI (all_gather of sizes + padded gather)
+        if world > 1 and final:  # blocking gather (all_gather of sizes + padded gather)
             gather_bytes(seqs, dst=0, device=cdev)
         return n_filled, seqs, st
 
@@ -145,6 +151,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        step()  # untimed: sizes the gather buffers (the largest payload of any rank, plus head room)
+        cap = torch.tensor([idx.last_seq_bytes], dtype=torch.int64, device=cdev)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        pg = PipelinedGather(int(cap.item()) * 5 // 4 + (1 << 20), dst=0, device=cdev)
     for _ in range(a.warmup):
         step()
     barrier()
@@ -155,9 +166,11 @@ def main():
         n_filled, seqs, st = step()
         kernel_ms += st["kernel_ms"]; lines += st["index_lines"]; contig_nt += st["contig_nt"]; launches += st["n_launches"]
         host_ms += st["host_ms"]; d2h_ms += st["d2h_ms"]; post_ms += st["post_kernel_ms"]
+    if pg is not None:
+        pg.drain()  # the gathers still in flight belong to the timed steps
     barrier()
     elapsed = time.perf_counter() - t0
-    n_filled, seqs, _ = step(want_seqs=True)  # untimed pass whose sequences are verified below
+    n_filled, seqs, _ = step(want_seqs=True, final=True)  # untimed pass whose sequences are verified below
     if world > 1:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -254,8 +254,9 @@ class Index:
             arr[i] = CGap(g.source.encode(), g.target.encode(), m, seqs, names, rcs, int(g.is_anchor_repeated), int(g.reverse))
         return (arr, n, keep)
 
-    def fill_prepared(self, prepared, params=None, want_seqs=True):
-        """one mtg_fill_batch call; returns (results handle, n_filled per gap, uint8 array of the packed "seq\\n" bytes).  Free with free_results."""
+    def fill_prepared(self, prepared, params=None, want_seqs=True, out=None):
+        """one mtg_fill_batch call; returns (results handle, n_filled per gap, uint8 array of the packed "seq\\n" bytes).  Free with free_results.
+        out: optional uint8 array that receives the bytes (e.g. a page-locked buffer); self.last_seq_bytes = their number either way."""
         params = params or FillParams()
         arr, n, _ = prepared
         h = C.c_void_p()
@@ -267,9 +268,15 @@ class Index:
         _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nb), C.byref(ng)))
         if os.environ.get("MTG_BENCH_DEBUG"):
             sys.stderr.write("  [py] mtg_fill_batch %.1f ms, summary %.1f ms\n" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
+        self.last_seq_bytes = int(nb.value)
         if not want_seqs:
             return h, nf, None
-        buf = np.empty(max(int(nb.value), 1), dtype=np.uint8)
+        if out is not None:
+            if out.size < nb.value:
+                raise MtgError(2, "output buffer of %d bytes for %d bytes of sequences" % (out.size, nb.value))
+            buf = out
+        else:
+            buf = np.empty(max(int(nb.value), 1), dtype=np.uint8)
         _check(self.lib.mtg_results_copy_seqs(h, buf.ctypes.data_as(C.c_char_p), nb.value))
         return h, nf, buf[: nb.value]
 

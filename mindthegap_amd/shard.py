@@ -30,3 +30,81 @@ def gather_bytes(payload, dst=0, device=None):
     if rank != dst:
         return None
     return [b[:n].cpu().numpy() for b, n in zip(bufs, sizes)]
+
+
+class PipelinedGather:
+    """Per-step gather of a variable-length byte payload on rank dst that overlaps with the following steps: the payload is written
+    into a page-locked staging buffer, copied to the device on a side stream and gathered asynchronously (RCCL over xGMI; gloo with host
+    tensors in the CPU tests), double buffered.  Buffers have a fixed capacity agreed on beforehand; the first 16 bytes carry the
+    payload length."""
+
+    HEADER = 16
+
+    def __init__(self, capacity, dst=0, device=None, depth=2):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world, self.rank, self.dst, self.depth = dist.get_world_size(), dist.get_rank(), dst, depth
+        self.dev = device if device is not None else torch.device("cpu")
+        self.on_gpu = self.dev.type == "cuda"
+        n = int(capacity) + self.HEADER
+        self.stage = [torch.empty(n, dtype=torch.uint8) for _ in range(depth)]
+        if self.on_gpu:
+            self.stage = [t.pin_memory() for t in self.stage]
+            self.dbuf = [torch.empty(n, dtype=torch.uint8, device=self.dev) for _ in range(depth)]
+            self.stream = torch.cuda.Stream(device=self.dev)
+        else:
+            self.dbuf = self.stage
+            self.stream = None
+        self.recv = [[torch.empty(n, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] for _ in range(depth)] if self.rank == dst else None
+        self.work = [None] * depth
+        self.i = 0
+        self.done = -1  # buffer index of the last submitted step
+
+    def _wait(self, j):
+        if self.work[j] is not None:
+            if self.on_gpu:
+                with self.torch.cuda.stream(self.stream):
+                    self.work[j].wait()
+                self.stream.synchronize()
+            else:
+                self.work[j].wait()
+            self.work[j] = None
+
+    def buffer(self):
+        """numpy view of this step's payload area (capacity bytes); valid until submit()"""
+        j = self.i % self.depth
+        self._wait(j)
+        return self.stage[j].numpy()[self.HEADER:]
+
+    def submit(self, nbytes):
+        j = self.i % self.depth
+        if nbytes + self.HEADER > self.stage[j].numel():
+            raise ValueError("payload of %d bytes exceeds the agreed capacity" % nbytes)
+        self.stage[j].numpy()[: self.HEADER].view(np.int64)[0] = nbytes
+        if self.on_gpu:
+            self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
+            with self.torch.cuda.stream(self.stream):
+                self.dbuf[j].copy_(self.stage[j], non_blocking=True)
+                self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        else:
+            self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        self.done = j
+        self.i += 1
+
+    def drain(self):
+        for j in range(self.depth):
+            self._wait(j)
+        if self.on_gpu:
+            self.torch.cuda.synchronize(self.dev)
+
+    def last(self):
+        """after drain(): the payloads of the last submitted step, one numpy array per rank (rank dst only)"""
+        if self.rank != self.dst or self.done < 0:
+            return None
+        out = []
+        for t in self.recv[self.done]:
+            a = t.cpu().numpy()
+            n = int(a[: self.HEADER].view(np.int64)[0])
+            out.append(a[self.HEADER: self.HEADER + n].copy())
+        return out

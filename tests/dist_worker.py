@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 
 def main(out_path):
     import torch.distributed as dist
-    from mindthegap_amd.shard import gather_bytes, shard_range
+    from mindthegap_amd.shard import PipelinedGather, gather_bytes, shard_range
     from mindthegap_amd.synth import SynthSet
     from tests import emu_lib, oracle_lib
     dist.init_process_group("gloo")
@@ -29,7 +29,20 @@ def main(out_path):
     h, nf, seqs = idx.fill_prepared(mtg.Index.prepare_gaps(gaps))
     idx.free_results(h)
     parts = gather_bytes(np.asarray(seqs), dst=0)
+    # the per-step pipelined gather of bench.py: three steps in flight through two buffers, payloads written in place
+    import torch
+    cap = torch.tensor([len(seqs)], dtype=torch.int64)
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX)  # every rank must use the same capacity
+    pg = PipelinedGather(int(cap.item()) * 2 + 64, dst=0)
+    prepared = mtg.Index.prepare_gaps(gaps)
+    for step in range(3):
+        h, nf, s2 = idx.fill_prepared(prepared, out=pg.buffer())
+        idx.free_results(h)
+        pg.submit(len(s2))
+    pg.drain()
+    piped = pg.last()
     if rank == 0:
+        assert [p.tobytes() for p in piped] == [p.tobytes() for p in parts]
         with open(out_path, "wb") as f:
             for p in parts:
                 f.write(p.tobytes())
