@@ -318,3 +318,30 @@ def test_needleman_wunsch_kernel_matches_oracle(mtg):
     for (a, b), m in zip(pairs, got):
         want = olib.mtgo_needleman_wunsch(a.encode(), b.encode())
         assert np.float32(np.float32(m) / np.float32(max(len(a), len(b)))) == np.float32(want), (len(a), len(b), int(m), want)
+
+
+def test_pipelined_gather_on_rccl_single_rank(mtg):
+    """the N > 1 result path of bench.py (page-locked staging, side stream, asynchronous RCCL gather, double buffering) in a world of one
+    rank: the only RCCL configuration a one-GPU box offers"""
+    import torch
+    import torch.distributed as dist
+    from mindthegap_amd.shard import PipelinedGather
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dev = torch.device("cuda", 0)
+        pg = PipelinedGather(1 << 20, dst=0, device=dev)
+        rng = np.random.default_rng(1)
+        last = None
+        for step in range(5):
+            n = int(rng.integers(1, 1 << 20))
+            payload = rng.integers(0, 256, n, dtype=np.uint8)
+            pg.buffer()[:n] = payload
+            pg.submit(n)
+            last = payload
+        pg.drain()
+        got = pg.last()
+        assert len(got) == 1 and got[0].tobytes() == last.tobytes()
+    finally:
+        dist.destroy_process_group()
