@@ -47,8 +47,8 @@ struct FillCfg {
     uint64_t ilv_stride;  /* bytes per WAVE (64 gaps) in the lane-interleaved region */
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
-    uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_dfsf, o_dfsc,
-        o_dfsmask, o_dfsnt, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt;
+    uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_flaux0, o_flaux1, o_dfsf, o_dfsc,
+        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt;
 };
 
 enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
@@ -90,10 +90,13 @@ MTG_ILV(uint64_t, s_ifl0, c.o_ifl0)       /* nested frontline */
 MTG_ILV(uint64_t, s_ifl1, c.o_ifl1)
 MTG_ILV(uint8_t, s_flnt0, c.o_flnt0)
 MTG_ILV(uint8_t, s_flnt1, c.o_flnt1)
+MTG_ILV(uint32_t, s_flaux0, c.o_flaux0)   /* what is already known about a frontline node (node_aux) */
+MTG_ILV(uint32_t, s_flaux1, c.o_flaux1)
 MTG_ILV(uint64_t, s_dfsf, c.o_dfsf)       /* consensus enumeration stack */
 MTG_ILV(uint64_t, s_dfsc, c.o_dfsc)
 MTG_ILV(uint8_t, s_dfsmask, c.o_dfsmask)
 MTG_ILV(uint8_t, s_dfsnt, c.o_dfsnt)
+MTG_ILV(uint32_t, s_dfskid, c.o_dfskid)   /* node_aux of the children of a frame */
 MTG_ILV(uint8_t, s_cons, c.o_cons)        /* CONS_CAP x CONS_LEN nts */
 MTG_ILV(uint16_t, s_conslen, c.o_conslen)
 MTG_ILV(int32_t, s_nw, c.o_nw)            /* 4 rows x (CONS_LEN+1) */
@@ -133,10 +136,13 @@ inline void finalize_cfg(FillCfg& c)
     c.o_ifl1 = (uint32_t)b; b += 8ull * FL_CAP;
     c.o_flnt0 = (uint32_t)b; b += align_up(FL_CAP, 8);
     c.o_flnt1 = (uint32_t)b; b += align_up(FL_CAP, 8);
+    c.o_flaux0 = (uint32_t)b; b += 4ull * FL_CAP;
+    c.o_flaux1 = (uint32_t)b; b += 4ull * FL_CAP;
     c.o_dfsf = (uint32_t)b; b += 8ull * DFS_CAP;
     c.o_dfsc = (uint32_t)b; b += 8ull * DFS_CAP;
     c.o_dfsmask = (uint32_t)b; b += DFS_CAP;
     c.o_dfsnt = (uint32_t)b; b += DFS_CAP;
+    c.o_dfskid = (uint32_t)b; b += 4ull * DFS_CAP;
     c.o_cons = (uint32_t)b; b += align_up((uint64_t)CONS_CAP * CONS_LEN, 8);
     c.o_conslen = (uint32_t)b; b += align_up(2ull * CONS_CAP, 8);
     c.o_nw = (uint32_t)b; b += 4ull * 4 * (CONS_LEN + 1);
@@ -274,6 +280,28 @@ struct Worker {
     }
 };
 
+/* What one bucket read tells about the nodes ahead, carried along by the bubble routines so that they ask the index only for what
+ * they do not know yet.  node_aux of a node y: bit 31 = y has in-degree 1; bits 0..3 = c, bits 4.. = nucleotides: the next c nodes
+ * along y's single out-edge are known (y has out-degree 1 and leads, by the first nucleotide, to a node of in-degree 1 whose node_aux
+ * is this one shifted by one).  From a lookahead entry (MTG_LA_MAX = 14 nucleotides) at most 13 are kept so that it fits 32 bits. */
+enum : uint32_t { AUX_IN1 = 0x80000000u };
+enum : uint64_t { INV_SIMPLE = 1ull << 63, INV_KMER = (1ull << 62) - 1 }; /* flag on an entry of the involved list: known to be a simple node */
+/* node_aux of the successors of x, given x's right neighbourhood a (successors of x, their common in-edges, lookahead) */
+MTG_DEV uint32_t aux_of_children(const Adj& a)
+{
+    if (popc4(a.in) != 1) return 0u;
+    uint32_t aux = AUX_IN1;
+    if (popc4(a.out) == 1) {
+        uint32_t known = a.la & 15u;
+        if (known > 13u) known = 13u;
+        aux |= known | (((a.la >> 4) & ((1u << (2 * known)) - 1u)) << 4);
+    }
+    return aux;
+}
+/* node_aux of the single successor of a node whose own node_aux has a positive count */
+MTG_DEV uint32_t aux_step(uint32_t aux) { return AUX_IN1 | ((aux & 15u) - 1u) | (((aux & 0x7FFFFFFFu) >> 6) << 4); }
+MTG_DEV uint64_t inv_flags(uint32_t aux) { return (aux & 15u) ? INV_SIMPLE : 0ull; }
+
 /* [MEM] gatb FrontlineBranching::check: look for large in-branching at m.
  * dir: 0 = frontline moves along successors.  Only used with dir 0 on this path. */
 MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
@@ -336,25 +364,32 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
     int cur = 0, ncur = 1, depth = 0;
     s_fl0(W.cfg, W.S)[0] = start.f;
     s_flnt0(W.cfg, W.S)[0] = 255;
+    s_flaux0(W.cfg, W.S)[0] = 0;
     for (;;) {
         const SP<uint64_t> cf = cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S);
         const SP<uint8_t> cn = cur ? s_flnt1(W.cfg, W.S) : s_flnt0(W.cfg, W.S);
+        const SP<uint32_t> ca = cur ? s_flaux1(W.cfg, W.S) : s_flaux0(W.cfg, W.S);
         const SP<uint64_t> nf = cur ? s_fl0(W.cfg, W.S) : s_fl1(W.cfg, W.S);
         const SP<uint8_t> nn = cur ? s_flnt0(W.cfg, W.S) : s_flnt1(W.cfg, W.S);
+        const SP<uint32_t> na = cur ? s_flaux0(W.cfg, W.S) : s_flaux1(W.cfg, W.S);
         int nnext = 0;
         for (int i = 0; i < ncur; i++) {
-            if (depth > 0 && !fl_check(W, cf[i])) return 0;
+            const uint32_t aux = ca[i];
+            /* a node of in-degree 1 passes the check at once (its only predecessor is the frontline node it was reached from) */
+            if (depth > 0 && !(aux & AUX_IN1) && !fl_check(W, cf[i])) return 0;
             Kmer x = make_kmer(cf[i], k);
-            Adj a = adj_right(W.ix, x, W.mk1, W.lines);
+            uint32_t out, kid;
+            if (aux & 15u) { out = 1u << ((aux >> 4) & 3u); kid = aux_step(aux); } /* the way ahead is known: nothing to read */
+            else { const Adj a = adj_right(W.ix, x, W.mk1, W.lines); out = a.out; kid = aux_of_children(a); }
             for (uint32_t nt = 0; nt < 4; nt++) {
-                if (!(a.out & (1u << nt))) continue;
+                if (!(out & (1u << nt))) continue;
                 Kmer y = kmer_next(x, nt, k, W.mk);
                 uint64_t cy = canon(y);
                 if (!W.seen_test_add(cy)) continue;  /* already explored (on failure below the whole set is discarded anyway) */
                 if (W.is_marked(cy)) return 0; /* bubble touches an assembled region */
-                if (nnext < FL_CAP) { nf[nnext] = y.f; nn[nnext] = (cn[i] == 255) ? (uint8_t)nt : cn[i]; }
+                if (nnext < FL_CAP) { nf[nnext] = y.f; nn[nnext] = (cn[i] == 255) ? (uint8_t)nt : cn[i]; na[nnext] = kid; }
                 nnext++;
-                W.involve(cy);
+                W.involve(cy | inv_flags(kid));
             }
             if (W.status) return 0;
         }
@@ -381,6 +416,7 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
     const SP<uint64_t> dfs_c = s_dfsc(W.cfg, W.S);
     const SP<uint8_t> dfs_mask = s_dfsmask(W.cfg, W.S);
     const SP<uint8_t> dfs_nt = s_dfsnt(W.cfg, W.S);
+    const SP<uint32_t> dfs_kid = s_dfskid(W.cfg, W.S);
     const SP<uint8_t> cons = s_cons(W.cfg, W.S);
     const SP<uint16_t> cons_len = s_conslen(W.cfg, W.S);
     ncons = 0;
@@ -439,8 +475,14 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
                 ncons++;
                 dfs_mask[d] = 0; /* return */
             } else {
-                Kmer x = make_kmer(dfs_f[d], k);
-                dfs_mask[d] = (uint8_t)adj_right(W.ix, x, W.mk1, W.lines).out;
+                const uint32_t aux = d ? dfs_kid[d - 1] : 0u; /* what the parent's read told about this node */
+                if (aux & 15u) { dfs_mask[d] = (uint8_t)(1u << ((aux >> 4) & 3u)); dfs_kid[d] = aux_step(aux); }
+                else {
+                    Kmer x = make_kmer(dfs_f[d], k);
+                    const Adj a = adj_right(W.ix, x, W.mk1, W.lines);
+                    dfs_mask[d] = (uint8_t)a.out;
+                    dfs_kid[d] = aux_of_children(a);
+                }
             }
         }
         uint32_t mask = dfs_mask[d];
@@ -625,10 +667,12 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
     const SP<uint64_t> inv = s_inv(W.cfg, W.S);
     MTG_T0(t_mi);
     for (uint32_t i = 0; i < W.n_inv; i++) {
+        const uint64_t e = inv[i];
+        if (e & INV_SIMPLE) continue; /* one in-edge, one out-edge: not branching */
         Kmer x;
-        x.f = inv[i];
+        x.f = e & INV_KMER;
         x.r = revcomp(x.f, W.k);
-        if (W.is_branching(x)) W.mark_canon(inv[i]);
+        if (W.is_branching(x)) W.mark_canon(x.f);
     }
     MTG_T1(t_mi, 5);
     return s_conslen(W.cfg, W.S)[chosen];
