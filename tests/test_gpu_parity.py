@@ -345,3 +345,37 @@ def test_pipelined_gather_on_rccl_single_rank(mtg):
         assert len(got) == 1 and got[0].tobytes() == last.tobytes()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [31, 21, 16, 13])
+def test_stage_a_fuzz_on_device(mtg, k):
+    """the random graphs of the CPU-side fuzz (repeats, SNP / indel bubbles, tips, loops) and circular genomes through k_stage_a, every
+    k-mer size class: 31, 21 (bulk steps), 16 (smallest bulk size), 13 (per-nucleotide steps only); cut-offs and both end rules"""
+    import random
+    from tests import oracle_lib
+    from tests.test_emu_parity import _make_case, _rand_seq
+    for seed in range(12):
+        rng, g, seqs = _make_case(seed, k)
+        if seed % 3 == 2:  # a circular simple path next to the linear genome
+            c = _rand_seq(rng, rng.randrange(k + 5, 300))
+            seqs = seqs + [c + c[:k - 1]]
+            g = g + "N" + c + c[:k - 1]
+        o = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = o.export()
+        idx = mtg.Index.from_kmers(km, ct, k)
+        for mn, md, er in ((100, 10000, 0), (5, 300, 1), (20, 1500, 0)):
+            src, tgt = [], []
+            while len(src) < 24:
+                p = rng.randrange(0, len(g) - k)
+                s = g[p:p + k]
+                tp = rng.randrange(0, len(g) - k)
+                t = g[tp:tp + k]
+                if "N" in s or "N" in t:
+                    continue
+                src.append(s if rng.random() < 0.5 else _rc(s))
+                tgt.append(t)
+            got = idx.stage_a(src, tgt, mtg.FillParams(max_nodes=mn, max_depth=md, end_rule_nonbranching=er))
+            for s, t, c in zip(src, tgt, got):
+                assert c == o.stage_a(s, t, oracle_lib.default_params(max_nodes=mn, max_depth=md, end_rule_nonbranching=er))[0], (seed, k, s, t, mn, md, er)
+        idx.close()
+        o.close()
