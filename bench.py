@@ -160,12 +160,12 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = lines = contig_nt = launches = host_ms = d2h_ms = post_ms = 0
+    kernel_ms = lines = contig_nt = launches = host_ms = d2h_ms = post_ms = call_ms = 0
     n_filled, seqs = 0, np.empty(0, dtype=np.uint8)
     for _ in range(a.steps):
         n_filled, seqs, st = step()
         kernel_ms += st["kernel_ms"]; lines += st["index_lines"]; contig_nt += st["contig_nt"]; launches += st["n_launches"]
-        host_ms += st["host_ms"]; d2h_ms += st["d2h_ms"]; post_ms += st["post_kernel_ms"]
+        host_ms += st["host_ms"]; d2h_ms += st["d2h_ms"]; post_ms += st["post_kernel_ms"]; call_ms += st["total_ms"]
     if pg is not None:
         pg.drain()  # the gathers still in flight belong to the timed steps
     barrier()
@@ -254,7 +254,8 @@ def main():
                       "index": "exact k-mer set of the donor, abundance = 3 + hash %% 40 (no reads simulated)", "nb_solid_kmers": int(info["nb_solid_kmers"]),
                       "index_bytes": int(info["device_bytes"]), "index_build_s": t_index, "genome_gen_s": t_gen},
            "filled": n_filled_all, "filled_sequences_identical_to_truth": identical,
-           "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "post_kernel": post_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps},
+           "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "post_kernel": post_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps,
+                                 "c_call": call_ms / a.steps},
            "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:

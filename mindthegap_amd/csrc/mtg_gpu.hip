@@ -720,9 +720,10 @@ void* staging_host(const mtg_index* idx, int slot, size_t bytes)
 }
 
 /* The caller holds idx->ws.mtx (the workspace and the staging blocks belong to one batch at a time). */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* overlap)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* before_post,
+               const std::function<void()>* while_busy)
 {
-    bool overlap_done = false;
+    bool before_done = false, busy_done = false;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
     double tk = now_ms();
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
@@ -733,7 +734,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     batch.slot_of.clear();
     batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
-    if (n == 0) { if (overlap) (*overlap)(); if (stats) *stats = st; return MTG_OK; }
+    if (n == 0) { if (before_post) (*before_post)(); if (while_busy) (*while_busy)(); if (stats) *stats = st; return MTG_OK; }
     const int k = idx->dev.k;
 
     int ws_next = 0;
@@ -823,12 +824,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             HIP_TRY(hipEventRecord(ev1, 0));
             HIP_TRY(hipGetLastError());
             tick("host prep+launch");
-            if (overlap && !overlap_done) { overlap_done = true; (*overlap)(); tick("overlapped host work"); } /* the device is busy: the caller's turn */
+            if (before_post && !before_done) { before_done = true; (*before_post)(); tick("host work before k_post"); } /* the device is busy: the caller's turn */
             if (!targets_sent) { targets_sent = true; HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, 0)); }
             hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_cnt.as<unsigned long long>(), d_rec.as<SlotRec>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), m);
             HIP_TRY(hipEventRecord(ev2, 0));
             HIP_TRY(hipGetLastError());
+            if (while_busy && !busy_done) { busy_done = true; (*while_busy)(); tick("host work during kernels"); }
             unsigned long long totals[2] = {0, 0};
             HIP_TRY(hipMemcpy(totals, d_cnt.p, 16, hipMemcpyDeviceToHost)); /* waits for the kernels */
             tick("kernels");
@@ -854,17 +856,19 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             tick("d2h");
             t0 = now_ms();
             std::atomic<uint64_t> nt_sum{0}, lines{0};
-            std::atomic<bool> any_retry_a{false};
+            std::atomic<bool> any_retry_a{false}, any_general{false};
             parallel_for(((size_t)m + 4095) / 4096, p->nb_host_threads, [&](size_t b) {
                 uint64_t l = 0, t = 0;
-                bool r = false;
+                bool r = false, gen = false;
                 for (uint32_t s2 = (uint32_t)(b * 4096); s2 < std::min<uint64_t>(m, (b + 1) * 4096); s2++) {
                     l += h_rec[s2].o.lines;
                     if (h_rec[s2].o.status != GAP_OK) { r = true; continue; }
                     t += h_rec[s2].o.total_nt;
+                    if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gen = true;
                 }
                 lines += l; nt_sum += t;
                 if (r) any_retry_a = true;
+                if (gen) any_general = true;
             }, 1);
             const bool any_retry = any_retry_a.load();
             st.index_lines += lines.load();
@@ -881,7 +885,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             }
             /* multi-contig gaps: their contig-graph paths, while the chunk's scratch is still in place */
             static const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the enumeration to the host */
-            if (!host_paths) {
+            if (!host_paths && any_general.load()) {
                 std::vector<uint32_t> gslots;
                 for (uint32_t s2 = 0; s2 < m; s2++)
                     if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s2);
@@ -918,7 +922,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
     }
 #endif
-    if (overlap && !overlap_done) (*overlap)();
+    if (before_post && !before_done) (*before_post)();
+    if (while_busy && !busy_done) (*while_busy)();
     if (rc == MTG_OK && n_todo) {
         set_error("%zu gap(s) exceeded the largest traversal scratch tier", n_todo);
         rc = MTG_ERR_OVERFLOW;

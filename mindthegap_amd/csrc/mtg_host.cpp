@@ -629,13 +629,9 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     DevBatch batch;
     DevBatch& dev = batch;
     double t_marshal = 0;
-    const std::function<void()> overlap = [&]() {
-        const double t = now_ms();
-        parallel_for(n, nth, [&](size_t i) { src.targets(i, in); }, 512);
-        src.marshal(in, nth);
-        t_marshal = now_ms() - t;
-    };
-    int rc = device_run(idx, p, in, batch, &st, &overlap);
+    const std::function<void()> before_post = [&]() { parallel_for(n, nth, [&](size_t i) { src.targets(i, in); }, 512); };
+    const std::function<void()> while_busy = [&]() { const double t = now_ms(); src.marshal(in, nth); t_marshal = now_ms() - t; };
+    int rc = device_run(idx, p, in, batch, &st, &before_post, &while_busy);
     if (rc) return rc;
     if (dbg) fprintf(stderr, "  [fill_gaps] marshal (overlapped)   %.2f ms\n", t_marshal);
     std::vector<GapWork>& gaps = src.gaps();

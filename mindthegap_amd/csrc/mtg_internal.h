@@ -353,9 +353,11 @@ struct FillInput {
     static size_t n8(size_t n) { return (n + 7) & ~(size_t)7; }
 };
 
-/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status.  `overlap`, when given, is called
- * once on the calling thread while the device works on the first chunk. */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats, const std::function<void()>* overlap = nullptr);
+/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status.  The two hooks run once on the
+ * calling thread while the device works on the first chunk: `before_post` after the traversal kernel has been launched (it has to
+ * fill block C of the input, which is then sent and the post-processing kernel launched), `while_busy` after that launch. */
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats, const std::function<void()>* before_post = nullptr,
+               const std::function<void()>* while_busy = nullptr);
 enum { STAGING_CHUNK0 = 3 }; /* first staging block used for results */
 
 /* membership scan over packed sequences: host arrays in (words/off/len), bit output as in mtg_index_scan_packed_device; device = 1: the pointers are device pointers */

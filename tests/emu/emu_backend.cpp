@@ -156,9 +156,11 @@ int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint3
 /* the emulator keeps the marshalled input in the FillInput's own storage */
 void* staging_host(const mtg_index*, int, size_t) { return nullptr; }
 
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* overlap)
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* before_post,
+               const std::function<void()>* while_busy)
 {
-    if (overlap) (*overlap)();
+    if (before_post) (*before_post)();
+    if (while_busy) (*while_busy)();
     const size_t n = in.src.size();
     batch.n = n;
     batch.chunk_of.assign(n, 0);
