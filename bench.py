@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--nseq", type=int, default=0)
     ap.add_argument("--cpu-sites", type=int, default=30000, help="sites of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-index-seqs", type=int, default=30000, help="donor sequences in the CPU baseline's index")
+    ap.add_argument("--host-threads", type=int, default=-1, help="host threads per rank for the per-gap passes (default: all cores, at most 64, shared between the ranks)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the random-64B-line ceiling micro-benchmark")
     return ap.parse_args()
 
@@ -106,7 +107,7 @@ def main():
         expected.append(ins)
     prepared = mtg.Index.prepare_gaps(gaps)
     # N ranks share the host: each gets its share of the cores for the per-gap host passes (0 = the library's default, up to 64 threads)
-    host_threads = 0 if world == 1 else max(4, min(64, (os.cpu_count() or 64) // world))
+    host_threads = a.host_threads if a.host_threads >= 0 else (0 if world == 1 else max(4, min(64, (os.cpu_count() or 64) // world)))
     params = mtg.FillParams(max_nodes=100, max_depth=10000, nb_host_threads=host_threads)
     exp_digest = hashlib.sha256(("\n".join(expected) + "\n").encode()).hexdigest()
 
