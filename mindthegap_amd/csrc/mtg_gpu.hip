@@ -254,11 +254,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
                                              uint32_t want_all, unsigned long long* counters, SlotRec* recs, uint64_t* dense_words, uint32_t* dense_meta,
-                                             uint32_t n)
+                                             uint32_t slot_base, uint32_t n)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint64_t s_base[2];
-    const uint32_t slot = blockIdx.x;
+    const uint32_t slot = slot_base + blockIdx.x; /* this launch covers the slots [slot_base, n) */
     if (slot >= n) return;
     for (uint32_t i = threadIdx.x; i < 256; i += 64) hist[i] = 0;
     __syncthreads();
@@ -631,6 +631,7 @@ void index_release(mtg_index* idx)
     if (!idx) return;
     for (int i = 0; i < Workspace::NSLOTS; i++) if (idx->ws.ptr[i]) (void)hipFree(idx->ws.ptr[i]);
     for (int i = 0; i < Workspace::NHOST; i++) if (idx->ws.hptr[i]) (void)hipHostFree(idx->ws.hptr[i]);
+    if (idx->ws.copy_stream) (void)hipStreamDestroy((hipStream_t)idx->ws.copy_stream);
     index_forget_host_copy(idx);
     free_tables(idx);
     delete idx;
@@ -719,9 +720,21 @@ void* staging_host(const mtg_index* idx, int slot, size_t bytes)
     return ws.hptr[slot];
 }
 
-/* The caller holds idx->ws.mtx (the workspace and the staging blocks belong to one batch at a time). */
+namespace {
+struct EventSet { /* events of one device_run call */
+    std::vector<hipEvent_t> ev;
+    ~EventSet() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    hipError_t make(hipEvent_t& e) { hipError_t r = hipEventCreate(&e); if (r == hipSuccess) ev.push_back(e); return r; }
+};
+} // namespace
+
+/* The caller holds idx->ws.mtx (the workspace and the staging blocks belong to one batch at a time).
+ *
+ * One traversal launch covers as many gaps as fit the scratch; its post-processing runs as up to MTG_POST_PARTS launches over
+ * consecutive slot ranges, each with its own dense arrays and counters, so that a part's results travel back (copy stream) and are
+ * handed to the caller (on_ready) while the device works on the next part. */
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* before_post,
-               const std::function<void()>* while_busy)
+               const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)
 {
     bool before_done = false, busy_done = false;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -730,6 +743,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     if (int rc = ensure_device()) return rc;
     const size_t n = in.src.size();
     batch.n = n;
+    batch.part = ~(size_t)0;
     batch.chunk_of.clear();
     batch.slot_of.clear();
     batch.chunks.clear();
@@ -741,12 +755,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     auto wsbuf = [&]() { WsBuf b; b.ws = &idx->ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
           d_dm = wsbuf(), d_cnt = wsbuf();
-    /* the marshalled input: two blocks, two copies */
+    /* the marshalled input: blocks A and B now, block C (targets) once the caller has filled it */
     double t0 = now_ms();
     HIP_TRY(d_ina.alloc(in.bytes_a));
     HIP_TRY(d_inb.alloc(in.bytes_b));
     HIP_TRY(d_inc.alloc(in.bytes_c));
-    HIP_TRY(d_cnt.alloc(64));
+    HIP_TRY(d_cnt.alloc(16 * MTG_POST_PARTS));
     HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, 0));
     const uint8_t* da = d_ina.as<uint8_t>();
@@ -759,20 +773,33 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     const uint8_t* d_mis = da + FillInput::off_a(n, 6);
     const uint8_t* d_fok = da + FillInput::off_a(n, 7);
     const uint64_t* d_rw = d_inb.as<uint64_t>();
-    const uint64_t* d_tle = d_inc.as<uint64_t>(); /* sent after the overlapped host work, which is what fills it */
+    const uint64_t* d_tle = d_inc.as<uint64_t>(); /* sent after the caller's before_post work, which is what fills it */
     const uint64_t* d_tbad = d_tle + in.tle.size();
     bool targets_sent = false;
     st.h2d_ms += now_ms() - t0;
     tick("upload (async)");
 
-    hipEvent_t ev0, ev1, ev2;
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventCreate(&ev2));
+    EventSet events;
+    hipEvent_t ev0, ev1, ev2, evp[MTG_POST_PARTS];
+    HIP_TRY(events.make(ev0));
+    HIP_TRY(events.make(ev1));
+    HIP_TRY(events.make(ev2));
+    for (int q = 0; q < MTG_POST_PARTS; q++) HIP_TRY(events.make(evp[q]));
+    if (!idx->ws.copy_stream) {
+        hipStream_t cs;
+        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        idx->ws.copy_stream = (void*)cs;
+    }
+    hipStream_t copy_stream = (hipStream_t)idx->ws.copy_stream;
+    unsigned long long* h_tot = (unsigned long long*)staging_host(idx, Workspace::NHOST - 1, 16 * MTG_POST_PARTS);
+    std::vector<unsigned long long> h_tot_own(2 * MTG_POST_PARTS, 0);
+    if (!h_tot) h_tot = h_tot_own.data();
 
     std::vector<uint32_t> todo; /* empty at tier 0: every gap, in order */
     size_t n_todo = n;
     int rc = MTG_OK;
+    static const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the path enumeration to the host */
+    static const int env_parts = getenv("MTG_POST_PARTS") ? atoi(getenv("MTG_POST_PARTS")) : 0; /* test hook */
 
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
@@ -800,22 +827,19 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         std::vector<uint32_t> retry;
         for (size_t base = 0; base < n_todo; base += chunk) {
             const uint32_t m = (uint32_t)std::min(chunk, n_todo - base);
-            batch.chunks.emplace_back(new HostChunk());
-            HostChunk& hc = *batch.chunks.back();
-            const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
-            const bool identity = todo.empty() && base == 0 && m == n; /* the whole batch in one chunk: slot = gap */
+            const bool identity = todo.empty() && base == 0 && m == n; /* the whole batch in one traversal launch: slot = gap */
             const uint32_t* ids = nullptr;
             std::vector<uint32_t> seq_ids;
+            const uint32_t* host_ids = nullptr; /* gap of every slot of this launch (nullptr: identity) */
             if (!identity) {
                 t0 = now_ms();
-                const uint32_t* src_ids = nullptr;
-                if (todo.empty()) { seq_ids.resize(m); for (uint32_t s = 0; s < m; s++) seq_ids[s] = (uint32_t)(base + s); src_ids = seq_ids.data(); }
-                else src_ids = todo.data() + base;
-                HIP_TRY(hipMemcpy(d_ids.p, src_ids, (size_t)m * 4, hipMemcpyHostToDevice));
+                if (todo.empty()) { seq_ids.resize(m); for (uint32_t s = 0; s < m; s++) seq_ids[s] = (uint32_t)(base + s); host_ids = seq_ids.data(); }
+                else host_ids = todo.data() + base;
+                HIP_TRY(hipMemcpy(d_ids.p, host_ids, (size_t)m * 4, hipMemcpyHostToDevice));
                 ids = d_ids.as<uint32_t>();
                 st.h2d_ms += now_ms() - t0;
             }
-            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 64, 0));
+            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16 * MTG_POST_PARTS, 0));
             HIP_TRY(hipEventRecord(ev0, 0));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, 0));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, 0));
@@ -826,92 +850,118 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             tick("host prep+launch");
             if (before_post && !before_done) { before_done = true; (*before_post)(); tick("host work before k_post"); } /* the device is busy: the caller's turn */
             if (!targets_sent) { targets_sent = true; HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, 0)); }
-            hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
-                               in.want_all_contigs ? 1u : 0u, d_cnt.as<unsigned long long>(), d_rec.as<SlotRec>(), d_dw.as<uint64_t>(), d_dm.as<uint32_t>(), m);
+            /* post-processing in parts */
+            uint32_t nparts = env_parts > 0 ? (uint32_t)env_parts : (m >= 16384 ? (uint32_t)MTG_POST_PARTS : 1u);
+            if (nparts > (uint32_t)MTG_POST_PARTS) nparts = MTG_POST_PARTS;
+            uint32_t psize = (((m + nparts - 1) / nparts) + 63u) & ~63u; /* slots per part */
+            if (psize == 0) psize = 64;
+            nparts = (m + psize - 1) / psize;
+            for (uint32_t q = 0; q < nparts; q++) {
+                const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize);
+                hipLaunchKernelGGL(k_post, dim3(s1 - s0), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis,
+                                   d_fok, in.want_all_contigs ? 1u : 0u, d_cnt.as<unsigned long long>() + 2 * q, d_rec.as<SlotRec>(),
+                                   d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, s0, s1);
+                HIP_TRY(hipMemcpyAsync(h_tot + 2 * q, d_cnt.as<unsigned long long>() + 2 * q, 16, hipMemcpyDeviceToHost, 0));
+                HIP_TRY(hipEventRecord(evp[q], 0));
+            }
             HIP_TRY(hipEventRecord(ev2, 0));
             HIP_TRY(hipGetLastError());
             if (while_busy && !busy_done) { busy_done = true; (*while_busy)(); tick("host work during kernels"); }
-            unsigned long long totals[2] = {0, 0};
-            HIP_TRY(hipMemcpy(totals, d_cnt.p, 16, hipMemcpyDeviceToHost)); /* waits for the kernels */
-            tick("kernels");
+            const uint32_t first_chunk = (uint32_t)batch.chunks.size();
+            if (identity) batch.part = psize;
+            else if (batch.chunk_of.empty()) {
+                /* results are scattered over chunks from here on: keep an explicit map (earlier chunks, if any, came from an identity launch) */
+                batch.chunk_of.assign(n, 0);
+                batch.slot_of.resize(n);
+                for (size_t i = 0; i < n; i++) { batch.chunk_of[i] = batch.part == ~(size_t)0 ? 0u : (uint32_t)(i / batch.part); batch.slot_of[i] = batch.part == ~(size_t)0 ? (uint32_t)i : (uint32_t)(i % batch.part); }
+            }
+            for (uint32_t q = 0; q < nparts; q++) {
+                const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize), mq = s1 - s0;
+                HIP_TRY(hipEventSynchronize(evp[q]));
+                if (q == 0) tick("first part ready");
+                t0 = now_ms();
+                const uint64_t tw = h_tot[2 * q], tc = h_tot[2 * q + 1];
+                batch.chunks.emplace_back(new HostChunk());
+                HostChunk& hc = *batch.chunks.back();
+                const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
+                SlotRec* h_rec = nullptr;
+                uint64_t* h_w = nullptr;
+                uint32_t* h_m = nullptr;
+                void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST - 1 ? staging_host(idx, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(mq, tw, tc)) : nullptr;
+                hc.carve(block, mq, tw, tc, h_rec, h_w, h_m);
+                HIP_TRY(hipStreamWaitEvent(copy_stream, evp[q], 0));
+                HIP_TRY(hipMemcpyAsync(h_rec, d_rec.as<SlotRec>() + s0, (size_t)mq * sizeof(SlotRec), hipMemcpyDeviceToHost, copy_stream));
+                if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, tw * 8, hipMemcpyDeviceToHost, copy_stream));
+                if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, tc * 20, hipMemcpyDeviceToHost, copy_stream));
+                HIP_TRY(hipStreamSynchronize(copy_stream));
+                h_w[tw] = 0;
+                st.d2h_ms += now_ms() - t0;
+                t0 = now_ms();
+                std::atomic<uint64_t> nt_sum{0}, lines{0};
+                std::atomic<bool> any_retry_a{false}, any_general{false};
+                parallel_for(((size_t)mq + 4095) / 4096, p->nb_host_threads, [&](size_t b) {
+                    uint64_t l = 0, t = 0;
+                    bool r = false, gen = false;
+                    for (uint32_t s2 = (uint32_t)(b * 4096); s2 < std::min<uint64_t>(mq, (b + 1) * 4096); s2++) {
+                        l += h_rec[s2].o.lines;
+                        if (h_rec[s2].o.status != GAP_OK) { r = true; continue; }
+                        t += h_rec[s2].o.total_nt;
+                        if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gen = true;
+                    }
+                    lines += l; nt_sum += t;
+                    if (r) any_retry_a = true;
+                    if (gen) any_general = true;
+                }, 1);
+                const bool any_retry = any_retry_a.load();
+                st.index_lines += lines.load();
+                st.contig_nt += nt_sum.load();
+                if (!identity) {
+                    for (uint32_t s2 = 0; s2 < mq; s2++) {
+                        if (h_rec[s2].o.status != GAP_OK) continue;
+                        const uint32_t g = host_ids[s0 + s2];
+                        batch.chunk_of[g] = chunk_id;
+                        batch.slot_of[g] = s2;
+                    }
+                }
+                if (any_retry)
+                    for (uint32_t s2 = 0; s2 < mq; s2++)
+                        if (h_rec[s2].o.status != GAP_OK) retry.push_back(host_ids ? host_ids[s0 + s2] : (uint32_t)(s0 + s2));
+                /* multi-contig gaps: their contig-graph paths, while the launch's scratch is still in place */
+                if (!host_paths && any_general.load()) {
+                    std::vector<uint32_t> gslots;
+                    for (uint32_t s2 = 0; s2 < mq; s2++)
+                        if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s0 + s2);
+                    if (!gslots.empty()) {
+                        DevBuf d_gs, d_po;
+                        HIP_TRY(upload(d_gs, gslots));
+                        HIP_TRY(d_po.alloc(gslots.size() * (size_t)PATHS_WORDS * 4));
+                        hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
+                                           d_po.as<uint32_t>(), (uint32_t)gslots.size());
+                        HIP_TRY(hipGetLastError());
+                        hc.paths.resize(gslots.size() * (size_t)PATHS_WORDS);
+                        HIP_TRY(hipMemcpy(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost));
+                        hc.path_of.assign(mq, -1);
+                        for (size_t g2 = 0; g2 < gslots.size(); g2++) hc.path_of[gslots[g2] - s0] = (int32_t)g2;
+                    }
+                }
+                st.host_ms += now_ms() - t0;
+                /* hand the part to the caller: the gaps of its slots (those to be re-run excepted, the caller sees their status) */
+                if (on_ready) (*on_ready)(chunk_id, host_ids ? host_ids + s0 : nullptr, host_ids ? 0 : (size_t)s0, mq);
+            }
+            (void)first_chunk;
+            HIP_TRY(hipEventSynchronize(ev2));
+            tick("all parts done");
             float ms = 0, ms2 = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
             HIP_TRY(hipEventElapsedTime(&ms2, ev1, ev2));
             st.kernel_ms += ms;
             st.post_kernel_ms += ms2;
             st.n_launches++;
-            t0 = now_ms();
-            const uint64_t tw = totals[0], tc = totals[1];
-            SlotRec* h_rec = nullptr;
-            uint64_t* h_w = nullptr;
-            uint32_t* h_m = nullptr;
-            void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST ? staging_host(idx, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(m, tw, tc)) : nullptr;
-            hc.carve(block, m, tw, tc, h_rec, h_w, h_m);
-            HIP_TRY(hipMemcpyAsync(h_rec, d_rec.p, (size_t)m * sizeof(SlotRec), hipMemcpyDeviceToHost, 0));
-            if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.p, tw * 8, hipMemcpyDeviceToHost, 0));
-            if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.p, tc * 20, hipMemcpyDeviceToHost, 0));
-            HIP_TRY(hipStreamSynchronize(0));
-            h_w[tw] = 0;
-            st.d2h_ms += now_ms() - t0;
-            tick("d2h");
-            t0 = now_ms();
-            std::atomic<uint64_t> nt_sum{0}, lines{0};
-            std::atomic<bool> any_retry_a{false}, any_general{false};
-            parallel_for(((size_t)m + 4095) / 4096, p->nb_host_threads, [&](size_t b) {
-                uint64_t l = 0, t = 0;
-                bool r = false, gen = false;
-                for (uint32_t s2 = (uint32_t)(b * 4096); s2 < std::min<uint64_t>(m, (b + 1) * 4096); s2++) {
-                    l += h_rec[s2].o.lines;
-                    if (h_rec[s2].o.status != GAP_OK) { r = true; continue; }
-                    t += h_rec[s2].o.total_nt;
-                    if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gen = true;
-                }
-                lines += l; nt_sum += t;
-                if (r) any_retry_a = true;
-                if (gen) any_general = true;
-            }, 1);
-            const bool any_retry = any_retry_a.load();
-            st.index_lines += lines.load();
-            st.contig_nt += nt_sum.load();
-            if (!identity || any_retry) {
-                /* results are scattered over chunks from here on: keep an explicit map */
-                if (batch.chunk_of.empty()) { batch.chunk_of.assign(n, 0); batch.slot_of.resize(n); for (size_t i = 0; i < n; i++) batch.slot_of[i] = (uint32_t)i; }
-                for (uint32_t s2 = 0; s2 < m; s2++) {
-                    const uint32_t g = todo.empty() ? (uint32_t)(base + s2) : todo[base + s2];
-                    if (h_rec[s2].o.status != GAP_OK) { retry.push_back(g); continue; }
-                    batch.chunk_of[g] = chunk_id;
-                    batch.slot_of[g] = s2;
-                }
-            }
-            /* multi-contig gaps: their contig-graph paths, while the chunk's scratch is still in place */
-            static const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the enumeration to the host */
-            if (!host_paths && any_general.load()) {
-                std::vector<uint32_t> gslots;
-                for (uint32_t s2 = 0; s2 < m; s2++)
-                    if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s2);
-                if (!gslots.empty()) {
-                    DevBuf d_gs, d_po;
-                    HIP_TRY(upload(d_gs, gslots));
-                    HIP_TRY(d_po.alloc(gslots.size() * (size_t)PATHS_WORDS * 4));
-                    hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
-                                       d_po.as<uint32_t>(), (uint32_t)gslots.size());
-                    HIP_TRY(hipGetLastError());
-                    hc.paths.resize(gslots.size() * (size_t)PATHS_WORDS);
-                    HIP_TRY(hipMemcpy(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost));
-                    hc.path_of.assign(m, -1);
-                    for (size_t g2 = 0; g2 < gslots.size(); g2++) hc.path_of[gslots[g2]] = (int32_t)g2;
-                }
-            }
-            tick("distribute");
-            st.host_ms += now_ms() - t0;
         }
         if (tier > 0) st.n_retried_gaps += n_todo;
         todo.swap(retry);
         n_todo = todo.size();
     }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    (void)hipEventDestroy(ev2);
 #ifdef MTG_STAMPS
     {
         unsigned long long hs[16];

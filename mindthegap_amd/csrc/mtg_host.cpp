@@ -627,40 +627,55 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     mtg_batch_stats st{};
     st.host_ms = now_ms() - t_begin;
     DevBatch batch;
-    DevBatch& dev = batch;
-    double t_marshal = 0;
+    double t_marshal = 0, t_parts = 0;
+    bool marshalled = false;
     const std::function<void()> before_post = [&]() { parallel_for(n, nth, [&](size_t i) { src.targets(i, in); }, 512); };
-    const std::function<void()> while_busy = [&]() { const double t = now_ms(); src.marshal(in, nth); t_marshal = now_ms() - t; };
-    int rc = device_run(idx, p, in, batch, &st, &before_post, &while_busy);
-    if (rc) return rc;
-    if (dbg) fprintf(stderr, "  [fill_gaps] marshal (overlapped)   %.2f ms\n", t_marshal);
-    std::vector<GapWork>& gaps = src.gaps();
-    tk = now_ms();
-    double t0 = now_ms();
-    /* arena bytes of every block of gaps, then the gaps of a block one after the other */
+    const std::function<void()> while_busy = [&]() { const double t = now_ms(); src.marshal(in, nth); marshalled = true; t_marshal = now_ms() - t; };
+    /* Every chunk of results is turned into solutions as soon as it is back, while the device works on the next one: arena bytes of
+     * every block of its gaps, then the gaps of a block one after the other (the sequences of a chunk share one arena buffer). */
     const size_t B = RESULT_BLOCK, nb = (n + B - 1) / B;
-    std::vector<uint64_t> blk_arena(nb + 1, 0), blk_sols(nb, 0);
-    parallel_for(nb, nth, [&](size_t b) {
-        uint64_t sum = 0;
-        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) { const PostOut& po = dev.rec(i).p; sum += po.fast == 1 ? (uint64_t)(po.pos - (uint32_t)k) + 1 : 0; }
-        blk_arena[b + 1] = sum;
-    }, 1);
-    for (size_t b = 0; b < nb; b++) blk_arena[b + 1] += blk_arena[b];
-    tick("arena offsets");
-    char* const arena_base = arena.ensure(blk_arena[nb] + 1);
+    std::vector<std::atomic<uint64_t>> blk_sols(nb);
+    for (auto& c : blk_sols) c.store(0, std::memory_order_relaxed);
     std::vector<GenWork*> genw(n, nullptr); /* gaps whose solutions come out of the host's path enumeration */
     struct GenGuard { std::vector<GenWork*>& v; ~GenGuard() { for (GenWork* g : v) delete g; } } gen_guard{genw};
-    parallel_for(nb, nth, [&](size_t b) {
-        uint64_t off = blk_arena[b], nsol = 0;
-        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) {
-            const GapDev gd = dev[i];
-            genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
-            off += gd.p.fast == 1 ? (uint64_t)(gd.p.pos - (uint32_t)k) + 1 : 0;
-            nsol += gaps[i].sols.size();
-        }
-        blk_sols[b] = nsol;
-    }, 1);
-    tick("process gaps");
+    const std::function<void(size_t, const uint32_t*, size_t, size_t)> on_ready = [&](size_t chunk, const uint32_t* ids, size_t first, size_t count) {
+        const double t = now_ms();
+        if (!marshalled) { src.marshal(in, nth); marshalled = true; } /* the gap records have to exist by now */
+        std::vector<GapWork>& gaps = src.gaps();
+        const size_t nbp = (count + B - 1) / B;
+        std::vector<uint64_t> blk_arena(nbp + 1, 0);
+        auto gap_of = [&](size_t j) -> size_t { return ids ? ids[j] : first + j; };
+        auto arena_len = [&](const SlotRec& r) -> uint64_t { return (r.o.status == GAP_OK && r.p.fast == 1) ? (uint64_t)(r.p.pos - (uint32_t)k) + 1 : 0; };
+        parallel_for(nbp, nth, [&](size_t b) {
+            uint64_t sum = 0;
+            for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) sum += arena_len(batch.rec(gap_of(j)));
+            blk_arena[b + 1] = sum;
+        }, 1);
+        for (size_t b = 0; b < nbp; b++) blk_arena[b + 1] += blk_arena[b];
+        char* const arena_base = arena.ensure(chunk, blk_arena[nbp] + 1);
+        parallel_for(nbp, nth, [&](size_t b) {
+            uint64_t off = blk_arena[b], nsol = 0;
+            size_t cur_blk = ~(size_t)0;
+            for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
+                const size_t i = gap_of(j);
+                const GapDev gd = batch[i];
+                if (gd.o.status != GAP_OK) continue; /* re-run in a larger tier: comes back with a later chunk */
+                if (i / B != cur_blk) { if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed); nsol = 0; cur_blk = i / B; }
+                genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
+                off += gd.p.fast == 1 ? (uint64_t)(gd.p.pos - (uint32_t)k) + 1 : 0;
+                nsol += gaps[i].sols.size();
+            }
+            if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed);
+        }, 1);
+        t_parts += now_ms() - t;
+    };
+    int rc = device_run(idx, p, in, batch, &st, &before_post, &while_busy, &on_ready);
+    if (rc) return rc;
+    if (dbg) fprintf(stderr, "  [fill_gaps] marshal (overlapped) %.2f ms, chunks processed in %.2f ms\n", t_marshal, t_parts);
+    std::vector<GapWork>& gaps = src.gaps();
+    st.host_ms += t_parts;
+    tk = now_ms();
+    double t0 = now_ms();
     std::vector<size_t> gen_idx;
     for (size_t i = 0; i < n; i++) if (genw[i]) gen_idx.push_back(i);
     if (!gen_idx.empty()) {
@@ -685,10 +700,10 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
         std::vector<uint32_t> matches;
         if (!pairs.empty()) { rc = nw_run(idx, pairs, matches); if (rc) return rc; }
         parallel_for(gen_idx.size(), nth, [&](size_t ii) { finish_general(gaps[gen_idx[ii]], *genw[gen_idx[ii]], matches); }, 1);
-        for (size_t gi : gen_idx) blk_sols[gi / B] += gaps[gi].sols.size(); /* they had none when their block was counted */
+        for (size_t gi : gen_idx) blk_sols[gi / B].fetch_add(gaps[gi].sols.size(), std::memory_order_relaxed); /* they had none when their block was counted */
         tick("alignments");
     }
-    if (sol_blocks) sol_blocks->swap(blk_sols);
+    if (sol_blocks) { sol_blocks->resize(nb); for (size_t b = 0; b < nb; b++) (*sol_blocks)[b] = blk_sols[b].load(std::memory_order_relaxed); }
     /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);

@@ -29,6 +29,7 @@ struct Workspace {
     /* page-locked host staging blocks: 0..2 = the marshalled input of a batch, 3.. = what the first chunks of a batch brought back */
     void* hptr[NHOST] = {nullptr};
     size_t hcap[NHOST] = {0};
+    void* copy_stream = nullptr; /* hipStream_t for the copies back of a batch's parts */
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
 }
@@ -248,16 +249,17 @@ struct GapDev {
     }
 };
 struct DevBatch {
-    std::vector<uint32_t> chunk_of, slot_of; /* where gap i's results sit; both empty: chunk 0, slot i */
+    std::vector<uint32_t> chunk_of, slot_of; /* where gap i's results sit; both empty: chunk i / part, slot i % part */
     std::vector<std::unique_ptr<HostChunk>> chunks;
     size_t n = 0;
+    size_t part = ~(size_t)0; /* gaps per chunk while the map is implicit (the whole batch went through one traversal launch) */
     size_t size() const { return n; }
-    const mtg::SlotRec& rec(size_t i) const { return chunk_of.empty() ? chunks[0]->recs[i] : chunks[chunk_of[i]]->recs[slot_of[i]]; }
+    const mtg::SlotRec& rec(size_t i) const { return chunk_of.empty() ? chunks[i / part]->recs[i % part] : chunks[chunk_of[i]]->recs[slot_of[i]]; }
     /* view of gap i (cheap: a few pointer computations) */
     GapDev operator[](size_t i) const
     {
-        const HostChunk& c = chunk_of.empty() ? *chunks[0] : *chunks[chunk_of[i]];
-        const size_t slot = chunk_of.empty() ? i : slot_of[i];
+        const HostChunk& c = chunk_of.empty() ? *chunks[i / part] : *chunks[chunk_of[i]];
+        const size_t slot = chunk_of.empty() ? i % part : slot_of[i];
         const mtg::SlotRec& r = c.recs[slot];
         GapDev g;
         if (!c.path_of.empty() && c.path_of[slot] >= 0) g.paths = c.paths.data() + (size_t)c.path_of[slot] * mtg::PATHS_WORDS;
@@ -357,7 +359,11 @@ struct FillInput {
  * calling thread while the device works on the first chunk: `before_post` after the traversal kernel has been launched (it has to
  * fill block C of the input, which is then sent and the post-processing kernel launched), `while_busy` after that launch. */
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats, const std::function<void()>* before_post = nullptr,
-               const std::function<void()>* while_busy = nullptr);
+               const std::function<void()>* while_busy = nullptr, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready = nullptr);
+/* on_ready(chunk, ids, first, count): chunk `chunk` of `out` is complete and holds the results of the gaps ids[0..count) (ids == nullptr:
+ * the gaps first .. first + count - 1).  A gap whose status is not GAP_OK there is re-run in a larger scratch tier and announced again
+ * with a later chunk.  Called on the calling thread, in chunk order, while the device may still be working on later parts. */
+enum { MTG_POST_PARTS = 4 };
 enum { STAGING_CHUNK0 = 3 }; /* first staging block used for results */
 
 /* membership scan over packed sequences: host arrays in (words/off/len), bit output as in mtg_index_scan_packed_device; device = 1: the pointers are device pointers */
@@ -401,12 +407,14 @@ struct SeqBuf {
 /* storage of the common-path sequences of one batch; must outlive the GapWork results that point into it.  Raw and uninitialised: every
  * byte handed out is written by exactly one gap, and a recycled arena costs no page faults and no memset */
 struct FillArena {
-    std::unique_ptr<char[]> buf;
-    size_t cap = 0;
-    char* ensure(size_t n)
+    /* one buffer per chunk of a batch: the chunks are decoded as they come back from the device */
+    std::vector<std::unique_ptr<char[]>> buf;
+    std::vector<size_t> cap;
+    char* ensure(size_t chunk, size_t n)
     {
-        if (cap < n) { buf.reset(); cap = n + n / 8 + 64; buf.reset(new char[cap]); }
-        return buf.get();
+        if (buf.size() <= chunk) { buf.resize(chunk + 1); cap.resize(chunk + 1, 0); }
+        if (cap[chunk] < n) { buf[chunk].reset(); cap[chunk] = n + n / 8 + 64; buf[chunk].reset(new char[cap[chunk]]); }
+        return buf[chunk].get();
     }
 };
 

@@ -157,7 +157,7 @@ int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint3
 void* staging_host(const mtg_index*, int, size_t) { return nullptr; }
 
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* before_post,
-               const std::function<void()>* while_busy)
+               const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)
 {
     if (before_post) (*before_post)();
     if (while_busy) (*while_busy)();
@@ -222,6 +222,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         }
         if (o.status != GAP_OK) { set_error("gap %zu exceeded the largest traversal scratch tier", g); return MTG_ERR_OVERFLOW; }
     }
+    if (on_ready && n) (*on_ready)(0, nullptr, 0, n); /* the emulator hands everything over at once */
     if (stats) *stats = st;
     return MTG_OK;
 }
