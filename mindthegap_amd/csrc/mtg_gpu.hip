@@ -851,7 +851,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             if (before_post && !before_done) { before_done = true; (*before_post)(); tick("host work before k_post"); } /* the device is busy: the caller's turn */
             if (!targets_sent) { targets_sent = true; HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, 0)); }
             /* post-processing in parts */
-            uint32_t nparts = env_parts > 0 ? (uint32_t)env_parts : (m >= 16384 ? (uint32_t)MTG_POST_PARTS : 1u);
+            uint32_t nparts = env_parts > 0 ? (uint32_t)env_parts : (m >= 16384 ? 4u : 1u);
             if (nparts > (uint32_t)MTG_POST_PARTS) nparts = MTG_POST_PARTS;
             uint32_t psize = (((m + nparts - 1) / nparts) + 63u) & ~63u; /* slots per part */
             if (psize == 0) psize = 64;
@@ -897,24 +897,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 h_w[tw] = 0;
                 st.d2h_ms += now_ms() - t0;
                 t0 = now_ms();
-                std::atomic<uint64_t> nt_sum{0}, lines{0};
-                std::atomic<bool> any_retry_a{false}, any_general{false};
-                parallel_for(((size_t)mq + 4095) / 4096, p->nb_host_threads, [&](size_t b) {
-                    uint64_t l = 0, t = 0;
-                    bool r = false, gen = false;
-                    for (uint32_t s2 = (uint32_t)(b * 4096); s2 < std::min<uint64_t>(mq, (b + 1) * 4096); s2++) {
-                        l += h_rec[s2].o.lines;
-                        if (h_rec[s2].o.status != GAP_OK) { r = true; continue; }
-                        t += h_rec[s2].o.total_nt;
-                        if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gen = true;
-                    }
-                    lines += l; nt_sum += t;
-                    if (r) any_retry_a = true;
-                    if (gen) any_general = true;
-                }, 1);
-                const bool any_retry = any_retry_a.load();
-                st.index_lines += lines.load();
-                st.contig_nt += nt_sum.load();
+                /* statistics and what needs another look: a serial scan of a part's records costs less than a parallel region */
+                uint64_t nt_sum = 0, lines = 0;
+                bool any_retry = false, any_general = false;
+                for (uint32_t s2 = 0; s2 < mq; s2++) {
+                    lines += h_rec[s2].o.lines;
+                    if (h_rec[s2].o.status != GAP_OK) { any_retry = true; continue; }
+                    nt_sum += h_rec[s2].o.total_nt;
+                    if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) any_general = true;
+                }
+                st.index_lines += lines;
+                st.contig_nt += nt_sum;
                 if (!identity) {
                     for (uint32_t s2 = 0; s2 < mq; s2++) {
                         if (h_rec[s2].o.status != GAP_OK) continue;
@@ -927,7 +920,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                     for (uint32_t s2 = 0; s2 < mq; s2++)
                         if (h_rec[s2].o.status != GAP_OK) retry.push_back(host_ids ? host_ids[s0 + s2] : (uint32_t)(s0 + s2));
                 /* multi-contig gaps: their contig-graph paths, while the launch's scratch is still in place */
-                if (!host_paths && any_general.load()) {
+                if (!host_paths && any_general) {
                     std::vector<uint32_t> gslots;
                     for (uint32_t s2 = 0; s2 < mq; s2++)
                         if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s0 + s2);

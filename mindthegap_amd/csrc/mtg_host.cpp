@@ -643,18 +643,19 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
         if (!marshalled) { src.marshal(in, nth); marshalled = true; } /* the gap records have to exist by now */
         std::vector<GapWork>& gaps = src.gaps();
         const size_t nbp = (count + B - 1) / B;
-        std::vector<uint64_t> blk_arena(nbp + 1, 0);
         auto gap_of = [&](size_t j) -> size_t { return ids ? ids[j] : first + j; };
-        auto arena_len = [&](const SlotRec& r) -> uint64_t { return (r.o.status == GAP_OK && r.p.fast == 1) ? (uint64_t)(r.p.pos - (uint32_t)k) + 1 : 0; };
+        /* one pass: a block of gaps adds up the bytes its sequences need, takes them from the chunk's arena buffer (never more in total
+         * than 32 per dense word + one per gap) and writes its gaps one after the other */
+        const size_t arena_cap = (size_t)batch.chunks[chunk]->n_words * 32 + count + 64;
+        char* const arena_base = arena.ensure(chunk, arena_cap);
+        std::atomic<uint64_t> arena_used{0};
         parallel_for(nbp, nth, [&](size_t b) {
-            uint64_t sum = 0;
-            for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) sum += arena_len(batch.rec(gap_of(j)));
-            blk_arena[b + 1] = sum;
-        }, 1);
-        for (size_t b = 0; b < nbp; b++) blk_arena[b + 1] += blk_arena[b];
-        char* const arena_base = arena.ensure(chunk, blk_arena[nbp] + 1);
-        parallel_for(nbp, nth, [&](size_t b) {
-            uint64_t off = blk_arena[b], nsol = 0;
+            uint64_t need = 0;
+            for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
+                const SlotRec& r = batch.rec(gap_of(j));
+                need += (r.o.status == GAP_OK && r.p.fast == 1) ? (uint64_t)(r.p.pos - (uint32_t)k) + 1 : 0;
+            }
+            uint64_t off = arena_used.fetch_add(need, std::memory_order_relaxed), nsol = 0;
             size_t cur_blk = ~(size_t)0;
             for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
                 const size_t i = gap_of(j);

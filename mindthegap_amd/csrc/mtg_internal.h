@@ -23,7 +23,7 @@
 namespace mtgi {
 /* grow-only device buffers reused by successive batches on one index */
 struct Workspace {
-    enum { NSLOTS = 32, NHOST = 8 };
+    enum { NSLOTS = 32, NHOST = 16 };
     void* ptr[NSLOTS] = {nullptr};
     size_t cap[NSLOTS] = {0};
     /* page-locked host staging blocks: 0..2 = the marshalled input of a batch, 3.. = what the first chunks of a batch brought back */
@@ -204,6 +204,7 @@ struct HostChunk {
     const uint64_t* words = nullptr;
     const uint32_t* meta = nullptr;
     uint32_t m = 0;
+    uint64_t n_words = 0; /* dense words of the chunk */
     std::vector<uint64_t> own;
     /* contig-graph paths of the multi-contig gaps of the chunk (k_paths): PATHS_WORDS words per such gap, path_of[slot] = its rank or -1 */
     std::vector<uint32_t> paths;
@@ -216,7 +217,7 @@ struct HostChunk {
         r = (mtg::SlotRec*)b;
         w = (uint64_t*)(b + rec_bytes(m_));
         mt = (uint32_t*)(b + rec_bytes(m_) + (tw + 1) * 8);
-        recs = r; words = w; meta = mt; m = m_;
+        recs = r; words = w; meta = mt; m = m_; n_words = tw;
     }
     static size_t rec_bytes(uint32_t m_) { return ((size_t)m_ * sizeof(mtg::SlotRec) + 63) & ~(size_t)63; }
     static size_t bytes_for(uint32_t m_, uint64_t tw, uint64_t tc) { return (rec_bytes(m_) + (tw + 1) * 8 + tc * 20 + 64 + 7) & ~(size_t)7; }
@@ -363,7 +364,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
 /* on_ready(chunk, ids, first, count): chunk `chunk` of `out` is complete and holds the results of the gaps ids[0..count) (ids == nullptr:
  * the gaps first .. first + count - 1).  A gap whose status is not GAP_OK there is re-run in a larger scratch tier and announced again
  * with a later chunk.  Called on the calling thread, in chunk order, while the device may still be working on later parts. */
-enum { MTG_POST_PARTS = 4 };
+enum { MTG_POST_PARTS = 8 };
 enum { STAGING_CHUNK0 = 3 }; /* first staging block used for results */
 
 /* membership scan over packed sequences: host arrays in (words/off/len), bit output as in mtg_index_scan_packed_device; device = 1: the pointers are device pointers */

@@ -218,11 +218,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             batch.chunk_of[g] = (uint32_t)batch.chunks.size() - 1;
             batch.slot_of[g] = 0;
             st.contig_nt += o.total_nt;
+            if (on_ready) { const uint32_t gid = (uint32_t)g; (*on_ready)(batch.chunks.size() - 1, &gid, 0, 1); } /* one chunk per gap here */
             break;
         }
         if (o.status != GAP_OK) { set_error("gap %zu exceeded the largest traversal scratch tier", g); return MTG_ERR_OVERFLOW; }
     }
-    if (on_ready && n) (*on_ready)(0, nullptr, 0, n); /* the emulator hands everything over at once */
     if (stats) *stats = st;
     return MTG_OK;
 }
