@@ -798,8 +798,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     std::vector<uint32_t> todo; /* empty at tier 0: every gap, in order */
     size_t n_todo = n;
     int rc = MTG_OK;
-    static const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the path enumeration to the host */
-    static const int env_parts = getenv("MTG_POST_PARTS") ? atoi(getenv("MTG_POST_PARTS")) : 0; /* test hook */
+    const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the path enumeration to the host */
+    const int env_parts = getenv("MTG_POST_PARTS") ? atoi(getenv("MTG_POST_PARTS")) : 0; /* test hook */
 
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
@@ -810,6 +810,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                                  (uint64_t)cfg.cap_contigs * 20;
         const size_t cached = idx->ws.cap[d_zero.slot] + idx->ws.cap[d_raw.slot] + idx->ws.cap[d_ilv.slot] + idx->ws.cap[d_dw.slot] + idx->ws.cap[d_dm.slot]; /* already ours */
         size_t chunk = (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
+        const size_t env_chunk = getenv("MTG_MAX_CHUNK") ? (size_t)atol(getenv("MTG_MAX_CHUNK")) : 0; /* test hook: several launches per batch */
+        if (env_chunk && chunk > env_chunk) chunk = env_chunk;
         if (chunk > n_todo) chunk = n_todo;
         if (chunk > (1u << 20)) chunk = 1u << 20;
         if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }

@@ -379,3 +379,19 @@ def test_stage_a_fuzz_on_device(mtg, k):
                 assert c == o.stage_a(s, t, oracle_lib.default_params(max_nodes=mn, max_depth=md, end_rule_nonbranching=er))[0], (seed, k, s, t, mn, md, er)
         idx.close()
         o.close()
+
+
+@pytest.mark.parametrize("chunk,parts,host_paths", [(37, 3, False), (1000, 8, False), (0, 1, True)])
+def test_batches_split_into_launches_and_parts(mtg, tmp_path, monkeypatch, chunk, parts, host_paths):
+    """the batch machinery under test hooks: several traversal launches per batch (MTG_MAX_CHUNK), post-processing parts per launch
+    (MTG_POST_PARTS), path enumeration left to the host (MTG_HOST_PATHS); results must not depend on any of them"""
+    from tests.test_emu_parity import _allelic_inserts_case, _diploid_case, _edge_case_run
+    if chunk:
+        monkeypatch.setenv("MTG_MAX_CHUNK", str(chunk))
+    monkeypatch.setenv("MTG_POST_PARTS", str(parts))
+    if host_paths:
+        monkeypatch.setenv("MTG_HOST_PATHS", "1")
+    (tmp_path / "a").mkdir(); (tmp_path / "d").mkdir(); (tmp_path / "e").mkdir()
+    _allelic_inserts_case(mtg, tmp_path / "a", 60)
+    _diploid_case(mtg, tmp_path / "d", 100)
+    _edge_case_run(mtg, tmp_path / "e")
