@@ -122,8 +122,9 @@ def main():
         on rank 0 over RCCL / xGMI while the next step runs; the final, untimed pass uses the blocking gather and is verified."""
         tp0 = time.perf_counter()
         if pg is not None and not final:
-            h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=True, out=pg.buffer())
-            pg.submit(len(seqs))
+            h, nf, nbytes = idx.fill_prepared_serial(prepared, pg.buffer(), params)  # decoded straight into the page-locked gather buffer
+            seqs = None
+            pg.submit(nbytes)
         else:
             h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=want_seqs or final)
         st = mtg.last_batch_stats()

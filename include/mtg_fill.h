@@ -139,6 +139,12 @@ typedef struct mtg_gap_result {
 
 typedef struct mtg_results mtg_results;
 int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out);
+/* The same, and the filled sequences of the batch also laid out in seq_out: NUL-terminated, in gap order (solution order within a gap),
+ * *seq_bytes in total -- the form in which results travel between ranks.  In the common case they are decoded there directly (the
+ * results then point into seq_out, which must stay untouched until mtg_results_free); MTG_ERR_ARG when cap is too small (32 bytes per
+ * packed word of contig plus one per gap always suffice: a little over the sum of the insert lengths). */
+int mtg_fill_batch_serial(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t cap, uint64_t* seq_bytes,
+                          mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
 /* Every pointer obtained from r dies here.  The library keeps the storage of up to two freed result sets (a few hundred bytes per
  * gap plus the sequences) and hands it to the next batches, which then pay no allocation, page fault or memset. */

@@ -644,30 +644,51 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
         std::vector<GapWork>& gaps = src.gaps();
         const size_t nbp = (count + B - 1) / B;
         auto gap_of = [&](size_t j) -> size_t { return ids ? ids[j] : first + j; };
-        /* one pass: a block of gaps adds up the bytes its sequences need, takes them from the chunk's arena buffer (never more in total
-         * than 32 per dense word + one per gap) and writes its gaps one after the other */
+        /* one pass: a block of gaps adds up the bytes its sequences need, learns where the blocks before it end (they were handed out
+         * in order, and each publishes its end as soon as it knows its own size) and writes its gaps one after the other; the chunk
+         * never needs more than 32 bytes per dense word + one per gap */
         const size_t arena_cap = (size_t)batch.chunks[chunk]->n_words * 32 + count + 64;
-        char* const arena_base = arena.ensure(chunk, arena_cap);
-        std::atomic<uint64_t> arena_used{0};
+        bool external = false;
+        if (arena.ext_ok) {
+            /* the caller's buffer takes the chunk if it continues the gap order and fits */
+            if (!ids && first == arena.ext_next_gap && arena.ext_used + arena_cap <= arena.ext_cap) external = true;
+            else arena.ext_ok = false;
+        }
+        char* const arena_base = external ? arena.ext + arena.ext_used : arena.ensure(chunk, arena_cap);
+        std::vector<std::atomic<int64_t>> ends(nbp + 1);
+        for (auto& e : ends) e.store(-1, std::memory_order_relaxed);
+        ends[0].store(0, std::memory_order_release);
+        std::atomic<bool> incomplete{false};
         parallel_for(nbp, nth, [&](size_t b) {
             uint64_t need = 0;
             for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
                 const SlotRec& r = batch.rec(gap_of(j));
                 need += (r.o.status == GAP_OK && r.p.fast == 1) ? (uint64_t)(r.p.pos - (uint32_t)k) + 1 : 0;
             }
-            uint64_t off = arena_used.fetch_add(need, std::memory_order_relaxed), nsol = 0;
+            int64_t begin;
+            while ((begin = ends[b].load(std::memory_order_acquire)) < 0) Pool::cpu_relax();
+            ends[b + 1].store(begin + (int64_t)need, std::memory_order_release);
+            uint64_t off = (uint64_t)begin, nsol = 0;
             size_t cur_blk = ~(size_t)0;
+            bool odd = false;
             for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
                 const size_t i = gap_of(j);
                 const GapDev gd = batch[i];
-                if (gd.o.status != GAP_OK) continue; /* re-run in a larger tier: comes back with a later chunk */
+                if (gd.o.status != GAP_OK) { odd = true; continue; } /* re-run in a larger tier: comes back with a later chunk */
                 if (i / B != cur_blk) { if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed); nsol = 0; cur_blk = i / B; }
                 genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
+                if (genw[i]) odd = true;
                 off += gd.p.fast == 1 ? (uint64_t)(gd.p.pos - (uint32_t)k) + 1 : 0;
                 nsol += gaps[i].sols.size();
             }
             if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed);
+            if (odd) incomplete = true;
         }, 1);
+        if (external) {
+            arena.ext_used += (size_t)ends[nbp].load(std::memory_order_acquire);
+            arena.ext_next_gap = first + count;
+            if (incomplete.load()) arena.ext_ok = false; /* a gap of this chunk gets its sequences later, out of order */
+        }
         t_parts += now_ms() - t;
     };
     int rc = device_run(idx, p, in, batch, &st, &before_post, &while_busy, &on_ready);
@@ -872,7 +893,7 @@ struct AbiSource : mtgi::BatchSource {
 };
 } // namespace
 
-int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out)
+static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes, mtg_results** out)
 {
     if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     const double t_m0 = mtgi::now_ms();
@@ -881,11 +902,41 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     auto tick = [&](const char* what) { if (dbg) { const double t = mtgi::now_ms(); fprintf(stderr, "  [fill_batch] %-21s %.2f ms\n", what, t - tk); tk = t; } };
     mtg_results* R = results_acquire();
     R->nthreads = p->nb_host_threads;
+    R->arena.set_external(seq_out, seq_out ? (size_t)seq_cap : 0);
     AbiSource src(gaps, n, R);
     mtg_batch_stats st{};
     std::vector<uint64_t> sol_blocks;
     int rc = mtgi::fill_gaps(idx, p, src, R->arena, &st, &sol_blocks);
     if (rc) { results_release(R); return rc; }
+    if (seq_out) {
+        if (R->arena.ext_ok && R->arena.ext_next_gap == n) *seq_bytes = R->arena.ext_used; /* every sequence was decoded in place, in gap order */
+        else {
+            /* multi-contig gaps, re-run gaps or a buffer too small for the worst case: lay the sequences out again, in gap order, and
+             * make the solutions point there */
+            const size_t CH = 1024, nch = (n + CH - 1) / CH;
+            std::vector<uint64_t> choff(nch + 1, 0);
+            mtgi::parallel_for(nch, p->nb_host_threads, [&](size_t c) {
+                uint64_t b = 0;
+                for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) for (auto& s : R->gaps[i].sols) b += s.seq.size() + 1;
+                choff[c + 1] = b;
+            }, 1);
+            for (size_t c = 0; c < nch; c++) choff[c + 1] += choff[c];
+            if (choff[nch] > seq_cap) { results_release(R); mtgi::set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)choff[nch]); return MTG_ERR_ARG; }
+            char* tmp = R->arena.ensure(63, choff[nch] + 1); /* a buffer of its own (no chunk gets that far): the old places stay readable meanwhile */
+            mtgi::parallel_for(nch, p->nb_host_threads, [&](size_t c) {
+                uint64_t o = choff[c];
+                for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++)
+                    for (auto& s : R->gaps[i].sols) { memcpy(tmp + o, s.seq.data(), s.seq.size()); tmp[o + s.seq.size()] = 0; o += s.seq.size() + 1; }
+            }, 1);
+            memcpy(seq_out, tmp, choff[nch]);
+            mtgi::parallel_for(nch, p->nb_host_threads, [&](size_t c) {
+                uint64_t o = choff[c];
+                for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++)
+                    for (auto& s : R->gaps[i].sols) { const uint32_t len = (uint32_t)s.seq.size(); s.seq = std::string(); s.seq.view(seq_out + o, len); o += len + 1; }
+            }, 1);
+            *seq_bytes = choff[nch];
+        }
+    }
     const double t_m2 = mtgi::now_ms();
     tk = t_m2;
     const size_t B = mtgi::RESULT_BLOCK, nb = (n + B - 1) / B;
@@ -924,6 +975,15 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
     mtgi::stats_store(st);
     *out = R;
     return MTG_OK;
+}
+int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out)
+{
+    return fill_batch_impl(idx, p, gaps, n, nullptr, 0, nullptr, out);
+}
+int mtg_fill_batch_serial(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
+{
+    if (!seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    return fill_batch_impl(idx, p, gaps, n, seq_out, cap, seq_bytes, out);
 }
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->res.size()) ? &r->res[i] : nullptr; }
 void mtg_results_free(mtg_results* r)

@@ -80,14 +80,15 @@ public:
     }
     int size() const { return (int)threads_.size() + 1; }
 
-private:
-    enum { SPIN = 4000 };
     static void cpu_relax()
     {
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
 #endif
     }
+
+private:
+    enum { SPIN = 4000 };
     Pool()
     {
         int n = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 64u);
@@ -417,6 +418,12 @@ struct FillArena {
         if (cap[chunk] < n) { buf[chunk].reset(); cap[chunk] = n + n / 8 + 64; buf[chunk].reset(new char[cap[chunk]]); }
         return buf[chunk].get();
     }
+    /* Optional caller-owned buffer (mtg_fill_batch_serial): as long as the chunks arrive in gap order and fit, their sequences are laid
+     * out there one after the other, which makes the buffer the batch's serialised form without a copy. */
+    char* ext = nullptr;
+    size_t ext_cap = 0, ext_used = 0, ext_next_gap = 0;
+    bool ext_ok = false;
+    void set_external(char* p, size_t c) { ext = p; ext_cap = c; ext_used = 0; ext_next_gap = 0; ext_ok = p != nullptr; }
 };
 
 struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */

@@ -103,6 +103,7 @@ def _bind(lib):
     lib.mtg_default_params.argtypes = [P(Params)]
     lib.mtg_default_params.restype = None
     lib.mtg_fill_batch.argtypes = [C.c_void_p, P(Params), P(CGap), C.c_size_t, P(C.c_void_p)]
+    lib.mtg_fill_batch_serial.argtypes = [C.c_void_p, P(Params), P(CGap), C.c_size_t, C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_void_p)]
     lib.mtg_results_get.argtypes = [C.c_void_p, C.c_size_t]
     lib.mtg_results_get.restype = P(CGapResult)
     lib.mtg_results_free.argtypes = [C.c_void_p]
@@ -279,6 +280,20 @@ class Index:
             buf = np.empty(max(int(nb.value), 1), dtype=np.uint8)
         _check(self.lib.mtg_results_copy_seqs(h, buf.ctypes.data_as(C.c_char_p), nb.value))
         return h, nf, buf[: nb.value]
+
+    def fill_prepared_serial(self, prepared, out, params=None):
+        """mtg_fill_batch_serial: the batch's filled sequences end up in the uint8 array `out` (NUL-terminated, gap order), decoded there
+        directly in the common case; returns (results handle, n_filled per gap, number of bytes).  `out` must stay untouched until
+        free_results."""
+        params = params or FillParams()
+        arr, n, _ = prepared
+        h = C.c_void_p()
+        nb = C.c_uint64()
+        _check(self.lib.mtg_fill_batch_serial(self.h, C.byref(params.c), arr, n, out.ctypes.data_as(C.c_void_p), out.size, C.byref(nb), C.byref(h)))
+        nf = np.empty(n, dtype=np.uint32)
+        _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), None, None))
+        self.last_seq_bytes = int(nb.value)
+        return h, nf, int(nb.value)
 
     def free_results(self, h):
         self.lib.mtg_results_free(h)

@@ -36,13 +36,13 @@ def main(out_path):
     pg = PipelinedGather(int(cap.item()) * 2 + 64, dst=0)
     prepared = mtg.Index.prepare_gaps(gaps)
     for step in range(3):
-        h, nf, s2 = idx.fill_prepared(prepared, out=pg.buffer())
+        h, nf, nbytes = idx.fill_prepared_serial(prepared, pg.buffer())  # NUL-terminated sequences, written into the gather buffer
         idx.free_results(h)
-        pg.submit(len(s2))
+        pg.submit(nbytes)
     pg.drain()
     piped = pg.last()
     if rank == 0:
-        assert [p.tobytes() for p in piped] == [p.tobytes() for p in parts]
+        assert [p.tobytes().replace(b"\0", b"\n") for p in piped] == [p.tobytes() for p in parts]
         with open(out_path, "wb") as f:
             for p in parts:
                 f.write(p.tobytes())

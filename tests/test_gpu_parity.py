@@ -395,3 +395,54 @@ def test_batches_split_into_launches_and_parts(mtg, tmp_path, monkeypatch, chunk
     _allelic_inserts_case(mtg, tmp_path / "a", 60)
     _diploid_case(mtg, tmp_path / "d", 100)
     _edge_case_run(mtg, tmp_path / "e")
+
+
+def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
+    """mtg_fill_batch_serial: the sequences of a batch decoded straight into the caller's buffer (common path, several parts) and laid out
+    again when multi-contig gaps are present; both equal the concatenation of the per-gap results"""
+    from mindthegap_amd.synth import SynthSet
+    from tests.test_emu_parity import _rand_seq
+    import random
+    S = SynthSet(nseq=40000, n_sites=40000, seed=9)
+    import torch
+    dev = torch.device("cuda", 0)
+    w = torch.from_numpy(S.words.view(np.int64)).to(dev)
+    wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev)
+    ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
+    idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 40)
+    gaps = []
+    for i in range(S.n_sites):
+        l, r, _ = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+    prep = mtg.Index.prepare_gaps(gaps)
+    out = np.empty(64 << 20, dtype=np.uint8)
+    h, nf, nb = idx.fill_prepared_serial(prep, out)
+    got = out[:nb].tobytes()
+    idx.free_results(h)
+    assert (nf == 1).all()
+    assert got == b"".join(S.site(i)[2].encode() + b"\0" for i in range(S.n_sites))
+    # too small a buffer is refused
+    with pytest.raises(mtg.MtgError):
+        idx.fill_prepared_serial(prep, np.empty(1 << 20, dtype=np.uint8))
+    idx.close()
+    # multi-contig gaps: the fallback lays the sequences out again; compare with the plain results
+    rng = random.Random(3)
+    seqs, sites = [], []
+    for i in range(40):
+        L, R = _rand_seq(rng, 300), _rand_seq(rng, 300)
+        a, b = _rand_seq(rng, 200 + i), _rand_seq(rng, 300 + i)
+        seqs += [L + a + R, L + b + R] if i % 2 else [L + a + R]
+        sites.append((L[-31:], R[:31]))
+    from tests import oracle_lib
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    idx2 = mtg.Index.from_kmers(km, ct, 31)
+    gaps2 = [mtg.Gap(l, r, [(r, "t%d" % i, False)]) for i, (l, r) in enumerate(sites)]
+    plain = idx2.fill_batch(gaps2)
+    h, nf, nb = idx2.fill_prepared_serial(mtg.Index.prepare_gaps(gaps2), out)
+    got = out[:nb].tobytes()
+    idx2.free_results(h)
+    want = b"".join(f["seq"].encode() + b"\0" for g in plain for f in g["filled"])
+    assert got == want and max(len(g["filled"]) for g in plain) == 2
+    idx2.close()
+    o.close()
