@@ -244,6 +244,15 @@ def main():
             "note": "achieved follows SURVEY 8d (64 B per membership probe of the reference algorithm); the ADJ layout answers the ~8 probes of a node, and "
                     "the lookahead up to 15 nodes, with one 32-byte bucket read, so frac exceeds 1 by construction. The kernel is bound by dependent random "
                     "reads and the per-step VALU work, not by HBM bandwidth: see traffic (PMC) and frac_of_random_read_ceiling."}
+    # second kernel of the step: one abundance look-up (64 algorithmic bytes) per k-mer of source + fill
+    lookups = float(idx.last_seq_bytes)  # sum over the filled sites of (insert length + 1) = k-mers of source + fill
+    post_s = post_ms / max(launches, 1) * 1e-3
+    post_traffic = None
+    if traffic is not None:
+        post_traffic = json.load(open(pmc)).get("mtgi::k_post", {}).get("hbm_read_bytes_avg")
+    roof["post_kernel"] = {"kernel": "k_post", "bound": "hbm", "avg_kernel_ms": post_ms / max(launches, 1), "abundance_lookups_per_launch": lookups,
+                           "achieved": 64.0 * lookups / post_s / 1e9 if post_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                           "frac": (64.0 * lookups / post_s / 1e9 / 8000.0) if post_s > 0 else 0.0, "traffic": post_traffic}
     if not a.no_ceiling:
         tb = min(int(info["device_bytes"] // 2), 16 << 30)  # the ceiling is flat beyond ~16 GB (profiles/r01_random_line_ceiling.txt)
         ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), sites_per_gpu, 512, line_bytes)

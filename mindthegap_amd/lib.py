@@ -153,6 +153,7 @@ class Index:
     def __init__(self, handle):
         self.h = handle
         self.lib = load_library()
+        self.last_seq_bytes = 0
 
     @classmethod
     def from_reads(cls, paths, k=31, abundance_min=-1, abundance_max=0):
