@@ -88,8 +88,12 @@ MTG_DEV uint64_t le_kmer(const uint64_t* w, uint32_t j, uint64_t mk)
     return (lo | hi) & mk;
 }
 
-/* hist: 256 zeroed counters shared by the lanes (LDS on the device) */
-MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, PostOut& out)
+/* The scans read a contig through a tile of its words staged in LDS: one round of wide, coalesced loads per tile instead of one
+ * dependent round trip to memory per 64 positions (which is what bound this kernel: 47 round trips for a 3 kb contig). */
+enum { POST_TILE = 512 }; /* words = 16384 nucleotides */
+
+/* hist: 256 zeroed counters shared by the lanes; tile: POST_TILE + 2 words (both LDS on the device) */
+MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, uint64_t* tile, PostOut& out)
 {
     const int k = ix.k;
     const uint64_t mk = kmask(k);
@@ -113,22 +117,33 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
         const uint64_t* w = words + cstart[c];
         uint64_t best = 0;
         if (L >= (uint32_t)k && T.n) {
-            const uint32_t npos = L - (uint32_t)k + 1;
-            for (uint32_t j = lane; j < npos; j += MTG_NLANES) {
-                const uint64_t x = le_kmer(w, j, mk);
-                for (uint32_t t = 0; t < T.n; t++) {
-                    const uint64_t m = x ^ T.le[t];
-                    const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
+            const uint32_t npos = L - (uint32_t)k + 1, nwc = (L + 31) / 32;
+            for (uint32_t ws = 0; ws < nwc; ws += POST_TILE) {
+                const uint32_t tw = (nwc - ws) < (uint32_t)POST_TILE + 1 ? (nwc - ws) : (uint32_t)POST_TILE + 1; /* one word past the tile: a k-mer may straddle its end */
+                wave_sync(); /* the previous tile has been read */
+                for (uint32_t i = lane; i < tw; i += MTG_NLANES) tile[i] = w[ws + i];
+                if (lane == 0) tile[tw] = 0;
+                wave_sync();
+                const uint32_t j_lo = 32u * ws;
+                if (j_lo >= npos) break;
+                const uint32_t j_hi = (npos - j_lo) < 32u * POST_TILE ? npos : j_lo + 32u * POST_TILE;
+                for (uint32_t j = j_lo + lane; j < j_hi; j += MTG_NLANES) {
+                    const uint64_t x = le_kmer(tile, j - j_lo, mk);
+                    for (uint32_t t = 0; t < T.n; t++) {
+                        const uint64_t m = x ^ T.le[t];
+                        const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
 #ifdef MTG_EMU
-                    const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
+                        const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
 #else
-                    const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
+                        const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
 #endif
-                    if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
-                        const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t));
-                        best = key > best ? key : best;
+                        if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
+                            const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t));
+                            best = key > best ? key : best;
+                        }
                     }
                 }
+                if (j_hi >= npos) break;
             }
         }
         best = wave_max64(best);
@@ -153,6 +168,14 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     /* coverage of source + fill = the k-mers of contig0[0:pos0] */
     const uint64_t* w0 = words + cstart[0];
     const uint32_t nk = pos0 - (uint32_t)k + 1;
+    const uint32_t nw0 = (pos0 + 31) / 32; /* words holding contig0[0:pos0] */
+    if (nw0 <= (uint32_t)POST_TILE) {
+        wave_sync();
+        for (uint32_t i = lane; i < nw0; i += MTG_NLANES) tile[i] = w0[i];
+        if (lane == 0) tile[nw0] = 0;
+        wave_sync();
+        w0 = tile;
+    }
     uint32_t sum = 0, lines = 0;
     for (uint32_t j = lane; j < nk; j += MTG_NLANES) {
         Kmer x;

@@ -190,7 +190,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             T.fast_ok = in.fast_ok[g];
             uint32_t hist[256] = {0};
             PostOut po{};
-            post_gap(idx->dev, cfg, S, o, T, hist, po);
+            std::vector<uint64_t> tile(POST_TILE + 2);
+            post_gap(idx->dev, cfg, S, o, T, hist, tile.data(), po);
             uint32_t nw, nc;
             copy_plan(o, po, in.want_all_contigs, nw, nc);
             batch.chunks.emplace_back(new HostChunk());
