@@ -214,7 +214,10 @@ template <int SLOTS> MTG_DEV int table_or(const Table& t, uint64_t key, uint32_t
  * lists up to 14 further nucleotides of the unique simple path that starts with this node's single out-edge: every node on it has
  * exactly one in- and one out-edge, so the walker may take those steps without touching memory (partial unitig compaction, filled by
  * build_lookahead once all k-mers are inserted).  A bucket holds MTG_ADJ_SLOTS entries. */
-enum { MTG_LA_MAX = 14 };
+#ifndef MTG_LA_MAX_V
+#define MTG_LA_MAX_V 14 /* nucleotides of lookahead per direction in an ADJ entry (4-bit count + 2 bits each in 32 bits) */
+#endif
+enum { MTG_LA_MAX = MTG_LA_MAX_V };
 
 MTG_DEV uint32_t adj_get(const Table& t, uint64_t key, uint32_t& lines, uint64_t& aux)
 {
