@@ -848,10 +848,15 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             }
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16 * MTG_POST_PARTS, 0));
             HIP_TRY(hipEventRecord(ev0, 0));
-            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, 0));
-            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, 0));
-            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                               d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
+            {
+                /* the constants belong to the module, not to an index: batches on different indexes must not interleave these three */
+                static std::mutex launch_mtx;
+                std::lock_guard<std::mutex> lk(launch_mtx);
+                HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, 0));
+                HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, 0));
+                hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
+            }
             HIP_TRY(hipEventRecord(ev1, 0));
             HIP_TRY(hipGetLastError());
             tick("host prep+launch");

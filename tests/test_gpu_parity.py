@@ -446,3 +446,37 @@ def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
     assert got == want and max(len(g["filled"]) for g in plain) == 2
     idx2.close()
     o.close()
+
+
+def test_concurrent_batches_on_two_indexes(mtg, full_idx, ctg_idx, golden_dir):
+    """two host threads, each filling batches on its own index at the same time (the traversal kernel's constants are per module, the
+    worker pool, the result cache and the staging blocks are shared or per index): every result equals the single-threaded one"""
+    import threading
+    _, g1, _, _ = full_idx
+    _, g2, _, _ = ctg_idx
+    recs = _fasta(os.path.join(golden_dir, "full_test", "gold.breakpoints"))
+    gaps1 = [mtg.Gap(recs[i][1], recs[i + 1][1], [(recs[i + 1][1], recs[i][0].split()[0], False)]) for i in range(0, len(recs), 2)] * 40
+    ctgs = _fasta(os.path.join(golden_dir, "data", "contigs.fasta"))
+    gaps2 = []
+    for n, c in ctgs:  # contig mode in miniature: from the end of a contig to the starts of the others
+        tg = [(d[:31], m, False) for m, d in ctgs if m != n]
+        gaps2.append(mtg.Gap(c[-31:], "".join(t[0] for t in tg), tg))
+    gaps2 = gaps2 * 10
+    want1, want2 = g1.fill_batch(gaps1), g2.fill_batch(gaps2)
+    assert any(r["filled"] for r in want1) and any(r["filled"] for r in want2)
+    errors = []
+
+    def work(g, gaps, want):
+        try:
+            for _ in range(15):
+                if g.fill_batch(gaps) != want:
+                    errors.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=a) for a in ((g1, gaps1, want1), (g2, gaps2, want2), (g1, gaps1, want1))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
