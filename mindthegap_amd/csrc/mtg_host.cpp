@@ -689,6 +689,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
             arena.ext_next_gap = first + count;
             if (incomplete.load()) arena.ext_ok = false; /* a gap of this chunk gets its sequences later, out of order */
         }
+        if (!ids && !incomplete.load()) src.part_done(first, count, nth);
         t_parts += now_ms() - t;
     };
     int rc = device_run(idx, p, in, batch, &st, &before_post, &while_busy, &on_ready);
@@ -870,6 +871,8 @@ struct AbiSource : mtgi::BatchSource {
     void marshal(const mtgi::FillInput& in, int nthreads) override
     {
         R->gaps.resize(n);
+        R->res.resize(n);
+        if (R->filled_flat.size() < n) R->filled_flat.resize(n);
         R->targets.resize(in.tle.size());
         mtgi::parallel_for(n, nthreads, [&](size_t i) {
             const mtg_gap& a = g[i];
@@ -890,6 +893,38 @@ struct AbiSource : mtgi::BatchSource {
         }, 256);
     }
     std::vector<mtgi::GapWork>& gaps() override { return R->gaps; }
+    /* the C-ABI records of a finished part, written while the device works on the next one: such gaps have at most one solution, which
+     * takes the slot of its gap in filled_flat (sized for one per gap by marshal) */
+    size_t recorded = 0; /* gaps [0, recorded) have their records */
+    void part_done(size_t first, size_t count, int nthreads) override
+    {
+        if (first != recorded) return;
+        mtgi::parallel_for(count, nthreads, [&](size_t j) { write_record(first + j, R->filled_flat.data() + first + j); }, 512);
+        recorded = first + count;
+    }
+    /* returns the slot after the last one used */
+    mtg_filled* write_record(size_t i, mtg_filled* F0)
+    {
+        mtgi::GapWork& w = R->gaps[i];
+        mtg_gap_result& r = R->res[i];
+        r.filled = F0;
+        for (auto& s : w.sols) {
+            mtg_filled& f = *F0++;
+            f.seq = s.seq.c_str();
+            f.nb_errors_in_anchor = s.nb_errors;
+            f.target_index = s.target;
+            f.avg_coverage = s.avg;
+            f.median_coverage = s.median;
+            f.qual = s.qual;
+            f.solution_count = s.count;
+            f.solution_rank = s.rank;
+        }
+        r.nb_nodes = w.nb_nodes; r.total_nt = w.total_nt; r.nb_terminal = w.nb_terminal;
+        r.has_solution_counts = w.has_counts; r.nb_total_filled = w.nb_total_filled; r.nb_reported = (int)w.sols.size();
+        r.n_filled = (int)w.sols.size();
+        r.extension = w.extension.c_str();
+        return F0;
+    }
 };
 } // namespace
 
@@ -908,11 +943,13 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
     std::vector<uint64_t> sol_blocks;
     int rc = mtgi::fill_gaps(idx, p, src, R->arena, &st, &sol_blocks);
     if (rc) { results_release(R); return rc; }
+    bool relaid = false; /* the sequences were moved after the parts had been recorded */
     if (seq_out) {
         if (R->arena.ext_ok && R->arena.ext_next_gap == n) *seq_bytes = R->arena.ext_used; /* every sequence was decoded in place, in gap order */
         else {
             /* multi-contig gaps, re-run gaps or a buffer too small for the worst case: lay the sequences out again, in gap order, and
              * make the solutions point there */
+            relaid = true;
             const size_t CH = 1024, nch = (n + CH - 1) / CH;
             std::vector<uint64_t> choff(nch + 1, 0);
             mtgi::parallel_for(nch, p->nb_host_threads, [&](size_t c) {
@@ -939,34 +976,19 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
     }
     const double t_m2 = mtgi::now_ms();
     tk = t_m2;
-    const size_t B = mtgi::RESULT_BLOCK, nb = (n + B - 1) / B;
-    std::vector<uint64_t> blk_off(nb + 1, 0);
-    for (size_t b = 0; b < nb; b++) blk_off[b + 1] = blk_off[b] + sol_blocks[b];
-    R->res.resize(n);
-    R->filled_flat.resize(blk_off[nb]);
-    mtgi::parallel_for(nb, p->nb_host_threads, [&](size_t b) {
-        mtg_filled* F0 = R->filled_flat.data() + blk_off[b];
-        for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) {
-            mtgi::GapWork& w = R->gaps[i];
-            mtg_gap_result& r = R->res[i];
-            r.filled = F0;
-            for (auto& s : w.sols) {
-                mtg_filled& f = *F0++;
-                f.seq = s.seq.c_str();
-                f.nb_errors_in_anchor = s.nb_errors;
-                f.target_index = s.target;
-                f.avg_coverage = s.avg;
-                f.median_coverage = s.median;
-                f.qual = s.qual;
-                f.solution_count = s.count;
-                f.solution_rank = s.rank;
-            }
-            r.nb_nodes = w.nb_nodes; r.total_nt = w.total_nt; r.nb_terminal = w.nb_terminal;
-            r.has_solution_counts = w.has_counts; r.nb_total_filled = w.nb_total_filled; r.nb_reported = (int)w.sols.size();
-            r.n_filled = (int)w.sols.size();
-            r.extension = w.extension.c_str();
-        }
-    }, 1);
+    if (src.recorded == n && !relaid) {
+        /* every part wrote its records as it came back */
+    } else {
+        const size_t B = mtgi::RESULT_BLOCK, nb = (n + B - 1) / B;
+        std::vector<uint64_t> blk_off(nb + 1, 0);
+        for (size_t b = 0; b < nb; b++) blk_off[b + 1] = blk_off[b] + sol_blocks[b];
+        R->res.resize(n);
+        if (R->filled_flat.size() < blk_off[nb]) R->filled_flat.resize(blk_off[nb]);
+        mtgi::parallel_for(nb, p->nb_host_threads, [&](size_t b) {
+            mtg_filled* F0 = R->filled_flat.data() + blk_off[b];
+            for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) F0 = src.write_record(i, F0);
+        }, 1);
+    }
     /* the views on the caller's strings end here */
     tick("result records");
     st.marshal_ms = 0;

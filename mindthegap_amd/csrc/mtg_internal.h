@@ -505,6 +505,8 @@ struct BatchSource {
     /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
     virtual void marshal(const FillInput& in, int nthreads) = 0;
     virtual std::vector<GapWork>& gaps() = 0;
+    /* the gaps first .. first + count - 1 have their final solutions (none of them waits for the multi-contig path or for a re-run) */
+    virtual void part_done(size_t first, size_t count, int nthreads) { (void)first; (void)count; (void)nthreads; }
 };
 enum { RESULT_BLOCK = 512 };
 /* sol_blocks (optional): number of solutions in each block of RESULT_BLOCK gaps */
