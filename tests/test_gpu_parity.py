@@ -326,9 +326,11 @@ def test_pipelined_gather_on_rccl_single_rank(mtg):
     import torch
     import torch.distributed as dist
     from mindthegap_amd.shard import PipelinedGather
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import socket
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         dev = torch.device("cuda", 0)
         pg = PipelinedGather(1 << 20, dst=0, device=dev)
