@@ -24,7 +24,11 @@ def test_world_size_2_gloo_matches_truth(tmp_path):
     oracle_lib.build()
     out = str(tmp_path / "gathered.bin")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+    import socket
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "tests", "dist_worker.py"), out]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
