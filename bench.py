@@ -249,7 +249,10 @@ def main():
     post_s = post_ms / max(launches, 1) * 1e-3
     post_traffic = None
     if traffic is not None:
-        post_traffic = json.load(open(pmc)).get("mtgi::k_post", {}).get("hbm_read_bytes_avg")
+        pj = json.load(open(pmc))
+        kp, ka = pj.get("mtgi::k_post", {}), pj.get("mtgi::k_stage_a", {})
+        if kp.get("hbm_read_bytes_avg") and ka.get("launches_FETCH_SIZE"):  # k_post runs as several launches per traversal launch: sum them
+            post_traffic = kp["hbm_read_bytes_avg"] * kp["launches_FETCH_SIZE"] / ka["launches_FETCH_SIZE"]
     roof["post_kernel"] = {"kernel": "k_post", "bound": "hbm", "avg_kernel_ms": post_ms / max(launches, 1), "abundance_lookups_per_launch": lookups,
                            "achieved": 64.0 * lookups / post_s / 1e9 if post_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
                            "frac": (64.0 * lookups / post_s / 1e9 / 8000.0) if post_s > 0 else 0.0, "traffic": post_traffic}
