@@ -1,0 +1,35 @@
+"""soak: many batches on one index (alternating sizes, forward and serialised calls); prints host RSS and device memory at intervals"""
+import os, sys, time, resource
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+torch.cuda.init()
+import mindthegap_amd as mtg
+from mindthegap_amd.synth import SynthSet
+S = SynthSet(nseq=100000, n_sites=100000, seed=1, k=31)
+dev = torch.device("cuda", 0)
+w = torch.from_numpy(S.words.view(np.int64)).to(dev); wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev); ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
+idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 40)
+gaps = []
+for i in range(S.n_sites):
+    l, r, _ = S.site(i)
+    gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+preps = [mtg.Index.prepare_gaps(gaps[:n]) for n in (100000, 1000, 37000, 64, 100000)]
+sizes = [100000, 1000, 37000, 64, 100000]
+out = np.empty(80 << 20, dtype=np.uint8)
+def rss():
+    return int(open("/proc/self/statm").read().split()[1]) * 4096 / 2**20
+t0 = time.time()
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
+    j = it % len(preps)
+    if it % 3 == 0:
+        h, nf, nb = idx.fill_prepared_serial(preps[j], out)
+    else:
+        h, nf, _ = idx.fill_prepared(preps[j], want_seqs=(it % 7 == 0))
+    assert int((nf > 0).sum()) == sizes[j]
+    idx.free_results(h)
+    if it % 400 == 0:
+        free, total = torch.cuda.mem_get_info()
+        print("iter %5d  %.1f s  host RSS %.0f MB  device used %.2f GB" % (it, time.time() - t0, rss(), (total - free) / 2**30), flush=True)
+print("done", time.time() - t0)
