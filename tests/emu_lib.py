@@ -10,6 +10,11 @@ SRC = os.path.join(ROOT, "tests", "emu", "emu.cpp")
 SO = os.path.join(ROOT, "tests", "emu", "libmtg_emu.so")
 HDRS = [os.path.join(ROOT, "mindthegap_amd", "csrc", h) for h in ("mtg_dev.h", "mtg_traverse.h", "mtg_post.h", "mtg_paths.h", "mtg_hostutil.h")]
 
+# MTG_EMU_SANITIZE=1: build the emulation libraries with AddressSanitizer + UBSan (run pytest with LD_PRELOAD=$(gcc -print-file-name=libasan.so))
+SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-O1"] if os.environ.get("MTG_EMU_SANITIZE") else []
+if SAN:
+    SO = SO.replace(".so", "_san.so")
+
 _lib = None
 
 
@@ -19,7 +24,7 @@ def load():
         return _lib
     deps = [SRC] + HDRS
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SO, SRC])
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall"] + SAN + ["-o", SO, SRC])
     lib = C.CDLL(SO)
     P = C.POINTER
     lib.emu_index_create.restype = C.c_void_p
@@ -66,7 +71,7 @@ class EmuIndex:
 
 
 # ---- the product's host code + CLI linked against the emulated device backend (tests/emu/emu_backend.cpp) ----
-FULL_SO = os.path.join(ROOT, "tests", "emu", "libmtgfill_emu.so")
+FULL_SO = os.path.join(ROOT, "tests", "emu", "libmtgfill_emu_san.so" if SAN else "libmtgfill_emu.so")
 
 
 def build_full():
@@ -76,7 +81,7 @@ def build_full():
     deps = srcs + HDRS + [os.path.join(csrc, "mtg_internal.h"), os.path.join(ROOT, "include", "mtg_fill.h")]
     if not os.path.exists(FULL_SO) or any(os.path.getmtime(d) > os.path.getmtime(FULL_SO) for d in deps):
         tmp = FULL_SO + ".%d.tmp" % os.getpid()
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-o", tmp] + srcs + ["-lz"])
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"] + SAN + ["-o", tmp] + srcs + ["-lz"])
         os.replace(tmp, FULL_SO)
     return FULL_SO
 
