@@ -61,7 +61,9 @@ public:
                 std::lock_guard<std::mutex> lk(m_);
                 job_ = &job;
                 active_.store(helpers, std::memory_order_relaxed);
-                to_start_.store(helpers, std::memory_order_relaxed);
+                /* release: a helper that is still looking at the previous generation may take one of these slots through claim()
+                 * alone; it must see job_ */
+                to_start_.store(helpers, std::memory_order_release);
                 gen_.fetch_add(1, std::memory_order_release);
             }
             cv_.notify_all();
