@@ -463,3 +463,29 @@ def test_banded_nw_equals_full_matrix(oracle):
         ident = oracle.mtgo_needleman_wunsch(a.encode(), b.encode())
         expect = round(ident * max(len(a), len(b)))
         assert lib.emu_nw_matches(a.encode(), b.encode()) == expect, (a, b)
+
+
+def _abi_edge_cases(mtg_mod):
+    """empty batches (plain and serialised), a source shorter than k, a sequence buffer that is too small"""
+    s = _rand_seq(random.Random(11), 300)
+    o = oracle_lib.Index.from_sequences([s], 31, 1, 40)
+    km, ct = o.export()
+    idx = mtg_mod.Index.from_kmers(km, ct, 31)
+    assert idx.fill_batch([]) == []
+    out = np.empty(1024, dtype=np.uint8)
+    h, nf, nb = idx.fill_prepared_serial(mtg_mod.Index.prepare_gaps([]), out)
+    idx.free_results(h)
+    assert len(nf) == 0 and nb == 0
+    with pytest.raises(mtg_mod.MtgError):
+        idx.fill_batch([mtg_mod.Gap("ACGT", "ACGT", [("ACGT", "x", False)])])
+    g = mtg_mod.Gap(s[:31], s[100:131], [(s[100:131], "t", False)])
+    plain = idx.fill_batch([g])
+    assert plain[0]["filled"] and plain[0]["filled"][0]["seq"] == s[31:100]
+    with pytest.raises(mtg_mod.MtgError):
+        idx.fill_prepared_serial(mtg_mod.Index.prepare_gaps([g]), np.empty(8, dtype=np.uint8))
+    idx.close()
+    o.close()
+
+
+def test_abi_edge_cases_on_emulator(emu_product):
+    _abi_edge_cases(emu_product)

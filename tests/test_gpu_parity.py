@@ -482,3 +482,8 @@ def test_concurrent_batches_on_two_indexes(mtg, full_idx, ctg_idx, golden_dir):
     for t in ts:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_abi_edge_cases(mtg):
+    from tests.test_emu_parity import _abi_edge_cases
+    _abi_edge_cases(mtg)
