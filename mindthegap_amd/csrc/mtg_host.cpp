@@ -795,6 +795,10 @@ struct mtg_results {
     std::vector<mtgi::GapWork> gaps;
     std::vector<mtg_gap_result> res;
     int nthreads = 0; /* host threads of the batch that filled it */
+    /* kept up to date by the record writer: what mtg_results_summary reports */
+    std::vector<uint32_t> nfilled;
+    std::atomic<uint64_t> sum_bytes{0}, sum_filled{0};
+    bool summary_ready = false;
 };
 struct mtg_contigs {
     std::vector<std::vector<std::string>> c;
@@ -872,6 +876,7 @@ struct AbiSource : mtgi::BatchSource {
     {
         R->gaps.resize(n);
         R->res.resize(n);
+        R->nfilled.resize(n);
         if (R->filled_flat.size() < n) R->filled_flat.resize(n);
         R->targets.resize(in.tle.size());
         mtgi::parallel_for(n, nthreads, [&](size_t i) {
@@ -899,8 +904,26 @@ struct AbiSource : mtgi::BatchSource {
     void part_done(size_t first, size_t count, int nthreads) override
     {
         if (first != recorded) return;
-        mtgi::parallel_for(count, nthreads, [&](size_t j) { write_record(first + j, R->filled_flat.data() + first + j); }, 512);
+        const size_t CH = 512, nch = (count + CH - 1) / CH;
+        mtgi::parallel_for(nch, nthreads, [&](size_t c) {
+            uint64_t lb = 0, lf = 0;
+            for (size_t j = c * CH; j < std::min(count, (c + 1) * CH); j++) {
+                const size_t i = first + j;
+                write_record(i, R->filled_flat.data() + i);
+                tally(i, lb, lf);
+            }
+            R->sum_bytes.fetch_add(lb, std::memory_order_relaxed);
+            R->sum_filled.fetch_add(lf, std::memory_order_relaxed);
+        }, 1);
         recorded = first + count;
+    }
+    /* what mtg_results_summary reports about gap i */
+    void tally(size_t i, uint64_t& bytes, uint64_t& filled)
+    {
+        const mtgi::GapWork& w = R->gaps[i];
+        R->nfilled[i] = (uint32_t)w.sols.size();
+        filled += !w.sols.empty();
+        for (auto& s : w.sols) bytes += s.seq.size() + 1;
     }
     /* returns the slot after the last one used */
     mtg_filled* write_record(size_t i, mtg_filled* F0)
@@ -937,6 +960,7 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
     auto tick = [&](const char* what) { if (dbg) { const double t = mtgi::now_ms(); fprintf(stderr, "  [fill_batch] %-21s %.2f ms\n", what, t - tk); tk = t; } };
     mtg_results* R = results_acquire();
     R->nthreads = p->nb_host_threads;
+    R->sum_bytes.store(0); R->sum_filled.store(0); R->summary_ready = false;
     R->arena.set_external(seq_out, seq_out ? (size_t)seq_cap : 0);
     AbiSource src(gaps, n, R);
     mtg_batch_stats st{};
@@ -978,6 +1002,7 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
     tk = t_m2;
     if (src.recorded == n && !relaid) {
         /* every part wrote its records as it came back */
+        R->summary_ready = true;
     } else {
         const size_t B = mtgi::RESULT_BLOCK, nb = (n + B - 1) / B;
         std::vector<uint64_t> blk_off(nb + 1, 0);
@@ -988,6 +1013,7 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
             mtg_filled* F0 = R->filled_flat.data() + blk_off[b];
             for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) F0 = src.write_record(i, F0);
         }, 1);
+        R->summary_ready = false; /* computed on demand */
     }
     /* the views on the caller's strings end here */
     tick("result records");
@@ -1015,6 +1041,12 @@ void mtg_results_free(mtg_results* r)
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
 {
     if (!r) return MTG_ERR_ARG;
+    if (r->summary_ready) { /* tallied while the batch was assembled */
+        if (n_filled && !r->nfilled.empty()) memcpy(n_filled, r->nfilled.data(), r->nfilled.size() * sizeof(uint32_t));
+        if (seq_bytes) *seq_bytes = r->sum_bytes.load();
+        if (n_gaps_filled) *n_gaps_filled = r->sum_filled.load();
+        return MTG_OK;
+    }
     std::atomic<uint64_t> b{0}, nf{0};
     const size_t n = r->gaps.size();
     const size_t CH = 2048;
