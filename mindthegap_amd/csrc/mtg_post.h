@@ -58,6 +58,7 @@ MTG_DEV uint64_t wave_max64(uint64_t x) { return x; }
 MTG_DEV uint32_t wave_sum32(uint32_t x) { return x; }
 MTG_DEV void hist_add(uint32_t* h, uint32_t v) { h[v]++; }
 MTG_DEV void wave_sync() {}
+MTG_DEV bool wave_any(bool x) { return x; }
 #else
 #define MTG_LANE() (threadIdx.x & 63u)
 #define MTG_NLANES 64u
@@ -76,6 +77,7 @@ MTG_DEV uint32_t wave_sum32(uint32_t x)
     return x;
 }
 MTG_DEV void hist_add(uint32_t* h, uint32_t v) { atomicAdd(&h[v], 1u); }
+MTG_DEV bool wave_any(bool x) { return __ballot(x) != 0ull; }
 MTG_DEV void wave_sync() { __syncthreads(); }
 #endif
 
@@ -127,22 +129,28 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                 const uint32_t j_lo = 32u * ws;
                 if (j_lo >= npos) break;
                 const uint32_t j_hi = (npos - j_lo) < 32u * POST_TILE ? npos : j_lo + 32u * POST_TILE;
-                for (uint32_t j = j_lo + lane; j < j_hi; j += MTG_NLANES) {
-                    const uint64_t x = le_kmer(tile, j - j_lo, mk);
-                    for (uint32_t t = 0; t < T.n; t++) {
-                        const uint64_t m = x ^ T.le[t];
-                        const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
+                bool exact = false; /* an exact match is the largest possible count and the earliest one wins: nothing after it matters */
+                for (uint32_t jb = j_lo; jb < j_hi && !exact; jb += MTG_NLANES) {
+                    const uint32_t j = jb + lane;
+                    if (j < j_hi) {
+                        const uint64_t x = le_kmer(tile, j - j_lo, mk);
+                        for (uint32_t t = 0; t < T.n; t++) {
+                            const uint64_t m = x ^ T.le[t];
+                            const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
 #ifdef MTG_EMU
-                        const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
+                            const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
 #else
-                        const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
+                            const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
 #endif
-                        if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
-                            const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t));
-                            best = key > best ? key : best;
+                            if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
+                                const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t));
+                                best = key > best ? key : best;
+                            }
                         }
                     }
+                    exact = wave_any((uint32_t)(best >> 40) == (uint32_t)k);
                 }
+                if (exact) break;
                 if (j_hi >= npos) break;
             }
         }
