@@ -659,8 +659,10 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
         for (auto& e : ends) e.store(-1, std::memory_order_relaxed);
         ends[0].store(0, std::memory_order_release);
         std::atomic<bool> incomplete{false};
+        std::atomic<uint64_t> rec_bytes{0}, rec_filled{0};
+        const bool recording = !ids;
         parallel_for(nbp, nth, [&](size_t b) {
-            uint64_t need = 0;
+            uint64_t need = 0, rb = 0, rf = 0;
             for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
                 const SlotRec& r = batch.rec(gap_of(j));
                 need += (r.o.status == GAP_OK && r.p.fast == 1) ? (uint64_t)(r.p.pos - (uint32_t)k) + 1 : 0;
@@ -678,18 +680,20 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
                 if (i / B != cur_blk) { if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed); nsol = 0; cur_blk = i / B; }
                 genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
                 if (genw[i]) odd = true;
+                else if (recording) src.record_gap(i, rb, rf);
                 off += gd.p.fast == 1 ? (uint64_t)(gd.p.pos - (uint32_t)k) + 1 : 0;
                 nsol += gaps[i].sols.size();
             }
             if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed);
             if (odd) incomplete = true;
+            if (rb | rf) { rec_bytes.fetch_add(rb, std::memory_order_relaxed); rec_filled.fetch_add(rf, std::memory_order_relaxed); }
         }, 1);
         if (external) {
             arena.ext_used += (size_t)ends[nbp].load(std::memory_order_acquire);
             arena.ext_next_gap = first + count;
             if (incomplete.load()) arena.ext_ok = false; /* a gap of this chunk gets its sequences later, out of order */
         }
-        if (!ids && !incomplete.load()) src.part_done(first, count, nth);
+        if (recording) src.part_done(first, count, !incomplete.load(), rec_bytes.load(), rec_filled.load());
         t_parts += now_ms() - t;
     };
     int rc = device_run(idx, p, in, batch, &st, &before_post, &while_busy, &on_ready);
@@ -901,20 +905,16 @@ struct AbiSource : mtgi::BatchSource {
     /* the C-ABI records of a finished part, written while the device works on the next one: such gaps have at most one solution, which
      * takes the slot of its gap in filled_flat (sized for one per gap by marshal) */
     size_t recorded = 0; /* gaps [0, recorded) have their records */
-    void part_done(size_t first, size_t count, int nthreads) override
+    void record_gap(size_t i, uint64_t& bytes, uint64_t& filled) override
     {
-        if (first != recorded) return;
-        const size_t CH = 512, nch = (count + CH - 1) / CH;
-        mtgi::parallel_for(nch, nthreads, [&](size_t c) {
-            uint64_t lb = 0, lf = 0;
-            for (size_t j = c * CH; j < std::min(count, (c + 1) * CH); j++) {
-                const size_t i = first + j;
-                write_record(i, R->filled_flat.data() + i);
-                tally(i, lb, lf);
-            }
-            R->sum_bytes.fetch_add(lb, std::memory_order_relaxed);
-            R->sum_filled.fetch_add(lf, std::memory_order_relaxed);
-        }, 1);
+        write_record(i, R->filled_flat.data() + i);
+        tally(i, bytes, filled);
+    }
+    void part_done(size_t first, size_t count, bool clean, uint64_t bytes, uint64_t filled) override
+    {
+        if (first != recorded || !clean) return; /* from here on the records are rebuilt at the end */
+        R->sum_bytes.fetch_add(bytes, std::memory_order_relaxed);
+        R->sum_filled.fetch_add(filled, std::memory_order_relaxed);
         recorded = first + count;
     }
     /* what mtg_results_summary reports about gap i */

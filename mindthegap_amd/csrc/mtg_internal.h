@@ -507,8 +507,11 @@ struct BatchSource {
     /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
     virtual void marshal(const FillInput& in, int nthreads) = 0;
     virtual std::vector<GapWork>& gaps() = 0;
-    /* the gaps first .. first + count - 1 have their final solutions (none of them waits for the multi-contig path or for a re-run) */
-    virtual void part_done(size_t first, size_t count, int nthreads) { (void)first; (void)count; (void)nthreads; }
+    /* Result records as the chunks come back: record_gap(i, ...) from any thread once gap i has its final solutions (speculative: the
+     * caller may still find out that the chunk needs the multi-contig path or a re-run), then part_done(first, count, clean) once per
+     * chunk that was a contiguous range of gaps. */
+    virtual void record_gap(size_t i, uint64_t& bytes, uint64_t& filled) { (void)i; (void)bytes; (void)filled; }
+    virtual void part_done(size_t first, size_t count, bool clean, uint64_t bytes, uint64_t filled) { (void)first; (void)count; (void)clean; (void)bytes; (void)filled; }
 };
 enum { RESULT_BLOCK = 512 };
 /* sol_blocks (optional): number of solutions in each block of RESULT_BLOCK gaps */
