@@ -218,7 +218,8 @@ def main():
         # algorithmic probes per contig nucleotide, counted by the oracle on the sample
         sample_nt = sum(S.seq_len + int(S.ins_len[i]) - int(S.pos[i]) + k for i in range(ns))
         probes_per_nt = ost["probes"] / max(sample_nt, 1)
-        cpu = {"value": ns / ost["seconds"], "unit": "breakpoints/s", "cores": cores, "kind": "port",
+        cpu_model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
+        cpu = {"value": ns / ost["seconds"], "unit": "breakpoints/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
                "sample": "%d of the %d sites, index over the first %d donor sequences (%d k-mers), CPU restatement of the reference Filler (gatb-core unavailable)"
                          % (ns, sites_per_gpu, nidx, len(oidx)),
                "seconds": ost["seconds"], "identical_to_hip": cpu_seqs == hip_seqs and identical is not False}
