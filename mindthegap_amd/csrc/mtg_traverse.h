@@ -60,7 +60,9 @@ struct GapScratch {
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
     uint32_t lane;
+    uint16_t* fp; /* this lane's column of a small fingerprint table (FP_SLOTS rows of 64 lanes; LDS on the device), or null: no SNP fast path */
 };
+enum { FP_SLOTS = 128 };
 /* strided view of one lane's array in the interleaved region */
 template <typename T> struct SP {
     T* p;
@@ -156,6 +158,7 @@ MTG_DEV GapScratch carve(const FillCfg& c, uint8_t* zero_base, uint8_t* raw_base
     S.r = raw_base + gap * c.raw_stride;
     S.v = ilv_base + (gap >> 6) * c.ilv_stride;
     S.lane = (uint32_t)(gap & 63);
+    S.fp = nullptr;
     return S;
 }
 
@@ -633,6 +636,135 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
     return chosen;
 }
 
+/* ---- the SNP bubble, recognised and answered without the general machinery -------------------------------------------------------
+ * Pattern: the node has exactly two out-edges whose targets have in-degree 1; from there both branches are simple paths (every node
+ * one in-, one out-edge, known from bucket reads and lookahead runs) that step onto the same node e after the same number L <= 40 of
+ * nodes, spelling the same nucleotides after the first; no node of it is marked, and all its k-mers (with the node itself and the
+ * previous node) are pairwise distinct as canonical k-mers.  On such a subgraph the reference's explore_branching is determined:
+ *   find_end_of_branching  advances both branches level by level (every frontline check passes at once on in-degree 1) and stops at
+ *                          depth L + 1 with the single node e;
+ *   all_consensuses_between finds the two paths, in A, C, T, G order of their first nucleotide;
+ *   validate_consensuses   equal lengths, one substitution: identity (L / (L + 1)) >= 90 % is tested with the same float code; the
+ *                          consensus with the larger mean abundance over [node, branch nodes] wins, the first one on a tie;
+ *   marking                of the involved nodes only e is branching.
+ * Anything else -- including a fingerprint collision that turns out to be a real duplicate -- returns 0 and the caller runs the
+ * general code, so the fast path never decides a case it does not fully understand.  The distinctness test keeps 16-bit fingerprints
+ * of the canonical k-mers in a small table (LDS); a fingerprint seen before is checked exactly by walking the branches again. */
+MTG_DEV uint32_t fp_hash(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 32); }
+MTG_DEV void fp_clear(const GapScratch& S) { for (int i = 0; i < FP_SLOTS; i++) S.fp[(size_t)i * 64] = 0; }
+/* 0: new; 1: a k-mer with this fingerprint was added before */
+MTG_DEV int fp_add(const GapScratch& S, uint64_t c)
+{
+    const uint32_t h = fp_hash(c);
+    const uint16_t fp = (uint16_t)((h >> 16) | 1u);
+    uint32_t s = h & (FP_SLOTS - 1);
+    for (;;) {
+        const uint16_t v = S.fp[(size_t)s * 64];
+        if (v == 0) { S.fp[(size_t)s * 64] = fp; return 0; }
+        if (v == fp) return 1;
+        s = (s + 1) & (FP_SLOTS - 1);
+    }
+}
+/* is canonical k-mer c among: the node, prev_c, and the first `steps` nodes of each branch (the walk is replayed from the consensus
+ * nucleotides written so far), the node x of branch `skip_branch` at position `skip_pos` excepted */
+MTG_DEV bool snp_seen_exactly(Worker& W, const Kmer& cur, uint64_t prev_c, int steps, uint64_t c, int skip_branch, int skip_pos)
+{
+    if (canon(cur) == c || prev_c == c) return true;
+    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+    for (int br = 0; br < 2; br++) {
+        Kmer x = cur;
+        for (int i = 0; i < steps; i++) {
+            x = kmer_next(x, cons[(size_t)br * CONS_LEN + i], W.k, W.mk);
+            if (br == skip_branch && i + 1 == skip_pos) continue;
+            if (canon(x) == c) return true;
+        }
+    }
+    return false;
+}
+enum { SNP_MAX_L = 40 };
+/* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
+MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen)
+{
+    if (!W.S.fp || W.cfg.end_rule_nonbranching) return 0;
+    if (!(popc4(a.out) == 2 && popc4(a.in) == 1)) return 0;
+    const int k = W.k;
+    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+    const uint32_t nt0[2] = {(uint32_t)ctz4(a.out), (uint32_t)ctz4(a.out & (a.out - 1))};
+    Kmer x[2];
+    uint32_t aux[2] = {AUX_IN1, AUX_IN1};
+    for (int br = 0; br < 2; br++) { x[br] = kmer_next(cur, nt0[br], k, W.mk); cons[(size_t)br * CONS_LEN] = (uint8_t)nt0[br]; }
+    fp_clear(W.S);
+    fp_add(W.S, canon(cur));
+    if (fp_add(W.S, prev_c) && prev_c == canon(cur)) return 0;
+    int L = 0;
+    for (int step = 1; step <= SNP_MAX_L; step++) {
+        /* the nodes at position `step` of both branches: unmarked, new */
+        uint32_t nt[2];
+        for (int br = 0; br < 2; br++) {
+            const uint64_t c = canon(x[br]);
+            if (W.is_marked(c)) return 0;
+            if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, step, c, br, step)) return 0;
+            if (aux[br] & 15u) { nt[br] = (aux[br] >> 4) & 3u; aux[br] = aux_step(aux[br]); }
+            else {
+                const Adj r = adj_right(W.ix, x[br], W.mk1, W.lines);
+                if (popc4(r.out) != 1) return 0; /* dead end or a branching inside the bubble */
+                nt[br] = (uint32_t)ctz4(r.out);
+                aux[br] = aux_of_children(r);
+            }
+        }
+        if (W.status) return 0;
+        if (nt[0] != nt[1]) return 0; /* more than one substitution */
+        cons[step] = (uint8_t)nt[0];
+        cons[(size_t)CONS_LEN + step] = (uint8_t)nt[1];
+        const Kmer y0 = kmer_next(x[0], nt[0], k, W.mk), y1 = kmer_next(x[1], nt[1], k, W.mk);
+        if (y0.f == y1.f) { L = step; x[0] = y0; break; } /* the branches meet: x[0] = e */
+        if (!(aux[0] & AUX_IN1) || !(aux[1] & AUX_IN1)) return 0; /* a node with another way in: the frontline check would have work to do */
+        x[0] = y0;
+        x[1] = y1;
+    }
+    if (L == 0) return 0;
+    const Kmer e = x[0];
+    const uint64_t ce = canon(e);
+    if (W.is_marked(ce)) return 0;
+    if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, L, ce, -1, 0)) return 0;
+    const int n = L + 1;
+    if (n > W.cfg.mono_max_depth) return 0;
+    if (identity_below_90(n - 1, n, n)) return 0;
+    /* most abundant consensus: mean over the node and the L nodes of the branch (src: validate_consensuses), look-ups 4 + 4 at a time */
+    unsigned long sum[2] = {0, 0};
+    {
+        Kmer w[2] = {cur, cur};
+        uint32_t a0 = abundance(W.ix, cur, W.lines);
+        sum[0] = sum[1] = a0;
+        for (int i = 0; i < L; i += 4) {
+            uint64_t keys[8];
+            uint32_t ab[8];
+            const uint32_t cnt = (uint32_t)((L - i) < 4 ? (L - i) : 4);
+            for (int br = 0; br < 2; br++)
+                for (int u = 0; u < 4; u++) {
+                    keys[br * 4 + u] = 0;
+                    if ((uint32_t)u < cnt) { w[br] = kmer_next(w[br], cons[(size_t)br * CONS_LEN + i + u], k, W.mk); keys[br * 4 + u] = canon(w[br]); }
+                }
+            /* the two branches as one batch of 8: positions >= cnt of a branch are padding */
+            uint64_t k8[8];
+            uint32_t m = 0;
+            for (int br = 0; br < 2; br++) for (uint32_t u = 0; u < cnt; u++) k8[m++] = keys[br * 4 + u];
+            for (uint32_t u = m; u < 8; u++) k8[u] = 0;
+            abundance_batch<8>(W.ix, k8, m, ab, W.lines);
+            for (uint32_t u = 0; u < cnt; u++) { sum[0] += ab[u]; sum[1] += ab[cnt + u]; }
+        }
+    }
+    sum[0] /= (unsigned long)n;
+    sum[1] /= (unsigned long)n;
+    unsigned long best = 0;
+    chosen = -1;
+    for (int c = 0; c < 2; c++) if (sum[c] > best) { best = sum[c]; chosen = c; }
+    if (chosen < 0) return 0;
+    s_conslen(W.cfg, W.S)[0] = s_conslen(W.cfg, W.S)[1] = (uint16_t)n;
+    W.mark_canon(ce); /* e has two in-edges: the one branching node among the involved ones */
+    return n;
+}
+
 /* [MEM] MonumentTraversal::explore_branching.  On success the consensus sits in
  * S.cons[chosen] and its length is returned; 0 on failure. */
 MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev_c, int& chosen)
@@ -863,7 +995,9 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         /* ---- phase B: branching node ---- */
         if (!end_contig) {
             int chosen = -1;
-            const int n = explore_branching(W, cur, prev_c, chosen);
+            int n = snp_bubble_fast(W, cur, prev_c, a, chosen);
+            const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
+            if (!fast) n = explore_branching(W, cur, prev_c, chosen);
             if (n <= 0) {
                 end_contig = true;
             } else {
@@ -874,7 +1008,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
                     cur = kmer_next(cur, p[i], k, mk);
                     push_nt(p[i]);
                     len++;
-                    W.mark(cur);
+                    if (!fast) W.mark(cur);
                     if (r_is_kmer && cur.f == R.r0) found_R = true;
                     if (canon(cur) == start_c) looping = true;
                 }
