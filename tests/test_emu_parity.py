@@ -489,3 +489,82 @@ def _abi_edge_cases(mtg_mod):
 
 def test_abi_edge_cases_on_emulator(emu_product):
     _abi_edge_cases(emu_product)
+
+
+def _snp_case(rng, k, kind):
+    """a locus with two (or three) alleles around one site, built to sit on or just outside the pattern of the SNP fast path"""
+    L, R = _rand_seq(rng, rng.randrange(k + 5, 120)), _rand_seq(rng, rng.randrange(k + 5, 160))
+    sub = lambda c: rng.choice([x for x in "ACGT" if x != c])
+    a = L + R
+    p = len(L)
+    alleles = [a]
+    if kind == 0:      # one substitution
+        alleles.append(a[:p] + sub(a[p]) + a[p + 1:])
+    elif kind == 1:    # two substitutions closer than k
+        q = p + rng.randrange(1, k)
+        b = list(a); b[p] = sub(b[p]); b[min(q, len(b) - 2)] = sub(b[min(q, len(b) - 2)])
+        alleles.append("".join(b))
+    elif kind == 2:    # three alleles
+        x = sub(a[p]); y = rng.choice([c for c in "ACGT" if c not in (a[p], x)])
+        alleles += [a[:p] + x + a[p + 1:], a[:p] + y + a[p + 1:]]
+    elif kind == 3:    # substitution next to a short indel
+        alleles.append(a[:p] + sub(a[p]) + a[p + 1:p + 5] + a[p + 5 + rng.randrange(1, 4):])
+    elif kind == 4:    # substitution inside a reverse-complement palindrome (canonical duplicates along the branches)
+        h = _rand_seq(rng, rng.randrange(k // 2 + 2, k + 6))
+        pal = h + _rc(h)
+        a = L + pal + R
+        p = len(L) + rng.randrange(0, len(pal))
+        alleles = [a, a[:p] + sub(a[p]) + a[p + 1:]]
+    elif kind == 5:    # substitution inside a tandem repeat (loops, nodes met twice)
+        u = _rand_seq(rng, rng.randrange(3, k + 8))
+        rep = u * rng.randrange(2, 5)
+        a = L + rep + R
+        p = len(L) + rng.randrange(0, len(rep))
+        alleles = [a, a[:p] + sub(a[p]) + a[p + 1:]]
+    elif kind == 6:    # the bubble twice: a repeat that contains the site (second passage meets marked nodes)
+        core = a[p - k - 3:p + k + 3]
+        a2 = a + _rand_seq(rng, 60) + core + _rand_seq(rng, 80)
+        alleles = [a2, a2[:p] + sub(a2[p]) + a2[p + 1:]]
+    elif kind == 7:    # a tip hanging off a branch node, and one off the node before the bubble
+        b = a[:p] + sub(a[p]) + a[p + 1:]
+        q = p + rng.randrange(1, k - 1)
+        tip = b[q - k + 1:q + 1][:k - 1] + sub(b[q]) if q + 1 < len(b) else ""
+        alleles += [b, b[q - k + 1:q] + sub(b[q]) + _rand_seq(rng, rng.randrange(0, 12))]
+        alleles.append(a[p - k:p - 1] + sub(a[p - 1]) + _rand_seq(rng, rng.randrange(0, 10)))
+    elif kind == 8:    # substitution close to the end of the sequence (a branch that dead-ends before the others meet)
+        a = L + R[:rng.randrange(2, k + 2)]
+        alleles = [a, a[:p] + sub(a[p]) + a[p + 1:]]
+    else:              # two independent substitutions further apart than k (two clean bubbles in a row)
+        q = p + k + rng.randrange(1, 30)
+        b = list(a)
+        b[p] = sub(b[p])
+        if q < len(b) - 1:
+            b[q] = sub(b[q])
+        alleles += ["".join(b), a[:p] + sub(a[p]) + a[p + 1:]]
+    return a, [x for x in alleles if len(x) >= k]
+
+
+@pytest.mark.parametrize("k", [31, 21, 16, 13])
+def test_snp_fast_path_adversarial(k):
+    """the SNP fast path of the traversal against the oracle's general bubble code: loci on and just outside its pattern, both strands,
+    both end rules, abundances that differ between the alleles"""
+    rng = random.Random(4242 + k)
+    for case in range(260):
+        kind = case % 10
+        a, alleles = _snp_case(rng, k, kind)
+        seqs = []
+        for i, x in enumerate(alleles):  # unequal multiplicities give the alleles different abundances
+            seqs += [x] * (1 + (case + i) % 3)
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k, load_factor=0.5)
+        srcs = [a[:k], _rc(a[-k:])]
+        if len(a) > 3 * k:
+            srcs.append(a[k // 2:k // 2 + k])
+        for s in srcs:
+            for er in (0, 1):
+                t = a[-k:]
+                oc, _ = idx.stage_a(s, t, oracle_lib.default_params(end_rule_nonbranching=er))
+                ec, st, _, _ = emu.stage_a(s, t, 100, 10000, er)
+                assert st == 0 and ec == oc, (case, kind, k, s, er, seqs)
+        idx.close()
