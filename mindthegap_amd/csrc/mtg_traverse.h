@@ -639,12 +639,12 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
 /* ---- the SNP bubble, recognised and answered without the general machinery -------------------------------------------------------
  * Pattern: the node has exactly two out-edges whose targets have in-degree 1; from there both branches are simple paths (every node
  * one in-, one out-edge, known from bucket reads and lookahead runs) that step onto the same node e after the same number L <= 40 of
- * nodes, spelling the same nucleotides after the first; no node of it is marked, and all its k-mers (with the node itself and the
+ * nodes (their nucleotides may differ in more places than the first: two substitutions closer than k); no node of it is marked, and all its k-mers (with the node itself and the
  * previous node) are pairwise distinct as canonical k-mers.  On such a subgraph the reference's explore_branching is determined:
  *   find_end_of_branching  advances both branches level by level (every frontline check passes at once on in-degree 1) and stops at
  *                          depth L + 1 with the single node e;
  *   all_consensuses_between finds the two paths, in A, C, T, G order of their first nucleotide;
- *   validate_consensuses   equal lengths, one substitution: identity (L / (L + 1)) >= 90 % is tested with the same float code; the
+ *   validate_consensuses   equal lengths: identity >= 90 % is tested with the same alignment and float code; the
  *                          consensus with the larger mean abundance over [node, branch nodes] wins, the first one on a tie;
  *   marking                of the involved nodes only e is branching.
  * Anything else -- including a fingerprint collision that turns out to be a real duplicate -- returns 0 and the caller runs the
@@ -681,7 +681,7 @@ MTG_DEV bool snp_seen_exactly(Worker& W, const Kmer& cur, uint64_t prev_c, int s
     }
     return false;
 }
-enum { SNP_MAX_L = 40 };
+enum { SNP_MAX_L = 48 }; /* 2 * 48 + 3 fingerprints in FP_SLOTS = 128 slots */
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen)
 {
@@ -696,7 +696,7 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     fp_clear(W.S);
     fp_add(W.S, canon(cur));
     if (fp_add(W.S, prev_c) && prev_c == canon(cur)) return 0;
-    int L = 0;
+    int L = 0, h = 1; /* h: positions at which the two consensuses differ */
     for (int step = 1; step <= SNP_MAX_L; step++) {
         /* the nodes at position `step` of both branches: unmarked, new */
         uint32_t nt[2];
@@ -713,7 +713,7 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
             }
         }
         if (W.status) return 0;
-        if (nt[0] != nt[1]) return 0; /* more than one substitution */
+        h += nt[0] != nt[1];
         cons[step] = (uint8_t)nt[0];
         cons[(size_t)CONS_LEN + step] = (uint8_t)nt[1];
         const Kmer y0 = kmer_next(x[0], nt[0], k, W.mk), y1 = kmer_next(x[1], nt[1], k, W.mk);
@@ -729,7 +729,9 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, L, ce, -1, 0)) return 0;
     const int n = L + 1;
     if (n > W.cfg.mono_max_depth) return 0;
-    if (identity_below_90(n - 1, n, n)) return 0;
+    /* one substitution: the diagonal is the unique optimal alignment (see validate_consensuses); more: the exact banded alignment */
+    const int matches = h < 2 ? n - h : nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
+    if (identity_below_90(matches, n, n)) return 0;
     /* most abundant consensus: mean over the node and the L nodes of the branch (src: validate_consensuses), look-ups 4 + 4 at a time */
     unsigned long sum[2] = {0, 0};
     {
