@@ -235,11 +235,16 @@ struct Worker {
     }
     /* the three sets live in memory that is zero before a launch and must be zero again after it (nobody clears it in between) */
     MTG_DEV void marked_clear() { for (uint32_t i = 0; i < n_marked; i++) s_marked(cfg, S)[s_marklog(cfg, S)[i]] = 0; n_marked = 0; }
-    MTG_DEV bool is_marked(uint64_t c) const
+    /* register-only half of is_marked: false = certainly not marked */
+    MTG_DEV bool maybe_marked(uint64_t c) const
     {
         const uint32_t b = sig_bit(c);
         const uint64_t w = (b >> 6) == 0 ? msig0 : (b >> 6) == 1 ? msig1 : (b >> 6) == 2 ? msig2 : msig3;
-        if (!((w >> (b & 63)) & 1)) return false;
+        return ((w >> (b & 63)) & 1) != 0;
+    }
+    MTG_DEV bool is_marked(uint64_t c) const
+    {
+        if (!maybe_marked(c)) return false;
         return set_has(s_marked(cfg, S), cfg.mcap, c);
     }
     /* adds c to the frontline visited set; true when it was not there yet (one probe sequence for test + insert) */
@@ -697,12 +702,22 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     fp_add(W.S, canon(cur));
     if (fp_add(W.S, prev_c) && prev_c == canon(cur)) return 0;
     int L = 0, h = 1; /* h: positions at which the two consensuses differ */
+    /* nodes whose register signature says "perhaps marked": looked up in the marked set at the end, all lanes together, instead of one
+     * memory round trip per step for whichever lane has a signature collision */
+    uint64_t cand0 = 0, cand1 = 0, cand2 = 0, cand3 = 0;
+    int ncand = 0;
+    auto suspect = [&](uint64_t c) -> bool {
+        if (!W.maybe_marked(c)) return true;
+        if (ncand == 0) cand0 = c; else if (ncand == 1) cand1 = c; else if (ncand == 2) cand2 = c; else if (ncand == 3) cand3 = c; else return false;
+        ncand++;
+        return true;
+    };
     for (int step = 1; step <= SNP_MAX_L; step++) {
         /* the nodes at position `step` of both branches: unmarked, new */
         uint32_t nt[2];
         for (int br = 0; br < 2; br++) {
             const uint64_t c = canon(x[br]);
-            if (W.is_marked(c)) return 0;
+            if (!suspect(c)) return 0; /* too many to remember: the general code decides */
             if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, step, c, br, step)) return 0;
             if (aux[br] & 15u) { nt[br] = (aux[br] >> 4) & 3u; aux[br] = aux_step(aux[br]); }
             else {
@@ -725,7 +740,11 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     if (L == 0) return 0;
     const Kmer e = x[0];
     const uint64_t ce = canon(e);
-    if (W.is_marked(ce)) return 0;
+    if (!suspect(ce)) return 0;
+    for (int i = 0; i < ncand; i++) {
+        const uint64_t c = i == 0 ? cand0 : i == 1 ? cand1 : i == 2 ? cand2 : cand3;
+        if (set_has(s_marked(W.cfg, W.S), W.cfg.mcap, c)) return 0; /* the bubble touches an assembled region */
+    }
     if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, L, ce, -1, 0)) return 0;
     const int n = L + 1;
     if (n > W.cfg.mono_max_depth) return 0;
