@@ -379,6 +379,41 @@ MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t&
     return a;
 }
 MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines) { return adj_right_t(ix.adj, x, mk1, lines); }
+/* right neighbourhoods of two unrelated nodes with both home buckets in flight together; a key that is not in its home bucket of a full
+ * bucket is looked up again the ordinary way (rare) */
+MTG_DEV void adj_right2(const Index& ix, const Kmer& xa, const Kmer& xb, uint64_t mk1, uint32_t& lines, Adj& ra, Adj& rb)
+{
+    const Table& t = ix.adj;
+    const Kmer* xs[2] = {&xa, &xb};
+    Adj* rs[2] = {&ra, &rb};
+    U64x2 q[2][MTG_ADJ_SLOTS];
+    uint64_t want[2];
+    bool fw[2];
+    for (int u = 0; u < 2; u++) {
+        const uint64_t s = xs[u]->f & mk1, rsx = xs[u]->r >> 2;
+        fw[u] = s <= rsx;
+        const uint64_t H = mix(fw[u] ? s : rsx, t.key_bits);
+        const uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+        want[u] = (H & ((1ULL << t.tag_bits) - 1)) << MTG_DISP_BITS;
+        const U64x2* p = reinterpret_cast<const U64x2*>(t.slots + b * (2 * MTG_ADJ_SLOTS));
+MTG_UNROLL
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) q[u][i] = p[i];
+    }
+    for (int u = 0; u < 2; u++) {
+        uint32_t m = 0;
+        uint64_t aux = 0;
+MTG_UNROLL
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) {
+            const bool hit = (q[u][i].x >> 8) == want[u] && q[u][i].x != 0;
+            m |= hit ? (uint32_t)(q[u][i].x & 255) : 0u;
+            aux |= hit ? q[u][i].y : 0ull;
+        }
+        lines++;
+        if (!m && q[u][MTG_ADJ_SLOTS - 1].x != 0) { *rs[u] = adj_right_t(t, *xs[u], mk1, lines); continue; } /* perhaps displaced */
+        if (fw[u]) { rs[u]->out = m & 15u; rs[u]->in = m >> 4; rs[u]->la = (uint32_t)aux; }
+        else { rs[u]->out = comp_mask(m >> 4); rs[u]->in = comp_mask(m & 15u); rs[u]->la = (uint32_t)(aux >> 32); }
+    }
+}
 /* left neighbourhood of x: .in = predecessors of x, .out = successors of every predecessor. */
 MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {

@@ -60,9 +60,9 @@ struct GapScratch {
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
     uint32_t lane;
-    uint16_t* fp; /* this lane's column of a small fingerprint table (FP_SLOTS rows of 64 lanes; LDS on the device), or null: no SNP fast path */
+    uint8_t* fp; /* this lane's column of a small fingerprint table (FP_SLOTS rows of 64 lanes; LDS on the device), or null: no SNP fast path */
 };
-enum { FP_SLOTS = 128 };
+enum { FP_SLOTS = 256 };
 /* strided view of one lane's array in the interleaved region */
 template <typename T> struct SP {
     T* p;
@@ -657,47 +657,53 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
  * of the canonical k-mers in a small table (LDS); a fingerprint seen before is checked exactly by walking the branches again. */
 MTG_DEV uint32_t fp_hash(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 32); }
 MTG_DEV void fp_clear(const GapScratch& S) { for (int i = 0; i < FP_SLOTS; i++) S.fp[(size_t)i * 64] = 0; }
-/* 0: new; 1: a k-mer with this fingerprint was added before */
+/* 0: new; 1: a k-mer with this fingerprint was added before (8-bit fingerprints: a false alarm every hundred additions or so, settled
+ * exactly by snp_seen_exactly) */
 MTG_DEV int fp_add(const GapScratch& S, uint64_t c)
 {
     const uint32_t h = fp_hash(c);
-    const uint16_t fp = (uint16_t)((h >> 16) | 1u);
+    const uint8_t fp = (uint8_t)((h >> 24) | 1u);
     uint32_t s = h & (FP_SLOTS - 1);
     for (;;) {
-        const uint16_t v = S.fp[(size_t)s * 64];
+        const uint8_t v = S.fp[(size_t)s * 64];
         if (v == 0) { S.fp[(size_t)s * 64] = fp; return 0; }
         if (v == fp) return 1;
         s = (s + 1) & (FP_SLOTS - 1);
     }
 }
-/* is canonical k-mer c among: the node, prev_c, and the first `steps` nodes of each branch (the walk is replayed from the consensus
- * nucleotides written so far), the node x of branch `skip_branch` at position `skip_pos` excepted */
-MTG_DEV bool snp_seen_exactly(Worker& W, const Kmer& cur, uint64_t prev_c, int steps, uint64_t c, int skip_branch, int skip_pos)
+/* the nucleotides of one branch, 2 bits each, in registers (up to 64) */
+struct SnpSeq {
+    uint64_t lo, hi;
+    MTG_DEV uint32_t get(int i) const { return (uint32_t)((i < 32 ? lo >> (2 * i) : hi >> (2 * (i - 32))) & 3u); }
+    MTG_DEV void set(int i, uint32_t nt) { if (i < 32) lo |= (uint64_t)nt << (2 * i); else hi |= (uint64_t)nt << (2 * (i - 32)); }
+};
+/* is canonical k-mer c among: the node, prev_c, and the first `steps` nodes of each branch (the walk is replayed from the nucleotides
+ * known so far), the node of branch `skip_branch` at position `skip_pos` excepted */
+MTG_DEV bool snp_seen_exactly(const Worker& W, const Kmer& cur, uint64_t prev_c, const SnpSeq* seq, int steps, uint64_t c, int skip_branch, int skip_pos)
 {
     if (canon(cur) == c || prev_c == c) return true;
-    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
     for (int br = 0; br < 2; br++) {
         Kmer x = cur;
         for (int i = 0; i < steps; i++) {
-            x = kmer_next(x, cons[(size_t)br * CONS_LEN + i], W.k, W.mk);
+            x = kmer_next(x, seq[br].get(i), W.k, W.mk);
             if (br == skip_branch && i + 1 == skip_pos) continue;
             if (canon(x) == c) return true;
         }
     }
     return false;
 }
-enum { SNP_MAX_L = 48 }; /* 2 * 48 + 3 fingerprints in FP_SLOTS = 128 slots */
+enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches of up to 2k - 1 nodes; 2 * 62 + 3 fingerprints in 256 slots */
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen)
 {
     if (!W.S.fp || W.cfg.end_rule_nonbranching) return 0;
     if (!(popc4(a.out) == 2 && popc4(a.in) == 1)) return 0;
     const int k = W.k;
-    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
     const uint32_t nt0[2] = {(uint32_t)ctz4(a.out), (uint32_t)ctz4(a.out & (a.out - 1))};
     Kmer x[2];
     uint32_t aux[2] = {AUX_IN1, AUX_IN1};
-    for (int br = 0; br < 2; br++) { x[br] = kmer_next(cur, nt0[br], k, W.mk); cons[(size_t)br * CONS_LEN] = (uint8_t)nt0[br]; }
+    SnpSeq seq[2];
+    for (int br = 0; br < 2; br++) { x[br] = kmer_next(cur, nt0[br], k, W.mk); seq[br].lo = nt0[br]; seq[br].hi = 0; }
     fp_clear(W.S);
     fp_add(W.S, canon(cur));
     if (fp_add(W.S, prev_c) && prev_c == canon(cur)) return 0;
@@ -713,24 +719,28 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
         return true;
     };
     for (int step = 1; step <= SNP_MAX_L; step++) {
-        /* the nodes at position `step` of both branches: unmarked, new */
+        /* the nodes at position `step` of both branches: unmarked, new; their single out-edges (both bucket reads in flight together) */
         uint32_t nt[2];
+        Adj r[2];
+        const bool need0 = !(aux[0] & 15u), need1 = !(aux[1] & 15u);
+        if (need0 && need1) adj_right2(W.ix, x[0], x[1], W.mk1, W.lines, r[0], r[1]);
+        else if (need0) r[0] = adj_right(W.ix, x[0], W.mk1, W.lines);
+        else if (need1) r[1] = adj_right(W.ix, x[1], W.mk1, W.lines);
         for (int br = 0; br < 2; br++) {
             const uint64_t c = canon(x[br]);
             if (!suspect(c)) return 0; /* too many to remember: the general code decides */
-            if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, step, c, br, step)) return 0;
+            if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) return 0;
             if (aux[br] & 15u) { nt[br] = (aux[br] >> 4) & 3u; aux[br] = aux_step(aux[br]); }
             else {
-                const Adj r = adj_right(W.ix, x[br], W.mk1, W.lines);
-                if (popc4(r.out) != 1) return 0; /* dead end or a branching inside the bubble */
-                nt[br] = (uint32_t)ctz4(r.out);
-                aux[br] = aux_of_children(r);
+                if (popc4(r[br].out) != 1) return 0; /* dead end or a branching inside the bubble */
+                nt[br] = (uint32_t)ctz4(r[br].out);
+                aux[br] = aux_of_children(r[br]);
             }
         }
         if (W.status) return 0;
         h += nt[0] != nt[1];
-        cons[step] = (uint8_t)nt[0];
-        cons[(size_t)CONS_LEN + step] = (uint8_t)nt[1];
+        seq[0].set(step, nt[0]);
+        seq[1].set(step, nt[1]);
         const Kmer y0 = kmer_next(x[0], nt[0], k, W.mk), y1 = kmer_next(x[1], nt[1], k, W.mk);
         if (y0.f == y1.f) { L = step; x[0] = y0; break; } /* the branches meet: x[0] = e */
         if (!(aux[0] & AUX_IN1) || !(aux[1] & AUX_IN1)) return 0; /* a node with another way in: the frontline check would have work to do */
@@ -745,9 +755,13 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
         const uint64_t c = i == 0 ? cand0 : i == 1 ? cand1 : i == 2 ? cand2 : cand3;
         if (set_has(s_marked(W.cfg, W.S), W.cfg.mcap, c)) return 0; /* the bubble touches an assembled region */
     }
-    if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, L, ce, -1, 0)) return 0;
+    if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, seq, L, ce, -1, 0)) return 0;
     const int n = L + 1;
     if (n > W.cfg.mono_max_depth) return 0;
+    /* the consensus strings where the caller (and the alignment) expect them */
+    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+    for (int br = 0; br < 2; br++)
+        for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
     /* one substitution: the diagonal is the unique optimal alignment (see validate_consensuses); more: the exact banded alignment */
     const int matches = h < 2 ? n - h : nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
     if (identity_below_90(matches, n, n)) return 0;
@@ -755,23 +769,16 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     unsigned long sum[2] = {0, 0};
     {
         Kmer w[2] = {cur, cur};
-        uint32_t a0 = abundance(W.ix, cur, W.lines);
+        const uint32_t a0 = abundance(W.ix, cur, W.lines);
         sum[0] = sum[1] = a0;
         for (int i = 0; i < L; i += 4) {
-            uint64_t keys[8];
-            uint32_t ab[8];
             const uint32_t cnt = (uint32_t)((L - i) < 4 ? (L - i) : 4);
-            for (int br = 0; br < 2; br++)
-                for (int u = 0; u < 4; u++) {
-                    keys[br * 4 + u] = 0;
-                    if ((uint32_t)u < cnt) { w[br] = kmer_next(w[br], cons[(size_t)br * CONS_LEN + i + u], k, W.mk); keys[br * 4 + u] = canon(w[br]); }
-                }
-            /* the two branches as one batch of 8: positions >= cnt of a branch are padding */
             uint64_t k8[8];
-            uint32_t m = 0;
-            for (int br = 0; br < 2; br++) for (uint32_t u = 0; u < cnt; u++) k8[m++] = keys[br * 4 + u];
-            for (uint32_t u = m; u < 8; u++) k8[u] = 0;
-            abundance_batch<8>(W.ix, k8, m, ab, W.lines);
+            uint32_t ab[8];
+            for (int u = 0; u < 8; u++) k8[u] = 0;
+            for (int br = 0; br < 2; br++)
+                for (uint32_t u = 0; u < cnt; u++) { w[br] = kmer_next(w[br], seq[br].get(i + (int)u), k, W.mk); k8[(uint32_t)br * cnt + u] = canon(w[br]); }
+            abundance_batch<8>(W.ix, k8, 2 * cnt, ab, W.lines); /* first the cnt nodes of branch 0, then those of branch 1 */
             for (uint32_t u = 0; u < cnt; u++) { sum[0] += ab[u]; sum[1] += ab[cnt + u]; }
         }
     }

@@ -173,7 +173,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             FillCfg cfg = make_cfg(idx->dev.k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
             std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64, 0xCD), ilv(cfg.ilv_stride);
             GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
-            std::vector<uint16_t> fp_table(FP_SLOTS * 64);
+            std::vector<uint8_t> fp_table(FP_SLOTS * 64);
             S.fp = getenv("MTG_NO_SNP_FAST") ? nullptr : fp_table.data();
             SwfPattern R;
             R.words = in.rwords.data() + in.roff[g];
