@@ -389,6 +389,7 @@ MTG_DEV void adj_right2(const Index& ix, const Kmer& xa, const Kmer& xb, uint64_
     U64x2 q[2][MTG_ADJ_SLOTS];
     uint64_t want[2];
     bool fw[2];
+MTG_UNROLL
     for (int u = 0; u < 2; u++) {
         const uint64_t s = xs[u]->f & mk1, rsx = xs[u]->r >> 2;
         fw[u] = s <= rsx;
@@ -399,6 +400,7 @@ MTG_DEV void adj_right2(const Index& ix, const Kmer& xa, const Kmer& xb, uint64_
 MTG_UNROLL
         for (int i = 0; i < MTG_ADJ_SLOTS; i++) q[u][i] = p[i];
     }
+MTG_UNROLL
     for (int u = 0; u < 2; u++) {
         uint32_t m = 0;
         uint64_t aux = 0;
@@ -428,8 +430,8 @@ MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lin
 }
 MTG_DEV uint32_t abundance(const Index& ix, const Kmer& x, uint32_t& lines) { return table_get<MTG_ABND_SLOTS>(ix.abnd, canon(x), lines); }
 /* U independent look-ups with their first bucket reads in flight together (a lane that needs the abundances of a run of known k-mers);
- * keys[u] for u >= n are skipped and read as 0 */
-template <int U> MTG_DEV void abundance_batch(const Index& ix, const uint64_t* keys, uint32_t n, uint32_t* out, uint32_t& lines)
+ * only the keys whose bit is set in `valid` are looked up, the others read as 0 */
+template <int U> MTG_DEV void abundance_batch(const Index& ix, const uint64_t* keys, uint32_t valid, uint32_t* out, uint32_t& lines)
 {
     const Table& t = ix.abnd;
     U64x2 q[U][MTG_ABND_SLOTS / 2];
@@ -442,7 +444,7 @@ MTG_UNROLL
         const U64x2* p = reinterpret_cast<const U64x2*>(t.slots + b * MTG_ABND_SLOTS);
 MTG_UNROLL
         for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) {
-            if ((uint32_t)u < n) q[u][i] = p[i];
+            if ((valid >> u) & 1u) q[u][i] = p[i];
             else { q[u][i].x = 0; q[u][i].y = 0; }
         }
     }
@@ -454,7 +456,7 @@ MTG_UNROLL
             val |= ((q[u][i].x >> 8) == want[u]) ? (uint32_t)(q[u][i].x & 255) : 0u;
             val |= ((q[u][i].y >> 8) == want[u]) ? (uint32_t)(q[u][i].y & 255) : 0u;
         }
-        if ((uint32_t)u < n) {
+        if ((valid >> u) & 1u) {
             lines++;
             /* not in its home bucket and the bucket is full: the key may have spilled further (rare) */
             if (!val && q[u][MTG_ABND_SLOTS / 2 - 1].y != 0) val = table_get<MTG_ABND_SLOTS>(t, keys[u], lines);

@@ -234,12 +234,12 @@ __global__ void __launch_bounds__(64) k_stage_a(uint8_t* zero, uint8_t* raw, uin
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                 GapOut* out, uint32_t n)
 {
-    __shared__ uint8_t fp_table[FP_SLOTS * 64]; /* fingerprints of the SNP fast path: row = table slot, column = lane */
+    __shared__ __attribute__((aligned(16))) uint8_t fp_table[FP_SLOTS * 64]; /* fingerprints of the SNP fast path: row = table slot, column = lane */
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
     GapScratch S = carve(c_cfg, zero, raw, ilv, slot);
-    S.fp = fp_table + threadIdx.x;
+    S.fp = fp_table + threadIdx.x * 8; /* see fp_at */
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];
@@ -973,8 +973,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     {
         unsigned long long hs[16];
         if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(mtg::g_stamps), sizeof hs) == hipSuccess && hs[8])
-            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f\n", hs[8], (double)hs[0] / hs[8],
-                    (double)hs[1] / hs[8], (double)hs[2] / hs[8], (double)hs[3] / hs[8], (double)hs[4] / hs[8], (double)hs[5] / hs[8]);
+            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f | snp_fast %.0f consume %.0f\n", hs[8], (double)hs[0] / hs[8],
+                    (double)hs[1] / hs[8], (double)hs[2] / hs[8], (double)hs[3] / hs[8], (double)hs[4] / hs[8], (double)hs[5] / hs[8], (double)hs[6] / hs[8], (double)hs[7] / hs[8]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
     }

@@ -60,7 +60,7 @@ struct GapScratch {
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
     uint32_t lane;
-    uint8_t* fp; /* this lane's column of a small fingerprint table (FP_SLOTS rows of 64 lanes; LDS on the device), or null: no SNP fast path */
+    uint8_t* fp; /* this lane's part of a small fingerprint table (FP_SLOTS slots for each of 64 lanes, see fp_at; LDS on the device), or null: no SNP fast path */
 };
 enum { FP_SLOTS = 256 };
 /* strided view of one lane's array in the interleaved region */
@@ -656,7 +656,10 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
  * general code, so the fast path never decides a case it does not fully understand.  The distinctness test keeps 16-bit fingerprints
  * of the canonical k-mers in a small table (LDS); a fingerprint seen before is checked exactly by walking the branches again. */
 MTG_DEV uint32_t fp_hash(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 32); }
-MTG_DEV void fp_clear(const GapScratch& S) { for (int i = 0; i < FP_SLOTS; i++) S.fp[(size_t)i * 64] = 0; }
+/* layout: the slots of a lane in groups of 8 bytes (group g of lane l at g * 512 + l * 8), so that the table is cleared 8 slots at a
+ * time and the lanes of a wave never fight for a bank when they do */
+MTG_DEV uint8_t* fp_at(const GapScratch& S, uint32_t s) { return S.fp + (size_t)(s >> 3) * 512 + (s & 7u); }
+MTG_DEV void fp_clear(const GapScratch& S) { for (int g = 0; g < FP_SLOTS / 8; g++) *reinterpret_cast<uint64_t*>(S.fp + (size_t)g * 512) = 0; }
 /* 0: new; 1: a k-mer with this fingerprint was added before (8-bit fingerprints: a false alarm every hundred additions or so, settled
  * exactly by snp_seen_exactly) */
 MTG_DEV int fp_add(const GapScratch& S, uint64_t c)
@@ -665,8 +668,8 @@ MTG_DEV int fp_add(const GapScratch& S, uint64_t c)
     const uint8_t fp = (uint8_t)((h >> 24) | 1u);
     uint32_t s = h & (FP_SLOTS - 1);
     for (;;) {
-        const uint8_t v = S.fp[(size_t)s * 64];
-        if (v == 0) { S.fp[(size_t)s * 64] = fp; return 0; }
+        const uint8_t v = *fp_at(S, s);
+        if (v == 0) { *fp_at(S, s) = fp; return 0; }
         if (v == fp) return 1;
         s = (s + 1) & (FP_SLOTS - 1);
     }
@@ -682,6 +685,7 @@ struct SnpSeq {
 MTG_DEV bool snp_seen_exactly(const Worker& W, const Kmer& cur, uint64_t prev_c, const SnpSeq* seq, int steps, uint64_t c, int skip_branch, int skip_pos)
 {
     if (canon(cur) == c || prev_c == c) return true;
+MTG_UNROLL
     for (int br = 0; br < 2; br++) {
         Kmer x = cur;
         for (int i = 0; i < steps; i++) {
@@ -703,6 +707,7 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     Kmer x[2];
     uint32_t aux[2] = {AUX_IN1, AUX_IN1};
     SnpSeq seq[2];
+MTG_UNROLL
     for (int br = 0; br < 2; br++) { x[br] = kmer_next(cur, nt0[br], k, W.mk); seq[br].lo = nt0[br]; seq[br].hi = 0; }
     fp_clear(W.S);
     fp_add(W.S, canon(cur));
@@ -726,7 +731,8 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
         if (need0 && need1) adj_right2(W.ix, x[0], x[1], W.mk1, W.lines, r[0], r[1]);
         else if (need0) r[0] = adj_right(W.ix, x[0], W.mk1, W.lines);
         else if (need1) r[1] = adj_right(W.ix, x[1], W.mk1, W.lines);
-        for (int br = 0; br < 2; br++) {
+MTG_UNROLL
+        for (int br = 0; br < 2; br++) { /* unrolled: the per-branch state must stay in registers */
             const uint64_t c = canon(x[br]);
             if (!suspect(c)) return 0; /* too many to remember: the general code decides */
             if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) return 0;
@@ -760,6 +766,7 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     if (n > W.cfg.mono_max_depth) return 0;
     /* the consensus strings where the caller (and the alignment) expect them */
     const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+MTG_UNROLL
     for (int br = 0; br < 2; br++)
         for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
     /* one substitution: the diagonal is the unique optimal alignment (see validate_consensuses); more: the exact banded alignment */
@@ -772,14 +779,19 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
         const uint32_t a0 = abundance(W.ix, cur, W.lines);
         sum[0] = sum[1] = a0;
         for (int i = 0; i < L; i += 4) {
-            const uint32_t cnt = (uint32_t)((L - i) < 4 ? (L - i) : 4);
             uint64_t k8[8];
-            uint32_t ab[8];
-            for (int u = 0; u < 8; u++) k8[u] = 0;
-            for (int br = 0; br < 2; br++)
-                for (uint32_t u = 0; u < cnt; u++) { w[br] = kmer_next(w[br], seq[br].get(i + (int)u), k, W.mk); k8[(uint32_t)br * cnt + u] = canon(w[br]); }
-            abundance_batch<8>(W.ix, k8, 2 * cnt, ab, W.lines); /* first the cnt nodes of branch 0, then those of branch 1 */
-            for (uint32_t u = 0; u < cnt; u++) { sum[0] += ab[u]; sum[1] += ab[cnt + u]; }
+            uint32_t ab[8], valid = 0;
+MTG_UNROLL
+            for (int br = 0; br < 2; br++) {
+MTG_UNROLL
+                for (int u = 0; u < 4; u++) { /* branch br, position i + u -> slot 4 br + u */
+                    k8[br * 4 + u] = 0;
+                    if (i + u < L) { w[br] = kmer_next(w[br], seq[br].get(i + u), k, W.mk); k8[br * 4 + u] = canon(w[br]); valid |= 1u << (br * 4 + u); }
+                }
+            }
+            abundance_batch<8>(W.ix, k8, valid, ab, W.lines);
+MTG_UNROLL
+            for (int u = 0; u < 4; u++) { sum[0] += ab[u]; sum[1] += ab[4 + u]; }
         }
     }
     sum[0] /= (unsigned long)n;
