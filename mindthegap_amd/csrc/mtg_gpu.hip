@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(64) k_stage_a(uint8_t* zero, uint8_t* raw, uin
     if (slot >= n) return;
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
     GapScratch S = carve(c_cfg, zero, raw, ilv, slot);
-    S.fp = fp_table + threadIdx.x * 8; /* see fp_at */
+    S.fp = (MTG_LDS uint8_t*)fp_table + threadIdx.x * 8; /* see fp_at */
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];

@@ -60,7 +60,7 @@ struct GapScratch {
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
     uint32_t lane;
-    uint8_t* fp; /* this lane's part of a small fingerprint table (FP_SLOTS slots for each of 64 lanes, see fp_at; LDS on the device), or null: no SNP fast path */
+    MTG_LDS uint8_t* fp; /* this lane's part of a small fingerprint table (FP_SLOTS slots for each of 64 lanes, see fp_at; LDS on the device), or null: no SNP fast path */
 };
 enum { FP_SLOTS = 256 };
 /* strided view of one lane's array in the interleaved region */
@@ -658,8 +658,8 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
 MTG_DEV uint32_t fp_hash(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 32); }
 /* layout: the slots of a lane in groups of 8 bytes (group g of lane l at g * 512 + l * 8), so that the table is cleared 8 slots at a
  * time and the lanes of a wave never fight for a bank when they do */
-MTG_DEV uint8_t* fp_at(const GapScratch& S, uint32_t s) { return S.fp + (size_t)(s >> 3) * 512 + (s & 7u); }
-MTG_DEV void fp_clear(const GapScratch& S) { for (int g = 0; g < FP_SLOTS / 8; g++) *reinterpret_cast<uint64_t*>(S.fp + (size_t)g * 512) = 0; }
+MTG_DEV MTG_LDS uint8_t* fp_at(const GapScratch& S, uint32_t s) { return S.fp + (s >> 3) * 512u + (s & 7u); }
+MTG_DEV void fp_clear(const GapScratch& S) { for (int g = 0; g < FP_SLOTS / 8; g++) *reinterpret_cast<MTG_LDS uint64_t*>(S.fp + g * 512) = 0; }
 /* 0: new; 1: a k-mer with this fingerprint was added before (8-bit fingerprints: a false alarm every hundred additions or so, settled
  * exactly by snp_seen_exactly) */
 MTG_DEV int fp_add(const GapScratch& S, uint64_t c)
