@@ -234,12 +234,11 @@ __global__ void __launch_bounds__(64) k_stage_a(uint8_t* zero, uint8_t* raw, uin
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                 GapOut* out, uint32_t n)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t fp_table[FP_SLOTS * 64]; /* fingerprints of the SNP fast path: row = table slot, column = lane */
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
     GapScratch S = carve(c_cfg, zero, raw, ilv, slot);
-    S.fp = (MTG_LDS uint8_t*)fp_table + threadIdx.x * 8; /* see fp_at */
+    S.snp_fast = 1;
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];

@@ -60,7 +60,8 @@ struct GapScratch {
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
     uint32_t lane;
-    MTG_LDS uint8_t* fp; /* this lane's part of a small fingerprint table (FP_SLOTS slots for each of 64 lanes, see fp_at; LDS on the device), or null: no SNP fast path */
+    uint32_t snp_fast; /* 1: the SNP fast path may be used */
+    MTG_LDS uint8_t* fp; /* TEST-ONLY emulation: a fingerprint table (FP_SLOTS slots for each of 64 lanes, see fp_at) for the cross-check of the fast path's distinctness test */
 };
 enum { FP_SLOTS = 256 };
 /* strided view of one lane's array in the interleaved region */
@@ -159,6 +160,7 @@ MTG_DEV GapScratch carve(const FillCfg& c, uint8_t* zero_base, uint8_t* raw_base
     S.v = ilv_base + (gap >> 6) * c.ilv_stride;
     S.lane = (uint32_t)(gap & 63);
     S.fp = nullptr;
+    S.snp_fast = 0;
     return S;
 }
 
@@ -696,12 +698,19 @@ MTG_UNROLL
     }
     return false;
 }
-enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches of up to 2k - 1 nodes; 2 * 62 + 3 fingerprints in 256 slots */
+enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches of up to 2k - 1 nodes; the nucleotides of a branch fit two registers */
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen)
 {
-    if (!W.S.fp || W.cfg.end_rule_nonbranching) return 0;
+    if (!W.S.snp_fast || W.cfg.end_rule_nonbranching) return 0;
     if (!(popc4(a.out) == 2 && popc4(a.in) == 1)) return 0;
+    /* Pairwise distinctness of the canonical k-mers without a set.  Branch nodes have one in- and one out-edge, so do their reverse
+     * complements; the node has two out-edges and e two in-edges, so rc(node) has two in-edges and rc(e) two out-edges: neither can be
+     * a branch node, nor can the node itself.  Two branch nodes u, v = rc(u) of ONE branch force, by following the unique edges
+     * inwards, a node that is its own reverse complement or whose successor is; of DIFFERENT branches they force, the same way,
+     * rc(node) or rc(e) onto a branch (impossible) or e = rc(node).  Equal forward k-mers at different places force the node onto a
+     * branch (impossible).  What remains is tested per node below: self-rc, successor = rc, the previous node, and e against the
+     * node.  (The TEST-ONLY emulation keeps the fingerprint table and checks this reasoning against an explicit search on every bubble.) */
     const int k = W.k;
     const uint32_t nt0[2] = {(uint32_t)ctz4(a.out), (uint32_t)ctz4(a.out & (a.out - 1))};
     Kmer x[2];
@@ -709,9 +718,12 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     SnpSeq seq[2];
 MTG_UNROLL
     for (int br = 0; br < 2; br++) { x[br] = kmer_next(cur, nt0[br], k, W.mk); seq[br].lo = nt0[br]; seq[br].hi = 0; }
+#ifdef MTG_EMU
+    bool dup_exact = false; /* cross-check of the closed-form test */
     fp_clear(W.S);
     fp_add(W.S, canon(cur));
-    if (fp_add(W.S, prev_c) && prev_c == canon(cur)) return 0;
+    fp_add(W.S, prev_c);
+#endif
     int L = 0, h = 1; /* h: positions at which the two consensuses differ */
     /* nodes whose register signature says "perhaps marked": looked up in the marked set at the end, all lanes together, instead of one
      * memory round trip per step for whichever lane has a signature collision */
@@ -735,7 +747,10 @@ MTG_UNROLL
         for (int br = 0; br < 2; br++) { /* unrolled: the per-branch state must stay in registers */
             const uint64_t c = canon(x[br]);
             if (!suspect(c)) return 0; /* too many to remember: the general code decides */
-            if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) return 0;
+#ifdef MTG_EMU
+            if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) dup_exact = true;
+#endif
+            if (x[br].f == x[br].r || c == prev_c) return 0;
             if (aux[br] & 15u) { nt[br] = (aux[br] >> 4) & 3u; aux[br] = aux_step(aux[br]); }
             else {
                 if (popc4(r[br].out) != 1) return 0; /* dead end or a branching inside the bubble */
@@ -748,6 +763,7 @@ MTG_UNROLL
         seq[0].set(step, nt[0]);
         seq[1].set(step, nt[1]);
         const Kmer y0 = kmer_next(x[0], nt[0], k, W.mk), y1 = kmer_next(x[1], nt[1], k, W.mk);
+        if (y0.f == x[0].r || y1.f == x[1].r) return 0; /* a node followed by its own reverse complement */
         if (y0.f == y1.f) { L = step; x[0] = y0; break; } /* the branches meet: x[0] = e */
         if (!(aux[0] & AUX_IN1) || !(aux[1] & AUX_IN1)) return 0; /* a node with another way in: the frontline check would have work to do */
         x[0] = y0;
@@ -761,7 +777,11 @@ MTG_UNROLL
         const uint64_t c = i == 0 ? cand0 : i == 1 ? cand1 : i == 2 ? cand2 : cand3;
         if (set_has(s_marked(W.cfg, W.S), W.cfg.mcap, c)) return 0; /* the bubble touches an assembled region */
     }
-    if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, seq, L, ce, -1, 0)) return 0;
+#ifdef MTG_EMU
+    if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, seq, L, ce, -1, 0)) dup_exact = true;
+    if (dup_exact && !(ce == canon(cur) || ce == prev_c)) { W.status = 0xBAD0; return 0; } /* the closed-form test missed a duplicate */
+#endif
+    if (ce == canon(cur) || ce == prev_c) return 0; /* e is the node, its reverse complement or the previous node */
     const int n = L + 1;
     if (n > W.cfg.mono_max_depth) return 0;
     /* the consensus strings where the caller (and the alignment) expect them */

@@ -73,7 +73,8 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
         std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0xCD), ilv(cfg.ilv_stride);
         GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
         std::vector<uint8_t> fp_table(FP_SLOTS * 64);
-        S.fp = getenv("MTG_NO_SNP_FAST") ? nullptr : fp_table.data();
+        S.fp = fp_table.data();
+        S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
         std::vector<uint64_t> rw;
         size_t rl = strlen(R);
         pack_seq(R, rl, rw);

@@ -174,7 +174,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64, 0xCD), ilv(cfg.ilv_stride);
             GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
             std::vector<uint8_t> fp_table(FP_SLOTS * 64);
-            S.fp = getenv("MTG_NO_SNP_FAST") ? nullptr : fp_table.data();
+            S.fp = fp_table.data();
+            S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
             SwfPattern R;
             R.words = in.rwords.data() + in.roff[g];
             R.rlen = in.rlen[g];

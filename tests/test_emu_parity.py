@@ -534,6 +534,13 @@ def _snp_case(rng, k, kind):
     elif kind == 8:    # substitution close to the end of the sequence (a branch that dead-ends before the others meet)
         a = L + R[:rng.randrange(2, k + 2)]
         alleles = [a, a[:p] + sub(a[p]) + a[p + 1:]]
+    elif kind == 10:   # both alleles are reverse-complement palindromes: the branches run into their own reverse complements and meet at rc(node)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        U = _rand_seq(rng, rng.randrange(k + 2, 70))
+        W = _rand_seq(rng, rng.randrange(0, max(1, (k - 3) // 2)))
+        x = rng.choice("ACGT"); y = sub(x)
+        a = U + x + W + _rc(W) + comp[x] + _rc(U)
+        alleles = [a, U + y + W + _rc(W) + comp[y] + _rc(U)]
     else:              # two independent substitutions further apart than k (two clean bubbles in a row)
         q = p + k + rng.randrange(1, 30)
         b = list(a)
@@ -549,8 +556,8 @@ def test_snp_fast_path_adversarial(k):
     """the SNP fast path of the traversal against the oracle's general bubble code: loci on and just outside its pattern, both strands,
     both end rules, abundances that differ between the alleles"""
     rng = random.Random(4242 + k)
-    for case in range(260):
-        kind = case % 10
+    for case in range(286):
+        kind = case % 11
         a, alleles = _snp_case(rng, k, kind)
         seqs = []
         for i, x in enumerate(alleles):  # unequal multiplicities give the alleles different abundances
