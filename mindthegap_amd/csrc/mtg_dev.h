@@ -448,6 +448,35 @@ MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lin
     return a;
 }
 MTG_DEV uint32_t abundance(const Index& ix, const Kmer& x, uint32_t& lines) { return table_get<MTG_ABND_SLOTS>(ix.abnd, canon(x), lines); }
+/* an abundance look-up in two halves, so that the caller can do other work while the bucket travels */
+struct AbPending {
+    U64x2 q[MTG_ABND_SLOTS / 2];
+    uint64_t want, key;
+};
+MTG_DEV void ab_issue(const Index& ix, uint64_t canon_kmer, AbPending& p)
+{
+    const Table& t = ix.abnd;
+    const uint64_t H = mix(canon_kmer, t.key_bits);
+    const uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    p.want = (H & ((1ULL << t.tag_bits) - 1)) << MTG_DISP_BITS;
+    p.key = canon_kmer;
+    const U64x2* a = reinterpret_cast<const U64x2*>(t.slots + b * MTG_ABND_SLOTS);
+MTG_UNROLL
+    for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) p.q[i] = ld_table(a + i);
+}
+MTG_DEV uint32_t ab_finish(const Index& ix, const AbPending& p, uint32_t& lines)
+{
+    uint32_t val = 0;
+MTG_UNROLL
+    for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) {
+        val |= ((p.q[i].x >> 8) == p.want) ? (uint32_t)(p.q[i].x & 255) : 0u;
+        val |= ((p.q[i].y >> 8) == p.want) ? (uint32_t)(p.q[i].y & 255) : 0u;
+    }
+    lines++;
+    /* not in its home bucket and the bucket is full: the key may have spilled further (rare) */
+    if (!val && p.q[MTG_ABND_SLOTS / 2 - 1].y != 0) val = table_get<MTG_ABND_SLOTS>(ix.abnd, p.key, lines);
+    return val;
+}
 /* U independent look-ups with their first bucket reads in flight together (a lane that needs the abundances of a run of known k-mers);
  * only the keys whose bit is set in `valid` are looked up, the others read as 0 */
 template <int U> MTG_DEV void abundance_batch(const Index& ix, const uint64_t* keys, uint32_t valid, uint32_t* out, uint32_t& lines)

@@ -725,6 +725,12 @@ MTG_UNROLL
     fp_add(W.S, prev_c);
 #endif
     int L = 0, h = 1; /* h: positions at which the two consensuses differ */
+    /* abundances for the choice between the consensuses (mean over the node and the L nodes of a branch, validate_consensuses): the bucket
+     * of a node is requested when the node is reached and read one step later, behind the arithmetic of the step */
+    unsigned long sum[2] = {0, 0};
+    AbPending pend[2], pend_cur;
+    bool have_pend = false;
+    ab_issue(W.ix, canon(cur), pend_cur);
     /* nodes whose register signature says "perhaps marked": looked up in the marked set at the end, all lanes together, instead of one
      * memory round trip per step for whichever lane has a signature collision */
     uint64_t cand0 = 0, cand1 = 0, cand2 = 0, cand3 = 0;
@@ -743,9 +749,11 @@ MTG_UNROLL
         if (need0 && need1) adj_right2(W.ix, x[0], x[1], W.mk1, W.lines, r[0], r[1]);
         else if (need0) r[0] = adj_right(W.ix, x[0], W.mk1, W.lines);
         else if (need1) r[1] = adj_right(W.ix, x[1], W.mk1, W.lines);
+        if (have_pend) { sum[0] += ab_finish(W.ix, pend[0], W.lines); sum[1] += ab_finish(W.ix, pend[1], W.lines); }
 MTG_UNROLL
         for (int br = 0; br < 2; br++) { /* unrolled: the per-branch state must stay in registers */
             const uint64_t c = canon(x[br]);
+            ab_issue(W.ix, c, pend[br]);
             if (!suspect(c)) return 0; /* too many to remember: the general code decides */
 #ifdef MTG_EMU
             if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) dup_exact = true;
@@ -758,6 +766,7 @@ MTG_UNROLL
                 aux[br] = aux_of_children(r[br]);
             }
         }
+        have_pend = true;
         if (W.status) return 0;
         h += nt[0] != nt[1];
         seq[0].set(step, nt[0]);
@@ -792,27 +801,12 @@ MTG_UNROLL
     /* one substitution: the diagonal is the unique optimal alignment (see validate_consensuses); more: the exact banded alignment */
     const int matches = h < 2 ? n - h : nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
     if (identity_below_90(matches, n, n)) return 0;
-    /* most abundant consensus: mean over the node and the L nodes of the branch (src: validate_consensuses), look-ups 4 + 4 at a time */
-    unsigned long sum[2] = {0, 0};
+    /* most abundant consensus: the last step's buckets and the node's own */
+    if (have_pend) { sum[0] += ab_finish(W.ix, pend[0], W.lines); sum[1] += ab_finish(W.ix, pend[1], W.lines); }
     {
-        Kmer w[2] = {cur, cur};
-        const uint32_t a0 = abundance(W.ix, cur, W.lines);
-        sum[0] = sum[1] = a0;
-        for (int i = 0; i < L; i += 4) {
-            uint64_t k8[8];
-            uint32_t ab[8], valid = 0;
-MTG_UNROLL
-            for (int br = 0; br < 2; br++) {
-MTG_UNROLL
-                for (int u = 0; u < 4; u++) { /* branch br, position i + u -> slot 4 br + u */
-                    k8[br * 4 + u] = 0;
-                    if (i + u < L) { w[br] = kmer_next(w[br], seq[br].get(i + u), k, W.mk); k8[br * 4 + u] = canon(w[br]); valid |= 1u << (br * 4 + u); }
-                }
-            }
-            abundance_batch<8>(W.ix, k8, valid, ab, W.lines);
-MTG_UNROLL
-            for (int u = 0; u < 4; u++) { sum[0] += ab[u]; sum[1] += ab[4 + u]; }
-        }
+        const uint32_t a0 = ab_finish(W.ix, pend_cur, W.lines);
+        sum[0] += a0;
+        sum[1] += a0;
     }
     sum[0] /= (unsigned long)n;
     sum[1] /= (unsigned long)n;
