@@ -487,3 +487,30 @@ def test_concurrent_batches_on_two_indexes(mtg, full_idx, ctg_idx, golden_dir):
 def test_abi_edge_cases(mtg):
     from tests.test_emu_parity import _abi_edge_cases
     _abi_edge_cases(mtg)
+
+
+@pytest.mark.parametrize("k", [31, 21, 16])
+def test_snp_fast_path_adversarial_on_device(mtg, k):
+    """the loci of the CPU-side adversarial test (substitutions alone, in pairs, in palindromes and tandem repeats, next to indels and
+    tips, three alleles, repeated loci) through k_stage_a, whose SNP fast path has no cross-check on the device: contigs == oracle"""
+    import random
+    from tests import oracle_lib
+    from tests.test_emu_parity import _snp_case
+    rng = random.Random(31337 + k)
+    for case in range(132):
+        kind = case % 11
+        a, alleles = _snp_case(rng, k, kind)
+        seqs = []
+        for i, x in enumerate(alleles):
+            seqs += [x] * (1 + (case + i) % 3)
+        o = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = o.export()
+        idx = mtg.Index.from_kmers(km, ct, k)
+        src = [a[:k], _rc(a[-k:])] + ([a[k // 2:k // 2 + k]] if len(a) > 3 * k else [])
+        tgt = [a[-k:]] * len(src)
+        for er in (0, 1):
+            got = idx.stage_a(src, tgt, mtg.FillParams(end_rule_nonbranching=er))
+            for s, c in zip(src, got):
+                assert c == o.stage_a(s, a[-k:], oracle_lib.default_params(end_rule_nonbranching=er))[0], (case, kind, k, s, er, seqs)
+        idx.close()
+        o.close()
