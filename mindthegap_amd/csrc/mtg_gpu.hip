@@ -248,6 +248,17 @@ __global__ void __launch_bounds__(64) k_stage_a(uint8_t* zero, uint8_t* raw, uin
     out[slot] = o;
 }
 
+/* the targets of a batch from text to (little-endian k-mer, never-match mask): one target per thread */
+__global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __restrict__ tle, uint64_t* __restrict__ tbad, uint64_t nt, int k)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    uint64_t le, bad;
+    encode_target(traw + t * TARGET_SLOT, k, le, bad);
+    tle[t] = le;
+    tbad[t] = bad;
+}
+
 /* terminal-node search + coverage of the single-contig solution, one wave per gap; then the wave reserves room in the chunk's dense
  * arrays (two atomic counters) and copies there what the host needs of this gap: nw leading arena words and, for nc contigs, their
  * (length, first word) and terminal info.  counters: [0] words, [1] contig metadata entries */
@@ -738,10 +749,10 @@ struct EventSet { /* events of one device_run call */
  * One traversal launch covers as many gaps as fit the scratch; its post-processing runs as up to MTG_POST_PARTS launches over
  * consecutive slot ranges, each with its own dense arrays and counters, so that a part's results travel back (copy stream) and are
  * handed to the caller (on_ready) while the device works on the next part. */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* before_post,
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats,
                const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)
 {
-    bool before_done = false, busy_done = false;
+    bool busy_done = false;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
     double tk = now_ms();
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
@@ -753,14 +764,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     batch.slot_of.clear();
     batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
-    if (n == 0) { if (before_post) (*before_post)(); if (while_busy) (*while_busy)(); if (stats) *stats = st; return MTG_OK; }
+    if (n == 0) { if (while_busy) (*while_busy)(); if (stats) *stats = st; return MTG_OK; }
     const int k = idx->dev.k;
 
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &idx->ws; b.slot = ws_next++; return b; };
-    WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
+    WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
           d_dm = wsbuf(), d_cnt = wsbuf();
-    /* the marshalled input: blocks A and B now, block C (targets) once the caller has filled it */
+    /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device */
     double t0 = now_ms();
     HIP_TRY(d_ina.alloc(in.bytes_a));
     HIP_TRY(d_inb.alloc(in.bytes_b));
@@ -768,6 +779,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     HIP_TRY(d_cnt.alloc(16 * MTG_POST_PARTS));
     HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, 0));
+    const uint64_t n_targets = in.traw.size() / TARGET_SLOT;
+    HIP_TRY(d_tenc.alloc(n_targets * 16 + 64));
     const uint8_t* da = d_ina.as<uint8_t>();
     const uint64_t* d_src = (const uint64_t*)(da + FillInput::off_a(n, 0));
     const uint64_t* d_r0 = (const uint64_t*)(da + FillInput::off_a(n, 1));
@@ -778,9 +792,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     const uint8_t* d_mis = da + FillInput::off_a(n, 6);
     const uint8_t* d_fok = da + FillInput::off_a(n, 7);
     const uint64_t* d_rw = d_inb.as<uint64_t>();
-    const uint64_t* d_tle = d_inc.as<uint64_t>(); /* sent after the caller's before_post work, which is what fills it */
-    const uint64_t* d_tbad = d_tle + in.tle.size();
-    bool targets_sent = false;
+    uint64_t* d_tle = d_tenc.as<uint64_t>();
+    uint64_t* d_tbad = d_tle + n_targets;
+    if (n_targets) hipLaunchKernelGGL(k_encode_targets, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, 0, d_inc.as<uint8_t>(), d_tle, d_tbad, n_targets, k);
     st.h2d_ms += now_ms() - t0;
     tick("upload (async)");
 
@@ -861,8 +875,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             HIP_TRY(hipEventRecord(ev1, 0));
             HIP_TRY(hipGetLastError());
             tick("host prep+launch");
-            if (before_post && !before_done) { before_done = true; (*before_post)(); tick("host work before k_post"); } /* the device is busy: the caller's turn */
-            if (!targets_sent) { targets_sent = true; HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, 0)); }
             /* post-processing in parts */
             uint32_t nparts = env_parts > 0 ? (uint32_t)env_parts : (m >= 16384 ? 4u : 1u);
             if (nparts > (uint32_t)MTG_POST_PARTS) nparts = MTG_POST_PARTS;
@@ -978,7 +990,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
     }
 #endif
-    if (before_post && !before_done) (*before_post)();
     if (while_busy && !busy_done) (*while_busy)();
     if (rc == MTG_OK && n_todo) {
         set_error("%zu gap(s) exceeded the largest traversal scratch tier", n_todo);

@@ -229,11 +229,10 @@ void FillInput::alloc_b(uint64_t rw, uint64_t nt)
     block_b = idx ? staging_host(idx, 1, bytes_b) : nullptr;
     if (!block_b) { own_b.resize(bytes_b / 8 + 1); block_b = own_b.data(); }
     rwords.p = (uint64_t*)block_b; rwords.n = rw;
-    bytes_c = 16 * nt + 64;
+    bytes_c = (size_t)TARGET_SLOT * nt + 64;
     block_c = idx ? staging_host(idx, 2, bytes_c) : nullptr;
     if (!block_c) { own_c.resize(bytes_c / 8 + 1); block_c = own_c.data(); }
-    tle.p = (uint64_t*)block_c; tle.n = nt;
-    tbad.p = tle.p + nt; tbad.n = nt;
+    traw.p = (uint8_t*)block_c; traw.n = (size_t)TARGET_SLOT * nt;
 }
 void FillInput::layout()
 {
@@ -263,18 +262,12 @@ void FillInput::set_common(size_t g, std::string_view source, std::string_view s
 }
 void FillInput::set_target(size_t o, std::string_view seq)
 {
-    /* identNT (src/Utils.cpp:81-84) is case-insensitive equality: compare 2-bit codes and force a mismatch where the anchor
-     * character is not a nucleotide; an anchor shorter than k can never be matched */
-    uint64_t le = 0, bad = 0;
-    if ((int)seq.size() < k) bad = ~0ull;
-    else
-        for (int i = 0; i < k; i++) {
-            const unsigned char c = (unsigned char)seq[i], u = c & 0xDF;
-            le |= (uint64_t)nt_code(c) << (2 * i);
-            if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad |= 1ull << (2 * i);
-        }
-    tle[o] = le;
-    tbad[o] = bad & (0x5555555555555555ULL & kmask(k));
+    /* the first k characters as they are; the device encodes them (encode_target, mtg_post.h) */
+    uint8_t* slot = traw.p + o * TARGET_SLOT;
+    const bool usable = (int)seq.size() >= k;
+    memset(slot, 0, TARGET_SLOT);
+    if (usable) memcpy(slot, seq.data(), (size_t)k);
+    slot[TARGET_SLOT - 1] = usable ? 1 : 0;
 }
 void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis)
 {
@@ -582,9 +575,6 @@ struct VecSource : BatchSource {
     void input(size_t i, FillInput& in, int nb_mis_allowed) const override
     {
         in.set_common(i, g[i].source, swf[i], g[i].anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
-    }
-    void targets(size_t i, FillInput& in) const override
-    {
         size_t o = in.toff[i];
         for (const Target& t : g[i].targets) in.set_target(o++, t.seq);
     }
@@ -629,7 +619,6 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     DevBatch batch;
     double t_marshal = 0, t_parts = 0;
     bool marshalled = false;
-    const std::function<void()> before_post = [&]() { parallel_for(n, nth, [&](size_t i) { src.targets(i, in); }, 512); };
     const std::function<void()> while_busy = [&]() { const double t = now_ms(); src.marshal(in, nth); marshalled = true; t_marshal = now_ms() - t; };
     /* Every chunk of results is turned into solutions as soon as it is back, while the device works on the next one: arena bytes of
      * every block of its gaps, then the gaps of a block one after the other (the sequences of a chunk share one arena buffer). */
@@ -696,7 +685,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
         if (recording) src.part_done(first, count, !incomplete.load(), rec_bytes.load(), rec_filled.load());
         t_parts += now_ms() - t;
     };
-    int rc = device_run(idx, p, in, batch, &st, &before_post, &while_busy, &on_ready);
+    int rc = device_run(idx, p, in, batch, &st, &while_busy, &on_ready);
     if (rc) return rc;
     if (dbg) fprintf(stderr, "  [fill_gaps] marshal (overlapped) %.2f ms, chunks processed in %.2f ms\n", t_marshal, t_parts);
     std::vector<GapWork>& gaps = src.gaps();
@@ -870,10 +859,6 @@ struct AbiSource : mtgi::BatchSource {
     {
         const mtg_gap& a = g[i];
         in.set_common(i, std::string_view(a.source), std::string_view(a.target, in.rlen[i]), a.is_anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
-    }
-    void targets(size_t i, mtgi::FillInput& in) const override
-    {
-        const mtg_gap& a = g[i];
         for (int t = 0; t < a.n_targets; t++) in.set_target(in.toff[i] + (size_t)t, std::string_view(a.target_seqs[t]));
     }
     void marshal(const mtgi::FillInput& in, int nthreads) override
@@ -882,7 +867,7 @@ struct AbiSource : mtgi::BatchSource {
         R->res.resize(n);
         R->nfilled.resize(n);
         if (R->filled_flat.size() < n) R->filled_flat.resize(n);
-        R->targets.resize(in.tle.size());
+        R->targets.resize(in.traw.size() / mtg::TARGET_SLOT);
         mtgi::parallel_for(n, nthreads, [&](size_t i) {
             const mtg_gap& a = g[i];
             mtgi::GapWork& w = R->gaps[i];

@@ -302,8 +302,8 @@ struct FillInput {
     Arr<uint8_t> nbmis, fast_ok;
     /* block B */
     Arr<uint64_t> rwords;  /* packed swf patterns, concatenated */
-    /* block C: only the post-processing kernel reads it, so it may be filled and sent while the traversal kernel runs */
-    Arr<uint64_t> tle, tbad; /* targets of all gaps: little-endian k-mer, never-match mask */
+    /* block C: the targets of all gaps as text (mtg_post.h: TARGET_SLOT bytes each); the device turns them into k-mers and masks */
+    Arr<uint8_t> traw;
     void *block_a = nullptr, *block_b = nullptr, *block_c = nullptr;
     size_t bytes_a = 0, bytes_b = 0, bytes_c = 0;
     std::vector<uint64_t> own_a, own_b, own_c;
@@ -359,10 +359,9 @@ struct FillInput {
     static size_t n8(size_t n) { return (n + 7) & ~(size_t)7; }
 };
 
-/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status.  The two hooks run once on the
- * calling thread while the device works on the first chunk: `before_post` after the traversal kernel has been launched (it has to
- * fill block C of the input, which is then sent and the post-processing kernel launched), `while_busy` after that launch. */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats, const std::function<void()>* before_post = nullptr,
+/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status.  `while_busy` runs once on the
+ * calling thread after everything of the first traversal launch has been queued: the device needs nothing more from the host. */
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats,
                const std::function<void()>* while_busy = nullptr, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready = nullptr);
 /* on_ready(chunk, ids, first, count): chunk `chunk` of `out` is complete and holds the results of the gaps ids[0..count) (ids == nullptr:
  * the gaps first .. first + count - 1).  A gap whose status is not GAP_OK there is re-run in a larger scratch tier and announced again
@@ -500,10 +499,8 @@ struct BatchSource {
     virtual size_t count() const = 0;
     /* pass 1, any thread: lengths of gap i's source and swf pattern, number of targets; false: the gap is malformed */
     virtual bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const = 0;
-    /* pass 2, any thread: in.set_common(i, ...) */
+    /* pass 2, any thread: in.set_common(i, ...) and in.set_target(in.toff[i] + t, ...) for every target of gap i */
     virtual void input(size_t i, FillInput& in, int nb_mis_allowed) const = 0;
-    /* while the traversal kernel runs, any thread: in.set_target(in.toff[i] + t, ...) for every target of gap i */
-    virtual void targets(size_t i, FillInput& in) const = 0;
     /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
     virtual void marshal(const FillInput& in, int nthreads) = 0;
     virtual std::vector<GapWork>& gaps() = 0;

@@ -43,6 +43,24 @@ struct SlotRec {
     uint64_t wbase, cbase;
 };
 
+/* A target as the host hands it over: its first k characters in a TARGET_SLOT-byte slot, byte TARGET_SLOT - 1 = 1 when the anchor
+ * has at least k characters.  identNT (src/Utils.cpp:81-84) is case-insensitive equality: the k-mer is compared as 2-bit codes with a
+ * forced mismatch where the anchor character is not a nucleotide; an anchor shorter than k can never be matched. */
+enum { TARGET_SLOT = 32 };
+MTG_DEV void encode_target(const uint8_t* slot, int k, uint64_t& le, uint64_t& bad)
+{
+    le = 0;
+    bad = 0;
+    if (!slot[TARGET_SLOT - 1]) { bad = ~0ull; }
+    else
+        for (int i = 0; i < k; i++) {
+            const uint32_t c = slot[i], u = c & 0xDFu;
+            le |= (uint64_t)((c >> 1) & 3u) << (2 * i);
+            if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad |= 1ull << (2 * i);
+        }
+    bad &= 0x5555555555555555ULL & kmask(k);
+}
+
 struct PostTargets {
     const uint64_t* le;  /* target k-mers, little-endian packed (nt i at bits 2i), dictionary iteration order */
     const uint64_t* bad; /* bit 2i set: position i can never match (not ACGT) or the whole anchor is unusable */

@@ -156,11 +156,14 @@ int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint3
 /* the emulator keeps the marshalled input in the FillInput's own storage */
 void* staging_host(const mtg_index*, int, size_t) { return nullptr; }
 
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats, const std::function<void()>* before_post,
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats,
                const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)
 {
-    if (before_post) (*before_post)();
     if (while_busy) (*while_busy)();
+    /* stand-in for k_encode_targets */
+    const size_t n_targets = in.traw.size() / TARGET_SLOT;
+    std::vector<uint64_t> tle(n_targets), tbad(n_targets);
+    for (size_t t = 0; t < n_targets; t++) encode_target(in.traw.data() + t * TARGET_SLOT, idx->dev.k, tle[t], tbad[t]);
     const size_t n = in.src.size();
     batch.n = n;
     batch.chunk_of.assign(n, 0);
@@ -186,8 +189,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             st.index_lines += o.lines;
             if (o.status != GAP_OK) { st.n_retried_gaps++; continue; }
             PostTargets T;
-            T.le = in.tle.data() + in.toff[g];
-            T.bad = in.tbad.data() + in.toff[g];
+            T.le = tle.data() + in.toff[g];
+            T.bad = tbad.data() + in.toff[g];
             T.n = in.tcnt[g];
             T.nb_mis = in.nbmis[g];
             T.fast_ok = in.fast_ok[g];
