@@ -477,41 +477,6 @@ MTG_UNROLL
     if (!val && p.q[MTG_ABND_SLOTS / 2 - 1].y != 0) val = table_get<MTG_ABND_SLOTS>(ix.abnd, p.key, lines);
     return val;
 }
-/* U independent look-ups with their first bucket reads in flight together (a lane that needs the abundances of a run of known k-mers);
- * only the keys whose bit is set in `valid` are looked up, the others read as 0 */
-template <int U> MTG_DEV void abundance_batch(const Index& ix, const uint64_t* keys, uint32_t valid, uint32_t* out, uint32_t& lines)
-{
-    const Table& t = ix.abnd;
-    U64x2 q[U][MTG_ABND_SLOTS / 2];
-    uint64_t want[U];
-MTG_UNROLL
-    for (int u = 0; u < U; u++) {
-        const uint64_t H = mix(keys[u], t.key_bits);
-        const uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
-        want[u] = (H & ((1ULL << t.tag_bits) - 1)) << MTG_DISP_BITS;
-        const U64x2* p = reinterpret_cast<const U64x2*>(t.slots + b * MTG_ABND_SLOTS);
-MTG_UNROLL
-        for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) {
-            if ((valid >> u) & 1u) q[u][i] = ld_table(p + i);
-            else { q[u][i].x = 0; q[u][i].y = 0; }
-        }
-    }
-MTG_UNROLL
-    for (int u = 0; u < U; u++) {
-        uint32_t val = 0;
-MTG_UNROLL
-        for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) {
-            val |= ((q[u][i].x >> 8) == want[u]) ? (uint32_t)(q[u][i].x & 255) : 0u;
-            val |= ((q[u][i].y >> 8) == want[u]) ? (uint32_t)(q[u][i].y & 255) : 0u;
-        }
-        if ((valid >> u) & 1u) {
-            lines++;
-            /* not in its home bucket and the bucket is full: the key may have spilled further (rare) */
-            if (!val && q[u][MTG_ABND_SLOTS / 2 - 1].y != 0) val = table_get<MTG_ABND_SLOTS>(t, keys[u], lines);
-        } else val = 0;
-        out[u] = val;
-    }
-}
 
 /* index construction: one call per solid k-mer (canonical value c, abundance >= 1).
  * Returns bit 0 = displacement overflow, bit 1 = the k-mer was new. */

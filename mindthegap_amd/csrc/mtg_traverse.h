@@ -657,6 +657,7 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
  * Anything else -- including a fingerprint collision that turns out to be a real duplicate -- returns 0 and the caller runs the
  * general code, so the fast path never decides a case it does not fully understand.  The distinctness test keeps 16-bit fingerprints
  * of the canonical k-mers in a small table (LDS); a fingerprint seen before is checked exactly by walking the branches again. */
+#ifdef MTG_EMU /* TEST-ONLY: the explicit duplicate search that cross-checks the closed-form distinctness test on every bubble */
 MTG_DEV uint32_t fp_hash(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 32); }
 /* layout: the slots of a lane in groups of 8 bytes (group g of lane l at g * 512 + l * 8), so that the table is cleared 8 slots at a
  * time and the lanes of a wave never fight for a bank when they do */
@@ -676,12 +677,14 @@ MTG_DEV int fp_add(const GapScratch& S, uint64_t c)
         s = (s + 1) & (FP_SLOTS - 1);
     }
 }
+#endif
 /* the nucleotides of one branch, 2 bits each, in registers (up to 64) */
 struct SnpSeq {
     uint64_t lo, hi;
     MTG_DEV uint32_t get(int i) const { return (uint32_t)((i < 32 ? lo >> (2 * i) : hi >> (2 * (i - 32))) & 3u); }
     MTG_DEV void set(int i, uint32_t nt) { if (i < 32) lo |= (uint64_t)nt << (2 * i); else hi |= (uint64_t)nt << (2 * (i - 32)); }
 };
+#ifdef MTG_EMU
 /* is canonical k-mer c among: the node, prev_c, and the first `steps` nodes of each branch (the walk is replayed from the nucleotides
  * known so far), the node of branch `skip_branch` at position `skip_pos` excepted */
 MTG_DEV bool snp_seen_exactly(const Worker& W, const Kmer& cur, uint64_t prev_c, const SnpSeq* seq, int steps, uint64_t c, int skip_branch, int skip_pos)
@@ -698,6 +701,7 @@ MTG_UNROLL
     }
     return false;
 }
+#endif
 enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches of up to 2k - 1 nodes; the nucleotides of a branch fit two registers */
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen)
