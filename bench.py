@@ -268,7 +268,8 @@ def main():
            "config": {"workload": desc, "sites_per_gpu": sites_per_gpu, "donor_sequences": S.nseq, "k": k, "max_nodes": 100, "max_length": 10000,
                       "index": "exact k-mer set of the donor, abundance = 3 + hash %% 40 (no reads simulated)", "nb_solid_kmers": int(info["nb_solid_kmers"]),
                       "index_bytes": int(info["device_bytes"]), "index_build_s": t_index, "genome_gen_s": t_gen},
-           "filled": n_filled_all, "filled_sequences_identical_to_truth": identical,
+           "filled": n_filled_all, "filled_per_s": n_filled_all * a.steps / elapsed,
+           "filled_sequences_identical_to_truth": identical,
            "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "post_kernel": post_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps,
                                  "c_call": call_ms / a.steps},
            "roofline": roof, "cpu_baseline": cpu}
