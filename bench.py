@@ -33,7 +33,9 @@ def parse():
     ap.add_argument("--nseq", type=int, default=0)
     ap.add_argument("--cpu-sites", type=int, default=30000, help="sites of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-index-seqs", type=int, default=30000, help="donor sequences in the CPU baseline's index")
-    ap.add_argument("--host-threads", type=int, default=-1, help="host threads per rank for the per-gap passes (default: all cores, at most 64, shared between the ranks)")
+    ap.add_argument("--host-threads", type=int, default=-1, help="host threads per rank for the per-gap passes (default: the library's pool = CPU budget of the process, shared between the ranks)")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MTG_BENCH_IN_FLIGHT", "2")),
+                    help="steps in flight: caller threads issuing batches on the one index (the library runs two batches side by side)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the random-64B-line ceiling micro-benchmark")
     return ap.parse_args()
 
@@ -58,6 +60,9 @@ def main():
     from mindthegap_amd.shard import PipelinedGather, gather_bytes
     from mindthegap_amd.synth import SynthSet
 
+    # the ranks of a node share its CPUs (and, in a container, one CFS quota): each rank's worker pool gets its share
+    if world > 1:
+        os.environ.setdefault("MTG_POOL_THREADS", str(max(2, mtg.cpu_budget() // world)))
     lib = mtg.load_library()
     if not torch.cuda.is_available() or mtg.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -106,8 +111,8 @@ def main():
         gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
         expected.append(ins)
     prepared = mtg.Index.prepare_gaps(gaps)
-    # N ranks share the host: each gets its share of the cores for the per-gap host passes (0 = the library's default, up to 64 threads)
-    host_threads = a.host_threads if a.host_threads >= 0 else (0 if world == 1 else max(4, min(64, (os.cpu_count() or 64) // world)))
+    # 0 = the library's worker pool as it sized itself (CPU budget of the process, at most 64; MTG_POOL_THREADS above for N > 1)
+    host_threads = a.host_threads if a.host_threads >= 0 else 0
     params = mtg.FillParams(max_nodes=100, max_depth=10000, nb_host_threads=host_threads)
     exp_digest = hashlib.sha256(("\n".join(expected) + "\n").encode()).hexdigest()
 
@@ -122,9 +127,10 @@ def main():
         on rank 0 over RCCL / xGMI while the next step runs; the final, untimed pass uses the blocking gather and is verified."""
         tp0 = time.perf_counter()
         if pg is not None and not final:
-            h, nf, nbytes = idx.fill_prepared_serial(prepared, pg.buffer(), params)  # decoded straight into the page-locked gather buffer
+            j, buf = pg.acquire()
+            h, nf, nbytes = idx.fill_prepared_serial(prepared, buf, params)  # decoded straight into the page-locked gather buffer
             seqs = None
-            pg.submit(nbytes)
+            pg.submit(nbytes, j)
         else:
             h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=want_seqs or final)
         st = mtg.last_batch_stats()
@@ -157,17 +163,49 @@ def main():
         step()  # untimed: sizes the gather buffers (the largest payload of any rank, plus head room)
         cap = torch.tensor([idx.last_seq_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        pg = PipelinedGather(int(cap.item()) * 5 // 4 + (1 << 20), dst=0, device=cdev)
-    for _ in range(a.warmup):
-        step()
+        pg = PipelinedGather(int(cap.item()) * 5 // 4 + (1 << 20), dst=0, device=cdev, depth=2 * max(a.in_flight, 1))
+    import threading
+    acc = dict(kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, post_kernel_ms=0.0, total_ms=0.0)
+    acc_lock = threading.Lock()
+
+    def run_steps(count, record):
+        """`count` steps, a.in_flight of them in flight: caller threads take the next step off a shared counter, like the reference's
+        Dispatcher threads take the next group of records; every step is complete when this returns"""
+        todo = iter(range(count))
+        errors = []
+
+        def worker():
+            try:
+                while True:
+                    with acc_lock:
+                        if next(todo, None) is None:
+                            return
+                    _, _, st = step()
+                    if record:
+                        with acc_lock:
+                            for key in acc:
+                                acc[key] += st[key]
+            except BaseException as e:  # surfaced on the main thread
+                errors.append(e)
+
+        if a.in_flight <= 1:
+            worker()
+        else:
+            ts = [threading.Thread(target=worker) for _ in range(a.in_flight)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        if errors:
+            raise errors[0]
+
+    run_steps(a.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = lines = contig_nt = launches = host_ms = d2h_ms = post_ms = call_ms = 0
     n_filled, seqs = 0, np.empty(0, dtype=np.uint8)
-    for _ in range(a.steps):
-        n_filled, seqs, st = step()
-        kernel_ms += st["kernel_ms"]; lines += st["index_lines"]; contig_nt += st["contig_nt"]; launches += st["n_launches"]
-        host_ms += st["host_ms"]; d2h_ms += st["d2h_ms"]; post_ms += st["post_kernel_ms"]; call_ms += st["total_ms"]
+    run_steps(a.steps, True)
+    kernel_ms, lines, contig_nt, launches = acc["kernel_ms"], acc["index_lines"], acc["contig_nt"], acc["n_launches"]
+    host_ms, d2h_ms, post_ms, call_ms = acc["host_ms"], acc["d2h_ms"], acc["post_kernel_ms"], acc["total_ms"]
     if pg is not None:
         pg.drain()  # the gathers still in flight belong to the timed steps
     barrier()
@@ -198,7 +236,7 @@ def main():
         from tests import oracle_lib
         ns = min(a.cpu_sites, sites_per_gpu)
         nidx = max(min(a.cpu_index_seqs, S.nseq), ns)
-        cores = os.cpu_count() or 1
+        cores = mtg.cpu_budget()  # the threads the container may actually run (CFS quota), not the hardware threads of the host
         if het:  # both haplotypes of the sampled loci
             nl = S.nseq // 2
             nidx = max(min(a.cpu_index_seqs // 2, nl), ns)
@@ -267,7 +305,7 @@ def main():
            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": desc, "sites_per_gpu": sites_per_gpu, "donor_sequences": S.nseq, "k": k, "max_nodes": 100, "max_length": 10000,
                       "index": "exact k-mer set of the donor, abundance = 3 + hash %% 40 (no reads simulated)", "nb_solid_kmers": int(info["nb_solid_kmers"]),
-                      "index_bytes": int(info["device_bytes"]), "index_build_s": t_index, "genome_gen_s": t_gen},
+                      "index_bytes": int(info["device_bytes"]), "index_build_s": t_index, "genome_gen_s": t_gen, "steps_in_flight": a.in_flight},
            "filled": n_filled_all, "filled_per_s": n_filled_all * a.steps / elapsed,
            "filled_sequences_identical_to_truth": identical,
            "stage_ms_per_step": {"kernel": kernel_ms / a.steps, "post_kernel": post_ms / a.steps, "d2h": d2h_ms / a.steps, "host": host_ms / a.steps,

@@ -645,9 +645,12 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
 void index_release(mtg_index* idx)
 {
     if (!idx) return;
-    for (int i = 0; i < Workspace::NSLOTS; i++) if (idx->ws.ptr[i]) (void)hipFree(idx->ws.ptr[i]);
-    for (int i = 0; i < Workspace::NHOST; i++) if (idx->ws.hptr[i]) (void)hipHostFree(idx->ws.hptr[i]);
-    if (idx->ws.copy_stream) (void)hipStreamDestroy((hipStream_t)idx->ws.copy_stream);
+    for (Workspace& w : idx->ws) {
+        for (int i = 0; i < Workspace::NSLOTS; i++) if (w.ptr[i]) (void)hipFree(w.ptr[i]);
+        for (int i = 0; i < Workspace::NHOST; i++) if (w.hptr[i]) (void)hipHostFree(w.hptr[i]);
+        if (w.stream) (void)hipStreamDestroy((hipStream_t)w.stream);
+        if (w.copy_stream) (void)hipStreamDestroy((hipStream_t)w.copy_stream);
+    }
     index_forget_host_copy(idx);
     free_tables(idx);
     delete idx;
@@ -721,10 +724,10 @@ template <typename B, typename T> hipError_t upload(B& b, const std::vector<T>& 
 }
 } // namespace
 
-void* staging_host(const mtg_index* idx, int slot, size_t bytes)
+void* staging_host(Workspace* wsp, int slot, size_t bytes)
 {
-    Workspace& ws = idx->ws;
-    if (slot < 0 || slot >= Workspace::NHOST) return nullptr;
+    if (!wsp || slot < 0 || slot >= Workspace::NHOST) return nullptr;
+    Workspace& ws = *wsp;
     if (ws.hcap[slot] < bytes) {
         if (ws.hptr[slot]) (void)hipHostFree(ws.hptr[slot]);
         ws.hptr[slot] = nullptr;
@@ -744,7 +747,8 @@ struct EventSet { /* events of one device_run call */
 };
 } // namespace
 
-/* The caller holds idx->ws.mtx (the workspace and the staging blocks belong to one batch at a time).
+/* The caller holds the lock of in.ws (a workspace and its staging blocks belong to one batch at a time); everything the batch queues
+ * goes to the workspace's own streams, so that two batches on the device overlap.
  *
  * One traversal launch covers as many gaps as fit the scratch; its post-processing runs as up to MTG_POST_PARTS launches over
  * consecutive slot ranges, each with its own dense arrays and counters, so that a part's results travel back (copy stream) and are
@@ -757,6 +761,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     double tk = now_ms();
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
     if (int rc = ensure_device()) return rc;
+    if (!in.ws) { set_error("device_run: the input has no workspace"); return MTG_ERR_ARG; }
+    Workspace& ws = *in.ws;
+    if (!ws.stream) {
+        hipStream_t s0, s1;
+        HIP_TRY(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+        ws.stream = (void*)s0;
+        HIP_TRY(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+        ws.copy_stream = (void*)s1;
+        HIP_TRY(hipDeviceSynchronize()); /* the index was built or loaded on the null stream, which these streams do not wait for */
+    }
+    const hipStream_t stream = (hipStream_t)ws.stream, copy_stream = (hipStream_t)ws.copy_stream;
     const size_t n = in.src.size();
     batch.n = n;
     batch.part = ~(size_t)0;
@@ -768,7 +783,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     const int k = idx->dev.k;
 
     int ws_next = 0;
-    auto wsbuf = [&]() { WsBuf b; b.ws = &idx->ws; b.slot = ws_next++; return b; };
+    auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
           d_dm = wsbuf(), d_cnt = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device */
@@ -777,9 +792,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     HIP_TRY(d_inb.alloc(in.bytes_b));
     HIP_TRY(d_inc.alloc(in.bytes_c));
     HIP_TRY(d_cnt.alloc(16 * MTG_POST_PARTS));
-    HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, 0));
-    HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, 0));
-    HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, stream));
     const uint64_t n_targets = in.traw.size() / TARGET_SLOT;
     HIP_TRY(d_tenc.alloc(n_targets * 16 + 64));
     const uint8_t* da = d_ina.as<uint8_t>();
@@ -794,7 +809,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     const uint64_t* d_rw = d_inb.as<uint64_t>();
     uint64_t* d_tle = d_tenc.as<uint64_t>();
     uint64_t* d_tbad = d_tle + n_targets;
-    if (n_targets) hipLaunchKernelGGL(k_encode_targets, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, 0, d_inc.as<uint8_t>(), d_tle, d_tbad, n_targets, k);
+    if (n_targets) hipLaunchKernelGGL(k_encode_targets, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, stream, d_inc.as<uint8_t>(), d_tle, d_tbad, n_targets, k);
     st.h2d_ms += now_ms() - t0;
     tick("upload (async)");
 
@@ -804,13 +819,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
     for (int q = 0; q < MTG_POST_PARTS; q++) HIP_TRY(events.make(evp[q]));
-    if (!idx->ws.copy_stream) {
-        hipStream_t cs;
-        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        idx->ws.copy_stream = (void*)cs;
-    }
-    hipStream_t copy_stream = (hipStream_t)idx->ws.copy_stream;
-    unsigned long long* h_tot = (unsigned long long*)staging_host(idx, Workspace::NHOST - 1, 16 * MTG_POST_PARTS);
+    unsigned long long* h_tot = (unsigned long long*)staging_host(&ws, Workspace::NHOST - 1, 16 * MTG_POST_PARTS);
     std::vector<unsigned long long> h_tot_own(2 * MTG_POST_PARTS, 0);
     if (!h_tot) h_tot = h_tot_own.data();
 
@@ -828,7 +837,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
         const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + (uint64_t)cfg.cap_words * 8 +
                                  (uint64_t)cfg.cap_contigs * 20;
-        const size_t cached = idx->ws.cap[d_zero.slot] + idx->ws.cap[d_raw.slot] + idx->ws.cap[d_ilv.slot] + idx->ws.cap[d_dw.slot] + idx->ws.cap[d_dm.slot]; /* already ours */
+        const size_t cached = ws.cap[d_zero.slot] + ws.cap[d_raw.slot] + ws.cap[d_ilv.slot] + ws.cap[d_dw.slot] + ws.cap[d_dm.slot]; /* already ours */
         size_t chunk = (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
         const size_t env_chunk = getenv("MTG_MAX_CHUNK") ? (size_t)atol(getenv("MTG_MAX_CHUNK")) : 0; /* test hook: several launches per batch */
         if (env_chunk && chunk > env_chunk) chunk = env_chunk;
@@ -837,7 +846,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         if (chunk == 0) { set_error("not enough device memory for one gap at scratch tier %d (%llu bytes)", tier, (unsigned long long)per_gap); rc = MTG_ERR_NOMEM; break; }
         HIP_TRY(d_zero.alloc(chunk * cfg.zero_stride));
         /* zeroed once: every gap restores what it touched (stage_a_gap), so the region stays clean from launch to launch */
-        if (d_zero.fresh) HIP_TRY(hipMemsetAsync(d_zero.p, 0, idx->ws.cap[d_zero.slot], 0));
+        if (d_zero.fresh) HIP_TRY(hipMemsetAsync(d_zero.p, 0, ws.cap[d_zero.slot], stream));
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
         HIP_TRY(d_ilv.alloc(((chunk + 63) / 64) * cfg.ilv_stride));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
@@ -857,22 +866,22 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 t0 = now_ms();
                 if (todo.empty()) { seq_ids.resize(m); for (uint32_t s = 0; s < m; s++) seq_ids[s] = (uint32_t)(base + s); host_ids = seq_ids.data(); }
                 else host_ids = todo.data() + base;
-                HIP_TRY(hipMemcpy(d_ids.p, host_ids, (size_t)m * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpyAsync(d_ids.p, host_ids, (size_t)m * 4, hipMemcpyHostToDevice, stream)); /* host_ids outlives the launch */
                 ids = d_ids.as<uint32_t>();
                 st.h2d_ms += now_ms() - t0;
             }
-            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16 * MTG_POST_PARTS, 0));
-            HIP_TRY(hipEventRecord(ev0, 0));
-            {
-                /* the constants belong to the module, not to an index: batches on different indexes must not interleave these three */
-                static std::mutex launch_mtx;
-                std::lock_guard<std::mutex> lk(launch_mtx);
-                HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, 0));
-                HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, 0));
-                hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, 0, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
-            }
-            HIP_TRY(hipEventRecord(ev1, 0));
+            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16 * MTG_POST_PARTS, stream));
+            HIP_TRY(hipEventRecord(ev0, stream));
+            /* The traversal reads index shape and configuration from the module's constants: one traversal at a time on the device, whatever
+             * the index.  The lock is kept until this one has finished (below, after the host work that runs meanwhile); the traversal of
+             * the next batch then overlaps this batch's post-processing. */
+            static std::mutex traversal_mtx;
+            std::unique_lock<std::mutex> traversal_lock(traversal_mtx);
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                               d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
+            HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
             tick("host prep+launch");
             /* post-processing in parts */
@@ -883,15 +892,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             nparts = (m + psize - 1) / psize;
             for (uint32_t q = 0; q < nparts; q++) {
                 const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize);
-                hipLaunchKernelGGL(k_post, dim3(std::min<uint32_t>(s1 - s0, post_grid)), dim3(64), 0, 0, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis,
+                hipLaunchKernelGGL(k_post, dim3(std::min<uint32_t>(s1 - s0, post_grid)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis,
                                    d_fok, in.want_all_contigs ? 1u : 0u, d_cnt.as<unsigned long long>() + 2 * q, d_rec.as<SlotRec>(),
                                    d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, s0, s1);
-                HIP_TRY(hipMemcpyAsync(h_tot + 2 * q, d_cnt.as<unsigned long long>() + 2 * q, 16, hipMemcpyDeviceToHost, 0));
-                HIP_TRY(hipEventRecord(evp[q], 0));
+                HIP_TRY(hipMemcpyAsync(h_tot + 2 * q, d_cnt.as<unsigned long long>() + 2 * q, 16, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipEventRecord(evp[q], stream));
             }
-            HIP_TRY(hipEventRecord(ev2, 0));
+            HIP_TRY(hipEventRecord(ev2, stream));
             HIP_TRY(hipGetLastError());
             if (while_busy && !busy_done) { busy_done = true; (*while_busy)(); tick("host work during kernels"); }
+            HIP_TRY(hipEventSynchronize(ev1));
+            traversal_lock.unlock();
             const uint32_t first_chunk = (uint32_t)batch.chunks.size();
             if (identity) batch.part = psize;
             else if (batch.chunk_of.empty()) {
@@ -912,7 +923,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 SlotRec* h_rec = nullptr;
                 uint64_t* h_w = nullptr;
                 uint32_t* h_m = nullptr;
-                void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST - 1 ? staging_host(idx, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(mq, tw, tc)) : nullptr;
+                void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST - 1 ? staging_host(&ws, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(mq, tw, tc)) : nullptr;
                 hc.carve(block, mq, tw, tc, h_rec, h_w, h_m);
                 HIP_TRY(hipStreamWaitEvent(copy_stream, evp[q], 0));
                 HIP_TRY(hipMemcpyAsync(h_rec, d_rec.as<SlotRec>() + s0, (size_t)mq * sizeof(SlotRec), hipMemcpyDeviceToHost, copy_stream));
@@ -951,13 +962,15 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                         if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s0 + s2);
                     if (!gslots.empty()) {
                         DevBuf d_gs, d_po;
-                        HIP_TRY(upload(d_gs, gslots));
+                        HIP_TRY(d_gs.alloc(gslots.size() * 4));
+                        HIP_TRY(hipMemcpyAsync(d_gs.p, gslots.data(), gslots.size() * 4, hipMemcpyHostToDevice, stream));
                         HIP_TRY(d_po.alloc(gslots.size() * (size_t)PATHS_WORDS * 4));
-                        hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, 0, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
+                        hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
                                            d_po.as<uint32_t>(), (uint32_t)gslots.size());
                         HIP_TRY(hipGetLastError());
                         hc.paths.resize(gslots.size() * (size_t)PATHS_WORDS);
-                        HIP_TRY(hipMemcpy(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpyAsync(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost, stream));
+                        HIP_TRY(hipStreamSynchronize(stream));
                         hc.path_of.assign(mq, -1);
                         for (size_t g2 = 0; g2 < gslots.size(); g2++) hc.path_of[gslots[g2] - s0] = (int32_t)g2;
                     }

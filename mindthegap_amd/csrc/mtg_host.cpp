@@ -215,7 +215,7 @@ struct TermInfo { /* info_node_t, src/Filler.hpp:44-71 */
 void FillInput::resize(size_t n)
 {
     bytes_a = 34 * n8(n) + 64;
-    block_a = idx ? staging_host(idx, 0, bytes_a) : nullptr;
+    block_a = ws ? staging_host(ws, 0, bytes_a) : nullptr;
     if (!block_a) { own_a.resize(bytes_a / 8 + 1); block_a = own_a.data(); }
     uint8_t* b = (uint8_t*)block_a;
     src.p = (uint64_t*)(b + off_a(n, 0)); r0.p = (uint64_t*)(b + off_a(n, 1));
@@ -226,11 +226,11 @@ void FillInput::resize(size_t n)
 void FillInput::alloc_b(uint64_t rw, uint64_t nt)
 {
     bytes_b = 8 * rw + 64;
-    block_b = idx ? staging_host(idx, 1, bytes_b) : nullptr;
+    block_b = ws ? staging_host(ws, 1, bytes_b) : nullptr;
     if (!block_b) { own_b.resize(bytes_b / 8 + 1); block_b = own_b.data(); }
     rwords.p = (uint64_t*)block_b; rwords.n = rw;
     bytes_c = (size_t)TARGET_SLOT * nt + 64;
-    block_c = idx ? staging_host(idx, 2, bytes_c) : nullptr;
+    block_c = ws ? staging_host(ws, 2, bytes_c) : nullptr;
     if (!block_c) { own_c.resize(bytes_c / 8 + 1); block_c = own_c.data(); }
     traw.p = (uint8_t*)block_c; traw.n = (size_t)TARGET_SLOT * nt;
 }
@@ -598,11 +598,12 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
     double tk = t_begin;
     auto tick = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "  [fill_gaps] %-22s %.2f ms\n", what, t - tk); tk = t; } };
-    /* the staging blocks of the index hold this batch from here until its results have been taken out of them */
-    std::lock_guard<std::mutex> batch_lock(idx->ws.mtx);
+    /* one workspace of the index (staging blocks, device buffers, streams) holds this batch from here until its results have been
+     * taken out of it */
+    WorkspaceLock batch_lock = acquire_workspace(idx);
     FillInput in;
     in.k = k;
-    in.idx = idx;
+    in.ws = batch_lock.ws;
     std::atomic<long> bad_gap{-1}, short_gap{-1};
     in.plan(n, nth, [&](size_t i, size_t& swf_len, size_t& n_targets) {
         size_t src_len = 0;
@@ -798,7 +799,8 @@ struct mtg_contigs {
 };
 
 /* Result objects are recycled: a freed one keeps its storage (a few hundred bytes per gap plus the sequence arena) for the next batch,
- * which then pays neither page faults nor allocator traffic.  At most two are kept. */
+ * which then pays neither page faults nor allocator traffic.  At most four are kept (two batches in flight, each with
+ * the previous result still in its caller's hands). */
 namespace {
 std::mutex g_results_mtx;
 std::vector<mtg_results*> g_results_cache;
@@ -814,7 +816,7 @@ void results_release(mtg_results* r)
 {
     {
         std::lock_guard<std::mutex> lk(g_results_mtx);
-        if (g_results_cache.size() < 2) { g_results_cache.push_back(r); return; }
+        if (g_results_cache.size() < 4) { g_results_cache.push_back(r); return; }
     }
     delete r;
 }
@@ -1113,10 +1115,10 @@ int mtg_nw_matches(const char* const* a, const char* const* b, size_t n, uint32_
 int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* const* sources, const char* const* targets, size_t n, mtg_contigs** out)
 {
     if (!idx || !p || !out || (n && (!sources || !targets))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
-    std::lock_guard<std::mutex> batch_lock(idx->ws.mtx);
+    mtgi::WorkspaceLock batch_lock = mtgi::acquire_workspace(idx);
     mtgi::FillInput in;
     in.k = idx->dev.k;
-    in.idx = idx;
+    in.ws = batch_lock.ws;
     in.want_all_contigs = true;
     in.resize(n);
     for (size_t i = 0; i < n; i++) {

@@ -11,10 +11,13 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <sched.h>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -29,6 +32,7 @@ struct Workspace {
     /* page-locked host staging blocks: 0..2 = the marshalled input of a batch, 3.. = what the first chunks of a batch brought back */
     void* hptr[NHOST] = {nullptr};
     size_t hcap[NHOST] = {0};
+    void* stream = nullptr;      /* hipStream_t of the batch's copies in and kernels */
     void* copy_stream = nullptr; /* hipStream_t for the copies back of a batch's parts */
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
@@ -36,10 +40,31 @@ struct Workspace {
 
 struct mtg_index {
     mtg::Index dev{};          /* tables live in device memory */
-    mutable mtgi::Workspace ws;
+    /* two batches on one index run side by side (callers on several threads, like the reference's Dispatcher): each owns a workspace
+     * and its streams, so the traversal of one overlaps the post-processing and the host passes of the other */
+    enum { NWS = 2 };
+    mutable mtgi::Workspace ws[NWS];
     int device = 0;
     mtg_index_info info{};
 };
+
+namespace mtgi {
+struct WorkspaceLock {
+    Workspace* ws = nullptr;
+    std::unique_lock<std::mutex> lk;
+};
+/* a free workspace of the index, or (all taken) the next one in turn once its batch is done */
+inline WorkspaceLock acquire_workspace(const mtg_index* idx)
+{
+    for (int i = 0; i < mtg_index::NWS; i++) {
+        std::unique_lock<std::mutex> lk(idx->ws[i].mtx, std::try_to_lock);
+        if (lk.owns_lock()) return WorkspaceLock{&idx->ws[i], std::move(lk)};
+    }
+    static std::atomic<unsigned> turn{0};
+    Workspace& w = idx->ws[turn.fetch_add(1, std::memory_order_relaxed) % mtg_index::NWS];
+    return WorkspaceLock{&w, std::unique_lock<std::mutex>(w.mtx)};
+}
+}
 
 namespace mtgi {
 
@@ -82,6 +107,28 @@ public:
     }
     int size() const { return (int)threads_.size() + 1; }
 
+    /* CPUs this process may keep busy: the hardware threads, the affinity mask and the CFS bandwidth limit of its cgroup (a container
+     * with "16 CPUs" on a 256-thread host: threads beyond the quota only get the whole group throttled, spinning ones above all) */
+    static int cpu_budget()
+    {
+        int n = (int)std::max(1u, std::thread::hardware_concurrency());
+#ifdef __linux__
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+        long long quota = -1, period = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { /* cgroup v2: "<quota|max> <period>" */
+            char q[32] = "";
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+            if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+        }
+        if (quota > 0 && period > 0) n = std::min(n, (int)std::max<long long>(1, quota / period));
+#endif
+        return n;
+    }
+
     static void cpu_relax()
     {
 #if defined(__x86_64__) || defined(__i386__)
@@ -93,7 +140,8 @@ private:
     enum { SPIN = 4000 };
     Pool()
     {
-        int n = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 64u);
+        int n = std::min(cpu_budget(), 64);
+        if (const char* e = getenv("MTG_POOL_THREADS")) n = std::max(1, std::min(atoi(e), 256));
         for (int i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
     }
     ~Pool()
@@ -197,8 +245,8 @@ struct TargetSpan {
     const Target* end() const { return p + n; }
 };
 
-/* grow-only staging block `slot` of the index (page-locked on the device build); nullptr when it cannot be had */
-void* staging_host(const mtg_index* idx, int slot, size_t bytes);
+/* grow-only staging block `slot` of a workspace (page-locked on the device build); nullptr when it cannot be had */
+void* staging_host(Workspace* ws, int slot, size_t bytes);
 
 /* what a chunk of gaps brought back: one record per slot, the dense words and the dense contig metadata.  The three arrays sit in a
  * staging block of the index (first chunks of a batch) or in `own`. */
@@ -292,7 +340,7 @@ template <typename T> struct Arr {
 struct FillInput {
     int k = 31;
     bool want_all_contigs = false;
-    const mtg_index* idx = nullptr; /* whose staging blocks to use */
+    Workspace* ws = nullptr; /* whose staging blocks and device buffers to use (the caller holds its lock) */
     /* block A */
     Arr<uint64_t> src;     /* oriented source k-mer per gap */
     Arr<uint64_t> r0;      /* first k-mer of the pattern */

@@ -15,6 +15,30 @@ SO = os.path.join(LIBDIR, "libmtgfill.so")
 ERRORS = {1: "MTG_ERR_NO_DEVICE", 2: "MTG_ERR_ARG", 3: "MTG_ERR_IO", 4: "MTG_ERR_NOMEM", 5: "MTG_ERR_OVERFLOW", 6: "MTG_ERR_FORMAT"}
 
 
+
+def cpu_budget():
+    """CPUs this process may keep busy: hardware threads, affinity mask and the CFS bandwidth limit of its cgroup (what the library's
+    worker pool sizes itself by, Pool::cpu_budget in csrc/mtg_internal.h)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota, period = -1, 0
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota, period = int(q), int(per)
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota > 0 and period > 0:
+        n = min(n, max(1, quota // period))
+    return max(1, n)
+
 class MtgError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("%s: %s" % (ERRORS.get(code, code), msg))

@@ -1,6 +1,8 @@
 """Multi-GPU sharding of the fill hot path: sites (or seeds) are independent (Dispatcher.iterate, src/Filler.cpp:824,844), so
 each rank takes a contiguous slice, the index is replicated, and only the results travel: byte payloads are gathered on one
 rank with an all_gather of sizes followed by a padded gather (RCCL over xGMI with backend "nccl", gloo in the CPU tests)."""
+import threading
+
 import numpy as np
 
 
@@ -59,7 +61,9 @@ class PipelinedGather:
         self.recv = [[torch.empty(n, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] for _ in range(depth)] if self.rank == dst else None
         self.work = [None] * depth
         self.i = 0
+        self.cur = 0
         self.done = -1  # buffer index of the last submitted step
+        self.lock = threading.Lock()
 
     def _wait(self, j):
         if self.work[j] is not None:
@@ -71,26 +75,34 @@ class PipelinedGather:
                 self.work[j].wait()
             self.work[j] = None
 
-    def buffer(self):
-        """numpy view of this step's payload area (capacity bytes); valid until submit()"""
-        j = self.i % self.depth
-        self._wait(j)
-        return self.stage[j].numpy()[self.HEADER:]
+    def acquire(self):
+        """(j, numpy view of the payload area of staging buffer j); the buffer belongs to the caller until submit(nbytes, j).
+        Thread-safe: several steps may be in flight (depth must exceed their number for the gathers to overlap with them)."""
+        with self.lock:
+            j = self.i % self.depth
+            self.i += 1
+            self._wait(j)
+        return j, self.stage[j].numpy()[self.HEADER:]
 
-    def submit(self, nbytes):
-        j = self.i % self.depth
+    def buffer(self):
+        """numpy view of this step's payload area (capacity bytes); valid until submit()  (one step at a time)"""
+        self.cur, view = self.acquire()
+        return view
+
+    def submit(self, nbytes, j=None):
+        j = self.cur if j is None else j
         if nbytes + self.HEADER > self.stage[j].numel():
             raise ValueError("payload of %d bytes exceeds the agreed capacity" % nbytes)
         self.stage[j].numpy()[: self.HEADER].view(np.int64)[0] = nbytes
-        if self.on_gpu:
-            self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
-            with self.torch.cuda.stream(self.stream):
-                self.dbuf[j].copy_(self.stage[j], non_blocking=True)
+        with self.lock:  # collectives are issued one at a time, in the same number on every rank
+            if self.on_gpu:
+                self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
+                with self.torch.cuda.stream(self.stream):
+                    self.dbuf[j].copy_(self.stage[j], non_blocking=True)
+                    self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+            else:
                 self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
-        else:
-            self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
-        self.done = j
-        self.i += 1
+            self.done = j
 
     def drain(self):
         for j in range(self.depth):

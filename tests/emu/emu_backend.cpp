@@ -154,7 +154,7 @@ int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint3
 }
 
 /* the emulator keeps the marshalled input in the FillInput's own storage */
-void* staging_host(const mtg_index*, int, size_t) { return nullptr; }
+void* staging_host(Workspace*, int, size_t) { return nullptr; }
 
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats,
                const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)

@@ -451,8 +451,9 @@ def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
 
 
 def test_concurrent_batches_on_two_indexes(mtg, full_idx, ctg_idx, golden_dir):
-    """two host threads, each filling batches on its own index at the same time (the traversal kernel's constants are per module, the
-    worker pool, the result cache and the staging blocks are shared or per index): every result equals the single-threaded one"""
+    """four host threads, two per index, filling batches at the same time: two batches of an index run side by side on its two
+    workspaces and streams, the traversal kernel's constants are per module (one traversal at a time), the worker pool and the result
+    cache are shared: every result equals the single-threaded one"""
     import threading
     _, g1, _, _ = full_idx
     _, g2, _, _ = ctg_idx
@@ -476,7 +477,7 @@ def test_concurrent_batches_on_two_indexes(mtg, full_idx, ctg_idx, golden_dir):
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
 
-    ts = [threading.Thread(target=work, args=a) for a in ((g1, gaps1, want1), (g2, gaps2, want2), (g1, gaps1, want1))]
+    ts = [threading.Thread(target=work, args=a) for a in ((g1, gaps1, want1), (g2, gaps2, want2), (g1, gaps1, want1), (g2, gaps2, want2))]
     for t in ts:
         t.start()
     for t in ts:
