@@ -743,7 +743,9 @@ namespace {
 struct EventSet { /* events of one device_run call */
     std::vector<hipEvent_t> ev;
     ~EventSet() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
-    hipError_t make(hipEvent_t& e) { hipError_t r = hipEventCreate(&e); if (r == hipSuccess) ev.push_back(e); return r; }
+    /* blocking: a caller waiting for the device sleeps instead of spinning, its CPU time belongs to the worker pool (and, in a container,
+     * to the CPU quota the pool lives on) */
+    hipError_t make(hipEvent_t& e) { hipError_t r = hipEventCreateWithFlags(&e, hipEventBlockingSync); if (r == hipSuccess) ev.push_back(e); return r; }
 };
 } // namespace
 
@@ -814,7 +816,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     tick("upload (async)");
 
     EventSet events;
-    hipEvent_t ev0, ev1, ev2, evp[MTG_POST_PARTS];
+    hipEvent_t ev0, ev1, ev2, evc, evp[MTG_POST_PARTS];
+    HIP_TRY(events.make(evc));
     HIP_TRY(events.make(ev0));
     HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
@@ -929,7 +932,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 HIP_TRY(hipMemcpyAsync(h_rec, d_rec.as<SlotRec>() + s0, (size_t)mq * sizeof(SlotRec), hipMemcpyDeviceToHost, copy_stream));
                 if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, tw * 8, hipMemcpyDeviceToHost, copy_stream));
                 if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, tc * 20, hipMemcpyDeviceToHost, copy_stream));
-                HIP_TRY(hipStreamSynchronize(copy_stream));
+                HIP_TRY(hipEventRecord(evc, copy_stream));
+                HIP_TRY(hipEventSynchronize(evc));
                 h_w[tw] = 0;
                 st.d2h_ms += now_ms() - t0;
                 t0 = now_ms();
