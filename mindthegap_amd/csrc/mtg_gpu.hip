@@ -57,6 +57,14 @@ static int ensure_device()
     return MTG_OK;
 }
 
+/* the HIP device is a per-thread setting: a call on an index runs on the index's device whatever thread makes it */
+static int use_device_of(const mtg_index* idx)
+{
+    if (int rc = ensure_device()) return rc;
+    if (idx) HIP_TRY(hipSetDevice(idx->device));
+    return MTG_OK;
+}
+
 /* ------------------------------------------------------------------------------------------------ kernels */
 __device__ __forceinline__ uint64_t d_splitmix64(uint64_t x)
 {
@@ -658,7 +666,7 @@ void index_release(mtg_index* idx)
 
 int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
 {
-    if (int rc = ensure_device()) return rc;
+    if (int rc = use_device_of(idx)) return rc;
     if (!idx || (n && !kmers)) { set_error("null argument"); return MTG_ERR_ARG; }
     if (n == 0) return MTG_OK;
     uint64_t* d_k = nullptr;
@@ -762,7 +770,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
     double tk = now_ms();
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
-    if (int rc = ensure_device()) return rc;
+    if (int rc = use_device_of(idx)) return rc;
     if (!in.ws) { set_error("device_run: the input has no workspace"); return MTG_ERR_ARG; }
     Workspace& ws = *in.ws;
     if (!ws.stream) {
@@ -874,12 +882,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 st.h2d_ms += now_ms() - t0;
             }
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16 * MTG_POST_PARTS, stream));
-            HIP_TRY(hipEventRecord(ev0, stream));
             /* The traversal reads index shape and configuration from the module's constants: one traversal at a time on the device, whatever
              * the index.  The lock is kept until this one has finished (below, after the host work that runs meanwhile); the traversal of
              * the next batch then overlaps this batch's post-processing. */
             static std::mutex traversal_mtx;
             std::unique_lock<std::mutex> traversal_lock(traversal_mtx);
+            HIP_TRY(hipEventRecord(ev0, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
@@ -1019,7 +1027,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
 int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches)
 {
     (void)idx;
-    if (int rc = ensure_device()) return rc;
+    if (int rc = use_device_of(idx)) return rc;
     const size_t np = pairs.size();
     matches.assign(np, 0);
     if (np == 0) return MTG_OK;
@@ -1043,7 +1051,7 @@ int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<u
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits,
              int device_ptrs, mtg_scan_stats* st)
 {
-    if (int rc = ensure_device()) return rc;
+    if (int rc = use_device_of(idx)) return rc;
     if (!idx || !idx->dev.bloom.bits) { set_error("the index has no Bloom filter (MTG_BLOOM_BITS=0)"); return MTG_ERR_ARG; }
     if (nseq == 0) return MTG_OK;
     DevBuf d_w, d_o, d_l, d_b, d_c;

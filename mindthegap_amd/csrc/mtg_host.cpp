@@ -25,6 +25,9 @@
 #include <thread>
 #include <unordered_map>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 using namespace mtg;
 
@@ -243,21 +246,77 @@ void FillInput::layout()
     }
     alloc_b(rw, nt);
 }
+/* the marshalling of a gap is a few dozen characters turned into 2-bit codes: eight at a time where the CPU has pext */
+namespace {
+inline uint64_t reverse_fields(uint64_t x) /* the 32 two-bit fields of x in reverse order */
+{
+    x = __builtin_bswap64(x);
+    x = ((x & 0xF0F0F0F0F0F0F0F0ull) >> 4) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return ((x & 0xCCCCCCCCCCCCCCCCull) >> 2) | ((x & 0x3333333333333333ull) << 2);
+}
+#if defined(__x86_64__)
+__attribute__((target("bmi2"))) inline uint64_t pack32_bmi2(const char* b) /* 32 characters -> 32 codes, character i at bits 2i */
+{
+    uint64_t c[4];
+    memcpy(c, b, 32);
+    const uint64_t M = 0x0606060606060606ull; /* nt_code: bits 1-2 of the ASCII code */
+    return _pext_u64(c[0], M) | (_pext_u64(c[1], M) << 16) | (_pext_u64(c[2], M) << 32) | (_pext_u64(c[3], M) << 48);
+}
+const bool have_bmi2 = __builtin_cpu_supports("bmi2") && !getenv("MTG_NO_VEC");
+#endif
+inline uint64_t pack32(const char* b)
+{
+#if defined(__x86_64__)
+    if (have_bmi2) return pack32_bmi2(b);
+#endif
+    uint64_t w = 0;
+    for (int i = 0; i < 32; i++) w |= (uint64_t)nt_code((unsigned char)b[i]) << (2 * i);
+    return w;
+}
+/* codes of s[0, n) into out[0, n / 32] (LSB first, a last partial word zero-padded) */
+inline void pack_lsb(const char* s, size_t n, uint64_t* out)
+{
+    size_t i = 0, w = 0;
+    for (; i + 32 <= n; i += 32) out[w++] = pack32(s + i);
+    if (i < n) {
+        char b[32] = {0};
+        memcpy(b, s + i, n - i);
+        const size_t r = n - i;
+        out[w] = pack32(b) & (r < 32 ? (1ull << (2 * r)) - 1 : ~0ull);
+    }
+}
+inline bool all_upper_acgt(const char* s, size_t n)
+{
+    /* 'A' 0x41, 'C' 0x43, 'G' 0x47, 'T' 0x54: a table of the 256 codes */
+    static const struct Tab { bool ok[256]; Tab() { memset(ok, 0, sizeof ok); ok['A'] = ok['C'] = ok['G'] = ok['T'] = true; } } tab;
+    bool ok = true;
+    for (size_t i = 0; i < n; i++) ok &= tab.ok[(unsigned char)s[i]];
+    return ok;
+}
+} // namespace
+
 void FillInput::set_common(size_t g, std::string_view source, std::string_view swf_target, int nb_mis)
 {
-    src[g] = encode_kmer(source.data(), k);
+    const uint64_t kfields = kmask(k);
+    char sb[32] = {0};
+    memcpy(sb, source.data(), (size_t)k); /* k <= 31 characters; the caller has checked that the source has them */
+    const uint64_t sp = pack32(sb) & kfields;
+    src[g] = reverse_fields(sp) >> (64 - 2 * k); /* encode_kmer: first character in the highest field */
     const size_t rl = swf_target.size(), w0 = roff[g];
-    for (size_t w = 0; w < (rl + 31) / 32 + 1; w++) rwords[w0 + w] = 0; /* the block is recycled, not zeroed */
-    for (size_t i = 0; i < rl; i++) rwords[w0 + (i >> 5)] |= (uint64_t)nt_code((unsigned char)swf_target[i]) << (2 * (i & 31));
-    r0[g] = rl >= (size_t)k ? encode_kmer(swf_target.data(), k) : 0;
+    const size_t nw = (rl + 31) / 32 + 1;
+    rwords[w0 + nw - 1] = 0; /* the block is recycled, not zeroed */
+    if (nw >= 2) rwords[w0 + nw - 2] = 0;
+    pack_lsb(swf_target.data(), rl, rwords.p + w0);
+    r0[g] = rl >= (size_t)k ? reverse_fields(rwords[w0] & kfields) >> (64 - 2 * k) : 0;
     /* the early stop is a literal strstr in upper-case contigs (IterativeExtensions [MEM]): a pattern with any other character never matches */
-    for (size_t i = 0; i < rl; i++) {
-        const char c = swf_target[i];
-        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { rlen[g] = 0xFFFFFFFFu; r0[g] = 0; break; }
-    }
+    if (!all_upper_acgt(swf_target.data(), rl)) { rlen[g] = 0xFFFFFFFFu; r0[g] = 0; }
     nbmis[g] = (uint8_t)nb_mis;
     bool ok = (int)source.size() == k;
-    for (unsigned char c : source) ok = ok && !nt_bad(c);
+    if (ok) { /* nt_bad: bit 3 of the ASCII code, in any of the k characters */
+        uint64_t c[4];
+        memcpy(c, sb, 32);
+        ok = ((c[0] | c[1] | c[2] | c[3]) & 0x0808080808080808ull) == 0;
+    }
     fast_ok[g] = ok ? 1 : 0;
 }
 void FillInput::set_target(size_t o, std::string_view seq)
@@ -363,11 +422,40 @@ struct DecodeLut {
         }
     }
 };
+#if defined(__x86_64__)
+/* 32 nucleotides per step: the 2-bit codes are spread to one per byte (pdep) and looked up 32 at a time (vpshufb).  Returns how many
+ * nucleotides it wrote (a multiple of 32); the caller finishes the rest. */
+__attribute__((target("avx2,bmi2"))) static uint32_t decode_slice_avx2(const uint64_t* words, uint32_t from, uint32_t L, bool rc, char* dst)
+{
+    const uint64_t SPREAD = 0x0303030303030303ull;
+    const __m256i fwd = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i cmp = _mm256_setr_epi8('T', 'G', 'A', 'C', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'T', 'G', 'A', 'C', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    uint32_t i = 0;
+    for (; i + 32 <= L; i += 32) {
+        const uint32_t j = from + i, sh = 2 * (j & 31);
+        uint64_t w = words[j >> 5] >> sh;
+        if (sh) w |= words[(j >> 5) + 1] << (64 - sh);
+        const __m256i codes = _mm256_setr_epi64x((long long)_pdep_u64(w, SPREAD), (long long)_pdep_u64(w >> 16, SPREAD), (long long)_pdep_u64(w >> 32, SPREAD),
+                                                 (long long)_pdep_u64(w >> 48, SPREAD));
+        if (!rc) _mm256_storeu_si256((__m256i*)(dst + i), _mm256_shuffle_epi8(fwd, codes));
+        else {
+            const __m256i c = _mm256_shuffle_epi8(_mm256_shuffle_epi8(cmp, codes), rev); /* complemented, each half reversed */
+            _mm256_storeu_si256((__m256i*)(dst + (L - 32 - i)), _mm256_permute2x128_si256(c, c, 1));
+        }
+    }
+    return i;
+}
+#endif
 static void decode_slice(const uint64_t* words, uint32_t from, uint32_t L, bool rc, char* dst)
 {
     static const DecodeLut lut;
     static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
     uint32_t i = 0;
+#if defined(__x86_64__)
+    static const bool vec = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("MTG_NO_VEC");
+    if (vec) i = decode_slice_avx2(words, from, L, rc, dst);
+#endif
     for (; i + 4 <= L; i += 4) {
         const uint32_t j = from + i, sh = 2 * (j & 31);
         uint64_t w = words[j >> 5] >> sh;
