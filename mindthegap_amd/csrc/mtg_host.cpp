@@ -695,8 +695,9 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     std::atomic<long> bad_gap{-1}, short_gap{-1};
     in.plan(n, nth, [&](size_t i, size_t& swf_len, size_t& n_targets) {
         size_t src_len = 0;
-        if (!src.sizes(i, src_len, swf_len, n_targets)) { bad_gap = (long)i; swf_len = n_targets = 0; }
+        if (!src.sizes(i, src_len, swf_len, n_targets)) { bad_gap = (long)i; src_len = swf_len = n_targets = 0; }
         else if ((int)src_len < k) short_gap = (long)i;
+        in.slen[i] = (uint32_t)src_len;
     });
     if (bad_gap >= 0) { set_error("gap %ld: null field", bad_gap.load()); return MTG_ERR_ARG; }
     if (short_gap >= 0) { set_error("gap %ld: source sequence shorter than k", short_gap.load()); return MTG_ERR_ARG; }
@@ -756,6 +757,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
                 const GapDev gd = batch[i];
                 if (gd.o.status != GAP_OK) { odd = true; continue; } /* re-run in a larger tier: comes back with a later chunk */
                 if (i / B != cur_blk) { if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed); nsol = 0; cur_blk = i / B; }
+                if (gd.p.fast == 0 && gd.p.nb_terminal > 0) src.need_targets(i);
                 genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
                 if (genw[i]) odd = true;
                 else if (recording) src.record_gap(i, rb, rf);
@@ -937,8 +939,22 @@ struct AbiSource : mtgi::BatchSource {
     mtg_results* R;
     AbiSource(const mtg_gap* g_, size_t n_, mtg_results* R_) : g(g_), n(n_), R(R_) {}
     size_t count() const override { return n; }
+    /* the strings of a batch are wherever the caller has them: the two passes ask for those of the gaps a few places ahead early */
+    void prefetch(size_t i) const
+    {
+        static const bool on = !getenv("MTG_NO_PREFETCH");
+        if (!on) return;
+        if (i + 16 < n) { const mtg_gap& b = g[i + 16]; __builtin_prefetch(b.target_seqs); __builtin_prefetch(b.target_names); }
+        if (i + 8 < n) {
+            const mtg_gap& b = g[i + 8];
+            __builtin_prefetch(b.source);
+            __builtin_prefetch(b.target);
+            if (b.n_targets > 0 && b.target_seqs && b.target_names) { __builtin_prefetch(b.target_seqs[0]); __builtin_prefetch(b.target_names[0]); }
+        }
+    }
     bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const override
     {
+        prefetch(i);
         const mtg_gap& a = g[i];
         if (!a.source || !a.target || (a.n_targets > 0 && (!a.target_seqs || !a.target_names))) return false;
         for (int t = 0; t < a.n_targets; t++) if (!a.target_seqs[t] || !a.target_names[t]) return false;
@@ -947,12 +963,16 @@ struct AbiSource : mtgi::BatchSource {
     }
     void input(size_t i, mtgi::FillInput& in, int nb_mis_allowed) const override
     {
+        prefetch(i);
         const mtg_gap& a = g[i];
-        in.set_common(i, std::string_view(a.source), std::string_view(a.target, in.rlen[i]), a.is_anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
-        for (int t = 0; t < a.n_targets; t++) in.set_target(in.toff[i] + (size_t)t, std::string_view(a.target_seqs[t]));
+        in.set_common(i, std::string_view(a.source, in.slen[i]), std::string_view(a.target, in.rlen[i]), a.is_anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
+        /* of a target only the first k characters matter, and whether it has them */
+        for (int t = 0; t < a.n_targets; t++) in.set_target(in.toff[i] + (size_t)t, std::string_view(a.target_seqs[t], strnlen(a.target_seqs[t], (size_t)in.k)));
     }
+    const mtgi::FillInput* in_ = nullptr;
     void marshal(const mtgi::FillInput& in, int nthreads) override
     {
+        in_ = &in;
         R->gaps.resize(n);
         R->res.resize(n);
         R->nfilled.resize(n);
@@ -962,19 +982,25 @@ struct AbiSource : mtgi::BatchSource {
             const mtg_gap& a = g[i];
             mtgi::GapWork& w = R->gaps[i];
             w.reset(); /* a recycled object still holds the previous batch */
-            w.source = a.source;
+            w.source = std::string_view(a.source, in.slen[i]);
             w.anchor_repeated = a.is_anchor_repeated != 0;
             w.reverse = a.reverse != 0;
-            mtgi::Target* T0 = R->targets.data() + in.toff[i];
-            for (int t = 0; t < a.n_targets; t++) {
-                mtgi::Target& T = T0[t];
-                T.seq = a.target_seqs[t];
-                T.name = a.target_names[t];
-                T.is_rc = a.target_is_rc ? a.target_is_rc[t] != 0 : false;
-            }
-            w.targets.p = T0;
-            w.targets.n = (uint32_t)std::max(a.n_targets, 0);
         }, 256);
+    }
+    /* the dictionary of a gap (names, strands) is only read on the multi-contig path: built there, for the gaps that take it */
+    void need_targets(size_t i) override
+    {
+        const mtg_gap& a = g[i];
+        mtgi::GapWork& w = R->gaps[i];
+        mtgi::Target* T0 = R->targets.data() + in_->toff[i];
+        for (int t = 0; t < a.n_targets; t++) {
+            mtgi::Target& T = T0[t];
+            T.seq = a.target_seqs[t];
+            T.name = a.target_names[t];
+            T.is_rc = a.target_is_rc ? a.target_is_rc[t] != 0 : false;
+        }
+        w.targets.p = T0;
+        w.targets.n = (uint32_t)std::max(a.n_targets, 0);
     }
     std::vector<mtgi::GapWork>& gaps() override { return R->gaps; }
     /* the C-ABI records of a finished part, written while the device works on the next one: such gaps have at most one solution, which

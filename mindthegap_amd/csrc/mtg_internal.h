@@ -366,10 +366,12 @@ struct FillInput {
      * every block; fill: offsets of every gap of a block in turn, then st(i) (which calls set_common). */
     enum { BLOCK = 512 };
     std::vector<uint64_t> blk_rw, blk_nt;
+    std::vector<uint32_t> slen; /* host only: length of every gap's source (pass 1 has looked at it; nobody needs to again) */
     void alloc_b(uint64_t rw, uint64_t nt);
     template <typename SizeFn> void plan(size_t n, int nthreads, SizeFn sz)
     {
         resize(n);
+        slen.resize(n);
         const size_t nb = (n + BLOCK - 1) / BLOCK;
         blk_rw.assign(nb + 1, 0);
         blk_nt.assign(nb + 1, 0);
@@ -552,6 +554,9 @@ struct BatchSource {
     /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
     virtual void marshal(const FillInput& in, int nthreads) = 0;
     virtual std::vector<GapWork>& gaps() = 0;
+    /* any thread, before gap i goes down the multi-contig path (the only one that looks at the dictionary): make gaps()[i].targets valid
+     * if marshal left that for later */
+    virtual void need_targets(size_t i) { (void)i; }
     /* Result records as the chunks come back: record_gap(i, ...) from any thread once gap i has its final solutions (speculative: the
      * caller may still find out that the chunk needs the multi-contig path or a re-run), then part_done(first, count, clean) once per
      * chunk that was a contiguous range of gaps. */

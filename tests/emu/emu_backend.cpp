@@ -166,70 +166,115 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     for (size_t t = 0; t < n_targets; t++) encode_target(in.traw.data() + t * TARGET_SLOT, idx->dev.k, tle[t], tbad[t]);
     const size_t n = in.src.size();
     batch.n = n;
-    batch.chunk_of.assign(n, 0);
-    batch.slot_of.assign(n, 0);
     batch.chunks.clear();
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
-    for (size_t g = 0; g < n; g++) {
-        GapOut o{};
-        for (int tier = 0; tier <= MTG_MAX_TIER; tier++) {
-            FillCfg cfg = make_cfg(idx->dev.k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
-            std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64, 0xCD), ilv(cfg.ilv_stride);
-            GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
-            std::vector<uint8_t> fp_table(FP_SLOTS * 64);
-            S.fp = fp_table.data();
-            S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
-            SwfPattern R;
-            R.words = in.rwords.data() + in.roff[g];
-            R.rlen = in.rlen[g];
-            R.r0 = in.r0[g];
-            stage_a_gap(idx->dev, cfg, S, in.src[g], R, o);
-            /* the device never clears the zero region between launches: every exit path has to hand it back clean */
-            for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, o.status); return MTG_ERR_OVERFLOW; }
-            st.index_lines += o.lines;
-            if (o.status != GAP_OK) { st.n_retried_gaps++; continue; }
-            PostTargets T;
-            T.le = tle.data() + in.toff[g];
-            T.bad = tbad.data() + in.toff[g];
-            T.n = in.tcnt[g];
-            T.nb_mis = in.nbmis[g];
-            T.fast_ok = in.fast_ok[g];
-            uint32_t hist[256] = {0};
-            PostOut po{};
-            std::vector<uint64_t> tile(POST_TILE + 2);
-            post_gap(idx->dev, cfg, S, o, T, hist, tile.data(), po);
-            uint32_t nw, nc;
-            copy_plan(o, po, in.want_all_contigs, nw, nc);
+    batch.part = ~(size_t)0;
+    batch.chunk_of.clear();
+    batch.slot_of.clear();
+    /* Same shape as the device build: a launch covers the gaps still to do at a scratch tier; its results come back as parts of consecutive
+     * slots, each a chunk with dense word / metadata arrays in which the gaps reserved their room in no particular order (here: last slot
+     * first); the first launch maps gap i to chunk i / part, slot i % part, later ones through chunk_of / slot_of. */
+    const uint32_t psize = getenv("MTG_EMU_PART") ? (uint32_t)std::max(64, atoi(getenv("MTG_EMU_PART")) / 64 * 64) : 192u;
+    struct SlotData { GapOut o; PostOut po; uint32_t nw = 0, nc = 0; std::vector<uint64_t> words; std::vector<uint32_t> meta; std::vector<uint32_t> paths; bool general = false; };
+    std::vector<uint32_t> todo;
+    size_t n_todo = n;
+    for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
+        const bool identity = todo.empty();
+        FillCfg cfg = make_cfg(idx->dev.k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
+        std::vector<uint32_t> retry;
+        const uint32_t m = (uint32_t)n_todo;
+        if (identity) batch.part = psize;
+        else if (batch.chunk_of.empty()) {
+            batch.chunk_of.assign(n, 0);
+            batch.slot_of.resize(n);
+            for (size_t i = 0; i < n; i++) { batch.chunk_of[i] = batch.part == ~(size_t)0 ? 0u : (uint32_t)(i / batch.part); batch.slot_of[i] = batch.part == ~(size_t)0 ? (uint32_t)i : (uint32_t)(i % batch.part); }
+        }
+        for (uint32_t s0 = 0; s0 < m; s0 += psize) {
+            const uint32_t s1 = std::min(m, s0 + psize), mq = s1 - s0;
+            std::vector<SlotData> sd(mq);
+            for (uint32_t s = 0; s < mq; s++) {
+                const size_t g = identity ? (size_t)(s0 + s) : (size_t)todo[s0 + s];
+                SlotData& d = sd[s];
+                std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64, 0xCD), ilv(cfg.ilv_stride);
+                GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
+                std::vector<uint8_t> fp_table(FP_SLOTS * 64);
+                S.fp = fp_table.data();
+                S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
+                SwfPattern R;
+                R.words = in.rwords.data() + in.roff[g];
+                R.rlen = in.rlen[g];
+                R.r0 = in.r0[g];
+                stage_a_gap(idx->dev, cfg, S, in.src[g], R, d.o);
+                /* the device never clears the zero region between launches: every exit path has to hand it back clean */
+                for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, d.o.status); return MTG_ERR_OVERFLOW; }
+                st.index_lines += d.o.lines;
+                if (d.o.status != GAP_OK) { st.n_retried_gaps++; retry.push_back((uint32_t)g); continue; }
+                PostTargets T;
+                T.le = tle.data() + in.toff[g];
+                T.bad = tbad.data() + in.toff[g];
+                T.n = in.tcnt[g];
+                T.nb_mis = in.nbmis[g];
+                T.fast_ok = in.fast_ok[g];
+                uint32_t hist[256] = {0};
+                std::vector<uint64_t> tile(POST_TILE + 2);
+                post_gap(idx->dev, cfg, S, d.o, T, hist, tile.data(), d.po);
+                copy_plan(d.o, d.po, in.want_all_contigs, d.nw, d.nc);
+                d.words.assign(s_words(cfg, S), s_words(cfg, S) + d.nw);
+                d.meta.resize(5 * (size_t)d.nc);
+                for (uint32_t i = 0; i < d.nc; i++) {
+                    d.meta[i] = s_clen(cfg, S)[i];
+                    d.meta[d.nc + i] = s_cstart(cfg, S)[i];
+                    d.meta[2 * d.nc + i] = s_tpos(cfg, S)[i];
+                    d.meta[3 * d.nc + i] = s_terr(cfg, S)[i];
+                    d.meta[4 * d.nc + i] = s_ttgt(cfg, S)[i];
+                }
+                if (!getenv("MTG_HOST_PATHS") && d.po.fast == 0 && d.po.nb_terminal > 0) { /* stand-in for k_paths */
+                    PathsWork pw;
+                    d.paths.assign(PATHS_WORDS, 0);
+                    paths_gap(cfg, S, d.o, idx->dev.k, pw, d.paths.data());
+                    d.general = true;
+                }
+                st.contig_nt += d.o.total_nt;
+            }
+            uint64_t tw = 0, tc = 0;
+            for (const SlotData& d : sd) { tw += d.nw; tc += d.nc; }
             batch.chunks.emplace_back(new HostChunk());
             HostChunk& hc = *batch.chunks.back();
+            const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
             SlotRec* rec = nullptr;
             uint64_t* hw = nullptr;
             uint32_t* hm = nullptr;
-            hc.carve(nullptr, 1, nw, nc, rec, hw, hm);
-            rec->o = o; rec->p = po; rec->nw = nw; rec->nc = nc; rec->pad_ = 0; rec->wbase = 0; rec->cbase = 0;
-            for (uint32_t i = 0; i < nw; i++) hw[i] = s_words(cfg, S)[i];
-            hw[nw] = 0;
-            for (uint32_t i = 0; i < nc; i++) {
-                hm[i] = s_clen(cfg, S)[i];
-                hm[nc + i] = s_cstart(cfg, S)[i];
-                hm[2 * nc + i] = s_tpos(cfg, S)[i];
-                hm[3 * nc + i] = s_terr(cfg, S)[i];
-                hm[4 * nc + i] = s_ttgt(cfg, S)[i];
+            hc.carve(nullptr, mq, tw, tc, rec, hw, hm);
+            uint64_t wb = 0, cb = 0;
+            for (uint32_t s = mq; s-- > 0;) { /* room in the dense arrays in reverse slot order */
+                const SlotData& d = sd[s];
+                SlotRec& r = rec[s];
+                r.o = d.o; r.p = d.po; r.nw = d.nw; r.nc = d.nc; r.pad_ = 0; r.wbase = (decltype(r.wbase))wb; r.cbase = (decltype(r.cbase))cb;
+                if (d.o.status != GAP_OK) { r.nw = r.nc = 0; continue; }
+                for (uint32_t i = 0; i < d.nw; i++) hw[wb + i] = d.words[i];
+                for (size_t i = 0; i < d.meta.size(); i++) hm[5 * cb + i] = d.meta[i];
+                wb += d.nw;
+                cb += d.nc;
             }
-            if (!getenv("MTG_HOST_PATHS") && po.fast == 0 && po.nb_terminal > 0) { /* stand-in for k_paths */
-                PathsWork pw;
-                hc.paths.assign(PATHS_WORDS, 0);
-                paths_gap(cfg, S, o, idx->dev.k, pw, hc.paths.data());
-                hc.path_of.assign(1, 0);
+            hw[tw] = 0;
+            uint32_t ngen = 0;
+            for (const SlotData& d : sd) ngen += d.general;
+            if (ngen) {
+                hc.paths.resize((size_t)ngen * PATHS_WORDS);
+                hc.path_of.assign(mq, -1);
+                uint32_t r2 = 0;
+                for (uint32_t s = 0; s < mq; s++)
+                    if (sd[s].general) { std::copy(sd[s].paths.begin(), sd[s].paths.end(), hc.paths.begin() + (size_t)r2 * PATHS_WORDS); hc.path_of[s] = (int32_t)r2++; }
             }
-            batch.chunk_of[g] = (uint32_t)batch.chunks.size() - 1;
-            batch.slot_of[g] = 0;
-            st.contig_nt += o.total_nt;
-            if (on_ready) { const uint32_t gid = (uint32_t)g; (*on_ready)(batch.chunks.size() - 1, &gid, 0, 1); } /* one chunk per gap here */
-            break;
+            if (!identity)
+                for (uint32_t s = 0; s < mq; s++)
+                    if (sd[s].o.status == GAP_OK) { batch.chunk_of[todo[s0 + s]] = chunk_id; batch.slot_of[todo[s0 + s]] = s; }
+            if (on_ready) (*on_ready)(chunk_id, identity ? nullptr : todo.data() + s0, identity ? (size_t)s0 : 0, mq);
         }
-        if (o.status != GAP_OK) { set_error("gap %zu exceeded the largest traversal scratch tier", g); return MTG_ERR_OVERFLOW; }
+        todo.swap(retry);
+        n_todo = todo.size();
     }
+    if (n_todo) { set_error("%zu gap(s) exceeded the largest traversal scratch tier", n_todo); return MTG_ERR_OVERFLOW; }
     if (stats) *stats = st;
     return MTG_OK;
 }
