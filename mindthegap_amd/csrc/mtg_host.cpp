@@ -726,7 +726,9 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
         /* one pass: a block of gaps adds up the bytes its sequences need, learns where the blocks before it end (they were handed out
          * in order, and each publishes its end as soon as it knows its own size) and writes its gaps one after the other; the chunk
          * never needs more than 32 bytes per dense word + one per gap */
-        const size_t arena_cap = (size_t)batch.chunks[chunk]->n_words * 32 + count + 64;
+        const HostChunk& hc = *batch.chunks[chunk];
+        static const bool prefetch_words = !getenv("MTG_NO_PREFETCH");
+        const size_t arena_cap = (size_t)hc.n_words * 32 + count + 64;
         bool external = false;
         if (arena.ext_ok) {
             /* the caller's buffer takes the chunk if it continues the gap order and fits */
@@ -742,8 +744,9 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
         const bool recording = !ids;
         parallel_for(nbp, nth, [&](size_t b) {
             uint64_t need = 0, rb = 0, rf = 0;
+            /* slot j of the chunk holds gap gap_of(j) */
             for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
-                const SlotRec& r = batch.rec(gap_of(j));
+                const SlotRec& r = hc.recs[j];
                 need += (r.o.status == GAP_OK && r.p.fast == 1) ? (uint64_t)(r.p.pos - (uint32_t)k) + 1 : 0;
             }
             int64_t begin;
@@ -754,8 +757,14 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
             bool odd = false;
             for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
                 const size_t i = gap_of(j);
-                const GapDev gd = batch[i];
-                if (gd.o.status != GAP_OK) { odd = true; continue; } /* re-run in a larger tier: comes back with a later chunk */
+                if (prefetch_words && j + 8 < count) {
+                    /* the gaps reserved their room in the dense words in no particular order, and the copy from the device left them in
+                     * memory, not in a cache: ask for the words of a gap a few places ahead */
+                    const char* pw = (const char*)(hc.words + hc.recs[j + 8].wbase);
+                    __builtin_prefetch(pw); __builtin_prefetch(pw + 64); __builtin_prefetch(pw + 128);
+                }
+                if (hc.recs[j].o.status != GAP_OK) { odd = true; continue; } /* re-run in a larger tier: comes back with a later chunk */
+                const GapDev gd = DevBatch::view(hc, j);
                 if (i / B != cur_blk) { if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed); nsol = 0; cur_blk = i / B; }
                 if (gd.p.fast == 0 && gd.p.nb_terminal > 0) src.need_targets(i);
                 genw[i] = process_gap(gd, gaps[i], k, arena_base + off);

@@ -311,7 +311,11 @@ struct DevBatch {
     GapDev operator[](size_t i) const
     {
         const HostChunk& c = chunk_of.empty() ? *chunks[i / part] : *chunks[chunk_of[i]];
-        const size_t slot = chunk_of.empty() ? i % part : slot_of[i];
+        return view(c, chunk_of.empty() ? i % part : slot_of[i]);
+    }
+    /* view of the gap in slot `slot` of chunk c */
+    static GapDev view(const HostChunk& c, size_t slot)
+    {
         const mtg::SlotRec& r = c.recs[slot];
         GapDev g;
         if (!c.path_of.empty() && c.path_of[slot] >= 0) g.paths = c.paths.data() + (size_t)c.path_of[slot] * mtg::PATHS_WORDS;
@@ -484,6 +488,11 @@ struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
     float avg = 0, median = 0;
     int qual = 0, count = 0, rank = 0;
     size_t ab_off = 0, ab_n = 0; /* slice of the batched abundance query */
+    void reset() /* as freshly constructed, keeping the string's capacity */
+    {
+        seq.own.clear(); seq.p = nullptr; seq.n = 0;
+        nb_errors = 0; target = -1; avg = median = 0; qual = count = rank = 0; ab_off = ab_n = 0;
+    }
 };
 /* the solutions of one gap: nearly always zero or one, kept inline so that the common path never touches the heap */
 class SolVec {
@@ -500,7 +509,7 @@ public:
     Solution* begin() { return more_.empty() ? &first_ : more_.data(); }
     Solution* end() { return begin() + size(); }
     const Solution& operator[](size_t i) const { return begin()[i]; }
-    void clear() { if (has_first_) { first_ = Solution(); has_first_ = false; } more_.clear(); }
+    void clear() { if (has_first_) { first_.reset(); has_first_ = false; } more_.clear(); }
     void push_back(Solution&& s)
     {
         if (!has_first_ && more_.empty()) { first_ = std::move(s); has_first_ = true; return; }

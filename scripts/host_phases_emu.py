@@ -15,7 +15,7 @@ mtg = emu_lib.product_on_emulator()
 from mindthegap_amd.synth import SynthSet  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-S = SynthSet(nseq=400, n_sites=400, seq_len=2100, seed=1, ins_min=40, ins_max=60, k=31)
+S = SynthSet(nseq=400, n_sites=400, seq_len=2100, seed=1, ins_min=int(os.environ.get("INS_MIN", "40")), ins_max=int(os.environ.get("INS_MAX", "60")), k=31)
 seqs = [S.ascii(j) for j in range(S.nseq)]
 from tests import oracle_lib  # noqa: E402  (k-mer extraction only)
 o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
