@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny", "human-het"])
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the workload's)")
     ap.add_argument("--nseq", type=int, default=0)

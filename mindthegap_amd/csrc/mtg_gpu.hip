@@ -887,9 +887,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
              * the next batch then overlaps this batch's post-processing. */
             static std::mutex traversal_mtx;
             std::unique_lock<std::mutex> traversal_lock(traversal_mtx);
-            HIP_TRY(hipEventRecord(ev0, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. ev1 = the traversal kernel alone */
             hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
                                d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
             HIP_TRY(hipEventRecord(ev1, stream));
