@@ -189,15 +189,18 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             batch.slot_of.resize(n);
             for (size_t i = 0; i < n; i++) { batch.chunk_of[i] = batch.part == ~(size_t)0 ? 0u : (uint32_t)(i / batch.part); batch.slot_of[i] = batch.part == ~(size_t)0 ? (uint32_t)i : (uint32_t)(i % batch.part); }
         }
+        /* one scratch block for the launch, like a lane's on the device: the zero region is cleared once and must come back clean from
+         * every gap, the rest holds whatever the previous gap left (poisoned here) */
+        std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64), ilv(cfg.ilv_stride), fp_table(FP_SLOTS * 64);
         for (uint32_t s0 = 0; s0 < m; s0 += psize) {
             const uint32_t s1 = std::min(m, s0 + psize), mq = s1 - s0;
             std::vector<SlotData> sd(mq);
             for (uint32_t s = 0; s < mq; s++) {
                 const size_t g = identity ? (size_t)(s0 + s) : (size_t)todo[s0 + s];
                 SlotData& d = sd[s];
-                std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64, 0xCD), ilv(cfg.ilv_stride);
+                memset(raw.data(), 0xCD, raw.size());
+                memset(fp_table.data(), 0, fp_table.size());
                 GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
-                std::vector<uint8_t> fp_table(FP_SLOTS * 64);
                 S.fp = fp_table.data();
                 S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
                 SwfPattern R;

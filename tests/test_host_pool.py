@@ -11,3 +11,16 @@ def test_pool_patterns_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_concurrent_batches_on_one_index_under_thread_sanitizer(tmp_path):
+    """three threads x six batches on one (emulated) index: workspace hand-out, shared pool, result cache and the per-batch host state are
+    free of data races, and every batch equals the single-threaded one"""
+    exe = str(tmp_path / "concurrent_batches")
+    csrc = os.path.join(ROOT, "mindthegap_amd", "csrc")
+    srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("concurrent_batches.cpp", "emu_backend.cpp")] + [os.path.join(csrc, f) for f in ("mtg_host.cpp", "mtg_cli.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", exe] + srcs + ["-lz"])
+    env = dict(os.environ, MTG_POOL_THREADS="4", MTG_EMU_PART="256")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
