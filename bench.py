@@ -176,6 +176,7 @@ def main():
 
         def worker():
             try:
+                torch.cuda.set_device(local_rank)  # the current device is a per-thread setting
                 while True:
                     with acc_lock:
                         if next(todo, None) is None:

@@ -824,8 +824,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     tick("upload (async)");
 
     EventSet events;
-    hipEvent_t ev0, ev1, ev2, evc, evp[MTG_POST_PARTS];
-    HIP_TRY(events.make(evc));
+    hipEvent_t ev0, ev1, ev2, evp[MTG_POST_PARTS], evcp[MTG_POST_PARTS];
+    for (int q = 0; q < MTG_POST_PARTS; q++) HIP_TRY(events.make(evcp[q]));
     HIP_TRY(events.make(ev0));
     HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
@@ -922,7 +922,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 batch.slot_of.resize(n);
                 for (size_t i = 0; i < n; i++) { batch.chunk_of[i] = batch.part == ~(size_t)0 ? 0u : (uint32_t)(i / batch.part); batch.slot_of[i] = batch.part == ~(size_t)0 ? (uint32_t)i : (uint32_t)(i % batch.part); }
             }
-            for (uint32_t q = 0; q < nparts; q++) {
+            /* The copy back of part q is queued as soon as the part is done and runs while the host finishes part q - 1. */
+            struct PartState { uint32_t s0 = 0, mq = 0, chunk_id = 0; uint64_t tw = 0; SlotRec* h_rec = nullptr; uint64_t* h_w = nullptr; } ps[MTG_POST_PARTS];
+            for (uint32_t qq = 0; qq <= nparts; qq++) {
+              if (qq < nparts) {
+                const uint32_t q = qq;
                 const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize), mq = s1 - s0;
                 HIP_TRY(hipEventSynchronize(evp[q]));
                 if (q == 0) tick("first part ready");
@@ -940,8 +944,19 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 HIP_TRY(hipMemcpyAsync(h_rec, d_rec.as<SlotRec>() + s0, (size_t)mq * sizeof(SlotRec), hipMemcpyDeviceToHost, copy_stream));
                 if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, tw * 8, hipMemcpyDeviceToHost, copy_stream));
                 if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, tc * 20, hipMemcpyDeviceToHost, copy_stream));
-                HIP_TRY(hipEventRecord(evc, copy_stream));
-                HIP_TRY(hipEventSynchronize(evc));
+                HIP_TRY(hipEventRecord(evcp[q], copy_stream));
+                ps[q].s0 = s0; ps[q].mq = mq; ps[q].chunk_id = chunk_id; ps[q].tw = tw; ps[q].h_rec = h_rec; ps[q].h_w = h_w;
+                st.d2h_ms += now_ms() - t0;
+              }
+              if (qq > 0) {
+                const uint32_t q = qq - 1;
+                const uint32_t s0 = ps[q].s0, mq = ps[q].mq, chunk_id = ps[q].chunk_id;
+                const uint64_t tw = ps[q].tw;
+                SlotRec* const h_rec = ps[q].h_rec;
+                uint64_t* const h_w = ps[q].h_w;
+                HostChunk& hc = *batch.chunks[chunk_id];
+                t0 = now_ms();
+                HIP_TRY(hipEventSynchronize(evcp[q]));
                 h_w[tw] = 0;
                 st.d2h_ms += now_ms() - t0;
                 t0 = now_ms();
@@ -990,6 +1005,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 st.host_ms += now_ms() - t0;
                 /* hand the part to the caller: the gaps of its slots (those to be re-run excepted, the caller sees their status) */
                 if (on_ready) (*on_ready)(chunk_id, host_ids ? host_ids + s0 : nullptr, host_ids ? 0 : (size_t)s0, mq);
+              }
             }
             (void)first_chunk;
             HIP_TRY(hipEventSynchronize(ev2));

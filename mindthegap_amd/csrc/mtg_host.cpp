@@ -766,6 +766,7 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
                 if (hc.recs[j].o.status != GAP_OK) { odd = true; continue; } /* re-run in a larger tier: comes back with a later chunk */
                 const GapDev gd = DevBatch::view(hc, j);
                 if (i / B != cur_blk) { if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed); nsol = 0; cur_blk = i / B; }
+                src.init_gap(i);
                 if (gd.p.fast == 0 && gd.p.nb_terminal > 0) src.need_targets(i);
                 genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
                 if (genw[i]) odd = true;
@@ -987,14 +988,16 @@ struct AbiSource : mtgi::BatchSource {
         R->nfilled.resize(n);
         if (R->filled_flat.size() < n) R->filled_flat.resize(n);
         R->targets.resize(in.traw.size() / mtg::TARGET_SLOT);
-        mtgi::parallel_for(n, nthreads, [&](size_t i) {
-            const mtg_gap& a = g[i];
-            mtgi::GapWork& w = R->gaps[i];
-            w.reset(); /* a recycled object still holds the previous batch */
-            w.source = std::string_view(a.source, in.slen[i]);
-            w.anchor_repeated = a.is_anchor_repeated != 0;
-            w.reverse = a.reverse != 0;
-        }, 256);
+        (void)nthreads; /* the per-gap part happens in init_gap, when the gap's results are there: one visit of the record, not two */
+    }
+    void init_gap(size_t i) override
+    {
+        const mtg_gap& a = g[i];
+        mtgi::GapWork& w = R->gaps[i];
+        w.reset(); /* a recycled object still holds the previous batch */
+        w.source = std::string_view(a.source, in_->slen[i]);
+        w.anchor_repeated = a.is_anchor_repeated != 0;
+        w.reverse = a.reverse != 0;
     }
     /* the dictionary of a gap (names, strands) is only read on the multi-contig path: built there, for the gaps that take it */
     void need_targets(size_t i) override

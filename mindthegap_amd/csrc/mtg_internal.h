@@ -563,6 +563,8 @@ struct BatchSource {
     /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
     virtual void marshal(const FillInput& in, int nthreads) = 0;
     virtual std::vector<GapWork>& gaps() = 0;
+    /* any thread, once per gap, right before its results are looked at: gaps()[i] ready (source, flags) if marshal left that for later */
+    virtual void init_gap(size_t i) { (void)i; }
     /* any thread, before gap i goes down the multi-contig path (the only one that looks at the dictionary): make gaps()[i].targets valid
      * if marshal left that for later */
     virtual void need_targets(size_t i) { (void)i; }
