@@ -34,8 +34,8 @@ def parse():
     ap.add_argument("--cpu-sites", type=int, default=30000, help="sites of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-index-seqs", type=int, default=30000, help="donor sequences in the CPU baseline's index")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads per rank for the per-gap passes (default: the library's pool = CPU budget of the process, shared between the ranks)")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MTG_BENCH_IN_FLIGHT", "2")),
-                    help="steps in flight: caller threads issuing batches on the one index (the library runs two batches side by side)")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MTG_BENCH_IN_FLIGHT", "3")),
+                    help="steps in flight: caller threads issuing batches on the one index (the library runs up to three batches of an index side by side)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the random-64B-line ceiling micro-benchmark")
     return ap.parse_args()
 
@@ -163,7 +163,7 @@ def main():
         step()  # untimed: sizes the gather buffers (the largest payload of any rank, plus head room)
         cap = torch.tensor([idx.last_seq_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        pg = PipelinedGather(int(cap.item()) * 5 // 4 + (1 << 20), dst=0, device=cdev, depth=2 * max(a.in_flight, 1))
+        pg = PipelinedGather(int(cap.item()) * 5 // 4 + (1 << 20), dst=0, device=cdev, depth=max(a.in_flight, 1) + 1)
     import threading
     acc = dict(kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, post_kernel_ms=0.0, total_ms=0.0)
     acc_lock = threading.Lock()

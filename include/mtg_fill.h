@@ -146,7 +146,7 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
 int mtg_fill_batch_serial(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t cap, uint64_t* seq_bytes,
                           mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
-/* Every pointer obtained from r dies here.  The library keeps the storage of up to four freed result sets (a few hundred bytes per
+/* Every pointer obtained from r dies here.  The library keeps the storage of up to six freed result sets (a few hundred bytes per
  * gap plus the sequences) and hands it to the next batches, which then pay no allocation, page fault or memset. */
 void mtg_results_free(mtg_results* r);
 /* bulk view of a result set (for gathers / checksums): n_filled[i] = number of sequences of gap i (may be NULL);

@@ -899,7 +899,7 @@ struct mtg_contigs {
 };
 
 /* Result objects are recycled: a freed one keeps its storage (a few hundred bytes per gap plus the sequence arena) for the next batch,
- * which then pays neither page faults nor allocator traffic.  At most four are kept (two batches in flight, each with
+ * which then pays neither page faults nor allocator traffic.  At most six are kept (three batches in flight, each with
  * the previous result still in its caller's hands). */
 namespace {
 std::mutex g_results_mtx;
@@ -916,7 +916,7 @@ void results_release(mtg_results* r)
 {
     {
         std::lock_guard<std::mutex> lk(g_results_mtx);
-        if (g_results_cache.size() < 4) { g_results_cache.push_back(r); return; }
+        if (g_results_cache.size() < 6) { g_results_cache.push_back(r); return; }
     }
     delete r;
 }

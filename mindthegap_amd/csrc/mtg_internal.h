@@ -40,9 +40,9 @@ struct Workspace {
 
 struct mtg_index {
     mtg::Index dev{};          /* tables live in device memory */
-    /* two batches on one index run side by side (callers on several threads, like the reference's Dispatcher): each owns a workspace
+    /* a few batches on one index run side by side (callers on several threads, like the reference's Dispatcher): each owns a workspace
      * and its streams, so the traversal of one overlaps the post-processing and the host passes of the other */
-    enum { NWS = 2 };
+    enum { NWS = 3 };
     mutable mtgi::Workspace ws[NWS];
     int device = 0;
     mtg_index_info info{};
