@@ -43,6 +43,34 @@ def main(out_path):
     piped = pg.last()
     if rank == 0:
         assert [p.tobytes().replace(b"\0", b"\n") for p in piped] == [p.tobytes() for p in parts]
+    # bench.py's default: several steps in flight, issued from caller threads that share one PipelinedGather (acquire / submit(j))
+    import threading
+    pg2 = PipelinedGather(int(cap.item()) * 2 + 64, dst=0, depth=3)
+    todo, lock, errors = iter(range(6)), threading.Lock(), []
+
+    def worker():
+        try:
+            while True:
+                with lock:
+                    if next(todo, None) is None:
+                        return
+                j, buf = pg2.acquire()
+                h2, _, nb = idx.fill_prepared_serial(prepared, buf)
+                idx.free_results(h2)
+                pg2.submit(nb, j)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    pg2.drain()
+    piped2 = pg2.last()
+    if rank == 0:  # every step carries the same payload, so whichever step came last must equal the blocking gather
+        assert [p.tobytes().replace(b"\0", b"\n") for p in piped2] == [p.tobytes() for p in parts]
         with open(out_path, "wb") as f:
             for p in parts:
                 f.write(p.tobytes())
