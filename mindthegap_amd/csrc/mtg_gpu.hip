@@ -233,26 +233,29 @@ __global__ void k_query(Index ix, const uint64_t* __restrict__ kmers, size_t n, 
 /* Index and configuration of the traversal kernel live in constant memory: its code takes them by reference all over (Worker, the
  * bubble routines), and a by-value kernel argument whose address is taken is copied to private memory, which turned every field
  * access into a per-lane scratch load; a reference to a __constant__ object stays a scalar load. */
-__constant__ Index c_ix;
-__constant__ FillCfg c_cfg;
+enum { TRAVERSAL_SETS = mtg_index::NWS }; /* one set of constants per workspace number: that many traversals share the device */
+__constant__ Index c_ix[TRAVERSAL_SETS];
+__constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 
 /* one gap per lane, one wave per workgroup (waves retire independently) */
 __global__ void __launch_bounds__(64) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                                GapOut* out, uint32_t n)
+                                                GapOut* out, uint32_t n, uint32_t cset)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
+    const Index& ix = c_ix[cset]; /* cset is a kernel argument: still scalar loads */
+    const FillCfg& cfg = c_cfg[cset];
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
-    GapScratch S = carve(c_cfg, zero, raw, ilv, slot);
+    GapScratch S = carve(cfg, zero, raw, ilv, slot);
     S.snp_fast = 1;
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];
     R.r0 = r0[g];
     GapOut o;
-    stage_a_gap(c_ix, c_cfg, S, src[g], R, o);
+    stage_a_gap(ix, cfg, S, src[g], R, o);
     out[slot] = o;
 }
 
@@ -882,16 +885,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 st.h2d_ms += now_ms() - t0;
             }
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16 * MTG_POST_PARTS, stream));
-            /* The traversal reads index shape and configuration from the module's constants: one traversal at a time on the device, whatever
-             * the index.  The lock is kept until this one has finished (below, after the host work that runs meanwhile); the traversal of
-             * the next batch then overlaps this batch's post-processing. */
-            static std::mutex traversal_mtx;
-            std::unique_lock<std::mutex> traversal_lock(traversal_mtx);
-            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), 0, hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), 0, hipMemcpyHostToDevice, stream));
+            /* The traversal reads index shape and configuration from the module's constants, of which there is one set per workspace
+             * number: the batches of an index never share a set, batches of different indexes may, so a set is locked until the traversal
+             * that reads it has finished (below, after the host work that runs meanwhile). */
+            static std::mutex traversal_mtx[TRAVERSAL_SETS];
+            const uint32_t cset = (uint32_t)(&ws - idx->ws);
+            std::unique_lock<std::mutex> traversal_lock(traversal_mtx[cset]);
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. ev1 = the traversal kernel alone */
             hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                               d_rlen, d_r0, ids, d_out.as<GapOut>(), m);
+                               d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset);
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
             tick("host prep+launch");

@@ -452,7 +452,7 @@ def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
 
 def test_concurrent_batches_on_two_indexes(mtg, full_idx, ctg_idx, golden_dir):
     """four host threads, two per index, filling batches at the same time: two batches of an index run side by side on two of its
-    workspaces and streams, the traversal kernel's constants are per module (one traversal at a time), the worker pool and the result
+    workspaces and streams, the traversal kernel's constants are per module (one set per workspace number, locked while a traversal reads it), the worker pool and the result
     cache are shared: every result equals the single-threaded one"""
     import threading
     _, g1, _, _ = full_idx
