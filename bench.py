@@ -211,7 +211,7 @@ def main():
         pg.drain()  # the gathers still in flight belong to the timed steps
     barrier()
     elapsed = time.perf_counter() - t0
-    n_filled, seqs, _ = step(want_seqs=True, final=True)  # untimed pass whose sequences are verified below
+    n_filled, seqs, st_alone = step(want_seqs=True, final=True)  # untimed pass whose sequences are verified below (one batch on the device)
     if world > 1:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -281,9 +281,13 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes_per_launch, "probes_per_contig_nt": probes_per_nt,
             "bucket_reads_per_launch": lines / max(launches, 1), "bucket_bytes": line_bytes,
             "bucket_reads_per_s": lines / max(kernel_ms, 1e-9) * 1e3,
+            "avg_kernel_ms_one_batch_in_flight": st_alone["kernel_ms"] / max(st_alone["n_launches"], 1),
+            "frac_one_batch_in_flight": (64.0 * probes_per_nt * st_alone["contig_nt"] / max(st_alone["kernel_ms"], 1e-9) * 1e3 / 1e9) / 8000.0,
             "note": "achieved follows SURVEY 8d (64 B per membership probe of the reference algorithm); the ADJ layout answers the ~8 probes of a node, and "
                     "the lookahead up to 15 nodes, with one 32-byte bucket read, so frac exceeds 1 by construction. The kernel is bound by dependent random "
-                    "reads and the per-step VALU work, not by HBM bandwidth: see traffic (PMC) and frac_of_random_read_ceiling."}
+                    "reads and the per-step VALU work, not by HBM bandwidth: see traffic (PMC) and frac_of_random_read_ceiling. With several steps in flight the "
+                    "traversal of one batch shares the device with the kernels of the others, so its launches take longer than the kernel alone "
+                    "(*_one_batch_in_flight: the untimed verification pass) while the whole job is faster."}
     # second kernel of the step: one abundance look-up (64 algorithmic bytes) per k-mer of source + fill
     lookups = float(idx.last_seq_bytes)  # sum over the filled sites of (insert length + 1) = k-mers of source + fill
     post_s = post_ms / max(launches, 1) * 1e-3
