@@ -1,0 +1,67 @@
+/* TEST-ONLY: unit checks of the vectorised host helpers of mtg_host.cpp (file-local there, so the source is included here) against
+ * plain per-character code: decode_slice (pdep + vpshufb) for every alignment, length and direction, and FillInput::set_common
+ * (pext packing, k-mer by bit reversal, validity tests) against encode_kmer / per-character loops.  Links with emu_backend.cpp.  Prints OK. */
+#include "../../mindthegap_amd/csrc/mtg_host.cpp"
+#include <random>
+
+int main()
+{
+    std::mt19937_64 rng(11);
+    static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
+    /* decode_slice */
+    std::vector<uint64_t> words(40);
+    for (int round = 0; round < 200; round++) {
+        for (auto& w : words) w = rng();
+        for (uint32_t from = 0; from < 70; from += (round & 1) + 1)
+            for (uint32_t L : {0u, 1u, 3u, 4u, 31u, 32u, 33u, 63u, 64u, 65u, 100u, 517u, 1000u, (uint32_t)(rng() % 1100)}) {
+                if (from + L > 38 * 32) continue;
+                for (int rc = 0; rc < 2; rc++) {
+                    std::string got(L + 8, '#'), want(L, '?');
+                    mtgi::decode_slice(words.data(), from, L, rc != 0, &got[4]);
+                    for (uint32_t i = 0; i < L; i++) {
+                        const uint32_t j = from + i, c = (uint32_t)(words[j >> 5] >> (2 * (j & 31))) & 3;
+                        if (!rc) want[i] = NT[c]; else want[L - 1 - i] = NTC[c];
+                    }
+                    if (got.substr(4, L) != want || got.substr(0, 4) != "####" || got.substr(4 + L) != "####") {
+                        fprintf(stderr, "decode_slice from %u L %u rc %d differs\n", from, L, rc);
+                        return 1;
+                    }
+                }
+            }
+    }
+    /* set_common */
+    const char alphabet[] = "ACGTACGTACGTACGTNacgtnXR-";
+    for (int k : {31, 21, 16, 13}) {
+        for (int round = 0; round < 3000; round++) {
+            const bool clean = (round % 3) != 0;
+            auto rnd = [&](size_t n) { std::string s(n, 'A'); for (auto& c : s) c = clean ? "ACGT"[rng() & 3] : alphabet[rng() % (sizeof alphabet - 1)]; return s; };
+            const std::string source = rnd((size_t)k + (round % 5 == 0 ? rng() % 4 : 0));
+            const std::string pattern = rnd(round % 7 == 0 ? rng() % 200 : (size_t)k);
+            mtgi::FillInput in;
+            in.k = k;
+            in.resize(1);
+            in.size(0, pattern.size(), 0);
+            in.layout();
+            /* poison the pattern words: the block is recycled in the product */
+            for (size_t w = 0; w < in.rwords.size(); w++) in.rwords[w] = ~0ull;
+            in.set_common(0, source, pattern, 2);
+            const uint64_t want_src = mtg::encode_kmer(source.data(), k);
+            bool acgt = true;
+            for (char c : pattern) acgt = acgt && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
+            const uint64_t want_r0 = (pattern.size() >= (size_t)k && acgt) ? mtg::encode_kmer(pattern.data(), k) : 0;
+            bool fast = (int)source.size() == k;
+            for (unsigned char c : source) fast = fast && !mtgi::nt_bad(c);
+            bool ok = in.src[0] == want_src && in.r0[0] == want_r0 && in.fast_ok[0] == (fast ? 1 : 0) && in.nbmis[0] == 2 &&
+                      in.rlen[0] == (acgt ? (uint32_t)pattern.size() : 0xFFFFFFFFu);
+            const size_t nw = (pattern.size() + 31) / 32 + 1;
+            for (size_t w = 0; w < nw && ok; w++) {
+                uint64_t want = 0;
+                for (size_t i = w * 32; i < std::min(pattern.size(), (w + 1) * 32); i++) want |= (uint64_t)mtg::nt_code((unsigned char)pattern[i]) << (2 * (i & 31));
+                ok = in.rwords[in.roff[0] + w] == want;
+            }
+            if (!ok) { fprintf(stderr, "set_common k %d source %s pattern %s differs\n", k, source.c_str(), pattern.c_str()); return 1; }
+        }
+    }
+    printf("OK\n");
+    return 0;
+}

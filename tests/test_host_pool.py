@@ -24,3 +24,15 @@ def test_concurrent_batches_on_one_index_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_vectorised_host_helpers_match_scalar_code(tmp_path):
+    """decode_slice (pdep + vpshufb) for every alignment / length / direction and FillInput::set_common (pext packing, k-mer by bit
+    reversal, validity tests) against per-character code, with and without the vector paths (MTG_NO_VEC)"""
+    exe = str(tmp_path / "host_units")
+    csrc = os.path.join(ROOT, "mindthegap_amd", "csrc")
+    srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("host_units.cpp", "emu_backend.cpp")] + [os.path.join(csrc, "mtg_cli.cpp")]
+    subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-pthread", "-o", exe] + srcs + ["-lz"])
+    for extra in ({}, {"MTG_NO_VEC": "1"}):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, **extra))
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (extra, r.stdout[-300:], r.stderr[-1000:])
