@@ -345,6 +345,39 @@ def test_pipelined_gather_on_rccl_single_rank(mtg):
         pg.drain()
         got = pg.last()
         assert len(got) == 1 and got[0].tobytes() == last.tobytes()
+        # bench.py's default: steps in flight on caller threads sharing one gather (acquire / submit(j)); every payload ends with its
+        # own checksum, so whichever step was submitted last must come back intact
+        import threading
+        import zlib
+        pg2 = PipelinedGather(1 << 20, dst=0, device=dev, depth=4)
+        todo, lock, errors = iter(range(24)), threading.Lock(), []
+
+        def worker(seed):
+            try:
+                torch.cuda.set_device(0)
+                r2 = np.random.default_rng(seed)
+                while True:
+                    with lock:
+                        if next(todo, None) is None:
+                            return
+                    j, buf = pg2.acquire()
+                    n2 = int(r2.integers(8, 1 << 20))
+                    body = r2.integers(0, 256, n2 - 4, dtype=np.uint8)
+                    buf[: n2 - 4] = body
+                    buf[n2 - 4: n2] = np.frombuffer(np.uint32(zlib.crc32(body.tobytes())).tobytes(), dtype=np.uint8)
+                    pg2.submit(n2, j)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=worker, args=(s,)) for s in (5, 6, 7)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+        pg2.drain()
+        got = pg2.last()[0]
+        assert len(got) >= 8 and zlib.crc32(got[:-4].tobytes()) == int(np.frombuffer(got[-4:].tobytes(), dtype=np.uint32)[0])
     finally:
         dist.destroy_process_group()
 
