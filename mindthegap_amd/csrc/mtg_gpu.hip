@@ -929,87 +929,87 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             /* The copy back of part q is queued as soon as the part is done and runs while the host finishes part q - 1. */
             struct PartState { uint32_t s0 = 0, mq = 0, chunk_id = 0; uint64_t tw = 0; SlotRec* h_rec = nullptr; uint64_t* h_w = nullptr; } ps[MTG_POST_PARTS];
             for (uint32_t qq = 0; qq <= nparts; qq++) {
-              if (qq < nparts) {
-                const uint32_t q = qq;
-                const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize), mq = s1 - s0;
-                HIP_TRY(hipEventSynchronize(evp[q]));
-                if (q == 0) tick("first part ready");
-                t0 = now_ms();
-                const uint64_t tw = h_tot[2 * q], tc = h_tot[2 * q + 1];
-                batch.chunks.emplace_back(new HostChunk());
-                HostChunk& hc = *batch.chunks.back();
-                const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
-                SlotRec* h_rec = nullptr;
-                uint64_t* h_w = nullptr;
-                uint32_t* h_m = nullptr;
-                void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST - 1 ? staging_host(&ws, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(mq, tw, tc)) : nullptr;
-                hc.carve(block, mq, tw, tc, h_rec, h_w, h_m);
-                HIP_TRY(hipStreamWaitEvent(copy_stream, evp[q], 0));
-                HIP_TRY(hipMemcpyAsync(h_rec, d_rec.as<SlotRec>() + s0, (size_t)mq * sizeof(SlotRec), hipMemcpyDeviceToHost, copy_stream));
-                if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, tw * 8, hipMemcpyDeviceToHost, copy_stream));
-                if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, tc * 20, hipMemcpyDeviceToHost, copy_stream));
-                HIP_TRY(hipEventRecord(evcp[q], copy_stream));
-                ps[q].s0 = s0; ps[q].mq = mq; ps[q].chunk_id = chunk_id; ps[q].tw = tw; ps[q].h_rec = h_rec; ps[q].h_w = h_w;
-                st.d2h_ms += now_ms() - t0;
-              }
-              if (qq > 0) {
-                const uint32_t q = qq - 1;
-                const uint32_t s0 = ps[q].s0, mq = ps[q].mq, chunk_id = ps[q].chunk_id;
-                const uint64_t tw = ps[q].tw;
-                SlotRec* const h_rec = ps[q].h_rec;
-                uint64_t* const h_w = ps[q].h_w;
-                HostChunk& hc = *batch.chunks[chunk_id];
-                t0 = now_ms();
-                HIP_TRY(hipEventSynchronize(evcp[q]));
-                h_w[tw] = 0;
-                st.d2h_ms += now_ms() - t0;
-                t0 = now_ms();
-                /* statistics and what needs another look: a serial scan of a part's records costs less than a parallel region */
-                uint64_t nt_sum = 0, lines = 0;
-                bool any_retry = false, any_general = false;
-                for (uint32_t s2 = 0; s2 < mq; s2++) {
-                    lines += h_rec[s2].o.lines;
-                    if (h_rec[s2].o.status != GAP_OK) { any_retry = true; continue; }
-                    nt_sum += h_rec[s2].o.total_nt;
-                    if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) any_general = true;
+                if (qq < nparts) {
+                    const uint32_t q = qq;
+                    const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize), mq = s1 - s0;
+                    HIP_TRY(hipEventSynchronize(evp[q]));
+                    if (q == 0) tick("first part ready");
+                    t0 = now_ms();
+                    const uint64_t tw = h_tot[2 * q], tc = h_tot[2 * q + 1];
+                    batch.chunks.emplace_back(new HostChunk());
+                    HostChunk& hc = *batch.chunks.back();
+                    const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
+                    SlotRec* h_rec = nullptr;
+                    uint64_t* h_w = nullptr;
+                    uint32_t* h_m = nullptr;
+                    void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST - 1 ? staging_host(&ws, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(mq, tw, tc)) : nullptr;
+                    hc.carve(block, mq, tw, tc, h_rec, h_w, h_m);
+                    HIP_TRY(hipStreamWaitEvent(copy_stream, evp[q], 0));
+                    HIP_TRY(hipMemcpyAsync(h_rec, d_rec.as<SlotRec>() + s0, (size_t)mq * sizeof(SlotRec), hipMemcpyDeviceToHost, copy_stream));
+                    if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, tw * 8, hipMemcpyDeviceToHost, copy_stream));
+                    if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, tc * 20, hipMemcpyDeviceToHost, copy_stream));
+                    HIP_TRY(hipEventRecord(evcp[q], copy_stream));
+                    ps[q].s0 = s0; ps[q].mq = mq; ps[q].chunk_id = chunk_id; ps[q].tw = tw; ps[q].h_rec = h_rec; ps[q].h_w = h_w;
+                    st.d2h_ms += now_ms() - t0;
                 }
-                st.index_lines += lines;
-                st.contig_nt += nt_sum;
-                if (!identity) {
+                if (qq > 0) {
+                    const uint32_t q = qq - 1;
+                    const uint32_t s0 = ps[q].s0, mq = ps[q].mq, chunk_id = ps[q].chunk_id;
+                    const uint64_t tw = ps[q].tw;
+                    SlotRec* const h_rec = ps[q].h_rec;
+                    uint64_t* const h_w = ps[q].h_w;
+                    HostChunk& hc = *batch.chunks[chunk_id];
+                    t0 = now_ms();
+                    HIP_TRY(hipEventSynchronize(evcp[q]));
+                    h_w[tw] = 0;
+                    st.d2h_ms += now_ms() - t0;
+                    t0 = now_ms();
+                    /* statistics and what needs another look: a serial scan of a part's records costs less than a parallel region */
+                    uint64_t nt_sum = 0, lines = 0;
+                    bool any_retry = false, any_general = false;
                     for (uint32_t s2 = 0; s2 < mq; s2++) {
-                        if (h_rec[s2].o.status != GAP_OK) continue;
-                        const uint32_t g = host_ids[s0 + s2];
-                        batch.chunk_of[g] = chunk_id;
-                        batch.slot_of[g] = s2;
+                        lines += h_rec[s2].o.lines;
+                        if (h_rec[s2].o.status != GAP_OK) { any_retry = true; continue; }
+                        nt_sum += h_rec[s2].o.total_nt;
+                        if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) any_general = true;
                     }
-                }
-                if (any_retry)
-                    for (uint32_t s2 = 0; s2 < mq; s2++)
-                        if (h_rec[s2].o.status != GAP_OK) retry.push_back(host_ids ? host_ids[s0 + s2] : (uint32_t)(s0 + s2));
-                /* multi-contig gaps: their contig-graph paths, while the launch's scratch is still in place */
-                if (!host_paths && any_general) {
-                    std::vector<uint32_t> gslots;
-                    for (uint32_t s2 = 0; s2 < mq; s2++)
-                        if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s0 + s2);
-                    if (!gslots.empty()) {
-                        DevBuf d_gs, d_po;
-                        HIP_TRY(d_gs.alloc(gslots.size() * 4));
-                        HIP_TRY(hipMemcpyAsync(d_gs.p, gslots.data(), gslots.size() * 4, hipMemcpyHostToDevice, stream));
-                        HIP_TRY(d_po.alloc(gslots.size() * (size_t)PATHS_WORDS * 4));
-                        hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
-                                           d_po.as<uint32_t>(), (uint32_t)gslots.size());
-                        HIP_TRY(hipGetLastError());
-                        hc.paths.resize(gslots.size() * (size_t)PATHS_WORDS);
-                        HIP_TRY(hipMemcpyAsync(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost, stream));
-                        HIP_TRY(hipStreamSynchronize(stream));
-                        hc.path_of.assign(mq, -1);
-                        for (size_t g2 = 0; g2 < gslots.size(); g2++) hc.path_of[gslots[g2] - s0] = (int32_t)g2;
+                    st.index_lines += lines;
+                    st.contig_nt += nt_sum;
+                    if (!identity) {
+                        for (uint32_t s2 = 0; s2 < mq; s2++) {
+                            if (h_rec[s2].o.status != GAP_OK) continue;
+                            const uint32_t g = host_ids[s0 + s2];
+                            batch.chunk_of[g] = chunk_id;
+                            batch.slot_of[g] = s2;
+                        }
                     }
+                    if (any_retry)
+                        for (uint32_t s2 = 0; s2 < mq; s2++)
+                            if (h_rec[s2].o.status != GAP_OK) retry.push_back(host_ids ? host_ids[s0 + s2] : (uint32_t)(s0 + s2));
+                    /* multi-contig gaps: their contig-graph paths, while the launch's scratch is still in place */
+                    if (!host_paths && any_general) {
+                        std::vector<uint32_t> gslots;
+                        for (uint32_t s2 = 0; s2 < mq; s2++)
+                            if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s0 + s2);
+                        if (!gslots.empty()) {
+                            DevBuf d_gs, d_po;
+                            HIP_TRY(d_gs.alloc(gslots.size() * 4));
+                            HIP_TRY(hipMemcpyAsync(d_gs.p, gslots.data(), gslots.size() * 4, hipMemcpyHostToDevice, stream));
+                            HIP_TRY(d_po.alloc(gslots.size() * (size_t)PATHS_WORDS * 4));
+                            hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
+                                               d_po.as<uint32_t>(), (uint32_t)gslots.size());
+                            HIP_TRY(hipGetLastError());
+                            hc.paths.resize(gslots.size() * (size_t)PATHS_WORDS);
+                            HIP_TRY(hipMemcpyAsync(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost, stream));
+                            HIP_TRY(hipStreamSynchronize(stream));
+                            hc.path_of.assign(mq, -1);
+                            for (size_t g2 = 0; g2 < gslots.size(); g2++) hc.path_of[gslots[g2] - s0] = (int32_t)g2;
+                        }
+                    }
+                    st.host_ms += now_ms() - t0;
+                    /* hand the part to the caller: the gaps of its slots (those to be re-run excepted, the caller sees their status) */
+                    if (on_ready) (*on_ready)(chunk_id, host_ids ? host_ids + s0 : nullptr, host_ids ? 0 : (size_t)s0, mq);
                 }
-                st.host_ms += now_ms() - t0;
-                /* hand the part to the caller: the gaps of its slots (those to be re-run excepted, the caller sees their status) */
-                if (on_ready) (*on_ready)(chunk_id, host_ids ? host_ids + s0 : nullptr, host_ids ? 0 : (size_t)s0, mq);
-              }
             }
             (void)first_chunk;
             HIP_TRY(hipEventSynchronize(ev2));
