@@ -70,7 +70,7 @@ namespace mtgi {
 
 void set_error(const char* fmt, ...);
 
-/* persistent host worker pool for the per-gap loops (nthreads <= 0: all cores, capped at 64).  A batch runs a dozen short parallel
+/* persistent host worker pool for the per-gap loops (sized by cpu_budget(), at most 64; nthreads <= 0: all of it).  A batch runs a dozen short parallel
  * regions back to back, so idle workers first spin for a few tens of microseconds on the generation counter before they go to sleep,
  * and the caller never waits for a helper that has not started by the time the work has run out. */
 class Pool {
