@@ -574,7 +574,10 @@ struct BatchSource {
     virtual void record_gap(size_t i, uint64_t& bytes, uint64_t& filled) { (void)i; (void)bytes; (void)filled; }
     virtual void part_done(size_t first, size_t count, bool clean, uint64_t bytes, uint64_t filled) { (void)first; (void)count; (void)clean; (void)bytes; (void)filled; }
 };
-enum { RESULT_BLOCK = 512 };
+#ifndef MTG_RESULT_BLOCK_V
+#define MTG_RESULT_BLOCK_V 512
+#endif
+enum { RESULT_BLOCK = MTG_RESULT_BLOCK_V };
 /* sol_blocks (optional): number of solutions in each block of RESULT_BLOCK gaps */
 int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillArena& arena, mtg_batch_stats* stats_out, std::vector<uint64_t>* sol_blocks = nullptr);
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
