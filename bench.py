@@ -200,6 +200,21 @@ def main():
         if errors:
             raise errors[0]
 
+    if a.in_flight > 1:
+        # untimed set-up, not a warm-up step: every caller thread enters the library at the same moment, so that each of the index's
+        # workspaces (scratch, page-locked staging blocks, streams) has been allocated once before anything is timed
+        gate = threading.Barrier(a.in_flight)
+
+        def prime():
+            torch.cuda.set_device(local_rank)
+            gate.wait()
+            step()
+
+        ts = [threading.Thread(target=prime) for _ in range(a.in_flight)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
     run_steps(a.warmup, False)
     barrier()
     t0 = time.perf_counter()
