@@ -693,17 +693,27 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
     in.k = k;
     in.ws = batch_lock.ws;
     std::atomic<long> bad_gap{-1}, short_gap{-1};
-    in.plan(n, nth, [&](size_t i, size_t& swf_len, size_t& n_targets) {
+    const auto sizes_of = [&](size_t i, size_t& swf_len, size_t& n_targets) -> bool {
         size_t src_len = 0;
-        if (!src.sizes(i, src_len, swf_len, n_targets)) { bad_gap = (long)i; src_len = swf_len = n_targets = 0; }
-        else if ((int)src_len < k) short_gap = (long)i;
+        bool ok = true;
+        if (!src.sizes(i, src_len, swf_len, n_targets)) { bad_gap = (long)i; src_len = swf_len = n_targets = 0; ok = false; }
+        else if ((int)src_len < k) { short_gap = (long)i; ok = false; }
         in.slen[i] = (uint32_t)src_len;
-    });
-    if (bad_gap >= 0) { set_error("gap %ld: null field", bad_gap.load()); return MTG_ERR_ARG; }
-    if (short_gap >= 0) { set_error("gap %ld: source sequence shorter than k", short_gap.load()); return MTG_ERR_ARG; }
-    tick("input sizes + layout");
-    in.fill(nth, [&](size_t i) { src.input(i, in, p->nb_mis_allowed); });
-    tick("input set");
+        return ok;
+    };
+    const auto input_of = [&](size_t i) { src.input(i, in, p->nb_mis_allowed); };
+    const bool one_pass = in.plan_and_fill(n, nth, sizes_of, input_of);
+    if (one_pass) tick("input (one pass)");
+    else {
+        /* the first batch of its shape on this workspace (the staging blocks have to grow), or a malformed gap */
+        bad_gap = -1; short_gap = -1;
+        in.plan(n, nth, sizes_of);
+        if (bad_gap >= 0) { set_error("gap %ld: null field", bad_gap.load()); return MTG_ERR_ARG; }
+        if (short_gap >= 0) { set_error("gap %ld: source sequence shorter than k", short_gap.load()); return MTG_ERR_ARG; }
+        tick("input sizes + layout");
+        in.fill(nth, input_of);
+        tick("input set");
+    }
     mtg_batch_stats st{};
     st.host_ms = now_ms() - t_begin;
     DevBatch batch;

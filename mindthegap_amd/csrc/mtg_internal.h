@@ -394,6 +394,63 @@ struct FillInput {
         for (size_t b = 0; b < nb; b++) { blk_rw[b + 1] += blk_rw[b]; blk_nt[b + 1] += blk_nt[b]; }
         alloc_b(blk_rw[nb], blk_nt[nb]);
     }
+    /* Both passes in one when the staging blocks of the workspace are already large enough (every batch after the first of its shape):
+     * a block of gaps adds up its sizes, learns where the blocks before it end (they are handed out in order and publish their ends as
+     * soon as they know their own sizes), and writes its gaps there.  sz(i, swf_len, n_targets) returns false for a gap that must not
+     * be written (the caller reports the error).  Returns false, with nothing usable written, when a block did not fit or a gap was
+     * refused: the caller then runs plan() and fill(), which make the staging blocks grow. */
+    template <typename SizeFn, typename SetFn> bool plan_and_fill(size_t n, int nthreads, SizeFn sz, SetFn st)
+    {
+        resize(n);
+        slen.resize(n);
+        const size_t nb = (n + BLOCK - 1) / BLOCK;
+        blk_rw.assign(nb + 1, 0);
+        blk_nt.assign(nb + 1, 0);
+        const size_t cap_b = ws ? ws->hcap[1] : 0, cap_c = ws ? ws->hcap[2] : 0;
+        rwords.p = ws ? (uint64_t*)ws->hptr[1] : nullptr;
+        traw.p = ws ? (uint8_t*)ws->hptr[2] : nullptr;
+        std::vector<std::atomic<int64_t>> end_rw(nb + 1), end_nt(nb + 1);
+        for (size_t b = 0; b <= nb; b++) { end_rw[b].store(-1, std::memory_order_relaxed); end_nt[b].store(-1, std::memory_order_relaxed); }
+        end_nt[0].store(0, std::memory_order_relaxed);
+        end_rw[0].store(0, std::memory_order_release);
+        std::atomic<bool> deferred{false};
+        parallel_for(nb, nthreads, [&](size_t b) {
+            const size_t i0 = b * BLOCK, i1 = std::min(n, (b + 1) * (size_t)BLOCK);
+            uint64_t rw = 0, nt = 0;
+            bool ok = true;
+            for (size_t i = i0; i < i1; i++) {
+                size_t sl = 0, tn = 0;
+                ok = sz(i, sl, tn) && ok;
+                size(i, sl, tn);
+                rw += (sl + 31) / 32 + 1;
+                nt += tn;
+            }
+            int64_t rw0;
+            while ((rw0 = end_rw[b].load(std::memory_order_acquire)) < 0) Pool::cpu_relax();
+            const int64_t nt0 = end_nt[b].load(std::memory_order_relaxed);
+            end_nt[b + 1].store(nt0 + (int64_t)nt, std::memory_order_relaxed);
+            end_rw[b + 1].store(rw0 + (int64_t)rw, std::memory_order_release);
+            blk_rw[b] = (uint64_t)rw0;
+            blk_nt[b] = (uint64_t)nt0;
+            if (!ok || deferred.load(std::memory_order_relaxed) || 8 * ((uint64_t)rw0 + rw) + 64 > cap_b || (uint64_t)mtg::TARGET_SLOT * ((uint64_t)nt0 + nt) + 64 > cap_c) {
+                deferred.store(true, std::memory_order_relaxed);
+                return;
+            }
+            uint64_t r = (uint64_t)rw0, t = (uint64_t)nt0;
+            for (size_t i = i0; i < i1; i++) {
+                roff[i] = (uint32_t)r;
+                toff[i] = (uint32_t)t;
+                r += (rlen[i] + 31) / 32 + 1; /* before st(i): set() may flag the pattern by overwriting rlen */
+                t += tcnt[i];
+                st(i);
+            }
+        }, 1);
+        if (deferred.load()) return false; /* the caller falls back to plan() + fill(): sizes again (st may have flagged a pattern's length), larger blocks */
+        blk_rw[nb] = (uint64_t)end_rw[nb].load(std::memory_order_acquire);
+        blk_nt[nb] = (uint64_t)end_nt[nb].load(std::memory_order_relaxed);
+        alloc_b(blk_rw[nb], blk_nt[nb]); /* the same blocks: they were large enough */
+        return true;
+    }
     template <typename SetFn> void fill(int nthreads, SetFn st)
     {
         const size_t n = src.size(), nb = (n + BLOCK - 1) / BLOCK;

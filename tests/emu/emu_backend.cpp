@@ -62,6 +62,7 @@ void index_release(mtg_index* idx)
     if (!idx) return;
     index_forget_host_copy(idx);
     free(idx->dev.adj.slots); free(idx->dev.abnd.slots); free(idx->dev.bloom.bits);
+    for (Workspace& w : idx->ws) for (void* h : w.hptr) free(h);
     delete idx;
 }
 
@@ -153,8 +154,20 @@ int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint3
     return MTG_OK;
 }
 
-/* the emulator keeps the marshalled input in the FillInput's own storage */
-void* staging_host(Workspace*, int, size_t) { return nullptr; }
+/* grow-only staging blocks like the device build's, in ordinary memory (never shrunk, poisoned when they grow: a batch must write what it reads) */
+void* staging_host(Workspace* ws, int slot, size_t bytes)
+{
+    if (!ws || slot < 0 || slot >= Workspace::NHOST || slot >= STAGING_CHUNK0) return nullptr; /* results keep their own storage here */
+    if (ws->hcap[slot] < bytes) {
+        free(ws->hptr[slot]);
+        const size_t want = bytes + bytes / 4 + 4096;
+        ws->hptr[slot] = malloc(want);
+        if (!ws->hptr[slot]) { ws->hcap[slot] = 0; return nullptr; }
+        memset(ws->hptr[slot], 0xA5, want);
+        ws->hcap[slot] = want;
+    }
+    return ws->hptr[slot];
+}
 
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats,
                const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)
