@@ -483,6 +483,28 @@ def _abi_edge_cases(mtg_mod):
     assert plain[0]["filled"] and plain[0]["filled"][0]["seq"] == s[31:100]
     with pytest.raises(mtg_mod.MtgError):
         idx.fill_prepared_serial(mtg_mod.Index.prepare_gaps([g]), np.empty(8, dtype=np.uint8))
+    # several blocks of gaps through the input marshalling: the first batch of a shape makes the staging blocks grow (two passes), the
+    # following ones are written in one pass; a malformed gap in a late block is refused whatever the blocks before it wrote, a larger
+    # batch grows the blocks again, and the results never change
+    rng = random.Random(12)
+    many = []
+    for _ in range(1500):
+        a = rng.randrange(0, 150)
+        b = rng.randrange(a + 40, 260)
+        many.append(mtg_mod.Gap(s[a:a + 31], s[b:b + 31], [(s[b:b + 31], "t%d" % b, False), (_rand_seq(rng, 31), "decoy", False)]))
+    want = idx.fill_batch(many)
+    assert sum(1 for r in want if r["filled"]) > 1000
+    for gq, r in zip(many, want):  # the walk from s[a:a+31] meets the target at b: the fill is what lies between
+        a0, b0 = s.index(gq.source), s.index(gq.target)
+        assert [f["seq"] for f in r["filled"]] == [s[a0 + 31:b0]], (a0, b0)
+    assert idx.fill_batch(many) == want and idx.fill_batch(many) == want
+    bad = list(many)
+    bad[1300] = mtg_mod.Gap("ACGT", many[1300].target, many[1300].targets)
+    with pytest.raises(mtg_mod.MtgError):
+        idx.fill_batch(bad)
+    assert idx.fill_batch(many) == want
+    assert idx.fill_batch(many + many[:700]) == want + want[:700]
+    assert idx.fill_batch(many[:600]) == want[:600]
     idx.close()
     o.close()
 
