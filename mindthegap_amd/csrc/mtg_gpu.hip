@@ -851,13 +851,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
 
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
         const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + (uint64_t)cfg.cap_words * 8 +
                                  (uint64_t)cfg.cap_contigs * 20;
         const size_t cached = ws.cap[d_zero.slot] + ws.cap[d_raw.slot] + ws.cap[d_ilv.slot] + ws.cap[d_dw.slot] + ws.cap[d_dm.slot]; /* already ours */
-        size_t chunk = (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
+        size_t free_b = 0, total_b = 0;
+        /* steady state: every scratch buffer of the workspace already holds a batch of this size at this tier, nothing will be allocated */
+        const uint64_t m0 = std::min<uint64_t>(n_todo, 1u << 20);
+        const bool fits = ws.cap[d_zero.slot] >= m0 * cfg.zero_stride && ws.cap[d_raw.slot] >= m0 * cfg.raw_stride + 64 && ws.cap[d_ilv.slot] >= ((m0 + 63) / 64) * cfg.ilv_stride &&
+                          ws.cap[d_dw.slot] >= m0 * (uint64_t)cfg.cap_words * 8 + 64 && ws.cap[d_dm.slot] >= m0 * (uint64_t)cfg.cap_contigs * 20 + 64;
+        if (!fits) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        size_t chunk = fits ? (size_t)m0 : (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
         const size_t env_chunk = getenv("MTG_MAX_CHUNK") ? (size_t)atol(getenv("MTG_MAX_CHUNK")) : 0; /* test hook: several launches per batch */
         if (env_chunk && chunk > env_chunk) chunk = env_chunk;
         if (chunk > n_todo) chunk = n_todo;
