@@ -53,6 +53,8 @@ typedef struct mtg_index_info {
     uint32_t adj_bucket_bytes, abnd_bucket_bytes; /* one bucket = one read of the walk / of an abundance query */
     uint64_t bloom_blocks;      /* 64-byte blocks of the Bloom filter (0 = not built) */
     uint32_t bloom_minimizer;   /* minimizer length selecting the block */
+    uint64_t nb_unitigs;        /* maximal simple paths (>= 2 k-mers) held in the unitig store */
+    uint64_t unitig_bytes;      /* HBM held by the unitig store (2-bit sequences + one abundance byte per k-mer) */
 } mtg_index_info;
 
 /* Graph::create(props) from read files (src/Filler.cpp:172-213): paths_csv = comma separated FASTA/FASTQ(.gz);

@@ -317,10 +317,24 @@ struct Bloom {
 };
 enum { MTG_BLOOM_NHASH = 4 };
 
+/* Unitig store: the maximal simple paths of the graph (at least two k-mers each), 2-bit packed one after the other.  Unitig u occupies
+ * words[hdr] (header: its length in nucleotides) and the ceil(len / 32) words behind it, nucleotide i at bits 2 (i mod 32) of word
+ * hdr + 1 + i / 32; ab[(hdr + 1) * 32 + i] = abundance of the k-mer starting at nucleotide i (0 for the last k-1 nucleotides and the
+ * padding).  Every junction ((k-1)-mer between two consecutive k-mers) inside a unitig carries, in word 1 of its ADJ entry, a POINTER
+ * to its place in the store instead of an inline lookahead: a walker that reads such an entry knows the whole rest of the simple path
+ * and follows it with sequential reads (full unitig compaction; see us_* below for the construction). */
+struct UStore {
+    uint64_t* words;
+    uint8_t* ab;
+    uint64_t nwords;   /* words in use (0: no store) */
+    uint64_t nunitigs;
+};
+
 struct Index {
     Table adj;  /* canonical (k-1)-mer -> edge masks */
     Table abnd; /* canonical k-mer     -> abundance  */
     Bloom bloom;
+    UStore us;
     int k;
 };
 
@@ -384,7 +398,25 @@ struct Adj {
     uint32_t out; /* nts b such that x[1:]+b is solid  (successors of x)                     */
     uint32_t in;  /* nts a such that a+x[1:] is solid  (predecessors of every successor of x) */
     uint32_t la;  /* lookahead past the single successor, valid when out and in are single bits (adj_right only) */
+    uint64_t up;  /* 0, or the junction's place in the unitig store, resolved for the walking direction (up_* below; adj_right_t only) */
 };
+
+/* ---- word 1 of an ADJ entry, pointer form: [hdr : 32][off : 27][rc : 1][1111].  The low nibble 15 cannot be a lookahead count
+ * (MTG_LA_MAX <= 14).  hdr = header word of the unitig, off = nucleotide offset of the junction's first nucleotide in the stored
+ * unitig (1 <= off <= len - k), rc = the canonical (k-1)-mer appears reverse-complemented in the stored sequence.
+ * Resolved form (Adj::up): bit 0 = valid, bit 1 = the walk runs against the stored orientation, other fields unchanged. */
+enum : uint32_t { MTG_US_MAX_LEN = (1u << 27) - 1 };
+MTG_DEV bool up_is(uint64_t w1) { return (w1 & 15ull) == 15ull; }
+MTG_DEV uint64_t up_make(uint64_t hdr, uint32_t off, bool rc) { return 15ull | ((uint64_t)(rc ? 1 : 0) << 4) | ((uint64_t)off << 5) | (hdr << 32); }
+MTG_DEV uint64_t up_resolve(uint64_t w1, bool key_is_walk_orientation)
+{
+    const bool rc = (w1 >> 4) & 1;
+    const bool fwd = key_is_walk_orientation != rc; /* the (k-1)-mer as walked appears as it is in the store */
+    return (w1 & ~31ull) | 1ull | (fwd ? 0ull : 2ull);
+}
+MTG_DEV uint64_t up_hdr(uint64_t up) { return up >> 32; }
+MTG_DEV uint32_t up_off(uint64_t up) { return (uint32_t)(up >> 5) & MTG_US_MAX_LEN; }
+MTG_DEV bool up_bwd(uint64_t up) { return (up & 2ull) != 0; }
 
 /* right neighbourhood of x: successors of x and in-neighbours of those successors (one bucket read). */
 MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t& lines)
@@ -393,11 +425,58 @@ MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t&
     uint64_t aux;
     const uint32_t m = adj_get(adj, s <= rs ? s : rs, lines, aux);
     Adj a;
+    a.up = 0;
     if (s <= rs) { a.out = m & 15u; a.in = m >> 4; a.la = (uint32_t)aux; }
     else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); a.la = (uint32_t)(aux >> 32); }
+    if (up_is(aux)) { a.la = 0; a.up = up_resolve(aux, s <= rs); }
     return a;
 }
-MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines) { return adj_right_t(ix.adj, x, mk1, lines); }
+
+/* ---- reading the unitig store ---------------------------------------------------------------------------------------------------
+ * n <= 16 nucleotides of the store in walking order, first one in the lowest bits: forward = the nucleotides at pos, pos + 1, ...;
+ * backward = the complements of those at pos, pos - 1, ... (global nucleotide index = word * 32 + i) */
+MTG_DEV uint32_t us_peek(const uint64_t* words, uint64_t pos, uint32_t n, bool bwd)
+{
+    if (n == 0) return 0u;
+    const uint64_t lo = bwd ? pos - (n - 1) : pos;
+    const uint32_t sh = 2u * (uint32_t)(lo & 31u);
+    uint64_t v = words[lo >> 5] >> sh;
+    if ((uint32_t)(lo & 31u) + n > 32u) v |= words[(lo >> 5) + 1] << (64u - sh); /* sh > 0 here */
+    const uint32_t mask = n >= 16u ? 0xFFFFFFFFu : ((1u << (2u * n)) - 1u);
+    uint32_t r = (uint32_t)v & mask;
+    if (bwd) r = (rev_fields32(r) >> (32u - 2u * n)) ^ (0xAAAAAAAAu & mask);
+    return r;
+}
+/* the simple path behind a pointer: position of its first nucleotide (the junction's out-edge) and how many nucleotides follow the
+ * junction up to the end of the unitig in the walking direction (>= 1) */
+MTG_DEV void us_run(const UStore& us, uint64_t up, int k, uint64_t& pos, uint32_t& left)
+{
+    const uint64_t hdr = up_hdr(up);
+    const uint32_t off = up_off(up), len = (uint32_t)us.words[hdr];
+    const uint64_t base = (hdr + 1) * 32;
+    if (up_bwd(up)) { pos = base + off - 1; left = off; }
+    else { pos = base + off + (uint32_t)k - 1; left = len - (off + (uint32_t)k - 1); }
+}
+/* the lookahead word an inline entry would hold (count + up to MTG_LA_MAX nucleotides past the single out-edge), read through the pointer */
+MTG_DEV uint32_t la_from_up(const UStore& us, uint64_t up, int k, uint32_t& lines)
+{
+    uint64_t pos;
+    uint32_t left;
+    us_run(us, up, k, pos, left);
+    lines++;
+    uint32_t n = left - 1;
+    if (n > (uint32_t)MTG_LA_MAX) n = MTG_LA_MAX;
+    if (n == 0) return 0u;
+    const bool bwd = up_bwd(up);
+    return n | (us_peek(us.words, bwd ? pos - 1 : pos + 1, n, bwd) << 4);
+}
+/* for the bubble routines: the neighbourhood with its lookahead, whichever way the entry holds it */
+MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
+{
+    Adj a = adj_right_t(ix.adj, x, mk1, lines);
+    if (a.up && popc4(a.out) == 1 && popc4(a.in) == 1) a.la = la_from_up(ix.us, a.up, ix.k, lines);
+    return a;
+}
 /* right neighbourhoods of two unrelated nodes with both home buckets in flight together; a key that is not in its home bucket of a full
  * bucket is looked up again the ordinary way (rare) */
 MTG_DEV void adj_right2(const Index& ix, const Kmer& xa, const Kmer& xb, uint64_t mk1, uint32_t& lines, Adj& ra, Adj& rb)
@@ -431,9 +510,15 @@ MTG_UNROLL
         }
         lines++;
         if (!m && q[u][MTG_ADJ_SLOTS - 1].x != 0) { *rs[u] = adj_right_t(t, *xs[u], mk1, lines); continue; } /* perhaps displaced */
+        rs[u]->up = 0;
         if (fw[u]) { rs[u]->out = m & 15u; rs[u]->in = m >> 4; rs[u]->la = (uint32_t)aux; }
         else { rs[u]->out = comp_mask(m >> 4); rs[u]->in = comp_mask(m & 15u); rs[u]->la = (uint32_t)(aux >> 32); }
+        if (up_is(aux)) { rs[u]->la = 0; rs[u]->up = up_resolve(aux, fw[u]); }
     }
+    /* pointer entries: both lookaheads through the store, the reads of the two in flight together as far as the compiler allows */
+MTG_UNROLL
+    for (int u = 0; u < 2; u++)
+        if (rs[u]->up && popc4(rs[u]->out) == 1 && popc4(rs[u]->in) == 1) rs[u]->la = la_from_up(ix.us, rs[u]->up, ix.k, lines);
 }
 /* left neighbourhood of x: .in = predecessors of x, .out = successors of every predecessor. */
 MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
@@ -443,6 +528,7 @@ MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lin
     const uint32_t m = adj_get(ix.adj, p <= rp ? p : rp, lines, aux);
     Adj a;
     a.la = 0;
+    a.up = 0;
     if (p <= rp) { a.out = m & 15u; a.in = m >> 4; }
     else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
     return a;
@@ -534,6 +620,184 @@ MTG_DEV void build_lookahead(const Index& ix, const Kmer& x)
     la |= n;
     uint64_t* e = adj_find(ix.adj, key0);
     if (e) atomic_or64(e + 1, fwd0 ? (uint64_t)la : ((uint64_t)la << 32));
+}
+
+/* ---- unitig store construction (after every insertion and every lookahead) -------------------------------------------------------
+ * A junction between the consecutive solid k-mers p = a+J and y = J+b is ELIGIBLE when it is simple (y is the only successor of p, p
+ * the only predecessor of y) and neither a turning point nor a self loop: J is not its own reverse complement (then y = rc(p)), p != y,
+ * and neither k-mer is its own reverse complement.  Chains of eligible junctions are linear or closed; along a linear chain all canonical
+ * k-mers are distinct (a path that met rc(x) after x would be its own reverse complement and so have a palindromic junction or a
+ * self-complementary node in its middle), and two chains share a canonical k-mer only if one is the reverse complement of the other.
+ * The store holds every linear chain of at least two k-mers once (from the end with the smaller canonical k-mer); closed chains and
+ * single k-mers keep their inline lookaheads.  The property is symmetric under reverse complement, so it is a property of the
+ * canonical junction. */
+MTG_DEV bool us_eligible(const Kmer& p, const Kmer& y, int k)
+{
+    const uint64_t mk1 = kmask(k - 1);
+    if ((p.f & mk1) == (p.r >> 2)) return false; /* palindromic junction */
+    if (p.f == y.f) return false;                /* self loop */
+    if (p.f == p.r || y.f == y.r) return false;  /* self-complementary k-mer (even k) */
+    return true;
+}
+/* the solid oriented k-mer x starts a chain: it has no eligible junction on its left */
+MTG_DEV bool us_is_start(const Index& ix, const Kmer& x, uint32_t& lines)
+{
+    const int k = ix.k;
+    const Adj l = adj_left(ix, x, kmask(k - 1), lines);
+    if (!(popc4(l.in) == 1 && popc4(l.out) == 1)) return true;
+    const Kmer p = kmer_prev(x, (uint32_t)ctz4(l.in), k, kmask(k));
+    return !us_eligible(p, x, k);
+}
+/* Walks the chain that starts with x to its end.  Before the pointers are written the entries hold lookaheads, which save most of the
+ * reads: the junctions they cover are simple, their eligibility is checked on the k-mers.  sink(nt) receives every nucleotide after the
+ * first k-mer; returns the number of k-mers (capped so that the offsets fit a pointer), `end` = the last one. */
+template <typename Sink> MTG_DEV uint32_t us_walk(const Index& ix, const Kmer& x, Kmer& end, uint32_t& lines, Sink sink)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k), mk1 = kmask(k - 1);
+    const uint32_t cap = MTG_US_MAX_LEN - (uint32_t)k; /* k-mers */
+    Kmer cur = x;
+    uint32_t n = 1;
+    for (;;) {
+        const Adj a = adj_right_t(ix.adj, cur, mk1, lines);
+        if (!(popc4(a.out) == 1 && popc4(a.in) == 1)) break;
+        uint32_t nt = (uint32_t)ctz4(a.out), la = a.la, known = la & 15u;
+        la >>= 4;
+        bool stop = false;
+        for (;;) {
+            const Kmer y = kmer_next(cur, nt, k, mk);
+            if (!us_eligible(cur, y, k) || n >= cap) { stop = true; break; }
+            cur = y;
+            n++;
+            sink(nt);
+            if (known == 0) break;
+            nt = la & 3u;
+            la >>= 2;
+            known--;
+        }
+        if (stop) break;
+    }
+    end = cur;
+    return n;
+}
+struct UsNoSink { MTG_DEV void operator()(uint32_t) const {} };
+/* one record per stored unitig, in the order of their header words */
+struct UsRec {
+    uint64_t start_f; /* first k-mer, in the stored orientation */
+    uint32_t len_k;   /* k-mers */
+    uint32_t pad_;
+    uint64_t hdr;
+};
+/* pass 1, per solid oriented k-mer x: if x starts a chain of >= 2 k-mers and is the end the chain is stored from, reserves the chain's
+ * words and its record.  rec == nullptr: only counts the chain starts (every stored unitig has two, one per strand, so half their number
+ * bounds the number of records). */
+MTG_DEV uint64_t us_words_of(uint32_t len_k, int k) { return 1ull + ((uint64_t)len_k + (uint32_t)k - 1 + 31) / 32; }
+MTG_DEV void us_plan_start(const Index& ix, const Kmer& x, unsigned long long* cursor_words, unsigned long long* cursor_recs, UsRec* rec, uint64_t rec_cap, uint32_t& lines);
+MTG_DEV void us_plan(const Index& ix, const Kmer& x, unsigned long long* cursor_words, unsigned long long* cursor_recs, UsRec* rec, uint64_t rec_cap, uint32_t& lines)
+{
+    if (!us_is_start(ix, x, lines)) return;
+    if (!rec) {
+#ifdef MTG_EMU
+        __sync_fetch_and_add(cursor_recs, 1ull);
+#else
+        atomicAdd(cursor_recs, 1ull);
+#endif
+        return;
+    }
+    us_plan_start(ix, x, cursor_words, cursor_recs, rec, rec_cap, lines);
+}
+/* the same for an x known to start a chain (the device build collects the starts first, so that every lane of the walking kernel has one) */
+MTG_DEV void us_plan_start(const Index& ix, const Kmer& x, unsigned long long* cursor_words, unsigned long long* cursor_recs, UsRec* rec, uint64_t rec_cap, uint32_t& lines)
+{
+    Kmer end;
+    const uint32_t n = us_walk(ix, x, end, lines, UsNoSink());
+    if (n < 2) return;
+    /* the reverse complement of the chain starts with rc(end): the one whose first k-mer has the smaller canonical value is stored; the
+     * canonical k-mers of a chain are distinct, so there is no tie between different k-mers */
+    if (!(canon(x) < canon(end))) return;
+#ifdef MTG_EMU
+    const uint64_t r = __sync_fetch_and_add(cursor_recs, 1ull);
+    const uint64_t w = __sync_fetch_and_add(cursor_words, (unsigned long long)us_words_of(n, ix.k));
+#else
+    const uint64_t r = atomicAdd(cursor_recs, 1ull);
+    const uint64_t w = atomicAdd(cursor_words, (unsigned long long)us_words_of(n, ix.k));
+#endif
+    if (r < rec_cap) { rec[r].start_f = x.f; rec[r].len_k = n; rec[r].pad_ = 0; rec[r].hdr = w; }
+}
+/* pass 2, per record: the sequence of the unitig into the store */
+MTG_DEV void us_emit(const Index& ix, const UsRec& r, uint32_t& lines)
+{
+    const int k = ix.k;
+    uint64_t* w = ix.us.words + r.hdr;
+    w[0] = (uint64_t)r.len_k + (uint32_t)k - 1; /* length in nucleotides */
+    uint64_t acc = 0;
+    uint32_t nacc = 0, wpos = 1;
+    auto push = [&](uint32_t nt) {
+        acc |= (uint64_t)nt << (2 * nacc);
+        if (++nacc == 32) { w[wpos++] = acc; acc = 0; nacc = 0; }
+    };
+    for (int i = k - 1; i >= 0; i--) push((uint32_t)(r.start_f >> (2 * i)) & 3u);
+    Kmer end;
+    const Kmer x = make_kmer(r.start_f, k);
+    us_walk(ix, x, end, lines, push);
+    if (nacc) w[wpos] = acc;
+}
+/* pass 3, per k-mer i of a stored unitig (any thread): its abundance into the store and, for i >= 1, the pointer into the entry of the
+ * junction on its left.  Runs after every us_emit (the entries still hold lookaheads until here). */
+MTG_DEV void us_link(const Index& ix, const UsRec& r, uint32_t i, uint32_t& lines)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k), mk1 = kmask(k - 1);
+    const uint64_t* w = ix.us.words + r.hdr + 1;
+    const uint32_t s = 2u * (i & 31u);
+    const uint64_t lo = w[i >> 5] >> s;
+    const uint64_t hi = s ? (w[(i >> 5) + 1] << (64u - s)) : 0ull; /* the store is padded by one word */
+    Kmer x;
+    x.r = ((lo | hi) & mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
+    x.f = revcomp(x.r, k);
+    ix.us.ab[(r.hdr + 1) * 32 + i] = (uint8_t)table_get<MTG_ABND_SLOTS>(ix.abnd, canon(x), lines);
+    if (i == 0) return;
+    const uint64_t J = x.f >> 2, rJ = x.r & mk1;
+    uint64_t* e = adj_find(ix.adj, J <= rJ ? J : rJ);
+    if (e) e[1] = up_make(r.hdr, i, !(J <= rJ));
+}
+
+/* ---- the solid k-mers, read back from the ABND table: (bucket, tag) is lossless and the hash a bijection, so slot s of the table gives
+ * its canonical k-mer and abundance (0: empty slot).  Every distinct solid k-mer comes out exactly once, whatever the index was built
+ * from (used by the unitig construction and by the index writer). */
+MTG_DEV uint64_t unmix(uint64_t h, uint32_t key_bits)
+{
+    const uint64_t M = (1ULL << key_bits) - 1, C = 0xBF58476D1CE4E5B9ULL;
+    uint64_t inv = C; /* Newton iteration for the inverse of the odd multiplier modulo 2^64: 3 correct bits double every round */
+    for (int i = 0; i < 6; i++) inv *= 2 - C * inv;
+    const uint32_t sh = key_bits >> 1;
+    h ^= h >> sh;
+    h = (h * inv) & M;
+    h ^= h >> sh;
+    return h;
+}
+MTG_DEV uint32_t abnd_slot_kmer(const Table& t, uint64_t slot, uint64_t& kmer)
+{
+    const uint64_t v = t.slots[slot];
+    if (v == 0) return 0;
+    const uint64_t b = slot / MTG_ABND_SLOTS, tag = v >> (8 + MTG_DISP_BITS), disp = (v >> 8) & MTG_MAX_DISP;
+    const uint64_t home = b >= disp ? b - disp : b + t.nbuckets - disp;
+    /* H = tag + t * 2^tag_bits with bucket_of(H) == home: t is about home * 2^(key_bits - tag_bits) / nbuckets */
+    const uint32_t lg = t.key_bits - t.tag_bits; /* floor(log2 nbuckets) */
+#ifdef MTG_EMU
+    const uint64_t t0 = (uint64_t)((((unsigned __int128)home) << lg) / t.nbuckets);
+#else
+    const uint64_t t0 = lg < 32 ? ((home << lg) / t.nbuckets) : (uint64_t)(((double)home / (double)t.nbuckets) * (double)(1ull << lg));
+#endif
+    const uint64_t span = 1ull << lg;
+    for (int d = -2; d <= 3; d++) {
+        const uint64_t tt = t0 + (uint64_t)(int64_t)d;
+        if (tt >= span) continue; /* also catches the wrap below zero */
+        const uint64_t H = (tt << t.tag_bits) | tag;
+        if (bucket_of(H, t.nbuckets, t.key_bits) == home) { kmer = unmix(H, t.key_bits); return (uint32_t)(v & 255); }
+    }
+    kmer = ~0ULL; /* cannot happen: the slot was written from such an H */
+    return 0;
 }
 
 /* ---- k-mer counting (Graph::create's DSK step, /root/reference/src/Filler.cpp:172-213): exact open-addressing count table ---- */

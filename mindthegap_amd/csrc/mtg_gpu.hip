@@ -200,20 +200,70 @@ __global__ void k_lookahead_packed(Index ix, const uint64_t* __restrict__ words,
     }
 }
 
-/* counters[2] += branching nodes among kmers[] (in-degree != 1 or out-degree != 1) */
-__global__ void k_count_branching(Index ix, const uint64_t* __restrict__ kmers, size_t n, unsigned long long* counters)
+/* ---- unitig store construction (mtg_dev.h: us_*), over the solid k-mers read back from the ABND table ---- */
+/* counters[0] += chain starts; counters[1] += branching nodes (in-degree != 1 or out-degree != 1); counters[2] += solid k-mers.
+ * starts != nullptr: the oriented start k-mers are also collected there (counters[3] = cursor). */
+__global__ void k_us_starts(Index ix, unsigned long long* counters, uint64_t* starts, unsigned long long cap)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
     const uint64_t mk1 = kmask(ix.k - 1);
-    unsigned long long nb = 0;
     uint32_t lines = 0;
-    for (; i < n; i += stride) {
-        Kmer x = make_kmer(kmers[i], ix.k);
-        const int outd = popc4(adj_right(ix, x, mk1, lines).out), ind = popc4(adj_left(ix, x, mk1, lines).in);
-        nb += !(outd == 1 && ind == 1);
+    unsigned long long ns = 0, nbr = 0, nk = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        if (!abnd_slot_kmer(ix.abnd, s, c)) continue;
+        nk++;
+        Kmer o[2];
+        o[0] = make_kmer(c, ix.k);
+        o[1].f = o[0].r; o[1].r = o[0].f;
+        if (!starts) nbr += !(popc4(adj_right_t(ix.adj, o[0], mk1, lines).out) == 1 && popc4(adj_left(ix, o[0], mk1, lines).in) == 1);
+        for (int u = 0; u < (o[0].f == o[0].r ? 1 : 2); u++) {
+            if (!us_is_start(ix, o[u], lines)) continue;
+            ns++;
+            if (starts) { const unsigned long long at = atomicAdd(&counters[3], 1ull); if (at < cap) starts[at] = o[u].f; }
+        }
     }
-    if (nb) atomicAdd(&counters[2], nb);
+    if (!starts) { if (ns) atomicAdd(&counters[0], ns); if (nbr) atomicAdd(&counters[1], nbr); if (nk) atomicAdd(&counters[2], nk); }
+}
+/* one chain start per lane: walks to the other end; the end with the smaller canonical k-mer reserves the unitig's words and record.
+ * cursors[0] = words, cursors[1] = records */
+__global__ void __launch_bounds__(64) k_us_plan(Index ix, const uint64_t* __restrict__ starts, unsigned long long n, unsigned long long* cursors, UsRec* rec, unsigned long long rec_cap)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    us_plan_start(ix, make_kmer(starts[i], ix.k), &cursors[0], &cursors[1], rec, rec_cap, lines);
+}
+/* one stored unitig per lane: its sequence into the store */
+__global__ void __launch_bounds__(64) k_us_emit(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    us_emit(ix, rec[i], lines);
+}
+/* one stored unitig per wave, its k-mers dealt to the lanes: abundances into the store, pointers into the ADJ entries of its junctions */
+__global__ void __launch_bounds__(256) k_us_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lines = 0;
+    for (unsigned long long u = wave; u < n; u += nwaves) {
+        const UsRec r = rec[u];
+        for (uint32_t i = lane; i < r.len_k; i += 64) us_link(ix, r, i, lines);
+    }
+}
+/* the solid k-mers and their abundances out of the ABND table (index writer): out_k / out_a receive them in no particular order */
+__global__ void k_abnd_export(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned long long* cursor, unsigned long long cap)
+{
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        const uint32_t a = abnd_slot_kmer(ix.abnd, s, c);
+        if (!a) continue;
+        const unsigned long long at = atomicAdd(cursor, 1ull);
+        if (at < cap) { out_k[at] = c; out_a[at] = a; }
+    }
 }
 
 __global__ void k_query(Index ix, const uint64_t* __restrict__ kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
@@ -225,7 +275,7 @@ __global__ void k_query(Index ix, const uint64_t* __restrict__ kmers, size_t n, 
     for (; i < n; i += stride) {
         Kmer x = make_kmer(kmers[i] & kmask(ix.k), ix.k);
         if (abund) abund[i] = abundance(ix, x, lines);
-        if (succ) succ[i] = (uint8_t)adj_right(ix, x, mk1, lines).out;
+        if (succ) succ[i] = (uint8_t)adj_right_t(ix.adj, x, mk1, lines).out;
         if (pred) pred[i] = (uint8_t)adj_left(ix, x, mk1, lines).in;
     }
 }
@@ -286,6 +336,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_
 {
     __shared__ uint32_t hist[256];
     __shared__ uint64_t tile[POST_TILE + 2];
+    __shared__ uint64_t s_blk[64];
     __shared__ uint64_t s_base[2];
     /* this launch covers the slots [slot_base, n); a workgroup takes every gridDim.x-th of them.  One workgroup per slot measured best
      * (1.39 ms against 1.52-1.77 ms with 16384-2048 persistent workgroups): the kernel lives on the number of waves in flight. */
@@ -309,7 +360,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_
             T.n = tcnt[g];
             T.nb_mis = nbmis[g];
             T.fast_ok = fast_ok[g];
-            post_gap(ix, cfg, S, o, T, hist, tile, po);
+            post_gap(ix, cfg, S, o, T, hist, tile, s_blk, po);
         }
         uint32_t nw, nc;
         copy_plan(o, po, want_all != 0, nw, nc); /* po is uniform over the wave */
@@ -332,7 +383,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_
         }
         if (threadIdx.x == 0) {
             SlotRec r;
-            r.o = o; r.p = po; r.nw = nw; r.nc = nc; r.pad_ = 0; r.wbase = wbase; r.cbase = cbase;
+            r.o = o; r.p = po; r.nw = nw; r.nc = nc; r.wbase = wbase; r.cbase = cbase;
             recs[slot] = r;
         }
     }
@@ -518,6 +569,41 @@ __global__ void k_fill_random(uint64_t* p, uint64_t nwords, uint64_t seed)
 }
 
 /* ------------------------------------------------------------------------------------------------ index */
+namespace {
+/* owning device buffer: freed on every exit path */
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 8); }
+    void* release() { void* q = p; p = nullptr; return q; }
+    template <typename T> T* as() { return (T*)p; }
+};
+} // namespace
+
+static void free_tables(mtg_index* idx)
+{
+    if (idx->dev.adj.slots) (void)hipFree(idx->dev.adj.slots);
+    if (idx->dev.abnd.slots) (void)hipFree(idx->dev.abnd.slots);
+    if (idx->dev.bloom.bits) (void)hipFree(idx->dev.bloom.bits);
+    if (idx->dev.us.words) (void)hipFree(idx->dev.us.words);
+    if (idx->dev.us.ab) (void)hipFree(idx->dev.us.ab);
+    idx->dev.adj.slots = idx->dev.abnd.slots = nullptr;
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.us = UStore{};
+}
+namespace {
+/* an index under construction: tables and handle go away unless the build hands it over */
+struct IndexGuard {
+    mtg_index* idx;
+    explicit IndexGuard(mtg_index* i) : idx(i) {}
+    ~IndexGuard() { if (idx) { free_tables(idx); delete idx; } }
+    mtg_index* release() { mtg_index* i = idx; idx = nullptr; return i; }
+};
+} // namespace
+
 static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
 {
     const int k = idx->dev.k;
@@ -527,14 +613,8 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
     table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
     table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
     const size_t ba = idx->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
-    HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));
-    hipError_t e = hipMalloc((void**)&idx->dev.abnd.slots, bb);
-    if (e != hipSuccess) {
-        (void)hipFree(idx->dev.adj.slots);
-        idx->dev.adj.slots = nullptr;
-        set_error("hipMalloc of %zu bytes failed: %s", bb, hipGetErrorString(e));
-        return MTG_ERR_NOMEM;
-    }
+    HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));   /* a failure further down leaves the pointers to free_tables (IndexGuard) */
+    HIP_TRY(hipMalloc((void**)&idx->dev.abnd.slots, bb));
     const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
     size_t bc = 0;
     idx->dev.bloom.bits = nullptr;
@@ -542,8 +622,7 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
     if (bpk > 0) {
         bloom_shape(idx->dev.bloom, nkeys, bpk, k);
         bc = idx->dev.bloom.nblocks * 64;
-        hipError_t e2 = hipMalloc((void**)&idx->dev.bloom.bits, bc);
-        if (e2 != hipSuccess) { set_error("hipMalloc of %zu bytes failed: %s", bc, hipGetErrorString(e2)); return MTG_ERR_NOMEM; }
+        HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, bc));
         HIP_TRY(hipMemsetAsync(idx->dev.bloom.bits, 0, bc, 0));
     }
     HIP_TRY(hipMemsetAsync(idx->dev.adj.slots, 0, ba, 0));
@@ -557,62 +636,113 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
     idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
     return MTG_OK;
 }
-static void free_tables(mtg_index* idx)
+
+/* Unitig store of a finished index (every k-mer inserted, every lookahead written): chain starts -> one walk per start -> sequences ->
+ * abundances and junction pointers (mtg_dev.h: us_*).  Also fills nb_solid_kmers / nb_branching from the table itself.
+ * MTG_NO_UNITIGS=1 (test hook) leaves the index with inline lookaheads only. */
+static int build_unitigs(mtg_index* idx)
 {
-    if (idx->dev.adj.slots) (void)hipFree(idx->dev.adj.slots);
-    if (idx->dev.abnd.slots) (void)hipFree(idx->dev.abnd.slots);
-    if (idx->dev.bloom.bits) (void)hipFree(idx->dev.bloom.bits);
-    idx->dev.adj.slots = idx->dev.abnd.slots = nullptr;
-    idx->dev.bloom.bits = nullptr;
+    DevBuf d_cnt, d_starts, d_rec;
+    HIP_TRY(d_cnt.alloc(64));
+    HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_us_starts, dim3(blocks), dim3(256), 0, 0, idx->dev, d_cnt.as<unsigned long long>(), (uint64_t*)nullptr, 0ull);
+    HIP_TRY(hipGetLastError());
+    unsigned long long cnt[8];
+    HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
+    idx->info.nb_solid_kmers = cnt[2];
+    idx->info.nb_branching = cnt[1];
+    idx->info.nb_unitigs = 0;
+    idx->info.unitig_bytes = 0;
+    const unsigned long long n_starts = cnt[0];
+    if (n_starts == 0 || getenv("MTG_NO_UNITIGS")) return MTG_OK;
+    HIP_TRY(d_starts.alloc(n_starts * 8));
+    hipLaunchKernelGGL(k_us_starts, dim3(blocks), dim3(256), 0, 0, idx->dev, d_cnt.as<unsigned long long>(), d_starts.as<uint64_t>(), n_starts);
+    HIP_TRY(hipGetLastError());
+    const unsigned long long rec_cap = n_starts / 2 + 1; /* two starts per stored unitig (one per strand) */
+    HIP_TRY(d_rec.alloc(rec_cap * sizeof(UsRec)));
+    HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+    hipLaunchKernelGGL(k_us_plan, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, idx->dev, d_starts.as<uint64_t>(), n_starts, d_cnt.as<unsigned long long>(), d_rec.as<UsRec>(), rec_cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
+    const unsigned long long n_words = cnt[0], n_rec = cnt[1];
+    if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
+    d_starts.alloc(0);
+    if (n_rec == 0) return MTG_OK;
+    /* one word of padding: a k-mer read may look one word past the sequence it belongs to */
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.words, (n_words + 2) * 8));
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, (n_words + 2) * 32));
+    HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + 2) * 8, 0));
+    HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + 2) * 32, 0));
+    idx->dev.us.nwords = n_words;
+    idx->dev.us.nunitigs = n_rec;
+    hipLaunchKernelGGL(k_us_emit, dim3((unsigned)((n_rec + 63) / 64)), dim3(64), 0, 0, idx->dev, d_rec.as<UsRec>(), n_rec);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_us_link, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev, d_rec.as<UsRec>(), n_rec);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    idx->info.nb_unitigs = n_rec;
+    idx->info.unitig_bytes = (n_words + 2) * 40;
+    idx->info.device_bytes += idx->info.unitig_bytes;
+    return MTG_OK;
 }
 
 int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
 {
     if (int rc = ensure_device()) return rc;
     if (k < 11 || k > 31 || !out || (n && (!canon_kmers || !abundance))) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    mtg_index* idx = new mtg_index();
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
     idx->dev.k = k;
     HIP_TRY(hipGetDevice(&idx->device));
-    uint64_t* d_k = nullptr;
-    uint32_t* d_a = nullptr;
-    unsigned long long* d_cnt = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_k, (n + 1) * 8));
-    HIP_TRY(hipMalloc((void**)&d_a, (n + 1) * 4));
-    HIP_TRY(hipMalloc((void**)&d_cnt, 4 * 8));
-    HIP_TRY(hipMemcpy(d_k, canon_kmers, n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_a, abundance, n * 4, hipMemcpyHostToDevice));
+    DevBuf d_k, d_a, d_cnt;
+    HIP_TRY(d_cnt.alloc(4 * 8));
+    /* the k-mers go up in pieces (a saved human-size index is 36 GB of them) and each piece is inserted as it arrives */
+    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), (size_t)1 << 26);
+    HIP_TRY(d_k.alloc(piece * 8));
+    HIP_TRY(d_a.alloc(piece * 4));
     double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
     int rc = MTG_OK;
     for (int attempt = 0; attempt < 6; attempt++) {
+        free_tables(idx);
         rc = alloc_tables(idx, n, load);
-        if (rc) break;
-        HIP_TRY(hipMemset(d_cnt, 0, 32));
-        const int blocks = (int)std::min<size_t>((n + 255) / 256 + 1, 256 * 16);
-        hipLaunchKernelGGL(k_insert_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, d_a, n, d_cnt);
+        if (rc) return rc;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        for (size_t off = 0; off < n; off += piece) {
+            const size_t m = std::min(piece, n - off);
+            HIP_TRY(hipMemcpy(d_k.p, canon_kmers + off, m * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_a.p, abundance + off, m * 4, hipMemcpyHostToDevice));
+            const int blocks = (int)std::min<size_t>((m + 255) / 256 + 1, 256 * 16);
+            hipLaunchKernelGGL(k_insert_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(), m, d_cnt.as<unsigned long long>());
+            HIP_TRY(hipGetLastError());
+        }
         unsigned long long cnt[4];
-        HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
         if (!cnt[0]) {
-            hipLaunchKernelGGL(k_lookahead_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, n);
-            hipLaunchKernelGGL(k_count_branching, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, n, d_cnt);
-            HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
-            idx->info.nb_solid_kmers = cnt[1];
-            idx->info.nb_branching = cnt[2];
+            for (size_t off = 0; off < n; off += piece) { /* lookaheads need every k-mer in place: a second sweep over the pieces */
+                const size_t m = std::min(piece, n - off);
+                if (n > piece) {
+                    HIP_TRY(hipMemcpy(d_k.p, canon_kmers + off, m * 8, hipMemcpyHostToDevice));
+                }
+                const int blocks = (int)std::min<size_t>((m + 255) / 256 + 1, 256 * 16);
+                hipLaunchKernelGGL(k_lookahead_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), m);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipDeviceSynchronize());
             rc = MTG_OK;
             break;
         }
-        free_tables(idx);
         load *= 0.7;
         rc = MTG_ERR_OVERFLOW;
         set_error("index bucket displacement overflow");
     }
-    (void)hipFree(d_k);
-    (void)hipFree(d_a);
-    (void)hipFree(d_cnt);
-    if (rc) { free_tables(idx); delete idx; return rc; }
+    if (rc) return rc;
+    if (int rc2 = build_unitigs(idx)) return rc2;
     idx->info.k = k;
     idx->info.abundance_min = 0;
     idx->info.abundance_auto = -1;
-    *out = idx;
+    *out = g.release();
     return MTG_OK;
 }
 
@@ -620,41 +750,73 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
                              uint32_t abund_lo, uint32_t abund_span, mtg_index** out)
 {
     if (int rc = ensure_device()) return rc;
-    if (k < 11 || k > 31 || !out || !d_words || !d_word_off || !d_len) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    mtg_index* idx = new mtg_index();
+    if (k < 11 || k > 31 || !out || (nseq && (!d_words || !d_word_off || !d_len))) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
     idx->dev.k = k;
     HIP_TRY(hipGetDevice(&idx->device));
-    unsigned long long* d_cnt = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_cnt, 32));
+    DevBuf d_cnt;
+    HIP_TRY(d_cnt.alloc(32));
     double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
     int rc = MTG_OK;
     for (int attempt = 0; attempt < 6; attempt++) {
+        free_tables(idx);
         rc = alloc_tables(idx, total_kmers_ub, load);
-        if (rc) break;
-        HIP_TRY(hipMemset(d_cnt, 0, 32));
+        if (rc) return rc;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        if (nseq == 0) break; /* an empty graph: nothing to launch (a grid of zero blocks is an error that would surface later) */
         const int blocks = (int)std::min<size_t>(nseq, 256 * 32);
-        hipLaunchKernelGGL(k_insert_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq, abund_lo, abund_span, d_cnt);
+        hipLaunchKernelGGL(k_insert_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq, abund_lo, abund_span, d_cnt.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
         unsigned long long cnt[4];
-        HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
         if (!cnt[0]) {
             hipLaunchKernelGGL(k_lookahead_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq);
+            HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
-            idx->info.nb_solid_kmers = cnt[1];
-            idx->info.nb_branching = ~0ull; /* not computed on this path */
             rc = MTG_OK;
             break;
         }
-        free_tables(idx);
         load *= 0.7;
         rc = MTG_ERR_OVERFLOW;
         set_error("index bucket displacement overflow");
     }
-    (void)hipFree(d_cnt);
-    if (rc) { free_tables(idx); delete idx; return rc; }
+    if (rc) return rc;
+    if (int rc2 = build_unitigs(idx)) return rc2;
     idx->info.k = k;
     idx->info.abundance_min = (int)abund_lo;
     idx->info.abundance_auto = -1;
-    *out = idx;
+    *out = g.release();
+    return MTG_OK;
+}
+
+/* the solid k-mers of an index and their abundances, read back from its tables (for the index writer), in pieces of at most `piece`
+ * k-mers handed to sink(kmers, abundances, count) */
+int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink)
+{
+    if (int rc = use_device_of(idx)) return rc;
+    const uint64_t n = idx->info.nb_solid_kmers;
+    DevBuf d_k, d_a, d_cur;
+    HIP_TRY(d_k.alloc((n + 1) * 8));
+    HIP_TRY(d_a.alloc((n + 1) * 4));
+    HIP_TRY(d_cur.alloc(8));
+    HIP_TRY(hipMemset(d_cur.p, 0, 8));
+    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+    hipLaunchKernelGGL(k_abnd_export, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(),
+                       d_cur.as<unsigned long long>(), (unsigned long long)n);
+    HIP_TRY(hipGetLastError());
+    unsigned long long got = 0;
+    HIP_TRY(hipMemcpy(&got, d_cur.p, 8, hipMemcpyDeviceToHost));
+    if (got != n) { set_error("index export: %llu k-mers in the table, %llu expected", got, (unsigned long long)n); return MTG_ERR_FORMAT; }
+    const size_t piece = (size_t)1 << 24;
+    std::vector<uint64_t> hk(std::min<uint64_t>(n, piece));
+    std::vector<uint32_t> ha(hk.size());
+    for (uint64_t off = 0; off < n; off += piece) {
+        const size_t m = (size_t)std::min<uint64_t>(piece, n - off);
+        HIP_TRY(hipMemcpy(hk.data(), d_k.as<uint64_t>() + off, m * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ha.data(), d_a.as<uint32_t>() + off, m * 4, hipMemcpyDeviceToHost));
+        if (!sink(hk.data(), ha.data(), m)) { set_error("index export: the writer failed"); return MTG_ERR_IO; }
+    }
     return MTG_OK;
 }
 
@@ -677,35 +839,24 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
     if (int rc = use_device_of(idx)) return rc;
     if (!idx || (n && !kmers)) { set_error("null argument"); return MTG_ERR_ARG; }
     if (n == 0) return MTG_OK;
-    uint64_t* d_k = nullptr;
-    uint32_t* d_a = nullptr;
-    uint8_t *d_s = nullptr, *d_p = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_k, n * 8));
-    HIP_TRY(hipMemcpy(d_k, kmers, n * 8, hipMemcpyHostToDevice));
-    if (abund) HIP_TRY(hipMalloc((void**)&d_a, n * 4));
-    if (succ) HIP_TRY(hipMalloc((void**)&d_s, n));
-    if (pred) HIP_TRY(hipMalloc((void**)&d_p, n));
+    DevBuf d_k, d_a, d_s, d_p;
+    HIP_TRY(d_k.alloc(n * 8));
+    HIP_TRY(hipMemcpy(d_k.p, kmers, n * 8, hipMemcpyHostToDevice));
+    if (abund) HIP_TRY(d_a.alloc(n * 4));
+    if (succ) HIP_TRY(d_s.alloc(n));
+    if (pred) HIP_TRY(d_p.alloc(n));
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_query, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k, n, d_a, d_s, d_p);
+    hipLaunchKernelGGL(k_query, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), n, abund ? d_a.as<uint32_t>() : nullptr, succ ? d_s.as<uint8_t>() : nullptr,
+                       pred ? d_p.as<uint8_t>() : nullptr);
     HIP_TRY(hipGetLastError());
-    if (abund) HIP_TRY(hipMemcpy(abund, d_a, n * 4, hipMemcpyDeviceToHost));
-    if (succ) HIP_TRY(hipMemcpy(succ, d_s, n, hipMemcpyDeviceToHost));
-    if (pred) HIP_TRY(hipMemcpy(pred, d_p, n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_k);
-    if (d_a) (void)hipFree(d_a);
-    if (d_s) (void)hipFree(d_s);
-    if (d_p) (void)hipFree(d_p);
+    if (abund) HIP_TRY(hipMemcpy(abund, d_a.p, n * 4, hipMemcpyDeviceToHost));
+    if (succ) HIP_TRY(hipMemcpy(succ, d_s.p, n, hipMemcpyDeviceToHost));
+    if (pred) HIP_TRY(hipMemcpy(pred, d_p.p, n, hipMemcpyDeviceToHost));
     return MTG_OK;
 }
 
 /* ------------------------------------------------------------------------------------------------ fill batches */
 namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <typename T> T* as() { return (T*)p; }
-};
 /* a view on a cached, grow-only workspace buffer of the index (no hipMalloc / hipFree on the steady-state path) */
 struct WsBuf {
     void* p = nullptr;

@@ -39,7 +39,6 @@ struct SlotRec {
     GapOut o;
     PostOut p;
     uint32_t nw, nc;
-    uint32_t pad_;
     uint64_t wbase, cbase;
 };
 
@@ -112,8 +111,8 @@ MTG_DEV uint64_t le_kmer(const uint64_t* w, uint32_t j, uint64_t mk)
  * dependent round trip to memory per 64 positions (which is what bound this kernel: 47 round trips for a 3 kb contig). */
 enum { POST_TILE = 512 }; /* words = 16384 nucleotides */
 
-/* hist: 256 zeroed counters shared by the lanes; tile: POST_TILE + 2 words (both LDS on the device) */
-MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, uint64_t* tile, PostOut& out)
+/* hist: 256 zeroed counters shared by the lanes; tile: POST_TILE + 2 words; blk: 64 words (all LDS on the device) */
+MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, uint64_t* tile, uint64_t* blk, PostOut& out)
 {
     const int k = ix.k;
     const uint64_t mk = kmask(k);
@@ -190,7 +189,9 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     out.pos = pos0; out.errors = err0; out.target = tgt0;
     out.ab_sum = out.ab_n = out.med_hi = out.med_lo = 0;
     if (!(has0 && T.fast_ok)) return;
-    if (pos0 <= (uint32_t)k - 1) { out.fast = 2; return; } /* src/GraphAnalysis.cpp:404-407: nothing left of the first node */
+    /* src/GraphAnalysis.cpp:404-407 (pos <= k-1: nothing left of the first node) and :410-423 with pos == k (an empty substr): the
+     * sequence is empty and dropped by `sequence.length() > 0` (:449), so the gap has a terminal node but no solution */
+    if (pos0 <= (uint32_t)k) { out.fast = 2; return; }
     /* coverage of source + fill = the k-mers of contig0[0:pos0] */
     const uint64_t* w0 = words + cstart[0];
     const uint32_t nk = pos0 - (uint32_t)k + 1;
@@ -203,13 +204,60 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
         w0 = tile;
     }
     uint32_t sum = 0, lines = 0;
-    for (uint32_t j = lane; j < nk; j += MTG_NLANES) {
-        Kmer x;
-        x.r = le_kmer(w0, j, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk); /* little-endian image = reversed order: complementing it gives revcomp */
-        x.f = revcomp(x.r, k);
-        const uint32_t a = abundance(ix, x, lines);
-        sum += a;
-        hist_add(hist, a);
+    const uint64_t cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    if (ix.us.nwords == 0) {
+        for (uint32_t j = lane; j < nk; j += MTG_NLANES) {
+            Kmer x;
+            x.r = le_kmer(w0, j, mk) ^ cmpl; /* little-endian image = reversed order: complementing it gives revcomp */
+            x.f = revcomp(x.r, k);
+            const uint32_t a = abundance(ix, x, lines);
+            sum += a;
+            hist_add(hist, a);
+        }
+    } else {
+        /* The k-mers of a contig follow the unitigs of the graph, whose abundances lie in the store one byte per k-mer: per block of 64
+         * consecutive k-mers ONE look-up (the ADJ entry of the junction behind the block's first k-mer) tells where the block sits in
+         * the store; every lane then reads its k-mer there, checks that it is the one it holds (the block may run past the end of the
+         * unitig, or through a bubble), and takes the abundance byte next to it.  Whatever is not confirmed is looked up in the hash
+         * table as before, so the result is exact whatever the pointers say. */
+        const uint64_t mk1 = kmask(k - 1);
+        for (uint32_t r0 = 0; r0 < nk; r0 += 64u * 64u) {
+            const uint32_t nblk = (nk - r0 + 63u) / 64u < 64u ? (nk - r0 + 63u) / 64u : 64u;
+            wave_sync(); /* the previous round's block table has been read */
+            for (uint32_t b = lane; b < nblk; b += MTG_NLANES) {
+                Kmer x;
+                x.r = le_kmer(w0, r0 + 64u * b, mk) ^ cmpl;
+                x.f = revcomp(x.r, k);
+                uint64_t aux;
+                const uint64_t s = x.f & mk1, rs = x.r >> 2;
+                adj_get(ix.adj, s <= rs ? s : rs, lines, aux);
+                blk[b] = up_is(aux) ? up_resolve(aux, s <= rs) : 0ull;
+            }
+            wave_sync();
+            for (uint32_t b = 0; b < nblk; b++) {
+                const uint64_t up = blk[b];
+                const uint64_t hdr = up_hdr(up);
+                const uint32_t off = up_off(up);
+                const bool bwd = up_bwd(up);
+                const uint32_t len_k = up ? (uint32_t)ix.us.words[hdr] - (uint32_t)k + 1 : 0u;
+                for (uint32_t t = lane; t < 64u; t += MTG_NLANES) {
+                    const uint32_t j = r0 + 64u * b + t;
+                    if (j >= nk) break;
+                    Kmer x;
+                    x.r = le_kmer(w0, j, mk) ^ cmpl;
+                    x.f = revcomp(x.r, k);
+                    uint32_t a = 0;
+                    const uint32_t idx = bwd ? off - t : off - 1u + t; /* the k-mer's place in the unitig if the walk stayed on it */
+                    if (up && (bwd ? t <= off : idx < len_k)) {
+                        const uint64_t sr = le_kmer(ix.us.words + hdr + 1, idx, mk) ^ cmpl;
+                        if (sr == (bwd ? x.f : x.r)) a = ix.us.ab[(hdr + 1) * 32 + idx];
+                    }
+                    if (a == 0) a = abundance(ix, x, lines);
+                    sum += a;
+                    hist_add(hist, a);
+                }
+            }
+        }
     }
     sum = wave_sum32(sum);
     wave_sync();

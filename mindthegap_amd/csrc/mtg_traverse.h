@@ -875,6 +875,7 @@ struct GapOut {
     uint32_t lines;
     uint32_t total_nt;
     uint32_t n_words; /* words of the contig arena in use */
+    uint32_t store_reads; /* reads of the unitig store (headers and sequence words) */
 };
 
 /* the swf pattern R (gapFillFromSource's targetSequence, src/Filler.cpp:884): 2-bit packed, 32 nt per
@@ -959,6 +960,39 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     Kmer pv;
     pv.f = pv.r = 0;
     uint32_t pv_seq = 0, pv_cnt = 0;
+    /* A run: the rest of a unitig, announced by the pointer in the entry of one of its junctions.  While it lasts the walk gets its
+     * neighbourhoods -- single out-edge, in-degree 1, lookahead of up to MTG_LA_MAX nucleotides -- from sequential reads of the unitig
+     * store instead of one dependent random read per MTG_LA_MAX + 1 nodes; everything that consumes them is the lookahead code. */
+    const UStore us = ix.us;
+    uint64_t run_pos = 0;              /* store position of the next nucleotide of the run */
+    uint32_t run_left = 0, run_take = 0; /* nucleotides left / handed out with the last neighbourhood */
+    bool run_bwd = false;
+    uint32_t store_reads = 0;
+    /* neighbourhood of the node the walk stands on */
+    auto next_adj = [&](const Kmer& node) -> Adj {
+        if (run_left) { /* the last neighbourhood came from the run and all its nucleotides have been taken */
+            run_left -= run_take;
+            run_pos = run_bwd ? run_pos - run_take : run_pos + run_take;
+        }
+        Adj r;
+        if (run_left == 0) {
+            r = adj_right_t(adj, node, mk1, lines);
+            if (!(r.up && popc4(r.out) == 1 && popc4(r.in) == 1)) { run_take = 0; return r; }
+            us_run(us, r.up, k, run_pos, run_left);
+            run_bwd = up_bwd(r.up);
+            store_reads++;
+        } else {
+            r.out = 0; /* filled below */
+            r.in = 1u << ((uint32_t)(node.f >> (2 * (k - 1))) & 3u);
+        }
+        run_take = run_left < (uint32_t)MTG_LA_MAX + 1 ? run_left : (uint32_t)MTG_LA_MAX + 1;
+        const uint32_t seq = us_peek(us.words, run_pos, run_take, run_bwd);
+        store_reads++;
+        r.out = 1u << (seq & 3u);
+        r.la = (run_take - 1) | ((seq >> 2) << 4);
+        r.up = 0;
+        return r;
+    };
     for (;;) {
         if (!in_contig) {
             if (!(head < tail) || W.status != GAP_OK) break;
@@ -976,7 +1010,8 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             start_lo = (uint32_t)cur.f;
             start_rc_lo = (uint32_t)cur.r;
             watch_r = r_is_kmer && node_depth > k; /* found_R only matters there (see phase E) */
-            a = adj_right_t(adj, cur, mk1, lines);
+            run_left = 0;
+            a = next_adj(cur);
             in_contig = true;
         }
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
@@ -1042,7 +1077,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
                 }
                 if (end_contig) break;
             }
-            const Adj a2 = adj_right_t(adj, cur, mk1, lines);
+            const Adj a2 = next_adj(cur);
             if (!(popc4(a2.out) == 1 && indeg == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
             a = a2;
             if (canon(cur) == start_c || len > MAXLEN || ovf || W.status) { end_contig = true; break; } /* looping / limits */
@@ -1071,7 +1106,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
                     if (canon(cur) == start_c) looping = true;
                 }
                 if (looping || len > MAXLEN || ovf || W.status) end_contig = true;
-                else a = adj_right_t(adj, cur, mk1, lines);
+                else a = next_adj(cur);
             }
         }
         MTG_T1(t_b, 1);
@@ -1118,6 +1153,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     out.n_contigs = nb;
     out.status = W.status;
     out.lines = W.lines + lines;
+    out.store_reads = store_reads;
     out.total_nt = total_nt;
     out.n_words = wpos;
 }

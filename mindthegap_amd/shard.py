@@ -60,10 +60,14 @@ class PipelinedGather:
             self.stream = None
         self.recv = [[torch.empty(n, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] for _ in range(depth)] if self.rank == dst else None
         self.work = [None] * depth
-        self.i = 0
         self.cur = 0
         self.done = -1  # buffer index of the last submitted step
         self.lock = threading.Lock()
+        # ownership of the staging buffers: a buffer is free, or owned by a caller (acquire .. submit), or in flight (its gather queued);
+        # acquire() hands out only a buffer nobody owns, waiting for the oldest one in flight when none is free
+        self.cond = threading.Condition(self.lock)
+        self.free = list(range(depth))
+        self.in_flight = []  # submitted buffers, oldest first
 
     def _wait(self, j):
         if self.work[j] is not None:
@@ -78,10 +82,16 @@ class PipelinedGather:
     def acquire(self):
         """(j, numpy view of the payload area of staging buffer j); the buffer belongs to the caller until submit(nbytes, j).
         Thread-safe: several steps may be in flight (depth must exceed their number for the gathers to overlap with them)."""
-        with self.lock:
-            j = self.i % self.depth
-            self.i += 1
-            self._wait(j)
+        with self.cond:
+            while True:
+                if self.free:
+                    j = self.free.pop(0)
+                    break
+                if self.in_flight:
+                    j = self.in_flight.pop(0)  # the oldest gather: once it is done its buffers may be written again
+                    self._wait(j)
+                    break
+                self.cond.wait()  # every buffer is in the hands of another caller: one of them will submit
         return j, self.stage[j].numpy()[self.HEADER:]
 
     def buffer(self):
@@ -94,7 +104,7 @@ class PipelinedGather:
         if nbytes + self.HEADER > self.stage[j].numel():
             raise ValueError("payload of %d bytes exceeds the agreed capacity" % nbytes)
         self.stage[j].numpy()[: self.HEADER].view(np.int64)[0] = nbytes
-        with self.lock:  # collectives are issued one at a time, in the same number on every rank
+        with self.cond:  # collectives are issued one at a time, in the same number on every rank
             if self.on_gpu:
                 self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
                 with self.torch.cuda.stream(self.stream):
@@ -103,10 +113,15 @@ class PipelinedGather:
             else:
                 self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
             self.done = j
+            self.in_flight.append(j)  # the caller's ownership ends here: copy and gather are queued
+            self.cond.notify()
 
     def drain(self):
-        for j in range(self.depth):
-            self._wait(j)
+        with self.cond:
+            while self.in_flight:
+                j = self.in_flight.pop(0)
+                self._wait(j)
+                self.free.append(j)
         if self.on_gpu:
             self.torch.cuda.synchronize(self.dev)
 

@@ -6,6 +6,7 @@
  * library, which requires a HIP device.
  */
 #include "../../mindthegap_amd/csrc/mtg_hostutil.h"
+#include "emu_us.h"
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -16,6 +17,7 @@ using namespace mtg;
 struct EmuIndex {
     Index ix;
     std::vector<uint64_t> adj_slots, abnd_slots;
+    EmuUStore us;
 };
 
 extern "C" {
@@ -33,10 +35,12 @@ void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, 
         e->ix.abnd.slots = e->abnd_slots.data();
         e->ix.bloom.bits = nullptr;
         e->ix.bloom.nblocks = 0;
+        e->ix.us = UStore{};
         int fail = 0;
         for (size_t i = 0; i < n; i++) fail |= index_insert(e->ix, kmers[i], counts[i]) & 1;
         if (!fail) {
             for (size_t i = 0; i < n; i++) { Kmer x = make_kmer(kmers[i], k); build_lookahead(e->ix, x); Kmer y; y.f = x.r; y.r = x.f; build_lookahead(e->ix, y); }
+            emu_build_unitigs(e->ix, e->us);
             return e;
         }
         delete e;

@@ -6,6 +6,9 @@
  * (and sanitizers) without a GPU.  The product library never contains this file.
  */
 #include "../../mindthegap_amd/csrc/mtg_internal.h"
+#include "emu_us.h"
+#include <map>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -23,6 +26,9 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 void stats_store(const mtg_batch_stats& s) { g_stats = s; }
+
+static std::mutex g_us_mtx;
+static std::map<const mtg_index*, EmuUStore*> g_us; /* storage of the unitig stores of the live indexes */
 
 int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k, mtg_index** out)
 {
@@ -50,6 +56,12 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
             }
             idx->info.k = k; idx->info.nb_solid_kmers = created; idx->info.nb_branching = nbr; idx->info.abundance_auto = -1;
             idx->info.bloom_blocks = idx->dev.bloom.nblocks; idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
+            {
+                EmuUStore* st = new EmuUStore();
+                emu_build_unitigs(idx->dev, *st);
+                std::lock_guard<std::mutex> lk(g_us_mtx);
+                g_us[idx] = st;
+            }
             *out = idx;
             return MTG_OK;
         }
@@ -61,6 +73,7 @@ void index_release(mtg_index* idx)
 {
     if (!idx) return;
     index_forget_host_copy(idx);
+    { std::lock_guard<std::mutex> lk(g_us_mtx); auto it = g_us.find(idx); if (it != g_us.end()) { delete it->second; g_us.erase(it); } }
     free(idx->dev.adj.slots); free(idx->dev.abnd.slots); free(idx->dev.bloom.bits);
     for (Workspace& w : idx->ws) for (void* h : w.hptr) free(h);
     delete idx;
@@ -233,7 +246,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 T.fast_ok = in.fast_ok[g];
                 uint32_t hist[256] = {0};
                 std::vector<uint64_t> tile(POST_TILE + 2);
-                post_gap(idx->dev, cfg, S, d.o, T, hist, tile.data(), d.po);
+                uint64_t blk[64];
+                post_gap(idx->dev, cfg, S, d.o, T, hist, tile.data(), blk, d.po);
                 copy_plan(d.o, d.po, in.want_all_contigs, d.nw, d.nc);
                 d.words.assign(s_words(cfg, S), s_words(cfg, S) + d.nw);
                 d.meta.resize(5 * (size_t)d.nc);
@@ -265,7 +279,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
             for (uint32_t s = mq; s-- > 0;) { /* room in the dense arrays in reverse slot order */
                 const SlotData& d = sd[s];
                 SlotRec& r = rec[s];
-                r.o = d.o; r.p = d.po; r.nw = d.nw; r.nc = d.nc; r.pad_ = 0; r.wbase = (decltype(r.wbase))wb; r.cbase = (decltype(r.cbase))cb;
+                r.o = d.o; r.p = d.po; r.nw = d.nw; r.nc = d.nc; r.wbase = (decltype(r.wbase))wb; r.cbase = (decltype(r.cbase))cb;
                 if (d.o.status != GAP_OK) { r.nw = r.nc = 0; continue; }
                 for (uint32_t i = 0; i < d.nw; i++) hw[wb + i] = d.words[i];
                 for (size_t i = 0; i < d.meta.size(); i++) hm[5 * cb + i] = d.meta[i];

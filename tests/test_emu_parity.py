@@ -339,6 +339,9 @@ def _edge_case_files(tmp_path):
         ("bkpt12_chr1_pos_120_fuzzy_0_HOM", g[2000 - 31 + 9:2000 + 9], g[6000:6031], ""),  # long walk through SNP bubbles
         ("bkpt13_chr1_pos_130_fuzzy_0_HOM", g[2000 - 31 + 9:2000 + 9], g[6000:6031].lower(), ""),  # lowercase anchor: matched case-insensitively, never by strstr
         ("bkpt14_chr1_pos_140_fuzzy_0_HOM", g[2000 - 31 + 9:2000 + 9], g[6000:6040], ""),  # anchor record longer than k
+        ("bkpt15_chr1_pos_150_fuzzy_0_HOM", donor[1000 - 31:1000], donor[1000:1031], ""),  # adjacent anchors (target at pos == k): empty fill, no record
+        ("bkpt16_chr1_pos_160_fuzzy_0_HOM", donor[1000 - 31:1000], donor[1000 - 10:1021], ""),  # overlapping anchors (pos < k)
+        ("bkpt17_chr1_pos_170_fuzzy_0_HOM", donor[1000 - 31:1000], donor[1001:1032], ""),  # one nucleotide between the anchors
     ]
     bk = str(tmp_path / "edge.breakpoints")
     with open(bk, "w") as f:
