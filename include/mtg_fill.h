@@ -176,6 +176,12 @@ typedef struct mtg_batch_stats {
     uint64_t n_launches;
     uint64_t n_retried_gaps;     /* gaps re-run in a larger scratch tier */
     uint64_t contig_nt;          /* nucleotides of all contigs built */
+    uint64_t store_runs;         /* runs of nucleotides the traversal took from the unitig store (one header read each) */
+    uint64_t run_nt;             /* nucleotides of the contigs that came out of the unitig store */
+    uint64_t post_lines;         /* index buckets read by the coverage pass of k_post */
+    uint64_t contig_words;       /* 8-byte words of contig arena the traversal wrote */
+    uint64_t coverage_kmers;     /* k-mers whose abundance the coverage pass of k_post needed */
+    uint64_t dense_words;        /* 8-byte words k_post copied into the dense result arrays */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);
 

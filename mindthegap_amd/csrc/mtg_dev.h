@@ -447,6 +447,21 @@ MTG_DEV uint32_t us_peek(const uint64_t* words, uint64_t pos, uint32_t n, bool b
     if (bwd) r = (rev_fields32(r) >> (32u - 2u * n)) ^ (0xAAAAAAAAu & mask);
     return r;
 }
+/* the 32 two-bit fields of x in reverse order */
+MTG_DEV uint64_t rev_fields64(uint64_t x) { return ((uint64_t)rev_fields32((uint32_t)x) << 32) | (uint64_t)rev_fields32((uint32_t)(x >> 32)); }
+/* the same for up to 32 nucleotides, as a 64-bit word */
+MTG_DEV uint64_t us_peek64(const uint64_t* words, uint64_t pos, uint32_t n, bool bwd)
+{
+    if (n == 0) return 0ull;
+    const uint64_t lo = bwd ? pos - (n - 1) : pos;
+    const uint32_t sh = 2u * (uint32_t)(lo & 31u);
+    uint64_t v = words[lo >> 5] >> sh;
+    if ((uint32_t)(lo & 31u) + n > 32u) v |= words[(lo >> 5) + 1] << (64u - sh); /* sh > 0 here */
+    const uint64_t mask = n >= 32u ? ~0ull : ((1ull << (2u * n)) - 1ull);
+    v &= mask;
+    if (bwd) v = (rev_fields64(v) >> (64u - 2u * n)) ^ (0xAAAAAAAAAAAAAAAAULL & mask);
+    return v;
+}
 /* the simple path behind a pointer: position of its first nucleotide (the junction's out-edge) and how many nucleotides follow the
  * junction up to the end of the unitig in the walking direction (>= 1) */
 MTG_DEV void us_run(const UStore& us, uint64_t up, int k, uint64_t& pos, uint32_t& left)
@@ -712,6 +727,8 @@ MTG_DEV void us_plan_start(const Index& ix, const Kmer& x, unsigned long long* c
     Kmer end;
     const uint32_t n = us_walk(ix, x, end, lines, UsNoSink());
     if (n < 2) return;
+    if (n >= MTG_US_MAX_LEN - (uint32_t)ix.k) return; /* cut short by the offset range: not stored (its k-mers keep their lookaheads), so that the
+                                                        stored unitigs are whole chains and no canonical k-mer lies in two of them */
     /* the reverse complement of the chain starts with rc(end): the one whose first k-mer has the smaller canonical value is stored; the
      * canonical k-mers of a chain are distinct, so there is no tie between different k-mers */
     if (!(canon(x) < canon(end))) return;

@@ -328,7 +328,7 @@ __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __r
 /* terminal-node search + coverage of the single-contig solution, one wave per gap; then the wave reserves room in the chunk's dense
  * arrays (two atomic counters) and copies there what the host needs of this gap: nw leading arena words and, for nc contigs, their
  * (length, first word) and terminal info.  counters: [0] words, [1] contig metadata entries */
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
                                              uint32_t want_all, unsigned long long* counters, SlotRec* recs, uint64_t* dense_words, uint32_t* dense_meta,
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) k_
         __syncthreads();
         const GapOut o = outs[slot];
         PostOut po;
-        po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = 0;
+        po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = po.lines = 0;
         GapScratch S;
         S.z = nullptr;
         S.v = nullptr;
@@ -668,13 +668,14 @@ static int build_unitigs(mtg_index* idx)
     HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
     const unsigned long long n_words = cnt[0], n_rec = cnt[1];
     if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
-    d_starts.alloc(0);
+    (void)d_starts.alloc(0);
     if (n_rec == 0) return MTG_OK;
-    /* one word of padding: a k-mer read may look one word past the sequence it belongs to */
-    HIP_TRY(hipMalloc((void**)&idx->dev.us.words, (n_words + 2) * 8));
-    HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, (n_words + 2) * 32));
-    HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + 2) * 8, 0));
-    HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + 2) * 32, 0));
+    /* a few words of padding: the coverage pass may look up to 64 + k nucleotides past the end of a unitig */
+    const unsigned long long pad = 8;
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, (n_words + pad) * 32));
+    HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + pad) * 8, 0));
+    HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + pad) * 32, 0));
     idx->dev.us.nwords = n_words;
     idx->dev.us.nunitigs = n_rec;
     hipLaunchKernelGGL(k_us_emit, dim3((unsigned)((n_rec + 63) / 64)), dim3(64), 0, 0, idx->dev, d_rec.as<UsRec>(), n_rec);
@@ -683,7 +684,7 @@ static int build_unitigs(mtg_index* idx)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     idx->info.nb_unitigs = n_rec;
-    idx->info.unitig_bytes = (n_words + 2) * 40;
+    idx->info.unitig_bytes = (n_words + pad) * 40;
     idx->info.device_bytes += idx->info.unitig_bytes;
     return MTG_OK;
 }
@@ -1125,16 +1126,27 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                     st.d2h_ms += now_ms() - t0;
                     t0 = now_ms();
                     /* statistics and what needs another look: a serial scan of a part's records costs less than a parallel region */
-                    uint64_t nt_sum = 0, lines = 0;
+                    uint64_t nt_sum = 0, lines = 0, runs = 0, run_nt = 0, plines = 0, cwords = 0, cov = 0;
                     bool any_retry = false, any_general = false;
                     for (uint32_t s2 = 0; s2 < mq; s2++) {
                         lines += h_rec[s2].o.lines;
+                        runs += h_rec[s2].o.store_reads;
+                        run_nt += h_rec[s2].o.run_nt;
+                        cwords += h_rec[s2].o.n_words;
                         if (h_rec[s2].o.status != GAP_OK) { any_retry = true; continue; }
                         nt_sum += h_rec[s2].o.total_nt;
+                        plines += h_rec[s2].p.lines;
+                        cov += h_rec[s2].p.ab_n;
                         if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) any_general = true;
                     }
                     st.index_lines += lines;
                     st.contig_nt += nt_sum;
+                    st.store_runs += runs;
+                    st.run_nt += run_nt;
+                    st.post_lines += plines;
+                    st.contig_words += cwords;
+                    st.coverage_kmers += cov;
+                    st.dense_words += tw;
                     if (!identity) {
                         for (uint32_t s2 = 0; s2 < mq; s2++) {
                             if (h_rec[s2].o.status != GAP_OK) continue;

@@ -19,6 +19,7 @@ struct PostOut {
     uint32_t clen0;
     uint32_t ab_sum, ab_n;        /* coverage pass (fast == 1) */
     uint32_t med_hi, med_lo;      /* sorted[n/2], sorted[n/2-1] */
+    uint32_t lines;               /* index buckets read by the coverage pass (block look-ups + k-mers the store did not confirm) */
 };
 
 /* what to copy back for a gap: nw leading words of its arena, metadata of nc contigs (0 or all) */
@@ -187,7 +188,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     out.clen0 = o.n_contigs ? clen[0] : 0;
     out.fast = 0;
     out.pos = pos0; out.errors = err0; out.target = tgt0;
-    out.ab_sum = out.ab_n = out.med_hi = out.med_lo = 0;
+    out.ab_sum = out.ab_n = out.med_hi = out.med_lo = out.lines = 0;
     if (!(has0 && T.fast_ok)) return;
     /* src/GraphAnalysis.cpp:404-407 (pos <= k-1: nothing left of the first node) and :410-423 with pos == k (an empty substr): the
      * sequence is empty and dropped by `sequence.length() > 0` (:449), so the gap has a terminal node but no solution */
@@ -234,27 +235,39 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                 blk[b] = up_is(aux) ? up_resolve(aux, s <= rs) : 0ull;
             }
             wave_sync();
-            for (uint32_t b = 0; b < nblk; b++) {
-                const uint64_t up = blk[b];
-                const uint64_t hdr = up_hdr(up);
-                const uint32_t off = up_off(up);
-                const bool bwd = up_bwd(up);
-                const uint32_t len_k = up ? (uint32_t)ix.us.words[hdr] - (uint32_t)k + 1 : 0u;
+            /* four blocks at a time: the store reads of a lane (two words of sequence, one abundance byte per block) are independent of
+             * each other, so they are all issued before the first one is looked at */
+            for (uint32_t b0 = 0; b0 < nblk; b0 += 4) {
                 for (uint32_t t = lane; t < 64u; t += MTG_NLANES) {
-                    const uint32_t j = r0 + 64u * b + t;
-                    if (j >= nk) break;
-                    Kmer x;
-                    x.r = le_kmer(w0, j, mk) ^ cmpl;
-                    x.f = revcomp(x.r, k);
-                    uint32_t a = 0;
-                    const uint32_t idx = bwd ? off - t : off - 1u + t; /* the k-mer's place in the unitig if the walk stayed on it */
-                    if (up && (bwd ? t <= off : idx < len_k)) {
-                        const uint64_t sr = le_kmer(ix.us.words + hdr + 1, idx, mk) ^ cmpl;
-                        if (sr == (bwd ? x.f : x.r)) a = ix.us.ab[(hdr + 1) * 32 + idx];
+                    uint64_t sr[4];
+                    uint32_t av[4];
+                    bool in_store[4], bw[4];
+MTG_UNROLL
+                    for (uint32_t u = 0; u < 4; u++) {
+                        const uint32_t bb = b0 + u, j = r0 + 64u * bb + t;
+                        const uint64_t up = bb < nblk ? blk[bb] : 0ull;
+                        const uint32_t off = up_off(up);
+                        bw[u] = up_bwd(up);
+                        in_store[u] = up != 0ull && j < nk && (!bw[u] || t <= off);
+                        const uint32_t idx = bw[u] ? off - t : off - 1u + t; /* the k-mer's place in the unitig if the walk stayed on it */
+                        const uint64_t base = up_hdr(up) + 1;
+                        sr[u] = in_store[u] ? le_kmer(ix.us.words + base, idx, mk) ^ cmpl : 0ull;
+                        av[u] = in_store[u] ? (uint32_t)ix.us.ab[base * 32 + idx] : 0u;
                     }
-                    if (a == 0) a = abundance(ix, x, lines);
-                    sum += a;
-                    hist_add(hist, a);
+MTG_UNROLL
+                    for (uint32_t u = 0; u < 4; u++) {
+                        const uint32_t j = r0 + 64u * (b0 + u) + t;
+                        if (b0 + u >= nblk || j >= nk) continue;
+                        Kmer x;
+                        x.r = le_kmer(w0, j, mk) ^ cmpl;
+                        x.f = revcomp(x.r, k);
+                        /* the k-mer read from the store is this lane's k-mer (a read past the end of the unitig finds something else, or
+                         * a place where no k-mer starts: abundance byte 0) */
+                        uint32_t a = (in_store[u] && sr[u] == (bw[u] ? x.f : x.r)) ? av[u] : 0u;
+                        if (a == 0) a = abundance(ix, x, lines);
+                        sum += a;
+                        hist_add(hist, a);
+                    }
                 }
             }
         }
@@ -277,6 +290,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     out.ab_n = nk;
     out.med_hi = hi;
     out.med_lo = lo;
+    out.lines = wave_sum32(lines);
 }
 
 } // namespace mtg

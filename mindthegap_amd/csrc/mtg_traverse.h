@@ -875,7 +875,8 @@ struct GapOut {
     uint32_t lines;
     uint32_t total_nt;
     uint32_t n_words; /* words of the contig arena in use */
-    uint32_t store_reads; /* reads of the unitig store (headers and sequence words) */
+    uint32_t store_reads; /* runs taken from the unitig store (one header read each) */
+    uint32_t run_nt;      /* nucleotides of the contigs that came out of the store */
 };
 
 /* the swf pattern R (gapFillFromSource's targetSequence, src/Filler.cpp:884): 2-bit packed, 32 nt per
@@ -965,33 +966,132 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
      * store instead of one dependent random read per MTG_LA_MAX + 1 nodes; everything that consumes them is the lookahead code. */
     const UStore us = ix.us;
     uint64_t run_pos = 0;              /* store position of the next nucleotide of the run */
+    uint64_t run_base = 0;             /* store position of the first nucleotide of the run's unitig */
     uint32_t run_left = 0, run_take = 0; /* nucleotides left / handed out with the last neighbourhood */
     bool run_bwd = false;
-    uint32_t store_reads = 0;
+    uint32_t store_reads = 0, run_nt = 0;
+    /* index, in its unitig, of the k-mer the walk stands on while a run lasts (the run's next nucleotide extends that k-mer) */
+    auto run_idx = [&]() -> uint32_t { return run_bwd ? (uint32_t)(run_pos - run_base) + 1u : (uint32_t)(run_pos - run_base) - (uint32_t)k; };
+    /* the next nucleotides of the run as a neighbourhood with lookahead */
+    auto run_chunk = [&](const Kmer& node) -> Adj {
+        Adj r;
+        run_take = run_left < (uint32_t)MTG_LA_MAX + 1 ? run_left : (uint32_t)MTG_LA_MAX + 1;
+        const uint32_t seq = us_peek(us.words, run_pos, run_take, run_bwd);
+        run_nt += run_take;
+        r.out = 1u << (seq & 3u);
+        r.in = 1u << ((uint32_t)(node.f >> (2 * (k - 1))) & 3u);
+        r.la = (run_take - 1) | ((seq >> 2) << 4);
+        r.up = 0;
+        return r;
+    };
     /* neighbourhood of the node the walk stands on */
     auto next_adj = [&](const Kmer& node) -> Adj {
         if (run_left) { /* the last neighbourhood came from the run and all its nucleotides have been taken */
             run_left -= run_take;
             run_pos = run_bwd ? run_pos - run_take : run_pos + run_take;
         }
-        Adj r;
         if (run_left == 0) {
-            r = adj_right_t(adj, node, mk1, lines);
+            const Adj r = adj_right_t(adj, node, mk1, lines);
             if (!(r.up && popc4(r.out) == 1 && popc4(r.in) == 1)) { run_take = 0; return r; }
             us_run(us, r.up, k, run_pos, run_left);
             run_bwd = up_bwd(r.up);
+            run_base = (up_hdr(r.up) + 1) * 32;
             store_reads++;
-        } else {
-            r.out = 0; /* filled below */
-            r.in = 1u << ((uint32_t)(node.f >> (2 * (k - 1))) & 3u);
         }
-        run_take = run_left < (uint32_t)MTG_LA_MAX + 1 ? run_left : (uint32_t)MTG_LA_MAX + 1;
-        const uint32_t seq = us_peek(us.words, run_pos, run_take, run_bwd);
-        store_reads++;
-        r.out = 1u << (seq & 3u);
-        r.la = (run_take - 1) | ((seq >> 2) << 4);
-        r.up = 0;
-        return r;
+        return run_chunk(node);
+    };
+    /* Where, in the unitig store, the two k-mers sit that a walk along a simple path has to notice: the contig's start node (looping
+     * contig) and, below the first BFS level, the first k-mer of the target.  A k-mer followed by a junction inside a unitig is found
+     * through that junction's pointer (base = ~0: it is not).  The canonical k-mers of the stored unitigs are pairwise distinct, so
+     * a long run can only meet such a k-mer in its own unitig, at a position known beforehand; a k-mer that is the last of its unitig
+     * in its walking direction, or in no unitig, is never INSIDE a run (it can only be a run's last node, which the long step leaves to
+     * the step-by-step code). */
+    uint64_t start_base = ~0ull, r_base = ~0ull;
+    uint32_t start_idx = 0, r_idx = 0;
+    bool r_fwd = false, r_known = false;
+    auto locate = [&](const Adj& e, uint64_t& base, uint32_t& idx, bool& fwd) {
+        base = ~0ull;
+        if (!(e.up && popc4(e.out) == 1 && popc4(e.in) == 1)) return;
+        base = (up_hdr(e.up) + 1) * 32;
+        fwd = !up_bwd(e.up);
+        idx = fwd ? up_off(e.up) - 1u : up_off(e.up);
+    };
+    /* A long step: nb >= 32 nucleotides of the run straight into the contig (no node among them is the start node or, where it
+     * matters, the target's first k-mer; at least one nucleotide of the run stays behind for the step-by-step code). */
+    auto run_long_step = [&](uint32_t nbulk) {
+        const uint64_t* sw = us.words;
+        auto append = [&](uint64_t piece, uint32_t n) { /* n <= 32 nucleotides, zero above them */
+            acc |= piece << (2 * nacc);
+            const uint32_t tot = nacc + n;
+            if (tot >= 32) {
+                if (wpos >= cfg.cap_words) ovf = true; else words[wpos] = acc;
+                wpos++;
+                acc = nacc ? piece >> (2 * (32 - nacc)) : 0ull;
+                nacc = tot - 32;
+            } else nacc = tot;
+        };
+#ifdef MTG_EMU /* TEST-ONLY cross-check of the reasoning above: every node of the long step is looked at */
+        {
+            Kmer x = cur;
+            uint64_t p = run_pos;
+            for (uint32_t t = 0; t < nbulk; t++) {
+                x = kmer_next(x, us_peek(sw, p, 1, run_bwd), k, mk);
+                p = run_bwd ? p - 1 : p + 1;
+                if (canon(x) == start_c || (watch_r && x.f == R.r0)) W.status = 0xBAD1;
+            }
+        }
+#endif
+        run_nt -= run_take; /* the neighbourhood handed out last is taken back: its nucleotides are part of this step */
+        uint64_t p = run_pos;
+        uint32_t left = nbulk;
+        if (!run_bwd) {
+            const uint32_t inw = (uint32_t)(p & 31u);
+            if (inw) { /* up to the end of the source word */
+                const uint32_t n0 = 32u - inw < left ? 32u - inw : left;
+                append(us_peek64(sw, p, n0, false), n0);
+                p += n0; left -= n0;
+            }
+            const uint64_t* q = sw + (p >> 5);
+            const uint32_t nw = left >> 5;
+            for (uint32_t i = 0; i < nw; i += 8) { /* eight source words in flight */
+                uint64_t w[8];
+MTG_UNROLL
+                for (uint32_t u = 0; u < 8; u++) w[u] = (i + u < nw) ? q[i + u] : 0ull;
+MTG_UNROLL
+                for (uint32_t u = 0; u < 8; u++) if (i + u < nw) append(w[u], 32u);
+            }
+            p += 32ull * nw; left -= 32u * nw;
+            if (left) { append(us_peek64(sw, p, left, false), left); p += left; }
+        } else {
+            const uint32_t inw = (uint32_t)(p & 31u) + 1u; /* nucleotides of the source word at or below p */
+            if (inw < 32u) {
+                const uint32_t n0 = inw < left ? inw : left;
+                append(us_peek64(sw, p, n0, true), n0);
+                p -= n0; left -= n0;
+            }
+            const uint32_t nw = left >> 5;
+            if (nw) {
+                const uint64_t* q = sw + (p >> 5); /* p is the last nucleotide of this word */
+                for (uint32_t i = 0; i < nw; i += 8) {
+                    uint64_t w[8];
+MTG_UNROLL
+                    for (uint32_t u = 0; u < 8; u++) w[u] = (i + u < nw) ? *(q - (i + u)) : 0ull;
+MTG_UNROLL
+                    for (uint32_t u = 0; u < 8; u++) if (i + u < nw) append(rev_fields64(w[u]) ^ 0xAAAAAAAAAAAAAAAAULL, 32u);
+                }
+                p -= 32ull * nw; left -= 32u * nw;
+            }
+            if (left) { append(us_peek64(sw, p, left, true), left); p -= left; }
+        }
+        /* the node the walk now stands on: the last k nucleotides taken */
+        const uint64_t tail = us_peek64(sw, run_bwd ? p + (uint32_t)k : p - (uint32_t)k, (uint32_t)k, run_bwd);
+        cur.r = tail ^ (0xAAAAAAAAAAAAAAAAULL & mk); /* little-endian image = reversed order: complementing it gives the reverse complement */
+        cur.f = revcomp(cur.r, k);
+        run_pos = p;
+        run_left -= nbulk;
+        run_nt += nbulk;
+        len += nbulk;
+        store_reads += (nbulk >> 5) + 2;
     };
     for (;;) {
         if (!in_contig) {
@@ -1012,6 +1112,13 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             watch_r = r_is_kmer && node_depth > k; /* found_R only matters there (see phase E) */
             run_left = 0;
             a = next_adj(cur);
+            start_base = ~0ull;
+            if (run_left) { start_base = run_base; start_idx = run_idx(); }
+            if (watch_r && !r_known && us.nwords) { /* first contig below the first BFS level: where the target's first k-mer sits */
+                r_known = true;
+                const Adj e = adj_right_t(adj, make_kmer(R.r0, k), mk1, lines);
+                locate(e, r_base, r_idx, r_fwd);
+            }
             in_contig = true;
         }
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
@@ -1022,6 +1129,33 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         /* ---- phase W: simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has
          * exactly one in- and one out-edge (lookahead): those nodes are non-branching (nothing to mark) and need no read. */
         while (popc4(a.out) == 1 && popc4(a.in) <= 1) {
+            if (run_left >= 64u) {
+                /* a long run ahead: take it in one step, up to the nucleotide before the first node that needs a look */
+                uint32_t nbulk = run_left - 1u;
+                const uint32_t here = run_idx();
+                if (start_base == run_base) {
+                    const uint32_t t = run_bwd ? here - start_idx : start_idx - here; /* nucleotides until the walk stands on the start node */
+                    if (t - 1u < nbulk) nbulk = t - 1u; /* t == 0 (or behind the walk: wraps to a large value) leaves nbulk alone */
+#ifdef MTG_TRACE_BULK
+                    if (nbulk == t - 1u) fprintf(stderr, "BULK start-clamp t=%u\n", t);
+#endif
+                }
+                if (watch_r && r_base == run_base && r_fwd != run_bwd) {
+                    const uint32_t t = run_bwd ? here - r_idx : r_idx - here;
+                    if (t - 1u < nbulk) nbulk = t - 1u;
+#ifdef MTG_TRACE_BULK
+                    if (nbulk == t - 1u) fprintf(stderr, "BULK r-clamp t=%u\n", t);
+#endif
+                }
+                if (len + nbulk + 32u > MAXLEN) nbulk = MAXLEN > len + 32u ? MAXLEN - len - 32u : 0u;
+                if (nbulk >= 32u) {
+                    run_long_step(nbulk);
+                    lazy_prev = false;
+                    if (ovf || W.status) { end_contig = true; break; }
+                    a = run_chunk(cur);
+                    continue;
+                }
+            }
             uint32_t nt = (uint32_t)ctz4(a.out);
             uint32_t indeg = (uint32_t)popc4(a.in); /* in-degree of the node we step onto */
             uint32_t la = (indeg == 1) ? a.la : 0u;
@@ -1154,6 +1288,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     out.status = W.status;
     out.lines = W.lines + lines;
     out.store_reads = store_reads;
+    out.run_nt = run_nt;
     out.total_nt = total_nt;
     out.n_words = wpos;
 }

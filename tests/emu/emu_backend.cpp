@@ -265,6 +265,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                     d.general = true;
                 }
                 st.contig_nt += d.o.total_nt;
+                st.store_runs += d.o.store_reads; st.run_nt += d.o.run_nt; st.post_lines += d.po.lines; st.contig_words += d.o.n_words; st.coverage_kmers += d.po.ab_n;
             }
             uint64_t tw = 0, tc = 0;
             for (const SlotData& d : sd) { tw += d.nw; tc += d.nc; }

@@ -38,8 +38,8 @@ inline uint64_t emu_build_unitigs(mtg::Index& ix, EmuUStore& st)
     if (cr == 0) return 0;
     if (cr > recs.size()) abort(); /* the bound on the number of records does not hold */
     recs.resize(cr);
-    st.words.assign(cw + 2, 0);
-    st.ab.assign((cw + 2) * 32, 0);
+    st.words.assign(cw + 8, 0); /* padding as in the device build */
+    st.ab.assign((cw + 8) * 32, 0);
     ix.us.words = st.words.data();
     ix.us.ab = st.ab.data();
     ix.us.nwords = cw;

@@ -109,6 +109,70 @@ def test_stage_a_fuzz_against_oracle(k):
         emu.close()
 
 
+@pytest.mark.parametrize("k", [31, 24, 17, 13])
+def test_long_runs_through_the_unitig_store(k):
+    """long unitigs (hundreds to thousands of k-mers) joined by forks the bubble code cannot merge, so that the BFS builds several
+    contigs: walks take whole runs out of the unitig store in one step, in both orientations, and must still notice the start node
+    (a cycle that leads back into the unitig the contig began in) and, below the first BFS level, the target's first k-mer in the
+    middle of a run.  Checked against the oracle; the emulation build also looks at every node of every long step (status 0xBAD1)."""
+    rng = random.Random(777 + k)
+    for case in range(14):
+        segs = [_rand_seq(rng, rng.randrange(150, 2200)) for _ in range(rng.randrange(3, 7))]
+        g = "".join(segs)
+        seqs = [g]
+        cuts = np.cumsum([len(x) for x in segs])[:-1].tolist()
+        for c in cuts:  # an alternative allele at every joint: unrelated sequence of another length (no merge within the bubble limits sometimes, a bubble otherwise)
+            alt = _rand_seq(rng, rng.choice([1, 3, 40, 700]))
+            seqs.append(g[max(0, c - 2 * k):c] + alt + g[c + rng.choice([0, 1, 30]):c + 3 * k + 30])
+        if case % 3 == 0:  # close the genome into a cycle: a walk comes back to where it started, inside a long run
+            seqs.append(g[-(k - 1):] + g[:k + 5])
+        if case % 4 == 1:  # a repeat: the same long stretch twice (the second passage meets marked nodes / looping contigs)
+            a = rng.randrange(0, len(g) - 400)
+            seqs.append(g[a:a + 300] + _rand_seq(rng, 50) + g[a:a + 300])
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k, load_factor=0.5)
+        for _ in range(10):
+            p = rng.randrange(0, len(g) - k)
+            s = g[p:p + k] if rng.random() < 0.6 else _rc(g[p:p + k])
+            tp = rng.randrange(0, len(g) - k)
+            t = g[tp:tp + k] if rng.random() < 0.6 else _rc(g[tp:tp + k])
+            mn, md = rng.choice([100, 100, 8]), rng.choice([10000, 10000, 2500])
+            oc, _ = idx.stage_a(s, t, oracle_lib.default_params(max_nodes=mn, max_depth=md))
+            ec, st, lines, _ = emu.stage_a(s, t, mn, md, 0)
+            assert st == 0 and ec == oc, (case, k, s, t, mn, md)
+        idx.close()
+        emu.close()
+
+
+@pytest.mark.parametrize("k", [31, 22, 13])
+def test_looping_contig_through_long_runs(k):
+    """a cycle of a few thousand k-mers with short tips hanging off it: the tips are popped (explore_branching), so a walk goes all the
+    way round and meets its start node in the middle of a long run of the unitig it began in, walking either way"""
+    rng = random.Random(91 + k)
+    for case in range(10):
+        L = rng.randrange(400, 4000)
+        c = _rand_seq(rng, L)
+        seqs = [c + c[:k - 1]]
+        cc = c + c
+        for _ in range(rng.randrange(1, 4)):  # tips: k-1 nucleotides of the cycle, one different, a few more
+            q = rng.randrange(k, L)
+            seqs.append(cc[q:q + k - 1] + rng.choice([x for x in "ACGT" if x != cc[q + k - 1]]) + _rand_seq(rng, rng.randrange(0, k // 2)))
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k, load_factor=0.5)
+        for _ in range(8):
+            p = rng.randrange(0, L)
+            s = cc[p:p + k] if rng.random() < 0.5 else _rc(cc[p:p + k])
+            tp = rng.randrange(0, L)
+            t = cc[tp:tp + k] if rng.random() < 0.5 else _rc(cc[tp:tp + k])
+            oc, _ = idx.stage_a(s, t, oracle_lib.default_params(max_depth=100000))
+            ec, st, _, _ = emu.stage_a(s, t, 100, 100000, 0)
+            assert st == 0 and ec == oc, (case, k, s, t)
+        idx.close()
+        emu.close()
+
+
 def test_scratch_tier_escalation():
     """a gap that overflows the tier-0 contig arena is re-run in a larger tier with identical contigs"""
     rng = random.Random(5)
