@@ -147,6 +147,15 @@ int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gap
  * packed word of contig plus one per gap always suffice: a little over the sum of the insert lengths). */
 int mtg_fill_batch_serial(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t cap, uint64_t* seq_bytes,
                           mtg_results** out);
+/* A batch marshalled ahead of time and kept in device memory: what a caller that fills the same gaps more than once, or reads its
+ * breakpoints while an earlier batch is still on the device, would use instead of mtg_fill_batch (which does exactly this and then
+ * forgets the batch).  `gaps` and every string it points to must stay alive and unchanged for as long as the batch is used.  A batch can
+ * be filled by several threads at once. */
+typedef struct mtg_batch mtg_batch;
+int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_batch** out);
+void mtg_batch_free(mtg_batch* b);
+int mtg_fill_prepared(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, mtg_results** out);
+int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
 /* Every pointer obtained from r dies here.  The library keeps the storage of up to six freed result sets (a few hundred bytes per
  * gap plus the sequences) and hands it to the next batches, which then pay no allocation, page fault or memset. */

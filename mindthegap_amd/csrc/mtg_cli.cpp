@@ -37,34 +37,53 @@ static std::string revcomp_str(const std::string& s)
     return r;
 }
 
-/* the GapWork holds views: source, dict and the target store must outlive it */
-static GapWork make_gap(const std::string& source, const bkpt_dict_t& dict, bool repeated, bool reverse, std::vector<Target>& store)
-{
-    GapWork g;
-    g.source = source;
-    g.anchor_repeated = repeated;
-    g.reverse = reverse;
-    store.clear();
-    store.reserve(dict.size());
-    for (auto it = dict.begin(); it != dict.end(); ++it) {
-        Target t;
-        t.seq = it->first;
-        t.name = it->second.first;
-        t.is_rc = it->second.second;
-        store.push_back(t);
+/* one gapFillFromSource call as the C ABI wants it; the strings and arrays it points to live in the GapArgs */
+struct GapArgs {
+    std::string source, target; /* sourceSequence; targetSequence (the early-stop pattern) */
+    std::vector<std::string> tseq, tname; /* targetDictionary in iteration order */
+    std::vector<uint8_t> trc;
+    std::vector<const char*> pseq, pname;
+    bool repeated = false, reverse = false;
+    void set_dict(const bkpt_dict_t& dict)
+    {
+        for (auto it = dict.begin(); it != dict.end(); ++it) { tseq.push_back(it->first); tname.push_back(it->second.first); trc.push_back(it->second.second ? 1 : 0); }
     }
-    g.targets.p = store.data();
-    g.targets.n = (uint32_t)store.size();
-    return g;
-}
+    mtg_gap abi()
+    {
+        pseq.clear(); pname.clear();
+        for (size_t i = 0; i < tseq.size(); i++) { pseq.push_back(tseq[i].c_str()); pname.push_back(tname[i].c_str()); }
+        mtg_gap g;
+        g.source = source.c_str();
+        g.target = target.c_str();
+        g.n_targets = (int)tseq.size();
+        g.target_seqs = pseq.data();
+        g.target_names = pname.data();
+        g.target_is_rc = trc.data();
+        g.is_anchor_repeated = repeated;
+        g.reverse = reverse;
+        return g;
+    }
+};
+/* runs a batch through the C ABI; the results stay valid until the handle is freed */
+struct BatchRun {
+    mtg_results* h = nullptr;
+    ~BatchRun() { if (h) mtg_results_free(h); }
+    int run(const mtg_index* idx, const mtg_params& P, std::vector<GapArgs>& args)
+    {
+        std::vector<mtg_gap> gaps(args.size());
+        for (size_t i = 0; i < args.size(); i++) gaps[i] = args[i].abi();
+        return mtg_fill_batch(idx, &P, gaps.data(), gaps.size(), &h);
+    }
+    const mtg_gap_result& operator[](size_t i) const { return *mtg_results_get(h, i); }
+};
 
-static std::string info_string(const GapWork& g)
+static std::string info_string(const mtg_gap_result& g)
 {
     char buf[128];
     std::string s;
     snprintf(buf, sizeof buf, "\t%i\t%i\t%d", g.nb_nodes, g.total_nt, g.nb_terminal);
     s += buf;
-    if (g.nb_terminal > 0 && g.has_counts) { snprintf(buf, sizeof buf, "\t%d\t%d", g.nb_total_filled, (int)g.sols.size()); s += buf; }
+    if (g.nb_terminal > 0 && g.has_solution_counts) { snprintf(buf, sizeof buf, "\t%d\t%d", g.nb_total_filled, g.nb_reported); s += buf; }
     return s;
 }
 
@@ -79,45 +98,56 @@ struct Files {
     ~Files() { for (FILE* f : {insert, info, vcf, gfa, ext}) if (f) fclose(f); }
 };
 
-static std::string solu_str(const Solution& s)
+struct Sols { /* a run of solutions */
+    const mtg_filled* p = nullptr;
+    size_t n = 0;
+    const mtg_filled* begin() const { return p; }
+    const mtg_filled* end() const { return p + n; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
+static Sols sols_of(const mtg_gap_result& g) { Sols s; s.p = g.filled; s.n = (size_t)g.n_filled; return s; }
+
+static std::string solu_str(const mtg_filled& s)
 {
-    if (s.count <= 1) return "";
+    if (s.solution_count <= 1) return "";
     std::ostringstream o;
-    o << "solution " << s.rank << "/" << s.count;
+    o << "solution " << s.solution_rank << "/" << s.solution_count;
     return o.str();
 }
 
 /* writeFilledBreakpoint, src/Filler.cpp:1029-1093.  The bkpt-mode header passes its arguments in a different order
  * than its format (:1052-1054); the visible x86-64 result is NAME_len_L_qual_Q_avg_cov_A_median_cov_M   SOLU. */
-static void write_filled(Files& F, bool bkpt_mode, const GapWork& g, SolSpan sols, const std::string& seedName, const std::string& info)
+static void write_filled(Files& F, bool bkpt_mode, const GapArgs& g, Sols sols, const std::string& seedName, const std::string& info)
 {
     for (auto& s : sols) {
-        const int llen = (int)s.seq.length();
+        const int llen = (int)strlen(s.seq);
         const std::string solu = solu_str(s);
         if (bkpt_mode) {
-            fprintf(F.insert, ">%s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n", seedName.c_str(), llen, s.qual, (double)s.avg, (double)s.median, solu.c_str());
+            fprintf(F.insert, ">%s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n", seedName.c_str(), llen, s.qual, (double)s.avg_coverage, (double)s.median_coverage, solu.c_str());
         } else {
-            std::string targetName(g.targets[s.target].name);
-            if (g.targets[s.target].is_rc) targetName.append("_Rc");
-            int cov = s.median + 0.5;
+            std::string targetName(g.tname[s.target_index]);
+            if (g.trc[s.target_index]) targetName.append("_Rc");
+            int cov = s.median_coverage + 0.5;
             fprintf(F.insert, ">%s;%s;len_%d_qual_%d_median_cov_%d\t%s\n", seedName.c_str(), targetName.c_str(), llen, s.qual, cov, solu.c_str());
         }
-        fprintf(F.insert, "%.*s\n", llen, s.seq.c_str());
+        fprintf(F.insert, "%.*s\n", llen, s.seq);
     }
     fprintf(F.info, "%s\t%s\n", seedName.c_str(), info.c_str());
 }
 
 /* writeVcf, src/Filler.cpp:1095-1214 */
-static void write_vcf(Files& F, bool filter, SolSpan sols, const std::string& breakpointName, const std::string& sourceSequence)
+static void write_vcf(Files& F, bool filter, Sols sols, const std::string& breakpointName, const std::string& sourceSequence)
 {
     for (auto& s : sols) {
-        std::string insertion = s.seq.str();
+        const std::string seq(s.seq);
+        std::string insertion = seq;
         int repeatSize = 0;
-        int i = (int)sourceSequence.size() - 1, j = (int)s.seq.size() - 1;
+        int i = (int)sourceSequence.size() - 1, j = (int)seq.size() - 1;
         while (i > 0 && j >= 0) { /* longest common suffix with a circular insert index, :1107-1126 */
-            if (sourceSequence[i] != s.seq[j]) break;
+            if (sourceSequence[i] != seq[j]) break;
             repeatSize++; i--; j--;
-            if (j == -1) j = (int)s.seq.size() - 1;
+            if (j == -1) j = (int)seq.size() - 1;
         }
         insertion = sourceSequence.substr(sourceSequence.size() - (repeatSize + 1), repeatSize + 1) + insertion;
         insertion = insertion.substr(0, insertion.size() - repeatSize);
@@ -133,31 +163,31 @@ static void write_vcf(Files& F, bool filter, SolSpan sols, const std::string& br
             bkpt = tokens[0] + tokens[2]; position = std::to_string(atoi(tokens[4].c_str()) - repeatSize); chromosome = tokens[1]; genotype = tokens[7];
             GT = genotype == "HOM" ? "1/1" : "0/1";
         }
-        const int size = (int)(insertion.size() - ref.size()), nsol = s.count, npos = repeatSize + 1;
+        const int size = (int)(insertion.size() - ref.size()), nsol = s.solution_count, npos = repeatSize + 1;
         std::string filt = "PASS";
         if ((genotype == "HET" && nsol > 1) || (genotype == "HOM" && nsol > 1)) {
             if (filter) break;
             filt = "LOW_QUAL";
         }
         fprintf(F.vcf, "%s\t%s\t%s\t%s\t%s\t.\t%s\tTYPE=INS;LEN=%i;QUAL=%i;NSOL=%i;NPOS=%i;AVK=%.2f;MDK=%.2f\tGT\t%s\n", chromosome.c_str(), position.c_str(), bkpt.c_str(),
-                ref.c_str(), insertion.c_str(), filt.c_str(), size, s.qual, nsol, npos, (double)s.avg, (double)s.median, GT.c_str());
+                ref.c_str(), insertion.c_str(), filt.c_str(), size, s.qual, nsol, npos, (double)s.avg_coverage, (double)s.median_coverage, GT.c_str());
     }
 }
 
 /* writeToGFA, src/Filler.cpp:1216-1273 */
-static void write_gfa(Files& F, int trim, const GapWork& g, SolSpan sols, std::string seedName, bool isRc)
+static void write_gfa(Files& F, int trim, const GapArgs& g, Sols sols, std::string seedName, bool isRc)
 {
     const std::string seedNameNode = seedName;
     std::string seedDirection = "+";
     if (isRc) { seedName = seedName.substr(0, seedName.size() - 3); seedDirection = "-"; }
     for (auto& s : sols) {
-        const std::string tname(g.targets[s.target].name);
-        const bool trc = g.targets[s.target].is_rc;
+        const std::string tname(g.tname[s.target_index]);
+        const bool trc = g.trc[s.target_index] != 0;
         const std::string targetNameNode = trc ? tname + "_Rc" : tname;
-        int cov = s.median + 0.5;
-        const std::string nodeName = seedNameNode + ";" + targetNameNode + ";len_" + std::to_string((int)s.seq.length()) + "_qual_" + std::to_string(s.qual) +
+        int cov = s.median_coverage + 0.5;
+        const std::string nodeName = seedNameNode + ";" + targetNameNode + ";len_" + std::to_string((int)strlen(s.seq)) + "_qual_" + std::to_string(s.qual) +
                                      "_median_cov_" + std::to_string(cov) + " " + solu_str(s);
-        fprintf(F.gfa, "S\t%s\t%s\n", nodeName.c_str(), s.seq.c_str());
+        fprintf(F.gfa, "S\t%s\t%s\n", nodeName.c_str(), s.seq);
         fprintf(F.gfa, "L\t%s\t%s\t%s\t+\t%iM\n", seedName.c_str(), seedDirection.c_str(), nodeName.c_str(), trim);
         fprintf(F.gfa, "L\t%s\t+\t%s\t%s\t%iM\n", nodeName.c_str(), tname.c_str(), trc ? "-" : "+", trim);
     }
@@ -205,67 +235,64 @@ static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O,
     std::vector<std::pair<std::string, std::string>> recs;
     if (!read_sequences(O.bkpt, recs)) { set_error("cannot read %s", O.bkpt.c_str()); return MTG_ERR_IO; }
     const size_t nsites = recs.size() / 2; /* records 2i / 2i+1 = left / right k-mer, src/Filler.cpp:625-629 */
-    struct Site { std::string source, target, name, name_r; bool repeated; };
+    struct Site { std::string name, name_r; };
     std::vector<Site> sites(nsites);
-    std::vector<GapWork> fwd;
-    std::vector<std::string_view> swf;
-    std::vector<bkpt_dict_t> dicts(nsites), dicts_rev(nsites); /* kept alive: the gaps hold views on their strings */
-    std::vector<std::string> src_rev(nsites), tgt_rev(nsites);
-    std::vector<std::vector<Target>> tstore(nsites), tstore_rev(nsites);
+    std::vector<GapArgs> fwd(nsites);
     for (size_t i = 0; i < nsites; i++) {
         Site& s = sites[i];
-        s.source = recs[2 * i].second;
-        s.target = recs[2 * i + 1].second;
+        GapArgs& g = fwd[i];
+        g.source = recs[2 * i].second;
+        g.target = recs[2 * i + 1].second;
         s.name = short_name(recs[2 * i].first);
         s.name_r = short_name(recs[2 * i + 1].first);
-        s.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
-        bkpt_dict_t& dict = dicts[i];
-        dict.insert({s.target, std::make_pair(s.name_r, false)});
-        fwd.push_back(make_gap(s.source, dict, s.repeated, false, tstore[i]));
-        swf.push_back(s.target);
+        g.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
+        bkpt_dict_t dict;
+        dict.insert({g.target, std::make_pair(s.name_r, false)});
+        g.set_dict(dict);
     }
-    FillArena arena_fwd, arena_rev;
-    int rc = fill_gaps(idx, &P, fwd, swf, arena_fwd, nullptr);
+    BatchRun rf, rr;
+    int rc = rf.run(idx, P, fwd);
     if (rc) return rc;
     /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
     std::vector<size_t> rev_of;
-    std::vector<GapWork> rev;
-    std::vector<std::string_view> swf2;
+    std::vector<GapArgs> rev;
     if (!O.fwd_only)
         for (size_t i = 0; i < nsites; i++)
-            if (fwd[i].sols.empty()) {
-                const Site& s = sites[i];
-                tgt_rev[i] = revcomp_str(s.source);
-                src_rev[i] = revcomp_str(s.target);
-                bkpt_dict_t& dict = dicts_rev[i];
-                dict.insert({tgt_rev[i], std::make_pair(s.name, false)});
-                rev.push_back(make_gap(src_rev[i], dict, s.repeated, true, tstore_rev[i]));
-                swf2.push_back(tgt_rev[i]);
+            if (rf[i].n_filled == 0) {
+                GapArgs g;
+                g.target = revcomp_str(fwd[i].source);
+                g.source = revcomp_str(fwd[i].target);
+                g.repeated = fwd[i].repeated;
+                g.reverse = true;
+                bkpt_dict_t dict;
+                dict.insert({g.target, std::make_pair(sites[i].name, false)});
+                g.set_dict(dict);
+                rev.push_back(std::move(g));
                 rev_of.push_back(i);
             }
-    if (!rev.empty()) { rc = fill_gaps(idx, &P, rev, swf2, arena_rev, nullptr); if (rc) return rc; }
+    if (!rev.empty()) { rc = rr.run(idx, P, rev); if (rc) return rc; }
     std::vector<long> rev_idx(nsites, -1);
     for (size_t j = 0; j < rev_of.size(); j++) rev_idx[rev_of[j]] = (long)j;
     for (size_t i = 0; i < nsites; i++) {
         const Site& s = sites[i];
-        std::string info = info_string(fwd[i]);
+        std::string info = info_string(rf[i]);
         std::string name = s.name;
-        const SolVec* sols = &fwd[i].sols;
-        const GapWork* gw = &fwd[i];
+        const mtg_gap_result* res = &rf[i];
+        const GapArgs* gw = &fwd[i];
         if (rev_idx[i] >= 0) {
-            const GapWork& r = rev[rev_idx[i]];
-            info += info_string(r);
+            res = &rr[(size_t)rev_idx[i]];
+            info += info_string(*res);
             name = s.name_r; /* src/Filler.cpp:674 */
-            sols = &r.sols;
-            gw = &r;
+            gw = &rev[(size_t)rev_idx[i]];
         }
-        write_filled(F, true, *gw, *sols, name, info);
-        write_vcf(F, O.filter, *sols, name, s.source);
-        if (sols->empty() && O.extend) {
-            write_extension(F, fwd[i].extension, name, s.source);
-            write_extension(F, rev_idx[i] >= 0 ? rev[rev_idx[i]].extension : std::string(), name + "_reverse", revcomp_str(s.target));
+        const Sols sols = sols_of(*res);
+        write_filled(F, true, *gw, sols, name, info);
+        write_vcf(F, O.filter, sols, name, fwd[i].source);
+        if (sols.empty() && O.extend) {
+            write_extension(F, rf[i].extension, name, fwd[i].source);
+            write_extension(F, rev_idx[i] >= 0 ? std::string(rr[(size_t)rev_idx[i]].extension) : std::string(), name + "_reverse", revcomp_str(fwd[i].target));
         }
-        S.count(sols->size());
+        S.count(sols.size());
     }
     return MTG_OK;
 }
@@ -300,38 +327,36 @@ static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& 
         }
     }
     /* contigFunctor, src/Filler.cpp:492-572 */
-    std::vector<GapWork> gaps;
-    std::vector<std::string_view> swf;
-    std::vector<bkpt_dict_t> dicts(seeds.size()); /* kept alive: the gaps hold views on their strings */
-    std::vector<std::string> concs(seeds.size());
-    std::vector<std::vector<Target>> tstore(seeds.size());
+    std::vector<GapArgs> gaps(seeds.size());
     for (size_t si = 0; si < seeds.size(); si++) {
         auto& sd = seeds[si];
-        std::string& conc = concs[si];
-        bkpt_dict_t& dict = dicts[si];
+        GapArgs& g = gaps[si];
+        bkpt_dict_t dict;
         for (auto its = all_targets.begin(); its != all_targets.end(); ++its) {
             std::string tempName = its->second.first;
             if (its->second.second) tempName += "_Rc";
-            if (tempName.compare(sd.first) != 0) { conc.append(its->first); dict.insert({its->first, its->second}); }
+            if (tempName.compare(sd.first) != 0) { g.target.append(its->first); dict.insert({its->first, its->second}); }
         }
-        gaps.push_back(make_gap(sd.second, dict, false, false, tstore[si]));
-        swf.push_back(conc);
+        g.source = sd.second;
+        g.set_dict(dict);
     }
-    FillArena arena;
-    int rc = fill_gaps(idx, &P, gaps, swf, arena, nullptr);
+    BatchRun run;
+    int rc = run.run(idx, P, gaps);
     if (rc) return rc;
     for (size_t i = 0; i < seeds.size(); i++) {
         const std::string& seedName = seeds[i].first;
         const bool isRc = seedName.length() >= 3 && seedName.compare(seedName.length() - 3, 3, "_Rc") == 0;
-        std::vector<Solution> kept;
-        for (auto& s : gaps[i].sols) { /* drop loops: target == seed reversed, :540-557 */
-            const Target& t = gaps[i].targets[s.target];
-            const std::string revTargetName = t.is_rc ? std::string(t.name) : std::string(t.name) + "_Rc";
+        std::vector<mtg_filled> kept;
+        for (auto& s : sols_of(run[i])) { /* drop loops: target == seed reversed, :540-557 */
+            const std::string& tn = gaps[i].tname[s.target_index];
+            const std::string revTargetName = gaps[i].trc[s.target_index] ? tn : tn + "_Rc";
             if (revTargetName != seedName) kept.push_back(s);
         }
-        write_filled(F, false, gaps[i], kept, seedName, info_string(gaps[i]));
-        write_gfa(F, trim, gaps[i], kept, seedName, isRc);
-        if (kept.empty() && O.extend) write_extension(F, gaps[i].extension, seedName, seeds[i].second);
+        Sols ks;
+        ks.p = kept.data(); ks.n = kept.size();
+        write_filled(F, false, gaps[i], ks, seedName, info_string(run[i]));
+        write_gfa(F, trim, gaps[i], ks, seedName, isRc);
+        if (kept.empty() && O.extend) write_extension(F, run[i].extension, seedName, seeds[i].second);
         S.count(kept.size());
     }
     return MTG_OK;

@@ -1,0 +1,189 @@
+/*
+ * mtg_emit.h -- the results of a batch, produced on the device in their final form:
+ *   - where every gap's output goes (exclusive prefix sums over the slots of a part: no atomic reservation, and the sequences come out
+ *     in gap order, which is the serialised form of a batch)
+ *   - the filled sequence of the common case (contig0[k:pos], src/GraphAnalysis.cpp:386-423; reverse-complemented for a reverse attempt,
+ *     src/Filler.cpp:998-1001, src/Utils.hpp:78-83) and the extension sequence (get_first_contig, src/Filler.cpp:1381-1407) as ASCII
+ *   - the C-ABI records mtg_gap_result / mtg_filled (filled_insertion_t, src/Utils.hpp:46-104; infostring fields src/Filler.cpp:905,
+ *     1012-1016; compute_qual src/Utils.hpp:85-103), pointers already those of the host arrays the device buffers are copied into
+ * so that the host touches a gap only when it takes the multi-contig path or has to be re-run in a larger scratch tier.
+ * Compiled for gfx950 and, TEST-ONLY, for tests/emu (one lane).
+ */
+#ifndef MTG_EMIT_H
+#define MTG_EMIT_H
+#include "../../include/mtg_fill.h"
+#include "mtg_post.h"
+
+namespace mtg {
+
+enum : uint8_t { GAPF_REPEATED = 1, GAPF_REVERSE = 2 };
+
+/* what a gap contributes to the arrays of its batch */
+MTG_DEV void emit_plan(const GapOut& o, const PostOut& p, bool want_all, int k, uint32_t& nw, uint32_t& nc, uint32_t& asc, uint32_t& ext)
+{
+    nw = nc = asc = ext = 0;
+    if (o.status != GAP_OK) return;
+    if (want_all || (p.fast == 0 && p.nb_terminal > 0)) { nw = o.n_words; nc = o.n_contigs; } /* every contig: stage-A entry / multi-contig path on the host */
+    if (want_all) return;
+    if (p.fast == 1) asc = p.pos - (uint32_t)k + 1u;                                            /* the fill and its NUL */
+    else if (p.nb_terminal == 0 && o.n_contigs > 0 && p.clen0 > (uint32_t)k) ext = p.clen0 - (uint32_t)k + 1u; /* no terminal node: contig 0 past the seed */
+}
+
+/* totals of one part of a batch (device -> host) */
+struct PartTot {
+    uint64_t begin[4], end[4]; /* cursors before / after the part: dense words, dense metadata entries, sequence bytes, extension bytes */
+    uint64_t lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers;
+    uint32_t n_retry, n_general, n_filled, n_ext;
+};
+
+/* one slot's share of the sums (the scan kernel adds them up in slot order) */
+struct SlotSums {
+    uint64_t v[4];
+};
+MTG_DEV SlotSums slot_sums(const SlotRec& r)
+{
+    SlotSums s;
+    s.v[0] = r.nw; s.v[1] = r.nc; s.v[2] = r.asc; s.v[3] = r.ext;
+    return s;
+}
+
+/* ASCII of 16 consecutive nucleotides of a 2-bit packed sequence, first one in the lowest byte: codes = 32 bits, nucleotide i at bits 2i.
+ * comp: the complement letters. */
+MTG_DEV void ascii16(uint32_t codes, bool comp, uint32_t out[4])
+{
+    const uint32_t lut = comp ? 0x43414754u /* T G A C */ : 0x47544341u /* A C T G */;
+MTG_UNROLL
+    for (int q = 0; q < 4; q++) {
+        uint32_t w = 0;
+MTG_UNROLL
+        for (int b = 0; b < 4; b++) w |= ((lut >> (8u * ((codes >> (2 * (4 * q + b))) & 3u))) & 0xFFu) << (8 * b);
+        out[q] = w;
+    }
+}
+/* 16 nucleotides starting at nucleotide i of the packed words w (reads one word past the one holding nucleotide i + 15 at most) */
+MTG_DEV uint32_t codes16(const uint64_t* w, uint32_t i)
+{
+    const uint32_t s = 2u * (i & 31u);
+    uint64_t v = w[i >> 5] >> s;
+    if (s > 32u) v |= w[(i >> 5) + 1] << (64u - s);
+    return (uint32_t)v;
+}
+
+/* dst[0, L) = ASCII of src nucleotides [from, from + L), reverse-complemented when rc; dst[L] = 0.  The lanes of a wave write aligned
+ * 16-byte pieces of the destination (byte stores at the ragged ends), so the arena needs no padding between sequences. */
+MTG_DEV void emit_ascii(const uint64_t* src, uint32_t from, uint32_t L, bool rc, char* dst)
+{
+    const uint32_t lane = MTG_LANE();
+    const uint64_t d0 = (uint64_t)(uintptr_t)dst;
+    const uint32_t head = (uint32_t)((16u - (d0 & 15u)) & 15u); /* bytes before the first aligned piece */
+    const uint32_t npieces = 1u + (L > head ? (L - head + 15u) / 16u : 0u); /* piece 0 = the head (possibly empty) */
+    for (uint32_t pc = lane; pc < npieces; pc += MTG_NLANES) {
+        const uint32_t o0 = pc == 0 ? 0u : head + 16u * (pc - 1u);
+        uint32_t n = pc == 0 ? (head < L ? head : L) : (L - o0 < 16u ? L - o0 : 16u);
+        if (n == 0) continue;
+        /* output characters o0 .. o0 + n - 1: forward = nucleotides from + o0 ..; reverse = complements of from + L - 1 - o0 downwards */
+        uint32_t codes;
+        if (!rc) codes = codes16(src, from + o0);
+        else {
+            const uint32_t hi = from + L - 1u - o0;      /* the nucleotide of the first output character */
+            const uint32_t lo = hi >= 15u ? hi - 15u : 0u; /* 16 nucleotides ending at hi (fewer at the very start of the sequence) */
+            const uint32_t got = hi - lo + 1u;
+            codes = rev_fields32(codes16(src, lo)) >> (2u * (16u - got)); /* nucleotide hi first */
+        }
+        uint32_t out[4];
+        ascii16(codes, rc, out);
+        char* d = dst + o0;
+        if (n == 16u) {
+            U64x2 v;
+            v.x = (uint64_t)out[0] | ((uint64_t)out[1] << 32);
+            v.y = (uint64_t)out[2] | ((uint64_t)out[3] << 32);
+            *reinterpret_cast<U64x2*>(d) = v; /* aligned: pc >= 1 */
+        } else {
+            for (uint32_t b = 0; b < n; b++) d[b] = (char)((out[b >> 2] >> (8u * (b & 3u))) & 0xFFu);
+        }
+    }
+    if (lane == 0) dst[L] = 0;
+}
+
+/* host addresses of the arrays the device buffers of a batch are copied into */
+struct EmitHost {
+    char* seq;          /* sequence arena */
+    char* ext;          /* extension arena; ext[0] is a NUL every record without extension points to (the arena's cursor starts at 1) */
+    mtg_filled* fil;    /* one slot per gap (the common case has at most one solution) */
+};
+struct EmitDev {
+    char* seq;
+    char* ext;
+    uint64_t seq_cap, ext_cap;
+    mtg_gap_result* res; /* per slot of the launch */
+    mtg_filled* fil;     /* per slot of the launch */
+    uint64_t* dense_words;
+    uint32_t* dense_meta;
+};
+
+MTG_DEV int qual_of(uint32_t errors, bool repeated) /* compute_qual, src/Utils.hpp:85-103, for a single solution */
+{
+    int q = repeated ? 25 : 50;
+    if (errors == 1) q = 10;
+    if (errors == 2) q = 5;
+    return q;
+}
+
+/* everything a gap leaves behind: one wave per gap (one lane in the emulation).  gap = its index in the batch. */
+MTG_DEV void emit_gap(const FillCfg& cfg, const GapScratch& S, const SlotRec& r, uint32_t flags, uint32_t slot, uint64_t gap, int k, const EmitDev& D, const EmitHost& H)
+{
+    const uint32_t lane = MTG_LANE();
+    const uint64_t* w = s_words(cfg, S);
+    const bool reverse = (flags & GAPF_REVERSE) != 0;
+    const bool seq_ok = r.asc && r.abase + r.asc <= D.seq_cap, ext_ok = r.ext && r.ebase + r.ext <= D.ext_cap; /* an arena that is too small: the host grows it and asks again */
+    if (seq_ok) emit_ascii(w, (uint32_t)k, r.asc - 1u, reverse, D.seq + r.abase);
+    if (ext_ok) emit_ascii(w, (uint32_t)k, r.ext - 1u, false, D.ext + r.ebase);
+    uint64_t* dw = D.dense_words + r.wbase;
+    for (uint32_t i = lane; i < r.nw; i += MTG_NLANES) dw[i] = w[i];
+    uint32_t* dm = D.dense_meta + 5 * r.cbase;
+    for (uint32_t i = lane; i < r.nc; i += MTG_NLANES) {
+        dm[i] = s_clen(cfg, S)[i];
+        dm[r.nc + i] = s_cstart(cfg, S)[i];
+        dm[2 * r.nc + i] = s_tpos(cfg, S)[i];
+        dm[3 * r.nc + i] = s_terr(cfg, S)[i];
+        dm[4 * r.nc + i] = s_ttgt(cfg, S)[i];
+    }
+    if (lane != 0) return;
+    mtg_gap_result g;
+    g.nb_nodes = (int)r.o.n_contigs;
+    g.total_nt = (int)r.o.total_nt;
+    g.nb_terminal = (int)r.p.nb_terminal;
+    g.has_solution_counts = 0;
+    g.nb_total_filled = g.nb_reported = g.n_filled = 0;
+    g.filled = H.fil + gap;
+    g.extension = H.ext; /* "" */
+    if (r.o.status == GAP_OK) {
+        if (r.p.fast == 1) {
+            mtg_filled f;
+            f.seq = H.seq + r.abase;
+            f.nb_errors_in_anchor = (int)r.p.errors;
+            f.target_index = (int)r.p.target;
+#ifdef MTG_EMU
+            f.avg_coverage = (float)r.p.ab_sum / (float)r.p.ab_n;
+#else
+            f.avg_coverage = __fdiv_rn((float)r.p.ab_sum, (float)r.p.ab_n);
+#endif
+            f.median_coverage = (r.p.ab_n & 1u) ? (float)r.p.med_hi : 0.5f * (float)(r.p.med_hi + r.p.med_lo); /* exact: integers and halves */
+            f.qual = qual_of(r.p.errors, (flags & GAPF_REPEATED) != 0);
+            f.solution_count = 1;
+            f.solution_rank = 1;
+            D.fil[slot] = f;
+            g.has_solution_counts = 1;
+            g.nb_total_filled = g.nb_reported = g.n_filled = 1;
+        } else if (r.p.fast == 2) {
+            g.has_solution_counts = reverse ? 1 : 0; /* src/Filler.cpp:1012: counts are appended when something was found or on the reverse attempt */
+        } else if (r.p.nb_terminal == 0) {
+            if (r.ext) g.extension = H.ext + r.ebase;
+        }
+        /* fast == 0 with terminal nodes: the host fills the record in (multi-contig path) */
+    }
+    D.res[slot] = g;
+}
+
+} // namespace mtg
+#endif

@@ -325,23 +325,19 @@ __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __r
     tbad[t] = bad;
 }
 
-/* terminal-node search + coverage of the single-contig solution, one wave per gap; then the wave reserves room in the chunk's dense
- * arrays (two atomic counters) and copies there what the host needs of this gap: nw leading arena words and, for nc contigs, their
- * (length, first word) and terminal info.  counters: [0] words, [1] contig metadata entries */
+/* terminal-node search + coverage of the single-contig solution, one wave per gap; leaves the slot's record with what the gap will
+ * contribute to the arrays of its batch (mtg_emit.h: emit_plan).  Where it goes is decided by the scan kernels below. */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
-                                             uint32_t want_all, unsigned long long* counters, SlotRec* recs, uint64_t* dense_words, uint32_t* dense_meta,
-                                             uint32_t slot_base, uint32_t n)
+                                             uint32_t want_all, SlotRec* recs, uint32_t n)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint64_t tile[POST_TILE + 2];
     __shared__ uint64_t s_blk[64];
-    __shared__ uint64_t s_base[2];
-    /* this launch covers the slots [slot_base, n); a workgroup takes every gridDim.x-th of them.  One workgroup per slot measured best
-     * (1.39 ms against 1.52-1.77 ms with 16384-2048 persistent workgroups): the kernel lives on the number of waves in flight. */
-    for (uint32_t slot = slot_base + blockIdx.x; slot < n; slot += gridDim.x) {
-        __syncthreads(); /* the previous gap's readers of hist / s_base are done */
+    /* one workgroup per slot measured best (against persistent workgroups): the kernel lives on the number of waves in flight */
+    for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        __syncthreads(); /* the previous gap's readers of hist are done */
         for (uint32_t i = threadIdx.x; i < 256; i += 64) hist[i] = 0;
         __syncthreads();
         const GapOut o = outs[slot];
@@ -362,31 +358,131 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_
             T.fast_ok = fast_ok[g];
             post_gap(ix, cfg, S, o, T, hist, tile, s_blk, po);
         }
-        uint32_t nw, nc;
-        copy_plan(o, po, want_all != 0, nw, nc); /* po is uniform over the wave */
-        if (threadIdx.x == 0) {
-            s_base[0] = nw ? atomicAdd(&counters[0], (unsigned long long)nw) : 0ull;
-            s_base[1] = nc ? atomicAdd(&counters[1], (unsigned long long)nc) : 0ull;
-        }
-        __syncthreads();
-        const uint64_t wbase = s_base[0], cbase = s_base[1];
-        const uint64_t* w = s_words(cfg, S);
-        uint64_t* dw = dense_words + wbase;
-        for (uint32_t i = threadIdx.x; i < nw; i += 64) dw[i] = w[i];
-        uint32_t* dm = dense_meta + 5 * cbase;
-        for (uint32_t i = threadIdx.x; i < nc; i += 64) {
-            dm[i] = s_clen(cfg, S)[i];
-            dm[nc + i] = s_cstart(cfg, S)[i];
-            dm[2 * nc + i] = s_tpos(cfg, S)[i];
-            dm[3 * nc + i] = s_terr(cfg, S)[i];
-            dm[4 * nc + i] = s_ttgt(cfg, S)[i];
-        }
         if (threadIdx.x == 0) {
             SlotRec r;
-            r.o = o; r.p = po; r.nw = nw; r.nc = nc; r.wbase = wbase; r.cbase = cbase;
+            r.o = o; r.p = po;
+            emit_plan(o, po, want_all != 0, ix.k, r.nw, r.nc, r.asc, r.ext); /* po is uniform over the wave */
+            r.wbase = r.cbase = r.abase = r.ebase = 0;
+            r.rpos = r.gpos = 0;
             recs[slot] = r;
         }
     }
+}
+
+/* ---- where every slot's output goes: exclusive prefix sums, in slot order, of what the slots contribute to the dense words, the dense
+ * metadata, the sequence arena, the extension arena, the list of gaps to re-run and the list of multi-contig gaps.  k_scan1: one thread per
+ * slot, offsets inside its block of SCAN_SL slots + the block's totals and statistics; k_scan2 (one workgroup): offsets of the blocks on
+ * top of the batch's cursors, totals of the launch; k_emit adds the two. */
+enum { SCAN_SL = 256, SCAN_NV = 6, SCAN_NS = 9 };
+struct ScanBlock {
+    uint64_t v[SCAN_NV]; /* k_scan1: totals of the block; k_scan2: replaced by the block's base */
+    uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext */
+};
+__global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, ScanBlock* blocks)
+{
+    __shared__ uint64_t sh[SCAN_NV][SCAN_SL];
+    __shared__ unsigned long long ssum[SCAN_NS];
+    const uint32_t t = threadIdx.x, slot = blockIdx.x * SCAN_SL + t;
+    if (t < SCAN_NS) ssum[t] = 0;
+    uint64_t v[SCAN_NV] = {0, 0, 0, 0, 0, 0};
+    if (slot < m) {
+        const SlotRec& r = recs[slot];
+        const bool ok = r.o.status == GAP_OK;
+        v[0] = r.nw; v[1] = r.nc; v[2] = r.asc; v[3] = r.ext;
+        v[4] = ok ? 0 : 1;
+        v[5] = (ok && r.nc) ? 1 : 0; /* its contigs go back to the host: multi-contig path, or the stage-A entry */
+    }
+    for (int j = 0; j < SCAN_NV; j++) sh[j][t] = v[j];
+    __syncthreads();
+    if (slot < m) {
+        const SlotRec& r = recs[slot];
+        atomicAdd(&ssum[0], (unsigned long long)r.o.lines);
+        atomicAdd(&ssum[1], (unsigned long long)r.o.store_reads);
+        atomicAdd(&ssum[2], (unsigned long long)r.o.run_nt);
+        atomicAdd(&ssum[4], (unsigned long long)r.o.n_words);
+        if (r.o.status == GAP_OK) {
+            atomicAdd(&ssum[3], (unsigned long long)r.o.total_nt);
+            atomicAdd(&ssum[5], (unsigned long long)r.p.lines);
+            atomicAdd(&ssum[6], (unsigned long long)r.p.ab_n);
+            if (r.asc) atomicAdd(&ssum[7], 1ull);
+            if (r.ext) atomicAdd(&ssum[8], 1ull);
+        }
+    }
+    /* inclusive Hillis-Steele scan of the six columns */
+    for (uint32_t d = 1; d < SCAN_SL; d <<= 1) {
+        uint64_t add[SCAN_NV];
+        for (int j = 0; j < SCAN_NV; j++) add[j] = t >= d ? sh[j][t - d] : 0;
+        __syncthreads();
+        for (int j = 0; j < SCAN_NV; j++) sh[j][t] += add[j];
+        __syncthreads();
+    }
+    if (slot < m) {
+        SlotRec& r = recs[slot];
+        r.wbase = sh[0][t] - v[0]; r.cbase = sh[1][t] - v[1]; r.abase = sh[2][t] - v[2]; r.ebase = sh[3][t] - v[3];
+        r.rpos = (uint32_t)(sh[4][t] - v[4]); r.gpos = (uint32_t)(sh[5][t] - v[5]);
+    }
+    if (t < SCAN_NV) blocks[blockIdx.x].v[t] = sh[t][SCAN_SL - 1];
+    if (t < SCAN_NS) blocks[blockIdx.x].s[t] = ssum[t];
+}
+/* cursors[0..3]: words, metadata entries, sequence bytes, extension bytes of the batch so far */
+__global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nblocks, unsigned long long* cursors, PartTot* tot)
+{
+    enum { TILE = 1024 };
+    __shared__ uint64_t sh[SCAN_NV][TILE];
+    __shared__ uint64_t carry[SCAN_NV];
+    __shared__ unsigned long long ssum[SCAN_NS];
+    const uint32_t t = threadIdx.x;
+    if (t < SCAN_NV) carry[t] = t < 4 ? cursors[t] : 0;
+    if (t < SCAN_NS) ssum[t] = 0;
+    __syncthreads();
+    if (t < 4) tot->begin[t] = carry[t];
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += TILE) {
+        const uint32_t nb = nblocks - b0 < (uint32_t)TILE ? nblocks - b0 : (uint32_t)TILE;
+        for (uint32_t i = t; i < nb * SCAN_NV; i += 256) sh[i % SCAN_NV][i / SCAN_NV] = blocks[b0 + i / SCAN_NV].v[i % SCAN_NV];
+        for (uint32_t i = t; i < nb * SCAN_NS; i += 256) atomicAdd(&ssum[i % SCAN_NS], (unsigned long long)blocks[b0 + i / SCAN_NS].s[i % SCAN_NS]);
+        __syncthreads();
+        if (t < SCAN_NV) { /* one thread per column: the blocks' totals become their bases */
+            uint64_t run = carry[t];
+            for (uint32_t i = 0; i < nb; i++) { const uint64_t x = sh[t][i]; sh[t][i] = run; run += x; }
+            carry[t] = run;
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < nb * SCAN_NV; i += 256) blocks[b0 + i / SCAN_NV].v[i % SCAN_NV] = sh[i % SCAN_NV][i / SCAN_NV];
+        __syncthreads();
+    }
+    if (t < 4) { tot->end[t] = carry[t]; cursors[t] = carry[t]; }
+    if (t == 0) {
+        tot->n_retry = (uint32_t)carry[4];
+        tot->n_general = (uint32_t)carry[5];
+        tot->lines = ssum[0]; tot->store_runs = ssum[1]; tot->run_nt = ssum[2]; tot->contig_nt = ssum[3]; tot->contig_words = ssum[4];
+        tot->post_lines = ssum[5]; tot->cov_kmers = ssum[6];
+        tot->n_filled = (uint32_t)ssum[7]; tot->n_ext = (uint32_t)ssum[8];
+    }
+}
+/* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
+__global__ void __launch_bounds__(64) k_emit(FillCfg cfg, uint8_t* raw, SlotRec* recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
+                                             const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t* retry_list, uint32_t* general_list, uint32_t n)
+{
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    __shared__ SlotRec r;
+    if (threadIdx.x == 0) {
+        r = recs[slot];
+        const ScanBlock& b = blocks[slot / SCAN_SL];
+        r.wbase += b.v[0]; r.cbase += b.v[1]; r.abase += b.v[2]; r.ebase += b.v[3];
+        r.rpos += (uint32_t)b.v[4]; r.gpos += (uint32_t)b.v[5];
+        recs[slot] = r; /* absolute from here on (the host reads the records of the gaps it has to look at) */
+        if (r.o.status != GAP_OK) retry_list[r.rpos] = slot;
+        else if (r.nc) general_list[r.gpos] = slot;
+    }
+    __syncthreads();
+    GapScratch S;
+    S.z = nullptr;
+    S.v = nullptr;
+    S.lane = 0;
+    S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    const uint32_t g = ids ? ids[slot] : slot;
+    emit_gap(cfg, S, r, gflags[g], slot, g, k, D, H);
 }
 
 /* contig-graph walk of the multi-contig gaps of a chunk (mtg_paths.h), one wave per gap */
@@ -830,7 +926,6 @@ void index_release(mtg_index* idx)
         if (w.stream) (void)hipStreamDestroy((hipStream_t)w.stream);
         if (w.copy_stream) (void)hipStreamDestroy((hipStream_t)w.copy_stream);
     }
-    index_forget_host_copy(idx);
     free_tables(idx);
     delete idx;
 }
@@ -907,6 +1002,47 @@ void* staging_host(Workspace* wsp, int slot, size_t bytes)
     return ws.hptr[slot];
 }
 
+
+void* pinned_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+
+/* device copies of a marshalled batch: blocks A and B and the encoded targets (block C only serves to make those) */
+int batch_upload(const mtg_index* idx, FillInput& in)
+{
+    if (int rc = use_device_of(idx)) return rc;
+    batch_release_device(in);
+    DevBuf a, b, c, t;
+    const uint64_t n_targets = in.traw.size() / TARGET_SLOT;
+    HIP_TRY(a.alloc(in.bytes_a));
+    HIP_TRY(b.alloc(in.bytes_b));
+    HIP_TRY(c.alloc(in.bytes_c));
+    HIP_TRY(t.alloc(n_targets * 16 + 64));
+    HIP_TRY(hipMemcpy(a.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice));
+    if (n_targets) {
+        hipLaunchKernelGGL(k_encode_targets, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, 0, c.as<uint8_t>(), t.as<uint64_t>(), t.as<uint64_t>() + n_targets, n_targets, in.k);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    in.dev_a = a.release();
+    in.dev_b = b.release();
+    in.dev_tenc = t.release();
+    return MTG_OK;
+}
+void batch_release_device(FillInput& in)
+{
+    if (in.dev_a) (void)hipFree(in.dev_a);
+    if (in.dev_b) (void)hipFree(in.dev_b);
+    if (in.dev_tenc) (void)hipFree(in.dev_tenc);
+    in.dev_a = in.dev_b = in.dev_tenc = nullptr;
+}
+
 namespace {
 struct EventSet { /* events of one device_run call */
     std::vector<hipEvent_t> ev;
@@ -918,13 +1054,13 @@ struct EventSet { /* events of one device_run call */
 } // namespace
 
 /* The caller holds the lock of in.ws (a workspace and its staging blocks belong to one batch at a time); everything the batch queues
- * goes to the workspace's own streams, so that two batches on the device overlap.
+ * goes to the workspace's own stream, so that two batches on the device overlap.
  *
- * One traversal launch covers as many gaps as fit the scratch; its post-processing runs as up to MTG_POST_PARTS launches over
- * consecutive slot ranges, each with its own dense arrays and counters, so that a part's results travel back (copy stream) and are
- * handed to the caller (on_ready) while the device works on the next part. */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats,
-               const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)
+ * One launch = as many gaps as fit the scratch: traversal (k_stage_a), terminal search + coverage (k_post), layout of the results
+ * (k_scan1, k_scan2), results (k_emit); then the totals come back, and with them the sizes of the copies that bring the records and the
+ * sequences to the host arrays of `sink`.  The host looks at a gap only if it has to be re-run in a larger scratch tier or takes the
+ * multi-contig path (`special`). */
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, ResultSink& sink, DevBatch& special, mtg_batch_stats* stats, const std::function<void()>* while_busy)
 {
     bool busy_done = false;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -941,13 +1077,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         ws.copy_stream = (void*)s1;
         HIP_TRY(hipDeviceSynchronize()); /* the index was built or loaded on the null stream, which these streams do not wait for */
     }
-    const hipStream_t stream = (hipStream_t)ws.stream, copy_stream = (hipStream_t)ws.copy_stream;
+    const hipStream_t stream = (hipStream_t)ws.stream;
     const size_t n = in.src.size();
-    batch.n = n;
-    batch.part = ~(size_t)0;
-    batch.chunk_of.clear();
-    batch.slot_of.clear();
-    batch.chunks.clear();
+    special.chunks.clear();
+    special.special.clear();
+    sink.seq_used = 0;
+    sink.ext_used = 1;
+    sink.n_filled = 0;
+    sink.in_gap_order = true;
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
     if (n == 0) { if (while_busy) (*while_busy)(); if (stats) *stats = st; return MTG_OK; }
     const int k = idx->dev.k;
@@ -955,19 +1092,31 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_cnt = wsbuf();
-    /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device */
+          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf();
+    /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
+     * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
-    HIP_TRY(d_ina.alloc(in.bytes_a));
-    HIP_TRY(d_inb.alloc(in.bytes_b));
-    HIP_TRY(d_inc.alloc(in.bytes_c));
-    HIP_TRY(d_cnt.alloc(16 * MTG_POST_PARTS));
-    HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, stream));
     const uint64_t n_targets = in.traw.size() / TARGET_SLOT;
-    HIP_TRY(d_tenc.alloc(n_targets * 16 + 64));
-    const uint8_t* da = d_ina.as<uint8_t>();
+    const uint8_t* da;
+    const uint64_t* d_rw;
+    uint64_t* d_tle;
+    if (in.dev_a) {
+        da = (const uint8_t*)in.dev_a;
+        d_rw = (const uint64_t*)in.dev_b;
+        d_tle = (uint64_t*)in.dev_tenc;
+    } else {
+        HIP_TRY(d_ina.alloc(in.bytes_a));
+        HIP_TRY(d_inb.alloc(in.bytes_b));
+        HIP_TRY(d_inc.alloc(in.bytes_c));
+        HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_inb.p, in.block_b, in.bytes_b, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, stream));
+        HIP_TRY(d_tenc.alloc(n_targets * 16 + 64));
+        da = d_ina.as<uint8_t>();
+        d_rw = d_inb.as<uint64_t>();
+        d_tle = d_tenc.as<uint64_t>();
+        if (n_targets) hipLaunchKernelGGL(k_encode_targets, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, stream, d_inc.as<uint8_t>(), d_tle, d_tle + n_targets, n_targets, k);
+    }
     const uint64_t* d_src = (const uint64_t*)(da + FillInput::off_a(n, 0));
     const uint64_t* d_r0 = (const uint64_t*)(da + FillInput::off_a(n, 1));
     const uint32_t* d_roff = (const uint32_t*)(da + FillInput::off_a(n, 2));
@@ -976,42 +1125,42 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
     const uint32_t* d_tcnt = (const uint32_t*)(da + FillInput::off_a(n, 5));
     const uint8_t* d_mis = da + FillInput::off_a(n, 6);
     const uint8_t* d_fok = da + FillInput::off_a(n, 7);
-    const uint64_t* d_rw = d_inb.as<uint64_t>();
-    uint64_t* d_tle = d_tenc.as<uint64_t>();
+    const uint8_t* d_flags = da + FillInput::off_a(n, 8);
     uint64_t* d_tbad = d_tle + n_targets;
-    if (n_targets) hipLaunchKernelGGL(k_encode_targets, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, stream, d_inc.as<uint8_t>(), d_tle, d_tbad, n_targets, k);
+    HIP_TRY(d_cnt.alloc(64));
+    HIP_TRY(d_tot.alloc(sizeof(PartTot)));
+    {
+        const unsigned long long init[8] = {0, 0, 0, 1 /* the extension arena starts with the empty string */, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(d_cnt.p, init, 64, hipMemcpyHostToDevice, stream)); /* pageable source: copied before the call returns */
+    }
     st.h2d_ms += now_ms() - t0;
     tick("upload (async)");
 
     EventSet events;
-    hipEvent_t ev0, ev1, ev2, evp[MTG_POST_PARTS], evcp[MTG_POST_PARTS];
-    for (int q = 0; q < MTG_POST_PARTS; q++) HIP_TRY(events.make(evcp[q]));
+    hipEvent_t ev0, ev1, ev2, ev3;
     HIP_TRY(events.make(ev0));
     HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
-    for (int q = 0; q < MTG_POST_PARTS; q++) HIP_TRY(events.make(evp[q]));
-    unsigned long long* h_tot = (unsigned long long*)staging_host(&ws, Workspace::NHOST - 1, 16 * MTG_POST_PARTS);
-    std::vector<unsigned long long> h_tot_own(2 * MTG_POST_PARTS, 0);
-    if (!h_tot) h_tot = h_tot_own.data();
+    HIP_TRY(events.make(ev3));
+    PartTot* h_tot = (PartTot*)staging_host(&ws, Workspace::NHOST - 1, sizeof(PartTot) + 64);
+    if (!h_tot) { set_error("no page-locked memory for the totals of a launch"); return MTG_ERR_NOMEM; }
 
     std::vector<uint32_t> todo; /* empty at tier 0: every gap, in order */
     size_t n_todo = n;
     int rc = MTG_OK;
     const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the path enumeration to the host */
-    const uint32_t post_grid = getenv("MTG_POST_GRID") ? (uint32_t)atoi(getenv("MTG_POST_GRID")) : 0xFFFFFFFFu; /* cap on the workgroups of a k_post launch (test hook) */
-    const int env_parts = getenv("MTG_POST_PARTS") ? atoi(getenv("MTG_POST_PARTS")) : 0; /* test hook */
+    const bool want_records = sink.res != nullptr;
+    size_t launches = 0;
 
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
         /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
-        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + (uint64_t)cfg.cap_words * 8 +
-                                 (uint64_t)cfg.cap_contigs * 20;
-        const size_t cached = ws.cap[d_zero.slot] + ws.cap[d_raw.slot] + ws.cap[d_ilv.slot] + ws.cap[d_dw.slot] + ws.cap[d_dm.slot]; /* already ours */
+        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + sizeof(mtg_gap_result) + sizeof(mtg_filled);
+        const size_t cached = ws.cap[d_zero.slot] + ws.cap[d_raw.slot] + ws.cap[d_ilv.slot]; /* already ours */
         size_t free_b = 0, total_b = 0;
         /* steady state: every scratch buffer of the workspace already holds a batch of this size at this tier, nothing will be allocated */
         const uint64_t m0 = std::min<uint64_t>(n_todo, 1u << 20);
-        const bool fits = ws.cap[d_zero.slot] >= m0 * cfg.zero_stride && ws.cap[d_raw.slot] >= m0 * cfg.raw_stride + 64 && ws.cap[d_ilv.slot] >= ((m0 + 63) / 64) * cfg.ilv_stride &&
-                          ws.cap[d_dw.slot] >= m0 * (uint64_t)cfg.cap_words * 8 + 64 && ws.cap[d_dm.slot] >= m0 * (uint64_t)cfg.cap_contigs * 20 + 64;
+        const bool fits = ws.cap[d_zero.slot] >= m0 * cfg.zero_stride && ws.cap[d_raw.slot] >= m0 * cfg.raw_stride + 64 && ws.cap[d_ilv.slot] >= ((m0 + 63) / 64) * cfg.ilv_stride;
         if (!fits) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         size_t chunk = fits ? (size_t)m0 : (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
         const size_t env_chunk = getenv("MTG_MAX_CHUNK") ? (size_t)atol(getenv("MTG_MAX_CHUNK")) : 0; /* test hook: several launches per batch */
@@ -1027,13 +1176,21 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
         HIP_TRY(d_rec.alloc(chunk * sizeof(SlotRec)));
         HIP_TRY(d_ids.alloc(chunk * 4));
-        HIP_TRY(d_dw.alloc(chunk * (uint64_t)cfg.cap_words * 8 + 64));
-        HIP_TRY(d_dm.alloc(chunk * (uint64_t)cfg.cap_contigs * 20 + 64));
+        HIP_TRY(d_blocks.alloc(((chunk + SCAN_SL - 1) / SCAN_SL + 1) * sizeof(ScanBlock)));
+        HIP_TRY(d_res.alloc(chunk * sizeof(mtg_gap_result)));
+        HIP_TRY(d_fil.alloc(chunk * sizeof(mtg_filled)));
+        HIP_TRY(d_rlist.alloc(chunk * 4));
+        HIP_TRY(d_glist.alloc(chunk * 4));
+        HIP_TRY(d_seq.alloc(std::max<size_t>(sink.seq_cap, 64)));
+        HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
+        /* dense words / metadata: only the gaps that need the host bring their contigs back; sized by the last need, grown on demand below */
+        HIP_TRY(d_dw.alloc(std::max<size_t>(ws.cap[d_dw.slot], 1 << 20)));
+        HIP_TRY(d_dm.alloc(std::max<size_t>(ws.cap[d_dm.slot], 1 << 16)));
         tick("workspace alloc");
         std::vector<uint32_t> retry;
         for (size_t base = 0; base < n_todo; base += chunk) {
             const uint32_t m = (uint32_t)std::min(chunk, n_todo - base);
-            const bool identity = todo.empty() && base == 0 && m == n; /* the whole batch in one traversal launch: slot = gap */
+            const bool identity = todo.empty() && base == 0 && m == n; /* the whole batch in one launch: slot = gap */
             const uint32_t* ids = nullptr;
             std::vector<uint32_t> seq_ids;
             const uint32_t* host_ids = nullptr; /* gap of every slot of this launch (nullptr: identity) */
@@ -1044,8 +1201,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                 HIP_TRY(hipMemcpyAsync(d_ids.p, host_ids, (size_t)m * 4, hipMemcpyHostToDevice, stream)); /* host_ids outlives the launch */
                 ids = d_ids.as<uint32_t>();
                 st.h2d_ms += now_ms() - t0;
+                sink.in_gap_order = false;
             }
-            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16 * MTG_POST_PARTS, stream));
+            launches++;
             /* The traversal reads index shape and configuration from the module's constants, of which there is one set per workspace
              * number: the batches of an index never share a set, batches of different indexes may, so a set is locked until the traversal
              * that reads it has finished (below, after the host work that runs meanwhile). */
@@ -1059,133 +1217,140 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
                                d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset);
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
-            tick("host prep+launch");
-            /* post-processing in parts */
-            uint32_t nparts = env_parts > 0 ? (uint32_t)env_parts : (m >= 16384 ? 4u : 1u);
-            if (nparts > (uint32_t)MTG_POST_PARTS) nparts = MTG_POST_PARTS;
-            uint32_t psize = (((m + nparts - 1) / nparts) + 63u) & ~63u; /* slots per part */
-            if (psize == 0) psize = 64;
-            nparts = (m + psize - 1) / psize;
-            for (uint32_t q = 0; q < nparts; q++) {
-                const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize);
-                hipLaunchKernelGGL(k_post, dim3(std::min<uint32_t>(s1 - s0, post_grid)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis,
-                                   d_fok, in.want_all_contigs ? 1u : 0u, d_cnt.as<unsigned long long>() + 2 * q, d_rec.as<SlotRec>(),
-                                   d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, s0, s1);
-                HIP_TRY(hipMemcpyAsync(h_tot + 2 * q, d_cnt.as<unsigned long long>() + 2 * q, 16, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipEventRecord(evp[q], stream));
-            }
-            HIP_TRY(hipEventRecord(ev2, stream));
+            const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
+            hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
+                               in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
+            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16, stream)); /* the dense arrays hold one launch at a time; the two arenas the whole batch */
+            hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
+            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_tot, d_tot.p, sizeof(PartTot), hipMemcpyDeviceToHost, stream));
+            EmitDev D;
+            EmitHost H;
+            auto emit = [&]() -> int {
+                D.seq = d_seq.as<char>(); D.ext = d_ext.as<char>();
+                D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
+                D.res = d_res.as<mtg_gap_result>(); D.fil = d_fil.as<mtg_filled>();
+                D.dense_words = d_dw.as<uint64_t>(); D.dense_meta = d_dm.as<uint32_t>();
+                H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
+                hipLaunchKernelGGL(k_emit, dim3(m), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H, d_rlist.as<uint32_t>(),
+                                   d_glist.as<uint32_t>(), m);
+                HIP_TRY(hipGetLastError());
+                return MTG_OK;
+            };
+            /* the results are written right away, on the assumption that the arenas are large enough (they are, from the second batch of a
+             * shape on): the totals tell */
+            if (int erc = emit()) return erc;
+            HIP_TRY(hipEventRecord(ev2, stream));
+            tick("host prep+launch");
             if (while_busy && !busy_done) { busy_done = true; (*while_busy)(); tick("host work during kernels"); }
-            HIP_TRY(hipEventSynchronize(ev1));
-            traversal_lock.unlock();
-            const uint32_t first_chunk = (uint32_t)batch.chunks.size();
-            if (identity) batch.part = psize;
-            else if (batch.chunk_of.empty()) {
-                /* results are scattered over chunks from here on: keep an explicit map (earlier chunks, if any, came from an identity launch) */
-                batch.chunk_of.assign(n, 0);
-                batch.slot_of.resize(n);
-                for (size_t i = 0; i < n; i++) { batch.chunk_of[i] = batch.part == ~(size_t)0 ? 0u : (uint32_t)(i / batch.part); batch.slot_of[i] = batch.part == ~(size_t)0 ? (uint32_t)i : (uint32_t)(i % batch.part); }
-            }
-            /* The copy back of part q is queued as soon as the part is done and runs while the host finishes part q - 1. */
-            struct PartState { uint32_t s0 = 0, mq = 0, chunk_id = 0; uint64_t tw = 0; SlotRec* h_rec = nullptr; uint64_t* h_w = nullptr; } ps[MTG_POST_PARTS];
-            for (uint32_t qq = 0; qq <= nparts; qq++) {
-                if (qq < nparts) {
-                    const uint32_t q = qq;
-                    const uint32_t s0 = q * psize, s1 = std::min(m, s0 + psize), mq = s1 - s0;
-                    HIP_TRY(hipEventSynchronize(evp[q]));
-                    if (q == 0) tick("first part ready");
-                    t0 = now_ms();
-                    const uint64_t tw = h_tot[2 * q], tc = h_tot[2 * q + 1];
-                    batch.chunks.emplace_back(new HostChunk());
-                    HostChunk& hc = *batch.chunks.back();
-                    const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
-                    SlotRec* h_rec = nullptr;
-                    uint64_t* h_w = nullptr;
-                    uint32_t* h_m = nullptr;
-                    void* block = (int)chunk_id + STAGING_CHUNK0 < Workspace::NHOST - 1 ? staging_host(&ws, (int)chunk_id + STAGING_CHUNK0, HostChunk::bytes_for(mq, tw, tc)) : nullptr;
-                    hc.carve(block, mq, tw, tc, h_rec, h_w, h_m);
-                    HIP_TRY(hipStreamWaitEvent(copy_stream, evp[q], 0));
-                    HIP_TRY(hipMemcpyAsync(h_rec, d_rec.as<SlotRec>() + s0, (size_t)mq * sizeof(SlotRec), hipMemcpyDeviceToHost, copy_stream));
-                    if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.as<uint64_t>() + (uint64_t)s0 * cfg.cap_words, tw * 8, hipMemcpyDeviceToHost, copy_stream));
-                    if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.as<uint32_t>() + (uint64_t)s0 * cfg.cap_contigs * 5, tc * 20, hipMemcpyDeviceToHost, copy_stream));
-                    HIP_TRY(hipEventRecord(evcp[q], copy_stream));
-                    ps[q].s0 = s0; ps[q].mq = mq; ps[q].chunk_id = chunk_id; ps[q].tw = tw; ps[q].h_rec = h_rec; ps[q].h_w = h_w;
-                    st.d2h_ms += now_ms() - t0;
-                }
-                if (qq > 0) {
-                    const uint32_t q = qq - 1;
-                    const uint32_t s0 = ps[q].s0, mq = ps[q].mq, chunk_id = ps[q].chunk_id;
-                    const uint64_t tw = ps[q].tw;
-                    SlotRec* const h_rec = ps[q].h_rec;
-                    uint64_t* const h_w = ps[q].h_w;
-                    HostChunk& hc = *batch.chunks[chunk_id];
-                    t0 = now_ms();
-                    HIP_TRY(hipEventSynchronize(evcp[q]));
-                    h_w[tw] = 0;
-                    st.d2h_ms += now_ms() - t0;
-                    t0 = now_ms();
-                    /* statistics and what needs another look: a serial scan of a part's records costs less than a parallel region */
-                    uint64_t nt_sum = 0, lines = 0, runs = 0, run_nt = 0, plines = 0, cwords = 0, cov = 0;
-                    bool any_retry = false, any_general = false;
-                    for (uint32_t s2 = 0; s2 < mq; s2++) {
-                        lines += h_rec[s2].o.lines;
-                        runs += h_rec[s2].o.store_reads;
-                        run_nt += h_rec[s2].o.run_nt;
-                        cwords += h_rec[s2].o.n_words;
-                        if (h_rec[s2].o.status != GAP_OK) { any_retry = true; continue; }
-                        nt_sum += h_rec[s2].o.total_nt;
-                        plines += h_rec[s2].p.lines;
-                        cov += h_rec[s2].p.ab_n;
-                        if (h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) any_general = true;
-                    }
-                    st.index_lines += lines;
-                    st.contig_nt += nt_sum;
-                    st.store_runs += runs;
-                    st.run_nt += run_nt;
-                    st.post_lines += plines;
-                    st.contig_words += cwords;
-                    st.coverage_kmers += cov;
-                    st.dense_words += tw;
-                    if (!identity) {
-                        for (uint32_t s2 = 0; s2 < mq; s2++) {
-                            if (h_rec[s2].o.status != GAP_OK) continue;
-                            const uint32_t g = host_ids[s0 + s2];
-                            batch.chunk_of[g] = chunk_id;
-                            batch.slot_of[g] = s2;
-                        }
-                    }
-                    if (any_retry)
-                        for (uint32_t s2 = 0; s2 < mq; s2++)
-                            if (h_rec[s2].o.status != GAP_OK) retry.push_back(host_ids ? host_ids[s0 + s2] : (uint32_t)(s0 + s2));
-                    /* multi-contig gaps: their contig-graph paths, while the launch's scratch is still in place */
-                    if (!host_paths && any_general) {
-                        std::vector<uint32_t> gslots;
-                        for (uint32_t s2 = 0; s2 < mq; s2++)
-                            if (h_rec[s2].o.status == GAP_OK && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) gslots.push_back(s0 + s2);
-                        if (!gslots.empty()) {
-                            DevBuf d_gs, d_po;
-                            HIP_TRY(d_gs.alloc(gslots.size() * 4));
-                            HIP_TRY(hipMemcpyAsync(d_gs.p, gslots.data(), gslots.size() * 4, hipMemcpyHostToDevice, stream));
-                            HIP_TRY(d_po.alloc(gslots.size() * (size_t)PATHS_WORDS * 4));
-                            hipLaunchKernelGGL(k_paths, dim3((unsigned)gslots.size()), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_gs.as<uint32_t>(), k,
-                                               d_po.as<uint32_t>(), (uint32_t)gslots.size());
-                            HIP_TRY(hipGetLastError());
-                            hc.paths.resize(gslots.size() * (size_t)PATHS_WORDS);
-                            HIP_TRY(hipMemcpyAsync(hc.paths.data(), d_po.p, hc.paths.size() * 4, hipMemcpyDeviceToHost, stream));
-                            HIP_TRY(hipStreamSynchronize(stream));
-                            hc.path_of.assign(mq, -1);
-                            for (size_t g2 = 0; g2 < gslots.size(); g2++) hc.path_of[gslots[g2] - s0] = (int32_t)g2;
-                        }
-                    }
-                    st.host_ms += now_ms() - t0;
-                    /* hand the part to the caller: the gaps of its slots (those to be re-run excepted, the caller sees their status) */
-                    if (on_ready) (*on_ready)(chunk_id, host_ids ? host_ids + s0 : nullptr, host_ids ? 0 : (size_t)s0, mq);
-                }
-            }
-            (void)first_chunk;
             HIP_TRY(hipEventSynchronize(ev2));
-            tick("all parts done");
+            traversal_lock.unlock();
+            tick("totals ready");
+            t0 = now_ms();
+            PartTot tot = *h_tot;
+            /* an array that was too small: make it larger and write the launch's results again (its scratch is still in place) */
+            const uint64_t need_w = tot.end[0] * 8 + 64, need_m = tot.end[1] * 20 + 64;
+            bool again = false;
+            if (tot.end[2] > sink.seq_cap) {
+                /* the block may move: what earlier launches of the batch left in it is kept, the records that point there follow */
+                const uintptr_t old = (uintptr_t)sink.seq, old_end = old + sink.seq_cap;
+                if (!sink.grow_seq || !sink.grow_seq((size_t)tot.end[2], (size_t)tot.begin[2])) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)tot.end[2]); return MTG_ERR_ARG; }
+                if (want_records && tot.begin[2] > 0 && (uintptr_t)sink.seq != old)
+                    for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.fil[i].seq; if (q >= old && q < old_end) sink.fil[i].seq = sink.seq + (q - old); }
+                again = true;
+            }
+            if (tot.end[3] > sink.ext_cap) {
+                const uintptr_t old = (uintptr_t)sink.ext, old_end = old + sink.ext_cap;
+                if (!sink.grow_ext || !sink.grow_ext((size_t)tot.end[3], (size_t)tot.begin[3])) { set_error("extension buffer too small: %llu bytes needed", (unsigned long long)tot.end[3]); return MTG_ERR_NOMEM; }
+                if (want_records && launches > 1 && (uintptr_t)sink.ext != old)
+                    for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.res[i].extension; if (q >= old && q < old_end) sink.res[i].extension = sink.ext + (q - old); }
+                again = true;
+            }
+            if (need_w > ws.cap[d_dw.slot] || need_m > ws.cap[d_dm.slot]) again = true;
+            if (again) {
+                /* the dense arrays hold this launch only (offsets relative to the batch: the launch's part is copied from begin[]) */
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(d_seq.alloc(std::max<size_t>(sink.seq_cap, 64)));
+                HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
+                HIP_TRY(d_dw.alloc(need_w));
+                HIP_TRY(d_dm.alloc(need_m));
+                /* k_emit made the records' offsets absolute: run the layout again from the launch's begin */
+                HIP_TRY(hipMemcpyAsync(d_cnt.p, tot.begin, 32, hipMemcpyHostToDevice, stream));
+                hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
+                hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());
+                if (int erc = emit()) return erc;
+            }
+            /* bring the launch's results to the host */
+            std::vector<mtg_gap_result> tmp_res;
+            std::vector<mtg_filled> tmp_fil;
+            if (want_records) {
+                if (identity) {
+                    HIP_TRY(hipMemcpyAsync(sink.res, d_res.p, (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(sink.fil, d_fil.p, (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
+                } else {
+                    tmp_res.resize(m);
+                    tmp_fil.resize(m);
+                    HIP_TRY(hipMemcpyAsync(tmp_res.data(), d_res.p, (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(tmp_fil.data(), d_fil.p, (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
+                }
+                if (tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], d_seq.as<char>() + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
+                if (tot.end[3] > tot.begin[3]) HIP_TRY(hipMemcpyAsync(sink.ext + tot.begin[3], d_ext.as<char>() + tot.begin[3], tot.end[3] - tot.begin[3], hipMemcpyDeviceToHost, stream));
+            }
+            std::vector<uint32_t> rlist(tot.n_retry), glist(tot.n_general);
+            HostChunk* hc = nullptr;
+            SlotRec* h_rec = nullptr;
+            uint64_t* h_w = nullptr;
+            uint32_t* h_m = nullptr;
+            const uint64_t tw = tot.end[0], tc = tot.end[1];
+            if (tot.n_retry) HIP_TRY(hipMemcpyAsync(rlist.data(), d_rlist.p, (size_t)tot.n_retry * 4, hipMemcpyDeviceToHost, stream));
+            if (tot.n_general) {
+                special.chunks.emplace_back(new HostChunk());
+                hc = special.chunks.back().get();
+                hc->carve(m, tw, tc, h_rec, h_w, h_m);
+                HIP_TRY(hipMemcpyAsync(glist.data(), d_glist.p, (size_t)tot.n_general * 4, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(h_rec, d_rec.p, (size_t)m * sizeof(SlotRec), hipMemcpyDeviceToHost, stream));
+                if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.p, tw * 8, hipMemcpyDeviceToHost, stream));
+                if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.p, tc * 20, hipMemcpyDeviceToHost, stream));
+            }
+            HIP_TRY(hipEventRecord(ev3, stream));
+            HIP_TRY(hipEventSynchronize(ev3));
+            st.d2h_ms += now_ms() - t0;
+            tick("results on the host");
+            t0 = now_ms();
+            st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
+            st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += tw;
+            sink.seq_used = tot.end[2];
+            sink.ext_used = tot.end[3];
+            sink.n_filled += tot.n_filled;
+            if (want_records && !identity) /* records of a partial launch: to their gaps (a gap to be re-run gets its record again later) */
+                for (uint32_t s2 = 0; s2 < m; s2++) { sink.res[host_ids[s2]] = tmp_res[s2]; sink.fil[host_ids[s2]] = tmp_fil[s2]; }
+            for (uint32_t s2 : rlist) retry.push_back(host_ids ? host_ids[s2] : s2);
+            if (tot.n_retry) sink.in_gap_order = false;
+            if (hc) {
+                h_w[tw] = 0;
+                if (host_ids) hc->gap_of.assign(host_ids, host_ids + m);
+                const uint32_t chunk_id = (uint32_t)special.chunks.size() - 1;
+                std::vector<uint32_t> pslots; /* multi-contig gaps: their contig-graph paths, while the launch's scratch is still in place */
+                for (uint32_t s2 : glist) {
+                    special.special.push_back(SpecialGap{host_ids ? host_ids[s2] : s2, chunk_id, s2});
+                    if (!host_paths && !in.want_all_contigs && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) pslots.push_back(s2);
+                }
+                if (!pslots.empty()) {
+                    HIP_TRY(d_ids.alloc(std::max<size_t>(chunk, pslots.size()) * 4)); /* the traversal is over: its slot map is free */
+                    HIP_TRY(hipMemcpyAsync(d_ids.p, pslots.data(), pslots.size() * 4, hipMemcpyHostToDevice, stream));
+                    HIP_TRY(d_paths.alloc(pslots.size() * (size_t)PATHS_WORDS * 4));
+                    hipLaunchKernelGGL(k_paths, dim3((unsigned)pslots.size()), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_ids.as<uint32_t>(), k,
+                                       d_paths.as<uint32_t>(), (uint32_t)pslots.size());
+                    HIP_TRY(hipGetLastError());
+                    hc->paths.resize(pslots.size() * (size_t)PATHS_WORDS);
+                    HIP_TRY(hipMemcpyAsync(hc->paths.data(), d_paths.p, hc->paths.size() * 4, hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    hc->path_of.assign(m, -1);
+                    for (size_t g2 = 0; g2 < pslots.size(); g2++) hc->path_of[pslots[g2]] = (int32_t)g2;
+                }
+            }
+            st.host_ms += now_ms() - t0;
             float ms = 0, ms2 = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
             HIP_TRY(hipEventElapsedTime(&ms2, ev1, ev2));
@@ -1212,6 +1377,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, D
         set_error("%zu gap(s) exceeded the largest traversal scratch tier", n_todo);
         rc = MTG_ERR_OVERFLOW;
     }
+    if (launches > 1) sink.in_gap_order = false;
     if (stats) *stats = st;
     return rc;
 }

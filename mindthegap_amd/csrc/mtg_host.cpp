@@ -102,12 +102,6 @@ struct HostIndexData {
     std::vector<uint64_t> kmers;
     std::vector<uint32_t> counts;
 };
-static std::unordered_map<const mtg_index*, HostIndexData>& host_copies()
-{
-    static std::unordered_map<const mtg_index*, HostIndexData> m;
-    return m;
-}
-static std::mutex& host_copies_mtx() { static std::mutex m; return m; }
 
 int index_from_reads(const char* paths_csv, int k, int abundance_min, int abundance_max, mtg_index** out)
 {
@@ -149,26 +143,33 @@ int index_from_reads(const char* paths_csv, int k, int abundance_min, int abunda
     if (rc) return rc;
     (*out)->info.abundance_min = abundance_min;
     (*out)->info.abundance_auto = autoc;
-    std::lock_guard<std::mutex> lk(host_copies_mtx());
-    host_copies()[*out] = std::move(hd);
     return MTG_OK;
 }
 
 static const char IDX_MAGIC[8] = {'M', 'T', 'G', 'I', 'D', 'X', '1', 0};
 
+/* The container: magic, k, abundance_min, abundance_auto, number of k-mers, then (k-mer : 8 bytes, abundance : 4 bytes) records in
+ * no particular order.  The k-mers are read back from the device tables (the index keeps no host copy), in pieces. */
+static const char IDX_MAGIC2[8] = {'M', 'T', 'G', 'I', 'D', 'X', '2', 0};
 int index_save(const mtg_index* idx, const char* path)
 {
     if (!idx || !path) { set_error("null argument"); return MTG_ERR_ARG; }
-    std::lock_guard<std::mutex> lk(host_copies_mtx());
-    auto it = host_copies().find(idx);
-    if (it == host_copies().end()) { set_error("this index has no host copy of its k-mers and cannot be saved"); return MTG_ERR_ARG; }
     FILE* f = fopen(path, "wb");
     if (!f) { set_error("cannot write %s", path); return MTG_ERR_IO; }
     int32_t hdr[4] = {idx->info.k, idx->info.abundance_min, idx->info.abundance_auto, 0};
-    uint64_t n = it->second.kmers.size();
-    bool ok = fwrite(IDX_MAGIC, 1, 8, f) == 8 && fwrite(hdr, 4, 4, f) == 4 && fwrite(&n, 8, 1, f) == 1 &&
-              fwrite(it->second.kmers.data(), 8, n, f) == n && fwrite(it->second.counts.data(), 4, n, f) == n;
-    fclose(f);
+    const uint64_t n = idx->info.nb_solid_kmers;
+    bool ok = fwrite(IDX_MAGIC2, 1, 8, f) == 8 && fwrite(hdr, 4, 4, f) == 4 && fwrite(&n, 8, 1, f) == 1;
+    int rc = MTG_OK;
+    if (ok) {
+        std::vector<unsigned char> rec;
+        rc = index_export(idx, [&](const uint64_t* k, const uint32_t* a, size_t m) {
+            rec.resize(m * 12);
+            for (size_t i = 0; i < m; i++) { memcpy(rec.data() + 12 * i, k + i, 8); memcpy(rec.data() + 12 * i + 8, a + i, 4); }
+            return fwrite(rec.data(), 12, m, f) == m;
+        });
+    }
+    ok = ok && fclose(f) == 0;
+    if (rc) return rc;
     if (!ok) { set_error("short write on %s", path); return MTG_ERR_IO; }
     return MTG_OK;
 }
@@ -187,26 +188,30 @@ int index_load(const char* path, mtg_index** out)
         set_error("%s is an HDF5 file: GATB .h5 graphs are not readable by this library (SURVEY.md 8f-2); build the index with -in", path);
         return MTG_ERR_FORMAT;
     }
-    if (memcmp(magic, IDX_MAGIC, 8) != 0 || fread(hdr, 4, 4, f) != 4 || fread(&n, 8, 1, f) != 1) { fclose(f); set_error("%s: not a mtg index", path); return MTG_ERR_FORMAT; }
+    const bool v1 = memcmp(magic, IDX_MAGIC, 8) == 0, v2 = memcmp(magic, IDX_MAGIC2, 8) == 0;
+    if (!(v1 || v2) || fread(hdr, 4, 4, f) != 4 || fread(&n, 8, 1, f) != 1) { fclose(f); set_error("%s: not a mtg index", path); return MTG_ERR_FORMAT; }
     HostIndexData hd;
     hd.kmers.resize(n);
     hd.counts.resize(n);
-    bool ok = fread(hd.kmers.data(), 8, n, f) == n && fread(hd.counts.data(), 4, n, f) == n;
+    bool ok;
+    if (v1) ok = fread(hd.kmers.data(), 8, n, f) == n && fread(hd.counts.data(), 4, n, f) == n; /* version 1: all k-mers, then all abundances */
+    else {
+        ok = true;
+        std::vector<unsigned char> rec((size_t)12 << 20);
+        for (uint64_t off = 0; off < n && ok;) {
+            const size_t m = (size_t)std::min<uint64_t>(n - off, rec.size() / 12);
+            ok = fread(rec.data(), 12, m, f) == m;
+            for (size_t i = 0; i < m && ok; i++) { memcpy(&hd.kmers[off + i], rec.data() + 12 * i, 8); memcpy(&hd.counts[off + i], rec.data() + 12 * i + 8, 4); }
+            off += m;
+        }
+    }
     fclose(f);
     if (!ok) { set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
     int rc = index_from_kmers(hd.kmers.data(), hd.counts.data(), n, hdr[0], out);
     if (rc) return rc;
     (*out)->info.abundance_min = hdr[1];
     (*out)->info.abundance_auto = hdr[2];
-    std::lock_guard<std::mutex> lk(host_copies_mtx());
-    host_copies()[*out] = std::move(hd);
     return MTG_OK;
-}
-
-void index_forget_host_copy(const mtg_index* idx)
-{
-    std::lock_guard<std::mutex> lk(host_copies_mtx());
-    host_copies().erase(idx);
 }
 
 /* ------------------------------------------------------------------------------------------------ gap post-processing */
@@ -217,14 +222,14 @@ struct TermInfo { /* info_node_t, src/Filler.hpp:44-71 */
 /* marshalling of a batch of gapFillFromSource calls (targets == nullptr: contigs only, the stage A parity entry) */
 void FillInput::resize(size_t n)
 {
-    bytes_a = 34 * n8(n) + 64;
+    bytes_a = (size_t)BYTES_A_PER_GAP * n8(n) + 64;
     block_a = ws ? staging_host(ws, 0, bytes_a) : nullptr;
     if (!block_a) { own_a.resize(bytes_a / 8 + 1); block_a = own_a.data(); }
     uint8_t* b = (uint8_t*)block_a;
     src.p = (uint64_t*)(b + off_a(n, 0)); r0.p = (uint64_t*)(b + off_a(n, 1));
     roff.p = (uint32_t*)(b + off_a(n, 2)); rlen.p = (uint32_t*)(b + off_a(n, 3)); toff.p = (uint32_t*)(b + off_a(n, 4)); tcnt.p = (uint32_t*)(b + off_a(n, 5));
-    nbmis.p = b + off_a(n, 6); fast_ok.p = b + off_a(n, 7);
-    src.n = r0.n = roff.n = rlen.n = toff.n = tcnt.n = nbmis.n = fast_ok.n = n;
+    nbmis.p = b + off_a(n, 6); fast_ok.p = b + off_a(n, 7); flags.p = b + off_a(n, 8);
+    src.n = r0.n = roff.n = rlen.n = toff.n = tcnt.n = nbmis.n = fast_ok.n = flags.n = n;
 }
 void FillInput::alloc_b(uint64_t rw, uint64_t nt)
 {
@@ -295,8 +300,9 @@ inline bool all_upper_acgt(const char* s, size_t n)
 }
 } // namespace
 
-void FillInput::set_common(size_t g, std::string_view source, std::string_view swf_target, int nb_mis)
+void FillInput::set_common(size_t g, std::string_view source, std::string_view swf_target, int nb_mis, uint8_t gap_flags)
 {
+    flags[g] = gap_flags;
     const uint64_t kfields = kmask(k);
     char sb[32] = {0};
     memcpy(sb, source.data(), (size_t)k); /* k <= 31 characters; the caller has checked that the source has them */
@@ -328,15 +334,6 @@ void FillInput::set_target(size_t o, std::string_view seq)
     if (usable) memcpy(slot, seq.data(), (size_t)k);
     slot[TARGET_SLOT - 1] = usable ? 1 : 0;
 }
-void FillInput::set(size_t g, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis)
-{
-    set_common(g, source, swf_target, nb_mis);
-    if (targets) {
-        size_t o = toff[g];
-        for (const Target& t : *targets) set_target(o++, t.seq);
-    }
-}
-
 struct ContigGraph {
     std::vector<std::vector<int>> in_edges; /* ascending, unique (std::set order of src/GraphAnalysis.cpp:110) */
     ContigGraph(const GapDev& gc, int k)
@@ -407,68 +404,6 @@ static int compute_qual(const Solution& s, bool repeated) /* src/Utils.hpp:85-10
     return q;
 }
 
-/* ASCII of the packed nucleotides [from, from + L) of `words` (2 bits each, nucleotide i at bits 2(i mod 32) of word i / 32), four per
- * table lookup; reversed and complemented when rc is set.  Reads at most one word past the last one used (the chunk storage is padded). */
-struct DecodeLut {
-    uint32_t fwd[256], rc[256];
-    DecodeLut()
-    {
-        static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
-        for (int b = 0; b < 256; b++) {
-            char f[4], r[4];
-            for (int j = 0; j < 4; j++) { f[j] = NT[(b >> (2 * j)) & 3]; r[3 - j] = NTC[(b >> (2 * j)) & 3]; }
-            memcpy(&fwd[b], f, 4);
-            memcpy(&rc[b], r, 4);
-        }
-    }
-};
-#if defined(__x86_64__)
-/* 32 nucleotides per step: the 2-bit codes are spread to one per byte (pdep) and looked up 32 at a time (vpshufb).  Returns how many
- * nucleotides it wrote (a multiple of 32); the caller finishes the rest. */
-__attribute__((target("avx2,bmi2"))) static uint32_t decode_slice_avx2(const uint64_t* words, uint32_t from, uint32_t L, bool rc, char* dst)
-{
-    const uint64_t SPREAD = 0x0303030303030303ull;
-    const __m256i fwd = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
-    const __m256i cmp = _mm256_setr_epi8('T', 'G', 'A', 'C', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'T', 'G', 'A', 'C', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
-    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
-    uint32_t i = 0;
-    for (; i + 32 <= L; i += 32) {
-        const uint32_t j = from + i, sh = 2 * (j & 31);
-        uint64_t w = words[j >> 5] >> sh;
-        if (sh) w |= words[(j >> 5) + 1] << (64 - sh);
-        const __m256i codes = _mm256_setr_epi64x((long long)_pdep_u64(w, SPREAD), (long long)_pdep_u64(w >> 16, SPREAD), (long long)_pdep_u64(w >> 32, SPREAD),
-                                                 (long long)_pdep_u64(w >> 48, SPREAD));
-        if (!rc) _mm256_storeu_si256((__m256i*)(dst + i), _mm256_shuffle_epi8(fwd, codes));
-        else {
-            const __m256i c = _mm256_shuffle_epi8(_mm256_shuffle_epi8(cmp, codes), rev); /* complemented, each half reversed */
-            _mm256_storeu_si256((__m256i*)(dst + (L - 32 - i)), _mm256_permute2x128_si256(c, c, 1));
-        }
-    }
-    return i;
-}
-#endif
-static void decode_slice(const uint64_t* words, uint32_t from, uint32_t L, bool rc, char* dst)
-{
-    static const DecodeLut lut;
-    static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
-    uint32_t i = 0;
-#if defined(__x86_64__)
-    static const bool vec = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("MTG_NO_VEC");
-    if (vec) i = decode_slice_avx2(words, from, L, rc, dst);
-#endif
-    for (; i + 4 <= L; i += 4) {
-        const uint32_t j = from + i, sh = 2 * (j & 31);
-        uint64_t w = words[j >> 5] >> sh;
-        if (sh > 56) w |= words[(j >> 5) + 1] << (64 - sh);
-        if (!rc) memcpy(dst + i, &lut.fwd[w & 0xFF], 4);
-        else memcpy(dst + (L - 4 - i), &lut.rc[w & 0xFF], 4);
-    }
-    for (; i < L; i++) {
-        const uint32_t j = from + i, c = (uint32_t)(words[j >> 5] >> (2 * (j & 31))) & 3;
-        if (!rc) dst[i] = NT[c]; else dst[L - 1 - i] = NTC[c];
-    }
-}
-
 /* a gap whose solutions come out of the contig graph: candidate sequences per target (in the order the reference visits them), waiting
  * for the alignments of remove_almost_identical_solutions, which run on the device for the whole batch */
 struct GenWork {
@@ -476,41 +411,10 @@ struct GenWork {
     std::vector<std::vector<int64_t>> pair; /* per group, n x n: index into the batch's NW pairs for (row j, column i < j); -2: equal strings */
 };
 
-/* everything after the device kernels for one gapFillFromSource call, except the de-duplication and the coverage numbers of the general
- * path (returns the candidates of such a gap, nullptr otherwise) */
-static GenWork* process_gap(const GapDev& gc, GapWork& W, int k, char* arena_slot)
+/* Multi-contig gap (a terminal node that is not the simple case of contig 0): everything after the device kernels except the
+ * de-duplication and the coverage numbers.  Returns the candidates, nullptr when there is none. */
+static GenWork* process_general(const GapDev& gc, GapWork& W, int k)
 {
-    W.nb_nodes = (int)gc.o.n_contigs;
-    W.total_nt = (int)gc.o.total_nt;
-    W.nb_terminal = (int)gc.p.nb_terminal;
-    if (gc.p.nb_terminal == 0) { /* get_first_contig, src/Filler.cpp:1381-1407 */
-        W.extension.clear();
-        if (gc.o.n_contigs > 0 && (int)gc.p.clen0 > k) W.extension = gc.contig0_slice((uint32_t)k, gc.p.clen0);
-        return nullptr;
-    }
-    if (gc.p.fast == 2) { W.has_counts = W.reverse; return nullptr; } /* target at the very start of contig 0: empty fill */
-    if (gc.p.fast == 1) {
-        /* terminal node 0: find_all_paths_rev returns the single path [0] (src/GraphAnalysis.cpp:222-226) and
-         * paths_to_sequences keeps contig0[k:pos] (:386-423); coverage was computed on the device */
-        Solution& s = W.sols.emplace_first();
-        /* written straight into the batch arena (reverse-complemented when the attempt is a reverse one, src/Filler.cpp:998-1001) */
-        const uint32_t L = gc.p.pos - (uint32_t)k;
-        decode_slice(gc.words, (uint32_t)k, L, W.reverse, arena_slot);
-        arena_slot[L] = 0;
-        s.seq.view(arena_slot, L);
-        s.nb_errors = (int)gc.p.errors;
-        s.target = (int)gc.p.target;
-        s.count = 1;
-        s.rank = 1;
-        const uint64_t sum = gc.p.ab_sum;
-        s.avg = sum / (float)gc.p.ab_n;
-        s.median = (float)((gc.p.ab_n % 2 == 1) ? (double)gc.p.med_hi : 0.5 * (gc.p.med_hi + gc.p.med_lo));
-        s.ab_n = 0; /* no host-side coverage query needed */
-        s.qual = compute_qual(s, W.anchor_repeated);
-        W.nb_total_filled = 1;
-        W.has_counts = true;
-        return nullptr;
-    }
     GenWork* gw = nullptr;
     std::vector<TermInfo> terms;
     for (uint32_t c = 0; c < gc.o.n_contigs; c++)
@@ -648,194 +552,47 @@ static double median_of(std::vector<unsigned int>& v) /* src/Utils.cpp:241-254 *
     return 0.5 * (vn + v[n - 1]);
 }
 
-
-/* a batch whose GapWork records already exist (the CLI drivers) */
-struct VecSource : BatchSource {
-    std::vector<GapWork>& g;
-    const std::vector<std::string_view>& swf;
-    VecSource(std::vector<GapWork>& g_, const std::vector<std::string_view>& s_) : g(g_), swf(s_) {}
-    size_t count() const override { return g.size(); }
-    bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const override
-    {
-        src_len = g[i].source.size(); swf_len = swf[i].size(); n_targets = g[i].targets.size();
-        return true;
-    }
-    void input(size_t i, FillInput& in, int nb_mis_allowed) const override
-    {
-        in.set_common(i, g[i].source, swf[i], g[i].anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
-        size_t o = in.toff[i];
-        for (const Target& t : g[i].targets) in.set_target(o++, t.seq);
-    }
-    void marshal(const FillInput&, int) override {}
-    std::vector<GapWork>& gaps() override { return g; }
-};
-int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,
-              mtg_batch_stats* stats_out)
+/* The multi-contig gaps of a batch (`special`), on the host: candidates, alignments (device), greedy de-duplication, coverage (device).
+ * work[i] receives the solutions of special.special[i]; describe(gap, W) sets source, flags and dictionary of a gap. */
+static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch& special, const std::function<void(size_t, GapWork&)>& describe, std::vector<GapWork>& work)
 {
-    VecSource src(gaps, swf_targets);
-    return fill_gaps(idx, p, src, arena, stats_out, nullptr);
-}
-
-/* runs a batch of gapFillFromSource calls */
-int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillArena& arena, mtg_batch_stats* stats_out, std::vector<uint64_t>* sol_blocks)
-{
-    const int k = idx->dev.k;
-    const size_t n = src.count();
-    const int nth = p->nb_host_threads;
-    const double t_begin = now_ms();
-    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
-    double tk = t_begin;
-    auto tick = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "  [fill_gaps] %-22s %.2f ms\n", what, t - tk); tk = t; } };
-    /* one workspace of the index (staging blocks, device buffers, streams) holds this batch from here until its results have been
-     * taken out of it */
-    WorkspaceLock batch_lock = acquire_workspace(idx);
-    FillInput in;
-    in.k = k;
-    in.ws = batch_lock.ws;
-    std::atomic<long> bad_gap{-1}, short_gap{-1};
-    const auto sizes_of = [&](size_t i, size_t& swf_len, size_t& n_targets) -> bool {
-        size_t src_len = 0;
-        bool ok = true;
-        if (!src.sizes(i, src_len, swf_len, n_targets)) { bad_gap = (long)i; src_len = swf_len = n_targets = 0; ok = false; }
-        else if ((int)src_len < k) { short_gap = (long)i; ok = false; }
-        in.slen[i] = (uint32_t)src_len;
-        return ok;
-    };
-    const auto input_of = [&](size_t i) { src.input(i, in, p->nb_mis_allowed); };
-    const bool one_pass = in.plan_and_fill(n, nth, sizes_of, input_of);
-    if (one_pass) tick("input (one pass)");
-    else {
-        /* the first batch of its shape on this workspace (the staging blocks have to grow), or a malformed gap */
-        bad_gap = -1; short_gap = -1;
-        in.plan(n, nth, sizes_of);
-        if (bad_gap >= 0) { set_error("gap %ld: null field", bad_gap.load()); return MTG_ERR_ARG; }
-        if (short_gap >= 0) { set_error("gap %ld: source sequence shorter than k", short_gap.load()); return MTG_ERR_ARG; }
-        tick("input sizes + layout");
-        in.fill(nth, input_of);
-        tick("input set");
-    }
-    mtg_batch_stats st{};
-    st.host_ms = now_ms() - t_begin;
-    DevBatch batch;
-    double t_marshal = 0, t_parts = 0;
-    bool marshalled = false;
-    const std::function<void()> while_busy = [&]() { const double t = now_ms(); src.marshal(in, nth); marshalled = true; t_marshal = now_ms() - t; };
-    /* Every chunk of results is turned into solutions as soon as it is back, while the device works on the next one: arena bytes of
-     * every block of its gaps, then the gaps of a block one after the other (the sequences of a chunk share one arena buffer). */
-    const size_t B = RESULT_BLOCK, nb = (n + B - 1) / B;
-    std::vector<std::atomic<uint64_t>> blk_sols(nb);
-    for (auto& c : blk_sols) c.store(0, std::memory_order_relaxed);
-    std::vector<GenWork*> genw(n, nullptr); /* gaps whose solutions come out of the host's path enumeration */
+    const int k = idx->dev.k, nth = p->nb_host_threads;
+    const size_t ng = special.special.size();
+    work.clear();
+    work.resize(ng);
+    std::vector<GenWork*> genw(ng, nullptr);
     struct GenGuard { std::vector<GenWork*>& v; ~GenGuard() { for (GenWork* g : v) delete g; } } gen_guard{genw};
-    const std::function<void(size_t, const uint32_t*, size_t, size_t)> on_ready = [&](size_t chunk, const uint32_t* ids, size_t first, size_t count) {
-        const double t = now_ms();
-        if (!marshalled) { src.marshal(in, nth); marshalled = true; } /* the gap records have to exist by now */
-        std::vector<GapWork>& gaps = src.gaps();
-        const size_t nbp = (count + B - 1) / B;
-        auto gap_of = [&](size_t j) -> size_t { return ids ? ids[j] : first + j; };
-        /* one pass: a block of gaps adds up the bytes its sequences need, learns where the blocks before it end (they were handed out
-         * in order, and each publishes its end as soon as it knows its own size) and writes its gaps one after the other; the chunk
-         * never needs more than 32 bytes per dense word + one per gap */
-        const HostChunk& hc = *batch.chunks[chunk];
-        static const bool prefetch_words = !getenv("MTG_NO_PREFETCH");
-        const size_t arena_cap = (size_t)hc.n_words * 32 + count + 64;
-        bool external = false;
-        if (arena.ext_ok) {
-            /* the caller's buffer takes the chunk if it continues the gap order and fits */
-            if (!ids && first == arena.ext_next_gap && arena.ext_used + arena_cap <= arena.ext_cap) external = true;
-            else arena.ext_ok = false;
-        }
-        char* const arena_base = external ? arena.ext + arena.ext_used : arena.ensure(chunk, arena_cap);
-        std::vector<std::atomic<int64_t>> ends(nbp + 1);
-        for (auto& e : ends) e.store(-1, std::memory_order_relaxed);
-        ends[0].store(0, std::memory_order_release);
-        std::atomic<bool> incomplete{false};
-        std::atomic<uint64_t> rec_bytes{0}, rec_filled{0};
-        const bool recording = !ids;
-        parallel_for(nbp, nth, [&](size_t b) {
-            uint64_t need = 0, rb = 0, rf = 0;
-            /* slot j of the chunk holds gap gap_of(j) */
-            for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
-                const SlotRec& r = hc.recs[j];
-                need += (r.o.status == GAP_OK && r.p.fast == 1) ? (uint64_t)(r.p.pos - (uint32_t)k) + 1 : 0;
-            }
-            int64_t begin;
-            while ((begin = ends[b].load(std::memory_order_acquire)) < 0) Pool::cpu_relax();
-            ends[b + 1].store(begin + (int64_t)need, std::memory_order_release);
-            uint64_t off = (uint64_t)begin, nsol = 0;
-            size_t cur_blk = ~(size_t)0;
-            bool odd = false;
-            for (size_t j = b * B; j < std::min(count, (b + 1) * B); j++) {
-                const size_t i = gap_of(j);
-                if (prefetch_words && j + 8 < count) {
-                    /* the gaps reserved their room in the dense words in no particular order, and the copy from the device left them in
-                     * memory, not in a cache: ask for the words of a gap a few places ahead */
-                    const char* pw = (const char*)(hc.words + hc.recs[j + 8].wbase);
-                    __builtin_prefetch(pw); __builtin_prefetch(pw + 64); __builtin_prefetch(pw + 128);
+    parallel_for(ng, nth, [&](size_t i) {
+        const SpecialGap& sg = special.special[i];
+        describe(sg.gap, work[i]);
+        genw[i] = process_general(special.view(sg), work[i], k);
+    }, 1);
+    /* every alignment remove_almost_identical_solutions can ask for: a later candidate (rows) against an earlier one (columns) */
+    std::vector<NwPair> pairs;
+    for (size_t gi = 0; gi < ng; gi++) {
+        if (!genw[gi]) continue;
+        GenWork& gw = *genw[gi];
+        gw.pair.resize(gw.groups.size());
+        for (size_t g = 0; g < gw.groups.size(); g++) {
+            const std::vector<Solution>& tmp = gw.groups[g];
+            const size_t m = tmp.size();
+            if (m < 2) continue;
+            gw.pair[g].assign(m * m, -1);
+            for (size_t j = 1; j < m; j++)
+                for (size_t i = 0; i < j; i++) {
+                    if (tmp[j].seq == tmp[i].seq) { gw.pair[g][j * m + i] = -2; continue; }
+                    gw.pair[g][j * m + i] = (int64_t)pairs.size();
+                    pairs.push_back(NwPair{tmp[j].seq.data(), (uint32_t)tmp[j].seq.size(), tmp[i].seq.data(), (uint32_t)tmp[i].seq.size()});
                 }
-                if (hc.recs[j].o.status != GAP_OK) { odd = true; continue; } /* re-run in a larger tier: comes back with a later chunk */
-                const GapDev gd = DevBatch::view(hc, j);
-                if (i / B != cur_blk) { if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed); nsol = 0; cur_blk = i / B; }
-                src.init_gap(i);
-                if (gd.p.fast == 0 && gd.p.nb_terminal > 0) src.need_targets(i);
-                genw[i] = process_gap(gd, gaps[i], k, arena_base + off);
-                if (genw[i]) odd = true;
-                else if (recording) src.record_gap(i, rb, rf);
-                off += gd.p.fast == 1 ? (uint64_t)(gd.p.pos - (uint32_t)k) + 1 : 0;
-                nsol += gaps[i].sols.size();
-            }
-            if (nsol) blk_sols[cur_blk].fetch_add(nsol, std::memory_order_relaxed);
-            if (odd) incomplete = true;
-            if (rb | rf) { rec_bytes.fetch_add(rb, std::memory_order_relaxed); rec_filled.fetch_add(rf, std::memory_order_relaxed); }
-        }, 1);
-        if (external) {
-            arena.ext_used += (size_t)ends[nbp].load(std::memory_order_acquire);
-            arena.ext_next_gap = first + count;
-            if (incomplete.load()) arena.ext_ok = false; /* a gap of this chunk gets its sequences later, out of order */
         }
-        if (recording) src.part_done(first, count, !incomplete.load(), rec_bytes.load(), rec_filled.load());
-        t_parts += now_ms() - t;
-    };
-    int rc = device_run(idx, p, in, batch, &st, &while_busy, &on_ready);
-    if (rc) return rc;
-    if (dbg) fprintf(stderr, "  [fill_gaps] marshal (overlapped) %.2f ms, chunks processed in %.2f ms\n", t_marshal, t_parts);
-    std::vector<GapWork>& gaps = src.gaps();
-    st.host_ms += t_parts;
-    tk = now_ms();
-    double t0 = now_ms();
-    std::vector<size_t> gen_idx;
-    for (size_t i = 0; i < n; i++) if (genw[i]) gen_idx.push_back(i);
-    if (!gen_idx.empty()) {
-        /* every alignment remove_almost_identical_solutions can ask for: a later candidate (rows) against an earlier one (columns) */
-        std::vector<NwPair> pairs;
-        for (size_t gi : gen_idx) {
-            GenWork& gw = *genw[gi];
-            gw.pair.resize(gw.groups.size());
-            for (size_t g = 0; g < gw.groups.size(); g++) {
-                const std::vector<Solution>& tmp = gw.groups[g];
-                const size_t m = tmp.size();
-                if (m < 2) continue;
-                gw.pair[g].assign(m * m, -1);
-                for (size_t j = 1; j < m; j++)
-                    for (size_t i = 0; i < j; i++) {
-                        if (tmp[j].seq == tmp[i].seq) { gw.pair[g][j * m + i] = -2; continue; }
-                        gw.pair[g][j * m + i] = (int64_t)pairs.size();
-                        pairs.push_back(NwPair{tmp[j].seq.data(), (uint32_t)tmp[j].seq.size(), tmp[i].seq.data(), (uint32_t)tmp[i].seq.size()});
-                    }
-            }
-        }
-        std::vector<uint32_t> matches;
-        if (!pairs.empty()) { rc = nw_run(idx, pairs, matches); if (rc) return rc; }
-        parallel_for(gen_idx.size(), nth, [&](size_t ii) { finish_general(gaps[gen_idx[ii]], *genw[gen_idx[ii]], matches); }, 1);
-        for (size_t gi : gen_idx) blk_sols[gi / B].fetch_add(gaps[gi].sols.size(), std::memory_order_relaxed); /* they had none when their block was counted */
-        tick("alignments");
     }
-    if (sol_blocks) { sol_blocks->resize(nb); for (size_t b = 0; b < nb; b++) (*sol_blocks)[b] = blk_sols[b].load(std::memory_order_relaxed); }
-    /* coverage of the general-path solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
+    std::vector<uint32_t> matches;
+    if (!pairs.empty()) { if (int rc = nw_run(idx, pairs, matches)) return rc; }
+    parallel_for(ng, nth, [&](size_t i) { if (genw[i]) finish_general(work[i], *genw[i], matches); }, 1);
+    /* coverage of the solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);
-    for (size_t gi : gen_idx) {
-        GapWork& g = gaps[gi];
+    for (GapWork& g : work)
         for (auto& s : g.sols) {
             s.ab_off = q.size();
             uint64_t f = 0;
@@ -852,16 +609,10 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
             feed(s.seq.data(), s.seq.size());
             s.ab_n = q.size() - s.ab_off;
         }
-    }
-    st.host_ms += now_ms() - t0;
     std::vector<uint32_t> ab(q.size());
-    if (!q.empty()) {
-        rc = query_run(idx, q.data(), q.size(), ab.data(), nullptr, nullptr);
-        if (rc) return rc;
-    }
-    t0 = now_ms();
-    parallel_for(gen_idx.size(), p->nb_host_threads, [&](size_t ii) {
-        GapWork& g = gaps[gen_idx[ii]];
+    if (!q.empty()) { if (int rc = query_run(idx, q.data(), q.size(), ab.data(), nullptr, nullptr)) return rc; }
+    parallel_for(ng, nth, [&](size_t ii) {
+        GapWork& g = work[ii];
         for (auto& s : g.sols) {
             std::vector<unsigned int> v(ab.begin() + s.ab_off, ab.begin() + s.ab_off + s.ab_n);
             uint64_t sum = 0;
@@ -878,39 +629,67 @@ int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillA
             s.avg = sum / (float)v.size();
             s.median = v.empty() ? 0.f : (float)median_of(v);
             s.qual = compute_qual(s, g.anchor_repeated);
-            if (g.reverse && !s.seq.is_view()) s.seq = revcomp_str(s.seq.str()); /* views were written reverse-complemented */
+            if (g.reverse) s.seq = revcomp_str(s.seq);
         }
     }, 1);
-    st.host_ms += now_ms() - t0;
-    tick("general path");
-    st.total_ms = now_ms() - t_begin;
-    if (stats_out) *stats_out = st;
-    stats_store(st);
     return MTG_OK;
 }
 
 } // namespace mtgi
 
 /* ------------------------------------------------------------------------------------------------ C ABI (host side) */
+/* A batch of gapFillFromSource calls marshalled for the device (and, when prepared ahead, resident there). */
+struct mtg_batch {
+    mtgi::FillInput in;
+    const mtg_gap* gaps = nullptr; /* the caller's array: read again only for the gaps that take the multi-contig path */
+    size_t n = 0;
+    ~mtg_batch() { mtgi::batch_release_device(in); }
+};
+
 struct mtg_results {
-    mtgi::FillArena arena;
-    std::vector<mtgi::Target> targets; /* flat storage of every gap's dictionary */
-    std::vector<mtg_filled> filled_flat;
-    std::vector<mtgi::GapWork> gaps;
-    std::vector<mtg_gap_result> res;
-    int nthreads = 0; /* host threads of the batch that filled it */
-    /* kept up to date by the record writer: what mtg_results_summary reports */
-    std::vector<uint32_t> nfilled;
-    std::atomic<uint64_t> sum_bytes{0}, sum_filled{0};
-    bool summary_ready = false;
+    size_t n = 0, cap_n = 0;
+    mtg_gap_result* res = nullptr; /* page-locked: the device's records are copied straight into them */
+    mtg_filled* fil = nullptr;
+    char* seq = nullptr;           /* sequence arena (page-locked), or the caller's buffer */
+    size_t seq_cap = 0;
+    bool seq_external = false;
+    char* seq_own = nullptr;       /* the arena this object owns (kept while the caller's buffer is in use) */
+    size_t seq_own_cap = 0;
+    char* ext = nullptr;
+    size_t ext_cap = 0;
+    uint64_t seq_bytes = 0, n_gaps_filled = 0;
+    bool in_gap_order = true;      /* the arena holds exactly the batch's sequences, NUL-terminated, in gap order */
+    std::vector<mtgi::GapWork> gen;    /* multi-contig gaps: their solutions own their strings */
+    std::vector<mtg_filled> gen_fil;   /* and these are their records */
+    std::vector<char> relaid;          /* sequences laid out again in gap order (serialised form of a batch with multi-contig gaps) */
+    int nthreads = 0;
+    ~mtg_results()
+    {
+        mtgi::pinned_free(res);
+        mtgi::pinned_free(fil);
+        mtgi::pinned_free(seq_own);
+        mtgi::pinned_free(ext);
+    }
+    bool ensure(size_t n_)
+    {
+        n = n_;
+        if (cap_n >= n_ && res) return true;
+        mtgi::pinned_free(res);
+        mtgi::pinned_free(fil);
+        cap_n = n_ + n_ / 8 + 64;
+        res = (mtg_gap_result*)mtgi::pinned_alloc(cap_n * sizeof(mtg_gap_result));
+        fil = (mtg_filled*)mtgi::pinned_alloc(cap_n * sizeof(mtg_filled));
+        if (!res || !fil) { cap_n = 0; return false; }
+        return true;
+    }
 };
 struct mtg_contigs {
     std::vector<std::vector<std::string>> c;
 };
 
-/* Result objects are recycled: a freed one keeps its storage (a few hundred bytes per gap plus the sequence arena) for the next batch,
- * which then pays neither page faults nor allocator traffic.  At most six are kept (three batches in flight, each with
- * the previous result still in its caller's hands). */
+/* Result objects are recycled: a freed one keeps its page-locked arrays (a hundred bytes per gap plus the sequence arena) for the next
+ * batch, which then pays neither allocation nor page faults.  At most six are kept (three batches in flight, each with the previous
+ * result still in its caller's hands). */
 namespace {
 std::mutex g_results_mtx;
 std::vector<mtg_results*> g_results_cache;
@@ -924,14 +703,199 @@ mtg_results* results_acquire()
 }
 void results_release(mtg_results* r)
 {
+    r->gen.clear();
+    r->gen_fil.clear();
+    r->relaid.clear();
     {
         std::lock_guard<std::mutex> lk(g_results_mtx);
         if (g_results_cache.size() < 6) { g_results_cache.push_back(r); return; }
     }
     delete r;
 }
-} // namespace
 
+/* marshals gaps[0, n) into `in` (whose k and workspace are set); the strings are read here and, for the rare multi-contig gap, again later */
+int marshal_gaps(const mtg_gap* g, size_t n, const mtg_params* p, mtgi::FillInput& in)
+{
+    using namespace mtgi;
+    const int k = in.k, nth = p->nb_host_threads;
+    std::atomic<long> bad_gap{-1}, short_gap{-1};
+    static const bool prefetch_on = !getenv("MTG_NO_PREFETCH");
+    /* the strings of a batch are wherever the caller has them: the passes ask for those of the gaps a few places ahead early */
+    const auto prefetch = [&](size_t i) {
+        if (!prefetch_on) return;
+        if (i + 16 < n) { const mtg_gap& b = g[i + 16]; __builtin_prefetch(b.target_seqs); __builtin_prefetch(b.target_names); }
+        if (i + 8 < n) {
+            const mtg_gap& b = g[i + 8];
+            __builtin_prefetch(b.source);
+            __builtin_prefetch(b.target);
+            if (b.n_targets > 0 && b.target_seqs && b.target_names) { __builtin_prefetch(b.target_seqs[0]); __builtin_prefetch(b.target_names[0]); }
+        }
+    };
+    const auto sizes_of = [&](size_t i, size_t& swf_len, size_t& n_targets) -> bool {
+        prefetch(i);
+        const mtg_gap& a = g[i];
+        bool ok = a.source && a.target && !(a.n_targets > 0 && (!a.target_seqs || !a.target_names));
+        if (ok) for (int t = 0; t < a.n_targets; t++) if (!a.target_seqs[t] || !a.target_names[t]) ok = false;
+        size_t src_len = 0;
+        if (!ok) { bad_gap = (long)i; swf_len = n_targets = 0; }
+        else {
+            src_len = strlen(a.source); swf_len = strlen(a.target); n_targets = (size_t)std::max(a.n_targets, 0);
+            if ((int)src_len < k) { short_gap = (long)i; ok = false; }
+        }
+        in.slen[i] = (uint32_t)src_len;
+        return ok;
+    };
+    const auto input_of = [&](size_t i) {
+        prefetch(i);
+        const mtg_gap& a = g[i];
+        const uint8_t fl = (uint8_t)((a.is_anchor_repeated ? mtg::GAPF_REPEATED : 0) | (a.reverse ? mtg::GAPF_REVERSE : 0));
+        in.set_common(i, std::string_view(a.source, in.slen[i]), std::string_view(a.target, in.rlen[i]), a.is_anchor_repeated ? 0 : p->nb_mis_allowed, fl); /* src/Filler.cpp:859-863 */
+        /* of a target only the first k characters matter, and whether it has them */
+        for (int t = 0; t < a.n_targets; t++) in.set_target(in.toff[i] + (size_t)t, std::string_view(a.target_seqs[t], strnlen(a.target_seqs[t], (size_t)in.k)));
+    };
+    if (!in.plan_and_fill(n, nth, sizes_of, input_of)) {
+        /* the first batch of its shape on this workspace (the staging blocks have to grow), or a malformed gap */
+        bad_gap = -1; short_gap = -1;
+        in.plan(n, nth, sizes_of);
+        if (bad_gap >= 0) { set_error("gap %ld: null field", bad_gap.load()); return MTG_ERR_ARG; }
+        if (short_gap >= 0) { set_error("gap %ld: source sequence shorter than k", short_gap.load()); return MTG_ERR_ARG; }
+        in.fill(nth, input_of);
+    }
+    return MTG_OK;
+}
+
+/* runs a marshalled batch; gaps: the caller's array (multi-contig gaps look at their dictionary) */
+int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillInput& in, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes,
+                    mtg_results** out, double t_begin)
+{
+    using namespace mtgi;
+    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    double tk = now_ms();
+    auto tick = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "  [fill_batch] %-21s %.2f ms\n", what, t - tk); tk = t; } };
+    mtg_results* R = results_acquire();
+    struct Guard { mtg_results* r; ~Guard() { if (r) results_release(r); } } guard{R};
+    R->nthreads = p->nb_host_threads;
+    if (!R->ensure(n)) { set_error("no page-locked memory for the records of %zu gaps", n); return MTG_ERR_NOMEM; }
+    if (!R->ext) { R->ext_cap = 1 << 16; R->ext = (char*)pinned_alloc(R->ext_cap); if (!R->ext) { R->ext_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
+    R->ext[0] = 0;
+    R->seq_external = seq_out != nullptr;
+    if (seq_out) { R->seq = seq_out; R->seq_cap = (size_t)seq_cap; }
+    else {
+        if (!R->seq_own) { R->seq_own_cap = std::max<size_t>(n * 64, 1 << 16); R->seq_own = (char*)pinned_alloc(R->seq_own_cap); if (!R->seq_own) { R->seq_own_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
+        R->seq = R->seq_own;
+        R->seq_cap = R->seq_own_cap;
+    }
+    ResultSink sink;
+    sink.n = n;
+    sink.res = R->res; sink.fil = R->fil;
+    sink.seq = R->seq; sink.seq_cap = R->seq_cap;
+    sink.ext = R->ext; sink.ext_cap = R->ext_cap;
+    sink.grow_seq = [&](size_t need, size_t keep) -> bool {
+        if (R->seq_external) return false;
+        const size_t cap = need + need / 4 + 4096;
+        char* nb = (char*)pinned_alloc(cap);
+        if (!nb) return false;
+        if (keep) memcpy(nb, R->seq_own, keep);
+        pinned_free(R->seq_own);
+        R->seq_own = nb; R->seq_own_cap = cap;
+        R->seq = nb; R->seq_cap = cap;
+        sink.seq = nb; sink.seq_cap = cap;
+        return true;
+    };
+    sink.grow_ext = [&](size_t need, size_t keep) -> bool {
+        const size_t cap = need + need / 4 + 4096;
+        char* nb = (char*)pinned_alloc(cap);
+        if (!nb) return false;
+        memcpy(nb, R->ext, std::max<size_t>(keep, 1));
+        pinned_free(R->ext);
+        R->ext = nb; R->ext_cap = cap;
+        sink.ext = nb; sink.ext_cap = cap;
+        return true;
+    };
+    mtg_batch_stats st{};
+    st.host_ms = now_ms() - t_begin;
+    DevBatch special;
+    int rc = device_run(idx, p, in, sink, special, &st);
+    if (rc) return rc;
+    tick("device");
+    R->seq_bytes = sink.seq_used;
+    R->n_gaps_filled = sink.n_filled;
+    R->in_gap_order = sink.in_gap_order;
+    /* multi-contig gaps: solutions on the host, records rewritten */
+    if (!special.special.empty()) {
+        const double t0 = now_ms();
+        const auto describe = [&](size_t gi, GapWork& w) {
+            const mtg_gap& a = gaps[gi];
+            w.source = std::string_view(a.source, strlen(a.source));
+            w.anchor_repeated = a.is_anchor_repeated != 0;
+            w.reverse = a.reverse != 0;
+            w.target_store.resize((size_t)std::max(a.n_targets, 0));
+            for (int t = 0; t < a.n_targets; t++) {
+                Target& T = w.target_store[(size_t)t];
+                T.seq = a.target_seqs[t];
+                T.name = a.target_names[t];
+                T.is_rc = a.target_is_rc ? a.target_is_rc[t] != 0 : false;
+            }
+            w.targets.p = w.target_store.data();
+            w.targets.n = (uint32_t)w.target_store.size();
+        };
+        rc = run_general(idx, p, special, describe, R->gen);
+        if (rc) return rc;
+        size_t total = 0;
+        for (const GapWork& w : R->gen) total += w.sols.size();
+        R->gen_fil.resize(total);
+        size_t o = 0;
+        for (size_t i = 0; i < R->gen.size(); i++) {
+            const GapWork& w = R->gen[i];
+            mtg_gap_result& r = R->res[special.special[i].gap];
+            r.has_solution_counts = w.has_counts;
+            r.nb_total_filled = w.nb_total_filled;
+            r.nb_reported = r.n_filled = (int)w.sols.size();
+            r.filled = R->gen_fil.data() + o;
+            for (const Solution& s : w.sols) {
+                mtg_filled& f = R->gen_fil[o++];
+                f.seq = s.seq.c_str();
+                f.nb_errors_in_anchor = s.nb_errors;
+                f.target_index = s.target;
+                f.avg_coverage = s.avg;
+                f.median_coverage = s.median;
+                f.qual = s.qual;
+                f.solution_count = s.count;
+                f.solution_rank = s.rank;
+                R->seq_bytes += s.seq.size() + 1;
+            }
+            if (!w.sols.empty()) { R->n_gaps_filled++; R->in_gap_order = false; }
+        }
+        st.host_ms += now_ms() - t0;
+        tick("multi-contig gaps");
+    }
+    if (seq_out) {
+        if (R->in_gap_order) *seq_bytes = sink.seq_used; /* every sequence was written in place, in gap order */
+        else {
+            /* multi-contig gaps or re-run gaps: lay the sequences out again, in gap order, and make the records point there */
+            if (R->seq_bytes > seq_cap) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)R->seq_bytes); return MTG_ERR_ARG; }
+            R->relaid.resize(R->seq_bytes + 1);
+            uint64_t o = 0;
+            for (size_t i = 0; i < n; i++)
+                for (int j = 0; j < R->res[i].n_filled; j++) {
+                    mtg_filled& f = const_cast<mtg_filled&>(R->res[i].filled[j]);
+                    const size_t len = strlen(f.seq);
+                    memcpy(R->relaid.data() + o, f.seq, len + 1);
+                    f.seq = seq_out + o;
+                    o += len + 1;
+                }
+            memcpy(seq_out, R->relaid.data(), o);
+            *seq_bytes = o;
+            R->in_gap_order = true;
+        }
+    }
+    st.total_ms = now_ms() - t_begin;
+    stats_store(st);
+    guard.r = nullptr;
+    *out = R;
+    return MTG_OK;
+}
+} // namespace
 
 extern "C" {
 
@@ -951,201 +915,17 @@ int mtg_index_create_from_reads(const char* paths_csv, int k, int abundance_min,
 int mtg_index_save(const mtg_index* idx, const char* path) { return mtgi::index_save(idx, path); }
 int mtg_index_load(const char* path, mtg_index** out) { return mtgi::index_load(path, out); }
 
-/* a batch handed over through the C ABI: the GapWork records are written while the device is busy */
-namespace {
-struct AbiSource : mtgi::BatchSource {
-    const mtg_gap* g;
-    size_t n;
-    mtg_results* R;
-    AbiSource(const mtg_gap* g_, size_t n_, mtg_results* R_) : g(g_), n(n_), R(R_) {}
-    size_t count() const override { return n; }
-    /* the strings of a batch are wherever the caller has them: the two passes ask for those of the gaps a few places ahead early */
-    void prefetch(size_t i) const
-    {
-        static const bool on = !getenv("MTG_NO_PREFETCH");
-        if (!on) return;
-        if (i + 16 < n) { const mtg_gap& b = g[i + 16]; __builtin_prefetch(b.target_seqs); __builtin_prefetch(b.target_names); }
-        if (i + 8 < n) {
-            const mtg_gap& b = g[i + 8];
-            __builtin_prefetch(b.source);
-            __builtin_prefetch(b.target);
-            if (b.n_targets > 0 && b.target_seqs && b.target_names) { __builtin_prefetch(b.target_seqs[0]); __builtin_prefetch(b.target_names[0]); }
-        }
-    }
-    bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const override
-    {
-        prefetch(i);
-        const mtg_gap& a = g[i];
-        if (!a.source || !a.target || (a.n_targets > 0 && (!a.target_seqs || !a.target_names))) return false;
-        for (int t = 0; t < a.n_targets; t++) if (!a.target_seqs[t] || !a.target_names[t]) return false;
-        src_len = strlen(a.source); swf_len = strlen(a.target); n_targets = (size_t)std::max(a.n_targets, 0);
-        return true;
-    }
-    void input(size_t i, mtgi::FillInput& in, int nb_mis_allowed) const override
-    {
-        prefetch(i);
-        const mtg_gap& a = g[i];
-        in.set_common(i, std::string_view(a.source, in.slen[i]), std::string_view(a.target, in.rlen[i]), a.is_anchor_repeated ? 0 : nb_mis_allowed); /* src/Filler.cpp:859-863 */
-        /* of a target only the first k characters matter, and whether it has them */
-        for (int t = 0; t < a.n_targets; t++) in.set_target(in.toff[i] + (size_t)t, std::string_view(a.target_seqs[t], strnlen(a.target_seqs[t], (size_t)in.k)));
-    }
-    const mtgi::FillInput* in_ = nullptr;
-    void marshal(const mtgi::FillInput& in, int nthreads) override
-    {
-        in_ = &in;
-        R->gaps.resize(n);
-        R->res.resize(n);
-        R->nfilled.resize(n);
-        if (R->filled_flat.size() < n) R->filled_flat.resize(n);
-        R->targets.resize(in.traw.size() / mtg::TARGET_SLOT);
-        (void)nthreads; /* the per-gap part happens in init_gap, when the gap's results are there: one visit of the record, not two */
-    }
-    void init_gap(size_t i) override
-    {
-        const mtg_gap& a = g[i];
-        mtgi::GapWork& w = R->gaps[i];
-        w.reset(); /* a recycled object still holds the previous batch */
-        w.source = std::string_view(a.source, in_->slen[i]);
-        w.anchor_repeated = a.is_anchor_repeated != 0;
-        w.reverse = a.reverse != 0;
-    }
-    /* the dictionary of a gap (names, strands) is only read on the multi-contig path: built there, for the gaps that take it */
-    void need_targets(size_t i) override
-    {
-        const mtg_gap& a = g[i];
-        mtgi::GapWork& w = R->gaps[i];
-        mtgi::Target* T0 = R->targets.data() + in_->toff[i];
-        for (int t = 0; t < a.n_targets; t++) {
-            mtgi::Target& T = T0[t];
-            T.seq = a.target_seqs[t];
-            T.name = a.target_names[t];
-            T.is_rc = a.target_is_rc ? a.target_is_rc[t] != 0 : false;
-        }
-        w.targets.p = T0;
-        w.targets.n = (uint32_t)std::max(a.n_targets, 0);
-    }
-    std::vector<mtgi::GapWork>& gaps() override { return R->gaps; }
-    /* the C-ABI records of a finished part, written while the device works on the next one: such gaps have at most one solution, which
-     * takes the slot of its gap in filled_flat (sized for one per gap by marshal) */
-    size_t recorded = 0; /* gaps [0, recorded) have their records */
-    void record_gap(size_t i, uint64_t& bytes, uint64_t& filled) override
-    {
-        write_record(i, R->filled_flat.data() + i);
-        tally(i, bytes, filled);
-    }
-    void part_done(size_t first, size_t count, bool clean, uint64_t bytes, uint64_t filled) override
-    {
-        if (first != recorded || !clean) return; /* from here on the records are rebuilt at the end */
-        R->sum_bytes.fetch_add(bytes, std::memory_order_relaxed);
-        R->sum_filled.fetch_add(filled, std::memory_order_relaxed);
-        recorded = first + count;
-    }
-    /* what mtg_results_summary reports about gap i */
-    void tally(size_t i, uint64_t& bytes, uint64_t& filled)
-    {
-        const mtgi::GapWork& w = R->gaps[i];
-        R->nfilled[i] = (uint32_t)w.sols.size();
-        filled += !w.sols.empty();
-        for (auto& s : w.sols) bytes += s.seq.size() + 1;
-    }
-    /* returns the slot after the last one used */
-    mtg_filled* write_record(size_t i, mtg_filled* F0)
-    {
-        mtgi::GapWork& w = R->gaps[i];
-        mtg_gap_result& r = R->res[i];
-        r.filled = F0;
-        for (auto& s : w.sols) {
-            mtg_filled& f = *F0++;
-            f.seq = s.seq.c_str();
-            f.nb_errors_in_anchor = s.nb_errors;
-            f.target_index = s.target;
-            f.avg_coverage = s.avg;
-            f.median_coverage = s.median;
-            f.qual = s.qual;
-            f.solution_count = s.count;
-            f.solution_rank = s.rank;
-        }
-        r.nb_nodes = w.nb_nodes; r.total_nt = w.total_nt; r.nb_terminal = w.nb_terminal;
-        r.has_solution_counts = w.has_counts; r.nb_total_filled = w.nb_total_filled; r.nb_reported = (int)w.sols.size();
-        r.n_filled = (int)w.sols.size();
-        r.extension = w.extension.c_str();
-        return F0;
-    }
-};
-} // namespace
-
 static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes, mtg_results** out)
 {
     if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
-    const double t_m0 = mtgi::now_ms();
-    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
-    double tk = t_m0;
-    auto tick = [&](const char* what) { if (dbg) { const double t = mtgi::now_ms(); fprintf(stderr, "  [fill_batch] %-21s %.2f ms\n", what, t - tk); tk = t; } };
-    mtg_results* R = results_acquire();
-    R->nthreads = p->nb_host_threads;
-    R->sum_bytes.store(0); R->sum_filled.store(0); R->summary_ready = false;
-    R->arena.set_external(seq_out, seq_out ? (size_t)seq_cap : 0);
-    AbiSource src(gaps, n, R);
-    mtg_batch_stats st{};
-    std::vector<uint64_t> sol_blocks;
-    int rc = mtgi::fill_gaps(idx, p, src, R->arena, &st, &sol_blocks);
-    if (rc) { results_release(R); return rc; }
-    bool relaid = false; /* the sequences were moved after the parts had been recorded */
-    if (seq_out) {
-        if (R->arena.ext_ok && R->arena.ext_next_gap == n) *seq_bytes = R->arena.ext_used; /* every sequence was decoded in place, in gap order */
-        else {
-            /* multi-contig gaps, re-run gaps or a buffer too small for the worst case: lay the sequences out again, in gap order, and
-             * make the solutions point there */
-            relaid = true;
-            const size_t CH = 1024, nch = (n + CH - 1) / CH;
-            std::vector<uint64_t> choff(nch + 1, 0);
-            mtgi::parallel_for(nch, p->nb_host_threads, [&](size_t c) {
-                uint64_t b = 0;
-                for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) for (auto& s : R->gaps[i].sols) b += s.seq.size() + 1;
-                choff[c + 1] = b;
-            }, 1);
-            for (size_t c = 0; c < nch; c++) choff[c + 1] += choff[c];
-            if (choff[nch] > seq_cap) { results_release(R); mtgi::set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)choff[nch]); return MTG_ERR_ARG; }
-            char* tmp = R->arena.ensure(63, choff[nch] + 1); /* a buffer of its own (no chunk gets that far): the old places stay readable meanwhile */
-            mtgi::parallel_for(nch, p->nb_host_threads, [&](size_t c) {
-                uint64_t o = choff[c];
-                for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++)
-                    for (auto& s : R->gaps[i].sols) { memcpy(tmp + o, s.seq.data(), s.seq.size()); tmp[o + s.seq.size()] = 0; o += s.seq.size() + 1; }
-            }, 1);
-            memcpy(seq_out, tmp, choff[nch]);
-            mtgi::parallel_for(nch, p->nb_host_threads, [&](size_t c) {
-                uint64_t o = choff[c];
-                for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++)
-                    for (auto& s : R->gaps[i].sols) { const uint32_t len = (uint32_t)s.seq.size(); s.seq = std::string(); s.seq.view(seq_out + o, len); o += len + 1; }
-            }, 1);
-            *seq_bytes = choff[nch];
-        }
-    }
-    const double t_m2 = mtgi::now_ms();
-    tk = t_m2;
-    if (src.recorded == n && !relaid) {
-        /* every part wrote its records as it came back */
-        R->summary_ready = true;
-    } else {
-        const size_t B = mtgi::RESULT_BLOCK, nb = (n + B - 1) / B;
-        std::vector<uint64_t> blk_off(nb + 1, 0);
-        for (size_t b = 0; b < nb; b++) blk_off[b + 1] = blk_off[b] + sol_blocks[b];
-        R->res.resize(n);
-        if (R->filled_flat.size() < blk_off[nb]) R->filled_flat.resize(blk_off[nb]);
-        mtgi::parallel_for(nb, p->nb_host_threads, [&](size_t b) {
-            mtg_filled* F0 = R->filled_flat.data() + blk_off[b];
-            for (size_t i = b * B; i < std::min(n, (b + 1) * B); i++) F0 = src.write_record(i, F0);
-        }, 1);
-        R->summary_ready = false; /* computed on demand */
-    }
-    /* the views on the caller's strings end here */
-    tick("result records");
-    st.marshal_ms = 0;
-    st.result_ms = mtgi::now_ms() - t_m2;
-    st.total_ms = mtgi::now_ms() - t_m0;
-    mtgi::stats_store(st);
-    *out = R;
-    return MTG_OK;
+    const double t_begin = mtgi::now_ms();
+    /* one workspace of the index (staging blocks, device buffers, streams) holds this batch from here until its results are on the host */
+    mtgi::WorkspaceLock batch_lock = mtgi::acquire_workspace(idx);
+    mtgi::FillInput in;
+    in.k = idx->dev.k;
+    in.ws = batch_lock.ws;
+    if (int rc = marshal_gaps(gaps, n, p, in)) return rc;
+    return fill_marshalled(idx, p, in, gaps, n, seq_out, seq_cap, seq_bytes, out, t_begin);
 }
 int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out)
 {
@@ -1156,7 +936,45 @@ int mtg_fill_batch_serial(const mtg_index* idx, const mtg_params* p, const mtg_g
     if (!seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     return fill_batch_impl(idx, p, gaps, n, seq_out, cap, seq_bytes, out);
 }
-const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->res.size()) ? &r->res[i] : nullptr; }
+
+int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_batch** out)
+{
+    if (!idx || !p || !out || (n && !gaps)) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    std::unique_ptr<mtg_batch> b(new mtg_batch());
+    b->in.k = idx->dev.k;
+    b->in.ws = nullptr; /* its own storage: the batch outlives any workspace hold */
+    b->gaps = gaps;
+    b->n = n;
+    if (int rc = marshal_gaps(gaps, n, p, b->in)) return rc;
+    if (n) { if (int rc = mtgi::batch_upload(idx, b->in)) return rc; }
+    *out = b.release();
+    return MTG_OK;
+}
+void mtg_batch_free(mtg_batch* b) { delete b; }
+static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
+{
+    if (!idx || !p || !b || !out) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    if (b->in.k != idx->dev.k) { mtgi::set_error("the batch was prepared for k = %d", b->in.k); return MTG_ERR_ARG; }
+    const double t_begin = mtgi::now_ms();
+    mtgi::WorkspaceLock batch_lock = mtgi::acquire_workspace(idx);
+    mtgi::FillInput in; /* views of the batch's blocks (host and device); the workspace is this call's */
+    const mtgi::FillInput& s = b->in;
+    in.k = s.k; in.want_all_contigs = s.want_all_contigs;
+    in.src = s.src; in.r0 = s.r0; in.roff = s.roff; in.rlen = s.rlen; in.toff = s.toff; in.tcnt = s.tcnt; in.nbmis = s.nbmis; in.fast_ok = s.fast_ok; in.flags = s.flags;
+    in.rwords = s.rwords; in.traw = s.traw;
+    in.block_a = s.block_a; in.block_b = s.block_b; in.block_c = s.block_c; in.bytes_a = s.bytes_a; in.bytes_b = s.bytes_b; in.bytes_c = s.bytes_c;
+    in.dev_a = s.dev_a; in.dev_b = s.dev_b; in.dev_tenc = s.dev_tenc;
+    in.ws = batch_lock.ws;
+    return fill_marshalled(idx, p, in, b->gaps, b->n, seq_out, cap, seq_bytes, out, t_begin);
+}
+int mtg_fill_prepared(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, mtg_results** out) { return fill_prepared_impl(idx, p, b, nullptr, 0, nullptr, out); }
+int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
+{
+    if (!seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    return fill_prepared_impl(idx, p, b, seq_out, cap, seq_bytes, out);
+}
+
+const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->n) ? &r->res[i] : nullptr; }
 void mtg_results_free(mtg_results* r)
 {
     if (r) results_release(r); /* its storage serves the next batch */
@@ -1164,47 +982,39 @@ void mtg_results_free(mtg_results* r)
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
 {
     if (!r) return MTG_ERR_ARG;
-    if (r->summary_ready) { /* tallied while the batch was assembled */
-        if (n_filled && !r->nfilled.empty()) memcpy(n_filled, r->nfilled.data(), r->nfilled.size() * sizeof(uint32_t));
-        if (seq_bytes) *seq_bytes = r->sum_bytes.load();
-        if (n_gaps_filled) *n_gaps_filled = r->sum_filled.load();
-        return MTG_OK;
+    if (n_filled) {
+        const size_t n = r->n, CH = 4096;
+        mtgi::parallel_for((n + CH - 1) / CH, r->nthreads, [&](size_t c) {
+            for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) n_filled[i] = (uint32_t)r->res[i].n_filled;
+        }, 1);
     }
-    std::atomic<uint64_t> b{0}, nf{0};
-    const size_t n = r->gaps.size();
-    const size_t CH = 2048;
-    mtgi::parallel_for((n + CH - 1) / CH, r->nthreads, [&](size_t c) {
-        uint64_t lb = 0, lf = 0;
-        for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) {
-            if (n_filled) n_filled[i] = (uint32_t)r->gaps[i].sols.size();
-            lf += !r->gaps[i].sols.empty();
-            for (auto& s : r->gaps[i].sols) lb += s.seq.size() + 1;
-        }
-        b += lb; nf += lf;
-    }, 1);
-    if (seq_bytes) *seq_bytes = b.load();
-    if (n_gaps_filled) *n_gaps_filled = nf.load();
+    if (seq_bytes) *seq_bytes = r->seq_bytes;
+    if (n_gaps_filled) *n_gaps_filled = r->n_gaps_filled;
     return MTG_OK;
 }
 int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
 {
     if (!r || !dst) return MTG_ERR_ARG;
-    const size_t n = r->gaps.size();
-    std::vector<uint64_t> off(n + 1, 0);
-    for (size_t i = 0; i < n; i++) {
-        uint64_t b = 0;
-        for (auto& s : r->gaps[i].sols) b += s.seq.size() + 1;
-        off[i + 1] = off[i] + b;
+    if (r->seq_bytes > cap) { mtgi::set_error("destination too small"); return MTG_ERR_ARG; }
+    if (r->in_gap_order) {
+        /* the arena is the concatenation already, with NULs where the line ends go */
+        const size_t nb = (size_t)r->seq_bytes, CH = 1 << 16;
+        const char* src = r->seq;
+        mtgi::parallel_for((nb + CH - 1) / CH, r->nthreads, [&](size_t c) {
+            const size_t e = std::min(nb, (c + 1) * CH);
+            for (size_t i = c * CH; i < e; i++) { const char ch = src[i]; dst[i] = ch ? ch : '\n'; }
+        }, 1);
+        return MTG_OK;
     }
-    if (off[n] > cap) { mtgi::set_error("destination too small"); return MTG_ERR_ARG; }
-    mtgi::parallel_for(n, r->nthreads, [&](size_t i) {
-        uint64_t o = off[i];
-        for (auto& s : r->gaps[i].sols) {
-            memcpy(dst + o, s.seq.data(), s.seq.size());
-            o += s.seq.size();
+    uint64_t o = 0;
+    for (size_t i = 0; i < r->n; i++)
+        for (int j = 0; j < r->res[i].n_filled; j++) {
+            const char* s = r->res[i].filled[j].seq;
+            const size_t len = strlen(s);
+            memcpy(dst + o, s, len);
+            o += len;
             dst[o++] = '\n';
         }
-    }, 512);
     return MTG_OK;
 }
 int mtg_index_scan_sequences(const mtg_index* idx, const char* const* seqs, size_t nseq, int mode, uint8_t* const* out, mtg_scan_stats* st)
@@ -1258,21 +1068,25 @@ int mtg_stage_a_batch(const mtg_index* idx, const mtg_params* p, const char* con
     in.want_all_contigs = true;
     in.resize(n);
     for (size_t i = 0; i < n; i++) {
+        if (!sources[i] || !targets[i]) { mtgi::set_error("gap %zu: null field", i); return MTG_ERR_ARG; }
         if ((int)strlen(sources[i]) < idx->dev.k) { mtgi::set_error("gap %zu: source sequence shorter than k", i); return MTG_ERR_ARG; }
         in.size(i, strlen(targets[i]), 0);
     }
     in.layout();
-    for (size_t i = 0; i < n; i++) in.set(i, std::string_view(sources[i]), std::string_view(targets[i]), nullptr, 0);
-    mtgi::DevBatch batch;
-    mtgi::DevBatch& gc = batch;
+    for (size_t i = 0; i < n; i++) in.set_common(i, std::string_view(sources[i]), std::string_view(targets[i]), 0, 0);
+    mtgi::ResultSink sink; /* no records: the contigs themselves come back */
+    sink.n = n;
+    mtgi::DevBatch special;
     mtg_batch_stats st{};
-    int rc = mtgi::device_run(idx, p, in, batch, &st);
+    int rc = mtgi::device_run(idx, p, in, sink, special, &st);
     if (rc) return rc;
     mtgi::stats_store(st);
     mtg_contigs* C = new mtg_contigs();
     C->c.resize(n);
-    for (size_t i = 0; i < n; i++)
-        { const mtgi::GapDev gd = gc[i]; for (uint32_t j = 0; j < gd.o.n_contigs; j++) C->c[i].push_back(gd.contig(j)); }
+    for (const mtgi::SpecialGap& sg : special.special) {
+        const mtgi::GapDev gd = special.view(sg);
+        for (uint32_t j = 0; j < gd.o.n_contigs; j++) C->c[sg.gap].push_back(gd.contig(j));
+    }
     *out = C;
     return MTG_OK;
 }

@@ -8,6 +8,7 @@
 #include "../../include/mtg_fill.h"
 #include "mtg_hostutil.h"
 #include "mtg_paths.h"
+#include "mtg_emit.h"
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -227,14 +228,12 @@ template <typename G> inline uint64_t parallel_prefix(size_t n, int nthreads, ui
     return bs[nb];
 }
 
-/* one gapFillFromSource call and its results (host side) */
-/* strings of a batch are VIEWS on the caller's storage, which must stay alive until the results have been consumed */
-struct Target {
+/* ---- a batch of gapFillFromSource calls, marshalled for the device -------------------------------------------------------------------
+ * Three contiguous blocks that go up in one copy each (A: per-gap arrays, B: packed early-stop patterns, C: the targets as text).  With a
+ * workspace they sit in its page-locked staging blocks, otherwise in `own_*`. */
+struct Target { /* one entry of a gap's targetDictionary (views on the caller's strings) */
     std::string_view seq, name;
     bool is_rc = false;
-    uint64_t code = 0;    /* 2-bit code of the first k chars */
-    uint64_t badmask = 0; /* positions (pair-lsb) that can never match (not ACGT/acgt) */
-    bool usable = true;   /* at least k chars */
 };
 struct TargetSpan {
     const Target* p = nullptr;
@@ -247,92 +246,10 @@ struct TargetSpan {
 
 /* grow-only staging block `slot` of a workspace (page-locked on the device build); nullptr when it cannot be had */
 void* staging_host(Workspace* ws, int slot, size_t bytes);
+/* page-locked host memory for the result arrays of a batch (plain memory in the emulation); nullptr on failure */
+void* pinned_alloc(size_t bytes);
+void pinned_free(void* p);
 
-/* what a chunk of gaps brought back: one record per slot, the dense words and the dense contig metadata.  The three arrays sit in a
- * staging block of the index (first chunks of a batch) or in `own`. */
-struct HostChunk {
-    const mtg::SlotRec* recs = nullptr;
-    const uint64_t* words = nullptr;
-    const uint32_t* meta = nullptr;
-    uint32_t m = 0;
-    uint64_t n_words = 0; /* dense words of the chunk */
-    std::vector<uint64_t> own;
-    /* contig-graph paths of the multi-contig gaps of the chunk (k_paths): PATHS_WORDS words per such gap, path_of[slot] = its rank or -1 */
-    std::vector<uint32_t> paths;
-    std::vector<int32_t> path_of;
-    /* carves recs / words / meta for m slots, tw words, tc metadata entries out of `block` (or out of `own` when block is null) */
-    void carve(void* block, uint32_t m_, uint64_t tw, uint64_t tc, mtg::SlotRec*& r, uint64_t*& w, uint32_t*& mt)
-    {
-        if (!block) { own.resize(bytes_for(m_, tw, tc) / 8); block = own.data(); }
-        uint8_t* b = (uint8_t*)block;
-        r = (mtg::SlotRec*)b;
-        w = (uint64_t*)(b + rec_bytes(m_));
-        mt = (uint32_t*)(b + rec_bytes(m_) + (tw + 1) * 8);
-        recs = r; words = w; meta = mt; m = m_; n_words = tw;
-    }
-    static size_t rec_bytes(uint32_t m_) { return ((size_t)m_ * sizeof(mtg::SlotRec) + 63) & ~(size_t)63; }
-    static size_t bytes_for(uint32_t m_, uint64_t tw, uint64_t tc) { return (rec_bytes(m_) + (tw + 1) * 8 + tc * 20 + 64 + 7) & ~(size_t)7; }
-};
-
-/* what comes back from the device for one gap (views into a HostChunk) */
-struct GapDev {
-    mtg::GapOut o{};
-    mtg::PostOut p{};
-    /* contig data: all contigs when n_meta == o.n_contigs, otherwise only the leading words of contig 0 */
-    uint32_t n_meta = 0;
-    const uint64_t* words = nullptr;
-    const uint32_t *len = nullptr, *word_start = nullptr, *tpos = nullptr, *terr = nullptr, *ttgt = nullptr;
-    const uint32_t* paths = nullptr; /* k_paths record of the gap (mtg_paths.h), if the device enumerated its paths */
-    std::string contig(size_t i) const
-    {
-        std::string s;
-        mtg::unpack_seq(words + word_start[i], len[i], s);
-        return s;
-    }
-    /* contig0[from, to) from the leading words */
-    std::string contig0_slice(uint32_t from, uint32_t to) const
-    {
-        std::string s;
-        if (to <= from) return s;
-        static const char NT[4] = {'A', 'C', 'T', 'G'};
-        s.resize(to - from);
-        for (uint32_t i = from; i < to; i++) s[i - from] = NT[(words[i >> 5] >> (2 * (i & 31))) & 3];
-        return s;
-    }
-};
-struct DevBatch {
-    std::vector<uint32_t> chunk_of, slot_of; /* where gap i's results sit; both empty: chunk i / part, slot i % part */
-    std::vector<std::unique_ptr<HostChunk>> chunks;
-    size_t n = 0;
-    size_t part = ~(size_t)0; /* gaps per chunk while the map is implicit (the whole batch went through one traversal launch) */
-    size_t size() const { return n; }
-    const mtg::SlotRec& rec(size_t i) const { return chunk_of.empty() ? chunks[i / part]->recs[i % part] : chunks[chunk_of[i]]->recs[slot_of[i]]; }
-    /* view of gap i (cheap: a few pointer computations) */
-    GapDev operator[](size_t i) const
-    {
-        const HostChunk& c = chunk_of.empty() ? *chunks[i / part] : *chunks[chunk_of[i]];
-        return view(c, chunk_of.empty() ? i % part : slot_of[i]);
-    }
-    /* view of the gap in slot `slot` of chunk c */
-    static GapDev view(const HostChunk& c, size_t slot)
-    {
-        const mtg::SlotRec& r = c.recs[slot];
-        GapDev g;
-        if (!c.path_of.empty() && c.path_of[slot] >= 0) g.paths = c.paths.data() + (size_t)c.path_of[slot] * mtg::PATHS_WORDS;
-        g.o = r.o;
-        g.p = r.p;
-        g.n_meta = r.nc;
-        g.words = c.words + r.wbase;
-        if (g.n_meta) {
-            const uint32_t* b0 = c.meta + 5 * r.cbase;
-            g.len = b0; g.word_start = b0 + r.nc; g.tpos = b0 + 2 * (size_t)r.nc; g.terr = b0 + 3 * (size_t)r.nc; g.ttgt = b0 + 4 * (size_t)r.nc;
-        }
-        return g;
-    }
-};
-
-/* a batch of gapFillFromSource calls, marshalled for the device: two contiguous blocks (per-gap arrays; variable-length arrays) that
- * go up in one copy each.  With an index they sit in its page-locked staging blocks, otherwise in `own_*`. */
 template <typename T> struct Arr {
     T* p = nullptr;
     size_t n = 0;
@@ -344,14 +261,14 @@ template <typename T> struct Arr {
 struct FillInput {
     int k = 31;
     bool want_all_contigs = false;
-    Workspace* ws = nullptr; /* whose staging blocks and device buffers to use (the caller holds its lock) */
+    Workspace* ws = nullptr; /* whose staging blocks to use (the caller holds its lock); nullptr: own storage */
     /* block A */
     Arr<uint64_t> src;     /* oriented source k-mer per gap */
     Arr<uint64_t> r0;      /* first k-mer of the pattern */
     Arr<uint32_t> roff;    /* first word of gap i's pattern */
     Arr<uint32_t> rlen;    /* pattern length in nt */
     Arr<uint32_t> toff, tcnt;
-    Arr<uint8_t> nbmis, fast_ok;
+    Arr<uint8_t> nbmis, fast_ok, flags; /* flags: mtg_emit.h GAPF_* */
     /* block B */
     Arr<uint64_t> rwords;  /* packed swf patterns, concatenated */
     /* block C: the targets of all gaps as text (mtg_post.h: TARGET_SLOT bytes each); the device turns them into k-mers and masks */
@@ -359,19 +276,20 @@ struct FillInput {
     void *block_a = nullptr, *block_b = nullptr, *block_c = nullptr;
     size_t bytes_a = 0, bytes_b = 0, bytes_c = 0;
     std::vector<uint64_t> own_a, own_b, own_c;
+    /* device copies of the three blocks and of the encoded targets, when the batch was prepared ahead (mtg_batch): device_run then uploads nothing */
+    void* dev_a = nullptr; void* dev_b = nullptr; void* dev_tenc = nullptr;
     /* two-pass marshalling: size(i, ...) for every gap in order, then layout(), then set(i, ...) from any thread */
     void resize(size_t n);
     void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }
     void layout();
-    void set(size_t i, std::string_view source, std::string_view swf_target, const TargetSpan* targets, int nb_mis);
-    void set_common(size_t i, std::string_view source, std::string_view swf_target, int nb_mis);
+    void set_common(size_t i, std::string_view source, std::string_view swf_target, int nb_mis, uint8_t gap_flags);
     void set_target(size_t slot, std::string_view seq);
-    /* The two passes over blocks of gaps, each one parallel region.  plan: sz(i, swf_len, n_targets) for every gap, then the offsets of
-     * every block; fill: offsets of every gap of a block in turn, then st(i) (which calls set_common). */
     enum { BLOCK = 512 };
     std::vector<uint64_t> blk_rw, blk_nt;
     std::vector<uint32_t> slen; /* host only: length of every gap's source (pass 1 has looked at it; nobody needs to again) */
     void alloc_b(uint64_t rw, uint64_t nt);
+    /* The two passes over blocks of gaps, each one parallel region.  plan: sz(i, swf_len, n_targets) for every gap, then the offsets of
+     * every block; fill: offsets of every gap of a block in turn, then st(i) (which calls set_common). */
     template <typename SizeFn> void plan(size_t n, int nthreads, SizeFn sz)
     {
         resize(n);
@@ -465,20 +383,102 @@ struct FillInput {
             }
         }, 1);
     }
-    /* byte offsets of the arrays inside their block (the device copy has the same layout) */
-    static size_t off_a(size_t n, int which) { static const size_t mul[8] = {0, 8, 16, 20, 24, 28, 32, 33}; return mul[which] * n8(n); }
+    /* byte offsets of the arrays inside block A (the device copy has the same layout) */
+    static size_t off_a(size_t n, int which) { static const size_t mul[9] = {0, 8, 16, 20, 24, 28, 32, 33, 34}; return mul[which] * n8(n); }
     static size_t n8(size_t n) { return (n + 7) & ~(size_t)7; }
+    enum { BYTES_A_PER_GAP = 35 };
 };
 
-/* stage A + post-processing kernels for all gaps (chunked, tiered); fills out[i]; returns MTG_* status.  `while_busy` runs once on the
- * calling thread after everything of the first traversal launch has been queued: the device needs nothing more from the host. */
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& out, mtg_batch_stats* stats,
-               const std::function<void()>* while_busy = nullptr, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready = nullptr);
-/* on_ready(chunk, ids, first, count): chunk `chunk` of `out` is complete and holds the results of the gaps ids[0..count) (ids == nullptr:
- * the gaps first .. first + count - 1).  A gap whose status is not GAP_OK there is re-run in a larger scratch tier and announced again
- * with a later chunk.  Called on the calling thread, in chunk order, while the device may still be working on later parts. */
-enum { MTG_POST_PARTS = 8 };
-enum { STAGING_CHUNK0 = 3 }; /* first staging block used for results */
+/* ---- what comes back ---------------------------------------------------------------------------------------------------------------
+ * The common case never reaches the host as per-gap work: the device writes the C-ABI records and the ASCII sequences (mtg_emit.h) and
+ * they are copied into the arrays below.  Only multi-contig gaps (and the stage-A entry) bring their contigs back. */
+struct ResultSink {
+    size_t n = 0;
+    mtg_gap_result* res = nullptr; /* n records; nullptr: the caller only wants the contigs (stage-A entry) */
+    mtg_filled* fil = nullptr;     /* n records: slot i belongs to gap i */
+    char* seq = nullptr;           /* sequence arena: NUL-terminated fills, in gap order unless `in_gap_order` comes back false */
+    size_t seq_cap = 0;
+    char* ext = nullptr;           /* extension arena; ext[0] = 0 is the empty string of every record without extension */
+    size_t ext_cap = 0;
+    /* an arena turned out too small: must replace it by a block of at least `need` bytes whose first `keep` bytes are those of the old
+     * block, and set pointer and capacity (false: it cannot grow -- the caller's own buffer) */
+    std::function<bool(size_t need, size_t keep)> grow_seq, grow_ext;
+    uint64_t seq_used = 0, ext_used = 1;
+    uint64_t n_filled = 0;         /* gaps filled on the common path */
+    bool in_gap_order = true;
+};
+
+/* contigs of the gaps that need the host: one record per slot of a launch, the dense words and the dense contig metadata */
+struct HostChunk {
+    const mtg::SlotRec* recs = nullptr;
+    const uint64_t* words = nullptr;
+    const uint32_t* meta = nullptr;
+    uint32_t m = 0;
+    std::vector<uint64_t> own;
+    /* contig-graph paths of the multi-contig gaps of the chunk (k_paths): PATHS_WORDS words per such gap, path_of[slot] = its rank or -1 */
+    std::vector<uint32_t> paths;
+    std::vector<int32_t> path_of;
+    std::vector<uint32_t> gap_of; /* gap of every slot (empty: slot = gap) */
+    /* carves recs / words / meta for m slots, tw words, tc metadata entries out of `own` */
+    void carve(uint32_t m_, uint64_t tw, uint64_t tc, mtg::SlotRec*& r, uint64_t*& w, uint32_t*& mt)
+    {
+        own.resize(bytes_for(m_, tw, tc) / 8);
+        uint8_t* b = (uint8_t*)own.data();
+        r = (mtg::SlotRec*)b;
+        w = (uint64_t*)(b + rec_bytes(m_));
+        mt = (uint32_t*)(b + rec_bytes(m_) + (tw + 1) * 8);
+        recs = r; words = w; meta = mt; m = m_;
+    }
+    static size_t rec_bytes(uint32_t m_) { return ((size_t)m_ * sizeof(mtg::SlotRec) + 63) & ~(size_t)63; }
+    static size_t bytes_for(uint32_t m_, uint64_t tw, uint64_t tc) { return (rec_bytes(m_) + (tw + 1) * 8 + tc * 20 + 64 + 7) & ~(size_t)7; }
+};
+
+/* what comes back from the device for one gap (views into a HostChunk) */
+struct GapDev {
+    mtg::GapOut o{};
+    mtg::PostOut p{};
+    uint32_t n_meta = 0; /* contigs whose data came back (all of them, or none) */
+    const uint64_t* words = nullptr;
+    const uint32_t *len = nullptr, *word_start = nullptr, *tpos = nullptr, *terr = nullptr, *ttgt = nullptr;
+    const uint32_t* paths = nullptr; /* k_paths record of the gap (mtg_paths.h), if the device enumerated its paths */
+    std::string contig(size_t i) const
+    {
+        std::string s;
+        mtg::unpack_seq(words + word_start[i], len[i], s);
+        return s;
+    }
+};
+struct SpecialGap {
+    uint32_t gap, chunk, slot;
+};
+struct DevBatch {
+    std::vector<std::unique_ptr<HostChunk>> chunks; /* launches that had gaps for the host */
+    std::vector<SpecialGap> special;                 /* multi-contig gaps (every gap with want_all_contigs), in no particular order */
+    static GapDev view(const HostChunk& c, size_t slot)
+    {
+        const mtg::SlotRec& r = c.recs[slot];
+        GapDev g;
+        if (!c.path_of.empty() && c.path_of[slot] >= 0) g.paths = c.paths.data() + (size_t)c.path_of[slot] * mtg::PATHS_WORDS;
+        g.o = r.o;
+        g.p = r.p;
+        g.n_meta = r.nc;
+        g.words = c.words + r.wbase;
+        if (g.n_meta) {
+            const uint32_t* b0 = c.meta + 5 * r.cbase;
+            g.len = b0; g.word_start = b0 + r.nc; g.tpos = b0 + 2 * (size_t)r.nc; g.terr = b0 + 3 * (size_t)r.nc; g.ttgt = b0 + 4 * (size_t)r.nc;
+        }
+        return g;
+    }
+    GapDev view(const SpecialGap& s) const { return view(*chunks[s.chunk], s.slot); }
+};
+
+/* traversal + post-processing + result emission for all gaps (chunked, tiered); returns MTG_* status.  `while_busy` runs once on the
+ * calling thread after everything of the first launch has been queued: the device needs nothing more from the host. */
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, ResultSink& sink, DevBatch& special, mtg_batch_stats* stats,
+               const std::function<void()>* while_busy = nullptr);
+/* device copies of a marshalled batch (mtg_batch): block A, block B, encoded targets */
+int batch_upload(const mtg_index* idx, FillInput& in);
+void batch_release_device(FillInput& in);
 
 /* membership scan over packed sequences: host arrays in (words/off/len), bit output as in mtg_index_scan_packed_device; device = 1: the pointers are device pointers */
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int device_ptrs,
@@ -499,152 +499,35 @@ struct NwPair {
 int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches);
 
 int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
+/* the solid k-mers of an index with their abundances, read back from its device tables, in pieces handed to sink(kmers, abundances, count) */
+int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink);
 
 void stats_store(const mtg_batch_stats& s);
 
-/* a filled sequence: either an owned string (general path) or a NUL-terminated view into the batch arena (common path) */
-struct SeqBuf {
-    std::string own;
-    const char* p = nullptr;
-    uint32_t n = 0;
-    bool is_view() const { return p != nullptr; }
-    size_t size() const { return p ? n : own.size(); }
-    size_t length() const { return size(); }
-    const char* data() const { return p ? p : own.data(); }
-    const char* c_str() const { return p ? p : own.c_str(); }
-    char operator[](size_t i) const { return data()[i]; }
-    std::string str() const { return std::string(data(), size()); }
-    SeqBuf& operator=(std::string s) { own = std::move(s); p = nullptr; n = 0; return *this; }
-    void view(const char* q, uint32_t len) { p = q; n = len; }
-    bool operator==(const SeqBuf& o) const { return size() == o.size() && memcmp(data(), o.data(), size()) == 0; }
-};
-/* storage of the common-path sequences of one batch; must outlive the GapWork results that point into it.  Raw and uninitialised: every
- * byte handed out is written by exactly one gap, and a recycled arena costs no page faults and no memset */
-struct FillArena {
-    /* one buffer per chunk of a batch: the chunks are decoded as they come back from the device */
-    std::vector<std::unique_ptr<char[]>> buf;
-    std::vector<size_t> cap;
-    char* ensure(size_t chunk, size_t n)
-    {
-        if (buf.size() <= chunk) { buf.resize(chunk + 1); cap.resize(chunk + 1, 0); }
-        if (cap[chunk] < n) { buf[chunk].reset(); cap[chunk] = n + n / 8 + 64; buf[chunk].reset(new char[cap[chunk]]); }
-        return buf[chunk].get();
-    }
-    /* Optional caller-owned buffer (mtg_fill_batch_serial): as long as the chunks arrive in gap order and fit, their sequences are laid
-     * out there one after the other, which makes the buffer the batch's serialised form without a copy. */
-    char* ext = nullptr;
-    size_t ext_cap = 0, ext_used = 0, ext_next_gap = 0;
-    bool ext_ok = false;
-    void set_external(char* p, size_t c) { ext = p; ext_cap = c; ext_used = 0; ext_next_gap = 0; ext_ok = p != nullptr; }
-};
-
+/* ---- the multi-contig path on the host (gaps whose target is not on contig 0) ------------------------------------------------------- */
 struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */
-    SeqBuf seq;
+    std::string seq;
     int nb_errors = 0;
     int target = -1;
     float avg = 0, median = 0;
     int qual = 0, count = 0, rank = 0;
     size_t ab_off = 0, ab_n = 0; /* slice of the batched abundance query */
-    void reset() /* as freshly constructed, keeping the string's capacity */
-    {
-        seq.own.clear(); seq.p = nullptr; seq.n = 0;
-        nb_errors = 0; target = -1; avg = median = 0; qual = count = rank = 0; ab_off = ab_n = 0;
-    }
-};
-/* the solutions of one gap: nearly always zero or one, kept inline so that the common path never touches the heap */
-class SolVec {
-public:
-    SolVec() {}
-    SolVec(SolVec&& o) noexcept { take(o); }
-    SolVec& operator=(SolVec&& o) noexcept { if (this != &o) { clear(); more_.clear(); take(o); } return *this; }
-    SolVec(const SolVec&) = delete;
-    SolVec& operator=(const SolVec&) = delete;
-    size_t size() const { return more_.empty() ? (size_t)has_first_ : more_.size(); }
-    bool empty() const { return size() == 0; }
-    const Solution* begin() const { return more_.empty() ? &first_ : more_.data(); }
-    const Solution* end() const { return begin() + size(); }
-    Solution* begin() { return more_.empty() ? &first_ : more_.data(); }
-    Solution* end() { return begin() + size(); }
-    const Solution& operator[](size_t i) const { return begin()[i]; }
-    void clear() { if (has_first_) { first_.reset(); has_first_ = false; } more_.clear(); }
-    void push_back(Solution&& s)
-    {
-        if (!has_first_ && more_.empty()) { first_ = std::move(s); has_first_ = true; return; }
-        if (more_.empty()) { more_.reserve(4); more_.push_back(std::move(first_)); }
-        more_.push_back(std::move(s));
-    }
-    /* the inline slot, for writers that fill it in place */
-    Solution& emplace_first() { clear(); has_first_ = true; return first_; }
-
-private:
-    void take(SolVec& o) { first_ = std::move(o.first_); has_first_ = o.has_first_; more_ = std::move(o.more_); o.has_first_ = false; }
-    Solution first_;
-    bool has_first_ = false;
-    std::vector<Solution> more_; /* all solutions once there are two or more */
-};
-/* read-only view on a run of solutions (SolVec or std::vector) */
-struct SolSpan {
-    const Solution* p = nullptr;
-    size_t n = 0;
-    SolSpan(const SolVec& v) : p(v.begin()), n(v.size()) {}
-    SolSpan(const std::vector<Solution>& v) : p(v.data()), n(v.size()) {}
-    const Solution* begin() const { return p; }
-    const Solution* end() const { return p + n; }
-    size_t size() const { return n; }
-    bool empty() const { return n == 0; }
 };
 struct GapWork {
-    TargetSpan targets; /* targetDictionary in iteration order (storage owned by the caller of fill_gaps) */
+    TargetSpan targets; /* targetDictionary in iteration order */
+    std::vector<Target> target_store;
     std::string_view source;
     bool anchor_repeated = false, reverse = false;
-    int nb_nodes = 0, total_nt = 0, nb_terminal = 0, nb_total_filled = 0;
+    int nb_total_filled = 0;
     bool has_counts = false;
-    SolVec sols;
-    std::string extension;
-    /* back to the state of a fresh object, keeping the capacity of what it owns */
-    void reset()
-    {
-        targets = TargetSpan(); source = std::string_view(); anchor_repeated = reverse = has_counts = false;
-        nb_nodes = total_nt = nb_terminal = nb_total_filled = 0;
-        sols.clear(); extension.clear();
-    }
+    std::vector<Solution> sols;
 };
-/* where a batch of gapFillFromSource calls comes from */
-struct BatchSource {
-    virtual ~BatchSource() {}
-    virtual size_t count() const = 0;
-    /* pass 1, any thread: lengths of gap i's source and swf pattern, number of targets; false: the gap is malformed */
-    virtual bool sizes(size_t i, size_t& src_len, size_t& swf_len, size_t& n_targets) const = 0;
-    /* pass 2, any thread: in.set_common(i, ...) and in.set_target(in.toff[i] + t, ...) for every target of gap i */
-    virtual void input(size_t i, FillInput& in, int nb_mis_allowed) const = 0;
-    /* called once while the device works on the batch: whatever gaps() still lacks (source, targets, flags of every gap) */
-    virtual void marshal(const FillInput& in, int nthreads) = 0;
-    virtual std::vector<GapWork>& gaps() = 0;
-    /* any thread, once per gap, right before its results are looked at: gaps()[i] ready (source, flags) if marshal left that for later */
-    virtual void init_gap(size_t i) { (void)i; }
-    /* any thread, before gap i goes down the multi-contig path (the only one that looks at the dictionary): make gaps()[i].targets valid
-     * if marshal left that for later */
-    virtual void need_targets(size_t i) { (void)i; }
-    /* Result records as the chunks come back: record_gap(i, ...) from any thread once gap i has its final solutions (speculative: the
-     * caller may still find out that the chunk needs the multi-contig path or a re-run), then part_done(first, count, clean) once per
-     * chunk that was a contiguous range of gaps. */
-    virtual void record_gap(size_t i, uint64_t& bytes, uint64_t& filled) { (void)i; (void)bytes; (void)filled; }
-    virtual void part_done(size_t first, size_t count, bool clean, uint64_t bytes, uint64_t filled) { (void)first; (void)count; (void)clean; (void)bytes; (void)filled; }
-};
-#ifndef MTG_RESULT_BLOCK_V
-#define MTG_RESULT_BLOCK_V 512
-#endif
-enum { RESULT_BLOCK = MTG_RESULT_BLOCK_V };
-/* sol_blocks (optional): number of solutions in each block of RESULT_BLOCK gaps */
-int fill_gaps(const mtg_index* idx, const mtg_params* p, BatchSource& src, FillArena& arena, mtg_batch_stats* stats_out, std::vector<uint64_t>* sol_blocks = nullptr);
+
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
-int fill_gaps(const mtg_index* idx, const mtg_params* p, std::vector<GapWork>& gaps, const std::vector<std::string_view>& swf_targets, FillArena& arena,
-              mtg_batch_stats* stats_out);
 int index_from_kmers(const uint64_t*, const uint32_t*, size_t, int, mtg_index**);
 int index_from_reads(const char*, int, int, int, mtg_index**);
 int index_save(const mtg_index*, const char*);
 int index_load(const char*, mtg_index**);
-void index_forget_host_copy(const mtg_index* idx);
 int fill_main(int argc, const char* const* argv);
 
 } // namespace mtgi

@@ -22,25 +22,16 @@ struct PostOut {
     uint32_t lines;               /* index buckets read by the coverage pass (block look-ups + k-mers the store did not confirm) */
 };
 
-/* what to copy back for a gap: nw leading words of its arena, metadata of nc contigs (0 or all) */
-MTG_DEV void copy_plan(const GapOut& o, const PostOut& p, bool want_all, uint32_t& nw, uint32_t& nc)
-{
-    nw = nc = 0;
-    if (o.status != GAP_OK) return;
-    if (want_all || (p.fast == 0 && p.nb_terminal > 0)) { nw = o.n_words; nc = o.n_contigs; }
-    else if (p.fast == 1) nw = (p.pos + 31) / 32;
-    else if (p.fast == 2) nw = 0;
-    else nw = (p.clen0 + 31) / 32; /* no terminal node: contig 0 is the extension sequence */
-}
-
-/* everything the host learns about one gap of a chunk, written by k_post: the counters of both kernels and where the gap's words /
- * contig metadata sit in the chunk's dense arrays.  Metadata of a gap: 5 runs of nc entries at meta[5 * cbase] (length, first word,
- * terminal position, errors, target index). */
+/* everything the device keeps about one gap of a launch: the counters of the traversal and of the post-processing, what the gap
+ * contributes to the arrays of its batch (mtg_emit.h: emit_plan) and where (exclusive prefix sums in slot order).  Metadata of a gap: 5
+ * runs of nc entries at meta[5 * cbase] (length, first word, terminal position, errors, target index). */
 struct SlotRec {
     GapOut o;
     PostOut p;
-    uint32_t nw, nc;
-    uint64_t wbase, cbase;
+    uint32_t nw, nc;   /* dense words / contig metadata entries (multi-contig gaps and the stage-A entry only) */
+    uint32_t asc, ext; /* bytes in the sequence / extension arena, NUL included */
+    uint64_t wbase, cbase, abase, ebase;
+    uint32_t rpos, gpos; /* rank among the gaps to re-run / among the gaps that need the host */
 };
 
 /* A target as the host hands it over: its first k characters in a TARGET_SLOT-byte slot, byte TARGET_SLOT - 1 = 1 when the anchor
@@ -113,7 +104,9 @@ MTG_DEV uint64_t le_kmer(const uint64_t* w, uint32_t j, uint64_t mk)
 enum { POST_TILE = 512 }; /* words = 16384 nucleotides */
 
 /* hist: 256 zeroed counters shared by the lanes; tile: POST_TILE + 2 words; blk: 64 words (all LDS on the device) */
-MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, uint64_t* tile, uint64_t* blk, PostOut& out)
+/* dbg (timing experiments only, never set by the product): bit 0 = no coverage pass, bit 1 = no terminal search */
+MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, uint64_t* tile, uint64_t* blk, PostOut& out,
+                      uint32_t dbg = 0)
 {
     const int k = ix.k;
     const uint64_t mk = kmask(k);
@@ -132,7 +125,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     /* find_nodes_containing_multiple_R: the scan keeps the first (position-major, target-minor) occurrence of the best match count
      * >= k - nb_mis and stops at the first exact match (src/Filler.cpp:1341-1351); an exact match is the largest possible count, so the
      * result is the first occurrence of the maximum: an arg-max, evaluated here by all lanes at once. */
-    for (uint32_t c = 0; c < o.n_contigs; c++) {
+    for (uint32_t c = 0; c < ((dbg & 2u) ? 0u : o.n_contigs); c++) {
         const uint32_t L = clen[c];
         const uint64_t* w = words + cstart[c];
         uint64_t best = 0;
@@ -206,7 +199,8 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     }
     uint32_t sum = 0, lines = 0;
     const uint64_t cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
-    if (ix.us.nwords == 0) {
+    if (dbg & 1u) { if (lane == 0) hist[1] = nk; sum = lane == 0 ? nk : 0; } /* timing experiment: no look-ups */
+    else if (ix.us.nwords == 0) {
         for (uint32_t j = lane; j < nk; j += MTG_NLANES) {
             Kmer x;
             x.r = le_kmer(w0, j, mk) ^ cmpl; /* little-endian image = reversed order: complementing it gives revcomp */

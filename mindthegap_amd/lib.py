@@ -131,6 +131,11 @@ def _bind(lib):
     lib.mtg_default_params.restype = None
     lib.mtg_fill_batch.argtypes = [C.c_void_p, P(Params), P(CGap), C.c_size_t, P(C.c_void_p)]
     lib.mtg_fill_batch_serial.argtypes = [C.c_void_p, P(Params), P(CGap), C.c_size_t, C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_void_p)]
+    lib.mtg_batch_prepare.argtypes = [C.c_void_p, P(Params), P(CGap), C.c_size_t, P(C.c_void_p)]
+    lib.mtg_batch_free.argtypes = [C.c_void_p]
+    lib.mtg_batch_free.restype = None
+    lib.mtg_fill_prepared.argtypes = [C.c_void_p, P(Params), C.c_void_p, P(C.c_void_p)]
+    lib.mtg_fill_prepared_serial.argtypes = [C.c_void_p, P(Params), C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_void_p)]
     lib.mtg_results_get.argtypes = [C.c_void_p, C.c_size_t]
     lib.mtg_results_get.restype = P(CGapResult)
     lib.mtg_results_free.argtypes = [C.c_void_p]
@@ -172,6 +177,24 @@ class Gap:
         self.source, self.target = source, target
         self.targets = list(targets)  # [(kmer, name, is_rc)] in dictionary iteration order
         self.is_anchor_repeated, self.reverse = is_anchor_repeated, reverse
+
+
+class Batch:
+    """A batch of gaps marshalled once and kept in device memory (mtg_batch_prepare); fill it with Index.fill_prepared / fill_prepared_serial."""
+
+    def __init__(self, handle, n, keep):
+        self.h, self.n, self._keep = handle, n, keep  # _keep: the ctypes arrays the batch's strings live in
+
+    def close(self):
+        if self.h:
+            load_library().mtg_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Index:
@@ -283,14 +306,27 @@ class Index:
             arr[i] = CGap(g.source.encode(), g.target.encode(), m, seqs, names, rcs, int(g.is_anchor_repeated), int(g.reverse))
         return (arr, n, keep)
 
+    def prepare_batch(self, gaps, params=None):
+        """marshal a list of Gap (or the result of prepare_gaps) into a device-resident Batch"""
+        params = params or FillParams()
+        arr, n, keep = gaps if isinstance(gaps, tuple) else self.prepare_gaps(gaps)
+        h = C.c_void_p()
+        _check(self.lib.mtg_batch_prepare(self.h, C.byref(params.c), arr, n, C.byref(h)))
+        return Batch(h, n, (arr, keep))
+
     def fill_prepared(self, prepared, params=None, want_seqs=True, out=None):
-        """one mtg_fill_batch call; returns (results handle, n_filled per gap, uint8 array of the packed "seq\\n" bytes).  Free with free_results.
+        """one mtg_fill_batch (or, for a Batch, mtg_fill_prepared) call; returns (results handle, n_filled per gap, uint8 array of the packed
+        "seq\\n" bytes).  Free with free_results.
         out: optional uint8 array that receives the bytes (e.g. a page-locked buffer); self.last_seq_bytes = their number either way."""
         params = params or FillParams()
-        arr, n, _ = prepared
         h = C.c_void_p()
         t0 = time.perf_counter()
-        _check(self.lib.mtg_fill_batch(self.h, C.byref(params.c), arr, n, C.byref(h)))
+        if isinstance(prepared, Batch):
+            n = prepared.n
+            _check(self.lib.mtg_fill_prepared(self.h, C.byref(params.c), prepared.h, C.byref(h)))
+        else:
+            arr, n, _ = prepared
+            _check(self.lib.mtg_fill_batch(self.h, C.byref(params.c), arr, n, C.byref(h)))
         t1 = time.perf_counter()
         nf = np.empty(n, dtype=np.uint32)
         nb, ng = C.c_uint64(), C.c_uint64()
@@ -314,10 +350,14 @@ class Index:
         directly in the common case; returns (results handle, n_filled per gap, number of bytes).  `out` must stay untouched until
         free_results."""
         params = params or FillParams()
-        arr, n, _ = prepared
         h = C.c_void_p()
         nb = C.c_uint64()
-        _check(self.lib.mtg_fill_batch_serial(self.h, C.byref(params.c), arr, n, out.ctypes.data_as(C.c_void_p), out.size, C.byref(nb), C.byref(h)))
+        if isinstance(prepared, Batch):
+            n = prepared.n
+            _check(self.lib.mtg_fill_prepared_serial(self.h, C.byref(params.c), prepared.h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(nb), C.byref(h)))
+        else:
+            arr, n, _ = prepared
+            _check(self.lib.mtg_fill_batch_serial(self.h, C.byref(params.c), arr, n, out.ctypes.data_as(C.c_void_p), out.size, C.byref(nb), C.byref(h)))
         nf = np.empty(n, dtype=np.uint32)
         _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), None, None))
         self.last_seq_bytes = int(nb.value)

@@ -72,7 +72,6 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
 void index_release(mtg_index* idx)
 {
     if (!idx) return;
-    index_forget_host_copy(idx);
     { std::lock_guard<std::mutex> lk(g_us_mtx); auto it = g_us.find(idx); if (it != g_us.end()) { delete it->second; g_us.erase(it); } }
     free(idx->dev.adj.slots); free(idx->dev.abnd.slots); free(idx->dev.bloom.bits);
     for (Workspace& w : idx->ws) for (void* h : w.hptr) free(h);
@@ -170,7 +169,7 @@ int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint3
 /* grow-only staging blocks like the device build's, in ordinary memory (never shrunk, poisoned when they grow: a batch must write what it reads) */
 void* staging_host(Workspace* ws, int slot, size_t bytes)
 {
-    if (!ws || slot < 0 || slot >= Workspace::NHOST || slot >= STAGING_CHUNK0) return nullptr; /* results keep their own storage here */
+    if (!ws || slot < 0 || slot >= Workspace::NHOST) return nullptr;
     if (ws->hcap[slot] < bytes) {
         free(ws->hptr[slot]);
         const size_t want = bytes + bytes / 4 + 4096;
@@ -181,131 +180,197 @@ void* staging_host(Workspace* ws, int slot, size_t bytes)
     }
     return ws->hptr[slot];
 }
+void* pinned_alloc(size_t bytes)
+{
+    void* p = malloc(bytes ? bytes : 8);
+    if (p) memset(p, 0xA5, bytes ? bytes : 8); /* poisoned: a record must be written before it is read */
+    return p;
+}
+void pinned_free(void* p) { free(p); }
+int batch_upload(const mtg_index*, FillInput&) { return MTG_OK; } /* nothing to upload: the "device" reads the host blocks */
+void batch_release_device(FillInput&) {}
 
-int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, DevBatch& batch, mtg_batch_stats* stats,
-               const std::function<void()>* while_busy, const std::function<void(size_t, const uint32_t*, size_t, size_t)>* on_ready)
+int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink)
+{
+    std::vector<uint64_t> k;
+    std::vector<uint32_t> a;
+    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+    for (uint64_t s = 0; s < nslots; s++) {
+        uint64_t c;
+        const uint32_t ab = abnd_slot_kmer(idx->dev.abnd, s, c);
+        if (ab) { k.push_back(c); a.push_back(ab); }
+    }
+    if (k.size() != idx->info.nb_solid_kmers) { set_error("index export: %zu k-mers in the table, %llu expected", k.size(), (unsigned long long)idx->info.nb_solid_kmers); return MTG_ERR_FORMAT; }
+    const size_t piece = 1000; /* several pieces, like the device build */
+    for (size_t off = 0; off < k.size(); off += piece)
+        if (!sink(k.data() + off, a.data() + off, std::min(piece, k.size() - off))) { set_error("index export: the writer failed"); return MTG_ERR_IO; }
+    return MTG_OK;
+}
+
+/* Same shape as the device build: a launch covers the gaps still to do at a scratch tier (several launches per tier with MTG_MAX_CHUNK);
+ * per launch: traversal and post-processing of every slot, layout of the results by prefix sums in slot order, emission (records, ASCII,
+ * dense contig arrays of the gaps that need the host), arenas grown and the launch emitted again when they are too small. */
+int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, ResultSink& sink, DevBatch& special, mtg_batch_stats* stats, const std::function<void()>* while_busy)
 {
     if (while_busy) (*while_busy)();
+    const int k = idx->dev.k;
     /* stand-in for k_encode_targets */
     const size_t n_targets = in.traw.size() / TARGET_SLOT;
     std::vector<uint64_t> tle(n_targets), tbad(n_targets);
-    for (size_t t = 0; t < n_targets; t++) encode_target(in.traw.data() + t * TARGET_SLOT, idx->dev.k, tle[t], tbad[t]);
+    for (size_t t = 0; t < n_targets; t++) encode_target(in.traw.data() + t * TARGET_SLOT, k, tle[t], tbad[t]);
     const size_t n = in.src.size();
-    batch.n = n;
-    batch.chunks.clear();
+    special.chunks.clear();
+    special.special.clear();
+    sink.seq_used = 0;
+    sink.ext_used = 1;
+    sink.n_filled = 0;
+    sink.in_gap_order = true;
     mtg_batch_stats st = stats ? *stats : mtg_batch_stats{};
-    batch.part = ~(size_t)0;
-    batch.chunk_of.clear();
-    batch.slot_of.clear();
-    /* Same shape as the device build: a launch covers the gaps still to do at a scratch tier; its results come back as parts of consecutive
-     * slots, each a chunk with dense word / metadata arrays in which the gaps reserved their room in no particular order (here: last slot
-     * first); the first launch maps gap i to chunk i / part, slot i % part, later ones through chunk_of / slot_of. */
-    const uint32_t psize = getenv("MTG_EMU_PART") ? (uint32_t)std::max(64, atoi(getenv("MTG_EMU_PART")) / 64 * 64) : 192u;
-    struct SlotData { GapOut o; PostOut po; uint32_t nw = 0, nc = 0; std::vector<uint64_t> words; std::vector<uint32_t> meta; std::vector<uint32_t> paths; bool general = false; };
+    const bool want_records = sink.res != nullptr;
+    uint64_t cur_seq = 0, cur_ext = 1;
     std::vector<uint32_t> todo;
-    size_t n_todo = n;
+    size_t n_todo = n, launches = 0;
+    const size_t env_chunk = getenv("MTG_MAX_CHUNK") ? (size_t)atol(getenv("MTG_MAX_CHUNK")) : 0;
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
-        const bool identity = todo.empty();
-        FillCfg cfg = make_cfg(idx->dev.k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
+        FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
         std::vector<uint32_t> retry;
-        const uint32_t m = (uint32_t)n_todo;
-        if (identity) batch.part = psize;
-        else if (batch.chunk_of.empty()) {
-            batch.chunk_of.assign(n, 0);
-            batch.slot_of.resize(n);
-            for (size_t i = 0; i < n; i++) { batch.chunk_of[i] = batch.part == ~(size_t)0 ? 0u : (uint32_t)(i / batch.part); batch.slot_of[i] = batch.part == ~(size_t)0 ? (uint32_t)i : (uint32_t)(i % batch.part); }
-        }
-        /* one scratch block for the launch, like a lane's on the device: the zero region is cleared once and must come back clean from
-         * every gap, the rest holds whatever the previous gap left (poisoned here) */
-        std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride + 64), ilv(cfg.ilv_stride), fp_table(FP_SLOTS * 64);
-        for (uint32_t s0 = 0; s0 < m; s0 += psize) {
-            const uint32_t s1 = std::min(m, s0 + psize), mq = s1 - s0;
-            std::vector<SlotData> sd(mq);
-            for (uint32_t s = 0; s < mq; s++) {
-                const size_t g = identity ? (size_t)(s0 + s) : (size_t)todo[s0 + s];
-                SlotData& d = sd[s];
-                memset(raw.data(), 0xCD, raw.size());
+        const size_t chunk = env_chunk ? std::min(env_chunk, n_todo) : n_todo;
+        for (size_t base = 0; base < n_todo; base += chunk) {
+            const uint32_t m = (uint32_t)std::min(chunk, n_todo - base);
+            const bool identity = todo.empty() && base == 0 && m == n;
+            std::vector<uint32_t> ids(m);
+            for (uint32_t s = 0; s < m; s++) ids[s] = todo.empty() ? (uint32_t)(base + s) : todo[base + s];
+            if (!identity) sink.in_gap_order = false;
+            launches++;
+            /* every slot keeps its own scratch until the launch has been emitted, like on the device; the zero region is shared by the
+             * slots here (one lane at a time) and must come back clean from every gap */
+            std::vector<uint8_t> zero(cfg.zero_stride, 0), ilv(cfg.ilv_stride), fp_table(FP_SLOTS * 64);
+            std::vector<std::vector<uint8_t>> raws(m);
+            std::vector<SlotRec> recs(m);
+            for (uint32_t s = 0; s < m; s++) {
+                const size_t g = ids[s];
+                raws[s].assign(cfg.raw_stride + 64, 0xCD);
                 memset(fp_table.data(), 0, fp_table.size());
-                GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
+                GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
                 S.fp = fp_table.data();
                 S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
                 SwfPattern R;
                 R.words = in.rwords.data() + in.roff[g];
                 R.rlen = in.rlen[g];
                 R.r0 = in.r0[g];
-                stage_a_gap(idx->dev, cfg, S, in.src[g], R, d.o);
-                /* the device never clears the zero region between launches: every exit path has to hand it back clean */
-                for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, d.o.status); return MTG_ERR_OVERFLOW; }
-                st.index_lines += d.o.lines;
-                if (d.o.status != GAP_OK) { st.n_retried_gaps++; retry.push_back((uint32_t)g); continue; }
-                PostTargets T;
-                T.le = tle.data() + in.toff[g];
-                T.bad = tbad.data() + in.toff[g];
-                T.n = in.tcnt[g];
-                T.nb_mis = in.nbmis[g];
-                T.fast_ok = in.fast_ok[g];
-                uint32_t hist[256] = {0};
-                std::vector<uint64_t> tile(POST_TILE + 2);
-                uint64_t blk[64];
-                post_gap(idx->dev, cfg, S, d.o, T, hist, tile.data(), blk, d.po);
-                copy_plan(d.o, d.po, in.want_all_contigs, d.nw, d.nc);
-                d.words.assign(s_words(cfg, S), s_words(cfg, S) + d.nw);
-                d.meta.resize(5 * (size_t)d.nc);
-                for (uint32_t i = 0; i < d.nc; i++) {
-                    d.meta[i] = s_clen(cfg, S)[i];
-                    d.meta[d.nc + i] = s_cstart(cfg, S)[i];
-                    d.meta[2 * d.nc + i] = s_tpos(cfg, S)[i];
-                    d.meta[3 * d.nc + i] = s_terr(cfg, S)[i];
-                    d.meta[4 * d.nc + i] = s_ttgt(cfg, S)[i];
+                SlotRec& r = recs[s];
+                memset(&r, 0, sizeof r);
+                stage_a_gap(idx->dev, cfg, S, in.src[g], R, r.o);
+                for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, r.o.status); return MTG_ERR_OVERFLOW; }
+                if (r.o.status == GAP_OK) {
+                    PostTargets T;
+                    T.le = tle.data() + in.toff[g];
+                    T.bad = tbad.data() + in.toff[g];
+                    T.n = in.tcnt[g];
+                    T.nb_mis = in.nbmis[g];
+                    T.fast_ok = in.fast_ok[g];
+                    uint32_t hist[256] = {0};
+                    std::vector<uint64_t> tile(POST_TILE + 2);
+                    uint64_t blk[64];
+                    post_gap(idx->dev, cfg, S, r.o, T, hist, tile.data(), blk, r.p);
+                } else st.n_retried_gaps++;
+                emit_plan(r.o, r.p, in.want_all_contigs, k, r.nw, r.nc, r.asc, r.ext);
+            }
+            /* stand-in for k_scan1 / k_scan2: exclusive prefix sums in slot order on top of the batch's cursors */
+            PartTot tot;
+            memset(&tot, 0, sizeof tot);
+            tot.begin[2] = cur_seq; tot.begin[3] = cur_ext;
+            uint64_t c0 = 0, c1 = 0, c2 = cur_seq, c3 = cur_ext;
+            std::vector<uint32_t> rlist, glist;
+            for (uint32_t s = 0; s < m; s++) {
+                SlotRec& r = recs[s];
+                r.wbase = c0; r.cbase = c1; r.abase = c2; r.ebase = c3;
+                c0 += r.nw; c1 += r.nc; c2 += r.asc; c3 += r.ext;
+                tot.lines += r.o.lines; tot.store_runs += r.o.store_reads; tot.run_nt += r.o.run_nt; tot.contig_words += r.o.n_words;
+                if (r.o.status != GAP_OK) { r.rpos = (uint32_t)rlist.size(); rlist.push_back(s); continue; }
+                tot.contig_nt += r.o.total_nt; tot.post_lines += r.p.lines; tot.cov_kmers += r.p.ab_n;
+                tot.n_filled += r.asc != 0; tot.n_ext += r.ext != 0;
+                if (r.nc) { r.gpos = (uint32_t)glist.size(); glist.push_back(s); }
+            }
+            tot.end[0] = c0; tot.end[1] = c1; tot.end[2] = c2; tot.end[3] = c3;
+            tot.n_retry = (uint32_t)rlist.size(); tot.n_general = (uint32_t)glist.size();
+            cur_seq = c2; cur_ext = c3;
+            /* arenas: grown like in the device build (the first emission is skipped here: nothing would be written anyway) */
+            if (tot.end[2] > sink.seq_cap) {
+                const uintptr_t old = (uintptr_t)sink.seq, old_end = old + sink.seq_cap;
+                if (!sink.grow_seq || !sink.grow_seq((size_t)tot.end[2], (size_t)tot.begin[2])) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)tot.end[2]); return MTG_ERR_ARG; }
+                if (want_records && tot.begin[2] > 0 && (uintptr_t)sink.seq != old)
+                    for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.fil[i].seq; if (q >= old && q < old_end) sink.fil[i].seq = sink.seq + (q - old); }
+            }
+            if (tot.end[3] > sink.ext_cap) {
+                const uintptr_t old = (uintptr_t)sink.ext, old_end = old + sink.ext_cap;
+                if (!sink.grow_ext || !sink.grow_ext((size_t)tot.end[3], (size_t)tot.begin[3])) { set_error("extension buffer too small: %llu bytes needed", (unsigned long long)tot.end[3]); return MTG_ERR_NOMEM; }
+                if (want_records && launches > 1 && (uintptr_t)sink.ext != old)
+                    for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.res[i].extension; if (q >= old && q < old_end) sink.res[i].extension = sink.ext + (q - old); }
+            }
+            /* stand-in for k_emit */
+            HostChunk* hc = nullptr;
+            SlotRec* h_rec = nullptr;
+            uint64_t* h_w = nullptr;
+            uint32_t* h_m = nullptr;
+            std::vector<uint64_t> dw(c0 + 1);
+            std::vector<uint32_t> dm(5 * c1 + 1);
+            std::vector<mtg_gap_result> dres(m);
+            std::vector<mtg_filled> dfil(m);
+            std::vector<char> none(64);
+            EmitDev D;
+            D.seq = sink.seq ? sink.seq : none.data(); D.ext = sink.ext ? sink.ext : none.data();
+            D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
+            D.res = dres.data(); D.fil = dfil.data();
+            D.dense_words = dw.data(); D.dense_meta = dm.data();
+            EmitHost H;
+            H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
+            for (uint32_t s = 0; s < m; s++) {
+                GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
+                emit_gap(cfg, S, recs[s], in.flags[ids[s]], s, ids[s], k, D, H);
+            }
+            if (want_records)
+                for (uint32_t s = 0; s < m; s++) { sink.res[ids[s]] = dres[s]; if (recs[s].asc) sink.fil[ids[s]] = dfil[s]; }
+            st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
+            st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += c0;
+            sink.seq_used = tot.end[2];
+            sink.ext_used = tot.end[3];
+            sink.n_filled += tot.n_filled;
+            for (uint32_t s2 : rlist) retry.push_back(ids[s2]);
+            if (tot.n_retry) sink.in_gap_order = false;
+            if (tot.n_general) {
+                special.chunks.emplace_back(new HostChunk());
+                hc = special.chunks.back().get();
+                hc->carve(m, c0, c1, h_rec, h_w, h_m);
+                memcpy(h_rec, recs.data(), (size_t)m * sizeof(SlotRec));
+                memcpy(h_w, dw.data(), c0 * 8);
+                h_w[c0] = 0;
+                memcpy(h_m, dm.data(), c1 * 20);
+                if (!identity) hc->gap_of = ids;
+                const uint32_t chunk_id = (uint32_t)special.chunks.size() - 1;
+                std::vector<uint32_t> pslots;
+                for (uint32_t s2 : glist) {
+                    special.special.push_back(SpecialGap{ids[s2], chunk_id, s2});
+                    if (!getenv("MTG_HOST_PATHS") && !in.want_all_contigs && recs[s2].p.fast == 0 && recs[s2].p.nb_terminal > 0) pslots.push_back(s2);
                 }
-                if (!getenv("MTG_HOST_PATHS") && d.po.fast == 0 && d.po.nb_terminal > 0) { /* stand-in for k_paths */
-                    PathsWork pw;
-                    d.paths.assign(PATHS_WORDS, 0);
-                    paths_gap(cfg, S, d.o, idx->dev.k, pw, d.paths.data());
-                    d.general = true;
+                if (!pslots.empty()) { /* stand-in for k_paths */
+                    hc->paths.assign(pslots.size() * (size_t)PATHS_WORDS, 0);
+                    hc->path_of.assign(m, -1);
+                    for (size_t g2 = 0; g2 < pslots.size(); g2++) {
+                        PathsWork pw;
+                        GapScratch S = carve(cfg, zero.data(), raws[pslots[g2]].data(), ilv.data(), 0);
+                        paths_gap(cfg, S, recs[pslots[g2]].o, k, pw, hc->paths.data() + g2 * (size_t)PATHS_WORDS);
+                        hc->path_of[pslots[g2]] = (int32_t)g2;
+                    }
                 }
-                st.contig_nt += d.o.total_nt;
-                st.store_runs += d.o.store_reads; st.run_nt += d.o.run_nt; st.post_lines += d.po.lines; st.contig_words += d.o.n_words; st.coverage_kmers += d.po.ab_n;
             }
-            uint64_t tw = 0, tc = 0;
-            for (const SlotData& d : sd) { tw += d.nw; tc += d.nc; }
-            batch.chunks.emplace_back(new HostChunk());
-            HostChunk& hc = *batch.chunks.back();
-            const uint32_t chunk_id = (uint32_t)batch.chunks.size() - 1;
-            SlotRec* rec = nullptr;
-            uint64_t* hw = nullptr;
-            uint32_t* hm = nullptr;
-            hc.carve(nullptr, mq, tw, tc, rec, hw, hm);
-            uint64_t wb = 0, cb = 0;
-            for (uint32_t s = mq; s-- > 0;) { /* room in the dense arrays in reverse slot order */
-                const SlotData& d = sd[s];
-                SlotRec& r = rec[s];
-                r.o = d.o; r.p = d.po; r.nw = d.nw; r.nc = d.nc; r.wbase = (decltype(r.wbase))wb; r.cbase = (decltype(r.cbase))cb;
-                if (d.o.status != GAP_OK) { r.nw = r.nc = 0; continue; }
-                for (uint32_t i = 0; i < d.nw; i++) hw[wb + i] = d.words[i];
-                for (size_t i = 0; i < d.meta.size(); i++) hm[5 * cb + i] = d.meta[i];
-                wb += d.nw;
-                cb += d.nc;
-            }
-            hw[tw] = 0;
-            uint32_t ngen = 0;
-            for (const SlotData& d : sd) ngen += d.general;
-            if (ngen) {
-                hc.paths.resize((size_t)ngen * PATHS_WORDS);
-                hc.path_of.assign(mq, -1);
-                uint32_t r2 = 0;
-                for (uint32_t s = 0; s < mq; s++)
-                    if (sd[s].general) { std::copy(sd[s].paths.begin(), sd[s].paths.end(), hc.paths.begin() + (size_t)r2 * PATHS_WORDS); hc.path_of[s] = (int32_t)r2++; }
-            }
-            if (!identity)
-                for (uint32_t s = 0; s < mq; s++)
-                    if (sd[s].o.status == GAP_OK) { batch.chunk_of[todo[s0 + s]] = chunk_id; batch.slot_of[todo[s0 + s]] = s; }
-            if (on_ready) (*on_ready)(chunk_id, identity ? nullptr : todo.data() + s0, identity ? (size_t)s0 : 0, mq);
+            st.n_launches++;
         }
         todo.swap(retry);
         n_todo = todo.size();
     }
     if (n_todo) { set_error("%zu gap(s) exceeded the largest traversal scratch tier", n_todo); return MTG_ERR_OVERFLOW; }
+    if (launches > 1) sink.in_gap_order = false;
     if (stats) *stats = st;
     return MTG_OK;
 }

@@ -1,5 +1,5 @@
 /* TEST-ONLY: unit checks of the vectorised host helpers of mtg_host.cpp (file-local there, so the source is included here) against
- * plain per-character code: decode_slice (pdep + vpshufb) for every alignment, length and direction, and FillInput::set_common
+ * plain per-character code: the device's ASCII writer emit_ascii (one lane) for every alignment, length and direction, and FillInput::set_common
  * (pext packing, k-mer by bit reversal, validity tests) against encode_kmer / per-character loops.  Links with emu_backend.cpp.  Prints OK. */
 #include "../../mindthegap_amd/csrc/mtg_host.cpp"
 #include <random>
@@ -8,24 +8,28 @@ int main()
 {
     std::mt19937_64 rng(11);
     static const char NT[4] = {'A', 'C', 'T', 'G'}, NTC[4] = {'T', 'G', 'A', 'C'};
-    /* decode_slice */
+    /* emit_ascii (the device's 2-bit -> ASCII writer, mtg_emit.h; one lane here): every source offset, length, direction and
+     * destination alignment; nothing but [dst, dst + L] may be written */
     std::vector<uint64_t> words(40);
-    for (int round = 0; round < 200; round++) {
+    for (int round = 0; round < 120; round++) {
         for (auto& w : words) w = rng();
         for (uint32_t from = 0; from < 70; from += (round & 1) + 1)
-            for (uint32_t L : {0u, 1u, 3u, 4u, 31u, 32u, 33u, 63u, 64u, 65u, 100u, 517u, 1000u, (uint32_t)(rng() % 1100)}) {
+            for (uint32_t L : {0u, 1u, 3u, 4u, 15u, 16u, 17u, 31u, 32u, 33u, 63u, 64u, 65u, 100u, 517u, 1000u, (uint32_t)(rng() % 1100)}) {
                 if (from + L > 38 * 32) continue;
                 for (int rc = 0; rc < 2; rc++) {
-                    std::string got(L + 8, '#'), want(L, '?');
-                    mtgi::decode_slice(words.data(), from, L, rc != 0, &got[4]);
+                    const uint32_t al = (uint32_t)(rng() % 16);
+                    std::vector<char> buf(L + 64, '#');
+                    char* dst = buf.data() + 16 + al - ((uintptr_t)buf.data() & 15); /* alignment al modulo 16 */
+                    std::string want(L, '?');
+                    mtg::emit_ascii(words.data(), from, L, rc != 0, dst);
                     for (uint32_t i = 0; i < L; i++) {
                         const uint32_t j = from + i, c = (uint32_t)(words[j >> 5] >> (2 * (j & 31))) & 3;
                         if (!rc) want[i] = NT[c]; else want[L - 1 - i] = NTC[c];
                     }
-                    if (got.substr(4, L) != want || got.substr(0, 4) != "####" || got.substr(4 + L) != "####") {
-                        fprintf(stderr, "decode_slice from %u L %u rc %d differs\n", from, L, rc);
-                        return 1;
-                    }
+                    bool ok = std::string(dst, L) == want && dst[L] == 0;
+                    for (char* q = buf.data(); q < dst; q++) ok = ok && *q == '#';
+                    for (char* q = dst + L + 1; q < buf.data() + buf.size(); q++) ok = ok && *q == '#';
+                    if (!ok) { fprintf(stderr, "emit_ascii from %u L %u rc %d align %u differs\n", from, L, rc, al); return 1; }
                 }
             }
     }
@@ -44,7 +48,7 @@ int main()
             in.layout();
             /* poison the pattern words: the block is recycled in the product */
             for (size_t w = 0; w < in.rwords.size(); w++) in.rwords[w] = ~0ull;
-            in.set_common(0, source, pattern, 2);
+            in.set_common(0, source, pattern, 2, 0);
             const uint64_t want_src = mtg::encode_kmer(source.data(), k);
             bool acgt = true;
             for (char c : pattern) acgt = acgt && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
