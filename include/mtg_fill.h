@@ -177,7 +177,7 @@ void mtg_contigs_free(mtg_contigs* c);
 /* timings / counters of the last fill or stage-A batch on this thread */
 typedef struct mtg_batch_stats {
     double kernel_ms;            /* HIP-event time of the traversal kernel (k_stage_a) launches (sum over tiers / attempts) */
-    double post_kernel_ms;       /* HIP-event time of the terminal-search / coverage kernel (k_post) */
+    double post_kernel_ms;       /* HIP-event time of the terminal-search / coverage kernel (k_post) and of the two layout scans behind it */
     double total_ms;             /* wall time of the whole call */
     double h2d_ms, d2h_ms, host_ms;
     double marshal_ms, result_ms; /* mtg_fill_batch only: argument marshalling and result-arena construction */
@@ -190,7 +190,9 @@ typedef struct mtg_batch_stats {
     uint64_t post_lines;         /* index buckets read by the coverage pass of k_post */
     uint64_t contig_words;       /* 8-byte words of contig arena the traversal wrote */
     uint64_t coverage_kmers;     /* k-mers whose abundance the coverage pass of k_post needed */
-    uint64_t dense_words;        /* 8-byte words k_post copied into the dense result arrays */
+    uint64_t dense_words;        /* 8-byte words of contigs copied back for the multi-contig gaps */
+    double emit_kernel_ms;       /* HIP-event time of the result kernel (k_emit: ASCII sequences + records); post_kernel_ms = k_post + the layout scans */
+    uint64_t seq_bytes;          /* bytes of ASCII the result kernel wrote into the sequence arena */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);
 

@@ -1137,7 +1137,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     tick("upload (async)");
 
     EventSet events;
-    hipEvent_t ev0, ev1, ev2, ev3;
+    hipEvent_t ev0, ev1, ev2, ev3, eve;
+    HIP_TRY(events.make(eve));
     HIP_TRY(events.make(ev0));
     HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
@@ -1240,6 +1241,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             };
             /* the results are written right away, on the assumption that the arenas are large enough (they are, from the second batch of a
              * shape on): the totals tell */
+            HIP_TRY(hipEventRecord(eve, stream));
             if (int erc = emit()) return erc;
             HIP_TRY(hipEventRecord(ev2, stream));
             tick("host prep+launch");
@@ -1252,18 +1254,18 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* an array that was too small: make it larger and write the launch's results again (its scratch is still in place) */
             const uint64_t need_w = tot.end[0] * 8 + 64, need_m = tot.end[1] * 20 + 64;
             bool again = false;
-            if (tot.end[2] > sink.seq_cap) {
+            if (want_records && tot.end[2] > sink.seq_cap) {
                 /* the block may move: what earlier launches of the batch left in it is kept, the records that point there follow */
                 const uintptr_t old = (uintptr_t)sink.seq, old_end = old + sink.seq_cap;
                 if (!sink.grow_seq || !sink.grow_seq((size_t)tot.end[2], (size_t)tot.begin[2])) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)tot.end[2]); return MTG_ERR_ARG; }
-                if (want_records && tot.begin[2] > 0 && (uintptr_t)sink.seq != old)
+                if (tot.begin[2] > 0 && (uintptr_t)sink.seq != old)
                     for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.fil[i].seq; if (q >= old && q < old_end) sink.fil[i].seq = sink.seq + (q - old); }
                 again = true;
             }
-            if (tot.end[3] > sink.ext_cap) {
+            if (want_records && tot.end[3] > sink.ext_cap) {
                 const uintptr_t old = (uintptr_t)sink.ext, old_end = old + sink.ext_cap;
                 if (!sink.grow_ext || !sink.grow_ext((size_t)tot.end[3], (size_t)tot.begin[3])) { set_error("extension buffer too small: %llu bytes needed", (unsigned long long)tot.end[3]); return MTG_ERR_NOMEM; }
-                if (want_records && launches > 1 && (uintptr_t)sink.ext != old)
+                if (launches > 1 && (uintptr_t)sink.ext != old)
                     for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.res[i].extension; if (q >= old && q < old_end) sink.res[i].extension = sink.ext + (q - old); }
                 again = true;
             }
@@ -1351,11 +1353,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
             }
             st.host_ms += now_ms() - t0;
-            float ms = 0, ms2 = 0;
+            float ms = 0, ms2 = 0, ms3 = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-            HIP_TRY(hipEventElapsedTime(&ms2, ev1, ev2));
+            HIP_TRY(hipEventElapsedTime(&ms2, ev1, eve));
+            HIP_TRY(hipEventElapsedTime(&ms3, eve, ev2));
             st.kernel_ms += ms;
             st.post_kernel_ms += ms2;
+            st.emit_kernel_ms += ms3;
+            st.seq_bytes += tot.end[2] - tot.begin[2];
             st.n_launches++;
         }
         if (tier > 0) st.n_retried_gaps += n_todo;

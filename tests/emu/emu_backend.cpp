@@ -296,13 +296,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             tot.n_retry = (uint32_t)rlist.size(); tot.n_general = (uint32_t)glist.size();
             cur_seq = c2; cur_ext = c3;
             /* arenas: grown like in the device build (the first emission is skipped here: nothing would be written anyway) */
-            if (tot.end[2] > sink.seq_cap) {
+            if (want_records && tot.end[2] > sink.seq_cap) {
                 const uintptr_t old = (uintptr_t)sink.seq, old_end = old + sink.seq_cap;
                 if (!sink.grow_seq || !sink.grow_seq((size_t)tot.end[2], (size_t)tot.begin[2])) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)tot.end[2]); return MTG_ERR_ARG; }
                 if (want_records && tot.begin[2] > 0 && (uintptr_t)sink.seq != old)
                     for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.fil[i].seq; if (q >= old && q < old_end) sink.fil[i].seq = sink.seq + (q - old); }
             }
-            if (tot.end[3] > sink.ext_cap) {
+            if (want_records && tot.end[3] > sink.ext_cap) {
                 const uintptr_t old = (uintptr_t)sink.ext, old_end = old + sink.ext_cap;
                 if (!sink.grow_ext || !sink.grow_ext((size_t)tot.end[3], (size_t)tot.begin[3])) { set_error("extension buffer too small: %llu bytes needed", (unsigned long long)tot.end[3]); return MTG_ERR_NOMEM; }
                 if (want_records && launches > 1 && (uintptr_t)sink.ext != old)
@@ -365,6 +365,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
             }
             st.n_launches++;
+            st.seq_bytes += tot.end[2] - tot.begin[2];
         }
         todo.swap(retry);
         n_todo = todo.size();
