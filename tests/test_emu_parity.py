@@ -664,3 +664,50 @@ def test_snp_fast_path_adversarial(k):
                 ec, st, _, _ = emu.stage_a(s, t, 100, 10000, er)
                 assert st == 0 and ec == oc, (case, kind, k, s, er, seqs)
         idx.close()
+
+
+def test_index_container_written_from_the_tables(emu_product, tmp_path):
+    """mtg_index_save reads the solid k-mers back from the ABND table (lossless bucket + tag, inverted hash): the file holds exactly the
+    k-mers and abundances the index was built from (version 2 container, any order), loads again, and a version 1 file still loads"""
+    rng = random.Random(8)
+    for k in (31, 21, 12):
+        seqs = [_rand_seq(rng, rng.randrange(k, 900)) for _ in range(6)]
+        o = oracle_lib.Index.from_sequences(seqs + [seqs[0][:200]] * 300, k, 1, 40)  # multiplicities: abundances up to the 8-bit ceiling
+        km, ct = o.export()
+        g = emu_product.Index.from_kmers(km, ct, k)
+        p = str(tmp_path / ("i%d.mtgidx" % k))
+        g.save(p)
+        raw = open(p, "rb").read()
+        assert raw[:8] == b"MTGIDX2\0"
+        n = struct.unpack("<Q", raw[24:32])[0]
+        assert n == len(km)
+        rec = np.frombuffer(raw[32:], dtype=np.dtype([("k", "<u8"), ("a", "<u4")]))
+        order = np.argsort(rec["k"])
+        assert (rec["k"][order] == np.sort(km)).all()
+        assert (rec["a"][order] == np.minimum(ct[np.argsort(km)], 255)).all()
+        h = emu_product.Index.load(p)
+        q = np.concatenate([km, np.array([rng.getrandbits(2 * k) for _ in range(300)], dtype=np.uint64)])
+        assert (h.abundance(q) == g.abundance(q)).all()
+        _write_idx(str(tmp_path / "v1.mtgidx"), km, ct, k=k)
+        v1 = emu_product.Index.load(str(tmp_path / "v1.mtgidx"))
+        assert (v1.abundance(q) == g.abundance(q)).all()
+        for x in (g, h, v1):
+            x.close()
+        o.close()
+
+
+def test_stage_a_entry_of_the_product(emu_product):
+    """mtg_stage_a_batch (contigs only, no records) through the product's host code on the emulated device"""
+    rng = random.Random(4)
+    g = _rand_seq(rng, 3000)
+    seqs = [g, g[:1500] + ("A" if g[1500] != "A" else "C") + g[1501:], g[700:760] + "T"]
+    o = oracle_lib.Index.from_sequences(seqs, 31, 1, 40)
+    km, ct = o.export()
+    idx = emu_product.Index.from_kmers(km, ct, 31)
+    src = [g[0:31], g[100:131], _rc(g[2000:2031]), g[650:681]]
+    tgt = [g[500:531], g[900:931], _rc(g[1000:1031]), g[1200:1231]]
+    got = idx.stage_a(src, tgt)
+    for s, t, c in zip(src, tgt, got):
+        assert c == o.stage_a(s, t)[0], (s, t)
+    idx.close()
+    o.close()

@@ -1,0 +1,79 @@
+"""BASELINE config 4 at FULL size in the -m gpu suite: the synthetic human-scale set (3 Gbp donor as 600 000 x 5 kb sequences, index built on
+the device, 100 000 insertion sites, k = 31, -max-nodes 100), through the C ABI.  Size-independent property: every site is filled with
+exactly its inserted sequence; and the first 30 000 sites equal the CPU oracle's records (sequence, coverage, quality) one by one --
+compared with what the HIP path returned, never with the truth.  Reference counterpart: /root/reference/test/simple_full_test.sh:128-163."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mtg():
+    import torch
+    torch.cuda.init()
+    import mindthegap_amd
+    mindthegap_amd.load_library()
+    assert mindthegap_amd.device_count() >= 1
+    return mindthegap_amd
+
+
+def test_config4_full_size(mtg, tmp_path):
+    import torch
+    from mindthegap_amd.synth import SynthSet
+    from tests import oracle_lib
+    NSEQ, NSITES, NORACLE, K = 600000, 100000, 30000, 31
+    S = SynthSet(nseq=NSEQ, n_sites=NSITES, seed=1, k=K)
+    dev = torch.device("cuda", 0)
+    w = torch.from_numpy(S.words.view(np.int64)).to(dev)
+    wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev)
+    ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
+    idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, K, 3, 40)
+    del w, wo, ln
+    torch.cuda.empty_cache()
+    info = idx.info()
+    assert info["nb_solid_kmers"] > 2.9e9 and info["nb_unitigs"] >= NSEQ
+    gaps, truth = [], []
+    for i in range(NSITES):
+        l, r, ins = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+        truth.append(ins)
+    params = mtg.FillParams(max_nodes=100, max_depth=10000)
+    # through both entries: host strings, and a prepared (device-resident) batch
+    prepared = mtg.Index.prepare_gaps(gaps)
+    h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=True)
+    idx.free_results(h)
+    assert (nf == 1).all()
+    got = seqs.tobytes().decode().split("\n")[:-1]
+    assert got == truth  # every one of the 100 000 fills is exactly the inserted sequence
+    batch = idx.prepare_batch(prepared, params)
+    out = np.empty(len(seqs) + 1024, dtype=np.uint8)
+    h, nf2, nb = idx.fill_prepared_serial(batch, out, params)
+    idx.free_results(h)
+    assert nb == len(seqs) and out[:nb].tobytes() == seqs.tobytes().replace(b"\n", b"\0")
+    batch.close()
+    # record by record against the oracle on the first 30 000 sites (oracle index = the first 30 000 donor sequences)
+    res = idx.fill_batch(gaps[:NORACLE], params)
+    idx.close()
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(NORACLE)], K, 3, 40)
+    bk = str(tmp_path / "s.breakpoints")
+    S.write_breakpoints(bk, range(NORACLE))
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"), params=oracle_lib.default_params(nb_cores=max(1, min(16, os.cpu_count() or 1))))
+    o.close()
+    cpu = {}
+    name = None
+    for line in open(str(tmp_path / "cpu.insertions.fasta")):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            name = line[1:]
+        else:
+            cpu[name.split("_len_")[0]] = (name, line)
+    assert len(cpu) == NORACLE
+    for i in range(NORACLE):
+        r = res[i]
+        assert len(r["filled"]) == 1, i
+        f = r["filled"][0]
+        hdr = "%s_len_%d_qual_%d_avg_cov_%.2f_median_cov_%.2f   " % (S.site_name(i), len(f["seq"]), f["qual"], f["avg_coverage"], f["median_coverage"])
+        assert (hdr, f["seq"]) == cpu[S.site_name(i)], i  # the header carries length, quality, mean and median coverage (src/Filler.cpp:1052-1054)

@@ -548,3 +548,39 @@ def test_snp_fast_path_adversarial_on_device(mtg, k):
                 assert c == o.stage_a(s, a[-k:], oracle_lib.default_params(end_rule_nonbranching=er))[0], (case, kind, k, s, er, seqs)
         idx.close()
         o.close()
+
+
+@pytest.mark.parametrize("variant,err", [("E0", 0.0), ("E1", 0.001)])
+def test_config2_full_size(mtg, tmp_path, variant, err):
+    """BASELINE config 2 at FULL size: 5 Mbp donor as 1000 x 5 kb sequences, 1000 insertion sites, 30x 150-bp simulated reads
+    (1.06 M reads; E0 error-free, E1 0.1 % substitutions), index built from the reads by `-in` with -abundance-min 3 (k-mer counting on
+    the device), `MindTheGap fill` outputs byte-identical to the CPU oracle: FASTA with headers, info, VCF body.
+    Mirrors /root/reference/test/simple_full_test.sh:128-163 (index from reads, fill, compare with the expected files)."""
+    from mindthegap_amd.synth import SynthSet, simulate_reads
+    from tests import oracle_lib
+    S = SynthSet(nseq=1000, n_sites=1000, seed=1)
+    bk = str(tmp_path / "s.breakpoints")
+    S.write_breakpoints(bk)
+    reads = str(tmp_path / (variant + ".fa"))
+    n = simulate_reads(S, reads, 30, 150, err, seed=5)
+    assert n > 1000000
+    assert mtg.fill_main(["-in", reads, "-bkpt", bk, "-abundance-min", "3", "-out", str(tmp_path / "hip")]) == 0
+    o = oracle_lib.Index.from_files([reads], 31, 3)
+    st = o.fill_files("bkpt", bk, str(tmp_path / "cpu"), params=oracle_lib.default_params(nb_cores=1))
+    assert st["records"] == 1000
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), (variant, ext)
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf")), variant
+    seqs = [l for l in _read(str(tmp_path / "hip.insertions.fasta")).splitlines() if not l.startswith(">")]
+    if err == 0.0:  # error-free reads: the graph is the donor's, every fill is exactly the inserted sequence
+        assert seqs == [S.site(i)[2] for i in range(S.n_sites)]
+    else:
+        assert len(seqs) >= 990
+    # the index the CLI left behind (written from the device tables) loads again and holds the oracle's solid k-mers
+    g = mtg.Index.load(str(tmp_path / "hip.mtgidx"))
+    assert g.info()["nb_solid_kmers"] == len(o)
+    km, ct = o.export()
+    sel = np.random.default_rng(1).choice(len(km), 20000, replace=False)
+    assert (g.abundance(km[sel]) == np.minimum(ct[sel], 255)).all()
+    g.close()
+    o.close()
