@@ -1222,7 +1222,9 @@ MTG_UNROLL
         /* ---- phase B: branching node ---- */
         if (!end_contig) {
             int chosen = -1;
+            MTG_T0(t_snp);
             int n = snp_bubble_fast(W, cur, prev_c, a, chosen);
+            MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
             if (!fast) n = explore_branching(W, cur, prev_c, chosen);
             if (n <= 0) {
