@@ -494,7 +494,7 @@ MTG_DEV Adj adj_right(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& li
 }
 /* right neighbourhoods of two unrelated nodes with both home buckets in flight together; a key that is not in its home bucket of a full
  * bucket is looked up again the ordinary way (rare) */
-MTG_DEV void adj_right2(const Index& ix, const Kmer& xa, const Kmer& xb, uint64_t mk1, uint32_t& lines, Adj& ra, Adj& rb)
+MTG_DEV void adj_right2_raw(const Index& ix, const Kmer& xa, const Kmer& xb, uint64_t mk1, uint32_t& lines, Adj& ra, Adj& rb)
 {
     const Table& t = ix.adj;
     const Kmer* xs[2] = {&xa, &xb};
@@ -530,10 +530,17 @@ MTG_UNROLL
         else { rs[u]->out = comp_mask(m >> 4); rs[u]->in = comp_mask(m & 15u); rs[u]->la = (uint32_t)(aux >> 32); }
         if (up_is(aux)) { rs[u]->la = 0; rs[u]->up = up_resolve(aux, fw[u]); }
     }
-    /* pointer entries: both lookaheads through the store, the reads of the two in flight together as far as the compiler allows */
-MTG_UNROLL
-    for (int u = 0; u < 2; u++)
-        if (rs[u]->up && popc4(rs[u]->out) == 1 && popc4(rs[u]->in) == 1) rs[u]->la = la_from_up(ix.us, rs[u]->up, ix.k, lines);
+}
+/* the lookahead of a pointer entry, read through the store (for callers that got the entry from adj_right2_raw) */
+MTG_DEV void adj_resolve_la(const Index& ix, Adj& r, uint32_t& lines)
+{
+    if (r.up && popc4(r.out) == 1 && popc4(r.in) == 1) r.la = la_from_up(ix.us, r.up, ix.k, lines);
+}
+MTG_DEV void adj_right2(const Index& ix, const Kmer& xa, const Kmer& xb, uint64_t mk1, uint32_t& lines, Adj& ra, Adj& rb)
+{
+    adj_right2_raw(ix, xa, xb, mk1, lines, ra, rb);
+    adj_resolve_la(ix, ra, lines);
+    adj_resolve_la(ix, rb, lines);
 }
 /* left neighbourhood of x: .in = predecessors of x, .out = successors of every predecessor. */
 MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)

@@ -703,6 +703,79 @@ MTG_UNROLL
 }
 #endif
 enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches of up to 2k - 1 nodes; the nucleotides of a branch fit two registers */
+
+/* The same pattern read off the unitig store: between the node and e each branch of a SNP bubble is exactly one stored unitig (its first
+ * node follows the node's two-way junction, its last node precedes e's), so everything the step-by-step loop of snp_bubble_fast learns
+ * from one read per node -- the nucleotides, that the nodes are simple, their abundances -- comes with one round of reads: the two
+ * headers, then the two sequences and abundance runs together, then the two end junctions.  Strictly the pattern "both branches are
+ * single stored unitigs of equal length <= SNP_MAX_L whose last nodes lead to the same node"; anything else returns false and the
+ * step-by-step loop decides as before.  Nodes inside a stored unitig have one in- and one out-edge, are never marked (only branching
+ * nodes are, ever), are pairwise distinct and no palindromic junction or self-complementary k-mer lies inside a unitig (mtg_dev.h:
+ * us_eligible); the remaining tests of the loop (a branch node equal to the previous node, a node followed by its reverse complement at
+ * the ends) are made here on the k-mers.  x[] = the first nodes of the branches, r[] = their right neighbourhoods. */
+MTG_DEV_NOINLINE bool snp_bulk(Worker& W, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], int& L, int& h, SnpSeq seq[2], unsigned long sum[2], Kmer& e)
+{
+    const UStore& us = W.ix.us;
+    const int k = W.k;
+MTG_UNROLL
+    for (int br = 0; br < 2; br++)
+        if (!(r[br].up && popc4(r[br].out) == 1 && popc4(r[br].in) == 1)) return false;
+    uint64_t pos[2];
+    uint32_t left[2];
+    us_run(us, r[0].up, k, pos[0], left[0]);
+    us_run(us, r[1].up, k, pos[1], left[1]);
+    W.lines += 2;
+    if (left[0] != left[1] || left[0] + 1u > (uint32_t)SNP_MAX_L) return false;
+    const uint32_t m = left[0]; /* nodes of a branch behind its first one */
+    uint64_t lo[2], hi[2];
+    uint32_t s[2] = {0, 0};
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        const bool bwd = up_bwd(r[br].up);
+        lo[br] = us_peek64(us.words, pos[br], m < 32u ? m : 32u, bwd);
+        hi[br] = m > 32u ? us_peek64(us.words, bwd ? pos[br] - 32 : pos[br] + 32, m - 32u, bwd) : 0ull;
+        /* abundances of the m + 1 nodes: the k-mers at unitig index off - 1 .. off - 1 + m (forward) or off - m .. off (backward) */
+        const uint64_t base = (up_hdr(r[br].up) + 1) * 32;
+        const uint32_t off = up_off(r[br].up), first = bwd ? off - m : off - 1u;
+        for (uint32_t i = 0; i <= m; i++) s[br] += us.ab[base + first + i];
+    }
+    Kmer z[2] = {x[0], x[1]};
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        if (z[br].f == z[br].r || canon(z[br]) == prev_c) return false;
+        for (uint32_t i = 0; i < m; i++) {
+            const uint32_t nt = (uint32_t)((i < 32u ? lo[br] >> (2u * i) : hi[br] >> (2u * (i - 32u))) & 3ull);
+            const Kmer y = kmer_next(z[br], nt, k, W.mk);
+            if (y.f == z[br].r) return false;
+            z[br] = y;
+            if (y.f == y.r || canon(y) == prev_c) return false;
+        }
+    }
+    Adj re[2];
+    adj_right2_raw(W.ix, z[0], z[1], W.mk1, W.lines, re[0], re[1]);
+    if (popc4(re[0].out) != 1 || popc4(re[1].out) != 1) return false;
+    const uint32_t ne[2] = {(uint32_t)ctz4(re[0].out), (uint32_t)ctz4(re[1].out)};
+    const Kmer y0 = kmer_next(z[0], ne[0], k, W.mk), y1 = kmer_next(z[1], ne[1], k, W.mk);
+    if (y0.f == z[0].r || y1.f == z[1].r) return false;
+    if (y0.f != y1.f) return false; /* longer branches (several unitigs): the loop follows them */
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        seq[br].lo = (uint64_t)nt0[br] | (lo[br] << 2);
+        seq[br].hi = (lo[br] >> 62) | (hi[br] << 2);
+        seq[br].set((int)m + 1, ne[br]);
+        sum[br] = s[br];
+    }
+    const uint64_t dl = lo[0] ^ lo[1], dh = hi[0] ^ hi[1];
+#ifdef MTG_EMU
+    h = 1 + __builtin_popcountll((dl | (dl >> 1)) & 0x5555555555555555ULL) + __builtin_popcountll((dh | (dh >> 1)) & 0x5555555555555555ULL) + (ne[0] != ne[1] ? 1 : 0);
+#else
+    h = 1 + __popcll((dl | (dl >> 1)) & 0x5555555555555555ULL) + __popcll((dh | (dh >> 1)) & 0x5555555555555555ULL) + (ne[0] != ne[1] ? 1 : 0);
+#endif
+    L = (int)m + 1;
+    e = y0;
+    return true;
+}
+
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen)
 {
@@ -745,12 +818,40 @@ MTG_UNROLL
         ncand++;
         return true;
     };
-    for (int step = 1; step <= SNP_MAX_L; step++) {
+    /* the bulk form first (both branches read off the unitig store); the device takes its answer, the TEST-ONLY emulation runs the loop
+     * as well and compares (status 0xBAD2: different answers, 0xBAD3: the loop rejected what the bulk form accepted) */
+    Adj r1[2];
+    bool have_r1 = false, bulk_ok = false;
+    int bL = 0, bh = 0;
+    SnpSeq bseq[2];
+    unsigned long bsum[2] = {0, 0};
+    Kmer be;
+    be.f = be.r = 0;
+    bseq[0].lo = bseq[0].hi = bseq[1].lo = bseq[1].hi = 0;
+    if (W.ix.us.nwords) {
+        adj_right2_raw(W.ix, x[0], x[1], W.mk1, W.lines, r1[0], r1[1]);
+        have_r1 = true;
+        bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be);
+#ifdef MTG_TRACE_BULK
+        fprintf(stderr, "SNP bulk %d L=%d\n", (int)bulk_ok, bL);
+#endif
+    }
+#ifdef MTG_EMU
+    const bool run_loop = true;
+#define MTG_SNP_FAIL(code) do { if (bulk_ok && (code) != 1) W.status = 0xBAD3; return 0; } while (0)
+#else
+    const bool run_loop = !bulk_ok;
+#define MTG_SNP_FAIL(code) return 0
+#endif
+    if (!run_loop) { L = bL; h = bh; seq[0] = bseq[0]; seq[1] = bseq[1]; sum[0] = bsum[0]; sum[1] = bsum[1]; x[0] = be; }
+    else if (have_r1) { adj_resolve_la(W.ix, r1[0], W.lines); adj_resolve_la(W.ix, r1[1], W.lines); }
+    for (int step = 1; run_loop && step <= SNP_MAX_L; step++) {
         /* the nodes at position `step` of both branches: unmarked, new; their single out-edges (both bucket reads in flight together) */
         uint32_t nt[2];
         Adj r[2];
         const bool need0 = !(aux[0] & 15u), need1 = !(aux[1] & 15u);
-        if (need0 && need1) adj_right2(W.ix, x[0], x[1], W.mk1, W.lines, r[0], r[1]);
+        if (step == 1 && have_r1) { r[0] = r1[0]; r[1] = r1[1]; }
+        else if (need0 && need1) adj_right2(W.ix, x[0], x[1], W.mk1, W.lines, r[0], r[1]);
         else if (need0) r[0] = adj_right(W.ix, x[0], W.mk1, W.lines);
         else if (need1) r[1] = adj_right(W.ix, x[1], W.mk1, W.lines);
         if (have_pend) { sum[0] += ab_finish(W.ix, pend[0], W.lines); sum[1] += ab_finish(W.ix, pend[1], W.lines); }
@@ -758,14 +859,14 @@ MTG_UNROLL
         for (int br = 0; br < 2; br++) { /* unrolled: the per-branch state must stay in registers */
             const uint64_t c = canon(x[br]);
             ab_issue(W.ix, c, pend[br]);
-            if (!suspect(c)) return 0; /* too many to remember: the general code decides */
+            if (!suspect(c)) MTG_SNP_FAIL(1); /* too many to remember: the general code decides */
 #ifdef MTG_EMU
             if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) dup_exact = true;
 #endif
-            if (x[br].f == x[br].r || c == prev_c) return 0;
+            if (x[br].f == x[br].r || c == prev_c) MTG_SNP_FAIL(2);
             if (aux[br] & 15u) { nt[br] = (aux[br] >> 4) & 3u; aux[br] = aux_step(aux[br]); }
             else {
-                if (popc4(r[br].out) != 1) return 0; /* dead end or a branching inside the bubble */
+                if (popc4(r[br].out) != 1) MTG_SNP_FAIL(2); /* dead end or a branching inside the bubble */
                 nt[br] = (uint32_t)ctz4(r[br].out);
                 aux[br] = aux_of_children(r[br]);
             }
@@ -776,13 +877,14 @@ MTG_UNROLL
         seq[0].set(step, nt[0]);
         seq[1].set(step, nt[1]);
         const Kmer y0 = kmer_next(x[0], nt[0], k, W.mk), y1 = kmer_next(x[1], nt[1], k, W.mk);
-        if (y0.f == x[0].r || y1.f == x[1].r) return 0; /* a node followed by its own reverse complement */
+        if (y0.f == x[0].r || y1.f == x[1].r) MTG_SNP_FAIL(2); /* a node followed by its own reverse complement */
         if (y0.f == y1.f) { L = step; x[0] = y0; break; } /* the branches meet: x[0] = e */
-        if (!(aux[0] & AUX_IN1) || !(aux[1] & AUX_IN1)) return 0; /* a node with another way in: the frontline check would have work to do */
+        if (!(aux[0] & AUX_IN1) || !(aux[1] & AUX_IN1)) MTG_SNP_FAIL(2); /* a node with another way in: the frontline check would have work to do */
         x[0] = y0;
         x[1] = y1;
     }
-    if (L == 0) return 0;
+    if (L == 0) MTG_SNP_FAIL(2);
+#undef MTG_SNP_FAIL
     const Kmer e = x[0];
     const uint64_t ce = canon(e);
     if (!suspect(ce)) return 0;
@@ -807,6 +909,10 @@ MTG_UNROLL
     if (identity_below_90(matches, n, n)) return 0;
     /* most abundant consensus: the last step's buckets and the node's own */
     if (have_pend) { sum[0] += ab_finish(W.ix, pend[0], W.lines); sum[1] += ab_finish(W.ix, pend[1], W.lines); }
+#ifdef MTG_EMU
+    if (bulk_ok && (L != bL || h != bh || e.f != be.f || seq[0].lo != bseq[0].lo || seq[0].hi != bseq[0].hi || seq[1].lo != bseq[1].lo || seq[1].hi != bseq[1].hi ||
+                    sum[0] != bsum[0] || sum[1] != bsum[1])) { W.status = 0xBAD2; return 0; }
+#endif
     {
         const uint32_t a0 = ab_finish(W.ix, pend_cur, W.lines);
         sum[0] += a0;
