@@ -462,6 +462,28 @@ MTG_DEV uint64_t us_peek64(const uint64_t* words, uint64_t pos, uint32_t n, bool
     if (bwd) v = (rev_fields64(v) >> (64u - 2u * n)) ^ (0xAAAAAAAAAAAAAAAAULL & mask);
     return v;
 }
+/* sum of the abundance bytes ab[start, start + count), count <= 64: aligned 8-byte reads, all in flight together, bytes outside the range
+ * masked off (the array is padded past its end) */
+MTG_DEV uint32_t us_ab_sum(const uint8_t* ab, uint64_t start, uint32_t count)
+{
+    const uint64_t a0 = start & ~7ull, end = start + count;
+    uint64_t w[9];
+MTG_UNROLL
+    for (int j = 0; j < 9; j++) w[j] = (a0 + 8u * (uint32_t)j < end) ? *reinterpret_cast<const uint64_t*>(ab + a0 + 8u * (uint32_t)j) : 0ull;
+    uint32_t sum = 0;
+MTG_UNROLL
+    for (int j = 0; j < 9; j++) {
+        const uint64_t lo = a0 + 8u * (uint32_t)j; /* bytes lo .. lo + 7 */
+        uint64_t m = ~0ull;
+        if (lo < start) m &= ~0ull << (8u * (uint32_t)(start - lo));                       /* only j = 0 */
+        if (lo + 8 > end) m = lo >= end ? 0ull : (m & (~0ull >> (8u * (uint32_t)(lo + 8 - end))));
+        uint64_t x = w[j] & m;
+        x = (x & 0x00FF00FF00FF00FFULL) + ((x >> 8) & 0x00FF00FF00FF00FFULL);
+        x = (x & 0x0000FFFF0000FFFFULL) + ((x >> 16) & 0x0000FFFF0000FFFFULL);
+        sum += (uint32_t)x + (uint32_t)(x >> 32);
+    }
+    return sum;
+}
 /* the simple path behind a pointer: position of its first nucleotide (the junction's out-edge) and how many nucleotides follow the
  * junction up to the end of the unitig in the walking direction (>= 1) */
 MTG_DEV void us_run(const UStore& us, uint64_t up, int k, uint64_t& pos, uint32_t& left)

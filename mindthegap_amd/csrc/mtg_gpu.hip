@@ -1370,9 +1370,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
 #ifdef MTG_STAMPS
     {
         unsigned long long hs[16];
-        if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(mtg::g_stamps), sizeof hs) == hipSuccess && hs[8])
-            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f | snp_fast %.0f consume %.0f\n", hs[8], (double)hs[0] / hs[8],
-                    (double)hs[1] / hs[8], (double)hs[2] / hs[8], (double)hs[3] / hs[8], (double)hs[4] / hs[8], (double)hs[5] / hs[8], (double)hs[6] / hs[8], (double)hs[7] / hs[8]);
+        if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(mtg::g_stamps), sizeof hs) == hipSuccess && hs[15])
+            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f (long steps %.0f, bucket reads + run set-up %.0f) B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f | snp_fast %.0f consume %.0f\n", hs[15],
+                    (double)hs[0] / hs[15], (double)hs[8] / hs[15], (double)hs[9] / hs[15], (double)hs[1] / hs[15], (double)hs[2] / hs[15], (double)hs[3] / hs[15], (double)hs[4] / hs[15], (double)hs[5] / hs[15],
+                    (double)hs[6] / hs[15], (double)hs[7] / hs[15]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
     }

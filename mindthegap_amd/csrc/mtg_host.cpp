@@ -708,7 +708,7 @@ void results_release(mtg_results* r)
     r->relaid.clear();
     {
         std::lock_guard<std::mutex> lk(g_results_mtx);
-        if (g_results_cache.size() < 6) { g_results_cache.push_back(r); return; }
+        if (g_results_cache.size() < 12) { g_results_cache.push_back(r); return; }
     }
     delete r;
 }

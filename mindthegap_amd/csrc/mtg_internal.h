@@ -43,7 +43,7 @@ struct mtg_index {
     mtg::Index dev{};          /* tables live in device memory */
     /* a few batches on one index run side by side (callers on several threads, like the reference's Dispatcher): each owns a workspace
      * and its streams, so the traversal of one overlaps the post-processing and the host passes of the other */
-    enum { NWS = 3 };
+    enum { NWS = 6 };
     mutable mtgi::Workspace ws[NWS];
     int device = 0;
     mtg_index_info info{};

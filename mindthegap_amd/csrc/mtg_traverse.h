@@ -215,7 +215,7 @@ struct Worker {
     uint32_t n_marked, n_seen, n_iseen, n_inv;
     uint64_t msig0 = 0, msig1 = 0, msig2 = 0, msig3 = 0;
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     MTG_DEV Worker(const Index& i, const FillCfg& c, const GapScratch& s)
@@ -737,7 +737,7 @@ MTG_UNROLL
         /* abundances of the m + 1 nodes: the k-mers at unitig index off - 1 .. off - 1 + m (forward) or off - m .. off (backward) */
         const uint64_t base = (up_hdr(r[br].up) + 1) * 32;
         const uint32_t off = up_off(r[br].up), first = bwd ? off - m : off - 1u;
-        for (uint32_t i = 0; i <= m; i++) s[br] += us.ab[base + first + i];
+        s[br] = us_ab_sum(us.ab, base + first, m + 1u);
     }
     Kmer z[2] = {x[0], x[1]};
 MTG_UNROLL
@@ -777,7 +777,7 @@ MTG_UNROLL
 }
 
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
-MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen)
+MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen, SnpSeq& chosen_seq)
 {
     if (!W.S.snp_fast || W.cfg.end_rule_nonbranching) return 0;
     if (!(popc4(a.out) == 2 && popc4(a.in) == 1)) return 0;
@@ -899,13 +899,16 @@ MTG_UNROLL
     if (ce == canon(cur) || ce == prev_c) return 0; /* e is the node, its reverse complement or the previous node */
     const int n = L + 1;
     if (n > W.cfg.mono_max_depth) return 0;
-    /* the consensus strings where the caller (and the alignment) expect them */
-    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+    /* one substitution: the diagonal is the unique optimal alignment (see validate_consensuses); more: the exact banded alignment, which
+     * wants the consensus strings in the work area (the caller takes the chosen one from registers) */
+    int matches = n - h;
+    if (h >= 2) {
+        const SP<uint8_t> cons = s_cons(W.cfg, W.S);
 MTG_UNROLL
-    for (int br = 0; br < 2; br++)
-        for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
-    /* one substitution: the diagonal is the unique optimal alignment (see validate_consensuses); more: the exact banded alignment */
-    const int matches = h < 2 ? n - h : nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
+        for (int br = 0; br < 2; br++)
+            for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
+        matches = nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
+    }
     if (identity_below_90(matches, n, n)) return 0;
     /* most abundant consensus: the last step's buckets and the node's own */
     if (have_pend) { sum[0] += ab_finish(W.ix, pend[0], W.lines); sum[1] += ab_finish(W.ix, pend[1], W.lines); }
@@ -924,7 +927,7 @@ MTG_UNROLL
     chosen = -1;
     for (int c = 0; c < 2; c++) if (sum[c] > best) { best = sum[c]; chosen = c; }
     if (chosen < 0) return 0;
-    s_conslen(W.cfg, W.S)[0] = s_conslen(W.cfg, W.S)[1] = (uint16_t)n;
+    chosen_seq = seq[chosen];
     W.mark_canon(ce); /* e has two in-edges: the one branching node among the involved ones */
     return n;
 }
@@ -1097,12 +1100,17 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             run_pos = run_bwd ? run_pos - run_take : run_pos + run_take;
         }
         if (run_left == 0) {
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+            unsigned long long* stamp_acc = W.stamp_acc;
+#endif
+            MTG_T0(t_rd);
             const Adj r = adj_right_t(adj, node, mk1, lines);
-            if (!(r.up && popc4(r.out) == 1 && popc4(r.in) == 1)) { run_take = 0; return r; }
+            if (!(r.up && popc4(r.out) == 1 && popc4(r.in) == 1)) { run_take = 0; MTG_T1(t_rd, 9); return r; }
             us_run(us, r.up, k, run_pos, run_left);
             run_bwd = up_bwd(r.up);
             run_base = (up_hdr(r.up) + 1) * 32;
             store_reads++;
+            MTG_T1(t_rd, 9);
         }
         return run_chunk(node);
     };
@@ -1255,7 +1263,9 @@ MTG_UNROLL
                 }
                 if (len + nbulk + 32u > MAXLEN) nbulk = MAXLEN > len + 32u ? MAXLEN - len - 32u : 0u;
                 if (nbulk >= 32u) {
+                    MTG_T0(t_ls);
                     run_long_step(nbulk);
+                    MTG_T1(t_ls, 8);
                     lazy_prev = false;
                     if (ovf || W.status) { end_contig = true; break; }
                     a = run_chunk(cur);
@@ -1329,7 +1339,9 @@ MTG_UNROLL
         if (!end_contig) {
             int chosen = -1;
             MTG_T0(t_snp);
-            int n = snp_bubble_fast(W, cur, prev_c, a, chosen);
+            SnpSeq fast_seq;
+            fast_seq.lo = fast_seq.hi = 0;
+            int n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
             MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
             if (!fast) n = explore_branching(W, cur, prev_c, chosen);
@@ -1338,15 +1350,18 @@ MTG_UNROLL
             } else {
                 const SP<uint8_t> p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;
                 bool looping = false;
+                MTG_T0(t_cons);
                 for (int i = 0; i < n; i++) {
+                    const uint32_t nti = fast ? fast_seq.get(i) : (uint32_t)p[i];
                     prev_c = canon(cur);
-                    cur = kmer_next(cur, p[i], k, mk);
-                    push_nt(p[i]);
+                    cur = kmer_next(cur, nti, k, mk);
+                    push_nt(nti);
                     len++;
                     if (!fast) W.mark(cur);
                     if (r_is_kmer && cur.f == R.r0) found_R = true;
                     if (canon(cur) == start_c) looping = true;
                 }
+                MTG_T1(t_cons, 7);
                 if (looping || len > MAXLEN || ovf || W.status) end_contig = true;
                 else a = next_adj(cur);
             }
@@ -1385,8 +1400,8 @@ MTG_UNROLL
         }
     }
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
-    for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i], W.stamp_acc[i]);
-    atomicAdd(&g_stamps[8], 1ull);
+    for (int i = 0; i < 15; i++) atomicAdd(&g_stamps[i], W.stamp_acc[i]);
+    atomicAdd(&g_stamps[15], 1ull);
 #endif
     /* leave the zero-initialised region as it was found, whatever the exit path */
     W.seen_clear();

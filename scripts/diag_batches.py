@@ -8,7 +8,8 @@ import mindthegap_amd as mtg
 from mindthegap_amd.synth import SynthSet
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-S = SynthSet(nseq=600000, n_sites=nb * 100000, seed=1, k=31)
+het = 4 if os.environ.get("HET") else 0
+S = SynthSet(nseq=600000, n_sites=nb * 100000, seed=1, k=31, het_snps=het)
 dev = torch.device("cuda", 0)
 w = torch.from_numpy(S.words.view(np.int64)).to(dev); wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev); ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
 idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 40)
@@ -24,8 +25,8 @@ for b in range(nb):
         h, nf, _ = idx.fill_prepared(prep, params, want_seqs=False)
         st = mtg.last_batch_stats()
         idx.free_results(h)
-    print("batch", b, "k_stage_a %.3f post %.3f emit %.3f" % (st["kernel_ms"], st["post_kernel_ms"], st["emit_kernel_ms"]),
-          {k: st[k] for k in ("index_lines", "store_runs", "run_nt", "contig_nt", "n_launches", "n_retried_gaps", "post_lines", "coverage_kmers")}, "filled", int((nf > 0).sum()))
+    print("batch", b, "k_stage_a %.3f post %.3f emit %.3f host %.3f total %.3f" % (st["kernel_ms"], st["post_kernel_ms"], st["emit_kernel_ms"], st["host_ms"], st["total_ms"]),
+          {k: st[k] for k in ("index_lines", "store_runs", "run_nt", "contig_nt", "n_launches", "n_retried_gaps", "post_lines", "coverage_kmers", "dense_words")}, "filled", int((nf > 0).sum()))
     # the slowest walks: split the batch in 16 pieces and time each traversal alone
     if len(sys.argv) > 2:
         for piece in range(16):
@@ -33,4 +34,4 @@ for b in range(nb):
             h, nf, _ = idx.fill_prepared(sub, params, want_seqs=False)
             st = mtg.last_batch_stats()
             idx.free_results(h)
-            print("   piece %2d k_stage_a %.3f lines %d runs %d run_nt %d contig_nt %d" % (piece, st["kernel_ms"], st["index_lines"], st["store_runs"], st["run_nt"], st["contig_nt"]))
+            print("   piece %2d k_stage_a %.3f lines %d runs %d run_nt %d contig_nt %d dense %d host %.2f" % (piece, st["kernel_ms"], st["index_lines"], st["store_runs"], st["run_nt"], st["contig_nt"], st["dense_words"], st["host_ms"]))
