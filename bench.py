@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--cpu-sites", type=int, default=30000, help="sites of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-index-seqs", type=int, default=30000, help="donor sequences in the CPU baseline's index")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads per rank for the per-gap passes (default: the library's pool = CPU budget of the process, shared between the ranks)")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MTG_BENCH_IN_FLIGHT", "3")),
-                    help="batches in flight: caller threads issuing batches on the one index (the library runs up to three batches of an index side by side)")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MTG_BENCH_IN_FLIGHT", "6")),
+                    help="batches in flight: caller threads issuing batches on the one index (the library runs up to six batches of an index side by side)")
     ap.add_argument("--host-strings", action="store_true", help="marshal the sites from host strings inside every step (mtg_fill_batch) instead of filling prepared, device-resident batches")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the random-line ceiling micro-benchmark")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (host-string input, BASELINE configs[4] literal)")

@@ -86,9 +86,10 @@ static int auto_cutoff(const std::vector<uint64_t>& h, int floor_thr)
 {
     const size_t len = h.size();
     if (len < 5) return floor_thr;
-    std::vector<double> sm(len, 0.0);
-    sm[1] = 0.6 * h[1] + 0.4 * h[2];
-    for (size_t i = 2; i + 1 < len; i++) sm[i] = 0.2 * h[i - 1] + 0.6 * h[i] + 0.2 * h[i + 1];
+    /* integer entries, as in gatb's Histogram (the weighted sums are truncated): see the two datapoints in tests/test_micro_cases.py */
+    std::vector<uint64_t> sm(len, 0);
+    sm[1] = (uint64_t)(0.6 * (double)h[1] + 0.4 * (double)h[2]);
+    for (size_t i = 2; i + 1 < len; i++) sm[i] = (uint64_t)(0.2 * (double)h[i - 1] + 0.6 * (double)h[i] + 0.2 * (double)h[i + 1]);
     size_t valley = 2;
     while (valley + 2 < len && !(sm[valley] < sm[valley + 1])) valley++;
     size_t peak = valley;

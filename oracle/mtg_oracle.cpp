@@ -179,9 +179,13 @@ static int auto_cutoff_from_histogram(const vector<uint64_t>& histo /* index = a
 {
     size_t len = histo.size();
     if (len < 5) return floor_thr;
-    vector<double> sm(len, 0.0);
-    sm[1] = 0.6 * histo[1] + 0.4 * histo[2];
-    for (size_t i = 2; i + 1 < len; i++) sm[i] = 0.2 * histo[i - 1] + 0.6 * histo[i] + 0.2 * histo[i + 1];
+    /* gatb keeps the smoothed histogram in integer entries (Histogram::Entry::abundance is a u_int64_t [MEM]): the weighted sums are
+     * truncated.  Pinned by two datapoints: the golden cut-off 7 (test/full_test/gold_fill.output:11) and test/simple_test.sh's
+     * "clean-insert" case, whose fill only succeeds when the cut-off inferred from reads/master.fasta (a sparse histogram of counts
+     * 0..3) is at most 33 -- without the truncation the first minimum of that histogram is at 68. */
+    vector<uint64_t> sm(len, 0);
+    sm[1] = (uint64_t)(0.6 * histo[1] + 0.4 * histo[2]);
+    for (size_t i = 2; i + 1 < len; i++) sm[i] = (uint64_t)(0.2 * histo[i - 1] + 0.6 * histo[i] + 0.2 * histo[i + 1]);
     size_t valley = 2;
     while (valley + 2 < len && !(sm[valley] < sm[valley + 1])) valley++; /* first minimum */
     size_t peak = valley;
