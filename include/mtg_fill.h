@@ -70,6 +70,10 @@ int mtg_index_create_from_packed_device(const uint64_t* d_words, const uint64_t*
 /* Graph::load / save (src/Filler.cpp:222): this library's own container; a GATB .h5 gives MTG_ERR_FORMAT. */
 int mtg_index_load(const char* path, mtg_index** out);
 int mtg_index_save(const mtg_index* idx, const char* path);
+/* A copy of the index on another device of the node (tables and unitig store copied device to device, no rebuild): what the tool uses to
+ * run on every GPU, the reference's Dispatcher threads (src/Filler.cpp:824,844) becoming one host thread per device.  The copy is an
+ * independent index: free it with mtg_index_free. */
+int mtg_index_replicate(const mtg_index* idx, int device, mtg_index** out);
 int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info);
 void mtg_index_free(mtg_index* idx);
 

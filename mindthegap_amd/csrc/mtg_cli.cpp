@@ -16,6 +16,8 @@
 #include <fstream>
 #include <sstream>
 #include <unordered_map>
+#include <condition_variable>
+#include <thread>
 
 namespace mtgi {
 
@@ -89,7 +91,7 @@ static std::string info_string(const mtg_gap_result& g)
 
 struct Options {
     std::string in, graph, bkpt, contig, out;
-    int k = 31, abundance_min = -1, abundance_max = 0, max_nodes = 100, max_depth = 10000, overlap = 0, nb_cores = 0;
+    int k = 31, abundance_min = -1, abundance_max = 0, max_nodes = 100, max_depth = 10000, overlap = 0, nb_cores = 0, nb_gpus = 0;
     bool fwd_only = false, filter = false, extend = false, has_out = false;
 };
 
@@ -230,76 +232,154 @@ struct Summary {
     void count(size_t nsol) { nb_breakpoints++; if (nsol > 0) { nb_filled++; if (nsol > 1) nb_multiple++; } }
 };
 
-static int run_bkpt(const mtg_index* idx, const mtg_params& P, const Options& O, Files& F, Summary& S)
+/* The reference hands groups of records to its Dispatcher threads (src/Filler.cpp:824,844); here the sites go in batches to the devices:
+ * one host thread per device (each with its replica of the index) takes the next batch, and the calling thread writes the batches' records
+ * in input order as they become complete -- the reference's order with -nb-cores 1. */
+struct Replicas {
+    std::vector<const mtg_index*> idx; /* idx[0] = the index itself */
+    std::vector<mtg_index*> owned;
+    ~Replicas() { for (mtg_index* i : owned) mtg_index_free(i); }
+    int make(const mtg_index* primary, int want)
+    {
+        idx.push_back(primary);
+        const int ndev = mtg_device_count();
+        if (const char* e = getenv("MTG_NB_GPUS")) { if (want <= 0) want = atoi(e); }
+        int use = want > 0 ? std::min(want, ndev) : ndev;
+        for (int d = 0, made = 1; d < ndev && made < use; d++) {
+            if (d == primary->device) continue;
+            mtg_index* r = nullptr;
+            if (int rc = mtg_index_replicate(primary, d, &r)) return rc;
+            owned.push_back(r);
+            idx.push_back(r);
+            made++;
+        }
+        return MTG_OK;
+    }
+};
+static size_t cli_batch_size()
+{
+    const char* e = getenv("MTG_CLI_BATCH");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (size_t)v : (size_t)200000;
+}
+/* process(b, idx) for every batch b on the devices; consume(b) on the calling thread, in order, once batch b is complete */
+static int run_batches(const Replicas& R, size_t nb, const std::function<int(size_t, const mtg_index*)>& process, const std::function<void(size_t)>& consume)
+{
+    std::atomic<size_t> next{0};
+    std::vector<char> done(nb, 0);
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<int> err{MTG_OK};
+    std::string err_text;
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < R.idx.size() && d < std::max<size_t>(nb, 1); d++)
+        workers.emplace_back([&, d]() {
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b >= nb) return;
+                int rc = err.load() ? err.load() : process(b, R.idx[d]);
+                std::lock_guard<std::mutex> lk(m);
+                if (rc && !err.load()) { err = rc; err_text = mtg_last_error(); } /* the message is thread-local: keep the first one */
+                done[b] = 1;
+                cv.notify_all();
+            }
+        });
+    for (size_t b = 0; b < nb; b++) {
+        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done[b] != 0; }); }
+        if (!err.load()) consume(b);
+    }
+    for (auto& t : workers) t.join();
+    if (err.load()) set_error("%s", err_text.c_str());
+    return err.load();
+}
+
+static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Files& F, Summary& S)
 {
     std::vector<std::pair<std::string, std::string>> recs;
     if (!read_sequences(O.bkpt, recs)) { set_error("cannot read %s", O.bkpt.c_str()); return MTG_ERR_IO; }
     const size_t nsites = recs.size() / 2; /* records 2i / 2i+1 = left / right k-mer, src/Filler.cpp:625-629 */
     struct Site { std::string name, name_r; };
-    std::vector<Site> sites(nsites);
-    std::vector<GapArgs> fwd(nsites);
-    for (size_t i = 0; i < nsites; i++) {
-        Site& s = sites[i];
-        GapArgs& g = fwd[i];
-        g.source = recs[2 * i].second;
-        g.target = recs[2 * i + 1].second;
-        s.name = short_name(recs[2 * i].first);
-        s.name_r = short_name(recs[2 * i + 1].first);
-        g.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
-        bkpt_dict_t dict;
-        dict.insert({g.target, std::make_pair(s.name_r, false)});
-        g.set_dict(dict);
-    }
-    BatchRun rf, rr;
-    int rc = rf.run(idx, P, fwd);
-    if (rc) return rc;
-    /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
-    std::vector<size_t> rev_of;
-    std::vector<GapArgs> rev;
-    if (!O.fwd_only)
-        for (size_t i = 0; i < nsites; i++)
-            if (rf[i].n_filled == 0) {
-                GapArgs g;
-                g.target = revcomp_str(fwd[i].source);
-                g.source = revcomp_str(fwd[i].target);
-                g.repeated = fwd[i].repeated;
-                g.reverse = true;
-                bkpt_dict_t dict;
-                dict.insert({g.target, std::make_pair(sites[i].name, false)});
-                g.set_dict(dict);
-                rev.push_back(std::move(g));
-                rev_of.push_back(i);
+    struct Batch {
+        size_t s0 = 0, s1 = 0;
+        std::vector<Site> sites;
+        std::vector<GapArgs> fwd, rev;
+        std::vector<long> rev_idx;
+        BatchRun rf, rr;
+    };
+    const size_t B = cli_batch_size(), nb = (nsites + B - 1) / B;
+    std::vector<std::unique_ptr<Batch>> batches(nb);
+    const auto process = [&](size_t b, const mtg_index* idx) -> int {
+        std::unique_ptr<Batch> bt(new Batch());
+        bt->s0 = b * B; bt->s1 = std::min(nsites, (b + 1) * B);
+        const size_t n = bt->s1 - bt->s0;
+        bt->sites.resize(n);
+        bt->fwd.resize(n);
+        for (size_t j = 0; j < n; j++) {
+            const size_t i = bt->s0 + j;
+            Site& s = bt->sites[j];
+            GapArgs& g = bt->fwd[j];
+            g.source = recs[2 * i].second;
+            g.target = recs[2 * i + 1].second;
+            s.name = short_name(recs[2 * i].first);
+            s.name_r = short_name(recs[2 * i + 1].first);
+            g.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
+            bkpt_dict_t dict;
+            dict.insert({g.target, std::make_pair(s.name_r, false)});
+            g.set_dict(dict);
+        }
+        int rc = bt->rf.run(idx, P, bt->fwd);
+        if (rc) return rc;
+        /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
+        bt->rev_idx.assign(n, -1);
+        if (!O.fwd_only)
+            for (size_t j = 0; j < n; j++)
+                if (bt->rf[j].n_filled == 0) {
+                    GapArgs g;
+                    g.target = revcomp_str(bt->fwd[j].source);
+                    g.source = revcomp_str(bt->fwd[j].target);
+                    g.repeated = bt->fwd[j].repeated;
+                    g.reverse = true;
+                    bkpt_dict_t dict;
+                    dict.insert({g.target, std::make_pair(bt->sites[j].name, false)});
+                    g.set_dict(dict);
+                    bt->rev_idx[j] = (long)bt->rev.size();
+                    bt->rev.push_back(std::move(g));
+                }
+        if (!bt->rev.empty()) { rc = bt->rr.run(idx, P, bt->rev); if (rc) return rc; }
+        batches[b] = std::move(bt);
+        return MTG_OK;
+    };
+    const auto consume = [&](size_t b) {
+        Batch& bt = *batches[b];
+        for (size_t j = 0; j < bt.s1 - bt.s0; j++) {
+            const Site& s = bt.sites[j];
+            std::string info = info_string(bt.rf[j]);
+            std::string name = s.name;
+            const mtg_gap_result* res = &bt.rf[j];
+            const GapArgs* gw = &bt.fwd[j];
+            if (bt.rev_idx[j] >= 0) {
+                res = &bt.rr[(size_t)bt.rev_idx[j]];
+                info += info_string(*res);
+                name = s.name_r; /* src/Filler.cpp:674 */
+                gw = &bt.rev[(size_t)bt.rev_idx[j]];
             }
-    if (!rev.empty()) { rc = rr.run(idx, P, rev); if (rc) return rc; }
-    std::vector<long> rev_idx(nsites, -1);
-    for (size_t j = 0; j < rev_of.size(); j++) rev_idx[rev_of[j]] = (long)j;
-    for (size_t i = 0; i < nsites; i++) {
-        const Site& s = sites[i];
-        std::string info = info_string(rf[i]);
-        std::string name = s.name;
-        const mtg_gap_result* res = &rf[i];
-        const GapArgs* gw = &fwd[i];
-        if (rev_idx[i] >= 0) {
-            res = &rr[(size_t)rev_idx[i]];
-            info += info_string(*res);
-            name = s.name_r; /* src/Filler.cpp:674 */
-            gw = &rev[(size_t)rev_idx[i]];
+            const Sols sols = sols_of(*res);
+            write_filled(F, true, *gw, sols, name, info);
+            write_vcf(F, O.filter, sols, name, bt.fwd[j].source);
+            if (sols.empty() && O.extend) {
+                write_extension(F, bt.rf[j].extension, name, bt.fwd[j].source);
+                write_extension(F, bt.rev_idx[j] >= 0 ? std::string(bt.rr[(size_t)bt.rev_idx[j]].extension) : std::string(), name + "_reverse", revcomp_str(bt.fwd[j].target));
+            }
+            S.count(sols.size());
         }
-        const Sols sols = sols_of(*res);
-        write_filled(F, true, *gw, sols, name, info);
-        write_vcf(F, O.filter, sols, name, fwd[i].source);
-        if (sols.empty() && O.extend) {
-            write_extension(F, rf[i].extension, name, fwd[i].source);
-            write_extension(F, rev_idx[i] >= 0 ? std::string(rr[(size_t)rev_idx[i]].extension) : std::string(), name + "_reverse", revcomp_str(fwd[i].target));
-        }
-        S.count(sols.size());
-    }
-    return MTG_OK;
+        batches[b].reset(); /* its records and sequences are written */
+    };
+    return run_batches(R, nb, process, consume);
 }
 
-static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& O, Files& F, Summary& S, int trim)
+static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, Files& F, Summary& S, int trim)
 {
-    const int k = idx->info.k;
+    const int k = R.idx[0]->info.k;
     std::vector<std::pair<std::string, std::string>> recs;
     if (!read_sequences(O.contig, recs)) { set_error("cannot read %s", O.contig.c_str()); return MTG_ERR_IO; }
     bkpt_dict_t all_targets;
@@ -326,40 +406,56 @@ static int run_contig(const mtg_index* idx, const mtg_params& P, const Options& 
             }
         }
     }
-    /* contigFunctor, src/Filler.cpp:492-572 */
-    std::vector<GapArgs> gaps(seeds.size());
-    for (size_t si = 0; si < seeds.size(); si++) {
-        auto& sd = seeds[si];
-        GapArgs& g = gaps[si];
-        bkpt_dict_t dict;
-        for (auto its = all_targets.begin(); its != all_targets.end(); ++its) {
-            std::string tempName = its->second.first;
-            if (its->second.second) tempName += "_Rc";
-            if (tempName.compare(sd.first) != 0) { g.target.append(its->first); dict.insert({its->first, its->second}); }
+    /* contigFunctor, src/Filler.cpp:492-572; every seed sees the targets of all the other contigs (:522-533) */
+    struct Batch {
+        size_t s0 = 0, s1 = 0;
+        std::vector<GapArgs> gaps;
+        BatchRun run;
+    };
+    const size_t B = std::max<size_t>(1, cli_batch_size() / std::max<size_t>(1, all_targets.size() / 8)), nb = (seeds.size() + B - 1) / B; /* a gap carries the whole dictionary: fewer per batch */
+    std::vector<std::unique_ptr<Batch>> batches(nb);
+    const auto process = [&](size_t b, const mtg_index* idx) -> int {
+        std::unique_ptr<Batch> bt(new Batch());
+        bt->s0 = b * B; bt->s1 = std::min(seeds.size(), (b + 1) * B);
+        bt->gaps.resize(bt->s1 - bt->s0);
+        for (size_t si = bt->s0; si < bt->s1; si++) {
+            auto& sd = seeds[si];
+            GapArgs& g = bt->gaps[si - bt->s0];
+            bkpt_dict_t dict;
+            for (auto its = all_targets.begin(); its != all_targets.end(); ++its) {
+                std::string tempName = its->second.first;
+                if (its->second.second) tempName += "_Rc";
+                if (tempName.compare(sd.first) != 0) { g.target.append(its->first); dict.insert({its->first, its->second}); }
+            }
+            g.source = sd.second;
+            g.set_dict(dict);
         }
-        g.source = sd.second;
-        g.set_dict(dict);
-    }
-    BatchRun run;
-    int rc = run.run(idx, P, gaps);
-    if (rc) return rc;
-    for (size_t i = 0; i < seeds.size(); i++) {
-        const std::string& seedName = seeds[i].first;
-        const bool isRc = seedName.length() >= 3 && seedName.compare(seedName.length() - 3, 3, "_Rc") == 0;
-        std::vector<mtg_filled> kept;
-        for (auto& s : sols_of(run[i])) { /* drop loops: target == seed reversed, :540-557 */
-            const std::string& tn = gaps[i].tname[s.target_index];
-            const std::string revTargetName = gaps[i].trc[s.target_index] ? tn : tn + "_Rc";
-            if (revTargetName != seedName) kept.push_back(s);
+        if (int rc = bt->run.run(idx, P, bt->gaps)) return rc;
+        batches[b] = std::move(bt);
+        return MTG_OK;
+    };
+    const auto consume = [&](size_t b) {
+        Batch& bt = *batches[b];
+        for (size_t i = bt.s0; i < bt.s1; i++) {
+            const size_t j = i - bt.s0;
+            const std::string& seedName = seeds[i].first;
+            const bool isRc = seedName.length() >= 3 && seedName.compare(seedName.length() - 3, 3, "_Rc") == 0;
+            std::vector<mtg_filled> kept;
+            for (auto& s : sols_of(bt.run[j])) { /* drop loops: target == seed reversed, :540-557 */
+                const std::string& tn = bt.gaps[j].tname[s.target_index];
+                const std::string revTargetName = bt.gaps[j].trc[s.target_index] ? tn : tn + "_Rc";
+                if (revTargetName != seedName) kept.push_back(s);
+            }
+            Sols ks;
+            ks.p = kept.data(); ks.n = kept.size();
+            write_filled(F, false, bt.gaps[j], ks, seedName, info_string(bt.run[j]));
+            write_gfa(F, trim, bt.gaps[j], ks, seedName, isRc);
+            if (kept.empty() && O.extend) write_extension(F, bt.run[j].extension, seedName, seeds[i].second);
+            S.count(kept.size());
         }
-        Sols ks;
-        ks.p = kept.data(); ks.n = kept.size();
-        write_filled(F, false, gaps[i], ks, seedName, info_string(run[i]));
-        write_gfa(F, trim, gaps[i], ks, seedName, isRc);
-        if (kept.empty() && O.extend) write_extension(F, run[i].extension, seedName, seeds[i].second);
-        S.count(kept.size());
-    }
-    return MTG_OK;
+        batches[b].reset();
+    };
+    return run_batches(R, nb, process, consume);
 }
 
 int fill_main(int argc, const char* const* argv)
@@ -382,6 +478,7 @@ int fill_main(int argc, const char* const* argv)
         else if (a == "-max-length") { ok = val(v); O.max_depth = atoi(v.c_str()); }
         else if (a == "-overlap") { ok = val(v); O.overlap = atoi(v.c_str()); }
         else if (a == "-nb-cores") { ok = val(v); O.nb_cores = atoi(v.c_str()); }
+        else if (a == "-nb-gpus") { ok = val(v); O.nb_gpus = atoi(v.c_str()); } /* not an option of the reference: devices to use (0 = every visible one) */
         else if (a == "-max-memory" || a == "-max-disk" || a == "-verbose") ok = val(v);
         else if (a == "-fwd-only") O.fwd_only = true;
         else if (a == "-filter") O.filter = true;
@@ -435,7 +532,11 @@ int fill_main(int argc, const char* const* argv)
     P.nb_host_threads = O.nb_cores;
     Summary S;
     const time_t t_start = time(0);
-    rc = bkpt_mode ? run_bkpt(idx, P, O, F, S) : run_contig(idx, P, O, F, S, trim);
+    {
+        Replicas R;
+        rc = R.make(idx, O.nb_gpus);
+        if (!rc) rc = bkpt_mode ? run_bkpt(R, P, O, F, S) : run_contig(R, P, O, F, S, trim);
+    }
     const double seconds = difftime(time(0), t_start);
     if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); mtg_index_free(idx); return 1; }
     /* resumeParameters / resumeResults, src/Filler.cpp:385-481 */

@@ -887,6 +887,45 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
     return MTG_OK;
 }
 
+/* the whole index on another device: same shapes, tables and unitig store copied device to device */
+int index_replicate(const mtg_index* src, int device, mtg_index** out)
+{
+    if (!src || !out) { set_error("null argument"); return MTG_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { set_error("no such device: %d", device); return MTG_ERR_ARG; }
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    HIP_TRY(hipSetDevice(device));
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev = src->dev;
+    idx->info = src->info;
+    idx->device = device;
+    idx->dev.adj.slots = idx->dev.abnd.slots = nullptr; /* free_tables must only see what this copy owns */
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.us.words = nullptr;
+    idx->dev.us.ab = nullptr;
+    auto clone = [&](void** dst, const void* from, size_t bytes) -> int {
+        if (!from || !bytes) return MTG_OK;
+        HIP_TRY(hipMalloc(dst, bytes));
+        HIP_TRY(hipMemcpyPeer(*dst, device, from, src->device, bytes));
+        return MTG_OK;
+    };
+    const size_t ba = src->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = src->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS, bc = src->dev.bloom.nblocks * 64;
+    if (int rc = clone((void**)&idx->dev.adj.slots, src->dev.adj.slots, ba)) return rc;
+    if (int rc = clone((void**)&idx->dev.abnd.slots, src->dev.abnd.slots, bb)) return rc;
+    if (int rc = clone((void**)&idx->dev.bloom.bits, src->dev.bloom.bits, bc)) return rc;
+    if (src->dev.us.nwords) {
+        const size_t nw = src->dev.us.nwords + 8;
+        if (int rc = clone((void**)&idx->dev.us.words, src->dev.us.words, nw * 8)) return rc;
+        if (int rc = clone((void**)&idx->dev.us.ab, src->dev.us.ab, nw * 32)) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    *out = g.release();
+    return MTG_OK;
+}
+
 /* the solid k-mers of an index and their abundances, read back from its tables (for the index writer), in pieces of at most `piece`
  * k-mers handed to sink(kmers, abundances, count) */
 int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink)
@@ -1567,6 +1606,7 @@ int bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_l
 namespace mtgi {
 int index_from_kmers(const uint64_t*, const uint32_t*, size_t, int, mtg_index**);
 int index_from_packed_device(const uint64_t*, const uint64_t*, const uint32_t*, size_t, uint64_t, int, uint32_t, uint32_t, mtg_index**);
+int index_replicate(const mtg_index*, int, mtg_index**);
 void index_release(mtg_index*);
 int bench_random_lines(uint64_t, uint64_t, uint32_t, uint32_t, double*, double*);
 }
@@ -1595,6 +1635,7 @@ int mtg_index_create_from_packed_device(const uint64_t* d_words, const uint64_t*
     return mtgi::index_from_packed_device(d_words, d_word_off, d_len, nseq, ub, k, abund_lo, abund_span, out);
 }
 void mtg_index_free(mtg_index* idx) { mtgi::index_release(idx); }
+int mtg_index_replicate(const mtg_index* idx, int device, mtg_index** out) { return mtgi::index_replicate(idx, device, out); }
 int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info)
 {
     if (!idx || !info) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }

@@ -119,6 +119,7 @@ def _bind(lib):
     lib.mtg_index_create_from_packed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, P(C.c_void_p)]
     lib.mtg_index_load.argtypes = [C.c_char_p, P(C.c_void_p)]
     lib.mtg_index_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mtg_index_replicate.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p)]
     lib.mtg_index_get_info.argtypes = [C.c_void_p, P(IndexInfo)]
     lib.mtg_index_free.argtypes = [C.c_void_p]
     lib.mtg_index_free.restype = None

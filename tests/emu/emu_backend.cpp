@@ -379,8 +379,21 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
 
 extern "C" {
 const char* mtg_last_error(void) { return mtgi::g_err; }
-int mtg_device_count(void) { return 0; }
+/* TEST-ONLY: MTG_EMU_DEVICES pretends that many devices exist, so that the tool's multi-device driver can be exercised on the CPU */
+int mtg_device_count(void) { return getenv("MTG_EMU_DEVICES") ? atoi(getenv("MTG_EMU_DEVICES")) : 0; }
 int mtg_set_device(int) { return MTG_OK; }
+int mtg_index_replicate(const mtg_index* src, int device, mtg_index** out)
+{
+    /* a deep copy: the simplest way to get one is to rebuild from the k-mers read back from the source's table */
+    std::vector<uint64_t> k;
+    std::vector<uint32_t> a;
+    if (int rc = mtgi::index_export(src, [&](const uint64_t* kk, const uint32_t* aa, size_t m) { k.insert(k.end(), kk, kk + m); a.insert(a.end(), aa, aa + m); return true; })) return rc;
+    if (int rc = mtgi::index_from_kmers(k.data(), a.data(), k.size(), src->dev.k, out)) return rc;
+    (*out)->info.abundance_min = src->info.abundance_min;
+    (*out)->info.abundance_auto = src->info.abundance_auto;
+    (*out)->device = device;
+    return MTG_OK;
+}
 int mtg_index_create_from_kmers(const uint64_t* k, const uint32_t* a, size_t n, int kk, mtg_index** out) { return mtgi::index_from_kmers(k, a, n, kk, out); }
 void mtg_index_free(mtg_index* idx) { mtgi::index_release(idx); }
 int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info) { *info = idx->info; return MTG_OK; }

@@ -711,3 +711,26 @@ def test_stage_a_entry_of_the_product(emu_product):
         assert c == o.stage_a(s, t)[0], (s, t)
     idx.close()
     o.close()
+
+
+def test_cli_on_two_emulated_devices(emu_product, tmp_path, monkeypatch):
+    """the tool's multi-device driver (one host thread per device, an index replica each, sites dealt in batches, records written in
+    input order) on the emulation build with two pretended devices and batches of a few sites: the files equal the oracle's (written
+    with one thread, i.e. in input order), in both modes"""
+    monkeypatch.setenv("MTG_EMU_DEVICES", "2")
+    monkeypatch.setenv("MTG_CLI_BATCH", "5")
+    (tmp_path / "e").mkdir(); (tmp_path / "c").mkdir()
+    _edge_case_run(emu_product, tmp_path / "e")
+    _contig_gap_case(emu_product, tmp_path / "c", 6)
+    # the replicas are real copies: an index and its replica answer alike
+    rng = random.Random(2)
+    s = _rand_seq(rng, 400)
+    o = oracle_lib.Index.from_sequences([s], 31, 1, 40)
+    km, ct = o.export()
+    a = emu_product.Index.from_kmers(km, ct, 31)
+    import ctypes as C
+    h = C.c_void_p()
+    assert a.lib.mtg_index_replicate(a.h, 1, C.byref(h)) == 0
+    b = emu_product.Index(h)
+    assert (a.abundance(km) == b.abundance(km)).all() and a.info()["nb_unitigs"] == b.info()["nb_unitigs"]
+    a.close(); b.close(); o.close()

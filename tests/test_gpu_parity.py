@@ -584,3 +584,36 @@ def test_config2_full_size(mtg, tmp_path, variant, err):
     assert (g.abundance(km[sel]) == np.minimum(ct[sel], 255)).all()
     g.close()
     o.close()
+
+
+def test_index_replica_and_tool_on_replicas(mtg, tmp_path, monkeypatch):
+    """mtg_index_replicate (device-to-device copy of tables and unitig store; here onto the same device, the only one of the box) gives an
+    index that answers and fills like its source; and the tool run with small batches (MTG_CLI_BATCH) writes the same files as with one"""
+    import ctypes as C
+    from mindthegap_amd.synth import SynthSet
+    from tests import oracle_lib
+    from tests.test_emu_parity import _edge_case_run
+    S = SynthSet(nseq=300, n_sites=300, seed=5)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    a = mtg.Index.from_kmers(km, ct, 31)
+    h = C.c_void_p()
+    assert a.lib.mtg_index_replicate(a.h, 0, C.byref(h)) == 0
+    b = mtg.Index(h)
+    assert b.info()["nb_unitigs"] == a.info()["nb_unitigs"] > 0
+    q = np.concatenate([km, np.random.default_rng(3).integers(0, 1 << 62, 5000, dtype=np.uint64)])
+    assert (a.abundance(q) == b.abundance(q)).all()
+    sa, pa = a.neighbors(q)
+    sb, pb = b.neighbors(q)
+    assert (sa == sb).all() and (pa == pb).all()
+    gaps = []
+    for i in range(S.n_sites):
+        l, r, _ = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+    ra, rb = a.fill_batch(gaps), b.fill_batch(gaps)
+    assert ra == rb and [r["filled"][0]["seq"] for r in ra] == [S.site(i)[2] for i in range(S.n_sites)]
+    a.close()
+    assert b.fill_batch(gaps[:50]) == rb[:50]  # the replica does not depend on its source
+    b.close(); o.close()
+    monkeypatch.setenv("MTG_CLI_BATCH", "4")
+    _edge_case_run(mtg, tmp_path)
