@@ -494,6 +494,43 @@ MTG_DEV void us_run(const UStore& us, uint64_t up, int k, uint64_t& pos, uint32_
     if (up_bwd(up)) { pos = base + off - 1; left = off; }
     else { pos = base + off + (uint32_t)k - 1; left = len - (off + (uint32_t)k - 1); }
 }
+/* ---- a node's place in the unitig store, for the routines that advance whole stretches of a unitig at once (frontlines, path
+ * enumeration).  Known for a node whose right junction (in its walking orientation) lies inside a stored unitig: */
+struct RunAt {
+    uint64_t kpos;  /* store position (word * 32 + i) of the first nucleotide of the node's k-mer, in the stored orientation */
+    uint32_t ahead; /* nodes ahead of it in its walking direction within the unitig (the last one is the unitig's end node) */
+    uint32_t hdr;   /* header word of the unitig */
+    bool bwd;       /* the node walks against the stored orientation */
+};
+MTG_DEV bool run_at(const UStore& us, const Adj& r, int k, RunAt& out, uint32_t& lines)
+{
+    if (!(r.up && popc4(r.out) == 1 && popc4(r.in) == 1)) return false;
+    const uint64_t hdr = up_hdr(r.up);
+    const uint32_t off = up_off(r.up), len_k = (uint32_t)us.words[hdr] - (uint32_t)k + 1u;
+    lines++;
+    out.hdr = (uint32_t)hdr;
+    out.bwd = up_bwd(r.up);
+    const uint32_t idx = out.bwd ? off : off - 1u;
+    out.ahead = out.bwd ? idx : len_k - 1u - idx;
+    out.kpos = (hdr + 1) * 32 + idx;
+    return true;
+}
+/* the oriented node t nodes ahead of a node at kpos (t <= its `ahead`) */
+MTG_DEV Kmer run_node(const UStore& us, uint64_t kpos, bool bwd, uint32_t t, int k)
+{
+    const uint64_t p = bwd ? kpos - t : kpos + t;
+    const uint64_t mk = kmask(k);
+    Kmer x;
+    x.r = us_peek64(us.words, p, (uint32_t)k, false) ^ (0xAAAAAAAAAAAAAAAAULL & mk); /* little-endian image = reversed order: complemented = reverse complement */
+    x.f = revcomp(x.r, k);
+    if (bwd) { const uint64_t t2 = x.f; x.f = x.r; x.r = t2; }
+    return x;
+}
+/* the nucleotide that leads from the node at kpos to the next one in its walking direction */
+MTG_DEV uint32_t run_next_nt(const UStore& us, uint64_t kpos, bool bwd, int k)
+{
+    return us_peek(us.words, bwd ? kpos - 1 : kpos + (uint32_t)k, 1u, bwd);
+}
 /* the lookahead word an inline entry would hold (count + up to MTG_LA_MAX nucleotides past the single out-edge), read through the pointer */
 MTG_DEV uint32_t la_from_up(const UStore& us, uint64_t up, int k, uint32_t& lines)
 {

@@ -48,7 +48,7 @@ struct FillCfg {
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_flaux0, o_flaux1, o_dfsf, o_dfsc,
-        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt;
+        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra;
 };
 
 enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
@@ -95,6 +95,16 @@ MTG_ILV(uint8_t, s_flnt0, c.o_flnt0)
 MTG_ILV(uint8_t, s_flnt1, c.o_flnt1)
 MTG_ILV(uint32_t, s_flaux0, c.o_flaux0)   /* what is already known about a frontline node (node_aux) */
 MTG_ILV(uint32_t, s_flaux1, c.o_flaux1)
+MTG_ILV(uint64_t, s_flrp0, c.o_flrp0)     /* a frontline node's place in the unitig store (run_pack), 0 = unknown */
+MTG_ILV(uint64_t, s_flrp1, c.o_flrp1)
+MTG_ILV(uint32_t, s_flra0, c.o_flra0)     /* nodes ahead of it inside its unitig */
+MTG_ILV(uint32_t, s_flra1, c.o_flra1)
+MTG_ILV(uint64_t, s_iflrp0, c.o_iflrp0)   /* the same for the nested frontline */
+MTG_ILV(uint64_t, s_iflrp1, c.o_iflrp1)
+MTG_ILV(uint32_t, s_iflra0, c.o_iflra0)
+MTG_ILV(uint32_t, s_iflra1, c.o_iflra1)
+MTG_ILV(uint64_t, s_dfsrp, c.o_dfsrp)     /* the same for the frames of the consensus enumeration */
+MTG_ILV(uint32_t, s_dfsra, c.o_dfsra)
 MTG_ILV(uint64_t, s_dfsf, c.o_dfsf)       /* consensus enumeration stack */
 MTG_ILV(uint64_t, s_dfsc, c.o_dfsc)
 MTG_ILV(uint8_t, s_dfsmask, c.o_dfsmask)
@@ -149,6 +159,17 @@ inline void finalize_cfg(FillCfg& c)
     c.o_cons = (uint32_t)b; b += align_up((uint64_t)CONS_CAP * CONS_LEN, 8);
     c.o_conslen = (uint32_t)b; b += align_up(2ull * CONS_CAP, 8);
     c.o_nw = (uint32_t)b; b += 4ull * 4 * (CONS_LEN + 1);
+    b = align_up(b, 8);
+    c.o_flrp0 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_flrp1 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_iflrp0 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_iflrp1 = (uint32_t)b; b += 8ull * FL_CAP;
+    c.o_dfsrp = (uint32_t)b; b += 8ull * DFS_CAP;
+    c.o_flra0 = (uint32_t)b; b += 4ull * FL_CAP;
+    c.o_flra1 = (uint32_t)b; b += 4ull * FL_CAP;
+    c.o_iflra0 = (uint32_t)b; b += 4ull * FL_CAP;
+    c.o_iflra1 = (uint32_t)b; b += 4ull * FL_CAP;
+    c.o_dfsra = (uint32_t)b; b += 4ull * DFS_CAP;
     c.ilv_stride = align_up(b, 8) * 64;
 }
 
@@ -312,11 +333,19 @@ MTG_DEV uint32_t aux_of_children(const Adj& a)
 MTG_DEV uint32_t aux_step(uint32_t aux) { return AUX_IN1 | ((aux & 15u) - 1u) | (((aux & 0x7FFFFFFFu) >> 6) << 4); }
 MTG_DEV uint64_t inv_flags(uint32_t aux) { return (aux & 15u) ? INV_SIMPLE : 0ull; }
 
+/* a node's place in the unitig store packed into one word: [valid:1][bwd:1][hdr:24 low bits of the header word, for the distinctness
+ * test only][kpos:38].  The header word itself is recovered where needed from kpos (not needed: only compared). */
+enum : uint64_t { RP_VALID = 1ull << 63, RP_BWD = 1ull << 62, RP_KPOS = (1ull << 38) - 1 };
+MTG_DEV uint64_t rp_pack(const RunAt& r) { return RP_VALID | (r.bwd ? RP_BWD : 0ull) | ((uint64_t)(r.hdr & 0xFFFFFFu) << 38) | (r.kpos & RP_KPOS); }
+MTG_DEV uint64_t rp_step(uint64_t rp, uint32_t t) { return (rp & ~RP_KPOS) | (((rp & RP_BWD) ? (rp & RP_KPOS) - t : (rp & RP_KPOS) + t) & RP_KPOS); }
+MTG_DEV uint32_t rp_unitig(uint64_t rp) { return (uint32_t)(rp >> 38) & 0xFFFFFFu; } /* 24 bits of the header word: equal unitigs give equal values (a false "equal" only costs speed) */
+
 /* [MEM] gatb FrontlineBranching::check: look for large in-branching at m.
  * dir: 0 = frontline moves along successors.  Only used with dir 0 on this path. */
 MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
 {
     const int k = W.k;
+    const UStore& us = W.ix.us;
     Kmer m = make_kmer(mf, k);
     Adj l = adj_left(W.ix, m, W.mk1, W.lines);
     /* gatb's "just a speedup": with in-degree 1 the only predecessor is the frontline node m was reached from, which is in the visited set */
@@ -325,30 +354,77 @@ MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
         if (!(l.in & (1u << nt))) continue;
         Kmer b = kmer_prev(m, nt, k, W.mk);
         if (set_has(s_seen(W.cfg, W.S), W.cfg.seen_cap, canon(b))) continue;
-        /* plain frontline from b along predecessors, previous node = m */
+        /* plain frontline from b along predecessors, previous node = m.  Unitig-aware like find_end_of_branching: walking backwards from
+         * a node = walking forwards from its reverse complement, whose right junction tells where it sits in the store; when every node
+         * of this frontline has two or more nodes of its unitig behind it, and they sit in pairwise different unitigs, the frontline moves
+         * by the smallest such distance (less one) at once -- it keeps its size, so only the depth limit can end it meanwhile. */
         W.iseen_add(canon(b));
         W.iseen_add(canon(m));
         int cur = 0, ncur = 1, depth = 0, remaining = 0;
         s_ifl0(W.cfg, W.S)[0] = b.f;
+        s_iflrp0(W.cfg, W.S)[0] = 0;
+        s_iflra0(W.cfg, W.S)[0] = 0;
         for (;;) {
             /* go_next_depth */
             bool cont = true;
             int nnext = 0;
             const SP<uint64_t> cf = cur ? s_ifl1(W.cfg, W.S) : s_ifl0(W.cfg, W.S);
             const SP<uint64_t> nf = cur ? s_ifl0(W.cfg, W.S) : s_ifl1(W.cfg, W.S);
+            const SP<uint64_t> crp = cur ? s_iflrp1(W.cfg, W.S) : s_iflrp0(W.cfg, W.S);
+            const SP<uint64_t> nrp = cur ? s_iflrp0(W.cfg, W.S) : s_iflrp1(W.cfg, W.S);
+            const SP<uint32_t> cra = cur ? s_iflra1(W.cfg, W.S) : s_iflra0(W.cfg, W.S);
+            const SP<uint32_t> nra = cur ? s_iflra0(W.cfg, W.S) : s_iflra1(W.cfg, W.S);
+            if (us.nwords && ncur >= 1 && ncur <= FL_CAP && depth > 0) {
+                uint32_t D = 0xFFFFFFFFu;
+                bool ok = true;
+                for (int i = 0; i < ncur && ok; i++) {
+                    const uint32_t ra = cra[i];
+                    if (!(crp[i] & RP_VALID) || ra < 2u) ok = false;
+                    else if (ra - 1u < D) D = ra - 1u;
+                    for (int j = 0; j < i && ok; j++) if (rp_unitig(crp[j]) == rp_unitig(crp[i])) ok = false;
+                }
+                if (ok) {
+                    if ((uint32_t)depth + D > 3u * (uint32_t)k) { remaining = ncur; break; } /* it would still be there when the depth limit ends the search */
+                    for (int i = 0; i < ncur; i++) {
+                        const uint64_t rp = crp[i];
+                        cf[i] = run_node(us, rp & RP_KPOS, (rp & RP_BWD) != 0, D, k).r; /* the store walk is that of the reverse complement */
+                        crp[i] = rp_step(rp, D);
+                        cra[i] = cra[i] - D;
+                    }
+                    W.lines += (uint32_t)ncur;
+                    depth += (int)D;
+                    remaining = ncur;
+                    continue;
+                }
+            }
             for (int i = 0; i < ncur && cont; i++) {
                 Kmer x = make_kmer(cf[i], k);
-                Adj xl = adj_left(W.ix, x, W.mk1, W.lines);
+                uint32_t in_mask;
+                uint64_t krp = 0;
+                uint32_t kra = 0;
+                const uint64_t rp = crp[i];
+                if ((rp & RP_VALID) && cra[i] >= 1u) {
+                    in_mask = 1u << (run_next_nt(us, rp & RP_KPOS, (rp & RP_BWD) != 0, k) ^ 2u); /* the reverse complement's next nucleotide, complemented */
+                    krp = rp_step(rp, 1);
+                    kra = cra[i] - 1u;
+                } else {
+                    Kmer xr;
+                    xr.f = x.r; xr.r = x.f;
+                    const Adj ar = adj_right_t(W.ix.adj, xr, W.mk1, W.lines); /* the same entry adj_left(x) reads */
+                    in_mask = comp_mask(ar.out);
+                    RunAt r;
+                    if (us.nwords && run_at(us, ar, k, r, W.lines)) { krp = rp_step(rp_pack(r), 1); kra = r.ahead - 1u; }
+                }
                 for (uint32_t n2 = 0; n2 < 4; n2++) {
-                    if (!(xl.in & (1u << n2))) continue;
+                    if (!(in_mask & (1u << n2))) continue;
                     Kmer y = kmer_prev(x, n2, k, W.mk);
                     uint64_t cy = canon(y);
                     if (set_has(s_iseen(W.cfg, W.S), W.cfg.iseen_cap, cy)) continue;
                     if (W.is_marked(cy)) { cont = false; remaining = ncur - i - 1; break; }
-                    if (nnext < FL_CAP) nf[nnext] = y.f;
+                    if (nnext < FL_CAP) { nf[nnext] = y.f; nrp[nnext] = krp; nra[nnext] = kra; }
                     nnext++;
                     W.iseen_add(cy);
-                    W.involve(cy);
+                    W.involve(cy | (((krp & RP_VALID) && kra >= 1u) ? INV_SIMPLE : 0ull));
                 }
             }
             if (!cont) break;
@@ -365,23 +441,83 @@ MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
     return true;
 }
 
-/* [MEM] MonumentTraversal::find_end_of_branching.  Returns depth (0 = failure). */
-MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_t prev_c, uint64_t& end_f)
+/* [MEM] MonumentTraversal::find_end_of_branching.  Returns depth (0 = failure).
+ *
+ * Unitig-aware: a frontline node whose right junction lies inside a stored unitig knows the nodes ahead of it (run_at); its child
+ * inherits the knowledge.  When EVERY node of the frontline (at least two) has two or more nodes of its unitig ahead, the frontline
+ * advances by D = the smallest such distance (less one: a unitig's last node is always reached level by level) in one go.  Nothing the
+ * reference does on those D levels can change the outcome: the nodes passed have one in- and one out-edge (no FrontlineBranching check, no
+ * node is ever marked: only branching nodes are), the frontline keeps its size, and the visited set would only matter if a node passed
+ * were met again -- a node inside a unitig is reached through the unitig alone, so that takes another node of the frontline travelling the
+ * same unitig (the other way), or the unitig of the node before the start (which is in the visited set from the beginning): the frontline
+ * only skips while its nodes sit in pairwise different unitigs, none of them the previous node's.  The nodes passed are not entered into
+ * the visited set or the involved list (of the involved nodes only the branching ones are marked afterwards).  prev_c == 0 (no previous
+ * node: gatb's default-constructed node, whose k-mer value 0 is a real k-mer) keeps the level-by-level search. */
+MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_t prev_c, uint64_t& end_f, uint64_t& end_rp)
 {
     const int k = W.k;
+    const UStore& us = W.ix.us;
     W.seen_add(canon(start));
     W.seen_add(prev_c);
     int cur = 0, ncur = 1, depth = 0;
     s_fl0(W.cfg, W.S)[0] = start.f;
     s_flnt0(W.cfg, W.S)[0] = 255;
     s_flaux0(W.cfg, W.S)[0] = 0;
+    s_flrp0(W.cfg, W.S)[0] = 0;
+    s_flra0(W.cfg, W.S)[0] = 0;
+    const bool may_skip = us.nwords != 0 && prev_c != 0;
+    uint32_t prev_unitig = 0xFFFFFFFFu; /* unitig of the junction between the previous node and the start, looked up when the first skip is considered */
+    bool prev_known = false;
     for (;;) {
         const SP<uint64_t> cf = cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S);
         const SP<uint8_t> cn = cur ? s_flnt1(W.cfg, W.S) : s_flnt0(W.cfg, W.S);
         const SP<uint32_t> ca = cur ? s_flaux1(W.cfg, W.S) : s_flaux0(W.cfg, W.S);
+        const SP<uint64_t> crp = cur ? s_flrp1(W.cfg, W.S) : s_flrp0(W.cfg, W.S);
+        const SP<uint32_t> cra = cur ? s_flra1(W.cfg, W.S) : s_flra0(W.cfg, W.S);
         const SP<uint64_t> nf = cur ? s_fl0(W.cfg, W.S) : s_fl1(W.cfg, W.S);
         const SP<uint8_t> nn = cur ? s_flnt0(W.cfg, W.S) : s_flnt1(W.cfg, W.S);
         const SP<uint32_t> na = cur ? s_flaux0(W.cfg, W.S) : s_flaux1(W.cfg, W.S);
+        const SP<uint64_t> nrp = cur ? s_flrp0(W.cfg, W.S) : s_flrp1(W.cfg, W.S);
+        const SP<uint32_t> nra = cur ? s_flra0(W.cfg, W.S) : s_flra1(W.cfg, W.S);
+        /* ---- the skip */
+        if (may_skip && ncur >= 2 && ncur <= FL_CAP && depth > 0) {
+            uint32_t D = 0xFFFFFFFFu;
+            bool ok = true;
+            for (int i = 0; i < ncur && ok; i++) {
+                const uint32_t ra = cra[i];
+                if (!(crp[i] & RP_VALID) || ra < 2u) ok = false;
+                else if (ra - 1u < D) D = ra - 1u;
+            }
+            if (ok) {
+                if (!prev_known) { /* the junction between the previous node and the start = the start's left junction */
+                    prev_known = true;
+                    const uint64_t pj = start.f >> 2, rpj = start.r & W.mk1;
+                    uint64_t aux;
+                    adj_get(W.ix.adj, pj <= rpj ? pj : rpj, W.lines, aux);
+                    if (up_is(aux)) prev_unitig = (uint32_t)up_hdr(aux) & 0xFFFFFFu;
+                }
+                for (int i = 0; i < ncur && ok; i++) {
+                    const uint32_t u = rp_unitig(crp[i]);
+                    if (u == prev_unitig) ok = false;
+                    for (int j = 0; j < i && ok; j++) if (rp_unitig(crp[j]) == u) ok = false;
+                }
+            }
+            if (ok) {
+                /* D levels at once; the frontline keeps its size (>= 2), so the only way out is the depth limit */
+                if ((uint32_t)depth + D > (uint32_t)W.cfg.mono_max_depth) return 0;
+                for (int i = 0; i < ncur; i++) {
+                    const uint64_t rp = crp[i];
+                    cf[i] = run_node(us, rp & RP_KPOS, (rp & RP_BWD) != 0, D, k).f;
+                    crp[i] = rp_step(rp, D);
+                    cra[i] = cra[i] - D;
+                    ca[i] = AUX_IN1;
+                }
+                W.lines += (uint32_t)ncur;
+                depth += (int)D;
+                continue;
+            }
+        }
+        /* ---- one level */
         int nnext = 0;
         for (int i = 0; i < ncur; i++) {
             const uint32_t aux = ca[i];
@@ -389,17 +525,32 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
             if (depth > 0 && !(aux & AUX_IN1) && !fl_check(W, cf[i])) return 0;
             Kmer x = make_kmer(cf[i], k);
             uint32_t out, kid;
-            if (aux & 15u) { out = 1u << ((aux >> 4) & 3u); kid = aux_step(aux); } /* the way ahead is known: nothing to read */
-            else { const Adj a = adj_right(W.ix, x, W.mk1, W.lines); out = a.out; kid = aux_of_children(a); }
+            uint64_t krp = 0; /* the children's place in the store, when the node's right junction lies inside a unitig */
+            uint32_t kra = 0;
+            const uint64_t rp = crp[i];
+            if ((rp & RP_VALID) && cra[i] >= 1u) { /* inside a unitig: the way ahead is known */
+                out = 1u << run_next_nt(us, rp & RP_KPOS, (rp & RP_BWD) != 0, k);
+                kid = AUX_IN1;
+                krp = rp_step(rp, 1);
+                kra = cra[i] - 1u;
+            } else if (aux & 15u) { out = 1u << ((aux >> 4) & 3u); kid = aux_step(aux); } /* inline lookahead: nothing to read */
+            else {
+                Adj a = adj_right_t(W.ix.adj, x, W.mk1, W.lines);
+                RunAt r;
+                if (run_at(us, a, k, r, W.lines)) { krp = rp_step(rp_pack(r), 1); kra = r.ahead - 1u; }
+                else adj_resolve_la(W.ix, a, W.lines);
+                out = a.out;
+                kid = aux_of_children(a);
+            }
             for (uint32_t nt = 0; nt < 4; nt++) {
                 if (!(out & (1u << nt))) continue;
                 Kmer y = kmer_next(x, nt, k, W.mk);
                 uint64_t cy = canon(y);
                 if (!W.seen_test_add(cy)) continue;  /* already explored (on failure below the whole set is discarded anyway) */
                 if (W.is_marked(cy)) return 0; /* bubble touches an assembled region */
-                if (nnext < FL_CAP) { nf[nnext] = y.f; nn[nnext] = (cn[i] == 255) ? (uint8_t)nt : cn[i]; na[nnext] = kid; }
+                if (nnext < FL_CAP) { nf[nnext] = y.f; nn[nnext] = (cn[i] == 255) ? (uint8_t)nt : cn[i]; na[nnext] = kid; nrp[nnext] = krp; nra[nnext] = kra; }
                 nnext++;
-                W.involve(cy | inv_flags(kid));
+                W.involve(cy | ((kid & 15u) || ((krp & RP_VALID) && kra >= 1u) ? INV_SIMPLE : 0ull));
             }
             if (W.status) return 0;
         }
@@ -414,6 +565,7 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
         }
     }
     end_f = (cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S))[0];
+    end_rp = (cur ? s_flrp1(W.cfg, W.S) : s_flrp0(W.cfg, W.S))[0];
     return depth;
 }
 
@@ -937,12 +1089,13 @@ MTG_UNROLL
 MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev_c, int& chosen)
 {
     W.n_inv = 0;
-    uint64_t end_f = 0;
+    uint64_t end_f = 0, end_rp = 0;
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     unsigned long long* stamp_acc = W.stamp_acc;
 #endif
     MTG_T0(t_fe);
-    int d = find_end_of_branching(W, cur, prev_c, end_f);
+    int d = find_end_of_branching(W, cur, prev_c, end_f, end_rp);
+    (void)end_rp;
     W.seen_clear();
     MTG_T1(t_fe, 2);
 #ifdef MTG_TRACE
