@@ -154,16 +154,35 @@ __global__ void k_count_stats(CountTable t, uint32_t keep_min, unsigned long lon
     for (uint32_t j = threadIdx.x; j < 256 && j < nbins; j += blockDim.x) if (lh[j]) atomicAdd(&histo[j], (unsigned long long)lh[j]);
     if (keep) atomicAdd(n_keep, keep);
 }
-__global__ void k_count_emit(CountTable t, uint32_t keep_min, uint64_t* out_k, uint32_t* out_c, unsigned long long* cursor)
+/* the solid k-mers of a count table (count in [lo, hi]) straight into the index tables; counters as k_insert_kmers */
+__global__ void k_insert_from_counts(Index ix, CountTable t, uint32_t lo, uint32_t hi, unsigned long long* counters)
 {
+    unsigned long long created = 0;
+    int fail = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t key = t.keys[i];
         if (key == ~0ULL) continue;
         const uint32_t c = t.counts[i];
-        if (c < keep_min) continue;
-        const unsigned long long o = atomicAdd(cursor, 1ull);
-        out_k[o] = key;
-        out_c[o] = c;
+        if (c < lo || c > hi) continue;
+        const int r = index_insert(ix, key, c);
+        fail |= r & 1;
+        created += (r >> 1) & 1;
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (created) atomicAdd(&counters[1], created);
+}
+/* lookaheads for every solid k-mer, read back from the ABND table (an index that was not built from a k-mer list) */
+__global__ void k_lookahead_table(Index ix)
+{
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        if (!abnd_slot_kmer(ix.abnd, s, c)) continue;
+        Kmer x = make_kmer(c, ix.k);
+        build_lookahead(ix, x);
+        Kmer y;
+        y.f = x.r; y.r = x.f;
+        build_lookahead(ix, y);
     }
 }
 
@@ -1490,73 +1509,130 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const u
     return MTG_OK;
 }
 
-/* Graph::create's counting step on the device.  The text is processed in P passes (k-mers are assigned to a pass by a hash) when one
- * count table for all of them would not fit; within a pass the text is uploaded in chunks overlapping by k-1 characters. */
-int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<uint64_t>& histo, std::vector<uint64_t>& kmers, std::vector<uint32_t>& counts)
+/* Graph::create on the device.  The reads arrive as text blocks (whole reads separated by '\n'); k-mers are counted in an exact
+ * open-addressing table, in P passes over the reads when one table for all k-mers would not fit (a k-mer belongs to the pass its hash
+ * selects).  Round 1: every pass feeds the abundance histogram, from which the cut-off comes (automatic: gatb's Histogram heuristic).
+ * Round 2: the solid k-mers go from the count table straight into the index tables (one pass: the table of round 1 is still there;
+ * several: the passes are counted again).  Then lookaheads and the unitig store, both from the index's own tables. */
+int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_max, mtg_index** out)
 {
     if (int rc = ensure_device()) return rc;
-    kmers.clear();
-    counts.clear();
-    if (n < (size_t)k) return MTG_OK;
+    if (k < 11 || k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    const uint32_t nbins = 10003; /* STR_HISTOGRAM_MAX 10000, src/Filler.cpp:200 */
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t chunk = std::min<size_t>(n, (size_t)1 << 28);
-    const uint32_t nbins = (uint32_t)histo.size();
-    const size_t budget = (size_t)((double)free_b * 0.6);
+    const size_t budget = (size_t)((double)free_b * 0.45); /* the index tables have to fit next to the count table */
+    const size_t n_hint = std::max<size_t>(rs.size_hint(), 1 << 16);
     /* distinct k-mers <= instances; start from instances / 4 slots in total (30x data has ~25 instances per distinct k-mer) and grow on
-     * overflow; the slots are split over P passes when one table would not fit (a k-mer belongs to the pass its hash selects) */
+     * overflow */
     uint64_t total_slots = 1ull << 16;
-    while (total_slots < n / 4) total_slots <<= 1;
-    uint32_t forced = getenv("MTG_COUNT_PASSES") ? (uint32_t)atoi(getenv("MTG_COUNT_PASSES")) : 0;
-    for (int attempt = 0; attempt < 8; attempt++, total_slots <<= 1) {
+    while (total_slots < n_hint / 4) total_slots <<= 1;
+    const uint32_t forced = getenv("MTG_COUNT_PASSES") ? (uint32_t)atoi(getenv("MTG_COUNT_PASSES")) : 0;
+    DevBuf d_text, d_flags, d_histo;
+    const size_t text_cap = (size_t)80 << 20;
+    HIP_TRY(d_text.alloc(text_cap));
+    HIP_TRY(d_flags.alloc(64));
+    HIP_TRY(d_histo.alloc((size_t)nbins * 8));
+    std::vector<uint64_t> histo(nbins, 0);
+    for (int attempt = 0; attempt < 10; attempt++, total_slots <<= 1) {
         uint32_t npass = 1;
-        while (total_slots / npass * 12 + chunk + (64u << 20) > budget && npass < 1024) npass <<= 1;
+        while (total_slots / npass * 12 + (64u << 20) > budget && npass < 1024) npass <<= 1;
         if (forced > npass) npass = forced;
         uint64_t cap = 1ull << 10;
         while (cap < total_slots / npass) cap <<= 1;
-        if (cap * 12 + chunk + (64u << 20) > free_b) { set_error("not enough device memory to count %zu k-mer instances", n); return MTG_ERR_NOMEM; }
-        DevBuf d_keys, d_cnts, d_text, d_flags, d_histo;
-        HIP_TRY(d_keys.alloc(cap * 8)); HIP_TRY(d_cnts.alloc(cap * 4)); HIP_TRY(d_text.alloc(chunk + 64)); HIP_TRY(d_flags.alloc(64)); HIP_TRY(d_histo.alloc((size_t)nbins * 8));
-        HIP_TRY(hipMemset(d_histo.p, 0, (size_t)nbins * 8));
+        if (cap * 12 + (64u << 20) > free_b) { set_error("not enough device memory to count the k-mers of the reads"); return MTG_ERR_NOMEM; }
+        DevBuf d_keys, d_cnts;
+        HIP_TRY(d_keys.alloc(cap * 8));
+        HIP_TRY(d_cnts.alloc(cap * 4));
         CountTable t;
         t.keys = d_keys.as<uint64_t>();
         t.counts = d_cnts.as<uint32_t>();
         t.mask = cap - 1;
-        kmers.clear();
-        counts.clear();
-        bool overflow = false;
-        for (uint32_t pass = 0; pass < npass && !overflow; pass++) {
+        /* one pass over the reads into the (cleared) table; returns 1 when the table overflowed */
+        auto count_pass = [&](uint32_t pass, bool& overflow) -> int {
             HIP_TRY(hipMemset(d_keys.p, 0xFF, cap * 8));
             HIP_TRY(hipMemset(d_cnts.p, 0, cap * 4));
             HIP_TRY(hipMemset(d_flags.p, 0, 64));
-            for (size_t off = 0; off < n;) {
-                const size_t len = std::min(chunk, n - off);
-                HIP_TRY(hipMemcpy(d_text.p, text + off, len, hipMemcpyHostToDevice));
-                hipLaunchKernelGGL(k_count, dim3(256 * 32), dim3(256), 0, 0, t, d_text.as<char>(), (uint64_t)len, k, npass, pass, d_flags.as<unsigned long long>());
-                HIP_TRY(hipDeviceSynchronize());
-                if (off + len >= n) break;
-                off += len - (size_t)(k - 1); /* the next chunk re-reads the last k-1 characters so that no window is lost */
+            if (!rs.rewind()) { set_error("cannot read the input again"); return MTG_ERR_IO; }
+            const char* p = nullptr;
+            size_t n = 0;
+            while (rs.next_block(p, n)) {
+                for (size_t off = 0; off < n;) { /* a block larger than the device buffer goes in pieces that overlap by k-1 characters */
+                    const size_t len = std::min(text_cap - 64, n - off);
+                    HIP_TRY(hipMemcpy(d_text.p, p + off, len, hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(k_count, dim3(256 * 32), dim3(256), 0, 0, t, d_text.as<char>(), (uint64_t)len, k, npass, pass, d_flags.as<unsigned long long>());
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipDeviceSynchronize());
+                    if (off + len >= n) break;
+                    off += len - (size_t)(k - 1);
+                }
             }
+            if (rs.failed()) return MTG_ERR_IO;
             unsigned long long flags[8];
             HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
-            if (flags[0]) { overflow = true; break; } /* table too full: double the slots and start over */
-            hipLaunchKernelGGL(k_count_stats, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_histo.as<unsigned long long>(), nbins, d_flags.as<unsigned long long>() + 1);
-            HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
-            const size_t nk = (size_t)flags[1];
-            DevBuf d_ok, d_oc;
-            HIP_TRY(d_ok.alloc(nk * 8)); HIP_TRY(d_oc.alloc(nk * 4));
-            hipLaunchKernelGGL(k_count_emit, dim3(256 * 16), dim3(256), 0, 0, t, keep_min, d_ok.as<uint64_t>(), d_oc.as<uint32_t>(), d_flags.as<unsigned long long>() + 2);
+            overflow = flags[0] != 0;
+            return MTG_OK;
+        };
+        /* round 1: the histogram */
+        HIP_TRY(hipMemset(d_histo.p, 0, (size_t)nbins * 8));
+        bool overflow = false;
+        for (uint32_t pass = 0; pass < npass && !overflow; pass++) {
+            if (int rc = count_pass(pass, overflow)) return rc;
+            if (overflow) break; /* table too full: double the slots and start over */
+            hipLaunchKernelGGL(k_count_stats, dim3(256 * 16), dim3(256), 0, 0, t, 0u, d_histo.as<unsigned long long>(), nbins, d_flags.as<unsigned long long>() + 1);
             HIP_TRY(hipGetLastError());
-            const size_t base = kmers.size();
-            kmers.resize(base + nk);
-            counts.resize(base + nk);
-            if (nk) {
-                HIP_TRY(hipMemcpy(kmers.data() + base, d_ok.p, nk * 8, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(counts.data() + base, d_oc.p, nk * 4, hipMemcpyDeviceToHost));
-            }
         }
         if (overflow) continue;
         HIP_TRY(hipMemcpy(histo.data(), d_histo.p, (size_t)nbins * 8, hipMemcpyDeviceToHost));
+        int autoc = -1;
+        if (abundance_min < 0) { autoc = auto_cutoff(histo, 3); abundance_min = autoc; } /* auto never goes below 3 (src/Filler.cpp:201) */
+        const uint32_t lo = (uint32_t)std::max(abundance_min, 1), hi = abundance_max > 0 ? (uint32_t)abundance_max : 0xFFFFFFFFu;
+        uint64_t n_solid = 0;
+        for (uint32_t c = lo; c < nbins; c++) if (c <= hi || c == nbins - 1) n_solid += histo[c]; /* the last bin holds every larger count */
+        /* round 2: the index */
+        IndexGuard g(new mtg_index());
+        mtg_index* idx = g.idx;
+        idx->dev.k = k;
+        HIP_TRY(hipGetDevice(&idx->device));
+        DevBuf d_cnt;
+        HIP_TRY(d_cnt.alloc(32));
+        double load = 1.0;
+        int rc = MTG_OK;
+        for (int ia = 0; ia < 6; ia++) {
+            free_tables(idx);
+            rc = alloc_tables(idx, n_solid, load);
+            if (rc) return rc;
+            HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+            for (uint32_t pass = 0; pass < npass; pass++) {
+                if (npass > 1) { /* the table of the wanted pass has to be counted again (with one pass it still holds round 1's counts) */
+                    bool ovf2 = false;
+                    if (int rc2 = count_pass(pass, ovf2)) return rc2;
+                    if (ovf2) { set_error("k-mer count table overflowed on a repeated pass"); return MTG_ERR_OVERFLOW; }
+                }
+                hipLaunchKernelGGL(k_insert_from_counts, dim3(256 * 16), dim3(256), 0, 0, idx->dev, t, lo, hi, d_cnt.as<unsigned long long>());
+                HIP_TRY(hipGetLastError());
+            }
+            unsigned long long cnt[4];
+            HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+            if (!cnt[0]) { rc = MTG_OK; break; }
+            load *= 0.7;
+            rc = MTG_ERR_OVERFLOW;
+            set_error("index bucket displacement overflow");
+        }
+        if (rc) return rc;
+        (void)d_keys.alloc(0); /* the count table is done with: room for the unitig construction */
+        (void)d_cnts.alloc(0);
+        {
+            const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+            hipLaunchKernelGGL(k_lookahead_table, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        if (int rc2 = build_unitigs(idx)) return rc2;
+        idx->info.k = k;
+        idx->info.abundance_min = abundance_min;
+        idx->info.abundance_auto = autoc;
+        *out = g.release();
         return MTG_OK;
     }
     set_error("k-mer count table kept overflowing");

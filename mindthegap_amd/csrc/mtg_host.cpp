@@ -82,7 +82,7 @@ static inline bool nt_bad(unsigned char c) { return (c >> 3) & 1; } /* gatb: bit
 
 /* gatb's automatic solidity cut-off, restated: smoothed histogram, first minimum, coverage peak,
  * arg-min between; floor 3 (src/Filler.cpp:201).  One golden datapoint: 7 (test/full_test/gold_fill.output:11). */
-static int auto_cutoff(const std::vector<uint64_t>& h, int floor_thr)
+int auto_cutoff(const std::vector<uint64_t>& h, int floor_thr)
 {
     const size_t len = h.size();
     if (len < 5) return floor_thr;
@@ -104,11 +104,90 @@ struct HostIndexData {
     std::vector<uint32_t> counts;
 };
 
+/* FASTA / FASTQ (.gz) records of a list of files, one after the other, as text blocks for the device */
+namespace {
+struct FileReadStream : ReadStream {
+    std::vector<std::string> paths;
+    size_t cur = 0;
+    gzFile f = nullptr;
+    bool bad = false;
+    std::string block, line, bad_path;
+    std::vector<char> buf;
+    size_t hint = 0;
+    bool have_line = false; /* `line` holds a line that has been read ahead */
+    enum { BLOCK = 64 << 20 };
+    explicit FileReadStream(const std::vector<std::string>& p) : paths(p), buf(1 << 16)
+    {
+        for (const std::string& q : paths) {
+            FILE* t = fopen(q.c_str(), "rb");
+            if (!t) continue;
+            fseek(t, 0, SEEK_END);
+            const long sz = ftell(t);
+            fclose(t);
+            const bool gz = q.size() > 3 && q.compare(q.size() - 3, 3, ".gz") == 0;
+            hint += (size_t)std::max(0L, sz) * (gz ? 4 : 1);
+        }
+    }
+    ~FileReadStream() override { if (f) gzclose(f); }
+    bool rewind() override
+    {
+        if (f) { gzclose(f); f = nullptr; }
+        cur = 0;
+        bad = false;
+        have_line = false;
+        return true;
+    }
+    bool failed() const override { return bad; }
+    size_t size_hint() const override { return hint; }
+    bool getl()
+    {
+        line.clear();
+        bool got = false;
+        while (gzgets(f, buf.data(), (int)buf.size())) {
+            got = true;
+            size_t n = strlen(buf.data());
+            if (n && buf[n - 1] == '\n') {
+                line.append(buf.data(), n - 1);
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                return true;
+            }
+            line.append(buf.data(), n);
+        }
+        return got;
+    }
+    bool next_block(const char*& p, size_t& n) override
+    {
+        block.clear();
+        while (block.size() < (size_t)BLOCK) {
+            if (!f) {
+                if (cur >= paths.size()) break;
+                f = gzopen(paths[cur].c_str(), "rb");
+                if (!f) { bad = true; bad_path = paths[cur]; return false; }
+                gzbuffer(f, 1 << 20);
+                have_line = getl();
+            }
+            if (!have_line) { gzclose(f); f = nullptr; cur++; continue; }
+            if (!line.empty() && line[0] == '>') { /* FASTA record: the following lines up to the next header */
+                while ((have_line = getl()) && (line.empty() || line[0] != '>')) block += line;
+                block += '\n';
+            } else if (!line.empty() && line[0] == '@') { /* FASTQ record: sequence, '+', qualities */
+                if ((have_line = getl())) { block += line; block += '\n'; }
+                have_line = getl();
+                have_line = getl();
+                have_line = getl();
+            } else have_line = getl();
+        }
+        p = block.data();
+        n = block.size();
+        return n > 0;
+    }
+};
+} // namespace
+
 int index_from_reads(const char* paths_csv, int k, int abundance_min, int abundance_max, mtg_index** out)
 {
     if (!paths_csv || !out || k < 11 || k > 31) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    /* the reads, concatenated with '\n' separators (an invalid character by gatb's rule, so no k-mer spans two reads) */
-    std::string text;
+    std::vector<std::string> paths;
     std::string csv(paths_csv);
     size_t pos = 0;
     while (pos <= csv.size()) {
@@ -116,35 +195,13 @@ int index_from_reads(const char* paths_csv, int k, int abundance_min, int abunda
         if (e == std::string::npos) e = csv.size();
         std::string path = csv.substr(pos, e - pos);
         pos = e + 1;
-        if (path.empty()) continue;
-        std::vector<std::pair<std::string, std::string>> recs;
-        if (!read_sequences(path, recs)) { set_error("cannot read %s", path.c_str()); return MTG_ERR_IO; }
-        size_t add = 0;
-        for (auto& r : recs) add += r.second.size() + 1;
-        text.reserve(text.size() + add);
-        for (auto& r : recs) { text += r.second; text += '\n'; }
+        if (!path.empty()) paths.push_back(path);
     }
-    /* counting on the device (k_count); sum solidity over all files (STR_SOLIDITY_KIND "sum", src/Filler.cpp:177) */
-    std::vector<uint64_t> histo(10003, 0); /* STR_HISTOGRAM_MAX 10000, src/Filler.cpp:200 */
-    HostIndexData cand;
-    const uint32_t keep_min = abundance_min < 0 ? 3u : (uint32_t)std::max(abundance_min, 1); /* auto never goes below 3 (src/Filler.cpp:201) */
-    int rc = count_run(text.data(), text.size(), k, keep_min, histo, cand.kmers, cand.counts);
-    if (rc) return rc;
-    std::string().swap(text);
-    int autoc = -1;
-    if (abundance_min < 0) { autoc = auto_cutoff(histo, 3); abundance_min = autoc; }
-    /* deterministic container: sort the candidates by k-mer */
-    std::vector<size_t> order(cand.kmers.size());
-    for (size_t i = 0; i < order.size(); i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cand.kmers[a] < cand.kmers[b]; });
-    HostIndexData hd;
-    for (size_t i : order)
-        if ((int64_t)cand.counts[i] >= abundance_min && (abundance_max <= 0 || (int64_t)cand.counts[i] <= abundance_max)) { hd.kmers.push_back(cand.kmers[i]); hd.counts.push_back(cand.counts[i]); }
-    rc = index_from_kmers(hd.kmers.data(), hd.counts.data(), hd.kmers.size(), k, out);
-    if (rc) return rc;
-    (*out)->info.abundance_min = abundance_min;
-    (*out)->info.abundance_auto = autoc;
-    return MTG_OK;
+    /* sum solidity over all files (STR_SOLIDITY_KIND "sum", src/Filler.cpp:177): the files are one stream of reads */
+    FileReadStream rs(paths);
+    const int rc = index_from_stream(rs, k, abundance_min, abundance_max, out);
+    if (rs.failed()) { set_error("cannot read %s", rs.bad_path.c_str()); return MTG_ERR_IO; }
+    return rc;
 }
 
 static const char IDX_MAGIC[8] = {'M', 'T', 'G', 'I', 'D', 'X', '1', 0};

@@ -484,9 +484,20 @@ void batch_release_device(FillInput& in);
 int scan_run(const mtg_index* idx, const uint64_t* words, size_t nwords, const uint64_t* word_off, const uint32_t* len, size_t nseq, int mode, uint64_t* out_bits, int device_ptrs,
              mtg_scan_stats* st);
 
-/* counts the canonical k-mers of `text` (sequences separated by '\n'): histo[c] = number of distinct k-mers seen c times (c capped at
- * histo.size()-1), kmers/counts = the distinct k-mers seen at least keep_min times (unordered) */
-int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<uint64_t>& histo, std::vector<uint64_t>& kmers, std::vector<uint32_t>& counts);
+/* The reads of Graph::create as a stream of text blocks: whole sequences separated by '\n' (an invalid character by gatb's rule, so no k-mer
+ * spans two reads), at most a few hundred MB each; rewind() starts over (the counting may need several passes over the reads). */
+struct ReadStream {
+    virtual ~ReadStream() {}
+    virtual bool rewind() = 0;
+    virtual bool next_block(const char*& p, size_t& n) = 0; /* false: end of the reads (or an error: failed() tells) */
+    virtual bool failed() const = 0;
+    virtual size_t size_hint() const = 0; /* rough number of characters in all */
+};
+/* Graph::create (src/Filler.cpp:172-213) on the device: exact k-mer counts (DSK's role), abundance histogram, solidity cut-off
+ * (abundance_min < 0: automatic, floor 3), solid k-mers straight from the count table into the index tables, lookaheads, unitig store.
+ * No k-mer list ever exists on the host. */
+int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_max, mtg_index** out);
+int auto_cutoff(const std::vector<uint64_t>& histo, int floor_thr);
 
 /* Needleman-Wunsch of src/Utils.cpp:87-189 (match +10, mismatch -5, gap -5; traceback preference diagonal, up, left) for a batch of
  * sequence pairs: matches[p] = number of matching positions along the traceback of pair p (a = rows, b = columns) */

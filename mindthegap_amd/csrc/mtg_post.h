@@ -125,6 +125,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     /* find_nodes_containing_multiple_R: the scan keeps the first (position-major, target-minor) occurrence of the best match count
      * >= k - nb_mis and stops at the first exact match (src/Filler.cpp:1341-1351); an exact match is the largest possible count, so the
      * result is the first occurrence of the maximum: an arg-max, evaluated here by all lanes at once. */
+    const uint64_t le0 = T.n ? T.le[0] : 0ull, bad0 = T.n ? T.bad[0] : ~0ull;
     for (uint32_t c = 0; c < ((dbg & 2u) ? 0u : o.n_contigs); c++) {
         const uint32_t L = clen[c];
         const uint64_t* w = words + cstart[c];
@@ -146,8 +147,9 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                     if (j < j_hi) {
                         const uint64_t x = le_kmer(tile, j - j_lo, mk);
                         for (uint32_t t = 0; t < T.n; t++) {
-                            const uint64_t m = x ^ T.le[t];
-                            const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
+                            /* the first target from registers (breakpoint mode has one), the others from memory */
+                            const uint64_t m = x ^ (t == 0 ? le0 : T.le[t]);
+                            const uint64_t mism = ((m | (m >> 1)) & lsb) | (t == 0 ? bad0 : T.bad[t]);
 #ifdef MTG_EMU
                             const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
 #else

@@ -92,28 +92,39 @@ int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* a
     return MTG_OK;
 }
 
-int count_run(const char* text, size_t n, int k, uint32_t keep_min, std::vector<uint64_t>& histo, std::vector<uint64_t>& kmers, std::vector<uint32_t>& counts)
+/* stand-in for index_from_stream: the same count table and insertion functions, one pass, on the host */
+int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_max, mtg_index** out)
 {
-    kmers.clear();
-    counts.clear();
-    if (n < (size_t)k) return MTG_OK;
+    if (k < 11 || k > 31) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
     uint64_t cap = 1ull << 10;
-    while (cap < n / 4) cap <<= 1;
+    while (cap < std::max<size_t>(rs.size_hint(), 1 << 12) / 4) cap <<= 1;
+    std::vector<uint64_t> histo(10003, 0);
     for (;; cap <<= 1) {
         std::vector<uint64_t> keys(cap, ~0ULL);
         std::vector<uint32_t> cnts(cap, 0);
         CountTable t{keys.data(), cnts.data(), cap - 1};
         bool full = false;
-        for (size_t i = 0; i + k <= n && !full; i++) {
-            const uint64_t c = kmer_from_ascii(text, i, k);
-            if (c != ~0ULL && !count_insert(t, c)) full = true;
-        }
+        if (!rs.rewind()) return MTG_ERR_IO;
+        const char* p = nullptr;
+        size_t n = 0;
+        while (!full && rs.next_block(p, n))
+            for (size_t i = 0; i + k <= n && !full; i++) {
+                const uint64_t c = kmer_from_ascii(p, i, k);
+                if (c != ~0ULL && !count_insert(t, c)) full = true;
+            }
+        if (rs.failed()) return MTG_ERR_IO;
         if (full) continue;
-        for (uint64_t i = 0; i < cap; i++) {
-            if (keys[i] == ~0ULL) continue;
-            histo[std::min<size_t>(cnts[i], histo.size() - 1)]++;
-            if (cnts[i] >= keep_min) { kmers.push_back(keys[i]); counts.push_back(cnts[i]); }
-        }
+        std::fill(histo.begin(), histo.end(), 0);
+        for (uint64_t i = 0; i < cap; i++) if (keys[i] != ~0ULL) histo[std::min<size_t>(cnts[i], histo.size() - 1)]++;
+        int autoc = -1;
+        if (abundance_min < 0) { autoc = auto_cutoff(histo, 3); abundance_min = autoc; }
+        std::vector<uint64_t> km;
+        std::vector<uint32_t> ct;
+        for (uint64_t i = 0; i < cap; i++)
+            if (keys[i] != ~0ULL && (int64_t)cnts[i] >= std::max(abundance_min, 1) && (abundance_max <= 0 || (int64_t)cnts[i] <= abundance_max)) { km.push_back(keys[i]); ct.push_back(cnts[i]); }
+        if (int rc = index_from_kmers(km.data(), ct.data(), km.size(), k, out)) return rc;
+        (*out)->info.abundance_min = abundance_min;
+        (*out)->info.abundance_auto = autoc;
         return MTG_OK;
     }
 }
