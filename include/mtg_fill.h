@@ -55,6 +55,8 @@ typedef struct mtg_index_info {
     uint32_t bloom_minimizer;   /* minimizer length selecting the block */
     uint64_t nb_unitigs;        /* maximal simple paths (>= 2 k-mers) held in the unitig store */
     uint64_t unitig_bytes;      /* HBM held by the unitig store (2-bit sequences + one abundance byte per k-mer) */
+    uint64_t nb_saturated;      /* solid k-mers whose abundance exceeds 255 and is stored as 255 (gatb reports discretised values above ~70:
+                                   coverage statistics of very deep regions may differ from the reference's) */
 } mtg_index_info;
 
 /* Graph::create(props) from read files (src/Filler.cpp:172-213): paths_csv = comma separated FASTA/FASTQ(.gz);

@@ -509,6 +509,9 @@ int fill_main(int argc, const char* const* argv)
     }
     if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); return 1; }
     const int k = idx->info.k;
+    if (idx->info.nb_saturated)
+        fprintf(stderr, "Warning : %llu solid k-mers are more abundant than 255 and are stored as 255 (coverage statistics of such regions may differ from gatb's discretised values)\n",
+                (unsigned long long)idx->info.nb_saturated);
     const bool bkpt_mode = !O.bkpt.empty();
     Files F;
     const std::string insert_name = O.out + ".insertions.fasta", info_name = O.out + ".info.txt", vcf_name = O.out + ".insertions.vcf", gfa_name = O.out + ".gfa",

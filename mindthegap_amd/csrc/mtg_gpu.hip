@@ -79,15 +79,17 @@ __global__ void k_insert_kmers(Index ix, const uint64_t* __restrict__ kmers, con
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    unsigned long long created = 0;
+    unsigned long long created = 0, sat = 0;
     int fail = 0;
     for (; i < n; i += stride) {
         int r = index_insert(ix, kmers[i], ab[i]);
         fail |= r & 1;
         created += (r >> 1) & 1;
+        sat += ab[i] > 255u;
     }
     if (fail) atomicOr(&counters[0], 1ull);
     if (created) atomicAdd(&counters[1], created);
+    if (sat) atomicAdd(&counters[3], sat); /* abundances stored as 255 */
 }
 
 /* one workgroup per sequence; lanes stride over k-mer start positions */
@@ -157,7 +159,7 @@ __global__ void k_count_stats(CountTable t, uint32_t keep_min, unsigned long lon
 /* the solid k-mers of a count table (count in [lo, hi]) straight into the index tables; counters as k_insert_kmers */
 __global__ void k_insert_from_counts(Index ix, CountTable t, uint32_t lo, uint32_t hi, unsigned long long* counters)
 {
-    unsigned long long created = 0;
+    unsigned long long created = 0, sat = 0;
     int fail = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t key = t.keys[i];
@@ -167,9 +169,11 @@ __global__ void k_insert_from_counts(Index ix, CountTable t, uint32_t lo, uint32
         const int r = index_insert(ix, key, c);
         fail |= r & 1;
         created += (r >> 1) & 1;
+        sat += c > 255u;
     }
     if (fail) atomicOr(&counters[0], 1ull);
     if (created) atomicAdd(&counters[1], created);
+    if (sat) atomicAdd(&counters[3], sat);
 }
 /* lookaheads for every solid k-mer, read back from the ABND table (an index that was not built from a k-mer list) */
 __global__ void k_lookahead_table(Index ix)
@@ -835,6 +839,7 @@ int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, siz
         }
         unsigned long long cnt[4];
         HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+        idx->info.nb_saturated = cnt[3];
         if (!cnt[0]) {
             for (size_t off = 0; off < n; off += piece) { /* lookaheads need every k-mer in place: a second sweep over the pieces */
                 const size_t m = std::min(piece, n - off);
@@ -1614,6 +1619,7 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
             }
             unsigned long long cnt[4];
             HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+            idx->info.nb_saturated = cnt[3];
             if (!cnt[0]) { rc = MTG_OK; break; }
             load *= 0.7;
             rc = MTG_ERR_OVERFLOW;

@@ -45,7 +45,9 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
         idx->dev.bloom.bits = (uint32_t*)calloc(idx->dev.bloom.nblocks * 16, 4);
         int fail = 0;
         uint64_t created = 0;
-        for (size_t i = 0; i < n; i++) { int r = index_insert(idx->dev, kmers[i], ab[i]); fail |= r & 1; created += (r >> 1) & 1; }
+        uint64_t sat = 0;
+        for (size_t i = 0; i < n; i++) { int r = index_insert(idx->dev, kmers[i], ab[i]); fail |= r & 1; created += (r >> 1) & 1; sat += ab[i] > 255u; }
+        idx->info.nb_saturated = sat;
         if (!fail) {
             for (size_t i = 0; i < n; i++) { Kmer x = make_kmer(kmers[i], k); build_lookahead(idx->dev, x); Kmer y; y.f = x.r; y.r = x.f; build_lookahead(idx->dev, y); }
             uint64_t nbr = 0, mk1 = kmask(k - 1);

@@ -675,6 +675,7 @@ def test_index_container_written_from_the_tables(emu_product, tmp_path):
         o = oracle_lib.Index.from_sequences(seqs + [seqs[0][:200]] * 300, k, 1, 40)  # multiplicities: abundances up to the 8-bit ceiling
         km, ct = o.export()
         g = emu_product.Index.from_kmers(km, ct, k)
+        assert g.info()["nb_saturated"] == int((ct > 255).sum()) > 0  # counts above the 8-bit ceiling are reported, not silently clamped
         p = str(tmp_path / ("i%d.mtgidx" % k))
         g.save(p)
         raw = open(p, "rb").read()
