@@ -672,10 +672,12 @@ def test_index_container_written_from_the_tables(emu_product, tmp_path):
     rng = random.Random(8)
     for k in (31, 21, 12):
         seqs = [_rand_seq(rng, rng.randrange(k, 900)) for _ in range(6)]
-        o = oracle_lib.Index.from_sequences(seqs + [seqs[0][:200]] * 300, k, 1, 40)  # multiplicities: abundances up to the 8-bit ceiling
+        o = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
         km, ct = o.export()
+        ct = ct.copy()
+        ct[::7] = 250 + (np.arange(len(ct[::7])) % 400).astype(ct.dtype)  # abundances up to and beyond the 8-bit ceiling
         g = emu_product.Index.from_kmers(km, ct, k)
-        assert g.info()["nb_saturated"] == int((ct > 255).sum()) > 0  # counts above the 8-bit ceiling are reported, not silently clamped
+        assert g.info()["nb_saturated"] == int((ct > 255).sum()) > 0  # counts above the ceiling are reported, not silently clamped
         p = str(tmp_path / ("i%d.mtgidx" % k))
         g.save(p)
         raw = open(p, "rb").read()
