@@ -418,3 +418,20 @@ def random_line_ceiling(table_bytes, n_chains, chain_len, line_bytes=64):
     ms, gbps = C.c_double(), C.c_double()
     _check(load_library().mtg_bench_random_lines(table_bytes, n_chains, chain_len, line_bytes, C.byref(ms), C.byref(gbps)))
     return ms.value, gbps.value
+
+
+class Filler:
+    """The reference's tool object (src/Filler.hpp) as the tests and the Python callers see it: `run(argv)` takes the reference's own option
+    strings (src/Filler.cpp:76-113) and writes the same files; `gap_fill_from_source` is Filler::gapFillFromSource (src/Filler.hpp:188-189)
+    for a batch of gaps."""
+    STR_URI_BKPT, STR_URI_CONTIG, STR_URI_GRAPH, STR_URI_INPUT, STR_URI_OUTPUT = "-bkpt", "-contig", "-graph", "-in", "-out"
+    STR_MAX_DEPTH, STR_MAX_NODES, STR_CONTIG_OVERLAP, STR_FILTER, STR_FWD_ONLY, STR_EXTEND = "-max-length", "-max-nodes", "-overlap", "-filter", "-fwd-only", "-extend"
+    nb_mis_allowed = 2  # src/Filler.cpp:56
+
+    def run(self, argv):
+        """`MindTheGap fill <argv>`; returns the exit code (0 / 1)"""
+        return fill_main(list(argv))
+
+    def gap_fill_from_source(self, index, gaps, max_nodes=100, max_depth=10000):
+        """gaps: iterable of Gap; returns the per-gap result dicts of Index.fill_batch"""
+        return index.fill_batch(list(gaps), FillParams(max_nodes=max_nodes, max_depth=max_depth, nb_mis_allowed=self.nb_mis_allowed))
