@@ -176,7 +176,7 @@ def main():
 
     pg = None  # N > 1: pipelined gather of every batch's sequences on rank 0 (created after the first, untimed, pass)
     acc = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
-               post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, gaps=0)
+               post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, gaps=0)
     acc_lock = threading.Lock()
 
     def fill(b, prepared=None, want_seqs=False, record=False):
@@ -406,13 +406,19 @@ def main():
         return {"kernel": name, "bound": "hbm", "avg_kernel_ms": ms / L, "bytes_per_launch": bytes_per_launch, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "bytes_breakdown": parts}
 
-    sa_parts = {"adj_bucket_reads_x_%dB" % bucket: acc["index_lines"] / L * bucket, "unitig_headers_x_8B": acc["store_runs"] / L * 8, "unitig_sequence_2bit": acc["run_nt"] / L / 4,
-                "contig_words_written_x_8B": acc["contig_words"] / L * 8, "per_gap_input_and_record": gaps_l * (8 + 8 + 4 + 4 + 16 + 28)}
+    # k_stage_a: one 8-byte word per counted store read (unitig headers, the short reads around a long run), the nucleotides the lanes take out of the
+    # store themselves, the contig words the lanes write, one 16-byte command per run left to k_copy; k_copy: every word once in, once out
+    lane_nt = max(acc["run_nt"] - 32 * acc["copy_words"], 0)
+    sa_parts = {"adj_bucket_reads_x_%dB" % bucket: acc["index_lines"] / L * bucket, "unitig_store_word_reads_x_8B": acc["store_runs"] / L * 8, "unitig_sequence_2bit_taken_by_lanes": lane_nt / L / 4,
+                "contig_words_written_by_lanes_x_8B": (acc["contig_words"] - acc["copy_words"]) / L * 8, "copy_commands_x_16B": acc["copy_cmds"] / L * 16,
+                "per_gap_input_and_record": gaps_l * (8 + 8 + 4 + 4 + 16 + 36)}
+    cp_parts = {"unitig_words_read_x_8B": (acc["copy_words"] + acc["copy_cmds"]) / L * 8, "contig_words_written_x_8B": acc["copy_words"] / L * 8, "copy_commands_x_16B": acc["copy_cmds"] / L * 16,
+                "per_gap_record": gaps_l * 36}
     po_parts = {"contig_words_scanned_x_8B": acc["contig_words"] / L * 8, "bucket_reads_x_32B": acc["post_lines"] / L * 32,
-                "coverage_abundance_bytes_and_kmer_check": acc["coverage_kmers"] / L * (1 + 0.25 * (1 + k / 64.0)), "per_gap_record_and_targets": gaps_l * (28 + 128 + 16 + 2 * 128)}
-    em_parts = {"ascii_written": acc["seq_bytes"] / L, "contig_2bit_read": acc["seq_bytes"] / L / 4, "per_gap_records": gaps_l * (128 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / L * 16}
-    kerns = [kern("k_stage_a", acc["kernel_ms"], sum(sa_parts.values()), sa_parts), kern("k_post(+k_scan1,k_scan2)", acc["post_kernel_ms"], sum(po_parts.values()), po_parts),
-             kern("k_emit", acc["emit_kernel_ms"], sum(em_parts.values()), em_parts)]
+                "coverage_abundance_bytes_and_kmer_check": acc["coverage_kmers"] / L * (1 + 0.25 * (1 + k / 64.0)), "per_gap_record_and_targets": gaps_l * (36 + 136 + 16 + 2 * 128)}
+    em_parts = {"ascii_written": acc["seq_bytes"] / L, "contig_2bit_read": acc["seq_bytes"] / L / 4, "per_gap_records": gaps_l * (136 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / L * 16}
+    kerns = [kern("k_stage_a", acc["kernel_ms"], sum(sa_parts.values()), sa_parts), kern("k_copy", acc["copy_kernel_ms"], sum(cp_parts.values()), cp_parts),
+             kern("k_post(+k_scan1,k_scan2)", acc["post_kernel_ms"], sum(po_parts.values()), po_parts), kern("k_emit", acc["emit_kernel_ms"], sum(em_parts.values()), em_parts)]
     dom = max(kerns, key=lambda x: x["avg_kernel_ms"])
     roof = dict(dom)
     roof["kernels"] = kerns
@@ -431,7 +437,7 @@ def main():
                                               "equivalent_GBps_of_k_stage_a": 64.0 * probes_per_nt * acc["contig_nt"] / L / max(acc["kernel_ms"] / L * 1e-3, 1e-12) / 1e9}
     roof["pcie"] = {"result_bytes_per_launch": acc["seq_bytes"] / L + gaps_l * (56 + 40), "note": "records and ASCII sequences are copied to page-locked host memory inside every step"}
     if st_alone:
-        roof["one_batch_alone_ms"] = {"k_stage_a": st_alone["kernel_ms"] / max(st_alone["n_launches"], 1), "k_post+scans": st_alone["post_kernel_ms"] / max(st_alone["n_launches"], 1),
+        roof["one_batch_alone_ms"] = {"k_stage_a": st_alone["kernel_ms"] / max(st_alone["n_launches"], 1), "k_copy": st_alone["copy_kernel_ms"] / max(st_alone["n_launches"], 1), "k_post+scans": st_alone["post_kernel_ms"] / max(st_alone["n_launches"], 1),
                                       "k_emit": st_alone["emit_kernel_ms"] / max(st_alone["n_launches"], 1)}
     if not a.no_ceiling:
         tb = min(int(info["device_bytes"] // 2), 16 << 30)  # the ceiling is flat beyond ~16 GB (profiles/r01_random_line_ceiling.txt)
@@ -450,7 +456,7 @@ def main():
                             "ms_per_step_median": elapsed / a.steps * 1e3, "ms_per_step_max": max(times) / a.steps * 1e3, "timed_seconds_total": sum(times)},
            "filled": n_filled_all, "sites_verified": n_sites_all, "filled_per_s": value * n_filled_all / max(n_sites_all, 1),
            "filled_sequences_identical_to_truth": identical, "gathered_payload_verified": gathered_ok,
-           "stage_ms_per_batch": {"k_stage_a": acc["kernel_ms"] / L, "k_post+scans": acc["post_kernel_ms"] / L, "k_emit": acc["emit_kernel_ms"] / L, "d2h": acc["d2h_ms"] / L,
+           "stage_ms_per_batch": {"k_stage_a": acc["kernel_ms"] / L, "k_copy": acc["copy_kernel_ms"] / L, "k_post+scans": acc["post_kernel_ms"] / L, "k_emit": acc["emit_kernel_ms"] / L, "d2h": acc["d2h_ms"] / L,
                                   "host": acc["host_ms"] / L, "c_call": acc["total_ms"] / L},
            "roofline": roof, "cpu_baseline": cpu}
     out.update(secondary)

@@ -199,6 +199,9 @@ typedef struct mtg_batch_stats {
     uint64_t dense_words;        /* 8-byte words of contigs copied back for the multi-contig gaps */
     double emit_kernel_ms;       /* HIP-event time of the result kernel (k_emit: ASCII sequences + records); post_kernel_ms = k_post + the layout scans */
     uint64_t seq_bytes;          /* bytes of ASCII the result kernel wrote into the sequence arena */
+    double copy_kernel_ms;       /* HIP-event time of the copy kernel (k_copy: long runs of the contigs out of the unitig store, one wave per gap) */
+    uint64_t copy_words;         /* 8-byte words of contig arena it wrote */
+    uint64_t copy_cmds;          /* runs it copied (one 16-byte command each) */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);
 

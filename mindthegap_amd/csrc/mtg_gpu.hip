@@ -337,6 +337,19 @@ __global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a(uint8_t* zero, 
     out[slot] = o;
 }
 
+/* the long runs the traversal left as commands: one wave per gap, four gaps per workgroup (mtg_copy.h) */
+__global__ void __launch_bounds__(256) k_copy(UStore us, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, uint32_t n)
+{
+    const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (slot >= n) return;
+    GapScratch S;
+    S.z = nullptr;
+    S.v = nullptr;
+    S.lane = 0;
+    S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    copy_gap(us, cfg, S, outs[slot]);
+}
+
 /* the targets of a batch from text to (little-endian k-mer, never-match mask): one target per thread */
 __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __restrict__ tle, uint64_t* __restrict__ tbad, uint64_t nt, int k)
 {
@@ -396,10 +409,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_
  * metadata, the sequence arena, the extension arena, the list of gaps to re-run and the list of multi-contig gaps.  k_scan1: one thread per
  * slot, offsets inside its block of SCAN_SL slots + the block's totals and statistics; k_scan2 (one workgroup): offsets of the blocks on
  * top of the batch's cursors, totals of the launch; k_emit adds the two. */
-enum { SCAN_SL = 256, SCAN_NV = 6, SCAN_NS = 9 };
+enum { SCAN_SL = 256, SCAN_NV = 6, SCAN_NS = 11 };
 struct ScanBlock {
     uint64_t v[SCAN_NV]; /* k_scan1: totals of the block; k_scan2: replaced by the block's base */
-    uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext */
+    uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext, copy_words, copy_cmds */
 };
 __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, ScanBlock* blocks)
 {
@@ -423,6 +436,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
         atomicAdd(&ssum[1], (unsigned long long)r.o.store_reads);
         atomicAdd(&ssum[2], (unsigned long long)r.o.run_nt);
         atomicAdd(&ssum[4], (unsigned long long)r.o.n_words);
+        if (r.o.n_cmds) { atomicAdd(&ssum[9], (unsigned long long)r.o.copy_words); atomicAdd(&ssum[10], (unsigned long long)r.o.n_cmds); }
         if (r.o.status == GAP_OK) {
             atomicAdd(&ssum[3], (unsigned long long)r.o.total_nt);
             atomicAdd(&ssum[5], (unsigned long long)r.p.lines);
@@ -480,6 +494,7 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         tot->lines = ssum[0]; tot->store_runs = ssum[1]; tot->run_nt = ssum[2]; tot->contig_nt = ssum[3]; tot->contig_words = ssum[4];
         tot->post_lines = ssum[5]; tot->cov_kmers = ssum[6];
         tot->n_filled = (uint32_t)ssum[7]; tot->n_ext = (uint32_t)ssum[8];
+        tot->copy_words = ssum[9]; tot->copy_cmds = ssum[10];
     }
 }
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
@@ -1200,8 +1215,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     tick("upload (async)");
 
     EventSet events;
-    hipEvent_t ev0, ev1, ev2, ev3, eve;
+    hipEvent_t ev0, ev1, ev2, ev3, eve, evc;
     HIP_TRY(events.make(eve));
+    HIP_TRY(events.make(evc));
     HIP_TRY(events.make(ev0));
     HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
@@ -1218,6 +1234,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
 
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
+        static const bool no_defer = getenv("MTG_NO_DEFER") != nullptr; /* test hook: the lanes of the traversal copy their long runs themselves */
+        if (no_defer || !idx->dev.us.nwords) cfg.cmd_cap = 0;
         /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
         const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + sizeof(mtg_gap_result) + sizeof(mtg_filled);
         const size_t cached = ws.cap[d_zero.slot] + ws.cap[d_raw.slot] + ws.cap[d_ilv.slot]; /* already ours */
@@ -1281,6 +1299,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                                d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset);
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
+            /* ev1 .. evc: the long runs of the contigs, which the traversal only noted down */
+            if (cfg.cmd_cap) hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), m);
+            HIP_TRY(hipEventRecord(evc, stream));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
             hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
@@ -1385,6 +1406,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             t0 = now_ms();
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
             st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += tw;
+            st.copy_words += tot.copy_words; st.copy_cmds += tot.copy_cmds;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
             sink.n_filled += tot.n_filled;
@@ -1416,9 +1438,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
             }
             st.host_ms += now_ms() - t0;
-            float ms = 0, ms2 = 0, ms3 = 0;
+            float ms = 0, ms2 = 0, ms3 = 0, msc = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-            HIP_TRY(hipEventElapsedTime(&ms2, ev1, eve));
+            HIP_TRY(hipEventElapsedTime(&msc, ev1, evc));
+            HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
+            st.copy_kernel_ms += msc;
             HIP_TRY(hipEventElapsedTime(&ms3, eve, ev2));
             st.kernel_ms += ms;
             st.post_kernel_ms += ms2;

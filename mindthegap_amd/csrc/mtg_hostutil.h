@@ -58,6 +58,7 @@ inline FillCfg make_cfg(int k, int max_nodes, int max_depth, int end_rule_nonbra
     c.seen_cap = 2048u * mul;
     c.inv_cap = 2048u * mul;
     c.iseen_cap = 2048u * (mul > 8 ? 8 : mul);
+    c.cmd_cap = COPY_CMDS;
     finalize_cfg(c);
     return c;
 }

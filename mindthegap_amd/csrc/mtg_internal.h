@@ -9,6 +9,7 @@
 #include "mtg_hostutil.h"
 #include "mtg_paths.h"
 #include "mtg_emit.h"
+#include "mtg_copy.h"
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>

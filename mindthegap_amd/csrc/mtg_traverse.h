@@ -42,13 +42,14 @@ struct FillCfg {
     uint32_t seen_cap;    /* frontline visited set slots, power of two */
     uint32_t inv_cap;     /* involved list */
     uint32_t iseen_cap;   /* nested frontline visited set, power of two */
+    uint32_t cmd_cap;     /* deferred copies of a gap (CopyCmd), 0 = the lanes copy their long runs themselves */
     uint64_t zero_stride; /* bytes per gap in the zero-initialised region */
     uint64_t raw_stride;  /* bytes per gap in the raw region */
     uint64_t ilv_stride;  /* bytes per WAVE (64 gaps) in the lane-interleaved region */
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_flaux0, o_flaux1, o_dfsf, o_dfsc,
-        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra;
+        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra, o_cmd;
 };
 
 enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
@@ -83,6 +84,16 @@ MTG_ARR(uint32_t, s_clen, r, c.o_clen)       /* length in nt */
 MTG_ARR(uint64_t, s_qf, r, c.o_qf)           /* BFS queue: oriented k-mer */
 MTG_ARR(uint64_t, s_qc, r, c.o_qc)           /*   canonical k-mer (doubles as already_extended_from) */
 MTG_ARR(int32_t, s_qd, r, c.o_qd)
+/* A deferred copy: nwords whole words of the gap's contig arena, from word dst on, are the 32 * nwords nucleotides of the unitig store that
+ * start at position src >> 1 and run forward (bit 0 clear) or backward, complemented (bit 0 set).  Written by the traversal instead of the
+ * nucleotides themselves, executed by copy_gap (mtg_copy.h) with all lanes of a wave before anything reads the contigs. */
+struct CopyCmd {
+    uint64_t src;
+    uint32_t dst;
+    uint32_t nwords;
+};
+enum { COPY_CMDS = 32 };
+MTG_ARR(CopyCmd, s_cmd, r, c.o_cmd)
 MTG_ILV(uint32_t, s_marklog, c.o_marklog) /* slots used in marked[] */
 MTG_ILV(uint32_t, s_seenlog, c.o_seenlog) /* slots touched in seen[] */
 MTG_ILV(uint32_t, s_iseenlog, c.o_iseenlog)
@@ -136,6 +147,8 @@ inline void finalize_cfg(FillCfg& c)
     c.o_qf = (uint32_t)b; b += 8ull * c.qcap;
     c.o_qc = (uint32_t)b; b += 8ull * c.qcap;
     c.o_qd = (uint32_t)b; b += 4ull * c.qcap;
+    b = align_up(b, 16);
+    c.o_cmd = (uint32_t)b; b += 16ull * COPY_CMDS; /* the room is there whether or not cmd_cap lets it be used */
     c.raw_stride = align_up(b + 8, 64);
     /* interleaved per wave: byte offsets within one lane's share (every array starts 8-byte aligned) */
     b = 0;
@@ -1139,6 +1152,8 @@ struct GapOut {
     uint32_t n_words; /* words of the contig arena in use */
     uint32_t store_reads; /* runs taken from the unitig store (one header read each) */
     uint32_t run_nt;      /* nucleotides of the contigs that came out of the store */
+    uint32_t n_cmds;      /* deferred copies left in s_cmd */
+    uint32_t copy_words;  /* words of the contig arena they will fill */
 };
 
 /* the swf pattern R (gapFillFromSource's targetSequence, src/Filler.cpp:884): 2-bit packed, 32 nt per
@@ -1232,6 +1247,11 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     uint32_t run_left = 0, run_take = 0; /* nucleotides left / handed out with the last neighbourhood */
     bool run_bwd = false;
     uint32_t store_reads = 0, run_nt = 0;
+    /* long runs are not copied by the lane but left as commands for copy_gap -- unless the pattern is searched in the contigs right here
+     * (contig mode: contig_contains reads them) or the launch has no copy pass */
+    CopyCmd* const cmds = s_cmd(cfg, S);
+    const bool defer = r_is_kmer && cfg.cmd_cap != 0;
+    uint32_t ncmd = 0, copy_words = 0;
     /* index, in its unitig, of the k-mer the walk stands on while a run lasts (the run's next nucleotide extends that k-mer) */
     auto run_idx = [&]() -> uint32_t { return run_bwd ? (uint32_t)(run_pos - run_base) + 1u : (uint32_t)(run_pos - run_base) - (uint32_t)k; };
     /* the next nucleotides of the run as a neighbourhood with lookahead */
@@ -1311,7 +1331,33 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         run_nt -= run_take; /* the neighbourhood handed out last is taken back: its nucleotides are part of this step */
         uint64_t p = run_pos;
         uint32_t left = nbulk;
-        if (!run_bwd) {
+        if (defer && ncmd < cfg.cmd_cap) {
+            /* Deferred: the lane completes the word it is filling, leaves the whole words in between to copy_gap (one command), and takes
+             * the nucleotides past the last whole word into its accumulator: three short reads, all independent of each other, however
+             * long the run. */
+            if (nacc) { /* nbulk >= 32: the head always completes the word */
+                const uint32_t n0 = 32u - nacc;
+                append(us_peek64(sw, p, n0, run_bwd), n0);
+                p = run_bwd ? p - n0 : p + n0; left -= n0;
+            }
+            const uint32_t nw = left >> 5;
+            if (nw) {
+                if (wpos + nw > cfg.cap_words) ovf = true;
+                else {
+                    CopyCmd c;
+                    c.src = (p << 1) | (run_bwd ? 1ull : 0ull);
+                    c.dst = wpos;
+                    c.nwords = nw;
+                    cmds[ncmd++] = c;
+                    copy_words += nw;
+                }
+                wpos += nw;
+                p = run_bwd ? p - 32ull * nw : p + 32ull * nw; left -= 32u * nw;
+            }
+            if (left) { append(us_peek64(sw, p, left, run_bwd), left); p = run_bwd ? p - left : p + left; }
+            store_reads += 6;
+        } else if (!run_bwd) {
+            store_reads += (nbulk >> 5) + 2;
             const uint32_t inw = (uint32_t)(p & 31u);
             if (inw) { /* up to the end of the source word */
                 const uint32_t n0 = 32u - inw < left ? 32u - inw : left;
@@ -1330,6 +1376,7 @@ MTG_UNROLL
             p += 32ull * nw; left -= 32u * nw;
             if (left) { append(us_peek64(sw, p, left, false), left); p += left; }
         } else {
+            store_reads += (nbulk >> 5) + 2;
             const uint32_t inw = (uint32_t)(p & 31u) + 1u; /* nucleotides of the source word at or below p */
             if (inw < 32u) {
                 const uint32_t n0 = inw < left ? inw : left;
@@ -1358,7 +1405,6 @@ MTG_UNROLL
         run_left -= nbulk;
         run_nt += nbulk;
         len += nbulk;
-        store_reads += (nbulk >> 5) + 2;
     };
     for (;;) {
         if (!in_contig) {
@@ -1565,6 +1611,8 @@ MTG_UNROLL
     out.lines = W.lines + lines;
     out.store_reads = store_reads;
     out.run_nt = run_nt;
+    out.n_cmds = ncmd;
+    out.copy_words = copy_words;
     out.total_nt = total_nt;
     out.n_words = wpos;
 }

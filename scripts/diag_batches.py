@@ -25,8 +25,8 @@ for b in range(nb):
         h, nf, _ = idx.fill_prepared(prep, params, want_seqs=False)
         st = mtg.last_batch_stats()
         idx.free_results(h)
-    print("batch", b, "k_stage_a %.3f post %.3f emit %.3f host %.3f total %.3f" % (st["kernel_ms"], st["post_kernel_ms"], st["emit_kernel_ms"], st["host_ms"], st["total_ms"]),
-          {k: st[k] for k in ("index_lines", "store_runs", "run_nt", "contig_nt", "n_launches", "n_retried_gaps", "post_lines", "coverage_kmers", "dense_words")}, "filled", int((nf > 0).sum()))
+    print("batch", b, "k_stage_a %.3f copy %.3f post %.3f emit %.3f host %.3f total %.3f" % (st["kernel_ms"], st["copy_kernel_ms"], st["post_kernel_ms"], st["emit_kernel_ms"], st["host_ms"], st["total_ms"]),
+          {k: st[k] for k in ("index_lines", "store_runs", "run_nt", "contig_nt", "n_launches", "n_retried_gaps", "post_lines", "coverage_kmers", "dense_words", "copy_words", "copy_cmds")}, "filled", int((nf > 0).sum()))
     # the slowest walks: split the batch in 16 pieces and time each traversal alone
     if len(sys.argv) > 2:
         for piece in range(16):

@@ -6,6 +6,7 @@
  * library, which requires a HIP device.
  */
 #include "../../mindthegap_amd/csrc/mtg_hostutil.h"
+#include "../../mindthegap_amd/csrc/mtg_copy.h"
 #include "emu_us.h"
 #include <cstdlib>
 #include <cstring>
@@ -74,6 +75,7 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
     GapOut out{};
     for (int t = t0; t <= t1; t++) {
         FillCfg cfg = make_cfg(k, max_nodes, max_depth, end_rule, t);
+        if (getenv("MTG_NO_DEFER") || !e->ix.us.nwords) cfg.cmd_cap = 0;
         std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0xCD), ilv(cfg.ilv_stride);
         GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
         std::vector<uint8_t> fp_table(FP_SLOTS * 64);
@@ -87,6 +89,7 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
         pat.rlen = (uint32_t)rl;
         pat.r0 = rl >= (size_t)k ? encode_kmer(R, k) : 0;
         stage_a_gap(e->ix, cfg, S, encode_kmer(source, k), pat, out);
+        copy_gap(e->ix.us, cfg, S, out); /* the device's k_copy */
         /* the device relies on every gap handing the zero region back clean: make a violation visible as a status no test expects */
         for (uint8_t z : zero) if (z) { out.status = 0xDEAD; break; }
         if (out.status == 0xDEAD) break;

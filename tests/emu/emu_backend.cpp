@@ -246,6 +246,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     const size_t env_chunk = getenv("MTG_MAX_CHUNK") ? (size_t)atol(getenv("MTG_MAX_CHUNK")) : 0;
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
+        if (getenv("MTG_NO_DEFER") || !idx->dev.us.nwords) cfg.cmd_cap = 0;
         std::vector<uint32_t> retry;
         const size_t chunk = env_chunk ? std::min(env_chunk, n_todo) : n_todo;
         for (size_t base = 0; base < n_todo; base += chunk) {
@@ -274,6 +275,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 SlotRec& r = recs[s];
                 memset(&r, 0, sizeof r);
                 stage_a_gap(idx->dev, cfg, S, in.src[g], R, r.o);
+                copy_gap(idx->dev.us, cfg, S, r.o); /* k_copy */
+                st.copy_words += r.o.copy_words; st.copy_cmds += r.o.n_cmds;
                 for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, r.o.status); return MTG_ERR_OVERFLOW; }
                 if (r.o.status == GAP_OK) {
                     PostTargets T;

@@ -1,6 +1,7 @@
 """CPU-side logic tests: the device code (mtg_dev.h / mtg_traverse.h) executed by the TEST-ONLY host emulation
 harness, plus the product's host code and CLI linked against it, checked against the oracle and the goldens.
 These do not replace the -m gpu parity tests; they validate kernel and host logic before GPU time is spent."""
+import contextlib
 import os
 import random
 import struct
@@ -9,6 +10,23 @@ import numpy as np
 import pytest
 
 from tests import emu_lib, oracle_lib
+
+
+@contextlib.contextmanager
+def _env(name, value):
+    """an environment variable (a test hook of the emulation build) set for the calls inside, None = unset"""
+    old = os.environ.get(name)
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = value
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
 
 
 def _read(p):
@@ -139,8 +157,10 @@ def test_long_runs_through_the_unitig_store(k):
             t = g[tp:tp + k] if rng.random() < 0.6 else _rc(g[tp:tp + k])
             mn, md = rng.choice([100, 100, 8]), rng.choice([10000, 10000, 2500])
             oc, _ = idx.stage_a(s, t, oracle_lib.default_params(max_nodes=mn, max_depth=md))
-            ec, st, lines, _ = emu.stage_a(s, t, mn, md, 0)
-            assert st == 0 and ec == oc, (case, k, s, t, mn, md)
+            for own_copy in (False, True):  # the long runs left to the copy pass (k_copy) / copied by the walk itself
+                with _env("MTG_NO_DEFER", "1" if own_copy else None):
+                    ec, st, lines, _ = emu.stage_a(s, t, mn, md, 0)
+                assert st == 0 and ec == oc, (case, k, s, t, mn, md, own_copy)
         idx.close()
         emu.close()
 
@@ -167,8 +187,34 @@ def test_looping_contig_through_long_runs(k):
             tp = rng.randrange(0, L)
             t = cc[tp:tp + k] if rng.random() < 0.5 else _rc(cc[tp:tp + k])
             oc, _ = idx.stage_a(s, t, oracle_lib.default_params(max_depth=100000))
+            for own_copy in (False, True):
+                with _env("MTG_NO_DEFER", "1" if own_copy else None):
+                    ec, st, _, _ = emu.stage_a(s, t, 100, 100000, 0)
+                assert st == 0 and ec == oc, (case, k, s, t, own_copy)
+        idx.close()
+        emu.close()
+
+
+@pytest.mark.parametrize("k", [31, 17])
+def test_more_long_runs_than_copy_commands(k):
+    """a contig that crosses more long unitigs (60, separated by tips the bubble code pops) than a gap has copy commands (32): the
+    first runs are left to the copy pass, the others are copied by the walk itself, in both orientations"""
+    rng = random.Random(5 + k)
+    for case in range(4):
+        g = _rand_seq(rng, 60 * 110 + 200)
+        seqs = [g]
+        for j in range(1, 60):
+            q = j * 110 + rng.randrange(0, 20)
+            seqs.append(g[q:q + k - 1] + rng.choice([x for x in "ACGT" if x != g[q + k - 1]]) + _rand_seq(rng, rng.randrange(0, k // 2)))
+            seqs.append(_rc(_rc(g)[len(g) - q - 5:len(g) - q - 5 + k - 1] + "A"))  # some tips on the other strand (harmless when the k-mer exists)
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k, load_factor=0.5)
+        for s, t in ((g[:k], g[-k:]), (_rc(g[-k:]), _rc(g[:k])), (g[300:300 + k], g[3000:3000 + k])):
+            oc, _ = idx.stage_a(s, t, oracle_lib.default_params(max_depth=100000))
             ec, st, _, _ = emu.stage_a(s, t, 100, 100000, 0)
             assert st == 0 and ec == oc, (case, k, s, t)
+            assert max(len(c) for c in oc) > 33 * 110, [len(c) for c in oc]  # one contig does cross more than 32 of them
         idx.close()
         emu.close()
 
