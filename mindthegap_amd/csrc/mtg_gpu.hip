@@ -1458,11 +1458,21 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     {
         unsigned long long hs[16];
         if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(mtg::g_stamps), sizeof hs) == hipSuccess && hs[15])
-            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f (long steps %.0f, bucket reads + run set-up %.0f) B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f | snp_fast %.0f consume %.0f\n", hs[15],
+            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f (long steps %.0f, bucket reads + run set-up %.0f) B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f | snp_fast %.0f (alignment %.0f) consume %.0f"
+                            " | per lane: general bubbles %.3f, snp_fast answers %.3f (bulk form %.3f, with alignment %.3f)\n", hs[15],
                     (double)hs[0] / hs[15], (double)hs[8] / hs[15], (double)hs[9] / hs[15], (double)hs[1] / hs[15], (double)hs[2] / hs[15], (double)hs[3] / hs[15], (double)hs[4] / hs[15], (double)hs[5] / hs[15],
-                    (double)hs[6] / hs[15], (double)hs[7] / hs[15]);
+                    (double)hs[6] / hs[15], (double)hs[12] / hs[15], (double)hs[7] / hs[15], (double)hs[10] / hs[15], (double)hs[14] / hs[15], (double)hs[13] / hs[15], (double)hs[11] / hs[15]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
+        unsigned long long lf[40];
+        if (hipMemcpyFromSymbol(lf, HIP_SYMBOL(mtg::g_life), sizeof lf) == hipSuccess) {
+            fprintf(stderr, "  [stamps] traversal kernel: %llu ticks from the first lane's start to the last lane's end (%.3f ms of events); lanes by log2(life in ticks):", lf[33] - lf[32], st.kernel_ms);
+            for (int i = 10; i < 32; i++) if (lf[i]) fprintf(stderr, " 2^%d:%llu", i, lf[i]);
+            fprintf(stderr, "\n");
+        }
+        unsigned long long z2[40] = {0};
+        z2[32] = ~0ull;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_life), z2, sizeof z2);
     }
 #endif
     if (while_busy && !busy_done) (*while_busy)();

@@ -49,7 +49,7 @@ struct FillCfg {
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_flaux0, o_flaux1, o_dfsf, o_dfsc,
-        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra, o_cmd;
+        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra, o_dfsdep, o_dfsxsn, o_cmd;
 };
 
 enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
@@ -116,6 +116,8 @@ MTG_ILV(uint32_t, s_iflra0, c.o_iflra0)
 MTG_ILV(uint32_t, s_iflra1, c.o_iflra1)
 MTG_ILV(uint64_t, s_dfsrp, c.o_dfsrp)     /* the same for the frames of the consensus enumeration */
 MTG_ILV(uint32_t, s_dfsra, c.o_dfsra)
+MTG_ILV(uint32_t, s_dfsdep, c.o_dfsdep)   /* depth of a frame's node */
+MTG_ILV(uint32_t, s_dfsxsn, c.o_dfsxsn)   /* abundance sum of the path up to and including the frame's stretch */
 MTG_ILV(uint64_t, s_dfsf, c.o_dfsf)       /* consensus enumeration stack */
 MTG_ILV(uint64_t, s_dfsc, c.o_dfsc)
 MTG_ILV(uint8_t, s_dfsmask, c.o_dfsmask)
@@ -183,6 +185,8 @@ inline void finalize_cfg(FillCfg& c)
     c.o_iflra0 = (uint32_t)b; b += 4ull * FL_CAP;
     c.o_iflra1 = (uint32_t)b; b += 4ull * FL_CAP;
     c.o_dfsra = (uint32_t)b; b += 4ull * DFS_CAP;
+    c.o_dfsdep = (uint32_t)b; b += 4ull * DFS_CAP;
+    c.o_dfsxsn = (uint32_t)b; b += 4ull * DFS_CAP;
     c.ilv_stride = align_up(b, 8) * 64;
 }
 
@@ -230,11 +234,14 @@ MTG_DEV int set_add(uint64_t* tab, uint32_t cap, uint32_t& count, uint64_t c)
 /* diagnostic build (-DMTG_STAMPS): shader-clock time per phase, summed over lanes into a global array (never in the product build) */
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_life[40]; /* [0..31]: lanes by log2 of their life in clock ticks; [32] earliest start, [33] latest end (0 = unset) */
 #define MTG_T0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
 #define MTG_T1(v, slot) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[slot] += t_ - v; } while (0)
+#define MTG_COUNT(W_, slot) ((W_).stamp_acc[slot] += 1ull)
 #else
 #define MTG_T0(v)
 #define MTG_T1(v, slot)
+#define MTG_COUNT(W_, slot)
 #endif
 
 /* ---- per-gap walker state ------------------------------------------------------------------ */
@@ -582,9 +589,10 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
     return depth;
 }
 
-/* [MEM] MonumentTraversal::all_consensuses_between (SURVEY A.5(ii)), explicit stack.
- * Consensuses come out in lexicographic (A,C,T,G) order, which is std::set<Path> order. */
-MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint64_t end_c, int traversal_depth, int& ncons)
+#ifdef MTG_EMU
+/* TEST-ONLY: the enumeration node by node, one frame per node, exactly as the reference recurses; the emulation build runs it after
+ * all_consensuses_between and compares (status 0xBAD4) */
+MTG_DEV_NOINLINE bool all_consensuses_between_nodes(Worker& W, const Kmer& start, uint64_t end_c, int traversal_depth, int& ncons)
 {
     const int k = W.k;
     const SP<uint64_t> dfs_f = s_dfsf(W.cfg, W.S);
@@ -689,6 +697,202 @@ MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint
     path_clear();
     return ok;
 }
+#endif
+
+/* [MEM] MonumentTraversal::all_consensuses_between (SURVEY A.5(ii)), explicit stack.
+ * Consensuses come out in lexicographic (A,C,T,G) order, which is std::set<Path> order.
+ *
+ * Unitig-aware.  A frame is a node of the current path; a node whose right junction lies inside a stored unitig, with at least two nodes of
+ * the unitig ahead, has ONE child frame: the unitig's end node, `ahead` levels deeper.  What the reference does on the levels in between
+ * cannot change the outcome:
+ *   - the nodes passed have one out-edge (one recursive call each) and the depth test is monotone: it fails on one of them iff it fails on
+ *     the deepest, which is tested;
+ *   - none of them is the end node: a node that is not the first of its unitig (in the direction the frontline reached it) carries its place
+ *     in the store (end_rp), and a unitig that may be the end node's is walked node by node;
+ *   - none of them is on the path already: a node inside a unitig is reached through the unitig alone, so a path that holds it also holds
+ *     the node the stretch was entered by or the unitig's end node (either strand: same canonical k-mers), and those two are frames, tested
+ *     and kept in the path set as always; for the same reason a later node of the path that equals a passed node is caught at one of the two;
+ *   - the breadth test after each return is repeated unchanged (the number of consensuses does not change on the way up).
+ * The path's nucleotides are written in bulk from the store.  Along the way the abundances are summed (one byte per node next to the unitig,
+ * wide loads for a stretch; an ABND look-up for a node outside the store), so that every consensus comes with the sum the reference's
+ * most_abundant_consensus computes over [start, nodes before the end] (cons_sum), and validate_consensuses need not walk them again. */
+MTG_DEV SP<int32_t> s_cons_sum(const FillCfg& c, const GapScratch& S) { return s_nw(c, S) + 2 * (CONS_LEN + 1); } /* rows 2.. of the alignment area (nw_matches uses rows 0, 1) */
+MTG_DEV_NOINLINE bool all_consensuses_between(Worker& W, const Kmer& start, uint64_t end_c, uint64_t end_rp, int traversal_depth, int& ncons)
+{
+    const int k = W.k;
+    const UStore& us = W.ix.us;
+    const SP<uint64_t> dfs_f = s_dfsf(W.cfg, W.S);
+    const SP<uint64_t> dfs_c = s_dfsc(W.cfg, W.S);
+    const SP<uint8_t> dfs_mask = s_dfsmask(W.cfg, W.S);
+    const SP<uint8_t> dfs_nt = s_dfsnt(W.cfg, W.S);      /* by depth */
+    const SP<uint32_t> dfs_kid = s_dfskid(W.cfg, W.S);
+    const SP<uint64_t> dfs_rp = s_dfsrp(W.cfg, W.S);
+    const SP<uint32_t> dfs_ra = s_dfsra(W.cfg, W.S);
+    const SP<uint32_t> dfs_dep = s_dfsdep(W.cfg, W.S);   /* depth of the frame's node = nucleotides of the path before it */
+    const SP<uint32_t> dfs_xsn = s_dfsxsn(W.cfg, W.S);   /* abundances of the path's nodes before the frame's child */
+    const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+    const SP<uint16_t> cons_len = s_conslen(W.cfg, W.S);
+    const SP<int32_t> cons_sum = s_cons_sum(W.cfg, W.S);
+    ncons = 0;
+    int fr = 0; /* current frame */
+    dfs_f[0] = start.f;
+    dfs_c[0] = canon(start);
+    dfs_dep[0] = 0;
+    dfs_rp[0] = 0;
+    dfs_ra[0] = 0;
+    const uint32_t end_u = (end_rp & RP_VALID) ? rp_unitig(end_rp) : 0xFFFFFFFFu;
+    /* k-mers of the current path: kept in the nested-frontline hash set (idle here) so that the loop test is one probe instead of a scan
+     * of the whole path; a popped k-mer leaves a tombstone (canonical k-mers are < 2^62, so ~0 - 1 is free) */
+    uint64_t* pset = s_iseen(W.cfg, W.S);
+    const uint32_t pcap = W.cfg.iseen_cap;
+    const uint64_t TOMB = ~0ULL - 1;
+    uint32_t plog_n = 0;
+    const SP<uint32_t> plog = s_iseenlog(W.cfg, W.S);
+    /* 0: added, 1: already on the path, 2: table full.  A tombstone met on the way is reused only after the probe sequence has
+     * proven the key absent. */
+    auto path_add = [&](uint64_t c) -> int {
+        uint32_t h = set_hash(c, pcap);
+        int64_t tomb = -1;
+        for (;;) {
+            const uint64_t v = pset[h];
+            if (v == c + 1) return 1;
+            if (v == TOMB && tomb < 0) tomb = (int64_t)h;
+            if (v == 0) {
+                if (tomb >= 0) { pset[(uint32_t)tomb] = c + 1; return 0; }
+                if (plog_n + 2 >= pcap) return 2;
+                plog[plog_n++] = h;
+                pset[h] = c + 1;
+                return 0;
+            }
+            h = (h + 1) & (pcap - 1);
+        }
+    };
+    auto path_del = [&](uint64_t c) {
+        uint32_t h = set_hash(c, pcap);
+        for (;;) {
+            const uint64_t v = pset[h];
+            if (v == 0) return;
+            if (v == c + 1) { pset[h] = TOMB; return; }
+            h = (h + 1) & (pcap - 1);
+        }
+    };
+    auto path_clear = [&]() { for (uint32_t i = 0; i < plog_n; i++) pset[plog[i]] = 0; plog_n = 0; };
+    path_add(dfs_c[0]);
+    bool entering = true;
+    auto run = [&]() -> bool {
+    for (;;) {
+        if (entering) {
+            entering = false;
+            const int d = (int)dfs_dep[fr];
+            if (traversal_depth - d < -1) return false;
+            if (dfs_c[fr] == end_c) {
+                if (ncons >= CONS_CAP || d > CONS_LEN) { W.status = GAP_OVF_DFS; return false; }
+                for (int i = 0; i < d; i += 8) { /* eight at a time: the loads of a group do not wait for the stores of the one before */
+                    uint8_t t8[8];
+MTG_UNROLL
+                    for (int j = 0; j < 8; j++) t8[j] = (i + j < d) ? dfs_nt[i + j] : (uint8_t)0;
+MTG_UNROLL
+                    for (int j = 0; j < 8; j++) if (i + j < d) cons[(size_t)ncons * CONS_LEN + i + j] = t8[j];
+                }
+                cons_len[ncons] = (uint16_t)d;
+                cons_sum[ncons] = fr ? (int32_t)dfs_xsn[fr - 1] : 0;
+                ncons++;
+                dfs_mask[fr] = 0; /* return */
+            } else {
+                const Kmer x = make_kmer(dfs_f[fr], k);
+                const uint32_t xs = fr ? dfs_xsn[fr - 1] : 0u;
+                const uint32_t aux = fr ? dfs_kid[fr - 1] : 0u; /* what the parent's read told about this node */
+                uint64_t rp = dfs_rp[fr];
+                uint32_t ra = dfs_ra[fr], mask, kid, abx;
+                if ((rp & RP_VALID) && ra >= 1u) { /* inside a unitig: the way ahead is known */
+                    mask = 1u << run_next_nt(us, rp & RP_KPOS, (rp & RP_BWD) != 0, k);
+                    kid = AUX_IN1;
+                    abx = us.ab[rp & RP_KPOS];
+                    W.lines++;
+                } else if (aux & 15u) { /* inline lookahead (a junction that is in no stored unitig) */
+                    mask = 1u << ((aux >> 4) & 3u);
+                    kid = aux_step(aux);
+                    abx = abundance(W.ix, x, W.lines);
+                    rp = 0; ra = 0;
+                } else {
+                    Adj a = adj_right_t(W.ix.adj, x, W.mk1, W.lines);
+                    RunAt r;
+                    if (us.nwords && run_at(us, a, k, r, W.lines)) { rp = rp_pack(r); ra = r.ahead; abx = us.ab[r.kpos]; }
+                    else { adj_resolve_la(W.ix, a, W.lines); rp = 0; ra = 0; abx = abundance(W.ix, x, W.lines); }
+                    mask = a.out;
+                    kid = aux_of_children(a);
+                }
+                dfs_mask[fr] = (uint8_t)mask;
+                dfs_kid[fr] = kid;
+                dfs_rp[fr] = rp;
+                dfs_ra[fr] = ra;
+                dfs_xsn[fr] = xs + abx;
+            }
+        }
+        const uint32_t mask = dfs_mask[fr];
+        if (mask == 0) {
+            /* return to the parent; the parent re-checks the breadth limit after each child */
+            if (fr == 0) return true;
+            path_del(dfs_c[fr]);
+            fr--;
+            if (ncons > W.cfg.mono_max_breadth) return false;
+            continue;
+        }
+        const uint32_t nt = (uint32_t)ctz4(mask);
+        dfs_mask[fr] = (uint8_t)(mask & (mask - 1));
+        const int d = (int)dfs_dep[fr];
+        const uint64_t rp = dfs_rp[fr];
+        const uint32_t ra = dfs_ra[fr];
+        Kmer y;
+        uint32_t t = 1u, kra = 0;
+        uint64_t krp = 0;
+        if ((rp & RP_VALID) && ra >= 2u && rp_unitig(rp) != end_u) {
+            /* the whole stretch: the child is the unitig's end node */
+            t = ra;
+            if (d + (int)t > traversal_depth + 1) return false; /* the reference fails on the way */
+            const bool bwd = (rp & RP_BWD) != 0;
+            const uint64_t kpos = rp & RP_KPOS;
+            for (uint32_t i = 0; i < t; i += 16u) {
+                const uint32_t n = t - i < 16u ? t - i : 16u;
+                uint32_t seq = us_peek(us.words, bwd ? kpos - 1u - i : kpos + (uint32_t)k + i, n, bwd);
+                for (uint32_t j = 0; j < n; j++) { dfs_nt[(size_t)d + i + j] = (uint8_t)(seq & 3u); seq >>= 2; }
+            }
+            /* abundances of the t - 1 nodes passed (the node itself is in dfs_xsn[fr] already) */
+            uint32_t sum = 0;
+            for (uint32_t i = 1; i < t; i += 64u) {
+                const uint32_t n = t - i < 64u ? t - i : 64u; /* nodes i .. i + n - 1 ahead */
+                sum += us_ab_sum(us.ab, bwd ? kpos - (i + n - 1u) : kpos + i, n);
+            }
+            W.lines += (t >> 5) + 2u;
+            dfs_xsn[fr] += sum;
+            dfs_kid[fr] = AUX_IN1; /* the end node has in-degree 1; nothing is known beyond it */
+            y = run_node(us, kpos, bwd, t, k);
+            krp = rp_step(rp, t);
+            kra = 0;
+        } else {
+            const Kmer x = make_kmer(dfs_f[fr], k);
+            y = kmer_next(x, nt, k, W.mk);
+            dfs_nt[d] = (uint8_t)nt;
+            if ((rp & RP_VALID) && ra >= 1u) { krp = rp_step(rp, 1u); kra = ra - 1u; }
+        }
+        const uint64_t cy = canon(y);
+        if (fr + 1 >= DFS_CAP || d + (int)t >= DFS_CAP) { W.status = GAP_OVF_DFS; return false; }
+        const int pa = path_add(cy);
+        if (pa == 1) return false; /* loop inside the bubble */
+        if (pa == 2) { W.status = GAP_OVF_DFS; return false; }
+        fr++;
+        dfs_f[fr] = y.f;
+        dfs_c[fr] = cy;
+        dfs_dep[fr] = (uint32_t)d + t;
+        dfs_rp[fr] = krp;
+        dfs_ra[fr] = kra;
+        entering = true;
+    }
+    };
+    const bool ok = run();
+    path_clear();
+    return ok;
+}
 
 /* identity of src/Utils.cpp:87-189 (same routine in gatb's Traversal [MEM]) without the full matrix:
  * the traceback's choice at (i,j) only depends on scores already known when (i,j) is filled, so the
@@ -775,31 +979,56 @@ MTG_DEV_NOINLINE int validate_consensuses(Worker& W, const Kmer& start, int ncon
     for (int a = 0; a < ncons; a++)
         for (int b = a + 1; b < ncons; b++) {
             int na = cons_len[a], nb = cons_len[b];
-            /* equal lengths and at most one substitution (the SNP bubble): the diagonal alignment scores 10n - 15h and any alignment with
-             * a gap pair at most 10n - 20, so the diagonal is the unique optimum and the traceback counts n - h matches; no DP needed */
-            int m = -1;
-            if (na == nb) {
-                int h = 0;
-                const SP<uint8_t> pa = cons + (size_t)a * CONS_LEN;
-                const SP<uint8_t> pb = cons + (size_t)b * CONS_LEN;
-                for (int i = 0; i < na && h < 2; i++) h += pa[i] != pb[i];
-                if (h < 2) m = na - h;
+            /* The alignment is only asked whether its match count m reaches 90 % of the longer length.  An alignment with p aligned pairs, m
+             * of them matches, and g gap columns scores 15 m - 5 (p + g), and p + g >= max(na, nb); the optimal one scores at least s0, the
+             * score of "diagonal, then the length difference as end gaps".  So m >= (s0 + 5 max(na, nb)) / 15 on every optimal alignment,
+             * whichever the traceback picks; the float test is monotone in m: when the bound passes, m passes, and no DP is needed.  (Equal
+             * lengths, h substitutions: the bound is n - h; for h <= 1 it is the exact count.) */
+            const SP<uint8_t> pa = cons + (size_t)a * CONS_LEN;
+            const SP<uint8_t> pb = cons + (size_t)b * CONS_LEN;
+            const int mn = na < nb ? na : nb, mx = na < nb ? nb : na;
+            int s0 = -5 * (mx - mn);
+            for (int i = 0; i < mn; i += 8) {
+                uint8_t ta[8], tb[8];
+MTG_UNROLL
+                for (int j = 0; j < 8; j++) { ta[j] = (i + j < mn) ? pa[i + j] : (uint8_t)0; tb[j] = (i + j < mn) ? pb[i + j] : (uint8_t)0; }
+MTG_UNROLL
+                for (int j = 0; j < 8; j++) if (i + j < mn) s0 += (ta[j] == tb[j]) ? 10 : -5;
             }
-            if (m < 0) m = nw_matches(W, cons + (size_t)a * CONS_LEN, na, cons + (size_t)b * CONS_LEN, nb);
+            const int num = s0 + 5 * mx;
+            const int mlb = num <= 0 ? 0 : (num + 14) / 15;
+            int m = mlb;
+            const bool need_dp = identity_below_90(mlb, na, nb);
+            if (need_dp) m = nw_matches(W, pa, na, pb, nb);
+#ifdef MTG_EMU /* TEST-ONLY: the bound against the alignment itself */
+            {
+                const int mx_ = nw_matches(W, pa, na, pb, nb);
+                if (mx_ < mlb || (!need_dp && identity_below_90(mx_, na, nb))) { W.status = 0xBAD6; return -1; }
+                m = mx_;
+            }
+#endif
             if (identity_below_90(m, na, nb)) return -1;
         }
+    /* most abundant consensus: the sums come with the consensuses (all_consensuses_between) */
+    const SP<int32_t> cons_sum = s_cons_sum(W.cfg, W.S);
     unsigned long best = 0;
     int chosen = -1;
     for (int c = 0; c < ncons; c++) {
         int len = cons_len[c];
         if (len == 0) continue;
-        unsigned long sum = 0;
-        Kmer x = start;
-        const SP<uint8_t> p = cons + (size_t)c * CONS_LEN;
-        for (int i = 0; i < len; i++) {
-            sum += abundance(W.ix, x, W.lines);
-            x = kmer_next(x, p[i], k, W.mk);
+        unsigned long sum = (unsigned long)cons_sum[c];
+#ifdef MTG_EMU /* TEST-ONLY: the sum node by node, as the reference computes it */
+        {
+            unsigned long sum2 = 0;
+            Kmer x = start;
+            const SP<uint8_t> p = cons + (size_t)c * CONS_LEN;
+            for (int i = 0; i < len; i++) {
+                sum2 += abundance(W.ix, x, W.lines);
+                x = kmer_next(x, p[i], k, W.mk);
+            }
+            if (sum2 != sum) { W.status = 0xBAD5; return -1; }
         }
+#endif
         sum /= (unsigned long)len;
         if (sum > best) { best = sum; chosen = c; }
     }
@@ -878,7 +1107,7 @@ enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches o
  * nodes are, ever), are pairwise distinct and no palindromic junction or self-complementary k-mer lies inside a unitig (mtg_dev.h:
  * us_eligible); the remaining tests of the loop (a branch node equal to the previous node, a node followed by its reverse complement at
  * the ends) are made here on the k-mers.  x[] = the first nodes of the branches, r[] = their right neighbourhoods. */
-MTG_DEV_NOINLINE bool snp_bulk(Worker& W, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], int& L, int& h, SnpSeq seq[2], unsigned long sum[2], Kmer& e)
+MTG_DEV_NOINLINE bool snp_bulk(Worker& W, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], int& L, int& h, SnpSeq seq[2], unsigned long sum[2], Kmer& e, bool& hopeless)
 {
     const UStore& us = W.ix.us;
     const int k = W.k;
@@ -918,7 +1147,8 @@ MTG_UNROLL
     }
     Adj re[2];
     adj_right2_raw(W.ix, z[0], z[1], W.mk1, W.lines, re[0], re[1]);
-    if (popc4(re[0].out) != 1 || popc4(re[1].out) != 1) return false;
+    /* a branch whose unitig ends in a dead end or a fork: the step-by-step loop would walk both unitigs to find just that */
+    if (popc4(re[0].out) != 1 || popc4(re[1].out) != 1) { hopeless = true; return false; }
     const uint32_t ne[2] = {(uint32_t)ctz4(re[0].out), (uint32_t)ctz4(re[1].out)};
     const Kmer y0 = kmer_next(z[0], ne[0], k, W.mk), y1 = kmer_next(z[1], ne[1], k, W.mk);
     if (y0.f == z[0].r || y1.f == z[1].r) return false;
@@ -986,7 +1216,7 @@ MTG_UNROLL
     /* the bulk form first (both branches read off the unitig store); the device takes its answer, the TEST-ONLY emulation runs the loop
      * as well and compares (status 0xBAD2: different answers, 0xBAD3: the loop rejected what the bulk form accepted) */
     Adj r1[2];
-    bool have_r1 = false, bulk_ok = false;
+    bool have_r1 = false, bulk_ok = false, hopeless = false;
     int bL = 0, bh = 0;
     SnpSeq bseq[2];
     unsigned long bsum[2] = {0, 0};
@@ -996,7 +1226,10 @@ MTG_UNROLL
     if (W.ix.us.nwords) {
         adj_right2_raw(W.ix, x[0], x[1], W.mk1, W.lines, r1[0], r1[1]);
         have_r1 = true;
-        bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be);
+        bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be, hopeless);
+#ifndef MTG_EMU
+        if (hopeless) return 0;
+#endif
 #ifdef MTG_TRACE_BULK
         fprintf(stderr, "SNP bulk %d L=%d\n", (int)bulk_ok, bL);
 #endif
@@ -1049,6 +1282,9 @@ MTG_UNROLL
         x[1] = y1;
     }
     if (L == 0) MTG_SNP_FAIL(2);
+#ifdef MTG_EMU
+    if (hopeless) { W.status = 0xBAD8; return 0; } /* the bulk form gave up on a bubble the loop answers */
+#endif
 #undef MTG_SNP_FAIL
     const Kmer e = x[0];
     const uint64_t ce = canon(e);
@@ -1067,12 +1303,19 @@ MTG_UNROLL
     /* one substitution: the diagonal is the unique optimal alignment (see validate_consensuses); more: the exact banded alignment, which
      * wants the consensus strings in the work area (the caller takes the chosen one from registers) */
     int matches = n - h;
+    if (bulk_ok) MTG_COUNT(W, 13);
     if (h >= 2) {
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+        unsigned long long* stamp_acc = W.stamp_acc;
+#endif
+        MTG_COUNT(W, 11);
+        MTG_T0(t_nw);
         const SP<uint8_t> cons = s_cons(W.cfg, W.S);
 MTG_UNROLL
         for (int br = 0; br < 2; br++)
             for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
         matches = nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
+        MTG_T1(t_nw, 12);
     }
     if (identity_below_90(matches, n, n)) return 0;
     /* most abundant consensus: the last step's buckets and the node's own */
@@ -1094,6 +1337,7 @@ MTG_UNROLL
     if (chosen < 0) return 0;
     chosen_seq = seq[chosen];
     W.mark_canon(ce); /* e has two in-edges: the one branching node among the involved ones */
+    MTG_COUNT(W, 14);
     return n;
 }
 
@@ -1106,9 +1350,9 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     unsigned long long* stamp_acc = W.stamp_acc;
 #endif
+    MTG_COUNT(W, 10);
     MTG_T0(t_fe);
     int d = find_end_of_branching(W, cur, prev_c, end_f, end_rp);
-    (void)end_rp;
     W.seen_clear();
     MTG_T1(t_fe, 2);
 #ifdef MTG_TRACE
@@ -1118,8 +1362,27 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
     Kmer e = make_kmer(end_f, W.k);
     int ncons = 0;
     MTG_T0(t_dfs);
-    const bool okc = all_consensuses_between(W, cur, canon(e), d + 1, ncons);
+    const bool okc = all_consensuses_between(W, cur, canon(e), end_rp, d + 1, ncons);
     MTG_T1(t_dfs, 3);
+#ifdef MTG_EMU /* TEST-ONLY: the enumeration node by node must give the same consensuses in the same order */
+    if (!W.status) {
+        auto digest = [&](int n) -> uint64_t {
+            uint64_t h = 0x9E3779B97F4A7C15ULL * (uint64_t)(n + 1);
+            const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+            const SP<uint16_t> cons_len = s_conslen(W.cfg, W.S);
+            for (int c = 0; c < n; c++) {
+                h = (h ^ cons_len[c]) * 0x100000001B3ULL;
+                for (int i = 0; i < (int)cons_len[c]; i++) h = (h ^ cons[(size_t)c * CONS_LEN + i]) * 0x100000001B3ULL;
+            }
+            return h;
+        };
+        const uint64_t h1 = okc ? digest(ncons) : 0;
+        int ncons2 = 0;
+        const bool okc2 = all_consensuses_between_nodes(W, cur, canon(e), d + 1, ncons2);
+        if (W.status) return 0;
+        if (okc != okc2 || (okc && (ncons != ncons2 || h1 != digest(ncons2)))) { W.status = 0xBAD4; return 0; }
+    }
+#endif
     if (!okc) return 0;
     MTG_T0(t_val);
     chosen = validate_consensuses(W, cur, ncons);
@@ -1183,6 +1446,9 @@ MTG_DEV_NOINLINE bool contig_contains(const uint64_t* wd, uint32_t clen, const S
 MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out)
 {
     Worker W(ix, cfg, S);
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    const unsigned long long t_life0 = __builtin_amdgcn_s_memtime();
+#endif
     const int k = W.k;
     const uint64_t mk = W.mk, mk1 = W.mk1;
     const uint32_t MAXLEN = 10u * 1000 * 1000;
@@ -1550,13 +1816,37 @@ MTG_UNROLL
                 const SP<uint8_t> p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;
                 bool looping = false;
                 MTG_T0(t_cons);
+                /* terminator.mark() along the consensus of the general code: only branching nodes are marked, and a node inside a stored unitig
+                 * (not its end node) has one in- and one out-edge -- c_ra = nodes known to lie ahead of the current one in its unitig */
+                uint32_t c_ra = 0;
                 for (int i = 0; i < n; i++) {
                     const uint32_t nti = fast ? fast_seq.get(i) : (uint32_t)p[i];
                     prev_c = canon(cur);
                     cur = kmer_next(cur, nti, k, mk);
                     push_nt(nti);
                     len++;
-                    if (!fast) W.mark(cur);
+                    if (!fast) {
+#ifdef MTG_EMU
+                        const bool br_ref = W.is_branching(cur);
+                        bool br_here = false;
+#endif
+                        if (c_ra >= 2u) c_ra--;
+                        else {
+                            const bool in1 = c_ra == 1u; /* the end node of the unitig the path was in: its in-degree is known */
+                            c_ra = 0;
+                            const Adj r = adj_right_t(adj, cur, mk1, lines);
+                            const bool branching = popc4(r.out) != 1 || (!in1 && popc4(adj_left(W.ix, cur, mk1, lines).in) != 1);
+                            if (branching) W.mark_canon(canon(cur));
+                            RunAt ru;
+                            if (us.nwords && run_at(us, r, k, ru, lines)) c_ra = ru.ahead;
+#ifdef MTG_EMU
+                            br_here = branching;
+#endif
+                        }
+#ifdef MTG_EMU
+                        if (br_ref != br_here) W.status = 0xBAD7;
+#endif
+                    }
                     if (r_is_kmer && cur.f == R.r0) found_R = true;
                     if (canon(cur) == start_c) looping = true;
                 }
@@ -1601,6 +1891,12 @@ MTG_UNROLL
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     for (int i = 0; i < 15; i++) atomicAdd(&g_stamps[i], W.stamp_acc[i]);
     atomicAdd(&g_stamps[15], 1ull);
+    {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), life = t_end - t_life0;
+        atomicAdd(&g_life[63 - __clzll(life | 1ull)], 1ull);
+        atomicMin(&g_life[32], t_life0);
+        atomicMax(&g_life[33], t_end);
+    }
 #endif
     /* leave the zero-initialised region as it was found, whatever the exit path */
     W.seen_clear();

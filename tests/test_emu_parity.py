@@ -195,6 +195,38 @@ def test_looping_contig_through_long_runs(k):
         emu.close()
 
 
+@pytest.mark.parametrize("k", [31, 21, 16])
+def test_variant_pairs_at_distance_k(k):
+    """two haplotypes that differ by substitutions 1, k-1, k, k+1, 2k-1 and 2k apart, and by three substitutions k apart: at distance
+    exactly k the last nodes of the first bubble's branches both lead to both alleles of the next one (four, eight paths of 2k+1, 3k+1
+    nodes: the general bubble code, whose path enumeration and marking advance whole unitigs; the emulation build runs the node-by-node
+    forms next to them: statuses 0xBAD4..0xBAD8), below k the branches are longer single unitigs (the SNP fast path with an alignment
+    bound instead of the alignment)"""
+    rng = random.Random(1234 + k)
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    for case in range(6):
+        g = _rand_seq(rng, 4200)
+        h = list(g)
+        pos = 300
+        for dist in (1, k - 1, k, k + 1, 2 * k - 1, 2 * k):
+            for q in (pos, pos + dist):
+                h[q] = other[h[q]]
+            pos += dist + 6 * k + rng.randrange(0, 40)
+        for j in range(3):  # three in a row, k apart
+            h[pos + j * k] = other[h[pos + j * k]]
+        assert pos + 3 * k < len(g) - 300
+        seqs = [g, "".join(h)]
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k, load_factor=0.5)
+        for s, t in ((g[100:100 + k], g[-150:-150 + k]), (_rc(g[-120:-120 + k]), _rc(g[150:150 + k])), ("".join(h)[100:100 + k], "".join(h)[2000:2000 + k])):
+            oc, _ = idx.stage_a(s, t, oracle_lib.default_params(max_depth=100000))
+            ec, st, _, _ = emu.stage_a(s, t, 100, 100000, 0)
+            assert st == 0 and ec == oc, (case, k, s, t, hex(st))
+        idx.close()
+        emu.close()
+
+
 @pytest.mark.parametrize("k", [31, 17])
 def test_more_long_runs_than_copy_commands(k):
     """a contig that crosses more long unitigs (60, separated by tips the bubble code pops) than a gap has copy commands (32): the
