@@ -484,6 +484,33 @@ MTG_UNROLL
     }
     return sum;
 }
+/* the same when count (<= 64) is only known after the loads have been issued (it comes with another load of the same round): nine words
+ * are read whatever it is (the array is padded by more than that) and the bytes are masked afterwards */
+struct AbRun { uint64_t w[9]; uint64_t start; };
+MTG_DEV void us_ab_issue(const uint8_t* ab, uint64_t start, AbRun& r)
+{
+    const uint64_t a0 = start & ~7ull;
+    r.start = start;
+MTG_UNROLL
+    for (int j = 0; j < 9; j++) r.w[j] = *reinterpret_cast<const uint64_t*>(ab + a0 + 8u * (uint32_t)j);
+}
+MTG_DEV uint32_t us_ab_finish(const AbRun& r, uint32_t count)
+{
+    const uint64_t start = r.start, a0 = start & ~7ull, end = start + count;
+    uint32_t sum = 0;
+MTG_UNROLL
+    for (int j = 0; j < 9; j++) {
+        const uint64_t lo = a0 + 8u * (uint32_t)j;
+        uint64_t m = ~0ull;
+        if (lo < start) m &= ~0ull << (8u * (uint32_t)(start - lo));
+        if (lo + 8 > end) m = lo >= end ? 0ull : (m & (~0ull >> (8u * (uint32_t)(lo + 8 - end))));
+        uint64_t x = r.w[j] & m;
+        x = (x & 0x00FF00FF00FF00FFULL) + ((x >> 8) & 0x00FF00FF00FF00FFULL);
+        x = (x & 0x0000FFFF0000FFFFULL) + ((x >> 16) & 0x0000FFFF0000FFFFULL);
+        sum += (uint32_t)x + (uint32_t)(x >> 32);
+    }
+    return sum;
+}
 /* the simple path behind a pointer: position of its first nucleotide (the junction's out-edge) and how many nucleotides follow the
  * junction up to the end of the unitig in the walking direction (>= 1) */
 MTG_DEV void us_run(const UStore& us, uint64_t up, int k, uint64_t& pos, uint32_t& left)

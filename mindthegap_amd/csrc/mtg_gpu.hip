@@ -311,11 +311,13 @@ __constant__ Index c_ix[TRAVERSAL_SETS];
 __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 
 /* one gap per lane, one wave per workgroup (waves retire independently) */
-#ifdef MTG_STAGE_A_WAVES /* experiment: registers capped for this many waves per SIMD (the default build lets the compiler use what it needs: 2) */
-#define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
-#else
-#define MTG_STAGE_A_ATTR
+/* Registers capped for two waves per SIMD: the kernel lives on memory latency, and a batch of 100 000 gaps (1 563 waves) then fits the
+ * 2 048 wave slots of the chip in one round; left alone the compiler takes 289 registers (one wave per SIMD, two rounds).
+ * -DMTG_STAGE_A_WAVES=n: experiments with another cap. */
+#ifndef MTG_STAGE_A_WAVES
+#define MTG_STAGE_A_WAVES 2
 #endif
+#define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
 __global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,

@@ -1114,24 +1114,33 @@ MTG_DEV_NOINLINE bool snp_bulk(Worker& W, uint64_t prev_c, const Kmer x[2], cons
 MTG_UNROLL
     for (int br = 0; br < 2; br++)
         if (!(r[br].up && popc4(r[br].out) == 1 && popc4(r[br].in) == 1)) return false;
-    uint64_t pos[2];
-    uint32_t left[2];
-    us_run(us, r[0].up, k, pos[0], left[0]);
-    us_run(us, r[1].up, k, pos[1], left[1]);
+    /* one round of reads: the two headers (lengths; a branch walked against the stored orientation knows its length from the pointer), both
+     * sequences at their greatest possible length and both abundance runs; lengths are applied afterwards */
+    uint64_t pos[2], lo[2], hi[2];
+    uint32_t left[2], off_[2];
+    bool bw[2];
+    AbRun ar[2];
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        const uint64_t hdr = up_hdr(r[br].up), base = (hdr + 1) * 32;
+        off_[br] = up_off(r[br].up);
+        bw[br] = up_bwd(r[br].up);
+        pos[br] = bw[br] ? base + off_[br] - 1u : base + off_[br] + (uint32_t)k - 1u;
+        lo[br] = us_peek64(us.words, pos[br], 32u, bw[br]);
+        hi[br] = (bw[br] && off_[br] <= 32u) ? 0ull : us_peek64(us.words, bw[br] ? pos[br] - 32 : pos[br] + 32, 32u, bw[br]); /* backward: no more than off nucleotides lie before the junction */
+        left[br] = bw[br] ? off_[br] : (uint32_t)us.words[hdr] - (off_[br] + (uint32_t)k - 1u);
+        /* abundances of the m + 1 nodes: the k-mers at unitig index off - 1 .. off - 1 + m (forward) or off - m .. off (backward, m = off) */
+        us_ab_issue(us.ab, bw[br] ? base : base + off_[br] - 1u, ar[br]);
+    }
     W.lines += 2;
     if (left[0] != left[1] || left[0] + 1u > (uint32_t)SNP_MAX_L) return false;
     const uint32_t m = left[0]; /* nodes of a branch behind its first one */
-    uint64_t lo[2], hi[2];
-    uint32_t s[2] = {0, 0};
+    uint32_t s[2];
 MTG_UNROLL
     for (int br = 0; br < 2; br++) {
-        const bool bwd = up_bwd(r[br].up);
-        lo[br] = us_peek64(us.words, pos[br], m < 32u ? m : 32u, bwd);
-        hi[br] = m > 32u ? us_peek64(us.words, bwd ? pos[br] - 32 : pos[br] + 32, m - 32u, bwd) : 0ull;
-        /* abundances of the m + 1 nodes: the k-mers at unitig index off - 1 .. off - 1 + m (forward) or off - m .. off (backward) */
-        const uint64_t base = (up_hdr(r[br].up) + 1) * 32;
-        const uint32_t off = up_off(r[br].up), first = bwd ? off - m : off - 1u;
-        s[br] = us_ab_sum(us.ab, base + first, m + 1u);
+        lo[br] &= m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull);
+        hi[br] = m > 32u ? (hi[br] & ((1ull << (2u * (m - 32u))) - 1ull)) : 0ull;
+        s[br] = us_ab_finish(ar[br], m + 1u);
     }
     Kmer z[2] = {x[0], x[1]};
 MTG_UNROLL
@@ -1496,6 +1505,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     bool found_R = false;
     Adj a;
     a.out = a.in = a.la = 0;
+    bool a_is_cur = false; /* a is the right neighbourhood of cur (false from the moment cur moves on until the next read) */
     /* bulk steps of phase W: low halves of the k-mers to watch for, and the deferred "previous node" */
     const bool bulk_ok = k >= 16; /* a step never covers more than MTG_LA_MAX + 1 <= k nucleotides, and 32 bits are a suffix of the k-mer */
     const uint32_t r0_lo = (uint32_t)R.r0;
@@ -1545,11 +1555,26 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             MTG_T0(t_rd);
             const Adj r = adj_right_t(adj, node, mk1, lines);
             if (!(r.up && popc4(r.out) == 1 && popc4(r.in) == 1)) { run_take = 0; MTG_T1(t_rd, 9); return r; }
-            us_run(us, r.up, k, run_pos, run_left);
+            /* the unitig's length (header word; a walk against the stored orientation does not need it) and the first nucleotides of the
+             * run are read together: sixteen nucleotides whatever the run holds, cut to its length afterwards */
+            const uint64_t hdr = up_hdr(r.up);
+            const uint32_t off = up_off(r.up);
             run_bwd = up_bwd(r.up);
-            run_base = (up_hdr(r.up) + 1) * 32;
+            run_base = (hdr + 1) * 32;
+            run_pos = run_bwd ? run_base + off - 1u : run_base + off + (uint32_t)k - 1u;
+            const uint32_t seq16 = us_peek(us.words, run_pos, 16u, run_bwd);
+            run_left = run_bwd ? off : (uint32_t)us.words[hdr] - (off + (uint32_t)k - 1u);
             store_reads++;
             MTG_T1(t_rd, 9);
+            Adj c;
+            run_take = run_left < (uint32_t)MTG_LA_MAX + 1 ? run_left : (uint32_t)MTG_LA_MAX + 1;
+            const uint32_t seq = seq16 & (run_take >= 16u ? 0xFFFFFFFFu : ((1u << (2u * run_take)) - 1u));
+            run_nt += run_take;
+            c.out = 1u << (seq & 3u);
+            c.in = 1u << ((uint32_t)(node.f >> (2 * (k - 1))) & 3u);
+            c.la = (run_take - 1) | ((seq >> 2) << 4);
+            c.up = 0;
+            return c;
         }
         return run_chunk(node);
     };
@@ -1691,6 +1716,7 @@ MTG_UNROLL
             watch_r = r_is_kmer && node_depth > k; /* found_R only matters there (see phase E) */
             run_left = 0;
             a = next_adj(cur);
+            a_is_cur = true;
             start_base = ~0ull;
             if (run_left) { start_base = run_base; start_idx = run_idx(); }
             if (watch_r && !r_known && us.nwords) { /* first contig below the first BFS level: where the target's first k-mer sits */
@@ -1729,11 +1755,13 @@ MTG_UNROLL
                 if (len + nbulk + 32u > MAXLEN) nbulk = MAXLEN > len + 32u ? MAXLEN - len - 32u : 0u;
                 if (nbulk >= 32u) {
                     MTG_T0(t_ls);
+                    a_is_cur = false;
                     run_long_step(nbulk);
                     MTG_T1(t_ls, 8);
                     lazy_prev = false;
                     if (ovf || W.status) { end_contig = true; break; }
                     a = run_chunk(cur);
+                    a_is_cur = true;
                     continue;
                 }
             }
@@ -1745,6 +1773,7 @@ MTG_UNROLL
             /* The step covers j = known + 1 nucleotides.  Per nucleotide the reference only (a) compares the node with the start node
              * (looping contig) and (b), below the first BFS level, with the first k-mer of R.  Both are evaluated for all j nodes on the
              * low 32 bits of the forward k-mers; unless one of them may hit, or a limit is near, the step is then taken in one go. */
+            a_is_cur = false; /* the walk moves on */
             const uint32_t j = known + 1;
             const uint32_t seq = nt | (la << 2);
             bool bulk = bulk_ok && len + j <= MAXLEN;
@@ -1795,12 +1824,21 @@ MTG_UNROLL
             const Adj a2 = next_adj(cur);
             if (!(popc4(a2.out) == 1 && indeg == 1)) W.mark_canon(canon(cur)); /* terminator.mark(cur) */
             a = a2;
+            a_is_cur = true;
             if (canon(cur) == start_c || len > MAXLEN || ovf || W.status) { end_contig = true; break; } /* looping / limits */
         }
         if (lazy_prev) { prev_c = canon(kmer_advance(pv, pv_seq & ((1u << (2 * pv_cnt)) - 1u), pv_cnt, k, mk)); lazy_prev = false; }
         MTG_T1(t_w, 0);
         MTG_T0(t_b);
         /* ---- phase B: branching node ---- */
+        if (!end_contig && a.out == 0) {
+            /* dead end.  The reference still calls explore_branching here: its frontline has no successor to move to and gives up at once,
+             * nothing is marked and its visited set is dropped -- the contig ends, which is all that is left of the call. */
+            end_contig = true;
+#ifdef MTG_EMU /* TEST-ONLY: run it anyway and see that nothing comes of it */
+            { int ch_ = -1; const uint32_t nm_ = W.n_marked; if (explore_branching(W, cur, prev_c, ch_) != 0 || W.n_marked != nm_ || W.n_seen != 0) W.status = 0xBAD9; }
+#endif
+        }
         if (!end_contig) {
             int chosen = -1;
             MTG_T0(t_snp);
@@ -1819,6 +1857,7 @@ MTG_UNROLL
                 /* terminator.mark() along the consensus of the general code: only branching nodes are marked, and a node inside a stored unitig
                  * (not its end node) has one in- and one out-edge -- c_ra = nodes known to lie ahead of the current one in its unitig */
                 uint32_t c_ra = 0;
+                a_is_cur = false;
                 for (int i = 0; i < n; i++) {
                     const uint32_t nti = fast ? fast_seq.get(i) : (uint32_t)p[i];
                     prev_c = canon(cur);
@@ -1852,7 +1891,7 @@ MTG_UNROLL
                 }
                 MTG_T1(t_cons, 7);
                 if (looping || len > MAXLEN || ovf || W.status) end_contig = true;
-                else a = next_adj(cur);
+                else { a = next_adj(cur); a_is_cur = true; }
             }
         }
         MTG_T1(t_b, 1);
@@ -1873,7 +1912,10 @@ MTG_UNROLL
         if ((int)nb > cfg.max_nodes) break;
         if (node_depth + (int)clen > cfg.max_depth) continue;
         /* push the successors that were never extended from */
-        const Adj ea = adj_right_t(adj, cur, mk1, lines);
+        const Adj ea = a_is_cur ? a : adj_right_t(adj, cur, mk1, lines); /* the walk usually stopped on a node whose neighbourhood it has just read */
+#ifdef MTG_EMU
+        { uint32_t l_ = 0; if (adj_right_t(adj, cur, mk1, l_).out != ea.out) W.status = 0xBADA; }
+#endif
         for (uint32_t nt = 0; nt < 4; nt++) {
             if (!(ea.out & (1u << nt))) continue;
             const Kmer s = kmer_next(cur, nt, k, mk);

@@ -24,7 +24,9 @@ def load():
         return _lib
     deps = [SRC] + HDRS
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall"] + SAN + ["-o", SO, SRC])
+        tmp = SO + ".%d.tmp" % os.getpid()  # several pytest workers may build at once: each writes its own file, the rename is atomic
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall"] + SAN + ["-o", tmp, SRC])
+        os.replace(tmp, SO)
     lib = C.CDLL(SO)
     P = C.POINTER
     lib.emu_index_create.restype = C.c_void_p
