@@ -176,7 +176,7 @@ def main():
 
     pg = None  # N > 1: pipelined gather of every batch's sequences on rank 0 (created after the first, untimed, pass)
     acc = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
-               post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, gaps=0)
+               post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0, gaps=0)
     acc_lock = threading.Lock()
 
     def fill(b, prepared=None, want_seqs=False, record=False):
@@ -410,13 +410,14 @@ def main():
     # store themselves, the contig words the lanes write, one 16-byte command per run left to k_copy; k_copy: every word once in, once out
     lane_nt = max(acc["run_nt"] - 32 * acc["copy_words"], 0)
     sa_parts = {"adj_bucket_reads_x_%dB" % bucket: acc["index_lines"] / L * bucket, "unitig_store_word_reads_x_8B": acc["store_runs"] / L * 8, "unitig_sequence_2bit_taken_by_lanes": lane_nt / L / 4,
-                "contig_words_written_by_lanes_x_8B": (acc["contig_words"] - acc["copy_words"]) / L * 8, "copy_commands_x_16B": acc["copy_cmds"] / L * 16,
+                "contig_words_written_by_lanes_x_8B": (acc["contig_words"] - acc["copy_words"]) / L * 8, "copy_commands_x_24B": acc["copy_cmds"] / L * 24,
                 "per_gap_input_and_record": gaps_l * (8 + 8 + 4 + 4 + 16 + 36)}
-    cp_parts = {"unitig_words_read_x_8B": (acc["copy_words"] + acc["copy_cmds"]) / L * 8, "contig_words_written_x_8B": acc["copy_words"] / L * 8, "copy_commands_x_16B": acc["copy_cmds"] / L * 16,
+    cp_parts = {"unitig_words_read_x_8B": (acc["copy_words"] + acc["copy_cmds"]) / L * 8, "contig_words_written_x_8B": acc["copy_words"] / L * 8, "copy_commands_x_24B": acc["copy_cmds"] / L * 24,
                 "per_gap_record": gaps_l * 36}
     po_parts = {"contig_words_scanned_x_8B": acc["contig_words"] / L * 8, "bucket_reads_x_32B": acc["post_lines"] / L * 32,
-                "coverage_abundance_bytes_and_kmer_check": acc["coverage_kmers"] / L * (1 + 0.25 * (1 + k / 64.0)), "per_gap_record_and_targets": gaps_l * (36 + 136 + 16 + 2 * 128)}
-    em_parts = {"ascii_written": acc["seq_bytes"] / L, "contig_2bit_read": acc["seq_bytes"] / L / 4, "per_gap_records": gaps_l * (136 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / L * 16}
+                "coverage_abundance_bytes": acc["coverage_kmers"] / L, "coverage_kmer_check_of_looked_up_blocks": (acc["coverage_kmers"] - acc["coverage_direct_kmers"]) / L * 0.25 * (1 + k / 64.0),
+                "per_gap_record_and_targets": gaps_l * (36 + 144 + 16 + 2 * 128 + 24)}
+    em_parts = {"ascii_written": acc["seq_bytes"] / L, "contig_2bit_read": acc["seq_bytes"] / L / 4, "per_gap_records": gaps_l * (144 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / L * 16}
     kerns = [kern("k_stage_a", acc["kernel_ms"], sum(sa_parts.values()), sa_parts), kern("k_copy", acc["copy_kernel_ms"], sum(cp_parts.values()), cp_parts),
              kern("k_post(+k_scan1,k_scan2)", acc["post_kernel_ms"], sum(po_parts.values()), po_parts), kern("k_emit", acc["emit_kernel_ms"], sum(em_parts.values()), em_parts)]
     dom = max(kerns, key=lambda x: x["avg_kernel_ms"])

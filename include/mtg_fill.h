@@ -201,7 +201,8 @@ typedef struct mtg_batch_stats {
     uint64_t seq_bytes;          /* bytes of ASCII the result kernel wrote into the sequence arena */
     double copy_kernel_ms;       /* HIP-event time of the copy kernel (k_copy: long runs of the contigs out of the unitig store, one wave per gap) */
     uint64_t copy_words;         /* 8-byte words of contig arena it wrote */
-    uint64_t copy_cmds;          /* runs it copied (one 16-byte command each) */
+    uint64_t copy_cmds;          /* runs it copied (one 24-byte command each) */
+    uint64_t coverage_direct_kmers; /* of coverage_kmers: abundance bytes read at places known from the copy commands (no look-up, nothing to verify) */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);
 

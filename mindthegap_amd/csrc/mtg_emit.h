@@ -32,7 +32,7 @@ MTG_DEV void emit_plan(const GapOut& o, const PostOut& p, bool want_all, int k, 
 /* totals of one part of a batch (device -> host) */
 struct PartTot {
     uint64_t begin[4], end[4]; /* cursors before / after the part: dense words, dense metadata entries, sequence bytes, extension bytes */
-    uint64_t lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, copy_words, copy_cmds;
+    uint64_t lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, copy_words, copy_cmds, cov_direct;
     uint32_t n_retry, n_general, n_filled, n_ext;
 };
 

@@ -365,7 +365,10 @@ __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __r
 
 /* terminal-node search + coverage of the single-contig solution, one wave per gap; leaves the slot's record with what the gap will
  * contribute to the arrays of its batch (mtg_emit.h: emit_plan).  Where it goes is decided by the scan kernels below. */
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
+#ifndef MTG_POST_WAVES
+#define MTG_POST_WAVES 6
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POST_WAVES))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
                                              uint32_t want_all, SlotRec* recs, uint32_t n)
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_
         __syncthreads();
         const GapOut o = outs[slot];
         PostOut po;
-        po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = po.lines = 0;
+        po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = po.lines = po.direct = 0;
         GapScratch S;
         S.z = nullptr;
         S.v = nullptr;
@@ -411,10 +414,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_
  * metadata, the sequence arena, the extension arena, the list of gaps to re-run and the list of multi-contig gaps.  k_scan1: one thread per
  * slot, offsets inside its block of SCAN_SL slots + the block's totals and statistics; k_scan2 (one workgroup): offsets of the blocks on
  * top of the batch's cursors, totals of the launch; k_emit adds the two. */
-enum { SCAN_SL = 256, SCAN_NV = 6, SCAN_NS = 11 };
+enum { SCAN_SL = 256, SCAN_NV = 6, SCAN_NS = 12 };
 struct ScanBlock {
     uint64_t v[SCAN_NV]; /* k_scan1: totals of the block; k_scan2: replaced by the block's base */
-    uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext, copy_words, copy_cmds */
+    uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext, copy_words, copy_cmds, cov_direct */
 };
 __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, ScanBlock* blocks)
 {
@@ -443,6 +446,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
             atomicAdd(&ssum[3], (unsigned long long)r.o.total_nt);
             atomicAdd(&ssum[5], (unsigned long long)r.p.lines);
             atomicAdd(&ssum[6], (unsigned long long)r.p.ab_n);
+            if (r.p.direct) atomicAdd(&ssum[11], (unsigned long long)r.p.ab_n);
             if (r.asc) atomicAdd(&ssum[7], 1ull);
             if (r.ext) atomicAdd(&ssum[8], 1ull);
         }
@@ -496,7 +500,7 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         tot->lines = ssum[0]; tot->store_runs = ssum[1]; tot->run_nt = ssum[2]; tot->contig_nt = ssum[3]; tot->contig_words = ssum[4];
         tot->post_lines = ssum[5]; tot->cov_kmers = ssum[6];
         tot->n_filled = (uint32_t)ssum[7]; tot->n_ext = (uint32_t)ssum[8];
-        tot->copy_words = ssum[9]; tot->copy_cmds = ssum[10];
+        tot->copy_words = ssum[9]; tot->copy_cmds = ssum[10]; tot->cov_direct = ssum[11];
     }
 }
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
@@ -1408,7 +1412,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             t0 = now_ms();
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
             st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += tw;
-            st.copy_words += tot.copy_words; st.copy_cmds += tot.copy_cmds;
+            st.copy_words += tot.copy_words; st.copy_cmds += tot.copy_cmds; st.coverage_direct_kmers += tot.cov_direct;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
             sink.n_filled += tot.n_filled;

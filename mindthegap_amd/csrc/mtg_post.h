@@ -20,6 +20,7 @@ struct PostOut {
     uint32_t ab_sum, ab_n;        /* coverage pass (fast == 1) */
     uint32_t med_hi, med_lo;      /* sorted[n/2], sorted[n/2-1] */
     uint32_t lines;               /* index buckets read by the coverage pass (block look-ups + k-mers the store did not confirm) */
+    uint32_t direct;              /* 1: the abundances were read at places known from the traversal's copy command (no look-up) */
 };
 
 /* everything the device keeps about one gap of a launch: the counters of the traversal and of the post-processing, what the gap
@@ -68,6 +69,7 @@ MTG_DEV uint32_t wave_sum32(uint32_t x) { return x; }
 MTG_DEV void hist_add(uint32_t* h, uint32_t v) { h[v]++; }
 MTG_DEV void wave_sync() {}
 MTG_DEV bool wave_any(bool x) { return x; }
+MTG_DEV uint32_t wave_max32(uint32_t x) { return x; }
 #else
 #define MTG_LANE() (threadIdx.x & 63u)
 #define MTG_NLANES 64u
@@ -87,6 +89,11 @@ MTG_DEV uint32_t wave_sum32(uint32_t x)
 }
 MTG_DEV void hist_add(uint32_t* h, uint32_t v) { atomicAdd(&h[v], 1u); }
 MTG_DEV bool wave_any(bool x) { return __ballot(x) != 0ull; }
+MTG_DEV uint32_t wave_max32(uint32_t x)
+{
+    for (int m = 32; m >= 1; m >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)x, m, 64); x = y > x ? y : x; }
+    return x;
+}
 MTG_DEV void wave_sync() { __syncthreads(); }
 #endif
 
@@ -101,7 +108,10 @@ MTG_DEV uint64_t le_kmer(const uint64_t* w, uint32_t j, uint64_t mk)
 
 /* The scans read a contig through a tile of its words staged in LDS: one round of wide, coalesced loads per tile instead of one
  * dependent round trip to memory per 64 positions (which is what bound this kernel: 47 round trips for a 3 kb contig). */
-enum { POST_TILE = 512 }; /* words = 16384 nucleotides */
+#ifndef MTG_POST_TILE
+#define MTG_POST_TILE 512
+#endif
+enum { POST_TILE = MTG_POST_TILE }; /* words; 512 = 16384 nucleotides */
 
 /* hist: 256 zeroed counters shared by the lanes; tile: POST_TILE + 2 words; blk: 64 words (all LDS on the device) */
 /* dbg (timing experiments only, never set by the product): bit 0 = no coverage pass, bit 1 = no terminal search */
@@ -183,7 +193,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     out.clen0 = o.n_contigs ? clen[0] : 0;
     out.fast = 0;
     out.pos = pos0; out.errors = err0; out.target = tgt0;
-    out.ab_sum = out.ab_n = out.med_hi = out.med_lo = out.lines = 0;
+    out.ab_sum = out.ab_n = out.med_hi = out.med_lo = out.lines = out.direct = 0;
     if (!(has0 && T.fast_ok)) return;
     /* src/GraphAnalysis.cpp:404-407 (pos <= k-1: nothing left of the first node) and :410-423 with pos == k (an empty substr): the
      * sequence is empty and dropped by `sequence.length() > 0` (:449), so the gap has a terminal node but no solution */
@@ -192,16 +202,54 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     const uint64_t* w0 = words + cstart[0];
     const uint32_t nk = pos0 - (uint32_t)k + 1;
     const uint32_t nw0 = (pos0 + 31) / 32; /* words holding contig0[0:pos0] */
-    if (nw0 <= (uint32_t)POST_TILE) {
+    uint32_t sum = 0, lines = 0;
+    const uint64_t cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    /* The traversal took contig0[0:pos0] -- usually all of it -- out of ONE stretch of the unitig store and said so in the copy command it
+     * left (CopyCmd: the arena words it stands for and the nucleotides before them that continue the stretch): the k-mers of the region
+     * then sit at known places of the store, their abundance bytes next to them: no look-up, nothing to verify. */
+    int direct = -1;
+    if (ix.us.nwords != 0 && !(dbg & 1u)) {
+        const CopyCmd* cmds = s_cmd(cfg, S);
+        const uint64_t a_lo = 32ull * cstart[0], a_hi = a_lo + pos0;
+        for (uint32_t c = 0; c < o.n_cmds; c++) {
+            const uint64_t lo = 32ull * cmds[c].dst - cmds[c].lead, hi = 32ull * ((uint64_t)cmds[c].dst + cmds[c].nwords);
+            if (a_lo >= lo && a_hi <= hi) { direct = (int)c; break; }
+        }
+    }
+    if (direct < 0 && nw0 <= (uint32_t)POST_TILE) { /* the look-ups below read the region's k-mers many times: from LDS */
         wave_sync();
         for (uint32_t i = lane; i < nw0; i += MTG_NLANES) tile[i] = w0[i];
         if (lane == 0) tile[nw0] = 0;
         wave_sync();
         w0 = tile;
     }
-    uint32_t sum = 0, lines = 0;
-    const uint64_t cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
     if (dbg & 1u) { if (lane == 0) hist[1] = nk; sum = lane == 0 ? nk : 0; } /* timing experiment: no look-ups */
+    else if (direct >= 0) {
+        const CopyCmd cm = s_cmd(cfg, S)[direct];
+        const bool bwd = (cm.src & 1ull) != 0;
+        const int64_t p = (int64_t)(cm.src >> 1), rel0 = (int64_t)(32ull * cstart[0]) - (int64_t)(32ull * cm.dst);
+        for (uint32_t j = lane; j < nk; j += MTG_NLANES) {
+            const int64_t rel = rel0 + (int64_t)j; /* the k-mer's first nucleotide, relative to the command's first one */
+            const uint64_t kpos = (uint64_t)(bwd ? p - rel - (int64_t)(k - 1) : p + rel);
+            const uint32_t a = ix.us.ab[kpos];
+#ifdef MTG_EMU /* TEST-ONLY: the k-mer found there is the contig's, and the byte is its abundance */
+            {
+                Kmer x;
+                x.r = le_kmer(w0, j, mk) ^ cmpl;
+                x.f = revcomp(x.r, k);
+                const uint64_t sr = le_kmer(ix.us.words, kpos, mk) ^ cmpl;
+                uint32_t l_ = 0;
+                if (sr != (bwd ? x.f : x.r) || a == 0 || a != abundance(ix, x, l_)) {
+                    fprintf(stderr, "direct coverage: j %u nk %u pos0 %u cmd %d dst %u nwords %u lead %u bwd %d p %lld kpos %llu a %u ab %u sr %llx x.f %llx x.r %llx cstart0 %u ncmd %u\n", j, nk, pos0, direct, cm.dst, cm.nwords, cm.lead, (int)bwd, (long long)p, (unsigned long long)kpos, a, abundance(ix, x, l_), (unsigned long long)sr, (unsigned long long)x.f, (unsigned long long)x.r, cstart[0], o.n_cmds);
+                    __builtin_trap();
+                }
+            }
+#endif
+            sum += a;
+            hist_add(hist, a);
+        }
+        out.direct = 1;
+    }
     else if (ix.us.nwords == 0) {
         for (uint32_t j = lane; j < nk; j += MTG_NLANES) {
             Kmer x;
@@ -271,8 +319,9 @@ MTG_UNROLL
     sum = wave_sum32(sum);
     wave_sync();
     uint32_t hi = 0, lo = 0;
-    if (lane == 0) {
-        const uint32_t n2 = nk / 2; /* sorted[n2], sorted[n2-1] */
+    const uint32_t n2 = nk / 2; /* sorted[n2], sorted[n2-1] */
+#ifdef MTG_EMU
+    {
         uint32_t cum = 0;
         bool got_hi = false, got_lo = (n2 == 0);
         for (uint32_t v = 0; v < 256 && !(got_hi && got_lo); v++) {
@@ -281,6 +330,28 @@ MTG_UNROLL
             if (!got_hi && cum > n2) { hi = v; got_hi = true; }
         }
     }
+#else
+    {
+        /* four bins per lane, an inclusive scan over the lanes, and the two lanes that hold the ranks n2 - 1 and n2 say which bins they fall into */
+        uint32_t c4[4], s4 = 0;
+MTG_UNROLL
+        for (int i = 0; i < 4; i++) { c4[i] = hist[4u * lane + (uint32_t)i]; s4 += c4[i]; }
+        uint32_t incl = s4;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
+        uint32_t cum = incl - s4, f_hi = 0, f_lo = 0;
+MTG_UNROLL
+        for (int i = 0; i < 4; i++) {
+            const uint32_t nxt = cum + c4[i];
+            if (cum <= n2 && nxt > n2) f_hi = 4u * lane + (uint32_t)i + 1u;
+            if (n2 > 0 && cum <= n2 - 1u && nxt > n2 - 1u) f_lo = 4u * lane + (uint32_t)i + 1u;
+            cum = nxt;
+        }
+        f_hi = wave_max32(f_hi);
+        f_lo = wave_max32(f_lo);
+        hi = f_hi ? f_hi - 1u : 0u;
+        lo = f_lo ? f_lo - 1u : 0u;
+    }
+#endif
     out.fast = 1;
     out.ab_sum = sum;
     out.ab_n = nk;

@@ -91,6 +91,9 @@ struct CopyCmd {
     uint64_t src;
     uint32_t dst;
     uint32_t nwords;
+    uint32_t lead; /* nucleotides of the arena right before word dst that continue the same stretch of the store (the node the run was entered by, what the walk took
+                      from the run itself before the long step): k_post finds the abundances of the k-mers in [32 dst - lead, 32 (dst + nwords)) next to the stretch */
+    uint32_t pad_;
 };
 enum { COPY_CMDS = 32 };
 MTG_ARR(CopyCmd, s_cmd, r, c.o_cmd)
@@ -150,7 +153,7 @@ inline void finalize_cfg(FillCfg& c)
     c.o_qc = (uint32_t)b; b += 8ull * c.qcap;
     c.o_qd = (uint32_t)b; b += 4ull * c.qcap;
     b = align_up(b, 16);
-    c.o_cmd = (uint32_t)b; b += 16ull * COPY_CMDS; /* the room is there whether or not cmd_cap lets it be used */
+    c.o_cmd = (uint32_t)b; b += (uint64_t)sizeof(CopyCmd) * COPY_CMDS; /* the room is there whether or not cmd_cap lets it be used */
     c.raw_stride = align_up(b + 8, 64);
     /* interleaved per wave: byte offsets within one lane's share (every array starts 8-byte aligned) */
     b = 0;
@@ -1521,6 +1524,7 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     uint64_t run_pos = 0;              /* store position of the next nucleotide of the run */
     uint64_t run_base = 0;             /* store position of the first nucleotide of the run's unitig */
     uint32_t run_left = 0, run_take = 0; /* nucleotides left / handed out with the last neighbourhood */
+    uint32_t run_c0 = 0;               /* where, in the contig arena (nucleotide index), the stretch of the store the run belongs to begins: the first nucleotide of the node it was entered by */
     bool run_bwd = false;
     uint32_t store_reads = 0, run_nt = 0;
     /* long runs are not copied by the lane but left as commands for copy_gap -- unless the pattern is searched in the contigs right here
@@ -1562,6 +1566,9 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             run_bwd = up_bwd(r.up);
             run_base = (hdr + 1) * 32;
             run_pos = run_bwd ? run_base + off - 1u : run_base + off + (uint32_t)k - 1u;
+            /* the node's k nucleotides are the last ones written, and they precede the run in the store -- if the node is the k-mer the junction
+             * follows there (a source k-mer that is not in the graph may share its last k - 1 nucleotides with one that is) */
+            run_c0 = 32u * wpos + nacc - ((r.in == (1u << ((uint32_t)(node.f >> (2 * (k - 1))) & 3u))) ? (uint32_t)k : 0u);
             const uint32_t seq16 = us_peek(us.words, run_pos, 16u, run_bwd);
             run_left = run_bwd ? off : (uint32_t)us.words[hdr] - (off + (uint32_t)k - 1u);
             store_reads++;
@@ -1639,6 +1646,8 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
                     c.src = (p << 1) | (run_bwd ? 1ull : 0ull);
                     c.dst = wpos;
                     c.nwords = nw;
+                    c.lead = 32u * wpos - run_c0;
+                    c.pad_ = 0;
                     cmds[ncmd++] = c;
                     copy_words += nw;
                 }

@@ -304,7 +304,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 c0 += r.nw; c1 += r.nc; c2 += r.asc; c3 += r.ext;
                 tot.lines += r.o.lines; tot.store_runs += r.o.store_reads; tot.run_nt += r.o.run_nt; tot.contig_words += r.o.n_words;
                 if (r.o.status != GAP_OK) { r.rpos = (uint32_t)rlist.size(); rlist.push_back(s); continue; }
-                tot.contig_nt += r.o.total_nt; tot.post_lines += r.p.lines; tot.cov_kmers += r.p.ab_n;
+                tot.contig_nt += r.o.total_nt; tot.post_lines += r.p.lines; tot.cov_kmers += r.p.ab_n; if (r.p.direct) tot.cov_direct += r.p.ab_n;
                 tot.n_filled += r.asc != 0; tot.n_ext += r.ext != 0;
                 if (r.nc) { r.gpos = (uint32_t)glist.size(); glist.push_back(s); }
             }
@@ -348,7 +348,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             if (want_records)
                 for (uint32_t s = 0; s < m; s++) { sink.res[ids[s]] = dres[s]; if (recs[s].asc) sink.fil[ids[s]] = dfil[s]; }
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
-            st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += c0;
+            st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.coverage_direct_kmers += tot.cov_direct; st.dense_words += c0;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
             sink.n_filled += tot.n_filled;
