@@ -1080,6 +1080,12 @@ struct SnpSeq {
     uint64_t lo, hi;
     MTG_DEV uint32_t get(int i) const { return (uint32_t)((i < 32 ? lo >> (2 * i) : hi >> (2 * (i - 32))) & 3u); }
     MTG_DEV void set(int i, uint32_t nt) { if (i < 32) lo |= (uint64_t)nt << (2 * i); else hi |= (uint64_t)nt << (2 * (i - 32)); }
+    /* nucleotides a .. a + c - 1 (c <= 16), the first one in the lowest bits */
+    MTG_DEV uint32_t bits(int a, int c) const
+    {
+        const uint64_t w = a < 32 ? ((lo >> (2 * a)) | (a ? hi << (64 - 2 * a) : 0ull)) : (hi >> (2 * (a - 32)));
+        return (uint32_t)w & (c >= 16 ? 0xFFFFFFFFu : ((1u << (2 * c)) - 1u));
+    }
 };
 #ifdef MTG_EMU
 /* is canonical k-mer c among: the node, prev_c, and the first `steps` nodes of each branch (the walk is replayed from the nucleotides
@@ -1320,14 +1326,26 @@ MTG_UNROLL
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
         unsigned long long* stamp_acc = W.stamp_acc;
 #endif
-        MTG_COUNT(W, 11);
-        MTG_T0(t_nw);
-        const SP<uint8_t> cons = s_cons(W.cfg, W.S);
+        /* every optimal alignment of two sequences of length n that differ in h places has at least n - h matches (validate_consensuses):
+         * when that many pass the 90 % test, so does the traceback's count, whatever it is */
+        bool need_dp = identity_below_90(n - h, n, n);
+#ifdef MTG_EMU
+        const bool bound_says_pass = !need_dp;
+        need_dp = true;
+#endif
+        if (need_dp) {
+            MTG_COUNT(W, 11);
+            MTG_T0(t_nw);
+            const SP<uint8_t> cons = s_cons(W.cfg, W.S);
 MTG_UNROLL
-        for (int br = 0; br < 2; br++)
-            for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
-        matches = nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
-        MTG_T1(t_nw, 12);
+            for (int br = 0; br < 2; br++)
+                for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
+            matches = nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
+            MTG_T1(t_nw, 12);
+#ifdef MTG_EMU
+            if (matches < n - h || (bound_says_pass && identity_below_90(matches, n, n))) { W.status = 0xBAD6; return 0; }
+#endif
+        }
     }
     if (identity_below_90(matches, n, n)) return 0;
     /* most abundant consensus: the last step's buckets and the node's own */
@@ -1867,7 +1885,52 @@ MTG_UNROLL
                  * (not its end node) has one in- and one out-edge -- c_ra = nodes known to lie ahead of the current one in its unitig */
                 uint32_t c_ra = 0;
                 a_is_cur = false;
-                for (int i = 0; i < n; i++) {
+                /* The consensus of the SNP fast path in one go: its nodes are simple (nothing to mark); what the loop below tests per node -- the
+                 * start node, the target's first k-mer -- is tested on the low 32 bits of all n forward k-mers first, and only a possible hit
+                 * sends the walk through the loop. */
+                bool appended = false;
+                if (fast && bulk_ok) {
+                    uint32_t xlo = (uint32_t)cur.f, hit = 0;
+                    for (int i = 0; i < n; i++) {
+                        xlo = (xlo << 2) | fast_seq.get(i);
+                        hit |= ((xlo == start_lo) | (xlo == start_rc_lo) | ((xlo == r0_lo) & r_is_kmer)) ? 1u : 0u;
+                    }
+                    if (!hit) {
+                        Kmer y = cur;
+                        for (int done = 0; done < n - 1;) {
+                            const int c = n - 1 - done < 15 ? n - 1 - done : 15;
+                            y = kmer_advance(y, fast_seq.bits(done, c), (uint32_t)c, k, mk);
+                            done += c;
+                        }
+                        const Kmer z = kmer_next(y, fast_seq.get(n - 1), k, mk);
+#ifdef MTG_EMU /* TEST-ONLY: node by node */
+                        {
+                            Kmer q = cur, qp = cur;
+                            for (int i = 0; i < n; i++) { qp = q; q = kmer_next(q, fast_seq.get(i), k, mk); if (canon(q) == start_c || (r_is_kmer && q.f == R.r0)) W.status = 0xBADB; }
+                            if (q.f != z.f || q.r != z.r || qp.f != y.f) W.status = 0xBADB;
+                        }
+#endif
+                        prev_c = canon(y);
+                        cur = z;
+                        const uint32_t n_lo = n < 32 ? (uint32_t)n : 32u;
+                        for (uint32_t part = 0; part < 2; part++) {
+                            const uint32_t cnt = part == 0 ? n_lo : (uint32_t)n - n_lo;
+                            if (!cnt) break;
+                            const uint64_t piece = part == 0 ? (n_lo < 32u ? fast_seq.lo & ((1ull << (2 * n_lo)) - 1ull) : fast_seq.lo) : (fast_seq.hi & ((1ull << (2 * cnt)) - 1ull));
+                            acc |= piece << (2 * nacc);
+                            const uint32_t tot = nacc + cnt;
+                            if (tot >= 32) {
+                                if (wpos >= cfg.cap_words) ovf = true; else words[wpos] = acc;
+                                wpos++;
+                                acc = nacc ? piece >> (2 * (32 - nacc)) : 0ull;
+                                nacc = tot - 32;
+                            } else nacc = tot;
+                        }
+                        len += (uint32_t)n;
+                        appended = true;
+                    }
+                }
+                for (int i = 0; i < (appended ? 0 : n); i++) {
                     const uint32_t nti = fast ? fast_seq.get(i) : (uint32_t)p[i];
                     prev_c = canon(cur);
                     cur = kmer_next(cur, nti, k, mk);

@@ -2,7 +2,7 @@
 # instruction counts per kernel (one pass of SQ counters) on single batches: rocprofv3 --pmc of scripts/diag_batches.py
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/${1:-r2n}; rm -rf $O; mkdir -p $O
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $O/pmc -o pmc -- python3 scripts/diag_batches.py 1 > /dev/null 2> $O/pmc.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $O/pmc -o pmc -- python3 scripts/diag_batches.py 1 ${2:-} > /dev/null 2> $O/pmc.err
 python3 - $O <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/pmc/**/*counter_collection.csv", recursive=True)[0]
