@@ -73,6 +73,34 @@ __device__ __forceinline__ uint64_t d_splitmix64(uint64_t x)
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
     return x ^ (x >> 31);
 }
+/* Synthetic abundance of a k-mer of the benchmark sets: span > 0: lo + hash % span; span == 0: a Poisson(24) variate (30x reads
+ * of 150 nt leave a mean k-mer coverage of 24) drawn by inversion from the 64-bit hash, at least lo.  T[i] = floor(P(X <= i) * 2^64). */
+__device__ uint32_t d_synth_abundance(uint64_t c, uint32_t lo, uint32_t span)
+{
+    const uint64_t h = d_splitmix64(c);
+    if (span) return lo + (uint32_t)(h % span);
+    static const uint64_t T[64] = {
+        0x0000000029820F1FULL, 0x000000040DB37A1BULL, 0x00000032C0047DE8ULL, 0x000001A8528C9C4CULL,
+        0x00000A69C1BD52A7ULL, 0x00003470A440BDF3ULL, 0x0000DC8C2E4E6B24ULL, 0x00031CEA99EB0617ULL,
+        0x0009DE05DCC0D6EEULL, 0x001BE0F939A5AE81ULL, 0x00471B414BCAE716ULL, 0x00A56BDE8AA7BFA0ULL,
+        0x01620D19086170B3ULL, 0x02BE4A7152F35527ULL, 0x051345E41BED6F11ULL, 0x08CE71CEF7173222ULL,
+        0x0E6733AF3FD5D6BBULL, 0x164DEB0A00E2FB56ULL, 0x20D6DF830249D6D0ULL, 0x2E258D951F01A8AEULL,
+        0x3E1D91AADB117152ULL, 0x505D9655FB237B31ULL, 0x6446559C4CAB85F7ULL, 0x790CADE5ACE06FD0ULL,
+        0x8DD3062F0D1559A9ULL, 0xA1C4A29E73AE8C13ULL, 0xB42D81CA34D97F88ULL, 0xC48AB9F119717462ULL,
+        0xD2917C5B943CD88BULL, 0xDE2D2614CDB90820ULL, 0xE7767AA8FBB5FAFDULL, 0xEEA6FE347A273B24ULL,
+        0xF40B60DD18FC2B41ULL, 0xF7F74B8646AE4E3FULL, 0xFABBF12ADF6848D5ULL, 0xFCA1DF1814EF208BULL,
+        0xFDE5D30B8DF3B05AULL, 0xFEB7F4BE3D509803ULL, 0xFF3CABB5D47DCC02ULL, 0xFF8E5761E2C0FFB3ULL,
+        0xFFBF57FC51B61EB7ULL, 0xFFDC072B030D6910ULL, 0xFFEC6B45B1886EFAULL, 0xFFF59148ADB5489AULL,
+        0xFFFA8EBEAB9F33ACULL, 0xFFFD380EAA825BB5ULL, 0xFFFE9B8650E29D1FULL, 0xFFFF510A38E830E7ULL,
+        0xFFFFABCC2CEAFACCULL, 0xFFFFD8401225D09FULL, 0xFFFFED966BB2B223ULL, 0xFFFFF7A0F0313A61ULL,
+        0xFFFFFC4354BA6591ULL, 0xFFFFFE5C90BE8C72ULL, 0xFFFFFF4B5615BA2BULL, 0xFFFFFFB386F5F35CULL,
+        0xFFFFFFE02E317995ULL, 0xFFFFFFF2FB5802F0ULL, 0xFFFFFFFAC2FE06D0ULL, 0xFFFFFFFDED278637ULL,
+        0xFFFFFFFF31381F94ULL, 0xFFFFFFFFB0B85BEBULL, 0xFFFFFFFFE21349FCULL, 0xFFFFFFFFF4E0987CULL};
+    uint32_t a = 0;
+    for (uint32_t step = 32; step; step >>= 1) if (T[a + step - 1] <= h) a += step; /* a = number of thresholds <= h */
+    if (a < 64 && T[a] <= h) a++;
+    return a > lo ? a : lo;
+}
 
 /* counters[0] = overflow flag, counters[1] = new k-mers */
 __global__ void k_insert_kmers(Index ix, const uint64_t* __restrict__ kmers, const uint32_t* __restrict__ ab, size_t n, unsigned long long* counters)
@@ -114,7 +142,7 @@ __global__ void k_insert_packed(Index ix, const uint64_t* __restrict__ words, co
             f &= mk;
             const uint64_t r = revcomp(f, k);
             const uint64_t c = f < r ? f : r;
-            const uint32_t a = abund_lo + (uint32_t)(d_splitmix64(c) % (abund_span ? abund_span : 1u));
+            const uint32_t a = d_synth_abundance(c, abund_lo, abund_span);
             int rr = index_insert(ix, c, a);
             fail |= rr & 1;
             created += (rr >> 1) & 1;

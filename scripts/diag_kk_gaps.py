@@ -28,7 +28,7 @@ for r, ps in by.items():
 print("gaps whose two SNPs behind the site are exactly k apart:", len(sel))
 dev = torch.device("cuda", 0)
 w = torch.from_numpy(S.words.view(np.int64)).to(dev); wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev); ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
-idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 40)
+idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 0)
 params = mtg.FillParams(max_nodes=100, max_depth=10000)
 gaps = []
 for i in sel[:64]:

@@ -11,7 +11,7 @@ het = 4 if os.environ.get("HET") else 0
 S = SynthSet(nseq=600000, n_sites=100000, seed=1, k=31, het_snps=het)
 dev = torch.device("cuda", 0)
 w = torch.from_numpy(S.words.view(np.int64)).to(dev); wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev); ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
-idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 40)
+idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 0)
 params = mtg.FillParams(max_nodes=100, max_depth=10000)
 gaps = []
 for i in range(100000):

@@ -30,7 +30,7 @@ def test_config4_full_size(mtg, tmp_path):
     w = torch.from_numpy(S.words.view(np.int64)).to(dev)
     wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev)
     ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
-    idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, K, 3, 40)
+    idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, K, 3, 0)
     del w, wo, ln
     torch.cuda.empty_cache()
     info = idx.info()
@@ -57,7 +57,7 @@ def test_config4_full_size(mtg, tmp_path):
     # record by record against the oracle on the first 30 000 sites (oracle index = the first 30 000 donor sequences)
     res = idx.fill_batch(gaps[:NORACLE], params)
     idx.close()
-    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(NORACLE)], K, 3, 40)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(NORACLE)], K, 3, 0)
     bk = str(tmp_path / "s.breakpoints")
     S.write_breakpoints(bk, range(NORACLE))
     o.fill_files("bkpt", bk, str(tmp_path / "cpu"), params=oracle_lib.default_params(nb_cores=max(1, min(16, os.cpu_count() or 1))))

@@ -3,6 +3,8 @@
 FASTA, seed dictionary) and the graph KATs of both golden logs."""
 import os
 
+import numpy as np
+
 from tests import oracle_lib
 
 
@@ -64,3 +66,22 @@ def test_end_rule_switch_only_changes_info(oracle, golden_dir, tmp_path):
     idx.fill_files("contig", os.path.join(d, "contigs.fasta"), str(tmp_path / "alt"), params=p)
     assert _read(tmp_path / "alt.gfa") == _read(os.path.join(golden_dir, "contig_test", "gold.gfa"))
     idx.close()
+
+
+def test_synthetic_abundance_is_poisson_24():
+    """the abundance model of the synthetic benchmark sets (donor k-mers with Poisson(24) abundance): drawn by inversion from a
+    64-bit hash of the k-mer; mean and variance of 24, the frequencies follow the distribution, never below the solidity threshold"""
+    import math
+    import random
+    rng = random.Random(5)
+    g = "".join(rng.choice("ACGT") for _ in range(60000))
+    idx = oracle_lib.Index.from_sequences([g], 31, 3, 0)
+    km, ct = idx.export()
+    idx.close()
+    ct = np.asarray(ct, dtype=np.float64)
+    assert len(ct) > 59000 and ct.min() >= 3
+    assert abs(ct.mean() - 24.0) < 0.1 and abs(ct.var() - 24.0) < 0.6
+    for v in (15, 20, 24, 28, 35):
+        p = math.exp(-24.0) * 24.0 ** v / math.factorial(v)
+        n = float((ct == v).sum())
+        assert abs(n - p * len(ct)) < 5 * math.sqrt(p * len(ct)), (v, n, p * len(ct))
