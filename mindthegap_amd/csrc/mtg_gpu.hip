@@ -1172,6 +1172,31 @@ struct EventSet { /* events of one device_run call */
  * (k_scan1, k_scan2), results (k_emit); then the totals come back, and with them the sizes of the copies that bring the records and the
  * sequences to the host arrays of `sink`.  The host looks at a gap only if it has to be re-run in a larger scratch tier or takes the
  * multi-contig path (`special`). */
+/* at most MTG_COPY_SLOTS (default 3, 0 = no limit) batches copy their results to the host at the same time */
+struct CopyTurn {
+    static std::mutex& mtx() { static std::mutex m; return m; }
+    static std::condition_variable& cv() { static std::condition_variable c; return c; }
+    static int& busy() { static int b = 0; return b; }
+    static int slots() { static const int s = getenv("MTG_COPY_SLOTS") ? atoi(getenv("MTG_COPY_SLOTS")) : 3; return s; }
+    bool held = false;
+    CopyTurn()
+    {
+        if (slots() <= 0) return;
+        std::unique_lock<std::mutex> lk(mtx());
+        cv().wait(lk, [] { return busy() < slots(); });
+        busy()++;
+        held = true;
+    }
+    void release()
+    {
+        if (!held) return;
+        { std::lock_guard<std::mutex> lk(mtx()); busy()--; }
+        held = false;
+        cv().notify_one();
+    }
+    ~CopyTurn() { release(); }
+};
+
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, ResultSink& sink, DevBatch& special, mtg_batch_stats* stats, const std::function<void()>* while_busy)
 {
     bool busy_done = false;
@@ -1401,7 +1426,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());
                 if (int erc = emit()) return erc;
             }
-            /* bring the launch's results to the host */
+            /* bring the launch's results to the host.  Result copies of six batches at once share the link worse than two or three do
+             * (scripts/pcie_d2h.py: 57 GB/s with two streams copying, 47-52 with six), so the batches of a device take turns */
+            CopyTurn copy_turn;
             std::vector<mtg_gap_result> tmp_res;
             std::vector<mtg_filled> tmp_fil;
             if (want_records) {
@@ -1435,6 +1462,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             }
             HIP_TRY(hipEventRecord(ev3, stream));
             HIP_TRY(hipEventSynchronize(ev3));
+            copy_turn.release();
             st.d2h_ms += now_ms() - t0;
             tick("results on the host");
             t0 = now_ms();
