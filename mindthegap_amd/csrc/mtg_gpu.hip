@@ -857,18 +857,21 @@ static int build_unitigs(mtg_index* idx)
     return MTG_OK;
 }
 
-int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
+/* The index of a counted solid set that arrives in pieces (host arrays, or the records of a saved index read from its file: 36 GB at human
+ * size, never whole in host memory): fetch(off, m, k, a) hands over k-mers [off, off + m) and their abundances; every attempt to build the
+ * tables is one pass over the pieces, the lookaheads are then derived from the tables themselves. */
+int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** out)
 {
     if (int rc = ensure_device()) return rc;
-    if (k < 11 || k > 31 || !out || (n && (!canon_kmers || !abundance))) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (k < 11 || k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
     IndexGuard g(new mtg_index());
     mtg_index* idx = g.idx;
     idx->dev.k = k;
     HIP_TRY(hipGetDevice(&idx->device));
     DevBuf d_k, d_a, d_cnt;
     HIP_TRY(d_cnt.alloc(4 * 8));
-    /* the k-mers go up in pieces (a saved human-size index is 36 GB of them) and each piece is inserted as it arrives */
-    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), (size_t)1 << 26);
+    const size_t env_piece = getenv("MTG_LOAD_PIECE") ? (size_t)atol(getenv("MTG_LOAD_PIECE")) : 0; /* test hook: small pieces */
+    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
     HIP_TRY(d_k.alloc(piece * 8));
     HIP_TRY(d_a.alloc(piece * 4));
     double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
@@ -880,23 +883,23 @@ int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, siz
         HIP_TRY(hipMemset(d_cnt.p, 0, 32));
         for (size_t off = 0; off < n; off += piece) {
             const size_t m = std::min(piece, n - off);
-            HIP_TRY(hipMemcpy(d_k.p, canon_kmers + off, m * 8, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_a.p, abundance + off, m * 4, hipMemcpyHostToDevice));
+            const uint64_t* hk = nullptr;
+            const uint32_t* ha = nullptr;
+            if (!fetch(off, m, hk, ha)) return MTG_ERR_IO; /* the source has set the message */
+            HIP_TRY(hipMemcpy(d_k.p, hk, m * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_a.p, ha, m * 4, hipMemcpyHostToDevice));
             const int blocks = (int)std::min<size_t>((m + 255) / 256 + 1, 256 * 16);
             hipLaunchKernelGGL(k_insert_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(), m, d_cnt.as<unsigned long long>());
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize()); /* the source may reuse its buffers for the next piece */
         }
         unsigned long long cnt[4];
         HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
         idx->info.nb_saturated = cnt[3];
         if (!cnt[0]) {
-            for (size_t off = 0; off < n; off += piece) { /* lookaheads need every k-mer in place: a second sweep over the pieces */
-                const size_t m = std::min(piece, n - off);
-                if (n > piece) {
-                    HIP_TRY(hipMemcpy(d_k.p, canon_kmers + off, m * 8, hipMemcpyHostToDevice));
-                }
-                const int blocks = (int)std::min<size_t>((m + 255) / 256 + 1, 256 * 16);
-                hipLaunchKernelGGL(k_lookahead_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), m);
+            if (n) {
+                const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+                hipLaunchKernelGGL(k_lookahead_table, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipDeviceSynchronize());
@@ -914,6 +917,12 @@ int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, siz
     idx->info.abundance_auto = -1;
     *out = g.release();
     return MTG_OK;
+}
+
+int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
+{
+    if (n && (!canon_kmers || !abundance)) { set_error("invalid argument (null arrays)"); return MTG_ERR_ARG; }
+    return index_from_kmer_pieces(n, k, [&](size_t off, size_t, const uint64_t*& hk, const uint32_t*& ha) { hk = canon_kmers + off; ha = abundance + off; return true; }, out);
 }
 
 int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t total_kmers_ub, int k,
@@ -1293,7 +1302,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
 
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
-        static const bool no_defer = getenv("MTG_NO_DEFER") != nullptr; /* test hook: the lanes of the traversal copy their long runs themselves */
+        const bool no_defer = getenv("MTG_NO_DEFER") != nullptr; /* test hook: the lanes of the traversal copy their long runs themselves */
         if (no_defer || !idx->dev.us.nwords) cfg.cmd_cap = 0;
         /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
         const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + sizeof(mtg_gap_result) + sizeof(mtg_filled);

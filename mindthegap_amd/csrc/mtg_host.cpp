@@ -248,24 +248,36 @@ int index_load(const char* path, mtg_index** out)
     }
     const bool v1 = memcmp(magic, IDX_MAGIC, 8) == 0, v2 = memcmp(magic, IDX_MAGIC2, 8) == 0;
     if (!(v1 || v2) || fread(hdr, 4, 4, f) != 4 || fread(&n, 8, 1, f) != 1) { fclose(f); set_error("%s: not a mtg index", path); return MTG_ERR_FORMAT; }
-    HostIndexData hd;
-    hd.kmers.resize(n);
-    hd.counts.resize(n);
-    bool ok;
-    if (v1) ok = fread(hd.kmers.data(), 8, n, f) == n && fread(hd.counts.data(), 4, n, f) == n; /* version 1: all k-mers, then all abundances */
-    else {
-        ok = true;
-        std::vector<unsigned char> rec((size_t)12 << 20);
-        for (uint64_t off = 0; off < n && ok;) {
-            const size_t m = (size_t)std::min<uint64_t>(n - off, rec.size() / 12);
-            ok = fread(rec.data(), 12, m, f) == m;
-            for (size_t i = 0; i < m && ok; i++) { memcpy(&hd.kmers[off + i], rec.data() + 12 * i, 8); memcpy(&hd.counts[off + i], rec.data() + 12 * i + 8, 4); }
-            off += m;
+    /* the records go to the device piece by piece, straight from the file (every attempt to size the tables reads them once) */
+    const long data0 = ftell(f);
+    std::vector<uint64_t> pk;
+    std::vector<uint32_t> pa;
+    std::vector<unsigned char> rec;
+    auto fetch = [&](size_t off, size_t m, const uint64_t*& hk, const uint32_t*& ha) -> bool {
+        pk.resize(m);
+        pa.resize(m);
+        bool ok;
+        if (v1) { /* version 1: all k-mers, then all abundances */
+            ok = fseek(f, data0 + (long)(8 * off), SEEK_SET) == 0 && fread(pk.data(), 8, m, f) == m && fseek(f, data0 + (long)(8 * n + 4 * off), SEEK_SET) == 0 &&
+                 fread(pa.data(), 4, m, f) == m;
+        } else {
+            ok = fseek(f, data0 + (long)(12 * off), SEEK_SET) == 0;
+            rec.resize((size_t)12 << 20);
+            for (size_t done = 0; done < m && ok;) {
+                const size_t c = std::min(m - done, rec.size() / 12);
+                ok = fread(rec.data(), 12, c, f) == c;
+                for (size_t i = 0; i < c && ok; i++) { memcpy(&pk[done + i], rec.data() + 12 * i, 8); memcpy(&pa[done + i], rec.data() + 12 * i + 8, 4); }
+                done += c;
+            }
         }
-    }
+        if (!ok) set_error("%s: truncated", path);
+        hk = pk.data();
+        ha = pa.data();
+        return ok;
+    };
+    int rc = index_from_kmer_pieces((size_t)n, hdr[0], fetch, out);
     fclose(f);
-    if (!ok) { set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
-    int rc = index_from_kmers(hd.kmers.data(), hd.counts.data(), n, hdr[0], out);
+    if (rc == MTG_ERR_IO) rc = MTG_ERR_FORMAT;
     if (rc) return rc;
     (*out)->info.abundance_min = hdr[1];
     (*out)->info.abundance_auto = hdr[2];

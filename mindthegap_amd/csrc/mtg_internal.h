@@ -537,6 +537,9 @@ struct GapWork {
 
 bool read_sequences(const std::string& path, std::vector<std::pair<std::string, std::string>>& out);
 int index_from_kmers(const uint64_t*, const uint32_t*, size_t, int, mtg_index**);
+/* k-mers [off, off + m) and their abundances of a counted set that is handed over piece by piece (false: failed, message set) */
+using KmerFetch = std::function<bool(size_t off, size_t m, const uint64_t*& kmers, const uint32_t*& abundance)>;
+int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** out);
 int index_from_reads(const char*, int, int, int, mtg_index**);
 int index_save(const mtg_index*, const char*);
 int index_load(const char*, mtg_index**);

@@ -71,6 +71,23 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
         load *= 0.7;
     }
 }
+/* the piecewise source of the index reader: gathered here (MTG_LOAD_PIECE = k-mers per piece, as in the device build) */
+int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** out)
+{
+    const size_t env_piece = getenv("MTG_LOAD_PIECE") ? (size_t)atol(getenv("MTG_LOAD_PIECE")) : 0;
+    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
+    std::vector<uint64_t> km(n);
+    std::vector<uint32_t> ab(n);
+    for (size_t off = 0; off < n; off += piece) {
+        const size_t m = std::min(piece, n - off);
+        const uint64_t* hk = nullptr;
+        const uint32_t* ha = nullptr;
+        if (!fetch(off, m, hk, ha)) return MTG_ERR_IO;
+        memcpy(km.data() + off, hk, m * 8);
+        memcpy(ab.data() + off, ha, m * 4);
+    }
+    return index_from_kmers(km.data(), ab.data(), n, k, out);
+}
 void index_release(mtg_index* idx)
 {
     if (!idx) return;

@@ -744,7 +744,7 @@ def test_snp_fast_path_adversarial(k):
         idx.close()
 
 
-def test_index_container_written_from_the_tables(emu_product, tmp_path):
+def test_index_container_written_from_the_tables(emu_product, tmp_path, monkeypatch):
     """mtg_index_save reads the solid k-mers back from the ABND table (lossless bucket + tag, inverted hash): the file holds exactly the
     k-mers and abundances the index was built from (version 2 container, any order), loads again, and a version 1 file still loads"""
     rng = random.Random(8)
@@ -766,6 +766,7 @@ def test_index_container_written_from_the_tables(emu_product, tmp_path):
         order = np.argsort(rec["k"])
         assert (rec["k"][order] == np.sort(km)).all()
         assert (rec["a"][order] == np.minimum(ct[np.argsort(km)], 255)).all()
+        monkeypatch.setenv("MTG_LOAD_PIECE", "100")  # the reader hands the records over in pieces
         h = emu_product.Index.load(p)
         q = np.concatenate([km, np.array([rng.getrandbits(2 * k) for _ in range(300)], dtype=np.uint64)])
         assert (h.abundance(q) == g.abundance(q)).all()

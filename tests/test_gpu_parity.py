@@ -416,11 +416,14 @@ def test_stage_a_fuzz_on_device(mtg, k):
         o.close()
 
 
-@pytest.mark.parametrize("chunk,parts,host_paths", [(37, 3, False), (1000, 8, False), (0, 1, True)])
-def test_batches_split_into_launches_and_parts(mtg, tmp_path, monkeypatch, chunk, parts, host_paths):
+@pytest.mark.parametrize("chunk,parts,host_paths,own_copy", [(37, 3, False, False), (1000, 8, False, False), (0, 1, True, False), (0, 1, False, True)])
+def test_batches_split_into_launches_and_parts(mtg, tmp_path, monkeypatch, chunk, parts, host_paths, own_copy):
     """the batch machinery under test hooks: several traversal launches per batch (MTG_MAX_CHUNK), post-processing parts per launch
-    (MTG_POST_PARTS), path enumeration left to the host (MTG_HOST_PATHS); results must not depend on any of them"""
+    (MTG_POST_PARTS), path enumeration left to the host (MTG_HOST_PATHS), walks that copy their long runs themselves instead of leaving
+    them to k_copy (MTG_NO_DEFER); results must not depend on any of them"""
     from tests.test_emu_parity import _allelic_inserts_case, _diploid_case, _edge_case_run
+    if own_copy:
+        monkeypatch.setenv("MTG_NO_DEFER", "1")
     if chunk:
         monkeypatch.setenv("MTG_MAX_CHUNK", str(chunk))
     monkeypatch.setenv("MTG_POST_PARTS", str(parts))
@@ -551,7 +554,7 @@ def test_snp_fast_path_adversarial_on_device(mtg, k):
 
 
 @pytest.mark.parametrize("variant,err", [("E0", 0.0), ("E1", 0.001)])
-def test_config2_full_size(mtg, tmp_path, variant, err):
+def test_config2_full_size(mtg, tmp_path, monkeypatch, variant, err):
     """BASELINE config 2 at FULL size: 5 Mbp donor as 1000 x 5 kb sequences, 1000 insertion sites, 30x 150-bp simulated reads
     (1.06 M reads; E0 error-free, E1 0.1 % substitutions), index built from the reads by `-in` with -abundance-min 3 (k-mer counting on
     the device), `MindTheGap fill` outputs byte-identical to the CPU oracle: FASTA with headers, info, VCF body.
@@ -576,13 +579,18 @@ def test_config2_full_size(mtg, tmp_path, variant, err):
         assert seqs == [S.site(i)[2] for i in range(S.n_sites)]
     else:
         assert len(seqs) >= 990
-    # the index the CLI left behind (written from the device tables) loads again and holds the oracle's solid k-mers
+    # the index the CLI left behind (written from the device tables) loads again -- its records go to the device piece by piece, straight
+    # from the file (here in pieces of 700 000 k-mers) -- and holds the oracle's solid k-mers; the tool run on it writes the same files
+    monkeypatch.setenv("MTG_LOAD_PIECE", "700000")
     g = mtg.Index.load(str(tmp_path / "hip.mtgidx"))
     assert g.info()["nb_solid_kmers"] == len(o)
     km, ct = o.export()
     sel = np.random.default_rng(1).choice(len(km), 20000, replace=False)
     assert (g.abundance(km[sel]) == np.minimum(ct[sel], 255)).all()
     g.close()
+    assert mtg.fill_main(["-graph", str(tmp_path / "hip.mtgidx"), "-bkpt", bk, "-out", str(tmp_path / "again")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "again") + ext) == _read(str(tmp_path / "hip") + ext), (variant, ext)
     o.close()
 
 
