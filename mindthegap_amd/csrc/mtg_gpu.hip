@@ -1181,27 +1181,29 @@ struct EventSet { /* events of one device_run call */
  * (k_scan1, k_scan2), results (k_emit); then the totals come back, and with them the sizes of the copies that bring the records and the
  * sequences to the host arrays of `sink`.  The host looks at a gap only if it has to be re-run in a larger scratch tier or takes the
  * multi-contig path (`special`). */
-/* at most MTG_COPY_SLOTS (default 3, 0 = no limit) batches copy their results to the host at the same time */
+/* at most MTG_COPY_SLOTS (default 3, 0 = no limit) batches of one device copy their results to the host at the same time (every device has
+ * its own link: the tool's host threads, one per device, do not wait for each other) */
 struct CopyTurn {
-    static std::mutex& mtx() { static std::mutex m; return m; }
-    static std::condition_variable& cv() { static std::condition_variable c; return c; }
-    static int& busy() { static int b = 0; return b; }
+    enum { MAX_DEV = 64 };
+    struct State { std::mutex m; std::condition_variable c; int busy = 0; };
+    static State& state(int dev) { static State st[MAX_DEV]; return st[(unsigned)dev % MAX_DEV]; }
     static int slots() { static const int s = getenv("MTG_COPY_SLOTS") ? atoi(getenv("MTG_COPY_SLOTS")) : 3; return s; }
-    bool held = false;
-    CopyTurn()
+    State* held = nullptr;
+    explicit CopyTurn(int dev)
     {
         if (slots() <= 0) return;
-        std::unique_lock<std::mutex> lk(mtx());
-        cv().wait(lk, [] { return busy() < slots(); });
-        busy()++;
-        held = true;
+        State& st = state(dev);
+        std::unique_lock<std::mutex> lk(st.m);
+        st.c.wait(lk, [&] { return st.busy < slots(); });
+        st.busy++;
+        held = &st;
     }
     void release()
     {
         if (!held) return;
-        { std::lock_guard<std::mutex> lk(mtx()); busy()--; }
-        held = false;
-        cv().notify_one();
+        { std::lock_guard<std::mutex> lk(held->m); held->busy--; }
+        held->c.notify_one();
+        held = nullptr;
     }
     ~CopyTurn() { release(); }
 };
@@ -1437,7 +1439,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             }
             /* bring the launch's results to the host.  Result copies of six batches at once share the link worse than two or three do
              * (scripts/pcie_d2h.py: 57 GB/s with two streams copying, 47-52 with six), so the batches of a device take turns */
-            CopyTurn copy_turn;
+            CopyTurn copy_turn(idx->device);
             std::vector<mtg_gap_result> tmp_res;
             std::vector<mtg_filled> tmp_fil;
             if (want_records) {
