@@ -425,7 +425,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
             T.n = tcnt[g];
             T.nb_mis = nbmis[g];
             T.fast_ok = fast_ok[g];
+#ifdef MTG_POST_DBG /* timing experiments only (scripts/exp_post_parts.sh): parts of the kernel switched off, results wrong */
+            post_gap(ix, cfg, S, o, T, hist, tile, s_blk, po, MTG_POST_DBG);
+#else
             post_gap(ix, cfg, S, o, T, hist, tile, s_blk, po);
+#endif
         }
         if (threadIdx.x == 0) {
             SlotRec r;

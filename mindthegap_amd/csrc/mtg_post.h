@@ -69,6 +69,7 @@ MTG_DEV uint32_t wave_sum32(uint32_t x) { return x; }
 MTG_DEV void hist_add(uint32_t* h, uint32_t v) { h[v]++; }
 MTG_DEV void wave_sync() {}
 MTG_DEV bool wave_any(bool x) { return x; }
+MTG_DEV int wave_first(bool x) { return x ? 0 : -1; } /* the lowest lane with x, -1: none */
 MTG_DEV uint32_t wave_max32(uint32_t x) { return x; }
 #else
 #define MTG_LANE() (threadIdx.x & 63u)
@@ -89,6 +90,7 @@ MTG_DEV uint32_t wave_sum32(uint32_t x)
 }
 MTG_DEV void hist_add(uint32_t* h, uint32_t v) { atomicAdd(&h[v], 1u); }
 MTG_DEV bool wave_any(bool x) { return __ballot(x) != 0ull; }
+MTG_DEV int wave_first(bool x) { const unsigned long long m = __ballot(x); return m ? (int)__ffsll((long long)m) - 1 : -1; }
 MTG_DEV uint32_t wave_max32(uint32_t x)
 {
     for (int m = 32; m >= 1; m >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)x, m, 64); x = y > x ? y : x; }
@@ -136,11 +138,35 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
      * >= k - nb_mis and stops at the first exact match (src/Filler.cpp:1341-1351); an exact match is the largest possible count, so the
      * result is the first occurrence of the maximum: an arg-max, evaluated here by all lanes at once. */
     const uint64_t le0 = T.n ? T.le[0] : 0ull, bad0 = T.n ? T.bad[0] : ~0ull;
+    const bool single = T.n == 1;
     for (uint32_t c = 0; c < ((dbg & 2u) ? 0u : o.n_contigs); c++) {
         const uint32_t L = clen[c];
         const uint64_t* w = words + cstart[c];
         uint64_t best = 0;
-        if (L >= (uint32_t)k && T.n) {
+        /* One target without an unusable position (breakpoint mode): an exact occurrence is the largest possible count and the first one wins,
+         * whatever inexact matches precede it -- so the contig is first searched for the k-mer itself (a compare per position instead of the
+         * mismatch count), and the counting scan below only runs when it is not there. */
+        bool have_exact = false;
+        if (L >= (uint32_t)k && single && bad0 == 0ull) {
+            const uint32_t npos = L - (uint32_t)k + 1, nwc = (L + 31) / 32;
+            for (uint32_t ws = 0; ws < nwc && !have_exact; ws += POST_TILE) {
+                const uint32_t tw = (nwc - ws) < (uint32_t)POST_TILE + 1 ? (nwc - ws) : (uint32_t)POST_TILE + 1;
+                wave_sync();
+                for (uint32_t i = lane; i < tw; i += MTG_NLANES) tile[i] = w[ws + i];
+                if (lane == 0) tile[tw] = 0;
+                wave_sync();
+                const uint32_t j_lo = 32u * ws;
+                if (j_lo >= npos) break;
+                const uint32_t j_hi = (npos - j_lo) < 32u * POST_TILE ? npos : j_lo + 32u * POST_TILE;
+                for (uint32_t jb = j_lo; jb < j_hi; jb += MTG_NLANES) {
+                    const uint32_t j = jb + lane;
+                    const int f = wave_first(j < j_hi && le_kmer(tile, j - j_lo, mk) == le0);
+                    if (f >= 0) { have_exact = true; best = ((uint64_t)k << 40) | (ORD - (uint64_t)(jb + (uint32_t)f)); break; }
+                }
+                if (j_hi >= npos) break;
+            }
+        }
+        if (!have_exact && L >= (uint32_t)k && T.n) {
             const uint32_t npos = L - (uint32_t)k + 1, nwc = (L + 31) / 32;
             for (uint32_t ws = 0; ws < nwc; ws += POST_TILE) {
                 const uint32_t tw = (nwc - ws) < (uint32_t)POST_TILE + 1 ? (nwc - ws) : (uint32_t)POST_TILE + 1; /* one word past the tile: a k-mer may straddle its end */
@@ -166,7 +192,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                             const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
 #endif
                             if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
-                                const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t));
+                                const uint64_t key = ((uint64_t)nbm << 40) | (ORD - (single ? (uint64_t)j : (uint64_t)j * T.n + t));
                                 best = key > best ? key : best;
                             }
                         }
@@ -177,11 +203,12 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                 if (j_hi >= npos) break;
             }
         }
-        best = wave_max64(best);
+        if (!have_exact) best = wave_max64(best);
         if (best) {
             const uint32_t nbm = (uint32_t)(best >> 40);
             const uint64_t order = ORD - (best & ORD);
-            const uint32_t p = (uint32_t)(order / T.n), t = (uint32_t)(order % T.n);
+            /* one target (breakpoint mode): no 64-bit division, which costs a wave more than the scan of a short contig */
+            const uint32_t p = single ? (uint32_t)order : (uint32_t)(order / T.n), t = single ? 0u : (uint32_t)(order % T.n);
             if (lane == 0) { tpos[c] = p; terr[c] = (uint32_t)k - nbm; ttgt[c] = t; }
             if (c == 0) { has0 = true; pos0 = p; err0 = (uint32_t)k - nbm; tgt0 = t; }
             nterm++;
