@@ -175,6 +175,7 @@ def main():
         batches.append(b)
 
     pg = None  # N > 1: pipelined gather of every batch's sequences on rank 0 (created after the first, untimed, pass)
+    hbm_pool = None  # secondary measurement: device buffers the sequences are left in (queue of torch tensors)
     acc = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
                post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0, gaps=0)
     acc_lock = threading.Lock()
@@ -187,8 +188,18 @@ def main():
         seqs = None
         if pg is not None and not want_seqs:
             j, buf = pg.acquire()
-            h, nf, nbytes = idx.fill_prepared_serial(prepared, buf, params)  # written straight into the page-locked gather buffer
-            pg.submit(nbytes, j)
+            if pg.on_gpu and isinstance(prepared, mtg.Batch):
+                # the sequences stay in HBM: the result kernel writes them into the gather's device buffer, RCCL takes them from there
+                ptr, cap_b = pg.device_area(j)
+                h, nf, nbytes = idx.fill_prepared_serial_device(prepared, ptr, cap_b, params)
+                pg.submit(nbytes, j, on_device=True)
+            else:
+                h, nf, nbytes = idx.fill_prepared_serial(prepared, buf, params)  # written straight into the page-locked gather buffer
+                pg.submit(nbytes, j)
+        elif hbm_pool is not None and not want_seqs and isinstance(prepared, mtg.Batch):
+            t = hbm_pool.get()
+            h, nf, nbytes = idx.fill_prepared_serial_device(prepared, t.data_ptr(), t.numel(), params)
+            hbm_pool.put(t)
         else:
             h, nf, seqs = idx.fill_prepared(prepared, params, want_seqs=want_seqs)
         st = mtg.last_batch_stats()
@@ -357,6 +368,32 @@ def main():
         torch.cuda.synchronize()
         secondary["value_from_host_strings"] = batch_sites * a.steps / (time.perf_counter() - t0)
         secondary["value_from_host_strings_note"] = "same steps through mtg_fill_batch: the sites are marshalled from the caller's strings and uploaded inside every step"
+
+    # ---------------------------------------------------------------- secondary: the sequences left in HBM (a consumer on the device, or the send buffer of a gather):
+    # records still come to the host, the ASCII -- three quarters of the result bytes -- does not cross PCIe
+    if world == 1 and not a.no_secondary and not a.host_strings and batches:
+        import queue
+        cap_b = max(sum(len(e) + 1 for e in b.expected) for b in batches) * 5 // 4 + (1 << 20)
+        hbm_pool = queue.Queue()
+        for _ in range(max(1, a.in_flight)):
+            hbm_pool.put(torch.empty(cap_b, dtype=torch.uint8, device=dev))
+        run_block(max(a.warmup, 1), False)
+        ts = []
+        for r in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_block(a.steps, False, r * a.steps)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = hbm_pool.get()
+        b0 = batches[0]
+        h0, nf0, nb0 = idx.fill_prepared_serial_device(b0.prepared, t.data_ptr(), t.numel(), params)
+        idx.free_results(h0)
+        ok_hbm = hashlib.sha256(t[:nb0].cpu().numpy().tobytes()).hexdigest() == b0.digest if not het else None
+        hbm_pool = None
+        secondary["value_sequences_left_in_hbm"] = batch_sites * a.steps / float(np.median(ts))
+        secondary["value_sequences_left_in_hbm_note"] = ("same steps through mtg_fill_prepared_serial_device: records to the host, ASCII sequences into a device buffer of the caller "
+                                                         "(median of 5 blocks; one buffer verified against the truth: %s)" % ok_hbm)
 
     # ---------------------------------------------------------------- CPU baseline (oracle = "port"), bounded sample, rank 0, N = 1 only
     cpu = None

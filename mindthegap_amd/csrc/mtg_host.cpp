@@ -723,6 +723,7 @@ struct mtg_results {
     char* seq = nullptr;           /* sequence arena (page-locked), or the caller's buffer */
     size_t seq_cap = 0;
     bool seq_external = false;
+    bool seq_on_device = false;    /* the caller's buffer is device memory: the records' seq pointers are device addresses */
     char* seq_own = nullptr;       /* the arena this object owns (kept while the caller's buffer is in use) */
     size_t seq_own_cap = 0;
     char* ext = nullptr;
@@ -836,7 +837,7 @@ int marshal_gaps(const mtg_gap* g, size_t n, const mtg_params* p, mtgi::FillInpu
 
 /* runs a marshalled batch; gaps: the caller's array (multi-contig gaps look at their dictionary) */
 int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillInput& in, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes,
-                    mtg_results** out, double t_begin)
+                    mtg_results** out, double t_begin, bool seq_dev = false)
 {
     using namespace mtgi;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -849,6 +850,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     if (!R->ext) { R->ext_cap = 1 << 16; R->ext = (char*)pinned_alloc(R->ext_cap); if (!R->ext) { R->ext_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
     R->ext[0] = 0;
     R->seq_external = seq_out != nullptr;
+    R->seq_on_device = seq_dev && seq_out != nullptr;
     if (seq_out) { R->seq = seq_out; R->seq_cap = (size_t)seq_cap; }
     else {
         if (!R->seq_own) { R->seq_own_cap = std::max<size_t>(n * 64, 1 << 16); R->seq_own = (char*)pinned_alloc(R->seq_own_cap); if (!R->seq_own) { R->seq_own_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
@@ -859,6 +861,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     sink.n = n;
     sink.res = R->res; sink.fil = R->fil;
     sink.seq = R->seq; sink.seq_cap = R->seq_cap;
+    sink.seq_on_device = R->seq_on_device;
     sink.ext = R->ext; sink.ext_cap = R->ext_cap;
     sink.grow_seq = [&](size_t need, size_t keep) -> bool {
         if (R->seq_external) return false;
@@ -942,19 +945,29 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     if (seq_out) {
         if (R->in_gap_order) *seq_bytes = sink.seq_used; /* every sequence was written in place, in gap order */
         else {
-            /* multi-contig gaps or re-run gaps: lay the sequences out again, in gap order, and make the records point there */
+            /* multi-contig gaps or re-run gaps: lay the sequences out again, in gap order, and make the records point there.  A buffer in
+             * device memory comes to the host for that and goes back (rare: a batch with such a gap) */
             if (R->seq_bytes > seq_cap) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)R->seq_bytes); return MTG_ERR_ARG; }
+            std::vector<char> arena;
+            const uintptr_t d_lo = (uintptr_t)seq_out, d_hi = d_lo + sink.seq_used;
+            if (R->seq_on_device) {
+                arena.resize(sink.seq_used + 1);
+                if (int drc = device_download(idx, arena.data(), seq_out, sink.seq_used)) return drc;
+            }
             R->relaid.resize(R->seq_bytes + 1);
             uint64_t o = 0;
             for (size_t i = 0; i < n; i++)
                 for (int j = 0; j < R->res[i].n_filled; j++) {
                     mtg_filled& f = const_cast<mtg_filled&>(R->res[i].filled[j]);
-                    const size_t len = strlen(f.seq);
-                    memcpy(R->relaid.data() + o, f.seq, len + 1);
+                    const uintptr_t q = (uintptr_t)f.seq;
+                    const char* src = (R->seq_on_device && q >= d_lo && q < d_hi) ? arena.data() + (q - d_lo) : f.seq; /* the others are host strings of the multi-contig path */
+                    const size_t len = strlen(src);
+                    memcpy(R->relaid.data() + o, src, len + 1);
                     f.seq = seq_out + o;
                     o += len + 1;
                 }
-            memcpy(seq_out, R->relaid.data(), o);
+            if (R->seq_on_device) { if (int urc = device_upload(idx, seq_out, R->relaid.data(), o)) return urc; }
+            else memcpy(seq_out, R->relaid.data(), o);
             *seq_bytes = o;
             R->in_gap_order = true;
         }
@@ -1021,7 +1034,7 @@ int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* 
     return MTG_OK;
 }
 void mtg_batch_free(mtg_batch* b) { delete b; }
-static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
+static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out, bool seq_dev = false)
 {
     if (!idx || !p || !b || !out) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     if (b->in.k != idx->dev.k) { mtgi::set_error("the batch was prepared for k = %d", b->in.k); return MTG_ERR_ARG; }
@@ -1035,13 +1048,19 @@ static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const m
     in.block_a = s.block_a; in.block_b = s.block_b; in.block_c = s.block_c; in.bytes_a = s.bytes_a; in.bytes_b = s.bytes_b; in.bytes_c = s.bytes_c;
     in.dev_a = s.dev_a; in.dev_b = s.dev_b; in.dev_tenc = s.dev_tenc;
     in.ws = batch_lock.ws;
-    return fill_marshalled(idx, p, in, b->gaps, b->n, seq_out, cap, seq_bytes, out, t_begin);
+    return fill_marshalled(idx, p, in, b->gaps, b->n, seq_out, cap, seq_bytes, out, t_begin, seq_dev);
 }
 int mtg_fill_prepared(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, mtg_results** out) { return fill_prepared_impl(idx, p, b, nullptr, 0, nullptr, out); }
 int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
 {
     if (!seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     return fill_prepared_impl(idx, p, b, seq_out, cap, seq_bytes, out);
+}
+
+int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* d_seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
+{
+    if (!d_seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    return fill_prepared_impl(idx, p, b, d_seq_out, cap, seq_bytes, out, true);
 }
 
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->n) ? &r->res[i] : nullptr; }
@@ -1066,6 +1085,7 @@ int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
 {
     if (!r || !dst) return MTG_ERR_ARG;
     if (r->seq_bytes > cap) { mtgi::set_error("destination too small"); return MTG_ERR_ARG; }
+    if (r->seq_on_device) { mtgi::set_error("the sequences of these results are in the caller's device buffer"); return MTG_ERR_ARG; }
     if (r->in_gap_order) {
         /* the arena is the concatenation already, with NULs where the line ends go */
         const size_t nb = (size_t)r->seq_bytes, CH = 1 << 16;

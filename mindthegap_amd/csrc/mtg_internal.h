@@ -250,6 +250,9 @@ void* staging_host(Workspace* ws, int slot, size_t bytes);
 /* page-locked host memory for the result arrays of a batch (plain memory in the emulation); nullptr on failure */
 void* pinned_alloc(size_t bytes);
 void pinned_free(void* p);
+/* plain copies between the host and the index's device (rare paths of the host code that touch a caller's device buffer) */
+int device_download(const mtg_index* idx, void* host_dst, const void* dev_src, size_t bytes);
+int device_upload(const mtg_index* idx, void* dev_dst, const void* host_src, size_t bytes);
 
 template <typename T> struct Arr {
     T* p = nullptr;
@@ -399,6 +402,7 @@ struct ResultSink {
     mtg_filled* fil = nullptr;     /* n records: slot i belongs to gap i */
     char* seq = nullptr;           /* sequence arena: NUL-terminated fills, in gap order unless `in_gap_order` comes back false */
     size_t seq_cap = 0;
+    bool seq_on_device = false;    /* seq is memory of the index's device (the caller's): the result kernel writes there and nothing is copied to the host */
     char* ext = nullptr;           /* extension arena; ext[0] = 0 is the empty string of every record without extension */
     size_t ext_cap = 0;
     /* an arena turned out too small: must replace it by a block of at least `need` bytes whose first `keep` bytes are those of the old

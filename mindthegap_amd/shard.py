@@ -94,12 +94,20 @@ class PipelinedGather:
                 self.cond.wait()  # every buffer is in the hands of another caller: one of them will submit
         return j, self.stage[j].numpy()[self.HEADER:]
 
+    def device_area(self, j):
+        """(address, capacity) of the payload area of DEVICE buffer j (after acquire()): a producer on the device -- the fill writing its
+        sequences with mtg_fill_prepared_serial_device -- fills it in place and calls submit(nbytes, j, on_device=True); the payload then
+        never crosses PCIe on its way to the gather"""
+        if not self.on_gpu:
+            raise RuntimeError("device buffers exist only with a GPU backend")
+        return self.dbuf[j].data_ptr() + self.HEADER, self.dbuf[j].numel() - self.HEADER
+
     def buffer(self):
         """numpy view of this step's payload area (capacity bytes); valid until submit()  (one step at a time)"""
         self.cur, view = self.acquire()
         return view
 
-    def submit(self, nbytes, j=None):
+    def submit(self, nbytes, j=None, on_device=False):
         j = self.cur if j is None else j
         if nbytes + self.HEADER > self.stage[j].numel():
             raise ValueError("payload of %d bytes exceeds the agreed capacity" % nbytes)
@@ -108,7 +116,10 @@ class PipelinedGather:
             if self.on_gpu:
                 self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
                 with self.torch.cuda.stream(self.stream):
-                    self.dbuf[j].copy_(self.stage[j], non_blocking=True)
+                    if on_device:  # the payload is in dbuf[j] already: only its length goes up
+                        self.dbuf[j][: self.HEADER].copy_(self.stage[j][: self.HEADER], non_blocking=True)
+                    else:
+                        self.dbuf[j].copy_(self.stage[j], non_blocking=True)
                     self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
             else:
                 self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)

@@ -217,6 +217,9 @@ void* pinned_alloc(size_t bytes)
     return p;
 }
 void pinned_free(void* p) { free(p); }
+/* the emulated device's memory is host memory */
+int device_download(const mtg_index*, void* host_dst, const void* dev_src, size_t bytes) { memcpy(host_dst, dev_src, bytes); return MTG_OK; }
+int device_upload(const mtg_index*, void* dev_dst, const void* host_src, size_t bytes) { memcpy(dev_dst, host_src, bytes); return MTG_OK; }
 int batch_upload(const mtg_index*, FillInput&) { return MTG_OK; } /* nothing to upload: the "device" reads the host blocks */
 void batch_release_device(FillInput&) {}
 

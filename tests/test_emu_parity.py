@@ -778,6 +778,38 @@ def test_index_container_written_from_the_tables(emu_product, tmp_path, monkeypa
         o.close()
 
 
+def test_serialised_batch_left_on_the_device(emu_product):
+    """mtg_fill_prepared_serial_device on the emulation build (where device memory is host memory): the caller's buffer receives the same
+    bytes as the host variant, in place for single-contig gaps and re-laid -- through the host and back -- when a gap takes the
+    multi-contig path"""
+    rng = random.Random(3)
+    seqs, sites = [], []
+    for i in range(24):
+        L, R = _rand_seq(rng, 300), _rand_seq(rng, 300)
+        a, b = _rand_seq(rng, 200 + i), _rand_seq(rng, 300 + i)
+        seqs += [L + a + R, L + b + R] if i % 3 == 0 else [L + a + R]
+        sites.append((L[-31:], R[:31]))
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    idx = emu_product.Index.from_kmers(km, ct, 31)
+    for sel in (range(1, 24, 3), range(24)):  # single-contig gaps only; all of them
+        gaps = [emu_product.Gap(sites[i][0], sites[i][1], [(sites[i][1], "t%d" % i, False)]) for i in sel]
+        out = np.empty(1 << 20, dtype=np.uint8)
+        h, nf, nb = idx.fill_prepared_serial(emu_product.Index.prepare_gaps(gaps), out)
+        idx.free_results(h)
+        batch = idx.prepare_batch(gaps)
+        dev = np.full(1 << 20, 0xEE, dtype=np.uint8)
+        h, nf2, nb2 = idx.fill_prepared_serial_device(batch, dev.ctypes.data, dev.size)
+        idx.free_results(h)
+        assert nb2 == nb and (nf2 == nf).all() and dev[:nb2].tobytes() == out[:nb].tobytes() and nb > 0
+        with pytest.raises(emu_product.MtgError):
+            idx.fill_prepared_serial_device(batch, dev.ctypes.data, 64)
+        batch.close()
+    assert int(nf.max()) == 2  # the last selection held multi-contig gaps
+    idx.close()
+    o.close()
+
+
 def test_stage_a_entry_of_the_product(emu_product):
     """mtg_stage_a_batch (contigs only, no records) through the product's host code on the emulated device"""
     rng = random.Random(4)

@@ -378,6 +378,23 @@ def test_pipelined_gather_on_rccl_single_rank(mtg):
         pg2.drain()
         got = pg2.last()[0]
         assert len(got) >= 8 and zlib.crc32(got[:-4].tobytes()) == int(np.frombuffer(got[-4:].tobytes(), dtype=np.uint32)[0])
+        # payloads produced ON the device (bench.py with N > 1: the fill writes its sequences into the gather's device buffer,
+        # mtg_fill_prepared_serial_device): only the length goes through the staging buffer
+        pg3 = PipelinedGather(1 << 20, dst=0, device=dev, depth=3)
+        last = None
+        for step in range(6):
+            j, _ = pg3.acquire()
+            ptr, cap = pg3.device_area(j)
+            assert cap == 1 << 20 and ptr % 16 == 0
+            n = int(rng.integers(1, 1 << 20))
+            payload = torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8)).to(dev)
+            pg3.dbuf[j][pg3.HEADER: pg3.HEADER + n].copy_(payload)  # stands for the result kernel
+            torch.cuda.synchronize()
+            pg3.submit(n, j, on_device=True)
+            last = payload.cpu().numpy()
+        pg3.drain()
+        got = pg3.last()
+        assert len(got) == 1 and got[0].tobytes() == last.tobytes()
     finally:
         dist.destroy_process_group()
 
@@ -462,6 +479,15 @@ def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
     # too small a buffer is refused
     with pytest.raises(mtg.MtgError):
         idx.fill_prepared_serial(prep, np.empty(1 << 20, dtype=np.uint8))
+    # the same with the sequences left in device memory (mtg_fill_prepared_serial_device): the caller's device buffer holds the same bytes
+    batch = idx.prepare_batch(prep)
+    dbuf = torch.full((64 << 20,), 0xEE, dtype=torch.uint8, device=dev)
+    h, nf, nb2 = idx.fill_prepared_serial_device(batch, dbuf.data_ptr(), dbuf.numel())
+    idx.free_results(h)
+    assert nb2 == nb and (nf == 1).all() and dbuf[:nb2].cpu().numpy().tobytes() == got
+    with pytest.raises(mtg.MtgError):
+        idx.fill_prepared_serial_device(batch, dbuf.data_ptr(), 1 << 20)
+    batch.close()
     idx.close()
     # multi-contig gaps: the fallback lays the sequences out again; compare with the plain results
     rng = random.Random(3)
@@ -482,6 +508,11 @@ def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
     idx2.free_results(h)
     want = b"".join(f["seq"].encode() + b"\0" for g in plain for f in g["filled"])
     assert got == want and max(len(g["filled"]) for g in plain) == 2
+    batch2 = idx2.prepare_batch(gaps2)  # device buffer: the re-laid form goes through the host and back
+    h, nf, nb2 = idx2.fill_prepared_serial_device(batch2, dbuf.data_ptr(), dbuf.numel())
+    idx2.free_results(h)
+    assert dbuf[:nb2].cpu().numpy().tobytes() == want
+    batch2.close()
     idx2.close()
     o.close()
 
