@@ -103,11 +103,20 @@ def main():
     backend = os.environ.get("MTG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     lib.mtg_set_device(local_rank)
+    # test hook: MTG_BENCH_FORCE_GATHER=1 runs the N > 1 result path (process group, pipelined gather of every batch's sequences) in a
+    # world of one rank, the only RCCL configuration a one-GPU box offers
+    dist_on = world > 1 or bool(os.environ.get("MTG_BENCH_FORCE_GATHER"))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    elif dist_on:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
     dev = torch.device("cuda", local_rank)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
@@ -224,7 +233,7 @@ def main():
         return n_filled, seqs
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -276,7 +285,7 @@ def main():
             t.start()
         for t in ts:
             t.join()
-    if world > 1:
+    if dist_on:
         cap = torch.tensor([max([idx.last_seq_bytes] + [sum(len(e) + 1 for e in b.expected) for b in batches])], dtype=torch.int64, device=cdev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
         pg = PipelinedGather(int(cap.item()) * 5 // 4 + (1 << 20), dst=0, device=cdev, depth=max(a.in_flight, 1) + 1)
@@ -291,7 +300,7 @@ def main():
             pg.drain()  # the gathers still in flight belong to the timed steps
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([el], device=cdev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -299,7 +308,7 @@ def main():
 
     times = [timed_block(0)]
     repeats = a.repeats if a.repeats > 0 else int(min(60, max(5, np.ceil(1.0 / max(times[0], 1e-6)))))
-    if world > 1:  # every rank must run the same number of blocks
+    if dist_on:  # every rank must run the same number of blocks
         rt = torch.tensor([repeats], device=cdev, dtype=torch.int64)
         dist.broadcast(rt, src=0)
         repeats = int(rt.item())
@@ -326,7 +335,7 @@ def main():
         identical = None  # diploid: the truth is a haplotype mix, checked against the oracle below
     st_alone = mtg.last_batch_stats() if batches else None  # one batch alone on the device
     n_sites_rank = sum(b.n for b in batches)
-    if world > 1:
+    if dist_on:
         v = torch.tensor([n_filled_rank, n_sites_rank, 1 if identical in (True, None) else 0], device=cdev, dtype=torch.int64)
         dist.all_reduce(v)
         n_filled_all, n_sites_all, ident_all = int(v[0].item()), int(v[1].item()), int(v[2].item()) == world
@@ -336,7 +345,7 @@ def main():
         n_filled_all, n_sites_all = n_filled_rank, n_sites_rank
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -516,10 +525,17 @@ def main():
                                         "ratio_to_headline": d["value"] / value if value else None}
         except Exception as e:  # the headline line does not depend on it
             out["secondary_diploid"] = {"error": repr(e)[:300]}
-    print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         pg_saved.drain()
         dist.destroy_process_group()
+    # the JSON line is the last thing on stdout: whatever native libraries (RCCL's version banner) left in the C stdio buffer goes first
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
