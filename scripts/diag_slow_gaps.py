@@ -9,13 +9,15 @@ import mindthegap_amd as mtg
 from mindthegap_amd.synth import SynthSet
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-S = SynthSet(nseq=600000, n_sites=100000, seed=1, k=31, het_snps=4)
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # first site looked at
+het = 4 if os.environ.get("HET", "1") != "0" else 0  # HET=0: the haploid set
+S = SynthSet(nseq=600000, n_sites=int(os.environ.get("NSITES", max(100000, first + n))), seed=1, k=31, het_snps=het)  # NSITES=400000: the site set of bench.py
 dev = torch.device("cuda", 0)
 w = torch.from_numpy(S.words.view(np.int64)).to(dev); wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev); ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
 idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 0)
 params = mtg.FillParams(max_nodes=100, max_depth=10000)
 gaps = []
-for i in range(n):
+for i in range(first, first + n):
     l, r, ins = S.site(i)
     gaps.append(mtg.Gap(l, r, [(r, "x", False)]))
 
@@ -40,8 +42,8 @@ for pi in np.argsort(-times)[:6]:
     single.sort(reverse=True)
     ms, g = single[0]
     st = t_of(gaps[g:g + 1])[1]
-    ca, cb = S.codes(g).astype(np.int16), S.codes(g + nloci).astype(np.int16)
-    snps = np.nonzero(ca != cb)[0]
-    p, L = int(S.pos[g]), int(S.ins_len[g])
+    gs = first + g  # site number
+    snps = np.nonzero(S.codes(gs).astype(np.int16) != S.codes(gs + nloci).astype(np.int16))[0] if het else np.zeros(0, dtype=np.int64)
+    p, L = int(S.pos[gs]), int(S.ins_len[gs])
     print("piece %d: %.3f ms; slowest gap %d alone: %.3f ms (next %.3f); site pos %d ins %d len %d; SNPs at %s (relative to the end of the insertion: %s); lines %d store_runs %d contig_nt %d"
-          % (pi, times[pi], g, ms, single[1][0], p, L, int(S.lens[g]), snps.tolist(), (snps - (p + L)).tolist(), st["index_lines"], st["store_runs"], st["contig_nt"]))
+          % (pi, times[pi], gs, ms, single[1][0], p, L, int(S.lens[gs]), snps.tolist(), (snps - (p + L)).tolist(), st["index_lines"], st["store_runs"], st["contig_nt"]))
