@@ -490,6 +490,15 @@ def main():
         tb = min(int(info["device_bytes"] // 2), 16 << 30)  # the ceiling is flat beyond ~16 GB (profiles/r01_random_line_ceiling.txt)
         ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), batch_sites, 512, bucket)
         roof["random_read_ceiling_reads_per_s"] = gbps * 1e9 / bucket
+        # the traversal against the HBM-random-read roofline (north star): its dependent random reads (ADJ buckets + short reads of the unitig store)
+        # per second of kernel time, with six batches in flight and for one batch alone, over the measured ceiling of dependent random reads
+        rr = (acc["index_lines"] + acc["store_runs"]) / L
+        avg_s = acc["kernel_ms"] / L * 1e-3
+        roof["random_reads_of_k_stage_a"] = {"per_launch": rr, "reads_per_s": rr / avg_s if avg_s > 0 else 0.0, "frac_of_ceiling": rr / avg_s / roof["random_read_ceiling_reads_per_s"] if avg_s > 0 else 0.0}
+        if st_alone and st_alone["kernel_ms"] > 0:
+            rr1 = (st_alone["index_lines"] + st_alone["store_runs"]) / max(st_alone["n_launches"], 1)
+            t1 = st_alone["kernel_ms"] / max(st_alone["n_launches"], 1) * 1e-3
+            roof["random_reads_of_k_stage_a"]["alone"] = {"per_launch": rr1, "reads_per_s": rr1 / t1, "frac_of_ceiling": rr1 / t1 / roof["random_read_ceiling_reads_per_s"]}
 
     out = {"metric": "breakpoints filled/sec", "value": value, "unit": "breakpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
