@@ -1,4 +1,5 @@
-"""soak: many batches on one index (alternating sizes, forward and serialised calls); prints host RSS and device memory at intervals"""
+"""soak: many batches on one index (alternating sizes; host strings and prepared batches; plain, serialised and device-resident results); prints host
+RSS and device memory at intervals"""
 import os, sys, time, resource
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +19,8 @@ for i in range(S.n_sites):
 preps = [mtg.Index.prepare_gaps(gaps[:n]) for n in (100000, 1000, 37000, 64, 100000)]
 sizes = [100000, 1000, 37000, 64, 100000]
 out = np.empty(80 << 20, dtype=np.uint8)
+dbuf = torch.empty(80 << 20, dtype=torch.uint8, device=dev)
+batches = [idx.prepare_batch(p) for p in preps]  # prepared (device-resident) forms of the same batches
 def rss():
     return int(open("/proc/self/statm").read().split()[1]) * 4096 / 2**20
 t0 = time.time()
@@ -25,6 +28,10 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
     j = it % len(preps)
     if it % 3 == 0:
         h, nf, nb = idx.fill_prepared_serial(preps[j], out)
+    elif it % 5 == 0:
+        h, nf, nb = idx.fill_prepared_serial_device(batches[j], dbuf.data_ptr(), dbuf.numel())
+    elif it % 5 == 1:
+        h, nf, _ = idx.fill_prepared(batches[j], want_seqs=False)
     else:
         h, nf, _ = idx.fill_prepared(preps[j], want_seqs=(it % 7 == 0))
     assert int((nf > 0).sum()) == sizes[j]
