@@ -1142,7 +1142,10 @@ MTG_UNROLL
         us_ab_issue(us.ab, bw[br] ? base : base + off_[br] - 1u, ar[br]);
     }
     W.lines += 2;
-    if (left[0] != left[1] || left[0] + 1u > (uint32_t)SNP_MAX_L) return false;
+    /* a branch that stays inside one unitig for more than SNP_MAX_L nodes cannot meet the other one in time (the meeting node has two
+     * in-edges: it is inside no unitig): the step-by-step loop would walk all SNP_MAX_L steps to find that out */
+    if (left[0] + 1u > (uint32_t)SNP_MAX_L || left[1] + 1u > (uint32_t)SNP_MAX_L) { hopeless = true; return false; }
+    if (left[0] != left[1]) return false;
     const uint32_t m = left[0]; /* nodes of a branch behind its first one */
     uint32_t s[2];
 MTG_UNROLL
