@@ -198,9 +198,11 @@ def main():
         if pg is not None and not want_seqs:
             j, buf = pg.acquire()
             if pg.on_gpu and isinstance(prepared, mtg.Batch):
-                # the sequences stay in HBM: the result kernel writes them into the gather's device buffer, RCCL takes them from there
+                # the result kernel writes the sequences into the gather's device buffer: RCCL takes them from there (no trip to the host and
+                # back), and the batch's own stream copies them to the rank's page-locked buffer as well, so that every rank holds its records
+                # AND sequences in host memory exactly as a single GPU does -- `value` means the same at every N
                 ptr, cap_b = pg.device_area(j)
-                h, nf, nbytes = idx.fill_prepared_serial_device(prepared, ptr, cap_b, params)
+                h, nf, nbytes = idx.fill_prepared_serial_device(prepared, ptr, cap_b, params, host_out=buf)
                 pg.submit(nbytes, j, on_device=True)
             else:
                 h, nf, nbytes = idx.fill_prepared_serial(prepared, buf, params)  # written straight into the page-locked gather buffer
@@ -288,7 +290,7 @@ def main():
     if dist_on:
         cap = torch.tensor([max([idx.last_seq_bytes] + [sum(len(e) + 1 for e in b.expected) for b in batches])], dtype=torch.int64, device=cdev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        pg = PipelinedGather(int(cap.item()) * 5 // 4 + (1 << 20), dst=0, device=cdev, depth=max(a.in_flight, 1) + 1)
+        pg = PipelinedGather(int(cap.item()) * 51 // 50 + (1 << 16), dst=0, device=cdev, depth=max(a.in_flight, 1) + 1)  # the gather moves whole buffers: little slack (the batches and their sizes are known)
     run_block(a.warmup, False)
 
     # ---------------------------------------------------------------- the timed blocks: each EXACTLY a.steps steps between barrier + synchronize

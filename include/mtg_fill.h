@@ -163,10 +163,13 @@ int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* 
 void mtg_batch_free(mtg_batch* b);
 int mtg_fill_prepared(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, mtg_results** out);
 int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out);
-/* The same with the serialised sequences left in DEVICE memory: d_seq_out is a buffer on the index's device (a consumer on the device, or
- * the send buffer of a gather over RCCL / xGMI: the ASCII never crosses PCIe).  The records come to the host as always; the `seq` pointers
- * of their filled sequences are device addresses into d_seq_out.  The buffer is complete when the call returns. */
-int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* d_seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out);
+/* The same with the serialised sequences produced in DEVICE memory: d_seq_out is a buffer of `cap` bytes on the index's device (a consumer
+ * on the device, or the send buffer of a gather over RCCL / xGMI).  host_copy == NULL: they stay there only -- the ASCII never crosses PCIe, the
+ * records come to the host as always and the `seq` pointers of their filled sequences are device addresses into d_seq_out.  host_copy != NULL
+ * (cap bytes, page-locked for speed): they are copied there as well, by the batch's own stream, and the records point into host_copy as
+ * with mtg_fill_prepared_serial.  Both buffers are complete when the call returns. */
+int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* d_seq_out, uint64_t cap, char* host_copy, uint64_t* seq_bytes,
+                                    mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
 /* Every pointer obtained from r dies here.  The library keeps the storage of up to six freed result sets (a few hundred bytes per
  * gap plus the sequences) and hands it to the next batches, which then pay no allocation, page fault or memset. */

@@ -1349,7 +1349,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_fil.alloc(chunk * sizeof(mtg_filled)));
         HIP_TRY(d_rlist.alloc(chunk * 4));
         HIP_TRY(d_glist.alloc(chunk * 4));
-        HIP_TRY(d_seq.alloc(sink.seq_on_device ? 64 : std::max<size_t>(sink.seq_cap, 64))); /* a caller's device buffer is written in place */
+        HIP_TRY(d_seq.alloc(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64))); /* a caller's device buffer is written in place */
         HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
         /* dense words / metadata: only the gaps that need the host bring their contigs back; sized by the last need, grown on demand below */
         HIP_TRY(d_dw.alloc(std::max<size_t>(ws.cap[d_dw.slot], 1 << 20)));
@@ -1399,7 +1399,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             EmitDev D;
             EmitHost H;
             auto emit = [&]() -> int {
-                D.seq = sink.seq_on_device ? sink.seq : d_seq.as<char>(); D.ext = d_ext.as<char>();
+                D.seq = sink.seq_dev ? sink.seq_dev : d_seq.as<char>(); D.ext = d_ext.as<char>();
                 D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
                 D.res = d_res.as<mtg_gap_result>(); D.fil = d_fil.as<mtg_filled>();
                 D.dense_words = d_dw.as<uint64_t>(); D.dense_meta = d_dm.as<uint32_t>();
@@ -1443,7 +1443,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             if (again) {
                 /* the dense arrays hold this launch only (offsets relative to the batch: the launch's part is copied from begin[]) */
                 HIP_TRY(hipStreamSynchronize(stream));
-                if (!sink.seq_on_device) HIP_TRY(d_seq.alloc(std::max<size_t>(sink.seq_cap, 64)));
+                if (!sink.seq_dev) HIP_TRY(d_seq.alloc(std::max<size_t>(sink.seq_cap, 64)));
                 HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
                 HIP_TRY(d_dw.alloc(need_w));
                 HIP_TRY(d_dm.alloc(need_m));
@@ -1468,7 +1468,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     HIP_TRY(hipMemcpyAsync(tmp_res.data(), d_res.p, (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipMemcpyAsync(tmp_fil.data(), d_fil.p, (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
                 }
-                if (!sink.seq_on_device && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], d_seq.as<char>() + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
+                if (!sink.seq_on_device && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], (sink.seq_dev ? sink.seq_dev : d_seq.as<char>()) + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
                 if (tot.end[3] > tot.begin[3]) HIP_TRY(hipMemcpyAsync(sink.ext + tot.begin[3], d_ext.as<char>() + tot.begin[3], tot.end[3] - tot.begin[3], hipMemcpyDeviceToHost, stream));
             }
             std::vector<uint32_t> rlist(tot.n_retry), glist(tot.n_general);

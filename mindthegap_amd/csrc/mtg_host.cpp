@@ -837,7 +837,7 @@ int marshal_gaps(const mtg_gap* g, size_t n, const mtg_params* p, mtgi::FillInpu
 
 /* runs a marshalled batch; gaps: the caller's array (multi-contig gaps look at their dictionary) */
 int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillInput& in, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes,
-                    mtg_results** out, double t_begin, bool seq_dev = false)
+                    mtg_results** out, double t_begin, char* d_seq_out = nullptr)
 {
     using namespace mtgi;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -850,7 +850,8 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     if (!R->ext) { R->ext_cap = 1 << 16; R->ext = (char*)pinned_alloc(R->ext_cap); if (!R->ext) { R->ext_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
     R->ext[0] = 0;
     R->seq_external = seq_out != nullptr;
-    R->seq_on_device = seq_dev && seq_out != nullptr;
+    /* d_seq_out: the arena is produced in this device buffer of the caller; seq_out == d_seq_out: and stays there only */
+    R->seq_on_device = d_seq_out != nullptr && seq_out == d_seq_out;
     if (seq_out) { R->seq = seq_out; R->seq_cap = (size_t)seq_cap; }
     else {
         if (!R->seq_own) { R->seq_own_cap = std::max<size_t>(n * 64, 1 << 16); R->seq_own = (char*)pinned_alloc(R->seq_own_cap); if (!R->seq_own) { R->seq_own_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
@@ -862,6 +863,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     sink.res = R->res; sink.fil = R->fil;
     sink.seq = R->seq; sink.seq_cap = R->seq_cap;
     sink.seq_on_device = R->seq_on_device;
+    sink.seq_dev = d_seq_out;
     sink.ext = R->ext; sink.ext_cap = R->ext_cap;
     sink.grow_seq = [&](size_t need, size_t keep) -> bool {
         if (R->seq_external) return false;
@@ -967,7 +969,10 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
                     o += len + 1;
                 }
             if (R->seq_on_device) { if (int urc = device_upload(idx, seq_out, R->relaid.data(), o)) return urc; }
-            else memcpy(seq_out, R->relaid.data(), o);
+            else {
+                memcpy(seq_out, R->relaid.data(), o);
+                if (d_seq_out) { if (int urc = device_upload(idx, d_seq_out, R->relaid.data(), o)) return urc; } /* the device copy follows */
+            }
             *seq_bytes = o;
             R->in_gap_order = true;
         }
@@ -1034,7 +1039,7 @@ int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* 
     return MTG_OK;
 }
 void mtg_batch_free(mtg_batch* b) { delete b; }
-static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out, bool seq_dev = false)
+static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out, char* d_seq_out = nullptr)
 {
     if (!idx || !p || !b || !out) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     if (b->in.k != idx->dev.k) { mtgi::set_error("the batch was prepared for k = %d", b->in.k); return MTG_ERR_ARG; }
@@ -1048,7 +1053,7 @@ static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const m
     in.block_a = s.block_a; in.block_b = s.block_b; in.block_c = s.block_c; in.bytes_a = s.bytes_a; in.bytes_b = s.bytes_b; in.bytes_c = s.bytes_c;
     in.dev_a = s.dev_a; in.dev_b = s.dev_b; in.dev_tenc = s.dev_tenc;
     in.ws = batch_lock.ws;
-    return fill_marshalled(idx, p, in, b->gaps, b->n, seq_out, cap, seq_bytes, out, t_begin, seq_dev);
+    return fill_marshalled(idx, p, in, b->gaps, b->n, seq_out, cap, seq_bytes, out, t_begin, d_seq_out);
 }
 int mtg_fill_prepared(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, mtg_results** out) { return fill_prepared_impl(idx, p, b, nullptr, 0, nullptr, out); }
 int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
@@ -1057,10 +1062,10 @@ int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mt
     return fill_prepared_impl(idx, p, b, seq_out, cap, seq_bytes, out);
 }
 
-int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* d_seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
+int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* d_seq_out, uint64_t cap, char* host_copy, uint64_t* seq_bytes, mtg_results** out)
 {
     if (!d_seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
-    return fill_prepared_impl(idx, p, b, d_seq_out, cap, seq_bytes, out, true);
+    return fill_prepared_impl(idx, p, b, host_copy ? host_copy : d_seq_out, cap, seq_bytes, out, d_seq_out);
 }
 
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->n) ? &r->res[i] : nullptr; }

@@ -402,7 +402,8 @@ struct ResultSink {
     mtg_filled* fil = nullptr;     /* n records: slot i belongs to gap i */
     char* seq = nullptr;           /* sequence arena: NUL-terminated fills, in gap order unless `in_gap_order` comes back false */
     size_t seq_cap = 0;
-    bool seq_on_device = false;    /* seq is memory of the index's device (the caller's): the result kernel writes there and nothing is copied to the host */
+    char* seq_dev = nullptr;       /* a buffer of the caller on the index's device (seq_cap bytes): the result kernel writes the arena there instead of into the workspace */
+    bool seq_on_device = false;    /* no host copy is wanted: seq == seq_dev, the records carry device addresses and nothing of the arena is copied to the host */
     char* ext = nullptr;           /* extension arena; ext[0] = 0 is the empty string of every record without extension */
     size_t ext_cap = 0;
     /* an arena turned out too small: must replace it by a block of at least `need` bytes whose first `keep` bytes are those of the old

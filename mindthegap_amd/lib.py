@@ -138,7 +138,7 @@ def _bind(lib):
     lib.mtg_batch_free.restype = None
     lib.mtg_fill_prepared.argtypes = [C.c_void_p, P(Params), C.c_void_p, P(C.c_void_p)]
     lib.mtg_fill_prepared_serial.argtypes = [C.c_void_p, P(Params), C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_void_p)]
-    lib.mtg_fill_prepared_serial_device.argtypes = [C.c_void_p, P(Params), C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_void_p)]
+    lib.mtg_fill_prepared_serial_device.argtypes = [C.c_void_p, P(Params), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, P(C.c_uint64), P(C.c_void_p)]
     lib.mtg_results_get.argtypes = [C.c_void_p, C.c_size_t]
     lib.mtg_results_get.restype = P(CGapResult)
     lib.mtg_results_free.argtypes = [C.c_void_p]
@@ -366,13 +366,17 @@ class Index:
         self.last_seq_bytes = int(nb.value)
         return h, nf, int(nb.value)
 
-    def fill_prepared_serial_device(self, batch, dev_ptr, cap, params=None):
-        """mtg_fill_prepared_serial_device: the filled sequences of a prepared Batch stay in DEVICE memory, in the caller's buffer of `cap` bytes at
-        address dev_ptr on the index's device (NUL-terminated, gap order); returns (results handle, n_filled per gap, number of bytes)."""
+    def fill_prepared_serial_device(self, batch, dev_ptr, cap, params=None, host_out=None):
+        """mtg_fill_prepared_serial_device: the filled sequences of a prepared Batch are produced in DEVICE memory, in the caller's buffer of `cap`
+        bytes at address dev_ptr on the index's device (NUL-terminated, gap order); host_out (uint8 array of at least cap bytes, e.g. page-locked):
+        they are copied there as well.  Returns (results handle, n_filled per gap, number of bytes)."""
         params = params or FillParams()
         h = C.c_void_p()
         nb = C.c_uint64()
-        _check(self.lib.mtg_fill_prepared_serial_device(self.h, C.byref(params.c), batch.h, C.c_void_p(dev_ptr), cap, C.byref(nb), C.byref(h)))
+        if host_out is not None and host_out.size < cap:
+            raise MtgError(2, "host copy of %d bytes for a device buffer of %d" % (host_out.size, cap))
+        hp = host_out.ctypes.data_as(C.c_void_p) if host_out is not None else None
+        _check(self.lib.mtg_fill_prepared_serial_device(self.h, C.byref(params.c), batch.h, C.c_void_p(dev_ptr), cap, hp, C.byref(nb), C.byref(h)))
         nf = np.empty(batch.n, dtype=np.uint32)
         _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), None, None))
         self.last_seq_bytes = int(nb.value)

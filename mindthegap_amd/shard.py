@@ -60,6 +60,7 @@ class PipelinedGather:
             self.stream = None
         self.recv = [[torch.empty(n, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] for _ in range(depth)] if self.rank == dst else None
         self.work = [None] * depth
+        self.events = [None] * depth  # GPU: completion of buffer j's gather on the side stream
         self.cur = 0
         self.done = -1  # buffer index of the last submitted step
         self.lock = threading.Lock()
@@ -70,28 +71,30 @@ class PipelinedGather:
         self.in_flight = []  # submitted buffers, oldest first
 
     def _wait(self, j):
-        if self.work[j] is not None:
-            if self.on_gpu:
-                with self.torch.cuda.stream(self.stream):
-                    self.work[j].wait()
-                self.stream.synchronize()
-            else:
-                self.work[j].wait()
-            self.work[j] = None
+        """blocks until the gather of buffer j (already taken off the in-flight list by the caller) is complete; called WITHOUT the lock, so
+        that one caller waiting for its buffer does not keep the others from acquiring and submitting theirs"""
+        if self.on_gpu:
+            if self.events[j] is not None:
+                self.events[j].synchronize()  # recorded on the side stream right behind this buffer's gather: nothing later is waited for
+        elif self.work[j] is not None:
+            self.work[j].wait()
+        self.work[j] = None
 
     def acquire(self):
         """(j, numpy view of the payload area of staging buffer j); the buffer belongs to the caller until submit(nbytes, j).
         Thread-safe: several steps may be in flight (depth must exceed their number for the gathers to overlap with them)."""
+        wait_for = None
         with self.cond:
             while True:
                 if self.free:
                     j = self.free.pop(0)
                     break
                 if self.in_flight:
-                    j = self.in_flight.pop(0)  # the oldest gather: once it is done its buffers may be written again
-                    self._wait(j)
+                    j = wait_for = self.in_flight.pop(0)  # the oldest gather: once it is done its buffers may be written again
                     break
                 self.cond.wait()  # every buffer is in the hands of another caller: one of them will submit
+        if wait_for is not None:
+            self._wait(wait_for)
         return j, self.stage[j].numpy()[self.HEADER:]
 
     def device_area(self, j):
@@ -107,7 +110,10 @@ class PipelinedGather:
         self.cur, view = self.acquire()
         return view
 
-    def submit(self, nbytes, j=None, on_device=False):
+    def submit(self, nbytes, j=None, on_device=False, host_copy=False):
+        """queue the gather of buffer j.  on_device: the payload was produced in the device buffer (device_area); host_copy: it is also
+        brought to the page-locked staging buffer of this rank (so that a rank's results are in its host memory as they are without a
+        gather), on the side stream, next to the gather"""
         j = self.cur if j is None else j
         if nbytes + self.HEADER > self.stage[j].numel():
             raise ValueError("payload of %d bytes exceeds the agreed capacity" % nbytes)
@@ -118,9 +124,15 @@ class PipelinedGather:
                 with self.torch.cuda.stream(self.stream):
                     if on_device:  # the payload is in dbuf[j] already: only its length goes up
                         self.dbuf[j][: self.HEADER].copy_(self.stage[j][: self.HEADER], non_blocking=True)
+                        if host_copy and nbytes:
+                            self.stage[j][self.HEADER: self.HEADER + nbytes].copy_(self.dbuf[j][self.HEADER: self.HEADER + nbytes], non_blocking=True)
                     else:
                         self.dbuf[j].copy_(self.stage[j], non_blocking=True)
                     self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+                    self.work[j].wait()  # the side stream waits for the collective (the host does not)
+                    if self.events[j] is None:
+                        self.events[j] = self.torch.cuda.Event()
+                    self.events[j].record(self.stream)
             else:
                 self.work[j] = self.dist.gather(self.dbuf[j], self.recv[j] if self.rank == self.dst else None, dst=self.dst, async_op=True)
             self.done = j
@@ -128,11 +140,15 @@ class PipelinedGather:
             self.cond.notify()
 
     def drain(self):
-        with self.cond:
-            while self.in_flight:
+        while True:
+            with self.cond:
+                if not self.in_flight:
+                    break
                 j = self.in_flight.pop(0)
-                self._wait(j)
+            self._wait(j)
+            with self.cond:
                 self.free.append(j)
+                self.cond.notify()
         if self.on_gpu:
             self.torch.cuda.synchronize(self.dev)
 

@@ -11,5 +11,5 @@ done
 MTG_BENCH_FORCE_GATHER=1 timeout 600 python bench.py --cpu-sites 0 --no-ceiling --no-secondary > $O/dry_rccl1.json 2> $O/dry_rccl1.err
 python3 -c "
 import json
-d=[json.loads(l) for l in open('$O/dry_rccl1.json') if l.startswith('{"metric"')][-1]
+d=json.loads(open('$O/dry_rccl1.json').read().strip().splitlines()[-1])
 print('one rank over RCCL, sequences gathered from HBM: value %.4g ms/step %.3f gathered payload verified %s identical to truth %s' % (d['value'], d['ms_per_step'], d['gathered_payload_verified'], d['filled_sequences_identical_to_truth']))"

@@ -355,7 +355,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             std::vector<mtg_filled> dfil(m);
             std::vector<char> none(64);
             EmitDev D;
-            D.seq = sink.seq ? sink.seq : none.data(); D.ext = sink.ext ? sink.ext : none.data();
+            D.seq = sink.seq ? sink.seq : none.data(); D.ext = sink.ext ? sink.ext : none.data(); /* the emulated device writes the host arena directly; a caller's "device" buffer is mirrored below */
             D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
             D.res = dres.data(); D.fil = dfil.data();
             D.dense_words = dw.data(); D.dense_meta = dm.data();
@@ -367,6 +367,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             }
             if (want_records)
                 for (uint32_t s = 0; s < m; s++) { sink.res[ids[s]] = dres[s]; if (recs[s].asc) sink.fil[ids[s]] = dfil[s]; }
+            /* a caller's "device" buffer next to a host copy: the arena is the same bytes in both */
+            if (sink.seq_dev && sink.seq && sink.seq_dev != sink.seq && tot.end[2] > tot.begin[2] && tot.end[2] <= sink.seq_cap)
+                memcpy(sink.seq_dev + tot.begin[2], sink.seq + tot.begin[2], tot.end[2] - tot.begin[2]);
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
             st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.coverage_direct_kmers += tot.cov_direct; st.dense_words += c0;
             sink.seq_used = tot.end[2];

@@ -802,6 +802,11 @@ def test_serialised_batch_left_on_the_device(emu_product):
         h, nf2, nb2 = idx.fill_prepared_serial_device(batch, dev.ctypes.data, dev.size)
         idx.free_results(h)
         assert nb2 == nb and (nf2 == nf).all() and dev[:nb2].tobytes() == out[:nb].tobytes() and nb > 0
+        dev[:] = 0xEE  # a host copy next to the device buffer: both hold the serialised batch
+        hcopy = np.full(1 << 20, 0xDD, dtype=np.uint8)
+        h, nf3, nb3 = idx.fill_prepared_serial_device(batch, dev.ctypes.data, dev.size, host_out=hcopy)
+        idx.free_results(h)
+        assert nb3 == nb and dev[:nb3].tobytes() == out[:nb].tobytes() and hcopy[:nb3].tobytes() == out[:nb].tobytes()
         with pytest.raises(emu_product.MtgError):
             idx.fill_prepared_serial_device(batch, dev.ctypes.data, 64)
         batch.close()

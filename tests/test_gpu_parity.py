@@ -390,11 +390,12 @@ def test_pipelined_gather_on_rccl_single_rank(mtg):
             payload = torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8)).to(dev)
             pg3.dbuf[j][pg3.HEADER: pg3.HEADER + n].copy_(payload)  # stands for the result kernel
             torch.cuda.synchronize()
-            pg3.submit(n, j, on_device=True)
-            last = payload.cpu().numpy()
+            pg3.submit(n, j, on_device=True, host_copy=True)
+            last, last_j = payload.cpu().numpy(), j
         pg3.drain()
         got = pg3.last()
         assert len(got) == 1 and got[0].tobytes() == last.tobytes()
+        assert pg3.stage[last_j].numpy()[pg3.HEADER: pg3.HEADER + len(last)].tobytes() == last.tobytes()  # the rank's own host copy
     finally:
         dist.destroy_process_group()
 
@@ -485,6 +486,11 @@ def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
     h, nf, nb2 = idx.fill_prepared_serial_device(batch, dbuf.data_ptr(), dbuf.numel())
     idx.free_results(h)
     assert nb2 == nb and (nf == 1).all() and dbuf[:nb2].cpu().numpy().tobytes() == got
+    dbuf.fill_(0xEE)  # and with a host copy next to it (the multi-GPU gather: device buffer for RCCL, host buffer for the rank's own results)
+    hcopy = torch.empty(dbuf.numel(), dtype=torch.uint8).pin_memory()
+    h, nf, nb3 = idx.fill_prepared_serial_device(batch, dbuf.data_ptr(), dbuf.numel(), host_out=hcopy.numpy())
+    idx.free_results(h)
+    assert nb3 == nb and dbuf[:nb3].cpu().numpy().tobytes() == got and hcopy.numpy()[:nb3].tobytes() == got
     with pytest.raises(mtg.MtgError):
         idx.fill_prepared_serial_device(batch, dbuf.data_ptr(), 1 << 20)
     batch.close()
@@ -512,6 +518,10 @@ def test_serialised_batch_in_place_and_fallback(mtg, tmp_path):
     h, nf, nb2 = idx2.fill_prepared_serial_device(batch2, dbuf.data_ptr(), dbuf.numel())
     idx2.free_results(h)
     assert dbuf[:nb2].cpu().numpy().tobytes() == want
+    dbuf.fill_(0xEE)
+    h, nf, nb3 = idx2.fill_prepared_serial_device(batch2, dbuf.data_ptr(), dbuf.numel(), host_out=hcopy.numpy())
+    idx2.free_results(h)
+    assert dbuf[:nb3].cpu().numpy().tobytes() == want and hcopy.numpy()[:nb3].tobytes() == want
     batch2.close()
     idx2.close()
     o.close()
