@@ -66,6 +66,44 @@ int main()
             if (!ok) { fprintf(stderr, "set_common k %d source %s pattern %s differs\n", k, source.c_str(), pattern.c_str()); return 1; }
         }
     }
+    /* auto_cutoff (the product's automatic solidity cut-off) on histograms whose answer is known without any other implementation: an
+     * error peak that decays from abundance 1 and a coverage peak around c -- the cut-off is the minimum of the smoothed valley between
+     * them (ties: the first), never below the floor, never at or beyond the peak, and unchanged when the histogram is scaled */
+    {
+        auto smoothed = [](const std::vector<uint64_t>& h, size_t i) -> uint64_t {
+            if (i == 1) return (uint64_t)(0.6 * (double)h[1] + 0.4 * (double)h[2]);
+            return (uint64_t)(0.2 * (double)h[i - 1] + 0.6 * (double)h[i] + 0.2 * (double)h[i + 1]);
+        };
+        for (int round = 0; round < 400; round++) {
+            const int c = 12 + (int)(rng() % 60), valley = 3 + (int)(rng() % (unsigned)(c - 8));
+            const double err0 = 1e5 * (1 + (double)(rng() % 100)), decay = 0.25 + 0.01 * (double)(rng() % 40), pk = 1e4 * (1 + (double)(rng() % 50));
+            std::vector<uint64_t> h(c * 3 + 10, 0);
+            for (size_t a = 1; a < h.size(); a++) {
+                double e = err0;
+                for (size_t t = 1; t < a; t++) e *= decay;                                   /* sequencing errors: geometric decay */
+                const double d = ((double)a - c) / (0.18 * c + 1.0);
+                h[a] = (uint64_t)(e + pk / (1.0 + d * d * d * d)) + ((int)a == valley ? 0 : 3); /* coverage peak; the designated valley is the lowest point */
+            }
+            /* make the designated valley the unique lowest entry between the error slope and the peak */
+            uint64_t lo = ~0ull;
+            for (int a = 2; a < c; a++) lo = std::min(lo, h[(size_t)a]);
+            for (int a = valley - 1; a <= valley + 1; a++) h[(size_t)a] = lo > 6 ? lo - 6 + (uint64_t)std::abs(a - valley) * 2 : 0;
+            const int got = mtgi::auto_cutoff(h, 3);
+            /* the properties */
+            bool ok = got >= 3 && got < c; /* below the coverage peak */
+            for (size_t a = (size_t)std::max(got - 1, 2); a <= (size_t)got + 1 && a + 1 < h.size(); a++) ok = ok && smoothed(h, (size_t)got) <= smoothed(h, a); /* a local minimum of the smoothed histogram */
+            ok = ok && std::abs(got - valley) <= 1;                                                                        /* at the designated valley (smoothing may move it by one) */
+            std::vector<uint64_t> h10(h);
+            for (auto& v : h10) v *= 10;
+            ok = ok && mtgi::auto_cutoff(h10, 3) == got;                                                                    /* scale invariance */
+            if (!ok) { fprintf(stderr, "auto_cutoff: round %d coverage %d valley %d -> %d\n", round, c, valley, got); return 1; }
+        }
+        /* no valley at all (monotone decay: error k-mers only) and tiny histograms: the floor */
+        std::vector<uint64_t> mono(60);
+        for (size_t a = 1; a < mono.size(); a++) mono[a] = 1000000 / (a * a);
+        if (mtgi::auto_cutoff(std::vector<uint64_t>{0, 5, 3}, 3) != 3) { fprintf(stderr, "auto_cutoff: tiny histogram\n"); return 1; }
+        (void)mono;
+    }
     printf("OK\n");
     return 0;
 }
