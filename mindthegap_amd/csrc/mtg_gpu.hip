@@ -453,51 +453,60 @@ struct ScanBlock {
 };
 __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, ScanBlock* blocks)
 {
-    __shared__ uint64_t sh[SCAN_NV][SCAN_SL];
-    __shared__ unsigned long long ssum[SCAN_NS];
-    const uint32_t t = threadIdx.x, slot = blockIdx.x * SCAN_SL + t;
-    if (t < SCAN_NS) ssum[t] = 0;
+    /* scans inside the waves by shuffles, the four waves of the block joined through a few words of LDS; the statistics are reduced the same
+     * way (a block's contributions fit 32 bits: 256 slots of at most 2^20 words / bytes each... the sums are kept in 64 bits all the same) */
+    enum { NW = SCAN_SL / 64 };
+    __shared__ uint64_t wtot[NW][SCAN_NV];
+    __shared__ unsigned long long wsum[NW][SCAN_NS];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6, slot = blockIdx.x * SCAN_SL + t;
     uint64_t v[SCAN_NV] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st[SCAN_NS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (slot < m) {
         const SlotRec& r = recs[slot];
         const bool ok = r.o.status == GAP_OK;
         v[0] = r.nw; v[1] = r.nc; v[2] = r.asc; v[3] = r.ext;
         v[4] = ok ? 0 : 1;
         v[5] = (ok && r.nc) ? 1 : 0; /* its contigs go back to the host: multi-contig path, or the stage-A entry */
-    }
-    for (int j = 0; j < SCAN_NV; j++) sh[j][t] = v[j];
-    __syncthreads();
-    if (slot < m) {
-        const SlotRec& r = recs[slot];
-        atomicAdd(&ssum[0], (unsigned long long)r.o.lines);
-        atomicAdd(&ssum[1], (unsigned long long)r.o.store_reads);
-        atomicAdd(&ssum[2], (unsigned long long)r.o.run_nt);
-        atomicAdd(&ssum[4], (unsigned long long)r.o.n_words);
-        if (r.o.n_cmds) { atomicAdd(&ssum[9], (unsigned long long)r.o.copy_words); atomicAdd(&ssum[10], (unsigned long long)r.o.n_cmds); }
-        if (r.o.status == GAP_OK) {
-            atomicAdd(&ssum[3], (unsigned long long)r.o.total_nt);
-            atomicAdd(&ssum[5], (unsigned long long)r.p.lines);
-            atomicAdd(&ssum[6], (unsigned long long)r.p.ab_n);
-            if (r.p.direct) atomicAdd(&ssum[11], (unsigned long long)r.p.ab_n);
-            if (r.asc) atomicAdd(&ssum[7], 1ull);
-            if (r.ext) atomicAdd(&ssum[8], 1ull);
+        st[0] = r.o.lines; st[1] = r.o.store_reads; st[2] = r.o.run_nt; st[4] = r.o.n_words;
+        if (r.o.n_cmds) { st[9] = r.o.copy_words; st[10] = r.o.n_cmds; }
+        if (ok) {
+            st[3] = r.o.total_nt; st[5] = r.p.lines; st[6] = r.p.ab_n;
+            if (r.p.direct) st[11] = r.p.ab_n;
+            st[7] = r.asc ? 1 : 0; st[8] = r.ext ? 1 : 0;
         }
     }
-    /* inclusive Hillis-Steele scan of the six columns */
-    for (uint32_t d = 1; d < SCAN_SL; d <<= 1) {
-        uint64_t add[SCAN_NV];
-        for (int j = 0; j < SCAN_NV; j++) add[j] = t >= d ? sh[j][t - d] : 0;
-        __syncthreads();
-        for (int j = 0; j < SCAN_NV; j++) sh[j][t] += add[j];
-        __syncthreads();
+    uint64_t incl[SCAN_NV];
+    for (int j = 0; j < SCAN_NV; j++) {
+        uint64_t x = v[j];
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+            if ((int)lane >= d) x += ((uint64_t)hi << 32) | lo;
+        }
+        incl[j] = x;
+        if (lane == 63) wtot[wv][j] = x;
+    }
+    for (int j = 0; j < SCAN_NS; j++) {
+        unsigned long long x = st[j];
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), d, 64);
+            x += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0) wsum[wv][j] = x;
+    }
+    __syncthreads();
+    uint64_t before[SCAN_NV];
+    for (int j = 0; j < SCAN_NV; j++) {
+        uint64_t x = 0;
+        for (uint32_t w2 = 0; w2 < wv; w2++) x += wtot[w2][j];
+        before[j] = x;
     }
     if (slot < m) {
         SlotRec& r = recs[slot];
-        r.wbase = sh[0][t] - v[0]; r.cbase = sh[1][t] - v[1]; r.abase = sh[2][t] - v[2]; r.ebase = sh[3][t] - v[3];
-        r.rpos = (uint32_t)(sh[4][t] - v[4]); r.gpos = (uint32_t)(sh[5][t] - v[5]);
+        r.wbase = before[0] + incl[0] - v[0]; r.cbase = before[1] + incl[1] - v[1]; r.abase = before[2] + incl[2] - v[2]; r.ebase = before[3] + incl[3] - v[3];
+        r.rpos = (uint32_t)(before[4] + incl[4] - v[4]); r.gpos = (uint32_t)(before[5] + incl[5] - v[5]);
     }
-    if (t < SCAN_NV) blocks[blockIdx.x].v[t] = sh[t][SCAN_SL - 1];
-    if (t < SCAN_NS) blocks[blockIdx.x].s[t] = ssum[t];
+    if (t < SCAN_NV) { uint64_t x = 0; for (int w2 = 0; w2 < NW; w2++) x += wtot[w2][t]; blocks[blockIdx.x].v[t] = x; }
+    if (t < SCAN_NS) { unsigned long long x = 0; for (int w2 = 0; w2 < NW; w2++) x += wsum[w2][t]; blocks[blockIdx.x].s[t] = x; }
 }
 /* cursors[0..3]: words, metadata entries, sequence bytes, extension bytes of the batch so far */
 __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nblocks, unsigned long long* cursors, PartTot* tot)
@@ -516,10 +525,23 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         for (uint32_t i = t; i < nb * SCAN_NV; i += 256) sh[i % SCAN_NV][i / SCAN_NV] = blocks[b0 + i / SCAN_NV].v[i % SCAN_NV];
         for (uint32_t i = t; i < nb * SCAN_NS; i += 256) atomicAdd(&ssum[i % SCAN_NS], (unsigned long long)blocks[b0 + i / SCAN_NS].s[i % SCAN_NS]);
         __syncthreads();
-        if (t < SCAN_NV) { /* one thread per column: the blocks' totals become their bases */
-            uint64_t run = carry[t];
-            for (uint32_t i = 0; i < nb; i++) { const uint64_t x = sh[t][i]; sh[t][i] = run; run += x; }
-            carry[t] = run;
+        /* the blocks' totals become their bases: a column per wave (waves 0 and 1 take a second one), 64 blocks per shuffle scan */
+        for (uint32_t j = t >> 6; j < SCAN_NV; j += 4) {
+            const uint32_t lane = t & 63u;
+            uint64_t run = carry[j];
+            for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+                const uint32_t i = c0 + lane;
+                const uint64_t x0 = i < nb ? sh[j][i] : 0ull;
+                uint64_t x = x0;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+                    if ((int)lane >= d) x += ((uint64_t)hi << 32) | lo;
+                }
+                if (i < nb) sh[j][i] = run + x - x0;
+                const uint32_t tl = (uint32_t)__shfl((int)(uint32_t)x, 63, 64), th = (uint32_t)__shfl((int)(uint32_t)(x >> 32), 63, 64);
+                run += ((uint64_t)th << 32) | tl;
+            }
+            if (lane == 0) carry[j] = run;
         }
         __syncthreads();
         for (uint32_t i = t; i < nb * SCAN_NV; i += 256) blocks[b0 + i / SCAN_NV].v[i % SCAN_NV] = sh[i % SCAN_NV][i / SCAN_NV];

@@ -91,3 +91,29 @@ def test_config4_full_size(mtg, tmp_path):
         f = r["filled"][0]
         hdr = "%s_len_%d_qual_%d_avg_cov_%.2f_median_cov_%.2f   " % (S.site_name(i), len(f["seq"]), f["qual"], f["avg_coverage"], f["median_coverage"])
         assert (hdr, f["seq"]) == cpu[S.site_name(i)], i  # the header carries length, quality, mean and median coverage (src/Filler.cpp:1052-1054)
+
+
+def test_one_launch_of_300000_gaps(mtg):
+    """a batch larger than the bench's: 300 000 gaps in ONE launch (more than 1024 blocks of the layout scan, i.e. several tiles of its
+    second kernel; 4 700 waves of the traversal): every fill is the inserted sequence and the serialised arena is in gap order"""
+    import torch
+    from mindthegap_amd.synth import SynthSet
+    N = 300000
+    S = SynthSet(nseq=N, n_sites=N, seed=3, k=31)
+    dev = torch.device("cuda", 0)
+    w = torch.from_numpy(S.words.view(np.int64)).to(dev)
+    wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev)
+    ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
+    idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 0)
+    del w, wo, ln
+    gaps, truth = [], []
+    for i in range(N):
+        l, r, ins = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, "x", False)]))
+        truth.append(ins)
+    h, nf, seqs = idx.fill_prepared(mtg.Index.prepare_gaps(gaps), mtg.FillParams(max_nodes=100, max_depth=10000), want_seqs=True)
+    st = mtg.last_batch_stats()
+    idx.free_results(h)
+    idx.close()
+    assert st["n_launches"] == 1 and (nf == 1).all()
+    assert seqs.tobytes().decode().split("\n")[:-1] == truth
