@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny", "human-het"])
+    ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=["human", "ecoli", "tiny", "human-het", "human-indel"])
     ap.add_argument("--sites", type=int, default=0, help="sites per batch (default: the workload's)")
     ap.add_argument("--batches", type=int, default=4, help="distinct batches of sites rotated through the steps (N = 1 and weak scaling)")
     ap.add_argument("--nseq", type=int, default=0)
@@ -59,6 +59,7 @@ WORKLOADS = {
     "human": (600000, 100000, "synthetic human-scale: 3 Gbp i.i.d. donor as 600000 x 5 kb sequences, 100000 insertion sites (50-1000 nt) per batch, k=31, max-nodes 100"),
     "ecoli": (1000, 1000, "synthetic E.coli-scale: 5 Mbp donor as 1000 x 5 kb sequences, 1000 insertion sites, k=31"),
     "human-het": (600000, 100000, "secondary, divergence-heavy: diploid donor, 300000 loci x 2 haplotypes x 5 kb with 4 heterozygous SNPs per locus, 100000 insertion sites per batch"),
+    "human-indel": (600000, 100000, "diagnostic, general bubble code: the diploid donor of human-het with two deletions of 1-3 nt per locus in the second haplotype besides the 4 SNPs (bubbles with branches of different lengths), 100000 insertion sites per batch"),
     "tiny": (400, 256, "tiny smoke workload"),
 }
 
@@ -122,7 +123,8 @@ def main():
 
     nseq0, sites0, desc = WORKLOADS[a.workload]
     batch_sites = a.sites or sites0
-    het = 4 if a.workload == "human-het" else 0
+    het = 4 if a.workload in ("human-het", "human-indel") else 0
+    indels = 2 if a.workload == "human-indel" else 0
     nloci0 = (a.nseq or nseq0) // (2 if het else 1)
     scaling = a.scaling if a.scaling != "auto" else ("strong" if world > 1 else "weak")
     if world == 1:
@@ -149,7 +151,7 @@ def main():
 
     # ---------------------------------------------------------------- synthetic donor genome + index (not timed as "fill")
     t0 = time.time()
-    S = SynthSet(nseq=nseq, n_sites=n_sites_total, seed=1, k=k, het_snps=het)
+    S = SynthSet(nseq=nseq, n_sites=n_sites_total, seed=1, k=k, het_snps=het, het_indels=indels)
     t_gen = time.time() - t0
     t0 = time.time()
     w = torch.from_numpy(S.words.view(np.int64)).to(dev)

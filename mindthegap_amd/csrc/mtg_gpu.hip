@@ -1569,7 +1569,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     {
         unsigned long long hs[16];
         if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(mtg::g_stamps), sizeof hs) == hipSuccess && hs[15])
-            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f (long steps %.0f, bucket reads + run set-up %.0f) B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f | snp_fast %.0f (alignment %.0f) consume %.0f"
+            fprintf(stderr, "  [stamps] lanes %llu  avg cycles/lane: W %.0f (long steps %.0f, bucket reads + run set-up %.0f) B %.0f | find_end %.0f dfs %.0f validate %.0f mark_inv %.0f | snp_fast %.0f (in-branching checks of find_end / alignment %.0f) consume %.0f"
                             " | per lane: general bubbles %.3f, snp_fast answers %.3f (bulk form %.3f, with alignment %.3f)\n", hs[15],
                     (double)hs[0] / hs[15], (double)hs[8] / hs[15], (double)hs[9] / hs[15], (double)hs[1] / hs[15], (double)hs[2] / hs[15], (double)hs[3] / hs[15], (double)hs[4] / hs[15], (double)hs[5] / hs[15],
                     (double)hs[6] / hs[15], (double)hs[12] / hs[15], (double)hs[7] / hs[15], (double)hs[10] / hs[15], (double)hs[14] / hs[15], (double)hs[13] / hs[15], (double)hs[11] / hs[15]);

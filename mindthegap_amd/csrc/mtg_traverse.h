@@ -545,7 +545,13 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
         for (int i = 0; i < ncur; i++) {
             const uint32_t aux = ca[i];
             /* a node of in-degree 1 passes the check at once (its only predecessor is the frontline node it was reached from) */
-            if (depth > 0 && !(aux & AUX_IN1) && !fl_check(W, cf[i])) return 0;
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+            unsigned long long* stamp_acc = W.stamp_acc;
+#endif
+            MTG_T0(t_flc);
+            const bool flc_ok = !(depth > 0 && !(aux & AUX_IN1)) || fl_check(W, cf[i]);
+            MTG_T1(t_flc, 12);
+            if (!flc_ok) return 0;
             Kmer x = make_kmer(cf[i], k);
             uint32_t out, kid;
             uint64_t krp = 0; /* the children's place in the store, when the node's right junction lies inside a unitig */
@@ -998,6 +1004,22 @@ MTG_UNROLL
 MTG_UNROLL
                 for (int j = 0; j < 8; j++) if (i + j < mn) s0 += (ta[j] == tb[j]) ? 10 : -5;
             }
+            if (mx != mn && identity_below_90((s0 + 5 * mx <= 0) ? 0 : (s0 + 5 * mx + 14) / 15, na, nb)) {
+                /* Different lengths (an insertion or deletion between two alleles) and the first bound does not pass: behind the indel the
+                 * diagonal compares shifted sequences.  The alignments "diagonal up to position p, the length difference as ONE gap there,
+                 * shifted diagonal behind it" are alignments too, so the best of them is a lower bound of the optimal score as well; their scores
+                 * follow from one another (moving the gap one place to the right trades one shifted pair for one straight pair). */
+                const SP<uint8_t> lg = na >= nb ? pa : pb, sh = na >= nb ? pb : pa; /* the longer, the shorter */
+                const int dl = mx - mn;
+                int sc = -5 * dl; /* p = 0: every pair shifted */
+                for (int i = 0; i < mn; i++) sc += (lg[i + dl] == sh[i]) ? 10 : -5;
+                int best = sc;
+                for (int p = 0; p < mn; p++) {
+                    sc += ((lg[p] == sh[p]) ? 10 : -5) - ((lg[p + dl] == sh[p]) ? 10 : -5);
+                    best = sc > best ? sc : best;
+                }
+                s0 = best > s0 ? best : s0;
+            }
             const int num = s0 + 5 * mx;
             const int mlb = num <= 0 ? 0 : (num + 14) / 15;
             int m = mlb;
@@ -1145,7 +1167,19 @@ MTG_UNROLL
     /* a branch that stays inside one unitig for more than SNP_MAX_L nodes cannot meet the other one in time (the meeting node has two
      * in-edges: it is inside no unitig): the step-by-step loop would walk all SNP_MAX_L steps to find that out */
     if (left[0] + 1u > (uint32_t)SNP_MAX_L || left[1] + 1u > (uint32_t)SNP_MAX_L) { hopeless = true; return false; }
-    if (left[0] != left[1]) return false;
+    if (left[0] != left[1]) {
+        /* Branches of different lengths (an insertion or deletion).  The step-by-step loop can only succeed if both branches step onto the
+         * same node at the same step; it gives up where the shorter branch leaves its unitig unless the junction there is simple (one in-,
+         * one out-edge: a unitig that ends at a palindromic junction) -- the longer branch is still inside its own unitig then, so the node
+         * stepped onto cannot be common.  One read of that junction instead of walking both branches node by node to find out. */
+        const int sb = left[0] < left[1] ? 0 : 1;
+        const uint64_t kp = (up_hdr(r[sb].up) + 1) * 32 + (bw[sb] ? off_[sb] : off_[sb] - 1u); /* the branch's first node in the store */
+        const Kmer zs = run_node(us, kp, bw[sb], left[sb], k);
+        const Adj re = adj_right_t(W.ix.adj, zs, W.mk1, W.lines);
+        W.lines++;
+        if (popc4(re.out) != 1 || popc4(re.in) != 1) hopeless = true;
+        return false;
+    }
     const uint32_t m = left[0]; /* nodes of a branch behind its first one */
     uint32_t s[2];
 MTG_UNROLL

@@ -13,11 +13,12 @@ class SynthSet:
     substitutions (>= 150 nt away from the insertion anchors and the ends), so every walk crosses SNP bubbles (multi-path bubbles
     are GATB-parity-unpinned logic; used as a secondary, divergence-heavy workload, never for the headline number)."""
 
-    def __init__(self, nseq, n_sites, seq_len=5000, seed=1, ins_min=50, ins_max=1000, k=31, het_snps=0):
+    def __init__(self, nseq, n_sites, seq_len=5000, seed=1, ins_min=50, ins_max=1000, k=31, het_snps=0, het_indels=0):
         nloci = nseq // 2 if het_snps else nseq
         assert n_sites <= nloci
         rng = np.random.default_rng(seed)
         self.k, self.nseq, self.n_sites, self.seq_len, self.het_snps = k, nseq, n_sites, seq_len, het_snps
+        self.het_indels = het_indels
         self.ins_len = np.exp(rng.uniform(np.log(ins_min), np.log(ins_max), n_sites)).astype(np.int64)  # log-uniform
         self.pos = rng.integers(1000, seq_len - 1000 + 1, n_sites)
         self.lens = np.full(nseq, seq_len, dtype=np.uint32)
@@ -46,6 +47,30 @@ class SynthSet:
                 old = (self.words[rows, w] >> b) & np.uint64(3)
                 new = (old + delta) & np.uint64(3)
                 self.words[rows, w] = (self.words[rows, w] & ~(np.uint64(3) << b)) | (new << b)
+
+        if het_snps and het_indels:
+            # het_indels deletions of 1..3 nt per locus in the second haplotype (alternating left / right of the insertion like the SNPs, 100 nt
+            # away from anchors, ends and -- mostly -- SNPs): bubbles whose branches differ in length (the general bubble code, not the SNP path)
+            sh = (np.arange(32, dtype=np.uint64) * np.uint64(2))
+            for j in range(nloci):
+                row = nloci + j
+                c = ((self.words[row][:, None] >> sh[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)[: int(self.lens[row])]
+                p0, L = int(pos[j]), int(lens[j])
+                cut = []
+                for d_i in range(het_indels):
+                    lo, hi = (100, p0 - 100) if (j + d_i) % 2 == 0 else (p0 + int(ins[j]) + 100, L - 100)
+                    if hi - lo < 10:
+                        continue
+                    q = int(lo + rng.integers(0, hi - lo))
+                    cut.append((q, int(rng.integers(1, 4))))
+                keep = np.ones(len(c), dtype=bool)
+                for q, n in cut:
+                    keep[q:q + n] = False
+                c = c[keep]
+                self.lens[row] = len(c)
+                pad = np.zeros(self.words_per_seq * 32, dtype=np.uint64)
+                pad[: len(c)] = c
+                self.words[row] = (pad.reshape(-1, 32) << sh[None, :]).sum(axis=1, dtype=np.uint64)
 
     @property
     def total_kmers_upper_bound(self):

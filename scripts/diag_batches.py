@@ -9,7 +9,7 @@ from mindthegap_amd.synth import SynthSet
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 het = 4 if os.environ.get("HET") else 0
-S = SynthSet(nseq=600000, n_sites=nb * 100000, seed=1, k=31, het_snps=het)
+S = SynthSet(nseq=600000, n_sites=nb * 100000, seed=1, k=31, het_snps=het, het_indels=2 if os.environ.get("INDEL") else 0)  # HET=1 INDEL=1: deletions besides the SNPs
 dev = torch.device("cuda", 0)
 w = torch.from_numpy(S.words.view(np.int64)).to(dev); wo = torch.from_numpy(S.word_off.view(np.int64)).to(dev); ln = torch.from_numpy(S.lens.view(np.int32)).to(dev)
 idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), S.nseq, S.total_kmers_upper_bound, 31, 3, 0)
