@@ -157,7 +157,8 @@ int mtg_fill_batch_serial(const mtg_index* idx, const mtg_params* p, const mtg_g
 /* A batch marshalled ahead of time and kept in device memory: what a caller that fills the same gaps more than once, or reads its
  * breakpoints while an earlier batch is still on the device, would use instead of mtg_fill_batch (which does exactly this and then
  * forgets the batch).  `gaps` and every string it points to must stay alive and unchanged for as long as the batch is used.  A batch can
- * be filled by several threads at once. */
+ * be filled by several threads at once.  Its device copies live on the device of `idx`: filling it with an index of another device (a
+ * replica made by mtg_index_replicate), or with another nb_mis_allowed than it was prepared with, is refused with MTG_ERR_ARG. */
 typedef struct mtg_batch mtg_batch;
 int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_batch** out);
 void mtg_batch_free(mtg_batch* b);

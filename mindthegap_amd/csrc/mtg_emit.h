@@ -119,6 +119,7 @@ struct EmitDev {
     mtg_filled* fil;     /* per slot of the launch */
     uint64_t* dense_words;
     uint32_t* dense_meta;
+    uint64_t dense_cap_words, dense_cap_contigs; /* room in the two dense arrays (words; contigs, five metadata entries each) */
 };
 
 MTG_DEV int qual_of(uint32_t errors, bool repeated) /* compute_qual, src/Utils.hpp:85-103, for a single solution */
@@ -138,10 +139,13 @@ MTG_DEV void emit_gap(const FillCfg& cfg, const GapScratch& S, const SlotRec& r,
     const bool seq_ok = r.asc && r.abase + r.asc <= D.seq_cap, ext_ok = r.ext && r.ebase + r.ext <= D.ext_cap; /* an arena that is too small: the host grows it and asks again */
     if (seq_ok) emit_ascii(w, (uint32_t)k, r.asc - 1u, reverse, D.seq + r.abase);
     if (ext_ok) emit_ascii(w, (uint32_t)k, r.ext - 1u, false, D.ext + r.ebase);
+    /* the dense arrays are sized by the last need and k_emit runs before the launch's totals are known: a gap that does not fit writes
+     * nothing, the host sees the totals, grows the arrays and emits the launch again (like the two arenas above) */
+    const bool dense_ok = r.wbase + r.nw <= D.dense_cap_words && r.cbase + r.nc <= D.dense_cap_contigs;
     uint64_t* dw = D.dense_words + r.wbase;
-    for (uint32_t i = lane; i < r.nw; i += MTG_NLANES) dw[i] = w[i];
+    for (uint32_t i = lane; i < (dense_ok ? r.nw : 0u); i += MTG_NLANES) dw[i] = w[i];
     uint32_t* dm = D.dense_meta + 5 * r.cbase;
-    for (uint32_t i = lane; i < r.nc; i += MTG_NLANES) {
+    for (uint32_t i = lane; i < (dense_ok ? r.nc : 0u); i += MTG_NLANES) {
         dm[i] = s_clen(cfg, S)[i];
         dm[r.nc + i] = s_cstart(cfg, S)[i];
         dm[2 * r.nc + i] = s_tpos(cfg, S)[i];

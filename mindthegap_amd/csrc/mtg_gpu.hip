@@ -1397,9 +1397,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* The traversal reads index shape and configuration from the module's constants, of which there is one set per workspace
              * number: the batches of an index never share a set, batches of different indexes may, so a set is locked until the traversal
              * that reads it has finished (below, after the host work that runs meanwhile). */
-            static std::mutex traversal_mtx[TRAVERSAL_SETS];
+            /* the constants exist once per device: the lock is the (device, set)'s, so that the tool's host threads -- one or more per
+             * device, each on its own replica -- only ever wait for a batch of another index on their own device */
+            static std::mutex traversal_mtx[CopyTurn::MAX_DEV][TRAVERSAL_SETS];
             const uint32_t cset = (uint32_t)(&ws - idx->ws);
-            std::unique_lock<std::mutex> traversal_lock(traversal_mtx[cset]);
+            std::unique_lock<std::mutex> traversal_lock(traversal_mtx[(unsigned)idx->device % CopyTurn::MAX_DEV][cset]);
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. ev1 = the traversal kernel alone */
@@ -1425,6 +1427,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
                 D.res = d_res.as<mtg_gap_result>(); D.fil = d_fil.as<mtg_filled>();
                 D.dense_words = d_dw.as<uint64_t>(); D.dense_meta = d_dm.as<uint32_t>();
+                D.dense_cap_words = ws.cap[d_dw.slot] / 8; D.dense_cap_contigs = ws.cap[d_dm.slot] / 20;
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
                 hipLaunchKernelGGL(k_emit, dim3(m), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H, d_rlist.as<uint32_t>(),
                                    d_glist.as<uint32_t>(), m);

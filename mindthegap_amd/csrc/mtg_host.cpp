@@ -73,8 +73,12 @@ bool read_sequences(const std::string& path, std::vector<std::pair<std::string, 
             have = getl(line);
         }
     }
+    /* gzgets returns NULL at the end of the file and on an error alike: a truncated or corrupt .gz must not pass for a short file */
+    int zerr = Z_OK;
+    (void)gzerror(f, &zerr);
+    const bool clean = gzeof(f) && (zerr == Z_OK || zerr == Z_STREAM_END);
     gzclose(f);
-    return true;
+    return clean;
 }
 
 /* ------------------------------------------------------------------------------------------------ index from reads */
@@ -153,6 +157,10 @@ struct FileReadStream : ReadStream {
             }
             line.append(buf.data(), n);
         }
+        /* NULL from gzgets: the end of the file, or a read / inflate error (truncated or corrupt .gz) -- only the first is a clean end */
+        int zerr = Z_OK;
+        (void)gzerror(f, &zerr);
+        if (!gzeof(f) || !(zerr == Z_OK || zerr == Z_STREAM_END)) { bad = true; bad_path = paths[cur]; }
         return got;
     }
     bool next_block(const char*& p, size_t& n) override
@@ -166,6 +174,7 @@ struct FileReadStream : ReadStream {
                 gzbuffer(f, 1 << 20);
                 have_line = getl();
             }
+            if (bad) return false;
             if (!have_line) { gzclose(f); f = nullptr; cur++; continue; }
             if (!line.empty() && line[0] == '>') { /* FASTA record: the following lines up to the next header */
                 while ((have_line = getl()) && (line.empty() || line[0] != '>')) block += line;
@@ -177,6 +186,7 @@ struct FileReadStream : ReadStream {
                 have_line = getl();
             } else have_line = getl();
         }
+        if (bad) return false;
         p = block.data();
         n = block.size();
         return n > 0;
@@ -250,6 +260,13 @@ int index_load(const char* path, mtg_index** out)
     if (!(v1 || v2) || fread(hdr, 4, 4, f) != 4 || fread(&n, 8, 1, f) != 1) { fclose(f); set_error("%s: not a mtg index", path); return MTG_ERR_FORMAT; }
     /* the records go to the device piece by piece, straight from the file (every attempt to size the tables reads them once) */
     const long data0 = ftell(f);
+    {
+        /* the header's record count against what the file holds, before anything is sized by it */
+        fseek(f, 0, SEEK_END);
+        const long fsize = ftell(f);
+        fseek(f, data0, SEEK_SET);
+        if (hdr[0] < 11 || hdr[0] > 31 || fsize < data0 || n > (uint64_t)(fsize - data0) / 12) { fclose(f); set_error("%s: truncated (the header announces %llu k-mers)", path, (unsigned long long)n); return MTG_ERR_FORMAT; }
+    }
     std::vector<uint64_t> pk;
     std::vector<uint32_t> pa;
     std::vector<unsigned char> rec;
@@ -713,6 +730,8 @@ struct mtg_batch {
     mtgi::FillInput in;
     const mtg_gap* gaps = nullptr; /* the caller's array: read again only for the gaps that take the multi-contig path */
     size_t n = 0;
+    int device = 0;         /* where the device copies live: the batch can only be filled with an index of that device */
+    int nb_mis_allowed = 0; /* marshalled into the batch (per-gap mismatch allowance): the params of a fill must agree */
     ~mtg_batch() { mtgi::batch_release_device(in); }
 };
 
@@ -1033,6 +1052,8 @@ int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* 
     b->in.ws = nullptr; /* its own storage: the batch outlives any workspace hold */
     b->gaps = gaps;
     b->n = n;
+    b->device = idx->device;
+    b->nb_mis_allowed = p->nb_mis_allowed;
     if (int rc = marshal_gaps(gaps, n, p, b->in)) return rc;
     if (n) { if (int rc = mtgi::batch_upload(idx, b->in)) return rc; }
     *out = b.release();
@@ -1043,6 +1064,8 @@ static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const m
 {
     if (!idx || !p || !b || !out) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     if (b->in.k != idx->dev.k) { mtgi::set_error("the batch was prepared for k = %d", b->in.k); return MTG_ERR_ARG; }
+    if (b->device != idx->device) { mtgi::set_error("the batch was prepared on device %d, the index lives on device %d (prepare one batch per replica)", b->device, idx->device); return MTG_ERR_ARG; }
+    if (b->nb_mis_allowed != p->nb_mis_allowed) { mtgi::set_error("the batch was prepared with nb_mis_allowed = %d", b->nb_mis_allowed); return MTG_ERR_ARG; }
     const double t_begin = mtgi::now_ms();
     mtgi::WorkspaceLock batch_lock = mtgi::acquire_workspace(idx);
     mtgi::FillInput in; /* views of the batch's blocks (host and device); the workspace is this call's */

@@ -349,21 +349,30 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             SlotRec* h_rec = nullptr;
             uint64_t* h_w = nullptr;
             uint32_t* h_m = nullptr;
-            std::vector<uint64_t> dw(c0 + 1);
-            std::vector<uint32_t> dm(5 * c1 + 1);
+            /* the dense arrays start deliberately small, as on the device where they are sized by the last need: the first emission writes
+             * only the gaps that fit, the totals say what is missing, the arrays grow and the launch is emitted again (under the sanitizers a
+             * write past the small arrays would be seen) */
+            std::vector<uint64_t> dw(std::min<uint64_t>(c0, 16) + 1);
+            std::vector<uint32_t> dm(5 * std::min<uint64_t>(c1, 2) + 1);
             std::vector<mtg_gap_result> dres(m);
             std::vector<mtg_filled> dfil(m);
             std::vector<char> none(64);
             EmitDev D;
-            D.seq = sink.seq ? sink.seq : none.data(); D.ext = sink.ext ? sink.ext : none.data(); /* the emulated device writes the host arena directly; a caller's "device" buffer is mirrored below */
-            D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
-            D.res = dres.data(); D.fil = dfil.data();
-            D.dense_words = dw.data(); D.dense_meta = dm.data();
             EmitHost H;
-            H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
-            for (uint32_t s = 0; s < m; s++) {
-                GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
-                emit_gap(cfg, S, recs[s], in.flags[ids[s]], s, ids[s], k, D, H);
+            for (int pass = 0; pass < 2; pass++) {
+                D.seq = sink.seq ? sink.seq : none.data(); D.ext = sink.ext ? sink.ext : none.data(); /* the emulated device writes the host arena directly; a caller's "device" buffer is mirrored below */
+                D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
+                D.res = dres.data(); D.fil = dfil.data();
+                D.dense_words = dw.data(); D.dense_meta = dm.data();
+                D.dense_cap_words = dw.size() - 1; D.dense_cap_contigs = (dm.size() - 1) / 5;
+                H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
+                for (uint32_t s = 0; s < m; s++) {
+                    GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
+                    emit_gap(cfg, S, recs[s], in.flags[ids[s]], s, ids[s], k, D, H);
+                }
+                if (c0 <= D.dense_cap_words && c1 <= D.dense_cap_contigs) break;
+                dw.assign(c0 + 1, 0);
+                dm.assign(5 * c1 + 1, 0);
             }
             if (want_records)
                 for (uint32_t s = 0; s < m; s++) { sink.res[ids[s]] = dres[s]; if (recs[s].asc) sink.fil[ids[s]] = dfil[s]; }
