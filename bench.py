@@ -188,7 +188,7 @@ def main():
     pg = None  # N > 1: pipelined gather of every batch's sequences on rank 0 (created after the first, untimed, pass)
     hbm_pool = None  # secondary measurement: device buffers the sequences are left in (queue of torch tensors)
     acc = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
-               post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0, gaps=0)
+               post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0, finish_kernel_ms=0.0, n_parked_gaps=0, gaps=0)
     acc_lock = threading.Lock()
 
     def fill(b, prepared=None, want_seqs=False, record=False):
@@ -516,7 +516,7 @@ def main():
                             "ms_per_step_median": elapsed / a.steps * 1e3, "ms_per_step_max": max(times) / a.steps * 1e3, "timed_seconds_total": sum(times)},
            "filled": n_filled_all, "sites_verified": n_sites_all, "filled_per_s": value * n_filled_all / max(n_sites_all, 1),
            "filled_sequences_identical_to_truth": identical, "gathered_payload_verified": gathered_ok,
-           "stage_ms_per_batch": {"k_stage_a": acc["kernel_ms"] / L, "k_copy": acc["copy_kernel_ms"] / L, "k_post+scans": acc["post_kernel_ms"] / L, "k_emit": acc["emit_kernel_ms"] / L, "d2h": acc["d2h_ms"] / L,
+           "stage_ms_per_batch": {"k_stage_a+k_finish": acc["kernel_ms"] / L, "k_finish": acc["finish_kernel_ms"] / L, "parked_gaps": acc["n_parked_gaps"] / L, "k_copy": acc["copy_kernel_ms"] / L, "k_post+scans": acc["post_kernel_ms"] / L, "k_emit": acc["emit_kernel_ms"] / L, "d2h": acc["d2h_ms"] / L,
                                   "host": acc["host_ms"] / L, "c_call": acc["total_ms"] / L},
            "roofline": roof, "cpu_baseline": cpu}
     out.update(secondary)

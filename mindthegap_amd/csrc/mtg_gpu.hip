@@ -338,18 +338,36 @@ enum { TRAVERSAL_SETS = mtg_index::NWS }; /* one set of constants per workspace 
 __constant__ Index c_ix[TRAVERSAL_SETS];
 __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 
-/* one gap per lane, one wave per workgroup (waves retire independently) */
-/* Registers capped for two waves per SIMD: the kernel lives on memory latency, and a batch of 100 000 gaps (1 563 waves) then fits the
- * 2 048 wave slots of the chip in one round; left alone the compiler takes 289 registers (one wave per SIMD, two rounds).
- * -DMTG_STAGE_A_WAVES=n: experiments with another cap. */
+/* ---- the traversal: two kernels.
+ *
+ * k_stage_a, the walk kernel: one gap per lane, one wave per workgroup (waves retire independently).  A lane follows its simple paths
+ * (whole unitigs at a time) and answers the strict SNP pattern itself; at any other branching node it PARKS its gap: the walk's state goes
+ * to the gap's raw block (WalkSave) and the slot to the launch's work list -- one atomic per wave, the lanes' places from a ballot and a
+ * prefix popcount.
+ *
+ * k_finish, the finishing kernel: a group of G lanes (a wave, or an aligned part of one) takes a parked gap off the work list and runs
+ * the rest of its life: frontier expansion one lane per (node, nucleotide) with ballots, visited sets / frontlines / path enumeration /
+ * consensuses in LDS (mtg_bubble.h), the walk between two branching nodes by all lanes of the group with the same values.
+ *
+ * MTG_CLASSIC_WALK=1 (A/B measurements and tests): one kernel, every bubble resolved by its lane from HBM scratch (the round-2 shape). */
+/* Registers of the classic form are capped for two waves per SIMD (left alone the compiler takes 289, one wave per SIMD); the walk kernel
+ * without the general bubble code needs fewer.  -DMTG_STAGE_A_WAVES=n / -DMTG_WALK_WAVES=n: experiments with another cap. */
 #ifndef MTG_STAGE_A_WAVES
 #define MTG_STAGE_A_WAVES 2
 #endif
+#ifndef MTG_WALK_WAVES
+#define MTG_WALK_WAVES 2
+#endif
 #define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
-__global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
-                                                const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
-                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                                GapOut* out, uint32_t n, uint32_t cset)
+struct ParkList { /* device: the work list of one launch */
+    uint32_t count;   /* gaps parked by k_stage_a */
+    uint32_t ticket;  /* next entry to hand out in k_finish */
+    uint32_t pad_[2];
+    uint32_t slot[1]; /* count entries */
+};
+template <int MODE>
+__device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
+                                             const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset, ParkList* park)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
@@ -363,8 +381,66 @@ __global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a(uint8_t* zero, 
     R.rlen = rlen[g];
     R.r0 = r0[g];
     GapOut o;
-    stage_a_gap(ix, cfg, S, src[g], R, o);
+    stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr);
     out[slot] = o;
+    if (MODE == WALK_PARK) {
+        const bool parked = o.status == GAP_PARKED;
+        const unsigned long long pm = __ballot(parked);
+        if (pm) {
+            const int leader = __ffsll((long long)pm) - 1;
+            const uint32_t lane = threadIdx.x & 63u;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&park->count, (uint32_t)__popcll(pm));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (parked) park->slot[base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = slot;
+        }
+    }
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
+                                                const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
+                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
+                                                GapOut* out, uint32_t n, uint32_t cset, ParkList* park)
+{
+    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park);
+}
+__global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
+                                                const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
+                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
+                                                GapOut* out, uint32_t n, uint32_t cset)
+{
+    stage_a_lane<WALK_CLASSIC>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, nullptr);
+}
+/* the parked gaps of a launch, one group of G lanes each; the groups take the entries of the work list one after the other (a ticket per
+ * group), so that a long-lived gap does not hold up the others */
+#ifndef MTG_FINISH_WAVES
+#define MTG_FINISH_WAVES 2
+#endif
+template <int G>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FINISH_WAVES))) k_finish(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
+                                               const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t cset, ParkList* park)
+{
+    __shared__ BubbleLds lds[64 / G];
+    const Index& ix = c_ix[cset];
+    const FillCfg& cfg = c_cfg[cset];
+    const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1), gbase = lane & ~(uint32_t)(G - 1);
+    const uint32_t count = park->count;
+    for (;;) {
+        uint32_t t = 0;
+        if (gl == 0) t = atomicAdd(&park->ticket, 1u);
+        t = (uint32_t)__shfl((int)t, (int)gbase, 64);
+        if (t >= count) return;
+        const uint32_t slot = park->slot[t];
+        const uint32_t g = ids ? ids[slot] : slot;
+        GapScratch S = carve(cfg, zero, raw, ilv, slot);
+        S.snp_fast = 1;
+        SwfPattern R;
+        R.words = rwords + roff[g];
+        R.rlen = rlen[g];
+        R.r0 = r0[g];
+        GapOut o;
+        stage_a_walk<WALK_FINISH, G>(ix, cfg, S, 0, R, o, &lds[lane / G]);
+        if (gl == 0) out[slot] = o;
+    }
 }
 
 /* the long runs the traversal left as commands: one wave per gap, four gaps per workgroup (mtg_copy.h) */
@@ -1278,7 +1354,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf();
+          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
@@ -1323,13 +1399,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     tick("upload (async)");
 
     EventSet events;
-    hipEvent_t ev0, ev1, ev2, ev3, eve, evc;
+    hipEvent_t ev0, ev1, ev2, ev3, eve, evc, evf;
     HIP_TRY(events.make(eve));
     HIP_TRY(events.make(evc));
     HIP_TRY(events.make(ev0));
     HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
     HIP_TRY(events.make(ev3));
+    HIP_TRY(events.make(evf));
     PartTot* h_tot = (PartTot*)staging_host(&ws, Workspace::NHOST - 1, sizeof(PartTot) + 64);
     if (!h_tot) { set_error("no page-locked memory for the totals of a launch"); return MTG_ERR_NOMEM; }
 
@@ -1371,6 +1448,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_fil.alloc(chunk * sizeof(mtg_filled)));
         HIP_TRY(d_rlist.alloc(chunk * 4));
         HIP_TRY(d_glist.alloc(chunk * 4));
+        HIP_TRY(d_park.alloc(chunk * 4 + sizeof(ParkList)));
         HIP_TRY(d_seq.alloc(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64))); /* a caller's device buffer is written in place */
         HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
         /* dense words / metadata: only the gaps that need the host bring their contigs back; sized by the last need, grown on demand below */
@@ -1404,9 +1482,34 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             std::unique_lock<std::mutex> traversal_lock(traversal_mtx[(unsigned)idx->device % CopyTurn::MAX_DEV][cset]);
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. ev1 = the traversal kernel alone */
-            hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                               d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset);
+            static const bool classic_walk = getenv("MTG_CLASSIC_WALK") != nullptr; /* A/B hook: every bubble by its lane, from HBM scratch */
+            static const int finish_g = getenv("MTG_FINISH_G") ? atoi(getenv("MTG_FINISH_G")) : 16; /* lanes per parked gap: 8, 16, 32 or 64 */
+            if (!classic_walk) HIP_TRY(hipMemsetAsync(d_park.p, 0, 16, stream));
+            HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel alone, evf .. ev1 = the finishing kernel */
+            if (classic_walk) {
+                hipLaunchKernelGGL(k_stage_a_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset);
+                HIP_TRY(hipEventRecord(evf, stream));
+            } else {
+                hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, d_park.as<ParkList>());
+                HIP_TRY(hipEventRecord(evf, stream));
+                /* the grid is sized without knowing how many gaps were parked: enough groups to fill the device, each taking entries of the
+                 * work list until it is empty (none: the groups leave at once) */
+                const uint32_t per_wg = 64u / (uint32_t)finish_g;
+                const uint32_t nwg = std::min<uint32_t>((m + per_wg - 1) / per_wg, 256u * 16u);
+#define MTG_LAUNCH_FINISH(GG) hipLaunchKernelGGL(k_finish<GG>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, d_park.as<ParkList>())
+                switch (finish_g) {
+#ifdef MTG_FINISH_ALL_G /* experiments: every group size */
+                    case 8: MTG_LAUNCH_FINISH(8); break;
+                    case 32: MTG_LAUNCH_FINISH(32); break;
+#endif
+                    case 64: MTG_LAUNCH_FINISH(64); break;
+                    default: MTG_LAUNCH_FINISH(16); break;
+                }
+#undef MTG_LAUNCH_FINISH
+                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 4, hipMemcpyDeviceToHost, stream)); /* how many were parked (statistics) */
+            }
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
             /* ev1 .. evc: the long runs of the contigs, which the traversal only noted down */
@@ -1552,8 +1655,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
             }
             st.host_ms += now_ms() - t0;
-            float ms = 0, ms2 = 0, ms3 = 0, msc = 0;
+            float ms = 0, ms2 = 0, ms3 = 0, msc = 0, msf = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+            HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
+            st.finish_kernel_ms += msf;
+            if (!classic_walk) st.n_parked_gaps += *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot));
             HIP_TRY(hipEventElapsedTime(&msc, ev1, evc));
             HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
             st.copy_kernel_ms += msc;

@@ -23,7 +23,9 @@ enum GapStatus {
     GAP_OVF_SEEN = 3,    /* frontline visited set full    */
     GAP_OVF_INVOLVED = 4,
     GAP_OVF_QUEUE = 5,
-    GAP_OVF_DFS = 6
+    GAP_OVF_DFS = 6,
+    GAP_PARKED = 100     /* the walk kernel met a branching node that is not the strict SNP pattern: its state is saved (WalkSave) and the
+                            finishing kernel takes the gap from there (never seen outside the two kernels) */
 };
 
 /* uniform launch configuration */
@@ -49,7 +51,7 @@ struct FillCfg {
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_flaux0, o_flaux1, o_dfsf, o_dfsc,
-        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra, o_dfsdep, o_dfsxsn, o_cmd;
+        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra, o_dfsdep, o_dfsxsn, o_cmd, o_save;
 };
 
 enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
@@ -97,6 +99,14 @@ struct CopyCmd {
 };
 enum { COPY_CMDS = 32 };
 MTG_ARR(CopyCmd, s_cmd, r, c.o_cmd)
+/* a walk interrupted at a branching node (GAP_PARKED): everything stage_a_gap needs to go on from there, whoever resumes it.  The contigs
+ * built so far, the queue and the copy commands are in the gap's raw block, the marked set in its zero block. */
+struct WalkSave {
+    uint64_t cur_f, prev_c, start_f, acc, start_base, r_base, msig[4];
+    uint32_t len, c_first, nacc, wpos, head, tail, nb, total_nt, start_idx, r_idx, ncmd, copy_words, store_reads, run_nt, lines, n_marked, flags, pad_;
+    int32_t node_depth, pad2_;
+};
+MTG_ARR(WalkSave, s_save, r, c.o_save)
 MTG_ILV(uint32_t, s_marklog, c.o_marklog) /* slots used in marked[] */
 MTG_ILV(uint32_t, s_seenlog, c.o_seenlog) /* slots touched in seen[] */
 MTG_ILV(uint32_t, s_iseenlog, c.o_iseenlog)
@@ -154,6 +164,8 @@ inline void finalize_cfg(FillCfg& c)
     c.o_qd = (uint32_t)b; b += 4ull * c.qcap;
     b = align_up(b, 16);
     c.o_cmd = (uint32_t)b; b += (uint64_t)sizeof(CopyCmd) * COPY_CMDS; /* the room is there whether or not cmd_cap lets it be used */
+    b = align_up(b, 16);
+    c.o_save = (uint32_t)b; b += (uint64_t)sizeof(WalkSave);
     c.raw_stride = align_up(b + 8, 64);
     /* interleaved per wave: byte offsets within one lane's share (every array starts 8-byte aligned) */
     b = 0;
@@ -258,6 +270,7 @@ struct Worker {
     uint32_t status;
     uint32_t n_marked, n_seen, n_iseen, n_inv;
     uint64_t msig0 = 0, msig1 = 0, msig2 = 0, msig3 = 0;
+    bool no_dp = false; /* the SNP fast path gives up where it would need the alignment itself (the walk kernel: the bubble is then parked) */
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     unsigned long long stamp_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1366,6 +1379,7 @@ MTG_UNROLL
         /* every optimal alignment of two sequences of length n that differ in h places has at least n - h matches (validate_consensuses):
          * when that many pass the 90 % test, so does the traceback's count, whatever it is */
         bool need_dp = identity_below_90(n - h, n, n);
+        if (need_dp && W.no_dp) return 0; /* the general code answers this bubble the same way, with the alignment */
 #ifdef MTG_EMU
         const bool bound_says_pass = !need_dp;
         need_dp = true;
@@ -1509,10 +1523,44 @@ MTG_DEV_NOINLINE bool contig_contains(const uint64_t* wd, uint32_t clen, const S
     return false;
 }
 
-/* [MEM] IterativeExtensions::construct_linear_seqs + Traversal::traverse (A.5). */
-MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out)
+} // namespace mtg
+#include "mtg_bubble.h"
+namespace mtg {
+
+/* [MEM] IterativeExtensions::construct_linear_seqs + Traversal::traverse (A.5).
+ *
+ * Three forms of the same walk:
+ *   WALK_CLASSIC  everything by the one lane, the general bubble code from HBM scratch (the reference form; tests, fallback);
+ *   WALK_PARK     the walk kernel: simple paths and the strict SNP pattern; at any other branching node the walk's state goes to the gap's
+ *                 WalkSave and the gap comes back GAP_PARKED;
+ *   WALK_FINISH   the finishing kernel: G lanes resume ONE parked gap.  The walk itself is run by all G lanes with the same values (a load
+ *                 is one request per group, the stores write the same bytes), so that the lanes arrive together at every branching node,
+ *                 which the group then resolves from its LDS area (mtg_bubble.h); what does not fit there runs the general code. */
+enum { WALK_CLASSIC = 0, WALK_PARK = 1, WALK_FINISH = 2 };
+#ifdef MTG_EMU /* TEST-ONLY: how the group form answered (MTG_EMU_COOP_STATS=1 prints the tally when the process ends) */
+} // namespace mtg
+#include <cstdio>
+#include <cstdlib>
+namespace mtg {
+inline void coop_tally(int n)
+{
+    static struct Tally {
+        unsigned long ok = 0, fail = 0, big[10] = {0};
+        ~Tally()
+        {
+            if (getenv("MTG_EMU_COOP_STATS"))
+                fprintf(stderr, "[emu] group form of explore_branching: %lu consensus, %lu rejected; too big: sets %lu, in-branching check %lu, depth %lu, consensuses %lu, frames %lu, path set %lu, alignment needed %lu, end rule %lu\n",
+                        ok, fail, big[1], big[2], big[3], big[4], big[5], big[6], big[7], big[8]);
+        }
+    } t;
+    if (n > 0) t.ok++; else if (n == COOP_FAIL) t.fail++; else t.big[-n < 10 ? -n : 9]++;
+}
+#endif
+template <int MODE, int G>
+MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLds* L)
 {
     Worker W(ix, cfg, S);
+    W.no_dp = MODE == WALK_PARK;
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     const unsigned long long t_life0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1545,10 +1593,12 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     };
 
     int head = 0, tail = 0;
-    q_f[0] = src_f;
-    q_c[0] = canon(make_kmer(src_f, k));
-    q_d[0] = 0;
-    tail = 1;
+    if (MODE != WALK_FINISH) {
+        q_f[0] = src_f;
+        q_c[0] = canon(make_kmer(src_f, k));
+        q_d[0] = 0;
+        tail = 1;
+    }
     uint32_t nb = 0, total_nt = 0;
 
     /* One flat loop per lane instead of nested BFS / traverse loops: every iteration a lane (W) walks its simple path up to the next
@@ -1761,7 +1811,32 @@ MTG_UNROLL
         run_nt += nbulk;
         len += nbulk;
     };
+    /* ---- a parked walk goes on where it stopped: at the branching node, the SNP attempt behind it */
+    bool resuming = false, parked = false;
+    if (MODE == WALK_FINISH) {
+        const WalkSave sv = *s_save(cfg, S);
+        resuming = true;
+        cur = make_kmer(sv.cur_f, k);
+        prev_c = sv.prev_c;
+        const Kmer st = make_kmer(sv.start_f, k);
+        start_c = canon(st); start_lo = (uint32_t)st.f; start_rc_lo = (uint32_t)st.r;
+        acc = sv.acc; nacc = sv.nacc; wpos = sv.wpos;
+        start_base = sv.start_base; start_idx = sv.start_idx;
+        r_base = sv.r_base; r_idx = sv.r_idx;
+        found_R = (sv.flags & 1u) != 0; r_fwd = (sv.flags & 2u) != 0; r_known = (sv.flags & 4u) != 0;
+        len = sv.len; c_first = sv.c_first; node_depth = sv.node_depth;
+        head = (int)sv.head; tail = (int)sv.tail; nb = sv.nb; total_nt = sv.total_nt;
+        ncmd = sv.ncmd; copy_words = sv.copy_words; store_reads = sv.store_reads; run_nt = sv.run_nt; lines = sv.lines;
+        W.n_marked = sv.n_marked; W.msig0 = sv.msig[0]; W.msig1 = sv.msig[1]; W.msig2 = sv.msig[2]; W.msig3 = sv.msig[3];
+        watch_r = r_is_kmer && node_depth > k;
+        in_contig = true;
+        uint32_t l_ = 0; /* the neighbourhood the walk stood on (read once already: not counted again) */
+        a = adj_right_t(adj, cur, mk1, l_);
+        a_is_cur = true;
+    }
     for (;;) {
+        bool end_contig = false;
+        if (!resuming) {
         if (!in_contig) {
             if (!(head < tail) || W.status != GAP_OK) break;
             const uint64_t node_f = q_f[head];
@@ -1793,7 +1868,6 @@ MTG_UNROLL
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
         unsigned long long* stamp_acc = W.stamp_acc;
 #endif
-        bool end_contig = false;
         MTG_T0(t_w);
         /* ---- phase W: simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has
          * exactly one in- and one out-edge (lookahead): those nodes are non-branching (nothing to mark) and need no read. */
@@ -1893,7 +1967,6 @@ MTG_UNROLL
         }
         if (lazy_prev) { prev_c = canon(kmer_advance(pv, pv_seq & ((1u << (2 * pv_cnt)) - 1u), pv_cnt, k, mk)); lazy_prev = false; }
         MTG_T1(t_w, 0);
-        MTG_T0(t_b);
         /* ---- phase B: branching node ---- */
         if (!end_contig && a.out == 0) {
             /* dead end.  The reference still calls explore_branching here: its frontline has no successor to move to and gives up at once,
@@ -1903,15 +1976,73 @@ MTG_UNROLL
             { int ch_ = -1; const uint32_t nm_ = W.n_marked; if (explore_branching(W, cur, prev_c, ch_) != 0 || W.n_marked != nm_ || W.n_seen != 0) W.status = 0xBAD9; }
 #endif
         }
+        } /* !resuming */
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+        unsigned long long* stamp_acc = W.stamp_acc;
+#endif
+        MTG_T0(t_b);
         if (!end_contig) {
             int chosen = -1;
             MTG_T0(t_snp);
             SnpSeq fast_seq;
             fast_seq.lo = fast_seq.hi = 0;
-            int n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
+            int n = 0;
+            if (!resuming) n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
+            resuming = false;
             MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
-            if (!fast) n = explore_branching(W, cur, prev_c, chosen);
+            bool coop = false;        /* the consensus sits in the group's LDS area */
+            if (!fast) {
+                if (MODE == WALK_PARK) {
+                    /* not the strict SNP pattern: the gap is parked here and a group of lanes takes it over (k_finish) */
+                    WalkSave sv;
+                    sv.cur_f = cur.f; sv.prev_c = prev_c;
+                    sv.start_f = ((uint32_t)start_c == start_lo) ? start_c : revcomp(start_c, k); /* the oriented start node, from its canonical form and the low half of its forward form (only the canonical form and the two low halves are used) */
+                    sv.acc = acc; sv.nacc = nacc; sv.wpos = wpos;
+                    sv.start_base = start_base; sv.start_idx = start_idx; sv.r_base = r_base; sv.r_idx = r_idx;
+                    sv.flags = (found_R ? 1u : 0u) | (r_fwd ? 2u : 0u) | (r_known ? 4u : 0u);
+                    sv.len = len; sv.c_first = c_first; sv.node_depth = node_depth;
+                    sv.head = (uint32_t)head; sv.tail = (uint32_t)tail; sv.nb = nb; sv.total_nt = total_nt;
+                    sv.ncmd = ncmd; sv.copy_words = copy_words; sv.store_reads = store_reads; sv.run_nt = run_nt; sv.lines = W.lines + lines;
+                    sv.n_marked = W.n_marked; sv.msig[0] = W.msig0; sv.msig[1] = W.msig1; sv.msig[2] = W.msig2; sv.msig[3] = W.msig3;
+                    sv.pad_ = 0; sv.pad2_ = 0;
+                    *s_save(cfg, S) = sv;
+                    parked = true;
+                    break;
+                }
+                if (MODE == WALK_FINISH) {
+                    n = coop_explore<G>(W, *L, cur, prev_c, chosen);
+#ifdef MTG_EMU
+                    coop_tally(n);
+#endif
+#ifdef MTG_EMU /* TEST-ONLY: the general code next to every answer of the group form -- same verdict, same consensus, same marks (0xBADC) */
+                    if (n >= 0 && W.status == GAP_OK) {
+                        uint32_t planned_new = 0;
+                        for (uint32_t i = 0; i < (n > 0 ? L->n_marks : 0u); i++) {
+                            bool dup = W.is_marked(L->marks[i]);
+                            for (uint32_t j = 0; j < i && !dup; j++) dup = L->marks[j] == L->marks[i];
+                            planned_new += dup ? 0u : 1u;
+                        }
+                        const uint32_t nm0 = W.n_marked;
+                        int ch2 = -1;
+                        const int n2 = explore_branching(W, cur, prev_c, ch2);
+                        if (W.status == GAP_OK) {
+                            bool same = (n2 > 0) == (n > 0);
+                            if (same && n > 0) {
+                                same = n2 == n && W.n_marked - nm0 == planned_new;
+                                const SP<uint8_t> p2 = s_cons(cfg, S) + (size_t)ch2 * CONS_LEN;
+                                for (int i = 0; i < n && same; i++) same = p2[i] == L->b.cons[chosen][i];
+                                for (uint32_t i = 0; i < L->n_marks && same; i++) same = W.is_marked(L->marks[i]);
+                            }
+                            if (same && n <= 0) same = W.n_marked == nm0;
+                            if (!same) W.status = 0xBADC;
+                        }
+                    }
+#endif
+                    if (n < 0) n = explore_branching(W, cur, prev_c, chosen); /* too big for the LDS areas: the one-lane form from HBM scratch */
+                    else { coop = true; if (n > 0) coop_apply_marks<G>(W, *L); }
+                } else if (MODE == WALK_CLASSIC) n = explore_branching(W, cur, prev_c, chosen);
+            }
             if (n <= 0) {
                 end_contig = true;
             } else {
@@ -1968,7 +2099,7 @@ MTG_UNROLL
                     }
                 }
                 for (int i = 0; i < (appended ? 0 : n); i++) {
-                    const uint32_t nti = fast ? fast_seq.get(i) : (uint32_t)p[i];
+                    const uint32_t nti = fast ? fast_seq.get(i) : coop ? (uint32_t)L->b.cons[chosen][i] : (uint32_t)p[i];
                     prev_c = canon(cur);
                     cur = kmer_next(cur, nti, k, mk);
                     push_nt(nti);
@@ -2049,12 +2180,12 @@ MTG_UNROLL
         atomicMax(&g_life[33], t_end);
     }
 #endif
-    /* leave the zero-initialised region as it was found, whatever the exit path */
+    /* leave the zero-initialised region as it was found, whatever the exit path (a parked walk keeps its marked set: it goes on) */
     W.seen_clear();
     W.iseen_clear();
-    W.marked_clear();
+    if (!parked) W.marked_clear();
     out.n_contigs = nb;
-    out.status = W.status;
+    out.status = parked ? (uint32_t)GAP_PARKED : W.status;
     out.lines = W.lines + lines;
     out.store_reads = store_reads;
     out.run_nt = run_nt;
@@ -2062,6 +2193,10 @@ MTG_UNROLL
     out.copy_words = copy_words;
     out.total_nt = total_nt;
     out.n_words = wpos;
+}
+MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out)
+{
+    stage_a_walk<WALK_CLASSIC, 1>(ix, cfg, S, src_f, R, out, nullptr);
 }
 
 } // namespace mtg

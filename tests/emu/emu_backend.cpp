@@ -294,7 +294,16 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 R.r0 = in.r0[g];
                 SlotRec& r = recs[s];
                 memset(&r, 0, sizeof r);
-                stage_a_gap(idx->dev, cfg, S, in.src[g], R, r.o);
+                /* k_stage_a parks the gap at the first branching node that is not the strict SNP pattern, k_finish resumes it */
+                if (getenv("MTG_EMU_CLASSIC")) stage_a_gap(idx->dev, cfg, S, in.src[g], R, r.o);
+                else {
+                    stage_a_walk<WALK_PARK, 1>(idx->dev, cfg, S, in.src[g], R, r.o, nullptr);
+                    if (r.o.status == GAP_PARKED) {
+                        static thread_local BubbleLds lds;
+                        st.n_parked_gaps++;
+                        stage_a_walk<WALK_FINISH, 1>(idx->dev, cfg, S, 0, R, r.o, &lds);
+                    }
+                }
                 copy_gap(idx->dev.us, cfg, S, r.o); /* k_copy */
                 st.copy_words += r.o.copy_words; st.copy_cmds += r.o.n_cmds;
                 for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, r.o.status); return MTG_ERR_OVERFLOW; }
