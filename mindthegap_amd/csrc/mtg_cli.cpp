@@ -10,6 +10,7 @@
  */
 #include "mtg_internal.h"
 
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -18,6 +19,7 @@
 #include <unordered_map>
 #include <condition_variable>
 #include <thread>
+#include <zlib.h>
 
 namespace mtgi {
 
@@ -99,6 +101,35 @@ struct Files {
     FILE *insert = nullptr, *info = nullptr, *vcf = nullptr, *gfa = nullptr, *ext = nullptr;
     ~Files() { for (FILE* f : {insert, info, vcf, gfa, ext}) if (f) fclose(f); }
 };
+/* the text a run of sites adds to the output files: formatted by whoever has the records (several threads, one piece each), written by the
+ * one thread that owns the files, in input order */
+struct OutText {
+    std::string insert, info, vcf, gfa, ext;
+    void write(Files& F) const
+    {
+        if (F.insert && !insert.empty()) fwrite(insert.data(), 1, insert.size(), F.insert);
+        if (F.info && !info.empty()) fwrite(info.data(), 1, info.size(), F.info);
+        if (F.vcf && !vcf.empty()) fwrite(vcf.data(), 1, vcf.size(), F.vcf);
+        if (F.gfa && !gfa.empty()) fwrite(gfa.data(), 1, gfa.size(), F.gfa);
+        if (F.ext && !ext.empty()) fwrite(ext.data(), 1, ext.size(), F.ext);
+    }
+};
+static void appendf(std::string& o, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static void appendf(std::string& o, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    const int n = vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (n < 0) return;
+    if ((size_t)n < sizeof buf) { o.append(buf, (size_t)n); return; }
+    std::vector<char> big((size_t)n + 1);
+    va_start(ap, fmt);
+    vsnprintf(big.data(), big.size(), fmt, ap);
+    va_end(ap);
+    o.append(big.data(), (size_t)n);
+}
 
 struct Sols { /* a run of solutions */
     const mtg_filled* p = nullptr;
@@ -113,71 +144,95 @@ static Sols sols_of(const mtg_gap_result& g) { Sols s; s.p = g.filled; s.n = (si
 static std::string solu_str(const mtg_filled& s)
 {
     if (s.solution_count <= 1) return "";
-    std::ostringstream o;
-    o << "solution " << s.solution_rank << "/" << s.solution_count;
-    return o.str();
+    char b[64];
+    snprintf(b, sizeof b, "solution %d/%d", s.solution_rank, s.solution_count);
+    return b;
 }
+/* the targetDictionary of a gap as the writers see it */
+struct DictView {
+    const std::string* tname = nullptr;
+    const uint8_t* trc = nullptr;
+};
 
 /* writeFilledBreakpoint, src/Filler.cpp:1029-1093.  The bkpt-mode header passes its arguments in a different order
  * than its format (:1052-1054); the visible x86-64 result is NAME_len_L_qual_Q_avg_cov_A_median_cov_M   SOLU. */
-static void write_filled(Files& F, bool bkpt_mode, const GapArgs& g, Sols sols, const std::string& seedName, const std::string& info)
+static void write_filled(OutText& F, bool bkpt_mode, const DictView& g, Sols sols, std::string_view seedName, const std::string& info)
 {
     for (auto& s : sols) {
         const int llen = (int)strlen(s.seq);
         const std::string solu = solu_str(s);
         if (bkpt_mode) {
-            fprintf(F.insert, ">%s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n", seedName.c_str(), llen, s.qual, (double)s.avg_coverage, (double)s.median_coverage, solu.c_str());
+            appendf(F.insert, ">%.*s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n", (int)seedName.size(), seedName.data(), llen, s.qual, (double)s.avg_coverage, (double)s.median_coverage, solu.c_str());
         } else {
             std::string targetName(g.tname[s.target_index]);
             if (g.trc[s.target_index]) targetName.append("_Rc");
             int cov = s.median_coverage + 0.5;
-            fprintf(F.insert, ">%s;%s;len_%d_qual_%d_median_cov_%d\t%s\n", seedName.c_str(), targetName.c_str(), llen, s.qual, cov, solu.c_str());
+            appendf(F.insert, ">%.*s;%s;len_%d_qual_%d_median_cov_%d\t%s\n", (int)seedName.size(), seedName.data(), targetName.c_str(), llen, s.qual, cov, solu.c_str());
         }
-        fprintf(F.insert, "%.*s\n", llen, s.seq);
+        F.insert.append(s.seq, (size_t)llen);
+        F.insert += '\n';
     }
-    fprintf(F.info, "%s\t%s\n", seedName.c_str(), info.c_str());
+    F.info.append(seedName.data(), seedName.size());
+    F.info += '\t';
+    F.info += info;
+    F.info += '\n';
 }
 
 /* writeVcf, src/Filler.cpp:1095-1214 */
-static void write_vcf(Files& F, bool filter, Sols sols, const std::string& breakpointName, const std::string& sourceSequence)
+static void write_vcf(OutText& F, bool filter, Sols sols, std::string_view breakpointName, std::string_view sourceSequence)
 {
     for (auto& s : sols) {
-        const std::string seq(s.seq);
-        std::string insertion = seq;
+        const size_t slen = strlen(s.seq), srcn = sourceSequence.size();
         int repeatSize = 0;
-        int i = (int)sourceSequence.size() - 1, j = (int)seq.size() - 1;
+        int i = (int)srcn - 1, j = (int)slen - 1;
         while (i > 0 && j >= 0) { /* longest common suffix with a circular insert index, :1107-1126 */
-            if (sourceSequence[i] != seq[j]) break;
+            if (sourceSequence[(size_t)i] != s.seq[j]) break;
             repeatSize++; i--; j--;
-            if (j == -1) j = (int)seq.size() - 1;
+            if (j == -1) j = (int)slen - 1;
         }
-        insertion = sourceSequence.substr(sourceSequence.size() - (repeatSize + 1), repeatSize + 1) + insertion;
-        insertion = insertion.substr(0, insertion.size() - repeatSize);
-        const std::string ref = sourceSequence.substr(sourceSequence.size() - (repeatSize + 1), 1);
-        std::vector<std::string> tokens;
-        { std::istringstream iss(breakpointName); std::string tok; while (getline(iss, tok, '_')) tokens.push_back(tok); }
-        std::string bkpt = breakpointName, position = ".", chromosome = ".", GT = "./.", genotype = "";
-        if (tokens.size() == 7) {
-            bkpt = tokens[0]; position = std::to_string(atoi(tokens[3].c_str()) - repeatSize); chromosome = tokens[1]; genotype = tokens[6];
+        /* insertion = the last repeatSize + 1 nucleotides of the source + the sequence, less its last repeatSize characters (:1147-1149) */
+        std::string insertion(sourceSequence.substr(srcn - (size_t)(repeatSize + 1), (size_t)repeatSize + 1));
+        insertion.append(s.seq, slen);
+        insertion.resize(insertion.size() - (size_t)repeatSize);
+        const char ref = sourceSequence[srcn - (size_t)(repeatSize + 1)];
+        /* the name cut at its underscores (:1165-1182) */
+        std::string_view tokens[9];
+        size_t ntok = 0;
+        {
+            size_t b = 0;
+            for (;;) {
+                const size_t e = breakpointName.find('_', b);
+                if (ntok < 9) tokens[ntok] = breakpointName.substr(b, e == std::string_view::npos ? std::string_view::npos : e - b);
+                ntok++;
+                if (e == std::string_view::npos) break;
+                b = e + 1;
+            }
+            if (!breakpointName.empty() && breakpointName.back() == '_') ntok--; /* getline yields no empty last token */
+        }
+        std::string bkpt(breakpointName), position = ".", chromosome = ".", GT = "./.", genotype = "";
+        auto to_int = [](std::string_view t) { return atoi(std::string(t).c_str()); };
+        if (ntok == 7) {
+            bkpt = std::string(tokens[0]); position = std::to_string(to_int(tokens[3]) - repeatSize); chromosome = std::string(tokens[1]); genotype = std::string(tokens[6]);
             GT = genotype == "HOM" ? "1/1" : "0/1";
         }
-        if (tokens.size() == 8) {
-            bkpt = tokens[0] + tokens[2]; position = std::to_string(atoi(tokens[4].c_str()) - repeatSize); chromosome = tokens[1]; genotype = tokens[7];
+        if (ntok == 8) {
+            bkpt = std::string(tokens[0]) + std::string(tokens[2]); position = std::to_string(to_int(tokens[4]) - repeatSize); chromosome = std::string(tokens[1]); genotype = std::string(tokens[7]);
             GT = genotype == "HOM" ? "1/1" : "0/1";
         }
-        const int size = (int)(insertion.size() - ref.size()), nsol = s.solution_count, npos = repeatSize + 1;
-        std::string filt = "PASS";
+        const int size = (int)insertion.size() - 1, nsol = s.solution_count, npos = repeatSize + 1;
+        const char* filt = "PASS";
         if ((genotype == "HET" && nsol > 1) || (genotype == "HOM" && nsol > 1)) {
             if (filter) break;
             filt = "LOW_QUAL";
         }
-        fprintf(F.vcf, "%s\t%s\t%s\t%s\t%s\t.\t%s\tTYPE=INS;LEN=%i;QUAL=%i;NSOL=%i;NPOS=%i;AVK=%.2f;MDK=%.2f\tGT\t%s\n", chromosome.c_str(), position.c_str(), bkpt.c_str(),
-                ref.c_str(), insertion.c_str(), filt.c_str(), size, s.qual, nsol, npos, (double)s.avg_coverage, (double)s.median_coverage, GT.c_str());
+        appendf(F.vcf, "%s\t%s\t%s\t%c\t", chromosome.c_str(), position.c_str(), bkpt.c_str(), ref);
+        F.vcf += insertion;
+        appendf(F.vcf, "\t.\t%s\tTYPE=INS;LEN=%i;QUAL=%i;NSOL=%i;NPOS=%i;AVK=%.2f;MDK=%.2f\tGT\t%s\n", filt, size, s.qual, nsol, npos, (double)s.avg_coverage, (double)s.median_coverage, GT.c_str());
     }
 }
 
 /* writeToGFA, src/Filler.cpp:1216-1273 */
-static void write_gfa(Files& F, int trim, const GapArgs& g, Sols sols, std::string seedName, bool isRc)
+static void write_gfa(OutText& F, int trim, const DictView& g, Sols sols, std::string seedName, bool isRc)
 {
     const std::string seedNameNode = seedName;
     std::string seedDirection = "+";
@@ -189,18 +244,19 @@ static void write_gfa(Files& F, int trim, const GapArgs& g, Sols sols, std::stri
         int cov = s.median_coverage + 0.5;
         const std::string nodeName = seedNameNode + ";" + targetNameNode + ";len_" + std::to_string((int)strlen(s.seq)) + "_qual_" + std::to_string(s.qual) +
                                      "_median_cov_" + std::to_string(cov) + " " + solu_str(s);
-        fprintf(F.gfa, "S\t%s\t%s\n", nodeName.c_str(), s.seq);
-        fprintf(F.gfa, "L\t%s\t%s\t%s\t+\t%iM\n", seedName.c_str(), seedDirection.c_str(), nodeName.c_str(), trim);
-        fprintf(F.gfa, "L\t%s\t+\t%s\t%s\t%iM\n", nodeName.c_str(), tname.c_str(), trc ? "-" : "+", trim);
+        F.gfa += "S\t"; F.gfa += nodeName; F.gfa += '\t'; F.gfa += s.seq; F.gfa += '\n';
+        appendf(F.gfa, "L\t%s\t%s\t%s\t+\t%iM\n", seedName.c_str(), seedDirection.c_str(), nodeName.c_str(), trim);
+        appendf(F.gfa, "L\t%s\t+\t%s\t%s\t%iM\n", nodeName.c_str(), tname.c_str(), trc ? "-" : "+", trim);
     }
 }
 
-static void write_extension(Files& F, const std::string& contigSeq, const std::string& seedName, const std::string& sourceSequence) /* :1275-1291 */
+static void write_extension(OutText& F, const char* contigSeq, std::string_view seedName, const char* suffix, std::string_view sourceSequence) /* :1275-1291 */
 {
-    const int llen = (int)contigSeq.length();
+    const size_t llen = contigSeq ? strlen(contigSeq) : 0;
     if (llen > 0) {
-        fprintf(F.ext, ">%s_len_%d source=%s\n", seedName.c_str(), llen, sourceSequence.c_str());
-        fprintf(F.ext, "%.*s\n", llen, contigSeq.c_str());
+        appendf(F.ext, ">%.*s%s_len_%d source=%.*s\n", (int)seedName.size(), seedName.data(), suffix, (int)llen, (int)sourceSequence.size(), sourceSequence.data());
+        F.ext.append(contigSeq, llen);
+        F.ext += '\n';
     }
 }
 
@@ -229,12 +285,12 @@ static void usage()
 
 struct Summary {
     int nb_breakpoints = 0, nb_filled = 0, nb_multiple = 0, nb_contigs = 0, nb_used_contigs = 0;
-    void count(size_t nsol) { nb_breakpoints++; if (nsol > 0) { nb_filled++; if (nsol > 1) nb_multiple++; } }
 };
 
-/* The reference hands groups of records to its Dispatcher threads (src/Filler.cpp:824,844); here the sites go in batches to the devices:
- * one host thread per device (each with its replica of the index) takes the next batch, and the calling thread writes the batches' records
- * in input order as they become complete -- the reference's order with -nb-cores 1. */
+/* The reference hands groups of records to its Dispatcher threads (src/Filler.cpp:824,844); here the sites go in batches to the devices.
+ * Every device (each with its replica of the index) is served by MTG_CLI_IN_FLIGHT host threads (default 3: the library runs up to six
+ * batches of an index side by side), each of which takes the next batch, fills it and formats its text; the calling thread writes the
+ * batches' text in input order as it becomes complete -- the reference's order with -nb-cores 1. */
 struct Replicas {
     std::vector<const mtg_index*> idx; /* idx[0] = the index itself */
     std::vector<mtg_index*> owned;
@@ -260,121 +316,301 @@ static size_t cli_batch_size()
 {
     const char* e = getenv("MTG_CLI_BATCH");
     const long v = e ? atol(e) : 0;
-    return v > 0 ? (size_t)v : (size_t)200000;
+    return v > 0 ? (size_t)v : (size_t)100000;
 }
-/* process(b, idx) for every batch b on the devices; consume(b) on the calling thread, in order, once batch b is complete */
-static int run_batches(const Replicas& R, size_t nb, const std::function<int(size_t, const mtg_index*)>& process, const std::function<void(size_t)>& consume)
+static int cli_in_flight()
 {
-    std::atomic<size_t> next{0};
-    std::vector<char> done(nb, 0);
+    const char* e = getenv("MTG_CLI_IN_FLIGHT");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? std::min(v, (int)mtg_index::NWS) : 3;
+}
+/* next(b) hands out batch b (false: the input is exhausted; called by one thread at a time, in order); process(b, idx) runs it on a
+ * device; consume(b) on the calling thread, in order, once batch b is complete.  At most `window` batches are between next() and the end of
+ * consume() at any time (bounded memory).  The first error stops the hand-out; what was complete before it is still consumed in order. */
+static int run_batches(const Replicas& R, const std::function<bool(size_t)>& next, const std::function<int(size_t, const mtg_index*)>& process,
+                       const std::function<void(size_t)>& consume)
+{
     std::mutex m;
     std::condition_variable cv;
-    std::atomic<int> err{MTG_OK};
+    size_t handed = 0, consumed = 0; /* batches handed out / consumed */
+    bool exhausted = false;
+    std::vector<char> done; /* done[b]: batch b has been processed */
+    int err = MTG_OK;
     std::string err_text;
-    std::vector<std::thread> workers;
-    for (size_t d = 0; d < R.idx.size() && d < std::max<size_t>(nb, 1); d++)
-        workers.emplace_back([&, d]() {
-            for (;;) {
-                const size_t b = next.fetch_add(1);
-                if (b >= nb) return;
-                int rc = err.load() ? err.load() : process(b, R.idx[d]);
-                std::lock_guard<std::mutex> lk(m);
-                if (rc && !err.load()) { err = rc; err_text = mtg_last_error(); } /* the message is thread-local: keep the first one */
-                done[b] = 1;
-                cv.notify_all();
+    const int per_dev = cli_in_flight();
+    const size_t window = (size_t)per_dev * R.idx.size() + 2;
+    auto worker = [&](size_t d) {
+        for (;;) {
+            size_t b;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return exhausted || err || handed - consumed < window; });
+                if (exhausted || err) return;
+                b = handed;
+                if (!next(b)) { exhausted = true; cv.notify_all(); return; }
+                handed++;
+                done.push_back(0);
             }
-        });
-    for (size_t b = 0; b < nb; b++) {
-        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done[b] != 0; }); }
-        if (!err.load()) consume(b);
+            const int rc = process(b, R.idx[d]);
+            std::lock_guard<std::mutex> lk(m);
+            if (rc && !err) { err = rc; err_text = mtg_last_error(); } /* the message is thread-local: keep the first one */
+            done[b] = rc ? 2 : 1;
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < R.idx.size(); d++)
+        for (int t = 0; t < per_dev; t++) workers.emplace_back(worker, d);
+    for (;;) {
+        size_t b;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return (consumed < handed && done[consumed]) || ((exhausted || err) && consumed == handed); });
+            if (consumed == handed) break;
+            b = consumed;
+            if (done[b] == 2 || err) { consumed++; cv.notify_all(); continue; } /* a failed batch, or one behind a failure: nothing is written after the error */
+        }
+        consume(b);
+        std::lock_guard<std::mutex> lk(m);
+        consumed++;
+        cv.notify_all();
     }
     for (auto& t : workers) t.join();
-    if (err.load()) set_error("%s", err_text.c_str());
-    return err.load();
+    if (err) set_error("%s", err_text.c_str());
+    return err;
+}
+
+/* ---- the breakpoint file as a stream of batches (src/Filler.cpp:285,844: records 2i / 2i+1 = left / right k-mer of site i).  A batch owns
+ * the text of its records; headers and sequences are NUL-terminated in place, so that the gaps handed to the library point straight into it. */
+struct BkptRec { const char* hdr; uint32_t hdr_len; const char* seq; uint32_t seq_len; };
+struct BkptReader {
+    gzFile f = nullptr;
+    std::vector<char> carry; /* the beginning of the next batch: a partial record, or records beyond the batch size */
+    bool eof = false, bad = false;
+    size_t per_batch; /* records */
+    explicit BkptReader(size_t sites_per_batch) : per_batch(2 * sites_per_batch) {}
+    ~BkptReader() { if (f) gzclose(f); }
+    bool open(const std::string& path) { f = gzopen(path.c_str(), "rb"); if (f) gzbuffer(f, 1 << 20); return f != nullptr; }
+    /* the text of the next per_batch records (fewer at the end of the file) into `text`; false: no record is left */
+    bool next(std::vector<char>& text)
+    {
+        text.clear();
+        text.swap(carry);
+        size_t scanned = 0, nrec = 0; /* record starts seen in text[0, scanned) */
+        size_t cut = std::string::npos;
+        for (;;) {
+            /* record starts: a '>' (FASTA) at the beginning of a line */
+            for (; scanned < text.size(); scanned++) {
+                if (text[scanned] == '>' && (scanned == 0 || text[scanned - 1] == '\n')) {
+                    if (nrec == per_batch) { cut = scanned; break; }
+                    nrec++;
+                }
+            }
+            if (cut != std::string::npos || eof) break;
+            const size_t old = text.size(), want = (size_t)8 << 20;
+            text.resize(old + want);
+            const int got = gzread(f, text.data() + old, (unsigned)want);
+            if (got < 0) { bad = true; eof = true; text.resize(old); break; }
+            text.resize(old + (size_t)got);
+            if ((size_t)got < want) {
+                int zerr = Z_OK;
+                (void)gzerror(f, &zerr);
+                if (!gzeof(f) || !(zerr == Z_OK || zerr == Z_STREAM_END)) bad = true; /* a truncated or corrupt .gz does not pass for a short file */
+                eof = true;
+            }
+        }
+        if (cut != std::string::npos) { carry.assign(text.begin() + (ptrdiff_t)cut, text.end()); text.resize(cut); }
+        text.push_back('\n'); /* the last record may lack its line end */
+        text.push_back('\0');
+        return nrec > 0 && !bad;
+    }
+};
+/* the records of a batch's text: header lines cut at their end, sequence lines joined in place (a sequence may span several lines) */
+static void parse_records(std::vector<char>& text, std::vector<BkptRec>& recs)
+{
+    recs.clear();
+    char* p = text.data();
+    char* const end = p + text.size() - 1; /* the final NUL */
+    while (p < end) {
+        if (*p != '>') { char* nl = (char*)memchr(p, '\n', (size_t)(end - p)); p = nl ? nl + 1 : end; continue; } /* anything before the first record */
+        char* nl = (char*)memchr(p, '\n', (size_t)(end - p));
+        if (!nl) nl = end;
+        BkptRec r;
+        r.hdr = p + 1;
+        char* he = nl;
+        if (he > p + 1 && he[-1] == '\r') he--;
+        *he = 0;
+        r.hdr_len = (uint32_t)(he - (p + 1));
+        p = nl < end ? nl + 1 : end;
+        char* out = p; /* the sequence is compacted to here */
+        r.seq = out;
+        while (p < end && *p != '>') {
+            char* l2 = (char*)memchr(p, '\n', (size_t)(end - p));
+            if (!l2) l2 = end;
+            char* le = l2;
+            if (le > p && le[-1] == '\r') le--;
+            if (out != p) memmove(out, p, (size_t)(le - p));
+            out += le - p;
+            p = l2 < end ? l2 + 1 : end;
+        }
+        r.seq_len = (uint32_t)(out - r.seq);
+        *out = 0; /* out < p: at least the line end of the header or of a sequence line lies in between (or the final NUL) */
+        recs.push_back(r);
+    }
+}
+static void revcomp_into(const char* s, size_t n, std::string& o) /* revcomp_sequence, src/Utils.cpp:44-77: other characters are dropped */
+{
+    for (size_t i = n; i-- > 0;) {
+        switch (s[i]) {
+            case 'a': o += 't'; break; case 't': o += 'a'; break; case 'c': o += 'g'; break; case 'g': o += 'c'; break;
+            case 'A': o += 'T'; break; case 'T': o += 'A'; break; case 'C': o += 'G'; break; case 'G': o += 'C'; break;
+        }
+    }
 }
 
 static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Files& F, Summary& S)
 {
-    std::vector<std::pair<std::string, std::string>> recs;
-    if (!read_sequences(O.bkpt, recs)) { set_error("cannot read %s", O.bkpt.c_str()); return MTG_ERR_IO; }
-    const size_t nsites = recs.size() / 2; /* records 2i / 2i+1 = left / right k-mer, src/Filler.cpp:625-629 */
-    struct Site { std::string name, name_r; };
+    BkptReader reader(cli_batch_size());
+    if (!reader.open(O.bkpt)) { set_error("cannot read %s", O.bkpt.c_str()); return MTG_ERR_IO; }
     struct Batch {
-        size_t s0 = 0, s1 = 0;
-        std::vector<Site> sites;
-        std::vector<GapArgs> fwd, rev;
+        std::vector<char> text;
+        std::vector<BkptRec> recs;
+        size_t n = 0; /* sites */
+        std::vector<mtg_gap> fwd, rev;
+        std::vector<const char*> tseq, tname, rtseq, rtname; /* the one-entry dictionaries: the arrays the gaps point into */
+        std::vector<uint32_t> name_len, name_r_len;          /* the names cut at their first space (src/Filler.cpp:631-636) */
         std::vector<long> rev_idx;
-        BatchRun rf, rr;
+        std::vector<size_t> rev_off; /* reverse attempts: source / target strings in rev_text */
+        std::string rev_text;
+        mtg_results *rf = nullptr, *rr = nullptr;
+        std::vector<OutText> out; /* one piece per FORMAT_CHUNK sites */
+        size_t filled = 0, multiple = 0;
+        ~Batch() { if (rf) mtg_results_free(rf); if (rr) mtg_results_free(rr); }
     };
-    const size_t B = cli_batch_size(), nb = (nsites + B - 1) / B;
-    std::vector<std::unique_ptr<Batch>> batches(nb);
-    const auto process = [&](size_t b, const mtg_index* idx) -> int {
+    enum { FORMAT_CHUNK = 2048 };
+    static const uint8_t not_rc = 0;
+    std::mutex bm;
+    std::vector<std::unique_ptr<Batch>> batches;
+    const auto next = [&](size_t b) -> bool {
         std::unique_ptr<Batch> bt(new Batch());
-        bt->s0 = b * B; bt->s1 = std::min(nsites, (b + 1) * B);
-        const size_t n = bt->s1 - bt->s0;
-        bt->sites.resize(n);
-        bt->fwd.resize(n);
+        if (!reader.next(bt->text)) return false;
+        std::lock_guard<std::mutex> lk(bm);
+        if (batches.size() <= b) batches.resize(b + 1);
+        batches[b] = std::move(bt);
+        return true;
+    };
+    const auto process = [&](size_t b, const mtg_index* idx) -> int {
+        Batch* btp;
+        { std::lock_guard<std::mutex> lk(bm); btp = batches[b].get(); }
+        Batch& bt = *btp;
+        parse_records(bt.text, bt.recs);
+        const size_t n = bt.recs.size() / 2; /* records 2i / 2i+1 = left / right k-mer, src/Filler.cpp:625-629 */
+        bt.n = n;
+        bt.fwd.resize(n); bt.tseq.resize(n); bt.tname.resize(n); bt.name_len.resize(n); bt.name_r_len.resize(n);
         for (size_t j = 0; j < n; j++) {
-            const size_t i = bt->s0 + j;
-            Site& s = bt->sites[j];
-            GapArgs& g = bt->fwd[j];
-            g.source = recs[2 * i].second;
-            g.target = recs[2 * i + 1].second;
-            s.name = short_name(recs[2 * i].first);
-            s.name_r = short_name(recs[2 * i + 1].first);
-            g.repeated = recs[2 * i].first.find("REPEATED") != std::string::npos || recs[2 * i + 1].first.find("REPEATED") != std::string::npos;
-            bkpt_dict_t dict;
-            dict.insert({g.target, std::make_pair(s.name_r, false)});
-            g.set_dict(dict);
+            const BkptRec &l = bt.recs[2 * j], &r = bt.recs[2 * j + 1];
+            const void* sp = memchr(l.hdr, ' ', l.hdr_len);
+            bt.name_len[j] = sp ? (uint32_t)((const char*)sp - l.hdr) : l.hdr_len;
+            sp = memchr(r.hdr, ' ', r.hdr_len);
+            bt.name_r_len[j] = sp ? (uint32_t)((const char*)sp - r.hdr) : r.hdr_len;
+            bt.tseq[j] = r.seq;
+            bt.tname[j] = r.hdr; /* the value of the dictionary entry: only multi-contig gaps look at it, and only to group by it */
+            mtg_gap& g = bt.fwd[j];
+            g.source = l.seq;
+            g.target = r.seq;
+            g.n_targets = 1;
+            g.target_seqs = &bt.tseq[j];
+            g.target_names = &bt.tname[j];
+            g.target_is_rc = &not_rc;
+            g.is_anchor_repeated = (std::string_view(l.hdr, l.hdr_len).find("REPEATED") != std::string_view::npos || std::string_view(r.hdr, r.hdr_len).find("REPEATED") != std::string_view::npos) ? 1 : 0;
+            g.reverse = 0;
         }
-        int rc = bt->rf.run(idx, P, bt->fwd);
+        int rc = mtg_fill_batch(idx, &P, bt.fwd.data(), n, &bt.rf);
         if (rc) return rc;
         /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
-        bt->rev_idx.assign(n, -1);
-        if (!O.fwd_only)
+        bt.rev_idx.assign(n, -1);
+        if (!O.fwd_only) {
             for (size_t j = 0; j < n; j++)
-                if (bt->rf[j].n_filled == 0) {
-                    GapArgs g;
-                    g.target = revcomp_str(bt->fwd[j].source);
-                    g.source = revcomp_str(bt->fwd[j].target);
-                    g.repeated = bt->fwd[j].repeated;
-                    g.reverse = true;
-                    bkpt_dict_t dict;
-                    dict.insert({g.target, std::make_pair(bt->sites[j].name, false)});
-                    g.set_dict(dict);
-                    bt->rev_idx[j] = (long)bt->rev.size();
-                    bt->rev.push_back(std::move(g));
+                if (mtg_results_get(bt.rf, j)->n_filled == 0) {
+                    bt.rev_idx[j] = (long)(bt.rev_off.size() / 2);
+                    bt.rev_off.push_back(bt.rev_text.size());
+                    revcomp_into(bt.fwd[j].target, strlen(bt.fwd[j].target), bt.rev_text); /* the reverse attempt's source */
+                    bt.rev_text += '\0';
+                    bt.rev_off.push_back(bt.rev_text.size());
+                    revcomp_into(bt.fwd[j].source, strlen(bt.fwd[j].source), bt.rev_text); /* and its target */
+                    bt.rev_text += '\0';
                 }
-        if (!bt->rev.empty()) { rc = bt->rr.run(idx, P, bt->rev); if (rc) return rc; }
-        batches[b] = std::move(bt);
+            const size_t nr = bt.rev_off.size() / 2;
+            bt.rev.resize(nr); bt.rtseq.resize(nr); bt.rtname.resize(nr);
+            size_t q = 0;
+            for (size_t j = 0; j < n; j++)
+                if (bt.rev_idx[j] >= 0) {
+                    mtg_gap& g = bt.rev[q];
+                    g.source = bt.rev_text.data() + bt.rev_off[2 * q];
+                    g.target = bt.rev_text.data() + bt.rev_off[2 * q + 1];
+                    bt.rtseq[q] = g.target;
+                    bt.rtname[q] = bt.recs[2 * j].hdr;
+                    g.n_targets = 1;
+                    g.target_seqs = &bt.rtseq[q];
+                    g.target_names = &bt.rtname[q];
+                    g.target_is_rc = &not_rc;
+                    g.is_anchor_repeated = bt.fwd[j].is_anchor_repeated;
+                    g.reverse = 1;
+                    q++;
+                }
+            if (nr) { rc = mtg_fill_batch(idx, &P, bt.rev.data(), nr, &bt.rr); if (rc) return rc; }
+        }
+        /* the batch's text, formatted in pieces by the library's worker pool (the writers of src/Filler.cpp:1029-1214) */
+        const size_t npieces = (n + FORMAT_CHUNK - 1) / FORMAT_CHUNK;
+        bt.out.resize(npieces);
+        std::vector<size_t> pf(npieces, 0), pm(npieces, 0);
+        parallel_for(npieces, P.nb_host_threads, [&](size_t pc) {
+            OutText& T = bt.out[pc];
+            const size_t j1 = std::min(n, (pc + 1) * (size_t)FORMAT_CHUNK);
+            T.insert.reserve((j1 - pc * FORMAT_CHUNK) * 512);
+            T.vcf.reserve((j1 - pc * FORMAT_CHUNK) * 600);
+            std::string info;
+            for (size_t j = pc * FORMAT_CHUNK; j < j1; j++) {
+                const BkptRec &l = bt.recs[2 * j], &r = bt.recs[2 * j + 1];
+                const mtg_gap_result* res = mtg_results_get(bt.rf, j);
+                info = info_string(*res);
+                std::string_view name(l.hdr, bt.name_len[j]);
+                if (bt.rev_idx[j] >= 0) {
+                    res = mtg_results_get(bt.rr, (size_t)bt.rev_idx[j]);
+                    info += info_string(*res);
+                    name = std::string_view(r.hdr, bt.name_r_len[j]); /* src/Filler.cpp:674 */
+                }
+                const Sols sols = sols_of(*res);
+                write_filled(T, true, DictView{}, sols, name, info);
+                write_vcf(T, O.filter, sols, name, std::string_view(l.seq, l.seq_len));
+                if (sols.empty() && O.extend) {
+                    write_extension(T, mtg_results_get(bt.rf, j)->extension, name, "", std::string_view(l.seq, l.seq_len));
+                    std::string rsrc;
+                    revcomp_into(r.seq, r.seq_len, rsrc);
+                    write_extension(T, bt.rev_idx[j] >= 0 ? mtg_results_get(bt.rr, (size_t)bt.rev_idx[j])->extension : "", name, "_reverse", rsrc);
+                }
+                pf[pc] += sols.size() > 0;
+                pm[pc] += sols.size() > 1;
+            }
+        }, 1);
+        for (size_t pc = 0; pc < npieces; pc++) { bt.filled += pf[pc]; bt.multiple += pm[pc]; }
+        /* records and sequences are in the text now */
+        mtg_results_free(bt.rf); bt.rf = nullptr;
+        if (bt.rr) { mtg_results_free(bt.rr); bt.rr = nullptr; }
+        std::vector<char>().swap(bt.text);
         return MTG_OK;
     };
     const auto consume = [&](size_t b) {
-        Batch& bt = *batches[b];
-        for (size_t j = 0; j < bt.s1 - bt.s0; j++) {
-            const Site& s = bt.sites[j];
-            std::string info = info_string(bt.rf[j]);
-            std::string name = s.name;
-            const mtg_gap_result* res = &bt.rf[j];
-            const GapArgs* gw = &bt.fwd[j];
-            if (bt.rev_idx[j] >= 0) {
-                res = &bt.rr[(size_t)bt.rev_idx[j]];
-                info += info_string(*res);
-                name = s.name_r; /* src/Filler.cpp:674 */
-                gw = &bt.rev[(size_t)bt.rev_idx[j]];
-            }
-            const Sols sols = sols_of(*res);
-            write_filled(F, true, *gw, sols, name, info);
-            write_vcf(F, O.filter, sols, name, bt.fwd[j].source);
-            if (sols.empty() && O.extend) {
-                write_extension(F, bt.rf[j].extension, name, bt.fwd[j].source);
-                write_extension(F, bt.rev_idx[j] >= 0 ? std::string(bt.rr[(size_t)bt.rev_idx[j]].extension) : std::string(), name + "_reverse", revcomp_str(bt.fwd[j].target));
-            }
-            S.count(sols.size());
-        }
-        batches[b].reset(); /* its records and sequences are written */
+        std::unique_ptr<Batch> bt;
+        { std::lock_guard<std::mutex> lk(bm); bt = std::move(batches[b]); }
+        for (const OutText& T : bt->out) T.write(F);
+        S.nb_breakpoints += (int)bt->n;
+        S.nb_filled += (int)bt->filled;
+        S.nb_multiple += (int)bt->multiple;
     };
-    return run_batches(R, nb, process, consume);
+    const int rc = run_batches(R, next, process, consume);
+    if (!rc && reader.bad) { set_error("cannot read %s (truncated or corrupt)", O.bkpt.c_str()); return MTG_ERR_IO; }
+    return rc;
 }
 
 static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, Files& F, Summary& S, int trim)
@@ -411,9 +647,13 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
         size_t s0 = 0, s1 = 0;
         std::vector<GapArgs> gaps;
         BatchRun run;
+        OutText out;
+        size_t n = 0, filled = 0, multiple = 0;
     };
     const size_t B = std::max<size_t>(1, cli_batch_size() / std::max<size_t>(1, all_targets.size() / 8)), nb = (seeds.size() + B - 1) / B; /* a gap carries the whole dictionary: fewer per batch */
+    std::mutex bm;
     std::vector<std::unique_ptr<Batch>> batches(nb);
+    const auto next = [&](size_t b) -> bool { return b < nb; };
     const auto process = [&](size_t b, const mtg_index* idx) -> int {
         std::unique_ptr<Batch> bt(new Batch());
         bt->s0 = b * B; bt->s1 = std::min(seeds.size(), (b + 1) * B);
@@ -431,31 +671,39 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
             g.set_dict(dict);
         }
         if (int rc = bt->run.run(idx, P, bt->gaps)) return rc;
-        batches[b] = std::move(bt);
-        return MTG_OK;
-    };
-    const auto consume = [&](size_t b) {
-        Batch& bt = *batches[b];
-        for (size_t i = bt.s0; i < bt.s1; i++) {
-            const size_t j = i - bt.s0;
+        for (size_t i = bt->s0; i < bt->s1; i++) {
+            const size_t j = i - bt->s0;
             const std::string& seedName = seeds[i].first;
             const bool isRc = seedName.length() >= 3 && seedName.compare(seedName.length() - 3, 3, "_Rc") == 0;
             std::vector<mtg_filled> kept;
-            for (auto& s : sols_of(bt.run[j])) { /* drop loops: target == seed reversed, :540-557 */
-                const std::string& tn = bt.gaps[j].tname[s.target_index];
-                const std::string revTargetName = bt.gaps[j].trc[s.target_index] ? tn : tn + "_Rc";
+            for (auto& s : sols_of(bt->run[j])) { /* drop loops: target == seed reversed, :540-557 */
+                const std::string& tn = bt->gaps[j].tname[s.target_index];
+                const std::string revTargetName = bt->gaps[j].trc[s.target_index] ? tn : tn + "_Rc";
                 if (revTargetName != seedName) kept.push_back(s);
             }
             Sols ks;
             ks.p = kept.data(); ks.n = kept.size();
-            write_filled(F, false, bt.gaps[j], ks, seedName, info_string(bt.run[j]));
-            write_gfa(F, trim, bt.gaps[j], ks, seedName, isRc);
-            if (kept.empty() && O.extend) write_extension(F, bt.run[j].extension, seedName, seeds[i].second);
-            S.count(kept.size());
+            const DictView dv{bt->gaps[j].tname.data(), bt->gaps[j].trc.data()};
+            write_filled(bt->out, false, dv, ks, seedName, info_string(bt->run[j]));
+            write_gfa(bt->out, trim, dv, ks, seedName, isRc);
+            if (kept.empty() && O.extend) write_extension(bt->out, bt->run[j].extension, seedName, "", seeds[i].second);
+            bt->n++;
+            bt->filled += kept.size() > 0;
+            bt->multiple += kept.size() > 1;
         }
-        batches[b].reset();
+        std::lock_guard<std::mutex> lk(bm);
+        batches[b] = std::move(bt);
+        return MTG_OK;
     };
-    return run_batches(R, nb, process, consume);
+    const auto consume = [&](size_t b) {
+        std::unique_ptr<Batch> bt;
+        { std::lock_guard<std::mutex> lk(bm); bt = std::move(batches[b]); }
+        bt->out.write(F);
+        S.nb_breakpoints += (int)bt->n;
+        S.nb_filled += (int)bt->filled;
+        S.nb_multiple += (int)bt->multiple;
+    };
+    return run_batches(R, next, process, consume);
 }
 
 int fill_main(int argc, const char* const* argv)

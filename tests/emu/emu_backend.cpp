@@ -246,6 +246,9 @@ int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*,
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, ResultSink& sink, DevBatch& special, mtg_batch_stats* stats, const std::function<void()>* while_busy)
 {
     if (while_busy) (*while_busy)();
+    /* TEST-ONLY fault injection: every batch on the named pretended device fails (the tool's multi-device driver must stop and report) */
+    if (const char* e = getenv("MTG_EMU_FAIL_DEVICE"))
+        if (atoi(e) == idx->device) { set_error("injected failure on device %d", idx->device); return MTG_ERR_NOMEM; }
     const int k = idx->dev.k;
     /* stand-in for k_encode_targets */
     const size_t n_targets = in.traw.size() / TARGET_SLOT;

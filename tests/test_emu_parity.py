@@ -853,3 +853,45 @@ def test_cli_on_two_emulated_devices(emu_product, tmp_path, monkeypatch):
     b = emu_product.Index(h)
     assert (a.abundance(km) == b.abundance(km)).all() and a.info()["nb_unitigs"] == b.info()["nb_unitigs"]
     a.close(); b.close(); o.close()
+
+
+def test_cli_on_three_emulated_devices_with_a_failing_one(emu_product, tmp_path, monkeypatch):
+    """the tool's driver (MTG_CLI_IN_FLIGHT host threads per device, batches handed out as a stream, text written in input order) on three
+    pretended devices; then the same with every batch of device 1 failing: the tool stops with the reference's exit code 1 and the first
+    error's message, and what it wrote before is a prefix of the complete files (nothing out of order, nothing after the failure)"""
+    monkeypatch.setenv("MTG_EMU_DEVICES", "3")
+    monkeypatch.setenv("MTG_CLI_BATCH", "3")
+    monkeypatch.setenv("MTG_CLI_IN_FLIGHT", "2")
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=40, n_sites=40, seed=21)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    idxf = str(tmp_path / "t.mtgidx")
+    _write_idx(idxf, km, ct)
+    bk = str(tmp_path / "t.breakpoints")
+    S.write_breakpoints(bk)
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    # the same input gzip-compressed, with the sequences of some records wrapped over several lines and CR LF line ends
+    import gzip
+    lines = _read(bk).splitlines()
+    with gzip.open(str(tmp_path / "w.breakpoints.gz"), "wt", newline="") as f:
+        for i, l in enumerate(lines):
+            if not l.startswith(">") and i % 6 == 1:
+                f.write(l[:10] + "\r\n" + l[10:20] + "\n" + l[20:] + "\n")
+            else:
+                f.write(l + ("\r\n" if i % 4 == 0 else "\n"))
+    assert emu_product.Filler().run(["-graph", idxf, "-bkpt", str(tmp_path / "w.breakpoints.gz"), "-out", str(tmp_path / "gz")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "gz") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    # device 1 fails
+    monkeypatch.setenv("MTG_EMU_FAIL_DEVICE", "1")
+    assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "bad")]) == 1
+    full = _read(str(tmp_path / "cpu.insertions.fasta"))
+    part = _read(str(tmp_path / "bad.insertions.fasta"))
+    assert full.startswith(part) and len(part) < len(full)
+    assert _read(str(tmp_path / "cpu.info.txt")).startswith(_read(str(tmp_path / "bad.info.txt")))
+    o.close()
