@@ -171,6 +171,11 @@ int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mt
  * with mtg_fill_prepared_serial.  Both buffers are complete when the call returns. */
 int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* d_seq_out, uint64_t cap, char* host_copy, uint64_t* seq_bytes,
                                     mtg_results** out);
+/* The same, and the whole batch -- records AND sequences -- also in relocatable form (mtg_wire_* below), tagged, in DEVICE memory: d_wire is a
+ * buffer of `cap` bytes on the index's device, typically the send buffer of a gather over RCCL / xGMI.  The result kernel writes the
+ * payload there next to the records (no host pass); the results come to the host as with mtg_fill_prepared.  The payload is complete when
+ * the call returns. */
+int mtg_fill_prepared_wire_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, uint64_t tag, void* d_wire, uint64_t cap, uint64_t* wire_bytes, mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
 /* Every pointer obtained from r dies here.  The library keeps the storage of up to six freed result sets (a few hundred bytes per
  * gap plus the sequences) and hands it to the next batches, which then pay no allocation, page fault or memset. */
@@ -179,6 +184,54 @@ void mtg_results_free(mtg_results* r);
  * *seq_bytes = size of the concatenation "seq\n" of all filled sequences in gap order, which mtg_results_copy_seqs writes to dst */
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled);
 int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * A result set in relocatable form (offsets, no pointers): what travels between the ranks of a multi-GPU job -- one process per GPU, every
+ * rank fills its shard of the sites, the rank that owns the output files gathers the shards' records AND sequences and writes them in
+ * input order (the reference's writers under flockfile, src/Filler.cpp:682-683,1029-1214).  Layout:
+ *   mtg_wire_header | n_gaps x mtg_wire_gap | n_filled x mtg_wire_filled | seq_bytes (NUL-terminated fills) | ext_bytes (NUL-terminated extensions)
+ * every section 8-byte aligned.  tag is the caller's (the global index of the batch: gathers of several batches in flight arrive in any order).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct mtg_wire_header {
+    uint64_t magic;                   /* "MTGWIRE1" */
+    uint64_t tag;
+    uint64_t n_gaps, n_filled, seq_bytes, ext_bytes;
+    uint64_t total_bytes;             /* of the whole payload, header included */
+    uint64_t checksum;                /* of everything behind the header (a sum of 64-bit words scrambled by their position) */
+} mtg_wire_header;
+typedef struct mtg_wire_gap {         /* mtg_gap_result */
+    int32_t nb_nodes, total_nt, nb_terminal, has_solution_counts, nb_total_filled, nb_reported, n_filled;
+    uint32_t first_filled;            /* index of its first mtg_wire_filled */
+    uint64_t ext_off;                 /* offset of its extension sequence in the extension section (the empty string at offset 0) */
+} mtg_wire_gap;
+typedef struct mtg_wire_filled {      /* mtg_filled */
+    uint64_t seq_off;                 /* offset in the sequence section */
+    uint32_t seq_len;
+    int32_t nb_errors_in_anchor, target_index, qual, solution_count, solution_rank;
+    float avg_coverage, median_coverage;
+} mtg_wire_filled;
+int mtg_results_wire_size(const mtg_results* r, uint64_t* bytes);
+int mtg_results_to_wire(const mtg_results* r, uint64_t tag, void* dst, uint64_t cap, uint64_t* bytes);
+/* The reverse: a result set whose records point into `wire` (which must stay alive and unchanged until mtg_results_free); the payload is
+ * validated (magic, sizes, offsets, checksum: MTG_ERR_FORMAT).  Needs no device. */
+int mtg_results_from_wire(const void* wire, uint64_t bytes, mtg_results** out, uint64_t* tag);
+
+/* The tool's writers for a run of breakpoint sites (writeFilledBreakpoint, writeVcf, writeExtensions; src/Filler.cpp:1029-1214,1275-1291)
+ * on result sets that may have come over the wire: the text the sites add to <out>.insertions.fasta, .info.txt, .insertions.vcf and
+ * .extensions.fasta, in site order.  rev / rev_index: the reverse attempts (src/Filler.cpp:669-680): rev_index[i] = index in `rev` of site
+ * i's reverse attempt or -1 (rev may be NULL when there is none).  Needs no device. */
+typedef struct mtg_site {
+    const char* name;                 /* header of the left k-mer's record up to the first space (src/Filler.cpp:631-636) */
+    const char* name_r;               /* the same of the right k-mer's record */
+    const char* source;               /* the left k-mer's sequence */
+    const char* target;               /* the right k-mer's sequence */
+} mtg_site;
+typedef struct mtg_text {
+    char *fasta, *info, *vcf, *ext;   /* not NUL-terminated */
+    uint64_t fasta_bytes, info_bytes, vcf_bytes, ext_bytes;
+} mtg_text;
+int mtg_format_bkpt(const mtg_site* sites, size_t n, const mtg_results* fwd, const mtg_results* rev, const int64_t* rev_index, int filter, int extend, mtg_text* out);
+void mtg_text_free(mtg_text* t);
 
 /* Stage A only (gatb IterativeExtensions::construct_linear_seqs, call site src/Filler.cpp:884): contigs of each gap
  * as ASCII, for parity tests and the info file.  sources[i] / targets[i] are NUL terminated strings. */

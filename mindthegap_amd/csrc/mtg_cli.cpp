@@ -468,6 +468,31 @@ static void revcomp_into(const char* s, size_t n, std::string& o) /* revcomp_seq
     }
 }
 
+/* what one breakpoint site adds to the output files (breakpointFunctor, src/Filler.cpp:665-683, and the writers behind it): fwd = the
+ * forward attempt's record, rev = the reverse attempt's (nullptr: there was none) */
+struct SiteRef { std::string_view name, name_r, source, target; };
+static size_t format_bkpt_site(OutText& T, const SiteRef& s, const mtg_gap_result* fwd, const mtg_gap_result* rev, bool filter, bool extend, std::string& info)
+{
+    const mtg_gap_result* res = fwd;
+    info = info_string(*fwd);
+    std::string_view name = s.name;
+    if (rev) {
+        res = rev;
+        info += info_string(*rev);
+        name = s.name_r; /* src/Filler.cpp:674 */
+    }
+    const Sols sols = sols_of(*res);
+    write_filled(T, true, DictView{}, sols, name, info);
+    write_vcf(T, filter, sols, name, s.source);
+    if (sols.empty() && extend) {
+        write_extension(T, fwd->extension, name, "", s.source);
+        std::string rsrc;
+        revcomp_into(s.target.data(), s.target.size(), rsrc);
+        write_extension(T, rev ? rev->extension : "", name, "_reverse", rsrc);
+    }
+    return sols.size();
+}
+
 static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Files& F, Summary& S)
 {
     BkptReader reader(cli_batch_size());
@@ -572,25 +597,10 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
             std::string info;
             for (size_t j = pc * FORMAT_CHUNK; j < j1; j++) {
                 const BkptRec &l = bt.recs[2 * j], &r = bt.recs[2 * j + 1];
-                const mtg_gap_result* res = mtg_results_get(bt.rf, j);
-                info = info_string(*res);
-                std::string_view name(l.hdr, bt.name_len[j]);
-                if (bt.rev_idx[j] >= 0) {
-                    res = mtg_results_get(bt.rr, (size_t)bt.rev_idx[j]);
-                    info += info_string(*res);
-                    name = std::string_view(r.hdr, bt.name_r_len[j]); /* src/Filler.cpp:674 */
-                }
-                const Sols sols = sols_of(*res);
-                write_filled(T, true, DictView{}, sols, name, info);
-                write_vcf(T, O.filter, sols, name, std::string_view(l.seq, l.seq_len));
-                if (sols.empty() && O.extend) {
-                    write_extension(T, mtg_results_get(bt.rf, j)->extension, name, "", std::string_view(l.seq, l.seq_len));
-                    std::string rsrc;
-                    revcomp_into(r.seq, r.seq_len, rsrc);
-                    write_extension(T, bt.rev_idx[j] >= 0 ? mtg_results_get(bt.rr, (size_t)bt.rev_idx[j])->extension : "", name, "_reverse", rsrc);
-                }
-                pf[pc] += sols.size() > 0;
-                pm[pc] += sols.size() > 1;
+                const SiteRef site{std::string_view(l.hdr, bt.name_len[j]), std::string_view(r.hdr, bt.name_r_len[j]), std::string_view(l.seq, l.seq_len), std::string_view(r.seq, r.seq_len)};
+                const size_t nsol = format_bkpt_site(T, site, mtg_results_get(bt.rf, j), bt.rev_idx[j] >= 0 ? mtg_results_get(bt.rr, (size_t)bt.rev_idx[j]) : nullptr, O.filter, O.extend, info);
+                pf[pc] += nsol > 0;
+                pm[pc] += nsol > 1;
             }
         }, 1);
         for (size_t pc = 0; pc < npieces; pc++) { bt.filled += pf[pc]; bt.multiple += pm[pc]; }
@@ -819,3 +829,44 @@ int fill_main(int argc, const char* const* argv)
 } // namespace mtgi
 
 extern "C" int mtg_fill_main(int argc, const char* const* argv) { return mtgi::fill_main(argc, argv); }
+
+extern "C" int mtg_format_bkpt(const mtg_site* sites, size_t n, const mtg_results* fwd, const mtg_results* rev, const int64_t* rev_index, int filter, int extend, mtg_text* out)
+{
+    using namespace mtgi;
+    if (!out || (n && (!sites || !fwd))) { set_error("null argument"); return MTG_ERR_ARG; }
+    memset(out, 0, sizeof *out);
+    enum { CHUNK = 2048 };
+    const size_t npieces = (n + CHUNK - 1) / CHUNK;
+    std::vector<OutText> pieces(npieces);
+    std::atomic<int> bad{0};
+    parallel_for(npieces, 0, [&](size_t pc) {
+        std::string info;
+        for (size_t j = pc * CHUNK; j < std::min(n, (pc + 1) * (size_t)CHUNK); j++) {
+            const mtg_site& s = sites[j];
+            const mtg_gap_result* f = mtg_results_get(fwd, j);
+            const mtg_gap_result* r = (rev_index && rev_index[j] >= 0) ? (rev ? mtg_results_get(rev, (size_t)rev_index[j]) : nullptr) : nullptr;
+            if (!s.name || !s.name_r || !s.source || !s.target || !f || (rev_index && rev_index[j] >= 0 && !r)) { bad = 1; continue; }
+            format_bkpt_site(pieces[pc], SiteRef{s.name, s.name_r, s.source, s.target}, f, r, filter != 0, extend != 0, info);
+        }
+    }, 1);
+    if (bad) { set_error("a site lacks a field or its record"); return MTG_ERR_ARG; }
+    auto join = [&](std::string OutText::*m, char*& dst, uint64_t& bytes) -> bool {
+        uint64_t t = 0;
+        for (const OutText& p : pieces) t += (p.*m).size();
+        dst = (char*)malloc(t ? t : 1);
+        if (!dst) return false;
+        uint64_t o = 0;
+        for (const OutText& p : pieces) { memcpy(dst + o, (p.*m).data(), (p.*m).size()); o += (p.*m).size(); }
+        bytes = t;
+        return true;
+    };
+    if (!join(&OutText::insert, out->fasta, out->fasta_bytes) || !join(&OutText::info, out->info, out->info_bytes) || !join(&OutText::vcf, out->vcf, out->vcf_bytes) ||
+        !join(&OutText::ext, out->ext, out->ext_bytes)) { mtg_text_free(out); set_error("out of memory"); return MTG_ERR_NOMEM; }
+    return MTG_OK;
+}
+extern "C" void mtg_text_free(mtg_text* t)
+{
+    if (!t) return;
+    free(t->fasta); free(t->info); free(t->vcf); free(t->ext);
+    memset(t, 0, sizeof *t);
+}

@@ -26,6 +26,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MTG_DEV __device__ __forceinline__
+#define MTG_HD __host__ __device__ __forceinline__ /* small helpers the host side of mtg_gpu.hip shares with the kernels */
 #ifndef MTG_NOINLINE_BUBBLES
 #define MTG_DEV_NOINLINE __device__ __forceinline__
 #else
@@ -37,6 +38,7 @@
 #else
 #define MTG_EMU 1
 #define MTG_DEV inline
+#define MTG_HD inline
 #define MTG_DEV_NOINLINE inline
 #define MTG_UNROLL
 #define MTG_LDS

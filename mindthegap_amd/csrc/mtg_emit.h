@@ -120,7 +120,29 @@ struct EmitDev {
     uint64_t* dense_words;
     uint32_t* dense_meta;
     uint64_t dense_cap_words, dense_cap_contigs; /* room in the two dense arrays (words; contigs, five metadata entries each) */
+    /* the batch in relocatable form (include/mtg_fill.h: mtg_wire_*), produced next to the records: nullptr = not wanted.  Only a batch
+     * that is one launch in gap order can leave this way (the totals tell; the host falls back to mtg_results_to_wire otherwise). */
+    uint8_t* wire;
+    uint64_t wire_cap, wire_tag;
+    const PartTot* tot;  /* the launch's totals (device memory, complete before k_emit starts) */
+    uint32_t wire_gaps;  /* gaps of the batch */
 };
+/* where the sections of a relocatable batch begin */
+struct WireLayout {
+    uint64_t o_gaps, o_filled, o_seq, o_ext, total;
+};
+MTG_HD WireLayout wire_layout(uint64_t n_gaps, uint64_t n_filled, uint64_t seq_bytes, uint64_t ext_bytes)
+{
+    WireLayout w;
+    w.o_gaps = sizeof(mtg_wire_header);
+    w.o_filled = w.o_gaps + ((n_gaps * sizeof(mtg_wire_gap) + 7) & ~7ull);
+    w.o_seq = w.o_filled + ((n_filled * sizeof(mtg_wire_filled) + 7) & ~7ull);
+    w.o_ext = w.o_seq + ((seq_bytes + 7) & ~7ull);
+    w.total = w.o_ext + ((ext_bytes + 7) & ~7ull);
+    return w;
+}
+/* checksum of a payload's body (mtg_wire_header::checksum): word i contributes (w ^ i * C1) * C2, summed modulo 2^64 */
+MTG_HD uint64_t wire_word_sum(uint64_t w, uint64_t i) { return (w ^ (i * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull; }
 
 MTG_DEV int qual_of(uint32_t errors, bool repeated) /* compute_qual, src/Utils.hpp:85-103, for a single solution */
 {
@@ -136,9 +158,20 @@ MTG_DEV void emit_gap(const FillCfg& cfg, const GapScratch& S, const SlotRec& r,
     const uint32_t lane = MTG_LANE();
     const uint64_t* w = s_words(cfg, S);
     const bool reverse = (flags & GAPF_REVERSE) != 0;
-    const bool seq_ok = r.asc && r.abase + r.asc <= D.seq_cap, ext_ok = r.ext && r.ebase + r.ext <= D.ext_cap; /* an arena that is too small: the host grows it and asks again */
-    if (seq_ok) emit_ascii(w, (uint32_t)k, r.asc - 1u, reverse, D.seq + r.abase);
+    /* relocatable form: the sequence section of the payload IS the batch's sequence arena; the sections' places follow from the totals */
+    WireLayout wl;
+    wl.o_gaps = wl.o_filled = wl.o_seq = wl.o_ext = wl.total = 0;
+    bool wire_ok = false;
+    if (D.wire) {
+        wl = wire_layout(D.wire_gaps, D.tot->n_filled, D.tot->end[2], D.tot->end[3]);
+        wire_ok = wl.total <= D.wire_cap && D.tot->n_retry == 0 && D.tot->n_general == 0;
+    }
+    char* const seq_arena = wire_ok ? (char*)D.wire + wl.o_seq : D.seq;
+    const uint64_t seq_cap = wire_ok ? D.tot->end[2] : D.seq_cap;
+    const bool seq_ok = r.asc && seq_arena && r.abase + r.asc <= seq_cap, ext_ok = r.ext && r.ebase + r.ext <= D.ext_cap; /* an arena that is too small: the host grows it and asks again */
+    if (seq_ok) emit_ascii(w, (uint32_t)k, r.asc - 1u, reverse, seq_arena + r.abase);
     if (ext_ok) emit_ascii(w, (uint32_t)k, r.ext - 1u, false, D.ext + r.ebase);
+    if (wire_ok && r.ext) emit_ascii(w, (uint32_t)k, r.ext - 1u, false, (char*)D.wire + wl.o_ext + r.ebase);
     /* the dense arrays are sized by the last need and k_emit runs before the launch's totals are known: a gap that does not fit writes
      * nothing, the host sees the totals, grows the arrays and emits the launch again (like the two arenas above) */
     const bool dense_ok = r.wbase + r.nw <= D.dense_cap_words && r.cbase + r.nc <= D.dense_cap_contigs;
@@ -187,6 +220,32 @@ MTG_DEV void emit_gap(const FillCfg& cfg, const GapScratch& S, const SlotRec& r,
         /* fast == 0 with terminal nodes: the host fills the record in (multi-contig path) */
     }
     D.res[slot] = g;
+    if (wire_ok) {
+        mtg_wire_gap wg;
+        wg.nb_nodes = g.nb_nodes; wg.total_nt = g.total_nt; wg.nb_terminal = g.nb_terminal; wg.has_solution_counts = g.has_solution_counts;
+        wg.nb_total_filled = g.nb_total_filled; wg.nb_reported = g.nb_reported; wg.n_filled = g.n_filled;
+        wg.first_filled = r.fpos;
+        wg.ext_off = (r.o.status == GAP_OK && r.p.fast == 0 && r.p.nb_terminal == 0 && r.ext) ? r.ebase : 0ull;
+        reinterpret_cast<mtg_wire_gap*>(D.wire + wl.o_gaps)[gap] = wg;
+        if (g.n_filled == 1) {
+            const mtg_filled& f = D.fil[slot];
+            mtg_wire_filled wf;
+            wf.seq_off = r.abase; wf.seq_len = r.asc - 1u;
+            wf.nb_errors_in_anchor = f.nb_errors_in_anchor; wf.target_index = f.target_index; wf.qual = f.qual;
+            wf.solution_count = 1; wf.solution_rank = 1;
+            wf.avg_coverage = f.avg_coverage; wf.median_coverage = f.median_coverage;
+            reinterpret_cast<mtg_wire_filled*>(D.wire + wl.o_filled)[r.fpos] = wf;
+        }
+        if (gap == 0) { /* the header (its checksum comes from wire_finish), the empty extension and the sections' padding */
+            mtg_wire_header h;
+            h.magic = 0x3145524957474D54ull; h.tag = D.wire_tag; h.n_gaps = D.wire_gaps; h.n_filled = D.tot->n_filled;
+            h.seq_bytes = D.tot->end[2]; h.ext_bytes = D.tot->end[3]; h.total_bytes = wl.total; h.checksum = 0;
+            *reinterpret_cast<mtg_wire_header*>(D.wire) = h;
+            D.wire[wl.o_ext] = 0;
+            for (uint64_t x = wl.o_seq + h.seq_bytes; x < wl.o_ext; x++) D.wire[x] = 0;
+            for (uint64_t x = wl.o_ext + h.ext_bytes; x < wl.total; x++) D.wire[x] = 0;
+        }
+    }
 }
 
 } // namespace mtg

@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
  * metadata, the sequence arena, the extension arena, the list of gaps to re-run and the list of multi-contig gaps.  k_scan1: one thread per
  * slot, offsets inside its block of SCAN_SL slots + the block's totals and statistics; k_scan2 (one workgroup): offsets of the blocks on
  * top of the batch's cursors, totals of the launch; k_emit adds the two. */
-enum { SCAN_SL = 256, SCAN_NV = 6, SCAN_NS = 12 };
+enum { SCAN_SL = 256, SCAN_NV = 7, SCAN_NS = 12 };
 struct ScanBlock {
     uint64_t v[SCAN_NV]; /* k_scan1: totals of the block; k_scan2: replaced by the block's base */
     uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext, copy_words, copy_cmds, cov_direct */
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
     __shared__ uint64_t wtot[NW][SCAN_NV];
     __shared__ unsigned long long wsum[NW][SCAN_NS];
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6, slot = blockIdx.x * SCAN_SL + t;
-    uint64_t v[SCAN_NV] = {0, 0, 0, 0, 0, 0};
+    uint64_t v[SCAN_NV] = {0, 0, 0, 0, 0, 0, 0};
     unsigned long long st[SCAN_NS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (slot < m) {
         const SlotRec& r = recs[slot];
@@ -543,6 +543,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
         v[0] = r.nw; v[1] = r.nc; v[2] = r.asc; v[3] = r.ext;
         v[4] = ok ? 0 : 1;
         v[5] = (ok && r.nc) ? 1 : 0; /* its contigs go back to the host: multi-contig path, or the stage-A entry */
+        v[6] = r.asc ? 1 : 0;        /* filled on the common path: one solution */
         st[0] = r.o.lines; st[1] = r.o.store_reads; st[2] = r.o.run_nt; st[4] = r.o.n_words;
         if (r.o.n_cmds) { st[9] = r.o.copy_words; st[10] = r.o.n_cmds; }
         if (ok) {
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
     if (slot < m) {
         SlotRec& r = recs[slot];
         r.wbase = before[0] + incl[0] - v[0]; r.cbase = before[1] + incl[1] - v[1]; r.abase = before[2] + incl[2] - v[2]; r.ebase = before[3] + incl[3] - v[3];
-        r.rpos = (uint32_t)(before[4] + incl[4] - v[4]); r.gpos = (uint32_t)(before[5] + incl[5] - v[5]);
+        r.rpos = (uint32_t)(before[4] + incl[4] - v[4]); r.gpos = (uint32_t)(before[5] + incl[5] - v[5]); r.fpos = (uint32_t)(before[6] + incl[6] - v[6]);
     }
     if (t < SCAN_NV) { uint64_t x = 0; for (int w2 = 0; w2 < NW; w2++) x += wtot[w2][t]; blocks[blockIdx.x].v[t] = x; }
     if (t < SCAN_NS) { unsigned long long x = 0; for (int w2 = 0; w2 < NW; w2++) x += wsum[w2][t]; blocks[blockIdx.x].s[t] = x; }
@@ -644,7 +645,7 @@ __global__ void __launch_bounds__(64) k_emit(FillCfg cfg, uint8_t* raw, SlotRec*
         r = recs[slot];
         const ScanBlock& b = blocks[slot / SCAN_SL];
         r.wbase += b.v[0]; r.cbase += b.v[1]; r.abase += b.v[2]; r.ebase += b.v[3];
-        r.rpos += (uint32_t)b.v[4]; r.gpos += (uint32_t)b.v[5];
+        r.rpos += (uint32_t)b.v[4]; r.gpos += (uint32_t)b.v[5]; r.fpos += (uint32_t)b.v[6];
         recs[slot] = r; /* absolute from here on (the host reads the records of the gaps it has to look at) */
         if (r.o.status != GAP_OK) retry_list[r.rpos] = slot;
         else if (r.nc) general_list[r.gpos] = slot;
@@ -657,6 +658,22 @@ __global__ void __launch_bounds__(64) k_emit(FillCfg cfg, uint8_t* raw, SlotRec*
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
     const uint32_t g = ids ? ids[slot] : slot;
     emit_gap(cfg, S, r, gflags[g], slot, g, k, D, H);
+}
+
+/* checksum of a relocatable batch's body into its header (mtg_wire_header::checksum): a sum of scrambled 64-bit words, any order */
+__global__ void __launch_bounds__(256) k_wire_sum(uint8_t* wire, uint64_t cap)
+{
+    mtg_wire_header* h = reinterpret_cast<mtg_wire_header*>(wire);
+    if (h->magic != 0x3145524957474D54ull || h->total_bytes > cap) return; /* the batch did not leave in this form (the host knows from the totals) */
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(wire + sizeof(mtg_wire_header));
+    const uint64_t n = (h->total_bytes - sizeof(mtg_wire_header)) / 8;
+    uint64_t s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) s += wire_word_sum(w[i], i);
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)s, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(s >> 32), d, 64);
+        s += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long*>(&h->checksum), (unsigned long long)s);
 }
 
 /* contig-graph walk of the multi-contig gaps of a chunk (mtg_paths.h), one wave per gap */
@@ -1531,9 +1548,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 D.res = d_res.as<mtg_gap_result>(); D.fil = d_fil.as<mtg_filled>();
                 D.dense_words = d_dw.as<uint64_t>(); D.dense_meta = d_dm.as<uint32_t>();
                 D.dense_cap_words = ws.cap[d_dw.slot] / 8; D.dense_cap_contigs = ws.cap[d_dm.slot] / 20;
+                const bool want_wire = sink.wire_dev != nullptr && identity && tier == 0;
+                D.wire = want_wire ? (uint8_t*)sink.wire_dev : nullptr; D.wire_cap = sink.wire_cap; D.wire_tag = sink.wire_tag;
+                D.tot = d_tot.as<PartTot>(); D.wire_gaps = m;
+                if (want_wire) HIP_TRY(hipMemsetAsync(sink.wire_dev, 0, sizeof(mtg_wire_header), stream)); /* no header, no payload (k_wire_sum) */
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
                 hipLaunchKernelGGL(k_emit, dim3(m), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H, d_rlist.as<uint32_t>(),
                                    d_glist.as<uint32_t>(), m);
+                if (want_wire) hipLaunchKernelGGL(k_wire_sum, dim3(256 * 4), dim3(256), 0, stream, (uint8_t*)sink.wire_dev, sink.wire_cap);
                 HIP_TRY(hipGetLastError());
                 return MTG_OK;
             };
@@ -1596,7 +1618,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     HIP_TRY(hipMemcpyAsync(tmp_res.data(), d_res.p, (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipMemcpyAsync(tmp_fil.data(), d_fil.p, (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
                 }
-                if (!sink.seq_on_device && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], (sink.seq_dev ? sink.seq_dev : d_seq.as<char>()) + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
+                /* a batch that left in relocatable form has its sequences in the payload's sequence section */
+                const WireLayout wl = wire_layout(m, tot.n_filled, tot.end[2], tot.end[3]);
+                const bool wired = sink.wire_dev != nullptr && identity && tier == 0 && wl.total <= sink.wire_cap && tot.n_retry == 0 && tot.n_general == 0;
+                if (sink.wire_dev && identity && tier == 0) { sink.wire_ok = wired; sink.wire_bytes = wired ? wl.total : 0; }
+                const char* seq_src = wired ? (const char*)sink.wire_dev + wl.o_seq : (sink.seq_dev ? sink.seq_dev : d_seq.as<char>());
+                if (!sink.seq_on_device && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], seq_src + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
                 if (tot.end[3] > tot.begin[3]) HIP_TRY(hipMemcpyAsync(sink.ext + tot.begin[3], d_ext.as<char>() + tot.begin[3], tot.end[3] - tot.begin[3], hipMemcpyDeviceToHost, stream));
             }
             std::vector<uint32_t> rlist(tot.n_retry), glist(tot.n_general);

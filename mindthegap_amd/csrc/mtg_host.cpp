@@ -753,8 +753,10 @@ struct mtg_results {
     std::vector<mtg_filled> gen_fil;   /* and these are their records */
     std::vector<char> relaid;          /* sequences laid out again in gap order (serialised form of a batch with multi-contig gaps) */
     int nthreads = 0;
+    bool plain = false;                /* made by mtg_results_from_wire: malloc'd records pointing into the caller's payload, no device */
     ~mtg_results()
     {
+        if (plain) { free(res); free(fil); return; }
         mtgi::pinned_free(res);
         mtgi::pinned_free(fil);
         mtgi::pinned_free(seq_own);
@@ -776,6 +778,27 @@ struct mtg_results {
 struct mtg_contigs {
     std::vector<std::vector<std::string>> c;
 };
+
+/* ---- the relocatable form of a result set (include/mtg_fill.h: mtg_wire_*) */
+namespace {
+const uint64_t WIRE_MAGIC = 0x3145524957474D54ull; /* "MTGWIRE1" */
+inline uint64_t up8(uint64_t x) { return (x + 7) & ~7ull; }
+uint64_t wire_checksum(const void* p, uint64_t bytes, int nthreads)
+{
+    const uint64_t* w = (const uint64_t*)p;
+    const uint64_t n = bytes / 8, CH = 1 << 16, nch = (n + CH - 1) / CH;
+    std::vector<uint64_t> part(nch, 0);
+    mtgi::parallel_for((size_t)nch, nthreads, [&](size_t c) {
+        uint64_t s = 0;
+        const uint64_t e = std::min<uint64_t>(n, (c + 1) * CH);
+        for (uint64_t i = c * CH; i < e; i++) s += (w[i] ^ (i * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+        part[c] = s;
+    }, 1);
+    uint64_t s = 0;
+    for (uint64_t v : part) s += v;
+    return s;
+}
+}
 
 /* Result objects are recycled: a freed one keeps its page-locked arrays (a hundred bytes per gap plus the sequence arena) for the next
  * batch, which then pays neither allocation nor page faults.  At most six are kept (three batches in flight, each with the previous
@@ -855,8 +878,13 @@ int marshal_gaps(const mtg_gap* g, size_t n, const mtg_params* p, mtgi::FillInpu
 }
 
 /* runs a marshalled batch; gaps: the caller's array (multi-contig gaps look at their dictionary) */
+struct WireReq { /* the batch also in relocatable form, in a device buffer of the caller */
+    void* dev = nullptr;
+    uint64_t cap = 0, tag = 0;
+    uint64_t* bytes = nullptr;
+};
 int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillInput& in, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes,
-                    mtg_results** out, double t_begin, char* d_seq_out = nullptr)
+                    mtg_results** out, double t_begin, char* d_seq_out = nullptr, const WireReq* wire = nullptr)
 {
     using namespace mtgi;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -884,6 +912,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     sink.seq_on_device = R->seq_on_device;
     sink.seq_dev = d_seq_out;
     sink.ext = R->ext; sink.ext_cap = R->ext_cap;
+    if (wire) { sink.wire_dev = wire->dev; sink.wire_cap = wire->cap; sink.wire_tag = wire->tag; }
     sink.grow_seq = [&](size_t need, size_t keep) -> bool {
         if (R->seq_external) return false;
         const size_t cap = need + need / 4 + 4096;
@@ -996,6 +1025,19 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
             R->in_gap_order = true;
         }
     }
+    if (wire) {
+        if (sink.wire_ok && special.special.empty()) *wire->bytes = sink.wire_bytes; /* the result kernel has written it */
+        else {
+            /* several launches, re-run gaps or multi-contig gaps: the finished result set is serialised here and sent up (rare) */
+            uint64_t need = 0;
+            if (int wrc = mtg_results_wire_size(R, &need)) return wrc;
+            if (need > wire->cap) { set_error("wire buffer too small: %llu bytes needed", (unsigned long long)need); return MTG_ERR_ARG; }
+            std::vector<uint64_t> tmp(need / 8 + 1);
+            if (int wrc = mtg_results_to_wire(R, wire->tag, tmp.data(), need, &need)) return wrc;
+            if (int urc = device_upload(idx, wire->dev, tmp.data(), need)) return urc;
+            *wire->bytes = need;
+        }
+    }
     st.total_ms = now_ms() - t_begin;
     stats_store(st);
     guard.r = nullptr;
@@ -1060,7 +1102,8 @@ int mtg_batch_prepare(const mtg_index* idx, const mtg_params* p, const mtg_gap* 
     return MTG_OK;
 }
 void mtg_batch_free(mtg_batch* b) { delete b; }
-static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out, char* d_seq_out = nullptr)
+static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out, char* d_seq_out = nullptr,
+                              const WireReq* wire = nullptr)
 {
     if (!idx || !p || !b || !out) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     if (b->in.k != idx->dev.k) { mtgi::set_error("the batch was prepared for k = %d", b->in.k); return MTG_ERR_ARG; }
@@ -1076,7 +1119,7 @@ static int fill_prepared_impl(const mtg_index* idx, const mtg_params* p, const m
     in.block_a = s.block_a; in.block_b = s.block_b; in.block_c = s.block_c; in.bytes_a = s.bytes_a; in.bytes_b = s.bytes_b; in.bytes_c = s.bytes_c;
     in.dev_a = s.dev_a; in.dev_b = s.dev_b; in.dev_tenc = s.dev_tenc;
     in.ws = batch_lock.ws;
-    return fill_marshalled(idx, p, in, b->gaps, b->n, seq_out, cap, seq_bytes, out, t_begin, d_seq_out);
+    return fill_marshalled(idx, p, in, b->gaps, b->n, seq_out, cap, seq_bytes, out, t_begin, d_seq_out, wire);
 }
 int mtg_fill_prepared(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, mtg_results** out) { return fill_prepared_impl(idx, p, b, nullptr, 0, nullptr, out); }
 int mtg_fill_prepared_serial(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
@@ -1091,9 +1134,18 @@ int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, c
     return fill_prepared_impl(idx, p, b, host_copy ? host_copy : d_seq_out, cap, seq_bytes, out, d_seq_out);
 }
 
+int mtg_fill_prepared_wire_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, uint64_t tag, void* d_wire, uint64_t cap, uint64_t* wire_bytes, mtg_results** out)
+{
+    if (!d_wire || !wire_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    WireReq w;
+    w.dev = d_wire; w.cap = cap; w.tag = tag; w.bytes = wire_bytes;
+    return fill_prepared_impl(idx, p, b, nullptr, 0, nullptr, out, nullptr, &w);
+}
+
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i) { return (r && i < r->n) ? &r->res[i] : nullptr; }
 void mtg_results_free(mtg_results* r)
 {
+    if (r && r->plain) { delete r; return; }
     if (r) results_release(r); /* its storage serves the next batch */
 }
 int mtg_results_summary(const mtg_results* r, uint32_t* n_filled, uint64_t* seq_bytes, uint64_t* n_gaps_filled)
@@ -1135,6 +1187,139 @@ int mtg_results_copy_seqs(const mtg_results* r, char* dst, uint64_t cap)
         }
     return MTG_OK;
 }
+static void wire_counts(const mtg_results* r, uint64_t& n_filled, uint64_t& seq_bytes, uint64_t& ext_bytes)
+{
+    n_filled = 0; seq_bytes = 0; ext_bytes = 1;
+    for (size_t i = 0; i < r->n; i++) {
+        const mtg_gap_result& g = r->res[i];
+        n_filled += (uint64_t)g.n_filled;
+        if (g.extension && g.extension[0]) ext_bytes += strlen(g.extension) + 1;
+    }
+    seq_bytes = r->seq_bytes;
+}
+int mtg_results_wire_size(const mtg_results* r, uint64_t* bytes)
+{
+    if (!r || !bytes) return MTG_ERR_ARG;
+    if (r->seq_on_device) { mtgi::set_error("the sequences of these results are in the caller's device buffer"); return MTG_ERR_ARG; }
+    uint64_t nf, sb, eb;
+    wire_counts(r, nf, sb, eb);
+    *bytes = sizeof(mtg_wire_header) + up8(r->n * sizeof(mtg_wire_gap)) + up8(nf * sizeof(mtg_wire_filled)) + up8(sb) + up8(eb);
+    return MTG_OK;
+}
+int mtg_results_to_wire(const mtg_results* r, uint64_t tag, void* dst, uint64_t cap, uint64_t* bytes)
+{
+    if (!r || !dst || !bytes) return MTG_ERR_ARG;
+    uint64_t total = 0;
+    if (int rc = mtg_results_wire_size(r, &total)) return rc;
+    if (total > cap) { mtgi::set_error("wire buffer too small: %llu bytes needed", (unsigned long long)total); return MTG_ERR_ARG; }
+    uint64_t nf, sb, eb;
+    wire_counts(r, nf, sb, eb);
+    uint8_t* b = (uint8_t*)dst;
+    mtg_wire_header* h = (mtg_wire_header*)b;
+    mtg_wire_gap* wg = (mtg_wire_gap*)(b + sizeof(mtg_wire_header));
+    mtg_wire_filled* wf = (mtg_wire_filled*)((uint8_t*)wg + up8(r->n * sizeof(mtg_wire_gap)));
+    char* ws = (char*)wf + up8(nf * sizeof(mtg_wire_filled));
+    char* we = ws + up8(sb);
+    const size_t n = r->n, CH = 4096, nch = (n + CH - 1) / CH;
+    /* where every gap's solutions, sequences and extension go: prefix sums over pieces of gaps */
+    std::vector<uint64_t> cf(nch + 1, 0), cs(nch + 1, 0), ce(nch + 1, 0);
+    mtgi::parallel_for(nch, r->nthreads, [&](size_t c) {
+        uint64_t f = 0, q = 0, e = 0;
+        for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) {
+            const mtg_gap_result& g = r->res[i];
+            f += (uint64_t)g.n_filled;
+            for (int j = 0; j < g.n_filled; j++) q += strlen(g.filled[j].seq) + 1;
+            if (g.extension && g.extension[0]) e += strlen(g.extension) + 1;
+        }
+        cf[c + 1] = f; cs[c + 1] = q; ce[c + 1] = e;
+    }, 1);
+    ce[0] = 1; /* offset 0 of the extension section is the empty string */
+    for (size_t c = 0; c < nch; c++) { cf[c + 1] += cf[c]; cs[c + 1] += cs[c]; ce[c + 1] += ce[c]; }
+    if (cf[nch] != nf || cs[nch] != sb || ce[nch] != eb) { mtgi::set_error("result set changed while it was serialised"); return MTG_ERR_ARG; }
+    we[0] = 0;
+    mtgi::parallel_for(nch, r->nthreads, [&](size_t c) {
+        uint64_t f = cf[c], q = cs[c], e = ce[c];
+        for (size_t i = c * CH; i < std::min(n, (c + 1) * CH); i++) {
+            const mtg_gap_result& g = r->res[i];
+            mtg_wire_gap& o = wg[i];
+            o.nb_nodes = g.nb_nodes; o.total_nt = g.total_nt; o.nb_terminal = g.nb_terminal; o.has_solution_counts = g.has_solution_counts;
+            o.nb_total_filled = g.nb_total_filled; o.nb_reported = g.nb_reported; o.n_filled = g.n_filled;
+            o.first_filled = (uint32_t)f;
+            o.ext_off = 0;
+            if (g.extension && g.extension[0]) { const size_t l = strlen(g.extension) + 1; memcpy(we + e, g.extension, l); o.ext_off = e; e += l; }
+            for (int j = 0; j < g.n_filled; j++) {
+                const mtg_filled& s = g.filled[j];
+                mtg_wire_filled& w = wf[f++];
+                const size_t l = strlen(s.seq);
+                memcpy(ws + q, s.seq, l + 1);
+                w.seq_off = q; w.seq_len = (uint32_t)l;
+                w.nb_errors_in_anchor = s.nb_errors_in_anchor; w.target_index = s.target_index; w.qual = s.qual;
+                w.solution_count = s.solution_count; w.solution_rank = s.solution_rank;
+                w.avg_coverage = s.avg_coverage; w.median_coverage = s.median_coverage;
+                q += l + 1;
+            }
+        }
+    }, 1);
+    /* the padding of the sections is part of the checksum: make it defined */
+    for (uint64_t x = r->n * sizeof(mtg_wire_gap); x < up8(r->n * sizeof(mtg_wire_gap)); x++) ((uint8_t*)wg)[x] = 0;
+    for (uint64_t x = nf * sizeof(mtg_wire_filled); x < up8(nf * sizeof(mtg_wire_filled)); x++) ((uint8_t*)wf)[x] = 0;
+    for (uint64_t x = sb; x < up8(sb); x++) ws[x] = 0;
+    for (uint64_t x = eb; x < up8(eb); x++) we[x] = 0;
+    h->magic = WIRE_MAGIC; h->tag = tag; h->n_gaps = n; h->n_filled = nf; h->seq_bytes = sb; h->ext_bytes = eb; h->total_bytes = total;
+    h->checksum = wire_checksum(b + sizeof(mtg_wire_header), total - sizeof(mtg_wire_header), r->nthreads);
+    *bytes = total;
+    return MTG_OK;
+}
+int mtg_results_from_wire(const void* wire, uint64_t bytes, mtg_results** out, uint64_t* tag)
+{
+    if (!wire || !out) return MTG_ERR_ARG;
+    const uint8_t* b = (const uint8_t*)wire;
+    const mtg_wire_header* h = (const mtg_wire_header*)b;
+    if (bytes < sizeof(mtg_wire_header) || h->magic != WIRE_MAGIC || h->total_bytes > bytes || (h->total_bytes & 7) || h->ext_bytes < 1) { mtgi::set_error("not a result payload"); return MTG_ERR_FORMAT; }
+    const uint64_t want = sizeof(mtg_wire_header) + up8(h->n_gaps * sizeof(mtg_wire_gap)) + up8(h->n_filled * sizeof(mtg_wire_filled)) + up8(h->seq_bytes) + up8(h->ext_bytes);
+    if (h->n_gaps > (1ull << 40) || h->n_filled > (1ull << 40) || want != h->total_bytes) { mtgi::set_error("result payload: inconsistent sizes"); return MTG_ERR_FORMAT; }
+    if (wire_checksum(b + sizeof(mtg_wire_header), h->total_bytes - sizeof(mtg_wire_header), 0) != h->checksum) { mtgi::set_error("result payload: checksum mismatch"); return MTG_ERR_FORMAT; }
+    const mtg_wire_gap* wg = (const mtg_wire_gap*)(b + sizeof(mtg_wire_header));
+    const mtg_wire_filled* wf = (const mtg_wire_filled*)((const uint8_t*)wg + up8(h->n_gaps * sizeof(mtg_wire_gap)));
+    const char* ws = (const char*)wf + up8(h->n_filled * sizeof(mtg_wire_filled));
+    const char* we = ws + up8(h->seq_bytes);
+    std::unique_ptr<mtg_results> R(new mtg_results());
+    R->n = (size_t)h->n_gaps;
+    R->plain = true;
+    R->res = (mtg_gap_result*)malloc(std::max<size_t>(R->n, 1) * sizeof(mtg_gap_result));
+    R->fil = (mtg_filled*)malloc(std::max<size_t>((size_t)h->n_filled, 1) * sizeof(mtg_filled));
+    if (!R->res || !R->fil) { mtgi::set_error("out of memory"); return MTG_ERR_NOMEM; }
+    R->seq = const_cast<char*>(ws); R->seq_external = true; R->seq_cap = (size_t)h->seq_bytes;
+    R->seq_bytes = h->seq_bytes;
+    R->in_gap_order = true;
+    bool ok = true;
+    for (uint64_t f = 0; f < h->n_filled; f++) {
+        const mtg_wire_filled& w = wf[f];
+        if (w.seq_off + w.seq_len + 1 > h->seq_bytes || ws[w.seq_off + w.seq_len] != 0) { ok = false; break; }
+        mtg_filled& s = R->fil[f];
+        s.seq = ws + w.seq_off;
+        s.nb_errors_in_anchor = w.nb_errors_in_anchor; s.target_index = w.target_index; s.avg_coverage = w.avg_coverage; s.median_coverage = w.median_coverage;
+        s.qual = w.qual; s.solution_count = w.solution_count; s.solution_rank = w.solution_rank;
+    }
+    uint64_t filled_gaps = 0;
+    for (uint64_t i = 0; i < h->n_gaps && ok; i++) {
+        const mtg_wire_gap& g = wg[i];
+        if (g.n_filled < 0 || (uint64_t)g.first_filled + (uint64_t)g.n_filled > h->n_filled || g.ext_off >= h->ext_bytes) { ok = false; break; }
+        mtg_gap_result& o = R->res[i];
+        o.nb_nodes = g.nb_nodes; o.total_nt = g.total_nt; o.nb_terminal = g.nb_terminal; o.has_solution_counts = g.has_solution_counts;
+        o.nb_total_filled = g.nb_total_filled; o.nb_reported = g.nb_reported; o.n_filled = g.n_filled;
+        o.filled = R->fil + g.first_filled;
+        o.extension = we + g.ext_off;
+        filled_gaps += g.n_filled > 0;
+    }
+    if (ok && we[h->ext_bytes - 1] != 0) ok = false;
+    if (!ok) { mtgi::set_error("result payload: offsets out of range"); return MTG_ERR_FORMAT; }
+    R->n_gaps_filled = filled_gaps;
+    if (tag) *tag = h->tag;
+    *out = R.release();
+    return MTG_OK;
+}
+
 int mtg_index_scan_sequences(const mtg_index* idx, const char* const* seqs, size_t nseq, int mode, uint8_t* const* out, mtg_scan_stats* st)
 {
     if (!idx || (nseq && (!seqs || !out))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }

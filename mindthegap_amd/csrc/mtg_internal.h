@@ -412,6 +412,12 @@ struct ResultSink {
     uint64_t seq_used = 0, ext_used = 1;
     uint64_t n_filled = 0;         /* gaps filled on the common path */
     bool in_gap_order = true;
+    /* the batch also in relocatable form (mtg_wire_*), produced by the result kernel in this device buffer of the caller: the send buffer of
+     * a gather.  wire_ok comes back false when the batch could not leave that way (several launches, re-run gaps, multi-contig gaps whose
+     * records the host writes): the caller then serialises the finished result set itself (mtg_results_to_wire) */
+    void* wire_dev = nullptr;
+    uint64_t wire_cap = 0, wire_tag = 0, wire_bytes = 0;
+    bool wire_ok = false;
 };
 
 /* contigs of the gaps that need the host: one record per slot of a launch, the dense words and the dense contig metadata */

@@ -33,6 +33,7 @@ struct SlotRec {
     uint32_t asc, ext; /* bytes in the sequence / extension arena, NUL included */
     uint64_t wbase, cbase, abase, ebase;
     uint32_t rpos, gpos; /* rank among the gaps to re-run / among the gaps that need the host */
+    uint32_t fpos, pad_; /* rank among the filled gaps (the index of its mtg_wire_filled when the batch leaves in relocatable form) */
 };
 
 /* A target as the host hands it over: its first k characters in a TARGET_SLOT-byte slot, byte TARGET_SLOT - 1 = 1 when the anchor

@@ -98,6 +98,22 @@ class BatchStats(C.Structure):
                 ("copy_cmds", C.c_uint64), ("coverage_direct_kmers", C.c_uint64), ("finish_kernel_ms", C.c_double), ("n_parked_gaps", C.c_uint64)]
 
 
+class WireHeader(C.Structure):
+    _fields_ = [("magic", C.c_uint64), ("tag", C.c_uint64), ("n_gaps", C.c_uint64), ("n_filled", C.c_uint64), ("seq_bytes", C.c_uint64), ("ext_bytes", C.c_uint64),
+                ("total_bytes", C.c_uint64), ("checksum", C.c_uint64)]
+
+
+class CSite(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("name_r", C.c_char_p), ("source", C.c_char_p), ("target", C.c_char_p)]
+
+
+class CText(C.Structure):
+    _fields_ = [("fasta", C.c_void_p), ("info", C.c_void_p), ("vcf", C.c_void_p), ("ext", C.c_void_p),
+                ("fasta_bytes", C.c_uint64), ("info_bytes", C.c_uint64), ("vcf_bytes", C.c_uint64), ("ext_bytes", C.c_uint64)]
+
+
+WIRE_HEADER_BYTES = C.sizeof(WireHeader)
+
 _lib = None
 
 
@@ -152,6 +168,13 @@ def _bind(lib):
     lib.mtg_contigs_get.restype = C.c_char_p
     lib.mtg_contigs_free.argtypes = [C.c_void_p]
     lib.mtg_contigs_free.restype = None
+    lib.mtg_fill_prepared_wire_device.argtypes = [C.c_void_p, P(Params), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_void_p)]
+    lib.mtg_results_wire_size.argtypes = [C.c_void_p, P(C.c_uint64)]
+    lib.mtg_results_to_wire.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, P(C.c_uint64)]
+    lib.mtg_results_from_wire.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p), P(C.c_uint64)]
+    lib.mtg_format_bkpt.argtypes = [P(CSite), C.c_size_t, C.c_void_p, C.c_void_p, P(C.c_int64), C.c_int, C.c_int, P(CText)]
+    lib.mtg_text_free.argtypes = [P(CText)]
+    lib.mtg_text_free.restype = None
     lib.mtg_last_batch_stats.argtypes = [P(BatchStats)]
     lib.mtg_fill_main.argtypes = [C.c_int, P(C.c_char_p)]
     lib.mtg_nw_matches.argtypes = [P(C.c_char_p), P(C.c_char_p), C.c_size_t, P(C.c_uint32)]
@@ -317,6 +340,19 @@ class Index:
         _check(self.lib.mtg_batch_prepare(self.h, C.byref(params.c), arr, n, C.byref(h)))
         return Batch(h, n, (arr, keep))
 
+    def fill_prepared_wire_device(self, batch, tag, d_ptr, cap, params=None):
+        """mtg_fill_prepared_wire_device: fills the prepared Batch; the whole batch in relocatable form (records AND sequences, tagged) is
+        written by the result kernel into the device buffer at d_ptr (cap bytes).  Returns (results handle, n_filled per gap, payload bytes)."""
+        params = params or FillParams()
+        h = C.c_void_p()
+        nb = C.c_uint64()
+        _check(self.lib.mtg_fill_prepared_wire_device(self.h, C.byref(params.c), batch.h, int(tag), C.c_void_p(d_ptr), int(cap), C.byref(nb), C.byref(h)))
+        nf = np.empty(batch.n, dtype=np.uint32)
+        sb = C.c_uint64()
+        _check(self.lib.mtg_results_summary(h, nf.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(sb), None))
+        self.last_seq_bytes = int(sb.value)
+        return h, nf, int(nb.value)
+
     def fill_prepared(self, prepared, params=None, want_seqs=True, out=None):
         """one mtg_fill_batch (or, for a Batch, mtg_fill_prepared) call; returns (results handle, n_filled per gap, uint8 array of the packed
         "seq\\n" bytes).  Free with free_results.
@@ -408,6 +444,71 @@ class Index:
         if self.h:
             self.lib.mtg_index_free(self.h)
             self.h = None
+
+
+def results_to_wire(h, tag, out=None):
+    """mtg_results_to_wire: the result set h (records AND sequences) in relocatable form, tagged; written into the uint8 array `out`
+    (e.g. the page-locked buffer of a gather) or a new array.  Returns the payload (a view of `out`)."""
+    lib = load_library()
+    need = C.c_uint64()
+    _check(lib.mtg_results_wire_size(h, C.byref(need)))
+    if out is None:
+        out = np.empty(int(need.value), dtype=np.uint8)
+    if out.size < need.value:
+        raise MtgError(2, "wire buffer of %d bytes for a payload of %d" % (out.size, need.value))
+    got = C.c_uint64()
+    _check(lib.mtg_results_to_wire(h, int(tag), out.ctypes.data_as(C.c_void_p), out.size, C.byref(got)))
+    return out[: int(got.value)]
+
+
+def wire_header(payload):
+    """the mtg_wire_header of a payload (uint8 array) as a dict"""
+    h = WireHeader.from_buffer_copy(np.ascontiguousarray(payload[:WIRE_HEADER_BYTES]).tobytes())
+    return {f[0]: int(getattr(h, f[0])) for f in WireHeader._fields_}
+
+
+class WireResults:
+    """mtg_results_from_wire: a result set rebuilt from a payload (validated: sizes, offsets, checksum); the payload is kept alive."""
+
+    def __init__(self, payload):
+        self.lib = load_library()
+        self.payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        self.h = C.c_void_p()
+        tag = C.c_uint64()
+        _check(self.lib.mtg_results_from_wire(self.payload.ctypes.data_as(C.c_void_p), self.payload.size, C.byref(self.h), C.byref(tag)))
+        self.tag = int(tag.value)
+        self.n = wire_header(self.payload)["n_gaps"]
+
+    def close(self):
+        if self.h:
+            self.lib.mtg_results_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def format_bkpt(sites, fwd, rev=None, rev_index=None, filter=False, extend=False):
+    """mtg_format_bkpt: the text a run of breakpoint sites adds to the tool's output files.  sites: [(name, name_r, source, target)];
+    fwd / rev: result handles (c_void_p or WireResults); rev_index: per site, index into rev or -1.  Returns dict of bytes."""
+    lib = load_library()
+    n = len(sites)
+    arr = (CSite * max(n, 1))()
+    keep = []
+    for i, (a, b, c, d) in enumerate(sites):
+        vals = [x.encode() if isinstance(x, str) else x for x in (a, b, c, d)]
+        keep.append(vals)
+        arr[i].name, arr[i].name_r, arr[i].source, arr[i].target = vals
+    hf = fwd.h if isinstance(fwd, WireResults) else fwd
+    hr = rev.h if isinstance(rev, WireResults) else rev
+    ri = None
+    if rev_index is not None:
+        ri = np.ascontiguousarray(rev_index, dtype=np.int64)
+    t = CText()
+    _check(lib.mtg_format_bkpt(arr, n, hf, hr, ri.ctypes.data_as(C.POINTER(C.c_int64)) if ri is not None else None, int(filter), int(extend), C.byref(t)))
+    out = {k: C.string_at(getattr(t, k), getattr(t, k + "_bytes")) if getattr(t, k + "_bytes") else b"" for k in ("fasta", "info", "vcf", "ext")}
+    lib.mtg_text_free(C.byref(t))
+    return out
 
 
 def last_batch_stats():

@@ -333,6 +333,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             for (uint32_t s = 0; s < m; s++) {
                 SlotRec& r = recs[s];
                 r.wbase = c0; r.cbase = c1; r.abase = c2; r.ebase = c3;
+                r.fpos = tot.n_filled;
                 c0 += r.nw; c1 += r.nc; c2 += r.asc; c3 += r.ext;
                 tot.lines += r.o.lines; tot.store_runs += r.o.store_reads; tot.run_nt += r.o.run_nt; tot.contig_words += r.o.n_words;
                 if (r.o.status != GAP_OK) { r.rpos = (uint32_t)rlist.size(); rlist.push_back(s); continue; }
@@ -377,6 +378,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 D.res = dres.data(); D.fil = dfil.data();
                 D.dense_words = dw.data(); D.dense_meta = dm.data();
                 D.dense_cap_words = dw.size() - 1; D.dense_cap_contigs = (dm.size() - 1) / 5;
+                const bool want_wire = sink.wire_dev != nullptr && identity && tier == 0;
+                D.wire = want_wire ? (uint8_t*)sink.wire_dev : nullptr; D.wire_cap = sink.wire_cap; D.wire_tag = sink.wire_tag;
+                D.tot = &tot; D.wire_gaps = m;
+                if (want_wire) memset(sink.wire_dev, 0, sizeof(mtg_wire_header));
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
                 for (uint32_t s = 0; s < m; s++) {
                     GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
@@ -385,6 +390,20 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 if (c0 <= D.dense_cap_words && c1 <= D.dense_cap_contigs) break;
                 dw.assign(c0 + 1, 0);
                 dm.assign(5 * c1 + 1, 0);
+            }
+            {   /* stand-in for k_wire_sum and for the host's view of the launch (device_run of mtg_gpu.hip) */
+                const WireLayout wl = wire_layout(m, tot.n_filled, tot.end[2], tot.end[3]);
+                const bool wired = sink.wire_dev != nullptr && identity && tier == 0 && wl.total <= sink.wire_cap && tot.n_retry == 0 && tot.n_general == 0;
+                if (sink.wire_dev && identity && tier == 0) { sink.wire_ok = wired; sink.wire_bytes = wired ? wl.total : 0; }
+                if (wired) {
+                    mtg_wire_header* h = (mtg_wire_header*)sink.wire_dev;
+                    const uint64_t* w = (const uint64_t*)((const uint8_t*)sink.wire_dev + sizeof(mtg_wire_header));
+                    uint64_t sum = 0;
+                    for (uint64_t i = 0; i < (h->total_bytes - sizeof(mtg_wire_header)) / 8; i++) sum += wire_word_sum(w[i], i);
+                    h->checksum = sum;
+                    /* the sequences were written into the payload: the host arena gets its copy from there */
+                    if (sink.seq && tot.end[2] > tot.begin[2]) memcpy(sink.seq + tot.begin[2], (const char*)sink.wire_dev + wl.o_seq + tot.begin[2], tot.end[2] - tot.begin[2]);
+                }
             }
             if (want_records)
                 for (uint32_t s = 0; s < m; s++) { sink.res[ids[s]] = dres[s]; if (recs[s].asc) sink.fil[ids[s]] = dfil[s]; }

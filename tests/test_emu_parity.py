@@ -895,3 +895,57 @@ def test_cli_on_three_emulated_devices_with_a_failing_one(emu_product, tmp_path,
     assert full.startswith(part) and len(part) < len(full)
     assert _read(str(tmp_path / "cpu.info.txt")).startswith(_read(str(tmp_path / "bad.info.txt")))
     o.close()
+
+
+def test_results_over_the_wire(emu_product):
+    """the relocatable form of a result set (what the ranks of a multi-GPU job send to the rank that writes the files): serialised on the
+    host (mtg_results_to_wire) and by the result kernel (mtg_fill_prepared_wire_device: the same bytes), rebuilt (mtg_results_from_wire:
+    validated), and formatted by the tool's writers (mtg_format_bkpt) to the same text as the original records"""
+    from mindthegap_amd import lib as L
+    from mindthegap_amd.synth import SynthSet
+    mtg = emu_product
+    for het in (0, 4):  # haploid: every gap on the common path (device emission); diploid with allelic inserts: some through the general path
+        S = SynthSet(nseq=60 if not het else 80, n_sites=30, seed=5, het_snps=het)
+        o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+        km, ct = o.export()
+        idx = mtg.Index.from_kmers(km, ct, 31)
+        sites, gaps = [], []
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            if i % 7 == 3:
+                r = _rc(l)[:31]  # nothing to find: extension instead of a fill
+            sites.append((S.site_name(i), S.site_name(i), l, r))
+            gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+        params = mtg.FillParams()
+        strings = mtg.Index.prepare_gaps(gaps)
+        batch = idx.prepare_batch(strings, params)
+        h, nf, _ = idx.fill_prepared(batch, params, want_seqs=False)
+        direct = L.format_bkpt(sites, h, extend=True)
+        assert direct["fasta"].count(b">") == int((nf > 0).sum()) and direct["info"].count(b"\n") == len(sites)
+        payload = L.results_to_wire(h, 1234)
+        hd = L.wire_header(payload)
+        assert hd["tag"] == 1234 and hd["n_gaps"] == len(sites) and hd["total_bytes"] == payload.size
+        w = L.WireResults(payload)
+        assert w.tag == 1234
+        assert L.format_bkpt(sites, w, extend=True) == direct
+        w.close()
+        # the result kernel's payload: byte for byte the host's
+        buf = np.zeros(payload.size + 4096, dtype=np.uint8)
+        h2, nf2, nb = idx.fill_prepared_wire_device(batch, 1234, buf.ctypes.data, buf.size, params)
+        assert nb == payload.size and (nf2 == nf).all()
+        assert buf[:nb].tobytes() == payload.tobytes()
+        idx.free_results(h2)
+        # a buffer that is too small for the payload is an error, not a truncated payload
+        small = np.zeros(payload.size // 2, dtype=np.uint8)
+        with pytest.raises(L.MtgError):
+            idx.fill_prepared_wire_device(batch, 1, small.ctypes.data, small.size, params)
+        # a damaged payload is refused
+        bad = payload.copy()
+        bad[bad.size // 2] ^= 1
+        with pytest.raises(L.MtgError):
+            L.WireResults(bad)
+        bad = payload[: payload.size - 8].copy()
+        with pytest.raises(L.MtgError):
+            L.WireResults(bad)
+        idx.free_results(h)
+        batch.close(); idx.close(); o.close()
