@@ -231,6 +231,8 @@ typedef struct mtg_text {
     uint64_t fasta_bytes, info_bytes, vcf_bytes, ext_bytes;
 } mtg_text;
 int mtg_format_bkpt(const mtg_site* sites, size_t n, const mtg_results* fwd, const mtg_results* rev, const int64_t* rev_index, int filter, int extend, mtg_text* out);
+/* writeVcfHeader (src/Filler.cpp:349-383) into out->vcf: sample = the reads / graph the index came from, prefix = the output prefix */
+int mtg_format_vcf_header(const char* sample, const char* prefix, mtg_text* out);
 void mtg_text_free(mtg_text* t);
 
 /* Stage A only (gatb IterativeExtensions::construct_linear_seqs, call site src/Filler.cpp:884): contigs of each gap

@@ -260,10 +260,11 @@ static void write_extension(OutText& F, const char* contigSeq, std::string_view 
     }
 }
 
-static void write_vcf_header(FILE* f, const std::string& sample, const std::string& prefix) /* src/Filler.cpp:349-383 */
+static std::string vcf_header(const std::string& sample, const std::string& prefix) /* src/Filler.cpp:349-383 */
 {
     time_t now = time(NULL);
-    fprintf(f,
+    std::string o;
+    appendf(o,
             "##fileformat=VCFv4.1\n##filedate=%s##source=MindTheGap fill version %s\n##SAMPLE=file:%s\n##REF=file:%s\n"
             "##INFO=<ID=TYPE,Number=1,Type=String,Description=\"INS\">\n##INFO=<ID=LEN,Number=1,Type=Integer,Description=\"variant size\">\n"
             "##INFO=<=QUAL,Number=.,Type=Integer,Description=\"Quality of the insertion\">\n"
@@ -273,6 +274,12 @@ static void write_vcf_header(FILE* f, const std::string& sample, const std::stri
             "##INFO=<ID=NPOS,Number=1,Type=Integer,Description=\"number of alternative positions for the insertion site (= size of repeat (fuzzy) +1)\">\n"
             "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tG1\n",
             ctime(&now), MTG_VERSION, sample.c_str(), prefix.c_str());
+    return o;
+}
+static void write_vcf_header(FILE* f, const std::string& sample, const std::string& prefix)
+{
+    const std::string h = vcf_header(sample, prefix);
+    fwrite(h.data(), 1, h.size(), f);
 }
 
 static void usage()
@@ -862,6 +869,17 @@ extern "C" int mtg_format_bkpt(const mtg_site* sites, size_t n, const mtg_result
     };
     if (!join(&OutText::insert, out->fasta, out->fasta_bytes) || !join(&OutText::info, out->info, out->info_bytes) || !join(&OutText::vcf, out->vcf, out->vcf_bytes) ||
         !join(&OutText::ext, out->ext, out->ext_bytes)) { mtg_text_free(out); set_error("out of memory"); return MTG_ERR_NOMEM; }
+    return MTG_OK;
+}
+extern "C" int mtg_format_vcf_header(const char* sample, const char* prefix, mtg_text* out)
+{
+    if (!sample || !prefix || !out) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    memset(out, 0, sizeof *out);
+    const std::string h = mtgi::vcf_header(sample, prefix);
+    out->vcf = (char*)malloc(h.size() + 1);
+    if (!out->vcf) { mtgi::set_error("out of memory"); return MTG_ERR_NOMEM; }
+    memcpy(out->vcf, h.data(), h.size());
+    out->vcf_bytes = h.size();
     return MTG_OK;
 }
 extern "C" void mtg_text_free(mtg_text* t)

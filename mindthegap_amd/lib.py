@@ -173,6 +173,7 @@ def _bind(lib):
     lib.mtg_results_to_wire.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, P(C.c_uint64)]
     lib.mtg_results_from_wire.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p), P(C.c_uint64)]
     lib.mtg_format_bkpt.argtypes = [P(CSite), C.c_size_t, C.c_void_p, C.c_void_p, P(C.c_int64), C.c_int, C.c_int, P(CText)]
+    lib.mtg_format_vcf_header.argtypes = [C.c_char_p, C.c_char_p, P(CText)]
     lib.mtg_text_free.argtypes = [P(CText)]
     lib.mtg_text_free.restype = None
     lib.mtg_last_batch_stats.argtypes = [P(BatchStats)]
@@ -507,6 +508,16 @@ def format_bkpt(sites, fwd, rev=None, rev_index=None, filter=False, extend=False
     t = CText()
     _check(lib.mtg_format_bkpt(arr, n, hf, hr, ri.ctypes.data_as(C.POINTER(C.c_int64)) if ri is not None else None, int(filter), int(extend), C.byref(t)))
     out = {k: C.string_at(getattr(t, k), getattr(t, k + "_bytes")) if getattr(t, k + "_bytes") else b"" for k in ("fasta", "info", "vcf", "ext")}
+    lib.mtg_text_free(C.byref(t))
+    return out
+
+
+def vcf_header(sample, prefix):
+    """mtg_format_vcf_header: the header the tool writes at the top of <prefix>.insertions.vcf"""
+    lib = load_library()
+    t = CText()
+    _check(lib.mtg_format_vcf_header(sample.encode(), prefix.encode(), C.byref(t)))
+    out = C.string_at(t.vcf, t.vcf_bytes)
     lib.mtg_text_free(C.byref(t))
     return out
 

@@ -38,11 +38,15 @@ class PipelinedGather:
     """Per-step gather of a variable-length byte payload on rank dst that overlaps with the following steps: the payload is written
     into a page-locked staging buffer, copied to the device on a side stream and gathered asynchronously (RCCL over xGMI; gloo with host
     tensors in the CPU tests), double buffered.  Buffers have a fixed capacity agreed on beforehand; the first 16 bytes carry the
-    payload length."""
+    payload length and the payload's TAG (the global index of the batch it holds: several batches are in flight and the callers of a
+    rank race, so payloads reach the destination in any order -- the tag is what lets it put them back in input order).
+
+    on_arrival (rank dst only): called with [(rank, tag, payload tensor)] for every completed gather, before its buffers are reused, by
+    whichever thread waits for that gather; the tensors live where the collective left them (device memory with RCCL)."""
 
     HEADER = 16
 
-    def __init__(self, capacity, dst=0, device=None, depth=2):
+    def __init__(self, capacity, dst=0, device=None, depth=2, on_arrival=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -63,6 +67,9 @@ class PipelinedGather:
         self.events = [None] * depth  # GPU: completion of buffer j's gather on the side stream
         self.cur = 0
         self.done = -1  # buffer index of the last submitted step
+        self.on_arrival = on_arrival
+        self.arrival_lock = threading.Lock()
+        self.delivered = [True] * depth  # buffer j's payloads have been handed to on_arrival
         self.lock = threading.Lock()
         # ownership of the staging buffers: a buffer is free, or owned by a caller (acquire .. submit), or in flight (its gather queued);
         # acquire() hands out only a buffer nobody owns, waiting for the oldest one in flight when none is free
@@ -79,6 +86,19 @@ class PipelinedGather:
         elif self.work[j] is not None:
             self.work[j].wait()
         self.work[j] = None
+        if self.on_arrival is not None and self.rank == self.dst and not self.delivered[j]:
+            with self.arrival_lock:  # one delivery at a time: the consumer need not be thread-safe
+                if not self.delivered[j]:
+                    self.delivered[j] = True
+                    self.on_arrival(self.payloads(j))
+
+    def payloads(self, j):
+        """[(rank, tag, payload tensor)] of the completed gather in buffer j (rank dst)"""
+        out = []
+        for r, t in enumerate(self.recv[j]):
+            hd = t[: self.HEADER].cpu().numpy().view(np.int64)
+            out.append((r, int(hd[1]), t[self.HEADER: self.HEADER + int(hd[0])]))
+        return out
 
     def acquire(self):
         """(j, numpy view of the payload area of staging buffer j); the buffer belongs to the caller until submit(nbytes, j).
@@ -110,14 +130,16 @@ class PipelinedGather:
         self.cur, view = self.acquire()
         return view
 
-    def submit(self, nbytes, j=None, on_device=False, host_copy=False):
+    def submit(self, nbytes, j=None, on_device=False, host_copy=False, tag=-1):
         """queue the gather of buffer j.  on_device: the payload was produced in the device buffer (device_area); host_copy: it is also
         brought to the page-locked staging buffer of this rank (so that a rank's results are in its host memory as they are without a
         gather), on the side stream, next to the gather"""
         j = self.cur if j is None else j
         if nbytes + self.HEADER > self.stage[j].numel():
             raise ValueError("payload of %d bytes exceeds the agreed capacity" % nbytes)
-        self.stage[j].numpy()[: self.HEADER].view(np.int64)[0] = nbytes
+        hd = self.stage[j].numpy()[: self.HEADER].view(np.int64)
+        hd[0], hd[1] = nbytes, tag
+        self.delivered[j] = False
         with self.cond:  # collectives are issued one at a time, in the same number on every rank
             if self.on_gpu:
                 self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
@@ -162,3 +184,163 @@ class PipelinedGather:
             n = int(a[: self.HEADER].view(np.int64)[0])
             out.append(a[self.HEADER: self.HEADER + n].copy())
         return out
+
+
+# ---- checking a payload where it arrived -------------------------------------------------------------------------------------------------
+_C1 = np.uint64(0x9E3779B97F4A7C15).astype(np.int64)
+_C2 = np.uint64(0xBF58476D1CE4E5B9).astype(np.int64)
+WIRE_MAGIC = 0x3145524957474D54
+WIRE_HEADER = 64
+
+
+def wire_check(payload):
+    """validates a relocatable batch (include/mtg_fill.h: mtg_wire_header) on the device (or host) the tensor lives on, without moving it:
+    magic, sizes and the checksum of the body recomputed with tensor arithmetic (64-bit wrap-around = the C side's).  Returns the header
+    as a dict with 'ok'."""
+    import torch
+    n = payload.numel()
+    if n < WIRE_HEADER:
+        return {"ok": False, "why": "short"}
+    hd = payload[:WIRE_HEADER].cpu().numpy().view(np.uint64)
+    h = {"magic": int(hd[0]), "tag": int(hd[1]), "n_gaps": int(hd[2]), "n_filled": int(hd[3]), "seq_bytes": int(hd[4]), "ext_bytes": int(hd[5]),
+         "total_bytes": int(hd[6]), "checksum": int(hd[7])}
+    if h["magic"] != WIRE_MAGIC or h["total_bytes"] != n or n % 8:
+        h.update(ok=False, why="header")
+        return h
+    body = payload[WIRE_HEADER:].view(torch.int64)
+    idx = torch.arange(body.numel(), dtype=torch.int64, device=body.device)
+    s = int((((body ^ (idx * int(_C1))) * int(_C2)).sum()).item()) & 0xFFFFFFFFFFFFFFFF
+    h.update(ok=(s == h["checksum"]), why="" if s == h["checksum"] else "checksum")
+    return h
+
+
+class OrderedArrivals:
+    """rank dst: payloads arrive tagged with their global batch index, in any order; take() hands them out in index order.  The payloads
+    are copied to host memory on arrival (the gather's buffers are reused)."""
+
+    def __init__(self, n_batches, check=None):
+        self.n = n_batches
+        self.check = check  # payload tensor -> header dict with 'ok' (wire_check for a bare relocatable batch)
+        self.have = {}
+        self.next = 0
+        self.cond = threading.Condition()
+        self.bad = []
+
+    def arrive(self, items):
+        with self.cond:
+            for rank, tag, t in items:
+                if tag < 0:
+                    continue  # a rank with fewer batches than the others sends empty payloads to keep the collectives in step
+                if self.check is not None:
+                    h = self.check(t)
+                    if not h["ok"] or h["tag"] != tag:
+                        self.bad.append((rank, tag, h.get("why")))
+                self.have[tag] = t.cpu().numpy().copy()
+            self.cond.notify_all()
+
+    def take(self, timeout=600.0):
+        """the payload of the next batch in input order (blocks until it has arrived); None after the last"""
+        with self.cond:
+            if self.next >= self.n:
+                return None
+            if not self.cond.wait_for(lambda: self.next in self.have, timeout=timeout):
+                raise RuntimeError("batch %d never arrived" % self.next)
+            p = self.have.pop(self.next)
+            self.next += 1
+            return p
+
+
+def fill_bkpt_sharded(idx, sites, out_prefix, params=None, batch_sites=100000, device=None, extend=False, filter=False, fwd_only=False, in_flight=2, sample="index"):
+    """`MindTheGap fill -bkpt` over the ranks of a torch.distributed job (one process per GPU, the index replicated): the sites -- the same
+    list of (name, name_r, source, target) on every rank -- are cut into batches of batch_sites, batch b goes to rank shard of its
+    position (contiguous shards), every rank fills its batches (forward attempt, reverse attempt for the unfilled sites) and sends the
+    results -- records AND sequences, relocatable form, tagged with the batch index -- to rank 0, which puts them back in input order and
+    writes <out_prefix>.insertions.fasta / .info.txt / .insertions.vcf exactly as the single-process tool does (src/Filler.cpp:682-683).
+    With a GPU backend the forward payload is produced by the result kernel straight in the gather's device buffer.
+    Returns the number of sites (rank 0) / None."""
+    import torch
+    import torch.distributed as dist
+    from . import lib as L
+    rank, world = dist.get_rank(), dist.get_world_size()
+    params = params or L.FillParams()
+    nb = (len(sites) + batch_sites - 1) // batch_sites
+    blo, bhi = shard_range(nb, rank, world)
+    mine = list(range(blo, bhi))
+    per_rank = max(shard_range(nb, r, world)[1] - shard_range(nb, r, world)[0] for r in range(world))
+    cap_local = 0
+    for b in mine:  # generous: the sequences can be as long as the traversal's limits allow; agreed on below
+        cap_local = max(cap_local, 4096 + (min(len(sites), (b + 1) * batch_sites) - b * batch_sites) * 2 * (200 + 2 * 10000))
+    cap = torch.tensor([cap_local], dtype=torch.int64, device=device if device is not None else torch.device("cpu"))
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+    cap = min(int(cap.item()), 1 << 30)
+    arrivals = OrderedArrivals(nb) if rank == 0 else None
+    pg = PipelinedGather(cap, dst=0, device=device, depth=in_flight + 1, on_arrival=arrivals.arrive if rank == 0 else None)
+    rc_tab = str.maketrans("ACGTacgt", "TGCAtgca")
+
+    def one(b):
+        s0, s1 = b * batch_sites, min(len(sites), (b + 1) * batch_sites)
+        gaps = [L.Gap(st[2], st[3], [(st[3], st[1], False)], is_anchor_repeated=bool(st[4]) if len(st) > 4 else False) for st in sites[s0:s1]]
+        h, nf, _ = idx.fill_prepared(L.Index.prepare_gaps(gaps), params, want_seqs=False)
+        unf = [] if fwd_only else [j for j in range(s1 - s0) if nf[j] == 0]
+        rev_index = np.full(s1 - s0, -1, dtype=np.int64)
+        h2 = None
+        if unf:
+            rg = []
+            for q, j in enumerate(unf):
+                st = sites[s0 + j]
+                name, src, tgt = st[0], st[2], st[3]
+                rs, rt = tgt[::-1].translate(rc_tab), src[::-1].translate(rc_tab)
+                rg.append(L.Gap(rs, rt, [(rt, name, False)], is_anchor_repeated=bool(st[4]) if len(st) > 4 else False, reverse=True))
+                rev_index[j] = q
+            h2, _, _ = idx.fill_prepared(L.Index.prepare_gaps(rg), params, want_seqs=False)
+        # payload: [n | rev wire bytes | fwd wire | rev wire | rev_index]: two relocatable result sets and the map between them
+        j, buf = pg.acquire()
+        fw = L.results_to_wire(h, b, buf[32:])
+        off = 32 + fw.size
+        rv_n = 0
+        if h2 is not None:
+            rv = L.results_to_wire(h2, b, buf[off:])
+            rv_n = rv.size
+        off2 = off + rv_n
+        buf[off2: off2 + rev_index.nbytes] = rev_index.view(np.uint8)
+        hd = buf[:32].view(np.int64)
+        hd[0], hd[1], hd[2], hd[3] = s1 - s0, fw.size, rv_n, b
+        idx.free_results(h)
+        if h2 is not None:
+            idx.free_results(h2)
+        pg.submit(off2 + rev_index.nbytes, j, tag=b)
+
+    for i in range(per_rank):
+        if i < len(mine):
+            one(mine[i])
+        else:  # keep the collectives in step with the ranks that have one batch more
+            j, _ = pg.acquire()
+            pg.submit(0, j, tag=-1)
+    pg.drain()
+    if rank != 0:
+        return None
+    # rank 0: the batches in input order, through the tool's own writers
+    n_written = 0
+    with open(out_prefix + ".insertions.fasta", "wb") as ffa, open(out_prefix + ".info.txt", "wb") as finfo, open(out_prefix + ".insertions.vcf", "wb") as fvcf:
+        fext = open(out_prefix + ".extensions.fasta", "wb") if extend else None
+        fvcf.write(L.vcf_header(sample, out_prefix))
+        for b in range(nb):
+            p = arrivals.have.pop(b)
+            hd = p[:32].view(np.int64)
+            n, fw_n, rv_n = int(hd[0]), int(hd[1]), int(hd[2])
+            assert int(hd[3]) == b
+            fw = L.WireResults(p[32: 32 + fw_n])
+            rv = L.WireResults(p[32 + fw_n: 32 + fw_n + rv_n]) if rv_n else None
+            rev_index = p[32 + fw_n + rv_n: 32 + fw_n + rv_n + 8 * n].view(np.int64)
+            s0 = b * batch_sites
+            text = L.format_bkpt([st[:4] for st in sites[s0: s0 + n]], fw, rv, rev_index, filter=filter, extend=extend)
+            ffa.write(text["fasta"]); finfo.write(text["info"]); fvcf.write(text["vcf"])
+            if fext:
+                fext.write(text["ext"])
+            fw.close()
+            if rv:
+                rv.close()
+            n_written += n
+        if fext:
+            fext.close()
+    return n_written

@@ -74,6 +74,16 @@ def main(out_path):
         with open(out_path, "wb") as f:
             for p in parts:
                 f.write(p.tobytes())
+    # the whole path a multi-GPU run of the tool takes: shards of batches, results (records AND sequences, tagged with their batch index) gathered on
+    # rank 0, put back in input order and written by the tool's own writers -- the files must equal those of the single-process tool
+    from mindthegap_amd.shard import fill_bkpt_sharded
+    sites = []
+    for i in range(S.n_sites):
+        l, r, _ = S.site(i)
+        if i % 5 == 2:
+            r = l[::-1].translate(str.maketrans("ACGT", "TGCA"))  # an anchor pair with nothing in between: reverse attempt, no fill
+        sites.append((S.site_name(i), S.site_name(i), l, r))
+    fill_bkpt_sharded(idx, sites, out_path + ".sharded", batch_sites=3, extend=True)
     dist.barrier()
     dist.destroy_process_group()
 
