@@ -285,6 +285,9 @@ int mtg_nw_matches(const char* const* a, const char* const* b, size_t n, uint32_
  * Returns the process exit code of the reference (0 / 1).
  * ---------------------------------------------------------------------------------------------------------- */
 int mtg_fill_main(int argc, const char* const* argv);
+/* The same behind Graph::load / Graph::create (src/Filler.cpp:172-226): the graph is an index that is already resident (options -in / -graph
+ * are not expected; the index stays the caller's).  What a long-lived caller uses to run the tool's drivers and writers repeatedly. */
+int mtg_fill_main_on_index(mtg_index* idx, int argc, const char* const* argv);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Bench support: measured ceiling of dependent random reads of line_bytes (16/32/64/128) over a table of the given size.

@@ -723,7 +723,9 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
     return run_batches(R, next, process, consume);
 }
 
-int fill_main(int argc, const char* const* argv)
+static int run_tool(Options& O, mtg_index* idx, bool resident);
+/* resident != nullptr: the graph is this index, already on a device (mtg_fill_main_on_index): -in / -graph are not expected */
+static int fill_main_impl(int argc, const char* const* argv, mtg_index* resident)
 {
     Options O;
     for (int i = 0; i < argc; i++) {
@@ -753,7 +755,8 @@ int fill_main(int argc, const char* const* argv)
         if (!ok) { fprintf(stderr, "EXCEPTION: missing value for option '%s'\n", a.c_str()); return 1; }
     }
     /* src/Filler.cpp:140-150 */
-    if (O.graph.empty() == O.in.empty()) { fprintf(stderr, "EXCEPTION: options -graph and -in are incompatible, but at least one of these is mandatory\n"); return 1; }
+    if (!resident && O.graph.empty() == O.in.empty()) { fprintf(stderr, "EXCEPTION: options -graph and -in are incompatible, but at least one of these is mandatory\n"); return 1; }
+    if (resident && !(O.graph.empty() && O.in.empty())) { fprintf(stderr, "EXCEPTION: the graph is already resident: options -graph and -in are not expected\n"); return 1; }
     if (O.bkpt.empty() == O.contig.empty()) { fprintf(stderr, "EXCEPTION: option -bkpt and -contig are incompatible, but at least one of these is mandatory\n"); return 1; }
     if (!O.has_out) { /* src/Filler.cpp:154-165 */
         time_t now = time(0);
@@ -762,9 +765,11 @@ int fill_main(int argc, const char* const* argv)
         strftime(buf, sizeof(buf), "%Y-%m-%d.%I:%M", &tstruct);
         O.out = std::string("MindTheGap_Expe-") + buf;
     }
-    mtg_index* idx = nullptr;
-    int rc;
-    if (!O.in.empty()) {
+    mtg_index* idx = resident;
+    int rc = MTG_OK;
+    if (resident) {
+        O.graph = "(resident index)";
+    } else if (!O.in.empty()) {
         rc = index_from_reads(O.in.c_str(), O.k, O.abundance_min, O.abundance_max, &idx);
         if (!rc) (void)index_save(idx, (O.out + ".mtgidx").c_str()); /* the reference leaves <out>.h5 behind */
     } else {
@@ -773,6 +778,15 @@ int fill_main(int argc, const char* const* argv)
         if (!rc) fprintf(stderr, "done\n");
     }
     if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); return 1; }
+    rc = run_tool(O, idx, resident != nullptr);
+    if (!resident) mtg_index_free(idx);
+    return rc;
+}
+int fill_main(int argc, const char* const* argv) { return fill_main_impl(argc, argv, nullptr); }
+
+static int run_tool(Options& O, mtg_index* idx, bool resident)
+{
+    int rc = MTG_OK;
     const int k = idx->info.k;
     if (idx->info.nb_saturated)
         fprintf(stderr, "Warning : %llu solid k-mers are more abundant than 255 and are stored as 255 (coverage statistics of such regions may differ from gatb's discretised values)\n",
@@ -786,10 +800,10 @@ int fill_main(int argc, const char* const* argv)
         if (!f) fprintf(stderr, "EXCEPTION: Cannot open file %s for writing\n", name.c_str());
         return f != nullptr;
     };
-    if (!open_w(F.insert, insert_name) || !open_w(F.info, info_name)) { mtg_index_free(idx); return 1; }
-    if (bkpt_mode) { if (!open_w(F.vcf, vcf_name)) { mtg_index_free(idx); return 1; } write_vcf_header(F.vcf, O.in.empty() ? O.graph : O.in, O.out); }
-    else if (!open_w(F.gfa, gfa_name)) { mtg_index_free(idx); return 1; }
-    if (O.extend && !open_w(F.ext, ext_name)) { mtg_index_free(idx); return 1; }
+    if (!open_w(F.insert, insert_name) || !open_w(F.info, info_name)) return 1;
+    if (bkpt_mode) { if (!open_w(F.vcf, vcf_name)) return 1; write_vcf_header(F.vcf, O.in.empty() ? O.graph : O.in, O.out); }
+    else if (!open_w(F.gfa, gfa_name)) return 1;
+    if (O.extend && !open_w(F.ext, ext_name)) return 1;
     int trim = O.overlap; /* src/Filler.cpp:299-307 */
     if (trim == 0) trim = k;
     if (trim < k) { trim = k; fprintf(stderr, "Warning :  the contig overlap parameter should be greater or equal to kmer size, setting it to %d\n", k); }
@@ -806,7 +820,8 @@ int fill_main(int argc, const char* const* argv)
         if (!rc) rc = bkpt_mode ? run_bkpt(R, P, O, F, S) : run_contig(R, P, O, F, S, trim);
     }
     const double seconds = difftime(time(0), t_start);
-    if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); mtg_index_free(idx); return 1; }
+    if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); return 1; }
+    if (resident && getenv("MTG_TOOL_QUIET")) return 0; /* measurements: no summary */
     /* resumeParameters / resumeResults, src/Filler.cpp:385-481 */
     printf("MindTheGap fill\n    version                                  : %s\n    backend                                  : mindthegap_amd (HIP, gfx950)\n", MTG_VERSION);
     printf("Parameters\n    Input data\n");
@@ -829,13 +844,17 @@ int fill_main(int argc, const char* const* argv)
     else printf("        assembly graph file                      : %s\n", gfa_name.c_str());
     printf("        assembly statistics file                 : %s\n", info_name.c_str());
     if (O.extend) printf("        extension sequence file                  : %s\n", ext_name.c_str());
-    mtg_index_free(idx);
     return 0;
 }
 
 } // namespace mtgi
 
 extern "C" int mtg_fill_main(int argc, const char* const* argv) { return mtgi::fill_main(argc, argv); }
+extern "C" int mtg_fill_main_on_index(mtg_index* idx, int argc, const char* const* argv)
+{
+    if (!idx) { mtgi::set_error("null argument"); return 1; }
+    return mtgi::fill_main_impl(argc, argv, idx);
+}
 
 extern "C" int mtg_format_bkpt(const mtg_site* sites, size_t n, const mtg_results* fwd, const mtg_results* rev, const int64_t* rev_index, int filter, int extend, mtg_text* out)
 {

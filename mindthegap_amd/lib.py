@@ -178,6 +178,7 @@ def _bind(lib):
     lib.mtg_text_free.restype = None
     lib.mtg_last_batch_stats.argtypes = [P(BatchStats)]
     lib.mtg_fill_main.argtypes = [C.c_int, P(C.c_char_p)]
+    lib.mtg_fill_main_on_index.argtypes = [C.c_void_p, C.c_int, P(C.c_char_p)]
     lib.mtg_nw_matches.argtypes = [P(C.c_char_p), P(C.c_char_p), C.c_size_t, P(C.c_uint32)]
     lib.mtg_bench_random_lines.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, P(C.c_double), P(C.c_double)]
     return lib
@@ -340,6 +341,11 @@ class Index:
         h = C.c_void_p()
         _check(self.lib.mtg_batch_prepare(self.h, C.byref(params.c), arr, n, C.byref(h)))
         return Batch(h, n, (arr, keep))
+
+    def fill_main(self, argv):
+        """mtg_fill_main_on_index: `MindTheGap fill <argv>` with this resident index as the graph; returns the exit code"""
+        arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        return self.lib.mtg_fill_main_on_index(self.h, len(argv), arr)
 
     def fill_prepared_wire_device(self, batch, tag, d_ptr, cap, params=None):
         """mtg_fill_prepared_wire_device: fills the prepared Batch; the whole batch in relocatable form (records AND sequences, tagged) is

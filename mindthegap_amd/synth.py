@@ -13,7 +13,7 @@ class SynthSet:
     substitutions (>= 150 nt away from the insertion anchors and the ends), so every walk crosses SNP bubbles (multi-path bubbles
     are GATB-parity-unpinned logic; used as a secondary, divergence-heavy workload, never for the headline number)."""
 
-    def __init__(self, nseq, n_sites, seq_len=5000, seed=1, ins_min=50, ins_max=1000, k=31, het_snps=0, het_indels=0):
+    def __init__(self, nseq, n_sites, seq_len=5000, seed=1, ins_min=50, ins_max=1000, k=31, het_snps=0, het_indels=0, tips=0.0):
         nloci = nseq // 2 if het_snps else nseq
         assert n_sites <= nloci
         rng = np.random.default_rng(seed)
@@ -72,9 +72,52 @@ class SynthSet:
                 pad[: len(c)] = c
                 self.words[row] = (pad.reshape(-1, 32) << sh[None, :]).sum(axis=1, dtype=np.uint64)
 
+        # tips > 0: erroneous fragments, what sequencing errors that survive the solidity cut-off leave in a real graph: `tips` fragments per
+        # donor sequence, each a copy of k+1 .. k+45 donor nucleotides with one substitution -- near an end of the fragment a dead-end branch
+        # (a tip, up to k nodes), in its middle a bubble of k nodes.  They are extra sequences of the index (extra_*), never sites.
+        self.extra_words = np.zeros((0, 3), dtype=np.uint64)
+        self.extra_lens = np.zeros(0, dtype=np.uint32)
+        if tips > 0:
+            nfrag = int(tips * nseq)
+            frng = np.random.default_rng(seed + 1000003)
+            rows = frng.integers(0, nseq, nfrag)
+            flen = frng.integers(k + 1, k + 46, nfrag)
+            p = (frng.random(nfrag) * (self.lens[rows].astype(np.int64) - flen)).astype(np.int64)
+            q = (frng.random(nfrag) * flen).astype(np.int64)
+            w0, sh_ = p // 32, (2 * (p % 32)).astype(np.uint64)
+            W = np.stack([self.words[rows, np.minimum(w0 + i, self.words_per_seq - 1)] for i in range(4)], axis=1)
+            hi_sh = (np.uint64(64) - sh_) % np.uint64(64)
+            out = np.empty((nfrag, 3), dtype=np.uint64)
+            for i in range(3):
+                lo_part = W[:, i] >> sh_
+                hi_part = np.where(sh_ > 0, W[:, i + 1] << hi_sh, np.uint64(0))
+                out[:, i] = lo_part | hi_part
+            # the substitution: add 1..3 to the code at q
+            delta = frng.integers(1, 4, nfrag).astype(np.uint64)
+            qw, qb = q // 32, (2 * (q % 32)).astype(np.uint64)
+            idx = np.arange(nfrag)
+            old_c = (out[idx, qw] >> qb) & np.uint64(3)
+            out[idx, qw] = (out[idx, qw] & ~(np.uint64(3) << qb)) | (((old_c + delta) & np.uint64(3)) << qb)
+            self.extra_words, self.extra_lens = out, flen.astype(np.uint32)
+
+    def packed(self):
+        """(words, word offsets, lengths, number of sequences) of everything that goes into the index: the donor and the erroneous fragments"""
+        if len(self.extra_lens) == 0:
+            return self.words.reshape(-1), self.word_off, self.lens, self.nseq
+        base = np.uint64(self.words.size)
+        words = np.concatenate([self.words.reshape(-1), self.extra_words.reshape(-1), np.zeros(2, dtype=np.uint64)])
+        off = np.concatenate([self.word_off, base + np.arange(len(self.extra_lens), dtype=np.uint64) * np.uint64(3)])
+        return words, off, np.concatenate([self.lens, self.extra_lens]), self.nseq + len(self.extra_lens)
+
+    def extra_ascii(self, j):
+        w = self.extra_words[j]
+        sh = (np.arange(32, dtype=np.uint64) * np.uint64(2))
+        c = ((w[:, None] >> sh[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)
+        return NT[c[: int(self.extra_lens[j])]].tobytes().decode()
+
     @property
     def total_kmers_upper_bound(self):
-        return int(self.lens.astype(np.int64).sum() - (self.k - 1) * self.nseq)
+        return int(self.lens.astype(np.int64).sum() - (self.k - 1) * self.nseq) + int((self.extra_lens.astype(np.int64) - (self.k - 1)).sum())
 
     def codes(self, j):
         """2-bit codes of donor sequence j"""
