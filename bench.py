@@ -180,7 +180,7 @@ def main():
     params = mtg.FillParams(max_nodes=100, max_depth=10000, nb_host_threads=host_threads)
     STAT_KEYS = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
                      post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0,
-                     finish_kernel_ms=0.0, n_parked_gaps=0, gaps=0)
+                     finish_kernel_ms=0.0, n_parked_gaps=0, n_lean_gaps=0, gaps=0)
 
     class B:
         pass
@@ -622,7 +622,7 @@ def main():
                             "ms_per_step_median": elapsed / a.steps * 1e3, "ms_per_step_max": max(times) / a.steps * 1e3, "timed_seconds_total": sum(times)},
            "filled": R0["n_filled"], "sites_verified": R0["n_sites"], "filled_per_s": value * R0["n_filled"] / max(R0["n_sites"], 1),
            "filled_sequences_identical_to_truth": R0["identical"], "gathered_payload_verified": R0["gathered"],
-           "stage_ms_per_batch": {"k_stage_a+k_finish": acc["kernel_ms"] / Ln, "k_finish": acc["finish_kernel_ms"] / Ln, "parked_gaps": acc["n_parked_gaps"] / Ln, "k_copy": acc["copy_kernel_ms"] / Ln,
+           "stage_ms_per_batch": {"k_stage_a+k_finish": acc["kernel_ms"] / Ln, "k_finish": acc["finish_kernel_ms"] / Ln, "parked_gaps": acc["n_parked_gaps"] / Ln, "lean_gaps": acc["n_lean_gaps"] / Ln, "k_copy": acc["copy_kernel_ms"] / Ln,
                                   "k_post+scans": acc["post_kernel_ms"] / Ln, "k_emit": acc["emit_kernel_ms"] / Ln, "d2h": acc["d2h_ms"] / Ln,
                                   "host": acc["host_ms"] / Ln, "c_call": acc["total_ms"] / Ln},
            "roofline": roof, "cpu_baseline": cpu}

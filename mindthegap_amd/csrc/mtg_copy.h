@@ -14,11 +14,56 @@
 
 namespace mtg {
 
-MTG_DEV void copy_gap(const UStore& us, const FillCfg& cfg, const GapScratch& S, const GapOut& o)
+/* contig nucleotide x of a command's stretch (x in arena coordinates, 32 * dst - lead <= x < 32 * (dst + nwords)) <-> nucleotide of the store */
+MTG_DEV uint64_t cmd_store_nt(const CopyCmd& cm, int64_t x)
 {
-    if (o.status != GAP_OK || o.n_cmds == 0) return;
+    const int64_t rel = x - (int64_t)(32ull * cm.dst);
+    return (cm.src & 1ull) ? (uint64_t)((int64_t)(cm.src >> 1) - rel) : (uint64_t)((int64_t)(cm.src >> 1) + rel);
+}
+
+/* target: the gap's single target k-mer (forward value) when the lean form may be used (one usable target, a source of exactly k nucleotides,
+ * records wanted), ~0 otherwise */
+MTG_DEV void copy_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint64_t target)
+{
+    const UStore& us = ix.us;
+    LeanRec* lr = s_lean(cfg, S);
+    if (o.status != GAP_OK) return;
     const CopyCmd* cmds = s_cmd(cfg, S);
     uint64_t* words = s_words(cfg, S);
+    const int k = ix.k;
+    /* ---- the lean form: where is the target?  One look-up (the junction behind the target's k-mer) instead of copying the contig -- on the
+     * bench set 2 500 nucleotides past the target -- and searching it.  An exact occurrence at a known place is what
+     * find_nodes_containing_multiple_R reports (src/Filler.cpp:1341-1351: the first exact match ends the scan, and a contig never holds a
+     * node twice), so k_post takes the position as it is; the emulation build runs the search as well and compares. */
+    bool lean = false;
+    uint32_t pos0 = 0, ci = 0;
+    if (target != ~0ull && o.n_contigs == 1 && o.n_cmds != 0 && us.nwords != 0) {
+        uint32_t l_ = 0;
+        const Adj e = adj_right_t(ix.adj, make_kmer(target, k), kmask(k - 1), l_);
+        if (e.up && popc4(e.out) == 1 && popc4(e.in) == 1) {
+            const bool fwd = !up_bwd(e.up); /* the target as given appears as it is stored */
+            const uint64_t q = (up_hdr(e.up) + 1) * 32 + (fwd ? up_off(e.up) - 1u : up_off(e.up)); /* first nucleotide of its k-mer in the store */
+            const uint32_t clen0 = s_clen(cfg, S)[0];
+            const int64_t a0 = (int64_t)(32ull * s_cstart(cfg, S)[0]);
+            for (uint32_t c = 0; c < o.n_cmds && !lean; c++) {
+                const CopyCmd cm = cmds[c];
+                const bool bwd = (cm.src & 1ull) != 0;
+                if (bwd == fwd) continue; /* the walk must run the way the target reads */
+                const int64_t p = (int64_t)(cm.src >> 1), lo = (int64_t)(32ull * cm.dst) - (int64_t)cm.lead, hi = (int64_t)(32ull * ((uint64_t)cm.dst + cm.nwords));
+                /* arena nucleotide of the k-mer's first nucleotide in walking order */
+                const int64_t a = bwd ? (int64_t)(32ull * cm.dst) + (p - (int64_t)(q + (uint64_t)k - 1)) : (int64_t)(32ull * cm.dst) + ((int64_t)q - p);
+                if (a < lo || a + k > hi || a0 < lo) continue;
+                const int64_t ps = a - a0;
+                if (ps <= (int64_t)k || ps + k > (int64_t)clen0) continue; /* an empty fill, or not on this contig: the general code decides */
+                lean = true; pos0 = (uint32_t)ps; ci = c;
+            }
+        }
+    }
+    if (MTG_LANE() == 0) { LeanRec r; r.valid = lean ? 1u : 0u; r.pos0 = pos0; r.cmd = ci; r.pad_ = 0; *lr = r; }
+#ifndef MTG_EMU
+    if (lean) return; /* nothing of the contig is read from the arena (the emulation build copies all the same: its cross-checks read it) */
+#endif
+    if (o.n_cmds == 0) return;
     /* the lane's words t, t + NLANES, ... in the concatenation of the commands: (c, base) follows t */
     uint32_t c = 0, base = 0;
     CopyCmd cm = cmds[0];

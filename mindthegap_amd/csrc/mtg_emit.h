@@ -12,7 +12,7 @@
 #ifndef MTG_EMIT_H
 #define MTG_EMIT_H
 #include "../../include/mtg_fill.h"
-#include "mtg_post.h"
+#include "mtg_copy.h"
 
 namespace mtg {
 
@@ -32,7 +32,7 @@ MTG_DEV void emit_plan(const GapOut& o, const PostOut& p, bool want_all, int k, 
 /* totals of one part of a batch (device -> host) */
 struct PartTot {
     uint64_t begin[4], end[4]; /* cursors before / after the part: dense words, dense metadata entries, sequence bytes, extension bytes */
-    uint64_t lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, copy_words, copy_cmds, cov_direct;
+    uint64_t lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, copy_words, copy_cmds, cov_direct, n_lean;
     uint32_t n_retry, n_general, n_filled, n_ext;
 };
 
@@ -153,7 +153,7 @@ MTG_DEV int qual_of(uint32_t errors, bool repeated) /* compute_qual, src/Utils.h
 }
 
 /* everything a gap leaves behind: one wave per gap (one lane in the emulation).  gap = its index in the batch. */
-MTG_DEV void emit_gap(const FillCfg& cfg, const GapScratch& S, const SlotRec& r, uint32_t flags, uint32_t slot, uint64_t gap, int k, const EmitDev& D, const EmitHost& H)
+MTG_DEV void emit_gap(const UStore& us, const FillCfg& cfg, const GapScratch& S, const SlotRec& r, uint32_t flags, uint32_t slot, uint64_t gap, int k, const EmitDev& D, const EmitHost& H)
 {
     const uint32_t lane = MTG_LANE();
     const uint64_t* w = s_words(cfg, S);
@@ -169,7 +169,15 @@ MTG_DEV void emit_gap(const FillCfg& cfg, const GapScratch& S, const SlotRec& r,
     char* const seq_arena = wire_ok ? (char*)D.wire + wl.o_seq : D.seq;
     const uint64_t seq_cap = wire_ok ? D.tot->end[2] : D.seq_cap;
     const bool seq_ok = r.asc && seq_arena && r.abase + r.asc <= seq_cap, ext_ok = r.ext && r.ebase + r.ext <= D.ext_cap; /* an arena that is too small: the host grows it and asks again */
-    if (seq_ok) emit_ascii(w, (uint32_t)k, r.asc - 1u, reverse, seq_arena + r.abase);
+    if (seq_ok && r.p.lean) {
+        /* the lean form: the contig was never materialised, its fill is a stretch of the unitig store (forward, or read backwards and complemented) */
+        const CopyCmd cm = s_cmd(cfg, S)[r.p.lean - 1u];
+        const uint32_t L = r.asc - 1u;
+        const int64_t x0 = (int64_t)(32ull * s_cstart(cfg, S)[0]) + k;
+        const bool bwd = (cm.src & 1ull) != 0;
+        const uint64_t from = bwd ? cmd_store_nt(cm, x0 + (int64_t)L - 1) : cmd_store_nt(cm, x0);
+        emit_ascii(us.words + (from >> 5), (uint32_t)(from & 31ull), L, bwd ? !reverse : reverse, seq_arena + r.abase);
+    } else if (seq_ok) emit_ascii(w, (uint32_t)k, r.asc - 1u, reverse, seq_arena + r.abase);
     if (ext_ok) emit_ascii(w, (uint32_t)k, r.ext - 1u, false, D.ext + r.ebase);
     if (wire_ok && r.ext) emit_ascii(w, (uint32_t)k, r.ext - 1u, false, (char*)D.wire + wl.o_ext + r.ebase);
     /* the dense arrays are sized by the last need and k_emit runs before the launch's totals are known: a gap that does not fit writes

@@ -444,7 +444,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
 }
 
 /* the long runs the traversal left as commands: one wave per gap, four gaps per workgroup (mtg_copy.h) */
-__global__ void __launch_bounds__(256) k_copy(UStore us, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, uint32_t n)
+__global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
+                                              const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
+                                              uint32_t lean_allowed, uint32_t n)
 {
     const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (slot >= n) return;
@@ -453,7 +455,11 @@ __global__ void __launch_bounds__(256) k_copy(UStore us, FillCfg cfg, uint8_t* r
     S.v = nullptr;
     S.lane = 0;
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
-    copy_gap(us, cfg, S, outs[slot]);
+    /* the lean form needs one usable target and a source of exactly k nucleotides (what the common-case result of k_post needs anyway) */
+    const uint32_t g = ids ? ids[slot] : slot;
+    uint64_t target = ~0ull;
+    if (lean_allowed && tcnt[g] == 1u && fast_ok[g] && tbad[toff[g]] == 0ull) target = rev_fields64(tle[toff[g]]) >> (64 - 2 * ix.k);
+    copy_gap(ix, cfg, S, outs[slot], target);
 }
 
 /* the targets of a batch from text to (little-endian k-mer, never-match mask): one target per thread */
@@ -487,7 +493,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
         __syncthreads();
         const GapOut o = outs[slot];
         PostOut po;
-        po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = po.lines = po.direct = 0;
+        po.nb_terminal = po.fast = po.pos = po.errors = po.target = po.clen0 = po.ab_sum = po.ab_n = po.med_hi = po.med_lo = po.lines = po.direct = po.lean = 0;
         GapScratch S;
         S.z = nullptr;
         S.v = nullptr;
@@ -522,7 +528,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
  * metadata, the sequence arena, the extension arena, the list of gaps to re-run and the list of multi-contig gaps.  k_scan1: one thread per
  * slot, offsets inside its block of SCAN_SL slots + the block's totals and statistics; k_scan2 (one workgroup): offsets of the blocks on
  * top of the batch's cursors, totals of the launch; k_emit adds the two. */
-enum { SCAN_SL = 256, SCAN_NV = 7, SCAN_NS = 12 };
+enum { SCAN_SL = 256, SCAN_NV = 7, SCAN_NS = 13 };
 struct ScanBlock {
     uint64_t v[SCAN_NV]; /* k_scan1: totals of the block; k_scan2: replaced by the block's base */
     uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext, copy_words, copy_cmds, cov_direct */
@@ -536,7 +542,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
     __shared__ unsigned long long wsum[NW][SCAN_NS];
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6, slot = blockIdx.x * SCAN_SL + t;
     uint64_t v[SCAN_NV] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st[SCAN_NS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st[SCAN_NS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (slot < m) {
         const SlotRec& r = recs[slot];
         const bool ok = r.o.status == GAP_OK;
@@ -549,7 +555,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
         if (ok) {
             st[3] = r.o.total_nt; st[5] = r.p.lines; st[6] = r.p.ab_n;
             if (r.p.direct) st[11] = r.p.ab_n;
-            st[7] = r.asc ? 1 : 0; st[8] = r.ext ? 1 : 0;
+            st[7] = r.asc ? 1 : 0; st[8] = r.ext ? 1 : 0; st[12] = r.p.lean ? 1 : 0;
         }
     }
     uint64_t incl[SCAN_NV];
@@ -631,11 +637,11 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         tot->lines = ssum[0]; tot->store_runs = ssum[1]; tot->run_nt = ssum[2]; tot->contig_nt = ssum[3]; tot->contig_words = ssum[4];
         tot->post_lines = ssum[5]; tot->cov_kmers = ssum[6];
         tot->n_filled = (uint32_t)ssum[7]; tot->n_ext = (uint32_t)ssum[8];
-        tot->copy_words = ssum[9]; tot->copy_cmds = ssum[10]; tot->cov_direct = ssum[11];
+        tot->copy_words = ssum[9]; tot->copy_cmds = ssum[10]; tot->cov_direct = ssum[11]; tot->n_lean = ssum[12];
     }
 }
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
-__global__ void __launch_bounds__(64) k_emit(FillCfg cfg, uint8_t* raw, SlotRec* recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* raw, SlotRec* recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
                                              const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t* retry_list, uint32_t* general_list, uint32_t n)
 {
     const uint32_t slot = blockIdx.x;
@@ -657,7 +663,7 @@ __global__ void __launch_bounds__(64) k_emit(FillCfg cfg, uint8_t* raw, SlotRec*
     S.lane = 0;
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
     const uint32_t g = ids ? ids[slot] : slot;
-    emit_gap(cfg, S, r, gflags[g], slot, g, k, D, H);
+    emit_gap(us, cfg, S, r, gflags[g], slot, g, k, D, H);
 }
 
 /* checksum of a relocatable batch's body into its header (mtg_wire_header::checksum): a sum of scrambled 64-bit words, any order */
@@ -1530,7 +1536,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
             /* ev1 .. evc: the long runs of the contigs, which the traversal only noted down */
-            if (cfg.cmd_cap) hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), m);
+            static const bool no_lean = getenv("MTG_NO_LEAN") != nullptr; /* A/B and test hook: every contig is materialised */
+            hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
+                               (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m);
             HIP_TRY(hipEventRecord(evc, stream));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
             hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
@@ -1553,7 +1561,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 D.tot = d_tot.as<PartTot>(); D.wire_gaps = m;
                 if (want_wire) HIP_TRY(hipMemsetAsync(sink.wire_dev, 0, sizeof(mtg_wire_header), stream)); /* no header, no payload (k_wire_sum) */
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
-                hipLaunchKernelGGL(k_emit, dim3(m), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H, d_rlist.as<uint32_t>(),
+                hipLaunchKernelGGL(k_emit, dim3(m), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H, d_rlist.as<uint32_t>(),
                                    d_glist.as<uint32_t>(), m);
                 if (want_wire) hipLaunchKernelGGL(k_wire_sum, dim3(256 * 4), dim3(256), 0, stream, (uint8_t*)sink.wire_dev, sink.wire_cap);
                 HIP_TRY(hipGetLastError());
@@ -1650,7 +1658,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             t0 = now_ms();
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
             st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += tw;
-            st.copy_words += tot.copy_words; st.copy_cmds += tot.copy_cmds; st.coverage_direct_kmers += tot.cov_direct;
+            st.copy_words += tot.copy_words; st.copy_cmds += tot.copy_cmds; st.coverage_direct_kmers += tot.cov_direct; st.n_lean_gaps += tot.n_lean;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
             sink.n_filled += tot.n_filled;

@@ -21,6 +21,7 @@ struct PostOut {
     uint32_t med_hi, med_lo;      /* sorted[n/2], sorted[n/2-1] */
     uint32_t lines;               /* index buckets read by the coverage pass (block look-ups + k-mers the store did not confirm) */
     uint32_t direct;              /* 1: the abundances were read at places known from the traversal's copy command (no look-up) */
+    uint32_t lean;                /* 1 + index of the copy command: the contig was never materialised (LeanRec); coverage and ASCII come from the unitig store */
 };
 
 /* everything the device keeps about one gap of a launch: the counters of the traversal and of the post-processing, what the gap
@@ -140,7 +141,24 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
      * result is the first occurrence of the maximum: an arg-max, evaluated here by all lanes at once. */
     const uint64_t le0 = T.n ? T.le[0] : 0ull, bad0 = T.n ? T.bad[0] : ~0ull;
     const bool single = T.n == 1;
-    for (uint32_t c = 0; c < ((dbg & 2u) ? 0u : o.n_contigs); c++) {
+    /* the lean form (mtg_copy.h): the target's place in the only contig is known, the contig itself was not materialised */
+    const LeanRec lean = *s_lean(cfg, S);
+    out.lean = 0;
+    if (lean.valid) {
+#ifdef MTG_EMU /* TEST-ONLY: the search the lean form replaces finds the same place (the emulation build has copied the contig) */
+        {
+            const uint32_t L0 = clen[0];
+            const uint64_t* w = words + cstart[0];
+            uint32_t first = 0xFFFFFFFFu;
+            for (uint32_t j = 0; j + (uint32_t)k <= L0; j++) if (le_kmer(w, j, mk) == le0) { first = j; break; }
+            if (first != lean.pos0 || !single || bad0 != 0ull || o.n_contigs != 1) { fprintf(stderr, "lean form: target at %u, search finds %u\n", lean.pos0, first); __builtin_trap(); }
+        }
+#endif
+        if (lane == 0) { tpos[0] = lean.pos0; terr[0] = 0; ttgt[0] = 0; }
+        has0 = true; pos0 = lean.pos0; err0 = 0; tgt0 = 0; nterm = 1;
+        out.lean = 1u + lean.cmd;
+    }
+    for (uint32_t c = 0; c < (((dbg & 2u) || lean.valid) ? 0u : o.n_contigs); c++) {
         const uint32_t L = clen[c];
         const uint64_t* w = words + cstart[c];
         uint64_t best = 0;

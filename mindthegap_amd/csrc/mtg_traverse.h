@@ -51,7 +51,7 @@ struct FillCfg {
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_flaux0, o_flaux1, o_dfsf, o_dfsc,
-        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra, o_dfsdep, o_dfsxsn, o_cmd, o_save;
+        o_dfsmask, o_dfsnt, o_dfskid, o_cons, o_conslen, o_nw, o_tpos, o_terr, o_ttgt, o_flrp0, o_flrp1, o_flra0, o_flra1, o_iflrp0, o_iflrp1, o_iflra0, o_iflra1, o_dfsrp, o_dfsra, o_dfsdep, o_dfsxsn, o_cmd, o_save, o_lean;
 };
 
 enum { FL_CAP = 96, DFS_CAP = 512, CONS_CAP = 22, CONS_LEN = 512 };
@@ -107,6 +107,16 @@ struct WalkSave {
     int32_t node_depth, pad2_;
 };
 MTG_ARR(WalkSave, s_save, r, c.o_save)
+/* A gap whose only contig holds the target at a place known without looking at the contig (the target's k-mer sits in a stored unitig, and the
+ * stretch of the contig from its start to the target came out of that unitig in one run): nothing of the contig needs to be materialised --
+ * coverage and ASCII are read off the unitig store (mtg_copy.h: copy_gap decides, k_post and k_emit follow). */
+struct LeanRec {
+    uint32_t valid; /* 0 / 1 */
+    uint32_t pos0;  /* position of the target in contig 0 */
+    uint32_t cmd;   /* the copy command that describes the run */
+    uint32_t pad_;
+};
+MTG_ARR(LeanRec, s_lean, r, c.o_lean)
 MTG_ILV(uint32_t, s_marklog, c.o_marklog) /* slots used in marked[] */
 MTG_ILV(uint32_t, s_seenlog, c.o_seenlog) /* slots touched in seen[] */
 MTG_ILV(uint32_t, s_iseenlog, c.o_iseenlog)
@@ -166,6 +176,7 @@ inline void finalize_cfg(FillCfg& c)
     c.o_cmd = (uint32_t)b; b += (uint64_t)sizeof(CopyCmd) * COPY_CMDS; /* the room is there whether or not cmd_cap lets it be used */
     b = align_up(b, 16);
     c.o_save = (uint32_t)b; b += (uint64_t)sizeof(WalkSave);
+    c.o_lean = (uint32_t)b; b += 16;
     c.raw_stride = align_up(b + 8, 64);
     /* interleaved per wave: byte offsets within one lane's share (every array starts 8-byte aligned) */
     b = 0;

@@ -98,7 +98,7 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
                 stage_a_walk<WALK_FINISH, 1>(e->ix, cfg, S, 0, pat, out, &lds);
             }
         }
-        copy_gap(e->ix.us, cfg, S, out); /* the device's k_copy */
+        copy_gap(e->ix, cfg, S, out, ~0ull); /* the device's k_copy */
         /* the device relies on every gap handing the zero region back clean: make a violation visible as a status no test expects */
         for (uint8_t z : zero) if (z) { out.status = 0xDEAD; break; }
         if (out.status == 0xDEAD) break;

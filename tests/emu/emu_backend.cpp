@@ -307,7 +307,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                         stage_a_walk<WALK_FINISH, 1>(idx->dev, cfg, S, 0, R, r.o, &lds);
                     }
                 }
-                copy_gap(idx->dev.us, cfg, S, r.o); /* k_copy */
+                {   /* k_copy */
+                    uint64_t target = ~0ull;
+                    if (!in.want_all_contigs && !getenv("MTG_NO_LEAN") && cfg.cmd_cap && r.o.status == GAP_OK && in.tcnt[g] == 1u && in.fast_ok[g] && tbad[in.toff[g]] == 0ull)
+                        target = rev_fields64(tle[in.toff[g]]) >> (64 - 2 * k);
+                    copy_gap(idx->dev, cfg, S, r.o, target);
+                }
                 st.copy_words += r.o.copy_words; st.copy_cmds += r.o.n_cmds;
                 for (uint8_t z : zero) if (z) { set_error("gap %zu: zero-initialised scratch not restored (status %u)", g, r.o.status); return MTG_ERR_OVERFLOW; }
                 if (r.o.status == GAP_OK) {
@@ -338,7 +343,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 tot.lines += r.o.lines; tot.store_runs += r.o.store_reads; tot.run_nt += r.o.run_nt; tot.contig_words += r.o.n_words;
                 if (r.o.status != GAP_OK) { r.rpos = (uint32_t)rlist.size(); rlist.push_back(s); continue; }
                 tot.contig_nt += r.o.total_nt; tot.post_lines += r.p.lines; tot.cov_kmers += r.p.ab_n; if (r.p.direct) tot.cov_direct += r.p.ab_n;
-                tot.n_filled += r.asc != 0; tot.n_ext += r.ext != 0;
+                tot.n_filled += r.asc != 0; tot.n_ext += r.ext != 0; tot.n_lean += r.p.lean != 0;
                 if (r.nc) { r.gpos = (uint32_t)glist.size(); glist.push_back(s); }
             }
             tot.end[0] = c0; tot.end[1] = c1; tot.end[2] = c2; tot.end[3] = c3;
@@ -385,7 +390,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
                 for (uint32_t s = 0; s < m; s++) {
                     GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
-                    emit_gap(cfg, S, recs[s], in.flags[ids[s]], s, ids[s], k, D, H);
+                    emit_gap(idx->dev.us, cfg, S, recs[s], in.flags[ids[s]], s, ids[s], k, D, H);
                 }
                 if (c0 <= D.dense_cap_words && c1 <= D.dense_cap_contigs) break;
                 dw.assign(c0 + 1, 0);
@@ -411,7 +416,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             if (sink.seq_dev && sink.seq && sink.seq_dev != sink.seq && tot.end[2] > tot.begin[2] && tot.end[2] <= sink.seq_cap)
                 memcpy(sink.seq_dev + tot.begin[2], sink.seq + tot.begin[2], tot.end[2] - tot.begin[2]);
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
-            st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.coverage_direct_kmers += tot.cov_direct; st.dense_words += c0;
+            st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.coverage_direct_kmers += tot.cov_direct; st.n_lean_gaps += tot.n_lean; st.dense_words += c0;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
             sink.n_filled += tot.n_filled;

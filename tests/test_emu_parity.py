@@ -887,7 +887,8 @@ def test_cli_on_three_emulated_devices_with_a_failing_one(emu_product, tmp_path,
     assert emu_product.Filler().run(["-graph", idxf, "-bkpt", str(tmp_path / "w.breakpoints.gz"), "-out", str(tmp_path / "gz")]) == 0
     for ext in (".insertions.fasta", ".info.txt"):
         assert _read(str(tmp_path / "gz") + ext) == _read(str(tmp_path / "cpu") + ext), ext
-    # device 1 fails
+    # device 1 fails (one site per batch: forty batches, so that its two host threads certainly get some)
+    monkeypatch.setenv("MTG_CLI_BATCH", "1")
     monkeypatch.setenv("MTG_EMU_FAIL_DEVICE", "1")
     assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "bad")]) == 1
     full = _read(str(tmp_path / "cpu.insertions.fasta"))
