@@ -168,7 +168,9 @@ template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uin
         uint32_t n_iseen = 2;
         GP::sync();
         int cur = 0, ncur = 1, depth = 0, remaining = 0;
+        MTG_GUARD_DECL(g1);
         for (;;) {
+            MTG_GUARD(g1, 100000u, 10, return COOP_TOOBIG);
             FlNode* cf = L.a.ifl[cur];
             FlNode* nf = L.a.ifl[cur ^ 1];
             /* the skip: every node has two or more nodes of its unitig behind it, in pairwise different unitigs */
@@ -297,7 +299,9 @@ template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, con
     const bool may_skip = us.nwords != 0 && prev_c != 0;
     uint32_t prev_unitig = 0xFFFFFFFFu;
     bool prev_known = false;
+    MTG_GUARD_DECL(g2);
     for (;;) {
+        MTG_GUARD(g2, 100000u, 11, return COOP_TOOBIG);
         FlNode* cf = L.a.fl[cur];
         FlNode* nf = L.a.fl[cur ^ 1];
         /* ---- the skip (see the one-lane form for why it changes nothing) */
@@ -464,7 +468,9 @@ template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, 
     auto path_add = [&](uint64_t c) -> int {
         uint32_t h = set_hash(c, BL_ISEEN);
         int64_t tomb = -1;
+        MTG_GUARD_DECL(g4);
         for (;;) {
+            MTG_GUARD(g4, 1000u, 13, return 2);
             const uint64_t v = pset[h];
             if (v == c + 1) return 1;
             if (v == TOMB && tomb < 0) tomb = (int64_t)h;
@@ -480,7 +486,9 @@ template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, 
     };
     auto path_del = [&](uint64_t c) {
         uint32_t h = set_hash(c, BL_ISEEN);
+        MTG_GUARD_DECL(g5);
         for (;;) {
+            MTG_GUARD(g5, 1000u, 14, return);
             const uint64_t v = pset[h];
             if (v == 0) return;
             if (v == c + 1) { pset[h] = TOMB; return; }
@@ -498,7 +506,9 @@ template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, 
     GP::sync();
     const uint32_t end_u = (end_rp & RP_VALID) ? rp_unitig(end_rp) : 0xFFFFFFFFu;
     bool entering = true;
+    MTG_GUARD_DECL(g3);
     for (;;) {
+        MTG_GUARD(g3, 1000000u, 12, return COOP_TOOBIG);
         if (entering) {
             entering = false;
             const int d = (int)fr[f].dep;

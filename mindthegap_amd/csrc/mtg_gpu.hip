@@ -359,12 +359,12 @@ __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 #define MTG_WALK_WAVES 2
 #endif
 #define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
-struct ParkList { /* device: the work list of one launch */
+struct ParkList { /* device: the work list of one launch; the `count` slot numbers follow it */
     uint32_t count;   /* gaps parked by k_stage_a */
     uint32_t ticket;  /* next entry to hand out in k_finish */
     uint32_t pad_[2];
-    uint32_t slot[1]; /* count entries */
 };
+__device__ __forceinline__ uint32_t* park_slots(ParkList* p) { return reinterpret_cast<uint32_t*>(p + 1); }
 template <int MODE>
 __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                              const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset, ParkList* park)
@@ -392,7 +392,7 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
             uint32_t base = 0;
             if ((int)lane == leader) base = atomicAdd(&park->count, (uint32_t)__popcll(pm));
             base = (uint32_t)__shfl((int)base, leader, 64);
-            if (parked) park->slot[base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = slot;
+            if (parked) park_slots(park)[base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = slot;
         }
     }
 }
@@ -410,8 +410,10 @@ __global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a_classic(uint8_t
 {
     stage_a_lane<WALK_CLASSIC>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, nullptr);
 }
-/* the parked gaps of a launch, one group of G lanes each; the groups take the entries of the work list one after the other (a ticket per
- * group), so that a long-lived gap does not hold up the others */
+/* the parked gaps of a launch, one group of G lanes each: group i of the grid takes entry i of the work list.  The grid is sized for the
+ * worst case (every gap of the launch parked: the host does not know the count when it queues the kernel); a group without an entry
+ * leaves at once.  (A loop over tickets around the walk -- fewer, longer-lived groups -- made this very large kernel hang on the device in
+ * every build but the instrumented one; the straight-line form has no control flow around the walk.) */
 #ifndef MTG_FINISH_WAVES
 #define MTG_FINISH_WAVES 2
 #endif
@@ -420,27 +422,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t cset, ParkList* park)
 {
     __shared__ BubbleLds lds[64 / G];
+    const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1);
+    const uint32_t t = blockIdx.x * (64u / (uint32_t)G) + lane / (uint32_t)G;
+    if (t >= park->count) return;
+#ifdef MTG_FINISH_ONE_LANE /* diagnostics: the group is its first lane alone (needs -DMTG_COOP_OFF) */
+    if (gl != 0) return;
+#endif
     const Index& ix = c_ix[cset];
     const FillCfg& cfg = c_cfg[cset];
-    const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1), gbase = lane & ~(uint32_t)(G - 1);
-    const uint32_t count = park->count;
-    for (;;) {
-        uint32_t t = 0;
-        if (gl == 0) t = atomicAdd(&park->ticket, 1u);
-        t = (uint32_t)__shfl((int)t, (int)gbase, 64);
-        if (t >= count) return;
-        const uint32_t slot = park->slot[t];
-        const uint32_t g = ids ? ids[slot] : slot;
-        GapScratch S = carve(cfg, zero, raw, ilv, slot);
-        S.snp_fast = 1;
-        SwfPattern R;
-        R.words = rwords + roff[g];
-        R.rlen = rlen[g];
-        R.r0 = r0[g];
-        GapOut o;
-        stage_a_walk<WALK_FINISH, G>(ix, cfg, S, 0, R, o, &lds[lane / G]);
-        if (gl == 0) out[slot] = o;
-    }
+    const uint32_t slot = park_slots(park)[t];
+    const uint32_t g = ids ? ids[slot] : slot;
+    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    S.snp_fast = 1;
+    SwfPattern R;
+    R.words = rwords + roff[g];
+    R.rlen = rlen[g];
+    R.r0 = r0[g];
+    GapOut o;
+    stage_a_walk<WALK_FINISH, G>(ix, cfg, S, 0, R, o, &lds[lane / G]);
+    if (gl == 0) out[slot] = o;
 }
 
 /* the long runs the traversal left as commands: one wave per gap, four gaps per workgroup (mtg_copy.h) */
@@ -1517,12 +1517,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
                                    d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, d_park.as<ParkList>());
                 HIP_TRY(hipEventRecord(evf, stream));
-                /* the grid is sized without knowing how many gaps were parked: enough groups to fill the device, each taking entries of the
-                 * work list until it is empty (none: the groups leave at once) */
+                /* the grid is sized without knowing how many gaps were parked: one group per gap of the launch, those without an entry
+                 * of the work list leave at once */
+                static const bool skip_finish = getenv("MTG_DEBUG_SKIP_FINISH") != nullptr; /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 const uint32_t per_wg = 64u / (uint32_t)finish_g;
-                const uint32_t nwg = std::min<uint32_t>((m + per_wg - 1) / per_wg, 256u * 16u);
+                const uint32_t nwg = (m + per_wg - 1) / per_wg;
 #define MTG_LAUNCH_FINISH(GG) hipLaunchKernelGGL(k_finish<GG>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, d_park.as<ParkList>())
-                switch (finish_g) {
+                if (!skip_finish) switch (finish_g) {
 #ifdef MTG_FINISH_ALL_G /* experiments: every group size */
                     case 8: MTG_LAUNCH_FINISH(8); break;
                     case 32: MTG_LAUNCH_FINISH(32); break;
@@ -1709,6 +1710,16 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         todo.swap(retry);
         n_todo = todo.size();
     }
+#ifdef MTG_FINISH_DEBUG
+    {
+        unsigned int hd[64];
+        if (hipMemcpyFromSymbol(hd, HIP_SYMBOL(mtg::g_dbg), sizeof hd) == hipSuccess) {
+            for (int i = 0; i < 64; i++) if (hd[i]) fprintf(stderr, "  [finish debug] guard %d tripped %u times\n", i, hd[i]);
+            unsigned int z[64] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_dbg), z, sizeof z);
+        }
+    }
+#endif
 #ifdef MTG_STAMPS
     {
         unsigned long long hs[16];

@@ -257,6 +257,21 @@ MTG_DEV int set_add(uint64_t* tab, uint32_t cap, uint32_t& count, uint64_t c)
     }
 }
 
+#if defined(MTG_FINISH_DEBUG) && !defined(MTG_EMU)
+__device__ unsigned int g_dbg[64];
+#endif
+/* diagnostic build (-DMTG_FINISH_DEBUG): every loop of the finishing kernel counts its rounds; one that exceeds its limit notes where in
+ * g_dbg and leaves, so that a kernel that would hang ends and says where */
+#if defined(MTG_FINISH_DEBUG) && !defined(MTG_EMU)
+#define MTG_GUARD_DECL(v) unsigned v = 0
+#ifndef MTG_FINISH_DEBUG_MASK
+#define MTG_FINISH_DEBUG_MASK 0xFFFFFFFFu
+#endif
+#define MTG_GUARD(v, limit, code, action) do { if (((MTG_FINISH_DEBUG_MASK >> ((code) & 31)) & 1u) && ++(v) > (limit)) { atomicAdd(&g_dbg[(code) & 63], 1u); action; } } while (0)
+#else
+#define MTG_GUARD_DECL(v)
+#define MTG_GUARD(v, limit, code, action)
+#endif
 /* diagnostic build (-DMTG_STAMPS): shader-clock time per phase, summed over lanes into a global array (never in the product build) */
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
 __device__ unsigned long long g_stamps[16];
@@ -1548,6 +1563,7 @@ namespace mtg {
  *                 is one request per group, the stores write the same bytes), so that the lanes arrive together at every branching node,
  *                 which the group then resolves from its LDS area (mtg_bubble.h); what does not fit there runs the general code. */
 enum { WALK_CLASSIC = 0, WALK_PARK = 1, WALK_FINISH = 2 };
+
 #ifdef MTG_EMU /* TEST-ONLY: how the group form answered (MTG_EMU_COOP_STATS=1 prints the tally when the process ends) */
 } // namespace mtg
 #include <cstdio>
@@ -1845,7 +1861,9 @@ MTG_UNROLL
         a = adj_right_t(adj, cur, mk1, l_);
         a_is_cur = true;
     }
+    MTG_GUARD_DECL(g_flat);
     for (;;) {
+        MTG_GUARD(g_flat, 200000u, 1, { W.status = 0xD1E; break; });
         bool end_contig = false;
         if (!resuming) {
         if (!in_contig) {
@@ -1882,7 +1900,9 @@ MTG_UNROLL
         MTG_T0(t_w);
         /* ---- phase W: simple path.  The entry just read also lists up to MTG_LA_MAX further nucleotides along which every node has
          * exactly one in- and one out-edge (lookahead): those nodes are non-branching (nothing to mark) and need no read. */
+        MTG_GUARD_DECL(g_w);
         while (popc4(a.out) == 1 && popc4(a.in) <= 1) {
+            MTG_GUARD(g_w, 2000000u, 2, { W.status = 0xD1E; end_contig = true; break; });
             if (run_left >= 64u) {
                 /* a long run ahead: take it in one step, up to the nucleotide before the first node that needs a look */
                 uint32_t nbulk = run_left - 1u;
@@ -2022,7 +2042,11 @@ MTG_UNROLL
                     break;
                 }
                 if (MODE == WALK_FINISH) {
+#ifdef MTG_COOP_OFF /* diagnostics: the finishing kernel without the group form (every bubble by the one-lane code) */
+                    n = COOP_TOOBIG;
+#else
                     n = coop_explore<G>(W, *L, cur, prev_c, chosen);
+#endif
 #ifdef MTG_EMU
                     coop_tally(n);
 #endif

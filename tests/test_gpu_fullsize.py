@@ -55,8 +55,61 @@ def test_config4_full_size(mtg, tmp_path):
     idx.free_results(h)
     assert nb == len(seqs) and out[:nb].tobytes() == seqs.tobytes().replace(b"\n", b"\0")
     batch.close()
-    # record by record against the oracle on the first 30 000 sites (oracle index = the first 30 000 donor sequences)
-    res = idx.fill_batch(gaps[:NORACLE], params)
+    # record by record against the oracle on the first 30 000 sites AND on every site of the batch whose walk leaves its own donor sequence (a
+    # chance collision of two 30-mers of the 3 Gbp donor: several contigs, the general bubble code at scale).  The oracle's index = the first
+    # 30 000 donor sequences + everything those walks can see of the full graph: the closure of their source k-mers under successors, widened
+    # by 100 steps in both directions (the bubble code looks at most 3k = 93 nodes back), read off the device index itself.
+    res_all = idx.fill_batch(gaps, params)
+    crossers = [i for i in range(NSITES) if res_all[i]["nb_nodes"] > 1]
+    sample = list(range(NORACLE)) + [i for i in crossers if i >= NORACLE]
+    res = [res_all[i] for i in sample]
+    mask = np.uint64((1 << (2 * K)) - 1)
+
+    def enc(s):
+        v = 0
+        for ch in s:
+            v = (v << 2) | ((ord(ch) >> 1) & 3)
+        return v
+
+    def revc(x):
+        y = 0
+        for _ in range(K):
+            y = (y << 2) | ((x & 3) ^ 2)
+            x >>= 2
+        return y
+
+    def step(front, fwd=True, back=False):
+        """oriented k-mers one edge away from the oriented k-mers of `front` (successors and / or predecessors), as the device index sees them"""
+        arr = np.array(sorted(front), dtype=np.uint64)
+        su, pr = idx.neighbors(arr)
+        out = set()
+        for x, sm, pm in zip(arr.tolist(), su.tolist(), pr.tolist()):
+            if fwd:
+                for nt in range(4):
+                    if sm >> nt & 1:
+                        out.add(((x << 2) | nt) & int(mask))
+            if back:
+                for nt in range(4):
+                    if pm >> nt & 1:
+                        out.add((x >> 2) | (nt << (2 * (K - 1))))
+        return out
+
+    closure = set()
+    if crossers:
+        front = {enc(gaps[i].source) for i in crossers}
+        seen = set(front)
+        rounds = 0
+        while front and rounds < 20000 and len(seen) < 2000000:  # forward closure: what the walks can reach
+            front = step(front) - seen
+            seen |= front
+            rounds += 1
+        front = set(seen)
+        for _ in range(100):  # and what the bubble code can see around it
+            front = step(front, fwd=True, back=True) - seen
+            seen |= front
+        closure = seen
+    NT = "ACTG"
+    extra = ["".join(NT[(x >> (2 * (K - 1 - t))) & 3] for t in range(K)) for x in sorted(closure)]
     # the human-size index through its container (36 GB): written from the device tables, loaded again piece by piece straight from the
     # file (Graph::load of src/Filler.cpp:222 at the scale the judge's round-1 review said had never been run), same records afterwards
     import shutil
@@ -69,11 +122,11 @@ def test_config4_full_size(mtg, tmp_path):
         os.remove(pth)
         info2 = idx.info()
         assert info2["nb_solid_kmers"] == info["nb_solid_kmers"] and info2["nb_unitigs"] == info["nb_unitigs"]
-        assert idx.fill_batch(gaps[:NORACLE], params) == res
+        assert idx.fill_batch([gaps[i] for i in sample], params) == res
     idx.close()
-    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(NORACLE)], K, 3, 0)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(NORACLE)] + extra, K, 3, 0)
     bk = str(tmp_path / "s.breakpoints")
-    S.write_breakpoints(bk, range(NORACLE))
+    S.write_breakpoints(bk, sample)
     o.fill_files("bkpt", bk, str(tmp_path / "cpu"), params=oracle_lib.default_params(nb_cores=max(1, min(16, os.cpu_count() or 1))))
     o.close()
     cpu = {}
@@ -83,14 +136,26 @@ def test_config4_full_size(mtg, tmp_path):
         if line.startswith(">"):
             name = line[1:]
         else:
-            cpu[name.split("_len_")[0]] = (name, line)
-    assert len(cpu) == NORACLE
-    for i in range(NORACLE):
-        r = res[i]
-        assert len(r["filled"]) == 1, i
-        f = r["filled"][0]
-        hdr = "%s_len_%d_qual_%d_avg_cov_%.2f_median_cov_%.2f   " % (S.site_name(i), len(f["seq"]), f["qual"], f["avg_coverage"], f["median_coverage"])
-        assert (hdr, f["seq"]) == cpu[S.site_name(i)], i  # the header carries length, quality, mean and median coverage (src/Filler.cpp:1052-1054)
+            cpu.setdefault(name.split("_len_")[0], []).append((name, line))
+    info = {}
+    for line in open(str(tmp_path / "cpu.info.txt")):
+        f = line.rstrip("\n").split("\t")
+        info[f[0]] = [int(x) for x in f[1:] if x != ""]
+    assert len(cpu) == len(sample)
+    n_multi = 0
+    for q, i in enumerate(sample):
+        r = res[q]
+        # the header carries length, quality, mean and median coverage, the solution's rank (src/Filler.cpp:1052-1054); multi-solution sites write one record per solution
+        mine = []
+        for f in r["filled"]:
+            solu = "solution %d/%d" % (f["solution_rank"], f["solution_count"]) if f["solution_count"] > 1 else ""
+            mine.append(("%s_len_%d_qual_%d_avg_cov_%.2f_median_cov_%.2f   %s" % (S.site_name(i), len(f["seq"]), f["qual"], f["avg_coverage"], f["median_coverage"], solu), f["seq"]))
+        assert sorted(mine) == sorted(cpu[S.site_name(i)]), i
+        # the info row: nodes, nucleotides, terminal nodes of the forward attempt (the most sensitive output: contig boundaries)
+        assert info[S.site_name(i)][:3] == [r["nb_nodes"], r["total_nt"], r["nb_terminal"]], i
+        n_multi += r["nb_nodes"] > 1
+    assert n_multi == len(crossers)
+    print("config 4: %d sites compared record by record, %d of them cross a chance collision (several contigs)" % (len(sample), len(crossers)))
 
 
 def test_one_launch_of_300000_gaps(mtg):
