@@ -57,6 +57,10 @@ typedef struct mtg_index_info {
     uint64_t unitig_bytes;      /* HBM held by the unitig store (2-bit sequences + one abundance byte per k-mer) */
     uint64_t nb_saturated;      /* solid k-mers whose abundance exceeds 255 and is stored as 255 (gatb reports discretised values above ~70:
                                    coverage statistics of very deep regions may differ from the reference's) */
+    uint32_t sparse;            /* 1: the sparse form -- the ADJ table holds every second junction of a stored unitig (and all others), the ABND
+                                   table only the k-mers of no stored unitig; the rest is read off the unitig store */
+    uint32_t pad_;
+    uint64_t nb_kmers_outside_unitigs;
 } mtg_index_info;
 
 /* Graph::create(props) from read files (src/Filler.cpp:172-213): paths_csv = comma separated FASTA/FASTQ(.gz);

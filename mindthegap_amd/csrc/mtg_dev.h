@@ -48,9 +48,9 @@
 namespace mtg {
 
 /* A=0 C=1 T=2 G=3 ((ascii>>1)&3); complement = code ^ 2; first nt in the most significant bits. */
-MTG_DEV uint64_t kmask(int k) { return (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1); }
+MTG_HD uint64_t kmask(int k) { return (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1); }
 
-MTG_DEV uint64_t revcomp(uint64_t x, int k)
+MTG_HD uint64_t revcomp(uint64_t x, int k)
 {
     x ^= 0xAAAAAAAAAAAAAAAAULL;
     x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
@@ -110,6 +110,9 @@ struct Table {
     uint64_t nbuckets;
     uint32_t key_bits; /* 2m */
     uint32_t tag_bits; /* key_bits - floor(log2(nbuckets)), <= 50 */
+    /* ADJ only, non-null on a SPARSE index (see "sparse index" below): the words of the unitig store, through which the neighbourhood of a
+     * junction that has no entry of its own is read */
+    const uint64_t* sp_words;
 };
 /* slots per bucket: ADJ buckets are small because the walk pays per line touched, not per byte */
 #ifndef MTG_ADJ_SLOTS
@@ -420,12 +423,23 @@ MTG_DEV uint64_t up_hdr(uint64_t up) { return up >> 32; }
 MTG_DEV uint32_t up_off(uint64_t up) { return (uint32_t)(up >> 5) & MTG_US_MAX_LEN; }
 MTG_DEV bool up_bwd(uint64_t up) { return (up & 2ull) != 0; }
 
-/* right neighbourhood of x: successors of x and in-neighbours of those successors (one bucket read). */
-MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t& lines)
+/* ---- sparse index.  Inside a stored unitig every junction is simple: the k-mer before it has one successor, the one after it one
+ * predecessor, and both are written in the store.  A SPARSE index keeps the ADJ entry of an interior junction (offset off, 1 <= off <= number
+ * of k-mers - 1) only when off is odd or the last one: every k-mer of a stored unitig still has an entry next to it (its left or its right
+ * junction), whose pointer says where the k-mer sits, and the store says the rest.  The ABND table of a sparse index holds only the k-mers
+ * that are in no stored unitig (the abundances of the others are the bytes next to the store).  At human scale: ADJ 112 GB -> about a
+ * third, ABND 41 GB -> next to nothing.
+ *
+ * The look-ups below are exact on both forms.  A key without an entry is either a junction that is not in the graph, or one that was left
+ * out: then the OTHER junction of the query k-mer has an entry with a pointer, the k-mer is checked against the store there (a k-mer that
+ * is not solid never passes: a simple junction has one k-mer on each side), and the neighbourhood is read off the store.  The junction
+ * left out is interior, so the k-mer is not the unitig's last (first) one and the neighbour exists. */
+MTG_DEV Adj adj_right_raw(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t& lines, uint32_t& mask_found)
 {
     const uint64_t s = x.f & mk1, rs = x.r >> 2;
     uint64_t aux;
     const uint32_t m = adj_get(adj, s <= rs ? s : rs, lines, aux);
+    mask_found = m;
     Adj a;
     a.up = 0;
     if (s <= rs) { a.out = m & 15u; a.in = m >> 4; a.la = (uint32_t)aux; }
@@ -464,6 +478,83 @@ MTG_DEV uint64_t us_peek64(const uint64_t* words, uint64_t pos, uint32_t n, bool
     if (bwd) v = (rev_fields64(v) >> (64u - 2u * n)) ^ (0xAAAAAAAAAAAAAAAAULL & mask);
     return v;
 }
+/* the k nucleotides of the store that start at pos, as a k-mer image: first nucleotide in the lowest bits.  For an oriented k-mer x read
+ * along the store this is x.r ^ (0xAAAA.. & mask); for one read against the store, x.f ^ (0xAAAA.. & mask) of its reverse complement */
+MTG_DEV uint64_t us_kmer_le(const uint64_t* words, uint64_t pos, int k) { return us_peek64(words, pos, (uint32_t)k, false); }
+
+/* the neighbourhood of an interior junction of a stored unitig, read off the store: `up` = the junction's place, resolved for the walking
+ * direction (bit 1: against the stored orientation) */
+MTG_DEV void adj_of_interior(const uint64_t* words, uint64_t up, int k, uint32_t& out, uint32_t& in)
+{
+    const uint64_t base = (up_hdr(up) + 1) * 32;
+    const uint32_t off = up_off(up);
+    if (!up_bwd(up)) { out = 1u << us_peek(words, base + off + (uint32_t)k - 1u, 1u, false); in = 1u << us_peek(words, base + off - 1u, 1u, false); }
+    else { out = 1u << us_peek(words, base + off - 1u, 1u, true); in = 1u << us_peek(words, base + off + (uint32_t)k - 1u, 1u, true); }
+}
+/* Sparse index: the place of the junction j (a (k-1)-mer, jf in walking orientation, jr its reverse complement) when it is an interior junction
+ * WITHOUT an entry; 0 when there is none.  Such a junction has an even offset and is not the last one, so the junction one nucleotide
+ * further along the unitig has an entry: its key is j without its first nucleotide plus one of four nucleotides.  Only needed for
+ * queries about k-mers that are not solid (a solid k-mer finds its place through its other junction). */
+MTG_DEV uint64_t locate_junction(const Table& adj, uint64_t jf, uint64_t jr, uint32_t& lines)
+{
+    const int k = (int)(adj.key_bits >> 1) + 1;
+    const uint64_t mk1 = kmask(k - 1), cmpl1 = 0xAAAAAAAAAAAAAAAAULL & mk1;
+    for (uint32_t b = 0; b < 4; b++) {
+        const uint64_t kf = ((jf << 2) | b) & mk1, kr = (jr >> 2) | ((uint64_t)(b ^ 2u) << (2 * (k - 2)));
+        uint64_t aux;
+        if (!adj_get(adj, kf <= kr ? kf : kr, lines, aux) || !up_is(aux)) continue;
+        const uint64_t w = up_resolve(aux, kf <= kr);
+        const uint64_t base = (up_hdr(w) + 1) * 32;
+        const uint32_t off = up_off(w);
+        lines++;
+        if (!up_bwd(w)) {
+            if (off < 2u) continue;
+            if (us_peek64(adj.sp_words, base + off - 1u, (uint32_t)k - 1u, false) != (jr ^ cmpl1)) continue;
+            return (up_hdr(w) << 32) | ((uint64_t)(off - 1u) << 5) | 1ull;
+        }
+        if (us_peek64(adj.sp_words, base + off + 1u, (uint32_t)k - 1u, false) != (jf ^ cmpl1)) continue;
+        return (up_hdr(w) << 32) | ((uint64_t)(off + 1u) << 5) | 3ull;
+    }
+    return 0ull;
+}
+
+/* right neighbourhood of x: successors of x and in-neighbours of those successors (one bucket read; on a sparse index a second one and
+ * two short reads of the store when the junction behind x has no entry) */
+MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t& lines)
+{
+    uint32_t m;
+    Adj a = adj_right_raw(adj, x, mk1, lines, m);
+    if (m != 0 || adj.sp_words == nullptr) return a;
+    /* through x's left junction: x is the k-mer behind it */
+    const int k = (int)(adj.key_bits >> 1) + 1;
+    const uint64_t mk = kmask(k), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    const uint64_t p = x.f >> 2, rp = x.r & mk1;
+    uint64_t aux;
+    if (adj_get(adj, p <= rp ? p : rp, lines, aux) && up_is(aux)) {
+        const uint64_t w = up_resolve(aux, p <= rp);
+        const uint64_t base = (up_hdr(w) + 1) * 32;
+        const uint32_t off = up_off(w);
+        lines += 2;
+        if (!up_bwd(w)) {
+            if (us_kmer_le(adj.sp_words, base + off, k) == (x.r ^ cmpl)) {
+                a.out = 1u << us_peek(adj.sp_words, base + off + (uint32_t)k, 1u, false);
+                a.in = 1u << ((uint32_t)(x.f >> (2 * (k - 1))) & 3u);
+                a.up = (up_hdr(w) << 32) | ((uint64_t)(off + 1u) << 5) | 1ull;
+                return a;
+            }
+        } else if (off >= 2u && us_kmer_le(adj.sp_words, base + off - 1u, k) == (x.f ^ cmpl)) {
+            a.out = 1u << us_peek(adj.sp_words, base + off - 2u, 1u, true);
+            a.in = 1u << ((uint32_t)(x.f >> (2 * (k - 1))) & 3u);
+            a.up = (up_hdr(w) << 32) | ((uint64_t)(off - 1u) << 5) | 3ull;
+            return a;
+        }
+    }
+    /* x is not solid: the junction behind it may still be one of the graph (the walk asks this of a source k-mer that is not in the graph) */
+    const uint64_t up = locate_junction(adj, x.f & mk1, x.r >> 2, lines);
+    if (up) { adj_of_interior(adj.sp_words, up, k, a.out, a.in); a.up = up; }
+    return a;
+}
+
 /* sum of the abundance bytes ab[start, start + count), count <= 64: aligned 8-byte reads, all in flight together, bytes outside the range
  * masked off (the array is padded past its end) */
 MTG_DEV uint32_t us_ab_sum(const uint8_t* ab, uint64_t start, uint32_t count)
@@ -612,7 +703,7 @@ MTG_UNROLL
             aux |= hit ? q[u][i].y : 0ull;
         }
         lines++;
-        if (!m && q[u][MTG_ADJ_SLOTS - 1].x != 0) { *rs[u] = adj_right_t(t, *xs[u], mk1, lines); continue; } /* perhaps displaced */
+        if (!m && (q[u][MTG_ADJ_SLOTS - 1].x != 0 || t.sp_words != nullptr)) { *rs[u] = adj_right_t(t, *xs[u], mk1, lines); continue; } /* perhaps displaced, or (sparse index) a junction without an entry */
         rs[u]->up = 0;
         if (fw[u]) { rs[u]->out = m & 15u; rs[u]->in = m >> 4; rs[u]->la = (uint32_t)aux; }
         else { rs[u]->out = comp_mask(m >> 4); rs[u]->in = comp_mask(m & 15u); rs[u]->la = (uint32_t)(aux >> 32); }
@@ -641,9 +732,80 @@ MTG_DEV Adj adj_left(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lin
     a.up = 0;
     if (p <= rp) { a.out = m & 15u; a.in = m >> 4; }
     else { a.out = comp_mask(m >> 4); a.in = comp_mask(m & 15u); }
+    if (m != 0 || ix.adj.sp_words == nullptr) return a;
+    /* sparse index: through x's right junction, x is the k-mer before it */
+    const int k = ix.k;
+    const uint64_t mk = kmask(k), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    const uint64_t s = x.f & mk1, rs = x.r >> 2;
+    if (adj_get(ix.adj, s <= rs ? s : rs, lines, aux) && up_is(aux)) {
+        const uint64_t w = up_resolve(aux, s <= rs);
+        const uint64_t base = (up_hdr(w) + 1) * 32;
+        const uint32_t off = up_off(w);
+        lines += 2;
+        if (!up_bwd(w)) {
+            if (off >= 2u && us_kmer_le(ix.adj.sp_words, base + off - 1u, k) == (x.r ^ cmpl)) {
+                a.in = 1u << us_peek(ix.adj.sp_words, base + off - 2u, 1u, false);
+                a.out = 1u << ((uint32_t)x.f & 3u);
+                return a;
+            }
+        } else if (us_kmer_le(ix.adj.sp_words, base + off, k) == (x.f ^ cmpl)) {
+            a.in = 1u << us_peek(ix.adj.sp_words, base + off + (uint32_t)k, 1u, true);
+            a.out = 1u << ((uint32_t)x.f & 3u);
+            return a;
+        }
+    }
+    const uint64_t up = locate_junction(ix.adj, p, rp, lines); /* x is not solid */
+    if (up) adj_of_interior(ix.adj.sp_words, up, k, a.out, a.in);
     return a;
 }
-MTG_DEV uint32_t abundance(const Index& ix, const Kmer& x, uint32_t& lines) { return table_get<MTG_ABND_SLOTS>(ix.abnd, canon(x), lines); }
+/* the stored unitig (24 bits of its header word, as rp_unitig) whose interior holds the junction on the left of x, 0xFFFFFFFF: none */
+MTG_DEV uint32_t left_junction_unitig(const Index& ix, const Kmer& x, uint64_t mk1, uint32_t& lines)
+{
+    const uint64_t p = x.f >> 2, rp = x.r & mk1;
+    uint64_t aux;
+    const uint32_t m = adj_get(ix.adj, p <= rp ? p : rp, lines, aux);
+    if (m != 0) return up_is(aux) ? (uint32_t)up_hdr(aux) & 0xFFFFFFu : 0xFFFFFFFFu;
+    if (ix.adj.sp_words == nullptr) return 0xFFFFFFFFu;
+    const int k = ix.k;
+    const uint64_t mk = kmask(k), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    const uint64_t s = x.f & mk1, rs = x.r >> 2;
+    if (adj_get(ix.adj, s <= rs ? s : rs, lines, aux) && up_is(aux)) {
+        const uint64_t w = up_resolve(aux, s <= rs);
+        const uint64_t base = (up_hdr(w) + 1) * 32;
+        const uint32_t off = up_off(w);
+        lines++;
+        const bool is_x = !up_bwd(w) ? (off >= 2u && us_kmer_le(ix.adj.sp_words, base + off - 1u, k) == (x.r ^ cmpl)) : us_kmer_le(ix.adj.sp_words, base + off, k) == (x.f ^ cmpl);
+        if (is_x) return (uint32_t)up_hdr(w) & 0xFFFFFFu;
+    }
+    const uint64_t up = locate_junction(ix.adj, p, rp, lines);
+    return up ? (uint32_t)up_hdr(up) & 0xFFFFFFu : 0xFFFFFFFFu;
+}
+/* abundance of x (0: not solid).  Sparse index: the byte next to x's place in the store, found through the junction behind or before it;
+ * the table only for the k-mers of no stored unitig */
+MTG_DEV uint32_t abundance(const Index& ix, const Kmer& x, uint32_t& lines)
+{
+    if (ix.adj.sp_words == nullptr) return table_get<MTG_ABND_SLOTS>(ix.abnd, canon(x), lines);
+    const int k = ix.k;
+    const uint64_t mk = kmask(k), mk1 = kmask(k - 1), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    uint64_t aux;
+    const uint64_t s = x.f & mk1, rs = x.r >> 2;
+    if (adj_get(ix.adj, s <= rs ? s : rs, lines, aux) && up_is(aux)) {
+        const uint64_t w = up_resolve(aux, s <= rs);
+        const uint64_t base = (up_hdr(w) + 1) * 32, idx = up_bwd(w) ? up_off(w) : up_off(w) - 1u;
+        lines++;
+        return us_kmer_le(ix.us.words, base + idx, k) == (up_bwd(w) ? (x.f ^ cmpl) : (x.r ^ cmpl)) ? (uint32_t)ix.us.ab[base + idx] : 0u;
+    }
+    const uint64_t p = x.f >> 2, rp = x.r & mk1;
+    if (adj_get(ix.adj, p <= rp ? p : rp, lines, aux) && up_is(aux)) {
+        const uint64_t w = up_resolve(aux, p <= rp);
+        const uint32_t off = up_off(w);
+        if (up_bwd(w) && off < 1u) return 0u;
+        const uint64_t base = (up_hdr(w) + 1) * 32, idx = up_bwd(w) ? off - 1u : off;
+        lines++;
+        return us_kmer_le(ix.us.words, base + idx, k) == (up_bwd(w) ? (x.f ^ cmpl) : (x.r ^ cmpl)) ? (uint32_t)ix.us.ab[base + idx] : 0u;
+    }
+    return table_get<MTG_ABND_SLOTS>(ix.abnd, canon(x), lines);
+}
 /* an abundance look-up in two halves, so that the caller can do other work while the bucket travels */
 struct AbPending {
     U64x2 q[MTG_ABND_SLOTS / 2];
@@ -662,6 +824,7 @@ MTG_UNROLL
 }
 MTG_DEV uint32_t ab_finish(const Index& ix, const AbPending& p, uint32_t& lines)
 {
+    if (ix.adj.sp_words != nullptr) return abundance(ix, make_kmer(p.key, ix.k), lines); /* sparse index: the byte lies next to the store (the bucket requested by ab_issue only serves the k-mers of no unitig) */
     uint32_t val = 0;
 MTG_UNROLL
     for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) {
@@ -872,6 +1035,67 @@ MTG_DEV void us_link(const Index& ix, const UsRec& r, uint32_t i, uint32_t& line
     const uint64_t J = x.f >> 2, rJ = x.r & mk1;
     uint64_t* e = adj_find(ix.adj, J <= rJ ? J : rJ);
     if (e) e[1] = up_make(r.hdr, i, !(J <= rJ));
+}
+
+/* ---- the sparse index, built from the unitig store (see "sparse index" above): per k-mer i of a stored unitig, the entries its junctions
+ * need in the tables `ix` (new, empty but for what other k-mers have contributed): the end junctions of the unitig get the k-mer's edge bits
+ * (what index_insert contributes on that side), an interior junction that is kept gets its two bits and its pointer.  Returns 1 when an
+ * insertion overflowed its displacement range.  with_bloom: the k-mer also enters the Bloom filter (an index rebuilt from its container). */
+MTG_DEV bool sparse_keeps(uint32_t off, uint32_t len_k) { return (off & 1u) != 0 || off == len_k - 1u; }
+MTG_DEV int sparse_link(const Index& ix, const UsRec& r, uint32_t i, bool with_bloom)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k), mk1 = kmask(k - 1);
+    const uint64_t* w = ix.us.words + r.hdr + 1;
+    const uint32_t sft = 2u * (i & 31u);
+    const uint64_t lo = w[i >> 5] >> sft;
+    const uint64_t hi = sft ? (w[(i >> 5) + 1] << (64u - sft)) : 0ull; /* the store is padded by one word */
+    Kmer x;
+    x.r = ((lo | hi) & mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
+    x.f = revcomp(x.r, k);
+    int fail = 0;
+    if (with_bloom && ix.bloom.bits) bloom_insert(ix.bloom, x, k);
+    const uint32_t a = (uint32_t)(x.f >> (2 * (k - 1))) & 3u, b = (uint32_t)x.f & 3u;
+    const uint64_t pre = x.f >> 2, rpre = x.r & mk1;  /* the junction before x: pre + b is solid */
+    const uint64_t suf = x.f & mk1, rsuf = x.r >> 2;  /* the junction behind x: a + suf is solid */
+    const uint32_t pre_bit = pre <= rpre ? 1u << b : 1u << (4 + (b ^ 2u)), suf_bit = suf <= rsuf ? 1u << (4 + a) : 1u << (a ^ 2u);
+    /* an end junction may be its own reverse complement: the two strands of the k-mer then contribute different bits (index_insert adds both) */
+    const uint32_t pre_bit2 = rpre <= pre ? 1u << (4 + (b ^ 2u)) : 1u << b, suf_bit2 = rsuf <= suf ? 1u << (a ^ 2u) : 1u << (4 + a);
+    if (i == 0) fail |= adj_or(ix.adj, pre <= rpre ? pre : rpre, pre_bit | pre_bit2) & 1;
+    else if (sparse_keeps(i, r.len_k)) {
+        /* the interior junction between k-mers i - 1 and i: x's bit on this side and that of the k-mer before it */
+        const uint32_t a0 = (uint32_t)((w[(i - 1) >> 5] >> (2u * ((i - 1) & 31u))) & 3ull); /* first nucleotide of k-mer i - 1 */
+        const uint32_t prev_bit = pre <= rpre ? 1u << (4 + a0) : 1u << (a0 ^ 2u);          /* its "a + suf is solid" on the junction pre */
+        const uint64_t key = pre <= rpre ? pre : rpre;
+        fail |= adj_or(ix.adj, key, pre_bit | prev_bit) & 1;
+        uint64_t* e = adj_find(ix.adj, key);
+        if (e) e[1] = up_make(r.hdr, i, !(pre <= rpre));
+    }
+    if (i == r.len_k - 1) fail |= adj_or(ix.adj, suf <= rsuf ? suf : rsuf, suf_bit | suf_bit2) & 1;
+    return fail;
+}
+/* is the solid canonical k-mer c one of a stored unitig?  (on the dense index the unitigs were built from: every interior junction has its pointer) */
+MTG_DEV bool kmer_stored(const Index& ix, uint64_t c, uint32_t& lines)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k), mk1 = kmask(k - 1), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    const Kmer x = make_kmer(c, k);
+    uint64_t aux;
+    const uint64_t s = x.f & mk1, rs = x.r >> 2;
+    if (adj_get(ix.adj, s <= rs ? s : rs, lines, aux) && up_is(aux)) {
+        const uint64_t wv = up_resolve(aux, s <= rs);
+        const uint64_t base = (up_hdr(wv) + 1) * 32, idx = up_bwd(wv) ? up_off(wv) : up_off(wv) - 1u;
+        if (us_kmer_le(ix.us.words, base + idx, k) == (up_bwd(wv) ? (x.f ^ cmpl) : (x.r ^ cmpl))) return true;
+    }
+    const uint64_t p = x.f >> 2, rp = x.r & mk1;
+    if (adj_get(ix.adj, p <= rp ? p : rp, lines, aux) && up_is(aux)) {
+        const uint64_t wv = up_resolve(aux, p <= rp);
+        const uint32_t off = up_off(wv);
+        if (up_bwd(wv) && off < 1u) return false;
+        const uint64_t base = (up_hdr(wv) + 1) * 32, idx = up_bwd(wv) ? off - 1u : off;
+        if (us_kmer_le(ix.us.words, base + idx, k) == (up_bwd(wv) ? (x.f ^ cmpl) : (x.r ^ cmpl))) return true;
+    }
+    return false;
 }
 
 /* ---- the solid k-mers, read back from the ABND table: (bucket, tag) is lossless and the hash a bijection, so slot s of the table gives

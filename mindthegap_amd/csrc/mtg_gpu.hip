@@ -304,6 +304,57 @@ __global__ void __launch_bounds__(256) k_us_link(Index ix, const UsRec* __restri
         for (uint32_t i = lane; i < r.len_k; i += 64) us_link(ix, r, i, lines);
     }
 }
+/* ---- the sparse form (mtg_dev.h: "sparse index") ----
+ * the k-mers of no stored unitig, out of the ABND table of the index the unitigs were built from (or of a sparse one): out == nullptr counts */
+__global__ void k_leftovers(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned long long* cursor, unsigned long long cap)
+{
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
+    uint32_t lines = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        const uint32_t a = abnd_slot_kmer(ix.abnd, s, c);
+        if (!a || (ix.us.nwords && kmer_stored(ix, c, lines))) continue;
+        const unsigned long long at = atomicAdd(cursor, 1ull);
+        if (out_k && at < cap) { out_k[at] = c; out_a[at] = a; }
+    }
+}
+/* one stored unitig per wave, its k-mers dealt to the lanes: the entries of its junctions in the new tables; counters[0] = overflow flag */
+__global__ void __launch_bounds__(256) k_sparse_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n, int with_bloom, unsigned long long* counters)
+{
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    int fail = 0;
+    for (unsigned long long u = wave; u < n; u += nwaves) {
+        const UsRec r = rec[u];
+        for (uint32_t i = lane; i < r.len_k; i += 64) fail |= sparse_link(ix, r, i, with_bloom != 0);
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+}
+/* lookaheads of the entries at the two ends of every stored unitig (the only entries around a stored k-mer that are no pointers) */
+__global__ void k_sparse_ends(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (unsigned long long)gridDim.x * blockDim.x) {
+        const UsRec r = rec[u];
+        const Kmer first = make_kmer(r.start_f, ix.k);
+        Kmer fr;
+        fr.f = first.r; fr.r = first.f;
+        build_lookahead(ix, fr);
+        build_lookahead(ix, run_node(ix.us, (r.hdr + 1) * 32, false, r.len_k - 1, ix.k));
+    }
+}
+/* the records of the stored unitigs from the store itself (an index that comes from its container): hdr[u] = header word of unitig u */
+__global__ void k_recs_from_store(UStore us, const uint64_t* __restrict__ hdr, unsigned long long n, int k, UsRec* rec)
+{
+    const unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    UsRec r;
+    r.hdr = hdr[u];
+    r.len_k = (uint32_t)us.words[r.hdr] - (uint32_t)k + 1u;
+    r.pad_ = 0;
+    r.start_f = run_node(us, (r.hdr + 1) * 32, false, 0, k).f;
+    rec[u] = r;
+}
+
 /* the solid k-mers and their abundances out of the ABND table (index writer): out_k / out_a receive them in no particular order */
 __global__ void k_abnd_export(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned long long* cursor, unsigned long long cap)
 {
@@ -815,7 +866,7 @@ __global__ void __launch_bounds__(SCAN_TILE) k_scan(Index ix, const uint64_t* __
                 n_pos += res;
                 if (res && mode == 1) {
                     uint32_t lines = 0;
-                    res = table_get<MTG_ABND_SLOTS>(ix.abnd, c, lines) != 0;
+                    res = abundance(ix, x, lines) != 0;
                     n_conf += res;
                 }
             }
@@ -933,6 +984,7 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
 /* Unitig store of a finished index (every k-mer inserted, every lookahead written): chain starts -> one walk per start -> sequences ->
  * abundances and junction pointers (mtg_dev.h: us_*).  Also fills nb_solid_kmers / nb_branching from the table itself.
  * MTG_NO_UNITIGS=1 (test hook) leaves the index with inline lookaheads only. */
+static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left);
 static int build_unitigs(mtg_index* idx)
 {
     DevBuf d_cnt, d_starts, d_rec;
@@ -979,7 +1031,93 @@ static int build_unitigs(mtg_index* idx)
     idx->info.nb_unitigs = n_rec;
     idx->info.unitig_bytes = (n_words + pad) * 40;
     idx->info.device_bytes += idx->info.unitig_bytes;
-    return MTG_OK;
+    /* the dense tables have served: the index proper is the store plus the few k-mers of no unitig (MTG_DENSE_INDEX=1: A/B and test hook) */
+    if (getenv("MTG_DENSE_INDEX")) return MTG_OK;
+    return sparsify(idx, d_rec.as<UsRec>(), n_rec, false, nullptr, nullptr, 0);
+}
+
+/* The sparse form.  From a dense index with its store (from_container == false: the k-mers of no unitig are read off its ABND table, the
+ * dense tables are freed at the end) or from the store alone (an index out of its container: idx holds only the store; the k-mers of no
+ * unitig are handed over, the Bloom filter is filled here).  New tables: ADJ with the entries the sparse form keeps, ABND with the k-mers
+ * of no unitig. */
+static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left)
+{
+    const int k = idx->dev.k;
+    DevBuf d_cnt, own_k, own_a;
+    HIP_TRY(d_cnt.alloc(64));
+    if (!from_container) {
+        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+        const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, (uint64_t*)nullptr, (uint32_t*)nullptr, d_cnt.as<unsigned long long>(), 0ull);
+        HIP_TRY(hipMemcpy(&n_left, d_cnt.p, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(own_k.alloc((n_left + 1) * 8));
+        HIP_TRY(own_a.alloc((n_left + 1) * 4));
+        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, own_k.as<uint64_t>(), own_a.as<uint32_t>(), d_cnt.as<unsigned long long>(), (unsigned long long)n_left);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        d_left_k = own_k.as<uint64_t>();
+        d_left_a = own_a.as<uint32_t>();
+    }
+    /* entries of the new ADJ: per unitig its kept interior junctions (every second one and the last) and its two ends; two per k-mer of no unitig */
+    std::vector<UsRec> h_rec;
+    uint64_t nkeys = 2 * n_left + 1024;
+    {
+        h_rec.resize(n_rec);
+        if (n_rec) HIP_TRY(hipMemcpy(h_rec.data(), d_rec, n_rec * sizeof(UsRec), hipMemcpyDeviceToHost));
+        for (const UsRec& r : h_rec) nkeys += r.len_k / 2 + 3;
+        std::vector<UsRec>().swap(h_rec);
+    }
+    Index old = idx->dev;
+    double load = 1.0;
+    int rc = MTG_OK;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        Index nx = old;
+        nx.adj.sp_words = nullptr; /* raw look-ups while the tables are being built */
+        const double load_adj = (getenv("MTG_SPARSE_ADJ_LOAD") ? atof(getenv("MTG_SPARSE_ADJ_LOAD")) : 0.7) * load;
+        table_shape(nx.adj, buckets_for(nkeys, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
+        table_shape(nx.abnd, buckets_for(n_left + 1024, 0.6 * load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+        const size_t ba = nx.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = nx.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
+        DevBuf na, nb;
+        HIP_TRY(na.alloc(ba));
+        HIP_TRY(nb.alloc(bb));
+        HIP_TRY(hipMemset(na.p, 0, ba));
+        HIP_TRY(hipMemset(nb.p, 0, bb));
+        nx.adj.slots = na.as<uint64_t>();
+        nx.abnd.slots = nb.as<uint64_t>();
+        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+        if (n_rec) hipLaunchKernelGGL(k_sparse_link, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, nx, d_rec, n_rec, from_container ? 1 : 0, d_cnt.as<unsigned long long>());
+        if (n_left) {
+            Index nxb = nx;
+            if (!from_container) nxb.bloom.bits = nullptr; /* the filter holds every k-mer already */
+            hipLaunchKernelGGL(k_insert_kmers, dim3((unsigned)std::min<unsigned long long>((n_left + 255) / 256 + 1, 256 * 16)), dim3(256), 0, 0, nxb, d_left_k, d_left_a, (size_t)n_left, d_cnt.as<unsigned long long>());
+        }
+        HIP_TRY(hipGetLastError());
+        unsigned long long cnt[8];
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
+        if (cnt[0]) { load *= 0.7; rc = MTG_ERR_OVERFLOW; set_error("index bucket displacement overflow (sparse form)"); continue; }
+        if (from_container) idx->info.nb_saturated = cnt[3];
+        /* lookaheads of the entries that are no pointers: around the k-mers of no unitig and at the unitigs' ends */
+        if (n_left) hipLaunchKernelGGL(k_lookahead_kmers, dim3((unsigned)std::min<unsigned long long>((n_left + 255) / 256 + 1, 256 * 16)), dim3(256), 0, 0, nx, d_left_k, (size_t)n_left);
+        if (n_rec) hipLaunchKernelGGL(k_sparse_ends, dim3((unsigned)std::min<unsigned long long>((n_rec + 255) / 256, 256 * 16)), dim3(256), 0, 0, nx, d_rec, n_rec);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        /* the new tables take the place of the old ones */
+        if (old.adj.slots) (void)hipFree(old.adj.slots);
+        if (old.abnd.slots) (void)hipFree(old.abnd.slots);
+        nx.adj.sp_words = nx.us.words;
+        idx->dev = nx;
+        (void)na.release();
+        (void)nb.release();
+        idx->info.device_bytes = ba + bb + idx->dev.bloom.nblocks * 64 + idx->info.unitig_bytes;
+        idx->info.adj_buckets = nx.adj.nbuckets;
+        idx->info.abnd_buckets = nx.abnd.nbuckets;
+        idx->info.sparse = 1;
+        idx->info.nb_kmers_outside_unitigs = n_left;
+        return MTG_OK;
+    }
+    return rc;
 }
 
 /* The index of a counted solid set that arrives in pieces (host arrays, or the records of a saved index read from its file: 36 GB at human
@@ -1128,6 +1266,7 @@ int index_replicate(const mtg_index* src, int device, mtg_index** out)
         if (int rc = clone((void**)&idx->dev.us.words, src->dev.us.words, nw * 8)) return rc;
         if (int rc = clone((void**)&idx->dev.us.ab, src->dev.us.ab, nw * 32)) return rc;
     }
+    if (src->dev.adj.sp_words) idx->dev.adj.sp_words = idx->dev.us.words; /* the sparse form reads this copy's store */
     HIP_TRY(hipDeviceSynchronize());
     *out = g.release();
     return MTG_OK;
@@ -1160,6 +1299,119 @@ int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*,
         HIP_TRY(hipMemcpy(ha.data(), d_a.as<uint32_t>() + off, m * 4, hipMemcpyDeviceToHost));
         if (!sink(hk.data(), ha.data(), m)) { set_error("index export: the writer failed"); return MTG_ERR_IO; }
     }
+    return MTG_OK;
+}
+
+int index_dump(const mtg_index* idx, IndexDump& d)
+{
+    if (int rc = use_device_of(idx)) return rc;
+    d.k = idx->dev.k; d.abundance_min = idx->info.abundance_min; d.abundance_auto = idx->info.abundance_auto;
+    d.nb_solid = idx->info.nb_solid_kmers; d.nb_branching = idx->info.nb_branching; d.nb_saturated = idx->info.nb_saturated;
+    d.n_words = idx->dev.us.nwords; d.n_unitigs = idx->dev.us.nunitigs;
+    d.words.clear(); d.ab.clear();
+    if (d.n_words) {
+        const uint64_t nw = d.n_words + 8;
+        d.words.resize(nw);
+        d.ab.resize(nw * 32);
+        HIP_TRY(hipMemcpy(d.words.data(), idx->dev.us.words, nw * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d.ab.data(), idx->dev.us.ab, nw * 32, hipMemcpyDeviceToHost));
+    }
+    DevBuf d_cnt, d_k, d_a;
+    HIP_TRY(d_cnt.alloc(8));
+    HIP_TRY(hipMemset(d_cnt.p, 0, 8));
+    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, (uint64_t*)nullptr, (uint32_t*)nullptr, d_cnt.as<unsigned long long>(), 0ull);
+    unsigned long long n_left = 0;
+    HIP_TRY(hipMemcpy(&n_left, d_cnt.p, 8, hipMemcpyDeviceToHost));
+    d.left_k.resize(n_left);
+    d.left_a.resize(n_left);
+    if (n_left) {
+        HIP_TRY(d_k.alloc(n_left * 8));
+        HIP_TRY(d_a.alloc(n_left * 4));
+        HIP_TRY(hipMemset(d_cnt.p, 0, 8));
+        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d_cnt.as<unsigned long long>(), n_left);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(d.left_k.data(), d_k.p, n_left * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d.left_a.data(), d_a.p, n_left * 4, hipMemcpyDeviceToHost));
+    }
+    return MTG_OK;
+}
+
+/* an index out of its container: the store goes up as it is, the tables are derived from it (sparsify); nothing is counted or walked */
+int index_from_dump(const IndexDump& d, mtg_index** out)
+{
+    if (int rc = ensure_device()) return rc;
+    if (d.k < 11 || d.k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (getenv("MTG_DENSE_INDEX") || d.n_words == 0) {
+        /* test hook / an index without stored unitigs: through the list of its k-mers */
+        std::vector<uint64_t> km(d.left_k);
+        std::vector<uint32_t> ab(d.left_a);
+        const uint64_t mk = kmask(d.k);
+        for (uint64_t h = 0; h < d.n_words;) {
+            const uint64_t len = d.words[h];
+            for (uint64_t i = 0; i + d.k <= len; i++) {
+                const uint64_t p = (h + 1) * 32 + i, lo = d.words[p >> 5] >> (2 * (p & 31)), hi = (p & 31) ? d.words[(p >> 5) + 1] << (64 - 2 * (p & 31)) : 0;
+                const uint64_t r = ((lo | hi) & mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk), f = revcomp(r, d.k);
+                km.push_back(f < r ? f : r);
+                ab.push_back(d.ab[p]);
+            }
+            h += 1 + (len + 31) / 32;
+        }
+        int rc = index_from_kmers(km.data(), ab.data(), km.size(), d.k, out);
+        if (!rc) { (*out)->info.abundance_min = d.abundance_min; (*out)->info.abundance_auto = d.abundance_auto; }
+        return rc;
+    }
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = d.k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    const uint64_t nw = d.n_words + 8;
+    if (d.words.size() < nw || d.ab.size() < nw * 32 || d.left_k.size() != d.left_a.size()) { set_error("index container: inconsistent sizes"); return MTG_ERR_FORMAT; }
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.words, nw * 8));
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, nw * 32));
+    HIP_TRY(hipMemcpy(idx->dev.us.words, d.words.data(), nw * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(idx->dev.us.ab, d.ab.data(), nw * 32, hipMemcpyHostToDevice));
+    idx->dev.us.nwords = d.n_words;
+    /* the header words of the unitigs, one after the other */
+    std::vector<uint64_t> hdr;
+    hdr.reserve(d.n_unitigs);
+    for (uint64_t h = 0; h < d.n_words;) {
+        const uint64_t len = d.words[h];
+        if (len < (uint64_t)d.k + 1 || len > MTG_US_MAX_LEN) { set_error("index container: damaged unitig store"); return MTG_ERR_FORMAT; }
+        hdr.push_back(h);
+        h += 1 + (len + 31) / 32;
+    }
+    idx->dev.us.nunitigs = hdr.size();
+    DevBuf d_hdr, d_rec, d_k, d_a;
+    const auto upload = [](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.alloc(bytes);
+        if (e != hipSuccess || !bytes) return e;
+        return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(upload(d_hdr, hdr.data(), hdr.size() * 8));
+    HIP_TRY(d_rec.alloc((hdr.size() + 1) * sizeof(UsRec)));
+    hipLaunchKernelGGL(k_recs_from_store, dim3((unsigned)((hdr.size() + 255) / 256)), dim3(256), 0, 0, idx->dev.us, d_hdr.as<uint64_t>(), (unsigned long long)hdr.size(), d.k, d_rec.as<UsRec>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(upload(d_k, d.left_k.data(), d.left_k.size() * 8));
+    HIP_TRY(upload(d_a, d.left_a.data(), d.left_a.size() * 4));
+    const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
+    if (bpk > 0) {
+        bloom_shape(idx->dev.bloom, d.nb_solid, bpk, d.k);
+        HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, idx->dev.bloom.nblocks * 64));
+        HIP_TRY(hipMemset(idx->dev.bloom.bits, 0, idx->dev.bloom.nblocks * 64));
+    }
+    idx->info.k = d.k;
+    idx->info.abundance_min = d.abundance_min; idx->info.abundance_auto = d.abundance_auto;
+    idx->info.nb_solid_kmers = d.nb_solid; idx->info.nb_branching = d.nb_branching; idx->info.nb_saturated = d.nb_saturated;
+    idx->info.nb_unitigs = hdr.size();
+    idx->info.unitig_bytes = nw * 40;
+    idx->info.bloom_blocks = idx->dev.bloom.nblocks;
+    idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
+    idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
+    idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
+    if (int rc = sparsify(idx, d_rec.as<UsRec>(), hdr.size(), true, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d.left_k.size())) return rc;
+    *out = g.release();
     return MTG_OK;
 }
 

@@ -219,27 +219,60 @@ static const char IDX_MAGIC[8] = {'M', 'T', 'G', 'I', 'D', 'X', '1', 0};
 /* The container: magic, k, abundance_min, abundance_auto, number of k-mers, then (k-mer : 8 bytes, abundance : 4 bytes) records in
  * no particular order.  The k-mers are read back from the device tables (the index keeps no host copy), in pieces. */
 static const char IDX_MAGIC2[8] = {'M', 'T', 'G', 'I', 'D', 'X', '2', 0};
+/* Version 3: the index as it is: the unitig store (2-bit sequences + one abundance byte per k-mer) and the k-mers of no stored unitig.
+ *   magic | int32 k, abundance_min, abundance_auto, 0 | uint64 nb_solid, nb_branching, nb_saturated, n_words, n_unitigs, n_left |
+ *   (n_words + 8) words | (n_words + 8) * 32 abundance bytes | n_left x (k-mer : 8 bytes, abundance : 4 bytes)
+ * At human scale 4 GB instead of the 36 GB of the k-mer list (version 2, still read), and nothing is rebuilt on load but the tables. */
+static const char IDX_MAGIC3[8] = {'M', 'T', 'G', 'I', 'D', 'X', '3', 0};
 int index_save(const mtg_index* idx, const char* path)
 {
     if (!idx || !path) { set_error("null argument"); return MTG_ERR_ARG; }
+    IndexDump d;
+    if (int rc = index_dump(idx, d)) return rc;
     FILE* f = fopen(path, "wb");
     if (!f) { set_error("cannot write %s", path); return MTG_ERR_IO; }
-    int32_t hdr[4] = {idx->info.k, idx->info.abundance_min, idx->info.abundance_auto, 0};
-    const uint64_t n = idx->info.nb_solid_kmers;
-    bool ok = fwrite(IDX_MAGIC2, 1, 8, f) == 8 && fwrite(hdr, 4, 4, f) == 4 && fwrite(&n, 8, 1, f) == 1;
-    int rc = MTG_OK;
-    if (ok) {
-        std::vector<unsigned char> rec;
-        rc = index_export(idx, [&](const uint64_t* k, const uint32_t* a, size_t m) {
-            rec.resize(m * 12);
-            for (size_t i = 0; i < m; i++) { memcpy(rec.data() + 12 * i, k + i, 8); memcpy(rec.data() + 12 * i + 8, a + i, 4); }
-            return fwrite(rec.data(), 12, m, f) == m;
-        });
+    const int32_t hdr[4] = {d.k, d.abundance_min, d.abundance_auto, 0};
+    const uint64_t cnt[6] = {d.nb_solid, d.nb_branching, d.nb_saturated, d.n_words, d.n_unitigs, (uint64_t)d.left_k.size()};
+    bool ok = fwrite(IDX_MAGIC3, 1, 8, f) == 8 && fwrite(hdr, 4, 4, f) == 4 && fwrite(cnt, 8, 6, f) == 6;
+    const uint64_t nw = d.n_words ? d.n_words + 8 : 0;
+    if (ok && nw) ok = fwrite(d.words.data(), 8, nw, f) == nw && fwrite(d.ab.data(), 1, nw * 32, f) == nw * 32;
+    if (ok && !d.left_k.empty()) {
+        std::vector<unsigned char> rec(d.left_k.size() * 12);
+        for (size_t i = 0; i < d.left_k.size(); i++) { memcpy(rec.data() + 12 * i, &d.left_k[i], 8); memcpy(rec.data() + 12 * i + 8, &d.left_a[i], 4); }
+        ok = fwrite(rec.data(), 12, d.left_k.size(), f) == d.left_k.size();
     }
-    ok = ok && fclose(f) == 0;
-    if (rc) return rc;
+    ok = (fclose(f) == 0) && ok;
     if (!ok) { set_error("short write on %s", path); return MTG_ERR_IO; }
     return MTG_OK;
+}
+
+static int index_load_v3(FILE* f, const char* path, mtg_index** out)
+{
+    int32_t hdr[4];
+    uint64_t cnt[6];
+    if (fread(hdr, 4, 4, f) != 4 || fread(cnt, 8, 6, f) != 6) { set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
+    const long data0 = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const long fsize = ftell(f);
+    fseek(f, data0, SEEK_SET);
+    const uint64_t nw = cnt[3] ? cnt[3] + 8 : 0;
+    if (hdr[0] < 11 || hdr[0] > 31 || fsize < data0 || cnt[3] > (1ull << 40) || cnt[5] > (1ull << 40) || nw * 40 + cnt[5] * 12 != (uint64_t)(fsize - data0)) {
+        set_error("%s: truncated or damaged (the header announces %llu store words and %llu k-mers)", path, (unsigned long long)cnt[3], (unsigned long long)cnt[5]);
+        return MTG_ERR_FORMAT;
+    }
+    IndexDump d;
+    d.k = hdr[0]; d.abundance_min = hdr[1]; d.abundance_auto = hdr[2];
+    d.nb_solid = cnt[0]; d.nb_branching = cnt[1]; d.nb_saturated = cnt[2]; d.n_words = cnt[3]; d.n_unitigs = cnt[4];
+    d.words.resize(nw); d.ab.resize(nw * 32);
+    bool ok = (!nw || (fread(d.words.data(), 8, nw, f) == nw && fread(d.ab.data(), 1, nw * 32, f) == nw * 32));
+    d.left_k.resize(cnt[5]); d.left_a.resize(cnt[5]);
+    if (ok && cnt[5]) {
+        std::vector<unsigned char> rec(cnt[5] * 12);
+        ok = fread(rec.data(), 12, cnt[5], f) == cnt[5];
+        for (size_t i = 0; i < cnt[5] && ok; i++) { memcpy(&d.left_k[i], rec.data() + 12 * i, 8); memcpy(&d.left_a[i], rec.data() + 12 * i + 8, 4); }
+    }
+    if (!ok) { set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
+    return index_from_dump(d, out);
 }
 
 int index_load(const char* path, mtg_index** out)
@@ -256,6 +289,7 @@ int index_load(const char* path, mtg_index** out)
         set_error("%s is an HDF5 file: GATB .h5 graphs are not readable by this library (SURVEY.md 8f-2); build the index with -in", path);
         return MTG_ERR_FORMAT;
     }
+    if (memcmp(magic, IDX_MAGIC3, 8) == 0) { const int rc3 = index_load_v3(f, path, out); fclose(f); return rc3; }
     const bool v1 = memcmp(magic, IDX_MAGIC, 8) == 0, v2 = memcmp(magic, IDX_MAGIC2, 8) == 0;
     if (!(v1 || v2) || fread(hdr, 4, 4, f) != 4 || fread(&n, 8, 1, f) != 1) { fclose(f); set_error("%s: not a mtg index", path); return MTG_ERR_FORMAT; }
     /* the records go to the device piece by piece, straight from the file (every attempt to size the tables reads them once) */

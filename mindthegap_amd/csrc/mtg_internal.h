@@ -524,6 +524,18 @@ int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<u
 int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
 /* the solid k-mers of an index with their abundances, read back from its device tables, in pieces handed to sink(kmers, abundances, count) */
 int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink);
+/* An index as it is kept in its container (version 3): the unitig store -- 2-bit sequences and one abundance byte per k-mer -- and the k-mers
+ * of no stored unitig.  Nothing else is needed to put the index back on a device: its tables are derived from the store (sparse form). */
+struct IndexDump {
+    int k = 0, abundance_min = 0, abundance_auto = -1;
+    uint64_t nb_solid = 0, nb_branching = 0, nb_saturated = 0, n_words = 0, n_unitigs = 0;
+    std::vector<uint64_t> words;  /* n_words in use + padding */
+    std::vector<uint8_t> ab;      /* 32 bytes per word */
+    std::vector<uint64_t> left_k; /* canonical k-mers of no stored unitig */
+    std::vector<uint32_t> left_a; /* their abundances */
+};
+int index_dump(const mtg_index* idx, IndexDump& d);
+int index_from_dump(const IndexDump& d, mtg_index** out);
 
 void stats_store(const mtg_batch_stats& s);
 

@@ -553,10 +553,7 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
             if (ok) {
                 if (!prev_known) { /* the junction between the previous node and the start = the start's left junction */
                     prev_known = true;
-                    const uint64_t pj = start.f >> 2, rpj = start.r & W.mk1;
-                    uint64_t aux;
-                    adj_get(W.ix.adj, pj <= rpj ? pj : rpj, W.lines, aux);
-                    if (up_is(aux)) prev_unitig = (uint32_t)up_hdr(aux) & 0xFFFFFFu;
+                    prev_unitig = left_junction_unitig(W.ix, start, W.mk1, W.lines);
                 }
                 for (int i = 0; i < ncur && ok; i++) {
                     const uint32_t u = rp_unitig(crp[i]);

@@ -66,7 +66,8 @@ class Params(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("k", C.c_int), ("abundance_min", C.c_int), ("abundance_auto", C.c_int), ("nb_solid_kmers", C.c_uint64),
                 ("nb_branching", C.c_uint64), ("device_bytes", C.c_uint64), ("adj_buckets", C.c_uint64), ("abnd_buckets", C.c_uint64), ("adj_bucket_bytes", C.c_uint32), ("abnd_bucket_bytes", C.c_uint32), ("bloom_blocks", C.c_uint64), ("bloom_minimizer", C.c_uint32),
-                ("nb_unitigs", C.c_uint64), ("unitig_bytes", C.c_uint64), ("nb_saturated", C.c_uint64)]
+                ("nb_unitigs", C.c_uint64), ("unitig_bytes", C.c_uint64), ("nb_saturated", C.c_uint64), ("sparse", C.c_uint32), ("pad_", C.c_uint32),
+                ("nb_kmers_outside_unitigs", C.c_uint64)]
 
 
 class CGap(C.Structure):

@@ -6,7 +6,7 @@ wl=${@:-human-indel human-het human}
 out=gpurun_out/$tag
 mkdir -p $out
 for w in $wl; do
-  for mode in classic g16 g64; do
+  for mode in ${MODES:-classic g16 g64}; do
     case $mode in
       classic) export MTG_CLASSIC_WALK=1; unset MTG_FINISH_G;;
       g16) unset MTG_CLASSIC_WALK; export MTG_FINISH_G=16;;

@@ -37,11 +37,13 @@ void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, 
         e->ix.bloom.bits = nullptr;
         e->ix.bloom.nblocks = 0;
         e->ix.us = UStore{};
+        e->ix.adj.sp_words = nullptr;
         int fail = 0;
         for (size_t i = 0; i < n; i++) fail |= index_insert(e->ix, kmers[i], counts[i]) & 1;
         if (!fail) {
             for (size_t i = 0; i < n; i++) { Kmer x = make_kmer(kmers[i], k); build_lookahead(e->ix, x); Kmer y; y.f = x.r; y.r = x.f; build_lookahead(e->ix, y); }
             emu_build_unitigs(e->ix, e->us);
+            if (emu_sparsify(e->ix, e->us)) { e->adj_slots.clear(); e->adj_slots.shrink_to_fit(); e->abnd_slots.clear(); e->abnd_slots.shrink_to_fit(); }
             return e;
         }
         delete e;

@@ -60,7 +60,10 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
             idx->info.bloom_blocks = idx->dev.bloom.nblocks; idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
             {
                 EmuUStore* st = new EmuUStore();
-                emu_build_unitigs(idx->dev, *st);
+                idx->info.nb_unitigs = emu_build_unitigs(idx->dev, *st);
+                uint64_t* dense_adj = idx->dev.adj.slots;
+                uint64_t* dense_abnd = idx->dev.abnd.slots;
+                if (emu_sparsify(idx->dev, *st)) { free(dense_adj); free(dense_abnd); idx->info.sparse = 1; } /* the tables now live in *st */
                 std::lock_guard<std::mutex> lk(g_us_mtx);
                 g_us[idx] = st;
             }
@@ -91,8 +94,10 @@ int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** 
 void index_release(mtg_index* idx)
 {
     if (!idx) return;
+    const bool sparse = idx->dev.adj.sp_words != nullptr; /* the tables of the sparse form live in the EmuUStore */
     { std::lock_guard<std::mutex> lk(g_us_mtx); auto it = g_us.find(idx); if (it != g_us.end()) { delete it->second; g_us.erase(it); } }
-    free(idx->dev.adj.slots); free(idx->dev.abnd.slots); free(idx->dev.bloom.bits);
+    if (!sparse) { free(idx->dev.adj.slots); free(idx->dev.abnd.slots); }
+    free(idx->dev.bloom.bits);
     for (Workspace& w : idx->ws) for (void* h : w.hptr) free(h);
     delete idx;
 }
@@ -223,16 +228,58 @@ int device_upload(const mtg_index*, void* dev_dst, const void* host_src, size_t 
 int batch_upload(const mtg_index*, FillInput&) { return MTG_OK; } /* nothing to upload: the "device" reads the host blocks */
 void batch_release_device(FillInput&) {}
 
-int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink)
+int index_dump(const mtg_index* idx, IndexDump& d)
 {
-    std::vector<uint64_t> k;
-    std::vector<uint32_t> a;
+    d.k = idx->dev.k; d.abundance_min = idx->info.abundance_min; d.abundance_auto = idx->info.abundance_auto;
+    d.nb_solid = idx->info.nb_solid_kmers; d.nb_branching = idx->info.nb_branching; d.nb_saturated = idx->info.nb_saturated;
+    d.n_words = idx->dev.us.nwords; d.n_unitigs = idx->dev.us.nunitigs;
+    d.words.clear(); d.ab.clear(); d.left_k.clear(); d.left_a.clear();
+    if (d.n_words) { d.words.assign(idx->dev.us.words, idx->dev.us.words + d.n_words + 8); d.ab.assign(idx->dev.us.ab, idx->dev.us.ab + (d.n_words + 8) * 32); }
+    uint32_t lines = 0;
     const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
     for (uint64_t s = 0; s < nslots; s++) {
         uint64_t c;
         const uint32_t ab = abnd_slot_kmer(idx->dev.abnd, s, c);
-        if (ab) { k.push_back(c); a.push_back(ab); }
+        if (ab && !(idx->dev.us.nwords && kmer_stored(idx->dev, c, lines))) { d.left_k.push_back(c); d.left_a.push_back(ab); }
     }
+    return MTG_OK;
+}
+/* every solid k-mer of a dump: the stored ones expanded, then the others */
+static void dump_kmers(const IndexDump& d, std::vector<uint64_t>& km, std::vector<uint32_t>& ab)
+{
+    const uint64_t mk = kmask(d.k);
+    for (uint64_t h = 0; h < d.n_words;) {
+        const uint64_t len = d.words[h];
+        for (uint64_t i = 0; i + d.k <= len; i++) {
+            const uint64_t p = (h + 1) * 32 + i, lo = d.words[p >> 5] >> (2 * (p & 31)), hi = (p & 31) ? d.words[(p >> 5) + 1] << (64 - 2 * (p & 31)) : 0;
+            const uint64_t r = ((lo | hi) & mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk), f = revcomp(r, d.k);
+            km.push_back(f < r ? f : r);
+            ab.push_back(d.ab[p]);
+        }
+        h += 1 + (len + 31) / 32;
+    }
+    km.insert(km.end(), d.left_k.begin(), d.left_k.end());
+    ab.insert(ab.end(), d.left_a.begin(), d.left_a.end());
+}
+int index_from_dump(const IndexDump& d, mtg_index** out)
+{
+    /* the emulation rebuilds from the k-mers (its tables are host memory); the device build derives the tables from the store itself */
+    std::vector<uint64_t> km;
+    std::vector<uint32_t> ab;
+    dump_kmers(d, km, ab);
+    if (km.size() != d.nb_solid) { set_error("index container: %zu k-mers, %llu announced", km.size(), (unsigned long long)d.nb_solid); return MTG_ERR_FORMAT; }
+    if (int rc = index_from_kmers(km.data(), ab.data(), km.size(), d.k, out)) return rc;
+    (*out)->info.abundance_min = d.abundance_min;
+    (*out)->info.abundance_auto = d.abundance_auto;
+    return MTG_OK;
+}
+int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink)
+{
+    std::vector<uint64_t> k;
+    std::vector<uint32_t> a;
+    IndexDump d;
+    index_dump(idx, d);
+    dump_kmers(d, k, a);
     if (k.size() != idx->info.nb_solid_kmers) { set_error("index export: %zu k-mers in the table, %llu expected", k.size(), (unsigned long long)idx->info.nb_solid_kmers); return MTG_ERR_FORMAT; }
     const size_t piece = 1000; /* several pieces, like the device build */
     for (size_t off = 0; off < k.size(); off += piece)

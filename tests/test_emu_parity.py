@@ -744,9 +744,45 @@ def test_snp_fast_path_adversarial(k):
         idx.close()
 
 
+def _container_v3_kmers(raw, k):
+    """(canonical k-mers, abundances) of a version 3 index container: the stored unitigs expanded + the k-mers of no unitig"""
+    assert raw[:8] == b"MTGIDX3\0"
+    kk, amin, aauto, _ = struct.unpack("<4i", raw[8:24])
+    nb_solid, nb_br, nb_sat, n_words, n_unitigs, n_left = struct.unpack("<6Q", raw[24:72])
+    assert kk == k
+    nw = n_words + 8 if n_words else 0
+    words = np.frombuffer(raw[72:72 + 8 * nw], dtype="<u8")
+    ab = np.frombuffer(raw[72 + 8 * nw:72 + 40 * nw], dtype=np.uint8)
+    rec = np.frombuffer(raw[72 + 40 * nw:], dtype=np.dtype([("k", "<u8"), ("a", "<u4")]))
+    assert len(rec) == n_left
+    km, ct = [int(x) for x in rec["k"]], [int(x) for x in rec["a"]]
+    h, nu = 0, 0
+    while h < n_words:
+        ln = int(words[h])
+        codes = []
+        for i in range(ln):
+            p = (h + 1) * 32 + i
+            codes.append((int(words[p >> 5]) >> (2 * (p & 31))) & 3)
+        for i in range(ln - k + 1):
+            f = 0
+            for c in codes[i:i + k]:
+                f = (f << 2) | c
+            r = 0
+            for c in reversed(codes[i:i + k]):
+                r = (r << 2) | (c ^ 2)
+            km.append(min(f, r))
+            ct.append(int(ab[(h + 1) * 32 + i]))
+        h += 1 + (ln + 31) // 32
+        nu += 1
+    assert nu == n_unitigs and len(km) == nb_solid
+    return np.array(km, dtype=np.uint64), np.array(ct, dtype=np.uint32), n_unitigs
+
+
 def test_index_container_written_from_the_tables(emu_product, tmp_path, monkeypatch):
-    """mtg_index_save reads the solid k-mers back from the ABND table (lossless bucket + tag, inverted hash): the file holds exactly the
-    k-mers and abundances the index was built from (version 2 container, any order), loads again, and a version 1 file still loads"""
+    """mtg_index_save writes the index as it is (version 3 container): the unitig store -- 2-bit sequences and one abundance byte per k-mer --
+    and the k-mers of no stored unitig (read back from the ABND table: lossless bucket + tag, inverted hash).  Together they are exactly the
+    k-mers and abundances the index was built from; the file loads again (tables derived from the store), and files of versions 1 and 2
+    (k-mer lists) still load"""
     rng = random.Random(8)
     for k in (31, 21, 12):
         seqs = [_rand_seq(rng, rng.randrange(k, 900)) for _ in range(6)]
@@ -758,22 +794,32 @@ def test_index_container_written_from_the_tables(emu_product, tmp_path, monkeypa
         assert g.info()["nb_saturated"] == int((ct > 255).sum()) > 0  # counts above the ceiling are reported, not silently clamped
         p = str(tmp_path / ("i%d.mtgidx" % k))
         g.save(p)
-        raw = open(p, "rb").read()
-        assert raw[:8] == b"MTGIDX2\0"
-        n = struct.unpack("<Q", raw[24:32])[0]
-        assert n == len(km)
-        rec = np.frombuffer(raw[32:], dtype=np.dtype([("k", "<u8"), ("a", "<u4")]))
-        order = np.argsort(rec["k"])
-        assert (rec["k"][order] == np.sort(km)).all()
-        assert (rec["a"][order] == np.minimum(ct[np.argsort(km)], 255)).all()
-        monkeypatch.setenv("MTG_LOAD_PIECE", "100")  # the reader hands the records over in pieces
+        fk, fa, nu = _container_v3_kmers(open(p, "rb").read(), k)
+        assert nu == g.info()["nb_unitigs"] > 0
+        order = np.argsort(fk)
+        assert (fk[order] == np.sort(km)).all()
+        assert (fa[order] == np.minimum(ct[np.argsort(km)], 255)).all()
         h = emu_product.Index.load(p)
         q = np.concatenate([km, np.array([rng.getrandbits(2 * k) for _ in range(300)], dtype=np.uint64)])
         assert (h.abundance(q) == g.abundance(q)).all()
+        hs, hp = h.neighbors(q)
+        gs, gp = g.neighbors(q)
+        assert (hs == gs).all() and (hp == gp).all() and h.info()["nb_unitigs"] == nu
         _write_idx(str(tmp_path / "v1.mtgidx"), km, ct, k=k)
         v1 = emu_product.Index.load(str(tmp_path / "v1.mtgidx"))
         assert (v1.abundance(q) == g.abundance(q)).all()
-        for x in (g, h, v1):
+        with open(str(tmp_path / "v2.mtgidx"), "wb") as f:  # version 2: (k-mer, abundance) records
+            f.write(b"MTGIDX2\0" + struct.pack("<4i", k, 3, -1, 0) + struct.pack("<Q", len(km)))
+            f.write(np.rec.fromarrays([km, ct.astype(np.uint32)], dtype=np.dtype([("k", "<u8"), ("a", "<u4")])).tobytes())
+        monkeypatch.setenv("MTG_LOAD_PIECE", "100")  # the reader hands the records over in pieces
+        v2 = emu_product.Index.load(str(tmp_path / "v2.mtgidx"))
+        assert (v2.abundance(q) == g.abundance(q)).all()
+        # a damaged container is refused, not half-loaded
+        raw = open(p, "rb").read()
+        open(str(tmp_path / "cut.mtgidx"), "wb").write(raw[:-5])
+        with pytest.raises(Exception):
+            emu_product.Index.load(str(tmp_path / "cut.mtgidx"))
+        for x in (g, h, v1, v2):
             x.close()
         o.close()
 
