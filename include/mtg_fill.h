@@ -273,6 +273,7 @@ typedef struct mtg_batch_stats {
     uint64_t coverage_direct_kmers; /* of coverage_kmers: abundance bytes read at places known from the copy commands (no look-up, nothing to verify) */
     double finish_kernel_ms;     /* HIP-event time of the finishing kernel (k_finish: parked gaps resumed by groups of lanes, bubbles resolved from LDS) */
     uint64_t n_parked_gaps;      /* gaps the walk kernel parked at a branching node that is not the strict SNP pattern */
+    uint64_t n_rounds;           /* bubble rounds queued between launches of the walk kernel (0: the parked gaps went straight to k_finish) */
     uint64_t n_lean_gaps;        /* gaps whose contig was never materialised: target located in the unitig store, coverage and ASCII read off the store */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);

@@ -26,8 +26,9 @@
 
 namespace mtg {
 
-/* capacities of the LDS form (anything larger is answered "too big") */
-enum { BL_SEEN = 128, BL_FL = 24, BL_INV = 48, BL_ISEEN = 64, BL_IFL = 12, BL_FR = 32, BL_NT = 128, BL_CONS = 8, BL_CLEN = 128, BL_MARKS = 48 };
+/* capacities of the LDS form (anything larger is answered "too big").  The area of a gap is what limits how many gaps a compute unit serves
+ * at a time (160 KB of LDS), and the bubbles of real data are small: a frontline of two or three nodes, a few dozen nodes seen. */
+enum { BL_SEEN = 64, BL_FL = 12, BL_INV = 24, BL_ISEEN = 32, BL_IFL = 6, BL_FR = 16, BL_NT = 96, BL_CONS = 4, BL_CLEN = 96 };
 
 struct FlNode { /* a frontline node: oriented k-mer, its place in the unitig store (rp_pack, 0 = unknown), nodes ahead in its unitig, node_aux */
     uint64_t f, rp;
@@ -42,16 +43,15 @@ struct DfsFrame {
     uint32_t ra, dep, xsn, kid, mask, pad_;
 };
 struct BubbleLds {
-    uint64_t inv[BL_INV];     /* involved nodes that are not known to be simple (canonical k-mers): candidates for marking */
-    uint64_t marks[BL_MARKS]; /* the branching ones among them (the plan; applied by apply_marks) */
+    uint64_t inv[BL_INV];     /* involved nodes that are not known to be simple (canonical k-mers): candidates for marking; once the bubble is
+                                 answered, its first n_marks entries are the nodes to mark (the plan; applied by coop_apply_marks) */
     uint8_t invbr[BL_INV];
-    uint32_t n_inv, n_marks, n_seen, n_iseen;
+    uint32_t n_marks, pad_;
     union {
         struct { /* find_end_of_branching */
             uint64_t seen[BL_SEEN];
             FlNode fl[2][BL_FL];
             FlExp ex[BL_FL];
-            uint64_t itc[64];        /* candidates of the chunk being expanded, by lane of the group (canonical k-mer + 1, 0 = none) */
             uint64_t iseen[BL_ISEEN];
             FlNode ifl[2][BL_IFL];
             FlExp iex[BL_IFL];
@@ -77,6 +77,7 @@ template <int G> struct Grp {
     static bool any(bool p) { return p; }
     static bool all(bool p) { return p; }
     static uint32_t min32(uint32_t v) { return v; }
+    static uint64_t from_lane64(uint64_t v, int) { return v; }
     static void sync() {}
 };
 MTG_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
@@ -99,6 +100,13 @@ template <int G> struct Grp {
     {
         for (int m = G / 2; m >= 1; m >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)v, m, 64); v = y < v ? y : v; }
         return v;
+    }
+    /* the value lane j of the group holds */
+    MTG_DEV static uint64_t from_lane64(uint64_t v, int j)
+    {
+        const int src = (int)(lane() & ~(uint32_t)(G - 1)) + j;
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+        return ((uint64_t)hi << 32) | lo;
     }
     /* what the lanes of the group wrote to their LDS area is visible to its other lanes: they are lanes of one wave, whose LDS operations
      * execute in order; the fences keep the compiler from moving the accesses */
@@ -263,7 +271,7 @@ template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uin
                     n_inv += (uint32_t)popc64(ib);
                     GP::sync();
                 }
-                if (n_iseen > (uint32_t)BL_ISEEN * 3u / 4u || n_inv > (uint32_t)BL_INV) return COOP_BIG_CHECK;
+                if (n_iseen > (uint32_t)BL_ISEEN * 3u / 4u || n_inv > (uint32_t)BL_INV || (nnext > BL_IFL && nnext <= 10)) return COOP_BIG_CHECK;
             }
             if (!cont) break;
             cur ^= 1; ncur = nnext; remaining = ncur; depth++;
@@ -398,17 +406,17 @@ template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, con
                         cand = !lset_has(L.a.seen, BL_SEEN, cy);
                     }
                 }
-                /* a node reached twice in this chunk: the first one in (node, nucleotide) order stands, as in the one-lane form */
-                L.a.itc[gl] = cand ? cy + 1 : 0ull;
-                GP::sync();
+                /* a node reached twice in this chunk: the first one in (node, nucleotide) order stands, as in the one-lane form (every
+                 * candidate's k-mer is passed round the group) */
                 uint64_t cb = GP::ballot(cand);
-                if (cand) {
-                    uint64_t mlow = cb & ((1ull << gl) - 1ull);
-                    while (mlow) {
-                        const int b2 = ctz64(mlow);
-                        if (L.a.itc[b2] == cy + 1) { cand = false; break; }
-                        mlow &= mlow - 1ull;
+                {
+                    bool dup = false;
+                    for (uint64_t m = cb; m; m &= m - 1ull) {
+                        const int b2 = ctz64(m);
+                        const uint64_t other = GP::from_lane64(cy, b2);
+                        if ((uint32_t)b2 < gl && other == cy) dup = true;
                     }
+                    if (dup) cand = false;
                 }
                 cb = GP::ballot(cand);
                 if (GP::any(cand && W.is_marked(cy))) return COOP_FAIL; /* the bubble touches an assembled region */
@@ -428,6 +436,7 @@ template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, con
                 n_inv += (uint32_t)popc64(ib);
                 GP::sync();
                 if (nnext > W.cfg.mono_max_breadth) return COOP_FAIL; /* the one-lane form finishes the level first; nothing it does there changes the answer */
+                if (nnext > BL_FL) return COOP_TOOBIG;
                 if (n_seen > (uint32_t)BL_SEEN * 3u / 4u || n_inv > (uint32_t)BL_INV) return COOP_TOOBIG;
             }
         }
@@ -668,7 +677,7 @@ template <int G> MTG_DEV_NOINLINE int coop_validate(Worker& W, BubbleLds& L, int
 }
 
 /* [MEM] MonumentTraversal::explore_branching by the group: the plan.  Returns the length of the chosen consensus (its nucleotides in
- * L.b.cons[chosen], the nodes to mark in L.marks[0, L.n_marks)), COOP_FAIL (the one-lane form would return 0) or COOP_TOOBIG.  Nothing
+ * L.b.cons[chosen], the nodes to mark in L.inv[0, L.n_marks)), COOP_FAIL (the one-lane form would return 0) or COOP_TOOBIG.  Nothing
  * outside L is written: apply_marks makes the plan effective. */
 template <int G> MTG_DEV_NOINLINE int coop_explore(Worker& W, BubbleLds& L, const Kmer& cur, uint64_t prev_c, int& chosen)
 {
@@ -697,7 +706,7 @@ template <int G> MTG_DEV_NOINLINE int coop_explore(Worker& W, BubbleLds& L, cons
     }
     GP::sync();
     uint32_t nm = 0;
-    for (uint32_t i = 0; i < n_inv; i++) if (L.invbr[i]) { if (gl == 0) L.marks[nm] = L.inv[i]; nm++; }
+    for (uint32_t i = 0; i < n_inv; i++) if (L.invbr[i]) { if (gl == 0) L.inv[nm] = L.inv[i]; nm++; } /* compacted in place: nm <= i */
     if (gl == 0) L.n_marks = nm;
     GP::sync();
     return (int)L.b.len[chosen];
@@ -705,7 +714,7 @@ template <int G> MTG_DEV_NOINLINE int coop_explore(Worker& W, BubbleLds& L, cons
 template <int G> MTG_DEV void coop_apply_marks(Worker& W, BubbleLds& L)
 {
     const uint32_t nm = L.n_marks;
-    for (uint32_t i = 0; i < nm; i++) W.mark_canon(L.marks[i]);
+    for (uint32_t i = 0; i < nm; i++) W.mark_canon(L.inv[i]);
 }
 
 } // namespace mtg

@@ -410,18 +410,39 @@ __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 #define MTG_WALK_WAVES 2
 #endif
 #define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
-struct ParkList { /* device: the work list of one launch; the `count` slot numbers follow it */
-    uint32_t count;   /* gaps parked by k_stage_a */
-    uint32_t ticket;  /* next entry to hand out in k_finish */
-    uint32_t pad_[2];
+/* device: the work lists of one launch.  count[i] = entries of list i; list i = cap slot numbers at lists + i * cap.  List 2r holds the gaps
+ * parked by the r-th launch of the walk kernel (at a branching node), list 2r + 1 those of them whose bubble did not fit the LDS areas. */
+enum { PARK_LISTS = 16 };
+struct ParkCtl {
+    uint32_t count[PARK_LISTS];
 };
-__device__ __forceinline__ uint32_t* park_slots(ParkList* p) { return reinterpret_cast<uint32_t*>(p + 1); }
+__device__ __forceinline__ uint32_t* park_list(ParkCtl* p, uint32_t cap, uint32_t i) { return reinterpret_cast<uint32_t*>(p + 1) + (size_t)i * cap; }
+/* the lanes of a wave that park their gap append it to a list: one atomic per wave, the places from a ballot and a prefix popcount */
+__device__ __forceinline__ void park_append(ParkCtl* park, uint32_t cap, uint32_t list, bool parked, uint32_t slot)
+{
+    const unsigned long long pm = __ballot(parked);
+    if (!pm) return;
+    const int leader = __ffsll((long long)pm) - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&park->count[list], (uint32_t)__popcll(pm));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (parked) park_list(park, cap, list)[base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = slot;
+}
+/* one gap per lane.  in_list < 0: the gaps of the launch, from their source k-mers; otherwise the gaps of that work list, resumed (a bubble
+ * kernel has answered the branching node they stand on).  out_list: where the gaps that park (again) go. */
 template <int MODE>
 __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
-                                             const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset, ParkList* park)
+                                             const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset,
+                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t slot = t;
+    if (in_list < 0) { if (t >= n) return; }
+    else {
+        if (t >= park->count[in_list]) return;
+        slot = park_list(park, cap, (uint32_t)in_list)[t];
+    }
     const Index& ix = c_ix[cset]; /* cset is a kernel argument: still scalar loads */
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
@@ -432,56 +453,76 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
     R.rlen = rlen[g];
     R.r0 = r0[g];
     GapOut o;
-    stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr);
+    stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr, in_list >= 0);
     out[slot] = o;
-    if (MODE == WALK_PARK) {
-        const bool parked = o.status == GAP_PARKED;
-        const unsigned long long pm = __ballot(parked);
-        if (pm) {
-            const int leader = __ffsll((long long)pm) - 1;
-            const uint32_t lane = threadIdx.x & 63u;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&park->count, (uint32_t)__popcll(pm));
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            if (parked) park_slots(park)[base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = slot;
-        }
-    }
+    if (MODE == WALK_PARK) park_append(park, cap, out_list, o.status == GAP_PARKED, slot);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                                GapOut* out, uint32_t n, uint32_t cset, ParkList* park)
+                                                GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
 {
-    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park);
+    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list);
 }
 __global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                 GapOut* out, uint32_t n, uint32_t cset)
 {
-    stage_a_lane<WALK_CLASSIC>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, nullptr);
+    stage_a_lane<WALK_CLASSIC>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, nullptr, 0, -1, 0);
 }
-/* the parked gaps of a launch, one group of G lanes each: group i of the grid takes entry i of the work list.  The grid is sized for the
- * worst case (every gap of the launch parked: the host does not know the count when it queues the kernel); a group without an entry
- * leaves at once.  (A loop over tickets around the walk -- fewer, longer-lived groups -- made this very large kernel hang on the device in
- * every build but the instrumented one; the straight-line form has no control flow around the walk.) */
+/* ---- the rounds between two launches of the walk kernel: the branching nodes of the parked gaps, answered on their own.
+ * k_bubble: a group of G lanes per gap of list `in_list`, frontier expansion and path enumeration from LDS (mtg_bubble.h); a bubble that does
+ * not fit the LDS areas sends its gap to list in_list + 1, where k_bubble_classic answers it with one lane from HBM scratch. */
+#ifndef MTG_BUBBLE_WAVES
+#define MTG_BUBBLE_WAVES 4
+#endif
+template <int G>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_BUBBLE_WAVES))) k_bubble(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
+{
+    __shared__ BubbleLds lds[64 / G];
+    const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1);
+    const uint32_t t = blockIdx.x * (64u / (uint32_t)G) + lane / (uint32_t)G;
+    if (t >= park->count[in_list]) return;
+    const Index& ix = c_ix[cset];
+    const FillCfg& cfg = c_cfg[cset];
+    const uint32_t slot = park_list(park, cap, in_list)[t];
+    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    const bool done = bubble_coop<G>(ix, cfg, S, lds[lane / G]);
+    if (!done && gl == 0) park_list(park, cap, in_list + 1)[atomicAdd(&park->count[in_list + 1], 1u)] = slot;
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_bubble_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= park->count[in_list]) return;
+    const Index& ix = c_ix[cset];
+    const FillCfg& cfg = c_cfg[cset];
+    const uint32_t slot = park_list(park, cap, in_list)[t];
+    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    bubble_classic(ix, cfg, S);
+}
+/* the gaps that are still parked after the rounds (all of them when there are no rounds), one group of G lanes each, to the end of their
+ * walks: group i of the grid takes entry i of the list.  The grid is sized for the worst case (the host does not know the count when it
+ * queues the kernel); a group without an entry leaves at once.  (A loop over tickets around the walk -- fewer, longer-lived groups -- made
+ * this very large kernel hang on the device in every build but an instrumented one; the straight-line form has no control flow around the walk.) */
 #ifndef MTG_FINISH_WAVES
 #define MTG_FINISH_WAVES 2
 #endif
 template <int G>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FINISH_WAVES))) k_finish(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
-                                               const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t cset, ParkList* park)
+                                               const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t cset,
+                                               ParkCtl* park, uint32_t cap, uint32_t in_list)
 {
     __shared__ BubbleLds lds[64 / G];
     const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1);
     const uint32_t t = blockIdx.x * (64u / (uint32_t)G) + lane / (uint32_t)G;
-    if (t >= park->count) return;
+    if (t >= park->count[in_list]) return;
 #ifdef MTG_FINISH_ONE_LANE /* diagnostics: the group is its first lane alone (needs -DMTG_COOP_OFF) */
     if (gl != 0) return;
 #endif
     const Index& ix = c_ix[cset];
     const FillCfg& cfg = c_cfg[cset];
-    const uint32_t slot = park_slots(park)[t];
+    const uint32_t slot = park_list(park, cap, in_list)[t];
     const uint32_t g = ids ? ids[slot] : slot;
     GapScratch S = carve(cfg, zero, raw, ilv, slot);
     S.snp_fast = 1;
@@ -1723,7 +1764,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_fil.alloc(chunk * sizeof(mtg_filled)));
         HIP_TRY(d_rlist.alloc(chunk * 4));
         HIP_TRY(d_glist.alloc(chunk * 4));
-        HIP_TRY(d_park.alloc(chunk * 4 + sizeof(ParkList)));
+        HIP_TRY(d_park.alloc((size_t)chunk * 4 * PARK_LISTS + sizeof(ParkCtl)));
         HIP_TRY(d_seq.alloc(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64))); /* a caller's device buffer is written in place */
         HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
         /* dense words / metadata: only the gaps that need the host bring their contigs back; sized by the last need, grown on demand below */
@@ -1758,33 +1799,46 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
             static const bool classic_walk = getenv("MTG_CLASSIC_WALK") != nullptr; /* A/B hook: every bubble by its lane, from HBM scratch */
-            static const int finish_g = getenv("MTG_FINISH_G") ? atoi(getenv("MTG_FINISH_G")) : 16; /* lanes per parked gap: 8, 16, 32 or 64 */
-            if (!classic_walk) HIP_TRY(hipMemsetAsync(d_park.p, 0, 16, stream));
-            HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel alone, evf .. ev1 = the finishing kernel */
+            static const int finish_g = getenv("MTG_FINISH_G") ? atoi(getenv("MTG_FINISH_G")) : 16; /* lanes per parked gap: 8, 16 or 64 */
+            static const int env_rounds = getenv("MTG_ROUNDS") ? atoi(getenv("MTG_ROUNDS")) : -1;
+            /* Rounds: when many gaps park (bubbles all over the data), their branching nodes are answered by the bubble kernels and the walks go
+             * on in the walk kernel, one gap per lane again -- walking is cheap at full width, only the bubbles need a group -- for a few
+             * rounds; what is still parked then (and everything, when few gaps park) is finished by groups in k_finish.  The host does not
+             * know the counts when it queues the kernels: the number of rounds follows the previous launch of this workspace. */
+            int rounds = env_rounds >= 0 ? env_rounds : ((uint64_t)ws.park_hint * 50 > m ? 3 : 0);
+            if (rounds > (PARK_LISTS - 2) / 2) rounds = (PARK_LISTS - 2) / 2;
+            ParkCtl* const park = d_park.as<ParkCtl>();
+            if (!classic_walk) HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream));
+            HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
             if (classic_walk) {
                 hipLaunchKernelGGL(k_stage_a_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
                                    d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset);
                 HIP_TRY(hipEventRecord(evf, stream));
             } else {
                 hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, d_park.as<ParkList>());
+                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
                 HIP_TRY(hipEventRecord(evf, stream));
-                /* the grid is sized without knowing how many gaps were parked: one group per gap of the launch, those without an entry
-                 * of the work list leave at once */
                 static const bool skip_finish = getenv("MTG_DEBUG_SKIP_FINISH") != nullptr; /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 const uint32_t per_wg = 64u / (uint32_t)finish_g;
-                const uint32_t nwg = (m + per_wg - 1) / per_wg;
-#define MTG_LAUNCH_FINISH(GG) hipLaunchKernelGGL(k_finish<GG>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, d_park.as<ParkList>())
-                if (!skip_finish) switch (finish_g) {
-#ifdef MTG_FINISH_ALL_G /* experiments: every group size */
-                    case 8: MTG_LAUNCH_FINISH(8); break;
-                    case 32: MTG_LAUNCH_FINISH(32); break;
-#endif
-                    case 64: MTG_LAUNCH_FINISH(64); break;
-                    default: MTG_LAUNCH_FINISH(16); break;
+                const uint32_t nwg = (m + per_wg - 1) / per_wg; /* one group per gap of the launch: those without an entry of the list leave at once */
+                for (int r = 0; r < rounds; r++) {
+                    const uint32_t lin = 2u * (uint32_t)r;
+                    switch (finish_g) {
+                        case 8: hipLaunchKernelGGL(k_bubble<8>, dim3((m + 7) / 8), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
+                        case 64: hipLaunchKernelGGL(k_bubble<64>, dim3(m), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
+                        default: hipLaunchKernelGGL(k_bubble<16>, dim3((m + 3) / 4), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
+                    }
+                    hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin + 1);
+                    hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
                 }
-#undef MTG_LAUNCH_FINISH
-                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 4, hipMemcpyDeviceToHost, stream)); /* how many were parked (statistics) */
+                const uint32_t lfin = 2u * (uint32_t)rounds;
+                if (!skip_finish) switch (finish_g) {
+                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3((m + 7) / 8), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(m), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                }
+                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, stream)); /* how many were parked: statistics, and the hint for the next launch */
             }
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
@@ -1947,7 +2001,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
             HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
             st.finish_kernel_ms += msf;
-            if (!classic_walk) st.n_parked_gaps += *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot));
+            if (!classic_walk) { const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot)); st.n_parked_gaps += np; st.n_rounds += (uint64_t)rounds; if (tier == 0 && identity) ws.park_hint = np; }
             HIP_TRY(hipEventElapsedTime(&msc, ev1, evc));
             HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
             st.copy_kernel_ms += msc;

@@ -36,6 +36,7 @@ struct Workspace {
     size_t hcap[NHOST] = {0};
     void* stream = nullptr;      /* hipStream_t of the batch's copies in and kernels */
     void* copy_stream = nullptr; /* hipStream_t for the copies back of a batch's parts */
+    uint32_t park_hint = 0; /* gaps the walk kernel parked in this workspace's previous whole-batch launch: how many rounds the next one queues */
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
 }

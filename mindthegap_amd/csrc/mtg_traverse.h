@@ -103,8 +103,9 @@ MTG_ARR(CopyCmd, s_cmd, r, c.o_cmd)
  * built so far, the queue and the copy commands are in the gap's raw block, the marked set in its zero block. */
 struct WalkSave {
     uint64_t cur_f, prev_c, start_f, acc, start_base, r_base, msig[4];
-    uint32_t len, c_first, nacc, wpos, head, tail, nb, total_nt, start_idx, r_idx, ncmd, copy_words, store_reads, run_nt, lines, n_marked, flags, pad_;
-    int32_t node_depth, pad2_;
+    uint32_t len, c_first, nacc, wpos, head, tail, nb, total_nt, start_idx, r_idx, ncmd, copy_words, store_reads, run_nt, lines, n_marked, flags;
+    uint32_t answered;  /* 1: a bubble kernel has answered the branching node the walk stands on: bn, bchosen, the consensus in the gap's s_cons area */
+    int32_t node_depth, bn, bchosen, pad_;
 };
 MTG_ARR(WalkSave, s_save, r, c.o_save)
 /* A gap whose only contig holds the target at a place known without looking at the contig (the target's k-mer sits in a stored unitig, and the
@@ -1581,7 +1582,7 @@ inline void coop_tally(int n)
 }
 #endif
 template <int MODE, int G>
-MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLds* L)
+MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLds* L, bool resume = (MODE == WALK_FINISH))
 {
     Worker W(ix, cfg, S);
     W.no_dp = MODE == WALK_PARK;
@@ -1617,7 +1618,7 @@ MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch&
     };
 
     int head = 0, tail = 0;
-    if (MODE != WALK_FINISH) {
+    if (!resume) {
         q_f[0] = src_f;
         q_c[0] = canon(make_kmer(src_f, k));
         q_d[0] = 0;
@@ -1836,10 +1837,13 @@ MTG_UNROLL
         len += nbulk;
     };
     /* ---- a parked walk goes on where it stopped: at the branching node, the SNP attempt behind it */
-    bool resuming = false, parked = false;
-    if (MODE == WALK_FINISH) {
+    bool resuming = false, parked = false, answered = false;
+    int saved_n = 0, saved_chosen = -1;
+    if (resume) {
         const WalkSave sv = *s_save(cfg, S);
         resuming = true;
+        answered = sv.answered != 0;
+        saved_n = sv.bn; saved_chosen = sv.bchosen;
         cur = make_kmer(sv.cur_f, k);
         prev_c = sv.prev_c;
         const Kmer st = make_kmer(sv.start_f, k);
@@ -1848,6 +1852,8 @@ MTG_UNROLL
         start_base = sv.start_base; start_idx = sv.start_idx;
         r_base = sv.r_base; r_idx = sv.r_idx;
         found_R = (sv.flags & 1u) != 0; r_fwd = (sv.flags & 2u) != 0; r_known = (sv.flags & 4u) != 0;
+        if (sv.flags & 0x80000000u) W.status = GAP_OVF_SEEN; /* the bubble kernel ran out of a work area: the gap is run again in a larger scratch tier */
+        if (sv.flags & 0x40000000u) W.status = 0xBADC;       /* TEST-ONLY emulation: the group form and the one-lane form disagreed */
         len = sv.len; c_first = sv.c_first; node_depth = sv.node_depth;
         head = (int)sv.head; tail = (int)sv.tail; nb = sv.nb; total_nt = sv.total_nt;
         ncmd = sv.ncmd; copy_words = sv.copy_words; store_reads = sv.store_reads; run_nt = sv.run_nt; lines = sv.lines;
@@ -2020,10 +2026,15 @@ MTG_UNROLL
             MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
             bool coop = false;        /* the consensus sits in the group's LDS area */
-            if (!fast) {
+            if (!fast && answered) {
+                /* a bubble kernel has answered this branching node while the gap was parked (the consensus where the one-lane code leaves it) */
+                n = saved_n; chosen = saved_chosen;
+                answered = false;
+            } else if (!fast) {
                 if (MODE == WALK_PARK) {
-                    /* not the strict SNP pattern: the gap is parked here and a group of lanes takes it over (k_finish) */
+                    /* not the strict SNP pattern: the gap is parked here and a group of lanes takes it over (k_bubble / k_finish) */
                     WalkSave sv;
+                    sv.answered = 0; sv.bn = 0; sv.bchosen = -1;
                     sv.cur_f = cur.f; sv.prev_c = prev_c;
                     sv.start_f = ((uint32_t)start_c == start_lo) ? start_c : revcomp(start_c, k); /* the oriented start node, from its canonical form and the low half of its forward form (only the canonical form and the two low halves are used) */
                     sv.acc = acc; sv.nacc = nacc; sv.wpos = wpos;
@@ -2033,7 +2044,7 @@ MTG_UNROLL
                     sv.head = (uint32_t)head; sv.tail = (uint32_t)tail; sv.nb = nb; sv.total_nt = total_nt;
                     sv.ncmd = ncmd; sv.copy_words = copy_words; sv.store_reads = store_reads; sv.run_nt = run_nt; sv.lines = W.lines + lines;
                     sv.n_marked = W.n_marked; sv.msig[0] = W.msig0; sv.msig[1] = W.msig1; sv.msig[2] = W.msig2; sv.msig[3] = W.msig3;
-                    sv.pad_ = 0; sv.pad2_ = 0;
+                    sv.pad_ = 0;
                     *s_save(cfg, S) = sv;
                     parked = true;
                     break;
@@ -2051,8 +2062,8 @@ MTG_UNROLL
                     if (n >= 0 && W.status == GAP_OK) {
                         uint32_t planned_new = 0;
                         for (uint32_t i = 0; i < (n > 0 ? L->n_marks : 0u); i++) {
-                            bool dup = W.is_marked(L->marks[i]);
-                            for (uint32_t j = 0; j < i && !dup; j++) dup = L->marks[j] == L->marks[i];
+                            bool dup = W.is_marked(L->inv[i]);
+                            for (uint32_t j = 0; j < i && !dup; j++) dup = L->inv[j] == L->inv[i];
                             planned_new += dup ? 0u : 1u;
                         }
                         const uint32_t nm0 = W.n_marked;
@@ -2064,7 +2075,7 @@ MTG_UNROLL
                                 same = n2 == n && W.n_marked - nm0 == planned_new;
                                 const SP<uint8_t> p2 = s_cons(cfg, S) + (size_t)ch2 * CONS_LEN;
                                 for (int i = 0; i < n && same; i++) same = p2[i] == L->b.cons[chosen][i];
-                                for (uint32_t i = 0; i < L->n_marks && same; i++) same = W.is_marked(L->marks[i]);
+                                for (uint32_t i = 0; i < L->n_marks && same; i++) same = W.is_marked(L->inv[i]);
                             }
                             if (same && n <= 0) same = W.n_marked == nm0;
                             if (!same) W.status = 0xBADC;
@@ -2229,6 +2240,81 @@ MTG_UNROLL
 MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out)
 {
     stage_a_walk<WALK_CLASSIC, 1>(ix, cfg, S, src_f, R, out, nullptr);
+}
+
+/* ---- the branching node of a parked gap, answered on its own (the rounds between the walk kernel's launches): the walk's state says which
+ * node, the answer goes back into it (WalkSave::answered) and the walk kernel takes it from there.
+ * bubble_coop: by a group of G lanes from LDS; false = too big for the LDS areas (the gap goes to bubble_classic).
+ * bubble_classic: by one lane from HBM scratch. */
+MTG_DEV void bubble_store(const FillCfg& cfg, const GapScratch& S, Worker& W, WalkSave& sv, int n, int chosen)
+{
+    sv.answered = 1; sv.bn = n; sv.bchosen = chosen;
+    sv.n_marked = W.n_marked; sv.msig[0] = W.msig0; sv.msig[1] = W.msig1; sv.msig[2] = W.msig2; sv.msig[3] = W.msig3;
+    sv.lines += W.lines;
+    *s_save(cfg, S) = sv;
+}
+MTG_DEV void bubble_load(Worker& W, const WalkSave& sv)
+{
+    W.n_marked = sv.n_marked; W.msig0 = sv.msig[0]; W.msig1 = sv.msig[1]; W.msig2 = sv.msig[2]; W.msig3 = sv.msig[3];
+}
+template <int G> MTG_DEV bool bubble_coop(const Index& ix, const FillCfg& cfg, const GapScratch& S, BubbleLds& L)
+{
+    typedef Grp<G> GP;
+    WalkSave sv = *s_save(cfg, S);
+    Worker W(ix, cfg, S);
+    bubble_load(W, sv);
+    const Kmer cur = make_kmer(sv.cur_f, ix.k);
+    int chosen = -1;
+    const int n = coop_explore<G>(W, L, cur, sv.prev_c, chosen);
+#ifdef MTG_EMU
+    coop_tally(n);
+#endif
+    if (n < 0) return false;
+#ifdef MTG_EMU /* TEST-ONLY: the general code next to the group form's answer: same verdict, consensus and marks */
+    {
+        uint32_t planned_new = 0;
+        for (uint32_t i = 0; i < (n > 0 ? L.n_marks : 0u); i++) {
+            bool dup = W.is_marked(L.inv[i]);
+            for (uint32_t j = 0; j < i && !dup; j++) dup = L.inv[j] == L.inv[i];
+            planned_new += dup ? 0u : 1u;
+        }
+        Worker W2(ix, cfg, S);
+        bubble_load(W2, sv);
+        const uint32_t nm0 = W2.n_marked;
+        int ch2 = -1;
+        const int n2 = explore_branching(W2, cur, sv.prev_c, ch2);
+        bool same = W2.status != GAP_OK || (n2 > 0) == (n > 0);
+        if (W2.status == GAP_OK && same && n > 0) {
+            same = n2 == n && W2.n_marked - nm0 == planned_new;
+            const SP<uint8_t> p2 = s_cons(cfg, S) + (size_t)ch2 * CONS_LEN;
+            for (int i = 0; i < n && same; i++) same = p2[i] == L.b.cons[chosen][i];
+            for (uint32_t i = 0; i < L.n_marks && same; i++) same = W2.is_marked(L.inv[i]);
+        }
+        if (W2.status == GAP_OK && same && n <= 0) same = W2.n_marked == nm0;
+        if (!same) sv.flags |= 0x40000000u;
+        /* the general code has made the marks: undo them, the group form makes its own below (the same ones) */
+        for (uint32_t i = nm0; i < W2.n_marked; i++) s_marked(cfg, S)[s_marklog(cfg, S)[i]] = 0;
+    }
+#endif
+    if (n > 0) {
+        coop_apply_marks<G>(W, L);
+        /* the consensus where the walk expects it: consensus 0 of the gap's area in HBM (the lanes of the group write it together) */
+        const SP<uint8_t> cons = s_cons(cfg, S);
+        for (int i = (int)GP::gl(); i < n; i += GP::N) cons[(size_t)i] = L.b.cons[chosen][i];
+    }
+    if (GP::gl() == 0) bubble_store(cfg, S, W, sv, n, 0);
+    return true;
+}
+MTG_DEV void bubble_classic(const Index& ix, const FillCfg& cfg, const GapScratch& S)
+{
+    WalkSave sv = *s_save(cfg, S);
+    Worker W(ix, cfg, S);
+    bubble_load(W, sv);
+    const Kmer cur = make_kmer(sv.cur_f, ix.k);
+    int chosen = -1;
+    int n = explore_branching(W, cur, sv.prev_c, chosen);
+    if (W.status) { n = 0; sv.flags |= 0x80000000u; } /* a work area of this scratch tier overflowed: the walk ends the gap with that status */
+    bubble_store(cfg, S, W, sv, n, chosen);
 }
 
 } // namespace mtg

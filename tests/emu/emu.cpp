@@ -8,6 +8,7 @@
 #include "../../mindthegap_amd/csrc/mtg_hostutil.h"
 #include "../../mindthegap_amd/csrc/mtg_copy.h"
 #include "emu_us.h"
+#include "emu_walk.h"
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -90,16 +91,7 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
         pat.words = rw.data();
         pat.rlen = (uint32_t)rl;
         pat.r0 = rl >= (size_t)k ? encode_kmer(R, k) : 0;
-        /* as on the device: the walk kernel parks the gap at the first branching node that is not the strict SNP pattern, the finishing
-         * kernel (a group of one lane here) resumes it with the LDS form of the bubble code; MTG_EMU_CLASSIC=1: the one-lane reference form */
-        if (getenv("MTG_EMU_CLASSIC")) stage_a_gap(e->ix, cfg, S, encode_kmer(source, k), pat, out);
-        else {
-            stage_a_walk<WALK_PARK, 1>(e->ix, cfg, S, encode_kmer(source, k), pat, out, nullptr);
-            if (out.status == GAP_PARKED) {
-                static thread_local BubbleLds lds;
-                stage_a_walk<WALK_FINISH, 1>(e->ix, cfg, S, 0, pat, out, &lds);
-            }
-        }
+        mtg::emu_walk(e->ix, cfg, S, encode_kmer(source, k), pat, out); /* emu_walk.h: the device's launch sequence */
         copy_gap(e->ix, cfg, S, out, ~0ull); /* the device's k_copy */
         /* the device relies on every gap handing the zero region back clean: make a violation visible as a status no test expects */
         for (uint8_t z : zero) if (z) { out.status = 0xDEAD; break; }

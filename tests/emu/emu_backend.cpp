@@ -7,6 +7,7 @@
  */
 #include "../../mindthegap_amd/csrc/mtg_internal.h"
 #include "emu_us.h"
+#include "emu_walk.h"
 #include <map>
 #include <mutex>
 #include <cstdarg>
@@ -344,16 +345,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 R.r0 = in.r0[g];
                 SlotRec& r = recs[s];
                 memset(&r, 0, sizeof r);
-                /* k_stage_a parks the gap at the first branching node that is not the strict SNP pattern, k_finish resumes it */
-                if (getenv("MTG_EMU_CLASSIC")) stage_a_gap(idx->dev, cfg, S, in.src[g], R, r.o);
-                else {
-                    stage_a_walk<WALK_PARK, 1>(idx->dev, cfg, S, in.src[g], R, r.o, nullptr);
-                    if (r.o.status == GAP_PARKED) {
-                        static thread_local BubbleLds lds;
-                        st.n_parked_gaps++;
-                        stage_a_walk<WALK_FINISH, 1>(idx->dev, cfg, S, 0, R, r.o, &lds);
-                    }
-                }
+                st.n_parked_gaps += emu_walk(idx->dev, cfg, S, in.src[g], R, r.o); /* emu_walk.h: the device's launch sequence */
                 {   /* k_copy */
                     uint64_t target = ~0ull;
                     if (!in.want_all_contigs && !getenv("MTG_NO_LEAN") && cfg.cmd_cap && r.o.status == GAP_OK && in.tcnt[g] == 1u && in.fast_ok[g] && tbad[in.toff[g]] == 0ull)
