@@ -160,8 +160,8 @@ template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uin
     const Kmer m = make_kmer(mf, k);
     const Adj l = adj_left(W.ix, m, W.mk1, W.lines);
     if (popc4(l.in) == 1) return 1;
-    for (uint32_t nt = 0; nt < 4; nt++) {
-        if (!(l.in & (1u << nt))) continue;
+    for (uint32_t em = l.in & 15u; em; em &= em - 1u) {
+        const uint32_t nt = low_nt(em);
         const Kmer b = kmer_prev(m, nt, k, W.mk);
         if (lset_has(L.a.seen, BL_SEEN, canon(b))) continue;
         for (uint32_t i = gl; i < (uint32_t)BL_ISEEN; i += GP::N) L.a.iseen[i] = 0;

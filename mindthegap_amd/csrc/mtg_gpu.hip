@@ -415,7 +415,20 @@ __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 enum { PARK_LISTS = 16 };
 struct ParkCtl {
     uint32_t count[PARK_LISTS];
+#ifdef MTG_BUBBLE_TIMING /* diagnostics build: how long the lanes and the waves of the bubble kernels ran (bins of log2 of 10 ns ticks) */
+    uint32_t hist_lane[32], hist_wave[32], hist_walk_lane[32], hist_walk_wave[32];
+#endif
 };
+#ifdef MTG_BUBBLE_TIMING
+__device__ __forceinline__ void timing_note(uint32_t* hl, uint32_t* hw, uint64_t t0)
+{
+    const uint64_t dl = wall_clock64() - t0;
+    atomicAdd(&hl[63 - __clzll((long long)(dl | 1ull))], 1u);
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long act = __ballot(1);
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) { const uint64_t dw = wall_clock64() - t0; atomicAdd(&hw[63 - __clzll((long long)(dw | 1ull))], 1u); }
+}
+#endif
 __device__ __forceinline__ uint32_t* park_list(ParkCtl* p, uint32_t cap, uint32_t i) { return reinterpret_cast<uint32_t*>(p + 1) + (size_t)i * cap; }
 /* the lanes of a wave that park their gap append it to a list: one atomic per wave, the places from a ballot and a prefix popcount */
 __device__ __forceinline__ void park_append(ParkCtl* park, uint32_t cap, uint32_t list, bool parked, uint32_t slot)
@@ -453,7 +466,13 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
     R.rlen = rlen[g];
     R.r0 = r0[g];
     GapOut o;
+#ifdef MTG_BUBBLE_TIMING
+    const uint64_t t0 = wall_clock64();
+#endif
     stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr, in_list >= 0);
+#ifdef MTG_BUBBLE_TIMING
+    if (MODE == WALK_PARK && in_list >= 0) timing_note(park->hist_walk_lane, park->hist_walk_wave, t0);
+#endif
     out[slot] = o;
     if (MODE == WALK_PARK) park_append(park, cap, out_list, o.status == GAP_PARKED, slot);
 }
@@ -499,7 +518,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t slot = park_list(park, cap, in_list)[t];
     GapScratch S = carve(cfg, zero, raw, ilv, slot);
+#ifdef MTG_BUBBLE_TIMING
+    const uint64_t t0 = wall_clock64();
+#endif
     bubble_classic(ix, cfg, S);
+#ifdef MTG_BUBBLE_TIMING
+    timing_note(park->hist_lane, park->hist_wave, t0);
+#endif
 }
 /* the gaps that are still parked after the rounds (all of them when there are no rounds), one group of G lanes each, to the end of their
  * walks: group i of the grid takes entry i of the list.  The grid is sized for the worst case (the host does not know the count when it
@@ -1821,8 +1846,15 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 static const bool skip_finish = getenv("MTG_DEBUG_SKIP_FINISH") != nullptr; /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 const uint32_t per_wg = 64u / (uint32_t)finish_g;
                 const uint32_t nwg = (m + per_wg - 1) / per_wg; /* one group per gap of the launch: those without an entry of the list leave at once */
+                static const bool one_lane_bubbles = getenv("MTG_BUBBLE_ONE_LANE") != nullptr; /* A/B hook: every bubble of the rounds by one lane (all lanes of a wave in the bubble code together) */
                 for (int r = 0; r < rounds; r++) {
                     const uint32_t lin = 2u * (uint32_t)r;
+                    if (one_lane_bubbles) {
+                        hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin);
+                        hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                                           d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
+                        continue;
+                    }
                     switch (finish_g) {
                         case 8: hipLaunchKernelGGL(k_bubble<8>, dim3((m + 7) / 8), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
                         case 64: hipLaunchKernelGGL(k_bubble<64>, dim3(m), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
@@ -1839,6 +1871,19 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                 }
                 HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, stream)); /* how many were parked: statistics, and the hint for the next launch */
+#ifdef MTG_BUBBLE_TIMING
+                {
+                    static ParkCtl hc; static int shown = 0;
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    HIP_TRY(hipMemcpy(&hc, d_park.p, sizeof hc, hipMemcpyDeviceToHost));
+                    if (shown++ < 3) {
+                        fprintf(stderr, "[timing] lists:"); for (int i = 0; i < PARK_LISTS; i++) fprintf(stderr, " %u", hc.count[i]); fprintf(stderr, "\n");
+                        const char* nm[4] = {"bubble lane", "bubble wave", "resumed walk lane", "resumed walk wave"};
+                        const uint32_t* hh[4] = {hc.hist_lane, hc.hist_wave, hc.hist_walk_lane, hc.hist_walk_wave};
+                        for (int j = 0; j < 4; j++) { fprintf(stderr, "[timing] %s, log2(10 ns ticks) bins:", nm[j]); for (int i = 0; i < 24; i++) fprintf(stderr, " %u", hh[j][i]); fprintf(stderr, "\n"); }
+                    }
+                }
+#endif
             }
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
@@ -2036,6 +2081,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     (double)hs[6] / hs[15], (double)hs[12] / hs[15], (double)hs[7] / hs[15], (double)hs[10] / hs[15], (double)hs[14] / hs[15], (double)hs[13] / hs[15], (double)hs[11] / hs[15]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
+        unsigned long long fe[16];
+        if (hipMemcpyFromSymbol(fe, HIP_SYMBOL(mtg::g_fe), sizeof fe) == hipSuccess && fe[0])
+            fprintf(stderr, "  [stamps] find_end_of_branching: %llu calls; per call: levels %.2f nodes %.2f skips %.2f | ticks: skip section %.0f (left junction %.0f) children from the store %.0f ADJ read + run set-up %.0f visited set + involved list %.0f\n",
+                    fe[0], (double)fe[1] / fe[0], (double)fe[7] / fe[0], (double)fe[8] / fe[0], (double)fe[2] / fe[0], (double)fe[3] / fe[0], (double)fe[4] / fe[0], (double)fe[5] / fe[0], (double)fe[6] / fe[0]);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_fe), z, sizeof z);
         unsigned long long lf[40];
         if (hipMemcpyFromSymbol(lf, HIP_SYMBOL(mtg::g_life), sizeof lf) == hipSuccess) {
             fprintf(stderr, "  [stamps] traversal kernel: %llu ticks from the first lane's start to the last lane's end (%.3f ms of events); lanes by log2(life in ticks):", lf[33] - lf[32], st.kernel_ms);

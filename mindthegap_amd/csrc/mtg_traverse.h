@@ -276,6 +276,7 @@ __device__ unsigned int g_dbg[64];
 /* diagnostic build (-DMTG_STAMPS): shader-clock time per phase, summed over lanes into a global array (never in the product build) */
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_fe[16]; /* find_end_of_branching in detail: [0] calls [1] levels [2] skip section [3] left junction [4] children known from the store [5] ADJ read + run set-up [6] visited set + involved list [7] nodes [8] skips */
 __device__ unsigned long long g_life[40]; /* [0..31]: lanes by log2 of their life in clock ticks; [32] earliest start, [33] latest end (0 = unset) */
 #define MTG_T0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
 #define MTG_T1(v, slot) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[slot] += t_ - v; } while (0)
@@ -401,6 +402,10 @@ MTG_DEV uint64_t inv_flags(uint32_t aux) { return (aux & 15u) ? INV_SIMPLE : 0ul
 enum : uint64_t { RP_VALID = 1ull << 63, RP_BWD = 1ull << 62, RP_KPOS = (1ull << 38) - 1 };
 MTG_DEV uint64_t rp_pack(const RunAt& r) { return RP_VALID | (r.bwd ? RP_BWD : 0ull) | ((uint64_t)(r.hdr & 0xFFFFFFu) << 38) | (r.kpos & RP_KPOS); }
 MTG_DEV uint64_t rp_step(uint64_t rp, uint32_t t) { return (rp & ~RP_KPOS) | (((rp & RP_BWD) ? (rp & RP_KPOS) - t : (rp & RP_KPOS) + t) & RP_KPOS); }
+/* lowest set bit of a 4-bit edge mask.  The loops over the edges of a node go from set bit to set bit (ascending nucleotide, as the
+ * reference enumerates) instead of over the four nucleotides: the lanes of a wave then run the loop body -- whose memory reads are what a
+ * trip costs -- together for their first edge, whatever its nucleotide, and not once per nucleotide any lane has. */
+MTG_DEV uint32_t low_nt(uint32_t m) { return (m & 1u) ? 0u : (m & 2u) ? 1u : (m & 4u) ? 2u : 3u; }
 MTG_DEV uint32_t rp_unitig(uint64_t rp) { return (uint32_t)(rp >> 38) & 0xFFFFFFu; } /* 24 bits of the header word: equal unitigs give equal values (a false "equal" only costs speed) */
 
 /* [MEM] gatb FrontlineBranching::check: look for large in-branching at m.
@@ -413,8 +418,8 @@ MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
     Adj l = adj_left(W.ix, m, W.mk1, W.lines);
     /* gatb's "just a speedup": with in-degree 1 the only predecessor is the frontline node m was reached from, which is in the visited set */
     if (popc4(l.in) == 1) return true;
-    for (uint32_t nt = 0; nt < 4; nt++) {
-        if (!(l.in & (1u << nt))) continue;
+    for (uint32_t em = l.in & 15u; em; em &= em - 1u) {
+        const uint32_t nt = low_nt(em);
         Kmer b = kmer_prev(m, nt, k, W.mk);
         if (set_has(s_seen(W.cfg, W.S), W.cfg.seen_cap, canon(b))) continue;
         /* plain frontline from b along predecessors, previous node = m.  Unitig-aware like find_end_of_branching: walking backwards from
@@ -478,8 +483,8 @@ MTG_DEV_NOINLINE bool fl_check(Worker& W, uint64_t mf)
                     RunAt r;
                     if (us.nwords && run_at(us, ar, k, r, W.lines)) { krp = rp_step(rp_pack(r), 1); kra = r.ahead - 1u; }
                 }
-                for (uint32_t n2 = 0; n2 < 4; n2++) {
-                    if (!(in_mask & (1u << n2))) continue;
+                for (uint32_t em = in_mask & 15u; em; em &= em - 1u) {
+                    const uint32_t n2 = low_nt(em);
                     Kmer y = kmer_prev(x, n2, k, W.mk);
                     uint64_t cy = canon(y);
                     if (set_has(s_iseen(W.cfg, W.S), W.cfg.iseen_cap, cy)) continue;
@@ -531,6 +536,16 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
     const bool may_skip = us.nwords != 0 && prev_c != 0;
     uint32_t prev_unitig = 0xFFFFFFFFu; /* unitig of the junction between the previous node and the start, looked up when the first skip is considered */
     bool prev_known = false;
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    struct FeAcc { unsigned long long v[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0}; MTG_DEV ~FeAcc() { for (int i = 0; i < 9; i++) if (v[i]) atomicAdd(&g_fe[i], v[i]); } } fe;
+#define FE_T0(x) unsigned long long x = __builtin_amdgcn_s_memtime()
+#define FE_T1(x, slot) fe.v[slot] += __builtin_amdgcn_s_memtime() - x
+#define FE_N(slot, n) fe.v[slot] += (n)
+#else
+#define FE_T0(x)
+#define FE_T1(x, slot)
+#define FE_N(slot, n)
+#endif
     for (;;) {
         const SP<uint64_t> cf = cur ? s_fl1(W.cfg, W.S) : s_fl0(W.cfg, W.S);
         const SP<uint8_t> cn = cur ? s_flnt1(W.cfg, W.S) : s_flnt0(W.cfg, W.S);
@@ -543,6 +558,7 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
         const SP<uint64_t> nrp = cur ? s_flrp0(W.cfg, W.S) : s_flrp1(W.cfg, W.S);
         const SP<uint32_t> nra = cur ? s_flra0(W.cfg, W.S) : s_flra1(W.cfg, W.S);
         /* ---- the skip */
+        FE_T0(t_sk);
         if (may_skip && ncur >= 2 && ncur <= FL_CAP && depth > 0) {
             uint32_t D = 0xFFFFFFFFu;
             bool ok = true;
@@ -554,7 +570,9 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
             if (ok) {
                 if (!prev_known) { /* the junction between the previous node and the start = the start's left junction */
                     prev_known = true;
+                    FE_T0(t_lj);
                     prev_unitig = left_junction_unitig(W.ix, start, W.mk1, W.lines);
+                    FE_T1(t_lj, 3);
                 }
                 for (int i = 0; i < ncur && ok; i++) {
                     const uint32_t u = rp_unitig(crp[i]);
@@ -574,10 +592,13 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
                 }
                 W.lines += (uint32_t)ncur;
                 depth += (int)D;
+                FE_T1(t_sk, 2); FE_N(8, 1);
                 continue;
             }
         }
+        FE_T1(t_sk, 2);
         /* ---- one level */
+        FE_N(1, 1); FE_N(7, ncur);
         int nnext = 0;
         for (int i = 0; i < ncur; i++) {
             const uint32_t aux = ca[i];
@@ -594,11 +615,13 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
             uint64_t krp = 0; /* the children's place in the store, when the node's right junction lies inside a unitig */
             uint32_t kra = 0;
             const uint64_t rp = crp[i];
+            FE_T0(t_ch);
             if ((rp & RP_VALID) && cra[i] >= 1u) { /* inside a unitig: the way ahead is known */
                 out = 1u << run_next_nt(us, rp & RP_KPOS, (rp & RP_BWD) != 0, k);
                 kid = AUX_IN1;
                 krp = rp_step(rp, 1);
                 kra = cra[i] - 1u;
+                FE_T1(t_ch, 4);
             } else if (aux & 15u) { out = 1u << ((aux >> 4) & 3u); kid = aux_step(aux); } /* inline lookahead: nothing to read */
             else {
                 Adj a = adj_right_t(W.ix.adj, x, W.mk1, W.lines);
@@ -607,9 +630,11 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
                 else adj_resolve_la(W.ix, a, W.lines);
                 out = a.out;
                 kid = aux_of_children(a);
+                FE_T1(t_ch, 5);
             }
-            for (uint32_t nt = 0; nt < 4; nt++) {
-                if (!(out & (1u << nt))) continue;
+            FE_T0(t_set);
+            for (uint32_t em = out & 15u; em; em &= em - 1u) {
+                const uint32_t nt = low_nt(em);
                 Kmer y = kmer_next(x, nt, k, W.mk);
                 uint64_t cy = canon(y);
                 if (!W.seen_test_add(cy)) continue;  /* already explored (on failure below the whole set is discarded anyway) */
@@ -618,6 +643,7 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
                 nnext++;
                 W.involve(cy | ((kid & 15u) || ((krp & RP_VALID) && kra >= 1u) ? INV_SIMPLE : 0ull));
             }
+            FE_T1(t_set, 6);
             if (W.status) return 0;
         }
         cur ^= 1; ncur = nnext; depth++;
@@ -2199,8 +2225,8 @@ MTG_UNROLL
 #ifdef MTG_EMU
         { uint32_t l_ = 0; if (adj_right_t(adj, cur, mk1, l_).out != ea.out) W.status = 0xBADA; }
 #endif
-        for (uint32_t nt = 0; nt < 4; nt++) {
-            if (!(ea.out & (1u << nt))) continue;
+        for (uint32_t em = ea.out & 15u; em; em &= em - 1u) {
+            const uint32_t nt = low_nt(em);
             const Kmer s = kmer_next(cur, nt, k, mk);
             const uint64_t cs = canon(s);
             bool seen = false;
@@ -2315,6 +2341,9 @@ MTG_DEV void bubble_classic(const Index& ix, const FillCfg& cfg, const GapScratc
     int n = explore_branching(W, cur, sv.prev_c, chosen);
     if (W.status) { n = 0; sv.flags |= 0x80000000u; } /* a work area of this scratch tier overflowed: the walk ends the gap with that status */
     bubble_store(cfg, S, W, sv, n, chosen);
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    for (int i = 0; i < 15; i++) if (W.stamp_acc[i]) atomicAdd(&g_stamps[i], W.stamp_acc[i]);
+#endif
 }
 
 } // namespace mtg

@@ -11,6 +11,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 SO = os.path.join(LIBDIR, "libmtgfill.so")
+if os.environ.get("MTG_LIBRARY_PATH"):  # diagnostics: another build of the same HIP library (e.g. with device-side timing compiled in)
+    SO = os.environ["MTG_LIBRARY_PATH"]
 
 ERRORS = {1: "MTG_ERR_NO_DEVICE", 2: "MTG_ERR_ARG", 3: "MTG_ERR_IO", 4: "MTG_ERR_NOMEM", 5: "MTG_ERR_OVERFLOW", 6: "MTG_ERR_FORMAT"}
 

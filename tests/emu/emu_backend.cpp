@@ -9,6 +9,7 @@
 #include "emu_us.h"
 #include "emu_walk.h"
 #include <map>
+#include <memory>
 #include <mutex>
 #include <cstdarg>
 #include <cstdio>
@@ -330,11 +331,19 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* every slot keeps its own scratch until the launch has been emitted, like on the device; the zero region is shared by the
              * slots here (one lane at a time) and must come back clean from every gap */
             std::vector<uint8_t> zero(cfg.zero_stride, 0), ilv(cfg.ilv_stride), fp_table(FP_SLOTS * 64);
-            std::vector<std::vector<uint8_t>> raws(m);
+            /* MTG_EMU_NO_POISON=1 (bench.py's same-algorithm CPU number): the scratch of a slot is not filled with a pattern first -- the fill is
+             * the emulator's check that nothing is read before it is written, and costs more than the walk itself */
+            static const bool poison = getenv("MTG_EMU_NO_POISON") == nullptr;
+            struct RawBuf { uint8_t* p; uint8_t* data() const { return p; } };
+            std::vector<RawBuf> raws(m);
+            static thread_local std::vector<uint8_t> raw_arena; /* kept between launches: a fresh allocation per slot spends its time in page faults */
+            const size_t raw_each = ((size_t)cfg.raw_stride + 64 + 63) & ~(size_t)63;
+            if (raw_arena.size() < raw_each * m) raw_arena.resize(raw_each * m);
             std::vector<SlotRec> recs(m);
             for (uint32_t s = 0; s < m; s++) {
                 const size_t g = ids[s];
-                raws[s].assign(cfg.raw_stride + 64, 0xCD);
+                raws[s].p = raw_arena.data() + raw_each * s;
+                if (poison) memset(raws[s].data(), 0xCD, cfg.raw_stride + 64);
                 memset(fp_table.data(), 0, fp_table.size());
                 GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
                 S.fp = fp_table.data();
