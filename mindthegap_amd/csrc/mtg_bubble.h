@@ -27,8 +27,10 @@
 namespace mtg {
 
 /* capacities of the LDS form (anything larger is answered "too big").  The area of a gap is what limits how many gaps a compute unit serves
- * at a time (160 KB of LDS), and the bubbles of real data are small: a frontline of two or three nodes, a few dozen nodes seen. */
-enum { BL_SEEN = 64, BL_FL = 12, BL_INV = 24, BL_ISEEN = 32, BL_IFL = 6, BL_FR = 16, BL_NT = 96, BL_CONS = 4, BL_CLEN = 96 };
+ * at a time (160 KB of LDS): the bubble kernel of the rounds, which may have every gap of a launch before it, takes the small ones (the bubbles
+ * of heterozygous data: a frontline of two or three nodes, a few dozen nodes seen), the finishing kernel, with a few gaps left, the large ones. */
+struct CapsSmall { enum { SEEN = 64, FL = 12, INV = 24, ISEEN = 32, IFL = 6, FR = 16, NT = 96, CONS = 4, CLEN = 96 }; };
+struct CapsLarge { enum { SEEN = 256, FL = 24, INV = 96, ISEEN = 64, IFL = 12, FR = 32, NT = 128, CONS = 8, CLEN = 128 }; };
 
 struct FlNode { /* a frontline node: oriented k-mer, its place in the unitig store (rp_pack, 0 = unknown), nodes ahead in its unitig, node_aux */
     uint64_t f, rp;
@@ -42,30 +44,33 @@ struct DfsFrame {
     uint64_t f, c, rp;
     uint32_t ra, dep, xsn, kid, mask, pad_;
 };
-struct BubbleLds {
-    uint64_t inv[BL_INV];     /* involved nodes that are not known to be simple (canonical k-mers): candidates for marking; once the bubble is
+template <class C> struct BubbleLdsT {
+    typedef C Caps;
+    uint64_t inv[C::INV];     /* involved nodes that are not known to be simple (canonical k-mers): candidates for marking; once the bubble is
                                  answered, its first n_marks entries are the nodes to mark (the plan; applied by coop_apply_marks) */
-    uint8_t invbr[BL_INV];
+    uint8_t invbr[C::INV];
     uint32_t n_marks, pad_;
     union {
         struct { /* find_end_of_branching */
-            uint64_t seen[BL_SEEN];
-            FlNode fl[2][BL_FL];
-            FlExp ex[BL_FL];
-            uint64_t iseen[BL_ISEEN];
-            FlNode ifl[2][BL_IFL];
-            FlExp iex[BL_IFL];
+            uint64_t seen[C::SEEN];
+            FlNode fl[2][C::FL];
+            FlExp ex[C::FL];
+            uint64_t iseen[C::ISEEN];
+            FlNode ifl[2][C::IFL];
+            FlExp iex[C::IFL];
         } a;
         struct { /* all_consensuses_between + validate_consensuses */
-            uint64_t pset[BL_ISEEN];
-            DfsFrame fr[BL_FR];
-            uint8_t nt[BL_NT + 16];
-            uint8_t cons[BL_CONS][BL_CLEN];
-            uint16_t len[BL_CONS];
-            int32_t sum[BL_CONS];
+            uint64_t pset[C::ISEEN];
+            DfsFrame fr[C::FR];
+            uint8_t nt[C::NT + 16];
+            uint8_t cons[C::CONS][C::CLEN];
+            uint16_t len[C::CONS];
+            int32_t sum[C::CONS];
         } b;
     };
 };
+typedef BubbleLdsT<CapsSmall> BubbleLds;    /* k_bubble */
+typedef BubbleLdsT<CapsLarge> BubbleLdsBig; /* k_finish */
 
 /* ---- a group of lanes: G consecutive lanes of a wave (G a power of two, 64 = the whole wave).  Control flow inside the routines below is
  * uniform over the group; the emulation build has one lane per group. */
@@ -151,7 +156,7 @@ enum { COOP_FAIL = 0, COOP_TOOBIG = -1, COOP_BIG_CHECK = -2, COOP_BIG_DEPTH = -3
 
 /* [MEM] gatb FrontlineBranching::check for the frontline node mf, by the group (one-lane form: fl_check).  1 = passes, 0 = large
  * in-branching, COOP_TOOBIG.  n_inv: the involved list's length (uniform). */
-template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uint64_t mf, uint32_t& n_inv)
+template <int G, class LT> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, LT& L, uint64_t mf, uint32_t& n_inv)
 {
     typedef Grp<G> GP;
     const int k = W.k;
@@ -163,12 +168,12 @@ template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uin
     for (uint32_t em = l.in & 15u; em; em &= em - 1u) {
         const uint32_t nt = low_nt(em);
         const Kmer b = kmer_prev(m, nt, k, W.mk);
-        if (lset_has(L.a.seen, BL_SEEN, canon(b))) continue;
-        for (uint32_t i = gl; i < (uint32_t)BL_ISEEN; i += GP::N) L.a.iseen[i] = 0;
+        if (lset_has(L.a.seen, LT::Caps::SEEN, canon(b))) continue;
+        for (uint32_t i = gl; i < (uint32_t)LT::Caps::ISEEN; i += GP::N) L.a.iseen[i] = 0;
         GP::sync();
         if (gl == 0) {
-            lset_insert(L.a.iseen, BL_ISEEN, canon(b));
-            lset_insert(L.a.iseen, BL_ISEEN, canon(m));
+            lset_insert(L.a.iseen, LT::Caps::ISEEN, canon(b));
+            lset_insert(L.a.iseen, LT::Caps::ISEEN, canon(m));
             FlNode s;
             s.f = b.f; s.rp = 0; s.ra = 0; s.aux = 0;
             L.a.ifl[0][0] = s;
@@ -244,7 +249,7 @@ template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uin
                     if (n2 < 4u && (e.out & (1u << n2))) {
                         y = kmer_prev(x, n2, k, W.mk);
                         cy = canon(y);
-                        cand = !lset_has(L.a.iseen, BL_ISEEN, cy);
+                        cand = !lset_has(L.a.iseen, LT::Caps::ISEEN, cy);
                         /* a sibling with a smaller nucleotide and the same canonical k-mer comes first */
                         for (uint32_t n1 = 0; n1 < n2 && cand; n1++)
                             if ((e.out & (1u << n1)) && canon(kmer_prev(x, n1, k, W.mk)) == cy) cand = false;
@@ -256,22 +261,22 @@ template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uin
                     const uint64_t below = take & ((1ull << gl) - 1ull);
                     if ((take >> gl) & 1ull) {
                         const int pos = nnext + popc64(below);
-                        if (pos < BL_IFL) { FlNode s; s.f = y.f; s.rp = e.krp; s.ra = e.kra; s.aux = 0; nf[pos] = s; }
-                        lset_insert(L.a.iseen, BL_ISEEN, cy);
+                        if (pos < LT::Caps::IFL) { FlNode s; s.f = y.f; s.rp = e.krp; s.ra = e.kra; s.aux = 0; nf[pos] = s; }
+                        lset_insert(L.a.iseen, LT::Caps::ISEEN, cy);
                     }
                     /* involved: only the nodes not known to be simple are remembered */
                     const bool simple = (e.krp & RP_VALID) && e.kra >= 1u;
                     const uint64_t ib = simple ? 0ull : take;
                     if ((ib >> gl) & 1ull) {
                         const uint32_t ipos = n_inv + (uint32_t)popc64(ib & ((1ull << gl) - 1ull));
-                        if (ipos < (uint32_t)BL_INV) L.inv[ipos] = cy;
+                        if (ipos < (uint32_t)LT::Caps::INV) L.inv[ipos] = cy;
                     }
                     nnext += popc64(take);
                     n_iseen += (uint32_t)popc64(take);
                     n_inv += (uint32_t)popc64(ib);
                     GP::sync();
                 }
-                if (n_iseen > (uint32_t)BL_ISEEN * 3u / 4u || n_inv > (uint32_t)BL_INV || (nnext > BL_IFL && nnext <= 10)) return COOP_BIG_CHECK;
+                if (n_iseen > (uint32_t)LT::Caps::ISEEN * 3u / 4u || n_inv > (uint32_t)LT::Caps::INV || (nnext > LT::Caps::IFL && nnext <= 10)) return COOP_BIG_CHECK;
             }
             if (!cont) break;
             cur ^= 1; ncur = nnext; remaining = ncur; depth++;
@@ -286,17 +291,17 @@ template <int G> MTG_DEV_NOINLINE int coop_fl_check(Worker& W, BubbleLds& L, uin
 
 /* [MEM] MonumentTraversal::find_end_of_branching by the group (one-lane form: find_end_of_branching).  Returns the depth (> 0), COOP_FAIL or
  * COOP_TOOBIG; leaves the involved list in L.inv / n_inv. */
-template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, const Kmer& start, uint64_t prev_c, uint64_t& end_f, uint64_t& end_rp, uint32_t& n_inv)
+template <int G, class LT> MTG_DEV_NOINLINE int coop_find_end(Worker& W, LT& L, const Kmer& start, uint64_t prev_c, uint64_t& end_f, uint64_t& end_rp, uint32_t& n_inv)
 {
     typedef Grp<G> GP;
     const int k = W.k;
     const UStore& us = W.ix.us;
     const uint32_t gl = GP::gl();
-    for (uint32_t i = gl; i < (uint32_t)BL_SEEN; i += GP::N) L.a.seen[i] = 0;
+    for (uint32_t i = gl; i < (uint32_t)LT::Caps::SEEN; i += GP::N) L.a.seen[i] = 0;
     GP::sync();
     if (gl == 0) {
-        lset_insert(L.a.seen, BL_SEEN, canon(start));
-        lset_insert(L.a.seen, BL_SEEN, prev_c);
+        lset_insert(L.a.seen, LT::Caps::SEEN, canon(start));
+        lset_insert(L.a.seen, LT::Caps::SEEN, prev_c);
         FlNode s;
         s.f = start.f; s.rp = 0; s.ra = 0; s.aux = 0;
         L.a.fl[0][0] = s;
@@ -403,7 +408,7 @@ template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, con
                     if (e.out & (1u << nt)) {
                         y = kmer_next(make_kmer(cf[node].f, k), nt, k, W.mk);
                         cy = canon(y);
-                        cand = !lset_has(L.a.seen, BL_SEEN, cy);
+                        cand = !lset_has(L.a.seen, LT::Caps::SEEN, cy);
                     }
                 }
                 /* a node reached twice in this chunk: the first one in (node, nucleotide) order stands, as in the one-lane form (every
@@ -424,11 +429,11 @@ template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, con
                 const uint64_t ib = GP::ballot(cand && !simple);
                 if (cand) {
                     const int pos = nnext + popc64(cb & ((1ull << gl) - 1ull));
-                    if (pos < BL_FL) { FlNode s; s.f = y.f; s.rp = e.krp; s.ra = e.kra; s.aux = e.kid; nf[pos] = s; }
-                    lset_insert(L.a.seen, BL_SEEN, cy);
+                    if (pos < LT::Caps::FL) { FlNode s; s.f = y.f; s.rp = e.krp; s.ra = e.kra; s.aux = e.kid; nf[pos] = s; }
+                    lset_insert(L.a.seen, LT::Caps::SEEN, cy);
                     if (!simple) {
                         const uint32_t ipos = n_inv + (uint32_t)popc64(ib & ((1ull << gl) - 1ull));
-                        if (ipos < (uint32_t)BL_INV) L.inv[ipos] = cy;
+                        if (ipos < (uint32_t)LT::Caps::INV) L.inv[ipos] = cy;
                     }
                 }
                 nnext += popc64(cb);
@@ -436,8 +441,8 @@ template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, con
                 n_inv += (uint32_t)popc64(ib);
                 GP::sync();
                 if (nnext > W.cfg.mono_max_breadth) return COOP_FAIL; /* the one-lane form finishes the level first; nothing it does there changes the answer */
-                if (nnext > BL_FL) return COOP_TOOBIG;
-                if (n_seen > (uint32_t)BL_SEEN * 3u / 4u || n_inv > (uint32_t)BL_INV) return COOP_TOOBIG;
+                if (nnext > LT::Caps::FL) return COOP_TOOBIG;
+                if (n_seen > (uint32_t)LT::Caps::SEEN * 3u / 4u || n_inv > (uint32_t)LT::Caps::INV) return COOP_TOOBIG;
             }
         }
         cur ^= 1; ncur = nnext; depth++;
@@ -455,24 +460,24 @@ template <int G> MTG_DEV_NOINLINE int coop_find_end(Worker& W, BubbleLds& L, con
  * which explains the unitig-wise frames).  The enumeration is a depth-first search whose steps depend on each other: every lane of the
  * group runs it with the same values (the loads are one request per group), the bulk copies of nucleotides are dealt to the lanes.
  * 1 = ok (ncons consensuses in L.b), COOP_FAIL, COOP_TOOBIG. */
-template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, const Kmer& start, uint64_t end_c, uint64_t end_rp, int traversal_depth, int& ncons)
+template <int G, class LT> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, LT& L, const Kmer& start, uint64_t end_c, uint64_t end_rp, int traversal_depth, int& ncons)
 {
     typedef Grp<G> GP;
     const int k = W.k;
     const UStore& us = W.ix.us;
     const uint32_t gl = GP::gl();
-    if (traversal_depth + 2 > BL_NT || traversal_depth + 2 > BL_CLEN) return COOP_BIG_DEPTH;
+    if (traversal_depth + 2 > LT::Caps::NT || traversal_depth + 2 > LT::Caps::CLEN) return COOP_BIG_DEPTH;
     DfsFrame* fr = L.b.fr;
     uint8_t* dfs_nt = L.b.nt;
     uint64_t* pset = L.b.pset;
     const uint64_t TOMB = ~0ULL - 1;
-    for (uint32_t i = gl; i < (uint32_t)BL_ISEEN; i += GP::N) pset[i] = 0;
+    for (uint32_t i = gl; i < (uint32_t)LT::Caps::ISEEN; i += GP::N) pset[i] = 0;
     GP::sync();
     ncons = 0;
     uint32_t n_path = 0; /* slots of the path set in use (tombstones included) */
     /* 0: added, 1: already on the path, 2: full.  Every lane performs the same operations on the same words. */
     auto path_add = [&](uint64_t c) -> int {
-        uint32_t h = set_hash(c, BL_ISEEN);
+        uint32_t h = set_hash(c, LT::Caps::ISEEN);
         int64_t tomb = -1;
         MTG_GUARD_DECL(g4);
         for (;;) {
@@ -482,23 +487,23 @@ template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, 
             if (v == TOMB && tomb < 0) tomb = (int64_t)h;
             if (v == 0) {
                 if (tomb >= 0) { pset[(uint32_t)tomb] = c + 1; return 0; }
-                if (n_path + 2 >= (uint32_t)BL_ISEEN * 3u / 4u) return 2;
+                if (n_path + 2 >= (uint32_t)LT::Caps::ISEEN * 3u / 4u) return 2;
                 n_path++;
                 pset[h] = c + 1;
                 return 0;
             }
-            h = (h + 1) & (BL_ISEEN - 1);
+            h = (h + 1) & (LT::Caps::ISEEN - 1);
         }
     };
     auto path_del = [&](uint64_t c) {
-        uint32_t h = set_hash(c, BL_ISEEN);
+        uint32_t h = set_hash(c, LT::Caps::ISEEN);
         MTG_GUARD_DECL(g5);
         for (;;) {
             MTG_GUARD(g5, 1000u, 14, return);
             const uint64_t v = pset[h];
             if (v == 0) return;
             if (v == c + 1) { pset[h] = TOMB; return; }
-            h = (h + 1) & (BL_ISEEN - 1);
+            h = (h + 1) & (LT::Caps::ISEEN - 1);
         }
     };
     int f = 0;
@@ -520,8 +525,8 @@ template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, 
             const int d = (int)fr[f].dep;
             if (traversal_depth - d < -1) return COOP_FAIL;
             if (fr[f].c == end_c) {
-                if (ncons >= BL_CONS) return COOP_BIG_NCONS;
-                if (d > BL_CLEN) return COOP_BIG_DEPTH;
+                if (ncons >= LT::Caps::CONS) return COOP_BIG_NCONS;
+                if (d > LT::Caps::CLEN) return COOP_BIG_DEPTH;
                 for (int i = (int)gl; i < d; i += GP::N) L.b.cons[ncons][i] = dfs_nt[i];
                 if (gl == 0) { L.b.len[ncons] = (uint16_t)d; L.b.sum[ncons] = f ? (int32_t)fr[f - 1].xsn : 0; }
                 ncons++;
@@ -606,7 +611,7 @@ template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, 
             if ((rp & RP_VALID) && ra >= 1u) { krp = rp_step(rp, 1u); kra = ra - 1u; }
         }
         const uint64_t cy = canon(y);
-        if (f + 1 >= BL_FR || d + (int)t >= BL_NT) return COOP_BIG_FRAMES;
+        if (f + 1 >= LT::Caps::FR || d + (int)t >= LT::Caps::NT) return COOP_BIG_FRAMES;
         GP::sync();
         const int pa = path_add(cy);
         if (pa == 1) return COOP_FAIL; /* loop inside the bubble */
@@ -624,7 +629,7 @@ template <int G> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, BubbleLds& L, 
 
 /* [MEM] MonumentTraversal::validate_consensuses + most_abundant_consensus on the consensuses in L.b (one-lane form: validate_consensuses).
  * Index of the chosen consensus, -1 = rejected, -2 = the alignment itself is needed (left to the one-lane form). */
-template <int G> MTG_DEV_NOINLINE int coop_validate(Worker& W, BubbleLds& L, int ncons)
+template <int G, class LT> MTG_DEV_NOINLINE int coop_validate(Worker& W, LT& L, int ncons)
 {
     if (ncons <= 0) return -1;
     const int k = W.k;
@@ -679,7 +684,7 @@ template <int G> MTG_DEV_NOINLINE int coop_validate(Worker& W, BubbleLds& L, int
 /* [MEM] MonumentTraversal::explore_branching by the group: the plan.  Returns the length of the chosen consensus (its nucleotides in
  * L.b.cons[chosen], the nodes to mark in L.inv[0, L.n_marks)), COOP_FAIL (the one-lane form would return 0) or COOP_TOOBIG.  Nothing
  * outside L is written: apply_marks makes the plan effective. */
-template <int G> MTG_DEV_NOINLINE int coop_explore(Worker& W, BubbleLds& L, const Kmer& cur, uint64_t prev_c, int& chosen)
+template <int G, class LT> MTG_DEV_NOINLINE int coop_explore(Worker& W, LT& L, const Kmer& cur, uint64_t prev_c, int& chosen)
 {
     typedef Grp<G> GP;
     if (W.cfg.end_rule_nonbranching) return COOP_BIG_RULE;
@@ -711,7 +716,7 @@ template <int G> MTG_DEV_NOINLINE int coop_explore(Worker& W, BubbleLds& L, cons
     GP::sync();
     return (int)L.b.len[chosen];
 }
-template <int G> MTG_DEV void coop_apply_marks(Worker& W, BubbleLds& L)
+template <int G, class LT> MTG_DEV void coop_apply_marks(Worker& W, LT& L)
 {
     const uint32_t nm = L.n_marks;
     for (uint32_t i = 0; i < nm; i++) W.mark_canon(L.inv[i]);

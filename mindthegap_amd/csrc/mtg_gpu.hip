@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t cset,
                                                ParkCtl* park, uint32_t cap, uint32_t in_list)
 {
-    __shared__ BubbleLds lds[64 / G];
+    __shared__ BubbleLdsBig lds[64 / G];
     const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1);
     const uint32_t t = blockIdx.x * (64u / (uint32_t)G) + lane / (uint32_t)G;
     if (t >= park->count[in_list]) return;
@@ -1830,7 +1830,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
              * on in the walk kernel, one gap per lane again -- walking is cheap at full width, only the bubbles need a group -- for a few
              * rounds; what is still parked then (and everything, when few gaps park) is finished by groups in k_finish.  The host does not
              * know the counts when it queues the kernels: the number of rounds follows the previous launch of this workspace. */
-            int rounds = env_rounds >= 0 ? env_rounds : ((uint64_t)ws.park_hint * 50 > m ? 3 : 0);
+            int rounds = env_rounds >= 0 ? env_rounds : ((uint64_t)ws.park_hint * 2 > m ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
             if (rounds > (PARK_LISTS - 2) / 2) rounds = (PARK_LISTS - 2) / 2;
             ParkCtl* const park = d_park.as<ParkCtl>();
             if (!classic_walk) HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream));
@@ -1846,7 +1846,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 static const bool skip_finish = getenv("MTG_DEBUG_SKIP_FINISH") != nullptr; /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 const uint32_t per_wg = 64u / (uint32_t)finish_g;
                 const uint32_t nwg = (m + per_wg - 1) / per_wg; /* one group per gap of the launch: those without an entry of the list leave at once */
-                static const bool one_lane_bubbles = getenv("MTG_BUBBLE_ONE_LANE") != nullptr; /* A/B hook: every bubble of the rounds by one lane (all lanes of a wave in the bubble code together) */
+                /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with small bubbles that
+                 * keeps more of them in flight than a group of lanes per bubble does (MTG_BUBBLE_GROUPS=1: k_bubble<G>, the LDS form, first) */
+                static const bool one_lane_bubbles = getenv("MTG_BUBBLE_GROUPS") == nullptr;
                 for (int r = 0; r < rounds; r++) {
                     const uint32_t lin = 2u * (uint32_t)r;
                     if (one_lane_bubbles) {

@@ -1608,7 +1608,7 @@ inline void coop_tally(int n)
 }
 #endif
 template <int MODE, int G>
-MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLds* L, bool resume = (MODE == WALK_FINISH))
+MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLdsBig* L, bool resume = (MODE == WALK_FINISH))
 {
     Worker W(ix, cfg, S);
     W.no_dp = MODE == WALK_PARK;

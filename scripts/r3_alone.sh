@@ -6,9 +6,9 @@ O=gpurun_out/${1:-r3_alone}; mkdir -p $O
 for mode in ${MODES:-classic g16r0 g16r3}; do
   case $mode in
     classic) export MTG_CLASSIC_WALK=1; unset MTG_FINISH_G MTG_ROUNDS;;
-    auto) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS;;
-    o*r*) unset MTG_CLASSIC_WALK; export MTG_BUBBLE_ONE_LANE=1 MTG_FINISH_G=16 MTG_ROUNDS=${mode#*r};;
-    g*r*) unset MTG_CLASSIC_WALK MTG_BUBBLE_ONE_LANE; g=${mode#g}; export MTG_FINISH_G=${g%r*} MTG_ROUNDS=${mode#*r};;
+    auto) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS MTG_BUBBLE_GROUPS;;
+    o*r*) unset MTG_CLASSIC_WALK; unset MTG_BUBBLE_GROUPS; export MTG_FINISH_G=16 MTG_ROUNDS=${mode#*r};;
+    g*r*) unset MTG_CLASSIC_WALK; export MTG_BUBBLE_GROUPS=1; g=${mode#g}; export MTG_FINISH_G=${g%r*} MTG_ROUNDS=${mode#*r};;
   esac
   rm -rf $O/alone_$mode
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/alone_$mode -o alone -- python3 scripts/diag_batches.py ${NB:-2} > $O/alone_$mode.out 2> $O/alone_$mode.err

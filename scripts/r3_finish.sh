@@ -11,9 +11,9 @@ for w in $wl; do
       classic) export MTG_CLASSIC_WALK=1; unset MTG_FINISH_G MTG_ROUNDS;;
       g16) unset MTG_CLASSIC_WALK; export MTG_FINISH_G=16 MTG_ROUNDS=0;;
       g64) unset MTG_CLASSIC_WALK; export MTG_FINISH_G=64 MTG_ROUNDS=0;;
-      auto) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS;;
-      o*r*) unset MTG_CLASSIC_WALK; export MTG_BUBBLE_ONE_LANE=1 MTG_FINISH_G=16 MTG_ROUNDS=${mode#*r};;
-      g*r*) unset MTG_CLASSIC_WALK MTG_BUBBLE_ONE_LANE; g=${mode#g}; export MTG_FINISH_G=${g%r*} MTG_ROUNDS=${mode#*r};;
+      auto) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS MTG_BUBBLE_GROUPS;;
+      o*r*) unset MTG_CLASSIC_WALK; unset MTG_BUBBLE_GROUPS; export MTG_FINISH_G=16 MTG_ROUNDS=${mode#*r};;
+      g*r*) unset MTG_CLASSIC_WALK; export MTG_BUBBLE_GROUPS=1; g=${mode#g}; export MTG_FINISH_G=${g%r*} MTG_ROUNDS=${mode#*r};;
     esac
     timeout 600 python bench.py --workload $w --batches ${NBATCH:-3} --in-flight ${INFLIGHT:-6} --cpu-sites 0 --no-ceiling --no-secondary --steps 20 --warmup 5 > $out/bench_${w}_${mode}.json 2> $out/bench_${w}_${mode}.err
     python - $out/bench_${w}_${mode}.json $w $mode <<'PY'

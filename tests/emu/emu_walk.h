@@ -12,13 +12,14 @@ inline uint32_t emu_walk(const Index& ix, const FillCfg& cfg, GapScratch& S, uin
     static const bool coop_off = getenv("MTG_EMU_BUBBLE_CLASSIC") != nullptr; /* every bubble of the rounds through k_bubble_classic */
     if (classic) { stage_a_gap(ix, cfg, S, src_f, R, out); return 0; }
     static thread_local BubbleLds lds;
+    static thread_local BubbleLdsBig lds_big;
     stage_a_walk<WALK_PARK, 1>(ix, cfg, S, src_f, R, out, nullptr);
     if (out.status != GAP_PARKED) return 0;
     for (int r = 0; r < rounds && out.status == GAP_PARKED; r++) {
         if (coop_off || !bubble_coop<1>(ix, cfg, S, lds)) bubble_classic(ix, cfg, S);
         stage_a_walk<WALK_PARK, 1>(ix, cfg, S, 0, R, out, nullptr, true);
     }
-    if (out.status == GAP_PARKED) stage_a_walk<WALK_FINISH, 1>(ix, cfg, S, 0, R, out, &lds);
+    if (out.status == GAP_PARKED) stage_a_walk<WALK_FINISH, 1>(ix, cfg, S, 0, R, out, &lds_big);
     return 1;
 }
 }
