@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=list(WORKLOADS))
     ap.add_argument("--sites", type=int, default=0, help="sites per batch (default: the workload's)")
+    ap.add_argument("--no-children", action="store_true", help="skip the secondary workloads (child processes)")
+    ap.add_argument("--tool-sites", type=int, default=2000000, help="sites of the tool measurement (the sites of the batches, repeated)")
     ap.add_argument("--batches", type=int, default=4, help="distinct batches of sites rotated through the steps (N = 1 and weak scaling)")
     ap.add_argument("--nseq", type=int, default=0)
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"], help="N > 1: strong (default) = one fixed site set sharded over the ranks; weak = one batch per rank and step")
@@ -277,7 +279,7 @@ def main():
                 j, _buf = pg.acquire()
                 pg.submit(0, j, tag=-1)
 
-        def run_block(count, record, first_step=0, host_strings=False):
+        def run_block(count, record, first_step=0, host_strings=False, host_text=False):
             """`count` steps, a.in_flight batches in flight: caller threads take the next batch off a shared list, like the reference's
             Dispatcher threads take the next group of records; every batch is complete when this returns"""
             work = []
@@ -294,7 +296,7 @@ def main():
                             b = next(it, None)
                         if b is None:
                             return
-                        fill(b, prepared=b.strings if host_strings else None, record=record)
+                        fill(b, prepared=b.strings if host_strings else b.text if host_text else None, record=record)
                 except BaseException as e:  # surfaced on the main thread
                     errors.append(e)
 
@@ -458,6 +460,28 @@ def main():
         secondary["value_from_host_strings_note"] = ("same steps through mtg_fill_batch: the sites are marshalled from the caller's strings (three C strings per site, wherever the caller has them) and "
                                                      "uploaded inside every step; median of 3 blocks, %d pool threads" % (int(os.environ.get("MTG_POOL_THREADS", "0")) or mtg.cpu_budget()))
 
+    # ---------------------------------------------------------------- secondary: the same steps from one block of text per batch (mtg_fill_text): the host copies the
+    # block and its offset arrays into page-locked memory, the device encodes sources, patterns and dictionary keys (k_marshal_text, k_marshal_targets)
+    if single and not a.no_secondary and not a.host_strings and batches:
+        for b in batches:
+            b.text = mtg.TextGaps(b.gaps)  # the block a breakpoint-file reader would hold; built outside the steps, like the strings above
+        R0["run_block"](max(a.warmup, 1), False, host_text=True)
+        ts = []
+        for r in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            R0["run_block"](a.steps, False, r * a.steps, host_text=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        _, seqs_t = R0["fill"](batches[0], prepared=batches[0].text, want_seqs=True)
+        ok_text = (hashlib.sha256(seqs_t.tobytes().replace(b"\n", b"\0")).hexdigest() == batches[0].digest) if not (het or tips) else None
+        secondary["value_from_host_text"] = batch_sites * a.steps / float(np.median(ts))
+        secondary["value_from_host_text_note"] = ("same steps through mtg_fill_text: every step copies its sites' text block (%d bytes for %d sites) and offset arrays into page-locked memory, uploads "
+                                                  "them and encodes on the device; median of 3 blocks, %d pool threads; sequences of one batch identical to the truth: %s"
+                                                  % (len(batches[0].text.text), batches[0].n, int(os.environ.get("MTG_POOL_THREADS", "0")) or mtg.cpu_budget(), ok_text))
+        for b in batches:
+            b.text = None
+
     # ---------------------------------------------------------------- secondary: the sequences left in HBM (a consumer on the device, or the send buffer of a gather):
     # records still come to the host, the ASCII -- three quarters of the result bytes -- does not cross PCIe
     if single and not a.no_secondary and not a.host_strings and batches:
@@ -496,6 +520,12 @@ def main():
                 bk = os.path.join(d, "sites.breakpoints")
                 site_ids = [i for b in batches for i in range(b.s0, b.s0 + b.n)]
                 S.write_breakpoints(bk, site_ids)
+                reps = max(1, a.tool_sites // max(len(site_ids), 1))  # a run long enough that the first and the last batch (nothing else in flight) do not set the rate
+                if reps > 1:
+                    one = open(bk, "rb").read()
+                    with open(bk, "wb") as f:
+                        for _ in range(reps):
+                            f.write(one)
                 os.environ["MTG_TOOL_QUIET"] = "1"  # no summary on stdout: this process prints one JSON line
                 idx.fill_main(["-bkpt", bk, "-out", os.path.join(d, "warm")])  # page cache, the workspaces of the tool's host threads
                 t0 = time.perf_counter()
@@ -505,8 +535,10 @@ def main():
                 seqs = b"\0".join(l for l in fa.split(b"\n") if l and not l.startswith(b">")) + b"\0"
                 want = hashlib.sha256(("\0".join(e for b in batches for e in b.expected) + "\0").encode()).hexdigest()
                 out_bytes = sum(os.path.getsize(os.path.join(d, "tool" + e)) for e in (".insertions.fasta", ".info.txt", ".insertions.vcf"))
-                secondary["tool_sites_per_s"] = len(site_ids) / el
-                secondary["tool"] = {"sites": len(site_ids), "seconds": el, "exit_code": rc_tool, "output_bytes": out_bytes, "output_GBps": out_bytes / el / 1e9, "input_bytes": os.path.getsize(bk),
+                if reps > 1:
+                    seqs = seqs[: len(seqs) // reps] if seqs == seqs[: len(seqs) // reps] * reps else b"repetitions differ"
+                secondary["tool_sites_per_s"] = len(site_ids) * reps / el
+                secondary["tool"] = {"sites": len(site_ids) * reps, "distinct_sites": len(site_ids), "seconds": el, "exit_code": rc_tool, "output_bytes": out_bytes, "output_GBps": out_bytes / el / 1e9, "input_bytes": os.path.getsize(bk),
                                      "sequences_identical_to_truth": (hashlib.sha256(seqs).hexdigest() == want) if not (het or tips) else None, "output_dir": "memory-backed (/dev/shm)" if base else "temporary directory",
                                      "what": "MindTheGap fill -bkpt <sites> -out <prefix> on the resident index: breakpoint file read and parsed as a stream, batches of 100000 sites, 3 host threads per device, "
                                              "FASTA / info / VCF text formatted by the worker pool and written in input order; wall time of the whole call"}
@@ -629,7 +661,7 @@ def main():
     out.update(secondary)
     # ---------------------------------------------------------------- secondary lines: the workloads whose walks cross bubbles (SNPs; indels; tips and error bubbles), each
     # as a child process once this one has given the device back (two human-scale indexes do not fit the HBM together)
-    if single and not a.no_secondary and a.workload == "human" and not a.host_strings:
+    if single and not a.no_secondary and not a.no_children and a.workload == "human" and not a.host_strings:
         for b in batches:
             if hasattr(b.prepared, "close"):
                 b.prepared.close()

@@ -180,6 +180,32 @@ int mtg_fill_prepared_serial_device(const mtg_index* idx, const mtg_params* p, c
  * payload there next to the records (no host pass); the results come to the host as with mtg_fill_prepared.  The payload is complete when
  * the call returns. */
 int mtg_fill_prepared_wire_device(const mtg_index* idx, const mtg_params* p, const mtg_batch* b, uint64_t tag, void* d_wire, uint64_t cap, uint64_t* wire_bytes, mtg_results** out);
+/* A batch of gapFillFromSource calls whose strings lie in ONE block of text, the way a reader of a breakpoint file has them: strings are
+ * (offset, length) pairs into the block, no pointer per string, no NUL terminators.  The library copies the block and the offset arrays into
+ * page-locked memory, sends them up and ENCODES ON THE DEVICE (source k-mers, early-stop patterns, dictionary keys: k_marshal_text,
+ * k_marshal_targets) -- the host does no per-string work, so a caller with one or two threads feeds the device as fast as a prepared batch
+ * does.  Results exactly as mtg_fill_batch for the same strings.  Every offset + length must lie inside the block (MTG_ERR_ARG otherwise);
+ * a source shorter than k is MTG_ERR_ARG as in mtg_fill_batch.  The block and the arrays must stay unchanged until the call returns (the
+ * rare multi-contig gap reads its strings again). */
+typedef struct mtg_text_gaps {
+    const char* text;                 /* the block */
+    uint64_t text_bytes;
+    uint64_t n;                       /* gaps */
+    const uint64_t* source_off;       /* sourceSequence of gap i = text[source_off[i], + source_len[i]) */
+    const uint32_t* source_len;
+    const uint64_t* pattern_off;      /* targetSequence: the early-stop pattern R */
+    const uint32_t* pattern_len;
+    const uint32_t* dict_first;       /* n + 1 entries: targetDictionary of gap i = entries [dict_first[i], dict_first[i + 1]) of the arrays below, in iteration order */
+    const uint64_t* dict_seq_off;     /*   key: k-mer string */
+    const uint32_t* dict_seq_len;
+    const uint64_t* dict_name_off;    /*   value.first */
+    const uint32_t* dict_name_len;
+    const uint8_t* dict_is_rc;        /*   value.second (NULL: all 0) */
+    const uint8_t* gap_flags;         /* per gap, bit 0: is_anchor_repeated, bit 1: reverse (NULL: all 0) */
+} mtg_text_gaps;
+int mtg_fill_text(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, mtg_results** out);
+/* and the filled sequences laid out in seq_out as with mtg_fill_batch_serial */
+int mtg_fill_text_serial(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);
 /* Every pointer obtained from r dies here.  The library keeps the storage of up to six freed result sets (a few hundred bytes per
  * gap plus the sequences) and hands it to the next batches, which then pay no allocation, page fault or memset. */

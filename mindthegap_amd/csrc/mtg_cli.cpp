@@ -20,6 +20,8 @@
 #include <condition_variable>
 #include <thread>
 #include <zlib.h>
+#include <atomic>
+#include <chrono>
 
 namespace mtgi {
 
@@ -407,11 +409,15 @@ struct BkptReader {
         size_t cut = std::string::npos;
         for (;;) {
             /* record starts: a '>' (FASTA) at the beginning of a line */
-            for (; scanned < text.size(); scanned++) {
-                if (text[scanned] == '>' && (scanned == 0 || text[scanned - 1] == '\n')) {
+            while (scanned < text.size()) {
+                const char* hit = (const char*)memchr(text.data() + scanned, '>', text.size() - scanned);
+                if (!hit) { scanned = text.size(); break; }
+                scanned = (size_t)(hit - text.data());
+                if (scanned == 0 || text[scanned - 1] == '\n') {
                     if (nrec == per_batch) { cut = scanned; break; }
                     nrec++;
                 }
+                scanned++;
             }
             if (cut != std::string::npos || eof) break;
             const size_t old = text.size(), want = (size_t)8 << 20;
@@ -508,11 +514,24 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         std::vector<char> text;
         std::vector<BkptRec> recs;
         size_t n = 0; /* sites */
-        std::vector<mtg_gap> fwd, rev;
-        std::vector<const char*> tseq, tname, rtseq, rtname; /* the one-entry dictionaries: the arrays the gaps point into */
+        /* the gaps as the library takes them from text (mtg_fill_text): offsets into bt.text (forward attempts) or rev_text (reverse attempts) */
+        struct TextArrays {
+            std::vector<uint64_t> so, po, no;
+            std::vector<uint32_t> sl, pl, nl, first;
+            std::vector<uint8_t> flags;
+            void resize(size_t n) { so.resize(n); po.resize(n); no.resize(n); sl.resize(n); pl.resize(n); nl.resize(n); flags.resize(n); first.resize(n + 1); for (size_t i = 0; i <= n; i++) first[i] = (uint32_t)i; }
+            mtg_text_gaps view(const char* text, size_t bytes) const
+            {
+                mtg_text_gaps g{};
+                g.text = text; g.text_bytes = bytes; g.n = so.size();
+                g.source_off = so.data(); g.source_len = sl.data(); g.pattern_off = po.data(); g.pattern_len = pl.data();
+                g.dict_first = first.data(); g.dict_seq_off = po.data(); g.dict_seq_len = pl.data(); /* the one-entry dictionary: the pattern itself */
+                g.dict_name_off = no.data(); g.dict_name_len = nl.data(); g.dict_is_rc = nullptr; g.gap_flags = flags.data();
+                return g;
+            }
+        } fwd, rev;
         std::vector<uint32_t> name_len, name_r_len;          /* the names cut at their first space (src/Filler.cpp:631-636) */
         std::vector<long> rev_idx;
-        std::vector<size_t> rev_off; /* reverse attempts: source / target strings in rev_text */
         std::string rev_text;
         mtg_results *rf = nullptr, *rr = nullptr;
         std::vector<OutText> out; /* one piece per FORMAT_CHUNK sites */
@@ -520,12 +539,18 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         ~Batch() { if (rf) mtg_results_free(rf); if (rr) mtg_results_free(rr); }
     };
     enum { FORMAT_CHUNK = 2048 };
-    static const uint8_t not_rc = 0;
+    /* MTG_TOOL_TIMERS=1: where the time of a run goes (summed over the worker threads; read and write are one thread each) */
+    static const bool timers = getenv("MTG_TOOL_TIMERS") != nullptr;
+    std::atomic<long long> t_read{0}, t_parse{0}, t_fill{0}, t_rev{0}, t_format{0}, t_write{0};
+    const auto usec = [] { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::mutex bm;
     std::vector<std::unique_ptr<Batch>> batches;
     const auto next = [&](size_t b) -> bool {
         std::unique_ptr<Batch> bt(new Batch());
-        if (!reader.next(bt->text)) return false;
+        const long long tr = usec();
+        const bool more = reader.next(bt->text);
+        t_read += usec() - tr;
+        if (!more) return false;
         std::lock_guard<std::mutex> lk(bm);
         if (batches.size() <= b) batches.resize(b + 1);
         batches[b] = std::move(bt);
@@ -535,63 +560,59 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         Batch* btp;
         { std::lock_guard<std::mutex> lk(bm); btp = batches[b].get(); }
         Batch& bt = *btp;
+        long long tp = usec();
         parse_records(bt.text, bt.recs);
         const size_t n = bt.recs.size() / 2; /* records 2i / 2i+1 = left / right k-mer, src/Filler.cpp:625-629 */
         bt.n = n;
-        bt.fwd.resize(n); bt.tseq.resize(n); bt.tname.resize(n); bt.name_len.resize(n); bt.name_r_len.resize(n);
+        bt.fwd.resize(n); bt.name_len.resize(n); bt.name_r_len.resize(n);
+        const char* const t0 = bt.text.data();
         for (size_t j = 0; j < n; j++) {
             const BkptRec &l = bt.recs[2 * j], &r = bt.recs[2 * j + 1];
             const void* sp = memchr(l.hdr, ' ', l.hdr_len);
             bt.name_len[j] = sp ? (uint32_t)((const char*)sp - l.hdr) : l.hdr_len;
             sp = memchr(r.hdr, ' ', r.hdr_len);
             bt.name_r_len[j] = sp ? (uint32_t)((const char*)sp - r.hdr) : r.hdr_len;
-            bt.tseq[j] = r.seq;
-            bt.tname[j] = r.hdr; /* the value of the dictionary entry: only multi-contig gaps look at it, and only to group by it */
-            mtg_gap& g = bt.fwd[j];
-            g.source = l.seq;
-            g.target = r.seq;
-            g.n_targets = 1;
-            g.target_seqs = &bt.tseq[j];
-            g.target_names = &bt.tname[j];
-            g.target_is_rc = &not_rc;
-            g.is_anchor_repeated = (std::string_view(l.hdr, l.hdr_len).find("REPEATED") != std::string_view::npos || std::string_view(r.hdr, r.hdr_len).find("REPEATED") != std::string_view::npos) ? 1 : 0;
-            g.reverse = 0;
+            bt.fwd.so[j] = (uint64_t)(l.seq - t0); bt.fwd.sl[j] = l.seq_len;
+            bt.fwd.po[j] = (uint64_t)(r.seq - t0); bt.fwd.pl[j] = r.seq_len; /* target sequence = key of the one-entry dictionary */
+            bt.fwd.no[j] = (uint64_t)(r.hdr - t0); bt.fwd.nl[j] = r.hdr_len;  /* its value: only multi-contig gaps look at it, and only to group by it */
+            const bool rep = std::string_view(l.hdr, l.hdr_len).find("REPEATED") != std::string_view::npos || std::string_view(r.hdr, r.hdr_len).find("REPEATED") != std::string_view::npos;
+            bt.fwd.flags[j] = rep ? 1 : 0;
         }
-        int rc = mtg_fill_batch(idx, &P, bt.fwd.data(), n, &bt.rf);
+        /* the strings stay text: the library sends the block up and encodes on the device (mtg_fill_text) */
+        const mtg_text_gaps gf = bt.fwd.view(t0, bt.text.size());
+        t_parse += usec() - tp; tp = usec();
+        int rc = mtg_fill_text(idx, &P, &gf, &bt.rf);
         if (rc) return rc;
+        t_fill += usec() - tp; tp = usec();
         /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
         bt.rev_idx.assign(n, -1);
         if (!O.fwd_only) {
-            for (size_t j = 0; j < n; j++)
-                if (mtg_results_get(bt.rf, j)->n_filled == 0) {
-                    bt.rev_idx[j] = (long)(bt.rev_off.size() / 2);
-                    bt.rev_off.push_back(bt.rev_text.size());
-                    revcomp_into(bt.fwd[j].target, strlen(bt.fwd[j].target), bt.rev_text); /* the reverse attempt's source */
-                    bt.rev_text += '\0';
-                    bt.rev_off.push_back(bt.rev_text.size());
-                    revcomp_into(bt.fwd[j].source, strlen(bt.fwd[j].source), bt.rev_text); /* and its target */
-                    bt.rev_text += '\0';
-                }
-            const size_t nr = bt.rev_off.size() / 2;
-            bt.rev.resize(nr); bt.rtseq.resize(nr); bt.rtname.resize(nr);
+            size_t nr = 0;
+            for (size_t j = 0; j < n; j++) if (mtg_results_get(bt.rf, j)->n_filled == 0) bt.rev_idx[j] = (long)nr++;
+            bt.rev.resize(nr);
             size_t q = 0;
-            for (size_t j = 0; j < n; j++)
+            for (size_t j = 0; j < n && nr; j++)
                 if (bt.rev_idx[j] >= 0) {
-                    mtg_gap& g = bt.rev[q];
-                    g.source = bt.rev_text.data() + bt.rev_off[2 * q];
-                    g.target = bt.rev_text.data() + bt.rev_off[2 * q + 1];
-                    bt.rtseq[q] = g.target;
-                    bt.rtname[q] = bt.recs[2 * j].hdr;
-                    g.n_targets = 1;
-                    g.target_seqs = &bt.rtseq[q];
-                    g.target_names = &bt.rtname[q];
-                    g.target_is_rc = &not_rc;
-                    g.is_anchor_repeated = bt.fwd[j].is_anchor_repeated;
-                    g.reverse = 1;
+                    const BkptRec &l = bt.recs[2 * j], &r = bt.recs[2 * j + 1];
+                    bt.rev.so[q] = bt.rev_text.size();
+                    revcomp_into(r.seq, r.seq_len, bt.rev_text); /* the reverse attempt's source */
+                    bt.rev.sl[q] = (uint32_t)(bt.rev_text.size() - bt.rev.so[q]);
+                    bt.rev.po[q] = bt.rev_text.size();
+                    revcomp_into(l.seq, l.seq_len, bt.rev_text); /* and its target */
+                    bt.rev.pl[q] = (uint32_t)(bt.rev_text.size() - bt.rev.po[q]);
+                    bt.rev.no[q] = bt.rev_text.size();
+                    bt.rev_text.append(l.hdr, l.hdr_len);
+                    bt.rev.nl[q] = l.hdr_len;
+                    bt.rev.flags[q] = (uint8_t)(bt.fwd.flags[j] | 2);
                     q++;
                 }
-            if (nr) { rc = mtg_fill_batch(idx, &P, bt.rev.data(), nr, &bt.rr); if (rc) return rc; }
+            if (nr) {
+                const mtg_text_gaps gr = bt.rev.view(bt.rev_text.data(), bt.rev_text.size());
+                rc = mtg_fill_text(idx, &P, &gr, &bt.rr);
+                if (rc) return rc;
+            }
         }
+        t_rev += usec() - tp; tp = usec();
         /* the batch's text, formatted in pieces by the library's worker pool (the writers of src/Filler.cpp:1029-1214) */
         const size_t npieces = (n + FORMAT_CHUNK - 1) / FORMAT_CHUNK;
         bt.out.resize(npieces);
@@ -615,17 +636,23 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         mtg_results_free(bt.rf); bt.rf = nullptr;
         if (bt.rr) { mtg_results_free(bt.rr); bt.rr = nullptr; }
         std::vector<char>().swap(bt.text);
+        t_format += usec() - tp;
         return MTG_OK;
     };
     const auto consume = [&](size_t b) {
         std::unique_ptr<Batch> bt;
         { std::lock_guard<std::mutex> lk(bm); bt = std::move(batches[b]); }
+        const long long tw = usec();
         for (const OutText& T : bt->out) T.write(F);
+        t_write += usec() - tw;
         S.nb_breakpoints += (int)bt->n;
         S.nb_filled += (int)bt->filled;
         S.nb_multiple += (int)bt->multiple;
     };
     const int rc = run_batches(R, next, process, consume);
+    if (timers)
+        fprintf(stderr, "[tool] ms summed over threads: read %.1f | parse + gaps %.1f, forward fill %.1f, reverse attempts %.1f, format %.1f | write %.1f\n", t_read / 1e3, t_parse / 1e3, t_fill / 1e3,
+                t_rev / 1e3, t_format / 1e3, t_write / 1e3);
     if (!rc && reader.bad) { set_error("cannot read %s (truncated or corrupt)", O.bkpt.c_str()); return MTG_ERR_IO; }
     return rc;
 }

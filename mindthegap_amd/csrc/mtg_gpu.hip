@@ -15,6 +15,7 @@
  *   k_chase                          : dependent random 64-byte reads (measured roofline ceiling)
  */
 #include "mtg_internal.h"
+#include "mtg_marshal.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdarg>
@@ -579,6 +580,29 @@ __global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* ra
     copy_gap(ix, cfg, S, outs[slot], target);
 }
 
+/* mtg_fill_text: a batch whose strings are still text (mtg_marshal.h).  One gap per thread: source k-mer, packed pattern, its first k-mer,
+ * whether the fast forms apply; one dictionary entry per thread: little-endian k-mer and never-match mask.  The reads are a few dozen bytes
+ * per thread at unrelated places of the block: 100 000 gaps take some tens of microseconds, against 1-2 ms of two host threads. */
+__global__ void k_marshal_text(const uint8_t* __restrict__ text, const uint64_t* __restrict__ soff, const uint32_t* __restrict__ slen, const uint64_t* __restrict__ poff,
+                               const uint32_t* __restrict__ roff, uint32_t* rlen, uint64_t* src, uint64_t* r0, uint8_t* fast_ok, uint64_t* rw, uint32_t n, int k)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint64_t s, r;
+    uint32_t rl;
+    uint8_t fo;
+    marshal_text_gap(text, soff[g], slen[g], poff[g], rlen[g], k, rw + roff[g], s, r, rl, fo);
+    src[g] = s; r0[g] = r; rlen[g] = rl; fast_ok[g] = fo;
+}
+__global__ void k_marshal_targets(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doff, const uint32_t* __restrict__ dlen, uint64_t* __restrict__ tle, uint64_t* __restrict__ tbad,
+                                  uint32_t nt, int k)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    uint64_t le, bad;
+    marshal_text_target(text, doff[t], dlen[t], k, le, bad);
+    tle[t] = le; tbad[t] = bad;
+}
 /* the targets of a batch from text to (little-endian k-mer, never-match mask): one target per thread */
 __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __restrict__ tle, uint64_t* __restrict__ tbad, uint64_t nt, int k)
 {
@@ -1699,11 +1723,32 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
-    const uint64_t n_targets = in.traw.size() / TARGET_SLOT;
+    const uint64_t n_targets = in.text_mode ? in.n_text_targets : in.traw.size() / TARGET_SLOT;
     const uint8_t* da;
     const uint64_t* d_rw;
     uint64_t* d_tle;
-    if (in.dev_a) {
+    if (in.text_mode) {
+        /* the strings are still text: block A (integer columns) and the text block go up, the device encodes (mtg_marshal.h) */
+        HIP_TRY(d_ina.alloc(in.bytes_a));
+        HIP_TRY(d_inb.alloc(in.bytes_b));
+        HIP_TRY(d_inc.alloc(in.bytes_c));
+        HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, stream));
+        HIP_TRY(d_tenc.alloc(n_targets * 16 + 64));
+        uint8_t* a = d_ina.as<uint8_t>();
+        const uint8_t* c = d_inc.as<uint8_t>();
+        const size_t nn = n, nt = (size_t)n_targets;
+        hipLaunchKernelGGL(k_marshal_text, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c + FillInput::text_block_off(nn, nt, 5), (const uint64_t*)(c + FillInput::text_block_off(nn, nt, 0)),
+                           (const uint32_t*)(c + FillInput::text_block_off(nn, nt, 3)), (const uint64_t*)(c + FillInput::text_block_off(nn, nt, 1)), (const uint32_t*)(a + FillInput::off_a(n, 2)),
+                           (uint32_t*)(a + FillInput::off_a(n, 3)), (uint64_t*)(a + FillInput::off_a(n, 0)), (uint64_t*)(a + FillInput::off_a(n, 1)), a + FillInput::off_a(n, 7), d_inb.as<uint64_t>(),
+                           (uint32_t)n, k);
+        da = a;
+        d_rw = d_inb.as<uint64_t>();
+        d_tle = d_tenc.as<uint64_t>();
+        if (n_targets) hipLaunchKernelGGL(k_marshal_targets, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, stream, c + FillInput::text_block_off(nn, nt, 5),
+                                          (const uint64_t*)(c + FillInput::text_block_off(nn, nt, 2)), (const uint32_t*)(c + FillInput::text_block_off(nn, nt, 4)), d_tle, d_tle + n_targets, (uint32_t)n_targets, k);
+        HIP_TRY(hipGetLastError());
+    } else if (in.dev_a) {
         da = (const uint8_t*)in.dev_a;
         d_rw = (const uint64_t*)in.dev_b;
         d_tle = (uint64_t*)in.dev_tenc;

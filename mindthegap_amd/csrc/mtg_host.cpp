@@ -918,7 +918,7 @@ struct WireReq { /* the batch also in relocatable form, in a device buffer of th
     uint64_t* bytes = nullptr;
 };
 int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillInput& in, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes,
-                    mtg_results** out, double t_begin, char* d_seq_out = nullptr, const WireReq* wire = nullptr)
+                    mtg_results** out, double t_begin, char* d_seq_out = nullptr, const WireReq* wire = nullptr, const mtg_text_gaps* tg = nullptr)
 {
     using namespace mtgi;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -982,6 +982,23 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     if (!special.special.empty()) {
         const double t0 = now_ms();
         const auto describe = [&](size_t gi, GapWork& w) {
+            if (tg) { /* mtg_fill_text: the strings of the gap are pieces of the caller's block */
+                w.source = std::string_view(tg->text + tg->source_off[gi], tg->source_len[gi]);
+                const uint8_t fl = tg->gap_flags ? tg->gap_flags[gi] : 0;
+                w.anchor_repeated = (fl & 1) != 0;
+                w.reverse = (fl & 2) != 0;
+                const uint32_t t0 = tg->dict_first[gi], t1 = tg->dict_first[gi + 1];
+                w.target_store.resize(t1 - t0);
+                for (uint32_t t = t0; t < t1; t++) {
+                    Target& T = w.target_store[t - t0];
+                    T.seq = std::string_view(tg->text + tg->dict_seq_off[t], tg->dict_seq_len[t]);
+                    T.name = std::string_view(tg->text + tg->dict_name_off[t], tg->dict_name_len[t]);
+                    T.is_rc = tg->dict_is_rc ? tg->dict_is_rc[t] != 0 : false;
+                }
+                w.targets.p = w.target_store.data();
+                w.targets.n = (uint32_t)w.target_store.size();
+                return;
+            }
             const mtg_gap& a = gaps[gi];
             w.source = std::string_view(a.source, strlen(a.source));
             w.anchor_repeated = a.is_anchor_repeated != 0;
@@ -1109,6 +1126,75 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
     in.ws = batch_lock.ws;
     if (int rc = marshal_gaps(gaps, n, p, in)) return rc;
     return fill_marshalled(idx, p, in, gaps, n, seq_out, seq_cap, seq_bytes, out, t_begin);
+}
+/* mtg_fill_text: what the host does for a batch whose strings are still text -- the integer columns of block A from the caller's arrays
+ * (no string is looked at), the offset arrays and the block itself copied into the page-locked text block; the device does the rest */
+static int fill_text_impl(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes, mtg_results** out)
+{
+    using namespace mtgi;
+    if (!idx || !p || !out || !g) { set_error("null argument"); return MTG_ERR_ARG; }
+    const size_t n = (size_t)g->n;
+    if (n && (!g->text || !g->source_off || !g->source_len || !g->pattern_off || !g->pattern_len || !g->dict_first)) { set_error("null argument"); return MTG_ERR_ARG; }
+    const size_t nt = n ? g->dict_first[n] : 0;
+    if (nt && (!g->dict_seq_off || !g->dict_seq_len || !g->dict_name_off || !g->dict_name_len)) { set_error("null argument"); return MTG_ERR_ARG; }
+    if (n >> 31 || nt >> 31 || g->text_bytes >> 40) { set_error("batch too large"); return MTG_ERR_ARG; }
+    const double t_begin = now_ms();
+    WorkspaceLock batch_lock = acquire_workspace(idx);
+    FillInput in;
+    in.k = idx->dev.k;
+    in.ws = batch_lock.ws;
+    in.text_mode = true;
+    const int k = in.k;
+    in.resize(n);
+    /* one pass over the arrays: bounds, offsets of the patterns and of the dictionaries */
+    const uint64_t tb = g->text_bytes;
+    uint64_t rw = 0;
+    long bad = -1, shortg = -1, order = -1;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t sl = g->source_len[i], pl = g->pattern_len[i];
+        if (g->source_off[i] > tb || sl > tb - g->source_off[i] || g->pattern_off[i] > tb || pl > tb - g->pattern_off[i]) bad = (long)i;
+        if ((int)sl < k) shortg = (long)i;
+        if (g->dict_first[i + 1] < g->dict_first[i]) order = (long)i;
+        const uint8_t fl = g->gap_flags ? g->gap_flags[i] : 0;
+        in.roff[i] = (uint32_t)rw;
+        in.rlen[i] = pl;
+        rw += (pl + 31u) / 32u + 1u;
+        in.toff[i] = g->dict_first[i];
+        in.tcnt[i] = g->dict_first[i + 1] - g->dict_first[i];
+        in.nbmis[i] = (uint8_t)((fl & 1) ? 0 : p->nb_mis_allowed); /* src/Filler.cpp:859-863 */
+        in.flags[i] = (uint8_t)(((fl & 1) ? mtg::GAPF_REPEATED : 0) | ((fl & 2) ? mtg::GAPF_REVERSE : 0));
+    }
+    if (order >= 0) { set_error("gap %ld: dict_first is not ascending", order); return MTG_ERR_ARG; }
+    for (size_t t = 0; t < nt; t++)
+        if (g->dict_seq_off[t] > tb || g->dict_seq_len[t] > tb - g->dict_seq_off[t] || g->dict_name_off[t] > tb || g->dict_name_len[t] > tb - g->dict_name_off[t]) bad = (long)n;
+    if (bad >= 0) { set_error(bad == (long)n ? "a dictionary entry lies outside the text block" : "gap %ld: a string lies outside the text block", bad); return MTG_ERR_ARG; }
+    if (shortg >= 0) { set_error("gap %ld: source sequence shorter than k", shortg); return MTG_ERR_ARG; }
+    if (rw >> 31) { set_error("batch too large"); return MTG_ERR_ARG; }
+    in.n_rwords = rw;
+    in.n_text_targets = nt;
+    in.text_bytes = tb;
+    in.bytes_b = 8 * rw + 64;
+    in.bytes_c = FillInput::text_block_off(n, nt, 5) + tb + 64;
+    in.block_c = in.ws ? staging_host(in.ws, 2, in.bytes_c) : nullptr;
+    if (!in.block_c) { in.own_c.resize(in.bytes_c / 8 + 1); in.block_c = in.own_c.data(); }
+    uint8_t* c = (uint8_t*)in.block_c;
+    if (n) {
+        memcpy(c + FillInput::text_block_off(n, nt, 0), g->source_off, 8 * n);
+        memcpy(c + FillInput::text_block_off(n, nt, 1), g->pattern_off, 8 * n);
+        memcpy(c + FillInput::text_block_off(n, nt, 3), g->source_len, 4 * n);
+    }
+    if (nt) {
+        memcpy(c + FillInput::text_block_off(n, nt, 2), g->dict_seq_off, 8 * nt);
+        memcpy(c + FillInput::text_block_off(n, nt, 4), g->dict_seq_len, 4 * nt);
+    }
+    if (tb) memcpy(c + FillInput::text_block_off(n, nt, 5), g->text, tb);
+    return fill_marshalled(idx, p, in, nullptr, n, seq_out, seq_cap, seq_bytes, out, t_begin, nullptr, nullptr, g);
+}
+int mtg_fill_text(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, mtg_results** out) { return fill_text_impl(idx, p, g, nullptr, 0, nullptr, out); }
+int mtg_fill_text_serial(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
+{
+    if (!seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    return fill_text_impl(idx, p, g, seq_out, cap, seq_bytes, out);
 }
 int mtg_fill_batch(const mtg_index* idx, const mtg_params* p, const mtg_gap* gaps, size_t n, mtg_results** out)
 {

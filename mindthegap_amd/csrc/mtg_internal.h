@@ -45,7 +45,10 @@ struct mtg_index {
     mtg::Index dev{};          /* tables live in device memory */
     /* a few batches on one index run side by side (callers on several threads, like the reference's Dispatcher): each owns a workspace
      * and its streams, so the traversal of one overlaps the post-processing and the host passes of the other */
-    enum { NWS = 6 };
+#ifndef MTG_NWS
+#define MTG_NWS 6 /* batches one index serves at a time (each with its own device scratch, streams and staging blocks) */
+#endif
+    enum { NWS = MTG_NWS };
     mutable mtgi::Workspace ws[NWS];
     int device = 0;
     mtg_index_info info{};
@@ -283,6 +286,17 @@ struct FillInput {
     std::vector<uint64_t> own_a, own_b, own_c;
     /* device copies of the three blocks and of the encoded targets, when the batch was prepared ahead (mtg_batch): device_run then uploads nothing */
     void* dev_a = nullptr; void* dev_b = nullptr; void* dev_tenc = nullptr;
+    /* mtg_fill_text: the strings are still text.  Block A then holds only the integer columns the host can write without looking at a
+     * string (roff, rlen, toff, tcnt, nbmis, flags), block B does not exist on the host (n_rwords words on the device), and block C is the
+     * text block: [source_off 8n | pattern_off 8n | dict_seq_off 8nt | source_len 4n | dict_seq_len 4nt | pad to 8 | text]; the device
+     * writes src, r0, fast_ok, the patterns and the encoded targets (mtg_marshal.h). */
+    bool text_mode = false;
+    uint64_t n_rwords = 0, n_text_targets = 0, text_bytes = 0;
+    static size_t text_block_off(size_t n, size_t nt, int which) /* 0 source_off, 1 pattern_off, 2 dict_seq_off, 3 source_len, 4 dict_seq_len, 5 text */
+    {
+        const size_t o[6] = {0, 8 * n, 16 * n, 16 * n + 8 * nt, 20 * n + 8 * nt, (20 * n + 12 * nt + 7) & ~(size_t)7};
+        return o[which];
+    }
     /* two-pass marshalling: size(i, ...) for every gap in order, then layout(), then set(i, ...) from any thread */
     void resize(size_t n);
     void size(size_t i, size_t swf_len, size_t n_targets) { rlen[i] = (uint32_t)swf_len; tcnt[i] = (uint32_t)n_targets; }

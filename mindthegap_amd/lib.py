@@ -137,6 +137,8 @@ def _bind(lib):
     lib.mtg_index_create_from_reads.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, P(C.c_void_p)]
     lib.mtg_index_create_from_kmers.argtypes = [P(C.c_uint64), P(C.c_uint32), C.c_size_t, C.c_int, P(C.c_void_p)]
     lib.mtg_index_create_from_packed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, P(C.c_void_p)]
+    lib.mtg_fill_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_void_p)]
+    lib.mtg_fill_text_serial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, P(C.c_uint64), P(C.c_void_p)]
     lib.mtg_index_load.argtypes = [C.c_char_p, P(C.c_void_p)]
     lib.mtg_index_save.argtypes = [C.c_void_p, C.c_char_p]
     lib.mtg_index_replicate.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p)]
@@ -208,6 +210,53 @@ class Gap:
         self.source, self.target = source, target
         self.targets = list(targets)  # [(kmer, name, is_rc)] in dictionary iteration order
         self.is_anchor_repeated, self.reverse = is_anchor_repeated, reverse
+
+
+class CTextGaps(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("text_bytes", C.c_uint64), ("n", C.c_uint64), ("source_off", C.c_void_p), ("source_len", C.c_void_p), ("pattern_off", C.c_void_p),
+                ("pattern_len", C.c_void_p), ("dict_first", C.c_void_p), ("dict_seq_off", C.c_void_p), ("dict_seq_len", C.c_void_p), ("dict_name_off", C.c_void_p),
+                ("dict_name_len", C.c_void_p), ("dict_is_rc", C.c_void_p), ("gap_flags", C.c_void_p)]
+
+
+class TextGaps:
+    """mtg_text_gaps: a batch whose strings are (offset, length) pairs into one block of text (what mtg_fill_text encodes on the device).
+    Built here from a list of Gap by laying their strings out one after the other; a reader of a breakpoint file would point into its buffer."""
+
+    def __init__(self, gaps):
+        parts, off = [], 0
+
+        def put(s):
+            nonlocal off
+            b = s.encode() if isinstance(s, str) else s
+            parts.append(b)
+            o = off
+            off += len(b)
+            return o, len(b)
+
+        n = len(gaps)
+        so, sl, po, pl = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        first = np.zeros(n + 1, np.uint32)
+        flags = np.zeros(max(n, 1), np.uint8)
+        do, dl, no, nl, rc = [], [], [], [], []
+        for i, g in enumerate(gaps):
+            so[i], sl[i] = put(g.source)
+            po[i], pl[i] = put(g.target)
+            for (kmer, name, is_rc) in g.targets:
+                a, b = put(kmer)
+                do.append(a)
+                dl.append(b)
+                a, b = put(name)
+                no.append(a)
+                nl.append(b)
+                rc.append(1 if is_rc else 0)
+            first[i + 1] = len(do)
+            flags[i] = (1 if g.is_anchor_repeated else 0) | (2 if g.reverse else 0)
+        self.n = n
+        self.text = np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8).copy()
+        self.arrays = dict(source_off=so, source_len=sl, pattern_off=po, pattern_len=pl, dict_first=first, dict_seq_off=np.array(do + [0], np.uint64), dict_seq_len=np.array(dl + [0], np.uint32),
+                           dict_name_off=np.array(no + [0], np.uint64), dict_name_len=np.array(nl + [0], np.uint32), dict_is_rc=np.array(rc + [0], np.uint8), gap_flags=flags)
+        self.c = CTextGaps(self.text.ctypes.data, len(self.text) - 1, n, *[self.arrays[k].ctypes.data for k in ("source_off", "source_len", "pattern_off", "pattern_len", "dict_first", "dict_seq_off",
+                                                                                                            "dict_seq_len", "dict_name_off", "dict_name_len", "dict_is_rc", "gap_flags")])
 
 
 class Batch:
@@ -373,6 +422,9 @@ class Index:
         if isinstance(prepared, Batch):
             n = prepared.n
             _check(self.lib.mtg_fill_prepared(self.h, C.byref(params.c), prepared.h, C.byref(h)))
+        elif isinstance(prepared, TextGaps):
+            n = prepared.n
+            _check(self.lib.mtg_fill_text(self.h, C.byref(params.c), C.byref(prepared.c), C.byref(h)))
         else:
             arr, n, _ = prepared
             _check(self.lib.mtg_fill_batch(self.h, C.byref(params.c), arr, n, C.byref(h)))

@@ -6,6 +6,7 @@
  * (and sanitizers) without a GPU.  The product library never contains this file.
  */
 #include "../../mindthegap_amd/csrc/mtg_internal.h"
+#include "../../mindthegap_amd/csrc/mtg_marshal.h"
 #include "emu_us.h"
 #include "emu_walk.h"
 #include <map>
@@ -299,11 +300,25 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     if (const char* e = getenv("MTG_EMU_FAIL_DEVICE"))
         if (atoi(e) == idx->device) { set_error("injected failure on device %d", idx->device); return MTG_ERR_NOMEM; }
     const int k = idx->dev.k;
-    /* stand-in for k_encode_targets */
-    const size_t n_targets = in.traw.size() / TARGET_SLOT;
-    std::vector<uint64_t> tle(n_targets), tbad(n_targets);
-    for (size_t t = 0; t < n_targets; t++) encode_target(in.traw.data() + t * TARGET_SLOT, k, tle[t], tbad[t]);
     const size_t n = in.src.size();
+    /* stand-in for k_encode_targets, or (mtg_fill_text) for k_marshal_text and k_marshal_targets: the same per-gap functions, from the text block */
+    const size_t n_targets = in.text_mode ? (size_t)in.n_text_targets : in.traw.size() / TARGET_SLOT;
+    std::vector<uint64_t> tle(n_targets), tbad(n_targets), text_rw;
+    if (in.text_mode) {
+        const uint8_t* c = (const uint8_t*)in.block_c;
+        const uint8_t* text = c + FillInput::text_block_off(n, n_targets, 5);
+        const uint64_t* soff = (const uint64_t*)(c + FillInput::text_block_off(n, n_targets, 0));
+        const uint64_t* poff = (const uint64_t*)(c + FillInput::text_block_off(n, n_targets, 1));
+        const uint64_t* doff = (const uint64_t*)(c + FillInput::text_block_off(n, n_targets, 2));
+        const uint32_t* slen = (const uint32_t*)(c + FillInput::text_block_off(n, n_targets, 3));
+        const uint32_t* dlen = (const uint32_t*)(c + FillInput::text_block_off(n, n_targets, 4));
+        text_rw.assign(in.n_rwords + 1, 0xA5A5A5A5A5A5A5A5ull);
+        FillInput& w = const_cast<FillInput&>(in); /* block B exists on the device only: here it is this vector */
+        w.rwords.p = text_rw.data(); w.rwords.n = in.n_rwords;
+        for (size_t g = 0; g < n; g++) marshal_text_gap(text, soff[g], slen[g], poff[g], in.rlen[g], k, text_rw.data() + in.roff[g], in.src[g], in.r0[g], in.rlen[g], in.fast_ok[g]);
+        for (size_t t = 0; t < n_targets; t++) marshal_text_target(text, doff[t], dlen[t], k, tle[t], tbad[t]);
+    } else
+        for (size_t t = 0; t < n_targets; t++) encode_target(in.traw.data() + t * TARGET_SLOT, k, tle[t], tbad[t]);
     special.chunks.clear();
     special.special.clear();
     sink.seq_used = 0;

@@ -996,3 +996,9 @@ def test_results_over_the_wire(emu_product):
             L.WireResults(bad)
         idx.free_results(h)
         batch.close(); idx.close(); o.close()
+
+
+def test_text_batches_marshalled_by_the_device_code(emu_product):
+    """mtg_fill_text on the emulator: tests/text_cases.py"""
+    from tests import text_cases
+    text_cases.run(emu_product, oracle_lib)

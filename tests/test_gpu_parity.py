@@ -666,3 +666,11 @@ def test_index_replica_and_tool_on_replicas(mtg, tmp_path, monkeypatch):
     b.close(); o.close()
     monkeypatch.setenv("MTG_CLI_BATCH", "4")
     _edge_case_run(mtg, tmp_path)
+
+
+def test_text_batches_marshalled_on_the_device(mtg):
+    """mtg_fill_text: strings as offsets into one block of text, encoded by k_marshal_text / k_marshal_targets, against mtg_fill_batch on the
+    same strings (lower case, N, keys and patterns shorter or longer than k, empty and multiple dictionaries, repeated anchors, reverse
+    attempts); malformed batches are refused"""
+    from tests import oracle_lib, text_cases
+    text_cases.run(mtg, oracle_lib)
