@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=list(WORKLOADS))
     ap.add_argument("--sites", type=int, default=0, help="sites per batch (default: the workload's)")
+    ap.add_argument("--cpu-same-sites", type=int, default=1000, help="sites (and donor sequences) of the same-algorithm CPU measurement (0: skip)")
     ap.add_argument("--no-children", action="store_true", help="skip the secondary workloads (child processes)")
     ap.add_argument("--tool-sites", type=int, default=2000000, help="sites of the tool measurement (the sites of the batches, repeated)")
     ap.add_argument("--batches", type=int, default=4, help="distinct batches of sites rotated through the steps (N = 1 and weak scaling)")
@@ -581,6 +582,31 @@ def main():
                "seconds": ost["seconds"], "identical_to_hip": cpu_seqs == hip_seqs and len(hip_seqs) > 0,
                "reference_binary": reference_binary() or "no MindTheGap install on this machine (BASELINE.md section 2): the port is timed"}
         oidx.close()
+        # the product's own algorithm on the host cores (tests/emu build without its cross-checks, one process per core): what a CPU does with the
+        # unitig-store walk the GPU runs -- the GPU/CPU ratio of the same algorithm, next to the ratio against the reference's algorithm above
+        if a.cpu_same_sites > 0 and not het:
+            try:
+                nsa = min(a.cpu_same_sites, b0.n)
+                o2 = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(nsa)], k, 3, 0)  # k-mer counting only (the emulated index is built from the counts)
+                km2, ct2 = o2.export()
+                o2.close()
+                with tempfile.TemporaryDirectory() as d:
+                    np.save(os.path.join(d, "km.npy"), km2)
+                    np.save(os.path.join(d, "ct.npy"), ct2)
+                    json.dump([(g.source, g.target, g.targets[0][1]) for g in b0.gaps[:nsa]], open(os.path.join(d, "gaps.json"), "w"))
+                    procs = max(1, min(cores, 16))
+                    cp = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu_cpu_rate.py"), os.path.join(d, "km.npy"), os.path.join(d, "ct.npy"), os.path.join(d, "gaps.json"), str(procs)],
+                                        capture_output=True, text=True, timeout=600)
+                    sa = json.loads(cp.stdout.strip().splitlines()[-1])
+                res2 = idx.fill_batch(b0.gaps[:nsa], params)
+                hip2 = hashlib.sha256("\n".join(sorted(f["seq"] for r in res2 for f in r["filled"])).encode()).hexdigest()
+                cpu["same_algorithm_value"] = sa["sites"] / sa["seconds"]
+                cpu["same_algorithm"] = {"unit": "breakpoints/s", "processes": sa["processes"], "sites": sa["sites"], "distinct_sites": sa["distinct_sites"], "seconds": sa["seconds"],
+                                         "identical_to_hip": sa["sha256"] == hip2,
+                                         "what": "the device code compiled for the host (tests/emu, cross-checks compiled out), one process per core, each with its own index over the first %d donor "
+                                                 "sequences and a slice of their sites (repeated to >= 3000 per process); traversal + copy + post + emit of mtg_fill_batch, as on the device" % nsa}
+            except Exception as e:
+                cpu["same_algorithm"] = {"error": repr(e)[:300]}
 
     # ---------------------------------------------------------------- roofline.  What binds the job is the link to the host: every step copies its results
     # (records + ASCII sequences) into page-locked host memory.  Under it, per kernel of a step, the bytes the implemented layout has to move against HBM.

@@ -20,6 +20,10 @@
 #include <condition_variable>
 #include <thread>
 #include <zlib.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
+#include <deque>
 #include <atomic>
 #include <chrono>
 
@@ -102,6 +106,7 @@ struct Options {
 struct Files {
     FILE *insert = nullptr, *info = nullptr, *vcf = nullptr, *gfa = nullptr, *ext = nullptr;
     ~Files() { for (FILE* f : {insert, info, vcf, gfa, ext}) if (f) fclose(f); }
+    FILE* stream(int i) const { return i == 0 ? insert : i == 1 ? info : i == 2 ? vcf : i == 3 ? gfa : ext; }
 };
 /* the text a run of sites adds to the output files: formatted by whoever has the records (several threads, one piece each), written by the
  * one thread that owns the files, in input order */
@@ -115,6 +120,86 @@ struct OutText {
         if (F.gfa && !gfa.empty()) fwrite(gfa.data(), 1, gfa.size(), F.gfa);
         if (F.ext && !ext.empty()) fwrite(ext.data(), 1, ext.size(), F.ext);
     }
+};
+/* The output files of a long run, written by several threads: the pieces of text get their places in input order (one thread hands them
+ * out, as it would have written them), the bytes go there with pwrite from a few writer threads -- a memory-backed or page-cached file takes
+ * several GB/s from each.  Whatever was written through the FILE* before begin() stays in front; after finish() the FILE* continue behind. */
+struct PositionedWriter {
+    struct Job { std::shared_ptr<void> owner; const OutText* T; off_t at[5]; };
+    Files& F;
+    int fd[5];
+    off_t pos[5];
+    std::vector<std::thread> threads;
+    std::mutex mtx;
+    std::condition_variable cv_job, cv_room;
+    std::deque<Job> q;
+    size_t pending_bytes = 0;
+    bool done = false;
+    std::atomic<bool> failed{false};
+    explicit PositionedWriter(Files& f) : F(f)
+    {
+        for (int i = 0; i < 5; i++) {
+            FILE* s = F.stream(i);
+            fd[i] = -1; pos[i] = 0;
+            if (s) { fflush(s); fd[i] = fileno(s); pos[i] = ftello(s); }
+        }
+        const int nw = std::max(1, std::min(6, Pool::cpu_budget() / 2));
+        for (int t = 0; t < nw; t++) threads.emplace_back([this] { run(); });
+    }
+    static const std::string& text_of(const OutText& T, int i) { return i == 0 ? T.insert : i == 1 ? T.info : i == 2 ? T.vcf : i == 3 ? T.gfa : T.ext; }
+    /* called in input order: the piece's places are the current ends of the files */
+    void add(std::shared_ptr<void> owner, const OutText& T)
+    {
+        Job j;
+        j.owner = std::move(owner); j.T = &T;
+        size_t bytes = 0;
+        for (int i = 0; i < 5; i++) { j.at[i] = pos[i]; if (fd[i] >= 0) { pos[i] += (off_t)text_of(T, i).size(); bytes += text_of(T, i).size(); } }
+        std::unique_lock<std::mutex> lk(mtx);
+        cv_room.wait(lk, [&] { return pending_bytes < ((size_t)1 << 30); }); /* formatted text waiting for its writer: bounded */
+        pending_bytes += bytes;
+        q.push_back(std::move(j));
+        cv_job.notify_one();
+    }
+    void run()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mtx);
+                cv_job.wait(lk, [&] { return done || !q.empty(); });
+                if (q.empty()) return;
+                j = std::move(q.front());
+                q.pop_front();
+            }
+            size_t bytes = 0;
+            for (int i = 0; i < 5; i++) {
+                if (fd[i] < 0) continue;
+                const std::string& t = text_of(*j.T, i);
+                bytes += t.size();
+                size_t w = 0;
+                while (w < t.size()) {
+                    const ssize_t got = ::pwrite(fd[i], t.data() + w, t.size() - w, j.at[i] + (off_t)w);
+                    if (got < 0) { if (errno == EINTR) continue; failed = true; break; }
+                    w += (size_t)got;
+                }
+            }
+            j.owner.reset();
+            std::lock_guard<std::mutex> lk(mtx);
+            pending_bytes -= bytes;
+            cv_room.notify_all();
+        }
+    }
+    /* true when every byte is in its file; the FILE* then continue behind what was written */
+    bool finish()
+    {
+        { std::lock_guard<std::mutex> lk(mtx); done = true; }
+        cv_job.notify_all();
+        for (std::thread& t : threads) t.join();
+        threads.clear();
+        for (int i = 0; i < 5; i++) if (fd[i] >= 0) fseeko(F.stream(i), pos[i], SEEK_SET);
+        return !failed;
+    }
+    ~PositionedWriter() { if (!threads.empty()) finish(); }
 };
 static void appendf(std::string& o, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 static void appendf(std::string& o, const char* fmt, ...)
@@ -394,12 +479,26 @@ static int run_batches(const Replicas& R, const std::function<bool(size_t)>& nex
 struct BkptRec { const char* hdr; uint32_t hdr_len; const char* seq; uint32_t seq_len; };
 struct BkptReader {
     gzFile f = nullptr;
+    int fd = -1; /* a file that is not gzip-compressed is read with read(2): zlib's pass-through copies and checksums for nothing */
     std::vector<char> carry; /* the beginning of the next batch: a partial record, or records beyond the batch size */
     bool eof = false, bad = false;
     size_t per_batch; /* records */
     explicit BkptReader(size_t sites_per_batch) : per_batch(2 * sites_per_batch) {}
-    ~BkptReader() { if (f) gzclose(f); }
-    bool open(const std::string& path) { f = gzopen(path.c_str(), "rb"); if (f) gzbuffer(f, 1 << 20); return f != nullptr; }
+    ~BkptReader() { if (f) gzclose(f); if (fd >= 0) ::close(fd); }
+    bool open(const std::string& path)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = ::pread(fd, magic, 2, 0);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            ::close(fd); fd = -1;
+            f = gzopen(path.c_str(), "rb");
+            if (f) gzbuffer(f, 1 << 20);
+            return f != nullptr;
+        }
+        return true;
+    }
     /* the text of the next per_batch records (fewer at the end of the file) into `text`; false: no record is left */
     bool next(std::vector<char>& text)
     {
@@ -422,6 +521,18 @@ struct BkptReader {
             if (cut != std::string::npos || eof) break;
             const size_t old = text.size(), want = (size_t)8 << 20;
             text.resize(old + want);
+            if (fd >= 0) {
+                size_t have = 0;
+                while (have < want) {
+                    const ssize_t got = ::read(fd, text.data() + old + have, want - have);
+                    if (got < 0) { if (errno == EINTR) continue; bad = true; eof = true; break; }
+                    if (got == 0) { eof = true; break; }
+                    have += (size_t)got;
+                }
+                text.resize(old + have);
+                if (bad) break;
+                continue;
+            }
             const int got = gzread(f, text.data() + old, (unsigned)want);
             if (got < 0) { bad = true; eof = true; text.resize(old); break; }
             text.resize(old + (size_t)got);
@@ -543,6 +654,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
     static const bool timers = getenv("MTG_TOOL_TIMERS") != nullptr;
     std::atomic<long long> t_read{0}, t_parse{0}, t_fill{0}, t_rev{0}, t_format{0}, t_write{0};
     const auto usec = [] { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    PositionedWriter writer(F);
     std::mutex bm;
     std::vector<std::unique_ptr<Batch>> batches;
     const auto next = [&](size_t b) -> bool {
@@ -643,13 +755,20 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         std::unique_ptr<Batch> bt;
         { std::lock_guard<std::mutex> lk(bm); bt = std::move(batches[b]); }
         const long long tw = usec();
-        for (const OutText& T : bt->out) T.write(F);
+        std::shared_ptr<Batch> keep(bt.release()); /* the text lives until its last piece is in the files */
+        for (const OutText& T : keep->out) writer.add(keep, T);
+        Batch* const btq = keep.get();
         t_write += usec() - tw;
-        S.nb_breakpoints += (int)bt->n;
-        S.nb_filled += (int)bt->filled;
-        S.nb_multiple += (int)bt->multiple;
+        S.nb_breakpoints += (int)btq->n;
+        S.nb_filled += (int)btq->filled;
+        S.nb_multiple += (int)btq->multiple;
     };
-    const int rc = run_batches(R, next, process, consume);
+    int rc = run_batches(R, next, process, consume);
+    {
+        const long long tw = usec();
+        if (!writer.finish() && !rc) { set_error("cannot write the output files"); rc = MTG_ERR_IO; }
+        t_write += usec() - tw;
+    }
     if (timers)
         fprintf(stderr, "[tool] ms summed over threads: read %.1f | parse + gaps %.1f, forward fill %.1f, reverse attempts %.1f, format %.1f | write %.1f\n", t_read / 1e3, t_parse / 1e3, t_fill / 1e3,
                 t_rev / 1e3, t_format / 1e3, t_write / 1e3);

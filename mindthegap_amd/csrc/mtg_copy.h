@@ -60,7 +60,7 @@ MTG_DEV void copy_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
         }
     }
     if (MTG_LANE() == 0) { LeanRec r; r.valid = lean ? 1u : 0u; r.pos0 = pos0; r.cmd = ci; r.pad_ = 0; *lr = r; }
-#ifndef MTG_EMU
+#ifndef MTG_XCHECK
     if (lean) return; /* nothing of the contig is read from the arena (the emulation build copies all the same: its cross-checks read it) */
 #endif
     if (o.n_cmds == 0) return;

@@ -37,6 +37,10 @@
 #define MTG_GLOBAL __attribute__((address_space(1))) /* same for the index tables: global_load instead of flat_load */
 #else
 #define MTG_EMU 1
+#ifndef MTG_NO_XCHECK
+#define MTG_XCHECK 1 /* TEST-ONLY cross-checks of the emulation build: every shortcut of the device code next to the form it replaces (statuses 0xBAD*).
+                        -DMTG_NO_XCHECK leaves them out: the device code alone on the host, for bench.py's same-algorithm CPU number */
+#endif
 #define MTG_DEV inline
 #define MTG_HD inline
 #define MTG_DEV_NOINLINE inline

@@ -145,7 +145,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     const LeanRec lean = *s_lean(cfg, S);
     out.lean = 0;
     if (lean.valid) {
-#ifdef MTG_EMU /* TEST-ONLY: the search the lean form replaces finds the same place (the emulation build has copied the contig) */
+#ifdef MTG_XCHECK /* TEST-ONLY: the search the lean form replaces finds the same place (the emulation build has copied the contig) */
         {
             const uint32_t L0 = clen[0];
             const uint64_t* w = words + cstart[0];
@@ -278,7 +278,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
             const int64_t rel = rel0 + (int64_t)j; /* the k-mer's first nucleotide, relative to the command's first one */
             const uint64_t kpos = (uint64_t)(bwd ? p - rel - (int64_t)(k - 1) : p + rel);
             const uint32_t a = ix.us.ab[kpos];
-#ifdef MTG_EMU /* TEST-ONLY: the k-mer found there is the contig's, and the byte is its abundance */
+#ifdef MTG_XCHECK /* TEST-ONLY: the k-mer found there is the contig's, and the byte is its abundance */
             {
                 Kmer x;
                 x.r = le_kmer(w0, j, mk) ^ cmpl;

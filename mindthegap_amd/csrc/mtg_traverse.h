@@ -661,7 +661,7 @@ MTG_DEV_NOINLINE int find_end_of_branching(Worker& W, const Kmer& start, uint64_
     return depth;
 }
 
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
 /* TEST-ONLY: the enumeration node by node, one frame per node, exactly as the reference recurses; the emulation build runs it after
  * all_consensuses_between and compares (status 0xBAD4) */
 MTG_DEV_NOINLINE bool all_consensuses_between_nodes(Worker& W, const Kmer& start, uint64_t end_c, int traversal_depth, int& ncons)
@@ -1088,7 +1088,7 @@ MTG_UNROLL
             int m = mlb;
             const bool need_dp = identity_below_90(mlb, na, nb);
             if (need_dp) m = nw_matches(W, pa, na, pb, nb);
-#ifdef MTG_EMU /* TEST-ONLY: the bound against the alignment itself */
+#ifdef MTG_XCHECK /* TEST-ONLY: the bound against the alignment itself */
             {
                 const int mx_ = nw_matches(W, pa, na, pb, nb);
                 if (mx_ < mlb || (!need_dp && identity_below_90(mx_, na, nb))) { W.status = 0xBAD6; return -1; }
@@ -1105,7 +1105,7 @@ MTG_UNROLL
         int len = cons_len[c];
         if (len == 0) continue;
         unsigned long sum = (unsigned long)cons_sum[c];
-#ifdef MTG_EMU /* TEST-ONLY: the sum node by node, as the reference computes it */
+#ifdef MTG_XCHECK /* TEST-ONLY: the sum node by node, as the reference computes it */
         {
             unsigned long sum2 = 0;
             Kmer x = start;
@@ -1139,7 +1139,7 @@ MTG_UNROLL
  * Anything else -- including a fingerprint collision that turns out to be a real duplicate -- returns 0 and the caller runs the
  * general code, so the fast path never decides a case it does not fully understand.  The distinctness test keeps 16-bit fingerprints
  * of the canonical k-mers in a small table (LDS); a fingerprint seen before is checked exactly by walking the branches again. */
-#ifdef MTG_EMU /* TEST-ONLY: the explicit duplicate search that cross-checks the closed-form distinctness test on every bubble */
+#ifdef MTG_XCHECK /* TEST-ONLY: the explicit duplicate search that cross-checks the closed-form distinctness test on every bubble */
 MTG_DEV uint32_t fp_hash(uint64_t c) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 32); }
 /* layout: the slots of a lane in groups of 8 bytes (group g of lane l at g * 512 + l * 8), so that the table is cleared 8 slots at a
  * time and the lanes of a wave never fight for a bank when they do */
@@ -1172,7 +1172,7 @@ struct SnpSeq {
         return (uint32_t)w & (c >= 16 ? 0xFFFFFFFFu : ((1u << (2 * c)) - 1u));
     }
 };
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
 /* is canonical k-mer c among: the node, prev_c, and the first `steps` nodes of each branch (the walk is replayed from the nucleotides
  * known so far), the node of branch `skip_branch` at position `skip_pos` excepted */
 MTG_DEV bool snp_seen_exactly(const Worker& W, const Kmer& cur, uint64_t prev_c, const SnpSeq* seq, int steps, uint64_t c, int skip_branch, int skip_pos)
@@ -1308,7 +1308,7 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
     SnpSeq seq[2];
 MTG_UNROLL
     for (int br = 0; br < 2; br++) { x[br] = kmer_next(cur, nt0[br], k, W.mk); seq[br].lo = nt0[br]; seq[br].hi = 0; }
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
     bool dup_exact = false; /* cross-check of the closed-form test */
     fp_clear(W.S);
     fp_add(W.S, canon(cur));
@@ -1345,14 +1345,14 @@ MTG_UNROLL
         adj_right2_raw(W.ix, x[0], x[1], W.mk1, W.lines, r1[0], r1[1]);
         have_r1 = true;
         bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be, hopeless);
-#ifndef MTG_EMU
+#ifndef MTG_XCHECK
         if (hopeless) return 0;
 #endif
 #ifdef MTG_TRACE_BULK
         fprintf(stderr, "SNP bulk %d L=%d\n", (int)bulk_ok, bL);
 #endif
     }
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
     const bool run_loop = true;
 #define MTG_SNP_FAIL(code) do { if (bulk_ok && (code) != 1) W.status = 0xBAD3; return 0; } while (0)
 #else
@@ -1376,7 +1376,7 @@ MTG_UNROLL
             const uint64_t c = canon(x[br]);
             ab_issue(W.ix, c, pend[br]);
             if (!suspect(c)) MTG_SNP_FAIL(1); /* too many to remember: the general code decides */
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
             if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) dup_exact = true;
 #endif
             if (x[br].f == x[br].r || c == prev_c) MTG_SNP_FAIL(2);
@@ -1400,7 +1400,7 @@ MTG_UNROLL
         x[1] = y1;
     }
     if (L == 0) MTG_SNP_FAIL(2);
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
     if (hopeless) { W.status = 0xBAD8; return 0; } /* the bulk form gave up on a bubble the loop answers */
 #endif
 #undef MTG_SNP_FAIL
@@ -1411,7 +1411,7 @@ MTG_UNROLL
         const uint64_t c = i == 0 ? cand0 : i == 1 ? cand1 : i == 2 ? cand2 : cand3;
         if (set_has(s_marked(W.cfg, W.S), W.cfg.mcap, c)) return 0; /* the bubble touches an assembled region */
     }
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
     if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, seq, L, ce, -1, 0)) dup_exact = true;
     if (dup_exact && !(ce == canon(cur) || ce == prev_c)) { W.status = 0xBAD0; return 0; } /* the closed-form test missed a duplicate */
 #endif
@@ -1430,7 +1430,7 @@ MTG_UNROLL
          * when that many pass the 90 % test, so does the traceback's count, whatever it is */
         bool need_dp = identity_below_90(n - h, n, n);
         if (need_dp && W.no_dp) return 0; /* the general code answers this bubble the same way, with the alignment */
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
         const bool bound_says_pass = !need_dp;
         need_dp = true;
 #endif
@@ -1443,7 +1443,7 @@ MTG_UNROLL
                 for (int i = 0; i < n; i++) cons[(size_t)br * CONS_LEN + i] = (uint8_t)seq[br].get(i);
             matches = nw_matches(W, cons, n, cons + (size_t)CONS_LEN, n);
             MTG_T1(t_nw, 12);
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
             if (matches < n - h || (bound_says_pass && identity_below_90(matches, n, n))) { W.status = 0xBAD6; return 0; }
 #endif
         }
@@ -1451,7 +1451,7 @@ MTG_UNROLL
     if (identity_below_90(matches, n, n)) return 0;
     /* most abundant consensus: the last step's buckets and the node's own */
     if (have_pend) { sum[0] += ab_finish(W.ix, pend[0], W.lines); sum[1] += ab_finish(W.ix, pend[1], W.lines); }
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
     if (bulk_ok && (L != bL || h != bh || e.f != be.f || seq[0].lo != bseq[0].lo || seq[0].hi != bseq[0].hi || seq[1].lo != bseq[1].lo || seq[1].hi != bseq[1].hi ||
                     sum[0] != bsum[0] || sum[1] != bsum[1])) { W.status = 0xBAD2; return 0; }
 #endif
@@ -1495,7 +1495,7 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
     MTG_T0(t_dfs);
     const bool okc = all_consensuses_between(W, cur, canon(e), end_rp, d + 1, ncons);
     MTG_T1(t_dfs, 3);
-#ifdef MTG_EMU /* TEST-ONLY: the enumeration node by node must give the same consensuses in the same order */
+#ifdef MTG_XCHECK /* TEST-ONLY: the enumeration node by node must give the same consensuses in the same order */
     if (!W.status) {
         auto digest = [&](int n) -> uint64_t {
             uint64_t h = 0x9E3779B97F4A7C15ULL * (uint64_t)(n + 1);
@@ -1771,7 +1771,7 @@ MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch&
                 nacc = tot - 32;
             } else nacc = tot;
         };
-#ifdef MTG_EMU /* TEST-ONLY cross-check of the reasoning above: every node of the long step is looked at */
+#ifdef MTG_XCHECK /* TEST-ONLY cross-check of the reasoning above: every node of the long step is looked at */
         {
             Kmer x = cur;
             uint64_t p = run_pos;
@@ -2032,7 +2032,7 @@ MTG_UNROLL
             /* dead end.  The reference still calls explore_branching here: its frontline has no successor to move to and gives up at once,
              * nothing is marked and its visited set is dropped -- the contig ends, which is all that is left of the call. */
             end_contig = true;
-#ifdef MTG_EMU /* TEST-ONLY: run it anyway and see that nothing comes of it */
+#ifdef MTG_XCHECK /* TEST-ONLY: run it anyway and see that nothing comes of it */
             { int ch_ = -1; const uint32_t nm_ = W.n_marked; if (explore_branching(W, cur, prev_c, ch_) != 0 || W.n_marked != nm_ || W.n_seen != 0) W.status = 0xBAD9; }
 #endif
         }
@@ -2084,7 +2084,7 @@ MTG_UNROLL
 #ifdef MTG_EMU
                     coop_tally(n);
 #endif
-#ifdef MTG_EMU /* TEST-ONLY: the general code next to every answer of the group form -- same verdict, same consensus, same marks (0xBADC) */
+#ifdef MTG_XCHECK /* TEST-ONLY: the general code next to every answer of the group form -- same verdict, same consensus, same marks (0xBADC) */
                     if (n >= 0 && W.status == GAP_OK) {
                         uint32_t planned_new = 0;
                         for (uint32_t i = 0; i < (n > 0 ? L->n_marks : 0u); i++) {
@@ -2140,7 +2140,7 @@ MTG_UNROLL
                             done += c;
                         }
                         const Kmer z = kmer_next(y, fast_seq.get(n - 1), k, mk);
-#ifdef MTG_EMU /* TEST-ONLY: node by node */
+#ifdef MTG_XCHECK /* TEST-ONLY: node by node */
                         {
                             Kmer q = cur, qp = cur;
                             for (int i = 0; i < n; i++) { qp = q; q = kmer_next(q, fast_seq.get(i), k, mk); if (canon(q) == start_c || (r_is_kmer && q.f == R.r0)) W.status = 0xBADB; }
@@ -2174,7 +2174,7 @@ MTG_UNROLL
                     push_nt(nti);
                     len++;
                     if (!fast) {
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
                         const bool br_ref = W.is_branching(cur);
                         bool br_here = false;
 #endif
@@ -2187,11 +2187,11 @@ MTG_UNROLL
                             if (branching) W.mark_canon(canon(cur));
                             RunAt ru;
                             if (us.nwords && run_at(us, r, k, ru, lines)) c_ra = ru.ahead;
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
                             br_here = branching;
 #endif
                         }
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
                         if (br_ref != br_here) W.status = 0xBAD7;
 #endif
                     }
@@ -2222,7 +2222,7 @@ MTG_UNROLL
         if (node_depth + (int)clen > cfg.max_depth) continue;
         /* push the successors that were never extended from */
         const Adj ea = a_is_cur ? a : adj_right_t(adj, cur, mk1, lines); /* the walk usually stopped on a node whose neighbourhood it has just read */
-#ifdef MTG_EMU
+#ifdef MTG_XCHECK
         { uint32_t l_ = 0; if (adj_right_t(adj, cur, mk1, l_).out != ea.out) W.status = 0xBADA; }
 #endif
         for (uint32_t em = ea.out & 15u; em; em &= em - 1u) {
@@ -2296,7 +2296,7 @@ template <int G> MTG_DEV bool bubble_coop(const Index& ix, const FillCfg& cfg, c
     coop_tally(n);
 #endif
     if (n < 0) return false;
-#ifdef MTG_EMU /* TEST-ONLY: the general code next to the group form's answer: same verdict, consensus and marks */
+#ifdef MTG_XCHECK /* TEST-ONLY: the general code next to the group form's answer: same verdict, consensus and marks */
     {
         uint32_t planned_new = 0;
         for (uint32_t i = 0; i < (n > 0 ? L.n_marks : 0u); i++) {
