@@ -112,6 +112,7 @@ struct Files {
  * one thread that owns the files, in input order */
 struct OutText {
     std::string insert, info, vcf, gfa, ext;
+    void clear() { insert.clear(); info.clear(); vcf.clear(); gfa.clear(); ext.clear(); } /* the capacities stay */
     void write(Files& F) const
     {
         if (F.insert && !insert.empty()) fwrite(insert.data(), 1, insert.size(), F.insert);
@@ -121,6 +122,29 @@ struct OutText {
         if (F.ext && !ext.empty()) fwrite(ext.data(), 1, ext.size(), F.ext);
     }
 };
+/* Buffers of a long run are used again: a batch's text (17 MB) and its formatted pieces (88 MB) in fresh memory cost a page fault per 4 KB,
+ * which at 20 batches a second was most of the reader's and a third of the formatters' time.  Process-wide, bounded. */
+template <class T> struct Recycler {
+    std::mutex m;
+    std::vector<T> free;
+    size_t keep;
+    explicit Recycler(size_t k) : keep(k) {}
+    T get()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (free.empty()) return T();
+        T t = std::move(free.back());
+        free.pop_back();
+        return t;
+    }
+    void put(T&& t)
+    {
+        t.clear();
+        std::lock_guard<std::mutex> lk(m);
+        if (free.size() < keep) free.push_back(std::move(t));
+    }
+};
+static Recycler<OutText>& piece_pool() { static Recycler<OutText> p(512); return p; }
 /* The output files of a long run, written by several threads: the pieces of text get their places in input order (one thread hands them
  * out, as it would have written them), the bytes go there with pwrite from a few writer threads -- a memory-backed or page-cached file takes
  * several GB/s from each.  Whatever was written through the FILE* before begin() stays in front; after finish() the FILE* continue behind. */
@@ -424,7 +448,7 @@ static int cli_in_flight()
 static int run_batches(const Replicas& R, const std::function<bool(size_t)>& next, const std::function<int(size_t, const mtg_index*)>& process,
                        const std::function<void(size_t)>& consume)
 {
-    std::mutex m;
+    std::mutex m, read_m;
     std::condition_variable cv;
     size_t handed = 0, consumed = 0; /* batches handed out / consumed */
     bool exhausted = false;
@@ -440,8 +464,13 @@ static int run_batches(const Replicas& R, const std::function<bool(size_t)>& nex
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return exhausted || err || handed - consumed < window; });
                 if (exhausted || err) return;
-                b = handed;
-                if (!next(b)) { exhausted = true; cv.notify_all(); return; }
+            }
+            {   /* the next batch is read by one worker at a time, in order, but not under the scheduler's lock: completions and the writer go on */
+                std::lock_guard<std::mutex> rl(read_m);
+                { std::lock_guard<std::mutex> lk(m); if (exhausted || err) return; b = handed; }
+                const bool more = next(b);
+                std::lock_guard<std::mutex> lk(m);
+                if (!more) { exhausted = true; cv.notify_all(); return; }
                 handed++;
                 done.push_back(0);
             }
@@ -477,10 +506,22 @@ static int run_batches(const Replicas& R, const std::function<bool(size_t)>& nex
 /* ---- the breakpoint file as a stream of batches (src/Filler.cpp:285,844: records 2i / 2i+1 = left / right k-mer of site i).  A batch owns
  * the text of its records; headers and sequences are NUL-terminated in place, so that the gaps handed to the library point straight into it. */
 struct BkptRec { const char* hdr; uint32_t hdr_len; const char* seq; uint32_t seq_len; };
+/* the text of a batch: a vector whose resize() leaves the new bytes as they are (they are read into at once; zeroing 17 MB per batch was a
+ * third of the reader's time) */
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+typedef std::vector<char, NoInitAlloc<char>> TextBuf;
+static Recycler<TextBuf>& text_pool() { static Recycler<TextBuf> p(16); return p; }
 struct BkptReader {
     gzFile f = nullptr;
     int fd = -1; /* a file that is not gzip-compressed is read with read(2): zlib's pass-through copies and checksums for nothing */
-    std::vector<char> carry; /* the beginning of the next batch: a partial record, or records beyond the batch size */
+    TextBuf carry; /* the beginning of the next batch: a partial record, or records beyond the batch size */
     bool eof = false, bad = false;
     size_t per_batch; /* records */
     explicit BkptReader(size_t sites_per_batch) : per_batch(2 * sites_per_batch) {}
@@ -500,10 +541,14 @@ struct BkptReader {
         return true;
     }
     /* the text of the next per_batch records (fewer at the end of the file) into `text`; false: no record is left */
-    bool next(std::vector<char>& text)
+    size_t last_bytes = 0;
+    bool next(TextBuf& text)
     {
+        text = text_pool().get();
         text.clear();
-        text.swap(carry);
+        text.insert(text.end(), carry.begin(), carry.end());
+        carry.clear();
+        text.reserve(last_bytes + last_bytes / 16 + ((size_t)9 << 20)); /* one allocation: the batches of a file are of a size */
         size_t scanned = 0, nrec = 0; /* record starts seen in text[0, scanned) */
         size_t cut = std::string::npos;
         for (;;) {
@@ -544,13 +589,14 @@ struct BkptReader {
             }
         }
         if (cut != std::string::npos) { carry.assign(text.begin() + (ptrdiff_t)cut, text.end()); text.resize(cut); }
+        last_bytes = text.size();
         text.push_back('\n'); /* the last record may lack its line end */
         text.push_back('\0');
         return nrec > 0 && !bad;
     }
 };
 /* the records of a batch's text: header lines cut at their end, sequence lines joined in place (a sequence may span several lines) */
-static void parse_records(std::vector<char>& text, std::vector<BkptRec>& recs)
+static void parse_records(TextBuf& text, std::vector<BkptRec>& recs)
 {
     recs.clear();
     char* p = text.data();
@@ -622,7 +668,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
     BkptReader reader(cli_batch_size());
     if (!reader.open(O.bkpt)) { set_error("cannot read %s", O.bkpt.c_str()); return MTG_ERR_IO; }
     struct Batch {
-        std::vector<char> text;
+        TextBuf text;
         std::vector<BkptRec> recs;
         size_t n = 0; /* sites */
         /* the gaps as the library takes them from text (mtg_fill_text): offsets into bt.text (forward attempts) or rev_text (reverse attempts) */
@@ -647,13 +693,21 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         mtg_results *rf = nullptr, *rr = nullptr;
         std::vector<OutText> out; /* one piece per FORMAT_CHUNK sites */
         size_t filled = 0, multiple = 0;
-        ~Batch() { if (rf) mtg_results_free(rf); if (rr) mtg_results_free(rr); }
+        ~Batch()
+        {
+            if (rf) mtg_results_free(rf);
+            if (rr) mtg_results_free(rr);
+            for (OutText& T : out) piece_pool().put(std::move(T));
+            if (text.capacity()) text_pool().put(std::move(text));
+        }
     };
     enum { FORMAT_CHUNK = 2048 };
     /* MTG_TOOL_TIMERS=1: where the time of a run goes (summed over the worker threads; read and write are one thread each) */
     static const bool timers = getenv("MTG_TOOL_TIMERS") != nullptr;
     std::atomic<long long> t_read{0}, t_parse{0}, t_fill{0}, t_rev{0}, t_format{0}, t_write{0};
     const auto usec = [] { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const long long w_start = usec();
+    std::atomic<long long> w_first_read{0}, w_last_done{0};
     PositionedWriter writer(F);
     std::mutex bm;
     std::vector<std::unique_ptr<Batch>> batches;
@@ -662,6 +716,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         const long long tr = usec();
         const bool more = reader.next(bt->text);
         t_read += usec() - tr;
+        if (!w_first_read) w_first_read = usec();
         if (!more) return false;
         std::lock_guard<std::mutex> lk(bm);
         if (batches.size() <= b) batches.resize(b + 1);
@@ -731,6 +786,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         std::vector<size_t> pf(npieces, 0), pm(npieces, 0);
         parallel_for(npieces, P.nb_host_threads, [&](size_t pc) {
             OutText& T = bt.out[pc];
+            T = piece_pool().get();
             const size_t j1 = std::min(n, (pc + 1) * (size_t)FORMAT_CHUNK);
             T.insert.reserve((j1 - pc * FORMAT_CHUNK) * 512);
             T.vcf.reserve((j1 - pc * FORMAT_CHUNK) * 600);
@@ -747,8 +803,10 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         /* records and sequences are in the text now */
         mtg_results_free(bt.rf); bt.rf = nullptr;
         if (bt.rr) { mtg_results_free(bt.rr); bt.rr = nullptr; }
-        std::vector<char>().swap(bt.text);
+        text_pool().put(std::move(bt.text));
+        bt.text = TextBuf();
         t_format += usec() - tp;
+        w_last_done = usec();
         return MTG_OK;
     };
     const auto consume = [&](size_t b) {
@@ -769,6 +827,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         if (!writer.finish() && !rc) { set_error("cannot write the output files"); rc = MTG_ERR_IO; }
         t_write += usec() - tw;
     }
+    if (timers) fprintf(stderr, "[tool] wall ms: first batch read %.1f, last batch processed %.1f, files complete %.1f\n", (w_first_read - w_start) / 1e3, (w_last_done - w_start) / 1e3, (usec() - w_start) / 1e3);
     if (timers)
         fprintf(stderr, "[tool] ms summed over threads: read %.1f | parse + gaps %.1f, forward fill %.1f, reverse attempts %.1f, format %.1f | write %.1f\n", t_read / 1e3, t_parse / 1e3, t_fill / 1e3,
                 t_rev / 1e3, t_format / 1e3, t_write / 1e3);
