@@ -10,6 +10,7 @@
  */
 #include "mtg_internal.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -87,13 +88,12 @@ struct BatchRun {
     const mtg_gap_result& operator[](size_t i) const { return *mtg_results_get(h, i); }
 };
 
-static std::string info_string(const mtg_gap_result& g)
+static void put_int(std::string& o, long long v);
+static std::string info_string(const mtg_gap_result& g) /* "\t%i\t%i\t%d" [ "\t%d\t%d" ] */
 {
-    char buf[128];
     std::string s;
-    snprintf(buf, sizeof buf, "\t%i\t%i\t%d", g.nb_nodes, g.total_nt, g.nb_terminal);
-    s += buf;
-    if (g.nb_terminal > 0 && g.has_solution_counts) { snprintf(buf, sizeof buf, "\t%d\t%d", g.nb_total_filled, g.nb_reported); s += buf; }
+    s += '\t'; put_int(s, g.nb_nodes); s += '\t'; put_int(s, g.total_nt); s += '\t'; put_int(s, g.nb_terminal);
+    if (g.nb_terminal > 0 && g.has_solution_counts) { s += '\t'; put_int(s, g.nb_total_filled); s += '\t'; put_int(s, g.nb_reported); }
     return s;
 }
 
@@ -242,6 +242,35 @@ static void appendf(std::string& o, const char* fmt, ...)
     o.append(big.data(), (size_t)n);
 }
 
+/* the writers' numbers without printf: a decimal integer, and a double with two decimals exactly as "%.2f" prints it (round to nearest on
+ * the exact binary value; the shortcut decides by x * 100 only when that is safely away from a tie, anything else goes to snprintf) */
+static void put_int(std::string& o, long long v)
+{
+    char b[24];
+    int n = 0;
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) b[n++] = '-';
+    while (n) o += b[--n];
+}
+static void put_fixed2(std::string& o, double x)
+{
+    if (x >= 0 && x < 1e9) {
+        const double t = x * 100.0, fl = std::floor(t), fr = t - fl;
+        if (std::fabs(fr - 0.5) > 1e-6) {
+            const unsigned long long r = (unsigned long long)fl + (fr > 0.5 ? 1u : 0u);
+            put_int(o, (long long)(r / 100));
+            o += '.';
+            o += (char)('0' + (r / 10) % 10);
+            o += (char)('0' + r % 10);
+            return;
+        }
+    }
+    char b[400];
+    const int n = snprintf(b, sizeof b, "%.2f", x);
+    if (n > 0) o.append(b, std::min((size_t)n, sizeof b - 1));
+}
+
 struct Sols { /* a run of solutions */
     const mtg_filled* p = nullptr;
     size_t n = 0;
@@ -272,8 +301,14 @@ static void write_filled(OutText& F, bool bkpt_mode, const DictView& g, Sols sol
     for (auto& s : sols) {
         const int llen = (int)strlen(s.seq);
         const std::string solu = solu_str(s);
-        if (bkpt_mode) {
-            appendf(F.insert, ">%.*s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n", (int)seedName.size(), seedName.data(), llen, s.qual, (double)s.avg_coverage, (double)s.median_coverage, solu.c_str());
+        if (bkpt_mode) { /* ">%.*s_len_%d_qual_%i_avg_cov_%.2f_median_cov_%.2f   %s\n" */
+            std::string& o = F.insert;
+            o += '>'; o.append(seedName.data(), seedName.size());
+            o += "_len_"; put_int(o, llen);
+            o += "_qual_"; put_int(o, s.qual);
+            o += "_avg_cov_"; put_fixed2(o, (double)s.avg_coverage);
+            o += "_median_cov_"; put_fixed2(o, (double)s.median_coverage);
+            o += "   "; o += solu; o += '\n';
         } else {
             std::string targetName(g.tname[s.target_index]);
             if (g.trc[s.target_index]) targetName.append("_Rc");
@@ -301,11 +336,10 @@ static void write_vcf(OutText& F, bool filter, Sols sols, std::string_view break
             repeatSize++; i--; j--;
             if (j == -1) j = (int)slen - 1;
         }
-        /* insertion = the last repeatSize + 1 nucleotides of the source + the sequence, less its last repeatSize characters (:1147-1149) */
-        std::string insertion(sourceSequence.substr(srcn - (size_t)(repeatSize + 1), (size_t)repeatSize + 1));
-        insertion.append(s.seq, slen);
-        insertion.resize(insertion.size() - (size_t)repeatSize);
-        const char ref = sourceSequence[srcn - (size_t)(repeatSize + 1)];
+        /* insertion = the last repeatSize + 1 nucleotides of the source + the sequence, less its last repeatSize characters (:1147-1149):
+         * the first slen + 1 characters of that concatenation */
+        const size_t tail0 = srcn - (size_t)(repeatSize + 1), tail_n = (size_t)repeatSize + 1, ins_n = slen + 1;
+        const char ref = sourceSequence[tail0];
         /* the name cut at its underscores (:1165-1182) */
         std::string_view tokens[9];
         size_t ntok = 0;
@@ -320,25 +354,38 @@ static void write_vcf(OutText& F, bool filter, Sols sols, std::string_view break
             }
             if (!breakpointName.empty() && breakpointName.back() == '_') ntok--; /* getline yields no empty last token */
         }
-        std::string bkpt(breakpointName), position = ".", chromosome = ".", GT = "./.", genotype = "";
-        auto to_int = [](std::string_view t) { return atoi(std::string(t).c_str()); };
-        if (ntok == 7) {
-            bkpt = std::string(tokens[0]); position = std::to_string(to_int(tokens[3]) - repeatSize); chromosome = std::string(tokens[1]); genotype = std::string(tokens[6]);
-            GT = genotype == "HOM" ? "1/1" : "0/1";
-        }
-        if (ntok == 8) {
-            bkpt = std::string(tokens[0]) + std::string(tokens[2]); position = std::to_string(to_int(tokens[4]) - repeatSize); chromosome = std::string(tokens[1]); genotype = std::string(tokens[7]);
-            GT = genotype == "HOM" ? "1/1" : "0/1";
-        }
-        const int size = (int)insertion.size() - 1, nsol = s.solution_count, npos = repeatSize + 1;
+        auto to_int = [](std::string_view t) { char b[32]; const size_t n = std::min(t.size(), sizeof b - 1); memcpy(b, t.data(), n); b[n] = 0; return t.size() < sizeof b ? atoi(b) : atoi(std::string(t).c_str()); };
+        const bool named = ntok == 7 || ntok == 8;
+        const std::string_view genotype = ntok == 7 ? tokens[6] : ntok == 8 ? tokens[7] : std::string_view();
+        const int nsol = s.solution_count, npos = repeatSize + 1;
         const char* filt = "PASS";
         if ((genotype == "HET" && nsol > 1) || (genotype == "HOM" && nsol > 1)) {
             if (filter) break;
             filt = "LOW_QUAL";
         }
-        appendf(F.vcf, "%s\t%s\t%s\t%c\t", chromosome.c_str(), position.c_str(), bkpt.c_str(), ref);
-        F.vcf += insertion;
-        appendf(F.vcf, "\t.\t%s\tTYPE=INS;LEN=%i;QUAL=%i;NSOL=%i;NPOS=%i;AVK=%.2f;MDK=%.2f\tGT\t%s\n", filt, size, s.qual, nsol, npos, (double)s.avg_coverage, (double)s.median_coverage, GT.c_str());
+        std::string& o = F.vcf; /* "%s\t%s\t%s\t%c\t" chromosome, position, bkpt, ref */
+        if (named) o.append(tokens[1].data(), tokens[1].size()); else o += '.';
+        o += '\t';
+        if (named) put_int(o, (long long)to_int(tokens[ntok == 7 ? 3 : 4]) - repeatSize); else o += '.';
+        o += '\t';
+        if (!named) o.append(breakpointName.data(), breakpointName.size());
+        else { o.append(tokens[0].data(), tokens[0].size()); if (ntok == 8) o.append(tokens[2].data(), tokens[2].size()); }
+        o += '\t'; o += ref; o += '\t';
+        {
+            const size_t from_tail = std::min(tail_n, ins_n);
+            o.append(sourceSequence.data() + tail0, from_tail);
+            if (ins_n > from_tail) o.append(s.seq, ins_n - from_tail);
+        }
+        /* "\t.\t%s\tTYPE=INS;LEN=%i;QUAL=%i;NSOL=%i;NPOS=%i;AVK=%.2f;MDK=%.2f\tGT\t%s\n" */
+        o += "\t.\t"; o += filt;
+        o += "\tTYPE=INS;LEN="; put_int(o, (long long)ins_n - 1);
+        o += ";QUAL="; put_int(o, s.qual);
+        o += ";NSOL="; put_int(o, nsol);
+        o += ";NPOS="; put_int(o, npos);
+        o += ";AVK="; put_fixed2(o, (double)s.avg_coverage);
+        o += ";MDK="; put_fixed2(o, (double)s.median_coverage);
+        o += "\tGT\t"; o += !named ? "./." : genotype == "HOM" ? "1/1" : "0/1";
+        o += '\n';
     }
 }
 
