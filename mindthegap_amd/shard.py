@@ -193,10 +193,10 @@ WIRE_MAGIC = 0x3145524957474D54
 WIRE_HEADER = 64
 
 
-def wire_check(payload):
+def wire_check(payload, checksum=True):
     """validates a relocatable batch (include/mtg_fill.h: mtg_wire_header) on the device (or host) the tensor lives on, without moving it:
-    magic, sizes and the checksum of the body recomputed with tensor arithmetic (64-bit wrap-around = the C side's).  Returns the header
-    as a dict with 'ok'."""
+    magic, sizes and (checksum=True) the checksum of the body recomputed with tensor arithmetic (64-bit wrap-around = the C side's; five passes
+    over the payload).  Returns the header as a dict with 'ok'."""
     import torch
     n = payload.numel()
     if n < WIRE_HEADER:
@@ -206,6 +206,9 @@ def wire_check(payload):
          "total_bytes": int(hd[6]), "checksum": int(hd[7])}
     if h["magic"] != WIRE_MAGIC or h["total_bytes"] != n or n % 8:
         h.update(ok=False, why="header")
+        return h
+    if not checksum:  # header only: what the receiving rank can afford for every payload inside a timed step
+        h.update(ok=True, why="")
         return h
     body = payload[WIRE_HEADER:].view(torch.int64)
     idx = torch.arange(body.numel(), dtype=torch.int64, device=body.device)

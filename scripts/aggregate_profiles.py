@@ -24,7 +24,8 @@ def find(d, pat):
 
 
 def short(name):
-    return name.split("(")[0].split("<")[0].strip()
+    n = name.split("(")[0].split("<")[0].strip()
+    return n[5:] if n.startswith("void ") else n  # template kernels print their return type
 
 
 def stats(d, out):

@@ -1,5 +1,6 @@
 #!/bin/bash
 # the evidence kept under profiles/ for round 3.  Run on the GPU box:  bash scripts/profile_round3.sh <tag>   (then copy gpurun_out/<tag>/* to profiles/r03_*)
+#   (MTG_HEAD=<commit> in the environment names the code in pmc.json)
 #   kernel statistics of the bench command (rocprofv3 --kernel-trace --stats), with six batches in flight and with ONE (the kernels' own times);
 #   the two PMC passes (each on its own, no trace domain); the default bench line (PMC traffic of this very code in it); the N > 1 result
 #   path on one GPU (two gloo ranks; one RCCL rank); the input-side rates with two pool threads; the walk modes on the secondary workloads
@@ -31,4 +32,5 @@ MTG_BENCH_FORCE_GATHER=1 timeout 600 python bench.py $B > $O/dry_one_rank_rccl.j
 } > $O/host_threads.txt 2>&1
 MODES="classic g16r0 or6 auto" scripts/r3_finish.sh $T/modes human-indel human-tips human-het > /dev/null 2>&1; cp $O/modes/summary.txt $O/walk_modes.txt; rm -rf $O/modes
 HET=1 INDEL=1 MODES="classic or6 g16r3" scripts/r3_alone.sh $T/alone > /dev/null 2>&1; cp $O/alone/alone_summary.txt $O/walk_modes_one_batch_alone_indel.txt; rm -rf $O/alone
+timeout 2400 python -u -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error|human-scale index|config 4" | tail -n 8 > $O/gpu_tests.txt
 tail -c 300 $O/bench_default.json; echo; cat $O/bench_default_wall.txt $O/host_threads.txt; grep -E "k_stage_a|k_finish|k_bubble|k_copy|k_post|k_emit|k_scan|k_marshal" $O/kernel_stats_one_batch_in_flight.csv | cut -c1-160

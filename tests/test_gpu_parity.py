@@ -674,3 +674,34 @@ def test_text_batches_marshalled_on_the_device(mtg):
     attempts); malformed batches are refused"""
     from tests import oracle_lib, text_cases
     text_cases.run(mtg, oracle_lib)
+
+
+def test_first_stage_a_batch_larger_than_the_initial_dense_arrays(mtg):
+    """the dense contig arrays of a fresh workspace start small (1 MB of words) and k_emit is queued before the totals of the launch are known:
+    a FIRST stage-A batch with 6 MB of contigs (every gap hands all its words over) must come back complete -- k_emit skips what does not
+    fit, the host grows the arrays and emits again -- and nothing outside them may have been written (the fills afterwards are intact)"""
+    from mindthegap_amd.synth import SynthSet
+    from tests import oracle_lib
+    S = SynthSet(nseq=2400, n_sites=2400, seed=21)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 0)
+    km, ct = o.export()
+    g = mtg.Index.from_kmers(km, ct, 31)  # a fresh index: fresh workspaces
+    src, tgt = [], []
+    for i in range(S.n_sites):
+        l, r, _ = S.site(i)
+        src.append(l)
+        tgt.append("ACGT" * 20)  # never found: the walk runs to the end of its donor sequence (a contig of 2-5 kb per gap)
+    got = g.stage_a(src, tgt)
+    total_nt = sum(len(c) for cs in got for c in cs)
+    assert total_nt > 5_000_000
+    for i in list(range(0, 60)) + list(range(S.n_sites - 60, S.n_sites)) + list(range(700, 2400, 97)):
+        assert got[i] == o.stage_a(src[i], tgt[i])[0], i
+    # the same workspaces afterwards: ordinary fills, every one identical to its inserted sequence
+    gaps, want = [], []
+    for i in range(600):
+        l, r, ins = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+        want.append(ins)
+    res = g.fill_batch(gaps)
+    assert [r["filled"][0]["seq"] if r["filled"] else None for r in res] == want
+    g.close(); o.close()
