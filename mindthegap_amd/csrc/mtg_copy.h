@@ -21,20 +21,20 @@ MTG_DEV uint64_t cmd_store_nt(const CopyCmd& cm, int64_t x)
     return (cm.src & 1ull) ? (uint64_t)((int64_t)(cm.src >> 1) - rel) : (uint64_t)((int64_t)(cm.src >> 1) + rel);
 }
 
-/* target: the gap's single target k-mer (forward value) when the lean form may be used (one usable target, a source of exactly k nucleotides,
- * records wanted), ~0 otherwise */
-MTG_DEV void copy_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint64_t target)
+/* ---- the lean form: where is the target?  One look-up (the junction behind the target's k-mer) instead of copying the contig -- on the
+ * bench set 2 500 nucleotides past the target -- and searching it.  An exact occurrence at a known place is what
+ * find_nodes_containing_multiple_R reports (src/Filler.cpp:1341-1351: the first exact match ends the scan, and a contig never holds a
+ * node twice), so k_post takes the position as it is; the emulation build runs the search as well and compares.
+ * target: the gap's single target k-mer (forward value) when the lean form may be used (one usable target, a source of exactly k
+ * nucleotides, records wanted), ~0 otherwise.  Decided by ONE lane (k_lean: one gap per lane); returns whether the gap's commands still
+ * have to be executed (copy_cmds). */
+MTG_DEV bool lean_decide(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint64_t target)
 {
     const UStore& us = ix.us;
     LeanRec* lr = s_lean(cfg, S);
-    if (o.status != GAP_OK) return;
+    if (o.status != GAP_OK) return false;
     const CopyCmd* cmds = s_cmd(cfg, S);
-    uint64_t* words = s_words(cfg, S);
     const int k = ix.k;
-    /* ---- the lean form: where is the target?  One look-up (the junction behind the target's k-mer) instead of copying the contig -- on the
-     * bench set 2 500 nucleotides past the target -- and searching it.  An exact occurrence at a known place is what
-     * find_nodes_containing_multiple_R reports (src/Filler.cpp:1341-1351: the first exact match ends the scan, and a contig never holds a
-     * node twice), so k_post takes the position as it is; the emulation build runs the search as well and compares. */
     bool lean = false;
     uint32_t pos0 = 0, ci = 0;
     if (target != ~0ull && o.n_contigs == 1 && o.n_cmds != 0 && us.nwords != 0) {
@@ -59,11 +59,20 @@ MTG_DEV void copy_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
             }
         }
     }
-    if (MTG_LANE() == 0) { LeanRec r; r.valid = lean ? 1u : 0u; r.pos0 = pos0; r.cmd = ci; r.pad_ = 0; *lr = r; }
-#ifndef MTG_XCHECK
-    if (lean) return; /* nothing of the contig is read from the arena (the emulation build copies all the same: its cross-checks read it) */
+    { LeanRec r; r.valid = lean ? 1u : 0u; r.pos0 = pos0; r.cmd = ci; r.pad_ = 0; *lr = r; }
+#ifdef MTG_XCHECK
+    return o.n_cmds != 0; /* the emulation build copies all the same: its cross-checks read the contig */
+#else
+    return !lean && o.n_cmds != 0; /* a lean gap: nothing of the contig is read from the arena */
 #endif
-    if (o.n_cmds == 0) return;
+}
+/* the gap's commands, by a whole wave */
+MTG_DEV void copy_cmds(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o)
+{
+    const UStore& us = ix.us;
+    if (o.status != GAP_OK || o.n_cmds == 0) return;
+    const CopyCmd* cmds = s_cmd(cfg, S);
+    uint64_t* words = s_words(cfg, S);
     /* the lane's words t, t + NLANES, ... in the concatenation of the commands: (c, base) follows t */
     uint32_t c = 0, base = 0;
     CopyCmd cm = cmds[0];
@@ -74,6 +83,11 @@ MTG_DEV void copy_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
         const uint64_t p = cm.src >> 1;
         words[cm.dst + w] = us_peek64(us.words, bwd ? p - 32ull * w : p + 32ull * w, 32u, bwd);
     }
+}
+/* both, one gap at a time (the emulation) */
+MTG_DEV void copy_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint64_t target)
+{
+    if (lean_decide(ix, cfg, S, o, target)) copy_cmds(ix, cfg, S, o);
 }
 
 } // namespace mtg

@@ -561,23 +561,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
     if (gl == 0) out[slot] = o;
 }
 
-/* the long runs the traversal left as commands: one wave per gap, four gaps per workgroup (mtg_copy.h) */
-__global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
-                                              const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
-                                              uint32_t lean_allowed, uint32_t n)
+/* the long runs the traversal left as commands (mtg_copy.h).  k_lean, one gap per lane: is the target inside a run the walk took (the lean
+ * form: nothing is copied, k_post and k_emit read the store)?  The gaps that do need their commands executed go on a work list (ballot +
+ * prefix popcount, as for parking).  k_copy, one wave per listed gap, four per workgroup: the grid covers the launch (the host does not
+ * know the count), a wave beyond the list leaves after one scalar read. */
+enum { COPY_LIST = PARK_LISTS - 1 };
+__global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
+                                             const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
+                                             uint32_t lean_allowed, uint32_t n, ParkCtl* park, uint32_t cap)
 {
-    const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (slot >= n) return;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    bool need = false;
+    if (slot < n) {
+        GapScratch S;
+        S.z = nullptr;
+        S.v = nullptr;
+        S.lane = 0;
+        S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        /* the lean form needs one usable target and a source of exactly k nucleotides (what the common-case result of k_post needs anyway) */
+        const uint32_t g = ids ? ids[slot] : slot;
+        uint64_t target = ~0ull;
+        if (lean_allowed && tcnt[g] == 1u && fast_ok[g] && tbad[toff[g]] == 0ull) target = rev_fields64(tle[toff[g]]) >> (64 - 2 * ix.k);
+        need = lean_decide(ix, cfg, S, outs[slot], target);
+    }
+    park_append(park, cap, COPY_LIST, need, slot);
+}
+__global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap)
+{
+    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= park->count[COPY_LIST]) return;
+    const uint32_t slot = park_list(park, cap, COPY_LIST)[t];
     GapScratch S;
     S.z = nullptr;
     S.v = nullptr;
     S.lane = 0;
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
-    /* the lean form needs one usable target and a source of exactly k nucleotides (what the common-case result of k_post needs anyway) */
-    const uint32_t g = ids ? ids[slot] : slot;
-    uint64_t target = ~0ull;
-    if (lean_allowed && tcnt[g] == 1u && fast_ok[g] && tbad[toff[g]] == 0ull) target = rev_fields64(tle[toff[g]]) >> (64 - 2 * ix.k);
-    copy_gap(ix, cfg, S, outs[slot], target);
+    copy_cmds(ix, cfg, S, outs[slot]);
 }
 
 /* mtg_fill_text: a batch whose strings are still text (mtg_marshal.h).  One gap per thread: source k-mer, packed pattern, its first k-mer,
@@ -1878,7 +1897,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             int rounds = env_rounds >= 0 ? env_rounds : ((uint64_t)ws.park_hint * 2 > m ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
             if (rounds > (PARK_LISTS - 2) / 2) rounds = (PARK_LISTS - 2) / 2;
             ParkCtl* const park = d_park.as<ParkCtl>();
-            if (!classic_walk) HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream));
+            HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
             if (classic_walk) {
                 hipLaunchKernelGGL(k_stage_a_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
@@ -1936,8 +1955,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipGetLastError());
             /* ev1 .. evc: the long runs of the contigs, which the traversal only noted down */
             static const bool no_lean = getenv("MTG_NO_LEAN") != nullptr; /* A/B and test hook: every contig is materialised */
-            hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
-                               (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m);
+            hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
+                               (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m, park, m);
+            hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m);
             HIP_TRY(hipEventRecord(evc, stream));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
             hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
