@@ -561,6 +561,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
     if (gl == 0) out[slot] = o;
 }
 
+/* the same with one LANE per parked gap and the general code on HBM scratch (A/B hook, MTG_FINISH_G=1): the group form is faster even
+ * for a handful of parked gaps */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_finish_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ rwords,
+                                               const uint32_t* __restrict__ roff, const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
+                                               GapOut* out, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= park->count[in_list]) return;
+    const Index& ix = c_ix[cset];
+    const FillCfg& cfg = c_cfg[cset];
+    const uint32_t slot = park_list(park, cap, in_list)[t];
+    const uint32_t g = ids ? ids[slot] : slot;
+    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    S.snp_fast = 1;
+    SwfPattern R;
+    R.words = rwords + roff[g];
+    R.rlen = rlen[g];
+    R.r0 = r0[g];
+    GapOut o;
+    stage_a_walk<WALK_FINISH, 1>(ix, cfg, S, 0, R, o, nullptr);
+    out[slot] = o;
+}
+
 /* the long runs the traversal left as commands (mtg_copy.h).  k_lean, one gap per lane: is the target inside a run the walk took (the lean
  * form: nothing is copied, k_post and k_emit read the store)?  The gaps that do need their commands executed go on a work list (ballot +
  * prefix popcount, as for parking).  k_copy, one wave per listed gap, four per workgroup: the grid covers the launch (the host does not
@@ -1931,7 +1954,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                                        d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
                 }
                 const uint32_t lfin = 2u * (uint32_t)rounds;
-                if (!skip_finish) switch (finish_g) {
+                /* how the tail is finished: a group of lanes per parked gap, bubbles from LDS.  One lane per gap (MTG_FINISH_G=1, or below
+                 * MTG_FINISH_LANE_BELOW parked gaps in the workspace's previous launch) was measured and is slower at every size: 0.11 against
+                 * 0.10 ms for the haploid set's 1-5 gaps, 0.83 against 0.35 for 108 (heterozygous SNPs), 1.12 against 0.56 for 12 000 (tips). */
+                static const int finish_lane_below = getenv("MTG_FINISH_LANE_BELOW") ? atoi(getenv("MTG_FINISH_LANE_BELOW")) : 0;
+                const bool lane_finish = finish_g == 1 || (!getenv("MTG_FINISH_G") && rounds == 0 && ws.park_hint < (uint32_t)finish_lane_below);
+                if (!skip_finish && lane_finish)
+                    hipLaunchKernelGGL(k_finish_lane, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin);
+                else if (!skip_finish) switch (finish_g) {
                     case 8: hipLaunchKernelGGL(k_finish<8>, dim3((m + 7) / 8), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                     case 64: hipLaunchKernelGGL(k_finish<64>, dim3(m), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                     default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;

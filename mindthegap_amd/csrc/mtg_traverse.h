@@ -2079,7 +2079,7 @@ MTG_UNROLL
 #ifdef MTG_COOP_OFF /* diagnostics: the finishing kernel without the group form (every bubble by the one-lane code) */
                     n = COOP_TOOBIG;
 #else
-                    n = coop_explore<G>(W, *L, cur, prev_c, chosen);
+                    n = L ? coop_explore<G>(W, *L, cur, prev_c, chosen) : COOP_TOOBIG; /* no LDS areas: the one-lane finishing kernel (a handful of parked gaps) */
 #endif
 #ifdef MTG_EMU
                     coop_tally(n);
