@@ -565,6 +565,8 @@ def main():
             seqs_ascii = [S.ascii(j) for j in range(nidx)] + [S.ascii(nl + j) for j in range(nidx)]
         else:
             seqs_ascii = [S.ascii(j) for j in range(nidx)]
+            if tips:  # the erroneous fragments copied from the sampled donor sequences: the tips and error bubbles their walks meet
+                seqs_ascii += [S.extra_ascii(int(j)) for j in np.nonzero(S.extra_rows < nidx)[0]]
         oidx = oracle_lib.Index.from_sequences(seqs_ascii, k, 3, 0)
         with tempfile.TemporaryDirectory() as d:
             bk = os.path.join(d, "s.breakpoints")
@@ -648,7 +650,7 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
     if a.workload == "human" and batch_sites == 100000 and os.path.exists(pmc):
         pj = json.load(open(pmc))
-        fill_kernels = ("k_stage_a", "k_finish", "k_bubble", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
+        fill_kernels = ("k_stage_a", "k_finish", "k_bubble", "k_lean", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
         by_kernel = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pj.get("kernels", {}).items() if kn.split("::")[-1].startswith(fill_kernels)}
         # `traffic`: HBM bytes per launch of the dominant kernel (with the scans it is reported with); every kernel of a fill under traffic_by_kernel
         dk = dom["kernel"].split("(")[0]

@@ -77,6 +77,7 @@ class SynthSet:
         # (a tip, up to k nodes), in its middle a bubble of k nodes.  They are extra sequences of the index (extra_*), never sites.
         self.extra_words = np.zeros((0, 3), dtype=np.uint64)
         self.extra_lens = np.zeros(0, dtype=np.uint32)
+        self.extra_rows = np.zeros(0, dtype=np.int64)
         if tips > 0:
             nfrag = int(tips * nseq)
             frng = np.random.default_rng(seed + 1000003)
@@ -99,6 +100,7 @@ class SynthSet:
             old_c = (out[idx, qw] >> qb) & np.uint64(3)
             out[idx, qw] = (out[idx, qw] & ~(np.uint64(3) << qb)) | (((old_c + delta) & np.uint64(3)) << qb)
             self.extra_words, self.extra_lens = out, flen.astype(np.uint32)
+            self.extra_rows = rows  # the donor sequence every fragment is a corrupted copy of
 
     def packed(self):
         """(words, word offsets, lengths, number of sequences) of everything that goes into the index: the donor and the erroneous fragments"""
