@@ -219,12 +219,13 @@ def main():
         def on_arrival(items):
             """rank 0, for every completed gather: every rank's payload is validated where it arrived (device memory with RCCL): header, sizes,
             the checksum of its records and sequences recomputed by tensor arithmetic.  keep: the payloads of a verification step come to the host."""
-            for r, tag, t in items:
+            for it in items:
+                r, tag, t = it
                 if tag < 0:
                     continue
                 # inside the timed steps the header (magic, tag, sizes) of every payload; the checksum of every payload's records and sequences is
                 # recomputed in the verification step (keep is set), which sees every batch of every rank once (MTG_BENCH_WIRE_CHECK=full: always)
-                h = wire_check(t, checksum=st["keep"] is not None or full_wire_check)
+                h = wire_check(t, checksum=st["keep"] is not None or full_wire_check, head=getattr(it, "head", None))
                 if not h["ok"] or h["tag"] != tag:
                     st["bad"].append((r, tag, h.get("why")))
                 st["seen"][(r, tag)] = h.get("checksum")

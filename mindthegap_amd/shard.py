@@ -94,10 +94,16 @@ class PipelinedGather:
 
     def payloads(self, j):
         """[(rank, tag, payload tensor)] of the completed gather in buffer j (rank dst)"""
+        # one copy to the host for the heads of all ranks' buffers (the gather's own 16 bytes and the first 64 of the payload, a relocatable
+        # batch's header): a synchronisation per rank and field was most of what an arrival cost the thread that waited for it
+        H = self.HEADER + WIRE_HEADER
+        heads = self.torch.stack([t[:H] for t in self.recv[j]]).cpu().numpy() if self.recv[j][0].numel() >= H else None
         out = []
         for r, t in enumerate(self.recv[j]):
-            hd = t[: self.HEADER].cpu().numpy().view(np.int64)
-            out.append((r, int(hd[1]), t[self.HEADER: self.HEADER + int(hd[0])]))
+            hd = (heads[r, : self.HEADER] if heads is not None else t[: self.HEADER].cpu().numpy()).view(np.int64)
+            item = GatherItem((r, int(hd[1]), t[self.HEADER: self.HEADER + int(hd[0])]))
+            item.head = heads[r, self.HEADER:].copy() if heads is not None and int(hd[0]) >= WIRE_HEADER else None
+            out.append(item)
         return out
 
     def acquire(self):
@@ -193,7 +199,12 @@ WIRE_MAGIC = 0x3145524957474D54
 WIRE_HEADER = 64
 
 
-def wire_check(payload, checksum=True):
+class GatherItem(tuple):
+    """(rank, tag, payload tensor) of a completed gather; .head = the payload's first 64 bytes on the host (numpy uint8) when it has them"""
+    head = None
+
+
+def wire_check(payload, checksum=True, head=None):
     """validates a relocatable batch (include/mtg_fill.h: mtg_wire_header) on the device (or host) the tensor lives on, without moving it:
     magic, sizes and (checksum=True) the checksum of the body recomputed with tensor arithmetic (64-bit wrap-around = the C side's; five passes
     over the payload).  Returns the header as a dict with 'ok'."""
@@ -201,7 +212,7 @@ def wire_check(payload, checksum=True):
     n = payload.numel()
     if n < WIRE_HEADER:
         return {"ok": False, "why": "short"}
-    hd = payload[:WIRE_HEADER].cpu().numpy().view(np.uint64)
+    hd = (head if head is not None else payload[:WIRE_HEADER].cpu().numpy()).view(np.uint64)  # head: already on the host (GatherItem.head)
     h = {"magic": int(hd[0]), "tag": int(hd[1]), "n_gaps": int(hd[2]), "n_filled": int(hd[3]), "seq_bytes": int(hd[4]), "ext_bytes": int(hd[5]),
          "total_bytes": int(hd[6]), "checksum": int(hd[7])}
     if h["magic"] != WIRE_MAGIC or h["total_bytes"] != n or n % 8:
