@@ -339,7 +339,7 @@ def main():
             need = max([0] + [sum(len(e) + 1 for e in b.expected) + 96 * b.n + 4096 for b in batches])
             cap = torch.tensor([need], dtype=torch.int64, device=cdev)
             dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-            st["pg"] = PipelinedGather(int(cap.item()) * 51 // 50 + (1 << 16), dst=0, device=cdev, depth=max(a.in_flight, 1) + 1, on_arrival=on_arrival if rank == 0 else None)
+            st["pg"] = PipelinedGather(int(cap.item()) * 51 // 50 + (1 << 16), dst=0, device=cdev, depth=int(os.environ.get("MTG_BENCH_GATHER_DEPTH", "0")) or max(a.in_flight, 1) + 1, on_arrival=on_arrival if rank == 0 else None)
         run_block(a.warmup, False)
 
         def timed_block(first_step):
