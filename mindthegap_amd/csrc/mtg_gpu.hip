@@ -1560,24 +1560,51 @@ void index_release(mtg_index* idx)
     delete idx;
 }
 
-int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
+/* a device buffer of one call: the cached slot of a workspace when the call belongs to a batch (grow-only: no hipMalloc / hipFree in the
+ * steady state -- hipFree waits for the whole device, i.e. for every other batch in flight), memory of its own otherwise */
+struct CallBuf {
+    void* p = nullptr;
+    bool own = false;
+    hipError_t alloc(Workspace* ws, int slot, size_t bytes)
+    {
+        bytes = bytes ? bytes : 8;
+        if (!ws) { own = true; return hipMalloc(&p, bytes); }
+        if (ws->cap[slot] < bytes) {
+            if (ws->ptr[slot]) (void)hipFree(ws->ptr[slot]);
+            ws->ptr[slot] = nullptr; ws->cap[slot] = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            const hipError_t e = hipMalloc(&ws->ptr[slot], want);
+            if (e != hipSuccess) return e;
+            ws->cap[slot] = want;
+        }
+        p = ws->ptr[slot];
+        return hipSuccess;
+    }
+    ~CallBuf() { if (own && p) (void)hipFree(p); }
+    template <typename T> T* as() { return (T*)p; }
+};
+enum { CALL_SLOT0 = 23 }; /* workspace slots 0 .. 22 belong to device_run; a batch's later calls (k_query, k_nw) use 23 .. 30, one call at a time */
+
+int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred, Workspace* ws)
 {
     if (int rc = use_device_of(idx)) return rc;
     if (!idx || (n && !kmers)) { set_error("null argument"); return MTG_ERR_ARG; }
     if (n == 0) return MTG_OK;
-    DevBuf d_k, d_a, d_s, d_p;
-    HIP_TRY(d_k.alloc(n * 8));
-    HIP_TRY(hipMemcpy(d_k.p, kmers, n * 8, hipMemcpyHostToDevice));
-    if (abund) HIP_TRY(d_a.alloc(n * 4));
-    if (succ) HIP_TRY(d_s.alloc(n));
-    if (pred) HIP_TRY(d_p.alloc(n));
+    hipStream_t stream = ws ? (hipStream_t)ws->stream : nullptr;
+    CallBuf d_k, d_a, d_s, d_p;
+    HIP_TRY(d_k.alloc(ws, CALL_SLOT0 + 0, n * 8));
+    HIP_TRY(hipMemcpyAsync(d_k.p, kmers, n * 8, hipMemcpyHostToDevice, stream));
+    if (abund) HIP_TRY(d_a.alloc(ws, CALL_SLOT0 + 1, n * 4));
+    if (succ) HIP_TRY(d_s.alloc(ws, CALL_SLOT0 + 2, n));
+    if (pred) HIP_TRY(d_p.alloc(ws, CALL_SLOT0 + 3, n));
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_query, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), n, abund ? d_a.as<uint32_t>() : nullptr, succ ? d_s.as<uint8_t>() : nullptr,
+    hipLaunchKernelGGL(k_query, dim3(blocks), dim3(256), 0, stream, idx->dev, d_k.as<uint64_t>(), n, abund ? d_a.as<uint32_t>() : nullptr, succ ? d_s.as<uint8_t>() : nullptr,
                        pred ? d_p.as<uint8_t>() : nullptr);
     HIP_TRY(hipGetLastError());
-    if (abund) HIP_TRY(hipMemcpy(abund, d_a.p, n * 4, hipMemcpyDeviceToHost));
-    if (succ) HIP_TRY(hipMemcpy(succ, d_s.p, n, hipMemcpyDeviceToHost));
-    if (pred) HIP_TRY(hipMemcpy(pred, d_p.p, n, hipMemcpyDeviceToHost));
+    if (abund) HIP_TRY(hipMemcpyAsync(abund, d_a.p, n * 4, hipMemcpyDeviceToHost, stream));
+    if (succ) HIP_TRY(hipMemcpyAsync(succ, d_s.p, n, hipMemcpyDeviceToHost, stream));
+    if (pred) HIP_TRY(hipMemcpyAsync(pred, d_p.p, n, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return MTG_OK;
 }
 
@@ -2204,7 +2231,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     return rc;
 }
 
-int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches)
+int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches, Workspace* ws)
 {
     (void)idx;
     if (int rc = use_device_of(idx)) return rc;
@@ -2217,14 +2244,22 @@ int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<u
     for (size_t i = 0; i < np; i++) { oa[i] = nt; nt += pairs[i].na; ob[i] = nt; nt += pairs[i].nb; la[i] = pairs[i].na; lb[i] = pairs[i].nb; bo[i] = nbnd; nbnd += (uint64_t)pairs[i].na + 1; }
     std::vector<uint8_t> text(nt + 1);
     for (size_t i = 0; i < np; i++) { memcpy(text.data() + oa[i], pairs[i].a, pairs[i].na); memcpy(text.data() + ob[i], pairs[i].b, pairs[i].nb); }
-    DevBuf d_text, d_oa, d_ob, d_la, d_lb, d_bo, d_bnd, d_out;
-    HIP_TRY(upload(d_text, text)); HIP_TRY(upload(d_oa, oa)); HIP_TRY(upload(d_ob, ob)); HIP_TRY(upload(d_la, la)); HIP_TRY(upload(d_lb, lb)); HIP_TRY(upload(d_bo, bo));
-    HIP_TRY(d_bnd.alloc(nbnd * sizeof(int2)));
-    HIP_TRY(d_out.alloc(np * 4));
-    hipLaunchKernelGGL(k_nw, dim3((unsigned)np), dim3(64), 0, 0, d_text.as<uint8_t>(), d_oa.as<uint64_t>(), d_la.as<uint32_t>(), d_ob.as<uint64_t>(), d_lb.as<uint32_t>(),
+    hipStream_t stream = ws ? (hipStream_t)ws->stream : nullptr;
+    CallBuf d_text, d_oa, d_ob, d_la, d_lb, d_bo, d_bnd, d_out;
+    const auto up = [&](CallBuf& b, int slot, const void* src, size_t bytes) -> hipError_t {
+        const hipError_t e = b.alloc(ws, CALL_SLOT0 + slot, bytes);
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, stream);
+    };
+    HIP_TRY(up(d_text, 0, text.data(), text.size())); HIP_TRY(up(d_oa, 1, oa.data(), np * 8)); HIP_TRY(up(d_ob, 2, ob.data(), np * 8)); HIP_TRY(up(d_la, 3, la.data(), np * 4));
+    HIP_TRY(up(d_lb, 4, lb.data(), np * 4)); HIP_TRY(up(d_bo, 5, bo.data(), np * 8));
+    HIP_TRY(d_bnd.alloc(ws, CALL_SLOT0 + 6, nbnd * sizeof(int2)));
+    HIP_TRY(d_out.alloc(ws, CALL_SLOT0 + 7, np * 4));
+    hipLaunchKernelGGL(k_nw, dim3((unsigned)np), dim3(64), 0, stream, d_text.as<uint8_t>(), d_oa.as<uint64_t>(), d_la.as<uint32_t>(), d_ob.as<uint64_t>(), d_lb.as<uint32_t>(),
                        d_bnd.as<int2>(), d_bo.as<uint64_t>(), d_out.as<uint32_t>(), (uint32_t)np);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(matches.data(), d_out.p, np * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(matches.data(), d_out.p, np * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return MTG_OK;
 }
 

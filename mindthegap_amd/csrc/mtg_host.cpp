@@ -675,7 +675,7 @@ static double median_of(std::vector<unsigned int>& v) /* src/Utils.cpp:241-254 *
 
 /* The multi-contig gaps of a batch (`special`), on the host: candidates, alignments (device), greedy de-duplication, coverage (device).
  * work[i] receives the solutions of special.special[i]; describe(gap, W) sets source, flags and dictionary of a gap. */
-static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch& special, const std::function<void(size_t, GapWork&)>& describe, std::vector<GapWork>& work)
+static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch& special, const std::function<void(size_t, GapWork&)>& describe, std::vector<GapWork>& work, Workspace* ws)
 {
     const int k = idx->dev.k, nth = p->nb_host_threads;
     const size_t ng = special.special.size();
@@ -708,7 +708,7 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
         }
     }
     std::vector<uint32_t> matches;
-    if (!pairs.empty()) { if (int rc = nw_run(idx, pairs, matches)) return rc; }
+    if (!pairs.empty()) { if (int rc = nw_run(idx, pairs, matches, ws)) return rc; }
     parallel_for(ng, nth, [&](size_t i) { if (genw[i]) finish_general(work[i], *genw[i], matches); }, 1);
     /* coverage of the solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
@@ -731,7 +731,7 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
             s.ab_n = q.size() - s.ab_off;
         }
     std::vector<uint32_t> ab(q.size());
-    if (!q.empty()) { if (int rc = query_run(idx, q.data(), q.size(), ab.data(), nullptr, nullptr)) return rc; }
+    if (!q.empty()) { if (int rc = query_run(idx, q.data(), q.size(), ab.data(), nullptr, nullptr, ws)) return rc; }
     parallel_for(ng, nth, [&](size_t ii) {
         GapWork& g = work[ii];
         for (auto& s : g.sols) {
@@ -1013,7 +1013,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
             w.targets.p = w.target_store.data();
             w.targets.n = (uint32_t)w.target_store.size();
         };
-        rc = run_general(idx, p, special, describe, R->gen);
+        rc = run_general(idx, p, special, describe, R->gen, in.ws);
         if (rc) return rc;
         size_t total = 0;
         for (const GapWork& w : R->gen) total += w.sols.size();

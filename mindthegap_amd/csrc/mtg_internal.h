@@ -534,9 +534,11 @@ struct NwPair {
     const char* b;
     uint32_t nb;
 };
-int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches);
+/* ws: the workspace of the batch that asks (its cached device buffers and its stream: no hipMalloc / hipFree -- hipFree waits for the whole
+ * device, i.e. for every other batch in flight -- and no copy on the null stream); nullptr: buffers of the call's own */
+int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches, Workspace* ws = nullptr);
 
-int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred);
+int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred, Workspace* ws = nullptr);
 /* the solid k-mers of an index with their abundances, read back from its device tables, in pieces handed to sink(kmers, abundances, count) */
 int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink);
 /* An index as it is kept in its container (version 3): the unitig store -- 2-bit sequences and one abundance byte per k-mer -- and the k-mers

@@ -105,7 +105,7 @@ void index_release(mtg_index* idx)
     delete idx;
 }
 
-int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
+int query_run(const mtg_index* idx, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred, Workspace*)
 {
     const int k = idx->dev.k;
     const uint64_t mk1 = kmask(k - 1);
@@ -180,7 +180,7 @@ int scan_run(const mtg_index* idx, const uint64_t* words, size_t, const uint64_t
 }
 
 /* stand-in for k_nw: the two-row integer DP with the traceback's match count carried forward (scores are exact multiples of 5) */
-int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches)
+int nw_run(const mtg_index*, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches, Workspace*)
 {
     matches.assign(pairs.size(), 0);
     for (size_t p = 0; p < pairs.size(); p++) {
