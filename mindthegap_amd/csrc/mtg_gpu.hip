@@ -1985,10 +1985,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                  * MTG_FINISH_LANE_BELOW parked gaps in the workspace's previous launch) was measured and is slower at every size: 0.11 against
                  * 0.10 ms for the haploid set's 1-5 gaps, 0.83 against 0.35 for 108 (heterozygous SNPs), 1.12 against 0.56 for 12 000 (tips). */
                 static const int finish_lane_below = getenv("MTG_FINISH_LANE_BELOW") ? atoi(getenv("MTG_FINISH_LANE_BELOW")) : 0;
+                /* lanes per parked gap in the finishing kernel: a whole wave while few gaps are parked (their chains are what the kernel takes:
+                 * 0.17 against 0.32 ms for the 108 gaps of the heterozygous set), 16 when there are many (12 000 on the tips set: 0.46 against 0.63) */
+                static const int finish_wave_below = getenv("MTG_FINISH_WAVE_BELOW") ? atoi(getenv("MTG_FINISH_WAVE_BELOW")) : 2048;
+                const int fin_g = getenv("MTG_FINISH_G") ? finish_g : (rounds == 0 && ws.park_hint < (uint32_t)finish_wave_below ? 64 : 16);
                 const bool lane_finish = finish_g == 1 || (!getenv("MTG_FINISH_G") && rounds == 0 && ws.park_hint < (uint32_t)finish_lane_below);
                 if (!skip_finish && lane_finish)
                     hipLaunchKernelGGL(k_finish_lane, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin);
-                else if (!skip_finish) switch (finish_g) {
+                else if (!skip_finish) switch (fin_g) {
                     case 8: hipLaunchKernelGGL(k_finish<8>, dim3((m + 7) / 8), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                     case 64: hipLaunchKernelGGL(k_finish<64>, dim3(m), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                     default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
