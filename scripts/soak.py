@@ -1,4 +1,4 @@
-"""soak: many batches on one index (alternating sizes; host strings and prepared batches; plain, serialised and device-resident results); prints host
+"""soak: many batches on one index (alternating sizes; host strings, prepared batches and text blocks; plain, serialised, device-resident and relocatable results); prints host
 RSS and device memory at intervals"""
 import os, sys, time, resource
 import numpy as np
@@ -21,12 +21,17 @@ sizes = [100000, 1000, 37000, 64, 100000]
 out = np.empty(80 << 20, dtype=np.uint8)
 dbuf = torch.empty(80 << 20, dtype=torch.uint8, device=dev)
 batches = [idx.prepare_batch(p) for p in preps]  # prepared (device-resident) forms of the same batches
+texts = [mtg.TextGaps(gaps[:n]) for n in sizes]    # the same batches as blocks of text (mtg_fill_text)
 def rss():
     return int(open("/proc/self/statm").read().split()[1]) * 4096 / 2**20
 t0 = time.time()
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
     j = it % len(preps)
-    if it % 3 == 0:
+    if it % 11 == 0:  # one block of text, marshalled on the device
+        h, nf, _ = idx.fill_prepared(texts[j], want_seqs=False)
+    elif it % 13 == 0:  # the relocatable form, written by the result kernel into a device buffer
+        h, nf, nb = idx.fill_prepared_wire_device(batches[j], it, dbuf.data_ptr(), dbuf.numel())
+    elif it % 3 == 0:
         h, nf, nb = idx.fill_prepared_serial(preps[j], out)
     elif it % 5 == 0:
         h, nf, nb = idx.fill_prepared_serial_device(batches[j], dbuf.data_ptr(), dbuf.numel())

@@ -1002,3 +1002,14 @@ def test_text_batches_marshalled_by_the_device_code(emu_product):
     """mtg_fill_text on the emulator: tests/text_cases.py"""
     from tests import text_cases
     text_cases.run(emu_product, oracle_lib)
+
+
+def test_cli_reads_its_breakpoint_file_mapped_and_with_read(emu_product, tmp_path, monkeypatch):
+    """the tool's reader: a plain breakpoint file is mapped and every worker copies its batch (the default); MTG_CLI_NO_MMAP=1 reads it with
+    read(2) in 8 MB pieces -- batches of three sites, so that records straddle the boundaries; both give the oracle's files (a .gz goes
+    through zlib: test_cli_on_three_emulated_devices_with_a_failing_one)"""
+    monkeypatch.setenv("MTG_CLI_BATCH", "3")
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    _edge_case_run(emu_product, tmp_path / "a")
+    monkeypatch.setenv("MTG_CLI_NO_MMAP", "1")
+    _edge_case_run(emu_product, tmp_path / "b")
