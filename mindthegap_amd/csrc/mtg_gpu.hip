@@ -1943,8 +1943,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* Rounds: when many gaps park (bubbles all over the data), their branching nodes are answered by the bubble kernels and the walks go
              * on in the walk kernel, one gap per lane again -- walking is cheap at full width, only the bubbles need a group -- for a few
              * rounds; what is still parked then (and everything, when few gaps park) is finished by groups in k_finish.  The host does not
-             * know the counts when it queues the kernels: the number of rounds follows the previous launch of this workspace. */
-            int rounds = env_rounds >= 0 ? env_rounds : ((uint64_t)ws.park_hint * 2 > m ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
+             * know the counts when it queues the kernels: the number of rounds follows the share of gaps the previous launch of this workspace parked
+             * (a workspace without a launch yet: the latest figure of any workspace of the index). */
+            const uint32_t park_share = ws.park_share != ~0u ? ws.park_share : idx->park_share_any.load(std::memory_order_relaxed);
+            const uint32_t park_hint = (uint32_t)(((uint64_t)park_share * m) >> 16); /* gaps this launch is expected to park */
+            int rounds = env_rounds >= 0 ? env_rounds : (park_share > 32768u ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
             if (rounds > (PARK_LISTS - 2) / 2) rounds = (PARK_LISTS - 2) / 2;
             ParkCtl* const park = d_park.as<ParkCtl>();
             HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
@@ -1988,8 +1991,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 /* lanes per parked gap in the finishing kernel: a whole wave while few gaps are parked (their chains are what the kernel takes:
                  * 0.17 against 0.32 ms for the 108 gaps of the heterozygous set), 16 when there are many (12 000 on the tips set: 0.46 against 0.63) */
                 static const int finish_wave_below = getenv("MTG_FINISH_WAVE_BELOW") ? atoi(getenv("MTG_FINISH_WAVE_BELOW")) : 2048;
-                const int fin_g = getenv("MTG_FINISH_G") ? finish_g : (rounds == 0 && ws.park_hint < (uint32_t)finish_wave_below ? 64 : 16);
-                const bool lane_finish = finish_g == 1 || (!getenv("MTG_FINISH_G") && rounds == 0 && ws.park_hint < (uint32_t)finish_lane_below);
+                const int fin_g = getenv("MTG_FINISH_G") ? finish_g : (rounds == 0 && park_hint < (uint32_t)finish_wave_below ? 64 : 16);
+                const bool lane_finish = finish_g == 1 || (!getenv("MTG_FINISH_G") && rounds == 0 && park_hint < (uint32_t)finish_lane_below);
                 if (!skip_finish && lane_finish)
                     hipLaunchKernelGGL(k_finish_lane, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin);
                 else if (!skip_finish) switch (fin_g) {
@@ -2174,7 +2177,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
             HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
             st.finish_kernel_ms += msf;
-            if (!classic_walk) { const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot)); st.n_parked_gaps += np; st.n_rounds += (uint64_t)rounds; if (tier == 0 && identity) ws.park_hint = np; }
+            if (!classic_walk) { const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot)); st.n_parked_gaps += np; st.n_rounds += (uint64_t)rounds; if (tier == 0 && identity && m >= 64) { ws.park_share = (uint32_t)std::min<uint64_t>(((uint64_t)np << 16) / m, 65536u); idx->park_share_any.store(ws.park_share, std::memory_order_relaxed); } }
             HIP_TRY(hipEventElapsedTime(&msc, ev1, evc));
             HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
             st.copy_kernel_ms += msc;

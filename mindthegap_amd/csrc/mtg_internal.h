@@ -36,7 +36,9 @@ struct Workspace {
     size_t hcap[NHOST] = {0};
     void* stream = nullptr;      /* hipStream_t of the batch's copies in and kernels */
     void* copy_stream = nullptr; /* hipStream_t for the copies back of a batch's parts */
-    uint32_t park_hint = 0; /* gaps the walk kernel parked in this workspace's previous whole-batch launch: how many rounds the next one queues */
+    /* share of the gaps (in 65536ths) the walk kernel parked in this workspace's previous whole-batch launch: how the next launch serves its
+     * parked gaps (rounds or not, lanes per gap in the finishing kernel); ~0 = no launch yet: the index's latest figure is taken */
+    uint32_t park_share = ~0u;
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
 }
@@ -49,6 +51,7 @@ struct mtg_index {
 #define MTG_NWS 6 /* batches one index serves at a time (each with its own device scratch, streams and staging blocks) */
 #endif
     enum { NWS = MTG_NWS };
+    mutable std::atomic<uint32_t> park_share_any{0}; /* the latest park share any workspace of this index has seen (a fresh workspace starts from it) */
     mutable mtgi::Workspace ws[NWS];
     int device = 0;
     mtg_index_info info{};
