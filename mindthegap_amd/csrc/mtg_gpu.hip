@@ -448,7 +448,7 @@ __device__ __forceinline__ void park_append(ParkCtl* park, uint32_t cap, uint32_
 template <int MODE>
 __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                              const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset,
-                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
+                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, uint32_t snp_mode = 1)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t slot = t;
@@ -461,7 +461,7 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
     GapScratch S = carve(cfg, zero, raw, ilv, slot);
-    S.snp_fast = 1;
+    S.snp_fast = (int)snp_mode; /* 2: park at SNP bubbles too (mtg_traverse.h: park_all) */
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];
@@ -480,9 +480,9 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                                GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
+                                                GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, uint32_t snp_mode)
 {
-    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list);
+    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list, snp_mode);
 }
 __global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
@@ -508,6 +508,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_BUB
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t slot = park_list(park, cap, in_list)[t];
     GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    S.snp_fast = 1; /* the strict SNP pattern is answered by the fast path here as in the walk */
     const bool done = bubble_coop<G>(ix, cfg, S, lds[lane / G]);
     if (!done && gl == 0) park_list(park, cap, in_list + 1)[atomicAdd(&park->count[in_list + 1], 1u)] = slot;
 }
@@ -519,6 +520,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t slot = park_list(park, cap, in_list)[t];
     GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    S.snp_fast = 1; /* the strict SNP pattern is answered by the fast path here as in the walk */
 #ifdef MTG_BUBBLE_TIMING
     const uint64_t t0 = wall_clock64();
 #endif
@@ -1945,7 +1947,18 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
              * rounds; what is still parked then (and everything, when few gaps park) is finished by groups in k_finish.  The host does not
              * know the counts when it queues the kernels: the number of rounds follows the share of gaps the previous launch of this workspace parked
              * (a workspace without a launch yet: the latest figure of any workspace of the index). */
-            const uint32_t park_share = ws.park_share != ~0u ? ws.park_share : idx->park_share_any.load(std::memory_order_relaxed);
+            /* Walk mode of the launch.  0 (always, unless forced): the walking lane answers the strict SNP pattern itself.  1 (MTG_PARK_SNP=1, an A/B
+             * hook): it parks there as well and the bubble kernel of the rounds answers it with the same fast path for all parked gaps at once --
+             * built because the lanes of a wave meet their SNPs at different steps, and on the heterozygous set a wave spends four times as long
+             * in bubble code run by a few lanes at a time as on walking.  Measured and not used: every resumed launch of the walk kernel costs
+             * 45 us however short its segments (human-het: 7 launches 0.33 ms + bubble kernels 0.5 ms against 0.40 + 0.19 ms; 99 against 103 M/s),
+             * the first bubble kernel waits for the launch's hundred general bubbles anyway, and a set with indels needs more rounds than it has
+             * (25 against 33 M/s); choosing between the modes from the launches' own times picked the wrong one under six batches in flight. */
+            static const int env_park_snp = getenv("MTG_PARK_SNP") ? atoi(getenv("MTG_PARK_SNP")) : 0;
+            const bool whole = tier == 0 && identity && m >= 4096;
+            const int wmode = (env_park_snp > 0 && !classic_walk) ? 1 : 0;
+            const uint32_t own_share = wmode ? ws.mode_share[1] : (ws.mode_share[0] != ~0u ? ws.mode_share[0] : ws.park_share);
+            const uint32_t park_share = own_share != ~0u ? own_share : (wmode ? 65536u : idx->park_share_any.load(std::memory_order_relaxed));
             const uint32_t park_hint = (uint32_t)(((uint64_t)park_share * m) >> 16); /* gaps this launch is expected to park */
             int rounds = env_rounds >= 0 ? env_rounds : (park_share > 32768u ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
             if (rounds > (PARK_LISTS - 2) / 2) rounds = (PARK_LISTS - 2) / 2;
@@ -1958,7 +1971,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 HIP_TRY(hipEventRecord(evf, stream));
             } else {
                 hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
+                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u, wmode ? 2u : 1u);
                 HIP_TRY(hipEventRecord(evf, stream));
                 static const bool skip_finish = getenv("MTG_DEBUG_SKIP_FINISH") != nullptr; /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 const uint32_t per_wg = 64u / (uint32_t)finish_g;
@@ -1971,7 +1984,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     if (one_lane_bubbles) {
                         hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin);
                         hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                           d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
+                                           d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2, wmode ? 2u : 1u);
                         continue;
                     }
                     switch (finish_g) {
@@ -1981,7 +1994,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     }
                     hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin + 1);
                     hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2, wmode ? 2u : 1u);
                 }
                 const uint32_t lfin = 2u * (uint32_t)rounds;
                 /* how the tail is finished: a group of lanes per parked gap, bubbles from LDS.  One lane per gap (MTG_FINISH_G=1, or below
@@ -2177,7 +2190,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
             HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
             st.finish_kernel_ms += msf;
-            if (!classic_walk) { const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot)); st.n_parked_gaps += np; st.n_rounds += (uint64_t)rounds; if (tier == 0 && identity && m >= 64) { ws.park_share = (uint32_t)std::min<uint64_t>(((uint64_t)np << 16) / m, 65536u); idx->park_share_any.store(ws.park_share, std::memory_order_relaxed); } }
+            if (!classic_walk) { const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot)); st.n_parked_gaps += np; st.n_rounds += (uint64_t)rounds; if (tier == 0 && identity && m >= 64) {
+                    const uint32_t share = (uint32_t)std::min<uint64_t>(((uint64_t)np << 16) / m, 65536u);
+                    ws.mode_share[wmode] = share;
+                    if (!wmode) { ws.park_share = share; idx->park_share_any.store(share, std::memory_order_relaxed); }
+                    if (whole) { ws.mode_ns_per_gap[wmode] = ms * 1e6f / (float)m; ws.mode_launches++; } /* ev0 .. ev1: the walk, its rounds and the finishing kernel (with whatever else the device was doing: the launches of a workspace see the same company) */
+                } }
             HIP_TRY(hipEventElapsedTime(&msc, ev1, evc));
             HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
             st.copy_kernel_ms += msc;

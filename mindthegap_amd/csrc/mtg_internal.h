@@ -39,6 +39,11 @@ struct Workspace {
     /* share of the gaps (in 65536ths) the walk kernel parked in this workspace's previous whole-batch launch: how the next launch serves its
      * parked gaps (rounds or not, lanes per gap in the finishing kernel); ~0 = no launch yet: the index's latest figure is taken */
     uint32_t park_share = ~0u;
+    /* the same per walk mode (0: the walk answers strict SNP bubbles itself, 1: it parks there too and the bubble kernel answers them), with
+     * the traversal's time per gap the mode took last time: the next whole-batch launch takes the faster mode and tries the other now and then */
+    uint32_t mode_share[2] = {~0u, ~0u};
+    float mode_ns_per_gap[2] = {0.f, 0.f};
+    uint32_t mode_launches = 0;
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
 }

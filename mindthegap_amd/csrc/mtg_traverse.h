@@ -104,8 +104,10 @@ MTG_ARR(CopyCmd, s_cmd, r, c.o_cmd)
 struct WalkSave {
     uint64_t cur_f, prev_c, start_f, acc, start_base, r_base, msig[4];
     uint32_t len, c_first, nacc, wpos, head, tail, nb, total_nt, start_idx, r_idx, ncmd, copy_words, store_reads, run_nt, lines, n_marked, flags;
-    uint32_t answered;  /* 1: a bubble kernel has answered the branching node the walk stands on: bn, bchosen, the consensus in the gap's s_cons area */
+    uint32_t answered;  /* 1: a bubble kernel has answered the branching node the walk stands on: bn, bchosen, the consensus in the gap's s_cons area;
+                           2: it was the strict SNP pattern: bn nucleotides in snp_lo / snp_hi (the SNP fast path's answer, consumed as the walk consumes its own) */
     int32_t node_depth, bn, bchosen, pad_;
+    uint64_t snp_lo, snp_hi;
 };
 MTG_ARR(WalkSave, s_save, r, c.o_save)
 /* A gap whose only contig holds the target at a place known without looking at the contig (the target's k-mer sits in a stored unitig, and the
@@ -1865,11 +1867,20 @@ MTG_UNROLL
     /* ---- a parked walk goes on where it stopped: at the branching node, the SNP attempt behind it */
     bool resuming = false, parked = false, answered = false;
     int saved_n = 0, saved_chosen = -1;
+    bool answered_snp = false; /* the bubble kernel found the strict SNP pattern at the node the walk stands on: its answer is consumed like the walk's own */
+    SnpSeq saved_snp;
+    saved_snp.lo = saved_snp.hi = 0;
+    /* S.snp_fast == 2 (the walk kernel, when the launch serves bubbles in rounds): the walk parks at EVERY branching node, also where the SNP
+     * fast path would answer -- the lanes of a wave meet their SNPs at different steps, and a wave in which one lane at a time runs the bubble
+     * code while 63 wait spends four times as long there as on the walking; the bubble kernel runs it for all parked gaps at once */
+    const bool park_all = MODE == WALK_PARK && S.snp_fast == 2;
     if (resume) {
         const WalkSave sv = *s_save(cfg, S);
         resuming = true;
-        answered = sv.answered != 0;
+        answered = sv.answered == 1;
+        answered_snp = sv.answered == 2;
         saved_n = sv.bn; saved_chosen = sv.bchosen;
+        saved_snp.lo = sv.snp_lo; saved_snp.hi = sv.snp_hi;
         cur = make_kmer(sv.cur_f, k);
         prev_c = sv.prev_c;
         const Kmer st = make_kmer(sv.start_f, k);
@@ -2047,7 +2058,8 @@ MTG_UNROLL
             SnpSeq fast_seq;
             fast_seq.lo = fast_seq.hi = 0;
             int n = 0;
-            if (!resuming) n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
+            if (resuming && answered_snp) { n = saved_n; chosen = saved_chosen; fast_seq = saved_snp; answered_snp = false; }
+            else if (!resuming && !park_all) n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
             resuming = false;
             MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
@@ -2272,9 +2284,9 @@ MTG_DEV void stage_a_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
  * node, the answer goes back into it (WalkSave::answered) and the walk kernel takes it from there.
  * bubble_coop: by a group of G lanes from LDS; false = too big for the LDS areas (the gap goes to bubble_classic).
  * bubble_classic: by one lane from HBM scratch. */
-MTG_DEV void bubble_store(const FillCfg& cfg, const GapScratch& S, Worker& W, WalkSave& sv, int n, int chosen)
+MTG_DEV void bubble_store(const FillCfg& cfg, const GapScratch& S, Worker& W, WalkSave& sv, int n, int chosen, uint32_t kind = 1)
 {
-    sv.answered = 1; sv.bn = n; sv.bchosen = chosen;
+    sv.answered = kind; sv.bn = n; sv.bchosen = chosen;
     sv.n_marked = W.n_marked; sv.msig[0] = W.msig0; sv.msig[1] = W.msig1; sv.msig[2] = W.msig2; sv.msig[3] = W.msig3;
     sv.lines += W.lines;
     *s_save(cfg, S) = sv;
@@ -2283,6 +2295,22 @@ MTG_DEV void bubble_load(Worker& W, const WalkSave& sv)
 {
     W.n_marked = sv.n_marked; W.msig0 = sv.msig[0]; W.msig1 = sv.msig[1]; W.msig2 = sv.msig[2]; W.msig3 = sv.msig[3];
 }
+/* the strict SNP pattern at the parked node (the walk kernel parks there too when the launch serves bubbles in rounds): the fast path's answer,
+ * exactly as the walking lane would have computed it (the node's neighbourhood is read the way a resumed walk reads it); true = answered */
+MTG_DEV bool bubble_snp(const Index& ix, const FillCfg& cfg, const GapScratch& S, Worker& W, WalkSave& sv, const Kmer& cur, bool store)
+{
+    if (!S.snp_fast) return false;
+    const Adj a = adj_right_t(ix.adj, cur, W.mk1, W.lines);
+    SnpSeq fs;
+    fs.lo = fs.hi = 0;
+    int chosen = -1;
+    const int n = snp_bubble_fast(W, cur, sv.prev_c, a, chosen, fs);
+    if (n <= 0 || W.status) return false;
+    sv.snp_lo = fs.lo; sv.snp_hi = fs.hi;
+    if (store) bubble_store(cfg, S, W, sv, n, chosen, 2);
+    else { sv.bn = n; sv.bchosen = chosen; }
+    return true;
+}
 template <int G> MTG_DEV bool bubble_coop(const Index& ix, const FillCfg& cfg, const GapScratch& S, BubbleLds& L)
 {
     typedef Grp<G> GP;
@@ -2290,6 +2318,17 @@ template <int G> MTG_DEV bool bubble_coop(const Index& ix, const FillCfg& cfg, c
     Worker W(ix, cfg, S);
     bubble_load(W, sv);
     const Kmer cur = make_kmer(sv.cur_f, ix.k);
+    {   /* every lane of the group runs the fast path (as the group's lanes run the walk in k_finish); one stores */
+        Worker Ws(ix, cfg, S);
+        bubble_load(Ws, sv);
+        WalkSave svs = sv;
+        if (bubble_snp(ix, cfg, S, Ws, svs, cur, false)) { if (GP::gl() == 0) bubble_store(cfg, S, Ws, svs, svs.bn, svs.bchosen, 2); GP::sync(); return true; }
+        if (Ws.status) { /* TEST-ONLY emulation: a cross-check of the fast path failed */
+            if (GP::gl() == 0) { svs.flags |= 0x40000000u; bubble_store(cfg, S, Ws, svs, 0, -1); }
+            GP::sync();
+            return true;
+        }
+    }
     int chosen = -1;
     const int n = coop_explore<G>(W, L, cur, sv.prev_c, chosen);
 #ifdef MTG_EMU
@@ -2337,6 +2376,8 @@ MTG_DEV void bubble_classic(const Index& ix, const FillCfg& cfg, const GapScratc
     Worker W(ix, cfg, S);
     bubble_load(W, sv);
     const Kmer cur = make_kmer(sv.cur_f, ix.k);
+    if (bubble_snp(ix, cfg, S, W, sv, cur, true)) return;
+    if (W.status) { sv.flags |= 0x40000000u; bubble_store(cfg, S, W, sv, 0, -1); return; } /* TEST-ONLY emulation: a cross-check of the fast path failed */
     int chosen = -1;
     int n = explore_branching(W, cur, sv.prev_c, chosen);
     if (W.status) { n = 0; sv.flags |= 0x80000000u; } /* a work area of this scratch tier overflowed: the walk ends the gap with that status */

@@ -11,7 +11,9 @@ for w in $wl; do
       classic) export MTG_CLASSIC_WALK=1; unset MTG_FINISH_G MTG_ROUNDS;;
       g16) unset MTG_CLASSIC_WALK; export MTG_FINISH_G=16 MTG_ROUNDS=0;;
       g64) unset MTG_CLASSIC_WALK; export MTG_FINISH_G=64 MTG_ROUNDS=0;;
-      auto) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS MTG_BUBBLE_GROUPS;;
+      auto) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS MTG_BUBBLE_GROUPS MTG_PARK_SNP;;
+    snp0) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS MTG_BUBBLE_GROUPS; export MTG_PARK_SNP=0;;
+    snp1) unset MTG_CLASSIC_WALK MTG_FINISH_G MTG_ROUNDS MTG_BUBBLE_GROUPS; export MTG_PARK_SNP=1;;
       o*r*) unset MTG_CLASSIC_WALK; unset MTG_BUBBLE_GROUPS; export MTG_FINISH_G=16 MTG_ROUNDS=${mode#*r};;
       g*r*) unset MTG_CLASSIC_WALK; export MTG_BUBBLE_GROUPS=1; g=${mode#g}; export MTG_FINISH_G=${g%r*} MTG_ROUNDS=${mode#*r};;
     esac
