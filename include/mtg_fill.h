@@ -82,6 +82,16 @@ int mtg_index_save(const mtg_index* idx, const char* path);
  * independent index: free it with mtg_index_free. */
 int mtg_index_replicate(const mtg_index* idx, int device, mtg_index** out);
 int mtg_index_get_info(const mtg_index* idx, mtg_index_info* info);
+/* How Graph::create / Graph::load (src/Filler.cpp:172-226) went on the device: one record per phase of the construction (kernel or group of
+ * kernels, in order) with its device time and the bytes the implemented layout has to move for it (0: not accounted), the most device
+ * memory the construction held at any moment, and its whole duration.  out may be NULL (n receives the number of phases). */
+typedef struct mtg_build_phase {
+    char name[32];
+    double ms;
+    uint64_t bytes;   /* bytes of the implemented layout the phase must read + write (random accesses counted as the lines they touch) */
+    uint64_t units;   /* what the phase processed: k-mers, junctions, table slots ... (named in DESIGN.md section 3) */
+} mtg_build_phase;
+int mtg_index_build_profile(const mtg_index* idx, mtg_build_phase* out, size_t cap, size_t* n, uint64_t* peak_device_bytes, double* total_ms);
 void mtg_index_free(mtg_index* idx);
 
 /* Batched graph queries (host arrays in, host arrays out).  kmers[] in any orientation.

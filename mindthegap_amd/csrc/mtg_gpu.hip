@@ -356,6 +356,142 @@ __global__ void k_recs_from_store(UStore us, const uint64_t* __restrict__ hdr, u
     rec[u] = r;
 }
 
+/* ---- the lean build (mtg_dev.h: "the lean build"): junction table -> unitig store -> sparse tables ---- */
+/* abundance of a k-mer of the synthetic sets: a function of the k-mer, no table */
+struct AbSynth {
+    uint32_t lo, span;
+    __device__ uint32_t operator()(uint64_t c, uint32_t&) const { return d_synth_abundance(c, lo, span); }
+};
+/* sum of v over the wave, valid in lane 0 */
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;
+}
+/* the junctions of packed sequences: one workgroup per sequence, lanes stride over the (k-1)-mer positions; a junction's entry gets the
+ * bits of the k-mers on its two sides in ONE table operation (index_insert makes four per k-mer).  counters[0] = overflow flag */
+__global__ void __launch_bounds__(256) k_jt_insert_packed(Table jt, int k, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len,
+                                                          size_t nseq, unsigned long long* counters)
+{
+    const uint64_t mk1 = kmask(k - 1), cmpl1 = 0xAAAAAAAAAAAAAAAAULL & mk1;
+    int fail = 0;
+    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const uint64_t* w = words + word_off[s];
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        for (uint32_t q = threadIdx.x; q + (uint32_t)k - 1 <= L; q += blockDim.x) {
+            /* nucleotides q-1 .. q+k-1 in one little-endian window [a][J: k-1][b] (at most 32 nucleotides: one 64-bit value) */
+            const bool has_a = q >= 1, has_b = q + (uint32_t)k - 1 < L;
+            const uint32_t q0 = has_a ? q - 1 : q, sh = 2u * (q0 & 31u), need = (uint32_t)k - 1u + (has_a ? 1u : 0u) + (has_b ? 1u : 0u);
+            uint64_t win = w[q0 >> 5] >> sh; /* nt q0 + i at bits 2i */
+            if ((q0 & 31u) + need > 32u) win |= w[(q0 >> 5) + 1] << (64u - sh); /* sh > 0 here */
+            const uint32_t a = (uint32_t)win & 3u;
+            const uint64_t body = has_a ? win >> 2 : win;
+            const uint64_t jle = body & mk1;                                      /* J, little-endian image */
+            const uint32_t b = (uint32_t)(body >> (2 * (k - 1))) & 3u;
+            const uint64_t jr = jle ^ cmpl1, jf = revcomp(jr, k - 1);             /* complemented image = reverse complement */
+            fail |= jt_insert_junction(jt, jf, jr, has_a, a, has_b, b) & 1;
+        }
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+}
+/* a counted solid set handed over as a list: abundances into the (dense) ABND table that serves as their source, junctions into the
+ * junction table.  counters[0] = overflow flag, counters[3] += abundances above 255 */
+__global__ void k_jt_insert_kmers(Table jt, Table abnd, int k, const uint64_t* __restrict__ kmers, const uint32_t* __restrict__ ab, size_t n, unsigned long long* counters)
+{
+    unsigned long long sat = 0;
+    int fail = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t c = kmers[i];
+        fail |= table_or<MTG_ABND_SLOTS>(abnd, c, ab_stored(ab[i])) & 1;
+        fail |= jt_insert_kmer(jt, c, k);
+        sat += ab[i] > 255u;
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (sat) atomicAdd(&counters[3], sat);
+}
+/* the solid k-mers of a count table (count in [lo, hi]) into the junction table; with_abnd: also into an ABND table (several counting
+ * passes: the count table of a pass does not outlive it) */
+__global__ void k_jt_insert_from_counts(Table jt, Table abnd, int with_abnd, int k, CountTable t, uint32_t lo, uint32_t hi, unsigned long long* counters)
+{
+    unsigned long long sat = 0;
+    int fail = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = t.keys[i];
+        if (key == ~0ULL) continue;
+        const uint32_t c = t.counts[i];
+        if (c < lo || c > hi) continue;
+        if (with_abnd) { fail |= table_or<MTG_ABND_SLOTS>(abnd, key, ab_stored(c)) & 1; sat += c > 255u; }
+        fail |= jt_insert_kmer(jt, key, k);
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (sat) atomicAdd(&counters[3], sat);
+}
+/* one streaming pass over the junction table (jt_scan_entry); collect = 0: counts starts / k-mers of no chain and the statistics,
+ * collect = 1: fills the lists (the statistics are left alone) */
+template <typename Src>
+__global__ void __launch_bounds__(256) k_jt_scan(Table jt, int k, Src src, unsigned long long* counters, int collect, uint64_t* starts, unsigned long long cap_starts,
+                                                 uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left)
+{
+    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
+    JtAcc acc{};
+    uint32_t lines = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t J;
+        const uint32_t m = jt_slot_key(jt, s, J);
+        if (!m) continue;
+        jt_scan_entry(jt, k, J, m, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+    }
+    if (collect) return;
+    for (int j = 0; j < 6; j++) {
+        const unsigned long long v = wave_sum_u64(acc.c[j]);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&counters[j], v);
+    }
+}
+template <typename Src>
+__global__ void __launch_bounds__(256) k_jt_unstored(Table jt, Index nx, Src src, unsigned long long* counters, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left)
+{
+    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
+    uint32_t lines = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t J;
+        const uint32_t m = jt_slot_key(jt, s, J);
+        if (!m) continue;
+        jt_unstored_entry(jt, nx, J, m, src, counters, left_k, left_a, cap_left, lines);
+    }
+}
+/* one chain start per lane: the walk to the other end; the end the chain is stored from reserves words and record */
+__global__ void __launch_bounds__(64) k_jt_plan(Table jt, int k, const uint64_t* __restrict__ starts, unsigned long long n, unsigned long long* counters, UsRec* rec, unsigned long long rec_cap)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    jt_plan_start(jt, k, make_kmer(starts[i], k), counters, rec, rec_cap, lines);
+}
+/* one stored unitig per lane: its sequence into the store */
+__global__ void __launch_bounds__(64) k_jt_emit(Table jt, UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    jt_emit(jt, us, k, rec[i], lines);
+}
+/* one stored unitig per wave, its k-mers dealt to the lanes: abundances from the source into the store.  counters[JT_C_SAT] += those above 255 */
+template <typename Src>
+__global__ void __launch_bounds__(256) k_us_ab(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, Src src, unsigned long long* counters)
+{
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lines = 0;
+    unsigned long long sat = 0;
+    for (unsigned long long u = wave; u < n; u += nwaves) {
+        const UsRec r = rec[u];
+        for (uint32_t i = lane; i < r.len_k; i += 64) sat += us_ab_fill(us, k, r, i, src, lines);
+    }
+    sat = wave_sum_u64(sat);
+    if (lane == 0 && sat) atomicAdd(&counters[JT_C_SAT], sat);
+}
+
 /* the solid k-mers and their abundances out of the ABND table (index writer): out_k / out_a receive them in no particular order */
 __global__ void k_abnd_export(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned long long* cursor, unsigned long long cap)
 {
@@ -1061,6 +1197,62 @@ struct DevBuf {
 };
 } // namespace
 
+namespace {
+/* device times and memory of an index construction (mtg_index_build_profile) */
+struct BuildProf {
+    std::vector<mtg_build_phase> phases;
+    size_t base_used = 0, peak = 0;
+    std::chrono::steady_clock::time_point t0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BuildProf()
+    {
+        t0 = std::chrono::steady_clock::now();
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess) base_used = t - f;
+    }
+    ~BuildProf() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    BuildProf(const BuildProf&) = delete;
+    /* call after allocations: the most memory held beyond what the device held when the construction began */
+    void sample()
+    {
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) != hipSuccess) return;
+        const size_t used = t - f;
+        if (used > base_used && used - base_used > peak) peak = used - base_used;
+    }
+    void begin() { sample(); (void)hipEventRecord(e0, 0); }
+    /* closes the phase opened by begin(): waits for the null stream */
+    hipError_t end(const char* name, uint64_t bytes, uint64_t units)
+    {
+        (void)hipEventRecord(e1, 0);
+        const hipError_t e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+        mtg_build_phase ph{};
+        snprintf(ph.name, sizeof ph.name, "%s", name);
+        ph.ms = ms; ph.bytes = bytes; ph.units = units;
+        phases.push_back(ph);
+        return e == hipSuccess ? hipGetLastError() : e;
+    }
+    void host_phase(const char* name, double ms, uint64_t bytes, uint64_t units)
+    {
+        mtg_build_phase ph{};
+        snprintf(ph.name, sizeof ph.name, "%s", name);
+        ph.ms = ms; ph.bytes = bytes; ph.units = units;
+        phases.push_back(ph);
+    }
+    void store(mtg_index* idx)
+    {
+        sample();
+        idx->build_phases = phases;
+        idx->build_peak_bytes = peak;
+        idx->build_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+} // namespace
+
 static void free_tables(mtg_index* idx)
 {
     if (idx->dev.adj.slots) (void)hipFree(idx->dev.adj.slots);
@@ -1118,7 +1310,16 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
 /* Unitig store of a finished index (every k-mer inserted, every lookahead written): chain starts -> one walk per start -> sequences ->
  * abundances and junction pointers (mtg_dev.h: us_*).  Also fills nb_solid_kmers / nb_branching from the table itself.
  * MTG_NO_UNITIGS=1 (test hook) leaves the index with inline lookaheads only. */
-static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left);
+namespace {
+/* the k-mers of no stored unitig of a construction that can only name them once the unitigs' entries are in the new tables (lean build, a
+ * closed or over-long chain in the graph): called with the sparse ADJ table holding every unitig pointer; fills the lists */
+struct LateLeftovers {
+    unsigned long long n_upper = 0; /* bound on their number, for the shape of the tables */
+    std::function<int(const Index& nx, DevBuf& left_k, DevBuf& left_a, unsigned long long& n_left)> collect;
+};
+} // namespace
+static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
+                    BuildProf* prof = nullptr, const LateLeftovers* late = nullptr);
 static int build_unitigs(mtg_index* idx)
 {
     DevBuf d_cnt, d_starts, d_rec;
@@ -1174,12 +1375,14 @@ static int build_unitigs(mtg_index* idx)
  * dense tables are freed at the end) or from the store alone (an index out of its container: idx holds only the store; the k-mers of no
  * unitig are handed over, the Bloom filter is filled here).  New tables: ADJ with the entries the sparse form keeps, ABND with the k-mers
  * of no unitig. */
-static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left)
+static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
+                    BuildProf* prof, const LateLeftovers* late)
 {
     const int k = idx->dev.k;
     DevBuf d_cnt, own_k, own_a;
     HIP_TRY(d_cnt.alloc(64));
     if (!from_container) {
+        if (prof) prof->begin();
         HIP_TRY(hipMemset(d_cnt.p, 0, 64));
         const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
         const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
@@ -1193,15 +1396,15 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         HIP_TRY(hipDeviceSynchronize());
         d_left_k = own_k.as<uint64_t>();
         d_left_a = own_a.as<uint32_t>();
+        if (prof) HIP_TRY(prof->end("leftovers_dense", 2 * nslots * 8, nslots));
     }
+    const unsigned long long n_left_shape = late ? std::max(late->n_upper, n_left) : n_left;
     /* entries of the new ADJ: per unitig its kept interior junctions (every second one and the last) and its two ends; two per k-mer of no unitig */
-    std::vector<UsRec> h_rec;
-    uint64_t nkeys = 2 * n_left + 1024;
+    uint64_t nkeys = 2 * n_left_shape + 1024, n_unitig_kmers = 0;
     {
-        h_rec.resize(n_rec);
+        std::vector<UsRec> h_rec(n_rec);
         if (n_rec) HIP_TRY(hipMemcpy(h_rec.data(), d_rec, n_rec * sizeof(UsRec), hipMemcpyDeviceToHost));
-        for (const UsRec& r : h_rec) nkeys += r.len_k / 2 + 3;
-        std::vector<UsRec>().swap(h_rec);
+        for (const UsRec& r : h_rec) { nkeys += r.len_k / 2 + 3; n_unitig_kmers += r.len_k; }
     }
     Index old = idx->dev;
     double load = 1.0;
@@ -1211,17 +1414,38 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         nx.adj.sp_words = nullptr; /* raw look-ups while the tables are being built */
         const double load_adj = (getenv("MTG_SPARSE_ADJ_LOAD") ? atof(getenv("MTG_SPARSE_ADJ_LOAD")) : 0.7) * load;
         table_shape(nx.adj, buckets_for(nkeys, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
-        table_shape(nx.abnd, buckets_for(n_left + 1024, 0.6 * load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+        table_shape(nx.abnd, buckets_for(n_left_shape + 1024, 0.6 * load, 2 * k, MTG_ABND_SLOTS), 2 * k);
         const size_t ba = nx.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = nx.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
         DevBuf na, nb;
         HIP_TRY(na.alloc(ba));
         HIP_TRY(nb.alloc(bb));
-        HIP_TRY(hipMemset(na.p, 0, ba));
-        HIP_TRY(hipMemset(nb.p, 0, bb));
+        if (prof) prof->begin();
+        HIP_TRY(hipMemsetAsync(na.p, 0, ba, 0));
+        HIP_TRY(hipMemsetAsync(nb.p, 0, bb, 0));
+        if (prof) HIP_TRY(prof->end("clear_sparse_tables", ba + bb, 0));
         nx.adj.slots = na.as<uint64_t>();
         nx.abnd.slots = nb.as<uint64_t>();
         HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+        if (prof) prof->begin();
         if (n_rec) hipLaunchKernelGGL(k_sparse_link, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, nx, d_rec, n_rec, from_container ? 1 : 0, d_cnt.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        /* per k-mer: its window of the store (8), every second one an ADJ bucket read and written (2 x 32), with the filter a block (64 + 64) */
+        if (prof) HIP_TRY(prof->end(from_container ? "sparse_link+bloom" : "sparse_link", n_unitig_kmers * (8 + 32 + (from_container && nx.bloom.bits ? 128 : 0)), n_unitig_kmers));
+        DevBuf late_k, late_a;
+        if (late) {
+            unsigned long long cnt0[8];
+            HIP_TRY(hipMemcpy(cnt0, d_cnt.p, 64, hipMemcpyDeviceToHost));
+            if (cnt0[0]) { load *= 0.7; rc = MTG_ERR_OVERFLOW; set_error("index bucket displacement overflow (sparse form)"); continue; }
+            if (prof) prof->begin();
+            Index nxs = nx;
+            nxs.adj.sp_words = nx.us.words; /* the look-ups of kmer_stored go through the pointers */
+            if (int rc2 = late->collect(nxs, late_k, late_a, n_left)) return rc2;
+            if (n_left > n_left_shape) { set_error("more k-mers outside the unitigs (%llu) than the junction table accounts for (%llu)", n_left, n_left_shape); return MTG_ERR_OVERFLOW; }
+            d_left_k = late_k.as<uint64_t>();
+            d_left_a = late_a.as<uint32_t>();
+            if (prof) HIP_TRY(prof->end("late_leftovers", 0, n_left));
+        }
+        if (prof) prof->begin();
         if (n_left) {
             Index nxb = nx;
             if (!from_container) nxb.bloom.bits = nullptr; /* the filter holds every k-mer already */
@@ -1231,11 +1455,11 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         unsigned long long cnt[8];
         HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
         if (cnt[0]) { load *= 0.7; rc = MTG_ERR_OVERFLOW; set_error("index bucket displacement overflow (sparse form)"); continue; }
-        if (from_container) idx->info.nb_saturated = cnt[3];
         /* lookaheads of the entries that are no pointers: around the k-mers of no unitig and at the unitigs' ends */
         if (n_left) hipLaunchKernelGGL(k_lookahead_kmers, dim3((unsigned)std::min<unsigned long long>((n_left + 255) / 256 + 1, 256 * 16)), dim3(256), 0, 0, nx, d_left_k, (size_t)n_left);
         if (n_rec) hipLaunchKernelGGL(k_sparse_ends, dim3((unsigned)std::min<unsigned long long>((n_rec + 255) / 256, 256 * 16)), dim3(256), 0, 0, nx, d_rec, n_rec);
         HIP_TRY(hipGetLastError());
+        if (prof) HIP_TRY(prof->end("leftovers+ends", n_left * 5 * 32 + n_rec * 2 * 16 * 32, n_left + 2 * n_rec));
         HIP_TRY(hipDeviceSynchronize());
         /* the new tables take the place of the old ones */
         if (old.adj.slots) (void)hipFree(old.adj.slots);
@@ -1247,11 +1471,249 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         idx->info.device_bytes = ba + bb + idx->dev.bloom.nblocks * 64 + idx->info.unitig_bytes;
         idx->info.adj_buckets = nx.adj.nbuckets;
         idx->info.abnd_buckets = nx.abnd.nbuckets;
-        idx->info.sparse = 1;
+        idx->info.sparse = nx.us.words ? 1 : 0; /* no stored unitig: every k-mer has its full entries, the look-ups are the raw ones */
         idx->info.nb_kmers_outside_unitigs = n_left;
         return MTG_OK;
     }
     return rc;
+}
+
+/* ---- the lean build: Graph::create without dense tables (mtg_dev.h: "the lean build").  jt = the filled junction table (in jt_buf), src = where
+ * the abundances are asked; release_source() frees what src reads once the store holds every abundance.  Leaves idx with the unitig store,
+ * the sparse tables derived from it, the Bloom filter and the graph's statistics. */
+template <typename Src>
+static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const Src& src, const std::function<void()>& release_source, uint64_t sat_at_insert, BuildProf& prof)
+{
+    const int k = idx->dev.k;
+    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
+    const unsigned scan_blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+    DevBuf d_cnt, d_starts, d_rec, d_left_k, d_left_a;
+    HIP_TRY(d_cnt.alloc(JT_C_N * 8));
+    HIP_TRY(hipMemset(d_cnt.p, 0, JT_C_N * 8));
+    unsigned long long* cnt_d = d_cnt.as<unsigned long long>();
+    unsigned long long cnt[JT_C_N];
+    /* chain starts, k-mers of no chain, statistics: counted, then collected */
+    prof.begin();
+    hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, k, src, cnt_d, 0, (uint64_t*)nullptr, 0ull, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull);
+    HIP_TRY(prof.end("jt_scan_count", nslots * 8, nslots));
+    HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
+    const unsigned long long n_starts = cnt[JT_C_STARTS], n_single = cnt[JT_C_LEFT], interior = cnt[JT_C_INTERIOR];
+    idx->info.nb_solid_kmers = (cnt[JT_C_ORIENTED] + cnt[JT_C_SELF]) / 2;
+    idx->info.nb_branching = (2 * cnt[JT_C_IN_NOT1] - cnt[JT_C_BOTH_NOT1] + cnt[JT_C_SELF_BRANCH]) / 2;
+    idx->info.nb_unitigs = 0;
+    idx->info.unitig_bytes = 0;
+    HIP_TRY(d_starts.alloc((n_starts + 1) * 8));
+    HIP_TRY(d_left_k.alloc((n_single + 1) * 8));
+    HIP_TRY(d_left_a.alloc((n_single + 1) * 4));
+    HIP_TRY(hipMemset(cnt_d + JT_C_STARTS, 0, 8));
+    HIP_TRY(hipMemset(cnt_d + JT_C_LEFT, 0, 8));
+    prof.begin();
+    hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, k, src, cnt_d, 1, d_starts.as<uint64_t>(), n_starts, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), n_single);
+    HIP_TRY(prof.end("jt_scan_collect", nslots * 8 + n_starts * 8 + n_single * 12, nslots));
+    /* abundances above 255: of the single k-mers (counted by the pass above), then of the unitigs' k-mers (k_us_ab), each on its own */
+    unsigned long long sat_single = 0, sat_unitigs = 0, sat_late = 0;
+    HIP_TRY(hipMemcpy(&sat_single, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(cnt_d + JT_C_SAT, 0, 8));
+    unsigned long long n_words = 0, n_rec = 0, stored_views = 0;
+    if (n_starts) {
+        const unsigned long long rec_cap = n_starts / 2 + 1; /* two starts per stored unitig (one per strand) */
+        HIP_TRY(d_rec.alloc(rec_cap * sizeof(UsRec)));
+        prof.begin();
+        hipLaunchKernelGGL(k_jt_plan, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, jt, k, d_starts.as<uint64_t>(), n_starts, cnt_d, d_rec.as<UsRec>(), rec_cap);
+        HIP_TRY(prof.end("jt_plan", (interior + n_starts) * 32, interior + n_starts)); /* both strands of every chain: one bucket per step */
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
+        n_words = cnt[JT_C_WORDS]; n_rec = cnt[JT_C_RECS]; stored_views = cnt[JT_C_STORED_VIEWS];
+        if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
+    }
+    (void)d_starts.alloc(0);
+    if (n_rec) {
+        const unsigned long long pad = 8; /* the coverage pass may look up to 64 + k nucleotides past the end of a unitig */
+        HIP_TRY(hipMalloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
+        HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, (n_words + pad) * 32));
+        prof.begin();
+        HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + pad) * 8, 0));
+        HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + pad) * 32, 0));
+        idx->dev.us.nwords = n_words;
+        idx->dev.us.nunitigs = n_rec;
+        hipLaunchKernelGGL(k_jt_emit, dim3((unsigned)((n_rec + 63) / 64)), dim3(64), 0, 0, jt, idx->dev.us, k, d_rec.as<UsRec>(), n_rec);
+        HIP_TRY(prof.end("jt_emit", (stored_views / 2) * 32 + n_words * 48, stored_views / 2 + n_rec));
+        prof.begin();
+        hipLaunchKernelGGL(k_us_ab<Src>, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, src, cnt_d);
+        HIP_TRY(prof.end("us_abundances", (stored_views / 2 + n_rec) * 9, stored_views / 2 + n_rec));
+        HIP_TRY(hipMemcpy(&sat_unitigs, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
+        idx->info.nb_unitigs = n_rec;
+        idx->info.unitig_bytes = (n_words + pad) * 40;
+    }
+    /* the Bloom filter of the sequence scan: filled from the store and the k-mers of no unitig while the sparse tables are written */
+    const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.bloom.nblocks = 0;
+    if (bpk > 0) bloom_shape(idx->dev.bloom, idx->info.nb_solid_kmers, bpk, k);
+    idx->info.bloom_blocks = idx->dev.bloom.nblocks;
+    idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
+    idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
+    idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
+    const auto alloc_bloom = [&]() -> int {
+        if (!idx->dev.bloom.nblocks) return MTG_OK;
+        HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, idx->dev.bloom.nblocks * 64));
+        HIP_TRY(hipMemsetAsync(idx->dev.bloom.bits, 0, idx->dev.bloom.nblocks * 64, 0));
+        return MTG_OK;
+    };
+    int rc;
+    if (interior == stored_views) {
+        /* every chain is a stored unitig: the k-mers of no unitig are the single ones the scan found; table and source have served */
+        prof.sample();
+        (void)jt_buf.alloc(0);
+        release_source();
+        if (int rc2 = alloc_bloom()) return rc2;
+        rc = sparsify(idx, d_rec.as<UsRec>(), n_rec, true, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), n_single, &prof, nullptr);
+    } else {
+        /* a closed chain, or one too long for the offsets of a pointer: its k-mers belong to no unitig, and only the finished pointers tell which */
+        if (int rc2 = alloc_bloom()) return rc2;
+        (void)d_left_k.alloc(0);
+        (void)d_left_a.alloc(0);
+        sat_single = 0; /* the late pass finds the single k-mers again */
+        LateLeftovers late;
+        late.n_upper = n_single + (interior - stored_views) / 2 + n_starts + 16;
+        late.collect = [&](const Index& nx, DevBuf& lk, DevBuf& la, unsigned long long& n_left) -> int {
+            HIP_TRY(hipMemset(cnt_d + JT_C_LEFT, 0, 8));
+            hipLaunchKernelGGL(k_jt_unstored<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, nx, src, cnt_d, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull);
+            HIP_TRY(hipGetLastError());
+            unsigned long long n = 0;
+            HIP_TRY(hipMemcpy(&n, cnt_d + JT_C_LEFT, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(lk.alloc((n + 1) * 8));
+            HIP_TRY(la.alloc((n + 1) * 4));
+            HIP_TRY(hipMemset(cnt_d + JT_C_LEFT, 0, 8));
+            HIP_TRY(hipMemset(cnt_d + JT_C_SAT, 0, 8)); /* an attempt with more buckets counts again */
+            hipLaunchKernelGGL(k_jt_unstored<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, nx, src, cnt_d, lk.as<uint64_t>(), la.as<uint32_t>(), n);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            n_left = n;
+            return MTG_OK;
+        };
+        rc = sparsify(idx, d_rec.as<UsRec>(), n_rec, true, nullptr, nullptr, 0, &prof, &late);
+        HIP_TRY(hipMemcpy(&sat_late, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
+        prof.sample();
+        (void)jt_buf.alloc(0);
+        release_source();
+    }
+    if (rc) return rc;
+    idx->info.nb_saturated = sat_at_insert + sat_single + sat_unitigs + sat_late;
+    return MTG_OK;
+}
+
+/* MTG_DENSE_INDEX=1 / MTG_NO_UNITIGS=1 (test hooks: the dense form of the index, the index without a unitig store) and MTG_LEGACY_BUILD=1
+ * (A/B) take the construction of rounds 1-3: dense ADJ + ABND tables, lookaheads, the store from them, then the sparse form */
+static bool legacy_build() { return getenv("MTG_DENSE_INDEX") || getenv("MTG_NO_UNITIGS") || getenv("MTG_LEGACY_BUILD"); }
+static double jt_load() { return getenv("MTG_JT_LOAD") ? atof(getenv("MTG_JT_LOAD")) : 0.7; }
+/* a cleared table of MTG_ABND_SLOTS-slot buckets for nkeys keys of key_bits bits */
+static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase)
+{
+    table_shape(t, buckets_for(nkeys, load, key_bits, MTG_ABND_SLOTS), key_bits);
+    t.sp_words = nullptr;
+    const size_t bytes = t.nbuckets * 8 * MTG_ABND_SLOTS;
+    HIP_TRY(buf.alloc(bytes));
+    t.slots = buf.as<uint64_t>();
+    prof.begin();
+    HIP_TRY(hipMemsetAsync(buf.p, 0, bytes, 0));
+    HIP_TRY(prof.end(phase, bytes, 0));
+    return MTG_OK;
+}
+
+static int index_from_kmer_pieces_lean(size_t n, int k, const KmerFetch& fetch, mtg_index** out)
+{
+    BuildProf prof;
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    DevBuf d_k, d_a, d_cnt, jt_buf, abnd_buf;
+    HIP_TRY(d_cnt.alloc(4 * 8));
+    const size_t env_piece = getenv("MTG_LOAD_PIECE") ? (size_t)atol(getenv("MTG_LOAD_PIECE")) : 0; /* test hook: small pieces */
+    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
+    HIP_TRY(d_k.alloc(piece * 8));
+    HIP_TRY(d_a.alloc(piece * 4));
+    Table jt{}, abnd{};
+    double load = 1.0;
+    int rc = MTG_OK;
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n + n / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt")) return rc2;
+        if (int rc2 = alloc_slot_table(abnd, abnd_buf, n, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        double ms = 0;
+        for (size_t off = 0; off < n; off += piece) {
+            const size_t m = std::min(piece, n - off);
+            const uint64_t* hk = nullptr;
+            const uint32_t* ha = nullptr;
+            if (!fetch(off, m, hk, ha)) return MTG_ERR_IO; /* the source has set the message */
+            HIP_TRY(hipMemcpy(d_k.p, hk, m * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_a.p, ha, m * 4, hipMemcpyHostToDevice));
+            prof.begin();
+            hipLaunchKernelGGL(k_jt_insert_kmers, dim3((unsigned)std::min<size_t>((m + 255) / 256 + 1, 256 * 16)), dim3(256), 0, 0, jt, abnd, k, d_k.as<uint64_t>(), d_a.as<uint32_t>(), m, d_cnt.as<unsigned long long>());
+            HIP_TRY(prof.end("jt_insert_kmers", 0, m)); /* also: the source may reuse its buffers for the next piece */
+            ms += prof.phases.back().ms;
+            prof.phases.pop_back();
+        }
+        prof.host_phase("jt_insert_kmers", ms, (uint64_t)n * (12 + 3 * 64), n); /* a k-mer: its list entry, an ABND bucket and two junction buckets read and written */
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+        if (!cnt[0]) { rc = MTG_OK; break; }
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    if (rc) return rc;
+    (void)d_k.alloc(0);
+    (void)d_a.alloc(0);
+    AbFromTable src;
+    src.abnd = abnd;
+    if (int rc2 = build_from_jt(idx, jt_buf, jt, src, [&] { (void)abnd_buf.alloc(0); }, cnt[3], prof)) return rc2;
+    idx->info.k = k;
+    idx->info.abundance_min = 0;
+    idx->info.abundance_auto = -1;
+    prof.store(idx);
+    *out = g.release();
+    return MTG_OK;
+}
+
+static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t total_kmers_ub, int k,
+                                         uint32_t abund_lo, uint32_t abund_span, mtg_index** out)
+{
+    BuildProf prof;
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    DevBuf d_cnt, jt_buf;
+    HIP_TRY(d_cnt.alloc(32));
+    Table jt{};
+    double load = 1.0;
+    int rc = MTG_OK;
+    const uint64_t n_junctions_ub = total_kmers_ub + nseq + 1024; /* a sequence of L >= k nucleotides has L - k + 2 junction positions */
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt")) return rc2;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        if (nseq == 0) break; /* an empty graph: nothing to launch */
+        prof.begin();
+        hipLaunchKernelGGL(k_jt_insert_packed, dim3((unsigned)std::min<size_t>(nseq, 256 * 32)), dim3(256), 0, 0, jt, k, d_words, d_word_off, d_len, nseq, d_cnt.as<unsigned long long>());
+        HIP_TRY(prof.end("jt_insert_packed", n_junctions_ub * (64 + 1), n_junctions_ub)); /* a junction position: its bucket read and written (2 x 32), its nucleotides */
+        unsigned long long cnt[4];
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+        if (!cnt[0]) { rc = MTG_OK; break; }
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    if (rc) return rc;
+    AbSynth src;
+    src.lo = abund_lo; src.span = abund_span;
+    if (int rc2 = build_from_jt(idx, jt_buf, jt, src, [] {}, 0, prof)) return rc2;
+    idx->info.k = k;
+    idx->info.abundance_min = (int)abund_lo;
+    idx->info.abundance_auto = -1;
+    prof.store(idx);
+    *out = g.release();
+    return MTG_OK;
 }
 
 /* The index of a counted solid set that arrives in pieces (host arrays, or the records of a saved index read from its file: 36 GB at human
@@ -1261,6 +1723,7 @@ int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** 
 {
     if (int rc = ensure_device()) return rc;
     if (k < 11 || k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (!legacy_build()) return index_from_kmer_pieces_lean(n, k, fetch, out);
     IndexGuard g(new mtg_index());
     mtg_index* idx = g.idx;
     idx->dev.k = k;
@@ -1327,6 +1790,7 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
 {
     if (int rc = ensure_device()) return rc;
     if (k < 11 || k > 31 || !out || (nseq && (!d_words || !d_word_off || !d_len))) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (!legacy_build()) return index_from_packed_device_lean(d_words, d_word_off, d_len, nseq, total_kmers_ub, k, abund_lo, abund_span, out);
     IndexGuard g(new mtg_index());
     mtg_index* idx = g.idx;
     idx->dev.k = k;
@@ -2337,6 +2801,7 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
     if (int rc = ensure_device()) return rc;
     if (k < 11 || k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
     const uint32_t nbins = 10003; /* STR_HISTOGRAM_MAX 10000, src/Filler.cpp:200 */
+    BuildProf prof;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = (size_t)((double)free_b * 0.45); /* the index tables have to fit next to the count table */
@@ -2416,6 +2881,54 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
         HIP_TRY(d_cnt.alloc(32));
         double load = 1.0;
         int rc = MTG_OK;
+        if (!legacy_build()) {
+            /* the lean build: the solid k-mers' junctions into the junction table; their abundances stay in the count table (one counting
+             * pass) or go into an ABND table of their own (several: the count table of a pass does not outlive it) */
+            prof.host_phase("count_reads", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - prof.t0).count(), 0, n_solid);
+            DevBuf jt_buf, abnd_buf;
+            Table jt{}, abnd{};
+            unsigned long long cnt[4] = {0, 0, 0, 0};
+            for (int ia = 0; ia < 6; ia++) {
+                if (int rc2 = alloc_slot_table(jt, jt_buf, n_solid + n_solid / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt")) return rc2;
+                if (npass > 1) if (int rc2 = alloc_slot_table(abnd, abnd_buf, n_solid, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
+                HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+                for (uint32_t pass = 0; pass < npass; pass++) {
+                    if (npass > 1) {
+                        bool ovf2 = false;
+                        if (int rc2 = count_pass(pass, ovf2)) return rc2;
+                        if (ovf2) { set_error("k-mer count table overflowed on a repeated pass"); return MTG_ERR_OVERFLOW; }
+                    }
+                    prof.begin();
+                    hipLaunchKernelGGL(k_jt_insert_from_counts, dim3(256 * 16), dim3(256), 0, 0, jt, abnd, npass > 1 ? 1 : 0, k, t, lo, hi, d_cnt.as<unsigned long long>());
+                    HIP_TRY(prof.end("jt_insert_from_counts", (t.mask + 1) * 12 + n_solid / npass * (2 * 64 + (npass > 1 ? 64 : 0)), n_solid / npass));
+                }
+                HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+                if (!cnt[0]) { rc = MTG_OK; break; }
+                load *= 0.7;
+                rc = MTG_ERR_OVERFLOW;
+                set_error("index bucket displacement overflow");
+            }
+            if (rc) return rc;
+            (void)d_text.alloc(0);
+            if (npass == 1) {
+                AbFromCounts src;
+                src.t = t;
+                rc = build_from_jt(idx, jt_buf, jt, src, [&] { (void)d_keys.alloc(0); (void)d_cnts.alloc(0); }, 0, prof);
+            } else {
+                (void)d_keys.alloc(0);
+                (void)d_cnts.alloc(0);
+                AbFromTable src;
+                src.abnd = abnd;
+                rc = build_from_jt(idx, jt_buf, jt, src, [&] { (void)abnd_buf.alloc(0); }, cnt[3], prof);
+            }
+            if (rc) return rc;
+            idx->info.k = k;
+            idx->info.abundance_min = abundance_min;
+            idx->info.abundance_auto = autoc;
+            prof.store(idx);
+            *out = g.release();
+            return MTG_OK;
+        }
         for (int ia = 0; ia < 6; ia++) {
             free_tables(idx);
             rc = alloc_tables(idx, n_solid, load);

@@ -1112,6 +1112,15 @@ int mtg_index_create_from_reads(const char* paths_csv, int k, int abundance_min,
 {
     return mtgi::index_from_reads(paths_csv, k, abundance_min, abundance_max, out);
 }
+int mtg_index_build_profile(const mtg_index* idx, mtg_build_phase* out, size_t cap, size_t* n, uint64_t* peak_device_bytes, double* total_ms)
+{
+    if (!idx) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    if (n) *n = idx->build_phases.size();
+    if (out) for (size_t i = 0; i < cap && i < idx->build_phases.size(); i++) out[i] = idx->build_phases[i];
+    if (peak_device_bytes) *peak_device_bytes = idx->build_peak_bytes;
+    if (total_ms) *total_ms = idx->build_total_ms;
+    return MTG_OK;
+}
 int mtg_index_save(const mtg_index* idx, const char* path) { return mtgi::index_save(idx, path); }
 int mtg_index_load(const char* path, mtg_index** out) { return mtgi::index_load(path, out); }
 

@@ -60,6 +60,11 @@ struct mtg_index {
     mutable mtgi::Workspace ws[NWS];
     int device = 0;
     mtg_index_info info{};
+    /* how the index came to be (mtg_index_build_profile): the phases of its construction with their device times, and the most device
+     * memory the construction held at any time (tables under construction + what it was built from + the finished parts) */
+    std::vector<mtg_build_phase> build_phases;
+    uint64_t build_peak_bytes = 0;
+    double build_total_ms = 0;
 };
 
 namespace mtgi {

@@ -101,6 +101,10 @@ class BatchStats(C.Structure):
                 ("copy_cmds", C.c_uint64), ("coverage_direct_kmers", C.c_uint64), ("finish_kernel_ms", C.c_double), ("n_parked_gaps", C.c_uint64), ("n_rounds", C.c_uint64), ("n_lean_gaps", C.c_uint64)]
 
 
+class BuildPhase(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("ms", C.c_double), ("bytes", C.c_uint64), ("units", C.c_uint64)]
+
+
 class WireHeader(C.Structure):
     _fields_ = [("magic", C.c_uint64), ("tag", C.c_uint64), ("n_gaps", C.c_uint64), ("n_filled", C.c_uint64), ("seq_bytes", C.c_uint64), ("ext_bytes", C.c_uint64),
                 ("total_bytes", C.c_uint64), ("checksum", C.c_uint64)]
@@ -143,6 +147,7 @@ def _bind(lib):
     lib.mtg_index_save.argtypes = [C.c_void_p, C.c_char_p]
     lib.mtg_index_replicate.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p)]
     lib.mtg_index_get_info.argtypes = [C.c_void_p, P(IndexInfo)]
+    lib.mtg_index_build_profile.argtypes = [C.c_void_p, P(BuildPhase), C.c_size_t, P(C.c_size_t), P(C.c_uint64), P(C.c_double)]
     lib.mtg_index_free.argtypes = [C.c_void_p]
     lib.mtg_index_free.restype = None
     lib.mtg_index_contains.argtypes = [C.c_void_p, P(C.c_uint64), C.c_size_t, P(C.c_uint8)]
@@ -320,6 +325,15 @@ class Index:
         i = IndexInfo()
         _check(self.lib.mtg_index_get_info(self.h, C.byref(i)))
         return {f[0]: getattr(i, f[0]) for f in IndexInfo._fields_}
+
+    def build_profile(self):
+        """how the index was constructed: {"phases": [{name, ms, bytes, units}], "peak_device_bytes", "total_ms"}"""
+        n, peak, total = C.c_size_t(), C.c_uint64(), C.c_double()
+        _check(self.lib.mtg_index_build_profile(self.h, None, 0, C.byref(n), C.byref(peak), C.byref(total)))
+        arr = (BuildPhase * max(n.value, 1))()
+        _check(self.lib.mtg_index_build_profile(self.h, arr, n.value, C.byref(n), C.byref(peak), C.byref(total)))
+        return {"phases": [{"name": arr[i].name.decode(), "ms": arr[i].ms, "bytes": arr[i].bytes, "units": arr[i].units} for i in range(n.value)],
+                "peak_device_bytes": peak.value, "total_ms": total.value}
 
     def contains(self, kmers):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)

@@ -26,6 +26,14 @@ extern "C" {
 
 void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, int k, double load)
 {
+    if (!emu_legacy_build()) {
+        EmuIndex* e = new EmuIndex();
+        e->ix.k = k;
+        e->ix.bloom.bits = nullptr;
+        e->ix.bloom.nblocks = 0;
+        emu_build_lean(e->ix, e->us, kmers, counts, n);
+        return e;
+    }
     for (;;) {
         EmuIndex* e = new EmuIndex();
         e->ix.k = k;

@@ -36,6 +36,26 @@ static std::map<const mtg_index*, EmuUStore*> g_us; /* storage of the unitig sto
 int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k, mtg_index** out)
 {
     if (k < 11 || k > 31) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (!emu_legacy_build()) {
+        /* the lean build, as index_from_kmer_pieces_lean of mtg_gpu.hip */
+        mtg_index* idx = new mtg_index();
+        idx->dev.k = k;
+        bloom_shape(idx->dev.bloom, n, 12.0, k);
+        idx->dev.bloom.bits = (uint32_t*)calloc(idx->dev.bloom.nblocks * 16, 4);
+        EmuUStore* st = new EmuUStore();
+        const EmuLeanStats ls = emu_build_lean(idx->dev, *st, kmers, ab, n);
+        idx->info.k = k; idx->info.nb_solid_kmers = ls.nb_solid; idx->info.nb_branching = ls.nb_branching; idx->info.abundance_auto = -1;
+        idx->info.nb_saturated = ls.nb_saturated; idx->info.nb_unitigs = ls.nb_unitigs; idx->info.nb_kmers_outside_unitigs = ls.nb_left;
+        idx->info.bloom_blocks = idx->dev.bloom.nblocks; idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
+        idx->info.sparse = idx->dev.us.words ? 1 : 0;
+        mtg_build_phase ph{};
+        snprintf(ph.name, sizeof ph.name, "%s", ls.late ? "emulated_lean_late" : "emulated_lean");
+        ph.units = n;
+        idx->build_phases.push_back(ph);
+        { std::lock_guard<std::mutex> lk(g_us_mtx); g_us[idx] = st; }
+        *out = idx;
+        return MTG_OK;
+    }
     double load = 0.5;
     for (;;) {
         mtg_index* idx = new mtg_index();
@@ -97,8 +117,8 @@ int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** 
 void index_release(mtg_index* idx)
 {
     if (!idx) return;
-    const bool sparse = idx->dev.adj.sp_words != nullptr; /* the tables of the sparse form live in the EmuUStore */
-    { std::lock_guard<std::mutex> lk(g_us_mtx); auto it = g_us.find(idx); if (it != g_us.end()) { delete it->second; g_us.erase(it); } }
+    bool sparse = idx->dev.adj.sp_words != nullptr; /* the tables of the sparse form live in the EmuUStore */
+    { std::lock_guard<std::mutex> lk(g_us_mtx); auto it = g_us.find(idx); if (it != g_us.end()) { sparse = sparse || idx->dev.adj.slots == it->second->sp_adj.data(); delete it->second; g_us.erase(it); } }
     if (!sparse) { free(idx->dev.adj.slots); free(idx->dev.abnd.slots); }
     free(idx->dev.bloom.bits);
     for (Workspace& w : idx->ws) for (void* h : w.hptr) free(h);

@@ -6,6 +6,8 @@
 #define MTG_EMU_US_H
 #include "../../mindthegap_amd/csrc/mtg_hostutil.h"
 #include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <vector>
 
 struct EmuUStore {
@@ -99,5 +101,158 @@ inline bool emu_sparsify(mtg::Index& ix, EmuUStore& st)
         ix = nx;
         return true;
     }
+}
+
+/* ---- the lean build (mtg_dev.h: "the lean build"; the device's build_from_jt + sparsify in mtg_gpu.hip), run serially with the same
+ * device functions: junction table + an ABND table as the abundances' source -> scan -> plan -> emit -> abundances -> sparse tables. ---- */
+inline bool emu_legacy_build() { return getenv("MTG_DENSE_INDEX") || getenv("MTG_NO_UNITIGS") || getenv("MTG_LEGACY_BUILD"); }
+
+/* the tables of the sparse form from the store and the k-mers of no unitig (lk / la); `late`, when set, names those k-mers once the unitigs'
+ * pointers are in the new ADJ table (a closed or over-long chain in the graph).  The Bloom filter of ix (if any) is filled here. */
+inline void emu_sparse_from_store(mtg::Index& ix, EmuUStore& st, std::vector<uint64_t>& lk, std::vector<uint32_t>& la, uint64_t n_left_ub,
+                                  const std::function<void(const mtg::Index& nx, std::vector<uint64_t>&, std::vector<uint32_t>&)>* late)
+{
+    using namespace mtg;
+    const uint64_t n_shape = late ? std::max<uint64_t>(n_left_ub, lk.size()) : lk.size();
+    uint64_t nkeys = 2 * n_shape + 64;
+    for (const UsRec& r : st.recs) nkeys += r.len_k / 2 + 3;
+    const uint64_t bloom_words = ix.bloom.bits ? ix.bloom.nblocks * 16 : 0;
+    for (double load = 0.5;; load *= 0.7) {
+        Index nx = ix;
+        table_shape(nx.adj, buckets_for(nkeys, load, 2 * (ix.k - 1), MTG_ADJ_SLOTS), 2 * (ix.k - 1));
+        table_shape(nx.abnd, buckets_for(n_shape + 16, load, 2 * ix.k, MTG_ABND_SLOTS), 2 * ix.k);
+        st.sp_adj.assign(nx.adj.nbuckets * MTG_ADJ_SLOTS * 2, 0);
+        st.sp_abnd.assign(nx.abnd.nbuckets * MTG_ABND_SLOTS, 0);
+        nx.adj.slots = st.sp_adj.data();
+        nx.abnd.slots = st.sp_abnd.data();
+        nx.adj.sp_words = nullptr;
+        if (bloom_words) memset(ix.bloom.bits, 0, bloom_words * 4);
+        int fail = 0;
+        for (const UsRec& r : st.recs)
+            for (uint32_t i = 0; i < r.len_k; i++) fail |= sparse_link(nx, r, i, true);
+        if (fail) continue;
+        if (late) {
+            Index nxs = nx;
+            nxs.adj.sp_words = nx.us.words;
+            (*late)(nxs, lk, la);
+            if (lk.size() > n_shape) abort(); /* the bound on the k-mers of no unitig does not hold */
+        }
+        for (size_t i = 0; i < lk.size(); i++) fail |= index_insert(nx, lk[i], la[i]) & 1;
+        if (fail) continue;
+        for (size_t i = 0; i < lk.size(); i++) { Kmer x = make_kmer(lk[i], ix.k); build_lookahead(nx, x); Kmer y; y.f = x.r; y.r = x.f; build_lookahead(nx, y); }
+        for (const UsRec& r : st.recs) {
+            const Kmer first = make_kmer(r.start_f, ix.k);
+            Kmer fr;
+            fr.f = first.r; fr.r = first.f;
+            build_lookahead(nx, fr);
+            build_lookahead(nx, run_node(nx.us, (r.hdr + 1) * 32, false, r.len_k - 1, ix.k));
+        }
+        nx.adj.sp_words = nx.us.words;
+        ix = nx;
+        return;
+    }
+}
+
+struct EmuLeanStats {
+    uint64_t nb_solid = 0, nb_branching = 0, nb_unitigs = 0, nb_saturated = 0, nb_left = 0;
+    bool late = false;
+};
+/* ix: k set, bloom shaped and allocated (or none), no tables.  Leaves ix as the device's lean build leaves its index. */
+inline EmuLeanStats emu_build_lean(mtg::Index& ix, EmuUStore& st, const uint64_t* kmers, const uint32_t* counts, size_t n)
+{
+    using namespace mtg;
+    const int k = ix.k;
+    EmuLeanStats out;
+    std::vector<uint64_t> jt_slots, src_slots;
+    Table jt{}, abnd{};
+    for (double load = 0.5;; load *= 0.7) {
+        table_shape(jt, buckets_for(n + n / 8 + 16, load, 2 * (k - 1), MTG_ABND_SLOTS), 2 * (k - 1));
+        table_shape(abnd, buckets_for(n, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+        jt.sp_words = abnd.sp_words = nullptr;
+        jt_slots.assign(jt.nbuckets * MTG_ABND_SLOTS, 0);
+        src_slots.assign(abnd.nbuckets * MTG_ABND_SLOTS, 0);
+        jt.slots = jt_slots.data();
+        abnd.slots = src_slots.data();
+        int fail = 0;
+        out.nb_saturated = 0;
+        for (size_t i = 0; i < n; i++) {
+            fail |= table_or<MTG_ABND_SLOTS>(abnd, kmers[i], ab_stored(counts[i])) & 1;
+            fail |= jt_insert_kmer(jt, kmers[i], k);
+            out.nb_saturated += counts[i] > 255u;
+        }
+        if (!fail) break;
+    }
+    AbFromTable src;
+    src.abnd = abnd;
+    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
+    unsigned long long counters[JT_C_N] = {0};
+    uint32_t lines = 0;
+    JtAcc acc{};
+    for (uint64_t s = 0; s < nslots; s++) {
+        uint64_t J;
+        const uint32_t m = jt_slot_key(jt, s, J);
+        if (m) jt_scan_entry(jt, k, J, m, src, acc, counters, (uint64_t*)nullptr, 0ull, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull, lines);
+    }
+    out.nb_solid = (acc.c[JT_C_ORIENTED] + acc.c[JT_C_SELF]) / 2;
+    out.nb_branching = (2 * acc.c[JT_C_IN_NOT1] - acc.c[JT_C_BOTH_NOT1] + acc.c[JT_C_SELF_BRANCH]) / 2;
+    const uint64_t interior = acc.c[JT_C_INTERIOR];
+    std::vector<uint64_t> starts(counters[JT_C_STARTS] + 1), lk(counters[JT_C_LEFT]);
+    std::vector<uint32_t> la(counters[JT_C_LEFT]);
+    const uint64_t n_starts = counters[JT_C_STARTS], n_single = counters[JT_C_LEFT];
+    counters[JT_C_STARTS] = counters[JT_C_LEFT] = 0;
+    JtAcc acc2{};
+    for (uint64_t s = 0; s < nslots; s++) {
+        uint64_t J;
+        const uint32_t m = jt_slot_key(jt, s, J);
+        if (m) jt_scan_entry(jt, k, J, m, src, acc2, counters, starts.data(), n_starts, lk.data(), la.data(), n_single, lines);
+    }
+    if (counters[JT_C_STARTS] != n_starts || counters[JT_C_LEFT] != n_single) abort();
+    counters[JT_C_SAT] = 0; /* the source holds stored (clamped) abundances: those above 255 were counted at insertion */
+    std::vector<UsRec> recs(n_starts / 2 + 1);
+    for (uint64_t i = 0; i < n_starts; i++) jt_plan_start(jt, k, make_kmer(starts[i], k), counters, recs.data(), recs.size(), lines);
+    const uint64_t n_rec = counters[JT_C_RECS], cw = counters[JT_C_WORDS];
+    if (n_rec > recs.size()) abort();
+    recs.resize(n_rec);
+    ix.us = UStore{};
+    if (n_rec) {
+        st.words.assign(cw + 8, 0);
+        st.ab.assign((cw + 8) * 32, 0);
+        ix.us.words = st.words.data();
+        ix.us.ab = st.ab.data();
+        ix.us.nwords = cw;
+        ix.us.nunitigs = n_rec;
+        for (const UsRec& r : recs) jt_emit(jt, ix.us, k, r, lines);
+        for (const UsRec& r : recs)
+            for (uint32_t i = 0; i < r.len_k; i++) us_ab_fill(ix.us, k, r, i, src, lines);
+    }
+    st.recs = recs;
+    out.nb_unitigs = n_rec;
+    ix.adj = Table{};
+    ix.abnd = Table{};
+    if (interior == counters[JT_C_STORED_VIEWS]) emu_sparse_from_store(ix, st, lk, la, lk.size(), nullptr);
+    else {
+        out.late = true;
+        const std::function<void(const Index&, std::vector<uint64_t>&, std::vector<uint32_t>&)> late = [&](const Index& nx, std::vector<uint64_t>& k2, std::vector<uint32_t>& a2) {
+            counters[JT_C_LEFT] = 0;
+            for (uint64_t s = 0; s < nslots; s++) {
+                uint64_t J;
+                const uint32_t m = jt_slot_key(jt, s, J);
+                if (m) jt_unstored_entry(jt, nx, J, m, src, counters, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull, lines);
+            }
+            const uint64_t nl = counters[JT_C_LEFT];
+            k2.assign(nl, 0);
+            a2.assign(nl, 0);
+            counters[JT_C_LEFT] = 0;
+            for (uint64_t s = 0; s < nslots; s++) {
+                uint64_t J;
+                const uint32_t m = jt_slot_key(jt, s, J);
+                if (m) jt_unstored_entry(jt, nx, J, m, src, counters, k2.data(), a2.data(), nl, lines);
+            }
+        };
+        lk.clear(); la.clear();
+        emu_sparse_from_store(ix, st, lk, la, n_single + (interior - counters[JT_C_STORED_VIEWS]) / 2 + n_starts + 16, &late);
+    }
+    out.nb_left = lk.size();
+    return out;
 }
 #endif

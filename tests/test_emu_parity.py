@@ -1013,3 +1013,74 @@ def test_cli_reads_its_breakpoint_file_mapped_and_with_read(emu_product, tmp_pat
     _edge_case_run(emu_product, tmp_path / "a")
     monkeypatch.setenv("MTG_CLI_NO_MMAP", "1")
     _edge_case_run(emu_product, tmp_path / "b")
+
+
+def _lean_cases(rng, k):
+    """graphs that meet every branch of the lean build: random genomes with bubbles and tips, circular simple paths (closed chains: the late
+    pass), palindromic junctions, homopolymer loops, self-complementary k-mers (even k), single k-mers between two forks"""
+    cases = []
+    _, g, seqs = _make_case(rng.randrange(1 << 30), k)
+    cases.append(("random", seqs))
+    c = _rand_seq(rng, rng.randrange(3 * k, 400))
+    cases.append(("circle", [c + c[:k - 1]]))                       # every junction simple: one closed chain, no chain start
+    cases.append(("circle+genome", seqs + [c + c[:k - 1]]))
+    half = _rand_seq(rng, (k - 1) // 2 + ((k - 1) & 1))
+    pal = half[:(k - 1) // 2] + _rc(half[:(k - 1) // 2]) if (k - 1) % 2 == 0 else None
+    if pal:
+        cases.append(("palindromic junction", [_rand_seq(rng, 60) + pal + _rand_seq(rng, 60), _rand_seq(rng, 40) + pal + _rand_seq(rng, 40)]))
+    cases.append(("homopolymer", [_rand_seq(rng, 50) + "A" * (k + 7) + _rand_seq(rng, 50), "T" * (2 * k)]))
+    if k % 2 == 0:
+        h = _rand_seq(rng, k // 2)
+        cases.append(("self-complementary k-mer", [_rand_seq(rng, 70) + h + _rc(h) + _rand_seq(rng, 70)]))
+    a, b = _rand_seq(rng, 200), _rand_seq(rng, 200)
+    x = _rand_seq(rng, k)                                            # one k-mer with two ways in and two ways out
+    cases.append(("single k-mer between forks", [a[:100] + x + a[100:], b[:100] + x + b[100:]]))
+    cases.append(("short sequences", [_rand_seq(rng, k), _rand_seq(rng, k + 1), _rand_seq(rng, k - 1)]))
+    return cases
+
+
+@pytest.mark.parametrize("k", [31, 22, 16, 13])
+def test_lean_build_equals_the_legacy_build(emu_product, tmp_path, k):
+    """round 4: the index built from the junction table alone (no dense ADJ / ABND tables, chain starts and the k-mers of no unitig out of one
+    streaming pass, abundances asked of their source) is the index the construction of rounds 1-3 builds: same statistics, same stored
+    k-mers and abundances, same answers to every query -- on graphs with closed chains (the late pass), palindromic junctions,
+    self-complementary k-mers, homopolymer loops and isolated k-mers"""
+    rng = random.Random(400 + k)
+    seen_late = False
+    for rep in range(15):
+        for name, seqs in _lean_cases(rng, k):
+            o = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+            km, ct = o.export()
+            o.close()
+            if len(km) == 0:
+                continue
+            ct = ct.copy()
+            ct[::5] = 200 + (np.arange(len(ct[::5])) % 300).astype(ct.dtype)
+            lean = emu_product.Index.from_kmers(km, ct, k)
+            with _env("MTG_LEGACY_BUILD", "1"):
+                old = emu_product.Index.from_kmers(km, ct, k)
+            li, oi = lean.info(), old.info()
+            for f in ("nb_solid_kmers", "nb_branching", "nb_unitigs", "nb_saturated"):  # (the legacy emulation does not count the k-mers outside unitigs)
+                assert li[f] == oi[f], (name, k, f, li[f], oi[f], seqs)
+            assert li["nb_solid_kmers"] == len(km)
+            seen_late = seen_late or lean.build_profile()["phases"][0]["name"] == "emulated_lean_late"
+            lean.save(str(tmp_path / "l.idx"))
+            old.save(str(tmp_path / "o.idx"))
+            lk, la, lu = _container_v3_kmers(open(str(tmp_path / "l.idx"), "rb").read(), k)
+            ok, oa, ou = _container_v3_kmers(open(str(tmp_path / "o.idx"), "rb").read(), k)
+            assert lu == ou and (np.sort(lk) == np.sort(ok)).all() and (la[np.argsort(lk)] == oa[np.argsort(ok)]).all(), (name, k)
+            assert (la[np.argsort(lk)] == np.minimum(ct[np.argsort(km)], 255)).all()
+            nb = []
+            for x in km[:400]:
+                x = int(x)
+                for b in range(4):
+                    nb.append(((x << 2) | b) & ((1 << (2 * k)) - 1))
+                    nb.append((x >> 2) | (b << (2 * (k - 1))))
+            q = np.concatenate([km, np.array(nb + [rng.getrandbits(2 * k) for _ in range(300)], dtype=np.uint64)])
+            assert (lean.abundance(q) == old.abundance(q)).all(), (name, k)
+            ls, lp = lean.neighbors(q)
+            os_, op = old.neighbors(q)
+            assert (ls == os_).all() and (lp == op).all(), (name, k)
+            lean.close()
+            old.close()
+    assert seen_late  # a closed chain was met
