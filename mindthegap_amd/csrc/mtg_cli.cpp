@@ -516,7 +516,14 @@ static int run_batches(const Replicas& R, const std::function<bool(size_t)>& nex
             }
             {   /* the next batch is read by one worker at a time, in order, but not under the scheduler's lock: completions and the writer go on */
                 std::lock_guard<std::mutex> rl(read_m);
-                { std::lock_guard<std::mutex> lk(m); if (exhausted || err) return; b = handed; }
+                {
+                    /* the window is checked again by the one worker that holds the reader: several may have passed the wait above for the
+                     * same free place, and each would otherwise hand out a batch (the window would be exceeded by the number of workers) */
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return exhausted || err || handed - consumed < window; });
+                    if (exhausted || err) return;
+                    b = handed;
+                }
                 const bool more = next(b);
                 std::lock_guard<std::mutex> lk(m);
                 if (!more) { exhausted = true; cv.notify_all(); return; }

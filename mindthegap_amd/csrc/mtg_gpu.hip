@@ -703,9 +703,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
  * for a handful of parked gaps */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_finish_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ rwords,
                                                const uint32_t* __restrict__ roff, const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                               GapOut* out, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
+                                               GapOut* out, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list, uint32_t first)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = first + blockIdx.x * blockDim.x + threadIdx.x; /* entries below `first` belong to the groups of k_finish<G> */
     if (t >= park->count[in_list]) return;
     const Index& ix = c_ix[cset];
     const FillCfg& cfg = c_cfg[cset];
@@ -807,6 +807,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
     __shared__ uint32_t hist[256];
     __shared__ uint64_t tile[POST_TILE + 2];
     __shared__ uint64_t s_blk[64];
+    __shared__ __attribute__((aligned(8))) uint32_t s_rec[sizeof(SlotRec) / 4];
+    static_assert(sizeof(SlotRec) % 4 == 0 && sizeof(SlotRec) / 4 <= 64, "one lane per 4 bytes of a slot record");
     /* one workgroup per slot measured best (against persistent workgroups): the kernel lives on the number of waves in flight */
     for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
         __syncthreads(); /* the previous gap's readers of hist are done */
@@ -834,14 +836,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
             post_gap(ix, cfg, S, o, T, hist, tile, s_blk, po);
 #endif
         }
+        /* the record leaves in ONE coalesced store of the wave (38 lanes x 4 bytes): lane 0 storing its 38 fields one by one made the kernel
+         * write 1.1 KB of partial lines per gap (PMC WRITE_SIZE 111.6 MB per launch for 15 MB of records, round 3) */
         if (threadIdx.x == 0) {
             SlotRec r;
             r.o = o; r.p = po;
             emit_plan(o, po, want_all != 0, ix.k, r.nw, r.nc, r.asc, r.ext); /* po is uniform over the wave */
             r.wbase = r.cbase = r.abase = r.ebase = 0;
             r.rpos = r.gpos = 0;
-            recs[slot] = r;
+            r.fpos = r.pad_ = 0;
+            *reinterpret_cast<SlotRec*>(s_rec) = r;
         }
+        __syncthreads();
+        if (threadIdx.x < sizeof(SlotRec) / 4) reinterpret_cast<uint32_t*>(recs + slot)[threadIdx.x] = s_rec[threadIdx.x];
     }
 }
 
@@ -1412,7 +1419,7 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
     for (int attempt = 0; attempt < 6; attempt++) {
         Index nx = old;
         nx.adj.sp_words = nullptr; /* raw look-ups while the tables are being built */
-        const double load_adj = (getenv("MTG_SPARSE_ADJ_LOAD") ? atof(getenv("MTG_SPARSE_ADJ_LOAD")) : 0.7) * load;
+        const double load_adj = (getenv("MTG_SPARSE_ADJ_LOAD") ? atof(getenv("MTG_SPARSE_ADJ_LOAD")) : 0.49) * load; /* 0.7 overflows the displacement range at human scale (2-slot buckets) and cost a second attempt; 0.49 is what that attempt ran at */
         table_shape(nx.adj, buckets_for(nkeys, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
         table_shape(nx.abnd, buckets_for(n_left_shape + 1024, 0.6 * load, 2 * k, MTG_ABND_SLOTS), 2 * k);
         const size_t ba = nx.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = nx.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
@@ -2404,7 +2411,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
             static const bool classic_walk = getenv("MTG_CLASSIC_WALK") != nullptr; /* A/B hook: every bubble by its lane, from HBM scratch */
-            static const int finish_g = getenv("MTG_FINISH_G") ? atoi(getenv("MTG_FINISH_G")) : 16; /* lanes per parked gap: 8, 16 or 64 */
+            /* lanes per parked gap: 1, 8, 16 or 64 (anything else, a typo included, is 16) */
+            static const int finish_g = [] { const int v = getenv("MTG_FINISH_G") ? atoi(getenv("MTG_FINISH_G")) : 16; return (v == 1 || v == 8 || v == 16 || v == 64) ? v : 16; }();
             static const int env_rounds = getenv("MTG_ROUNDS") ? atoi(getenv("MTG_ROUNDS")) : -1;
             /* Rounds: when many gaps park (bubbles all over the data), their branching nodes are answered by the bubble kernels and the walks go
              * on in the walk kernel, one gap per lane again -- walking is cheap at full width, only the bubbles need a group -- for a few
@@ -2438,8 +2446,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                                    d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u, wmode ? 2u : 1u);
                 HIP_TRY(hipEventRecord(evf, stream));
                 static const bool skip_finish = getenv("MTG_DEBUG_SKIP_FINISH") != nullptr; /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
-                const uint32_t per_wg = 64u / (uint32_t)finish_g;
-                const uint32_t nwg = (m + per_wg - 1) / per_wg; /* one group per gap of the launch: those without an entry of the list leave at once */
                 /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with small bubbles that
                  * keeps more of them in flight than a group of lanes per bubble does (MTG_BUBBLE_GROUPS=1: k_bubble<G>, the LDS form, first) */
                 static const bool one_lane_bubbles = getenv("MTG_BUBBLE_GROUPS") == nullptr;
@@ -2470,13 +2476,22 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 static const int finish_wave_below = getenv("MTG_FINISH_WAVE_BELOW") ? atoi(getenv("MTG_FINISH_WAVE_BELOW")) : 2048;
                 const int fin_g = getenv("MTG_FINISH_G") ? finish_g : (rounds == 0 && park_hint < (uint32_t)finish_wave_below ? 64 : 16);
                 const bool lane_finish = finish_g == 1 || (!getenv("MTG_FINISH_G") && rounds == 0 && park_hint < (uint32_t)finish_lane_below);
-                if (!skip_finish && lane_finish)
-                    hipLaunchKernelGGL(k_finish_lane, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin);
-                else if (!skip_finish) switch (fin_g) {
-                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3((m + 7) / 8), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
-                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(m), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                /* The grid.  The host does not know how many gaps are parked when it queues the kernel, and 100 000 groups that read one
+                 * scalar and leave cost 63 us (round 3: 13 % of a haploid batch's kernels, for 5 parked gaps).  So the groups take the first
+                 * `fin_entries` entries of the list -- four times what the previous launch of this workspace parked, plus 256 -- and the
+                 * entries beyond, if a launch parks more than that after all, are walked one gap per lane (k_finish_lane, a grid of
+                 * (m - fin_entries) / 64 workgroups: slower per gap, but only for the launch that outgrew the hint; the next one follows). */
+                static const bool finish_full_grid = getenv("MTG_FINISH_FULL_GRID") != nullptr; /* A/B hook: one group per gap of the launch, as in round 3 */
+                const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (finish_full_grid ? m : (uint32_t)std::min<uint64_t>(m, 4ull * park_hint + 256ull));
+                const uint32_t per_wg = 64u / (uint32_t)fin_g;
+                const uint32_t nwg = (fin_entries + per_wg - 1) / per_wg;
+                if (!skip_finish && nwg) switch (fin_g) {
+                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                     default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                 }
+                if (!skip_finish && fin_entries < m)
+                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries);
                 HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, stream)); /* how many were parked: statistics, and the hint for the next launch */
 #ifdef MTG_BUBBLE_TIMING
                 {

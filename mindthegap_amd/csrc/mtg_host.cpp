@@ -1409,8 +1409,11 @@ int mtg_results_from_wire(const void* wire, uint64_t bytes, mtg_results** out, u
     const uint8_t* b = (const uint8_t*)wire;
     const mtg_wire_header* h = (const mtg_wire_header*)b;
     if (bytes < sizeof(mtg_wire_header) || h->magic != WIRE_MAGIC || h->total_bytes > bytes || (h->total_bytes & 7) || h->ext_bytes < 1) { mtgi::set_error("not a result payload"); return MTG_ERR_FORMAT; }
+    /* every section is bounded by the payload before anything is added up: sizes near 2^64 must not wrap the sum back onto total_bytes */
+    const uint64_t tb = h->total_bytes;
+    if (tb < sizeof(mtg_wire_header) || h->seq_bytes > tb || h->ext_bytes > tb || h->n_gaps > tb / sizeof(mtg_wire_gap) || h->n_filled > tb / sizeof(mtg_wire_filled)) { mtgi::set_error("result payload: inconsistent sizes"); return MTG_ERR_FORMAT; }
     const uint64_t want = sizeof(mtg_wire_header) + up8(h->n_gaps * sizeof(mtg_wire_gap)) + up8(h->n_filled * sizeof(mtg_wire_filled)) + up8(h->seq_bytes) + up8(h->ext_bytes);
-    if (h->n_gaps > (1ull << 40) || h->n_filled > (1ull << 40) || want != h->total_bytes) { mtgi::set_error("result payload: inconsistent sizes"); return MTG_ERR_FORMAT; }
+    if (want != tb) { mtgi::set_error("result payload: inconsistent sizes"); return MTG_ERR_FORMAT; }
     if (wire_checksum(b + sizeof(mtg_wire_header), h->total_bytes - sizeof(mtg_wire_header), 0) != h->checksum) { mtgi::set_error("result payload: checksum mismatch"); return MTG_ERR_FORMAT; }
     const mtg_wire_gap* wg = (const mtg_wire_gap*)(b + sizeof(mtg_wire_header));
     const mtg_wire_filled* wf = (const mtg_wire_filled*)((const uint8_t*)wg + up8(h->n_gaps * sizeof(mtg_wire_gap)));
@@ -1428,7 +1431,7 @@ int mtg_results_from_wire(const void* wire, uint64_t bytes, mtg_results** out, u
     bool ok = true;
     for (uint64_t f = 0; f < h->n_filled; f++) {
         const mtg_wire_filled& w = wf[f];
-        if (w.seq_off + w.seq_len + 1 > h->seq_bytes || ws[w.seq_off + w.seq_len] != 0) { ok = false; break; }
+        if (w.seq_off >= h->seq_bytes || w.seq_len >= h->seq_bytes - w.seq_off || ws[w.seq_off + w.seq_len] != 0) { ok = false; break; } /* no sum that could wrap */
         mtg_filled& s = R->fil[f];
         s.seq = ws + w.seq_off;
         s.nb_errors_in_anchor = w.nb_errors_in_anchor; s.target_index = w.target_index; s.avg_coverage = w.avg_coverage; s.median_coverage = w.median_coverage;

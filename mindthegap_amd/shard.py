@@ -264,34 +264,48 @@ class OrderedArrivals:
             return p
 
 
+_RC = dict(zip("ACGTacgt", "TGCAtgca"))
+
+
+def revcomp_dropping(s):
+    """revcomp_sequence (src/Utils.cpp:44-77): complements A, C, G, T in either case and DROPS every other character"""
+    return "".join(_RC[c] for c in reversed(s) if c in _RC)
+
+
 def fill_bkpt_sharded(idx, sites, out_prefix, params=None, batch_sites=100000, device=None, extend=False, filter=False, fwd_only=False, in_flight=2, sample="index"):
-    """`MindTheGap fill -bkpt` over the ranks of a torch.distributed job (one process per GPU, the index replicated): the sites -- the same
-    list of (name, name_r, source, target) on every rank -- are cut into batches of batch_sites, batch b goes to rank shard of its
-    position (contiguous shards), every rank fills its batches (forward attempt, reverse attempt for the unfilled sites) and sends the
-    results -- records AND sequences, relocatable form, tagged with the batch index -- to rank 0, which puts them back in input order and
-    writes <out_prefix>.insertions.fasta / .info.txt / .insertions.vcf exactly as the single-process tool does (src/Filler.cpp:682-683).
-    With a GPU backend the forward payload is produced by the result kernel straight in the gather's device buffer.
+    """`MindTheGap fill -bkpt` over the ranks of a torch.distributed job (one process per GPU, the index replicated, all ranks on one node
+    and one file system): the sites -- the same list of (name, name_r, source, target) on every rank -- are cut into batches of batch_sites,
+    batch b goes to rank b mod world (cyclic), every rank fills its batches (forward attempt, reverse attempt for the unfilled
+    sites) and formats them with the tool's own writers (mtg_format_bkpt).  No result byte travels between the ranks: after every round
+    (one batch per rank) an all_gather of the four pieces' SIZES gives every rank the file offsets of that round's batches in input order,
+    and each rank writes its own pieces with pwrite -- the files are those of the single-process tool, byte for byte
+    (src/Filler.cpp:682-683 writes under a lock in completion order; input order is its -nb-cores 1 order).  The fill of a rank's next
+    batch runs while a helper thread formats and writes the previous one (in_flight batches are held at most).
     Returns the number of sites (rank 0) / None."""
+    import os
+    import queue
     import torch
     import torch.distributed as dist
     from . import lib as L
     rank, world = dist.get_rank(), dist.get_world_size()
     params = params or L.FillParams()
     nb = (len(sites) + batch_sites - 1) // batch_sites
-    blo, bhi = shard_range(nb, rank, world)
-    mine = list(range(blo, bhi))
-    per_rank = max(shard_range(nb, r, world)[1] - shard_range(nb, r, world)[0] for r in range(world))
-    cap_local = 0
-    for b in mine:  # generous: the sequences can be as long as the traversal's limits allow; agreed on below
-        cap_local = max(cap_local, 4096 + (min(len(sites), (b + 1) * batch_sites) - b * batch_sites) * 2 * (200 + 2 * 10000))
-    cap = torch.tensor([cap_local], dtype=torch.int64, device=device if device is not None else torch.device("cpu"))
-    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-    cap = min(int(cap.item()), 1 << 30)
-    arrivals = OrderedArrivals(nb) if rank == 0 else None
-    pg = PipelinedGather(cap, dst=0, device=device, depth=in_flight + 1, on_arrival=arrivals.arrive if rank == 0 else None)
-    rc_tab = str.maketrans("ACGTacgt", "TGCAtgca")
+    rounds = (nb + world - 1) // world
+    cdev = device if device is not None else torch.device("cpu")
+    names = [".insertions.fasta", ".info.txt", ".insertions.vcf"] + ([".extensions.fasta"] if extend else [])
+    keys = ["fasta", "info", "vcf"] + (["ext"] if extend else [])
+    header = L.vcf_header(sample, out_prefix)
+    if rank == 0:  # the files exist (and hold the VCF header) before anyone writes a piece
+        for nm in names:
+            with open(out_prefix + nm, "wb") as f:
+                if nm == ".insertions.vcf":
+                    f.write(header)
+    dist.barrier()
+    fds = [os.open(out_prefix + nm, os.O_WRONLY) for nm in names]
+    base = [len(header) if nm == ".insertions.vcf" else 0 for nm in names]  # file offset of the next round, per file
 
     def one(b):
+        """fills and formats batch b; returns the text pieces in the order of `names`"""
         s0, s1 = b * batch_sites, min(len(sites), (b + 1) * batch_sites)
         gaps = [L.Gap(st[2], st[3], [(st[3], st[1], False)], is_anchor_repeated=bool(st[4]) if len(st) > 4 else False) for st in sites[s0:s1]]
         h, nf, _ = idx.fill_prepared(L.Index.prepare_gaps(gaps), params, want_seqs=False)
@@ -303,58 +317,65 @@ def fill_bkpt_sharded(idx, sites, out_prefix, params=None, batch_sites=100000, d
             for q, j in enumerate(unf):
                 st = sites[s0 + j]
                 name, src, tgt = st[0], st[2], st[3]
-                rs, rt = tgt[::-1].translate(rc_tab), src[::-1].translate(rc_tab)
+                rs, rt = revcomp_dropping(tgt), revcomp_dropping(src)
                 rg.append(L.Gap(rs, rt, [(rt, name, False)], is_anchor_repeated=bool(st[4]) if len(st) > 4 else False, reverse=True))
                 rev_index[j] = q
             h2, _, _ = idx.fill_prepared(L.Index.prepare_gaps(rg), params, want_seqs=False)
-        # payload: [n | rev wire bytes | fwd wire | rev wire | rev_index]: two relocatable result sets and the map between them
-        j, buf = pg.acquire()
-        fw = L.results_to_wire(h, b, buf[32:])
-        off = 32 + fw.size
-        rv_n = 0
-        if h2 is not None:
-            rv = L.results_to_wire(h2, b, buf[off:])
-            rv_n = rv.size
-        off2 = off + rv_n
-        buf[off2: off2 + rev_index.nbytes] = rev_index.view(np.uint8)
-        hd = buf[:32].view(np.int64)
-        hd[0], hd[1], hd[2], hd[3] = s1 - s0, fw.size, rv_n, b
+        text = L.format_bkpt([st[:4] for st in sites[s0:s1]], h, h2, rev_index, filter=filter, extend=extend)
         idx.free_results(h)
         if h2 is not None:
             idx.free_results(h2)
-        pg.submit(off2 + rev_index.nbytes, j, tag=b)
+        return [text[k] for k in keys]
 
-    for i in range(per_rank):
-        if i < len(mine):
-            one(mine[i])
-        else:  # keep the collectives in step with the ranks that have one batch more
-            j, _ = pg.acquire()
-            pg.submit(0, j, tag=-1)
-    pg.drain()
-    if rank != 0:
-        return None
-    # rank 0: the batches in input order, through the tool's own writers
-    n_written = 0
-    with open(out_prefix + ".insertions.fasta", "wb") as ffa, open(out_prefix + ".info.txt", "wb") as finfo, open(out_prefix + ".insertions.vcf", "wb") as fvcf:
-        fext = open(out_prefix + ".extensions.fasta", "wb") if extend else None
-        fvcf.write(L.vcf_header(sample, out_prefix))
-        for b in range(nb):
-            p = arrivals.have.pop(b)
-            hd = p[:32].view(np.int64)
-            n, fw_n, rv_n = int(hd[0]), int(hd[1]), int(hd[2])
-            assert int(hd[3]) == b
-            fw = L.WireResults(p[32: 32 + fw_n])
-            rv = L.WireResults(p[32 + fw_n: 32 + fw_n + rv_n]) if rv_n else None
-            rev_index = p[32 + fw_n + rv_n: 32 + fw_n + rv_n + 8 * n].view(np.int64)
-            s0 = b * batch_sites
-            text = L.format_bkpt([st[:4] for st in sites[s0: s0 + n]], fw, rv, rev_index, filter=filter, extend=extend)
-            ffa.write(text["fasta"]); finfo.write(text["info"]); fvcf.write(text["vcf"])
-            if fext:
-                fext.write(text["ext"])
-            fw.close()
-            if rv:
-                rv.close()
-            n_written += n
-        if fext:
-            fext.close()
-    return n_written
+    # the writer of this rank: takes (round, pieces) in round order, agrees on the offsets with the other ranks' writers, writes
+    todo = queue.Queue(maxsize=max(1, in_flight))
+    err = []
+
+    def writer():
+        try:
+            for i in range(rounds):
+                item = todo.get()
+                if item is None:
+                    return
+                pieces = item if item else None
+                mine = torch.tensor([len(p) for p in pieces] if pieces is not None else [0] * len(names), dtype=torch.int64, device=cdev)
+                allsz = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allsz, mine)  # one small collective per round, issued by every rank's writer in the same order
+                allsz = torch.stack(allsz).cpu().numpy()  # [rank, file]
+                for f in range(len(names)):
+                    off = base[f] + int(allsz[:rank, f].sum())
+                    if pieces is not None and len(pieces[f]):
+                        mv, done = memoryview(pieces[f]), 0
+                        while done < len(mv):
+                            done += os.pwrite(fds[f], mv[done:], off + done)
+                    base[f] += int(allsz[:, f].sum())
+        except BaseException as e:  # surfaced below
+            err.append(e)
+
+    wt = threading.Thread(target=writer)
+    wt.start()
+    try:
+        for i in range(rounds):
+            b = i * world + rank
+            todo.put(one(b) if b < nb else _EMPTY_ROUND)  # a rank without a batch in the last round still takes part in the exchange of sizes
+            if err:
+                break
+    except BaseException:
+        todo.put(None)  # the writer leaves (the job is lost: the other ranks' writers wait for this rank's sizes until their timeout)
+        wt.join()
+        raise
+    if err:
+        try:
+            todo.put_nowait(None)
+        except queue.Full:
+            pass
+    wt.join()
+    for fd in fds:
+        os.close(fd)
+    if err:
+        raise err[0]
+    dist.barrier()
+    return len(sites) if rank == 0 else None
+
+
+_EMPTY_ROUND = ()

@@ -82,6 +82,8 @@ def main(out_path):
         l, r, _ = S.site(i)
         if i % 5 == 2:
             r = l[::-1].translate(str.maketrans("ACGT", "TGCA"))  # an anchor pair with nothing in between: reverse attempt, no fill
+        if i % 7 == 3:
+            l = l[:10] + "N" + l[11:]  # a character revcomp_sequence drops (src/Utils.cpp:44-77): the reverse attempt's target is one shorter
         sites.append((S.site_name(i), S.site_name(i), l, r))
     fill_bkpt_sharded(idx, sites, out_path + ".sharded", batch_sites=3, extend=True)
     dist.barrier()

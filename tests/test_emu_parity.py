@@ -1084,3 +1084,24 @@ def test_lean_build_equals_the_legacy_build(emu_product, tmp_path, k):
             lean.close()
             old.close()
     assert seen_late  # a closed chain was met
+
+
+def test_wire_payload_with_wrapping_sizes_is_refused(emu_product):
+    """mtg_results_from_wire bounds every section by the payload before it adds sizes up: a header whose seq_bytes is close to 2^64 makes
+    the sum of the sections wrap back onto total_bytes (and carries a valid checksum -- it is not cryptographic); such a payload is
+    MTG_ERR_FORMAT, not a read far outside the buffer"""
+    from mindthegap_amd import lib as L
+    M = (1 << 64) - 1
+    body = np.zeros(5, dtype=np.uint64)  # one mtg_wire_filled (40 bytes): seq_off = 2^40, seq_len = 0
+    body[0] = 1 << 40
+    c1, c2 = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9
+    cs = 0
+    for i, w in enumerate(body.tolist()):
+        cs = (cs + ((w ^ ((i * c1) & M)) * c2)) & M
+    hdr = np.array([L.WIRE_MAGIC if hasattr(L, "WIRE_MAGIC") else 0x3145524957474D54, 7, 0, 1, (1 << 64) - 8, 8, 104, cs], dtype=np.uint64)
+    payload = np.concatenate([hdr, body]).view(np.uint8)
+    assert payload.size == 104
+    with pytest.raises(Exception) as e:
+        L.WireResults(payload)
+    assert "FORMAT" in str(e.value) or "payload" in str(e.value)
+    # and a well-formed payload still loads (test_results_over_the_wire covers the contents)
