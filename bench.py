@@ -176,6 +176,7 @@ def main():
     torch.cuda.synchronize()
     t_index = time.time() - t0
     info = idx.info()
+    bprof = idx.build_profile()
     del w, wo, ln, pw
     torch.cuda.empty_cache()
 
@@ -183,7 +184,7 @@ def main():
     params = mtg.FillParams(max_nodes=100, max_depth=10000, nb_host_threads=host_threads)
     STAT_KEYS = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
                      post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0,
-                     finish_kernel_ms=0.0, n_parked_gaps=0, n_lean_gaps=0, gaps=0)
+                     finish_kernel_ms=0.0, n_parked_gaps=0, n_lean_gaps=0, lean_kernel_ms=0.0, copy_words_executed=0, copy_cmds_executed=0, post_scanned_words=0, gaps=0)
 
     class B:
         pass
@@ -408,7 +409,21 @@ def main():
                 identical = identical and hashlib.sha256(seqs.tobytes().replace(b"\n", b"\0")).hexdigest() == b.digest
         if het or tips:
             identical = None  # alleles / error bubbles: the truth is a mix, checked against the oracle (cpu_baseline, tests)
-        st_alone = mtg.last_batch_stats() if batches else None  # one batch alone on the device
+        # the kernels' own times: every distinct batch once more (twice when there are few), ONE batch on the device at a time; the averages are what
+        # every roofline fraction below is computed from (under six batches in flight a kernel's events also span other batches' workgroups)
+        st_alone = None
+        if batches and not (pg_saved is not None):
+            runs = []
+            for b in (batches * 2 if len(batches) < 4 else batches):
+                if not isinstance(b.prepared, mtg.Batch):
+                    break
+                torch.cuda.synchronize()
+                h_a, _nf_a, _ = idx.fill_prepared(b.prepared, params, want_seqs=False)
+                runs.append(mtg.last_batch_stats())
+                idx.free_results(h_a)
+            if runs:
+                st_alone = {key: sum(r[key] for r in runs) for key in runs[0]}
+                st_alone["runs"] = len(runs)
         n_sites_rank = sum(b.n for b in batches)
         if dist_on:
             v = torch.tensor([n_filled_rank, n_sites_rank, 1 if identical in (True, None) else 0], device=cdev, dtype=torch.int64)
@@ -548,6 +563,39 @@ def main():
                                      "what": "MindTheGap fill -bkpt <sites> -out <prefix> on the resident index: breakpoint file mapped, batches of 100000 sites handed out as a stream, 3 host threads per device "
                                              "copy and parse their batch, pass its text to mtg_fill_text (marshalled on the device), format FASTA / info / VCF in pieces on the worker pool; the pieces are "
                                              "placed in input order and written with pwrite by writer threads; wall time of the whole call"}
+                # ---- end to end, BASELINE config 4 LITERALLY (100 000 sites): what a user of the tool waits for.  (a) index construction from the donor
+                # in HBM (index_build above) + `MindTheGap fill -bkpt` on it, files written; (b) `MindTheGap fill -graph <container> -bkpt`: container read,
+                # index derived on the device, fill, files written -- one call of the tool's entry point, wall time.
+                if a.workload == "human" and not os.environ.get("MTG_BENCH_NO_E2E"):
+                    try:
+                        ids1 = site_ids[:batch_sites]
+                        bk1 = os.path.join(d, "cfg4.breakpoints")
+                        S.write_breakpoints(bk1, ids1)
+                        t0 = time.perf_counter()
+                        rc_a = idx.fill_main(["-bkpt", bk1, "-out", os.path.join(d, "e2e_a")])
+                        t_tool1 = time.perf_counter() - t0
+                        cont = os.path.join(d, "cfg4.mtgidx")
+                        t0 = time.perf_counter()
+                        idx.save(cont)
+                        t_save = time.perf_counter() - t0
+                        t0 = time.perf_counter()
+                        rc_b = mtg.fill_main(["-graph", cont, "-bkpt", bk1, "-out", os.path.join(d, "e2e_b")])
+                        t_graph = time.perf_counter() - t0
+                        want1 = hashlib.sha256(("\0".join(batches[0].expected[:len(ids1)]) + "\0").encode()).hexdigest()
+
+                        def fasta_ok(prefix):
+                            fa1 = open(prefix + ".insertions.fasta", "rb").read()
+                            return hashlib.sha256(b"\0".join(l for l in fa1.split(b"\n") if l and not l.startswith(b">")) + b"\0").hexdigest() == want1
+                        out_b = sum(os.path.getsize(os.path.join(d, "e2e_b" + e)) for e in (".insertions.fasta", ".info.txt", ".insertions.vcf"))
+                        secondary["end_to_end"] = {"config": "BASELINE configs[3] literally: %d sites, 3 Gbp donor, k=31, max-nodes 100; input = breakpoint file, output = FASTA + info + VCF files (%s)" % (len(ids1), "memory-backed /dev/shm" if base else "temporary directory"),
+                                                   "from_donor_in_hbm": {"seconds": t_index + t_tool1, "index_build_s": t_index, "tool_fill_and_files_s": t_tool1, "exit_code": rc_a, "sequences_identical_to_truth": fasta_ok(os.path.join(d, "e2e_a")),
+                                                                         "what": "mtg_index_create_from_packed_device (index_build) + MindTheGap fill -bkpt on the resident index"},
+                                                   "from_container": {"seconds": t_graph, "exit_code": rc_b, "container_bytes": os.path.getsize(cont), "container_write_s_untimed": t_save, "output_bytes": out_b,
+                                                                      "sequences_identical_to_truth": fasta_ok(os.path.join(d, "e2e_b")),
+                                                                      "what": "MindTheGap fill -graph <container v3> -bkpt <sites> -out <prefix>: ONE call -- container read, unitig store uploaded, tables derived on the device, 100 000 fills, three files written"},
+                                                   "sites_per_s_from_container": len(ids1) / t_graph}
+                    except Exception as e:
+                        secondary["end_to_end"] = {"error": repr(e)[:300]}
         except Exception as e:  # the headline line does not depend on it
             secondary["tool"] = {"error": repr(e)[:300]}
 
@@ -568,7 +616,9 @@ def main():
             seqs_ascii = [S.ascii(j) for j in range(nidx)]
             if tips:  # the erroneous fragments copied from the sampled donor sequences: the tips and error bubbles their walks meet
                 seqs_ascii += [S.extra_ascii(int(j)) for j in np.nonzero(S.extra_rows < nidx)[0]]
+        t0 = time.perf_counter()
         oidx = oracle_lib.Index.from_sequences(seqs_ascii, k, 3, 0)
+        t_oidx = time.perf_counter() - t0
         with tempfile.TemporaryDirectory() as d:
             bk = os.path.join(d, "s.breakpoints")
             S.write_breakpoints(bk, range(ns))
@@ -586,7 +636,7 @@ def main():
         cpu = {"value": ns / ost["seconds"], "unit": "breakpoints/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
                "sample": "%d of the %d sites of batch 0, index over the first %d donor sequences (%d k-mers), CPU restatement of the reference Filler (gatb-core unavailable)"
                          % (ns, b0.n, nidx, len(oidx)),
-               "seconds": ost["seconds"], "identical_to_hip": cpu_seqs == hip_seqs and len(hip_seqs) > 0,
+               "seconds": ost["seconds"], "index_seconds": t_oidx, "index_kmers": len(oidx), "identical_to_hip": cpu_seqs == hip_seqs and len(hip_seqs) > 0,
                "reference_binary": reference_binary() or "no MindTheGap install on this machine (BASELINE.md section 2): the port is timed"}
         oidx.close()
         # the product's own algorithm on the host cores (tests/emu build without its cross-checks, one process per core): what a CPU does with the
@@ -615,31 +665,58 @@ def main():
             except Exception as e:
                 cpu["same_algorithm"] = {"error": repr(e)[:300]}
 
+    if cpu and isinstance(secondary.get("end_to_end"), dict) and "from_container" in secondary["end_to_end"]:
+        e2e = secondary["end_to_end"]
+        nsites = batch_sites
+        # the CPU port over the same span (index + fill), measured on its bounded sample; the whole of config 4 was NOT run on the CPU: the scaled figure is an
+        # extrapolation (fill time by sites, index time by k-mers) and says so
+        est = cpu["seconds"] * nsites / max(ns, 1) + cpu["index_seconds"] * float(info["nb_solid_kmers"]) / max(cpu["index_kmers"], 1)
+        e2e["cpu_port_same_span"] = {"measured": {"sites": ns, "index_kmers": cpu["index_kmers"], "index_s": cpu["index_seconds"], "fill_s": cpu["seconds"], "cores": cpu["cores"]},
+                                     "scaled_to_config4_estimate_s": est, "scaling": "fill_s x 100000 / sites + index_s x 3.0e9 / index_kmers (k-mer counting of the oracle is a hash-map insert per k-mer; no file I/O on either side of the index step)",
+                                     "ratio_estimate_from_container": est / max(e2e["from_container"]["seconds"], 1e-9), "ratio_estimate_from_donor_in_hbm": est / max(e2e["from_donor_in_hbm"]["seconds"], 1e-9)}
+
     # ---------------------------------------------------------------- roofline.  What binds the job is the link to the host: every step copies its results
-    # (records + ASCII sequences) into page-locked host memory.  Under it, per kernel of a step, the bytes the implemented layout has to move against HBM.
+    # (records + ASCII sequences) into page-locked host memory.  Under it, per kernel of a step, the bytes the implemented layout has to move against HBM:
+    # counted by the kernels themselves for the launches of the timed region (a LEAN gap -- target located in the unitig store -- has no copy
+    # command executed and no contig scanned: copy_words_executed / post_scanned_words), divided by the kernel's OWN time (one batch on the device).
     Ln = max(acc["n_launches"], 1)
     gaps_l = acc["gaps"] / Ln
     bucket = int(info["adj_bucket_bytes"])
+    nl1 = max(st_alone["n_launches"], 1) if st_alone else 0
 
-    def kern(name, ms, bytes_per_launch, parts):
-        avg_s = ms / Ln * 1e-3
-        ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        return {"kernel": name, "bound": "hbm", "avg_kernel_ms": ms / Ln, "bytes_per_launch": bytes_per_launch, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "bytes_breakdown": parts}
+    def alone_ms(*keys_plus_minus):
+        """average time of a kernel (group) with one batch on the device: sum of the +keys minus the -keys"""
+        if not st_alone:
+            return None
+        return sum((-1.0 if kk.startswith("-") else 1.0) * st_alone[kk.lstrip("-")] for kk in keys_plus_minus) / nl1
+
+    def kern(name, ms_in_flight, ms_alone, bytes_per_launch, parts):
+        own = ms_alone if ms_alone else ms_in_flight  # N > 1 / host-string runs have no pass with one batch alone
+        ach = bytes_per_launch / (own * 1e-3) / 1e9 if own and own > 0 else 0.0
+        return {"kernel": name, "bound": "hbm", "avg_kernel_ms": own, "avg_kernel_ms_with_%d_batches_in_flight" % a.in_flight: ms_in_flight, "bytes_per_launch": bytes_per_launch,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "bytes_breakdown": parts}
 
     lane_nt = max(acc["run_nt"] - 32 * acc["copy_words"], 0)
+    n_lean_l = acc["n_lean_gaps"] / Ln
     sa_parts = {"adj_bucket_reads_x_%dB" % bucket: acc["index_lines"] / Ln * bucket, "unitig_store_word_reads_x_8B": acc["store_runs"] / Ln * 8, "unitig_sequence_2bit_taken_by_lanes": lane_nt / Ln / 4,
                 "contig_words_written_by_lanes_x_8B": (acc["contig_words"] - acc["copy_words"]) / Ln * 8, "copy_commands_x_24B": acc["copy_cmds"] / Ln * 24,
                 "per_gap_input_and_record": gaps_l * (8 + 8 + 4 + 4 + 16 + 36), "parked_gap_state_x_2x176B": acc["n_parked_gaps"] / Ln * 352}
-    cp_parts = {"unitig_words_read_x_8B": (acc["copy_words"] + acc["copy_cmds"]) / Ln * 8, "contig_words_written_x_8B": acc["copy_words"] / Ln * 8, "copy_commands_x_24B": acc["copy_cmds"] / Ln * 24,
-                "per_gap_record": gaps_l * 36}
-    po_parts = {"contig_words_scanned_x_8B": acc["contig_words"] / Ln * 8, "bucket_reads_x_32B": acc["post_lines"] / Ln * 32,
+    # k_lean, one gap per lane: the gap's record, its target (k-mer, mask, offsets), the ADJ bucket of the target's junction, contig length / start, its commands, the 16-byte LeanRec it leaves
+    ln_parts = {"per_gap_record_target_and_leanrec": gaps_l * (36 + 25 + 8 + 16), "adj_bucket_of_the_target_x_%dB" % bucket: gaps_l * bucket, "copy_commands_read_x_24B": acc["copy_cmds"] / Ln * 24}
+    # k_copy, one wave per LISTED gap (the gaps that are not lean): only their commands are executed
+    listed = max(gaps_l - n_lean_l, 0.0)
+    cp_parts = {"unitig_words_read_x_8B": (acc["copy_words_executed"] + acc["copy_cmds_executed"]) / Ln * 8, "contig_words_written_x_8B": acc["copy_words_executed"] / Ln * 8,
+                "copy_commands_x_24B": acc["copy_cmds_executed"] / Ln * 24, "per_listed_gap_record": listed * (36 + 4), "list_count_read_by_every_wave_of_the_grid": gaps_l / 4 * 4}
+    po_parts = {"contig_words_scanned_x_8B": acc["post_scanned_words"] / Ln * 8, "bucket_reads_x_32B": acc["post_lines"] / Ln * 32,
                 "coverage_abundance_bytes": acc["coverage_kmers"] / Ln, "coverage_kmer_check_of_looked_up_blocks": (acc["coverage_kmers"] - acc["coverage_direct_kmers"]) / Ln * 0.25 * (1 + k / 64.0),
-                "per_gap_record_and_targets": gaps_l * (36 + 152 + 16 + 2 * 128 + 24)}
-    em_parts = {"ascii_written": acc["seq_bytes"] / Ln, "contig_2bit_read": acc["seq_bytes"] / Ln / 4, "per_gap_records": gaps_l * (152 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / Ln * 16}
-    kerns = [kern("k_stage_a(+k_finish)", acc["kernel_ms"], sum(sa_parts.values()), sa_parts), kern("k_copy", acc["copy_kernel_ms"], sum(cp_parts.values()), cp_parts),
-             kern("k_post(+k_scan1,k_scan2)", acc["post_kernel_ms"], sum(po_parts.values()), po_parts), kern("k_emit", acc["emit_kernel_ms"], sum(em_parts.values()), em_parts)]
-    dom = max(kerns, key=lambda x: x["avg_kernel_ms"])
+                "per_gap_gapout_target_leanrec_command_read": gaps_l * (36 + 26 + 16 + 24), "per_gap_slot_record_written_160B_and_rewritten_by_the_scan_48B": gaps_l * (160 + 160 + 48)}
+    em_parts = {"ascii_written": acc["seq_bytes"] / Ln, "sequence_2bit_read": acc["seq_bytes"] / Ln / 4, "per_gap_records": gaps_l * (160 + 160 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / Ln * 16}
+    kerns = [kern("k_stage_a(+k_finish)", acc["kernel_ms"] / Ln, alone_ms("kernel_ms"), sum(sa_parts.values()), sa_parts),
+             kern("k_lean", acc["lean_kernel_ms"] / Ln, alone_ms("lean_kernel_ms"), sum(ln_parts.values()), ln_parts),
+             kern("k_copy", (acc["copy_kernel_ms"] - acc["lean_kernel_ms"]) / Ln, alone_ms("copy_kernel_ms", "-lean_kernel_ms"), sum(cp_parts.values()), cp_parts),
+             kern("k_post(+k_scan1,k_scan2)", acc["post_kernel_ms"] / Ln, alone_ms("post_kernel_ms"), sum(po_parts.values()), po_parts),
+             kern("k_emit", acc["emit_kernel_ms"] / Ln, alone_ms("emit_kernel_ms"), sum(em_parts.values()), em_parts)]
+    dom = max(kerns, key=lambda x: x["avg_kernel_ms"] or 0.0)
     result_bytes = acc["seq_bytes"] / Ln + gaps_l * (56 + 40)
     ms_per_batch_of_rank = elapsed / a.steps * 1e3 / max(1, (len(batches) if not cfg0["rotate"] else 1))  # this rank finishes a batch every so many ms
     pcie_ach = result_bytes / (ms_per_batch_of_rank * 1e-3) / 1e9 if ms_per_batch_of_rank > 0 else 0.0
@@ -647,9 +724,11 @@ def main():
             "achieved": pcie_ach, "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": pcie_ach / PCIE_PEAK_GBS, "bytes_per_launch": result_bytes,
             "measured_link_ceiling_GBps": "scripts/pcie_d2h.py: 57 with two or three copies in flight",
             "traffic": None, "traffic_source": None,
-            "dominant_kernel": dom["kernel"], "kernels": kerns, "launches": int(acc["n_launches"])}
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
-    if a.workload == "human" and batch_sites == 100000 and os.path.exists(pmc):
+            "dominant_kernel": dom["kernel"], "dominant_kernel_frac_of_hbm_peak": dom["frac"], "kernels": kerns, "launches": int(acc["n_launches"]),
+            "kernel_times": "avg_kernel_ms = HIP events on the batch's stream with ONE batch on the device (%s launches after the timed blocks); the same command under rocprofv3 --kernel-trace --stats with --in-flight 1 is profiles/r04_kernel_stats_one_batch_in_flight.csv"
+                            % (st_alone["runs"] if st_alone else 0)}
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json")) if os.path.exists(q)), None)
+    if a.workload == "human" and batch_sites == 100000 and pmc:
         pj = json.load(open(pmc))
         fill_kernels = ("k_stage_a", "k_finish", "k_bubble", "k_lean", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
         by_kernel = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pj.get("kernels", {}).items() if kn.split("::")[-1].startswith(fill_kernels)}
@@ -657,15 +736,27 @@ def main():
         dk = dom["kernel"].split("(")[0]
         roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_scan1", "k_scan2")) or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble"))))) or None
         roof["traffic_by_kernel"] = by_kernel
-        roof["traffic_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, HEAD %s): HBM bytes per launch" % pj.get("head", "?")
+        roof["traffic_is"] = "REPLAYED, not measured in this run: counters cannot be read from inside the process"
+        roof["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, no trace domain, the bench command of scripts/profile_round4.sh, HEAD %s): "
+                                  "average HBM bytes per launch.  FETCH_SIZE correction: none -- the guide's x2 applies to wide coalesced 16 B/lane streams; these kernels read "
+                                  "scattered buckets and 8 B/lane runs, and FETCH_SIZE was calibrated at 1.000 on this library's scattered 16-byte reads (profiles/r01_pmc_fetch_size.json)"
+                                  % (os.path.relpath(pmc, ROOT), pj.get("head", "?")))
+        for kr in kerns:
+            tk = kr["kernel"].split("(")[0]
+            tv = sum(v for kn, v in by_kernel.items() if v and (kn == tk or (tk == "k_post" and kn in ("k_scan1", "k_scan2")) or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble")))))
+            kr["traffic"] = tv or None
+            kr["traffic_over_bytes"] = (tv / kr["bytes_per_launch"]) if tv and kr["bytes_per_launch"] else None
     # what the reference's algorithm would have moved for the same contigs (64 B per membership probe, probes counted by the oracle):
-    # kept for comparison only -- the unitig layout reads one bucket and one stretch of 2-bit sequence where gatb probes 8 Bloom blocks per nucleotide
+    # kept for comparison only -- the unitig layout reads one bucket and one stretch of 2-bit sequence where gatb probes 8 Bloom blocks per nucleotide.
+    # That work has not vanished: it is done ONCE, when the index is built (index_build below carries its clock and its roofline).
     roof["reference_algorithm_equivalent"] = {"bytes_per_launch": 64.0 * probes_per_nt * acc["contig_nt"] / Ln, "probes_per_contig_nt": probes_per_nt,
-                                              "equivalent_GBps_of_k_stage_a": 64.0 * probes_per_nt * acc["contig_nt"] / Ln / max(acc["kernel_ms"] / Ln * 1e-3, 1e-12) / 1e9}
+                                              "equivalent_GBps_of_k_stage_a": 64.0 * probes_per_nt * acc["contig_nt"] / Ln / max((alone_ms("kernel_ms") or acc["kernel_ms"] / Ln) * 1e-3, 1e-12) / 1e9,
+                                              "note": "a step does not move these bytes (frac would exceed 1): the walk reads the unitig store the index build derived from the k-mer set; see index_build"}
     if st_alone:
-        nl1 = max(st_alone["n_launches"], 1)
-        roof["one_batch_alone_ms"] = {"k_stage_a+k_finish": st_alone["kernel_ms"] / nl1, "k_finish": st_alone["finish_kernel_ms"] / nl1, "k_copy": st_alone["copy_kernel_ms"] / nl1,
-                                      "k_post+scans": st_alone["post_kernel_ms"] / nl1, "k_emit": st_alone["emit_kernel_ms"] / nl1, "parked_gaps": st_alone["n_parked_gaps"] / nl1}
+        roof["one_batch_alone_ms"] = {"k_stage_a+k_finish": st_alone["kernel_ms"] / nl1, "k_finish": st_alone["finish_kernel_ms"] / nl1, "k_lean": st_alone["lean_kernel_ms"] / nl1,
+                                      "k_copy": (st_alone["copy_kernel_ms"] - st_alone["lean_kernel_ms"]) / nl1,
+                                      "k_post+scans": st_alone["post_kernel_ms"] / nl1, "k_emit": st_alone["emit_kernel_ms"] / nl1, "parked_gaps": st_alone["n_parked_gaps"] / nl1,
+                                      "sum": (st_alone["kernel_ms"] + st_alone["copy_kernel_ms"] + st_alone["post_kernel_ms"] + st_alone["emit_kernel_ms"]) / nl1, "launches": nl1}
     if not a.no_ceiling:
         tb = min(int(info["device_bytes"] // 2), 16 << 30)  # the ceiling is flat beyond ~16 GB (profiles/r01_random_line_ceiling.txt)
         ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), batch_sites, 512, bucket)
@@ -676,9 +767,29 @@ def main():
         avg_s = acc["kernel_ms"] / Ln * 1e-3
         roof["random_reads_of_k_stage_a"] = {"per_launch": rr, "reads_per_s": rr / avg_s if avg_s > 0 else 0.0, "frac_of_ceiling": rr / avg_s / roof["random_read_ceiling_reads_per_s"] if avg_s > 0 else 0.0}
         if st_alone and st_alone["kernel_ms"] > 0:
-            rr1 = (st_alone["index_lines"] + st_alone["store_runs"]) / max(st_alone["n_launches"], 1)
-            t1 = st_alone["kernel_ms"] / max(st_alone["n_launches"], 1) * 1e-3
+            rr1 = (st_alone["index_lines"] + st_alone["store_runs"]) / nl1
+            t1 = st_alone["kernel_ms"] / nl1 * 1e-3
             roof["random_reads_of_k_stage_a"]["alone"] = {"per_launch": rr1, "reads_per_s": rr1 / t1, "frac_of_ceiling": rr1 / t1 / roof["random_read_ceiling_reads_per_s"]}
+
+    # ---------------------------------------------------------------- the index construction under a clock and a roofline (Graph::create, src/Filler.cpp:172-226): per
+    # phase the device time (HIP events inside the library) and the bytes the implemented layout must move; against it the reference
+    # algorithm's probes for the same k-mer set (8 membership probes of 64 B per k-mer -- what the walk no longer does per step)
+    dev_s = sum(ph["ms"] for ph in bprof["phases"]) / 1e3
+    lay_b = sum(ph["bytes"] for ph in bprof["phases"])
+    ref_b = float(info["nb_solid_kmers"]) * 8 * 64
+    index_build = {"seconds": t_index, "device_seconds": dev_s, "library_seconds": bprof["total_ms"] / 1e3, "peak_device_bytes": bprof["peak_device_bytes"], "resident_bytes": int(info["device_bytes"]),
+                   "source": "2-bit packed donor sequences resident in HBM (mtg_index_create_from_packed_device); abundances a function of the k-mer",
+                   "phases": [{"name": ph["name"], "ms": ph["ms"], "bytes": ph["bytes"], "units": ph["units"], "GBps": ph["bytes"] / max(ph["ms"], 1e-9) / 1e6,
+                               "frac_of_hbm_peak": ph["bytes"] / max(ph["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS} for ph in bprof["phases"]],
+                   "bytes_of_the_layout": lay_b, "achieved_GBps": lay_b / max(dev_s, 1e-9) / 1e9, "frac_of_hbm_peak": lay_b / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS,
+                   "reference_algorithm_equivalent": {"bytes": ref_b, "what": "k-mers x 8 membership probes x 64 B (SURVEY 8d)", "GBps_over_the_whole_build": ref_b / max(t_index, 1e-9) / 1e9,
+                                                      "frac_of_hbm_peak": ref_b / max(t_index, 1e-9) / 1e9 / HBM_PEAK_GBS},
+                   "traffic": None}
+    pmcb = os.path.join(ROOT, "profiles", "r04_pmc_build.json")
+    if a.workload == "human" and os.path.exists(pmcb):
+        pb = json.load(open(pmcb))
+        index_build["traffic"] = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pb.get("kernels", {}).items()}
+        index_build["traffic_is"] = "REPLAYED from profiles/r04_pmc_build.json (rocprofv3 --pmc passes of scripts/r4_build.py, HEAD %s); FETCH_SIZE x2 applied to no kernel (8 B/lane table scans, scattered buckets)" % pb.get("head", "?")
 
     out = {"metric": "breakpoints filled/sec", "value": value, "unit": "breakpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -690,12 +801,13 @@ def main():
                       "output": "C-ABI records + ASCII sequences in page-locked host memory" + ("; every batch also gathered on rank 0 in relocatable form (records + sequences), validated there" if dist_on else "")},
            "timed_blocks": {"blocks": len(times), "steps_per_block": a.steps, "reported": "median", "ms_per_step_min": min(times) / a.steps * 1e3,
                             "ms_per_step_median": elapsed / a.steps * 1e3, "ms_per_step_max": max(times) / a.steps * 1e3, "timed_seconds_total": sum(times)},
-           "filled": R0["n_filled"], "sites_verified": R0["n_sites"], "filled_per_s": value * R0["n_filled"] / max(R0["n_sites"], 1),
+           "filled": R0["n_filled"], "sites_verified": R0["n_sites"] if R0["identical"] is not None else None, "sites_run_in_the_untimed_pass": R0["n_sites"],
+           "filled_per_s": value * R0["n_filled"] / max(R0["n_sites"], 1),
            "filled_sequences_identical_to_truth": R0["identical"], "gathered_payload_verified": R0["gathered"],
-           "stage_ms_per_batch": {"k_stage_a+k_finish": acc["kernel_ms"] / Ln, "k_finish": acc["finish_kernel_ms"] / Ln, "parked_gaps": acc["n_parked_gaps"] / Ln, "lean_gaps": acc["n_lean_gaps"] / Ln, "k_copy": acc["copy_kernel_ms"] / Ln,
+           "stage_ms_per_batch": {"k_stage_a+k_finish": acc["kernel_ms"] / Ln, "k_finish": acc["finish_kernel_ms"] / Ln, "parked_gaps": acc["n_parked_gaps"] / Ln, "lean_gaps": acc["n_lean_gaps"] / Ln, "k_lean": acc["lean_kernel_ms"] / Ln, "k_copy": (acc["copy_kernel_ms"] - acc["lean_kernel_ms"]) / Ln,
                                   "k_post+scans": acc["post_kernel_ms"] / Ln, "k_emit": acc["emit_kernel_ms"] / Ln, "d2h": acc["d2h_ms"] / Ln,
                                   "host": acc["host_ms"] / Ln, "c_call": acc["total_ms"] / Ln},
-           "roofline": roof, "cpu_baseline": cpu}
+           "roofline": roof, "cpu_baseline": cpu, "index_build": index_build}
     out.update(secondary)
     # ---------------------------------------------------------------- secondary lines: the workloads whose walks cross bubbles (SNPs; indels; tips and error bubbles), each
     # as a child process once this one has given the device back (two human-scale indexes do not fit the HBM together)
@@ -708,11 +820,17 @@ def main():
         torch.cuda.empty_cache()
         for wl, key in (("human-het", "secondary_diploid"), ("human-indel", "secondary_indel"), ("human-tips", "secondary_tips")):
             try:
-                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--batches", "3", "--cpu-sites", "0", "--no-ceiling", "--no-secondary",
-                                     "--steps", str(a.steps), "--warmup", str(a.warmup), "--in-flight", str(a.in_flight), "--repeats", "5"], capture_output=True, text=True, timeout=400)
+                # every child checks a sample of its sites against the oracle (cpu_baseline leg: 6 000 sites, index over the donor sequences of those loci): the
+                # alleles and error bubbles of these sets have no closed-form truth, the oracle's fills are the reference
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--batches", "3", "--cpu-sites", "6000", "--cpu-index-seqs", "12000", "--cpu-same-sites", "0",
+                                     "--no-ceiling", "--no-secondary", "--steps", str(a.steps), "--warmup", str(a.warmup), "--in-flight", str(a.in_flight), "--repeats", "5"],
+                                    capture_output=True, text=True, timeout=600)
                 d = json.loads(cp.stdout.strip().splitlines()[-1])
+                cb = d.get("cpu_baseline") or {}
                 out[key] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "timed_blocks": d["timed_blocks"],
-                            "filled": d["filled"], "sites_verified": d["sites_verified"], "one_batch_alone_ms": d["roofline"].get("one_batch_alone_ms"),
+                            "filled": d["filled"], "sites_run_in_the_untimed_pass": d["sites_run_in_the_untimed_pass"],
+                            "identical_to_oracle": cb.get("identical_to_hip"), "oracle_sample": cb.get("sample"), "oracle_sites_per_s": cb.get("value"),
+                            "one_batch_alone_ms": d["roofline"].get("one_batch_alone_ms"),
                             "stage_ms_per_batch": d["stage_ms_per_batch"], "ratio_to_headline": d["value"] / value if value else None}
             except Exception as e:  # the headline line does not depend on it
                 out[key] = {"error": repr(e)[:300]}

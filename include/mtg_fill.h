@@ -311,6 +311,10 @@ typedef struct mtg_batch_stats {
     uint64_t n_parked_gaps;      /* gaps the walk kernel parked at a branching node that is not the strict SNP pattern */
     uint64_t n_rounds;           /* bubble rounds queued between launches of the walk kernel (0: the parked gaps went straight to k_finish) */
     uint64_t n_lean_gaps;        /* gaps whose contig was never materialised: target located in the unitig store, coverage and ASCII read off the store */
+    double lean_kernel_ms;       /* of copy_kernel_ms: the decision kernel (k_lean, one gap per lane); the rest is k_copy over the gaps that need it */
+    uint64_t copy_words_executed; /* of copy_words: those k_copy really wrote (a lean gap's commands are never executed) */
+    uint64_t copy_cmds_executed;
+    uint64_t post_scanned_words; /* of contig_words: those k_post's terminal search really read (a lean gap's contig is never scanned) */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);
 

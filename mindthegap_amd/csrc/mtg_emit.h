@@ -33,6 +33,7 @@ MTG_DEV void emit_plan(const GapOut& o, const PostOut& p, bool want_all, int k, 
 struct PartTot {
     uint64_t begin[4], end[4]; /* cursors before / after the part: dense words, dense metadata entries, sequence bytes, extension bytes */
     uint64_t lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, copy_words, copy_cmds, cov_direct, n_lean;
+    uint64_t copy_words_exec, copy_cmds_exec, scan_words; /* what k_copy executed and k_post scanned: nothing of a lean gap */
     uint32_t n_retry, n_general, n_filled, n_ext;
 };
 

@@ -807,8 +807,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
     __shared__ uint32_t hist[256];
     __shared__ uint64_t tile[POST_TILE + 2];
     __shared__ uint64_t s_blk[64];
-    __shared__ __attribute__((aligned(8))) uint32_t s_rec[sizeof(SlotRec) / 4];
-    static_assert(sizeof(SlotRec) % 4 == 0 && sizeof(SlotRec) / 4 <= 64, "one lane per 4 bytes of a slot record");
     /* one workgroup per slot measured best (against persistent workgroups): the kernel lives on the number of waves in flight */
     for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
         __syncthreads(); /* the previous gap's readers of hist are done */
@@ -836,8 +834,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
             post_gap(ix, cfg, S, o, T, hist, tile, s_blk, po);
 #endif
         }
-        /* the record leaves in ONE coalesced store of the wave (38 lanes x 4 bytes): lane 0 storing its 38 fields one by one made the kernel
-         * write 1.1 KB of partial lines per gap (PMC WRITE_SIZE 111.6 MB per launch for 15 MB of records, round 3) */
+        /* the record leaves lane 0 in ten 16-byte stores (SlotRec is 16-byte aligned): field by field it made the kernel write 1.1 KB of
+         * partial lines per gap (PMC WRITE_SIZE 111.6 MB per launch for 15 MB of records, round 3).  A coalesced store of the wave through
+         * LDS was measured as well: fewer bytes still, but 36 us more -- the kernel is bound by instruction issue, not by its traffic. */
         if (threadIdx.x == 0) {
             SlotRec r;
             r.o = o; r.p = po;
@@ -845,10 +844,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
             r.wbase = r.cbase = r.abase = r.ebase = 0;
             r.rpos = r.gpos = 0;
             r.fpos = r.pad_ = 0;
-            *reinterpret_cast<SlotRec*>(s_rec) = r;
+            r.pad2_[0] = r.pad2_[1] = 0;
+            recs[slot] = r;
         }
-        __syncthreads();
-        if (threadIdx.x < sizeof(SlotRec) / 4) reinterpret_cast<uint32_t*>(recs + slot)[threadIdx.x] = s_rec[threadIdx.x];
     }
 }
 
@@ -856,10 +854,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
  * metadata, the sequence arena, the extension arena, the list of gaps to re-run and the list of multi-contig gaps.  k_scan1: one thread per
  * slot, offsets inside its block of SCAN_SL slots + the block's totals and statistics; k_scan2 (one workgroup): offsets of the blocks on
  * top of the batch's cursors, totals of the launch; k_emit adds the two. */
-enum { SCAN_SL = 256, SCAN_NV = 7, SCAN_NS = 13 };
+enum { SCAN_SL = 256, SCAN_NV = 7, SCAN_NS = 16 };
 struct ScanBlock {
     uint64_t v[SCAN_NV]; /* k_scan1: totals of the block; k_scan2: replaced by the block's base */
-    uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext, copy_words, copy_cmds, cov_direct */
+    uint64_t s[SCAN_NS]; /* sums: lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, n_filled, n_ext, copy_words, copy_cmds, cov_direct, n_lean,
+                            copy words / commands k_copy executed (not those of lean gaps), contig words k_post scanned (not those of lean gaps) */
 };
 __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, ScanBlock* blocks)
 {
@@ -870,7 +869,7 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
     __shared__ unsigned long long wsum[NW][SCAN_NS];
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6, slot = blockIdx.x * SCAN_SL + t;
     uint64_t v[SCAN_NV] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st[SCAN_NS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st[SCAN_NS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (slot < m) {
         const SlotRec& r = recs[slot];
         const bool ok = r.o.status == GAP_OK;
@@ -885,6 +884,8 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
             if (r.p.direct) st[11] = r.p.ab_n;
             st[7] = r.asc ? 1 : 0; st[8] = r.ext ? 1 : 0; st[12] = r.p.lean ? 1 : 0;
         }
+        /* a lean gap's commands are never executed and its contig is never scanned: what k_copy and k_post really touched */
+        if (!(ok && r.p.lean)) { if (r.o.n_cmds) { st[13] = r.o.copy_words; st[14] = r.o.n_cmds; } if (ok) st[15] = r.o.n_words; }
     }
     uint64_t incl[SCAN_NV];
     for (int j = 0; j < SCAN_NV; j++) {
@@ -966,6 +967,7 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         tot->post_lines = ssum[5]; tot->cov_kmers = ssum[6];
         tot->n_filled = (uint32_t)ssum[7]; tot->n_ext = (uint32_t)ssum[8];
         tot->copy_words = ssum[9]; tot->copy_cmds = ssum[10]; tot->cov_direct = ssum[11]; tot->n_lean = ssum[12];
+        tot->copy_words_exec = ssum[13]; tot->copy_cmds_exec = ssum[14]; tot->scan_words = ssum[15];
     }
 }
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
@@ -2327,7 +2329,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     tick("upload (async)");
 
     EventSet events;
-    hipEvent_t ev0, ev1, ev2, ev3, eve, evc, evf;
+    hipEvent_t ev0, ev1, ev2, ev3, eve, evc, evf, evl;
     HIP_TRY(events.make(eve));
     HIP_TRY(events.make(evc));
     HIP_TRY(events.make(ev0));
@@ -2335,6 +2337,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     HIP_TRY(events.make(ev2));
     HIP_TRY(events.make(ev3));
     HIP_TRY(events.make(evf));
+    HIP_TRY(events.make(evl));
     PartTot* h_tot = (PartTot*)staging_host(&ws, Workspace::NHOST - 1, sizeof(PartTot) + 64);
     if (!h_tot) { set_error("no page-locked memory for the totals of a launch"); return MTG_ERR_NOMEM; }
 
@@ -2513,6 +2516,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             static const bool no_lean = getenv("MTG_NO_LEAN") != nullptr; /* A/B and test hook: every contig is materialised */
             hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
                                (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m, park, m);
+            HIP_TRY(hipEventRecord(evl, stream)); /* ev1 .. evl: k_lean; evl .. evc: k_copy */
             hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m);
             HIP_TRY(hipEventRecord(evc, stream));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
@@ -2634,6 +2638,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
             st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += tw;
             st.copy_words += tot.copy_words; st.copy_cmds += tot.copy_cmds; st.coverage_direct_kmers += tot.cov_direct; st.n_lean_gaps += tot.n_lean;
+            st.copy_words_executed += tot.copy_words_exec; st.copy_cmds_executed += tot.copy_cmds_exec; st.post_scanned_words += tot.scan_words;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
             sink.n_filled += tot.n_filled;
@@ -2676,6 +2681,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     if (whole) { ws.mode_ns_per_gap[wmode] = ms * 1e6f / (float)m; ws.mode_launches++; } /* ev0 .. ev1: the walk, its rounds and the finishing kernel (with whatever else the device was doing: the launches of a workspace see the same company) */
                 } }
             HIP_TRY(hipEventElapsedTime(&msc, ev1, evc));
+            { float msl = 0; HIP_TRY(hipEventElapsedTime(&msl, ev1, evl)); st.lean_kernel_ms += msl; }
             HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
             st.copy_kernel_ms += msc;
             HIP_TRY(hipEventElapsedTime(&ms3, eve, ev2));

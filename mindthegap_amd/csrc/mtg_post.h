@@ -27,7 +27,7 @@ struct PostOut {
 /* everything the device keeps about one gap of a launch: the counters of the traversal and of the post-processing, what the gap
  * contributes to the arrays of its batch (mtg_emit.h: emit_plan) and where (exclusive prefix sums in slot order).  Metadata of a gap: 5
  * runs of nc entries at meta[5 * cbase] (length, first word, terminal position, errors, target index). */
-struct SlotRec {
+struct alignas(16) SlotRec {
     GapOut o;
     PostOut p;
     uint32_t nw, nc;   /* dense words / contig metadata entries (multi-contig gaps and the stage-A entry only) */
@@ -35,6 +35,7 @@ struct SlotRec {
     uint64_t wbase, cbase, abase, ebase;
     uint32_t rpos, gpos; /* rank among the gaps to re-run / among the gaps that need the host */
     uint32_t fpos, pad_; /* rank among the filled gaps (the index of its mtg_wire_filled when the batch leaves in relocatable form) */
+    uint32_t pad2_[2];   /* 160 bytes: whole 16-byte pieces (k_post stores the record with ten wide stores) */
 };
 
 /* A target as the host hands it over: its first k characters in a TARGET_SLOT-byte slot, byte TARGET_SLOT - 1 = 1 when the anchor

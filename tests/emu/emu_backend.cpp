@@ -431,6 +431,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 if (r.o.status != GAP_OK) { r.rpos = (uint32_t)rlist.size(); rlist.push_back(s); continue; }
                 tot.contig_nt += r.o.total_nt; tot.post_lines += r.p.lines; tot.cov_kmers += r.p.ab_n; if (r.p.direct) tot.cov_direct += r.p.ab_n;
                 tot.n_filled += r.asc != 0; tot.n_ext += r.ext != 0; tot.n_lean += r.p.lean != 0;
+                if (!r.p.lean) { if (r.o.n_cmds) { tot.copy_words_exec += r.o.copy_words; tot.copy_cmds_exec += r.o.n_cmds; } tot.scan_words += r.o.n_words; }
                 if (r.nc) { r.gpos = (uint32_t)glist.size(); glist.push_back(s); }
             }
             tot.end[0] = c0; tot.end[1] = c1; tot.end[2] = c2; tot.end[3] = c3;
@@ -504,6 +505,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 memcpy(sink.seq_dev + tot.begin[2], sink.seq + tot.begin[2], tot.end[2] - tot.begin[2]);
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
             st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.coverage_direct_kmers += tot.cov_direct; st.n_lean_gaps += tot.n_lean; st.dense_words += c0;
+            st.copy_words_executed += tot.copy_words_exec; st.copy_cmds_executed += tot.copy_cmds_exec; st.post_scanned_words += tot.scan_words;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
             sink.n_filled += tot.n_filled;
