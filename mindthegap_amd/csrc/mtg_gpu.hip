@@ -18,6 +18,8 @@
 #include "mtg_marshal.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <thread>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1955,13 +1957,19 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
         std::vector<uint64_t> km(d.left_k);
         std::vector<uint32_t> ab(d.left_a);
         const uint64_t mk = kmask(d.k);
+        std::vector<uint8_t> ab_all; /* a container that is being read: its abundance bytes, whole */
+        if (d.ab_read && d.n_words) {
+            ab_all.resize((d.n_words + 8) * 32);
+            if (!d.ab_read(0, ab_all.size(), ab_all.data())) { set_error("index container: short read"); return MTG_ERR_FORMAT; }
+        }
+        const uint8_t* dab = d.ab_read ? ab_all.data() : d.ab.data();
         for (uint64_t h = 0; h < d.n_words;) {
             const uint64_t len = d.words[h];
             for (uint64_t i = 0; i + d.k <= len; i++) {
                 const uint64_t p = (h + 1) * 32 + i, lo = d.words[p >> 5] >> (2 * (p & 31)), hi = (p & 31) ? d.words[(p >> 5) + 1] << (64 - 2 * (p & 31)) : 0;
                 const uint64_t r = ((lo | hi) & mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk), f = revcomp(r, d.k);
                 km.push_back(f < r ? f : r);
-                ab.push_back(d.ab[p]);
+                ab.push_back(dab[p]);
             }
             h += 1 + (len + 31) / 32;
         }
@@ -1969,16 +1977,47 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
         if (!rc) { (*out)->info.abundance_min = d.abundance_min; (*out)->info.abundance_auto = d.abundance_auto; }
         return rc;
     }
+    BuildProf prof;
     IndexGuard g(new mtg_index());
     mtg_index* idx = g.idx;
     idx->dev.k = d.k;
     HIP_TRY(hipGetDevice(&idx->device));
     const uint64_t nw = d.n_words + 8;
-    if (d.words.size() < nw || d.ab.size() < nw * 32 || d.left_k.size() != d.left_a.size()) { set_error("index container: inconsistent sizes"); return MTG_ERR_FORMAT; }
+    const bool streamed = (bool)d.ab_read;
+    if (d.words.size() < nw || (!streamed && d.ab.size() < nw * 32) || d.left_k.size() != d.left_a.size()) { set_error("index container: inconsistent sizes"); return MTG_ERR_FORMAT; }
     HIP_TRY(hipMalloc((void**)&idx->dev.us.words, nw * 8));
     HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, nw * 32));
+    const auto t_up0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpy(idx->dev.us.words, d.words.data(), nw * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(idx->dev.us.ab, d.ab.data(), nw * 32, hipMemcpyHostToDevice));
+    /* the abundance bytes: either in host memory already, or (a container that is being read) straight from the file in page-locked pieces,
+     * by a few threads with a stream each -- and while the tables are derived below: those kernels read the store's words only */
+    std::vector<std::thread> uploaders;
+    std::atomic<uint64_t> next_piece{0};
+    std::atomic<int> up_err{0};
+    struct JoinAll { std::vector<std::thread>& ts; ~JoinAll() { for (auto& t : ts) if (t.joinable()) t.join(); } } join_all{uploaders};
+    if (!streamed) HIP_TRY(hipMemcpy(idx->dev.us.ab, d.ab.data(), nw * 32, hipMemcpyHostToDevice));
+    else {
+        const uint64_t total = nw * 32, piece = (uint64_t)32 << 20, npieces = (total + piece - 1) / piece;
+        const int nthreads = (int)std::min<uint64_t>(npieces, (uint64_t)std::min(8, std::max(2, Pool::cpu_budget() / 2)));
+        uint8_t* dst = idx->dev.us.ab;
+        const int device = idx->device;
+        for (int t = 0; t < nthreads; t++)
+            uploaders.emplace_back([&, dst, device, total, piece, npieces] {
+                void* pin = nullptr;
+                hipStream_t st = nullptr;
+                if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin, piece, hipHostMallocDefault) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) up_err.store(1);
+                else
+                    for (;;) {
+                        const uint64_t c = next_piece.fetch_add(1);
+                        if (c >= npieces || up_err.load()) break;
+                        const uint64_t off = c * piece, n = std::min(piece, total - off);
+                        if (!d.ab_read(off, (size_t)n, pin)) { up_err.store(2); break; }
+                        if (hipMemcpyAsync(dst + off, pin, n, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { up_err.store(1); break; }
+                    }
+                if (st) (void)hipStreamDestroy(st);
+                if (pin) (void)hipHostFree(pin);
+            });
+    }
     idx->dev.us.nwords = d.n_words;
     /* the header words of the unitigs, one after the other */
     std::vector<uint64_t> hdr;
@@ -2002,6 +2041,7 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
     HIP_TRY(hipGetLastError());
     HIP_TRY(upload(d_k, d.left_k.data(), d.left_k.size() * 8));
     HIP_TRY(upload(d_a, d.left_a.data(), d.left_a.size() * 4));
+    prof.host_phase("store_words_up+headers", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(), nw * 8, hdr.size());
     const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
     if (bpk > 0) {
         bloom_shape(idx->dev.bloom, d.nb_solid, bpk, d.k);
@@ -2017,7 +2057,14 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
     idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
     idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
     idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
-    if (int rc = sparsify(idx, d_rec.as<UsRec>(), hdr.size(), true, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d.left_k.size())) return rc;
+    if (int rc = sparsify(idx, d_rec.as<UsRec>(), hdr.size(), true, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d.left_k.size(), &prof)) return rc;
+    const auto t_j0 = std::chrono::steady_clock::now();
+    for (auto& t : uploaders) t.join();
+    if (up_err.load()) { set_error(up_err.load() == 2 ? "index container: short read" : "index container: the upload of the abundance bytes failed"); return up_err.load() == 2 ? MTG_ERR_FORMAT : MTG_ERR_NO_DEVICE; }
+    if (streamed) prof.host_phase("abundances_file_to_hbm", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(), nw * 32, nw * 32);
+    (void)t_j0;
+    HIP_TRY(hipDeviceSynchronize());
+    prof.store(idx);
     *out = g.release();
     return MTG_OK;
 }

@@ -13,6 +13,7 @@
  * The temp-file round trips of the reference (contigs FASTA + dot graph per gap) are not reproduced.
  */
 #include "mtg_internal.h"
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -246,6 +247,31 @@ int index_save(const mtg_index* idx, const char* path)
     return MTG_OK;
 }
 
+/* bytes [off, off + n) of the file into dst, by a few threads (the page cache, or a memory-backed file system, gives one reader 3-5 GB/s) */
+static bool pread_all(int fd, void* dst, size_t n, uint64_t off)
+{
+    size_t done = 0;
+    while (done < n) {
+        const ssize_t r = ::pread(fd, (char*)dst + done, n - done, (off_t)(off + done));
+        if (r <= 0) return false;
+        done += (size_t)r;
+    }
+    return true;
+}
+static bool pread_parallel(int fd, void* dst, size_t n, uint64_t off)
+{
+    const size_t nt = n < ((size_t)64 << 20) ? 1 : (size_t)std::min(8, std::max(1, Pool::cpu_budget()));
+    if (nt == 1) return pread_all(fd, dst, n, off);
+    std::vector<std::thread> ts;
+    std::atomic<bool> ok{true};
+    const size_t piece = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
+    for (size_t t = 0; t < nt; t++) {
+        const size_t lo = std::min(n, t * piece), hi = std::min(n, (t + 1) * piece);
+        if (lo < hi) ts.emplace_back([=, &ok] { if (!pread_all(fd, (char*)dst + lo, hi - lo, off + lo)) ok.store(false); });
+    }
+    for (auto& t : ts) t.join();
+    return ok.load();
+}
 static int index_load_v3(FILE* f, const char* path, mtg_index** out)
 {
     int32_t hdr[4];
@@ -263,15 +289,20 @@ static int index_load_v3(FILE* f, const char* path, mtg_index** out)
     IndexDump d;
     d.k = hdr[0]; d.abundance_min = hdr[1]; d.abundance_auto = hdr[2];
     d.nb_solid = cnt[0]; d.nb_branching = cnt[1]; d.nb_saturated = cnt[2]; d.n_words = cnt[3]; d.n_unitigs = cnt[4];
-    d.words.resize(nw); d.ab.resize(nw * 32);
-    bool ok = (!nw || (fread(d.words.data(), 8, nw, f) == nw && fread(d.ab.data(), 1, nw * 32, f) == nw * 32));
+    /* the words (a fifth of the store) come to host memory -- the walk over the unitigs' header words needs them -- read by several threads;
+     * the abundance bytes go from the file to the device in page-locked pieces while the tables are being derived (index_from_dump) */
+    const int fd = fileno(f);
+    d.words.resize(nw);
+    bool ok = !nw || pread_parallel(fd, d.words.data(), nw * 8, (uint64_t)data0);
+    const uint64_t ab0 = (uint64_t)data0 + nw * 8, left0 = ab0 + nw * 32;
     d.left_k.resize(cnt[5]); d.left_a.resize(cnt[5]);
     if (ok && cnt[5]) {
         std::vector<unsigned char> rec(cnt[5] * 12);
-        ok = fread(rec.data(), 12, cnt[5], f) == cnt[5];
+        ok = pread_parallel(fd, rec.data(), rec.size(), left0);
         for (size_t i = 0; i < cnt[5] && ok; i++) { memcpy(&d.left_k[i], rec.data() + 12 * i, 8); memcpy(&d.left_a[i], rec.data() + 12 * i + 8, 4); }
     }
     if (!ok) { set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
+    if (nw) d.ab_read = [fd, ab0](uint64_t off, size_t n, void* dst) { return pread_all(fd, dst, n, ab0 + off); };
     return index_from_dump(d, out);
 }
 

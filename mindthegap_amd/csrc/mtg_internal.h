@@ -563,6 +563,10 @@ struct IndexDump {
     std::vector<uint8_t> ab;      /* 32 bytes per word */
     std::vector<uint64_t> left_k; /* canonical k-mers of no stored unitig */
     std::vector<uint32_t> left_a; /* their abundances */
+    /* a container that goes to the device while it is being read (index_load): `ab` stays empty and the abundance bytes -- four fifths of the
+     * file -- are handed over piece by piece: ab_read(off, n, dst) copies bytes [off, off + n) of the abundance section to dst; it is
+     * called from several threads at once, each with a page-locked dst of its own */
+    std::function<bool(uint64_t off, size_t n, void* dst)> ab_read;
 };
 int index_dump(const mtg_index* idx, IndexDump& d);
 int index_from_dump(const IndexDump& d, mtg_index** out);

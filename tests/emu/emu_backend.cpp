@@ -284,9 +284,19 @@ static void dump_kmers(const IndexDump& d, std::vector<uint64_t>& km, std::vecto
     km.insert(km.end(), d.left_k.begin(), d.left_k.end());
     ab.insert(ab.end(), d.left_a.begin(), d.left_a.end());
 }
-int index_from_dump(const IndexDump& d, mtg_index** out)
+int index_from_dump(const IndexDump& d0, mtg_index** out)
 {
     /* the emulation rebuilds from the k-mers (its tables are host memory); the device build derives the tables from the store itself */
+    IndexDump local;
+    if (d0.ab_read) { /* a container that is being read: the abundance bytes in pieces, as the device build asks for them */
+        local = d0;
+        local.ab.assign(d0.words.size() * 32, 0);
+        const size_t piece = 1000;
+        for (size_t off = 0; off < local.ab.size(); off += piece)
+            if (!d0.ab_read(off, std::min(piece, local.ab.size() - off), local.ab.data() + off)) { set_error("index container: short read"); return MTG_ERR_FORMAT; }
+        local.ab_read = nullptr;
+    }
+    const IndexDump& d = d0.ab_read ? local : d0;
     std::vector<uint64_t> km;
     std::vector<uint32_t> ab;
     dump_kmers(d, km, ab);
