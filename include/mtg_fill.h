@@ -214,6 +214,27 @@ typedef struct mtg_text_gaps {
     const uint8_t* gap_flags;         /* per gap, bit 0: is_anchor_repeated, bit 1: reverse (NULL: all 0) */
 } mtg_text_gaps;
 int mtg_fill_text(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, mtg_results** out);
+/* mtg_fill_text for the gaps of BREAKPOINT sites (one-entry dictionaries), and the text the tool's writers add to its output files for them
+ * -- writeFilledBreakpoint (src/Filler.cpp:1029-1093), the info line, writeVcf (:1095-1214) -- FORMATTED ON THE DEVICE from the records and
+ * sequences the result kernel has just written there: what crosses PCIe is the files' next bytes, and the host only writes them.
+ * name_off / name_len: breakpointName of site i = text[name_off[i], + name_len[i]) (the left record's header up to its first space).
+ * The device writes the SIMPLE sites -- one solution, found on the common path of this (forward) attempt; every other site (no solution: the
+ * caller's reverse attempt decides; several solutions; a record the host wrote) is listed in complex_sites with the offsets where the
+ * caller's own text for it belongs, and its record is in *out as always (the ASCII arena of the simple sites is NOT brought to the host:
+ * their records' seq pointers must not be followed).  *text: NULL for a new object, or one to use again (its arenas are page-locked). */
+typedef struct mtg_formatted mtg_formatted;
+typedef struct mtg_formatted_view {
+    const char* text[3];            /* FASTA, info, VCF bytes of the simple sites, in site order */
+    uint64_t bytes[3];
+    uint64_t n_sites, n_simple;
+    const uint32_t* complex_sites;  /* ascending */
+    const uint64_t* complex_off[3]; /* complex_off[s][j]: bytes of text[s] that precede the text of site complex_sites[j] */
+    uint64_t n_complex;
+    double kernel_ms;               /* HIP-event time of the three formatting kernels */
+} mtg_formatted_view;
+int mtg_fill_text_formatted(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, const uint64_t* name_off, const uint32_t* name_len, mtg_results** out, mtg_formatted** text);
+int mtg_formatted_get(const mtg_formatted* t, mtg_formatted_view* v);
+void mtg_formatted_free(mtg_formatted* t);
 /* and the filled sequences laid out in seq_out as with mtg_fill_batch_serial */
 int mtg_fill_text_serial(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out);
 const mtg_gap_result* mtg_results_get(const mtg_results* r, size_t i);

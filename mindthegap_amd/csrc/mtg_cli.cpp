@@ -147,11 +147,21 @@ template <class T> struct Recycler {
     }
 };
 static Recycler<OutText>& piece_pool() { static Recycler<OutText> p(512); return p; }
+/* the library's formatted-text objects (three page-locked arenas each) go round as the batches do */
+struct FormattedPool {
+    std::mutex m;
+    std::vector<mtg_formatted*> free;
+    mtg_formatted* get() { std::lock_guard<std::mutex> lk(m); if (free.empty()) return nullptr; mtg_formatted* t = free.back(); free.pop_back(); return t; }
+    void put(mtg_formatted* t) { if (!t) return; std::lock_guard<std::mutex> lk(m); if (free.size() < 12) free.push_back(t); else mtg_formatted_free(t); }
+    ~FormattedPool() { for (mtg_formatted* t : free) mtg_formatted_free(t); }
+};
+static FormattedPool& ftext_pool() { static FormattedPool p; return p; }
 /* The output files of a long run, written by several threads: the pieces of text get their places in input order (one thread hands them
  * out, as it would have written them), the bytes go there with pwrite from a few writer threads -- a memory-backed or page-cached file takes
  * several GB/s from each.  Whatever was written through the FILE* before begin() stays in front; after finish() the FILE* continue behind. */
 struct PositionedWriter {
-    struct Job { std::shared_ptr<void> owner; const OutText* T; off_t at[5]; };
+    struct Span { const char* p = nullptr; size_t n = 0; };
+    struct Job { std::shared_ptr<void> owner; Span s[5]; off_t at[5]; };
     Files& F;
     int fd[5];
     off_t pos[5];
@@ -176,10 +186,17 @@ struct PositionedWriter {
     /* called in input order: the piece's places are the current ends of the files */
     void add(std::shared_ptr<void> owner, const OutText& T)
     {
+        Span sp[5];
+        for (int i = 0; i < 5; i++) { sp[i].p = text_of(T, i).data(); sp[i].n = text_of(T, i).size(); }
+        add_spans(std::move(owner), sp);
+    }
+    /* the same for bytes that live somewhere else (a batch's text formatted on the device: page-locked arenas of the library) */
+    void add_spans(std::shared_ptr<void> owner, const Span sp[5])
+    {
         Job j;
-        j.owner = std::move(owner); j.T = &T;
+        j.owner = std::move(owner);
         size_t bytes = 0;
-        for (int i = 0; i < 5; i++) { j.at[i] = pos[i]; if (fd[i] >= 0) { pos[i] += (off_t)text_of(T, i).size(); bytes += text_of(T, i).size(); } }
+        for (int i = 0; i < 5; i++) { j.s[i] = sp[i]; j.at[i] = pos[i]; if (fd[i] >= 0) { pos[i] += (off_t)sp[i].n; bytes += sp[i].n; } }
         std::unique_lock<std::mutex> lk(mtx);
         cv_room.wait(lk, [&] { return pending_bytes < ((size_t)1 << 30); }); /* formatted text waiting for its writer: bounded */
         pending_bytes += bytes;
@@ -200,11 +217,11 @@ struct PositionedWriter {
             size_t bytes = 0;
             for (int i = 0; i < 5; i++) {
                 if (fd[i] < 0) continue;
-                const std::string& t = text_of(*j.T, i);
-                bytes += t.size();
+                const Span& t = j.s[i];
+                bytes += t.n;
                 size_t w = 0;
-                while (w < t.size()) {
-                    const ssize_t got = ::pwrite(fd[i], t.data() + w, t.size() - w, j.at[i] + (off_t)w);
+                while (w < t.n) {
+                    const ssize_t got = ::pwrite(fd[i], t.p + w, t.n - w, j.at[i] + (off_t)w);
                     if (got < 0) { if (errno == EINTR) continue; failed = true; break; }
                     w += (size_t)got;
                 }
@@ -782,6 +799,9 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
             }
         } fwd, rev;
         std::vector<uint32_t> name_len, name_r_len;          /* the names cut at their first space (src/Filler.cpp:631-636) */
+        std::vector<uint64_t> name_off;                      /* where the left record's name starts in the batch's text */
+        mtg_formatted* ftext = nullptr;                      /* the text of the simple sites, formatted on the device (page-locked arenas of the library) */
+        std::vector<uint32_t> host_sites;                    /* device formatting: the sites the host formats, ascending; out[q] = the text of host_sites[q] */
         std::vector<long> rev_idx;
         std::string rev_text;
         mtg_results *rf = nullptr, *rr = nullptr;
@@ -791,6 +811,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         {
             if (rf) mtg_results_free(rf);
             if (rr) mtg_results_free(rr);
+            if (ftext) ftext_pool().put(std::move(ftext));
             for (OutText& T : out) piece_pool().put(std::move(T));
             if (text.capacity()) text_pool().put(std::move(text));
         }
@@ -826,12 +847,13 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         parse_records(bt.text, bt.recs);
         const size_t n = bt.recs.size() / 2; /* records 2i / 2i+1 = left / right k-mer, src/Filler.cpp:625-629 */
         bt.n = n;
-        bt.fwd.resize(n); bt.name_len.resize(n); bt.name_r_len.resize(n);
+        bt.fwd.resize(n); bt.name_len.resize(n); bt.name_r_len.resize(n); bt.name_off.resize(n);
         const char* const t0 = bt.text.data();
         for (size_t j = 0; j < n; j++) {
             const BkptRec &l = bt.recs[2 * j], &r = bt.recs[2 * j + 1];
             const void* sp = memchr(l.hdr, ' ', l.hdr_len);
             bt.name_len[j] = sp ? (uint32_t)((const char*)sp - l.hdr) : l.hdr_len;
+            bt.name_off[j] = (uint64_t)(l.hdr - t0);
             sp = memchr(r.hdr, ' ', r.hdr_len);
             bt.name_r_len[j] = sp ? (uint32_t)((const char*)sp - r.hdr) : r.hdr_len;
             bt.fwd.so[j] = (uint64_t)(l.seq - t0); bt.fwd.sl[j] = l.seq_len;
@@ -843,7 +865,11 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         /* the strings stay text: the library sends the block up and encodes on the device (mtg_fill_text) */
         const mtg_text_gaps gf = bt.fwd.view(t0, bt.text.size());
         t_parse += usec() - tp; tp = usec();
-        int rc = mtg_fill_text(idx, &P, &gf, &bt.rf);
+        /* the text of the sites with one solution is written on the device (mtg_fill_text_formatted); MTG_HOST_FORMAT=1: A/B hook, every site by the host's writers */
+        static const bool dev_format = getenv("MTG_HOST_FORMAT") == nullptr;
+        int rc;
+        if (dev_format) { bt.ftext = ftext_pool().get(); rc = mtg_fill_text_formatted(idx, &P, &gf, bt.name_off.data(), bt.name_len.data(), &bt.rf, &bt.ftext); }
+        else rc = mtg_fill_text(idx, &P, &gf, &bt.rf);
         if (rc) return rc;
         t_fill += usec() - tp; tp = usec();
         /* reverse attempt for the sites without solution, src/Filler.cpp:669-680 */
@@ -875,6 +901,29 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
             }
         }
         t_rev += usec() - tp; tp = usec();
+        if (bt.ftext) {
+            /* the device has written the simple sites; the host's writers take the others (reverse attempts, several solutions, records the host
+             * wrote), one small piece per site, placed between the device's bytes when the batch is consumed */
+            mtg_formatted_view fv;
+            if ((rc = mtg_formatted_get(bt.ftext, &fv))) return rc;
+            bt.host_sites.assign(fv.complex_sites, fv.complex_sites + fv.n_complex);
+            bt.out.resize(bt.host_sites.size());
+            std::vector<size_t> pf(bt.host_sites.size(), 0), pm(bt.host_sites.size(), 0);
+            parallel_for((bt.host_sites.size() + 63) / 64, P.nb_host_threads, [&](size_t pc) {
+                std::string info;
+                for (size_t q = pc * 64; q < std::min(bt.host_sites.size(), (pc + 1) * 64); q++) {
+                    const size_t j = bt.host_sites[q];
+                    OutText& T = bt.out[q];
+                    T = piece_pool().get();
+                    const BkptRec &l = bt.recs[2 * j], &r = bt.recs[2 * j + 1];
+                    const SiteRef site{std::string_view(l.hdr, bt.name_len[j]), std::string_view(r.hdr, bt.name_r_len[j]), std::string_view(l.seq, l.seq_len), std::string_view(r.seq, r.seq_len)};
+                    const size_t nsol = format_bkpt_site(T, site, mtg_results_get(bt.rf, j), bt.rev_idx[j] >= 0 ? mtg_results_get(bt.rr, (size_t)bt.rev_idx[j]) : nullptr, O.filter, O.extend, info);
+                    pf[q] = nsol > 0; pm[q] = nsol > 1;
+                }
+            }, 1);
+            bt.filled = (size_t)fv.n_simple;
+            for (size_t q = 0; q < bt.host_sites.size(); q++) { bt.filled += pf[q]; bt.multiple += pm[q]; }
+        } else {
         /* the batch's text, formatted in pieces by the library's worker pool (the writers of src/Filler.cpp:1029-1214) */
         const size_t npieces = (n + FORMAT_CHUNK - 1) / FORMAT_CHUNK;
         bt.out.resize(npieces);
@@ -895,6 +944,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
             }
         }, 1);
         for (size_t pc = 0; pc < npieces; pc++) { bt.filled += pf[pc]; bt.multiple += pm[pc]; }
+        }
         /* records and sequences are in the text now */
         mtg_results_free(bt.rf); bt.rf = nullptr;
         if (bt.rr) { mtg_results_free(bt.rr); bt.rr = nullptr; }
@@ -909,7 +959,30 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         { std::lock_guard<std::mutex> lk(bm); bt = std::move(batches[b]); }
         const long long tw = usec();
         std::shared_ptr<Batch> keep(bt.release()); /* the text lives until its last piece is in the files */
-        for (const OutText& T : keep->out) writer.add(keep, T);
+        if (keep->ftext) {
+            /* the device's bytes in pieces of a few MB (so that several writer threads share a batch), the host's sites between them where they belong */
+            mtg_formatted_view fv;
+            (void)mtg_formatted_get(keep->ftext, &fv);
+            uint64_t cur[3] = {0, 0, 0};
+            const auto device_bytes_up_to = [&](const uint64_t upto[3]) {
+                const size_t piece = (size_t)4 << 20;
+                for (int s3 = 0; s3 < 3; s3++)
+                    while (cur[s3] < upto[s3]) {
+                        PositionedWriter::Span sp[5];
+                        const size_t nb = (size_t)std::min<uint64_t>(piece, upto[s3] - cur[s3]);
+                        sp[s3].p = fv.text[s3] + cur[s3]; sp[s3].n = nb; /* FASTA, info, VCF are streams 0, 1, 2 of the writer as well */
+                        writer.add_spans(keep, sp);
+                        cur[s3] += nb;
+                    }
+            };
+            for (size_t q = 0; q < keep->host_sites.size(); q++) {
+                const uint64_t upto[3] = {fv.complex_off[0][q], fv.complex_off[1][q], fv.complex_off[2][q]};
+                device_bytes_up_to(upto);
+                writer.add(keep, keep->out[q]);
+            }
+            device_bytes_up_to(fv.bytes);
+        } else
+            for (const OutText& T : keep->out) writer.add(keep, T);
         Batch* const btq = keep.get();
         t_write += usec() - tw;
         S.nb_breakpoints += (int)btq->n;

@@ -43,9 +43,15 @@ MTG_DEV bool lean_decide(const Index& ix, const FillCfg& cfg, const GapScratch& 
         if (e.up && popc4(e.out) == 1 && popc4(e.in) == 1) {
             const bool fwd = !up_bwd(e.up); /* the target as given appears as it is stored */
             const uint64_t q = (up_hdr(e.up) + 1) * 32 + (fwd ? up_off(e.up) - 1u : up_off(e.up)); /* first nucleotide of its k-mer in the store */
+            /* the junction behind a k-mer that is NOT solid can be one of the graph all the same (adj_right_t answers for the junction): the
+             * k-mer the store holds there must be the target itself, or the counting search decides (it may still match with mismatches).
+             * Round 4: found by a site whose anchor differs from the graph in its first nucleotide -- the record said 0 errors for 1. */
+            const Kmer tk = make_kmer(target, k);
+            const uint64_t cmpl = 0xAAAAAAAAAAAAAAAAULL & kmask(k);
+            const bool is_target = us_kmer_le(us.words, q, k) == (fwd ? (tk.r ^ cmpl) : (tk.f ^ cmpl));
             const uint32_t clen0 = s_clen(cfg, S)[0];
             const int64_t a0 = (int64_t)(32ull * s_cstart(cfg, S)[0]);
-            for (uint32_t c = 0; c < o.n_cmds && !lean; c++) {
+            for (uint32_t c = 0; c < o.n_cmds && !lean && is_target; c++) {
                 const CopyCmd cm = cmds[c];
                 const bool bwd = (cm.src & 1ull) != 0;
                 if (bwd == fwd) continue; /* the walk must run the way the target reads */

@@ -17,6 +17,7 @@
 #ifndef MTG_FORMAT_H
 #define MTG_FORMAT_H
 #include "mtg_post.h"
+#include <math.h>
 
 namespace mtg {
 
@@ -65,7 +66,7 @@ template <typename Sink> MTG_DEV void fmt_int(Sink& o, int s, long long v)
 MTG_DEV bool fmt_fixed2_ok(float x) { return x >= 0.0f && x < 1.0e9f; }
 template <typename Sink> MTG_DEV void fmt_fixed2(Sink& o, int s, float x)
 {
-    const double t = (double)x * 100.0, fl = floor(t), fr = t - fl;
+    const double t = (double)x * 100.0, fl = ::floor(t), fr = t - fl;
     const unsigned long long f0 = (unsigned long long)fl;
     const unsigned long long r = f0 + ((fr > 0.5 || (fr == 0.5 && (f0 & 1ull))) ? 1ull : 0ull);
     fmt_int(o, s, (long long)(r / 100));

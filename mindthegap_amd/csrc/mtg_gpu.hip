@@ -972,6 +972,108 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         tot->copy_words_exec = ssum[13]; tot->copy_cmds_exec = ssum[14]; tot->scan_words = ssum[15];
     }
 }
+/* ---- the tool's text on the device (mtg_format.h): one wave per site.  pass 0: is the site simple, and how many bytes does it add to the
+ * three files; pass 1 (after the scan): the bytes, at the site's offsets.  The records are the batch's C-ABI records (their seq pointers
+ * are addresses of the HOST arena: the same offsets in the workspace's arena d_seq). */
+struct FmtArgs {
+    const mtg_gap_result* res;
+    const mtg_filled* fil;
+    const char* text;            /* the batch's text block on the device */
+    const uint64_t* source_off;
+    const uint32_t* source_len;
+    const uint64_t* name_off;
+    const uint32_t* name_len;
+    const char* d_seq;           /* the sequence arena on the device */
+    uint64_t host_seq;           /* address the arena has (would have) on the host */
+    uint64_t seq_used;
+    uint64_t host_fil;           /* address of the host's fil array: res[i].filled == host_fil + i * sizeof(mtg_filled) on the common path */
+    FmtRec* rec;
+    char* out[FMT_STREAMS];
+    uint32_t n;
+};
+__device__ __forceinline__ bool fmt_load_site(const FmtArgs& A, uint32_t i, FmtSite& t)
+{
+    const mtg_gap_result r = A.res[i];
+    /* the common path leaves a gap's one solution in slot i of the fil array; anything else (no solution, a record the host wrote) is not ours */
+    if (r.n_filled != 1 || (uint64_t)(uintptr_t)r.filled != A.host_fil + (uint64_t)i * sizeof(mtg_filled)) return false;
+    const mtg_filled f = A.fil[i];
+    const uint64_t q = (uint64_t)(uintptr_t)f.seq;
+    if (q < A.host_seq || q >= A.host_seq + A.seq_used) return false;
+    t.name = A.text + A.name_off[i]; t.name_len = A.name_len[i];
+    t.source = A.text + A.source_off[i]; t.source_len = A.source_len[i];
+    t.seq = A.d_seq + (q - A.host_seq);
+    t.seq_len = fmt_strlen(t.seq);
+    t.nb_nodes = r.nb_nodes; t.total_nt = r.total_nt; t.nb_terminal = r.nb_terminal; t.has_counts = r.has_solution_counts;
+    t.nb_total_filled = r.nb_total_filled; t.nb_reported = r.nb_reported;
+    t.qual = f.qual; t.solution_count = f.solution_count; t.avg = f.avg_coverage; t.median = f.median_coverage;
+    return fmt_site_simple(t);
+}
+__global__ void __launch_bounds__(64) k_fmt_size(FmtArgs A)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= A.n) return;
+    FmtSite t;
+    FmtCount c;
+    c.n[0] = c.n[1] = c.n[2] = 0;
+    const bool simple = fmt_load_site(A, i, t);
+    if (simple) format_site(c, t);
+    if (threadIdx.x == 0) { FmtRec r; r.size[0] = c.n[0]; r.size[1] = c.n[1]; r.size[2] = c.n[2]; r.simple = simple ? 1u : 0u; r.off[0] = r.off[1] = r.off[2] = 0; A.rec[i] = r; }
+}
+/* exclusive prefix sums of the three sizes in site order, the list of the sites left to the host with the offsets where their text belongs;
+ * tot[0..2] = bytes, tot[3] = simple sites, tot[4] = sites for the host.  One workgroup. */
+__global__ void __launch_bounds__(1024) k_fmt_scan(FmtRec* rec, uint32_t n, uint32_t* cplx, uint64_t* cplx_off, unsigned long long* tot)
+{
+    __shared__ unsigned long long wsum[16][4];
+    __shared__ unsigned long long carry[4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    if (t < 4) carry[t] = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
+        const uint32_t i = b0 + t;
+        unsigned long long v[4] = {0, 0, 0, 0};
+        if (i < n) { v[0] = rec[i].size[0]; v[1] = rec[i].size[1]; v[2] = rec[i].size[2]; v[3] = rec[i].simple ? 0 : 1; }
+        unsigned long long incl[4];
+        for (int j = 0; j < 4; j++) {
+            unsigned long long x = v[j];
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+                if ((int)lane >= d) x += ((unsigned long long)hi << 32) | lo;
+            }
+            incl[j] = x;
+            if (lane == 63) wsum[wv][j] = x;
+        }
+        __syncthreads();
+        unsigned long long before[4];
+        for (int j = 0; j < 4; j++) {
+            unsigned long long x = carry[j];
+            for (uint32_t w2 = 0; w2 < wv; w2++) x += wsum[w2][j];
+            before[j] = x;
+        }
+        if (i < n) {
+            const unsigned long long o0 = before[0] + incl[0] - v[0], o1 = before[1] + incl[1] - v[1], o2 = before[2] + incl[2] - v[2];
+            rec[i].off[0] = o0; rec[i].off[1] = o1; rec[i].off[2] = o2;
+            if (v[3]) { const unsigned long long c = before[3] + incl[3] - 1; cplx[c] = i; cplx_off[3 * c] = o0; cplx_off[3 * c + 1] = o1; cplx_off[3 * c + 2] = o2; }
+        }
+        __syncthreads();
+        if (t < 4) { unsigned long long x = carry[t]; for (int w2 = 0; w2 < 16; w2++) x += wsum[w2][t]; carry[t] = x; }
+        __syncthreads();
+    }
+    if (t < 3) tot[t] = carry[t];
+    if (t == 3) { tot[4] = carry[3]; tot[3] = (unsigned long long)n - carry[3]; }
+}
+__global__ void __launch_bounds__(64) k_fmt_write(FmtArgs A)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= A.n) return;
+    const FmtRec r = A.rec[i];
+    if (!r.simple) return;
+    FmtSite t;
+    if (!fmt_load_site(A, i, t)) return;
+    FmtWrite w;
+    w.p[0] = A.out[0] + r.off[0]; w.p[1] = A.out[1] + r.off[1]; w.p[2] = A.out[2] + r.off[2];
+    format_site(w, t);
+}
+
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
 __global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* raw, SlotRec* recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
                                              const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t* retry_list, uint32_t* general_list, uint32_t n)
@@ -1998,7 +2100,8 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
     if (!streamed) HIP_TRY(hipMemcpy(idx->dev.us.ab, d.ab.data(), nw * 32, hipMemcpyHostToDevice));
     else {
         const uint64_t total = nw * 32, piece = (uint64_t)32 << 20, npieces = (total + piece - 1) / piece;
-        const int nthreads = (int)std::min<uint64_t>(npieces, (uint64_t)std::min(8, std::max(2, Pool::cpu_budget() / 2)));
+        const int env_threads = getenv("MTG_LOAD_THREADS") ? atoi(getenv("MTG_LOAD_THREADS")) : 0;
+        const int nthreads = (int)std::min<uint64_t>(npieces, (uint64_t)(env_threads > 0 ? std::min(env_threads, 32) : std::min(8, std::max(2, Pool::cpu_budget() / 2))));
         uint8_t* dst = idx->dev.us.ab;
         const int device = idx->device;
         for (int t = 0; t < nthreads; t++)
@@ -2657,7 +2760,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 const bool wired = sink.wire_dev != nullptr && identity && tier == 0 && wl.total <= sink.wire_cap && tot.n_retry == 0 && tot.n_general == 0;
                 if (sink.wire_dev && identity && tier == 0) { sink.wire_ok = wired; sink.wire_bytes = wired ? wl.total : 0; }
                 const char* seq_src = wired ? (const char*)sink.wire_dev + wl.o_seq : (sink.seq_dev ? sink.seq_dev : d_seq.as<char>());
-                if (!sink.seq_on_device && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], seq_src + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
+                if (!sink.seq_on_device && !sink.seq_stays_in_workspace && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], seq_src + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
                 if (tot.end[3] > tot.begin[3]) HIP_TRY(hipMemcpyAsync(sink.ext + tot.begin[3], d_ext.as<char>() + tot.begin[3], tot.end[3] - tot.begin[3], hipMemcpyDeviceToHost, stream));
             }
             std::vector<uint32_t> rlist(tot.n_retry), glist(tot.n_general);
@@ -2784,8 +2887,110 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         rc = MTG_ERR_OVERFLOW;
     }
     if (launches > 1) sink.in_gap_order = false;
+    sink.device_records_whole = rc == MTG_OK && launches == 1 && st.n_retried_gaps == 0 && special.special.empty();
     if (stats) *stats = st;
     return rc;
+}
+
+int workspace_arena_download(const mtg_index* idx, Workspace* ws, char* dst, uint64_t bytes)
+{
+    if (int rc = use_device_of(idx)) return rc;
+    if (!ws || !ws->ptr[Workspace::SLOT_SEQ] || ws->cap[Workspace::SLOT_SEQ] < bytes) { set_error("the workspace holds no sequence arena of %llu bytes", (unsigned long long)bytes); return MTG_ERR_ARG; }
+    if (bytes) HIP_TRY(hipMemcpy(dst, ws->ptr[Workspace::SLOT_SEQ], bytes, hipMemcpyDeviceToHost));
+    return MTG_OK;
+}
+/* the text of a batch's simple sites, formatted on the device and brought to page-locked host memory (mtg_internal.h: FormatIn / FormatOut) */
+int format_run(const mtg_index* idx, const FormatIn& fi, FormatOut& out)
+{
+    if (int rc = use_device_of(idx)) return rc;
+    if (!fi.ws || !fi.ws->stream) { set_error("format_run: no batch has run on this workspace"); return MTG_ERR_ARG; }
+    Workspace& ws = *fi.ws;
+    const hipStream_t stream = (hipStream_t)ws.stream;
+    const uint32_t n = (uint32_t)fi.n;
+    out.n = n; out.n_simple = 0;
+    out.bytes[0] = out.bytes[1] = out.bytes[2] = 0;
+    out.complex_sites.clear();
+    for (int s2 = 0; s2 < FMT_STREAMS; s2++) out.complex_off[s2].clear();
+    if (n == 0) return MTG_OK;
+    int slot = Workspace::SLOT_FMT0;
+    auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = slot++; return b; };
+    WsBuf d_names = wsbuf(), d_rec = wsbuf(), d_cplx = wsbuf(), d_tot = wsbuf(), d_o0 = wsbuf(), d_o1 = wsbuf(), d_o2 = wsbuf(), d_recs_up = wsbuf();
+    HIP_TRY(d_names.alloc((size_t)n * 12));
+    HIP_TRY(d_rec.alloc((size_t)n * sizeof(FmtRec)));
+    HIP_TRY(d_cplx.alloc((size_t)n * 28 + 64));
+    HIP_TRY(d_tot.alloc(64));
+    HIP_TRY(hipMemcpyAsync(d_names.p, fi.name_off, (size_t)n * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync((uint8_t*)d_names.p + (size_t)n * 8, fi.name_len, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    FmtArgs A;
+    if (fi.device_records_whole && ws.ptr[Workspace::SLOT_RES] && ws.ptr[Workspace::SLOT_FIL]) {
+        A.res = (const mtg_gap_result*)ws.ptr[Workspace::SLOT_RES];
+        A.fil = (const mtg_filled*)ws.ptr[Workspace::SLOT_FIL];
+    } else { /* several launches, re-run gaps, gaps the host finished: the records as the host has them go up */
+        HIP_TRY(d_recs_up.alloc((size_t)n * (sizeof(mtg_gap_result) + sizeof(mtg_filled))));
+        HIP_TRY(hipMemcpyAsync(d_recs_up.p, fi.res, (size_t)n * sizeof(mtg_gap_result), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync((uint8_t*)d_recs_up.p + (size_t)n * sizeof(mtg_gap_result), fi.fil, (size_t)n * sizeof(mtg_filled), hipMemcpyHostToDevice, stream));
+        A.res = (const mtg_gap_result*)d_recs_up.p;
+        A.fil = (const mtg_filled*)((uint8_t*)d_recs_up.p + (size_t)n * sizeof(mtg_gap_result));
+    }
+    const uint8_t* c = (const uint8_t*)ws.ptr[Workspace::SLOT_TEXT_BLOCK];
+    A.text = (const char*)(c + FillInput::text_block_off(fi.n, fi.nt, 5));
+    A.source_off = (const uint64_t*)(c + FillInput::text_block_off(fi.n, fi.nt, 0));
+    A.source_len = (const uint32_t*)(c + FillInput::text_block_off(fi.n, fi.nt, 3));
+    A.name_off = (const uint64_t*)d_names.p;
+    A.name_len = (const uint32_t*)((uint8_t*)d_names.p + (size_t)n * 8);
+    A.d_seq = (const char*)ws.ptr[Workspace::SLOT_SEQ];
+    A.host_seq = (uint64_t)(uintptr_t)fi.host_seq;
+    A.seq_used = fi.seq_used;
+    A.host_fil = (uint64_t)(uintptr_t)fi.fil;
+    A.rec = d_rec.as<FmtRec>();
+    A.out[0] = A.out[1] = A.out[2] = nullptr;
+    A.n = n;
+    EventSet events;
+    hipEvent_t e0, e1;
+    HIP_TRY(events.make(e0));
+    HIP_TRY(events.make(e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(k_fmt_size, dim3(n), dim3(64), 0, stream, A);
+    hipLaunchKernelGGL(k_fmt_scan, dim3(1), dim3(1024), 0, stream, d_rec.as<FmtRec>(), n, d_cplx.as<uint32_t>(), (uint64_t*)((uint8_t*)d_cplx.p + (((size_t)n * 4 + 7) & ~(size_t)7)), d_tot.as<unsigned long long>());
+    HIP_TRY(hipGetLastError());
+    unsigned long long* h_tot = (unsigned long long*)staging_host(&ws, Workspace::NHOST - 2, 64);
+    if (!h_tot) { set_error("no page-locked memory"); return MTG_ERR_NOMEM; }
+    HIP_TRY(hipMemcpyAsync(h_tot, d_tot.p, 40, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    WsBuf* d_o[3] = {&d_o0, &d_o1, &d_o2};
+    for (int s2 = 0; s2 < FMT_STREAMS; s2++) {
+        out.bytes[s2] = h_tot[s2];
+        HIP_TRY(d_o[s2]->alloc((size_t)h_tot[s2] + 64));
+        A.out[s2] = d_o[s2]->as<char>();
+        if (out.cap[s2] < h_tot[s2] + 64) {
+            pinned_free(out.text[s2]);
+            out.cap[s2] = (size_t)h_tot[s2] + (size_t)h_tot[s2] / 4 + 4096;
+            out.text[s2] = (char*)pinned_alloc(out.cap[s2]);
+            if (!out.text[s2]) { out.cap[s2] = 0; set_error("no page-locked memory for %llu bytes of text", h_tot[s2]); return MTG_ERR_NOMEM; }
+        }
+    }
+    out.n_simple = h_tot[3];
+    const size_t nc = (size_t)h_tot[4];
+    hipLaunchKernelGGL(k_fmt_write, dim3(n), dim3(64), 0, stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, stream));
+    {
+        CopyTurn copy_turn(idx->device);
+        for (int s2 = 0; s2 < FMT_STREAMS; s2++)
+            if (out.bytes[s2]) HIP_TRY(hipMemcpyAsync(out.text[s2], A.out[s2], out.bytes[s2], hipMemcpyDeviceToHost, stream));
+        std::vector<uint64_t> co(3 * nc);
+        out.complex_sites.resize(nc);
+        if (nc) {
+            HIP_TRY(hipMemcpyAsync(out.complex_sites.data(), d_cplx.p, nc * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(co.data(), (uint8_t*)d_cplx.p + (((size_t)n * 4 + 7) & ~(size_t)7), nc * 24, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int s2 = 0; s2 < FMT_STREAMS; s2++) { out.complex_off[s2].resize(nc); for (size_t i = 0; i < nc; i++) out.complex_off[s2][i] = co[3 * i + s2]; }
+    }
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    out.kernel_ms = ms;
+    return MTG_OK;
 }
 
 int nw_run(const mtg_index* idx, const std::vector<NwPair>& pairs, std::vector<uint32_t>& matches, Workspace* ws)

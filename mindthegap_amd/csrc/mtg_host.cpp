@@ -843,6 +843,11 @@ struct mtg_results {
 struct mtg_contigs {
     std::vector<std::vector<std::string>> c;
 };
+/* the text of a batch's simple sites, formatted on the device (mtg_fill_text_formatted); the arenas are page-locked and kept from batch to batch */
+struct mtg_formatted {
+    mtgi::FormatOut o;
+    ~mtg_formatted() { for (int s = 0; s < mtg::FMT_STREAMS; s++) mtgi::pinned_free(o.text[s]); }
+};
 
 /* ---- the relocatable form of a result set (include/mtg_fill.h: mtg_wire_*) */
 namespace {
@@ -948,8 +953,14 @@ struct WireReq { /* the batch also in relocatable form, in a device buffer of th
     uint64_t cap = 0, tag = 0;
     uint64_t* bytes = nullptr;
 };
+/* mtg_fill_text_formatted: the names of the sites (into the caller's text block) and the object that receives the text */
+struct FormatReq {
+    const uint64_t* name_off;
+    const uint32_t* name_len;
+    mtg_formatted* out;
+};
 int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillInput& in, const mtg_gap* gaps, size_t n, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes,
-                    mtg_results** out, double t_begin, char* d_seq_out = nullptr, const WireReq* wire = nullptr, const mtg_text_gaps* tg = nullptr)
+                    mtg_results** out, double t_begin, char* d_seq_out = nullptr, const WireReq* wire = nullptr, const mtg_text_gaps* tg = nullptr, const FormatReq* fmt = nullptr)
 {
     using namespace mtgi;
     static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
@@ -978,6 +989,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     sink.seq_dev = d_seq_out;
     sink.ext = R->ext; sink.ext_cap = R->ext_cap;
     if (wire) { sink.wire_dev = wire->dev; sink.wire_cap = wire->cap; sink.wire_tag = wire->tag; }
+    sink.seq_stays_in_workspace = fmt != nullptr && !seq_out; /* the text is formatted on the device: the ASCII arena does not come to the host */
     sink.grow_seq = [&](size_t need, size_t keep) -> bool {
         if (R->seq_external) return false;
         const size_t cap = need + need / 4 + 4096;
@@ -1120,6 +1132,24 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
             *wire->bytes = need;
         }
     }
+    if (fmt && tg) {
+        /* the tool's text for the sites with one solution of the common path, on the device (mtg_format.h); the records and the arena are where
+         * device_run left them on this batch's workspace */
+        FormatIn fi;
+        fi.ws = in.ws; fi.n = n; fi.nt = n ? tg->dict_first[n] : 0;
+        fi.res = R->res; fi.fil = R->fil;
+        fi.device_records_whole = sink.device_records_whole && special.special.empty();
+        fi.host_seq = R->seq; fi.seq_used = sink.seq_used;
+        fi.host_text = tg->text; fi.source_off = tg->source_off; fi.source_len = tg->source_len;
+        fi.name_off = fmt->name_off; fi.name_len = fmt->name_len;
+        if (int frc = format_run(idx, fi, fmt->out->o)) return frc;
+        /* a site left to the caller whose sequence lies in the arena: the arena comes to the host after all (rare: a value the formatter does not cover) */
+        bool need_arena = false;
+        const uintptr_t a_lo = (uintptr_t)R->seq, a_hi = a_lo + sink.seq_used;
+        for (uint32_t ci : fmt->out->o.complex_sites)
+            for (int j = 0; j < R->res[ci].n_filled; j++) { const uintptr_t q = (uintptr_t)R->res[ci].filled[j].seq; if (q >= a_lo && q < a_hi) need_arena = true; }
+        if (need_arena && sink.seq_stays_in_workspace) { if (int drc = workspace_arena_download(idx, in.ws, R->seq, sink.seq_used)) return drc; }
+    }
     st.total_ms = now_ms() - t_begin;
     stats_store(st);
     guard.r = nullptr;
@@ -1169,7 +1199,7 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
 }
 /* mtg_fill_text: what the host does for a batch whose strings are still text -- the integer columns of block A from the caller's arrays
  * (no string is looked at), the offset arrays and the block itself copied into the page-locked text block; the device does the rest */
-static int fill_text_impl(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes, mtg_results** out)
+static int fill_text_impl(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes, mtg_results** out, const FormatReq* fmt = nullptr)
 {
     using namespace mtgi;
     if (!idx || !p || !out || !g) { set_error("null argument"); return MTG_ERR_ARG; }
@@ -1232,8 +1262,27 @@ static int fill_text_impl(const mtg_index* idx, const mtg_params* p, const mtg_t
         const size_t piece = (size_t)1 << 20, npieces = ((size_t)tb + piece - 1) / piece;
         parallel_for(npieces, p->nb_host_threads, [&](size_t i) { memcpy(dst + i * piece, g->text + i * piece, std::min(piece, (size_t)tb - i * piece)); }, 1);
     }
-    return fill_marshalled(idx, p, in, nullptr, n, seq_out, seq_cap, seq_bytes, out, t_begin, nullptr, nullptr, g);
+    if (fmt) for (size_t i = 0; i < n; i++) if (fmt->name_off[i] > tb || fmt->name_len[i] > tb - fmt->name_off[i]) { set_error("gap %zu: the name lies outside the text block", i); return MTG_ERR_ARG; }
+    return fill_marshalled(idx, p, in, nullptr, n, seq_out, seq_cap, seq_bytes, out, t_begin, nullptr, nullptr, g, fmt);
 }
+int mtg_fill_text_formatted(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, const uint64_t* name_off, const uint32_t* name_len, mtg_results** out, mtg_formatted** text)
+{
+    if (!text || (g && g->n && (!name_off || !name_len))) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    if (!*text) *text = new mtg_formatted();
+    FormatReq fr{name_off, name_len, *text};
+    return fill_text_impl(idx, p, g, nullptr, 0, nullptr, out, &fr);
+}
+int mtg_formatted_get(const mtg_formatted* t, mtg_formatted_view* v)
+{
+    if (!t || !v) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    for (int s = 0; s < 3; s++) { v->text[s] = t->o.text[s]; v->bytes[s] = t->o.bytes[s]; v->complex_off[s] = t->o.complex_off[s].data(); }
+    v->n_sites = t->o.n; v->n_simple = t->o.n_simple;
+    v->complex_sites = t->o.complex_sites.data();
+    v->n_complex = t->o.complex_sites.size();
+    v->kernel_ms = t->o.kernel_ms;
+    return MTG_OK;
+}
+void mtg_formatted_free(mtg_formatted* t) { delete t; }
 int mtg_fill_text(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, mtg_results** out) { return fill_text_impl(idx, p, g, nullptr, 0, nullptr, out); }
 int mtg_fill_text_serial(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
 {

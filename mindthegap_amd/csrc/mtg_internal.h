@@ -10,6 +10,7 @@
 #include "mtg_paths.h"
 #include "mtg_emit.h"
 #include "mtg_copy.h"
+#include "mtg_format.h"
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -28,7 +29,9 @@
 namespace mtgi {
 /* grow-only device buffers reused by successive batches on one index */
 struct Workspace {
-    enum { NSLOTS = 32, NHOST = 16 };
+    enum { NSLOTS = 40, NHOST = 16 };
+    /* slots device_run fills that a later step of the same batch reads (format_run): the marshalled text block and the sequence arena */
+    enum { SLOT_TEXT_BLOCK = 2, SLOT_SEQ = 14, SLOT_RES = 16, SLOT_FIL = 17, SLOT_FMT0 = 32 };
     void* ptr[NSLOTS] = {nullptr};
     size_t cap[NSLOTS] = {0};
     /* page-locked host staging blocks: 0..2 = the marshalled input of a batch, 3.. = what the first chunks of a batch brought back */
@@ -432,6 +435,9 @@ struct ResultSink {
     size_t seq_cap = 0;
     char* seq_dev = nullptr;       /* a buffer of the caller on the index's device (seq_cap bytes): the result kernel writes the arena there instead of into the workspace */
     bool seq_on_device = false;    /* no host copy is wanted: seq == seq_dev, the records carry device addresses and nothing of the arena is copied to the host */
+    bool seq_stays_in_workspace = false; /* the arena is produced in the workspace's own device buffer and NOT copied to `seq` (the records still carry the
+                                            addresses it would have there): the batch's text is formatted on the device next (format_run) */
+    bool device_records_whole = false;   /* out: the workspace's device copies of the records are those of the whole batch (one launch, nothing re-run, no gap for the host) */
     char* ext = nullptr;           /* extension arena; ext[0] = 0 is the empty string of every record without extension */
     size_t ext_cap = 0;
     /* an arena turned out too small: must replace it by a block of at least `need` bytes whose first `keep` bytes are those of the old
@@ -572,6 +578,35 @@ int index_dump(const mtg_index* idx, IndexDump& d);
 int index_from_dump(const IndexDump& d, mtg_index** out);
 
 void stats_store(const mtg_batch_stats& s);
+
+/* ---- the tool's text, formatted on the device (mtg_format.h).  Called by the batch that has just run device_run on `ws` (the workspace is
+ * still its own): the marshalled text block and the sequence arena are where that run left them. */
+struct FormatIn {
+    Workspace* ws = nullptr;
+    size_t n = 0, nt = 0;                 /* sites, dictionary entries (the layout of the text block) */
+    const mtg_gap_result* res = nullptr;  /* the batch's records as the caller will see them (host) */
+    const mtg_filled* fil = nullptr;      /* slot i = site i (common path) */
+    bool device_records_whole = false;
+    const char* host_seq = nullptr;       /* the address range the records' seq pointers of the common path lie in ... */
+    uint64_t seq_used = 0;                /* ... and its length: those sequences are in the workspace's arena at the same offsets */
+    const char* host_text = nullptr;      /* the caller's block (the emulation reads it; the device has its copy) */
+    const uint64_t* source_off = nullptr; /* per site, into the block */
+    const uint32_t* source_len = nullptr;
+    const uint64_t* name_off = nullptr;   /* breakpointName of site i = text[name_off[i], + name_len[i]) */
+    const uint32_t* name_len = nullptr;
+};
+struct FormatOut {
+    char* text[mtg::FMT_STREAMS] = {nullptr, nullptr, nullptr}; /* page-locked, grow-only */
+    size_t cap[mtg::FMT_STREAMS] = {0, 0, 0};
+    uint64_t bytes[mtg::FMT_STREAMS] = {0, 0, 0};
+    uint64_t n = 0, n_simple = 0;
+    std::vector<uint32_t> complex_sites;                  /* ascending: the sites the device did not write */
+    std::vector<uint64_t> complex_off[mtg::FMT_STREAMS];  /* where their text belongs: the bytes of the simple sites before them */
+    double kernel_ms = 0;
+};
+int format_run(const mtg_index* idx, const FormatIn& fi, FormatOut& out);
+/* the sequence arena the batch's device_run left in the workspace, to host memory (a batch whose arena stayed on the device and is needed after all) */
+int workspace_arena_download(const mtg_index* idx, Workspace* ws, char* dst, uint64_t bytes);
 
 /* ---- the multi-contig path on the host (gaps whose target is not on contig 0) ------------------------------------------------------- */
 struct Solution { /* filled_insertion_t, src/Utils.hpp:46-104 */

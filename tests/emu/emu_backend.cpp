@@ -306,6 +306,59 @@ int index_from_dump(const IndexDump& d0, mtg_index** out)
     (*out)->info.abundance_auto = d.abundance_auto;
     return MTG_OK;
 }
+/* stand-in for k_fmt_size / k_fmt_scan / k_fmt_write: the same formatter (mtg_format.h), one site after the other.  The emulation's arena is host
+ * memory: the records' seq pointers are followed as they are. */
+int format_run(const mtg_index*, const FormatIn& fi, FormatOut& out)
+{
+    const size_t n = fi.n;
+    out.n = n; out.n_simple = 0;
+    out.complex_sites.clear();
+    for (int s = 0; s < FMT_STREAMS; s++) { out.complex_off[s].clear(); out.bytes[s] = 0; }
+    std::vector<FmtSite> sites(n);
+    std::vector<char> simple(n, 0);
+    std::vector<FmtRec> rec(n);
+    uint64_t cur[FMT_STREAMS] = {0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        const mtg_gap_result& r = fi.res[i];
+        FmtSite& t = sites[i];
+        bool ok = r.n_filled == 1 && r.filled == fi.fil + i;
+        if (ok) {
+            const mtg_filled& f = fi.fil[i];
+            const uintptr_t q = (uintptr_t)f.seq;
+            ok = q >= (uintptr_t)fi.host_seq && q < (uintptr_t)fi.host_seq + fi.seq_used;
+            if (ok) {
+                t.name = fi.host_text + fi.name_off[i]; t.name_len = fi.name_len[i];
+                t.source = fi.host_text + fi.source_off[i]; t.source_len = fi.source_len[i];
+                t.seq = f.seq; t.seq_len = fmt_strlen(f.seq);
+                t.nb_nodes = r.nb_nodes; t.total_nt = r.total_nt; t.nb_terminal = r.nb_terminal; t.has_counts = r.has_solution_counts;
+                t.nb_total_filled = r.nb_total_filled; t.nb_reported = r.nb_reported;
+                t.qual = f.qual; t.solution_count = f.solution_count; t.avg = f.avg_coverage; t.median = f.median_coverage;
+                ok = fmt_site_simple(t);
+            }
+        }
+        simple[i] = ok;
+        FmtCount c;
+        c.n[0] = c.n[1] = c.n[2] = 0;
+        if (ok) format_site(c, t);
+        for (int s = 0; s < FMT_STREAMS; s++) { rec[i].size[s] = c.n[s]; rec[i].off[s] = cur[s]; cur[s] += c.n[s]; }
+        if (!ok) { out.complex_sites.push_back((uint32_t)i); for (int s = 0; s < FMT_STREAMS; s++) out.complex_off[s].push_back(rec[i].off[s]); }
+        else out.n_simple++;
+    }
+    for (int s = 0; s < FMT_STREAMS; s++) {
+        out.bytes[s] = cur[s];
+        if (out.cap[s] < cur[s] + 64) { free(out.text[s]); out.cap[s] = (size_t)cur[s] + 4096; out.text[s] = (char*)malloc(out.cap[s]); memset(out.text[s], 0xA5, out.cap[s]); }
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (!simple[i]) continue;
+        FmtWrite w;
+        for (int s = 0; s < FMT_STREAMS; s++) w.p[s] = out.text[s] + rec[i].off[s];
+        format_site(w, sites[i]);
+        for (int s = 0; s < FMT_STREAMS; s++) if (w.p[s] != out.text[s] + rec[i].off[s] + rec[i].size[s]) { set_error("formatter: the size pass and the write pass disagree at site %zu", i); return MTG_ERR_OVERFLOW; }
+    }
+    return MTG_OK;
+}
+int workspace_arena_download(const mtg_index*, Workspace*, char*, uint64_t) { return MTG_OK; } /* the emulation's arena is the host's */
+
 int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink)
 {
     std::vector<uint64_t> k;

@@ -3,6 +3,7 @@
  * (pext packing, k-mer by bit reversal, validity tests) against encode_kmer / per-character loops.  Links with emu_backend.cpp.  Prints OK. */
 #include "../../mindthegap_amd/csrc/mtg_host.cpp"
 #include <random>
+#include <cmath>
 
 int main()
 {
@@ -103,6 +104,32 @@ int main()
         for (size_t a = 1; a < mono.size(); a++) mono[a] = 1000000 / (a * a);
         if (mtgi::auto_cutoff(std::vector<uint64_t>{0, 5, 3}, 3) != 3) { fprintf(stderr, "auto_cutoff: tiny histogram\n"); return 1; }
         (void)mono;
+    }
+    /* "%.2f" of the device formatter (mtg_format.h: fmt_fixed2, exact for a float promoted to double) against printf: random values, exact
+     * ties (multiples of 1/8, sums over n for the n that divide 200), and the floats next to them */
+    {
+        struct Buf { char b[64]; int n = 0; void ch(int, char c) { b[n++] = c; } void bytes(int, const char* p, uint32_t l) { memcpy(b + n, p, l); n += (int)l; } };
+        auto check = [&](float x) -> bool {
+            if (!mtg::fmt_fixed2_ok(x)) return true;
+            Buf o;
+            mtg::fmt_fixed2(o, 0, x);
+            char want[64];
+            const int wn = snprintf(want, sizeof want, "%.2f", (double)x);
+            if (wn != o.n || memcmp(want, o.b, (size_t)wn) != 0) { fprintf(stderr, "fmt_fixed2(%.9g) = %.*s, printf says %s\n", (double)x, o.n, o.b, want); return false; }
+            return true;
+        };
+        std::uniform_real_distribution<float> U(0.f, 3000.f), V(0.f, 9.9e8f);
+        for (int i = 0; i < 2000000; i++) if (!check(U(rng)) || !check(V(rng))) return 1;
+        for (uint32_t m = 0; m < 400000; m++) {
+            const float t = (float)m / 8.0f; /* .125, .375, .625, .875: exact ties of the second decimal */
+            if (!check(t) || !check(std::nextafter(t, 0.f)) || !check(std::nextafter(t, 1e9f))) return 1;
+        }
+        for (uint32_t n : {1u, 2u, 4u, 5u, 8u, 10u, 20u, 25u, 40u, 50u, 100u, 200u, 31u, 970u, 333u})
+            for (uint32_t sum = 0; sum < 60000; sum += 7) if (!check((float)sum / (float)n)) return 1; /* avg = sum / (float)n, src/Filler.cpp:986 */
+        /* atoi of a token */
+        for (const char* tkn : {"0", "12", "+12", "-7", " 42", "x3", "", "0012", "99999999999", "3x", "\t5"}) {
+            if (mtg::fmt_atoi(tkn, (uint32_t)strlen(tkn)) != (long long)atoi(tkn)) { fprintf(stderr, "fmt_atoi(\"%s\") differs from atoi\n", tkn); return 1; }
+        }
     }
     printf("OK\n");
     return 0;

@@ -1105,3 +1105,39 @@ def test_wire_payload_with_wrapping_sizes_is_refused(emu_product):
         L.WireResults(payload)
     assert "FORMAT" in str(e.value) or "payload" in str(e.value)
     # and a well-formed payload still loads (test_results_over_the_wire covers the contents)
+
+
+def test_device_formatted_text_equals_the_host_writers(emu_product, tmp_path):
+    """round 4: `MindTheGap fill -bkpt` writes the text of every site with one solution on the device (mtg_format.h: FASTA header + sequence, info
+    line, VCF line with its name tokens, repeat size, %.2f numbers); the host's writers -- the restatement of src/Filler.cpp:1029-1214 the
+    goldens pin -- take the others.  The same run with MTG_HOST_FORMAT=1 (every site by the host) must give the same files, byte for
+    byte: names with 7, 8 and other numbers of tokens, a trailing underscore, positions atoi reads in its own way, sites without solution
+    (reverse attempt), -extend and -filter, batches of 4 sites so that host and device text interleave"""
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=40, n_sites=36, seed=9)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    o.close()
+    idxf = str(tmp_path / "s.mtgidx")
+    _write_idx(idxf, km, ct)
+    names = ["bkpt%d_chr1_pos_%d_fuzzy_0_HOM", "bkpt%d_chr2_x_pos_%d_fuzzy_0_HET", "plain%d_%d", "bkpt%d_chr1_pos_+%d_fuzzy_0_HET", "bkpt%d_chr1_pos_x%d_fuzzy_0_HOM",
+             "bkpt%d_chr1_pos_%d_fuzzy_0_HOM_", "a%d_b_c_d_e_f_g_h_i_j_%d", "bkpt%d_chrX_pos_00%d_fuzzy_3_HET"]
+    bk = str(tmp_path / "s.breakpoints")
+    with open(bk, "w") as f:
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            if i % 6 == 4:
+                r = _rc(l)  # nothing in between: no solution forward, reverse attempt
+            if i % 9 == 7:
+                l = l[:30] + ("A" if l[30] != "A" else "C")  # a source that is not in the graph: no solution either way
+            nm = names[i % len(names)] % (i, 1000 + 37 * i)
+            f.write(">%s left_kmer\n%s\n>%s right_kmer\n%s\n" % (nm, l, nm, r))
+    outs = {}
+    for mode, env in (("device", None), ("host", "1")):
+        with _env("MTG_HOST_FORMAT", env), _env("MTG_CLI_BATCH", "4"):
+            assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / mode), "-extend", "-filter"]) == 0
+        outs[mode] = {e: open(str(tmp_path / mode) + e, "rb").read() for e in (".insertions.fasta", ".info.txt", ".extensions.fasta")}
+        outs[mode][".vcf"] = b"\n".join(l for l in open(str(tmp_path / mode) + ".insertions.vcf", "rb").read().split(b"\n") if not l.startswith(b"##"))
+    for e in outs["host"]:
+        assert outs["device"][e] == outs["host"][e], e
+    assert outs["host"][".insertions.fasta"].count(b">") >= 20 and len(outs["host"][".vcf"]) > 2000
