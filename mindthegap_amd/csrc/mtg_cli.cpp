@@ -172,32 +172,6 @@ struct PositionedWriter {
     size_t pending_bytes = 0;
     bool done = false;
     std::atomic<bool> failed{false};
-    /* Mapped output (MTG_WRITE_MMAP=0 turns it off).  write(2) on one file is serialised by the file's lock: on the memory-backed file system
-     * of the GPU box any number of threads writing ONE file reach 8.7 GB/s together (scripts/tmpfs_write_ceiling.py), which held the tool at
-     * 11-12 M sites/s.  Through a shared mapping the writer threads fault the file's pages in side by side: the file is grown in steps of
-     * CHUNK bytes, each step mapped once, the bytes copied with memcpy; finish() cuts the file to its length. */
-    enum : size_t { CHUNK = (size_t)256 << 20 };
-    struct Mapped { std::vector<char*> chunk; off_t size = 0; bool off = false; };
-    Mapped map_[5];
-    std::mutex map_mtx;
-    bool use_mmap = true;
-    /* address of byte `at` of stream i (its chunk mapped on demand); nullptr: this stream is written with pwrite */
-    char* mapped(int i, off_t at)
-    {
-        Mapped& m = map_[i];
-        const size_t c = (size_t)at / CHUNK;
-        std::lock_guard<std::mutex> lk(map_mtx);
-        if (m.off) return nullptr;
-        if (m.chunk.size() <= c) m.chunk.resize(c + 1, nullptr);
-        if (!m.chunk[c]) {
-            const off_t need = (off_t)((c + 1) * CHUNK);
-            if (m.size < need) { if (ftruncate(fd[i], need) != 0) { m.off = true; return nullptr; } m.size = need; }
-            void* p = mmap(nullptr, CHUNK, PROT_READ | PROT_WRITE, MAP_SHARED, fd[i], (off_t)(c * CHUNK));
-            if (p == MAP_FAILED) { m.off = true; return nullptr; }
-            m.chunk[c] = (char*)p;
-        }
-        return m.chunk[c] + ((size_t)at - c * CHUNK);
-    }
     explicit PositionedWriter(Files& f) : F(f)
     {
         for (int i = 0; i < 5; i++) {
@@ -205,7 +179,6 @@ struct PositionedWriter {
             fd[i] = -1; pos[i] = 0;
             if (s) { fflush(s); fd[i] = fileno(s); pos[i] = ftello(s); }
         }
-        if (const char* e = getenv("MTG_WRITE_MMAP")) use_mmap = atoi(e) != 0;
         const int nw = std::max(1, std::min(12, Pool::cpu_budget() - 2)); /* a memory-backed file takes ≈ 1.2 GB/s from a thread (page allocation + copy): 6 writers were the tool's last 85 ms */
         for (int t = 0; t < nw; t++) threads.emplace_back([this] { run(); });
     }
@@ -247,14 +220,6 @@ struct PositionedWriter {
                 const Span& t = j.s[i];
                 bytes += t.n;
                 size_t w = 0;
-                while (use_mmap && w < t.n) { /* through the mapping, chunk by chunk */
-                    const off_t at = j.at[i] + (off_t)w;
-                    char* dst = mapped(i, at);
-                    if (!dst) break; /* this stream cannot be mapped: pwrite takes the rest */
-                    const size_t room = CHUNK - ((size_t)at % CHUNK), nb = std::min(room, t.n - w);
-                    memcpy(dst, t.p + w, nb);
-                    w += nb;
-                }
                 while (w < t.n) {
                     const ssize_t got = ::pwrite(fd[i], t.p + w, t.n - w, j.at[i] + (off_t)w);
                     if (got < 0) { if (errno == EINTR) continue; failed = true; break; }
@@ -274,12 +239,6 @@ struct PositionedWriter {
         cv_job.notify_all();
         for (std::thread& t : threads) t.join();
         threads.clear();
-        for (int i = 0; i < 5; i++) {
-            for (char* c : map_[i].chunk) if (c) munmap(c, CHUNK);
-            map_[i].chunk.clear();
-            if (fd[i] >= 0 && map_[i].size > pos[i]) { if (ftruncate(fd[i], pos[i]) != 0) failed = true; } /* the file was grown in whole chunks */
-            map_[i].size = 0;
-        }
         for (int i = 0; i < 5; i++) if (fd[i] >= 0) fseeko(F.stream(i), pos[i], SEEK_SET);
         return !failed;
     }
@@ -1210,7 +1169,7 @@ static int run_tool(Options& O, mtg_index* idx, bool resident)
     const std::string insert_name = O.out + ".insertions.fasta", info_name = O.out + ".info.txt", vcf_name = O.out + ".insertions.vcf", gfa_name = O.out + ".gfa",
                       ext_name = O.out + ".extensions.fasta";
     auto open_w = [&](FILE*& f, const std::string& name) -> bool {
-        f = fopen(name.c_str(), "w+"); /* read-write: the writer threads may map the file (PositionedWriter) */
+        f = fopen(name.c_str(), "w");
         if (!f) fprintf(stderr, "EXCEPTION: Cannot open file %s for writing\n", name.c_str());
         return f != nullptr;
     };
