@@ -74,7 +74,142 @@ typedef BubbleLdsT<CapsLarge> BubbleLdsBig; /* k_finish */
 
 /* ---- a group of lanes: G consecutive lanes of a wave (G a power of two, 64 = the whole wave).  Control flow inside the routines below is
  * uniform over the group; the emulation build has one lane per group. */
-#ifdef MTG_EMU
+#if defined(MTG_EMU) && defined(MTG_EMU_LANES)
+} // namespace mtg
+#include <pthread.h>
+#include <dlfcn.h>
+#include <time.h>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+namespace mtg {
+/* TEST-ONLY (tests/emu, -DMTG_EMU_LANES=N): the group form executed by N lanes IN LOCK STEP.  Every lane is a host thread with its own copy
+ * of the per-lane state (the Worker, the locals of the routines); the group's collectives -- ballot, shuffle, minimum, sync -- are
+ * rendezvous of all N, so the lanes advance from collective to collective together, as the lanes of a wave advance from instruction to
+ * instruction.  Between two collectives the lanes touch shared memory (the LDS areas) only at places the code assigns to them by lane
+ * number, or through the atomic compare-and-swap of the sets: what ballot compaction, chunk-wise de-duplication and the prefix popcounts
+ * compute with several lanes is then really computed by several lanes, under AddressSanitizer / UBSan / ThreadSanitizer.  A rendezvous
+ * that not all lanes reach (divergent control flow around a collective -- a hang on the device) is a deadlock here: the watchdog of the
+ * test reports it.  emu_group_run(f) runs f(lane) on the N lanes and returns lane 0's value; the lanes must return the same value. */
+struct EmuLanes {
+    enum { N = MTG_EMU_LANES };
+    pthread_mutex_t m = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t c = PTHREAD_COND_INITIALIZER;
+    int arrived = 0;
+    unsigned long gen = 0;
+    uint64_t slot[N];
+    int ret[N];
+    void* site[N];   /* where every lane last entered a collective: printed when a rendezvous is not reached by all */
+    int done[N];     /* the lane has left the group's routine */
+    EmuLanes() { for (int j = 0; j < N; j++) { site[j] = nullptr; done[j] = 0; ret[j] = 0; slot[j] = 0; } }
+    /* a rendezvous of the N lanes.  A lane that has RETURNED while others still wait, or a wait of 20 s, is a divergence: reported and fatal
+     * (on the device: a hang, or lanes computing with another lane's stale values) */
+    void wait(void* from)
+    {
+        pthread_mutex_lock(&m);
+        site[emu_lane_of()] = from;
+        const unsigned long my = gen;
+        if (++arrived == N) { arrived = 0; gen++; pthread_cond_broadcast(&c); }
+        else {
+            struct timespec ts;
+            clock_gettime(CLOCK_REALTIME, &ts);
+            ts.tv_sec += 20;
+            while (gen == my) {
+                int finished = 0;
+                for (int j = 0; j < N; j++) finished += done[j];
+                if (finished || pthread_cond_timedwait(&c, &m, &ts) != 0) {
+                    if (gen != my) break;
+                    fprintf(stderr, "[emu lanes] a rendezvous of the group was not reached by all %d lanes (%d returned):", (int)N, finished);
+                    for (int j = 0; j < N; j++) {
+                        Dl_info di;
+                        const bool ok = site[j] && dladdr(site[j], &di) && di.dli_fbase;
+                        fprintf(stderr, " lane %d %s at +0x%lx;", j, done[j] ? "returned, last" : "waits/last", ok ? (unsigned long)((char*)site[j] - (char*)di.dli_fbase) : 0ul);
+                    }
+                    fprintf(stderr, "\n");
+                    abort();
+                }
+            }
+        }
+        pthread_mutex_unlock(&m);
+    }
+    void leave(uint32_t lane) { pthread_mutex_lock(&m); done[lane] = 1; pthread_cond_broadcast(&c); pthread_mutex_unlock(&m); }
+    static uint32_t emu_lane_of();
+};
+inline thread_local EmuLanes* emu_group = nullptr; /* null: outside a group run, the code is one lane */
+inline thread_local uint32_t emu_lane = 0;
+inline uint32_t EmuLanes::emu_lane_of() { return emu_lane; }
+template <int G> struct Grp {
+    enum { N = MTG_EMU_LANES };
+    static uint32_t gl() { return emu_lane; }
+    __attribute__((noinline)) static uint64_t ballot(bool p)
+    {
+        EmuLanes* g = emu_group;
+        if (!g) return p ? 1ull : 0ull;
+        g->slot[emu_lane] = p ? 1ull : 0ull;
+        g->wait(__builtin_return_address(0));
+        uint64_t b = 0;
+        for (int j = 0; j < N; j++) b |= g->slot[j] << j;
+        g->wait(__builtin_return_address(0));
+        return b;
+    }
+    __attribute__((always_inline)) static bool any(bool p) { return ballot(p) != 0ull; }
+    __attribute__((always_inline)) static bool all(bool p) { return ballot(!p) == 0ull; }
+    __attribute__((noinline)) static uint32_t min32(uint32_t v)
+    {
+        EmuLanes* g = emu_group;
+        if (!g) return v;
+        g->slot[emu_lane] = v;
+        g->wait(__builtin_return_address(0));
+        uint32_t m = v;
+        for (int j = 0; j < N; j++) if ((uint32_t)g->slot[j] < m) m = (uint32_t)g->slot[j];
+        g->wait(__builtin_return_address(0));
+        return m;
+    }
+    __attribute__((noinline)) static uint64_t from_lane64(uint64_t v, int j)
+    {
+        EmuLanes* g = emu_group;
+        if (!g) return v;
+        g->slot[emu_lane] = v;
+        g->wait(__builtin_return_address(0));
+        const uint64_t r = g->slot[j];
+        g->wait(__builtin_return_address(0));
+        return r;
+    }
+    __attribute__((noinline)) static void sync() { if (emu_group) emu_group->wait(__builtin_return_address(0)); }
+    /* an operation every lane of a wave performs identically on the SAME shared words (read, decide, write: consistent because the lanes of a
+     * wave execute each instruction together): threads that are not in lock step between collectives cannot do that, so lane 0 performs
+     * it between two rendezvous and the others take its result */
+    template <typename F> __attribute__((noinline)) static int uniform(F f)
+    {
+        EmuLanes* g = emu_group;
+        if (!g) return f();
+        g->wait(__builtin_return_address(0));
+        if (emu_lane == 0) g->slot[0] = (uint64_t)(int64_t)f();
+        g->wait(__builtin_return_address(0));
+        const int r = (int)(int64_t)g->slot[0];
+        g->wait(__builtin_return_address(0));
+        return r;
+    }
+};
+template <typename F> int emu_group_run(F f)
+{
+    EmuLanes g;
+    std::vector<std::thread> ts;
+    for (uint32_t lane = 1; lane < (uint32_t)EmuLanes::N; lane++)
+        ts.emplace_back([&g, &f, lane] { emu_group = &g; emu_lane = lane; g.ret[lane] = f(lane); g.leave(lane); emu_group = nullptr; emu_lane = 0; });
+    emu_group = &g; emu_lane = 0;
+    g.ret[0] = f(0u);
+    g.leave(0);
+    emu_group = nullptr;
+    for (auto& t : ts) t.join();
+    for (int j = 1; j < EmuLanes::N; j++) if (g.ret[j] != g.ret[0]) return -0x7BADD; /* the lanes disagree about a uniform value */
+    return g.ret[0];
+}
+MTG_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
+MTG_DEV int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+MTG_DEV uint64_t lds_cas64(uint64_t* p, uint64_t cmp, uint64_t val) { return __sync_val_compare_and_swap(p, cmp, val); }
+#elif defined(MTG_EMU)
 template <int G> struct Grp {
     enum { N = 1 };
     static uint32_t gl() { return 0; }
@@ -84,6 +219,7 @@ template <int G> struct Grp {
     static uint32_t min32(uint32_t v) { return v; }
     static uint64_t from_lane64(uint64_t v, int) { return v; }
     static void sync() {}
+    template <typename F> static int uniform(F f) { return f(); }
 };
 MTG_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
 MTG_DEV int ctz64(uint64_t x) { return __builtin_ctzll(x); }
@@ -121,6 +257,9 @@ template <int G> struct Grp {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    /* an operation all lanes perform identically on the same LDS words (the lanes of a wave execute every instruction together: reads before
+     * writes, for all of them).  Named so that the test build with one host thread per lane can let one lane perform it (see EmuLanes). */
+    template <typename F> MTG_DEV static int uniform(F f) { return f(); }
 };
 MTG_DEV int popc64(uint64_t x) { return __popcll(x); }
 MTG_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
@@ -513,7 +652,7 @@ template <int G, class LT> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, LT& 
         fr[0] = z;
     }
     GP::sync();
-    path_add(fr[0].c);
+    GP::uniform([&] { return path_add(fr[0].c); });
     GP::sync();
     const uint32_t end_u = (end_rp & RP_VALID) ? rp_unitig(end_rp) : 0xFFFFFFFFu;
     bool entering = true;
@@ -566,7 +705,7 @@ template <int G, class LT> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, LT& 
             if (f == 0) return 1;
             const uint64_t cdel = fr[f].c;
             GP::sync();
-            path_del(cdel);
+            GP::uniform([&] { path_del(cdel); return 0; });
             GP::sync();
             f--;
             if (ncons > W.cfg.mono_max_breadth) return COOP_FAIL;
@@ -613,7 +752,7 @@ template <int G, class LT> MTG_DEV_NOINLINE int coop_consensuses(Worker& W, LT& 
         const uint64_t cy = canon(y);
         if (f + 1 >= LT::Caps::FR || d + (int)t >= LT::Caps::NT) return COOP_BIG_FRAMES;
         GP::sync();
-        const int pa = path_add(cy);
+        const int pa = GP::uniform([&] { return path_add(cy); });
         if (pa == 1) return COOP_FAIL; /* loop inside the bubble */
         if (pa == 2) return COOP_BIG_PATH;
         f++;

@@ -1595,17 +1595,19 @@ enum { WALK_CLASSIC = 0, WALK_PARK = 1, WALK_FINISH = 2 };
 #include <cstdio>
 #include <cstdlib>
 namespace mtg {
+struct CoopTally {
+    unsigned long ok = 0, fail = 0, big[10] = {0};
+    ~CoopTally()
+    {
+        if (getenv("MTG_EMU_COOP_STATS"))
+            fprintf(stderr, "[emu] group form of explore_branching: %lu consensus, %lu rejected; too big: sets %lu, in-branching check %lu, depth %lu, consensuses %lu, frames %lu, path set %lu, alignment needed %lu, end rule %lu\n",
+                    ok, fail, big[1], big[2], big[3], big[4], big[5], big[6], big[7], big[8]);
+    }
+};
+inline CoopTally& coop_tally_state() { static CoopTally t; return t; }
 inline void coop_tally(int n)
 {
-    static struct Tally {
-        unsigned long ok = 0, fail = 0, big[10] = {0};
-        ~Tally()
-        {
-            if (getenv("MTG_EMU_COOP_STATS"))
-                fprintf(stderr, "[emu] group form of explore_branching: %lu consensus, %lu rejected; too big: sets %lu, in-branching check %lu, depth %lu, consensuses %lu, frames %lu, path set %lu, alignment needed %lu, end rule %lu\n",
-                        ok, fail, big[1], big[2], big[3], big[4], big[5], big[6], big[7], big[8]);
-        }
-    } t;
+    CoopTally& t = coop_tally_state();
     if (n > 0) t.ok++; else if (n == COOP_FAIL) t.fail++; else t.big[-n < 10 ? -n : 9]++;
 }
 #endif
@@ -2091,7 +2093,21 @@ MTG_UNROLL
 #ifdef MTG_COOP_OFF /* diagnostics: the finishing kernel without the group form (every bubble by the one-lane code) */
                     n = COOP_TOOBIG;
 #else
+#ifdef MTG_EMU_LANES /* TEST-ONLY: the group form by N lanes in lock step (mtg_bubble.h: EmuLanes); each lane has its own Worker, lane 0's comes back */
+                    if (L) {
+                        n = emu_group_run([&](uint32_t lane) {
+                            Worker Wl = W;
+                            int ch = -1;
+                            const int r = coop_explore<G>(Wl, *L, cur, prev_c, ch);
+                            if (lane == 0) { chosen = ch; W.lines = Wl.lines; W.status = Wl.status; }
+                            return r > 0 ? (r << 4) | (ch & 15) : r; /* the lanes must agree on the length AND on the consensus chosen */
+                        });
+                        if (n == -0x7BADD) { W.status = 0xBADD; n = COOP_FAIL; }
+                        else if (n > 0) n >>= 4;
+                    } else n = COOP_TOOBIG;
+#else
                     n = L ? coop_explore<G>(W, *L, cur, prev_c, chosen) : COOP_TOOBIG; /* no LDS areas: the one-lane finishing kernel (a handful of parked gaps) */
+#endif
 #endif
 #ifdef MTG_EMU
                     coop_tally(n);
@@ -2330,7 +2346,19 @@ template <int G> MTG_DEV bool bubble_coop(const Index& ix, const FillCfg& cfg, c
         }
     }
     int chosen = -1;
+#ifdef MTG_EMU_LANES /* TEST-ONLY: by N lanes in lock step (see stage_a_walk) */
+    int n = emu_group_run([&](uint32_t lane) {
+        Worker Wl = W;
+        int ch = -1;
+        const int r = coop_explore<G>(Wl, L, cur, sv.prev_c, ch);
+        if (lane == 0) { chosen = ch; W.lines = Wl.lines; W.status = Wl.status; }
+        return r > 0 ? (r << 4) | (ch & 15) : r;
+    });
+    if (n == -0x7BADD) { sv.flags |= 0x40000000u; n = COOP_FAIL; }
+    else if (n > 0) n >>= 4;
+#else
     const int n = coop_explore<G>(W, L, cur, sv.prev_c, chosen);
+#endif
 #ifdef MTG_EMU
     coop_tally(n);
 #endif
@@ -2365,7 +2393,11 @@ template <int G> MTG_DEV bool bubble_coop(const Index& ix, const FillCfg& cfg, c
         coop_apply_marks<G>(W, L);
         /* the consensus where the walk expects it: consensus 0 of the gap's area in HBM (the lanes of the group write it together) */
         const SP<uint8_t> cons = s_cons(cfg, S);
+#ifdef MTG_EMU_LANES
+        for (int i = 0; i < n; i++) cons[(size_t)i] = L.b.cons[chosen][i]; /* outside the group run: one lane */
+#else
         for (int i = (int)GP::gl(); i < n; i += GP::N) cons[(size_t)i] = L.b.cons[chosen][i];
+#endif
     }
     if (GP::gl() == 0) bubble_store(cfg, S, W, sv, n, 0);
     return true;

@@ -60,6 +60,13 @@ void* emu_index_create(const uint64_t* kmers, const uint32_t* counts, size_t n, 
     }
 }
 void emu_index_free(void* p) { delete (EmuIndex*)p; }
+/* how many branching nodes the group form of the bubble code has answered so far (consensus found / rejected), and how many it passed on as too big */
+void emu_coop_counts(unsigned long* out)
+{
+    const CoopTally& t = coop_tally_state();
+    out[0] = t.ok; out[1] = t.fail; out[2] = 0;
+    for (int i = 0; i < 10; i++) out[2] += t.big[i];
+}
 
 void emu_query(void* p, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
 {

@@ -16,18 +16,25 @@ if SAN:
     SO = SO.replace(".so", "_san.so")
 
 _lib = None
+_lanes_libs = {}
 
 
-def load():
+def load(lanes=0, tsan=False):
+    """lanes = N > 0: the build whose group form of the bubble code runs on N lanes in lock step (one host thread per lane, rendezvous at
+    the group's collectives: mtg_bubble.h, MTG_EMU_LANES); tsan: that build under ThreadSanitizer (a separate process must load it)"""
     global _lib
-    if _lib is not None:
+    if lanes == 0 and _lib is not None:
         return _lib
+    if lanes and (lanes, tsan) in _lanes_libs:
+        return _lanes_libs[(lanes, tsan)]
+    so = SO if not lanes else SO.replace(".so", "_lanes%d%s.so" % (lanes, "_tsan" if tsan else ""))
+    extra = [] if not lanes else ["-DMTG_EMU_LANES=%d" % lanes, "-pthread"] + (["-fsanitize=thread", "-O1"] if tsan else [])
     deps = [SRC] + HDRS
-    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        tmp = SO + ".%d.tmp" % os.getpid()  # several pytest workers may build at once: each writes its own file, the rename is atomic
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall"] + SAN + ["-o", tmp, SRC])
-        os.replace(tmp, SO)
-    lib = C.CDLL(SO)
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        tmp = so + ".%d.tmp" % os.getpid()  # several pytest workers may build at once: each writes its own file, the rename is atomic
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall"] + SAN + extra + ["-o", tmp, SRC])
+        os.replace(tmp, so)
+    lib = C.CDLL(so)
     P = C.POINTER
     lib.emu_index_create.restype = C.c_void_p
     lib.emu_index_create.argtypes = [P(C.c_uint64), P(C.c_uint32), C.c_size_t, C.c_int, C.c_double]
@@ -37,13 +44,17 @@ def load():
     lib.emu_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
     lib.emu_free.argtypes = [C.c_void_p]
     lib.emu_nw_matches.argtypes = [C.c_char_p, C.c_char_p]
-    _lib = lib
+    lib.emu_coop_counts.argtypes = [P(C.c_ulong)]
+    if lanes:
+        _lanes_libs[(lanes, tsan)] = lib
+    else:
+        _lib = lib
     return lib
 
 
 class EmuIndex:
-    def __init__(self, kmers, counts, k, load_factor=0.6):
-        self.lib = load()
+    def __init__(self, kmers, counts, k, load_factor=0.6, lanes=0):
+        self.lib = load(lanes)
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
         counts = np.ascontiguousarray(counts, dtype=np.uint32)
         self.k = k
@@ -96,3 +107,10 @@ def product_on_emulator():
     from mindthegap_amd import lib as L
     L._lib = L._bind(C.CDLL(FULL_SO))
     return mindthegap_amd
+
+
+def coop_counts(lanes=0):
+    """(answered with a consensus, rejected, passed on as too big) by the group form of the bubble code in the emulation library so far"""
+    a = (C.c_ulong * 3)()
+    load(lanes).emu_coop_counts(a)
+    return tuple(int(x) for x in a)

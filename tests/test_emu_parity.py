@@ -1141,3 +1141,37 @@ def test_device_formatted_text_equals_the_host_writers(emu_product, tmp_path):
     for e in outs["host"]:
         assert outs["device"][e] == outs["host"][e], e
     assert outs["host"][".insertions.fasta"].count(b">") >= 20 and len(outs["host"][".vcf"]) > 2000
+
+
+@pytest.mark.parametrize("lanes,rounds", [(4, "0"), (4, "2"), (16, "0")])
+def test_group_form_of_the_bubble_code_on_lanes_in_lock_step(lanes, rounds):
+    """round 4: the cooperative code where it is cooperative.  The emulation build with -DMTG_EMU_LANES=N runs the group form of
+    explore_branching (mtg_bubble.h: frontline expansion with ballot compaction, chunk-wise de-duplication in lane order, the four
+    successors of a node by four lanes, LDS sets filled by compare-and-swap, the enumeration's frames, the marks' plan) on N lanes, one
+    host thread each, meeting at every collective (ballot / shuffle / minimum / sync), instead of one lane that plays all of them.  Every
+    answer is compared with the one-lane general code (0xBADC), the lanes must agree on every uniform result (0xBADD), and the contigs
+    must be the oracle's -- on the random graphs of the fuzz (bubbles, tips, repeats, loops) and the variant pairs whose bubbles the group
+    form resolves.  rounds = 0: every parked gap goes to the finishing kernel's group form (large LDS areas); 2: bubble kernel (small
+    areas) + resumed walks first.  (The library with the lanes is a build of its own; tests/emu_lib.load(lanes, tsan=True) builds it under
+    ThreadSanitizer.)"""
+    with _env("MTG_ROUNDS", rounds):
+        before = emu_lib.coop_counts(lanes)
+        k = 21
+        for seed in range(6 if lanes > 4 else 14):
+            rng, g, seqs = _make_case(100 + seed, k)
+            idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+            km, ct = idx.export()
+            emu = emu_lib.EmuIndex(km, ct, k, lanes=lanes)
+            for _ in range(6):
+                p = rng.randrange(0, len(g) - k)
+                s_ = g[p:p + k] if rng.random() < 0.5 else _rc(g[p:p + k])
+                tp = rng.randrange(0, len(g) - k)
+                t = g[tp:tp + k]
+                er = rng.choice([0, 0, 1])
+                oc, _ = idx.stage_a(s_, t, oracle_lib.default_params(end_rule_nonbranching=er))
+                ec, st, _, _ = emu.stage_a(s_, t, 100, 10000, er)
+                assert st == 0 and ec == oc, (lanes, rounds, seed, s_, t, er, hex(st))
+            idx.close()
+            emu.close()
+        after = emu_lib.coop_counts(lanes)
+        assert after[0] - before[0] >= 5 and after[1] - before[1] >= 1, (before, after)  # the lanes did answer bubbles: consensuses and rejections

@@ -1,11 +1,14 @@
 """Parity tests proper: the HIP path (through the C ABI of include/mtg_fill.h) against the CPU oracle, the committed
 golden files and size-independent properties.  Bit-exact everywhere (integer / byte / text work)."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _read(p):
@@ -705,3 +708,28 @@ def test_first_stage_a_batch_larger_than_the_initial_dense_arrays(mtg):
     res = g.fill_batch(gaps)
     assert [r["filled"][0]["seq"] if r["filled"] else None for r in res] == want
     g.close(); o.close()
+
+
+LAUNCH_SEQUENCES = [
+    {"MTG_ROUNDS": "6"},                                   # six rounds of bubble kernel (one lane per bubble) + resumed walks, then the finishing kernel
+    {"MTG_ROUNDS": "3", "MTG_BUBBLE_GROUPS": "1"},         # rounds with the LDS group form k_bubble<16> first
+    {"MTG_ROUNDS": "0", "MTG_FINISH_G": "64"},             # every parked gap straight to k_finish<64>
+    {"MTG_ROUNDS": "0", "MTG_FINISH_G": "16", "MTG_FINISH_FULL_GRID": "1"},  # k_finish<16>, one group per gap of the launch (the grid of round 3)
+    {"MTG_FINISH_G": "1"},                                 # one lane per parked gap (k_finish_lane)
+    {"MTG_CLASSIC_WALK": "1"},                             # the round-2 kernel: every bubble by its walking lane
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq", LAUNCH_SEQUENCES, ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
+def test_bubble_tests_under_every_launch_sequence(seq):
+    """the walk / bubble / finishing kernels are chosen per launch from what the previous launch parked; every sequence the library can
+    queue -- rounds with either bubble kernel, the finishing kernel with 16 or 64 lanes per gap or one, its grid sized from the hint or for
+    the worst case, the round-2 kernel -- must give the oracle's contigs and files on the tests whose walks cross bubbles.  The switches
+    are read once per process: each sequence runs the selected tests in a process of its own."""
+    env = dict(os.environ, **seq)
+    sel = "fuzz_on_device or adversarial or diploid or allelic or tier_retry or golden or synthetic_sites"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_micro_cases.py"), "-m", "gpu", "-x", "-q",
+                        "-p", "no:cacheprovider", "-k", "(%s) and not launch_sequence" % sel], env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout.strip().splitlines() or [""])[-1]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (seq, r.stdout[-1500:], r.stderr[-800:])
