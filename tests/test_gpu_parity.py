@@ -731,5 +731,6 @@ def test_bubble_tests_under_every_launch_sequence(seq):
     sel = "fuzz_on_device or adversarial or diploid or allelic or tier_retry or golden or synthetic_sites"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_micro_cases.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider", "-k", "(%s) and not launch_sequence" % sel], env=env, capture_output=True, text=True, timeout=1500)
-    tail = (r.stdout.strip().splitlines() or [""])[-1]
-    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (seq, r.stdout[-1500:], r.stderr[-800:])
+    import re
+    summary = re.findall(r"(\d+) passed", r.stdout)  # (the tool's own report on stdout may follow pytest's line)
+    assert r.returncode == 0 and summary and int(summary[-1]) >= 10 and not re.search(r"\d+ (failed|error)", r.stdout), (seq, r.stdout[-1500:], r.stderr[-800:])
