@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""round 4: a READS-BUILT workload at scale -- what the unitig store is worth on a graph that was not generated unitig by unitig.
+A donor of nseq x 5 kb (default 40 000 = 200 Mbp) with one insertion per sequence, 30x reads of 150 nt with 0.5 % substitutions written to a
+FASTA file, the index through `-in` (k-mer counting on the device, -abundance-min 3: erroneous k-mers seen three times survive as tips and
+bubbles), one site per donor sequence.  Reports: solid k-mers, unitigs, index bytes per k-mer, the phases of the construction, the fill rate
+(prepared batches, as bench.py's `value`), and -- the parity evidence -- the fills of the first `--oracle-seqs` sites against the CPU oracle
+whose index is counted from the reads of exactly those donor sequences.  Prints one JSON line last."""
+import argparse, json, os, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mindthegap_amd as mtg
+from mindthegap_amd.synth import SynthSet, NT
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nseq", type=int, default=40000)
+ap.add_argument("--err", type=float, default=0.005)
+ap.add_argument("--oracle-seqs", type=int, default=1500)
+ap.add_argument("--steps", type=int, default=20)
+a = ap.parse_args()
+S = SynthSet(nseq=a.nseq, n_sites=a.nseq, seed=2, k=31)
+d = tempfile.mkdtemp()
+reads, reads_o = os.path.join(d, "reads.fasta"), os.path.join(d, "reads_oracle.fasta")
+comp = np.array([2, 3, 0, 1], dtype=np.uint8)
+t0 = time.time()
+nreads = 0
+with open(reads, "wb") as f, open(reads_o, "wb") as fo:
+    for j in range(S.nseq):
+        rng = np.random.default_rng(1000003 * 7 + j)  # the reads of a donor sequence depend on nothing but its number
+        c = S.codes(j)
+        L = len(c)
+        nr = int(round(30 * L / 150))
+        st = rng.integers(0, L - 150 + 1, nr)
+        m = c[st[:, None] + np.arange(150)[None, :]]
+        rev = rng.integers(0, 2, nr).astype(bool)
+        m[rev] = comp[m[rev][:, ::-1]]
+        e = rng.random(m.shape) < a.err
+        m[e] = (m[e] + rng.integers(1, 4, int(e.sum())).astype(np.uint8)) & 3  # a substitution: one of the three other nucleotides
+        out = np.empty((nr, 154), dtype=np.uint8)
+        out[:, 0] = ord(">"); out[:, 1] = ord("r"); out[:, 2] = 10; out[:, 153] = 10
+        out[:, 3:153] = NT[m]
+        b = out.tobytes()
+        f.write(b)
+        if j < a.oracle_seqs:
+            fo.write(b)
+        nreads += nr
+t_gen = time.time() - t0
+t0 = time.time()
+idx = mtg.Index.from_reads([reads], 31, 3, 0)
+t_index = time.time() - t0
+info, prof = idx.info(), idx.build_profile()
+params = mtg.FillParams(max_nodes=100, max_depth=10000)
+B = 100000
+batches = []
+for s0 in range(0, S.n_sites, B):
+    gaps = []
+    for i in range(s0, min(S.n_sites, s0 + B)):
+        l, r, _ = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+    batches.append((gaps, idx.prepare_batch(mtg.Index.prepare_gaps(gaps), params)))
+import threading
+def run(steps):
+    work = [b for _ in range(steps) for b in batches]
+    it = iter(work); lock = threading.Lock()
+    def w():
+        while True:
+            with lock:
+                b = next(it, None)
+            if b is None:
+                return
+            h, nf, _ = idx.fill_prepared(b[1], params, want_seqs=False)
+            idx.free_results(h)
+    ts = [threading.Thread(target=w) for _ in range(6)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+run(3)
+t0 = time.perf_counter(); run(a.steps); el = time.perf_counter() - t0
+rate = S.n_sites * a.steps / el
+st = None
+h, nf, _ = idx.fill_prepared(batches[0][1], params, want_seqs=False)
+st = mtg.last_batch_stats(); idx.free_results(h)
+n_filled = int((nf > 0).sum())
+# parity: the first oracle_seqs sites, HIP (forward attempt + reverse attempt, as the tool) against the oracle on the reads of those sequences
+from tests import oracle_lib
+ns = min(a.oracle_seqs, S.n_sites)
+bk = os.path.join(d, "s.breakpoints")
+S.write_breakpoints(bk, range(ns))
+t0 = time.time()
+oidx = oracle_lib.Index.from_files([reads_o], 31, 3, 0)
+ost = oidx.fill_files("bkpt", bk, os.path.join(d, "cpu"), params=oracle_lib.default_params(nb_cores=mtg.cpu_budget()))
+t_oracle = time.time() - t0
+assert idx.fill_main(["-bkpt", bk, "-out", os.path.join(d, "hip")]) == 0
+def recs(p):
+    out, cur = [], None
+    for l in open(p):
+        if l.startswith(">"):
+            cur = [l.split("_len_")[0], ""]; out.append(cur)
+        else:
+            cur[1] += l.strip()
+    return sorted(map(tuple, out))
+same = recs(os.path.join(d, "hip.insertions.fasta")) == recs(os.path.join(d, "cpu.insertions.fasta"))
+truth = sum(1 for (n, s) in recs(os.path.join(d, "hip.insertions.fasta")) if s in {S.site(i)[2] for i in range(ns)})
+out = {"workload": "reads-built: donor %d x 5 kb = %.0f Mbp, %d reads of 150 nt (30x) with %.1f %% substitutions through -in, -abundance-min 3, %d sites" % (S.nseq, S.lens.sum() / 1e6, nreads, 100 * a.err, S.n_sites),
+       "reads_fasta_GB": os.path.getsize(reads) / 1e9, "reads_generated_s": t_gen, "index_from_reads_s": t_index, "nb_solid_kmers": info["nb_solid_kmers"], "nb_unitigs": info["nb_unitigs"],
+       "kmers_per_unitig": info["nb_solid_kmers"] / max(info["nb_unitigs"], 1), "kmers_outside_unitigs": info["nb_kmers_outside_unitigs"], "nb_branching": info["nb_branching"],
+       "index_bytes": info["device_bytes"], "index_bytes_per_kmer": info["device_bytes"] / max(info["nb_solid_kmers"], 1), "build_peak_bytes": prof["peak_device_bytes"],
+       "build_phases_ms": {ph["name"]: round(ph["ms"], 2) for ph in prof["phases"]},
+       "value": rate, "unit": "breakpoints/s", "steps": a.steps, "sites_per_step": S.n_sites, "filled_forward_in_batch_0": n_filled, "sites_in_batch_0": len(batches[0][0]),
+       "parked_gaps_in_batch_0": st["n_parked_gaps"], "lean_gaps_in_batch_0": st["n_lean_gaps"], "one_batch_alone_ms": {"walk+finish": st["kernel_ms"], "lean+copy": st["copy_kernel_ms"], "post": st["post_kernel_ms"], "emit": st["emit_kernel_ms"]},
+       "oracle_sample": {"sites": ns, "identical_to_hip": bool(same), "fills_equal_to_the_inserted_sequence": truth, "oracle_s": t_oracle, "what": "FASTA records (name, sequence) of MindTheGap fill -bkpt on the HIP path == CPU oracle with its index counted from the reads of the first %d donor sequences" % ns}}
+for fn in os.listdir(d):
+    os.remove(os.path.join(d, fn))
+os.rmdir(d)
+print(json.dumps(out), flush=True)
