@@ -837,6 +837,16 @@ def main():
                             "stage_ms_per_batch": d["stage_ms_per_batch"], "ratio_to_headline": d["value"] / value if value else None}
             except Exception as e:  # the headline line does not depend on it
                 out[key] = {"error": repr(e)[:300]}
+        # a fourth secondary, of another kind: an index COUNTED FROM READS (200 Mbp donor, 30x reads with 0.5 % substitutions through -in): the graph has the
+        # tips and bubbles sequencing errors leave, unitigs end where they do in data; rate, unitig statistics, and a sample against the oracle
+        if not os.environ.get("MTG_BENCH_NO_READS"):
+            try:
+                cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r4_reads_workload.py"), "--steps", str(a.steps)], capture_output=True, text=True, timeout=600)
+                d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
+                d["ratio_to_headline"] = d["value"] / value if value else None
+                out["secondary_reads_built"] = d
+            except Exception as e:
+                out["secondary_reads_built"] = {"error": repr(e)[:300]}
     if dist_on:
         for r in results:
             if r["pg"] is not None:

@@ -72,6 +72,15 @@ def run(steps):
     ts = [threading.Thread(target=w) for _ in range(6)]
     for t in ts: t.start()
     for t in ts: t.join()
+# every one of the index's six workspaces is allocated before anything is timed: six callers enter the library at the same moment (bench.py's priming step)
+gate = threading.Barrier(6)
+def prime():
+    gate.wait()
+    h, nf, _ = idx.fill_prepared(batches[0][1], params, want_seqs=False)
+    idx.free_results(h)
+ts = [threading.Thread(target=prime) for _ in range(6)]
+for t in ts: t.start()
+for t in ts: t.join()
 run(3)
 t0 = time.perf_counter(); run(a.steps); el = time.perf_counter() - t0
 rate = S.n_sites * a.steps / el
