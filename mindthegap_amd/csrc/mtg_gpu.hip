@@ -1298,13 +1298,21 @@ __global__ void k_fill_random(uint64_t* p, uint64_t nwords, uint64_t seed)
 /* ------------------------------------------------------------------------------------------------ index */
 namespace {
 /* owning device buffer: freed on every exit path */
+/* wall time this thread has spent in hipMalloc / hipFree (an index construction reports it: BuildProf) */
+static thread_local double tl_alloc_ms = 0;
+struct AllocTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocTimer() { tl_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+static hipError_t timed_malloc(void** p, size_t bytes) { AllocTimer t; return hipMalloc(p, bytes); }
+static hipError_t timed_free(void* p) { AllocTimer t; return hipFree(p); }
 struct DevBuf {
     void* p = nullptr;
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 8); }
+    ~DevBuf() { if (p) (void)timed_free(p); }
+    hipError_t alloc(size_t bytes) { if (p) { (void)timed_free(p); p = nullptr; } return timed_malloc(&p, bytes ? bytes : 8); }
     void* release() { void* q = p; p = nullptr; return q; }
     template <typename T> T* as() { return (T*)p; }
 };
@@ -1356,9 +1364,11 @@ struct BuildProf {
         ph.ms = ms; ph.bytes = bytes; ph.units = units;
         phases.push_back(ph);
     }
+    double alloc0 = tl_alloc_ms;
     void store(mtg_index* idx)
     {
         sample();
+        host_phase("hipMalloc+hipFree (host wall)", tl_alloc_ms - alloc0, 0, 0);
         idx->build_phases = phases;
         idx->build_peak_bytes = peak;
         idx->build_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1575,8 +1585,8 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         if (prof) HIP_TRY(prof->end("leftovers+ends", n_left * 5 * 32 + n_rec * 2 * 16 * 32, n_left + 2 * n_rec));
         HIP_TRY(hipDeviceSynchronize());
         /* the new tables take the place of the old ones */
-        if (old.adj.slots) (void)hipFree(old.adj.slots);
-        if (old.abnd.slots) (void)hipFree(old.abnd.slots);
+        if (old.adj.slots) (void)timed_free(old.adj.slots);
+        if (old.abnd.slots) (void)timed_free(old.abnd.slots);
         nx.adj.sp_words = nx.us.words;
         idx->dev = nx;
         (void)na.release();
@@ -1641,8 +1651,8 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     (void)d_starts.alloc(0);
     if (n_rec) {
         const unsigned long long pad = 8; /* the coverage pass may look up to 64 + k nucleotides past the end of a unitig */
-        HIP_TRY(hipMalloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
-        HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, (n_words + pad) * 32));
+        HIP_TRY(timed_malloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
+        HIP_TRY(timed_malloc((void**)&idx->dev.us.ab, (n_words + pad) * 32));
         prof.begin();
         HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + pad) * 8, 0));
         HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + pad) * 32, 0));
@@ -1668,7 +1678,7 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
     const auto alloc_bloom = [&]() -> int {
         if (!idx->dev.bloom.nblocks) return MTG_OK;
-        HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, idx->dev.bloom.nblocks * 64));
+        HIP_TRY(timed_malloc((void**)&idx->dev.bloom.bits, idx->dev.bloom.nblocks * 64));
         HIP_TRY(hipMemsetAsync(idx->dev.bloom.bits, 0, idx->dev.bloom.nblocks * 64, 0));
         return MTG_OK;
     };
@@ -2087,8 +2097,8 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
     const uint64_t nw = d.n_words + 8;
     const bool streamed = (bool)d.ab_read;
     if (d.words.size() < nw || (!streamed && d.ab.size() < nw * 32) || d.left_k.size() != d.left_a.size()) { set_error("index container: inconsistent sizes"); return MTG_ERR_FORMAT; }
-    HIP_TRY(hipMalloc((void**)&idx->dev.us.words, nw * 8));
-    HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, nw * 32));
+    HIP_TRY(timed_malloc((void**)&idx->dev.us.words, nw * 8));
+    HIP_TRY(timed_malloc((void**)&idx->dev.us.ab, nw * 32));
     const auto t_up0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpy(idx->dev.us.words, d.words.data(), nw * 8, hipMemcpyHostToDevice));
     /* the abundance bytes: either in host memory already, or (a container that is being read) straight from the file in page-locked pieces,
