@@ -1304,16 +1304,36 @@ struct AllocTimer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ~AllocTimer() { tl_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
-static hipError_t timed_malloc(void** p, size_t bytes) { AllocTimer t; return hipMalloc(p, bytes); }
-static hipError_t timed_free(void* p) { AllocTimer t; return hipFree(p); }
+static hipError_t timed_malloc(void** p, size_t bytes)
+{
+    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e;
+    { AllocTimer t; e = hipMalloc(p, bytes); }
+    if (dbg && bytes > ((size_t)64 << 20)) fprintf(stderr, "  [alloc] hipMalloc %.2f GB: %.1f ms\n", bytes / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return e;
+}
+static hipError_t timed_free(void* p)
+{
+    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e;
+    { AllocTimer t; e = hipFree(p); }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (dbg && ms > 5.0) fprintf(stderr, "  [alloc] hipFree: %.1f ms\n", ms);
+    return e;
+}
 struct DevBuf {
     void* p = nullptr;
+    size_t cap = 0;
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { if (p) (void)timed_free(p); }
-    hipError_t alloc(size_t bytes) { if (p) { (void)timed_free(p); p = nullptr; } return timed_malloc(&p, bytes ? bytes : 8); }
-    void* release() { void* q = p; p = nullptr; return q; }
+    hipError_t alloc(size_t bytes) { if (p) { (void)timed_free(p); p = nullptr; cap = 0; } const hipError_t e = timed_malloc(&p, bytes ? bytes : 8); if (e == hipSuccess) cap = bytes ? bytes : 8; return e; }
+    void* release() { void* q = p; p = nullptr; cap = 0; return q; }
+    /* takes over the memory of another buffer */
+    void adopt(DevBuf& o) { if (p) (void)timed_free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
     template <typename T> T* as() { return (T*)p; }
 };
 } // namespace
@@ -1442,7 +1462,7 @@ struct LateLeftovers {
 };
 } // namespace
 static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
-                    BuildProf* prof = nullptr, const LateLeftovers* late = nullptr);
+                    BuildProf* prof = nullptr, const LateLeftovers* late = nullptr, DevBuf* adj_reuse = nullptr);
 static int build_unitigs(mtg_index* idx)
 {
     DevBuf d_cnt, d_starts, d_rec;
@@ -1499,7 +1519,7 @@ static int build_unitigs(mtg_index* idx)
  * unitig are handed over, the Bloom filter is filled here).  New tables: ADJ with the entries the sparse form keeps, ABND with the k-mers
  * of no unitig. */
 static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
-                    BuildProf* prof, const LateLeftovers* late)
+                    BuildProf* prof, const LateLeftovers* late, DevBuf* adj_reuse)
 {
     const int k = idx->dev.k;
     DevBuf d_cnt, own_k, own_a;
@@ -1540,7 +1560,11 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         table_shape(nx.abnd, buckets_for(n_left_shape + 1024, 0.6 * load, 2 * k, MTG_ABND_SLOTS), 2 * k);
         const size_t ba = nx.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = nx.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
         DevBuf na, nb;
-        HIP_TRY(na.alloc(ba));
+        /* the junction table has served and is large enough: its memory becomes the ADJ table (a second allocation of this size after freeing the
+         * first cost 2 s of hipMalloc on the GPU box: the freed memory is scrubbed before it is handed out again) */
+        if (adj_reuse && adj_reuse->p && adj_reuse->cap >= ba) na.adopt(*adj_reuse);
+        else { if (adj_reuse && adj_reuse->p) (void)adj_reuse->alloc(0); HIP_TRY(na.alloc(ba)); }
+        const size_t ba_held = na.cap; /* a table that took over the junction table's memory holds all of it */
         HIP_TRY(nb.alloc(bb));
         if (prof) prof->begin();
         HIP_TRY(hipMemsetAsync(na.p, 0, ba, 0));
@@ -1591,7 +1615,7 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         idx->dev = nx;
         (void)na.release();
         (void)nb.release();
-        idx->info.device_bytes = ba + bb + idx->dev.bloom.nblocks * 64 + idx->info.unitig_bytes;
+        idx->info.device_bytes = std::max(ba, ba_held) + bb + idx->dev.bloom.nblocks * 64 + idx->info.unitig_bytes;
         idx->info.adj_buckets = nx.adj.nbuckets;
         idx->info.abnd_buckets = nx.abnd.nbuckets;
         idx->info.sparse = nx.us.words ? 1 : 0; /* no stored unitig: every k-mer has its full entries, the look-ups are the raw ones */
@@ -1686,10 +1710,10 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     if (interior == stored_views) {
         /* every chain is a stored unitig: the k-mers of no unitig are the single ones the scan found; table and source have served */
         prof.sample();
-        (void)jt_buf.alloc(0);
         release_source();
         if (int rc2 = alloc_bloom()) return rc2;
-        rc = sparsify(idx, d_rec.as<UsRec>(), n_rec, true, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), n_single, &prof, nullptr);
+        rc = sparsify(idx, d_rec.as<UsRec>(), n_rec, true, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), n_single, &prof, nullptr, &jt_buf); /* the table's memory is used again */
+        (void)jt_buf.alloc(0);
     } else {
         /* a closed chain, or one too long for the offsets of a pointer: its k-mers belong to no unitig, and only the finished pointers tell which */
         if (int rc2 = alloc_bloom()) return rc2;
@@ -1730,12 +1754,18 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
 static bool legacy_build() { return getenv("MTG_DENSE_INDEX") || getenv("MTG_NO_UNITIGS") || getenv("MTG_LEGACY_BUILD"); }
 static double jt_load() { return getenv("MTG_JT_LOAD") ? atof(getenv("MTG_JT_LOAD")) : 0.7; }
 /* a cleared table of MTG_ABND_SLOTS-slot buckets for nkeys keys of key_bits bits */
-static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase)
+/* bytes the sparse ADJ table of a graph of n k-mers will take, give or take: half the junctions and a little (sparsify) */
+static size_t adj_bytes_estimate(uint64_t n, int k)
+{
+    return (size_t)buckets_for(n / 2 + n / 128 + 8192, 0.49, 2 * (k - 1), MTG_ADJ_SLOTS) * 16 * MTG_ADJ_SLOTS;
+}
+/* min_bytes: the buffer is made at least this large (the junction table's memory is handed on to the sparse ADJ table) */
+static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase, size_t min_bytes = 0)
 {
     table_shape(t, buckets_for(nkeys, load, key_bits, MTG_ABND_SLOTS), key_bits);
     t.sp_words = nullptr;
     const size_t bytes = t.nbuckets * 8 * MTG_ABND_SLOTS;
-    HIP_TRY(buf.alloc(bytes));
+    if (!(buf.p && buf.cap >= std::max(bytes, min_bytes))) HIP_TRY(buf.alloc(std::max(bytes, min_bytes)));
     t.slots = buf.as<uint64_t>();
     prof.begin();
     HIP_TRY(hipMemsetAsync(buf.p, 0, bytes, 0));
@@ -1761,7 +1791,7 @@ static int index_from_kmer_pieces_lean(size_t n, int k, const KmerFetch& fetch, 
     int rc = MTG_OK;
     unsigned long long cnt[4] = {0, 0, 0, 0};
     for (int attempt = 0; attempt < 6; attempt++) {
-        if (int rc2 = alloc_slot_table(jt, jt_buf, n + n / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt")) return rc2;
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n + n / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n, k))) return rc2;
         if (int rc2 = alloc_slot_table(abnd, abnd_buf, n, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
         HIP_TRY(hipMemset(d_cnt.p, 0, 32));
         double ms = 0;
@@ -1814,7 +1844,7 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
     int rc = MTG_OK;
     const uint64_t n_junctions_ub = total_kmers_ub + nseq + 1024; /* a sequence of L >= k nucleotides has L - k + 2 junction positions */
     for (int attempt = 0; attempt < 6; attempt++) {
-        if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt")) return rc2;
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k))) return rc2;
         HIP_TRY(hipMemset(d_cnt.p, 0, 32));
         if (nseq == 0) break; /* an empty graph: nothing to launch */
         prof.begin();
@@ -3172,7 +3202,7 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
             Table jt{}, abnd{};
             unsigned long long cnt[4] = {0, 0, 0, 0};
             for (int ia = 0; ia < 6; ia++) {
-                if (int rc2 = alloc_slot_table(jt, jt_buf, n_solid + n_solid / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt")) return rc2;
+                if (int rc2 = alloc_slot_table(jt, jt_buf, n_solid + n_solid / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n_solid, k))) return rc2;
                 if (npass > 1) if (int rc2 = alloc_slot_table(abnd, abnd_buf, n_solid, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
                 HIP_TRY(hipMemset(d_cnt.p, 0, 32));
                 for (uint32_t pass = 0; pass < npass; pass++) {
