@@ -1292,6 +1292,100 @@ MTG_UNROLL
 }
 
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
+MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev_c, int& chosen);
+#ifdef MTG_EMU
+inline unsigned long& tip_fast_answers() { static unsigned long n = 0; return n; } /* TEST-ONLY: tips the fast path has answered (the tests want to see some) */
+#endif
+/* ---- the TIP, recognised and answered like the SNP bubble (round 4).  Sequencing errors near the end of a read leave short dead-end branches
+ * (abundance >= the cut-off three times over: rare per site, but 8-12 % of the walks of a reads-built graph meet one).  Pattern: the node has two
+ * out-edges whose targets have in-degree 1; one branch T is a simple path of Lt <= k nodes that ends in a dead end -- one k-mer of no unitig, or
+ * one whole stored unitig whose last node has no successor --, the other branch M is a stored unitig with at least Lt + 1 nodes behind its first
+ * (so that m(Lt+1) is an interior node).  On such a subgraph the reference's explore_branching is determined:
+ *   find_end_of_branching   advances both branches level by level (in-degree 1 everywhere: every frontline check passes); at depth Lt the tip's
+ *                           last node is reached -- branching, so it must not be node-marked --, at depth Lt + 1 it contributes nothing and the
+ *                           frontline is the single node m(Lt+1): end, depth Lt + 1;
+ *   all_consensuses_between finds one path (the tip dies out), of Lt + 1 nucleotides;
+ *   validate_consensuses    one consensus: accepted iff its length <= k + 1 (a "short dead-end alternative");
+ *   marking                 of the involved nodes only the tip's last node is branching.
+ * Distinctness needs no set, as for the SNP pattern: T and M are whole chains from their first nodes (their left junction is the node's
+ * two-way junction), of different lengths, so neither is the other's reverse complement and their canonical k-mers are pairwise distinct; the
+ * node (two out-edges) and its reverse complement (two in-edges) are no interior node and not the dead end (in-degree 1); the previous node leads
+ * to the node, which no node of T or M does, and its reverse complement would make the node its own reverse complement (tested).  Anything else
+ * returns 0 and the general code decides.  The TEST-ONLY emulation runs the general code next to every answer (0xBADE). */
+MTG_DEV_NOINLINE int tip_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], SnpSeq& out_seq)
+{
+    const int k = W.k;
+    const UStore& us = W.ix.us;
+    if (cur.f == cur.r || !us.nwords) return 0;
+    int tb = -1;
+    uint32_t Lt = 0;
+    Kmer last;
+    last.f = last.r = 0;
+    RunAt ra[2];
+    bool has_run[2] = {false, false};
+    if (r[0].out == 0 || r[1].out == 0) {
+        if (r[0].out == 0 && r[1].out == 0) return 0; /* both branches die: the frontline empties, the general code says so */
+        tb = r[0].out == 0 ? 0 : 1;
+        Lt = 1;
+        last = x[tb];
+    } else {
+        has_run[0] = run_at(us, r[0], k, ra[0], W.lines);
+        has_run[1] = run_at(us, r[1], k, ra[1], W.lines);
+        if (!has_run[0] || !has_run[1] || ra[0].ahead == ra[1].ahead) return 0;
+        tb = ra[0].ahead < ra[1].ahead ? 0 : 1;
+        if (ra[tb].ahead + 1u > (uint32_t)k) return 0; /* a dead-end alternative longer than k nodes: the reference rejects it (and the contig ends) */
+        last = run_node(us, ra[tb].kpos, ra[tb].bwd, ra[tb].ahead, k);
+        const Adj rl = adj_right_t(W.ix.adj, last, W.mk1, W.lines);
+        if (rl.out != 0) return 0; /* the shorter branch goes on: not a tip */
+        Lt = ra[tb].ahead + 1u;
+    }
+    const int mb = 1 - tb;
+    if (!has_run[mb]) has_run[mb] = run_at(us, r[mb], k, ra[mb], W.lines);
+    if (!has_run[mb] || ra[mb].ahead < Lt + 1u) return 0; /* m(Lt+1) must be an interior node of M's unitig */
+    const uint64_t c_last = canon(last);
+    if (last.f == last.r || c_last == prev_c || c_last == canon(cur)) return 0;
+    if (W.is_marked(c_last)) return 0; /* the bubble touches an assembled region */
+    const int n = (int)Lt + 1;
+    if (n > W.cfg.mono_max_depth) return 0;
+    /* the consensus: M's first nucleotide and the Lt behind it, off the store */
+    SnpSeq seq;
+    seq.lo = nt0[mb]; seq.hi = 0;
+    {
+        const bool bwd = ra[mb].bwd;
+        for (uint32_t done = 0; done < Lt;) {
+            const uint32_t c = Lt - done < 16u ? Lt - done : 16u;
+            const uint64_t pos = bwd ? ra[mb].kpos - 1u - done : ra[mb].kpos + (uint32_t)k + done;
+            uint32_t bits = us_peek(us.words, pos, c, bwd);
+            for (uint32_t j = 0; j < c; j++) { seq.set((int)(1u + done + j), bits & 3u); bits >>= 2; }
+            done += c;
+        }
+        W.lines += 2;
+    }
+#ifdef MTG_XCHECK /* TEST-ONLY: the general code on the same node: same length, same consensus, the one mark */
+    {
+        const uint32_t nm0 = W.n_marked;
+        int ch2 = -1;
+        const int n2 = explore_branching(W, cur, prev_c, ch2);
+        if (W.status == GAP_OK) {
+            bool same = n2 == n && W.n_marked - nm0 == 1u && W.is_marked(c_last);
+            const SP<uint8_t> p2 = s_cons(W.cfg, W.S) + (size_t)(ch2 < 0 ? 0 : ch2) * CONS_LEN;
+            for (int i = 0; i < n && same; i++) same = p2[i] == (uint8_t)seq.get(i);
+            if (!same) W.status = 0xBADE;
+        }
+        out_seq = seq;
+        if (W.status == GAP_OK) tip_fast_answers()++;
+        return W.status == GAP_OK ? n : 0; /* the general code has made the mark */
+    }
+#else
+    W.mark_canon(c_last);
+    out_seq = seq;
+#ifdef MTG_EMU
+    tip_fast_answers()++;
+#endif
+    return n;
+#endif
+}
+
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen, SnpSeq& chosen_seq)
 {
     if (!W.S.snp_fast || W.cfg.end_rule_nonbranching) return 0;
@@ -1346,6 +1440,11 @@ MTG_UNROLL
     if (W.ix.us.nwords) {
         adj_right2_raw(W.ix, x[0], x[1], W.mk1, W.lines, r1[0], r1[1]);
         have_r1 = true;
+        {   /* a tip first (one branch dies within k nodes, the other goes on): answered on the spot */
+            const int tn = tip_fast(W, cur, prev_c, x, nt0, r1, chosen_seq);
+            if (W.status) return 0;
+            if (tn > 0) { chosen = 0; MTG_COUNT(W, 14); return tn; }
+        }
         bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be, hopeless);
 #ifndef MTG_XCHECK
         if (hopeless) return 0;

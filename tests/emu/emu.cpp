@@ -66,6 +66,7 @@ void emu_coop_counts(unsigned long* out)
     const CoopTally& t = coop_tally_state();
     out[0] = t.ok; out[1] = t.fail; out[2] = 0;
     for (int i = 0; i < 10; i++) out[2] += t.big[i];
+    out[3] = tip_fast_answers();
 }
 
 void emu_query(void* p, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)

@@ -119,8 +119,8 @@ int main()
             return true;
         };
         std::uniform_real_distribution<float> U(0.f, 3000.f), V(0.f, 9.9e8f);
-        for (int i = 0; i < 2000000; i++) if (!check(U(rng)) || !check(V(rng))) return 1;
-        for (uint32_t m = 0; m < 400000; m++) {
+        for (int i = 0; i < 500000; i++) if (!check(U(rng)) || !check(V(rng))) return 1;
+        for (uint32_t m = 0; m < 200000; m++) {
             const float t = (float)m / 8.0f; /* .125, .375, .625, .875: exact ties of the second decimal */
             if (!check(t) || !check(std::nextafter(t, 0.f)) || !check(std::nextafter(t, 1e9f))) return 1;
         }

@@ -1175,3 +1175,36 @@ def test_group_form_of_the_bubble_code_on_lanes_in_lock_step(lanes, rounds):
             emu.close()
         after = emu_lib.coop_counts(lanes)
         assert after[0] - before[0] >= 5 and after[1] - before[1] >= 1, (before, after)  # the lanes did answer bubbles: consensuses and rejections
+
+
+@pytest.mark.parametrize("k", [31, 21, 13])
+def test_tip_fast_path_against_the_general_code(k):
+    """round 4: a walk that meets a short dead-end branch (what a sequencing error near the end of a read leaves) answers it on the spot
+    (mtg_traverse.h: tip_fast) instead of parking the gap.  The emulation runs the general explore_branching next to every answer (0xBADE:
+    length, consensus, the one mark) and the contigs must be the oracle's.  Tips of 1 .. k+2 nodes on either branch (the k+1-node tip is the
+    longest the reference pops, the next one ends the contig), on both strands, a tip whose end is reached twice, two tips at one node."""
+    rng = random.Random(77 + k)
+    before = emu_lib.coop_counts()[3]
+    for rep in range(12):
+        g = _rand_seq(rng, rng.randrange(600, 1500))
+        seqs = [g]
+        spots = sorted(rng.sample(range(60, len(g) - 80), 5))
+        for j, p in enumerate(spots):
+            L = [1, 2, k - 1, k, k + 1, k + 2, 3, 7][(rep + j) % 8]
+            first = rng.choice([c for c in "ACGT" if c != g[p]])  # leaves the genome after g[p-k:p], never comes back
+            tip = g[p - k:p] + first + _rand_seq(rng, L - 1)
+            seqs.append(tip if rng.random() < 0.5 else _rc(tip))
+            if rep % 4 == 3 and j == 0:  # a second tip at the same node
+                other = rng.choice([c for c in "ACGT" if c not in (g[p], first)])
+                seqs.append(g[p - k:p] + other + _rand_seq(rng, 2))
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k)
+        for s_, t in ((g[:k], g[-k:]), (_rc(g[-k:]), _rc(g[:k]))):
+            for er in (0, 1):
+                oc, _ = idx.stage_a(s_, t, oracle_lib.default_params(end_rule_nonbranching=er))
+                ec, st, _, _ = emu.stage_a(s_, t, 100, 10000, er)
+                assert st == 0 and ec == oc, (k, rep, hex(st), seqs)
+        idx.close()
+        emu.close()
+    assert emu_lib.coop_counts()[3] - before >= 20  # the fast path did answer tips
