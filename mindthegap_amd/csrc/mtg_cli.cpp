@@ -179,7 +179,9 @@ struct PositionedWriter {
             fd[i] = -1; pos[i] = 0;
             if (s) { fflush(s); fd[i] = fileno(s); pos[i] = ftello(s); }
         }
-        const int nw = std::max(1, std::min(12, Pool::cpu_budget() - 2)); /* a memory-backed file takes ≈ 1.2 GB/s from a thread (page allocation + copy): 6 writers were the tool's last 85 ms */
+        /* writers: write(2) on ONE file is serialised by the file's lock -- the memory-backed file system of the GPU box takes 8.7 GB/s for a file from 1,
+         * 2, 4 or 12 threads alike (scripts/tmpfs_write_ceiling.py) -- so two per large file are all that help; more only take CPUs from the workers */
+        const int nw = std::max(1, std::min(getenv("MTG_CLI_WRITERS") ? atoi(getenv("MTG_CLI_WRITERS")) : 6, Pool::cpu_budget() - 2));
         for (int t = 0; t < nw; t++) threads.emplace_back([this] { run(); });
     }
     static const std::string& text_of(const OutText& T, int i) { return i == 0 ? T.insert : i == 1 ? T.info : i == 2 ? T.vcf : i == 3 ? T.gfa : T.ext; }
@@ -868,7 +870,11 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         /* the text of the sites with one solution is written on the device (mtg_fill_text_formatted); MTG_HOST_FORMAT=1: A/B hook, every site by the host's writers */
         static const bool dev_format = getenv("MTG_HOST_FORMAT") == nullptr;
         int rc;
-        if (dev_format) { bt.ftext = ftext_pool().get(); rc = mtg_fill_text_formatted(idx, &P, &gf, bt.name_off.data(), bt.name_len.data(), &bt.rf, &bt.ftext); }
+        /* with the text formatted on the device a call needs the worker pool for one thing only, the copy of its 13 MB block of text: two threads do
+         * that (measured: 10.9-12.4 M sites/s with two pool threads, 6.7-10.8 with sixteen that spin next to the writers on a 16-CPU quota) */
+        mtg_params Pf = P;
+        if (dev_format && (Pf.nb_host_threads <= 0 || Pf.nb_host_threads > 2)) Pf.nb_host_threads = 2;
+        if (dev_format) { bt.ftext = ftext_pool().get(); rc = mtg_fill_text_formatted(idx, &Pf, &gf, bt.name_off.data(), bt.name_len.data(), &bt.rf, &bt.ftext); }
         else rc = mtg_fill_text(idx, &P, &gf, &bt.rf);
         if (rc) return rc;
         t_fill += usec() - tp; tp = usec();
@@ -896,7 +902,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
                 }
             if (nr) {
                 const mtg_text_gaps gr = bt.rev.view(bt.rev_text.data(), bt.rev_text.size());
-                rc = mtg_fill_text(idx, &P, &gr, &bt.rr);
+                rc = mtg_fill_text(idx, dev_format ? &Pf : &P, &gr, &bt.rr);
                 if (rc) return rc;
             }
         }
