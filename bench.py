@@ -97,7 +97,7 @@ def main():
     import torch.distributed as dist
     import mindthegap_amd as mtg
     from mindthegap_amd import lib as L
-    from mindthegap_amd.shard import PipelinedGather, shard_range, wire_check
+    from mindthegap_amd.shard import PipelinedGather, SlottedGather, shard_range, wire_check
     from mindthegap_amd.synth import SynthSet
 
     # the ranks of a node share its CPUs (and, in a container, one CFS quota): each rank's worker pool gets its share
@@ -343,7 +343,15 @@ def main():
             need = max([0] + [sum(len(e) + 1 for e in b.expected) + 96 * b.n + 4096 for b in batches])
             cap = torch.tensor([need], dtype=torch.int64, device=cdev)
             dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-            st["pg"] = PipelinedGather(int(cap.item()) * 51 // 50 + (1 << 16), dst=0, device=cdev, depth=int(os.environ.get("MTG_BENCH_GATHER_DEPTH", "0")) or max(a.in_flight, 1) + 1, on_arrival=on_arrival if rank == 0 else None)
+            # several payloads per collective when a rank has several batches per step (the orchestration of a gather, not its bytes, is what a rank pays per batch)
+            slots = int(os.environ.get("MTG_BENCH_GATHER_SLOTS", "0")) or (3 if cfg["max_per_rank"] >= 3 else 1)
+            depth = int(os.environ.get("MTG_BENCH_GATHER_DEPTH", "0")) or (max(a.in_flight, 1) + 1 if slots == 1 else max(3, (max(a.in_flight, 1) + slots - 1) // slots + 2))
+            cap_p = int(cap.item()) * 51 // 50 + (1 << 16)
+            if slots > 1:
+                st["pg"] = SlottedGather(cap_p, slots=slots, dst=0, device=cdev, depth=depth, on_arrival=on_arrival if rank == 0 else None)
+            else:
+                st["pg"] = PipelinedGather(cap_p, dst=0, device=cdev, depth=depth, on_arrival=on_arrival if rank == 0 else None)
+            st["gather_slots"] = slots
         run_block(a.warmup, False)
 
         def timed_block(first_step):
@@ -532,6 +540,41 @@ def main():
         secondary["value_sequences_left_in_hbm"] = batch_sites * a.steps / float(np.median(ts))
         secondary["value_sequences_left_in_hbm_note"] = ("same steps through mtg_fill_prepared_serial_device: records to the host, ASCII sequences into a device buffer of the caller "
                                                          "(median of 5 blocks; one buffer verified against the truth: %s)" % ok_hbm)
+
+    # ---------------------------------------------------------------- secondary: what ONE rank of an 8-GPU job does per step -- the shard sizes of strong scaling at N = 8
+    # (75 000 sites per rank of the 600 000-site set; 12 500 of BASELINE config 5's literal 100 000), filled as prepared batches with six in flight, no gather:
+    # the fixed costs of a launch (eight kernels of 45-60 us floors, the copies' latencies) are what an 8-GPU run pays 8 x per step
+    if single and not a.no_secondary and not a.host_strings and batches and batch_sites >= 100000:
+        outlook = {}
+        for per_rank in (75000, 12500):
+            try:
+                sub = idx.prepare_batch(mtg.Index.prepare_gaps(batches[0].gaps[:per_rank]), params)
+                def run_sub(count):
+                    it = iter(range(count))
+                    lk = threading.Lock()
+                    def w():
+                        torch.cuda.set_device(local_rank)
+                        while True:
+                            with lk:
+                                if next(it, None) is None:
+                                    return
+                            h_s, _nf, _ = idx.fill_prepared(sub, params, want_seqs=False)
+                            idx.free_results(h_s)
+                    ts_ = [threading.Thread(target=w) for _ in range(max(1, a.in_flight))]
+                    for t_ in ts_: t_.start()
+                    for t_ in ts_: t_.join()
+                run_sub(12)
+                reps = []
+                for _ in range(5):
+                    torch.cuda.synchronize(); t0 = time.perf_counter(); run_sub(a.steps); torch.cuda.synchronize(); reps.append(time.perf_counter() - t0)
+                t_b = float(np.median(reps)) / a.steps
+                outlook[str(per_rank)] = {"sites_per_rank_and_step": per_rank, "ms_per_step_of_one_rank": t_b * 1e3, "sites_per_s_of_one_rank": per_rank / t_b,
+                                          "times_8_if_the_ranks_do_not_interfere": 8 * per_rank / t_b, "efficiency_vs_8x_the_headline": (8 * per_rank / t_b) / (8 * value) if value else None}
+                sub.close()
+            except Exception as e:
+                outlook[str(per_rank)] = {"error": repr(e)[:200]}
+        secondary["eight_gpu_outlook_from_one_rank"] = {"what": "one rank's share of a strong-scaling step at N = 8, measured on this one GPU (prepared batches, six in flight, results to host memory, NO gather and no second rank: "
+                                                                "an upper bound of what eight ranks reach together; the gather's per-batch cost is in profiles/r04_dry_one_rank_rccl.json)", "shards": outlook}
 
     # ---------------------------------------------------------------- secondary: the tool.  `MindTheGap fill -bkpt` on the sites of the batches, through the library's
     # own tool entry on the index that is already in HBM (mtg_fill_main_on_index = Filler::execute behind the graph load: the load of a 36 GB

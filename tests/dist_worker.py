@@ -74,6 +74,47 @@ def main(out_path):
         with open(out_path, "wb") as f:
             for p in parts:
                 f.write(p.tobytes())
+    # several payloads per collective (SlottedGather: what bench.py uses when a rank has several batches per step): seven tagged payloads through buffers of
+    # two slots from two caller threads; rank 0 must see every (rank, tag) once, with the payload that rank sent under that tag
+    from mindthegap_amd.shard import SlottedGather
+    seen3, lock3 = {}, threading.Lock()
+
+    def arrive3(items):
+        with lock3:
+            for it in items:
+                r, tag, t = it
+                if tag >= 0:
+                    assert (r, tag) not in seen3
+                    seen3[(r, tag)] = t.cpu().numpy().tobytes()
+
+    sg = SlottedGather(256, slots=2, dst=0, depth=3, on_arrival=arrive3 if rank == 0 else None)
+    todo3 = iter(range(7))
+
+    def worker3():
+        try:
+            while True:
+                with lock:
+                    t = next(todo3, None)
+                if t is None:
+                    return
+                h3, buf3 = sg.acquire()
+                msg = ("rank %d payload %d " % (rank, t)).encode() * (1 + t)
+                buf3[: len(msg)] = np.frombuffer(msg, dtype=np.uint8)
+                sg.submit(len(msg), h3, tag=t)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker3) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    sg.drain()
+    if rank == 0:
+        assert sorted(seen3) == [(r, t) for r in range(world) for t in range(7)], sorted(seen3)
+        for (r, t), b in seen3.items():
+            assert b == ("rank %d payload %d " % (r, t)).encode() * (1 + t)
     # the whole path a multi-GPU run of the tool takes: shards of batches, results (records AND sequences, tagged with their batch index) gathered on
     # rank 0, put back in input order and written by the tool's own writers -- the files must equal those of the single-process tool
     from mindthegap_amd.shard import fill_bkpt_sharded
