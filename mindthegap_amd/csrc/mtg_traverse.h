@@ -13,6 +13,10 @@
 #ifndef MTG_TRAVERSE_H
 #define MTG_TRAVERSE_H
 #include "mtg_dev.h"
+#ifdef MTG_EMU
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace mtg {
 
@@ -1295,6 +1299,7 @@ MTG_UNROLL
 MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev_c, int& chosen);
 #ifdef MTG_EMU
 inline unsigned long& tip_fast_answers() { static unsigned long n = 0; return n; } /* TEST-ONLY: tips the fast path has answered (the tests want to see some) */
+inline unsigned long& indel_bulk_answers() { static unsigned long n = 0; return n; } /* the same for the unequal-length bubbles */
 #endif
 /* ---- the TIP, recognised and answered like the SNP bubble (round 4).  Sequencing errors near the end of a read leave short dead-end branches
  * (abundance >= the cut-off three times over: rare per site, but 8-12 % of the walks of a reads-built graph meet one).  Pattern: the node has two
@@ -1386,6 +1391,170 @@ MTG_DEV_NOINLINE int tip_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const
 #endif
 }
 
+/* ---- the INDEL bubble: two whole-unitig branches of DIFFERENT lengths that lead to the same node (round 4).  A heterozygous insertion or
+ * deletion: the node has two out-edges whose targets have in-degree 1, branch S is a stored unitig (or one k-mer) of Ls nodes, branch G one of
+ * Lg = Ls + delta nodes, the last nodes of both have the single successor e (two in-edges), and e starts a stored unitig with at least delta + 1
+ * nodes behind it.  On such a subgraph the reference's explore_branching is determined:
+ *   find_end_of_branching   both branches advance level by level; S steps onto e at depth Ls + 1 and goes on along e's unitig; when G steps
+ *                           onto e (depth Lg + 1) e is already seen, the frontline is the single node c(delta) -- delta nodes past e --: end,
+ *                           depth d = Lg + 1.  (The in-branching check of e walks back along G and ends at the node, which is marked: no large
+ *                           in-branching; see delta = 2 below for the node that is not.)
+ *   all_consensuses_between two paths to that end: through S, d nucleotides; through G, d + delta.  The depth allowance is d + 1 and a frame
+ *                           deeper than d + 2 fails the whole enumeration: delta >= 3 -> explore_branching returns 0; delta = 1, 2 -> two consensuses.
+ *   validate_consensuses    lengths d and d + delta (the standard-deviation rule passes), identity by the alignment's lower bounds exactly as the
+ *                           general code computes them (if they do not settle it the general code is left to decide, with the alignment);
+ *                           the larger integer mean abundance over [node, path nodes without the end] wins, the first (smaller first
+ *                           nucleotide) on a tie;
+ *   marking                 of the involved nodes only e is branching.
+ * Returns the length of the chosen consensus (its nucleotides in out_seq), -1 when the reference's answer is "no consensus" (delta >= 3: the
+ * contig ends here, nothing is marked), 0 when this is not the pattern.  The TEST-ONLY emulation runs the general code next to every answer (0xBADF). */
+MTG_DEV_NOINLINE int indel_bulk(Worker& W, const Kmer& cur, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], SnpSeq& out_seq)
+{
+    const int k = W.k;
+    const UStore& us = W.ix.us;
+    if (cur.f == cur.r || !us.nwords) return 0;
+    /* the two branches: whole chains from their first nodes; a branch of one k-mer has its end junction right behind its first node */
+    uint32_t Lb[2];
+    Kmer lastn[2];
+    RunAt ra[2];
+    bool run[2];
+    Adj rl[2];
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        run[br] = false;
+        if (popc4(r[br].out) != 1) return 0;
+        if (popc4(r[br].in) == 1) {
+            if (!run_at(us, r[br], k, ra[br], W.lines)) return 0;
+            run[br] = true;
+            Lb[br] = ra[br].ahead + 1u;
+            if (Lb[br] > (uint32_t)SNP_MAX_L) return 0;
+            lastn[br] = run_node(us, ra[br].kpos, ra[br].bwd, ra[br].ahead, k);
+            rl[br] = adj_right_t(W.ix.adj, lastn[br], W.mk1, W.lines);
+        } else { Lb[br] = 1u; lastn[br] = x[br]; rl[br] = r[br]; }
+        if (popc4(rl[br].out) != 1 || popc4(rl[br].in) != 2) return 0;
+        if (lastn[br].f == lastn[br].r) return 0;
+    }
+    if (Lb[0] == Lb[1]) return 0; /* equal lengths: the SNP forms */
+    const Kmer e = kmer_next(lastn[0], (uint32_t)ctz4(rl[0].out), k, W.mk);
+    {
+        const Kmer e1 = kmer_next(lastn[1], (uint32_t)ctz4(rl[1].out), k, W.mk);
+        if (e.f != e1.f) return 0;
+    }
+    const uint64_t ce = canon(e);
+    if (e.f == e.r || ce == canon(cur) || ce == prev_c || e.f == lastn[0].r || e.f == lastn[1].r) return 0;
+    const int sb = Lb[0] < Lb[1] ? 0 : 1, gb = 1 - sb;
+    const uint32_t delta = Lb[gb] - Lb[sb], d = Lb[gb] + 1u;
+    if ((int)(d + delta) > SNP_MAX_L || (int)d > W.cfg.mono_max_depth) return 0;
+    /* e's continuation: a stored unitig that starts with e, delta + 1 nodes at least behind it */
+    const Adj re = adj_right_t(W.ix.adj, e, W.mk1, W.lines);
+    RunAt rae;
+    if (!run_at(us, re, k, rae, W.lines) || rae.ahead < delta + 1u) return 0;
+    if (W.is_marked(ce)) return 0; /* the bubble touches an assembled region: the general code says what follows */
+    /* delta = 2: when e is checked for in-branching its second predecessor (G's last node) has not been reached yet, and a frontline walks back
+     * from it along G; it stops at the node BECAUSE the node is marked (every branching node the walk has stepped onto is) -- the first node of
+     * a contig is not, the frontline goes on behind it and what it meets there joins the involved nodes: the general code's business */
+    if (delta == 2u && !W.is_marked(canon(cur))) return 0;
+    int answer;
+    SnpSeq seq[2];
+    unsigned long sum[2] = {0, 0};
+    int len[2] = {0, 0};
+    if (delta >= 3u) answer = -1;
+    else {
+        /* the nucleotides: first one, the branch's own (off the store), the step onto e, delta of e's unitig */
+        const uint32_t ne_first = (uint32_t)ctz4(re.out);
+        uint32_t tail = ne_first; /* c(1) .. c(delta): at most two nucleotides */
+        if (delta == 2u) tail |= us_peek(us.words, rae.bwd ? rae.kpos - 2u : rae.kpos + (uint32_t)k + 1u, 1u, rae.bwd) << 2; /* the nucleotide behind c(1) */
+        /* abundances of the nodes both paths share: the node, e, c(1) .. c(delta - 1) */
+        unsigned long shared = abundance(W.ix, cur, W.lines) + abundance(W.ix, e, W.lines);
+        if (delta == 2u) shared += abundance(W.ix, run_node(us, rae.kpos, rae.bwd, 1u, k), W.lines);
+MTG_UNROLL
+        for (int br = 0; br < 2; br++) {
+            seq[br].lo = nt0[br]; seq[br].hi = 0;
+            int n = 1;
+            unsigned long sb_ = 0;
+            if (run[br]) {
+                const uint32_t m = ra[br].ahead; /* nodes behind the first */
+                for (uint32_t done = 0; done < m;) {
+                    const uint32_t c = m - done < 16u ? m - done : 16u;
+                    uint32_t bits = us_peek(us.words, ra[br].bwd ? ra[br].kpos - 1u - done : ra[br].kpos + (uint32_t)k + done, c, ra[br].bwd);
+                    for (uint32_t j = 0; j < c; j++) { seq[br].set(n++, bits & 3u); bits >>= 2; }
+                    done += c;
+                }
+                /* abundance bytes of the branch's m + 1 k-mers: they start at kpos (forward) or kpos - m (backward) */
+                const uint64_t a0 = ra[br].bwd ? ra[br].kpos - m : ra[br].kpos;
+                for (uint32_t i = 0; i <= m; i += 64u) sb_ += us_ab_sum(us.ab, a0 + i, (m + 1u - i) < 64u ? (m + 1u - i) : 64u);
+            } else sb_ = abundance(W.ix, x[br], W.lines);
+            seq[br].set(n++, (uint32_t)ctz4(rl[br].out));
+            for (uint32_t j = 0; j < delta; j++) /* both paths end at c(delta) */ seq[br].set(n++, (tail >> (2u * j)) & 3u);
+            len[br] = n;
+            sum[br] = shared + sb_;
+        }
+        W.lines += 4;
+        if (len[sb] != (int)d || len[gb] != (int)(d + delta)) return 0;
+        /* validate_consensuses on the two strings (the same integers) */
+        const int na = len[0], nb = len[1], mn = na < nb ? na : nb, mx = na < nb ? nb : na;
+        int mean = (na + nb) / 2;
+        if (mean > W.cfg.mono_max_depth) answer = -1;
+        else {
+            long long ss = 0;
+            { const long long d0 = (long long)na - mean, d1 = (long long)nb - mean; ss = d0 * d0 + d1 * d1; }
+            const long long t5 = mean / 5;
+            if (ss > t5 * t5 * 2) answer = -1;
+            else {
+                const SnpSeq& lg = na >= nb ? seq[0] : seq[1];
+                const SnpSeq& sh = na >= nb ? seq[1] : seq[0];
+                int s0 = -5 * (mx - mn);
+                for (int i = 0; i < mn; i++) s0 += (seq[0].get(i) == seq[1].get(i)) ? 10 : -5;
+                if (identity_below_90((s0 + 5 * mx <= 0) ? 0 : (s0 + 5 * mx + 14) / 15, na, nb)) {
+                    const int dl = mx - mn;
+                    int sc = -5 * dl;
+                    for (int i = 0; i < mn; i++) sc += (lg.get(i + dl) == sh.get(i)) ? 10 : -5;
+                    int best = sc;
+                    for (int p2 = 0; p2 < mn; p2++) {
+                        sc += ((lg.get(p2) == sh.get(p2)) ? 10 : -5) - ((lg.get(p2 + dl) == sh.get(p2)) ? 10 : -5);
+                        best = sc > best ? sc : best;
+                    }
+                    s0 = best > s0 ? best : s0;
+                }
+                const int num = s0 + 5 * mx;
+                const int mlb = num <= 0 ? 0 : (num + 14) / 15;
+                if (identity_below_90(mlb, na, nb)) return 0; /* the bound does not settle it: the general code runs the alignment */
+                unsigned long best = 0;
+                int ch = -1;
+                for (int c = 0; c < 2; c++) { const unsigned long m2 = sum[c] / (unsigned long)len[c]; if (m2 > best) { best = m2; ch = c; } }
+                if (ch < 0 || len[ch] > W.cfg.mono_max_depth) answer = -1;
+                else { answer = len[ch]; out_seq = seq[ch]; }
+            }
+        }
+    }
+#ifdef MTG_XCHECK /* TEST-ONLY: the general code on the same node */
+    {
+        const uint32_t nm0 = W.n_marked;
+        int ch2 = -1;
+        const int n2 = explore_branching(W, cur, prev_c, ch2);
+        if (W.status == GAP_OK) {
+            bool same;
+            if (answer < 0) same = n2 == 0 && W.n_marked == nm0;
+            else {
+                same = n2 == answer && W.n_marked - nm0 == 1u && W.is_marked(ce);
+                const SP<uint8_t> p2 = s_cons(W.cfg, W.S) + (size_t)(ch2 < 0 ? 0 : ch2) * CONS_LEN;
+                for (int i = 0; i < answer && same; i++) same = p2[i] == (uint8_t)out_seq.get(i);
+            }
+            if (!same) W.status = 0xBADF;
+        }
+        if (W.status != GAP_OK) return 0;
+        indel_bulk_answers()++;
+        return answer; /* the general code has made the mark */
+    }
+#else
+    if (answer > 0) W.mark_canon(ce);
+#ifdef MTG_EMU
+    indel_bulk_answers()++;
+#endif
+    return answer;
+#endif
+}
+
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen, SnpSeq& chosen_seq)
 {
     if (!W.S.snp_fast || W.cfg.end_rule_nonbranching) return 0;
@@ -1444,6 +1613,11 @@ MTG_UNROLL
             const int tn = tip_fast(W, cur, prev_c, x, nt0, r1, chosen_seq);
             if (W.status) return 0;
             if (tn > 0) { chosen = 0; MTG_COUNT(W, 14); return tn; }
+        }
+        {   /* two unitig branches of different lengths onto one node: an insertion / deletion, answered or refused on the spot (-1: no consensus) */
+            const int in_ = indel_bulk(W, cur, prev_c, x, nt0, r1, chosen_seq);
+            if (W.status) return 0;
+            if (in_ != 0) { chosen = 0; return in_; }
         }
         bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be, hopeless);
 #ifndef MTG_XCHECK
@@ -2164,8 +2338,12 @@ MTG_UNROLL
             resuming = false;
             MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
+            const bool refused = n < 0 || W.status != GAP_OK; /* the fast forms know the reference's answer is "no consensus" (indel_bulk): the contig ends here, nothing is parked.
+                                                               * (A status can only come from the TEST-ONLY cross-checks inside the fast forms: it must end the gap here -- a parked walk
+                                                               * is resumed with a fresh status and would bury it.) */
             bool coop = false;        /* the consensus sits in the group's LDS area */
-            if (!fast && answered) {
+            if (refused) n = 0;
+            else if (!fast && answered) {
                 /* a bubble kernel has answered this branching node while the gap was parked (the consensus where the one-lane code leaves it) */
                 n = saved_n; chosen = saved_chosen;
                 answered = false;

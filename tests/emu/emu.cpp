@@ -67,6 +67,7 @@ void emu_coop_counts(unsigned long* out)
     out[0] = t.ok; out[1] = t.fail; out[2] = 0;
     for (int i = 0; i < 10; i++) out[2] += t.big[i];
     out[3] = tip_fast_answers();
+    out[4] = indel_bulk_answers();
 }
 
 void emu_query(void* p, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
@@ -112,6 +113,7 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
         /* the device relies on every gap handing the zero region back clean: make a violation visible as a status no test expects */
         for (uint8_t z : zero) if (z) { out.status = 0xDEAD; break; }
         if (out.status == 0xDEAD) break;
+        if (out.status > GAP_OVF_DFS) break; /* not an overflow (a cross-check's 0xBAD*, a guard): a larger tier must not paper over it */
         if (tier_used) *tier_used = (uint32_t)t;
         if (out.status == GAP_OK) {
             joined.clear();

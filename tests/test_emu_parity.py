@@ -1208,3 +1208,36 @@ def test_tip_fast_path_against_the_general_code(k):
         idx.close()
         emu.close()
     assert emu_lib.coop_counts()[3] - before >= 20  # the fast path did answer tips
+
+
+@pytest.mark.parametrize("k", [31, 21, 13])
+def test_indel_bubbles_answered_by_the_walking_lane(k):
+    """round 4: two unitig branches of different lengths onto one node (a heterozygous insertion / deletion) are answered where the walk meets
+    them (mtg_traverse.h: indel_bulk): a length difference of 1 or 2 gives two consensuses and the more abundant one is taken, 3 and more is
+    the reference's "no consensus" (the depth allowance of its path enumeration) and the contig ends without a park.  The emulation runs the
+    general explore_branching next to every answer (0xBADF: length, consensus, marks) and the contigs must be the oracle's.  Deletions of
+    1 .. 5 nucleotides in one allele, on both strands, next to each other and next to SNPs, with abundances that favour either allele."""
+    rng = random.Random(1234 + k)
+    before = emu_lib.coop_counts()[4]
+    for rep in range(14):
+        g = _rand_seq(rng, rng.randrange(700, 1600))
+        h2 = list(g)
+        cuts = sorted(rng.sample(range(80, len(g) - 120), 5), reverse=True)
+        for j, p in enumerate(cuts):
+            dl = [1, 2, 3, 4, 5, 1, 2, 2][(rep + j) % 8]
+            del h2[p:p + dl]
+            if (rep + j) % 5 == 0:  # a SNP close by: the branches are no single unitigs any more, the general code decides
+                q = p - rng.randrange(2, k + 3)
+                h2[q] = rng.choice([c for c in "ACGT" if c != h2[q]])
+        h2 = "".join(h2)
+        seqs = [g, h2] + ([g] if rep % 3 == 0 else []) + ([h2, h2] if rep % 3 == 1 else [])  # abundances: equal, first allele heavier, second heavier
+        idx = oracle_lib.Index.from_sequences(seqs, k, 1, 0) if rep % 2 else oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = idx.export()
+        emu = emu_lib.EmuIndex(km, ct, k)
+        for s_, t in ((g[:k], g[-k:]), (_rc(g[-k:]), _rc(g[:k])), (h2[:k], h2[-k:])):
+            oc, _ = idx.stage_a(s_, t, oracle_lib.default_params())
+            ec, st, _, _ = emu.stage_a(s_, t, 100, 10000, 0)
+            assert st == 0 and ec == oc, (k, rep, hex(st), seqs)
+        idx.close()
+        emu.close()
+    assert emu_lib.coop_counts()[4] - before >= 30  # the bulk form did answer such bubbles
