@@ -1300,6 +1300,7 @@ MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev
 #ifdef MTG_EMU
 inline unsigned long& tip_fast_answers() { static unsigned long n = 0; return n; } /* TEST-ONLY: tips the fast path has answered (the tests want to see some) */
 inline unsigned long& indel_bulk_answers() { static unsigned long n = 0; return n; } /* the same for the unequal-length bubbles */
+inline unsigned long& merge_fast_answers() { static unsigned long n = 0; return n; } /* and for the nodes whose one successor has another predecessor */
 #endif
 /* ---- the TIP, recognised and answered like the SNP bubble (round 4).  Sequencing errors near the end of a read leave short dead-end branches
  * (abundance >= the cut-off three times over: rare per site, but 8-12 % of the walks of a reads-built graph meet one).  Pattern: the node has two
@@ -1555,9 +1556,55 @@ MTG_UNROLL
 #endif
 }
 
+/* ---- A node with ONE successor that has another predecessor as well (a side branch running into a junction: every contig that starts on an
+ * allele of a refused bubble ends up here, every tip walked from its far end, every read-error branch).  The simple-path rule stops at such a
+ * node (in-degree of the successor > 1) and the reference calls explore_branching, which on this subgraph is determined (default
+ * end rule; the caller has excluded the other):
+ *   find_end_of_branching   the frontline {node} moves to {e} at depth 1 -- unless e is the node's own reverse complement or the previous node
+ *                           (already seen: the frontline empties) or a marked node (the bubble touches an assembled region) -- and a frontline of
+ *                           one node is the end: depth 1, no in-branching check is ever run (checks start at depth 1, on the way to depth 2);
+ *   all_consensuses_between the one nucleotide;
+ *   validate_consensuses    one consensus of length 1: passes; its integer mean abundance is the node's own abundance, which must beat 0;
+ *   marking                 the involved nodes are {e}: branching (two in-edges), marked.
+ * Returns 1 (the nucleotide in out_seq) or 0 (not this pattern, or the answer is "no consensus": the general code says so).  The TEST-ONLY
+ * emulation runs the general code next to every answer (0xBAE0). */
+MTG_DEV_NOINLINE int merge_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, SnpSeq& out_seq)
+{
+    if (popc4(a.out) != 1) return 0;
+    const uint32_t nt = (uint32_t)ctz4(a.out);
+    const Kmer e = kmer_next(cur, nt, W.k, W.mk);
+    const uint64_t ce = canon(e);
+    if (ce == canon(cur) || ce == prev_c) return 0;
+    if (W.is_marked(ce)) return 0;
+    if (abundance(W.ix, cur, W.lines) == 0) return 0;
+    out_seq.lo = nt; out_seq.hi = 0;
+#ifdef MTG_XCHECK
+    {
+        const uint32_t nm0 = W.n_marked;
+        int ch2 = -1;
+        const int n2 = explore_branching(W, cur, prev_c, ch2);
+        if (W.status == GAP_OK && !(n2 == 1 && W.n_marked - nm0 == 1u && W.is_marked(ce) && s_cons(W.cfg, W.S)[(size_t)(ch2 < 0 ? 0 : ch2) * CONS_LEN] == (uint8_t)nt)) W.status = 0xBAE0;
+        if (W.status != GAP_OK) return 0;
+        merge_fast_answers()++;
+        return 1; /* the general code has made the mark */
+    }
+#else
+    W.mark_canon(ce);
+#ifdef MTG_EMU
+    merge_fast_answers()++;
+#endif
+    return 1;
+#endif
+}
+
 MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, int& chosen, SnpSeq& chosen_seq)
 {
     if (!W.S.snp_fast || W.cfg.end_rule_nonbranching) return 0;
+    if (popc4(a.out) == 1) {
+        const int mn = merge_fast(W, cur, prev_c, a, chosen_seq);
+        if (mn > 0) { chosen = 0; MTG_COUNT(W, 14); }
+        return mn;
+    }
     if (!(popc4(a.out) == 2 && popc4(a.in) == 1)) return 0;
     /* Pairwise distinctness of the canonical k-mers without a set.  Branch nodes have one in- and one out-edge, so do their reverse
      * complements; the node has two out-edges and e two in-edges, so rc(node) has two in-edges and rc(e) two out-edges: neither can be

@@ -68,6 +68,7 @@ void emu_coop_counts(unsigned long* out)
     for (int i = 0; i < 10; i++) out[2] += t.big[i];
     out[3] = tip_fast_answers();
     out[4] = indel_bulk_answers();
+    out[5] = merge_fast_answers();
 }
 
 void emu_query(void* p, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)

@@ -1213,12 +1213,12 @@ def test_tip_fast_path_against_the_general_code(k):
 @pytest.mark.parametrize("k", [31, 21, 13])
 def test_indel_bubbles_answered_by_the_walking_lane(k):
     """round 4: two unitig branches of different lengths onto one node (a heterozygous insertion / deletion) are answered where the walk meets
-    them (mtg_traverse.h: indel_bulk): a length difference of 1 or 2 gives two consensuses and the more abundant one is taken, 3 and more is
+    them (mtg_traverse.h: indel_bulk; merge_fast for the nodes that run into a junction): a length difference of 1 or 2 gives two consensuses and the more abundant one is taken, 3 and more is
     the reference's "no consensus" (the depth allowance of its path enumeration) and the contig ends without a park.  The emulation runs the
     general explore_branching next to every answer (0xBADF: length, consensus, marks) and the contigs must be the oracle's.  Deletions of
     1 .. 5 nucleotides in one allele, on both strands, next to each other and next to SNPs, with abundances that favour either allele."""
     rng = random.Random(1234 + k)
-    before = emu_lib.coop_counts()[4]
+    before, merges_before = emu_lib.coop_counts()[4], emu_lib.coop_counts()[5]
     for rep in range(14):
         g = _rand_seq(rng, rng.randrange(700, 1600))
         h2 = list(g)
@@ -1241,3 +1241,6 @@ def test_indel_bubbles_answered_by_the_walking_lane(k):
         idx.close()
         emu.close()
     assert emu_lib.coop_counts()[4] - before >= 30  # the bulk form did answer such bubbles
+    # the contigs that start on the alleles of a refused bubble run into the node behind it, which has two predecessors: the general code's one-nucleotide
+    # answer, given by the walking lane as well (merge_fast, cross-checked the same way: 0xBAE0)
+    assert emu_lib.coop_counts()[5] - merges_before >= 10
