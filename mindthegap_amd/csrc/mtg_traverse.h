@@ -1297,6 +1297,18 @@ MTG_UNROLL
 
 /* returns the consensus length (cons[chosen] filled) or 0: not the pattern */
 MTG_DEV_NOINLINE int explore_branching(Worker& W, const Kmer& cur, uint64_t prev_c, int& chosen);
+#ifdef MTG_XCHECK
+/* TEST-ONLY: a fast form says "the reference finds no consensus at this node" -- the general code must say the same and mark nothing (else `code`) */
+inline unsigned long* refusal_counts() { static unsigned long n[4] = {0, 0, 0, 0}; return n; } /* per code: 0xBAE0 (one successor), 0xBAE1 (a marked successor), 0xBAE2 (SNP pattern onto a marked node) */
+inline void xcheck_refusal(Worker& W, const Kmer& cur, uint64_t prev_c, uint32_t code)
+{
+    refusal_counts()[code & 3u]++;
+    const uint32_t nm0 = W.n_marked;
+    int ch = -1;
+    const int n2 = explore_branching(W, cur, prev_c, ch);
+    if (W.status == GAP_OK && !(n2 == 0 && W.n_marked == nm0)) W.status = code;
+}
+#endif
 #ifdef MTG_EMU
 inline unsigned long& tip_fast_answers() { static unsigned long n = 0; return n; } /* TEST-ONLY: tips the fast path has answered (the tests want to see some) */
 inline unsigned long& indel_bulk_answers() { static unsigned long n = 0; return n; } /* the same for the unequal-length bubbles */
@@ -1450,16 +1462,17 @@ MTG_UNROLL
     const Adj re = adj_right_t(W.ix.adj, e, W.mk1, W.lines);
     RunAt rae;
     if (!run_at(us, re, k, rae, W.lines) || rae.ahead < delta + 1u) return 0;
-    if (W.is_marked(ce)) return 0; /* the bubble touches an assembled region: the general code says what follows */
+    /* e marked: the bubble touches an assembled region -- the frontline gives up when S steps onto e, whatever the rest looks like */
+    const bool e_marked = W.is_marked(ce);
     /* delta = 2: when e is checked for in-branching its second predecessor (G's last node) has not been reached yet, and a frontline walks back
      * from it along G; it stops at the node BECAUSE the node is marked (every branching node the walk has stepped onto is) -- the first node of
      * a contig is not, the frontline goes on behind it and what it meets there joins the involved nodes: the general code's business */
-    if (delta == 2u && !W.is_marked(canon(cur))) return 0;
+    if (!e_marked && delta == 2u && !W.is_marked(canon(cur))) return 0;
     int answer;
     SnpSeq seq[2];
     unsigned long sum[2] = {0, 0};
     int len[2] = {0, 0};
-    if (delta >= 3u) answer = -1;
+    if (delta >= 3u || e_marked) answer = -1;
     else {
         /* the nucleotides: first one, the branch's own (off the store), the step onto e, delta of e's unitig */
         const uint32_t ne_first = (uint32_t)ctz4(re.out);
@@ -1561,12 +1574,13 @@ MTG_UNROLL
  * node (in-degree of the successor > 1) and the reference calls explore_branching, which on this subgraph is determined (default
  * end rule; the caller has excluded the other):
  *   find_end_of_branching   the frontline {node} moves to {e} at depth 1 -- unless e is the node's own reverse complement or the previous node
- *                           (already seen: the frontline empties) or a marked node (the bubble touches an assembled region) -- and a frontline of
- *                           one node is the end: depth 1, no in-branching check is ever run (checks start at depth 1, on the way to depth 2);
+ *                           (already seen: the frontline empties) or a marked node (the bubble touches an assembled region: the second contig to
+ *                           arrive at a junction), which all mean "no consensus" -- and a frontline of one node is the end: depth 1, no
+ *                           in-branching check is ever run (checks start at depth 1, on the way to depth 2);
  *   all_consensuses_between the one nucleotide;
  *   validate_consensuses    one consensus of length 1: passes; its integer mean abundance is the node's own abundance, which must beat 0;
  *   marking                 the involved nodes are {e}: branching (two in-edges), marked.
- * Returns 1 (the nucleotide in out_seq) or 0 (not this pattern, or the answer is "no consensus": the general code says so).  The TEST-ONLY
+ * Returns 1 (the nucleotide in out_seq), -1 ("no consensus": the contig ends here, nothing is marked, nothing parked) or 0 (not this pattern).  The TEST-ONLY
  * emulation runs the general code next to every answer (0xBAE0). */
 MTG_DEV_NOINLINE int merge_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a, SnpSeq& out_seq)
 {
@@ -1574,8 +1588,16 @@ MTG_DEV_NOINLINE int merge_fast(Worker& W, const Kmer& cur, uint64_t prev_c, con
     const uint32_t nt = (uint32_t)ctz4(a.out);
     const Kmer e = kmer_next(cur, nt, W.k, W.mk);
     const uint64_t ce = canon(e);
-    if (ce == canon(cur) || ce == prev_c) return 0;
-    if (W.is_marked(ce)) return 0;
+    if (ce == canon(cur) || ce == prev_c || W.is_marked(ce)) { /* seen already, or marked: the frontline has nowhere to go or gives up -- "no consensus", nothing marked */
+#ifdef MTG_XCHECK
+        xcheck_refusal(W, cur, prev_c, 0xBAE0);
+        if (W.status) return 0;
+#endif
+#ifdef MTG_EMU
+        merge_fast_answers()++;
+#endif
+        return -1;
+    }
     if (abundance(W.ix, cur, W.lines) == 0) return 0;
     out_seq.lo = nt; out_seq.hi = 0;
 #ifdef MTG_XCHECK
@@ -1604,6 +1626,19 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
         const int mn = merge_fast(W, cur, prev_c, a, chosen_seq);
         if (mn > 0) { chosen = 0; MTG_COUNT(W, 14); }
         return mn;
+    }
+    {   /* a successor that is marked (and not seen already: the node's reverse complement, the previous node): the reference's frontline gives up on
+         * its first step, whatever else leaves the node -- "no consensus", nothing marked */
+        const uint64_t cc = canon(cur);
+        for (uint32_t em = a.out & 15u; em; em &= em - 1u) {
+            const uint64_t cs = canon(kmer_next(cur, low_nt(em), W.k, W.mk));
+            if (cs == cc || cs == prev_c || !W.is_marked(cs)) continue;
+#ifdef MTG_XCHECK
+            xcheck_refusal(W, cur, prev_c, 0xBAE1);
+            if (W.status) return 0;
+#endif
+            return -1;
+        }
     }
     if (!(popc4(a.out) == 2 && popc4(a.in) == 1)) return 0;
     /* Pairwise distinctness of the canonical k-mers without a set.  Branch nodes have one in- and one out-edge, so do their reverse
@@ -1731,7 +1766,16 @@ MTG_UNROLL
     if (!suspect(ce)) return 0;
     for (int i = 0; i < ncand; i++) {
         const uint64_t c = i == 0 ? cand0 : i == 1 ? cand1 : i == 2 ? cand2 : cand3;
-        if (set_has(s_marked(W.cfg, W.S), W.cfg.mcap, c)) return 0; /* the bubble touches an assembled region */
+        if (set_has(s_marked(W.cfg, W.S), W.cfg.mcap, c)) {
+            /* The bubble touches an assembled region.  Only branching nodes are ever marked and the nodes of the two branches have one way in and
+             * one way out: the marked node is e, and the reference's frontline, which has come as far as this loop has (same nodes, same order,
+             * no in-branching to check), gives up when it steps onto it: "no consensus", nothing marked -- the contig ends here, without a park. */
+#ifdef MTG_XCHECK
+            xcheck_refusal(W, cur, prev_c, 0xBAE2);
+            if (W.status) return 0;
+#endif
+            return -1;
+        }
     }
 #ifdef MTG_XCHECK
     if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, seq, L, ce, -1, 0)) dup_exact = true;

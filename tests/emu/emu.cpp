@@ -69,6 +69,11 @@ void emu_coop_counts(unsigned long* out)
     out[3] = tip_fast_answers();
     out[4] = indel_bulk_answers();
     out[5] = merge_fast_answers();
+#ifdef MTG_XCHECK
+    for (int i = 0; i < 3; i++) out[6 + i] = refusal_counts()[i];
+#else
+    out[6] = out[7] = out[8] = 0;
+#endif
 }
 
 void emu_query(void* p, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)

@@ -111,6 +111,6 @@ def product_on_emulator():
 
 def coop_counts(lanes=0):
     """(answered with a consensus, rejected, passed on as too big, tips answered by the fast path) by the group form of the bubble code in the emulation library so far"""
-    a = (C.c_ulong * 6)()
+    a = (C.c_ulong * 9)()
     load(lanes).emu_coop_counts(a)
-    return tuple(int(x) for x in a)  # the fourth: tips answered by the walking lane's fast path (tip_fast); the fifth: unequal-length bubbles (indel_bulk); the sixth: nodes whose one successor has a second predecessor (merge_fast)
+    return tuple(int(x) for x in a)  # the fourth: tips answered by the walking lane's fast path (tip_fast); the fifth: unequal-length bubbles (indel_bulk); the sixth: nodes whose one successor has a second predecessor (merge_fast); then the refusals the cross-checking build has verified: one successor / a marked successor / the SNP pattern onto a marked node

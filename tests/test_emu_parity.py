@@ -1218,7 +1218,7 @@ def test_indel_bubbles_answered_by_the_walking_lane(k):
     general explore_branching next to every answer (0xBADF: length, consensus, marks) and the contigs must be the oracle's.  Deletions of
     1 .. 5 nucleotides in one allele, on both strands, next to each other and next to SNPs, with abundances that favour either allele."""
     rng = random.Random(1234 + k)
-    before, merges_before = emu_lib.coop_counts()[4], emu_lib.coop_counts()[5]
+    before, merges_before, refused_before = emu_lib.coop_counts()[4], emu_lib.coop_counts()[5], emu_lib.coop_counts()[6]
     for rep in range(14):
         g = _rand_seq(rng, rng.randrange(700, 1600))
         h2 = list(g)
@@ -1244,3 +1244,5 @@ def test_indel_bubbles_answered_by_the_walking_lane(k):
     # the contigs that start on the alleles of a refused bubble run into the node behind it, which has two predecessors: the general code's one-nucleotide
     # answer, given by the walking lane as well (merge_fast, cross-checked the same way: 0xBAE0)
     assert emu_lib.coop_counts()[5] - merges_before >= 10
+    # ... and the second contig to arrive at that node finds it marked: "no consensus" said on the spot (the general code run next to it agrees, 0xBAE0)
+    assert emu_lib.coop_counts()[6] - refused_before >= 5
