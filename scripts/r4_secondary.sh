@@ -12,7 +12,7 @@ w, p = sys.argv[1], sys.argv[2]
 try:
     d = json.loads([l for l in open(p) if l.startswith("{")][-1])
     k = {x["kernel"]: round(x["avg_kernel_ms"] or 0.0, 3) for x in d["roofline"].get("kernels", [])}
-    print(w, round(d["value"] / 1e6, 1), "M/s; identical to the oracle sample:", d["cpu_baseline"].get("identical_to_oracle"), "; kernels alone (ms):", k)
+    print(w, round(d["value"] / 1e6, 1), "M/s; identical to the oracle sample:", d["cpu_baseline"].get("identical_to_hip"), "; kernels alone (ms):", k)
 except Exception as e:
     print(w, "FAILED", e)
 PY
