@@ -357,6 +357,22 @@ int mtg_fill_main(int argc, const char* const* argv);
 int mtg_fill_main_on_index(mtg_index* idx, int argc, const char* const* argv);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Tuning: every switch of the library -- capacities, A/B hooks of measured alternatives, hooks the tests use to force rare paths,
+ * diagnostics -- is an entry of ONE table (mindthegap_amd/csrc/mtg_tuning.h: name, default, kind, what it does; INTEGRATION.md prints it).
+ * An entry NAME starts from the environment variable MTG_NAME (or from MTG_TUNING="NAME=value,NAME=value"), and these calls list, read and
+ * set the entries at run time.  A value set here holds for the calls that begin after it; an index keeps the capacities it was built with.
+ * There is no equivalent in the reference (its options are all on the command line, src/Filler.cpp:95-135, and are mtg_params here): the
+ * table only steers HOW this library computes, never WHAT -- every setting gives the same results, which is what the tests use it for.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t mtg_tuning_count(void);
+/* entry i: its name (without the MTG_ prefix), default ("" = not set), kind ("cap", "ab", "test", "diag") and description; static strings */
+int mtg_tuning_describe(size_t i, const char** name, const char** dflt, const char** kind, const char** what);
+/* the current value of an entry, "" when it is not set; MTG_ERR_ARG: no such entry, or cap too small */
+int mtg_tuning_get(const char* name, char* value, size_t cap);
+/* value NULL or "": "not set" -- overriding the environment and the default (to return to the default, set the default string) */
+int mtg_tuning_set(const char* name, const char* value);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Bench support: measured ceiling of dependent random reads of line_bytes (16/32/64/128) over a table of the given size.
  * ---------------------------------------------------------------------------------------------------------- */
 int mtg_bench_random_lines(uint64_t table_bytes, uint64_t n_chains, uint32_t chain_len, uint32_t line_bytes, double* ms, double* gbps);

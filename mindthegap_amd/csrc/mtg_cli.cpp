@@ -181,7 +181,7 @@ struct PositionedWriter {
         }
         /* writers: write(2) on ONE file is serialised by the file's lock -- the memory-backed file system of the GPU box takes 8.7 GB/s for a file from 1,
          * 2, 4 or 12 threads alike (scripts/tmpfs_write_ceiling.py) -- so two per large file are all that help; more only take CPUs from the workers */
-        const int nw = std::max(1, std::min(getenv("MTG_CLI_WRITERS") ? atoi(getenv("MTG_CLI_WRITERS")) : 6, Pool::cpu_budget() - 2));
+        const int nw = std::max(1, std::min((int)tune::i(tune::T_CLI_WRITERS, 6), Pool::cpu_budget() - 2));
         for (int t = 0; t < nw; t++) threads.emplace_back([this] { run(); });
     }
     static const std::string& text_of(const OutText& T, int i) { return i == 0 ? T.insert : i == 1 ? T.info : i == 2 ? T.vcf : i == 3 ? T.gfa : T.ext; }
@@ -485,7 +485,7 @@ struct Replicas {
     {
         idx.push_back(primary);
         const int ndev = mtg_device_count();
-        if (const char* e = getenv("MTG_NB_GPUS")) { if (want <= 0) want = atoi(e); }
+        if (tune::is_set(tune::T_NB_GPUS)) { if (want <= 0) want = (int)tune::i(tune::T_NB_GPUS); }
         int use = want > 0 ? std::min(want, ndev) : ndev;
         for (int d = 0, made = 1; d < ndev && made < use; d++) {
             if (d == primary->device) continue;
@@ -500,14 +500,12 @@ struct Replicas {
 };
 static size_t cli_batch_size()
 {
-    const char* e = getenv("MTG_CLI_BATCH");
-    const long v = e ? atol(e) : 0;
+    const long v = tune::i(tune::T_CLI_BATCH, 0);
     return v > 0 ? (size_t)v : (size_t)100000;
 }
 static int cli_in_flight()
 {
-    const char* e = getenv("MTG_CLI_IN_FLIGHT");
-    const int v = e ? atoi(e) : 0;
+    const int v = (int)tune::i(tune::T_CLI_IN_FLIGHT, 0);
     return v > 0 ? std::min(v, (int)mtg_index::NWS) : 3;
 }
 /* next(b) hands out batch b (false: the input is exhausted; called by one thread at a time, in order); process(b, idx) runs it on a
@@ -646,7 +644,7 @@ struct BkptReader {
             return f != nullptr;
         }
         struct stat sb;
-        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !getenv("MTG_CLI_NO_MMAP")) {
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !tune::on(tune::T_CLI_NO_MMAP)) {
             void* m = ::mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) { map = (const char*)m; map_size = (size_t)sb.st_size; (void)::madvise(m, map_size, MADV_SEQUENTIAL); }
         }
@@ -820,7 +818,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
     };
     enum { FORMAT_CHUNK = 2048 };
     /* MTG_TOOL_TIMERS=1: where the time of a run goes (summed over the worker threads; read and write are one thread each) */
-    static const bool timers = getenv("MTG_TOOL_TIMERS") != nullptr;
+    const bool timers = tune::on(tune::T_TOOL_TIMERS);
     std::atomic<long long> t_read{0}, t_parse{0}, t_fill{0}, t_rev{0}, t_format{0}, t_write{0};
     const auto usec = [] { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const long long w_start = usec();
@@ -868,7 +866,7 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
         const mtg_text_gaps gf = bt.fwd.view(t0, bt.text.size());
         t_parse += usec() - tp; tp = usec();
         /* the text of the sites with one solution is written on the device (mtg_fill_text_formatted); MTG_HOST_FORMAT=1: A/B hook, every site by the host's writers */
-        static const bool dev_format = getenv("MTG_HOST_FORMAT") == nullptr;
+        const bool dev_format = !tune::on(tune::T_HOST_FORMAT);
         int rc;
         /* with the text formatted on the device a call needs the worker pool for one thing only, the copy of its 13 MB block of text: two threads do
          * that (measured: 10.9-12.4 M sites/s with two pool threads, 6.7-10.8 with sixteen that spin next to the writers on a 16-CPU quota) */
@@ -1200,7 +1198,7 @@ static int run_tool(Options& O, mtg_index* idx, bool resident)
     }
     const double seconds = difftime(time(0), t_start);
     if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); return 1; }
-    if (resident && getenv("MTG_TOOL_QUIET")) return 0; /* measurements: no summary */
+    if (resident && tune::on(tune::T_TOOL_QUIET)) return 0; /* measurements: no summary */
     /* resumeParameters / resumeResults, src/Filler.cpp:385-481 */
     printf("MindTheGap fill\n    version                                  : %s\n    backend                                  : mindthegap_amd (HIP, gfx950)\n", MTG_VERSION);
     printf("Parameters\n    Input data\n");

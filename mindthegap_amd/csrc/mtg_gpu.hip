@@ -1306,7 +1306,7 @@ struct AllocTimer {
 };
 static hipError_t timed_malloc(void** p, size_t bytes)
 {
-    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    const bool dbg = tune::on(tune::T_DEBUG_TIMERS);
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e;
     { AllocTimer t; e = hipMalloc(p, bytes); }
@@ -1315,7 +1315,7 @@ static hipError_t timed_malloc(void** p, size_t bytes)
 }
 static hipError_t timed_free(void* p)
 {
-    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    const bool dbg = tune::on(tune::T_DEBUG_TIMERS);
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e;
     { AllocTimer t; e = hipFree(p); }
@@ -1421,14 +1421,14 @@ static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
 {
     const int k = idx->dev.k;
     /* ADJ entries are 16 bytes and looked up on a dependent chain: keep buckets sparse; ABND is only read by independent queries */
-    const double load_adj = (getenv("MTG_ADJ_LOAD") ? atof(getenv("MTG_ADJ_LOAD")) : 0.5) * load_scale;
-    const double load = (getenv("MTG_ABND_LOAD") ? atof(getenv("MTG_ABND_LOAD")) : 0.6) * load_scale;
+    const double load_adj = tune::f(tune::T_ADJ_LOAD, 0.5) * load_scale;
+    const double load = tune::f(tune::T_ABND_LOAD, 0.6) * load_scale;
     table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
     table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
     const size_t ba = idx->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
     HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));   /* a failure further down leaves the pointers to free_tables (IndexGuard) */
     HIP_TRY(hipMalloc((void**)&idx->dev.abnd.slots, bb));
-    const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
+    const double bpk = tune::f(tune::T_BLOOM_BITS, 12.0);
     size_t bc = 0;
     idx->dev.bloom.bits = nullptr;
     idx->dev.bloom.nblocks = 0;
@@ -1479,7 +1479,7 @@ static int build_unitigs(mtg_index* idx)
     idx->info.nb_unitigs = 0;
     idx->info.unitig_bytes = 0;
     const unsigned long long n_starts = cnt[0];
-    if (n_starts == 0 || getenv("MTG_NO_UNITIGS")) return MTG_OK;
+    if (n_starts == 0 || tune::on(tune::T_NO_UNITIGS)) return MTG_OK;
     HIP_TRY(d_starts.alloc(n_starts * 8));
     hipLaunchKernelGGL(k_us_starts, dim3(blocks), dim3(256), 0, 0, idx->dev, d_cnt.as<unsigned long long>(), d_starts.as<uint64_t>(), n_starts);
     HIP_TRY(hipGetLastError());
@@ -1510,7 +1510,7 @@ static int build_unitigs(mtg_index* idx)
     idx->info.unitig_bytes = (n_words + pad) * 40;
     idx->info.device_bytes += idx->info.unitig_bytes;
     /* the dense tables have served: the index proper is the store plus the few k-mers of no unitig (MTG_DENSE_INDEX=1: A/B and test hook) */
-    if (getenv("MTG_DENSE_INDEX")) return MTG_OK;
+    if (tune::on(tune::T_DENSE_INDEX)) return MTG_OK;
     return sparsify(idx, d_rec.as<UsRec>(), n_rec, false, nullptr, nullptr, 0);
 }
 
@@ -1555,7 +1555,7 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
     for (int attempt = 0; attempt < 6; attempt++) {
         Index nx = old;
         nx.adj.sp_words = nullptr; /* raw look-ups while the tables are being built */
-        const double load_adj = (getenv("MTG_SPARSE_ADJ_LOAD") ? atof(getenv("MTG_SPARSE_ADJ_LOAD")) : 0.49) * load; /* 0.7 overflows the displacement range at human scale (2-slot buckets) and cost a second attempt; 0.49 is what that attempt ran at */
+        const double load_adj = tune::f(tune::T_SPARSE_ADJ_LOAD, 0.49) * load; /* 0.7 overflows the displacement range at human scale (2-slot buckets) and cost a second attempt; 0.49 is what that attempt ran at */
         table_shape(nx.adj, buckets_for(nkeys, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
         table_shape(nx.abnd, buckets_for(n_left_shape + 1024, 0.6 * load, 2 * k, MTG_ABND_SLOTS), 2 * k);
         const size_t ba = nx.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = nx.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
@@ -1692,7 +1692,7 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
         idx->info.unitig_bytes = (n_words + pad) * 40;
     }
     /* the Bloom filter of the sequence scan: filled from the store and the k-mers of no unitig while the sparse tables are written */
-    const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
+    const double bpk = tune::f(tune::T_BLOOM_BITS, 12.0);
     idx->dev.bloom.bits = nullptr;
     idx->dev.bloom.nblocks = 0;
     if (bpk > 0) bloom_shape(idx->dev.bloom, idx->info.nb_solid_kmers, bpk, k);
@@ -1751,8 +1751,8 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
 
 /* MTG_DENSE_INDEX=1 / MTG_NO_UNITIGS=1 (test hooks: the dense form of the index, the index without a unitig store) and MTG_LEGACY_BUILD=1
  * (A/B) take the construction of rounds 1-3: dense ADJ + ABND tables, lookaheads, the store from them, then the sparse form */
-static bool legacy_build() { return getenv("MTG_DENSE_INDEX") || getenv("MTG_NO_UNITIGS") || getenv("MTG_LEGACY_BUILD"); }
-static double jt_load() { return getenv("MTG_JT_LOAD") ? atof(getenv("MTG_JT_LOAD")) : 0.7; }
+static bool legacy_build() { return tune::on(tune::T_DENSE_INDEX) || tune::on(tune::T_NO_UNITIGS) || tune::on(tune::T_LEGACY_BUILD); }
+static double jt_load() { return tune::f(tune::T_JT_LOAD, 0.7); }
 /* a cleared table of MTG_ABND_SLOTS-slot buckets for nkeys keys of key_bits bits */
 /* bytes the sparse ADJ table of a graph of n k-mers will take, give or take: half the junctions and a little (sparsify) */
 static size_t adj_bytes_estimate(uint64_t n, int k)
@@ -1782,7 +1782,7 @@ static int index_from_kmer_pieces_lean(size_t n, int k, const KmerFetch& fetch, 
     HIP_TRY(hipGetDevice(&idx->device));
     DevBuf d_k, d_a, d_cnt, jt_buf, abnd_buf;
     HIP_TRY(d_cnt.alloc(4 * 8));
-    const size_t env_piece = getenv("MTG_LOAD_PIECE") ? (size_t)atol(getenv("MTG_LOAD_PIECE")) : 0; /* test hook: small pieces */
+    const size_t env_piece = (size_t)tune::i(tune::T_LOAD_PIECE, 0); /* test hook: small pieces */
     const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
     HIP_TRY(d_k.alloc(piece * 8));
     HIP_TRY(d_a.alloc(piece * 4));
@@ -1883,7 +1883,7 @@ int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** 
     HIP_TRY(hipGetDevice(&idx->device));
     DevBuf d_k, d_a, d_cnt;
     HIP_TRY(d_cnt.alloc(4 * 8));
-    const size_t env_piece = getenv("MTG_LOAD_PIECE") ? (size_t)atol(getenv("MTG_LOAD_PIECE")) : 0; /* test hook: small pieces */
+    const size_t env_piece = (size_t)tune::i(tune::T_LOAD_PIECE, 0); /* test hook: small pieces */
     const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
     HIP_TRY(d_k.alloc(piece * 8));
     HIP_TRY(d_a.alloc(piece * 4));
@@ -2094,7 +2094,7 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
 {
     if (int rc = ensure_device()) return rc;
     if (d.k < 11 || d.k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    if (getenv("MTG_DENSE_INDEX") || d.n_words == 0) {
+    if (tune::on(tune::T_DENSE_INDEX) || d.n_words == 0) {
         /* test hook / an index without stored unitigs: through the list of its k-mers */
         std::vector<uint64_t> km(d.left_k);
         std::vector<uint32_t> ab(d.left_a);
@@ -2140,7 +2140,7 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
     if (!streamed) HIP_TRY(hipMemcpy(idx->dev.us.ab, d.ab.data(), nw * 32, hipMemcpyHostToDevice));
     else {
         const uint64_t total = nw * 32, piece = (uint64_t)32 << 20, npieces = (total + piece - 1) / piece;
-        const int env_threads = getenv("MTG_LOAD_THREADS") ? atoi(getenv("MTG_LOAD_THREADS")) : 0;
+        const int env_threads = (int)tune::i(tune::T_LOAD_THREADS, 0);
         const int nthreads = (int)std::min<uint64_t>(npieces, (uint64_t)(env_threads > 0 ? std::min(env_threads, 32) : std::min(8, std::max(2, Pool::cpu_budget() / 2))));
         uint8_t* dst = idx->dev.us.ab;
         const int device = idx->device;
@@ -2185,7 +2185,7 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
     HIP_TRY(upload(d_k, d.left_k.data(), d.left_k.size() * 8));
     HIP_TRY(upload(d_a, d.left_a.data(), d.left_a.size() * 4));
     prof.host_phase("store_words_up+headers", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(), nw * 8, hdr.size());
-    const double bpk = getenv("MTG_BLOOM_BITS") ? atof(getenv("MTG_BLOOM_BITS")) : 12.0;
+    const double bpk = tune::f(tune::T_BLOOM_BITS, 12.0);
     if (bpk > 0) {
         bloom_shape(idx->dev.bloom, d.nb_solid, bpk, d.k);
         HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, idx->dev.bloom.nblocks * 64));
@@ -2400,7 +2400,7 @@ struct CopyTurn {
     enum { MAX_DEV = 64 };
     struct State { std::mutex m; std::condition_variable c; int busy = 0; };
     static State& state(int dev) { static State st[MAX_DEV]; return st[(unsigned)dev % MAX_DEV]; }
-    static int slots() { static const int s = getenv("MTG_COPY_SLOTS") ? atoi(getenv("MTG_COPY_SLOTS")) : 3; return s; }
+    static int slots() { return (int)tune::i(tune::T_COPY_SLOTS, 3); }
     State* held = nullptr;
     explicit CopyTurn(int dev)
     {
@@ -2429,8 +2429,7 @@ static hipStream_t upload_stream_of(int dev)
 {
     static std::mutex m;
     static hipStream_t s[CopyTurn::MAX_DEV] = {};
-    static const bool own = getenv("MTG_UPLOAD_OWN_STREAM") != nullptr;
-    if (own) return nullptr;
+    if (tune::on(tune::T_UPLOAD_OWN_STREAM)) return nullptr;
     std::lock_guard<std::mutex> lk(m);
     hipStream_t& r = s[(unsigned)dev % CopyTurn::MAX_DEV];
     if (!r && hipStreamCreateWithFlags(&r, hipStreamNonBlocking) != hipSuccess) r = nullptr;
@@ -2440,7 +2439,7 @@ static hipStream_t upload_stream_of(int dev)
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, ResultSink& sink, DevBatch& special, mtg_batch_stats* stats, const std::function<void()>* while_busy)
 {
     bool busy_done = false;
-    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    const bool dbg = tune::on(tune::T_DEBUG_TIMERS);
     double tk = now_ms();
     auto tick = [&](const char* what) { if (dbg) { double t = now_ms(); fprintf(stderr, "  [device_run] %-18s %.2f ms\n", what, t - tk); tk = t; } };
     if (int rc = use_device_of(idx)) return rc;
@@ -2562,13 +2561,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     std::vector<uint32_t> todo; /* empty at tier 0: every gap, in order */
     size_t n_todo = n;
     int rc = MTG_OK;
-    const bool host_paths = getenv("MTG_HOST_PATHS") != nullptr; /* test hook: leave the path enumeration to the host */
+    const bool host_paths = tune::on(tune::T_HOST_PATHS); /* test hook: leave the path enumeration to the host */
     const bool want_records = sink.res != nullptr;
     size_t launches = 0;
 
     for (int tier = 0; tier <= MTG_MAX_TIER && n_todo; tier++) {
         FillCfg cfg = make_cfg(k, p->max_nodes, p->max_depth, p->end_rule_nonbranching, tier);
-        const bool no_defer = getenv("MTG_NO_DEFER") != nullptr; /* test hook: the lanes of the traversal copy their long runs themselves */
+        const bool no_defer = tune::on(tune::T_NO_DEFER); /* test hook: the lanes of the traversal copy their long runs themselves */
         if (no_defer || !idx->dev.us.nwords) cfg.cmd_cap = 0;
         /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
         const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + sizeof(mtg_gap_result) + sizeof(mtg_filled);
@@ -2579,7 +2578,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         const bool fits = ws.cap[d_zero.slot] >= m0 * cfg.zero_stride && ws.cap[d_raw.slot] >= m0 * cfg.raw_stride + 64 && ws.cap[d_ilv.slot] >= ((m0 + 63) / 64) * cfg.ilv_stride;
         if (!fits) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         size_t chunk = fits ? (size_t)m0 : (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
-        const size_t env_chunk = getenv("MTG_MAX_CHUNK") ? (size_t)atol(getenv("MTG_MAX_CHUNK")) : 0; /* test hook: several launches per batch */
+        const size_t env_chunk = (size_t)tune::i(tune::T_MAX_CHUNK, 0); /* test hook: several launches per batch */
         if (env_chunk && chunk > env_chunk) chunk = env_chunk;
         if (chunk > n_todo) chunk = n_todo;
         if (chunk > (1u << 20)) chunk = 1u << 20;
@@ -2631,10 +2630,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             std::unique_lock<std::mutex> traversal_lock(traversal_mtx[(unsigned)idx->device % CopyTurn::MAX_DEV][cset]);
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
-            static const bool classic_walk = getenv("MTG_CLASSIC_WALK") != nullptr; /* A/B hook: every bubble by its lane, from HBM scratch */
+            const bool classic_walk = tune::on(tune::T_CLASSIC_WALK); /* A/B hook: every bubble by its lane, from HBM scratch */
             /* lanes per parked gap: 1, 8, 16 or 64 (anything else, a typo included, is 16) */
-            static const int finish_g = [] { const int v = getenv("MTG_FINISH_G") ? atoi(getenv("MTG_FINISH_G")) : 16; return (v == 1 || v == 8 || v == 16 || v == 64) ? v : 16; }();
-            static const int env_rounds = getenv("MTG_ROUNDS") ? atoi(getenv("MTG_ROUNDS")) : -1;
+            const bool finish_g_set = tune::is_set(tune::T_FINISH_G);
+            const int finish_g = [] { const int v = (int)tune::i(tune::T_FINISH_G, 16); return (v == 1 || v == 8 || v == 16 || v == 64) ? v : 16; }();
+            const int env_rounds = (int)tune::i(tune::T_ROUNDS, -1);
             /* Rounds: when many gaps park (bubbles all over the data), their branching nodes are answered by the bubble kernels and the walks go
              * on in the walk kernel, one gap per lane again -- walking is cheap at full width, only the bubbles need a group -- for a few
              * rounds; what is still parked then (and everything, when few gaps park) is finished by groups in k_finish.  The host does not
@@ -2647,7 +2647,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
              * 45 us however short its segments (human-het: 7 launches 0.33 ms + bubble kernels 0.5 ms against 0.40 + 0.19 ms; 99 against 103 M/s),
              * the first bubble kernel waits for the launch's hundred general bubbles anyway, and a set with indels needs more rounds than it has
              * (25 against 33 M/s); choosing between the modes from the launches' own times picked the wrong one under six batches in flight. */
-            static const int env_park_snp = getenv("MTG_PARK_SNP") ? atoi(getenv("MTG_PARK_SNP")) : 0;
+            const int env_park_snp = (int)tune::i(tune::T_PARK_SNP, 0);
             const bool whole = tier == 0 && identity && m >= 4096;
             const int wmode = (env_park_snp > 0 && !classic_walk) ? 1 : 0;
             const uint32_t own_share = wmode ? ws.mode_share[1] : (ws.mode_share[0] != ~0u ? ws.mode_share[0] : ws.park_share);
@@ -2666,10 +2666,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
                                    d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u, wmode ? 2u : 1u);
                 HIP_TRY(hipEventRecord(evf, stream));
-                static const bool skip_finish = getenv("MTG_DEBUG_SKIP_FINISH") != nullptr; /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
+                const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with small bubbles that
                  * keeps more of them in flight than a group of lanes per bubble does (MTG_BUBBLE_GROUPS=1: k_bubble<G>, the LDS form, first) */
-                static const bool one_lane_bubbles = getenv("MTG_BUBBLE_GROUPS") == nullptr;
+                const bool one_lane_bubbles = !tune::on(tune::T_BUBBLE_GROUPS);
                 for (int r = 0; r < rounds; r++) {
                     const uint32_t lin = 2u * (uint32_t)r;
                     if (one_lane_bubbles) {
@@ -2691,18 +2691,18 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 /* how the tail is finished: a group of lanes per parked gap, bubbles from LDS.  One lane per gap (MTG_FINISH_G=1, or below
                  * MTG_FINISH_LANE_BELOW parked gaps in the workspace's previous launch) was measured and is slower at every size: 0.11 against
                  * 0.10 ms for the haploid set's 1-5 gaps, 0.83 against 0.35 for 108 (heterozygous SNPs), 1.12 against 0.56 for 12 000 (tips). */
-                static const int finish_lane_below = getenv("MTG_FINISH_LANE_BELOW") ? atoi(getenv("MTG_FINISH_LANE_BELOW")) : 0;
+                const int finish_lane_below = (int)tune::i(tune::T_FINISH_LANE_BELOW, 0);
                 /* lanes per parked gap in the finishing kernel: a whole wave while few gaps are parked (their chains are what the kernel takes:
                  * 0.17 against 0.32 ms for the 108 gaps of the heterozygous set), 16 when there are many (12 000 on the tips set: 0.46 against 0.63) */
-                static const int finish_wave_below = getenv("MTG_FINISH_WAVE_BELOW") ? atoi(getenv("MTG_FINISH_WAVE_BELOW")) : 2048;
-                const int fin_g = getenv("MTG_FINISH_G") ? finish_g : (rounds == 0 && park_hint < (uint32_t)finish_wave_below ? 64 : 16);
-                const bool lane_finish = finish_g == 1 || (!getenv("MTG_FINISH_G") && rounds == 0 && park_hint < (uint32_t)finish_lane_below);
+                const int finish_wave_below = (int)tune::i(tune::T_FINISH_WAVE_BELOW, 2048);
+                const int fin_g = finish_g_set ? finish_g : (rounds == 0 && park_hint < (uint32_t)finish_wave_below ? 64 : 16);
+                const bool lane_finish = (finish_g_set && finish_g == 1) || (!finish_g_set && rounds == 0 && park_hint < (uint32_t)finish_lane_below);
                 /* The grid.  The host does not know how many gaps are parked when it queues the kernel, and 100 000 groups that read one
                  * scalar and leave cost 63 us (round 3: 13 % of a haploid batch's kernels, for 5 parked gaps).  So the groups take the first
                  * `fin_entries` entries of the list -- four times what the previous launch of this workspace parked, plus 256 -- and the
                  * entries beyond, if a launch parks more than that after all, are walked one gap per lane (k_finish_lane, a grid of
                  * (m - fin_entries) / 64 workgroups: slower per gap, but only for the launch that outgrew the hint; the next one follows). */
-                static const bool finish_full_grid = getenv("MTG_FINISH_FULL_GRID") != nullptr; /* A/B hook: one group per gap of the launch, as in round 3 */
+                const bool finish_full_grid = tune::on(tune::T_FINISH_FULL_GRID); /* A/B hook: one group per gap of the launch, as in round 3 */
                 const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (finish_full_grid ? m : (uint32_t)std::min<uint64_t>(m, 4ull * park_hint + 256ull));
                 const uint32_t per_wg = 64u / (uint32_t)fin_g;
                 const uint32_t nwg = (fin_entries + per_wg - 1) / per_wg;
@@ -2731,7 +2731,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipGetLastError());
             /* ev1 .. evc: the long runs of the contigs, which the traversal only noted down */
-            static const bool no_lean = getenv("MTG_NO_LEAN") != nullptr; /* A/B and test hook: every contig is materialised */
+            const bool no_lean = tune::on(tune::T_NO_LEAN); /* A/B and test hook: every contig is materialised */
             hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
                                (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m, park, m);
             HIP_TRY(hipEventRecord(evl, stream)); /* ev1 .. evl: k_lean; evl .. evc: k_copy */
@@ -3151,7 +3151,7 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
      * overflow */
     uint64_t total_slots = 1ull << 16;
     while (total_slots < n_hint / 4) total_slots <<= 1;
-    const uint32_t forced = getenv("MTG_COUNT_PASSES") ? (uint32_t)atoi(getenv("MTG_COUNT_PASSES")) : 0;
+    const uint32_t forced = (uint32_t)tune::i(tune::T_COUNT_PASSES, 0);
     DevBuf d_text, d_flags, d_histo;
     const size_t text_cap = (size_t)80 << 20;
     HIP_TRY(d_text.alloc(text_cap));

@@ -23,6 +23,44 @@
 #include <cstring>
 #include <mutex>
 #include <set>
+
+/* ---- the tuning table (mtg_tuning.h): the C-ABI over it ---- */
+extern "C" {
+size_t mtg_tuning_count(void) { return (size_t)mtgi::tune::T_COUNT; }
+int mtg_tuning_describe(size_t i, const char** name, const char** dflt, const char** kind, const char** what)
+{
+    using namespace mtgi::tune;
+    if (i >= (size_t)T_COUNT) { mtgi::set_error("no tuning entry %zu", i); return MTG_ERR_ARG; }
+    if (name) *name = g_entries[i].name;
+    if (dflt) *dflt = g_entries[i].dflt;
+    if (kind) *kind = g_entries[i].kind;
+    if (what) *what = g_entries[i].what;
+    return MTG_OK;
+}
+int mtg_tuning_get(const char* name, char* value, size_t cap)
+{
+    using namespace mtgi::tune;
+    const int t = Values::find(name);
+    if (t < 0 || !value) { mtgi::set_error("no tuning entry named %s", name ? name : "(null)"); return MTG_ERR_ARG; }
+    Values& V = values();
+    std::lock_guard<std::mutex> lk(V.m);
+    const char* c = V.cur(t);
+    const size_t n = strlen(c);
+    if (n + 1 > cap) { mtgi::set_error("buffer too small"); return MTG_ERR_ARG; }
+    memcpy(value, c, n + 1);
+    return MTG_OK;
+}
+int mtg_tuning_set(const char* name, const char* value)
+{
+    using namespace mtgi::tune;
+    const int t = Values::find(name);
+    if (t < 0) { mtgi::set_error("no tuning entry named %s", name ? name : "(null)"); return MTG_ERR_ARG; }
+    Values& V = values();
+    std::lock_guard<std::mutex> lk(V.m);
+    if (!V.put(t, value)) { mtgi::set_error("value too long"); return MTG_ERR_ARG; }
+    return MTG_OK;
+}
+}
 #include <thread>
 #include <unordered_map>
 #include <zlib.h>
@@ -419,7 +457,7 @@ __attribute__((target("bmi2"))) inline uint64_t pack32_bmi2(const char* b) /* 32
     const uint64_t M = 0x0606060606060606ull; /* nt_code: bits 1-2 of the ASCII code */
     return _pext_u64(c[0], M) | (_pext_u64(c[1], M) << 16) | (_pext_u64(c[2], M) << 32) | (_pext_u64(c[3], M) << 48);
 }
-const bool have_bmi2 = __builtin_cpu_supports("bmi2") && !getenv("MTG_NO_VEC");
+const bool have_bmi2 = __builtin_cpu_supports("bmi2") && !tune::on(tune::T_NO_VEC);
 #endif
 inline uint64_t pack32(const char* b)
 {
@@ -902,7 +940,7 @@ int marshal_gaps(const mtg_gap* g, size_t n, const mtg_params* p, mtgi::FillInpu
     using namespace mtgi;
     const int k = in.k, nth = p->nb_host_threads;
     std::atomic<long> bad_gap{-1}, short_gap{-1};
-    static const bool prefetch_on = !getenv("MTG_NO_PREFETCH");
+    const bool prefetch_on = !tune::on(tune::T_NO_PREFETCH);
     /* the strings of a batch are wherever the caller has them: the passes ask for those of the gaps a few places ahead early */
     const auto prefetch = [&](size_t i) {
         if (!prefetch_on) return;
@@ -963,7 +1001,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
                     mtg_results** out, double t_begin, char* d_seq_out = nullptr, const WireReq* wire = nullptr, const mtg_text_gaps* tg = nullptr, const FormatReq* fmt = nullptr)
 {
     using namespace mtgi;
-    static const bool dbg = getenv("MTG_DEBUG_TIMERS") != nullptr;
+    const bool dbg = tune::on(tune::T_DEBUG_TIMERS);
     double tk = now_ms();
     auto tick = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "  [fill_batch] %-21s %.2f ms\n", what, t - tk); tk = t; } };
     mtg_results* R = results_acquire();

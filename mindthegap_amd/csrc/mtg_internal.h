@@ -11,6 +11,7 @@
 #include "mtg_emit.h"
 #include "mtg_copy.h"
 #include "mtg_format.h"
+#include "mtg_tuning.h"
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -163,7 +164,7 @@ private:
     Pool()
     {
         int n = std::min(cpu_budget(), 64);
-        if (const char* e = getenv("MTG_POOL_THREADS")) n = std::max(1, std::min(atoi(e), 256));
+        if (tune::is_set(tune::T_POOL_THREADS)) n = std::max(1, std::min((int)tune::i(tune::T_POOL_THREADS), 256));
         for (int i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
     }
     ~Pool()

@@ -1,0 +1,136 @@
+/*
+ * mtg_tuning.h -- every switch of the library in ONE table: its name, its default, what it does.
+ *
+ * Rounds 1-3 grew some forty getenv() calls next to the code they steer (capacities, A/B hooks of measured alternatives, hooks the tests use
+ * to force rare paths).  They are entries of MTG_TUNABLES now: the C-ABI lists, reads and sets them (include/mtg_fill.h: mtg_tuning_*), the
+ * environment still works -- entry X starts from the variable MTG_X, and MTG_TUNING="X=1,Y=0.5" sets several -- and the code asks
+ * tune::i(T_X) / tune::f(T_X) / tune::on(T_X) where it used to parse a string.  Value of an entry: what mtg_tuning_set (or MTG_TUNING) put
+ * there, else MTG_X of the environment as it is at the moment of the question, else the default; a change takes effect for the calls that
+ * begin after it (an index keeps the capacities it was built with).
+ *
+ * Kinds: "cap" a capacity or size a deployment may want to change; "ab" an A/B hook that keeps a measured alternative runnable (DESIGN.md
+ * says which measurement decided); "test" a hook the tests use to force a rare path; "diag" diagnostics on stderr.
+ * An empty default means "not set": flags are off, numbers take the value the code computes.
+ */
+#ifndef MTG_TUNING_H
+#define MTG_TUNING_H
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+
+/* X(name, default, kind, what) */
+#define MTG_TUNABLES(X) \
+    X(POOL_THREADS, "", "cap", "size of the host worker pool (default: the CPUs the process may use -- hardware threads, affinity mask, cgroup quota -- at most 64); read when the pool starts") \
+    X(COPY_SLOTS, "3", "cap", "batches of a device that copy their results to the host at the same time (0: no limit); more copies at once share the link worse") \
+    X(UPLOAD_OWN_STREAM, "", "ab", "every batch uploads its input on its own stream instead of the device's one upload stream (three uploads at a time take the link from the downloads: profiles/r04_text_entry.txt)") \
+    X(ADJ_LOAD, "0.5", "cap", "load factor of the dense junction table (legacy build)") \
+    X(ABND_LOAD, "0.6", "cap", "load factor of the abundance table") \
+    X(SPARSE_ADJ_LOAD, "0.49", "cap", "load factor of the sparse junction table, as a share of the dense one's; 0.7 overflows the displacement range at human scale") \
+    X(JT_LOAD, "0.7", "cap", "load factor of the lean build's junction table") \
+    X(BLOOM_BITS, "12", "cap", "Bloom filter bits per k-mer (0: no filter, no sequence scan)") \
+    X(LOAD_THREADS, "", "cap", "threads that stream a container's abundance bytes to the device (default: up to 8)") \
+    X(LOAD_PIECE, "", "test", "k-mers per piece when an index container is loaded (default 2^26): small pieces exercise the piece loop") \
+    X(COUNT_PASSES, "", "test", "force this many passes of the k-mer counting (default: as many as HBM needs)") \
+    X(LEGACY_BUILD, "", "ab", "the index construction of rounds 1-3 (dense tables first, then unitigs) instead of the lean build") \
+    X(DENSE_INDEX, "", "test", "keep the dense ADJ / ABND tables (every junction, every k-mer) instead of the sparse form") \
+    X(NO_UNITIGS, "", "test", "an index without unitig store (inline lookaheads only)") \
+    X(CLASSIC_WALK, "", "ab", "every bubble by its walking lane from HBM scratch (the round-2 kernel)") \
+    X(ROUNDS, "", "ab", "bubble rounds between launches of the walk kernel (default: 6 when most gaps of the previous launch parked, else 0)") \
+    X(FINISH_G, "", "ab", "lanes per parked gap in the finishing kernel: 1, 8, 16 or 64 (default: 64 while few gaps park, 16 otherwise)") \
+    X(FINISH_WAVE_BELOW, "2048", "ab", "a whole wave per parked gap while the previous launch parked fewer gaps than this") \
+    X(FINISH_LANE_BELOW, "0", "ab", "one lane per parked gap below this many parked gaps (measured slower at every size: 0)") \
+    X(FINISH_FULL_GRID, "", "ab", "the finishing kernel with one group per gap of the launch (round 3) instead of a grid sized from the previous launch's parked gaps") \
+    X(BUBBLE_GROUPS, "", "ab", "the rounds' bubbles by k_bubble<G> (LDS form) before the one-lane form") \
+    X(PARK_SNP, "", "ab", "the walk kernel parks at SNP bubbles too and the bubble kernel answers them (measured and not used)") \
+    X(NO_LEAN, "", "test", "every contig is materialised (no lean gaps)") \
+    X(NO_DEFER, "", "test", "the lanes of the traversal copy their long runs themselves (no copy commands, no k_copy work)") \
+    X(MAX_CHUNK, "", "test", "gaps per traversal launch (default: what the scratch holds): several launches per batch") \
+    X(HOST_PATHS, "", "test", "leave the path enumeration of multi-contig gaps to the host") \
+    X(DEBUG_SKIP_FINISH, "", "diag", "parked gaps stay parked (and fail as overflowing gaps)") \
+    X(DEBUG_TIMERS, "", "diag", "per-phase wall times of every batch and every index construction on stderr") \
+    X(NO_VEC, "", "test", "scalar instead of pext host code in the input pass") \
+    X(NO_PREFETCH, "", "test", "no software prefetch in the input pass") \
+    X(NB_GPUS, "", "cap", "the tool: devices to use (default: all visible; -nb-gpus overrides)") \
+    X(CLI_BATCH, "", "cap", "the tool: sites per batch (default 100 000)") \
+    X(CLI_IN_FLIGHT, "", "cap", "the tool: worker threads per device (default 3, at most 6)") \
+    X(CLI_WRITERS, "6", "cap", "the tool: threads that write the output files (at most the CPU budget - 2)") \
+    X(CLI_NO_MMAP, "", "test", "the tool reads its breakpoint file instead of mapping it") \
+    X(HOST_FORMAT, "", "ab", "the tool: every site's text by the host's writers (round 3) instead of the device's formatter") \
+    X(TOOL_TIMERS, "", "diag", "the tool: where the time of a run went (stderr)") \
+    X(TOOL_QUIET, "", "diag", "the tool on a resident index: no summary on stdout")
+
+namespace mtgi {
+namespace tune {
+enum Id {
+#define MTG_TUNE_ENUM(name, dflt, kind, what) T_##name,
+    MTG_TUNABLES(MTG_TUNE_ENUM)
+#undef MTG_TUNE_ENUM
+    T_COUNT
+};
+struct Entry { const char* name; const char* env; const char* dflt; const char* kind; const char* what; };
+inline const Entry g_entries[T_COUNT] = {
+#define MTG_TUNE_ROW(name, dflt, kind, what) {#name, "MTG_" #name, dflt, kind, what},
+    MTG_TUNABLES(MTG_TUNE_ROW)
+#undef MTG_TUNE_ROW
+};
+/* The value of an entry: what mtg_tuning_set (or MTG_TUNING, read once) has put there, else the environment variable MTG_<NAME> AS IT IS NOW
+ * (a caller that changes its environment between two calls is heard, as it was when the code asked getenv itself), else the default. */
+struct Values {
+    std::mutex m;
+    /* fixed storage: a reader must never see a string move.  A value longer than this is refused by mtg_tuning_set. */
+    char v[T_COUNT][64];
+    bool forced[T_COUNT];
+    Values()
+    {
+        memset(v, 0, sizeof v);
+        memset(forced, 0, sizeof forced);
+        if (const char* e = getenv("MTG_TUNING")) { /* NAME=value,NAME=value */
+            std::string all(e);
+            size_t b = 0;
+            while (b < all.size()) {
+                size_t c = all.find(',', b);
+                if (c == std::string::npos) c = all.size();
+                const std::string item = all.substr(b, c - b);
+                const size_t eq = item.find('=');
+                const std::string nm = item.substr(0, eq), val = eq == std::string::npos ? "1" : item.substr(eq + 1);
+                const int t = find(nm.c_str());
+                if (t >= 0) put(t, val.c_str());
+                else fprintf(stderr, "MTG_TUNING: no entry named %s (mtg_tuning_describe lists them)\n", nm.c_str());
+                b = c + 1;
+            }
+        }
+    }
+    static int find(const char* name)
+    {
+        if (!name) return -1;
+        if (!strncmp(name, "MTG_", 4)) name += 4;
+        for (int t = 0; t < T_COUNT; t++) if (!strcmp(g_entries[t].name, name)) return t;
+        return -1;
+    }
+    bool put(int t, const char* val)
+    {
+        const size_t n = val ? strlen(val) : 0;
+        if (n >= sizeof v[t]) return false;
+        memset(v[t], 0, sizeof v[t]);
+        if (n) memcpy(v[t], val, n);
+        forced[t] = true;
+        return true;
+    }
+    const char* cur(int t) const
+    {
+        if (forced[t]) return v[t];
+        if (const char* e = getenv(g_entries[t].env)) return *e ? e : "1"; /* MTG_X= (empty) switched a flag on when the code asked getenv() != NULL */
+        return g_entries[t].dflt;
+    }
+};
+inline Values& values() { static Values V; return V; }
+inline bool is_set(Id id) { return values().cur(id)[0] != 0; } /* has a value (mtg_tuning_set's, the environment's or its default) that is not empty */
+inline bool on(Id id) { return is_set(id); }                   /* flags: any value switches them on, as getenv() != NULL did */
+inline long i(Id id, long unset = 0) { const char* s = values().cur(id); return *s ? atol(s) : unset; } /* the value as an integer (not set: the argument) */
+inline double f(Id id, double unset = 0.0) { const char* s = values().cur(id); return *s ? atof(s) : unset; }
+} // namespace tune
+} // namespace mtgi
+#endif

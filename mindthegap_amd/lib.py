@@ -148,6 +148,11 @@ def _bind(lib):
     lib.mtg_index_save.argtypes = [C.c_void_p, C.c_char_p]
     lib.mtg_index_replicate.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p)]
     lib.mtg_index_get_info.argtypes = [C.c_void_p, P(IndexInfo)]
+    lib.mtg_tuning_count.restype = C.c_size_t
+    lib.mtg_tuning_count.argtypes = []
+    lib.mtg_tuning_describe.argtypes = [C.c_size_t, P(C.c_char_p), P(C.c_char_p), P(C.c_char_p), P(C.c_char_p)]
+    lib.mtg_tuning_get.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.mtg_tuning_set.argtypes = [C.c_char_p, C.c_char_p]
     lib.mtg_index_build_profile.argtypes = [C.c_void_p, P(BuildPhase), C.c_size_t, P(C.c_size_t), P(C.c_uint64), P(C.c_double)]
     lib.mtg_index_free.argtypes = [C.c_void_p]
     lib.mtg_index_free.restype = None
@@ -596,6 +601,24 @@ def vcf_header(sample, prefix):
     out = C.string_at(t.vcf, t.vcf_bytes)
     lib.mtg_text_free(C.byref(t))
     return out
+
+
+def tuning():
+    """every switch of the library (mtg_tuning_describe / mtg_tuning_get): [{name, default, kind, what, value}]; entry X starts from MTG_X in the environment"""
+    lib = load_library()
+    out = []
+    for i in range(lib.mtg_tuning_count()):
+        name, dflt, kind, what = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_char_p()
+        _check(lib.mtg_tuning_describe(i, C.byref(name), C.byref(dflt), C.byref(kind), C.byref(what)))
+        buf = C.create_string_buffer(64)
+        _check(lib.mtg_tuning_get(name.value, buf, 64))
+        out.append({"name": name.value.decode(), "default": dflt.value.decode(), "kind": kind.value.decode(), "what": what.value.decode(), "value": buf.value.decode()})
+    return out
+
+
+def tuning_set(name, value):
+    """mtg_tuning_set: holds for the calls that begin after it; None or "" = not set"""
+    _check(load_library().mtg_tuning_set(name.encode(), None if value is None else str(value).encode()))
 
 
 def last_batch_stats():
