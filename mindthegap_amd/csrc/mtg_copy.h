@@ -32,7 +32,7 @@ MTG_DEV bool lean_decide(const Index& ix, const FillCfg& cfg, const GapScratch& 
 {
     const UStore& us = ix.us;
     LeanRec* lr = s_lean(cfg, S);
-    if (o.status != GAP_OK) return false;
+    if (o.status != GAP_OK) { LeanRec r; r.valid = 0; r.pos0 = 0; r.cmd = 0; r.pad_ = 0; *lr = r; return false; } /* the record is read for every gap (k_lean's list for k_post) */
     const CopyCmd* cmds = s_cmd(cfg, S);
     const int k = ix.k;
     bool lean = false;

@@ -551,7 +551,7 @@ __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 #define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
 /* device: the work lists of one launch.  count[i] = entries of list i; list i = cap slot numbers at lists + i * cap.  List 2r holds the gaps
  * parked by the r-th launch of the walk kernel (at a branching node), list 2r + 1 those of them whose bubble did not fit the LDS areas. */
-enum { PARK_LISTS = 16 };
+enum { PARK_LISTS = 18 }; /* 0 .. 15: the rounds' lists of parked gaps; the last two: gaps for k_post's general form, gaps with copy commands to execute */
 struct ParkCtl {
     uint32_t count[PARK_LISTS];
 #ifdef MTG_BUBBLE_TIMING /* diagnostics build: how long the lanes and the waves of the bubble kernels ran (bins of log2 of 10 ns ticks) */
@@ -728,13 +728,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
  * form: nothing is copied, k_post and k_emit read the store)?  The gaps that do need their commands executed go on a work list (ballot +
  * prefix popcount, as for parking).  k_copy, one wave per listed gap, four per workgroup: the grid covers the launch (the host does not
  * know the count), a wave beyond the list leaves after one scalar read. */
-enum { COPY_LIST = PARK_LISTS - 1 };
+enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2 };
 __global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
                                              const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
                                              uint32_t lean_allowed, uint32_t n, ParkCtl* park, uint32_t cap)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    bool need = false;
+    bool need = false, general = false;
     if (slot < n) {
         GapScratch S;
         S.z = nullptr;
@@ -746,8 +746,10 @@ __global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw
         uint64_t target = ~0ull;
         if (lean_allowed && tcnt[g] == 1u && fast_ok[g] && tbad[toff[g]] == 0ull) target = rev_fields64(tle[toff[g]]) >> (64 - 2 * ix.k);
         need = lean_decide(ix, cfg, S, outs[slot], target);
+        general = !s_lean(cfg, S)->valid;
     }
     park_append(park, cap, COPY_LIST, need, slot);
+    park_append(park, cap, POST_LIST, general, slot); /* every gap that is not lean (a failed one too): k_post's general form */
 }
 __global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap)
 {
@@ -804,13 +806,18 @@ __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __r
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POST_WAVES))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
-                                             uint32_t want_all, SlotRec* recs, uint32_t n)
+                                             uint32_t want_all, SlotRec* recs, uint32_t n, ParkCtl* park)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint64_t tile[POST_TILE + 2];
     __shared__ uint64_t s_blk[64];
-    /* one workgroup per slot measured best (against persistent workgroups): the kernel lives on the number of waves in flight */
-    for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x) {
+    /* The gaps of the list k_lean has left (everything that is not lean; k_post_lean below has the others).  One workgroup per gap measured
+     * best (against persistent workgroups): the kernel lives on the number of waves in flight -- the host sizes the grid from what the
+     * previous launch listed, and the loop takes what a launch lists beyond that. */
+    const uint32_t n_listed = park->count[POST_LIST];
+    const uint32_t* list = park_list(park, n, POST_LIST);
+    for (uint32_t li = blockIdx.x; li < n_listed; li += gridDim.x) {
+        const uint32_t slot = list[li];
         __syncthreads(); /* the previous gap's readers of hist are done */
         for (uint32_t i = threadIdx.x; i < 256; i += 64) hist[i] = 0;
         __syncthreads();
@@ -849,6 +856,43 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
             r.pad2_[0] = r.pad2_[1] = 0;
             recs[slot] = r;
         }
+    }
+}
+
+/* the lean gaps (mtg_post.h: post_lean_*): sixteen lanes per gap, four gaps per wave; a gap that is not lean is left to k_post */
+enum { POST_LEAN_G = 16 };
+__global__ void __launch_bounds__(64) k_post_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, uint32_t want_all, SlotRec* recs, uint32_t n)
+{
+    __shared__ uint32_t hist[64 / POST_LEAN_G][256];
+    const uint32_t grp = threadIdx.x / POST_LEAN_G, gl = threadIdx.x % POST_LEAN_G;
+    const uint32_t slot = blockIdx.x * (64u / POST_LEAN_G) + grp;
+    for (uint32_t i = gl; i < 256u; i += POST_LEAN_G) hist[grp][i] = 0;
+    __syncthreads();
+    GapOut o;
+    LeanWork w;
+    bool lean = false;
+    if (slot < n) {
+        o = outs[slot];
+        GapScratch S;
+        S.z = nullptr;
+        S.v = nullptr;
+        S.lane = 0;
+        S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        lean = post_lean_accumulate<POST_LEAN_G>(ix, cfg, S, o, gl, hist[grp], w);
+    }
+    __syncthreads(); /* the histograms are complete */
+    if (!lean) return;
+    PostOut po;
+    post_lean_finish<POST_LEAN_G>(w, gl, hist[grp], po);
+    if (gl == 0) {
+        SlotRec r;
+        r.o = o; r.p = po;
+        emit_plan(o, po, want_all != 0, ix.k, r.nw, r.nc, r.asc, r.ext);
+        r.wbase = r.cbase = r.abase = r.ebase = 0;
+        r.rpos = r.gpos = 0;
+        r.fpos = r.pad_ = 0;
+        r.pad2_[0] = r.pad2_[1] = 0;
+        recs[slot] = r;
     }
 }
 
@@ -2654,7 +2698,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             const uint32_t park_share = own_share != ~0u ? own_share : (wmode ? 65536u : idx->park_share_any.load(std::memory_order_relaxed));
             const uint32_t park_hint = (uint32_t)(((uint64_t)park_share * m) >> 16); /* gaps this launch is expected to park */
             int rounds = env_rounds >= 0 ? env_rounds : (park_share > 32768u ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
-            if (rounds > (PARK_LISTS - 2) / 2) rounds = (PARK_LISTS - 2) / 2;
+            if (rounds > (PARK_LISTS - 4) / 2) rounds = (PARK_LISTS - 4) / 2;
             ParkCtl* const park = d_park.as<ParkCtl>();
             HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
@@ -2738,8 +2782,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m);
             HIP_TRY(hipEventRecord(evc, stream));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
-            hipLaunchKernelGGL(k_post, dim3(m), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
-                               in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
+            /* the lean gaps four per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
+             * listed, plus 1024 (a workspace without a launch yet: one per gap), the kernel's loop takes the rest */
+            const uint32_t general_hint = ws.post_general == ~0u ? m : (uint32_t)std::min<uint64_t>(m, 4ull * ws.post_general + 1024ull);
+            hipLaunchKernelGGL(k_post_lean, dim3((m + 3) / 4), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
+            hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
+                               in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park);
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16, stream)); /* the dense arrays hold one launch at a time; the two arenas the whole batch */
             hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
             hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());
@@ -2856,6 +2904,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             st.index_lines += tot.lines; st.contig_nt += tot.contig_nt; st.store_runs += tot.store_runs; st.run_nt += tot.run_nt; st.post_lines += tot.post_lines;
             st.contig_words += tot.contig_words; st.coverage_kmers += tot.cov_kmers; st.dense_words += tw;
             st.copy_words += tot.copy_words; st.copy_cmds += tot.copy_cmds; st.coverage_direct_kmers += tot.cov_direct; st.n_lean_gaps += tot.n_lean;
+            if (tier == 0 && identity) ws.post_general = m - (uint32_t)std::min<uint64_t>(tot.n_lean, m);
             st.copy_words_executed += tot.copy_words_exec; st.copy_cmds_executed += tot.copy_cmds_exec; st.post_scanned_words += tot.scan_words;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];

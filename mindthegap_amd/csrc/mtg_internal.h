@@ -43,6 +43,7 @@ struct Workspace {
     /* share of the gaps (in 65536ths) the walk kernel parked in this workspace's previous whole-batch launch: how the next launch serves its
      * parked gaps (rounds or not, lanes per gap in the finishing kernel); ~0 = no launch yet: the index's latest figure is taken */
     uint32_t park_share = ~0u;
+    uint32_t post_general = ~0u; /* gaps of this workspace's previous launch that were not lean (the grid of k_post's general form); ~0: no launch yet */
     /* the same per walk mode (0: the walk answers strict SNP bubbles itself, 1: it parks there too and the bubble kernel answers them), with
      * the traversal's time per gap the mode took last time: the next whole-batch launch takes the faster mode and tries the other now and then */
     uint32_t mode_share[2] = {~0u, ~0u};

@@ -407,5 +407,88 @@ MTG_UNROLL
     out.lines = wave_sum32(lines);
 }
 
+/* ---- The lean gap (mtg_copy.h: the target's place in the only contig is known from the copy command the walk left; nothing was copied).
+ * What post_gap does for it is small -- position and errors are known, the k-mers of source + fill are nk consecutive abundance bytes of the
+ * unitig store -- and a whole wave per gap spent most of its instructions on being a wave: 100 000 waves that each zero a histogram, reduce
+ * over 64 lanes and store a record made k_post the longest kernel of a haploid batch (0.21 of 0.52 ms, bound by instruction issue).  Here a
+ * gap is the work of GW lanes (16 on the device: four gaps per wave; 1 in the TEST-ONLY emulation, which runs this next to post_gap for every
+ * lean gap and compares the two records).  The byte range is read as aligned 8-byte words (sum and median do not care about the order, so a
+ * stretch walked backwards is the same range); `hist` = 256 zeroed counters of the group.
+ * post_lean_accumulate: false = not a lean gap (the general kernel's); then a barrier of the group; then post_lean_finish. */
+struct LeanWork { uint32_t pos0, cmd, clen0, nk, sum; };
+template <uint32_t GW> MTG_DEV bool post_lean_accumulate(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint32_t gl, uint32_t* hist, LeanWork& w)
+{
+    const LeanRec lean = *s_lean(cfg, S);
+    if (o.status != GAP_OK || !lean.valid) return false;
+    const uint32_t k = (uint32_t)ix.k;
+    const CopyCmd cm = s_cmd(cfg, S)[lean.cmd];
+    const uint32_t cstart0 = s_cstart(cfg, S)[0];
+    w.pos0 = lean.pos0; w.cmd = lean.cmd; w.clen0 = s_clen(cfg, S)[0];
+    w.nk = lean.pos0 - k + 1u; /* lean_decide: pos0 > k */
+    const bool bwd = (cm.src & 1ull) != 0;
+    const int64_t p = (int64_t)(cm.src >> 1), rel0 = (int64_t)(32ull * cstart0) - (int64_t)(32ull * cm.dst);
+    /* the abundance bytes of the k-mers 0 .. nk - 1 of the contig: ascending from p + rel0, or descending from p - rel0 - (k - 1) */
+    const uint64_t first = bwd ? (uint64_t)(p - (rel0 + (int64_t)(w.nk - 1u)) - (int64_t)(k - 1u)) : (uint64_t)(p + rel0);
+    const uint8_t* b0 = ix.us.ab + first;
+    const uint8_t* b1 = b0 + w.nk;
+    const uint8_t* a = (const uint8_t*)((uintptr_t)b0 & ~(uintptr_t)7) + 8u * gl;
+    uint32_t sum = 0;
+    for (; a < b1; a += 8u * GW) {
+        uint64_t v = *(const uint64_t*)a; /* aligned; the store's arrays are padded past their ends */
+MTG_UNROLL
+        for (uint32_t i = 0; i < 8u; i++, v >>= 8) {
+            if (a + i < b0 || a + i >= b1) continue;
+            const uint32_t x = (uint32_t)(v & 255ull);
+            sum += x;
+            hist_add(hist, x);
+        }
+    }
+    w.sum = sum;
+    if (gl == 0) { s_tpos(cfg, S)[0] = lean.pos0; s_terr(cfg, S)[0] = 0; s_ttgt(cfg, S)[0] = 0; }
+    return true;
+}
+/* the group's sum and the two middle values off the histogram (each lane 256 / GW bins, a scan over the GW lanes) */
+template <uint32_t GW> MTG_DEV void post_lean_finish(const LeanWork& w, uint32_t gl, const uint32_t* hist, PostOut& out)
+{
+    uint32_t sum = w.sum, hi = 0, lo = 0;
+    const uint32_t n2 = w.nk / 2;
+#ifdef MTG_EMU
+    {
+        uint32_t cum = 0;
+        bool got_hi = false, got_lo = (n2 == 0);
+        for (uint32_t v = 0; v < 256 && !(got_hi && got_lo); v++) {
+            cum += hist[v];
+            if (!got_lo && cum > n2 - 1) { lo = v; got_lo = true; }
+            if (!got_hi && cum > n2) { hi = v; got_hi = true; }
+        }
+    }
+#else
+    {
+        constexpr uint32_t B = 256u / GW;
+        for (uint32_t m = GW / 2; m >= 1; m >>= 1) sum += (uint32_t)__shfl_xor((int)sum, (int)m, (int)GW);
+        uint32_t s = 0;
+        for (uint32_t i = 0; i < B; i++) s += hist[B * gl + i];
+        uint32_t incl = s;
+        for (uint32_t d = 1; d < GW; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, (int)GW); if (gl >= d) incl += y; }
+        uint32_t cum = incl - s, f_hi = 0, f_lo = 0;
+        for (uint32_t i = 0; i < B; i++) {
+            const uint32_t nxt = cum + hist[B * gl + i];
+            if (cum <= n2 && nxt > n2) f_hi = B * gl + i + 1u;
+            if (n2 > 0 && cum <= n2 - 1u && nxt > n2 - 1u) f_lo = B * gl + i + 1u;
+            cum = nxt;
+        }
+        for (uint32_t m = GW / 2; m >= 1; m >>= 1) {
+            const uint32_t y = (uint32_t)__shfl_xor((int)f_hi, (int)m, (int)GW), z = (uint32_t)__shfl_xor((int)f_lo, (int)m, (int)GW);
+            f_hi = y > f_hi ? y : f_hi;
+            f_lo = z > f_lo ? z : f_lo;
+        }
+        hi = f_hi ? f_hi - 1u : 0u;
+        lo = f_lo ? f_lo - 1u : 0u;
+    }
+#endif
+    out.nb_terminal = 1; out.fast = 1; out.pos = w.pos0; out.errors = 0; out.target = 0; out.clen0 = w.clen0;
+    out.ab_sum = sum; out.ab_n = w.nk; out.med_hi = hi; out.med_lo = lo; out.lines = 0; out.direct = 1; out.lean = 1u + w.cmd;
+}
+
 } // namespace mtg
 #endif

@@ -1668,16 +1668,13 @@ MTG_UNROLL
     AbPending pend[2], pend_cur;
     bool have_pend = false;
     ab_issue(W.ix, canon(cur), pend_cur);
-    /* nodes whose register signature says "perhaps marked": looked up in the marked set at the end, all lanes together, instead of one
-     * memory round trip per step for whichever lane has a signature collision */
-    uint64_t cand0 = 0, cand1 = 0, cand2 = 0, cand3 = 0;
-    int ncand = 0;
-    auto suspect = [&](uint64_t c) -> bool {
-        if (!W.maybe_marked(c)) return true;
-        if (ncand == 0) cand0 = c; else if (ncand == 1) cand1 = c; else if (ncand == 2) cand2 = c; else if (ncand == 3) cand3 = c; else return false;
-        ncand++;
-        return true;
-    };
+    /* Marked nodes.  Only branching nodes are ever marked (every mark_canon is behind an in-/out-degree test) and the nodes of the two branches
+     * are tested simple below, so the one node of the pattern that can be marked is the meeting node e: ONE lookup at the end.  (Rounds 2-3 kept
+     * up to four "perhaps marked" branch nodes per bubble from the register signature and gave the bubble to the general code at the fifth: a
+     * thousandth of the heterozygous set's walks parked for that alone.  The TEST-ONLY emulation still looks every branch node up: 0xBAE3.) */
+#ifdef MTG_XCHECK
+    bool branch_node_marked = false;
+#endif
     /* the bulk form first (both branches read off the unitig store); the device takes its answer, the TEST-ONLY emulation runs the loop
      * as well and compares (status 0xBAD2: different answers, 0xBAD3: the loop rejected what the bulk form accepted) */
     Adj r1[2];
@@ -1732,7 +1729,9 @@ MTG_UNROLL
         for (int br = 0; br < 2; br++) { /* unrolled: the per-branch state must stay in registers */
             const uint64_t c = canon(x[br]);
             ab_issue(W.ix, c, pend[br]);
-            if (!suspect(c)) MTG_SNP_FAIL(1); /* too many to remember: the general code decides */
+#ifdef MTG_XCHECK
+            if (W.is_marked(c)) branch_node_marked = true;
+#endif
 #ifdef MTG_XCHECK
             if (fp_add(W.S, c) && snp_seen_exactly(W, cur, prev_c, seq, step, c, br, step)) dup_exact = true;
 #endif
@@ -1763,19 +1762,17 @@ MTG_UNROLL
 #undef MTG_SNP_FAIL
     const Kmer e = x[0];
     const uint64_t ce = canon(e);
-    if (!suspect(ce)) return 0;
-    for (int i = 0; i < ncand; i++) {
-        const uint64_t c = i == 0 ? cand0 : i == 1 ? cand1 : i == 2 ? cand2 : cand3;
-        if (set_has(s_marked(W.cfg, W.S), W.cfg.mcap, c)) {
-            /* The bubble touches an assembled region.  Only branching nodes are ever marked and the nodes of the two branches have one way in and
-             * one way out: the marked node is e, and the reference's frontline, which has come as far as this loop has (same nodes, same order,
-             * no in-branching to check), gives up when it steps onto it: "no consensus", nothing marked -- the contig ends here, without a park. */
 #ifdef MTG_XCHECK
-            xcheck_refusal(W, cur, prev_c, 0xBAE2);
-            if (W.status) return 0;
+    if (branch_node_marked) { W.status = 0xBAE3; return 0; } /* a simple node in the marked set: the reasoning above is wrong */
 #endif
-            return -1;
-        }
+    if (W.is_marked(ce)) {
+        /* The bubble touches an assembled region: the reference's frontline, which has come as far as this loop has (same nodes, same order,
+         * no in-branching to check), gives up when it steps onto e: "no consensus", nothing marked -- the contig ends here, without a park. */
+#ifdef MTG_XCHECK
+        xcheck_refusal(W, cur, prev_c, 0xBAE2);
+        if (W.status) return 0;
+#endif
+        return -1;
     }
 #ifdef MTG_XCHECK
     if (fp_add(W.S, ce) && snp_seen_exactly(W, cur, prev_c, seq, L, ce, -1, 0)) dup_exact = true;

@@ -476,6 +476,15 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     std::vector<uint64_t> tile(POST_TILE + 2);
                     uint64_t blk[64];
                     post_gap(idx->dev, cfg, S, r.o, T, hist, tile.data(), blk, r.p);
+                    {   /* the device's k_post_lean (mtg_post.h: the lean gap by a group of lanes, here one) must leave the same record */
+                        uint32_t hist2[256] = {0};
+                        LeanWork lw;
+                        PostOut p2;
+                        memset(&p2, 0, sizeof p2);
+                        const bool is_lean = post_lean_accumulate<1>(idx->dev, cfg, S, r.o, 0u, hist2, lw);
+                        if (is_lean) post_lean_finish<1>(lw, 0u, hist2, p2);
+                        if (is_lean != (r.p.lean != 0) || (is_lean && memcmp(&p2, &r.p, sizeof p2) != 0)) { set_error("gap %zu: the lean form of the post-processing and the general one disagree", g); return MTG_ERR_OVERFLOW; }
+                    }
                 } else st.n_retried_gaps++;
                 emit_plan(r.o, r.p, in.want_all_contigs, k, r.nw, r.nc, r.asc, r.ext);
             }
