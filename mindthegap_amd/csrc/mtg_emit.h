@@ -72,13 +72,12 @@ MTG_DEV uint32_t codes16(const uint64_t* w, uint32_t i)
 
 /* dst[0, L) = ASCII of src nucleotides [from, from + L), reverse-complemented when rc; dst[L] = 0.  The lanes of a wave write aligned
  * 16-byte pieces of the destination (byte stores at the ragged ends), so the arena needs no padding between sequences. */
-MTG_DEV void emit_ascii(const uint64_t* src, uint32_t from, uint32_t L, bool rc, char* dst)
+template <uint32_t GW> MTG_DEV void emit_ascii_g(const uint64_t* src, uint32_t from, uint32_t L, bool rc, char* dst, uint32_t lane)
 {
-    const uint32_t lane = MTG_LANE();
     const uint64_t d0 = (uint64_t)(uintptr_t)dst;
     const uint32_t head = (uint32_t)((16u - (d0 & 15u)) & 15u); /* bytes before the first aligned piece */
     const uint32_t npieces = 1u + (L > head ? (L - head + 15u) / 16u : 0u); /* piece 0 = the head (possibly empty) */
-    for (uint32_t pc = lane; pc < npieces; pc += MTG_NLANES) {
+    for (uint32_t pc = lane; pc < npieces; pc += GW) {
         const uint32_t o0 = pc == 0 ? 0u : head + 16u * (pc - 1u);
         uint32_t n = pc == 0 ? (head < L ? head : L) : (L - o0 < 16u ? L - o0 : 16u);
         if (n == 0) continue;
@@ -105,6 +104,8 @@ MTG_DEV void emit_ascii(const uint64_t* src, uint32_t from, uint32_t L, bool rc,
     }
     if (lane == 0) dst[L] = 0;
 }
+/* by the lanes of a wave (one lane in the emulation) */
+MTG_DEV void emit_ascii(const uint64_t* src, uint32_t from, uint32_t L, bool rc, char* dst) { emit_ascii_g<MTG_NLANES>(src, from, L, rc, dst, MTG_LANE()); }
 
 /* host addresses of the arrays the device buffers of a batch are copied into */
 struct EmitHost {
@@ -154,6 +155,57 @@ MTG_DEV int qual_of(uint32_t errors, bool repeated) /* compute_qual, src/Utils.h
 }
 
 /* everything a gap leaves behind: one wave per gap (one lane in the emulation).  gap = its index in the batch. */
+/* the record of the one solution the common path found (fast == 1): src/Filler.cpp:959-1003 */
+MTG_DEV mtg_filled filled_of(const PostOut& p, uint64_t abase, uint32_t flags, const EmitHost& H)
+{
+    mtg_filled f;
+    f.seq = H.seq + abase;
+    f.nb_errors_in_anchor = (int)p.errors;
+    f.target_index = (int)p.target;
+#ifdef MTG_EMU
+    f.avg_coverage = (float)p.ab_sum / (float)p.ab_n;
+#else
+    f.avg_coverage = __fdiv_rn((float)p.ab_sum, (float)p.ab_n);
+#endif
+    f.median_coverage = (p.ab_n & 1u) ? (float)p.med_hi : 0.5f * (float)(p.med_hi + p.med_lo); /* exact: integers and halves */
+    f.qual = qual_of(p.errors, (flags & GAPF_REPEATED) != 0);
+    f.solution_count = 1;
+    f.solution_rank = 1;
+    return f;
+}
+
+/* ---- The lean gap with its one solution, by GW lanes (k_emit_lean: eight lanes per gap, eight gaps per wave; one in the TEST-ONLY emulation,
+ * which runs it next to emit_gap and compares): the fill is a stretch of the unitig store, the two records are what emit_gap writes for
+ * fast == 1.  A wave per gap left two thirds of its lanes without a piece to write (300 characters are 20 pieces of 16) and spent the rest of
+ * its instructions on lane 0's record.  `r` holds the slot's offsets relative to its scan block, `abase` is the absolute one; nothing is
+ * written back to the slot record (the host looks at the records of the gaps it has to re-run or finish, never at a lean one's).
+ * false: not such a gap (or the batch leaves in relocatable form): the general kernel's. */
+MTG_DEV bool emit_is_lean(const SlotRec& r, const EmitDev& D) { return r.o.status == GAP_OK && r.p.lean != 0 && r.p.fast == 1 && r.nc == 0 && r.ext == 0 && D.wire == nullptr; }
+template <uint32_t GW> MTG_DEV void emit_lean(const UStore& us, const FillCfg& cfg, const GapScratch& S, const SlotRec& r, uint64_t abase, uint32_t flags, uint32_t slot, uint64_t gap, int k,
+                                              const EmitDev& D, const EmitHost& H, uint32_t gl)
+{
+    const bool reverse = (flags & GAPF_REVERSE) != 0;
+    if (r.asc && D.seq && abase + r.asc <= D.seq_cap) { /* an arena that is too small: the host grows it and asks again */
+        const CopyCmd cm = s_cmd(cfg, S)[r.p.lean - 1u];
+        const uint32_t L = r.asc - 1u;
+        const int64_t x0 = (int64_t)(32ull * s_cstart(cfg, S)[0]) + k;
+        const bool bwd = (cm.src & 1ull) != 0;
+        const uint64_t from = bwd ? cmd_store_nt(cm, x0 + (int64_t)L - 1) : cmd_store_nt(cm, x0);
+        emit_ascii_g<GW>(us.words + (from >> 5), (uint32_t)(from & 31ull), L, bwd ? !reverse : reverse, D.seq + abase, gl);
+    }
+    if (gl != 0) return;
+    mtg_gap_result g;
+    g.nb_nodes = (int)r.o.n_contigs;
+    g.total_nt = (int)r.o.total_nt;
+    g.nb_terminal = (int)r.p.nb_terminal;
+    g.has_solution_counts = 1;
+    g.nb_total_filled = g.nb_reported = g.n_filled = 1;
+    g.filled = H.fil + gap;
+    g.extension = H.ext; /* "" */
+    D.fil[slot] = filled_of(r.p, abase, flags, H);
+    D.res[slot] = g;
+}
+
 MTG_DEV void emit_gap(const UStore& us, const FillCfg& cfg, const GapScratch& S, const SlotRec& r, uint32_t flags, uint32_t slot, uint64_t gap, int k, const EmitDev& D, const EmitHost& H)
 {
     const uint32_t lane = MTG_LANE();
@@ -205,20 +257,7 @@ MTG_DEV void emit_gap(const UStore& us, const FillCfg& cfg, const GapScratch& S,
     g.extension = H.ext; /* "" */
     if (r.o.status == GAP_OK) {
         if (r.p.fast == 1) {
-            mtg_filled f;
-            f.seq = H.seq + r.abase;
-            f.nb_errors_in_anchor = (int)r.p.errors;
-            f.target_index = (int)r.p.target;
-#ifdef MTG_EMU
-            f.avg_coverage = (float)r.p.ab_sum / (float)r.p.ab_n;
-#else
-            f.avg_coverage = __fdiv_rn((float)r.p.ab_sum, (float)r.p.ab_n);
-#endif
-            f.median_coverage = (r.p.ab_n & 1u) ? (float)r.p.med_hi : 0.5f * (float)(r.p.med_hi + r.p.med_lo); /* exact: integers and halves */
-            f.qual = qual_of(r.p.errors, (flags & GAPF_REPEATED) != 0);
-            f.solution_count = 1;
-            f.solution_rank = 1;
-            D.fil[slot] = f;
+            D.fil[slot] = filled_of(r.p, r.abase, flags, H);
             g.has_solution_counts = 1;
             g.nb_total_filled = g.nb_reported = g.n_filled = 1;
         } else if (r.p.fast == 2) {

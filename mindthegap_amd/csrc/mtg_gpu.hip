@@ -859,8 +859,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
     }
 }
 
-/* the lean gaps (mtg_post.h: post_lean_*): sixteen lanes per gap, four gaps per wave; a gap that is not lean is left to k_post */
-enum { POST_LEAN_G = 16 };
+/* the lean gaps (mtg_post.h: post_lean_*): eight lanes per gap, eight gaps per wave; a gap that is not lean is left to k_post.
+ * Measured on the haploid set, k_post + scans of one batch alone: 0.222 ms with a wave per gap (round 3), 0.185 with 4 lanes per gap, 0.128 with 8, 0.136 with 16. */
+#ifndef MTG_POST_LEAN_G
+#define MTG_POST_LEAN_G 8
+#endif
+enum { POST_LEAN_G = MTG_POST_LEAN_G };
 __global__ void __launch_bounds__(64) k_post_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, uint32_t want_all, SlotRec* recs, uint32_t n)
 {
     __shared__ uint32_t hist[64 / POST_LEAN_G][256];
@@ -1120,11 +1124,16 @@ __global__ void __launch_bounds__(64) k_fmt_write(FmtArgs A)
 
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
 __global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* raw, SlotRec* recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
-                                             const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t* retry_list, uint32_t* general_list, uint32_t n)
+                                             const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t* retry_list, uint32_t* general_list, uint32_t n, ParkCtl* park,
+                                             uint32_t use_list)
 {
-    const uint32_t slot = blockIdx.x;
-    if (slot >= n) return;
+    /* use_list: the gaps of k_lean's list (everything that is not lean: k_emit_lean has the others), the grid sized by the host from what the
+     * previous launch listed; otherwise (a batch that leaves in relocatable form) every slot of the launch */
+    const uint32_t count = use_list ? park->count[POST_LIST] : n;
     __shared__ SlotRec r;
+    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+    const uint32_t slot = use_list ? park_list(park, n, POST_LIST)[li] : li;
+    __syncthreads(); /* the previous gap's readers of r are done */
     if (threadIdx.x == 0) {
         r = recs[slot];
         const ScanBlock& b = blocks[slot / SCAN_SL];
@@ -1142,6 +1151,24 @@ __global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* ra
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
     const uint32_t g = ids ? ids[slot] : slot;
     emit_gap(us, cfg, S, r, gflags[g], slot, g, k, D, H);
+    }
+}
+/* the lean gaps (mtg_emit.h: emit_lean): eight lanes per gap, eight gaps per wave */
+enum { EMIT_LEAN_G = 8 };
+__global__ void __launch_bounds__(64) k_emit_lean(UStore us, FillCfg cfg, uint8_t* raw, const SlotRec* __restrict__ recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
+                                                  const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t n)
+{
+    const uint32_t slot = blockIdx.x * (64u / EMIT_LEAN_G) + threadIdx.x / EMIT_LEAN_G, gl = threadIdx.x % EMIT_LEAN_G;
+    if (slot >= n) return;
+    const SlotRec r = recs[slot];
+    if (!emit_is_lean(r, D)) return;
+    GapScratch S;
+    S.z = nullptr;
+    S.v = nullptr;
+    S.lane = 0;
+    S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    const uint32_t g = ids ? ids[slot] : slot;
+    emit_lean<EMIT_LEAN_G>(us, cfg, S, r, r.abase + blocks[slot / SCAN_SL].v[2], gflags[g], slot, g, k, D, H, gl);
 }
 
 /* checksum of a relocatable batch's body into its header (mtg_wire_header::checksum): a sum of scrambled 64-bit words, any order */
@@ -2782,10 +2809,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m);
             HIP_TRY(hipEventRecord(evc, stream));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
-            /* the lean gaps four per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
+            /* the lean gaps eight per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
              * listed, plus 1024 (a workspace without a launch yet: one per gap), the kernel's loop takes the rest */
             const uint32_t general_hint = ws.post_general == ~0u ? m : (uint32_t)std::min<uint64_t>(m, 4ull * ws.post_general + 1024ull);
-            hipLaunchKernelGGL(k_post_lean, dim3((m + 3) / 4), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
+            hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
             hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park);
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16, stream)); /* the dense arrays hold one launch at a time; the two arenas the whole batch */
@@ -2806,8 +2833,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 D.tot = d_tot.as<PartTot>(); D.wire_gaps = m;
                 if (want_wire) HIP_TRY(hipMemsetAsync(sink.wire_dev, 0, sizeof(mtg_wire_header), stream)); /* no header, no payload (k_wire_sum) */
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
-                hipLaunchKernelGGL(k_emit, dim3(m), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H, d_rlist.as<uint32_t>(),
-                                   d_glist.as<uint32_t>(), m);
+                if (!want_wire)
+                    hipLaunchKernelGGL(k_emit_lean, dim3((m + 64 / EMIT_LEAN_G - 1) / (64 / EMIT_LEAN_G)), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(),
+                                       ids, d_flags, k, D, H, m);
+                hipLaunchKernelGGL(k_emit, dim3(want_wire ? m : general_hint), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H,
+                                   d_rlist.as<uint32_t>(), d_glist.as<uint32_t>(), m, park, want_wire ? 0u : 1u);
                 if (want_wire) hipLaunchKernelGGL(k_wire_sum, dim3(256 * 4), dim3(256), 0, stream, (uint8_t*)sink.wire_dev, sink.wire_cap);
                 HIP_TRY(hipGetLastError());
                 return MTG_OK;

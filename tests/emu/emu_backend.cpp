@@ -551,6 +551,22 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 for (uint32_t s = 0; s < m; s++) {
                     GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
                     emit_gap(idx->dev.us, cfg, S, recs[s], in.flags[ids[s]], s, ids[s], k, D, H);
+                    if (emit_is_lean(recs[s], D) && recs[s].asc && recs[s].abase + recs[s].asc <= D.seq_cap) {
+                        /* the device's k_emit_lean (mtg_emit.h: emit_lean, a group of lanes per gap, here one) must write the same bytes and records */
+                        std::vector<char> tmp(recs[s].asc + 32, 'x');
+                        mtg_gap_result g2;
+                        mtg_filled f2;
+                        memset(&g2, 0, sizeof g2); memset(&f2, 0, sizeof f2);
+                        EmitDev D2 = D;
+                        D2.seq = (char*)((uintptr_t)(tmp.data() + 16) - (uintptr_t)recs[s].abase); D2.seq_cap = recs[s].abase + recs[s].asc;
+                        D2.res = &g2; D2.fil = &f2;
+                        if (getenv("MTG_EMU_TRACE_LEAN")) fprintf(stderr, "[emu] lean emit checked\n");
+                        emit_lean<1>(idx->dev.us, cfg, S, recs[s], recs[s].abase, in.flags[ids[s]], 0, ids[s], k, D2, H, 0u);
+                        if (memcmp(tmp.data() + 16, D.seq + recs[s].abase, recs[s].asc) != 0 || memcmp(&g2, &D.res[s], sizeof g2) != 0 || memcmp(&f2, &D.fil[s], sizeof f2) != 0) {
+                            set_error("gap %u: the lean form of the result kernel and the general one disagree", ids[s]);
+                            return MTG_ERR_OVERFLOW;
+                        }
+                    }
                 }
                 if (c0 <= D.dense_cap_words && c1 <= D.dense_cap_contigs) break;
                 dw.assign(c0 + 1, 0);
