@@ -756,12 +756,12 @@ def main():
     po_parts = {"contig_words_scanned_x_8B": acc["post_scanned_words"] / Ln * 8, "bucket_reads_x_32B": acc["post_lines"] / Ln * 32,
                 "coverage_abundance_bytes": acc["coverage_kmers"] / Ln, "coverage_kmer_check_of_looked_up_blocks": (acc["coverage_kmers"] - acc["coverage_direct_kmers"]) / Ln * 0.25 * (1 + k / 64.0),
                 "per_gap_gapout_target_leanrec_command_read": gaps_l * (36 + 26 + 16 + 24), "per_gap_slot_record_written_160B_and_rewritten_by_the_scan_48B": gaps_l * (160 + 160 + 48)}
-    em_parts = {"ascii_written": acc["seq_bytes"] / Ln, "sequence_2bit_read": acc["seq_bytes"] / Ln / 4, "per_gap_records": gaps_l * (160 + 160 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / Ln * 16}
+    em_parts = {"ascii_written": acc["seq_bytes"] / Ln, "sequence_2bit_read": acc["seq_bytes"] / Ln / 4, "per_gap_records": n_lean_l * (160 + 56 + 40) + listed * (160 + 160 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / Ln * 16}
     kerns = [kern("k_stage_a(+k_finish)", acc["kernel_ms"] / Ln, alone_ms("kernel_ms"), sum(sa_parts.values()), sa_parts),
              kern("k_lean", acc["lean_kernel_ms"] / Ln, alone_ms("lean_kernel_ms"), sum(ln_parts.values()), ln_parts),
              kern("k_copy", (acc["copy_kernel_ms"] - acc["lean_kernel_ms"]) / Ln, alone_ms("copy_kernel_ms", "-lean_kernel_ms"), sum(cp_parts.values()), cp_parts),
-             kern("k_post(+k_scan1,k_scan2)", acc["post_kernel_ms"] / Ln, alone_ms("post_kernel_ms"), sum(po_parts.values()), po_parts),
-             kern("k_emit", acc["emit_kernel_ms"] / Ln, alone_ms("emit_kernel_ms"), sum(em_parts.values()), em_parts)]
+             kern("k_post(+k_post_lean,k_scan1,k_scan2)", acc["post_kernel_ms"] / Ln, alone_ms("post_kernel_ms"), sum(po_parts.values()), po_parts),
+             kern("k_emit(+k_emit_lean)", acc["emit_kernel_ms"] / Ln, alone_ms("emit_kernel_ms"), sum(em_parts.values()), em_parts)]
     dom = max(kerns, key=lambda x: x["avg_kernel_ms"] or 0.0)
     result_bytes = acc["seq_bytes"] / Ln + gaps_l * (56 + 40)
     ms_per_batch_of_rank = elapsed / a.steps * 1e3 / max(1, (len(batches) if not cfg0["rotate"] else 1))  # this rank finishes a batch every so many ms
@@ -780,7 +780,7 @@ def main():
         by_kernel = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pj.get("kernels", {}).items() if kn.split("::")[-1].startswith(fill_kernels)}
         # `traffic`: HBM bytes per launch of the dominant kernel (with the scans it is reported with); every kernel of a fill under traffic_by_kernel
         dk = dom["kernel"].split("(")[0]
-        roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_scan1", "k_scan2")) or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble"))))) or None
+        roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (dk == "k_emit" and kn == "k_emit_lean") or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble"))))) or None
         roof["traffic_by_kernel"] = by_kernel
         roof["traffic_is"] = "REPLAYED, not measured in this run: counters cannot be read from inside the process"
         roof["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, no trace domain, the bench command of scripts/profile_round4.sh, HEAD %s): "
@@ -789,7 +789,7 @@ def main():
                                   % (os.path.relpath(pmc, ROOT), pj.get("head", "?")))
         for kr in kerns:
             tk = kr["kernel"].split("(")[0]
-            tv = sum(v for kn, v in by_kernel.items() if v and (kn == tk or (tk == "k_post" and kn in ("k_scan1", "k_scan2")) or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble")))))
+            tv = sum(v for kn, v in by_kernel.items() if v and (kn == tk or (tk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (tk == "k_emit" and kn == "k_emit_lean") or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble")))))
             kr["traffic"] = tv or None
             kr["traffic_over_bytes"] = (tv / kr["bytes_per_launch"]) if tv and kr["bytes_per_launch"] else None
     # what the reference's algorithm would have moved for the same contigs (64 B per membership probe, probes counted by the oracle):
