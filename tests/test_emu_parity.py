@@ -319,6 +319,32 @@ def test_cli_on_emulator_reverse_attempts_and_extensions(emu_product, tmp_path):
     o.close()
 
 
+def test_cli_on_emulator_short_fills_every_alignment(emu_product, tmp_path):
+    """round 4: the lean forms of the post-processing and of the result kernel (mtg_post.h: post_lean_*, mtg_emit.h: emit_lean) read a fill's
+    abundance bytes as aligned 8-byte words and write its ASCII as aligned 16-byte pieces: fills of 1 .. 70 nucleotides, a third of them
+    found by the reverse attempt (stretches read backwards), against the oracle's files (sum and median are in the FASTA headers).  The
+    emulation runs both lean forms next to the general ones for every lean gap and compares records and bytes."""
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=160, n_sites=140, seed=23, ins_min=1, ins_max=70)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    bk = str(tmp_path / "short.breakpoints")
+    with open(bk, "w") as f:
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            if i % 3 == 1:
+                l = l[:15] + ("A" if l[15] != "A" else "C") + l[16:]
+            f.write(">%s left_kmer\n%s\n>%s right_kmer\n%s\n" % (S.site_name(i), l, S.site_name(i), r))
+    _write_idx(str(tmp_path / "short.mtgidx"), km, ct)
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert emu_product.Filler().run(["-graph", str(tmp_path / "short.mtgidx"), "-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    assert _read(str(tmp_path / "hip.insertions.fasta")).count(">") >= 125
+    o.close()
+
+
 def test_cli_on_emulator_bubbly_contig_mode(emu_product, tmp_path):
     """contig mode on a diploid-like graph (SNP bubbles + tips): multi-solution paths, NW dedupe, GFA order"""
     rng = random.Random(99)

@@ -209,6 +209,41 @@ def test_reverse_attempt_and_unfillable(mtg, tmp_path):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("host_format", [False, True])
+def test_short_fills_every_alignment_both_attempts(mtg, tmp_path, monkeypatch, host_format):
+    """round 4: the lean forms of the post-processing and of the result kernel (k_post_lean, k_emit_lean: eight lanes per gap) read the
+    abundance bytes of a fill as aligned 8-byte words and write its ASCII as aligned 16-byte pieces -- fills of 1 .. 70 nucleotides put
+    the byte range and the pieces at every alignment, with ragged heads and tails shorter than a word; a third of the sites are filled
+    by the reverse attempt (stretches read backwards and complemented).  Sum and median of the abundances are in the FASTA headers:
+    the files must be the oracle's, through the device's formatter and through the host's writers (records and sequences on the host)."""
+    from mindthegap_amd.synth import SynthSet
+    from tests import oracle_lib
+    if host_format:
+        monkeypatch.setenv("MTG_HOST_FORMAT", "1")
+    S = SynthSet(nseq=700, n_sites=600, seed=23, ins_min=1, ins_max=70)
+    seqs = [S.ascii(j) for j in range(S.nseq)]
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    bk = str(tmp_path / "short.breakpoints")
+    with open(bk, "w") as f:
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            if i % 3 == 1:  # break the left anchor in the middle: forward fails, the reverse attempt fills
+                l = l[:15] + ("A" if l[15] != "A" else "C") + l[16:]
+            f.write(">%s left_kmer\n%s\n>%s right_kmer\n%s\n" % (S.site_name(i), l, S.site_name(i), r))
+    import struct
+    idxf = str(tmp_path / "short.mtgidx")
+    with open(idxf, "wb") as fh:
+        fh.write(b"MTGIDX1\0" + struct.pack("<4i", 31, 3, -1, 0) + struct.pack("<Q", len(km)) + km.tobytes() + ct.astype(np.uint32).tobytes())
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert mtg.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    assert _read(str(tmp_path / "hip.insertions.fasta")).count(">") >= 550
+    o.close()
+
+
 @pytest.mark.parametrize("err", [0.0, 0.002])
 def test_simulated_reads_cfg2_shape(mtg, tmp_path, err, monkeypatch):
     """BASELINE config 2 at reduced size: 30x simulated reads (E0 error-free / E1-like with substitutions), index built by -in with
