@@ -156,19 +156,23 @@ struct FormattedPool {
     ~FormattedPool() { for (mtg_formatted* t : free) mtg_formatted_free(t); }
 };
 static FormattedPool& ftext_pool() { static FormattedPool p; return p; }
-/* The output files of a long run, written by several threads: the pieces of text get their places in input order (one thread hands them
- * out, as it would have written them), the bytes go there with pwrite from a few writer threads -- a memory-backed or page-cached file takes
- * several GB/s from each.  Whatever was written through the FILE* before begin() stays in front; after finish() the FILE* continue behind. */
+/* The output files of a long run, written by their own threads: the pieces of text get their places in input order (one thread hands them
+ * out, as it would have written them), the bytes go there with pwrite -- ONE writer thread per file.  write(2) on a file is serialised by
+ * the file's lock: the memory-backed file system of the GPU box takes 8-9 GB/s for a file from one thread, the same from two, and on some
+ * boxes HALF of it from four (scripts/tmpfs_write_ceiling.py: 8.1 / 7.7 / 3.7 / 3.5 GB/s with 1 / 2 / 4 / 8 threads; profiles/
+ * r04_tmpfs_write_ceiling.txt) -- six writers taking whole pieces, as before, put three or four of them on the two large files at any time.
+ * Different files do not share a lock: the FASTA and the VCF file (45 % and 52 % of the bytes) are written side by side at the rate of
+ * one each.  Whatever was written through the FILE* before begin() stays in front; after finish() the FILE* continue behind. */
 struct PositionedWriter {
     struct Span { const char* p = nullptr; size_t n = 0; };
-    struct Job { std::shared_ptr<void> owner; Span s[5]; off_t at[5]; };
+    struct Item { std::shared_ptr<void> owner; Span s; off_t at; };
     Files& F;
     int fd[5];
     off_t pos[5];
     std::vector<std::thread> threads;
     std::mutex mtx;
-    std::condition_variable cv_job, cv_room;
-    std::deque<Job> q;
+    std::condition_variable cv_job[5], cv_room;
+    std::deque<Item> q[5];
     size_t pending_bytes = 0;
     bool done = false;
     std::atomic<bool> failed{false};
@@ -179,10 +183,10 @@ struct PositionedWriter {
             fd[i] = -1; pos[i] = 0;
             if (s) { fflush(s); fd[i] = fileno(s); pos[i] = ftello(s); }
         }
-        /* writers: write(2) on ONE file is serialised by the file's lock -- the memory-backed file system of the GPU box takes 8.7 GB/s for a file from 1,
-         * 2, 4 or 12 threads alike (scripts/tmpfs_write_ceiling.py) -- so two per large file are all that help; more only take CPUs from the workers */
-        const int nw = std::max(1, std::min((int)tune::i(tune::T_CLI_WRITERS, 6), Pool::cpu_budget() - 2));
-        for (int t = 0; t < nw; t++) threads.emplace_back([this] { run(); });
+        const int per_file = std::max(1, (int)tune::i(tune::T_CLI_WRITERS, 1));
+        for (int i = 0; i < 5; i++)
+            if (fd[i] >= 0)
+                for (int t = 0; t < per_file; t++) threads.emplace_back([this, i] { run(i); });
     }
     static const std::string& text_of(const OutText& T, int i) { return i == 0 ? T.insert : i == 1 ? T.info : i == 2 ? T.vcf : i == 3 ? T.gfa : T.ext; }
     /* called in input order: the piece's places are the current ends of the files */
@@ -195,42 +199,42 @@ struct PositionedWriter {
     /* the same for bytes that live somewhere else (a batch's text formatted on the device: page-locked arenas of the library) */
     void add_spans(std::shared_ptr<void> owner, const Span sp[5])
     {
-        Job j;
-        j.owner = std::move(owner);
         size_t bytes = 0;
-        for (int i = 0; i < 5; i++) { j.s[i] = sp[i]; j.at[i] = pos[i]; if (fd[i] >= 0) { pos[i] += (off_t)sp[i].n; bytes += sp[i].n; } }
+        for (int i = 0; i < 5; i++) if (fd[i] >= 0) bytes += sp[i].n;
         std::unique_lock<std::mutex> lk(mtx);
         cv_room.wait(lk, [&] { return pending_bytes < ((size_t)1 << 30); }); /* formatted text waiting for its writer: bounded */
         pending_bytes += bytes;
-        q.push_back(std::move(j));
-        cv_job.notify_one();
+        for (int i = 0; i < 5; i++) {
+            if (fd[i] < 0 || sp[i].n == 0) continue;
+            Item it;
+            it.owner = owner; /* the text lives until the last of its files has it */
+            it.s = sp[i];
+            it.at = pos[i];
+            pos[i] += (off_t)sp[i].n;
+            q[i].push_back(std::move(it));
+            cv_job[i].notify_one();
+        }
     }
-    void run()
+    void run(int i)
     {
         for (;;) {
-            Job j;
+            Item it;
             {
                 std::unique_lock<std::mutex> lk(mtx);
-                cv_job.wait(lk, [&] { return done || !q.empty(); });
-                if (q.empty()) return;
-                j = std::move(q.front());
-                q.pop_front();
+                cv_job[i].wait(lk, [&] { return done || !q[i].empty(); });
+                if (q[i].empty()) return;
+                it = std::move(q[i].front());
+                q[i].pop_front();
             }
-            size_t bytes = 0;
-            for (int i = 0; i < 5; i++) {
-                if (fd[i] < 0) continue;
-                const Span& t = j.s[i];
-                bytes += t.n;
-                size_t w = 0;
-                while (w < t.n) {
-                    const ssize_t got = ::pwrite(fd[i], t.p + w, t.n - w, j.at[i] + (off_t)w);
-                    if (got < 0) { if (errno == EINTR) continue; failed = true; break; }
-                    w += (size_t)got;
-                }
+            size_t w = 0;
+            while (w < it.s.n) {
+                const ssize_t got = ::pwrite(fd[i], it.s.p + w, it.s.n - w, it.at + (off_t)w);
+                if (got < 0) { if (errno == EINTR) continue; failed = true; break; }
+                w += (size_t)got;
             }
-            j.owner.reset();
+            it.owner.reset();
             std::lock_guard<std::mutex> lk(mtx);
-            pending_bytes -= bytes;
+            pending_bytes -= it.s.n;
             cv_room.notify_all();
         }
     }
@@ -238,7 +242,7 @@ struct PositionedWriter {
     bool finish()
     {
         { std::lock_guard<std::mutex> lk(mtx); done = true; }
-        cv_job.notify_all();
+        for (int i = 0; i < 5; i++) cv_job[i].notify_all();
         for (std::thread& t : threads) t.join();
         threads.clear();
         for (int i = 0; i < 5; i++) if (fd[i] >= 0) fseeko(F.stream(i), pos[i], SEEK_SET);

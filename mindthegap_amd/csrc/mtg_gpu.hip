@@ -2812,9 +2812,25 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* the lean gaps eight per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
              * listed, plus 1024 (a workspace without a launch yet: one per gap), the kernel's loop takes the rest */
             const uint32_t general_hint = ws.post_general == ~0u ? m : (uint32_t)std::min<uint64_t>(m, 4ull * ws.post_general + 1024ull);
-            hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
-            hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
+            /* The general form is the latency of a few long gaps (30 us for the one or two of a haploid batch), the lean form the throughput of
+             * all the others: they touch different slots and run next to each other, the general one on the workspace's second stream
+             * (POST_ONE_STREAM of the tuning table: one after the other, as measured before). */
+            const hipStream_t side = (ws.copy_stream && !tune::on(tune::T_POST_ONE_STREAM)) ? (hipStream_t)ws.copy_stream : stream;
+            if (side != stream) {
+                hipEvent_t ev_fork;
+                HIP_TRY(events.make(ev_fork));
+                HIP_TRY(hipEventRecord(ev_fork, stream));
+                HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+            }
+            hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, side, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park);
+            hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
+            if (side != stream) {
+                hipEvent_t ev_join;
+                HIP_TRY(events.make(ev_join));
+                HIP_TRY(hipEventRecord(ev_join, side));
+                HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+            }
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16, stream)); /* the dense arrays hold one launch at a time; the two arenas the whole batch */
             hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
             hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());

@@ -45,6 +45,7 @@
     X(FINISH_FULL_GRID, "", "ab", "the finishing kernel with one group per gap of the launch (round 3) instead of a grid sized from the previous launch's parked gaps") \
     X(BUBBLE_GROUPS, "", "ab", "the rounds' bubbles by k_bubble<G> (LDS form) before the one-lane form") \
     X(PARK_SNP, "", "ab", "the walk kernel parks at SNP bubbles too and the bubble kernel answers them (measured and not used)") \
+    X(POST_ONE_STREAM, "", "ab", "the general form of k_post after the lean one on the batch's stream instead of next to it on the workspace's second stream") \
     X(NO_LEAN, "", "test", "every contig is materialised (no lean gaps)") \
     X(NO_DEFER, "", "test", "the lanes of the traversal copy their long runs themselves (no copy commands, no k_copy work)") \
     X(MAX_CHUNK, "", "test", "gaps per traversal launch (default: what the scratch holds): several launches per batch") \
@@ -56,7 +57,7 @@
     X(NB_GPUS, "", "cap", "the tool: devices to use (default: all visible; -nb-gpus overrides)") \
     X(CLI_BATCH, "", "cap", "the tool: sites per batch (default 100 000)") \
     X(CLI_IN_FLIGHT, "", "cap", "the tool: worker threads per device (default 3, at most 6)") \
-    X(CLI_WRITERS, "6", "cap", "the tool: threads that write the output files (at most the CPU budget - 2)") \
+    X(CLI_WRITERS, "1", "cap", "the tool: writer threads per output file (a file's lock serialises write(2): more than one per file was measured the same or slower)") \
     X(CLI_NO_MMAP, "", "test", "the tool reads its breakpoint file instead of mapping it") \
     X(HOST_FORMAT, "", "ab", "the tool: every site's text by the host's writers (round 3) instead of the device's formatter") \
     X(TOOL_TIMERS, "", "diag", "the tool: where the time of a run went (stderr)") \

@@ -25,3 +25,17 @@ for nt in (1, 2, 4, 8, 12, 16, 24):
         for t in ts: t.join()
         el = time.perf_counter() - t0
         print("%2d writer threads: %.2f GB/s (%.1f GB in %.2f s)" % (nt, total / el / 1e9, total / 1e9, el), flush=True)
+# several files, one writer thread each (what the tool does since round 4: a file's lock does not serialise writes to another file)
+for nf in (2, 3):
+    files = [tempfile.NamedTemporaryFile(dir=base) for _ in range(nf)]
+    per = total // nf // len(piece)
+    def one(fd):
+        for i in range(per):
+            os.pwrite(fd, piece, i * len(piece))
+    ts = [threading.Thread(target=one, args=(f.fileno(),)) for f in files]
+    t0 = time.perf_counter()
+    for t in ts: t.start()
+    for t in ts: t.join()
+    el = time.perf_counter() - t0
+    print("%d files, one writer thread each: %.2f GB/s in all (%.1f GB in %.2f s)" % (nf, nf * per * len(piece) / el / 1e9, nf * per * len(piece) / 1e9, el), flush=True)
+    for f in files: f.close()
