@@ -444,7 +444,7 @@ MTG_UNROLL
         }
     }
     w.sum = sum;
-    if (gl == 0) { s_tpos(cfg, S)[0] = lean.pos0; s_terr(cfg, S)[0] = 0; s_ttgt(cfg, S)[0] = 0; }
+    /* (the per-contig terminal arrays of the scratch are not written: they are read for the gaps whose contigs go to the host, never for a lean one) */
     return true;
 }
 /* the group's sum and the two middle values off the histogram (each lane 256 / GW bins, a scan over the GW lanes) */

@@ -1432,6 +1432,7 @@ MTG_DEV_NOINLINE int indel_bulk(Worker& W, const Kmer& cur, uint64_t prev_c, con
     RunAt ra[2];
     bool run[2];
     Adj rl[2];
+    /* the lengths first: equal ones are the SNP forms' (the common case on a heterozygous set: nothing more is read here) */
 MTG_UNROLL
     for (int br = 0; br < 2; br++) {
         run[br] = false;
@@ -1441,13 +1442,18 @@ MTG_UNROLL
             run[br] = true;
             Lb[br] = ra[br].ahead + 1u;
             if (Lb[br] > (uint32_t)SNP_MAX_L) return 0;
+        } else Lb[br] = 1u;
+    }
+    if (Lb[0] == Lb[1]) return 0;
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        if (run[br]) {
             lastn[br] = run_node(us, ra[br].kpos, ra[br].bwd, ra[br].ahead, k);
             rl[br] = adj_right_t(W.ix.adj, lastn[br], W.mk1, W.lines);
-        } else { Lb[br] = 1u; lastn[br] = x[br]; rl[br] = r[br]; }
+        } else { lastn[br] = x[br]; rl[br] = r[br]; }
         if (popc4(rl[br].out) != 1 || popc4(rl[br].in) != 2) return 0;
         if (lastn[br].f == lastn[br].r) return 0;
     }
-    if (Lb[0] == Lb[1]) return 0; /* equal lengths: the SNP forms */
     const Kmer e = kmer_next(lastn[0], (uint32_t)ctz4(rl[0].out), k, W.mk);
     {
         const Kmer e1 = kmer_next(lastn[1], (uint32_t)ctz4(rl[1].out), k, W.mk);
