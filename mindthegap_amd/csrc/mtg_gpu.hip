@@ -2369,6 +2369,19 @@ struct WsBuf {
         p = ws->ptr[slot];
         return hipSuccess;
     }
+    /* the same, but the first `keep` bytes survive a move (the stream must be idle: the copy runs on the null stream) */
+    hipError_t grow_keeping(size_t bytes, size_t keep)
+    {
+        if (ws->cap[slot] >= bytes || !ws->ptr[slot] || keep == 0) return alloc(bytes);
+        void* old = ws->ptr[slot];
+        const size_t old_cap = ws->cap[slot];
+        ws->ptr[slot] = nullptr;
+        ws->cap[slot] = 0;
+        hipError_t e = alloc(bytes);
+        if (e == hipSuccess) e = hipMemcpy(ws->ptr[slot], old, std::min(keep, old_cap), hipMemcpyDeviceToDevice);
+        (void)hipFree(old);
+        return e;
+    }
     template <typename T> T* as() { return (T*)p; }
 };
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -2668,7 +2681,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_rlist.alloc(chunk * 4));
         HIP_TRY(d_glist.alloc(chunk * 4));
         HIP_TRY(d_park.alloc((size_t)chunk * 4 * PARK_LISTS + sizeof(ParkCtl)));
-        HIP_TRY(d_seq.alloc(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64))); /* a caller's device buffer is written in place */
+        HIP_TRY(d_seq.grow_keeping(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64), sink.seq_dev ? 0 : (size_t)sink.seq_used)); /* a caller's device buffer is written in place; what an earlier tier left stays */
         HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
         /* dense words / metadata: only the gaps that need the host bring their contigs back; sized by the last need, grown on demand below */
         HIP_TRY(d_dw.alloc(std::max<size_t>(ws.cap[d_dw.slot], 1 << 20)));
@@ -2892,7 +2905,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             if (again) {
                 /* the dense arrays hold this launch only (offsets relative to the batch: the launch's part is copied from begin[]) */
                 HIP_TRY(hipStreamSynchronize(stream));
-                if (!sink.seq_dev) HIP_TRY(d_seq.alloc(std::max<size_t>(sink.seq_cap, 64)));
+                /* what earlier launches of the batch left in the arena stays: when the text is formatted on the device the arena's only copy is this one
+                 * (round 4: a batch of several launches lost the sequences of all but its last launch here -- the device formatter then wrote
+                 * "_len_0" records; found by running the GPU tests under MAX_CHUNK) */
+                if (!sink.seq_dev) HIP_TRY(d_seq.grow_keeping(std::max<size_t>(sink.seq_cap, 64), (size_t)tot.begin[2]));
                 HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
                 HIP_TRY(d_dw.alloc(need_w));
                 HIP_TRY(d_dm.alloc(need_m));

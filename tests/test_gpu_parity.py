@@ -292,6 +292,17 @@ def test_diploid_bubbles(mtg, tmp_path):
     _diploid_case(mtg, tmp_path, 200)
 
 
+@pytest.mark.parametrize("chunk", [37, 100])
+def test_device_formatted_text_of_a_batch_of_several_launches(mtg, tmp_path, monkeypatch, chunk):
+    """round 4: with the text formatted on the device the ASCII arena of a batch exists only in the workspace; a batch that needs several
+    launches (more gaps than the scratch holds; here MAX_CHUNK of the tuning table) grows that arena between its launches -- and lost what
+    the earlier launches had written there (records of length 0 in the FASTA file).  The diploid case through the tool, 37 and 100 gaps
+    per launch, against the oracle's files."""
+    from tests.test_emu_parity import _diploid_case
+    monkeypatch.setenv("MTG_MAX_CHUNK", str(chunk))
+    _diploid_case(mtg, tmp_path, 200)
+
+
 def test_allelic_inserts_general_path(mtg, tmp_path):
     """multi-contig gaps: contig graph, reverse DFS, path sequences and k_nw-based de-duplication against the oracle"""
     from tests.test_emu_parity import _allelic_inserts_case
