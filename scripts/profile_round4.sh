@@ -22,9 +22,14 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/bpmc_write -o pmc -- python
 python3 scripts/aggregate_profiles.py pmc $O/bpmc_fetch $O/bpmc_write $O/pmc_build.json
 rm -rf $O/stats $O/stats1 $O/pmc_fetch $O/pmc_write $O/bstats $O/bpmc_fetch $O/bpmc_write
 cp $O/pmc.json profiles/r04_pmc.json; cp $O/pmc_build.json profiles/r04_pmc_build.json   # on the box: the bench line below carries the traffic of this very code
+# the default bench BEFORE the legacy build: a process that exits with 200 GB allocated leaves the driver wiping that memory, and the next
+# process's first large hipMalloc waits for it (scripts/hipmalloc_latency.py: 0.3 ms on a quiet device, 6.6 s behind 49 GB of freed pieces) --
+# round 4's earlier bench lines carried 4 s of "hipmalloc_seconds" for that reason alone
+sleep 5
+S=$(date +%s); python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench.py: $(( $(date +%s) - S )) s wall" > $O/bench_default_wall.txt
 python3 scripts/r4_build.py > $O/build_lean.txt 2>&1
 MTG_LEGACY_BUILD=1 python3 scripts/r4_build.py > $O/build_legacy.txt 2>&1
-S=$(date +%s); python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench.py: $(( $(date +%s) - S )) s wall" > $O/bench_default_wall.txt
+sleep 5
 python3 scripts/r4_load.py > $O/container_load.txt 2>&1
 bash scripts/r4_load_sweep.sh > $O/container_load_fresh_processes.txt 2>&1
 MTG_BENCH_ONE_DEVICE=1 MTG_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 2 --nseq 120000 --sites 20000 --cpu-sites 0 --no-ceiling > $O/dry_two_ranks_gloo.json 2> $O/dry_two_ranks_gloo.err
