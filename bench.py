@@ -187,7 +187,7 @@ def main():
     params = mtg.FillParams(max_nodes=100, max_depth=10000, nb_host_threads=host_threads)
     STAT_KEYS = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
                      post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0,
-                     finish_kernel_ms=0.0, n_parked_gaps=0, n_lean_gaps=0, lean_kernel_ms=0.0, copy_words_executed=0, copy_cmds_executed=0, post_scanned_words=0, gaps=0)
+                     finish_kernel_ms=0.0, n_parked_gaps=0, n_lean_gaps=0, lean_kernel_ms=0.0, copy_words_executed=0, copy_cmds_executed=0, post_scanned_words=0, device_span_ms=0.0, gaps=0)
 
     class B:
         pass
@@ -802,7 +802,9 @@ def main():
         roof["one_batch_alone_ms"] = {"k_stage_a+k_finish": st_alone["kernel_ms"] / nl1, "k_finish": st_alone["finish_kernel_ms"] / nl1, "k_lean": st_alone["lean_kernel_ms"] / nl1,
                                       "k_copy": (st_alone["copy_kernel_ms"] - st_alone["lean_kernel_ms"]) / nl1,
                                       "k_post+scans": st_alone["post_kernel_ms"] / nl1, "k_emit": st_alone["emit_kernel_ms"] / nl1, "parked_gaps": st_alone["n_parked_gaps"] / nl1,
-                                      "sum": (st_alone["kernel_ms"] + st_alone["copy_kernel_ms"] + st_alone["post_kernel_ms"] + st_alone["emit_kernel_ms"]) / nl1, "launches": nl1}
+                                      "sum": (st_alone["kernel_ms"] + st_alone["copy_kernel_ms"] + st_alone["post_kernel_ms"] + st_alone["emit_kernel_ms"]) / nl1,
+                                      "first_kernel_to_last": st_alone["device_span_ms"] / nl1,  # less than the sum: k_finish runs next to k_lean, k_copy and k_post_lean (second stream)
+                                      "launches": nl1}
     if not a.no_ceiling:
         tb = min(int(info["device_bytes"] // 2), 16 << 30)  # the ceiling is flat beyond ~16 GB (profiles/r01_random_line_ceiling.txt)
         ms, gbps = mtg.random_line_ceiling(max(tb, 1 << 26), batch_sites, 512, bucket)

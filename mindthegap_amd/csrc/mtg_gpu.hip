@@ -551,7 +551,7 @@ __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 #define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
 /* device: the work lists of one launch.  count[i] = entries of list i; list i = cap slot numbers at lists + i * cap.  List 2r holds the gaps
  * parked by the r-th launch of the walk kernel (at a branching node), list 2r + 1 those of them whose bubble did not fit the LDS areas. */
-enum { PARK_LISTS = 18 }; /* 0 .. 15: the rounds' lists of parked gaps; the last two: gaps for k_post's general form, gaps with copy commands to execute */
+enum { PARK_LISTS = 19 }; /* 0 .. 15: the rounds' lists of parked gaps; the last three: gaps with copy commands among those finished late, gaps for k_post's general form, gaps with copy commands to execute */
 struct ParkCtl {
     uint32_t count[PARK_LISTS];
 #ifdef MTG_BUBBLE_TIMING /* diagnostics build: how long the lanes and the waves of the bubble kernels ran (bins of log2 of 10 ns ticks) */
@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
  * form: nothing is copied, k_post and k_emit read the store)?  The gaps that do need their commands executed go on a work list (ballot +
  * prefix popcount, as for parking).  k_copy, one wave per listed gap, four per workgroup: the grid covers the launch (the host does not
  * know the count), a wave beyond the list leaves after one scalar read. */
-enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2 };
+enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2, COPY_LIST_LATE = PARK_LISTS - 3 };
 __global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
                                              const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
                                              uint32_t lean_allowed, uint32_t n, ParkCtl* park, uint32_t cap)
@@ -751,17 +751,42 @@ __global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw
     park_append(park, cap, COPY_LIST, need, slot);
     park_append(park, cap, POST_LIST, general, slot); /* every gap that is not lean (a failed one too): k_post's general form */
 }
-__global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap)
+__global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap, uint32_t list)
 {
-    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (t >= park->count[COPY_LIST]) return;
-    const uint32_t slot = park_list(park, cap, COPY_LIST)[t];
-    GapScratch S;
-    S.z = nullptr;
-    S.v = nullptr;
-    S.lane = 0;
-    S.r = raw + (uint64_t)slot * cfg.raw_stride;
-    copy_cmds(ix, cfg, S, outs[slot]);
+    const uint32_t count = park->count[list];
+    for (uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6); t < count; t += gridDim.x * 4u) { /* the grid usually covers the launch; a smaller one (the late list) loops */
+        const uint32_t slot = park_list(park, cap, list)[t];
+        GapScratch S;
+        S.z = nullptr;
+        S.v = nullptr;
+        S.lane = 0;
+        S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        copy_cmds(ix, cfg, S, outs[slot]);
+    }
+}
+/* The gaps the finishing kernel has walked while k_lean, k_copy and k_post_lean were busy with all the others (see device_run): their
+ * records come over from the finishing kernel's own array, they are never lean (the general k_post / k_emit take them: k_lean has
+ * listed them as such when it saw them parked), and the ones with copy commands go on the late list.  One gap per lane. */
+__global__ void __launch_bounds__(64) k_late(Index ix, FillCfg cfg, uint8_t* raw, GapOut* outs, const GapOut* __restrict__ finished, ParkCtl* park, uint32_t cap, uint32_t in_list)
+{
+    const uint32_t count = park->count[in_list];
+    for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) { /* the same trips for every lane of the wave: the append below is the wave's */
+        const uint32_t t = base + threadIdx.x;
+        bool need = false;
+        uint32_t slot = 0;
+        if (t < count) {
+            slot = park_list(park, cap, in_list)[t];
+            const GapOut o = finished[slot];
+            outs[slot] = o;
+            GapScratch S;
+            S.z = nullptr;
+            S.v = nullptr;
+            S.lane = 0;
+            S.r = raw + (uint64_t)slot * cfg.raw_stride;
+            need = lean_decide(ix, cfg, S, o, ~0ull); /* no target: not lean; true when there are commands to execute */
+        }
+        park_append(park, cap, COPY_LIST_LATE, need, slot);
+    }
 }
 
 /* mtg_fill_text: a batch whose strings are still text (mtg_marshal.h).  One gap per thread: source k-mer, packed pattern, its first k-mer,
@@ -2552,7 +2577,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf();
+          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf(), d_out2 = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
@@ -2630,7 +2655,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     st.h2d_ms += now_ms() - t0;
     tick("upload (async)");
 
-    hipEvent_t ev0, ev1, ev2, ev3, eve, evc, evf, evl;
+    hipEvent_t ev0, ev1, ev2, ev3, eve, evc, evf, evl, evl0;
     HIP_TRY(events.make(eve));
     HIP_TRY(events.make(evc));
     HIP_TRY(events.make(ev0));
@@ -2639,6 +2664,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     HIP_TRY(events.make(ev3));
     HIP_TRY(events.make(evf));
     HIP_TRY(events.make(evl));
+    HIP_TRY(events.make(evl0));
     PartTot* h_tot = (PartTot*)staging_host(&ws, Workspace::NHOST - 1, sizeof(PartTot) + 64);
     if (!h_tot) { set_error("no page-locked memory for the totals of a launch"); return MTG_ERR_NOMEM; }
 
@@ -2673,6 +2699,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
         HIP_TRY(d_ilv.alloc(((chunk + 63) / 64) * cfg.ilv_stride));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
+        HIP_TRY(d_out2.alloc(chunk * sizeof(GapOut))); /* where the finishing kernel leaves its records while the other gaps are post-processed */
         HIP_TRY(d_rec.alloc(chunk * sizeof(SlotRec)));
         HIP_TRY(d_ids.alloc(chunk * 4));
         HIP_TRY(d_blocks.alloc(((chunk + SCAN_SL - 1) / SCAN_SL + 1) * sizeof(ScanBlock)));
@@ -2738,8 +2765,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             const uint32_t park_share = own_share != ~0u ? own_share : (wmode ? 65536u : idx->park_share_any.load(std::memory_order_relaxed));
             const uint32_t park_hint = (uint32_t)(((uint64_t)park_share * m) >> 16); /* gaps this launch is expected to park */
             int rounds = env_rounds >= 0 ? env_rounds : (park_share > 32768u ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
-            if (rounds > (PARK_LISTS - 4) / 2) rounds = (PARK_LISTS - 4) / 2;
+            if (rounds > (PARK_LISTS - 5) / 2) rounds = (PARK_LISTS - 5) / 2;
             ParkCtl* const park = d_park.as<ParkCtl>();
+            bool overlap_finish = false;
+            uint32_t late_list = 0, late_grid = 1;
             HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
             if (classic_walk) {
@@ -2751,6 +2780,18 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                                    d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u, wmode ? 2u : 1u);
                 HIP_TRY(hipEventRecord(evf, stream));
                 const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
+                /* FINISH_OVERLAP of the tuning table (A/B, off).  Without rounds the finishing kernel is the latency of a few parked walks (0.06 ms for two
+                 * gaps of a haploid batch, 0.22 ms for the hundred of the SNP set) on an otherwise idle device: it can run on the workspace's second
+                 * stream, writing its records to an array of its own, while k_lean, k_copy and k_post_lean take all the other gaps on the batch's
+                 * stream; k_late then brings the finished gaps over, and the general k_post (which k_lean has listed them for when it saw them parked)
+                 * follows on that stream.  Measured (scripts/r4_streams.sh): one batch alone 0.360 -> 0.337 ms (haploid), 0.836 -> 0.811 (SNP set) --
+                 * the general k_post of the finished gaps still follows the finishing kernel -- and with six batches in flight NOT faster (sequences
+                 * left in HBM 346 -> 341, 105 -> 107, 123 -> 122 M/s): other batches' kernels fill the device while one batch waits, and the extra
+                 * kernels and events cost what the overlap saves.  The same holds for the general k_post next to the lean one (POST_SECOND_STREAM). */
+                overlap_finish = rounds == 0 && !skip_finish && ws.copy_stream && tune::on(tune::T_FINISH_OVERLAP);
+                const hipStream_t fstream = overlap_finish ? (hipStream_t)ws.copy_stream : stream;
+                GapOut* const fin_out = overlap_finish ? d_out2.as<GapOut>() : d_out.as<GapOut>();
+                if (overlap_finish) HIP_TRY(hipStreamWaitEvent(fstream, evf, 0));
                 /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with small bubbles that
                  * keeps more of them in flight than a group of lanes per bubble does (MTG_BUBBLE_GROUPS=1: k_bubble<G>, the LDS form, first) */
                 const bool one_lane_bubbles = !tune::on(tune::T_BUBBLE_GROUPS);
@@ -2791,13 +2832,15 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 const uint32_t per_wg = 64u / (uint32_t)fin_g;
                 const uint32_t nwg = (fin_entries + per_wg - 1) / per_wg;
                 if (!skip_finish && nwg) switch (fin_g) {
-                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
-                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
-                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin); break;
+                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin); break;
+                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin); break;
                 }
                 if (!skip_finish && fin_entries < m)
-                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries);
-                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, stream)); /* how many were parked: statistics, and the hint for the next launch */
+                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin, fin_entries);
+                late_list = lfin;
+                late_grid = (uint32_t)std::min<uint64_t>((m + 63) / 64, (4ull * park_hint + 256ull + 63) / 64);
+                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, fstream)); /* how many were parked: statistics, and the hint for the next launch */
 #ifdef MTG_BUBBLE_TIMING
                 {
                     static ParkCtl hc; static int shown = 0;
@@ -2812,24 +2855,31 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
 #endif
             }
-            HIP_TRY(hipEventRecord(ev1, stream));
+            HIP_TRY(hipEventRecord(ev1, overlap_finish ? (hipStream_t)ws.copy_stream : stream)); /* the end of the walks: of the finishing kernel, wherever it ran */
+            HIP_TRY(hipEventRecord(evl0, stream));
             HIP_TRY(hipGetLastError());
-            /* ev1 .. evc: the long runs of the contigs, which the traversal only noted down */
+            /* evl0 .. evc: the long runs of the contigs, which the traversal only noted down */
             const bool no_lean = tune::on(tune::T_NO_LEAN); /* A/B and test hook: every contig is materialised */
             hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
                                (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m, park, m);
             HIP_TRY(hipEventRecord(evl, stream)); /* ev1 .. evl: k_lean; evl .. evc: k_copy */
-            hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m);
+            hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m, (uint32_t)COPY_LIST);
             HIP_TRY(hipEventRecord(evc, stream));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
             /* the lean gaps eight per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
              * listed, plus 1024 (a workspace without a launch yet: one per gap), the kernel's loop takes the rest */
             const uint32_t general_hint = ws.post_general == ~0u ? m : (uint32_t)std::min<uint64_t>(m, 4ull * ws.post_general + 1024ull);
             /* The general form is the latency of a few long gaps (30 us for the one or two of a haploid batch), the lean form the throughput of
-             * all the others: they touch different slots and run next to each other, the general one on the workspace's second stream
-             * (POST_ONE_STREAM of the tuning table: one after the other, as measured before). */
-            const hipStream_t side = (ws.copy_stream && !tune::on(tune::T_POST_ONE_STREAM)) ? (hipStream_t)ws.copy_stream : stream;
-            if (side != stream) {
+             * all the others: they touch different slots and CAN run next to each other (POST_SECOND_STREAM of the tuning table: 9 us shorter for
+             * one batch alone, 346 against 355 M/s with six in flight -- one stream per batch is the default). */
+            const hipStream_t side = (ws.copy_stream && (overlap_finish || tune::on(tune::T_POST_SECOND_STREAM))) ? (hipStream_t)ws.copy_stream : stream;
+            if (overlap_finish) {
+                /* the second stream has the finishing kernel in it: the finished gaps' records, their copy commands, then (below) the general k_post,
+                 * which also needs what k_lean and k_copy have done for the other listed gaps on the batch's stream (evc) */
+                hipLaunchKernelGGL(k_late, dim3(late_grid), dim3(64), 0, side, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_out2.as<GapOut>(), park, m, late_list);
+                hipLaunchKernelGGL(k_copy, dim3(late_grid * 16u), dim3(256), 0, side, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m, (uint32_t)COPY_LIST_LATE);
+                HIP_TRY(hipStreamWaitEvent(side, evc, 0));
+            } else if (side != stream) {
                 hipEvent_t ev_fork;
                 HIP_TRY(events.make(ev_fork));
                 HIP_TRY(hipEventRecord(ev_fork, stream));
@@ -3009,11 +3059,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     if (!wmode) { ws.park_share = share; idx->park_share_any.store(share, std::memory_order_relaxed); }
                     if (whole) { ws.mode_ns_per_gap[wmode] = ms * 1e6f / (float)m; ws.mode_launches++; } /* ev0 .. ev1: the walk, its rounds and the finishing kernel (with whatever else the device was doing: the launches of a workspace see the same company) */
                 } }
-            HIP_TRY(hipEventElapsedTime(&msc, ev1, evc));
-            { float msl = 0; HIP_TRY(hipEventElapsedTime(&msl, ev1, evl)); st.lean_kernel_ms += msl; }
+            HIP_TRY(hipEventElapsedTime(&msc, evl0, evc)); /* k_lean + k_copy; when the finishing kernel runs on the second stream they start behind the walk kernel, next to it */
+            { float msl = 0; HIP_TRY(hipEventElapsedTime(&msl, evl0, evl)); st.lean_kernel_ms += msl; }
             HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
             st.copy_kernel_ms += msc;
             HIP_TRY(hipEventElapsedTime(&ms3, eve, ev2));
+            { float mss = 0; HIP_TRY(hipEventElapsedTime(&mss, ev0, ev2)); st.device_span_ms += mss; }
             st.kernel_ms += ms;
             st.post_kernel_ms += ms2;
             st.emit_kernel_ms += ms3;

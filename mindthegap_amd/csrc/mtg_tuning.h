@@ -45,7 +45,8 @@
     X(FINISH_FULL_GRID, "", "ab", "the finishing kernel with one group per gap of the launch (round 3) instead of a grid sized from the previous launch's parked gaps") \
     X(BUBBLE_GROUPS, "", "ab", "the rounds' bubbles by k_bubble<G> (LDS form) before the one-lane form") \
     X(PARK_SNP, "", "ab", "the walk kernel parks at SNP bubbles too and the bubble kernel answers them (measured and not used)") \
-    X(POST_ONE_STREAM, "", "ab", "the general form of k_post after the lean one on the batch's stream instead of next to it on the workspace's second stream") \
+    X(POST_SECOND_STREAM, "", "ab", "the general form of k_post next to the lean one on the workspace's second stream (9 us shorter for one batch alone, no faster with six in flight: measured and not used)") \
+    X(FINISH_OVERLAP, "", "ab", "the finishing kernel on the second stream next to k_lean, k_copy and k_post_lean, its gaps brought over by k_late (25 us shorter for one batch alone, slower with six in flight: measured and not used)") \
     X(NO_LEAN, "", "test", "every contig is materialised (no lean gaps)") \
     X(NO_DEFER, "", "test", "the lanes of the traversal copy their long runs themselves (no copy commands, no k_copy work)") \
     X(MAX_CHUNK, "", "test", "gaps per traversal launch (default: what the scratch holds): several launches per batch") \
