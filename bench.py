@@ -510,6 +510,29 @@ def main():
         secondary["value_from_host_text_note"] = ("same steps through mtg_fill_text: every step copies its sites' text block (%d bytes for %d sites) and offset arrays into page-locked memory, uploads "
                                                   "them and encodes on the device; median of 3 blocks, %d pool threads; sequences of one batch identical to the truth: %s"
                                                   % (len(batches[0].text.text), batches[0].n, int(os.environ.get("MTG_POOL_THREADS", "0")) or mtg.cpu_budget(), ok_text))
+        # the same with the blocks page-locked by the caller once (mtg_host_register): no copy of the block inside the steps
+        try:
+            for b in batches:
+                b.text.register()
+            R0["run_block"](max(a.warmup, 1), False, host_text=True)
+            ts = []
+            for r in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                R0["run_block"](a.steps, False, r * a.steps, host_text=True)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            _, seqs_t = R0["fill"](batches[0], prepared=batches[0].text, want_seqs=True)
+            ok_reg = (hashlib.sha256(seqs_t.tobytes().replace(b"\n", b"\0")).hexdigest() == batches[0].digest) if not (het or tips) else None
+            secondary["value_from_registered_text"] = batch_sites * a.steps / float(np.median(ts))
+            secondary["value_from_registered_text_note"] = ("mtg_fill_text on blocks the caller has page-locked once (mtg_host_register): the block goes up from where it is, only the offset "
+                                                            "arrays are copied inside the step; sequences of one batch identical to the truth: %s" % ok_reg)
+        except Exception as e:
+            secondary["value_from_registered_text"] = None
+            secondary["value_from_registered_text_note"] = "failed: " + repr(e)[:200]
+        finally:
+            for b in batches:
+                b.text.unregister()
         for b in batches:
             b.text = None
 

@@ -214,6 +214,12 @@ typedef struct mtg_text_gaps {
     const uint8_t* gap_flags;         /* per gap, bit 0: is_anchor_repeated, bit 1: reverse (NULL: all 0) */
 } mtg_text_gaps;
 int mtg_fill_text(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, mtg_results** out);
+/* A caller that keeps its text where it is for many batches (a mapped or fully read breakpoint file) can page-lock it once: the block of a
+ * mtg_text_gaps that lies inside a registered range goes to the device straight from the caller's memory, without the copy into the
+ * library's page-locked block (13 MB per 100 000 sites).  The offset arrays are still copied (they are small).  The range must stay
+ * registered and unchanged while calls that use it run.  MTG_ERR_ARG: the range cannot be page-locked (or overlaps a registered one). */
+int mtg_host_register(void* p, size_t bytes);
+int mtg_host_unregister(void* p);
 /* mtg_fill_text for the gaps of BREAKPOINT sites (one-entry dictionaries), and the text the tool's writers add to its output files for them
  * -- writeFilledBreakpoint (src/Filler.cpp:1029-1093), the info line, writeVcf (:1095-1214) -- FORMATTED ON THE DEVICE from the records and
  * sequences the result kernel has just written there: what crosses PCIe is the files' next bytes, and the host only writes them.

@@ -2441,6 +2441,12 @@ void* pinned_alloc(size_t bytes)
     return p;
 }
 void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+int host_register(void* p, size_t bytes)
+{
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); set_error("cannot page-lock %zu bytes at %p", bytes, p); return MTG_ERR_ARG; }
+    return MTG_OK;
+}
+int host_unregister(void* p) { if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); set_error("%p is not page-locked", p); return MTG_ERR_ARG; } return MTG_OK; }
 int device_download(const mtg_index* idx, void* host_dst, const void* dev_src, size_t bytes)
 {
     if (int rc = use_device_of(idx)) return rc;
@@ -2602,7 +2608,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_inb.alloc(in.bytes_b));
         HIP_TRY(d_inc.alloc(in.bytes_c));
         HIP_TRY(hipMemcpyAsync(d_ina.p, in.block_a, in.bytes_a, hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, up));
+        if (in.text_direct) { /* the block from the caller's page-locked memory, the offset arrays from the staging block */
+            const size_t off5 = FillInput::text_block_off(n, (size_t)n_targets, 5);
+            HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, off5, hipMemcpyHostToDevice, up));
+            HIP_TRY(hipMemcpyAsync((uint8_t*)d_inc.p + off5, in.text_direct, in.text_bytes, hipMemcpyHostToDevice, up));
+        } else HIP_TRY(hipMemcpyAsync(d_inc.p, in.block_c, in.bytes_c, hipMemcpyHostToDevice, up));
         if (int rc = uploaded()) return rc;
         HIP_TRY(d_tenc.alloc(n_targets * 16 + 64));
         uint8_t* a = d_ina.as<uint8_t>();

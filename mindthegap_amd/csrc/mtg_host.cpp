@@ -1235,6 +1235,18 @@ static int fill_batch_impl(const mtg_index* idx, const mtg_params* p, const mtg_
     if (int rc = marshal_gaps(gaps, n, p, in)) return rc;
     return fill_marshalled(idx, p, in, gaps, n, seq_out, seq_cap, seq_bytes, out, t_begin);
 }
+/* the ranges callers have page-locked for mtg_fill_text (mtg_host_register): few, looked up once per batch */
+namespace {
+std::mutex g_reg_mtx;
+std::vector<std::pair<uintptr_t, size_t>> g_reg;
+bool registered_range(const void* p, size_t bytes)
+{
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> lk(g_reg_mtx);
+    for (const auto& r : g_reg) if (a >= r.first && a + bytes <= r.first + r.second) return true;
+    return false;
+}
+} // namespace
 /* mtg_fill_text: what the host does for a batch whose strings are still text -- the integer columns of block A from the caller's arrays
  * (no string is looked at), the offset arrays and the block itself copied into the page-locked text block; the device does the rest */
 static int fill_text_impl(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t seq_cap, uint64_t* seq_bytes, mtg_results** out, const FormatReq* fmt = nullptr)
@@ -1295,7 +1307,8 @@ static int fill_text_impl(const mtg_index* idx, const mtg_params* p, const mtg_t
         memcpy(c + FillInput::text_block_off(n, nt, 2), g->dict_seq_off, 8 * nt);
         memcpy(c + FillInput::text_block_off(n, nt, 4), g->dict_seq_len, 4 * nt);
     }
-    if (tb) { /* the block itself: 10-15 MB per 100 000 sites, a millisecond for one thread -- in pieces on the worker pool */
+    if (tb && registered_range(g->text, (size_t)tb)) in.text_direct = g->text; /* the caller has page-locked it (mtg_host_register): it goes up from where it is */
+    else if (tb) { /* the block itself: 10-15 MB per 100 000 sites, a millisecond for one thread -- in pieces on the worker pool */
         uint8_t* dst = c + FillInput::text_block_off(n, nt, 5);
         const size_t piece = (size_t)1 << 20, npieces = ((size_t)tb + piece - 1) / piece;
         parallel_for(npieces, p->nb_host_threads, [&](size_t i) { memcpy(dst + i * piece, g->text + i * piece, std::min(piece, (size_t)tb - i * piece)); }, 1);
@@ -1322,6 +1335,30 @@ int mtg_formatted_get(const mtg_formatted* t, mtg_formatted_view* v)
 }
 void mtg_formatted_free(mtg_formatted* t) { delete t; }
 int mtg_fill_text(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, mtg_results** out) { return fill_text_impl(idx, p, g, nullptr, 0, nullptr, out); }
+int mtg_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
+    const uintptr_t a = (uintptr_t)p;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mtx);
+        for (const auto& r : g_reg) if (a < r.first + r.second && r.first < a + bytes) { mtgi::set_error("the range overlaps a registered one"); return MTG_ERR_ARG; }
+    }
+    if (int rc = mtgi::host_register(p, bytes)) return rc;
+    std::lock_guard<std::mutex> lk(g_reg_mtx);
+    g_reg.emplace_back(a, bytes);
+    return MTG_OK;
+}
+int mtg_host_unregister(void* p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mtx);
+        auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const std::pair<uintptr_t, size_t>& r) { return r.first == a; });
+        if (it == g_reg.end()) { mtgi::set_error("%p was not registered", p); return MTG_ERR_ARG; }
+        g_reg.erase(it);
+    }
+    return mtgi::host_unregister(p);
+}
 int mtg_fill_text_serial(const mtg_index* idx, const mtg_params* p, const mtg_text_gaps* g, char* seq_out, uint64_t cap, uint64_t* seq_bytes, mtg_results** out)
 {
     if (!seq_out || !seq_bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }

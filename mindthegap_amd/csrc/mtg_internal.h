@@ -276,6 +276,8 @@ void* staging_host(Workspace* ws, int slot, size_t bytes);
 /* page-locked host memory for the result arrays of a batch (plain memory in the emulation); nullptr on failure */
 void* pinned_alloc(size_t bytes);
 void pinned_free(void* p);
+int host_register(void* p, size_t bytes); /* page-lock / release a caller's range (the backends) */
+int host_unregister(void* p);
 /* plain copies between the host and the index's device (rare paths of the host code that touch a caller's device buffer) */
 int device_download(const mtg_index* idx, void* host_dst, const void* dev_src, size_t bytes);
 int device_upload(const mtg_index* idx, void* dev_dst, const void* host_src, size_t bytes);
@@ -314,6 +316,7 @@ struct FillInput {
      * writes src, r0, fast_ok, the patterns and the encoded targets (mtg_marshal.h). */
     bool text_mode = false;
     uint64_t n_rwords = 0, n_text_targets = 0, text_bytes = 0;
+    const char* text_direct = nullptr; /* text mode: the block lies in memory the caller has page-locked (mtg_host_register): block_c holds the offset arrays only */
     static size_t text_block_off(size_t n, size_t nt, int which) /* 0 source_off, 1 pattern_off, 2 dict_seq_off, 3 source_len, 4 dict_seq_len, 5 text */
     {
         const size_t o[6] = {0, 8 * n, 16 * n, 16 * n + 8 * nt, 20 * n + 8 * nt, (20 * n + 12 * nt + 7) & ~(size_t)7};

@@ -148,6 +148,8 @@ def _bind(lib):
     lib.mtg_index_save.argtypes = [C.c_void_p, C.c_char_p]
     lib.mtg_index_replicate.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p)]
     lib.mtg_index_get_info.argtypes = [C.c_void_p, P(IndexInfo)]
+    lib.mtg_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.mtg_host_unregister.argtypes = [C.c_void_p]
     lib.mtg_tuning_count.restype = C.c_size_t
     lib.mtg_tuning_count.argtypes = []
     lib.mtg_tuning_describe.argtypes = [C.c_size_t, P(C.c_char_p), P(C.c_char_p), P(C.c_char_p), P(C.c_char_p)]
@@ -268,6 +270,25 @@ class TextGaps:
                            dict_name_off=np.array(no + [0], np.uint64), dict_name_len=np.array(nl + [0], np.uint32), dict_is_rc=np.array(rc + [0], np.uint8), gap_flags=flags)
         self.c = CTextGaps(self.text.ctypes.data, len(self.text) - 1, n, *[self.arrays[k].ctypes.data for k in ("source_off", "source_len", "pattern_off", "pattern_len", "dict_first", "dict_seq_off",
                                                                                                             "dict_seq_len", "dict_name_off", "dict_name_len", "dict_is_rc", "gap_flags")])
+        self.registered = False
+
+    def register(self):
+        """page-lock the block (mtg_host_register): mtg_fill_text then uploads it from here instead of copying it into its own page-locked block"""
+        if not self.registered:
+            _check(load_library().mtg_host_register(self.text.ctypes.data, len(self.text)))
+            self.registered = True
+        return self
+
+    def unregister(self):
+        if self.registered:
+            _check(load_library().mtg_host_unregister(self.text.ctypes.data))
+            self.registered = False
+
+    def __del__(self):
+        try:
+            self.unregister()
+        except Exception:
+            pass
 
 
 class Batch:

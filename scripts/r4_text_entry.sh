@@ -10,7 +10,7 @@ run() {
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
-    print(sys.argv[1], "prepared %.1f strings %.1f text %.1f M/s" % (d["value"] / 1e6, d.get("value_from_host_strings", 0) / 1e6, d.get("value_from_host_text", 0) / 1e6))
+    print(sys.argv[1], "prepared %.1f strings %.1f text %.1f registered text %.1f M/s" % (d["value"] / 1e6, d.get("value_from_host_strings", 0) / 1e6, d.get("value_from_host_text", 0) / 1e6, (d.get("value_from_registered_text") or 0) / 1e6))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY

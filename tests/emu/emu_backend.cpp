@@ -245,6 +245,8 @@ void* pinned_alloc(size_t bytes)
     return p;
 }
 void pinned_free(void* p) { free(p); }
+int host_register(void*, size_t) { return MTG_OK; } /* nothing to lock on the host */
+int host_unregister(void*) { return MTG_OK; }
 /* the emulated device's memory is host memory */
 int device_download(const mtg_index*, void* host_dst, const void* dev_src, size_t bytes) { memcpy(host_dst, dev_src, bytes); return MTG_OK; }
 int device_upload(const mtg_index*, void* dev_dst, const void* host_src, size_t bytes) { memcpy(dev_dst, host_src, bytes); return MTG_OK; }
@@ -389,7 +391,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     std::vector<uint64_t> tle(n_targets), tbad(n_targets), text_rw;
     if (in.text_mode) {
         const uint8_t* c = (const uint8_t*)in.block_c;
-        const uint8_t* text = c + FillInput::text_block_off(n, n_targets, 5);
+        const uint8_t* text = in.text_direct ? (const uint8_t*)in.text_direct : c + FillInput::text_block_off(n, n_targets, 5); /* mtg_host_register: the block stays where the caller has it */
         const uint64_t* soff = (const uint64_t*)(c + FillInput::text_block_off(n, n_targets, 0));
         const uint64_t* poff = (const uint64_t*)(c + FillInput::text_block_off(n, n_targets, 1));
         const uint64_t* doff = (const uint64_t*)(c + FillInput::text_block_off(n, n_targets, 2));

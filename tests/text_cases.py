@@ -13,19 +13,24 @@ def text_vs_strings(mtg, idx, gaps):
     params = mtg.FillParams()
     a = idx.fill_batch(gaps, params)
     tg = mtg.TextGaps(gaps)
-    h, nf, buf = idx.fill_prepared(tg, params)
     from mindthegap_amd import lib as L
-    b = []
-    for i in range(len(gaps)):
-        r = L.load_library().mtg_results_get(h, i).contents
-        b.append(dict(nb_nodes=r.nb_nodes, total_nt=r.total_nt, nb_terminal=r.nb_terminal, n=r.n_filled, ext=r.extension.decode(),
-                      filled=[(r.filled[j].seq.decode(), r.filled[j].nb_errors_in_anchor, r.filled[j].target_index, r.filled[j].qual, r.filled[j].avg_coverage, r.filled[j].median_coverage)
-                              for j in range(r.n_filled)]))
-    idx.free_results(h)
-    assert len(a) == len(b)
-    for x, y in zip(a, b):
-        assert (x["nb_nodes"], x["total_nt"], x["nb_terminal"], len(x["filled"]), x["extension"]) == (y["nb_nodes"], y["total_nt"], y["nb_terminal"], y["n"], y["ext"])
-        assert [(f["seq"], f["nb_errors_in_anchor"], f["target_index"], f["qual"], f["avg_coverage"], f["median_coverage"]) for f in x["filled"]] == y["filled"]
+    # twice: the block copied into the library's page-locked memory, and (round 4) uploaded from where it is once the caller has page-locked it
+    for registered in (False, True):
+        if registered:
+            tg.register()
+        h, nf, buf = idx.fill_prepared(tg, params)
+        b = []
+        for i in range(len(gaps)):
+            r = L.load_library().mtg_results_get(h, i).contents
+            b.append(dict(nb_nodes=r.nb_nodes, total_nt=r.total_nt, nb_terminal=r.nb_terminal, n=r.n_filled, ext=r.extension.decode(),
+                          filled=[(r.filled[j].seq.decode(), r.filled[j].nb_errors_in_anchor, r.filled[j].target_index, r.filled[j].qual, r.filled[j].avg_coverage, r.filled[j].median_coverage)
+                                  for j in range(r.n_filled)]))
+        idx.free_results(h)
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert (x["nb_nodes"], x["total_nt"], x["nb_terminal"], len(x["filled"]), x["extension"]) == (y["nb_nodes"], y["total_nt"], y["nb_terminal"], y["n"], y["ext"])
+            assert [(f["seq"], f["nb_errors_in_anchor"], f["target_index"], f["qual"], f["avg_coverage"], f["median_coverage"]) for f in x["filled"]] == y["filled"]
+    tg.unregister()
     return a
 
 
