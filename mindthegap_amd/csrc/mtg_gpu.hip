@@ -1178,8 +1178,11 @@ __global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* ra
     emit_gap(us, cfg, S, r, gflags[g], slot, g, k, D, H);
     }
 }
-/* the lean gaps (mtg_emit.h: emit_lean): eight lanes per gap, eight gaps per wave */
-enum { EMIT_LEAN_G = 8 };
+/* the lean gaps (mtg_emit.h: emit_lean): eight lanes per gap, eight gaps per wave (k_emit of one haploid batch alone: 0.063 ms with 4 lanes per gap, 0.055 with 8, 0.052 with 16) */
+#ifndef MTG_EMIT_LEAN_G
+#define MTG_EMIT_LEAN_G 8
+#endif
+enum { EMIT_LEAN_G = MTG_EMIT_LEAN_G };
 __global__ void __launch_bounds__(64) k_emit_lean(UStore us, FillCfg cfg, uint8_t* raw, const SlotRec* __restrict__ recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
                                                   const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t n)
 {
