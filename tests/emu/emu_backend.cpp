@@ -562,7 +562,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                         EmitDev D2 = D;
                         D2.seq = (char*)((uintptr_t)(tmp.data() + 16) - (uintptr_t)recs[s].abase); D2.seq_cap = recs[s].abase + recs[s].asc;
                         D2.res = &g2; D2.fil = &f2;
-                        if (getenv("MTG_EMU_TRACE_LEAN")) fprintf(stderr, "[emu] lean emit checked\n");
                         emit_lean<1>(idx->dev.us, cfg, S, recs[s], recs[s].abase, in.flags[ids[s]], 0, ids[s], k, D2, H, 0u);
                         if (memcmp(tmp.data() + 16, D.seq + recs[s].abase, recs[s].asc) != 0 || memcmp(&g2, &D.res[s], sizeof g2) != 0 || memcmp(&f2, &D.fil[s], sizeof f2) != 0) {
                             set_error("gap %u: the lean form of the result kernel and the general one disagree", ids[s]);
