@@ -47,7 +47,9 @@ WORKLOADS = {
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of the job (default: WORLD_SIZE, else 1).  N > 1 without WORLD_SIZE in the environment: this process starts the N ranks itself (torch.distributed.run)")
+    ap.add_argument("--full-line", action="store_true", help="print the whole detail object as the last line instead of the compact one (what the child processes of the secondary workloads hand to their parent)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the whole detail object is written (the last stdout line is the compact one)")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=os.environ.get("MTG_BENCH_WORKLOAD", "human"), choices=list(WORKLOADS))
@@ -88,11 +90,128 @@ def reference_binary():
     return None if "mindthegap_amd" in out else {"path": exe, "version": out.strip()}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes (torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1) before anything in this process has touched a GPU, pass their output through and leave with their exit code.
+    Never an exec: a process image is not replaced here."""
+    import socket
+    import torch  # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this machine shows %d GPU(s); refusing to print a %d-GPU line from fewer devices" % (n, have, n))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cp = subprocess.run(cmd, env=env)
+    raise SystemExit(cp.returncode)
+
+
+def _num(x, digits=4):
+    """a number of the compact line: rounded to `digits` significant figures (ints stay ints, None / bool / str pass)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+COMPACT_LIMIT = 6000  # bytes: what the driver's tail of stdout holds with room to spare (round 4's 24 KB line was not parsed)
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses, from the detail object: the contract's keys, a compact `roofline` (dominant fill kernel against HBM on
+    the bytes the layout must move; the link the job is bound by; the index construction on SURVEY 8d's bytes), a compact `cpu_baseline`,
+    `end_to_end` (config 4 literally) and one number per secondary.  Everything else is in the detail file."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    roof, cpu, ib, cfg = out.get("roofline") or {}, out.get("cpu_baseline") or {}, out.get("index_build") or {}, out.get("config") or {}
+    dom = next((kk for kk in roof.get("kernels", []) if kk.get("kernel") == roof.get("dominant_kernel")), {})
+    wall = next((kk for kk in roof.get("kernels", []) if str(kk.get("kernel", "")).startswith("k_stage_a")), {})
+    line = {kk: out.get(kk) for kk in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _num(out.get("value"), 6), _num(out.get("ms_per_step"), 5)
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:200], "sites_per_step": cfg.get("sites_per_step"), "sites_per_batch": cfg.get("sites_per_batch"),
+                      "sites_per_rank_and_step": cfg.get("sites_per_rank_and_step"), "site_set": cfg.get("site_set"), "k": cfg.get("k"), "max_nodes": cfg.get("max_nodes"),
+                      "nb_solid_kmers": cfg.get("nb_solid_kmers"), "index_bytes": cfg.get("index_bytes"), "batches_in_flight": cfg.get("batches_in_flight"),
+                      "input": cfg.get("input"), "output": str(cfg.get("output", ""))[:120]}
+    line["filled"], line["sites_verified"] = out.get("filled"), out.get("sites_verified")
+    line["filled_sequences_identical_to_truth"] = out.get("filled_sequences_identical_to_truth")
+    if out.get("gathered_payload_verified") is not None:
+        line["gathered_payload_verified"] = g(out, "gathered_payload_verified", "ok")
+    # the entries of the same steps: inputs resident in HBM (= value, the contract's wording), one block of text per batch, host strings, ...
+    line["value_prepared"] = _num(out.get("value"), 6)
+    for kk in ("value_from_host_text", "value_from_registered_text", "value_from_host_strings", "value_sequences_left_in_hbm", "tool_sites_per_s"):
+        if kk in out:
+            line[kk] = _num(out.get(kk))
+    line["roofline"] = {
+        "bound": "hbm", "kernel": dom.get("kernel"), "achieved": _num(dom.get("achieved")), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _num(dom.get("frac")),
+        "bytes_per_launch": _num(dom.get("bytes_per_launch"), 6), "bytes_are": "what the implemented layout must move per launch (counters of the timed launches)",
+        "avg_kernel_ms": _num(dom.get("avg_kernel_ms")), "traffic": _num(dom.get("traffic"), 6), "traffic_over_bytes": _num(dom.get("traffic_over_bytes")),
+        "traffic_is": "replayed from profiles/ (PMC FETCH_SIZE + WRITE_SIZE of this command)" if dom.get("traffic") else None,
+        "dominant_kernel": roof.get("dominant_kernel"), "dominant_kernel_frac": _num(roof.get("dominant_kernel_frac_of_hbm_peak")),
+        "walk_kernel": wall.get("kernel"), "walk_kernel_frac": _num(wall.get("frac")), "walk_kernel_ms": _num(wall.get("avg_kernel_ms")),
+        "walk_traffic_over_bytes": _num(wall.get("traffic_over_bytes")),
+        "random_read_frac": _num(g(roof, "random_reads_of_k_stage_a", "alone", "frac_of_ceiling") or g(roof, "random_reads_of_k_stage_a", "frac_of_ceiling")),
+        "sec8d_equivalent_frac_of_the_walk": _num(g(roof, "reference_algorithm_equivalent", "equivalent_GBps_of_k_stage_a") / HBM_PEAK_GBS) if g(roof, "reference_algorithm_equivalent", "equivalent_GBps_of_k_stage_a") else None,
+        "sec8d_note": "above 1: a step does not do SURVEY 8(d)'s 8 probes per nucleotide, the index construction did (build_frac)",
+        "build_frac": _num(ib.get("sec8d_frac_over_device_seconds")), "build_device_s": _num(ib.get("device_seconds")),
+        "job_bound": "pcie", "pcie_GBps": _num(roof.get("achieved")), "pcie_peak_GBps": PCIE_PEAK_GBS, "pcie_frac": _num(roof.get("frac")),
+        "kernels_alone_ms": {kk: _num(v, 3) for kk, v in (roof.get("one_batch_alone_ms") or {}).items() if kk != "launches"},
+    }
+    line["cpu_baseline"] = {"value": _num(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"), "sample": str(cpu.get("sample", ""))[:160],
+                            "identical_to_hip": cpu.get("identical_to_hip"), "same_algorithm_value": _num(cpu.get("same_algorithm_value")),
+                            "reference_binary": bool(isinstance(cpu.get("reference_binary"), dict))} if cpu else None
+    if ib:
+        line["index_build"] = {"seconds": _num(ib.get("seconds")), "device_seconds": _num(ib.get("device_seconds")), "hipmalloc_seconds": _num(ib.get("hipmalloc_seconds")),
+                               "peak_device_bytes": ib.get("peak_device_bytes"), "resident_bytes": ib.get("resident_bytes"),
+                               "sec8d_bytes": _num(g(ib, "reference_algorithm_equivalent", "bytes"), 5), "sec8d_frac_over_device_seconds": _num(ib.get("sec8d_frac_over_device_seconds")),
+                               "phases_ms": {ph["name"]: _num(ph["ms"], 3) for ph in ib.get("phases", []) if ph.get("ms", 0) >= 1.0}}
+    e2e = out.get("end_to_end")
+    if isinstance(e2e, dict):
+        line["end_to_end"] = {"sites": cfg.get("sites_per_batch"), "from_donor_in_hbm_s": _num(g(e2e, "from_donor_in_hbm", "seconds")), "from_container_s": _num(g(e2e, "from_container", "seconds")),
+                              "cpu_port_scaled_s": _num(g(e2e, "cpu_port_same_span", "scaled_to_config4_estimate_s")),
+                              "identical_to_truth": bool(g(e2e, "from_donor_in_hbm", "sequences_identical_to_truth") and g(e2e, "from_container", "sequences_identical_to_truth")) if "from_container" in e2e else None,
+                              "error": e2e.get("error")}
+    sec = {}
+    for kk, v in out.items():
+        if kk.startswith("secondary_") and isinstance(v, dict):
+            ident = v.get("identical_to_oracle")
+            if ident is None:
+                ident = g(v, "oracle_sample", "identical_to_hip")
+            sec[kk[len("secondary_"):]] = {"value": _num(v.get("value")), "ratio": _num(v.get("ratio_to_headline"), 3), "identical_to_oracle": ident, **({"error": str(v["error"])[:80]} if "error" in v else {})}
+    if sec:
+        line["secondary"] = sec
+    sh = g(out, "eight_gpu_outlook_from_one_rank", "shards")
+    if isinstance(sh, dict):
+        line["eight_gpu_outlook"] = {kk: {"ms_per_step": _num(v.get("ms_per_step_of_one_rank")), "efficiency": _num(v.get("efficiency_vs_8x_the_headline"), 3)} for kk, v in sh.items() if isinstance(v, dict)}
+    s5 = out.get("strong_scaling_config5_literal")
+    if isinstance(s5, dict):
+        line["config5_literal"] = {"site_set": s5.get("site_set"), "value": _num(s5.get("value"), 6), "ms_per_step": _num(s5.get("ms_per_step")), "identical": s5.get("filled_sequences_identical_to_truth"),
+                                   "gathered_ok": g(s5, "gathered_payload_verified", "ok")}
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    # the line must stay readable to the driver whatever a later round adds to the detail object: shed the optional parts, largest first
+    for drop in ("eight_gpu_outlook", "secondary", "index_build", "end_to_end"):
+        if len(json.dumps(line)) <= COMPACT_LIMIT:
+            break
+        line.pop(drop, None)
+    return line
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus or 1) > 1:
+        spawn_ranks(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus is not None and a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU): the line would carry the wrong n_gpus" % (a.gpus, world))
     import torch
     import torch.distributed as dist
     import mindthegap_amd as mtg
@@ -857,6 +976,8 @@ def main():
                    "bytes_of_the_layout": lay_b, "achieved_GBps": lay_b / max(dev_s, 1e-9) / 1e9, "frac_of_hbm_peak": lay_b / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS,
                    "reference_algorithm_equivalent": {"bytes": ref_b, "what": "k-mers x 8 membership probes x 64 B (SURVEY 8d)", "GBps_over_the_whole_build": ref_b / max(t_index, 1e-9) / 1e9,
                                                       "frac_of_hbm_peak": ref_b / max(t_index, 1e-9) / 1e9 / HBM_PEAK_GBS},
+                   # SURVEY 8(d)'s bytes over the DEVICE time of the construction (the kernels' own clock; `seconds` also holds hipMalloc, a box property)
+                   "sec8d_frac_over_device_seconds": ref_b / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS,
                    "traffic": None}
     pmcb = os.path.join(ROOT, "profiles", "r04_pmc_build.json")
     if a.workload == "human" and os.path.exists(pmcb):
@@ -896,7 +1017,7 @@ def main():
                 # every child checks a sample of its sites against the oracle (cpu_baseline leg: 6 000 sites, index over the donor sequences of those loci): the
                 # alleles and error bubbles of these sets have no closed-form truth, the oracle's fills are the reference
                 cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--batches", "3", "--cpu-sites", "6000", "--cpu-index-seqs", "12000", "--cpu-same-sites", "0",
-                                     "--no-ceiling", "--no-secondary", "--steps", str(a.steps), "--warmup", str(a.warmup), "--in-flight", str(a.in_flight), "--repeats", "5"],
+                                     "--no-ceiling", "--no-secondary", "--full-line", "--detail", "", "--steps", str(a.steps), "--warmup", str(a.warmup), "--in-flight", str(a.in_flight), "--repeats", "5"],
                                     capture_output=True, text=True, timeout=600)
                 d = json.loads(cp.stdout.strip().splitlines()[-1])
                 cb = d.get("cpu_baseline") or {}
@@ -917,6 +1038,18 @@ def main():
                 out["secondary_reads_built"] = d
             except Exception as e:
                 out["secondary_reads_built"] = {"error": repr(e)[:300]}
+        # BASELINE configs[1] (SURVEY 8d cfg 2): 5 Mbp donor as 1000 x 5 kb, 30x reads of 150 nt through -in with -abundance-min 3, 1000 sites -- E0 (error-free
+        # reads: pure simple paths, parity fully pinned) and E1 (0.1 % substitutions: a few tips survive), each with 300 sites against the oracle
+        if not os.environ.get("MTG_BENCH_NO_ECOLI"):
+            for err, key in ((0.0, "secondary_ecoli_E0"), (0.001, "secondary_ecoli_E1")):
+                try:
+                    cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r4_reads_workload.py"), "--nseq", "1000", "--err", str(err), "--oracle-seqs", "300", "--steps", str(max(a.steps, 50)),
+                                         "--label", "BASELINE configs[1] " + key[-2:]], capture_output=True, text=True, timeout=300)
+                    d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
+                    d["ratio_to_headline"] = d["value"] / value if value else None
+                    out[key] = d
+                except Exception as e:
+                    out[key] = {"error": repr(e)[:300]}
     if dist_on:
         for r in results:
             if r["pg"] is not None:
@@ -929,7 +1062,22 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(out), flush=True)
+    if a.full_line:
+        print(json.dumps(out), flush=True)
+        return
+    detail_path = a.detail or None
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+            side = os.path.join(ROOT, "gpurun_out")  # scratch that travels back from the GPU box
+            if os.path.isdir(side):
+                shutil.copyfile(detail_path, os.path.join(side, os.path.basename(detail_path)))
+        except OSError as e:
+            print("bench.py: detail file not written: %r" % (e,), file=sys.stderr)
+            detail_path = None
+    print(json.dumps(out), file=sys.stderr, flush=True)  # the whole detail object: stderr, never the last stdout line
+    print(json.dumps(compact_line(out, detail_path)), flush=True)
 
 
 if __name__ == "__main__":

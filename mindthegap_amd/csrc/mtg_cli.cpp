@@ -1202,7 +1202,7 @@ static int run_tool(Options& O, mtg_index* idx, bool resident)
     }
     const double seconds = difftime(time(0), t_start);
     if (rc) { fprintf(stderr, "EXCEPTION: %s\n", mtg_last_error()); return 1; }
-    if (resident && tune::on(tune::T_TOOL_QUIET)) return 0; /* measurements: no summary */
+    if (tune::on(tune::T_TOOL_QUIET)) return 0; /* measurements: no summary (a caller that owns stdout, bench.py) */
     /* resumeParameters / resumeResults, src/Filler.cpp:385-481 */
     printf("MindTheGap fill\n    version                                  : %s\n    backend                                  : mindthegap_amd (HIP, gfx950)\n", MTG_VERSION);
     printf("Parameters\n    Input data\n");

@@ -1,0 +1,1514 @@
+/*
+ * mtg_gpu_build.hip -- index construction on the device (Graph::create / Graph::load, /root/reference/src/Filler.cpp:172-226), gfx950 only.
+ *
+ *   k_jt_insert_* / k_jt_scan / k_jt_plan / k_jt_emit / k_us_ab / k_sparse_link : the lean build (mtg_dev.h: junction table -> unitig store -> sparse tables)
+ *   k_count / k_count_stats                                                      : exact k-mer counting of streamed reads (-in)
+ *   k_insert_* / k_lookahead_* / k_us_* / k_leftovers                            : the construction of rounds 1-3 (dense tables; test hooks)
+ */
+#include "mtg_gpu_common.h"
+
+namespace mtgi {
+
+/* ------------------------------------------------------------------------------------------------ kernels */
+/* Synthetic abundance of a k-mer of the benchmark sets: span > 0: lo + hash % span; span == 0: a Poisson(24) variate (30x reads
+ * of 150 nt leave a mean k-mer coverage of 24) drawn by inversion from the 64-bit hash, at least lo.  T[i] = floor(P(X <= i) * 2^64). */
+__device__ uint32_t d_synth_abundance(uint64_t c, uint32_t lo, uint32_t span)
+{
+    const uint64_t h = d_splitmix64(c);
+    if (span) return lo + (uint32_t)(h % span);
+    static const uint64_t T[64] = {
+        0x0000000029820F1FULL, 0x000000040DB37A1BULL, 0x00000032C0047DE8ULL, 0x000001A8528C9C4CULL,
+        0x00000A69C1BD52A7ULL, 0x00003470A440BDF3ULL, 0x0000DC8C2E4E6B24ULL, 0x00031CEA99EB0617ULL,
+        0x0009DE05DCC0D6EEULL, 0x001BE0F939A5AE81ULL, 0x00471B414BCAE716ULL, 0x00A56BDE8AA7BFA0ULL,
+        0x01620D19086170B3ULL, 0x02BE4A7152F35527ULL, 0x051345E41BED6F11ULL, 0x08CE71CEF7173222ULL,
+        0x0E6733AF3FD5D6BBULL, 0x164DEB0A00E2FB56ULL, 0x20D6DF830249D6D0ULL, 0x2E258D951F01A8AEULL,
+        0x3E1D91AADB117152ULL, 0x505D9655FB237B31ULL, 0x6446559C4CAB85F7ULL, 0x790CADE5ACE06FD0ULL,
+        0x8DD3062F0D1559A9ULL, 0xA1C4A29E73AE8C13ULL, 0xB42D81CA34D97F88ULL, 0xC48AB9F119717462ULL,
+        0xD2917C5B943CD88BULL, 0xDE2D2614CDB90820ULL, 0xE7767AA8FBB5FAFDULL, 0xEEA6FE347A273B24ULL,
+        0xF40B60DD18FC2B41ULL, 0xF7F74B8646AE4E3FULL, 0xFABBF12ADF6848D5ULL, 0xFCA1DF1814EF208BULL,
+        0xFDE5D30B8DF3B05AULL, 0xFEB7F4BE3D509803ULL, 0xFF3CABB5D47DCC02ULL, 0xFF8E5761E2C0FFB3ULL,
+        0xFFBF57FC51B61EB7ULL, 0xFFDC072B030D6910ULL, 0xFFEC6B45B1886EFAULL, 0xFFF59148ADB5489AULL,
+        0xFFFA8EBEAB9F33ACULL, 0xFFFD380EAA825BB5ULL, 0xFFFE9B8650E29D1FULL, 0xFFFF510A38E830E7ULL,
+        0xFFFFABCC2CEAFACCULL, 0xFFFFD8401225D09FULL, 0xFFFFED966BB2B223ULL, 0xFFFFF7A0F0313A61ULL,
+        0xFFFFFC4354BA6591ULL, 0xFFFFFE5C90BE8C72ULL, 0xFFFFFF4B5615BA2BULL, 0xFFFFFFB386F5F35CULL,
+        0xFFFFFFE02E317995ULL, 0xFFFFFFF2FB5802F0ULL, 0xFFFFFFFAC2FE06D0ULL, 0xFFFFFFFDED278637ULL,
+        0xFFFFFFFF31381F94ULL, 0xFFFFFFFFB0B85BEBULL, 0xFFFFFFFFE21349FCULL, 0xFFFFFFFFF4E0987CULL};
+    uint32_t a = 0;
+    for (uint32_t step = 32; step; step >>= 1) if (T[a + step - 1] <= h) a += step; /* a = number of thresholds <= h */
+    if (a < 64 && T[a] <= h) a++;
+    return a > lo ? a : lo;
+}
+
+/* counters[0] = overflow flag, counters[1] = new k-mers */
+__global__ void k_insert_kmers(Index ix, const uint64_t* __restrict__ kmers, const uint32_t* __restrict__ ab, size_t n, unsigned long long* counters)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned long long created = 0, sat = 0;
+    int fail = 0;
+    for (; i < n; i += stride) {
+        int r = index_insert(ix, kmers[i], ab[i]);
+        fail |= r & 1;
+        created += (r >> 1) & 1;
+        sat += ab[i] > 255u;
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (created) atomicAdd(&counters[1], created);
+    if (sat) atomicAdd(&counters[3], sat); /* abundances stored as 255 */
+}
+
+/* one workgroup per sequence; lanes stride over k-mer start positions */
+__global__ void k_insert_packed(Index ix, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len,
+                                size_t nseq, uint32_t abund_lo, uint32_t abund_span, unsigned long long* counters)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k);
+    unsigned long long created = 0;
+    int fail = 0;
+    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const uint64_t* w = words + word_off[s];
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        for (uint32_t p = threadIdx.x; p + k <= L; p += blockDim.x) {
+            /* nts p .. p+k-1, nt i at bits 2*(i%32) of word i/32 */
+            uint64_t f = 0;
+            for (int j = 0; j < k; j++) {
+                const uint32_t i = p + j;
+                f = (f << 2) | ((w[i >> 5] >> (2 * (i & 31))) & 3ull);
+            }
+            f &= mk;
+            const uint64_t r = revcomp(f, k);
+            const uint64_t c = f < r ? f : r;
+            const uint32_t a = d_synth_abundance(c, abund_lo, abund_span);
+            int rr = index_insert(ix, c, a);
+            fail |= rr & 1;
+            created += (rr >> 1) & 1;
+        }
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (created) atomicAdd(&counters[1], created);
+}
+
+/* k-mer counting: one text position per lane (adjacent lanes read adjacent bytes); flags[0] = table too full */
+__global__ void k_count(CountTable t, const char* __restrict__ text, uint64_t n, int k, uint32_t npass, uint32_t pass, unsigned long long* flags)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool full = false;
+    for (; i + k <= n; i += stride) {
+        const uint64_t c = kmer_from_ascii(text, i, k);
+        if (c == ~0ULL) continue;
+        if (npass > 1 && (uint32_t)((mix64(c ^ 0x5851F42D4C957F2DULL) >> 40) % npass) != pass) continue; /* this k-mer belongs to another pass */
+        if (!count_insert(t, c)) full = true;
+    }
+    if (full) atomicOr(&flags[0], 1ull);
+}
+/* abundance histogram of the distinct k-mers (per-workgroup LDS histogram for the low, hot bins) and number of candidates */
+__global__ void k_count_stats(CountTable t, uint32_t keep_min, unsigned long long* histo, uint32_t nbins, unsigned long long* n_keep)
+{
+    __shared__ unsigned int lh[256];
+    for (uint32_t j = threadIdx.x; j < 256; j += blockDim.x) lh[j] = 0;
+    __syncthreads();
+    unsigned long long keep = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (t.keys[i] == ~0ULL) continue;
+        const uint32_t c = t.counts[i];
+        const uint32_t b = c < nbins ? c : nbins - 1;
+        if (b < 256) atomicAdd(&lh[b], 1u); else atomicAdd(&histo[b], 1ull);
+        keep += c >= keep_min;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < 256 && j < nbins; j += blockDim.x) if (lh[j]) atomicAdd(&histo[j], (unsigned long long)lh[j]);
+    if (keep) atomicAdd(n_keep, keep);
+}
+/* the solid k-mers of a count table (count in [lo, hi]) straight into the index tables; counters as k_insert_kmers */
+__global__ void k_insert_from_counts(Index ix, CountTable t, uint32_t lo, uint32_t hi, unsigned long long* counters)
+{
+    unsigned long long created = 0, sat = 0;
+    int fail = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = t.keys[i];
+        if (key == ~0ULL) continue;
+        const uint32_t c = t.counts[i];
+        if (c < lo || c > hi) continue;
+        const int r = index_insert(ix, key, c);
+        fail |= r & 1;
+        created += (r >> 1) & 1;
+        sat += c > 255u;
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (created) atomicAdd(&counters[1], created);
+    if (sat) atomicAdd(&counters[3], sat);
+}
+/* lookaheads for every solid k-mer, read back from the ABND table (an index that was not built from a k-mer list) */
+__global__ void k_lookahead_table(Index ix)
+{
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        if (!abnd_slot_kmer(ix.abnd, s, c)) continue;
+        Kmer x = make_kmer(c, ix.k);
+        build_lookahead(ix, x);
+        Kmer y;
+        y.f = x.r; y.r = x.f;
+        build_lookahead(ix, y);
+    }
+}
+
+/* second build pass: lookaheads of the ADJ entries (after every k-mer has been inserted) */
+__global__ void k_lookahead_kmers(Index ix, const uint64_t* __restrict__ kmers, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Kmer x = make_kmer(kmers[i], ix.k);
+        build_lookahead(ix, x);
+        Kmer y;
+        y.f = x.r; y.r = x.f;
+        build_lookahead(ix, y);
+    }
+}
+__global__ void k_lookahead_packed(Index ix, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len, size_t nseq)
+{
+    const int k = ix.k;
+    const uint64_t mk = kmask(k);
+    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const uint64_t* w = words + word_off[s];
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        for (uint32_t p = threadIdx.x; p + k <= L; p += blockDim.x) {
+            Kmer x;
+            x.r = le_kmer(w, p, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
+            x.f = revcomp(x.r, k);
+            build_lookahead(ix, x);
+            Kmer y;
+            y.f = x.r; y.r = x.f;
+            build_lookahead(ix, y);
+        }
+    }
+}
+
+/* ---- unitig store construction (mtg_dev.h: us_*), over the solid k-mers read back from the ABND table ---- */
+/* counters[0] += chain starts; counters[1] += branching nodes (in-degree != 1 or out-degree != 1); counters[2] += solid k-mers.
+ * starts != nullptr: the oriented start k-mers are also collected there (counters[3] = cursor). */
+__global__ void k_us_starts(Index ix, unsigned long long* counters, uint64_t* starts, unsigned long long cap)
+{
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
+    const uint64_t mk1 = kmask(ix.k - 1);
+    uint32_t lines = 0;
+    unsigned long long ns = 0, nbr = 0, nk = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        if (!abnd_slot_kmer(ix.abnd, s, c)) continue;
+        nk++;
+        Kmer o[2];
+        o[0] = make_kmer(c, ix.k);
+        o[1].f = o[0].r; o[1].r = o[0].f;
+        if (!starts) nbr += !(popc4(adj_right_t(ix.adj, o[0], mk1, lines).out) == 1 && popc4(adj_left(ix, o[0], mk1, lines).in) == 1);
+        for (int u = 0; u < (o[0].f == o[0].r ? 1 : 2); u++) {
+            if (!us_is_start(ix, o[u], lines)) continue;
+            ns++;
+            if (starts) { const unsigned long long at = atomicAdd(&counters[3], 1ull); if (at < cap) starts[at] = o[u].f; }
+        }
+    }
+    if (!starts) { if (ns) atomicAdd(&counters[0], ns); if (nbr) atomicAdd(&counters[1], nbr); if (nk) atomicAdd(&counters[2], nk); }
+}
+/* one chain start per lane: walks to the other end; the end with the smaller canonical k-mer reserves the unitig's words and record.
+ * cursors[0] = words, cursors[1] = records */
+__global__ void __launch_bounds__(64) k_us_plan(Index ix, const uint64_t* __restrict__ starts, unsigned long long n, unsigned long long* cursors, UsRec* rec, unsigned long long rec_cap)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    us_plan_start(ix, make_kmer(starts[i], ix.k), &cursors[0], &cursors[1], rec, rec_cap, lines);
+}
+/* one stored unitig per lane: its sequence into the store */
+__global__ void __launch_bounds__(64) k_us_emit(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    us_emit(ix, rec[i], lines);
+}
+/* one stored unitig per wave, its k-mers dealt to the lanes: abundances into the store, pointers into the ADJ entries of its junctions */
+__global__ void __launch_bounds__(256) k_us_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lines = 0;
+    for (unsigned long long u = wave; u < n; u += nwaves) {
+        const UsRec r = rec[u];
+        for (uint32_t i = lane; i < r.len_k; i += 64) us_link(ix, r, i, lines);
+    }
+}
+/* ---- the sparse form (mtg_dev.h: "sparse index") ----
+ * the k-mers of no stored unitig, out of the ABND table of the index the unitigs were built from (or of a sparse one): out == nullptr counts */
+__global__ void k_leftovers(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned long long* cursor, unsigned long long cap)
+{
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
+    uint32_t lines = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        const uint32_t a = abnd_slot_kmer(ix.abnd, s, c);
+        if (!a || (ix.us.nwords && kmer_stored(ix, c, lines))) continue;
+        const unsigned long long at = atomicAdd(cursor, 1ull);
+        if (out_k && at < cap) { out_k[at] = c; out_a[at] = a; }
+    }
+}
+/* one stored unitig per wave, its k-mers dealt to the lanes: the entries of its junctions in the new tables; counters[0] = overflow flag */
+__global__ void __launch_bounds__(256) k_sparse_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n, int with_bloom, unsigned long long* counters)
+{
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    int fail = 0;
+    for (unsigned long long u = wave; u < n; u += nwaves) {
+        const UsRec r = rec[u];
+        for (uint32_t i = lane; i < r.len_k; i += 64) fail |= sparse_link(ix, r, i, with_bloom != 0);
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+}
+/* lookaheads of the entries at the two ends of every stored unitig (the only entries around a stored k-mer that are no pointers) */
+__global__ void k_sparse_ends(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (unsigned long long)gridDim.x * blockDim.x) {
+        const UsRec r = rec[u];
+        const Kmer first = make_kmer(r.start_f, ix.k);
+        Kmer fr;
+        fr.f = first.r; fr.r = first.f;
+        build_lookahead(ix, fr);
+        build_lookahead(ix, run_node(ix.us, (r.hdr + 1) * 32, false, r.len_k - 1, ix.k));
+    }
+}
+/* the records of the stored unitigs from the store itself (an index that comes from its container): hdr[u] = header word of unitig u */
+__global__ void k_recs_from_store(UStore us, const uint64_t* __restrict__ hdr, unsigned long long n, int k, UsRec* rec)
+{
+    const unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    UsRec r;
+    r.hdr = hdr[u];
+    r.len_k = (uint32_t)us.words[r.hdr] - (uint32_t)k + 1u;
+    r.pad_ = 0;
+    r.start_f = run_node(us, (r.hdr + 1) * 32, false, 0, k).f;
+    rec[u] = r;
+}
+
+/* ---- the lean build (mtg_dev.h: "the lean build"): junction table -> unitig store -> sparse tables ---- */
+/* abundance of a k-mer of the synthetic sets: a function of the k-mer, no table */
+struct AbSynth {
+    uint32_t lo, span;
+    __device__ uint32_t operator()(uint64_t c, uint32_t&) const { return d_synth_abundance(c, lo, span); }
+};
+/* sum of v over the wave, valid in lane 0 */
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;
+}
+/* the junctions of packed sequences: one workgroup per sequence, lanes stride over the (k-1)-mer positions; a junction's entry gets the
+ * bits of the k-mers on its two sides in ONE table operation (index_insert makes four per k-mer).  counters[0] = overflow flag */
+__global__ void __launch_bounds__(256) k_jt_insert_packed(Table jt, int k, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len,
+                                                          size_t nseq, unsigned long long* counters)
+{
+    const uint64_t mk1 = kmask(k - 1), cmpl1 = 0xAAAAAAAAAAAAAAAAULL & mk1;
+    int fail = 0;
+    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const uint64_t* w = words + word_off[s];
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        for (uint32_t q = threadIdx.x; q + (uint32_t)k - 1 <= L; q += blockDim.x) {
+            /* nucleotides q-1 .. q+k-1 in one little-endian window [a][J: k-1][b] (at most 32 nucleotides: one 64-bit value) */
+            const bool has_a = q >= 1, has_b = q + (uint32_t)k - 1 < L;
+            const uint32_t q0 = has_a ? q - 1 : q, sh = 2u * (q0 & 31u), need = (uint32_t)k - 1u + (has_a ? 1u : 0u) + (has_b ? 1u : 0u);
+            uint64_t win = w[q0 >> 5] >> sh; /* nt q0 + i at bits 2i */
+            if ((q0 & 31u) + need > 32u) win |= w[(q0 >> 5) + 1] << (64u - sh); /* sh > 0 here */
+            const uint32_t a = (uint32_t)win & 3u;
+            const uint64_t body = has_a ? win >> 2 : win;
+            const uint64_t jle = body & mk1;                                      /* J, little-endian image */
+            const uint32_t b = (uint32_t)(body >> (2 * (k - 1))) & 3u;
+            const uint64_t jr = jle ^ cmpl1, jf = revcomp(jr, k - 1);             /* complemented image = reverse complement */
+            fail |= jt_insert_junction(jt, jf, jr, has_a, a, has_b, b) & 1;
+        }
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+}
+/* a counted solid set handed over as a list: abundances into the (dense) ABND table that serves as their source, junctions into the
+ * junction table.  counters[0] = overflow flag, counters[3] += abundances above 255 */
+__global__ void k_jt_insert_kmers(Table jt, Table abnd, int k, const uint64_t* __restrict__ kmers, const uint32_t* __restrict__ ab, size_t n, unsigned long long* counters)
+{
+    unsigned long long sat = 0;
+    int fail = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t c = kmers[i];
+        fail |= table_or<MTG_ABND_SLOTS>(abnd, c, ab_stored(ab[i])) & 1;
+        fail |= jt_insert_kmer(jt, c, k);
+        sat += ab[i] > 255u;
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (sat) atomicAdd(&counters[3], sat);
+}
+/* the solid k-mers of a count table (count in [lo, hi]) into the junction table; with_abnd: also into an ABND table (several counting
+ * passes: the count table of a pass does not outlive it) */
+__global__ void k_jt_insert_from_counts(Table jt, Table abnd, int with_abnd, int k, CountTable t, uint32_t lo, uint32_t hi, unsigned long long* counters)
+{
+    unsigned long long sat = 0;
+    int fail = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = t.keys[i];
+        if (key == ~0ULL) continue;
+        const uint32_t c = t.counts[i];
+        if (c < lo || c > hi) continue;
+        if (with_abnd) { fail |= table_or<MTG_ABND_SLOTS>(abnd, key, ab_stored(c)) & 1; sat += c > 255u; }
+        fail |= jt_insert_kmer(jt, key, k);
+    }
+    if (fail) atomicOr(&counters[0], 1ull);
+    if (sat) atomicAdd(&counters[3], sat);
+}
+/* one streaming pass over the junction table (jt_scan_entry); collect = 0: counts starts / k-mers of no chain and the statistics,
+ * collect = 1: fills the lists (the statistics are left alone) */
+template <typename Src>
+__global__ void __launch_bounds__(256) k_jt_scan(Table jt, int k, Src src, unsigned long long* counters, int collect, uint64_t* starts, unsigned long long cap_starts,
+                                                 uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left)
+{
+    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
+    JtAcc acc{};
+    uint32_t lines = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t J;
+        const uint32_t m = jt_slot_key(jt, s, J);
+        if (!m) continue;
+        jt_scan_entry(jt, k, J, m, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+    }
+    if (collect) return;
+    for (int j = 0; j < 6; j++) {
+        const unsigned long long v = wave_sum_u64(acc.c[j]);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&counters[j], v);
+    }
+}
+template <typename Src>
+__global__ void __launch_bounds__(256) k_jt_unstored(Table jt, Index nx, Src src, unsigned long long* counters, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left)
+{
+    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
+    uint32_t lines = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t J;
+        const uint32_t m = jt_slot_key(jt, s, J);
+        if (!m) continue;
+        jt_unstored_entry(jt, nx, J, m, src, counters, left_k, left_a, cap_left, lines);
+    }
+}
+/* one chain start per lane: the walk to the other end; the end the chain is stored from reserves words and record */
+__global__ void __launch_bounds__(64) k_jt_plan(Table jt, int k, const uint64_t* __restrict__ starts, unsigned long long n, unsigned long long* counters, UsRec* rec, unsigned long long rec_cap)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    jt_plan_start(jt, k, make_kmer(starts[i], k), counters, rec, rec_cap, lines);
+}
+/* one stored unitig per lane: its sequence into the store */
+__global__ void __launch_bounds__(64) k_jt_emit(Table jt, UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lines = 0;
+    jt_emit(jt, us, k, rec[i], lines);
+}
+/* one stored unitig per wave, its k-mers dealt to the lanes: abundances from the source into the store.  counters[JT_C_SAT] += those above 255 */
+template <typename Src>
+__global__ void __launch_bounds__(256) k_us_ab(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, Src src, unsigned long long* counters)
+{
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lines = 0;
+    unsigned long long sat = 0;
+    for (unsigned long long u = wave; u < n; u += nwaves) {
+        const UsRec r = rec[u];
+        for (uint32_t i = lane; i < r.len_k; i += 64) sat += us_ab_fill(us, k, r, i, src, lines);
+    }
+    sat = wave_sum_u64(sat);
+    if (lane == 0 && sat) atomicAdd(&counters[JT_C_SAT], sat);
+}
+
+/* the solid k-mers and their abundances out of the ABND table (index writer): out_k / out_a receive them in no particular order */
+__global__ void k_abnd_export(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned long long* cursor, unsigned long long cap)
+{
+    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c;
+        const uint32_t a = abnd_slot_kmer(ix.abnd, s, c);
+        if (!a) continue;
+        const unsigned long long at = atomicAdd(cursor, 1ull);
+        if (at < cap) { out_k[at] = c; out_a[at] = a; }
+    }
+}
+
+
+namespace {
+/* device times and memory of an index construction (mtg_index_build_profile) */
+struct BuildProf {
+    std::vector<mtg_build_phase> phases;
+    size_t base_used = 0, peak = 0;
+    std::chrono::steady_clock::time_point t0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BuildProf()
+    {
+        t0 = std::chrono::steady_clock::now();
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess) base_used = t - f;
+    }
+    ~BuildProf() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    BuildProf(const BuildProf&) = delete;
+    /* call after allocations: the most memory held beyond what the device held when the construction began */
+    void sample()
+    {
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) != hipSuccess) return;
+        const size_t used = t - f;
+        if (used > base_used && used - base_used > peak) peak = used - base_used;
+    }
+    void begin() { sample(); (void)hipEventRecord(e0, 0); }
+    /* closes the phase opened by begin(): waits for the null stream */
+    hipError_t end(const char* name, uint64_t bytes, uint64_t units)
+    {
+        (void)hipEventRecord(e1, 0);
+        const hipError_t e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+        mtg_build_phase ph{};
+        snprintf(ph.name, sizeof ph.name, "%s", name);
+        ph.ms = ms; ph.bytes = bytes; ph.units = units;
+        phases.push_back(ph);
+        return e == hipSuccess ? hipGetLastError() : e;
+    }
+    void host_phase(const char* name, double ms, uint64_t bytes, uint64_t units)
+    {
+        mtg_build_phase ph{};
+        snprintf(ph.name, sizeof ph.name, "%s", name);
+        ph.ms = ms; ph.bytes = bytes; ph.units = units;
+        phases.push_back(ph);
+    }
+    double alloc0 = tl_alloc_ms;
+    void store(mtg_index* idx)
+    {
+        sample();
+        host_phase("hipMalloc+hipFree (host wall)", tl_alloc_ms - alloc0, 0, 0);
+        idx->build_phases = phases;
+        idx->build_peak_bytes = peak;
+        idx->build_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+} // namespace
+
+static void free_tables(mtg_index* idx)
+{
+    if (idx->dev.adj.slots) (void)hipFree(idx->dev.adj.slots);
+    if (idx->dev.abnd.slots) (void)hipFree(idx->dev.abnd.slots);
+    if (idx->dev.bloom.bits) (void)hipFree(idx->dev.bloom.bits);
+    if (idx->dev.us.words) (void)hipFree(idx->dev.us.words);
+    if (idx->dev.us.ab) (void)hipFree(idx->dev.us.ab);
+    idx->dev.adj.slots = idx->dev.abnd.slots = nullptr;
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.us = UStore{};
+}
+namespace {
+/* an index under construction: tables and handle go away unless the build hands it over */
+struct IndexGuard {
+    mtg_index* idx;
+    explicit IndexGuard(mtg_index* i) : idx(i) {}
+    ~IndexGuard() { if (idx) { free_tables(idx); delete idx; } }
+    mtg_index* release() { mtg_index* i = idx; idx = nullptr; return i; }
+};
+} // namespace
+
+static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
+{
+    const int k = idx->dev.k;
+    /* ADJ entries are 16 bytes and looked up on a dependent chain: keep buckets sparse; ABND is only read by independent queries */
+    const double load_adj = tune::f(tune::T_ADJ_LOAD, 0.5) * load_scale;
+    const double load = tune::f(tune::T_ABND_LOAD, 0.6) * load_scale;
+    table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
+    table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+    const size_t ba = idx->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
+    HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));   /* a failure further down leaves the pointers to free_tables (IndexGuard) */
+    HIP_TRY(hipMalloc((void**)&idx->dev.abnd.slots, bb));
+    const double bpk = tune::f(tune::T_BLOOM_BITS, 12.0);
+    size_t bc = 0;
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.bloom.nblocks = 0;
+    if (bpk > 0) {
+        bloom_shape(idx->dev.bloom, nkeys, bpk, k);
+        bc = idx->dev.bloom.nblocks * 64;
+        HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, bc));
+        HIP_TRY(hipMemsetAsync(idx->dev.bloom.bits, 0, bc, 0));
+    }
+    HIP_TRY(hipMemsetAsync(idx->dev.adj.slots, 0, ba, 0));
+    HIP_TRY(hipMemsetAsync(idx->dev.abnd.slots, 0, bb, 0));
+    idx->info.device_bytes = ba + bb + bc;
+    idx->info.bloom_blocks = idx->dev.bloom.nblocks;
+    idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
+    idx->info.adj_buckets = idx->dev.adj.nbuckets;
+    idx->info.abnd_buckets = idx->dev.abnd.nbuckets;
+    idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
+    idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
+    return MTG_OK;
+}
+
+/* Unitig store of a finished index (every k-mer inserted, every lookahead written): chain starts -> one walk per start -> sequences ->
+ * abundances and junction pointers (mtg_dev.h: us_*).  Also fills nb_solid_kmers / nb_branching from the table itself.
+ * MTG_NO_UNITIGS=1 (test hook) leaves the index with inline lookaheads only. */
+namespace {
+/* the k-mers of no stored unitig of a construction that can only name them once the unitigs' entries are in the new tables (lean build, a
+ * closed or over-long chain in the graph): called with the sparse ADJ table holding every unitig pointer; fills the lists */
+struct LateLeftovers {
+    unsigned long long n_upper = 0; /* bound on their number, for the shape of the tables */
+    std::function<int(const Index& nx, DevBuf& left_k, DevBuf& left_a, unsigned long long& n_left)> collect;
+};
+} // namespace
+static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
+                    BuildProf* prof = nullptr, const LateLeftovers* late = nullptr, DevBuf* adj_reuse = nullptr);
+static int build_unitigs(mtg_index* idx)
+{
+    DevBuf d_cnt, d_starts, d_rec;
+    HIP_TRY(d_cnt.alloc(64));
+    HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_us_starts, dim3(blocks), dim3(256), 0, 0, idx->dev, d_cnt.as<unsigned long long>(), (uint64_t*)nullptr, 0ull);
+    HIP_TRY(hipGetLastError());
+    unsigned long long cnt[8];
+    HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
+    idx->info.nb_solid_kmers = cnt[2];
+    idx->info.nb_branching = cnt[1];
+    idx->info.nb_unitigs = 0;
+    idx->info.unitig_bytes = 0;
+    const unsigned long long n_starts = cnt[0];
+    if (n_starts == 0 || tune::on(tune::T_NO_UNITIGS)) return MTG_OK;
+    HIP_TRY(d_starts.alloc(n_starts * 8));
+    hipLaunchKernelGGL(k_us_starts, dim3(blocks), dim3(256), 0, 0, idx->dev, d_cnt.as<unsigned long long>(), d_starts.as<uint64_t>(), n_starts);
+    HIP_TRY(hipGetLastError());
+    const unsigned long long rec_cap = n_starts / 2 + 1; /* two starts per stored unitig (one per strand) */
+    HIP_TRY(d_rec.alloc(rec_cap * sizeof(UsRec)));
+    HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+    hipLaunchKernelGGL(k_us_plan, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, idx->dev, d_starts.as<uint64_t>(), n_starts, d_cnt.as<unsigned long long>(), d_rec.as<UsRec>(), rec_cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
+    const unsigned long long n_words = cnt[0], n_rec = cnt[1];
+    if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
+    (void)d_starts.alloc(0);
+    if (n_rec == 0) return MTG_OK;
+    /* a few words of padding: the coverage pass may look up to 64 + k nucleotides past the end of a unitig */
+    const unsigned long long pad = 8;
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
+    HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, (n_words + pad) * 32));
+    HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + pad) * 8, 0));
+    HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + pad) * 32, 0));
+    idx->dev.us.nwords = n_words;
+    idx->dev.us.nunitigs = n_rec;
+    hipLaunchKernelGGL(k_us_emit, dim3((unsigned)((n_rec + 63) / 64)), dim3(64), 0, 0, idx->dev, d_rec.as<UsRec>(), n_rec);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_us_link, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev, d_rec.as<UsRec>(), n_rec);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    idx->info.nb_unitigs = n_rec;
+    idx->info.unitig_bytes = (n_words + pad) * 40;
+    idx->info.device_bytes += idx->info.unitig_bytes;
+    /* the dense tables have served: the index proper is the store plus the few k-mers of no unitig (MTG_DENSE_INDEX=1: A/B and test hook) */
+    if (tune::on(tune::T_DENSE_INDEX)) return MTG_OK;
+    return sparsify(idx, d_rec.as<UsRec>(), n_rec, false, nullptr, nullptr, 0);
+}
+
+/* The sparse form.  From a dense index with its store (from_container == false: the k-mers of no unitig are read off its ABND table, the
+ * dense tables are freed at the end) or from the store alone (an index out of its container: idx holds only the store; the k-mers of no
+ * unitig are handed over, the Bloom filter is filled here).  New tables: ADJ with the entries the sparse form keeps, ABND with the k-mers
+ * of no unitig. */
+static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
+                    BuildProf* prof, const LateLeftovers* late, DevBuf* adj_reuse)
+{
+    const int k = idx->dev.k;
+    DevBuf d_cnt, own_k, own_a;
+    HIP_TRY(d_cnt.alloc(64));
+    if (!from_container) {
+        if (prof) prof->begin();
+        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+        const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, (uint64_t*)nullptr, (uint32_t*)nullptr, d_cnt.as<unsigned long long>(), 0ull);
+        HIP_TRY(hipMemcpy(&n_left, d_cnt.p, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(own_k.alloc((n_left + 1) * 8));
+        HIP_TRY(own_a.alloc((n_left + 1) * 4));
+        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, own_k.as<uint64_t>(), own_a.as<uint32_t>(), d_cnt.as<unsigned long long>(), (unsigned long long)n_left);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        d_left_k = own_k.as<uint64_t>();
+        d_left_a = own_a.as<uint32_t>();
+        if (prof) HIP_TRY(prof->end("leftovers_dense", 2 * nslots * 8, nslots));
+    }
+    const unsigned long long n_left_shape = late ? std::max(late->n_upper, n_left) : n_left;
+    /* entries of the new ADJ: per unitig its kept interior junctions (every second one and the last) and its two ends; two per k-mer of no unitig */
+    uint64_t nkeys = 2 * n_left_shape + 1024, n_unitig_kmers = 0;
+    {
+        std::vector<UsRec> h_rec(n_rec);
+        if (n_rec) HIP_TRY(hipMemcpy(h_rec.data(), d_rec, n_rec * sizeof(UsRec), hipMemcpyDeviceToHost));
+        for (const UsRec& r : h_rec) { nkeys += r.len_k / 2 + 3; n_unitig_kmers += r.len_k; }
+    }
+    Index old = idx->dev;
+    double load = 1.0;
+    int rc = MTG_OK;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        Index nx = old;
+        nx.adj.sp_words = nullptr; /* raw look-ups while the tables are being built */
+        const double load_adj = tune::f(tune::T_SPARSE_ADJ_LOAD, 0.49) * load; /* 0.7 overflows the displacement range at human scale (2-slot buckets) and cost a second attempt; 0.49 is what that attempt ran at */
+        table_shape(nx.adj, buckets_for(nkeys, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
+        table_shape(nx.abnd, buckets_for(n_left_shape + 1024, 0.6 * load, 2 * k, MTG_ABND_SLOTS), 2 * k);
+        const size_t ba = nx.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = nx.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
+        DevBuf na, nb;
+        /* the junction table has served and is large enough: its memory becomes the ADJ table (a second allocation of this size after freeing the
+         * first cost 2 s of hipMalloc on the GPU box: the freed memory is scrubbed before it is handed out again) */
+        if (adj_reuse && adj_reuse->p && adj_reuse->cap >= ba) na.adopt(*adj_reuse);
+        else { if (adj_reuse && adj_reuse->p) (void)adj_reuse->alloc(0); HIP_TRY(na.alloc(ba)); }
+        const size_t ba_held = na.cap; /* a table that took over the junction table's memory holds all of it */
+        HIP_TRY(nb.alloc(bb));
+        if (prof) prof->begin();
+        HIP_TRY(hipMemsetAsync(na.p, 0, ba, 0));
+        HIP_TRY(hipMemsetAsync(nb.p, 0, bb, 0));
+        if (prof) HIP_TRY(prof->end("clear_sparse_tables", ba + bb, 0));
+        nx.adj.slots = na.as<uint64_t>();
+        nx.abnd.slots = nb.as<uint64_t>();
+        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
+        if (prof) prof->begin();
+        if (n_rec) hipLaunchKernelGGL(k_sparse_link, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, nx, d_rec, n_rec, from_container ? 1 : 0, d_cnt.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        /* per k-mer: its window of the store (8), every second one an ADJ bucket read and written (2 x 32), with the filter a block (64 + 64) */
+        if (prof) HIP_TRY(prof->end(from_container ? "sparse_link+bloom" : "sparse_link", n_unitig_kmers * (8 + 32 + (from_container && nx.bloom.bits ? 128 : 0)), n_unitig_kmers));
+        DevBuf late_k, late_a;
+        if (late) {
+            unsigned long long cnt0[8];
+            HIP_TRY(hipMemcpy(cnt0, d_cnt.p, 64, hipMemcpyDeviceToHost));
+            if (cnt0[0]) { load *= 0.7; rc = MTG_ERR_OVERFLOW; set_error("index bucket displacement overflow (sparse form)"); continue; }
+            if (prof) prof->begin();
+            Index nxs = nx;
+            nxs.adj.sp_words = nx.us.words; /* the look-ups of kmer_stored go through the pointers */
+            if (int rc2 = late->collect(nxs, late_k, late_a, n_left)) return rc2;
+            if (n_left > n_left_shape) { set_error("more k-mers outside the unitigs (%llu) than the junction table accounts for (%llu)", n_left, n_left_shape); return MTG_ERR_OVERFLOW; }
+            d_left_k = late_k.as<uint64_t>();
+            d_left_a = late_a.as<uint32_t>();
+            if (prof) HIP_TRY(prof->end("late_leftovers", 0, n_left));
+        }
+        if (prof) prof->begin();
+        if (n_left) {
+            Index nxb = nx;
+            if (!from_container) nxb.bloom.bits = nullptr; /* the filter holds every k-mer already */
+            hipLaunchKernelGGL(k_insert_kmers, dim3((unsigned)std::min<unsigned long long>((n_left + 255) / 256 + 1, 256 * 16)), dim3(256), 0, 0, nxb, d_left_k, d_left_a, (size_t)n_left, d_cnt.as<unsigned long long>());
+        }
+        HIP_TRY(hipGetLastError());
+        unsigned long long cnt[8];
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
+        if (cnt[0]) { load *= 0.7; rc = MTG_ERR_OVERFLOW; set_error("index bucket displacement overflow (sparse form)"); continue; }
+        /* lookaheads of the entries that are no pointers: around the k-mers of no unitig and at the unitigs' ends */
+        if (n_left) hipLaunchKernelGGL(k_lookahead_kmers, dim3((unsigned)std::min<unsigned long long>((n_left + 255) / 256 + 1, 256 * 16)), dim3(256), 0, 0, nx, d_left_k, (size_t)n_left);
+        if (n_rec) hipLaunchKernelGGL(k_sparse_ends, dim3((unsigned)std::min<unsigned long long>((n_rec + 255) / 256, 256 * 16)), dim3(256), 0, 0, nx, d_rec, n_rec);
+        HIP_TRY(hipGetLastError());
+        if (prof) HIP_TRY(prof->end("leftovers+ends", n_left * 5 * 32 + n_rec * 2 * 16 * 32, n_left + 2 * n_rec));
+        HIP_TRY(hipDeviceSynchronize());
+        /* the new tables take the place of the old ones */
+        if (old.adj.slots) (void)timed_free(old.adj.slots);
+        if (old.abnd.slots) (void)timed_free(old.abnd.slots);
+        nx.adj.sp_words = nx.us.words;
+        idx->dev = nx;
+        (void)na.release();
+        (void)nb.release();
+        idx->info.device_bytes = std::max(ba, ba_held) + bb + idx->dev.bloom.nblocks * 64 + idx->info.unitig_bytes;
+        idx->info.adj_buckets = nx.adj.nbuckets;
+        idx->info.abnd_buckets = nx.abnd.nbuckets;
+        idx->info.sparse = nx.us.words ? 1 : 0; /* no stored unitig: every k-mer has its full entries, the look-ups are the raw ones */
+        idx->info.nb_kmers_outside_unitigs = n_left;
+        return MTG_OK;
+    }
+    return rc;
+}
+
+/* ---- the lean build: Graph::create without dense tables (mtg_dev.h: "the lean build").  jt = the filled junction table (in jt_buf), src = where
+ * the abundances are asked; release_source() frees what src reads once the store holds every abundance.  Leaves idx with the unitig store,
+ * the sparse tables derived from it, the Bloom filter and the graph's statistics. */
+template <typename Src>
+static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const Src& src, const std::function<void()>& release_source, uint64_t sat_at_insert, BuildProf& prof)
+{
+    const int k = idx->dev.k;
+    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
+    const unsigned scan_blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+    DevBuf d_cnt, d_starts, d_rec, d_left_k, d_left_a;
+    HIP_TRY(d_cnt.alloc(JT_C_N * 8));
+    HIP_TRY(hipMemset(d_cnt.p, 0, JT_C_N * 8));
+    unsigned long long* cnt_d = d_cnt.as<unsigned long long>();
+    unsigned long long cnt[JT_C_N];
+    /* chain starts, k-mers of no chain, statistics: counted, then collected */
+    prof.begin();
+    hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, k, src, cnt_d, 0, (uint64_t*)nullptr, 0ull, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull);
+    HIP_TRY(prof.end("jt_scan_count", nslots * 8, nslots));
+    HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
+    const unsigned long long n_starts = cnt[JT_C_STARTS], n_single = cnt[JT_C_LEFT], interior = cnt[JT_C_INTERIOR];
+    idx->info.nb_solid_kmers = (cnt[JT_C_ORIENTED] + cnt[JT_C_SELF]) / 2;
+    idx->info.nb_branching = (2 * cnt[JT_C_IN_NOT1] - cnt[JT_C_BOTH_NOT1] + cnt[JT_C_SELF_BRANCH]) / 2;
+    idx->info.nb_unitigs = 0;
+    idx->info.unitig_bytes = 0;
+    HIP_TRY(d_starts.alloc((n_starts + 1) * 8));
+    HIP_TRY(d_left_k.alloc((n_single + 1) * 8));
+    HIP_TRY(d_left_a.alloc((n_single + 1) * 4));
+    HIP_TRY(hipMemset(cnt_d + JT_C_STARTS, 0, 8));
+    HIP_TRY(hipMemset(cnt_d + JT_C_LEFT, 0, 8));
+    prof.begin();
+    hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, k, src, cnt_d, 1, d_starts.as<uint64_t>(), n_starts, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), n_single);
+    HIP_TRY(prof.end("jt_scan_collect", nslots * 8 + n_starts * 8 + n_single * 12, nslots));
+    /* abundances above 255: of the single k-mers (counted by the pass above), then of the unitigs' k-mers (k_us_ab), each on its own */
+    unsigned long long sat_single = 0, sat_unitigs = 0, sat_late = 0;
+    HIP_TRY(hipMemcpy(&sat_single, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(cnt_d + JT_C_SAT, 0, 8));
+    unsigned long long n_words = 0, n_rec = 0, stored_views = 0;
+    if (n_starts) {
+        const unsigned long long rec_cap = n_starts / 2 + 1; /* two starts per stored unitig (one per strand) */
+        HIP_TRY(d_rec.alloc(rec_cap * sizeof(UsRec)));
+        prof.begin();
+        hipLaunchKernelGGL(k_jt_plan, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, jt, k, d_starts.as<uint64_t>(), n_starts, cnt_d, d_rec.as<UsRec>(), rec_cap);
+        HIP_TRY(prof.end("jt_plan", (interior + n_starts) * 32, interior + n_starts)); /* both strands of every chain: one bucket per step */
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
+        n_words = cnt[JT_C_WORDS]; n_rec = cnt[JT_C_RECS]; stored_views = cnt[JT_C_STORED_VIEWS];
+        if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
+    }
+    (void)d_starts.alloc(0);
+    if (n_rec) {
+        const unsigned long long pad = 8; /* the coverage pass may look up to 64 + k nucleotides past the end of a unitig */
+        HIP_TRY(timed_malloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
+        HIP_TRY(timed_malloc((void**)&idx->dev.us.ab, (n_words + pad) * 32));
+        prof.begin();
+        HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + pad) * 8, 0));
+        HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + pad) * 32, 0));
+        idx->dev.us.nwords = n_words;
+        idx->dev.us.nunitigs = n_rec;
+        hipLaunchKernelGGL(k_jt_emit, dim3((unsigned)((n_rec + 63) / 64)), dim3(64), 0, 0, jt, idx->dev.us, k, d_rec.as<UsRec>(), n_rec);
+        HIP_TRY(prof.end("jt_emit", (stored_views / 2) * 32 + n_words * 48, stored_views / 2 + n_rec));
+        prof.begin();
+        hipLaunchKernelGGL(k_us_ab<Src>, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, src, cnt_d);
+        HIP_TRY(prof.end("us_abundances", (stored_views / 2 + n_rec) * 9, stored_views / 2 + n_rec));
+        HIP_TRY(hipMemcpy(&sat_unitigs, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
+        idx->info.nb_unitigs = n_rec;
+        idx->info.unitig_bytes = (n_words + pad) * 40;
+    }
+    /* the Bloom filter of the sequence scan: filled from the store and the k-mers of no unitig while the sparse tables are written */
+    const double bpk = tune::f(tune::T_BLOOM_BITS, 12.0);
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.bloom.nblocks = 0;
+    if (bpk > 0) bloom_shape(idx->dev.bloom, idx->info.nb_solid_kmers, bpk, k);
+    idx->info.bloom_blocks = idx->dev.bloom.nblocks;
+    idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
+    idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
+    idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
+    const auto alloc_bloom = [&]() -> int {
+        if (!idx->dev.bloom.nblocks) return MTG_OK;
+        HIP_TRY(timed_malloc((void**)&idx->dev.bloom.bits, idx->dev.bloom.nblocks * 64));
+        HIP_TRY(hipMemsetAsync(idx->dev.bloom.bits, 0, idx->dev.bloom.nblocks * 64, 0));
+        return MTG_OK;
+    };
+    int rc;
+    if (interior == stored_views) {
+        /* every chain is a stored unitig: the k-mers of no unitig are the single ones the scan found; table and source have served */
+        prof.sample();
+        release_source();
+        if (int rc2 = alloc_bloom()) return rc2;
+        rc = sparsify(idx, d_rec.as<UsRec>(), n_rec, true, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), n_single, &prof, nullptr, &jt_buf); /* the table's memory is used again */
+        (void)jt_buf.alloc(0);
+    } else {
+        /* a closed chain, or one too long for the offsets of a pointer: its k-mers belong to no unitig, and only the finished pointers tell which */
+        if (int rc2 = alloc_bloom()) return rc2;
+        (void)d_left_k.alloc(0);
+        (void)d_left_a.alloc(0);
+        sat_single = 0; /* the late pass finds the single k-mers again */
+        LateLeftovers late;
+        late.n_upper = n_single + (interior - stored_views) / 2 + n_starts + 16;
+        late.collect = [&](const Index& nx, DevBuf& lk, DevBuf& la, unsigned long long& n_left) -> int {
+            HIP_TRY(hipMemset(cnt_d + JT_C_LEFT, 0, 8));
+            hipLaunchKernelGGL(k_jt_unstored<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, nx, src, cnt_d, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull);
+            HIP_TRY(hipGetLastError());
+            unsigned long long n = 0;
+            HIP_TRY(hipMemcpy(&n, cnt_d + JT_C_LEFT, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(lk.alloc((n + 1) * 8));
+            HIP_TRY(la.alloc((n + 1) * 4));
+            HIP_TRY(hipMemset(cnt_d + JT_C_LEFT, 0, 8));
+            HIP_TRY(hipMemset(cnt_d + JT_C_SAT, 0, 8)); /* an attempt with more buckets counts again */
+            hipLaunchKernelGGL(k_jt_unstored<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, nx, src, cnt_d, lk.as<uint64_t>(), la.as<uint32_t>(), n);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            n_left = n;
+            return MTG_OK;
+        };
+        rc = sparsify(idx, d_rec.as<UsRec>(), n_rec, true, nullptr, nullptr, 0, &prof, &late);
+        HIP_TRY(hipMemcpy(&sat_late, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
+        prof.sample();
+        (void)jt_buf.alloc(0);
+        release_source();
+    }
+    if (rc) return rc;
+    idx->info.nb_saturated = sat_at_insert + sat_single + sat_unitigs + sat_late;
+    return MTG_OK;
+}
+
+/* MTG_DENSE_INDEX=1 / MTG_NO_UNITIGS=1 (test hooks: the dense form of the index, the index without a unitig store) and MTG_LEGACY_BUILD=1
+ * (A/B) take the construction of rounds 1-3: dense ADJ + ABND tables, lookaheads, the store from them, then the sparse form */
+static bool legacy_build() { return tune::on(tune::T_DENSE_INDEX) || tune::on(tune::T_NO_UNITIGS) || tune::on(tune::T_LEGACY_BUILD); }
+static double jt_load() { return tune::f(tune::T_JT_LOAD, 0.7); }
+/* a cleared table of MTG_ABND_SLOTS-slot buckets for nkeys keys of key_bits bits */
+/* bytes the sparse ADJ table of a graph of n k-mers will take, give or take: half the junctions and a little (sparsify) */
+static size_t adj_bytes_estimate(uint64_t n, int k)
+{
+    return (size_t)buckets_for(n / 2 + n / 128 + 8192, 0.49, 2 * (k - 1), MTG_ADJ_SLOTS) * 16 * MTG_ADJ_SLOTS;
+}
+/* min_bytes: the buffer is made at least this large (the junction table's memory is handed on to the sparse ADJ table) */
+static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase, size_t min_bytes = 0)
+{
+    table_shape(t, buckets_for(nkeys, load, key_bits, MTG_ABND_SLOTS), key_bits);
+    t.sp_words = nullptr;
+    const size_t bytes = t.nbuckets * 8 * MTG_ABND_SLOTS;
+    if (!(buf.p && buf.cap >= std::max(bytes, min_bytes))) HIP_TRY(buf.alloc(std::max(bytes, min_bytes)));
+    t.slots = buf.as<uint64_t>();
+    prof.begin();
+    HIP_TRY(hipMemsetAsync(buf.p, 0, bytes, 0));
+    HIP_TRY(prof.end(phase, bytes, 0));
+    return MTG_OK;
+}
+
+static int index_from_kmer_pieces_lean(size_t n, int k, const KmerFetch& fetch, mtg_index** out)
+{
+    BuildProf prof;
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    DevBuf d_k, d_a, d_cnt, jt_buf, abnd_buf;
+    HIP_TRY(d_cnt.alloc(4 * 8));
+    const size_t env_piece = (size_t)tune::i(tune::T_LOAD_PIECE, 0); /* test hook: small pieces */
+    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
+    HIP_TRY(d_k.alloc(piece * 8));
+    HIP_TRY(d_a.alloc(piece * 4));
+    Table jt{}, abnd{};
+    double load = 1.0;
+    int rc = MTG_OK;
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n + n / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n, k))) return rc2;
+        if (int rc2 = alloc_slot_table(abnd, abnd_buf, n, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        double ms = 0;
+        for (size_t off = 0; off < n; off += piece) {
+            const size_t m = std::min(piece, n - off);
+            const uint64_t* hk = nullptr;
+            const uint32_t* ha = nullptr;
+            if (!fetch(off, m, hk, ha)) return MTG_ERR_IO; /* the source has set the message */
+            HIP_TRY(hipMemcpy(d_k.p, hk, m * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_a.p, ha, m * 4, hipMemcpyHostToDevice));
+            prof.begin();
+            hipLaunchKernelGGL(k_jt_insert_kmers, dim3((unsigned)std::min<size_t>((m + 255) / 256 + 1, 256 * 16)), dim3(256), 0, 0, jt, abnd, k, d_k.as<uint64_t>(), d_a.as<uint32_t>(), m, d_cnt.as<unsigned long long>());
+            HIP_TRY(prof.end("jt_insert_kmers", 0, m)); /* also: the source may reuse its buffers for the next piece */
+            ms += prof.phases.back().ms;
+            prof.phases.pop_back();
+        }
+        prof.host_phase("jt_insert_kmers", ms, (uint64_t)n * (12 + 3 * 64), n); /* a k-mer: its list entry, an ABND bucket and two junction buckets read and written */
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+        if (!cnt[0]) { rc = MTG_OK; break; }
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    if (rc) return rc;
+    (void)d_k.alloc(0);
+    (void)d_a.alloc(0);
+    AbFromTable src;
+    src.abnd = abnd;
+    if (int rc2 = build_from_jt(idx, jt_buf, jt, src, [&] { (void)abnd_buf.alloc(0); }, cnt[3], prof)) return rc2;
+    idx->info.k = k;
+    idx->info.abundance_min = 0;
+    idx->info.abundance_auto = -1;
+    prof.store(idx);
+    *out = g.release();
+    return MTG_OK;
+}
+
+static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t total_kmers_ub, int k,
+                                         uint32_t abund_lo, uint32_t abund_span, mtg_index** out)
+{
+    BuildProf prof;
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    DevBuf d_cnt, jt_buf;
+    HIP_TRY(d_cnt.alloc(32));
+    Table jt{};
+    double load = 1.0;
+    int rc = MTG_OK;
+    const uint64_t n_junctions_ub = total_kmers_ub + nseq + 1024; /* a sequence of L >= k nucleotides has L - k + 2 junction positions */
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k))) return rc2;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        if (nseq == 0) break; /* an empty graph: nothing to launch */
+        prof.begin();
+        hipLaunchKernelGGL(k_jt_insert_packed, dim3((unsigned)std::min<size_t>(nseq, 256 * 32)), dim3(256), 0, 0, jt, k, d_words, d_word_off, d_len, nseq, d_cnt.as<unsigned long long>());
+        HIP_TRY(prof.end("jt_insert_packed", n_junctions_ub * (64 + 1), n_junctions_ub)); /* a junction position: its bucket read and written (2 x 32), its nucleotides */
+        unsigned long long cnt[4];
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+        if (!cnt[0]) { rc = MTG_OK; break; }
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    if (rc) return rc;
+    AbSynth src;
+    src.lo = abund_lo; src.span = abund_span;
+    if (int rc2 = build_from_jt(idx, jt_buf, jt, src, [] {}, 0, prof)) return rc2;
+    idx->info.k = k;
+    idx->info.abundance_min = (int)abund_lo;
+    idx->info.abundance_auto = -1;
+    prof.store(idx);
+    *out = g.release();
+    return MTG_OK;
+}
+
+/* The index of a counted solid set that arrives in pieces (host arrays, or the records of a saved index read from its file: 36 GB at human
+ * size, never whole in host memory): fetch(off, m, k, a) hands over k-mers [off, off + m) and their abundances; every attempt to build the
+ * tables is one pass over the pieces, the lookaheads are then derived from the tables themselves. */
+int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** out)
+{
+    if (int rc = ensure_device()) return rc;
+    if (k < 11 || k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (!legacy_build()) return index_from_kmer_pieces_lean(n, k, fetch, out);
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    DevBuf d_k, d_a, d_cnt;
+    HIP_TRY(d_cnt.alloc(4 * 8));
+    const size_t env_piece = (size_t)tune::i(tune::T_LOAD_PIECE, 0); /* test hook: small pieces */
+    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
+    HIP_TRY(d_k.alloc(piece * 8));
+    HIP_TRY(d_a.alloc(piece * 4));
+    double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
+    int rc = MTG_OK;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        free_tables(idx);
+        rc = alloc_tables(idx, n, load);
+        if (rc) return rc;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        for (size_t off = 0; off < n; off += piece) {
+            const size_t m = std::min(piece, n - off);
+            const uint64_t* hk = nullptr;
+            const uint32_t* ha = nullptr;
+            if (!fetch(off, m, hk, ha)) return MTG_ERR_IO; /* the source has set the message */
+            HIP_TRY(hipMemcpy(d_k.p, hk, m * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_a.p, ha, m * 4, hipMemcpyHostToDevice));
+            const int blocks = (int)std::min<size_t>((m + 255) / 256 + 1, 256 * 16);
+            hipLaunchKernelGGL(k_insert_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(), m, d_cnt.as<unsigned long long>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize()); /* the source may reuse its buffers for the next piece */
+        }
+        unsigned long long cnt[4];
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+        idx->info.nb_saturated = cnt[3];
+        if (!cnt[0]) {
+            if (n) {
+                const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+                hipLaunchKernelGGL(k_lookahead_table, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipDeviceSynchronize());
+            rc = MTG_OK;
+            break;
+        }
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    if (rc) return rc;
+    if (int rc2 = build_unitigs(idx)) return rc2;
+    idx->info.k = k;
+    idx->info.abundance_min = 0;
+    idx->info.abundance_auto = -1;
+    *out = g.release();
+    return MTG_OK;
+}
+
+int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
+{
+    if (n && (!canon_kmers || !abundance)) { set_error("invalid argument (null arrays)"); return MTG_ERR_ARG; }
+    return index_from_kmer_pieces(n, k, [&](size_t off, size_t, const uint64_t*& hk, const uint32_t*& ha) { hk = canon_kmers + off; ha = abundance + off; return true; }, out);
+}
+
+int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t total_kmers_ub, int k,
+                             uint32_t abund_lo, uint32_t abund_span, mtg_index** out)
+{
+    if (int rc = ensure_device()) return rc;
+    if (k < 11 || k > 31 || !out || (nseq && (!d_words || !d_word_off || !d_len))) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (!legacy_build()) return index_from_packed_device_lean(d_words, d_word_off, d_len, nseq, total_kmers_ub, k, abund_lo, abund_span, out);
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    DevBuf d_cnt;
+    HIP_TRY(d_cnt.alloc(32));
+    double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
+    int rc = MTG_OK;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        free_tables(idx);
+        rc = alloc_tables(idx, total_kmers_ub, load);
+        if (rc) return rc;
+        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+        if (nseq == 0) break; /* an empty graph: nothing to launch (a grid of zero blocks is an error that would surface later) */
+        const int blocks = (int)std::min<size_t>(nseq, 256 * 32);
+        hipLaunchKernelGGL(k_insert_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq, abund_lo, abund_span, d_cnt.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        unsigned long long cnt[4];
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+        if (!cnt[0]) {
+            hipLaunchKernelGGL(k_lookahead_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            rc = MTG_OK;
+            break;
+        }
+        load *= 0.7;
+        rc = MTG_ERR_OVERFLOW;
+        set_error("index bucket displacement overflow");
+    }
+    if (rc) return rc;
+    if (int rc2 = build_unitigs(idx)) return rc2;
+    idx->info.k = k;
+    idx->info.abundance_min = (int)abund_lo;
+    idx->info.abundance_auto = -1;
+    *out = g.release();
+    return MTG_OK;
+}
+
+/* the whole index on another device: same shapes, tables and unitig store copied device to device */
+int index_replicate(const mtg_index* src, int device, mtg_index** out)
+{
+    if (!src || !out) { set_error("null argument"); return MTG_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { set_error("no such device: %d", device); return MTG_ERR_ARG; }
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    HIP_TRY(hipSetDevice(device));
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev = src->dev;
+    idx->info = src->info;
+    idx->device = device;
+    idx->dev.adj.slots = idx->dev.abnd.slots = nullptr; /* free_tables must only see what this copy owns */
+    idx->dev.bloom.bits = nullptr;
+    idx->dev.us.words = nullptr;
+    idx->dev.us.ab = nullptr;
+    auto clone = [&](void** dst, const void* from, size_t bytes) -> int {
+        if (!from || !bytes) return MTG_OK;
+        HIP_TRY(hipMalloc(dst, bytes));
+        HIP_TRY(hipMemcpyPeer(*dst, device, from, src->device, bytes));
+        return MTG_OK;
+    };
+    const size_t ba = src->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = src->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS, bc = src->dev.bloom.nblocks * 64;
+    if (int rc = clone((void**)&idx->dev.adj.slots, src->dev.adj.slots, ba)) return rc;
+    if (int rc = clone((void**)&idx->dev.abnd.slots, src->dev.abnd.slots, bb)) return rc;
+    if (int rc = clone((void**)&idx->dev.bloom.bits, src->dev.bloom.bits, bc)) return rc;
+    if (src->dev.us.nwords) {
+        const size_t nw = src->dev.us.nwords + 8;
+        if (int rc = clone((void**)&idx->dev.us.words, src->dev.us.words, nw * 8)) return rc;
+        if (int rc = clone((void**)&idx->dev.us.ab, src->dev.us.ab, nw * 32)) return rc;
+    }
+    if (src->dev.adj.sp_words) idx->dev.adj.sp_words = idx->dev.us.words; /* the sparse form reads this copy's store */
+    HIP_TRY(hipDeviceSynchronize());
+    *out = g.release();
+    return MTG_OK;
+}
+
+/* the solid k-mers of an index and their abundances, read back from its tables (for the index writer), in pieces of at most `piece`
+ * k-mers handed to sink(kmers, abundances, count) */
+int index_export(const mtg_index* idx, const std::function<bool(const uint64_t*, const uint32_t*, size_t)>& sink)
+{
+    if (int rc = use_device_of(idx)) return rc;
+    const uint64_t n = idx->info.nb_solid_kmers;
+    DevBuf d_k, d_a, d_cur;
+    HIP_TRY(d_k.alloc((n + 1) * 8));
+    HIP_TRY(d_a.alloc((n + 1) * 4));
+    HIP_TRY(d_cur.alloc(8));
+    HIP_TRY(hipMemset(d_cur.p, 0, 8));
+    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+    hipLaunchKernelGGL(k_abnd_export, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(),
+                       d_cur.as<unsigned long long>(), (unsigned long long)n);
+    HIP_TRY(hipGetLastError());
+    unsigned long long got = 0;
+    HIP_TRY(hipMemcpy(&got, d_cur.p, 8, hipMemcpyDeviceToHost));
+    if (got != n) { set_error("index export: %llu k-mers in the table, %llu expected", got, (unsigned long long)n); return MTG_ERR_FORMAT; }
+    const size_t piece = (size_t)1 << 24;
+    std::vector<uint64_t> hk(std::min<uint64_t>(n, piece));
+    std::vector<uint32_t> ha(hk.size());
+    for (uint64_t off = 0; off < n; off += piece) {
+        const size_t m = (size_t)std::min<uint64_t>(piece, n - off);
+        HIP_TRY(hipMemcpy(hk.data(), d_k.as<uint64_t>() + off, m * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ha.data(), d_a.as<uint32_t>() + off, m * 4, hipMemcpyDeviceToHost));
+        if (!sink(hk.data(), ha.data(), m)) { set_error("index export: the writer failed"); return MTG_ERR_IO; }
+    }
+    return MTG_OK;
+}
+
+int index_dump(const mtg_index* idx, IndexDump& d)
+{
+    if (int rc = use_device_of(idx)) return rc;
+    d.k = idx->dev.k; d.abundance_min = idx->info.abundance_min; d.abundance_auto = idx->info.abundance_auto;
+    d.nb_solid = idx->info.nb_solid_kmers; d.nb_branching = idx->info.nb_branching; d.nb_saturated = idx->info.nb_saturated;
+    d.n_words = idx->dev.us.nwords; d.n_unitigs = idx->dev.us.nunitigs;
+    d.words.clear(); d.ab.clear();
+    if (d.n_words) {
+        const uint64_t nw = d.n_words + 8;
+        d.words.resize(nw);
+        d.ab.resize(nw * 32);
+        HIP_TRY(hipMemcpy(d.words.data(), idx->dev.us.words, nw * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d.ab.data(), idx->dev.us.ab, nw * 32, hipMemcpyDeviceToHost));
+    }
+    DevBuf d_cnt, d_k, d_a;
+    HIP_TRY(d_cnt.alloc(8));
+    HIP_TRY(hipMemset(d_cnt.p, 0, 8));
+    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, (uint64_t*)nullptr, (uint32_t*)nullptr, d_cnt.as<unsigned long long>(), 0ull);
+    unsigned long long n_left = 0;
+    HIP_TRY(hipMemcpy(&n_left, d_cnt.p, 8, hipMemcpyDeviceToHost));
+    d.left_k.resize(n_left);
+    d.left_a.resize(n_left);
+    if (n_left) {
+        HIP_TRY(d_k.alloc(n_left * 8));
+        HIP_TRY(d_a.alloc(n_left * 4));
+        HIP_TRY(hipMemset(d_cnt.p, 0, 8));
+        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d_cnt.as<unsigned long long>(), n_left);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(d.left_k.data(), d_k.p, n_left * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d.left_a.data(), d_a.p, n_left * 4, hipMemcpyDeviceToHost));
+    }
+    return MTG_OK;
+}
+
+/* an index out of its container: the store goes up as it is, the tables are derived from it (sparsify); nothing is counted or walked */
+int index_from_dump(const IndexDump& d, mtg_index** out)
+{
+    if (int rc = ensure_device()) return rc;
+    if (d.k < 11 || d.k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    if (tune::on(tune::T_DENSE_INDEX) || d.n_words == 0) {
+        /* test hook / an index without stored unitigs: through the list of its k-mers */
+        std::vector<uint64_t> km(d.left_k);
+        std::vector<uint32_t> ab(d.left_a);
+        const uint64_t mk = kmask(d.k);
+        std::vector<uint8_t> ab_all; /* a container that is being read: its abundance bytes, whole */
+        if (d.ab_read && d.n_words) {
+            ab_all.resize((d.n_words + 8) * 32);
+            if (!d.ab_read(0, ab_all.size(), ab_all.data())) { set_error("index container: short read"); return MTG_ERR_FORMAT; }
+        }
+        const uint8_t* dab = d.ab_read ? ab_all.data() : d.ab.data();
+        for (uint64_t h = 0; h < d.n_words;) {
+            const uint64_t len = d.words[h];
+            for (uint64_t i = 0; i + d.k <= len; i++) {
+                const uint64_t p = (h + 1) * 32 + i, lo = d.words[p >> 5] >> (2 * (p & 31)), hi = (p & 31) ? d.words[(p >> 5) + 1] << (64 - 2 * (p & 31)) : 0;
+                const uint64_t r = ((lo | hi) & mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk), f = revcomp(r, d.k);
+                km.push_back(f < r ? f : r);
+                ab.push_back(dab[p]);
+            }
+            h += 1 + (len + 31) / 32;
+        }
+        int rc = index_from_kmers(km.data(), ab.data(), km.size(), d.k, out);
+        if (!rc) { (*out)->info.abundance_min = d.abundance_min; (*out)->info.abundance_auto = d.abundance_auto; }
+        return rc;
+    }
+    BuildProf prof;
+    IndexGuard g(new mtg_index());
+    mtg_index* idx = g.idx;
+    idx->dev.k = d.k;
+    HIP_TRY(hipGetDevice(&idx->device));
+    const uint64_t nw = d.n_words + 8;
+    const bool streamed = (bool)d.ab_read;
+    if (d.words.size() < nw || (!streamed && d.ab.size() < nw * 32) || d.left_k.size() != d.left_a.size()) { set_error("index container: inconsistent sizes"); return MTG_ERR_FORMAT; }
+    HIP_TRY(timed_malloc((void**)&idx->dev.us.words, nw * 8));
+    HIP_TRY(timed_malloc((void**)&idx->dev.us.ab, nw * 32));
+    const auto t_up0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipMemcpy(idx->dev.us.words, d.words.data(), nw * 8, hipMemcpyHostToDevice));
+    /* the abundance bytes: either in host memory already, or (a container that is being read) straight from the file in page-locked pieces,
+     * by a few threads with a stream each -- and while the tables are derived below: those kernels read the store's words only */
+    std::vector<std::thread> uploaders;
+    std::atomic<uint64_t> next_piece{0};
+    std::atomic<int> up_err{0};
+    struct JoinAll { std::vector<std::thread>& ts; ~JoinAll() { for (auto& t : ts) if (t.joinable()) t.join(); } } join_all{uploaders};
+    if (!streamed) HIP_TRY(hipMemcpy(idx->dev.us.ab, d.ab.data(), nw * 32, hipMemcpyHostToDevice));
+    else {
+        const uint64_t total = nw * 32, piece = (uint64_t)32 << 20, npieces = (total + piece - 1) / piece;
+        const int env_threads = (int)tune::i(tune::T_LOAD_THREADS, 0);
+        const int nthreads = (int)std::min<uint64_t>(npieces, (uint64_t)(env_threads > 0 ? std::min(env_threads, 32) : std::min(8, std::max(2, Pool::cpu_budget() / 2))));
+        uint8_t* dst = idx->dev.us.ab;
+        const int device = idx->device;
+        for (int t = 0; t < nthreads; t++)
+            uploaders.emplace_back([&, dst, device, total, piece, npieces] {
+                void* pin = nullptr;
+                hipStream_t st = nullptr;
+                if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin, piece, hipHostMallocDefault) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) up_err.store(1);
+                else
+                    for (;;) {
+                        const uint64_t c = next_piece.fetch_add(1);
+                        if (c >= npieces || up_err.load()) break;
+                        const uint64_t off = c * piece, n = std::min(piece, total - off);
+                        if (!d.ab_read(off, (size_t)n, pin)) { up_err.store(2); break; }
+                        if (hipMemcpyAsync(dst + off, pin, n, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { up_err.store(1); break; }
+                    }
+                if (st) (void)hipStreamDestroy(st);
+                if (pin) (void)hipHostFree(pin);
+            });
+    }
+    idx->dev.us.nwords = d.n_words;
+    /* the header words of the unitigs, one after the other */
+    std::vector<uint64_t> hdr;
+    hdr.reserve(d.n_unitigs);
+    for (uint64_t h = 0; h < d.n_words;) {
+        const uint64_t len = d.words[h];
+        if (len < (uint64_t)d.k + 1 || len > MTG_US_MAX_LEN) { set_error("index container: damaged unitig store"); return MTG_ERR_FORMAT; }
+        hdr.push_back(h);
+        h += 1 + (len + 31) / 32;
+    }
+    idx->dev.us.nunitigs = hdr.size();
+    DevBuf d_hdr, d_rec, d_k, d_a;
+    const auto upload = [](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.alloc(bytes);
+        if (e != hipSuccess || !bytes) return e;
+        return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(upload(d_hdr, hdr.data(), hdr.size() * 8));
+    HIP_TRY(d_rec.alloc((hdr.size() + 1) * sizeof(UsRec)));
+    hipLaunchKernelGGL(k_recs_from_store, dim3((unsigned)((hdr.size() + 255) / 256)), dim3(256), 0, 0, idx->dev.us, d_hdr.as<uint64_t>(), (unsigned long long)hdr.size(), d.k, d_rec.as<UsRec>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(upload(d_k, d.left_k.data(), d.left_k.size() * 8));
+    HIP_TRY(upload(d_a, d.left_a.data(), d.left_a.size() * 4));
+    prof.host_phase("store_words_up+headers", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(), nw * 8, hdr.size());
+    const double bpk = tune::f(tune::T_BLOOM_BITS, 12.0);
+    if (bpk > 0) {
+        bloom_shape(idx->dev.bloom, d.nb_solid, bpk, d.k);
+        HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, idx->dev.bloom.nblocks * 64));
+        HIP_TRY(hipMemset(idx->dev.bloom.bits, 0, idx->dev.bloom.nblocks * 64));
+    }
+    idx->info.k = d.k;
+    idx->info.abundance_min = d.abundance_min; idx->info.abundance_auto = d.abundance_auto;
+    idx->info.nb_solid_kmers = d.nb_solid; idx->info.nb_branching = d.nb_branching; idx->info.nb_saturated = d.nb_saturated;
+    idx->info.nb_unitigs = hdr.size();
+    idx->info.unitig_bytes = nw * 40;
+    idx->info.bloom_blocks = idx->dev.bloom.nblocks;
+    idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
+    idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
+    idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
+    if (int rc = sparsify(idx, d_rec.as<UsRec>(), hdr.size(), true, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d.left_k.size(), &prof)) return rc;
+    const auto t_j0 = std::chrono::steady_clock::now();
+    for (auto& t : uploaders) t.join();
+    if (up_err.load()) { set_error(up_err.load() == 2 ? "index container: short read" : "index container: the upload of the abundance bytes failed"); return up_err.load() == 2 ? MTG_ERR_FORMAT : MTG_ERR_NO_DEVICE; }
+    if (streamed) prof.host_phase("abundances_file_to_hbm", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(), nw * 32, nw * 32);
+    (void)t_j0;
+    HIP_TRY(hipDeviceSynchronize());
+    prof.store(idx);
+    *out = g.release();
+    return MTG_OK;
+}
+
+void index_release(mtg_index* idx)
+{
+    if (!idx) return;
+    for (Workspace& w : idx->ws) {
+        for (int i = 0; i < Workspace::NSLOTS; i++) if (w.ptr[i]) (void)hipFree(w.ptr[i]);
+        for (int i = 0; i < Workspace::NHOST; i++) if (w.hptr[i]) (void)hipHostFree(w.hptr[i]);
+        if (w.stream) (void)hipStreamDestroy((hipStream_t)w.stream);
+        if (w.copy_stream) (void)hipStreamDestroy((hipStream_t)w.copy_stream);
+    }
+    free_tables(idx);
+    delete idx;
+}
+
+
+/* Graph::create on the device.  The reads arrive as text blocks (whole reads separated by '\n'); k-mers are counted in an exact
+ * open-addressing table, in P passes over the reads when one table for all k-mers would not fit (a k-mer belongs to the pass its hash
+ * selects).  Round 1: every pass feeds the abundance histogram, from which the cut-off comes (automatic: gatb's Histogram heuristic).
+ * Round 2: the solid k-mers go from the count table straight into the index tables (one pass: the table of round 1 is still there;
+ * several: the passes are counted again).  Then lookaheads and the unitig store, both from the index's own tables. */
+int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_max, mtg_index** out)
+{
+    if (int rc = ensure_device()) return rc;
+    if (k < 11 || k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
+    const uint32_t nbins = 10003; /* STR_HISTOGRAM_MAX 10000, src/Filler.cpp:200 */
+    BuildProf prof;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = (size_t)((double)free_b * 0.45); /* the index tables have to fit next to the count table */
+    const size_t n_hint = std::max<size_t>(rs.size_hint(), 1 << 16);
+    /* distinct k-mers <= instances; start from instances / 4 slots in total (30x data has ~25 instances per distinct k-mer) and grow on
+     * overflow */
+    uint64_t total_slots = 1ull << 16;
+    while (total_slots < n_hint / 4) total_slots <<= 1;
+    const uint32_t forced = (uint32_t)tune::i(tune::T_COUNT_PASSES, 0);
+    DevBuf d_text, d_flags, d_histo;
+    const size_t text_cap = (size_t)80 << 20;
+    HIP_TRY(d_text.alloc(text_cap));
+    HIP_TRY(d_flags.alloc(64));
+    HIP_TRY(d_histo.alloc((size_t)nbins * 8));
+    std::vector<uint64_t> histo(nbins, 0);
+    for (int attempt = 0; attempt < 10; attempt++, total_slots <<= 1) {
+        uint32_t npass = 1;
+        while (total_slots / npass * 12 + (64u << 20) > budget && npass < 1024) npass <<= 1;
+        if (forced > npass) npass = forced;
+        uint64_t cap = 1ull << 10;
+        while (cap < total_slots / npass) cap <<= 1;
+        if (cap * 12 + (64u << 20) > free_b) { set_error("not enough device memory to count the k-mers of the reads"); return MTG_ERR_NOMEM; }
+        DevBuf d_keys, d_cnts;
+        HIP_TRY(d_keys.alloc(cap * 8));
+        HIP_TRY(d_cnts.alloc(cap * 4));
+        CountTable t;
+        t.keys = d_keys.as<uint64_t>();
+        t.counts = d_cnts.as<uint32_t>();
+        t.mask = cap - 1;
+        /* one pass over the reads into the (cleared) table; returns 1 when the table overflowed */
+        auto count_pass = [&](uint32_t pass, bool& overflow) -> int {
+            HIP_TRY(hipMemset(d_keys.p, 0xFF, cap * 8));
+            HIP_TRY(hipMemset(d_cnts.p, 0, cap * 4));
+            HIP_TRY(hipMemset(d_flags.p, 0, 64));
+            if (!rs.rewind()) { set_error("cannot read the input again"); return MTG_ERR_IO; }
+            const char* p = nullptr;
+            size_t n = 0;
+            while (rs.next_block(p, n)) {
+                for (size_t off = 0; off < n;) { /* a block larger than the device buffer goes in pieces that overlap by k-1 characters */
+                    const size_t len = std::min(text_cap - 64, n - off);
+                    HIP_TRY(hipMemcpy(d_text.p, p + off, len, hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(k_count, dim3(256 * 32), dim3(256), 0, 0, t, d_text.as<char>(), (uint64_t)len, k, npass, pass, d_flags.as<unsigned long long>());
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipDeviceSynchronize());
+                    if (off + len >= n) break;
+                    off += len - (size_t)(k - 1);
+                }
+            }
+            if (rs.failed()) return MTG_ERR_IO;
+            unsigned long long flags[8];
+            HIP_TRY(hipMemcpy(flags, d_flags.p, 64, hipMemcpyDeviceToHost));
+            overflow = flags[0] != 0;
+            return MTG_OK;
+        };
+        /* round 1: the histogram */
+        HIP_TRY(hipMemset(d_histo.p, 0, (size_t)nbins * 8));
+        bool overflow = false;
+        for (uint32_t pass = 0; pass < npass && !overflow; pass++) {
+            if (int rc = count_pass(pass, overflow)) return rc;
+            if (overflow) break; /* table too full: double the slots and start over */
+            hipLaunchKernelGGL(k_count_stats, dim3(256 * 16), dim3(256), 0, 0, t, 0u, d_histo.as<unsigned long long>(), nbins, d_flags.as<unsigned long long>() + 1);
+            HIP_TRY(hipGetLastError());
+        }
+        if (overflow) continue;
+        HIP_TRY(hipMemcpy(histo.data(), d_histo.p, (size_t)nbins * 8, hipMemcpyDeviceToHost));
+        int autoc = -1;
+        if (abundance_min < 0) { autoc = auto_cutoff(histo, 3); abundance_min = autoc; } /* auto never goes below 3 (src/Filler.cpp:201) */
+        const uint32_t lo = (uint32_t)std::max(abundance_min, 1), hi = abundance_max > 0 ? (uint32_t)abundance_max : 0xFFFFFFFFu;
+        uint64_t n_solid = 0;
+        for (uint32_t c = lo; c < nbins; c++) if (c <= hi || c == nbins - 1) n_solid += histo[c]; /* the last bin holds every larger count */
+        /* round 2: the index */
+        IndexGuard g(new mtg_index());
+        mtg_index* idx = g.idx;
+        idx->dev.k = k;
+        HIP_TRY(hipGetDevice(&idx->device));
+        DevBuf d_cnt;
+        HIP_TRY(d_cnt.alloc(32));
+        double load = 1.0;
+        int rc = MTG_OK;
+        if (!legacy_build()) {
+            /* the lean build: the solid k-mers' junctions into the junction table; their abundances stay in the count table (one counting
+             * pass) or go into an ABND table of their own (several: the count table of a pass does not outlive it) */
+            prof.host_phase("count_reads", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - prof.t0).count(), 0, n_solid);
+            DevBuf jt_buf, abnd_buf;
+            Table jt{}, abnd{};
+            unsigned long long cnt[4] = {0, 0, 0, 0};
+            for (int ia = 0; ia < 6; ia++) {
+                if (int rc2 = alloc_slot_table(jt, jt_buf, n_solid + n_solid / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n_solid, k))) return rc2;
+                if (npass > 1) if (int rc2 = alloc_slot_table(abnd, abnd_buf, n_solid, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
+                HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+                for (uint32_t pass = 0; pass < npass; pass++) {
+                    if (npass > 1) {
+                        bool ovf2 = false;
+                        if (int rc2 = count_pass(pass, ovf2)) return rc2;
+                        if (ovf2) { set_error("k-mer count table overflowed on a repeated pass"); return MTG_ERR_OVERFLOW; }
+                    }
+                    prof.begin();
+                    hipLaunchKernelGGL(k_jt_insert_from_counts, dim3(256 * 16), dim3(256), 0, 0, jt, abnd, npass > 1 ? 1 : 0, k, t, lo, hi, d_cnt.as<unsigned long long>());
+                    HIP_TRY(prof.end("jt_insert_from_counts", (t.mask + 1) * 12 + n_solid / npass * (2 * 64 + (npass > 1 ? 64 : 0)), n_solid / npass));
+                }
+                HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+                if (!cnt[0]) { rc = MTG_OK; break; }
+                load *= 0.7;
+                rc = MTG_ERR_OVERFLOW;
+                set_error("index bucket displacement overflow");
+            }
+            if (rc) return rc;
+            (void)d_text.alloc(0);
+            if (npass == 1) {
+                AbFromCounts src;
+                src.t = t;
+                rc = build_from_jt(idx, jt_buf, jt, src, [&] { (void)d_keys.alloc(0); (void)d_cnts.alloc(0); }, 0, prof);
+            } else {
+                (void)d_keys.alloc(0);
+                (void)d_cnts.alloc(0);
+                AbFromTable src;
+                src.abnd = abnd;
+                rc = build_from_jt(idx, jt_buf, jt, src, [&] { (void)abnd_buf.alloc(0); }, cnt[3], prof);
+            }
+            if (rc) return rc;
+            idx->info.k = k;
+            idx->info.abundance_min = abundance_min;
+            idx->info.abundance_auto = autoc;
+            prof.store(idx);
+            *out = g.release();
+            return MTG_OK;
+        }
+        for (int ia = 0; ia < 6; ia++) {
+            free_tables(idx);
+            rc = alloc_tables(idx, n_solid, load);
+            if (rc) return rc;
+            HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+            for (uint32_t pass = 0; pass < npass; pass++) {
+                if (npass > 1) { /* the table of the wanted pass has to be counted again (with one pass it still holds round 1's counts) */
+                    bool ovf2 = false;
+                    if (int rc2 = count_pass(pass, ovf2)) return rc2;
+                    if (ovf2) { set_error("k-mer count table overflowed on a repeated pass"); return MTG_ERR_OVERFLOW; }
+                }
+                hipLaunchKernelGGL(k_insert_from_counts, dim3(256 * 16), dim3(256), 0, 0, idx->dev, t, lo, hi, d_cnt.as<unsigned long long>());
+                HIP_TRY(hipGetLastError());
+            }
+            unsigned long long cnt[4];
+            HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+            idx->info.nb_saturated = cnt[3];
+            if (!cnt[0]) { rc = MTG_OK; break; }
+            load *= 0.7;
+            rc = MTG_ERR_OVERFLOW;
+            set_error("index bucket displacement overflow");
+        }
+        if (rc) return rc;
+        (void)d_keys.alloc(0); /* the count table is done with: room for the unitig construction */
+        (void)d_cnts.alloc(0);
+        {
+            const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
+            hipLaunchKernelGGL(k_lookahead_table, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        if (int rc2 = build_unitigs(idx)) return rc2;
+        idx->info.k = k;
+        idx->info.abundance_min = abundance_min;
+        idx->info.abundance_auto = autoc;
+        *out = g.release();
+        return MTG_OK;
+    }
+    set_error("k-mer count table kept overflowing");
+    return MTG_ERR_OVERFLOW;
+}
+
+
+} // namespace mtgi

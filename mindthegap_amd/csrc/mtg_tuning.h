@@ -62,7 +62,7 @@
     X(CLI_NO_MMAP, "", "test", "the tool reads its breakpoint file instead of mapping it") \
     X(HOST_FORMAT, "", "ab", "the tool: every site's text by the host's writers (round 3) instead of the device's formatter") \
     X(TOOL_TIMERS, "", "diag", "the tool: where the time of a run went (stderr)") \
-    X(TOOL_QUIET, "", "diag", "the tool on a resident index: no summary on stdout")
+    X(TOOL_QUIET, "", "diag", "the tool: no summary on stdout")
 
 namespace mtgi {
 namespace tune {

@@ -16,6 +16,7 @@ ap.add_argument("--nseq", type=int, default=40000)
 ap.add_argument("--err", type=float, default=0.005)
 ap.add_argument("--oracle-seqs", type=int, default=1500)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--label", default="", help="a name for the line (bench.py: BASELINE configs[1], E0 / E1)")
 a = ap.parse_args()
 S = SynthSet(nseq=a.nseq, n_sites=a.nseq, seed=2, k=31)
 d = tempfile.mkdtemp()
@@ -108,7 +109,7 @@ def recs(p):
     return sorted(map(tuple, out))
 same = recs(os.path.join(d, "hip.insertions.fasta")) == recs(os.path.join(d, "cpu.insertions.fasta"))
 truth = sum(1 for (n, s) in recs(os.path.join(d, "hip.insertions.fasta")) if s in {S.site(i)[2] for i in range(ns)})
-out = {"workload": "reads-built: donor %d x 5 kb = %.0f Mbp, %d reads of 150 nt (30x) with %.1f %% substitutions through -in, -abundance-min 3, %d sites" % (S.nseq, S.lens.sum() / 1e6, nreads, 100 * a.err, S.n_sites),
+out = {"label": a.label, "workload": "reads-built: donor %d x 5 kb = %.0f Mbp, %d reads of 150 nt (30x) with %.1f %% substitutions through -in, -abundance-min 3, %d sites" % (S.nseq, S.lens.sum() / 1e6, nreads, 100 * a.err, S.n_sites),
        "reads_fasta_GB": os.path.getsize(reads) / 1e9, "reads_generated_s": t_gen, "index_from_reads_s": t_index, "nb_solid_kmers": info["nb_solid_kmers"], "nb_unitigs": info["nb_unitigs"],
        "kmers_per_unitig": info["nb_solid_kmers"] / max(info["nb_unitigs"], 1), "kmers_outside_unitigs": info["nb_kmers_outside_unitigs"], "nb_branching": info["nb_branching"],
        "index_bytes": info["device_bytes"], "index_bytes_per_kmer": info["device_bytes"] / max(info["nb_solid_kmers"], 1), "build_peak_bytes": prof["peak_device_bytes"],
