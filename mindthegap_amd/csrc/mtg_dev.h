@@ -201,6 +201,14 @@ MTG_DEV uint64_t atomic_cas64(uint64_t* p, uint64_t cmp, uint64_t val)
     return (uint64_t)atomicCAS(reinterpret_cast<unsigned long long*>(p), (unsigned long long)cmp, (unsigned long long)val);
 #endif
 }
+MTG_DEV unsigned long long atomic_add64(unsigned long long* p, unsigned long long v)
+{
+#ifdef MTG_EMU
+    return __sync_fetch_and_add(p, v);
+#else
+    return atomicAdd(p, v);
+#endif
+}
 MTG_DEV void atomic_or64(uint64_t* p, uint64_t bits)
 {
 #ifdef MTG_EMU
@@ -1197,291 +1205,6 @@ MTG_DEV uint32_t count_lookup(const CountTable& t, uint64_t c, uint32_t& lines)
         h = (h + 1) & t.mask;
     }
     return 0;
-}
-
-/* ---- the lean build (round 4): the graph as a JUNCTION TABLE, the unitig store straight from it -------------------------------------
- * Graph::create without the dense tables (/root/reference/src/Filler.cpp:172-226).  The edge masks of the canonical (k-1)-mers ARE the
- * solid set: the k-mer J+b is solid iff bit b of J's entry is set, so a table of 8-byte slots [tag | disp | mask] (the layout of the ABND
- * table, key_bits = 2(k-1), MTG_ABND_SLOTS slots per 32-byte bucket) answers every neighbourhood question of the construction:
- *   - a junction seen in one of its two orientations is a VIEW {out: nts b with J+b solid, in: nts a with a+J solid};
- *   - every oriented solid k-mer is "prefix view + one out-nucleotide" exactly once (a palindromic junction has one view);
- *   - a view that is simple (one in, one out) and eligible (us_eligible) is the interior of a chain; every k-mer behind any other view
- *     starts a chain, or is a k-mer of no chain when its right view is no interior either.
- * So chain starts, the k-mers of no unitig and the statistics of the graph come out of ONE streaming pass over the table with a probe
- * only next to the (rare) views that are no chain interior, instead of a neighbourhood look-up per solid k-mer.  The abundances never
- * enter a table of their own: they are asked of the SOURCE the k-mers came from (a count table, a k-mer table, or a function of the k-mer)
- * when the store is written. */
-struct JView {
-    uint32_t out, in;
-};
-MTG_DEV JView jt_view(uint32_t m, bool key_is_oriented)
-{
-    JView v;
-    if (key_is_oriented) { v.out = m & 15u; v.in = m >> 4; }
-    else { v.out = comp_mask(m >> 4); v.in = comp_mask(m & 15u); }
-    return v;
-}
-MTG_DEV bool jt_simple(const JView& v) { return popc4(v.out) == 1 && popc4(v.in) == 1; }
-/* the view behind x (its successors, the predecessors of those) and before x (its predecessors, the successors of those) */
-MTG_DEV JView jt_right(const Table& jt, const Kmer& x, uint64_t mk1, uint32_t& lines)
-{
-    const uint64_t s = x.f & mk1, rs = x.r >> 2;
-    return jt_view(table_get<MTG_ABND_SLOTS>(jt, s <= rs ? s : rs, lines), s <= rs);
-}
-MTG_DEV JView jt_left(const Table& jt, const Kmer& x, uint64_t mk1, uint32_t& lines)
-{
-    const uint64_t p = x.f >> 2, rp = x.r & mk1;
-    return jt_view(table_get<MTG_ABND_SLOTS>(jt, p <= rp ? p : rp, lines), p <= rp);
-}
-/* table_or with the bucket read in one go before any atomic (the entry usually exists with its bits, or the first free slot takes it).
- * A stale read is harmless: the tag part of a slot is written once, a slot seen empty is claimed by compare-and-swap, bits seen missing
- * are OR-ed in again.  Returns as table_or. */
-MTG_DEV int jt_or(const Table& t, uint64_t key, uint32_t bits)
-{
-    const uint64_t H = mix(key, t.key_bits);
-    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
-    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
-    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
-        const uint64_t want = (tag << MTG_DISP_BITS) | d;
-        uint64_t* p = t.slots + b * MTG_ABND_SLOTS;
-        uint64_t q[MTG_ABND_SLOTS];
-MTG_UNROLL
-        for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) { const U64x2 v = ld_table(reinterpret_cast<const U64x2*>(p) + i); q[2 * i] = v.x; q[2 * i + 1] = v.y; }
-        for (int i = 0; i < MTG_ABND_SLOTS; i++) {
-            uint64_t v = q[i];
-            if (v == 0) {
-                v = atomic_cas64(p + i, 0, (want << 8) | bits);
-                if (v == 0) return 2;
-            }
-            if ((v >> 8) == want) {
-                if ((v & bits) != bits) atomic_or64(p + i, bits);
-                return 0;
-            }
-        }
-        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
-    }
-    return 1;
-}
-/* one occurrence of the junction J ((k-1)-mer jf, its reverse complement jr) with the nucleotide before it (a, when has_a: the k-mer a+J is
- * solid) and behind it (b, when has_b: J+b is solid): what index_insert contributes to J's entry from the k-mers on its two sides (a
- * palindromic junction gets the bits of both strands).  Returns as table_or. */
-MTG_DEV int jt_insert_junction(const Table& jt, uint64_t jf, uint64_t jr, bool has_a, uint32_t a, bool has_b, uint32_t b)
-{
-    uint32_t bits = 0;
-    if (jf <= jr) bits |= (has_b ? 1u << b : 0u) | (has_a ? 1u << (4 + a) : 0u);
-    if (jr <= jf) bits |= (has_b ? 1u << (4 + (b ^ 2u)) : 0u) | (has_a ? 1u << (a ^ 2u) : 0u);
-    if (!bits) return 0;
-    return jt_or(jt, jf <= jr ? jf : jr, bits);
-}
-/* the two junctions of the solid canonical k-mer c */
-MTG_DEV int jt_insert_kmer(const Table& jt, uint64_t c, int k)
-{
-    const uint64_t mk1 = kmask(k - 1);
-    const uint64_t r = revcomp(c, k);
-    int fail = jt_insert_junction(jt, c >> 2, r & mk1, false, 0u, true, (uint32_t)c & 3u) & 1;
-    fail |= jt_insert_junction(jt, c & mk1, r >> 2, true, (uint32_t)(c >> (2 * (k - 1))) & 3u, false, 0u) & 1;
-    return fail;
-}
-/* what the tables store of an abundance */
-MTG_DEV uint32_t ab_stored(uint32_t a) { return a > 255u ? 255u : (a ? a : 1u); }
-/* abundance sources of the lean build */
-struct AbFromTable {
-    Table abnd;
-    MTG_DEV uint32_t operator()(uint64_t c, uint32_t& lines) const { return table_get<MTG_ABND_SLOTS>(abnd, c, lines); }
-};
-struct AbFromCounts {
-    CountTable t;
-    MTG_DEV uint32_t operator()(uint64_t c, uint32_t& lines) const { return count_lookup(t, c, lines); }
-};
-
-/* counters of the scan (one slot each, added up by the kernels) */
-enum {
-    JT_C_ORIENTED = 0, /* oriented solid k-mers */
-    JT_C_IN_NOT1,      /* ... whose in-degree is not 1 */
-    JT_C_BOTH_NOT1,    /* ... whose in- and out-degree are both not 1 */
-    JT_C_SELF,         /* self-complementary k-mers (even k) */
-    JT_C_SELF_BRANCH,  /* ... that are branching */
-    JT_C_INTERIOR,     /* views that are the interior of a chain (two per eligible junction) */
-    JT_C_STARTS,       /* cursor of the starts list */
-    JT_C_LEFT,         /* cursor of the list of k-mers of no chain */
-    JT_C_SAT,          /* abundances above 255 */
-    JT_C_WORDS,        /* cursor of the store's words (plan) */
-    JT_C_RECS,         /* cursor of the records (plan) */
-    JT_C_STORED_VIEWS, /* interior views of the stored unitigs (plan): equal to JT_C_INTERIOR unless a chain is closed or too long */
-    JT_C_N
-};
-struct JtAcc {
-    unsigned long long c[6];
-};
-/* the key of slot s of a table of MTG_ABND_SLOTS-slot buckets, and its value (0: empty) */
-MTG_DEV uint32_t jt_slot_key(const Table& t, uint64_t slot, uint64_t& key) { return abnd_slot_kmer(t, slot, key); }
-/* is the view {v of the oriented junction jf} the interior of a chain?  p = a+J, y = J+b its two k-mers */
-MTG_DEV bool jt_view_interior(const JView& v, uint64_t jf, int k, Kmer& p, Kmer& y)
-{
-    if (!jt_simple(v)) return false;
-    const uint64_t mk = kmask(k);
-    p = make_kmer((((uint64_t)ctz4(v.in) << (2 * (k - 1))) | jf) & mk, k);
-    y = kmer_next(p, (uint32_t)ctz4(v.out), k, mk);
-    return us_eligible(p, y, k);
-}
-/* Scan, per entry (canonical junction J with mask m): statistics into acc, and for every view that is no chain interior the k-mers behind
- * it: chain starts (oriented k-mer, forward value) into starts[], k-mers of no chain (canonical, with the abundance the source gives) into
- * left_k / left_a.  Lists may be null (counting pass); cursors count either way. */
-template <typename Src>
-MTG_DEV void jt_scan_entry(const Table& jt, int k, uint64_t J, uint32_t m, const Src& src, JtAcc& acc, unsigned long long* counters,
-                           uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
-{
-    const uint64_t mk = kmask(k), mk1 = kmask(k - 1);
-    const uint64_t rJ = revcomp(J, k - 1);
-    const int nviews = (J == rJ) ? 1 : 2;
-    for (int w = 0; w < nviews; w++) {
-        const uint64_t jf = w ? rJ : J;
-        const JView v = jt_view(m, w == 0);
-        const int n_out = popc4(v.out), n_in = popc4(v.in);
-        acc.c[JT_C_ORIENTED] += (unsigned)n_out;
-        if (n_in != 1) acc.c[JT_C_IN_NOT1] += (unsigned)n_out;
-        Kmer p, y;
-        if (jt_view_interior(v, jf, k, p, y)) { acc.c[JT_C_INTERIOR]++; continue; }
-        for (uint32_t rest = v.out; rest; rest &= rest - 1) {
-            const uint32_t b = (uint32_t)ctz4(rest);
-            const Kmer x = make_kmer(((jf << 2) | b) & mk, k);
-            const bool self = x.f == x.r;
-            const JView r = jt_right(jt, x, mk1, lines);
-            const int out_x = popc4(r.out);
-            acc.c[JT_C_SELF] += self;
-            if (n_in != 1 && out_x != 1) acc.c[JT_C_BOTH_NOT1]++;
-            if (self && (n_in != 1 || out_x != 1)) acc.c[JT_C_SELF_BRANCH]++;
-            bool chain = false;
-            if (jt_simple(r)) chain = us_eligible(x, kmer_next(x, (uint32_t)ctz4(r.out), k, mk), k);
-            if (chain) {
-#ifdef MTG_EMU
-                const unsigned long long at = __sync_fetch_and_add(&counters[JT_C_STARTS], 1ull);
-#else
-                const unsigned long long at = atomicAdd(&counters[JT_C_STARTS], 1ull);
-#endif
-                if (starts && at < cap_starts) starts[at] = x.f;
-            } else if (x.f <= x.r) {
-#ifdef MTG_EMU
-                const unsigned long long at = __sync_fetch_and_add(&counters[JT_C_LEFT], 1ull);
-#else
-                const unsigned long long at = atomicAdd(&counters[JT_C_LEFT], 1ull);
-#endif
-                if (left_k && at < cap_left) {
-                    const uint32_t a = src(x.f, lines);
-                    left_k[at] = x.f;
-                    left_a[at] = ab_stored(a);
-                    if (a > 255u) {
-#ifdef MTG_EMU
-                        __sync_fetch_and_add(&counters[JT_C_SAT], 1ull);
-#else
-                        atomicAdd(&counters[JT_C_SAT], 1ull);
-#endif
-                    }
-                }
-            }
-        }
-    }
-}
-/* the chain that starts with x, walked on the junction table (us_walk without lookaheads) */
-template <typename Sink> MTG_DEV uint32_t jt_walk(const Table& jt, int k, const Kmer& x, Kmer& end, uint32_t& lines, Sink sink)
-{
-    const uint64_t mk = kmask(k), mk1 = kmask(k - 1);
-    const uint32_t cap = MTG_US_MAX_LEN - (uint32_t)k; /* k-mers */
-    Kmer cur = x;
-    uint32_t n = 1;
-    for (;;) {
-        const JView a = jt_right(jt, cur, mk1, lines);
-        if (!jt_simple(a)) break;
-        const uint32_t nt = (uint32_t)ctz4(a.out);
-        const Kmer y = kmer_next(cur, nt, k, mk);
-        if (!us_eligible(cur, y, k) || n >= cap) break;
-        cur = y;
-        n++;
-        sink(nt);
-    }
-    end = cur;
-    return n;
-}
-/* per chain start (us_plan_start on the junction table): the end the chain is stored from reserves words and record */
-MTG_DEV void jt_plan_start(const Table& jt, int k, const Kmer& x, unsigned long long* counters, UsRec* rec, uint64_t rec_cap, uint32_t& lines)
-{
-    Kmer end;
-    const uint32_t n = jt_walk(jt, k, x, end, lines, UsNoSink());
-    if (n < 2) return;
-    if (n >= MTG_US_MAX_LEN - (uint32_t)k) return;
-    if (!(canon(x) < canon(end))) return;
-#ifdef MTG_EMU
-    const uint64_t r = __sync_fetch_and_add(&counters[JT_C_RECS], 1ull);
-    const uint64_t w = __sync_fetch_and_add(&counters[JT_C_WORDS], (unsigned long long)us_words_of(n, k));
-    __sync_fetch_and_add(&counters[JT_C_STORED_VIEWS], 2ull * (n - 1));
-#else
-    const uint64_t r = atomicAdd(&counters[JT_C_RECS], 1ull);
-    const uint64_t w = atomicAdd(&counters[JT_C_WORDS], (unsigned long long)us_words_of(n, k));
-    atomicAdd(&counters[JT_C_STORED_VIEWS], 2ull * (n - 1));
-#endif
-    if (r < rec_cap) { rec[r].start_f = x.f; rec[r].len_k = n; rec[r].pad_ = 0; rec[r].hdr = w; }
-}
-/* per record: the sequence of the unitig into the store (us_emit on the junction table) */
-MTG_DEV void jt_emit(const Table& jt, const UStore& us, int k, const UsRec& r, uint32_t& lines)
-{
-    uint64_t* w = us.words + r.hdr;
-    w[0] = (uint64_t)r.len_k + (uint32_t)k - 1;
-    uint64_t acc = 0;
-    uint32_t nacc = 0, wpos = 1;
-    auto push = [&](uint32_t nt) {
-        acc |= (uint64_t)nt << (2 * nacc);
-        if (++nacc == 32) { w[wpos++] = acc; acc = 0; nacc = 0; }
-    };
-    for (int i = k - 1; i >= 0; i--) push((uint32_t)(r.start_f >> (2 * i)) & 3u);
-    Kmer end;
-    jt_walk(jt, k, make_kmer(r.start_f, k), end, lines, push);
-    if (nacc) w[wpos] = acc;
-}
-/* per k-mer i of a stored unitig: its abundance, asked of the source, into the store; returns 1 when it exceeds 255 */
-template <typename Src> MTG_DEV uint32_t us_ab_fill(const UStore& us, int k, const UsRec& r, uint32_t i, const Src& src, uint32_t& lines)
-{
-    const uint64_t mk = kmask(k);
-    const uint64_t le = us_kmer_le(us.words, (r.hdr + 1) * 32 + i, k);
-    const uint64_t xr = le ^ (0xAAAAAAAAAAAAAAAAULL & mk), xf = revcomp(xr, k);
-    const uint32_t a = src(xf < xr ? xf : xr, lines);
-    us.ab[(r.hdr + 1) * 32 + i] = (uint8_t)ab_stored(a);
-    return a > 255u;
-}
-/* a closed or over-long chain was met (rare): every canonical k-mer of the junction table that the finished unitig pointers of `nx` (the
- * sparse ADJ under construction, store attached) do not reach is a k-mer of no unitig.  Per entry, as the scan. */
-template <typename Src>
-MTG_DEV void jt_unstored_entry(const Table& jt, const Index& nx, uint64_t J, uint32_t m, const Src& src, unsigned long long* counters,
-                               uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
-{
-    const int k = nx.k;
-    const uint64_t mk = kmask(k);
-    const uint64_t rJ = revcomp(J, k - 1);
-    const int nviews = (J == rJ) ? 1 : 2;
-    for (int w = 0; w < nviews; w++) {
-        const uint64_t jf = w ? rJ : J;
-        const JView v = jt_view(m, w == 0);
-        for (uint32_t rest = v.out; rest; rest &= rest - 1) {
-            const Kmer x = make_kmer(((jf << 2) | (uint32_t)ctz4(rest)) & mk, k);
-            if (!(x.f <= x.r) || kmer_stored(nx, x.f, lines)) continue;
-#ifdef MTG_EMU
-            const unsigned long long at = __sync_fetch_and_add(&counters[JT_C_LEFT], 1ull);
-#else
-            const unsigned long long at = atomicAdd(&counters[JT_C_LEFT], 1ull);
-#endif
-            if (left_k && at < cap_left) {
-                const uint32_t a = src(x.f, lines);
-                left_k[at] = x.f;
-                left_a[at] = ab_stored(a);
-                if (a > 255u) {
-#ifdef MTG_EMU
-                    __sync_fetch_and_add(&counters[JT_C_SAT], 1ull);
-#else
-                    atomicAdd(&counters[JT_C_SAT], 1ull);
-#endif
-                }
-            }
-        }
-    }
 }
 
 } // namespace mtg

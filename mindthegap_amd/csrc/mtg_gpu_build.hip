@@ -1,11 +1,12 @@
 /*
  * mtg_gpu_build.hip -- index construction on the device (Graph::create / Graph::load, /root/reference/src/Filler.cpp:172-226), gfx950 only.
  *
- *   k_jt_insert_* / k_jt_scan / k_jt_plan / k_jt_emit / k_us_ab / k_sparse_link : the lean build (mtg_dev.h: junction table -> unitig store -> sparse tables)
+ *   k_jt_insert_* / k_jt_scan / k_jt_plan_emit / k_us_compact / k_us_ab / k_sparse_link : the lean build (mtg_dev.h: junction table -> unitig store -> sparse tables)
  *   k_count / k_count_stats                                                      : exact k-mer counting of streamed reads (-in)
  *   k_insert_* / k_lookahead_* / k_us_* / k_leftovers                            : the construction of rounds 1-3 (dense tables; test hooks)
  */
 #include "mtg_gpu_common.h"
+#include "mtg_build.h"
 
 namespace mtgi {
 
@@ -255,15 +256,61 @@ __global__ void k_leftovers(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned
         if (out_k && at < cap) { out_k[at] = c; out_a[at] = a; }
     }
 }
-/* one stored unitig per wave, its k-mers dealt to the lanes: the entries of its junctions in the new tables; counters[0] = overflow flag */
-__global__ void __launch_bounds__(256) k_sparse_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n, int with_bloom, unsigned long long* counters)
+/* one stored unitig per wave (a wave per workgroup), its k-mers dealt to the lanes: the entries of its junctions in the new tables;
+ * counters[0] = overflow flag.
+ * with_bloom: the k-mers also enter the Bloom filter, and not one by one.  Consecutive k-mers of a unitig share their minimizer, hence their
+ * 64-byte block, for about (k - m + 1) / 2 positions; four atomics per k-mer (round 4) made every wave instruction touch half a dozen lines
+ * four times over (PMC: 112 bytes of HBM traffic per k-mer for the filter alone, 100 of the kernel's 220 ms).  Now the lanes of a run of equal
+ * blocks OR their bits together in LDS (eight 64-bit words per run) and the wave flushes eight runs per instruction, the eight words of a run
+ * on eight neighbouring lanes: one line per run instead of four per k-mer. */
+__global__ void __launch_bounds__(64) k_sparse_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n, int with_bloom, unsigned long long* counters)
 {
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ unsigned long long s_bits[64 * 8];
+    __shared__ unsigned long long s_blk[64];
+    const uint32_t lane = threadIdx.x;
+    const int k = ix.k;
+    const bool bloom = with_bloom != 0 && ix.bloom.bits != nullptr;
+    Index nb = ix;
+    nb.bloom.bits = nullptr; /* sparse_link's own insertion is off: the filter is filled below */
     int fail = 0;
-    for (unsigned long long u = wave; u < n; u += nwaves) {
+    for (unsigned long long u = blockIdx.x; u < n; u += gridDim.x) {
         const UsRec r = rec[u];
-        for (uint32_t i = lane; i < r.len_k; i += 64) fail |= sparse_link(ix, r, i, with_bloom != 0);
+        for (uint32_t base = 0; base < r.len_k; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < r.len_k;
+            if (valid) fail |= sparse_link(nb, r, i, false);
+            if (!bloom) continue;
+            unsigned long long blk = ~0ull, hb = 0;
+            if (valid) {
+                const uint64_t mk = kmask(k);
+                Kmer x;
+                x.r = us_kmer_le(ix.us.words, (r.hdr + 1) * 32 + i, k) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
+                x.f = revcomp(x.r, k);
+                blk = bloom_block(ix.bloom, x, k);
+                hb = bloom_bits(canon(x));
+            }
+            const unsigned long long prev = __shfl_up(blk, 1, 64);
+            const bool lead = valid && (lane == 0 || prev != blk);
+            const unsigned long long lm = __ballot(lead);
+            const uint32_t run = (uint32_t)__popcll(lm & ((2ull << lane) - 1ull)) - 1u; /* leaders at or below this lane, minus one */
+            const uint32_t nruns = (uint32_t)__popcll(lm);
+            for (uint32_t t = lane; t < nruns * 8u; t += 64) s_bits[t] = 0ull;
+            if (lead) s_blk[run] = blk;
+            __syncthreads();
+            if (valid) {
+MTG_UNROLL
+                for (int j = 0; j < MTG_BLOOM_NHASH; j++) {
+                    const uint32_t bit = (uint32_t)(hb >> (9 * j)) & 511u;
+                    atomicOr(&s_bits[run * 8u + (bit >> 6)], 1ull << (bit & 63u));
+                }
+            }
+            __syncthreads();
+            for (uint32_t t = lane; t < nruns * 8u; t += 64) {
+                const unsigned long long v = s_bits[t];
+                if (v) atomicOr(reinterpret_cast<unsigned long long*>(ix.bloom.bits + s_blk[t >> 3] * 16) + (t & 7u), v);
+            }
+            __syncthreads();
+        }
     }
     if (fail) atomicOr(&counters[0], 1ull);
 }
@@ -363,22 +410,17 @@ __global__ void k_jt_insert_from_counts(Table jt, Table abnd, int with_abnd, int
     if (fail) atomicOr(&counters[0], 1ull);
     if (sat) atomicAdd(&counters[3], sat);
 }
-/* one streaming pass over the junction table (jt_scan_entry); collect = 0: counts starts / k-mers of no chain and the statistics,
- * collect = 1: fills the lists (the statistics are left alone) */
+/* ONE streaming pass over the junction table, a bucket per lane (jt_scan_bucket: two 16-byte reads, the keys from one division): statistics,
+ * chain starts and the k-mers of no chain.  The lists have the capacities the host guessed; the cursors count past them (round 4 scanned
+ * twice: count, then collect -- 2 x 48 ms at human scale, bound by the arithmetic of decoding every slot on its own). */
 template <typename Src>
-__global__ void __launch_bounds__(256) k_jt_scan(Table jt, int k, Src src, unsigned long long* counters, int collect, uint64_t* starts, unsigned long long cap_starts,
+__global__ void __launch_bounds__(256) k_jt_scan(Table jt, int k, Src src, unsigned long long* counters, uint64_t* starts, unsigned long long cap_starts,
                                                  uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left)
 {
-    const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
     JtAcc acc{};
     uint32_t lines = 0;
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t J;
-        const uint32_t m = jt_slot_key(jt, s, J);
-        if (!m) continue;
-        jt_scan_entry(jt, k, J, m, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
-    }
-    if (collect) return;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < jt.nbuckets; b += (uint64_t)gridDim.x * blockDim.x)
+        jt_scan_bucket(jt, k, b, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
     for (int j = 0; j < 6; j++) {
         const unsigned long long v = wave_sum_u64(acc.c[j]);
         if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&counters[j], v);
@@ -396,21 +438,25 @@ __global__ void __launch_bounds__(256) k_jt_unstored(Table jt, Index nx, Src src
         jt_unstored_entry(jt, nx, J, m, src, counters, left_k, left_a, cap_left, lines);
     }
 }
-/* one chain start per lane: the walk to the other end; the end the chain is stored from reserves words and record */
-__global__ void __launch_bounds__(64) k_jt_plan(Table jt, int k, const uint64_t* __restrict__ starts, unsigned long long n, unsigned long long* counters, UsRec* rec, unsigned long long rec_cap)
+/* one chain start per lane: the walk to the other end with the sequence written into chunks on the way (jt_plan_emit_start); the end the
+ * chain is stored from reserves words and record */
+__global__ void __launch_bounds__(64) k_jt_plan_emit(Table jt, int k, const uint64_t* __restrict__ starts, unsigned long long n, ChunkPool pool, unsigned long long* counters, UsRec* rec,
+                                                     uint64_t* rec_chunk, unsigned long long rec_cap)
 {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t lines = 0;
-    jt_plan_start(jt, k, make_kmer(starts[i], k), counters, rec, rec_cap, lines);
+    jt_plan_emit_start(jt, k, make_kmer(starts[i], k), pool, counters, rec, rec_chunk, rec_cap, lines);
 }
-/* one stored unitig per lane: its sequence into the store */
-__global__ void __launch_bounds__(64) k_jt_emit(Table jt, UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n)
+/* one stored unitig per wave: its words from the chunk chain to their place in the store (us_compact).  counters[JT_C_SAT + 0 ...]: none;
+ * flag[0] |= 1 when a chain is shorter than its record */
+__global__ void __launch_bounds__(256) k_us_compact(UStore us, int k, const UsRec* __restrict__ rec, const uint64_t* __restrict__ rec_chunk, unsigned long long n, ChunkPool pool, unsigned long long* flag)
 {
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t lines = 0;
-    jt_emit(jt, us, k, rec[i], lines);
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool bad = false;
+    for (unsigned long long u = wave; u < n; u += nwaves) bad = !us_compact(us, k, rec[u], rec_chunk[u], pool, lane, 64u) || bad;
+    if (bad && lane == 0) atomicOr(&flag[0], 1ull);
 }
 /* one stored unitig per wave, its k-mers dealt to the lanes: abundances from the source into the store.  counters[JT_C_SAT] += those above 255 */
 template <typename Src>
@@ -678,7 +724,7 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         nx.abnd.slots = nb.as<uint64_t>();
         HIP_TRY(hipMemset(d_cnt.p, 0, 64));
         if (prof) prof->begin();
-        if (n_rec) hipLaunchKernelGGL(k_sparse_link, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, nx, d_rec, n_rec, from_container ? 1 : 0, d_cnt.as<unsigned long long>());
+        if (n_rec) hipLaunchKernelGGL(k_sparse_link, dim3((unsigned)std::min<unsigned long long>(n_rec, 256 * 256)), dim3(64), 0, 0, nx, d_rec, n_rec, from_container ? 1 : 0, d_cnt.as<unsigned long long>());
         HIP_TRY(hipGetLastError());
         /* per k-mer: its window of the store (8), every second one an ADJ bucket read and written (2 x 32), with the filter a block (64 + 64) */
         if (prof) HIP_TRY(prof->end(from_container ? "sparse_link+bloom" : "sparse_link", n_unitig_kmers * (8 + 32 + (from_container && nx.bloom.bits ? 128 : 0)), n_unitig_kmers));
@@ -739,42 +785,62 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
     const unsigned scan_blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
     DevBuf d_cnt, d_starts, d_rec, d_left_k, d_left_a;
-    HIP_TRY(d_cnt.alloc(JT_C_N * 8));
-    HIP_TRY(hipMemset(d_cnt.p, 0, JT_C_N * 8));
+    HIP_TRY(d_cnt.alloc((JT_C_N + 2) * 8)); /* + the chunk pool's cursor, the compaction's flag */
+    HIP_TRY(hipMemset(d_cnt.p, 0, (JT_C_N + 2) * 8));
     unsigned long long* cnt_d = d_cnt.as<unsigned long long>();
     unsigned long long cnt[JT_C_N];
-    /* chain starts, k-mers of no chain, statistics: counted, then collected */
-    prof.begin();
-    hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, k, src, cnt_d, 0, (uint64_t*)nullptr, 0ull, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull);
-    HIP_TRY(prof.end("jt_scan_count", nslots * 8, nslots));
-    HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
-    const unsigned long long n_starts = cnt[JT_C_STARTS], n_single = cnt[JT_C_LEFT], interior = cnt[JT_C_INTERIOR];
+    /* chain starts, k-mers of no chain, statistics: ONE pass with lists of guessed capacity; a graph with more starts than the guess (the cursors
+     * count past the capacities) is scanned a second time with lists of the exact sizes */
+    unsigned long long n_starts = 0, n_single = 0, interior = 0, sat_single = 0;
+    unsigned long long cap_starts = std::max<unsigned long long>(1ull << 20, nslots / 16), cap_left = std::max<unsigned long long>(1ull << 18, nslots / 128);
+    {
+        size_t f = 0, t = 0; /* the guess never takes more than a quarter of what is free (288 GB: it does not bind; a small device: two passes) */
+        if (hipMemGetInfo(&f, &t) == hipSuccess) { cap_starts = std::min<unsigned long long>(cap_starts, f / 4 / 8 + 1024); cap_left = std::min<unsigned long long>(cap_left, f / 8 / 12 + 1024); }
+    }
+    const unsigned scan_grid = (unsigned)std::min<uint64_t>((jt.nbuckets + 255) / 256, 256 * 32);
+    for (int pass = 0; pass < 2; pass++) {
+        HIP_TRY(d_starts.alloc((cap_starts + 1) * 8));
+        HIP_TRY(d_left_k.alloc((cap_left + 1) * 8));
+        HIP_TRY(d_left_a.alloc((cap_left + 1) * 4));
+        HIP_TRY(hipMemset(d_cnt.p, 0, JT_C_N * 8));
+        prof.begin();
+        hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_grid), dim3(256), 0, 0, jt, k, src, cnt_d, d_starts.as<uint64_t>(), cap_starts, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), cap_left);
+        HIP_TRY(prof.end(pass ? "jt_scan_again" : "jt_scan", nslots * 8, nslots));
+        HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
+        n_starts = cnt[JT_C_STARTS]; n_single = cnt[JT_C_LEFT]; interior = cnt[JT_C_INTERIOR]; sat_single = cnt[JT_C_SAT];
+        if (n_starts <= cap_starts && n_single <= cap_left) break;
+        if (pass) { set_error("junction table scan: %llu chain starts and %llu single k-mers do not fit lists sized for them", n_starts, n_single); return MTG_ERR_OVERFLOW; }
+        cap_starts = n_starts; cap_left = n_single;
+    }
     idx->info.nb_solid_kmers = (cnt[JT_C_ORIENTED] + cnt[JT_C_SELF]) / 2;
     idx->info.nb_branching = (2 * cnt[JT_C_IN_NOT1] - cnt[JT_C_BOTH_NOT1] + cnt[JT_C_SELF_BRANCH]) / 2;
     idx->info.nb_unitigs = 0;
     idx->info.unitig_bytes = 0;
-    HIP_TRY(d_starts.alloc((n_starts + 1) * 8));
-    HIP_TRY(d_left_k.alloc((n_single + 1) * 8));
-    HIP_TRY(d_left_a.alloc((n_single + 1) * 4));
-    HIP_TRY(hipMemset(cnt_d + JT_C_STARTS, 0, 8));
-    HIP_TRY(hipMemset(cnt_d + JT_C_LEFT, 0, 8));
-    prof.begin();
-    hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_blocks), dim3(256), 0, 0, jt, k, src, cnt_d, 1, d_starts.as<uint64_t>(), n_starts, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), n_single);
-    HIP_TRY(prof.end("jt_scan_collect", nslots * 8 + n_starts * 8 + n_single * 12, nslots));
-    /* abundances above 255: of the single k-mers (counted by the pass above), then of the unitigs' k-mers (k_us_ab), each on its own */
-    unsigned long long sat_single = 0, sat_unitigs = 0, sat_late = 0;
-    HIP_TRY(hipMemcpy(&sat_single, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
+    /* abundances above 255: of the single k-mers (counted by the scan), then of the unitigs' k-mers (k_us_ab), each on its own */
+    unsigned long long sat_unitigs = 0, sat_late = 0;
     HIP_TRY(hipMemset(cnt_d + JT_C_SAT, 0, 8));
     unsigned long long n_words = 0, n_rec = 0, stored_views = 0;
+    DevBuf d_pool, d_rec_chunk;
+    ChunkPool pool{};
     if (n_starts) {
         const unsigned long long rec_cap = n_starts / 2 + 1; /* two starts per stored unitig (one per strand) */
         HIP_TRY(d_rec.alloc(rec_cap * sizeof(UsRec)));
+        HIP_TRY(d_rec_chunk.alloc(rec_cap * 8));
+        /* the chunks of every walk (both ends of every chain walk it: interior + n_starts steps in all) */
+        pool.cap_chunks = chunk_pool_need(interior + n_starts, n_starts, k);
+        HIP_TRY(d_pool.alloc(pool.cap_chunks * MTG_CHUNK_WORDS * 8));
+        pool.words = d_pool.as<uint64_t>();
+        HIP_TRY(hipMemset(cnt_d + JT_C_N, 0, 16));
+        pool.cursor = cnt_d + JT_C_N;
         prof.begin();
-        hipLaunchKernelGGL(k_jt_plan, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, jt, k, d_starts.as<uint64_t>(), n_starts, cnt_d, d_rec.as<UsRec>(), rec_cap);
-        HIP_TRY(prof.end("jt_plan", (interior + n_starts) * 32, interior + n_starts)); /* both strands of every chain: one bucket per step */
+        hipLaunchKernelGGL(k_jt_plan_emit, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, jt, k, d_starts.as<uint64_t>(), n_starts, pool, cnt_d, d_rec.as<UsRec>(), d_rec_chunk.as<uint64_t>(), rec_cap);
+        HIP_TRY(prof.end("jt_plan+emit", (interior + n_starts) * 32 + (interior + n_starts) / 2, interior + n_starts)); /* both strands of every chain: one bucket per step, a quarter byte written */
+        unsigned long long tail[2];
         HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tail, cnt_d + JT_C_N, 16, hipMemcpyDeviceToHost));
         n_words = cnt[JT_C_WORDS]; n_rec = cnt[JT_C_RECS]; stored_views = cnt[JT_C_STORED_VIEWS];
         if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
+        if (tail[0] > pool.cap_chunks) { set_error("unitig construction: %llu chunks of sequence for a pool of %llu", tail[0], (unsigned long long)pool.cap_chunks); return MTG_ERR_OVERFLOW; }
     }
     (void)d_starts.alloc(0);
     if (n_rec) {
@@ -786,8 +852,14 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
         HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + pad) * 32, 0));
         idx->dev.us.nwords = n_words;
         idx->dev.us.nunitigs = n_rec;
-        hipLaunchKernelGGL(k_jt_emit, dim3((unsigned)((n_rec + 63) / 64)), dim3(64), 0, 0, jt, idx->dev.us, k, d_rec.as<UsRec>(), n_rec);
-        HIP_TRY(prof.end("jt_emit", (stored_views / 2) * 32 + n_words * 48, stored_views / 2 + n_rec));
+        HIP_TRY(hipMemset(cnt_d + JT_C_N + 1, 0, 8));
+        hipLaunchKernelGGL(k_us_compact, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), d_rec_chunk.as<uint64_t>(), n_rec, pool, cnt_d + JT_C_N + 1);
+        HIP_TRY(prof.end("us_compact", n_words * 16 + n_words * 40, n_rec)); /* the words out of their chunks and into the store; the clearing of words and abundance bytes */
+        unsigned long long short_chain = 0;
+        HIP_TRY(hipMemcpy(&short_chain, cnt_d + JT_C_N + 1, 8, hipMemcpyDeviceToHost));
+        if (short_chain) { set_error("unitig construction: a chunk chain is shorter than its record"); return MTG_ERR_OVERFLOW; }
+        (void)d_pool.alloc(0);
+        (void)d_rec_chunk.alloc(0);
         prof.begin();
         hipLaunchKernelGGL(k_us_ab<Src>, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, src, cnt_d);
         HIP_TRY(prof.end("us_abundances", (stored_views / 2 + n_rec) * 9, stored_views / 2 + n_rec));

@@ -32,20 +32,18 @@ __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
  * k_finish, the finishing kernel: a group of G lanes (a wave, or an aligned part of one) takes a parked gap off the work list and runs
  * the rest of its life: frontier expansion one lane per (node, nucleotide) with ballots, visited sets / frontlines / path enumeration /
  * consensuses in LDS (mtg_bubble.h), the walk between two branching nodes by all lanes of the group with the same values.
- *
- * MTG_CLASSIC_WALK=1 (A/B measurements and tests): one kernel, every bubble resolved by its lane from HBM scratch (the round-2 shape). */
-/* Registers of the classic form are capped for two waves per SIMD (left alone the compiler takes 289, one wave per SIMD); the walk kernel
- * without the general bubble code needs fewer.  -DMTG_STAGE_A_WAVES=n / -DMTG_WALK_WAVES=n: experiments with another cap. */
+ */
+/* Registers of the kernels that hold the general bubble code (k_bubble_classic, k_finish_lane) are capped for two waves per SIMD (left alone the
+ * compiler takes 289, one wave per SIMD); the walk kernel without it needs fewer.  -DMTG_STAGE_A_WAVES=n / -DMTG_WALK_WAVES=n: experiments with another cap. */
 #ifndef MTG_STAGE_A_WAVES
 #define MTG_STAGE_A_WAVES 2
 #endif
 #ifndef MTG_WALK_WAVES
 #define MTG_WALK_WAVES 2
 #endif
-#define MTG_STAGE_A_ATTR __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES)))
 /* device: the work lists of one launch.  count[i] = entries of list i; list i = cap slot numbers at lists + i * cap.  List 2r holds the gaps
  * parked by the r-th launch of the walk kernel (at a branching node), list 2r + 1 those of them whose bubble did not fit the LDS areas. */
-enum { PARK_LISTS = 19 }; /* 0 .. 15: the rounds' lists of parked gaps; the last three: gaps with copy commands among those finished late, gaps for k_post's general form, gaps with copy commands to execute */
+enum { PARK_LISTS = 19 }; /* 0 .. 15: the rounds' lists of parked gaps; the last two: gaps for k_post's general form, gaps with copy commands to execute */
 struct ParkCtl {
     uint32_t count[PARK_LISTS];
 #ifdef MTG_BUBBLE_TIMING /* diagnostics build: how long the lanes and the waves of the bubble kernels ran (bins of log2 of 10 ns ticks) */
@@ -80,7 +78,7 @@ __device__ __forceinline__ void park_append(ParkCtl* park, uint32_t cap, uint32_
 template <int MODE>
 __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                              const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset,
-                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, uint32_t snp_mode = 1)
+                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t slot = t;
@@ -93,7 +91,7 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
     GapScratch S = carve(cfg, zero, raw, ilv, slot);
-    S.snp_fast = (int)snp_mode; /* 2: park at SNP bubbles too (mtg_traverse.h: park_all) */
+    S.snp_fast = 1; /* the walking lane answers the strict SNP pattern itself */
     SwfPattern R;
     R.words = rwords + roff[g];
     R.rlen = rlen[g];
@@ -112,38 +110,14 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                                GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, uint32_t snp_mode)
+                                                GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
 {
-    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list, snp_mode);
+    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list);
 }
-__global__ void __launch_bounds__(64) MTG_STAGE_A_ATTR k_stage_a_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
-                                                const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
-                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                                GapOut* out, uint32_t n, uint32_t cset)
-{
-    stage_a_lane<WALK_CLASSIC>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, nullptr, 0, -1, 0);
-}
-/* ---- the rounds between two launches of the walk kernel: the branching nodes of the parked gaps, answered on their own.
- * k_bubble: a group of G lanes per gap of list `in_list`, frontier expansion and path enumeration from LDS (mtg_bubble.h); a bubble that does
- * not fit the LDS areas sends its gap to list in_list + 1, where k_bubble_classic answers it with one lane from HBM scratch. */
-#ifndef MTG_BUBBLE_WAVES
-#define MTG_BUBBLE_WAVES 4
-#endif
-template <int G>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_BUBBLE_WAVES))) k_bubble(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
-{
-    __shared__ BubbleLds lds[64 / G];
-    const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1);
-    const uint32_t t = blockIdx.x * (64u / (uint32_t)G) + lane / (uint32_t)G;
-    if (t >= park->count[in_list]) return;
-    const Index& ix = c_ix[cset];
-    const FillCfg& cfg = c_cfg[cset];
-    const uint32_t slot = park_list(park, cap, in_list)[t];
-    GapScratch S = carve(cfg, zero, raw, ilv, slot);
-    S.snp_fast = 1; /* the strict SNP pattern is answered by the fast path here as in the walk */
-    const bool done = bubble_coop<G>(ix, cfg, S, lds[lane / G]);
-    if (!done && gl == 0) park_list(park, cap, in_list + 1)[atomicAdd(&park->count[in_list + 1], 1u)] = slot;
-}
+/* ---- the rounds between two launches of the walk kernel: the branching nodes of the parked gaps, answered on their own, one lane per
+ * bubble from HBM scratch -- all 64 lanes of a wave are in the bubble code at the same time.  (k_bubble<G>, a group of G lanes per bubble with
+ * LDS work areas, was the alternative of round 3; it lost on the narrow bubbles of heterozygous data -- DESIGN.md section 4 -- and is gone.  The
+ * group form lives on where few gaps are in the bubble code: k_finish<G>.) */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_bubble_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,7 +196,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
  * form: nothing is copied, k_post and k_emit read the store)?  The gaps that do need their commands executed go on a work list (ballot +
  * prefix popcount, as for parking).  k_copy, one wave per listed gap, four per workgroup: the grid covers the launch (the host does not
  * know the count), a wave beyond the list leaves after one scalar read. */
-enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2, COPY_LIST_LATE = PARK_LISTS - 3 };
+enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2 };
 __global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
                                              const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
                                              uint32_t lean_allowed, uint32_t n, ParkCtl* park, uint32_t cap)
@@ -248,7 +222,7 @@ __global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw
 __global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap, uint32_t list)
 {
     const uint32_t count = park->count[list];
-    for (uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6); t < count; t += gridDim.x * 4u) { /* the grid usually covers the launch; a smaller one (the late list) loops */
+    for (uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6); t < count; t += gridDim.x * 4u) { /* the grid covers the launch */
         const uint32_t slot = park_list(park, cap, list)[t];
         GapScratch S;
         S.z = nullptr;
@@ -258,31 +232,6 @@ __global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* ra
         copy_cmds(ix, cfg, S, outs[slot]);
     }
 }
-/* The gaps the finishing kernel has walked while k_lean, k_copy and k_post_lean were busy with all the others (see device_run): their
- * records come over from the finishing kernel's own array, they are never lean (the general k_post / k_emit take them: k_lean has
- * listed them as such when it saw them parked), and the ones with copy commands go on the late list.  One gap per lane. */
-__global__ void __launch_bounds__(64) k_late(Index ix, FillCfg cfg, uint8_t* raw, GapOut* outs, const GapOut* __restrict__ finished, ParkCtl* park, uint32_t cap, uint32_t in_list)
-{
-    const uint32_t count = park->count[in_list];
-    for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) { /* the same trips for every lane of the wave: the append below is the wave's */
-        const uint32_t t = base + threadIdx.x;
-        bool need = false;
-        uint32_t slot = 0;
-        if (t < count) {
-            slot = park_list(park, cap, in_list)[t];
-            const GapOut o = finished[slot];
-            outs[slot] = o;
-            GapScratch S;
-            S.z = nullptr;
-            S.v = nullptr;
-            S.lane = 0;
-            S.r = raw + (uint64_t)slot * cfg.raw_stride;
-            need = lean_decide(ix, cfg, S, o, ~0ull); /* no target: not lean; true when there are commands to execute */
-        }
-        park_append(park, cap, COPY_LIST_LATE, need, slot);
-    }
-}
-
 /* mtg_fill_text: a batch whose strings are still text (mtg_marshal.h).  One gap per thread: source k-mer, packed pattern, its first k-mer,
  * whether the fast forms apply; one dictionary entry per thread: little-endian k-mer and never-match mask.  The reads are a few dozen bytes
  * per thread at unrelated places of the block: 100 000 gaps take some tens of microseconds, against 1-2 ms of two host threads. */
@@ -705,7 +654,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf(), d_out2 = wsbuf();
+          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
@@ -831,7 +780,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
         HIP_TRY(d_ilv.alloc(((chunk + 63) / 64) * cfg.ilv_stride));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
-        HIP_TRY(d_out2.alloc(chunk * sizeof(GapOut))); /* where the finishing kernel leaves its records while the other gaps are post-processed */
         HIP_TRY(d_rec.alloc(chunk * sizeof(SlotRec)));
         HIP_TRY(d_ids.alloc(chunk * 4));
         HIP_TRY(d_blocks.alloc(((chunk + SCAN_SL - 1) / SCAN_SL + 1) * sizeof(ScanBlock)));
@@ -873,7 +821,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             std::unique_lock<std::mutex> traversal_lock(traversal_mtx[(unsigned)idx->device % CopyTurn::MAX_DEV][cset]);
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
-            const bool classic_walk = tune::on(tune::T_CLASSIC_WALK); /* A/B hook: every bubble by its lane, from HBM scratch */
             /* lanes per parked gap: 1, 8, 16 or 64 (anything else, a typo included, is 16) */
             const bool finish_g_set = tune::is_set(tune::T_FINISH_G);
             const int finish_g = [] { const int v = (int)tune::i(tune::T_FINISH_G, 16); return (v == 1 || v == 8 || v == 16 || v == 64) ? v : 16; }();
@@ -883,96 +830,54 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
              * rounds; what is still parked then (and everything, when few gaps park) is finished by groups in k_finish.  The host does not
              * know the counts when it queues the kernels: the number of rounds follows the share of gaps the previous launch of this workspace parked
              * (a workspace without a launch yet: the latest figure of any workspace of the index). */
-            /* Walk mode of the launch.  0 (always, unless forced): the walking lane answers the strict SNP pattern itself.  1 (MTG_PARK_SNP=1, an A/B
-             * hook): it parks there as well and the bubble kernel of the rounds answers it with the same fast path for all parked gaps at once --
-             * built because the lanes of a wave meet their SNPs at different steps, and on the heterozygous set a wave spends four times as long
-             * in bubble code run by a few lanes at a time as on walking.  Measured and not used: every resumed launch of the walk kernel costs
-             * 45 us however short its segments (human-het: 7 launches 0.33 ms + bubble kernels 0.5 ms against 0.40 + 0.19 ms; 99 against 103 M/s),
-             * the first bubble kernel waits for the launch's hundred general bubbles anyway, and a set with indels needs more rounds than it has
-             * (25 against 33 M/s); choosing between the modes from the launches' own times picked the wrong one under six batches in flight. */
-            const int env_park_snp = (int)tune::i(tune::T_PARK_SNP, 0);
-            const bool whole = tier == 0 && identity && m >= 4096;
-            const int wmode = (env_park_snp > 0 && !classic_walk) ? 1 : 0;
-            const uint32_t own_share = wmode ? ws.mode_share[1] : (ws.mode_share[0] != ~0u ? ws.mode_share[0] : ws.park_share);
-            const uint32_t park_share = own_share != ~0u ? own_share : (wmode ? 65536u : idx->park_share_any.load(std::memory_order_relaxed));
+            const uint32_t park_share = ws.park_share != ~0u ? ws.park_share : idx->park_share_any.load(std::memory_order_relaxed);
             const uint32_t park_hint = (uint32_t)(((uint64_t)park_share * m) >> 16); /* gaps this launch is expected to park */
             int rounds = env_rounds >= 0 ? env_rounds : (park_share > 32768u ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
             if (rounds > (PARK_LISTS - 5) / 2) rounds = (PARK_LISTS - 5) / 2;
             ParkCtl* const park = d_park.as<ParkCtl>();
-            bool overlap_finish = false;
-            uint32_t late_list = 0, late_grid = 1;
             HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
-            if (classic_walk) {
-                hipLaunchKernelGGL(k_stage_a_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset);
-                HIP_TRY(hipEventRecord(evf, stream));
-            } else {
+            {
                 hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u, wmode ? 2u : 1u);
+                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
                 HIP_TRY(hipEventRecord(evf, stream));
                 const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
-                /* FINISH_OVERLAP of the tuning table (A/B, off).  Without rounds the finishing kernel is the latency of a few parked walks (0.06 ms for two
-                 * gaps of a haploid batch, 0.22 ms for the hundred of the SNP set) on an otherwise idle device: it can run on the workspace's second
-                 * stream, writing its records to an array of its own, while k_lean, k_copy and k_post_lean take all the other gaps on the batch's
-                 * stream; k_late then brings the finished gaps over, and the general k_post (which k_lean has listed them for when it saw them parked)
-                 * follows on that stream.  Measured (scripts/r4_streams.sh): one batch alone 0.360 -> 0.337 ms (haploid), 0.836 -> 0.811 (SNP set) --
-                 * the general k_post of the finished gaps still follows the finishing kernel -- and with six batches in flight NOT faster (sequences
-                 * left in HBM 346 -> 341, 105 -> 107, 123 -> 122 M/s): other batches' kernels fill the device while one batch waits, and the extra
-                 * kernels and events cost what the overlap saves.  The same holds for the general k_post next to the lean one (POST_SECOND_STREAM). */
-                overlap_finish = rounds == 0 && !skip_finish && ws.copy_stream && tune::on(tune::T_FINISH_OVERLAP);
-                const hipStream_t fstream = overlap_finish ? (hipStream_t)ws.copy_stream : stream;
-                GapOut* const fin_out = overlap_finish ? d_out2.as<GapOut>() : d_out.as<GapOut>();
-                if (overlap_finish) HIP_TRY(hipStreamWaitEvent(fstream, evf, 0));
-                /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with small bubbles that
-                 * keeps more of them in flight than a group of lanes per bubble does (MTG_BUBBLE_GROUPS=1: k_bubble<G>, the LDS form, first) */
-                const bool one_lane_bubbles = !tune::on(tune::T_BUBBLE_GROUPS);
+                /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with the narrow bubbles of
+                 * heterozygous data that keeps more of them in flight than a group of lanes per bubble does (round 3 measured the LDS group form
+                 * k_bubble<G> here: 20-22 against 25 M/s on the indel set, 51 against 63 on tips; removed in round 5) */
                 for (int r = 0; r < rounds; r++) {
                     const uint32_t lin = 2u * (uint32_t)r;
-                    if (one_lane_bubbles) {
-                        hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin);
-                        hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                           d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2, wmode ? 2u : 1u);
-                        continue;
-                    }
-                    switch (finish_g) {
-                        case 8: hipLaunchKernelGGL(k_bubble<8>, dim3((m + 7) / 8), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
-                        case 64: hipLaunchKernelGGL(k_bubble<64>, dim3(m), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
-                        default: hipLaunchKernelGGL(k_bubble<16>, dim3((m + 3) / 4), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin); break;
-                    }
-                    hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin + 1);
+                    hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin);
                     hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
-                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2, wmode ? 2u : 1u);
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
                 }
                 const uint32_t lfin = 2u * (uint32_t)rounds;
-                /* how the tail is finished: a group of lanes per parked gap, bubbles from LDS.  One lane per gap (MTG_FINISH_G=1, or below
-                 * MTG_FINISH_LANE_BELOW parked gaps in the workspace's previous launch) was measured and is slower at every size: 0.11 against
-                 * 0.10 ms for the haploid set's 1-5 gaps, 0.83 against 0.35 for 108 (heterozygous SNPs), 1.12 against 0.56 for 12 000 (tips). */
-                const int finish_lane_below = (int)tune::i(tune::T_FINISH_LANE_BELOW, 0);
+                /* how the tail is finished: a group of lanes per parked gap, bubbles from LDS.  One lane per gap (MTG_FINISH_G=1) was measured and is
+                 * slower at every size: 0.11 against 0.10 ms for the haploid set's 1-5 gaps, 0.83 against 0.35 for 108 (heterozygous SNPs), 1.12
+                 * against 0.56 for 12 000 (tips). */
                 /* lanes per parked gap in the finishing kernel: a whole wave while few gaps are parked (their chains are what the kernel takes:
                  * 0.17 against 0.32 ms for the 108 gaps of the heterozygous set), 16 when there are many (12 000 on the tips set: 0.46 against 0.63) */
                 const int finish_wave_below = (int)tune::i(tune::T_FINISH_WAVE_BELOW, 2048);
                 const int fin_g = finish_g_set ? finish_g : (rounds == 0 && park_hint < (uint32_t)finish_wave_below ? 64 : 16);
-                const bool lane_finish = (finish_g_set && finish_g == 1) || (!finish_g_set && rounds == 0 && park_hint < (uint32_t)finish_lane_below);
+                const bool lane_finish = finish_g_set && finish_g == 1;
                 /* The grid.  The host does not know how many gaps are parked when it queues the kernel, and 100 000 groups that read one
                  * scalar and leave cost 63 us (round 3: 13 % of a haploid batch's kernels, for 5 parked gaps).  So the groups take the first
                  * `fin_entries` entries of the list -- four times what the previous launch of this workspace parked, plus 256 -- and the
                  * entries beyond, if a launch parks more than that after all, are walked one gap per lane (k_finish_lane, a grid of
                  * (m - fin_entries) / 64 workgroups: slower per gap, but only for the launch that outgrew the hint; the next one follows). */
-                const bool finish_full_grid = tune::on(tune::T_FINISH_FULL_GRID); /* A/B hook: one group per gap of the launch, as in round 3 */
-                const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (finish_full_grid ? m : (uint32_t)std::min<uint64_t>(m, 4ull * park_hint + 256ull));
                 const uint32_t per_wg = 64u / (uint32_t)fin_g;
+                /* whole workgroups: k_finish<G> is bounded by the list's count only, so the entries it takes and those k_finish_lane starts from must
+                 * meet at a multiple of per_wg (the advisor's round-4 finding: G = 8 with an odd hint walked four entries twice) */
+                const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (uint32_t)std::min<uint64_t>(m, ((4ull * park_hint + 256ull + per_wg - 1) / per_wg) * per_wg);
                 const uint32_t nwg = (fin_entries + per_wg - 1) / per_wg;
                 if (!skip_finish && nwg) switch (fin_g) {
-                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin); break;
-                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin); break;
-                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin); break;
+                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                 }
                 if (!skip_finish && fin_entries < m)
-                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, fstream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, fin_out, cset, park, m, lfin, fin_entries);
-                late_list = lfin;
-                late_grid = (uint32_t)std::min<uint64_t>((m + 63) / 64, (4ull * park_hint + 256ull + 63) / 64);
-                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, fstream)); /* how many were parked: statistics, and the hint for the next launch */
+                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries);
+                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, stream)); /* how many were parked: statistics, and the hint for the next launch */
 #ifdef MTG_BUBBLE_TIMING
                 {
                     static ParkCtl hc; static int shown = 0;
@@ -987,7 +892,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
 #endif
             }
-            HIP_TRY(hipEventRecord(ev1, overlap_finish ? (hipStream_t)ws.copy_stream : stream)); /* the end of the walks: of the finishing kernel, wherever it ran */
+            HIP_TRY(hipEventRecord(ev1, stream)); /* the end of the walks */
             HIP_TRY(hipEventRecord(evl0, stream));
             HIP_TRY(hipGetLastError());
             /* evl0 .. evc: the long runs of the contigs, which the traversal only noted down */
@@ -1001,31 +906,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* the lean gaps eight per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
              * listed, plus 1024 (a workspace without a launch yet: one per gap), the kernel's loop takes the rest */
             const uint32_t general_hint = ws.post_general == ~0u ? m : (uint32_t)std::min<uint64_t>(m, 4ull * ws.post_general + 1024ull);
-            /* The general form is the latency of a few long gaps (30 us for the one or two of a haploid batch), the lean form the throughput of
-             * all the others: they touch different slots and CAN run next to each other (POST_SECOND_STREAM of the tuning table: 9 us shorter for
-             * one batch alone, 346 against 355 M/s with six in flight -- one stream per batch is the default). */
-            const hipStream_t side = (ws.copy_stream && (overlap_finish || tune::on(tune::T_POST_SECOND_STREAM))) ? (hipStream_t)ws.copy_stream : stream;
-            if (overlap_finish) {
-                /* the second stream has the finishing kernel in it: the finished gaps' records, their copy commands, then (below) the general k_post,
-                 * which also needs what k_lean and k_copy have done for the other listed gaps on the batch's stream (evc) */
-                hipLaunchKernelGGL(k_late, dim3(late_grid), dim3(64), 0, side, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_out2.as<GapOut>(), park, m, late_list);
-                hipLaunchKernelGGL(k_copy, dim3(late_grid * 16u), dim3(256), 0, side, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m, (uint32_t)COPY_LIST_LATE);
-                HIP_TRY(hipStreamWaitEvent(side, evc, 0));
-            } else if (side != stream) {
-                hipEvent_t ev_fork;
-                HIP_TRY(events.make(ev_fork));
-                HIP_TRY(hipEventRecord(ev_fork, stream));
-                HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
-            }
-            hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, side, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
+            /* The general form is the latency of a few long gaps (30 us for the one or two of a haploid batch), the lean form the throughput of all
+             * the others.  Both on the batch's one stream: the general form next to the lean one on a second stream, and the finishing kernel there as
+             * well, were built and measured in round 4 (9 and 25 us shorter for one batch alone, no faster with six in flight) and removed in round 5. */
+            hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park);
             hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
-            if (side != stream) {
-                hipEvent_t ev_join;
-                HIP_TRY(events.make(ev_join));
-                HIP_TRY(hipEventRecord(ev_join, side));
-                HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
-            }
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16, stream)); /* the dense arrays hold one launch at a time; the two arenas the whole batch */
             hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
             hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());
@@ -1185,13 +1071,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
             HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
             st.finish_kernel_ms += msf;
-            if (!classic_walk) { const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot)); st.n_parked_gaps += np; st.n_rounds += (uint64_t)rounds; if (tier == 0 && identity && m >= 64) {
+            {
+                const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot));
+                st.n_parked_gaps += np;
+                st.n_rounds += (uint64_t)rounds;
+                if (tier == 0 && identity && m >= 64) { /* the share of gaps this launch parked: how the workspace's next launch serves its parked gaps */
                     const uint32_t share = (uint32_t)std::min<uint64_t>(((uint64_t)np << 16) / m, 65536u);
-                    ws.mode_share[wmode] = share;
-                    if (!wmode) { ws.park_share = share; idx->park_share_any.store(share, std::memory_order_relaxed); }
-                    if (whole) { ws.mode_ns_per_gap[wmode] = ms * 1e6f / (float)m; ws.mode_launches++; } /* ev0 .. ev1: the walk, its rounds and the finishing kernel (with whatever else the device was doing: the launches of a workspace see the same company) */
-                } }
-            HIP_TRY(hipEventElapsedTime(&msc, evl0, evc)); /* k_lean + k_copy; when the finishing kernel runs on the second stream they start behind the walk kernel, next to it */
+                    ws.park_share = share;
+                    idx->park_share_any.store(share, std::memory_order_relaxed);
+                }
+            }
+            HIP_TRY(hipEventElapsedTime(&msc, evl0, evc)); /* k_lean + k_copy */
             { float msl = 0; HIP_TRY(hipEventElapsedTime(&msl, evl0, evl)); st.lean_kernel_ms += msl; }
             HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
             st.copy_kernel_ms += msc;

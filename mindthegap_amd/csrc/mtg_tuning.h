@@ -37,16 +37,9 @@
     X(LEGACY_BUILD, "", "ab", "the index construction of rounds 1-3 (dense tables first, then unitigs) instead of the lean build") \
     X(DENSE_INDEX, "", "test", "keep the dense ADJ / ABND tables (every junction, every k-mer) instead of the sparse form") \
     X(NO_UNITIGS, "", "test", "an index without unitig store (inline lookaheads only)") \
-    X(CLASSIC_WALK, "", "ab", "every bubble by its walking lane from HBM scratch (the round-2 kernel)") \
     X(ROUNDS, "", "ab", "bubble rounds between launches of the walk kernel (default: 6 when most gaps of the previous launch parked, else 0)") \
     X(FINISH_G, "", "ab", "lanes per parked gap in the finishing kernel: 1, 8, 16 or 64 (default: 64 while few gaps park, 16 otherwise)") \
     X(FINISH_WAVE_BELOW, "2048", "ab", "a whole wave per parked gap while the previous launch parked fewer gaps than this") \
-    X(FINISH_LANE_BELOW, "0", "ab", "one lane per parked gap below this many parked gaps (measured slower at every size: 0)") \
-    X(FINISH_FULL_GRID, "", "ab", "the finishing kernel with one group per gap of the launch (round 3) instead of a grid sized from the previous launch's parked gaps") \
-    X(BUBBLE_GROUPS, "", "ab", "the rounds' bubbles by k_bubble<G> (LDS form) before the one-lane form") \
-    X(PARK_SNP, "", "ab", "the walk kernel parks at SNP bubbles too and the bubble kernel answers them (measured and not used)") \
-    X(POST_SECOND_STREAM, "", "ab", "the general form of k_post next to the lean one on the workspace's second stream (9 us shorter for one batch alone, no faster with six in flight: measured and not used)") \
-    X(FINISH_OVERLAP, "", "ab", "the finishing kernel on the second stream next to k_lean, k_copy and k_post_lean, its gaps brought over by k_late (25 us shorter for one batch alone, slower with six in flight: measured and not used)") \
     X(NO_LEAN, "", "test", "every contig is materialised (no lean gaps)") \
     X(NO_DEFER, "", "test", "the lanes of the traversal copy their long runs themselves (no copy commands, no k_copy work)") \
     X(MAX_CHUNK, "", "test", "gaps per traversal launch (default: what the scratch holds): several launches per batch") \

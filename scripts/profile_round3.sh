@@ -30,7 +30,5 @@ MTG_BENCH_FORCE_GATHER=1 timeout 600 python bench.py $B > $O/dry_one_rank_rccl.j
  unset MTG_POOL_THREADS
  cat /sys/fs/cgroup/cpu.max 2>/dev/null
 } > $O/host_threads.txt 2>&1
-MODES="classic g16r0 or6 auto" scripts/r3_finish.sh $T/modes human-indel human-tips human-het > /dev/null 2>&1; cp $O/modes/summary.txt $O/walk_modes.txt; rm -rf $O/modes
-HET=1 INDEL=1 MODES="classic or6 g16r3" scripts/r3_alone.sh $T/alone > /dev/null 2>&1; cp $O/alone/alone_summary.txt $O/walk_modes_one_batch_alone_indel.txt; rm -rf $O/alone
 timeout 2400 python -u -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error|human-scale index|config 4" | tail -n 8 > $O/gpu_tests.txt
 tail -c 300 $O/bench_default.json; echo; cat $O/bench_default_wall.txt $O/host_threads.txt; grep -E "k_stage_a|k_finish|k_bubble|k_copy|k_post|k_emit|k_scan|k_marshal" $O/kernel_stats_one_batch_in_flight.csv | cut -c1-160

@@ -5,6 +5,7 @@
 #ifndef MTG_EMU_US_H
 #define MTG_EMU_US_H
 #include "../../mindthegap_amd/csrc/mtg_hostutil.h"
+#include "../../mindthegap_amd/csrc/mtg_build.h"
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -185,33 +186,50 @@ inline EmuLeanStats emu_build_lean(mtg::Index& ix, EmuUStore& st, const uint64_t
     AbFromTable src;
     src.abnd = abnd;
     const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
-    unsigned long long counters[JT_C_N] = {0};
+    unsigned long long counters[JT_C_N + 2] = {0};
     uint32_t lines = 0;
-    JtAcc acc{};
-    for (uint64_t s = 0; s < nslots; s++) {
-        uint64_t J;
-        const uint32_t m = jt_slot_key(jt, s, J);
-        if (m) jt_scan_entry(jt, k, J, m, src, acc, counters, (uint64_t*)nullptr, 0ull, (uint64_t*)nullptr, (uint32_t*)nullptr, 0ull, lines);
+    /* the bucket-wise decoding of the scan against the slot-wise one it replaced (every occupied slot) */
+    for (uint64_t b = 0; b < jt.nbuckets; b++) {
+        const uint64_t first = bucket_first_h(b, jt.nbuckets, jt.key_bits);
+        for (int i = 0; i < MTG_ABND_SLOTS; i++) {
+            const uint64_t v = jt.slots[b * MTG_ABND_SLOTS + i];
+            if (!v) continue;
+            uint64_t j1, j2;
+            const uint32_t m1 = jt_slot_key(jt, b * MTG_ABND_SLOTS + i, j1), m2 = slot_key_in_bucket(jt, b, first, v, j2);
+            if (m1 != m2 || j1 != j2) abort();
+        }
     }
+    /* as build_from_jt: ONE pass with lists of guessed capacity -- here a guess that is too small for all but the smallest graphs, so that the
+     * second pass with the exact sizes is what most tests run -- statistics, chain starts, k-mers of no chain */
+    JtAcc acc{};
+    uint64_t cap_starts = 4, cap_left = 2, n_starts = 0, n_single = 0;
+    std::vector<uint64_t> starts, lk;
+    std::vector<uint32_t> la;
+    for (int pass = 0; pass < 2; pass++) {
+        starts.assign(cap_starts + 1, 0); lk.assign(cap_left + 1, 0); la.assign(cap_left + 1, 0);
+        acc = JtAcc{};
+        memset(counters, 0, sizeof counters);
+        for (uint64_t b = 0; b < jt.nbuckets; b++) jt_scan_bucket(jt, k, b, src, acc, counters, starts.data(), cap_starts, lk.data(), la.data(), cap_left, lines);
+        n_starts = counters[JT_C_STARTS]; n_single = counters[JT_C_LEFT];
+        if (n_starts <= cap_starts && n_single <= cap_left) break;
+        if (pass) abort();
+        cap_starts = n_starts; cap_left = n_single;
+    }
+    lk.resize(n_single); la.resize(n_single);
     out.nb_solid = (acc.c[JT_C_ORIENTED] + acc.c[JT_C_SELF]) / 2;
     out.nb_branching = (2 * acc.c[JT_C_IN_NOT1] - acc.c[JT_C_BOTH_NOT1] + acc.c[JT_C_SELF_BRANCH]) / 2;
     const uint64_t interior = acc.c[JT_C_INTERIOR];
-    std::vector<uint64_t> starts(counters[JT_C_STARTS] + 1), lk(counters[JT_C_LEFT]);
-    std::vector<uint32_t> la(counters[JT_C_LEFT]);
-    const uint64_t n_starts = counters[JT_C_STARTS], n_single = counters[JT_C_LEFT];
-    counters[JT_C_STARTS] = counters[JT_C_LEFT] = 0;
-    JtAcc acc2{};
-    for (uint64_t s = 0; s < nslots; s++) {
-        uint64_t J;
-        const uint32_t m = jt_slot_key(jt, s, J);
-        if (m) jt_scan_entry(jt, k, J, m, src, acc2, counters, starts.data(), n_starts, lk.data(), la.data(), n_single, lines);
-    }
-    if (counters[JT_C_STARTS] != n_starts || counters[JT_C_LEFT] != n_single) abort();
     counters[JT_C_SAT] = 0; /* the source holds stored (clamped) abundances: those above 255 were counted at insertion */
     std::vector<UsRec> recs(n_starts / 2 + 1);
-    for (uint64_t i = 0; i < n_starts; i++) jt_plan_start(jt, k, make_kmer(starts[i], k), counters, recs.data(), recs.size(), lines);
+    std::vector<uint64_t> rec_chunk(recs.size(), ~0ull);
+    ChunkPool pool{};
+    pool.cap_chunks = chunk_pool_need(interior + n_starts, n_starts, k);
+    std::vector<uint64_t> pool_words(pool.cap_chunks * MTG_CHUNK_WORDS, 0xDEADDEADDEADDEADull);
+    pool.words = pool_words.data();
+    pool.cursor = &counters[JT_C_N];
+    for (uint64_t i = 0; i < n_starts; i++) jt_plan_emit_start(jt, k, make_kmer(starts[i], k), pool, counters, recs.data(), rec_chunk.data(), recs.size(), lines);
     const uint64_t n_rec = counters[JT_C_RECS], cw = counters[JT_C_WORDS];
-    if (n_rec > recs.size()) abort();
+    if (n_rec > recs.size() || counters[JT_C_N] > pool.cap_chunks) abort();
     recs.resize(n_rec);
     ix.us = UStore{};
     if (n_rec) {
@@ -221,7 +239,21 @@ inline EmuLeanStats emu_build_lean(mtg::Index& ix, EmuUStore& st, const uint64_t
         ix.us.ab = st.ab.data();
         ix.us.nwords = cw;
         ix.us.nunitigs = n_rec;
-        for (const UsRec& r : recs) jt_emit(jt, ix.us, k, r, lines);
+        for (uint64_t u = 0; u < n_rec; u++) {
+            const UsRec& r = recs[u];
+            if (!us_compact(ix.us, k, r, rec_chunk[u], pool, 0, 1)) abort();
+            /* the words the chunks brought against a second walk of the chain (what round 4's separate emit pass wrote) */
+            std::vector<uint32_t> nts;
+            for (int i = k - 1; i >= 0; i--) nts.push_back((uint32_t)(r.start_f >> (2 * i)) & 3u);
+            Kmer end;
+            if (jt_walk(jt, k, make_kmer(r.start_f, k), end, lines, [&](uint32_t c) { nts.push_back(c); }) != r.len_k) abort();
+            if (ix.us.words[r.hdr] != (uint64_t)r.len_k + (uint32_t)k - 1 || nts.size() != (size_t)r.len_k + (size_t)k - 1) abort();
+            for (size_t i = 0; i < nts.size(); i += 32) {
+                uint64_t w = 0;
+                for (size_t j = i; j < nts.size() && j < i + 32; j++) w |= (uint64_t)nts[j] << (2 * (j - i));
+                if (ix.us.words[r.hdr + 1 + i / 32] != w) abort();
+            }
+        }
         for (const UsRec& r : recs)
             for (uint32_t i = 0; i < r.len_k; i++) us_ab_fill(ix.us, k, r, i, src, lines);
     }

@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "emu", "emu.cpp")
 SO = os.path.join(ROOT, "tests", "emu", "libmtg_emu.so")
-HDRS = [os.path.join(ROOT, "mindthegap_amd", "csrc", h) for h in ("mtg_dev.h", "mtg_traverse.h", "mtg_bubble.h", "mtg_post.h", "mtg_paths.h", "mtg_emit.h", "mtg_copy.h", "mtg_marshal.h", "mtg_format.h", "mtg_tuning.h", "mtg_hostutil.h")] + [os.path.join(ROOT, "tests", "emu", h) for h in ("emu_us.h", "emu_walk.h")]
+HDRS = [os.path.join(ROOT, "mindthegap_amd", "csrc", h) for h in ("mtg_dev.h", "mtg_build.h", "mtg_traverse.h", "mtg_bubble.h", "mtg_post.h", "mtg_paths.h", "mtg_emit.h", "mtg_copy.h", "mtg_marshal.h", "mtg_format.h", "mtg_tuning.h", "mtg_hostutil.h")] + [os.path.join(ROOT, "tests", "emu", h) for h in ("emu_us.h", "emu_walk.h")]
 
 # MTG_EMU_SANITIZE=1: build the emulation libraries with AddressSanitizer + UBSan (run pytest with LD_PRELOAD=$(gcc -print-file-name=libasan.so))
 SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-O1"] if os.environ.get("MTG_EMU_SANITIZE") else []

@@ -758,11 +758,10 @@ def test_first_stage_a_batch_larger_than_the_initial_dense_arrays(mtg):
 
 LAUNCH_SEQUENCES = [
     {"MTG_ROUNDS": "6"},                                   # six rounds of bubble kernel (one lane per bubble) + resumed walks, then the finishing kernel
-    {"MTG_ROUNDS": "3", "MTG_BUBBLE_GROUPS": "1"},         # rounds with the LDS group form k_bubble<16> first
+    {"MTG_ROUNDS": "3", "MTG_FINISH_G": "16"},             # three rounds, the tail by k_finish<16>
     {"MTG_ROUNDS": "0", "MTG_FINISH_G": "64"},             # every parked gap straight to k_finish<64>
-    {"MTG_ROUNDS": "0", "MTG_FINISH_G": "16", "MTG_FINISH_FULL_GRID": "1"},  # k_finish<16>, one group per gap of the launch (the grid of round 3)
+    {"MTG_ROUNDS": "0", "MTG_FINISH_G": "8"},              # k_finish<8>: the grid's whole workgroups and k_finish_lane's first entry must meet (round-4 advisor)
     {"MTG_FINISH_G": "1"},                                 # one lane per parked gap (k_finish_lane)
-    {"MTG_CLASSIC_WALK": "1"},                             # the round-2 kernel: every bubble by its walking lane
 ]
 
 
@@ -770,8 +769,7 @@ LAUNCH_SEQUENCES = [
 @pytest.mark.parametrize("seq", LAUNCH_SEQUENCES, ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_bubble_tests_under_every_launch_sequence(seq):
     """the walk / bubble / finishing kernels are chosen per launch from what the previous launch parked; every sequence the library can
-    queue -- rounds with either bubble kernel, the finishing kernel with 16 or 64 lanes per gap or one, its grid sized from the hint or for
-    the worst case, the round-2 kernel -- must give the oracle's contigs and files on the tests whose walks cross bubbles.  The switches
+    queue -- rounds of bubble kernel and resumed walks, the finishing kernel with 8, 16 or 64 lanes per gap or one -- must give the oracle's contigs and files on the tests whose walks cross bubbles.  The switches
     are read once per process: each sequence runs the selected tests in a process of its own."""
     env = dict(os.environ, **seq)
     sel = "fuzz_on_device or adversarial or diploid or allelic or tier_retry or golden or synthetic_sites"
