@@ -377,7 +377,9 @@ size_t mtg_tuning_count(void);
 int mtg_tuning_describe(size_t i, const char** name, const char** dflt, const char** kind, const char** what);
 /* the current value of an entry, "" when it is not set; MTG_ERR_ARG: no such entry, or cap too small */
 int mtg_tuning_get(const char* name, char* value, size_t cap);
-/* value NULL or "": "not set" -- overriding the environment and the default (to return to the default, set the default string) */
+/* value NULL or "": "not set" -- overriding the environment and the default (to return to the default, set the default string).  A flag
+ * ("" by default) is ON for any value but "0": NAME=0 leaves it off.  An environment variable set to the empty string switches a flag on and
+ * leaves a number unset. */
 int mtg_tuning_set(const char* name, const char* value);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -1394,6 +1394,7 @@ void index_release(mtg_index* idx)
     for (Workspace& w : idx->ws) {
         for (int i = 0; i < Workspace::NSLOTS; i++) if (w.ptr[i]) (void)hipFree(w.ptr[i]);
         for (int i = 0; i < Workspace::NHOST; i++) if (w.hptr[i]) (void)hipHostFree(w.hptr[i]);
+        for (int i = 0; i < Workspace::NEVENTS; i++) if (w.events[i]) (void)hipEventDestroy((hipEvent_t)w.events[i]);
         if (w.stream) (void)hipStreamDestroy((hipStream_t)w.stream);
         if (w.copy_stream) (void)hipStreamDestroy((hipStream_t)w.copy_stream);
     }

@@ -438,18 +438,20 @@ __global__ void __launch_bounds__(SCAN_SL) k_scan1(SlotRec* recs, uint32_t m, Sc
     if (t < SCAN_NV) { uint64_t x = 0; for (int w2 = 0; w2 < NW; w2++) x += wtot[w2][t]; blocks[blockIdx.x].v[t] = x; }
     if (t < SCAN_NS) { unsigned long long x = 0; for (int w2 = 0; w2 < NW; w2++) x += wsum[w2][t]; blocks[blockIdx.x].s[t] = x; }
 }
-/* cursors[0..3]: words, metadata entries, sequence bytes, extension bytes of the batch so far */
-__global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nblocks, unsigned long long* cursors, PartTot* tot)
+/* begin.v[0..3]: words, metadata entries, sequence bytes, extension bytes of the batch so far (the host knows them: it has seen the previous
+ * launch's totals).  The totals go to the device copy k_emit reads AND straight into the host's page-locked copy (host_tot: a store over the
+ * link instead of a copy the host would have to queue), with the number of gaps the walk kernel parked. */
+struct ScanBegin { uint64_t v[4]; };
+__global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nblocks, ScanBegin begin, PartTot* tot, PartTot* host_tot, const ParkCtl* park)
 {
     enum { TILE = 1024 };
     __shared__ uint64_t sh[SCAN_NV][TILE];
     __shared__ uint64_t carry[SCAN_NV];
     __shared__ unsigned long long ssum[SCAN_NS];
     const uint32_t t = threadIdx.x;
-    if (t < SCAN_NV) carry[t] = t < 4 ? cursors[t] : 0;
+    if (t < SCAN_NV) carry[t] = t < 4 ? begin.v[t] : 0;
     if (t < SCAN_NS) ssum[t] = 0;
     __syncthreads();
-    if (t < 4) tot->begin[t] = carry[t];
     for (uint32_t b0 = 0; b0 < nblocks; b0 += TILE) {
         const uint32_t nb = nblocks - b0 < (uint32_t)TILE ? nblocks - b0 : (uint32_t)TILE;
         for (uint32_t i = t; i < nb * SCAN_NV; i += 256) sh[i % SCAN_NV][i / SCAN_NV] = blocks[b0 + i / SCAN_NV].v[i % SCAN_NV];
@@ -477,15 +479,21 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         for (uint32_t i = t; i < nb * SCAN_NV; i += 256) blocks[b0 + i / SCAN_NV].v[i % SCAN_NV] = sh[i % SCAN_NV][i / SCAN_NV];
         __syncthreads();
     }
-    if (t < 4) { tot->end[t] = carry[t]; cursors[t] = carry[t]; }
-    if (t == 0) {
-        tot->n_retry = (uint32_t)carry[4];
-        tot->n_general = (uint32_t)carry[5];
-        tot->lines = ssum[0]; tot->store_runs = ssum[1]; tot->run_nt = ssum[2]; tot->contig_nt = ssum[3]; tot->contig_words = ssum[4];
-        tot->post_lines = ssum[5]; tot->cov_kmers = ssum[6];
-        tot->n_filled = (uint32_t)ssum[7]; tot->n_ext = (uint32_t)ssum[8];
-        tot->copy_words = ssum[9]; tot->copy_cmds = ssum[10]; tot->cov_direct = ssum[11]; tot->n_lean = ssum[12];
-        tot->copy_words_exec = ssum[13]; tot->copy_cmds_exec = ssum[14]; tot->scan_words = ssum[15];
+    __syncthreads();
+    if (t == 0) { /* one thread, from the block's shared sums: the same record to the device's copy and to the host's */
+        PartTot pt;
+        for (int j = 0; j < 4; j++) { pt.begin[j] = begin.v[j]; pt.end[j] = carry[j]; }
+        pt.n_retry = (uint32_t)carry[4];
+        pt.n_general = (uint32_t)carry[5];
+        pt.lines = ssum[0]; pt.store_runs = ssum[1]; pt.run_nt = ssum[2]; pt.contig_nt = ssum[3]; pt.contig_words = ssum[4];
+        pt.post_lines = ssum[5]; pt.cov_kmers = ssum[6];
+        pt.n_filled = (uint32_t)ssum[7]; pt.n_ext = (uint32_t)ssum[8];
+        pt.copy_words = ssum[9]; pt.copy_cmds = ssum[10]; pt.cov_direct = ssum[11]; pt.n_lean = ssum[12];
+        pt.copy_words_exec = ssum[13]; pt.copy_cmds_exec = ssum[14]; pt.scan_words = ssum[15];
+        pt.n_parked = park ? park->count[0] : 0u;
+        pt.pad_ = 0;
+        *tot = pt;
+        if (host_tot) *host_tot = pt;
     }
 }
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
@@ -654,12 +662,24 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_cnt = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf();
+          d_dm = wsbuf(), d_combo = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
     const uint64_t n_targets = in.text_mode ? in.n_text_targets : in.traw.size() / TARGET_SLOT;
-    EventSet events;
+    /* the events of a batch belong to its workspace: made once (round 4 created and destroyed nine per batch: eighteen runtime calls of the ~50 a
+     * batch made, and the runtime serialises them across the caller threads) */
+    struct WsEvents {
+        Workspace& w;
+        int next = 0;
+        hipError_t make(hipEvent_t& e)
+        {
+            if (next >= Workspace::NEVENTS) return hipErrorOutOfMemory;
+            if (!w.events[next]) { hipEvent_t ne; const hipError_t r = hipEventCreateWithFlags(&ne, hipEventBlockingSync); if (r != hipSuccess) return r; w.events[next] = (void*)ne; }
+            e = (hipEvent_t)w.events[next++];
+            return hipSuccess;
+        }
+    } events{ws};
     hipStream_t up = (in.text_mode || !in.dev_a) ? upload_stream_of(idx->device) : nullptr;
     if (!up) up = stream;
     auto uploaded = [&]() -> int { /* the batch's stream goes on when its blocks have arrived */
@@ -727,25 +747,30 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     const uint8_t* d_fok = da + FillInput::off_a(n, 7);
     const uint8_t* d_flags = da + FillInput::off_a(n, 8);
     uint64_t* d_tbad = d_tle + n_targets;
-    HIP_TRY(d_cnt.alloc(64));
     HIP_TRY(d_tot.alloc(sizeof(PartTot)));
-    {
-        const unsigned long long init[8] = {0, 0, 0, 1 /* the extension arena starts with the empty string */, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(d_cnt.p, init, 64, hipMemcpyHostToDevice, stream)); /* pageable source: copied before the call returns */
-    }
+    /* where the batch's two arenas stand: sequence bytes and extension bytes so far (the extension arena starts with the empty string); the layout
+     * kernel gets them by value */
+    uint64_t arena_used[2] = {0, 1};
     st.h2d_ms += now_ms() - t0;
     tick("upload (async)");
 
-    hipEvent_t ev0, ev1, ev2, ev3, eve, evc, evf, evl, evl0;
-    HIP_TRY(events.make(eve));
-    HIP_TRY(events.make(evc));
+    /* ev0 .. ev2: the kernels of a launch, ev3: its results on the host.  KERNEL_TIMERS of the tuning table: the six events between the kernels as
+     * well (mtg_last_batch_stats then carries every kernel's own time: what bench.py's pass with one batch alone asks for); off, a batch records three
+     * events instead of nine and asks for one elapsed time instead of seven */
+    const bool ktimers = tune::on(tune::T_KERNEL_TIMERS);
+    hipEvent_t ev0, ev1 = nullptr, ev2, ev3, eve = nullptr, evc = nullptr, evf = nullptr, evl = nullptr, evl0 = nullptr;
     HIP_TRY(events.make(ev0));
-    HIP_TRY(events.make(ev1));
     HIP_TRY(events.make(ev2));
     HIP_TRY(events.make(ev3));
-    HIP_TRY(events.make(evf));
-    HIP_TRY(events.make(evl));
-    HIP_TRY(events.make(evl0));
+    if (ktimers) {
+        HIP_TRY(events.make(eve));
+        HIP_TRY(events.make(evc));
+        HIP_TRY(events.make(ev1));
+        HIP_TRY(events.make(evf));
+        HIP_TRY(events.make(evl));
+        HIP_TRY(events.make(evl0));
+    }
+    auto mark = [&](hipEvent_t e) -> hipError_t { return e ? hipEventRecord(e, stream) : hipSuccess; };
     PartTot* h_tot = (PartTot*)staging_host(&ws, Workspace::NHOST - 1, sizeof(PartTot) + 64);
     if (!h_tot) { set_error("no page-locked memory for the totals of a launch"); return MTG_ERR_NOMEM; }
 
@@ -783,12 +808,22 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_rec.alloc(chunk * sizeof(SlotRec)));
         HIP_TRY(d_ids.alloc(chunk * 4));
         HIP_TRY(d_blocks.alloc(((chunk + SCAN_SL - 1) / SCAN_SL + 1) * sizeof(ScanBlock)));
-        HIP_TRY(d_res.alloc(chunk * sizeof(mtg_gap_result)));
-        HIP_TRY(d_fil.alloc(chunk * sizeof(mtg_filled)));
+        /* ONE block [records | filled | sequence arena] when the host's result object is laid out the same way (ResultSink::combo): the results
+         * of a whole-batch launch then cross the link as one copy instead of three (round 4: 5.3 MB of a 12 500-gap batch in three copies came
+         * over at 42 GB/s, the 40 MB of a 100 000-gap batch at 54) */
+        const bool combo = want_records && sink.combo != nullptr && !sink.seq_dev && !sink.seq_on_device && !sink.seq_stays_in_workspace && !sink.wire_dev;
+        if (!combo) {
+            HIP_TRY(d_res.alloc(chunk * sizeof(mtg_gap_result)));
+            HIP_TRY(d_fil.alloc(chunk * sizeof(mtg_filled)));
+        }
         HIP_TRY(d_rlist.alloc(chunk * 4));
         HIP_TRY(d_glist.alloc(chunk * 4));
         HIP_TRY(d_park.alloc((size_t)chunk * 4 * PARK_LISTS + sizeof(ParkCtl)));
-        HIP_TRY(d_seq.grow_keeping(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64), sink.seq_dev ? 0 : (size_t)sink.seq_used)); /* a caller's device buffer is written in place; what an earlier tier left stays */
+        if (combo) HIP_TRY(d_combo.grow_keeping(sink.combo_off_seq + std::max<size_t>(sink.seq_cap, 64), sink.combo_off_seq + (size_t)sink.seq_used));
+        else HIP_TRY(d_seq.grow_keeping(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64), sink.seq_dev ? 0 : (size_t)sink.seq_used)); /* a caller's device buffer is written in place; what an earlier tier left stays */
+        auto p_res = [&]() { return combo ? (mtg_gap_result*)d_combo.p : d_res.as<mtg_gap_result>(); };
+        auto p_fil = [&]() { return combo ? (mtg_filled*)((char*)d_combo.p + sink.combo_off_fil) : d_fil.as<mtg_filled>(); };
+        auto p_seq = [&]() { return combo ? (char*)d_combo.p + sink.combo_off_seq : d_seq.as<char>(); };
         HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
         /* dense words / metadata: only the gaps that need the host bring their contigs back; sized by the last need, grown on demand below */
         HIP_TRY(d_dw.alloc(std::max<size_t>(ws.cap[d_dw.slot], 1 << 20)));
@@ -819,8 +854,19 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             static std::mutex traversal_mtx[CopyTurn::MAX_DEV][TRAVERSAL_SETS];
             const uint32_t cset = (uint32_t)(&ws - idx->ws);
             std::unique_lock<std::mutex> traversal_lock(traversal_mtx[(unsigned)idx->device % CopyTurn::MAX_DEV][cset]);
-            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
+            {   /* the set keeps what it was last given: batch after batch of one index at one tier upload nothing (two runtime calls per batch in round 4) */
+                struct Held { Index ix; FillCfg cfg; bool valid = false; };
+                static Held held[CopyTurn::MAX_DEV][TRAVERSAL_SETS];
+                Held& h = held[(unsigned)idx->device % CopyTurn::MAX_DEV][cset];
+                if (!h.valid || memcmp(&h.ix, &idx->dev, sizeof(Index)) != 0 || memcmp(&h.cfg, &cfg, sizeof(FillCfg)) != 0) {
+                    h.valid = false;
+                    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ix), &idx->dev, sizeof(Index), cset * sizeof(Index), hipMemcpyHostToDevice, stream));
+                    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cfg), &cfg, sizeof(FillCfg), cset * sizeof(FillCfg), hipMemcpyHostToDevice, stream));
+                    memcpy(&h.ix, &idx->dev, sizeof(Index));
+                    memcpy(&h.cfg, &cfg, sizeof(FillCfg));
+                    h.valid = true;
+                }
+            }
             /* lanes per parked gap: 1, 8, 16 or 64 (anything else, a typo included, is 16) */
             const bool finish_g_set = tune::is_set(tune::T_FINISH_G);
             const int finish_g = [] { const int v = (int)tune::i(tune::T_FINISH_G, 16); return (v == 1 || v == 8 || v == 16 || v == 64) ? v : 16; }();
@@ -840,7 +886,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             {
                 hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
                                    d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
-                HIP_TRY(hipEventRecord(evf, stream));
+                HIP_TRY(mark(evf));
                 const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with the narrow bubbles of
                  * heterozygous data that keeps more of them in flight than a group of lanes per bubble does (round 3 measured the LDS group form
@@ -877,7 +923,6 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
                 if (!skip_finish && fin_entries < m)
                     hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries);
-                HIP_TRY(hipMemcpyAsync((uint8_t*)h_tot + sizeof(PartTot), d_park.p, 8, hipMemcpyDeviceToHost, stream)); /* how many were parked: statistics, and the hint for the next launch */
 #ifdef MTG_BUBBLE_TIMING
                 {
                     static ParkCtl hc; static int shown = 0;
@@ -892,16 +937,16 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
 #endif
             }
-            HIP_TRY(hipEventRecord(ev1, stream)); /* the end of the walks */
-            HIP_TRY(hipEventRecord(evl0, stream));
+            HIP_TRY(mark(ev1)); /* the end of the walks */
+            HIP_TRY(mark(evl0));
             HIP_TRY(hipGetLastError());
             /* evl0 .. evc: the long runs of the contigs, which the traversal only noted down */
             const bool no_lean = tune::on(tune::T_NO_LEAN); /* A/B and test hook: every contig is materialised */
             hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
                                (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m, park, m);
-            HIP_TRY(hipEventRecord(evl, stream)); /* ev1 .. evl: k_lean; evl .. evc: k_copy */
+            HIP_TRY(mark(evl)); /* ev1 .. evl: k_lean; evl .. evc: k_copy */
             hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m, (uint32_t)COPY_LIST);
-            HIP_TRY(hipEventRecord(evc, stream));
+            HIP_TRY(mark(evc));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
             /* the lean gaps eight per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
              * listed, plus 1024 (a workspace without a launch yet: one per gap), the kernel's loop takes the rest */
@@ -912,17 +957,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park);
             hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
-            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 16, stream)); /* the dense arrays hold one launch at a time; the two arenas the whole batch */
+            /* the dense arrays hold one launch at a time; the two arenas the whole batch */
+            const ScanBegin sbegin{{0, 0, arena_used[0], arena_used[1]}};
             hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
-            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());
+            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, sbegin, d_tot.as<PartTot>(), h_tot, park);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(h_tot, d_tot.p, sizeof(PartTot), hipMemcpyDeviceToHost, stream));
             EmitDev D;
             EmitHost H;
             auto emit = [&]() -> int {
-                D.seq = sink.seq_dev ? sink.seq_dev : d_seq.as<char>(); D.ext = d_ext.as<char>();
+                D.seq = sink.seq_dev ? sink.seq_dev : p_seq(); D.ext = d_ext.as<char>();
                 D.seq_cap = sink.seq_cap; D.ext_cap = sink.ext_cap;
-                D.res = d_res.as<mtg_gap_result>(); D.fil = d_fil.as<mtg_filled>();
+                D.res = p_res(); D.fil = p_fil();
                 D.dense_words = d_dw.as<uint64_t>(); D.dense_meta = d_dm.as<uint32_t>();
                 D.dense_cap_words = ws.cap[d_dw.slot] / 8; D.dense_cap_contigs = ws.cap[d_dm.slot] / 20;
                 const bool want_wire = sink.wire_dev != nullptr && identity && tier == 0;
@@ -941,7 +986,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             };
             /* the results are written right away, on the assumption that the arenas are large enough (they are, from the second batch of a
              * shape on): the totals tell */
-            HIP_TRY(hipEventRecord(eve, stream));
+            HIP_TRY(mark(eve));
             if (int erc = emit()) return erc;
             HIP_TRY(hipEventRecord(ev2, stream));
             tick("host prep+launch");
@@ -957,9 +1002,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             if (want_records && tot.end[2] > sink.seq_cap) {
                 /* the block may move: what earlier launches of the batch left in it is kept, the records that point there follow */
                 const uintptr_t old = (uintptr_t)sink.seq, old_end = old + sink.seq_cap;
+                const uintptr_t old_fil = (uintptr_t)sink.fil, old_fil_end = old_fil + n * sizeof(mtg_filled);
                 if (!sink.grow_seq || !sink.grow_seq((size_t)tot.end[2], (size_t)tot.begin[2])) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)tot.end[2]); return MTG_ERR_ARG; }
-                if (tot.begin[2] > 0 && (uintptr_t)sink.seq != old)
+                if (launches > 1 && (uintptr_t)sink.seq != old)
                     for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.fil[i].seq; if (q >= old && q < old_end) sink.fil[i].seq = sink.seq + (q - old); }
+                /* the arena is part of one block with the records (ResultSink::combo): the filled records moved with it */
+                if (launches > 1 && (uintptr_t)sink.fil != old_fil)
+                    for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.res[i].filled; if (q >= old_fil && q < old_fil_end) sink.res[i].filled = (const mtg_filled*)((const char*)sink.fil + (q - old_fil)); }
                 again = true;
             }
             if (want_records && tot.end[3] > sink.ext_cap) {
@@ -976,14 +1025,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 /* what earlier launches of the batch left in the arena stays: when the text is formatted on the device the arena's only copy is this one
                  * (round 4: a batch of several launches lost the sequences of all but its last launch here -- the device formatter then wrote
                  * "_len_0" records; found by running the GPU tests under MAX_CHUNK) */
-                if (!sink.seq_dev) HIP_TRY(d_seq.grow_keeping(std::max<size_t>(sink.seq_cap, 64), (size_t)tot.begin[2]));
+                if (combo) HIP_TRY(d_combo.grow_keeping(sink.combo_off_seq + std::max<size_t>(sink.seq_cap, 64), sink.combo_off_seq + (size_t)tot.begin[2]));
+                else if (!sink.seq_dev) HIP_TRY(d_seq.grow_keeping(std::max<size_t>(sink.seq_cap, 64), (size_t)tot.begin[2]));
                 HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
                 HIP_TRY(d_dw.alloc(need_w));
                 HIP_TRY(d_dm.alloc(need_m));
                 /* k_emit made the records' offsets absolute: run the layout again from the launch's begin */
-                HIP_TRY(hipMemcpyAsync(d_cnt.p, tot.begin, 32, hipMemcpyHostToDevice, stream));
                 hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
-                hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, d_cnt.as<unsigned long long>(), d_tot.as<PartTot>());
+                hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, stream, d_blocks.as<ScanBlock>(), nblocks, sbegin, d_tot.as<PartTot>(), (PartTot*)nullptr, park);
                 if (int erc = emit()) return erc;
             }
             /* bring the launch's results to the host.  Result copies of six batches at once share the link worse than two or three do
@@ -991,22 +1040,24 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             CopyTurn copy_turn(idx->device);
             std::vector<mtg_gap_result> tmp_res;
             std::vector<mtg_filled> tmp_fil;
+            const bool one_copy = combo && identity && tot.begin[2] == 0; /* records, filled records and sequences of the launch: one block on both sides */
             if (want_records) {
-                if (identity) {
-                    HIP_TRY(hipMemcpyAsync(sink.res, d_res.p, (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
-                    HIP_TRY(hipMemcpyAsync(sink.fil, d_fil.p, (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
+                if (one_copy) HIP_TRY(hipMemcpyAsync(sink.combo, d_combo.p, sink.combo_off_seq + (size_t)tot.end[2], hipMemcpyDeviceToHost, stream));
+                else if (identity) {
+                    HIP_TRY(hipMemcpyAsync(sink.res, p_res(), (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(sink.fil, p_fil(), (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
                 } else {
                     tmp_res.resize(m);
                     tmp_fil.resize(m);
-                    HIP_TRY(hipMemcpyAsync(tmp_res.data(), d_res.p, (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
-                    HIP_TRY(hipMemcpyAsync(tmp_fil.data(), d_fil.p, (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(tmp_res.data(), p_res(), (size_t)m * sizeof(mtg_gap_result), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(tmp_fil.data(), p_fil(), (size_t)m * sizeof(mtg_filled), hipMemcpyDeviceToHost, stream));
                 }
                 /* a batch that left in relocatable form has its sequences in the payload's sequence section */
                 const WireLayout wl = wire_layout(m, tot.n_filled, tot.end[2], tot.end[3]);
                 const bool wired = sink.wire_dev != nullptr && identity && tier == 0 && wl.total <= sink.wire_cap && tot.n_retry == 0 && tot.n_general == 0;
                 if (sink.wire_dev && identity && tier == 0) { sink.wire_ok = wired; sink.wire_bytes = wired ? wl.total : 0; }
-                const char* seq_src = wired ? (const char*)sink.wire_dev + wl.o_seq : (sink.seq_dev ? sink.seq_dev : d_seq.as<char>());
-                if (!sink.seq_on_device && !sink.seq_stays_in_workspace && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], seq_src + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
+                const char* seq_src = wired ? (const char*)sink.wire_dev + wl.o_seq : (sink.seq_dev ? sink.seq_dev : p_seq());
+                if (!one_copy && !sink.seq_on_device && !sink.seq_stays_in_workspace && tot.end[2] > tot.begin[2]) HIP_TRY(hipMemcpyAsync(sink.seq + tot.begin[2], seq_src + tot.begin[2], tot.end[2] - tot.begin[2], hipMemcpyDeviceToHost, stream));
                 if (tot.end[3] > tot.begin[3]) HIP_TRY(hipMemcpyAsync(sink.ext + tot.begin[3], d_ext.as<char>() + tot.begin[3], tot.end[3] - tot.begin[3], hipMemcpyDeviceToHost, stream));
             }
             std::vector<uint32_t> rlist(tot.n_retry), glist(tot.n_general);
@@ -1038,6 +1089,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             st.copy_words_executed += tot.copy_words_exec; st.copy_cmds_executed += tot.copy_cmds_exec; st.post_scanned_words += tot.scan_words;
             sink.seq_used = tot.end[2];
             sink.ext_used = tot.end[3];
+            arena_used[0] = tot.end[2];
+            arena_used[1] = tot.end[3];
             sink.n_filled += tot.n_filled;
             if (want_records && !identity) /* records of a partial launch: to their gaps (a gap to be re-run gets its record again later) */
                 for (uint32_t s2 = 0; s2 < m; s2++) { sink.res[host_ids[s2]] = tmp_res[s2]; sink.fil[host_ids[s2]] = tmp_fil[s2]; }
@@ -1067,12 +1120,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 }
             }
             st.host_ms += now_ms() - t0;
-            float ms = 0, ms2 = 0, ms3 = 0, msc = 0, msf = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-            HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
-            st.finish_kernel_ms += msf;
             {
-                const uint32_t np = *(const uint32_t*)((const uint8_t*)h_tot + sizeof(PartTot));
+                const uint32_t np = tot.n_parked;
                 st.n_parked_gaps += np;
                 st.n_rounds += (uint64_t)rounds;
                 if (tier == 0 && identity && m >= 64) { /* the share of gaps this launch parked: how the workspace's next launch serves its parked gaps */
@@ -1081,15 +1130,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     idx->park_share_any.store(share, std::memory_order_relaxed);
                 }
             }
-            HIP_TRY(hipEventElapsedTime(&msc, evl0, evc)); /* k_lean + k_copy */
-            { float msl = 0; HIP_TRY(hipEventElapsedTime(&msl, evl0, evl)); st.lean_kernel_ms += msl; }
-            HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
-            st.copy_kernel_ms += msc;
-            HIP_TRY(hipEventElapsedTime(&ms3, eve, ev2));
             { float mss = 0; HIP_TRY(hipEventElapsedTime(&mss, ev0, ev2)); st.device_span_ms += mss; }
-            st.kernel_ms += ms;
-            st.post_kernel_ms += ms2;
-            st.emit_kernel_ms += ms3;
+            if (ktimers) {
+                float ms = 0, ms2 = 0, ms3 = 0, msc = 0, msf = 0, msl = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+                HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
+                HIP_TRY(hipEventElapsedTime(&msc, evl0, evc)); /* k_lean + k_copy */
+                HIP_TRY(hipEventElapsedTime(&msl, evl0, evl));
+                HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
+                HIP_TRY(hipEventElapsedTime(&ms3, eve, ev2));
+                st.kernel_ms += ms; st.finish_kernel_ms += msf; st.lean_kernel_ms += msl; st.copy_kernel_ms += msc; st.post_kernel_ms += ms2; st.emit_kernel_ms += ms3;
+            }
             st.seq_bytes += tot.end[2] - tot.begin[2];
             st.n_launches++;
         }

@@ -42,9 +42,8 @@ int mtg_tuning_get(const char* name, char* value, size_t cap)
     using namespace mtgi::tune;
     const int t = Values::find(name);
     if (t < 0 || !value) { mtgi::set_error("no tuning entry named %s", name ? name : "(null)"); return MTG_ERR_ARG; }
-    Values& V = values();
-    std::lock_guard<std::mutex> lk(V.m);
-    const char* c = V.cur(t);
+    char c[64];
+    (void)values().read(t, c, true); /* as a flag reads it: an empty environment variable is "1" */
     const size_t n = strlen(c);
     if (n + 1 > cap) { mtgi::set_error("buffer too small"); return MTG_ERR_ARG; }
     memcpy(value, c, n + 1);
@@ -839,7 +838,13 @@ struct mtg_batch {
 };
 
 struct mtg_results {
-    size_t n = 0, cap_n = 0;
+    size_t n = 0;
+    /* ONE page-locked block [records | filled records | sequence arena]: the device lays its copies out the same way and the results of a batch
+     * cross the link in one copy (round 4: three arrays, three copies) */
+    char* blk = nullptr;
+    size_t blk_cap = 0;
+    static size_t off_fil(size_t n) { return (n * sizeof(mtg_gap_result) + 63) & ~(size_t)63; }
+    static size_t off_seq(size_t n) { return (off_fil(n) + n * sizeof(mtg_filled) + 63) & ~(size_t)63; }
     mtg_gap_result* res = nullptr; /* page-locked: the device's records are copied straight into them */
     mtg_filled* fil = nullptr;
     char* seq = nullptr;           /* sequence arena (page-locked), or the caller's buffer */
@@ -860,21 +865,41 @@ struct mtg_results {
     ~mtg_results()
     {
         if (plain) { free(res); free(fil); return; }
-        mtgi::pinned_free(res);
-        mtgi::pinned_free(fil);
-        mtgi::pinned_free(seq_own);
+        mtgi::pinned_free(blk);
         mtgi::pinned_free(ext);
     }
-    bool ensure(size_t n_)
+    /* the parts of the block for n_ gaps (the arena: what is left of the block, at least seq_min bytes) */
+    void carve(size_t n_)
     {
         n = n_;
-        if (cap_n >= n_ && res) return true;
-        mtgi::pinned_free(res);
-        mtgi::pinned_free(fil);
-        cap_n = n_ + n_ / 8 + 64;
-        res = (mtg_gap_result*)mtgi::pinned_alloc(cap_n * sizeof(mtg_gap_result));
-        fil = (mtg_filled*)mtgi::pinned_alloc(cap_n * sizeof(mtg_filled));
-        if (!res || !fil) { cap_n = 0; return false; }
+        res = (mtg_gap_result*)blk;
+        fil = (mtg_filled*)(blk + off_fil(n_));
+        seq_own = blk + off_seq(n_);
+        seq_own_cap = blk_cap - off_seq(n_);
+    }
+    bool ensure(size_t n_, size_t seq_min)
+    {
+        const size_t need = off_seq(n_) + seq_min;
+        if (blk_cap < need || !blk) {
+            mtgi::pinned_free(blk);
+            blk_cap = need + need / 8 + 4096;
+            blk = (char*)mtgi::pinned_alloc(blk_cap);
+            if (!blk) { blk_cap = 0; res = nullptr; fil = nullptr; seq_own = nullptr; seq_own_cap = 0; return false; }
+        }
+        carve(n_);
+        return true;
+    }
+    /* a larger block whose first off_seq(n) + keep bytes are the old one's */
+    bool grow(size_t seq_need, size_t keep)
+    {
+        const size_t cap = off_seq(n) + seq_need + seq_need / 4 + 4096;
+        char* nb = (char*)mtgi::pinned_alloc(cap);
+        if (!nb) return false;
+        if (blk) memcpy(nb, blk, off_seq(n) + keep);
+        mtgi::pinned_free(blk);
+        blk = nb;
+        blk_cap = cap;
+        carve(n);
         return true;
     }
 };
@@ -1007,7 +1032,7 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     mtg_results* R = results_acquire();
     struct Guard { mtg_results* r; ~Guard() { if (r) results_release(r); } } guard{R};
     R->nthreads = p->nb_host_threads;
-    if (!R->ensure(n)) { set_error("no page-locked memory for the records of %zu gaps", n); return MTG_ERR_NOMEM; }
+    if (!R->ensure(n, std::max<size_t>(n * 64, 1 << 16))) { set_error("no page-locked memory for the results of %zu gaps", n); return MTG_ERR_NOMEM; }
     if (!R->ext) { R->ext_cap = 1 << 16; R->ext = (char*)pinned_alloc(R->ext_cap); if (!R->ext) { R->ext_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
     R->ext[0] = 0;
     R->seq_external = seq_out != nullptr;
@@ -1015,7 +1040,6 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     R->seq_on_device = d_seq_out != nullptr && seq_out == d_seq_out;
     if (seq_out) { R->seq = seq_out; R->seq_cap = (size_t)seq_cap; }
     else {
-        if (!R->seq_own) { R->seq_own_cap = std::max<size_t>(n * 64, 1 << 16); R->seq_own = (char*)pinned_alloc(R->seq_own_cap); if (!R->seq_own) { R->seq_own_cap = 0; set_error("no page-locked memory"); return MTG_ERR_NOMEM; } }
         R->seq = R->seq_own;
         R->seq_cap = R->seq_own_cap;
     }
@@ -1028,16 +1052,14 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
     sink.ext = R->ext; sink.ext_cap = R->ext_cap;
     if (wire) { sink.wire_dev = wire->dev; sink.wire_cap = wire->cap; sink.wire_tag = wire->tag; }
     sink.seq_stays_in_workspace = fmt != nullptr && !seq_out; /* the text is formatted on the device: the ASCII arena does not come to the host */
+    if (!seq_out && !d_seq_out && !wire && !fmt) { sink.combo = R->blk; sink.combo_off_fil = mtg_results::off_fil(n); sink.combo_off_seq = mtg_results::off_seq(n); }
     sink.grow_seq = [&](size_t need, size_t keep) -> bool {
         if (R->seq_external) return false;
-        const size_t cap = need + need / 4 + 4096;
-        char* nb = (char*)pinned_alloc(cap);
-        if (!nb) return false;
-        if (keep) memcpy(nb, R->seq_own, keep);
-        pinned_free(R->seq_own);
-        R->seq_own = nb; R->seq_own_cap = cap;
-        R->seq = nb; R->seq_cap = cap;
-        sink.seq = nb; sink.seq_cap = cap;
+        if (!R->grow(need, keep)) return false; /* the whole block moves: records, filled records, arena */
+        R->seq = R->seq_own; R->seq_cap = R->seq_own_cap;
+        sink.res = R->res; sink.fil = R->fil;
+        sink.seq = R->seq; sink.seq_cap = R->seq_cap;
+        if (sink.combo) sink.combo = R->blk;
         return true;
     };
     sink.grow_ext = [&](size_t need, size_t keep) -> bool {

@@ -30,7 +30,7 @@
 namespace mtgi {
 /* grow-only device buffers reused by successive batches on one index */
 struct Workspace {
-    enum { NSLOTS = 40, NHOST = 16 };
+    enum { NSLOTS = 40, NHOST = 16, NEVENTS = 16 };
     /* slots device_run fills that a later step of the same batch reads (format_run): the marshalled text block and the sequence arena */
     enum { SLOT_TEXT_BLOCK = 2, SLOT_SEQ = 14, SLOT_RES = 16, SLOT_FIL = 17, SLOT_FMT0 = 32 };
     void* ptr[NSLOTS] = {nullptr};
@@ -38,17 +38,13 @@ struct Workspace {
     /* page-locked host staging blocks: 0..2 = the marshalled input of a batch, 3.. = what the first chunks of a batch brought back */
     void* hptr[NHOST] = {nullptr};
     size_t hcap[NHOST] = {0};
+    void* events[NEVENTS] = {nullptr}; /* hipEvent_t: the events a batch records, made on first use */
     void* stream = nullptr;      /* hipStream_t of the batch's copies in and kernels */
     void* copy_stream = nullptr; /* hipStream_t for the copies back of a batch's parts */
     /* share of the gaps (in 65536ths) the walk kernel parked in this workspace's previous whole-batch launch: how the next launch serves its
      * parked gaps (rounds or not, lanes per gap in the finishing kernel); ~0 = no launch yet: the index's latest figure is taken */
     uint32_t park_share = ~0u;
     uint32_t post_general = ~0u; /* gaps of this workspace's previous launch that were not lean (the grid of k_post's general form); ~0: no launch yet */
-    /* the same per walk mode (0: the walk answers strict SNP bubbles itself, 1: it parks there too and the bubble kernel answers them), with
-     * the traversal's time per gap the mode took last time: the next whole-batch launch takes the faster mode and tries the other now and then */
-    uint32_t mode_share[2] = {~0u, ~0u};
-    float mode_ns_per_gap[2] = {0.f, 0.f};
-    uint32_t mode_launches = 0;
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
 }
@@ -442,6 +438,11 @@ struct ResultSink {
     mtg_filled* fil = nullptr;     /* n records: slot i belongs to gap i */
     char* seq = nullptr;           /* sequence arena: NUL-terminated fills, in gap order unless `in_gap_order` comes back false */
     size_t seq_cap = 0;
+    /* res, fil and seq are parts of ONE page-locked block: res == combo, fil == combo + combo_off_fil, seq == combo + combo_off_seq (the offsets a
+     * function of n).  The device then lays its copies out the same way and a whole-batch launch brings its results over in one copy.  grow_seq
+     * moves the whole block (and sets res, fil, seq, combo anew). */
+    char* combo = nullptr;
+    size_t combo_off_fil = 0, combo_off_seq = 0;
     char* seq_dev = nullptr;       /* a buffer of the caller on the index's device (seq_cap bytes): the result kernel writes the arena there instead of into the workspace */
     bool seq_on_device = false;    /* no host copy is wanted: seq == seq_dev, the records carry device addresses and nothing of the arena is copied to the host */
     bool seq_stays_in_workspace = false; /* the arena is produced in the workspace's own device buffer and NOT copied to `seq` (the records still carry the

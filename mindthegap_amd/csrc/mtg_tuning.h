@@ -45,6 +45,7 @@
     X(MAX_CHUNK, "", "test", "gaps per traversal launch (default: what the scratch holds): several launches per batch") \
     X(HOST_PATHS, "", "test", "leave the path enumeration of multi-contig gaps to the host") \
     X(DEBUG_SKIP_FINISH, "", "diag", "parked gaps stay parked (and fail as overflowing gaps)") \
+    X(KERNEL_TIMERS, "", "diag", "every batch records an event between its kernels and mtg_last_batch_stats carries each kernel's own time (off: three events per batch instead of nine, only device_span_ms)") \
     X(DEBUG_TIMERS, "", "diag", "per-phase wall times of every batch and every index construction on stderr") \
     X(NO_VEC, "", "test", "scalar instead of pext host code in the input pass") \
     X(NO_PREFETCH, "", "test", "no software prefetch in the input pass") \
@@ -114,18 +115,30 @@ struct Values {
         forced[t] = true;
         return true;
     }
-    const char* cur(int t) const
+    /* the value of entry t into out (at most 63 characters); returns whether the entry has one.  Taken under the table's lock: mtg_tuning_set may
+     * run while batches read their switches (round 4 read the strings lock-free while put() rewrote them: a data race the advisor named).
+     * flag: an environment variable set to the empty string counts as "1" for a flag (MTG_X= switched it on when the code asked getenv() != NULL)
+     * and as "not set" for a number. */
+    bool read(int t, char out[64], bool flag)
     {
-        if (forced[t]) return v[t];
-        if (const char* e = getenv(g_entries[t].env)) return *e ? e : "1"; /* MTG_X= (empty) switched a flag on when the code asked getenv() != NULL */
-        return g_entries[t].dflt;
+        std::lock_guard<std::mutex> lk(m);
+        const char* src = nullptr;
+        if (forced[t]) src = v[t];
+        else if (const char* e = getenv(g_entries[t].env)) src = *e ? e : (flag ? "1" : "");
+        else src = g_entries[t].dflt;
+        size_t n = strlen(src);
+        if (n > 63) n = 63;
+        memcpy(out, src, n);
+        out[n] = 0;
+        return n != 0;
     }
 };
 inline Values& values() { static Values V; return V; }
-inline bool is_set(Id id) { return values().cur(id)[0] != 0; } /* has a value (mtg_tuning_set's, the environment's or its default) that is not empty */
-inline bool on(Id id) { return is_set(id); }                   /* flags: any value switches them on, as getenv() != NULL did */
-inline long i(Id id, long unset = 0) { const char* s = values().cur(id); return *s ? atol(s) : unset; } /* the value as an integer (not set: the argument) */
-inline double f(Id id, double unset = 0.0) { const char* s = values().cur(id); return *s ? atof(s) : unset; }
+inline bool is_set(Id id) { char b[64]; return values().read(id, b, true); } /* has a value (mtg_tuning_set's, the environment's or its default) that is not empty */
+/* flags: any value but "0" switches them on (NO_LEAN=0 and MTG_TUNING=NO_LEAN=0 leave the flag off; round 4 took every non-empty value for on) */
+inline bool on(Id id) { char b[64]; return values().read(id, b, true) && strcmp(b, "0") != 0; }
+inline long i(Id id, long unset = 0) { char b[64]; return values().read(id, b, false) ? atol(b) : unset; } /* the value as an integer (not set: the argument) */
+inline double f(Id id, double unset = 0.0) { char b[64]; return values().read(id, b, false) ? atof(b) : unset; }
 } // namespace tune
 } // namespace mtgi
 #endif

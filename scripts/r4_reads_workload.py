@@ -86,8 +86,10 @@ run(3)
 t0 = time.perf_counter(); run(a.steps); el = time.perf_counter() - t0
 rate = S.n_sites * a.steps / el
 st = None
+mtg.tuning_set("KERNEL_TIMERS", "1")
 h, nf, _ = idx.fill_prepared(batches[0][1], params, want_seqs=False)
 st = mtg.last_batch_stats(); idx.free_results(h)
+mtg.tuning_set("KERNEL_TIMERS", None)
 n_filled = int((nf > 0).sum())
 # parity: the first oracle_seqs sites, HIP (forward attempt + reverse attempt, as the tool) against the oracle on the reads of those sequences
 from tests import oracle_lib

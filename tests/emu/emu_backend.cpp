@@ -514,9 +514,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* arenas: grown like in the device build (the first emission is skipped here: nothing would be written anyway) */
             if (want_records && tot.end[2] > sink.seq_cap) {
                 const uintptr_t old = (uintptr_t)sink.seq, old_end = old + sink.seq_cap;
+                const uintptr_t old_fil = (uintptr_t)sink.fil, old_fil_end = old_fil + n * sizeof(mtg_filled);
                 if (!sink.grow_seq || !sink.grow_seq((size_t)tot.end[2], (size_t)tot.begin[2])) { set_error("sequence buffer too small: %llu bytes needed", (unsigned long long)tot.end[2]); return MTG_ERR_ARG; }
-                if (want_records && tot.begin[2] > 0 && (uintptr_t)sink.seq != old)
+                if (want_records && launches > 1 && (uintptr_t)sink.seq != old)
                     for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.fil[i].seq; if (q >= old && q < old_end) sink.fil[i].seq = sink.seq + (q - old); }
+                /* as device_run: the arena is one block with the records, the filled records moved with it */
+                if (want_records && launches > 1 && (uintptr_t)sink.fil != old_fil)
+                    for (size_t i = 0; i < n; i++) { const uintptr_t q = (uintptr_t)sink.res[i].filled; if (q >= old_fil && q < old_fil_end) sink.res[i].filled = (const mtg_filled*)((const char*)sink.fil + (q - old_fil)); }
             }
             if (want_records && tot.end[3] > sink.ext_cap) {
                 const uintptr_t old = (uintptr_t)sink.ext, old_end = old + sink.ext_cap;
