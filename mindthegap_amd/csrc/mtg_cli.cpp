@@ -485,20 +485,47 @@ struct Replicas {
     std::vector<const mtg_index*> idx; /* idx[0] = the index itself */
     std::vector<mtg_index*> owned;
     ~Replicas() { for (mtg_index* i : owned) mtg_index_free(i); }
+    /* The replicas of a node, as a DOUBLING TREE (1 -> 2 -> 4 -> 8): in every round each device that holds the index clones it to one that does
+     * not, all pairs of a round at the same time (a host thread per destination; the five buffers of a replica in flight together, peer access
+     * enabled both ways: index_replicate).  Round 4 cloned from device 0 to the others one after the other: seven blocking copies of 58 GB over
+     * one link each for a node of eight -- several seconds for a job whose fills take milliseconds; three rounds of concurrent copies over
+     * distinct xGMI links now.  MTG_TOOL_TIMERS=1 prints the time. */
     int make(const mtg_index* primary, int want)
     {
         idx.push_back(primary);
         const int ndev = mtg_device_count();
         if (tune::is_set(tune::T_NB_GPUS)) { if (want <= 0) want = (int)tune::i(tune::T_NB_GPUS); }
-        int use = want > 0 ? std::min(want, ndev) : ndev;
-        for (int d = 0, made = 1; d < ndev && made < use; d++) {
-            if (d == primary->device) continue;
-            mtg_index* r = nullptr;
-            if (int rc = mtg_index_replicate(primary, d, &r)) return rc;
-            owned.push_back(r);
-            idx.push_back(r);
-            made++;
+        const int use = want > 0 ? std::min(want, ndev) : ndev;
+        std::vector<int> targets;
+        for (int d = 0; d < ndev && (int)targets.size() + 1 < use; d++) if (d != primary->device) targets.push_back(d);
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t next = 0;
+        int rounds = 0;
+        while (next < targets.size()) {
+            const size_t pairs = std::min(idx.size(), targets.size() - next);
+            std::vector<mtg_index*> made(pairs, nullptr);
+            std::vector<int> rcs(pairs, MTG_OK);
+            std::vector<std::string> msgs(pairs);
+            std::vector<std::thread> th;
+            for (size_t p = 0; p < pairs; p++)
+                th.emplace_back([&, p] {
+                    rcs[p] = mtg_index_replicate(idx[p], targets[next + p], &made[p]);
+                    if (rcs[p]) msgs[p] = mtg_last_error(); /* the message is the worker thread's: brought over below */
+                });
+            for (std::thread& t : th) t.join();
+            int rc = MTG_OK;
+            for (size_t p = 0; p < pairs; p++) {
+                if (made[p]) owned.push_back(made[p]); /* freed with the others whatever happens next */
+                if (rcs[p] && !rc) { rc = rcs[p]; mtgi::set_error("%s", msgs[p].c_str()); }
+            }
+            if (rc) return rc;
+            for (size_t p = 0; p < pairs; p++) idx.push_back(made[p]);
+            next += pairs;
+            rounds++;
         }
+        if (tune::on(tune::T_TOOL_TIMERS) && !targets.empty())
+            fprintf(stderr, "[tool] index replicated to %zu more device(s) in %d round(s): %.3f s\n", targets.size(), rounds,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         return MTG_OK;
     }
 };

@@ -1178,23 +1178,29 @@ int index_replicate(const mtg_index* src, int device, mtg_index** out)
     idx->dev.bloom.bits = nullptr;
     idx->dev.us.words = nullptr;
     idx->dev.us.ab = nullptr;
-    auto clone = [&](void** dst, const void* from, size_t bytes) -> int {
-        if (!from || !bytes) return MTG_OK;
-        HIP_TRY(hipMalloc(dst, bytes));
-        HIP_TRY(hipMemcpyPeer(*dst, device, from, src->device, bytes));
-        return MTG_OK;
-    };
-    const size_t ba = src->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = src->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS, bc = src->dev.bloom.nblocks * 64;
-    if (int rc = clone((void**)&idx->dev.adj.slots, src->dev.adj.slots, ba)) return rc;
-    if (int rc = clone((void**)&idx->dev.abnd.slots, src->dev.abnd.slots, bb)) return rc;
-    if (int rc = clone((void**)&idx->dev.bloom.bits, src->dev.bloom.bits, bc)) return rc;
-    if (src->dev.us.nwords) {
-        const size_t nw = src->dev.us.nwords + 8;
-        if (int rc = clone((void**)&idx->dev.us.words, src->dev.us.words, nw * 8)) return rc;
-        if (int rc = clone((void**)&idx->dev.us.ab, src->dev.us.ab, nw * 32)) return rc;
+    /* peer access both ways (a copy between two devices then goes over their xGMI link without a bounce; "already enabled" is fine), every
+     * buffer allocated first, then the five copies in flight together on one stream of the destination */
+    if (device != src->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+            if (hipDeviceEnablePeerAccess(src->device, 0) != hipSuccess) (void)hipGetLastError();
+            (void)hipSetDevice(src->device);
+            if (hipDeviceEnablePeerAccess(device, 0) != hipSuccess) (void)hipGetLastError();
+            HIP_TRY(hipSetDevice(device));
+        }
     }
+    hipStream_t cs = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{cs};
+    struct Part { void** dst; const void* from; size_t bytes; };
+    const size_t ba = src->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = src->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS, bc = src->dev.bloom.nblocks * 64;
+    const size_t nw = src->dev.us.nwords ? src->dev.us.nwords + 8 : 0;
+    const Part parts[5] = {{(void**)&idx->dev.adj.slots, src->dev.adj.slots, ba}, {(void**)&idx->dev.abnd.slots, src->dev.abnd.slots, bb}, {(void**)&idx->dev.bloom.bits, src->dev.bloom.bits, bc},
+                           {(void**)&idx->dev.us.words, src->dev.us.words, nw * 8}, {(void**)&idx->dev.us.ab, src->dev.us.ab, nw * 32}};
+    for (const Part& p : parts) if (p.from && p.bytes) HIP_TRY(hipMalloc(p.dst, p.bytes)); /* a failure leaves what was allocated to free_tables (IndexGuard) */
+    for (const Part& p : parts) if (p.from && p.bytes) HIP_TRY(hipMemcpyPeerAsync(*p.dst, device, p.from, src->device, p.bytes, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
     if (src->dev.adj.sp_words) idx->dev.adj.sp_words = idx->dev.us.words; /* the sparse form reads this copy's store */
-    HIP_TRY(hipDeviceSynchronize());
     *out = g.release();
     return MTG_OK;
 }

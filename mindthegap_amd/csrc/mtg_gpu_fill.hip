@@ -649,6 +649,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     }
     const hipStream_t stream = (hipStream_t)ws.stream;
     const size_t n = in.src.size();
+    enum : size_t { SEQ_SLACK = 64 }; /* the device's formatter measures a sequence 64 characters at a time (fmt_strlen): the last one may be read that far past its NUL */
     special.chunks.clear();
     special.special.clear();
     sink.seq_used = 0;
@@ -819,8 +820,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         HIP_TRY(d_rlist.alloc(chunk * 4));
         HIP_TRY(d_glist.alloc(chunk * 4));
         HIP_TRY(d_park.alloc((size_t)chunk * 4 * PARK_LISTS + sizeof(ParkCtl)));
-        if (combo) HIP_TRY(d_combo.grow_keeping(sink.combo_off_seq + std::max<size_t>(sink.seq_cap, 64), sink.combo_off_seq + (size_t)sink.seq_used));
-        else HIP_TRY(d_seq.grow_keeping(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64), sink.seq_dev ? 0 : (size_t)sink.seq_used)); /* a caller's device buffer is written in place; what an earlier tier left stays */
+        if (combo) HIP_TRY(d_combo.grow_keeping(sink.combo_off_seq + std::max<size_t>(sink.seq_cap, 64) + SEQ_SLACK, sink.combo_off_seq + (size_t)sink.seq_used));
+        else HIP_TRY(d_seq.grow_keeping(sink.seq_dev ? 64 : std::max<size_t>(sink.seq_cap, 64) + SEQ_SLACK, sink.seq_dev ? 0 : (size_t)sink.seq_used)); /* a caller's device buffer is written in place; what an earlier tier left stays */
         auto p_res = [&]() { return combo ? (mtg_gap_result*)d_combo.p : d_res.as<mtg_gap_result>(); };
         auto p_fil = [&]() { return combo ? (mtg_filled*)((char*)d_combo.p + sink.combo_off_fil) : d_fil.as<mtg_filled>(); };
         auto p_seq = [&]() { return combo ? (char*)d_combo.p + sink.combo_off_seq : d_seq.as<char>(); };
@@ -1025,8 +1026,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 /* what earlier launches of the batch left in the arena stays: when the text is formatted on the device the arena's only copy is this one
                  * (round 4: a batch of several launches lost the sequences of all but its last launch here -- the device formatter then wrote
                  * "_len_0" records; found by running the GPU tests under MAX_CHUNK) */
-                if (combo) HIP_TRY(d_combo.grow_keeping(sink.combo_off_seq + std::max<size_t>(sink.seq_cap, 64), sink.combo_off_seq + (size_t)tot.begin[2]));
-                else if (!sink.seq_dev) HIP_TRY(d_seq.grow_keeping(std::max<size_t>(sink.seq_cap, 64), (size_t)tot.begin[2]));
+                if (combo) HIP_TRY(d_combo.grow_keeping(sink.combo_off_seq + std::max<size_t>(sink.seq_cap, 64) + SEQ_SLACK, sink.combo_off_seq + (size_t)tot.begin[2]));
+                else if (!sink.seq_dev) HIP_TRY(d_seq.grow_keeping(std::max<size_t>(sink.seq_cap, 64) + SEQ_SLACK, (size_t)tot.begin[2]));
                 HIP_TRY(d_ext.alloc(std::max<size_t>(sink.ext_cap, 64)));
                 HIP_TRY(d_dw.alloc(need_w));
                 HIP_TRY(d_dm.alloc(need_m));

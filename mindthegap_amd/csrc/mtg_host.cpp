@@ -1361,12 +1361,9 @@ int mtg_host_register(void* p, size_t bytes)
 {
     if (!p || !bytes) { mtgi::set_error("null argument"); return MTG_ERR_ARG; }
     const uintptr_t a = (uintptr_t)p;
-    {
-        std::lock_guard<std::mutex> lk(g_reg_mtx);
-        for (const auto& r : g_reg) if (a < r.first + r.second && r.first < a + bytes) { mtgi::set_error("the range overlaps a registered one"); return MTG_ERR_ARG; }
-    }
+    std::lock_guard<std::mutex> lk(g_reg_mtx); /* one critical section: the overlap check, the page-locking and the entry belong together */
+    for (const auto& r : g_reg) if (a < r.first + r.second && r.first < a + bytes) { mtgi::set_error("the range overlaps a registered one"); return MTG_ERR_ARG; }
     if (int rc = mtgi::host_register(p, bytes)) return rc;
-    std::lock_guard<std::mutex> lk(g_reg_mtx);
     g_reg.emplace_back(a, bytes);
     return MTG_OK;
 }

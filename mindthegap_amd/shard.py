@@ -266,13 +266,17 @@ class SlottedGather:
             self.inner.submit(self.K * self.SLOT_HDR + self.K * self.cap, j, on_device=bool(self.mode[j]), tag=int(tab[1]))
 
     def flush(self):
-        """the open buffer leaves with its remaining slots empty"""
-        while True:
-            with self.lock:
-                if self.open is None:
-                    return
-            h, _ = self.acquire()
-            self.submit(0, h, tag=-1)
+        """the open buffer leaves with its remaining slots empty.  Only ever pads an EXISTING open buffer: its remaining slots are taken under the
+        lock in one go, and nothing here fetches a fresh buffer (round 4 re-checked `open` outside acquire(): a thread taking the last slot in
+        between made flush pad a new buffer -- one collective more on this rank only, a hang).  Not to be called while other threads acquire()."""
+        with self.lock:
+            if self.open is None:
+                return
+            j, first = self.open, self.next_slot
+            self.open = None
+            self.next_slot = self.K
+        for s in range(first, self.K):
+            self.submit(0, j * self.K + s, tag=-1)
 
     def drain(self):
         self.flush()
@@ -457,22 +461,36 @@ def fill_bkpt_sharded(idx, sites, out_prefix, params=None, batch_sites=100000, d
 
     wt = threading.Thread(target=writer)
     wt.start()
+
+    def hand_over(item):
+        """puts item on the writer's queue without ever blocking behind a writer that has died (a failed pwrite, a collective that timed out):
+        the put is retried in short waits that look at the writer's state; False = the writer is gone"""
+        while True:
+            if err or not wt.is_alive():
+                return False
+            try:
+                todo.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+
+    failure = None
     try:
         for i in range(rounds):
             b = i * world + rank
-            todo.put(one(b) if b < nb else _EMPTY_ROUND)  # a rank without a batch in the last round still takes part in the exchange of sizes
-            if err:
+            # a rank without a batch in the last round still takes part in the exchange of sizes
+            if not hand_over(one(b) if b < nb else _EMPTY_ROUND):
                 break
-    except BaseException:
-        todo.put(None)  # the writer leaves (the job is lost: the other ranks' writers wait for this rank's sizes until their timeout)
-        wt.join()
-        raise
-    if err:
-        try:
-            todo.put_nowait(None)
-        except queue.Full:
-            pass
+    except BaseException as e:  # the fill failed: the writer leaves (the other ranks' writers wait for this rank's sizes until their timeout)
+        failure = e
+    # the sentinel: only needed when the writer has not seen all its rounds; never a blocking put (round 4 could hang here with a full queue and a dead writer)
+    if (failure is not None or err) and wt.is_alive():
+        hand_over(None)
     wt.join()
+    if failure is not None:
+        for fd in fds:
+            os.close(fd)
+        raise failure
     for fd in fds:
         os.close(fd)
     if err:

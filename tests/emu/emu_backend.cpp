@@ -650,6 +650,14 @@ int mtg_device_count(void) { return getenv("MTG_EMU_DEVICES") ? atoi(getenv("MTG
 int mtg_set_device(int) { return MTG_OK; }
 int mtg_index_replicate(const mtg_index* src, int device, mtg_index** out)
 {
+    /* TEST-ONLY: which device cloned to which (the tool replicates as a doubling tree), and a replication that fails */
+    if (const char* lg = getenv("MTG_EMU_REPLICATE_LOG")) {
+        static std::mutex log_mtx;
+        std::lock_guard<std::mutex> lk(log_mtx);
+        if (FILE* f = fopen(lg, "a")) { fprintf(f, "%d %d\n", src->device, device); fclose(f); }
+    }
+    if (const char* e = getenv("MTG_EMU_FAIL_REPLICATE"))
+        if (atoi(e) == device) { mtgi::set_error("injected failure replicating to device %d", device); return MTG_ERR_NOMEM; }
     /* a deep copy: the simplest way to get one is to rebuild from the k-mers read back from the source's table */
     std::vector<uint64_t> k;
     std::vector<uint32_t> a;

@@ -927,6 +927,51 @@ def test_cli_on_two_emulated_devices(emu_product, tmp_path, monkeypatch):
     a.close(); b.close(); o.close()
 
 
+def test_cli_on_eight_emulated_devices(emu_product, tmp_path, monkeypatch, capfd):
+    """a node of eight: the index reaches the other seven devices as a doubling tree (0->1; 0->2, 1->3; 0->4, 1->5, 2->6, 3->7: three rounds, the
+    pairs of a round at the same time), the files are the oracle's; a batch failing on device 5 stops the tool with exit code 1 and a prefix of
+    the files; a REPLICATION failing (to device 6) stops it before any site is filled, with that replication's message"""
+    monkeypatch.setenv("MTG_EMU_DEVICES", "8")
+    monkeypatch.setenv("MTG_CLI_BATCH", "2")
+    monkeypatch.setenv("MTG_CLI_IN_FLIGHT", "2")
+    log = str(tmp_path / "replicas.log")
+    monkeypatch.setenv("MTG_EMU_REPLICATE_LOG", log)
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=48, n_sites=48, seed=23)
+    o = oracle_lib.Index.from_sequences([S.ascii(j) for j in range(S.nseq)], 31, 3, 40)
+    km, ct = o.export()
+    idxf = str(tmp_path / "t.mtgidx")
+    _write_idx(idxf, km, ct)
+    bk = str(tmp_path / "t.breakpoints")
+    S.write_breakpoints(bk)
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"))
+    assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    for ext in (".insertions.fasta", ".info.txt"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _vcf_body(str(tmp_path / "hip.insertions.vcf")) == _vcf_body(str(tmp_path / "cpu.insertions.vcf"))
+    pairs = sorted(tuple(int(x) for x in l.split()) for l in open(log))
+    assert pairs == sorted([(0, 1), (0, 2), (1, 3), (0, 4), (1, 5), (2, 6), (3, 7)])
+    # fewer devices than the node has (-nb-gpus 5): 0->1; 0->2, 1->3; 0->4
+    os.remove(log)
+    assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "five"), "-nb-gpus", "5"]) == 0
+    assert _read(str(tmp_path / "five.insertions.fasta")) == _read(str(tmp_path / "cpu.insertions.fasta"))
+    assert sorted(tuple(int(x) for x in l.split()) for l in open(log)) == sorted([(0, 1), (0, 2), (1, 3), (0, 4)])
+    # every batch of device 5 fails
+    monkeypatch.setenv("MTG_CLI_BATCH", "1")
+    monkeypatch.setenv("MTG_EMU_FAIL_DEVICE", "5")
+    assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "bad")]) == 1
+    full, part = _read(str(tmp_path / "cpu.insertions.fasta")), _read(str(tmp_path / "bad.insertions.fasta"))
+    assert full.startswith(part) and len(part) < len(full)
+    monkeypatch.delenv("MTG_EMU_FAIL_DEVICE")
+    # the replication to device 6 fails: nothing is filled, the message is the replication's
+    monkeypatch.setenv("MTG_EMU_FAIL_REPLICATE", "6")
+    capfd.readouterr()
+    assert emu_product.Filler().run(["-graph", idxf, "-bkpt", bk, "-out", str(tmp_path / "norep")]) == 1
+    assert "replicating to device 6" in capfd.readouterr().err
+    assert _read(str(tmp_path / "norep.insertions.fasta")) == ""
+    o.close()
+
+
 def test_cli_on_three_emulated_devices_with_a_failing_one(emu_product, tmp_path, monkeypatch):
     """the tool's driver (MTG_CLI_IN_FLIGHT host threads per device, batches handed out as a stream, text written in input order) on three
     pretended devices; then the same with every batch of device 1 failing: the tool stops with the reference's exit code 1 and the first
