@@ -190,3 +190,74 @@ def test_one_launch_of_300000_gaps(mtg):
     idx.close()
     assert st["n_launches"] == 1 and (nf == 1).all()
     assert seqs.tobytes().decode().split("\n")[:-1] == truth
+
+
+@pytest.mark.parametrize("name,het,indels,tips,n_oracle", [("het", 4, 0, 0.0, 15000), ("indel", 4, 2, 0.0, 15000), ("tips", 0, 0, 1.0 / 3.0, 30000)])
+def test_secondaries_full_size(mtg, tmp_path, name, het, indels, tips, n_oracle):
+    """the bubble-heavy secondary workloads of bench.py INSIDE the GPU suite: 100 000 sites in one batch on a diploid donor with heterozygous SNPs
+    (het), with deletions of 1-3 nt besides (indel: the general bubble code, refusals, multi-contig gaps through the host path), and on a
+    haploid donor with erroneous fragments in the index (tips) -- the fast forms of the walk (tip_fast, indel_bulk, merge_fast, the refusals),
+    the parked gaps' finishing kernel, k_paths / k_nw.  The first n_oracle sites are compared RECORD BY RECORD (name, length, quality, mean and
+    median coverage, solution rank, sequence; nodes / nucleotides / terminal nodes of the info row) with the CPU oracle, whose index holds the
+    donor sequences those sites' walks can see (both haplotypes of their loci; the fragments copied from them).  Parity unpinned vs GATB for
+    the bubble rules themselves: this is HIP == oracle at full batch size."""
+    import torch
+    from mindthegap_amd.synth import SynthSet
+    from tests import oracle_lib
+    K, NSITES = 31, 100000
+    nseq = NSITES * (2 if het else 1)
+    S = SynthSet(nseq=nseq, n_sites=NSITES, seed=1, k=K, het_snps=het, het_indels=indels, tips=tips)
+    dev = torch.device("cuda", 0)
+    pw, po, pl, pn = S.packed()
+    w = torch.from_numpy(pw.view(np.int64)).to(dev)
+    wo = torch.from_numpy(po.view(np.int64)).to(dev)
+    ln = torch.from_numpy(pl.view(np.int32)).to(dev)
+    idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), pn, S.total_kmers_upper_bound, K, 3, 0)
+    del w, wo, ln
+    torch.cuda.empty_cache()
+    gaps = []
+    for i in range(NSITES):
+        l, r, _ = S.site(i)
+        gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+    params = mtg.FillParams(max_nodes=100, max_depth=10000)
+    res = idx.fill_batch(gaps, params)
+    st = mtg.last_batch_stats()
+    # the unfilled sites get the reverse attempt, as the tool does (src/Filler.cpp:669-680): compared through the tool below
+    n_filled = sum(1 for r in res if r["filled"])
+    assert n_filled > 0.6 * NSITES, n_filled
+    # the oracle's graph: the donor sequences of the sampled loci (both haplotypes; the erroneous fragments copied from them)
+    if het:
+        nl = S.nseq // 2
+        seqs = [S.ascii(j) for j in range(n_oracle)] + [S.ascii(nl + j) for j in range(n_oracle)]
+    else:
+        seqs = [S.ascii(j) for j in range(n_oracle)] + [S.extra_ascii(int(j)) for j in np.nonzero(S.extra_rows < n_oracle)[0]]
+    o = oracle_lib.Index.from_sequences(seqs, K, 3, 0)
+    del seqs
+    bk = str(tmp_path / "s.breakpoints")
+    S.write_breakpoints(bk, range(n_oracle))
+    o.fill_files("bkpt", bk, str(tmp_path / "cpu"), params=oracle_lib.default_params(nb_cores=max(1, min(16, os.cpu_count() or 1))))
+    o.close()
+    # the HIP side through the tool on the resident index (forward + reverse attempts, FASTA / info / VCF as the oracle writes them)
+    assert idx.fill_main(["-bkpt", bk, "-out", str(tmp_path / "hip")]) == 0
+    idx.close()
+
+    def records(prefix):
+        out, name_ = {}, None
+        for line in open(prefix + ".insertions.fasta"):
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                name_ = line[1:]
+            else:
+                out.setdefault(name_.split("_len_")[0], []).append((name_, line))
+        return {k2: sorted(v) for k2, v in out.items()}
+
+    def info_rows(prefix):
+        return {f[0]: f[1:] for f in (line.rstrip("\n").split("\t") for line in open(prefix + ".info.txt"))}
+
+    cpu, hip = records(str(tmp_path / "cpu")), records(str(tmp_path / "hip"))
+    assert len(cpu) > 0.6 * n_oracle
+    assert hip == cpu  # every record of every site: header (length, quality, coverages, solution rank) and sequence
+    assert info_rows(str(tmp_path / "hip")) == info_rows(str(tmp_path / "cpu"))  # nodes, nucleotides, terminal nodes, solution counts of both attempts
+    multi = sum(1 for v in cpu.values() if len(v) > 1)
+    print("secondary %s at full size: %d gaps parked, %d lean, %d of 100000 filled forward; %d sites compared record by record with the oracle (%d with several solutions)"
+          % (name, st["n_parked_gaps"], st["n_lean_gaps"], n_filled, n_oracle, multi))
