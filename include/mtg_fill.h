@@ -342,8 +342,9 @@ typedef struct mtg_batch_stats {
     uint64_t copy_words_executed; /* of copy_words: those k_copy really wrote (a lean gap's commands are never executed) */
     uint64_t copy_cmds_executed;
     uint64_t post_scanned_words; /* of contig_words: those k_post's terminal search really read (a lean gap's contig is never scanned) */
-    double device_span_ms;       /* first kernel of a launch to its last, summed over the launches: less than the sum of the kernel times above since round 4 (the
-                                    finishing kernel runs next to k_lean, k_copy and k_post_lean on a second stream) */
+    double device_span_ms;       /* first kernel of a launch to its last, summed over the launches */
+    uint64_t n_general_device;   /* multi-contig gaps finished on the device (k_general: candidate sequences, de-duplication, coverage, ASCII) */
+    uint64_t n_general_host;     /* multi-contig gaps the host's path took (several targets, a candidate that does not fit the work areas, an unknown k-mer; HOST_GENERAL) */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);
 

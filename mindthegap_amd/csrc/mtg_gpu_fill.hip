@@ -578,6 +578,24 @@ __global__ void __launch_bounds__(64) k_paths(FillCfg cfg, uint8_t* raw, const G
     paths_gap(cfg, S, outs[slot], k, W, out + (uint64_t)blockIdx.x * PATHS_WORDS);
 }
 
+/* the multi-contig gaps of a launch on the device (mtg_general.h), one wave per gap of the launch's list: paths -> candidate sequences ->
+ * de-duplication -> coverage, quality, ASCII.  slots = the list k_emit made (general_list); paths = k_paths' blocks in the same order. */
+__global__ void __launch_bounds__(64) k_general(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ ids,
+                                                const uint32_t* __restrict__ paths, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok, const uint64_t* __restrict__ src,
+                                                const uint8_t* __restrict__ gflags, int k, GenDev D, uint32_t n)
+{
+    __shared__ GenWork W;
+    if (blockIdx.x >= n) return;
+    const uint32_t slot = slots[blockIdx.x];
+    const uint32_t g = ids ? ids[slot] : slot;
+    GapScratch S;
+    S.z = nullptr;
+    S.v = nullptr;
+    S.lane = 0;
+    S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    gen_gap(ix, cfg, S, outs[slot], k, paths + (uint64_t)blockIdx.x * PATHS_WORDS, tcnt[g], fast_ok[g] != 0, src[g], gflags[g], D, blockIdx.x, W);
+}
+
 
 /* device copies of a marshalled batch: blocks A and B and the encoded targets (block C only serves to make those) */
 int batch_upload(const mtg_index* idx, FillInput& in)
@@ -663,7 +681,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_combo = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf();
+          d_dm = wsbuf(), d_combo = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf(), d_ggaps = wsbuf(), d_gsols = wsbuf(), d_gascii = wsbuf(), d_gtmp = wsbuf(), d_gbnd = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
@@ -1062,20 +1080,52 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 if (tot.end[3] > tot.begin[3]) HIP_TRY(hipMemcpyAsync(sink.ext + tot.begin[3], d_ext.as<char>() + tot.begin[3], tot.end[3] - tot.begin[3], hipMemcpyDeviceToHost, stream));
             }
             std::vector<uint32_t> rlist(tot.n_retry), glist(tot.n_general);
+            /* The multi-contig gaps on the DEVICE (round 5; HOST_GENERAL of the tuning table: the host's path for all of them, as until round 4): k_paths
+             * and k_general over the list k_emit made, queued before the result copies; what comes back is a header per gap, the solutions and their
+             * ASCII -- not every record of the launch, the gaps' contigs and 16 KB of paths per gap (540 MB of a 100 000-gap indel batch). */
+            const bool dev_general = tot.n_general > 0 && !host_paths && !in.want_all_contigs && !tune::on(tune::T_HOST_GENERAL);
+            GenCtl* h_gctl = nullptr;
+            GenDev GD{};
+            if (dev_general) {
+                const uint64_t ng = tot.n_general;
+                HIP_TRY(d_paths.alloc(ng * (size_t)PATHS_WORDS * 4));
+                HIP_TRY(d_ggaps.alloc(ng * sizeof(GenGap) + sizeof(GenCtl)));
+                GD.cap_sols = 4 * ng + 1024; GD.cap_ascii = ng * 1280 + (1u << 20); GD.cap_tmp = ng * 48 + (1u << 17); GD.cap_bnd = 1u << 22;
+                HIP_TRY(d_gsols.alloc(GD.cap_sols * sizeof(GenSol)));
+                HIP_TRY(d_gascii.alloc(GD.cap_ascii + 64));
+                HIP_TRY(d_gtmp.alloc(GD.cap_tmp * 8));
+                HIP_TRY(d_gbnd.alloc(GD.cap_bnd * sizeof(NwCell)));
+                GD.ctl = (GenCtl*)d_ggaps.p;
+                GD.gaps = (GenGap*)((char*)d_ggaps.p + sizeof(GenCtl));
+                GD.sols = d_gsols.as<GenSol>(); GD.ascii = d_gascii.as<char>(); GD.tmp = d_gtmp.as<uint64_t>(); GD.bnd = d_gbnd.as<NwCell>();
+                HIP_TRY(hipMemsetAsync(GD.ctl, 0, sizeof(GenCtl), stream));
+                hipLaunchKernelGGL(k_paths, dim3((unsigned)ng), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_glist.as<uint32_t>(), k, d_paths.as<uint32_t>(), (uint32_t)ng);
+                hipLaunchKernelGGL(k_general, dim3((unsigned)ng), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_glist.as<uint32_t>(), ids, d_paths.as<uint32_t>(),
+                                   d_tcnt, d_fok, d_src, d_flags, k, GD, (uint32_t)ng);
+                HIP_TRY(hipGetLastError());
+                h_gctl = (GenCtl*)staging_host(&ws, Workspace::NHOST - 2, sizeof(GenCtl) + ng * sizeof(GenGap) + 64);
+                if (!h_gctl) { set_error("no page-locked memory for the multi-contig gaps of a launch"); return MTG_ERR_NOMEM; }
+                HIP_TRY(hipMemcpyAsync(h_gctl, d_ggaps.p, sizeof(GenCtl) + ng * sizeof(GenGap), hipMemcpyDeviceToHost, stream));
+            }
             HostChunk* hc = nullptr;
             SlotRec* h_rec = nullptr;
             uint64_t* h_w = nullptr;
             uint32_t* h_m = nullptr;
             const uint64_t tw = tot.end[0], tc = tot.end[1];
             if (tot.n_retry) HIP_TRY(hipMemcpyAsync(rlist.data(), d_rlist.p, (size_t)tot.n_retry * 4, hipMemcpyDeviceToHost, stream));
-            if (tot.n_general) {
-                special.chunks.emplace_back(new HostChunk());
-                hc = special.chunks.back().get();
+            /* the contigs of the gaps the host works on (every record of the launch, the dense words and metadata) */
+            auto contigs_to_host = [&]() -> int {
                 hc->carve(m, tw, tc, h_rec, h_w, h_m);
-                HIP_TRY(hipMemcpyAsync(glist.data(), d_glist.p, (size_t)tot.n_general * 4, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipMemcpyAsync(h_rec, d_rec.p, (size_t)m * sizeof(SlotRec), hipMemcpyDeviceToHost, stream));
                 if (tw) HIP_TRY(hipMemcpyAsync(h_w, d_dw.p, tw * 8, hipMemcpyDeviceToHost, stream));
                 if (tc) HIP_TRY(hipMemcpyAsync(h_m, d_dm.p, tc * 20, hipMemcpyDeviceToHost, stream));
+                return MTG_OK;
+            };
+            if (tot.n_general) {
+                special.chunks.emplace_back(new HostChunk());
+                hc = special.chunks.back().get();
+                HIP_TRY(hipMemcpyAsync(glist.data(), d_glist.p, (size_t)tot.n_general * 4, hipMemcpyDeviceToHost, stream));
+                if (!dev_general) { if (int crc = contigs_to_host()) return crc; }
             }
             HIP_TRY(hipEventRecord(ev3, stream));
             HIP_TRY(hipEventSynchronize(ev3));
@@ -1097,13 +1147,47 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 for (uint32_t s2 = 0; s2 < m; s2++) { sink.res[host_ids[s2]] = tmp_res[s2]; sink.fil[host_ids[s2]] = tmp_fil[s2]; }
             for (uint32_t s2 : rlist) retry.push_back(host_ids ? host_ids[s2] : s2);
             if (tot.n_retry) sink.in_gap_order = false;
-            if (hc) {
+            if (hc && dev_general) {
+                /* what the device made of the launch's multi-contig gaps: solutions and their ASCII for the gaps it finished; the contigs and the paths
+                 * of the gaps it left to the host (rare: several targets, a candidate that does not fit, an unknown k-mer) */
+                const uint64_t ng = tot.n_general;
+                const GenCtl ctl = *h_gctl;
+                const GenGap* hg = (const GenGap*)(h_gctl + 1);
+                hc->gen_gaps.assign(hg, hg + ng);
+                uint64_t n_host = 0;
+                for (uint64_t i = 0; i < ng; i++) n_host += hg[i].status != GEN_OK;
+                const uint64_t ns = std::min<uint64_t>(ctl.n_sols, GD.cap_sols), na = std::min<uint64_t>(ctl.ascii_bytes, GD.cap_ascii);
+                hc->gen_sols.resize(ns);
+                hc->gen_ascii.resize(na + 1);
+                if (ns) HIP_TRY(hipMemcpyAsync(hc->gen_sols.data(), d_gsols.p, ns * sizeof(GenSol), hipMemcpyDeviceToHost, stream));
+                if (na) HIP_TRY(hipMemcpyAsync(hc->gen_ascii.data(), d_gascii.p, na, hipMemcpyDeviceToHost, stream));
+                if (host_ids) hc->gap_of.assign(host_ids, host_ids + m);
+                const uint32_t chunk_id = (uint32_t)special.chunks.size() - 1;
+                for (uint32_t i = 0; i < (uint32_t)ng; i++) special.special.push_back(SpecialGap{host_ids ? host_ids[glist[i]] : glist[i], chunk_id, glist[i], i});
+                if (n_host) {
+                    if (int crc = contigs_to_host()) return crc;
+                    hc->paths.resize(n_host * (size_t)PATHS_WORDS);
+                    hc->path_of.assign(m, -1);
+                    uint64_t q = 0;
+                    for (uint32_t i = 0; i < (uint32_t)ng; i++)
+                        if (hg[i].status != GEN_OK) {
+                            HIP_TRY(hipMemcpyAsync(hc->paths.data() + q * PATHS_WORDS, d_paths.as<uint32_t>() + (size_t)i * PATHS_WORDS, (size_t)PATHS_WORDS * 4, hipMemcpyDeviceToHost, stream));
+                            hc->path_of[glist[i]] = (int32_t)q++;
+                        }
+                }
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (n_host) h_w[tw] = 0;
+                st.n_general_host += n_host;
+                st.n_general_device += ng - n_host;
+            } else if (hc) {
                 h_w[tw] = 0;
                 if (host_ids) hc->gap_of.assign(host_ids, host_ids + m);
                 const uint32_t chunk_id = (uint32_t)special.chunks.size() - 1;
                 std::vector<uint32_t> pslots; /* multi-contig gaps: their contig-graph paths, while the launch's scratch is still in place */
+                st.n_general_host += glist.size();
+                uint32_t grank = 0;
                 for (uint32_t s2 : glist) {
-                    special.special.push_back(SpecialGap{host_ids ? host_ids[s2] : s2, chunk_id, s2});
+                    special.special.push_back(SpecialGap{host_ids ? host_ids[s2] : s2, chunk_id, s2, grank++});
                     if (!host_paths && !in.want_all_contigs && h_rec[s2].p.fast == 0 && h_rec[s2].p.nb_terminal > 0) pslots.push_back(s2);
                 }
                 if (!pslots.empty()) {

@@ -751,11 +751,69 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
     work.resize(ng);
     std::vector<GenWork*> genw(ng, nullptr);
     struct GenGuard { std::vector<GenWork*>& v; ~GenGuard() { for (GenWork* g : v) delete g; } } gen_guard{genw};
+    /* a gap the device has finished (k_general, mtg_general.h): its solutions as they came back */
+    auto from_device = [&](const SpecialGap& sg, GapWork& W) -> bool {
+        const HostChunk& c = *special.chunks[sg.chunk];
+        if (sg.rank >= c.gen_gaps.size() || c.gen_gaps[sg.rank].status != GEN_OK) return false;
+        const GenGap& g = c.gen_gaps[sg.rank];
+        W.nb_total_filled += (int)g.nb_total_filled;
+        W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
+        for (uint32_t j = 0; j < g.n_sols; j++) {
+            const GenSol& d = c.gen_sols[g.first_sol + j];
+            Solution s;
+            s.seq.assign(c.gen_ascii.data() + d.seq_off, d.seq_len);
+            s.nb_errors = d.nb_errors; s.target = (int)d.target; s.count = d.count; s.rank = d.rank; s.qual = d.qual; s.avg = d.avg; s.median = d.median;
+            s.ab_n = 0; /* coverage done */
+            W.sols.push_back(std::move(s));
+        }
+        return true;
+    };
+    std::vector<char> on_device(ng, 0);
+    /* TEST-ONLY (HostChunk::gen_check, set by the emulation's device_run): the gaps the device function finished ALSO take the host's path, in
+     * `check`, and the two answers are compared at the end */
+    std::vector<GapWork> check;
+    std::vector<size_t> check_of;
+    for (size_t i = 0; i < ng; i++) {
+        const HostChunk& c = *special.chunks[special.special[i].chunk];
+        if (c.gen_check && special.special[i].rank < c.gen_gaps.size() && c.gen_gaps[special.special[i].rank].status == GEN_OK) check_of.push_back(i);
+    }
     parallel_for(ng, nth, [&](size_t i) {
         const SpecialGap& sg = special.special[i];
         describe(sg.gap, work[i]);
+        if (from_device(sg, work[i])) { on_device[i] = 1; return; }
         genw[i] = process_general(special.view(sg), work[i], k);
     }, 1);
+    if (!check_of.empty()) {
+        DevBatch sub; /* the same gaps as a batch of their own with the device's answers hidden: run_general's host path, whole */
+        for (size_t i : check_of) {
+            const SpecialGap& sg = special.special[i];
+            sub.special.push_back(SpecialGap{sg.gap, 0, sg.slot, ~0u});
+        }
+        /* one chunk per source chunk would need re-indexing; the emulation's batches of this kind come from one launch: check that and borrow it */
+        const uint32_t ch0 = special.special[check_of[0]].chunk;
+        for (size_t i : check_of) if (special.special[i].chunk != ch0) { set_error("general-path cross-check: gaps of several launches"); return MTG_ERR_OVERFLOW; }
+        HostChunk* borrowed = special.chunks[ch0].get();
+        sub.chunks.emplace_back(borrowed);
+        struct Unborrow { DevBatch& b; ~Unborrow() { (void)b.chunks[0].release(); } } unborrow{sub};
+        const bool saved = borrowed->gen_check;
+        borrowed->gen_check = false;
+        std::vector<GenGap> hidden;
+        hidden.swap(borrowed->gen_gaps);
+        const int crc = run_general(idx, p, sub, describe, check, ws);
+        hidden.swap(borrowed->gen_gaps);
+        borrowed->gen_check = saved;
+        if (crc) return crc;
+        for (size_t q = 0; q < check_of.size(); q++) {
+            const GapWork& a = work[check_of[q]];
+            const GapWork& b = check[q];
+            bool same = a.sols.size() == b.sols.size() && a.nb_total_filled == b.nb_total_filled && a.has_counts == b.has_counts;
+            for (size_t j = 0; same && j < a.sols.size(); j++) {
+                const Solution &x = a.sols[j], &y = b.sols[j];
+                same = x.seq == y.seq && x.nb_errors == y.nb_errors && x.target == y.target && x.avg == y.avg && x.median == y.median && x.qual == y.qual && x.count == y.count && x.rank == y.rank;
+            }
+            if (!same) { set_error("gap %u: the device's multi-contig path (mtg_general.h) and the host's disagree", special.special[check_of[q]].gap); return MTG_ERR_OVERFLOW; }
+        }
+    }
     /* every alignment remove_almost_identical_solutions can ask for: a later candidate (rows) against an earlier one (columns) */
     std::vector<NwPair> pairs;
     for (size_t gi = 0; gi < ng; gi++) {
@@ -781,7 +839,9 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
     /* coverage of the solutions: abundance of every k-mer of source + seq (src/Filler.cpp:959-988), one batched device query */
     std::vector<uint64_t> q;
     const uint64_t mk = kmask(k);
-    for (GapWork& g : work)
+    for (size_t gi = 0; gi < ng; gi++) {
+        GapWork& g = work[gi];
+        if (on_device[gi]) continue; /* coverage, quality and orientation are the device's */
         for (auto& s : g.sols) {
             s.ab_off = q.size();
             uint64_t f = 0;
@@ -798,10 +858,12 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
             feed(s.seq.data(), s.seq.size());
             s.ab_n = q.size() - s.ab_off;
         }
+    }
     std::vector<uint32_t> ab(q.size());
     if (!q.empty()) { if (int rc = query_run(idx, q.data(), q.size(), ab.data(), nullptr, nullptr, ws)) return rc; }
     parallel_for(ng, nth, [&](size_t ii) {
         GapWork& g = work[ii];
+        if (on_device[ii]) return;
         for (auto& s : g.sols) {
             std::vector<unsigned int> v(ab.begin() + s.ab_off, ab.begin() + s.ab_off + s.ab_n);
             uint64_t sum = 0;

@@ -8,6 +8,7 @@
 #include "../../include/mtg_fill.h"
 #include "mtg_hostutil.h"
 #include "mtg_paths.h"
+#include "mtg_general.h"
 #include "mtg_emit.h"
 #include "mtg_copy.h"
 #include "mtg_format.h"
@@ -475,6 +476,13 @@ struct HostChunk {
     std::vector<uint32_t> paths;
     std::vector<int32_t> path_of;
     std::vector<uint32_t> gap_of; /* gap of every slot (empty: slot = gap) */
+    /* what the device made of the launch's multi-contig gaps (k_general, mtg_general.h): a header per gap in the order of the launch's list (empty:
+     * the host takes them all), the solutions and their ASCII */
+    std::vector<mtg::GenGap> gen_gaps;
+    std::vector<mtg::GenSol> gen_sols;
+    std::vector<char> gen_ascii;
+    bool gen_check = false; /* TEST-ONLY (set by the emulation's device_run, which always brings the contigs along): the host's path runs next to every
+                               device answer and run_general compares the two */
     /* carves recs / words / meta for m slots, tw words, tc metadata entries out of `own` */
     void carve(uint32_t m_, uint64_t tw, uint64_t tc, mtg::SlotRec*& r, uint64_t*& w, uint32_t*& mt)
     {
@@ -506,6 +514,7 @@ struct GapDev {
 };
 struct SpecialGap {
     uint32_t gap, chunk, slot;
+    uint32_t rank; /* its place in the launch's list of multi-contig gaps (HostChunk::gen_gaps) */
 };
 struct DevBatch {
     std::vector<std::unique_ptr<HostChunk>> chunks; /* launches that had gaps for the host */

@@ -111,6 +111,47 @@ MTG_DEV uint64_t le_kmer(const uint64_t* w, uint32_t j, uint64_t mk)
     return (lo | hi) & mk;
 }
 
+/* sorted[n / 2] (hi) and sorted[n / 2 - 1] (lo) of n values 0 .. 255 given as a histogram of 256 bins (the exact median of src/Utils.cpp:241-254 is hi
+ * for odd n, their mean for even n); by the lanes of a wave after a wave_sync */
+MTG_DEV void hist_median(const uint32_t* hist, uint32_t nk, uint32_t& hi, uint32_t& lo)
+{
+    const uint32_t n2 = nk / 2;
+    hi = 0; lo = 0;
+#ifdef MTG_EMU
+    {
+        uint32_t cum = 0;
+        bool got_hi = false, got_lo = (n2 == 0);
+        for (uint32_t v = 0; v < 256 && !(got_hi && got_lo); v++) {
+            cum += hist[v];
+            if (!got_lo && cum > n2 - 1) { lo = v; got_lo = true; }
+            if (!got_hi && cum > n2) { hi = v; got_hi = true; }
+        }
+    }
+#else
+    {
+        /* four bins per lane, an inclusive scan over the lanes, and the two lanes that hold the ranks n2 - 1 and n2 say which bins they fall into */
+        const uint32_t lane = MTG_LANE();
+        uint32_t c4[4], s4 = 0;
+MTG_UNROLL
+        for (int i = 0; i < 4; i++) { c4[i] = hist[4u * lane + (uint32_t)i]; s4 += c4[i]; }
+        uint32_t incl = s4;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
+        uint32_t cum = incl - s4, f_hi = 0, f_lo = 0;
+MTG_UNROLL
+        for (int i = 0; i < 4; i++) {
+            const uint32_t nxt = cum + c4[i];
+            if (cum <= n2 && nxt > n2) f_hi = 4u * lane + (uint32_t)i + 1u;
+            if (n2 > 0 && cum <= n2 - 1u && nxt > n2 - 1u) f_lo = 4u * lane + (uint32_t)i + 1u;
+            cum = nxt;
+        }
+        f_hi = wave_max32(f_hi);
+        f_lo = wave_max32(f_lo);
+        hi = f_hi ? f_hi - 1u : 0u;
+        lo = f_lo ? f_lo - 1u : 0u;
+    }
+#endif
+}
+
 /* The scans read a contig through a tile of its words staged in LDS: one round of wide, coalesced loads per tile instead of one
  * dependent round trip to memory per 64 positions (which is what bound this kernel: 47 round trips for a 3 kb contig). */
 #ifndef MTG_POST_TILE
@@ -366,39 +407,7 @@ MTG_UNROLL
     sum = wave_sum32(sum);
     wave_sync();
     uint32_t hi = 0, lo = 0;
-    const uint32_t n2 = nk / 2; /* sorted[n2], sorted[n2-1] */
-#ifdef MTG_EMU
-    {
-        uint32_t cum = 0;
-        bool got_hi = false, got_lo = (n2 == 0);
-        for (uint32_t v = 0; v < 256 && !(got_hi && got_lo); v++) {
-            cum += hist[v];
-            if (!got_lo && cum > n2 - 1) { lo = v; got_lo = true; }
-            if (!got_hi && cum > n2) { hi = v; got_hi = true; }
-        }
-    }
-#else
-    {
-        /* four bins per lane, an inclusive scan over the lanes, and the two lanes that hold the ranks n2 - 1 and n2 say which bins they fall into */
-        uint32_t c4[4], s4 = 0;
-MTG_UNROLL
-        for (int i = 0; i < 4; i++) { c4[i] = hist[4u * lane + (uint32_t)i]; s4 += c4[i]; }
-        uint32_t incl = s4;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
-        uint32_t cum = incl - s4, f_hi = 0, f_lo = 0;
-MTG_UNROLL
-        for (int i = 0; i < 4; i++) {
-            const uint32_t nxt = cum + c4[i];
-            if (cum <= n2 && nxt > n2) f_hi = 4u * lane + (uint32_t)i + 1u;
-            if (n2 > 0 && cum <= n2 - 1u && nxt > n2 - 1u) f_lo = 4u * lane + (uint32_t)i + 1u;
-            cum = nxt;
-        }
-        f_hi = wave_max32(f_hi);
-        f_lo = wave_max32(f_lo);
-        hi = f_hi ? f_hi - 1u : 0u;
-        lo = f_lo ? f_lo - 1u : 0u;
-    }
-#endif
+    hist_median(hist, nk, hi, lo);
     out.fast = 1;
     out.ab_sum = sum;
     out.ab_n = nk;

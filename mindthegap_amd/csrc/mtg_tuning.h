@@ -43,6 +43,7 @@
     X(NO_LEAN, "", "test", "every contig is materialised (no lean gaps)") \
     X(NO_DEFER, "", "test", "the lanes of the traversal copy their long runs themselves (no copy commands, no k_copy work)") \
     X(MAX_CHUNK, "", "test", "gaps per traversal launch (default: what the scratch holds): several launches per batch") \
+    X(HOST_GENERAL, "", "test", "the multi-contig gaps by the host's path (candidate sequences, de-duplication, coverage: as until round 4) instead of k_general") \
     X(HOST_PATHS, "", "test", "leave the path enumeration of multi-contig gaps to the host") \
     X(DEBUG_SKIP_FINISH, "", "diag", "parked gaps stay parked (and fail as overflowing gaps)") \
     X(KERNEL_TIMERS, "", "diag", "every batch records an event between its kernels and mtg_last_batch_stats carries each kernel's own time (off: three events per batch instead of nine, only device_span_ms)") \

@@ -615,8 +615,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 if (!identity) hc->gap_of = ids;
                 const uint32_t chunk_id = (uint32_t)special.chunks.size() - 1;
                 std::vector<uint32_t> pslots;
+                uint32_t grank = 0;
                 for (uint32_t s2 : glist) {
-                    special.special.push_back(SpecialGap{ids[s2], chunk_id, s2});
+                    special.special.push_back(SpecialGap{ids[s2], chunk_id, s2, grank++});
                     if (!getenv("MTG_HOST_PATHS") && !in.want_all_contigs && recs[s2].p.fast == 0 && recs[s2].p.nb_terminal > 0) pslots.push_back(s2);
                 }
                 if (!pslots.empty()) { /* stand-in for k_paths */
@@ -629,6 +630,34 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                         hc->path_of[pslots[g2]] = (int32_t)g2;
                     }
                 }
+                /* stand-in for k_general (mtg_general.h): the multi-contig gaps finished by the device function, one lane.  The host's path sees the
+                 * same gaps (their contigs and paths are here anyway) and run_general compares the two answers: gen_check. */
+                if (!getenv("MTG_HOST_PATHS") && !getenv("MTG_HOST_GENERAL") && !in.want_all_contigs && pslots.size() == glist.size()) {
+                    const size_t ng = glist.size();
+                    /* small arenas: a launch with many or long solutions overflows them and those gaps fall back to the host, as on the device */
+                    const bool tiny = getenv("MTG_EMU_GEN_TINY") != nullptr;
+                    std::vector<GenSol> sols(tiny ? 3 : 4 * ng + 64);
+                    std::vector<char> ascii(tiny ? 600 : ng * 1280 + (1u << 16));
+                    std::vector<uint64_t> tmp(tiny ? 40 : ng * 64 + (1u << 14));
+                    GenCtl ctl{};
+                    hc->gen_gaps.assign(ng, GenGap{});
+                    GenDev GD{};
+                    GD.gaps = hc->gen_gaps.data(); GD.sols = sols.data(); GD.ascii = ascii.data(); GD.tmp = tmp.data(); GD.bnd = nullptr;
+                    GD.cap_sols = sols.size(); GD.cap_ascii = ascii.size(); GD.cap_tmp = tmp.size(); GD.cap_bnd = ~0ull; GD.ctl = &ctl;
+                    for (size_t g2 = 0; g2 < ng; g2++) {
+                        const uint32_t s2 = glist[g2], gi = ids[s2];
+                        GenWork* gw = new GenWork();
+                        GapScratch S = carve(cfg, zero.data(), raws[s2].data(), ilv.data(), 0);
+                        gen_gap(idx->dev, cfg, S, recs[s2].o, k, hc->paths.data() + (size_t)hc->path_of[s2] * PATHS_WORDS, in.tcnt[gi], in.fast_ok[gi] != 0, in.src[gi], in.flags[gi], GD,
+                                (uint32_t)g2, *gw);
+                        delete gw;
+                    }
+                    hc->gen_sols.assign(sols.begin(), sols.begin() + std::min<size_t>(ctl.n_sols, sols.size()));
+                    hc->gen_ascii.assign(ascii.begin(), ascii.begin() + std::min<size_t>(ctl.ascii_bytes, ascii.size()));
+                    hc->gen_ascii.push_back(0);
+                    hc->gen_check = true;
+                    for (size_t g2 = 0; g2 < ng; g2++) { if (hc->gen_gaps[g2].status == GEN_OK) st.n_general_device++; else st.n_general_host++; }
+                } else st.n_general_host += glist.size();
             }
             st.n_launches++;
             st.seq_bytes += tot.end[2] - tot.begin[2];

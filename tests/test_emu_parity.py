@@ -603,6 +603,63 @@ def test_cli_on_emulator_allelic_inserts(emu_product, tmp_path):
     _allelic_inserts_case(emu_product, tmp_path, 16)
 
 
+def test_multi_contig_gaps_by_the_device_function(emu_product, tmp_path, monkeypatch):
+    """mtg_general.h (k_general on the device): the multi-contig gaps of the allelic-insert set -- paths as a set, paths_to_sequences,
+    remove_almost_identical_solutions with the wave's alignment, coverage, quality, ASCII -- are finished by the device function, and the host's
+    path, run next to every one of them by the emulation build, agrees (HostChunk::gen_check: a disagreement is an error of the fill).  Then the
+    same with work arenas too small for most gaps (they fall back to the host, as on the device when an arena overflows), with the host's path
+    alone (HOST_GENERAL), on reverse attempts, and against the oracle."""
+    rng = random.Random(78)
+    seqs, gaps = [], []
+    for i in range(24):
+        L, R = _rand_seq(rng, 300), _rand_seq(rng, 300)
+        a = _rand_seq(rng, rng.randrange(120, 700))
+        if i % 3 == 0:
+            p = rng.randrange(40, len(a) - 60)
+            b = a[:p] + a[p + 30:]                      # the alleles align at > 90 %: one solution survives
+        elif i % 3 == 1:
+            b = _rand_seq(rng, rng.randrange(120, 700))  # unrelated alleles: two solutions
+        else:
+            b = a[:60] + _rand_seq(rng, 40) + a[60:]     # an insertion inside the insert
+        seqs += [L + a + R, L + b + R]
+        gaps.append((L[-31:], R[:31]))
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    idx = emu_product.Index.from_kmers(km, ct, 31)
+
+    def run(reverse):
+        gl = []
+        for (l, r) in gaps:
+            if reverse:
+                gl.append(emu_product.Gap(_rc(r), _rc(l), [(_rc(l), "x", False)], reverse=True))
+            else:
+                gl.append(emu_product.Gap(l, r, [(r, "x", False)]))
+        res = idx.fill_batch(gl)
+        return res, emu_product.last_batch_stats()
+
+    res, st = run(False)
+    assert st["n_general_device"] >= 12 and st["n_general_host"] == 0, st
+    assert sum(1 for r in res if len(r["filled"]) == 2) >= 4 and sum(1 for r in res if len(r["filled"]) == 1) >= 4
+    monkeypatch.setenv("MTG_HOST_GENERAL", "1")
+    res_h, st_h = run(False)
+    assert st_h["n_general_device"] == 0 and st_h["n_general_host"] >= 12
+    assert res_h == res
+    monkeypatch.delenv("MTG_HOST_GENERAL")
+    monkeypatch.setenv("MTG_EMU_GEN_TINY", "1")
+    res_t, st_t = run(False)
+    assert st_t["n_general_host"] >= 6 and st_t["n_general_device"] >= 1, st_t
+    assert res_t == res
+    monkeypatch.delenv("MTG_EMU_GEN_TINY")
+    res_r, st_r = run(True)
+    assert st_r["n_general_device"] >= 12
+    for a, b in zip(res, res_r):  # the reverse attempt reports the reverse complements of what it assembled: as many solutions, and the same inserts where both alleles survive
+        assert len(a["filled"]) == len(b["filled"])
+        if len(a["filled"]) == 2:
+            assert sorted(f["seq"] for f in a["filled"]) == sorted(f["seq"] for f in b["filled"])
+    idx.close()
+    o.close()
+
+
 def test_cli_on_emulator_diploid(emu_product, tmp_path):
     _diploid_case(emu_product, tmp_path, 10)
 
