@@ -907,7 +907,10 @@ MTG_DEV void build_lookahead(const Index& ix, const Kmer& x)
     if (e) atomic_or64(e + 1, fwd0 ? (uint64_t)la : ((uint64_t)la << 32));
 }
 
-/* ---- unitig store construction (after every insertion and every lookahead) -------------------------------------------------------
+/* ---- unitig store construction from DENSE tables (after every insertion and every lookahead): the construction of rounds 1-3.  The product
+ * builds the store from the junction table since round 4 (mtg_build.h) and dropped this path in round 5; us_is_start / us_walk / us_plan /
+ * us_emit / us_link below are kept as the TEST-ONLY reference construction of the emulation (tests/emu/emu_us.h), which builds every index
+ * both ways and compares them (test_lean_build_equals_the_legacy_build) -------------------------------------------------------
  * A junction between the consecutive solid k-mers p = a+J and y = J+b is ELIGIBLE when it is simple (y is the only successor of p, p
  * the only predecessor of y) and neither a turning point nor a self loop: J is not its own reverse complement (then y = rc(p)), p != y,
  * and neither k-mer is its own reverse complement.  Chains of eligible junctions are linear or closed; along a linear chain all canonical

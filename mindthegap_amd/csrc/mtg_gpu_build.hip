@@ -3,7 +3,8 @@
  *
  *   k_jt_insert_* / k_jt_scan / k_jt_plan_emit / k_us_compact / k_us_ab / k_sparse_link : the lean build (mtg_dev.h: junction table -> unitig store -> sparse tables)
  *   k_count / k_count_stats                                                      : exact k-mer counting of streamed reads (-in)
- *   k_insert_* / k_lookahead_* / k_us_* / k_leftovers                            : the construction of rounds 1-3 (dense tables; test hooks)
+ *   k_insert_kmers / k_lookahead_kmers / k_sparse_ends / k_leftovers             : the k-mers of no unitig in the sparse tables; the container writer
+ * (the construction of rounds 1-3 -- dense ADJ / ABND tables, lookaheads for every junction, the store derived from them -- left in round 5)
  */
 #include "mtg_gpu_common.h"
 #include "mtg_build.h"
@@ -58,37 +59,6 @@ __global__ void k_insert_kmers(Index ix, const uint64_t* __restrict__ kmers, con
     if (sat) atomicAdd(&counters[3], sat); /* abundances stored as 255 */
 }
 
-/* one workgroup per sequence; lanes stride over k-mer start positions */
-__global__ void k_insert_packed(Index ix, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len,
-                                size_t nseq, uint32_t abund_lo, uint32_t abund_span, unsigned long long* counters)
-{
-    const int k = ix.k;
-    const uint64_t mk = kmask(k);
-    unsigned long long created = 0;
-    int fail = 0;
-    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
-        const uint64_t* w = words + word_off[s];
-        const uint32_t L = len[s];
-        if (L < (uint32_t)k) continue;
-        for (uint32_t p = threadIdx.x; p + k <= L; p += blockDim.x) {
-            /* nts p .. p+k-1, nt i at bits 2*(i%32) of word i/32 */
-            uint64_t f = 0;
-            for (int j = 0; j < k; j++) {
-                const uint32_t i = p + j;
-                f = (f << 2) | ((w[i >> 5] >> (2 * (i & 31))) & 3ull);
-            }
-            f &= mk;
-            const uint64_t r = revcomp(f, k);
-            const uint64_t c = f < r ? f : r;
-            const uint32_t a = d_synth_abundance(c, abund_lo, abund_span);
-            int rr = index_insert(ix, c, a);
-            fail |= rr & 1;
-            created += (rr >> 1) & 1;
-        }
-    }
-    if (fail) atomicOr(&counters[0], 1ull);
-    if (created) atomicAdd(&counters[1], created);
-}
 
 /* k-mer counting: one text position per lane (adjacent lanes read adjacent bytes); flags[0] = table too full */
 __global__ void k_count(CountTable t, const char* __restrict__ text, uint64_t n, int k, uint32_t npass, uint32_t pass, unsigned long long* flags)
@@ -122,39 +92,6 @@ __global__ void k_count_stats(CountTable t, uint32_t keep_min, unsigned long lon
     for (uint32_t j = threadIdx.x; j < 256 && j < nbins; j += blockDim.x) if (lh[j]) atomicAdd(&histo[j], (unsigned long long)lh[j]);
     if (keep) atomicAdd(n_keep, keep);
 }
-/* the solid k-mers of a count table (count in [lo, hi]) straight into the index tables; counters as k_insert_kmers */
-__global__ void k_insert_from_counts(Index ix, CountTable t, uint32_t lo, uint32_t hi, unsigned long long* counters)
-{
-    unsigned long long created = 0, sat = 0;
-    int fail = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = t.keys[i];
-        if (key == ~0ULL) continue;
-        const uint32_t c = t.counts[i];
-        if (c < lo || c > hi) continue;
-        const int r = index_insert(ix, key, c);
-        fail |= r & 1;
-        created += (r >> 1) & 1;
-        sat += c > 255u;
-    }
-    if (fail) atomicOr(&counters[0], 1ull);
-    if (created) atomicAdd(&counters[1], created);
-    if (sat) atomicAdd(&counters[3], sat);
-}
-/* lookaheads for every solid k-mer, read back from the ABND table (an index that was not built from a k-mer list) */
-__global__ void k_lookahead_table(Index ix)
-{
-    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t c;
-        if (!abnd_slot_kmer(ix.abnd, s, c)) continue;
-        Kmer x = make_kmer(c, ix.k);
-        build_lookahead(ix, x);
-        Kmer y;
-        y.f = x.r; y.r = x.f;
-        build_lookahead(ix, y);
-    }
-}
 
 /* second build pass: lookaheads of the ADJ entries (after every k-mer has been inserted) */
 __global__ void k_lookahead_kmers(Index ix, const uint64_t* __restrict__ kmers, size_t n)
@@ -169,79 +106,8 @@ __global__ void k_lookahead_kmers(Index ix, const uint64_t* __restrict__ kmers, 
         build_lookahead(ix, y);
     }
 }
-__global__ void k_lookahead_packed(Index ix, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len, size_t nseq)
-{
-    const int k = ix.k;
-    const uint64_t mk = kmask(k);
-    for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
-        const uint64_t* w = words + word_off[s];
-        const uint32_t L = len[s];
-        if (L < (uint32_t)k) continue;
-        for (uint32_t p = threadIdx.x; p + k <= L; p += blockDim.x) {
-            Kmer x;
-            x.r = le_kmer(w, p, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
-            x.f = revcomp(x.r, k);
-            build_lookahead(ix, x);
-            Kmer y;
-            y.f = x.r; y.r = x.f;
-            build_lookahead(ix, y);
-        }
-    }
-}
 
 /* ---- unitig store construction (mtg_dev.h: us_*), over the solid k-mers read back from the ABND table ---- */
-/* counters[0] += chain starts; counters[1] += branching nodes (in-degree != 1 or out-degree != 1); counters[2] += solid k-mers.
- * starts != nullptr: the oriented start k-mers are also collected there (counters[3] = cursor). */
-__global__ void k_us_starts(Index ix, unsigned long long* counters, uint64_t* starts, unsigned long long cap)
-{
-    const uint64_t nslots = ix.abnd.nbuckets * MTG_ABND_SLOTS;
-    const uint64_t mk1 = kmask(ix.k - 1);
-    uint32_t lines = 0;
-    unsigned long long ns = 0, nbr = 0, nk = 0;
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t c;
-        if (!abnd_slot_kmer(ix.abnd, s, c)) continue;
-        nk++;
-        Kmer o[2];
-        o[0] = make_kmer(c, ix.k);
-        o[1].f = o[0].r; o[1].r = o[0].f;
-        if (!starts) nbr += !(popc4(adj_right_t(ix.adj, o[0], mk1, lines).out) == 1 && popc4(adj_left(ix, o[0], mk1, lines).in) == 1);
-        for (int u = 0; u < (o[0].f == o[0].r ? 1 : 2); u++) {
-            if (!us_is_start(ix, o[u], lines)) continue;
-            ns++;
-            if (starts) { const unsigned long long at = atomicAdd(&counters[3], 1ull); if (at < cap) starts[at] = o[u].f; }
-        }
-    }
-    if (!starts) { if (ns) atomicAdd(&counters[0], ns); if (nbr) atomicAdd(&counters[1], nbr); if (nk) atomicAdd(&counters[2], nk); }
-}
-/* one chain start per lane: walks to the other end; the end with the smaller canonical k-mer reserves the unitig's words and record.
- * cursors[0] = words, cursors[1] = records */
-__global__ void __launch_bounds__(64) k_us_plan(Index ix, const uint64_t* __restrict__ starts, unsigned long long n, unsigned long long* cursors, UsRec* rec, unsigned long long rec_cap)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t lines = 0;
-    us_plan_start(ix, make_kmer(starts[i], ix.k), &cursors[0], &cursors[1], rec, rec_cap, lines);
-}
-/* one stored unitig per lane: its sequence into the store */
-__global__ void __launch_bounds__(64) k_us_emit(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t lines = 0;
-    us_emit(ix, rec[i], lines);
-}
-/* one stored unitig per wave, its k-mers dealt to the lanes: abundances into the store, pointers into the ADJ entries of its junctions */
-__global__ void __launch_bounds__(256) k_us_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n)
-{
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t lines = 0;
-    for (unsigned long long u = wave; u < n; u += nwaves) {
-        const UsRec r = rec[u];
-        for (uint32_t i = lane; i < r.len_k; i += 64) us_link(ix, r, i, lines);
-    }
-}
 /* ---- the sparse form (mtg_dev.h: "sparse index") ----
  * the k-mers of no stored unitig, out of the ABND table of the index the unitigs were built from (or of a sparse one): out == nullptr counts */
 __global__ void k_leftovers(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned long long* cursor, unsigned long long cap)
@@ -567,42 +433,6 @@ struct IndexGuard {
 };
 } // namespace
 
-static int alloc_tables(mtg_index* idx, uint64_t nkeys, double load_scale)
-{
-    const int k = idx->dev.k;
-    /* ADJ entries are 16 bytes and looked up on a dependent chain: keep buckets sparse; ABND is only read by independent queries */
-    const double load_adj = tune::f(tune::T_ADJ_LOAD, 0.5) * load_scale;
-    const double load = tune::f(tune::T_ABND_LOAD, 0.6) * load_scale;
-    table_shape(idx->dev.adj, buckets_for(nkeys + nkeys / 8 + 1024, load_adj, 2 * (k - 1), MTG_ADJ_SLOTS), 2 * (k - 1));
-    table_shape(idx->dev.abnd, buckets_for(nkeys, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
-    const size_t ba = idx->dev.adj.nbuckets * 16 * MTG_ADJ_SLOTS, bb = idx->dev.abnd.nbuckets * 8 * MTG_ABND_SLOTS;
-    HIP_TRY(hipMalloc((void**)&idx->dev.adj.slots, ba));   /* a failure further down leaves the pointers to free_tables (IndexGuard) */
-    HIP_TRY(hipMalloc((void**)&idx->dev.abnd.slots, bb));
-    const double bpk = tune::f(tune::T_BLOOM_BITS, 12.0);
-    size_t bc = 0;
-    idx->dev.bloom.bits = nullptr;
-    idx->dev.bloom.nblocks = 0;
-    if (bpk > 0) {
-        bloom_shape(idx->dev.bloom, nkeys, bpk, k);
-        bc = idx->dev.bloom.nblocks * 64;
-        HIP_TRY(hipMalloc((void**)&idx->dev.bloom.bits, bc));
-        HIP_TRY(hipMemsetAsync(idx->dev.bloom.bits, 0, bc, 0));
-    }
-    HIP_TRY(hipMemsetAsync(idx->dev.adj.slots, 0, ba, 0));
-    HIP_TRY(hipMemsetAsync(idx->dev.abnd.slots, 0, bb, 0));
-    idx->info.device_bytes = ba + bb + bc;
-    idx->info.bloom_blocks = idx->dev.bloom.nblocks;
-    idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
-    idx->info.adj_buckets = idx->dev.adj.nbuckets;
-    idx->info.abnd_buckets = idx->dev.abnd.nbuckets;
-    idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
-    idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
-    return MTG_OK;
-}
-
-/* Unitig store of a finished index (every k-mer inserted, every lookahead written): chain starts -> one walk per start -> sequences ->
- * abundances and junction pointers (mtg_dev.h: us_*).  Also fills nb_solid_kmers / nb_branching from the table itself.
- * MTG_NO_UNITIGS=1 (test hook) leaves the index with inline lookaheads only. */
 namespace {
 /* the k-mers of no stored unitig of a construction that can only name them once the unitigs' entries are in the new tables (lean build, a
  * closed or over-long chain in the graph): called with the sparse ADJ table holding every unitig pointer; fills the lists */
@@ -613,84 +443,15 @@ struct LateLeftovers {
 } // namespace
 static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
                     BuildProf* prof = nullptr, const LateLeftovers* late = nullptr, DevBuf* adj_reuse = nullptr);
-static int build_unitigs(mtg_index* idx)
-{
-    DevBuf d_cnt, d_starts, d_rec;
-    HIP_TRY(d_cnt.alloc(64));
-    HIP_TRY(hipMemset(d_cnt.p, 0, 64));
-    const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
-    const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(k_us_starts, dim3(blocks), dim3(256), 0, 0, idx->dev, d_cnt.as<unsigned long long>(), (uint64_t*)nullptr, 0ull);
-    HIP_TRY(hipGetLastError());
-    unsigned long long cnt[8];
-    HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
-    idx->info.nb_solid_kmers = cnt[2];
-    idx->info.nb_branching = cnt[1];
-    idx->info.nb_unitigs = 0;
-    idx->info.unitig_bytes = 0;
-    const unsigned long long n_starts = cnt[0];
-    if (n_starts == 0 || tune::on(tune::T_NO_UNITIGS)) return MTG_OK;
-    HIP_TRY(d_starts.alloc(n_starts * 8));
-    hipLaunchKernelGGL(k_us_starts, dim3(blocks), dim3(256), 0, 0, idx->dev, d_cnt.as<unsigned long long>(), d_starts.as<uint64_t>(), n_starts);
-    HIP_TRY(hipGetLastError());
-    const unsigned long long rec_cap = n_starts / 2 + 1; /* two starts per stored unitig (one per strand) */
-    HIP_TRY(d_rec.alloc(rec_cap * sizeof(UsRec)));
-    HIP_TRY(hipMemset(d_cnt.p, 0, 64));
-    hipLaunchKernelGGL(k_us_plan, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, idx->dev, d_starts.as<uint64_t>(), n_starts, d_cnt.as<unsigned long long>(), d_rec.as<UsRec>(), rec_cap);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(cnt, d_cnt.p, 64, hipMemcpyDeviceToHost));
-    const unsigned long long n_words = cnt[0], n_rec = cnt[1];
-    if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
-    (void)d_starts.alloc(0);
-    if (n_rec == 0) return MTG_OK;
-    /* a few words of padding: the coverage pass may look up to 64 + k nucleotides past the end of a unitig */
-    const unsigned long long pad = 8;
-    HIP_TRY(hipMalloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
-    HIP_TRY(hipMalloc((void**)&idx->dev.us.ab, (n_words + pad) * 32));
-    HIP_TRY(hipMemsetAsync(idx->dev.us.words, 0, (n_words + pad) * 8, 0));
-    HIP_TRY(hipMemsetAsync(idx->dev.us.ab, 0, (n_words + pad) * 32, 0));
-    idx->dev.us.nwords = n_words;
-    idx->dev.us.nunitigs = n_rec;
-    hipLaunchKernelGGL(k_us_emit, dim3((unsigned)((n_rec + 63) / 64)), dim3(64), 0, 0, idx->dev, d_rec.as<UsRec>(), n_rec);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_us_link, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev, d_rec.as<UsRec>(), n_rec);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    idx->info.nb_unitigs = n_rec;
-    idx->info.unitig_bytes = (n_words + pad) * 40;
-    idx->info.device_bytes += idx->info.unitig_bytes;
-    /* the dense tables have served: the index proper is the store plus the few k-mers of no unitig (MTG_DENSE_INDEX=1: A/B and test hook) */
-    if (tune::on(tune::T_DENSE_INDEX)) return MTG_OK;
-    return sparsify(idx, d_rec.as<UsRec>(), n_rec, false, nullptr, nullptr, 0);
-}
-
-/* The sparse form.  From a dense index with its store (from_container == false: the k-mers of no unitig are read off its ABND table, the
- * dense tables are freed at the end) or from the store alone (an index out of its container: idx holds only the store; the k-mers of no
- * unitig are handed over, the Bloom filter is filled here).  New tables: ADJ with the entries the sparse form keeps, ABND with the k-mers
- * of no unitig. */
+/* The sparse form, from the unitig store (idx holds only the store: the lean build, or an index out of its container) and the k-mers of no
+ * unitig, which are handed over; the Bloom filter is filled here.  New tables: ADJ with the entries the sparse form keeps, ABND with the
+ * k-mers of no unitig.  (from_container is true for every caller since round 5: the build that derived the store from dense tables is gone.) */
 static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
                     BuildProf* prof, const LateLeftovers* late, DevBuf* adj_reuse)
 {
     const int k = idx->dev.k;
     DevBuf d_cnt, own_k, own_a;
     HIP_TRY(d_cnt.alloc(64));
-    if (!from_container) {
-        if (prof) prof->begin();
-        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
-        const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
-        const unsigned blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
-        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, (uint64_t*)nullptr, (uint32_t*)nullptr, d_cnt.as<unsigned long long>(), 0ull);
-        HIP_TRY(hipMemcpy(&n_left, d_cnt.p, 8, hipMemcpyDeviceToHost));
-        HIP_TRY(own_k.alloc((n_left + 1) * 8));
-        HIP_TRY(own_a.alloc((n_left + 1) * 4));
-        HIP_TRY(hipMemset(d_cnt.p, 0, 64));
-        hipLaunchKernelGGL(k_leftovers, dim3(blocks), dim3(256), 0, 0, idx->dev, own_k.as<uint64_t>(), own_a.as<uint32_t>(), d_cnt.as<unsigned long long>(), (unsigned long long)n_left);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
-        d_left_k = own_k.as<uint64_t>();
-        d_left_a = own_a.as<uint32_t>();
-        if (prof) HIP_TRY(prof->end("leftovers_dense", 2 * nslots * 8, nslots));
-    }
     const unsigned long long n_left_shape = late ? std::max(late->n_upper, n_left) : n_left;
     /* entries of the new ADJ: per unitig its kept interior junctions (every second one and the last) and its two ends; two per k-mer of no unitig */
     uint64_t nkeys = 2 * n_left_shape + 1024, n_unitig_kmers = 0;
@@ -925,9 +686,6 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     return MTG_OK;
 }
 
-/* MTG_DENSE_INDEX=1 / MTG_NO_UNITIGS=1 (test hooks: the dense form of the index, the index without a unitig store) and MTG_LEGACY_BUILD=1
- * (A/B) take the construction of rounds 1-3: dense ADJ + ABND tables, lookaheads, the store from them, then the sparse form */
-static bool legacy_build() { return tune::on(tune::T_DENSE_INDEX) || tune::on(tune::T_NO_UNITIGS) || tune::on(tune::T_LEGACY_BUILD); }
 static double jt_load() { return tune::f(tune::T_JT_LOAD, 0.7); }
 /* a cleared table of MTG_ABND_SLOTS-slot buckets for nkeys keys of key_bits bits */
 /* bytes the sparse ADJ table of a graph of n k-mers will take, give or take: half the junctions and a little (sparsify) */
@@ -1052,60 +810,7 @@ int index_from_kmer_pieces(size_t n, int k, const KmerFetch& fetch, mtg_index** 
 {
     if (int rc = ensure_device()) return rc;
     if (k < 11 || k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    if (!legacy_build()) return index_from_kmer_pieces_lean(n, k, fetch, out);
-    IndexGuard g(new mtg_index());
-    mtg_index* idx = g.idx;
-    idx->dev.k = k;
-    HIP_TRY(hipGetDevice(&idx->device));
-    DevBuf d_k, d_a, d_cnt;
-    HIP_TRY(d_cnt.alloc(4 * 8));
-    const size_t env_piece = (size_t)tune::i(tune::T_LOAD_PIECE, 0); /* test hook: small pieces */
-    const size_t piece = std::min<size_t>(std::max<size_t>(n, 1), env_piece ? env_piece : (size_t)1 << 26);
-    HIP_TRY(d_k.alloc(piece * 8));
-    HIP_TRY(d_a.alloc(piece * 4));
-    double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
-    int rc = MTG_OK;
-    for (int attempt = 0; attempt < 6; attempt++) {
-        free_tables(idx);
-        rc = alloc_tables(idx, n, load);
-        if (rc) return rc;
-        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
-        for (size_t off = 0; off < n; off += piece) {
-            const size_t m = std::min(piece, n - off);
-            const uint64_t* hk = nullptr;
-            const uint32_t* ha = nullptr;
-            if (!fetch(off, m, hk, ha)) return MTG_ERR_IO; /* the source has set the message */
-            HIP_TRY(hipMemcpy(d_k.p, hk, m * 8, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_a.p, ha, m * 4, hipMemcpyHostToDevice));
-            const int blocks = (int)std::min<size_t>((m + 255) / 256 + 1, 256 * 16);
-            hipLaunchKernelGGL(k_insert_kmers, dim3(blocks), dim3(256), 0, 0, idx->dev, d_k.as<uint64_t>(), d_a.as<uint32_t>(), m, d_cnt.as<unsigned long long>());
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipDeviceSynchronize()); /* the source may reuse its buffers for the next piece */
-        }
-        unsigned long long cnt[4];
-        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
-        idx->info.nb_saturated = cnt[3];
-        if (!cnt[0]) {
-            if (n) {
-                const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
-                hipLaunchKernelGGL(k_lookahead_table, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev);
-                HIP_TRY(hipGetLastError());
-            }
-            HIP_TRY(hipDeviceSynchronize());
-            rc = MTG_OK;
-            break;
-        }
-        load *= 0.7;
-        rc = MTG_ERR_OVERFLOW;
-        set_error("index bucket displacement overflow");
-    }
-    if (rc) return rc;
-    if (int rc2 = build_unitigs(idx)) return rc2;
-    idx->info.k = k;
-    idx->info.abundance_min = 0;
-    idx->info.abundance_auto = -1;
-    *out = g.release();
-    return MTG_OK;
+    return index_from_kmer_pieces_lean(n, k, fetch, out);
 }
 
 int index_from_kmers(const uint64_t* canon_kmers, const uint32_t* abundance, size_t n, int k, mtg_index** out)
@@ -1119,44 +824,7 @@ int index_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off
 {
     if (int rc = ensure_device()) return rc;
     if (k < 11 || k > 31 || !out || (nseq && (!d_words || !d_word_off || !d_len))) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    if (!legacy_build()) return index_from_packed_device_lean(d_words, d_word_off, d_len, nseq, total_kmers_ub, k, abund_lo, abund_span, out);
-    IndexGuard g(new mtg_index());
-    mtg_index* idx = g.idx;
-    idx->dev.k = k;
-    HIP_TRY(hipGetDevice(&idx->device));
-    DevBuf d_cnt;
-    HIP_TRY(d_cnt.alloc(32));
-    double load = 1.0; /* scale of the default load factors; lowered when an insertion overflows its displacement range */
-    int rc = MTG_OK;
-    for (int attempt = 0; attempt < 6; attempt++) {
-        free_tables(idx);
-        rc = alloc_tables(idx, total_kmers_ub, load);
-        if (rc) return rc;
-        HIP_TRY(hipMemset(d_cnt.p, 0, 32));
-        if (nseq == 0) break; /* an empty graph: nothing to launch (a grid of zero blocks is an error that would surface later) */
-        const int blocks = (int)std::min<size_t>(nseq, 256 * 32);
-        hipLaunchKernelGGL(k_insert_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq, abund_lo, abund_span, d_cnt.as<unsigned long long>());
-        HIP_TRY(hipGetLastError());
-        unsigned long long cnt[4];
-        HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
-        if (!cnt[0]) {
-            hipLaunchKernelGGL(k_lookahead_packed, dim3(blocks), dim3(256), 0, 0, idx->dev, d_words, d_word_off, d_len, nseq);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipDeviceSynchronize());
-            rc = MTG_OK;
-            break;
-        }
-        load *= 0.7;
-        rc = MTG_ERR_OVERFLOW;
-        set_error("index bucket displacement overflow");
-    }
-    if (rc) return rc;
-    if (int rc2 = build_unitigs(idx)) return rc2;
-    idx->info.k = k;
-    idx->info.abundance_min = (int)abund_lo;
-    idx->info.abundance_auto = -1;
-    *out = g.release();
-    return MTG_OK;
+    return index_from_packed_device_lean(d_words, d_word_off, d_len, nseq, total_kmers_ub, k, abund_lo, abund_span, out);
 }
 
 /* the whole index on another device: same shapes, tables and unitig store copied device to device */
@@ -1276,8 +944,8 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
 {
     if (int rc = ensure_device()) return rc;
     if (d.k < 11 || d.k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
-    if (tune::on(tune::T_DENSE_INDEX) || d.n_words == 0) {
-        /* test hook / an index without stored unitigs: through the list of its k-mers */
+    if (d.n_words == 0) {
+        /* an index without stored unitigs: through the list of its k-mers */
         std::vector<uint64_t> km(d.left_k);
         std::vector<uint32_t> ab(d.left_a);
         const uint64_t mk = kmask(d.k);
@@ -1499,7 +1167,7 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
         HIP_TRY(d_cnt.alloc(32));
         double load = 1.0;
         int rc = MTG_OK;
-        if (!legacy_build()) {
+        {
             /* the lean build: the solid k-mers' junctions into the junction table; their abundances stay in the count table (one counting
              * pass) or go into an ABND table of their own (several: the count table of a pass does not outlive it) */
             prof.host_phase("count_reads", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - prof.t0).count(), 0, n_solid);
@@ -1547,43 +1215,6 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
             *out = g.release();
             return MTG_OK;
         }
-        for (int ia = 0; ia < 6; ia++) {
-            free_tables(idx);
-            rc = alloc_tables(idx, n_solid, load);
-            if (rc) return rc;
-            HIP_TRY(hipMemset(d_cnt.p, 0, 32));
-            for (uint32_t pass = 0; pass < npass; pass++) {
-                if (npass > 1) { /* the table of the wanted pass has to be counted again (with one pass it still holds round 1's counts) */
-                    bool ovf2 = false;
-                    if (int rc2 = count_pass(pass, ovf2)) return rc2;
-                    if (ovf2) { set_error("k-mer count table overflowed on a repeated pass"); return MTG_ERR_OVERFLOW; }
-                }
-                hipLaunchKernelGGL(k_insert_from_counts, dim3(256 * 16), dim3(256), 0, 0, idx->dev, t, lo, hi, d_cnt.as<unsigned long long>());
-                HIP_TRY(hipGetLastError());
-            }
-            unsigned long long cnt[4];
-            HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
-            idx->info.nb_saturated = cnt[3];
-            if (!cnt[0]) { rc = MTG_OK; break; }
-            load *= 0.7;
-            rc = MTG_ERR_OVERFLOW;
-            set_error("index bucket displacement overflow");
-        }
-        if (rc) return rc;
-        (void)d_keys.alloc(0); /* the count table is done with: room for the unitig construction */
-        (void)d_cnts.alloc(0);
-        {
-            const uint64_t nslots = idx->dev.abnd.nbuckets * MTG_ABND_SLOTS;
-            hipLaunchKernelGGL(k_lookahead_table, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32)), dim3(256), 0, 0, idx->dev);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipDeviceSynchronize());
-        }
-        if (int rc2 = build_unitigs(idx)) return rc2;
-        idx->info.k = k;
-        idx->info.abundance_min = abundance_min;
-        idx->info.abundance_auto = autoc;
-        *out = g.release();
-        return MTG_OK;
     }
     set_error("k-mer count table kept overflowing");
     return MTG_ERR_OVERFLOW;

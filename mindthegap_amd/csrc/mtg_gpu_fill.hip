@@ -1166,14 +1166,20 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 for (uint32_t i = 0; i < (uint32_t)ng; i++) special.special.push_back(SpecialGap{host_ids ? host_ids[glist[i]] : glist[i], chunk_id, glist[i], i});
                 if (n_host) {
                     if (int crc = contigs_to_host()) return crc;
-                    hc->paths.resize(n_host * (size_t)PATHS_WORDS);
                     hc->path_of.assign(m, -1);
-                    uint64_t q = 0;
-                    for (uint32_t i = 0; i < (uint32_t)ng; i++)
-                        if (hg[i].status != GEN_OK) {
-                            HIP_TRY(hipMemcpyAsync(hc->paths.data() + q * PATHS_WORDS, d_paths.as<uint32_t>() + (size_t)i * PATHS_WORDS, (size_t)PATHS_WORDS * 4, hipMemcpyDeviceToHost, stream));
-                            hc->path_of[glist[i]] = (int32_t)q++;
-                        }
+                    if (2 * n_host > ng) { /* most of them (contig mode: every gap has several targets): the blocks in one copy */
+                        hc->paths.resize(ng * (size_t)PATHS_WORDS);
+                        HIP_TRY(hipMemcpyAsync(hc->paths.data(), d_paths.p, ng * (size_t)PATHS_WORDS * 4, hipMemcpyDeviceToHost, stream));
+                        for (uint32_t i = 0; i < (uint32_t)ng; i++) if (hg[i].status != GEN_OK) hc->path_of[glist[i]] = (int32_t)i;
+                    } else {
+                        hc->paths.resize(n_host * (size_t)PATHS_WORDS);
+                        uint64_t q = 0;
+                        for (uint32_t i = 0; i < (uint32_t)ng; i++)
+                            if (hg[i].status != GEN_OK) {
+                                HIP_TRY(hipMemcpyAsync(hc->paths.data() + q * PATHS_WORDS, d_paths.as<uint32_t>() + (size_t)i * PATHS_WORDS, (size_t)PATHS_WORDS * 4, hipMemcpyDeviceToHost, stream));
+                                hc->path_of[glist[i]] = (int32_t)q++;
+                            }
+                    }
                 }
                 HIP_TRY(hipStreamSynchronize(stream));
                 if (n_host) h_w[tw] = 0;

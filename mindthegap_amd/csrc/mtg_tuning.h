@@ -26,17 +26,12 @@
     X(POOL_THREADS, "", "cap", "size of the host worker pool (default: the CPUs the process may use -- hardware threads, affinity mask, cgroup quota -- at most 64); read when the pool starts") \
     X(COPY_SLOTS, "3", "cap", "batches of a device that copy their results to the host at the same time (0: no limit); more copies at once share the link worse") \
     X(UPLOAD_OWN_STREAM, "", "ab", "every batch uploads its input on its own stream instead of the device's one upload stream (three uploads at a time take the link from the downloads: profiles/r04_text_entry.txt)") \
-    X(ADJ_LOAD, "0.5", "cap", "load factor of the dense junction table (legacy build)") \
-    X(ABND_LOAD, "0.6", "cap", "load factor of the abundance table") \
     X(SPARSE_ADJ_LOAD, "0.49", "cap", "load factor of the sparse junction table, as a share of the dense one's; 0.7 overflows the displacement range at human scale") \
     X(JT_LOAD, "0.7", "cap", "load factor of the lean build's junction table") \
     X(BLOOM_BITS, "12", "cap", "Bloom filter bits per k-mer (0: no filter, no sequence scan)") \
     X(LOAD_THREADS, "", "cap", "threads that stream a container's abundance bytes to the device (default: up to 8)") \
     X(LOAD_PIECE, "", "test", "k-mers per piece when an index container is loaded (default 2^26): small pieces exercise the piece loop") \
     X(COUNT_PASSES, "", "test", "force this many passes of the k-mer counting (default: as many as HBM needs)") \
-    X(LEGACY_BUILD, "", "ab", "the index construction of rounds 1-3 (dense tables first, then unitigs) instead of the lean build") \
-    X(DENSE_INDEX, "", "test", "keep the dense ADJ / ABND tables (every junction, every k-mer) instead of the sparse form") \
-    X(NO_UNITIGS, "", "test", "an index without unitig store (inline lookaheads only)") \
     X(ROUNDS, "", "ab", "bubble rounds between launches of the walk kernel (default: 6 when most gaps of the previous launch parked, else 0)") \
     X(FINISH_G, "", "ab", "lanes per parked gap in the finishing kernel: 1, 8, 16 or 64 (default: 64 while few gaps park, 16 otherwise)") \
     X(FINISH_WAVE_BELOW, "2048", "ab", "a whole wave per parked gap while the previous launch parked fewer gaps than this") \
