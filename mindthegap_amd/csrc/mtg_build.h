@@ -64,15 +64,48 @@ MTG_DEV JView jt_view(uint32_t m, bool key_is_oriented)
 }
 MTG_DEV bool jt_simple(const JView& v) { return popc4(v.out) == 1 && popc4(v.in) == 1; }
 /* the view behind x (its successors, the predecessors of those) and before x (its predecessors, the successors of those) */
+/* A junction's slot carries, while the chains are walked, one more bit: JT_MARK, "a walker crossed here at a multiple of JT_MARK_EVERY steps"
+ * (below: the walks that meet in the middle).  Bit 63 is free because the junction table has at least 2^(key_bits - 49) buckets (jt_min_buckets);
+ * every reader of the table masks it. */
+static const uint64_t JT_MARK = 1ull << 63;
+MTG_HD uint64_t jt_min_buckets(uint32_t key_bits) { return key_bits > 49 ? (1ULL << (key_bits - 49)) : 1; }
+/* the slot of `key` (nullptr: absent) and its word without the mark; marked: the mark was set when the bucket was read */
+MTG_DEV uint64_t jt_lookup(const Table& t, uint64_t key, uint32_t& lines, uint64_t*& slot, bool& marked)
+{
+    const uint64_t H = mix(key, t.key_bits);
+    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    slot = nullptr;
+    marked = false;
+    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
+        uint64_t* p = t.slots + b * MTG_ABND_SLOTS;
+        uint64_t q[MTG_ABND_SLOTS];
+MTG_UNROLL
+        for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) { const U64x2 v = ld_table(reinterpret_cast<const U64x2*>(p) + i); q[2 * i] = v.x; q[2 * i + 1] = v.y; }
+        lines++;
+        const uint64_t want = (tag << MTG_DISP_BITS) | d;
+        for (int i = 0; i < MTG_ABND_SLOTS; i++) {
+            const uint64_t v = q[i] & ~JT_MARK;
+            if (v != 0 && (v >> 8) == want) { slot = p + i; marked = (q[i] & JT_MARK) != 0; return v; }
+        }
+        if (q[MTG_ABND_SLOTS - 1] == 0) return 0; /* slots fill in order: a free last slot means the key cannot be further away */
+        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
+    }
+    return 0;
+}
 MTG_DEV JView jt_right(const Table& jt, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     const uint64_t s = x.f & mk1, rs = x.r >> 2;
-    return jt_view(table_get<MTG_ABND_SLOTS>(jt, s <= rs ? s : rs, lines), s <= rs);
+    uint64_t* slot;
+    bool marked;
+    return jt_view((uint32_t)(jt_lookup(jt, s <= rs ? s : rs, lines, slot, marked) & 255u), s <= rs);
 }
 MTG_DEV JView jt_left(const Table& jt, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     const uint64_t p = x.f >> 2, rp = x.r & mk1;
-    return jt_view(table_get<MTG_ABND_SLOTS>(jt, p <= rp ? p : rp, lines), p <= rp);
+    uint64_t* slot;
+    bool marked;
+    return jt_view((uint32_t)(jt_lookup(jt, p <= rp ? p : rp, lines, slot, marked) & 255u), p <= rp);
 }
 /* table_or with the bucket read in one go before any atomic (the entry usually exists with its bits, or the first free slot takes it).
  * A stale read is harmless: the tag part of a slot is written once, a slot seen empty is claimed by compare-and-swap, bits seen missing
@@ -155,7 +188,13 @@ struct JtAcc {
     unsigned long long c[6];
 };
 /* the key of slot s of a table of MTG_ABND_SLOTS-slot buckets, and its value (0: empty) */
-MTG_DEV uint32_t jt_slot_key(const Table& t, uint64_t slot, uint64_t& key) { return abnd_slot_kmer(t, slot, key); }
+MTG_DEV uint32_t jt_slot_key(const Table& t, uint64_t slot, uint64_t& key)
+{
+    const uint64_t v = t.slots[slot] & ~JT_MARK;
+    if (v == 0) return 0;
+    const uint64_t b = slot / MTG_ABND_SLOTS;
+    return slot_key_in_bucket(t, b, bucket_first_h(b, t.nbuckets, t.key_bits), v, key);
+}
 /* is the view {v of the oriented junction jf} the interior of a chain?  p = a+J, y = J+b its two k-mers */
 MTG_DEV bool jt_view_interior(const JView& v, uint64_t jf, int k, Kmer& p, Kmer& y)
 {
@@ -311,41 +350,198 @@ struct ChunkWriter {
     MTG_DEV void end() { if (nacc) word(acc); }
     MTG_DEV bool ok() const { return cur != ~0ull; }
 };
-/* per chain start: the walk to the other end, the sequence into chunks on the way; the end the chain is stored from reserves words and record
- * and notes its first chunk (rec_chunk[r]).  counters as jt_plan_start. */
-MTG_DEV void jt_plan_emit_start(const Table& jt, int k, const Kmer& x, const ChunkPool& pool, unsigned long long* counters, UsRec* rec, uint64_t* rec_chunk, uint64_t rec_cap, uint32_t& lines)
+/* ---- the two walks of a chain MEET IN THE MIDDLE (round 5).  A chain has a start at each end, and each start's walker needs the chain's
+ * length and its other end to know whether it owns the chain; walking the whole chain from both ends (rounds 1-4, and the first form of this
+ * round) reads every junction twice.  Now a walker leaves a MARK at every JT_MARK_EVERY-th junction it crosses -- the junction's key with
+ * (walker, crossings so far) in a side table, then bit JT_MARK of the junction's slot -- and a walker
+ * that is about to cross a marked junction looks the mark up: it is the other walker's (a junction lies on one chain, and a walker never
+ * comes back to its own), and crossings of the one plus crossings of the other are the chain's junctions: the length is known, the partner
+ * is known (its start k-mer is the chain's other end), the walker stops.  Its sequence so far and the partner's, reverse-complemented,
+ * are the unitig (us_compact: both are the same sequence where they overlap, so every nucleotide is simply OR-ed into place).  The two
+ * walkers of a chain read each junction once between them, plus at most JT_MARK_EVERY on either side of where they meet; a walker whose
+ * partner has not started yet (or sits in a later wave) walks the whole chain and the partner meets its first mark after a few steps.
+ * Nothing waits for anything: a mark that is not seen (a stale line, a side-table entry whose value is still on its way) only lets the
+ * walker go on to the next one. */
+enum { JT_MARK_EVERY = 32 };
+struct MarkTab {
+    uint64_t* keys; /* canonical junction; ~0: free */
+    uint64_t* vals; /* walker << 32 | crossings; ~0: not written yet */
+    uint64_t mask;  /* capacity - 1 (a power of two) */
+};
+MTG_DEV uint64_t marks_load(const uint64_t* p)
 {
-    ChunkWriter W;
-    W.begin(pool);
-    for (int i = k - 1; i >= 0; i--) W.nt((uint32_t)(x.f >> (2 * i)) & 3u);
-    Kmer end;
-    const uint32_t n = jt_walk(jt, k, x, end, lines, [&](uint32_t c) { W.nt(c); });
-    W.end();
-    if (n < 2) return;
-    if (n >= MTG_US_MAX_LEN - (uint32_t)k) return;
-    if (!(canon(x) < canon(end))) return;
-    const uint64_t r = atomic_add64(&counters[JT_C_RECS], 1ull);
-    const uint64_t w = atomic_add64(&counters[JT_C_WORDS], (unsigned long long)us_words_of(n, k));
-    atomic_add64(&counters[JT_C_STORED_VIEWS], 2ull * (n - 1));
-    if (r < rec_cap) { rec[r].start_f = x.f; rec[r].len_k = n; rec[r].pad_ = 0; rec[r].hdr = w; rec_chunk[r] = W.ok() ? W.first : ~0ull; }
+#ifdef MTG_EMU
+    return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* past the CU's L1: another CU wrote it */
+#endif
 }
-/* per record: header word and sequence words of the unitig from its chunk chain into the store.  lane / nlanes: the lanes of a group share
- * the words of every chunk (the device: a wave per unitig; the emulation: one lane).  Returns false when the chain is shorter than the record
- * says (the pool ran out during the walk). */
-MTG_DEV bool us_compact(const UStore& us, int k, const UsRec& r, uint64_t first_chunk, const ChunkPool& pool, uint32_t lane, uint32_t nlanes)
+/* 0: (key -> val) is in the table now; 1: key was there, its value in `other`; 2: there but its value not visible yet, or the table is full */
+MTG_DEV int marks_insert(const MarkTab& m, uint64_t key, uint64_t val, uint64_t& other)
+{
+    uint64_t h = mix64(key) & m.mask;
+    for (uint32_t probe = 0; probe < 64; probe++) {
+        uint64_t cur = marks_load(m.keys + h);
+        if (cur == ~0ULL) cur = atomic_cas64(m.keys + h, ~0ULL, key);
+        if (cur == ~0ULL) {
+#ifdef MTG_EMU
+            __atomic_store_n(m.vals + h, val, __ATOMIC_RELEASE);
+#else
+            __hip_atomic_store(m.vals + h, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            return 0;
+        }
+        if (cur == key) { other = marks_load(m.vals + h); return other == ~0ULL ? 2 : 1; }
+        h = (h + 1) & m.mask;
+    }
+    return 2;
+}
+MTG_DEV bool marks_find(const MarkTab& m, uint64_t key, uint64_t& val)
+{
+    uint64_t h = mix64(key) & m.mask;
+    for (uint32_t probe = 0; probe < 64; probe++) {
+        const uint64_t cur = marks_load(m.keys + h);
+        if (cur == ~0ULL) return false;
+        if (cur == key) { val = marks_load(m.vals + h); return val != ~0ULL; }
+        h = (h + 1) & m.mask;
+    }
+    return false;
+}
+/* what the walkers of a launch share */
+struct WalkShared {
+    Table jt;
+    int k;
+    ChunkPool pool;
+    MarkTab marks;
+    const uint64_t* starts;       /* start k-mers (forward values), one per walker */
+    unsigned long long* counters; /* JT_C_* */
+    UsRec* rec;
+    uint64_t* rec_walk;           /* per record: owner | partner << 32 (partner 0xFFFFFFFF: the owner walked the whole chain) */
+    uint64_t rec_cap;
+    uint64_t* w_chunk;            /* per walker: first chunk of its sequence (~0: the pool ran out) */
+    uint32_t* w_cnt;              /* per walker: k-mers it holds */
+};
+/* one walker.  begin(), then step() until it returns false (the device: a loop in the lane; the TEST-ONLY emulation steps all walkers of a
+ * graph in turns, so that they do meet in the middle) */
+struct JtWalker {
+    uint32_t self, n, lines;
+    Kmer cur;
+    uint64_t start_f;
+    ChunkWriter W;
+    bool done;
+    MTG_DEV void begin(const WalkShared& S, uint32_t i)
+    {
+        self = i; n = 1; lines = 0; done = false;
+        start_f = S.starts[i];
+        cur = make_kmer(start_f, S.k);
+        W.begin(S.pool);
+        for (int j = S.k - 1; j >= 0; j--) W.nt((uint32_t)(start_f >> (2 * j)) & 3u);
+    }
+    /* the walk is over: total = k-mers of the chain, partner = the walker of its other end (0xFFFFFFFF: this one reached it), end_c = canonical k-mer of the other end */
+    MTG_DEV void finish(const WalkShared& S, uint32_t total, uint32_t partner, uint64_t end_c)
+    {
+        done = true;
+        W.end();
+        S.w_chunk[self] = W.ok() ? W.first : ~0ULL;
+        S.w_cnt[self] = n;
+        const Kmer x = make_kmer(start_f, S.k);
+        if (total < 2 || total >= MTG_US_MAX_LEN - (uint32_t)S.k) return;
+        if (!(canon(x) < end_c)) return; /* the chain is stored from the end with the smaller canonical k-mer */
+        const uint64_t r = atomic_add64(&S.counters[JT_C_RECS], 1ull);
+        const uint64_t w = atomic_add64(&S.counters[JT_C_WORDS], (unsigned long long)us_words_of(total, S.k));
+        atomic_add64(&S.counters[JT_C_STORED_VIEWS], 2ull * (total - 1));
+        if (r < S.rec_cap) { S.rec[r].start_f = start_f; S.rec[r].len_k = total; S.rec[r].pad_ = 0; S.rec[r].hdr = w; S.rec_walk[r] = (uint64_t)self | ((uint64_t)partner << 32); }
+    }
+    MTG_DEV bool step(const WalkShared& S)
+    {
+        if (done) return false;
+        const int k = S.k;
+        const uint64_t mk = kmask(k), mk1 = kmask(k - 1);
+        const uint64_t s = cur.f & mk1, rs = cur.r >> 2;
+        const bool fwd = s <= rs;
+        const uint64_t J = fwd ? s : rs;
+        uint64_t* slot;
+        bool marked;
+        const uint64_t v = jt_lookup(S.jt, J, lines, slot, marked);
+        const JView a = jt_view((uint32_t)(v & 255u), fwd);
+        const uint32_t cap = MTG_US_MAX_LEN - (uint32_t)k;
+        if (!jt_simple(a)) { finish(S, n, 0xFFFFFFFFu, canon(cur)); return false; }
+        const uint32_t nt = (uint32_t)ctz4(a.out);
+        const Kmer y = kmer_next(cur, nt, k, mk);
+        if (!us_eligible(cur, y, k) || n >= cap) { finish(S, n, 0xFFFFFFFFu, canon(cur)); return false; }
+        if (marked) {
+            /* the other walker crossed this junction as its u-th: n junctions on this side of it (it included), u on the other */
+            uint64_t mv;
+            if (marks_find(S.marks, J, mv) && (uint32_t)(mv >> 32) != self) {
+                const uint32_t partner = (uint32_t)(mv >> 32), u = (uint32_t)mv;
+                finish(S, n + u, partner, canon(make_kmer(S.starts[partner], k)));
+                return false;
+            }
+        }
+        cur = y;
+        n++;
+        W.nt(nt);
+        const uint32_t c = n - 1; /* junctions crossed */
+        if (c % JT_MARK_EVERY == 0 && slot) {
+            uint64_t other = 0;
+            const int r = marks_insert(S.marks, J, ((uint64_t)self << 32) | c, other);
+            if (r == 0) atomic_or64(slot, JT_MARK); /* no fence between the entry and the mark (an agent-scope release writes the L2 back: 94 M of them doubled the kernel's time):
+                                                        a reader that sees the mark before the entry's value, or before its key, walks on to the next mark */ else if (r == 1 && (uint32_t)(other >> 32) != self) {
+                /* the other walker marked this very junction (as its u-th): c crossings on this side, it included */
+                const uint32_t partner = (uint32_t)(other >> 32), u = (uint32_t)other;
+                finish(S, c + u, partner, canon(make_kmer(S.starts[partner], k)));
+                return false;
+            }
+        }
+        return true;
+    }
+};
+/* OR n nucleotides (2-bit fields of v, lowest first) into the sequence words w at nucleotide p0 (the words are zero where nothing was written) */
+MTG_DEV void seq_or(uint64_t* w, uint64_t p0, uint64_t v, uint32_t n)
+{
+    if (n == 0) return;
+    const uint32_t sh = 2u * (uint32_t)(p0 & 31u);
+    atomic_or64(w + (p0 >> 5), v << sh);
+    if (sh && (p0 & 31u) + n > 32u) atomic_or64(w + (p0 >> 5) + 1, v >> (64u - sh));
+}
+/* word j of a walker's chunk chain needs the chain walked: the callers below go through a chain once, chunk by chunk */
+/* per record: header word and sequence of the unitig into the store, from the owner's chunks (its nucleotides at their places) and, when the
+ * walks met, from the partner's (reverse-complemented, from the other end).  lane / nlanes: the lanes of a group share the words of every
+ * chunk (the device: a wave per unitig; the emulation: one lane).  false: a chain of chunks is shorter than its walker's count says. */
+MTG_DEV bool us_compact(const UStore& us, int k, const UsRec& r, uint64_t walk, const WalkShared& S, uint32_t lane, uint32_t nlanes)
 {
     uint64_t* w = us.words + r.hdr;
-    const uint64_t nw = us_words_of(r.len_k, k) - 1; /* sequence words */
-    if (lane == 0) w[0] = (uint64_t)r.len_k + (uint32_t)k - 1;
-    uint64_t c = first_chunk, done = 0;
-    while (done < nw) {
-        if (c == ~0ull || c >= pool.cap_chunks) return false;
-        const uint64_t* src = pool.words + c * MTG_CHUNK_WORDS;
-        const uint64_t take = nw - done < MTG_CHUNK_PAYLOAD ? nw - done : MTG_CHUNK_PAYLOAD;
-        for (uint64_t t = lane; t < take; t += nlanes) w[1 + done + t] = src[1 + t];
-        done += take;
-        const uint64_t link = src[0];
-        c = link ? link - 1 : ~0ull;
+    const uint64_t L = (uint64_t)r.len_k + (uint32_t)k - 1; /* nucleotides */
+    if (lane == 0) w[0] = L;
+    const uint32_t owner = (uint32_t)walk, partner = (uint32_t)(walk >> 32);
+    for (int side = 0; side < 2; side++) {
+        const uint32_t who = side ? partner : owner;
+        if (who == 0xFFFFFFFFu) continue;
+        uint64_t have = (uint64_t)S.w_cnt[who] + (uint32_t)k - 1; /* nucleotides of this walker's sequence */
+        if (have > L) have = L;
+        const uint64_t nw = (have + 31) / 32;
+        uint64_t c = S.w_chunk[who], done = 0;
+        while (done < nw) {
+            if (c == ~0ULL || c >= S.pool.cap_chunks) return false;
+            const uint64_t* src = S.pool.words + c * MTG_CHUNK_WORDS;
+            const uint64_t take = nw - done < MTG_CHUNK_PAYLOAD ? nw - done : MTG_CHUNK_PAYLOAD;
+            for (uint64_t t = lane; t < take; t += nlanes) {
+                const uint64_t wq = done + t;                                             /* word of the walker's sequence */
+                const uint32_t cnt = (uint32_t)(have - 32 * wq < 32 ? have - 32 * wq : 32); /* nucleotides in it */
+                uint64_t v = src[1 + t];
+                if (cnt < 32) v &= (1ull << (2 * cnt)) - 1ull;
+                if (!side) seq_or(w + 1, 32 * wq, v, cnt);
+                else {
+                    /* the partner's nucleotide q sits at L - 1 - q, complemented: the word's nucleotides in reverse order */
+                    uint64_t rv = rev_fields64(v) >> (2u * (32u - cnt));
+                    rv ^= cnt < 32 ? (0xAAAAAAAAAAAAAAAAULL & ((1ull << (2 * cnt)) - 1ull)) : 0xAAAAAAAAAAAAAAAAULL;
+                    seq_or(w + 1, L - 32 * wq - cnt, rv, cnt);
+                }
+            }
+            done += take;
+            const uint64_t link = src[0];
+            c = link ? link - 1 : ~0ULL;
+        }
     }
     return true;
 }

@@ -304,24 +304,24 @@ __global__ void __launch_bounds__(256) k_jt_unstored(Table jt, Index nx, Src src
         jt_unstored_entry(jt, nx, J, m, src, counters, left_k, left_a, cap_left, lines);
     }
 }
-/* one chain start per lane: the walk to the other end with the sequence written into chunks on the way (jt_plan_emit_start); the end the
- * chain is stored from reserves words and record */
-__global__ void __launch_bounds__(64) k_jt_plan_emit(Table jt, int k, const uint64_t* __restrict__ starts, unsigned long long n, ChunkPool pool, unsigned long long* counters, UsRec* rec,
-                                                     uint64_t* rec_chunk, unsigned long long rec_cap)
+/* one chain start per lane: its walker (mtg_build.h: JtWalker) -- the walk towards the other end with the sequence written into chunks on the
+ * way, until it reaches that end or meets the walker that started there */
+__global__ void __launch_bounds__(64) k_jt_walk(WalkShared S, unsigned long long n)
 {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t lines = 0;
-    jt_plan_emit_start(jt, k, make_kmer(starts[i], k), pool, counters, rec, rec_chunk, rec_cap, lines);
+    JtWalker w;
+    w.begin(S, (uint32_t)i);
+    while (w.step(S)) {}
 }
-/* one stored unitig per wave: its words from the chunk chain to their place in the store (us_compact).  counters[JT_C_SAT + 0 ...]: none;
- * flag[0] |= 1 when a chain is shorter than its record */
-__global__ void __launch_bounds__(256) k_us_compact(UStore us, int k, const UsRec* __restrict__ rec, const uint64_t* __restrict__ rec_chunk, unsigned long long n, ChunkPool pool, unsigned long long* flag)
+/* one stored unitig per wave: its words from the chunk chains of its walkers to their place in the store (us_compact); flag[0] |= 1 when a
+ * chain is shorter than its walker's count */
+__global__ void __launch_bounds__(256) k_us_compact(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, WalkShared S, unsigned long long* flag)
 {
     const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     bool bad = false;
-    for (unsigned long long u = wave; u < n; u += nwaves) bad = !us_compact(us, k, rec[u], rec_chunk[u], pool, lane, 64u) || bad;
+    for (unsigned long long u = wave; u < n; u += nwaves) bad = !us_compact(us, k, rec[u], S.rec_walk[u], S, lane, 64u) || bad;
     if (bad && lane == 0) atomicOr(&flag[0], 1ull);
 }
 /* one stored unitig per wave, its k-mers dealt to the lanes: abundances from the source into the store.  counters[JT_C_SAT] += those above 255 */
@@ -545,7 +545,25 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     const int k = idx->dev.k;
     const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
     const unsigned scan_blocks = (unsigned)std::min<uint64_t>((nslots + 255) / 256, 256 * 32);
-    DevBuf d_cnt, d_starts, d_rec, d_left_k, d_left_a;
+    /* What the construction needs only while the junction table is alive -- chain starts, the chunks, the marks, the walkers' arrays -- goes
+     * behind the table in ITS buffer, which is sized for the sparse ADJ table that takes it over (48.8 GB for a 34.2 GB table at human scale):
+     * no allocation (on this pool a hipMalloc that takes the process past what it has touched before can cost half a second), and the
+     * construction's peak stays the index's resident size.  A piece that does not fit gets memory of its own. */
+    struct Behind {
+        char* p; size_t cap, used = 0;
+        std::vector<std::unique_ptr<DevBuf>> own;
+        hipError_t take(void** out, size_t bytes)
+        {
+            bytes = (bytes + 255) & ~(size_t)255;
+            if (used + bytes <= cap) { *out = p + used; used += bytes; return hipSuccess; }
+            own.emplace_back(new DevBuf());
+            const hipError_t e = own.back()->alloc(bytes);
+            *out = own.back()->p;
+            return e;
+        }
+    } behind{(char*)jt_buf.p + ((nslots * 8 + 255) & ~(size_t)255), jt_buf.cap > ((nslots * 8 + 255) & ~(size_t)255) ? jt_buf.cap - ((nslots * 8 + 255) & ~(size_t)255) : 0};
+    DevBuf d_cnt, d_rec, d_left_k, d_left_a;
+    uint64_t* p_starts = nullptr;
     HIP_TRY(d_cnt.alloc((JT_C_N + 2) * 8)); /* + the chunk pool's cursor, the compaction's flag */
     HIP_TRY(hipMemset(d_cnt.p, 0, (JT_C_N + 2) * 8));
     unsigned long long* cnt_d = d_cnt.as<unsigned long long>();
@@ -560,12 +578,13 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     }
     const unsigned scan_grid = (unsigned)std::min<uint64_t>((jt.nbuckets + 255) / 256, 256 * 32);
     for (int pass = 0; pass < 2; pass++) {
-        HIP_TRY(d_starts.alloc((cap_starts + 1) * 8));
+        behind.used = 0; behind.own.clear();
+        HIP_TRY(behind.take((void**)&p_starts, (cap_starts + 1) * 8));
         HIP_TRY(d_left_k.alloc((cap_left + 1) * 8));
         HIP_TRY(d_left_a.alloc((cap_left + 1) * 4));
         HIP_TRY(hipMemset(d_cnt.p, 0, JT_C_N * 8));
         prof.begin();
-        hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_grid), dim3(256), 0, 0, jt, k, src, cnt_d, d_starts.as<uint64_t>(), cap_starts, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), cap_left);
+        hipLaunchKernelGGL(k_jt_scan<Src>, dim3(scan_grid), dim3(256), 0, 0, jt, k, src, cnt_d, p_starts, cap_starts, d_left_k.as<uint64_t>(), d_left_a.as<uint32_t>(), cap_left);
         HIP_TRY(prof.end(pass ? "jt_scan_again" : "jt_scan", nslots * 8, nslots));
         HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
         n_starts = cnt[JT_C_STARTS]; n_single = cnt[JT_C_LEFT]; interior = cnt[JT_C_INTERIOR]; sat_single = cnt[JT_C_SAT];
@@ -581,21 +600,44 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     unsigned long long sat_unitigs = 0, sat_late = 0;
     HIP_TRY(hipMemset(cnt_d + JT_C_SAT, 0, 8));
     unsigned long long n_words = 0, n_rec = 0, stored_views = 0;
-    DevBuf d_pool, d_rec_chunk;
-    ChunkPool pool{};
+    uint64_t *p_pool = nullptr, *p_rec_walk = nullptr, *p_marks = nullptr, *p_wchunk = nullptr;
+    uint32_t* p_wcnt = nullptr;
+    WalkShared WS{};
+    ChunkPool& pool = WS.pool;
     if (n_starts) {
+        if (n_starts > 0xFFFFFFF0ull) { set_error("unitig construction: %llu chain starts", n_starts); return MTG_ERR_OVERFLOW; } /* a walker is a 32-bit number */
         const unsigned long long rec_cap = n_starts / 2 + 1; /* two starts per stored unitig (one per strand) */
         HIP_TRY(d_rec.alloc(rec_cap * sizeof(UsRec)));
-        HIP_TRY(d_rec_chunk.alloc(rec_cap * 8));
-        /* the chunks of every walk (both ends of every chain walk it: interior + n_starts steps in all) */
+        HIP_TRY(behind.take((void**)&p_rec_walk, rec_cap * 8));
+        HIP_TRY(behind.take((void**)&p_wchunk, n_starts * 8));
+        HIP_TRY(behind.take((void**)&p_wcnt, n_starts * 4));
+        /* the chunks of every walk (at worst both ends of every chain walk all of it: interior + n_starts steps in all) */
         pool.cap_chunks = chunk_pool_need(interior + n_starts, n_starts, k);
-        HIP_TRY(d_pool.alloc(pool.cap_chunks * MTG_CHUNK_WORDS * 8));
-        pool.words = d_pool.as<uint64_t>();
+        HIP_TRY(behind.take((void**)&p_pool, pool.cap_chunks * MTG_CHUNK_WORDS * 8));
+        pool.words = p_pool;
         HIP_TRY(hipMemset(cnt_d + JT_C_N, 0, 16));
         pool.cursor = cnt_d + JT_C_N;
+        /* the marks: one per JT_MARK_EVERY crossings at worst, in a table at most half full */
+        uint64_t mcap = 1024;
+        while (mcap < 2 * ((interior + n_starts) / JT_MARK_EVERY + n_starts)) mcap <<= 1;
+        HIP_TRY(behind.take((void**)&p_marks, mcap * 16));
+        WS.jt = jt; WS.k = k;
+        WS.marks.keys = p_marks; WS.marks.vals = p_marks + mcap; WS.marks.mask = mcap - 1;
+        WS.starts = p_starts; WS.counters = cnt_d; WS.rec = d_rec.as<UsRec>(); WS.rec_walk = p_rec_walk; WS.rec_cap = rec_cap;
+        WS.w_chunk = p_wchunk; WS.w_cnt = p_wcnt;
         prof.begin();
-        hipLaunchKernelGGL(k_jt_plan_emit, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, jt, k, d_starts.as<uint64_t>(), n_starts, pool, cnt_d, d_rec.as<UsRec>(), d_rec_chunk.as<uint64_t>(), rec_cap);
-        HIP_TRY(prof.end("jt_plan+emit", (interior + n_starts) * 32 + (interior + n_starts) / 2, interior + n_starts)); /* both strands of every chain: one bucket per step, a quarter byte written */
+        HIP_TRY(hipMemsetAsync(p_marks, 0xFF, mcap * 16, 0));
+        HIP_TRY(prof.end("clear_marks", mcap * 16, 0));
+        prof.begin();
+        hipLaunchKernelGGL(k_jt_walk, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, WS, n_starts);
+        HIP_TRY(prof.end("jt_walk", (interior / 2 + n_starts) * 32 + (interior / 2 + n_starts) / 4 + ((interior / 2) / JT_MARK_EVERY) * 3 * 64, interior / 2 + n_starts)); /* a chain's junctions once between its two walkers: one bucket per step, a quarter byte written; a mark every 32 */
+        if (tune::on(tune::T_DEBUG_TIMERS)) { /* how much of the chains the walkers walked between them (1.0: every junction once) */
+            std::vector<uint32_t> wc(n_starts);
+            HIP_TRY(hipMemcpy(wc.data(), p_wcnt, n_starts * 4, hipMemcpyDeviceToHost));
+            unsigned long long steps = 0;
+            for (uint32_t c : wc) steps += c;
+            fprintf(stderr, "  [build] walkers: %llu starts, %llu k-mers held in all, %llu interior views / 2 = %.3f of the chains\n", n_starts, steps, interior / 2, (double)steps / (double)(interior / 2 + 1));
+        }
         unsigned long long tail[2];
         HIP_TRY(hipMemcpy(cnt, d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(tail, cnt_d + JT_C_N, 16, hipMemcpyDeviceToHost));
@@ -603,7 +645,6 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
         if (n_rec > rec_cap) { set_error("unitig construction: %llu records for %llu chain starts", n_rec, n_starts); return MTG_ERR_OVERFLOW; }
         if (tail[0] > pool.cap_chunks) { set_error("unitig construction: %llu chunks of sequence for a pool of %llu", tail[0], (unsigned long long)pool.cap_chunks); return MTG_ERR_OVERFLOW; }
     }
-    (void)d_starts.alloc(0);
     if (n_rec) {
         const unsigned long long pad = 8; /* the coverage pass may look up to 64 + k nucleotides past the end of a unitig */
         HIP_TRY(timed_malloc((void**)&idx->dev.us.words, (n_words + pad) * 8));
@@ -614,13 +655,12 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
         idx->dev.us.nwords = n_words;
         idx->dev.us.nunitigs = n_rec;
         HIP_TRY(hipMemset(cnt_d + JT_C_N + 1, 0, 8));
-        hipLaunchKernelGGL(k_us_compact, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), d_rec_chunk.as<uint64_t>(), n_rec, pool, cnt_d + JT_C_N + 1);
+        hipLaunchKernelGGL(k_us_compact, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, WS, cnt_d + JT_C_N + 1);
         HIP_TRY(prof.end("us_compact", n_words * 16 + n_words * 40, n_rec)); /* the words out of their chunks and into the store; the clearing of words and abundance bytes */
         unsigned long long short_chain = 0;
         HIP_TRY(hipMemcpy(&short_chain, cnt_d + JT_C_N + 1, 8, hipMemcpyDeviceToHost));
         if (short_chain) { set_error("unitig construction: a chunk chain is shorter than its record"); return MTG_ERR_OVERFLOW; }
-        (void)d_pool.alloc(0);
-        (void)d_rec_chunk.alloc(0);
+        behind.own.clear(); /* the pieces behind the table are dead from here on: its buffer becomes the sparse ADJ table below */
         prof.begin();
         hipLaunchKernelGGL(k_us_ab<Src>, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, src, cnt_d);
         HIP_TRY(prof.end("us_abundances", (stored_views / 2 + n_rec) * 9, stored_views / 2 + n_rec));
@@ -694,9 +734,9 @@ static size_t adj_bytes_estimate(uint64_t n, int k)
     return (size_t)buckets_for(n / 2 + n / 128 + 8192, 0.49, 2 * (k - 1), MTG_ADJ_SLOTS) * 16 * MTG_ADJ_SLOTS;
 }
 /* min_bytes: the buffer is made at least this large (the junction table's memory is handed on to the sparse ADJ table) */
-static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase, size_t min_bytes = 0)
+static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase, size_t min_bytes = 0, uint64_t min_buckets = 0)
 {
-    table_shape(t, buckets_for(nkeys, load, key_bits, MTG_ABND_SLOTS), key_bits);
+    table_shape(t, std::max<uint64_t>(buckets_for(nkeys, load, key_bits, MTG_ABND_SLOTS), min_buckets), key_bits);
     t.sp_words = nullptr;
     const size_t bytes = t.nbuckets * 8 * MTG_ABND_SLOTS;
     if (!(buf.p && buf.cap >= std::max(bytes, min_bytes))) HIP_TRY(buf.alloc(std::max(bytes, min_bytes)));
@@ -725,7 +765,7 @@ static int index_from_kmer_pieces_lean(size_t n, int k, const KmerFetch& fetch, 
     int rc = MTG_OK;
     unsigned long long cnt[4] = {0, 0, 0, 0};
     for (int attempt = 0; attempt < 6; attempt++) {
-        if (int rc2 = alloc_slot_table(jt, jt_buf, n + n / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n, k))) return rc2;
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n + n / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n, k), jt_min_buckets(2 * (k - 1)))) return rc2;
         if (int rc2 = alloc_slot_table(abnd, abnd_buf, n, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
         HIP_TRY(hipMemset(d_cnt.p, 0, 32));
         double ms = 0;
@@ -778,7 +818,7 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
     int rc = MTG_OK;
     const uint64_t n_junctions_ub = total_kmers_ub + nseq + 1024; /* a sequence of L >= k nucleotides has L - k + 2 junction positions */
     for (int attempt = 0; attempt < 6; attempt++) {
-        if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k))) return rc2;
+        if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k), jt_min_buckets(2 * (k - 1)))) return rc2;
         HIP_TRY(hipMemset(d_cnt.p, 0, 32));
         if (nseq == 0) break; /* an empty graph: nothing to launch */
         prof.begin();
@@ -1175,7 +1215,7 @@ int index_from_stream(ReadStream& rs, int k, int abundance_min, int abundance_ma
             Table jt{}, abnd{};
             unsigned long long cnt[4] = {0, 0, 0, 0};
             for (int ia = 0; ia < 6; ia++) {
-                if (int rc2 = alloc_slot_table(jt, jt_buf, n_solid + n_solid / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n_solid, k))) return rc2;
+                if (int rc2 = alloc_slot_table(jt, jt_buf, n_solid + n_solid / 8 + 1024, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(n_solid, k), jt_min_buckets(2 * (k - 1)))) return rc2;
                 if (npass > 1) if (int rc2 = alloc_slot_table(abnd, abnd_buf, n_solid, 0.6 * load, 2 * k, prof, "clear_abnd_source")) return rc2;
                 HIP_TRY(hipMemset(d_cnt.p, 0, 32));
                 for (uint32_t pass = 0; pass < npass; pass++) {

@@ -76,6 +76,9 @@ void emu_coop_counts(unsigned long* out)
 #endif
 }
 
+/* stored unitigs of the lean builds so far whose two walkers met in the middle / whose owner walked the whole chain (mtg_build.h: JtWalker) */
+void emu_walk_counts(unsigned long* out) { out[0] = emu_walks_met; out[1] = emu_walks_whole; }
+
 void emu_query(void* p, const uint64_t* kmers, size_t n, uint32_t* abund, uint8_t* succ, uint8_t* pred)
 {
     EmuIndex* e = (EmuIndex*)p;

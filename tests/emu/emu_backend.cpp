@@ -673,6 +673,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
 } // namespace mtgi
 
 extern "C" {
+/* TEST-ONLY: stored unitigs of the lean builds so far whose two walkers met in the middle / whose owner walked the whole chain */
+void emu_walk_counts(unsigned long* out) { out[0] = emu_walks_met; out[1] = emu_walks_whole; }
 const char* mtg_last_error(void) { return mtgi::g_err; }
 /* TEST-ONLY: MTG_EMU_DEVICES pretends that many devices exist, so that the tool's multi-device driver can be exercised on the CPU */
 int mtg_device_count(void) { return getenv("MTG_EMU_DEVICES") ? atoi(getenv("MTG_EMU_DEVICES")) : 0; }

@@ -154,6 +154,8 @@ inline void emu_sparse_from_store(mtg::Index& ix, EmuUStore& st, std::vector<uin
     }
 }
 
+/* TEST-ONLY tallies: stored unitigs whose two walkers met (the owner's sequence and the partner's were joined) / whose owner walked all of it */
+static unsigned long long emu_walks_met = 0, emu_walks_whole = 0;
 struct EmuLeanStats {
     uint64_t nb_solid = 0, nb_branching = 0, nb_unitigs = 0, nb_saturated = 0, nb_left = 0;
     bool late = false;
@@ -167,7 +169,7 @@ inline EmuLeanStats emu_build_lean(mtg::Index& ix, EmuUStore& st, const uint64_t
     std::vector<uint64_t> jt_slots, src_slots;
     Table jt{}, abnd{};
     for (double load = 0.5;; load *= 0.7) {
-        table_shape(jt, buckets_for(n + n / 8 + 16, load, 2 * (k - 1), MTG_ABND_SLOTS), 2 * (k - 1));
+        table_shape(jt, std::max<uint64_t>(buckets_for(n + n / 8 + 16, load, 2 * (k - 1), MTG_ABND_SLOTS), jt_min_buckets(2 * (k - 1))), 2 * (k - 1));
         table_shape(abnd, buckets_for(n, load, 2 * k, MTG_ABND_SLOTS), 2 * k);
         jt.sp_words = abnd.sp_words = nullptr;
         jt_slots.assign(jt.nbuckets * MTG_ABND_SLOTS, 0);
@@ -221,16 +223,53 @@ inline EmuLeanStats emu_build_lean(mtg::Index& ix, EmuUStore& st, const uint64_t
     const uint64_t interior = acc.c[JT_C_INTERIOR];
     counters[JT_C_SAT] = 0; /* the source holds stored (clamped) abundances: those above 255 were counted at insertion */
     std::vector<UsRec> recs(n_starts / 2 + 1);
-    std::vector<uint64_t> rec_chunk(recs.size(), ~0ull);
-    ChunkPool pool{};
+    std::vector<uint64_t> rec_walk(recs.size(), ~0ull), w_chunk(n_starts + 1, ~0ull);
+    std::vector<uint32_t> w_cnt(n_starts + 1, 0);
+    WalkShared WS{};
+    ChunkPool& pool = WS.pool;
     pool.cap_chunks = chunk_pool_need(interior + n_starts, n_starts, k);
     std::vector<uint64_t> pool_words(pool.cap_chunks * MTG_CHUNK_WORDS, 0xDEADDEADDEADDEADull);
     pool.words = pool_words.data();
     pool.cursor = &counters[JT_C_N];
-    for (uint64_t i = 0; i < n_starts; i++) jt_plan_emit_start(jt, k, make_kmer(starts[i], k), pool, counters, recs.data(), rec_chunk.data(), recs.size(), lines);
+    uint64_t mcap = 16;
+    while (mcap < 2 * ((interior + n_starts) / JT_MARK_EVERY + n_starts)) mcap <<= 1;
+    std::vector<uint64_t> marks(2 * mcap, ~0ull);
+    WS.jt = jt; WS.k = k;
+    WS.marks.keys = marks.data(); WS.marks.vals = marks.data() + mcap; WS.marks.mask = mcap - 1;
+    WS.starts = starts.data(); WS.counters = counters; WS.rec = recs.data(); WS.rec_walk = rec_walk.data(); WS.rec_cap = recs.size();
+    WS.w_chunk = w_chunk.data(); WS.w_cnt = w_cnt.data();
+    {   /* the walkers of the graph in TURNS, an uneven number of steps each (1, 2 or 3, by the walker's number and the round), so that the two
+           walkers of a chain meet in its middle, near one end, or not at all (MTG_EMU_WALK_SERIAL=1: one after the other, as a device whose
+           waves never overlap: the second walker of every chain meets the first one's mark after a few steps) */
+        std::vector<JtWalker> wk(n_starts);
+        const bool serial = getenv("MTG_EMU_WALK_SERIAL") != nullptr;
+        if (serial) {
+            for (uint64_t i = 0; i < n_starts; i++) { wk[i].begin(WS, (uint32_t)i); while (wk[i].step(WS)) {} }
+        } else {
+            for (uint64_t i = 0; i < n_starts; i++) wk[i].begin(WS, (uint32_t)i);
+            uint64_t live = n_starts, round = 0;
+            while (live) {
+                live = 0;
+                for (uint64_t i = 0; i < n_starts; i++) {
+                    if (wk[i].done) continue;
+                    const uint32_t turns = 1 + (uint32_t)((i * 2654435761ull + round * 40503ull) >> 7) % 3;
+                    bool on = true;
+                    for (uint32_t t = 0; t < turns && on; t++) on = wk[i].step(WS);
+                    live += on;
+                }
+                round++;
+            }
+        }
+    }
     const uint64_t n_rec = counters[JT_C_RECS], cw = counters[JT_C_WORDS];
     if (n_rec > recs.size() || counters[JT_C_N] > pool.cap_chunks) abort();
     recs.resize(n_rec);
+    /* every chain is stored once: the two walkers of a chain agree on its length and on who owns it */
+    {
+        uint64_t met = 0;
+        for (uint64_t u = 0; u < n_rec; u++) met += (uint32_t)(rec_walk[u] >> 32) != 0xFFFFFFFFu;
+        emu_walks_met += met; emu_walks_whole += n_rec - met;
+    }
     ix.us = UStore{};
     if (n_rec) {
         st.words.assign(cw + 8, 0);
@@ -241,8 +280,8 @@ inline EmuLeanStats emu_build_lean(mtg::Index& ix, EmuUStore& st, const uint64_t
         ix.us.nunitigs = n_rec;
         for (uint64_t u = 0; u < n_rec; u++) {
             const UsRec& r = recs[u];
-            if (!us_compact(ix.us, k, r, rec_chunk[u], pool, 0, 1)) abort();
-            /* the words the chunks brought against a second walk of the chain (what round 4's separate emit pass wrote) */
+            if (!us_compact(ix.us, k, r, rec_walk[u], WS, 0, 1)) abort();
+            /* the words the chunks of the two walkers brought against ONE walk of the whole chain (what round 4's separate emit pass wrote) */
             std::vector<uint32_t> nts;
             for (int i = k - 1; i >= 0; i--) nts.push_back((uint32_t)(r.start_f >> (2 * i)) & 3u);
             Kmer end;

@@ -45,6 +45,7 @@ def load(lanes=0, tsan=False):
     lib.emu_free.argtypes = [C.c_void_p]
     lib.emu_nw_matches.argtypes = [C.c_char_p, C.c_char_p]
     lib.emu_coop_counts.argtypes = [P(C.c_ulong)]
+    lib.emu_walk_counts.argtypes = [P(C.c_ulong)]
     if lanes:
         _lanes_libs[(lanes, tsan)] = lib
     else:
@@ -107,6 +108,19 @@ def product_on_emulator():
     from mindthegap_amd import lib as L
     L._lib = L._bind(C.CDLL(FULL_SO))
     return mindthegap_amd
+
+
+def walk_counts(full=False):
+    """(stored unitigs whose two walkers met in the middle, stored unitigs whose owner walked the whole chain) over the lean builds so far, of
+    tests/emu/libemu or (full) of the product on the emulator"""
+    a = (C.c_ulong * 2)()
+    if full:
+        lib = C.CDLL(build_full())
+        lib.emu_walk_counts.argtypes = [C.POINTER(C.c_ulong)]
+        lib.emu_walk_counts(a)
+    else:
+        load().emu_walk_counts(a)
+    return int(a[0]), int(a[1])
 
 
 def coop_counts(lanes=0):

@@ -1214,6 +1214,45 @@ def test_lean_build_equals_the_legacy_build(emu_product, tmp_path, k):
     assert seen_late  # a closed chain was met
 
 
+@pytest.mark.parametrize("serial", [False, True])
+def test_walkers_of_a_chain_meet_in_the_middle(emu_product, tmp_path, monkeypatch, serial):
+    """round 5: the two walkers of a chain stop where they meet (marks every 32 junctions, mtg_build.h: JtWalker) and the unitig is the
+    owner's sequence joined with the partner's reverse complement.  Long chains (hundreds to thousands of k-mers, their lengths around the
+    multiples of 32 and of a chunk's 992 nucleotides), walkers stepped in turns -- they meet in the middle, near an end, on the very junction
+    both mark -- or one after the other (the second walker meets the first one's mark after a few steps); the emulation compares every stored
+    unitig with ONE walk of its chain, and the index answers every query like the dense reference construction."""
+    if serial:
+        monkeypatch.setenv("MTG_EMU_WALK_SERIAL", "1")
+    rng = random.Random(900 + int(serial))
+    k = 31
+    before = emu_lib.walk_counts(full=True)
+    for rep in range(6):
+        seqs = []
+        for L in [33, 61, 62, 63, 64, 65, 66, 95, 96, 97, 127, 128, 129, 500, 991, 992, 993, 1022, 1023, 1024, 1025, 2000, 2017, 3100, 4999]:
+            seqs.append(_rand_seq(rng, L + k - 1 + rng.randrange(0, 3)))
+        a = _rand_seq(rng, 3000)
+        seqs += [a[:1500], a[1400:]]                      # a chain through the overlap of two sequences
+        seqs.append(_rand_seq(rng, 700) + a[200:260] + _rand_seq(rng, 900))  # a repeat: the chains around it end at its forks
+        o = oracle_lib.Index.from_sequences(seqs, k, 1, 40)
+        km, ct = o.export()
+        o.close()
+        lean = emu_product.Index.from_kmers(km, ct, k)
+        with _env("MTG_LEGACY_BUILD", "1"):
+            old = emu_product.Index.from_kmers(km, ct, k)
+        li, oi = lean.info(), old.info()
+        for f in ("nb_solid_kmers", "nb_branching", "nb_unitigs"):
+            assert li[f] == oi[f], (f, li[f], oi[f])
+        q = np.concatenate([km, np.array([rng.getrandbits(2 * k) for _ in range(500)], dtype=np.uint64)])
+        assert (lean.abundance(q) == old.abundance(q)).all()
+        ls, lp = lean.neighbors(q)
+        os_, op = old.neighbors(q)
+        assert (ls == os_).all() and (lp == op).all()
+        lean.close()
+        old.close()
+    met, whole = (x - y for x, y in zip(emu_lib.walk_counts(full=True), before))
+    assert met >= 60 and whole >= 20, (met, whole)   # long chains are joined from two walks; chains under 32 junctions are walked whole
+
+
 def test_wire_payload_with_wrapping_sizes_is_refused(emu_product):
     """mtg_results_from_wire bounds every section by the payload before it adds sizes up: a header whose seq_bytes is close to 2^64 makes
     the sum of the sections wrap back onto total_bytes (and carries a valid checksum -- it is not cryptographic); such a payload is
