@@ -323,6 +323,38 @@ MTG_DEV int adj_or(const Table& t, uint64_t key, uint32_t bits)
     return 1;
 }
 
+/* the entry of a key that is inserted ONCE (an interior junction of a stored unitig, by the one lane that has it): bits and word 1 in one pass
+ * over the bucket -- the bucket read in one go, a compare-and-swap on the first free slot, the store of word 1 -- where adj_or + adj_find + a
+ * store walked the bucket three times word by word.  (A blind compare-and-swap on each slot in turn, without the read, was measured: 223
+ * against 122 ms for the human-scale table -- an atomic on an occupied slot costs more than the read that avoids it.)  Returns as adj_or. */
+MTG_DEV int adj_set_new(const Table& t, uint64_t key, uint32_t bits, uint64_t w1)
+{
+    const uint64_t H = mix(key, t.key_bits);
+    uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
+    const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
+        const uint64_t want = (tag << MTG_DISP_BITS) | d;
+        uint64_t* p = t.slots + b * (2 * MTG_ADJ_SLOTS);
+        U64x2 q[MTG_ADJ_SLOTS];
+MTG_UNROLL
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) q[i] = ld_table(reinterpret_cast<const U64x2*>(p) + i);
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) {
+            uint64_t v = q[i].x; /* a stale read is harmless: a slot seen free is claimed by compare-and-swap, which says what is there now */
+            if (v == 0) {
+                v = atomic_cas64(p + 2 * i, 0, (want << 8) | bits);
+                if (v == 0) { p[2 * i + 1] = w1; return 2; }
+            }
+            if ((v >> 8) == want) {
+                if ((v & bits) != bits) atomic_or64(p + 2 * i, bits);
+                p[2 * i + 1] = w1;
+                return 0;
+            }
+        }
+        b = (b + 1 == t.nbuckets) ? 0 : b + 1;
+    }
+    return 1;
+}
+
 /* Blocked Bloom filter over the solid canonical k-mers, for membership scans along sequences (the `find`-style consumer,
  * /root/reference/src/FindBreakpoints.hpp:851-853,1012-1046; gatb's BLOOM_NEIGHBOR idea, src/Filler.cpp:189).  A block is 512 bits =
  * one 64-byte line; all NHASH bits of a k-mer fall in the block selected by the hash of the k-mer's MINIMIZER (smallest hashed
@@ -362,6 +394,23 @@ MTG_DEV uint64_t mix64(uint64_t x)
     x ^= x >> 33;
     return x;
 }
+/* the block of a k-mer whose smallest hashed canonical mm-mer hashes to `best` */
+MTG_DEV uint64_t bloom_block_of_min(const Bloom& bl, uint64_t best)
+{
+    best = mix64(best + 0x9E3779B97F4A7C15ULL); /* the minimum of several hashes is not uniform: scramble it again */
+#ifdef MTG_EMU
+    return (uint64_t)(((unsigned __int128)best * bl.nblocks) >> 64);
+#else
+    return __umul64hi(best, bl.nblocks);
+#endif
+}
+/* hash of the canonical mm-mer whose little-endian image (first nucleotide lowest, as the unitig store holds it) is le: what bloom_block
+ * takes the minimum of */
+MTG_DEV uint64_t bloom_mmer_hash(uint64_t le, int mm)
+{
+    const uint64_t r = le ^ (0xAAAAAAAAAAAAAAAAULL & kmask(mm)), f = revcomp(r, mm);
+    return mix64(f < r ? f : r);
+}
 /* block of the oriented k-mer x: orientation independent (canonical mm-mers) */
 MTG_DEV uint64_t bloom_block(const Bloom& bl, const Kmer& x, int k)
 {
@@ -374,12 +423,7 @@ MTG_DEV uint64_t bloom_block(const Bloom& bl, const Kmer& x, int k)
         const uint64_t h = mix64(a < b ? a : b);
         best = h < best ? h : best;
     }
-    best = mix64(best + 0x9E3779B97F4A7C15ULL); /* the minimum of several hashes is not uniform: scramble it again */
-#ifdef MTG_EMU
-    return (uint64_t)(((unsigned __int128)best * bl.nblocks) >> 64);
-#else
-    return __umul64hi(best, bl.nblocks);
-#endif
+    return bloom_block_of_min(bl, best);
 }
 /* bit positions inside the block: 4 x 9 bits of a hash of the canonical k-mer */
 MTG_DEV uint64_t bloom_bits(uint64_t canon_kmer) { return mix64(canon_kmer ^ 0x9E3779B97F4A7C15ULL); }
@@ -1082,9 +1126,7 @@ MTG_DEV int sparse_link(const Index& ix, const UsRec& r, uint32_t i, bool with_b
         const uint32_t a0 = (uint32_t)((w[(i - 1) >> 5] >> (2u * ((i - 1) & 31u))) & 3ull); /* first nucleotide of k-mer i - 1 */
         const uint32_t prev_bit = pre <= rpre ? 1u << (4 + a0) : 1u << (a0 ^ 2u);          /* its "a + suf is solid" on the junction pre */
         const uint64_t key = pre <= rpre ? pre : rpre;
-        fail |= adj_or(ix.adj, key, pre_bit | prev_bit) & 1;
-        uint64_t* e = adj_find(ix.adj, key);
-        if (e) e[1] = up_make(r.hdr, i, !(pre <= rpre));
+        fail |= adj_set_new(ix.adj, key, pre_bit | prev_bit, up_make(r.hdr, i, !(pre <= rpre))) & 1;
     }
     if (i == r.len_k - 1) fail |= adj_or(ix.adj, suf <= rsuf ? suf : rsuf, suf_bit | suf_bit2) & 1;
     return fail;

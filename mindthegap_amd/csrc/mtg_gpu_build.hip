@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(64) k_sparse_link(Index ix, const UsRec* __res
 {
     __shared__ unsigned long long s_bits[64 * 8];
     __shared__ unsigned long long s_blk[64];
+    __shared__ unsigned long long s_mh[64 + 32]; /* hashes of the tile's m-mers (k - m <= 31) */
     const uint32_t lane = threadIdx.x;
     const int k = ix.k;
     const bool bloom = with_bloom != 0 && ix.bloom.bits != nullptr;
@@ -146,13 +147,22 @@ __global__ void __launch_bounds__(64) k_sparse_link(Index ix, const UsRec* __res
             const bool valid = i < r.len_k;
             if (valid) fail |= sparse_link(nb, r, i, false);
             if (!bloom) continue;
+            /* the minimizer of a k-mer is the smallest hash among its k - m + 1 m-mers, and neighbouring k-mers share all but one of them: the tile's
+             * m-mers are hashed ONCE, by the lanes, into LDS (64 + k - m of them; two 64-bit multiplications each), and a k-mer takes the minimum
+             * over its window there -- bloom_block hashed fifteen m-mers per k-mer */
+            const int mm = ix.bloom.mm;
+            const uint32_t span = (uint32_t)(k - mm), tile_n = (r.len_k - base < 64u ? r.len_k - base : 64u) + span; /* m-mers of the tile's k-mers */
+            for (uint32_t t = lane; t < tile_n; t += 64) s_mh[t] = bloom_mmer_hash(us_peek64(ix.us.words, (r.hdr + 1) * 32 + base + t, (uint32_t)mm, false), mm);
+            __syncthreads();
             unsigned long long blk = ~0ull, hb = 0;
             if (valid) {
                 const uint64_t mk = kmask(k);
                 Kmer x;
                 x.r = us_kmer_le(ix.us.words, (r.hdr + 1) * 32 + i, k) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
                 x.f = revcomp(x.r, k);
-                blk = bloom_block(ix.bloom, x, k);
+                unsigned long long best = ~0ull;
+                for (uint32_t t = 0; t <= span; t++) { const unsigned long long h = s_mh[lane + t]; best = h < best ? h : best; }
+                blk = bloom_block_of_min(ix.bloom, best);
                 hb = bloom_bits(canon(x));
             }
             const unsigned long long prev = __shfl_up(blk, 1, 64);
