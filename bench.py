@@ -407,38 +407,56 @@ def main():
                 j, _buf = pg.acquire()
                 pg.submit(0, j, tag=-1)
 
+        # The caller threads of the job: a.in_flight of them, started ONCE (the reference's Dispatcher keeps its worker threads for the whole run
+        # too).  Round 4 started and joined six Python threads inside every timed block: 0.5 ms of a 15 ms block of 20 steps -- 3-4 % of the
+        # headline, and a third of a block of 12 500-site steps (the 8-GPU outlook).
+        import queue as _queue
+        tasks = _queue.Queue()
+        done_cv = threading.Condition()
+        pending = [0]
+        errors = []
+
+        def caller():
+            torch.cuda.set_device(local_rank)  # the current device is a per-thread setting
+            while True:
+                item = tasks.get()
+                if item is None:
+                    return
+                fn, args = item
+                try:
+                    fn(*args)
+                except BaseException as e:  # surfaced on the main thread
+                    errors.append(e)
+                with done_cv:
+                    pending[0] -= 1
+                    if pending[0] == 0:
+                        done_cv.notify_all()
+
+        callers = [threading.Thread(target=caller, daemon=True) for _ in range(max(1, a.in_flight))]
+        for t in callers:
+            t.start()
+
+        def run_tasks(items):
+            """every item (function, arguments) on the caller threads; returns when all are done"""
+            if not items:
+                return
+            with done_cv:
+                pending[0] += len(items)
+            for it_ in items:
+                tasks.put(it_)
+            with done_cv:
+                while pending[0]:
+                    done_cv.wait()
+            if errors:
+                raise errors[0]
+
         def run_block(count, record, first_step=0, host_strings=False, host_text=False):
-            """`count` steps, a.in_flight batches in flight: caller threads take the next batch off a shared list, like the reference's
+            """`count` steps, a.in_flight batches in flight: the caller threads take the next batch off a shared queue, like the reference's
             Dispatcher threads take the next group of records; every batch is complete when this returns"""
             work = []
             for s in range(first_step, first_step + count):
                 work += [batches[s % len(batches)]] if rotate else list(batches)
-            it = iter(work)
-            errors = []
-
-            def worker():
-                try:
-                    torch.cuda.set_device(local_rank)  # the current device is a per-thread setting
-                    while True:
-                        with acc_lock:
-                            b = next(it, None)
-                        if b is None:
-                            return
-                        fill(b, prepared=b.strings if host_strings else b.text if host_text else None, record=record)
-                except BaseException as e:  # surfaced on the main thread
-                    errors.append(e)
-
-            nthreads = max(1, min(a.in_flight, len(work)))
-            if nthreads <= 1:
-                worker()
-            else:
-                ts = [threading.Thread(target=worker) for _ in range(nthreads)]
-                for t in ts:
-                    t.start()
-                for t in ts:
-                    t.join()
-            if errors:
-                raise errors[0]
+            run_tasks([(lambda b: fill(b, prepared=b.strings if host_strings else b.text if host_text else None, record=record), (b,)) for b in work])
             if st["pg"] is not None and not rotate:
                 pad_gathers(count * (cfg["max_per_rank"] - len(batches)))
 
@@ -566,7 +584,7 @@ def main():
         else:
             n_filled_all, n_sites_all = n_filled_rank, n_sites_rank
         return dict(acc=acc, batches=batches, st=st, pg=pg_saved, times=times, elapsed=elapsed, gathered=gathered, identical=identical, st_alone=st_alone,
-                    n_filled=n_filled_all, n_sites=n_sites_all, fill=fill, run_block=run_block, value=cfg["step_sites"] * a.steps / elapsed)
+                    n_filled=n_filled_all, n_sites=n_sites_all, fill=fill, run_block=run_block, run_tasks=run_tasks, value=cfg["step_sites"] * a.steps / elapsed)
 
     results = []
     for ci, c in enumerate(configs):
@@ -694,30 +712,24 @@ def main():
             try:
                 sub = idx.prepare_batch(mtg.Index.prepare_gaps(batches[0].gaps[:per_rank]), params)
                 def run_sub(count):
-                    it = iter(range(count))
-                    lk = threading.Lock()
-                    def w():
-                        torch.cuda.set_device(local_rank)
-                        while True:
-                            with lk:
-                                if next(it, None) is None:
-                                    return
-                            h_s, _nf, _ = idx.fill_prepared(sub, params, want_seqs=False)
-                            idx.free_results(h_s)
-                    ts_ = [threading.Thread(target=w) for _ in range(max(1, a.in_flight))]
-                    for t_ in ts_: t_.start()
-                    for t_ in ts_: t_.join()
+                    def one():
+                        h_s, _nf, _ = idx.fill_prepared(sub, params, want_seqs=False)
+                        idx.free_results(h_s)
+                    R0["run_tasks"]([(one, ())] * count)
                 run_sub(12)
+                # blocks long enough for the steady state: a block of 20 steps of 0.1 ms is mostly the pipeline filling and draining (six batches in
+                # flight, 0.3 ms from a batch's first kernel to its results on the host)
+                sub_steps = max(a.steps, 240)
                 reps = []
                 for _ in range(5):
-                    torch.cuda.synchronize(); t0 = time.perf_counter(); run_sub(a.steps); torch.cuda.synchronize(); reps.append(time.perf_counter() - t0)
-                t_b = float(np.median(reps)) / a.steps
+                    torch.cuda.synchronize(); t0 = time.perf_counter(); run_sub(sub_steps); torch.cuda.synchronize(); reps.append(time.perf_counter() - t0)
+                t_b = float(np.median(reps)) / sub_steps
                 outlook[str(per_rank)] = {"sites_per_rank_and_step": per_rank, "ms_per_step_of_one_rank": t_b * 1e3, "sites_per_s_of_one_rank": per_rank / t_b,
                                           "times_8_if_the_ranks_do_not_interfere": 8 * per_rank / t_b, "efficiency_vs_8x_the_headline": (8 * per_rank / t_b) / (8 * value) if value else None}
                 sub.close()
             except Exception as e:
                 outlook[str(per_rank)] = {"error": repr(e)[:200]}
-        secondary["eight_gpu_outlook_from_one_rank"] = {"what": "one rank's share of a strong-scaling step at N = 8, measured on this one GPU (prepared batches, six in flight, results to host memory, NO gather and no second rank: "
+        secondary["eight_gpu_outlook_from_one_rank"] = {"what": "one rank's share of a strong-scaling step at N = 8, measured on this one GPU in its steady state (blocks of at least 240 steps; prepared batches, six in flight, results to host memory, NO gather and no second rank: "
                                                                 "an upper bound of what eight ranks reach together; the gather's per-batch cost is in profiles/r04_dry_one_rank_rccl.json)", "shards": outlook}
 
     # ---------------------------------------------------------------- secondary: the tool.  `MindTheGap fill -bkpt` on the sites of the batches, through the library's

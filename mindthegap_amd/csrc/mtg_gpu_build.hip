@@ -989,9 +989,38 @@ int index_dump(const mtg_index* idx, IndexDump& d)
     return MTG_OK;
 }
 
+namespace {
+struct AdjPrealloc {
+    std::thread th;
+    DevBuf buf;
+    hipError_t err = hipSuccess;
+};
+} // namespace
+void* adj_prealloc_begin(uint64_t nb_solid, int k)
+{
+    if (ensure_device() || nb_solid == 0 || k < 11 || k > 31) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    AdjPrealloc* a = new AdjPrealloc();
+    const size_t bytes = adj_bytes_estimate(nb_solid, k);
+    a->th = std::thread([a, dev, bytes] {
+        a->err = hipSetDevice(dev);
+        if (a->err == hipSuccess) a->err = a->buf.alloc(bytes);
+    });
+    return a;
+}
+void adj_prealloc_drop(void* handle)
+{
+    AdjPrealloc* a = (AdjPrealloc*)handle;
+    if (!a) return;
+    if (a->th.joinable()) a->th.join();
+    delete a;
+}
+
 /* an index out of its container: the store goes up as it is, the tables are derived from it (sparsify); nothing is counted or walked */
 int index_from_dump(const IndexDump& d, mtg_index** out)
 {
+    struct PreGuard { void* h; ~PreGuard() { adj_prealloc_drop(h); } } pre_guard{d.prealloc};
     if (int rc = ensure_device()) return rc;
     if (d.k < 11 || d.k > 31 || !out) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
     if (d.n_words == 0) {
@@ -1100,7 +1129,13 @@ int index_from_dump(const IndexDump& d, mtg_index** out)
     idx->info.bloom_minimizer = (uint32_t)idx->dev.bloom.mm;
     idx->info.adj_bucket_bytes = 16 * MTG_ADJ_SLOTS;
     idx->info.abnd_bucket_bytes = 8 * MTG_ABND_SLOTS;
-    if (int rc = sparsify(idx, d_rec.as<UsRec>(), hdr.size(), true, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d.left_k.size(), &prof)) return rc;
+    DevBuf* adj_pre = nullptr;
+    if (AdjPrealloc* a = (AdjPrealloc*)d.prealloc) {
+        if (a->th.joinable()) a->th.join();
+        if (a->err == hipSuccess && a->buf.p) adj_pre = &a->buf; /* too small after all, or failed: sparsify allocates its own */
+        else (void)hipGetLastError();
+    }
+    if (int rc = sparsify(idx, d_rec.as<UsRec>(), hdr.size(), true, d_k.as<uint64_t>(), d_a.as<uint32_t>(), d.left_k.size(), &prof, nullptr, adj_pre)) return rc;
     const auto t_j0 = std::chrono::steady_clock::now();
     for (auto& t : uploaders) t.join();
     if (up_err.load()) { set_error(up_err.load() == 2 ? "index container: short read" : "index container: the upload of the abundance bytes failed"); return up_err.load() == 2 ? MTG_ERR_FORMAT : MTG_ERR_NO_DEVICE; }

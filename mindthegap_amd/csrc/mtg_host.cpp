@@ -326,6 +326,8 @@ static int index_load_v3(FILE* f, const char* path, mtg_index** out)
     IndexDump d;
     d.k = hdr[0]; d.abundance_min = hdr[1]; d.abundance_auto = hdr[2];
     d.nb_solid = cnt[0]; d.nb_branching = cnt[1]; d.nb_saturated = cnt[2]; d.n_words = cnt[3]; d.n_unitigs = cnt[4];
+    if (d.n_words) d.prealloc = adj_prealloc_begin(d.nb_solid, d.k); /* the largest allocation of the load starts now, on a helper thread, and the file is read meanwhile */
+    struct DropPre { IndexDump& d; bool handed = false; ~DropPre() { if (!handed) adj_prealloc_drop(d.prealloc); } } drop_pre{d};
     /* the words (a fifth of the store) come to host memory -- the walk over the unitigs' header words needs them -- read by several threads;
      * the abundance bytes go from the file to the device in page-locked pieces while the tables are being derived (index_from_dump) */
     const int fd = fileno(f);
@@ -340,6 +342,7 @@ static int index_load_v3(FILE* f, const char* path, mtg_index** out)
     }
     if (!ok) { set_error("%s: truncated", path); return MTG_ERR_FORMAT; }
     if (nw) d.ab_read = [fd, ab0](uint64_t off, size_t n, void* dst) { return pread_all(fd, dst, n, ab0 + off); };
+    drop_pre.handed = true; /* index_from_dump takes the pre-allocation over (and drops it on every path) */
     return index_from_dump(d, out);
 }
 

@@ -592,7 +592,14 @@ struct IndexDump {
      * file -- are handed over piece by piece: ab_read(off, n, dst) copies bytes [off, off + n) of the abundance section to dst; it is
      * called from several threads at once, each with a page-locked dst of its own */
     std::function<bool(uint64_t off, size_t n, void* dst)> ab_read;
+    /* adj_prealloc_begin's handle (or null): the memory of the largest table, being allocated on a helper thread since the container's header
+     * was read -- on this pool a first large hipMalloc can take seconds, which the reading of the file then hides */
+    void* prealloc = nullptr;
 };
+/* starts a thread that allocates the device memory the sparse ADJ table of an index of nb_solid k-mers will take; index_from_dump takes it over
+ * (adj_prealloc_drop: the load did not get that far) */
+void* adj_prealloc_begin(uint64_t nb_solid, int k);
+void adj_prealloc_drop(void* handle);
 int index_dump(const mtg_index* idx, IndexDump& d);
 int index_from_dump(const IndexDump& d, mtg_index** out);
 

@@ -58,21 +58,29 @@ for s0 in range(0, S.n_sites, B):
         l, r, _ = S.site(i)
         gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
     batches.append((gaps, idx.prepare_batch(mtg.Index.prepare_gaps(gaps), params)))
-import threading
+import threading, queue
+# six caller threads, started once (the reference's Dispatcher keeps its workers for the whole run): a block of steps is their queue filled and drained
+_tasks = queue.Queue(); _cv = threading.Condition(); _pending = [0]
+def _caller():
+    while True:
+        b = _tasks.get()
+        h, nf, _ = idx.fill_prepared(b[1], params, want_seqs=False)
+        idx.free_results(h)
+        with _cv:
+            _pending[0] -= 1
+            if _pending[0] == 0:
+                _cv.notify_all()
+for _ in range(6):
+    threading.Thread(target=_caller, daemon=True).start()
 def run(steps):
     work = [b for _ in range(steps) for b in batches]
-    it = iter(work); lock = threading.Lock()
-    def w():
-        while True:
-            with lock:
-                b = next(it, None)
-            if b is None:
-                return
-            h, nf, _ = idx.fill_prepared(b[1], params, want_seqs=False)
-            idx.free_results(h)
-    ts = [threading.Thread(target=w) for _ in range(6)]
-    for t in ts: t.start()
-    for t in ts: t.join()
+    with _cv:
+        _pending[0] += len(work)
+    for b in work:
+        _tasks.put(b)
+    with _cv:
+        while _pending[0]:
+            _cv.wait()
 # every one of the index's six workspaces is allocated before anything is timed: six callers enter the library at the same moment (bench.py's priming step)
 gate = threading.Barrier(6)
 def prime():

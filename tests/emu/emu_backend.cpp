@@ -286,6 +286,8 @@ static void dump_kmers(const IndexDump& d, std::vector<uint64_t>& km, std::vecto
     km.insert(km.end(), d.left_k.begin(), d.left_k.end());
     ab.insert(ab.end(), d.left_a.begin(), d.left_a.end());
 }
+void* adj_prealloc_begin(uint64_t, int) { return nullptr; } /* the emulation has no device memory to allocate ahead */
+void adj_prealloc_drop(void*) {}
 int index_from_dump(const IndexDump& d0, mtg_index** out)
 {
     /* the emulation rebuilds from the k-mers (its tables are host memory); the device build derives the tables from the store itself */
