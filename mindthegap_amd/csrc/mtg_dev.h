@@ -26,7 +26,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MTG_DEV __device__ __forceinline__
-#define MTG_HD __host__ __device__ __forceinline__ /* small helpers the host side of mtg_gpu.hip shares with the kernels */
+#define MTG_HD __host__ __device__ __forceinline__ /* small helpers the host side of the mtg_gpu_*.hip units shares with the kernels */
 #ifndef MTG_NOINLINE_BUBBLES
 #define MTG_DEV_NOINLINE __device__ __forceinline__
 #else

@@ -1,7 +1,7 @@
 /*
  * mtg_host.cpp -- host orchestration of libmtgfill.so.
  *
- * The device builds the contigs of every gap (stage A, mtg_gpu.hip) and answers abundance queries; this file
+ * The device builds the contigs of every gap (stage A, mtg_gpu_fill.hip) and answers abundance queries; this file
  * holds the rest of Filler::gapFillFromSource (/root/reference/src/Filler.cpp:854-1026) for a whole batch:
  *   contig graph      IGraphOutput::construct_graph / print_edges   src/IGraphOutput.cpp:97-133,144-179
  *   terminal nodes    Filler::find_nodes_containing_multiple_R      src/Filler.cpp:1294-1378

@@ -1,7 +1,10 @@
 /*
  * mtg_internal.h -- interfaces between the translation units of libmtgfill.so
- *   mtg_gpu.hip   : HIP kernels, device memory, index construction, stage A batches
- *   mtg_host.cpp  : host orchestration of gapFillFromSource (contig graph, paths, dedupe, writers), CLI
+ *   mtg_gpu_build.hip : index construction on the device (junction table, walks, unitig store, sparse tables), container load, replicas
+ *   mtg_gpu_fill.hip  : the fill kernels and the launch sequence of a batch (device_run)
+ *   mtg_gpu_misc.hip  : queries, sequence scan, alignments, the tool's formatter, the device side of the C ABI
+ *   mtg_host.cpp      : host orchestration of gapFillFromSource (marshalling, result objects, the multi-contig gaps the device leaves), index files
+ *   mtg_cli.cpp       : the MindTheGap fill tool on the C-ABI records
  */
 #ifndef MTG_INTERNAL_H
 #define MTG_INTERNAL_H

@@ -1,5 +1,5 @@
 /* Marshalling of gapFillFromSource calls from a block of text, per gap and per dictionary entry: what FillInput::set_common / set_target
- * (mtg_host.cpp) do with the caller's strings on the host, as functions the device runs (k_marshal_text, k_marshal_targets in mtg_gpu.hip;
+ * (mtg_host.cpp) do with the caller's strings on the host, as functions the device runs (k_marshal_text, k_marshal_targets in mtg_gpu_fill.hip;
  * the emulation build calls them on the host).  Same results bit for bit: the two paths are compared by the tests. */
 #pragma once
 #include "mtg_dev.h"

@@ -1,5 +1,5 @@
 /*
- * tests/emu/emu_backend.cpp -- TEST-ONLY stand-in for mtg_gpu.hip: the same device functions
+ * tests/emu/emu_backend.cpp -- TEST-ONLY stand-in for mtg_gpu_build.hip / mtg_gpu_fill.hip / mtg_gpu_misc.hip: the same device functions
  * (mtg_dev.h / mtg_traverse.h) executed lane by lane on the host, behind the internal interface of
  * mtg_internal.h.  Linked with the product's host translation units (mtg_host.cpp, mtg_cli.cpp) into
  * tests/emu/libmtgfill_emu.so so that the CPU test-suite can run the whole `MindTheGap fill` logic
@@ -37,7 +37,7 @@ int index_from_kmers(const uint64_t* kmers, const uint32_t* ab, size_t n, int k,
 {
     if (k < 11 || k > 31) { set_error("invalid argument (11 <= k <= 31)"); return MTG_ERR_ARG; }
     if (!emu_legacy_build()) {
-        /* the lean build, as index_from_kmer_pieces_lean of mtg_gpu.hip */
+        /* the lean build, as index_from_kmer_pieces_lean of mtg_gpu_build.hip */
         mtg_index* idx = new mtg_index();
         idx->dev.k = k;
         bloom_shape(idx->dev.bloom, n, 12.0, k);
@@ -579,7 +579,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 dw.assign(c0 + 1, 0);
                 dm.assign(5 * c1 + 1, 0);
             }
-            {   /* stand-in for k_wire_sum and for the host's view of the launch (device_run of mtg_gpu.hip) */
+            {   /* stand-in for k_wire_sum and for the host's view of the launch (device_run of mtg_gpu_fill.hip) */
                 const WireLayout wl = wire_layout(m, tot.n_filled, tot.end[2], tot.end[3]);
                 const bool wired = sink.wire_dev != nullptr && identity && tier == 0 && wl.total <= sink.wire_cap && tot.n_retry == 0 && tot.n_general == 0;
                 if (sink.wire_dev && identity && tier == 0) { sink.wire_ok = wired; sink.wire_bytes = wired ? wl.total : 0; }

@@ -1,5 +1,5 @@
 /*
- * tests/emu/emu_us.h -- TEST-ONLY: the unitig store construction of the device build (kernels k_us_* of mtg_gpu.hip), run serially
+ * tests/emu/emu_us.h -- TEST-ONLY: the unitig store construction of the device build (the dense reference construction: the product built its store this way until round 4), run serially
  * with the same device functions (mtg_dev.h: us_plan / us_emit / us_link over the solid k-mers read back from the ABND table).
  */
 #ifndef MTG_EMU_US_H
@@ -56,7 +56,7 @@ inline uint64_t emu_build_unitigs(mtg::Index& ix, EmuUStore& st)
     return cr;
 }
 
-/* the sparse form of a dense index with its unitig store (the device build: sparsify in mtg_gpu.hip): new tables from the store and the
+/* the sparse form of a dense index with its unitig store (sparsify in mtg_gpu_build.hip): new tables from the store and the
  * k-mers of no stored unitig; `ix` then points to them (the caller frees the dense tables).  MTG_DENSE_INDEX=1 keeps the dense form. */
 inline bool emu_sparsify(mtg::Index& ix, EmuUStore& st)
 {
@@ -104,7 +104,7 @@ inline bool emu_sparsify(mtg::Index& ix, EmuUStore& st)
     }
 }
 
-/* ---- the lean build (mtg_dev.h: "the lean build"; the device's build_from_jt + sparsify in mtg_gpu.hip), run serially with the same
+/* ---- the lean build (mtg_build.h; the device build_from_jt + sparsify in mtg_gpu_build.hip), run serially with the same
  * device functions: junction table + an ABND table as the abundances' source -> scan -> plan -> emit -> abundances -> sparse tables. ---- */
 inline bool emu_legacy_build() { return getenv("MTG_DENSE_INDEX") || getenv("MTG_NO_UNITIGS") || getenv("MTG_LEGACY_BUILD"); }
 
