@@ -927,9 +927,9 @@ def main():
             "measured_link_ceiling_GBps": "scripts/pcie_d2h.py: 57 with two or three copies in flight",
             "traffic": None, "traffic_source": None,
             "dominant_kernel": dom["kernel"], "dominant_kernel_frac_of_hbm_peak": dom["frac"], "kernels": kerns, "launches": int(acc["n_launches"]),
-            "kernel_times": "avg_kernel_ms = HIP events on the batch's stream with ONE batch on the device (%s launches after the timed blocks); the same command under rocprofv3 --kernel-trace --stats with --in-flight 1 is profiles/r04_kernel_stats_one_batch_in_flight.csv"
+            "kernel_times": "avg_kernel_ms = HIP events on the batch's stream with ONE batch on the device (%s launches after the timed blocks); the same command under rocprofv3 --kernel-trace --stats with --in-flight 1 is profiles/r05_kernel_stats_one_batch_in_flight.csv"
                             % (st_alone["runs"] if st_alone else 0)}
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json")) if os.path.exists(q)), None)
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json")) if os.path.exists(q)), None)
     if a.workload == "human" and batch_sites == 100000 and pmc:
         pj = json.load(open(pmc))
         fill_kernels = ("k_stage_a", "k_finish", "k_bubble", "k_lean", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
@@ -939,7 +939,7 @@ def main():
         roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (dk == "k_emit" and kn == "k_emit_lean") or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble"))))) or None
         roof["traffic_by_kernel"] = by_kernel
         roof["traffic_is"] = "REPLAYED, not measured in this run: counters cannot be read from inside the process"
-        roof["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, no trace domain, the bench command of scripts/profile_round4.sh, HEAD %s): "
+        roof["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, no trace domain, the bench command of scripts/profile_round5.sh, HEAD %s): "
                                   "average HBM bytes per launch.  FETCH_SIZE correction: none -- the guide's x2 applies to wide coalesced 16 B/lane streams; these kernels read "
                                   "scattered buckets and 8 B/lane runs, and FETCH_SIZE was calibrated at 1.000 on this library's scattered 16-byte reads (profiles/r01_pmc_fetch_size.json)"
                                   % (os.path.relpath(pmc, ROOT), pj.get("head", "?")))
@@ -993,11 +993,11 @@ def main():
                    # SURVEY 8(d)'s bytes over the DEVICE time of the construction (the kernels' own clock; `seconds` also holds hipMalloc, a box property)
                    "sec8d_frac_over_device_seconds": ref_b / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS,
                    "traffic": None}
-    pmcb = os.path.join(ROOT, "profiles", "r04_pmc_build.json")
+    pmcb = next((q for q in (os.path.join(ROOT, "profiles", "r05_pmc_build.json"), os.path.join(ROOT, "profiles", "r04_pmc_build.json")) if os.path.exists(q)), os.path.join(ROOT, "profiles", "r05_pmc_build.json"))
     if a.workload == "human" and os.path.exists(pmcb):
         pb = json.load(open(pmcb))
         index_build["traffic"] = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pb.get("kernels", {}).items()}
-        index_build["traffic_is"] = "REPLAYED from profiles/r04_pmc_build.json (rocprofv3 --pmc passes of scripts/r4_build.py, HEAD %s); FETCH_SIZE x2 applied to no kernel (8 B/lane table scans, scattered buckets)" % pb.get("head", "?")
+        index_build["traffic_is"] = "REPLAYED from %s (rocprofv3 --pmc passes of scripts/r4_build.py, HEAD %s); FETCH_SIZE x2 applied to no kernel (16 B/lane table scans, scattered buckets)" % (os.path.relpath(pmcb, ROOT), pb.get("head", "?"))
 
     out = {"metric": "breakpoints filled/sec", "value": value, "unit": "breakpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
