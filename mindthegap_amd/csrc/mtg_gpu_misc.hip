@@ -215,8 +215,10 @@ __global__ void __launch_bounds__(SCAN_TILE) k_scan(Index ix, const uint64_t* __
     __shared__ uint64_t s_bid[SCAN_TILE];
     __shared__ uint64_t s_slot_bid[SCAN_TILE];
     __shared__ uint32_t s_wave_cnt[SCAN_TILE / 64];
-    const int k = ix.k;
-    const uint64_t mk = kmask(k);
+    __shared__ uint64_t s_mh[SCAN_TILE + 32]; /* hashes of the tile's m-mers */
+    const int k = ix.k, mm = ix.bloom.mm;
+    const uint32_t span = (uint32_t)(k - mm);
+    const uint64_t mk = kmask(k), mmask = kmask(mm);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     unsigned long long n_k = 0, n_pos = 0, n_conf = 0, n_staged = 0;
     for (size_t s = blockIdx.x; s < nseq; s += gridDim.x) {
@@ -228,13 +230,26 @@ __global__ void __launch_bounds__(SCAN_TILE) k_scan(Index ix, const uint64_t* __
         for (uint32_t base = 0; base < npos; base += SCAN_TILE) {
             const uint32_t p = base + tid;
             const bool valid = p < npos;
+            /* the minimizer of a k-mer is the smallest hash among its k - m + 1 m-mers and neighbouring k-mers share all but one of them: the
+             * tile's m-mers are hashed once (256 + k - m of them, one or two per thread) and a k-mer takes the minimum over its window in LDS
+             * (rounds 1-4: bloom_block hashed fifteen m-mers per k-mer -- the kernel was bound by those multiplications, not by its reads) */
+            const uint32_t tile_k = npos - base < (uint32_t)SCAN_TILE ? npos - base : (uint32_t)SCAN_TILE, tile_m = tile_k + span;
+            for (uint32_t t = tid; t < tile_m; t += SCAN_TILE) {
+                const uint32_t j = base + t, sh = 2u * (j & 31u);
+                uint64_t v = w[j >> 5] >> sh;
+                if ((j & 31u) + (uint32_t)mm > 32u) v |= w[(j >> 5) + 1] << (64u - sh);
+                s_mh[t] = bloom_mmer_hash(v & mmask, mm);
+            }
+            __syncthreads();
             Kmer x;
             x.f = x.r = 0;
             uint64_t b = ~0ull;
             if (valid) {
                 x.r = le_kmer(w, p, mk) ^ (0xAAAAAAAAAAAAAAAAULL & mk);
                 x.f = revcomp(x.r, k);
-                b = bloom_block(ix.bloom, x, k);
+                uint64_t best = ~0ull;
+                for (uint32_t t = 0; t <= span; t++) { const uint64_t h = s_mh[tid + t]; best = h < best ? h : best; }
+                b = bloom_block_of_min(ix.bloom, best);
             }
             s_bid[tid] = b;
             __syncthreads();
