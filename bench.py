@@ -560,7 +560,7 @@ def main():
         # the kernels' own times: every distinct batch once more (twice when there are few), ONE batch on the device at a time; the averages are what
         # every roofline fraction below is computed from (under six batches in flight a kernel's events also span other batches' workgroups)
         st_alone = None
-        if batches and not (pg_saved is not None):
+        if batches:  # every rank for itself (no collective in it); rank 0's is reported
             runs = []
             mtg.tuning_set("KERNEL_TIMERS", "1")  # an event between the kernels: each kernel's own time in the statistics (off in the timed blocks: three events per batch instead of nine)
             for b in (batches * 2 if len(batches) < 4 else batches):
