@@ -6,6 +6,7 @@
  */
 #ifndef MTG_BUILD_H
 #define MTG_BUILD_H
+#include <math.h>
 #include "mtg_dev.h"
 
 namespace mtg {
@@ -16,16 +17,21 @@ namespace mtg {
  * the streaming pass over the junction table pays (k_jt_scan). */
 MTG_DEV uint64_t bucket_first_h(uint64_t home, uint64_t nb, uint32_t key_bits)
 {
-#ifdef MTG_EMU
-    return (uint64_t)(((((unsigned __int128)home) << key_bits) + nb - 1) / nb);
-#else
     if (home == 0) return 0;
     /* an estimate in double (off by at most a few thousand), corrected exactly: home * 2^key_bits - e * nb is small, so its low 64 bits are it */
     const uint64_t e = (uint64_t)((double)home * ((double)(1ull << key_bits) / (double)nb));
     const int64_t diff = (int64_t)((home << key_bits) - e * nb);
-    const int64_t q = diff >= 0 ? (int64_t)(((uint64_t)diff + nb - 1) / nb) : -(int64_t)((uint64_t)(-diff) / nb);
-    return (uint64_t)((int64_t)e + q);
+    /* ceil(diff / nb) without a 64-bit division (a few hundred instructions on this machine, once per bucket of a 10^9-bucket table): |diff| is
+     * below 2^46 and nb below 2^40, both exact in double, so the quotient's estimate is off by at most one */
+    int64_t q = (int64_t)floor((double)diff / (double)nb);
+    while (q * (int64_t)nb < diff) q++;          /* the smallest q with q * nb >= diff */
+    while ((q - 1) * (int64_t)nb >= diff) q--;
+    const uint64_t first = (uint64_t)((int64_t)e + q);
+#ifdef MTG_EMU
+    /* the emulator checks the device's arithmetic against the 128-bit quotient on every bucket it decodes */
+    if (first != (uint64_t)(((((unsigned __int128)home) << key_bits) + nb - 1) / nb)) abort();
 #endif
+    return first;
 }
 /* key and value of slot word v found in bucket b, given first = bucket_first_h(b) (used when the slot sits in its home bucket) */
 MTG_DEV uint32_t slot_key_in_bucket(const Table& t, uint64_t b, uint64_t first_b, uint64_t v, uint64_t& key)
@@ -216,8 +222,16 @@ MTG_DEV void jt_scan_entry(const Table& jt, int k, uint64_t J, uint32_t m, const
     /* the entry of nearly every junction of a genome: one bit on each side.  Both views are then simple, and eligibility is a property of the
      * canonical junction (us_eligible is symmetric under reverse complement): two oriented k-mers, two interior views, nothing to probe */
     if (popc4(m & 15u) == 1 && popc4(m >> 4) == 1 && J != rJ) {
-        Kmer p, y;
-        if (jt_view_interior(jt_view(m, true), J, k, p, y)) { acc.c[JT_C_ORIENTED] += 2; acc.c[JT_C_INTERIOR] += 2; return; }
+        if (k & 1) {
+            /* odd k: no k-mer is its own reverse complement, the junction is not palindromic (J != rJ): us_eligible only rules out the self
+             * loop a+J == J+b, i.e. J a run of one nucleotide entered and left by that nucleotide */
+            const uint32_t a = (uint32_t)ctz4(m >> 4), b = (uint32_t)ctz4(m & 15u);
+            const uint64_t run = (0x5555555555555555ULL & kmask(k - 1)) * a; /* k - 1 times the nucleotide a */
+            if (!(a == b && J == run)) { acc.c[JT_C_ORIENTED] += 2; acc.c[JT_C_INTERIOR] += 2; return; }
+        } else {
+            Kmer p, y;
+            if (jt_view_interior(jt_view(m, true), J, k, p, y)) { acc.c[JT_C_ORIENTED] += 2; acc.c[JT_C_INTERIOR] += 2; return; }
+        }
     }
     const int nviews = (J == rJ) ? 1 : 2;
     for (int w = 0; w < nviews; w++) {

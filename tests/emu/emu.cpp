@@ -157,6 +157,17 @@ extern "C" void emu_debug_adj(void* p, uint64_t key)
 }
 
 /* unit access to the device NW routine (banded, exact) for tests */
+/* bucket_first_h at the sizes of a real table (the emulated builds only reach small ones): it aborts on a difference from the 128-bit quotient */
+extern "C" uint64_t emu_bucket_first_sweep(uint64_t nb, uint32_t key_bits, uint64_t n, uint64_t seed)
+{
+    uint64_t acc = 0, s = seed;
+    for (uint64_t i = 0; i < n; i++) {
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        const uint64_t home = i < 4 ? (i < 2 ? i : nb - (i - 1)) : (uint64_t)(((unsigned __int128)(s >> 1) * nb) >> 63);
+        acc ^= bucket_first_h(home, nb, key_bits);
+    }
+    return acc;
+}
 extern "C" int emu_nw_matches(const char* a, const char* b)
 {
     FillCfg cfg = make_cfg(31, 100, 10000, 0, 0);

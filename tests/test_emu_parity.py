@@ -2,6 +2,7 @@
 harness, plus the product's host code and CLI linked against it, checked against the oracle and the goldens.
 These do not replace the -m gpu parity tests; they validate kernel and host logic before GPU time is spent."""
 import contextlib
+import ctypes as C
 import os
 import random
 import struct
@@ -1413,3 +1414,14 @@ def test_indel_bubbles_answered_by_the_walking_lane(k):
     assert emu_lib.coop_counts()[5] - merges_before >= 10
     # ... and the second contig to arrive at that node finds it marked: "no consensus" said on the spot (the general code run next to it agrees, 0xBAE0)
     assert emu_lib.coop_counts()[6] - refused_before >= 5
+
+
+@pytest.mark.parametrize("nb,key_bits", [(1_000_000_007, 60), (1 << 30, 60), ((1 << 30) + 1, 60), (3_000_000_019, 60), (1 << 11, 60),
+                                          (40_000_003, 40), (1 << 36, 60), (977, 24)])
+def test_bucket_arithmetic_of_the_scan_at_real_table_sizes(nb, key_bits):
+    """bucket_first_h (mtg_build.h) estimates in double and corrects without a 64-bit division; the emulator's copy aborts when it differs from
+    the 128-bit quotient.  The emulated builds use small tables, this sweeps the bucket counts of a 3.1 G-k-mer table."""
+    lib = emu_lib.load()
+    lib.emu_bucket_first_sweep.restype = C.c_uint64
+    lib.emu_bucket_first_sweep.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
+    lib.emu_bucket_first_sweep(nb, key_bits, 2_000_000, 12345)
