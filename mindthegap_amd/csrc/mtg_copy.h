@@ -31,9 +31,9 @@ MTG_DEV uint64_t cmd_store_nt(const CopyCmd& cm, int64_t x)
 MTG_DEV bool lean_decide(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint64_t target)
 {
     const UStore& us = ix.us;
-    LeanRec* lr = s_lean(cfg, S);
-    if (o.status != GAP_OK) { LeanRec r; r.valid = 0; r.pos0 = 0; r.cmd = 0; r.pad_ = 0; *lr = r; return false; } /* the record is read for every gap (k_lean's list for k_post) */
-    const CopyCmd* cmds = s_cmd(cfg, S);
+    const SP<LeanRec> lr = s_lean(cfg, S);
+    if (o.status != GAP_OK) { LeanRec r; r.valid = 0; r.pos0 = 0; r.cmd = 0; r.pad_ = 0; lr[0] = r; return false; } /* the record is read for every gap (k_lean's list for k_post) */
+    const SP<CopyCmd> cmds = s_cmd(cfg, S);
     const int k = ix.k;
     bool lean = false;
     uint32_t pos0 = 0, ci = 0;
@@ -65,7 +65,7 @@ MTG_DEV bool lean_decide(const Index& ix, const FillCfg& cfg, const GapScratch& 
             }
         }
     }
-    { LeanRec r; r.valid = lean ? 1u : 0u; r.pos0 = pos0; r.cmd = ci; r.pad_ = 0; *lr = r; }
+    { LeanRec r; r.valid = lean ? 1u : 0u; r.pos0 = pos0; r.cmd = ci; r.pad_ = 0; lr[0] = r; }
 #ifdef MTG_XCHECK
     return o.n_cmds != 0; /* the emulation build copies all the same: its cross-checks read the contig */
 #else
@@ -77,7 +77,7 @@ MTG_DEV void copy_cmds(const Index& ix, const FillCfg& cfg, const GapScratch& S,
 {
     const UStore& us = ix.us;
     if (o.status != GAP_OK || o.n_cmds == 0) return;
-    const CopyCmd* cmds = s_cmd(cfg, S);
+    const SP<CopyCmd> cmds = s_cmd(cfg, S);
     uint64_t* words = s_words(cfg, S);
     /* the lane's words t, t + NLANES, ... in the concatenation of the commands: (c, base) follows t */
     uint32_t c = 0, base = 0;

@@ -203,11 +203,11 @@ MTG_DEV uint32_t gen_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
 {
     const uint32_t lane = MTG_LANE();
     const uint64_t* words = s_words(cfg, S);
-    const uint32_t* cstart = s_cstart(cfg, S);
-    const uint32_t* clen = s_clen(cfg, S);
-    const uint32_t* tpos = s_tpos(cfg, S);
-    const uint32_t* terr = s_terr(cfg, S);
-    const uint32_t* ttgt = s_ttgt(cfg, S);
+    const SP<uint32_t> cstart = s_cstart(cfg, S);
+    const SP<uint32_t> clen = s_clen(cfg, S);
+    const SP<uint32_t> tpos = s_tpos(cfg, S);
+    const SP<uint32_t> terr = s_terr(cfg, S);
+    const SP<uint32_t> ttgt = s_ttgt(cfg, S);
     const uint32_t K = (uint32_t)k;
     GenGap out;
     out.status = GEN_HOST; out.n_sols = 0; out.first_sol = 0; out.nb_total_filled = 0;

@@ -76,7 +76,7 @@ __device__ __forceinline__ void park_append(ParkCtl* park, uint32_t cap, uint32_
 /* one gap per lane.  in_list < 0: the gaps of the launch, from their source k-mers; otherwise the gaps of that work list, resumed (a bubble
  * kernel has answered the branching node they stand on).  out_list: where the gaps that park (again) go. */
 template <int MODE>
-__device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
+__device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                              const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset,
                                              ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
 {
@@ -90,7 +90,7 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
     const Index& ix = c_ix[cset]; /* cset is a kernel argument: still scalar loads */
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t g = ids ? ids[slot] : slot; /* gap id in the input arrays; scratch is indexed by slot */
-    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    GapScratch S = carve(cfg, zero, raw, ilv, head, slot);
     S.snp_fast = 1; /* the walking lane answers the strict SNP pattern itself */
     SwfPattern R;
     R.words = rwords + roff[g];
@@ -107,25 +107,25 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
     out[slot] = o;
     if (MODE == WALK_PARK) park_append(park, cap, out_list, o.status == GAP_PARKED, slot);
 }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ src,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                 GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
 {
-    stage_a_lane<WALK_PARK>(zero, raw, ilv, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list);
+    stage_a_lane<WALK_PARK>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list);
 }
 /* ---- the rounds between two launches of the walk kernel: the branching nodes of the parked gaps, answered on their own, one lane per
  * bubble from HBM scratch -- all 64 lanes of a wave are in the bubble code at the same time.  (k_bubble<G>, a group of G lanes per bubble with
  * LDS work areas, was the alternative of round 3; it lost on the narrow bubbles of heterozygous data -- DESIGN.md section 4 -- and is gone.  The
  * group form lives on where few gaps are in the bubble code: k_finish<G>.) */
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_bubble_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_bubble_classic(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= park->count[in_list]) return;
     const Index& ix = c_ix[cset];
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t slot = park_list(park, cap, in_list)[t];
-    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    GapScratch S = carve(cfg, zero, raw, ilv, head, slot);
     S.snp_fast = 1; /* the strict SNP pattern is answered by the fast path here as in the walk */
 #ifdef MTG_BUBBLE_TIMING
     const uint64_t t0 = wall_clock64();
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
 #define MTG_FINISH_WAVES 2
 #endif
 template <int G>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FINISH_WAVES))) k_finish(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FINISH_WAVES))) k_finish(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t cset,
                                                ParkCtl* park, uint32_t cap, uint32_t in_list)
 {
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t slot = park_list(park, cap, in_list)[t];
     const uint32_t g = ids ? ids[slot] : slot;
-    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    GapScratch S = carve(cfg, zero, raw, ilv, head, slot);
     S.snp_fast = 1;
     SwfPattern R;
     R.words = rwords + roff[g];
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
 
 /* the same with one LANE per parked gap and the general code on HBM scratch (A/B hook, MTG_FINISH_G=1): the group form is faster even
  * for a handful of parked gaps */
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_finish_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, const uint64_t* __restrict__ rwords,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_finish_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ rwords,
                                                const uint32_t* __restrict__ roff, const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                GapOut* out, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list, uint32_t first)
 {
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
     const FillCfg& cfg = c_cfg[cset];
     const uint32_t slot = park_list(park, cap, in_list)[t];
     const uint32_t g = ids ? ids[slot] : slot;
-    GapScratch S = carve(cfg, zero, raw, ilv, slot);
+    GapScratch S = carve(cfg, zero, raw, ilv, head, slot);
     S.snp_fast = 1;
     SwfPattern R;
     R.words = rwords + roff[g];
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
  * prefix popcount, as for parking).  k_copy, one wave per listed gap, four per workgroup: the grid covers the launch (the host does not
  * know the count), a wave beyond the list leaves after one scalar read. */
 enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2 };
-__global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
+__global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
                                              const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
                                              uint32_t lean_allowed, uint32_t n, ParkCtl* park, uint32_t cap)
 {
@@ -207,19 +207,20 @@ __global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw
         GapScratch S;
         S.z = nullptr;
         S.v = nullptr;
-        S.lane = 0;
+        S.lane = slot & 63u;
         S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
         /* the lean form needs one usable target and a source of exactly k nucleotides (what the common-case result of k_post needs anyway) */
         const uint32_t g = ids ? ids[slot] : slot;
         uint64_t target = ~0ull;
         if (lean_allowed && tcnt[g] == 1u && fast_ok[g] && tbad[toff[g]] == 0ull) target = rev_fields64(tle[toff[g]]) >> (64 - 2 * ix.k);
         need = lean_decide(ix, cfg, S, outs[slot], target);
-        general = !s_lean(cfg, S)->valid;
+        general = !s_lean(cfg, S)[0].valid;
     }
     park_append(park, cap, COPY_LIST, need, slot);
     park_append(park, cap, POST_LIST, general, slot); /* every gap that is not lean (a failed one too): k_post's general form */
 }
-__global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap, uint32_t list)
+__global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap, uint32_t list)
 {
     const uint32_t count = park->count[list];
     for (uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6); t < count; t += gridDim.x * 4u) { /* the grid covers the launch */
@@ -227,8 +228,9 @@ __global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* ra
         GapScratch S;
         S.z = nullptr;
         S.v = nullptr;
-        S.lane = 0;
+        S.lane = slot & 63u;
         S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
         copy_cmds(ix, cfg, S, outs[slot]);
     }
 }
@@ -271,7 +273,7 @@ __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __r
 #ifndef MTG_POST_WAVES
 #define MTG_POST_WAVES 6
 #endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POST_WAVES))) k_post(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POST_WAVES))) k_post(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
                                              uint32_t want_all, SlotRec* recs, uint32_t n, ParkCtl* park)
@@ -295,8 +297,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
         GapScratch S;
         S.z = nullptr;
         S.v = nullptr;
-        S.lane = 0;
+        S.lane = slot & 63u;
         S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
         if (o.status == GAP_OK) {
             const uint32_t g = ids ? ids[slot] : slot;
             PostTargets T;
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
 #define MTG_POST_LEAN_G 8
 #endif
 enum { POST_LEAN_G = MTG_POST_LEAN_G };
-__global__ void __launch_bounds__(64) k_post_lean(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, uint32_t want_all, SlotRec* recs, uint32_t n)
+__global__ void __launch_bounds__(64) k_post_lean(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, uint32_t want_all, SlotRec* recs, uint32_t n)
 {
     __shared__ uint32_t hist[64 / POST_LEAN_G][256];
     const uint32_t grp = threadIdx.x / POST_LEAN_G, gl = threadIdx.x % POST_LEAN_G;
@@ -348,8 +351,9 @@ __global__ void __launch_bounds__(64) k_post_lean(Index ix, FillCfg cfg, uint8_t
         GapScratch S;
         S.z = nullptr;
         S.v = nullptr;
-        S.lane = 0;
+        S.lane = slot & 63u;
         S.r = raw + (uint64_t)slot * cfg.raw_stride;
+        S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
         lean = post_lean_accumulate<POST_LEAN_G>(ix, cfg, S, o, gl, hist[grp], w);
     }
     __syncthreads(); /* the histograms are complete */
@@ -497,7 +501,7 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
     }
 }
 /* everything a gap leaves behind (mtg_emit.h: emit_gap), one wave per slot */
-__global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* raw, SlotRec* recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* raw, uint8_t* head, SlotRec* recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
                                              const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t* retry_list, uint32_t* general_list, uint32_t n, ParkCtl* park,
                                              uint32_t use_list)
 {
@@ -521,8 +525,9 @@ __global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* ra
     GapScratch S;
     S.z = nullptr;
     S.v = nullptr;
-    S.lane = 0;
+    S.lane = slot & 63u;
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
     const uint32_t g = ids ? ids[slot] : slot;
     emit_gap(us, cfg, S, r, gflags[g], slot, g, k, D, H);
     }
@@ -532,7 +537,7 @@ __global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* ra
 #define MTG_EMIT_LEAN_G 8
 #endif
 enum { EMIT_LEAN_G = MTG_EMIT_LEAN_G };
-__global__ void __launch_bounds__(64) k_emit_lean(UStore us, FillCfg cfg, uint8_t* raw, const SlotRec* __restrict__ recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(64) k_emit_lean(UStore us, FillCfg cfg, uint8_t* raw, uint8_t* head, const SlotRec* __restrict__ recs, const ScanBlock* __restrict__ blocks, const uint32_t* __restrict__ ids,
                                                   const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t n)
 {
     const uint32_t slot = blockIdx.x * (64u / EMIT_LEAN_G) + threadIdx.x / EMIT_LEAN_G, gl = threadIdx.x % EMIT_LEAN_G;
@@ -542,8 +547,9 @@ __global__ void __launch_bounds__(64) k_emit_lean(UStore us, FillCfg cfg, uint8_
     GapScratch S;
     S.z = nullptr;
     S.v = nullptr;
-    S.lane = 0;
+    S.lane = slot & 63u;
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
     const uint32_t g = ids ? ids[slot] : slot;
     emit_lean<EMIT_LEAN_G>(us, cfg, S, r, r.abase + blocks[slot / SCAN_SL].v[2], gflags[g], slot, g, k, D, H, gl);
 }
@@ -565,7 +571,7 @@ __global__ void __launch_bounds__(256) k_wire_sum(uint8_t* wire, uint64_t cap)
 }
 
 /* contig-graph walk of the multi-contig gaps of a chunk (mtg_paths.h), one wave per gap */
-__global__ void __launch_bounds__(64) k_paths(FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ slots, int k, uint32_t* out, uint32_t n)
+__global__ void __launch_bounds__(64) k_paths(FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, const uint32_t* __restrict__ slots, int k, uint32_t* out, uint32_t n)
 {
     __shared__ PathsWork W;
     if (blockIdx.x >= n) return;
@@ -573,14 +579,15 @@ __global__ void __launch_bounds__(64) k_paths(FillCfg cfg, uint8_t* raw, const G
     GapScratch S;
     S.z = nullptr;
     S.v = nullptr;
-    S.lane = 0;
+    S.lane = slot & 63u;
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
     paths_gap(cfg, S, outs[slot], k, W, out + (uint64_t)blockIdx.x * PATHS_WORDS);
 }
 
 /* the multi-contig gaps of a launch on the device (mtg_general.h), one wave per gap of the launch's list: paths -> candidate sequences ->
  * de-duplication -> coverage, quality, ASCII.  slots = the list k_emit made (general_list); paths = k_paths' blocks in the same order. */
-__global__ void __launch_bounds__(64) k_general(Index ix, FillCfg cfg, uint8_t* raw, const GapOut* __restrict__ outs, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(64) k_general(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ ids,
                                                 const uint32_t* __restrict__ paths, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok, const uint64_t* __restrict__ src,
                                                 const uint8_t* __restrict__ gflags, int k, GenDev D, uint32_t n)
 {
@@ -591,8 +598,9 @@ __global__ void __launch_bounds__(64) k_general(Index ix, FillCfg cfg, uint8_t* 
     GapScratch S;
     S.z = nullptr;
     S.v = nullptr;
-    S.lane = 0;
+    S.lane = slot & 63u;
     S.r = raw + (uint64_t)slot * cfg.raw_stride;
+    S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
     gen_gap(ix, cfg, S, outs[slot], k, paths + (uint64_t)blockIdx.x * PATHS_WORDS, tcnt[g], fast_ok[g] != 0, src[g], gflags[g], D, blockIdx.x, W);
 }
 
@@ -681,7 +689,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_combo = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf(), d_ggaps = wsbuf(), d_gsols = wsbuf(), d_gascii = wsbuf(), d_gtmp = wsbuf(), d_gbnd = wsbuf();
+          d_dm = wsbuf(), d_combo = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf(), d_ggaps = wsbuf(), d_gsols = wsbuf(), d_gascii = wsbuf(), d_gtmp = wsbuf(), d_gbnd = wsbuf(), d_head = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
@@ -805,12 +813,13 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         const bool no_defer = tune::on(tune::T_NO_DEFER); /* test hook: the lanes of the traversal copy their long runs themselves */
         if (no_defer || !idx->dev.us.nwords) cfg.cmd_cap = 0;
         /* scratch of a gap + worst-case room in the dense arrays (its whole contig arena and the metadata of every contig) */
-        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + sizeof(mtg_gap_result) + sizeof(mtg_filled);
-        const size_t cached = ws.cap[d_zero.slot] + ws.cap[d_raw.slot] + ws.cap[d_ilv.slot]; /* already ours */
+        const uint64_t per_gap = cfg.zero_stride + cfg.raw_stride + cfg.ilv_stride / 64 + cfg.hd_stride / 64 + sizeof(GapOut) + sizeof(SlotRec) + 64 + sizeof(mtg_gap_result) + sizeof(mtg_filled);
+        const size_t cached = ws.cap[d_zero.slot] + ws.cap[d_raw.slot] + ws.cap[d_ilv.slot] + ws.cap[d_head.slot]; /* already ours */
         size_t free_b = 0, total_b = 0;
         /* steady state: every scratch buffer of the workspace already holds a batch of this size at this tier, nothing will be allocated */
         const uint64_t m0 = std::min<uint64_t>(n_todo, 1u << 20);
-        const bool fits = ws.cap[d_zero.slot] >= m0 * cfg.zero_stride && ws.cap[d_raw.slot] >= m0 * cfg.raw_stride + 64 && ws.cap[d_ilv.slot] >= ((m0 + 63) / 64) * cfg.ilv_stride;
+        const bool fits = ws.cap[d_zero.slot] >= m0 * cfg.zero_stride && ws.cap[d_raw.slot] >= m0 * cfg.raw_stride + 64 && ws.cap[d_ilv.slot] >= ((m0 + 63) / 64) * cfg.ilv_stride &&
+                          ws.cap[d_head.slot] >= ((m0 + 63) / 64) * cfg.hd_stride;
         if (!fits) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         size_t chunk = fits ? (size_t)m0 : (size_t)(((double)free_b * 0.6 + (double)cached) / (double)per_gap);
         const size_t env_chunk = (size_t)tune::i(tune::T_MAX_CHUNK, 0); /* test hook: several launches per batch */
@@ -822,6 +831,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         /* zeroed once: every gap restores what it touched (stage_a_gap), so the region stays clean from launch to launch */
         if (d_zero.fresh) HIP_TRY(hipMemsetAsync(d_zero.p, 0, ws.cap[d_zero.slot], stream));
         HIP_TRY(d_raw.alloc(chunk * cfg.raw_stride + 64));
+        HIP_TRY(d_head.alloc(((chunk + 63) / 64) * cfg.hd_stride));
         HIP_TRY(d_ilv.alloc(((chunk + 63) / 64) * cfg.ilv_stride));
         HIP_TRY(d_out.alloc(chunk * sizeof(GapOut)));
         HIP_TRY(d_rec.alloc(chunk * sizeof(SlotRec)));
@@ -903,7 +913,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
             {
-                hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
                                    d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
                 HIP_TRY(mark(evf));
                 const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
@@ -912,8 +922,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                  * k_bubble<G> here: 20-22 against 25 M/s on the indel set, 51 against 63 on tips; removed in round 5) */
                 for (int r = 0; r < rounds; r++) {
                     const uint32_t lin = 2u * (uint32_t)r;
-                    hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), cset, park, m, lin);
-                    hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_src, d_rw, d_roff,
+                    hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), cset, park, m, lin);
+                    hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
                                        d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
                 }
                 const uint32_t lfin = 2u * (uint32_t)rounds;
@@ -936,12 +946,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (uint32_t)std::min<uint64_t>(m, ((4ull * park_hint + 256ull + per_wg - 1) / per_wg) * per_wg);
                 const uint32_t nwg = (fin_entries + per_wg - 1) / per_wg;
                 if (!skip_finish && nwg) switch (fin_g) {
-                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
-                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
-                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
                 }
                 if (!skip_finish && fin_entries < m)
-                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries);
+                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries);
 #ifdef MTG_BUBBLE_TIMING
                 {
                     static ParkCtl hc; static int shown = 0;
@@ -961,10 +971,10 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipGetLastError());
             /* evl0 .. evc: the long runs of the contigs, which the traversal only noted down */
             const bool no_lean = tune::on(tune::T_NO_LEAN); /* A/B and test hook: every contig is materialised */
-            hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
+            hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
                                (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m, park, m);
             HIP_TRY(mark(evl)); /* ev1 .. evl: k_lean; evl .. evc: k_copy */
-            hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), park, m, (uint32_t)COPY_LIST);
+            hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), park, m, (uint32_t)COPY_LIST);
             HIP_TRY(mark(evc));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
             /* the lean gaps eight per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
@@ -973,9 +983,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* The general form is the latency of a few long gaps (30 us for the one or two of a haploid batch), the lean form the throughput of all
              * the others.  Both on the batch's one stream: the general form next to the lean one on a second stream, and the finishing kernel there as
              * well, were built and measured in round 4 (9 and 25 us shorter for one batch alone, no faster with six in flight) and removed in round 5. */
-            hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
+            hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
                                in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park);
-            hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
+            hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
             /* the dense arrays hold one launch at a time; the two arenas the whole batch */
             const ScanBegin sbegin{{0, 0, arena_used[0], arena_used[1]}};
             hipLaunchKernelGGL(k_scan1, dim3(nblocks), dim3(SCAN_SL), 0, stream, d_rec.as<SlotRec>(), m, d_blocks.as<ScanBlock>());
@@ -995,9 +1005,9 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 if (want_wire) HIP_TRY(hipMemsetAsync(sink.wire_dev, 0, sizeof(mtg_wire_header), stream)); /* no header, no payload (k_wire_sum) */
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
                 if (!want_wire)
-                    hipLaunchKernelGGL(k_emit_lean, dim3((m + 64 / EMIT_LEAN_G - 1) / (64 / EMIT_LEAN_G)), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(),
+                    hipLaunchKernelGGL(k_emit_lean, dim3((m + 64 / EMIT_LEAN_G - 1) / (64 / EMIT_LEAN_G)), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(),
                                        ids, d_flags, k, D, H, m);
-                hipLaunchKernelGGL(k_emit, dim3(want_wire ? m : general_hint), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H,
+                hipLaunchKernelGGL(k_emit, dim3(want_wire ? m : general_hint), dim3(64), 0, stream, idx->dev.us, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_rec.as<SlotRec>(), d_blocks.as<ScanBlock>(), ids, d_flags, k, D, H,
                                    d_rlist.as<uint32_t>(), d_glist.as<uint32_t>(), m, park, want_wire ? 0u : 1u);
                 if (want_wire) hipLaunchKernelGGL(k_wire_sum, dim3(256 * 4), dim3(256), 0, stream, (uint8_t*)sink.wire_dev, sink.wire_cap);
                 HIP_TRY(hipGetLastError());
@@ -1099,8 +1109,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 GD.gaps = (GenGap*)((char*)d_ggaps.p + sizeof(GenCtl));
                 GD.sols = d_gsols.as<GenSol>(); GD.ascii = d_gascii.as<char>(); GD.tmp = d_gtmp.as<uint64_t>(); GD.bnd = d_gbnd.as<NwCell>();
                 HIP_TRY(hipMemsetAsync(GD.ctl, 0, sizeof(GenCtl), stream));
-                hipLaunchKernelGGL(k_paths, dim3((unsigned)ng), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_glist.as<uint32_t>(), k, d_paths.as<uint32_t>(), (uint32_t)ng);
-                hipLaunchKernelGGL(k_general, dim3((unsigned)ng), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_glist.as<uint32_t>(), ids, d_paths.as<uint32_t>(),
+                hipLaunchKernelGGL(k_paths, dim3((unsigned)ng), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), d_glist.as<uint32_t>(), k, d_paths.as<uint32_t>(), (uint32_t)ng);
+                hipLaunchKernelGGL(k_general, dim3((unsigned)ng), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), d_glist.as<uint32_t>(), ids, d_paths.as<uint32_t>(),
                                    d_tcnt, d_fok, d_src, d_flags, k, GD, (uint32_t)ng);
                 HIP_TRY(hipGetLastError());
                 h_gctl = (GenCtl*)staging_host(&ws, Workspace::NHOST - 2, sizeof(GenCtl) + ng * sizeof(GenGap) + 64);
@@ -1200,7 +1210,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     HIP_TRY(d_ids.alloc(std::max<size_t>(chunk, pslots.size()) * 4)); /* the traversal is over: its slot map is free */
                     HIP_TRY(hipMemcpyAsync(d_ids.p, pslots.data(), pslots.size() * 4, hipMemcpyHostToDevice, stream));
                     HIP_TRY(d_paths.alloc(pslots.size() * (size_t)PATHS_WORDS * 4));
-                    hipLaunchKernelGGL(k_paths, dim3((unsigned)pslots.size()), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_out.as<GapOut>(), d_ids.as<uint32_t>(), k,
+                    hipLaunchKernelGGL(k_paths, dim3((unsigned)pslots.size()), dim3(64), 0, stream, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), d_ids.as<uint32_t>(), k,
                                        d_paths.as<uint32_t>(), (uint32_t)pslots.size());
                     HIP_TRY(hipGetLastError());
                     hc->paths.resize(pslots.size() * (size_t)PATHS_WORDS);

@@ -42,10 +42,10 @@ MTG_DEV void paths_gap(const FillCfg& cfg, const GapScratch& S, const GapOut& o,
     const uint32_t lane = MTG_LANE();
     const uint32_t n = o.n_contigs;
     const uint64_t* words = s_words(cfg, S);
-    const uint32_t* cstart = s_cstart(cfg, S);
-    const uint32_t* clen = s_clen(cfg, S);
-    const uint32_t* tpos = s_tpos(cfg, S);
-    const uint32_t* ttgt = s_ttgt(cfg, S);
+    const SP<uint32_t> cstart = s_cstart(cfg, S);
+    const SP<uint32_t> clen = s_clen(cfg, S);
+    const SP<uint32_t> tpos = s_tpos(cfg, S);
+    const SP<uint32_t> ttgt = s_ttgt(cfg, S);
     if (n == 0 || n > PATHS_MAXN) {
         if (lane == 0) { out[0] = 1; out[1] = 0; }
         return;

@@ -169,11 +169,11 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     const uint64_t lsb = 0x5555555555555555ULL & mk;
     const uint32_t lane = MTG_LANE();
     const uint64_t* words = s_words(cfg, S);
-    const uint32_t* cstart = s_cstart(cfg, S);
-    const uint32_t* clen = s_clen(cfg, S);
-    uint32_t* tpos = s_tpos(cfg, S);
-    uint32_t* terr = s_terr(cfg, S);
-    uint32_t* ttgt = s_ttgt(cfg, S);
+    const SP<uint32_t> cstart = s_cstart(cfg, S);
+    const SP<uint32_t> clen = s_clen(cfg, S);
+    const SP<uint32_t> tpos = s_tpos(cfg, S);
+    const SP<uint32_t> terr = s_terr(cfg, S);
+    const SP<uint32_t> ttgt = s_ttgt(cfg, S);
     const uint64_t ORD = (1ull << 40) - 1;
     uint32_t nterm = 0;
     uint32_t pos0 = 0, err0 = 0, tgt0 = 0;
@@ -184,7 +184,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
     const uint64_t le0 = T.n ? T.le[0] : 0ull, bad0 = T.n ? T.bad[0] : ~0ull;
     const bool single = T.n == 1;
     /* the lean form (mtg_copy.h): the target's place in the only contig is known, the contig itself was not materialised */
-    const LeanRec lean = *s_lean(cfg, S);
+    const LeanRec lean = s_lean(cfg, S)[0];
     out.lean = 0;
     if (lean.valid) {
 #ifdef MTG_XCHECK /* TEST-ONLY: the search the lean form replaces finds the same place (the emulation build has copied the contig) */
@@ -297,7 +297,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
      * then sit at known places of the store, their abundance bytes next to them: no look-up, nothing to verify. */
     int direct = -1;
     if (ix.us.nwords != 0 && !(dbg & 1u)) {
-        const CopyCmd* cmds = s_cmd(cfg, S);
+        const SP<CopyCmd> cmds = s_cmd(cfg, S);
         const uint64_t a_lo = 32ull * cstart[0], a_hi = a_lo + pos0;
         for (uint32_t c = 0; c < o.n_cmds; c++) {
             const uint64_t lo = 32ull * cmds[c].dst - cmds[c].lead, hi = 32ull * ((uint64_t)cmds[c].dst + cmds[c].nwords);
@@ -427,7 +427,7 @@ MTG_UNROLL
 struct LeanWork { uint32_t pos0, cmd, clen0, nk, sum; };
 template <uint32_t GW> MTG_DEV bool post_lean_accumulate(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint32_t gl, uint32_t* hist, LeanWork& w)
 {
-    const LeanRec lean = *s_lean(cfg, S);
+    const LeanRec lean = s_lean(cfg, S)[0];
     if (o.status != GAP_OK || !lean.valid) return false;
     const uint32_t k = (uint32_t)ix.k;
     const CopyCmd cm = s_cmd(cfg, S)[lean.cmd];

@@ -52,6 +52,7 @@ struct FillCfg {
     uint64_t zero_stride; /* bytes per gap in the zero-initialised region */
     uint64_t raw_stride;  /* bytes per gap in the raw region */
     uint64_t ilv_stride;  /* bytes per WAVE (64 gaps) in the lane-interleaved region */
+    uint64_t hd_stride;   /* bytes per 64 gaps in the region of the small per-gap arrays (interleaved over the 64 gaps) */
     /* byte offsets of the per-gap arrays (filled by finalize_cfg) */
     uint32_t z_seen, z_iseen;
     uint32_t o_cstart, o_clen, o_qf, o_qc, o_qd, o_marklog, o_seenlog, o_iseenlog, o_inv, o_fl0, o_fl1, o_ifl0, o_ifl1, o_flnt0, o_flnt1, o_flaux0, o_flaux1, o_dfsf, o_dfsc,
@@ -66,6 +67,10 @@ struct GapScratch {
     uint8_t* r; /* raw, contiguous per gap: contigs, queue, terminal info (read by k_post / k_compact / the host) */
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
+    uint8_t* h; /* the small per-gap arrays every kernel of a launch reads or writes -- contig starts / lengths / terminal info, the queue, the copy
+                   commands, the lean record --, interleaved over 64 consecutive gaps like v: with a gap per lane (the walk, k_lean) or a few lanes per gap
+                   (k_post_lean, k_emit_lean) neighbouring lanes touch neighbouring bytes, and a write of element 0 by the 64 lanes of a wave fills whole
+                   memory lines (contiguous per gap, every such write dirtied a line of its own: 620 bytes written per gap for some 100 of content) */
     uint32_t lane;
     uint32_t snp_fast; /* 1: the SNP fast path may be used */
     MTG_LDS uint8_t* fp; /* TEST-ONLY emulation: a fingerprint table (FP_SLOTS slots for each of 64 lanes, see fp_at) for the cross-check of the fast path's distinctness test */
@@ -79,17 +84,19 @@ template <typename T> struct SP {
 };
 #define MTG_ILV(T, name, off) \
     MTG_DEV SP<T> name(const FillCfg& c, const GapScratch& S) { SP<T> r; r.p = reinterpret_cast<T*>(S.v + (uint64_t)(off) * 64) + S.lane; return r; }
+#define MTG_HIL(T, name, off) \
+    MTG_DEV SP<T> name(const FillCfg& c, const GapScratch& S) { SP<T> r; r.p = reinterpret_cast<T*>(S.h + (uint64_t)(off) * 64) + S.lane; return r; }
 #define MTG_ARR(T, name, base, off) \
     MTG_DEV T* name(const FillCfg& c, const GapScratch& S) { return reinterpret_cast<T*>(S.base + (off)); }
 MTG_ARR(uint64_t, s_marked, z, 0)
 MTG_ARR(uint64_t, s_seen, z, c.z_seen)
 MTG_ARR(uint64_t, s_iseen, z, c.z_iseen)
 MTG_ARR(uint64_t, s_words, r, 0)             /* contig arena */
-MTG_ARR(uint32_t, s_cstart, r, c.o_cstart)   /* first word of contig i */
-MTG_ARR(uint32_t, s_clen, r, c.o_clen)       /* length in nt */
-MTG_ARR(uint64_t, s_qf, r, c.o_qf)           /* BFS queue: oriented k-mer */
-MTG_ARR(uint64_t, s_qc, r, c.o_qc)           /*   canonical k-mer (doubles as already_extended_from) */
-MTG_ARR(int32_t, s_qd, r, c.o_qd)
+MTG_HIL(uint32_t, s_cstart, c.o_cstart)   /* first word of contig i */
+MTG_HIL(uint32_t, s_clen, c.o_clen)       /* length in nt */
+MTG_HIL(uint64_t, s_qf, c.o_qf)           /* BFS queue: oriented k-mer */
+MTG_HIL(uint64_t, s_qc, c.o_qc)           /*   canonical k-mer (doubles as already_extended_from) */
+MTG_HIL(int32_t, s_qd, c.o_qd)
 /* A deferred copy: nwords whole words of the gap's contig arena, from word dst on, are the 32 * nwords nucleotides of the unitig store that
  * start at position src >> 1 and run forward (bit 0 clear) or backward, complemented (bit 0 set).  Written by the traversal instead of the
  * nucleotides themselves, executed by copy_gap (mtg_copy.h) with all lanes of a wave before anything reads the contigs. */
@@ -102,7 +109,7 @@ struct CopyCmd {
     uint32_t pad_;
 };
 enum { COPY_CMDS = 32 };
-MTG_ARR(CopyCmd, s_cmd, r, c.o_cmd)
+MTG_HIL(CopyCmd, s_cmd, c.o_cmd)
 /* a walk interrupted at a branching node (GAP_PARKED): everything stage_a_gap needs to go on from there, whoever resumes it.  The contigs
  * built so far, the queue and the copy commands are in the gap's raw block, the marked set in its zero block. */
 struct WalkSave {
@@ -123,7 +130,7 @@ struct LeanRec {
     uint32_t cmd;   /* the copy command that describes the run */
     uint32_t pad_;
 };
-MTG_ARR(LeanRec, s_lean, r, c.o_lean)
+MTG_HIL(LeanRec, s_lean, c.o_lean)
 MTG_ILV(uint32_t, s_marklog, c.o_marklog) /* slots used in marked[] */
 MTG_ILV(uint32_t, s_seenlog, c.o_seenlog) /* slots touched in seen[] */
 MTG_ILV(uint32_t, s_iseenlog, c.o_iseenlog)
@@ -156,9 +163,9 @@ MTG_ILV(uint32_t, s_dfskid, c.o_dfskid)   /* node_aux of the children of a frame
 MTG_ILV(uint8_t, s_cons, c.o_cons)        /* CONS_CAP x CONS_LEN nts */
 MTG_ILV(uint16_t, s_conslen, c.o_conslen)
 MTG_ILV(int32_t, s_nw, c.o_nw)            /* 4 rows x (CONS_LEN+1) */
-MTG_ARR(uint32_t, s_tpos, r, c.o_tpos)       /* per contig: position of the best target match (0xFFFFFFFF: none) */
-MTG_ARR(uint32_t, s_terr, r, c.o_terr)       /*             mismatches in the anchor */
-MTG_ARR(uint32_t, s_ttgt, r, c.o_ttgt)       /*             index of the target */
+MTG_HIL(uint32_t, s_tpos, c.o_tpos)       /* per contig: position of the best target match (0xFFFFFFFF: none) */
+MTG_HIL(uint32_t, s_terr, c.o_terr)       /*             mismatches in the anchor */
+MTG_HIL(uint32_t, s_ttgt, c.o_ttgt)       /*             index of the target */
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
@@ -168,9 +175,15 @@ inline void finalize_cfg(FillCfg& c)
     c.z_seen = 8u * c.mcap;
     c.z_iseen = c.z_seen + 8u * c.seen_cap;
     c.zero_stride = align_up((uint64_t)c.z_iseen + 8ull * c.iseen_cap, 64);
-    /* contiguous per gap */
+    /* contiguous per gap: the contig arena, the state of a parked walk */
     uint64_t b = 8ull * c.cap_words;
+    b = align_up(b, 16);
+    c.o_save = (uint32_t)b; b += (uint64_t)sizeof(WalkSave);
+    c.raw_stride = align_up(b + 8, 64);
+    /* interleaved over 64 gaps: byte offsets within one gap's share (every array starts 8-byte aligned) */
+    b = 0;
     c.o_cstart = (uint32_t)b; b += 4ull * c.cap_contigs;
+    b = align_up(b, 8);
     c.o_clen = (uint32_t)b; b += 4ull * c.cap_contigs;
     c.o_tpos = (uint32_t)b; b += 4ull * c.cap_contigs;
     c.o_terr = (uint32_t)b; b += 4ull * c.cap_contigs;
@@ -179,12 +192,10 @@ inline void finalize_cfg(FillCfg& c)
     c.o_qf = (uint32_t)b; b += 8ull * c.qcap;
     c.o_qc = (uint32_t)b; b += 8ull * c.qcap;
     c.o_qd = (uint32_t)b; b += 4ull * c.qcap;
-    b = align_up(b, 16);
+    b = align_up(b, 8);
     c.o_cmd = (uint32_t)b; b += (uint64_t)sizeof(CopyCmd) * COPY_CMDS; /* the room is there whether or not cmd_cap lets it be used */
-    b = align_up(b, 16);
-    c.o_save = (uint32_t)b; b += (uint64_t)sizeof(WalkSave);
     c.o_lean = (uint32_t)b; b += 16;
-    c.raw_stride = align_up(b + 8, 64);
+    c.hd_stride = align_up(b, 8) * 64;
     /* interleaved per wave: byte offsets within one lane's share (every array starts 8-byte aligned) */
     b = 0;
     c.o_marklog = (uint32_t)b; b += align_up(4ull * c.mcap, 8);
@@ -223,12 +234,13 @@ inline void finalize_cfg(FillCfg& c)
     c.ilv_stride = align_up(b, 8) * 64;
 }
 
-MTG_DEV GapScratch carve(const FillCfg& c, uint8_t* zero_base, uint8_t* raw_base, uint8_t* ilv_base, uint64_t gap)
+MTG_DEV GapScratch carve(const FillCfg& c, uint8_t* zero_base, uint8_t* raw_base, uint8_t* ilv_base, uint8_t* head_base, uint64_t gap)
 {
     GapScratch S;
     S.z = zero_base + gap * c.zero_stride;
     S.r = raw_base + gap * c.raw_stride;
     S.v = ilv_base + (gap >> 6) * c.ilv_stride;
+    S.h = head_base + (gap >> 6) * c.hd_stride;
     S.lane = (uint32_t)(gap & 63);
     S.fp = nullptr;
     S.snp_fast = 0;
@@ -1991,9 +2003,9 @@ MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch&
     const uint32_t MAXLEN = 10u * 1000 * 1000;
     const Table adj = ix.adj; /* local copy: the hot loop must not reload the table shape through the Worker */
     const bool r_is_kmer = (R.rlen == (uint32_t)k);
-    uint64_t* q_f = s_qf(cfg, S);
-    uint64_t* q_c = s_qc(cfg, S);
-    int32_t* q_d = s_qd(cfg, S);
+    const SP<uint64_t> q_f = s_qf(cfg, S);
+    const SP<uint64_t> q_c = s_qc(cfg, S);
+    const SP<int32_t> q_d = s_qd(cfg, S);
 
     /* contig writer and hot counters live in registers: the Worker's address escapes to the noinline bubble code, so its fields are
      * memory-resident and must stay out of the per-nucleotide path */
@@ -2056,7 +2068,7 @@ MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch&
     uint32_t store_reads = 0, run_nt = 0;
     /* long runs are not copied by the lane but left as commands for copy_gap -- unless the pattern is searched in the contigs right here
      * (contig mode: contig_contains reads them) or the launch has no copy pass */
-    CopyCmd* const cmds = s_cmd(cfg, S);
+    const SP<CopyCmd> cmds = s_cmd(cfg, S);
     const bool defer = r_is_kmer && cfg.cmd_cap != 0;
     uint32_t ncmd = 0, copy_words = 0;
     /* index, in its unitig, of the k-mer the walk stands on while a run lasts (the run's next nucleotide extends that k-mer) */

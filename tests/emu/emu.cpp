@@ -105,8 +105,8 @@ char* emu_stage_a(void* p, int max_nodes, int max_depth, int end_rule, const cha
     for (int t = t0; t <= t1; t++) {
         FillCfg cfg = make_cfg(k, max_nodes, max_depth, end_rule, t);
         if (getenv("MTG_NO_DEFER") || !e->ix.us.nwords) cfg.cmd_cap = 0;
-        std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0xCD), ilv(cfg.ilv_stride);
-        GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
+        std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0xCD), ilv(cfg.ilv_stride), head(cfg.hd_stride, 0xCD);
+        GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), head.data(), 0);
         std::vector<uint8_t> fp_table(FP_SLOTS * 64);
         S.fp = fp_table.data();
         S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
@@ -171,8 +171,8 @@ extern "C" uint64_t emu_bucket_first_sweep(uint64_t nb, uint32_t key_bits, uint6
 extern "C" int emu_nw_matches(const char* a, const char* b)
 {
     FillCfg cfg = make_cfg(31, 100, 10000, 0, 0);
-    std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0), ilv(cfg.ilv_stride, 0);
-    GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), 0);
+    std::vector<uint8_t> zero(cfg.zero_stride, 0), raw(cfg.raw_stride, 0), ilv(cfg.ilv_stride, 0), head(cfg.hd_stride, 0);
+    GapScratch S = carve(cfg, zero.data(), raw.data(), ilv.data(), head.data(), 0);
     Index ix{};
     ix.k = 31;
     Worker W(ix, cfg, S);

@@ -19,6 +19,15 @@
 using namespace mtg;
 
 namespace mtgi {
+/* the scratch of slot s of a launch: zero and work regions shared by the slots (one gap at a time), a raw block of its own, its place in the
+ * launch's interleaved region of small arrays */
+static GapScratch carve_slot(const FillCfg& cfg, uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* heads, uint32_t s)
+{
+    GapScratch S = carve(cfg, zero, raw, ilv, heads, 0);
+    S.h = heads + (uint64_t)(s >> 6) * cfg.hd_stride;
+    S.lane = s & 63u;
+    return S;
+}
 static thread_local char g_err[512] = "";
 static thread_local mtg_batch_stats g_stats{};
 void set_error(const char* fmt, ...)
@@ -441,6 +450,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             static thread_local std::vector<uint8_t> raw_arena; /* kept between launches: a fresh allocation per slot spends its time in page faults */
             const size_t raw_each = ((size_t)cfg.raw_stride + 64 + 63) & ~(size_t)63;
             if (raw_arena.size() < raw_each * m) raw_arena.resize(raw_each * m);
+            /* the small per-gap arrays, interleaved over 64 slots as on the device */
+            static thread_local std::vector<uint8_t> head_arena;
+            const size_t head_bytes = (size_t)((m + 63) / 64) * cfg.hd_stride;
+            if (head_arena.size() < head_bytes) head_arena.resize(head_bytes);
+            if (poison) memset(head_arena.data(), 0xCD, head_bytes);
+            uint8_t* const heads = head_arena.data();
             std::vector<SlotRec> recs(m);
             for (uint32_t s = 0; s < m; s++) {
                 const size_t g = ids[s];
@@ -449,7 +464,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
 #ifdef MTG_XCHECK
                 memset(fp_table.data(), 0, fp_table.size());
 #endif
-                GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
+                GapScratch S = carve_slot(cfg, zero.data(), raws[s].data(), ilv.data(), heads, s);
                 S.fp = fp_table.data();
                 S.snp_fast = getenv("MTG_NO_SNP_FAST") ? 0 : 1;
                 SwfPattern R;
@@ -557,7 +572,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 if (want_wire) memset(sink.wire_dev, 0, sizeof(mtg_wire_header));
                 H.seq = sink.seq; H.ext = sink.ext; H.fil = sink.fil;
                 for (uint32_t s = 0; s < m; s++) {
-                    GapScratch S = carve(cfg, zero.data(), raws[s].data(), ilv.data(), 0);
+                    GapScratch S = carve_slot(cfg, zero.data(), raws[s].data(), ilv.data(), heads, s);
                     emit_gap(idx->dev.us, cfg, S, recs[s], in.flags[ids[s]], s, ids[s], k, D, H);
                     if (emit_is_lean(recs[s], D) && recs[s].asc && recs[s].abase + recs[s].asc <= D.seq_cap) {
                         /* the device's k_emit_lean (mtg_emit.h: emit_lean, a group of lanes per gap, here one) must write the same bytes and records */
@@ -627,7 +642,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     hc->path_of.assign(m, -1);
                     for (size_t g2 = 0; g2 < pslots.size(); g2++) {
                         PathsWork pw;
-                        GapScratch S = carve(cfg, zero.data(), raws[pslots[g2]].data(), ilv.data(), 0);
+                        GapScratch S = carve_slot(cfg, zero.data(), raws[pslots[g2]].data(), ilv.data(), heads, pslots[g2]);
                         paths_gap(cfg, S, recs[pslots[g2]].o, k, pw, hc->paths.data() + g2 * (size_t)PATHS_WORDS);
                         hc->path_of[pslots[g2]] = (int32_t)g2;
                     }
@@ -649,7 +664,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     for (size_t g2 = 0; g2 < ng; g2++) {
                         const uint32_t s2 = glist[g2], gi = ids[s2];
                         GenWork* gw = new GenWork();
-                        GapScratch S = carve(cfg, zero.data(), raws[s2].data(), ilv.data(), 0);
+                        GapScratch S = carve_slot(cfg, zero.data(), raws[s2].data(), ilv.data(), heads, s2);
                         gen_gap(idx->dev, cfg, S, recs[s2].o, k, hc->paths.data() + (size_t)hc->path_of[s2] * PATHS_WORDS, in.tcnt[gi], in.fast_ok[gi] != 0, in.src[gi], in.flags[gi], GD,
                                 (uint32_t)g2, *gw);
                         delete gw;
