@@ -152,7 +152,7 @@ def compact_line(out, detail_path=None):
     line["roofline"] = {
         "bound": "hbm", "kernel": dom.get("kernel"), "achieved": _num(dom.get("achieved")), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _num(dom.get("frac")),
         "bytes_per_launch": _num(dom.get("bytes_per_launch"), 6), "bytes_are": "what the implemented layout must move per launch (counters of the timed launches)",
-        "avg_kernel_ms": _num(dom.get("avg_kernel_ms")), "traffic": _num(dom.get("traffic"), 6), "traffic_over_bytes": _num(dom.get("traffic_over_bytes")),
+        "avg_kernel_ms": _num(dom.get("avg_kernel_ms")), "traffic": _num(dom.get("traffic"), 6), "traffic_over_bytes": _num(dom.get("traffic_over_bytes")), "traffic_over_request_bytes": _num(dom.get("traffic_over_request_bytes")),
         "traffic_is": "replayed from profiles/ (PMC FETCH_SIZE + WRITE_SIZE of this command)" if dom.get("traffic") else None,
         "dominant_kernel": roof.get("dominant_kernel"), "dominant_kernel_frac": _num(roof.get("dominant_kernel_frac_of_hbm_peak")),
         "walk_kernel": wall.get("kernel"), "walk_kernel_frac": _num(wall.get("frac")), "walk_kernel_ms": _num(wall.get("avg_kernel_ms")),
@@ -948,6 +948,10 @@ def main():
             tv = sum(v for kn, v in by_kernel.items() if v and (kn == tk or (tk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (tk == "k_emit" and kn == "k_emit_lean") or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble")))))
             kr["traffic"] = tv or None
             kr["traffic_over_bytes"] = (tv / kr["bytes_per_launch"]) if tv and kr["bytes_per_launch"] else None
+            # the fabric serves (and FETCH_SIZE counts) a scattered read as a 64-byte request: the same layout with every bucket read at 64 B
+            rb = kr["bytes_per_launch"] + sum(v for pk, v in kr["bytes_breakdown"].items() if "bucket" in pk and pk.endswith("x_32B"))
+            kr["bytes_per_launch_at_64B_requests"] = rb
+            kr["traffic_over_request_bytes"] = (tv / rb) if tv and rb else None
     # what the reference's algorithm would have moved for the same contigs (64 B per membership probe, probes counted by the oracle):
     # kept for comparison only -- the unitig layout reads one bucket and one stretch of 2-bit sequence where gatb probes 8 Bloom blocks per nucleotide.
     # That work has not vanished: it is done ONCE, when the index is built (index_build below carries its clock and its roofline).

@@ -8,8 +8,11 @@
  *     (nw_wave: the sweep of k_nw, here on 2-bit sequences);
  *   - coverage of source + sequence (src/Filler.cpp:959-988): abundance of every k-mer, float mean, exact median; compute_qual
  *     (src/Utils.hpp:85-103); the reverse complement of a reverse attempt (:78-83); the solutions' ASCII.
- * What stays on the host: gaps whose dictionary has several targets (contig mode: the order of the groups is libstdc++'s hash order of the
- * target NAMES), gaps k_paths could not enumerate, a source that is not k clean nucleotides, a k-mer of abundance 0 (the host
+ * A dictionary with several targets (contig mode): the reference groups the paths by target NAME and works through the groups in libstdc++'s hash
+ * order of those names.  The device groups by target (in the order of first appearance in the sorted paths = the order the reference
+ * inserts the names), answers every group, and says which target each group belongs to (a header record before the group's solutions); the host,
+ * which has the names, puts the groups in the map's order (mtg_host.cpp: run_general).
+ * What stays on the host: gaps k_paths could not enumerate, a source that is not k clean nucleotides, a k-mer of abundance 0 (the host
  * prints the reference's warning), and whatever does not fit the work areas: such a gap says so (GenGap::status) and the host's path, which
  * is also the specification the TEST-ONLY emulation checks every device answer against, takes it.
  * Compiled for gfx950 and, TEST-ONLY, for tests/emu (one lane).
@@ -34,9 +37,12 @@ struct GenSol {
     float avg, median;
 };
 struct GenGap {
-    uint32_t status;   /* GEN_OK: sols[first_sol .. first_sol + n_sols) are the gap's solutions; GEN_HOST: the host's path takes the gap */
+    uint32_t status;   /* GEN_OK: sols[first_sol .. first_sol + n_sols) are the gap's records; GEN_HOST: the host's path takes the gap */
     uint32_t n_sols, first_sol;
     uint32_t nb_total_filled; /* candidates before the de-duplication (info.txt) */
+    uint32_t n_groups; /* 1: the records are the solutions.  > 1 (several targets reached): every group is a header record (rank 0, target = the group's
+                          target, count = its solutions) followed by its solutions, groups in the order the reference inserts their names */
+    uint32_t pad_;
 };
 /* cursors of a launch (the host reads them back) */
 struct GenCtl {
@@ -63,6 +69,10 @@ struct GenWork {
     uint32_t f_src[GEN_MAX_CAND];         /* kept solutions: whose sequence, with whose errors, for which target */
     int32_t f_err[GEN_MAX_CAND];
     uint32_t f_tgt[GEN_MAX_CAND];
+    uint32_t p_grp[GEN_MAX_CAND];         /* group of sorted path i */
+    uint32_t g_tgt[GEN_MAX_CAND];         /* groups: target, first candidate (one more entry: the end), kept solutions */
+    uint32_t g_c0[GEN_MAX_CAND + 1];
+    uint32_t g_f0[GEN_MAX_CAND + 1];
     uint32_t scal[8];                     /* lane 0's verdicts, read by all */
 };
 
@@ -210,13 +220,13 @@ MTG_DEV uint32_t gen_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
     const SP<uint32_t> ttgt = s_ttgt(cfg, S);
     const uint32_t K = (uint32_t)k;
     GenGap out;
-    out.status = GEN_HOST; out.n_sols = 0; out.first_sol = 0; out.nb_total_filled = 0;
+    out.status = GEN_HOST; out.n_sols = 0; out.first_sol = 0; out.nb_total_filled = 0; out.n_groups = 1; out.pad_ = 0;
     auto leave = [&](uint32_t status) -> uint32_t {
         out.status = status;
         if (lane == 0) D.gaps[rank] = out;
         return status;
     };
-    if (n_targets != 1 || !source_ok || paths[0] != 0 || paths[1] > GEN_MAX_CAND || o.n_contigs == 0) return leave(GEN_HOST);
+    if (n_targets == 0 || !source_ok || paths[0] != 0 || paths[1] > GEN_MAX_CAND || o.n_contigs == 0) return leave(GEN_HOST);
     const uint32_t np0 = paths[1];
     /* the set of paths: sorted by their node vectors, equal ones once (lane 0; a handful of short vectors) */
     if (lane == 0) {
@@ -239,12 +249,25 @@ MTG_DEV uint32_t gen_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             q += 2 + len;
         }
         W.scal[0] = n;
+        /* the groups: paths of one target (paths_to_compare[name], src/Filler.cpp:924-936), numbered in the order of first appearance */
+        uint32_t ng = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t t = paths[W.p_off[i]];
+            uint32_t g = 0;
+            while (g < ng && W.g_tgt[g] != t) g++;
+            if (g == ng) W.g_tgt[ng++] = t;
+            W.p_grp[i] = g;
+        }
+        W.scal[5] = ng;
     }
     wave_sync();
-    const uint32_t np = W.scal[0];
+    const uint32_t np = W.scal[0], n_groups = W.scal[5];
     /* paths_to_sequences: every path's sequence, built in LDS, kept (2-bit) in the launch's arena of candidates */
     uint32_t nc = 0;
+    for (uint32_t grp = 0; grp < n_groups; grp++) {
+    if (lane == 0) W.g_c0[grp] = nc;
     for (uint32_t pi = 0; pi < np; pi++) {
+        if (W.p_grp[pi] != grp) continue;
         const uint32_t q = W.p_off[pi], plen = paths[q + 1];
         for (uint32_t w = lane; w < GEN_SEQ_WORDS + 2; w += MTG_NLANES) W.seq[w] = 0;
         wave_sync();
@@ -294,24 +317,28 @@ MTG_DEV uint32_t gen_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         nc++;
         wave_sync();
     }
+    }
+    if (lane == 0) W.g_c0[n_groups] = nc;
+    wave_sync();
     out.nb_total_filled = nc;
-    if (nc == 0) { out.n_sols = 0; return leave(GEN_OK); }
+    out.n_groups = n_groups;
+    if (nc == 0) { out.n_sols = 0; out.n_groups = 1; return leave(GEN_OK); } /* nothing to order */
 #ifndef MTG_EMU
     __threadfence_block(); /* the candidates are read back from the arena below */
 #endif
-    /* remove_almost_identical_solutions(.., 90) */
+    /* remove_almost_identical_solutions(.., 90), group by group: a group's kept solutions are f_src[g_f0[g] .. g_f0[g + 1]) */
     uint32_t nf = 0;
-    if (nc == 1) {
-        if (lane == 0) { W.f_src[0] = 0; W.f_err[0] = W.c_err[0]; W.f_tgt[0] = W.c_tgt[0]; }
-        nf = 1;
-        wave_sync();
-    } else {
-        if (lane == 0) { W.f_src[0] = 0; W.f_err[0] = W.c_err[0]; W.f_tgt[0] = W.c_tgt[0]; }
-        nf = 1;
-        wave_sync();
-        for (uint32_t j = 0; j < nc; j++) {
+    for (uint32_t grp = 0; grp < n_groups; grp++) {
+        const uint32_t c0 = W.g_c0[grp], c1 = W.g_c0[grp + 1], f0 = nf;
+        if (lane == 0) W.g_f0[grp] = f0;
+        if (c1 > c0) {
+            if (lane == 0) { W.f_src[nf] = c0; W.f_err[nf] = W.c_err[c0]; W.f_tgt[nf] = W.c_tgt[c0]; }
+            nf++;
+            wave_sync();
+        }
+        for (uint32_t j = c0; j < c1 && c1 - c0 > 1u; j++) {
             bool similar = false;
-            for (uint32_t f = 0; f < nf; f++) {
+            for (uint32_t f = f0; f < nf; f++) {
                 const uint32_t i = W.f_src[f];
                 bool same = i == j;
                 if (!same) {
@@ -347,21 +374,33 @@ MTG_DEV uint32_t gen_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
             }
         }
     }
+    if (lane == 0) W.g_f0[n_groups] = nf;
+    wave_sync();
     /* the kept solutions: coverage of source + sequence, quality, ASCII (reverse-complemented for a reverse attempt) */
     unsigned long long ascii_need = 0;
     for (uint32_t f = 0; f < nf; f++) ascii_need += (unsigned long long)W.c_len[W.f_src[f]] + 1u;
+    const uint32_t n_rec = nf + (n_groups > 1u ? n_groups : 0u); /* a header record before every group when there are several */
     if (lane == 0) {
-        const unsigned long long s0 = gen_reserve(&D.ctl->n_sols, nf), a0 = gen_reserve(&D.ctl->ascii_bytes, ascii_need);
+        const unsigned long long s0 = gen_reserve(&D.ctl->n_sols, n_rec), a0 = gen_reserve(&D.ctl->ascii_bytes, ascii_need);
         W.scal[1] = (uint32_t)s0; W.scal[2] = (uint32_t)(s0 >> 32); W.scal[3] = (uint32_t)a0; W.scal[4] = (uint32_t)(a0 >> 32);
     }
     wave_sync();
     const uint64_t s0 = (uint64_t)W.scal[1] | ((uint64_t)W.scal[2] << 32);
     uint64_t a0 = (uint64_t)W.scal[3] | ((uint64_t)W.scal[4] << 32);
-    if (s0 + nf > D.cap_sols || a0 + ascii_need > D.cap_ascii) return leave(GEN_HOST);
+    if (s0 + n_rec > D.cap_sols || a0 + ascii_need > D.cap_ascii) return leave(GEN_HOST);
     const uint64_t mk = kmask(k), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
     const bool reverse = (flags & GAPF_REVERSE) != 0, repeated = (flags & GAPF_REPEATED) != 0;
     bool unknown = false;
-    for (uint32_t f = 0; f < nf; f++) {
+    uint32_t rec = 0;
+    for (uint32_t grp = 0; grp < n_groups; grp++) {
+    const uint32_t gf0 = W.g_f0[grp], gn = W.g_f0[grp + 1] - gf0; /* the group's solutions */
+    if (n_groups > 1u) {
+        GenSol hd;
+        hd.seq_off = 0; hd.seq_len = 0; hd.target = W.g_tgt[grp]; hd.nb_errors = 0; hd.qual = 0; hd.count = (int32_t)gn; hd.rank = 0; hd.avg = 0.f; hd.median = 0.f;
+        if (lane == 0) D.sols[s0 + rec] = hd;
+        rec++;
+    }
+    for (uint32_t f = gf0; f < gf0 + gn; f++) {
         const uint32_t c = W.f_src[f], L = W.c_len[c];
         const uint64_t* cw = D.tmp + W.c_off[c];
         /* source + sequence, little-endian, in LDS: L + 1 k-mers */
@@ -392,8 +431,8 @@ MTG_DEV uint32_t gen_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         s.seq_len = L;
         s.target = W.f_tgt[f];
         s.nb_errors = W.f_err[f];
-        s.count = (int32_t)nf;
-        s.rank = (int32_t)f + 1;
+        s.count = (int32_t)gn;
+        s.rank = (int32_t)(f - gf0) + 1;
 #ifdef MTG_EMU
         s.avg = (float)sum / (float)nk;
 #else
@@ -402,17 +441,19 @@ MTG_DEV uint32_t gen_gap(const Index& ix, const FillCfg& cfg, const GapScratch& 
         s.median = (nk & 1u) ? (float)hi : 0.5f * (float)(hi + lo);
         int q = 50; /* compute_qual, src/Utils.hpp:85-103 */
         if (repeated) q = 25;
-        if (nf > 1) q = 15;
+        if (gn > 1) q = 15;
         if (s.nb_errors == 1) q = 10;
         if (s.nb_errors == 2) q = 5;
         s.qual = q;
-        if (lane == 0) D.sols[s0 + f] = s;
+        if (lane == 0) D.sols[s0 + rec] = s;
+        rec++;
         emit_ascii(cw, 0, L, reverse, D.ascii + a0);
         a0 += (uint64_t)L + 1u;
         wave_sync();
     }
+    }
     if (wave_any(unknown)) return leave(GEN_HOST); /* "WARNING Unknown kmer" is the host's to print (src/Filler.cpp:980-982) */
-    out.n_sols = nf;
+    out.n_sols = n_rec;
     out.first_sol = (uint32_t)s0;
     return leave(GEN_OK);
 }

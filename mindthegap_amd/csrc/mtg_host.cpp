@@ -759,16 +759,35 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
         const HostChunk& c = *special.chunks[sg.chunk];
         if (sg.rank >= c.gen_gaps.size() || c.gen_gaps[sg.rank].status != GEN_OK) return false;
         const GenGap& g = c.gen_gaps[sg.rank];
-        W.nb_total_filled += (int)g.nb_total_filled;
-        W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
-        for (uint32_t j = 0; j < g.n_sols; j++) {
+        auto take = [&](uint32_t j) {
             const GenSol& d = c.gen_sols[g.first_sol + j];
             Solution s;
             s.seq.assign(c.gen_ascii.data() + d.seq_off, d.seq_len);
             s.nb_errors = d.nb_errors; s.target = (int)d.target; s.count = d.count; s.rank = d.rank; s.qual = d.qual; s.avg = d.avg; s.median = d.median;
             s.ab_n = 0; /* coverage done */
             W.sols.push_back(std::move(s));
+        };
+        if (g.n_groups > 1) {
+            /* several targets reached (contig mode): the device answered group by group, in the order the reference INSERTS the groups' names into
+             * its unordered_map<string, set<path>> (src/Filler.cpp:924-936); the solutions come out in the order that map is ITERATED, which is
+             * libstdc++'s business: the same insertions into the same kind of map give it.  Two targets under one name would be one group there:
+             * such a gap (not seen with the reference's dictionaries: a name and its _Rc form per contig end) takes the host's path. */
+            std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> order; /* name -> first record, records */
+            for (uint32_t j = 0; j < g.n_sols;) {
+                const GenSol& h = c.gen_sols[g.first_sol + j];
+                if (h.rank != 0 || h.target >= W.targets.size() || j + 1u + (uint32_t)h.count > g.n_sols) return false;
+                std::string key(W.targets[h.target].name);
+                if (W.targets[h.target].is_rc) key += "_Rc";
+                if (!order.emplace(std::move(key), std::make_pair(j + 1u, (uint32_t)h.count)).second) return false;
+                j += 1u + (uint32_t)h.count;
+            }
+            for (auto it = order.begin(); it != order.end(); ++it)
+                for (uint32_t j = 0; j < it->second.second; j++) take(it->second.first + j);
+        } else {
+            for (uint32_t j = 0; j < g.n_sols; j++) take(j);
         }
+        W.nb_total_filled += (int)g.nb_total_filled;
+        W.has_counts = (W.nb_total_filled > 0) || W.reverse; /* src/Filler.cpp:1012 */
         return true;
     };
     std::vector<char> on_device(ng, 0);

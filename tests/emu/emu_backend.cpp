@@ -9,6 +9,7 @@
 #include "../../mindthegap_amd/csrc/mtg_marshal.h"
 #include "emu_us.h"
 #include "emu_walk.h"
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -28,6 +29,7 @@ static GapScratch carve_slot(const FillCfg& cfg, uint8_t* zero, uint8_t* raw, ui
     S.lane = s & 63u;
     return S;
 }
+static std::atomic<unsigned long> emu_gen_multi{0}, emu_gen_multi_host{0}; /* TEST-ONLY: gaps with several reached targets the device function finished / left to the host */
 static thread_local char g_err[512] = "";
 static thread_local mtg_batch_stats g_stats{};
 void set_error(const char* fmt, ...)
@@ -673,7 +675,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     hc->gen_ascii.assign(ascii.begin(), ascii.begin() + std::min<size_t>(ctl.ascii_bytes, ascii.size()));
                     hc->gen_ascii.push_back(0);
                     hc->gen_check = true;
-                    for (size_t g2 = 0; g2 < ng; g2++) { if (hc->gen_gaps[g2].status == GEN_OK) st.n_general_device++; else st.n_general_host++; }
+                    for (size_t g2 = 0; g2 < ng; g2++) {
+                        if (hc->gen_gaps[g2].status == GEN_OK) st.n_general_device++; else st.n_general_host++;
+                        if (hc->gen_gaps[g2].status == GEN_OK && hc->gen_gaps[g2].n_groups > 1) emu_gen_multi++;
+                        if (hc->gen_gaps[g2].status != GEN_OK && in.tcnt[ids[glist[g2]]] > 1) emu_gen_multi_host++;
+                    }
                 } else st.n_general_host += glist.size();
             }
             st.n_launches++;
@@ -692,6 +698,8 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
 extern "C" {
 /* TEST-ONLY: stored unitigs of the lean builds so far whose two walkers met in the middle / whose owner walked the whole chain */
 void emu_walk_counts(unsigned long* out) { out[0] = emu_walks_met; out[1] = emu_walks_whole; }
+/* TEST-ONLY: multi-contig gaps with several reached targets finished by the device function / multi-target gaps it left to the host */
+void emu_gen_counts(unsigned long* out) { out[0] = mtgi::emu_gen_multi; out[1] = mtgi::emu_gen_multi_host; }
 const char* mtg_last_error(void) { return mtgi::g_err; }
 /* TEST-ONLY: MTG_EMU_DEVICES pretends that many devices exist, so that the tool's multi-device driver can be exercised on the CPU */
 int mtg_device_count(void) { return getenv("MTG_EMU_DEVICES") ? atoi(getenv("MTG_EMU_DEVICES")) : 0; }

@@ -110,6 +110,15 @@ def product_on_emulator():
     return mindthegap_amd
 
 
+def gen_counts():
+    """(multi-contig gaps with several reached targets the device function finished, multi-target gaps it left to the host) of the product on the emulator"""
+    a = (C.c_ulong * 2)()
+    lib = C.CDLL(build_full())
+    lib.emu_gen_counts.argtypes = [C.POINTER(C.c_ulong)]
+    lib.emu_gen_counts(a)
+    return int(a[0]), int(a[1])
+
+
 def walk_counts(full=False):
     """(stored unitigs whose two walkers met in the middle, stored unitigs whose owner walked the whole chain) over the lean builds so far, of
     tests/emu/libemu or (full) of the product on the emulator"""

@@ -1425,3 +1425,54 @@ def test_bucket_arithmetic_of_the_scan_at_real_table_sizes(nb, key_bits):
     lib.emu_bucket_first_sweep.restype = C.c_uint64
     lib.emu_bucket_first_sweep.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
     lib.emu_bucket_first_sweep(nb, key_bits, 2_000_000, 12345)
+
+
+def _contig_several_targets_case(mtg_mod, tmp_path, monkeypatch, nloci, counts=None):
+    """contig mode with seeds whose local graph reaches SEVERAL other contigs (two or three haplotypes that continue into different contigs): the
+    reference groups the paths by target name in an unordered_map and reports the groups in libstdc++'s iteration order (src/Filler.cpp:924-936).
+    The device function answers every group (mtg_general.h: header records), the host orders them with the same map (mtg_host.cpp: run_general).
+    Names of many shapes, so that the map's order differs from the insertion order somewhere.  Files against the oracle's, with the device
+    function and with the host's path alone (HOST_GENERAL)."""
+    rng = random.Random(4242)
+    seqs, contigs = [], []
+    names = []
+    for i in range(nloci):
+        X, Y, Z = _rand_seq(rng, 500), _rand_seq(rng, 500), _rand_seq(rng, 500)
+        a, b = _rand_seq(rng, rng.randrange(60, 300)), _rand_seq(rng, rng.randrange(60, 300))
+        if i % 4 == 3:  # a third continuation: three groups
+            V, c = _rand_seq(rng, 500), _rand_seq(rng, rng.randrange(60, 300))
+            seqs.append(X + c + V)
+            contigs.append(V[80:])
+        seqs += [X + a + Y, X + b + Z]
+        contigs += [X[:420], Y[80:], Z[80:]]
+    for i in range(len(contigs)):
+        names.append(rng.choice(["ctg%d", "c%d", "scaffold_%d_len", "NODE_%d_length_100_cov_3.5", "x%dy"]) % rng.randrange(1, 10 ** rng.randrange(1, 7)) + "_%d" % i)
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    cf = str(tmp_path / "c.fa")
+    with open(cf, "w") as f:
+        for n, c in zip(names, contigs):
+            f.write(">%s\n%s\n" % (n, c))
+    _write_idx(str(tmp_path / "m.mtgidx"), km, ct)
+    o.fill_files("contig", cf, str(tmp_path / "cpu"))
+    before = counts() if counts else None
+    assert mtg_mod.Filler().run(["-graph", str(tmp_path / "m.mtgidx"), "-contig", cf, "-out", str(tmp_path / "hip")]) == 0
+    after = counts() if counts else None
+    for ext in (".insertions.fasta", ".info.txt", ".gfa", "_seed_dictionary.fasta"):
+        assert _read(str(tmp_path / "hip") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    assert _read(str(tmp_path / "hip.insertions.fasta")).count(">") >= 4 * nloci  # both continuations from the X contig's end, and each back from the other side
+    monkeypatch.setenv("MTG_HOST_GENERAL", "1")
+    assert mtg_mod.Filler().run(["-graph", str(tmp_path / "m.mtgidx"), "-contig", cf, "-out", str(tmp_path / "host")]) == 0
+    monkeypatch.delenv("MTG_HOST_GENERAL")
+    for ext in (".insertions.fasta", ".info.txt", ".gfa"):
+        assert _read(str(tmp_path / "host") + ext) == _read(str(tmp_path / "cpu") + ext), ext
+    o.close()
+    return before, after
+
+
+def test_contig_mode_gaps_that_reach_several_targets_by_the_device_function(emu_product, tmp_path, monkeypatch):
+    """the emulation build runs the host's whole path next to every gap the device function finishes (HostChunk::gen_check) and counts the gaps with
+    several groups it finished / the multi-target gaps it left to the host"""
+    before, after = _contig_several_targets_case(emu_product, tmp_path, monkeypatch, 14, emu_lib.gen_counts)
+    assert after[0] - before[0] >= 10, (before, after)   # the seeds at the ends of the X contigs, at least
+    assert after[1] - before[1] == 0, (before, after)    # none of this set's multi-target gaps needs the host

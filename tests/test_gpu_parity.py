@@ -309,6 +309,13 @@ def test_allelic_inserts_general_path(mtg, tmp_path):
     _allelic_inserts_case(mtg, tmp_path, 120)
 
 
+def test_contig_mode_gaps_that_reach_several_targets(mtg, tmp_path, monkeypatch):
+    """k_general with several groups per gap (contig mode: a seed whose graph reaches two or three other contigs), the host ordering the groups like
+    the reference's unordered_map; against the oracle's files, and the host's path alone (HOST_GENERAL) against them too"""
+    from tests.test_emu_parity import _contig_several_targets_case
+    _contig_several_targets_case(mtg, tmp_path, monkeypatch, 60)
+
+
 def test_scratch_tier_retry_inside_a_batch(mtg):
     """one gap of the batch walks a 150 kb unitig and overflows the tier-0 contig arena: it is re-run in a larger tier on the device while
     its neighbours keep their tier-0 results; contigs identical to the oracle's"""
