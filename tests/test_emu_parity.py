@@ -1476,3 +1476,35 @@ def test_contig_mode_gaps_that_reach_several_targets_by_the_device_function(emu_
     before, after = _contig_several_targets_case(emu_product, tmp_path, monkeypatch, 14, emu_lib.gen_counts)
     assert after[0] - before[0] >= 10, (before, after)   # the seeds at the ends of the X contigs, at least
     assert after[1] - before[1] == 0, (before, after)    # none of this set's multi-target gaps needs the host
+
+
+def _several_targets_batch_case(mtg, monkeypatch):
+    """the same shape through the batch entry, where the statistics of the call say who finished the multi-contig gaps: the device (k_general with
+    groups), none left to the host; the records equal those of the host's path alone (which the file tests pin against the oracle)"""
+    rng = random.Random(515)
+    seqs, gaps = [], []
+    for i in range(40):
+        X, Y, Z = _rand_seq(rng, 300), _rand_seq(rng, 300), _rand_seq(rng, 300)
+        a, b = _rand_seq(rng, rng.randrange(60, 300)), _rand_seq(rng, rng.randrange(60, 300))
+        seqs += [X + a + Y, X + b + Z]
+        tg = [(Y[40:71], "n%d_%d" % (rng.randrange(10 ** 6), i), False), (Z[40:71], "q%d" % rng.randrange(10 ** 4), True), (_rand_seq(rng, 31), "unreached", False)]
+        rng.shuffle(tg)
+        gaps.append(mtg.Gap(X[200:231], "".join(t[0] for t in tg), tg))
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    o.close()
+    idx = mtg.Index.from_kmers(km, ct, 31)
+    res = idx.fill_batch(gaps)
+    st = mtg.last_batch_stats()
+    assert st["n_general_device"] >= 40 and st["n_general_host"] == 0, st
+    assert all(len(r["filled"]) == 2 for r in res)
+    monkeypatch.setenv("MTG_HOST_GENERAL", "1")
+    res_h = idx.fill_batch(gaps)
+    st_h = mtg.last_batch_stats()
+    assert st_h["n_general_device"] == 0 and st_h["n_general_host"] >= 40, st_h
+    assert res_h == res
+    idx.close()
+
+
+def test_gaps_with_several_reached_targets_stay_on_the_device_function(emu_product, monkeypatch):
+    _several_targets_batch_case(emu_product, monkeypatch)

@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI of include/mtg_fill.h) against the CPU oracle, the committed
 golden files and size-independent properties.  Bit-exact everywhere (integer / byte / text work)."""
 import os
+import random
 import subprocess
 import sys
 
@@ -314,6 +315,11 @@ def test_contig_mode_gaps_that_reach_several_targets(mtg, tmp_path, monkeypatch)
     the reference's unordered_map; against the oracle's files, and the host's path alone (HOST_GENERAL) against them too"""
     from tests.test_emu_parity import _contig_several_targets_case
     _contig_several_targets_case(mtg, tmp_path, monkeypatch, 60)
+
+
+def test_gaps_with_several_reached_targets_stay_on_the_device(mtg, monkeypatch):
+    from tests.test_emu_parity import _several_targets_batch_case
+    _several_targets_batch_case(mtg, monkeypatch)
 
 
 def test_scratch_tier_retry_inside_a_batch(mtg):
