@@ -255,7 +255,9 @@ class TextGaps:
             so[i], sl[i] = put(g.source)
             po[i], pl[i] = put(g.target)
             for (kmer, name, is_rc) in g.targets:
-                a, b = put(kmer)
+                # a one-entry dictionary whose sequence is the pattern itself (breakpoint mode) points at the pattern's bytes, as the tool's reader of a
+                # breakpoint file does (mtg_cli.cpp): the right k-mer stands once in the block
+                a, b = (int(po[i]), int(pl[i])) if kmer == g.target else put(kmer)
                 do.append(a)
                 dl.append(b)
                 a, b = put(name)
