@@ -155,7 +155,7 @@ def compact_line(out, detail_path=None):
         "avg_kernel_ms": _num(dom.get("avg_kernel_ms")), "traffic": _num(dom.get("traffic"), 6), "traffic_over_bytes": _num(dom.get("traffic_over_bytes")), "traffic_over_request_bytes": _num(dom.get("traffic_over_request_bytes")),
         "traffic_is": "replayed from profiles/ (PMC FETCH_SIZE + WRITE_SIZE of this command)" if dom.get("traffic") else None,
         "dominant_kernel": roof.get("dominant_kernel"), "dominant_kernel_frac": _num(roof.get("dominant_kernel_frac_of_hbm_peak")),
-        "walk_kernel": wall.get("kernel"), "walk_kernel_frac": _num(wall.get("frac")), "walk_kernel_ms": _num(wall.get("avg_kernel_ms")),
+        "walk_kernel": wall.get("kernel"), "first_walk_by_light_kernel": _num((roof.get("first_walk_kernel") or {}).get("k_walk (light: simple paths only)")), "walk_kernel_frac": _num(wall.get("frac")), "walk_kernel_ms": _num(wall.get("avg_kernel_ms")),
         "walk_traffic_over_bytes": _num(wall.get("traffic_over_bytes")),
         "random_read_frac": _num(g(roof, "random_reads_of_k_stage_a", "alone", "frac_of_ceiling") or g(roof, "random_reads_of_k_stage_a", "frac_of_ceiling")),
         "sec8d_equivalent_frac_of_the_walk": _num(g(roof, "reference_algorithm_equivalent", "equivalent_GBps_of_k_stage_a") / HBM_PEAK_GBS) if g(roof, "reference_algorithm_equivalent", "equivalent_GBps_of_k_stage_a") else None,
@@ -306,7 +306,7 @@ def main():
     params = mtg.FillParams(max_nodes=100, max_depth=10000, nb_host_threads=host_threads)
     STAT_KEYS = dict(kernel_ms=0.0, post_kernel_ms=0.0, emit_kernel_ms=0.0, index_lines=0, contig_nt=0, n_launches=0, host_ms=0.0, d2h_ms=0.0, total_ms=0.0, store_runs=0, run_nt=0,
                      post_lines=0, contig_words=0, coverage_kmers=0, dense_words=0, seq_bytes=0, copy_kernel_ms=0.0, copy_words=0, copy_cmds=0, coverage_direct_kmers=0,
-                     finish_kernel_ms=0.0, n_parked_gaps=0, n_lean_gaps=0, lean_kernel_ms=0.0, copy_words_executed=0, copy_cmds_executed=0, post_scanned_words=0, device_span_ms=0.0, gaps=0)
+                     finish_kernel_ms=0.0, n_parked_gaps=0, n_lean_gaps=0, lean_kernel_ms=0.0, copy_words_executed=0, copy_cmds_executed=0, post_scanned_words=0, device_span_ms=0.0, n_light_walks=0, n_branching_gaps=0, gaps=0)
 
     class B:
         pass
@@ -927,16 +927,18 @@ def main():
             "measured_link_ceiling_GBps": "scripts/pcie_d2h.py: 57 with two or three copies in flight",
             "traffic": None, "traffic_source": None,
             "dominant_kernel": dom["kernel"], "dominant_kernel_frac_of_hbm_peak": dom["frac"], "kernels": kerns, "launches": int(acc["n_launches"]),
+            "first_walk_kernel": {"k_walk (light: simple paths only)": int(acc["n_light_walks"]), "k_stage_a (full)": int(acc["n_launches"] - acc["n_light_walks"]),
+                                  "gaps_that_met_a_branching_node_per_launch": acc["n_branching_gaps"] / Ln},
             "kernel_times": "avg_kernel_ms = HIP events on the batch's stream with ONE batch on the device (%s launches after the timed blocks); the same command under rocprofv3 --kernel-trace --stats with --in-flight 1 is profiles/r05_kernel_stats_one_batch_in_flight.csv"
                             % (st_alone["runs"] if st_alone else 0)}
     pmc = next((q for q in (os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json")) if os.path.exists(q)), None)
     if a.workload == "human" and batch_sites == 100000 and pmc:
         pj = json.load(open(pmc))
-        fill_kernels = ("k_stage_a", "k_finish", "k_bubble", "k_lean", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
+        fill_kernels = ("k_stage_a", "k_walk", "k_finish", "k_bubble", "k_lean", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
         by_kernel = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pj.get("kernels", {}).items() if kn.split("::")[-1].startswith(fill_kernels)}
         # `traffic`: HBM bytes per launch of the dominant kernel (with the scans it is reported with); every kernel of a fill under traffic_by_kernel
         dk = dom["kernel"].split("(")[0]
-        roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (dk == "k_emit" and kn == "k_emit_lean") or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble"))))) or None
+        roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (dk == "k_emit" and kn == "k_emit_lean") or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble", "k_walk"))))) or None
         roof["traffic_by_kernel"] = by_kernel
         roof["traffic_is"] = "REPLAYED, not measured in this run: counters cannot be read from inside the process"
         roof["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, no trace domain, the bench command of scripts/profile_round5.sh, HEAD %s): "
@@ -945,7 +947,7 @@ def main():
                                   % (os.path.relpath(pmc, ROOT), pj.get("head", "?")))
         for kr in kerns:
             tk = kr["kernel"].split("(")[0]
-            tv = sum(v for kn, v in by_kernel.items() if v and (kn == tk or (tk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (tk == "k_emit" and kn == "k_emit_lean") or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble")))))
+            tv = sum(v for kn, v in by_kernel.items() if v and (kn == tk or (tk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (tk == "k_emit" and kn == "k_emit_lean") or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble", "k_walk")))))
             kr["traffic"] = tv or None
             kr["traffic_over_bytes"] = (tv / kr["bytes_per_launch"]) if tv and kr["bytes_per_launch"] else None
             # the fabric serves (and FETCH_SIZE counts) a scattered read as a 64-byte request: the same layout with every bucket read at 64 B

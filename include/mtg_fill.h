@@ -344,7 +344,9 @@ typedef struct mtg_batch_stats {
     uint64_t post_scanned_words; /* of contig_words: those k_post's terminal search really read (a lean gap's contig is never scanned) */
     double device_span_ms;       /* first kernel of a launch to its last, summed over the launches */
     uint64_t n_general_device;   /* multi-contig gaps finished on the device (k_general: candidate sequences, de-duplication, coverage, ASCII) */
-    uint64_t n_general_host;     /* multi-contig gaps the host's path took (several targets, a candidate that does not fit the work areas, an unknown k-mer; HOST_GENERAL) */
+    uint64_t n_general_host;     /* multi-contig gaps the host's path took (a candidate that does not fit the work areas, an unknown k-mer; HOST_GENERAL) */
+    uint64_t n_light_walks;      /* launches whose first walk ran in the light kernel (k_walk: simple paths only; chosen when the previous launch hardly met a branching node) */
+    uint64_t n_branching_gaps;   /* gaps whose first walk stood on a branching node at least once */
 } mtg_batch_stats;
 int mtg_last_batch_stats(mtg_batch_stats* s);
 

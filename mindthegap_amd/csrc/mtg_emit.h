@@ -35,7 +35,7 @@ struct PartTot {
     uint64_t lines, store_runs, run_nt, contig_nt, contig_words, post_lines, cov_kmers, copy_words, copy_cmds, cov_direct, n_lean;
     uint64_t copy_words_exec, copy_cmds_exec, scan_words; /* what k_copy executed and k_post scanned: nothing of a lean gap */
     uint32_t n_retry, n_general, n_filled, n_ext;
-    uint32_t n_parked, pad_; /* gaps the walk kernel's first launch parked (the hint for the workspace's next launch) */
+    uint32_t n_parked, n_branching; /* gaps the walk kernel's first launch parked / whose walk stood on a branching node at least once (the hints for the workspace's next launch) */
 };
 
 /* one slot's share of the sums (the scan kernel adds them up in slot order) */

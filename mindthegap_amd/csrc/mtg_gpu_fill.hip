@@ -46,6 +46,8 @@ __constant__ FillCfg c_cfg[TRAVERSAL_SETS];
 enum { PARK_LISTS = 19 }; /* 0 .. 15: the rounds' lists of parked gaps; the last two: gaps for k_post's general form, gaps with copy commands to execute */
 struct ParkCtl {
     uint32_t count[PARK_LISTS];
+    uint32_t n_branching; /* gaps of the launch whose walk (first launch of the walk kernel) stood on a branching node with successors */
+    uint32_t pad_[3];
 #ifdef MTG_BUBBLE_TIMING /* diagnostics build: how long the lanes and the waves of the bubble kernels ran (bins of log2 of 10 ns ticks) */
     uint32_t hist_lane[32], hist_wave[32], hist_walk_lane[32], hist_walk_wave[32];
 #endif
@@ -100,12 +102,24 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
 #ifdef MTG_BUBBLE_TIMING
     const uint64_t t0 = wall_clock64();
 #endif
-    stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr, in_list >= 0);
+    uint32_t met = 0;
+    stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr, in_list >= 0, &met);
 #ifdef MTG_BUBBLE_TIMING
     if (MODE == WALK_PARK && in_list >= 0) timing_note(park->hist_walk_lane, park->hist_walk_wave, t0);
 #endif
     out[slot] = o;
-    if (MODE == WALK_PARK) park_append(park, cap, out_list, o.status == GAP_PARKED, slot);
+    if (in_list < 0) { /* how much of the data branches: what chooses the next launch's walk kernel (one atomic per wave that met any) */
+        const unsigned long long bm = __ballot(met != 0u);
+        if (bm && (int)(threadIdx.x & 63u) == __ffsll((long long)bm) - 1) atomicAdd(&park->n_branching, (uint32_t)__popcll(bm));
+    }
+    if (MODE == WALK_PARK || MODE == WALK_SIMPLE) park_append(park, cap, out_list, o.status == GAP_PARKED, slot);
+}
+/* the light walk kernel (WALK_SIMPLE): simple paths only, every branching node parks the gap.  No bubble code in its call graph */
+__global__ void __launch_bounds__(64) k_walk(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords,
+                                             const uint32_t* __restrict__ roff, const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
+                                             GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap)
+{
+    stage_a_lane<WALK_SIMPLE>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, -1, 0u);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
@@ -495,7 +509,8 @@ __global__ void __launch_bounds__(256) k_scan2(ScanBlock* blocks, uint32_t nbloc
         pt.copy_words = ssum[9]; pt.copy_cmds = ssum[10]; pt.cov_direct = ssum[11]; pt.n_lean = ssum[12];
         pt.copy_words_exec = ssum[13]; pt.copy_cmds_exec = ssum[14]; pt.scan_words = ssum[15];
         pt.n_parked = park ? park->count[0] : 0u;
-        pt.pad_ = 0;
+        pt.n_branching = park ? park->n_branching : 0u;
+
         *tot = pt;
         if (host_tot) *host_tot = pt;
     }
@@ -908,13 +923,24 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             const uint32_t park_share = ws.park_share != ~0u ? ws.park_share : idx->park_share_any.load(std::memory_order_relaxed);
             const uint32_t park_hint = (uint32_t)(((uint64_t)park_share * m) >> 16); /* gaps this launch is expected to park */
             int rounds = env_rounds >= 0 ? env_rounds : (park_share > 32768u ? 6 : 0); /* measured: with an eighth of the gaps parked the finishing kernel alone is faster, with all of them six rounds are */
+            /* The light walk kernel (k_walk: simple paths only, every branching node parks) where hardly any walk of the previous launch met a
+             * branching node -- a haploid donor: 2 of 100 000 -- and the full one (k_stage_a: SNP / tip / indel / merge forms in the walking lane)
+             * everywhere else; LIGHT_WALK=1 / 0 forces either (tests run the bubble cases under both). */
+            const uint32_t branch_share = ws.branch_share != ~0u ? ws.branch_share : idx->branch_share_any.load(std::memory_order_relaxed);
+            const int env_light = (int)tune::i(tune::T_LIGHT_WALK, -1);
+            const bool light = env_light >= 0 ? env_light != 0 : (branch_share != ~0u && branch_share < 512u && env_rounds < 0);
+            const uint32_t first_hint = light && branch_share != ~0u ? (uint32_t)(((uint64_t)branch_share * m) >> 16) : park_hint; /* gaps the first walk launch is expected to park */
             if (rounds > (PARK_LISTS - 5) / 2) rounds = (PARK_LISTS - 5) / 2;
             ParkCtl* const park = d_park.as<ParkCtl>();
             HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
             {
-                hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
-                                   d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
+                if (light)
+                    hipLaunchKernelGGL(k_walk, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m);
+                else
+                    hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
                 HIP_TRY(mark(evf));
                 const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with the narrow bubbles of
@@ -933,7 +959,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 /* lanes per parked gap in the finishing kernel: a whole wave while few gaps are parked (their chains are what the kernel takes:
                  * 0.17 against 0.32 ms for the 108 gaps of the heterozygous set), 16 when there are many (12 000 on the tips set: 0.46 against 0.63) */
                 const int finish_wave_below = (int)tune::i(tune::T_FINISH_WAVE_BELOW, 2048);
-                const int fin_g = finish_g_set ? finish_g : (rounds == 0 && park_hint < (uint32_t)finish_wave_below ? 64 : 16);
+                const int fin_g = finish_g_set ? finish_g : (rounds == 0 && first_hint < (uint32_t)finish_wave_below ? 64 : 16);
                 const bool lane_finish = finish_g_set && finish_g == 1;
                 /* The grid.  The host does not know how many gaps are parked when it queues the kernel, and 100 000 groups that read one
                  * scalar and leave cost 63 us (round 3: 13 % of a haploid batch's kernels, for 5 parked gaps).  So the groups take the first
@@ -943,7 +969,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 const uint32_t per_wg = 64u / (uint32_t)fin_g;
                 /* whole workgroups: k_finish<G> is bounded by the list's count only, so the entries it takes and those k_finish_lane starts from must
                  * meet at a multiple of per_wg (the advisor's round-4 finding: G = 8 with an odd hint walked four entries twice) */
-                const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (uint32_t)std::min<uint64_t>(m, ((4ull * park_hint + 256ull + per_wg - 1) / per_wg) * per_wg);
+                const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (uint32_t)std::min<uint64_t>(m, ((4ull * first_hint + 256ull + per_wg - 1) / per_wg) * per_wg);
                 const uint32_t nwg = (fin_entries + per_wg - 1) / per_wg;
                 if (!skip_finish && nwg) switch (fin_g) {
                     case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
@@ -1225,10 +1251,15 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 const uint32_t np = tot.n_parked;
                 st.n_parked_gaps += np;
                 st.n_rounds += (uint64_t)rounds;
+                st.n_light_walks += light ? 1u : 0u;
+                st.n_branching_gaps += tot.n_branching;
                 if (tier == 0 && identity && m >= 64) { /* the share of gaps this launch parked: how the workspace's next launch serves its parked gaps */
                     const uint32_t share = (uint32_t)std::min<uint64_t>(((uint64_t)np << 16) / m, 65536u);
                     ws.park_share = share;
                     idx->park_share_any.store(share, std::memory_order_relaxed);
+                    const uint32_t bshare = (uint32_t)std::min<uint64_t>(((uint64_t)tot.n_branching << 16) / m, 65536u);
+                    ws.branch_share = bshare;
+                    idx->branch_share_any.store(bshare, std::memory_order_relaxed);
                 }
             }
             { float mss = 0; HIP_TRY(hipEventElapsedTime(&mss, ev0, ev2)); st.device_span_ms += mss; }

@@ -48,6 +48,7 @@ struct Workspace {
     /* share of the gaps (in 65536ths) the walk kernel parked in this workspace's previous whole-batch launch: how the next launch serves its
      * parked gaps (rounds or not, lanes per gap in the finishing kernel); ~0 = no launch yet: the index's latest figure is taken */
     uint32_t park_share = ~0u;
+    uint32_t branch_share = ~0u; /* share (16.16) of the previous launch's gaps whose walk stood on a branching node: below 1/128 the next launch starts with the light walk kernel */
     uint32_t post_general = ~0u; /* gaps of this workspace's previous launch that were not lean (the grid of k_post's general form); ~0: no launch yet */
     std::mutex mtx; /* held by a batch from marshalling until its results have been consumed */
 };
@@ -61,6 +62,7 @@ struct mtg_index {
 #define MTG_NWS 6 /* batches one index serves at a time (each with its own device scratch, streams and staging blocks) */
 #endif
     enum { NWS = MTG_NWS };
+    mutable std::atomic<uint32_t> branch_share_any{~0u}; /* the same for the branching share (~0: no launch yet -- the full walk kernel) */
     mutable std::atomic<uint32_t> park_share_any{0}; /* the latest park share any workspace of this index has seen (a fresh workspace starts from it) */
     mutable mtgi::Workspace ws[NWS];
     int device = 0;

@@ -1966,8 +1966,11 @@ namespace mtg {
  *                 WalkSave and the gap comes back GAP_PARKED;
  *   WALK_FINISH   the finishing kernel: G lanes resume ONE parked gap.  The walk itself is run by all G lanes with the same values (a load
  *                 is one request per group, the stores write the same bytes), so that the lanes arrive together at every branching node,
- *                 which the group then resolves from its LDS area (mtg_bubble.h); what does not fit there runs the general code. */
-enum { WALK_CLASSIC = 0, WALK_PARK = 1, WALK_FINISH = 2 };
+ *                 which the group then resolves from its LDS area (mtg_bubble.h); what does not fit there runs the general code;
+ *   WALK_SIMPLE   the light walk kernel (round 5): simple paths ONLY -- it parks at every branching node, none of the bubble code is in its
+ *                 call graph (a tenth of WALK_PARK's 260 KB of instructions, a fraction of its registers).  For launches on data where
+ *                 hardly any walk meets a branching node (a haploid donor); the parked few are resumed by the finishing kernel. */
+enum { WALK_CLASSIC = 0, WALK_PARK = 1, WALK_FINISH = 2, WALK_SIMPLE = 3 };
 
 #ifdef MTG_EMU /* TEST-ONLY: how the group form answered (MTG_EMU_COOP_STATS=1 prints the tally when the process ends) */
 } // namespace mtg
@@ -1991,7 +1994,8 @@ inline void coop_tally(int n)
 }
 #endif
 template <int MODE, int G>
-MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLdsBig* L, bool resume = (MODE == WALK_FINISH))
+MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLdsBig* L, bool resume = (MODE == WALK_FINISH),
+                          uint32_t* met_branching = nullptr /* set to 1 when the walk stood on a branching node with successors at least once */)
 {
     Worker W(ix, cfg, S);
     W.no_dp = MODE == WALK_PARK;
@@ -2254,7 +2258,7 @@ MTG_UNROLL
     /* S.snp_fast == 2 (the walk kernel, when the launch serves bubbles in rounds): the walk parks at EVERY branching node, also where the SNP
      * fast path would answer -- the lanes of a wave meet their SNPs at different steps, and a wave in which one lane at a time runs the bubble
      * code while 63 wait spends four times as long there as on the walking; the bubble kernel runs it for all parked gaps at once */
-    const bool park_all = MODE == WALK_PARK && S.snp_fast == 2;
+    const bool park_all = MODE == WALK_SIMPLE || (MODE == WALK_PARK && S.snp_fast == 2);
     if (resume) {
         const WalkSave sv = *s_save(cfg, S);
         resuming = true;
@@ -2434,13 +2438,14 @@ MTG_UNROLL
 #endif
         MTG_T0(t_b);
         if (!end_contig) {
+            if (met_branching) *met_branching = 1u;
             int chosen = -1;
             MTG_T0(t_snp);
             SnpSeq fast_seq;
             fast_seq.lo = fast_seq.hi = 0;
             int n = 0;
             if (resuming && answered_snp) { n = saved_n; chosen = saved_chosen; fast_seq = saved_snp; answered_snp = false; }
-            else if (!resuming && !park_all) n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
+            else if (MODE != WALK_SIMPLE && !resuming && !park_all) n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
             resuming = false;
             MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */
@@ -2454,7 +2459,7 @@ MTG_UNROLL
                 n = saved_n; chosen = saved_chosen;
                 answered = false;
             } else if (!fast) {
-                if (MODE == WALK_PARK) {
+                if (MODE == WALK_PARK || MODE == WALK_SIMPLE) {
                     /* not the strict SNP pattern: the gap is parked here and a group of lanes takes it over (k_bubble / k_finish) */
                     WalkSave sv;
                     sv.answered = 0; sv.bn = 0; sv.bchosen = -1;
@@ -2523,7 +2528,7 @@ MTG_UNROLL
                     else { coop = true; if (n > 0) coop_apply_marks<G>(W, *L); }
                 } else if (MODE == WALK_CLASSIC) n = explore_branching(W, cur, prev_c, chosen);
             }
-            if (n <= 0) {
+            if (MODE == WALK_SIMPLE || n <= 0) { /* (the light kernel never has a consensus to consume: it parked above, or the contig ends on a status) */
                 end_contig = true;
             } else {
                 const SP<uint8_t> p = s_cons(cfg, S) + (size_t)chosen * CONS_LEN;

@@ -99,7 +99,8 @@ class BatchStats(C.Structure):
                 ("store_runs", C.c_uint64), ("run_nt", C.c_uint64), ("post_lines", C.c_uint64), ("contig_words", C.c_uint64), ("coverage_kmers", C.c_uint64),
                 ("dense_words", C.c_uint64), ("emit_kernel_ms", C.c_double), ("seq_bytes", C.c_uint64), ("copy_kernel_ms", C.c_double), ("copy_words", C.c_uint64),
                 ("copy_cmds", C.c_uint64), ("coverage_direct_kmers", C.c_uint64), ("finish_kernel_ms", C.c_double), ("n_parked_gaps", C.c_uint64), ("n_rounds", C.c_uint64), ("n_lean_gaps", C.c_uint64),
-                ("lean_kernel_ms", C.c_double), ("copy_words_executed", C.c_uint64), ("copy_cmds_executed", C.c_uint64), ("post_scanned_words", C.c_uint64), ("device_span_ms", C.c_double), ("n_general_device", C.c_uint64), ("n_general_host", C.c_uint64)]
+                ("lean_kernel_ms", C.c_double), ("copy_words_executed", C.c_uint64), ("copy_cmds_executed", C.c_uint64), ("post_scanned_words", C.c_uint64), ("device_span_ms", C.c_double), ("n_general_device", C.c_uint64), ("n_general_host", C.c_uint64), ("n_light_walks", C.c_uint64),
+                ("n_branching_gaps", C.c_uint64)]
 
 
 class BuildPhase(C.Structure):

@@ -2,7 +2,8 @@
  * not the strict SNP pattern; for MTG_ROUNDS rounds (default 2 here, so that both the rounds and the finishing kernel are exercised) the
  * bubble kernels answer the node (the LDS form first, the one-lane form when it does not fit) and the walk kernel resumes; k_finish takes
  * what is still parked.  MTG_EMU_CLASSIC=1: the one-lane reference form of the whole walk.  MTG_EMU_PARK_SNP=1: the walks of the rounds park at
- * SNP bubbles too and the bubble kernels answer them with the fast path (what a launch with many bubbles does). */
+ * SNP bubbles too and the bubble kernels answer them with the fast path (what a launch with many bubbles does).  MTG_LIGHT_WALK=1: the first
+ * walk is the light kernel's (WALK_SIMPLE). */
 #pragma once
 #include <cstdlib>
 namespace mtg {
@@ -17,7 +18,11 @@ inline uint32_t emu_walk(const Index& ix, const FillCfg& cfg, GapScratch& S, uin
     if (park_snp && snp0) S.snp_fast = 2;
     static thread_local BubbleLds lds;
     static thread_local BubbleLdsBig lds_big;
-    stage_a_walk<WALK_PARK, 1>(ix, cfg, S, src_f, R, out, nullptr);
+    /* MTG_LIGHT_WALK=1 (read at every gap: tests switch it): the launch's first walk by the light kernel's form -- simple paths only, the gap parks at
+     * its first branching node whatever its shape -- and the rounds / the finishing form take it from there, as on the device */
+    const char* lw = getenv("MTG_LIGHT_WALK");
+    if (lw && lw[0] == '1') stage_a_walk<WALK_SIMPLE, 1>(ix, cfg, S, src_f, R, out, nullptr);
+    else stage_a_walk<WALK_PARK, 1>(ix, cfg, S, src_f, R, out, nullptr);
     if (out.status != GAP_PARKED) { S.snp_fast = snp0; return 0; }
     for (int r = 0; r < rounds && out.status == GAP_PARKED; r++) {
         if (coop_off || !bubble_coop<1>(ix, cfg, S, lds)) bubble_classic(ix, cfg, S);

@@ -1508,3 +1508,15 @@ def _several_targets_batch_case(mtg, monkeypatch):
 
 def test_gaps_with_several_reached_targets_stay_on_the_device_function(emu_product, monkeypatch):
     _several_targets_batch_case(emu_product, monkeypatch)
+
+
+def test_light_walk_form_on_data_with_bubbles(emu_product, tmp_path, monkeypatch):
+    """round 5: the light walk kernel (WALK_SIMPLE: simple paths only, the gap parks at its first branching node whatever its shape) is what a launch
+    starts with when the previous one hardly met a branching node -- and a batch of another kind may follow: every bubble case must come out the
+    same when the first walk is the light one (LIGHT_WALK=1 forces it; the rounds and the finishing form take the parked gaps from there)."""
+    monkeypatch.setenv("MTG_LIGHT_WALK", "1")
+    _diploid_case(emu_product, tmp_path, 10)
+    (tmp_path / "al").mkdir()
+    _allelic_inserts_case(emu_product, tmp_path / "al", 8)
+    (tmp_path / "ct").mkdir()
+    _contig_several_targets_case(emu_product, tmp_path / "ct", monkeypatch, 6)

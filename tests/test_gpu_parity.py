@@ -775,6 +775,9 @@ LAUNCH_SEQUENCES = [
     {"MTG_ROUNDS": "0", "MTG_FINISH_G": "64"},             # every parked gap straight to k_finish<64>
     {"MTG_ROUNDS": "0", "MTG_FINISH_G": "8"},              # k_finish<8>: the grid's whole workgroups and k_finish_lane's first entry must meet (round-4 advisor)
     {"MTG_FINISH_G": "1"},                                 # one lane per parked gap (k_finish_lane)
+    {"MTG_LIGHT_WALK": "1"},                               # the first walk by the light kernel (every branching node parks), then whatever the park share asks for
+    {"MTG_LIGHT_WALK": "1", "MTG_ROUNDS": "2"},            # light walk, two rounds of bubble kernel + resumed full walks, the finishing kernel
+    {"MTG_LIGHT_WALK": "0"},                               # never the light kernel
 ]
 
 
