@@ -914,7 +914,7 @@ def main():
                 "per_gap_gapout_target_leanrec_command_read": gaps_l * (36 + 26 + 16 + 24), "per_gap_slot_record_written_160B_and_rewritten_by_the_scan_48B": gaps_l * (160 + 160 + 48)}
     em_parts = {"ascii_written": acc["seq_bytes"] / Ln, "sequence_2bit_read": acc["seq_bytes"] / Ln / 4, "per_gap_records": n_lean_l * (160 + 56 + 40) + listed * (160 + 160 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / Ln * 16}
     kerns = [kern("k_stage_a(+k_finish)", acc["kernel_ms"] / Ln, alone_ms("kernel_ms"), sum(sa_parts.values()), sa_parts),
-             kern("k_lean", acc["lean_kernel_ms"] / Ln, alone_ms("lean_kernel_ms"), sum(ln_parts.values()), ln_parts),
+             kern("lean decision (in the walk kernels since late round 5: time 0, bytes counted here)", acc["lean_kernel_ms"] / Ln, alone_ms("lean_kernel_ms"), sum(ln_parts.values()), ln_parts),
              kern("k_copy", (acc["copy_kernel_ms"] - acc["lean_kernel_ms"]) / Ln, alone_ms("copy_kernel_ms", "-lean_kernel_ms"), sum(cp_parts.values()), cp_parts),
              kern("k_post(+k_post_lean,k_scan1,k_scan2)", acc["post_kernel_ms"] / Ln, alone_ms("post_kernel_ms"), sum(po_parts.values()), po_parts),
              kern("k_emit(+k_emit_lean)", acc["emit_kernel_ms"] / Ln, alone_ms("emit_kernel_ms"), sum(em_parts.values()), em_parts)]

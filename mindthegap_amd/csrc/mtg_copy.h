@@ -26,7 +26,7 @@ MTG_DEV uint64_t cmd_store_nt(const CopyCmd& cm, int64_t x)
  * find_nodes_containing_multiple_R reports (src/Filler.cpp:1341-1351: the first exact match ends the scan, and a contig never holds a
  * node twice), so k_post takes the position as it is; the emulation build runs the search as well and compares.
  * target: the gap's single target k-mer (forward value) when the lean form may be used (one usable target, a source of exactly k
- * nucleotides, records wanted), ~0 otherwise.  Decided by ONE lane (k_lean: one gap per lane); returns whether the gap's commands still
+ * nucleotides, records wanted), ~0 otherwise.  Decided by ONE lane (the one that finished the walk: mtg_gpu_fill.hip, lean_and_list); returns whether the gap's commands still
  * have to be executed (copy_cmds). */
 MTG_DEV bool lean_decide(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint64_t target)
 {

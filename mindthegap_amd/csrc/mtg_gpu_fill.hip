@@ -4,7 +4,7 @@
  *   k_stage_a                        : breadth-first contig construction of one gap per lane
  *                                      (IterativeExtensions::construct_linear_seqs, /root/reference/src/Filler.cpp:884)
  *   k_bubble* / k_finish*            : the branching nodes of parked gaps (MonumentTraversal::explore_branching): groups of lanes, LDS work areas
- *   k_lean / k_copy                  : where the target lies in the run a walk took; the long runs of the contigs out of the unitig store
+ *   (lean_and_list) / k_copy         : where the target lies in the run a walk took (by the walking lane); the long runs of the contigs out of the unitig store
  *   k_post / k_post_lean             : terminal-node search per contig + coverage of the single-contig solution
  *                                      (find_nodes_containing_multiple_R, src/Filler.cpp:1294-1378; coverage :959-988)
  *   k_scan1 / k_scan2 / k_emit*      : layout of a batch's results and the results themselves (records + ASCII)
@@ -75,12 +75,39 @@ __device__ __forceinline__ void park_append(ParkCtl* park, uint32_t cap, uint32_
     base = (uint32_t)__shfl((int)base, leader, 64);
     if (parked) park_list(park, cap, list)[base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = slot;
 }
+/* ---- what becomes of a walk's long runs (mtg_copy.h), decided by the lane that finished the walk (a kernel of its own, k_lean, until late round 5:
+ * one more launch and another read of the record, the commands and the contig's start / length the lane has just written): is the target inside a run
+ * the walk took (the lean form: nothing is copied, k_post_lean and k_emit_lean read the store)?  The gaps that do need their commands executed go on
+ * COPY_LIST, every gap that is not lean on POST_LIST (ballot + prefix popcount, as for parking).  decides: the lane holds a finished gap. */
+enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2 };
+struct LeanIn {
+    const uint64_t* tle;      /* encoded targets, their never-match masks */
+    const uint64_t* tbad;
+    const uint32_t* toff;     /* per gap: first target, number of targets */
+    const uint32_t* tcnt;
+    const uint8_t* fast_ok;   /* per gap: the source is exactly k clean nucleotides */
+    uint32_t lean_allowed;
+    uint32_t decide_parked;   /* diagnostics (DEBUG_SKIP_FINISH): nobody will finish the parked gaps, the first walk lists them as they are */
+};
+__device__ __forceinline__ void lean_and_list(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint32_t g, uint32_t slot, bool decides, const LeanIn& li, ParkCtl* park, uint32_t cap)
+{
+    bool need = false, general = false;
+    if (decides) {
+        /* the lean form needs one usable target and a source of exactly k nucleotides (what the common-case result of k_post needs anyway) */
+        uint64_t target = ~0ull;
+        if (li.lean_allowed && li.tcnt[g] == 1u && li.fast_ok[g] && li.tbad[li.toff[g]] == 0ull) target = rev_fields64(li.tle[li.toff[g]]) >> (64 - 2 * ix.k);
+        need = lean_decide(ix, cfg, S, o, target);
+        general = !s_lean(cfg, S)[0].valid;
+    }
+    park_append(park, cap, COPY_LIST, need, slot);
+    park_append(park, cap, POST_LIST, general, slot); /* every gap that is not lean (a failed one too): k_post's general form */
+}
 /* one gap per lane.  in_list < 0: the gaps of the launch, from their source k-mers; otherwise the gaps of that work list, resumed (a bubble
  * kernel has answered the branching node they stand on).  out_list: where the gaps that park (again) go. */
 template <int MODE>
 __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                              const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset,
-                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
+                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, const LeanIn& li)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t slot = t;
@@ -113,20 +140,21 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
         if (bm && (int)(threadIdx.x & 63u) == __ffsll((long long)bm) - 1) atomicAdd(&park->n_branching, (uint32_t)__popcll(bm));
     }
     if (MODE == WALK_PARK || MODE == WALK_SIMPLE) park_append(park, cap, out_list, o.status == GAP_PARKED, slot);
+    lean_and_list(ix, cfg, S, o, g, slot, o.status != GAP_PARKED || li.decide_parked != 0u, li, park, cap);
 }
 /* the light walk kernel (WALK_SIMPLE): simple paths only, every branching node parks the gap.  No bubble code in its call graph */
 __global__ void __launch_bounds__(64) k_walk(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords,
                                              const uint32_t* __restrict__ roff, const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                             GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap)
+                                             GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, LeanIn li)
 {
-    stage_a_lane<WALK_SIMPLE>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, -1, 0u);
+    stage_a_lane<WALK_SIMPLE>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, -1, 0u, li);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WALK_WAVES))) k_stage_a(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src,
                                                 const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                                GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list)
+                                                GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, LeanIn li)
 {
-    stage_a_lane<WALK_PARK>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list);
+    stage_a_lane<WALK_PARK>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list, li);
 }
 /* ---- the rounds between two launches of the walk kernel: the branching nodes of the parked gaps, answered on their own, one lane per
  * bubble from HBM scratch -- all 64 lanes of a wave are in the bubble code at the same time.  (k_bubble<G>, a group of G lanes per bubble with
@@ -159,7 +187,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
 template <int G>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FINISH_WAVES))) k_finish(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                                const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t cset,
-                                               ParkCtl* park, uint32_t cap, uint32_t in_list)
+                                               ParkCtl* park, uint32_t cap, uint32_t in_list, LeanIn li)
 {
     __shared__ BubbleLdsBig lds[64 / G];
     const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1);
@@ -181,13 +209,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
     GapOut o;
     stage_a_walk<WALK_FINISH, G>(ix, cfg, S, 0, R, o, &lds[lane / G]);
     if (gl == 0) out[slot] = o;
+    lean_and_list(ix, cfg, S, o, g, slot, gl == 0, li, park, cap);
 }
 
 /* the same with one LANE per parked gap and the general code on HBM scratch (A/B hook, MTG_FINISH_G=1): the group form is faster even
  * for a handful of parked gaps */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STAGE_A_WAVES))) k_finish_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ rwords,
                                                const uint32_t* __restrict__ roff, const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
-                                               GapOut* out, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list, uint32_t first)
+                                               GapOut* out, uint32_t cset, ParkCtl* park, uint32_t cap, uint32_t in_list, uint32_t first, LeanIn li)
 {
     const uint32_t t = first + blockIdx.x * blockDim.x + threadIdx.x; /* entries below `first` belong to the groups of k_finish<G> */
     if (t >= park->count[in_list]) return;
@@ -204,36 +233,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
     GapOut o;
     stage_a_walk<WALK_FINISH, 1>(ix, cfg, S, 0, R, o, nullptr);
     out[slot] = o;
+    lean_and_list(ix, cfg, S, o, g, slot, true, li, park, cap);
 }
 
-/* the long runs the traversal left as commands (mtg_copy.h).  k_lean, one gap per lane: is the target inside a run the walk took (the lean
- * form: nothing is copied, k_post and k_emit read the store)?  The gaps that do need their commands executed go on a work list (ballot +
- * prefix popcount, as for parking).  k_copy, one wave per listed gap, four per workgroup: the grid covers the launch (the host does not
- * know the count), a wave beyond the list leaves after one scalar read. */
-enum { COPY_LIST = PARK_LISTS - 1, POST_LIST = PARK_LISTS - 2 };
-__global__ void __launch_bounds__(64) k_lean(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ tle,
-                                             const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ fast_ok,
-                                             uint32_t lean_allowed, uint32_t n, ParkCtl* park, uint32_t cap)
-{
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    bool need = false, general = false;
-    if (slot < n) {
-        GapScratch S;
-        S.z = nullptr;
-        S.v = nullptr;
-        S.lane = slot & 63u;
-        S.r = raw + (uint64_t)slot * cfg.raw_stride;
-        S.h = head + (uint64_t)(slot >> 6) * cfg.hd_stride;
-        /* the lean form needs one usable target and a source of exactly k nucleotides (what the common-case result of k_post needs anyway) */
-        const uint32_t g = ids ? ids[slot] : slot;
-        uint64_t target = ~0ull;
-        if (lean_allowed && tcnt[g] == 1u && fast_ok[g] && tbad[toff[g]] == 0ull) target = rev_fields64(tle[toff[g]]) >> (64 - 2 * ix.k);
-        need = lean_decide(ix, cfg, S, outs[slot], target);
-        general = !s_lean(cfg, S)[0].valid;
-    }
-    park_append(park, cap, COPY_LIST, need, slot);
-    park_append(park, cap, POST_LIST, general, slot); /* every gap that is not lean (a failed one too): k_post's general form */
-}
+/* the long runs the traversal left as commands (mtg_copy.h), for the gaps on COPY_LIST (lean_and_list above).  k_copy, one wave per listed gap, four per
+ * workgroup: the grid covers the launch (the host does not know the count), a wave beyond the list leaves after one scalar read. */
 __global__ void __launch_bounds__(256) k_copy(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, ParkCtl* park, uint32_t cap, uint32_t list)
 {
     const uint32_t count = park->count[list];
@@ -295,7 +299,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
     __shared__ uint32_t hist[256];
     __shared__ uint64_t tile[POST_TILE + 2];
     __shared__ uint64_t s_blk[64];
-    /* The gaps of the list k_lean has left (everything that is not lean; k_post_lean below has the others).  One workgroup per gap measured
+    /* The gaps of POST_LIST (lean_and_list) (everything that is not lean; k_post_lean below has the others).  One workgroup per gap measured
      * best (against persistent workgroups): the kernel lives on the number of waves in flight -- the host sizes the grid from what the
      * previous launch listed, and the loop takes what a launch lists beyond that. */
     const uint32_t n_listed = park->count[POST_LIST];
@@ -520,7 +524,7 @@ __global__ void __launch_bounds__(64) k_emit(UStore us, FillCfg cfg, uint8_t* ra
                                              const uint8_t* __restrict__ gflags, int k, EmitDev D, EmitHost H, uint32_t* retry_list, uint32_t* general_list, uint32_t n, ParkCtl* park,
                                              uint32_t use_list)
 {
-    /* use_list: the gaps of k_lean's list (everything that is not lean: k_emit_lean has the others), the grid sized by the host from what the
+    /* use_list: the gaps of POST_LIST (everything that is not lean: k_emit_lean has the others), the grid sized by the host from what the
      * previous launch listed; otherwise (a batch that leaves in relocatable form) every slot of the launch */
     const uint32_t count = use_list ? park->count[POST_LIST] : n;
     __shared__ SlotRec r;
@@ -934,15 +938,20 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             ParkCtl* const park = d_park.as<ParkCtl>();
             HIP_TRY(hipMemsetAsync(d_park.p, 0, sizeof(ParkCtl), stream)); /* the work lists of the launch: parked gaps, gaps with commands to execute */
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
+            const bool no_lean = tune::on(tune::T_NO_LEAN); /* A/B and test hook: every contig is materialised */
+            const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
+            LeanIn li;
+            li.tle = d_tle; li.tbad = d_tbad; li.toff = d_toff; li.tcnt = d_tcnt; li.fast_ok = d_fok;
+            li.lean_allowed = (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u;
+            li.decide_parked = skip_finish ? 1u : 0u;
             {
                 if (light)
                     hipLaunchKernelGGL(k_walk, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
-                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m);
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, li);
                 else
                     hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
-                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u);
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, -1, 0u, li);
                 HIP_TRY(mark(evf));
-                const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
                 /* the bubbles of a round by one lane each: every lane of a wave is in the bubble code at the same time, and with the narrow bubbles of
                  * heterozygous data that keeps more of them in flight than a group of lanes per bubble does (round 3 measured the LDS group form
                  * k_bubble<G> here: 20-22 against 25 M/s on the indel set, 51 against 63 on tips; removed in round 5) */
@@ -950,7 +959,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     const uint32_t lin = 2u * (uint32_t)r;
                     hipLaunchKernelGGL(k_bubble_classic, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), cset, park, m, lin);
                     hipLaunchKernelGGL(k_stage_a, dim3((m + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_src, d_rw, d_roff,
-                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2);
+                                       d_rlen, d_r0, ids, d_out.as<GapOut>(), m, cset, park, m, (int)lin, lin + 2, li);
                 }
                 const uint32_t lfin = 2u * (uint32_t)rounds;
                 /* how the tail is finished: a group of lanes per parked gap, bubbles from LDS.  One lane per gap (MTG_FINISH_G=1) was measured and is
@@ -972,12 +981,12 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 const uint32_t fin_entries = (lane_finish || skip_finish) ? 0u : (uint32_t)std::min<uint64_t>(m, ((4ull * first_hint + 256ull + per_wg - 1) / per_wg) * per_wg);
                 const uint32_t nwg = (fin_entries + per_wg - 1) / per_wg;
                 if (!skip_finish && nwg) switch (fin_g) {
-                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
-                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
-                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin); break;
+                    case 8: hipLaunchKernelGGL(k_finish<8>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, li); break;
+                    case 64: hipLaunchKernelGGL(k_finish<64>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, li); break;
+                    default: hipLaunchKernelGGL(k_finish<16>, dim3(nwg), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, li); break;
                 }
                 if (!skip_finish && fin_entries < m)
-                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries);
+                    hipLaunchKernelGGL(k_finish_lane, dim3((m - fin_entries + 63) / 64), dim3(64), 0, stream, d_zero.as<uint8_t>(), d_raw.as<uint8_t>(), d_ilv.as<uint8_t>(), d_head.as<uint8_t>(), d_rw, d_roff, d_rlen, d_r0, ids, d_out.as<GapOut>(), cset, park, m, lfin, fin_entries, li);
 #ifdef MTG_BUBBLE_TIMING
                 {
                     static ParkCtl hc; static int shown = 0;
@@ -996,14 +1005,11 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(mark(evl0));
             HIP_TRY(hipGetLastError());
             /* evl0 .. evc: the long runs of the contigs, which the traversal only noted down */
-            const bool no_lean = tune::on(tune::T_NO_LEAN); /* A/B and test hook: every contig is materialised */
-            hipLaunchKernelGGL(k_lean, dim3((m + 63) / 64), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_fok,
-                               (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u, m, park, m);
-            HIP_TRY(mark(evl)); /* ev1 .. evl: k_lean; evl .. evc: k_copy */
+            HIP_TRY(mark(evl)); /* (evl0 .. evl was k_lean: the walking lanes decide now) evl .. evc: k_copy */
             hipLaunchKernelGGL(k_copy, dim3((m + 3) / 4), dim3(256), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), park, m, (uint32_t)COPY_LIST);
             HIP_TRY(mark(evc));
             const uint32_t nblocks = (m + SCAN_SL - 1) / SCAN_SL;
-            /* the lean gaps eight per wave; the others (k_lean's list) a wave each: a grid of four times what the previous launch of this workspace
+            /* the lean gaps eight per wave; the others (POST_LIST) a wave each: a grid of four times what the previous launch of this workspace
              * listed, plus 1024 (a workspace without a launch yet: one per gap), the kernel's loop takes the rest */
             const uint32_t general_hint = ws.post_general == ~0u ? m : (uint32_t)std::min<uint64_t>(m, 4ull * ws.post_general + 1024ull);
             /* The general form is the latency of a few long gaps (30 us for the one or two of a haploid batch), the lean form the throughput of all
@@ -1267,7 +1273,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                 float ms = 0, ms2 = 0, ms3 = 0, msc = 0, msf = 0, msl = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
                 HIP_TRY(hipEventElapsedTime(&msf, evf, ev1));
-                HIP_TRY(hipEventElapsedTime(&msc, evl0, evc)); /* k_lean + k_copy */
+                HIP_TRY(hipEventElapsedTime(&msc, evl0, evc)); /* k_copy (k_lean's share is the walk kernels' now) */
                 HIP_TRY(hipEventElapsedTime(&msl, evl0, evl));
                 HIP_TRY(hipEventElapsedTime(&ms2, evc, eve));
                 HIP_TRY(hipEventElapsedTime(&ms3, eve, ev2));

@@ -68,7 +68,7 @@ struct GapScratch {
     uint8_t* v; /* work areas of the bubble code, interleaved over the 64 lanes of a wave: element i of lane l sits at (i * 64 + l), so
                    that lanes touching the same index (frontline slot, DFS depth, ...) make one coalesced request instead of 64 */
     uint8_t* h; /* the small per-gap arrays every kernel of a launch reads or writes -- contig starts / lengths / terminal info, the queue, the copy
-                   commands, the lean record --, interleaved over 64 consecutive gaps like v: with a gap per lane (the walk, k_lean) or a few lanes per gap
+                   commands, the lean record --, interleaved over 64 consecutive gaps like v: with a gap per lane (the walk and its lean decision) or a few lanes per gap
                    (k_post_lean, k_emit_lean) neighbouring lanes touch neighbouring bytes, and a write of element 0 by the 64 lanes of a wave fills whole
                    memory lines (contiguous per gap, every such write dirtied a line of its own: 620 bytes written per gap for some 100 of content) */
     uint32_t lane;
