@@ -903,7 +903,7 @@ def main():
     sa_parts = {"adj_bucket_reads_x_%dB" % bucket: acc["index_lines"] / Ln * bucket, "unitig_store_word_reads_x_8B": acc["store_runs"] / Ln * 8, "unitig_sequence_2bit_taken_by_lanes": lane_nt / Ln / 4,
                 "contig_words_written_by_lanes_x_8B": (acc["contig_words"] - acc["copy_words"]) / Ln * 8, "copy_commands_x_24B": acc["copy_cmds"] / Ln * 24,
                 "per_gap_input_and_record": gaps_l * (8 + 8 + 4 + 4 + 16 + 36), "parked_gap_state_x_2x176B": acc["n_parked_gaps"] / Ln * 352}
-    # k_lean, one gap per lane: the gap's record, its target (k-mer, mask, offsets), the ADJ bucket of the target's junction, contig length / start, its commands, the 16-byte LeanRec it leaves
+    # the lean decision (by the walking lane; the kernel k_lean until late round 5): the gap's record, its target (k-mer, mask, offsets), the ADJ bucket of the target's junction, contig length / start, its commands, the 16-byte LeanRec it leaves
     ln_parts = {"per_gap_record_target_and_leanrec": gaps_l * (36 + 25 + 8 + 16), "adj_bucket_of_the_target_x_%dB" % bucket: gaps_l * bucket, "copy_commands_read_x_24B": acc["copy_cmds"] / Ln * 24}
     # k_copy, one wave per LISTED gap (the gaps that are not lean): only their commands are executed
     listed = max(gaps_l - n_lean_l, 0.0)
@@ -913,8 +913,8 @@ def main():
                 "coverage_abundance_bytes": acc["coverage_kmers"] / Ln, "coverage_kmer_check_of_looked_up_blocks": (acc["coverage_kmers"] - acc["coverage_direct_kmers"]) / Ln * 0.25 * (1 + k / 64.0),
                 "per_gap_gapout_target_leanrec_command_read": gaps_l * (36 + 26 + 16 + 24), "per_gap_slot_record_written_160B_and_rewritten_by_the_scan_48B": gaps_l * (160 + 160 + 48)}
     em_parts = {"ascii_written": acc["seq_bytes"] / Ln, "sequence_2bit_read": acc["seq_bytes"] / Ln / 4, "per_gap_records": n_lean_l * (160 + 56 + 40) + listed * (160 + 160 + 56 + 40), "dense_contigs_x_16B": acc["dense_words"] / Ln * 16}
+    sa_parts.update({"lean_decision_" + pk: pv for pk, pv in ln_parts.items()})  # the walking lane decides the lean form at the end of its walk (k_lean until late round 5)
     kerns = [kern("k_stage_a(+k_finish)", acc["kernel_ms"] / Ln, alone_ms("kernel_ms"), sum(sa_parts.values()), sa_parts),
-             kern("lean decision (in the walk kernels since late round 5: time 0, bytes counted here)", acc["lean_kernel_ms"] / Ln, alone_ms("lean_kernel_ms"), sum(ln_parts.values()), ln_parts),
              kern("k_copy", (acc["copy_kernel_ms"] - acc["lean_kernel_ms"]) / Ln, alone_ms("copy_kernel_ms", "-lean_kernel_ms"), sum(cp_parts.values()), cp_parts),
              kern("k_post(+k_post_lean,k_scan1,k_scan2)", acc["post_kernel_ms"] / Ln, alone_ms("post_kernel_ms"), sum(po_parts.values()), po_parts),
              kern("k_emit(+k_emit_lean)", acc["emit_kernel_ms"] / Ln, alone_ms("emit_kernel_ms"), sum(em_parts.values()), em_parts)]
@@ -936,9 +936,17 @@ def main():
         pj = json.load(open(pmc))
         fill_kernels = ("k_stage_a", "k_walk", "k_finish", "k_bubble", "k_lean", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
         by_kernel = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pj.get("kernels", {}).items() if kn.split("::")[-1].startswith(fill_kernels)}
+        # a launch starts with k_walk OR k_stage_a (the light or the full walk kernel): their two averages are one entry, weighted by their launches
+        n_by = {kn.split("::")[-1]: kv.get("launches_FETCH_SIZE", 0) for kn, kv in pj.get("kernels", {}).items()}
+        if by_kernel.get("k_walk") and by_kernel.get("k_stage_a"):
+            nw_, ns_ = n_by.get("k_walk", 0), n_by.get("k_stage_a", 0)
+            by_kernel["k_stage_a"] = (by_kernel["k_walk"] * nw_ + by_kernel["k_stage_a"] * ns_) / max(nw_ + ns_, 1)
+            by_kernel["k_walk_or_k_stage_a_launches"] = {"k_walk": nw_, "k_stage_a": ns_, "k_walk_bytes_per_launch": by_kernel.pop("k_walk")}
+        elif by_kernel.get("k_walk"):
+            by_kernel["k_stage_a"] = by_kernel.pop("k_walk")
         # `traffic`: HBM bytes per launch of the dominant kernel (with the scans it is reported with); every kernel of a fill under traffic_by_kernel
         dk = dom["kernel"].split("(")[0]
-        roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and (kn == dk or (dk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (dk == "k_emit" and kn == "k_emit_lean") or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble", "k_walk"))))) or None
+        roof["traffic"] = sum(v for kn, v in by_kernel.items() if v and not isinstance(v, dict) and (kn == dk or (dk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (dk == "k_emit" and kn == "k_emit_lean") or (dk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble", "k_walk"))))) or None
         roof["traffic_by_kernel"] = by_kernel
         roof["traffic_is"] = "REPLAYED, not measured in this run: counters cannot be read from inside the process"
         roof["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, no trace domain, the bench command of scripts/profile_round5.sh, HEAD %s): "
@@ -947,7 +955,7 @@ def main():
                                   % (os.path.relpath(pmc, ROOT), pj.get("head", "?")))
         for kr in kerns:
             tk = kr["kernel"].split("(")[0]
-            tv = sum(v for kn, v in by_kernel.items() if v and (kn == tk or (tk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (tk == "k_emit" and kn == "k_emit_lean") or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble", "k_walk")))))
+            tv = sum(v for kn, v in by_kernel.items() if v and not isinstance(v, dict) and (kn == tk or (tk == "k_post" and kn in ("k_post_lean", "k_scan1", "k_scan2")) or (tk == "k_emit" and kn == "k_emit_lean") or (tk == "k_stage_a" and kn.startswith(("k_finish", "k_bubble", "k_walk")))))
             kr["traffic"] = tv or None
             kr["traffic_over_bytes"] = (tv / kr["bytes_per_launch"]) if tv and kr["bytes_per_launch"] else None
             # the fabric serves (and FETCH_SIZE counts) a scattered read as a 64-byte request: the same layout with every bucket read at 64 B
@@ -961,7 +969,7 @@ def main():
                                               "equivalent_GBps_of_k_stage_a": 64.0 * probes_per_nt * acc["contig_nt"] / Ln / max((alone_ms("kernel_ms") or acc["kernel_ms"] / Ln) * 1e-3, 1e-12) / 1e9,
                                               "note": "a step does not move these bytes (frac would exceed 1): the walk reads the unitig store the index build derived from the k-mer set; see index_build"}
     if st_alone:
-        roof["one_batch_alone_ms"] = {"k_stage_a+k_finish": st_alone["kernel_ms"] / nl1, "k_finish": st_alone["finish_kernel_ms"] / nl1, "k_lean": st_alone["lean_kernel_ms"] / nl1,
+        roof["one_batch_alone_ms"] = {"k_stage_a+k_finish": st_alone["kernel_ms"] / nl1, "k_finish": st_alone["finish_kernel_ms"] / nl1, "event_gap_before_k_copy": st_alone["lean_kernel_ms"] / nl1,
                                       "k_copy": (st_alone["copy_kernel_ms"] - st_alone["lean_kernel_ms"]) / nl1,
                                       "k_post+scans": st_alone["post_kernel_ms"] / nl1, "k_emit": st_alone["emit_kernel_ms"] / nl1, "parked_gaps": st_alone["n_parked_gaps"] / nl1,
                                       "sum": (st_alone["kernel_ms"] + st_alone["copy_kernel_ms"] + st_alone["post_kernel_ms"] + st_alone["emit_kernel_ms"]) / nl1,
@@ -1018,7 +1026,7 @@ def main():
            "filled": R0["n_filled"], "sites_verified": R0["n_sites"] if R0["identical"] is not None else None, "sites_run_in_the_untimed_pass": R0["n_sites"],
            "filled_per_s": value * R0["n_filled"] / max(R0["n_sites"], 1),
            "filled_sequences_identical_to_truth": R0["identical"], "gathered_payload_verified": R0["gathered"],
-           "stage_ms_per_batch": {"k_stage_a+k_finish": acc["kernel_ms"] / Ln, "k_finish": acc["finish_kernel_ms"] / Ln, "parked_gaps": acc["n_parked_gaps"] / Ln, "lean_gaps": acc["n_lean_gaps"] / Ln, "k_lean": acc["lean_kernel_ms"] / Ln, "k_copy": (acc["copy_kernel_ms"] - acc["lean_kernel_ms"]) / Ln,
+           "stage_ms_per_batch": {"k_stage_a+k_finish": acc["kernel_ms"] / Ln, "k_finish": acc["finish_kernel_ms"] / Ln, "parked_gaps": acc["n_parked_gaps"] / Ln, "lean_gaps": acc["n_lean_gaps"] / Ln, "event_gap_before_k_copy": acc["lean_kernel_ms"] / Ln, "k_copy": (acc["copy_kernel_ms"] - acc["lean_kernel_ms"]) / Ln,
                                   "k_post+scans": acc["post_kernel_ms"] / Ln, "k_emit": acc["emit_kernel_ms"] / Ln, "d2h": acc["d2h_ms"] / Ln,
                                   "host": acc["host_ms"] / Ln, "c_call": acc["total_ms"] / Ln, "first_kernel_to_last": acc["device_span_ms"] / Ln,
                                   "note": "kernel columns are 0 unless KERNEL_TIMERS is set: the timed blocks record three events per batch; roofline.one_batch_alone_ms has every kernel's own time"},
