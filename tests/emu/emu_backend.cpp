@@ -586,7 +586,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                         D2.seq = (char*)((uintptr_t)(tmp.data() + 16) - (uintptr_t)recs[s].abase); D2.seq_cap = recs[s].abase + recs[s].asc;
                         D2.res = &g2; D2.fil = &f2;
                         emit_lean<1>(idx->dev.us, cfg, S, recs[s], recs[s].abase, in.flags[ids[s]], 0, ids[s], k, D2, H, 0u);
-                        if (memcmp(tmp.data() + 16, D.seq + recs[s].abase, recs[s].asc) != 0 || memcmp(&g2, &D.res[s], sizeof g2) != 0 || memcmp(&f2, &D.fil[s], sizeof f2) != 0) {
+                        /* field by field: the structs have padding (behind n_filled, at the end of mtg_filled) that neither form writes */
+                        const mtg_gap_result& g1 = D.res[s];
+                        const mtg_filled& f1 = D.fil[s];
+                        const bool same_res = g2.nb_nodes == g1.nb_nodes && g2.total_nt == g1.total_nt && g2.nb_terminal == g1.nb_terminal && g2.has_solution_counts == g1.has_solution_counts &&
+                                              g2.nb_total_filled == g1.nb_total_filled && g2.nb_reported == g1.nb_reported && g2.n_filled == g1.n_filled && g2.filled == g1.filled && g2.extension == g1.extension;
+                        const bool same_fil = f2.seq == f1.seq && f2.nb_errors_in_anchor == f1.nb_errors_in_anchor && f2.target_index == f1.target_index && f2.avg_coverage == f1.avg_coverage &&
+                                              f2.median_coverage == f1.median_coverage && f2.qual == f1.qual && f2.solution_count == f1.solution_count && f2.solution_rank == f1.solution_rank;
+                        if (memcmp(tmp.data() + 16, D.seq + recs[s].abase, recs[s].asc) != 0 || !same_res || !same_fil) {
                             set_error("gap %u: the lean form of the result kernel and the general one disagree", ids[s]);
                             return MTG_ERR_OVERFLOW;
                         }
