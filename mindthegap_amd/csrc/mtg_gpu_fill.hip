@@ -89,13 +89,19 @@ struct LeanIn {
     uint32_t lean_allowed;
     uint32_t decide_parked;   /* diagnostics (DEBUG_SKIP_FINISH): nobody will finish the parked gaps, the first walk lists them as they are */
 };
-__device__ __forceinline__ void lean_and_list(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint32_t g, uint32_t slot, bool decides, const LeanIn& li, ParkCtl* park, uint32_t cap)
+/* the gap's single target k-mer (forward value) when the lean form may be used -- one usable target and a source of exactly k nucleotides (what the
+ * common-case result of k_post needs anyway) --, ~0 otherwise.  Read BEFORE the walk: two dependent rounds of input reads that would otherwise sit
+ * behind it */
+__device__ __forceinline__ uint64_t lean_target(const LeanIn& li, uint32_t g, int k)
+{
+    uint64_t target = ~0ull;
+    if (li.lean_allowed && li.tcnt[g] == 1u && li.fast_ok[g] && li.tbad[li.toff[g]] == 0ull) target = rev_fields64(li.tle[li.toff[g]]) >> (64 - 2 * k);
+    return target;
+}
+__device__ __forceinline__ void lean_and_list(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, uint64_t target, uint32_t slot, bool decides, ParkCtl* park, uint32_t cap)
 {
     bool need = false, general = false;
     if (decides) {
-        /* the lean form needs one usable target and a source of exactly k nucleotides (what the common-case result of k_post needs anyway) */
-        uint64_t target = ~0ull;
-        if (li.lean_allowed && li.tcnt[g] == 1u && li.fast_ok[g] && li.tbad[li.toff[g]] == 0ull) target = rev_fields64(li.tle[li.toff[g]]) >> (64 - 2 * ix.k);
         need = lean_decide(ix, cfg, S, o, target);
         general = !s_lean(cfg, S)[0].valid;
     }
@@ -130,6 +136,7 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
     const uint64_t t0 = wall_clock64();
 #endif
     uint32_t met = 0;
+    const uint64_t target = lean_target(li, g, ix.k);
     stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr, in_list >= 0, &met);
 #ifdef MTG_BUBBLE_TIMING
     if (MODE == WALK_PARK && in_list >= 0) timing_note(park->hist_walk_lane, park->hist_walk_wave, t0);
@@ -140,7 +147,7 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
         if (bm && (int)(threadIdx.x & 63u) == __ffsll((long long)bm) - 1) atomicAdd(&park->n_branching, (uint32_t)__popcll(bm));
     }
     if (MODE == WALK_PARK || MODE == WALK_SIMPLE) park_append(park, cap, out_list, o.status == GAP_PARKED, slot);
-    lean_and_list(ix, cfg, S, o, g, slot, o.status != GAP_PARKED || li.decide_parked != 0u, li, park, cap);
+    lean_and_list(ix, cfg, S, o, target, slot, o.status != GAP_PARKED || li.decide_parked != 0u, park, cap);
 }
 /* the light walk kernel (WALK_SIMPLE): simple paths only, every branching node parks the gap.  No bubble code in its call graph */
 __global__ void __launch_bounds__(64) k_walk(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords,
@@ -207,9 +214,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_FIN
     R.rlen = rlen[g];
     R.r0 = r0[g];
     GapOut o;
+    const uint64_t target = lean_target(li, g, ix.k);
     stage_a_walk<WALK_FINISH, G>(ix, cfg, S, 0, R, o, &lds[lane / G]);
     if (gl == 0) out[slot] = o;
-    lean_and_list(ix, cfg, S, o, g, slot, gl == 0, li, park, cap);
+    lean_and_list(ix, cfg, S, o, target, slot, gl == 0, park, cap);
 }
 
 /* the same with one LANE per parked gap and the general code on HBM scratch (A/B hook, MTG_FINISH_G=1): the group form is faster even
@@ -231,9 +239,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
     R.rlen = rlen[g];
     R.r0 = r0[g];
     GapOut o;
+    const uint64_t target = lean_target(li, g, ix.k);
     stage_a_walk<WALK_FINISH, 1>(ix, cfg, S, 0, R, o, nullptr);
     out[slot] = o;
-    lean_and_list(ix, cfg, S, o, g, slot, true, li, park, cap);
+    lean_and_list(ix, cfg, S, o, target, slot, true, park, cap);
 }
 
 /* the long runs the traversal left as commands (mtg_copy.h), for the gaps on COPY_LIST (lean_and_list above).  k_copy, one wave per listed gap, four per
