@@ -1315,6 +1315,14 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     (double)hs[6] / hs[15], (double)hs[12] / hs[15], (double)hs[7] / hs[15], (double)hs[10] / hs[15], (double)hs[14] / hs[15], (double)hs[13] / hs[15], (double)hs[11] / hs[15]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_stamps), z, sizeof z);
+        unsigned long long ff[16];
+        if (hipMemcpyFromSymbol(ff, HIP_SYMBOL(mtg::g_forms), sizeof ff) == hipSuccess && ff[15]) {
+            const char* nm[7] = {"merge_fast", "marked-successor test", "first reads of both branches", "tip_fast", "indel_bulk", "snp_bulk", "step-by-step loop"};
+            fprintf(stderr, "  [stamps] fast forms per lane (%llu lanes):", ff[15]);
+            for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.2f calls x %.0f ticks;", nm[i], (double)ff[2 * i + 1] / ff[15], ff[2 * i + 1] ? (double)ff[2 * i] / ff[2 * i + 1] : 0.0);
+            fprintf(stderr, " loop steps per lane %.2f\n", (double)ff[14] / ff[15]);
+        }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_forms), z, sizeof z);
         unsigned long long fe[16];
         if (hipMemcpyFromSymbol(fe, HIP_SYMBOL(mtg::g_fe), sizeof fe) == hipSuccess && fe[0])
             fprintf(stderr, "  [stamps] find_end_of_branching: %llu calls; per call: levels %.2f nodes %.2f skips %.2f | ticks: skip section %.0f (left junction %.0f) children from the store %.0f ADJ read + run set-up %.0f visited set + involved list %.0f\n",

@@ -294,12 +294,17 @@ __device__ unsigned int g_dbg[64];
 /* diagnostic build (-DMTG_STAMPS): shader-clock time per phase, summed over lanes into a global array (never in the product build) */
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_forms[16]; /* the fast forms in detail, ticks and calls: [0,1] merge_fast [2,3] marked-successor test [4,5] first reads of the two branches [6,7] tip_fast [8,9] indel_bulk [10,11] snp_bulk [12,13] the step-by-step loop [14] its steps [15] lanes */
 __device__ unsigned long long g_fe[16]; /* find_end_of_branching in detail: [0] calls [1] levels [2] skip section [3] left junction [4] children known from the store [5] ADJ read + run set-up [6] visited set + involved list [7] nodes [8] skips */
 __device__ unsigned long long g_life[40]; /* [0..31]: lanes by log2 of their life in clock ticks; [32] earliest start, [33] latest end (0 = unset) */
 #define MTG_T0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
 #define MTG_T1(v, slot) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[slot] += t_ - v; } while (0)
 #define MTG_COUNT(W_, slot) ((W_).stamp_acc[slot] += 1ull)
+#define MTG_F0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
+#define MTG_F1(W_, v, slot) do { (W_).form_acc[slot] += __builtin_amdgcn_s_memtime() - v; (W_).form_acc[(slot) + 1] += 1ull; } while (0)
 #else
+#define MTG_F0(v)
+#define MTG_F1(W_, v, slot)
 #define MTG_T0(v)
 #define MTG_T1(v, slot)
 #define MTG_COUNT(W_, slot)
@@ -319,6 +324,7 @@ struct Worker {
     bool no_dp = false; /* the SNP fast path gives up where it would need the alignment itself (the walk kernel: the bubble is then parked) */
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     unsigned long long stamp_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long form_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     MTG_DEV Worker(const Index& i, const FillCfg& c, const GapScratch& s)
@@ -1641,13 +1647,16 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
 {
     if (!W.S.snp_fast || W.cfg.end_rule_nonbranching) return 0;
     if (popc4(a.out) == 1) {
+        MTG_F0(f_m);
         const int mn = merge_fast(W, cur, prev_c, a, chosen_seq);
+        MTG_F1(W, f_m, 0);
         if (mn > 0) { chosen = 0; MTG_COUNT(W, 14); }
         return mn;
     }
     {   /* a successor that is marked (and not seen already: the node's reverse complement, the previous node): the reference's frontline gives up on
          * its first step, whatever else leaves the node -- "no consensus", nothing marked */
         const uint64_t cc = canon(cur);
+        MTG_F0(f_ms);
         for (uint32_t em = a.out & 15u; em; em &= em - 1u) {
             const uint64_t cs = canon(kmer_next(cur, low_nt(em), W.k, W.mk));
             if (cs == cc || cs == prev_c || !W.is_marked(cs)) continue;
@@ -1657,6 +1666,7 @@ MTG_DEV_NOINLINE int snp_bubble_fast(Worker& W, const Kmer& cur, uint64_t prev_c
 #endif
             return -1;
         }
+        MTG_F1(W, f_ms, 2);
     }
     if (!(popc4(a.out) == 2 && popc4(a.in) == 1)) return 0;
     /* Pairwise distinctness of the canonical k-mers without a set.  Branch nodes have one in- and one out-edge, so do their reverse
@@ -1704,19 +1714,27 @@ MTG_UNROLL
     be.f = be.r = 0;
     bseq[0].lo = bseq[0].hi = bseq[1].lo = bseq[1].hi = 0;
     if (W.ix.us.nwords) {
+        MTG_F0(f_r1);
         adj_right2_raw(W.ix, x[0], x[1], W.mk1, W.lines, r1[0], r1[1]);
+        MTG_F1(W, f_r1, 4);
         have_r1 = true;
         {   /* a tip first (one branch dies within k nodes, the other goes on): answered on the spot */
+            MTG_F0(f_t);
             const int tn = tip_fast(W, cur, prev_c, x, nt0, r1, chosen_seq);
+            MTG_F1(W, f_t, 6);
             if (W.status) return 0;
             if (tn > 0) { chosen = 0; MTG_COUNT(W, 14); return tn; }
         }
         {   /* two unitig branches of different lengths onto one node: an insertion / deletion, answered or refused on the spot (-1: no consensus) */
+            MTG_F0(f_i);
             const int in_ = indel_bulk(W, cur, prev_c, x, nt0, r1, chosen_seq);
+            MTG_F1(W, f_i, 8);
             if (W.status) return 0;
             if (in_ != 0) { chosen = 0; return in_; }
         }
+        MTG_F0(f_s);
         bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be, hopeless);
+        MTG_F1(W, f_s, 10);
 #ifndef MTG_XCHECK
         if (hopeless) return 0;
 #endif
@@ -1729,11 +1747,22 @@ MTG_UNROLL
 #define MTG_SNP_FAIL(code) do { if (bulk_ok && (code) != 1) W.status = 0xBAD3; return 0; } while (0)
 #else
     const bool run_loop = !bulk_ok;
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+#define MTG_SNP_FAIL(code) do { W.form_acc[12] += __builtin_amdgcn_s_memtime() - f_loop0; return 0; } while (0)
+#else
 #define MTG_SNP_FAIL(code) return 0
+#endif
 #endif
     if (!run_loop) { L = bL; h = bh; seq[0] = bseq[0]; seq[1] = bseq[1]; sum[0] = bsum[0]; sum[1] = bsum[1]; x[0] = be; }
     else if (have_r1) { adj_resolve_la(W.ix, r1[0], W.lines); adj_resolve_la(W.ix, r1[1], W.lines); }
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    const unsigned long long f_loop0 = __builtin_amdgcn_s_memtime();
+    if (run_loop) W.form_acc[13] += 1ull;
+#endif
     for (int step = 1; run_loop && step <= SNP_MAX_L; step++) {
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+        W.form_acc[14] += 1ull;
+#endif
         /* the nodes at position `step` of both branches: unmarked, new; their single out-edges (both bucket reads in flight together) */
         uint32_t nt[2];
         Adj r[2];
@@ -1774,6 +1803,9 @@ MTG_UNROLL
         x[1] = y1;
     }
     if (L == 0) MTG_SNP_FAIL(2);
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    if (run_loop) W.form_acc[12] += __builtin_amdgcn_s_memtime() - f_loop0;
+#endif
 #ifdef MTG_XCHECK
     if (hopeless) { W.status = 0xBAD8; return 0; } /* the bulk form gave up on a bubble the loop answers */
 #endif
@@ -2658,6 +2690,8 @@ MTG_UNROLL
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     for (int i = 0; i < 15; i++) atomicAdd(&g_stamps[i], W.stamp_acc[i]);
     atomicAdd(&g_stamps[15], 1ull);
+    for (int i = 0; i < 15; i++) if (W.form_acc[i]) atomicAdd(&g_forms[i], W.form_acc[i]);
+    atomicAdd(&g_forms[15], 1ull);
     {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime(), life = t_end - t_life0;
         atomicAdd(&g_life[63 - __clzll(life | 1ull)], 1ull);
