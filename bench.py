@@ -216,7 +216,7 @@ def main():
     import torch.distributed as dist
     import mindthegap_amd as mtg
     from mindthegap_amd import lib as L
-    from mindthegap_amd.shard import PipelinedGather, SlottedGather, shard_range, wire_check
+    from mindthegap_amd.shard import PipelinedGather, SlottedGather, gather_slots_for, shard_range, strong_plan, wire_check
     from mindthegap_amd.synth import SynthSet
 
     # the ranks of a node share its CPUs (and, in a container, one CFS quota): each rank's worker pool gets its share
@@ -268,13 +268,10 @@ def main():
         big = min(nloci0, 6 * batch_sites)
         sets = [a.strong_sites] if a.strong_sites else [big] + ([batch_sites] if big != batch_sites else [])
         for total_sites in sets:
-            lo, hi = shard_range(total_sites, rank, world)
-            bs = min(batch_sites, max(1, (total_sites + world - 1) // world))
-            # global batch index = position of the batch in site order: rank r's batches follow those of the ranks before it
-            per_rank = [(shard_range(total_sites, r, world)[1] - shard_range(total_sites, r, world)[0] + bs - 1) // bs for r in range(world)]
-            first = sum(per_rank[:rank])
-            my = [(first + i, s, min(s + bs, hi)) for i, s in enumerate(range(lo, hi, bs))]
-            configs.append(dict(total=total_sites, my=my, step_sites=total_sites, rotate=False, n_batches_job=sum(per_rank), max_per_rank=max(per_rank)))
+            # global batch index = position of the batch in site order: rank r's batches follow those of the ranks before it (shard.py: strong_plan,
+            # exercised at world sizes 2 and 8 by tests/test_distributed_cpu.py)
+            pl_ = strong_plan(total_sites, batch_sites, rank, world)
+            configs.append(dict(total=total_sites, my=pl_["my"], step_sites=total_sites, rotate=False, n_batches_job=pl_["n_batches_job"], max_per_rank=pl_["max_per_rank"]))
     else:
         nb = max(1, min(a.batches, nloci0 // (batch_sites * world)))
         my = [(rank * nb + b, (rank * nb + b) * batch_sites, (rank * nb + b + 1) * batch_sites) for b in range(nb)]
@@ -481,7 +478,8 @@ def main():
             cap = torch.tensor([need], dtype=torch.int64, device=cdev)
             dist.all_reduce(cap, op=dist.ReduceOp.MAX)
             # several payloads per collective when a rank has several batches per step (the orchestration of a gather, not its bytes, is what a rank pays per batch)
-            slots = int(os.environ.get("MTG_BENCH_GATHER_SLOTS", "0")) or (min(6, cfg["max_per_rank"]) if cfg["max_per_rank"] >= 3 else 1)  # measured on one RCCL rank: 94 M/s with 1 slot, 76 with 3, 101 with 6 (one collective per step)
+            slots, depth = gather_slots_for(cfg["max_per_rank"], a.in_flight)  # measured on one RCCL rank: 94 M/s with 1 slot, 76 with 3, 101 with 6 (one collective per step)
+            slots = int(os.environ.get("MTG_BENCH_GATHER_SLOTS", "0")) or slots
             depth = int(os.environ.get("MTG_BENCH_GATHER_DEPTH", "0")) or (max(a.in_flight, 1) + 1 if slots == 1 else max(3, (max(a.in_flight, 1) + slots - 1) // slots + 2))
             cap_p = int(cap.item()) * 51 // 50 + (1 << 16)
             if slots > 1:

@@ -1330,13 +1330,17 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_fe), z, sizeof z);
         unsigned long long lf[40];
         if (hipMemcpyFromSymbol(lf, HIP_SYMBOL(mtg::g_life), sizeof lf) == hipSuccess) {
-            fprintf(stderr, "  [stamps] traversal kernel: %llu ticks from the first lane's start to the last lane's end (%.3f ms of events); lanes by log2(life in ticks):", lf[33] - lf[32], st.kernel_ms);
+            fprintf(stderr, "  [stamps] traversal kernel: %llu ticks from the first lane's start to the last lane's end (%.3f ms of events); lanes by log2(life in ticks):", lf[33] - ~lf[32], st.kernel_ms);
             for (int i = 10; i < 32; i++) if (lf[i]) fprintf(stderr, " 2^%d:%llu", i, lf[i]);
             fprintf(stderr, "\n");
         }
         unsigned long long z2[40] = {0};
-        z2[32] = ~0ull;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_life), z2, sizeof z2);
+        unsigned long long ph[8];
+        if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(mtg::g_phase), sizeof ph) == hipSuccess && hs[15])
+            fprintf(stderr, "  [stamps] outside W and B, per lane: contig starts %.2f x %.0f ticks; phase E %.2f x %.0f ticks; flat-loop iterations %.2f; from the lane's last iteration to the wave's end %.0f ticks\n",
+                    (double)ph[1] / hs[15], ph[1] ? (double)ph[0] / ph[1] : 0.0, (double)ph[3] / hs[15], ph[3] ? (double)ph[2] / ph[3] : 0.0, (double)ph[4] / hs[15], (double)ph[5] / hs[15]);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mtg::g_phase), z2, sizeof ph);
     }
 #endif
     if (while_busy && !busy_done) (*while_busy)();

@@ -791,6 +791,7 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
         return true;
     };
     std::vector<char> on_device(ng, 0);
+    std::atomic<bool> no_contigs{false};
     /* TEST-ONLY (HostChunk::gen_check, set by the emulation's device_run): the gaps the device function finished ALSO take the host's path, in
      * `check`, and the two answers are compared at the end */
     std::vector<GapWork> check;
@@ -803,8 +804,13 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
         const SpecialGap& sg = special.special[i];
         describe(sg.gap, work[i]);
         if (from_device(sg, work[i])) { on_device[i] = 1; return; }
+        /* the host's path needs the gap's contigs: a launch whose multi-contig gaps the device all finished did not bring them (device_run copies
+         * them when a gap came back GEN_HOST).  A finished gap the host cannot take over -- two targets under one name are screened out before the
+         * launch (FillInput::host_general), so this is a malformed answer -- is an error of the batch, not a read through a null pointer. */
+        if (!special.chunks[sg.chunk]->recs) { no_contigs.store(true, std::memory_order_relaxed); return; }
         genw[i] = process_general(special.view(sg), work[i], k);
     }, 1);
+    if (no_contigs.load()) { set_error("a multi-contig gap the device reported finished could not be taken from its answer, and its contigs are not on the host"); return MTG_ERR_FORMAT; }
     if (!check_of.empty()) {
         DevBatch sub; /* the same gaps as a batch of their own with the device's answers hidden: run_general's host path, whole */
         for (size_t i : check_of) {

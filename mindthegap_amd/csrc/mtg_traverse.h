@@ -296,7 +296,8 @@ __device__ unsigned int g_dbg[64];
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_forms[16]; /* the fast forms in detail, ticks and calls: [0,1] merge_fast [2,3] marked-successor test [4,5] first reads of the two branches [6,7] tip_fast [8,9] indel_bulk [10,11] snp_bulk [12,13] the step-by-step loop [14] its steps [15] lanes */
 __device__ unsigned long long g_fe[16]; /* find_end_of_branching in detail: [0] calls [1] levels [2] skip section [3] left junction [4] children known from the store [5] ADJ read + run set-up [6] visited set + involved list [7] nodes [8] skips */
-__device__ unsigned long long g_life[40]; /* [0..31]: lanes by log2 of their life in clock ticks; [32] earliest start, [33] latest end (0 = unset) */
+__device__ unsigned long long g_life[40]; /* [0..31]: lanes by log2 of their life in clock ticks; [32] ~(earliest start), [33] latest end (0 = unset) */
+__device__ unsigned long long g_phase[8]; /* the flat loop outside W and B: [0] ticks starting a contig (pop, first neighbourhood, the target's place) [1] contigs started [2] ticks in phase E (close, push successors) [3] contigs closed [4] iterations of the flat loop [5] ticks from the lane's own last iteration to the wave's end */
 #define MTG_T0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
 #define MTG_T1(v, slot) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[slot] += t_ - v; } while (0)
 #define MTG_COUNT(W_, slot) ((W_).stamp_acc[slot] += 1ull)
@@ -325,6 +326,7 @@ struct Worker {
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     unsigned long long stamp_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long form_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long phase_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
 
     MTG_DEV Worker(const Index& i, const FillCfg& c, const GapScratch& s)
@@ -2325,12 +2327,22 @@ MTG_UNROLL
         a_is_cur = true;
     }
     MTG_GUARD_DECL(g_flat);
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+    unsigned long long t_last_iter = t_life0;
+#endif
     for (;;) {
         MTG_GUARD(g_flat, 200000u, 1, { W.status = 0xD1E; break; });
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+        W.phase_acc[4] += 1ull;
+        t_last_iter = __builtin_amdgcn_s_memtime();
+#endif
         bool end_contig = false;
         if (!resuming) {
         if (!in_contig) {
             if (!(head < tail) || W.status != GAP_OK) break;
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+            const unsigned long long t_cs0 = __builtin_amdgcn_s_memtime();
+#endif
             const uint64_t node_f = q_f[head];
             node_depth = q_d[head];
             head++;
@@ -2356,6 +2368,9 @@ MTG_UNROLL
                 locate(e, r_base, r_idx, r_fwd);
             }
             in_contig = true;
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+            W.phase_acc[0] += __builtin_amdgcn_s_memtime() - t_cs0; W.phase_acc[1] += 1ull;
+#endif
         }
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
         unsigned long long* stamp_acc = W.stamp_acc;
@@ -2660,6 +2675,10 @@ MTG_UNROLL
         MTG_T1(t_b, 1);
         if (!end_contig) continue;
         /* ---- phase E: the contig is complete ---- */
+#if defined(MTG_STAMPS) && !defined(MTG_EMU)
+        const unsigned long long t_e0 = __builtin_amdgcn_s_memtime();
+        struct PhaseE { unsigned long long t0; unsigned long long* acc; __device__ ~PhaseE() { acc[2] += __builtin_amdgcn_s_memtime() - t0; acc[3] += 1ull; } } phase_e_{t_e0, W.phase_acc};
+#endif
         in_contig = false;
         flush();
         if (ovf) W.status = GAP_OVF_CONTIG;
@@ -2701,8 +2720,10 @@ MTG_UNROLL
     {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime(), life = t_end - t_life0;
         atomicAdd(&g_life[63 - __clzll(life | 1ull)], 1ull);
-        atomicMin(&g_life[32], t_life0);
+        atomicMax(&g_life[32], ~t_life0);
         atomicMax(&g_life[33], t_end);
+        W.phase_acc[5] = t_end - t_last_iter;
+        for (int i = 0; i < 6; i++) atomicAdd(&g_phase[i], W.phase_acc[i]);
     }
 #endif
     /* leave the zero-initialised region as it was found, whatever the exit path (a parked walk keeps its marked set: it goes on) */

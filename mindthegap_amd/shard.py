@@ -13,6 +13,31 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def strong_plan(total_sites, batch_sites, rank, world):
+    """Strong scaling of one fixed site set (bench.py, BASELINE config 5): the sites are sharded contiguously over the ranks (shard_range), a
+    rank cuts its shard into batches of at most `batch_sites` sites, and a batch's GLOBAL index is its position in site order -- rank r's
+    batches follow those of the ranks before it -- so that rank 0 can put gathered payloads back in input order by their tags.  Returns
+    {my: [(global batch index, first site, end site)], per_rank: batches of every rank, n_batches_job, max_per_rank}: a rank with fewer
+    batches than max_per_rank pads its gathers (every rank must issue the same collectives)."""
+    lo, hi = shard_range(total_sites, rank, world)
+    bs = min(batch_sites, max(1, (total_sites + world - 1) // world))
+    per_rank = []
+    for r in range(world):
+        l, h = shard_range(total_sites, r, world)
+        per_rank.append((h - l + bs - 1) // bs)
+    first = sum(per_rank[:rank])
+    my = [(first + i, s, min(s + bs, hi)) for i, s in enumerate(range(lo, hi, bs))]
+    return dict(my=my, per_rank=per_rank, n_batches_job=sum(per_rank), max_per_rank=max(per_rank) if per_rank else 0, batch_sites=bs)
+
+
+def gather_slots_for(max_per_rank, in_flight):
+    """(slots, depth) of the gather bench.py uses for a rank with up to max_per_rank batches per step: several payloads per collective once a
+    rank has three or more batches per step (what a rank pays per gather is its orchestration, not its bytes)"""
+    slots = min(6, max_per_rank) if max_per_rank >= 3 else 1
+    depth = max(in_flight, 1) + 1 if slots == 1 else max(3, (max(in_flight, 1) + slots - 1) // slots + 2)
+    return slots, depth
+
+
 def gather_bytes(payload, dst=0, device=None):
     """payload: 1-D uint8 numpy array of this rank.  Returns the list of all ranks' payloads on rank dst, None elsewhere."""
     import torch

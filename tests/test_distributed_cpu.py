@@ -1,7 +1,10 @@
-"""N > 1 path on CPU: world_size-2 gloo job; shards + gather must reproduce the single-process result."""
+"""N > 1 path on CPU: world_size-2 and world_size-8 gloo jobs; shards + gather must reproduce the single-process result."""
+import json
 import os
 import subprocess
 import sys
+
+import pytest
 
 from mindthegap_amd.shard import shard_range
 from mindthegap_amd.synth import SynthSet
@@ -18,7 +21,8 @@ def test_shard_range_partitions():
             assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
 
 
-def test_world_size_2_gloo_matches_truth(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_job_matches_truth(tmp_path, world):
     from tests import emu_lib, oracle_lib
     emu_lib.build_full()  # build once here: the two ranks must not race on the compiler
     oracle_lib.build()
@@ -28,10 +32,15 @@ def test_world_size_2_gloo_matches_truth(tmp_path):
     with socket.socket() as sk:  # a free port for the rendezvous
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "tests", "dist_worker.py"), out]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # bench.py's N > 1 path (tests/dist_worker.py: bench_shaped_job): every payload of every rank and step verified on rank 0; at eight ranks some
+    # ranks pad their collectives, and the last set runs through the slotted gather
+    v = json.load(open(out + ".bench_shaped.json"))
+    assert [x["batches"] for x in v] == [sum(x["per_rank"]) for x in v] and all(len(x["per_rank"]) == world for x in v)
+    assert any(x["padded_ranks"] > 0 for x in v) and any(x["slots"] > 1 for x in v), v
     S = SynthSet(nseq=24, n_sites=20, seed=3)
     expected = "".join(S.site(i)[2] + "\n" for i in range(S.n_sites)).encode()
     assert open(out, "rb").read() == expected  # rank order == site order, every fill identical to the inserted sequence
