@@ -342,17 +342,23 @@ struct Worker {
         const int slot = set_add(s_marked(cfg, S), cfg.mcap, n_marked, c);
         if (slot == -2) status = GAP_OVF_MARKED;
         if (slot >= 0) s_marklog(cfg, S)[n_marked - 1] = (uint32_t)slot;
-        const uint32_t b = sig_bit(c);
+        const uint32_t b = sig_bit(c), q = b >> 6;
         const uint64_t m = 1ull << (b & 63);
-        if ((b >> 6) == 0) msig0 |= m; else if ((b >> 6) == 1) msig1 |= m; else if ((b >> 6) == 2) msig2 |= m; else msig3 |= m;
+        /* four unconditional ORs of selected VALUES: an if / else chain over the four words became one read-modify-write through a selected ADDRESS
+         * (round 6, read off the IR), and a Worker whose address is computed at run time lives in private memory with every one of its fields --
+         * lines, status, the counters -- a scratch access per use */
+        msig0 |= q == 0u ? m : 0ull;
+        msig1 |= q == 1u ? m : 0ull;
+        msig2 |= q == 2u ? m : 0ull;
+        msig3 |= q == 3u ? m : 0ull;
     }
     /* the three sets live in memory that is zero before a launch and must be zero again after it (nobody clears it in between) */
     MTG_DEV void marked_clear() { for (uint32_t i = 0; i < n_marked; i++) s_marked(cfg, S)[s_marklog(cfg, S)[i]] = 0; n_marked = 0; }
     /* register-only half of is_marked: false = certainly not marked */
     MTG_DEV bool maybe_marked(uint64_t c) const
     {
-        const uint32_t b = sig_bit(c);
-        const uint64_t w = (b >> 6) == 0 ? msig0 : (b >> 6) == 1 ? msig1 : (b >> 6) == 2 ? msig2 : msig3;
+        const uint32_t b = sig_bit(c), q = b >> 6;
+        const uint64_t w = (q == 0u ? msig0 : 0ull) | (q == 1u ? msig1 : 0ull) | (q == 2u ? msig2 : 0ull) | (q == 3u ? msig3 : 0ull); /* values, not a selected address (see mark_canon) */
         return ((w >> (b & 63)) & 1) != 0;
     }
     MTG_DEV bool is_marked(uint64_t c) const
@@ -1218,6 +1224,167 @@ MTG_UNROLL
 #endif
 enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches of up to 2k - 1 nodes; the nucleotides of a branch fit two registers */
 
+/* one of two values by a run-time flag, field by field: `arr[flag]` on a local array is a load through a computed ADDRESS, and an object whose
+ * address is computed lives in private memory (scratch) with everything in it; selected values stay in registers */
+MTG_DEV uint32_t pick(bool second, uint32_t a, uint32_t b) { return second ? b : a; }
+MTG_DEV uint64_t pick(bool second, uint64_t a, uint64_t b) { return second ? b : a; }
+MTG_DEV bool pick(bool second, bool a, bool b) { return second ? b : a; }
+MTG_DEV int pick(bool second, int a, int b) { return second ? b : a; }
+/* (structs: every field is loaded by value first -- `c ? b.f : a.f` on two lvalues is an lvalue, i.e. a selected address again) */
+MTG_DEV Kmer pick(bool second, const Kmer& a, const Kmer& b) { Kmer r; r.f = pick(second, a.f, b.f); r.r = pick(second, a.r, b.r); return r; }
+MTG_DEV SnpSeq pick(bool second, const SnpSeq& a, const SnpSeq& b) { SnpSeq r; r.lo = pick(second, a.lo, b.lo); r.hi = pick(second, a.hi, b.hi); return r; }
+MTG_DEV Adj pick(bool second, const Adj& a, const Adj& b) { Adj r; r.out = pick(second, a.out, b.out); r.in = pick(second, a.in, b.in); r.la = pick(second, a.la, b.la); r.up = pick(second, a.up, b.up); return r; }
+/* ---- a node with TWO out-edges, read once for all the fast forms (round 6).
+ * tip_fast, indel_bulk and snp_bulk each read what they needed when they needed it: the unitig headers twice over, the branches' last nodes and
+ * their junctions one after the other, the node's own abundance at the very end through two table look-ups and a read of the store -- a dozen
+ * to twenty DEPENDENT rounds of reads for an insertion / deletion, eight for a SNP, and a wave pays them for every lane that stands on such a node
+ * (profiles/r06_walk_stamps_before.txt: indel_bulk 2.2 calls x 101 k ticks, snp_bulk 1.7 x 69 k per lane of the indel set, where a round of
+ * reads is worth 15-20 k).  Everything the three forms ask of the index and the store is a function of the two first nodes, so it is read here in
+ * THREE rounds, each with all its loads in flight together:
+ *   round A  the right neighbourhoods of the two first nodes (their home buckets), and the bucket of the node's own LEFT junction (the node has
+ *            two out-edges: its right junction is no unitig's interior; if it lies in a stored unitig at all it is that unitig's last node and its
+ *            left junction carries the pointer);
+ *   round B  per branch that starts a run: the unitig's header word (its length), the 64 nucleotides behind the first node, nine words of
+ *            abundance bytes; the node's own k-mer in the store and its abundance byte;
+ *   round C  the right neighbourhoods of the branches' LAST nodes, for branches of at most SNP_MAX_L nodes (the nodes come out of the
+ *            nucleotides by shifts, no read).
+ * The forms then decide on registers; only the insertion / deletion goes on to read the meeting node's neighbourhood (round D) and the start of its
+ * unitig (round E).  Nothing here decides anything: the forms test what they tested before, on the same values. */
+struct Fork2 {
+    Adj r[2];            /* right neighbourhoods of the branches' first nodes */
+    bool run[2];         /* the branch starts a run: ra, lo, hi, ar are valid */
+    RunAt ra[2];
+    uint64_t lo[2], hi[2]; /* the 64 nucleotides behind the first node in walking order (past the unitig's end: whatever the store holds there) */
+    AbRun ar[2];         /* abundance bytes from the branch's first k-mer on (forward) or up to it (backward): us_ab_finish(ar, ahead + 1) */
+    bool has_last[2];    /* last / rl are valid: a branch of one k-mer outside a run (last = the first node, rl = r) or a run of at most SNP_MAX_L nodes */
+    Kmer last[2];
+    Adj rl[2];
+    uint32_t ab_cur;     /* abundance of the node itself */
+};
+/* the node t <= 62 nodes ahead of x along the nucleotides lo | hi (first one in the lowest bits of lo) */
+MTG_DEV Kmer kmer_ahead(const Kmer& x, uint64_t lo, uint64_t hi, uint32_t t, int k, uint64_t mk)
+{
+    Kmer y = x;
+    uint32_t done = 0;
+    while (done < t) {
+        const uint32_t cmax = k < 15 ? (uint32_t)k : 15u, c = t - done < cmax ? t - done : cmax;
+        const uint64_t w = done < 32u ? ((lo >> (2u * done)) | (done ? hi << (64u - 2u * done) : 0ull)) : (hi >> (2u * (done - 32u)));
+        y = kmer_advance(y, (uint32_t)w & ((1u << (2u * c)) - 1u), c, k, mk);
+        done += c;
+    }
+    return y;
+}
+MTG_DEV_NOINLINE void fork2_read(Worker& W, const Kmer& cur, const Kmer x[2], Fork2& F)
+{
+    const UStore& us = W.ix.us;
+    const int k = W.k;
+    const uint64_t mk = W.mk, mk1 = W.mk1, cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
+    /* ---- round A */
+    const Table& t = W.ix.adj;
+    const uint64_t p = cur.f >> 2, rp = cur.r & mk1;
+    const bool pf = p <= rp;
+    const uint64_t Hc = mix(pf ? p : rp, t.key_bits);
+    const uint64_t want_c = (Hc & ((1ULL << t.tag_bits) - 1)) << MTG_DISP_BITS;
+    U64x2 qc[MTG_ADJ_SLOTS];
+    {
+        const U64x2* pc = reinterpret_cast<const U64x2*>(t.slots + bucket_of(Hc, t.nbuckets, t.key_bits) * (2 * MTG_ADJ_SLOTS));
+MTG_UNROLL
+        for (int i = 0; i < MTG_ADJ_SLOTS; i++) qc[i] = ld_table(pc + i);
+    }
+    adj_right2_raw(W.ix, x[0], x[1], mk1, W.lines, F.r[0], F.r[1]);
+    /* the node's own place: through the pointer of its left junction, if the home bucket holds it */
+    uint64_t aux_c = 0;
+    bool hit_c = false;
+MTG_UNROLL
+    for (int i = 0; i < MTG_ADJ_SLOTS; i++) {
+        const bool h = (qc[i].x >> 8) == want_c && qc[i].x != 0;
+        hit_c = hit_c || h;
+        aux_c |= h ? qc[i].y : 0ull;
+    }
+    const bool cur_ptr = hit_c && up_is(aux_c) && us.nwords != 0;
+    uint64_t cur_at = 0;
+    bool cur_bwd = false;
+    if (cur_ptr) { /* as abundance(): the k-mer behind (forward) or before (backward) the junction */
+        const uint64_t w = up_resolve(aux_c, pf);
+        const uint32_t off = up_off(w);
+        cur_bwd = up_bwd(w);
+        cur_at = (up_hdr(w) + 1) * 32 + (cur_bwd ? off - 1u : off);
+    }
+    /* ---- round B */
+    uint64_t cur_le = 0;
+    uint32_t cur_byte = 0;
+    const bool cur_ok = cur_ptr && !(cur_bwd && up_off(up_resolve(aux_c, pf)) < 1u);
+    if (cur_ok) { cur_le = us_kmer_le(us.words, cur_at, k); cur_byte = us.ab[cur_at]; }
+    uint32_t len_w[2] = {0, 0};
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        F.run[br] = us.nwords != 0 && F.r[br].up && popc4(F.r[br].out) == 1 && popc4(F.r[br].in) == 1;
+        F.has_last[br] = false;
+        F.ra[br].ahead = 0; F.ra[br].kpos = 0; F.ra[br].hdr = 0; F.ra[br].bwd = false;
+        F.lo[br] = F.hi[br] = 0;
+        if (!F.run[br]) continue;
+        const uint64_t hdr = up_hdr(F.r[br].up);
+        const uint32_t off = up_off(F.r[br].up);
+        const bool bw = up_bwd(F.r[br].up);
+        const uint32_t idx = bw ? off : off - 1u;
+        F.ra[br].hdr = (uint32_t)hdr;
+        F.ra[br].bwd = bw;
+        F.ra[br].kpos = (hdr + 1) * 32 + idx;
+        len_w[br] = bw ? 0u : (uint32_t)us.words[hdr];
+        const uint64_t pos = bw ? F.ra[br].kpos - 1u : F.ra[br].kpos + (uint32_t)k;
+        F.lo[br] = us_peek64(us.words, pos, 32u, bw);
+        F.hi[br] = (bw && off <= 32u) ? 0ull : us_peek64(us.words, bw ? pos - 32 : pos + 32, 32u, bw); /* backward: no more than off nucleotides lie before the junction */
+        us_ab_issue(us.ab, bw ? (hdr + 1) * 32 : F.ra[br].kpos, F.ar[br]);
+        F.ra[br].ahead = bw ? idx : 0u;
+    }
+    W.lines += 2;
+MTG_UNROLL
+    for (int br = 0; br < 2; br++) {
+        /* a first node outside a run that has one successor: the branch may be that one k-mer (indel_bulk's one-k-mer branch); a run of at most
+         * SNP_MAX_L nodes: its last node out of the nucleotides.  (One assignment of each field on every path: stores to the same field from
+         * several places were merged into one store through a selected address, which put the whole structure into private memory.) */
+        const bool single = !F.run[br] && popc4(F.r[br].out) == 1;
+        uint32_t ahead = F.ra[br].ahead;
+        if (F.run[br] && !F.ra[br].bwd) ahead = len_w[br] - (uint32_t)k + 1u - 1u - (uint32_t)(F.ra[br].kpos - ((uint64_t)F.ra[br].hdr + 1) * 32);
+        const bool short_run = F.run[br] && ahead + 1u <= (uint32_t)SNP_MAX_L;
+        const Kmer z = kmer_ahead(x[br], F.lo[br], F.hi[br], short_run ? ahead : 0u, k, mk); /* (0 nodes ahead: the first node itself) */
+        F.ra[br].ahead = ahead;
+        F.has_last[br] = single || short_run;
+        F.last[br].f = z.f; F.last[br].r = z.r;
+    }
+    /* ---- round C */
+    {
+        const bool n0 = F.run[0] && F.has_last[0], n1 = F.run[1] && F.has_last[1];
+        Adj q0 = F.r[0], q1 = F.r[1]; /* (a branch of one k-mer: its last node is its first) */
+        if (n0 && n1) adj_right2_raw(W.ix, F.last[0], F.last[1], mk1, W.lines, q0, q1);
+        else if (n0) q0 = adj_right_t(t, F.last[0], mk1, W.lines);
+        else if (n1) q1 = adj_right_t(t, F.last[1], mk1, W.lines);
+        F.rl[0].out = q0.out; F.rl[0].in = q0.in; F.rl[0].la = q0.la; F.rl[0].up = q0.up;
+        F.rl[1].out = q1.out; F.rl[1].in = q1.in; F.rl[1].la = q1.la; F.rl[1].up = q1.up;
+    }
+    /* the node's abundance: the byte next to its k-mer when the left junction's pointer led to it, else the ordinary look-up */
+    if (cur_ok && cur_le == (cur_bwd ? (cur.f ^ cmpl) : (cur.r ^ cmpl))) { F.ab_cur = cur_byte; W.lines += 2; }
+    else F.ab_cur = abundance(W.ix, cur, W.lines);
+#ifdef MTG_XCHECK /* TEST-ONLY: every value against the functions the forms called before */
+    {
+        uint32_t l_ = 0;
+        if (F.ab_cur != abundance(W.ix, cur, l_)) W.status = 0xBAE4;
+        for (int br = 0; br < 2; br++) {
+            RunAt q;
+            const bool rn = us.nwords != 0 && run_at(us, F.r[br], k, q, l_);
+            if (rn != F.run[br]) { W.status = 0xBAE4; continue; }
+            if (!rn) continue;
+            if (q.kpos != F.ra[br].kpos || q.ahead != F.ra[br].ahead || q.bwd != F.ra[br].bwd || q.hdr != F.ra[br].hdr) W.status = 0xBAE4;
+            if (F.has_last[br]) {
+                const Kmer z = run_node(us, q.kpos, q.bwd, q.ahead, k);
+                const Adj a2 = adj_right_t(t, z, mk1, l_);
+                if (z.f != F.last[br].f || z.r != F.last[br].r || a2.out != F.rl[br].out || a2.in != F.rl[br].in || a2.up != F.rl[br].up) W.status = 0xBAE4;
+            }
+        }
+    }
+#endif
+}
+
 /* The same pattern read off the unitig store: between the node and e each branch of a SNP bubble is exactly one stored unitig (its first
  * node follows the node's two-way junction, its last node precedes e's), so everything the step-by-step loop of snp_bubble_fast learns
  * from one read per node -- the nucleotides, that the nodes are simple, their abundances -- comes with one round of reads: the two
@@ -1227,32 +1394,16 @@ enum { SNP_MAX_L = 62 }; /* two substitutions closer than k = 31 make branches o
  * nodes are, ever), are pairwise distinct and no palindromic junction or self-complementary k-mer lies inside a unitig (mtg_dev.h:
  * us_eligible); the remaining tests of the loop (a branch node equal to the previous node, a node followed by its reverse complement at
  * the ends) are made here on the k-mers.  x[] = the first nodes of the branches, r[] = their right neighbourhoods. */
-MTG_DEV_NOINLINE bool snp_bulk(Worker& W, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], int& L, int& h, SnpSeq seq[2], unsigned long sum[2], Kmer& e, bool& hopeless)
+MTG_DEV_NOINLINE bool snp_bulk(Worker& W, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Fork2& F, int& L, int& h, SnpSeq seq[2], unsigned long sum[2], Kmer& e, bool& hopeless)
 {
-    const UStore& us = W.ix.us;
     const int k = W.k;
+    const Adj* const r = F.r;
 MTG_UNROLL
     for (int br = 0; br < 2; br++)
-        if (!(r[br].up && popc4(r[br].out) == 1 && popc4(r[br].in) == 1)) return false;
-    /* one round of reads: the two headers (lengths; a branch walked against the stored orientation knows its length from the pointer), both
-     * sequences at their greatest possible length and both abundance runs; lengths are applied afterwards */
-    uint64_t pos[2], lo[2], hi[2];
-    uint32_t left[2], off_[2];
-    bool bw[2];
-    AbRun ar[2];
-MTG_UNROLL
-    for (int br = 0; br < 2; br++) {
-        const uint64_t hdr = up_hdr(r[br].up), base = (hdr + 1) * 32;
-        off_[br] = up_off(r[br].up);
-        bw[br] = up_bwd(r[br].up);
-        pos[br] = bw[br] ? base + off_[br] - 1u : base + off_[br] + (uint32_t)k - 1u;
-        lo[br] = us_peek64(us.words, pos[br], 32u, bw[br]);
-        hi[br] = (bw[br] && off_[br] <= 32u) ? 0ull : us_peek64(us.words, bw[br] ? pos[br] - 32 : pos[br] + 32, 32u, bw[br]); /* backward: no more than off nucleotides lie before the junction */
-        left[br] = bw[br] ? off_[br] : (uint32_t)us.words[hdr] - (off_[br] + (uint32_t)k - 1u);
-        /* abundances of the m + 1 nodes: the k-mers at unitig index off - 1 .. off - 1 + m (forward) or off - m .. off (backward, m = off) */
-        us_ab_issue(us.ab, bw[br] ? base : base + off_[br] - 1u, ar[br]);
-    }
-    W.lines += 2;
+        if (!(r[br].up && popc4(r[br].out) == 1 && popc4(r[br].in) == 1) || !F.run[br]) return false;
+    /* the two headers (lengths), both sequences at their greatest possible length and both abundance runs came with fork2_read; lengths are applied here */
+    uint64_t lo[2] = {F.lo[0], F.lo[1]}, hi[2] = {F.hi[0], F.hi[1]};
+    const uint32_t left[2] = {F.ra[0].ahead, F.ra[1].ahead};
     /* a branch that stays inside one unitig for more than SNP_MAX_L nodes cannot meet the other one in time (the meeting node has two
      * in-edges: it is inside no unitig): the step-by-step loop would walk all SNP_MAX_L steps to find that out */
     if (left[0] + 1u > (uint32_t)SNP_MAX_L || left[1] + 1u > (uint32_t)SNP_MAX_L) { hopeless = true; return false; }
@@ -1260,13 +1411,10 @@ MTG_UNROLL
         /* Branches of different lengths (an insertion or deletion).  The step-by-step loop can only succeed if both branches step onto the
          * same node at the same step; it gives up where the shorter branch leaves its unitig unless the junction there is simple (one in-,
          * one out-edge: a unitig that ends at a palindromic junction) -- the longer branch is still inside its own unitig then, so the node
-         * stepped onto cannot be common.  One read of that junction instead of walking both branches node by node to find out. */
-        const int sb = left[0] < left[1] ? 0 : 1;
-        const uint64_t kp = (up_hdr(r[sb].up) + 1) * 32 + (bw[sb] ? off_[sb] : off_[sb] - 1u); /* the branch's first node in the store */
-        const Kmer zs = run_node(us, kp, bw[sb], left[sb], k);
-        const Adj re = adj_right_t(W.ix.adj, zs, W.mk1, W.lines);
-        W.lines++;
-        if (popc4(re.out) != 1 || popc4(re.in) != 1) hopeless = true;
+         * stepped onto cannot be common.  That junction came with fork2_read. */
+        const bool sb1 = !(left[0] < left[1]);
+        const uint32_t re_out = pick(sb1, F.rl[0].out, F.rl[1].out), re_in = pick(sb1, F.rl[0].in, F.rl[1].in);
+        if (popc4(re_out) != 1 || popc4(re_in) != 1) hopeless = true;
         return false;
     }
     const uint32_t m = left[0]; /* nodes of a branch behind its first one */
@@ -1275,7 +1423,7 @@ MTG_UNROLL
     for (int br = 0; br < 2; br++) {
         lo[br] &= m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull);
         hi[br] = m > 32u ? (hi[br] & ((1ull << (2u * (m - 32u))) - 1ull)) : 0ull;
-        s[br] = us_ab_finish(ar[br], m + 1u);
+        s[br] = us_ab_finish(F.ar[br], m + 1u);
     }
     Kmer z[2] = {x[0], x[1]};
     {   /* the nodes of both branches: none its own reverse complement, none followed by it, none the previous node.  Both branches in one iteration
@@ -1295,8 +1443,10 @@ MTG_UNROLL
         if (bad) return false;
         z[0] = z0; z[1] = z1;
     }
-    Adj re[2];
-    adj_right2_raw(W.ix, z[0], z[1], W.mk1, W.lines, re[0], re[1]);
+#ifdef MTG_XCHECK
+    if (z[0].f != F.last[0].f || z[1].f != F.last[1].f || !F.has_last[0] || !F.has_last[1]) { W.status = 0xBAE4; return false; }
+#endif
+    const Adj re[2] = {F.rl[0], F.rl[1]}; /* the branches' end junctions (fork2_read, round C) */
     /* a branch whose unitig ends in a dead end or a fork: the step-by-step loop would walk both unitigs to find just that */
     if (popc4(re[0].out) != 1 || popc4(re[1].out) != 1) { hopeless = true; return false; }
     const uint32_t ne[2] = {(uint32_t)ctz4(re[0].out), (uint32_t)ctz4(re[1].out)};
@@ -1356,36 +1506,35 @@ inline unsigned long& merge_fast_answers() { static unsigned long n = 0; return 
  * node (two out-edges) and its reverse complement (two in-edges) are no interior node and not the dead end (in-degree 1); the previous node leads
  * to the node, which no node of T or M does, and its reverse complement would make the node its own reverse complement (tested).  Anything else
  * returns 0 and the general code decides.  The TEST-ONLY emulation runs the general code next to every answer (0xBADE). */
-MTG_DEV_NOINLINE int tip_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], SnpSeq& out_seq)
+MTG_DEV_NOINLINE int tip_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Fork2& F, SnpSeq& out_seq)
 {
+    const Adj* const r = F.r;
     const int k = W.k;
     const UStore& us = W.ix.us;
     if (cur.f == cur.r || !us.nwords) return 0;
-    int tb = -1;
+    bool tb1; /* the tip is branch 1 (else branch 0); the other branch M goes on */
     uint32_t Lt = 0;
     Kmer last;
     last.f = last.r = 0;
-    RunAt ra[2];
-    bool has_run[2] = {false, false};
+    const RunAt* const ra = F.ra;
+    const bool* const has_run = F.run;
     if (r[0].out == 0 || r[1].out == 0) {
         if (r[0].out == 0 && r[1].out == 0) return 0; /* both branches die: the frontline empties, the general code says so */
-        tb = r[0].out == 0 ? 0 : 1;
+        tb1 = r[0].out != 0;
         Lt = 1;
-        last = x[tb];
+        last = pick(tb1, x[0], x[1]);
     } else {
-        has_run[0] = run_at(us, r[0], k, ra[0], W.lines);
-        has_run[1] = run_at(us, r[1], k, ra[1], W.lines);
         if (!has_run[0] || !has_run[1] || ra[0].ahead == ra[1].ahead) return 0;
-        tb = ra[0].ahead < ra[1].ahead ? 0 : 1;
-        if (ra[tb].ahead + 1u > (uint32_t)k) return 0; /* a dead-end alternative longer than k nodes: the reference rejects it (and the contig ends) */
-        last = run_node(us, ra[tb].kpos, ra[tb].bwd, ra[tb].ahead, k);
-        const Adj rl = adj_right_t(W.ix.adj, last, W.mk1, W.lines);
-        if (rl.out != 0) return 0; /* the shorter branch goes on: not a tip */
-        Lt = ra[tb].ahead + 1u;
+        tb1 = !(ra[0].ahead < ra[1].ahead);
+        const uint32_t t_ahead = pick(tb1, ra[0].ahead, ra[1].ahead);
+        if (t_ahead + 1u > (uint32_t)k) return 0; /* a dead-end alternative longer than k nodes: the reference rejects it (and the contig ends) */
+        if (!pick(tb1, F.has_last[0], F.has_last[1])) return 0; /* (k <= 31 < SNP_MAX_L: the last node of so short a branch is always known) */
+        last = pick(tb1, F.last[0], F.last[1]);
+        if (pick(tb1, F.rl[0].out, F.rl[1].out) != 0) return 0; /* the shorter branch goes on: not a tip */
+        Lt = t_ahead + 1u;
     }
-    const int mb = 1 - tb;
-    if (!has_run[mb]) has_run[mb] = run_at(us, r[mb], k, ra[mb], W.lines);
-    if (!has_run[mb] || ra[mb].ahead < Lt + 1u) return 0; /* m(Lt+1) must be an interior node of M's unitig */
+    const bool mb1 = !tb1;
+    if (!pick(mb1, has_run[0], has_run[1]) || pick(mb1, ra[0].ahead, ra[1].ahead) < Lt + 1u) return 0; /* m(Lt+1) must be an interior node of M's unitig */
     const uint64_t c_last = canon(last);
     if (last.f == last.r || c_last == prev_c || c_last == canon(cur)) return 0;
     if (W.is_marked(c_last)) return 0; /* the bubble touches an assembled region */
@@ -1393,17 +1542,9 @@ MTG_DEV_NOINLINE int tip_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const
     if (n > W.cfg.mono_max_depth) return 0;
     /* the consensus: M's first nucleotide and the Lt behind it, off the store */
     SnpSeq seq;
-    seq.lo = nt0[mb]; seq.hi = 0;
-    {
-        const bool bwd = ra[mb].bwd;
-        for (uint32_t done = 0; done < Lt;) {
-            const uint32_t c = Lt - done < 16u ? Lt - done : 16u;
-            const uint64_t pos = bwd ? ra[mb].kpos - 1u - done : ra[mb].kpos + (uint32_t)k + done;
-            uint32_t bits = us_peek(us.words, pos, c, bwd);
-            for (uint32_t j = 0; j < c; j++) { seq.set((int)(1u + done + j), bits & 3u); bits >>= 2; }
-            done += c;
-        }
-        W.lines += 2;
+    seq.lo = pick(mb1, nt0[0], nt0[1]); seq.hi = 0;
+    {   /* Lt <= k <= 31 nucleotides: they lie in the first word read behind M's first node */
+        seq.lo |= (pick(mb1, F.lo[0], F.lo[1]) & ((1ull << (2u * Lt)) - 1ull)) << 2; /* positions 1 .. Lt: 2 + 2 Lt <= 64 bits */
     }
 #ifdef MTG_XCHECK /* TEST-ONLY: the general code on the same node: same length, same consensus, the one mark */
     {
@@ -1447,24 +1588,25 @@ MTG_DEV_NOINLINE int tip_fast(Worker& W, const Kmer& cur, uint64_t prev_c, const
  *   marking                 of the involved nodes only e is branching.
  * Returns the length of the chosen consensus (its nucleotides in out_seq), -1 when the reference's answer is "no consensus" (delta >= 3: the
  * contig ends here, nothing is marked), 0 when this is not the pattern.  The TEST-ONLY emulation runs the general code next to every answer (0xBADF). */
-MTG_DEV_NOINLINE int indel_bulk(Worker& W, const Kmer& cur, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Adj r[2], SnpSeq& out_seq)
+MTG_DEV_NOINLINE int indel_bulk(Worker& W, const Kmer& cur, uint64_t prev_c, const Kmer x[2], const uint32_t nt0[2], const Fork2& F, SnpSeq& out_seq)
 {
+    const Adj* const r = F.r;
     const int k = W.k;
     const UStore& us = W.ix.us;
     if (cur.f == cur.r || !us.nwords) return 0;
     /* the two branches: whole chains from their first nodes; a branch of one k-mer has its end junction right behind its first node */
     uint32_t Lb[2];
     Kmer lastn[2];
-    RunAt ra[2];
+    const RunAt* const ra = F.ra;
     bool run[2];
     Adj rl[2];
-    /* the lengths first: equal ones are the SNP forms' (the common case on a heterozygous set: nothing more is read here) */
+    /* the lengths first: equal ones are the SNP forms' (the common case on a heterozygous set) */
 MTG_UNROLL
     for (int br = 0; br < 2; br++) {
         run[br] = false;
         if (popc4(r[br].out) != 1) return 0;
         if (popc4(r[br].in) == 1) {
-            if (!run_at(us, r[br], k, ra[br], W.lines)) return 0;
+            if (!F.run[br]) return 0;
             run[br] = true;
             Lb[br] = ra[br].ahead + 1u;
             if (Lb[br] > (uint32_t)SNP_MAX_L) return 0;
@@ -1473,10 +1615,8 @@ MTG_UNROLL
     if (Lb[0] == Lb[1]) return 0;
 MTG_UNROLL
     for (int br = 0; br < 2; br++) {
-        if (run[br]) {
-            lastn[br] = run_node(us, ra[br].kpos, ra[br].bwd, ra[br].ahead, k);
-            rl[br] = adj_right_t(W.ix.adj, lastn[br], W.mk1, W.lines);
-        } else { lastn[br] = x[br]; rl[br] = r[br]; }
+        if (!F.has_last[br]) return 0; /* (a run of at most SNP_MAX_L nodes, or one k-mer with one successor: both were read) */
+        lastn[br] = F.last[br]; rl[br] = F.rl[br];
         if (popc4(rl[br].out) != 1 || popc4(rl[br].in) != 2) return 0;
         if (lastn[br].f == lastn[br].r) return 0;
     }
@@ -1487,13 +1627,32 @@ MTG_UNROLL
     }
     const uint64_t ce = canon(e);
     if (e.f == e.r || ce == canon(cur) || ce == prev_c || e.f == lastn[0].r || e.f == lastn[1].r) return 0;
-    const int sb = Lb[0] < Lb[1] ? 0 : 1, gb = 1 - sb;
-    const uint32_t delta = Lb[gb] - Lb[sb], d = Lb[gb] + 1u;
+    const bool sb1 = !(Lb[0] < Lb[1]); /* the short branch is branch 1 */
+    const uint32_t Ls_ = pick(sb1, Lb[0], Lb[1]), Lg_ = pick(!sb1, Lb[0], Lb[1]);
+    const uint32_t delta = Lg_ - Ls_, d = Lg_ + 1u;
     if ((int)(d + delta) > SNP_MAX_L || (int)d > W.cfg.mono_max_depth) return 0;
-    /* e's continuation: a stored unitig that starts with e, delta + 1 nodes at least behind it */
+    /* e's continuation: a stored unitig that starts with e, delta + 1 nodes at least behind it (round D: e's neighbourhood; round E, all in flight
+     * together: the unitig's length, the nucleotide behind c(1), the abundance bytes of e and c(1) -- e is solid (an edge of the exact table leads to
+     * it) and the k-mer before a simple junction of a stored unitig is unique, so e's byte is the one at its place) */
     const Adj re = adj_right_t(W.ix.adj, e, W.mk1, W.lines);
     RunAt rae;
-    if (!run_at(us, re, k, rae, W.lines) || rae.ahead < delta + 1u) return 0;
+    if (!(re.up && popc4(re.out) == 1 && popc4(re.in) == 1)) return 0;
+    uint32_t ab_e = 0, ab_c1 = 0, nt_c2 = 0;
+    {
+        const uint64_t hdr = up_hdr(re.up);
+        const uint32_t off = up_off(re.up);
+        rae.hdr = (uint32_t)hdr; rae.bwd = up_bwd(re.up);
+        const uint32_t idx = rae.bwd ? off : off - 1u;
+        rae.kpos = (hdr + 1) * 32 + idx;
+        const uint32_t lw = rae.bwd ? 0u : (uint32_t)us.words[hdr];
+        /* the reads of what delta <= 2 needs, issued before the length is known (one or two nodes past e: inside the padded store whatever the length) */
+        ab_e = us.ab[rae.kpos];
+        ab_c1 = us.ab[rae.bwd ? rae.kpos - 1u : rae.kpos + 1u];
+        nt_c2 = us_peek(us.words, rae.bwd ? rae.kpos - 2u : rae.kpos + (uint32_t)k + 1u, 1u, rae.bwd);
+        rae.ahead = rae.bwd ? idx : lw - (uint32_t)k + 1u - 1u - idx;
+        W.lines++;
+    }
+    if (rae.ahead < delta + 1u) return 0;
     /* e marked: the bubble touches an assembled region -- the frontline gives up when S steps onto e, whatever the rest looks like */
     const bool e_marked = W.is_marked(ce);
     /* delta = 2: when e is checked for in-branching its second predecessor (G's last node) has not been reached yet, and a frontline walks back
@@ -1509,26 +1668,34 @@ MTG_UNROLL
         /* the nucleotides: first one, the branch's own (off the store), the step onto e, delta of e's unitig */
         const uint32_t ne_first = (uint32_t)ctz4(re.out);
         uint32_t tail = ne_first; /* c(1) .. c(delta): at most two nucleotides */
-        if (delta == 2u) tail |= us_peek(us.words, rae.bwd ? rae.kpos - 2u : rae.kpos + (uint32_t)k + 1u, 1u, rae.bwd) << 2; /* the nucleotide behind c(1) */
+        if (delta == 2u) tail |= nt_c2 << 2; /* the nucleotide behind c(1) */
         /* abundances of the nodes both paths share: the node, e, c(1) .. c(delta - 1) */
-        unsigned long shared = abundance(W.ix, cur, W.lines) + abundance(W.ix, e, W.lines);
-        if (delta == 2u) shared += abundance(W.ix, run_node(us, rae.kpos, rae.bwd, 1u, k), W.lines);
+        unsigned long shared = (unsigned long)F.ab_cur + ab_e;
+        if (delta == 2u) shared += ab_c1;
+#ifdef MTG_XCHECK /* TEST-ONLY: the bytes against the look-ups they replace */
+        {
+            uint32_t l_ = 0;
+            if (ab_e != abundance(W.ix, e, l_) || (delta == 2u && (ab_c1 != abundance(W.ix, run_node(us, rae.kpos, rae.bwd, 1u, k), l_) ||
+                                                                    nt_c2 != us_peek(us.words, rae.bwd ? rae.kpos - 2u : rae.kpos + (uint32_t)k + 1u, 1u, rae.bwd)))) { W.status = 0xBAE4; return 0; }
+        }
+#endif
 MTG_UNROLL
         for (int br = 0; br < 2; br++) {
             seq[br].lo = nt0[br]; seq[br].hi = 0;
             int n = 1;
             unsigned long sb_ = 0;
             if (run[br]) {
-                const uint32_t m = ra[br].ahead; /* nodes behind the first */
-                for (uint32_t done = 0; done < m;) {
-                    const uint32_t c = m - done < 16u ? m - done : 16u;
-                    uint32_t bits = us_peek(us.words, ra[br].bwd ? ra[br].kpos - 1u - done : ra[br].kpos + (uint32_t)k + done, c, ra[br].bwd);
-                    for (uint32_t j = 0; j < c; j++) { seq[br].set(n++, bits & 3u); bits >>= 2; }
-                    done += c;
-                }
+                const uint32_t m = ra[br].ahead; /* nodes behind the first: m + 1 <= SNP_MAX_L */
+                const uint64_t l = m >= 32u ? F.lo[br] : (F.lo[br] & ((1ull << (2u * m)) - 1ull));
+                const uint64_t h = m > 32u ? (F.hi[br] & ((1ull << (2u * (m - 32u))) - 1ull)) : 0ull;
+                seq[br].lo |= l << 2;
+                seq[br].hi = (l >> 62) | (h << 2);
+                n += (int)m;
                 /* abundance bytes of the branch's m + 1 k-mers: they start at kpos (forward) or kpos - m (backward) */
-                const uint64_t a0 = ra[br].bwd ? ra[br].kpos - m : ra[br].kpos;
-                for (uint32_t i = 0; i <= m; i += 64u) sb_ += us_ab_sum(us.ab, a0 + i, (m + 1u - i) < 64u ? (m + 1u - i) : 64u);
+                sb_ = us_ab_finish(F.ar[br], m + 1u);
+#ifdef MTG_XCHECK
+                { const uint64_t a0 = ra[br].bwd ? ra[br].kpos - m : ra[br].kpos; if (sb_ != us_ab_sum(us.ab, a0, m + 1u)) { W.status = 0xBAE4; return 0; } }
+#endif
             } else sb_ = abundance(W.ix, x[br], W.lines);
             seq[br].set(n++, (uint32_t)ctz4(rl[br].out));
             for (uint32_t j = 0; j < delta; j++) /* both paths end at c(delta) */ seq[br].set(n++, (tail >> (2u * j)) & 3u);
@@ -1536,7 +1703,7 @@ MTG_UNROLL
             sum[br] = shared + sb_;
         }
         W.lines += 4;
-        if (len[sb] != (int)d || len[gb] != (int)(d + delta)) return 0;
+        if (pick(sb1, len[0], len[1]) != (int)d || pick(!sb1, len[0], len[1]) != (int)(d + delta)) return 0;
         /* validate_consensuses on the two strings (the same integers) */
         const int na = len[0], nb = len[1], mn = na < nb ? na : nb, mx = na < nb ? nb : na;
         int mean = (na + nb) / 2;
@@ -1547,8 +1714,8 @@ MTG_UNROLL
             const long long t5 = mean / 5;
             if (ss > t5 * t5 * 2) answer = -1;
             else {
-                const SnpSeq& lg = na >= nb ? seq[0] : seq[1];
-                const SnpSeq& sh = na >= nb ? seq[1] : seq[0];
+                const SnpSeq lg = pick(!(na >= nb), seq[0], seq[1]);
+                const SnpSeq sh = pick(na >= nb, seq[0], seq[1]);
                 int s0 = -5 * (mx - mn);
                 for (int i = 0; i < mn; i++) s0 += (seq[0].get(i) == seq[1].get(i)) ? 10 : -5;
                 if (identity_below_90((s0 + 5 * mx <= 0) ? 0 : (s0 + 5 * mx + 14) / 15, na, nb)) {
@@ -1568,8 +1735,9 @@ MTG_UNROLL
                 unsigned long best = 0;
                 int ch = -1;
                 for (int c = 0; c < 2; c++) { const unsigned long m2 = sum[c] / (unsigned long)len[c]; if (m2 > best) { best = m2; ch = c; } }
-                if (ch < 0 || len[ch] > W.cfg.mono_max_depth) answer = -1;
-                else { answer = len[ch]; out_seq = seq[ch]; }
+                const int len_ch = pick(ch == 1, len[0], len[1]);
+                if (ch < 0 || len_ch > W.cfg.mono_max_depth) answer = -1;
+                else { answer = len_ch; out_seq = pick(ch == 1, seq[0], seq[1]); }
             }
         }
     }
@@ -1703,7 +1871,7 @@ MTG_UNROLL
     unsigned long sum[2] = {0, 0};
     AbPending pend[2], pend_cur;
     bool have_pend = false;
-    ab_issue(W.ix, canon(cur), pend_cur);
+    if (!W.ix.us.nwords) ab_issue(W.ix, canon(cur), pend_cur); /* with a unitig store the node's abundance comes with fork2_read */
     /* Marked nodes.  Only branching nodes are ever marked (every mark_canon is behind an in-/out-degree test) and the nodes of the two branches
      * are tested simple below, so the one node of the pattern that can be marked is the meeting node e: ONE lookup at the end.  (Rounds 2-3 kept
      * up to four "perhaps marked" branch nodes per bubble from the register signature and gave the bubble to the general code at the fifth: a
@@ -1721,27 +1889,31 @@ MTG_UNROLL
     Kmer be;
     be.f = be.r = 0;
     bseq[0].lo = bseq[0].hi = bseq[1].lo = bseq[1].hi = 0;
+    Fork2 F;
+    F.ab_cur = 0;
     if (W.ix.us.nwords) {
         MTG_F0(f_r1);
-        adj_right2_raw(W.ix, x[0], x[1], W.mk1, W.lines, r1[0], r1[1]);
+        fork2_read(W, cur, x, F); /* everything the three forms below ask of the index and the store, in three rounds of reads */
+        r1[0] = F.r[0]; r1[1] = F.r[1];
         MTG_F1(W, f_r1, 4);
+        if (W.status) return 0;
         have_r1 = true;
         {   /* a tip first (one branch dies within k nodes, the other goes on): answered on the spot */
             MTG_F0(f_t);
-            const int tn = tip_fast(W, cur, prev_c, x, nt0, r1, chosen_seq);
+            const int tn = tip_fast(W, cur, prev_c, x, nt0, F, chosen_seq);
             MTG_F1(W, f_t, 6);
             if (W.status) return 0;
             if (tn > 0) { chosen = 0; MTG_COUNT(W, 14); return tn; }
         }
         {   /* two unitig branches of different lengths onto one node: an insertion / deletion, answered or refused on the spot (-1: no consensus) */
             MTG_F0(f_i);
-            const int in_ = indel_bulk(W, cur, prev_c, x, nt0, r1, chosen_seq);
+            const int in_ = indel_bulk(W, cur, prev_c, x, nt0, F, chosen_seq);
             MTG_F1(W, f_i, 8);
             if (W.status) return 0;
             if (in_ != 0) { chosen = 0; return in_; }
         }
         MTG_F0(f_s);
-        bulk_ok = snp_bulk(W, prev_c, x, nt0, r1, bL, bh, bseq, bsum, be, hopeless);
+        bulk_ok = snp_bulk(W, prev_c, x, nt0, F, bL, bh, bseq, bsum, be, hopeless);
         MTG_F1(W, f_s, 10);
 #ifndef MTG_XCHECK
         if (hopeless) return 0;
@@ -1877,7 +2049,7 @@ MTG_UNROLL
                     sum[0] != bsum[0] || sum[1] != bsum[1])) { W.status = 0xBAD2; return 0; }
 #endif
     {
-        const uint32_t a0 = ab_finish(W.ix, pend_cur, W.lines);
+        const uint32_t a0 = W.ix.us.nwords ? F.ab_cur : ab_finish(W.ix, pend_cur, W.lines);
         sum[0] += a0;
         sum[1] += a0;
     }
@@ -1887,7 +2059,7 @@ MTG_UNROLL
     chosen = -1;
     for (int c = 0; c < 2; c++) if (sum[c] > best) { best = sum[c]; chosen = c; }
     if (chosen < 0) return 0;
-    chosen_seq = seq[chosen];
+    chosen_seq = pick(chosen == 1, seq[0], seq[1]);
     W.mark_canon(ce); /* e has two in-edges: the one branching node among the involved ones */
     MTG_COUNT(W, 14);
     return n;
