@@ -113,7 +113,7 @@ __device__ __forceinline__ void lean_and_list(const Index& ix, const FillCfg& cf
 template <int MODE>
 __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_t* ilv, uint8_t* head, const uint64_t* __restrict__ src, const uint64_t* __restrict__ rwords, const uint32_t* __restrict__ roff,
                                              const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids, GapOut* out, uint32_t n, uint32_t cset,
-                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, const LeanIn& li)
+                                             ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, const LeanIn& li, uint32_t* walk_park = nullptr)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t slot = t;
@@ -137,7 +137,7 @@ __device__ __forceinline__ void stage_a_lane(uint8_t* zero, uint8_t* raw, uint8_
 #endif
     uint32_t met = 0;
     const uint64_t target = lean_target(li, g, ix.k);
-    stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr, in_list >= 0, &met);
+    stage_a_walk<MODE, 1>(ix, cfg, S, src[g], R, o, nullptr, in_list >= 0, &met, walk_park);
 #ifdef MTG_BUBBLE_TIMING
     if (MODE == WALK_PARK && in_list >= 0) timing_note(park->hist_walk_lane, park->hist_walk_wave, t0);
 #endif
@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_WAL
                                                 const uint32_t* __restrict__ rlen, const uint64_t* __restrict__ r0, const uint32_t* __restrict__ ids,
                                                 GapOut* out, uint32_t n, uint32_t cset, ParkCtl* park, uint32_t cap, int in_list, uint32_t out_list, LeanIn li)
 {
-    stage_a_lane<WALK_PARK>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list, li);
+    __shared__ uint32_t s_walk_park[WALK_PARK_WORDS * 64]; /* one wave per workgroup: the walking lanes' own state while the fork forms run (mtg_traverse.h: WALK_PARK_WORDS) */
+    stage_a_lane<WALK_PARK>(zero, raw, ilv, head, src, rwords, roff, rlen, r0, ids, out, n, cset, park, cap, in_list, out_list, li, s_walk_park);
 }
 /* ---- the rounds between two launches of the walk kernel: the branching nodes of the parked gaps, answered on their own, one lane per
  * bubble from HBM scratch -- all 64 lanes of a wave are in the bubble code at the same time.  (k_bubble<G>, a group of G lanes per bubble with

@@ -1255,7 +1255,8 @@ struct Fork2 {
     bool run[2];         /* the branch starts a run: ra, lo, hi, ar are valid */
     RunAt ra[2];
     uint64_t lo[2], hi[2]; /* the 64 nucleotides behind the first node in walking order (past the unitig's end: whatever the store holds there) */
-    AbRun ar[2];         /* abundance bytes from the branch's first k-mer on (forward) or up to it (backward): us_ab_finish(ar, ahead + 1) */
+    uint64_t ab_at[2];   /* where the abundance bytes of the branch's ahead + 1 k-mers start: us_ab_sum(us.ab, ab_at, ahead + 1), read by the form that accepts the bubble
+                            (they were read with everything else at first: thirty-six registers held across two rounds of reads and three forms for the half of the forks that use them) */
     bool has_last[2];    /* last / rl are valid: a branch of one k-mer outside a run (last = the first node, rl = r) or a run of at most SNP_MAX_L nodes */
     Kmer last[2];
     Adj rl[2];
@@ -1321,7 +1322,7 @@ MTG_UNROLL
         F.run[br] = us.nwords != 0 && F.r[br].up && popc4(F.r[br].out) == 1 && popc4(F.r[br].in) == 1;
         F.has_last[br] = false;
         F.ra[br].ahead = 0; F.ra[br].kpos = 0; F.ra[br].hdr = 0; F.ra[br].bwd = false;
-        F.lo[br] = F.hi[br] = 0;
+        F.lo[br] = F.hi[br] = 0; F.ab_at[br] = 0;
         if (!F.run[br]) continue;
         const uint64_t hdr = up_hdr(F.r[br].up);
         const uint32_t off = up_off(F.r[br].up);
@@ -1334,7 +1335,7 @@ MTG_UNROLL
         const uint64_t pos = bw ? F.ra[br].kpos - 1u : F.ra[br].kpos + (uint32_t)k;
         F.lo[br] = us_peek64(us.words, pos, 32u, bw);
         F.hi[br] = (bw && off <= 32u) ? 0ull : us_peek64(us.words, bw ? pos - 32 : pos + 32, 32u, bw); /* backward: no more than off nucleotides lie before the junction */
-        us_ab_issue(us.ab, bw ? (hdr + 1) * 32 : F.ra[br].kpos, F.ar[br]);
+        F.ab_at[br] = bw ? (hdr + 1) * 32 : F.ra[br].kpos;
         F.ra[br].ahead = bw ? idx : 0u;
     }
     W.lines += 2;
@@ -1423,7 +1424,7 @@ MTG_UNROLL
     for (int br = 0; br < 2; br++) {
         lo[br] &= m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull);
         hi[br] = m > 32u ? (hi[br] & ((1ull << (2u * (m - 32u))) - 1ull)) : 0ull;
-        s[br] = us_ab_finish(F.ar[br], m + 1u);
+        s[br] = 0;
     }
     Kmer z[2] = {x[0], x[1]};
     {   /* the nodes of both branches: none its own reverse complement, none followed by it, none the previous node.  Both branches in one iteration
@@ -1453,6 +1454,8 @@ MTG_UNROLL
     const Kmer y0 = kmer_next(z[0], ne[0], k, W.mk), y1 = kmer_next(z[1], ne[1], k, W.mk);
     if (y0.f == z[0].r || y1.f == z[1].r) return false;
     if (y0.f != y1.f) return false; /* longer branches (several unitigs): the loop follows them */
+    s[0] = us_ab_sum(W.ix.us.ab, F.ab_at[0], m + 1u); /* the pattern holds: the abundances of both branches (the reads of the two sums are in flight together) */
+    s[1] = us_ab_sum(W.ix.us.ab, F.ab_at[1], m + 1u);
 MTG_UNROLL
     for (int br = 0; br < 2; br++) {
         seq[br].lo = (uint64_t)nt0[br] | (lo[br] << 2);
@@ -1692,9 +1695,9 @@ MTG_UNROLL
                 seq[br].hi = (l >> 62) | (h << 2);
                 n += (int)m;
                 /* abundance bytes of the branch's m + 1 k-mers: they start at kpos (forward) or kpos - m (backward) */
-                sb_ = us_ab_finish(F.ar[br], m + 1u);
+                sb_ = us_ab_sum(us.ab, F.ab_at[br], m + 1u);
 #ifdef MTG_XCHECK
-                { const uint64_t a0 = ra[br].bwd ? ra[br].kpos - m : ra[br].kpos; if (sb_ != us_ab_sum(us.ab, a0, m + 1u)) { W.status = 0xBAE4; return 0; } }
+                { const uint64_t a0 = ra[br].bwd ? ra[br].kpos - m : ra[br].kpos; if (a0 != F.ab_at[br]) { W.status = 0xBAE4; return 0; } }
 #endif
             } else sb_ = abundance(W.ix, x[br], W.lines);
             seq[br].set(n++, (uint32_t)ctz4(rl[br].out));
@@ -2205,9 +2208,17 @@ inline void coop_tally(int n)
     if (n > 0) t.ok++; else if (n == COOP_FAIL) t.fail++; else t.big[-n < 10 ? -n : 9]++;
 }
 #endif
+/* The walk's loop-carried state -- contig writer, queue indices, the run it is in, where start node and target sit, counters: some forty words a
+ * lane -- is of no use to the forms that answer a branching node, and the forms need a hundred registers of their own (fork2_read).  Kept in
+ * registers across them, the two together exceed the kernel's 256 and the compiler spills to private memory: 615 dwords in round 6's first build,
+ * 1 350 spill stores per wave and launch, two thirds of the kernel's write requests (PMC: 168 per gap), each a trip to the L2 or further.  The
+ * walking lane therefore puts its own state into the wave's LDS right before the forms and takes it back right after (volatile: the compiler may
+ * not keep the values in registers "as well"): their live ranges end at the forms' door.  Forty ds_write + forty ds_read per branching node. */
+enum { WALK_PARK_WORDS = 40 };
 template <int MODE, int G>
 MTG_DEV void stage_a_walk(const Index& ix, const FillCfg& cfg, const GapScratch& S, uint64_t src_f, const SwfPattern& R, GapOut& out, BubbleLdsBig* L, bool resume = (MODE == WALK_FINISH),
-                          uint32_t* met_branching = nullptr /* set to 1 when the walk stood on a branching node with successors at least once */)
+                          uint32_t* met_branching = nullptr /* set to 1 when the walk stood on a branching node with successors at least once */,
+                          uint32_t* walk_park = nullptr /* WALK_PARK_WORDS x 64 words of LDS of the wave (word i of lane l at [i * 64 + l]): where the walk's own state waits while the fork forms run */)
 {
     Worker W(ix, cfg, S);
     W.no_dp = MODE == WALK_PARK;
@@ -2498,6 +2509,30 @@ MTG_UNROLL
         a = adj_right_t(adj, cur, mk1, l_);
         a_is_cur = true;
     }
+    /* the walk's own state to the wave's LDS (out_) and back (see WALK_PARK_WORDS) */
+    auto walk_state = [&](bool out_) {
+#ifdef MTG_EMU
+        volatile uint32_t* const pk = walk_park + (S.lane & 63u);
+#else   /* an LDS pointer by type: through the generic one the accesses were flat_load / flat_store (round 6: twice the kernel's vector memory reads) */
+        volatile __attribute__((address_space(3))) uint32_t* const pk = (volatile __attribute__((address_space(3))) uint32_t*)walk_park + (S.lane & 63u);
+#endif
+        uint32_t i_ = 0;
+#define MTG_PK32(v) do { if (out_) pk[i_ * 64u] = (uint32_t)(v); else (v) = (decltype(v))pk[i_ * 64u]; i_++; } while (0)
+#define MTG_PK64(v) do { if (out_) { pk[i_ * 64u] = (uint32_t)(v); pk[(i_ + 1u) * 64u] = (uint32_t)((uint64_t)(v) >> 32); } \
+                         else { const uint64_t lo_ = pk[i_ * 64u], hi_ = pk[(i_ + 1u) * 64u]; (v) = lo_ | (hi_ << 32); } i_ += 2u; } while (0)
+        uint32_t fl = 0;
+        if (out_) fl = (ovf ? 1u : 0u) | (in_contig ? 2u : 0u) | (found_R ? 4u : 0u) | (a_is_cur ? 8u : 0u) | (watch_r ? 16u : 0u) | (run_bwd ? 32u : 0u) | (r_fwd ? 64u : 0u) |
+                       (r_known ? 128u : 0u) | (answered ? 256u : 0u);
+        MTG_PK32(fl);
+        if (!out_) { ovf = fl & 1u; in_contig = fl & 2u; found_R = fl & 4u; a_is_cur = fl & 8u; watch_r = fl & 16u; run_bwd = fl & 32u; r_fwd = fl & 64u; r_known = fl & 128u; answered = fl & 256u; }
+        MTG_PK64(acc); MTG_PK64(start_c); MTG_PK64(run_pos); MTG_PK64(run_base); MTG_PK64(start_base); MTG_PK64(r_base);
+        MTG_PK32(nacc); MTG_PK32(wpos); MTG_PK32(lines); MTG_PK32(head); MTG_PK32(tail); MTG_PK32(nb); MTG_PK32(total_nt); MTG_PK32(len); MTG_PK32(c_first);
+        MTG_PK32(node_depth); MTG_PK32(start_lo); MTG_PK32(start_rc_lo); MTG_PK32(run_left); MTG_PK32(run_take); MTG_PK32(run_c0); MTG_PK32(store_reads);
+        MTG_PK32(run_nt); MTG_PK32(ncmd); MTG_PK32(copy_words); MTG_PK32(start_idx); MTG_PK32(r_idx); MTG_PK32(saved_n); MTG_PK32(saved_chosen);
+#undef MTG_PK32
+#undef MTG_PK64
+        if (out_) { pv.f = pv.r = 0; pv_seq = pv_cnt = 0; } /* (only read under lazy_prev, which is false here: dead, and now the compiler knows) */
+    };
     MTG_GUARD_DECL(g_flat);
 #if defined(MTG_STAMPS) && !defined(MTG_EMU)
     unsigned long long t_last_iter = t_life0;
@@ -2670,7 +2705,11 @@ MTG_UNROLL
             fast_seq.lo = fast_seq.hi = 0;
             int n = 0;
             if (resuming && answered_snp) { n = saved_n; chosen = saved_chosen; fast_seq = saved_snp; answered_snp = false; }
-            else if (MODE != WALK_SIMPLE && !resuming && !park_all) n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
+            else if (MODE != WALK_SIMPLE && !resuming && !park_all) {
+                if (walk_park) walk_state(true);
+                n = snp_bubble_fast(W, cur, prev_c, a, chosen, fast_seq);
+                if (walk_park) walk_state(false);
+            }
             resuming = false;
             MTG_T1(t_snp, 6);
             const bool fast = n > 0; /* its nodes are simple and the last one is already marked: nothing to ask the index on the way */

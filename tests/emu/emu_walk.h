@@ -18,15 +18,16 @@ inline uint32_t emu_walk(const Index& ix, const FillCfg& cfg, GapScratch& S, uin
     if (park_snp && snp0) S.snp_fast = 2;
     static thread_local BubbleLds lds;
     static thread_local BubbleLdsBig lds_big;
+    static thread_local uint32_t walk_park[WALK_PARK_WORDS * 64]; /* the walk kernel's LDS words (the walk's own state while the fork forms run) */
     /* MTG_LIGHT_WALK=1 (read at every gap: tests switch it): the launch's first walk by the light kernel's form -- simple paths only, the gap parks at
      * its first branching node whatever its shape -- and the rounds / the finishing form take it from there, as on the device */
     const char* lw = getenv("MTG_LIGHT_WALK");
     if (lw && lw[0] == '1') stage_a_walk<WALK_SIMPLE, 1>(ix, cfg, S, src_f, R, out, nullptr);
-    else stage_a_walk<WALK_PARK, 1>(ix, cfg, S, src_f, R, out, nullptr);
+    else stage_a_walk<WALK_PARK, 1>(ix, cfg, S, src_f, R, out, nullptr, false, nullptr, walk_park);
     if (out.status != GAP_PARKED) { S.snp_fast = snp0; return 0; }
     for (int r = 0; r < rounds && out.status == GAP_PARKED; r++) {
         if (coop_off || !bubble_coop<1>(ix, cfg, S, lds)) bubble_classic(ix, cfg, S);
-        stage_a_walk<WALK_PARK, 1>(ix, cfg, S, 0, R, out, nullptr, true);
+        stage_a_walk<WALK_PARK, 1>(ix, cfg, S, 0, R, out, nullptr, true, nullptr, walk_park);
     }
     S.snp_fast = snp0;
     if (out.status == GAP_PARKED) stage_a_walk<WALK_FINISH, 1>(ix, cfg, S, 0, R, out, &lds_big);
