@@ -2191,7 +2191,56 @@ enum { WALK_CLASSIC = 0, WALK_PARK = 1, WALK_FINISH = 2, WALK_SIMPLE = 3 };
 } // namespace mtg
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
 namespace mtg {
+/* TEST-ONLY (MTG_EMU_PARK_STATS=1): what the nodes look like at which the walk kernel parks a gap -- a tally by shape, printed when the process
+ * ends (scripts/r6_park_reasons.py: which pattern the fast forms would have to learn next) */
+struct ParkTally {
+    std::map<std::string, unsigned long> n;
+    std::mutex m;
+    ~ParkTally() { if (getenv("MTG_EMU_PARK_STATS")) for (auto& kv : n) fprintf(stderr, "[emu] parked %8lu  %s\n", kv.second, kv.first.c_str()); }
+};
+inline ParkTally& park_tally_state() { static ParkTally t; return t; }
+inline void emu_park_note(Worker& W, const Kmer& cur, uint64_t prev_c, const Adj& a)
+{
+    if (!getenv("MTG_EMU_PARK_STATS")) return;
+    char buf[256];
+    const int o = popc4(a.out), in = popc4(a.in);
+    std::string key;
+    snprintf(buf, sizeof buf, "out %d in %d", o, in);
+    key = buf;
+    if (o == 2 && in == 1 && W.ix.us.nwords) {
+        const uint32_t nt0[2] = {(uint32_t)ctz4(a.out), (uint32_t)ctz4(a.out & (a.out - 1))};
+        Kmer x[2] = {kmer_next(cur, nt0[0], W.k, W.mk), kmer_next(cur, nt0[1], W.k, W.mk)};
+        Fork2 F;
+        F.ab_cur = 0;
+        const uint32_t st = W.status, ln = W.lines;
+        fork2_read(W, cur, x, F);
+        W.status = st; W.lines = ln;
+        for (int br = 0; br < 2; br++) {
+            snprintf(buf, sizeof buf, " | br%d %s ahead %s first(out %d in %d)", br, F.run[br] ? "run" : "norun", !F.run[br] ? "-" : F.ra[br].ahead + 1u <= (uint32_t)SNP_MAX_L ? (F.ra[br].ahead < (uint32_t)W.k ? "<k" : "<=62") : ">62",
+                     popc4(F.r[br].out), popc4(F.r[br].in));
+            key += buf;
+            if (F.has_last[br]) { snprintf(buf, sizeof buf, " last(out %d in %d)", popc4(F.rl[br].out), popc4(F.rl[br].in)); key += buf; }
+        }
+        if (F.run[0] && F.run[1]) {
+            const long d = (long)F.ra[0].ahead - (long)F.ra[1].ahead;
+            snprintf(buf, sizeof buf, " | dlen %ld", d < 0 ? -d : d);
+            key += buf;
+            if (F.has_last[0] && F.has_last[1] && popc4(F.rl[0].out) == 1 && popc4(F.rl[1].out) == 1) {
+                const Kmer e0 = kmer_next(F.last[0], (uint32_t)ctz4(F.rl[0].out), W.k, W.mk), e1 = kmer_next(F.last[1], (uint32_t)ctz4(F.rl[1].out), W.k, W.mk);
+                key += e0.f == e1.f ? " same-e" : " diff-e";
+                if (e0.f == e1.f) key += W.is_marked(canon(e0)) ? " e-marked" : " e-unmarked";
+            }
+        }
+        key += W.is_marked(canon(cur)) ? " | node marked" : " | node unmarked";
+    }
+    ParkTally& t = park_tally_state();
+    std::lock_guard<std::mutex> lk(t.m);
+    t.n[key]++;
+}
 struct CoopTally {
     unsigned long ok = 0, fail = 0, big[10] = {0};
     ~CoopTally()
@@ -2514,7 +2563,7 @@ MTG_UNROLL
 #ifdef MTG_EMU
         volatile uint32_t* const pk = walk_park + (S.lane & 63u);
 #else   /* an LDS pointer by type: through the generic one the accesses were flat_load / flat_store (round 6: twice the kernel's vector memory reads) */
-        volatile __attribute__((address_space(3))) uint32_t* const pk = (volatile __attribute__((address_space(3))) uint32_t*)walk_park + (S.lane & 63u);
+        volatile __attribute__((address_space(3))) uint32_t* const pk = (volatile __attribute__((address_space(3))) uint32_t*)walk_park + (threadIdx.x & 63u); /* the lane of the WAVE (S.lane is the slot's: the resumed gaps of a work list share values) */
 #endif
         uint32_t i_ = 0;
 #define MTG_PK32(v) do { if (out_) pk[i_ * 64u] = (uint32_t)(v); else (v) = (decltype(v))pk[i_ * 64u]; i_++; } while (0)
@@ -2739,6 +2788,9 @@ MTG_UNROLL
                     sv.pad_ = 0;
                     *s_save(cfg, S) = sv;
                     parked = true;
+#ifdef MTG_EMU
+                    emu_park_note(W, cur, prev_c, a);
+#endif
                     break;
                 }
                 if (MODE == WALK_FINISH) {

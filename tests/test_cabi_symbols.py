@@ -78,6 +78,6 @@ def test_tuning_table_lists_reads_and_sets_every_switch():
         for f in files:
             if f.endswith((".cpp", ".h", ".hip")):
                 for m in re.finditer(r'getenv\("(MTG_[A-Z0-9_]+)"\)', open(os.path.join(dirpath, f), errors="replace").read()):
-                    if m.group(1) not in ("MTG_TUNING", "MTG_EMU_COOP_STATS"):  # the second: TEST-ONLY emulation build
+                    if m.group(1) not in ("MTG_TUNING", "MTG_EMU_COOP_STATS", "MTG_EMU_PARK_STATS"):  # the last two: TEST-ONLY emulation build (#ifdef MTG_EMU)
                         stray.append((f, m.group(1)))
     assert not stray, stray
