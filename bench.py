@@ -184,7 +184,8 @@ def compact_line(out, detail_path=None):
             ident = v.get("identical_to_oracle")
             if ident is None:
                 ident = g(v, "oracle_sample", "identical_to_hip")
-            sec[kk[len("secondary_"):]] = {"value": _num(v.get("value")), "ratio": _num(v.get("ratio_to_headline"), 3), "identical_to_oracle": ident, **({"error": str(v["error"])[:80]} if "error" in v else {})}
+            sec[kk[len("secondary_"):]] = {"value": _num(v.get("value")), "ratio": _num(v.get("ratio_to_headline"), 3), "identical_to_oracle": ident, **({"unit": v["unit"]} if v.get("unit") not in (None, "breakpoints/s") else {}),
+                                           **({"error": str(v["error"])[:80]} if "error" in v else {})}
     if sec:
         line["secondary"] = sec
     sh = g(out, "eight_gpu_outlook_from_one_rank", "shards")
@@ -1075,6 +1076,16 @@ def main():
                     d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
                     d["ratio_to_headline"] = d["value"] / value if value else None
                     out[key] = d
+                except Exception as e:
+                    out[key] = {"error": repr(e)[:300]}
+        # contig mode (BASELINE configs[2]), the tool on a resident index: the reference's bundled case (GFA == gold.gfa), 2 000 and
+        # 10 000 contigs cut from a synthetic donor with the all-pairs dictionary (2 (N - 1) targets per seed), a sample of the seeds against the CPU oracle
+        if not os.environ.get("MTG_BENCH_NO_CONTIG"):
+            for key, args, tmo in (("secondary_contig_bundled", ["--bundled"], 120), ("secondary_contig_2k", ["--contigs", "2000", "--oracle-stride", "40", "--repeats", "2"], 180),
+                                   ("secondary_contig_10k", ["--contigs", "10000", "--oracle-stride", "400", "--repeats", "1"], 400)):
+                try:
+                    cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r6_contig_workload.py")] + args, capture_output=True, text=True, timeout=tmo)
+                    out[key] = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
                 except Exception as e:
                     out[key] = {"error": repr(e)[:300]}
     if dist_on:

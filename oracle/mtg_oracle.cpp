@@ -1060,7 +1060,7 @@ extern "C" {
 void mtgo_default_params(mtgo_params* p)
 {
     p->max_nodes = 100; p->max_depth = 10000; p->nb_mis_allowed = 2; p->overlap = 0; p->fwd_only = 0; p->filter = 0; p->extend = 0;
-    p->nb_cores = 1; p->end_rule_nonbranching = 0;
+    p->nb_cores = 1; p->end_rule_nonbranching = 0; p->seed_stride = 0;
 }
 
 mtgo_index* mtgo_index_from_files(const char* paths_csv, int k, int abundance_min, int abundance_max)
@@ -1249,7 +1249,8 @@ int mtgo_fill_files(const mtgo_index* idx, const mtgo_params* P, int mode, const
         }
         seedFile.close();
         auto t0 = chrono::steady_clock::now();
-        dispatch(seeds.size(), P->nb_cores, 30, [&](size_t i) { F.do_seed(seeds[i], all_targetDictionary); });
+        const size_t stride = P->seed_stride > 1 ? (size_t)P->seed_stride : 1;
+        dispatch(seeds.size(), P->nb_cores, 30, [&](size_t i) { if (i % stride == 0) F.do_seed(seeds[i], all_targetDictionary); });
         t_fill = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
     }
     fclose(F.insert_file); fclose(F.info_file);

@@ -34,6 +34,8 @@ typedef struct mtgo_params {
     int nb_cores;         /* worker threads (records dispatched 30 per task, src/Filler.cpp:824,844) */
     int end_rule_nonbranching; /* 0 (default): find_end_of_branching succeeds as soon as frontline size==1;
                                   1: additionally require the end node to be non-branching */
+    int seed_stride;      /* contig mode, checker's convenience (not a reference option): > 1 = only every seed_stride-th seed is filled, against the
+                             FULL all-pairs dictionary -- a sample of a large contig set (the reference's own cost per seed grows with the set) */
 } mtgo_params;
 
 void mtgo_default_params(mtgo_params* p);

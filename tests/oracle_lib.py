@@ -13,7 +13,7 @@ SO = os.path.join(ODIR, "_build", "libmtg_oracle.so")
 class Params(C.Structure):
     _fields_ = [("max_nodes", C.c_int), ("max_depth", C.c_int), ("nb_mis_allowed", C.c_int), ("overlap", C.c_int),
                 ("fwd_only", C.c_int), ("filter", C.c_int), ("extend", C.c_int), ("nb_cores", C.c_int),
-                ("end_rule_nonbranching", C.c_int)]
+                ("end_rule_nonbranching", C.c_int), ("seed_stride", C.c_int)]
 
 
 def build():

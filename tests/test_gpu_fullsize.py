@@ -261,3 +261,20 @@ def test_secondaries_full_size(mtg, tmp_path, name, het, indels, tips, n_oracle)
     multi = sum(1 for v in cpu.values() if len(v) > 1)
     print("secondary %s at full size: %d gaps parked, %d lean, %d of 100000 filled forward; %d sites compared record by record with the oracle (%d with several solutions)"
           % (name, st["n_parked_gaps"], st["n_lean_gaps"], n_filled, n_oracle, multi))
+
+
+@pytest.mark.gpu
+def test_contig_mode_2000_contigs_all_pairs_dictionary():
+    """BASELINE configs[2] at scale: MindTheGap fill -contig on 2 000 contigs cut from a synthetic donor -- 4 000 seeds, each with the
+    all-pairs dictionary of 3 998 targets (src/Filler.cpp:755-829) -- through the HIP path; every 40th seed is filled by the CPU oracle against the FULL
+    dictionary: info rows, FASTA records and the GFA's fill segments / links must be the tool's.  (The same script is bench.py's secondary_contig_*.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cp = subprocess.run([sys.executable, os.path.join(root, "scripts", "r6_contig_workload.py"), "--contigs", "2000", "--oracle-stride", "40", "--repeats", "1"],
+                        capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["seeds"] == 4000 and d["fill_records"] > 2000
+    assert d["oracle_sample"]["seeds"] == 100 and d["oracle_sample"]["fill_records"] > 50 and d["identical_to_oracle"] is True
