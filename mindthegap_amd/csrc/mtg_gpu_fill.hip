@@ -187,8 +187,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_STA
 }
 /* the gaps that are still parked after the rounds (all of them when there are no rounds), one group of G lanes each, to the end of their
  * walks: group i of the grid takes entry i of the list.  The grid is sized for the worst case (the host does not know the count when it
- * queues the kernel); a group without an entry leaves at once.  (A loop over tickets around the walk -- fewer, longer-lived groups -- made
- * this very large kernel hang on the device in every build but an instrumented one; the straight-line form has no control flow around the walk.) */
+ * queues the kernel); a group without an entry leaves at once.  (A loop over tickets around the walk -- fewer, longer-lived groups -- hung on the
+ * device in round 3.  Round 6 reproduced it in sixty lines, scripts/r6_ticket_loop.hip, profiles/r06_ticket_loop.txt: it is not the size of the
+ * kernel.  With hipcc 7.2 (clang 22.0.0git roc-7.2.0) the shape "the group's first lane takes the ticket under `if (lane == 0)`, the others get it
+ * by shuffle, the loop body holds ballots / shuffles" is compiled so that every lane but the first is marked done after the first pass through
+ * the body and parks in a loop without exit at the kernel's end -- also with one group per wave, also with the body inlined, also at -O1; without
+ * collectives in the body, or with EVERY lane taking a ticket (no branch around the atomic), the same loop runs and agrees with the straight-line
+ * form entry by entry.  The product keeps the straight-line form.) */
 #ifndef MTG_FINISH_WAVES
 #define MTG_FINISH_WAVES 2
 #endif
