@@ -32,6 +32,7 @@
 #else
 #define MTG_DEV_NOINLINE __device__ __noinline__
 #endif
+#define MTG_DEV_COLD __device__ __noinline__ /* a rarely taken, large piece (the sparse index's second look-up, the alignment): a real call, so that its registers are not part of every kernel that might take it */
 #define MTG_UNROLL _Pragma("unroll")
 #define MTG_LDS /* a typed LDS pointer (address_space(3), ds_* instructions) measured SLOWER than the generic one for the fingerprint table: 6.1 against 5.1 ms on the diploid set */
 #define MTG_GLOBAL __attribute__((address_space(1))) /* same for the index tables: global_load instead of flat_load */
@@ -44,6 +45,7 @@
 #define MTG_DEV inline
 #define MTG_HD inline
 #define MTG_DEV_NOINLINE inline
+#define MTG_DEV_COLD inline
 #define MTG_UNROLL
 #define MTG_LDS
 #define MTG_GLOBAL
@@ -576,11 +578,22 @@ MTG_DEV uint64_t locate_junction(const Table& adj, uint64_t jf, uint64_t jr, uin
 
 /* right neighbourhood of x: successors of x and in-neighbours of those successors (one bucket read; on a sparse index a second one and
  * two short reads of the store when the junction behind x has no entry) */
+struct AdjLines { Adj a; uint32_t lines; };
+MTG_DEV_COLD AdjLines adj_right_sparse(const Table adj, const Kmer x, uint64_t mk1, Adj a);
 MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t& lines)
 {
     uint32_t m;
-    Adj a = adj_right_raw(adj, x, mk1, lines, m);
+    const Adj a = adj_right_raw(adj, x, mk1, lines, m);
     if (m != 0 || adj.sp_words == nullptr) return a;
+    const AdjLines r = adj_right_sparse(adj, x, mk1, a); /* (by value both ways: a reference into a real call would put the caller's variable into memory) */
+    lines += r.lines;
+    return r.a;
+}
+/* the junction behind x has no entry: through the other junction of x, or x is not solid */
+MTG_DEV_COLD AdjLines adj_right_sparse(const Table adj, const Kmer x, uint64_t mk1, Adj a)
+{
+    uint32_t lines = 0;
+    AdjLines out;
     /* through x's left junction: x is the k-mer behind it */
     const int k = (int)(adj.key_bits >> 1) + 1;
     const uint64_t mk = kmask(k), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk;
@@ -596,19 +609,22 @@ MTG_DEV Adj adj_right_t(const Table& adj, const Kmer& x, uint64_t mk1, uint32_t&
                 a.out = 1u << us_peek(adj.sp_words, base + off + (uint32_t)k, 1u, false);
                 a.in = 1u << ((uint32_t)(x.f >> (2 * (k - 1))) & 3u);
                 a.up = (up_hdr(w) << 32) | ((uint64_t)(off + 1u) << 5) | 1ull;
-                return a;
+                out.a = a; out.lines = lines;
+                return out;
             }
         } else if (off >= 2u && us_kmer_le(adj.sp_words, base + off - 1u, k) == (x.f ^ cmpl)) {
             a.out = 1u << us_peek(adj.sp_words, base + off - 2u, 1u, true);
             a.in = 1u << ((uint32_t)(x.f >> (2 * (k - 1))) & 3u);
             a.up = (up_hdr(w) << 32) | ((uint64_t)(off - 1u) << 5) | 3ull;
-            return a;
+            out.a = a; out.lines = lines;
+            return out;
         }
     }
     /* x is not solid: the junction behind it may still be one of the graph (the walk asks this of a source k-mer that is not in the graph) */
     const uint64_t up = locate_junction(adj, x.f & mk1, x.r >> 2, lines);
     if (up) { adj_of_interior(adj.sp_words, up, k, a.out, a.in); a.up = up; }
-    return a;
+    out.a = a; out.lines = lines;
+    return out;
 }
 
 /* sum of the abundance bytes ab[start, start + count), count <= 64: aligned 8-byte reads, all in flight together, bytes outside the range
