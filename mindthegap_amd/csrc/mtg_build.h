@@ -116,9 +116,11 @@ MTG_DEV JView jt_left(const Table& jt, const Kmer& x, uint64_t mk1, uint32_t& li
 /* table_or with the bucket read in one go before any atomic (the entry usually exists with its bits, or the first free slot takes it).
  * A stale read is harmless: the tag part of a slot is written once, a slot seen empty is claimed by compare-and-swap, bits seen missing
  * are OR-ed in again.  Returns as table_or. */
-MTG_DEV int jt_or(const Table& t, uint64_t key, uint32_t bits)
+MTG_DEV int jt_or_h(const Table& t, uint64_t H, uint32_t bits);
+MTG_DEV int jt_or(const Table& t, uint64_t key, uint32_t bits) { return jt_or_h(t, mix(key, t.key_bits), bits); }
+/* the same for a key given by its hash H = mix(key) (the partitioned construction carries hashes, not keys) */
+MTG_DEV int jt_or_h(const Table& t, uint64_t H, uint32_t bits)
 {
-    const uint64_t H = mix(key, t.key_bits);
     uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
     const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
     for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
@@ -145,11 +147,16 @@ MTG_UNROLL
 /* one occurrence of the junction J ((k-1)-mer jf, its reverse complement jr) with the nucleotide before it (a, when has_a: the k-mer a+J is
  * solid) and behind it (b, when has_b: J+b is solid): what index_insert contributes to J's entry from the k-mers on its two sides (a
  * palindromic junction gets the bits of both strands).  Returns as table_or. */
-MTG_DEV int jt_insert_junction(const Table& jt, uint64_t jf, uint64_t jr, bool has_a, uint32_t a, bool has_b, uint32_t b)
+MTG_DEV uint32_t jt_junction_bits(uint64_t jf, uint64_t jr, bool has_a, uint32_t a, bool has_b, uint32_t b)
 {
     uint32_t bits = 0;
     if (jf <= jr) bits |= (has_b ? 1u << b : 0u) | (has_a ? 1u << (4 + a) : 0u);
     if (jr <= jf) bits |= (has_b ? 1u << (4 + (b ^ 2u)) : 0u) | (has_a ? 1u << (a ^ 2u) : 0u);
+    return bits;
+}
+MTG_DEV int jt_insert_junction(const Table& jt, uint64_t jf, uint64_t jr, bool has_a, uint32_t a, bool has_b, uint32_t b)
+{
+    const uint32_t bits = jt_junction_bits(jf, jr, has_a, a, has_b, b);
     if (!bits) return 0;
     return jt_or(jt, jf <= jr ? jf : jr, bits);
 }

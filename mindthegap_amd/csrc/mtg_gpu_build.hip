@@ -254,6 +254,274 @@ __global__ void __launch_bounds__(256) k_jt_insert_packed(Table jt, int k, const
     }
     if (fail) atomicOr(&counters[0], 1ull);
 }
+/* ---- the junction table of packed sequences, PARTITIONED (round 6).  k_jt_insert_packed makes one read and one compare-and-swap per junction
+ * position on a random bucket of a 34 GB table: 3.0e9 of each at human scale, 170 ms, which is the rate this memory gives scattered atomics --
+ * the table's bytes crossed the memory bus a dozen times.  bucket_of() is monotone in the hash, so the junctions can be sorted by where they
+ * go instead: with the bucket count a multiple of 2^(b1 + b2), the hashes with the same top b1 + b2 bits own one SEGMENT of m consecutive buckets
+ * (at most 2 048: 64 KB), and
+ *   1. k_bin_positions   streams the sequences and writes an 8-byte record per junction position -- [hash without its top b1 bits | edge bits] --
+ *                        into the region of its level-1 bin (2^b1 bins, eight regions each: one per XCD, so that a memory line is written by
+ *                        one L2), a tile of 8 192 records at a time: histogram in LDS, one global atomic per bin and tile, runs of ~8 records;
+ *   2. k_bin_records     reads a level-1 bin and deals its records to the 2^b2 segments below it -- INTO THE TABLE'S OWN MEMORY: a segment's
+ *                        region holds its record list (word 0: the count) until the table is built there;
+ *   3. k_build_segments  one workgroup per segment: the list is read once, the segment is built in LDS (the same probing as jt_or, LDS
+ *                        atomics) and written over the list in one coalesced sweep;
+ *   4. what did not fit -- a record beyond a region's capacity, a key displaced past its segment's last bucket -- is on an overflow list and
+ *                        goes in with the ordinary insertion (k_jt_overflow) once the segments are written: a few per million.
+ * The level-1 regions live behind the table in its buffer (the sparse ADJ table that takes the buffer over is larger), the sequences go through
+ * in chunks that fit there.  Traffic: 24 GB of records written and read twice, the table written once -- no clearing pass, no atomic on
+ * device memory but the bins' cursors. */
+struct BinShape {
+    uint32_t kb, b1, b2;  /* key bits; bits of the level-1 bin, of the segment below it */
+    uint64_t m;           /* buckets per segment */
+    uint64_t cap1;        /* records per (level-1 bin, XCD) region */
+    uint64_t seg_words;   /* m * MTG_ABND_SLOTS */
+};
+struct BinOverflow {
+    uint64_t* h;          /* hash, edge bits: two words per entry */
+    unsigned long long* cursor;
+    unsigned long long cap;
+};
+__device__ __forceinline__ void bin_overflow_push(const BinOverflow& ov, uint64_t H, uint32_t bits)
+{
+    const unsigned long long at = atomicAdd(ov.cursor, 1ull);
+    if (at < ov.cap) { ov.h[2 * at] = H; ov.h[2 * at + 1] = bits; }
+}
+enum { BIN_TILE = 8192 };
+#ifndef MTG_BIN1_TILE
+#define MTG_BIN1_TILE 4096
+#endif
+#ifndef MTG_BIN1_THREADS
+#define MTG_BIN1_THREADS 512
+#endif
+#ifndef MTG_BIN1_GROUPS
+#define MTG_BIN1_GROUPS 768
+#endif
+/* a tile of staged (hash, bits) pairs of this workgroup to ITS regions of the level-1 bins (region (bin, workgroup): no other workgroup writes there, so
+ * the cursors are the workgroup's own, in LDS, for as long as it runs -- with cursors in device memory the bins took an atomic per eight records, and
+ * scattered atomics are what the construction is leaving behind) */
+__device__ __forceinline__ void bin1_flush(const BinShape& S, uint32_t n, const uint64_t* s_h, const uint8_t* s_b, uint32_t* s_hist, uint32_t* s_base, uint32_t* s_cur, uint64_t* bins1, const BinOverflow& ov)
+{
+    const uint32_t nb1 = 1u << S.b1;
+    for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_hist[(uint32_t)(s_h[i] >> (S.kb - S.b1))], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) {
+        s_base[b] = s_cur[b];
+        s_cur[b] += s_hist[b];
+        s_hist[b] = 0;
+    }
+    __syncthreads();
+    const uint64_t low = (1ull << (S.kb - S.b1)) - 1ull;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t H = s_h[i];
+        const uint32_t b = (uint32_t)(H >> (S.kb - S.b1));
+        const uint64_t pos = (uint64_t)s_base[b] + atomicAdd(&s_hist[b], 1u);
+        if (pos < S.cap1) bins1[((uint64_t)b * gridDim.x + blockIdx.x) * S.cap1 + pos] = ((H & low) << 8) | s_b[i];
+        else bin_overflow_push(ov, H, s_b[i]);
+    }
+    __syncthreads();
+}
+__global__ void __launch_bounds__(MTG_BIN1_THREADS) k_bin_positions(BinShape S, int k, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len,
+                                                       size_t s0, size_t s1, uint64_t* bins1, uint32_t* cur1, BinOverflow ov)
+{
+    extern __shared__ uint64_t s_dyn[];
+    uint64_t* s_h = s_dyn;                                        /* MTG_BIN1_TILE hashes */
+    uint8_t* s_b = reinterpret_cast<uint8_t*>(s_dyn + MTG_BIN1_TILE);  /* MTG_BIN1_TILE edge masks */
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_b + MTG_BIN1_TILE);
+    uint32_t* s_base = s_hist + 1024;
+    uint32_t* s_cur = s_base + 1024;
+    __shared__ uint32_t s_n;
+    const uint32_t nb1 = 1u << S.b1;
+    for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) s_cur[b] = 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t mk1 = kmask(k - 1), cmpl1 = 0xAAAAAAAAAAAAAAAAULL & mk1;
+    for (size_t s = s0 + blockIdx.x; s < s1; s += gridDim.x) {
+        const uint64_t* w = words + word_off[s];
+        const uint32_t L = len[s];
+        if (L < (uint32_t)k) continue;
+        const uint32_t npos = L - (uint32_t)k + 2u; /* junction positions 0 .. L - k + 1 */
+        for (uint32_t q0 = 0; q0 < npos; q0 += blockDim.x) {
+            const uint32_t n_now = s_n; /* every thread reads the count BEFORE any wave of this round adds to it: the barrier keeps the test uniform */
+            __syncthreads();
+            if (n_now + blockDim.x > MTG_BIN1_TILE) {
+                bin1_flush(S, n_now, s_h, s_b, s_hist, s_base, s_cur, bins1, ov);
+                if (threadIdx.x == 0) s_n = 0;
+                __syncthreads();
+            }
+            const uint32_t q = q0 + threadIdx.x;
+            uint64_t H = 0;
+            uint32_t bits = 0;
+            if (q < npos) { /* as k_jt_insert_packed: nucleotides q-1 .. q+k-1 in one little-endian window [a][J: k-1][b] */
+                const bool has_a = q >= 1, has_b = q + (uint32_t)k - 1 < L;
+                const uint32_t qa = has_a ? q - 1 : q, sh = 2u * (qa & 31u), need = (uint32_t)k - 1u + (has_a ? 1u : 0u) + (has_b ? 1u : 0u);
+                uint64_t win = w[qa >> 5] >> sh;
+                if ((qa & 31u) + need > 32u) win |= w[(qa >> 5) + 1] << (64u - sh);
+                const uint32_t a = (uint32_t)win & 3u;
+                const uint64_t body = has_a ? win >> 2 : win;
+                const uint64_t jle = body & mk1;
+                const uint32_t b = (uint32_t)(body >> (2 * (k - 1))) & 3u;
+                const uint64_t jr = jle ^ cmpl1, jf = revcomp(jr, k - 1);
+                bits = jt_junction_bits(jf, jr, has_a, a, has_b, b);
+                H = mix(jf <= jr ? jf : jr, S.kb);
+            }
+            /* the wave's records one after the other in the staging arrays */
+            const unsigned long long mball = __ballot(bits != 0u);
+            uint32_t wbase = 0;
+            if ((threadIdx.x & 63u) == 0 && mball) wbase = atomicAdd(&s_n, (uint32_t)__popcll(mball));
+            wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+            if (bits) {
+                const uint32_t at = wbase + (uint32_t)__popcll(mball & ((1ull << (threadIdx.x & 63u)) - 1ull));
+                s_h[at] = H;
+                s_b[at] = (uint8_t)bits;
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t n = s_n;
+    if (n) bin1_flush(S, n, s_h, s_b, s_hist, s_base, s_cur, bins1, ov);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) cur1[(uint64_t)b * gridDim.x + blockIdx.x] = s_cur[b]; /* records of region (b, this workgroup): may exceed cap1 (the rest went to the overflow list) */
+}
+/* workgroup p: the records of level-1 bin p -- its G regions, one after the other, tile by tile -- to the lists of the 2^b2 segments below it, in the
+ * table's own memory.  One workgroup writes all the lists of its bin, so their cursors are its own too: in LDS while it runs, in the lists' count words
+ * (word 0 of a segment's region) between the chunks of the input. */
+__global__ void __launch_bounds__(1024) k_bin_records(BinShape S, const uint64_t* __restrict__ bins1, const uint32_t* __restrict__ cur1, uint32_t G, uint64_t* table, BinOverflow ov)
+{
+    extern __shared__ uint64_t s_dyn2[];
+    uint64_t* s_r = s_dyn2; /* BIN_TILE records */
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_dyn2 + BIN_TILE);
+    uint32_t* s_base = s_hist + 2048;
+    uint32_t* s_cur = s_base + 2048;
+    const uint32_t nb2 = 1u << S.b2, p = blockIdx.x;
+    const uint32_t sh2 = S.kb - S.b1 - S.b2 + 8u; /* the sub-bin's bits in a record */
+    for (uint32_t b = threadIdx.x; b < nb2; b += blockDim.x) s_cur[b] = (uint32_t)table[(((uint64_t)p << S.b2) | b) * S.seg_words];
+    __syncthreads();
+    uint32_t g = 0;
+    uint64_t off = 0; /* records of region g already taken */
+    while (g < G) {
+        /* a tile: what is left of region g, then whole further regions while they fit */
+        uint32_t fill = 0;
+        while (g < G && fill < BIN_TILE) {
+            const uint64_t c = cur1[(uint64_t)p * G + g];
+            const uint64_t n = c < S.cap1 ? c : S.cap1;
+            const uint64_t left = n - off;
+            const uint32_t take = (uint32_t)(left < BIN_TILE - fill ? left : BIN_TILE - fill);
+            if (take < left && fill) break; /* a region is split only when it does not fit an empty tile */
+            const uint64_t* src = bins1 + ((uint64_t)p * G + g) * S.cap1 + off;
+            for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) s_r[fill + i] = src[i];
+            fill += take;
+            if (take == left) { g++; off = 0; } else off += take;
+        }
+        for (uint32_t b = threadIdx.x; b < nb2; b += blockDim.x) s_hist[b] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < fill; i += blockDim.x) atomicAdd(&s_hist[(uint32_t)(s_r[i] >> sh2) & (nb2 - 1u)], 1u);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb2; b += blockDim.x) {
+            s_base[b] = s_cur[b];
+            s_cur[b] += s_hist[b];
+            s_hist[b] = 0;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < fill; i += blockDim.x) {
+            const uint64_t rec = s_r[i];
+            const uint32_t b = (uint32_t)(rec >> sh2) & (nb2 - 1u);
+            const uint64_t pos = (uint64_t)s_base[b] + atomicAdd(&s_hist[b], 1u);
+            const uint64_t seg = ((uint64_t)p << S.b2) | b;
+            if (pos + 1 < S.seg_words) table[seg * S.seg_words + 1 + pos] = rec;
+            else bin_overflow_push(ov, ((uint64_t)p << (S.kb - S.b1)) | (rec >> 8), (uint32_t)rec & 255u);
+        }
+        __syncthreads();
+    }
+    for (uint32_t b = threadIdx.x; b < nb2; b += blockDim.x) table[(((uint64_t)p << S.b2) | b) * S.seg_words] = s_cur[b];
+}
+/* word 0 of every segment's region: the count of its list */
+__global__ void k_bin_clear_counts(BinShape S, uint64_t* table, uint64_t nseg)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nseg; j += (uint64_t)gridDim.x * blockDim.x) table[j * S.seg_words] = 0;
+}
+/* one segment per workgroup and turn: its list -> its buckets, built in LDS.  A turn is a chain of latencies (count, records, barrier, barrier, write), so
+ * several small workgroups share a compute unit rather than one large one. */
+#ifndef MTG_SEG_THREADS
+#define MTG_SEG_THREADS 512
+#endif
+/* a workgroup barrier that waits for the wave's LDS operations only: the lists' loads and the segments' stores of neighbouring turns stay in flight
+ * across it (__syncthreads() drains them: every turn then pays the memory's latency three times over) */
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ void __launch_bounds__(MTG_SEG_THREADS) k_build_segments(BinShape S, Table jt, uint64_t nseg, BinOverflow ov)
+{
+    extern __shared__ uint64_t s_tab[]; /* seg_words slots (a multiple of four: whole 32-byte buckets) */
+    const uint64_t tagm = (1ull << jt.tag_bits) - 1ull;
+    const uint32_t nq = (uint32_t)(S.seg_words / 2); /* 16-byte pieces */
+    for (uint64_t j = blockIdx.x; j < nseg; j += gridDim.x) {
+        uint64_t* reg = jt.slots + j * S.seg_words;
+        const unsigned long long c = reg[0];
+        const uint64_t n = c < S.seg_words - 1 ? c : S.seg_words - 1;
+        {
+            U64x2 z; z.x = z.y = 0;
+            for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) reinterpret_cast<U64x2*>(s_tab)[i] = z;
+        }
+        lds_barrier();
+        const uint64_t hi = (j >> S.b2) << (S.kb - S.b1);
+        const uint64_t b0 = j * S.m;
+        for (uint64_t base = 0; base < n; base += (uint64_t)blockDim.x * 8u) {
+            uint64_t cur[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint64_t i = base + (uint64_t)u * blockDim.x + threadIdx.x; cur[u] = i < n ? reg[1 + i] : 0ull; } /* eight loads in flight (a record's edge bits are never 0) */
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t rec = cur[u];
+                if (!rec) continue;
+                const uint64_t H = hi | (rec >> 8);
+                const uint32_t bits = (uint32_t)rec & 255u;
+                const uint64_t bl0 = bucket_of(H, jt.nbuckets, jt.key_bits) - b0;
+                const uint64_t tag = H & tagm;
+                bool done = false;
+                for (uint32_t d = 0; d <= MTG_MAX_DISP && !done; d++) {
+                    const uint64_t bl = bl0 + d;
+                    if (bl >= S.m) break; /* past the segment's last bucket: the ordinary insertion, later */
+                    const uint64_t want = (tag << MTG_DISP_BITS) | d;
+                    unsigned long long* p = reinterpret_cast<unsigned long long*>(s_tab + bl * MTG_ABND_SLOTS);
+                    /* the bucket in one go (two 16-byte reads), then one compare-and-swap on the slot it points to; a lost race reads the bucket again */
+                    for (int turn = 0; turn < 6 && !done; turn++) {
+                        const volatile unsigned long long* pv = p; /* (four reads issued together; volatile: a turn after a lost race must see the winner's slot) */
+                        const unsigned long long q[4] = {pv[0], pv[1], pv[2], pv[3]};
+                        int hit = -1, fr = -1;
+#pragma unroll
+                        for (int t = 3; t >= 0; t--) { if (q[t] == 0ull) fr = t; if ((q[t] >> 8) == want && q[t] != 0ull) hit = t; }
+                        if (hit >= 0) { if ((q[hit] & bits) != bits) atomicOr(p + hit, (unsigned long long)bits); done = true; break; }
+                        if (fr < 0) break; /* a full bucket: the next one */
+                        const unsigned long long v = atomicCAS(p + fr, 0ull, (unsigned long long)((want << 8) | bits));
+                        if (v == 0ull) { done = true; break; }
+                        if ((v >> 8) == want) { if ((v & bits) != bits) atomicOr(p + fr, (unsigned long long)bits); done = true; break; }
+                    }
+                }
+                if (!done) bin_overflow_push(ov, H, bits);
+            }
+        }
+        lds_barrier();
+#ifndef SEG_NO_WRITE
+        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) reinterpret_cast<U64x2*>(reg)[i] = reinterpret_cast<const U64x2*>(s_tab)[i];
+#else
+        if (threadIdx.x == 0) reg[0] = s_tab[0];
+#endif
+        lds_barrier();
+    }
+}
+/* the overflow list through the ordinary insertion; counters[0] = displacement overflow */
+__global__ void k_jt_overflow(Table jt, const uint64_t* __restrict__ h, unsigned long long n, unsigned long long* counters)
+{
+    unsigned long long fail = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const int f = jt_or_h(jt, h[2 * i], (uint32_t)h[2 * i + 1]) & 1;
+        if (f) { counters[3] = h[2 * i]; counters[1] = h[2 * i + 1]; }
+        fail += f;
+    }
+    if (fail) { atomicOr(&counters[0], 1ull); atomicAdd(&counters[2], fail); }
+}
+
 /* a counted solid set handed over as a list: abundances into the (dense) ABND table that serves as their source, junctions into the
  * junction table.  counters[0] = overflow flag, counters[3] += abundances above 255 */
 __global__ void k_jt_insert_kmers(Table jt, Table abnd, int k, const uint64_t* __restrict__ kmers, const uint32_t* __restrict__ ab, size_t n, unsigned long long* counters)
@@ -401,6 +669,7 @@ struct BuildProf {
         snprintf(ph.name, sizeof ph.name, "%s", name);
         ph.ms = ms; ph.bytes = bytes; ph.units = units;
         phases.push_back(ph);
+        if (tune::on(tune::T_DEBUG_TIMERS)) fprintf(stderr, "  [build] %-24s %9.2f ms\n", name, ms);
         return e == hipSuccess ? hipGetLastError() : e;
     }
     void host_phase(const char* name, double ms, uint64_t bytes, uint64_t units)
@@ -744,13 +1013,14 @@ static size_t adj_bytes_estimate(uint64_t n, int k)
     return (size_t)buckets_for(n / 2 + n / 128 + 8192, 0.49, 2 * (k - 1), MTG_ADJ_SLOTS) * 16 * MTG_ADJ_SLOTS;
 }
 /* min_bytes: the buffer is made at least this large (the junction table's memory is handed on to the sparse ADJ table) */
-static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase, size_t min_bytes = 0, uint64_t min_buckets = 0)
+static int alloc_slot_table(Table& t, DevBuf& buf, uint64_t nkeys, double load, uint32_t key_bits, BuildProf& prof, const char* phase, size_t min_bytes = 0, uint64_t min_buckets = 0, bool clear = true)
 {
     table_shape(t, std::max<uint64_t>(buckets_for(nkeys, load, key_bits, MTG_ABND_SLOTS), min_buckets), key_bits);
     t.sp_words = nullptr;
     const size_t bytes = t.nbuckets * 8 * MTG_ABND_SLOTS;
     if (!(buf.p && buf.cap >= std::max(bytes, min_bytes))) HIP_TRY(buf.alloc(std::max(bytes, min_bytes)));
     t.slots = buf.as<uint64_t>();
+    if (!clear) return MTG_OK; /* (the partitioned construction writes every word of the table itself) */
     prof.begin();
     HIP_TRY(hipMemsetAsync(buf.p, 0, bytes, 0));
     HIP_TRY(prof.end(phase, bytes, 0));
@@ -813,6 +1083,98 @@ static int index_from_kmer_pieces_lean(size_t n, int k, const KmerFetch& fetch, 
     return MTG_OK;
 }
 
+/* the shape of the partitioned construction for a table of at least nb0 buckets; false: the table is too small for it to pay (or k too small for the record) */
+static bool bin_shape(uint64_t nb0, uint32_t key_bits, BinShape& S, uint64_t& nb)
+{
+    const uint64_t max_m = 2048; /* 64 KB of LDS per segment */
+    uint32_t b = 0;
+    while (((nb0 + (1ull << b) - 1) >> b) > max_m) b++;
+    if (b < 8 || b > 21 || key_bits < b + 8) return false;
+    S.kb = key_bits;
+    S.b1 = std::min<uint32_t>(10, (b + 1) / 2);
+    S.b2 = b - S.b1;
+    if (key_bits - S.b1 + 8 > 64) return false;
+    S.m = (nb0 + (1ull << b) - 1) >> b;
+    S.seg_words = S.m * MTG_ABND_SLOTS;
+    S.cap1 = 0;
+    nb = S.m << b;
+    return true;
+}
+/* jt has the shape bin_shape asked for and is NOT cleared; spare: device memory behind the table (bytes) the level-1 regions may use.
+ * Returns MTG_OK with cnt0 = 1 when a key was displaced too far (the caller retries with a lower load), MTG_ERR_OVERFLOW when the overflow list
+ * did not hold what the regions could not (the caller falls back to the ordinary insertion). */
+static int jt_insert_partitioned(const Table& jt, BinShape S, int k, const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t n_junctions_ub,
+                                 uint8_t* spare, size_t spare_bytes, unsigned long long* d_cnt, unsigned long long& cnt0, BuildProf& prof)
+{
+    const uint32_t G = MTG_BIN1_GROUPS; /* workgroups of k_bin_positions = regions per level-1 bin */
+    const uint64_t nseg = jt.nbuckets / S.m, nreg = ((uint64_t)1 << S.b1) * G;
+    DevBuf d_cur, d_ov, d_tmp;
+    const unsigned long long ov_cap = 1ull << 22;
+    HIP_TRY(d_cur.alloc(nreg * 4 + 64));
+    HIP_TRY(d_ov.alloc(ov_cap * 16 + 64));
+    /* the level-1 regions: behind the table when there is room for at least an eighth of the records at a time, else a buffer of their own */
+    uint64_t want = std::min<uint64_t>(n_junctions_ub, 1ull << 29) * 8 * 5 / 4 + nreg * 64 * 8;
+    uint8_t* regions = spare;
+    size_t reg_bytes = spare_bytes & ~(size_t)63;
+    if (reg_bytes < std::min<uint64_t>(want, (n_junctions_ub / 8 + 1) * 8 * 5 / 4 + nreg * 64 * 8)) {
+        HIP_TRY(d_tmp.alloc(want));
+        regions = d_tmp.as<uint8_t>();
+        reg_bytes = want;
+    }
+    S.cap1 = reg_bytes / 8 / nreg;
+    if (S.cap1 < 64) { set_error("partitioned junction table: no room for the level-1 regions"); return MTG_ERR_NOMEM; }
+    const uint64_t chunk_positions = S.cap1 * nreg * 5 / 6; /* a region's share of a chunk varies by a few percent (its size is in the thousands) */
+    const double per_seq = (double)n_junctions_ub / (double)std::max<size_t>(nseq, 1);
+    const size_t seq_per_chunk = (size_t)std::max<double>(1.0, (double)chunk_positions / std::max(per_seq, 1.0));
+    BinOverflow ov{d_ov.as<uint64_t>(), reinterpret_cast<unsigned long long*>(d_ov.as<uint8_t>() + ov_cap * 16), ov_cap};
+    HIP_TRY(hipMemsetAsync(ov.cursor, 0, 8, 0));
+    const size_t lds1 = (size_t)MTG_BIN1_TILE * 9 + 3 * 1024 * 4, lds2 = (size_t)BIN_TILE * 8 + 3 * 2048 * 4, lds3 = S.seg_words * 8;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_positions), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_segments), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    hipLaunchKernelGGL(k_bin_clear_counts, dim3(1024), dim3(256), 0, 0, S, jt.slots, nseg);
+    for (size_t s0 = 0; s0 < nseq; s0 += seq_per_chunk) {
+        const size_t s1 = std::min(nseq, s0 + seq_per_chunk);
+        const uint64_t units = (uint64_t)((double)(s1 - s0) * per_seq);
+        prof.begin();
+        hipLaunchKernelGGL(k_bin_positions, dim3(G), dim3(MTG_BIN1_THREADS), lds1, 0, S, k, d_words, d_word_off, d_len, s0, s1, reinterpret_cast<uint64_t*>(regions), d_cur.as<uint32_t>(), ov);
+        HIP_TRY(prof.end("jt_bin_positions", units * (8 + 1), units)); /* a record written; the nucleotides */
+        prof.begin();
+        hipLaunchKernelGGL(k_bin_records, dim3(1u << S.b1), dim3(1024), lds2, 0, S, reinterpret_cast<const uint64_t*>(regions), d_cur.as<const uint32_t>(), G, jt.slots, ov);
+        HIP_TRY(prof.end("jt_bin_records", units * 16, units)); /* a record read and written */
+    }
+    prof.begin();
+    hipLaunchKernelGGL(k_build_segments, dim3((unsigned)std::min<uint64_t>(nseg, 256 * 8)), dim3(MTG_SEG_THREADS), lds3, 0, S, jt, nseg, ov);
+    HIP_TRY(prof.end("jt_build_segments", n_junctions_ub * 8 + jt.nbuckets * 8 * MTG_ABND_SLOTS, nseg)); /* the lists read, the table written */
+    unsigned long long n_ov = 0;
+    HIP_TRY(hipMemcpy(&n_ov, ov.cursor, 8, hipMemcpyDeviceToHost));
+    if (n_ov > ov_cap) { set_error("partitioned junction table: %llu records left over", n_ov); return MTG_ERR_OVERFLOW; }
+    if (n_ov) {
+        prof.begin();
+        hipLaunchKernelGGL(k_jt_overflow, dim3((unsigned)std::min<unsigned long long>((n_ov + 255) / 256, 4096)), dim3(256), 0, 0, jt, ov.h, n_ov, d_cnt);
+        HIP_TRY(prof.end("jt_insert_leftover", n_ov * 64, n_ov));
+    }
+    unsigned long long cnt[4];
+    HIP_TRY(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+    cnt0 = cnt[0];
+    if (tune::on(tune::T_DEBUG_TIMERS)) fprintf(stderr, "  [partitioned jt] segments %llu of %llu buckets, regions of %llu records, leftover %llu, displaced too far %llu (last: hash %llx bits %llx, bucket %llu of %llu)\n", (unsigned long long)nseg, (unsigned long long)S.m, (unsigned long long)S.cap1, n_ov, cnt[2],
+                                                cnt[3], cnt[1], (unsigned long long)(((unsigned __int128)cnt[3] * jt.nbuckets) >> jt.key_bits), (unsigned long long)jt.nbuckets);
+    if (tune::on(tune::T_DEBUG_TIMERS) && cnt[2]) {
+        const uint64_t b = (uint64_t)(((unsigned __int128)cnt[3] * jt.nbuckets) >> jt.key_bits);
+        std::vector<uint64_t> w(70 * MTG_ABND_SLOTS);
+        const uint64_t bstart = b >= 3 ? b - 3 : 0;
+        (void)hipMemcpy(w.data(), jt.slots + bstart * MTG_ABND_SLOTS, w.size() * 8, hipMemcpyDeviceToHost);
+        unsigned nz = 0;
+        for (uint64_t x : w) nz += x != 0;
+        fprintf(stderr, "  [partitioned jt] buckets %llu..: %u of %zu slots occupied; segment %llu, bucket %llu in it; words:", (unsigned long long)bstart, nz, w.size(), (unsigned long long)(b / S.m), (unsigned long long)(b % S.m));
+        for (int i = 0; i < 24; i++) fprintf(stderr, " %llx", (unsigned long long)w[i]);
+        fprintf(stderr, "\n");
+        unsigned long long c0 = 0;
+        (void)c0;
+    }
+    return MTG_OK;
+}
+
 static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq, uint64_t total_kmers_ub, int k,
                                          uint32_t abund_lo, uint32_t abund_span, mtg_index** out)
 {
@@ -827,7 +1189,31 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
     double load = 1.0;
     int rc = MTG_OK;
     const uint64_t n_junctions_ub = total_kmers_ub + nseq + 1024; /* a sequence of L >= k nucleotides has L - k + 2 junction positions */
+    /* large tables are built partition by partition (jt_insert_partitioned); BUILD_PARTITIONED = 0 / 1 of the tuning table forces either way */
+    bool partitioned_ok = true;
     for (int attempt = 0; attempt < 6; attempt++) {
+        const uint32_t kb = 2 * (uint32_t)(k - 1);
+        BinShape BS{};
+        uint64_t nb_part = 0;
+        /* (a little emptier than the scattered insertion's table: the segments are filled in whatever order the lanes come, and at 0.7 a cluster of sixty full
+         * buckets -- one in a billion buckets has one -- sent a key past the 63 buckets a look-up follows in half the runs; the buffer is sized for the larger
+         * sparse ADJ table anyway) */
+        const uint64_t nb0 = std::max<uint64_t>(buckets_for(n_junctions_ub, std::min(jt_load(), 0.62) * load, kb, MTG_ABND_SLOTS), jt_min_buckets(kb));
+        const bool want_part = partitioned_ok && nseq != 0 && (tune::is_set(tune::T_BUILD_PARTITIONED) ? tune::on(tune::T_BUILD_PARTITIONED) : n_junctions_ub >= (1ull << 27)) && bin_shape(nb0, kb, BS, nb_part);
+        if (want_part) {
+            if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, kb, prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k), nb_part, false)) return rc2;
+            HIP_TRY(hipMemset(d_cnt.p, 0, 32));
+            const size_t tb = jt.nbuckets * 8 * MTG_ABND_SLOTS;
+            unsigned long long cnt0 = 0;
+            const int prc = jt_insert_partitioned(jt, BS, k, d_words, d_word_off, d_len, nseq, n_junctions_ub, jt_buf.as<uint8_t>() + tb, jt_buf.cap > tb ? jt_buf.cap - tb : 0, d_cnt.as<unsigned long long>(), cnt0, prof);
+            if (prc == MTG_ERR_OVERFLOW) { partitioned_ok = false; attempt--; continue; } /* very uneven sequences or hashes: the ordinary insertion */
+            if (prc) return prc;
+            if (!cnt0) { rc = MTG_OK; break; }
+            load *= 0.7;
+            rc = MTG_ERR_OVERFLOW;
+            set_error("index bucket displacement overflow");
+            continue;
+        }
         if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k), jt_min_buckets(2 * (k - 1)))) return rc2;
         HIP_TRY(hipMemset(d_cnt.p, 0, 32));
         if (nseq == 0) break; /* an empty graph: nothing to launch */

@@ -208,7 +208,10 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
          * whatever inexact matches precede it -- so the contig is first searched for the k-mer itself (a compare per position instead of the
          * mismatch count), and the counting scan below only runs when it is not there. */
         bool have_exact = false;
-        if (L >= (uint32_t)k && single && bad0 == 0ull) {
+        /* (contig 0 only: that is where the target of a filled gap sits.  The further contigs of a multi-contig gap -- the alleles behind a refused
+         * bubble, the rest of the donor sequence -- do not hold it, and searching them for the k-mer first and counting mismatches afterwards read
+         * each of them twice: the counting scan finds an exact occurrence just as well, and stops at it.) */
+        if (L >= (uint32_t)k && single && bad0 == 0ull && c == 0) {
             const uint32_t npos = L - (uint32_t)k + 1, nwc = (L + 31) / 32;
             for (uint32_t ws = 0; ws < nwc && !have_exact; ws += POST_TILE) {
                 const uint32_t tw = (nwc - ws) < (uint32_t)POST_TILE + 1 ? (nwc - ws) : (uint32_t)POST_TILE + 1;

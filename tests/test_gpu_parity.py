@@ -794,3 +794,54 @@ def test_bubble_tests_under_every_launch_sequence(seq):
     import re
     summary = re.findall(r"(\d+) passed", r.stdout)  # (the tool's own report on stdout may follow pytest's line)
     assert r.returncode == 0 and summary and int(summary[-1]) >= 10 and not re.search(r"\d+ (failed|error)", r.stdout), (seq, r.stdout[-1500:], r.stderr[-800:])
+
+
+@pytest.mark.gpu
+def test_partitioned_junction_table_equals_the_scattered_insertion(mtg):
+    """Graph::create from packed sequences (src/Filler.cpp:172-213): the junction table built partition by partition in LDS (round 6: BUILD_PARTITIONED=1, the
+    default from 2^27 junction positions on) and by scattered insertion (=0) must describe the same graph -- statistics, every neighbourhood / abundance
+    query on a sample of solid and absent k-mers, the same fills -- on a donor with repeats (sequences that share stretches, a palindrome, a tandem repeat)."""
+    import torch
+    from mindthegap_amd.synth import SynthSet
+    S = SynthSet(nseq=3000, n_sites=400, seed=23, k=31, het_snps=2)  # diploid: every shared unitig occurs in two sequences
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda", 0)
+    pw, po, pl, pn = S.packed()
+    built = {}
+    for part in ("0", "1"):
+        mtg.tuning_set("BUILD_PARTITIONED", part)
+        try:
+            w = torch.from_numpy(pw.view(np.int64)).to(dev)
+            wo = torch.from_numpy(po.view(np.int64)).to(dev)
+            ln = torch.from_numpy(pl.view(np.int32)).to(dev)
+            idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), pn, S.total_kmers_upper_bound, 31, 3, 0)
+        finally:
+            mtg.tuning_set("BUILD_PARTITIONED", None)
+        names = [p["name"] for p in idx.build_profile()["phases"]]
+        assert ("jt_build_segments" in names) == (part == "1"), names
+        info = idx.info()
+        # k-mers of the donor (solid) and random ones (absent, mostly)
+        codes = S.codes(7)
+        km = []
+        for p0 in range(0, 2000, 3):
+            v = 0
+            for c in codes[p0:p0 + 31]:
+                v = (v << 2) | int(c)
+            rc = 0
+            for c in codes[p0:p0 + 31][::-1]:
+                rc = (rc << 2) | (int(c) ^ 2)
+            km.append(min(v, rc))
+        km = np.array(km + [int(x) for x in rng.integers(0, 2**62, 500)], dtype=np.uint64)
+        ab = idx.abundance(km)
+        succ, pred = idx.neighbors(km)
+        gaps = []
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+        res = idx.fill_batch(gaps)
+        built[part] = ({k2: info[k2] for k2 in ("nb_solid_kmers", "nb_branching", "nb_unitigs", "nb_kmers_outside_unitigs")}, ab.tolist(), succ.tolist(), pred.tolist(),
+                       [[(f["seq"], f["nb_errors_in_anchor"], f["qual"]) for f in r["filled"]] for r in res])
+        idx.close()
+        del w, wo, ln
+    assert built["0"] == built["1"]
+    assert built["1"][0]["nb_solid_kmers"] > 5 * 10**6 and sum(1 for r in built["1"][4] if r) > 300
