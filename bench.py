@@ -95,7 +95,7 @@ def spawn_ranks(n):
     rendezvous on 127.0.0.1) before anything in this process has touched a GPU, pass their output through and leave with their exit code.
     Never an exec: a process image is not replaced here."""
     import socket
-    import torch  # device_count() does not initialise the GPU on this image
+    import torch  # device_count() may initialise the HIP runtime in THIS process (a build without amdsmi falls back to hipGetDeviceCount): the ranks are therefore only ever started as children, never by replacing this process
     have = torch.cuda.device_count()
     if have < n:
         raise SystemExit("bench.py --gpus %d: this machine shows %d GPU(s); refusing to print a %d-GPU line from fewer devices" % (n, have, n))
@@ -151,7 +151,7 @@ def compact_line(out, detail_path=None):
             line[kk] = _num(out.get(kk))
     line["roofline"] = {
         "bound": "hbm", "kernel": dom.get("kernel"), "achieved": _num(dom.get("achieved")), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _num(dom.get("frac")),
-        "bytes_per_launch": _num(dom.get("bytes_per_launch"), 6), "bytes_are": "what the implemented layout must move per launch (counters of the timed launches)",
+        "frac_basis": "layout bytes", "bytes_per_launch": _num(dom.get("bytes_per_launch"), 6), "bytes_are": "what the implemented layout must move per launch (counters of the timed launches)",
         "avg_kernel_ms": _num(dom.get("avg_kernel_ms")), "traffic": _num(dom.get("traffic"), 6), "traffic_over_bytes": _num(dom.get("traffic_over_bytes")), "traffic_over_request_bytes": _num(dom.get("traffic_over_request_bytes")),
         "traffic_is": "replayed from profiles/ (PMC FETCH_SIZE + WRITE_SIZE of this command)" if dom.get("traffic") else None,
         "dominant_kernel": roof.get("dominant_kernel"), "dominant_kernel_frac": _num(roof.get("dominant_kernel_frac_of_hbm_peak")),
@@ -159,6 +159,7 @@ def compact_line(out, detail_path=None):
         "walk_traffic_over_bytes": _num(wall.get("traffic_over_bytes")),
         "random_read_frac": _num(g(roof, "random_reads_of_k_stage_a", "alone", "frac_of_ceiling") or g(roof, "random_reads_of_k_stage_a", "frac_of_ceiling")),
         "sec8d_equivalent_frac_of_the_walk": _num(g(roof, "reference_algorithm_equivalent", "equivalent_GBps_of_k_stage_a") / HBM_PEAK_GBS) if g(roof, "reference_algorithm_equivalent", "equivalent_GBps_of_k_stage_a") else None,
+        "sec8d_frac_of_step": _num(g(roof, "reference_algorithm_equivalent", "bytes_per_launch") / (out.get("ms_per_step") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if g(roof, "reference_algorithm_equivalent", "bytes_per_launch") and out.get("ms_per_step") else None,
         "sec8d_note": "above 1: a step does not do SURVEY 8(d)'s 8 probes per nucleotide, the index construction did (build_frac)",
         "build_frac": _num(ib.get("sec8d_frac_over_device_seconds")), "build_device_s": _num(ib.get("device_seconds")),
         "job_bound": "pcie", "pcie_GBps": _num(roof.get("achieved")), "pcie_peak_GBps": PCIE_PEAK_GBS, "pcie_frac": _num(roof.get("frac")),
@@ -176,6 +177,8 @@ def compact_line(out, detail_path=None):
     if isinstance(e2e, dict):
         line["end_to_end"] = {"sites": cfg.get("sites_per_batch"), "from_donor_in_hbm_s": _num(g(e2e, "from_donor_in_hbm", "seconds")), "from_container_s": _num(g(e2e, "from_container", "seconds")),
                               "cpu_port_scaled_s": _num(g(e2e, "cpu_port_same_span", "scaled_to_config4_estimate_s")),
+                              "from_container_load_s": _num(g(e2e, "from_container_split", "load_container_s")), "from_container_fill_and_files_s": _num(g(e2e, "from_container_split", "fill_and_files_s")),
+                              "index_build_s": _num(g(e2e, "from_donor_in_hbm", "index_build_s")), "fill_and_files_s": _num(g(e2e, "from_donor_in_hbm", "tool_fill_and_files_s")),
                               "identical_to_truth": bool(g(e2e, "from_donor_in_hbm", "sequences_identical_to_truth") and g(e2e, "from_container", "sequences_identical_to_truth")) if "from_container" in e2e else None,
                               "error": e2e.get("error")}
     sec = {}
@@ -445,8 +448,10 @@ def main():
             with done_cv:
                 while pending[0]:
                     done_cv.wait()
-            if errors:
-                raise errors[0]
+                errs = errors[:]  # taken and cleared under the lock: a failure of one measurement must not fail every later one (advisor, round 5)
+                del errors[:]
+            if errs:
+                raise errs[0]
 
         def run_block(count, record, first_step=0, host_strings=False, host_text=False):
             """`count` steps, a.in_flight batches in flight: the caller threads take the next batch off a shared queue, like the reference's
@@ -582,7 +587,11 @@ def main():
                 identical = ident_all
         else:
             n_filled_all, n_sites_all = n_filled_rank, n_sites_rank
-        return dict(acc=acc, batches=batches, st=st, pg=pg_saved, times=times, elapsed=elapsed, gathered=gathered, identical=identical, st_alone=st_alone,
+        def stop_callers():
+            """the caller threads of this configuration leave (one sentinel each); the report's later measurements start their own through run_tasks no more"""
+            for _ in callers:
+                tasks.put(None)
+        return dict(acc=acc, batches=batches, st=st, pg=pg_saved, times=times, elapsed=elapsed, gathered=gathered, identical=identical, st_alone=st_alone, stop_callers=stop_callers,
                     n_filled=n_filled_all, n_sites=n_sites_all, fill=fill, run_block=run_block, run_tasks=run_tasks, value=cfg["step_sites"] * a.steps / elapsed)
 
     results = []
@@ -782,6 +791,21 @@ def main():
                         t0 = time.perf_counter()
                         rc_b = mtg.fill_main(["-graph", cont, "-bkpt", bk1, "-out", os.path.join(d, "e2e_b")])
                         t_graph = time.perf_counter() - t0
+                        # the same span in its parts (verdict r5, item 8): the container read and the tables derived (Index.load), then the tool on the loaded index
+                        split = None
+                        try:
+                            t0 = time.perf_counter()
+                            idx2 = mtg.Index.load(cont)
+                            t_load = time.perf_counter() - t0
+                            t0 = time.perf_counter()
+                            rc_c = idx2.fill_main(["-bkpt", bk1, "-out", os.path.join(d, "e2e_c")])
+                            t_fill2 = time.perf_counter() - t0
+                            idx2.close()
+                            split = {"load_container_s": max(t_graph - t_fill2, 0.0), "fill_and_files_s": t_fill2, "load_measured_in_a_call_of_its_own_s": t_load, "exit_code": rc_c,
+                                     "note": "fill_and_files_s: MindTheGap fill -bkpt on an index loaded by Index.load (a second run); load_container_s = the one-call figure minus it (file read, store uploaded, tables derived on the device); "
+                                             "the load timed in a call of its own happens while the first index is still resident: its 48 GB hipMalloc is a property of the box on the day (0.3 ms ... 4 s, profiles/r04_hipmalloc_latency.txt)"}
+                        except Exception as e2:
+                            split = {"error": repr(e2)[:200]}
                         want1 = hashlib.sha256(("\0".join(batches[0].expected[:len(ids1)]) + "\0").encode()).hexdigest()
 
                         def fasta_ok(prefix):
@@ -794,6 +818,7 @@ def main():
                                                    "from_container": {"seconds": t_graph, "exit_code": rc_b, "container_bytes": os.path.getsize(cont), "container_write_s_untimed": t_save, "output_bytes": out_b,
                                                                       "sequences_identical_to_truth": fasta_ok(os.path.join(d, "e2e_b")),
                                                                       "what": "MindTheGap fill -graph <container v3> -bkpt <sites> -out <prefix>: ONE call -- container read, unitig store uploaded, tables derived on the device, 100 000 fills, three files written"},
+                                                   "from_container_split": split,
                                                    "sites_per_s_from_container": len(ids1) / t_graph}
                     except Exception as e:
                         secondary["end_to_end"] = {"error": repr(e)[:300]}
@@ -928,9 +953,9 @@ def main():
             "dominant_kernel": dom["kernel"], "dominant_kernel_frac_of_hbm_peak": dom["frac"], "kernels": kerns, "launches": int(acc["n_launches"]),
             "first_walk_kernel": {"k_walk (light: simple paths only)": int(acc["n_light_walks"]), "k_stage_a (full)": int(acc["n_launches"] - acc["n_light_walks"]),
                                   "gaps_that_met_a_branching_node_per_launch": acc["n_branching_gaps"] / Ln},
-            "kernel_times": "avg_kernel_ms = HIP events on the batch's stream with ONE batch on the device (%s launches after the timed blocks); the same command under rocprofv3 --kernel-trace --stats with --in-flight 1 is profiles/r05_kernel_stats_one_batch_in_flight.csv"
+            "kernel_times": "avg_kernel_ms = HIP events on the batch's stream with ONE batch on the device (%s launches after the timed blocks); the same command under rocprofv3 --kernel-trace --stats with --in-flight 1 is profiles/r06_kernel_stats_one_batch_in_flight.csv"
                             % (st_alone["runs"] if st_alone else 0)}
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json")) if os.path.exists(q)), None)
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r06_pmc.json"), os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json")) if os.path.exists(q)), None)
     if a.workload == "human" and batch_sites == 100000 and pmc:
         pj = json.load(open(pmc))
         fill_kernels = ("k_stage_a", "k_walk", "k_finish", "k_bubble", "k_lean", "k_copy", "k_post", "k_scan1", "k_scan2", "k_emit", "k_wire_sum", "k_marshal", "k_encode_targets")
@@ -1006,14 +1031,14 @@ def main():
                    # SURVEY 8(d)'s bytes over the DEVICE time of the construction (the kernels' own clock; `seconds` also holds hipMalloc, a box property)
                    "sec8d_frac_over_device_seconds": ref_b / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS,
                    "traffic": None}
-    pmcb = next((q for q in (os.path.join(ROOT, "profiles", "r05_pmc_build.json"), os.path.join(ROOT, "profiles", "r04_pmc_build.json")) if os.path.exists(q)), os.path.join(ROOT, "profiles", "r05_pmc_build.json"))
+    pmcb = next((q for q in (os.path.join(ROOT, "profiles", "r06_pmc_build.json"), os.path.join(ROOT, "profiles", "r05_pmc_build.json"), os.path.join(ROOT, "profiles", "r04_pmc_build.json")) if os.path.exists(q)), os.path.join(ROOT, "profiles", "r05_pmc_build.json"))
     if a.workload == "human" and os.path.exists(pmcb):
         pb = json.load(open(pmcb))
         index_build["traffic"] = {kn.split("::")[-1]: kv.get("hbm_bytes_per_launch") for kn, kv in pb.get("kernels", {}).items()}
         index_build["traffic_is"] = "REPLAYED from %s (rocprofv3 --pmc passes of scripts/r4_build.py, HEAD %s); FETCH_SIZE x2 applied to no kernel (16 B/lane table scans, scattered buckets)" % (os.path.relpath(pmcb, ROOT), pb.get("head", "?"))
 
     out = {"metric": "breakpoints filled/sec", "value": value, "unit": "breakpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": scaling if world > 1 else "none", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": desc, "sites_per_step": step_sites, "sites_per_batch": batch_sites, "sites_per_rank_and_step": sites_per_rank_step, "distinct_batches_per_rank": len(batches),
                       "site_set": cfg0["total"], "donor_sequences": S.nseq, "erroneous_fragments": int(len(S.extra_lens)), "k": k, "max_nodes": 100, "max_length": 10000,
                       "index": "exact k-mer set of the donor, abundance of a k-mer = Poisson(24) drawn from its hash, at least 3 (SURVEY 8d; no reads simulated)", "nb_solid_kmers": int(info["nb_solid_kmers"]),
@@ -1081,7 +1106,7 @@ def main():
         # contig mode (BASELINE configs[2]), the tool on a resident index: the reference's bundled case (GFA == gold.gfa), 2 000 and
         # 10 000 contigs cut from a synthetic donor with the all-pairs dictionary (2 (N - 1) targets per seed), a sample of the seeds against the CPU oracle
         if not os.environ.get("MTG_BENCH_NO_CONTIG"):
-            for key, args, tmo in (("secondary_contig_bundled", ["--bundled"], 120), ("secondary_contig_2k", ["--contigs", "2000", "--oracle-stride", "40", "--repeats", "2"], 180),
+            for key, args, tmo in (("secondary_contig_bundled", ["--bundled"], 120), ("secondary_contig_2k", ["--contigs", "2000", "--oracle-stride", "40", "--repeats", "1"], 180),
                                    ("secondary_contig_10k", ["--contigs", "10000", "--oracle-stride", "400", "--repeats", "1"], 400)):
                 try:
                     cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r6_contig_workload.py")] + args, capture_output=True, text=True, timeout=tmo)

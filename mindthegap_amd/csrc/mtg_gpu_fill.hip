@@ -955,6 +955,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             HIP_TRY(hipEventRecord(ev0, stream)); /* ev0 .. evf = the walk kernel's first launch, evf .. ev1 = rounds and the finishing kernel */
             const bool no_lean = tune::on(tune::T_NO_LEAN); /* A/B and test hook: every contig is materialised */
             const bool skip_finish = tune::on(tune::T_DEBUG_SKIP_FINISH); /* diagnostics: the parked gaps stay parked (and fail as overflowing gaps) */
+            if (skip_finish) rounds = 0; /* (with rounds a resumed walk would list a gap its first walk has already listed: the lists hold one entry per gap -- advisor, round 5) */
             LeanIn li;
             li.tle = d_tle; li.tbad = d_tbad; li.toff = d_toff; li.tcnt = d_tcnt; li.fast_ok = d_fok;
             li.lean_allowed = (in.want_all_contigs || no_lean || !cfg.cmd_cap) ? 0u : 1u;
@@ -1140,7 +1141,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
             /* The multi-contig gaps on the DEVICE (round 5; HOST_GENERAL of the tuning table: the host's path for all of them, as until round 4): k_paths
              * and k_general over the list k_emit made, queued before the result copies; what comes back is a header per gap, the solutions and their
              * ASCII -- not every record of the launch, the gaps' contigs and 16 KB of paths per gap (540 MB of a 100 000-gap indel batch). */
-            const bool dev_general = tot.n_general > 0 && !host_paths && !in.want_all_contigs && !tune::on(tune::T_HOST_GENERAL);
+            const bool dev_general = tot.n_general > 0 && !host_paths && !in.want_all_contigs && !tune::on(tune::T_HOST_GENERAL) && !tl_host_general;
             GenCtl* h_gctl = nullptr;
             GenDev GD{};
             if (dev_general) {

@@ -721,6 +721,8 @@ static void finish_general(GapWork& W, GenWork& gw, const std::vector<uint32_t>&
     }
 }
 
+thread_local bool tl_host_general = false;
+
 static std::string revcomp_str(const std::string& s) /* revcomp_sequence, src/Utils.cpp:44-77: other characters are dropped */
 {
     std::string r;
@@ -805,12 +807,16 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
         describe(sg.gap, work[i]);
         if (from_device(sg, work[i])) { on_device[i] = 1; return; }
         /* the host's path needs the gap's contigs: a launch whose multi-contig gaps the device all finished did not bring them (device_run copies
-         * them when a gap came back GEN_HOST).  A finished gap the host cannot take over -- two targets under one name are screened out before the
-         * launch (FillInput::host_general), so this is a malformed answer -- is an error of the batch, not a read through a null pointer. */
+         * them when a gap came back GEN_HOST).  A finished gap the host cannot take over (two targets under one name: one group in the reference) asks
+         * for the batch to be run again with the host's path for every multi-contig gap (fill_marshalled) -- not a read through a null pointer. */
         if (!special.chunks[sg.chunk]->recs) { no_contigs.store(true, std::memory_order_relaxed); return; }
         genw[i] = process_general(special.view(sg), work[i], k);
     }, 1);
-    if (no_contigs.load()) { set_error("a multi-contig gap the device reported finished could not be taken from its answer, and its contigs are not on the host"); return MTG_ERR_FORMAT; }
+    if (no_contigs.load()) {
+        if (!tl_host_general) return MTG_INTERNAL_RETRY_HOST_GENERAL;
+        set_error("a multi-contig gap could not be taken from the device's answer, and its contigs are not on the host");
+        return MTG_ERR_FORMAT;
+    }
     if (!check_of.empty()) {
         DevBatch sub; /* the same gaps as a batch of their own with the device's answers hidden: run_general's host path, whole */
         for (size_t i : check_of) {
@@ -832,6 +838,7 @@ static int run_general(const mtg_index* idx, const mtg_params* p, const DevBatch
         borrowed->gen_check = saved;
         if (crc) return crc;
         for (size_t q = 0; q < check_of.size(); q++) {
+            if (!on_device[check_of[q]]) continue; /* the host could not take this gap from the device's answer (two targets under one name): its own path is what runs, below */
             const GapWork& a = work[check_of[q]];
             const GapWork& b = check[q];
             bool same = a.sols.size() == b.sols.size() && a.nb_total_filled == b.nb_total_filled && a.has_counts == b.has_counts;
@@ -1207,6 +1214,11 @@ int fill_marshalled(const mtg_index* idx, const mtg_params* p, const mtgi::FillI
             w.targets.n = (uint32_t)w.target_store.size();
         };
         rc = run_general(idx, p, special, describe, R->gen, in.ws);
+        if (rc == MTG_INTERNAL_RETRY_HOST_GENERAL) {
+            /* once more, every multi-contig gap by the host's path (its contigs come along): this attempt's result object goes back to the pool */
+            struct Flag { Flag() { tl_host_general = true; } ~Flag() { tl_host_general = false; } } flag;
+            return fill_marshalled(idx, p, in, gaps, n, seq_out, seq_cap, seq_bytes, out, t_begin, d_seq_out, wire, tg, fmt);
+        }
         if (rc) return rc;
         size_t total = 0;
         for (const GapWork& w : R->gen) total += w.sols.size();

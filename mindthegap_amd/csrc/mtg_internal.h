@@ -542,6 +542,10 @@ struct DevBatch {
     GapDev view(const SpecialGap& s) const { return view(*chunks[s.chunk], s.slot); }
 };
 
+/* set by fill_marshalled around the second attempt at a batch one of whose multi-contig gaps the host could not take from the device's answer (two targets
+ * under one name: the reference keeps their paths in ONE group): device_run then hands every multi-contig gap to the host's path, contigs and all */
+extern thread_local bool tl_host_general;
+enum { MTG_INTERNAL_RETRY_HOST_GENERAL = -1000 }; /* run_general's "do the launch again with the host's path" (never leaves the library) */
 /* traversal + post-processing + result emission for all gaps (chunked, tiered); returns MTG_* status.  `while_busy` runs once on the
  * calling thread after everything of the first launch has been queued: the device needs nothing more from the host. */
 int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, ResultSink& sink, DevBatch& special, mtg_batch_stats* stats,

@@ -1522,3 +1522,35 @@ def test_light_walk_form_on_data_with_bubbles(emu_product, tmp_path, monkeypatch
     _allelic_inserts_case(emu_product, tmp_path / "al", 8)
     (tmp_path / "ct").mkdir()
     _contig_several_targets_case(emu_product, tmp_path / "ct", monkeypatch, 6)
+
+
+def _duplicate_target_names_case(mtg):
+    """two REACHED targets of a gap under one name (and orientation): the reference keeps their paths in one group of its map (src/Filler.cpp:924-936), the
+    device function answers two -- the host cannot take such a gap from the device's answer and the batch is run again with the host's path for its
+    multi-contig gaps (advisor r5: a launch whose gaps the device all finished has no contigs on the host).  Records == those of the host's path alone."""
+    rng = random.Random(616)
+    seqs, gaps = [], []
+    for i in range(24):
+        X, Y, Z = _rand_seq(rng, 300), _rand_seq(rng, 300), _rand_seq(rng, 300)
+        a, b = _rand_seq(rng, rng.randrange(60, 300)), _rand_seq(rng, rng.randrange(60, 300))
+        seqs += [X + a + Y, X + b + Z]
+        dup = i % 3 != 2
+        tg = [(Y[40:71], "twin_%d" % i, False), (Z[40:71], "twin_%d" % i if dup else "other_%d" % i, False), (_rand_seq(rng, 31), "unreached", True)]
+        gaps.append(mtg.Gap(X[200:231], "".join(t[0] for t in tg), tg))
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    o.close()
+    idx = mtg.Index.from_kmers(km, ct, 31)
+    res = idx.fill_batch(gaps)
+    mtg.tuning_set("HOST_GENERAL", "1")
+    try:
+        want = idx.fill_batch(gaps)
+    finally:
+        mtg.tuning_set("HOST_GENERAL", None)
+    idx.close()
+    assert res == want
+    assert sum(1 for r in res if len(r["filled"]) >= 2) >= 20
+
+
+def test_two_reached_targets_under_one_name(emu_product):
+    _duplicate_target_names_case(emu_product)

@@ -845,3 +845,9 @@ def test_partitioned_junction_table_equals_the_scattered_insertion(mtg):
         del w, wo, ln
     assert built["0"] == built["1"]
     assert built["1"][0]["nb_solid_kmers"] > 5 * 10**6 and sum(1 for r in built["1"][4] if r) > 300
+
+
+@pytest.mark.gpu
+def test_two_reached_targets_under_one_name_on_device(mtg):
+    from tests.test_emu_parity import _duplicate_target_names_case
+    _duplicate_target_names_case(mtg)
