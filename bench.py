@@ -126,6 +126,14 @@ def _num(x, digits=4):
 COMPACT_LIMIT = 6000  # bytes: what the driver's tail of stdout holds with room to spare (round 4's 24 KB line was not parsed)
 
 
+def _phase_sums(phases):
+    """name -> ms of the construction's phases of at least 1 ms; a phase that runs once per chunk of the input (the partitioned junction table) is its sum"""
+    acc = {}
+    for ph in phases:
+        acc[ph["name"]] = acc.get(ph["name"], 0.0) + ph.get("ms", 0.0)
+    return {k: _num(v, 3) for k, v in acc.items() if v >= 1.0}
+
+
 def compact_line(out, detail_path=None):
     """The ONE line the driver parses, from the detail object: the contract's keys, a compact `roofline` (dominant fill kernel against HBM on
     the bytes the layout must move; the link the job is bound by; the index construction on SURVEY 8d's bytes), a compact `cpu_baseline`,
@@ -172,7 +180,7 @@ def compact_line(out, detail_path=None):
         line["index_build"] = {"seconds": _num(ib.get("seconds")), "device_seconds": _num(ib.get("device_seconds")), "hipmalloc_seconds": _num(ib.get("hipmalloc_seconds")),
                                "peak_device_bytes": ib.get("peak_device_bytes"), "resident_bytes": ib.get("resident_bytes"),
                                "sec8d_bytes": _num(g(ib, "reference_algorithm_equivalent", "bytes"), 5), "sec8d_frac_over_device_seconds": _num(ib.get("sec8d_frac_over_device_seconds")),
-                               "phases_ms": {ph["name"]: _num(ph["ms"], 3) for ph in ib.get("phases", []) if ph.get("ms", 0) >= 1.0}}
+                               "phases_ms": _phase_sums(ib.get("phases", []))}
     e2e = out.get("end_to_end")
     if isinstance(e2e, dict):
         line["end_to_end"] = {"sites": cfg.get("sites_per_batch"), "from_donor_in_hbm_s": _num(g(e2e, "from_donor_in_hbm", "seconds")), "from_container_s": _num(g(e2e, "from_container", "seconds")),
