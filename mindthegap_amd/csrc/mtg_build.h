@@ -428,6 +428,37 @@ MTG_DEV bool marks_find(const MarkTab& m, uint64_t key, uint64_t& val)
     }
     return false;
 }
+/* a set of 62-bit keys (canonical k-mers, canonical junctions) in open addressing: a slot holds key + 1, 0 = free.  Filled and read by different kernels. */
+struct KeySet {
+    uint64_t* keys;
+    uint64_t mask; /* capacity - 1 (a power of two) */
+};
+/* true: the key is in the set now and was not before */
+MTG_DEV bool keyset_insert(const KeySet& s, uint64_t key)
+{
+    uint64_t h = mix64(key) & s.mask;
+    for (uint32_t probe = 0; probe < 512; probe++) {
+        uint64_t cur = marks_load(s.keys + h);
+        if (cur == 0) cur = atomic_cas64(s.keys + h, 0, key + 1);
+        if (cur == 0) return true;
+        if (cur == key + 1) return false;
+        h = (h + 1) & s.mask;
+    }
+    return false;
+}
+MTG_DEV bool keyset_has(const KeySet& s, uint64_t key)
+{
+    uint64_t h = mix64(key) & s.mask;
+    for (uint32_t probe = 0; probe < 512; probe++) {
+        const uint64_t cur = s.keys[h];
+        if (cur == 0) return false;
+        if (cur == key + 1) return true;
+        h = (h + 1) & s.mask;
+    }
+    return true; /* (a set this full is not built; "perhaps" is the safe answer for both users) */
+}
+/* a record whose unitig was found by POSITION in a packed sequence (mtg_gpu_build.hip: k_pos_plan): no walker holds its sequence */
+static const uint32_t REC_BY_POSITION = 0xFFFFFFFEu;
 /* what the walkers of a launch share */
 struct WalkShared {
     Table jt;
@@ -441,6 +472,7 @@ struct WalkShared {
     uint64_t rec_cap;
     uint64_t* w_chunk;            /* per walker: first chunk of its sequence (~0: the pool ran out) */
     uint32_t* w_cnt;              /* per walker: k-mers it holds */
+    KeySet done;                  /* keys == nullptr: none.  Canonical end k-mers of the chains that are stored already (found by position): their walkers leave at once */
 };
 /* one walker.  begin(), then step() until it returns false (the device: a loop in the lane; the TEST-ONLY emulation steps all walkers of a
  * graph in turns, so that they do meet in the middle) */
@@ -455,6 +487,7 @@ struct JtWalker {
         self = i; n = 1; lines = 0; done = false;
         start_f = S.starts[i];
         cur = make_kmer(start_f, S.k);
+        if (S.done.keys && keyset_has(S.done, canon(cur))) { done = true; S.w_chunk[self] = ~0ULL; S.w_cnt[self] = 0; W.pool = S.pool; W.first = W.cur = ~0ULL; W.wpos = 1; W.acc = 0; W.nacc = 0; return; }
         W.begin(S.pool);
         for (int j = S.k - 1; j >= 0; j--) W.nt((uint32_t)(start_f >> (2 * j)) & 3u);
     }
@@ -533,8 +566,9 @@ MTG_DEV bool us_compact(const UStore& us, int k, const UsRec& r, uint64_t walk, 
 {
     uint64_t* w = us.words + r.hdr;
     const uint64_t L = (uint64_t)r.len_k + (uint32_t)k - 1; /* nucleotides */
-    if (lane == 0) w[0] = L;
     const uint32_t owner = (uint32_t)walk, partner = (uint32_t)(walk >> 32);
+    if (owner == REC_BY_POSITION) return true; /* its sequence comes straight from the packed input (k_us_from_seq) */
+    if (lane == 0) w[0] = L;
     for (int side = 0; side < 2; side++) {
         const uint32_t who = side ? partner : owner;
         if (who == 0xFFFFFFFFu) continue;

@@ -297,6 +297,9 @@ enum { BIN_TILE = 8192 };
 #ifndef MTG_BIN1_GROUPS
 #define MTG_BIN1_GROUPS 768
 #endif
+#ifndef BIN1_U
+#define BIN1_U 4
+#endif
 /* a tile of staged (hash, bits) pairs of this workgroup to ITS regions of the level-1 bins (region (bin, workgroup): no other workgroup writes there, so
  * the cursors are the workgroup's own, in LDS, for as long as it runs -- with cursors in device memory the bins took an atomic per eight records, and
  * scattered atomics are what the construction is leaving behind) */
@@ -343,39 +346,45 @@ __global__ void __launch_bounds__(MTG_BIN1_THREADS) k_bin_positions(BinShape S, 
         const uint32_t L = len[s];
         if (L < (uint32_t)k) continue;
         const uint32_t npos = L - (uint32_t)k + 2u; /* junction positions 0 .. L - k + 1 */
-        for (uint32_t q0 = 0; q0 < npos; q0 += blockDim.x) {
+        for (uint32_t q0 = 0; q0 < npos; q0 += blockDim.x * BIN1_U) { /* BIN1_U positions a lane and turn: their loads are in flight together, the turn's two barriers are shared */
             const uint32_t n_now = s_n; /* every thread reads the count BEFORE any wave of this round adds to it: the barrier keeps the test uniform */
             __syncthreads();
-            if (n_now + blockDim.x > MTG_BIN1_TILE) {
+            if (n_now + blockDim.x * BIN1_U > MTG_BIN1_TILE) {
                 bin1_flush(S, n_now, s_h, s_b, s_hist, s_base, s_cur, bins1, ov);
                 if (threadIdx.x == 0) s_n = 0;
                 __syncthreads();
             }
-            const uint32_t q = q0 + threadIdx.x;
-            uint64_t H = 0;
-            uint32_t bits = 0;
-            if (q < npos) { /* as k_jt_insert_packed: nucleotides q-1 .. q+k-1 in one little-endian window [a][J: k-1][b] */
-                const bool has_a = q >= 1, has_b = q + (uint32_t)k - 1 < L;
-                const uint32_t qa = has_a ? q - 1 : q, sh = 2u * (qa & 31u), need = (uint32_t)k - 1u + (has_a ? 1u : 0u) + (has_b ? 1u : 0u);
-                uint64_t win = w[qa >> 5] >> sh;
-                if ((qa & 31u) + need > 32u) win |= w[(qa >> 5) + 1] << (64u - sh);
-                const uint32_t a = (uint32_t)win & 3u;
-                const uint64_t body = has_a ? win >> 2 : win;
-                const uint64_t jle = body & mk1;
-                const uint32_t b = (uint32_t)(body >> (2 * (k - 1))) & 3u;
-                const uint64_t jr = jle ^ cmpl1, jf = revcomp(jr, k - 1);
-                bits = jt_junction_bits(jf, jr, has_a, a, has_b, b);
-                H = mix(jf <= jr ? jf : jr, S.kb);
+            uint64_t Hs[BIN1_U];
+            uint32_t bs[BIN1_U];
+#pragma unroll
+            for (int u = 0; u < BIN1_U; u++) {
+                const uint32_t q = q0 + (uint32_t)u * blockDim.x + threadIdx.x;
+                Hs[u] = 0; bs[u] = 0;
+                if (q < npos) { /* as k_jt_insert_packed: nucleotides q-1 .. q+k-1 in one little-endian window [a][J: k-1][b] */
+                    const bool has_a = q >= 1, has_b = q + (uint32_t)k - 1 < L;
+                    const uint32_t qa = has_a ? q - 1 : q, sh = 2u * (qa & 31u), need = (uint32_t)k - 1u + (has_a ? 1u : 0u) + (has_b ? 1u : 0u);
+                    uint64_t win = w[qa >> 5] >> sh;
+                    if ((qa & 31u) + need > 32u) win |= w[(qa >> 5) + 1] << (64u - sh);
+                    const uint32_t a = (uint32_t)win & 3u;
+                    const uint64_t body = has_a ? win >> 2 : win;
+                    const uint64_t jle = body & mk1;
+                    const uint32_t b = (uint32_t)(body >> (2 * (k - 1))) & 3u;
+                    const uint64_t jr = jle ^ cmpl1, jf = revcomp(jr, k - 1);
+                    bs[u] = jt_junction_bits(jf, jr, has_a, a, has_b, b);
+                    Hs[u] = mix(jf <= jr ? jf : jr, S.kb);
+                }
             }
-            /* the wave's records one after the other in the staging arrays */
-            const unsigned long long mball = __ballot(bits != 0u);
-            uint32_t wbase = 0;
-            if ((threadIdx.x & 63u) == 0 && mball) wbase = atomicAdd(&s_n, (uint32_t)__popcll(mball));
-            wbase = (uint32_t)__shfl((int)wbase, 0, 64);
-            if (bits) {
-                const uint32_t at = wbase + (uint32_t)__popcll(mball & ((1ull << (threadIdx.x & 63u)) - 1ull));
-                s_h[at] = H;
-                s_b[at] = (uint8_t)bits;
+#pragma unroll
+            for (int u = 0; u < BIN1_U; u++) { /* the wave's records one after the other in the staging arrays */
+                const unsigned long long mball = __ballot(bs[u] != 0u);
+                uint32_t wbase = 0;
+                if ((threadIdx.x & 63u) == 0 && mball) wbase = atomicAdd(&s_n, (uint32_t)__popcll(mball));
+                wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+                if (bs[u]) {
+                    const uint32_t at = wbase + (uint32_t)__popcll(mball & ((1ull << (threadIdx.x & 63u)) - 1ull));
+                    s_h[at] = Hs[u];
+                    s_b[at] = (uint8_t)bs[u];
+                }
             }
             __syncthreads();
         }
