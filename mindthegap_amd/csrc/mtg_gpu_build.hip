@@ -611,6 +611,146 @@ __global__ void __launch_bounds__(256) k_us_compact(UStore us, int k, const UsRe
     for (unsigned long long u = wave; u < n; u += nwaves) bad = !us_compact(us, k, rec[u], S.rec_walk[u], S, lane, 64u) || bad;
     if (bad && lane == 0) atomicOr(&flag[0], 1ull);
 }
+/* ---- chains found by POSITION (round 6).  When the graph comes from packed sequences whose every k-mer is solid, a chain of the graph that lies
+ * whole inside one sequence need not be WALKED on the junction table (one dependent random read per junction: 3.0e9 of them, 97 ms at human scale,
+ * the rate this memory gives random lines): it is the piece of the sequence between two consecutive junctions that are no chain interior, and those
+ * -- the left junction of every chain start, both junctions of every k-mer of no chain: what the scan has just listed -- are few (two per chain).
+ * They go into a set (with a bit filter that stays in L2 in front of it); one streaming pass over the sequences asks every junction position of
+ * it, cuts each sequence at its hits and turns every piece between two hits into a record of the store, owned as the walkers decide it (the end with the
+ * smaller canonical k-mer; none when the two are equal) and claimed once (the same chain may lie in many sequences) in a set of finished chains.
+ * The walkers of those chains' starts leave at once (JtWalker::begin); chains that no sequence holds whole -- put together from overlapping
+ * sequences -- are walked as before.  The sequence of such a record is copied from the input (k_us_from_seq), not from chunks. */
+struct PackedSeqs {
+    const uint64_t* words;    /* 2-bit nucleotides, 32 a word, every sequence from a word boundary */
+    const uint64_t* word_off; /* per sequence: its first word */
+    const uint32_t* len;      /* per sequence: nucleotides */
+    size_t nseq;
+};
+struct PosSets {
+    KeySet stops;         /* canonical junctions that are no chain interior */
+    uint32_t* filter;     /* one bit per hash value of a stop */
+    uint64_t filter_mask; /* bits - 1 */
+    KeySet done;          /* canonical end k-mers of the claimed chains */
+};
+__device__ __forceinline__ uint64_t pos_filter_bit(const PosSets& P, uint64_t key) { return (mix64(key) >> 24) & P.filter_mask; }
+__device__ __forceinline__ void pos_add_stop(const PosSets& P, uint64_t jf, uint64_t jr)
+{
+    const uint64_t key = jf <= jr ? jf : jr;
+    (void)keyset_insert(P.stops, key);
+    const uint64_t b = pos_filter_bit(P, key);
+    atomicOr(&P.filter[b >> 5], 1u << (b & 31u));
+}
+__global__ void __launch_bounds__(256) k_pos_stops(PosSets P, int k, const uint64_t* __restrict__ starts, unsigned long long n_starts, const uint64_t* __restrict__ left_k, unsigned long long n_left)
+{
+    const uint64_t mk1 = kmask(k - 1);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_starts + n_left; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const bool lone = i >= n_starts;
+        const Kmer x = make_kmer(lone ? left_k[i - n_starts] : starts[i], k);
+        pos_add_stop(P, x.f >> 2, x.r & mk1);           /* the junction on its left */
+        if (lone) pos_add_stop(P, x.f & mk1, x.r >> 2); /* a k-mer of no chain: the one on its right as well */
+    }
+}
+enum { POS_U = 4, POS_TILE = 256 * POS_U };
+__global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int k, WalkShared S, uint64_t* __restrict__ pos_src)
+{
+    __shared__ uint32_t s_list[POS_TILE + 1]; /* [0]: the last stop of the tiles before (or none), then this tile's stops in order */
+    __shared__ uint32_t s_wc[POS_U * 4];
+    __shared__ uint32_t s_prev;
+    const uint64_t mk = kmask(k), mk1 = kmask(k - 1), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk, cmpl1 = 0xAAAAAAAAAAAAAAAAULL & mk1;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t cap = MTG_US_MAX_LEN - (uint32_t)k;
+    for (size_t s = blockIdx.x; s < in.nseq; s += gridDim.x) {
+        const uint32_t L = in.len[s];
+        if (L < (uint32_t)k) continue;
+        const uint64_t* __restrict__ w = in.words + in.word_off[s];
+        const uint32_t npos = L - (uint32_t)k + 2u;
+        if (threadIdx.x == 0) s_prev = 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t q0 = 0; q0 < npos; q0 += POS_TILE) {
+            bool stop[POS_U];
+#pragma unroll
+            for (int u = 0; u < POS_U; u++) {
+                const uint32_t q = q0 + (uint32_t)u * 256u + threadIdx.x;
+                stop[u] = false;
+                if (q < npos) { /* the junction at q: nucleotides q .. q + k - 2 */
+                    const uint32_t sh = 2u * (q & 31u);
+                    uint64_t win = w[q >> 5] >> sh;
+                    if ((q & 31u) + (uint32_t)k - 1u > 32u) win |= w[(q >> 5) + 1] << (64u - sh);
+                    const uint64_t jr = (win & mk1) ^ cmpl1, jf = revcomp(jr, k - 1);
+                    const uint64_t key = jf <= jr ? jf : jr;
+                    const uint64_t b = pos_filter_bit(P, key);
+                    if ((P.filter[b >> 5] >> (b & 31u)) & 1u) stop[u] = keyset_has(P.stops, key);
+                }
+            }
+            unsigned long long mball[POS_U];
+#pragma unroll
+            for (int u = 0; u < POS_U; u++) {
+                mball[u] = __ballot(stop[u]);
+                if (lane == 0) s_wc[u * 4 + (int)wave] = (uint32_t)__popcll(mball[u]);
+            }
+            __syncthreads();
+            uint32_t total = 0;
+#pragma unroll
+            for (int u = 0; u < POS_U; u++) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const uint32_t c = s_wc[u * 4 + v];
+                    if (stop[u] && (uint32_t)v == wave) s_list[1 + total + (uint32_t)__popcll(mball[u] & ((1ull << lane) - 1ull))] = q0 + (uint32_t)u * 256u + threadIdx.x;
+                    total += c;
+                }
+            }
+            if (threadIdx.x == 0) s_list[0] = s_prev;
+            __syncthreads();
+            /* the pieces: k-mers a .. b - 1 between the consecutive stops a < b */
+            for (uint32_t i = threadIdx.x; i < total; i += 256u) {
+                const uint32_t a = s_list[i], b = s_list[i + 1];
+                if (a == 0xFFFFFFFFu) continue;
+                const uint32_t len_k = b - a;
+                if (len_k < 2u || len_k >= cap) continue; /* one k-mer: the scan has it; too long for a unitig: the walkers and the late pass, as ever */
+                Kmer X, Y;
+                X.r = us_peek64(w, a, (uint32_t)k, false) ^ cmpl; X.f = revcomp(X.r, k);
+                Y.r = us_peek64(w, b - 1u, (uint32_t)k, false) ^ cmpl; Y.f = revcomp(Y.r, k);
+                const uint64_t cX = canon(X), cY = canon(Y);
+                if (cX == cY) continue; /* no walker owns such a chain either */
+                const bool fwd = cX < cY; /* the chain is stored from the end with the smaller canonical k-mer */
+                if (!keyset_insert(P.done, fwd ? cX : cY)) continue; /* claimed from another sequence (or the set is full: then the walkers do it) */
+                (void)keyset_insert(P.done, fwd ? cY : cX);
+                const uint64_t r = atomicAdd(&S.counters[JT_C_RECS], 1ull);
+                const uint64_t wd = atomicAdd(&S.counters[JT_C_WORDS], (unsigned long long)us_words_of(len_k, k));
+                atomicAdd(&S.counters[JT_C_STORED_VIEWS], 2ull * (len_k - 1u));
+                if (r < S.rec_cap) {
+                    S.rec[r].start_f = fwd ? X.f : Y.r; S.rec[r].len_k = len_k; S.rec[r].pad_ = 0; S.rec[r].hdr = wd;
+                    S.rec_walk[r] = (uint64_t)REC_BY_POSITION | (0xFFFFFFFFull << 32);
+                    pos_src[r] = ((in.word_off[s] * 32ull + a) << 1) | (fwd ? 0ull : 1ull);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0 && total) s_prev = s_list[total];
+            /* (the next tile's first barrier orders this store before s_list[0] is written from it) */
+        }
+        __syncthreads();
+    }
+}
+/* one record found by position per wave: header word and sequence from the packed input, as it stands or reverse-complemented */
+__global__ void __launch_bounds__(256) k_us_from_seq(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, const uint64_t* __restrict__ rec_walk,
+                                                     const uint64_t* __restrict__ pos_src, const uint64_t* __restrict__ words)
+{
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (unsigned long long u = wave; u < n; u += nwaves) {
+        if ((uint32_t)rec_walk[u] != REC_BY_POSITION) continue;
+        const UsRec r = rec[u];
+        const uint64_t L = (uint64_t)r.len_k + (uint32_t)k - 1;
+        const uint64_t nt0 = pos_src[u] >> 1;
+        const bool rev = pos_src[u] & 1ull;
+        uint64_t* o = us.words + r.hdr;
+        if (lane == 0) o[0] = L;
+        for (uint64_t j = lane; 32 * j < L; j += 64) {
+            const uint32_t cnt = (uint32_t)(L - 32 * j < 32 ? L - 32 * j : 32);
+            o[1 + j] = rev ? us_peek64(words, nt0 + L - 1 - 32 * j, cnt, true) : us_peek64(words, nt0 + 32 * j, cnt, false);
+        }
+    }
+}
 /* one stored unitig per wave, its k-mers dealt to the lanes: abundances from the source into the store.  counters[JT_C_SAT] += those above 255 */
 template <typename Src>
 __global__ void __launch_bounds__(256) k_us_ab(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, Src src, unsigned long long* counters)
@@ -828,7 +968,8 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
  * the abundances are asked; release_source() frees what src reads once the store holds every abundance.  Leaves idx with the unitig store,
  * the sparse tables derived from it, the Bloom filter and the graph's statistics. */
 template <typename Src>
-static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const Src& src, const std::function<void()>& release_source, uint64_t sat_at_insert, BuildProf& prof)
+static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const Src& src, const std::function<void()>& release_source, uint64_t sat_at_insert, BuildProf& prof,
+                         const PackedSeqs* packed = nullptr /* the sequences the table was made from, every k-mer of theirs solid: chains are looked for by position first */)
 {
     const int k = idx->dev.k;
     const uint64_t nslots = jt.nbuckets * MTG_ABND_SLOTS;
@@ -890,6 +1031,8 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
     unsigned long long n_words = 0, n_rec = 0, stored_views = 0;
     uint64_t *p_pool = nullptr, *p_rec_walk = nullptr, *p_marks = nullptr, *p_wchunk = nullptr;
     uint32_t* p_wcnt = nullptr;
+    uint64_t* p_pos_src = nullptr;
+    bool positional = false;
     WalkShared WS{};
     ChunkPool& pool = WS.pool;
     if (n_starts) {
@@ -916,6 +1059,31 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
         prof.begin();
         HIP_TRY(hipMemsetAsync(p_marks, 0xFF, mcap * 16, 0));
         HIP_TRY(prof.end("clear_marks", mcap * 16, 0));
+        positional = packed && packed->nseq && (tune::is_set(tune::T_BUILD_POSITIONAL) ? tune::on(tune::T_BUILD_POSITIONAL) : true);
+        if (positional) {
+            /* the chains that lie whole in one sequence, by position (k_pos_plan); what is left is walked */
+            const unsigned long long n_stops = n_starts + 2 * n_single;
+            uint64_t scap = 1024, dcap = 1024, fbits = 1ull << 16;
+            while (scap < 2 * n_stops) scap <<= 1;
+            while (dcap < 2 * n_starts) dcap <<= 1;
+            while (fbits < 16 * n_stops && fbits < (1ull << 32)) fbits <<= 1; /* 4 MB at human scale: it stays in every L2 */
+            PosSets PS{};
+            HIP_TRY(behind.take((void**)&PS.stops.keys, scap * 8));
+            HIP_TRY(behind.take((void**)&PS.done.keys, dcap * 8));
+            HIP_TRY(behind.take((void**)&PS.filter, fbits / 8));
+            HIP_TRY(behind.take((void**)&p_pos_src, rec_cap * 8));
+            PS.stops.mask = scap - 1; PS.done.mask = dcap - 1; PS.filter_mask = fbits - 1;
+            prof.begin();
+            HIP_TRY(hipMemsetAsync(PS.stops.keys, 0, scap * 8, 0));
+            HIP_TRY(hipMemsetAsync(PS.done.keys, 0, dcap * 8, 0));
+            HIP_TRY(hipMemsetAsync(PS.filter, 0, fbits / 8, 0));
+            hipLaunchKernelGGL(k_pos_stops, dim3((unsigned)std::min<unsigned long long>((n_stops + 255) / 256, 256 * 16)), dim3(256), 0, 0, PS, k, (const uint64_t*)p_starts, n_starts, (const uint64_t*)d_left_k.as<uint64_t>(), n_single);
+            HIP_TRY(prof.end("pos_stops", n_stops * 24 + scap * 8 + dcap * 8 + fbits / 8, n_stops));
+            prof.begin();
+            hipLaunchKernelGGL(k_pos_plan, dim3((unsigned)std::min<size_t>(packed->nseq, 256 * 8)), dim3(256), 0, 0, PS, *packed, k, WS, p_pos_src);
+            HIP_TRY(prof.end("pos_plan", (interior / 2 + n_starts) / 4 + n_starts * 40, interior / 2 + n_starts)); /* the sequences once; per chain its record and its two claims */
+            WS.done = PS.done;
+        }
         prof.begin();
         hipLaunchKernelGGL(k_jt_walk, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, WS, n_starts);
         HIP_TRY(prof.end("jt_walk", (interior / 2 + n_starts) * 32 + (interior / 2 + n_starts) / 4 + ((interior / 2) / JT_MARK_EVERY) * 3 * 64, interior / 2 + n_starts)); /* a chain's junctions once between its two walkers: one bucket per step, a quarter byte written; a mark every 32 */
@@ -945,6 +1113,11 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
         HIP_TRY(hipMemset(cnt_d + JT_C_N + 1, 0, 8));
         hipLaunchKernelGGL(k_us_compact, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, WS, cnt_d + JT_C_N + 1);
         HIP_TRY(prof.end("us_compact", n_words * 16 + n_words * 40, n_rec)); /* the words out of their chunks and into the store; the clearing of words and abundance bytes */
+        if (positional) {
+            prof.begin();
+            hipLaunchKernelGGL(k_us_from_seq, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, (const uint64_t*)p_rec_walk, (const uint64_t*)p_pos_src, packed->words);
+            HIP_TRY(prof.end("us_from_seq", n_words * 16, n_rec));
+        }
         unsigned long long short_chain = 0;
         HIP_TRY(hipMemcpy(&short_chain, cnt_d + JT_C_N + 1, 8, hipMemcpyDeviceToHost));
         if (short_chain) { set_error("unitig construction: a chunk chain is shorter than its record"); return MTG_ERR_OVERFLOW; }
@@ -1239,7 +1412,8 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
     if (rc) return rc;
     AbSynth src;
     src.lo = abund_lo; src.span = abund_span;
-    if (int rc2 = build_from_jt(idx, jt_buf, jt, src, [] {}, 0, prof)) return rc2;
+    const PackedSeqs packed{d_words, d_word_off, d_len, nseq};
+    if (int rc2 = build_from_jt(idx, jt_buf, jt, src, [] {}, 0, prof, &packed)) return rc2;
     idx->info.k = k;
     idx->info.abundance_min = (int)abund_lo;
     idx->info.abundance_auto = -1;

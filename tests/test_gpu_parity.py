@@ -847,6 +847,100 @@ def test_partitioned_junction_table_equals_the_scattered_insertion(mtg):
     assert built["1"][0]["nb_solid_kmers"] > 5 * 10**6 and sum(1 for r in built["1"][4] if r) > 300
 
 
+def _pack_codes(seqs):
+    """2-bit code arrays -> (words, word offsets, lengths): 32 nucleotides a word, lowest bits first, every sequence from a word boundary (+ one spare word)"""
+    words, off, lens = [], [], []
+    at = 0
+    sh = np.arange(32, dtype=np.uint64) * np.uint64(2)
+    for c in seqs:
+        n = len(c)
+        nw = (n + 31) // 32 + 1
+        buf = np.zeros(nw * 32, dtype=np.uint64)
+        buf[:n] = c
+        words.append((buf.reshape(nw, 32) << sh[None, :]).sum(axis=1, dtype=np.uint64))
+        off.append(at)
+        lens.append(n)
+        at += nw
+    return np.concatenate(words), np.array(off, dtype=np.uint64), np.array(lens, dtype=np.uint32)
+
+
+@pytest.mark.gpu
+def test_chains_found_by_position_equal_the_walked_ones(mtg):
+    """Graph::create from packed sequences (src/Filler.cpp:172-213), the unitigs of the index: found by position in the sequences (round 6: BUILD_POSITIONAL=1, the
+    default) and walked on the junction table (=0) must give the same index -- statistics, contains / abundance / neighbourhood of EVERY k-mer of every sequence
+    (each goes through its unitig in the store) and of absent ones, the same fills -- on a diploid donor plus the shapes that decide who stores a chain: a
+    sequence twice, a sequence and its reverse complement, two overlapping windows of one stretch (no sequence holds the chain whole: it is walked), a
+    substitution (branching), a tandem repeat, a homopolymer, a hairpin (a stretch followed by its reverse complement), a cycle written twice round,
+    sequences of k - 1, k and k + 1 nucleotides."""
+    import torch
+    from mindthegap_amd.synth import SynthSet
+    k = 31
+    S = SynthSet(nseq=2000, n_sites=300, seed=29, k=k, het_snps=2)
+    rng = np.random.default_rng(11)
+    rc = lambda c: (c[::-1] ^ 2).astype(np.uint8)
+    g = rng.integers(0, 4, 6000).astype(np.uint8)
+    h = rng.integers(0, 4, 900).astype(np.uint8)
+    snp = h.copy(); snp[450] ^= 1
+    cyc = rng.integers(0, 4, 211).astype(np.uint8)
+    extra = [g[:1500], g[:1500], rc(g[1500:2600]), g[1500:2600], g[2600:4200], g[3600:5200], h, snp,
+             np.tile(np.array([0, 1], dtype=np.uint8), 100), np.zeros(120, dtype=np.uint8), np.concatenate([g[5200:5500], rc(g[5200:5500])]),
+             np.concatenate([cyc, cyc, cyc[:k]]), g[5600:5600 + k - 1], g[5700:5700 + k], g[5800:5800 + k + 1], rc(g[5800:5800 + k + 1])]
+    ew, eo, el = _pack_codes(extra)
+    pw, po, pl, pn = S.packed()
+    words = np.concatenate([pw, ew, np.zeros(2, dtype=np.uint64)])
+    off = np.concatenate([po, eo + np.uint64(pw.size)])
+    lens = np.concatenate([pl, el])
+    nseq = pn + len(extra)
+    ub = int(np.maximum(lens.astype(np.int64) - (k - 1), 0).sum())
+    # every k-mer of the extra sequences and of a sample of the donor's, canonical; and absent ones
+    def kmers_of(c):
+        out = []
+        for p0 in range(0, len(c) - k + 1):
+            v = 0
+            for x in c[p0:p0 + k]:
+                v = (v << 2) | int(x)
+            r = 0
+            for x in c[p0:p0 + k][::-1]:
+                r = (r << 2) | (int(x) ^ 2)
+            out.append(min(v, r))
+        return out
+    km = []
+    for c in extra:
+        km += kmers_of(c)
+    for j in (0, 1, 2, 3, 1001):
+        km += kmers_of(S.codes(j)[:1200])
+    km = np.array(km + [int(x) for x in rng.integers(0, 2**62, 500)], dtype=np.uint64)
+    dev = torch.device("cuda", 0)
+    built = {}
+    for pos in ("0", "1"):
+        mtg.tuning_set("BUILD_POSITIONAL", pos)
+        try:
+            w = torch.from_numpy(words.view(np.int64)).to(dev)
+            wo = torch.from_numpy(off.view(np.int64)).to(dev)
+            ln = torch.from_numpy(lens.view(np.int32)).to(dev)
+            idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), nseq, ub, k, 3, 40)
+        finally:
+            mtg.tuning_set("BUILD_POSITIONAL", None)
+        names = [p["name"] for p in idx.build_profile()["phases"]]
+        assert ("pos_plan" in names) == (pos == "1"), names
+        info = idx.info()
+        has = idx.contains(km)
+        ab = idx.abundance(km)
+        succ, pred = idx.neighbors(km)
+        gaps = []
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+        res = idx.fill_batch(gaps)
+        built[pos] = ({k2: info[k2] for k2 in ("nb_solid_kmers", "nb_branching", "nb_unitigs", "nb_kmers_outside_unitigs", "unitig_bytes")}, has.tolist(), ab.tolist(), succ.tolist(), pred.tolist(),
+                      [[(f["seq"], f["nb_errors_in_anchor"], f["qual"]) for f in r["filled"]] for r in res])
+        idx.close()
+        del w, wo, ln
+    for a, b, what in zip(built["0"], built["1"], ("info", "contains", "abundance", "successors", "predecessors", "fills")):
+        assert a == b, what
+    assert all(built["1"][1][:len(km) - 500]) and sum(1 for r in built["1"][5] if r) > 200
+
+
 @pytest.mark.gpu
 def test_two_reached_targets_under_one_name_on_device(mtg):
     from tests.test_emu_parity import _duplicate_target_names_case
