@@ -58,6 +58,14 @@ MTG_HD uint64_t kmask(int k) { return (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1
 
 MTG_HD uint64_t revcomp(uint64_t x, int k)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* the device reverses the bits of a word in one instruction: the two halves reversed and exchanged, then the two bits of every field back in order
+     * (a dozen operations instead of the fifty of the five exchanges below; the index construction computes one of these per junction position) */
+    uint32_t lo = __builtin_bitreverse32((uint32_t)(x >> 32) ^ 0xAAAAAAAAu), hi = __builtin_bitreverse32((uint32_t)x ^ 0xAAAAAAAAu);
+    lo = ((lo >> 1) & 0x55555555u) | ((lo & 0x55555555u) << 1);
+    hi = ((hi >> 1) & 0x55555555u) | ((hi & 0x55555555u) << 1);
+    return (((uint64_t)hi << 32) | lo) >> (64 - 2 * k);
+#endif
     x ^= 0xAAAAAAAAAAAAAAAAULL;
     x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
     x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);

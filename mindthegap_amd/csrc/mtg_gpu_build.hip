@@ -288,22 +288,76 @@ __device__ __forceinline__ void bin_overflow_push(const BinOverflow& ov, uint64_
     if (at < ov.cap) { ov.h[2 * at] = H; ov.h[2 * at + 1] = bits; }
 }
 enum { BIN_TILE = 8192 };
+/* MTG_BIN_SORTED: a tile's records are put in the order of their bins IN LDS before they leave, so that neighbouring lanes write neighbouring words (a
+ * record a lane to 1 024 bins is a write request per record -- 2.9e9 of them in k_bin_positions, PMC; in bin order a request carries a bin's run) */
+#ifndef MTG_BIN_SORTED
+#define MTG_BIN_SORTED 1
+#endif
 #ifndef MTG_BIN1_TILE
-#define MTG_BIN1_TILE 4096
+#define MTG_BIN1_TILE (MTG_BIN_SORTED ? 8192 : 4096)
 #endif
 #ifndef MTG_BIN1_THREADS
-#define MTG_BIN1_THREADS 512
+#define MTG_BIN1_THREADS (MTG_BIN_SORTED ? 1024 : 512)
 #endif
 #ifndef MTG_BIN1_GROUPS
-#define MTG_BIN1_GROUPS 768
+#define MTG_BIN1_GROUPS (MTG_BIN_SORTED ? 256 : 768)
 #endif
 #ifndef BIN1_U
-#define BIN1_U 4
+#define BIN1_U (MTG_BIN_SORTED ? 2 : 4)
 #endif
+/* exclusive prefix sums of cnt[0 .. nb) into pre[0 .. nb) by the whole workgroup (nb a power of two; s_wt: one word per wave).  Ends with a barrier. */
+__device__ __forceinline__ void block_prefix(const uint32_t* cnt, uint32_t* pre, uint32_t nb, uint32_t* s_wt)
+{
+    const uint32_t per = nb > blockDim.x ? nb / blockDim.x : 1u; /* consecutive bins a thread */
+    const uint32_t b0 = threadIdx.x * per, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t mine = 0;
+    if (b0 < nb) for (uint32_t j = 0; j < per; j++) mine += cnt[b0 + j];
+    uint32_t inc = mine;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+    if (lane == 63u) s_wt[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t v = 0; v < wave; v++) before += s_wt[v];
+    uint32_t run = before + inc - mine;
+    if (b0 < nb) for (uint32_t j = 0; j < per; j++) { const uint32_t c = cnt[b0 + j]; pre[b0 + j] = run; run += c; }
+    __syncthreads();
+}
 /* a tile of staged (hash, bits) pairs of this workgroup to ITS regions of the level-1 bins (region (bin, workgroup): no other workgroup writes there, so
  * the cursors are the workgroup's own, in LDS, for as long as it runs -- with cursors in device memory the bins took an atomic per eight records, and
  * scattered atomics are what the construction is leaving behind) */
-__device__ __forceinline__ void bin1_flush(const BinShape& S, uint32_t n, const uint64_t* s_h, const uint8_t* s_b, uint32_t* s_hist, uint32_t* s_base, uint32_t* s_cur, uint64_t* bins1, const BinOverflow& ov)
+#if MTG_BIN_SORTED
+__device__ __forceinline__ void bin1_flush(const BinShape& S, uint32_t n, const uint64_t* s_h, const uint8_t* s_b, uint32_t* s_hist, uint32_t* s_pre, uint32_t* s_cur, uint64_t* bins1, const BinOverflow& ov,
+                                           uint64_t* s_oh, uint8_t* s_ob, uint32_t* s_wt)
+{
+    const uint32_t nb1 = 1u << S.b1, shb = S.kb - S.b1;
+    for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_hist[(uint32_t)(s_h[i] >> shb)], 1u);
+    __syncthreads();
+    block_prefix(s_hist, s_pre, nb1, s_wt);
+    for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) { s_cur[b] += s_hist[b]; s_hist[b] = 0; } /* the region's cursor BEFORE this tile: s_cur - (the bin's count = s_hist once the tile is sorted) */
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t H = s_h[i];
+        const uint32_t b = (uint32_t)(H >> shb);
+        const uint32_t at = s_pre[b] + atomicAdd(&s_hist[b], 1u);
+        s_oh[at] = H;
+        s_ob[at] = s_b[i];
+    }
+    __syncthreads();
+    const uint64_t low = (1ull << shb) - 1ull;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { /* lane i, lane i + 1: the same bin's next word, nearly always */
+        const uint64_t H = s_oh[i];
+        const uint32_t b = (uint32_t)(H >> shb);
+        const uint64_t pos = (uint64_t)(s_cur[b] - s_hist[b]) + (i - s_pre[b]);
+        if (pos < S.cap1) bins1[(((uint64_t)blockIdx.x << S.b1) + b) * S.cap1 + pos] = ((H & low) << 8) | s_ob[i];
+        else bin_overflow_push(ov, H, s_ob[i]);
+    }
+    __syncthreads();
+}
+#else
+__device__ __forceinline__ void bin1_flush(const BinShape& S, uint32_t n, const uint64_t* s_h, const uint8_t* s_b, uint32_t* s_hist, uint32_t* s_base, uint32_t* s_cur, uint64_t* bins1, const BinOverflow& ov,
+                                           uint64_t*, uint8_t*, uint32_t*)
 {
     const uint32_t nb1 = 1u << S.b1;
     for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) s_hist[b] = 0;
@@ -321,21 +375,34 @@ __device__ __forceinline__ void bin1_flush(const BinShape& S, uint32_t n, const 
         const uint64_t H = s_h[i];
         const uint32_t b = (uint32_t)(H >> (S.kb - S.b1));
         const uint64_t pos = (uint64_t)s_base[b] + atomicAdd(&s_hist[b], 1u);
-        if (pos < S.cap1) bins1[((uint64_t)b * gridDim.x + blockIdx.x) * S.cap1 + pos] = ((H & low) << 8) | s_b[i];
+        if (pos < S.cap1) bins1[(((uint64_t)blockIdx.x << S.b1) + b) * S.cap1 + pos] = ((H & low) << 8) | s_b[i];
         else bin_overflow_push(ov, H, s_b[i]);
     }
     __syncthreads();
 }
+#endif
 __global__ void __launch_bounds__(MTG_BIN1_THREADS) k_bin_positions(BinShape S, int k, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ len,
                                                        size_t s0, size_t s1, uint64_t* bins1, uint32_t* cur1, BinOverflow ov)
 {
     extern __shared__ uint64_t s_dyn[];
     uint64_t* s_h = s_dyn;                                        /* MTG_BIN1_TILE hashes */
+#if !MTG_BIN_SORTED
     uint8_t* s_b = reinterpret_cast<uint8_t*>(s_dyn + MTG_BIN1_TILE);  /* MTG_BIN1_TILE edge masks */
+#endif
+#if MTG_BIN_SORTED
+    uint64_t* s_oh = s_dyn + MTG_BIN1_TILE;                       /* the tile again, in bin order */
+    uint8_t* s_b = reinterpret_cast<uint8_t*>(s_dyn + 2 * MTG_BIN1_TILE);
+    uint8_t* s_ob = s_b + MTG_BIN1_TILE;
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_ob + MTG_BIN1_TILE);
+#else
+    uint64_t* s_oh = nullptr;
+    uint8_t* s_ob = nullptr;
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_b + MTG_BIN1_TILE);
+#endif
     uint32_t* s_base = s_hist + 1024;
     uint32_t* s_cur = s_base + 1024;
     __shared__ uint32_t s_n;
+    __shared__ uint32_t s_wt[16];
     const uint32_t nb1 = 1u << S.b1;
     for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) s_cur[b] = 0;
     if (threadIdx.x == 0) s_n = 0;
@@ -350,7 +417,7 @@ __global__ void __launch_bounds__(MTG_BIN1_THREADS) k_bin_positions(BinShape S, 
             const uint32_t n_now = s_n; /* every thread reads the count BEFORE any wave of this round adds to it: the barrier keeps the test uniform */
             __syncthreads();
             if (n_now + blockDim.x * BIN1_U > MTG_BIN1_TILE) {
-                bin1_flush(S, n_now, s_h, s_b, s_hist, s_base, s_cur, bins1, ov);
+                bin1_flush(S, n_now, s_h, s_b, s_hist, s_base, s_cur, bins1, ov, s_oh, s_ob, s_wt);
                 if (threadIdx.x == 0) s_n = 0;
                 __syncthreads();
             }
@@ -390,7 +457,7 @@ __global__ void __launch_bounds__(MTG_BIN1_THREADS) k_bin_positions(BinShape S, 
         }
     }
     const uint32_t n = s_n;
-    if (n) bin1_flush(S, n, s_h, s_b, s_hist, s_base, s_cur, bins1, ov);
+    if (n) bin1_flush(S, n, s_h, s_b, s_hist, s_base, s_cur, bins1, ov, s_oh, s_ob, s_wt);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb1; b += blockDim.x) cur1[(uint64_t)b * gridDim.x + blockIdx.x] = s_cur[b]; /* records of region (b, this workgroup): may exceed cap1 (the rest went to the overflow list) */
 }
@@ -401,7 +468,13 @@ __global__ void __launch_bounds__(1024) k_bin_records(BinShape S, const uint64_t
 {
     extern __shared__ uint64_t s_dyn2[];
     uint64_t* s_r = s_dyn2; /* BIN_TILE records */
+#if MTG_BIN_SORTED
+    uint64_t* s_o = s_dyn2 + BIN_TILE; /* the tile again, in bin order */
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_dyn2 + 2 * BIN_TILE);
+    __shared__ uint32_t s_wt[16];
+#else
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_dyn2 + BIN_TILE);
+#endif
     uint32_t* s_base = s_hist + 2048;
     uint32_t* s_cur = s_base + 2048;
     const uint32_t nb2 = 1u << S.b2, p = blockIdx.x;
@@ -419,7 +492,7 @@ __global__ void __launch_bounds__(1024) k_bin_records(BinShape S, const uint64_t
             const uint64_t left = n - off;
             const uint32_t take = (uint32_t)(left < BIN_TILE - fill ? left : BIN_TILE - fill);
             if (take < left && fill) break; /* a region is split only when it does not fit an empty tile */
-            const uint64_t* src = bins1 + ((uint64_t)p * G + g) * S.cap1 + off;
+            const uint64_t* src = bins1 + (((uint64_t)g << S.b1) + p) * S.cap1 + off; /* a workgroup's regions lie together (its writes stay within a few pages); this reader takes 14 KB from each */
             for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) s_r[fill + i] = src[i];
             fill += take;
             if (take == left) { g++; off = 0; } else off += take;
@@ -428,6 +501,27 @@ __global__ void __launch_bounds__(1024) k_bin_records(BinShape S, const uint64_t
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < fill; i += blockDim.x) atomicAdd(&s_hist[(uint32_t)(s_r[i] >> sh2) & (nb2 - 1u)], 1u);
         __syncthreads();
+#if MTG_BIN_SORTED
+        block_prefix(s_hist, s_base /* the prefix sums */, nb2, s_wt);
+        for (uint32_t b = threadIdx.x; b < nb2; b += blockDim.x) { s_cur[b] += s_hist[b]; s_hist[b] = 0; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < fill; i += blockDim.x) {
+            const uint64_t rec = s_r[i];
+            const uint32_t b = (uint32_t)(rec >> sh2) & (nb2 - 1u);
+            s_o[s_base[b] + atomicAdd(&s_hist[b], 1u)] = rec;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < fill; i += blockDim.x) {
+            const uint64_t rec = s_o[i];
+            const uint32_t b = (uint32_t)(rec >> sh2) & (nb2 - 1u);
+            const uint64_t pos = (uint64_t)(s_cur[b] - s_hist[b]) + (i - s_base[b]);
+            const uint64_t seg = ((uint64_t)p << S.b2) | b;
+            if (pos + 1 < S.seg_words) table[seg * S.seg_words + 1 + pos] = rec;
+            else bin_overflow_push(ov, ((uint64_t)p << (S.kb - S.b1)) | (rec >> 8), (uint32_t)rec & 255u);
+        }
+        __syncthreads();
+        continue;
+#endif
         for (uint32_t b = threadIdx.x; b < nb2; b += blockDim.x) {
             s_base[b] = s_cur[b];
             s_cur[b] += s_hist[b];
@@ -629,16 +723,30 @@ struct PackedSeqs {
 struct PosSets {
     KeySet stops;         /* canonical junctions that are no chain interior */
     uint32_t* filter;     /* one bit per hash value of a stop */
-    uint64_t filter_mask; /* bits - 1 */
+    uint32_t filter_shift; /* 32 - log2(bits) */
     KeySet done;          /* canonical end k-mers of the claimed chains */
 };
-__device__ __forceinline__ uint64_t pos_filter_bit(const PosSets& P, uint64_t key) { return (mix64(key) >> 24) & P.filter_mask; }
+/* the filter is a blocked one: a stop sets three bits of ONE 32-bit word (one load a question; with two stops a word on average one question in
+ * two hundred is answered "perhaps" -- with one bit it was one in sixteen, and a wave of 64 then went to the set itself on nearly every turn).
+ * Four 32-bit multiplications: a 64-bit mix is eight, and this is asked of every junction position. */
+struct PosProbe { uint32_t word, mask; };
+__device__ __forceinline__ PosProbe pos_filter_probe(const PosSets& P, uint64_t key)
+{
+    uint32_t h = ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA77u);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    const uint32_t g = (h * 0x297A2D39u) >> 17; /* fifteen bits: three places in the word */
+    PosProbe p;
+    p.word = h >> P.filter_shift;
+    p.mask = (1u << (g & 31u)) | (1u << ((g >> 5) & 31u)) | (1u << (g >> 10));
+    return p;
+}
 __device__ __forceinline__ void pos_add_stop(const PosSets& P, uint64_t jf, uint64_t jr)
 {
     const uint64_t key = jf <= jr ? jf : jr;
     (void)keyset_insert(P.stops, key);
-    const uint64_t b = pos_filter_bit(P, key);
-    atomicOr(&P.filter[b >> 5], 1u << (b & 31u));
+    const PosProbe pr = pos_filter_probe(P, key);
+    atomicOr(&P.filter[pr.word], pr.mask);
 }
 __global__ void __launch_bounds__(256) k_pos_stops(PosSets P, int k, const uint64_t* __restrict__ starts, unsigned long long n_starts, const uint64_t* __restrict__ left_k, unsigned long long n_left)
 {
@@ -650,15 +758,18 @@ __global__ void __launch_bounds__(256) k_pos_stops(PosSets P, int k, const uint6
         if (lone) pos_add_stop(P, x.f & mk1, x.r >> 2); /* a k-mer of no chain: the one on its right as well */
     }
 }
-enum { POS_U = 4, POS_TILE = 256 * POS_U };
+enum { POS_R = 16, POS_TILE = 256 * POS_R };
+/* a lane takes POS_R consecutive junction positions: the first junction from the words, the next ones by one nucleotide each (two shifts instead of a
+ * reverse complement a position), the filter's bit from a hash of three 32-bit multiplications */
 __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int k, WalkShared S, uint64_t* __restrict__ pos_src)
 {
     __shared__ uint32_t s_list[POS_TILE + 1]; /* [0]: the last stop of the tiles before (or none), then this tile's stops in order */
-    __shared__ uint32_t s_wc[POS_U * 4];
+    __shared__ uint32_t s_wc[4];
     __shared__ uint32_t s_prev;
     const uint64_t mk = kmask(k), mk1 = kmask(k - 1), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk, cmpl1 = 0xAAAAAAAAAAAAAAAAULL & mk1;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t cap = MTG_US_MAX_LEN - (uint32_t)k;
+    const uint32_t top = 2u * ((uint32_t)k - 2u);
     for (size_t s = blockIdx.x; s < in.nseq; s += gridDim.x) {
         const uint32_t L = in.len[s];
         if (L < (uint32_t)k) continue;
@@ -667,37 +778,49 @@ __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int 
         if (threadIdx.x == 0) s_prev = 0xFFFFFFFFu;
         __syncthreads();
         for (uint32_t q0 = 0; q0 < npos; q0 += POS_TILE) {
-            bool stop[POS_U];
+            const uint32_t qb = q0 + threadIdx.x * POS_R;
+            uint32_t stops = 0, cand = 0;
+            if (qb < npos) {
+                /* the junction at qb: nucleotides qb .. qb + k - 2; then the nucleotides that follow it, one a position */
+                uint64_t jr = us_peek64(w, qb, (uint32_t)k - 1u, false) ^ cmpl1, jf = revcomp(jr, k - 1);
+                const uint32_t a = qb + (uint32_t)k - 1u;
+                const uint32_t nnext = a < L ? (L - a < POS_R ? L - a : POS_R) : 0u;
+                const uint64_t next = nnext ? us_peek64(w, a, nnext, false) : 0ull;
+                const uint32_t nq = npos - qb < POS_R ? npos - qb : POS_R;
 #pragma unroll
-            for (int u = 0; u < POS_U; u++) {
-                const uint32_t q = q0 + (uint32_t)u * 256u + threadIdx.x;
-                stop[u] = false;
-                if (q < npos) { /* the junction at q: nucleotides q .. q + k - 2 */
-                    const uint32_t sh = 2u * (q & 31u);
-                    uint64_t win = w[q >> 5] >> sh;
-                    if ((q & 31u) + (uint32_t)k - 1u > 32u) win |= w[(q >> 5) + 1] << (64u - sh);
-                    const uint64_t jr = (win & mk1) ^ cmpl1, jf = revcomp(jr, k - 1);
-                    const uint64_t key = jf <= jr ? jf : jr;
-                    const uint64_t b = pos_filter_bit(P, key);
-                    if ((P.filter[b >> 5] >> (b & 31u)) & 1u) stop[u] = keyset_has(P.stops, key);
+                for (uint32_t r = 0; r < POS_R; r++) {
+                    if (r < nq) {
+                        const uint64_t key = jf <= jr ? jf : jr;
+                        const PosProbe pr = pos_filter_probe(P, key);
+                        if ((P.filter[pr.word] & pr.mask) == pr.mask) cand |= 1u << r; /* (no branch, no second look here: the sixteen loads are in flight together) */
+                        const uint32_t c = (uint32_t)(next >> (2u * r)) & 3u;
+                        jf = ((jf << 2) | c) & mk1;
+                        jr = (jr >> 2) | ((uint64_t)(c ^ 2u) << top);
+                    }
                 }
             }
-            unsigned long long mball[POS_U];
-#pragma unroll
-            for (int u = 0; u < POS_U; u++) {
-                mball[u] = __ballot(stop[u]);
-                if (lane == 0) s_wc[u * 4 + (int)wave] = (uint32_t)__popcll(mball[u]);
+            /* the filter's "perhaps" to the set of stops: a few a wave and tile */
+            while (__ballot(cand != 0u)) {
+                if (cand) {
+                    const uint32_t r = (uint32_t)__builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    const uint64_t jr = us_peek64(w, qb + r, (uint32_t)k - 1u, false) ^ cmpl1, jf = revcomp(jr, k - 1);
+                    if (keyset_has(P.stops, jf <= jr ? jf : jr)) stops |= 1u << r;
+                }
             }
+            /* the tile's stops in the order of their positions: lane after lane */
+            const uint32_t c = (uint32_t)__popc(stops);
+            uint32_t inc = c;
+            if (__ballot(c != 0u)) {
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+            }
+            if (lane == 63u) s_wc[wave] = inc;
             __syncthreads();
-            uint32_t total = 0;
-#pragma unroll
-            for (int u = 0; u < POS_U; u++) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const uint32_t c = s_wc[u * 4 + v];
-                    if (stop[u] && (uint32_t)v == wave) s_list[1 + total + (uint32_t)__popcll(mball[u] & ((1ull << lane) - 1ull))] = q0 + (uint32_t)u * 256u + threadIdx.x;
-                    total += c;
-                }
+            uint32_t before = 0, total = 0;
+            for (uint32_t v = 0; v < 4; v++) { const uint32_t t = s_wc[v]; if (v < wave) before += t; total += t; }
+            {
+                uint32_t at = 1u + before + inc - c;
+                for (uint32_t rest = stops; rest; rest &= rest - 1u) s_list[at++] = qb + (uint32_t)__builtin_ctz(rest);
             }
             if (threadIdx.x == 0) s_list[0] = s_prev;
             __syncthreads();
@@ -1066,13 +1189,14 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
             uint64_t scap = 1024, dcap = 1024, fbits = 1ull << 16;
             while (scap < 2 * n_stops) scap <<= 1;
             while (dcap < 2 * n_starts) dcap <<= 1;
-            while (fbits < 16 * n_stops && fbits < (1ull << 32)) fbits <<= 1; /* 4 MB at human scale: it stays in every L2 */
+            uint32_t flog = 16;
+            while (fbits < 16 * n_stops && fbits < (1ull << 31)) { fbits <<= 1; flog++; } /* 4 MB at human scale: it stays in every L2 */
             PosSets PS{};
             HIP_TRY(behind.take((void**)&PS.stops.keys, scap * 8));
             HIP_TRY(behind.take((void**)&PS.done.keys, dcap * 8));
             HIP_TRY(behind.take((void**)&PS.filter, fbits / 8));
             HIP_TRY(behind.take((void**)&p_pos_src, rec_cap * 8));
-            PS.stops.mask = scap - 1; PS.done.mask = dcap - 1; PS.filter_mask = fbits - 1;
+            PS.stops.mask = scap - 1; PS.done.mask = dcap - 1; PS.filter_shift = 32 - (flog - 5); /* the word of a key: the top bits of its hash */
             prof.begin();
             HIP_TRY(hipMemsetAsync(PS.stops.keys, 0, scap * 8, 0));
             HIP_TRY(hipMemsetAsync(PS.done.keys, 0, dcap * 8, 0));
@@ -1310,7 +1434,7 @@ static int jt_insert_partitioned(const Table& jt, BinShape S, int k, const uint6
     const size_t seq_per_chunk = (size_t)std::max<double>(1.0, (double)chunk_positions / std::max(per_seq, 1.0));
     BinOverflow ov{d_ov.as<uint64_t>(), reinterpret_cast<unsigned long long*>(d_ov.as<uint8_t>() + ov_cap * 16), ov_cap};
     HIP_TRY(hipMemsetAsync(ov.cursor, 0, 8, 0));
-    const size_t lds1 = (size_t)MTG_BIN1_TILE * 9 + 3 * 1024 * 4, lds2 = (size_t)BIN_TILE * 8 + 3 * 2048 * 4, lds3 = S.seg_words * 8;
+    const size_t lds1 = (size_t)MTG_BIN1_TILE * 9 * (MTG_BIN_SORTED ? 2 : 1) + 3 * 1024 * 4, lds2 = (size_t)BIN_TILE * 8 * (MTG_BIN_SORTED ? 2 : 1) + 3 * 2048 * 4, lds3 = S.seg_words * 8;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_positions), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_segments), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
