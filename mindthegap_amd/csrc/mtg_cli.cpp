@@ -18,6 +18,7 @@
 #include <fstream>
 #include <sstream>
 #include <unordered_map>
+#include "mtg_dict_order.h"
 #include <condition_variable>
 #include <thread>
 #include <zlib.h>
@@ -56,6 +57,8 @@ struct GapArgs {
     std::vector<std::string> tseq, tname; /* targetDictionary in iteration order */
     std::vector<uint8_t> trc;
     std::vector<const char*> pseq, pname;
+    std::vector<uint32_t> tidx; /* contig mode: the dictionary's entries as numbers into the job's table of targets (pseq / pname / trc are filled from it: no string is copied per seed) */
+    bool shared_dict = false;
     bool repeated = false, reverse = false;
     void set_dict(const bkpt_dict_t& dict)
     {
@@ -63,12 +66,14 @@ struct GapArgs {
     }
     mtg_gap abi()
     {
-        pseq.clear(); pname.clear();
-        for (size_t i = 0; i < tseq.size(); i++) { pseq.push_back(tseq[i].c_str()); pname.push_back(tname[i].c_str()); }
+        if (!shared_dict) {
+            pseq.clear(); pname.clear();
+            for (size_t i = 0; i < tseq.size(); i++) { pseq.push_back(tseq[i].c_str()); pname.push_back(tname[i].c_str()); }
+        }
         mtg_gap g;
         g.source = source.c_str();
         g.target = target.c_str();
-        g.n_targets = (int)tseq.size();
+        g.n_targets = (int)pseq.size();
         g.target_seqs = pseq.data();
         g.target_names = pname.data();
         g.target_is_rc = trc.data();
@@ -317,6 +322,8 @@ static std::string solu_str(const mtg_filled& s)
 struct DictView {
     const std::string* tname = nullptr;
     const uint8_t* trc = nullptr;
+    const uint32_t* idx = nullptr; /* non-null: entry t's name is tname[idx[t]] (contig mode: the names of the job's targets, once) */
+    const std::string& name_of(int t) const { return tname[idx ? idx[t] : (uint32_t)t]; }
 };
 
 /* writeFilledBreakpoint, src/Filler.cpp:1029-1093.  The bkpt-mode header passes its arguments in a different order
@@ -335,7 +342,7 @@ static void write_filled(OutText& F, bool bkpt_mode, const DictView& g, Sols sol
             o += "_median_cov_"; put_fixed2(o, (double)s.median_coverage);
             o += "   "; o += solu; o += '\n';
         } else {
-            std::string targetName(g.tname[s.target_index]);
+            std::string targetName(g.name_of(s.target_index));
             if (g.trc[s.target_index]) targetName.append("_Rc");
             int cov = s.median_coverage + 0.5;
             appendf(F.insert, ">%.*s;%s;len_%d_qual_%d_median_cov_%d\t%s\n", (int)seedName.size(), seedName.data(), targetName.c_str(), llen, s.qual, cov, solu.c_str());
@@ -421,7 +428,7 @@ static void write_gfa(OutText& F, int trim, const DictView& g, Sols sols, std::s
     std::string seedDirection = "+";
     if (isRc) { seedName = seedName.substr(0, seedName.size() - 3); seedDirection = "-"; }
     for (auto& s : sols) {
-        const std::string tname(g.tname[s.target_index]);
+        const std::string tname(g.name_of(s.target_index));
         const bool trc = g.trc[s.target_index] != 0;
         const std::string targetNameNode = trc ? tname + "_Rc" : tname;
         int cov = s.median_coverage + 0.5;
@@ -1067,7 +1074,30 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
             }
         }
     }
-    /* contigFunctor, src/Filler.cpp:492-572; every seed sees the targets of all the other contigs (:522-533) */
+    /* contigFunctor, src/Filler.cpp:492-572; every seed sees the targets of all the other contigs (:522-533).  The targets once, in the iteration order
+     * of their dictionary: a seed's own dictionary is this one without its contig's entry, in the order mtg_dict_order.h derives from the hash codes */
+    struct Targets {
+        std::vector<const char*> seq, pname;
+        std::vector<std::string> name;
+        std::vector<uint8_t> rc;
+        std::vector<size_t> code;
+        std::string text; /* every key one after the other: the early-stop pattern of a seed is this without its own entry */
+        std::unordered_map<std::string, std::vector<uint32_t>> by_seed_name; /* the entries a seed of that name leaves out */
+    } T;
+    {
+        const size_t n = all_targets.size();
+        T.seq.reserve(n); T.name.reserve(n); T.rc.reserve(n); T.code.reserve(n); T.text.reserve(n * (size_t)k);
+        uint32_t i = 0;
+        for (auto its = all_targets.begin(); its != all_targets.end(); ++its, ++i) {
+            T.seq.push_back(its->first.c_str());
+            T.name.push_back(its->second.first);
+            T.rc.push_back(its->second.second ? 1 : 0);
+            T.code.push_back(std::hash<std::string>()(its->first));
+            T.text.append(its->first);
+            T.by_seed_name[its->second.second ? its->second.first + "_Rc" : its->second.first].push_back(i);
+        }
+        for (const std::string& nm : T.name) T.pname.push_back(nm.c_str());
+    }
     struct Batch {
         size_t s0 = 0, s1 = 0;
         std::vector<GapArgs> gaps;
@@ -1083,18 +1113,32 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
         std::unique_ptr<Batch> bt(new Batch());
         bt->s0 = b * B; bt->s1 = std::min(seeds.size(), (b + 1) * B);
         bt->gaps.resize(bt->s1 - bt->s0);
-        for (size_t si = bt->s0; si < bt->s1; si++) {
+        /* (the seeds of a batch over the host's worker pool: a seed's dictionary is 2 (N - 1) entries to put in order and to point at) */
+        parallel_for(bt->s1 - bt->s0, P.nb_host_threads, [&](size_t sj) {
+            static thread_local mtgcli::DictOrder dict_order;
+            static thread_local std::vector<uint8_t> skip;
+            if (skip.size() != T.seq.size()) skip.assign(T.seq.size(), 0);
+            const size_t si = bt->s0 + sj;
             auto& sd = seeds[si];
             GapArgs& g = bt->gaps[si - bt->s0];
-            bkpt_dict_t dict;
-            for (auto its = all_targets.begin(); its != all_targets.end(); ++its) {
-                std::string tempName = its->second.first;
-                if (its->second.second) tempName += "_Rc";
-                if (tempName.compare(sd.first) != 0) { g.target.append(its->first); dict.insert({its->first, its->second}); }
+            const auto own = T.by_seed_name.find(sd.first);
+            static const std::vector<uint32_t> none;
+            const std::vector<uint32_t>& out = own == T.by_seed_name.end() ? none : own->second; /* ascending */
+            /* targetSequence: the keys (k characters each) of every other entry, in the order of the dictionary of all (:526-531) */
+            {
+                size_t from = 0;
+                g.target.reserve(T.text.size());
+                for (uint32_t o : out) { g.target.append(T.text, from, (size_t)o * (size_t)k - from); from = ((size_t)o + 1) * (size_t)k; }
+                g.target.append(T.text, from, std::string::npos);
             }
+            for (uint32_t o : out) skip[o] = 1;
+            dict_order.order(T.code.data(), (uint32_t)T.seq.size(), out.empty() ? nullptr : skip.data(), g.tidx);
+            for (uint32_t o : out) skip[o] = 0;
+            g.shared_dict = true;
+            g.pseq.resize(g.tidx.size()); g.pname.resize(g.tidx.size()); g.trc.resize(g.tidx.size());
+            for (size_t t = 0; t < g.tidx.size(); t++) { const uint32_t e = g.tidx[t]; g.pseq[t] = T.seq[e]; g.pname[t] = T.pname[e]; g.trc[t] = T.rc[e]; }
             g.source = sd.second;
-            g.set_dict(dict);
-        }
+        }, 1);
         if (int rc = bt->run.run(idx, P, bt->gaps)) return rc;
         for (size_t i = bt->s0; i < bt->s1; i++) {
             const size_t j = i - bt->s0;
@@ -1102,13 +1146,13 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
             const bool isRc = seedName.length() >= 3 && seedName.compare(seedName.length() - 3, 3, "_Rc") == 0;
             std::vector<mtg_filled> kept;
             for (auto& s : sols_of(bt->run[j])) { /* drop loops: target == seed reversed, :540-557 */
-                const std::string& tn = bt->gaps[j].tname[s.target_index];
+                const std::string& tn = T.name[bt->gaps[j].tidx[s.target_index]];
                 const std::string revTargetName = bt->gaps[j].trc[s.target_index] ? tn : tn + "_Rc";
                 if (revTargetName != seedName) kept.push_back(s);
             }
             Sols ks;
             ks.p = kept.data(); ks.n = kept.size();
-            const DictView dv{bt->gaps[j].tname.data(), bt->gaps[j].trc.data()};
+            const DictView dv{T.name.data(), bt->gaps[j].trc.data(), bt->gaps[j].tidx.data()};
             write_filled(bt->out, false, dv, ks, seedName, info_string(bt->run[j]));
             write_gfa(bt->out, trim, dv, ks, seedName, isRc);
             if (kept.empty() && O.extend) write_extension(bt->out, bt->run[j].extension, seedName, "", seeds[i].second);

@@ -303,13 +303,23 @@ __global__ void k_encode_targets(const uint8_t* __restrict__ traw, uint64_t* __r
 
 /* terminal-node search + coverage of the single-contig solution, one wave per gap; leaves the slot's record with what the gap will
  * contribute to the arrays of its batch (mtg_emit.h: emit_plan).  Where it goes is decided by the scan kernels below. */
+/* the piece index of a batch's dictionaries (mtg_post.h): a workgroup per gap and turn, its targets dealt to the threads */
+__global__ void __launch_bounds__(256) k_post_index(uint32_t* head, uint32_t* next, uint32_t mask, const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
+                                                    const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, uint32_t n, int k)
+{
+    for (uint32_t g = blockIdx.x; g < n; g += gridDim.x) {
+        const uint32_t c = tcnt[g], o = toff[g], mis = nbmis[g];
+        if (c < (uint32_t)POST_INDEX_MIN) continue; /* (such a gap's search goes over its targets) */
+        for (uint32_t t = threadIdx.x; t < c; t += blockDim.x) post_index_add(head, next, mask, g, o + t, tle[o + t], tbad[o + t], mis, k);
+    }
+}
 #ifndef MTG_POST_WAVES
 #define MTG_POST_WAVES 6
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POST_WAVES))) k_post(Index ix, FillCfg cfg, uint8_t* raw, uint8_t* head, const GapOut* __restrict__ outs, const uint32_t* __restrict__ ids,
                                              const uint64_t* __restrict__ tle, const uint64_t* __restrict__ tbad, const uint32_t* __restrict__ toff,
                                              const uint32_t* __restrict__ tcnt, const uint8_t* __restrict__ nbmis, const uint8_t* __restrict__ fast_ok,
-                                             uint32_t want_all, SlotRec* recs, uint32_t n, ParkCtl* park)
+                                             uint32_t want_all, SlotRec* recs, uint32_t n, ParkCtl* park, const uint32_t* __restrict__ pi_head, const uint32_t* __restrict__ pi_next, uint32_t pi_mask)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint64_t tile[POST_TILE + 2];
@@ -341,6 +351,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MTG_POS
             T.n = tcnt[g];
             T.nb_mis = nbmis[g];
             T.fast_ok = fast_ok[g];
+            T.pi_head = pi_head; T.pi_next = pi_next; T.pi_mask = pi_mask; T.gbase = toff[g]; T.gid = g;
 #ifdef MTG_POST_DBG /* timing experiments only (scripts/exp_post_parts.sh): parts of the kernel switched off, results wrong */
             post_gap(ix, cfg, S, o, T, hist, tile, s_blk, po, MTG_POST_DBG);
 #else
@@ -723,7 +734,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     int ws_next = 0;
     auto wsbuf = [&]() { WsBuf b; b.ws = &ws; b.slot = ws_next++; return b; };
     WsBuf d_ina = wsbuf(), d_inb = wsbuf(), d_inc = wsbuf(), d_tenc = wsbuf(), d_ilv = wsbuf(), d_zero = wsbuf(), d_raw = wsbuf(), d_out = wsbuf(), d_rec = wsbuf(), d_ids = wsbuf(), d_dw = wsbuf(),
-          d_dm = wsbuf(), d_combo = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf(), d_ggaps = wsbuf(), d_gsols = wsbuf(), d_gascii = wsbuf(), d_gtmp = wsbuf(), d_gbnd = wsbuf(), d_head = wsbuf();
+          d_dm = wsbuf(), d_combo = wsbuf(), d_blocks = wsbuf(), d_seq = wsbuf(), d_ext = wsbuf(), d_res = wsbuf(), d_fil = wsbuf(), d_tot = wsbuf(), d_rlist = wsbuf(), d_glist = wsbuf(), d_paths = wsbuf(), d_park = wsbuf(), d_ggaps = wsbuf(), d_gsols = wsbuf(), d_gascii = wsbuf(), d_gtmp = wsbuf(), d_gbnd = wsbuf(), d_head = wsbuf(), d_pidx = wsbuf();
     /* the marshalled input: three blocks, three copies; the targets (block C, text) become k-mers and masks on the device.  A batch that
      * was prepared ahead (mtg_batch) is resident already */
     double t0 = now_ms();
@@ -808,6 +819,22 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
     const uint8_t* d_fok = da + FillInput::off_a(n, 7);
     const uint8_t* d_flags = da + FillInput::off_a(n, 8);
     uint64_t* d_tbad = d_tle + n_targets;
+    /* dictionaries of many targets (contig mode: every seed has the targets of all other contigs): their pieces in one hash table, so that the
+     * terminal search looks a contig position up instead of counting against every target (mtg_post.h: the piece index) */
+    uint32_t* d_pi_head = nullptr;
+    uint32_t* d_pi_next = nullptr;
+    uint32_t pi_mask = 0;
+    if (n_targets >= (uint64_t)POST_INDEX_MIN * n && n_targets < (1ull << 30) && !tune::on(tune::T_NO_POST_INDEX)) {
+        uint64_t cap = 1024;
+        while (cap < 4 * n_targets) cap <<= 1;
+        HIP_TRY(d_pidx.alloc((cap + 4 * n_targets) * 4));
+        d_pi_head = d_pidx.as<uint32_t>();
+        d_pi_next = d_pi_head + cap;
+        pi_mask = (uint32_t)(cap - 1);
+        HIP_TRY(hipMemsetAsync(d_pi_head, 0xFF, cap * 4, stream));
+        hipLaunchKernelGGL(k_post_index, dim3((unsigned)std::min<size_t>(n, 4096)), dim3(256), 0, stream, d_pi_head, d_pi_next, pi_mask, (const uint64_t*)d_tle, (const uint64_t*)d_tbad, d_toff, d_tcnt, d_mis, (uint32_t)n, k);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(d_tot.alloc(sizeof(PartTot)));
     /* where the batch's two arenas stand: sequence bytes and extension bytes so far (the extension arena starts with the empty string); the layout
      * kernel gets them by value */
@@ -1032,7 +1059,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
              * the others.  Both on the batch's one stream: the general form next to the lean one on a second stream, and the finishing kernel there as
              * well, were built and measured in round 4 (9 and 25 us shorter for one batch alone, no faster with six in flight) and removed in round 5. */
             hipLaunchKernelGGL(k_post, dim3(general_hint), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), ids, d_tle, d_tbad, d_toff, d_tcnt, d_mis, d_fok,
-                               in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park);
+                               in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m, park, (const uint32_t*)d_pi_head, (const uint32_t*)d_pi_next, pi_mask);
             hipLaunchKernelGGL(k_post_lean, dim3((m + 64 / POST_LEAN_G - 1) / (64 / POST_LEAN_G)), dim3(64), 0, stream, idx->dev, cfg, d_raw.as<uint8_t>(), d_head.as<uint8_t>(), d_out.as<GapOut>(), in.want_all_contigs ? 1u : 0u, d_rec.as<SlotRec>(), m);
             /* the dense arrays hold one launch at a time; the two arenas the whole batch */
             const ScanBegin sbegin{{0, 0, arena_used[0], arena_used[1]}};

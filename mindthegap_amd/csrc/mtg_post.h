@@ -62,7 +62,46 @@ struct PostTargets {
     uint32_t n;
     uint32_t nb_mis;
     uint32_t fast_ok;    /* the source sequence is exactly k valid nucleotides */
+    /* the piece index of the batch's dictionaries (below); pi_head == nullptr: none */
+    const uint32_t* pi_head = nullptr;
+    const uint32_t* pi_next = nullptr;
+    uint32_t pi_mask = 0;
+    uint32_t gbase = 0;  /* the number of this gap's first target among the targets of the batch */
+    uint32_t gid = 0;    /* the gap's number in the batch */
 };
+
+/* ---- The piece index (round 6): the terminal search without a pass over the dictionary per contig position.  A contig position matches a target
+ * when at most nb_mis of the k nucleotides differ (find_nodes_containing_multiple_R, src/Filler.cpp:1341-1351); cut the k nucleotides into
+ * nb_mis + 1 pieces and one piece at least is free of differences (and of the target's unusable characters, which count as differences).  So every
+ * piece of every target of the batch goes into ONE chained hash table (key: gap, piece number, the piece's nucleotides; entry: target << 2 | piece),
+ * and a contig position looks its nb_mis + 1 pieces up and counts the differences only against the targets it finds there.  Every pair (position,
+ * target) within nb_mis is among them, pairs that are not are harmless (the count decides, as it does in the pass over all targets), the result is
+ * the same arg-max.  Contig mode hands every seed the targets of all other contigs (src/Filler.cpp:522-533): at 10 000 contigs the pass made 20 000
+ * counts per contig position, 24 ms per batch of 40 seeds and 99 % of the job's device time. */
+enum { POST_PIECES_MAX = 4, POST_INDEX_MIN = 16, POST_INDEX_NIL = 0xFFFFFFFFu };
+MTG_DEV bool post_index_usable(int k, uint32_t nb_mis) { return nb_mis + 1u <= (uint32_t)POST_PIECES_MAX && (uint32_t)k / (nb_mis + 1u) >= 8u; }
+MTG_DEV uint32_t post_piece_begin(uint32_t p, uint32_t np, int k) { return p * (uint32_t)k / np; }
+MTG_DEV uint32_t post_piece_slot(uint64_t piece, uint32_t p, uint32_t gid, uint32_t mask)
+{
+    return (uint32_t)(mix64(((piece << 2) | p) ^ ((uint64_t)gid * 0x9E3779B97F4A7C15ULL)) >> 20) & mask;
+}
+/* target number gt (of the batch) of gap gid: its pieces into the table (any thread) */
+MTG_DEV void post_index_add(uint32_t* head, uint32_t* next, uint32_t mask, uint32_t gid, uint32_t gt, uint64_t le, uint64_t bad, uint32_t nb_mis, int k)
+{
+    if (!post_index_usable(k, nb_mis)) return;
+    const uint32_t np = nb_mis + 1u;
+    for (uint32_t p = 0; p < np; p++) {
+        const uint32_t b = post_piece_begin(p, np, k), e = post_piece_begin(p + 1u, np, k);
+        const uint64_t pm = (1ull << (2u * (e - b))) - 1ull;
+        if ((bad >> (2u * b)) & pm) continue; /* an unusable character in the piece: it cannot be the piece without a difference */
+        const uint32_t h = post_piece_slot((le >> (2u * b)) & pm, p, gid, mask), ent = (gt << 2) | p;
+#ifdef MTG_EMU
+        next[ent] = __atomic_exchange_n(&head[h], ent, __ATOMIC_RELAXED);
+#else
+        next[ent] = atomicExch(&head[h], ent);
+#endif
+    }
+}
 
 #ifdef MTG_EMU
 #define MTG_LANE() 0u
@@ -183,6 +222,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
      * result is the first occurrence of the maximum: an arg-max, evaluated here by all lanes at once. */
     const uint64_t le0 = T.n ? T.le[0] : 0ull, bad0 = T.n ? T.bad[0] : ~0ull;
     const bool single = T.n == 1;
+    const bool indexed = T.pi_head != nullptr && T.n >= (uint32_t)POST_INDEX_MIN && post_index_usable(k, T.nb_mis);
     /* the lean form (mtg_copy.h): the target's place in the only contig is known, the contig itself was not materialised */
     const LeanRec lean = s_lean(cfg, S)[0];
     out.lean = 0;
@@ -244,7 +284,31 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                 bool exact = false; /* an exact match is the largest possible count and the earliest one wins: nothing after it matters */
                 for (uint32_t jb = j_lo; jb < j_hi && !exact; jb += MTG_NLANES) {
                     const uint32_t j = jb + lane;
-                    if (j < j_hi) {
+                    if (j < j_hi && indexed) {
+                        const uint64_t x = le_kmer(tile, j - j_lo, mk);
+                        const uint32_t np = T.nb_mis + 1u;
+                        for (uint32_t p = 0; p < np; p++) {
+                            const uint32_t pb = post_piece_begin(p, np, k), pe = post_piece_begin(p + 1u, np, k);
+                            uint32_t e = T.pi_head[post_piece_slot((x >> (2u * pb)) & ((1ull << (2u * (pe - pb))) - 1ull), p, T.gid, T.pi_mask)];
+                            while (e != (uint32_t)POST_INDEX_NIL) {
+                                const uint32_t t = (e >> 2) - T.gbase;
+                                if (t < T.n && (e & 3u) == p) {
+                                    const uint64_t m = x ^ T.le[t];
+                                    const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
+#ifdef MTG_EMU
+                                    const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
+#else
+                                    const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
+#endif
+                                    if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
+                                        const uint64_t key = ((uint64_t)nbm << 40) | (ORD - (single ? (uint64_t)j : (uint64_t)j * T.n + t));
+                                        best = key > best ? key : best;
+                                    }
+                                }
+                                e = T.pi_next[e];
+                            }
+                        }
+                    } else if (j < j_hi) {
                         const uint64_t x = le_kmer(tile, j - j_lo, mk);
                         for (uint32_t t = 0; t < T.n; t++) {
                             /* the first target from registers (breakpoint mode has one), the others from memory */
@@ -268,6 +332,20 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
             }
         }
         if (!have_exact) best = wave_max64(best);
+#ifdef MTG_XCHECK /* TEST-ONLY: the pass over every target finds the same arg-max as the piece index */
+        if (indexed && L >= (uint32_t)k) {
+            uint64_t want = 0;
+            for (uint32_t j = 0; j + (uint32_t)k <= L && (uint32_t)(want >> 40) != (uint32_t)k; j++) {
+                const uint64_t x = le_kmer(w, j, mk);
+                for (uint32_t t = 0; t < T.n; t++) {
+                    const uint64_t m = x ^ T.le[t];
+                    const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(((m | (m >> 1)) & lsb) | T.bad[t]);
+                    if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) { const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t)); want = key > want ? key : want; }
+                }
+            }
+            if (want != best) { fprintf(stderr, "piece index: contig %u of gap %u: arg-max %llx, the pass over %u targets finds %llx\n", c, T.gid, (unsigned long long)best, T.n, (unsigned long long)want); __builtin_trap(); }
+        }
+#endif
         if (best) {
             const uint32_t nbm = (uint32_t)(best >> 40);
             const uint64_t order = ORD - (best & ORD);

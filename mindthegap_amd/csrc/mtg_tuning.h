@@ -38,6 +38,7 @@
     X(BUILD_POSITIONAL, "", "ab", "packed sequences: the chains that lie whole in one sequence are found by position (1, default) or every chain is walked on the junction table (0)") \
     X(FINISH_G, "", "ab", "lanes per parked gap in the finishing kernel: 1, 8, 16 or 64 (default: 64 while few gaps park, 16 otherwise)") \
     X(FINISH_WAVE_BELOW, "2048", "ab", "a whole wave per parked gap while the previous launch parked fewer gaps than this") \
+    X(NO_POST_INDEX, "", "test", "the terminal search counts every contig position against every target of its gap (no piece index of the batch's dictionaries)") \
     X(NO_LEAN, "", "test", "every contig is materialised (no lean gaps)") \
     X(NO_DEFER, "", "test", "the lanes of the traversal copy their long runs themselves (no copy commands, no k_copy work)") \
     X(MAX_CHUNK, "", "test", "gaps per traversal launch (default: what the scratch holds): several launches per batch") \

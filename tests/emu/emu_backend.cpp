@@ -417,6 +417,20 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
         for (size_t t = 0; t < n_targets; t++) marshal_text_target(text, doff[t], dlen[t], k, tle[t], tbad[t]);
     } else
         for (size_t t = 0; t < n_targets; t++) encode_target(in.traw.data() + t * TARGET_SLOT, k, tle[t], tbad[t]);
+    /* stand-in for k_post_index: the piece index of the batch's dictionaries (mtg_post.h), built whenever a batch has a target (the device asks for
+     * sixteen a gap on average): the emulation's cross-check in post_gap compares its result with the pass over every target */
+    std::vector<uint32_t> pi_head, pi_next;
+    uint32_t pi_mask = 0;
+    if (n_targets && n_targets < (1ull << 30)) {
+        uint64_t cap = 1024;
+        while (cap < 4 * n_targets) cap <<= 1;
+        pi_mask = (uint32_t)(cap - 1);
+        pi_head.assign(cap, (uint32_t)POST_INDEX_NIL);
+        pi_next.assign(n_targets * 4, (uint32_t)POST_INDEX_NIL);
+        for (size_t g = 0; g < n; g++)
+            for (uint32_t t = 0; t < in.tcnt[g]; t++)
+                post_index_add(pi_head.data(), pi_next.data(), pi_mask, (uint32_t)g, in.toff[g] + t, tle[in.toff[g] + t], tbad[in.toff[g] + t], in.nbmis[g], k);
+    }
     special.chunks.clear();
     special.special.clear();
     sink.seq_used = 0;
@@ -493,6 +507,7 @@ int device_run(const mtg_index* idx, const mtg_params* p, const FillInput& in, R
                     T.n = in.tcnt[g];
                     T.nb_mis = in.nbmis[g];
                     T.fast_ok = in.fast_ok[g];
+                    if (!pi_head.empty()) { T.pi_head = pi_head.data(); T.pi_next = pi_next.data(); T.pi_mask = pi_mask; T.gbase = in.toff[g]; T.gid = (uint32_t)g; }
                     uint32_t hist[256] = {0};
                     std::vector<uint64_t> tile(POST_TILE + 2);
                     uint64_t blk[64];
