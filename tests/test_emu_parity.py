@@ -444,19 +444,33 @@ def test_sequence_scan_on_emulator(emu_product):
     _scan_case(emu_product)
 
 
-def _contig_gap_case(mtg_mod, tmp_path, nseq):
+def _contig_gap_case(mtg_mod, tmp_path, nseq, mutate=False):
     """contig mode at scale: every donor sequence is cut into two contigs around a hole; each seed sees the targets of all other
-    contigs (2 * (#contigs) - 1 anchors), the fill must bridge the hole.  Files must equal the oracle's byte for byte."""
+    contigs (2 * (#contigs) - 1 anchors), the fill must bridge the hole.  Files must equal the oracle's byte for byte.
+    mutate: the right contigs' target k-mers (contig[31:62]) differ from the graph -- one, two or three substitutions, an N, lowercase -- so that the
+    terminal search has to find them within nb_mis_allowed = 2 among the hundreds of targets of the dictionary (or not at all), src/Filler.cpp:1341-1351."""
     from mindthegap_amd.synth import SynthSet
     S = SynthSet(nseq=nseq, n_sites=nseq, seed=31)
     seqs = [S.ascii(j) for j in range(S.nseq)]
     o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
     km, ct = o.export()
     contigs = str(tmp_path / "contigs.fa")
+
+    def sub(t, i):
+        return t[:i] + ("A" if t[i] != "A" else "C") + t[i + 1:]
     with open(contigs, "w") as f:
         for j, s in enumerate(seqs):
             p, L = int(S.pos[j]), int(S.ins_len[j])
-            f.write(">c%dL\n%s\n>c%dR\n%s\n" % (j, s[:p], j, s[p + L:]))
+            right = s[p + L:]
+            if mutate:
+                m = j % 8
+                if m == 1: right = sub(right, 31 + 5)
+                elif m == 2: right = sub(sub(right, 31), 31 + 30)          # the first and the last nucleotide of the target: the middle piece is intact
+                elif m == 3: right = sub(sub(sub(right, 33), 44), 57)      # three: not found
+                elif m == 4: right = right[:40] + "N" + right[41:]         # one forced mismatch
+                elif m == 5: right = right[:31] + right[31:62].lower() + right[62:]
+                elif m == 6: right = sub(sub(right, 31 + 9), 31 + 10)      # both in one piece
+            f.write(">c%dL\n%s\n>c%dR\n%s\n" % (j, s[:p], j, right))
     idxf = str(tmp_path / "c.mtgidx")
     _write_idx(idxf, km, ct)
     o.fill_files("contig", contigs, str(tmp_path / "cpu"), params=oracle_lib.default_params(nb_cores=4))
@@ -467,12 +481,18 @@ def _contig_gap_case(mtg_mod, tmp_path, nseq):
     assert sorted(_read(str(tmp_path / "hip.gfa")).splitlines()) == sorted(_read(str(tmp_path / "cpu.gfa")).splitlines())
     assert sorted(_read(str(tmp_path / "hip.insertions.fasta")).splitlines()) == sorted(_read(str(tmp_path / "cpu.insertions.fasta")).splitlines())
     nfill = sum(1 for l in _read(str(tmp_path / "hip.gfa")).splitlines() if l.startswith("S") and ";" in l)
-    assert nfill >= 2 * nseq  # both directions of every hole
+    assert nfill >= (nseq if mutate else 2 * nseq)  # both directions of every hole (mutated targets: the forward direction of five in eight at least)
     o.close()
 
 
 def test_contig_mode_many_targets_on_emulator(emu_product, tmp_path):
     _contig_gap_case(emu_product, tmp_path, 8)
+
+
+def test_contig_mode_inexact_targets_among_many_on_emulator(emu_product, tmp_path):
+    """round 6: the piece index of the terminal search (mtg_post.h) on targets that match within two differences only; the emulation compares every
+    contig's arg-max with the pass over all targets"""
+    _contig_gap_case(emu_product, tmp_path, 16, mutate=True)
 
 
 def _edge_case_files(tmp_path):

@@ -282,6 +282,17 @@ def test_contig_mode_many_targets(mtg, tmp_path):
     _contig_gap_case(mtg, tmp_path, 200)
 
 
+def test_contig_mode_inexact_targets_among_many(mtg, tmp_path, monkeypatch):
+    """round 6: the terminal search through the piece index of the batch's dictionaries (k_post_index; a contig position's nb_mis + 1 pieces looked up
+    instead of a count against each of ~480 targets): targets that differ from the graph by one, two (in different pieces, in one piece), three
+    substitutions, an N, lowercase -- files equal to the oracle's, with the index and (NO_POST_INDEX) with the pass over every target"""
+    from tests.test_emu_parity import _contig_gap_case
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    _contig_gap_case(mtg, tmp_path / "a", 120, mutate=True)
+    monkeypatch.setenv("MTG_NO_POST_INDEX", "1")
+    _contig_gap_case(mtg, tmp_path / "b", 120, mutate=True)
+
+
 def test_cli_edge_cases(mtg, tmp_path):
     """REPEATED anchors, mismatching / N / lowercase / long anchors, unfillable sites, -fwd-only -filter -extend, -max-nodes / -max-length"""
     from tests.test_emu_parity import _edge_case_run
