@@ -293,14 +293,16 @@ enum { BIN_TILE = 8192 };
 #ifndef MTG_BIN_SORTED
 #define MTG_BIN_SORTED 1
 #endif
+/* (sorted: two workgroups a compute unit with tiles of 3 584 records measured best -- 50.7 ms for the two binning kernels; one workgroup with 8 192: 54.5,
+ * three with 2 048: 50.9, scripts/r6_binsort_ab.sh and the EXTRA= variants of the Makefile) */
 #ifndef MTG_BIN1_TILE
-#define MTG_BIN1_TILE (MTG_BIN_SORTED ? 8192 : 4096)
+#define MTG_BIN1_TILE (MTG_BIN_SORTED ? 3584 : 4096)
 #endif
 #ifndef MTG_BIN1_THREADS
-#define MTG_BIN1_THREADS (MTG_BIN_SORTED ? 1024 : 512)
+#define MTG_BIN1_THREADS 512
 #endif
 #ifndef MTG_BIN1_GROUPS
-#define MTG_BIN1_GROUPS (MTG_BIN_SORTED ? 256 : 768)
+#define MTG_BIN1_GROUPS (MTG_BIN_SORTED ? 512 : 768)
 #endif
 #ifndef BIN1_U
 #define BIN1_U (MTG_BIN_SORTED ? 2 : 4)

@@ -882,7 +882,8 @@ def test_chains_found_by_position_equal_the_walked_ones(mtg):
     (each goes through its unitig in the store) and of absent ones, the same fills -- on a diploid donor plus the shapes that decide who stores a chain: a
     sequence twice, a sequence and its reverse complement, two overlapping windows of one stretch (no sequence holds the chain whole: it is walked), a
     substitution (branching), a tandem repeat, a homopolymer, a hairpin (a stretch followed by its reverse complement), a cycle written twice round,
-    sequences of k - 1, k and k + 1 nucleotides."""
+    sequences of k - 1, k and k + 1 nucleotides, one chain of 70 000 nucleotides (tiles of k_pos_plan without a stop), a string of 400 short
+    stretches between copies of one k-mer (hundreds of stops a tile)."""
     import torch
     from mindthegap_amd.synth import SynthSet
     k = 31
@@ -893,7 +894,10 @@ def test_chains_found_by_position_equal_the_walked_ones(mtg):
     h = rng.integers(0, 4, 900).astype(np.uint8)
     snp = h.copy(); snp[450] ^= 1
     cyc = rng.integers(0, 4, 211).astype(np.uint8)
-    extra = [g[:1500], g[:1500], rc(g[1500:2600]), g[1500:2600], g[2600:4200], g[3600:5200], h, snp,
+    long_one = rng.integers(0, 4, 70000).astype(np.uint8)  # seventeen tiles of k_pos_plan with no stop between the first and the last
+    linker = rng.integers(0, 4, k).astype(np.uint8)
+    beads = np.concatenate([np.concatenate([linker, rng.integers(0, 4, 9 + i % 23).astype(np.uint8)]) for i in range(400)])  # a stop every few dozen positions: hundreds a tile
+    extra = [long_one, beads, g[:1500], g[:1500], rc(g[1500:2600]), g[1500:2600], g[2600:4200], g[3600:5200], h, snp,
              np.tile(np.array([0, 1], dtype=np.uint8), 100), np.zeros(120, dtype=np.uint8), np.concatenate([g[5200:5500], rc(g[5200:5500])]),
              np.concatenate([cyc, cyc, cyc[:k]]), g[5600:5600 + k - 1], g[5700:5700 + k], g[5800:5800 + k + 1], rc(g[5800:5800 + k + 1])]
     ew, eo, el = _pack_codes(extra)
