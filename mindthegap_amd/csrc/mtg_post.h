@@ -198,6 +198,45 @@ MTG_UNROLL
 #endif
 enum { POST_TILE = MTG_POST_TILE }; /* words; 512 = 16384 nucleotides */
 
+/* the terminal search of one contig through the piece index: this lane's best key (count << 40 | ORD - (position * n + target)) over the positions
+ * lane, lane + 64, ...; the caller takes the wave's maximum.  The contig is read where it lies (a position costs nb_mis + 1 look-ups; its word is the
+ * least of it). */
+MTG_DEV_COLD uint64_t post_search_indexed(const PostTargets T, const uint64_t* w, uint32_t L, int k)
+{
+    const uint64_t mk = kmask(k), lsb = 0x5555555555555555ULL & mk, ORD = (1ull << 40) - 1;
+    const uint32_t np = T.nb_mis + 1u, npos = L - (uint32_t)k + 1;
+    uint64_t best = 0;
+    for (uint32_t jb = 0; jb < npos; jb += MTG_NLANES) {
+        const uint32_t j = jb + MTG_LANE();
+        if (j < npos) {
+            const uint64_t x = le_kmer(w, j, mk);
+            for (uint32_t p = 0; p < np; p++) {
+                const uint32_t pb = post_piece_begin(p, np, k), pe = post_piece_begin(p + 1u, np, k);
+                uint32_t e = T.pi_head[post_piece_slot((x >> (2u * pb)) & ((1ull << (2u * (pe - pb))) - 1ull), p, T.gid, T.pi_mask)];
+                while (e != (uint32_t)POST_INDEX_NIL) {
+                    const uint32_t t = (e >> 2) - T.gbase;
+                    if (t < T.n && (e & 3u) == p) {
+                        const uint64_t m = x ^ T.le[t];
+                        const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
+#ifdef MTG_EMU
+                        const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
+#else
+                        const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
+#endif
+                        if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
+                            const uint64_t key = ((uint64_t)nbm << 40) | (ORD - ((uint64_t)j * T.n + t));
+                            best = key > best ? key : best;
+                        }
+                    }
+                    e = T.pi_next[e];
+                }
+            }
+        }
+        if (wave_any((uint32_t)(best >> 40) == (uint32_t)k)) break; /* an exact match: the largest count, and no later position comes before it */
+    }
+    return best;
+}
+
 /* hist: 256 zeroed counters shared by the lanes; tile: POST_TILE + 2 words; blk: 64 words (all LDS on the device) */
 /* dbg (timing experiments only, never set by the product): bit 0 = no coverage pass, bit 1 = no terminal search */
 MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, const GapOut& o, const PostTargets& T, uint32_t* hist, uint64_t* tile, uint64_t* blk, PostOut& out,
@@ -270,7 +309,8 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                 if (j_hi >= npos) break;
             }
         }
-        if (!have_exact && L >= (uint32_t)k && T.n) {
+        if (indexed && L >= (uint32_t)k) best = post_search_indexed(T, w, L, k); /* a call: the pass below keeps the registers it had before the index existed */
+        else if (!have_exact && L >= (uint32_t)k && T.n) {
             const uint32_t npos = L - (uint32_t)k + 1, nwc = (L + 31) / 32;
             for (uint32_t ws = 0; ws < nwc; ws += POST_TILE) {
                 const uint32_t tw = (nwc - ws) < (uint32_t)POST_TILE + 1 ? (nwc - ws) : (uint32_t)POST_TILE + 1; /* one word past the tile: a k-mer may straddle its end */
@@ -284,31 +324,7 @@ MTG_DEV void post_gap(const Index& ix, const FillCfg& cfg, const GapScratch& S, 
                 bool exact = false; /* an exact match is the largest possible count and the earliest one wins: nothing after it matters */
                 for (uint32_t jb = j_lo; jb < j_hi && !exact; jb += MTG_NLANES) {
                     const uint32_t j = jb + lane;
-                    if (j < j_hi && indexed) {
-                        const uint64_t x = le_kmer(tile, j - j_lo, mk);
-                        const uint32_t np = T.nb_mis + 1u;
-                        for (uint32_t p = 0; p < np; p++) {
-                            const uint32_t pb = post_piece_begin(p, np, k), pe = post_piece_begin(p + 1u, np, k);
-                            uint32_t e = T.pi_head[post_piece_slot((x >> (2u * pb)) & ((1ull << (2u * (pe - pb))) - 1ull), p, T.gid, T.pi_mask)];
-                            while (e != (uint32_t)POST_INDEX_NIL) {
-                                const uint32_t t = (e >> 2) - T.gbase;
-                                if (t < T.n && (e & 3u) == p) {
-                                    const uint64_t m = x ^ T.le[t];
-                                    const uint64_t mism = ((m | (m >> 1)) & lsb) | T.bad[t];
-#ifdef MTG_EMU
-                                    const uint32_t nbm = (uint32_t)k - (uint32_t)__builtin_popcountll(mism);
-#else
-                                    const uint32_t nbm = (uint32_t)k - (uint32_t)__popcll(mism);
-#endif
-                                    if (nbm + T.nb_mis >= (uint32_t)k && nbm > 0) {
-                                        const uint64_t key = ((uint64_t)nbm << 40) | (ORD - (single ? (uint64_t)j : (uint64_t)j * T.n + t));
-                                        best = key > best ? key : best;
-                                    }
-                                }
-                                e = T.pi_next[e];
-                            }
-                        }
-                    } else if (j < j_hi) {
+                    if (j < j_hi) {
                         const uint64_t x = le_kmer(tile, j - j_lo, mk);
                         for (uint32_t t = 0; t < T.n; t++) {
                             /* the first target from registers (breakpoint mode has one), the others from memory */
