@@ -1048,6 +1048,11 @@ static int run_bkpt(const Replicas& R, const mtg_params& P, const Options& O, Fi
 static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, Files& F, Summary& S, int trim)
 {
     const int k = R.idx[0]->info.k;
+    /* DEBUG_TIMERS: where a contig job's time goes (thread time of the workers for the three per-batch parts) */
+    const bool dbg = tune::on(tune::T_DEBUG_TIMERS);
+    const auto clock_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::atomic<long> us_prep{0}, us_run{0}, us_text{0};
+    const double t_begin = clock_ms();
     std::vector<std::pair<std::string, std::string>> recs;
     if (!read_sequences(O.contig, recs)) { set_error("cannot read %s", O.contig.c_str()); return MTG_ERR_IO; }
     bkpt_dict_t all_targets;
@@ -1113,6 +1118,7 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
         std::unique_ptr<Batch> bt(new Batch());
         bt->s0 = b * B; bt->s1 = std::min(seeds.size(), (b + 1) * B);
         bt->gaps.resize(bt->s1 - bt->s0);
+        const double tp0 = clock_ms();
         /* (the seeds of a batch over the host's worker pool: a seed's dictionary is 2 (N - 1) entries to put in order and to point at) */
         parallel_for(bt->s1 - bt->s0, P.nb_host_threads, [&](size_t sj) {
             static thread_local mtgcli::DictOrder dict_order;
@@ -1139,7 +1145,10 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
             for (size_t t = 0; t < g.tidx.size(); t++) { const uint32_t e = g.tidx[t]; g.pseq[t] = T.seq[e]; g.pname[t] = T.pname[e]; g.trc[t] = T.rc[e]; }
             g.source = sd.second;
         }, 1);
+        const double tp1 = clock_ms();
         if (int rc = bt->run.run(idx, P, bt->gaps)) return rc;
+        const double tp2 = clock_ms();
+        us_prep += (long)((tp1 - tp0) * 1e3); us_run += (long)((tp2 - tp1) * 1e3);
         for (size_t i = bt->s0; i < bt->s1; i++) {
             const size_t j = i - bt->s0;
             const std::string& seedName = seeds[i].first;
@@ -1160,10 +1169,12 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
             bt->filled += kept.size() > 0;
             bt->multiple += kept.size() > 1;
         }
+        us_text += (long)((clock_ms() - tp2) * 1e3);
         std::lock_guard<std::mutex> lk(bm);
         batches[b] = std::move(bt);
         return MTG_OK;
     };
+    const double t_setup = clock_ms();
     const auto consume = [&](size_t b) {
         std::unique_ptr<Batch> bt;
         { std::lock_guard<std::mutex> lk(bm); bt = std::move(batches[b]); }
@@ -1172,7 +1183,10 @@ static int run_contig(const Replicas& R, const mtg_params& P, const Options& O, 
         S.nb_filled += (int)bt->filled;
         S.nb_multiple += (int)bt->multiple;
     };
-    return run_batches(R, next, process, consume);
+    const int rc_all = run_batches(R, next, process, consume);
+    if (dbg) fprintf(stderr, "  [contig] %zu seeds x %zu targets in %zu batches: contigs read + dictionary %.1f ms, batches %.1f ms wall (workers' time: dictionaries of the seeds %.1f, mtg_fill_batch %.1f, text %.1f ms)\n",
+                     seeds.size(), all_targets.size(), nb, t_setup - t_begin, clock_ms() - t_setup, us_prep / 1e3, us_run / 1e3, us_text / 1e3);
+    return rc_all;
 }
 
 static int run_tool(Options& O, mtg_index* idx, bool resident);

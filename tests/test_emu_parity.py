@@ -1528,6 +1528,44 @@ def _several_targets_batch_case(mtg, monkeypatch):
     idx.close()
 
 
+def _wide_dictionary_case(mtg):
+    """gaps whose dictionary has more than a thousand targets (the marshaller deals such a dictionary to the pool target by target instead of gap by
+    gap, round 6) next to ordinary ones: the reached target is found wherever it stands in the dictionary -- first, last, in the middle, within two
+    differences, lowercase -- and the records equal those of the same gaps with the unreached targets left out (indices mapped)"""
+    rng = random.Random(99)
+    seqs, gaps, small = [], [], []
+    for i in range(12):
+        X, Y = _rand_seq(rng, 300), _rand_seq(rng, 300)
+        a = _rand_seq(rng, rng.randrange(60, 300))
+        seqs.append(X + a + Y)
+        true = Y[40:71]
+        if i % 4 == 1:
+            true = true[:7] + ("A" if true[7] != "A" else "C") + true[8:]
+        if i % 4 == 2:
+            true = true.lower()
+        n = 0 if i % 3 == 2 else 1500 + 37 * i
+        decoys = [(_rand_seq(rng, 31), "d%d_%d" % (i, j), bool(j & 1)) for j in range(n)]
+        at = {0: 0, 1: n, 2: n // 2}[i % 3] if n else 0
+        tg = decoys[:at] + [(true, "hit%d" % i, False)] + decoys[at:]
+        gaps.append(mtg.Gap(X[200:231], "".join(t[0] for t in tg), tg))
+        small.append((mtg.Gap(X[200:231], "".join(t[0] for t in tg), [(true, "hit%d" % i, False)]), at))
+    o = oracle_lib.Index.from_sequences(seqs, 31, 3, 40)
+    km, ct = o.export()
+    o.close()
+    idx = mtg.Index.from_kmers(km, ct, 31)
+    res = idx.fill_batch(gaps)
+    ref = idx.fill_batch([g for g, _ in small])
+    assert all(len(r["filled"]) == 1 for r in res)
+    for r, q, (_, at) in zip(res, ref, small):
+        assert [dict(f, target_index=0) for f in r["filled"]] == [dict(f, target_index=0) for f in q["filled"]]
+        assert r["filled"][0]["target_index"] == at
+    idx.close()
+
+
+def test_dictionaries_of_more_than_a_thousand_targets_on_emulator(emu_product):
+    _wide_dictionary_case(emu_product)
+
+
 def test_gaps_with_several_reached_targets_stay_on_the_device_function(emu_product, monkeypatch):
     _several_targets_batch_case(emu_product, monkeypatch)
 

@@ -293,6 +293,11 @@ def test_contig_mode_inexact_targets_among_many(mtg, tmp_path, monkeypatch):
     _contig_gap_case(mtg, tmp_path / "b", 120, mutate=True)
 
 
+def test_dictionaries_of_more_than_a_thousand_targets(mtg):
+    from tests.test_emu_parity import _wide_dictionary_case
+    _wide_dictionary_case(mtg)
+
+
 def test_cli_edge_cases(mtg, tmp_path):
     """REPEATED anchors, mismatching / N / lowercase / long anchors, unfillable sites, -fwd-only -filter -extend, -max-nodes / -max-length"""
     from tests.test_emu_parity import _edge_case_run
