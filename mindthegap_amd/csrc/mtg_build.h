@@ -433,19 +433,21 @@ struct KeySet {
     uint64_t* keys;
     uint64_t mask; /* capacity - 1 (a power of two) */
 };
-/* true: the key is in the set now and was not before */
-MTG_DEV bool keyset_insert(const KeySet& s, uint64_t key)
+/* 0: the key is in the set now and was not before; 1: it was there; 2: no free slot within reach (the set is far too full: its maker gives up on it) */
+MTG_DEV int keyset_put(const KeySet& s, uint64_t key)
 {
     uint64_t h = mix64(key) & s.mask;
     for (uint32_t probe = 0; probe < 512; probe++) {
         uint64_t cur = marks_load(s.keys + h);
         if (cur == 0) cur = atomic_cas64(s.keys + h, 0, key + 1);
-        if (cur == 0) return true;
-        if (cur == key + 1) return false;
+        if (cur == 0) return 0;
+        if (cur == key + 1) return 1;
         h = (h + 1) & s.mask;
     }
-    return false;
+    return 2;
 }
+/* true: the key is in the set now and was not before */
+MTG_DEV bool keyset_insert(const KeySet& s, uint64_t key) { return keyset_put(s, key) == 0; }
 MTG_DEV bool keyset_has(const KeySet& s, uint64_t key)
 {
     uint64_t h = mix64(key) & s.mask;

@@ -743,22 +743,27 @@ __device__ __forceinline__ PosProbe pos_filter_probe(const PosSets& P, uint64_t 
     p.mask = (1u << (g & 31u)) | (1u << ((g >> 5) & 31u)) | (1u << (g >> 10));
     return p;
 }
-__device__ __forceinline__ void pos_add_stop(const PosSets& P, uint64_t jf, uint64_t jr)
+/* false: the set could not take the key (it never happens at half load; a set without one of its stops would merge two chains, so the host then walks every chain) */
+__device__ __forceinline__ bool pos_add_stop(const PosSets& P, uint64_t jf, uint64_t jr)
 {
     const uint64_t key = jf <= jr ? jf : jr;
-    (void)keyset_insert(P.stops, key);
+    if (keyset_put(P.stops, key) == 2) return false;
     const PosProbe pr = pos_filter_probe(P, key);
     atomicOr(&P.filter[pr.word], pr.mask);
+    return true;
 }
-__global__ void __launch_bounds__(256) k_pos_stops(PosSets P, int k, const uint64_t* __restrict__ starts, unsigned long long n_starts, const uint64_t* __restrict__ left_k, unsigned long long n_left)
+__global__ void __launch_bounds__(256) k_pos_stops(PosSets P, int k, const uint64_t* __restrict__ starts, unsigned long long n_starts, const uint64_t* __restrict__ left_k, unsigned long long n_left,
+                                                   unsigned long long* failed)
 {
     const uint64_t mk1 = kmask(k - 1);
+    bool ok = true;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_starts + n_left; i += (unsigned long long)gridDim.x * blockDim.x) {
         const bool lone = i >= n_starts;
         const Kmer x = make_kmer(lone ? left_k[i - n_starts] : starts[i], k);
-        pos_add_stop(P, x.f >> 2, x.r & mk1);           /* the junction on its left */
-        if (lone) pos_add_stop(P, x.f & mk1, x.r >> 2); /* a k-mer of no chain: the one on its right as well */
+        ok = pos_add_stop(P, x.f >> 2, x.r & mk1) && ok;           /* the junction on its left */
+        if (lone) ok = pos_add_stop(P, x.f & mk1, x.r >> 2) && ok; /* a k-mer of no chain: the one on its right as well */
     }
+    if (!ok) atomicOr(failed, 1ull);
 }
 enum { POS_R = 16, POS_TILE = 256 * POS_R };
 /* a lane takes POS_R consecutive junction positions: the first junction from the words, the next ones by one nucleotide each (two shifts instead of a
@@ -1203,12 +1208,19 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
             HIP_TRY(hipMemsetAsync(PS.stops.keys, 0, scap * 8, 0));
             HIP_TRY(hipMemsetAsync(PS.done.keys, 0, dcap * 8, 0));
             HIP_TRY(hipMemsetAsync(PS.filter, 0, fbits / 8, 0));
-            hipLaunchKernelGGL(k_pos_stops, dim3((unsigned)std::min<unsigned long long>((n_stops + 255) / 256, 256 * 16)), dim3(256), 0, 0, PS, k, (const uint64_t*)p_starts, n_starts, (const uint64_t*)d_left_k.as<uint64_t>(), n_single);
+            HIP_TRY(hipMemsetAsync(cnt_d + JT_C_N + 1, 0, 8, 0)); /* (the compaction's flag, free until then) */
+            hipLaunchKernelGGL(k_pos_stops, dim3((unsigned)std::min<unsigned long long>((n_stops + 255) / 256, 256 * 16)), dim3(256), 0, 0, PS, k, (const uint64_t*)p_starts, n_starts, (const uint64_t*)d_left_k.as<uint64_t>(), n_single,
+                               cnt_d + JT_C_N + 1);
             HIP_TRY(prof.end("pos_stops", n_stops * 24 + scap * 8 + dcap * 8 + fbits / 8, n_stops));
-            prof.begin();
-            hipLaunchKernelGGL(k_pos_plan, dim3((unsigned)std::min<size_t>(packed->nseq, 256 * 8)), dim3(256), 0, 0, PS, *packed, k, WS, p_pos_src);
-            HIP_TRY(prof.end("pos_plan", (interior / 2 + n_starts) / 4 + n_starts * 40, interior / 2 + n_starts)); /* the sequences once; per chain its record and its two claims */
-            WS.done = PS.done;
+            unsigned long long stops_failed = 0;
+            HIP_TRY(hipMemcpy(&stops_failed, cnt_d + JT_C_N + 1, 8, hipMemcpyDeviceToHost));
+            if (stops_failed) positional = false; /* a stop is missing from the set: every chain is walked */
+            else {
+                prof.begin();
+                hipLaunchKernelGGL(k_pos_plan, dim3((unsigned)std::min<size_t>(packed->nseq, 256 * 8)), dim3(256), 0, 0, PS, *packed, k, WS, p_pos_src);
+                HIP_TRY(prof.end("pos_plan", (interior / 2 + n_starts) / 4 + n_starts * 40, interior / 2 + n_starts)); /* the sequences once; per chain its record and its two claims */
+                WS.done = PS.done;
+            }
         }
         prof.begin();
         hipLaunchKernelGGL(k_jt_walk, dim3((unsigned)((n_starts + 63) / 64)), dim3(64), 0, 0, WS, n_starts);
