@@ -129,7 +129,10 @@ __global__ void k_leftovers(Index ix, uint64_t* out_k, uint32_t* out_a, unsigned
  * four times over (PMC: 112 bytes of HBM traffic per k-mer for the filter alone, 100 of the kernel's 220 ms).  Now the lanes of a run of equal
  * blocks OR their bits together in LDS (eight 64-bit words per run) and the wave flushes eight runs per instruction, the eight words of a run
  * on eight neighbouring lanes: one line per run instead of four per k-mer. */
-__global__ void __launch_bounds__(64) k_sparse_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n, int with_bloom, unsigned long long* counters)
+/* items != nullptr: the work is dealt in PIECES of unitigs ((unitig, first k-mer) pairs, US_PIECE k-mers each) instead of whole unitigs: a store
+ * of a few unitigs of millions of k-mers would give a few waves all the work (round 6: 37 unitigs of 125 Mbp, 11.8 s) */
+enum : uint32_t { US_PIECE = 1u << 15, US_LONG = 1u << 18 };
+__global__ void __launch_bounds__(64) k_sparse_link(Index ix, const UsRec* __restrict__ rec, unsigned long long n, int with_bloom, unsigned long long* counters, const uint2* __restrict__ items)
 {
     __shared__ unsigned long long s_bits[64 * 8];
     __shared__ unsigned long long s_blk[64];
@@ -140,18 +143,19 @@ __global__ void __launch_bounds__(64) k_sparse_link(Index ix, const UsRec* __res
     Index nb = ix;
     nb.bloom.bits = nullptr; /* sparse_link's own insertion is off: the filter is filled below */
     int fail = 0;
-    for (unsigned long long u = blockIdx.x; u < n; u += gridDim.x) {
-        const UsRec r = rec[u];
-        for (uint32_t base = 0; base < r.len_k; base += 64) {
+    for (unsigned long long w = blockIdx.x; w < n; w += gridDim.x) {
+        const UsRec r = rec[items ? items[w].x : w];
+        const uint32_t base_begin = items ? items[w].y : 0u, base_end = items ? (r.len_k - base_begin < (uint32_t)US_PIECE ? r.len_k : base_begin + (uint32_t)US_PIECE) : r.len_k;
+        for (uint32_t base = base_begin; base < base_end; base += 64) {
             const uint32_t i = base + lane;
-            const bool valid = i < r.len_k;
+            const bool valid = i < base_end;
             if (valid) fail |= sparse_link(nb, r, i, false);
             if (!bloom) continue;
             /* the minimizer of a k-mer is the smallest hash among its k - m + 1 m-mers, and neighbouring k-mers share all but one of them: the tile's
              * m-mers are hashed ONCE, by the lanes, into LDS (64 + k - m of them; two 64-bit multiplications each), and a k-mer takes the minimum
              * over its window there -- bloom_block hashed fifteen m-mers per k-mer */
             const int mm = ix.bloom.mm;
-            const uint32_t span = (uint32_t)(k - mm), tile_n = (r.len_k - base < 64u ? r.len_k - base : 64u) + span; /* m-mers of the tile's k-mers */
+            const uint32_t span = (uint32_t)(k - mm), tile_n = (base_end - base < 64u ? base_end - base : 64u) + span; /* m-mers of the tile's k-mers */
             for (uint32_t t = lane; t < tile_n; t += 64) s_mh[t] = bloom_mmer_hash(us_peek64(ix.us.words, (r.hdr + 1) * 32 + base + t, (uint32_t)mm, false), mm);
             __syncthreads();
             unsigned long long blk = ~0ull, hb = 0;
@@ -883,15 +887,16 @@ __global__ void __launch_bounds__(256) k_us_from_seq(UStore us, int k, const UsR
 }
 /* one stored unitig per wave, its k-mers dealt to the lanes: abundances from the source into the store.  counters[JT_C_SAT] += those above 255 */
 template <typename Src>
-__global__ void __launch_bounds__(256) k_us_ab(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, Src src, unsigned long long* counters)
+__global__ void __launch_bounds__(256) k_us_ab(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, Src src, unsigned long long* counters, const uint2* __restrict__ items)
 {
     const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t lines = 0;
     unsigned long long sat = 0;
-    for (unsigned long long u = wave; u < n; u += nwaves) {
-        const UsRec r = rec[u];
-        for (uint32_t i = lane; i < r.len_k; i += 64) sat += us_ab_fill(us, k, r, i, src, lines);
+    for (unsigned long long w = wave; w < n; w += nwaves) { /* (items: pieces of unitigs, as in k_sparse_link) */
+        const UsRec r = rec[items ? items[w].x : w];
+        const uint32_t i0 = items ? items[w].y : 0u, i1 = items ? (r.len_k - i0 < (uint32_t)US_PIECE ? r.len_k : i0 + (uint32_t)US_PIECE) : r.len_k;
+        for (uint32_t i = i0 + lane; i < i1; i += 64) sat += us_ab_fill(us, k, r, i, src, lines);
     }
     sat = wave_sum_u64(sat);
     if (lane == 0 && sat) atomicAdd(&counters[JT_C_SAT], sat);
@@ -999,6 +1004,27 @@ struct LateLeftovers {
     std::function<int(const Index& nx, DevBuf& left_k, DevBuf& left_a, unsigned long long& n_left)> collect;
 };
 } // namespace
+__global__ void k_rec_longest(const UsRec* __restrict__ rec, unsigned long long n, unsigned long long* out)
+{
+    unsigned long long m = 0;
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (unsigned long long)gridDim.x * blockDim.x) m = rec[u].len_k > m ? rec[u].len_k : m;
+    if (m) atomicMax(out, m);
+}
+/* the (unitig, first k-mer) pieces of a store with a LONG unitig (US_LONG k-mers or more) -- empty when it has none: the kernels then take whole unitigs */
+static int unitig_pieces(const std::vector<UsRec>& h_rec, DevBuf& d_items, unsigned long long& n_items)
+{
+    n_items = 0;
+    bool any_long = false;
+    for (const UsRec& r : h_rec) any_long = any_long || r.len_k >= (uint32_t)US_LONG;
+    if (!any_long) return MTG_OK;
+    std::vector<uint2> items;
+    for (size_t u = 0; u < h_rec.size(); u++)
+        for (uint32_t b = 0; b < h_rec[u].len_k; b += (uint32_t)US_PIECE) { uint2 it; it.x = (uint32_t)u; it.y = b; items.push_back(it); }
+    HIP_TRY(d_items.alloc(items.size() * sizeof(uint2)));
+    HIP_TRY(hipMemcpy(d_items.p, items.data(), items.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    n_items = items.size();
+    return MTG_OK;
+}
 static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec, bool from_container, const uint64_t* d_left_k, const uint32_t* d_left_a, unsigned long long n_left,
                     BuildProf* prof = nullptr, const LateLeftovers* late = nullptr, DevBuf* adj_reuse = nullptr);
 /* The sparse form, from the unitig store (idx holds only the store: the lean build, or an index out of its container) and the k-mers of no
@@ -1013,10 +1039,13 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
     const unsigned long long n_left_shape = late ? std::max(late->n_upper, n_left) : n_left;
     /* entries of the new ADJ: per unitig its kept interior junctions (every second one and the last) and its two ends; two per k-mer of no unitig */
     uint64_t nkeys = 2 * n_left_shape + 1024, n_unitig_kmers = 0;
+    DevBuf d_items;
+    unsigned long long n_items = 0;
     {
         std::vector<UsRec> h_rec(n_rec);
         if (n_rec) HIP_TRY(hipMemcpy(h_rec.data(), d_rec, n_rec * sizeof(UsRec), hipMemcpyDeviceToHost));
         for (const UsRec& r : h_rec) { nkeys += r.len_k / 2 + 3; n_unitig_kmers += r.len_k; }
+        if (int rc2 = unitig_pieces(h_rec, d_items, n_items)) return rc2;
     }
     Index old = idx->dev;
     double load = 1.0;
@@ -1043,7 +1072,11 @@ static int sparsify(mtg_index* idx, const UsRec* d_rec, unsigned long long n_rec
         nx.abnd.slots = nb.as<uint64_t>();
         HIP_TRY(hipMemset(d_cnt.p, 0, 64));
         if (prof) prof->begin();
-        if (n_rec) hipLaunchKernelGGL(k_sparse_link, dim3((unsigned)std::min<unsigned long long>(n_rec, 256 * 256)), dim3(64), 0, 0, nx, d_rec, n_rec, from_container ? 1 : 0, d_cnt.as<unsigned long long>());
+        if (n_rec) {
+            const unsigned long long n_work = n_items ? n_items : n_rec;
+            hipLaunchKernelGGL(k_sparse_link, dim3((unsigned)std::min<unsigned long long>(n_work, 256 * 256)), dim3(64), 0, 0, nx, d_rec, n_work, from_container ? 1 : 0, d_cnt.as<unsigned long long>(),
+                               n_items ? (const uint2*)d_items.as<uint2>() : (const uint2*)nullptr);
+        }
         HIP_TRY(hipGetLastError());
         /* per k-mer: its window of the store (8), every second one an ADJ bucket read and written (2 x 32), with the filter a block (64 + 64) */
         if (prof) HIP_TRY(prof->end(from_container ? "sparse_link+bloom" : "sparse_link", n_unitig_kmers * (8 + 32 + (from_container && nx.bloom.bits ? 128 : 0)), n_unitig_kmers));
@@ -1261,7 +1294,23 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
         if (short_chain) { set_error("unitig construction: a chunk chain is shorter than its record"); return MTG_ERR_OVERFLOW; }
         behind.own.clear(); /* the pieces behind the table are dead from here on: its buffer becomes the sparse ADJ table below */
         prof.begin();
-        hipLaunchKernelGGL(k_us_ab<Src>, dim3((unsigned)std::min<unsigned long long>((n_rec + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_rec, src, cnt_d);
+        {
+            DevBuf d_items, d_max;
+            unsigned long long n_items = 0, longest = 0;
+            HIP_TRY(d_max.alloc(8));
+            HIP_TRY(hipMemsetAsync(d_max.p, 0, 8, 0));
+            hipLaunchKernelGGL(k_rec_longest, dim3((unsigned)std::min<unsigned long long>((n_rec + 255) / 256, 1024)), dim3(256), 0, 0, d_rec.as<UsRec>(), n_rec, d_max.as<unsigned long long>());
+            HIP_TRY(hipMemcpy(&longest, d_max.p, 8, hipMemcpyDeviceToHost));
+            if (longest >= (unsigned long long)US_LONG) { /* rare: the records come to the host for the list of pieces */
+                std::vector<UsRec> h_rec(n_rec);
+                HIP_TRY(hipMemcpy(h_rec.data(), d_rec.p, n_rec * sizeof(UsRec), hipMemcpyDeviceToHost));
+                if (int rc2 = unitig_pieces(h_rec, d_items, n_items)) return rc2;
+            }
+            const unsigned long long n_work = n_items ? n_items : n_rec;
+            hipLaunchKernelGGL(k_us_ab<Src>, dim3((unsigned)std::min<unsigned long long>((n_work + 3) / 4, 256 * 64)), dim3(256), 0, 0, idx->dev.us, k, d_rec.as<UsRec>(), n_work, src, cnt_d,
+                               n_items ? (const uint2*)d_items.as<uint2>() : (const uint2*)nullptr);
+            HIP_TRY(hipDeviceSynchronize()); /* (the pieces' list goes out of scope) */
+        }
         HIP_TRY(prof.end("us_abundances", (stored_views / 2 + n_rec) * 9, stored_views / 2 + n_rec));
         HIP_TRY(hipMemcpy(&sat_unitigs, cnt_d + JT_C_SAT, 8, hipMemcpyDeviceToHost));
         idx->info.nb_unitigs = n_rec;
@@ -1503,12 +1552,53 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
     mtg_index* idx = g.idx;
     idx->dev.k = k;
     HIP_TRY(hipGetDevice(&idx->device));
-    DevBuf d_cnt, jt_buf;
+    DevBuf d_cnt, jt_buf, d_split_off, d_split_len;
     HIP_TRY(d_cnt.alloc(32));
+    const uint64_t* ins_word_off = d_word_off; /* what the INSERTION streams: the sequences, the long ones in pieces */
+    const uint32_t* ins_len = d_len;
+    size_t ins_nseq = nseq;
+    /* LONG sequences are taken in pieces.  The kernels that stream the sequences give a sequence to a workgroup (k_bin_positions, k_jt_insert_packed,
+     * k_pos_plan): a donor of a few chromosome-sized sequences would keep a few workgroups busy and the rest of the device idle.  A piece of a
+     * sequence that starts at a multiple of 32 nucleotides (a word boundary) and shares its last k - 1 nucleotides with the next piece is a sequence
+     * like any other, the pieces have the sequence's k-mers exactly once, and the junction they share gets its two sides from the two pieces (the
+     * table ORs them): the same graph.  Only the insertion sees the pieces: the chains are looked for in the sequences as they came (a chain that
+     * crosses a cut would lie whole in no piece and be left to its walkers -- 142 s for 24 chains of 125 Mbp, scripts/r6_long_sequences.py).
+     * The lengths come to the host for this (4 bytes a sequence). */
+    if (nseq) {
+        enum : uint32_t { PIECE = 1u << 16 };
+        std::vector<uint32_t> h_len(nseq);
+        HIP_TRY(hipMemcpy(h_len.data(), d_len, nseq * 4, hipMemcpyDeviceToHost));
+        uint32_t longest = 0;
+        for (uint32_t L : h_len) longest = std::max(longest, L);
+        if (longest > 2u * PIECE && !tune::on(tune::T_NO_SPLIT_LONG)) {
+            std::vector<uint64_t> h_off(nseq);
+            HIP_TRY(hipMemcpy(h_off.data(), d_word_off, nseq * 8, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> p_off;
+            std::vector<uint32_t> p_len;
+            p_off.reserve(nseq + nseq / 8); p_len.reserve(nseq + nseq / 8);
+            for (size_t s2 = 0; s2 < nseq; s2++) {
+                const uint32_t L = h_len[s2];
+                if (L <= 2u * PIECE) { p_off.push_back(h_off[s2]); p_len.push_back(L); continue; }
+                for (uint64_t at = 0; at < L; at += PIECE) {
+                    const uint64_t rest = L - at;
+                    if (rest < (uint64_t)k && at) break; /* (its k-mers are the piece before's: that one ran to the sequence's end) */
+                    p_off.push_back(h_off[s2] + at / 32);
+                    p_len.push_back((uint32_t)std::min<uint64_t>(rest, (uint64_t)PIECE + (uint64_t)k - 1));
+                }
+            }
+            HIP_TRY(d_split_off.alloc(p_off.size() * 8));
+            HIP_TRY(d_split_len.alloc(p_len.size() * 4));
+            HIP_TRY(hipMemcpy(d_split_off.p, p_off.data(), p_off.size() * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_split_len.p, p_len.data(), p_len.size() * 4, hipMemcpyHostToDevice));
+            ins_word_off = d_split_off.as<uint64_t>();
+            ins_len = d_split_len.as<uint32_t>();
+            ins_nseq = p_off.size();
+        }
+    }
     Table jt{};
     double load = 1.0;
     int rc = MTG_OK;
-    const uint64_t n_junctions_ub = total_kmers_ub + nseq + 1024; /* a sequence of L >= k nucleotides has L - k + 2 junction positions */
+    const uint64_t n_junctions_ub = total_kmers_ub + ins_nseq + 1024; /* a sequence of L >= k nucleotides has L - k + 2 junction positions */
     /* large tables are built partition by partition (jt_insert_partitioned); BUILD_PARTITIONED = 0 / 1 of the tuning table forces either way */
     bool partitioned_ok = true;
     for (int attempt = 0; attempt < 6; attempt++) {
@@ -1519,13 +1609,13 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
          * buckets -- one in a billion buckets has one -- sent a key past the 63 buckets a look-up follows in half the runs; the buffer is sized for the larger
          * sparse ADJ table anyway) */
         const uint64_t nb0 = std::max<uint64_t>(buckets_for(n_junctions_ub, std::min(jt_load(), 0.62) * load, kb, MTG_ABND_SLOTS), jt_min_buckets(kb));
-        const bool want_part = partitioned_ok && nseq != 0 && (tune::is_set(tune::T_BUILD_PARTITIONED) ? tune::on(tune::T_BUILD_PARTITIONED) : n_junctions_ub >= (1ull << 27)) && bin_shape(nb0, kb, BS, nb_part);
+        const bool want_part = partitioned_ok && ins_nseq != 0 && (tune::is_set(tune::T_BUILD_PARTITIONED) ? tune::on(tune::T_BUILD_PARTITIONED) : n_junctions_ub >= (1ull << 27)) && bin_shape(nb0, kb, BS, nb_part);
         if (want_part) {
             if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, kb, prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k), nb_part, false)) return rc2;
             HIP_TRY(hipMemset(d_cnt.p, 0, 32));
             const size_t tb = jt.nbuckets * 8 * MTG_ABND_SLOTS;
             unsigned long long cnt0 = 0;
-            const int prc = jt_insert_partitioned(jt, BS, k, d_words, d_word_off, d_len, nseq, n_junctions_ub, jt_buf.as<uint8_t>() + tb, jt_buf.cap > tb ? jt_buf.cap - tb : 0, d_cnt.as<unsigned long long>(), cnt0, prof);
+            const int prc = jt_insert_partitioned(jt, BS, k, d_words, ins_word_off, ins_len, ins_nseq, n_junctions_ub, jt_buf.as<uint8_t>() + tb, jt_buf.cap > tb ? jt_buf.cap - tb : 0, d_cnt.as<unsigned long long>(), cnt0, prof);
             if (prc == MTG_ERR_OVERFLOW) { partitioned_ok = false; attempt--; continue; } /* very uneven sequences or hashes: the ordinary insertion */
             if (prc) return prc;
             if (!cnt0) { rc = MTG_OK; break; }
@@ -1536,9 +1626,9 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
         }
         if (int rc2 = alloc_slot_table(jt, jt_buf, n_junctions_ub, jt_load() * load, 2 * (k - 1), prof, "clear_jt", adj_bytes_estimate(total_kmers_ub, k), jt_min_buckets(2 * (k - 1)))) return rc2;
         HIP_TRY(hipMemset(d_cnt.p, 0, 32));
-        if (nseq == 0) break; /* an empty graph: nothing to launch */
+        if (ins_nseq == 0) break; /* an empty graph: nothing to launch */
         prof.begin();
-        hipLaunchKernelGGL(k_jt_insert_packed, dim3((unsigned)std::min<size_t>(nseq, 256 * 32)), dim3(256), 0, 0, jt, k, d_words, d_word_off, d_len, nseq, d_cnt.as<unsigned long long>());
+        hipLaunchKernelGGL(k_jt_insert_packed, dim3((unsigned)std::min<size_t>(ins_nseq, 256 * 32)), dim3(256), 0, 0, jt, k, d_words, ins_word_off, ins_len, ins_nseq, d_cnt.as<unsigned long long>());
         HIP_TRY(prof.end("jt_insert_packed", n_junctions_ub * (64 + 1), n_junctions_ub)); /* a junction position: its bucket read and written (2 x 32), its nucleotides */
         unsigned long long cnt[4];
         HIP_TRY(hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));

@@ -35,6 +35,7 @@
     X(ROUNDS, "", "ab", "bubble rounds between launches of the walk kernel (default: 6 when most gaps of the previous launch parked, else 0)") \
     X(LIGHT_WALK, "", "ab", "1 / 0: the first walk of a launch by the light kernel (simple paths only, every branching node parks) / by the full one; default: light when fewer than 1 in 128 gaps of the previous launch met a branching node") \
     X(BUILD_PARTITIONED, "", "ab", "the junction table of packed sequences built partition by partition in LDS (1) or by scattered insertion (0); default: partitioned from 2^27 junction positions on") \
+    X(NO_SPLIT_LONG, "", "test", "index construction from packed sequences: a sequence of more than 131 072 nucleotides stays one work item (no pieces of 65 536 that share k - 1 nucleotides)") \
     X(BUILD_POSITIONAL, "", "ab", "packed sequences: the chains that lie whole in one sequence are found by position (1, default) or every chain is walked on the junction table (0)") \
     X(FINISH_G, "", "ab", "lanes per parked gap in the finishing kernel: 1, 8, 16 or 64 (default: 64 while few gaps park, 16 otherwise)") \
     X(FINISH_WAVE_BELOW, "2048", "ab", "a whole wave per parked gap while the previous launch parked fewer gaps than this") \

@@ -962,6 +962,86 @@ def test_chains_found_by_position_equal_the_walked_ones(mtg):
 
 
 @pytest.mark.gpu
+def test_long_sequences_taken_in_pieces_give_the_same_index(mtg):
+    """Graph::create from packed sequences (src/Filler.cpp:172-213): a sequence of more than 131 072 nucleotides is taken in pieces of 65 536 that share
+    k - 1 nucleotides (round 6: the streaming kernels give a sequence to a workgroup, and a donor of a few chromosomes would keep a few busy) -- the same
+    k-mers once, the junction at a cut from its two pieces -- and must give the index of the unsplit input (NO_SPLIT_LONG=1): statistics, contains /
+    abundance / neighbourhood of the k-mers around every cut and of samples elsewhere, fills of sites that lie in the long sequences."""
+    import torch
+    from mindthegap_amd.synth import SynthSet
+    k = 31
+    S = SynthSet(nseq=300, n_sites=100, seed=41, k=k)
+    rng = np.random.default_rng(17)
+    rep = rng.integers(0, 4, 3000).astype(np.uint8)
+    a = rng.integers(0, 4, 400000).astype(np.uint8)
+    a[65536 - 1500:65536 + 1500] = rep          # a repeat across the first cut ...
+    b = rng.integers(0, 4, 140000).astype(np.uint8)
+    b[20000:23000] = rep                        # ... and inside another sequence: the chains around the cut branch there
+    extra = [a, b, rng.integers(0, 4, 131072).astype(np.uint8), rng.integers(0, 4, 131073).astype(np.uint8), rng.integers(0, 4, 2 * 65536 + 65536 + 20).astype(np.uint8)]
+    ew, eo, el = _pack_codes(extra)
+    pw, po, pl, pn = S.packed()
+    words = np.concatenate([pw, ew, np.zeros(2, dtype=np.uint64)])
+    off = np.concatenate([po, eo + np.uint64(pw.size)])
+    lens = np.concatenate([pl, el])
+    nseq = pn + len(extra)
+    ub = int(np.maximum(lens.astype(np.int64) - (k - 1), 0).sum())
+
+    def kmers_of(c):
+        out = []
+        for p0 in range(0, len(c) - k + 1):
+            v = 0
+            for x in c[p0:p0 + k]:
+                v = (v << 2) | int(x)
+            r = 0
+            for x in c[p0:p0 + k][::-1]:
+                r = (r << 2) | (int(x) ^ 2)
+            out.append(min(v, r))
+        return out
+    km = []
+    for c in extra:
+        for cut in range(65536, len(c), 65536):
+            km += kmers_of(c[max(0, cut - 80):cut + 80])
+        km += kmers_of(c[:200]) + kmers_of(c[-200:]) + kmers_of(c[len(c) // 3:len(c) // 3 + 150])
+    # the unitig behind the repeat of the first sequence has 333 000 k-mers: the link and the abundances take it in pieces of 32 768 k-mers, from either end
+    for j in range(1, 11):
+        for at in (65536 + 1500 + j * 32768, 400000 - (k - 1) - j * 32768):
+            km += kmers_of(extra[0][at - 70:at + 70])
+    km = np.array(km + [int(x) for x in rng.integers(0, 2**62, 300)], dtype=np.uint64)
+    dev = torch.device("cuda", 0)
+    built = {}
+    for whole in ("1", None):
+        mtg.tuning_set("NO_SPLIT_LONG", whole)
+        try:
+            w = torch.from_numpy(words.view(np.int64)).to(dev)
+            wo = torch.from_numpy(off.view(np.int64)).to(dev)
+            ln = torch.from_numpy(lens.view(np.int32)).to(dev)
+            idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), nseq, ub, k, 3, 40)
+        finally:
+            mtg.tuning_set("NO_SPLIT_LONG", None)
+        info = idx.info()
+        has, ab = idx.contains(km), idx.abundance(km)
+        succ, pred = idx.neighbors(km)
+        # sites in the long sequences: from 31 nucleotides before a cut to 31 after it, and across the repeat
+        gaps = []
+        for c in (extra[0], extra[4]):
+            for cut in range(65536, len(c) - 2000, 65536):
+                for l0, r0 in ((cut - 400, cut + 300), (cut - 31, cut + 31), (cut + 5, cut + 900)):
+                    l = "".join("ACTG"[x] for x in c[l0 - k:l0]); r = "".join("ACTG"[x] for x in c[r0:r0 + k])
+                    gaps.append(mtg.Gap(l, r, [(r, "s%d_%d" % (cut, l0), False)]))
+        for i in range(S.n_sites):
+            l, r, _ = S.site(i)
+            gaps.append(mtg.Gap(l, r, [(r, S.site_name(i), False)]))
+        res = idx.fill_batch(gaps)
+        built[whole] = ({k2: info[k2] for k2 in ("nb_solid_kmers", "nb_branching", "nb_unitigs", "nb_kmers_outside_unitigs", "unitig_bytes")}, has.tolist(), ab.tolist(), succ.tolist(), pred.tolist(),
+                        [[(f["seq"], f["nb_errors_in_anchor"], f["qual"]) for f in r["filled"]] for r in res])
+        idx.close()
+        del w, wo, ln
+    for x, y, what in zip(built["1"], built[None], ("info", "contains", "abundance", "successors", "predecessors", "fills")):
+        assert x == y, what
+    assert all(built[None][1][:len(km) - 300]) and sum(1 for r in built[None][5] if r) > 100
+
+
+@pytest.mark.gpu
 def test_two_reached_targets_under_one_name_on_device(mtg):
     from tests.test_emu_parity import _duplicate_target_names_case
     _duplicate_target_names_case(mtg)
