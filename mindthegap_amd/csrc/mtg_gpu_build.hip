@@ -1455,7 +1455,10 @@ static int index_from_kmer_pieces_lean(size_t n, int k, const KmerFetch& fetch, 
 /* the shape of the partitioned construction for a table of at least nb0 buckets; false: the table is too small for it to pay (or k too small for the record) */
 static bool bin_shape(uint64_t nb0, uint32_t key_bits, BinShape& S, uint64_t& nb)
 {
-    const uint64_t max_m = 2048; /* 64 KB of LDS per segment */
+#ifndef MTG_SEG_MAX_M
+#define MTG_SEG_MAX_M 2048
+#endif
+    const uint64_t max_m = MTG_SEG_MAX_M; /* 2 048: 64 KB of LDS per segment */
     uint32_t b = 0;
     while (((nb0 + (1ull << b) - 1) >> b) > max_m) b++;
     if (b < 8 || b > 21 || key_bits < b + 8) return false;
