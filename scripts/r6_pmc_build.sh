@@ -13,7 +13,7 @@ acc = defaultdict(lambda: defaultdict(float))
 for f in glob.glob(os.path.join(O, "p_*", "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "k_bin" in k or "k_build_seg" in k or "k_jt_walk" in k or "k_sparse_link" in k:
+        if any(w in k for w in ("k_bin", "k_build_seg", "k_jt_walk", "k_sparse_link", "k_pos_plan", "k_jt_scan", "k_us_ab")):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, cs in sorted(acc.items()):
     print(k, {c: "%.3g" % v for c, v in sorted(cs.items())})
