@@ -116,13 +116,15 @@ MTG_DEV JView jt_left(const Table& jt, const Kmer& x, uint64_t mk1, uint32_t& li
 /* table_or with the bucket read in one go before any atomic (the entry usually exists with its bits, or the first free slot takes it).
  * A stale read is harmless: the tag part of a slot is written once, a slot seen empty is claimed by compare-and-swap, bits seen missing
  * are OR-ed in again.  Returns as table_or. */
-MTG_DEV int jt_or_h(const Table& t, uint64_t H, uint32_t bits);
-MTG_DEV int jt_or(const Table& t, uint64_t key, uint32_t bits) { return jt_or_h(t, mix(key, t.key_bits), bits); }
+/* mark: 0, or JT_MARK for a junction the scan must look at in full (jt_special): the entry carries the bit from its first insertion on */
+MTG_DEV int jt_or_h(const Table& t, uint64_t H, uint32_t bits, uint64_t mark = 0);
+MTG_DEV int jt_or(const Table& t, uint64_t key, uint32_t bits, uint64_t mark = 0) { return jt_or_h(t, mix(key, t.key_bits), bits, mark); }
 /* the same for a key given by its hash H = mix(key) (the partitioned construction carries hashes, not keys) */
-MTG_DEV int jt_or_h(const Table& t, uint64_t H, uint32_t bits)
+MTG_DEV int jt_or_h(const Table& t, uint64_t H, uint32_t bits, uint64_t mark)
 {
     uint64_t b = bucket_of(H, t.nbuckets, t.key_bits);
     const uint64_t tag = H & ((1ULL << t.tag_bits) - 1);
+    const uint64_t add = (uint64_t)bits | mark;
     for (uint32_t d = 0; d <= MTG_MAX_DISP; d++) {
         const uint64_t want = (tag << MTG_DISP_BITS) | d;
         uint64_t* p = t.slots + b * MTG_ABND_SLOTS;
@@ -132,17 +134,30 @@ MTG_UNROLL
         for (int i = 0; i < MTG_ABND_SLOTS; i++) {
             uint64_t v = q[i];
             if (v == 0) {
-                v = atomic_cas64(p + i, 0, (want << 8) | bits);
+                v = atomic_cas64(p + i, 0, (want << 8) | add);
                 if (v == 0) return 2;
             }
-            if ((v >> 8) == want) {
-                if ((v & bits) != bits) atomic_or64(p + i, bits);
+            if (((v & ~JT_MARK) >> 8) == want) {
+                if ((v & add) != add) atomic_or64(p + i, add);
                 return 0;
             }
         }
         b = (b + 1 == t.nbuckets) ? 0 : b + 1;
     }
     return 1;
+}
+/* The junctions whose entry the scan cannot judge by its edge bits alone (odd k; jt_scan_bucket): the palindromic ones (one view instead of two) and
+ * the runs of one nucleotide (the self loop a + J == J + b that us_eligible rules out).  One junction in 10^9 of a random sequence; they are flagged
+ * with JT_MARK when they are inserted, every other entry with one bit on each side is a chain interior without its key being looked at -- getting
+ * the key back (the hash undone, a division's worth of arithmetic for a displaced slot) and its reverse complement made k_jt_scan the one kernel of
+ * the construction that is bound by its vector instructions (290 per entry, round 6).  Even k: no flags, the scan looks at every key as before. */
+MTG_DEV bool jt_special(uint64_t jf, uint64_t jr, uint32_t key_bits)
+{
+    if ((key_bits & 2u) != 0) return false; /* key_bits = 2 (k - 1): k - 1 odd, k even */
+    const uint64_t lsb = 0x5555555555555555ULL & ((1ULL << key_bits) - 1ULL);
+    const uint32_t c = (uint32_t)jf & 3u;
+    const uint64_t run = ((c & 1u) ? lsb : 0ULL) | ((c & 2u) ? lsb << 1 : 0ULL);
+    return jf == jr || jf == run;
 }
 /* one occurrence of the junction J ((k-1)-mer jf, its reverse complement jr) with the nucleotide before it (a, when has_a: the k-mer a+J is
  * solid) and behind it (b, when has_b: J+b is solid): what index_insert contributes to J's entry from the k-mers on its two sides (a
@@ -158,7 +173,7 @@ MTG_DEV int jt_insert_junction(const Table& jt, uint64_t jf, uint64_t jr, bool h
 {
     const uint32_t bits = jt_junction_bits(jf, jr, has_a, a, has_b, b);
     if (!bits) return 0;
-    return jt_or(jt, jf <= jr ? jf : jr, bits);
+    return jt_or(jt, jf <= jr ? jf : jr, bits, jt_special(jf, jr, jt.key_bits) ? JT_MARK : 0ULL);
 }
 /* the two junctions of the solid canonical k-mer c */
 MTG_DEV int jt_insert_kmer(const Table& jt, uint64_t c, int k)
@@ -278,25 +293,61 @@ MTG_DEV void jt_scan_entry(const Table& jt, int k, uint64_t J, uint32_t m, const
 /* the scan, one BUCKET at a time (the device: one lane per bucket, two 16-byte reads): the keys of its slots from one division
  * (bucket_first_h), then jt_scan_entry.  With lists large enough the ONE pass leaves statistics, chain starts and the k-mers of no chain; the
  * cursors count past the capacities, so a caller whose guess was too small learns the exact sizes and scans again. */
+MTG_DEV void jt_bucket_words(const Table& jt, uint64_t b, uint64_t* q)
+{
+    const uint64_t* p = jt.slots + b * MTG_ABND_SLOTS;
+MTG_UNROLL
+    for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) { const U64x2 v = ld_table(reinterpret_cast<const U64x2*>(p) + i); q[2 * i] = v.x; q[2 * i + 1] = v.y; }
+}
+template <typename Src>
+MTG_DEV void jt_scan_bucket_words(const Table& jt, int k, uint64_t b, const uint64_t* q, const Src& src, JtAcc& acc, unsigned long long* counters,
+                                  uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines);
 template <typename Src>
 MTG_DEV void jt_scan_bucket(const Table& jt, int k, uint64_t b, const Src& src, JtAcc& acc, unsigned long long* counters,
                             uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
 {
     uint64_t q[MTG_ABND_SLOTS];
-    const uint64_t* p = jt.slots + b * MTG_ABND_SLOTS;
-MTG_UNROLL
-    for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) { const U64x2 v = ld_table(reinterpret_cast<const U64x2*>(p) + i); q[2 * i] = v.x; q[2 * i + 1] = v.y; }
+    jt_bucket_words(jt, b, q);
+    jt_scan_bucket_words(jt, k, b, q, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+}
+/* the same with the bucket's words in hand (the device reads the buckets of several turns before it looks at the first: k_jt_scan) */
+template <typename Src>
+MTG_DEV void jt_scan_bucket_words(const Table& jt, int k, uint64_t b, const uint64_t* q, const Src& src, JtAcc& acc, unsigned long long* counters,
+                                  uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
+{
     bool any = false;
 MTG_UNROLL
     for (int i = 0; i < MTG_ABND_SLOTS; i++) any = any || q[i] != 0;
     if (!any) return;
-    const uint64_t first = bucket_first_h(b, jt.nbuckets, jt.key_bits);
+    const bool by_flag = (k & 1) != 0;
+    uint64_t first = 0;
+    bool have_first = false;
+    uint32_t n_fast = 0;
     for (int i = 0; i < MTG_ABND_SLOTS; i++) {
         if (q[i] == 0) continue;
+        const uint32_t bits = (uint32_t)q[i] & 255u;
+        /* odd k: an entry without the flag and with one bit on each side is a chain interior (two oriented k-mers, two interior views): nothing to probe,
+         * and its key is not needed (jt_special) */
+        const uint32_t lo = bits & 15u, hi = bits >> 4;
+        if (by_flag && !(q[i] & JT_MARK) && lo != 0u && hi != 0u && (lo & (lo - 1u)) == 0u && (hi & (hi - 1u)) == 0u) {
+#ifdef MTG_XCHECK /* TEST-ONLY: the key says the same */
+            {
+                uint64_t Jx;
+                (void)slot_key_in_bucket(jt, b, bucket_first_h(b, jt.nbuckets, jt.key_bits), q[i], Jx);
+                if (jt_special(Jx, revcomp(Jx, k - 1), jt.key_bits)) abort();
+            }
+#endif
+            n_fast++;
+            continue;
+        }
+        if (!have_first) { first = bucket_first_h(b, jt.nbuckets, jt.key_bits); have_first = true; }
+        /* (the flag stays: a second pass of the scan needs it again, a flagged junction is no chain interior, so no walker crosses it, and a walker that
+         * met the bit without an entry in the side table would only walk on) */
         uint64_t J;
-        const uint32_t m = slot_key_in_bucket(jt, b, first, q[i], J);
+        const uint32_t m = slot_key_in_bucket(jt, b, first, q[i] & ~JT_MARK, J);
         if (m) jt_scan_entry(jt, k, J, m, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
     }
+    acc.c[JT_C_ORIENTED] += 2u * n_fast; acc.c[JT_C_INTERIOR] += 2u * n_fast;
 }
 /* the chain that starts with x, walked on the junction table (us_walk without lookaheads) */
 template <typename Sink> MTG_DEV uint32_t jt_walk(const Table& jt, int k, const Kmer& x, Kmer& end, uint32_t& lines, Sink sink)

@@ -445,6 +445,9 @@ __global__ void __launch_bounds__(MTG_BIN1_THREADS) k_bin_positions(BinShape S, 
                     const uint64_t jr = jle ^ cmpl1, jf = revcomp(jr, k - 1);
                     bs[u] = jt_junction_bits(jf, jr, has_a, a, has_b, b);
                     Hs[u] = mix(jf <= jr ? jf : jr, S.kb);
+                    /* a junction the scan must look at in full (jt_special: palindromic, or a run of one nucleotide) goes in by the ordinary insertion, which
+                     * flags its entry: every occurrence of it, so none reaches a segment */
+                    if (bs[u] && jt_special(jf, jr, S.kb)) { bin_overflow_push(ov, Hs[u], bs[u] | 0x100u); bs[u] = 0; }
                 }
             }
 #pragma unroll
@@ -624,7 +627,7 @@ __global__ void k_jt_overflow(Table jt, const uint64_t* __restrict__ h, unsigned
 {
     unsigned long long fail = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const int f = jt_or_h(jt, h[2 * i], (uint32_t)h[2 * i + 1]) & 1;
+        const int f = jt_or_h(jt, h[2 * i], (uint32_t)h[2 * i + 1] & 255u, (h[2 * i + 1] & 0x100ull) ? JT_MARK : 0ull) & 1;
         if (f) { counters[3] = h[2 * i]; counters[1] = h[2 * i + 1]; }
         fail += f;
     }
@@ -672,8 +675,18 @@ __global__ void __launch_bounds__(256) k_jt_scan(Table jt, int k, Src src, unsig
 {
     JtAcc acc{};
     uint32_t lines = 0;
-    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < jt.nbuckets; b += (uint64_t)gridDim.x * blockDim.x)
-        jt_scan_bucket(jt, k, b, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+    /* four buckets of a lane in flight (with the common entry judged by its bits the pass waits for the table, not for its arithmetic) */
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < jt.nbuckets; b += 4 * stride) {
+        uint64_t q[4][MTG_ABND_SLOTS];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (b + (uint64_t)u * stride < jt.nbuckets) jt_bucket_words(jt, b + (uint64_t)u * stride, q[u]);
+            else for (int i = 0; i < MTG_ABND_SLOTS; i++) q[u][i] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) jt_scan_bucket_words(jt, k, b + (uint64_t)u * stride, q[u], src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+    }
     for (int j = 0; j < 6; j++) {
         const unsigned long long v = wave_sum_u64(acc.c[j]);
         if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&counters[j], v);

@@ -194,7 +194,7 @@ inline EmuLeanStats emu_build_lean(mtg::Index& ix, EmuUStore& st, const uint64_t
     for (uint64_t b = 0; b < jt.nbuckets; b++) {
         const uint64_t first = bucket_first_h(b, jt.nbuckets, jt.key_bits);
         for (int i = 0; i < MTG_ABND_SLOTS; i++) {
-            const uint64_t v = jt.slots[b * MTG_ABND_SLOTS + i];
+            const uint64_t v = jt.slots[b * MTG_ABND_SLOTS + i] & ~JT_MARK; /* (a flagged junction, jt_special: the flag is not part of the entry) */
             if (!v) continue;
             uint64_t j1, j2;
             const uint32_t m1 = jt_slot_key(jt, b * MTG_ABND_SLOTS + i, j1), m2 = slot_key_in_bucket(jt, b, first, v, j2);
