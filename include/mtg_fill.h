@@ -71,7 +71,8 @@ int mtg_index_create_from_kmers(const uint64_t* canon_kmers, const uint32_t* abu
 /* Graph whose nodes are all k-mers of the given sequences (2-bit packed, 32 nt per uint64_t word, nt i at bits
  * 2*(i%32); seq s occupies words [word_off[s], ...) and has len[s] nts; arrays in DEVICE memory).  Abundance of a
  * k-mer (deterministic): abund_span > 0: abund_lo + hash(k-mer) % abund_span; abund_span == 0: a Poisson(24) variate drawn from the hash
- * (SURVEY.md 8d), at least abund_lo.  Used for the synthetic benchmark sets. */
+ * (SURVEY.md 8d), at least abund_lo.  Used for the synthetic benchmark sets.  Sequences of any length (shorter than k: ignored; a donor of a few
+ * chromosome-sized sequences is taken in pieces internally); total_kmers_upper_bound >= the sum of max(len - k + 1, 0). */
 int mtg_index_create_from_packed_device(const uint64_t* d_words, const uint64_t* d_word_off, const uint32_t* d_len, size_t nseq,
                                         uint64_t total_kmers_upper_bound, int k, uint32_t abund_lo, uint32_t abund_span, mtg_index** out);
 /* Graph::load / save (src/Filler.cpp:222): this library's own container; a GATB .h5 gives MTG_ERR_FORMAT. */
