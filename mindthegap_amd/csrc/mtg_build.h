@@ -235,9 +235,21 @@ MTG_DEV bool jt_view_interior(const JView& v, uint64_t jf, int k, Kmer& p, Kmer&
 /* Scan, per entry (canonical junction J with mask m): statistics into acc, and for every view that is no chain interior the k-mers behind
  * it: chain starts (oriented k-mer, forward value) into starts[], k-mers of no chain (canonical, with the abundance the source gives) into
  * left_k / left_a.  Lists may be null (counting pass); cursors count either way. */
-template <typename Src>
+/* where the scan puts a chain start: the list in device memory behind its cursor (one atomic a start -- on ONE word: 1.2e6 of them are 8 ms of the
+ * human-scale scan, 150 M a second is what a line takes), or (the device, k_jt_scan) a queue of the wave in LDS that is emptied with one atomic */
+struct ScanStartsGlobal {
+    unsigned long long* counters;
+    uint64_t* starts;
+    unsigned long long cap_starts;
+    MTG_DEV void operator()(uint64_t start_f) const
+    {
+        const unsigned long long at = atomic_add64(&counters[JT_C_STARTS], 1ull);
+        if (starts && at < cap_starts) starts[at] = start_f;
+    }
+};
+template <typename Src, typename StartSink>
 MTG_DEV void jt_scan_entry(const Table& jt, int k, uint64_t J, uint32_t m, const Src& src, JtAcc& acc, unsigned long long* counters,
-                           uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
+                           const StartSink& put_start, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
 {
     const uint64_t mk = kmask(k), mk1 = kmask(k - 1);
     const uint64_t rJ = revcomp(J, k - 1);
@@ -275,10 +287,8 @@ MTG_DEV void jt_scan_entry(const Table& jt, int k, uint64_t J, uint32_t m, const
             if (self && (n_in != 1 || out_x != 1)) acc.c[JT_C_SELF_BRANCH]++;
             bool chain = false;
             if (jt_simple(r)) chain = us_eligible(x, kmer_next(x, (uint32_t)ctz4(r.out), k, mk), k);
-            if (chain) {
-                const unsigned long long at = atomic_add64(&counters[JT_C_STARTS], 1ull);
-                if (starts && at < cap_starts) starts[at] = x.f;
-            } else if (x.f <= x.r) {
+            if (chain) put_start(x.f);
+            else if (x.f <= x.r) {
                 const unsigned long long at = atomic_add64(&counters[JT_C_LEFT], 1ull);
                 if (left_k && at < cap_left) {
                     const uint32_t a = src(x.f, lines);
@@ -299,21 +309,22 @@ MTG_DEV void jt_bucket_words(const Table& jt, uint64_t b, uint64_t* q)
 MTG_UNROLL
     for (int i = 0; i < MTG_ABND_SLOTS / 2; i++) { const U64x2 v = ld_table(reinterpret_cast<const U64x2*>(p) + i); q[2 * i] = v.x; q[2 * i + 1] = v.y; }
 }
-template <typename Src>
+template <typename Src, typename StartSink>
 MTG_DEV void jt_scan_bucket_words(const Table& jt, int k, uint64_t b, const uint64_t* q, const Src& src, JtAcc& acc, unsigned long long* counters,
-                                  uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines);
+                                  const StartSink& put_start, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines);
 template <typename Src>
 MTG_DEV void jt_scan_bucket(const Table& jt, int k, uint64_t b, const Src& src, JtAcc& acc, unsigned long long* counters,
                             uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
 {
     uint64_t q[MTG_ABND_SLOTS];
     jt_bucket_words(jt, b, q);
-    jt_scan_bucket_words(jt, k, b, q, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+    const ScanStartsGlobal put_start{counters, starts, cap_starts};
+    jt_scan_bucket_words(jt, k, b, q, src, acc, counters, put_start, left_k, left_a, cap_left, lines);
 }
 /* the same with the bucket's words in hand (the device reads the buckets of several turns before it looks at the first: k_jt_scan) */
-template <typename Src>
+template <typename Src, typename StartSink>
 MTG_DEV void jt_scan_bucket_words(const Table& jt, int k, uint64_t b, const uint64_t* q, const Src& src, JtAcc& acc, unsigned long long* counters,
-                                  uint64_t* starts, unsigned long long cap_starts, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
+                                  const StartSink& put_start, uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left, uint32_t& lines)
 {
     bool any = false;
 MTG_UNROLL
@@ -345,7 +356,7 @@ MTG_UNROLL
          * met the bit without an entry in the side table would only walk on) */
         uint64_t J;
         const uint32_t m = slot_key_in_bucket(jt, b, first, q[i] & ~JT_MARK, J);
-        if (m) jt_scan_entry(jt, k, J, m, src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+        if (m) jt_scan_entry(jt, k, J, m, src, acc, counters, put_start, left_k, left_a, cap_left, lines);
     }
     acc.c[JT_C_ORIENTED] += 2u * n_fast; acc.c[JT_C_INTERIOR] += 2u * n_fast;
 }

@@ -669,15 +669,55 @@ __global__ void k_jt_insert_from_counts(Table jt, Table abnd, int with_abnd, int
 /* ONE streaming pass over the junction table, a bucket per lane (jt_scan_bucket: two 16-byte reads, the keys from one division): statistics,
  * chain starts and the k-mers of no chain.  The lists have the capacities the host guessed; the cursors count past them (round 4 scanned
  * twice: count, then collect -- 2 x 48 ms at human scale, bound by the arithmetic of decoding every slot on its own). */
+/* the chain starts a wave finds wait in a queue of its own in LDS and leave together: one atomic on the list's cursor per SCAN_Q_FLUSH starts instead of
+ * one each (1.2e6 atomics on one word were half the pass: 16 -> 9 ms) */
+enum { SCAN_Q = 192, SCAN_Q_FLUSH = 64 };
+struct ScanQueue {
+    uint32_t n;
+    uint32_t pad_;
+    uint64_t v[SCAN_Q];
+};
+struct ScanStartsQueued {
+    ScanQueue* q;
+    ScanStartsGlobal direct; /* a full queue (a wave that met more than SCAN_Q starts between two looks at it) */
+    __device__ void operator()(uint64_t start_f) const
+    {
+        const uint32_t at = atomicAdd(&q->n, 1u);
+        if (at < (uint32_t)SCAN_Q) q->v[at] = start_f;
+        else direct(start_f);
+    }
+};
+/* the wave's lanes together: the queue's entries to the list (all of them when `all`, else only once SCAN_Q_FLUSH wait) */
+__device__ __forceinline__ void scan_queue_flush(ScanQueue* q, const ScanStartsGlobal& g, bool all)
+{
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t waiting = *(volatile uint32_t*)&q->n;
+    const uint32_t n = waiting < (uint32_t)SCAN_Q ? waiting : (uint32_t)SCAN_Q; /* (what came past the end went to the list directly) */
+    if (n == 0 || (!all && n < (uint32_t)SCAN_Q_FLUSH)) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&g.counters[JT_C_STARTS], (unsigned long long)n);
+    base = (unsigned long long)__shfl((long long)base, 0, 64);
+    for (uint32_t i = lane; i < n; i += 64) if (g.starts && base + i < g.cap_starts) g.starts[base + i] = q->v[i];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) *(volatile uint32_t*)&q->n = 0;
+    __builtin_amdgcn_wave_barrier();
+}
 template <typename Src>
 __global__ void __launch_bounds__(256) k_jt_scan(Table jt, int k, Src src, unsigned long long* counters, uint64_t* starts, unsigned long long cap_starts,
                                                  uint64_t* left_k, uint32_t* left_a, unsigned long long cap_left)
 {
+    __shared__ ScanQueue s_q[4];
+    ScanQueue* const myq = &s_q[threadIdx.x >> 6];
+    if ((threadIdx.x & 63u) == 0) myq->n = 0;
+    __builtin_amdgcn_wave_barrier();
+    const ScanStartsGlobal direct{counters, starts, cap_starts};
+    const ScanStartsQueued put_start{myq, direct};
     JtAcc acc{};
     uint32_t lines = 0;
     /* four buckets of a lane in flight (with the common entry judged by its bits the pass waits for the table, not for its arithmetic) */
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < jt.nbuckets; b += 4 * stride) {
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b - (threadIdx.x & 63u) < jt.nbuckets; b += 4 * stride) { /* (the wave's lanes stay together: they empty the queue together) */
         uint64_t q[4][MTG_ABND_SLOTS];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -685,8 +725,10 @@ __global__ void __launch_bounds__(256) k_jt_scan(Table jt, int k, Src src, unsig
             else for (int i = 0; i < MTG_ABND_SLOTS; i++) q[u][i] = 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) jt_scan_bucket_words(jt, k, b + (uint64_t)u * stride, q[u], src, acc, counters, starts, cap_starts, left_k, left_a, cap_left, lines);
+        for (int u = 0; u < 4; u++) jt_scan_bucket_words(jt, k, b + (uint64_t)u * stride, q[u], src, acc, counters, put_start, left_k, left_a, cap_left, lines);
+        scan_queue_flush(myq, direct, false);
     }
+    scan_queue_flush(myq, direct, true);
     for (int j = 0; j < 6; j++) {
         const unsigned long long v = wave_sum_u64(acc.c[j]);
         if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&counters[j], v);
@@ -782,7 +824,45 @@ __global__ void __launch_bounds__(256) k_pos_stops(PosSets P, int k, const uint6
     }
     if (!ok) atomicOr(failed, 1ull);
 }
-enum { POS_R = 16, POS_TILE = 256 * POS_R };
+enum { POS_R = 16, POS_TILE = 256 * POS_R, POS_Q = 512 };
+struct PosPiece {
+    uint64_t start_f, src; /* first k-mer in the stored orientation; (first nucleotide in the input << 1) | against the input */
+    uint32_t len_k, pad_;
+};
+/* the whole workgroup: the queued pieces become records -- their words in the store reserved with one atomic, their numbers with another */
+__device__ __forceinline__ void pos_queue_flush(const WalkShared& S, uint64_t* pos_src, int k, const PosPiece* s_pq, uint32_t* s_pn, uint32_t* s_pw, uint32_t* s_ppre, uint32_t* s_wt)
+{
+    __shared__ unsigned long long s_base[2];
+    __shared__ unsigned long long s_views;
+    __syncthreads();
+    const uint32_t n = *s_pn;
+    if (n == 0) return; /* (uniform: every thread read the same count) */
+    if (threadIdx.x == 0) s_views = 0;
+    for (uint32_t t = threadIdx.x; t < (uint32_t)POS_Q; t += blockDim.x) s_pw[t] = t < n ? (uint32_t)us_words_of(s_pq[t].len_k, k) : 0u;
+    __syncthreads();
+    block_prefix(s_pw, s_ppre, (uint32_t)POS_Q, s_wt);
+    unsigned long long v = 0;
+    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) v += 2ull * (s_pq[t].len_k - 1u);
+    if (v) atomicAdd(&s_views, v);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base[0] = atomicAdd(&S.counters[JT_C_RECS], (unsigned long long)n);
+        s_base[1] = atomicAdd(&S.counters[JT_C_WORDS], (unsigned long long)s_ppre[n - 1] + s_pw[n - 1]);
+        atomicAdd(&S.counters[JT_C_STORED_VIEWS], s_views);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+        const uint64_t r = s_base[0] + t;
+        if (r < S.rec_cap) {
+            S.rec[r].start_f = s_pq[t].start_f; S.rec[r].len_k = s_pq[t].len_k; S.rec[r].pad_ = 0; S.rec[r].hdr = s_base[1] + s_ppre[t];
+            S.rec_walk[r] = (uint64_t)REC_BY_POSITION | (0xFFFFFFFFull << 32);
+            pos_src[r] = s_pq[t].src;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *s_pn = 0;
+    __syncthreads();
+}
 /* a lane takes POS_R consecutive junction positions: the first junction from the words, the next ones by one nucleotide each (two shifts instead of a
  * reverse complement a position), the filter's bit from a hash of three 32-bit multiplications */
 __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int k, WalkShared S, uint64_t* __restrict__ pos_src)
@@ -790,6 +870,11 @@ __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int 
     __shared__ uint32_t s_list[POS_TILE + 1]; /* [0]: the last stop of the tiles before (or none), then this tile's stops in order */
     __shared__ uint32_t s_wc[4];
     __shared__ uint32_t s_prev;
+    __shared__ PosPiece s_pq[POS_Q];          /* claimed pieces that wait for their records */
+    __shared__ uint32_t s_pw[POS_Q], s_ppre[POS_Q], s_wc2[16];
+    __shared__ uint32_t s_pn;
+    if (threadIdx.x == 0) s_pn = 0;
+    __syncthreads();
     const uint64_t mk = kmask(k), mk1 = kmask(k - 1), cmpl = 0xAAAAAAAAAAAAAAAAULL & mk, cmpl1 = 0xAAAAAAAAAAAAAAAAULL & mk1;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t cap = MTG_US_MAX_LEN - (uint32_t)k;
@@ -848,28 +933,35 @@ __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int 
             }
             if (threadIdx.x == 0) s_list[0] = s_prev;
             __syncthreads();
-            /* the pieces: k-mers a .. b - 1 between the consecutive stops a < b */
-            for (uint32_t i = threadIdx.x; i < total; i += 256u) {
-                const uint32_t a = s_list[i], b = s_list[i + 1];
-                if (a == 0xFFFFFFFFu) continue;
-                const uint32_t len_k = b - a;
-                if (len_k < 2u || len_k >= cap) continue; /* one k-mer: the scan has it; too long for a unitig: the walkers and the late pass, as ever */
-                Kmer X, Y;
-                X.r = us_peek64(w, a, (uint32_t)k, false) ^ cmpl; X.f = revcomp(X.r, k);
-                Y.r = us_peek64(w, b - 1u, (uint32_t)k, false) ^ cmpl; Y.f = revcomp(Y.r, k);
-                const uint64_t cX = canon(X), cY = canon(Y);
-                if (cX == cY) continue; /* no walker owns such a chain either */
-                const bool fwd = cX < cY; /* the chain is stored from the end with the smaller canonical k-mer */
-                if (!keyset_insert(P.done, fwd ? cX : cY)) continue; /* claimed from another sequence (or the set is full: then the walkers do it) */
-                (void)keyset_insert(P.done, fwd ? cY : cX);
-                const uint64_t r = atomicAdd(&S.counters[JT_C_RECS], 1ull);
-                const uint64_t wd = atomicAdd(&S.counters[JT_C_WORDS], (unsigned long long)us_words_of(len_k, k));
-                atomicAdd(&S.counters[JT_C_STORED_VIEWS], 2ull * (len_k - 1u));
-                if (r < S.rec_cap) {
-                    S.rec[r].start_f = fwd ? X.f : Y.r; S.rec[r].len_k = len_k; S.rec[r].pad_ = 0; S.rec[r].hdr = wd;
-                    S.rec_walk[r] = (uint64_t)REC_BY_POSITION | (0xFFFFFFFFull << 32);
-                    pos_src[r] = ((in.word_off[s] * 32ull + a) << 1) | (fwd ? 0ull : 1ull);
+            /* the pieces: k-mers a .. b - 1 between the consecutive stops a < b.  A claimed piece waits in the workgroup's queue (LDS); the queue is emptied with
+             * three atomics for all it holds (pos_queue_flush) instead of three a piece: the counters share a memory line, and a line takes 150 M atomics a
+             * second -- 1.8e6 of them were 6 of this pass's 24 ms */
+            for (uint32_t i0 = 0; i0 < total; i0 += 256u) {
+                const uint32_t waiting = s_pn; /* every thread reads the count BEFORE any thread of this round adds to it: the barrier keeps the test uniform */
+                __syncthreads();
+                if (waiting + 256u > (uint32_t)POS_Q) pos_queue_flush(S, pos_src, k, s_pq, &s_pn, s_pw, s_ppre, s_wc2);
+                const uint32_t i = i0 + threadIdx.x;
+                if (i < total) {
+                    const uint32_t a = s_list[i], b = s_list[i + 1];
+                    const uint32_t len_k = b - a;
+                    /* (one k-mer: the scan has it; too long for a unitig: the walkers and the late pass, as ever) */
+                    if (a != 0xFFFFFFFFu && len_k >= 2u && len_k < cap) {
+                        Kmer X, Y;
+                        X.r = us_peek64(w, a, (uint32_t)k, false) ^ cmpl; X.f = revcomp(X.r, k);
+                        Y.r = us_peek64(w, b - 1u, (uint32_t)k, false) ^ cmpl; Y.f = revcomp(Y.r, k);
+                        const uint64_t cX = canon(X), cY = canon(Y);
+                        const bool fwd = cX < cY; /* the chain is stored from the end with the smaller canonical k-mer; equal: no walker owns such a chain either */
+                        /* claimed from another sequence already (or the set is full: then the walkers do it)? */
+                        if (cX != cY && keyset_insert(P.done, fwd ? cX : cY)) {
+                            (void)keyset_insert(P.done, fwd ? cY : cX);
+                            const uint32_t at = atomicAdd(&s_pn, 1u);
+                            PosPiece pc;
+                            pc.start_f = fwd ? X.f : Y.r; pc.src = ((in.word_off[s] * 32ull + a) << 1) | (fwd ? 0ull : 1ull); pc.len_k = len_k;
+                            s_pq[at] = pc;
+                        }
+                    }
                 }
+                __syncthreads();
             }
             __syncthreads();
             if (threadIdx.x == 0 && total) s_prev = s_list[total];
@@ -877,6 +969,7 @@ __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int 
         }
         __syncthreads();
     }
+    pos_queue_flush(S, pos_src, k, s_pq, &s_pn, s_pw, s_ppre, s_wc2);
 }
 /* one record found by position per wave: header word and sequence from the packed input, as it stands or reverse-complemented */
 __global__ void __launch_bounds__(256) k_us_from_seq(UStore us, int k, const UsRec* __restrict__ rec, unsigned long long n, const uint64_t* __restrict__ rec_walk,
