@@ -582,37 +582,10 @@ __global__ void __launch_bounds__(MTG_SEG_THREADS) k_build_segments(BinShape S, 
             uint64_t cur[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) { const uint64_t i = base + (uint64_t)u * blockDim.x + threadIdx.x; cur[u] = i < n ? reg[1 + i] : 0ull; } /* eight loads in flight (a record's edge bits are never 0) */
-            /* a first try at every record's home bucket, the eight of a lane one after the other without a loop between them (their LDS reads overlap; four
-             * records in five end here), then the probing loop for what is left: a full home bucket, a lost race */
-            uint32_t again = 0;
-#ifndef SEG_NO_FIRST_TRY
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint64_t rec = cur[u];
                 if (!rec) continue;
-                const uint64_t H = hi | (rec >> 8);
-                const uint32_t bits = (uint32_t)rec & 255u;
-                const uint64_t bl0 = bucket_of(H, jt.nbuckets, jt.key_bits) - b0;
-                const uint64_t want = (H & tagm) << MTG_DISP_BITS;
-                unsigned long long* p = reinterpret_cast<unsigned long long*>(s_tab + bl0 * MTG_ABND_SLOTS);
-                const volatile unsigned long long* pv = p;
-                const unsigned long long q[4] = {pv[0], pv[1], pv[2], pv[3]};
-                int hit = -1, fr = -1;
-#pragma unroll
-                for (int t = 3; t >= 0; t--) { if (q[t] == 0ull) fr = t; if ((q[t] >> 8) == want && q[t] != 0ull) hit = t; }
-                if (hit >= 0) { if ((q[hit] & bits) != bits) atomicOr(p + hit, (unsigned long long)bits); }
-                else if (fr >= 0) {
-                    const unsigned long long v = atomicCAS(p + fr, 0ull, (unsigned long long)((want << 8) | bits));
-                    if (v != 0ull) { if ((v >> 8) == want) { if ((v & bits) != bits) atomicOr(p + fr, (unsigned long long)bits); } else again |= 1u << u; }
-                } else again |= 1u << u;
-            }
-#else
-            again = 0xFFu;
-#endif
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint64_t rec = cur[u];
-                if (!rec || !((again >> u) & 1u)) continue;
                 const uint64_t H = hi | (rec >> 8);
                 const uint32_t bits = (uint32_t)rec & 255u;
                 const uint64_t bl0 = bucket_of(H, jt.nbuckets, jt.key_bits) - b0;
