@@ -780,6 +780,7 @@ struct PackedSeqs {
     const uint64_t* word_off; /* per sequence: its first word */
     const uint32_t* len;      /* per sequence: nucleotides */
     size_t nseq;
+    uint32_t longest;         /* the longest of them (0: not known) */
 };
 struct PosSets {
     KeySet stops;         /* canonical junctions that are no chain interior */
@@ -824,7 +825,7 @@ __global__ void __launch_bounds__(256) k_pos_stops(PosSets P, int k, const uint6
     }
     if (!ok) atomicOr(failed, 1ull);
 }
-enum { POS_R = 16, POS_TILE = 256 * POS_R, POS_Q = 512 };
+enum { POS_R = 16, POS_TILE = 256 * POS_R, POS_Q = 512, POS_CHUNK = 1 << 17 /* positions: 32 tiles */ };
 struct PosPiece {
     uint64_t start_f, src; /* first k-mer in the stored orientation; (first nucleotide in the input << 1) | against the input */
     uint32_t len_k, pad_;
@@ -884,9 +885,17 @@ __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int 
         if (L < (uint32_t)k) continue;
         const uint64_t* __restrict__ w = in.words + in.word_off[s];
         const uint32_t npos = L - (uint32_t)k + 2u;
+        /* a sequence is taken in chunks of POS_CHUNK positions, chunk c by the workgroups with blockIdx.y == c mod gridDim.y (one chunk, gridDim.y == 1,
+         * unless the host has seen a long sequence): a chunk's workgroup owns the pieces that BEGIN at a stop of its chunk, and goes on past the chunk's
+         * end until it has met the stop that ends the last of them (have_prev and total are the same in every thread) */
+        for (uint32_t c = blockIdx.y; (uint64_t)c * POS_CHUNK < npos; c += gridDim.y) {
+        const uint32_t q_begin = c * (uint32_t)POS_CHUNK, q_own_end = npos - q_begin < (uint32_t)POS_CHUNK ? npos : q_begin + (uint32_t)POS_CHUNK;
+        bool have_prev = false;
         if (threadIdx.x == 0) s_prev = 0xFFFFFFFFu;
         __syncthreads();
-        for (uint32_t q0 = 0; q0 < npos; q0 += POS_TILE) {
+        for (uint32_t q0 = q_begin; q0 < npos; q0 += POS_TILE) {
+            const bool past = q0 >= q_own_end;
+            if (past && !have_prev) break;
             const uint32_t qb = q0 + threadIdx.x * POS_R;
             uint32_t stops = 0, cand = 0;
             if (qb < npos) {
@@ -933,6 +942,7 @@ __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int 
             }
             if (threadIdx.x == 0) s_list[0] = s_prev;
             __syncthreads();
+            if (past && total > 1u) total = 1u; /* beyond the chunk only the stop that ends its last piece counts */
             /* the pieces: k-mers a .. b - 1 between the consecutive stops a < b.  A claimed piece waits in the workgroup's queue (LDS); the queue is emptied with
              * three atomics for all it holds (pos_queue_flush) instead of three a piece: the counters share a memory line, and a line takes 150 M atomics a
              * second -- 1.8e6 of them were 6 of this pass's 24 ms */
@@ -966,8 +976,11 @@ __global__ void __launch_bounds__(256) k_pos_plan(PosSets P, PackedSeqs in, int 
             __syncthreads();
             if (threadIdx.x == 0 && total) s_prev = s_list[total];
             /* (the next tile's first barrier orders this store before s_list[0] is written from it) */
+            have_prev = have_prev || total != 0u;
+            if (past && total) break;
         }
         __syncthreads();
+        }
     }
     pos_queue_flush(S, pos_src, k, s_pq, &s_pn, s_pw, s_ppre, s_wc2);
 }
@@ -1356,7 +1369,8 @@ static int build_from_jt(mtg_index* idx, DevBuf& jt_buf, const Table& jt, const 
             if (stops_failed) positional = false; /* a stop is missing from the set: every chain is walked */
             else {
                 prof.begin();
-                hipLaunchKernelGGL(k_pos_plan, dim3((unsigned)std::min<size_t>(packed->nseq, 256 * 8)), dim3(256), 0, 0, PS, *packed, k, WS, p_pos_src);
+                const unsigned chunks = packed->longest > (uint32_t)POS_CHUNK ? (unsigned)std::min<uint64_t>(((uint64_t)packed->longest + POS_CHUNK - 1) / POS_CHUNK, 64) : 1u;
+                hipLaunchKernelGGL(k_pos_plan, dim3((unsigned)std::min<size_t>(packed->nseq, 256 * 8), chunks), dim3(256), 0, 0, PS, *packed, k, WS, p_pos_src);
                 HIP_TRY(prof.end("pos_plan", (interior / 2 + n_starts) / 4 + n_starts * 40, interior / 2 + n_starts)); /* the sequences once; per chain its record and its two claims */
                 WS.done = PS.done;
             }
@@ -1587,7 +1601,11 @@ static int jt_insert_partitioned(const Table& jt, BinShape S, int k, const uint6
     const uint32_t G = MTG_BIN1_GROUPS; /* workgroups of k_bin_positions = regions per level-1 bin */
     const uint64_t nseg = jt.nbuckets / S.m, nreg = ((uint64_t)1 << S.b1) * G;
     DevBuf d_cur, d_ov, d_tmp;
-    const unsigned long long ov_cap = 1ull << 22;
+    /* what the regions and the segments' lists cannot hold goes through the ordinary insertion afterwards: a few in a million for a donor without
+     * repeats, but every occurrence of a junction that occurs 300 000 times lands in one segment (scripts/r6_long_sequences.py ... repeats: 10^7 left
+     * over).  A sixty-fourth of the positions may be left over before the whole insertion falls back (the ordinary insertion reads a hot entry from
+     * cache and finds its bits there: repeats cost it nothing) */
+    const unsigned long long ov_cap = std::max<unsigned long long>(1ull << 22, n_junctions_ub / 64);
     HIP_TRY(d_cur.alloc(nreg * 4 + 64));
     HIP_TRY(d_ov.alloc(ov_cap * 16 + 64));
     /* the level-1 regions: behind the table when there is room for at least an eighth of the records at a time, else a buffer of their own */
@@ -1673,11 +1691,11 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
      * table ORs them): the same graph.  Only the insertion sees the pieces: the chains are looked for in the sequences as they came (a chain that
      * crosses a cut would lie whole in no piece and be left to its walkers -- 142 s for 24 chains of 125 Mbp, scripts/r6_long_sequences.py).
      * The lengths come to the host for this (4 bytes a sequence). */
+    uint32_t longest = 0;
     if (nseq) {
         enum : uint32_t { PIECE = 1u << 16 };
         std::vector<uint32_t> h_len(nseq);
         HIP_TRY(hipMemcpy(h_len.data(), d_len, nseq * 4, hipMemcpyDeviceToHost));
-        uint32_t longest = 0;
         for (uint32_t L : h_len) longest = std::max(longest, L);
         if (longest > 2u * PIECE && !tune::on(tune::T_NO_SPLIT_LONG)) {
             std::vector<uint64_t> h_off(nseq);
@@ -1749,7 +1767,7 @@ static int index_from_packed_device_lean(const uint64_t* d_words, const uint64_t
     if (rc) return rc;
     AbSynth src;
     src.lo = abund_lo; src.span = abund_span;
-    const PackedSeqs packed{d_words, d_word_off, d_len, nseq};
+    const PackedSeqs packed{d_words, d_word_off, d_len, nseq, longest};
     if (int rc2 = build_from_jt(idx, jt_buf, jt, src, [] {}, 0, prof, &packed)) return rc2;
     idx->info.k = k;
     idx->info.abundance_min = (int)abund_lo;

@@ -13,6 +13,10 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(7)
 wps = (L + 31) // 32 + 1
 w = torch.randint(-2**63, 2**63 - 1, (nseq * wps,), dtype=torch.int64, device=dev, generator=g)
+if len(sys.argv) > 3 and sys.argv[3] == "repeats":  # the same 64 nucleotides every 313 words (10 kb): the chains end there, as they do at the repeats of a real genome
+    v = w.view(nseq, wps)
+    v[:, 5::313] = 0x1B27E4D8C6A59F03
+    v[:, 6::313] = 0x5AC3F10E9B7D2648
 wo = (torch.arange(nseq, dtype=torch.int64, device=dev) * wps)
 ln = torch.full((nseq,), L, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
