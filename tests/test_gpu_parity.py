@@ -823,6 +823,16 @@ def test_partitioned_junction_table_equals_the_scattered_insertion(mtg):
     rng = np.random.default_rng(5)
     dev = torch.device("cuda", 0)
     pw, po, pl, pn = S.packed()
+    # ... and one 64-mer 6 000 times (between stretches of 40 random nucleotides): every occurrence of each of its junctions lands in ONE segment of the
+    # partitioned table, whose list holds ~4 600 records -- the rest goes through the list of leftovers and the ordinary insertion
+    rep = rng.integers(0, 4, 64).astype(np.uint8)
+    beads = [np.concatenate([np.concatenate([rep, rng.integers(0, 4, 40).astype(np.uint8)]) for _ in range(60)]) for _ in range(100)]
+    ew, eo, el = _pack_codes(beads)
+    pw = np.concatenate([pw, ew, np.zeros(2, dtype=np.uint64)])
+    po = np.concatenate([po, eo + np.uint64(pw.size - ew.size - 2)])
+    pl = np.concatenate([pl, el])
+    pn = pn + len(beads)
+    ub = int(np.maximum(pl.astype(np.int64) - 30, 0).sum())
     built = {}
     for part in ("0", "1"):
         mtg.tuning_set("BUILD_PARTITIONED", part)
@@ -830,7 +840,7 @@ def test_partitioned_junction_table_equals_the_scattered_insertion(mtg):
             w = torch.from_numpy(pw.view(np.int64)).to(dev)
             wo = torch.from_numpy(po.view(np.int64)).to(dev)
             ln = torch.from_numpy(pl.view(np.int32)).to(dev)
-            idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), pn, S.total_kmers_upper_bound, 31, 3, 0)
+            idx = mtg.Index.from_packed_device(w.data_ptr(), wo.data_ptr(), ln.data_ptr(), pn, ub, 31, 3, 0)
         finally:
             mtg.tuning_set("BUILD_PARTITIONED", None)
         names = [p["name"] for p in idx.build_profile()["phases"]]
